@@ -1,0 +1,116 @@
+"""CPU: the numpy oracle reproduces every golden vector captured from the reference (<= 1e-12, fp64)."""
+import numpy as np
+import pytest
+
+from oracle import gcrnn_oracle as orc
+from conftest import load_golden
+
+TOL = 1e-12
+VARIANTS = [('none', False, None), ('time', True, None), ('node', False, 'node'),
+            ('edge', False, 'edge'), ('time_node', True, 'node'), ('time_edge', True, 'edge')]
+
+
+def maxdiff(a, b):
+    return float(np.max(np.abs(a - b)))
+
+
+def test_g1_lsigf():
+    g = load_golden('g1_lsigf')
+    assert maxdiff(orc.lsigf(g['h'], g['S'], g['x'], g['b']), g['y_bias']) <= TOL
+    assert maxdiff(orc.lsigf(g['h'], g['S'], g['x']), g['y_nobias']) <= TOL
+    assert maxdiff(orc.lsigf(g['h2'], g['S2'], g['x'], g['b']), g['y_e2']) <= TOL
+
+
+def test_g2_graphfilter_zero_pad():
+    g = load_golden('g2_graphfilter')
+    p = g['params']
+    assert maxdiff(orc.graph_filter(p['weight'], p['bias'], g['S'], g['x']), g['y']) <= TOL
+    ys = orc.graph_filter(p['weight'], p['bias'], g['S'], g['x_short'])
+    assert ys.shape == g['y_short'].shape and maxdiff(ys, g['y_short']) <= TOL
+
+
+@pytest.mark.parametrize('name,tg,sg', VARIANTS)
+def test_g3_cell_variants(name, tg, sg):
+    g = load_golden('g3_cell_' + name)
+    H = orc.ggcrnn_cell(g['params'], g['S'], g['X'], g['h0'], tg, sg)
+    assert maxdiff(H, g['H']) <= TOL
+
+
+@pytest.mark.parametrize('name,tg', [('none', False), ('time', True)])
+def test_g3_cell_nobias_unequal_taps(name, tg):
+    g = load_golden('g3_cell_%s_nobias' % name)
+    assert 'bias' not in g['params']
+    assert maxdiff(orc.ggcrnn_cell(g['params'], g['S'], g['X'], g['h0'], tg, None), g['H']) <= TOL
+
+
+def test_gate_uses_initial_state_not_previous():
+    """Appendix B.3: gates read h0; replacing h0 by h_{t-1} in the gate must change the output."""
+    g = load_golden('g3_cell_time')
+    p, S, X, h0 = g['params'], g['S'], g['X'], g['h0']
+    H = orc.ggcrnn_cell(p, S, X, h0, True, None)
+    # one manual step t=1 with the gate (wrongly) fed h_0 := H[:,0]
+    sub = {k[len('GFL_in.'):]: v for k, v in p.items() if k.startswith('GFL_in.')}
+    c_wrong = np.tanh(orc.lsigf(sub['weight_A'], S, X[:, 1], sub['bias']) + orc.lsigf(sub['weight_B'], S, H[:, 0], sub['bias']))
+    c_right = np.tanh(orc.lsigf(sub['weight_A'], S, X[:, 1], sub['bias']) + orc.lsigf(sub['weight_B'], S, h0, sub['bias']))
+    assert maxdiff(c_wrong, c_right) > 1e-3
+
+
+@pytest.mark.parametrize('mlp', ['multipMlp', 'oneMlp'])
+@pytest.mark.parametrize('name,tg', [('none', False), ('time', True)])
+def test_g5_regression(mlp, name, tg):
+    g = load_golden('g5_reg_%s_%s' % (mlp, name))
+    y = orc.gated_gcrnn_regression(g['params'], g['S'], g['x'], g['h0'], tg, None, mlp)
+    assert y.shape == g['y'].shape and maxdiff(y, g['y']) <= TOL
+
+
+@pytest.mark.parametrize('tag', ['T20K4', 'T200K3'])
+@pytest.mark.parametrize('name,tg', [('none', False), ('time', True)])
+def test_g5_classification(tag, name, tg):
+    g = load_golden('g5_cls_%s_%s' % (tag, name))
+    y = orc.gated_gcrnn_classification(g['params'], g['S'], g['x'], g['h0'], tg, None)
+    assert maxdiff(y, g['y']) <= 1e-11
+
+
+@pytest.mark.parametrize('name,tg', [('GCRNNMLP', False), ('TimeGCRNNMLP', True)])
+def test_g6_loss_and_metric_at_step0(name, tg):
+    g = load_golden('g6_trace_' + name)
+    y0 = orc.gated_gcrnn_regression(g['params0'], g['S'], g['x'], g['h0'], tg, None, 'multipMlp')
+    assert abs(orc.batch_time_l1_loss(y0, g['y']) - g['loss'][0]) <= TOL
+    assert abs(orc.batch_time_mse_loss(y0, g['y']) - g['metric'][0]) <= 1e-10
+    assert g['loss'][-1] < g['loss'][0]          # the captured trace is a descending one
+
+
+def test_g7_csr_indices_exact():
+    g = np.load(__import__('os').path.join(__import__('conftest').GOLDEN, 'g7_csr.npz'))
+    for tag in ('dir30', 'adj59', 'sbm50'):
+        M = g[tag + '/dense']
+        for nm, mat in (('S', M), ('ST', M.T)):
+            rp, col, val = orc.csr_from_dense(mat)
+            assert np.array_equal(rp, g['%s/%s_rowptr' % (tag, nm)])
+            assert np.array_equal(col, g['%s/%s_col' % (tag, nm)])
+            assert np.array_equal(val, g['%s/%s_val' % (tag, nm)])
+    assert g['adj59/S_rowptr'][-1] == 590 and np.all(np.diff(g['adj59/S_rowptr']) == 10)   # 10-NN graph
+
+
+def test_g8_midsize_samples():
+    g = load_golden('g8_mid')
+    N, B, T, G, F, K = [int(v) for v in g['shape']]
+    S = np.zeros((1, N, N))
+    S[0, g['coo_row'], g['coo_col']] = g['coo_val']
+    rng = np.random.default_rng(int(g['x_seed'][0]))
+    X = rng.standard_normal((B, T, G, N))
+    H = orc.ggcrnn_cell(g['params'], S, X, np.zeros((B, F, N)))
+    assert maxdiff(H.reshape(-1)[g['sample_idx']], g['sample_val']) <= 1e-11
+    assert abs(H.sum() - g['checksum'][0]) <= 1e-8
+    assert maxdiff(H[0, 3, 0], g['H_b0_t3_f0']) <= 1e-11
+
+
+def test_csr_row_spmm_equals_dense_shift():
+    """Node-major CSR(S^T) SpMM == the reference's row-vector shift x @ S."""
+    g = load_golden('g1_lsigf')
+    S, x = g['S'][0], g['x']
+    rp, col, val = orc.csr_from_dense(S.T.copy())
+    xn = x.transpose(2, 0, 1).reshape(S.shape[0], -1)              # [N][B*G]
+    yn = orc.csr_matvec_rows(rp, col, val, xn)
+    ref = (x @ S).transpose(2, 0, 1).reshape(S.shape[0], -1)
+    assert maxdiff(yn, ref) <= 1e-13
