@@ -1,0 +1,342 @@
+"""Graph-ML primitives of the GCRNN hot path on MI355X (HIP kernels behind include/gcrnn.h).
+
+Mirrors the public surface of the reference's Utils/graphML.py for the hot path
+only: same names, positional signatures, parameter
+names and shapes, `addGSO`, state_dict keys and AssertionError conventions.
+
+    LSIGF(h, S, x, b=None)                                    reference graphML.py:47-140
+    GraphFilter(G, F, K, E=1, bias=True)                      reference graphML.py:1086-1205
+    GraphAttentional(G, F, K, E=1, nonlinearity, concatenate) reference graphML.py:1999-2128
+    GGCRNNCell(G, F, Kin, Kst, sigma, time_gating, spatial_gating, E, bias)
+                                                              reference graphML.py:2130-2427
+
+Differences (all documented in DESIGN.md): the GSO is converted to CSR once in
+`addGSO` (the dense tensor is kept only as a buffer for checkpoint/inspection);
+data runs in a node-major layout internally; `.to(device)` moves the graph too
+(the reference does not, architectures.py:1638-1645); inputs must live on a ROCm
+device -- there is no CPU path.
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from .. import ops
+from ..graph import GraphOperator, as_operator
+
+zeroTolerance = 1e-9   # reference graphML.py:42
+infiniteNumber = 1e12  # reference graphML.py:43
+
+
+def LSIGF(h, S, x, b=None):
+    """y = sum_e sum_k h[:, e, k, :] (x S_e^k) + b   --  drop-in for reference LSIGF (graphML.py:47-140).
+
+    h: F x E x K x G, S: E x N x N dense tensor (or a GraphOperator), x: B x G x N, b: F x 1.
+    Returns B x F x N. Shape errors raise AssertionError as in the reference (graphML.py:99-104).
+    """
+    F, E, K, G = h.shape
+    graph = as_operator(S)
+    assert graph.E == E
+    N = graph.N
+    B = x.shape[0]
+    assert x.shape[1] == G
+    assert x.shape[2] == N
+    Xn = ops.pack_node_major(x.reshape(B, 1, G, N))
+    if graph.device != x.device:
+        graph = graph.to(x.device)
+    Yn = ops.lsigf_node_major(Xn, h, b, graph, 1.0)
+    return ops.unpack_node_major(Yn).reshape(B, F, N)
+
+
+class GraphFilter(nn.Module):
+    """Linear graph filter layer; parameters `weight` F x E x K x G, `bias` F x 1 (reference graphML.py:1086-1205)."""
+
+    def __init__(self, G, F, K, E=1, bias=True):
+        super().__init__()
+        self.G, self.F, self.K, self.E = G, F, K, E
+        self.S = None
+        self.graph = None
+        self.weight = nn.parameter.Parameter(torch.empty(F, E, K, G))
+        if bias:
+            self.bias = nn.parameter.Parameter(torch.empty(F, 1))
+        else:
+            self.register_parameter('bias', None)
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        stdv = 1. / math.sqrt(self.G * self.K)          # reference graphML.py:1159-1164
+        self.weight.data.uniform_(-stdv, stdv)
+        if self.bias is not None:
+            self.bias.data.uniform_(-stdv, stdv)
+
+    def addGSO(self, S):
+        graph = as_operator(S)
+        assert graph.E == self.E
+        self.N = graph.N
+        self.S = S
+        self.graph = graph
+
+    def _apply(self, fn, *args, **kwargs):
+        super()._apply(fn, *args, **kwargs)
+        if self.graph is not None:
+            self.graph = self.graph.to(self.weight.device)
+        return self
+
+    def forward_node_major(self, Xn):
+        return ops.lsigf_node_major(Xn, self.weight, self.bias, self.graph, 1.0)
+
+    def forward(self, x):
+        B, F, Nin = x.shape
+        if Nin < self.N:                                 # zero padding, reference graphML.py:1181-1185
+            x = torch.cat((x, torch.zeros(B, F, self.N - Nin, dtype=x.dtype, device=x.device)), dim=2)
+        u = LSIGF(self.weight, self.graph, x, self.bias)
+        if Nin < self.N:                                 # reference graphML.py:1192-1193
+            u = u[:, :, :Nin]
+        return u
+
+    def extra_repr(self):
+        return 'in_features=%d, out_features=%d, filter_taps=%d, edge_features=%d, bias=%s, %s' % (
+            self.G, self.F, self.K, self.E, self.bias is not None,
+            'GSO stored' if self.graph is not None else 'no GSO stored')
+
+
+def _graph_attention_node_major(u, mixer, weight, graph, negative_slope=0.2):
+    """GAT on the CSR support of S + I (reference graphAttention, graphML.py:521-627), node-major.
+
+    u: [N][B][G]; mixer: K x E x 2F; weight: K x E x F x G  ->  [N][B][K*F] (heads concatenated, pre-ReLU).
+    Edge (m, n) of the support carries e = LeakyReLU(a1.Wx_n + a2.Wx_m); alpha = softmax over the
+    neighbours n of row m; y_n = sum_m Wx_m (S+I)[m, n] alpha[m, n].
+    """
+    N, B, G = u.shape
+    K, E, F, _ = weight.shape
+    rows, cols = graph.mask.rows(), graph.mask.col.long()
+    outs = []
+    for k in range(K):
+        yk = None
+        for e in range(E):
+            Wx = torch.matmul(u, weight[k, e].t())                    # N x B x F
+            s1 = torch.matmul(Wx, mixer[k, e, :F])                    # N x B   (a1 . Wx_n)
+            s2 = torch.matmul(Wx, mixer[k, e, F:])                    # N x B   (a2 . Wx_m)
+            eij = nn.functional.leaky_relu(s1[cols] + s2[rows], negative_slope)     # nnz x B
+            mx = torch.full((N, B), -float('inf'), dtype=u.dtype, device=u.device).scatter_reduce(
+                0, rows.view(-1, 1).expand(-1, B), eij, 'amax', include_self=True)
+            ex = torch.exp(eij - mx[rows])
+            den = torch.zeros((N, B), dtype=u.dtype, device=u.device).index_add_(0, rows, ex)
+            coef = (ex / den[rows]) * graph.mask_vals[e].to(u.dtype).view(-1, 1)    # (S+I)[m,n] alpha[m,n]
+            y = torch.zeros((N, B, F), dtype=u.dtype, device=u.device).index_add_(0, cols, Wx[rows] * coef.unsqueeze(2))
+            yk = y if yk is None else yk + y
+        outs.append(yk)
+    return torch.cat(outs, dim=2)
+
+
+class GraphAttentional(nn.Module):
+    """Graph attention layer used as the edge gate (reference graphML.py:1999-2128): `mixer` K x E x 2F, `weight` K x E x F x G."""
+
+    def __init__(self, G, F, K, E=1, nonlinearity=nn.functional.relu, concatenate=True):
+        super().__init__()
+        self.G, self.F, self.K, self.E = G, F, K, E
+        self.S = None
+        self.graph = None
+        self.nonlinearity = nonlinearity
+        self.concatenate = concatenate
+        self.mixer = nn.parameter.Parameter(torch.empty(K, E, 2 * F))
+        self.weight = nn.parameter.Parameter(torch.empty(K, E, F, G))
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        stdv = 1. / math.sqrt(self.G * self.K)          # reference graphML.py:2069-2073
+        self.weight.data.uniform_(-stdv, stdv)
+        self.mixer.data.uniform_(-stdv, stdv)
+
+    def addGSO(self, S):
+        graph = as_operator(S)
+        assert graph.E == self.E
+        self.N = graph.N
+        self.S = S
+        self.graph = graph
+
+    def _apply(self, fn, *args, **kwargs):
+        super()._apply(fn, *args, **kwargs)
+        if self.graph is not None:
+            self.graph = self.graph.to(self.weight.device)
+        return self
+
+    def forward_node_major(self, un):
+        """un: [T][N][B][G] -> [T][N][B][K*F] (concatenate) or [T][N][B][F] (mean)."""
+        outs = []
+        for t in range(un.shape[0]):
+            y = _graph_attention_node_major(un[t], self.mixer, self.weight, self.graph)
+            if self.concatenate:
+                y = self.nonlinearity(y)                                     # reference graphML.py:2101
+            else:
+                N, B, _ = y.shape
+                y = self.nonlinearity(y.view(N, B, self.K, self.F).mean(dim=2))   # reference graphML.py:2110-2112
+            outs.append(y)
+        return torch.stack(outs, 0)
+
+    def forward(self, x):
+        ops.require_device(x)
+        B, F, Nin = x.shape
+        if Nin < self.N:
+            x = torch.cat((x, torch.zeros(B, F, self.N - Nin, dtype=x.dtype, device=x.device)), dim=2)
+        un = ops.pack_node_major(x.reshape(B, 1, F, self.N))
+        y = ops.unpack_node_major(self.forward_node_major(un)).reshape(B, -1, self.N)
+        if Nin < self.N:
+            y = y[:, :, :Nin]
+        return y
+
+    def extra_repr(self):
+        return 'in_features=%d, out_features=%d, attention_heads=%d, edge_features=%d, %s' % (
+            self.G, self.F, self.K, self.E,
+            ('GSO stored: number_nodes=%d' % self.N) if self.graph is not None else 'no GSO stored')
+
+
+class GGCRNNCell(nn.Module):
+    """Gated graph convolutional recurrent cell (reference graphML.py:2130-2427).
+
+        h_t = sigma( gi_t [ni_t .] (A(S) x_t + b) + gf_t [nf_t .] (B(S) h_{t-1} + b) )
+
+    Parameters: weight_A F x E x Kin x G, weight_B F x E x Kst x F, bias F x 1 (one bias, added by
+    both filters). Gate sub-networks are created in addGSO under the reference's names
+    (GFL_in/MLP_in/GFL_forget/MLP_forget/GFL_out/MLP_out, GRNN_node_*/GFL_node_*,
+    input_attention/forget_attention) so state_dicts are interchangeable. As in the reference every
+    gate is computed from (x_t, h0) -- the initial state -- so all gates and A(S)x_t are evaluated for
+    the whole sequence in one batched pass before the sequential state recurrence.
+    forward(X: B x T x G x N, h0: B x F x N) -> H: B x T x F x N.
+    """
+
+    def __init__(self, G, F, Kin, Kst, sigma=nn.Tanh, time_gating=True, spatial_gating=None, E=1, bias=True):
+        super().__init__()
+        self.G, self.F, self.Kin, self.Kst, self.E = G, F, Kin, Kst, E
+        self.S = None
+        self.graph = None
+        self.weight_A = nn.parameter.Parameter(torch.empty(F, E, Kin, G))
+        self.weight_B = nn.parameter.Parameter(torch.empty(F, E, Kst, F))
+        self.sigma = sigma
+        self.time_gating = time_gating
+        self.spatial_gating = spatial_gating
+        self.bias_flag = bias
+        if bias:
+            self.bias = nn.parameter.Parameter(torch.empty(F, 1))
+        else:
+            self.register_parameter('bias', None)
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        stdv = 1. / math.sqrt(self.G * self.Kin)        # all three with the INPUT filter's stdv (graphML.py:2229-2235)
+        self.weight_A.data.uniform_(-stdv, stdv)
+        self.weight_B.data.uniform_(-stdv, stdv)
+        if self.bias is not None:
+            self.bias.data.uniform_(-stdv, stdv)
+
+    def _sub_cell(self):
+        c = GGCRNNCell(self.G, self.F, self.Kin, self.Kst, self.sigma, time_gating=False, E=self.E, bias=self.bias_flag)
+        c.addGSO(self.graph)
+        return c
+
+    def addGSO(self, S):
+        """Store the GSO (dense E x N x N tensor or GraphOperator) and (re-)create the gate sub-networks,
+        in the reference's construction order so that seeded initialisation matches (graphML.py:2237-2334)."""
+        if isinstance(S, torch.Tensor):
+            assert len(S.shape) == 3
+            assert S.shape[0] == self.E
+            assert S.shape[2] == S.shape[1]
+        graph = as_operator(S)
+        assert graph.E == self.E
+        self.N = graph.N
+        self.S = S
+        self.graph = graph
+        if self.time_gating == True:  # noqa: E712  (the reference compares with ==)
+            dimInputMLP = self.N * self.F
+            self.GFL_in = self._sub_cell()
+            self.MLP_in = nn.Sequential(nn.Linear(dimInputMLP, 1, bias=self.bias_flag), nn.Sigmoid())
+            self.GFL_forget = self._sub_cell()
+            self.MLP_forget = nn.Sequential(nn.Linear(dimInputMLP, 1, bias=self.bias_flag), nn.Sigmoid())
+            self.GFL_out = self._sub_cell()      # built and saved but never used (graphML.py:2280-2290)
+            self.MLP_out = nn.Sequential(nn.Linear(dimInputMLP, 1, bias=self.bias_flag), nn.Sigmoid())
+        if self.spatial_gating is not None:
+            if self.spatial_gating == 'node':
+                self.GRNN_node_in = self._sub_cell()
+                gni = GraphFilter(self.F, 1, self.Kst, self.E, self.bias_flag)
+                gni.addGSO(self.graph)
+                self.GFL_node_in = nn.Sequential(gni, nn.Sigmoid())
+                self.GRNN_node_forget = self._sub_cell()
+                gnf = GraphFilter(self.F, 1, self.Kst, self.E, self.bias_flag)
+                gnf.addGSO(self.graph)
+                self.GFL_node_forget = nn.Sequential(gnf, nn.Sigmoid())
+            elif self.spatial_gating == 'edge':
+                self.input_attention = GraphAttentional(self.F, self.F, 1)
+                self.input_attention.addGSO(self.graph)
+                self.forget_attention = GraphAttentional(self.F, self.F, 1)
+                self.forget_attention.addGSO(self.graph)
+
+    def _apply(self, fn, *args, **kwargs):
+        super()._apply(fn, *args, **kwargs)
+        if self.graph is not None:
+            self.graph = self.graph.to(self.weight_A.device)
+        return self
+
+    # -- node-major building blocks ---------------------------------------------------------------
+    def _gate_state(self, Xn, h0n):
+        """sigma(A(S)x_t + b + B(S)h0 + b) for all t of an un-gated sub-cell: [T][N][B][F] (graphML.py:2362)."""
+        ya = ops.lsigf_node_major(Xn, self.weight_A, self.bias, self.graph, 1.0)
+        yb = ops.lsigf_node_major(h0n, self.weight_B, self.bias, self.graph, 1.0)
+        return self.sigma(ya + yb)
+
+    @staticmethod
+    def _time_gate(sub, mlp, Xn, h0n):
+        """sigmoid(Linear(vec_{F,N}(c_t)))  ->  [T][1][B][1]  (graphML.py:2364-2366)."""
+        c = sub._gate_state(Xn, h0n)                                   # T x N x B x F
+        lin = mlp[0]
+        T, N, B, F = c.shape
+        wnf = lin.weight.view(F, N).t().contiguous()                    # row-major vec over (f, n) -> [N][F]
+        g = torch.einsum('tnbf,nf->tb', c, wnf)
+        if lin.bias is not None:
+            g = g + lin.bias
+        return torch.sigmoid(g).view(T, 1, B, 1)
+
+    @staticmethod
+    def _node_gate(sub, gfl, Xn, h0n):
+        """sigmoid(GraphFilter_{F->1}(d_t))  ->  [T][N][B][1]  (graphML.py:2383-2389)."""
+        d = sub._gate_state(Xn, h0n)
+        return torch.sigmoid(gfl[0].forward_node_major(d))
+
+    def forward(self, X, h0):
+        assert h0.shape[0] == X.shape[0]
+        ops.require_device(X, h0, self.weight_A)
+        B, T, F_in, N = X.shape
+        assert F_in == self.G and N == self.N
+        Xn = ops.pack_node_major(X)                                     # T x N x B x G
+        h0n = ops.pack_node_major(h0.reshape(B, 1, self.F, N))          # 1 x N x B x F
+        ya = ops.lsigf_node_major(Xn, self.weight_A, self.bias, self.graph, 1.0)      # all t at once
+        gi = gf = None
+        if self.time_gating == True:  # noqa: E712
+            gi = self._time_gate(self.GFL_in, self.MLP_in, Xn, h0n)
+            gf = self._time_gate(self.GFL_forget, self.MLP_forget, Xn, h0n)
+        if self.spatial_gating == 'node':
+            ni = self._node_gate(self.GRNN_node_in, self.GFL_node_in, Xn, h0n)
+            nf = self._node_gate(self.GRNN_node_forget, self.GFL_node_forget, Xn, h0n)
+            ya = ni * ya
+        elif self.spatial_gating == 'edge':
+            ya = self.input_attention.forward_node_major(ya)
+        if gi is not None:
+            ya = gi * ya
+        h = h0n
+        Hs = []
+        for t in range(T):
+            yb = ops.lsigf_node_major(h, self.weight_B, self.bias, self.graph, 1.0)   # 1 x N x B x F
+            if self.spatial_gating == 'node':
+                yb = nf[t:t + 1] * yb
+            elif self.spatial_gating == 'edge':
+                yb = self.forget_attention.forward_node_major(yb)
+            if gf is not None:
+                yb = gf[t:t + 1] * yb
+            h = self.sigma(ya[t:t + 1] + yb)
+            Hs.append(h)
+        Hn = torch.cat(Hs, dim=0)                                       # T x N x B x F
+        return ops.unpack_node_major(Hn)
+
+    def extra_repr(self):
+        return 'in_features=%d, state_features=%d, taps=(%d,%d), time_gating=%s, spatial_gating=%s, %s' % (
+            self.G, self.F, self.Kin, self.Kst, self.time_gating, self.spatial_gating,
+            ('GSO stored: number_nodes=%d' % self.N) if self.graph is not None else 'no GSO stored')

@@ -1,0 +1,64 @@
+"""ctypes binding of libgcrnn_hip.so (the C ABI declared in include/gcrnn.h).
+
+There is no CPU fallback: if the library is missing, import fails loudly with
+the build command. Entry points return an int status; `check` raises.
+"""
+import ctypes as C
+import os
+
+from . import build as _build
+
+F32, F64, BF16 = 0, 1, 2
+
+_c_i64 = C.c_int64
+_c_p = C.c_void_p
+
+
+class GcrnnError(RuntimeError):
+    pass
+
+
+def _load():
+    path = _build.LIBPATH
+    if not os.path.exists(path):
+        raise ImportError(
+            'gated_gcrnns_amd: %s is missing. Build it with `python -m gated_gcrnns_amd.build` '
+            '(needs hipcc; there is no CPU fallback).' % path)
+    lib = C.CDLL(path)
+    sig = {
+        'gcrnn_version': (C.c_int, []),
+        'gcrnn_status_string': (C.c_char_p, [C.c_int]),
+        'gcrnn_csr_count': (C.c_int, [_c_p, _c_i64, C.c_int, C.c_int, C.c_double, C.POINTER(_c_i64)]),
+        'gcrnn_csr_fill': (C.c_int, [_c_p, _c_i64, C.c_int, C.c_int, C.c_double, _c_p, _c_p, _c_p]),
+        'gcrnn_degree_order': (C.c_int, [_c_p, _c_i64, _c_p]),
+        'gcrnn_pack_node_major': (C.c_int, [C.c_int, _c_p, _c_p, _c_i64, _c_i64, _c_i64, _c_i64, _c_p, _c_p]),
+        'gcrnn_unpack_node_major': (C.c_int, [C.c_int, _c_p, _c_p, _c_i64, _c_i64, _c_i64, _c_i64, _c_p, _c_p]),
+        'gcrnn_spmm': (C.c_int, [C.c_int, _c_i64, _c_p, _c_p, _c_p, _c_p, _c_p, _c_i64, _c_i64, C.c_int, _c_p]),
+        'gcrnn_taps_forward': (C.c_int, [C.c_int, _c_p, _c_p, _c_i64, _c_p, _c_p, C.c_double, _c_p,
+                                         _c_i64, _c_i64, _c_i64, _c_i64, C.c_int, _c_p]),
+        'gcrnn_taps_backward_data': (C.c_int, [C.c_int, _c_p, _c_p, _c_p, _c_p, _c_i64,
+                                               _c_i64, _c_i64, _c_i64, _c_i64, _c_p]),
+        'gcrnn_taps_backward_weight': (C.c_int, [C.c_int, _c_p, _c_p, _c_p, _c_i64, _c_p, _c_p, C.c_double,
+                                                 _c_i64, _c_i64, _c_i64, _c_i64, _c_p]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    return lib, sorted(sig)
+
+
+lib, EXPORTS = _load()
+
+
+def check(status, what=''):
+    if status != 0:
+        raise GcrnnError('%s failed: %s (status %d)' % (what or 'gcrnn call', lib.gcrnn_status_string(status).decode(), status))
+
+
+def dtype_code(torch_dtype):
+    import torch
+    try:
+        return {torch.float32: F32, torch.float64: F64, torch.bfloat16: BF16}[torch_dtype]
+    except KeyError:
+        raise GcrnnError('unsupported dtype %s (float32, float64, bfloat16)' % torch_dtype)

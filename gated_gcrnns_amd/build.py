@@ -1,0 +1,60 @@
+"""Build recipe for libgcrnn_hip.so (hipcc, gfx950 only, in-tree).
+
+    python -m gated_gcrnns_amd.build            # or __graft_entry__.build()
+
+hipcc cross-compiles without a GPU; the built .so is git-ignored but travels to
+the GPU box with the source snapshot.
+"""
+import glob
+import os
+import subprocess
+import sys
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(PKG, 'csrc')
+LIBDIR = os.path.join(PKG, 'lib')
+LIBPATH = os.path.join(LIBDIR, 'libgcrnn_hip.so')
+HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+FLAGS = ['-O3', '-std=c++17', '--offload-arch=gfx950', '-fPIC', '-shared', '-Wno-unused-result']
+
+
+def sources():
+    return sorted(glob.glob(os.path.join(CSRC, '*.hip')) + glob.glob(os.path.join(CSRC, '*.cpp')))
+
+
+def needs_build():
+    if not os.path.exists(LIBPATH):
+        return True
+    t = os.path.getmtime(LIBPATH)
+    deps = sources() + glob.glob(os.path.join(CSRC, '*.h')) + [os.path.join(os.path.dirname(PKG), 'include', 'gcrnn.h')]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=True):
+    """Compile every HIP/C++ source under csrc/ into lib/libgcrnn_hip.so."""
+    if not force and not needs_build():
+        return LIBPATH
+    os.makedirs(LIBDIR, exist_ok=True)
+    # compile objects one by one (parallel-friendly, clearer errors), then link
+    objs = []
+    procs = []
+    for src in sources():
+        obj = os.path.join(LIBDIR, os.path.basename(src) + '.o')
+        objs.append(obj)
+        cmd = [HIPCC] + [f for f in FLAGS if f != '-shared'] + ['-c', src, '-o', obj]
+        if verbose:
+            print(' '.join(cmd), flush=True)
+        procs.append((src, subprocess.Popen(cmd)))
+    for src, p in procs:
+        if p.wait() != 0:
+            raise RuntimeError('hipcc failed on %s' % src)
+    cmd = [HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIBPATH] + objs
+    if verbose:
+        print(' '.join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return LIBPATH
+
+
+if __name__ == '__main__':
+    build(force='--force' in sys.argv)
+    print(LIBPATH)

@@ -1,0 +1,21 @@
+// Shared helpers for the gfx950 kernels of libgcrnn_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_bf16.h>
+#include <stdint.h>
+#include "../../include/gcrnn.h"
+
+#define GCRNN_CHECK_LAUNCH()                                   \
+  do {                                                         \
+    hipError_t e__ = hipGetLastError();                        \
+    if (e__ != hipSuccess) return GCRNN_ERR_LAUNCH;            \
+  } while (0)
+
+static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// 16-byte vector of T (4 x f32 or 2 x f64)
+template <typename T> struct Vec16;
+template <> struct Vec16<float> { typedef float4 type; static constexpr int n = 4; };
+template <> struct Vec16<double> { typedef double2 type; static constexpr int n = 2; };

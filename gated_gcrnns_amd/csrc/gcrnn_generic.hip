@@ -1,0 +1,375 @@
+// Any-shape kernels of the GCRNN hot path for gfx950: layout pack/unpack, batched CSR row
+// SpMM (the graph shift), and the filter-tap GEMMs (forward / data-grad / weight-grad).
+// These are the "streaming" regime of DESIGN.md: every hop is one HBM/L2 pass over a
+// node-major [N][L] matrix. The fused per-sequence kernels live in gcrnn_small.hip /
+// gcrnn_fused.hip.
+#include "gcrnn_common.h"
+
+// ------------------------------------------------------------------------------------------
+// layout: user [B][T][C][N]  <->  node-major [T][N][B][C]
+// For a fixed t this is a transpose of the (Q = B*C) x N matrix whose row q = (b, c) starts at
+// ((b*T + t)*C + c)*N.  32x32 LDS tile, 256 threads (32 x 8).
+// ------------------------------------------------------------------------------------------
+template <typename T, bool PACK>
+__global__ __launch_bounds__(256) void layout_kernel(const T* __restrict__ src, T* __restrict__ dst, int64_t B,
+                                                     int64_t Tn, int64_t C, int64_t N,
+                                                     const int32_t* __restrict__ perm) {
+  __shared__ T tile[32][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int64_t n0 = (int64_t)blockIdx.x * 32, q0 = (int64_t)blockIdx.y * 32, t = blockIdx.z;
+  const int64_t Q = B * C;
+  if (PACK) {
+    // read user rows q (coalesced along n), write node-major rows n (coalesced along q)
+    const int64_t n = n0 + tx;
+    const int64_t nsrc = (n < N) ? (perm ? (int64_t)perm[n] : n) : 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int64_t q = q0 + ty + 8 * i;
+      T v = T(0);
+      if (q < Q && n < N) {
+        const int64_t b = q / C, c = q - b * C;
+        v = src[((b * Tn + t) * C + c) * N + nsrc];
+      }
+      tile[ty + 8 * i][tx] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int64_t nn = n0 + ty + 8 * i, q = q0 + tx;
+      if (nn < N && q < Q) dst[(t * N + nn) * Q + q] = tile[tx][ty + 8 * i];
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int64_t nn = n0 + ty + 8 * i, q = q0 + tx;
+      tile[ty + 8 * i][tx] = (nn < N && q < Q) ? src[(t * N + nn) * Q + q] : T(0);
+    }
+    __syncthreads();
+    const int64_t n = n0 + tx;
+    const int64_t ndst = (n < N) ? (perm ? (int64_t)perm[n] : n) : 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int64_t q = q0 + ty + 8 * i;
+      if (q < Q && n < N) {
+        const int64_t b = q / C, c = q - b * C;
+        dst[((b * Tn + t) * C + c) * N + ndst] = tile[tx][ty + 8 * i];
+      }
+    }
+  }
+}
+
+template <bool PACK>
+static int layout_launch(int dtype, const void* src, void* dst, int64_t B, int64_t T, int64_t C, int64_t N,
+                         const int32_t* perm, void* stream) {
+  if (!src || !dst) return GCRNN_ERR_NULL_POINTER;
+  if (B <= 0 || T <= 0 || C <= 0 || N <= 0 || T > 65535) return GCRNN_ERR_BAD_SHAPE;
+  const int64_t gy = cdiv(B * C, 32);
+  if (gy > 65535) return GCRNN_ERR_BAD_SHAPE;
+  dim3 grid((unsigned)cdiv(N, 32), (unsigned)gy, (unsigned)T);
+  if (dtype == GCRNN_F32)
+    layout_kernel<float, PACK><<<grid, 256, 0, as_stream(stream)>>>((const float*)src, (float*)dst, B, T, C, N, perm);
+  else if (dtype == GCRNN_F64)
+    layout_kernel<double, PACK><<<grid, 256, 0, as_stream(stream)>>>((const double*)src, (double*)dst, B, T, C, N, perm);
+  else if (dtype == GCRNN_BF16)
+    layout_kernel<uint16_t, PACK><<<grid, 256, 0, as_stream(stream)>>>((const uint16_t*)src, (uint16_t*)dst, B, T, C,
+                                                                         N, perm);  // bf16 moves as raw 16-bit words
+  else
+    return GCRNN_ERR_BAD_DTYPE;
+  GCRNN_CHECK_LAUNCH();
+  return GCRNN_OK;
+}
+
+extern "C" int gcrnn_pack_node_major(int dtype, const void* src, void* dst, int64_t B, int64_t T, int64_t C,
+                                     int64_t N, const int32_t* perm, void* stream) {
+  return layout_launch<true>(dtype, src, dst, B, T, C, N, perm, stream);
+}
+extern "C" int gcrnn_unpack_node_major(int dtype, const void* src, void* dst, int64_t B, int64_t T, int64_t C,
+                                       int64_t N, const int32_t* perm, void* stream) {
+  return layout_launch<false>(dtype, src, dst, B, T, C, N, perm, stream);
+}
+
+// ------------------------------------------------------------------------------------------
+// graph shift: Y[i][n][:] = sum_j val[j] * X[i][col[j]][:]
+// One workgroup per (row n, column chunk, batch i). The neighbour loop is wave-uniform
+// (rowptr/col/val depend on blockIdx only -> scalar loads); each lane streams 16 B of every
+// neighbour row, so a wave reads 1 KiB contiguous per neighbour.
+// ------------------------------------------------------------------------------------------
+template <typename T, int V>
+__global__ void spmm_kernel(int64_t N, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+                            const T* __restrict__ val, const T* __restrict__ X, T* __restrict__ Y, int64_t L,
+                            int accumulate) {
+  const int64_t n = blockIdx.x;
+  const int64_t l = ((int64_t)blockIdx.y * blockDim.x + threadIdx.x) * V;
+  if (l >= L) return;
+  const int64_t base = (int64_t)blockIdx.z * N * L;
+  const int s = rowptr[n], e = rowptr[n + 1];
+  T acc[V];
+#pragma unroll
+  for (int v = 0; v < V; ++v) acc[v] = T(0);
+  const T* xb = X + base + l;
+  for (int j = s; j < e; ++j) {
+    const int64_t c = col[j];
+    const T w = val[j];
+    if (V > 1) {
+      typedef typename Vec16<T>::type VT;
+      const VT xv = *reinterpret_cast<const VT*>(xb + c * L);
+      const T* xs = reinterpret_cast<const T*>(&xv);
+#pragma unroll
+      for (int v = 0; v < V; ++v) acc[v] += w * xs[v];
+    } else {
+      acc[0] += w * xb[c * L];
+    }
+  }
+  T* yp = Y + base + n * L + l;
+  if (V > 1) {
+    typedef typename Vec16<T>::type VT;
+    VT out;
+    T* os = reinterpret_cast<T*>(&out);
+    if (accumulate) out = *reinterpret_cast<const VT*>(yp);
+#pragma unroll
+    for (int v = 0; v < V; ++v) os[v] = accumulate ? (os[v] + acc[v]) : acc[v];
+    *reinterpret_cast<VT*>(yp) = out;
+  } else {
+    yp[0] = accumulate ? (yp[0] + acc[0]) : acc[0];
+  }
+}
+
+template <typename T>
+static int spmm_launch(int64_t N, const int32_t* rowptr, const int32_t* col, const void* val, const void* X, void* Y,
+                       int64_t L, int64_t nbatch, int accumulate, void* stream) {
+  constexpr int V = Vec16<T>::n;
+  const bool vec = (L % V == 0) && ((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(Y)) % 16 == 0);
+  const int64_t lanes = vec ? L / V : L;
+  int threads = lanes >= 256 ? 256 : (int)(cdiv(lanes, 64) * 64);
+  const int64_t gy = cdiv(lanes, threads);
+  if (gy > 65535 || nbatch > 65535) return GCRNN_ERR_BAD_SHAPE;
+  dim3 grid((unsigned)N, (unsigned)gy, (unsigned)nbatch);
+  if (vec)
+    spmm_kernel<T, V><<<grid, threads, 0, as_stream(stream)>>>(N, rowptr, col, (const T*)val, (const T*)X, (T*)Y, L, accumulate);
+  else
+    spmm_kernel<T, 1><<<grid, threads, 0, as_stream(stream)>>>(N, rowptr, col, (const T*)val, (const T*)X, (T*)Y, L, accumulate);
+  GCRNN_CHECK_LAUNCH();
+  return GCRNN_OK;
+}
+
+extern "C" int gcrnn_spmm(int dtype, int64_t N, const int32_t* rowptr, const int32_t* col, const void* val,
+                          const void* X, void* Y, int64_t L, int64_t nbatch, int accumulate, void* stream) {
+  if (!rowptr || !X || !Y) return GCRNN_ERR_NULL_POINTER;
+  if (N <= 0 || L <= 0 || nbatch <= 0 || N > 2147483647LL) return GCRNN_ERR_BAD_SHAPE;
+  if (X == Y) return GCRNN_ERR_UNSUPPORTED;  // a hop cannot run in place
+  if (dtype == GCRNN_F32) return spmm_launch<float>(N, rowptr, col, val, X, Y, L, nbatch, accumulate, stream);
+  if (dtype == GCRNN_F64) return spmm_launch<double>(N, rowptr, col, val, X, Y, L, nbatch, accumulate, stream);
+  return GCRNN_ERR_BAD_DTYPE;
+}
+
+// ------------------------------------------------------------------------------------------
+// filter taps: three GEMM flavours over one 64x64x16 LDS-tiled kernel with accessor functors.
+//   C(i, j) (+)= sum_k A(i, k) * B(k, j),  k in [blockIdx.z * ksplit, ...)
+// ------------------------------------------------------------------------------------------
+template <typename T>
+struct TapOperand {  // element (r, kk) of the concatenated hop matrix [rows][KK*G]
+  const T* z0;
+  const T* zrest;
+  int64_t zstride;
+  int G;
+  __device__ __forceinline__ const T* ptr(int64_t r, int64_t kk) const {
+    const int64_t k = kk / G, g = kk - k * G;
+    const T* base = (k == 0) ? z0 : (zrest + (k - 1) * zstride);
+    return base + r * G + g;
+  }
+};
+
+// forward: A(i,k) = Zcat[i][k] (k fast), B(k,j) = w[j][k] (k fast), C -> y[i][j]
+template <typename T>
+struct FwdA { TapOperand<T> z; static constexpr bool KFAST = true;
+  __device__ __forceinline__ T operator()(int64_t i, int64_t k) const { return *z.ptr(i, k); } };
+template <typename T>
+struct FwdB { const T* w; int64_t Kd; static constexpr bool KFAST = true;
+  __device__ __forceinline__ T operator()(int64_t k, int64_t j) const { return w[j * Kd + k]; } };
+template <typename T>
+struct FwdC { T* y; const T* bias; T bias_scale; int F; int accumulate;
+  __device__ __forceinline__ void operator()(int64_t i, int64_t j, T v) const {
+    if (bias) v += bias_scale * bias[j];
+    T* p = y + i * F + j;
+    *p = accumulate ? (*p + v) : v;
+  } };
+
+// backward data: A(i,k=f) = dy[i][f] (k fast), B(k=f, j=kk) = w[f][kk] (j fast), C -> dz_k[i][g]
+template <typename T>
+struct BdA { const T* dy; int F; static constexpr bool KFAST = true;
+  __device__ __forceinline__ T operator()(int64_t i, int64_t k) const { return dy[i * F + k]; } };
+template <typename T>
+struct BdB { const T* w; int64_t Kd; static constexpr bool KFAST = false;
+  __device__ __forceinline__ T operator()(int64_t k, int64_t j) const { return w[k * Kd + j]; } };
+template <typename T>
+struct BdC { TapOperand<T> dz;
+  __device__ __forceinline__ void operator()(int64_t i, int64_t j, T v) const { *const_cast<T*>(dz.ptr(i, j)) = v; } };
+
+// backward weight: A(i=f, k=r) = dy[r][f] (i fast), B(k=r, j=kk) = Zcat[r][kk] (j fast), C -> atomicAdd dw[f][kk]
+template <typename T>
+struct BwA { const T* dy; int F; static constexpr bool KFAST = false;
+  __device__ __forceinline__ T operator()(int64_t i, int64_t k) const { return dy[k * F + i]; } };
+template <typename T>
+struct BwB { TapOperand<T> z; static constexpr bool KFAST = false;
+  __device__ __forceinline__ T operator()(int64_t k, int64_t j) const { return *z.ptr(k, j); } };
+template <typename T>
+struct BwC { T* dw; int64_t Kd;
+  __device__ __forceinline__ void operator()(int64_t i, int64_t j, T v) const { atomicAdd(dw + i * Kd + j, v); } };
+
+template <typename T, typename AL, typename BL, typename CS>
+__global__ __launch_bounds__(256) void gemm64_kernel(AL a, BL b, CS c, int64_t M, int64_t Nc, int64_t Kd,
+                                                     int64_t ksplit) {
+  __shared__ T As[16][64 + 4];
+  __shared__ T Bs[16][64 + 4];
+  const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+  const int64_t m0 = (int64_t)blockIdx.x * 64, n0 = (int64_t)blockIdx.y * 64;
+  const int64_t kbeg = (int64_t)blockIdx.z * ksplit;
+  const int64_t kend = (kbeg + ksplit < Kd) ? (kbeg + ksplit) : Kd;
+  T acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = T(0);
+
+  for (int64_t k0 = kbeg; k0 < kend; k0 += 16) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int e = tid + i * 256;
+      const int r = AL::KFAST ? (e >> 4) : (e & 63);
+      const int kk = AL::KFAST ? (e & 15) : (e >> 6);
+      As[kk][r] = (m0 + r < M && k0 + kk < kend) ? a(m0 + r, k0 + kk) : T(0);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int e = tid + i * 256;
+      const int cc = BL::KFAST ? (e >> 4) : (e & 63);
+      const int kk = BL::KFAST ? (e & 15) : (e >> 6);
+      Bs[kk][cc] = (n0 + cc < Nc && k0 + kk < kend) ? b(k0 + kk, n0 + cc) : T(0);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) {
+      T av[4], bv[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) av[i] = As[kk][ty * 4 + i];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bv[j] = Bs[kk][tx * 4 + j];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] += av[i] * bv[j];
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int64_t m = m0 + ty * 4 + i;
+    if (m >= M) continue;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int64_t n = n0 + tx * 4 + j;
+      if (n < Nc) c(m, n, acc[i][j]);
+    }
+  }
+}
+
+// dbias[f] += scale * sum_r dy[r][f]
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ dy, T* __restrict__ dbias, T scale,
+                                                     int64_t rows, int F, int64_t rows_per_block) {
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+  const int64_t r1 = (r0 + rows_per_block < rows) ? r0 + rows_per_block : rows;
+  // thread handles column f = tid % Fp over rows tid / Fp + i * (256 / Fp); generic: loop columns
+  for (int f = threadIdx.x; f < F; f += blockDim.x) {
+    T s = T(0);
+    for (int64_t r = r0; r < r1; ++r) s += dy[r * F + f];
+    atomicAdd(dbias + f, scale * s);
+  }
+}
+
+static bool tap_shape_ok(int64_t rows, int64_t KK, int64_t G, int64_t F) {
+  return rows > 0 && KK > 0 && G > 0 && F > 0 && G < (1 << 30) && F < (1 << 30) && KK * G < (1LL << 31);
+}
+
+template <typename T>
+static int taps_fwd(const void* z0, const void* zrest, int64_t zstride, const void* w, const void* bias,
+                    double bias_scale, void* y, int64_t rows, int64_t KK, int64_t G, int64_t F, int accumulate,
+                    void* stream) {
+  const int64_t Kd = KK * G;
+  FwdA<T> a{{(const T*)z0, (const T*)zrest, zstride, (int)G}};
+  FwdB<T> b{(const T*)w, Kd};
+  FwdC<T> c{(T*)y, (const T*)bias, (T)bias_scale, (int)F, accumulate};
+  dim3 grid((unsigned)cdiv(rows, 64), (unsigned)cdiv(F, 64), 1);
+  gemm64_kernel<T><<<grid, 256, 0, as_stream(stream)>>>(a, b, c, rows, F, Kd, Kd);
+  GCRNN_CHECK_LAUNCH();
+  return GCRNN_OK;
+}
+
+extern "C" int gcrnn_taps_forward(int dtype, const void* z0, const void* zrest, int64_t zstride, const void* w,
+                                  const void* bias, double bias_scale, void* y, int64_t rows, int64_t KK, int64_t G,
+                                  int64_t F, int accumulate, void* stream) {
+  if (!z0 || !w || !y || (KK > 1 && !zrest)) return GCRNN_ERR_NULL_POINTER;
+  if (!tap_shape_ok(rows, KK, G, F) || cdiv(F, 64) > 65535) return GCRNN_ERR_BAD_SHAPE;
+  if (dtype == GCRNN_F32) return taps_fwd<float>(z0, zrest, zstride, w, bias, bias_scale, y, rows, KK, G, F, accumulate, stream);
+  if (dtype == GCRNN_F64) return taps_fwd<double>(z0, zrest, zstride, w, bias, bias_scale, y, rows, KK, G, F, accumulate, stream);
+  return GCRNN_ERR_BAD_DTYPE;
+}
+
+template <typename T>
+static int taps_bwd_data(const void* dy, const void* w, void* dz0, void* dzrest, int64_t zstride, int64_t rows,
+                         int64_t KK, int64_t G, int64_t F, void* stream) {
+  const int64_t Kd = KK * G;
+  BdA<T> a{(const T*)dy, (int)F};
+  BdB<T> b{(const T*)w, Kd};
+  BdC<T> c{{(const T*)dz0, (const T*)dzrest, zstride, (int)G}};
+  dim3 grid((unsigned)cdiv(rows, 64), (unsigned)cdiv(Kd, 64), 1);
+  gemm64_kernel<T><<<grid, 256, 0, as_stream(stream)>>>(a, b, c, rows, Kd, F, F);
+  GCRNN_CHECK_LAUNCH();
+  return GCRNN_OK;
+}
+
+extern "C" int gcrnn_taps_backward_data(int dtype, const void* dy, const void* w, void* dz0, void* dzrest,
+                                        int64_t zstride, int64_t rows, int64_t KK, int64_t G, int64_t F,
+                                        void* stream) {
+  if (!dy || !w || !dz0 || (KK > 1 && !dzrest)) return GCRNN_ERR_NULL_POINTER;
+  if (!tap_shape_ok(rows, KK, G, F) || cdiv(KK * G, 64) > 65535) return GCRNN_ERR_BAD_SHAPE;
+  if (dtype == GCRNN_F32) return taps_bwd_data<float>(dy, w, dz0, dzrest, zstride, rows, KK, G, F, stream);
+  if (dtype == GCRNN_F64) return taps_bwd_data<double>(dy, w, dz0, dzrest, zstride, rows, KK, G, F, stream);
+  return GCRNN_ERR_BAD_DTYPE;
+}
+
+template <typename T>
+static int taps_bwd_weight(const void* dy, const void* z0, const void* zrest, int64_t zstride, void* dw, void* dbias,
+                           double bias_scale, int64_t rows, int64_t KK, int64_t G, int64_t F, void* stream) {
+  const int64_t Kd = KK * G;
+  BwA<T> a{(const T*)dy, (int)F};
+  BwB<T> b{{(const T*)z0, (const T*)zrest, zstride, (int)G}};
+  BwC<T> c{(T*)dw, Kd};
+  // split the (huge) row reduction so that the grid fills the chip: aim at >= 1024 workgroups
+  const int64_t tiles = cdiv(F, 64) * cdiv(Kd, 64);
+  int64_t splits = cdiv(1024, tiles);
+  int64_t ksplit = cdiv(cdiv(rows, splits), 16) * 16;
+  if (ksplit < 256) ksplit = 256;
+  splits = cdiv(rows, ksplit);
+  if (splits > 65535) { ksplit = cdiv(cdiv(rows, 65535), 16) * 16; splits = cdiv(rows, ksplit); }
+  dim3 grid((unsigned)cdiv(F, 64), (unsigned)cdiv(Kd, 64), (unsigned)splits);
+  gemm64_kernel<T><<<grid, 256, 0, as_stream(stream)>>>(a, b, c, F, Kd, rows, ksplit);
+  GCRNN_CHECK_LAUNCH();
+  if (dbias) {
+    const int64_t rpb = 512;
+    colsum_kernel<T><<<(unsigned)cdiv(rows, rpb), 256, 0, as_stream(stream)>>>((const T*)dy, (T*)dbias, (T)bias_scale,
+                                                                                rows, (int)F, rpb);
+    GCRNN_CHECK_LAUNCH();
+  }
+  return GCRNN_OK;
+}
+
+extern "C" int gcrnn_taps_backward_weight(int dtype, const void* dy, const void* z0, const void* zrest,
+                                          int64_t zstride, void* dw, void* dbias, double bias_scale, int64_t rows,
+                                          int64_t KK, int64_t G, int64_t F, void* stream) {
+  if (!dy || !z0 || !dw || (KK > 1 && !zrest)) return GCRNN_ERR_NULL_POINTER;
+  if (!tap_shape_ok(rows, KK, G, F) || cdiv(F, 64) > 2147483647LL || cdiv(KK * G, 64) > 65535) return GCRNN_ERR_BAD_SHAPE;
+  if (dtype == GCRNN_F32) return taps_bwd_weight<float>(dy, z0, zrest, zstride, dw, dbias, bias_scale, rows, KK, G, F, stream);
+  if (dtype == GCRNN_F64) return taps_bwd_weight<double>(dy, z0, zrest, zstride, dw, dbias, bias_scale, rows, KK, G, F, stream);
+  return GCRNN_ERR_BAD_DTYPE;
+}

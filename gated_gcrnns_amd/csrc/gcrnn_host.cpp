@@ -1,0 +1,72 @@
+// Host-side entry points of libgcrnn_hip.so: version/status strings and graph preparation
+// (dense GSO -> CSR, degree ordering). No GPU is touched here, so these run in CPU-only tests.
+#include <algorithm>
+#include <cmath>
+#include <numeric>
+#include <vector>
+#include "../../include/gcrnn.h"
+
+extern "C" int gcrnn_version(void) { return 100; }  // 0.1.0
+
+extern "C" const char* gcrnn_status_string(int status) {
+  switch (status) {
+    case GCRNN_OK: return "ok";
+    case GCRNN_ERR_BAD_DTYPE: return "unsupported dtype for this entry point";
+    case GCRNN_ERR_BAD_SHAPE: return "bad shape (zero/negative size or a grid limit exceeded)";
+    case GCRNN_ERR_NULL_POINTER: return "null pointer for a required argument";
+    case GCRNN_ERR_UNSUPPORTED: return "unsupported argument combination";
+    case GCRNN_ERR_LAUNCH: return "HIP kernel launch failed";
+    case GCRNN_ERR_WORKSPACE: return "workspace too small";
+    default: return "unknown status";
+  }
+}
+
+static inline bool keep(double v, double tol) { return std::fabs(v) > tol; }
+
+// entry (i, j) of the operator whose CSR we build: S^T[i][j] = S[j][i]; identity optionally added
+static inline double entry(const double* S, int64_t N, int transpose, int add_identity, int64_t i, int64_t j) {
+  double v = transpose ? S[j * N + i] : S[i * N + j];
+  if (add_identity && i == j) v += 1.0;
+  return v;
+}
+
+extern "C" int gcrnn_csr_count(const double* S, int64_t N, int transpose, int add_identity, double tol, int64_t* nnz) {
+  if (!S || !nnz) return GCRNN_ERR_NULL_POINTER;
+  if (N <= 0 || tol < 0) return GCRNN_ERR_BAD_SHAPE;
+  int64_t c = 0;
+  for (int64_t i = 0; i < N; ++i)
+    for (int64_t j = 0; j < N; ++j) c += keep(entry(S, N, transpose, add_identity, i, j), tol);
+  *nnz = c;
+  return GCRNN_OK;
+}
+
+extern "C" int gcrnn_csr_fill(const double* S, int64_t N, int transpose, int add_identity, double tol, int32_t* rowptr,
+                              int32_t* col, double* val) {
+  if (!S || !rowptr) return GCRNN_ERR_NULL_POINTER;
+  if (N <= 0 || N > 2147483647LL || tol < 0) return GCRNN_ERR_BAD_SHAPE;
+  int64_t c = 0;
+  rowptr[0] = 0;
+  for (int64_t i = 0; i < N; ++i) {
+    for (int64_t j = 0; j < N; ++j) {
+      const double v = entry(S, N, transpose, add_identity, i, j);
+      if (keep(v, tol)) {
+        if (c >= 2147483647LL) return GCRNN_ERR_BAD_SHAPE;
+        if (col) col[c] = (int32_t)j;
+        if (val) val[c] = v;
+        ++c;
+      }
+    }
+    rowptr[i + 1] = (int32_t)c;
+  }
+  return GCRNN_OK;
+}
+
+extern "C" int gcrnn_degree_order(const int32_t* rowptr, int64_t N, int32_t* order) {
+  if (!rowptr || !order) return GCRNN_ERR_NULL_POINTER;
+  if (N <= 0 || N > 2147483647LL) return GCRNN_ERR_BAD_SHAPE;
+  std::iota(order, order + N, 0);
+  std::stable_sort(order, order + N, [rowptr](int32_t a, int32_t b) {
+    return (rowptr[a + 1] - rowptr[a]) > (rowptr[b + 1] - rowptr[b]);
+  });
+  return GCRNN_OK;
+}

@@ -1,0 +1,148 @@
+"""Graph shift operator (GSO) preparation: dense E x N x N  ->  device CSR.
+
+The reference keeps S dense and shifts with x @ S (Utils/graphML.py:116-123).
+Here each edge-feature slice S_e becomes
+  fwd  = CSR(S_e^T)   the shift on node-major data  ((x S)[:, n] = sum_m S[m, n] x[:, m])
+  adj  = CSR(S_e)     its adjoint (backward pass)
+  mask = CSR pattern and values of S_e + I restricted to |.| > 1e-9: the attention
+         support of graphAttention (Utils/graphML.py:577, 611-613), row m -> columns n.
+Index arrays are int32 and are built by the C ABI's host routines
+(gcrnn_csr_count / gcrnn_csr_fill), so they are exact by construction.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+
+ZERO_TOLERANCE = 1e-9
+
+
+class CSR(object):
+    """rowptr/col int32 + values (float64 master copy, cast per dtype on demand), all on one device."""
+
+    def __init__(self, rowptr, col, val, device):
+        self.N = int(rowptr.size - 1)
+        self.nnz = int(col.size)
+        self.rowptr = torch.from_numpy(rowptr).to(device)
+        self.col = torch.from_numpy(col).to(device)
+        self._val64 = torch.from_numpy(val).to(device)
+        self._vals = {torch.float64: self._val64}
+        self._rows = None
+
+    def val(self, dtype):
+        if dtype == torch.bfloat16:
+            dtype = torch.float32
+        v = self._vals.get(dtype)
+        if v is None:
+            v = self._val64.to(dtype)
+            self._vals[dtype] = v
+        return v
+
+    def rows(self):
+        """Expanded row index per non-zero (int64), for index-based composed ops."""
+        if self._rows is None:
+            counts = (self.rowptr[1:] - self.rowptr[:-1]).long()
+            self._rows = torch.repeat_interleave(torch.arange(self.N, device=self.rowptr.device), counts)
+        return self._rows
+
+    def to(self, device):
+        out = CSR.__new__(CSR)
+        out.N, out.nnz = self.N, self.nnz
+        out.rowptr, out.col = self.rowptr.to(device), self.col.to(device)
+        out._val64 = self._val64.to(device)
+        out._vals = {torch.float64: out._val64}
+        out._rows = None
+        return out
+
+
+def csr_from_dense(S, transpose=False, add_identity=False, tol=0.0):
+    """Host CSR arrays (rowptr int32[N+1], col int32[nnz], val float64[nnz]) via the C ABI."""
+    S = np.ascontiguousarray(np.asarray(S, dtype=np.float64))
+    assert S.ndim == 2 and S.shape[0] == S.shape[1]
+    N = S.shape[0]
+    nnz = C.c_int64(0)
+    sp = S.ctypes.data_as(C.c_void_p)
+    _lib.check(_lib.lib.gcrnn_csr_count(sp, N, int(transpose), int(add_identity), float(tol), C.byref(nnz)), 'csr_count')
+    rowptr = np.empty(N + 1, dtype=np.int32)
+    col = np.empty(nnz.value, dtype=np.int32)
+    val = np.empty(nnz.value, dtype=np.float64)
+    _lib.check(_lib.lib.gcrnn_csr_fill(sp, N, int(transpose), int(add_identity), float(tol),
+                                       rowptr.ctypes.data_as(C.c_void_p), col.ctypes.data_as(C.c_void_p),
+                                       val.ctypes.data_as(C.c_void_p)), 'csr_fill')
+    return rowptr, col, val
+
+
+def degree_order(rowptr):
+    rowptr = np.ascontiguousarray(rowptr, dtype=np.int32)
+    order = np.empty(rowptr.size - 1, dtype=np.int32)
+    _lib.check(_lib.lib.gcrnn_degree_order(rowptr.ctypes.data_as(C.c_void_p), rowptr.size - 1,
+                                           order.ctypes.data_as(C.c_void_p)), 'degree_order')
+    return order
+
+
+class GraphOperator(object):
+    """Device-resident sparse form of a GSO  S: E x N x N  (numpy array or torch tensor)."""
+
+    def __init__(self, S, device=None):
+        if isinstance(S, torch.Tensor):
+            if device is None:
+                device = S.device
+            S = S.detach().cpu().numpy()
+        S = np.asarray(S, dtype=np.float64)
+        assert S.ndim == 3, 'GSO must be E x N x N'
+        assert S.shape[1] == S.shape[2]
+        self.E, self.N = int(S.shape[0]), int(S.shape[1])
+        self.device = torch.device(device if device is not None else 'cpu')
+        self.fwd = [CSR(*csr_from_dense(S[e], transpose=True), device=self.device) for e in range(self.E)]
+        self.adj = [CSR(*csr_from_dense(S[e], transpose=False), device=self.device) for e in range(self.E)]
+        # attention support: mask = sum_e |S_e + I| > 1e-9 (graphML.py:577, 611-613); values S_e + I on it
+        Splus = S + np.eye(self.N).reshape(1, self.N, self.N)
+        mask = (np.abs(Splus).sum(axis=0) > ZERO_TOLERANCE).astype(np.float64)
+        rp, col, _ = csr_from_dense(mask)
+        self.mask = CSR(rp, col, np.ones(col.size), device=self.device)
+        rows = np.repeat(np.arange(self.N), np.diff(rp))
+        self.mask_vals = [torch.from_numpy(np.ascontiguousarray(Splus[e][rows, col])).to(self.device) for e in range(self.E)]
+        self.nnz = sum(c.nnz for c in self.fwd)
+
+    def to(self, device):
+        device = torch.device(device)
+        if device.type == 'cuda' and device.index is None:
+            device = torch.device('cuda', torch.cuda.current_device())
+        if device == self.device:
+            return self
+        moved = self.__dict__.setdefault('_moved', {})
+        if device in moved:
+            return moved[device]
+        out = GraphOperator.__new__(GraphOperator)
+        out.E, out.N, out.nnz, out.device = self.E, self.N, self.nnz, device
+        out.fwd = [c.to(device) for c in self.fwd]
+        out.adj = [c.to(device) for c in self.adj]
+        out.mask = self.mask.to(device)
+        out.mask_vals = [v.to(device) for v in self.mask_vals]
+        moved[device] = out
+        out._moved = {self.device: self}
+        return out
+
+    def __repr__(self):
+        return 'GraphOperator(E=%d, N=%d, nnz=%d, device=%s)' % (self.E, self.N, self.nnz, self.device)
+
+
+_CACHE = {}
+
+
+def as_operator(S):
+    """Accept a GraphOperator or a dense E x N x N tensor (cached on its storage + version)."""
+    if isinstance(S, GraphOperator):
+        return S
+    assert isinstance(S, torch.Tensor), 'GSO must be a torch.Tensor or a GraphOperator'
+    assert S.dim() == 3, 'GSO must be E x N x N'
+    key = (S.data_ptr(), tuple(S.shape), S._version, str(S.device), S.dtype)
+    op = _CACHE.get(key)
+    if op is None:
+        if len(_CACHE) > 16:
+            _CACHE.clear()
+        op = GraphOperator(S, device=S.device)
+        _CACHE[key] = op
+    return op

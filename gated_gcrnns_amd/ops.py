@@ -1,0 +1,199 @@
+"""torch.autograd bindings over the C ABI (include/gcrnn.h).
+
+Everything here moves raw device pointers into libgcrnn_hip.so on the current
+HIP stream; torch only owns the memory. CPU tensors are rejected: the product
+has no CPU path (the CPU restatement lives in oracle/ and is test-only).
+
+Node-major layout used by every op: X[T][N][B][C] (see include/gcrnn.h).
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import lib, check, dtype_code, GcrnnError
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def require_device(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise GcrnnError('gated_gcrnns_amd has no CPU path: move the module and its inputs to a ROCm '
+                             'device (model.to("cuda"), x.cuda()); got a tensor on %s' % t.device)
+
+
+# ------------------------------------------------------------------------------------------ layout
+def _pack_raw(x, perm=None):
+    B, T, Cc, N = x.shape
+    out = torch.empty((T, N, B, Cc), dtype=x.dtype, device=x.device)
+    check(lib.gcrnn_pack_node_major(dtype_code(x.dtype), _p(x), _p(out), B, T, Cc, N, _p(perm), _stream()), 'pack')
+    return out
+
+
+def _unpack_raw(X, perm=None):
+    T, N, B, Cc = X.shape
+    out = torch.empty((B, T, Cc, N), dtype=X.dtype, device=X.device)
+    check(lib.gcrnn_unpack_node_major(dtype_code(X.dtype), _p(X), _p(out), B, T, Cc, N, _p(perm), _stream()), 'unpack')
+    return out
+
+
+class _Pack(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        return _pack_raw(x.contiguous())
+
+    @staticmethod
+    def backward(ctx, g):
+        return _unpack_raw(g.contiguous())
+
+
+class _Unpack(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, X):
+        return _unpack_raw(X.contiguous())
+
+    @staticmethod
+    def backward(ctx, g):
+        return _pack_raw(g.contiguous())
+
+
+def pack_node_major(x):
+    """user [B][T][C][N] -> node-major [T][N][B][C]"""
+    require_device(x)
+    assert x.dim() == 4
+    return _Pack.apply(x)
+
+
+def unpack_node_major(X):
+    """node-major [T][N][B][C] -> user [B][T][C][N]"""
+    require_device(X)
+    assert X.dim() == 4
+    return _Unpack.apply(X)
+
+
+# ------------------------------------------------------------------------------------------ shift
+def spmm_raw(csr, X, out=None, accumulate=False):
+    """Y[i][n][:] (+)= sum_j val[j] X[i][col[j]][:] on a contiguous [nbatch][N][L...] tensor."""
+    N = csr.N
+    assert X.is_contiguous() and X.dim() >= 3
+    nbatch = X.shape[0]
+    assert X.shape[1] == N, 'node-major tensor has %d rows, graph has %d nodes' % (X.shape[1], N)
+    L = X[0, 0].numel()
+    if out is None:
+        assert not accumulate
+        out = torch.empty_like(X)
+    check(lib.gcrnn_spmm(dtype_code(X.dtype), N, _p(csr.rowptr), _p(csr.col), _p(csr.val(X.dtype)), _p(X), _p(out),
+                         L, nbatch, int(accumulate), _stream()), 'spmm')
+    return out
+
+
+class _Shift(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, X, fwd, adj):
+        ctx.adj = adj
+        return spmm_raw(fwd, X.contiguous())
+
+    @staticmethod
+    def backward(ctx, g):
+        return spmm_raw(ctx.adj, g.contiguous()), None, None
+
+
+def graph_shift(X, graph, e=0):
+    """One application of the GSO on node-major data: the reference's x @ S_e (graphML.py:123)."""
+    require_device(X)
+    return _Shift.apply(X, graph.fwd[e], graph.adj[e])
+
+
+# ------------------------------------------------------------------------------------------ LSIGF
+class _LSIGF(torch.autograd.Function):
+    """Node-major linear shift-invariant graph filter (graphML.py:47-140) for all E, K.
+
+    forward : hops z_{e,k} = P_e z_{e,k-1} (CSR(S_e^T) SpMM), then one tap GEMM per edge feature.
+    backward: dz = dy W (tap GEMM), reverse hop chain with CSR(S_e) in Horner form, dW by a
+              row-reduction GEMM. The hop matrices are saved, not recomputed.
+    """
+
+    @staticmethod
+    def forward(ctx, X, w, bias, graph, bias_scale):
+        T, N, B, G = X.shape
+        F, E, K, Gw = w.shape
+        assert Gw == G and E == graph.E and N == graph.N
+        dt = dtype_code(X.dtype)
+        X = X.contiguous()
+        rows = T * N * B
+        zstride = rows * G
+        zrest = torch.empty((E, max(K - 1, 1), T, N, B, G), dtype=X.dtype, device=X.device) if K > 1 else None
+        y = torch.empty((T, N, B, F), dtype=X.dtype, device=X.device)
+        wc = w.contiguous()
+        bvec = bias.contiguous().view(-1) if bias is not None else None
+        st = _stream()
+        for e in range(E):
+            src = X
+            for k in range(1, K):
+                spmm_raw(graph.fwd[e], src, out=zrest[e, k - 1])
+                src = zrest[e, k - 1]
+            we = wc[:, e].contiguous() if E > 1 else wc
+            check(lib.gcrnn_taps_forward(dt, _p(X), _p(zrest[e]) if K > 1 else None, zstride, _p(we),
+                                         _p(bvec) if e == 0 else None, float(bias_scale), _p(y), rows, K, G, F,
+                                         int(e > 0), st), 'taps_forward')
+        ctx.save_for_backward(X, zrest, wc)
+        ctx.graph = graph
+        ctx.has_bias = bias is not None
+        ctx.bias_shape = tuple(bias.shape) if bias is not None else None
+        ctx.bias_scale = float(bias_scale)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        X, zrest, wc = ctx.saved_tensors
+        graph = ctx.graph
+        T, N, B, G = X.shape
+        F, E, K, _ = wc.shape
+        dt = dtype_code(X.dtype)
+        dy = dy.contiguous()
+        rows = T * N * B
+        zstride = rows * G
+        st = _stream()
+        need_x, need_w, need_b = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.needs_input_grad[2] and ctx.has_bias
+        dX = None
+        dW = torch.zeros_like(wc) if need_w else None
+        db = torch.zeros(F, dtype=X.dtype, device=X.device) if need_b else None
+        for e in range(E):
+            we = wc[:, e].contiguous() if E > 1 else wc
+            if need_x:
+                dz0 = torch.empty_like(X)
+                dzr = torch.empty((max(K - 1, 1), T, N, B, G), dtype=X.dtype, device=X.device) if K > 1 else None
+                check(lib.gcrnn_taps_backward_data(dt, _p(dy), _p(we), _p(dz0), _p(dzr), zstride, rows, K, G, F, st),
+                      'taps_backward_data')
+                # dX += dz0 + A(dz1 + A(dz2 + ... A dz_{K-1}))   with A = adjoint shift = CSR(S_e) SpMM
+                for k in range(K - 1, 0, -1):
+                    dst = dzr[k - 2] if k >= 2 else dz0
+                    spmm_raw(graph.adj[e], dzr[k - 1], out=dst, accumulate=True)
+                dX = dz0 if dX is None else dX.add_(dz0)
+            if need_w or need_b:
+                dwe = dW if E == 1 else torch.zeros((F, K, G), dtype=X.dtype, device=X.device)
+                if not need_w:
+                    dwe = torch.zeros((F, K, G), dtype=X.dtype, device=X.device)
+                check(lib.gcrnn_taps_backward_weight(dt, _p(dy), _p(X), _p(zrest[e]) if K > 1 else None, zstride,
+                                                     _p(dwe), _p(db) if (need_b and e == 0) else None,
+                                                     ctx.bias_scale, rows, K, G, F, st), 'taps_backward_weight')
+                if need_w and E > 1:
+                    dW[:, e] = dwe
+        if db is not None:
+            db = db.view(ctx.bias_shape)
+        return dX, dW, db, None, None
+
+
+def lsigf_node_major(X, w, bias, graph, bias_scale=1.0):
+    """X: [T][N][B][G] node-major -> [T][N][B][F]; w: F x E x K x G; bias: F x 1 or None."""
+    require_device(X, w, bias)
+    if w.dtype != X.dtype:
+        raise GcrnnError('filter taps are %s but the signal is %s' % (w.dtype, X.dtype))
+    return _LSIGF.apply(X, w, bias, graph, bias_scale)

@@ -1,0 +1,99 @@
+/*
+ * gcrnn.h -- C ABI of the MI355X-native gated-GCRNN hot path (libgcrnn_hip.so).
+ *
+ * The reference (luanaruiz9/gated_gcrnns) is pure Python/PyTorch and has no
+ * FFI; its hot path sits behind torch.nn.Module classes.  This header is the
+ * boundary a binding of that path would target: plain pointers and sizes, no
+ * torch types.  Every entry point names the reference code it replaces
+ * (paths relative to the reference repo).  The Python nn.Module mirror in
+ * gated_gcrnns_amd/ reaches these through ctypes.
+ *
+ * Conventions
+ *   - dtype: GCRNN_F32 / GCRNN_F64 (/ GCRNN_BF16 where stated): element type of
+ *     every data/weight pointer of the call.
+ *   - "user layout"      x[B][T][C][N]   node index minor   (graphML.py:2186-2192)
+ *   - "node-major layout" X[T][N][B][C]  channel minor; one (t) slice is an
+ *     [N][L = B*C] row matrix on which the graph shift is a CSR row SpMM.
+ *   - The graph shift operator S (E = 1 slice) is passed as CSR arrays that live
+ *     in DEVICE memory: int32 rowptr[N+1], int32 col[nnz], val[nnz] (dtype of
+ *     the call; fp32 for GCRNN_BF16).  The reference's row-vector shift
+ *     (x S)[g,n] = sum_m x[g,m] S[m,n] (graphML.py:116-123) is a row SpMM with
+ *     CSR(S^T) on node-major data; its adjoint uses CSR(S).
+ *   - stream: a hipStream_t passed as void* (NULL = default stream).  No entry
+ *     point allocates, frees or synchronises; all are hipGraph-capturable.
+ *   - return: 0 = GCRNN_OK, otherwise an error code (gcrnn_status_string()).
+ *     Shape errors are reported, never clamped; the Python mirror raises.
+ */
+#ifndef GCRNN_H
+#define GCRNN_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { GCRNN_F32 = 0, GCRNN_F64 = 1, GCRNN_BF16 = 2 };
+
+enum {
+  GCRNN_OK = 0,
+  GCRNN_ERR_BAD_DTYPE = 1,
+  GCRNN_ERR_BAD_SHAPE = 2,
+  GCRNN_ERR_NULL_POINTER = 3,
+  GCRNN_ERR_UNSUPPORTED = 4,
+  GCRNN_ERR_LAUNCH = 5,
+  GCRNN_ERR_WORKSPACE = 6
+};
+
+int gcrnn_version(void);
+const char* gcrnn_status_string(int status);
+
+/* ---- host-side graph preparation (no GPU needed) ------------------------------------------
+ * Dense S (row-major N x N, double) -> CSR with ascending columns, keeping |S[i][j]| > tol.
+ * transpose != 0 builds CSR of S^T (the forward shift operator on node-major data);
+ * add_identity != 0 builds the pattern of S + I used by the attention mask
+ * (graphML.py:577, 611-613).  Replaces the dense E x N x N GSO of graphML.py:117,123. */
+int gcrnn_csr_count(const double* S, int64_t N, int transpose, int add_identity, double tol, int64_t* nnz);
+int gcrnn_csr_fill(const double* S, int64_t N, int transpose, int add_identity, double tol,
+                   int32_t* rowptr, int32_t* col, double* val);
+/* Row processing order for the fused kernels: nodes sorted by descending degree (stable). */
+int gcrnn_degree_order(const int32_t* rowptr, int64_t N, int32_t* order);
+
+/* ---- layout ------------------------------------------------------------------------------
+ * pack:   dst[t][n'][b][c] = src[b][t][c][perm ? perm[n'] : n']     (user -> node-major)
+ * unpack: dst[b][t][c][perm ? perm[n'] : n'] = src[t][n'][b][c]     (node-major -> user)
+ * perm (device int32[N]) may be NULL.  These replace the reference's narrow/view/cat state
+ * plumbing (graphML.py:2353-2354, 2425-2427). */
+int gcrnn_pack_node_major(int dtype, const void* src, void* dst, int64_t B, int64_t T, int64_t C, int64_t N,
+                          const int32_t* perm, void* stream);
+int gcrnn_unpack_node_major(int dtype, const void* src, void* dst, int64_t B, int64_t T, int64_t C, int64_t N,
+                            const int32_t* perm, void* stream);
+
+/* ---- graph shift: batched CSR row SpMM ------------------------------------------------------
+ * Y[i][n][l] = (accumulate ? Y[i][n][l] : 0) + sum_{j in row n} val[j] * X[i][col[j]][l],  i < nbatch, l < L.
+ * Replaces x = torch.matmul(x, S) (graphML.py:123) and, with CSR(S), its adjoint. */
+int gcrnn_spmm(int dtype, int64_t N, const int32_t* rowptr, const int32_t* col, const void* val,
+               const void* X, void* Y, int64_t L, int64_t nbatch, int accumulate, void* stream);
+
+/* ---- filter taps ----------------------------------------------------------------------------
+ * rows = number of (t, n, b) rows; KK = E*K taps; z_0 = z0, z_k = zrest + (k-1)*zstride (k >= 1),
+ * each [rows][G]; w = [F][KK][G] (the reference's F x E x K x G weight, graphML.py:2215-2216);
+ * bias = [F] or NULL.
+ * forward : y[r][f] = (accumulate ? y[r][f] : 0) + sum_{k,g} z_k[r][g] w[f][k][g] + bias_scale*bias[f]
+ *           (graphML.py:134-139; bias_scale = 2 folds the double bias add of graphML.py:2420-2421)
+ * bwd_data: dz_k[r][g] = sum_f dy[r][f] w[f][k][g]           (dz0 / dzrest mirror z0 / zrest)
+ * bwd_wgt : dw[f][k][g] += sum_r dy[r][f] z_k[r][g] ; dbias[f] += bias_scale * sum_r dy[r][f]
+ *           (dw / dbias are accumulated into; the caller zeroes them). */
+int gcrnn_taps_forward(int dtype, const void* z0, const void* zrest, int64_t zstride, const void* w,
+                       const void* bias, double bias_scale, void* y, int64_t rows, int64_t KK, int64_t G,
+                       int64_t F, int accumulate, void* stream);
+int gcrnn_taps_backward_data(int dtype, const void* dy, const void* w, void* dz0, void* dzrest, int64_t zstride,
+                             int64_t rows, int64_t KK, int64_t G, int64_t F, void* stream);
+int gcrnn_taps_backward_weight(int dtype, const void* dy, const void* z0, const void* zrest, int64_t zstride,
+                               void* dw, void* dbias, double bias_scale, int64_t rows, int64_t KK, int64_t G,
+                               int64_t F, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GCRNN_H */

@@ -1,0 +1,107 @@
+"""CPU: the C-ABI library loads, exports every symbol include/gcrnn.h declares, and its host logic
+(CSR construction, degree order, argument validation) is exact. No GPU compute is called."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT, GOLDEN
+from gated_gcrnns_amd import _lib
+from gated_gcrnns_amd.graph import GraphOperator, csr_from_dense, degree_order
+from oracle import gcrnn_oracle as orc
+
+
+def header_functions():
+    txt = open(os.path.join(ROOT, 'include', 'gcrnn.h')).read()
+    txt = re.sub(r'/\*.*?\*/', '', txt, flags=re.S)
+    return sorted(set(re.findall(r'\b(gcrnn_[a-z0-9_]+)\s*\(', txt)))
+
+
+def test_library_exports_every_declared_symbol():
+    names = header_functions()
+    assert len(names) >= 10
+    lib = C.CDLL(_lib._build.LIBPATH)
+    for n in names:
+        assert hasattr(lib, n), 'libgcrnn_hip.so does not export %s' % n
+    assert sorted(_lib.EXPORTS) == names, 'ctypes binding and header disagree'
+    assert _lib.lib.gcrnn_version() >= 100
+    assert _lib.lib.gcrnn_status_string(0) == b'ok'
+
+
+@pytest.mark.parametrize('tag', ['dir30', 'adj59', 'sbm50'])
+def test_csr_builder_is_index_exact(tag):
+    g = np.load(os.path.join(GOLDEN, 'g7_csr.npz'))
+    M = g[tag + '/dense']
+    for nm, tr in (('S', False), ('ST', True)):
+        rp, col, val = csr_from_dense(M, transpose=tr)
+        assert np.array_equal(rp, g['%s/%s_rowptr' % (tag, nm)])
+        assert np.array_equal(col, g['%s/%s_col' % (tag, nm)])
+        assert np.array_equal(val, g['%s/%s_val' % (tag, nm)])
+    rp, col, _ = csr_from_dense(M, add_identity=True, tol=1e-9)
+    assert np.array_equal(rp, g[tag + '/mask_rowptr']) and np.array_equal(col, g[tag + '/mask_col'])
+
+
+def test_csr_edge_cases():
+    Z = np.zeros((5, 5))
+    rp, col, val = csr_from_dense(Z)
+    assert rp.tolist() == [0] * 6 and col.size == 0                    # empty graph
+    rp, col, val = csr_from_dense(Z, add_identity=True, tol=1e-9)
+    assert col.tolist() == [0, 1, 2, 3, 4] and val.tolist() == [1.0] * 5
+    M = -np.eye(3)                                                      # S + I cancels: support empty
+    rp, col, _ = csr_from_dense(M, add_identity=True, tol=1e-9)
+    assert col.size == 0
+    D = np.arange(1, 17, dtype=np.float64).reshape(4, 4)               # full matrix, directed
+    rp, col, val = csr_from_dense(D, transpose=True)
+    assert np.array_equal(val.reshape(4, 4), D.T)
+    nnz = C.c_int64()
+    assert _lib.lib.gcrnn_csr_count(None, 4, 0, 0, 0.0, C.byref(nnz)) == 3          # null pointer
+    assert _lib.lib.gcrnn_csr_count(D.ctypes.data_as(C.c_void_p), 0, 0, 0, 0.0, C.byref(nnz)) == 2   # bad shape
+
+
+def test_graph_operator_matches_oracle_and_degree_order():
+    rng = np.random.default_rng(0)
+    S = (rng.random((1, 40, 40)) < 0.1) * rng.standard_normal((1, 40, 40))
+    op = GraphOperator(S)
+    rp, col, val = orc.csr_from_dense(S[0].T.copy())
+    assert np.array_equal(op.fwd[0].rowptr.numpy(), rp) and np.array_equal(op.fwd[0].col.numpy(), col)
+    assert np.array_equal(op.fwd[0].val(torch.float64).numpy(), val)
+    assert op.fwd[0].val(torch.float32).dtype == torch.float32
+    order = degree_order(op.fwd[0].rowptr.numpy())
+    deg = np.diff(rp)
+    assert sorted(order.tolist()) == list(range(40))
+    assert np.all(np.diff(deg[order]) <= 0)
+    # stable: equal degrees keep ascending node id
+    for d in np.unique(deg):
+        ids = order[deg[order] == d]
+        assert np.all(np.diff(ids) > 0)
+
+
+def test_argument_validation_without_gpu():
+    """Bad arguments are rejected before any launch (so these calls are safe on a CPU-only box)."""
+    lib = _lib.lib
+    one = C.c_void_p(16)
+    assert lib.gcrnn_spmm(0, 10, None, None, None, one, one, 4, 1, 0, None) == 3
+    assert lib.gcrnn_spmm(0, 0, one, one, one, one, C.c_void_p(32), 4, 1, 0, None) == 2
+    assert lib.gcrnn_spmm(0, 10, one, one, one, one, one, 4, 1, 0, None) == 4            # in place
+    assert lib.gcrnn_spmm(7, 10, one, one, one, one, C.c_void_p(32), 4, 1, 0, None) == 1   # dtype
+    assert lib.gcrnn_pack_node_major(0, None, one, 1, 1, 1, 1, None, None) == 3
+    assert lib.gcrnn_pack_node_major(0, one, one, 1, 0, 1, 1, None, None) == 2
+    assert lib.gcrnn_taps_forward(0, one, None, 0, one, None, 1.0, one, 8, 3, 2, 5, 0, None) == 3   # K>1 needs zrest
+    assert lib.gcrnn_taps_forward(0, one, one, 0, one, None, 1.0, one, 0, 3, 2, 5, 0, None) == 2
+    with pytest.raises(_lib.GcrnnError):
+        _lib.check(2, 'x')
+
+
+def test_module_rejects_cpu_tensors_loudly():
+    import gated_gcrnns_amd.Utils.graphML as gml
+    cell = gml.GGCRNNCell(2, 3, 2, 2, torch.tanh, False, None, 1, True)
+    cell.addGSO(torch.eye(6).reshape(1, 6, 6))
+    with pytest.raises(_lib.GcrnnError, match='no CPU path'):
+        cell(torch.zeros(1, 2, 2, 6), torch.zeros(1, 3, 6))
+    with pytest.raises(AssertionError):                                  # reference graphML.py:2339
+        cell(torch.zeros(2, 2, 2, 6), torch.zeros(1, 3, 6))
+    with pytest.raises(AssertionError):                                  # reference graphML.py:2239-2243
+        cell.addGSO(torch.eye(6))

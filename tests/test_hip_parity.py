@@ -1,0 +1,194 @@
+"""GPU (-m gpu): the HIP path behind the nn.Module surface reproduces the reference's golden vectors.
+
+Tolerances (BASELINE.json north_star / SURVEY.md 8c): fp32 kernels vs the fp64 reference <= 1e-5 absolute
+on tanh-bounded outputs; fp64 kernels <= 1e-11 (summation order differs from the dense reference).
+Gradients are compared relative to the gradient's own max magnitude.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from oracle import gcrnn_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+VARIANTS = [('none', False, None), ('time', True, None), ('node', False, 'node'),
+            ('edge', False, 'edge'), ('time_node', True, 'node'), ('time_edge', True, 'edge')]
+DTYPES = [(torch.float64, 1e-11, 1e-10), (torch.float32, 1e-5, 2e-5)]
+
+
+@pytest.fixture(scope='module')
+def dev():
+    assert torch.cuda.is_available(), 'these tests need a ROCm device'
+    return torch.device('cuda:0')
+
+
+def gml():
+    import gated_gcrnns_amd.Utils.graphML as m
+    return m
+
+
+def archit():
+    import gated_gcrnns_amd.Modules.architectures as m
+    return m
+
+
+def T(a, dt, dev, grad=False):
+    return torch.tensor(a, dtype=dt, device=dev, requires_grad=grad)
+
+
+def maxdiff(t, ref):
+    return float(np.max(np.abs(t.detach().double().cpu().numpy() - ref)))
+
+
+def relgrad(t, ref):
+    return float(np.max(np.abs(t.detach().double().cpu().numpy() - ref)) / (np.max(np.abs(ref)) + 1e-30))
+
+
+@pytest.mark.parametrize('dt,tol,gtol', DTYPES)
+def test_g1_lsigf_forward_and_grads(dev, dt, tol, gtol):
+    g = load_golden('g1_lsigf')
+    S = T(g['S'], dt, dev)
+    h, x, b = T(g['h'], dt, dev, True), T(g['x'], dt, dev, True), T(g['b'], dt, dev, True)
+    y = gml().LSIGF(h, S, x, b)
+    assert maxdiff(y, g['y_bias']) <= tol
+    assert maxdiff(gml().LSIGF(h, S, x), g['y_nobias']) <= tol
+    (y * T(g['r'], dt, dev)).sum().backward()
+    assert relgrad(h.grad, g['grad_h']) <= gtol
+    assert relgrad(x.grad, g['grad_x']) <= gtol
+    assert relgrad(b.grad, g['grad_b']) <= gtol
+    # two edge features
+    y2 = gml().LSIGF(T(g['h2'], dt, dev), T(g['S2'], dt, dev), x.detach(), b.detach())
+    assert maxdiff(y2, g['y_e2']) <= tol
+
+
+@pytest.mark.parametrize('dt,tol,gtol', DTYPES)
+def test_g2_graphfilter_zero_pad(dev, dt, tol, gtol):
+    g = load_golden('g2_graphfilter')
+    gf = gml().GraphFilter(2, 5, 3)
+    gf.addGSO(T(g['S'], dt, dev))
+    gf.load_state_dict({k: torch.tensor(v) for k, v in g['params'].items()})
+    gf = gf.to(dev).to(dt)
+    assert maxdiff(gf(T(g['x'], dt, dev)), g['y']) <= tol
+    ys = gf(T(g['x_short'], dt, dev))
+    assert tuple(ys.shape) == g['y_short'].shape and maxdiff(ys, g['y_short']) <= tol
+
+
+def build_cell(g, tg, sg, dt, dev, bias=True, Kst=3):
+    cell = gml().GGCRNNCell(2, 5, 3, Kst, torch.tanh, tg, sg, 1, bias)
+    cell.addGSO(torch.tensor(g['S']))
+    cell.load_state_dict({k: torch.tensor(v) for k, v in g['params'].items()})
+    return cell.to(dev).to(dt)
+
+
+@pytest.mark.parametrize('dt,tol,gtol', DTYPES)
+@pytest.mark.parametrize('name,tg,sg', VARIANTS)
+def test_g3_g4_cell_forward_and_grads(dev, name, tg, sg, dt, tol, gtol):
+    g = load_golden('g3_cell_' + name)
+    cell = build_cell(g, tg, sg, dt, dev)
+    X, h0 = T(g['X'], dt, dev, True), T(g['h0'], dt, dev, True)
+    H = cell(X, h0)
+    assert tuple(H.shape) == g['H'].shape
+    assert maxdiff(H, g['H']) <= tol
+    H.sum().backward()
+    for k, p in cell.named_parameters():
+        ref = g['grad_sum'].get(k)
+        if ref is None:                                   # GFL_out / MLP_out never get gradients (Appendix B.4)
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
+        else:
+            assert relgrad(p.grad, ref) <= gtol, k
+    assert relgrad(X.grad, g['grad_sum_X']) <= gtol
+    assert relgrad(h0.grad, g['grad_sum_h0']) <= gtol
+    # second loss: L1 against a random target
+    cell.zero_grad(); X.grad = None; h0.grad = None
+    torch.nn.L1Loss()(cell(X, h0), T(g['target'], dt, dev)).backward()
+    for k, p in cell.named_parameters():
+        ref = g['grad_l1'].get(k)
+        if ref is not None:
+            assert relgrad(p.grad, ref) <= gtol, k
+    assert relgrad(X.grad, g['grad_l1_X']) <= gtol
+
+
+@pytest.mark.parametrize('name,tg', [('none', False), ('time', True)])
+def test_g3_nobias_unequal_taps(dev, name, tg):
+    g = load_golden('g3_cell_%s_nobias' % name)
+    cell = build_cell(g, tg, None, torch.float64, dev, bias=False, Kst=2)
+    assert maxdiff(cell(T(g['X'], torch.float64, dev), T(g['h0'], torch.float64, dev)), g['H']) <= 1e-11
+
+
+@pytest.mark.parametrize('dt,tol,gtol', DTYPES)
+@pytest.mark.parametrize('mlp,dims', [('multipMlp', [1]), ('oneMlp', [50])])
+@pytest.mark.parametrize('name,tg', [('none', False), ('time', True)])
+def test_g5_regression_models(dev, mlp, dims, name, tg, dt, tol, gtol):
+    g = load_golden('g5_reg_%s_%s' % (mlp, name))
+    m = archit().GatedGCRNNforRegression(1, 20, 2, 2, torch.tanh, torch.nn.ReLU, dims, g['S'][0], True,
+                                         time_gating=tg, spatial_gating=None, mlpType=mlp)
+    m.load_state_dict({k: torch.tensor(v) for k, v in g['params'].items()})
+    m = m.to(dev).to(dt)
+    y = m(T(g['x'], dt, dev), T(g['h0'], dt, dev))
+    assert tuple(y.shape) == g['y'].shape
+    assert maxdiff(y, g['y']) <= 10 * tol          # the head sums 20..1000 state entries
+
+
+@pytest.mark.parametrize('tag,K', [('T20K4', 4), ('T200K3', 3)])
+@pytest.mark.parametrize('name,tg', [('none', False), ('time', True)])
+def test_g5_classification_seismic_graph(dev, tag, K, name, tg):
+    g = load_golden('g5_cls_%s_%s' % (tag, name))
+    for dt, tol in ((torch.float64, 1e-10), (torch.float32, 2e-4)):
+        m = archit().GatedGCRNNforClassification(1, 20, K, K, torch.tanh, torch.nn.ReLU, [11], g['S'][0], True,
+                                                 time_gating=tg, spatial_gating=None)
+        m.load_state_dict({k: torch.tensor(v) for k, v in g['params'].items()})
+        m = m.to(dev).to(dt)
+        x, h0 = T(g['x'], dt, dev), T(g['h0'], dt, dev)
+        assert maxdiff(m(x, h0), g['y']) <= tol      # logits sum 1180 state entries
+        Hl = m.stateGCRNN(x, h0)[:, -1]
+        assert maxdiff(Hl, g['h_last']) <= (1e-11 if dt == torch.float64 else 1e-5)
+
+
+def test_g8_midsize_n1000(dev):
+    g = load_golden('g8_mid')
+    N, B, Tn, G, F, K = [int(v) for v in g['shape']]
+    S = np.zeros((1, N, N))
+    S[0, g['coo_row'], g['coo_col']] = g['coo_val']
+    X = np.random.default_rng(int(g['x_seed'][0])).standard_normal((B, Tn, G, N))
+    for dt, tol in ((torch.float64, 1e-11), (torch.float32, 1e-5)):
+        cell = gml().GGCRNNCell(G, F, K, K, torch.tanh, False, None, 1, True)
+        cell.addGSO(torch.tensor(S))
+        cell.load_state_dict({k: torch.tensor(v) for k, v in g['params'].items()})
+        cell = cell.to(dev).to(dt)
+        H = cell(T(X, dt, dev), torch.zeros(B, F, N, dtype=dt, device=dev))
+        Hn = H.double().cpu().numpy()
+        assert np.max(np.abs(Hn.reshape(-1)[g['sample_idx']] - g['sample_val'])) <= tol
+        assert np.max(np.abs(Hn[0, 3, 0] - g['H_b0_t3_f0'])) <= tol
+        assert abs(Hn.sum() - g['checksum'][0]) <= (1e-7 if dt == torch.float64 else 5e-2)
+
+
+def test_layout_roundtrip_and_shift_linearity(dev):
+    """Size-independent properties at a larger size: pack/unpack is an exact inverse; the CSR shift is linear
+    and equals the dense row-vector shift x @ S computed by the oracle on a sample."""
+    from gated_gcrnns_amd import ops
+    from gated_gcrnns_amd.graph import GraphOperator
+    rng = np.random.default_rng(3)
+    N, B, Tn, Cc = 777, 5, 3, 9
+    S = ((rng.random((1, N, N)) < 0.01) * rng.standard_normal((1, N, N)))
+    op = GraphOperator(S, device=dev)
+    x = torch.randn(B, Tn, Cc, N, dtype=torch.float64, device=dev)
+    xn = ops.pack_node_major(x)
+    assert tuple(xn.shape) == (Tn, N, B, Cc)
+    assert torch.equal(ops.unpack_node_major(xn), x)                     # bit-exact inverse
+    assert torch.equal(xn[1, :, 2, 4], x[2, 1, 4, :])
+    y = ops.graph_shift(xn, op)
+    ref = x.cpu().numpy() @ S[0]
+    assert maxdiff(ops.unpack_node_major(y), ref) <= 1e-12
+    a = torch.randn_like(xn)
+    lhs = ops.graph_shift(2.5 * xn - a, op)
+    assert float((lhs - (2.5 * y - ops.graph_shift(a, op))).abs().max()) <= 1e-12
+    # empty rows and ragged degrees: a graph with isolated nodes
+    S2 = S.copy(); S2[0, :, :50] = 0.0; S2[0, :50, :] = 0.0
+    op2 = GraphOperator(S2, device=dev)
+    y2 = ops.graph_shift(xn, op2)
+    assert float(y2[:, :50].abs().max()) == 0.0
+    # bf16 layout moves raw words
+    xb = x.to(torch.bfloat16)
+    assert torch.equal(ops.unpack_node_major(ops.pack_node_major(xb)), xb)
