@@ -6,6 +6,11 @@ the build command. Entry points return an int status; `check` raises.
 import ctypes as C
 import os
 
+# torch FIRST: it ships its own libamdhip64.so.7. libgcrnn_hip.so must bind to that same runtime instance
+# (device pointers and streams are only meaningful inside one HIP runtime); loading ours first would pull
+# the system /opt/rocm runtime into the process beside torch's and launches would see "no device".
+import torch  # noqa: F401
+
 from . import build as _build
 
 F32, F64, BF16 = 0, 1, 2
@@ -20,6 +25,8 @@ class GcrnnError(RuntimeError):
 
 def _load():
     path = _build.LIBPATH
+    if _build.needs_build() and os.path.exists(_build.HIPCC):
+        _build.build(verbose=False)          # in-tree, gfx950; sources newer than the .so (or no .so yet)
     if not os.path.exists(path):
         raise ImportError(
             'gated_gcrnns_amd: %s is missing. Build it with `python -m gated_gcrnns_amd.build` '
@@ -28,6 +35,7 @@ def _load():
     sig = {
         'gcrnn_version': (C.c_int, []),
         'gcrnn_status_string': (C.c_char_p, [C.c_int]),
+        'gcrnn_last_hip_error': (C.c_char_p, []),
         'gcrnn_csr_count': (C.c_int, [_c_p, _c_i64, C.c_int, C.c_int, C.c_double, C.POINTER(_c_i64)]),
         'gcrnn_csr_fill': (C.c_int, [_c_p, _c_i64, C.c_int, C.c_int, C.c_double, _c_p, _c_p, _c_p]),
         'gcrnn_degree_order': (C.c_int, [_c_p, _c_i64, _c_p]),
@@ -53,7 +61,9 @@ lib, EXPORTS = _load()
 
 def check(status, what=''):
     if status != 0:
-        raise GcrnnError('%s failed: %s (status %d)' % (what or 'gcrnn call', lib.gcrnn_status_string(status).decode(), status))
+        detail = lib.gcrnn_last_hip_error().decode() if status == 5 else ''
+        raise GcrnnError('%s failed: %s (status %d) %s' % (what or 'gcrnn call', lib.gcrnn_status_string(status).decode(),
+                                                        status, detail))
 
 
 def dtype_code(torch_dtype):

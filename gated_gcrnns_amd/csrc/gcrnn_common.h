@@ -5,10 +5,17 @@
 #include <stdint.h>
 #include "../../include/gcrnn.h"
 
+// hipGetLastError() is per-thread and sticky until read: other runtime users (PyTorch) leave benign
+// codes behind, so clear it before a launch and read it right after.
+#define GCRNN_PRE_LAUNCH() (void)hipGetLastError()
+extern "C" void gcrnn_note_hip_error(int code, const char* what);
 #define GCRNN_CHECK_LAUNCH()                                   \
   do {                                                         \
     hipError_t e__ = hipGetLastError();                        \
-    if (e__ != hipSuccess) return GCRNN_ERR_LAUNCH;            \
+    if (e__ != hipSuccess) {                                   \
+      gcrnn_note_hip_error((int)e__, hipGetErrorString(e__));  \
+      return GCRNN_ERR_LAUNCH;                                 \
+    }                                                          \
   } while (0)
 
 static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }

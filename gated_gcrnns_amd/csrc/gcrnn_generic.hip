@@ -65,6 +65,7 @@ static int layout_launch(int dtype, const void* src, void* dst, int64_t B, int64
   if (B <= 0 || T <= 0 || C <= 0 || N <= 0 || T > 65535) return GCRNN_ERR_BAD_SHAPE;
   const int64_t gy = cdiv(B * C, 32);
   if (gy > 65535) return GCRNN_ERR_BAD_SHAPE;
+  GCRNN_PRE_LAUNCH();
   dim3 grid((unsigned)cdiv(N, 32), (unsigned)gy, (unsigned)T);
   if (dtype == GCRNN_F32)
     layout_kernel<float, PACK><<<grid, 256, 0, as_stream(stream)>>>((const float*)src, (float*)dst, B, T, C, N, perm);
@@ -143,6 +144,7 @@ static int spmm_launch(int64_t N, const int32_t* rowptr, const int32_t* col, con
   int threads = lanes >= 256 ? 256 : (int)(cdiv(lanes, 64) * 64);
   const int64_t gy = cdiv(lanes, threads);
   if (gy > 65535 || nbatch > 65535) return GCRNN_ERR_BAD_SHAPE;
+  GCRNN_PRE_LAUNCH();
   dim3 grid((unsigned)N, (unsigned)gy, (unsigned)nbatch);
   if (vec)
     spmm_kernel<T, V><<<grid, threads, 0, as_stream(stream)>>>(N, rowptr, col, (const T*)val, (const T*)X, (T*)Y, L, accumulate);
@@ -299,6 +301,7 @@ static int taps_fwd(const void* z0, const void* zrest, int64_t zstride, const vo
   FwdA<T> a{{(const T*)z0, (const T*)zrest, zstride, (int)G}};
   FwdB<T> b{(const T*)w, Kd};
   FwdC<T> c{(T*)y, (const T*)bias, (T)bias_scale, (int)F, accumulate};
+  GCRNN_PRE_LAUNCH();
   dim3 grid((unsigned)cdiv(rows, 64), (unsigned)cdiv(F, 64), 1);
   gemm64_kernel<T><<<grid, 256, 0, as_stream(stream)>>>(a, b, c, rows, F, Kd, Kd);
   GCRNN_CHECK_LAUNCH();
@@ -322,6 +325,7 @@ static int taps_bwd_data(const void* dy, const void* w, void* dz0, void* dzrest,
   BdA<T> a{(const T*)dy, (int)F};
   BdB<T> b{(const T*)w, Kd};
   BdC<T> c{{(const T*)dz0, (const T*)dzrest, zstride, (int)G}};
+  GCRNN_PRE_LAUNCH();
   dim3 grid((unsigned)cdiv(rows, 64), (unsigned)cdiv(Kd, 64), 1);
   gemm64_kernel<T><<<grid, 256, 0, as_stream(stream)>>>(a, b, c, rows, Kd, F, F);
   GCRNN_CHECK_LAUNCH();
@@ -352,6 +356,7 @@ static int taps_bwd_weight(const void* dy, const void* z0, const void* zrest, in
   if (ksplit < 256) ksplit = 256;
   splits = cdiv(rows, ksplit);
   if (splits > 65535) { ksplit = cdiv(cdiv(rows, 65535), 16) * 16; splits = cdiv(rows, ksplit); }
+  GCRNN_PRE_LAUNCH();
   dim3 grid((unsigned)cdiv(F, 64), (unsigned)cdiv(Kd, 64), (unsigned)splits);
   gemm64_kernel<T><<<grid, 256, 0, as_stream(stream)>>>(a, b, c, F, Kd, rows, ksplit);
   GCRNN_CHECK_LAUNCH();

@@ -2,6 +2,7 @@
 // (dense GSO -> CSR, degree ordering). No GPU is touched here, so these run in CPU-only tests.
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
 #include <numeric>
 #include <vector>
 #include "../../include/gcrnn.h"
@@ -20,6 +21,13 @@ extern "C" const char* gcrnn_status_string(int status) {
     default: return "unknown status";
   }
 }
+
+// last HIP runtime error seen by a launch check (diagnostics for GCRNN_ERR_LAUNCH)
+static thread_local char g_last_hip_error[256] = "";
+extern "C" void gcrnn_note_hip_error(int code, const char* what) {
+  snprintf(g_last_hip_error, sizeof(g_last_hip_error), "hip error %d: %s", code, what ? what : "?");
+}
+extern "C" const char* gcrnn_last_hip_error(void) { return g_last_hip_error; }
 
 static inline bool keep(double v, double tol) { return std::fabs(v) > tol; }
 

@@ -47,6 +47,8 @@ enum {
 
 int gcrnn_version(void);
 const char* gcrnn_status_string(int status);
+/* Text of the HIP runtime error behind the calling thread's last GCRNN_ERR_LAUNCH ("" if none). */
+const char* gcrnn_last_hip_error(void);
 
 /* ---- host-side graph preparation (no GPU needed) ------------------------------------------
  * Dense S (row-major N x N, double) -> CSR with ascending columns, keeping |S[i][j]| > tol.

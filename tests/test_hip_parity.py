@@ -66,7 +66,7 @@ def test_g1_lsigf_forward_and_grads(dev, dt, tol, gtol):
 @pytest.mark.parametrize('dt,tol,gtol', DTYPES)
 def test_g2_graphfilter_zero_pad(dev, dt, tol, gtol):
     g = load_golden('g2_graphfilter')
-    gf = gml().GraphFilter(2, 5, 3)
+    gf = gml().GraphFilter(2, 5, 3).double()
     gf.addGSO(T(g['S'], dt, dev))
     gf.load_state_dict({k: torch.tensor(v) for k, v in g['params'].items()})
     gf = gf.to(dev).to(dt)
@@ -78,6 +78,7 @@ def test_g2_graphfilter_zero_pad(dev, dt, tol, gtol):
 def build_cell(g, tg, sg, dt, dev, bias=True, Kst=3):
     cell = gml().GGCRNNCell(2, 5, 3, Kst, torch.tanh, tg, sg, 1, bias)
     cell.addGSO(torch.tensor(g['S']))
+    cell = cell.double()                     # goldens are fp64: load at full precision, cast afterwards
     cell.load_state_dict({k: torch.tensor(v) for k, v in g['params'].items()})
     return cell.to(dev).to(dt)
 
@@ -123,7 +124,7 @@ def test_g3_nobias_unequal_taps(dev, name, tg):
 def test_g5_regression_models(dev, mlp, dims, name, tg, dt, tol, gtol):
     g = load_golden('g5_reg_%s_%s' % (mlp, name))
     m = archit().GatedGCRNNforRegression(1, 20, 2, 2, torch.tanh, torch.nn.ReLU, dims, g['S'][0], True,
-                                         time_gating=tg, spatial_gating=None, mlpType=mlp)
+                                         time_gating=tg, spatial_gating=None, mlpType=mlp).double()
     m.load_state_dict({k: torch.tensor(v) for k, v in g['params'].items()})
     m = m.to(dev).to(dt)
     y = m(T(g['x'], dt, dev), T(g['h0'], dt, dev))
@@ -137,7 +138,7 @@ def test_g5_classification_seismic_graph(dev, tag, K, name, tg):
     g = load_golden('g5_cls_%s_%s' % (tag, name))
     for dt, tol in ((torch.float64, 1e-10), (torch.float32, 2e-4)):
         m = archit().GatedGCRNNforClassification(1, 20, K, K, torch.tanh, torch.nn.ReLU, [11], g['S'][0], True,
-                                                 time_gating=tg, spatial_gating=None)
+                                                 time_gating=tg, spatial_gating=None).double()
         m.load_state_dict({k: torch.tensor(v) for k, v in g['params'].items()})
         m = m.to(dev).to(dt)
         x, h0 = T(g['x'], dt, dev), T(g['h0'], dt, dev)
@@ -153,12 +154,12 @@ def test_g8_midsize_n1000(dev):
     S[0, g['coo_row'], g['coo_col']] = g['coo_val']
     X = np.random.default_rng(int(g['x_seed'][0])).standard_normal((B, Tn, G, N))
     for dt, tol in ((torch.float64, 1e-11), (torch.float32, 1e-5)):
-        cell = gml().GGCRNNCell(G, F, K, K, torch.tanh, False, None, 1, True)
+        cell = gml().GGCRNNCell(G, F, K, K, torch.tanh, False, None, 1, True).double()
         cell.addGSO(torch.tensor(S))
         cell.load_state_dict({k: torch.tensor(v) for k, v in g['params'].items()})
         cell = cell.to(dev).to(dt)
         H = cell(T(X, dt, dev), torch.zeros(B, F, N, dtype=dt, device=dev))
-        Hn = H.double().cpu().numpy()
+        Hn = H.detach().double().cpu().numpy()
         assert np.max(np.abs(Hn.reshape(-1)[g['sample_idx']] - g['sample_val'])) <= tol
         assert np.max(np.abs(Hn[0, 3, 0] - g['H_b0_t3_f0'])) <= tol
         assert abs(Hn.sum() - g['checksum'][0]) <= (1e-7 if dt == torch.float64 else 5e-2)
