@@ -90,7 +90,7 @@ def main():
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--batch', type=int, default=256, help='sequences per GPU per step')
-    ap.add_argument('--dtype', default='f32', choices=['bf16', 'f32', 'f64'])
+    ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32', 'f64'])
     ap.add_argument('--mode', default='fwd', choices=['fwd', 'train'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     args = ap.parse_args()

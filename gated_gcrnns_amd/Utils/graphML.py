@@ -306,6 +306,8 @@ class GGCRNNCell(nn.Module):
         ops.require_device(X, h0, self.weight_A)
         B, T, F_in, N = X.shape
         assert F_in == self.G and N == self.N
+        if self._use_fused(X, h0):
+            return self._forward_fused(X, h0)
         Xn = ops.pack_node_major(X)                                     # T x N x B x G
         h0n = ops.pack_node_major(h0.reshape(B, 1, self.F, N))          # 1 x N x B x F
         ya = ops.lsigf_node_major(Xn, self.weight_A, self.bias, self.graph, 1.0)      # all t at once
@@ -335,6 +337,23 @@ class GGCRNNCell(nn.Module):
             Hs.append(h)
         Hn = torch.cat(Hs, dim=0)                                       # T x N x B x F
         return ops.unpack_node_major(Hn)
+
+    # -- fused flagship path (bf16, un-gated / time-gated, sigma = tanh, inference) -------------------
+    def _use_fused(self, X, h0):
+        if torch.is_grad_enabled() and (X.requires_grad or h0.requires_grad or self.weight_A.requires_grad):
+            return False            # BPTT runs on the composed path
+        if self.spatial_gating is not None or self.sigma not in (torch.tanh, nn.functional.tanh):
+            return False
+        if self.time_gating == True:  # noqa: E712   (gate pre-pass in bf16 not wired yet)
+            return False
+        return ops.fused_supported(self.N, self.F, self.G, self.Kin, self.Kst, X.dtype, self.E) and \
+            self.weight_A.dtype == X.dtype and h0.dtype == X.dtype
+
+    def _forward_fused(self, X, h0):
+        gi = gf = None
+        if self.time_gating == True:  # noqa: E712
+            raise NotImplementedError('time-gated fused path needs bf16 gate pre-pass')
+        return ops.fused_cell_forward(X, h0, self.weight_A, self.weight_B, self.bias, self.graph, gi, gf)
 
     def extra_repr(self):
         return 'in_features=%d, state_features=%d, taps=(%d,%d), time_gating=%s, spatial_gating=%s, %s' % (

@@ -48,6 +48,15 @@ def _load():
                                                _c_i64, _c_i64, _c_i64, _c_i64, _c_p]),
         'gcrnn_taps_backward_weight': (C.c_int, [C.c_int, _c_p, _c_p, _c_p, _c_i64, _c_p, _c_p, C.c_double,
                                                  _c_i64, _c_i64, _c_i64, _c_i64, _c_p]),
+        'gcrnn_ell_size': (C.c_int, [_c_p, _c_i64, _c_p, C.c_int, C.c_int, _c_i64, C.POINTER(_c_i64)]),
+        'gcrnn_ell_fill': (C.c_int, [_c_p, _c_p, _c_p, _c_i64, _c_p, C.c_int, C.c_int, _c_i64, _c_p, _c_p, _c_p]),
+        'gcrnn_fused_supported': (C.c_int, [_c_i64, _c_i64, _c_i64, _c_i64]),
+        'gcrnn_fused_padded_nodes': (_c_i64, []),
+        'gcrnn_pack_seq_major': (C.c_int, [C.c_int, _c_p, _c_p, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_p, _c_p]),
+        'gcrnn_unpack_seq_major': (C.c_int, [C.c_int, _c_p, _c_p, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_p, _c_p]),
+        'gcrnn_fused_pack_weights': (C.c_int, [C.c_int, _c_p, _c_p, _c_p, _c_i64, _c_i64, _c_i64, _c_i64, _c_p]),
+        'gcrnn_fused_forward_bf16': (C.c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p,
+                                               _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_p]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)          # AttributeError if the symbol is not exported

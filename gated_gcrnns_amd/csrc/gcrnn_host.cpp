@@ -78,3 +78,61 @@ extern "C" int gcrnn_degree_order(const int32_t* rowptr, int64_t N, int32_t* ord
   });
   return GCRNN_OK;
 }
+
+// ---- sliced ELL for the fused kernels ---------------------------------------------------------
+// Nodes are renumbered by `order` (position p holds original node order[p]); tiles of `tile` positions.
+// Tile t stores deg_t = max degree in the tile rounded up to `pad` entries per position, laid out
+// [entry][position-in-tile] so that one wave reads 16 consecutive (col, val) pairs per entry.
+// colpos = neighbour's POSITION (renumbered); padding entries are (0, 0.0).
+static int ell_tile_deg(const int32_t* rowptr, const int32_t* order, int64_t N, int64_t t, int tile, int pad) {
+  int d = 0;
+  for (int r = 0; r < tile; ++r) {
+    const int64_t p = t * tile + r;
+    if (p < N) {
+      const int32_t n = order ? order[p] : (int32_t)p;
+      d = std::max(d, rowptr[n + 1] - rowptr[n]);
+    }
+  }
+  return (d + pad - 1) / pad * pad;
+}
+
+extern "C" int gcrnn_ell_size(const int32_t* rowptr, int64_t N, const int32_t* order, int tile, int pad,
+                              int64_t ntiles, int64_t* nentries) {
+  if (!rowptr || !nentries) return GCRNN_ERR_NULL_POINTER;
+  if (N <= 0 || tile <= 0 || pad <= 0 || ntiles * tile < N) return GCRNN_ERR_BAD_SHAPE;
+  int64_t tot = 0;
+  for (int64_t t = 0; t < ntiles; ++t) tot += ell_tile_deg(rowptr, order, N, t, tile, pad);
+  *nentries = tot;   // in units of `tile` (col,val) pairs
+  return GCRNN_OK;
+}
+
+extern "C" int gcrnn_ell_fill(const int32_t* rowptr, const int32_t* col, const double* val, int64_t N,
+                              const int32_t* order, int tile, int pad, int64_t ntiles, int32_t* tile_off,
+                              int32_t* ell_col, float* ell_val) {
+  if (!rowptr || !col || !val || !tile_off || !ell_col || !ell_val) return GCRNN_ERR_NULL_POINTER;
+  if (N <= 0 || tile <= 0 || pad <= 0 || ntiles * tile < N) return GCRNN_ERR_BAD_SHAPE;
+  std::vector<int32_t> pos(N);
+  for (int64_t p = 0; p < N; ++p) pos[order ? order[p] : p] = (int32_t)p;
+  int64_t off = 0;
+  for (int64_t t = 0; t < ntiles; ++t) {
+    tile_off[t] = (int32_t)off;
+    const int d = ell_tile_deg(rowptr, order, N, t, tile, pad);
+    for (int e = 0; e < d; ++e)
+      for (int r = 0; r < tile; ++r) {
+        const int64_t p = t * tile + r;
+        int32_t c = 0;
+        float v = 0.f;
+        if (p < N) {
+          const int32_t n = order ? order[p] : (int32_t)p;
+          const int32_t j = rowptr[n] + e;
+          if (j < rowptr[n + 1]) { c = pos[col[j]]; v = (float)val[j]; }
+        }
+        ell_col[(off + e) * tile + r] = c;
+        ell_val[(off + e) * tile + r] = v;
+      }
+    off += d;
+    if (off > 2147483647LL / tile) return GCRNN_ERR_BAD_SHAPE;
+  }
+  tile_off[ntiles] = (int32_t)off;
+  return GCRNN_OK;
+}

@@ -106,6 +106,36 @@ class GraphOperator(object):
         self.mask_vals = [torch.from_numpy(np.ascontiguousarray(Splus[e][rows, col])).to(self.device) for e in range(self.E)]
         self.nnz = sum(c.nnz for c in self.fwd)
 
+    def fused_plan(self):
+        """Degree-sorted sliced ELL of CSR(S^T) for the fused step kernels (E = 1): device tensors
+        order (int32 [N]), tile_off (int32 [ntiles+1]), ell_col (int32 [entries*16]), ell_val (fp32)."""
+        plan = self.__dict__.get('_fused_plan')
+        if plan is not None:
+            return plan
+        assert self.E == 1
+        npad = int(_lib.lib.gcrnn_fused_padded_nodes())
+        assert self.N <= npad
+        ntiles = npad // 16
+        c = self.fwd[0]
+        rowptr = np.ascontiguousarray(c.rowptr.cpu().numpy())
+        col = np.ascontiguousarray(c.col.cpu().numpy())
+        val = np.ascontiguousarray(c.val(torch.float64).cpu().numpy())
+        order = degree_order(rowptr)
+        nent = C.c_int64(0)
+        vp = lambda a: a.ctypes.data_as(C.c_void_p)
+        _lib.check(_lib.lib.gcrnn_ell_size(vp(rowptr), self.N, vp(order), 16, 4, ntiles, C.byref(nent)), 'ell_size')
+        tile_off = np.zeros(ntiles + 1, dtype=np.int32)
+        ell_col = np.zeros(max(nent.value, 1) * 16, dtype=np.int32)
+        ell_val = np.zeros(max(nent.value, 1) * 16, dtype=np.float32)
+        _lib.check(_lib.lib.gcrnn_ell_fill(vp(rowptr), vp(col), vp(val), self.N, vp(order), 16, 4, ntiles,
+                                           vp(tile_off), vp(ell_col), vp(ell_val)), 'ell_fill')
+        dev = self.device
+        plan = dict(npad=npad, order=torch.from_numpy(order).to(dev), tile_off=torch.from_numpy(tile_off).to(dev),
+                    ell_col=torch.from_numpy(ell_col).to(dev), ell_val=torch.from_numpy(ell_val).to(dev),
+                    entries=int(nent.value))
+        self._fused_plan = plan
+        return plan
+
     def to(self, device):
         device = torch.device(device)
         if device.type == 'cuda' and device.index is None:

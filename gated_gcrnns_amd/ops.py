@@ -197,3 +197,48 @@ def lsigf_node_major(X, w, bias, graph, bias_scale=1.0):
     if w.dtype != X.dtype:
         raise GcrnnError('filter taps are %s but the signal is %s' % (w.dtype, X.dtype))
     return _LSIGF.apply(X, w, bias, graph, bias_scale)
+
+
+# ------------------------------------------------------------------------------------------ fused flagship path
+def fused_supported(N, F, G, Kin, Kst, dtype, E=1):
+    return (E == 1 and dtype == torch.bfloat16 and
+            bool(lib.gcrnn_fused_supported(int(N), int(F), int(G), int(max(Kin, Kst)))))
+
+
+def fused_cell_forward(X, h0, wA, wB, bias, graph, gi=None, gf=None, return_states=False):
+    """Whole GGCRNNCell forward (un-gated or time-gated) on the fused bf16 step kernel.
+
+    X: B x T x G x N bf16, h0: B x F x N bf16 (user layout) -> H: B x T x F x N bf16.
+    gi / gf: fp32 [T][B] time gates or None. Inference only (no autograd graph is recorded).
+    """
+    require_device(X, h0, wA, wB, bias)
+    B, T, G, N = X.shape
+    F = wA.shape[0]
+    Kin, Kst = wA.shape[2], wB.shape[2]
+    K = max(Kin, Kst)
+    plan = graph.fused_plan()
+    npad = plan['npad']
+    st = _stream()
+    dev = X.device
+    X = X.contiguous()
+    h0 = h0.contiguous()
+    xs = torch.empty((T, B, npad, G), dtype=torch.bfloat16, device=dev)
+    h0s = torch.empty((1, B, npad, F), dtype=torch.bfloat16, device=dev)
+    hs = torch.empty((T, B, npad, F), dtype=torch.bfloat16, device=dev)
+    check(lib.gcrnn_pack_seq_major(_lib.BF16, _p(X), _p(xs), B, T, G, N, npad, _p(plan['order']), st), 'pack_seq')
+    check(lib.gcrnn_pack_seq_major(_lib.BF16, _p(h0), _p(h0s), B, 1, F, N, npad, _p(plan['order']), st), 'pack_seq')
+    wpack = torch.empty(((F // 16) * K * ((F + G) // 32) * 64 * 8,), dtype=torch.bfloat16, device=dev)
+    check(lib.gcrnn_fused_pack_weights(dtype_code(wA.dtype), _p(wA.contiguous()), _p(wB.contiguous()), _p(wpack),
+                                       F, G, Kin, Kst, st), 'pack_weights')
+    b32 = bias.detach().float().contiguous().view(-1) if bias is not None else None
+    if gi is not None:
+        gi = gi.float().contiguous()
+        gf = gf.float().contiguous()
+    check(lib.gcrnn_fused_forward_bf16(_p(xs), _p(h0s), _p(hs), _p(wpack), _p(b32), _p(gi), _p(gf),
+                                       _p(plan['tile_off']), _p(plan['ell_col']), _p(plan['ell_val']),
+                                       B, T, N, F, G, K, st), 'fused_forward')
+    if return_states:
+        return hs, plan
+    H = torch.empty((B, T, F, N), dtype=torch.bfloat16, device=dev)
+    check(lib.gcrnn_unpack_seq_major(_lib.BF16, _p(hs), _p(H), B, T, F, N, npad, _p(plan['order']), st), 'unpack_seq')
+    return H

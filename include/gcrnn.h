@@ -95,6 +95,38 @@ int gcrnn_taps_backward_weight(int dtype, const void* dy, const void* z0, const 
                                void* dw, void* dbias, double bias_scale, int64_t rows, int64_t KK, int64_t G,
                                int64_t F, void* stream);
 
+/* ==== fused flagship path (N <= gcrnn_fused_padded_nodes(), bf16 storage, fp32 accumulate) =====
+ * Replaces the whole body of GGCRNNCell.forward's time loop (graphML.py:2351-2427) for the un-gated and
+ * the time-gated cell: one launch per step computes h_t = tanh(gi (A(S)x_t + b) + gf (B(S)h_{t-1} + b)).
+ *
+ * Graph: degree-sorted sliced ELL built on the host from CSR(S^T):
+ *   order[p]   = original node at position p (gcrnn_degree_order);  tile = 16 positions;
+ *   tile_off[] = first entry of each tile (ntiles+1 values), entries padded to multiples of `pad` (= 4);
+ *   ell_col / ell_val = [entry][16]: neighbour POSITION and weight (0, 0.0 for padding). */
+int gcrnn_ell_size(const int32_t* rowptr, int64_t N, const int32_t* order, int tile, int pad, int64_t ntiles,
+                   int64_t* nentries);
+int gcrnn_ell_fill(const int32_t* rowptr, const int32_t* col, const double* val, int64_t N, const int32_t* order,
+                   int tile, int pad, int64_t ntiles, int32_t* tile_off, int32_t* ell_col, float* ell_val);
+/* 1 if gcrnn_fused_forward_bf16 has a kernel for this shape (K = max(Kin, Kst) taps). */
+int gcrnn_fused_supported(int64_t N, int64_t F, int64_t G, int64_t K);
+int64_t gcrnn_fused_padded_nodes(void);
+/* user [B][T][C][N] <-> sequence-major [T][B][NPad][C]; position p holds node perm[p]; rows >= N are zero.
+ * dtype GCRNN_BF16 or GCRNN_F32 (same type both sides). */
+int gcrnn_pack_seq_major(int dtype, const void* src, void* dst, int64_t B, int64_t T, int64_t C, int64_t N,
+                         int64_t NPad, const int32_t* perm, void* stream);
+int gcrnn_unpack_seq_major(int dtype, const void* src, void* dst, int64_t B, int64_t T, int64_t C, int64_t N,
+                           int64_t NPad, const int32_t* perm, void* stream);
+/* weight_A [F][Kin][G] and weight_B [F][Kst][F] (E = 1; wdtype GCRNN_F32 or GCRNN_BF16) -> bf16 MFMA A-operand
+ * fragments wpack[F/16][K][(F+G)/32][64 lanes][8], K = max(Kin, Kst), missing taps zero. */
+int gcrnn_fused_pack_weights(int wdtype, const void* wA, const void* wB, void* wpack, int64_t F, int64_t G,
+                             int64_t Kin, int64_t Kst, void* stream);
+/* xs [T][B][NPad][G], h0 [B][NPad][F], hs [T][B][NPad][F]: bf16 sequence-major; bias fp32 [F] or NULL;
+ * gi / gf fp32 [T][B] time gates or both NULL (un-gated). T launches on `stream`. */
+int gcrnn_fused_forward_bf16(const void* xs, const void* h0, void* hs, const void* wpack, const float* bias,
+                             const float* gi, const float* gf, const int32_t* tile_off, const int32_t* ell_col,
+                             const float* ell_val, int64_t B, int64_t T, int64_t N, int64_t F, int64_t G, int64_t K,
+                             void* stream);
+
 #ifdef __cplusplus
 }
 #endif
