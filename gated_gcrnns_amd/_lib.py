@@ -55,8 +55,11 @@ def _load():
         'gcrnn_pack_seq_major': (C.c_int, [C.c_int, _c_p, _c_p, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_p, _c_p]),
         'gcrnn_unpack_seq_major': (C.c_int, [C.c_int, _c_p, _c_p, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_p, _c_p]),
         'gcrnn_fused_pack_weights': (C.c_int, [C.c_int, _c_p, _c_p, _c_p, _c_i64, _c_i64, _c_i64, _c_i64, _c_p]),
-        'gcrnn_fused_forward_bf16': (C.c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p,
-                                               _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_p]),
+        'gcrnn_fused_forward_bf16': (C.c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p,
+                                               _c_p, _c_p,
+                                               _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_p]),
+        'gcrnn_ell_conflict_cycles': (C.c_int, [_c_p, _c_i64, C.POINTER(_c_i64)]),
+        'gcrnn_ell_pack_lds': (C.c_int, [_c_p, _c_p, _c_i64, _c_p, _c_p]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)          # AttributeError if the symbol is not exported

@@ -14,11 +14,13 @@
 //     A operand = weight fragments, pre-arranged per lane in LDS (one ds_read_b128 each);
 //     B operand = 8 consecutive bf16 features of one node, a 16-byte global load from the node-major row;
 //     D: lane holds 4 consecutive output features of node (lane & 15) -> exactly one 16-byte LDS slot.
-//     u_{K-1} goes to LDS, u_0..u_{K-2} stay in registers (8 tiles x (K-1) x 4 fp32 per lane).
-// Phase 2 (LDS gather): K-1 hops acc'[n] = sum_m P[n,m] acc[m] + u_k[n] on a fp32 [1024][16] image in LDS
-//     (64-byte rows), double-buffered, one barrier per hop. The graph comes as degree-sorted sliced ELL
-//     (16 nodes per slice, entries [e][16]), so the neighbour loop is wave-uniform and its (col,val)
-//     loads are 128-byte coalesced; each gather is one ds_read_b128 + 4 FMAs per lane.
+//     u_{K-1} goes to LDS, u_0..u_{K-2} stay in registers (8 tiles x K x 4 fp32 per lane).
+// Phase 2 (LDS gather): K-1 hops acc'[n] = sum_m P[n,m] acc[m] + u_k[n] on ONE fp32 [1024][16] image in LDS
+//     (64-byte rows): a hop's results stay in the tap's registers until every wave has finished reading, then
+//     are written back (two barriers per hop). That leaves room to keep the graph itself in LDS: a
+//     degree-sorted sliced ELL (16 nodes per slice, entries [e][16], u16 column + f32 weight), so the
+//     neighbour loop is wave-uniform, no gather ever waits on global memory, and each gather is one
+//     ds_read_b128 + 4 FMAs per lane. Graphs whose ELL does not fit are read from global memory instead.
 // Epilogue: + bias, tanh, bf16 store of the chunk into the node-major state h_t[b][n][c*16 .. +15].
 //
 // HBM traffic per (sequence, step): read x_t and h_{t-1} (each N*64*2 B; the 4 chunk workgroups of a sequence
@@ -40,6 +42,13 @@ __device__ __forceinline__ uint16_t f2bf(float f) {
   return __builtin_bit_cast(uint16_t, (__bf16)f);   // v_cvt_pk_bf16_f32: round-to-nearest-even, NaN-safe
 }
 __device__ __forceinline__ float bf2f(uint16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
+
+// tanh(x) = 1 - 2 / (1 + exp(2x)) on the hardware exp2/rcp units: abs error < 3e-7 for all x (inf-safe: exp -> inf
+// gives 1, exp -> 0 gives -1), far below the bf16 rounding of the stored state.
+__device__ __forceinline__ float fast_tanh(float x) {
+  const float e = __builtin_amdgcn_exp2f(x * 2.8853900817779268f);      // exp(2x)
+  return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + e);
+}
 
 // ------------------------------------------------------------------------------------------
 // layout: user [B][T][C][N]  <->  sequence-major [T][B][NP][C], node positions renumbered by perm,
@@ -85,12 +94,72 @@ __global__ __launch_bounds__(256) void seq_layout_kernel(const E* __restrict__ s
   }
 }
 
+// Fast path for 16-bit elements, no permutation, even N and C: 64 (c) x 64 (n) tiles, every thread moves one
+// 4-byte pair per row, so both the user side (rows of n) and the sequence-major side (rows of c) are touched
+// in 128-byte segments.
+template <bool PACK>
+__global__ __launch_bounds__(256) void seq_layout16_kernel(const uint16_t* __restrict__ src, uint16_t* __restrict__ dst,
+                                                           int B, int Tn, int C, int N, int NPad) {
+  __shared__ uint16_t tile[64][66];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int n0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+  const int bt = blockIdx.z, b = bt / Tn, t = bt - b * Tn;
+  const int64_t ubase = ((int64_t)(b * Tn + t) * C) * N;
+  const int64_t sbase = ((int64_t)(t * B + b) * NPad) * C;
+  if (PACK) {
+    const int n = n0 + 2 * tx;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int c = c0 + ty + 8 * i;
+      uint32_t v = 0;
+      if (c < C && n < N) v = *reinterpret_cast<const uint32_t*>(src + ubase + (int64_t)c * N + n);
+      *reinterpret_cast<uint32_t*>(&tile[ty + 8 * i][2 * tx]) = v;
+    }
+    __syncthreads();
+    const int c = c0 + 2 * tx;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int nl = ty + 8 * i, nn = n0 + nl;
+      if (nn < NPad && c < C) {
+        const uint32_t v = (uint32_t)tile[2 * tx][nl] | ((uint32_t)tile[2 * tx + 1][nl] << 16);
+        *reinterpret_cast<uint32_t*>(dst + sbase + (int64_t)nn * C + c) = v;     // rows >= N receive the zeros
+      }
+    }
+  } else {
+    const int c = c0 + 2 * tx;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int nl = ty + 8 * i, nn = n0 + nl;
+      uint32_t v = 0;
+      if (nn < N && c < C) v = *reinterpret_cast<const uint32_t*>(src + sbase + (int64_t)nn * C + c);
+      tile[2 * tx][nl] = (uint16_t)(v & 0xffffu);
+      tile[2 * tx + 1][nl] = (uint16_t)(v >> 16);
+    }
+    __syncthreads();
+    const int n = n0 + 2 * tx;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int cc = c0 + ty + 8 * i;
+      if (cc < C && n < N)
+        *reinterpret_cast<uint32_t*>(dst + ubase + (int64_t)cc * N + n) = *reinterpret_cast<const uint32_t*>(&tile[ty + 8 * i][2 * tx]);
+    }
+  }
+}
+
 template <bool PACK>
 static int seq_layout_launch(int dtype, const void* src, void* dst, int64_t B, int64_t T, int64_t C, int64_t N,
                              int64_t NPad, const int32_t* perm, void* stream) {
   if (!src || !dst) return GCRNN_ERR_NULL_POINTER;
   if (B <= 0 || T <= 0 || C <= 0 || N <= 0 || NPad < N || B * T > 65535 || cdiv(C, 32) > 65535) return GCRNN_ERR_BAD_SHAPE;
   GCRNN_PRE_LAUNCH();
+  const bool aligned = ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 3) == 0;
+  if (dtype == GCRNN_BF16 && !perm && (N % 2 == 0) && (C % 2 == 0) && aligned) {
+    dim3 grid((unsigned)cdiv(PACK ? NPad : N, 64), (unsigned)cdiv(C, 64), (unsigned)(B * T));
+    seq_layout16_kernel<PACK><<<grid, 256, 0, as_stream(stream)>>>((const uint16_t*)src, (uint16_t*)dst, (int)B, (int)T,
+                                                                    (int)C, (int)N, (int)NPad);
+    GCRNN_CHECK_LAUNCH();
+    return GCRNN_OK;
+  }
   dim3 grid((unsigned)cdiv(PACK ? NPad : N, 32), (unsigned)cdiv(C, 32), (unsigned)(B * T));
   if (dtype == GCRNN_BF16)
     seq_layout_kernel<uint16_t, PACK><<<grid, 256, 0, as_stream(stream)>>>((const uint16_t*)src, (uint16_t*)dst, (int)B,
@@ -159,26 +228,45 @@ extern "C" int gcrnn_fused_pack_weights(int wdtype, const void* wA, const void* 
 // ------------------------------------------------------------------------------------------
 // the fused step
 // ------------------------------------------------------------------------------------------
-template <int K, int HS, int XS, bool GATED>
+// Hand-pipelined LDS reads for the hop loop (cdna_hip_programming.md section 5.7): hipcc does not count asm loads,
+// so every wait below is ours. LDS ops of one wave return in order, hence lgkmcnt(N) = "all but the N youngest".
+#define DS_READ_B64(dst, addr) asm volatile("ds_read_b64 %0, %1" : "=v"(dst) : "v"(addr))
+#define DS_READ_B128(dst, addr) asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(addr))
+#define LGKM_WAIT(n)                                              \
+  do {                                                            \
+    asm volatile("s_waitcnt lgkmcnt(" #n ")" ::: "memory");       \
+    __builtin_amdgcn_sched_barrier(0);                            \
+  } while (0)
+#define KEEP_ALIVE(v) asm volatile("" ::"v"(v))
+
+// LDS map (dynamic): state [NP][16] fp32 (64 KiB) | weight fragments K*KS KiB | RESIDENT: lval4 (f32x4), lcol4 (u16x4).
+// Tiles hold 16 nodes of similar degree: tile_nodes[p] lists the node of every slot p (degree-sorted order,
+// padded with node ids >= N that have no edges); memory rows are in natural node order.
+template <int K, int HS, int XS, bool GATED, bool RESIDENT>
 __global__ __launch_bounds__(512, 2) void fused_step_kernel(
-    const uint16_t* __restrict__ xt,      // [B][NP][G]   bf16
-    const uint16_t* __restrict__ hprev,   // [B][NP][F]   bf16
-    uint16_t* __restrict__ hout,          // [B][NP][F]   bf16
-    const uint4* __restrict__ wpack,      // [F/16][K][KS][64] x 16 B
-    const float* __restrict__ bias,       // [F] or null
-    const float* __restrict__ gi,         // [B] (GATED)
-    const float* __restrict__ gf,         // [B] (GATED)
-    const int32_t* __restrict__ tile_off, // [NP/16 + 1], in entries
-    const int32_t* __restrict__ ell_col,  // [entries][16] neighbour position
-    const float* __restrict__ ell_val,    // [entries][16]
-    int B, int N) {
+    const uint16_t* __restrict__ xt,        // [B][NP][G]   bf16
+    const uint16_t* __restrict__ hprev,     // [B][NP][F]   bf16
+    uint16_t* __restrict__ hout,            // [B][NP][F]   bf16
+    const uint4* __restrict__ wpack,        // [F/16][K][KS][64] x 16 B
+    const float* __restrict__ bias,         // [F] or null
+    const float* __restrict__ gi,           // [B] (GATED)
+    const float* __restrict__ gf,           // [B] (GATED)
+    const int32_t* __restrict__ tile_nodes, // [NP] node id of each tile slot
+    const int32_t* __restrict__ tile_off,   // [NP/16 + 1], in entries
+    const int32_t* __restrict__ ell_col,    // [entries][16] neighbour node id            (used when !RESIDENT)
+    const float* __restrict__ ell_val,      // [entries][16]
+    const float4* __restrict__ ell_val4,    // [entries/4][16] x 4 weights                  (LDS image, RESIDENT)
+    const uint2* __restrict__ ell_col4,     // [entries/4][16] x 4 u16 (row offset | swizzle)
+    int entries, int B, int N) {
   constexpr int KS = HS + XS;
   constexpr int F = 32 * HS, G = 32 * XS;
   constexpr int NCH = F / FC;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* buf0 = reinterpret_cast<float*>(smem);
-  float* buf1 = buf0 + NP * FC;
-  uint4* wl = reinterpret_cast<uint4*>(buf1 + NP * FC);
+  float* state = reinterpret_cast<float*>(smem);
+  uint4* wl = reinterpret_cast<uint4*>(smem + NP * FC * 4);
+  // resident graph: per group of 4 entries and tile slot r:  lval4[g][r] = 4 weights, lcol4[g][r] = 4 x u16 = (col * 64)
+  float4* lval4 = reinterpret_cast<float4*>(smem + NP * FC * 4 + K * KS * 1024);
+  uint2* lcol4 = reinterpret_cast<uint2*>(lval4 + (RESIDENT ? entries * 4 : 0));
 
   // XCD-aware placement: the NCH chunk workgroups of one sequence get block ids that are equal mod 8,
   // i.e. one XCD under round-robin dispatch (speed only; nothing depends on it).
@@ -187,10 +275,22 @@ __global__ __launch_bounds__(512, 2) void fused_step_kernel(
   const int chunk = rem >> 3, b = grp * 8 + (rem & 7);
   if (b >= B) return;
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // provably wave-uniform -> scalar loads below
   const int r = lane & 15, q = lane >> 4;
 
   for (int i = tid; i < K * KS * 64; i += 512) wl[i] = wpack[(int64_t)chunk * K * KS * 64 + i];
+  if (RESIDENT) {
+    const int n = (entries >> 2) * 16;                         // the host packed the LDS image: straight copies
+    for (int i = tid; i < n; i += 512) { lval4[i] = ell_val4[i]; lcol4[i] = ell_col4[i]; }
+  }
+  // per-wave tile ranges, fetched once through the scalar path
+  int tbeg[TILES], tend[TILES];
+#pragma unroll
+  for (int i = 0; i < TILES; ++i) {
+    tbeg[i] = tile_off[i * WAVES + wave];
+    tend[i] = tile_off[i * WAVES + wave + 1];
+  }
   __syncthreads();
 
   const uint16_t* hb = hprev + (int64_t)b * NP * F;
@@ -198,12 +298,19 @@ __global__ __launch_bounds__(512, 2) void fused_step_kernel(
   float gin = 1.f, gfo = 1.f;
   if (GATED) { gin = gi[b]; gfo = gf[b]; }
 
-  f32x4 u[TILES][K > 1 ? K - 1 : 1];
+  f32x4 u[TILES][K];
+  int nodes[TILES];
+  int woff[TILES];      // byte offset of this lane's quad in the swizzled state row of its node
+#pragma unroll
+  for (int i = 0; i < TILES; ++i) {
+    nodes[i] = tile_nodes[(i * WAVES + wave) * 16 + r];
+    woff[i] = nodes[i] * (FC * 4) + ((q ^ ((nodes[i] >> 2) & 3)) << 4);
+  }
 
   // ---- phase 1: taps on the matrix cores ------------------------------------------------------
 #pragma unroll
   for (int i = 0; i < TILES; ++i) {
-    const int node = (i * WAVES + wave) * 16 + r;
+    const int node = nodes[i];
     bf16x8 bfrag[KS];
 #pragma unroll
     for (int s = 0; s < HS; ++s)
@@ -234,70 +341,151 @@ __global__ __launch_bounds__(512, 2) void fused_step_kernel(
           acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bfrag[s], acc, 0, 0, 0);
         }
       }
-      if (tap == K - 1) *reinterpret_cast<f32x4*>(buf0 + node * FC + q * 4) = acc;
-      else u[i][tap] = acc;
+      u[i][tap] = acc;
     }
+    *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(state) + woff[i]) = u[i][K - 1];
   }
   __syncthreads();
 
-  // ---- phase 2: Horner hops in LDS ---------------------------------------------------------------
+  // ---- phase 2: Horner hops, state image in LDS -------------------------------------------------
+  const char* sbytes = reinterpret_cast<const char*>(state);
+  const int qoff = q * 16;
+  // 32-bit LDS byte addresses for the asm reads (low half of the flat LDS address = offset in the allocation)
+  const uint32_t lds0 = (uint32_t)reinterpret_cast<uintptr_t>(smem);
+  const uint32_t qx = (uint32_t)qoff;     // stored column = (col << 6) | (swizzle << 4);  ^ (q << 4) selects this lane's quad
+  const uint32_t lds_val = lds0 + NP * FC * 4 + K * KS * 1024;
+  const uint32_t lds_col = lds_val + (RESIDENT ? entries * 64 : 0);
+#pragma unroll
+  for (int j = 1; j < K; ++j) {
+#pragma unroll
+    for (int i = 0; i < TILES; ++i) {
+      const int beg = tbeg[i], end = tend[i];
+      f32x4 acc = u[i][K - 1 - j];
+      if (RESIDENT) {
+        // 4 entries per trip: one ds_read_b64 (4 pre-scaled u16 columns) + one ds_read_b128 (4 weights), then
+        // 4 gathers of 16 B and 16 FMAs. Two-deep software pipeline: the (col,val) of trip g+2 and the gathers of
+        // trip g+1 are issued before the FMAs of trip g, so every wait is on a load issued a whole trip earlier.
+        // The empty asm statements pin that order (hipcc otherwise sinks the prefetches to their uses).
+        const int g0 = beg >> 2, gend = end >> 2;
+        if (g0 < gend) {
+          // Ping-pong register sets E / O hold alternate groups. In the trip of group g (set E):
+          //   issue cols(g+2) -> cE; wait cols(g+1) = cO; issue vals(g+1) -> vO and the 4 gathers of g+1 -> xO;
+          //   wait vE, xE (issued one trip ago); 16 FMAs of group g.
+          // Both waits are lgkmcnt(6): 6 younger LDS reads are allowed to stay in flight.
+          const int glast = gend - 1;
+          const uint32_t colb = lds_col + r * 8, valb = lds_val + r * 16;
+          uint64_t cE, cO;
+          f32x4 vE, vO, xE0, xE1, xE2, xE3, xO0, xO1, xO2, xO3;
+          DS_READ_B64(cE, colb + g0 * 128);
+          DS_READ_B64(cO, colb + ((g0 + 1 < gend) ? g0 + 1 : glast) * 128);
+          DS_READ_B128(vE, valb + g0 * 256);
+          LGKM_WAIT(2);
+          DS_READ_B128(xE0, lds0 + (((uint32_t)cE & 0xffffu) ^ qx));
+          DS_READ_B128(xE1, lds0 + ((((uint32_t)cE >> 16) & 0xffffu) ^ qx));
+          DS_READ_B128(xE2, lds0 + (((uint32_t)(cE >> 32) & 0xffffu) ^ qx));
+          DS_READ_B128(xE3, lds0 + ((uint32_t)(cE >> 48) ^ qx));
+          int g = g0;
+          while (true) {
+            {   // ---- trip for group g, data in set E, prefetch into O ----
+              const int g1 = (g + 1 < gend) ? g + 1 : glast, g2 = (g + 2 < gend) ? g + 2 : glast;
+              DS_READ_B64(cE, colb + g2 * 128);
+              LGKM_WAIT(6);
+              DS_READ_B128(vO, valb + g1 * 256);
+              DS_READ_B128(xO0, lds0 + (((uint32_t)cO & 0xffffu) ^ qx));
+              DS_READ_B128(xO1, lds0 + ((((uint32_t)cO >> 16) & 0xffffu) ^ qx));
+              DS_READ_B128(xO2, lds0 + (((uint32_t)(cO >> 32) & 0xffffu) ^ qx));
+              DS_READ_B128(xO3, lds0 + ((uint32_t)(cO >> 48) ^ qx));
+              LGKM_WAIT(6);
+              acc += vE[0] * xE0;
+              acc += vE[1] * xE1;
+              acc += vE[2] * xE2;
+              acc += vE[3] * xE3;
+            }
+            if (++g >= gend) break;
+            {   // ---- trip for group g, data in set O, prefetch into E ----
+              const int g1 = (g + 1 < gend) ? g + 1 : glast, g2 = (g + 2 < gend) ? g + 2 : glast;
+              DS_READ_B64(cO, colb + g2 * 128);
+              LGKM_WAIT(6);
+              DS_READ_B128(vE, valb + g1 * 256);
+              DS_READ_B128(xE0, lds0 + (((uint32_t)cE & 0xffffu) ^ qx));
+              DS_READ_B128(xE1, lds0 + ((((uint32_t)cE >> 16) & 0xffffu) ^ qx));
+              DS_READ_B128(xE2, lds0 + (((uint32_t)(cE >> 32) & 0xffffu) ^ qx));
+              DS_READ_B128(xE3, lds0 + ((uint32_t)(cE >> 48) ^ qx));
+              LGKM_WAIT(6);
+              acc += vO[0] * xO0;
+              acc += vO[1] * xO1;
+              acc += vO[2] * xO2;
+              acc += vO[3] * xO3;
+            }
+            if (++g >= gend) break;
+          }
+          LGKM_WAIT(0);      // drain the tail prefetches before their registers may be reused
+          KEEP_ALIVE(cE); KEEP_ALIVE(cO); KEEP_ALIVE(vE); KEEP_ALIVE(vO);
+          KEEP_ALIVE(xE0); KEEP_ALIVE(xE1); KEEP_ALIVE(xE2); KEEP_ALIVE(xE3);
+          KEEP_ALIVE(xO0); KEEP_ALIVE(xO1); KEEP_ALIVE(xO2); KEEP_ALIVE(xO3);
+        }
+      } else {
+        for (int e = beg; e < end; e += 4) {      // entry counts are padded to multiples of 4
+          int cc[4]; float vv[4]; f32x4 xv[4];
+#pragma unroll
+          for (int p = 0; p < 4; ++p) { cc[p] = ell_col[(e + p) * 16 + r]; vv[p] = ell_val[(e + p) * 16 + r]; }
+#pragma unroll
+          for (int p = 0; p < 4; ++p)
+            xv[p] = *reinterpret_cast<const f32x4*>(sbytes + cc[p] * (FC * 4) + ((q ^ ((cc[p] >> 2) & 3)) << 4));
+#pragma unroll
+          for (int p = 0; p < 4; ++p) acc += vv[p] * xv[p];
+        }
+      }
+      u[i][K - 1 - j] = acc;        // the new value lives in the tap's registers until every wave has read `state`
+    }
+    if (j < K - 1) {
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < TILES; ++i) *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(state) + woff[i]) = u[i][K - 1 - j];
+      __syncthreads();
+    }
+  }
+
+  // ---- epilogue: bias, tanh, bf16 store into the node-major state h_t ------------------------------
   float bsum[4] = {0.f, 0.f, 0.f, 0.f};
   if (bias) {
     const float bs = gin + gfo;     // the one bias is added by both filters (graphML.py:2420-2421)
 #pragma unroll
     for (int c = 0; c < 4; ++c) bsum[c] = bs * bias[chunk * FC + q * 4 + c];
   }
-  const char* cur = reinterpret_cast<const char*>(buf0);
-  char* nxt = reinterpret_cast<char*>(buf1);
-  const int qoff = q * 16;
 #pragma unroll
-  for (int j = 1; j < K; ++j) {
-#pragma unroll
-    for (int i = 0; i < TILES; ++i) {
-      const int tile = i * WAVES + wave;
-      const int node = tile * 16 + r;
-      const int beg = __builtin_amdgcn_readfirstlane(tile_off[tile]);
-      const int end = __builtin_amdgcn_readfirstlane(tile_off[tile + 1]);
-      f32x4 acc = u[i][K - 1 - j];
-      for (int e = beg; e < end; e += 4) {      // entry counts are padded to multiples of 4
-        int cc[4]; float vv[4]; f32x4 xv[4];
-#pragma unroll
-        for (int p = 0; p < 4; ++p) { cc[p] = ell_col[(e + p) * 16 + r]; vv[p] = ell_val[(e + p) * 16 + r]; }
-#pragma unroll
-        for (int p = 0; p < 4; ++p) xv[p] = *reinterpret_cast<const f32x4*>(cur + cc[p] * (FC * 4) + qoff);
-#pragma unroll
-        for (int p = 0; p < 4; ++p) acc += vv[p] * xv[p];
-      }
-      if (j == K - 1) {
-        uint2 pk;
-        if (node < N) {
-          const float o0 = tanhf(acc[0] + bsum[0]), o1 = tanhf(acc[1] + bsum[1]);
-          const float o2 = tanhf(acc[2] + bsum[2]), o3 = tanhf(acc[3] + bsum[3]);
-          pk.x = (uint32_t)f2bf(o0) | ((uint32_t)f2bf(o1) << 16);
-          pk.y = (uint32_t)f2bf(o2) | ((uint32_t)f2bf(o3) << 16);
-        } else {
-          pk.x = 0u; pk.y = 0u;          // padded rows stay zero
-        }
-        *reinterpret_cast<uint2*>(hout + ((int64_t)b * NP + node) * F + chunk * FC + q * 4) = pk;
-      } else {
-        *reinterpret_cast<f32x4*>(nxt + node * (FC * 4) + qoff) = acc;
-      }
+  for (int i = 0; i < TILES; ++i) {
+    const int node = nodes[i];
+    const f32x4 acc = u[i][0];
+    uint2 pk;
+    if (node < N) {
+      const float o0 = fast_tanh(acc[0] + bsum[0]), o1 = fast_tanh(acc[1] + bsum[1]);
+      const float o2 = fast_tanh(acc[2] + bsum[2]), o3 = fast_tanh(acc[3] + bsum[3]);
+      pk.x = (uint32_t)f2bf(o0) | ((uint32_t)f2bf(o1) << 16);
+      pk.y = (uint32_t)f2bf(o2) | ((uint32_t)f2bf(o3) << 16);
+    } else {
+      pk.x = 0u; pk.y = 0u;          // padded rows stay zero
     }
-    if (j < K - 1) {
-      __syncthreads();
-      const char* t = cur; cur = nxt; nxt = const_cast<char*>(t);
-    }
+    *reinterpret_cast<uint2*>(hout + ((int64_t)b * NP + node) * F + chunk * FC + q * 4) = pk;
   }
 }
 
 template <int K, int HS, int XS>
 static int fused_forward_t(const void* xs, const void* h0, void* hs, const void* wpack, const float* bias,
-                           const float* gi, const float* gf, const int32_t* tile_off, const int32_t* ell_col,
-                           const float* ell_val, int64_t B, int64_t T, int64_t N, hipStream_t st) {
+                           const float* gi, const float* gf, const int32_t* tile_nodes, const int32_t* tile_off,
+                           const int32_t* ell_col, const float* ell_val, const void* ell_val4, const void* ell_col4,
+                           int64_t entries, int64_t B, int64_t T, int64_t N, hipStream_t st) {
   constexpr int F = 32 * HS, G = 32 * XS, KS = HS + XS;
-  const size_t lds = (size_t)2 * NP * FC * 4 + (size_t)K * KS * 64 * 16;
+  const size_t base = (size_t)NP * FC * 4 + (size_t)K * KS * 1024;
+  const size_t resident_bytes = base + (size_t)entries * 16 * 6;
+  const bool resident = resident_bytes <= 160 * 1024 && ell_val4 && ell_col4;
+  const size_t lds = resident ? resident_bytes : base;
   const bool gated = gi != nullptr;
-  auto kern = gated ? fused_step_kernel<K, HS, XS, true> : fused_step_kernel<K, HS, XS, false>;
+  typedef void (*kern_t)(const uint16_t*, const uint16_t*, uint16_t*, const uint4*, const float*, const float*,
+                         const float*, const int32_t*, const int32_t*, const int32_t*, const float*, const float4*,
+                         const uint2*, int, int, int);
+  kern_t kern = gated ? (resident ? (kern_t)fused_step_kernel<K, HS, XS, true, true> : (kern_t)fused_step_kernel<K, HS, XS, true, false>)
+                      : (resident ? (kern_t)fused_step_kernel<K, HS, XS, false, true> : (kern_t)fused_step_kernel<K, HS, XS, false, false>);
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
     return GCRNN_ERR_LAUNCH;
   const int NCH = F / FC;
@@ -309,23 +497,26 @@ static int fused_forward_t(const void* xs, const void* h0, void* hs, const void*
   for (int64_t t = 0; t < T; ++t) {
     const uint16_t* hp = (t == 0) ? (const uint16_t*)h0 : h + (t - 1) * hstep;
     kern<<<grid, 512, lds, st>>>(x + t * xstep, hp, h + t * hstep, (const uint4*)wpack, bias, gated ? gi + t * B : nullptr,
-                                 gated ? gf + t * B : nullptr, tile_off, ell_col, ell_val, (int)B, (int)N);
+                                 gated ? gf + t * B : nullptr, tile_nodes, tile_off, ell_col, ell_val,
+                                 (const float4*)ell_val4, (const uint2*)ell_col4, (int)entries, (int)B, (int)N);
   }
   GCRNN_CHECK_LAUNCH();
   return GCRNN_OK;
 }
 
 extern "C" int gcrnn_fused_forward_bf16(const void* xs, const void* h0, void* hs, const void* wpack, const float* bias,
-                                        const float* gi, const float* gf, const int32_t* tile_off,
-                                        const int32_t* ell_col, const float* ell_val, int64_t B, int64_t T, int64_t N,
-                                        int64_t F, int64_t G, int64_t K, void* stream) {
-  if (!xs || !h0 || !hs || !wpack || !tile_off || !ell_col || !ell_val) return GCRNN_ERR_NULL_POINTER;
+                                        const float* gi, const float* gf, const int32_t* tile_nodes,
+                                        const int32_t* tile_off, const int32_t* ell_col, const float* ell_val,
+                                        const void* ell_val4, const void* ell_col4, int64_t entries, int64_t B,
+                                        int64_t T, int64_t N, int64_t F, int64_t G, int64_t K, void* stream) {
+  if (!xs || !h0 || !hs || !wpack || !tile_nodes || !tile_off || !ell_col || !ell_val) return GCRNN_ERR_NULL_POINTER;
   if ((gi == nullptr) != (gf == nullptr)) return GCRNN_ERR_NULL_POINTER;
-  if (B <= 0 || T <= 0 || N <= 0 || N > NP || B > (1 << 24)) return GCRNN_ERR_BAD_SHAPE;
+  if (B <= 0 || T <= 0 || N <= 0 || N > NP || B > (1 << 24) || entries < 0 || entries % 4) return GCRNN_ERR_BAD_SHAPE;
   hipStream_t st = as_stream(stream);
 #define GCRNN_FUSED_CASE(KK, HH, XX) \
   if (K == KK && F == 32 * HH && G == 32 * XX) \
-    return fused_forward_t<KK, HH, XX>(xs, h0, hs, wpack, bias, gi, gf, tile_off, ell_col, ell_val, B, T, N, st);
+    return fused_forward_t<KK, HH, XX>(xs, h0, hs, wpack, bias, gi, gf, tile_nodes, tile_off, ell_col, ell_val, \
+                                       ell_val4, ell_col4, entries, B, T, N, st);
   GCRNN_FUSED_CASE(5, 2, 2)
   GCRNN_FUSED_CASE(4, 2, 2)
   GCRNN_FUSED_CASE(3, 2, 2)

@@ -129,10 +129,18 @@ class GraphOperator(object):
         ell_val = np.zeros(max(nent.value, 1) * 16, dtype=np.float32)
         _lib.check(_lib.lib.gcrnn_ell_fill(vp(rowptr), vp(col), vp(val), self.N, vp(order), 16, 4, ntiles,
                                            vp(tile_off), vp(ell_col), vp(ell_val)), 'ell_fill')
+        cyc = C.c_int64(0)
+        _lib.check(_lib.lib.gcrnn_ell_conflict_cycles(vp(ell_col), nent.value, C.byref(cyc)), 'ell_conflict_cycles')
+        val4 = np.zeros(max(nent.value, 4) * 16, dtype=np.float32)
+        col4 = np.zeros(max(nent.value, 4) * 16, dtype=np.uint16)
+        _lib.check(_lib.lib.gcrnn_ell_pack_lds(vp(ell_col), vp(ell_val), nent.value, vp(val4), vp(col4)), 'ell_pack_lds')
         dev = self.device
-        plan = dict(npad=npad, order=torch.from_numpy(order).to(dev), tile_off=torch.from_numpy(tile_off).to(dev),
+        tile_nodes = np.concatenate([order, np.arange(self.N, npad, dtype=np.int32)]).astype(np.int32)
+        plan = dict(npad=npad, order=torch.from_numpy(order).to(dev), tile_nodes=torch.from_numpy(tile_nodes).to(dev),
+                    tile_off=torch.from_numpy(tile_off).to(dev),
                     ell_col=torch.from_numpy(ell_col).to(dev), ell_val=torch.from_numpy(ell_val).to(dev),
-                    entries=int(nent.value))
+                    ell_val4=torch.from_numpy(val4).to(dev), ell_col4=torch.from_numpy(col4.view(np.int16)).to(dev),
+                    entries=int(nent.value), gather_cycles=int(cyc.value))
         self._fused_plan = plan
         return plan
 

@@ -225,8 +225,8 @@ def fused_cell_forward(X, h0, wA, wB, bias, graph, gi=None, gf=None, return_stat
     xs = torch.empty((T, B, npad, G), dtype=torch.bfloat16, device=dev)
     h0s = torch.empty((1, B, npad, F), dtype=torch.bfloat16, device=dev)
     hs = torch.empty((T, B, npad, F), dtype=torch.bfloat16, device=dev)
-    check(lib.gcrnn_pack_seq_major(_lib.BF16, _p(X), _p(xs), B, T, G, N, npad, _p(plan['order']), st), 'pack_seq')
-    check(lib.gcrnn_pack_seq_major(_lib.BF16, _p(h0), _p(h0s), B, 1, F, N, npad, _p(plan['order']), st), 'pack_seq')
+    check(lib.gcrnn_pack_seq_major(_lib.BF16, _p(X), _p(xs), B, T, G, N, npad, None, st), 'pack_seq')
+    check(lib.gcrnn_pack_seq_major(_lib.BF16, _p(h0), _p(h0s), B, 1, F, N, npad, None, st), 'pack_seq')
     wpack = torch.empty(((F // 16) * K * ((F + G) // 32) * 64 * 8,), dtype=torch.bfloat16, device=dev)
     check(lib.gcrnn_fused_pack_weights(dtype_code(wA.dtype), _p(wA.contiguous()), _p(wB.contiguous()), _p(wpack),
                                        F, G, Kin, Kst, st), 'pack_weights')
@@ -235,10 +235,11 @@ def fused_cell_forward(X, h0, wA, wB, bias, graph, gi=None, gf=None, return_stat
         gi = gi.float().contiguous()
         gf = gf.float().contiguous()
     check(lib.gcrnn_fused_forward_bf16(_p(xs), _p(h0s), _p(hs), _p(wpack), _p(b32), _p(gi), _p(gf),
-                                       _p(plan['tile_off']), _p(plan['ell_col']), _p(plan['ell_val']),
-                                       B, T, N, F, G, K, st), 'fused_forward')
+                                       _p(plan['tile_nodes']), _p(plan['tile_off']), _p(plan['ell_col']),
+                                       _p(plan['ell_val']), _p(plan['ell_val4']), _p(plan['ell_col4']),
+                                       plan['entries'], B, T, N, F, G, K, st), 'fused_forward')
     if return_states:
         return hs, plan
     H = torch.empty((B, T, F, N), dtype=torch.bfloat16, device=dev)
-    check(lib.gcrnn_unpack_seq_major(_lib.BF16, _p(hs), _p(H), B, T, F, N, npad, _p(plan['order']), st), 'unpack_seq')
+    check(lib.gcrnn_unpack_seq_major(_lib.BF16, _p(hs), _p(H), B, T, F, N, npad, None, st), 'unpack_seq')
     return H

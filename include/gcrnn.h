@@ -100,18 +100,25 @@ int gcrnn_taps_backward_weight(int dtype, const void* dy, const void* z0, const 
  * the time-gated cell: one launch per step computes h_t = tanh(gi (A(S)x_t + b) + gf (B(S)h_{t-1} + b)).
  *
  * Graph: degree-sorted sliced ELL built on the host from CSR(S^T):
- *   order[p]   = original node at position p (gcrnn_degree_order);  tile = 16 positions;
+ *   order[p]   = node in slot p (gcrnn_degree_order): tile t works on nodes order[16t .. 16t+15]; data rows
+ *                stay in natural node order, the ordering only groups nodes of similar degree into a tile;
  *   tile_off[] = first entry of each tile (ntiles+1 values), entries padded to multiples of `pad` (= 4);
- *   ell_col / ell_val = [entry][16]: neighbour POSITION and weight (0, 0.0 for padding). */
+ *   ell_col / ell_val = [entry][16]: neighbour node id and weight of each slot (0, 0.0 for padding). */
 int gcrnn_ell_size(const int32_t* rowptr, int64_t N, const int32_t* order, int tile, int pad, int64_t ntiles,
                    int64_t* nentries);
 int gcrnn_ell_fill(const int32_t* rowptr, const int32_t* col, const double* val, int64_t N, const int32_t* order,
                    int tile, int pad, int64_t ntiles, int32_t* tile_off, int32_t* ell_col, float* ell_val);
+/* For tile = 16, gcrnn_ell_fill orders each row's neighbours (and aims its zero-weight padding entries) so that the
+ * 16-lane groups of the kernel's ds_read_b128 gathers hit distinct LDS banks (maximum bipartite matching per entry).
+ * gcrnn_ell_conflict_cycles reports the resulting LDS cycles per gather summed over entries (4*entries = no conflict);
+ * gcrnn_ell_pack_lds builds the kernel's LDS image: val4 [entries/4][16][4] fp32, col4 [entries/4][16][4] uint16. */
+int gcrnn_ell_conflict_cycles(const int32_t* ell_col, int64_t entries, int64_t* cycles);
+int gcrnn_ell_pack_lds(const int32_t* ell_col, const float* ell_val, int64_t entries, float* val4, uint16_t* col4);
 /* 1 if gcrnn_fused_forward_bf16 has a kernel for this shape (K = max(Kin, Kst) taps). */
 int gcrnn_fused_supported(int64_t N, int64_t F, int64_t G, int64_t K);
 int64_t gcrnn_fused_padded_nodes(void);
-/* user [B][T][C][N] <-> sequence-major [T][B][NPad][C]; position p holds node perm[p]; rows >= N are zero.
- * dtype GCRNN_BF16 or GCRNN_F32 (same type both sides). */
+/* user [B][T][C][N] <-> sequence-major [T][B][NPad][C]; row p holds node perm[p] (perm NULL = identity);
+ * rows >= N are zero. dtype GCRNN_BF16 or GCRNN_F32 (same type both sides). */
 int gcrnn_pack_seq_major(int dtype, const void* src, void* dst, int64_t B, int64_t T, int64_t C, int64_t N,
                          int64_t NPad, const int32_t* perm, void* stream);
 int gcrnn_unpack_seq_major(int dtype, const void* src, void* dst, int64_t B, int64_t T, int64_t C, int64_t N,
@@ -120,11 +127,15 @@ int gcrnn_unpack_seq_major(int dtype, const void* src, void* dst, int64_t B, int
  * fragments wpack[F/16][K][(F+G)/32][64 lanes][8], K = max(Kin, Kst), missing taps zero. */
 int gcrnn_fused_pack_weights(int wdtype, const void* wA, const void* wB, void* wpack, int64_t F, int64_t G,
                              int64_t Kin, int64_t Kst, void* stream);
-/* xs [T][B][NPad][G], h0 [B][NPad][F], hs [T][B][NPad][F]: bf16 sequence-major; bias fp32 [F] or NULL;
- * gi / gf fp32 [T][B] time gates or both NULL (un-gated). T launches on `stream`. */
+/* xs [T][B][NPad][G], h0 [B][NPad][F], hs [T][B][NPad][F]: bf16 sequence-major, natural node order;
+ * bias fp32 [F] or NULL; gi / gf fp32 [T][B] time gates or both NULL (un-gated);
+ * tile_nodes int32 [NPad] = order padded with the unused row ids N..NPad-1; entries = tile_off[ntiles].
+ * ell_val4 / ell_col4 = device copies of gcrnn_ell_pack_lds's output (may be NULL).
+ * T launches on `stream`. The graph is kept resident in LDS when 64 KiB + weights + 96*entries B <= 160 KiB. */
 int gcrnn_fused_forward_bf16(const void* xs, const void* h0, void* hs, const void* wpack, const float* bias,
-                             const float* gi, const float* gf, const int32_t* tile_off, const int32_t* ell_col,
-                             const float* ell_val, int64_t B, int64_t T, int64_t N, int64_t F, int64_t G, int64_t K,
+                             const float* gi, const float* gf, const int32_t* tile_nodes, const int32_t* tile_off,
+                             const int32_t* ell_col, const float* ell_val, const void* ell_val4, const void* ell_col4,
+                             int64_t entries, int64_t B, int64_t T, int64_t N, int64_t F, int64_t G, int64_t K,
                              void* stream);
 
 #ifdef __cplusplus

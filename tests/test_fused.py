@@ -29,15 +29,17 @@ def test_ell_plan_reproduces_shift_exactly(N, density, iso):
     deg = np.count_nonzero(S[0].T, axis=1)
     assert np.all(np.diff(deg[order]) <= 0)                         # descending degree
     assert toff[0] == 0 and np.all(np.diff(toff) % 4 == 0) and toff[-1] == plan['entries']
-    # rebuild the dense operator in position space from the ELL and compare with P = S^T permuted
+    tn = plan['tile_nodes'].numpy()
+    assert np.array_equal(tn[:N], order) and np.array_equal(tn[N:], np.arange(N, plan['npad']))
+    # rebuild the dense operator from the ELL (slot -> node through tile_nodes) and compare with P = S^T
     P = np.zeros((plan['npad'], plan['npad']))
     for t in range(plan['npad'] // 16):
         for e in range(toff[t], toff[t + 1]):
             for r in range(16):
                 v = eval_[e * 16 + r]
                 if v != 0.0:
-                    P[t * 16 + r, ecol[e * 16 + r]] += v
-    ref = S[0].T[np.ix_(order, order)].astype(np.float32).astype(np.float64)
+                    P[tn[t * 16 + r], ecol[e * 16 + r]] += v
+    ref = S[0].T.astype(np.float32).astype(np.float64)
     assert np.array_equal(P[:N, :N], ref)
     assert not P[N:].any() and not P[:, N:].any()
     # padding waste stays small once rows are degree-sorted
