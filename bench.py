@@ -123,11 +123,27 @@ def main():
     X = torch.randn(B, T, G, N, device=dev, dtype=torch.float32, generator=gen).to(dt)
     h0 = torch.zeros(B, F, N, device=dev, dtype=dt)
 
+    sync_grads = None
+    if args.mode == 'train':
+        # one optimiser step of the k-step-prediction loop (reference train_rnn.py:247-281): forward, L1 loss on the
+        # state sequence, BPTT, ONE flat gradient all-reduce over RCCL, Adam. Runs on the fp32/fp64 composed path.
+        assert args.dtype in ('f32', 'f64'), 'training runs in f32 or f64 (bf16 is the inference mode)'
+        from gated_gcrnns_amd.parallel import FlatGradAllReduce
+        target = torch.randn(B, T, F, N, device=dev, dtype=dt, generator=None)
+        opt = torch.optim.Adam(cell.parameters(), lr=1e-3)
+        sync_grads = FlatGradAllReduce(cell.parameters()) if world > 1 else None
+
     def step():
         if args.mode == 'fwd':
             with torch.no_grad():
                 return cell(X, h0)
-        raise SystemExit('train mode not wired yet')
+        cell.zero_grad()
+        loss = torch.nn.functional.l1_loss(cell(X, h0), target)
+        loss.backward()
+        if sync_grads is not None:
+            sync_grads.all_reduce_()
+        opt.step()
+        return loss
 
     def sync():
         if world > 1:
@@ -153,6 +169,16 @@ def main():
     ms_per_step = 1e3 * wall / args.steps
     value = world * B * args.steps / wall
 
+    # ---- dominant kernel: the fused step kernel, timed live with HIP events on the stream it is launched on ----
+    kern = None
+    if args.dtype == 'bf16' and args.mode == 'fwd':
+        from gated_gcrnns_amd import ops
+        with torch.no_grad():
+            for _ in range(2):
+                ops.fused_cell_forward(X, h0, cell.weight_A, cell.weight_B, cell.bias, cell.graph, return_states=True)
+            torch.cuda.synchronize()
+            kern = ops.time_fused_step_kernel(X, h0, cell.weight_A, cell.weight_B, cell.bias, cell.graph, reps=3)
+
     if rank == 0:
         abytes = algorithmic_bytes_per_seq(T, N, G, F, elt) * B           # per step (= per launch chain), per GPU
         step_s = (dev_ms / 1e3) / args.steps
@@ -165,12 +191,30 @@ def main():
             'config': {'workload': 'BASELINE configs[1]: synthetic k-step prediction, sparse SBM N=1000 nnz=%d, K=5 taps, '
                                    'T=32, G=F=64, un-gated GGCRNNCell forward, h0=0' % nnz,
                        'batch_per_gpu': B, 'global_batch': world * B, 'mode': args.mode, 'parallelism': 'dp%d' % world},
-            'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': achieved / HBM_PEAK_GBS, 'traffic': None,
-                         'kernel': 'whole T-step recurrence (all launches of one step)',
-                         'algorithmic_bytes_per_step': abytes, 'device_ms_per_step': 1e3 * step_s,
-                         'gflop_per_step': flops_per_seq(T, N, nnz, K, G, F) * B / 1e9},
         }
+        if kern is not None:
+            # algorithmic bytes of ONE launch (one time step for the whole batch): read x_t, read h_{t-1}, write h_t
+            kbytes = elt * N * (G + 2 * F) * B
+            kach = kbytes / (kern['avg_us'] * 1e-6) / 1e9
+            traffic = None
+            tf = os.path.join(ROOT, 'profiles', 'step_kernel_traffic.json')
+            if os.path.exists(tf):
+                tj = json.load(open(tf))
+                if tj.get('batch') == B:
+                    traffic = tj['hbm_bytes_per_launch']
+            out['roofline'] = {'bound': 'hbm', 'achieved': kach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                               'frac': kach / HBM_PEAK_GBS, 'traffic': traffic,
+                               'kernel': 'fused_step_kernel<5,2,2> (one launch = one time step of the whole batch)',
+                               'kernel_avg_us': kern['avg_us'], 'launches_timed': kern['launches'],
+                               'algorithmic_bytes_per_launch': kbytes,
+                               'gflop_per_launch': flops_per_seq(1, N, nnz, K, G, F) * B / 1e9,
+                               'whole_step_GBps': achieved, 'device_ms_per_step': 1e3 * step_s}
+        else:
+            out['roofline'] = {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                               'frac': achieved / HBM_PEAK_GBS, 'traffic': None,
+                               'kernel': 'whole T-step recurrence (composed path: all launches of one step)',
+                               'algorithmic_bytes_per_step': abytes, 'device_ms_per_step': 1e3 * step_s,
+                               'gflop_per_step': flops_per_seq(T, N, nnz, K, G, F) * B / 1e9}
         if not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(S, params, T, G, F)
         print(json.dumps(out), flush=True)

@@ -1,0 +1,119 @@
+"""Training harness for GCRNN models on MI355X (counterpart of the reference's Modules/train_rnn.py:18-541,
+SURVEY.md section 8a row H1). Reproduces: the batch partition (reference :121-135), per-epoch permutation (:193),
+the B x T x N -> B x T x 1 x N input form (:218, :239), h0 = zeros(B, F, N) (:256), loss -> backward -> optimiser
+step (:270-276), the per-batch metric (:288), validation every `validationInterval` steps with best/last
+checkpoints named <name>Archit<label>.ckpt (reference model.py:107-118). Adds what the reference lacks:
+batch-sharded data parallelism with one flat gradient all-reduce per step (parallel.FlatGradAllReduce).
+"""
+import os
+import time
+
+import numpy as np
+import torch
+
+from ..parallel import FlatGradAllReduce, shard_range
+
+
+def batch_partition(nTrain, batchSize):
+    """Batch sizes and index boundaries exactly as the reference computes them (train_rnn.py:121-140)."""
+    if nTrain < batchSize:
+        sizes = [nTrain]
+    elif nTrain % batchSize != 0:
+        nBatches = int(np.ceil(nTrain / batchSize))
+        sizes = [batchSize] * nBatches
+        while sum(sizes) != nTrain:
+            sizes[-1] -= 1
+    else:
+        sizes = [batchSize] * (nTrain // batchSize)
+    return sizes, np.cumsum([0] + sizes).tolist()
+
+
+def train_step(archit, loss_fn, optim, x, y, stateFeat, sync=None):
+    """One optimiser step on a batch x, y: B x T x 1 x N (already on the device). Returns (loss, yHat)."""
+    B, N = x.shape[0], x.shape[3]
+    archit.zero_grad()
+    h0 = torch.zeros(B, stateFeat, N, dtype=x.dtype, device=x.device)
+    yHat = archit(x, h0)
+    loss = loss_fn(yHat, y)
+    loss.backward()
+    if sync is not None:
+        sync.all_reduce_()
+    optim.step()
+    return loss.detach(), yHat.detach()
+
+
+class TrainableModel(object):
+    """archit + loss + optimiser + name, with the reference's checkpoint naming (model.py:107-130)."""
+
+    def __init__(self, archit, loss, optim, name, saveDir, order=None):
+        self.archit, self.loss, self.optim, self.name, self.saveDir, self.order = archit, loss, optim, name, saveDir, order
+
+    def save(self, label=''):
+        d = os.path.join(self.saveDir, 'savedModels')
+        os.makedirs(d, exist_ok=True)
+        torch.save(self.archit.state_dict(), os.path.join(d, self.name + 'Archit' + label + '.ckpt'))
+        torch.save(self.optim.state_dict(), os.path.join(d, self.name + 'Optim' + label + '.ckpt'))
+
+    def load(self, label=''):
+        d = os.path.join(self.saveDir, 'savedModels')
+        self.archit.load_state_dict(torch.load(os.path.join(d, self.name + 'Archit' + label + '.ckpt')))
+        self.optim.load_state_dict(torch.load(os.path.join(d, self.name + 'Optim' + label + '.ckpt')))
+
+
+def MultipleModels(modelsDict, xTrain, yTrain, xValid, yValid, nEpochs, batchSize, seqLen, stateFeat,
+                   evaluate, validationInterval=5, rank=0, world=1, doPrint=False, rng=None):
+    """Train every model of `modelsDict` (name -> TrainableModel, names containing 'GCRNN') on the same batches.
+
+    xTrain / yTrain: nTrain x seqLen x N tensors (host or device); evaluate(yHat, y) is the dataset metric
+    (batchTimeMSELoss for k-step prediction). With world > 1 each rank takes its shard of every batch and the
+    gradients are averaged by one flat all-reduce. Returns dicts of per-step loss / metric / seconds per model.
+    """
+    rng = rng if rng is not None else np.random
+    nTrain = xTrain.shape[0]
+    sizes, index = batch_partition(nTrain, batchSize)
+    dev = next(iter(modelsDict.values())).archit.stateGCRNN.weight_A.device
+    dt = next(iter(modelsDict.values())).archit.stateGCRNN.weight_A.dtype
+    syncs = {k: (FlatGradAllReduce(m.archit.parameters()) if world > 1 else None) for k, m in modelsDict.items()}
+    lossTrain = {k: [] for k in modelsDict}
+    evalTrain = {k: [] for k in modelsDict}
+    evalValid = {k: [] for k in modelsDict}
+    timeTrain = {k: [] for k in modelsDict}
+    best = {}
+    for epoch in range(nEpochs):
+        perm = [int(i) for i in rng.permutation(nTrain)]
+        for b in range(len(sizes)):
+            idx = perm[index[b]:index[b + 1]]
+            lo, hi = shard_range(len(idx), rank, world)
+            idx = idx[lo:hi]
+            xb = xTrain[idx].view(len(idx), seqLen, -1).to(dev, dt)
+            yb = yTrain[idx].view(len(idx), seqLen, -1).to(dev, dt)
+            for key, m in modelsDict.items():
+                assert 'GCRNN' in key or 'gcrnn' in key or 'GCRnn' in key        # reference dispatches on the name
+                xo = xb[:, :, m.order] if m.order is not None else xb
+                xo, yo = xo.unsqueeze(2), yb.unsqueeze(2)                         # B x T x 1 x N
+                torch.cuda.synchronize() if dev.type == 'cuda' else None
+                t0 = time.perf_counter()
+                loss, yHat = train_step(m.archit, m.loss, m.optim, xo, yo, stateFeat, syncs[key])
+                torch.cuda.synchronize() if dev.type == 'cuda' else None
+                timeTrain[key].append(time.perf_counter() - t0)
+                lossTrain[key].append(float(loss))
+                evalTrain[key].append(float(evaluate(yHat, yo)))
+            step = epoch * len(sizes) + b
+            if validationInterval and step % validationInterval == 0 and xValid is not None:
+                xv = xValid.view(xValid.shape[0], seqLen, -1).to(dev, dt).unsqueeze(2)
+                yv = yValid.view(yValid.shape[0], seqLen, -1).to(dev, dt).unsqueeze(2)
+                for key, m in modelsDict.items():
+                    with torch.no_grad():
+                        h0 = torch.zeros(xv.shape[0], stateFeat, xv.shape[3], dtype=dt, device=dev)
+                        score = float(evaluate(m.archit(xv, h0), yv))
+                    evalValid[key].append(score)
+                    if key not in best or score < best[key]:
+                        best[key] = score
+                        if rank == 0:
+                            m.save(label='Best')
+                    if doPrint and rank == 0:
+                        print('[E %d B %d] %s valid %.4f' % (epoch + 1, b + 1, key, score))
+        if rank == 0:
+            for m in modelsDict.values():
+                m.save(label='Last')
+    return dict(lossTrain=lossTrain, evalTrain=evalTrain, evalValid=evalValid, timeTrain=timeTrain, bestScore=best)

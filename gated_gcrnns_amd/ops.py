@@ -205,6 +205,39 @@ def fused_supported(N, F, G, Kin, Kst, dtype, E=1):
             bool(lib.gcrnn_fused_supported(int(N), int(F), int(G), int(max(Kin, Kst)))))
 
 
+def time_fused_step_kernel(X, h0, wA, wB, bias, graph, reps=3):
+    """Average duration of ONE fused step launch, measured with HIP events on the launch stream
+    (inputs pre-packed, only the T step launches sit between the events)."""
+    B, T, G, N = X.shape
+    F = wA.shape[0]
+    Kin, Kst = wA.shape[2], wB.shape[2]
+    K = max(Kin, Kst)
+    plan = graph.fused_plan()
+    npad = plan['npad']
+    st = _stream()
+    dev = X.device
+    xs = torch.empty((T, B, npad, G), dtype=torch.bfloat16, device=dev)
+    h0s = torch.empty((1, B, npad, F), dtype=torch.bfloat16, device=dev)
+    hs = torch.empty((T, B, npad, F), dtype=torch.bfloat16, device=dev)
+    check(lib.gcrnn_pack_seq_major(_lib.BF16, _p(X.contiguous()), _p(xs), B, T, G, N, npad, None, st), 'pack_seq')
+    check(lib.gcrnn_pack_seq_major(_lib.BF16, _p(h0.contiguous()), _p(h0s), B, 1, F, N, npad, None, st), 'pack_seq')
+    wpack = torch.empty(((F // 16) * K * ((F + G) // 32) * 64 * 8,), dtype=torch.bfloat16, device=dev)
+    check(lib.gcrnn_fused_pack_weights(dtype_code(wA.dtype), _p(wA.contiguous()), _p(wB.contiguous()), _p(wpack),
+                                       F, G, Kin, Kst, st), 'pack_weights')
+    b32 = bias.detach().float().contiguous().view(-1) if bias is not None else None
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(reps):
+        check(lib.gcrnn_fused_forward_bf16(_p(xs), _p(h0s), _p(hs), _p(wpack), _p(b32), None, None,
+                                           _p(plan['tile_nodes']), _p(plan['tile_off']), _p(plan['ell_col']),
+                                           _p(plan['ell_val']), _p(plan['ell_val4']), _p(plan['ell_col4']),
+                                           plan['entries'], B, T, N, F, G, K, st), 'fused_forward')
+    e1.record()
+    torch.cuda.synchronize()
+    return {'avg_us': 1e3 * e0.elapsed_time(e1) / (reps * T), 'launches': reps * T}
+
+
 def fused_cell_forward(X, h0, wA, wB, bias, graph, gi=None, gf=None, return_states=False):
     """Whole GGCRNNCell forward (un-gated or time-gated) on the fused bf16 step kernel.
 

@@ -1,0 +1,94 @@
+"""CPU, world_size 2 over gloo: the batch-sharded data-parallel path (flat gradient all-reduce) reproduces the
+single-process large-batch gradient and keeps replicas identical. The per-rank compute here is a small torch
+model standing in for the HIP cell (no GPU in this container); what is under test is the N>1 logic itself:
+sharding, flat buffer layout incl. parameters without gradient, scaling, and the harness's batch partition."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from gated_gcrnns_amd.parallel import FlatGradAllReduce, shard_range, shard_batch
+from gated_gcrnns_amd.Modules.train_rnn import batch_partition
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+class Tiny(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.a = torch.nn.Linear(6, 5)
+        self.unused = torch.nn.Linear(3, 2)       # like GFL_out / MLP_out: saved, never used, no gradient
+        self.b = torch.nn.Linear(5, 1)
+
+    def forward(self, x):
+        return self.b(torch.tanh(self.a(x)))
+
+
+def worker(rank, world, port, ret):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.manual_seed(0)
+    model = Tiny().double()
+    x = torch.randn(10, 6, dtype=torch.float64)
+    y = torch.randn(10, 1, dtype=torch.float64)
+    # reference: the whole batch in one process
+    ref = Tiny().double()
+    ref.load_state_dict(model.state_dict())
+    torch.nn.functional.l1_loss(ref(x), y).backward()
+    xs, ys = shard_batch(rank, world, x, y)
+    sync = FlatGradAllReduce(model.parameters())
+    opt = torch.optim.Adam(model.parameters(), lr=1e-2)
+    torch.nn.functional.l1_loss(model(xs), ys).backward()
+    flat = sync.all_reduce_()                    # equal shards (5 + 5): weight 1/world
+    ok = True
+    for (n, p), (_, q) in zip(model.named_parameters(), ref.named_parameters()):
+        if q.grad is None:
+            ok &= bool(p.grad is not None and float(p.grad.abs().max()) == 0.0)
+        else:
+            ok &= bool(torch.allclose(p.grad, q.grad, atol=1e-12))
+    opt.step()
+    # replicas stay bit-identical after the step
+    mine = torch.cat([p.detach().reshape(-1) for p in model.parameters()])
+    gathered = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(gathered, mine)
+    ok &= bool(all(torch.equal(g, gathered[0]) for g in gathered))
+    ok &= flat.numel() == sum(p.numel() for p in model.parameters()) and flat.dtype == torch.float32
+    ret[rank] = ok
+    dist.destroy_process_group()
+
+
+def test_flat_allreduce_world2_matches_large_batch():
+    world = 2
+    port = free_port()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(worker, args=(world, port, ret), nprocs=world, join=True)
+    assert all(ret[r] for r in range(world)), dict(ret)
+
+
+def test_shard_range_is_a_partition():
+    for n in (0, 1, 7, 8, 100, 257):
+        for world in (1, 2, 3, 8):
+            spans = [shard_range(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+@pytest.mark.parametrize('nTrain,bs,expect', [(100, 20, [20] * 5), (95, 20, [20, 20, 20, 20, 15]), (7, 20, [7]),
+                                              (41, 20, [20, 20, 1])])
+def test_batch_partition_matches_reference_rule(nTrain, bs, expect):
+    sizes, index = batch_partition(nTrain, bs)
+    assert sizes == expect and index[-1] == nTrain and len(index) == len(sizes) + 1

@@ -1,0 +1,56 @@
+"""GPU: the training-loop counterpart reproduces the reference's first 20 Adam steps
+(golden G6: per-step L1 loss and RMSE-like metric on fixed graph / data / initial parameters)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize('name,tg', [('GCRNNMLP', False), ('TimeGCRNNMLP', True)])
+def test_g6_twenty_adam_steps_match_reference(name, tg):
+    import gated_gcrnns_amd.Modules.architectures as archit
+    from gated_gcrnns_amd.Modules.train_rnn import train_step
+    from gated_gcrnns_amd.Utils.miscTools import batchTimeL1Loss, batchTimeMSELoss
+    g = load_golden('g6_trace_' + name)
+    dev = torch.device('cuda:0')
+    m = archit.GatedGCRNNforRegression(1, 20, 3, 3, torch.tanh, torch.nn.ReLU, [1], g['S'][0], True,
+                                       time_gating=tg, spatial_gating=None, mlpType='multipMlp').double()
+    m.load_state_dict({k: torch.tensor(v) for k, v in g['params0'].items()})
+    m = m.to(dev)
+    opt = torch.optim.Adam(m.parameters(), lr=1e-3, betas=(0.9, 0.999))      # kStepPredGRNNs.py:158-161
+    x = torch.tensor(g['x'], device=dev)
+    y = torch.tensor(g['y'], device=dev)
+    losses, metrics = [], []
+    for it in range(20):
+        loss, yHat = train_step(m, batchTimeL1Loss, opt, x, y, 20)
+        losses.append(float(loss))
+        metrics.append(float(batchTimeMSELoss(yHat, y)))
+    assert np.max(np.abs(np.array(losses) - g['loss'])) <= 1e-9
+    assert np.max(np.abs(np.array(metrics) - g['metric'])) <= 1e-8
+    sd = m.state_dict()
+    for k, v in g['params20'].items():
+        assert np.max(np.abs(sd[k].cpu().numpy() - v)) <= 1e-8, k
+
+
+def test_harness_runs_and_checkpoints(tmp_path):
+    import gated_gcrnns_amd.Modules.architectures as archit
+    from gated_gcrnns_amd.Modules.train_rnn import MultipleModels, TrainableModel
+    from gated_gcrnns_amd.Utils.miscTools import batchTimeL1Loss, batchTimeMSELoss
+    g = load_golden('g6_trace_GCRNNMLP')
+    dev = torch.device('cuda:0')
+    torch.manual_seed(0)
+    m = archit.GatedGCRNNforRegression(1, 20, 3, 3, torch.tanh, torch.nn.ReLU, [1], g['S'][0], True,
+                                       time_gating=False, spatial_gating=None, mlpType='multipMlp').to(dev)
+    tm = TrainableModel(m, batchTimeL1Loss, torch.optim.Adam(m.parameters(), lr=1e-3), 'GCRNNMLP', str(tmp_path))
+    x = torch.tensor(g['x'][:, :, 0, :], dtype=torch.float32)          # nTrain x T x N
+    y = torch.tensor(g['y'][:, :, 0, :], dtype=torch.float32)
+    out = MultipleModels({'GCRNNMLP': tm}, x, y, x[:6], y[:6], nEpochs=2, batchSize=8, seqLen=5, stateFeat=20,
+                         evaluate=batchTimeMSELoss, validationInterval=2, rng=np.random.default_rng(0))
+    assert len(out['lossTrain']['GCRNNMLP']) == 2 * 3                    # 20 samples -> batches 8, 8, 4
+    assert out['lossTrain']['GCRNNMLP'][-1] < out['lossTrain']['GCRNNMLP'][0]
+    assert (tmp_path / 'savedModels' / 'GCRNNMLPArchitBest.ckpt').exists()
+    assert (tmp_path / 'savedModels' / 'GCRNNMLPArchitLast.ckpt').exists()
+    tm.load('Last')
