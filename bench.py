@@ -60,7 +60,7 @@ def cpu_baseline(S, params, T, G, F, seconds_budget=20.0):
     from oracle import gcrnn_oracle as orc
     N = S.shape[1]
     rng = np.random.default_rng(1)
-    Bc = 2
+    Bc = 8                                                     # the reference's own profiling batch
     X = rng.standard_normal((Bc, T, G, N)).astype(np.float32)
     h0 = np.zeros((Bc, F, N), np.float32)
     p32 = {k: v.astype(np.float32) for k, v in params.items()}
@@ -69,7 +69,7 @@ def cpu_baseline(S, params, T, G, F, seconds_budget=20.0):
     orc.ggcrnn_cell(p32, S32, X[:, :2], h0)                    # warm-up on 2 steps
     warm = time.perf_counter() - t0
     reps, times = 0, []
-    while reps < 3 and (sum(times) + (times[-1] if times else warm * T / 2)) < seconds_budget:
+    while reps < 5 and (sum(times) + (times[-1] if times else warm * T / 2)) < seconds_budget:
         t0 = time.perf_counter()
         orc.ggcrnn_cell(p32, S32, X, h0)
         times.append(time.perf_counter() - t0)

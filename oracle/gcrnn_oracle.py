@@ -50,7 +50,7 @@ def lsigf(h, S, x, b=None):
             if k > 0:
                 z = z @ S[e]                           # B x G x N, row-vector shift
             # y[b,f,n] += sum_g h[f,e,k,g] z[b,g,n]
-            y = y + np.einsum('fg,bgn->bfn', h[:, e, k, :], z)
+            y = y + np.matmul(h[:, e, k, :], z)                # [F x G] @ [B x G x N] -> B x F x N (BLAS)
     if b is not None:
         y = y + b.reshape(1, F, -1)
     return y
