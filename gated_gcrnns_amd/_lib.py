@@ -24,6 +24,9 @@ class GcrnnError(RuntimeError):
 
 
 def _load():
+    path = os.environ.get('GCRNN_LIBPATH')      # A/B builds for profiling (tools/ablate.sh); default: the in-tree library
+    if path:
+        return _bind(C.CDLL(path))
     path = _build.LIBPATH
     if _build.needs_build() and os.path.exists(_build.HIPCC):
         _build.build(verbose=False)          # in-tree, gfx950; sources newer than the .so (or no .so yet)
@@ -31,7 +34,10 @@ def _load():
         raise ImportError(
             'gated_gcrnns_amd: %s is missing. Build it with `python -m gated_gcrnns_amd.build` '
             '(needs hipcc; there is no CPU fallback).' % path)
-    lib = C.CDLL(path)
+    return _bind(C.CDLL(path))
+
+
+def _bind(lib):
     sig = {
         'gcrnn_version': (C.c_int, []),
         'gcrnn_status_string': (C.c_char_p, [C.c_int]),

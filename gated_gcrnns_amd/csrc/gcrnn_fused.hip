@@ -270,10 +270,13 @@ __global__ __launch_bounds__(512, 2) void fused_step_kernel(
 
   // XCD-aware placement: the NCH chunk workgroups of one sequence get block ids that are equal mod 8,
   // i.e. one XCD under round-robin dispatch (speed only; nothing depends on it).
+  // Each workgroup stays on its CU for the whole launch and walks the sequences b0, b0 + SEQ_SLOTS, ...: weights and
+  // graph are staged into LDS once per launch, not once per sequence.
   const int L = blockIdx.x;
   const int grp = L / (8 * NCH), rem = L - grp * (8 * NCH);
-  const int chunk = rem >> 3, b = grp * 8 + (rem & 7);
-  if (b >= B) return;
+  const int chunk = rem >> 3, b0 = grp * 8 + (rem & 7);
+  const int seq_slots = (gridDim.x / (8 * NCH)) * 8;
+  if (b0 >= B) return;
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // provably wave-uniform -> scalar loads below
@@ -281,43 +284,70 @@ __global__ __launch_bounds__(512, 2) void fused_step_kernel(
 
   for (int i = tid; i < K * KS * 64; i += 512) wl[i] = wpack[(int64_t)chunk * K * KS * 64 + i];
   if (RESIDENT) {
-    const int n = (entries >> 2) * 16;                         // the host packed the LDS image: straight copies
-    for (int i = tid; i < n; i += 512) { lval4[i] = ell_val4[i]; lcol4[i] = ell_col4[i]; }
+    const int n = (entries >> 2) * 16;                         // the host packed the LDS image: straight copies,
+    for (int i0 = 0; i0 < n; i0 += 512 * 4) {                  // 4 loads in flight per lane before the first LDS store
+      float4 tv[4]; uint2 tc[4];
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        const int i = i0 + p * 512 + tid;
+        if (i < n) { tv[p] = ell_val4[i]; tc[p] = ell_col4[i]; }
+      }
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        const int i = i0 + p * 512 + tid;
+        if (i < n) { lval4[i] = tv[p]; lcol4[i] = tc[p]; }
+      }
+    }
   }
   // per-wave tile ranges, fetched once through the scalar path
   int tbeg[TILES], tend[TILES];
 #pragma unroll
   for (int i = 0; i < TILES; ++i) {
-    tbeg[i] = tile_off[i * WAVES + wave];
-    tend[i] = tile_off[i * WAVES + wave + 1];
+    tbeg[i] = tile_off[wave * TILES + i];
+    tend[i] = tile_off[wave * TILES + i + 1];
   }
-  __syncthreads();
-
-  const uint16_t* hb = hprev + (int64_t)b * NP * F;
-  const uint16_t* xb = xt + (int64_t)b * NP * G;
-  float gin = 1.f, gfo = 1.f;
-  if (GATED) { gin = gi[b]; gfo = gf[b]; }
-
   f32x4 u[TILES][K];
   int nodes[TILES];
   int woff[TILES];      // byte offset of this lane's quad in the swizzled state row of its node
 #pragma unroll
   for (int i = 0; i < TILES; ++i) {
-    nodes[i] = tile_nodes[(i * WAVES + wave) * 16 + r];
+    nodes[i] = tile_nodes[(wave * TILES + i) * 16 + r];
     woff[i] = nodes[i] * (FC * 4) + ((q ^ ((nodes[i] >> 2) & 3)) << 4);
   }
+  float bvec[4] = {0.f, 0.f, 0.f, 0.f};
+  if (bias) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) bvec[c] = bias[chunk * FC + q * 4 + c];
+  }
+  __syncthreads();
+
+  for (int b = b0; b < B; b += seq_slots) {
+  const uint16_t* hb = hprev + (int64_t)b * NP * F;
+  const uint16_t* xb = xt + (int64_t)b * NP * G;
+  float gin = 1.f, gfo = 1.f;
+  if (GATED) { gin = gi[b]; gfo = gf[b]; }
 
   // ---- phase 1: taps on the matrix cores ------------------------------------------------------
+#ifdef GCRNN_ABLATE_PHASE1      // profiling builds only (tools/ablate.sh): results are wrong by construction
+#pragma unroll
+  for (int i = 0; i < TILES; ++i)
+#pragma unroll
+    for (int tap = 0; tap < K; ++tap) u[i][tap] = f32x4{0.f, 0.f, 0.f, (float)nodes[i]};
+#else
+  // all B-operand fragments of the wave (8 tiles x 4 x 16 B per lane) are requested before the first MFMA: one
+  // memory latency per sequence instead of one per tile; the registers are free again before the taps fill up.
+  bf16x8 bfr[TILES][KS];
 #pragma unroll
   for (int i = 0; i < TILES; ++i) {
-    const int node = nodes[i];
-    bf16x8 bfrag[KS];
 #pragma unroll
     for (int s = 0; s < HS; ++s)
-      bfrag[s] = *reinterpret_cast<const bf16x8*>(hb + (int64_t)node * F + 32 * s + 8 * q);
+      bfr[i][s] = *reinterpret_cast<const bf16x8*>(hb + (int64_t)nodes[i] * F + 32 * s + 8 * q);
 #pragma unroll
     for (int s = 0; s < XS; ++s)
-      bfrag[HS + s] = *reinterpret_cast<const bf16x8*>(xb + (int64_t)node * G + 32 * s + 8 * q);
+      bfr[i][HS + s] = *reinterpret_cast<const bf16x8*>(xb + (int64_t)nodes[i] * G + 32 * s + 8 * q);
+  }
+#pragma unroll
+  for (int i = 0; i < TILES; ++i) {
 #pragma unroll
     for (int tap = 0; tap < K; ++tap) {
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -326,26 +356,40 @@ __global__ __launch_bounds__(512, 2) void fused_step_kernel(
 #pragma unroll
         for (int s = 0; s < HS; ++s) {
           const bf16x8 a = __builtin_bit_cast(bf16x8, wl[(tap * KS + s) * 64 + lane]);
-          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bfrag[s], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bfr[i][s], acc, 0, 0, 0);
         }
 #pragma unroll
         for (int s = HS; s < KS; ++s) {
           const bf16x8 a = __builtin_bit_cast(bf16x8, wl[(tap * KS + s) * 64 + lane]);
-          accx = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bfrag[s], accx, 0, 0, 0);
+          accx = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bfr[i][s], accx, 0, 0, 0);
         }
         acc = gfo * acc + gin * accx;
       } else {
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
           const bf16x8 a = __builtin_bit_cast(bf16x8, wl[(tap * KS + s) * 64 + lane]);
-          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bfrag[s], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bfr[i][s], acc, 0, 0, 0);
         }
       }
       u[i][tap] = acc;
     }
     *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(state) + woff[i]) = u[i][K - 1];
   }
+#endif
   __syncthreads();
+
+  // L2 prefetch of the NEXT sequence of this workgroup: while the hops keep the LDS busy, every thread touches one
+  // 128-byte row (= one cache line) of [h | x]; the NCH chunk workgroups of a sequence share an XCD and split the
+  // 2 * NP rows between them. Phase 1 of the next sequence then streams from L2 instead of stalling on HBM.
+  uint32_t prefetched = 0;
+  if (b + seq_slots < B) {
+    const int line = chunk * (2 * NP / NCH) + tid;                       // 2*NP/NCH == 512 for F = 64
+    if (tid < 2 * NP / NCH) {
+      const uint16_t* pb = (line < NP) ? hprev + ((int64_t)(b + seq_slots) * NP + line) * F
+                                       : xt + ((int64_t)(b + seq_slots) * NP + (line - NP)) * G;
+      prefetched = *reinterpret_cast<const uint32_t*>(pb);
+    }
+  }
 
   // ---- phase 2: Horner hops, state image in LDS -------------------------------------------------
   const char* sbytes = reinterpret_cast<const char*>(state);
@@ -355,76 +399,81 @@ __global__ __launch_bounds__(512, 2) void fused_step_kernel(
   const uint32_t qx = (uint32_t)qoff;     // stored column = (col << 6) | (swizzle << 4);  ^ (q << 4) selects this lane's quad
   const uint32_t lds_val = lds0 + NP * FC * 4 + K * KS * 1024;
   const uint32_t lds_col = lds_val + (RESIDENT ? entries * 64 : 0);
+  // One gather trip of the resident pipeline: group g has its weights in VC and its 4 gathered quads in XC*;
+  // issue cols(g+2) -> CC, then (after cols(g+1) = CN landed) vals(g+1) -> VN and the gathers of g+1 -> XN*;
+  // then wait for VC / XC* (issued one trip earlier) and do the 16 FMAs. lgkmcnt(6): the 6 reads just issued may
+  // stay in flight. E and O name the two ping-pong register sets.
+#define GCRNN_TRIP(ACC, CC, CN, VC, VN, XC0, XC1, XC2, XC3, XN0, XN1, XN2, XN3)                    \
+  do {                                                                                             \
+    const int g1_ = (g + 1 < gwend) ? g + 1 : gwlast, g2_ = (g + 2 < gwend) ? g + 2 : gwlast;      \
+    DS_READ_B64(CC, colb + g2_ * 128);                                                             \
+    LGKM_WAIT(6);                                                                                  \
+    DS_READ_B128(VN, valb + g1_ * 256);                                                            \
+    DS_READ_B128(XN0, lds0 + (((uint32_t)CN & 0xffffu) ^ qx));                                     \
+    DS_READ_B128(XN1, lds0 + ((((uint32_t)CN >> 16) & 0xffffu) ^ qx));                             \
+    DS_READ_B128(XN2, lds0 + (((uint32_t)(CN >> 32) & 0xffffu) ^ qx));                             \
+    DS_READ_B128(XN3, lds0 + ((uint32_t)(CN >> 48) ^ qx));                                         \
+    LGKM_WAIT(6);                                                                                  \
+    ACC += VC[0] * XC0;                                                                            \
+    ACC += VC[1] * XC1;                                                                            \
+    ACC += VC[2] * XC2;                                                                            \
+    ACC += VC[3] * XC3;                                                                            \
+  } while (0)
+#define GCRNN_TRIP_E(ACC) GCRNN_TRIP(ACC, cE, cO, vE, vO, xE0, xE1, xE2, xE3, xO0, xO1, xO2, xO3)
+#define GCRNN_TRIP_O(ACC) GCRNN_TRIP(ACC, cO, cE, vO, vE, xO0, xO1, xO2, xO3, xE0, xE1, xE2, xE3)
+
+#ifdef GCRNN_ABLATE_HOPS
+#define GCRNN_HOP_FIRST K
+#else
+#define GCRNN_HOP_FIRST 1
+#endif
 #pragma unroll
-  for (int j = 1; j < K; ++j) {
+  for (int j = GCRNN_HOP_FIRST; j < K; ++j) {
+    if (RESIDENT) {
+      // The wave's 8 tiles are stored back to back, so its whole hop is ONE continuous stream of groups:
+      // the pipeline is primed once, runs across tile boundaries (only the accumulator changes) and is drained once.
+      const int gwbeg = tbeg[0] >> 2, gwend = tend[TILES - 1] >> 2, gwlast = gwend - 1;
+      const uint32_t colb = lds_col + r * 8, valb = lds_val + r * 16;
+      uint64_t cE = 0, cO = 0;
+      f32x4 vE, vO, xE0, xE1, xE2, xE3, xO0, xO1, xO2, xO3;
+      int g = gwbeg;
+      int par = 0;                      // 0: the current group sits in set E, 1: in set O   (wave-uniform)
+      if (gwbeg < gwend) {
+        DS_READ_B64(cE, colb + gwbeg * 128);
+        DS_READ_B64(cO, colb + ((gwbeg + 1 < gwend) ? gwbeg + 1 : gwlast) * 128);
+        DS_READ_B128(vE, valb + gwbeg * 256);
+        LGKM_WAIT(2);
+        DS_READ_B128(xE0, lds0 + (((uint32_t)cE & 0xffffu) ^ qx));
+        DS_READ_B128(xE1, lds0 + ((((uint32_t)cE >> 16) & 0xffffu) ^ qx));
+        DS_READ_B128(xE2, lds0 + (((uint32_t)(cE >> 32) & 0xffffu) ^ qx));
+        DS_READ_B128(xE3, lds0 + ((uint32_t)(cE >> 48) ^ qx));
+      }
 #pragma unroll
-    for (int i = 0; i < TILES; ++i) {
-      const int beg = tbeg[i], end = tend[i];
-      f32x4 acc = u[i][K - 1 - j];
-      if (RESIDENT) {
-        // 4 entries per trip: one ds_read_b64 (4 pre-scaled u16 columns) + one ds_read_b128 (4 weights), then
-        // 4 gathers of 16 B and 16 FMAs. Two-deep software pipeline: the (col,val) of trip g+2 and the gathers of
-        // trip g+1 are issued before the FMAs of trip g, so every wait is on a load issued a whole trip earlier.
-        // The empty asm statements pin that order (hipcc otherwise sinks the prefetches to their uses).
-        const int g0 = beg >> 2, gend = end >> 2;
-        if (g0 < gend) {
-          // Ping-pong register sets E / O hold alternate groups. In the trip of group g (set E):
-          //   issue cols(g+2) -> cE; wait cols(g+1) = cO; issue vals(g+1) -> vO and the 4 gathers of g+1 -> xO;
-          //   wait vE, xE (issued one trip ago); 16 FMAs of group g.
-          // Both waits are lgkmcnt(6): 6 younger LDS reads are allowed to stay in flight.
-          const int glast = gend - 1;
-          const uint32_t colb = lds_col + r * 8, valb = lds_val + r * 16;
-          uint64_t cE, cO;
-          f32x4 vE, vO, xE0, xE1, xE2, xE3, xO0, xO1, xO2, xO3;
-          DS_READ_B64(cE, colb + g0 * 128);
-          DS_READ_B64(cO, colb + ((g0 + 1 < gend) ? g0 + 1 : glast) * 128);
-          DS_READ_B128(vE, valb + g0 * 256);
-          LGKM_WAIT(2);
-          DS_READ_B128(xE0, lds0 + (((uint32_t)cE & 0xffffu) ^ qx));
-          DS_READ_B128(xE1, lds0 + ((((uint32_t)cE >> 16) & 0xffffu) ^ qx));
-          DS_READ_B128(xE2, lds0 + (((uint32_t)(cE >> 32) & 0xffffu) ^ qx));
-          DS_READ_B128(xE3, lds0 + ((uint32_t)(cE >> 48) ^ qx));
-          int g = g0;
-          while (true) {
-            {   // ---- trip for group g, data in set E, prefetch into O ----
-              const int g1 = (g + 1 < gend) ? g + 1 : glast, g2 = (g + 2 < gend) ? g + 2 : glast;
-              DS_READ_B64(cE, colb + g2 * 128);
-              LGKM_WAIT(6);
-              DS_READ_B128(vO, valb + g1 * 256);
-              DS_READ_B128(xO0, lds0 + (((uint32_t)cO & 0xffffu) ^ qx));
-              DS_READ_B128(xO1, lds0 + ((((uint32_t)cO >> 16) & 0xffffu) ^ qx));
-              DS_READ_B128(xO2, lds0 + (((uint32_t)(cO >> 32) & 0xffffu) ^ qx));
-              DS_READ_B128(xO3, lds0 + ((uint32_t)(cO >> 48) ^ qx));
-              LGKM_WAIT(6);
-              acc += vE[0] * xE0;
-              acc += vE[1] * xE1;
-              acc += vE[2] * xE2;
-              acc += vE[3] * xE3;
-            }
-            if (++g >= gend) break;
-            {   // ---- trip for group g, data in set O, prefetch into E ----
-              const int g1 = (g + 1 < gend) ? g + 1 : glast, g2 = (g + 2 < gend) ? g + 2 : glast;
-              DS_READ_B64(cO, colb + g2 * 128);
-              LGKM_WAIT(6);
-              DS_READ_B128(vE, valb + g1 * 256);
-              DS_READ_B128(xE0, lds0 + (((uint32_t)cE & 0xffffu) ^ qx));
-              DS_READ_B128(xE1, lds0 + ((((uint32_t)cE >> 16) & 0xffffu) ^ qx));
-              DS_READ_B128(xE2, lds0 + (((uint32_t)(cE >> 32) & 0xffffu) ^ qx));
-              DS_READ_B128(xE3, lds0 + ((uint32_t)(cE >> 48) ^ qx));
-              LGKM_WAIT(6);
-              acc += vO[0] * xO0;
-              acc += vO[1] * xO1;
-              acc += vO[2] * xO2;
-              acc += vO[3] * xO3;
-            }
-            if (++g >= gend) break;
+      for (int i = 0; i < TILES; ++i) {
+        const int ge = tend[i] >> 2;
+        f32x4 acc = u[i][K - 1 - j];
+        if (g < ge) {
+          if (par) { GCRNN_TRIP_O(acc); ++g; par = 0; }
+          while (g < ge) {
+            GCRNN_TRIP_E(acc);
+            if (++g >= ge) { par = 1; break; }
+            GCRNN_TRIP_O(acc);
+            ++g;
           }
-          LGKM_WAIT(0);      // drain the tail prefetches before their registers may be reused
-          KEEP_ALIVE(cE); KEEP_ALIVE(cO); KEEP_ALIVE(vE); KEEP_ALIVE(vO);
-          KEEP_ALIVE(xE0); KEEP_ALIVE(xE1); KEEP_ALIVE(xE2); KEEP_ALIVE(xE3);
-          KEEP_ALIVE(xO0); KEEP_ALIVE(xO1); KEEP_ALIVE(xO2); KEEP_ALIVE(xO3);
         }
-      } else {
+        u[i][K - 1 - j] = acc;      // the new value lives in the tap's registers until every wave has read `state`
+      }
+      if (gwbeg < gwend) {
+        LGKM_WAIT(0);                // drain the tail prefetches before their registers may be reused
+        KEEP_ALIVE(cE); KEEP_ALIVE(cO); KEEP_ALIVE(vE); KEEP_ALIVE(vO);
+        KEEP_ALIVE(xE0); KEEP_ALIVE(xE1); KEEP_ALIVE(xE2); KEEP_ALIVE(xE3);
+        KEEP_ALIVE(xO0); KEEP_ALIVE(xO1); KEEP_ALIVE(xO2); KEEP_ALIVE(xO3);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < TILES; ++i) {
+        const int beg = tbeg[i], end = tend[i];
+        f32x4 acc = u[i][K - 1 - j];
         for (int e = beg; e < end; e += 4) {      // entry counts are padded to multiples of 4
           int cc[4]; float vv[4]; f32x4 xv[4];
 #pragma unroll
@@ -435,8 +484,8 @@ __global__ __launch_bounds__(512, 2) void fused_step_kernel(
 #pragma unroll
           for (int p = 0; p < 4; ++p) acc += vv[p] * xv[p];
         }
+        u[i][K - 1 - j] = acc;
       }
-      u[i][K - 1 - j] = acc;        // the new value lives in the tap's registers until every wave has read `state`
     }
     if (j < K - 1) {
       __syncthreads();
@@ -445,13 +494,16 @@ __global__ __launch_bounds__(512, 2) void fused_step_kernel(
       __syncthreads();
     }
   }
+#undef GCRNN_TRIP_E
+#undef GCRNN_TRIP_O
+#undef GCRNN_TRIP
 
   // ---- epilogue: bias, tanh, bf16 store into the node-major state h_t ------------------------------
-  float bsum[4] = {0.f, 0.f, 0.f, 0.f};
-  if (bias) {
+  float bsum[4];
+  {
     const float bs = gin + gfo;     // the one bias is added by both filters (graphML.py:2420-2421)
 #pragma unroll
-    for (int c = 0; c < 4; ++c) bsum[c] = bs * bias[chunk * FC + q * 4 + c];
+    for (int c = 0; c < 4; ++c) bsum[c] = bs * bvec[c];
   }
 #pragma unroll
   for (int i = 0; i < TILES; ++i) {
@@ -468,6 +520,9 @@ __global__ __launch_bounds__(512, 2) void fused_step_kernel(
     }
     *reinterpret_cast<uint2*>(hout + ((int64_t)b * NP + node) * F + chunk * FC + q * 4) = pk;
   }
+  asm volatile("" ::"v"(prefetched));      // the prefetch load retires here at the latest
+  __syncthreads();     // the last hop's reads of `state` are done before the next sequence overwrites it
+  }  // sequences
 }
 
 template <int K, int HS, int XS>
@@ -489,7 +544,11 @@ static int fused_forward_t(const void* xs, const void* h0, void* hs, const void*
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
     return GCRNN_ERR_LAUNCH;
   const int NCH = F / FC;
-  const unsigned grid = (unsigned)(cdiv(B, 8) * 8 * NCH);
+  // one workgroup per CU: 256 / NCH sequence slots (rounded to the 8 XCDs), fewer when the batch is small
+  int64_t slots = cdiv(B, 8) * 8;
+  const int64_t max_slots = (256 / NCH) / 8 * 8 > 0 ? (256 / NCH) / 8 * 8 : 8;
+  if (slots > max_slots) slots = max_slots;
+  const unsigned grid = (unsigned)(slots * NCH);
   const uint16_t* x = (const uint16_t*)xs;
   uint16_t* h = (uint16_t*)hs;
   const int64_t xstep = B * NP * G, hstep = B * NP * F;

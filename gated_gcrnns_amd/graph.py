@@ -121,13 +121,24 @@ class GraphOperator(object):
         col = np.ascontiguousarray(c.col.cpu().numpy())
         val = np.ascontiguousarray(c.val(torch.float64).cpu().numpy())
         order = degree_order(rowptr)
+        # tiles of 16 slots in degree order; the kernel's wave w owns STORAGE tiles 8w .. 8w+7 (contiguous, so its hop
+        # is one stream of ELL groups) -- deal the degree-ranked tiles round-robin over the 8 waves to balance them.
+        slots = np.concatenate([order, np.arange(self.N, npad, dtype=np.int32)]).astype(np.int32).reshape(ntiles, 16)
+        waves, per = 8, ntiles // 8
+        storage = np.empty_like(slots)
+        for w in range(waves):
+            for i in range(per):
+                storage[w * per + i] = slots[i * waves + w]
+        order_full = storage.reshape(-1)                                   # node id (or padding row id >= N) per slot
         nent = C.c_int64(0)
         vp = lambda a: a.ctypes.data_as(C.c_void_p)
-        _lib.check(_lib.lib.gcrnn_ell_size(vp(rowptr), self.N, vp(order), 16, 4, ntiles, C.byref(nent)), 'ell_size')
+        # padding rows (ids >= N) have no edges: extend rowptr so that they can be addressed like nodes
+        rowptr_pad = np.concatenate([rowptr, np.full(npad - self.N, rowptr[-1], dtype=np.int32)]).astype(np.int32)
+        _lib.check(_lib.lib.gcrnn_ell_size(vp(rowptr_pad), npad, vp(order_full), 16, 4, ntiles, C.byref(nent)), 'ell_size')
         tile_off = np.zeros(ntiles + 1, dtype=np.int32)
         ell_col = np.zeros(max(nent.value, 1) * 16, dtype=np.int32)
         ell_val = np.zeros(max(nent.value, 1) * 16, dtype=np.float32)
-        _lib.check(_lib.lib.gcrnn_ell_fill(vp(rowptr), vp(col), vp(val), self.N, vp(order), 16, 4, ntiles,
+        _lib.check(_lib.lib.gcrnn_ell_fill(vp(rowptr_pad), vp(col), vp(val), npad, vp(order_full), 16, 4, ntiles,
                                            vp(tile_off), vp(ell_col), vp(ell_val)), 'ell_fill')
         cyc = C.c_int64(0)
         _lib.check(_lib.lib.gcrnn_ell_conflict_cycles(vp(ell_col), nent.value, C.byref(cyc)), 'ell_conflict_cycles')
@@ -135,7 +146,7 @@ class GraphOperator(object):
         col4 = np.zeros(max(nent.value, 4) * 16, dtype=np.uint16)
         _lib.check(_lib.lib.gcrnn_ell_pack_lds(vp(ell_col), vp(ell_val), nent.value, vp(val4), vp(col4)), 'ell_pack_lds')
         dev = self.device
-        tile_nodes = np.concatenate([order, np.arange(self.N, npad, dtype=np.int32)]).astype(np.int32)
+        tile_nodes = order_full
         plan = dict(npad=npad, order=torch.from_numpy(order).to(dev), tile_nodes=torch.from_numpy(tile_nodes).to(dev),
                     tile_off=torch.from_numpy(tile_off).to(dev),
                     ell_col=torch.from_numpy(ell_col).to(dev), ell_val=torch.from_numpy(ell_val).to(dev),
