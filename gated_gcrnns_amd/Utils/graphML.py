@@ -344,16 +344,17 @@ class GGCRNNCell(nn.Module):
             return False            # BPTT runs on the composed path
         if self.spatial_gating is not None or self.sigma not in (torch.tanh, nn.functional.tanh):
             return False
-        if self.time_gating == True:  # noqa: E712   (gate pre-pass in bf16 not wired yet)
-            return False
         return ops.fused_supported(self.N, self.F, self.G, self.Kin, self.Kst, X.dtype, self.E) and \
             self.weight_A.dtype == X.dtype and h0.dtype == X.dtype
 
     def _forward_fused(self, X, h0):
-        gi = gf = None
+        gates = None
         if self.time_gating == True:  # noqa: E712
-            raise NotImplementedError('time-gated fused path needs bf16 gate pre-pass')
-        return ops.fused_cell_forward(X, h0, self.weight_A, self.weight_B, self.bias, self.graph, gi, gf)
+            gates = {'in': (self.GFL_in.weight_A, self.GFL_in.weight_B, self.GFL_in.bias,
+                            self.MLP_in[0].weight, self.MLP_in[0].bias),
+                     'forget': (self.GFL_forget.weight_A, self.GFL_forget.weight_B, self.GFL_forget.bias,
+                                self.MLP_forget[0].weight, self.MLP_forget[0].bias)}
+        return ops.fused_cell_forward(X, h0, self.weight_A, self.weight_B, self.bias, self.graph, gates)
 
     def extra_repr(self):
         return 'in_features=%d, state_features=%d, taps=(%d,%d), time_gating=%s, spatial_gating=%s, %s' % (

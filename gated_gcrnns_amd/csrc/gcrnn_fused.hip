@@ -242,7 +242,7 @@ extern "C" int gcrnn_fused_pack_weights(int wdtype, const void* wA, const void* 
 // LDS map (dynamic): state [NP][16] fp32 (64 KiB) | weight fragments K*KS KiB | RESIDENT: lval4 (f32x4), lcol4 (u16x4).
 // Tiles hold 16 nodes of similar degree: tile_nodes[p] lists the node of every slot p (degree-sorted order,
 // padded with node ids >= N that have no edges); memory rows are in natural node order.
-template <int K, int HS, int XS, bool GATED, bool RESIDENT>
+template <int K, int HS, int XS, bool GATED, bool RESIDENT, bool GATEOUT = false>
 __global__ __launch_bounds__(512, 2) void fused_step_kernel(
     const uint16_t* __restrict__ xt,        // [B][NP][G]   bf16
     const uint16_t* __restrict__ hprev,     // [B][NP][F]   bf16
@@ -257,7 +257,9 @@ __global__ __launch_bounds__(512, 2) void fused_step_kernel(
     const float* __restrict__ ell_val,      // [entries][16]
     const float4* __restrict__ ell_val4,    // [entries/4][16] x 4 weights                  (LDS image, RESIDENT)
     const uint2* __restrict__ ell_col4,     // [entries/4][16] x 4 u16 (row offset | swizzle)
-    int entries, int B, int N) {
+    const float* __restrict__ gate_w,       // GATEOUT: [N][F] node-major weights of the gate's Linear(N*F -> 1)
+    float* __restrict__ gate_out,           // GATEOUT: [B] += sum_{n,f} tanh(pre)[n][f] * gate_w[n][f]   (caller zeroes)
+    int entries, int B, int hmod, int N) {
   constexpr int KS = HS + XS;
   constexpr int F = 32 * HS, G = 32 * XS;
   constexpr int NCH = F / FC;
@@ -322,10 +324,11 @@ __global__ __launch_bounds__(512, 2) void fused_step_kernel(
   __syncthreads();
 
   for (int b = b0; b < B; b += seq_slots) {
-  const uint16_t* hb = hprev + (int64_t)b * NP * F;
+  const uint16_t* hb = hprev + (int64_t)(b % hmod) * NP * F;     // hmod < B: every item of the gate pre-pass reads h0[b]
   const uint16_t* xb = xt + (int64_t)b * NP * G;
   float gin = 1.f, gfo = 1.f;
-  if (GATED) { gin = gi[b]; gfo = gf[b]; }
+  float gratio = 1.f;
+  if (GATED) { gin = gi[b]; gfo = gf[b]; gratio = gfo / fmaxf(gin, 1e-30f); }
 
   // ---- phase 1: taps on the matrix cores ------------------------------------------------------
 #ifdef GCRNN_ABLATE_PHASE1      // profiling builds only (tools/ablate.sh): results are wrong by construction
@@ -352,18 +355,24 @@ __global__ __launch_bounds__(512, 2) void fused_step_kernel(
     for (int tap = 0; tap < K; ++tap) {
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
       if (GATED) {
-        f32x4 accx = {0.f, 0.f, 0.f, 0.f};
+        // gi (x W_x) + gf (h W_h) on ONE accumulator: h-chain, scale by gf/gi, continue the chain with x, scale by gi.
+        // (gi = sigmoid(.) > 0; the wave-uniform guard covers an underflowed gate.)
 #pragma unroll
         for (int s = 0; s < HS; ++s) {
           const bf16x8 a = __builtin_bit_cast(bf16x8, wl[(tap * KS + s) * 64 + lane]);
           acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bfr[i][s], acc, 0, 0, 0);
         }
+        if (gin > 1e-30f) {
+          acc *= gratio;
 #pragma unroll
-        for (int s = HS; s < KS; ++s) {
-          const bf16x8 a = __builtin_bit_cast(bf16x8, wl[(tap * KS + s) * 64 + lane]);
-          accx = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bfr[i][s], accx, 0, 0, 0);
+          for (int s = HS; s < KS; ++s) {
+            const bf16x8 a = __builtin_bit_cast(bf16x8, wl[(tap * KS + s) * 64 + lane]);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bfr[i][s], acc, 0, 0, 0);
+          }
+          acc *= gin;
+        } else {
+          acc *= gfo;
         }
-        acc = gfo * acc + gin * accx;
       } else {
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
@@ -385,7 +394,7 @@ __global__ __launch_bounds__(512, 2) void fused_step_kernel(
   if (b + seq_slots < B) {
     const int line = chunk * (2 * NP / NCH) + tid;                       // 2*NP/NCH == 512 for F = 64
     if (tid < 2 * NP / NCH) {
-      const uint16_t* pb = (line < NP) ? hprev + ((int64_t)(b + seq_slots) * NP + line) * F
+      const uint16_t* pb = (line < NP) ? hprev + ((int64_t)((b + seq_slots) % hmod) * NP + line) * F
                                        : xt + ((int64_t)(b + seq_slots) * NP + (line - NP)) * G;
       prefetched = *reinterpret_cast<const uint32_t*>(pb);
     }
@@ -505,6 +514,23 @@ __global__ __launch_bounds__(512, 2) void fused_step_kernel(
 #pragma unroll
     for (int c = 0; c < 4; ++c) bsum[c] = bs * bvec[c];
   }
+  if (GATEOUT) {
+    // gate pre-pass: partial dot product of tanh(pre) with the gate's linear weights over this chunk, one atomic per wave
+    float part = 0.f;
+#pragma unroll
+    for (int i = 0; i < TILES; ++i) {
+      const int node = nodes[i];
+      if (node < N) {
+        const float4 w4 = *reinterpret_cast<const float4*>(gate_w + (int64_t)node * F + chunk * FC + q * 4);
+        const f32x4 acc = u[i][0];
+        part += fast_tanh(acc[0] + bsum[0]) * w4.x + fast_tanh(acc[1] + bsum[1]) * w4.y +
+                fast_tanh(acc[2] + bsum[2]) * w4.z + fast_tanh(acc[3] + bsum[3]) * w4.w;
+      }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) part += __shfl_down(part, off, 64);
+    if (lane == 0) atomicAdd(gate_out + b, part);
+  } else {
 #pragma unroll
   for (int i = 0; i < TILES; ++i) {
     const int node = nodes[i];
@@ -520,32 +546,40 @@ __global__ __launch_bounds__(512, 2) void fused_step_kernel(
     }
     *reinterpret_cast<uint2*>(hout + ((int64_t)b * NP + node) * F + chunk * FC + q * 4) = pk;
   }
+  }
   asm volatile("" ::"v"(prefetched));      // the prefetch load retires here at the latest
   __syncthreads();     // the last hop's reads of `state` are done before the next sequence overwrites it
   }  // sequences
 }
 
+typedef void (*fused_kern_t)(const uint16_t*, const uint16_t*, uint16_t*, const uint4*, const float*, const float*,
+                             const float*, const int32_t*, const int32_t*, const int32_t*, const float*, const float4*,
+                             const uint2*, const float*, float*, int, int, int, int);
+
+struct FusedGraphArgs {
+  const int32_t* tile_nodes; const int32_t* tile_off; const int32_t* ell_col; const float* ell_val;
+  const void* ell_val4; const void* ell_col4; int64_t entries;
+};
+
 template <int K, int HS, int XS>
-static int fused_forward_t(const void* xs, const void* h0, void* hs, const void* wpack, const float* bias,
-                           const float* gi, const float* gf, const int32_t* tile_nodes, const int32_t* tile_off,
-                           const int32_t* ell_col, const float* ell_val, const void* ell_val4, const void* ell_col4,
-                           int64_t entries, int64_t B, int64_t T, int64_t N, hipStream_t st) {
+static int fused_launch_t(int mode /*0 plain, 1 gated, 2 gate pre-pass*/, const void* xs, const void* h0, void* hs,
+                          const void* wpack, const float* bias, const float* gi, const float* gf, const float* gate_w,
+                          float* gate_out, const FusedGraphArgs& ga, int64_t B, int64_t T, int64_t N, hipStream_t st) {
   constexpr int F = 32 * HS, G = 32 * XS, KS = HS + XS;
   const size_t base = (size_t)NP * FC * 4 + (size_t)K * KS * 1024;
-  const size_t resident_bytes = base + (size_t)entries * 16 * 6;
-  const bool resident = resident_bytes <= 160 * 1024 && ell_val4 && ell_col4;
+  const size_t resident_bytes = base + (size_t)ga.entries * 16 * 6;
+  const bool resident = resident_bytes <= 160 * 1024 && ga.ell_val4 && ga.ell_col4;
   const size_t lds = resident ? resident_bytes : base;
-  const bool gated = gi != nullptr;
-  typedef void (*kern_t)(const uint16_t*, const uint16_t*, uint16_t*, const uint4*, const float*, const float*,
-                         const float*, const int32_t*, const int32_t*, const int32_t*, const float*, const float4*,
-                         const uint2*, int, int, int);
-  kern_t kern = gated ? (resident ? (kern_t)fused_step_kernel<K, HS, XS, true, true> : (kern_t)fused_step_kernel<K, HS, XS, true, false>)
-                      : (resident ? (kern_t)fused_step_kernel<K, HS, XS, false, true> : (kern_t)fused_step_kernel<K, HS, XS, false, false>);
+  fused_kern_t kern;
+  if (mode == 2)      kern = resident ? (fused_kern_t)fused_step_kernel<K, HS, XS, false, true, true> : (fused_kern_t)fused_step_kernel<K, HS, XS, false, false, true>;
+  else if (mode == 1) kern = resident ? (fused_kern_t)fused_step_kernel<K, HS, XS, true, true> : (fused_kern_t)fused_step_kernel<K, HS, XS, true, false>;
+  else                kern = resident ? (fused_kern_t)fused_step_kernel<K, HS, XS, false, true> : (fused_kern_t)fused_step_kernel<K, HS, XS, false, false>;
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
     return GCRNN_ERR_LAUNCH;
   const int NCH = F / FC;
+  const int64_t items = (mode == 2) ? B * T : B;       // the gate pre-pass has no recurrence: all (t, b) in one launch
   // one workgroup per CU: 256 / NCH sequence slots (rounded to the 8 XCDs), fewer when the batch is small
-  int64_t slots = cdiv(B, 8) * 8;
+  int64_t slots = cdiv(items, 8) * 8;
   const int64_t max_slots = (256 / NCH) / 8 * 8 > 0 ? (256 / NCH) / 8 * 8 : 8;
   if (slots > max_slots) slots = max_slots;
   const unsigned grid = (unsigned)(slots * NCH);
@@ -553,14 +587,38 @@ static int fused_forward_t(const void* xs, const void* h0, void* hs, const void*
   uint16_t* h = (uint16_t*)hs;
   const int64_t xstep = B * NP * G, hstep = B * NP * F;
   GCRNN_PRE_LAUNCH();
-  for (int64_t t = 0; t < T; ++t) {
-    const uint16_t* hp = (t == 0) ? (const uint16_t*)h0 : h + (t - 1) * hstep;
-    kern<<<grid, 512, lds, st>>>(x + t * xstep, hp, h + t * hstep, (const uint4*)wpack, bias, gated ? gi + t * B : nullptr,
-                                 gated ? gf + t * B : nullptr, tile_nodes, tile_off, ell_col, ell_val,
-                                 (const float4*)ell_val4, (const uint2*)ell_col4, (int)entries, (int)B, (int)N);
+  if (mode == 2) {
+    kern<<<grid, 512, lds, st>>>(x, (const uint16_t*)h0, nullptr, (const uint4*)wpack, bias, nullptr, nullptr, ga.tile_nodes,
+                                 ga.tile_off, ga.ell_col, ga.ell_val, (const float4*)ga.ell_val4, (const uint2*)ga.ell_col4,
+                                 gate_w, gate_out, (int)ga.entries, (int)items, (int)B, (int)N);
+  } else {
+    for (int64_t t = 0; t < T; ++t) {
+      const uint16_t* hp = (t == 0) ? (const uint16_t*)h0 : h + (t - 1) * hstep;
+      kern<<<grid, 512, lds, st>>>(x + t * xstep, hp, h + t * hstep, (const uint4*)wpack, bias, mode == 1 ? gi + t * B : nullptr,
+                                   mode == 1 ? gf + t * B : nullptr, ga.tile_nodes, ga.tile_off, ga.ell_col, ga.ell_val,
+                                   (const float4*)ga.ell_val4, (const uint2*)ga.ell_col4, nullptr, nullptr, (int)ga.entries,
+                                   (int)B, (int)B, (int)N);
+    }
   }
   GCRNN_CHECK_LAUNCH();
   return GCRNN_OK;
+}
+
+static int fused_dispatch(int mode, const void* xs, const void* h0, void* hs, const void* wpack, const float* bias,
+                          const float* gi, const float* gf, const float* gate_w, float* gate_out, const FusedGraphArgs& ga,
+                          int64_t B, int64_t T, int64_t N, int64_t F, int64_t G, int64_t K, hipStream_t st) {
+#define GCRNN_FUSED_CASE(KK, HH, XX) \
+  if (K == KK && F == 32 * HH && G == 32 * XX) \
+    return fused_launch_t<KK, HH, XX>(mode, xs, h0, hs, wpack, bias, gi, gf, gate_w, gate_out, ga, B, T, N, st);
+  GCRNN_FUSED_CASE(5, 2, 2)
+  GCRNN_FUSED_CASE(4, 2, 2)
+  GCRNN_FUSED_CASE(3, 2, 2)
+  GCRNN_FUSED_CASE(2, 2, 2)
+  GCRNN_FUSED_CASE(5, 1, 1)
+  GCRNN_FUSED_CASE(3, 1, 1)
+  GCRNN_FUSED_CASE(2, 1, 1)
+#undef GCRNN_FUSED_CASE
+  return GCRNN_ERR_UNSUPPORTED;
 }
 
 extern "C" int gcrnn_fused_forward_bf16(const void* xs, const void* h0, void* hs, const void* wpack, const float* bias,
@@ -571,20 +629,19 @@ extern "C" int gcrnn_fused_forward_bf16(const void* xs, const void* h0, void* hs
   if (!xs || !h0 || !hs || !wpack || !tile_nodes || !tile_off || !ell_col || !ell_val) return GCRNN_ERR_NULL_POINTER;
   if ((gi == nullptr) != (gf == nullptr)) return GCRNN_ERR_NULL_POINTER;
   if (B <= 0 || T <= 0 || N <= 0 || N > NP || B > (1 << 24) || entries < 0 || entries % 4) return GCRNN_ERR_BAD_SHAPE;
-  hipStream_t st = as_stream(stream);
-#define GCRNN_FUSED_CASE(KK, HH, XX) \
-  if (K == KK && F == 32 * HH && G == 32 * XX) \
-    return fused_forward_t<KK, HH, XX>(xs, h0, hs, wpack, bias, gi, gf, tile_nodes, tile_off, ell_col, ell_val, \
-                                       ell_val4, ell_col4, entries, B, T, N, st);
-  GCRNN_FUSED_CASE(5, 2, 2)
-  GCRNN_FUSED_CASE(4, 2, 2)
-  GCRNN_FUSED_CASE(3, 2, 2)
-  GCRNN_FUSED_CASE(2, 2, 2)
-  GCRNN_FUSED_CASE(5, 1, 1)
-  GCRNN_FUSED_CASE(3, 1, 1)
-  GCRNN_FUSED_CASE(2, 1, 1)
-#undef GCRNN_FUSED_CASE
-  return GCRNN_ERR_UNSUPPORTED;
+  const FusedGraphArgs ga{tile_nodes, tile_off, ell_col, ell_val, ell_val4, ell_col4, entries};
+  return fused_dispatch(gi ? 1 : 0, xs, h0, hs, wpack, bias, gi, gf, nullptr, nullptr, ga, B, T, N, F, G, K, as_stream(stream));
+}
+
+extern "C" int gcrnn_fused_gate_prepass_bf16(const void* xs, const void* h0, const void* wpack, const float* bias,
+                                             const float* gate_w, float* gate_out, const int32_t* tile_nodes,
+                                             const int32_t* tile_off, const int32_t* ell_col, const float* ell_val,
+                                             const void* ell_val4, const void* ell_col4, int64_t entries, int64_t B,
+                                             int64_t T, int64_t N, int64_t F, int64_t G, int64_t K, void* stream) {
+  if (!xs || !h0 || !wpack || !gate_w || !gate_out || !tile_nodes || !tile_off || !ell_col || !ell_val) return GCRNN_ERR_NULL_POINTER;
+  if (B <= 0 || T <= 0 || N <= 0 || N > NP || B * T > (1 << 24) || entries < 0 || entries % 4) return GCRNN_ERR_BAD_SHAPE;
+  const FusedGraphArgs ga{tile_nodes, tile_off, ell_col, ell_val, ell_val4, ell_col4, entries};
+  return fused_dispatch(2, xs, h0, nullptr, wpack, bias, nullptr, nullptr, gate_w, gate_out, ga, B, T, N, F, G, K, as_stream(stream));
 }
 
 extern "C" int gcrnn_fused_supported(int64_t N, int64_t F, int64_t G, int64_t K) {

@@ -238,17 +238,28 @@ def time_fused_step_kernel(X, h0, wA, wB, bias, graph, reps=3):
     return {'avg_us': 1e3 * e0.elapsed_time(e1) / (reps * T), 'launches': reps * T}
 
 
-def fused_cell_forward(X, h0, wA, wB, bias, graph, gi=None, gf=None, return_states=False):
+def _fused_pack_weights(wA, wB, st):
+    F, G = wA.shape[0], wA.shape[3]
+    Kin, Kst = wA.shape[2], wB.shape[2]
+    K = max(Kin, Kst)
+    wpack = torch.empty(((F // 16) * K * ((F + G) // 32) * 64 * 8,), dtype=torch.bfloat16, device=wA.device)
+    check(lib.gcrnn_fused_pack_weights(dtype_code(wA.dtype), _p(wA.contiguous()), _p(wB.contiguous()), _p(wpack),
+                                       F, G, Kin, Kst, st), 'pack_weights')
+    return wpack
+
+
+def fused_cell_forward(X, h0, wA, wB, bias, graph, gates=None, return_states=False):
     """Whole GGCRNNCell forward (un-gated or time-gated) on the fused bf16 step kernel.
 
     X: B x T x G x N bf16, h0: B x F x N bf16 (user layout) -> H: B x T x F x N bf16.
-    gi / gf: fp32 [T][B] time gates or None. Inference only (no autograd graph is recorded).
+    gates: None, or {'in': (wA_g, wB_g, bias_g, lin_weight [1, F*N], lin_bias), 'forget': (...)} -- the time-gate
+    sub-networks GFL_* / MLP_* of the reference (graphML.py:2248-2278); each gate costs one pre-pass launch over all
+    (t, b). Inference only (no autograd graph is recorded).
     """
     require_device(X, h0, wA, wB, bias)
     B, T, G, N = X.shape
     F = wA.shape[0]
-    Kin, Kst = wA.shape[2], wB.shape[2]
-    K = max(Kin, Kst)
+    K = max(wA.shape[2], wB.shape[2])
     plan = graph.fused_plan()
     npad = plan['npad']
     st = _stream()
@@ -260,17 +271,28 @@ def fused_cell_forward(X, h0, wA, wB, bias, graph, gi=None, gf=None, return_stat
     hs = torch.empty((T, B, npad, F), dtype=torch.bfloat16, device=dev)
     check(lib.gcrnn_pack_seq_major(_lib.BF16, _p(X), _p(xs), B, T, G, N, npad, None, st), 'pack_seq')
     check(lib.gcrnn_pack_seq_major(_lib.BF16, _p(h0), _p(h0s), B, 1, F, N, npad, None, st), 'pack_seq')
-    wpack = torch.empty(((F // 16) * K * ((F + G) // 32) * 64 * 8,), dtype=torch.bfloat16, device=dev)
-    check(lib.gcrnn_fused_pack_weights(dtype_code(wA.dtype), _p(wA.contiguous()), _p(wB.contiguous()), _p(wpack),
-                                       F, G, Kin, Kst, st), 'pack_weights')
+    gargs = (_p(plan['tile_nodes']), _p(plan['tile_off']), _p(plan['ell_col']), _p(plan['ell_val']),
+             _p(plan['ell_val4']), _p(plan['ell_col4']), plan['entries'])
+    gi = gf = None
+    if gates is not None:
+        g = {}
+        for name in ('in', 'forget'):
+            wA_g, wB_g, bias_g, lin_w, lin_b = gates[name]
+            assert max(wA_g.shape[2], wB_g.shape[2]) == K and wA_g.shape[0] == F
+            wp = _fused_pack_weights(wA_g, wB_g, st)
+            bg = bias_g.detach().float().contiguous().view(-1) if bias_g is not None else None
+            gw = lin_w.detach().float().view(F, N).t().contiguous()          # row-major vec over (f, n) -> [N][F]
+            acc = torch.zeros(T * B, dtype=torch.float32, device=dev)
+            check(lib.gcrnn_fused_gate_prepass_bf16(_p(xs), _p(h0s), _p(wp), _p(bg), _p(gw), _p(acc), *gargs,
+                                                    B, T, N, F, G, K, st), 'gate_prepass')
+            if lin_b is not None:
+                acc = acc + lin_b.detach().float()
+            g[name] = torch.sigmoid(acc).contiguous()                        # [T][B] fp32
+        gi, gf = g['in'], g['forget']
+    wpack = _fused_pack_weights(wA, wB, st)
     b32 = bias.detach().float().contiguous().view(-1) if bias is not None else None
-    if gi is not None:
-        gi = gi.float().contiguous()
-        gf = gf.float().contiguous()
-    check(lib.gcrnn_fused_forward_bf16(_p(xs), _p(h0s), _p(hs), _p(wpack), _p(b32), _p(gi), _p(gf),
-                                       _p(plan['tile_nodes']), _p(plan['tile_off']), _p(plan['ell_col']),
-                                       _p(plan['ell_val']), _p(plan['ell_val4']), _p(plan['ell_col4']),
-                                       plan['entries'], B, T, N, F, G, K, st), 'fused_forward')
+    check(lib.gcrnn_fused_forward_bf16(_p(xs), _p(h0s), _p(hs), _p(wpack), _p(b32), _p(gi), _p(gf), *gargs,
+                                       B, T, N, F, G, K, st), 'fused_forward')
     if return_states:
         return hs, plan
     H = torch.empty((B, T, F, N), dtype=torch.bfloat16, device=dev)

@@ -138,6 +138,17 @@ int gcrnn_fused_forward_bf16(const void* xs, const void* h0, void* hs, const voi
                              int64_t entries, int64_t B, int64_t T, int64_t N, int64_t F, int64_t G, int64_t K,
                              void* stream);
 
+/* Time-gate pre-pass (graphML.py:2357-2374): for every (t, b)
+ *   gate_out[t][b] += sum_{n,f} tanh( A_g(S) x_t + B_g(S) h0 + 2 b_g )[n][f] * gate_w[n][f]
+ * with the gate sub-cell's packed weights (gcrnn_fused_pack_weights of GFL_in / GFL_forget) and gate_w = the gate's
+ * Linear(N*F -> 1) weight re-laid node-major [N][F] (fp32). All T*B items run in ONE launch because the reference's gates
+ * read h0, never h_{t-1} (graphML.py:2362, 2370). The caller zeroes gate_out and applies sigmoid(gate_out + c). */
+int gcrnn_fused_gate_prepass_bf16(const void* xs, const void* h0, const void* wpack, const float* bias,
+                                  const float* gate_w, float* gate_out, const int32_t* tile_nodes,
+                                  const int32_t* tile_off, const int32_t* ell_col, const float* ell_val,
+                                  const void* ell_val4, const void* ell_col4, int64_t entries, int64_t B, int64_t T,
+                                  int64_t N, int64_t F, int64_t G, int64_t K, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

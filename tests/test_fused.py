@@ -87,3 +87,36 @@ def test_fused_step_matches_oracle(N, F, K, B, T, iso):
     assert err[:, 0].max() <= 4.0e-3, err[:, 0].max()
     assert err.max() <= 3.0e-2, err.max()
     assert err.mean() <= 2.0e-3, err.mean()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('N,F,K,B,T', [(1000, 64, 5, 5, 4), (200, 32, 3, 9, 3), (1000, 64, 3, 70, 2)])
+def test_fused_time_gated_matches_oracle(N, F, K, B, T):
+    """Time gating on the fused path: gate pre-pass (one launch over all (t, b)) + gated recurrence vs the fp64 oracle
+    on bf16-rounded operands. Non-zero h0 exercises the gates-read-h0 rule (graphML.py:2362, 2370)."""
+    import gated_gcrnns_amd.Utils.graphML as gml
+    dev = torch.device('cuda:0')
+    G = F
+    S = random_graph(N, min(0.5, 10.0 / N), 23)
+    rng = np.random.default_rng(9)
+    X = bf16_round(rng.standard_normal((B, T, G, N)))
+    h0 = bf16_round(0.5 * rng.standard_normal((B, F, N)))
+    torch.manual_seed(5)
+    cell = gml.GGCRNNCell(G, F, K, K, torch.tanh, True, None, 1, True)
+    cell.addGSO(torch.tensor(S))
+    with torch.no_grad():                               # make the scalar gates vary: larger MLP weights than the default init
+        cell.MLP_in[0].weight.mul_(8.0)
+        cell.MLP_forget[0].weight.mul_(8.0)
+    cell = cell.to(torch.bfloat16)
+    params = {k: v.detach().double().numpy() for k, v in cell.state_dict().items()}
+    S32 = S.astype(np.float32).astype(np.float64)
+    Href = orc.ggcrnn_cell(params, S32, X, h0, True, None)
+    cell = cell.to(dev)
+    with torch.no_grad():
+        Xd = torch.tensor(X, dtype=torch.bfloat16, device=dev)
+        hd = torch.tensor(h0, dtype=torch.bfloat16, device=dev)
+        assert cell._use_fused(Xd, hd)
+        H = cell(Xd, hd)
+    err = np.abs(H.double().cpu().numpy() - Href)
+    assert err[:, 0].max() <= 6.0e-3, err[:, 0].max()
+    assert err.max() <= 3.0e-2 and err.mean() <= 2.0e-3, (err.max(), err.mean())
