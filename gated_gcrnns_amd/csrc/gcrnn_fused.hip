@@ -30,6 +30,7 @@
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 
 namespace {
 constexpr int FC = 16;          // output features per workgroup
@@ -288,17 +289,15 @@ __global__ __launch_bounds__(512, 2) void fused_step_kernel(
   if (RESIDENT) {
     const int n = (entries >> 2) * 16;                         // the host packed the LDS image: straight copies,
     for (int i0 = 0; i0 < n; i0 += 512 * 4) {                  // 4 loads in flight per lane before the first LDS store
-      float4 tv[4]; uint2 tc[4];
-#pragma unroll
-      for (int p = 0; p < 4; ++p) {
-        const int i = i0 + p * 512 + tid;
-        if (i < n) { tv[p] = ell_val4[i]; tc[p] = ell_col4[i]; }
-      }
-#pragma unroll
-      for (int p = 0; p < 4; ++p) {
-        const int i = i0 + p * 512 + tid;
-        if (i < n) { lval4[i] = tv[p]; lcol4[i] = tc[p]; }
-      }
+      const int i_0 = i0 + tid, i_1 = i_0 + 512, i_2 = i_0 + 1024, i_3 = i_0 + 1536, nl = n - 1;
+      const float4 tv0 = ell_val4[i_0 < n ? i_0 : nl], tv1 = ell_val4[i_1 < n ? i_1 : nl];
+      const float4 tv2 = ell_val4[i_2 < n ? i_2 : nl], tv3 = ell_val4[i_3 < n ? i_3 : nl];
+      const uint2 tc0 = ell_col4[i_0 < n ? i_0 : nl], tc1 = ell_col4[i_1 < n ? i_1 : nl];
+      const uint2 tc2 = ell_col4[i_2 < n ? i_2 : nl], tc3 = ell_col4[i_3 < n ? i_3 : nl];
+      if (i_0 < n) { lval4[i_0] = tv0; lcol4[i_0] = tc0; }
+      if (i_1 < n) { lval4[i_1] = tv1; lcol4[i_1] = tc1; }
+      if (i_2 < n) { lval4[i_2] = tv2; lcol4[i_2] = tc2; }
+      if (i_3 < n) { lval4[i_3] = tv3; lcol4[i_3] = tc3; }
     }
   }
   // per-wave tile ranges, fetched once through the scalar path
@@ -308,13 +307,12 @@ __global__ __launch_bounds__(512, 2) void fused_step_kernel(
     tbeg[i] = tile_off[wave * TILES + i];
     tend[i] = tile_off[wave * TILES + i + 1];
   }
-  f32x4 u[TILES][K];
-  int nodes[TILES];
+  f32x4 u[TILES][K - 1];   // taps 0..K-2 (tap K-1 seeds the LDS state directly); later: the hop results
   int woff[TILES];      // byte offset of this lane's quad in the swizzled state row of its node
 #pragma unroll
   for (int i = 0; i < TILES; ++i) {
-    nodes[i] = tile_nodes[(wave * TILES + i) * 16 + r];
-    woff[i] = nodes[i] * (FC * 4) + ((q ^ ((nodes[i] >> 2) & 3)) << 4);
+    const int nd = tile_nodes[(wave * TILES + i) * 16 + r];
+    woff[i] = nd * (FC * 4) + ((q ^ ((nd >> 2) & 3)) << 4);          // node id = woff >> 6
   }
   float bvec[4] = {0.f, 0.f, 0.f, 0.f};
   if (bias) {
@@ -323,9 +321,16 @@ __global__ __launch_bounds__(512, 2) void fused_step_kernel(
   }
   __syncthreads();
 
+  // Row traffic goes through buffer instructions: descriptor in SGPRs (built from kernel arguments only, so provably
+  // wave-uniform), 32-bit lane offset, per-sequence base as the scalar offset -- no per-lane 64-bit pointers to keep
+  // alive (and spill) across the sequence loop.
+  const __amdgpu_buffer_rsrc_t rsrc_h = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(hprev), 0, hmod * (NP * F * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(xt), 0, B * (NP * G * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_o = __builtin_amdgcn_make_buffer_rsrc(hout, 0, GATEOUT ? 0 : B * (NP * F * 2), 0x00020000);
+
   for (int b = b0; b < B; b += seq_slots) {
-  const uint16_t* hb = hprev + (int64_t)(b % hmod) * NP * F;     // hmod < B: every item of the gate pre-pass reads h0[b]
-  const uint16_t* xb = xt + (int64_t)b * NP * G;
+  const int soff_h = (b % hmod) * (NP * F * 2);     // hmod < B: every item of the gate pre-pass reads h0[b]
+  const int soff_x = b * (NP * G * 2);
   float gin = 1.f, gfo = 1.f;
   float gratio = 1.f;
   if (GATED) { gin = gi[b]; gfo = gf[b]; gratio = gfo / fmaxf(gin, 1e-30f); }
@@ -335,19 +340,22 @@ __global__ __launch_bounds__(512, 2) void fused_step_kernel(
 #pragma unroll
   for (int i = 0; i < TILES; ++i)
 #pragma unroll
-    for (int tap = 0; tap < K; ++tap) u[i][tap] = f32x4{0.f, 0.f, 0.f, (float)nodes[i]};
+    for (int tap = 0; tap < K - 1; ++tap) u[i][tap] = f32x4{0.f, 0.f, 0.f, (float)woff[i]};
 #else
   // all B-operand fragments of the wave (8 tiles x 4 x 16 B per lane) are requested before the first MFMA: one
   // memory latency per sequence instead of one per tile; the registers are free again before the taps fill up.
   bf16x8 bfr[TILES][KS];
 #pragma unroll
   for (int i = 0; i < TILES; ++i) {
+    int w = woff[i];
+    asm volatile("" : "+v"(w));      // opaque per iteration: keeps hipcc from hoisting (and spilling) 16+ row offsets
+    const int roh = (w >> 6) * (F * 2) + 16 * q, rox = (w >> 6) * (G * 2) + 16 * q;
 #pragma unroll
     for (int s = 0; s < HS; ++s)
-      bfr[i][s] = *reinterpret_cast<const bf16x8*>(hb + (int64_t)nodes[i] * F + 32 * s + 8 * q);
+      bfr[i][s] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsrc_h, roh + 64 * s, soff_h, 0));
 #pragma unroll
     for (int s = 0; s < XS; ++s)
-      bfr[i][HS + s] = *reinterpret_cast<const bf16x8*>(xb + (int64_t)nodes[i] * G + 32 * s + 8 * q);
+      bfr[i][HS + s] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, rox + 64 * s, soff_x, 0));
   }
 #pragma unroll
   for (int i = 0; i < TILES; ++i) {
@@ -380,9 +388,9 @@ __global__ __launch_bounds__(512, 2) void fused_step_kernel(
           acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bfr[i][s], acc, 0, 0, 0);
         }
       }
-      u[i][tap] = acc;
+      if (tap == K - 1) *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(state) + woff[i]) = acc;
+      else u[i][tap] = acc;
     }
-    *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(state) + woff[i]) = u[i][K - 1];
   }
 #endif
   __syncthreads();
@@ -394,9 +402,9 @@ __global__ __launch_bounds__(512, 2) void fused_step_kernel(
   if (b + seq_slots < B) {
     const int line = chunk * (2 * NP / NCH) + tid;                       // 2*NP/NCH == 512 for F = 64
     if (tid < 2 * NP / NCH) {
-      const uint16_t* pb = (line < NP) ? hprev + ((int64_t)((b + seq_slots) % hmod) * NP + line) * F
-                                       : xt + ((int64_t)(b + seq_slots) * NP + (line - NP)) * G;
-      prefetched = *reinterpret_cast<const uint32_t*>(pb);
+      prefetched = (line < NP)
+          ? __builtin_amdgcn_raw_buffer_load_b32(rsrc_h, line * (F * 2), ((b + seq_slots) % hmod) * (NP * F * 2), 0)
+          : __builtin_amdgcn_raw_buffer_load_b32(rsrc_x, (line - NP) * (G * 2), (b + seq_slots) * (NP * G * 2), 0);
     }
   }
 
@@ -519,7 +527,9 @@ __global__ __launch_bounds__(512, 2) void fused_step_kernel(
     float part = 0.f;
 #pragma unroll
     for (int i = 0; i < TILES; ++i) {
-      const int node = nodes[i];
+      int wv = woff[i];
+      asm volatile("" : "+v"(wv));
+      const int node = wv >> 6;
       if (node < N) {
         const float4 w4 = *reinterpret_cast<const float4*>(gate_w + (int64_t)node * F + chunk * FC + q * 4);
         const f32x4 acc = u[i][0];
@@ -533,7 +543,9 @@ __global__ __launch_bounds__(512, 2) void fused_step_kernel(
   } else {
 #pragma unroll
   for (int i = 0; i < TILES; ++i) {
-    const int node = nodes[i];
+    int wv = woff[i];
+    asm volatile("" : "+v"(wv));
+    const int node = wv >> 6;
     const f32x4 acc = u[i][0];
     uint2 pk;
     if (node < N) {
@@ -544,7 +556,7 @@ __global__ __launch_bounds__(512, 2) void fused_step_kernel(
     } else {
       pk.x = 0u; pk.y = 0u;          // padded rows stay zero
     }
-    *reinterpret_cast<uint2*>(hout + ((int64_t)b * NP + node) * F + chunk * FC + q * 4) = pk;
+    __builtin_amdgcn_raw_buffer_store_b64(u32x2{pk.x, pk.y}, rsrc_o, node * (F * 2) + (chunk * FC + q * 4) * 2, b * (NP * F * 2), 0);
   }
   }
   asm volatile("" ::"v"(prefetched));      // the prefetch load retires here at the latest
