@@ -351,11 +351,15 @@ __global__ __launch_bounds__(512, 2) void fused_step_kernel(
     asm volatile("" : "+v"(w));      // opaque per iteration: keeps hipcc from hoisting (and spilling) 16+ row offsets
     const int roh = (w >> 6) * (F * 2) + 16 * q, rox = (w >> 6) * (G * 2) + 16 * q;
 #pragma unroll
+#ifdef GCRNN_ABLATE_P1_LOADS
+    for (int s = 0; s < KS; ++s) bfr[i][s] = __builtin_bit_cast(bf16x8, uint4{(unsigned)roh, (unsigned)rox, (unsigned)s, 1u});
+#else
     for (int s = 0; s < HS; ++s)
       bfr[i][s] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsrc_h, roh + 64 * s, soff_h, 0));
 #pragma unroll
     for (int s = 0; s < XS; ++s)
       bfr[i][HS + s] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, rox + 64 * s, soff_x, 0));
+#endif
   }
 #pragma unroll
   for (int i = 0; i < TILES; ++i) {
@@ -382,11 +386,16 @@ __global__ __launch_bounds__(512, 2) void fused_step_kernel(
           acc *= gfo;
         }
       } else {
+#ifdef GCRNN_ABLATE_P1_MFMA
+#pragma unroll
+        for (int s = 0; s < KS; ++s) { const f32x4 t = __builtin_bit_cast(f32x4, bfr[i][s]); acc += t * (float)(tap + 1); }
+#else
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
           const bf16x8 a = __builtin_bit_cast(bf16x8, wl[(tap * KS + s) * 64 + lane]);
           acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bfr[i][s], acc, 0, 0, 0);
         }
+#endif
       }
       if (tap == K - 1) *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(state) + woff[i]) = acc;
       else u[i][tap] = acc;
