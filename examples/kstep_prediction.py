@@ -1,0 +1,70 @@
+#!/usr/bin/env python3
+"""K-step prediction with gated GCRNNs on MI355X -- counterpart of the reference driver kStepPredGRNNs.py
+(graph -> S = W/lambda_max -> data -> models -> train -> test; its lines 598-1677), reduced to the GCRNN models.
+
+    python examples/kstep_prediction.py [--nodes 80] [--taps 5] [--seq 5] [--epochs 1] [--dtype f64]
+
+Defaults follow the reference driver (N=80 SBM 0.8/0.2, 5 taps, K=seqLen=5, F=20, batch 100, Adam 1e-3).
+"""
+import argparse
+import os
+import sys
+import tempfile
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+
+import gated_gcrnns_amd.Modules.architectures as archit
+from gated_gcrnns_amd.Modules.train_rnn import MultipleModels, TrainableModel
+from gated_gcrnns_amd.Utils import dataTools, miscTools
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--nodes', type=int, default=80)
+    ap.add_argument('--taps', type=int, default=5)
+    ap.add_argument('--seq', type=int, default=5)
+    ap.add_argument('--features', type=int, default=20)
+    ap.add_argument('--epochs', type=int, default=1)
+    ap.add_argument('--batch', type=int, default=100)
+    ap.add_argument('--ntrain', type=int, default=2000)
+    ap.add_argument('--dtype', default='f64', choices=['f32', 'f64'])
+    ap.add_argument('--seed', type=int, default=0)
+    args = ap.parse_args()
+    dt = torch.float64 if args.dtype == 'f64' else torch.float32
+    torch.set_default_dtype(dt)                                   # the reference driver runs in float64 (line 44)
+    dev = torch.device('cuda:0')
+    rng = np.random.default_rng(args.seed)
+    torch.manual_seed(args.seed)
+    W = dataTools.sbm_adjacency(args.nodes, 5, 0.8, 0.2, rng)
+    S = dataTools.normalised_gso(W)
+    K = args.seq
+    data = dataTools.KStepPrediction(W, K, args.ntrain, 200, 200, horizon=2 * K, rng=rng, dataType=dt)
+    saveDir = tempfile.mkdtemp(prefix='kstep_')
+    models = {}
+    for name, tg, sg in (('GCRNNMLP', False, None), ('TimeGCRNNMLP', True, None), ('NodeGCRNNMLP', False, 'node'),
+                         ('EdgeGCRNNMLP', False, 'edge')):
+        m = archit.GatedGCRNNforRegression(1, args.features, args.taps, args.taps, torch.tanh, torch.nn.ReLU, [1], S, True,
+                                           time_gating=tg, spatial_gating=sg, mlpType='multipMlp').to(dev)
+        opt = torch.optim.Adam(m.parameters(), lr=1e-3, betas=(0.9, 0.999))
+        models[name] = TrainableModel(m, miscTools.batchTimeL1Loss, opt, name, saveDir)
+    xT, yT = data.getSamples('train')
+    xV, yV = data.getSamples('valid')
+    out = MultipleModels(models, xT, yT, xV, yV, args.epochs, args.batch, data.seqLen, args.features,
+                         data.evaluate, validationInterval=5, rng=rng, doPrint=False)
+    xE, yE = data.getSamples('test')
+    xE = xE.view(xE.shape[0], data.seqLen, -1).to(dev).unsqueeze(2)
+    yE = yE.view(yE.shape[0], data.seqLen, -1).to(dev).unsqueeze(2)
+    for name, tm in models.items():
+        tm.load('Best')
+        with torch.no_grad():
+            h0 = torch.zeros(xE.shape[0], args.features, args.nodes, device=dev)
+            score = float(data.evaluate(tm.archit(xE, h0), yE))
+        t = np.median(out['timeTrain'][name])
+        print('%-14s test RMSE-metric %.4f   loss %.4f -> %.4f   median %.1f ms/batch (%.0f seq/s)' % (
+            name, score, out['lossTrain'][name][0], out['lossTrain'][name][-1], 1e3 * t, args.batch / t))
+
+
+if __name__ == '__main__':
+    main()

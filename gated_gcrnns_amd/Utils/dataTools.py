@@ -1,0 +1,88 @@
+"""Synthetic graph + k-step-prediction data for the GCRNN drivers (counterparts of the reference recipes:
+SBM graph Utils/graphTools.py:581-634, KStepPrediction Utils/dataTools.py:1200-1399). Host-side, numpy;
+only what the GCRNN hot path's callers need."""
+import numpy as np
+import torch
+
+
+def is_connected(W):
+    N = W.shape[0]
+    seen = np.zeros(N, bool)
+    seen[0] = True
+    frontier = np.array([0])
+    while frontier.size:
+        nxt = np.nonzero((np.abs(W[frontier]).sum(0) > 0) & ~seen)[0]
+        seen[nxt] = True
+        frontier = nxt
+    return bool(seen.all())
+
+
+def sbm_adjacency(N, nCommunities, probIntra, probInter, rng):
+    """Undirected stochastic block model, communities of floor/ceil(N/C) consecutive nodes, redrawn until connected."""
+    sizes = [N // nCommunities] * nCommunities
+    c = 0
+    while sum(sizes) < N:
+        sizes[c] += 1
+        c += 1
+    labels = np.repeat(np.arange(nCommunities), sizes)
+    P = np.where(labels[:, None] == labels[None, :], probIntra, probInter)
+    while True:
+        W = np.triu((rng.random((N, N)) < P).astype(np.float64), 1)
+        W = W + W.T
+        if is_connected(W):
+            return W
+
+
+def normalised_gso(W):
+    """S = W / lambda_max (kStepPredGRNNs.py:768); |.| for directed graphs (epicenterEstimation.py:619)."""
+    lam = np.max(np.abs(np.linalg.eigvalsh(W))) if np.allclose(W, W.T) else np.max(np.abs(np.linalg.eigvals(W)))
+    return W / lam
+
+
+class KStepPrediction(object):
+    """x_0 ~ U[0,1)^N, x_{t+1} = x_t A + spatial noise + temporal noise with A = W / lambda_max; a sample is the
+    first `seqLen` steps, its label the same sequence K steps ahead (reference dataTools.py:1275-1302).
+
+    samples[split]['signals' | 'labels']: n x (seqLen * N), as in the reference; getSamples returns torch tensors.
+    """
+
+    def __init__(self, W, K, nTrain, nValid, nTest, horizon, sigmaSpatial=0.1, sigmaTemporal=0.1,
+                 rhoSpatial=0.0, rhoTemporal=0.0, rng=None, dataType=torch.float64):
+        rng = rng if rng is not None else np.random.default_rng()
+        N = W.shape[0]
+        self.N, self.K, self.horizon, self.seqLen = N, K, horizon, horizon - K
+        self.nTrain, self.nValid, self.nTest = nTrain, nValid, nTest
+        A = normalised_gso(W)
+        nTotal = nTrain + nValid + nTest
+        covT = sigmaTemporal ** 2 * np.eye(horizon) + rhoTemporal ** 2 * np.ones((horizon, horizon))
+        tempNoise = rng.multivariate_normal(np.zeros(horizon), covT, (nTotal, N)).transpose(2, 0, 1)
+        x_t = rng.random((nTotal, N))
+        xs = [x_t]
+        for t in range(horizon):
+            if rhoSpatial == 0.0:
+                spatial = sigmaSpatial * rng.standard_normal((nTotal, N))
+            else:
+                covS = sigmaSpatial ** 2 * np.eye(N) + rhoSpatial ** 2 * np.ones((N, N))
+                spatial = rng.multivariate_normal(np.zeros(N), covS, nTotal)
+            x_t = x_t @ A + spatial + tempNoise[t]
+            xs.append(x_t)
+        x = np.concatenate(xs, axis=1)
+        labels = x[:, K * N:horizon * N]
+        signals = x[:, 0:(horizon * N - K * N)]
+        self.samples = {}
+        lo = 0
+        for split, n in (('train', nTrain), ('valid', nValid), ('test', nTest)):
+            self.samples[split] = {'signals': torch.tensor(signals[lo:lo + n], dtype=dataType),
+                                   'labels': torch.tensor(labels[lo:lo + n], dtype=dataType)}
+            lo += n
+
+    def getSamples(self, split, idx=None):
+        s = self.samples[split]
+        if idx is None:
+            return s['signals'], s['labels']
+        return s['signals'][idx], s['labels'][idx]
+
+    @staticmethod
+    def evaluate(yHat, y):
+        from .miscTools import batchTimeMSELoss
+        return batchTimeMSELoss(yHat, y)

@@ -193,3 +193,47 @@ def test_layout_roundtrip_and_shift_linearity(dev):
     # bf16 layout moves raw words
     xb = x.to(torch.bfloat16)
     assert torch.equal(ops.unpack_node_major(ops.pack_node_major(xb)), xb)
+
+
+def test_streaming_path_large_sparse_graph(dev):
+    """The any-size streaming path (the cfg5 regime: graph far beyond what fits on chip) against the oracle on a
+    directed N = 6000, density 2e-3 graph; fp32 tolerance 1e-5."""
+    rng = np.random.default_rng(11)
+    N, B, Tn, G, F, K = 6000, 3, 3, 8, 16, 3
+    S = ((rng.random((1, N, N)) < 2e-3) * rng.uniform(0.1, 1.0, (1, N, N)))
+    S = S / np.abs(S).sum(axis=1).max()                      # cheap spectral bound (SURVEY 8d, cfg5 recipe)
+    X = rng.standard_normal((B, Tn, G, N))
+    torch.manual_seed(4)
+    cell = gml().GGCRNNCell(G, F, K, K, torch.tanh, False, None, 1, True).double()
+    cell.addGSO(torch.tensor(S))
+    params = {k: v.detach().numpy().copy() for k, v in cell.state_dict().items()}
+    Href = orc.ggcrnn_cell(params, S, X, np.zeros((B, F, N)))
+    cell = cell.to(dev).float()
+    H = cell(T(X, torch.float32, dev), torch.zeros(B, F, N, dtype=torch.float32, device=dev))
+    assert maxdiff(H, Href) <= 1e-5
+
+
+def test_kstep_data_and_driver_pieces(dev):
+    """H2: data recipe shapes + one harness step on generated data (fp64)."""
+    from gated_gcrnns_amd.Utils import dataTools, miscTools
+    rng = np.random.default_rng(0)
+    W = dataTools.sbm_adjacency(40, 5, 0.8, 0.2, rng)
+    assert np.allclose(W, W.T) and dataTools.is_connected(W) and np.all(np.diag(W) == 0)
+    S = dataTools.normalised_gso(W)
+    assert abs(np.max(np.abs(np.linalg.eigvalsh(S))) - 1.0) < 1e-12
+    data = dataTools.KStepPrediction(W, 3, 30, 10, 10, horizon=6, rng=rng)
+    x, y = data.getSamples('train')
+    assert tuple(x.shape) == (30, 3 * 40) and tuple(y.shape) == (30, 3 * 40)
+    # the label is the signal K steps ahead: with noise off the recursion x_{t+1} = x_t A must hold exactly
+    d0 = dataTools.KStepPrediction(W, 1, 4, 1, 1, horizon=3, sigmaSpatial=0.0, sigmaTemporal=0.0, rng=rng)
+    xs, ys = d0.getSamples('train')
+    assert np.allclose(xs.numpy()[:, :40] @ S, ys.numpy()[:, :40], atol=1e-12)
+    m = archit().GatedGCRNNforRegression(1, 8, 3, 3, torch.tanh, torch.nn.ReLU, [1], S, True, time_gating=False,
+                                         spatial_gating=None, mlpType='multipMlp').double().to(dev)
+    xb = x.view(30, 3, 1, 40).to(dev)
+    yb = y.view(30, 3, 1, 40).to(dev)
+    from gated_gcrnns_amd.Modules.train_rnn import train_step
+    l0, _ = train_step(m, miscTools.batchTimeL1Loss, torch.optim.Adam(m.parameters(), lr=1e-2), xb, yb, 8)
+    for _ in range(10):
+        l1, yh = train_step(m, miscTools.batchTimeL1Loss, torch.optim.Adam(m.parameters(), lr=1e-2), xb, yb, 8)
+    assert float(l1) < float(l0) and float(data.evaluate(yh, yb)) > 0
