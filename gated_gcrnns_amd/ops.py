@@ -298,3 +298,28 @@ def fused_cell_forward(X, h0, wA, wB, bias, graph, gates=None, return_states=Fal
     H = torch.empty((B, T, F, N), dtype=torch.bfloat16, device=dev)
     check(lib.gcrnn_unpack_seq_major(_lib.BF16, _p(hs), _p(H), B, T, F, N, npad, None, st), 'unpack_seq')
     return H
+
+
+# ------------------------------------------------------------------------------------------ small-graph persistent path
+def small_supported(N, nnz, G, F, Kin, Kst, dtype, E=1):
+    if E != 1 or dtype not in (torch.float32, torch.float64):
+        return False
+    return bool(lib.gcrnn_small_supported(dtype_code(dtype), int(N), int(nnz), int(G), int(F), int(Kin), int(Kst)))
+
+
+def small_cell_forward(X, h0, wA, wB, bias, graph, gi=None, gf=None):
+    """Whole recurrence in one launch, one workgroup per sequence (small graphs). X: B x T x G x N, h0: B x F x N
+    (user layout, fp32 / fp64) -> H: B x T x F x N. gi / gf: [T][B] time gates or None. Inference only."""
+    require_device(X, h0, wA, wB, bias)
+    B, T, G, N = X.shape
+    F, Kin, Kst = wA.shape[0], wA.shape[2], wB.shape[2]
+    csr = graph.fwd[0]
+    H = torch.empty((B, T, F, N), dtype=X.dtype, device=X.device)
+    bvec = bias.detach().contiguous().view(-1) if bias is not None else None
+    if gi is not None:
+        gi, gf = gi.to(X.dtype).contiguous(), gf.to(X.dtype).contiguous()
+    check(lib.gcrnn_small_forward(dtype_code(X.dtype), _p(X.contiguous()), _p(h0.contiguous()), _p(wA.contiguous()),
+                                  _p(wB.contiguous()), _p(bvec), _p(gi), _p(gf), _p(csr.rowptr), _p(csr.col),
+                                  _p(csr.val(X.dtype)), _p(H), B, T, N, G, F, Kin, Kst, csr.nnz, _stream()),
+          'small_forward')
+    return H

@@ -149,6 +149,18 @@ int gcrnn_fused_gate_prepass_bf16(const void* xs, const void* h0, const void* wp
                                   const void* ell_val4, const void* ell_col4, int64_t entries, int64_t B, int64_t T,
                                   int64_t N, int64_t F, int64_t G, int64_t K, void* stream);
 
+/* ==== small-graph regime: the whole T-step recurrence of a sequence inside one workgroup, one launch ============
+ * Replaces GGCRNNCell.forward (graphML.py:2336-2427, un-gated or time-gated with precomputed gates) when
+ * K*(G+F)*N values plus weights and CSR fit in LDS (gcrnn_small_supported) -- the drivers' own configurations
+ * (N = 50..80, G = 1, F = 20). User layout in and out, no transposes:
+ *   X [B][T][G][N], h0 [B][F][N] -> H [B][T][F][N]; wA [F][Kin][G], wB [F][Kst][F], bias [F] or NULL (E = 1);
+ *   gi / gf [T][B] time gates or both NULL; CSR(S^T) rowptr/col/val (val in the data dtype). dtype F32 or F64. */
+int gcrnn_small_supported(int dtype, int64_t N, int64_t nnz, int64_t G, int64_t F, int64_t Kin, int64_t Kst);
+int gcrnn_small_forward(int dtype, const void* X, const void* h0, const void* wA, const void* wB, const void* bias,
+                        const void* gi, const void* gf, const int32_t* rowptr, const int32_t* col, const void* val,
+                        void* H, int64_t B, int64_t T, int64_t N, int64_t G, int64_t F, int64_t Kin, int64_t Kst,
+                        int64_t nnz, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

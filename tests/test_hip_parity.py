@@ -237,3 +237,36 @@ def test_kstep_data_and_driver_pieces(dev):
     for _ in range(10):
         l1, yh = train_step(m, miscTools.batchTimeL1Loss, torch.optim.Adam(m.parameters(), lr=1e-2), xb, yb, 8)
     assert float(l1) < float(l0) and float(data.evaluate(yh, yb)) > 0
+
+
+@pytest.mark.parametrize('name,tg', [('none', False), ('time', True)])
+def test_small_graph_persistent_kernel_g3(dev, name, tg):
+    """Small-graph regime: the one-launch persistent kernel (inference) against the G3 goldens, fp64 and fp32."""
+    g = load_golden('g3_cell_' + name)
+    for dt, tol in ((torch.float64, 1e-11), (torch.float32, 1e-5)):
+        cell = build_cell(g, tg, None, dt, dev)
+        X, h0 = T(g['X'], dt, dev), T(g['h0'], dt, dev)
+        with torch.no_grad():
+            assert cell._use_small(X, h0)
+            H = cell(X, h0)
+        assert maxdiff(H, g['H']) <= tol
+    g = load_golden('g3_cell_%s_nobias' % name)          # no bias, Kin != Kst
+    cell = build_cell(g, tg, None, torch.float64, dev, bias=False, Kst=2)
+    with torch.no_grad():
+        assert maxdiff(cell(T(g['X'], torch.float64, dev), T(g['h0'], torch.float64, dev)), g['H']) <= 1e-11
+
+
+@pytest.mark.parametrize('tag,K', [('T20K4', 4), ('T200K3', 3)])
+def test_small_graph_persistent_kernel_seismic(dev, tag, K):
+    """BASELINE configs[3]: directed 59-node seismograph graph, T = 200 -- one launch for the whole sequence."""
+    for name, tg in (('none', False), ('time', True)):
+        g = load_golden('g5_cls_%s_%s' % (tag, name))
+        m = archit().GatedGCRNNforClassification(1, 20, K, K, torch.tanh, torch.nn.ReLU, [11], g['S'][0], True,
+                                                 time_gating=tg, spatial_gating=None).double()
+        m.load_state_dict({k: torch.tensor(v) for k, v in g['params'].items()})
+        m = m.to(dev)
+        x, h0 = T(g['x'], torch.float64, dev), T(g['h0'], torch.float64, dev)
+        with torch.no_grad():
+            assert m.stateGCRNN._use_small(x, h0)
+            assert maxdiff(m(x, h0), g['y']) <= 1e-10
+            assert maxdiff(m.stateGCRNN(x, h0)[:, -1], g['h_last']) <= 1e-11
