@@ -14,7 +14,7 @@ template <> __device__ __forceinline__ float tanh_t<float>(float v) { return tan
 template <> __device__ __forceinline__ double tanh_t<double>(double v) { return tanh(v); }
 
 template <typename T>
-__global__ __launch_bounds__(256) void small_cell_kernel(
+__global__ __launch_bounds__(1024) void small_cell_kernel(
     const T* __restrict__ X,       // [B][Tn][G][N]
     const T* __restrict__ h0,      // [B][F][N]
     const T* __restrict__ wA,      // [F][Kin][G]
@@ -44,19 +44,34 @@ __global__ __launch_bounds__(256) void small_cell_kernel(
   for (int i = tid; i < F * N; i += nt) z[(size_t)G * N + i] = h0[(size_t)b * F * N + i];     // z_0[G + f][n] = h0
   __syncthreads();
 
+  // i -> (i / N, i % N) for i = tid, tid + 1024, ...: stepped without divisions (1024 = dq * N + dr)
+  const int dq = 1024 / N, dr = 1024 - dq * N;
+  const int q0 = tid / N, r0 = tid - q0 * N;
+  const int CN = C * N, FN = F * N;
+
+  // x_t is fetched one step ahead (first 1024 values per thread-pass in a register) so that its global-memory
+  // latency overlaps the previous step instead of sitting in front of a barrier
+  const T* xb = X + (size_t)b * Tn * G * N;
+  const int GN = G * N;
+  T xpre = (tid < GN) ? xb[tid] : T(0);
   for (int t = 0; t < Tn; ++t) {
-    const T* xt = X + ((size_t)b * Tn + t) * G * N;
-    for (int i = tid; i < G * N; i += nt) z[i] = xt[i];                                       // z_0[g][n] = x_t
+    const T* xt = xb + (size_t)t * GN;
+    if (tid < GN) z[tid] = xpre;                                                              // z_0[g][n] = x_t
+    for (int i = tid + 1024; i < GN; i += 1024) z[i] = xt[i];
+    if (t + 1 < Tn && tid < GN) xpre = xt[GN + tid];
     __syncthreads();
     for (int k = 1; k < K; ++k) {                                                            // z_k = z_{k-1} S
       const T* zp = z + (size_t)(k - 1) * C * N;
       T* zn = z + (size_t)k * C * N;
-      for (int i = tid; i < C * N; i += nt) {
-        const int c = i / N, n = i - c * N;
+      int cN = q0 * N, n = r0;                       // cN = c * N
+      for (int i = tid; i < CN; i += 1024) {
         // channels of a filter with fewer taps than K need no deeper hops, but computing them is harmless
         T acc = T(0);
-        for (int j = rpl[n]; j < rpl[n + 1]; ++j) acc += vall[j] * zp[c * N + coll[j]];
+        const T* zr = zp + cN;
+        for (int j = rpl[n]; j < rpl[n + 1]; ++j) acc += vall[j] * zr[coll[j]];
         zn[i] = acc;
+        n += dr; cN += dq * N;
+        if (n >= N) { n -= N; cN += N; }
       }
       __syncthreads();
     }
@@ -65,29 +80,41 @@ __global__ __launch_bounds__(256) void small_cell_kernel(
     T* Hout = H + ((size_t)b * Tn + t) * F * N;
     // taps: one output (f, n) per thread pass; all reads of z happen before the barrier, the new state is
     // written to z_0 after it
-    T hnew[8];                                      // F * N <= 8 * 256 is checked on the host
+    T hnew[4];                                      // F * N <= 4 * 1024 is checked on the host
+    int f = q0, n = r0;
 #pragma unroll
-    for (int p = 0; p < 8; ++p) {
-      const int i = tid + p * 256;
+    for (int p = 0; p < 4; ++p) {
+      const int i = tid + p * 1024;
       T out = T(0);
-      if (i < F * N) {
-        const int f = i / N, n = i - f * N;
+      if (i < FN) {
         T ya = T(0), yb = T(0);
-        for (int k = 0; k < Kin; ++k)
-          for (int g = 0; g < G; ++g) ya += wAl[(f * Kin + k) * G + g] * z[((size_t)k * C + g) * N + n];
-        for (int k = 0; k < Kst; ++k)
-          for (int g = 0; g < F; ++g) yb += wBl[(f * Kst + k) * F + g] * z[((size_t)k * C + G + g) * N + n];
+        const T* wa = wAl + f * Kin * G;
+        const T* wb = wBl + f * Kst * F;
+        for (int k = 0; k < Kin; ++k) {
+          const T* zc = z + k * CN + n;
+          for (int g = 0; g < G; ++g) ya += wa[k * G + g] * zc[g * N];
+        }
+        for (int k = 0; k < Kst; ++k) {
+          const T* zc = z + k * CN + G * N + n;
+          const T* wk = wb + k * F;
+          int g = 0;
+          for (; g + 4 <= F; g += 4)
+            yb += wk[g] * zc[g * N] + wk[g + 1] * zc[(g + 1) * N] + wk[g + 2] * zc[(g + 2) * N] + wk[g + 3] * zc[(g + 3) * N];
+          for (; g < F; ++g) yb += wk[g] * zc[g * N];
+        }
         const T bb = bias ? bias[f] : T(0);
         out = tanh_t<T>(gin * (ya + bb) + gfo * (yb + bb));
         Hout[i] = out;
       }
       hnew[p] = out;
+      n += dr; f += dq;
+      if (n >= N) { n -= N; f += 1; }
     }
     __syncthreads();
 #pragma unroll
-    for (int p = 0; p < 8; ++p) {
-      const int i = tid + p * 256;
-      if (i < F * N) z[(size_t)G * N + i] = hnew[p];
+    for (int p = 0; p < 4; ++p) {
+      const int i = tid + p * 1024;
+      if (i < FN) z[G * N + i] = hnew[p];
     }
     // the x_t copy of the next step touches z_0[0..G), disjoint from what was just written; its barrier orders both
   }
@@ -102,7 +129,7 @@ static size_t small_lds_bytes(int dtype, int64_t N, int64_t nnz, int64_t G, int6
 extern "C" int gcrnn_small_supported(int dtype, int64_t N, int64_t nnz, int64_t G, int64_t F, int64_t Kin, int64_t Kst) {
   if (dtype != GCRNN_F32 && dtype != GCRNN_F64) return 0;
   if (N <= 0 || G <= 0 || F <= 0 || Kin <= 0 || Kst <= 0 || nnz < 0) return 0;
-  if (F * N > 8 * 256) return 0;
+  if (F * N > 4 * 1024 || N > 1024) return 0;
   return small_lds_bytes(dtype, N, nnz, G, F, Kin, Kst) <= 150 * 1024 ? 1 : 0;
 }
 
@@ -115,7 +142,7 @@ static int small_launch(const void* X, const void* h0, const void* wA, const voi
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
     return GCRNN_ERR_LAUNCH;
   GCRNN_PRE_LAUNCH();
-  kern<<<(unsigned)B, 256, lds, st>>>((const T*)X, (const T*)h0, (const T*)wA, (const T*)wB, (const T*)bias, (const T*)gi,
+  kern<<<(unsigned)B, 1024, lds, st>>>((const T*)X, (const T*)h0, (const T*)wA, (const T*)wB, (const T*)bias, (const T*)gi,
                                       (const T*)gf, rowptr, col, (const T*)val, (T*)H, (int)Tn, (int)N, (int)G, (int)F,
                                       (int)Kin, (int)Kst, (int)nnz, (int)B);
   GCRNN_CHECK_LAUNCH();
