@@ -93,6 +93,7 @@ def main():
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32', 'f64'])
     ap.add_argument('--mode', default='fwd', choices=['fwd', 'train'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--hipgraph', type=int, default=0, help='replay the fused forward as one captured hipGraph (bf16 fwd)')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', '0'))
@@ -133,8 +134,15 @@ def main():
         opt = torch.optim.Adam(cell.parameters(), lr=1e-3)
         sync_grads = FlatGradAllReduce(cell.parameters()) if world > 1 else None
 
+    runner = None
+    if args.mode == 'fwd' and args.dtype == 'bf16' and args.hipgraph:
+        from gated_gcrnns_amd.ops import FusedForwardGraph
+        runner = FusedForwardGraph(cell, B, T)
+
     def step():
         if args.mode == 'fwd':
+            if runner is not None:
+                return runner(X, h0)          # copies X, h0 into the graph's static inputs, then ONE graph launch
             with torch.no_grad():
                 return cell(X, h0)
         cell.zero_grad()
@@ -190,7 +198,7 @@ def main():
             'data': 'synthetic',
             'config': {'workload': 'BASELINE configs[1]: synthetic k-step prediction, sparse SBM N=1000 nnz=%d, K=5 taps, '
                                    'T=32, G=F=64, un-gated GGCRNNCell forward, h0=0' % nnz,
-                       'batch_per_gpu': B, 'global_batch': world * B, 'mode': args.mode, 'parallelism': 'dp%d' % world},
+                       'batch_per_gpu': B, 'global_batch': world * B, 'mode': args.mode, 'hipgraph': bool(runner is not None), 'parallelism': 'dp%d' % world},
         }
         if kern is not None:
             # algorithmic bytes of ONE launch (one time step for the whole batch): read x_t, read h_{t-1}, write h_t

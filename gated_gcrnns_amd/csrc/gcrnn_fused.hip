@@ -259,7 +259,7 @@ __global__ __launch_bounds__(512, 2) void fused_step_kernel(
     const float4* __restrict__ ell_val4,    // [entries/4][16] x 4 weights                  (LDS image, RESIDENT)
     const uint2* __restrict__ ell_col4,     // [entries/4][16] x 4 u16 (row offset | swizzle)
     const float* __restrict__ gate_w,       // GATEOUT: [N][F] node-major weights of the gate's Linear(N*F -> 1)
-    float* __restrict__ gate_out,           // GATEOUT: [B] += sum_{n,f} tanh(pre)[n][f] * gate_w[n][f]   (caller zeroes)
+    float* __restrict__ gate_out,           // GATEOUT: [B][F/16][8] per-(chunk, wave) partials of sum_{n,f} tanh(pre) * gate_w
     int entries, int B, int hmod, int N) {
   constexpr int KS = HS + XS;
   constexpr int F = 32 * HS, G = 32 * XS;
@@ -548,7 +548,7 @@ __global__ __launch_bounds__(512, 2) void fused_step_kernel(
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) part += __shfl_down(part, off, 64);
-    if (lane == 0) atomicAdd(gate_out + b, part);
+    if (lane == 0) gate_out[(int64_t)b * (NCH * WAVES) + chunk * WAVES + wave] = part;   // fixed-order sum by the caller
   } else {
 #pragma unroll
   for (int i = 0; i < TILES; ++i) {

@@ -282,9 +282,10 @@ def fused_cell_forward(X, h0, wA, wB, bias, graph, gates=None, return_states=Fal
             wp = _fused_pack_weights(wA_g, wB_g, st)
             bg = bias_g.detach().float().contiguous().view(-1) if bias_g is not None else None
             gw = lin_w.detach().float().view(F, N).t().contiguous()          # row-major vec over (f, n) -> [N][F]
-            acc = torch.zeros(T * B, dtype=torch.float32, device=dev)
-            check(lib.gcrnn_fused_gate_prepass_bf16(_p(xs), _p(h0s), _p(wp), _p(bg), _p(gw), _p(acc), *gargs,
+            parts = torch.empty((T * B, (F // 16) * 8), dtype=torch.float32, device=dev)
+            check(lib.gcrnn_fused_gate_prepass_bf16(_p(xs), _p(h0s), _p(wp), _p(bg), _p(gw), _p(parts), *gargs,
                                                     B, T, N, F, G, K, st), 'gate_prepass')
+            acc = parts.sum(dim=1)                                            # fixed order: deterministic gates
             if lin_b is not None:
                 acc = acc + lin_b.detach().float()
             g[name] = torch.sigmoid(acc).contiguous()                        # [T][B] fp32
@@ -323,3 +324,36 @@ def small_cell_forward(X, h0, wA, wB, bias, graph, gi=None, gf=None):
                                   _p(csr.val(X.dtype)), _p(H), B, T, N, G, F, Kin, Kst, csr.nnz, _stream()),
           'small_forward')
     return H
+
+
+# ------------------------------------------------------------------------------------------ hipGraph replay
+class FusedForwardGraph(object):
+    """The fused forward of one fixed problem (shapes, weights, graph) captured as a hipGraph: pack -> gate pre-passes ->
+    T step launches -> unpack become one graph launch per call. Inputs are copied into static buffers; the output
+    tensor is reused between calls (clone it if it must survive the next replay).
+
+        runner = FusedForwardGraph(cell, B, T);  H = runner(X, h0)
+    """
+
+    def __init__(self, cell, B, T, device=None):
+        dev = device if device is not None else cell.weight_A.device
+        self.cell = cell
+        self.X = torch.zeros((B, T, cell.G, cell.N), dtype=torch.bfloat16, device=dev)
+        self.h0 = torch.zeros((B, cell.F, cell.N), dtype=torch.bfloat16, device=dev)
+        cell.graph.fused_plan()                                   # host-side preparation happens outside the capture
+        with torch.no_grad():
+            s = torch.cuda.Stream(device=dev)
+            s.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(s):
+                for _ in range(2):                                # warm-up on a side stream (allocator, func attributes)
+                    cell._forward_fused(self.X, self.h0)
+            torch.cuda.current_stream(dev).wait_stream(s)
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):
+                self.H = cell._forward_fused(self.X, self.h0)
+
+    def __call__(self, X, h0):
+        self.X.copy_(X)
+        self.h0.copy_(h0)
+        self.graph.replay()
+        return self.H

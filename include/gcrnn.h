@@ -139,10 +139,12 @@ int gcrnn_fused_forward_bf16(const void* xs, const void* h0, void* hs, const voi
                              void* stream);
 
 /* Time-gate pre-pass (graphML.py:2357-2374): for every (t, b)
- *   gate_out[t][b] += sum_{n,f} tanh( A_g(S) x_t + B_g(S) h0 + 2 b_g )[n][f] * gate_w[n][f]
+ *   sum over gate_out[t][b][0 .. F/16*8) = sum_{n,f} tanh( A_g(S) x_t + B_g(S) h0 + 2 b_g )[n][f] * gate_w[n][f]
+ *   (gate_out holds the F/16 * 8 per-workgroup-wave partials as plain stores: summing them in a fixed order keeps the
+ *    gate deterministic, which float atomics would not)
  * with the gate sub-cell's packed weights (gcrnn_fused_pack_weights of GFL_in / GFL_forget) and gate_w = the gate's
  * Linear(N*F -> 1) weight re-laid node-major [N][F] (fp32). All T*B items run in ONE launch because the reference's gates
- * read h0, never h_{t-1} (graphML.py:2362, 2370). The caller zeroes gate_out and applies sigmoid(gate_out + c). */
+ * read h0, never h_{t-1} (graphML.py:2362, 2370). The caller applies sigmoid(sum + c). */
 int gcrnn_fused_gate_prepass_bf16(const void* xs, const void* h0, const void* wpack, const float* bias,
                                   const float* gate_w, float* gate_out, const int32_t* tile_nodes,
                                   const int32_t* tile_off, const int32_t* ell_col, const float* ell_val,
