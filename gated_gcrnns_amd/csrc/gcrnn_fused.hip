@@ -210,7 +210,7 @@ __global__ void pack_weights_kernel(const W* __restrict__ wA, const W* __restric
 extern "C" int gcrnn_fused_pack_weights(int wdtype, const void* wA, const void* wB, void* wpack, int64_t F, int64_t G,
                                         int64_t Kin, int64_t Kst, void* stream) {
   if (!wA || !wB || !wpack) return GCRNN_ERR_NULL_POINTER;
-  if (F <= 0 || G <= 0 || F % FC || (F + G) % 32 || F % 8 || Kin <= 0 || Kst <= 0) return GCRNN_ERR_BAD_SHAPE;
+  if (F <= 0 || G < 0 || F % FC || (F + G) % 32 || F % 8 || Kin <= 0 || Kst <= 0) return GCRNN_ERR_BAD_SHAPE;
   const int K = (int)(Kin > Kst ? Kin : Kst);
   const int64_t total = (F / FC) * K * ((F + G) / 32) * 64 * 8;
   GCRNN_PRE_LAUNCH();
@@ -243,7 +243,8 @@ extern "C" int gcrnn_fused_pack_weights(int wdtype, const void* wA, const void* 
 // LDS map (dynamic): state [NP][16] fp32 (64 KiB) | weight fragments K*KS KiB | RESIDENT: lval4 (f32x4), lcol4 (u16x4).
 // Tiles hold 16 nodes of similar degree: tile_nodes[p] lists the node of every slot p (degree-sorted order,
 // padded with node ids >= N that have no edges); memory rows are in natural node order.
-template <int K, int HS, int XS, bool GATED, bool RESIDENT, bool GATEOUT = false>
+// EPI: 0 = state epilogue (bias, tanh, bf16 store), 1 = time-gate pre-pass (dot-reduce), 2 = BPTT data-gradient step
+template <int K, int HS, int XS, bool GATED, bool RESIDENT, int EPI = 0>
 __global__ __launch_bounds__(512, 2) void fused_step_kernel(
     const uint16_t* __restrict__ xt,        // [B][NP][G]   bf16
     const uint16_t* __restrict__ hprev,     // [B][NP][F]   bf16
@@ -260,10 +261,13 @@ __global__ __launch_bounds__(512, 2) void fused_step_kernel(
     const uint2* __restrict__ ell_col4,     // [entries/4][16] x 4 u16 (row offset | swizzle)
     const float* __restrict__ gate_w,       // GATEOUT: [N][F] node-major weights of the gate's Linear(N*F -> 1)
     float* __restrict__ gate_out,           // GATEOUT: [B][F/16][8] per-(chunk, wave) partials of sum_{n,f} tanh(pre) * gate_w
+    const uint16_t* __restrict__ aux0,      // EPI 2: upstream gradient dH_{t-1} [B][NP][F] bf16 (or null)
+    const uint16_t* __restrict__ aux1,      // EPI 2: state h_{t-1} [B][NP][F] bf16
     int entries, int B, int hmod, int N) {
   constexpr int KS = HS + XS;
   constexpr int F = 32 * HS, G = 32 * XS;
   constexpr int NCH = F / FC;
+  constexpr bool GATEOUT = (EPI == 1);
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* state = reinterpret_cast<float*>(smem);
   uint4* wl = reinterpret_cast<uint4*>(smem + NP * FC * 4);
@@ -327,6 +331,8 @@ __global__ __launch_bounds__(512, 2) void fused_step_kernel(
   const __amdgpu_buffer_rsrc_t rsrc_h = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(hprev), 0, hmod * (NP * F * 2), 0x00020000);
   const __amdgpu_buffer_rsrc_t rsrc_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(xt), 0, B * (NP * G * 2), 0x00020000);
   const __amdgpu_buffer_rsrc_t rsrc_o = __builtin_amdgcn_make_buffer_rsrc(hout, 0, GATEOUT ? 0 : B * (NP * F * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_a0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(aux0), 0, (EPI == 2 && aux0) ? B * (NP * F * 2) : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_a1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(aux1), 0, (EPI == 2 && aux0) ? B * (NP * F * 2) : 0, 0x00020000);
 
   for (int b = b0; b < B; b += seq_slots) {
   const int soff_h = (b % hmod) * (NP * F * 2);     // hmod < B: every item of the gate pre-pass reads h0[b]
@@ -409,8 +415,9 @@ __global__ __launch_bounds__(512, 2) void fused_step_kernel(
   // 2 * NP rows between them. Phase 1 of the next sequence then streams from L2 instead of stalling on HBM.
   uint32_t prefetched = 0;
   if (b + seq_slots < B) {
-    const int line = chunk * (2 * NP / NCH) + tid;                       // 2*NP/NCH == 512 for F = 64
-    if (tid < 2 * NP / NCH) {
+    constexpr int LINES = (XS > 0 ? 2 : 1) * NP;                         // rows of [h | x] (x absent in the BPTT step)
+    const int line = chunk * (LINES / NCH) + tid;                        // LINES / NCH == 512 for F = G = 64
+    if (tid < LINES / NCH) {
       prefetched = (line < NP)
           ? __builtin_amdgcn_raw_buffer_load_b32(rsrc_h, line * (F * 2), ((b + seq_slots) % hmod) * (NP * F * 2), 0)
           : __builtin_amdgcn_raw_buffer_load_b32(rsrc_x, (line - NP) * (G * 2), (b + seq_slots) * (NP * G * 2), 0);
@@ -549,6 +556,38 @@ __global__ __launch_bounds__(512, 2) void fused_step_kernel(
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) part += __shfl_down(part, off, 64);
     if (lane == 0) gate_out[(int64_t)b * (NCH * WAVES) + chunk * WAVES + wave] = part;   // fixed-order sum by the caller
+  } else if (EPI == 2) {
+    // BPTT data-gradient step: the hops just applied sum_k (S)^k (dpre_t W_k) = d h_{t-1} (recurrent part); add the
+    // upstream gradient of h_{t-1} and go through tanh':  dpre_{t-1} = (acc + dH_{t-1}) * (1 - h_{t-1}^2).
+    // With aux0 == null the raw state gradient is stored (d h0).
+#pragma unroll
+    for (int i = 0; i < TILES; ++i) {
+      int wv = woff[i];
+      asm volatile("" : "+v"(wv));
+      const int node = wv >> 6;
+      const int eoff = node * (F * 2) + (chunk * FC + q * 4) * 2;
+      f32x4 o = u[i][0];
+      if (aux0) {
+        const u32x2 g2 = __builtin_amdgcn_raw_buffer_load_b64(rsrc_a0, eoff, b * (NP * F * 2), 0);
+        const u32x2 h2 = __builtin_amdgcn_raw_buffer_load_b64(rsrc_a1, eoff, b * (NP * F * 2), 0);
+        const float g0 = bf2f((uint16_t)(g2[0] & 0xffffu)), g1 = bf2f((uint16_t)(g2[0] >> 16));
+        const float g2f = bf2f((uint16_t)(g2[1] & 0xffffu)), g3 = bf2f((uint16_t)(g2[1] >> 16));
+        const float h0f = bf2f((uint16_t)(h2[0] & 0xffffu)), h1 = bf2f((uint16_t)(h2[0] >> 16));
+        const float h2f = bf2f((uint16_t)(h2[1] & 0xffffu)), h3 = bf2f((uint16_t)(h2[1] >> 16));
+        o[0] = (o[0] + g0) * (1.f - h0f * h0f);
+        o[1] = (o[1] + g1) * (1.f - h1 * h1);
+        o[2] = (o[2] + g2f) * (1.f - h2f * h2f);
+        o[3] = (o[3] + g3) * (1.f - h3 * h3);
+      }
+      uint2 pk;
+      if (node < N) {
+        pk.x = (uint32_t)f2bf(o[0]) | ((uint32_t)f2bf(o[1]) << 16);
+        pk.y = (uint32_t)f2bf(o[2]) | ((uint32_t)f2bf(o[3]) << 16);
+      } else {
+        pk.x = 0u; pk.y = 0u;
+      }
+      __builtin_amdgcn_raw_buffer_store_b64(u32x2{pk.x, pk.y}, rsrc_o, eoff, b * (NP * F * 2), 0);
+    }
   } else {
 #pragma unroll
   for (int i = 0; i < TILES; ++i) {
@@ -575,7 +614,7 @@ __global__ __launch_bounds__(512, 2) void fused_step_kernel(
 
 typedef void (*fused_kern_t)(const uint16_t*, const uint16_t*, uint16_t*, const uint4*, const float*, const float*,
                              const float*, const int32_t*, const int32_t*, const int32_t*, const float*, const float4*,
-                             const uint2*, const float*, float*, int, int, int, int);
+                             const uint2*, const float*, float*, const uint16_t*, const uint16_t*, int, int, int, int);
 
 struct FusedGraphArgs {
   const int32_t* tile_nodes; const int32_t* tile_off; const int32_t* ell_col; const float* ell_val;
@@ -583,16 +622,19 @@ struct FusedGraphArgs {
 };
 
 template <int K, int HS, int XS>
-static int fused_launch_t(int mode /*0 plain, 1 gated, 2 gate pre-pass*/, const void* xs, const void* h0, void* hs,
-                          const void* wpack, const float* bias, const float* gi, const float* gf, const float* gate_w,
-                          float* gate_out, const FusedGraphArgs& ga, int64_t B, int64_t T, int64_t N, hipStream_t st) {
+static int fused_launch_t(int mode /*0 plain, 1 gated, 2 gate pre-pass, 3 BPTT data gradient*/, const void* xs, const void* h0,
+                          void* hs, const void* wpack, const float* bias, const float* gi, const float* gf,
+                          const float* gate_w, float* gate_out, const FusedGraphArgs& ga, int64_t B, int64_t T, int64_t N,
+                          hipStream_t st, const void* bw_dHs = nullptr, const void* bw_hs = nullptr, const void* bw_h0 = nullptr,
+                          void* bw_dh0 = nullptr) {
   constexpr int F = 32 * HS, G = 32 * XS, KS = HS + XS;
   const size_t base = (size_t)NP * FC * 4 + (size_t)K * KS * 1024;
   const size_t resident_bytes = base + (size_t)ga.entries * 16 * 6;
   const bool resident = resident_bytes <= 160 * 1024 && ga.ell_val4 && ga.ell_col4;
   const size_t lds = resident ? resident_bytes : base;
   fused_kern_t kern;
-  if (mode == 2)      kern = resident ? (fused_kern_t)fused_step_kernel<K, HS, XS, false, true, true> : (fused_kern_t)fused_step_kernel<K, HS, XS, false, false, true>;
+  if (mode == 3)      kern = resident ? (fused_kern_t)fused_step_kernel<K, HS, XS, false, true, 2> : (fused_kern_t)fused_step_kernel<K, HS, XS, false, false, 2>;
+  else if (mode == 2) kern = resident ? (fused_kern_t)fused_step_kernel<K, HS, XS, false, true, 1> : (fused_kern_t)fused_step_kernel<K, HS, XS, false, false, 1>;
   else if (mode == 1) kern = resident ? (fused_kern_t)fused_step_kernel<K, HS, XS, true, true> : (fused_kern_t)fused_step_kernel<K, HS, XS, true, false>;
   else                kern = resident ? (fused_kern_t)fused_step_kernel<K, HS, XS, false, true> : (fused_kern_t)fused_step_kernel<K, HS, XS, false, false>;
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
@@ -611,14 +653,29 @@ static int fused_launch_t(int mode /*0 plain, 1 gated, 2 gate pre-pass*/, const 
   if (mode == 2) {
     kern<<<grid, 512, lds, st>>>(x, (const uint16_t*)h0, nullptr, (const uint4*)wpack, bias, nullptr, nullptr, ga.tile_nodes,
                                  ga.tile_off, ga.ell_col, ga.ell_val, (const float4*)ga.ell_val4, (const uint2*)ga.ell_col4,
-                                 gate_w, gate_out, (int)ga.entries, (int)items, (int)B, (int)N);
+                                 gate_w, gate_out, nullptr, nullptr, (int)ga.entries, (int)items, (int)B, (int)N);
+  } else if (mode == 3) {
+    // BPTT: hs (= dpre, [T][B][NP][F]) already holds dpre_{T-1}; walk t = T-1 .. 1, then optionally d h0
+    const uint16_t* dH = (const uint16_t*)bw_dHs;
+    const uint16_t* hst = (const uint16_t*)bw_hs;
+    for (int64_t t = T - 1; t >= 1; --t) {
+      const uint16_t* hprev_state = (t - 1 >= 1 || true) ? hst + (t - 1) * hstep : nullptr;
+      kern<<<grid, 512, lds, st>>>(nullptr, h + t * hstep, h + (t - 1) * hstep, (const uint4*)wpack, nullptr, nullptr, nullptr,
+                                   ga.tile_nodes, ga.tile_off, ga.ell_col, ga.ell_val, (const float4*)ga.ell_val4,
+                                   (const uint2*)ga.ell_col4, nullptr, nullptr, dH + (t - 1) * hstep, hprev_state,
+                                   (int)ga.entries, (int)B, (int)B, (int)N);
+    }
+    if (bw_dh0)
+      kern<<<grid, 512, lds, st>>>(nullptr, h, (uint16_t*)bw_dh0, (const uint4*)wpack, nullptr, nullptr, nullptr, ga.tile_nodes,
+                                   ga.tile_off, ga.ell_col, ga.ell_val, (const float4*)ga.ell_val4, (const uint2*)ga.ell_col4,
+                                   nullptr, nullptr, nullptr, nullptr, (int)ga.entries, (int)B, (int)B, (int)N);
   } else {
     for (int64_t t = 0; t < T; ++t) {
       const uint16_t* hp = (t == 0) ? (const uint16_t*)h0 : h + (t - 1) * hstep;
       kern<<<grid, 512, lds, st>>>(x + t * xstep, hp, h + t * hstep, (const uint4*)wpack, bias, mode == 1 ? gi + t * B : nullptr,
                                    mode == 1 ? gf + t * B : nullptr, ga.tile_nodes, ga.tile_off, ga.ell_col, ga.ell_val,
-                                   (const float4*)ga.ell_val4, (const uint2*)ga.ell_col4, nullptr, nullptr, (int)ga.entries,
-                                   (int)B, (int)B, (int)N);
+                                   (const float4*)ga.ell_val4, (const uint2*)ga.ell_col4, nullptr, nullptr, nullptr, nullptr,
+                                   (int)ga.entries, (int)B, (int)B, (int)N);
     }
   }
   GCRNN_CHECK_LAUNCH();
@@ -627,10 +684,12 @@ static int fused_launch_t(int mode /*0 plain, 1 gated, 2 gate pre-pass*/, const 
 
 static int fused_dispatch(int mode, const void* xs, const void* h0, void* hs, const void* wpack, const float* bias,
                           const float* gi, const float* gf, const float* gate_w, float* gate_out, const FusedGraphArgs& ga,
-                          int64_t B, int64_t T, int64_t N, int64_t F, int64_t G, int64_t K, hipStream_t st) {
+                          int64_t B, int64_t T, int64_t N, int64_t F, int64_t G, int64_t K, hipStream_t st,
+                          const void* bw_dHs = nullptr, const void* bw_hs = nullptr, void* bw_dh0 = nullptr) {
 #define GCRNN_FUSED_CASE(KK, HH, XX) \
   if (K == KK && F == 32 * HH && G == 32 * XX) \
-    return fused_launch_t<KK, HH, XX>(mode, xs, h0, hs, wpack, bias, gi, gf, gate_w, gate_out, ga, B, T, N, st);
+    return fused_launch_t<KK, HH, XX>(mode, xs, h0, hs, wpack, bias, gi, gf, gate_w, gate_out, ga, B, T, N, st, bw_dHs, \
+                                      bw_hs, nullptr, bw_dh0);
   GCRNN_FUSED_CASE(5, 2, 2)
   GCRNN_FUSED_CASE(4, 2, 2)
   GCRNN_FUSED_CASE(3, 2, 2)
@@ -638,6 +697,13 @@ static int fused_dispatch(int mode, const void* xs, const void* h0, void* hs, co
   GCRNN_FUSED_CASE(5, 1, 1)
   GCRNN_FUSED_CASE(3, 1, 1)
   GCRNN_FUSED_CASE(2, 1, 1)
+  GCRNN_FUSED_CASE(5, 2, 0)      // BPTT data-gradient steps: the operand is dpre alone (no x part)
+  GCRNN_FUSED_CASE(4, 2, 0)
+  GCRNN_FUSED_CASE(3, 2, 0)
+  GCRNN_FUSED_CASE(2, 2, 0)
+  GCRNN_FUSED_CASE(5, 1, 0)
+  GCRNN_FUSED_CASE(3, 1, 0)
+  GCRNN_FUSED_CASE(2, 1, 0)
 #undef GCRNN_FUSED_CASE
   return GCRNN_ERR_UNSUPPORTED;
 }
@@ -663,6 +729,33 @@ extern "C" int gcrnn_fused_gate_prepass_bf16(const void* xs, const void* h0, con
   if (B <= 0 || T <= 0 || N <= 0 || N > NP || B * T > (1 << 24) || entries < 0 || entries % 4) return GCRNN_ERR_BAD_SHAPE;
   const FusedGraphArgs ga{tile_nodes, tile_off, ell_col, ell_val, ell_val4, ell_col4, entries};
   return fused_dispatch(2, xs, h0, nullptr, wpack, bias, nullptr, nullptr, gate_w, gate_out, ga, B, T, N, F, G, K, as_stream(stream));
+}
+
+// dpre[i] = dH[i] * (1 - h[i]^2) on bf16 arrays (the seed of the BPTT chain, t = T-1)
+__global__ void bwd_seed_kernel(const uint16_t* __restrict__ dH, const uint16_t* __restrict__ h, uint16_t* __restrict__ out, int64_t n) {
+  const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 2;
+  if (i >= n) return;
+  const uint32_t g = *reinterpret_cast<const uint32_t*>(dH + i), hv = *reinterpret_cast<const uint32_t*>(h + i);
+  const float g0 = bf2f((uint16_t)(g & 0xffffu)), g1 = bf2f((uint16_t)(g >> 16));
+  const float h0 = bf2f((uint16_t)(hv & 0xffffu)), h1 = bf2f((uint16_t)(hv >> 16));
+  *reinterpret_cast<uint32_t*>(out + i) = (uint32_t)f2bf(g0 * (1.f - h0 * h0)) | ((uint32_t)f2bf(g1 * (1.f - h1 * h1)) << 16);
+}
+
+extern "C" int gcrnn_fused_backward_data_bf16(const void* dHs, const void* hs, void* dpre, void* dh0, const void* wpackT,
+                                              const int32_t* tile_nodes, const int32_t* tile_off, const int32_t* ell_col,
+                                              const float* ell_val, const void* ell_val4, const void* ell_col4,
+                                              int64_t entries, int64_t B, int64_t T, int64_t N, int64_t F, int64_t K,
+                                              void* stream) {
+  if (!dHs || !hs || !dpre || !wpackT || !tile_nodes || !tile_off || !ell_col || !ell_val) return GCRNN_ERR_NULL_POINTER;
+  if (B <= 0 || T <= 0 || N <= 0 || N > NP || B > (1 << 24) || entries < 0 || entries % 4) return GCRNN_ERR_BAD_SHAPE;
+  const int64_t step = B * NP * F;
+  GCRNN_PRE_LAUNCH();
+  bwd_seed_kernel<<<(unsigned)cdiv(step / 2, 256), 256, 0, as_stream(stream)>>>(
+      (const uint16_t*)dHs + (T - 1) * step, (const uint16_t*)hs + (T - 1) * step, (uint16_t*)dpre + (T - 1) * step, step);
+  GCRNN_CHECK_LAUNCH();
+  const FusedGraphArgs ga{tile_nodes, tile_off, ell_col, ell_val, ell_val4, ell_col4, entries};
+  return fused_dispatch(3, nullptr, nullptr, dpre, wpackT, nullptr, nullptr, nullptr, nullptr, nullptr, ga, B, T, N, F, 0, K,
+                        as_stream(stream), dHs, hs, dh0);
 }
 
 extern "C" int gcrnn_fused_supported(int64_t N, int64_t F, int64_t G, int64_t K) {

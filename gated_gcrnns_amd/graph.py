@@ -106,17 +106,19 @@ class GraphOperator(object):
         self.mask_vals = [torch.from_numpy(np.ascontiguousarray(Splus[e][rows, col])).to(self.device) for e in range(self.E)]
         self.nnz = sum(c.nnz for c in self.fwd)
 
-    def fused_plan(self):
-        """Degree-sorted sliced ELL of CSR(S^T) for the fused step kernels (E = 1): device tensors
-        order (int32 [N]), tile_off (int32 [ntiles+1]), ell_col (int32 [entries*16]), ell_val (fp32)."""
-        plan = self.__dict__.get('_fused_plan')
+    def fused_plan(self, adjoint=False):
+        """Degree-sorted sliced ELL of CSR(S^T) (forward shift) or, with adjoint=True, of CSR(S) (the shift of the
+        backward pass) for the fused step kernels (E = 1): device tensors order (int32 [N]), tile_off
+        (int32 [ntiles+1]), ell_col (int32 [entries*16]), ell_val (fp32) and the packed LDS image."""
+        key = '_fused_plan_adj' if adjoint else '_fused_plan'
+        plan = self.__dict__.get(key)
         if plan is not None:
             return plan
         assert self.E == 1
         npad = int(_lib.lib.gcrnn_fused_padded_nodes())
         assert self.N <= npad
         ntiles = npad // 16
-        c = self.fwd[0]
+        c = self.adj[0] if adjoint else self.fwd[0]
         rowptr = np.ascontiguousarray(c.rowptr.cpu().numpy())
         col = np.ascontiguousarray(c.col.cpu().numpy())
         val = np.ascontiguousarray(c.val(torch.float64).cpu().numpy())
@@ -152,7 +154,7 @@ class GraphOperator(object):
                     ell_col=torch.from_numpy(ell_col).to(dev), ell_val=torch.from_numpy(ell_val).to(dev),
                     ell_val4=torch.from_numpy(val4).to(dev), ell_col4=torch.from_numpy(col4.view(np.int16)).to(dev),
                     entries=int(nent.value), gather_cycles=int(cyc.value))
-        self._fused_plan = plan
+        setattr(self, key, plan)
         return plan
 
     def to(self, device):
@@ -182,16 +184,21 @@ _CACHE = {}
 
 
 def as_operator(S):
-    """Accept a GraphOperator or a dense E x N x N tensor (cached on its storage + version)."""
+    """Accept a GraphOperator or a dense E x N x N tensor. Dense tensors are converted once and cached on
+    (storage address, shape, version, device, dtype); the cache entry holds a reference to the tensor so that its
+    address cannot be recycled for a different matrix while the entry is alive."""
     if isinstance(S, GraphOperator):
         return S
     assert isinstance(S, torch.Tensor), 'GSO must be a torch.Tensor or a GraphOperator'
     assert S.dim() == 3, 'GSO must be E x N x N'
     key = (S.data_ptr(), tuple(S.shape), S._version, str(S.device), S.dtype)
-    op = _CACHE.get(key)
-    if op is None:
-        if len(_CACHE) > 16:
-            _CACHE.clear()
-        op = GraphOperator(S, device=S.device)
-        _CACHE[key] = op
+    hit = _CACHE.get(key)
+    if hit is not None and hit[0] is S:
+        return hit[1]
+    if hit is not None and hit[0].data_ptr() == S.data_ptr() and hit[0]._version == S._version:
+        return hit[1]                      # a view of the same live storage
+    if len(_CACHE) > 16:
+        _CACHE.clear()
+    op = GraphOperator(S, device=S.device)
+    _CACHE[key] = (S, op)
     return op

@@ -301,6 +301,26 @@ def fused_cell_forward(X, h0, wA, wB, bias, graph, gates=None, return_states=Fal
     return H
 
 
+def fused_backward_data(dHs, hs, wB, graph, want_dh0=True):
+    """BPTT data-gradient chain of the un-gated fused cell. dHs, hs: [T][B][NPad][F] bf16 sequence-major (gradient of
+    the loss w.r.t. every state; the states). Returns (dpre [T][B][NPad][F] bf16, dh0 [B][NPad][F] bf16 or None)."""
+    T, B, npad, F = hs.shape
+    K = wB.shape[2]
+    plan = graph.fused_plan(adjoint=True)
+    st = _stream()
+    wBt = wB.detach()[:, 0].permute(2, 1, 0).contiguous().unsqueeze(1)      # [F_in][1][K][F_out]: transposed taps
+    F_, G0 = F, 0
+    wpack = torch.empty(((F // 16) * K * (F // 32) * 64 * 8,), dtype=torch.bfloat16, device=hs.device)
+    check(lib.gcrnn_fused_pack_weights(dtype_code(wBt.dtype), _p(wBt), _p(wBt), _p(wpack), F_, G0, K, K, st), 'pack_weights')
+    dpre = torch.empty_like(hs)
+    dh0 = torch.empty((B, npad, F), dtype=torch.bfloat16, device=hs.device) if want_dh0 else None
+    check(lib.gcrnn_fused_backward_data_bf16(_p(dHs), _p(hs), _p(dpre), _p(dh0), _p(wpack), _p(plan['tile_nodes']),
+                                             _p(plan['tile_off']), _p(plan['ell_col']), _p(plan['ell_val']),
+                                             _p(plan['ell_val4']), _p(plan['ell_col4']), plan['entries'],
+                                             B, T, graph.N, F, K, st), 'fused_backward_data')
+    return dpre, dh0
+
+
 # ------------------------------------------------------------------------------------------ small-graph persistent path
 def small_supported(N, nnz, G, F, Kin, Kst, dtype, E=1):
     if E != 1 or dtype not in (torch.float32, torch.float64):

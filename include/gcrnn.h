@@ -151,6 +151,17 @@ int gcrnn_fused_gate_prepass_bf16(const void* xs, const void* h0, const void* wp
                                   const void* ell_val4, const void* ell_col4, int64_t entries, int64_t B, int64_t T,
                                   int64_t N, int64_t F, int64_t G, int64_t K, void* stream);
 
+/* BPTT data gradient of the un-gated fused cell (adjoint of graphML.py:2420-2423), bf16 sequence-major arrays [T][B][NPad][F]:
+ *   dpre[T-1] = dHs[T-1] * (1 - hs[T-1]^2);   for t = T-1 .. 1:
+ *   dpre[t-1] = ( sum_k (S)^k (dpre[t] B_k) + dHs[t-1] ) * (1 - hs[t-1]^2);        dh0 = sum_k (S)^k (dpre[0] B_k)  (optional)
+ * dHs = gradient of the loss w.r.t. every state, hs = the states of the forward. wpackT = gcrnn_fused_pack_weights of the
+ * TRANSPOSED state taps (wB^T [F_in][Kst][F_out] passed as "wB", G = 0); the graph arrays are the ELL of CSR(S) (the adjoint
+ * shift). One launch per step; same kernel as the forward with a different epilogue. */
+int gcrnn_fused_backward_data_bf16(const void* dHs, const void* hs, void* dpre, void* dh0, const void* wpackT,
+                                   const int32_t* tile_nodes, const int32_t* tile_off, const int32_t* ell_col,
+                                   const float* ell_val, const void* ell_val4, const void* ell_col4, int64_t entries,
+                                   int64_t B, int64_t T, int64_t N, int64_t F, int64_t K, void* stream);
+
 /* ==== small-graph regime: the whole T-step recurrence of a sequence inside one workgroup, one launch ============
  * Replaces GGCRNNCell.forward (graphML.py:2336-2427, un-gated or time-gated with precomputed gates) when
  * K*(G+F)*N values plus weights and CSR fit in LDS (gcrnn_small_supported) -- the drivers' own configurations

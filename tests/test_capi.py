@@ -105,3 +105,20 @@ def test_module_rejects_cpu_tensors_loudly():
         cell(torch.zeros(2, 2, 2, 6), torch.zeros(1, 3, 6))
     with pytest.raises(AssertionError):                                  # reference graphML.py:2239-2243
         cell.addGSO(torch.eye(6))
+
+
+def test_gso_cache_is_not_fooled_by_recycled_storage():
+    """A freed dense GSO's address may be handed to a new tensor of the same shape: the cache must not return the old graph."""
+    from gated_gcrnns_amd.graph import as_operator
+    import gc
+    seen = []
+    for seed in range(6):
+        rng = np.random.default_rng(seed)
+        S = torch.tensor(((rng.random((1, 64, 64)) < 0.1) * rng.random((1, 64, 64))))
+        op = as_operator(S)
+        assert op.nnz == int(np.count_nonzero(S.numpy()))
+        ref = csr_from_dense(S[0].numpy(), transpose=True)
+        assert np.array_equal(op.fwd[0].col.numpy(), ref[1])
+        seen.append(S.data_ptr())
+        del S, op
+        gc.collect()

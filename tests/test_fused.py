@@ -144,3 +144,56 @@ def test_fused_forward_hipgraph_replay_is_bit_identical():
                 ref = cell(X, h0)
             out = runner(X, h0)
             assert torch.equal(out, ref)
+
+
+def _bwd_reference(S, params, X, h0, dH):
+    """fp32 autograd on the composed HIP path (itself pinned to the reference's gradients by the G4 goldens)."""
+    import gated_gcrnns_amd.Utils.graphML as gml
+    dev = torch.device('cuda:0')
+    F, _, K, G = params['weight_A'].shape
+    cell = gml.GGCRNNCell(G, F, K, params['weight_B'].shape[2], torch.tanh, False, None, 1, True)
+    cell.addGSO(torch.tensor(S))
+    cell.load_state_dict({k: torch.tensor(v, dtype=torch.float32) for k, v in params.items()})
+    cell = cell.to(dev)
+    Xd = torch.tensor(X, dtype=torch.float32, device=dev)
+    hd = torch.tensor(h0, dtype=torch.float32, device=dev, requires_grad=True)
+    H = cell(Xd, hd)
+    (H * torch.tensor(dH, dtype=torch.float32, device=dev)).sum().backward()
+    return cell, hd.grad.detach().cpu().numpy(), H.detach()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('N,F,K,B,T', [(1000, 64, 5, 4, 5), (200, 32, 3, 9, 4)])
+def test_fused_backward_data_chain(N, F, K, B, T):
+    """BPTT data-gradient chain on the fused kernel (bf16) vs fp32 autograd: d loss / d h0 depends on every step."""
+    import gated_gcrnns_amd.Utils.graphML as gml
+    from gated_gcrnns_amd import ops, _lib
+    dev = torch.device('cuda:0')
+    G = F
+    S = random_graph(N, min(0.5, 10.0 / N), 31)                       # directed: the adjoint graph differs from the forward one
+    rng = np.random.default_rng(3)
+    X = bf16_round(rng.standard_normal((B, T, G, N)))
+    h0 = bf16_round(0.5 * rng.standard_normal((B, F, N)))
+    dH = bf16_round(rng.standard_normal((B, T, F, N)))
+    torch.manual_seed(7)
+    cell = gml.GGCRNNCell(G, F, K, K, torch.tanh, False, None, 1, True)
+    cell.addGSO(torch.tensor(S))
+    cell = cell.to(torch.bfloat16)
+    params = {k: v.detach().float().numpy() for k, v in cell.state_dict().items()}
+    _, dh0_ref, _ = _bwd_reference(S, params, X, h0, dH)
+    cell = cell.to(dev)
+    with torch.no_grad():
+        Xd = torch.tensor(X, dtype=torch.bfloat16, device=dev)
+        hd = torch.tensor(h0, dtype=torch.bfloat16, device=dev)
+        hs, plan = ops.fused_cell_forward(Xd, hd, cell.weight_A, cell.weight_B, cell.bias, cell.graph, return_states=True)
+        npad = plan['npad']
+        dHd = torch.tensor(dH, dtype=torch.bfloat16, device=dev)
+        dHs = torch.empty((T, B, npad, F), dtype=torch.bfloat16, device=dev)
+        _lib.check(_lib.lib.gcrnn_pack_seq_major(_lib.BF16, ops._p(dHd), ops._p(dHs), B, T, F, N, npad, None, ops._stream()), 'pack')
+        dpre, dh0s = ops.fused_backward_data(dHs, hs, cell.weight_B, cell.graph)
+        dh0 = torch.empty((B, 1, F, N), dtype=torch.bfloat16, device=dev)
+        _lib.check(_lib.lib.gcrnn_unpack_seq_major(_lib.BF16, ops._p(dh0s), ops._p(dh0), B, 1, F, N, npad, None, ops._stream()), 'unpack')
+    got = dh0.float().cpu().numpy().reshape(B, F, N)
+    scale = np.abs(dh0_ref).max()
+    err = np.abs(got - dh0_ref)
+    assert scale > 0 and err.max() <= 4e-2 * scale and err.mean() <= 4e-3 * scale, (err.max() / scale, err.mean() / scale)
