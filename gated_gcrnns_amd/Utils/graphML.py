@@ -306,6 +306,8 @@ class GGCRNNCell(nn.Module):
         ops.require_device(X, h0, self.weight_A)
         B, T, F_in, N = X.shape
         assert F_in == self.G and N == self.N
+        if self._use_fused_training(X, h0):
+            return ops.fused_cell_train(X, h0, self.weight_A, self.weight_B, self.bias, self.graph)
         if self._use_fused(X, h0):
             return self._forward_fused(X, h0)
         if self._use_small(X, h0):
@@ -366,7 +368,22 @@ class GGCRNNCell(nn.Module):
         if self.spatial_gating is not None or self.sigma not in (torch.tanh, nn.functional.tanh):
             return False
         return ops.fused_supported(self.N, self.F, self.G, self.Kin, self.Kst, X.dtype, self.E) and \
-            self.weight_A.dtype == X.dtype and h0.dtype == X.dtype
+            self.weight_A.dtype in (X.dtype, torch.float32) and h0.dtype == X.dtype
+
+    def _use_fused_training(self, X, h0):
+        """bf16 activations (parameters bf16 or fp32 master weights), plain cell, gradients wanted for the parameters
+        (and optionally h0) but not for X: forward and BPTT on the fused kernels."""
+        if not torch.is_grad_enabled() or X.requires_grad:
+            return False
+        if not (self.weight_A.requires_grad or h0.requires_grad):
+            return False
+        if self.time_gating == True or self.spatial_gating is not None:  # noqa: E712
+            return False
+        if self.sigma not in (torch.tanh, nn.functional.tanh) or X.dtype != torch.bfloat16 or h0.dtype != X.dtype:
+            return False
+        if self.weight_A.dtype not in (torch.bfloat16, torch.float32):
+            return False
+        return ops.fused_training_supported(self.graph, self.N, self.F, self.G, self.Kin, self.Kst, self.E)
 
     def _forward_fused(self, X, h0):
         gates = None

@@ -68,6 +68,8 @@ def _bind(lib):
                                                     _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_p]),
         'gcrnn_fused_backward_data_bf16': (C.c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p,
                                                      _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_p]),
+        'gcrnn_fused_backward_weight_bf16': (C.c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p,
+                                                       _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_p]),
         'gcrnn_small_supported': (C.c_int, [C.c_int, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64]),
         'gcrnn_small_forward': (C.c_int, [C.c_int, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p,
                                           _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_p]),

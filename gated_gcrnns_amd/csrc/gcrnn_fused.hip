@@ -238,7 +238,127 @@ extern "C" int gcrnn_fused_pack_weights(int wdtype, const void* wA, const void* 
     asm volatile("s_waitcnt lgkmcnt(" #n ")" ::: "memory");       \
     __builtin_amdgcn_sched_barrier(0);                            \
   } while (0)
+#define LGKM_WAITN(n) LGKM_WAIT(n)
 #define KEEP_ALIVE(v) asm volatile("" ::"v"(v))
+
+// One gather trip of the resident pipeline: group g has its weights in VC and its 4 gathered quads in XC*;
+// issue cols(g+2) -> CC, then (after cols(g+1) = CN landed) vals(g+1) -> VN and the gathers of g+1 -> XN*;
+// then wait for VC / XC* (issued one trip earlier) and do the 16 FMAs. lgkmcnt(6): the 6 reads just issued may
+// stay in flight. E and O name the two ping-pong register sets. Uses the locals g, gwend, gwlast, colb, valb, lds0, qx.
+#if defined(GCRNN_DEBUG_SERIAL_WAITS)
+#define GCRNN_TRIP_WAIT LGKM_WAIT(0)
+#define GCRNN_TRIP_WAIT2 LGKM_WAIT(0)
+#elif defined(GCRNN_DEBUG_SERIAL_WAIT_A)
+#define GCRNN_TRIP_WAIT LGKM_WAIT(0)
+#define GCRNN_TRIP_WAIT2 LGKM_WAIT(6)
+#elif defined(GCRNN_DEBUG_SERIAL_WAIT_B)
+#define GCRNN_TRIP_WAIT LGKM_WAIT(6)
+#define GCRNN_TRIP_WAIT2 LGKM_WAIT(0)
+#elif defined(GCRNN_DEBUG_WAIT2)
+#define GCRNN_TRIP_WAIT LGKM_WAIT(6)
+#define GCRNN_TRIP_WAIT2 LGKM_WAITN(GCRNN_DEBUG_WAIT2)
+#else
+#define GCRNN_TRIP_WAIT LGKM_WAIT(6)
+#define GCRNN_TRIP_WAIT2 LGKM_WAIT(6)
+#endif
+#define GCRNN_TRIP(ACC, CC, CN, VC, VN, XC0, XC1, XC2, XC3, XN0, XN1, XN2, XN3)                    \
+  do {                                                                                             \
+    const int g1_ = (g + 1 < gwend) ? g + 1 : gwlast, g2_ = (g + 2 < gwend) ? g + 2 : gwlast;      \
+    DS_READ_B64(CC, colb + g2_ * 128);                                                             \
+    GCRNN_TRIP_WAIT;                                                                               \
+    DS_READ_B128(VN, valb + g1_ * 256);                                                            \
+    DS_READ_B128(XN0, lds0 + (((uint32_t)CN & 0xffffu) ^ qx));                                     \
+    DS_READ_B128(XN1, lds0 + ((((uint32_t)CN >> 16) & 0xffffu) ^ qx));                             \
+    DS_READ_B128(XN2, lds0 + (((uint32_t)(CN >> 32) & 0xffffu) ^ qx));                             \
+    DS_READ_B128(XN3, lds0 + ((uint32_t)(CN >> 48) ^ qx));                                         \
+    GCRNN_TRIP_WAIT2;                                                                              \
+    ACC += VC[0] * XC0;                                                                            \
+    ACC += VC[1] * XC1;                                                                            \
+    ACC += VC[2] * XC2;                                                                            \
+    ACC += VC[3] * XC3;                                                                            \
+  } while (0)
+#define GCRNN_TRIP_E(ACC) GCRNN_TRIP(ACC, cE, cO, vE, vO, xE0, xE1, xE2, xE3, xO0, xO1, xO2, xO3)
+#define GCRNN_TRIP_O(ACC) GCRNN_TRIP(ACC, cO, cE, vO, vE, xO0, xO1, xO2, xO3, xE0, xE1, xE2, xE3)
+
+// One hop of one wave over the LDS-resident graph: acc_i = INIT(i) + sum over the neighbours of tile i's slots, for
+// the wave's TILES tiles. The tiles are stored back to back, so the whole hop is ONE continuous stream of groups:
+// the pipeline is primed once, runs across tile boundaries (only the accumulator changes) and is drained once.
+// Uses the locals tbeg, tend, lds_col, lds_val, lds0, qx, r.
+#define GCRNN_HOP_STREAM(INIT, STORE)                                                              \
+  do {                                                                                             \
+    const int gwbeg = tbeg[0] >> 2, gwend = tend[TILES - 1] >> 2, gwlast = gwend - 1;              \
+    const uint32_t colb = lds_col + r * 8, valb = lds_val + r * 16;                                \
+    uint64_t cE = 0, cO = 0;                                                                       \
+    f32x4 vE, vO, xE0, xE1, xE2, xE3, xO0, xO1, xO2, xO3;                                          \
+    int g = gwbeg;                                                                                 \
+    int par = 0; /* 0: the current group sits in set E, 1: in set O (wave-uniform) */              \
+    if (gwbeg < gwend) {                                                                           \
+      DS_READ_B64(cE, colb + gwbeg * 128);                                                         \
+      DS_READ_B64(cO, colb + ((gwbeg + 1 < gwend) ? gwbeg + 1 : gwlast) * 128);                    \
+      DS_READ_B128(vE, valb + gwbeg * 256);                                                        \
+      LGKM_WAIT(2);                                                                                \
+      DS_READ_B128(xE0, lds0 + (((uint32_t)cE & 0xffffu) ^ qx));                                   \
+      DS_READ_B128(xE1, lds0 + ((((uint32_t)cE >> 16) & 0xffffu) ^ qx));                           \
+      DS_READ_B128(xE2, lds0 + (((uint32_t)(cE >> 32) & 0xffffu) ^ qx));                           \
+      DS_READ_B128(xE3, lds0 + ((uint32_t)(cE >> 48) ^ qx));                                       \
+    }                                                                                              \
+    _Pragma("unroll") for (int i = 0; i < TILES; ++i) {                                            \
+      const int ge = tend[i] >> 2;                                                                 \
+      f32x4 acc = INIT(i);                                                                         \
+      if (g < ge) {                                                                                \
+        if (par) { GCRNN_TRIP_O(acc); ++g; par = 0; }                                              \
+        while (g < ge) {                                                                           \
+          GCRNN_TRIP_E(acc);                                                                       \
+          if (++g >= ge) { par = 1; break; }                                                       \
+          GCRNN_TRIP_O(acc);                                                                       \
+          ++g;                                                                                     \
+        }                                                                                          \
+      }                                                                                            \
+      STORE(i, acc);                                                                               \
+    }                                                                                              \
+    if (gwbeg < gwend) {                                                                           \
+      LGKM_WAIT(0); /* drain the tail prefetches before their registers may be reused */           \
+      KEEP_ALIVE(cE); KEEP_ALIVE(cO); KEEP_ALIVE(vE); KEEP_ALIVE(vO);                              \
+      KEEP_ALIVE(xE0); KEEP_ALIVE(xE1); KEEP_ALIVE(xE2); KEEP_ALIVE(xE3);                          \
+      KEEP_ALIVE(xO0); KEEP_ALIVE(xO1); KEEP_ALIVE(xO2); KEEP_ALIVE(xO3);                          \
+    }                                                                                              \
+  } while (0)
+
+// Same hop, but the pipeline is primed and drained per tile: nothing is in flight at the control-flow joins between
+// the unrolled tiles. Needed where register pressure makes hipcc insert copies of the ping-pong sets at those joins
+// (a copy of a register whose asm load has not landed yet captures stale data: cdna_hip_programming.md 5.7 item 1).
+#define GCRNN_HOP_TILED(INIT, STORE)                                                               \
+  do {                                                                                             \
+    const uint32_t colb = lds_col + r * 8, valb = lds_val + r * 16;                                \
+    _Pragma("unroll") for (int i = 0; i < TILES; ++i) {                                            \
+      const int gwbeg = tbeg[i] >> 2, gwend = tend[i] >> 2, gwlast = gwend - 1;                    \
+      f32x4 acc = INIT(i);                                                                         \
+      if (gwbeg < gwend) {                                                                         \
+        uint64_t cE, cO;                                                                           \
+        f32x4 vE, vO, xE0, xE1, xE2, xE3, xO0, xO1, xO2, xO3;                                      \
+        DS_READ_B64(cE, colb + gwbeg * 128);                                                       \
+        DS_READ_B64(cO, colb + ((gwbeg + 1 < gwend) ? gwbeg + 1 : gwlast) * 128);                  \
+        DS_READ_B128(vE, valb + gwbeg * 256);                                                      \
+        LGKM_WAIT(2);                                                                              \
+        DS_READ_B128(xE0, lds0 + (((uint32_t)cE & 0xffffu) ^ qx));                                 \
+        DS_READ_B128(xE1, lds0 + ((((uint32_t)cE >> 16) & 0xffffu) ^ qx));                         \
+        DS_READ_B128(xE2, lds0 + (((uint32_t)(cE >> 32) & 0xffffu) ^ qx));                         \
+        DS_READ_B128(xE3, lds0 + ((uint32_t)(cE >> 48) ^ qx));                                     \
+        int g = gwbeg;                                                                             \
+        while (true) {                                                                             \
+          GCRNN_TRIP_E(acc);                                                                       \
+          if (++g >= gwend) break;                                                                 \
+          GCRNN_TRIP_O(acc);                                                                       \
+          if (++g >= gwend) break;                                                                 \
+        }                                                                                          \
+        LGKM_WAIT(0);                                                                              \
+        KEEP_ALIVE(cE); KEEP_ALIVE(cO); KEEP_ALIVE(vE); KEEP_ALIVE(vO);                            \
+        KEEP_ALIVE(xE0); KEEP_ALIVE(xE1); KEEP_ALIVE(xE2); KEEP_ALIVE(xE3);                        \
+        KEEP_ALIVE(xO0); KEEP_ALIVE(xO1); KEEP_ALIVE(xO2); KEEP_ALIVE(xO3);                        \
+      }                                                                                            \
+      STORE(i, acc);                                                                               \
+    }                                                                                              \
+  } while (0)
 
 // LDS map (dynamic): state [NP][16] fp32 (64 KiB) | weight fragments K*KS KiB | RESIDENT: lval4 (f32x4), lcol4 (u16x4).
 // Tiles hold 16 nodes of similar degree: tile_nodes[p] lists the node of every slot p (degree-sorted order,
@@ -432,29 +552,6 @@ __global__ __launch_bounds__(512, 2) void fused_step_kernel(
   const uint32_t qx = (uint32_t)qoff;     // stored column = (col << 6) | (swizzle << 4);  ^ (q << 4) selects this lane's quad
   const uint32_t lds_val = lds0 + NP * FC * 4 + K * KS * 1024;
   const uint32_t lds_col = lds_val + (RESIDENT ? entries * 64 : 0);
-  // One gather trip of the resident pipeline: group g has its weights in VC and its 4 gathered quads in XC*;
-  // issue cols(g+2) -> CC, then (after cols(g+1) = CN landed) vals(g+1) -> VN and the gathers of g+1 -> XN*;
-  // then wait for VC / XC* (issued one trip earlier) and do the 16 FMAs. lgkmcnt(6): the 6 reads just issued may
-  // stay in flight. E and O name the two ping-pong register sets.
-#define GCRNN_TRIP(ACC, CC, CN, VC, VN, XC0, XC1, XC2, XC3, XN0, XN1, XN2, XN3)                    \
-  do {                                                                                             \
-    const int g1_ = (g + 1 < gwend) ? g + 1 : gwlast, g2_ = (g + 2 < gwend) ? g + 2 : gwlast;      \
-    DS_READ_B64(CC, colb + g2_ * 128);                                                             \
-    LGKM_WAIT(6);                                                                                  \
-    DS_READ_B128(VN, valb + g1_ * 256);                                                            \
-    DS_READ_B128(XN0, lds0 + (((uint32_t)CN & 0xffffu) ^ qx));                                     \
-    DS_READ_B128(XN1, lds0 + ((((uint32_t)CN >> 16) & 0xffffu) ^ qx));                             \
-    DS_READ_B128(XN2, lds0 + (((uint32_t)(CN >> 32) & 0xffffu) ^ qx));                             \
-    DS_READ_B128(XN3, lds0 + ((uint32_t)(CN >> 48) ^ qx));                                         \
-    LGKM_WAIT(6);                                                                                  \
-    ACC += VC[0] * XC0;                                                                            \
-    ACC += VC[1] * XC1;                                                                            \
-    ACC += VC[2] * XC2;                                                                            \
-    ACC += VC[3] * XC3;                                                                            \
-  } while (0)
-#define GCRNN_TRIP_E(ACC) GCRNN_TRIP(ACC, cE, cO, vE, vO, xE0, xE1, xE2, xE3, xO0, xO1, xO2, xO3)
-#define GCRNN_TRIP_O(ACC) GCRNN_TRIP(ACC, cO, cE, vO, vE, xO0, xO1, xO2, xO3, xE0, xE1, xE2, xE3)
-
 #ifdef GCRNN_ABLATE_HOPS
 #define GCRNN_HOP_FIRST K
 #else
@@ -463,45 +560,11 @@ __global__ __launch_bounds__(512, 2) void fused_step_kernel(
 #pragma unroll
   for (int j = GCRNN_HOP_FIRST; j < K; ++j) {
     if (RESIDENT) {
-      // The wave's 8 tiles are stored back to back, so its whole hop is ONE continuous stream of groups:
-      // the pipeline is primed once, runs across tile boundaries (only the accumulator changes) and is drained once.
-      const int gwbeg = tbeg[0] >> 2, gwend = tend[TILES - 1] >> 2, gwlast = gwend - 1;
-      const uint32_t colb = lds_col + r * 8, valb = lds_val + r * 16;
-      uint64_t cE = 0, cO = 0;
-      f32x4 vE, vO, xE0, xE1, xE2, xE3, xO0, xO1, xO2, xO3;
-      int g = gwbeg;
-      int par = 0;                      // 0: the current group sits in set E, 1: in set O   (wave-uniform)
-      if (gwbeg < gwend) {
-        DS_READ_B64(cE, colb + gwbeg * 128);
-        DS_READ_B64(cO, colb + ((gwbeg + 1 < gwend) ? gwbeg + 1 : gwlast) * 128);
-        DS_READ_B128(vE, valb + gwbeg * 256);
-        LGKM_WAIT(2);
-        DS_READ_B128(xE0, lds0 + (((uint32_t)cE & 0xffffu) ^ qx));
-        DS_READ_B128(xE1, lds0 + ((((uint32_t)cE >> 16) & 0xffffu) ^ qx));
-        DS_READ_B128(xE2, lds0 + (((uint32_t)(cE >> 32) & 0xffffu) ^ qx));
-        DS_READ_B128(xE3, lds0 + ((uint32_t)(cE >> 48) ^ qx));
-      }
-#pragma unroll
-      for (int i = 0; i < TILES; ++i) {
-        const int ge = tend[i] >> 2;
-        f32x4 acc = u[i][K - 1 - j];
-        if (g < ge) {
-          if (par) { GCRNN_TRIP_O(acc); ++g; par = 0; }
-          while (g < ge) {
-            GCRNN_TRIP_E(acc);
-            if (++g >= ge) { par = 1; break; }
-            GCRNN_TRIP_O(acc);
-            ++g;
-          }
-        }
-        u[i][K - 1 - j] = acc;      // the new value lives in the tap's registers until every wave has read `state`
-      }
-      if (gwbeg < gwend) {
-        LGKM_WAIT(0);                // drain the tail prefetches before their registers may be reused
-        KEEP_ALIVE(cE); KEEP_ALIVE(cO); KEEP_ALIVE(vE); KEEP_ALIVE(vO);
-        KEEP_ALIVE(xE0); KEEP_ALIVE(xE1); KEEP_ALIVE(xE2); KEEP_ALIVE(xE3);
-        KEEP_ALIVE(xO0); KEEP_ALIVE(xO1); KEEP_ALIVE(xO2); KEEP_ALIVE(xO3);
-      }
+#define GCRNN_FWD_INIT(i) u[i][K - 1 - j]
+#define GCRNN_FWD_STORE(i, a) u[i][K - 1 - j] = a   /* the new value lives in the tap's registers until every wave has read `state` */
+      GCRNN_HOP_STREAM(GCRNN_FWD_INIT, GCRNN_FWD_STORE);
+#undef GCRNN_FWD_INIT
+#undef GCRNN_FWD_STORE
     } else {
 #pragma unroll
       for (int i = 0; i < TILES; ++i) {
@@ -527,9 +590,6 @@ __global__ __launch_bounds__(512, 2) void fused_step_kernel(
       __syncthreads();
     }
   }
-#undef GCRNN_TRIP_E
-#undef GCRNN_TRIP_O
-#undef GCRNN_TRIP
 
   // ---- epilogue: bias, tanh, bf16 store into the node-major state h_t ------------------------------
   float bsum[4];
@@ -729,6 +789,242 @@ extern "C" int gcrnn_fused_gate_prepass_bf16(const void* xs, const void* h0, con
   if (B <= 0 || T <= 0 || N <= 0 || N > NP || B * T > (1 << 24) || entries < 0 || entries % 4) return GCRNN_ERR_BAD_SHAPE;
   const FusedGraphArgs ga{tile_nodes, tile_off, ell_col, ell_val, ell_val4, ell_col4, entries};
   return fused_dispatch(2, xs, h0, nullptr, wpack, bias, nullptr, nullptr, gate_w, gate_out, ga, B, T, N, F, G, K, as_stream(stream));
+}
+
+// ------------------------------------------------------------------------------------------
+// BPTT weight gradient of the un-gated cell:   dW_k[f'][j] = sum_{t,b,n} du_k[t,b][n][f'] * z[t,b][n][j],
+//   du_0 = dpre_t,  du_k = S du_{k-1}  (adjoint hops, CSR(S)),   z = [h_{t-1} | x_t]   (adjoint of graphML.py:134-135).
+// One workgroup = one (item (t,b), 16-feature chunk of dpre); wave w owns input-feature tile w of z. Every item is
+// independent (no recurrence once dpre is known), so ONE launch covers all T*B items and each workgroup keeps its
+// K accumulator tiles D_k [16 f' x 16 j] in registers across its items; one atomic flush at the end.
+//  - node index = the MFMA contraction dimension. B operand: 8 consecutive nodes of one input feature = one 16-byte
+//    load from the USER layout (x[b][t][g][:], H[b][t-1][f][:] are node-contiguous), held in registers across the taps.
+//    A operand: du_k transposed, a bf16 [16 f'][512 nodes] LDS image per half of the nodes, row stride 1056 B chosen so
+//    that the 16-lane groups of ds_read_b128 hit 16 distinct 16-byte bank slots (slot = 2 f' + kg mod 16).
+//  - du_k is consumed by the GEMM of tap k and by the hop that produces du_{k+1}: no per-tap storage at all.
+// LDS: state fp32 [1024][16] (64 KiB) | graph image 96 B x entries | transposed half image (16.5 KiB).
+// ------------------------------------------------------------------------------------------
+namespace { constexpr int TSTRIDE = 1056; constexpr int TBYTES = 16 * TSTRIDE; }
+
+template <int K, int HS, int XS>
+__global__ __launch_bounds__(512, 2) void fused_wgrad_kernel(
+    const uint16_t* __restrict__ dpre,       // [T][B][NP][F] bf16 sequence-major
+    const uint16_t* __restrict__ Xuser,      // [B][T][G][N] bf16
+    const uint16_t* __restrict__ Huser,      // [B][T][F][N] bf16 (forward output)
+    const uint16_t* __restrict__ h0user,     // [B][F][N]   bf16
+    float* __restrict__ dW,                  // [F][K][F+G] fp32, += (atomics)
+    const int32_t* __restrict__ tile_nodes, const int32_t* __restrict__ tile_off,
+    const float4* __restrict__ ell_val4, const uint2* __restrict__ ell_col4, int entries, int B, int Tn, int N) {
+  constexpr int F = 32 * HS, G = 32 * XS, C = F + G, NCH = F / FC, JT = C / 16;
+  static_assert(JT <= WAVES, "one input-feature tile per wave");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* state = reinterpret_cast<float*>(smem);
+  float4* lval4 = reinterpret_cast<float4*>(smem + NP * FC * 4);
+  uint2* lcol4 = reinterpret_cast<uint2*>(lval4 + entries * 4);
+  char* tbuf = reinterpret_cast<char*>(lcol4 + entries * 4);
+
+  const int L = blockIdx.x;
+  const int grp = L / (8 * NCH), rem = L - grp * (8 * NCH);
+  const int chunk = rem >> 3, it0 = grp * 8 + (rem & 7);
+  const int seq_slots = (gridDim.x / (8 * NCH)) * 8;
+  const int items = B * Tn;
+  if (it0 >= items) return;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 15, q = lane >> 4;
+
+  {
+    const int n = (entries >> 2) * 16;
+    for (int i = tid; i < n; i += 512) { lval4[i] = ell_val4[i]; lcol4[i] = ell_col4[i]; }
+  }
+  int tbeg[TILES], tend[TILES], woff[TILES];
+#pragma unroll
+  for (int i = 0; i < TILES; ++i) {
+    tbeg[i] = tile_off[wave * TILES + i];
+    tend[i] = tile_off[wave * TILES + i + 1];
+    const int nd = tile_nodes[(wave * TILES + i) * 16 + r];
+    woff[i] = nd * (FC * 4) + ((q ^ ((nd >> 2) & 3)) << 4);
+  }
+  const int qoff = q * 16;
+  const uint32_t lds0 = (uint32_t)reinterpret_cast<uintptr_t>(smem);
+  const uint32_t qx = (uint32_t)qoff;
+  const uint32_t lds_val = lds0 + NP * FC * 4;
+  const uint32_t lds_col = lds_val + entries * 64;
+
+  f32x4 accD[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) accD[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const bool has_tile = wave < JT;
+  const bool is_x = wave >= F / 16;                 // wave-uniform: tiles 0..F/16-1 are h features, the rest x features
+  const int jrow = (is_x ? wave * 16 - F : wave * 16) + r;      // this lane's row (feature) inside its source block
+  const __amdgpu_buffer_rsrc_t rsrc_d = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(dpre), 0, Tn * B * (NP * F * 2) > 0 ? Tn * B * (NP * F * 2) : 0x7fffffff, 0x00020000);
+  __syncthreads();
+
+  for (int it = it0; it < items; it += seq_slots) {
+    const int t = it / B, b = it - t * B;
+    // ---- B operand: this wave's 16 input features x 1024 nodes, straight from the user layout --------------------
+    // The fragments of nodes 0..511 stay in registers across the taps; those of nodes 512..1023 are re-fetched per tap
+    // (L2-resident after the first tap) through registers that the hop pipeline has just released -- the kernel must
+    // stay spill-free: a spilled destination of an in-flight asm ds_read would be saved before its data lands.
+    bf16x8 bfr[16];
+    const uint16_t* zsrc;
+    int zrows;
+    if (is_x) { zsrc = Xuser + ((int64_t)b * Tn + t) * G * N; zrows = G; }
+    else if (t > 0) { zsrc = Huser + ((int64_t)b * Tn + (t - 1)) * F * N; zrows = F; }
+    else { zsrc = h0user + (int64_t)b * F * N; zrows = F; }
+    const __amdgpu_buffer_rsrc_t rsrc_z = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(zsrc), 0, has_tile ? zrows * N * 2 : 0, 0x00020000);
+    const int vo = (jrow * N + 8 * q) * 2;
+#pragma unroll
+    for (int s2 = 0; s2 < 16; ++s2)
+      bfr[s2] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsrc_z, vo + 64 * s2, 0, 0));
+    // ---- du_0 = dpre chunk of this item ------------------------------------------------------------------------
+    f32x4 cur[TILES];
+    const int soff_d = ((t * B + b) * NP) * (F * 2);
+#pragma unroll
+    for (int i = 0; i < TILES; ++i) {
+      int wv = woff[i];
+      asm volatile("" : "+v"(wv));
+      const u32x2 d2 = __builtin_amdgcn_raw_buffer_load_b64(rsrc_d, (wv >> 6) * (F * 2) + (chunk * FC + q * 4) * 2, soff_d, 0);
+      cur[i] = f32x4{bf2f((uint16_t)(d2[0] & 0xffffu)), bf2f((uint16_t)(d2[0] >> 16)),
+                     bf2f((uint16_t)(d2[1] & 0xffffu)), bf2f((uint16_t)(d2[1] >> 16))};
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      // S1: du_k -> LDS state rows (for the next hop) and the transposed bf16 image of nodes 0..511
+#pragma unroll
+      for (int i = 0; i < TILES; ++i) {
+        int wv = woff[i];
+        asm volatile("" : "+v"(wv));
+        if (k < K - 1) *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(state) + wv) = cur[i];
+        const int node = wv >> 6;
+        if (node < 512) {
+#pragma unroll
+          for (int c = 0; c < 4; ++c)
+            *reinterpret_cast<uint16_t*>(tbuf + (q * 4 + c) * TSTRIDE + node * 2) = f2bf(cur[i][c]);
+        }
+      }
+      __syncthreads();
+      // S2: D_k += du_k^T z over nodes 0..511
+      if (has_tile) {
+#pragma unroll
+        for (int s2 = 0; s2 < 16; ++s2) {
+          const bf16x8 a = *reinterpret_cast<const bf16x8*>(tbuf + r * TSTRIDE + (32 * s2 + 8 * q) * 2);
+          accD[k] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bfr[s2], accD[k], 0, 0, 0);
+        }
+      }
+      __syncthreads();
+      // S3: transposed image of nodes 512..1023
+#pragma unroll
+      for (int i = 0; i < TILES; ++i) {
+        int wv = woff[i];
+        asm volatile("" : "+v"(wv));
+        const int node = wv >> 6;
+        if (node >= 512) {
+#pragma unroll
+          for (int c = 0; c < 4; ++c)
+            *reinterpret_cast<uint16_t*>(tbuf + (q * 4 + c) * TSTRIDE + (node - 512) * 2) = f2bf(cur[i][c]);
+        }
+      }
+      __syncthreads();
+      // S4: du_{k+1} = S du_k (reads `state`; the transposed image of du_k stays valid);  S5: second half of the contraction
+      if (k < K - 1) {
+#ifdef GCRNN_WGRAD_PLAIN_HOP
+#pragma unroll
+        for (int i = 0; i < TILES; ++i) {
+          f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+          for (int gq = tbeg[i] >> 2; gq < (tend[i] >> 2); ++gq) {
+            const uint2 c4 = lcol4[gq * 16 + r];
+            const float4 v4 = lval4[gq * 16 + r];
+            const char* sb = reinterpret_cast<const char*>(state);
+            acc += v4.x * *reinterpret_cast<const f32x4*>(sb + ((c4.x & 0xffffu) ^ qx));
+            acc += v4.y * *reinterpret_cast<const f32x4*>(sb + ((c4.x >> 16) ^ qx));
+            acc += v4.z * *reinterpret_cast<const f32x4*>(sb + ((c4.y & 0xffffu) ^ qx));
+            acc += v4.w * *reinterpret_cast<const f32x4*>(sb + ((c4.y >> 16) ^ qx));
+          }
+          cur[i] = acc;
+        }
+#else
+        LGKM_WAIT(0);
+#define GCRNN_WG_INIT(i) f32x4{0.f, 0.f, 0.f, 0.f}
+#define GCRNN_WG_STORE(i, a) cur[i] = a
+        GCRNN_HOP_TILED(GCRNN_WG_INIT, GCRNN_WG_STORE);
+#undef GCRNN_WG_INIT
+#undef GCRNN_WG_STORE
+#ifdef GCRNN_DEBUG_BARRIER_AFTER_HOP
+        __syncthreads();
+#endif
+#endif
+      }
+      if (has_tile) {
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2) {
+          bf16x8 bl[8];
+#pragma unroll
+          for (int s2 = 0; s2 < 8; ++s2)
+            bl[s2] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsrc_z, vo + 64 * (16 + 8 * h2 + s2), 0, 0));
+#pragma unroll
+          for (int s2 = 0; s2 < 8; ++s2) {
+            const bf16x8 a = *reinterpret_cast<const bf16x8*>(tbuf + r * TSTRIDE + (32 * (8 * h2 + s2) + 8 * q) * 2);
+            accD[k] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bl[s2], accD[k], 0, 0, 0);
+          }
+        }
+      }
+      __syncthreads();
+    }
+  }
+  // ---- flush: D_k[f' = 4q + c][j = 16 wave + r] -> dW[chunk*16 + f'][k][j] -------------------------------------------
+  if (has_tile) {
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+        atomicAdd(dW + ((int64_t)(chunk * FC + q * 4 + c) * K + k) * C + wave * 16 + r, accD[k][c]);
+  }
+}
+
+template <int K, int HS, int XS>
+static int fused_wgrad_t(const void* dpre, const void* Xuser, const void* Huser, const void* h0user, float* dW,
+                         const FusedGraphArgs& ga, int64_t B, int64_t T, int64_t N, hipStream_t st) {
+  constexpr int F = 32 * HS;
+  const size_t lds = (size_t)NP * FC * 4 + (size_t)ga.entries * 96 + TBYTES;
+  if (lds > 160 * 1024 || !ga.ell_val4 || !ga.ell_col4) return GCRNN_ERR_UNSUPPORTED;
+  auto kern = fused_wgrad_kernel<K, HS, XS>;
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    return GCRNN_ERR_LAUNCH;
+  const int NCH = F / FC;
+  int64_t slots = cdiv(B * T, 8) * 8;
+  const int64_t max_slots = (256 / NCH) / 8 * 8 > 0 ? (256 / NCH) / 8 * 8 : 8;
+  if (slots > max_slots) slots = max_slots;
+  GCRNN_PRE_LAUNCH();
+  kern<<<(unsigned)(slots * NCH), 512, lds, st>>>((const uint16_t*)dpre, (const uint16_t*)Xuser, (const uint16_t*)Huser,
+                                                   (const uint16_t*)h0user, dW, ga.tile_nodes, ga.tile_off,
+                                                   (const float4*)ga.ell_val4, (const uint2*)ga.ell_col4, (int)ga.entries,
+                                                   (int)B, (int)T, (int)N);
+  GCRNN_CHECK_LAUNCH();
+  return GCRNN_OK;
+}
+
+extern "C" int gcrnn_fused_backward_weight_bf16(const void* dpre, const void* Xuser, const void* Huser, const void* h0user,
+                                                float* dW, const int32_t* tile_nodes, const int32_t* tile_off,
+                                                const void* ell_val4, const void* ell_col4, int64_t entries, int64_t B,
+                                                int64_t T, int64_t N, int64_t F, int64_t G, int64_t K, void* stream) {
+  if (!dpre || !Xuser || !Huser || !h0user || !dW || !tile_nodes || !tile_off || !ell_val4 || !ell_col4) return GCRNN_ERR_NULL_POINTER;
+  if (B <= 0 || T <= 0 || N <= 0 || N > NP || N % 8 || entries < 0 || entries % 4 || B * T > (1 << 24)) return GCRNN_ERR_BAD_SHAPE;
+  if (T * B * (NP * F * 2) > 2147483647LL) return GCRNN_ERR_BAD_SHAPE;      // 32-bit buffer offsets into dpre
+  const FusedGraphArgs ga{tile_nodes, tile_off, nullptr, nullptr, ell_val4, ell_col4, entries};
+  hipStream_t st = as_stream(stream);
+#define GCRNN_WG_CASE(KK, HH, XX) \
+  if (K == KK && F == 32 * HH && G == 32 * XX) return fused_wgrad_t<KK, HH, XX>(dpre, Xuser, Huser, h0user, dW, ga, B, T, N, st);
+  GCRNN_WG_CASE(5, 2, 2)
+  GCRNN_WG_CASE(4, 2, 2)
+  GCRNN_WG_CASE(3, 2, 2)
+  GCRNN_WG_CASE(2, 2, 2)
+  GCRNN_WG_CASE(5, 1, 1)
+  GCRNN_WG_CASE(3, 1, 1)
+  GCRNN_WG_CASE(2, 1, 1)
+#undef GCRNN_WG_CASE
+  return GCRNN_ERR_UNSUPPORTED;
 }
 
 // dpre[i] = dH[i] * (1 - h[i]^2) on bf16 arrays (the seed of the BPTT chain, t = T-1)

@@ -321,6 +321,81 @@ def fused_backward_data(dHs, hs, wB, graph, want_dh0=True):
     return dpre, dh0
 
 
+def fused_backward_weight(dpre, X, H, h0, graph, F, G, K):
+    """dW [F][K][F+G] fp32 (columns: F state features, then G input features) from dpre (sequence-major bf16) and the
+    user-layout bf16 tensors X [B][T][G][N], H [B][T][F][N] (forward output), h0 [B][F][N]."""
+    T, B = dpre.shape[0], dpre.shape[1]
+    plan = graph.fused_plan(adjoint=True)
+    dW = torch.zeros((F, K, F + G), dtype=torch.float32, device=dpre.device)
+    check(lib.gcrnn_fused_backward_weight_bf16(_p(dpre), _p(X.contiguous()), _p(H.contiguous()), _p(h0.contiguous()), _p(dW),
+                                               _p(plan['tile_nodes']), _p(plan['tile_off']), _p(plan['ell_val4']),
+                                               _p(plan['ell_col4']), plan['entries'], B, T, graph.N, F, G, K, _stream()),
+          'fused_backward_weight')
+    return dW
+
+
+def fused_training_supported(graph, N, F, G, Kin, Kst, E=1):
+    """The fused BPTT needs the forward kernel's shapes, node-contiguous rows that are 16-byte aligned (N % 8 == 0)
+    and the adjoint graph image next to the state and the transposed tile in LDS."""
+    if E != 1 or N % 8 != 0 or not bool(lib.gcrnn_fused_supported(int(N), int(F), int(G), int(max(Kin, Kst)))):
+        return False
+    entries = graph.fused_plan(adjoint=True)['entries']
+    return 65536 + 96 * entries + 16 * 1056 <= 160 * 1024
+
+
+class _FusedCell(torch.autograd.Function):
+    """Un-gated GGCRNNCell on the fused kernels, forward and BPTT (bf16 activations, fp32 or bf16 parameters).
+
+    backward = pack(dH) -> data-gradient chain (T launches of the step kernel on the adjoint graph with transposed taps)
+    -> ONE weight-gradient launch over all T*B items -> bias gradient 2 * sum(dpre). The gradient w.r.t. X is not
+    produced (the training loops never ask for it, train_rnn.py:247-276)."""
+
+    @staticmethod
+    def forward(ctx, X, h0, wA, wB, bias, graph):
+        hs, plan = fused_cell_forward(X, h0, wA, wB, bias, graph, return_states=True)
+        B, T, G, N = X.shape
+        F = wA.shape[0]
+        H = torch.empty((B, T, F, N), dtype=torch.bfloat16, device=X.device)
+        check(lib.gcrnn_unpack_seq_major(_lib.BF16, _p(hs), _p(H), B, T, F, N, plan['npad'], None, _stream()), 'unpack_seq')
+        ctx.save_for_backward(X, h0, wA, wB, bias, H, hs)
+        ctx.graph = graph
+        ctx.npad = plan['npad']
+        return H
+
+    @staticmethod
+    def backward(ctx, dH):
+        X, h0, wA, wB, bias, H, hs = ctx.saved_tensors
+        graph, npad = ctx.graph, ctx.npad
+        B, T, G, N = X.shape
+        F, Kin, Kst = wA.shape[0], wA.shape[2], wB.shape[2]
+        K = max(Kin, Kst)
+        if ctx.needs_input_grad[0]:
+            raise GcrnnError('the fused BPTT does not produce the gradient w.r.t. the input sequence X')
+        st = _stream()
+        dH = dH.to(torch.bfloat16).contiguous()
+        dHs = torch.empty((T, B, npad, F), dtype=torch.bfloat16, device=X.device)
+        check(lib.gcrnn_pack_seq_major(_lib.BF16, _p(dH), _p(dHs), B, T, F, N, npad, None, st), 'pack_seq')
+        wBk = wB if Kst == K else torch.cat([wB, wB.new_zeros(F, 1, K - Kst, F)], dim=2)
+        dpre, dh0s = fused_backward_data(dHs, hs, wBk, graph, want_dh0=ctx.needs_input_grad[1])
+        dW = fused_backward_weight(dpre, X, H, h0, graph, F, G, K)                  # [F][K][F+G] fp32
+        gA = dW[:, :Kin, F:].unsqueeze(1).to(wA.dtype) if ctx.needs_input_grad[2] else None
+        gB = dW[:, :Kst, :F].unsqueeze(1).to(wB.dtype) if ctx.needs_input_grad[3] else None
+        gb = None
+        if bias is not None and ctx.needs_input_grad[4]:
+            gb = (2.0 * dpre.float().sum(dim=(0, 1, 2))).view_as(bias).to(bias.dtype)   # the bias enters both filters
+        gh0 = None
+        if ctx.needs_input_grad[1]:
+            gh0 = torch.empty((B, 1, F, N), dtype=torch.bfloat16, device=X.device)
+            check(lib.gcrnn_unpack_seq_major(_lib.BF16, _p(dh0s), _p(gh0), B, 1, F, N, npad, None, st), 'unpack_seq')
+            gh0 = gh0.view(B, F, N).to(h0.dtype)
+        return None, gh0, gA, gB, gb, None
+
+
+def fused_cell_train(X, h0, wA, wB, bias, graph):
+    require_device(X, h0, wA, wB, bias)
+    return _FusedCell.apply(X, h0, wA, wB, bias, graph)
+
+
 # ------------------------------------------------------------------------------------------ small-graph persistent path
 def small_supported(N, nnz, G, F, Kin, Kst, dtype, E=1):
     if E != 1 or dtype not in (torch.float32, torch.float64):

@@ -162,6 +162,17 @@ int gcrnn_fused_backward_data_bf16(const void* dHs, const void* hs, void* dpre, 
                                    const float* ell_val, const void* ell_val4, const void* ell_col4, int64_t entries,
                                    int64_t B, int64_t T, int64_t N, int64_t F, int64_t K, void* stream);
 
+/* BPTT weight gradient of the un-gated fused cell (adjoint of the taps, graphML.py:134-135), all T*B items in ONE launch:
+ *   dW[f'][k][j] += sum_{t,b,n} (S^k dpre[t][b])[n][f'] * z[t][b][n][j],   z = [h_{t-1} | x_t],   j < F: weight_B, j >= F: weight_A
+ * dpre: output of gcrnn_fused_backward_data_bf16; Xuser [B][T][G][N], Huser [B][T][F][N] (the forward's output) and
+ * h0user [B][F][N] are the bf16 USER-layout tensors (node-contiguous rows feed the matrix cores directly; needs N % 8 == 0);
+ * dW fp32 [F][K][F+G], accumulated with atomics (caller zeroes); graph arrays = LDS image of the ELL of CSR(S).
+ * Returns GCRNN_ERR_UNSUPPORTED when the graph image does not fit in LDS next to the state. */
+int gcrnn_fused_backward_weight_bf16(const void* dpre, const void* Xuser, const void* Huser, const void* h0user, float* dW,
+                                     const int32_t* tile_nodes, const int32_t* tile_off, const void* ell_val4,
+                                     const void* ell_col4, int64_t entries, int64_t B, int64_t T, int64_t N, int64_t F,
+                                     int64_t G, int64_t K, void* stream);
+
 /* ==== small-graph regime: the whole T-step recurrence of a sequence inside one workgroup, one launch ============
  * Replaces GGCRNNCell.forward (graphML.py:2336-2427, un-gated or time-gated with precomputed gates) when
  * K*(G+F)*N values plus weights and CSR fit in LDS (gcrnn_small_supported) -- the drivers' own configurations
