@@ -128,9 +128,11 @@ def main():
     if args.mode == 'train':
         # one optimiser step of the k-step-prediction loop (reference train_rnn.py:247-281): forward, L1 loss on the
         # state sequence, BPTT, ONE flat gradient all-reduce over RCCL, Adam. Runs on the fp32/fp64 composed path.
-        assert args.dtype in ('f32', 'f64'), 'training runs in f32 or f64 (bf16 is the inference mode)'
+        # bf16: fp32 master weights, bf16 activations -> fused forward + fused BPTT; f32 / f64: composed path
         from gated_gcrnns_amd.parallel import FlatGradAllReduce
-        target = torch.randn(B, T, F, N, device=dev, dtype=dt, generator=None)
+        if args.dtype == 'bf16':
+            cell = cell.float()
+        target = torch.randn(B, T, F, N, device=dev, dtype=torch.float32).to(dt)
         opt = torch.optim.Adam(cell.parameters(), lr=1e-3)
         sync_grads = FlatGradAllReduce(cell.parameters()) if world > 1 else None
 
