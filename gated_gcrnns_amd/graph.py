@@ -202,3 +202,26 @@ def as_operator(S):
     op = GraphOperator(S, device=S.device)
     _CACHE[key] = (S, op)
     return op
+
+
+def operator_from_csr(rowptr, col, val, N, device=None):
+    """GraphOperator for graphs that cannot be held densely (BASELINE config 5: N = 1e5): `rowptr/col/val` is the CSR of
+    S itself (row m lists S[m, :]). The forward shift needs CSR(S^T), built here by a counting transpose; the attention
+    support (edge gate) is not built for such graphs."""
+    rowptr = np.ascontiguousarray(rowptr, dtype=np.int64)
+    col = np.ascontiguousarray(col, dtype=np.int32)
+    val = np.ascontiguousarray(val, dtype=np.float64)
+    assert rowptr.size == N + 1 and col.size == val.size == rowptr[-1]
+    rows = np.repeat(np.arange(N, dtype=np.int32), np.diff(rowptr))
+    order = np.lexsort((rows, col))                      # sort by (column, row): CSR of the transpose
+    t_rowptr = np.zeros(N + 1, dtype=np.int64)
+    np.add.at(t_rowptr, col.astype(np.int64) + 1, 1)
+    t_rowptr = np.cumsum(t_rowptr)
+    op = GraphOperator.__new__(GraphOperator)
+    op.E, op.N = 1, int(N)
+    op.device = torch.device(device if device is not None else 'cpu')
+    op.adj = [CSR(rowptr.astype(np.int32), col, val, device=op.device)]
+    op.fwd = [CSR(t_rowptr.astype(np.int32), rows[order].astype(np.int32), val[order], device=op.device)]
+    op.mask, op.mask_vals = None, None
+    op.nnz = int(col.size)
+    return op
