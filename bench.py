@@ -102,10 +102,11 @@ def main():
     assert world == args.gpus, 'launch with torch.distributed.run --nproc-per-node %d' % args.gpus
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
-    if world > 1:
+    dist_on = 'RANK' in os.environ and 'WORLD_SIZE' in os.environ          # launched by torch.distributed.run
+    if dist_on:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=dev)
+        dist.init_process_group('nccl', device_id=dev)                      # "nccl" is RCCL on ROCm
 
     import gated_gcrnns_amd.Utils.graphML as gml
 
@@ -134,7 +135,7 @@ def main():
             cell = cell.float()
         target = torch.randn(B, T, F, N, device=dev, dtype=torch.float32).to(dt)
         opt = torch.optim.Adam(cell.parameters(), lr=1e-3)
-        sync_grads = FlatGradAllReduce(cell.parameters()) if world > 1 else None
+        sync_grads = FlatGradAllReduce(cell.parameters()) if dist_on else None
 
     runner = None
     if args.mode == 'fwd' and args.dtype == 'bf16' and args.hipgraph:
@@ -156,7 +157,7 @@ def main():
         return loss
 
     def sync():
-        if world > 1:
+        if dist_on:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
@@ -172,7 +173,7 @@ def main():
     sync()
     wall = time.perf_counter() - t0
     dev_ms = ev0.elapsed_time(ev1)
-    if world > 1:
+    if dist_on:
         tw = torch.tensor([wall], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(tw, op=torch.distributed.ReduceOp.MAX)
         wall = float(tw.item())
@@ -228,7 +229,7 @@ def main():
         if not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(S, params, T, G, F)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist_on:
         torch.distributed.destroy_process_group()
 
 
