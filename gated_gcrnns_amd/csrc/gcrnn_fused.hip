@@ -382,7 +382,8 @@ __global__ __launch_bounds__(512, 2) void fused_step_kernel(
     const float* __restrict__ gate_w,       // GATEOUT: [N][F] node-major weights of the gate's Linear(N*F -> 1)
     float* __restrict__ gate_out,           // GATEOUT: [B][F/16][8] per-(chunk, wave) partials of sum_{n,f} tanh(pre) * gate_w
     const uint16_t* __restrict__ aux0,      // EPI 2: upstream gradient dH_{t-1} [B][NP][F] bf16 (or null)
-    const uint16_t* __restrict__ aux1,      // EPI 2: state h_{t-1} [B][NP][F] bf16
+    const uint16_t* __restrict__ aux1,      // EPI 2: state h_{t-1} [B][NP][F] bf16;  EPI 0: user-layout output H[.][t][F][N] (or null)
+    int ubstride,                           // EPI 0: elements between consecutive sequences of the user-layout output (T*F*N)
     int entries, int B, int hmod, int N) {
   constexpr int KS = HS + XS;
   constexpr int F = 32 * HS, G = 32 * XS;
@@ -665,6 +666,32 @@ __global__ __launch_bounds__(512, 2) void fused_step_kernel(
       pk.x = 0u; pk.y = 0u;          // padded rows stay zero
     }
     __builtin_amdgcn_raw_buffer_store_b64(u32x2{pk.x, pk.y}, rsrc_o, node * (F * 2) + (chunk * FC + q * 4) * 2, b * (NP * F * 2), 0);
+    u[i][0] = f32x4{__uint_as_float(pk.x), __uint_as_float(pk.y), 0.f, 0.f};      // keep the packed bf16 for the user-layout copy
+  }
+  if (EPI == 0 && aux1) {
+    // the state is also delivered in the USER layout H[b][t][f][:] (node-contiguous rows): transposed bf16 tile in LDS
+    // (row stride 2080 B), then 16-byte coalesced row stores -- replaces a separate unpack pass over the whole sequence.
+    constexpr int RS = 2 * NP + 32;
+    char* tst = reinterpret_cast<char*>(state);
+    __syncthreads();                                   // every wave has finished reading `state` in the last hop
+#pragma unroll
+    for (int i = 0; i < TILES; ++i) {
+      int wv = woff[i];
+      asm volatile("" : "+v"(wv));
+      const int node = wv >> 6;
+      const uint32_t p0 = __float_as_uint(u[i][0][0]), p1 = __float_as_uint(u[i][0][1]);
+      *reinterpret_cast<uint16_t*>(tst + (q * 4 + 0) * RS + node * 2) = (uint16_t)(p0 & 0xffffu);
+      *reinterpret_cast<uint16_t*>(tst + (q * 4 + 1) * RS + node * 2) = (uint16_t)(p0 >> 16);
+      *reinterpret_cast<uint16_t*>(tst + (q * 4 + 2) * RS + node * 2) = (uint16_t)(p1 & 0xffffu);
+      *reinterpret_cast<uint16_t*>(tst + (q * 4 + 3) * RS + node * 2) = (uint16_t)(p1 >> 16);
+    }
+    __syncthreads();
+    const int segs = N >> 3;                           // 16-byte segments per row (N % 8 == 0 checked by the host)
+    uint16_t* ub = const_cast<uint16_t*>(aux1) + (int64_t)b * ubstride + (int64_t)(chunk * FC) * N;
+    for (int idx = tid; idx < FC * segs; idx += 512) {
+      const int f = idx / segs, sg = idx - f * segs;
+      *reinterpret_cast<uint4*>(ub + (int64_t)f * N + sg * 8) = *reinterpret_cast<const uint4*>(tst + f * RS + sg * 16);
+    }
   }
   }
   asm volatile("" ::"v"(prefetched));      // the prefetch load retires here at the latest
@@ -674,7 +701,7 @@ __global__ __launch_bounds__(512, 2) void fused_step_kernel(
 
 typedef void (*fused_kern_t)(const uint16_t*, const uint16_t*, uint16_t*, const uint4*, const float*, const float*,
                              const float*, const int32_t*, const int32_t*, const int32_t*, const float*, const float4*,
-                             const uint2*, const float*, float*, const uint16_t*, const uint16_t*, int, int, int, int);
+                             const uint2*, const float*, float*, const uint16_t*, const uint16_t*, int, int, int, int, int);
 
 struct FusedGraphArgs {
   const int32_t* tile_nodes; const int32_t* tile_off; const int32_t* ell_col; const float* ell_val;
@@ -686,7 +713,7 @@ static int fused_launch_t(int mode /*0 plain, 1 gated, 2 gate pre-pass, 3 BPTT d
                           void* hs, const void* wpack, const float* bias, const float* gi, const float* gf,
                           const float* gate_w, float* gate_out, const FusedGraphArgs& ga, int64_t B, int64_t T, int64_t N,
                           hipStream_t st, const void* bw_dHs = nullptr, const void* bw_hs = nullptr, const void* bw_h0 = nullptr,
-                          void* bw_dh0 = nullptr) {
+                          void* bw_dh0 = nullptr, void* huser = nullptr) {
   constexpr int F = 32 * HS, G = 32 * XS, KS = HS + XS;
   const size_t base = (size_t)NP * FC * 4 + (size_t)K * KS * 1024;
   const size_t resident_bytes = base + (size_t)ga.entries * 16 * 6;
@@ -713,7 +740,7 @@ static int fused_launch_t(int mode /*0 plain, 1 gated, 2 gate pre-pass, 3 BPTT d
   if (mode == 2) {
     kern<<<grid, 512, lds, st>>>(x, (const uint16_t*)h0, nullptr, (const uint4*)wpack, bias, nullptr, nullptr, ga.tile_nodes,
                                  ga.tile_off, ga.ell_col, ga.ell_val, (const float4*)ga.ell_val4, (const uint2*)ga.ell_col4,
-                                 gate_w, gate_out, nullptr, nullptr, (int)ga.entries, (int)items, (int)B, (int)N);
+                                 gate_w, gate_out, nullptr, nullptr, 0, (int)ga.entries, (int)items, (int)B, (int)N);
   } else if (mode == 3) {
     // BPTT: hs (= dpre, [T][B][NP][F]) already holds dpre_{T-1}; walk t = T-1 .. 1, then optionally d h0
     const uint16_t* dH = (const uint16_t*)bw_dHs;
@@ -722,19 +749,20 @@ static int fused_launch_t(int mode /*0 plain, 1 gated, 2 gate pre-pass, 3 BPTT d
       const uint16_t* hprev_state = (t - 1 >= 1 || true) ? hst + (t - 1) * hstep : nullptr;
       kern<<<grid, 512, lds, st>>>(nullptr, h + t * hstep, h + (t - 1) * hstep, (const uint4*)wpack, nullptr, nullptr, nullptr,
                                    ga.tile_nodes, ga.tile_off, ga.ell_col, ga.ell_val, (const float4*)ga.ell_val4,
-                                   (const uint2*)ga.ell_col4, nullptr, nullptr, dH + (t - 1) * hstep, hprev_state,
+                                   (const uint2*)ga.ell_col4, nullptr, nullptr, dH + (t - 1) * hstep, hprev_state, 0,
                                    (int)ga.entries, (int)B, (int)B, (int)N);
     }
     if (bw_dh0)
       kern<<<grid, 512, lds, st>>>(nullptr, h, (uint16_t*)bw_dh0, (const uint4*)wpack, nullptr, nullptr, nullptr, ga.tile_nodes,
                                    ga.tile_off, ga.ell_col, ga.ell_val, (const float4*)ga.ell_val4, (const uint2*)ga.ell_col4,
-                                   nullptr, nullptr, nullptr, nullptr, (int)ga.entries, (int)B, (int)B, (int)N);
+                                   nullptr, nullptr, nullptr, nullptr, 0, (int)ga.entries, (int)B, (int)B, (int)N);
   } else {
     for (int64_t t = 0; t < T; ++t) {
       const uint16_t* hp = (t == 0) ? (const uint16_t*)h0 : h + (t - 1) * hstep;
       kern<<<grid, 512, lds, st>>>(x + t * xstep, hp, h + t * hstep, (const uint4*)wpack, bias, mode == 1 ? gi + t * B : nullptr,
                                    mode == 1 ? gf + t * B : nullptr, ga.tile_nodes, ga.tile_off, ga.ell_col, ga.ell_val,
-                                   (const float4*)ga.ell_val4, (const uint2*)ga.ell_col4, nullptr, nullptr, nullptr, nullptr,
+                                   (const float4*)ga.ell_val4, (const uint2*)ga.ell_col4, nullptr, nullptr, nullptr,
+                                   huser ? (const uint16_t*)huser + t * F * N : nullptr, (int)(T * F * N),
                                    (int)ga.entries, (int)B, (int)B, (int)N);
     }
   }
@@ -745,11 +773,12 @@ static int fused_launch_t(int mode /*0 plain, 1 gated, 2 gate pre-pass, 3 BPTT d
 static int fused_dispatch(int mode, const void* xs, const void* h0, void* hs, const void* wpack, const float* bias,
                           const float* gi, const float* gf, const float* gate_w, float* gate_out, const FusedGraphArgs& ga,
                           int64_t B, int64_t T, int64_t N, int64_t F, int64_t G, int64_t K, hipStream_t st,
-                          const void* bw_dHs = nullptr, const void* bw_hs = nullptr, void* bw_dh0 = nullptr) {
+                          const void* bw_dHs = nullptr, const void* bw_hs = nullptr, void* bw_dh0 = nullptr,
+                          void* huser = nullptr) {
 #define GCRNN_FUSED_CASE(KK, HH, XX) \
   if (K == KK && F == 32 * HH && G == 32 * XX) \
     return fused_launch_t<KK, HH, XX>(mode, xs, h0, hs, wpack, bias, gi, gf, gate_w, gate_out, ga, B, T, N, st, bw_dHs, \
-                                      bw_hs, nullptr, bw_dh0);
+                                      bw_hs, nullptr, bw_dh0, huser);
   GCRNN_FUSED_CASE(5, 2, 2)
   GCRNN_FUSED_CASE(4, 2, 2)
   GCRNN_FUSED_CASE(3, 2, 2)
@@ -772,12 +801,15 @@ extern "C" int gcrnn_fused_forward_bf16(const void* xs, const void* h0, void* hs
                                         const float* gi, const float* gf, const int32_t* tile_nodes,
                                         const int32_t* tile_off, const int32_t* ell_col, const float* ell_val,
                                         const void* ell_val4, const void* ell_col4, int64_t entries, int64_t B,
-                                        int64_t T, int64_t N, int64_t F, int64_t G, int64_t K, void* stream) {
+                                        int64_t T, int64_t N, int64_t F, int64_t G, int64_t K, void* Huser, void* stream) {
   if (!xs || !h0 || !hs || !wpack || !tile_nodes || !tile_off || !ell_col || !ell_val) return GCRNN_ERR_NULL_POINTER;
   if ((gi == nullptr) != (gf == nullptr)) return GCRNN_ERR_NULL_POINTER;
   if (B <= 0 || T <= 0 || N <= 0 || N > NP || B > (1 << 24) || entries < 0 || entries % 4) return GCRNN_ERR_BAD_SHAPE;
+  if (B * (NP * (F > G ? F : G) * 2) > 2147483647LL || T * F * N > 2147483647LL) return GCRNN_ERR_BAD_SHAPE;   // 32-bit buffer offsets
+  if (Huser && (N % 8 != 0 || (reinterpret_cast<uintptr_t>(Huser) & 15))) return GCRNN_ERR_BAD_SHAPE;
   const FusedGraphArgs ga{tile_nodes, tile_off, ell_col, ell_val, ell_val4, ell_col4, entries};
-  return fused_dispatch(gi ? 1 : 0, xs, h0, hs, wpack, bias, gi, gf, nullptr, nullptr, ga, B, T, N, F, G, K, as_stream(stream));
+  return fused_dispatch(gi ? 1 : 0, xs, h0, hs, wpack, bias, gi, gf, nullptr, nullptr, ga, B, T, N, F, G, K, as_stream(stream),
+                        nullptr, nullptr, nullptr, Huser);
 }
 
 extern "C" int gcrnn_fused_gate_prepass_bf16(const void* xs, const void* h0, const void* wpack, const float* bias,
@@ -813,6 +845,7 @@ __global__ __launch_bounds__(512, 2) void fused_wgrad_kernel(
     const uint16_t* __restrict__ Huser,      // [B][T][F][N] bf16 (forward output)
     const uint16_t* __restrict__ h0user,     // [B][F][N]   bf16
     float* __restrict__ dW,                  // [F][K][F+G] fp32, += (atomics)
+    float* __restrict__ dbsum,               // [F] fp32, += sum_{t,b,n} dpre (or null); the caller scales by 2 (bias enters both filters)
     const int32_t* __restrict__ tile_nodes, const int32_t* __restrict__ tile_off,
     const float4* __restrict__ ell_val4, const uint2* __restrict__ ell_col4, int entries, int B, int Tn, int N) {
   constexpr int F = 32 * HS, G = 32 * XS, C = F + G, NCH = F / FC, JT = C / 16;
@@ -822,6 +855,7 @@ __global__ __launch_bounds__(512, 2) void fused_wgrad_kernel(
   float4* lval4 = reinterpret_cast<float4*>(smem + NP * FC * 4);
   uint2* lcol4 = reinterpret_cast<uint2*>(lval4 + entries * 4);
   char* tbuf = reinterpret_cast<char*>(lcol4 + entries * 4);
+  float* lbias = reinterpret_cast<float*>(tbuf + TBYTES);          // [16] bias-gradient partial sums of this workgroup
 
   const int L = blockIdx.x;
   const int grp = L / (8 * NCH), rem = L - grp * (8 * NCH);
@@ -855,6 +889,7 @@ __global__ __launch_bounds__(512, 2) void fused_wgrad_kernel(
   f32x4 accD[K];
 #pragma unroll
   for (int k = 0; k < K; ++k) accD[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (tid < FC) lbias[tid] = 0.f;
   const bool has_tile = wave < JT;
   const bool is_x = wave >= F / 16;                 // wave-uniform: tiles 0..F/16-1 are h features, the rest x features
   const int jrow = (is_x ? wave * 16 - F : wave * 16) + r;      // this lane's row (feature) inside its source block
@@ -888,6 +923,18 @@ __global__ __launch_bounds__(512, 2) void fused_wgrad_kernel(
       const u32x2 d2 = __builtin_amdgcn_raw_buffer_load_b64(rsrc_d, (wv >> 6) * (F * 2) + (chunk * FC + q * 4) * 2, soff_d, 0);
       cur[i] = f32x4{bf2f((uint16_t)(d2[0] & 0xffffu)), bf2f((uint16_t)(d2[0] >> 16)),
                      bf2f((uint16_t)(d2[1] & 0xffffu)), bf2f((uint16_t)(d2[1] >> 16))};
+    }
+    if (dbsum) {                                        // sum of dpre over this item's nodes (padded rows are zero)
+      f32x4 bacc = cur[0];
+#pragma unroll
+      for (int i = 1; i < TILES; ++i) bacc += cur[i];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        float v = bacc[c];
+#pragma unroll
+        for (int off = 1; off < 16; off <<= 1) v += __shfl_xor(v, off, 64);     // over the 16 slots r of this quad
+        if (r == 0) atomicAdd(lbias + q * 4 + c, v);
+      }
     }
 #pragma unroll
     for (int k = 0; k < K; ++k) {
@@ -981,13 +1028,15 @@ __global__ __launch_bounds__(512, 2) void fused_wgrad_kernel(
       for (int c = 0; c < 4; ++c)
         atomicAdd(dW + ((int64_t)(chunk * FC + q * 4 + c) * K + k) * C + wave * 16 + r, accD[k][c]);
   }
+  __syncthreads();
+  if (dbsum && tid < FC) atomicAdd(dbsum + chunk * FC + tid, lbias[tid]);
 }
 
 template <int K, int HS, int XS>
-static int fused_wgrad_t(const void* dpre, const void* Xuser, const void* Huser, const void* h0user, float* dW,
+static int fused_wgrad_t(const void* dpre, const void* Xuser, const void* Huser, const void* h0user, float* dW, float* dbsum,
                          const FusedGraphArgs& ga, int64_t B, int64_t T, int64_t N, hipStream_t st) {
   constexpr int F = 32 * HS;
-  const size_t lds = (size_t)NP * FC * 4 + (size_t)ga.entries * 96 + TBYTES;
+  const size_t lds = (size_t)NP * FC * 4 + (size_t)ga.entries * 96 + TBYTES + 64;
   if (lds > 160 * 1024 || !ga.ell_val4 || !ga.ell_col4) return GCRNN_ERR_UNSUPPORTED;
   auto kern = fused_wgrad_kernel<K, HS, XS>;
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
@@ -998,7 +1047,7 @@ static int fused_wgrad_t(const void* dpre, const void* Xuser, const void* Huser,
   if (slots > max_slots) slots = max_slots;
   GCRNN_PRE_LAUNCH();
   kern<<<(unsigned)(slots * NCH), 512, lds, st>>>((const uint16_t*)dpre, (const uint16_t*)Xuser, (const uint16_t*)Huser,
-                                                   (const uint16_t*)h0user, dW, ga.tile_nodes, ga.tile_off,
+                                                   (const uint16_t*)h0user, dW, dbsum, ga.tile_nodes, ga.tile_off,
                                                    (const float4*)ga.ell_val4, (const uint2*)ga.ell_col4, (int)ga.entries,
                                                    (int)B, (int)T, (int)N);
   GCRNN_CHECK_LAUNCH();
@@ -1006,7 +1055,7 @@ static int fused_wgrad_t(const void* dpre, const void* Xuser, const void* Huser,
 }
 
 extern "C" int gcrnn_fused_backward_weight_bf16(const void* dpre, const void* Xuser, const void* Huser, const void* h0user,
-                                                float* dW, const int32_t* tile_nodes, const int32_t* tile_off,
+                                                float* dW, float* dbsum, const int32_t* tile_nodes, const int32_t* tile_off,
                                                 const void* ell_val4, const void* ell_col4, int64_t entries, int64_t B,
                                                 int64_t T, int64_t N, int64_t F, int64_t G, int64_t K, void* stream) {
   if (!dpre || !Xuser || !Huser || !h0user || !dW || !tile_nodes || !tile_off || !ell_val4 || !ell_col4) return GCRNN_ERR_NULL_POINTER;
@@ -1015,7 +1064,7 @@ extern "C" int gcrnn_fused_backward_weight_bf16(const void* dpre, const void* Xu
   const FusedGraphArgs ga{tile_nodes, tile_off, nullptr, nullptr, ell_val4, ell_col4, entries};
   hipStream_t st = as_stream(stream);
 #define GCRNN_WG_CASE(KK, HH, XX) \
-  if (K == KK && F == 32 * HH && G == 32 * XX) return fused_wgrad_t<KK, HH, XX>(dpre, Xuser, Huser, h0user, dW, ga, B, T, N, st);
+  if (K == KK && F == 32 * HH && G == 32 * XX) return fused_wgrad_t<KK, HH, XX>(dpre, Xuser, Huser, h0user, dW, dbsum, ga, B, T, N, st);
   GCRNN_WG_CASE(5, 2, 2)
   GCRNN_WG_CASE(4, 2, 2)
   GCRNN_WG_CASE(3, 2, 2)

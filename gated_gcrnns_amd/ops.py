@@ -232,7 +232,7 @@ def time_fused_step_kernel(X, h0, wA, wB, bias, graph, reps=3):
         check(lib.gcrnn_fused_forward_bf16(_p(xs), _p(h0s), _p(hs), _p(wpack), _p(b32), None, None,
                                            _p(plan['tile_nodes']), _p(plan['tile_off']), _p(plan['ell_col']),
                                            _p(plan['ell_val']), _p(plan['ell_val4']), _p(plan['ell_col4']),
-                                           plan['entries'], B, T, N, F, G, K, st), 'fused_forward')
+                                           plan['entries'], B, T, N, F, G, K, None, st), 'fused_forward')
     e1.record()
     torch.cuda.synchronize()
     return {'avg_us': 1e3 * e0.elapsed_time(e1) / (reps * T), 'launches': reps * T}
@@ -292,12 +292,14 @@ def fused_cell_forward(X, h0, wA, wB, bias, graph, gates=None, return_states=Fal
         gi, gf = g['in'], g['forget']
     wpack = _fused_pack_weights(wA, wB, st)
     b32 = bias.detach().float().contiguous().view(-1) if bias is not None else None
-    check(lib.gcrnn_fused_forward_bf16(_p(xs), _p(h0s), _p(hs), _p(wpack), _p(b32), _p(gi), _p(gf), *gargs,
-                                       B, T, N, F, G, K, st), 'fused_forward')
-    if return_states:
-        return hs, plan
     H = torch.empty((B, T, F, N), dtype=torch.bfloat16, device=dev)
-    check(lib.gcrnn_unpack_seq_major(_lib.BF16, _p(hs), _p(H), B, T, F, N, npad, None, st), 'unpack_seq')
+    direct = (N % 8 == 0)                 # the step kernels write the user layout themselves (16-byte row stores)
+    check(lib.gcrnn_fused_forward_bf16(_p(xs), _p(h0s), _p(hs), _p(wpack), _p(b32), _p(gi), _p(gf), *gargs,
+                                       B, T, N, F, G, K, _p(H) if direct else None, st), 'fused_forward')
+    if not direct:
+        check(lib.gcrnn_unpack_seq_major(_lib.BF16, _p(hs), _p(H), B, T, F, N, npad, None, st), 'unpack_seq')
+    if return_states:
+        return hs, plan, H
     return H
 
 
@@ -321,17 +323,19 @@ def fused_backward_data(dHs, hs, wB, graph, want_dh0=True):
     return dpre, dh0
 
 
-def fused_backward_weight(dpre, X, H, h0, graph, F, G, K):
+def fused_backward_weight(dpre, X, H, h0, graph, F, G, K, want_bias=False):
     """dW [F][K][F+G] fp32 (columns: F state features, then G input features) from dpre (sequence-major bf16) and the
-    user-layout bf16 tensors X [B][T][G][N], H [B][T][F][N] (forward output), h0 [B][F][N]."""
+    user-layout bf16 tensors X [B][T][G][N], H [B][T][F][N] (forward output), h0 [B][F][N].
+    With want_bias also returns sum_{t,b,n} dpre [F] (the bias gradient is twice that)."""
     T, B = dpre.shape[0], dpre.shape[1]
     plan = graph.fused_plan(adjoint=True)
     dW = torch.zeros((F, K, F + G), dtype=torch.float32, device=dpre.device)
+    dbs = torch.zeros(F, dtype=torch.float32, device=dpre.device) if want_bias else None
     check(lib.gcrnn_fused_backward_weight_bf16(_p(dpre), _p(X.contiguous()), _p(H.contiguous()), _p(h0.contiguous()), _p(dW),
-                                               _p(plan['tile_nodes']), _p(plan['tile_off']), _p(plan['ell_val4']),
+                                               _p(dbs), _p(plan['tile_nodes']), _p(plan['tile_off']), _p(plan['ell_val4']),
                                                _p(plan['ell_col4']), plan['entries'], B, T, graph.N, F, G, K, _stream()),
           'fused_backward_weight')
-    return dW
+    return (dW, dbs) if want_bias else dW
 
 
 def fused_training_supported(graph, N, F, G, Kin, Kst, E=1):
@@ -340,7 +344,7 @@ def fused_training_supported(graph, N, F, G, Kin, Kst, E=1):
     if E != 1 or N % 8 != 0 or not bool(lib.gcrnn_fused_supported(int(N), int(F), int(G), int(max(Kin, Kst)))):
         return False
     entries = graph.fused_plan(adjoint=True)['entries']
-    return 65536 + 96 * entries + 16 * 1056 <= 160 * 1024
+    return 65536 + 96 * entries + 16 * 1056 + 64 <= 160 * 1024
 
 
 class _FusedCell(torch.autograd.Function):
@@ -352,11 +356,7 @@ class _FusedCell(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, X, h0, wA, wB, bias, graph):
-        hs, plan = fused_cell_forward(X, h0, wA, wB, bias, graph, return_states=True)
-        B, T, G, N = X.shape
-        F = wA.shape[0]
-        H = torch.empty((B, T, F, N), dtype=torch.bfloat16, device=X.device)
-        check(lib.gcrnn_unpack_seq_major(_lib.BF16, _p(hs), _p(H), B, T, F, N, plan['npad'], None, _stream()), 'unpack_seq')
+        hs, plan, H = fused_cell_forward(X, h0, wA, wB, bias, graph, return_states=True)
         ctx.save_for_backward(X, h0, wA, wB, bias, H, hs)
         ctx.graph = graph
         ctx.npad = plan['npad']
@@ -377,12 +377,11 @@ class _FusedCell(torch.autograd.Function):
         check(lib.gcrnn_pack_seq_major(_lib.BF16, _p(dH), _p(dHs), B, T, F, N, npad, None, st), 'pack_seq')
         wBk = wB if Kst == K else torch.cat([wB, wB.new_zeros(F, 1, K - Kst, F)], dim=2)
         dpre, dh0s = fused_backward_data(dHs, hs, wBk, graph, want_dh0=ctx.needs_input_grad[1])
-        dW = fused_backward_weight(dpre, X, H, h0, graph, F, G, K)                  # [F][K][F+G] fp32
+        want_b = bias is not None and ctx.needs_input_grad[4]
+        dW, dbs = fused_backward_weight(dpre, X, H, h0, graph, F, G, K, want_bias=True)       # [F][K][F+G], [F] fp32
         gA = dW[:, :Kin, F:].unsqueeze(1).to(wA.dtype) if ctx.needs_input_grad[2] else None
         gB = dW[:, :Kst, :F].unsqueeze(1).to(wB.dtype) if ctx.needs_input_grad[3] else None
-        gb = None
-        if bias is not None and ctx.needs_input_grad[4]:
-            gb = (2.0 * dpre.float().sum(dim=(0, 1, 2))).view_as(bias).to(bias.dtype)   # the bias enters both filters
+        gb = (2.0 * dbs).view_as(bias).to(bias.dtype) if want_b else None            # the bias enters both filters
         gh0 = None
         if ctx.needs_input_grad[1]:
             gh0 = torch.empty((B, 1, F, N), dtype=torch.bfloat16, device=X.device)

@@ -131,12 +131,14 @@ int gcrnn_fused_pack_weights(int wdtype, const void* wA, const void* wB, void* w
  * bias fp32 [F] or NULL; gi / gf fp32 [T][B] time gates or both NULL (un-gated);
  * tile_nodes int32 [NPad] = order padded with the unused row ids N..NPad-1; entries = tile_off[ntiles].
  * ell_val4 / ell_col4 = device copies of gcrnn_ell_pack_lds's output (may be NULL).
+ * Huser (may be NULL; needs N % 8 == 0): the states are ALSO written in the user layout H[B][T][F][N] by the step kernels
+ * themselves (LDS-transposed 16-byte row stores), which replaces gcrnn_unpack_seq_major over the whole sequence.
  * T launches on `stream`. The graph is kept resident in LDS when 64 KiB + weights + 96*entries B <= 160 KiB. */
 int gcrnn_fused_forward_bf16(const void* xs, const void* h0, void* hs, const void* wpack, const float* bias,
                              const float* gi, const float* gf, const int32_t* tile_nodes, const int32_t* tile_off,
                              const int32_t* ell_col, const float* ell_val, const void* ell_val4, const void* ell_col4,
                              int64_t entries, int64_t B, int64_t T, int64_t N, int64_t F, int64_t G, int64_t K,
-                             void* stream);
+                             void* Huser, void* stream);
 
 /* Time-gate pre-pass (graphML.py:2357-2374): for every (t, b)
  *   sum over gate_out[t][b][0 .. F/16*8) = sum_{n,f} tanh( A_g(S) x_t + B_g(S) h0 + 2 b_g )[n][f] * gate_w[n][f]
@@ -169,7 +171,7 @@ int gcrnn_fused_backward_data_bf16(const void* dHs, const void* hs, void* dpre, 
  * dW fp32 [F][K][F+G], accumulated with atomics (caller zeroes); graph arrays = LDS image of the ELL of CSR(S).
  * Returns GCRNN_ERR_UNSUPPORTED when the graph image does not fit in LDS next to the state. */
 int gcrnn_fused_backward_weight_bf16(const void* dpre, const void* Xuser, const void* Huser, const void* h0user, float* dW,
-                                     const int32_t* tile_nodes, const int32_t* tile_off, const void* ell_val4,
+                                     float* dbsum /* [F] += sum dpre, or NULL; bias gradient = 2 * dbsum */, const int32_t* tile_nodes, const int32_t* tile_off, const void* ell_val4,
                                      const void* ell_col4, int64_t entries, int64_t B, int64_t T, int64_t N, int64_t F,
                                      int64_t G, int64_t K, void* stream);
 

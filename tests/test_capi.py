@@ -122,3 +122,29 @@ def test_gso_cache_is_not_fooled_by_recycled_storage():
         seen.append(S.data_ptr())
         del S, op
         gc.collect()
+
+
+def test_fused_kernels_are_spill_free():
+    """The hop pipelines keep inline-asm ds_read destinations in flight across compiler-scheduled code; a register spill
+    (scratch) in those kernels could save such a register before its data has landed. Enforce ScratchSize == 0 for every
+    fused kernel instantiation at build time (hipcc cross-compiles without a GPU)."""
+    import subprocess
+    from gated_gcrnns_amd import build as b
+    if not os.path.exists(b.HIPCC):
+        pytest.skip('hipcc not available')
+    src = os.path.join(b.CSRC, 'gcrnn_fused.hip')
+    out = subprocess.run([b.HIPCC, '-O3', '-std=c++17', '--offload-arch=gfx950', '-fPIC', '-c', src, '-o', os.devnull,
+                          '-Rpass-analysis=kernel-resource-usage'], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr[-2000:]
+    cur, bad, seen = None, [], 0
+    for line in out.stderr.splitlines():
+        m = re.search(r'Function Name: (\S+)', line)
+        if m:
+            cur = m.group(1)
+            continue
+        m = re.search(r'ScratchSize \[bytes/lane\]: (\d+)', line)
+        if m and cur and ('fused_step_kernel' in cur or 'fused_wgrad_kernel' in cur):
+            seen += 1
+            if int(m.group(1)) != 0:
+                bad.append((cur[:70], int(m.group(1))))
+    assert seen >= 20 and not bad, bad

@@ -188,7 +188,7 @@ def test_fused_backward_data_chain(N, F, K, B, T):
     with torch.no_grad():
         Xd = torch.tensor(X, dtype=torch.bfloat16, device=dev)
         hd = torch.tensor(h0, dtype=torch.bfloat16, device=dev)
-        hs, plan = ops.fused_cell_forward(Xd, hd, cell.weight_A, cell.weight_B, cell.bias, cell.graph, return_states=True)
+        hs, plan, _Hu = ops.fused_cell_forward(Xd, hd, cell.weight_A, cell.weight_B, cell.bias, cell.graph, return_states=True)
         npad = plan['npad']
         dHd = torch.tensor(dH, dtype=torch.bfloat16, device=dev)
         dHs = torch.empty((T, B, npad, F), dtype=torch.bfloat16, device=dev)
@@ -204,8 +204,9 @@ def test_fused_backward_data_chain(N, F, K, B, T):
     with torch.no_grad():
         H = torch.empty((B, T, F, N), dtype=torch.bfloat16, device=dev)
         _lib.check(_lib.lib.gcrnn_unpack_seq_major(_lib.BF16, ops._p(hs), ops._p(H), B, T, F, N, npad, None, ops._stream()), 'unpack')
-        dW = ops.fused_backward_weight(dpre, Xd, H, hd, cell.graph, F, G, K).cpu().numpy()
-        db = 2.0 * dpre.float().sum(dim=(0, 1, 2)).cpu().numpy()
+        dW, dbs = ops.fused_backward_weight(dpre, Xd, H, hd, cell.graph, F, G, K, want_bias=True)
+        dW, db = dW.cpu().numpy(), 2.0 * dbs.cpu().numpy()
+        assert np.allclose(db, 2.0 * dpre.float().sum(dim=(0, 1, 2)).cpu().numpy(), rtol=1e-3, atol=1e-3 * np.abs(db).max())
     ref_cell = _bwd_reference(S, params, X, h0, dH)[0]
     gB = ref_cell.weight_B.grad[:, 0].cpu().numpy()          # [F][K][F]
     gA = ref_cell.weight_A.grad[:, 0].cpu().numpy()          # [F][K][G]
