@@ -955,9 +955,13 @@ __global__ __launch_bounds__(512, 2) void fused_wgrad_kernel(
       // S2: D_k += du_k^T z over nodes 0..511
       if (has_tile) {
 #pragma unroll
-        for (int s2 = 0; s2 < 16; ++s2) {
-          const bf16x8 a = *reinterpret_cast<const bf16x8*>(tbuf + r * TSTRIDE + (32 * s2 + 8 * q) * 2);
-          accD[k] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bfr[s2], accD[k], 0, 0, 0);
+        for (int s4 = 0; s4 < 16; s4 += 4) {            // 4 A fragments in flight per batch: LDS latency overlaps the MFMAs
+          bf16x8 a4[4];
+#pragma unroll
+          for (int p = 0; p < 4; ++p)
+            a4[p] = *reinterpret_cast<const bf16x8*>(tbuf + r * TSTRIDE + (32 * (s4 + p) + 8 * q) * 2);
+#pragma unroll
+          for (int p = 0; p < 4; ++p) accD[k] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a4[p], bfr[s4 + p], accD[k], 0, 0, 0);
         }
       }
       __syncthreads();
@@ -1010,11 +1014,12 @@ __global__ __launch_bounds__(512, 2) void fused_wgrad_kernel(
 #pragma unroll
           for (int s2 = 0; s2 < 8; ++s2)
             bl[s2] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsrc_z, vo + 64 * (16 + 8 * h2 + s2), 0, 0));
+          bf16x8 al[8];
 #pragma unroll
-          for (int s2 = 0; s2 < 8; ++s2) {
-            const bf16x8 a = *reinterpret_cast<const bf16x8*>(tbuf + r * TSTRIDE + (32 * (8 * h2 + s2) + 8 * q) * 2);
-            accD[k] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bl[s2], accD[k], 0, 0, 0);
-          }
+          for (int s2 = 0; s2 < 8; ++s2)
+            al[s2] = *reinterpret_cast<const bf16x8*>(tbuf + r * TSTRIDE + (32 * (8 * h2 + s2) + 8 * q) * 2);
+#pragma unroll
+          for (int s2 = 0; s2 < 8; ++s2) accD[k] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[s2], bl[s2], accD[k], 0, 0, 0);
         }
       }
       __syncthreads();
