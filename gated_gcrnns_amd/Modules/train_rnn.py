@@ -117,3 +117,49 @@ def MultipleModels(modelsDict, xTrain, yTrain, xValid, yValid, nEpochs, batchSiz
             for m in modelsDict.values():
                 m.save(label='Last')
     return dict(lossTrain=lossTrain, evalTrain=evalTrain, evalValid=evalValid, timeTrain=timeTrain, bestScore=best)
+
+
+class GraphedTrainStep(object):
+    """One optimiser step (zero_grad -> forward -> loss -> BPTT -> Adam) captured as a hipGraph and replayed.
+
+    The reference's training configurations (N = 50..80 nodes, T = 5..20, batch 100; kStepPredGRNNs.py:110-127) are
+    launch-bound on a GPU: a step is several hundred tiny kernels. Capturing the whole step removes the per-launch host
+    cost. Inputs are copied into static buffers; the optimiser must be created with capturable=True (torch.optim.Adam).
+
+        step = GraphedTrainStep(archit, loss_fn, optim, x_example, y_example, stateFeat)
+        loss = step(x, y)        # x, y: B x T x 1 x N on the device, same shapes as the examples
+    """
+
+    def __init__(self, archit, loss_fn, optim, x, y, stateFeat, sync=None):
+        self.x = x.clone()
+        self.y = y.clone()
+        self.archit, self.loss_fn, self.optim = archit, loss_fn, optim
+        B, N = x.shape[0], x.shape[3]
+        self.h0 = torch.zeros(B, stateFeat, N, dtype=x.dtype, device=x.device)
+        assert sync is None, 'capture the single-GPU step; the flat all-reduce stays outside the graph'
+        s = torch.cuda.Stream(device=x.device)
+        s.wait_stream(torch.cuda.current_stream(x.device))
+        with torch.cuda.stream(s):
+            for _ in range(3):                                   # warm-up: allocator, lazily created optimiser state
+                self._eager()
+        torch.cuda.current_stream(x.device).wait_stream(s)
+        self.graph = torch.cuda.CUDAGraph()
+        self.optim.zero_grad(set_to_none=True)
+        with torch.cuda.graph(self.graph):
+            self.yHat = self.archit(self.x, self.h0)
+            self.loss = self.loss_fn(self.yHat, self.y)
+            self.loss.backward()
+            self.optim.step()
+
+    def _eager(self):
+        self.optim.zero_grad(set_to_none=True)
+        loss = self.loss_fn(self.archit(self.x, self.h0), self.y)
+        loss.backward()
+        self.optim.step()
+        return loss
+
+    def __call__(self, x, y):
+        self.x.copy_(x)
+        self.y.copy_(y)
+        self.graph.replay()
+        return self.loss.detach(), self.yHat.detach()

@@ -275,17 +275,30 @@ __global__ __launch_bounds__(256) void gemm64_kernel(AL a, BL b, CS c, int64_t M
   }
 }
 
-// dbias[f] += scale * sum_r dy[r][f]
+// dbias[f] += scale * sum_r dy[r][f].  256 threads = (256 / FP) row lanes x FP column lanes (FP = F rounded up to a
+// power of two, <= 256): every thread sums a strided subset of the block's rows, an LDS tree folds the row lanes,
+// one atomic per column and block.
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ dy, T* __restrict__ dbias, T scale,
-                                                     int64_t rows, int F, int64_t rows_per_block) {
+                                                     int64_t rows, int F, int FP, int64_t rows_per_block) {
+  __shared__ T part[256];
   const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
   const int64_t r1 = (r0 + rows_per_block < rows) ? r0 + rows_per_block : rows;
-  // thread handles column f = tid % Fp over rows tid / Fp + i * (256 / Fp); generic: loop columns
-  for (int f = threadIdx.x; f < F; f += blockDim.x) {
+  const int RL = 256 / FP;                       // row lanes
+  const int cf = threadIdx.x % FP, rl = threadIdx.x / FP;
+  for (int f0 = 0; f0 < F; f0 += FP) {
+    const int f = f0 + cf;
     T s = T(0);
-    for (int64_t r = r0; r < r1; ++r) s += dy[r * F + f];
-    atomicAdd(dbias + f, scale * s);
+    if (f < F)
+      for (int64_t r = r0 + rl; r < r1; r += RL) s += dy[r * F + f];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    for (int step = RL >> 1; step > 0; step >>= 1) {
+      if (rl < step) part[threadIdx.x] += part[threadIdx.x + step * FP];
+      __syncthreads();
+    }
+    if (rl == 0 && f < F) atomicAdd(dbias + f, scale * part[cf]);
+    __syncthreads();
   }
 }
 
@@ -353,7 +366,7 @@ static int taps_bwd_weight(const void* dy, const void* z0, const void* zrest, in
   const int64_t tiles = cdiv(F, 64) * cdiv(Kd, 64);
   int64_t splits = cdiv(1024, tiles);
   int64_t ksplit = cdiv(cdiv(rows, splits), 16) * 16;
-  if (ksplit < 256) ksplit = 256;
+  if (ksplit < 64) ksplit = 64;
   splits = cdiv(rows, ksplit);
   if (splits > 65535) { ksplit = cdiv(cdiv(rows, 65535), 16) * 16; splits = cdiv(rows, ksplit); }
   GCRNN_PRE_LAUNCH();
@@ -361,9 +374,13 @@ static int taps_bwd_weight(const void* dy, const void* z0, const void* zrest, in
   gemm64_kernel<T><<<grid, 256, 0, as_stream(stream)>>>(a, b, c, F, Kd, rows, ksplit);
   GCRNN_CHECK_LAUNCH();
   if (dbias) {
-    const int64_t rpb = 512;
+    int FP = 1;
+    while (FP < F && FP < 256) FP <<= 1;
+    int64_t rpb = cdiv(rows, 512);                 // ~512 blocks, at least 256/FP * 8 rows each
+    const int64_t min_rpb = (int64_t)(256 / FP) * 8;
+    if (rpb < min_rpb) rpb = min_rpb;
     colsum_kernel<T><<<(unsigned)cdiv(rows, rpb), 256, 0, as_stream(stream)>>>((const T*)dy, (T*)dbias, (T)bias_scale,
-                                                                                rows, (int)F, rpb);
+                                                                                rows, (int)F, FP, rpb);
     GCRNN_CHECK_LAUNCH();
   }
   return GCRNN_OK;

@@ -1,0 +1,36 @@
+#!/usr/bin/env python3
+"""Reference-driver-sized training step (N=80 SBM, taps 5, T=5, F=20, batch 100, fp64; kStepPredGRNNs.py defaults, BASELINE.md
+row R9): eager composed path vs the whole step captured as one hipGraph.  python3 tools/graphed_train_bench.py"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+import gated_gcrnns_amd.Modules.architectures as archit
+from gated_gcrnns_amd.Modules.train_rnn import train_step, GraphedTrainStep
+from gated_gcrnns_amd.Utils import dataTools, miscTools
+
+dev = torch.device('cuda:0')
+torch.set_default_dtype(torch.float64)
+rng = np.random.default_rng(0)
+W = dataTools.sbm_adjacency(80, 5, 0.8, 0.2, rng)
+S = dataTools.normalised_gso(W)
+data = dataTools.KStepPrediction(W, 5, 400, 10, 10, horizon=10, rng=rng)
+xT, yT = data.getSamples('train')
+x = xT[:100].view(100, 5, 1, 80).to(dev); y = yT[:100].view(100, 5, 1, 80).to(dev)
+for name, tg, sg in (('GCRNNMLP', False, None), ('TimeGCRNNMLP', True, None), ('NodeGCRNNMLP', False, 'node')):
+    res = {}
+    for mode in ('eager', 'hipgraph'):
+        torch.manual_seed(0)
+        m = archit.GatedGCRNNforRegression(1, 20, 5, 5, torch.tanh, torch.nn.ReLU, [1], S, True, time_gating=tg, spatial_gating=sg,
+                                           mlpType='multipMlp').to(dev)
+        opt = torch.optim.Adam(m.parameters(), lr=1e-3, capturable=(mode == 'hipgraph'))
+        if mode == 'eager':
+            fn = lambda: train_step(m, miscTools.batchTimeL1Loss, opt, x, y, 20)[0]
+        else:
+            g = GraphedTrainStep(m, miscTools.batchTimeL1Loss, opt, x, y, 20)
+            fn = lambda: g(x, y)[0]
+        for _ in range(3): l = fn()
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(20): l = fn()
+        torch.cuda.synchronize(); res[mode] = ((time.perf_counter() - t0) / 20, float(l))
+    print('%-14s fp64 B=100: eager %.2f ms/step (%.0f seq/s)   hipGraph %.2f ms/step (%.0f seq/s)   loss %.5f / %.5f' % (
+        name, 1e3 * res['eager'][0], 100 / res['eager'][0], 1e3 * res['hipgraph'][0], 100 / res['hipgraph'][0], res['eager'][1], res['hipgraph'][1]))
