@@ -11,6 +11,7 @@ import torch
 import torch.nn as nn
 
 from ..Utils import graphML as gml
+from .. import ops
 
 
 def _as_gso_tensor(GSO):
@@ -23,41 +24,11 @@ def _as_gso_tensor(GSO):
     return torch.tensor(np.asarray(GSO)) if not isinstance(GSO, torch.Tensor) else GSO
 
 
-class _RowLinearFn(torch.autograd.Function):
-    """y = x W^T + b over a huge number of rows (x: R x in, R = B*T*N for the per-node head). The weight gradient
-    dW = dy^T x reduces over R; a single out x R x in GEMM with out, in ~ 1..20 and R ~ 1e5..1e7 is a shape BLAS libraries
-    handle badly (measured: 4.3 ms per call in fp64 for 1 x 40000 x 20), so the reduction is split into R/C-deep batched
-    GEMMs followed by a sum over the C chunks."""
-
-    @staticmethod
-    def forward(ctx, x, w, b):
-        ctx.save_for_backward(x, w)
-        ctx.has_bias = b is not None
-        y = x @ w.t()
-        return y + b if b is not None else y
-
-    @staticmethod
-    def backward(ctx, dy):
-        x, w = ctx.saved_tensors
-        R = x.shape[0]
-        dx = dy @ w if ctx.needs_input_grad[0] else None
-        dw = db = None
-        if ctx.needs_input_grad[1]:
-            C = max(1, min(256, R // 512))
-            Rc = (R // C) * C
-            dw = torch.bmm(dy[:Rc].reshape(C, R // C, -1).transpose(1, 2), x[:Rc].reshape(C, R // C, -1)).sum(0)
-            if Rc < R:
-                dw = dw + dy[Rc:].t() @ x[Rc:]
-        if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = dy.sum(0)
-        return dx, dw, db
-
-
 def _apply_mlp_rows(mlp, x2d):
     """nn.Sequential of Linear / activation modules applied to rows, Linear layers through _RowLinearFn."""
     for layer in mlp:
         if isinstance(layer, nn.Linear):
-            x2d = _RowLinearFn.apply(x2d, layer.weight, layer.bias)
+            x2d = ops.row_linear(x2d, layer.weight, layer.bias)
         else:
             x2d = layer(x2d)
     return x2d

@@ -103,30 +103,22 @@ class GraphFilter(nn.Module):
 def _graph_attention_node_major(u, mixer, weight, graph, negative_slope=0.2):
     """GAT on the CSR support of S + I (reference graphAttention, graphML.py:521-627), node-major.
 
-    u: [N][B][G]; mixer: K x E x 2F; weight: K x E x F x G  ->  [N][B][K*F] (heads concatenated, pre-ReLU).
+    u: [T][N][B][G]; mixer: K x E x 2F; weight: K x E x F x G  ->  [T][N][B][K*F] (heads concatenated, pre-ReLU).
     Edge (m, n) of the support carries e = LeakyReLU(a1.Wx_n + a2.Wx_m); alpha = softmax over the
     neighbours n of row m; y_n = sum_m Wx_m (S+I)[m, n] alpha[m, n].
     """
-    N, B, G = u.shape
     K, E, F, _ = weight.shape
-    rows, cols = graph.mask.rows(), graph.mask.col.long()
     outs = []
     for k in range(K):
         yk = None
         for e in range(E):
-            Wx = torch.matmul(u, weight[k, e].t())                    # N x B x F
-            s1 = torch.matmul(Wx, mixer[k, e, :F])                    # N x B   (a1 . Wx_n)
-            s2 = torch.matmul(Wx, mixer[k, e, F:])                    # N x B   (a2 . Wx_m)
-            eij = nn.functional.leaky_relu(s1[cols] + s2[rows], negative_slope)     # nnz x B
-            mx = torch.full((N, B), -float('inf'), dtype=u.dtype, device=u.device).scatter_reduce(
-                0, rows.view(-1, 1).expand(-1, B), eij, 'amax', include_self=True)
-            ex = torch.exp(eij - mx[rows])
-            den = torch.zeros((N, B), dtype=u.dtype, device=u.device).index_add_(0, rows, ex)
-            coef = (ex / den[rows]) * graph.mask_vals[e].to(u.dtype).view(-1, 1)    # (S+I)[m,n] alpha[m,n]
-            y = torch.zeros((N, B, F), dtype=u.dtype, device=u.device).index_add_(0, cols, Wx[rows] * coef.unsqueeze(2))
+            Wx = ops.row_linear(u.reshape(-1, u.shape[3]), weight[k, e])          # (T N B) x F
+            s12 = ops.row_linear(Wx, mixer[k, e].view(2, F))                      # a1 . Wx_n | a2 . Wx_m
+            y = ops.edge_attention(Wx.view(*u.shape[:3], F), s12[:, 0].reshape(u.shape[:3]),
+                                   s12[:, 1].reshape(u.shape[:3]), graph, e, negative_slope)
             yk = y if yk is None else yk + y
         outs.append(yk)
-    return torch.cat(outs, dim=2)
+    return outs[0] if K == 1 else torch.cat(outs, dim=3)
 
 
 class GraphAttentional(nn.Module):
@@ -163,16 +155,11 @@ class GraphAttentional(nn.Module):
 
     def forward_node_major(self, un):
         """un: [T][N][B][G] -> [T][N][B][K*F] (concatenate) or [T][N][B][F] (mean)."""
-        outs = []
-        for t in range(un.shape[0]):
-            y = _graph_attention_node_major(un[t], self.mixer, self.weight, self.graph)
-            if self.concatenate:
-                y = self.nonlinearity(y)                                     # reference graphML.py:2101
-            else:
-                N, B, _ = y.shape
-                y = self.nonlinearity(y.view(N, B, self.K, self.F).mean(dim=2))   # reference graphML.py:2110-2112
-            outs.append(y)
-        return torch.stack(outs, 0)
+        y = _graph_attention_node_major(un, self.mixer, self.weight, self.graph)
+        if self.concatenate:
+            return self.nonlinearity(y)                                      # reference graphML.py:2101
+        T, N, B, _ = y.shape
+        return self.nonlinearity(y.view(T, N, B, self.K, self.F).mean(dim=3))     # reference graphML.py:2110-2112
 
     def forward(self, x):
         ops.require_device(x)

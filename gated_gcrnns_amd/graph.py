@@ -106,6 +106,24 @@ class GraphOperator(object):
         self.mask_vals = [torch.from_numpy(np.ascontiguousarray(Splus[e][rows, col])).to(self.device) for e in range(self.E)]
         self.nnz = sum(c.nnz for c in self.fwd)
 
+    def mask_transposed(self):
+        """Transposed attention support: (t_rowptr int32 [N+1], t_row int32 [nnz], t_pos int32 [nnz], edge_row int32 [nnz])
+        -- for column n the rows m with (m, n) in the support and the position of that edge in mask.col / mask_vals;
+        edge_row = the row of every edge in mask order."""
+        mt = self.__dict__.get('_mask_t')
+        if mt is None:
+            rp = self.mask.rowptr.cpu().numpy().astype(np.int64)
+            col = self.mask.col.cpu().numpy()
+            rows = np.repeat(np.arange(self.N, dtype=np.int32), np.diff(rp))
+            order = np.lexsort((rows, col))                          # by (column, row)
+            t_rowptr = np.zeros(self.N + 1, dtype=np.int64)
+            np.add.at(t_rowptr, col.astype(np.int64) + 1, 1)
+            t_rowptr = np.cumsum(t_rowptr).astype(np.int32)
+            mt = tuple(torch.from_numpy(np.ascontiguousarray(a)).to(self.device)
+                       for a in (t_rowptr, rows[order].astype(np.int32), order.astype(np.int32), rows))
+            self._mask_t = mt
+        return mt
+
     def fused_plan(self, adjoint=False):
         """Degree-sorted sliced ELL of CSR(S^T) (forward shift) or, with adjoint=True, of CSR(S) (the shift of the
         backward pass) for the fused step kernels (E = 1): device tensors order (int32 [N]), tile_off

@@ -225,6 +225,8 @@ def time_fused_step_kernel(X, h0, wA, wB, bias, graph, reps=3):
     check(lib.gcrnn_fused_pack_weights(dtype_code(wA.dtype), _p(wA.contiguous()), _p(wB.contiguous()), _p(wpack),
                                        F, G, Kin, Kst, st), 'pack_weights')
     b32 = bias.detach().float().contiguous().view(-1) if bias is not None else None
+    # same launch configuration as fused_cell_forward: the kernel also writes the user-layout output when it can
+    H = torch.empty((B, T, F, N), dtype=torch.bfloat16, device=dev) if N % 8 == 0 else None
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize()
     e0.record()
@@ -232,7 +234,8 @@ def time_fused_step_kernel(X, h0, wA, wB, bias, graph, reps=3):
         check(lib.gcrnn_fused_forward_bf16(_p(xs), _p(h0s), _p(hs), _p(wpack), _p(b32), None, None,
                                            _p(plan['tile_nodes']), _p(plan['tile_off']), _p(plan['ell_col']),
                                            _p(plan['ell_val']), _p(plan['ell_val4']), _p(plan['ell_col4']),
-                                           plan['entries'], B, T, N, F, G, K, None, st), 'fused_forward')
+                                           plan['entries'], B, T, N, F, G, K, _p(H) if H is not None else None, st),
+              'fused_forward')
     e1.record()
     torch.cuda.synchronize()
     return {'avg_us': 1e3 * e0.elapsed_time(e1) / (reps * T), 'launches': reps * T}
@@ -418,6 +421,84 @@ def small_cell_forward(X, h0, wA, wB, bias, graph, gi=None, gf=None):
                                   _p(csr.val(X.dtype)), _p(H), B, T, N, G, F, Kin, Kst, csr.nnz, _stream()),
           'small_forward')
     return H
+
+
+# ------------------------------------------------------------------------------------------ row-linear layers
+class _RowLinear(torch.autograd.Function):
+    """y = x W^T (+ b) over a huge number of rows (x: R x in; R = T*N*B node-rows of the per-node head and of the
+    attention projections). The weight gradient dW = dy^T x reduces over R: a single out x R x in GEMM / GEMV with
+    out, in ~ 1..64 and R ~ 1e5..1e7 is a shape the BLAS back ends handle badly (measured: 4.3 ms per call in fp64
+    for 1 x 40000 x 20), so the reduction is split into R/C-deep batched GEMMs followed by a sum over the C chunks."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = b is not None
+        y = x @ w.t()
+        return y + b if b is not None else y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        R = x.shape[0]
+        dx = dy @ w if ctx.needs_input_grad[0] else None
+        dw = db = None
+        if ctx.needs_input_grad[1]:
+            C = max(1, min(256, R // 512))
+            Rc = (R // C) * C
+            dw = torch.bmm(dy[:Rc].reshape(C, R // C, -1).transpose(1, 2), x[:Rc].reshape(C, R // C, -1)).sum(0)
+            if Rc < R:
+                dw = dw + dy[Rc:].t() @ x[Rc:]
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = dy.sum(0)
+        return dx, dw, db
+
+
+def row_linear(x2d, weight, bias=None):
+    return _RowLinear.apply(x2d, weight, bias)
+
+
+# ------------------------------------------------------------------------------------------ edge gate (attention)
+class _EdgeAttention(torch.autograd.Function):
+    """y[t, n] = sum_m softmax_row_m(LeakyReLU(s1[n] + s2[m])) (S+I)[m, n] Wx[t, m] on the CSR support (reference
+    graphAttention, graphML.py:605-625). Wx: [T][N][B][F], s1 / s2: [T][N][B]."""
+
+    @staticmethod
+    def forward(ctx, Wx, s1, s2, graph, e, slope):
+        Wx, s1, s2 = Wx.contiguous(), s1.contiguous(), s2.contiguous()
+        require_device(Wx, s1, s2)
+        T, N, B, F = Wx.shape
+        m = graph.mask
+        val = graph.mask_vals[e].to(Wx.dtype)
+        trp, trow, tpos, _ = graph.mask_transposed()
+        alpha = torch.empty((T, m.nnz, B), dtype=Wx.dtype, device=Wx.device)
+        y = torch.empty_like(Wx)
+        check(lib.gcrnn_attention_forward(dtype_code(Wx.dtype), _p(m.rowptr), _p(m.col), _p(val), _p(trp), _p(trow),
+                                          _p(tpos), _p(Wx), _p(s1), _p(s2), _p(alpha), _p(y), T, N, B, F, m.nnz,
+                                          float(slope), _stream()), 'attention_forward')
+        ctx.save_for_backward(Wx, s1, s2, alpha, val)
+        ctx.graph, ctx.slope = graph, float(slope)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        Wx, s1, s2, alpha, val = ctx.saved_tensors
+        T, N, B, F = Wx.shape
+        m = ctx.graph.mask
+        trp, trow, tpos, erow = ctx.graph.mask_transposed()
+        dy = dy.contiguous()
+        dWx = torch.empty_like(Wx)
+        ds1 = torch.empty_like(s1)
+        ds2 = torch.empty_like(s2)
+        dz = torch.empty_like(alpha)
+        check(lib.gcrnn_attention_backward(dtype_code(Wx.dtype), _p(m.rowptr), _p(m.col), _p(val), _p(erow), _p(trp),
+                                           _p(tpos), _p(Wx), _p(s1), _p(s2), _p(alpha), _p(dy), _p(dWx), _p(ds1), _p(ds2), _p(dz),
+                                           T, N, B, F, m.nnz, ctx.slope, _stream()), 'attention_backward')
+        return dWx, ds1, ds2, None, None, None
+
+
+def edge_attention(Wx, s1, s2, graph, e=0, negative_slope=0.2):
+    return _EdgeAttention.apply(Wx, s1, s2, graph, e, negative_slope)
 
 
 # ------------------------------------------------------------------------------------------ hipGraph replay

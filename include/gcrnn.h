@@ -187,6 +187,24 @@ int gcrnn_small_forward(int dtype, const void* X, const void* h0, const void* wA
                         void* H, int64_t B, int64_t T, int64_t N, int64_t G, int64_t F, int64_t Kin, int64_t Kst,
                         int64_t nnz, void* stream);
 
+/* ==== edge gate: graph attention on the CSR support of S + I ====================================================
+ * Replaces graphAttention (graphML.py:521-627: dense B x N x N scores, mask, softmax, weighted sum) inside
+ * GraphAttentional.forward (graphML.py:2099-2107). Node-major, T independent slices, dtype F32 / F64:
+ *   Wx [T][N][B][F] = W u,  s1 / s2 [T][N][B] = a1 . Wx / a2 . Wx  (graphML.py:585-603),
+ *   support row m: neighbours col[j], values val[j] = (S + I)[m][col[j]], |.| > 1e-9 (graphML.py:577, 611-613);
+ *   transposed support: for column n, t_row[q] = m and t_pos[q] = index of edge (m, n) in col / val.
+ *   alpha [T][nnz][B] (out; softmax over each row of LeakyReLU(s1[n] + s2[m]), kept for backward),
+ *   y [T][N][B][F] (out) = sum_m alpha[m->n] val[m->n] Wx[m]  (graphML.py:625), before the nonlinearity.
+ * backward: dy -> dWx (through the aggregation only), ds1, ds2; dz_scratch [T][nnz][B]. No atomics: deterministic. */
+int gcrnn_attention_forward(int dtype, const int32_t* rowptr, const int32_t* col, const void* val, const int32_t* t_rowptr,
+                            const int32_t* t_row, const int32_t* t_pos, const void* Wx, const void* s1, const void* s2,
+                            void* alpha, void* y, int64_t T, int64_t N, int64_t B, int64_t F, int64_t nnz,
+                            double negative_slope, void* stream);
+int gcrnn_attention_backward(int dtype, const int32_t* rowptr, const int32_t* col, const void* val,
+                             const int32_t* edge_row /* [nnz] row m of every edge */, const int32_t* t_rowptr, const int32_t* t_pos, const void* Wx, const void* s1, const void* s2,
+                             const void* alpha, const void* dy, void* dWx, void* ds1, void* ds2, void* dz_scratch, int64_t T,
+                             int64_t N, int64_t B, int64_t F, int64_t nnz, double negative_slope, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

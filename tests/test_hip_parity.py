@@ -270,3 +270,45 @@ def test_small_graph_persistent_kernel_seismic(dev, tag, K):
             assert m.stateGCRNN._use_small(x, h0)
             assert maxdiff(m(x, h0), g['y']) <= 1e-10
             assert maxdiff(m.stateGCRNN(x, h0)[:, -1], g['h_last']) <= 1e-11
+
+
+def _attention_torch(Wx, s1, s2, graph, slope=0.2):
+    """Index-op restatement of the edge softmax on the support (autograd supplies the reference gradients)."""
+    Tn, N, B, F = Wx.shape
+    rows, cols = graph.mask.rows(), graph.mask.col.long()
+    v = graph.mask_vals[0].to(Wx.dtype).view(1, -1, 1)
+    e = torch.nn.functional.leaky_relu(s1[:, cols] + s2[:, rows], slope)                      # T x nnz x B
+    mx = torch.full((Tn, N, B), -float('inf'), dtype=Wx.dtype, device=Wx.device).scatter_reduce(
+        1, rows.view(1, -1, 1).expand(Tn, -1, B), e, 'amax', include_self=True)
+    ex = torch.exp(e - mx[:, rows])
+    den = torch.zeros((Tn, N, B), dtype=Wx.dtype, device=Wx.device).index_add_(1, rows, ex)
+    coef = ex / den[:, rows] * v
+    return torch.zeros_like(Wx).index_add_(1, cols, Wx[:, rows] * coef.unsqueeze(3))
+
+
+@pytest.mark.parametrize('dt,tol', [(torch.float64, 1e-12), (torch.float32, 2e-5)])
+@pytest.mark.parametrize('N,B,F,Tn', [(30, 3, 5, 4), (80, 100, 20, 5), (257, 7, 33, 2)])
+def test_edge_attention_kernels(dev, dt, tol, N, B, F, Tn):
+    """gcrnn_attention_forward / _backward vs the index-op restatement: directed weighted graph, isolated nodes,
+    a node whose self-loop cancels (S[m][m] = -1 -> (S+I)[m][m] = 0 leaves the support)."""
+    from gated_gcrnns_amd import ops
+    from gated_gcrnns_amd.graph import GraphOperator
+    rng = np.random.default_rng(N)
+    S = rng.standard_normal((N, N)) * (rng.random((N, N)) < 0.1)
+    S[3, :] = 0; S[:, 3] = 0                 # isolated node: only its self-loop is in the support
+    S[5, 5] = -1.0                           # (S + I)[5][5] = 0
+    graph = GraphOperator(S[None], device=dev)
+    gen = torch.Generator(device='cpu'); gen.manual_seed(0)
+    mk = lambda *s: torch.randn(*s, generator=gen, dtype=torch.float64).to(dev).to(dt).requires_grad_(True)
+    Wx, s1, s2 = mk(Tn, N, B, F), mk(Tn, N, B), mk(Tn, N, B)
+    r = torch.randn(Tn, N, B, F, generator=gen, dtype=torch.float64).to(dev).to(dt)
+    y = ops.edge_attention(Wx, s1, s2, graph)
+    (y * r).sum().backward()
+    got = [y.detach().clone(), Wx.grad.clone(), s1.grad.clone(), s2.grad.clone()]
+    Wx.grad = s1.grad = s2.grad = None
+    yr = _attention_torch(Wx, s1, s2, graph)
+    (yr * r).sum().backward()
+    ref = [yr.detach(), Wx.grad, s1.grad, s2.grad]
+    for a, b in zip(got, ref):
+        scale = float(b.abs().max()) + 1e-30
+        assert float((a - b).abs().max()) / scale <= tol
