@@ -299,6 +299,8 @@ class GGCRNNCell(nn.Module):
             return self._forward_fused(X, h0)
         if self._use_small(X, h0):
             return self._forward_small(X, h0)
+        if self._use_small_training(X, h0):
+            return self._forward_small(X, h0, train=True)
         Xn = ops.pack_node_major(X)                                     # T x N x B x G
         h0n = ops.pack_node_major(h0.reshape(B, 1, self.F, N))          # 1 x N x B x F
         ya = ops.lsigf_node_major(Xn, self.weight_A, self.bias, self.graph, 1.0)      # all t at once
@@ -338,7 +340,16 @@ class GGCRNNCell(nn.Module):
         return self.weight_A.dtype == X.dtype and h0.dtype == X.dtype and \
             ops.small_supported(self.N, self.graph.fwd[0].nnz, self.G, self.F, self.Kin, self.Kst, X.dtype, self.E)
 
-    def _forward_small(self, X, h0):
+    def _use_small_training(self, X, h0):
+        """Small graphs, gradients wanted for parameters / h0 but not for X: forward and BPTT are one launch each."""
+        if not torch.is_grad_enabled() or X.requires_grad:
+            return False
+        if self.spatial_gating is not None or self.sigma not in (torch.tanh, nn.functional.tanh):
+            return False
+        return self.weight_A.dtype == X.dtype and h0.dtype == X.dtype and \
+            ops.small_training_supported(self.N, self.graph.fwd[0].nnz, self.G, self.F, self.Kin, self.Kst, X.dtype, self.E)
+
+    def _forward_small(self, X, h0, train=False):
         gi = gf = None
         if self.time_gating == True:  # noqa: E712   gates read (x_t, h0) only: one batched pass over all t
             B = X.shape[0]
@@ -346,6 +357,8 @@ class GGCRNNCell(nn.Module):
             h0n = ops.pack_node_major(h0.reshape(B, 1, self.F, self.N))
             gi = self._time_gate(self.GFL_in, self.MLP_in, Xn, h0n).reshape(X.shape[1], B)
             gf = self._time_gate(self.GFL_forget, self.MLP_forget, Xn, h0n).reshape(X.shape[1], B)
+        if train:
+            return ops.small_cell_train(X, h0, self.weight_A, self.weight_B, self.bias, self.graph, gi, gf)
         return ops.small_cell_forward(X, h0, self.weight_A, self.weight_B, self.bias, self.graph, gi, gf)
 
     # -- fused flagship path (bf16, un-gated / time-gated, sigma = tanh, inference) -------------------

@@ -219,10 +219,12 @@ def time_fused_step_kernel(X, h0, wA, wB, bias, graph, reps=3):
     xs = torch.empty((T, B, npad, G), dtype=torch.bfloat16, device=dev)
     h0s = torch.empty((1, B, npad, F), dtype=torch.bfloat16, device=dev)
     hs = torch.empty((T, B, npad, F), dtype=torch.bfloat16, device=dev)
-    check(lib.gcrnn_pack_seq_major(_lib.BF16, _p(X.contiguous()), _p(xs), B, T, G, N, npad, None, st), 'pack_seq')
-    check(lib.gcrnn_pack_seq_major(_lib.BF16, _p(h0.contiguous()), _p(h0s), B, 1, F, N, npad, None, st), 'pack_seq')
+    Xc, h0c = X.contiguous(), h0.contiguous()      # named: a temporary would be freed (and reusable) before the launch
+    check(lib.gcrnn_pack_seq_major(_lib.BF16, _p(Xc), _p(xs), B, T, G, N, npad, None, st), 'pack_seq')
+    check(lib.gcrnn_pack_seq_major(_lib.BF16, _p(h0c), _p(h0s), B, 1, F, N, npad, None, st), 'pack_seq')
     wpack = torch.empty(((F // 16) * K * ((F + G) // 32) * 64 * 8,), dtype=torch.bfloat16, device=dev)
-    check(lib.gcrnn_fused_pack_weights(dtype_code(wA.dtype), _p(wA.contiguous()), _p(wB.contiguous()), _p(wpack),
+    wAc, wBc = wA.contiguous(), wB.contiguous()
+    check(lib.gcrnn_fused_pack_weights(dtype_code(wA.dtype), _p(wAc), _p(wBc), _p(wpack),
                                        F, G, Kin, Kst, st), 'pack_weights')
     b32 = bias.detach().float().contiguous().view(-1) if bias is not None else None
     # same launch configuration as fused_cell_forward: the kernel also writes the user-layout output when it can
@@ -246,7 +248,8 @@ def _fused_pack_weights(wA, wB, st):
     Kin, Kst = wA.shape[2], wB.shape[2]
     K = max(Kin, Kst)
     wpack = torch.empty(((F // 16) * K * ((F + G) // 32) * 64 * 8,), dtype=torch.bfloat16, device=wA.device)
-    check(lib.gcrnn_fused_pack_weights(dtype_code(wA.dtype), _p(wA.contiguous()), _p(wB.contiguous()), _p(wpack),
+    wAc, wBc = wA.contiguous(), wB.contiguous()
+    check(lib.gcrnn_fused_pack_weights(dtype_code(wA.dtype), _p(wAc), _p(wBc), _p(wpack),
                                        F, G, Kin, Kst, st), 'pack_weights')
     return wpack
 
@@ -334,7 +337,8 @@ def fused_backward_weight(dpre, X, H, h0, graph, F, G, K, want_bias=False):
     plan = graph.fused_plan(adjoint=True)
     dW = torch.zeros((F, K, F + G), dtype=torch.float32, device=dpre.device)
     dbs = torch.zeros(F, dtype=torch.float32, device=dpre.device) if want_bias else None
-    check(lib.gcrnn_fused_backward_weight_bf16(_p(dpre), _p(X.contiguous()), _p(H.contiguous()), _p(h0.contiguous()), _p(dW),
+    Xc, Hc, h0c = X.contiguous(), H.contiguous(), h0.contiguous()
+    check(lib.gcrnn_fused_backward_weight_bf16(_p(dpre), _p(Xc), _p(Hc), _p(h0c), _p(dW),
                                                _p(dbs), _p(plan['tile_nodes']), _p(plan['tile_off']), _p(plan['ell_val4']),
                                                _p(plan['ell_col4']), plan['entries'], B, T, graph.N, F, G, K, _stream()),
           'fused_backward_weight')
@@ -416,11 +420,65 @@ def small_cell_forward(X, h0, wA, wB, bias, graph, gi=None, gf=None):
     bvec = bias.detach().contiguous().view(-1) if bias is not None else None
     if gi is not None:
         gi, gf = gi.to(X.dtype).contiguous(), gf.to(X.dtype).contiguous()
-    check(lib.gcrnn_small_forward(dtype_code(X.dtype), _p(X.contiguous()), _p(h0.contiguous()), _p(wA.contiguous()),
-                                  _p(wB.contiguous()), _p(bvec), _p(gi), _p(gf), _p(csr.rowptr), _p(csr.col),
-                                  _p(csr.val(X.dtype)), _p(H), B, T, N, G, F, Kin, Kst, csr.nnz, _stream()),
+    Xc, h0c, wAc, wBc, vals = X.contiguous(), h0.contiguous(), wA.contiguous(), wB.contiguous(), csr.val(X.dtype)
+    check(lib.gcrnn_small_forward(dtype_code(X.dtype), _p(Xc), _p(h0c), _p(wAc),
+                                  _p(wBc), _p(bvec), _p(gi), _p(gf), _p(csr.rowptr), _p(csr.col),
+                                  _p(vals), _p(H), B, T, N, G, F, Kin, Kst, csr.nnz, _stream()),
           'small_forward')
     return H
+
+
+def small_training_supported(N, nnz, G, F, Kin, Kst, dtype, E=1):
+    return small_supported(N, nnz, G, F, Kin, Kst, dtype, E) and bool(
+        lib.gcrnn_small_backward_supported(dtype_code(dtype), int(N), int(nnz), int(G), int(F), int(Kin), int(Kst)))
+
+
+class _SmallCell(torch.autograd.Function):
+    """Small-graph cell with BPTT: forward = one launch (small_cell_kernel), backward = one launch
+    (small_cell_bwd_kernel). Gradients for the parameters, the time gates and h0; none for X."""
+
+    @staticmethod
+    def forward(ctx, X, h0, wA, wB, bias, gi, gf, graph):
+        X, h0 = X.contiguous(), h0.contiguous()
+        H = small_cell_forward(X, h0, wA.detach(), wB.detach(), bias.detach() if bias is not None else None, graph,
+                               gi.detach() if gi is not None else None, gf.detach() if gf is not None else None)
+        ctx.save_for_backward(X, h0, H, wA, wB, bias, gi, gf)
+        ctx.graph = graph
+        return H
+
+    @staticmethod
+    def backward(ctx, dH):
+        X, h0, H, wA, wB, bias, gi, gf = ctx.saved_tensors
+        B, T, G, N = X.shape
+        F, Kin, Kst = wA.shape[0], wA.shape[2], wB.shape[2]
+        dt, dev = X.dtype, X.device
+        fwd, adj = ctx.graph.fwd[0], ctx.graph.adj[0]
+        pA = torch.empty((B, 2, F, Kin, G), dtype=dt, device=dev)
+        pB = torch.empty((B, 2, F, Kst, F), dtype=dt, device=dev)
+        pb = torch.empty((B, F), dtype=dt, device=dev)
+        dgi = dgf = None
+        if gi is not None:
+            gi, gf = gi.to(dt).contiguous(), gf.to(dt).contiguous()
+            dgi = torch.empty((T, B), dtype=dt, device=dev)
+            dgf = torch.empty((T, B), dtype=dt, device=dev)
+        dh0 = torch.empty_like(h0) if ctx.needs_input_grad[1] else None
+        bvec = bias.detach().contiguous().view(-1) if bias is not None else None
+        # every operand is a named local: a temporary (dH.contiguous(), a first-use adj.val(dt)) would be released --
+        # and its block handed to the next allocation -- before the launch
+        dHc, wAc, wBc, fval, aval = dH.contiguous(), wA.contiguous(), wB.contiguous(), fwd.val(dt), adj.val(dt)
+        check(lib.gcrnn_small_backward(dtype_code(dt), _p(X), _p(h0), _p(H), _p(dHc), _p(wAc),
+                                       _p(wBc), _p(bvec), _p(gi), _p(gf), _p(fwd.rowptr), _p(fwd.col),
+                                       _p(fval), _p(adj.rowptr), _p(adj.col), _p(aval), _p(pA), _p(pB), _p(pb),
+                                       _p(dgi), _p(dgf), _p(dh0), B, T, N, G, F, Kin, Kst, fwd.nnz, _stream()),
+              'small_backward')
+        dwA = pA.sum(dim=(0, 1)).view(F, 1, Kin, G)
+        dwB = pB.sum(dim=(0, 1)).view(F, 1, Kst, F)
+        db = pb.sum(dim=0).view(F, 1) if bias is not None else None
+        return None, dh0, dwA, dwB, db, dgi, dgf, None
+
+
+def small_cell_train(X, h0, wA, wB, bias, graph, gi=None, gf=None):
+    return _SmallCell.apply(X, h0, wA, wB, bias, gi, gf, graph)
 
 
 # ------------------------------------------------------------------------------------------ row-linear layers

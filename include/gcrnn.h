@@ -187,6 +187,18 @@ int gcrnn_small_forward(int dtype, const void* X, const void* h0, const void* wA
                         void* H, int64_t B, int64_t T, int64_t N, int64_t G, int64_t F, int64_t Kin, int64_t Kst,
                         int64_t nnz, void* stream);
 
+/* BPTT of the small-graph cell in one launch (adjoint of GGCRNNCell.forward, graphML.py:2336-2427; replaces the autograd
+ * graph PyTorch records for the T-step loop). H = forward output, dH = gradient w.r.t. every state [B][T][F][N];
+ * CSR(S^T) (rowptr/col/val) and CSR(S) (arowptr/acol/aval). Per-sequence partial sums, to be added over the first two
+ * dimensions by the caller in a fixed order:  pA [B][2][F][Kin][G], pB [B][2][F][Kst][F], pb [B][F];
+ * dgi / dgf [T][B] (time-gated cells, else NULL); dh0 [B][F][N] or NULL. dX is not produced. */
+int gcrnn_small_backward_supported(int dtype, int64_t N, int64_t nnz, int64_t G, int64_t F, int64_t Kin, int64_t Kst);
+int gcrnn_small_backward(int dtype, const void* X, const void* h0, const void* H, const void* dH, const void* wA,
+                         const void* wB, const void* bias, const void* gi, const void* gf, const int32_t* rowptr,
+                         const int32_t* col, const void* val, const int32_t* arowptr, const int32_t* acol, const void* aval,
+                         void* pA, void* pB, void* pb, void* dgi, void* dgf, void* dh0, int64_t B, int64_t T, int64_t N,
+                         int64_t G, int64_t F, int64_t Kin, int64_t Kst, int64_t nnz, void* stream);
+
 /* ==== edge gate: graph attention on the CSR support of S + I ====================================================
  * Replaces graphAttention (graphML.py:521-627: dense B x N x N scores, mask, softmax, weighted sum) inside
  * GraphAttentional.forward (graphML.py:2099-2107). Node-major, T independent slices, dtype F32 / F64:

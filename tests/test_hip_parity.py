@@ -312,3 +312,68 @@ def test_edge_attention_kernels(dev, dt, tol, N, B, F, Tn):
     for a, b in zip(got, ref):
         scale = float(b.abs().max()) + 1e-30
         assert float((a - b).abs().max()) / scale <= tol
+
+
+@pytest.mark.parametrize('dt,tol,gtol', DTYPES)
+@pytest.mark.parametrize('name,tg', [('none', False), ('time', True)])
+def test_small_graph_bptt_kernel_vs_reference_gradients(dev, name, tg, dt, tol, gtol):
+    """X without gradient -> GGCRNNCell runs forward and BPTT on the one-launch small-graph kernels
+    (gcrnn_small_forward / gcrnn_small_backward); parameter and h0 gradients vs the reference's (G4)."""
+    from gated_gcrnns_amd import ops
+    g = load_golden('g3_cell_' + name)
+    cell = build_cell(g, tg, None, dt, dev)
+    X, h0 = T(g['X'], dt, dev), T(g['h0'], dt, dev, True)
+    assert cell._use_small_training(X, h0)
+    calls = []
+    orig = ops.small_cell_train
+    ops.small_cell_train = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+    try:
+        H = cell(X, h0)
+    finally:
+        ops.small_cell_train = orig
+    assert calls, 'the small-graph training path did not run'
+    assert maxdiff(H, g['H']) <= tol
+    H.sum().backward()
+    for k, p in cell.named_parameters():
+        ref = g['grad_sum'].get(k)
+        if ref is not None:
+            assert relgrad(p.grad, ref) <= gtol, k
+    assert relgrad(h0.grad, g['grad_sum_h0']) <= gtol
+    cell.zero_grad(); h0.grad = None
+    torch.nn.L1Loss()(cell(X, h0), T(g['target'], dt, dev)).backward()
+    for k, p in cell.named_parameters():
+        ref = g['grad_l1'].get(k)
+        if ref is not None:
+            assert relgrad(p.grad, ref) <= gtol, k
+
+
+@pytest.mark.parametrize('dt,gtol', [(torch.float64, 1e-9), (torch.float32, 5e-4)])
+@pytest.mark.parametrize('N,G,F,Kin,Kst,Tn,B,tg', [(80, 1, 20, 5, 5, 5, 100, False), (59, 1, 20, 3, 3, 200, 16, True),
+                                                     (50, 1, 20, 2, 2, 8, 100, True), (64, 3, 7, 1, 4, 6, 5, False),
+                                                     (120, 2, 20, 3, 2, 4, 3, True)])
+def test_small_graph_bptt_kernel_vs_composed_path(dev, dt, gtol, N, G, F, Kin, Kst, Tn, B, tg):
+    """Same cell, same inputs: one-launch BPTT vs the composed (autograd over LSIGF nodes) path, incl. Kin != Kst,
+    even / odd N, P = 2 and P = 4 slot passes and the long T = 200 sequence."""
+    rng = np.random.default_rng(N + Tn)
+    S = rng.standard_normal((N, N)) * (rng.random((N, N)) < 0.08)
+    S = S / (np.abs(np.linalg.eigvals(S)).max() + 1e-9)
+    torch.manual_seed(0)
+    cell = gml().GGCRNNCell(G, F, Kin, Kst, torch.tanh, tg, None, 1, True)
+    cell.addGSO(torch.tensor(S[None]))
+    cell = cell.to(dev).to(dt)
+    X = torch.randn(B, Tn, G, N, dtype=torch.float64).to(dev).to(dt)
+    h0 = (0.3 * torch.randn(B, F, N, dtype=torch.float64)).to(dev).to(dt).requires_grad_(True)
+    r = torch.randn(B, Tn, F, N, dtype=torch.float64).to(dev).to(dt)
+    assert cell._use_small_training(X, h0)
+    (cell(X, h0) * r).sum().backward()
+    got = {k: p.grad.clone() for k, p in cell.named_parameters() if p.grad is not None}
+    got['h0'] = h0.grad.clone()
+    cell.zero_grad(); h0.grad = None
+    cell._use_small_training = lambda *a: False
+    (cell(X, h0) * r).sum().backward()
+    ref = {k: p.grad for k, p in cell.named_parameters() if p.grad is not None}
+    ref['h0'] = h0.grad
+    assert set(got) == set(ref)
+    for k in ref:
+        scale = float(ref[k].abs().max()) + 1e-30
+        assert float((got[k] - ref[k]).abs().max()) / scale <= gtol, k

@@ -34,3 +34,27 @@ for name, tg, sg in (('GCRNNMLP', False, None), ('TimeGCRNNMLP', True, None), ('
         torch.cuda.synchronize(); res[mode] = ((time.perf_counter() - t0) / 20, float(l))
     print('%-14s fp64 B=100: eager %.2f ms/step (%.0f seq/s)   hipGraph %.2f ms/step (%.0f seq/s)   loss %.5f / %.5f' % (
         name, 1e3 * res['eager'][0], 100 / res['eager'][0], 1e3 * res['hipgraph'][0], 100 / res['hipgraph'][0], res['eager'][1], res['hipgraph'][1]))
+
+# ---- BASELINE configs[3]: seismic graph N=59 (directed), K=3, T=200, G=1, F=20, batch 100, 11-class head (reference R7/R8)
+adj = np.load(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests', 'golden', 'adj59.npy'))
+S4 = dataTools.normalised_gso(adj)
+x4 = torch.randn(100, 200, 1, 59, device=dev)
+y4 = torch.randint(0, 11, (100,), device=dev)
+ce = torch.nn.CrossEntropyLoss()
+for name, tg in (('cfg4 GCRNN cls', False), ('cfg4 TimeGCRNN cls', True)):
+    res = {}
+    for mode in ('eager', 'hipgraph'):
+        torch.manual_seed(0)
+        m = archit.GatedGCRNNforClassification(1, 20, 3, 3, torch.tanh, torch.nn.ReLU, [11], S4, True, time_gating=tg).to(dev)
+        opt = torch.optim.Adam(m.parameters(), lr=1e-3, capturable=(mode == 'hipgraph'))
+        if mode == 'eager':
+            fn = lambda: train_step(m, ce, opt, x4, y4, 20)[0]
+        else:
+            g = GraphedTrainStep(m, ce, opt, x4, y4, 20)
+            fn = lambda: g(x4, y4)[0]
+        for _ in range(2): l = fn()
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(5): l = fn()
+        torch.cuda.synchronize(); res[mode] = ((time.perf_counter() - t0) / 5, float(l))
+    print('%-18s fp64 B=100 T=200: eager %.1f ms/step (%.0f seq/s)   hipGraph %.1f ms/step (%.0f seq/s)   loss %.5f / %.5f' % (
+        name, 1e3 * res['eager'][0], 100 / res['eager'][0], 1e3 * res['hipgraph'][0], 100 / res['hipgraph'][0], res['eager'][1], res['hipgraph'][1]))
