@@ -55,7 +55,8 @@ def _bind(lib):
         'gcrnn_taps_backward_weight': (C.c_int, [C.c_int, _c_p, _c_p, _c_p, _c_i64, _c_p, _c_p, C.c_double,
                                                  _c_i64, _c_i64, _c_i64, _c_i64, _c_p]),
         'gcrnn_ell_size': (C.c_int, [_c_p, _c_i64, _c_p, C.c_int, C.c_int, _c_i64, C.POINTER(_c_i64)]),
-        'gcrnn_ell_fill': (C.c_int, [_c_p, _c_p, _c_p, _c_i64, _c_p, C.c_int, C.c_int, _c_i64, _c_p, _c_p, _c_p]),
+        'gcrnn_ell_fill': (C.c_int, [_c_p, _c_p, _c_p, _c_i64, _c_p, C.c_int, C.c_int, _c_i64, _c_p, _c_p, _c_p, _c_p]),
+        'gcrnn_ell_assign_rows': (C.c_int, [_c_p, _c_p, _c_i64, _c_p, C.c_int, _c_i64, _c_p]),
         'gcrnn_fused_supported': (C.c_int, [_c_i64, _c_i64, _c_i64, _c_i64]),
         'gcrnn_fused_padded_nodes': (_c_i64, []),
         'gcrnn_pack_seq_major': (C.c_int, [C.c_int, _c_p, _c_p, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_p, _c_p]),
@@ -77,8 +78,8 @@ def _bind(lib):
         'gcrnn_small_backward': (C.c_int, [C.c_int] + [_c_p] * 21 + [_c_i64] * 8 + [_c_p]),
         'gcrnn_attention_forward': (C.c_int, [C.c_int] + [_c_p] * 11 + [_c_i64] * 5 + [C.c_double, _c_p]),
         'gcrnn_attention_backward': (C.c_int, [C.c_int] + [_c_p] * 15 + [_c_i64] * 5 + [C.c_double, _c_p]),
-        'gcrnn_ell_conflict_cycles': (C.c_int, [_c_p, _c_i64, C.POINTER(_c_i64)]),
-        'gcrnn_ell_pack_lds': (C.c_int, [_c_p, _c_p, _c_i64, _c_p, _c_p]),
+        'gcrnn_ell_conflict_cycles': (C.c_int, [_c_p, _c_i64, _c_p, C.POINTER(_c_i64)]),
+        'gcrnn_ell_pack_lds': (C.c_int, [_c_p, _c_p, _c_i64, _c_p, _c_p, _c_p]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)          # AttributeError if the symbol is not exported

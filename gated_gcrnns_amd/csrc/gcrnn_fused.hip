@@ -433,12 +433,9 @@ __global__ __launch_bounds__(512, 2) void fused_step_kernel(
     tend[i] = tile_off[wave * TILES + i + 1];
   }
   f32x4 u[TILES][K - 1];   // taps 0..K-2 (tap K-1 seeds the LDS state directly); later: the hop results
-  int woff[TILES];      // byte offset of this lane's quad in the swizzled state row of its node
+  int woff[TILES];      // low 16 bits: byte offset of this lane's quad in the (swizzled) state row of its node; high: node id
 #pragma unroll
-  for (int i = 0; i < TILES; ++i) {
-    const int nd = tile_nodes[(wave * TILES + i) * 16 + r];
-    woff[i] = nd * (FC * 4) + ((q ^ ((nd >> 2) & 3)) << 4);          // node id = woff >> 6
-  }
+  for (int i = 0; i < TILES; ++i) woff[i] = tile_nodes[(wave * TILES + i) * 16 + r] ^ (q << 4);   // slot = node << 16 | row << 6 | swz << 4
   float bvec[4] = {0.f, 0.f, 0.f, 0.f};
   if (bias) {
 #pragma unroll
@@ -476,7 +473,7 @@ __global__ __launch_bounds__(512, 2) void fused_step_kernel(
   for (int i = 0; i < TILES; ++i) {
     int w = woff[i];
     asm volatile("" : "+v"(w));      // opaque per iteration: keeps hipcc from hoisting (and spilling) 16+ row offsets
-    const int roh = (w >> 6) * (F * 2) + 16 * q, rox = (w >> 6) * (G * 2) + 16 * q;
+    const int roh = (w >> 16) * (F * 2) + 16 * q, rox = (w >> 16) * (G * 2) + 16 * q;
 #pragma unroll
 #ifdef GCRNN_ABLATE_P1_LOADS
     for (int s = 0; s < KS; ++s) bfr[i][s] = __builtin_bit_cast(bf16x8, uint4{(unsigned)roh, (unsigned)rox, (unsigned)s, 1u});
@@ -524,7 +521,11 @@ __global__ __launch_bounds__(512, 2) void fused_step_kernel(
         }
 #endif
       }
-      if (tap == K - 1) *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(state) + woff[i]) = acc;
+      if (tap == K - 1) {
+        int wv = woff[i];
+        asm volatile("" : "+v"(wv));      // opaque: the masked LDS offsets are not hoisted out of the tile loop
+        *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(state) + (wv & 0xffff)) = acc;
+      }
       else u[i][tap] = acc;
     }
   }
@@ -577,7 +578,7 @@ __global__ __launch_bounds__(512, 2) void fused_step_kernel(
           for (int p = 0; p < 4; ++p) { cc[p] = ell_col[(e + p) * 16 + r]; vv[p] = ell_val[(e + p) * 16 + r]; }
 #pragma unroll
           for (int p = 0; p < 4; ++p)
-            xv[p] = *reinterpret_cast<const f32x4*>(sbytes + cc[p] * (FC * 4) + ((q ^ ((cc[p] >> 2) & 3)) << 4));
+            xv[p] = *reinterpret_cast<const f32x4*>(sbytes + (cc[p] ^ qoff));      // ell_col = node_addr of the neighbour
 #pragma unroll
           for (int p = 0; p < 4; ++p) acc += vv[p] * xv[p];
         }
@@ -587,7 +588,11 @@ __global__ __launch_bounds__(512, 2) void fused_step_kernel(
     if (j < K - 1) {
       __syncthreads();
 #pragma unroll
-      for (int i = 0; i < TILES; ++i) *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(state) + woff[i]) = u[i][K - 1 - j];
+      for (int i = 0; i < TILES; ++i) {
+        int wv = woff[i];
+        asm volatile("" : "+v"(wv));
+        *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(state) + (wv & 0xffff)) = u[i][K - 1 - j];
+      }
       __syncthreads();
     }
   }
@@ -606,7 +611,7 @@ __global__ __launch_bounds__(512, 2) void fused_step_kernel(
     for (int i = 0; i < TILES; ++i) {
       int wv = woff[i];
       asm volatile("" : "+v"(wv));
-      const int node = wv >> 6;
+      const int node = wv >> 16;
       if (node < N) {
         const float4 w4 = *reinterpret_cast<const float4*>(gate_w + (int64_t)node * F + chunk * FC + q * 4);
         const f32x4 acc = u[i][0];
@@ -625,7 +630,7 @@ __global__ __launch_bounds__(512, 2) void fused_step_kernel(
     for (int i = 0; i < TILES; ++i) {
       int wv = woff[i];
       asm volatile("" : "+v"(wv));
-      const int node = wv >> 6;
+      const int node = wv >> 16;
       const int eoff = node * (F * 2) + (chunk * FC + q * 4) * 2;
       f32x4 o = u[i][0];
       if (aux0) {
@@ -654,7 +659,7 @@ __global__ __launch_bounds__(512, 2) void fused_step_kernel(
   for (int i = 0; i < TILES; ++i) {
     int wv = woff[i];
     asm volatile("" : "+v"(wv));
-    const int node = wv >> 6;
+    const int node = wv >> 16;
     const f32x4 acc = u[i][0];
     uint2 pk;
     if (node < N) {
@@ -678,7 +683,7 @@ __global__ __launch_bounds__(512, 2) void fused_step_kernel(
     for (int i = 0; i < TILES; ++i) {
       int wv = woff[i];
       asm volatile("" : "+v"(wv));
-      const int node = wv >> 6;
+      const int node = wv >> 16;
       const uint32_t p0 = __float_as_uint(u[i][0][0]), p1 = __float_as_uint(u[i][0][1]);
       *reinterpret_cast<uint16_t*>(tst + (q * 4 + 0) * RS + node * 2) = (uint16_t)(p0 & 0xffffu);
       *reinterpret_cast<uint16_t*>(tst + (q * 4 + 1) * RS + node * 2) = (uint16_t)(p0 >> 16);
@@ -878,7 +883,7 @@ __global__ __launch_bounds__(512, 2) void fused_wgrad_kernel(
     tbeg[i] = tile_off[wave * TILES + i];
     tend[i] = tile_off[wave * TILES + i + 1];
     const int nd = tile_nodes[(wave * TILES + i) * 16 + r];
-    woff[i] = nd * (FC * 4) + ((q ^ ((nd >> 2) & 3)) << 4);
+    woff[i] = nd ^ (q << 4);                       // slot = node << 16 | row << 6 | swz << 4
   }
   const int qoff = q * 16;
   const uint32_t lds0 = (uint32_t)reinterpret_cast<uintptr_t>(smem);
@@ -920,7 +925,7 @@ __global__ __launch_bounds__(512, 2) void fused_wgrad_kernel(
     for (int i = 0; i < TILES; ++i) {
       int wv = woff[i];
       asm volatile("" : "+v"(wv));
-      const u32x2 d2 = __builtin_amdgcn_raw_buffer_load_b64(rsrc_d, (wv >> 6) * (F * 2) + (chunk * FC + q * 4) * 2, soff_d, 0);
+      const u32x2 d2 = __builtin_amdgcn_raw_buffer_load_b64(rsrc_d, (wv >> 16) * (F * 2) + (chunk * FC + q * 4) * 2, soff_d, 0);
       cur[i] = f32x4{bf2f((uint16_t)(d2[0] & 0xffffu)), bf2f((uint16_t)(d2[0] >> 16)),
                      bf2f((uint16_t)(d2[1] & 0xffffu)), bf2f((uint16_t)(d2[1] >> 16))};
     }
@@ -943,8 +948,8 @@ __global__ __launch_bounds__(512, 2) void fused_wgrad_kernel(
       for (int i = 0; i < TILES; ++i) {
         int wv = woff[i];
         asm volatile("" : "+v"(wv));
-        if (k < K - 1) *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(state) + wv) = cur[i];
-        const int node = wv >> 6;
+        if (k < K - 1) *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(state) + (wv & 0xffff)) = cur[i];
+        const int node = wv >> 16;
         if (node < 512) {
 #pragma unroll
           for (int c = 0; c < 4; ++c)
@@ -970,7 +975,7 @@ __global__ __launch_bounds__(512, 2) void fused_wgrad_kernel(
       for (int i = 0; i < TILES; ++i) {
         int wv = woff[i];
         asm volatile("" : "+v"(wv));
-        const int node = wv >> 6;
+        const int node = wv >> 16;
         if (node >= 512) {
 #pragma unroll
           for (int c = 0; c < 4; ++c)

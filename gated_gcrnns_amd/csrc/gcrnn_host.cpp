@@ -1,6 +1,7 @@
 // Host-side entry points of libgcrnn_hip.so: version/status strings and graph preparation
 // (dense GSO -> CSR, degree ordering). No GPU is touched here, so these run in CPU-only tests.
 #include <algorithm>
+#include <array>
 #include <cmath>
 #include <cstdio>
 #include <numeric>
@@ -116,7 +117,21 @@ extern "C" int gcrnn_ell_size(const int32_t* rowptr, int64_t N, const int32_t* o
 //     key_r = (col_r & 15) ^ 4    for r in {4-11}
 // are distinct. The order of a row's neighbours is free and padding entries (weight 0) may point at any row, so
 // for every entry index we pick, per slot, an unused neighbour by maximum bipartite matching (slots x keys).
-static inline int ell_key(int r, int32_t col) { return ((r >= 4 && r < 12) ? ((col & 15) ^ 4) : (col & 15)); }
+//
+// Generalisation: the LDS row of a node and the XOR swizzle of its quads are free per node. node_addr[n] =
+// (row << 6) | (swz << 4) is the byte-offset code of node n's state row (NULL = the identity layout above: row n,
+// swz = (n >> 2) & 3). The bank-quad of node n seen by a lane with quad q is ((row & 3) << 2 | swz ^ q), so the node's
+// 4-bit key is key4 = (swz << 2) | (row & 3), and slots 4..11 see key4 ^ 4. gcrnn_ell_assign_rows picks the keys that
+// flatten every tile's key histogram (local search); rows are then dealt out within each (row & 3) class.
+static inline int node_key4(const int32_t* node_addr, int32_t col) {
+  if (!node_addr) return col & 15;
+  const int32_t a = node_addr[col];
+  return (((a >> 4) & 3) << 2) | ((a >> 6) & 3);
+}
+static inline int ell_key(int r, int32_t col, const int32_t* node_addr) {
+  const int k = node_key4(node_addr, col);
+  return (r >= 4 && r < 12) ? (k ^ 4) : k;
+}
 
 namespace {
 struct TileSched {
@@ -124,10 +139,11 @@ struct TileSched {
   std::vector<std::pair<int32_t, float>> rem[16];
   int pads[16];
   int match_key[16];   // key -> slot
+  const int32_t* node_addr = nullptr;
   bool try_slot(int r, bool used_key[16], int key_of[16], int depth) {
     // candidate keys of slot r: keys of its unused neighbours (wildcards are handled by the caller)
     for (size_t i = 0; i < rem[r].size(); ++i) {
-      const int k = ell_key(r, rem[r][i].first);
+      const int k = ell_key(r, rem[r][i].first, node_addr);
       if (used_key[k]) continue;
       used_key[k] = true;
       if (match_key[k] < 0 || try_slot(match_key[k], used_key, key_of, depth + 1)) {
@@ -139,16 +155,51 @@ struct TileSched {
     return false;
   }
 };
+
+// Exact schedule of one tile whose key histogram fits (every key at most d times): pad the slots x keys multigraph with
+// zero-weight wildcard edges to a d-regular bipartite multigraph and peel off d perfect matchings (Koenig) -- every entry
+// is conflict-free. M[r][k] = real edges, Dm[r][k] = wildcard edges.
+struct RegularPeel {
+  int M[16][16], Dm[16][16];
+  int mk[16];            // key -> slot of the current matching
+  bool aug(int r, bool seen[16]) {
+    for (int k = 0; k < 16; ++k) {
+      if (M[r][k] + Dm[r][k] == 0 || seen[k]) continue;
+      seen[k] = true;
+      if (mk[k] < 0 || aug(mk[k], seen)) { mk[k] = r; return true; }
+    }
+    return false;
+  }
+  bool perfect(int key_of[16]) {
+    for (int k = 0; k < 16; ++k) mk[k] = -1;
+    for (int r = 0; r < 16; ++r) {
+      bool seen[16] = {false};
+      if (!aug(r, seen)) return false;
+    }
+    for (int k = 0; k < 16; ++k) key_of[mk[k]] = k;
+    return true;
+  }
+};
 }  // namespace
 
 extern "C" int gcrnn_ell_fill(const int32_t* rowptr, const int32_t* col, const double* val, int64_t N,
-                              const int32_t* order, int tile, int pad, int64_t ntiles, int32_t* tile_off,
-                              int32_t* ell_col, float* ell_val) {
+                              const int32_t* order, int tile, int pad, int64_t ntiles, const int32_t* node_addr,
+                              int32_t* tile_off, int32_t* ell_col, float* ell_val) {
   if (!rowptr || !col || !val || !tile_off || !ell_col || !ell_val) return GCRNN_ERR_NULL_POINTER;
   if (N <= 0 || tile <= 0 || pad <= 0 || ntiles * tile < N) return GCRNN_ERR_BAD_SHAPE;
   const bool schedule = (tile == 16);
   int64_t off = 0;
   TileSched ts;
+  ts.node_addr = node_addr;
+  // a node for every key: where zero-weight padding entries point (rows 0..15 carry all 16 keys in the identity layout)
+  int32_t node_of_key[16];
+  for (int k = 0; k < 16; ++k) node_of_key[k] = -1;
+  if (schedule)
+    for (int64_t n = 0; n < N; ++n) {
+      const int k = node_key4(node_addr, (int32_t)n);
+      if (node_of_key[k] < 0) node_of_key[k] = (int32_t)n;
+    }
+  for (int k = 0; k < 16; ++k) if (node_of_key[k] < 0) node_of_key[k] = 0;
   for (int64_t t = 0; t < ntiles; ++t) {
     tile_off[t] = (int32_t)off;
     const int d = ell_tile_deg(rowptr, order, N, t, tile, pad);
@@ -176,6 +227,60 @@ extern "C" int gcrnn_ell_fill(const int32_t* rowptr, const int32_t* col, const d
         }
         ts.pads[r] = d - (int)ts.rem[r].size();
       }
+      // exact conflict-free schedule when no key is wanted more than d times
+      {
+        RegularPeel rp;
+        int kdeg[16] = {0};
+        for (int r = 0; r < 16; ++r)
+          for (int k = 0; k < 16; ++k) rp.M[r][k] = rp.Dm[r][k] = 0;
+        for (int r = 0; r < 16; ++r)
+          for (auto& cv : ts.rem[r]) { const int k = ell_key(r, cv.first, node_addr); ++rp.M[r][k]; ++kdeg[k]; }
+        int kmax = 0;
+        for (int k = 0; k < 16; ++k) kmax = std::max(kmax, kdeg[k]);
+        if (d > 0 && kmax <= d) {
+          int rdef[16], kdef[16];
+          for (int r = 0; r < 16; ++r) rdef[r] = ts.pads[r];
+          for (int k = 0; k < 16; ++k) kdef[k] = d - kdeg[k];
+          for (int r = 0; r < 16; ++r)
+            for (int k = 0; k < 16 && rdef[r] > 0; ++k) {
+              const int x = std::min(rdef[r], kdef[k]);
+              rp.Dm[r][k] += x; rdef[r] -= x; kdef[k] -= x;
+            }
+          bool ok = true;
+          for (int e = 0; e < d && ok; ++e) {
+            int key_of[16];
+            ok = rp.perfect(key_of);
+            if (!ok) break;
+            for (int r = 0; r < 16; ++r) {
+              const int k = key_of[r];
+              int32_t c; float v;
+              if (rp.M[r][k] > 0) {
+                --rp.M[r][k];
+                size_t i = 0;
+                while (ell_key(r, ts.rem[r][i].first, node_addr) != k) ++i;
+                c = ts.rem[r][i].first; v = ts.rem[r][i].second;
+                ts.rem[r].erase(ts.rem[r].begin() + i);
+              } else {
+                --rp.Dm[r][k];
+                c = node_of_key[(r >= 4 && r < 12) ? (k ^ 4) : k]; v = 0.f;
+              }
+              ell_col[(off + e) * 16 + r] = c;
+              ell_val[(off + e) * 16 + r] = v;
+            }
+          }
+          if (ok) { off += d; if (off > 2147483647LL / tile) return GCRNN_ERR_BAD_SHAPE; continue; }
+          // (cannot happen for a regular multigraph; fall through to the greedy schedule on a fresh copy)
+          for (int r = 0; r < 16; ++r) {
+            ts.rem[r].clear();
+            const int64_t p = t * 16 + r;
+            if (p < N) {
+              const int32_t n = order ? order[p] : (int32_t)p;
+              for (int32_t j = rowptr[n]; j < rowptr[n + 1]; ++j) ts.rem[r].push_back({col[j], (float)val[j]});
+            }
+            ts.pads[r] = d - (int)ts.rem[r].size();
+          }
+        }
+      }
       for (int e = 0; e < d; ++e) {
         int key_of[16];
         for (int r = 0; r < 16; ++r) key_of[r] = -1;
@@ -202,7 +307,7 @@ extern "C" int gcrnn_ell_fill(const int32_t* rowptr, const int32_t* col, const d
           float v = 0.f;
           if (key_of[r] >= 0) {
             for (size_t i = 0; i < ts.rem[r].size(); ++i)
-              if (ell_key(r, ts.rem[r][i].first) == key_of[r]) {
+              if (ell_key(r, ts.rem[r][i].first, node_addr) == key_of[r]) {
                 c = ts.rem[r][i].first; v = ts.rem[r][i].second;
                 ts.rem[r].erase(ts.rem[r].begin() + i);
                 break;
@@ -212,7 +317,7 @@ extern "C" int gcrnn_ell_fill(const int32_t* rowptr, const int32_t* col, const d
             while (k < 16 && key_taken[k]) ++k;
             if (k == 16) k = 0;
             key_taken[k] = true;
-            c = (r >= 4 && r < 12) ? (k ^ 4) : k;      // any row with that key; rows 0..15 always exist (NPad >= 16)
+            c = node_of_key[(r >= 4 && r < 12) ? (k ^ 4) : k];      // any node with that key
             v = 0.f;
             --ts.pads[r];
           } else {
@@ -233,13 +338,13 @@ extern "C" int gcrnn_ell_fill(const int32_t* rowptr, const int32_t* col, const d
 
 // LDS cycles the four 16-lane groups of one gather need, summed over all entries, under the swizzled layout
 // (diagnostic: 4 * entries = conflict-free).
-extern "C" int gcrnn_ell_conflict_cycles(const int32_t* ell_col, int64_t entries, int64_t* cycles) {
+extern "C" int gcrnn_ell_conflict_cycles(const int32_t* ell_col, int64_t entries, const int32_t* node_addr, int64_t* cycles) {
   if (!ell_col || !cycles) return GCRNN_ERR_NULL_POINTER;
   int64_t tot = 0;
   for (int64_t e = 0; e < entries; ++e) {
     int cnt[16] = {0};
     int mx = 0;
-    for (int r = 0; r < 16; ++r) mx = std::max(mx, ++cnt[ell_key(r, ell_col[e * 16 + r])]);
+    for (int r = 0; r < 16; ++r) mx = std::max(mx, ++cnt[ell_key(r, ell_col[e * 16 + r], node_addr)]);
     tot += 4 * mx;
   }
   *cycles = tot;
@@ -247,9 +352,9 @@ extern "C" int gcrnn_ell_conflict_cycles(const int32_t* ell_col, int64_t entries
 }
 
 // Pack a 16-slot ELL into the LDS image of the fused kernel: groups of 4 entries,
-//   val4[g][r][4] fp32 weights;  col4[g][r][4] u16 = (col << 6) | (((col >> 2) & 3) << 4)   (row offset | swizzle bits)
-extern "C" int gcrnn_ell_pack_lds(const int32_t* ell_col, const float* ell_val, int64_t entries, float* val4,
-                                  uint16_t* col4) {
+//   val4[g][r][4] fp32 weights;  col4[g][r][4] u16 = node_addr[col] = (row << 6) | (swz << 4)   (row offset | swizzle bits)
+extern "C" int gcrnn_ell_pack_lds(const int32_t* ell_col, const float* ell_val, int64_t entries, const int32_t* node_addr,
+                                  float* val4, uint16_t* col4) {
   if (!ell_col || !ell_val || !val4 || !col4) return GCRNN_ERR_NULL_POINTER;
   if (entries < 0 || entries % 4) return GCRNN_ERR_BAD_SHAPE;
   for (int64_t g = 0; g < entries / 4; ++g)
@@ -258,7 +363,103 @@ extern "C" int gcrnn_ell_pack_lds(const int32_t* ell_col, const float* ell_val, 
         const int32_t c = ell_col[(g * 4 + p) * 16 + r];
         if (c < 0 || c >= 1024) return GCRNN_ERR_BAD_SHAPE;
         val4[(g * 16 + r) * 4 + p] = ell_val[(g * 4 + p) * 16 + r];
-        col4[(g * 16 + r) * 4 + p] = (uint16_t)((c << 6) | (((c >> 2) & 3) << 4));
+        col4[(g * 16 + r) * 4 + p] = (uint16_t)(node_addr ? node_addr[c] : ((c << 6) | (((c >> 2) & 3) << 4)));
       }
+  return GCRNN_OK;
+}
+
+// Choose the LDS row and quad swizzle of every node (see the key model above) so that, for every tile, no key is wanted
+// by more neighbours than the tile has entries -- then gcrnn_ell_fill's exact schedule leaves no bank conflict at all.
+// Local search: nodes are visited in a fixed pseudo-random order; each takes the key that minimises
+// (sum over its tiles of max(d_t, busiest key), sum of squared overloads). Rows: class (row & 3) holds at most N / 4 nodes.
+// N = padded node count (multiple of 16, at most 1024), rowptr / order as for gcrnn_ell_fill (tile = 16).
+extern "C" int gcrnn_ell_assign_rows(const int32_t* rowptr, const int32_t* col, int64_t N, const int32_t* order, int pad,
+                                     int64_t ntiles, int32_t* node_addr) {
+  if (!rowptr || !col || !node_addr) return GCRNN_ERR_NULL_POINTER;
+  if (N <= 0 || N > 1024 || N % 16 || pad <= 0 || ntiles * 16 < N) return GCRNN_ERR_BAD_SHAPE;
+  std::vector<int> depth(ntiles);
+  for (int64_t t = 0; t < ntiles; ++t) depth[t] = ell_tile_deg(rowptr, order, N, t, 16, pad);
+  // incoming edges of every node: (tile, flip) with flip = 4 for slots 4..11
+  std::vector<std::vector<std::pair<int, int>>> in(N);
+  for (int64_t t = 0; t < ntiles; ++t)
+    for (int r = 0; r < 16; ++r) {
+      const int64_t p = t * 16 + r;
+      if (p >= N) continue;
+      const int32_t n = order ? order[p] : (int32_t)p;
+      for (int32_t j = rowptr[n]; j < rowptr[n + 1]; ++j) {
+        if (col[j] < 0 || col[j] >= N) return GCRNN_ERR_BAD_SHAPE;
+        in[col[j]].push_back({(int)t, (r >= 4 && r < 12) ? 4 : 0});
+      }
+    }
+  std::vector<int> key(N);
+  std::vector<std::array<int, 16>> cnt(ntiles);
+  for (auto& c : cnt) c.fill(0);
+  int cls[4] = {0, 0, 0, 0};
+  for (int64_t n = 0; n < N; ++n) {
+    key[n] = (int)(n & 15);
+    if (!in[n].empty()) ++cls[n & 3];                         // nodes nobody gathers (padding rows, sinks) take leftover rows
+    for (auto& e : in[n]) ++cnt[e.first][key[n] ^ e.second];
+  }
+  const int cap = (int)(N / 4);
+  std::vector<int32_t> visit(N);
+  std::iota(visit.begin(), visit.end(), 0);
+  uint64_t lcg = 0x9E3779B97F4A7C15ull;
+  for (int64_t i = N - 1; i > 0; --i) {                      // fixed shuffle: the plan is a pure function of the graph
+    lcg = lcg * 6364136223846793005ull + 1442695040888963407ull;
+    std::swap(visit[i], visit[(lcg >> 33) % (uint64_t)(i + 1)]);
+  }
+  std::vector<int> tiles;
+  for (int pass = 0; pass < 8; ++pass) {
+    bool changed = false;
+    for (int64_t vi = 0; vi < N; ++vi) {
+      const int32_t n = visit[vi];
+      if (in[n].empty()) continue;
+      tiles.clear();
+      for (auto& e : in[n]) tiles.push_back(e.first);
+      std::sort(tiles.begin(), tiles.end());
+      tiles.erase(std::unique(tiles.begin(), tiles.end()), tiles.end());
+      const int k0 = key[n];
+      for (auto& e : in[n]) --cnt[e.first][k0 ^ e.second];
+      long best1 = -1, best2 = -1;
+      int bestk = k0;
+      for (int kk = 0; kk < 16; ++kk) {
+        const int k = (k0 + kk) & 15;                          // the current key first: ties keep it
+        if ((k & 3) != (k0 & 3) && cls[k & 3] >= cap) continue;
+        for (auto& e : in[n]) ++cnt[e.first][k ^ e.second];
+        long c1 = 0, c2 = 0;
+        for (int t : tiles) {
+          int mx = 0;
+          for (int q = 0; q < 16; ++q) {
+            mx = std::max(mx, cnt[t][q]);
+            const int over = cnt[t][q] - depth[t] + 1;
+            if (over > 0) c2 += (long)over * over;
+          }
+          c1 += std::max(depth[t], mx);
+        }
+        for (auto& e : in[n]) --cnt[e.first][k ^ e.second];
+        if (best1 < 0 || c1 < best1 || (c1 == best1 && c2 < best2)) { best1 = c1; best2 = c2; bestk = k; }
+      }
+      if (bestk != k0) { changed = true; --cls[k0 & 3]; ++cls[bestk & 3]; key[n] = bestk; }
+      for (auto& e : in[n]) ++cnt[e.first][bestk ^ e.second];
+    }
+    if (!changed) break;
+  }
+  int next_row[4] = {0, 1, 2, 3};
+  for (int64_t n = 0; n < N; ++n) {
+    if (in[n].empty()) continue;
+    const int a = key[n] & 3;
+    const int row = next_row[a];
+    next_row[a] += 4;
+    if (row >= N) return GCRNN_ERR_WORKSPACE;                  // cannot happen: class sizes are capped at N / 4
+    node_addr[n] = (row << 6) | ((key[n] >> 2) << 4);
+  }
+  int a = 0;
+  for (int64_t n = 0; n < N; ++n) {
+    if (!in[n].empty()) continue;
+    while (a < 4 && next_row[a] >= N) ++a;
+    if (a == 4) return GCRNN_ERR_WORKSPACE;
+    node_addr[n] = (next_row[a] << 6) | ((key[n] >> 2) << 4);
+    next_row[a] += 4;
+  }
   return GCRNN_OK;
 }

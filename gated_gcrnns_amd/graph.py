@@ -158,18 +158,28 @@ class GraphOperator(object):
         tile_off = np.zeros(ntiles + 1, dtype=np.int32)
         ell_col = np.zeros(max(nent.value, 1) * 16, dtype=np.int32)
         ell_val = np.zeros(max(nent.value, 1) * 16, dtype=np.float32)
+        # LDS row + quad swizzle of every node, chosen so that the gathers of every tile spread over the 16 bank quads
+        node_addr = np.zeros(npad, dtype=np.int32)
+        _lib.check(_lib.lib.gcrnn_ell_assign_rows(vp(rowptr_pad), vp(col), npad, vp(order_full), 4, ntiles, vp(node_addr)),
+                   'ell_assign_rows')
         _lib.check(_lib.lib.gcrnn_ell_fill(vp(rowptr_pad), vp(col), vp(val), npad, vp(order_full), 16, 4, ntiles,
-                                           vp(tile_off), vp(ell_col), vp(ell_val)), 'ell_fill')
+                                           vp(node_addr), vp(tile_off), vp(ell_col), vp(ell_val)), 'ell_fill')
         cyc = C.c_int64(0)
-        _lib.check(_lib.lib.gcrnn_ell_conflict_cycles(vp(ell_col), nent.value, C.byref(cyc)), 'ell_conflict_cycles')
+        _lib.check(_lib.lib.gcrnn_ell_conflict_cycles(vp(ell_col), nent.value, vp(node_addr), C.byref(cyc)),
+                   'ell_conflict_cycles')
         val4 = np.zeros(max(nent.value, 4) * 16, dtype=np.float32)
         col4 = np.zeros(max(nent.value, 4) * 16, dtype=np.uint16)
-        _lib.check(_lib.lib.gcrnn_ell_pack_lds(vp(ell_col), vp(ell_val), nent.value, vp(val4), vp(col4)), 'ell_pack_lds')
+        _lib.check(_lib.lib.gcrnn_ell_pack_lds(vp(ell_col), vp(ell_val), nent.value, vp(node_addr), vp(val4), vp(col4)),
+                   'ell_pack_lds')
         dev = self.device
         tile_nodes = order_full
+        tile_slots = ((tile_nodes.astype(np.int64) << 16) | node_addr[tile_nodes]).astype(np.int32)   # what the kernels take
+        ell_addr = node_addr[ell_col].astype(np.int32)
         plan = dict(npad=npad, order=torch.from_numpy(order).to(dev), tile_nodes=torch.from_numpy(tile_nodes).to(dev),
+                    tile_slots=torch.from_numpy(tile_slots).to(dev), node_addr=torch.from_numpy(node_addr).to(dev),
                     tile_off=torch.from_numpy(tile_off).to(dev),
-                    ell_col=torch.from_numpy(ell_col).to(dev), ell_val=torch.from_numpy(ell_val).to(dev),
+                    ell_col=torch.from_numpy(ell_col).to(dev), ell_addr=torch.from_numpy(ell_addr).to(dev),
+                    ell_val=torch.from_numpy(ell_val).to(dev),
                     ell_val4=torch.from_numpy(val4).to(dev), ell_col4=torch.from_numpy(col4.view(np.int16)).to(dev),
                     entries=int(nent.value), gather_cycles=int(cyc.value))
         setattr(self, key, plan)

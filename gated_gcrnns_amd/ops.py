@@ -234,7 +234,7 @@ def time_fused_step_kernel(X, h0, wA, wB, bias, graph, reps=3):
     e0.record()
     for _ in range(reps):
         check(lib.gcrnn_fused_forward_bf16(_p(xs), _p(h0s), _p(hs), _p(wpack), _p(b32), None, None,
-                                           _p(plan['tile_nodes']), _p(plan['tile_off']), _p(plan['ell_col']),
+                                           _p(plan['tile_slots']), _p(plan['tile_off']), _p(plan['ell_addr']),
                                            _p(plan['ell_val']), _p(plan['ell_val4']), _p(plan['ell_col4']),
                                            plan['entries'], B, T, N, F, G, K, _p(H) if H is not None else None, st),
               'fused_forward')
@@ -277,7 +277,7 @@ def fused_cell_forward(X, h0, wA, wB, bias, graph, gates=None, return_states=Fal
     hs = torch.empty((T, B, npad, F), dtype=torch.bfloat16, device=dev)
     check(lib.gcrnn_pack_seq_major(_lib.BF16, _p(X), _p(xs), B, T, G, N, npad, None, st), 'pack_seq')
     check(lib.gcrnn_pack_seq_major(_lib.BF16, _p(h0), _p(h0s), B, 1, F, N, npad, None, st), 'pack_seq')
-    gargs = (_p(plan['tile_nodes']), _p(plan['tile_off']), _p(plan['ell_col']), _p(plan['ell_val']),
+    gargs = (_p(plan['tile_slots']), _p(plan['tile_off']), _p(plan['ell_addr']), _p(plan['ell_val']),
              _p(plan['ell_val4']), _p(plan['ell_col4']), plan['entries'])
     gi = gf = None
     if gates is not None:
@@ -322,8 +322,8 @@ def fused_backward_data(dHs, hs, wB, graph, want_dh0=True):
     check(lib.gcrnn_fused_pack_weights(dtype_code(wBt.dtype), _p(wBt), _p(wBt), _p(wpack), F_, G0, K, K, st), 'pack_weights')
     dpre = torch.empty_like(hs)
     dh0 = torch.empty((B, npad, F), dtype=torch.bfloat16, device=hs.device) if want_dh0 else None
-    check(lib.gcrnn_fused_backward_data_bf16(_p(dHs), _p(hs), _p(dpre), _p(dh0), _p(wpack), _p(plan['tile_nodes']),
-                                             _p(plan['tile_off']), _p(plan['ell_col']), _p(plan['ell_val']),
+    check(lib.gcrnn_fused_backward_data_bf16(_p(dHs), _p(hs), _p(dpre), _p(dh0), _p(wpack), _p(plan['tile_slots']),
+                                             _p(plan['tile_off']), _p(plan['ell_addr']), _p(plan['ell_val']),
                                              _p(plan['ell_val4']), _p(plan['ell_col4']), plan['entries'],
                                              B, T, graph.N, F, K, st), 'fused_backward_data')
     return dpre, dh0
@@ -339,7 +339,7 @@ def fused_backward_weight(dpre, X, H, h0, graph, F, G, K, want_bias=False):
     dbs = torch.zeros(F, dtype=torch.float32, device=dpre.device) if want_bias else None
     Xc, Hc, h0c = X.contiguous(), H.contiguous(), h0.contiguous()
     check(lib.gcrnn_fused_backward_weight_bf16(_p(dpre), _p(Xc), _p(Hc), _p(h0c), _p(dW),
-                                               _p(dbs), _p(plan['tile_nodes']), _p(plan['tile_off']), _p(plan['ell_val4']),
+                                               _p(dbs), _p(plan['tile_slots']), _p(plan['tile_off']), _p(plan['ell_val4']),
                                                _p(plan['ell_col4']), plan['entries'], B, T, graph.N, F, G, K, _stream()),
           'fused_backward_weight')
     return (dW, dbs) if want_bias else dW

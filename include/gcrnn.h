@@ -107,13 +107,22 @@ int gcrnn_taps_backward_weight(int dtype, const void* dy, const void* z0, const 
 int gcrnn_ell_size(const int32_t* rowptr, int64_t N, const int32_t* order, int tile, int pad, int64_t ntiles,
                    int64_t* nentries);
 int gcrnn_ell_fill(const int32_t* rowptr, const int32_t* col, const double* val, int64_t N, const int32_t* order,
-                   int tile, int pad, int64_t ntiles, int32_t* tile_off, int32_t* ell_col, float* ell_val);
-/* For tile = 16, gcrnn_ell_fill orders each row's neighbours (and aims its zero-weight padding entries) so that the
- * 16-lane groups of the kernel's ds_read_b128 gathers hit distinct LDS banks (maximum bipartite matching per entry).
- * gcrnn_ell_conflict_cycles reports the resulting LDS cycles per gather summed over entries (4*entries = no conflict);
- * gcrnn_ell_pack_lds builds the kernel's LDS image: val4 [entries/4][16][4] fp32, col4 [entries/4][16][4] uint16. */
-int gcrnn_ell_conflict_cycles(const int32_t* ell_col, int64_t entries, int64_t* cycles);
-int gcrnn_ell_pack_lds(const int32_t* ell_col, const float* ell_val, int64_t entries, float* val4, uint16_t* col4);
+                   int tile, int pad, int64_t ntiles, const int32_t* node_addr, int32_t* tile_off, int32_t* ell_col,
+                   float* ell_val);
+/* LDS placement of the hop state (tile = 16). node_addr[n] = (row << 6) | (swz << 4): node n's 64-byte state row sits at
+ * LDS row `row`, its four 16-byte quads XOR-swizzled by `swz` (NULL = identity: row n, swz (n >> 2) & 3).
+ * gcrnn_ell_assign_rows chooses rows and swizzles (local search over the 16 bank-quad keys a node can take) so that no
+ * tile asks for one key more often than it has entries; gcrnn_ell_fill then orders each row's neighbours -- and aims its
+ * zero-weight padding entries -- by peeling perfect matchings off the slots x keys multigraph: the 16-lane groups of the
+ * kernel's ds_read_b128 gathers hit distinct banks (greedy maximum matchings where a key is over-subscribed).
+ * gcrnn_ell_conflict_cycles reports the LDS cycles per gather summed over entries (4 * entries = conflict-free);
+ * gcrnn_ell_pack_lds builds the kernel's LDS image: val4 [entries/4][16][4] fp32, col4 [entries/4][16][4] uint16 =
+ * node_addr of the neighbour. N = padded node count here (multiple of 16, <= 1024). */
+int gcrnn_ell_assign_rows(const int32_t* rowptr, const int32_t* col, int64_t N, const int32_t* order, int pad,
+                          int64_t ntiles, int32_t* node_addr);
+int gcrnn_ell_conflict_cycles(const int32_t* ell_col, int64_t entries, const int32_t* node_addr, int64_t* cycles);
+int gcrnn_ell_pack_lds(const int32_t* ell_col, const float* ell_val, int64_t entries, const int32_t* node_addr, float* val4,
+                       uint16_t* col4);
 /* 1 if gcrnn_fused_forward_bf16 has a kernel for this shape (K = max(Kin, Kst) taps). */
 int gcrnn_fused_supported(int64_t N, int64_t F, int64_t G, int64_t K);
 int64_t gcrnn_fused_padded_nodes(void);
@@ -129,7 +138,8 @@ int gcrnn_fused_pack_weights(int wdtype, const void* wA, const void* wB, void* w
                              int64_t Kin, int64_t Kst, void* stream);
 /* xs [T][B][NPad][G], h0 [B][NPad][F], hs [T][B][NPad][F]: bf16 sequence-major, natural node order;
  * bias fp32 [F] or NULL; gi / gf fp32 [T][B] time gates or both NULL (un-gated);
- * tile_nodes int32 [NPad] = order padded with the unused row ids N..NPad-1; entries = tile_off[ntiles].
+ * tile_nodes int32 [NPad]: slot p = (node << 16) | node_addr[node], node = order padded with the unused row ids
+ * N..NPad-1; entries = tile_off[ntiles]; ell_col int32 [entries][16] = node_addr of each neighbour (NOT the node id).
  * ell_val4 / ell_col4 = device copies of gcrnn_ell_pack_lds's output (may be NULL).
  * Huser (may be NULL; needs N % 8 == 0): the states are ALSO written in the user layout H[B][T][F][N] by the step kernels
  * themselves (LDS-transposed 16-byte row stores), which replaces gcrnn_unpack_seq_major over the whole sequence.
