@@ -301,6 +301,8 @@ class GGCRNNCell(nn.Module):
             return self._forward_small(X, h0)
         if self._use_small_training(X, h0):
             return self._forward_small(X, h0, train=True)
+        if self._use_horner(X, h0):
+            return self._forward_horner(X, h0)
         Xn = ops.pack_node_major(X)                                     # T x N x B x G
         h0n = ops.pack_node_major(h0.reshape(B, 1, self.F, N))          # 1 x N x B x F
         ya = ops.lsigf_node_major(Xn, self.weight_A, self.bias, self.graph, 1.0)      # all t at once
@@ -329,6 +331,69 @@ class GGCRNNCell(nn.Module):
             h = self.sigma(ya[t:t + 1] + yb)
             Hs.append(h)
         Hn = torch.cat(Hs, dim=0)                                       # T x N x B x F
+        return ops.unpack_node_major(Hn)
+
+    # -- streaming inference in Horner form (any size, fp32 / fp64, un-gated / time-gated) ------------------
+    def _use_horner(self, X, h0):
+        if torch.is_grad_enabled() and (X.requires_grad or h0.requires_grad or self.weight_A.requires_grad):
+            return False            # BPTT runs on the LSIGF autograd nodes
+        if X.dtype == torch.bfloat16 and (self.F % 8 or self.time_gating == True):  # noqa: E712  (16-byte bf16 rows; gates are fp32/fp64 code)
+            return False
+        return self.spatial_gating is None and self.E == 1 and \
+            X.dtype in (torch.float32, torch.float64, torch.bfloat16) and self.weight_A.dtype == X.dtype and h0.dtype == X.dtype
+
+    def _forward_horner(self, X, h0):
+        """Taps and shifts act on different axes, so  pre_t = sum_k P^k (gi x_t A_k^T + gf h_{t-1} B_k^T) + (gi + gf) b  is
+        evaluated as  acc <- P acc + u_k  (k = K-1 .. 0): K-1 hops over F channels per step, x and h sharing them,
+        instead of the reference order's 2 (K-1) hops over G + F channels (graphML.py:118-135 applied twice per step).
+        Every hop is one accumulate-SpMM pass over the [N][B F] state; the taps are plain library GEMMs."""
+        B, T, G, N = X.shape
+        F, Kin, Kst = self.F, self.Kin, self.Kst
+        K = max(Kin, Kst)
+        Xn = ops.pack_node_major(X)                                     # T x N x B x G
+        h = ops.pack_node_major(h0.reshape(B, 1, F, N))                 # 1 x N x B x F
+        gi = gf = None
+        if self.time_gating == True:  # noqa: E712
+            gi = self._time_gate(self.GFL_in, self.MLP_in, Xn, h)       # T x 1 x B x 1
+            gf = self._time_gate(self.GFL_forget, self.MLP_forget, Xn, h)
+        wA = self.weight_A[:, 0]                                        # F x Kin x G
+        wB = self.weight_B[:, 0]                                        # F x Kst x F
+        # x-side taps of all steps in one GEMM per tap when they fit in 8 GiB, else per step
+        batched = Kin * T * N * B * F * X.element_size() <= (8 << 30)
+        ux = [torch.matmul(Xn, wA[:, k].t()) for k in range(Kin)] if batched else None
+        if ux is not None and gi is not None:
+            ux = [u * gi for u in ux]
+        csr = self.graph.fwd[0]
+        Hn = torch.empty((T, N, B, F), dtype=X.dtype, device=X.device)
+        for t in range(T):
+            acc = None
+            for k in range(K - 1, -1, -1):
+                u = None
+                if k < Kin:
+                    if ux is not None:
+                        u = ux[k][t:t + 1]
+                        if acc is not None or k < Kst:
+                            u = u.clone() if k >= Kst else u          # spmm accumulates in place: never into the cached taps
+                    else:
+                        u = torch.matmul(Xn[t:t + 1], wA[:, k].t())
+                        if gi is not None:
+                            u = u * gi[t:t + 1]
+                if k < Kst:
+                    uh = torch.matmul(h, wB[:, k].t())
+                    if gf is not None:
+                        uh = uh * gf[t:t + 1]
+                    u = uh if u is None else uh.add_(u)
+                if acc is not None:
+                    ops.spmm_raw(csr, acc, out=u, accumulate=True)      # u += P acc
+                acc = u
+            if self.bias is not None:
+                bb = self.bias.view(1, 1, 1, F)
+                acc = acc + (2.0 * bb if gi is None else (gi[t:t + 1] + gf[t:t + 1]) * bb)
+            if self.sigma in (torch.tanh, nn.functional.tanh):
+                h = torch.tanh(acc, out=Hn[t:t + 1])
+            else:
+                Hn[t:t + 1] = self.sigma(acc)
+                h = Hn[t:t + 1]
         return ops.unpack_node_major(Hn)
 
     # -- small-graph persistent path (fp32 / fp64, un-gated / time-gated, sigma = tanh, inference) -------

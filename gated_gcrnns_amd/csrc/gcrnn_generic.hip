@@ -135,6 +135,55 @@ __global__ void spmm_kernel(int64_t N, const int32_t* __restrict__ rowptr, const
   }
 }
 
+// bf16 storage, fp32 weights and accumulation: 8 values (16 B) per lane, L / 8 lanes per row, 64 / (L / 8) rows per
+// 64-thread workgroup when a row is narrower than a wave (the large-graph streaming path: half the gather bytes of fp32).
+__global__ __launch_bounds__(64) void spmm_bf16_kernel(int64_t N, const int32_t* __restrict__ rowptr,
+                                                       const int32_t* __restrict__ col, const float* __restrict__ val,
+                                                       const uint16_t* __restrict__ X, uint16_t* __restrict__ Y, int64_t L,
+                                                       int lanes_per_row, int accumulate) {
+  const int rows_per_block = lanes_per_row >= 64 ? 1 : 64 / lanes_per_row;
+  const int sub = lanes_per_row >= 64 ? 0 : threadIdx.x / lanes_per_row;
+  const int lane = lanes_per_row >= 64 ? threadIdx.x : threadIdx.x - sub * lanes_per_row;
+  const int64_t n = (int64_t)blockIdx.x * rows_per_block + sub;
+  const int64_t l = ((int64_t)blockIdx.y * 64 + lane) * 8;
+  if (n >= N || l >= L || sub >= rows_per_block) return;
+  const int64_t base = (int64_t)blockIdx.z * N * L;
+  float acc[8];
+#pragma unroll
+  for (int v = 0; v < 8; ++v) acc[v] = 0.f;
+  const uint16_t* xb = X + base + l;
+  for (int j = rowptr[n]; j < rowptr[n + 1]; ++j) {
+    const float w = val[j];
+    const uint4 xv = *reinterpret_cast<const uint4*>(xb + (int64_t)col[j] * L);
+    const uint32_t p[4] = {xv.x, xv.y, xv.z, xv.w};
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      acc[2 * v] += w * __uint_as_float(p[v] << 16);
+      acc[2 * v + 1] += w * __uint_as_float(p[v] & 0xffff0000u);
+    }
+  }
+  uint16_t* yp = Y + base + n * L + l;
+  if (accumulate) {
+    const uint4 yv = *reinterpret_cast<const uint4*>(yp);
+    const uint32_t p[4] = {yv.x, yv.y, yv.z, yv.w};
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      acc[2 * v] += __uint_as_float(p[v] << 16);
+      acc[2 * v + 1] += __uint_as_float(p[v] & 0xffff0000u);
+    }
+  }
+  uint32_t o[4];
+#pragma unroll
+  for (int v = 0; v < 4; ++v) {
+    // round to nearest even
+    uint32_t a = __float_as_uint(acc[2 * v]), b = __float_as_uint(acc[2 * v + 1]);
+    a += 0x7fffu + ((a >> 16) & 1u);
+    b += 0x7fffu + ((b >> 16) & 1u);
+    o[v] = (a >> 16) | (b & 0xffff0000u);
+  }
+  *reinterpret_cast<uint4*>(yp) = uint4{o[0], o[1], o[2], o[3]};
+}
+
 template <typename T>
 static int spmm_launch(int64_t N, const int32_t* rowptr, const int32_t* col, const void* val, const void* X, void* Y,
                        int64_t L, int64_t nbatch, int accumulate, void* stream) {
@@ -161,6 +210,20 @@ extern "C" int gcrnn_spmm(int dtype, int64_t N, const int32_t* rowptr, const int
   if (X == Y) return GCRNN_ERR_UNSUPPORTED;  // a hop cannot run in place
   if (dtype == GCRNN_F32) return spmm_launch<float>(N, rowptr, col, val, X, Y, L, nbatch, accumulate, stream);
   if (dtype == GCRNN_F64) return spmm_launch<double>(N, rowptr, col, val, X, Y, L, nbatch, accumulate, stream);
+  if (dtype == GCRNN_BF16) {                      // bf16 rows, fp32 `val`
+    if (L % 8 || ((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(Y)) % 16)) return GCRNN_ERR_UNSUPPORTED;
+    const int64_t lanes = L / 8;
+    int lpr = 64;
+    if (lanes < 64) { lpr = 1; while (lpr < lanes) lpr <<= 1; }       // power of two so that rows tile the 64 threads
+    const int rpb = lpr >= 64 ? 1 : 64 / lpr;
+    const int64_t gx = cdiv(N, rpb), gy = cdiv(lanes, 64);
+    if (gx > 2147483647LL || gy > 65535 || nbatch > 65535) return GCRNN_ERR_BAD_SHAPE;
+    GCRNN_PRE_LAUNCH();
+    spmm_bf16_kernel<<<dim3((unsigned)gx, (unsigned)gy, (unsigned)nbatch), 64, 0, as_stream(stream)>>>(
+        N, rowptr, col, (const float*)val, (const uint16_t*)X, (uint16_t*)Y, L, lpr, accumulate);
+    GCRNN_CHECK_LAUNCH();
+    return GCRNN_OK;
+  }
   return GCRNN_ERR_BAD_DTYPE;
 }
 

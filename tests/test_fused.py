@@ -259,3 +259,30 @@ def test_fused_training_autograd_end_to_end(master):
         sc = np.abs(gr).max()
         # L1 loss: dH = sign(H - target)/count flips where bf16 rounding moves H across the target: allow a few %
         assert np.abs(g - gr).max() <= 6e-2 * sc and np.abs(g - gr).mean() <= 1e-2 * sc, (name, np.abs(g - gr).max() / sc)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('N,F,K,B,T', [(1500, 32, 3, 4, 3), (2100, 64, 2, 2, 2), (1100, 8, 4, 3, 3)])
+def test_bf16_streaming_path_for_graphs_beyond_the_fused_kernel(N, F, K, B, T):
+    """N > 1024: bf16 inference runs in Horner form on the bf16 accumulate-SpMM (gcrnn_spmm GCRNN_BF16: bf16 rows, fp32
+    weights / accumulation) -- vs the fp64 oracle on the same bf16-rounded operands."""
+    import gated_gcrnns_amd.Utils.graphML as gml
+    dev = torch.device('cuda:0')
+    G = F
+    S = random_graph(N, 8.0 / N, 3)
+    rng = np.random.default_rng(11)
+    X = bf16_round(rng.standard_normal((B, T, G, N)))
+    h0 = bf16_round(0.5 * rng.standard_normal((B, F, N)))
+    torch.manual_seed(1)
+    cell = gml.GGCRNNCell(G, F, K, K, torch.tanh, False, None, 1, True)
+    cell.addGSO(torch.tensor(S))
+    params = {k: bf16_round(v.detach().numpy()) for k, v in cell.state_dict().items()}
+    cell = cell.to(dev).to(torch.bfloat16)
+    Xd = torch.tensor(X, dtype=torch.bfloat16, device=dev)
+    hd = torch.tensor(h0, dtype=torch.bfloat16, device=dev)
+    with torch.no_grad():
+        assert not cell._use_fused(Xd, hd) and cell._use_horner(Xd, hd)
+        H = cell(Xd, hd).double().cpu().numpy()
+    ref = orc.ggcrnn_cell(params, S, X, h0)
+    err = np.abs(H - ref)
+    assert err.max() <= 5e-2 and err.mean() <= 4e-3, (err.max(), err.mean())

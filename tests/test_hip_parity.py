@@ -377,3 +377,31 @@ def test_small_graph_bptt_kernel_vs_composed_path(dev, dt, gtol, N, G, F, Kin, K
     for k in ref:
         scale = float(ref[k].abs().max()) + 1e-30
         assert float((got[k] - ref[k]).abs().max()) / scale <= gtol, k
+
+
+@pytest.mark.parametrize('dt,tol,gtol', DTYPES)
+@pytest.mark.parametrize('name,tg', [('none', False), ('time', True)])
+@pytest.mark.parametrize('Kst', [3, 2])
+def test_horner_streaming_inference_vs_reference(dev, name, tg, Kst, dt, tol, gtol):
+    """no_grad forward in Horner form (taps first, K-1 accumulate-SpMM hops shared by x and h) vs the reference's states;
+    Kst = 2 < Kin = 3 exercises taps that only the input filter has."""
+    g = load_golden('g3_cell_' + name + ('' if Kst == 3 else '_kst2')) if Kst == 3 else None
+    if g is None:
+        # no golden with Kin != Kst for this variant: compare with the composed path instead
+        g3 = load_golden('g3_cell_' + name)
+        torch.manual_seed(3)
+        cell = gml().GGCRNNCell(2, 5, 3, Kst, torch.tanh, tg, None, 1, True)
+        cell.addGSO(torch.tensor(g3['S']))
+        cell = cell.to(dev).to(dt)
+        X, h0 = T(g3['X'], dt, dev), T(g3['h0'], dt, dev)
+        ref = cell(X, h0).detach().double().cpu().numpy()          # grad mode: composed / small-training path
+    else:
+        cell = build_cell(g, tg, None, dt, dev)
+        X, h0 = T(g['X'], dt, dev), T(g['h0'], dt, dev)
+        ref = g['H']
+    cell._use_small = lambda *a: False
+    assert cell._use_horner(X, h0) is False                         # gradients wanted -> not this path
+    with torch.no_grad():
+        assert cell._use_horner(X, h0)
+        H = cell(X, h0)
+    assert maxdiff(H, ref) <= tol

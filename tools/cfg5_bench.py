@@ -42,6 +42,10 @@ hop_bytes = nnz * (4 + s) + 2 * s * N * B * (G + F)
 step_bytes = (K - 1) * hop_bytes + s * N * B * (G + 2 * F)
 print('cfg5 N=%d nnz=%d K=%d T=%d G=F=%d B=%d fp32: %.1f ms per batch = %.1f seq/s ; %.2f ms/step ; algorithmic %.0f MB/step -> %.0f GB/s'
       % (N, nnz, K, T, F, B, 1e3 * dt, B / dt, 1e3 * dt / T, step_bytes / 1e6, step_bytes * T / dt / 1e9))
+# what a gather-based SpMM actually has to move through the cache hierarchy: every non-zero pulls one B*F-wide row
+gather = (K - 1) * nnz * B * F * s
+print('   gathered rows: %.1f GB/step (the [N][B F] state is %.0f MB: it lives in the 256 MB Infinity Cache, not in L2) -> %.2f TB/s'
+      % (gather / 1e9, N * B * F * s / 1e6, gather * T / dt / 1e12))
 # spot check against a CPU CSR evaluation of h_1 on a few nodes
 x0 = X[:, 0].double().cpu().numpy(); A = cell.weight_A.detach().double().cpu().numpy()[:, 0]
 b = cell.bias.detach().double().cpu().numpy().reshape(-1)
@@ -60,3 +64,18 @@ ref = np.tanh(pre)
 err = np.abs(H[:, 0][:, :, torch.tensor(probe, device=dev)].double().cpu().numpy() - ref).max()
 print('spot check of h_0 on 5 nodes vs CPU CSR evaluation: max |diff| = %.2e' % err)
 assert err < 1e-5
+
+# bf16 rows (half the gather bytes): same path on the bf16 accumulate-SpMM
+cellb = cell.to(torch.bfloat16)
+Xb, h0b = X.to(torch.bfloat16), h0.to(torch.bfloat16)
+with torch.no_grad():
+    for _ in range(2):
+        Hb = cellb(Xb, h0b)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        Hb = cellb(Xb, h0b)
+    torch.cuda.synchronize()
+dtb = (time.perf_counter() - t0) / reps
+print('cfg5 bf16: %.1f ms per batch = %.1f seq/s ; %.2f ms/step ; max |bf16 - fp32| = %.3e'
+      % (1e3 * dtb, B / dtb, 1e3 * dtb / T, float((Hb.float() - H).abs().max())))
