@@ -131,6 +131,7 @@ def main():
         # state sequence, BPTT, ONE flat gradient all-reduce over RCCL, Adam. Runs on the fp32/fp64 composed path.
         # bf16: fp32 master weights, bf16 activations -> fused forward + fused BPTT; f32 / f64: composed path
         from gated_gcrnns_amd.parallel import FlatGradAllReduce
+        from gated_gcrnns_amd.Utils.miscTools import batchTimeL1Loss
         if args.dtype == 'bf16':
             cell = cell.float()
         target = torch.randn(B, T, F, N, device=dev, dtype=torch.float32).to(dt)
@@ -149,7 +150,7 @@ def main():
             with torch.no_grad():
                 return cell(X, h0)
         cell.zero_grad()
-        loss = torch.nn.functional.l1_loss(cell(X, h0), target)
+        loss = batchTimeL1Loss(cell(X, h0), target)      # the drivers' loss (reference miscTools.py:112-119), one fused pass
         loss.backward()
         if sync_grads is not None:
             sync_grads.all_reduce_()

@@ -4,7 +4,11 @@ import torch
 
 def batchTimeL1Loss(x, y):
     """Mean absolute error over every entry (reference miscTools.py:112-119; its view(-1,N,F) is a no-op for a mean)."""
-    return torch.nn.functional.l1_loss(x, y.to(x.dtype))
+    from .. import ops
+    y = y.to(x.dtype)
+    if x.shape != y.shape:
+        x, y = torch.broadcast_tensors(x, y)
+    return ops.l1_loss(x, y)
 
 
 def batchTimeMSELoss(x, y):

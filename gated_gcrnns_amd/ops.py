@@ -481,6 +481,34 @@ def small_cell_train(X, h0, wA, wB, bias, graph, gi=None, gf=None):
     return _SmallCell.apply(X, h0, wA, wB, bias, gi, gf, graph)
 
 
+# ------------------------------------------------------------------------------------------ loss
+class _L1Loss(torch.autograd.Function):
+    """mean |x - y| with the gradient produced in the same pass (reference batchTimeL1Loss, miscTools.py:112-119)."""
+
+    @staticmethod
+    def forward(ctx, x, y):
+        require_device(x, y)
+        xc, yc = x.contiguous(), y.contiguous()
+        n = xc.numel()
+        want = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
+        grad = torch.empty_like(xc) if want else None
+        acc_dt = torch.float64 if xc.dtype == torch.float64 else torch.float32
+        partial = torch.empty((int(lib.gcrnn_l1_loss_blocks(n)),), dtype=acc_dt, device=xc.device)
+        check(lib.gcrnn_l1_loss(dtype_code(xc.dtype), _p(xc), _p(yc), _p(grad), _p(partial), n, 1.0 / n, _stream()), 'l1_loss')
+        ctx.grad = grad
+        return (partial.sum() / n).to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, gout):
+        g = ctx.grad * gout.to(ctx.grad.dtype) if ctx.grad is not None else None
+        return (g if ctx.needs_input_grad[0] else None), (-g if ctx.needs_input_grad[1] else None)
+
+
+def l1_loss(x, y):
+    assert x.shape == y.shape and x.dtype == y.dtype
+    return _L1Loss.apply(x, y)
+
+
 # ------------------------------------------------------------------------------------------ row-linear layers
 class _RowLinear(torch.autograd.Function):
     """y = x W^T (+ b) over a huge number of rows (x: R x in; R = T*N*B node-rows of the per-node head and of the

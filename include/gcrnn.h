@@ -209,6 +209,14 @@ int gcrnn_small_backward(int dtype, const void* X, const void* h0, const void* H
                          void* pA, void* pB, void* pb, void* dgi, void* dgf, void* dh0, int64_t B, int64_t T, int64_t N,
                          int64_t G, int64_t F, int64_t Kin, int64_t Kst, int64_t nnz, void* stream);
 
+/* ==== training-loop loss ==========================================================================================
+ * batchTimeL1Loss (Utils/miscTools.py:112-119 = nn.L1Loss: mean |x - y| over every entry) and its gradient in one pass.
+ * x, y, grad: n contiguous elements of `dtype` (F32 / F64 / BF16), 16-byte aligned; grad (may be NULL) =
+ * sign(x - y) * inv_n; partial: gcrnn_l1_loss_blocks(n) sums of |x - y| (fp32 for F32 / BF16, fp64 for F64) that the
+ * caller adds up in a fixed order and scales by inv_n. */
+int64_t gcrnn_l1_loss_blocks(int64_t n);
+int gcrnn_l1_loss(int dtype, const void* x, const void* y, void* grad, void* partial, int64_t n, double inv_n, void* stream);
+
 /* ==== edge gate: graph attention on the CSR support of S + I ====================================================
  * Replaces graphAttention (graphML.py:521-627: dense B x N x N scores, mask, softmax, weighted sum) inside
  * GraphAttentional.forward (graphML.py:2099-2107). Node-major, T independent slices, dtype F32 / F64:

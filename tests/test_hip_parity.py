@@ -405,3 +405,26 @@ def test_horner_streaming_inference_vs_reference(dev, name, tg, Kst, dt, tol, gt
         assert cell._use_horner(X, h0)
         H = cell(X, h0)
     assert maxdiff(H, ref) <= tol
+
+
+@pytest.mark.parametrize('dt,tol', [(torch.float64, 1e-13), (torch.float32, 1e-6), (torch.bfloat16, 2e-3)])
+@pytest.mark.parametrize('shape', [(3, 4, 5, 30), (100, 5, 1, 80), (7, 1, 1, 1), (4, 9, 64, 1000)])
+def test_l1_loss_kernel(dev, dt, tol, shape):
+    """gcrnn_l1_loss (batchTimeL1Loss, reference miscTools.py:112-119): value and both gradients vs torch, incl. exact ties
+    (sign(0) = 0), a ragged tail and an upstream gradient != 1."""
+    from gated_gcrnns_amd.Utils import miscTools
+    gen = torch.Generator(device='cpu'); gen.manual_seed(5)
+    x = torch.randn(*shape, generator=gen, dtype=torch.float64).to(dt).to(dev)
+    y = torch.randn(*shape, generator=gen, dtype=torch.float64).to(dt).to(dev)
+    y.view(-1)[::7] = x.view(-1)[::7]                               # ties
+    x.requires_grad_(True); y.requires_grad_(True)
+    loss = miscTools.batchTimeL1Loss(x, y)
+    (3.0 * loss).backward()
+    gx, gy = x.grad.clone(), y.grad.clone()
+    x.grad = y.grad = None
+    ref = torch.nn.functional.l1_loss(x.double(), y.double())
+    (3.0 * ref).backward()
+    assert abs(float(loss) - float(ref)) <= tol * max(1.0, abs(float(ref)))
+    n = x.numel()
+    assert float((gx.double() - x.grad.double()).abs().max()) <= tol * 3.0 / n + (1e-2 * 3.0 / n if dt == torch.bfloat16 else 0)
+    assert float((gy.double() - y.grad.double()).abs().max()) <= tol * 3.0 / n + (1e-2 * 3.0 / n if dt == torch.bfloat16 else 0)
