@@ -35,6 +35,16 @@ def build(force=False, verbose=True):
     if not force and not needs_build():
         return LIBPATH
     os.makedirs(LIBDIR, exist_ok=True)
+    # one builder at a time (N ranks of one node may import the package at once); late-comers find the work done
+    import fcntl
+    with open(os.path.join(LIBDIR, '.build.lock'), 'w') as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        if not force and not needs_build():
+            return LIBPATH
+        return _build_locked(verbose)
+
+
+def _build_locked(verbose):
     # compile objects one by one (parallel-friendly, clearer errors), then link
     objs = []
     procs = []
@@ -48,10 +58,12 @@ def build(force=False, verbose=True):
     for src, p in procs:
         if p.wait() != 0:
             raise RuntimeError('hipcc failed on %s' % src)
-    cmd = [HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIBPATH] + objs
+    tmp = LIBPATH + '.tmp.%d' % os.getpid()
+    cmd = [HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', tmp] + objs
     if verbose:
         print(' '.join(cmd), flush=True)
     subprocess.check_call(cmd)
+    os.replace(tmp, LIBPATH)                 # atomic: a concurrent dlopen sees the old or the new library, never a partial file
     return LIBPATH
 
 

@@ -106,6 +106,17 @@ class GraphOperator(object):
         self.mask_vals = [torch.from_numpy(np.ascontiguousarray(Splus[e][rows, col])).to(self.device) for e in range(self.E)]
         self.nnz = sum(c.nnz for c in self.fwd)
 
+    def dense(self, dtype, e=0):
+        """Dense S_e ([N][N], row m, column n) on the device, for the small-graph matrix-core kernels."""
+        cache = self.__dict__.setdefault('_dense', {})
+        key = (dtype, e)
+        if key not in cache:
+            c = self.adj[e]                                            # CSR(S): row m lists the columns n of S[m][:]
+            d = torch.zeros((self.N, self.N), dtype=dtype, device=self.device)
+            d[c.rows(), c.col.long()] = c.val(dtype)
+            cache[key] = d
+        return cache[key]
+
     def mask_transposed(self):
         """Transposed attention support: (t_rowptr int32 [N+1], t_row int32 [nnz], t_pos int32 [nnz], edge_row int32 [nnz])
         -- for column n the rows m with (m, n) in the support and the position of that edge in mask.col / mask_vals;

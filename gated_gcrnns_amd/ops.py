@@ -7,6 +7,7 @@ has no CPU path (the CPU restatement lives in oracle/ and is test-only).
 Node-major layout used by every op: X[T][N][B][C] (see include/gcrnn.h).
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -409,6 +410,13 @@ def small_supported(N, nnz, G, F, Kin, Kst, dtype, E=1):
     return bool(lib.gcrnn_small_supported(dtype_code(dtype), int(N), int(nnz), int(G), int(F), int(Kin), int(Kst)))
 
 
+def small_dense_supported(N, G, F, Kin, Kst, dtype, backward, gated):
+    if dtype not in (torch.float32, torch.float64) or os.environ.get('GCRNN_SMALL_GATHER'):   # env: A/B against the gather kernels
+        return False
+    return bool(lib.gcrnn_small_dense_supported(dtype_code(dtype), int(N), int(G), int(F), int(Kin), int(Kst),
+                                                int(backward), int(gated)))
+
+
 def small_cell_forward(X, h0, wA, wB, bias, graph, gi=None, gf=None):
     """Whole recurrence in one launch, one workgroup per sequence (small graphs). X: B x T x G x N, h0: B x F x N
     (user layout, fp32 / fp64) -> H: B x T x F x N. gi / gf: [T][B] time gates or None. Inference only."""
@@ -421,6 +429,11 @@ def small_cell_forward(X, h0, wA, wB, bias, graph, gi=None, gf=None):
     if gi is not None:
         gi, gf = gi.to(X.dtype).contiguous(), gf.to(X.dtype).contiguous()
     Xc, h0c, wAc, wBc, vals = X.contiguous(), h0.contiguous(), wA.contiguous(), wB.contiguous(), csr.val(X.dtype)
+    if small_dense_supported(N, G, F, Kin, Kst, X.dtype, backward=False, gated=gi is not None):
+        Sd = graph.dense(X.dtype)
+        check(lib.gcrnn_small_dense_forward(dtype_code(X.dtype), _p(Xc), _p(h0c), _p(wAc), _p(wBc), _p(bvec), _p(gi), _p(gf),
+                                            _p(Sd), _p(H), B, T, N, G, F, Kin, Kst, _stream()), 'small_dense_forward')
+        return H
     check(lib.gcrnn_small_forward(dtype_code(X.dtype), _p(Xc), _p(h0c), _p(wAc),
                                   _p(wBc), _p(bvec), _p(gi), _p(gf), _p(csr.rowptr), _p(csr.col),
                                   _p(vals), _p(H), B, T, N, G, F, Kin, Kst, csr.nnz, _stream()),
@@ -453,8 +466,9 @@ class _SmallCell(torch.autograd.Function):
         F, Kin, Kst = wA.shape[0], wA.shape[2], wB.shape[2]
         dt, dev = X.dtype, X.device
         fwd, adj = ctx.graph.fwd[0], ctx.graph.adj[0]
-        pA = torch.empty((B, 2, F, Kin, G), dtype=dt, device=dev)
-        pB = torch.empty((B, 2, F, Kst, F), dtype=dt, device=dev)
+        dense = small_dense_supported(N, G, F, Kin, Kst, dt, backward=True, gated=gi is not None)
+        pA = torch.empty((B, 1 if dense else 2, F, Kin, G), dtype=dt, device=dev)
+        pB = torch.empty((B, 1 if dense else 2, F, Kst, F), dtype=dt, device=dev)
         pb = torch.empty((B, F), dtype=dt, device=dev)
         dgi = dgf = None
         if gi is not None:
@@ -466,11 +480,17 @@ class _SmallCell(torch.autograd.Function):
         # every operand is a named local: a temporary (dH.contiguous(), a first-use adj.val(dt)) would be released --
         # and its block handed to the next allocation -- before the launch
         dHc, wAc, wBc, fval, aval = dH.contiguous(), wA.contiguous(), wB.contiguous(), fwd.val(dt), adj.val(dt)
-        check(lib.gcrnn_small_backward(dtype_code(dt), _p(X), _p(h0), _p(H), _p(dHc), _p(wAc),
-                                       _p(wBc), _p(bvec), _p(gi), _p(gf), _p(fwd.rowptr), _p(fwd.col),
-                                       _p(fval), _p(adj.rowptr), _p(adj.col), _p(aval), _p(pA), _p(pB), _p(pb),
-                                       _p(dgi), _p(dgf), _p(dh0), B, T, N, G, F, Kin, Kst, fwd.nnz, _stream()),
-              'small_backward')
+        if dense:
+            Sd = ctx.graph.dense(dt)
+            check(lib.gcrnn_small_dense_backward(dtype_code(dt), _p(X), _p(h0), _p(H), _p(dHc), _p(wAc), _p(wBc), _p(bvec),
+                                                 _p(gi), _p(gf), _p(Sd), _p(pA), _p(pB), _p(pb), _p(dgi), _p(dgf), _p(dh0),
+                                                 B, T, N, G, F, Kin, Kst, _stream()), 'small_dense_backward')
+        else:
+            check(lib.gcrnn_small_backward(dtype_code(dt), _p(X), _p(h0), _p(H), _p(dHc), _p(wAc),
+                                           _p(wBc), _p(bvec), _p(gi), _p(gf), _p(fwd.rowptr), _p(fwd.col),
+                                           _p(fval), _p(adj.rowptr), _p(adj.col), _p(aval), _p(pA), _p(pB), _p(pb),
+                                           _p(dgi), _p(dgf), _p(dh0), B, T, N, G, F, Kin, Kst, fwd.nnz, _stream()),
+                  'small_backward')
         dwA = pA.sum(dim=(0, 1)).view(F, 1, Kin, G)
         dwB = pB.sum(dim=(0, 1)).view(F, 1, Kst, F)
         db = pb.sum(dim=0).view(F, 1) if bias is not None else None

@@ -209,6 +209,21 @@ int gcrnn_small_backward(int dtype, const void* X, const void* h0, const void* H
                          void* pA, void* pB, void* pb, void* dgi, void* dgf, void* dh0, int64_t B, int64_t T, int64_t N,
                          int64_t G, int64_t F, int64_t Kin, int64_t Kst, int64_t nnz, void* stream);
 
+/* Same contract on the matrix cores for graphs whose DENSE N x N GSO fits in LDS (the drivers' N = 50..80): every hop,
+ * tap, weight-gradient and adjoint product of a time step is a small GEMM on v_mfma_f64_16x16x4_f64 /
+ * v_mfma_f32_16x16x4_f32 with operands read from LDS. Sdense = S itself, row-major [N][N] in the data dtype
+ * (z S: out[c][n] = sum_m z[c][m] S[m][n]). backward: pA [B][F][Kin][G], pB [B][F][Kst][F], pb [B][F] per-sequence
+ * partial sums (added over B by the caller), dgi / dgf / dh0 as for gcrnn_small_backward. */
+int gcrnn_small_dense_supported(int dtype, int64_t N, int64_t G, int64_t F, int64_t Kin, int64_t Kst, int backward,
+                                int gated);
+int gcrnn_small_dense_forward(int dtype, const void* X, const void* h0, const void* wA, const void* wB, const void* bias,
+                              const void* gi, const void* gf, const void* Sdense, void* H, int64_t B, int64_t T, int64_t N,
+                              int64_t G, int64_t F, int64_t Kin, int64_t Kst, void* stream);
+int gcrnn_small_dense_backward(int dtype, const void* X, const void* h0, const void* H, const void* dH, const void* wA,
+                               const void* wB, const void* bias, const void* gi, const void* gf, const void* Sdense,
+                               void* pA, void* pB, void* pb, void* dgi, void* dgf, void* dh0, int64_t B, int64_t T,
+                               int64_t N, int64_t G, int64_t F, int64_t Kin, int64_t Kst, void* stream);
+
 /* ==== training-loop loss ==========================================================================================
  * batchTimeL1Loss (Utils/miscTools.py:112-119 = nn.L1Loss: mean |x - y| over every entry) and its gradient in one pass.
  * x, y, grad: n contiguous elements of `dtype` (F32 / F64 / BF16), 16-byte aligned; grad (may be NULL) =

@@ -29,6 +29,17 @@ def gml():
     return m
 
 
+@pytest.fixture(params=['mfma', 'gather'])
+def small_impl(request, monkeypatch):
+    """The small-graph regime has two kernel families: dense-S matrix-core kernels (gcrnn_small_mfma.hip, preferred) and
+    CSR gather kernels (gcrnn_small.hip, any graph that fits in LDS). GCRNN_SMALL_GATHER forces the second."""
+    if request.param == 'gather':
+        monkeypatch.setenv('GCRNN_SMALL_GATHER', '1')
+    else:
+        monkeypatch.delenv('GCRNN_SMALL_GATHER', raising=False)
+    return request.param
+
+
 def archit():
     import gated_gcrnns_amd.Modules.architectures as m
     return m
@@ -240,7 +251,7 @@ def test_kstep_data_and_driver_pieces(dev):
 
 
 @pytest.mark.parametrize('name,tg', [('none', False), ('time', True)])
-def test_small_graph_persistent_kernel_g3(dev, name, tg):
+def test_small_graph_persistent_kernel_g3(dev, name, tg, small_impl):
     """Small-graph regime: the one-launch persistent kernel (inference) against the G3 goldens, fp64 and fp32."""
     g = load_golden('g3_cell_' + name)
     for dt, tol in ((torch.float64, 1e-11), (torch.float32, 1e-5)):
@@ -257,7 +268,7 @@ def test_small_graph_persistent_kernel_g3(dev, name, tg):
 
 
 @pytest.mark.parametrize('tag,K', [('T20K4', 4), ('T200K3', 3)])
-def test_small_graph_persistent_kernel_seismic(dev, tag, K):
+def test_small_graph_persistent_kernel_seismic(dev, tag, K, small_impl):
     """BASELINE configs[3]: directed 59-node seismograph graph, T = 200 -- one launch for the whole sequence."""
     for name, tg in (('none', False), ('time', True)):
         g = load_golden('g5_cls_%s_%s' % (tag, name))
@@ -316,7 +327,7 @@ def test_edge_attention_kernels(dev, dt, tol, N, B, F, Tn):
 
 @pytest.mark.parametrize('dt,tol,gtol', DTYPES)
 @pytest.mark.parametrize('name,tg', [('none', False), ('time', True)])
-def test_small_graph_bptt_kernel_vs_reference_gradients(dev, name, tg, dt, tol, gtol):
+def test_small_graph_bptt_kernel_vs_reference_gradients(dev, name, tg, dt, tol, gtol, small_impl):
     """X without gradient -> GGCRNNCell runs forward and BPTT on the one-launch small-graph kernels
     (gcrnn_small_forward / gcrnn_small_backward); parameter and h0 gradients vs the reference's (G4)."""
     from gated_gcrnns_amd import ops
@@ -351,7 +362,7 @@ def test_small_graph_bptt_kernel_vs_reference_gradients(dev, name, tg, dt, tol, 
 @pytest.mark.parametrize('N,G,F,Kin,Kst,Tn,B,tg', [(80, 1, 20, 5, 5, 5, 100, False), (59, 1, 20, 3, 3, 200, 16, True),
                                                      (50, 1, 20, 2, 2, 8, 100, True), (64, 3, 7, 1, 4, 6, 5, False),
                                                      (120, 2, 20, 3, 2, 4, 3, True)])
-def test_small_graph_bptt_kernel_vs_composed_path(dev, dt, gtol, N, G, F, Kin, Kst, Tn, B, tg):
+def test_small_graph_bptt_kernel_vs_composed_path(dev, dt, gtol, N, G, F, Kin, Kst, Tn, B, tg, small_impl):
     """Same cell, same inputs: one-launch BPTT vs the composed (autograd over LSIGF nodes) path, incl. Kin != Kst,
     even / odd N, P = 2 and P = 4 slot passes and the long T = 200 sequence."""
     rng = np.random.default_rng(N + Tn)
