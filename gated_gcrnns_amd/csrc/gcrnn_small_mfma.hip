@@ -28,7 +28,12 @@ template <> struct Mf<double> {
   typedef d4 acc;
   static __device__ __forceinline__ acc mma(double a, double b, acc c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
   static __device__ __forceinline__ int row(int lane, int r) { return (lane >> 4) + 4 * r; }
-  static __device__ __forceinline__ double tanh_(double v) { return tanh(v); }
+  // tanh(v) = sign(v) (1 - t) / (1 + t), t = exp(-2 |v|): no overflow, absolute error ~1e-16 -- a third of the
+  // instructions of the library tanh, which sits on the critical path of every time step
+  static __device__ __forceinline__ double tanh_(double v) {
+    const double t = exp(-2.0 * fabs(v));
+    return copysign((1.0 - t) / (1.0 + t), v);
+  }
 };
 template <> struct Mf<float> {
   typedef f4 acc;
@@ -47,14 +52,49 @@ __host__ __device__ inline int lds_stride(int n) {
   return s;
 }
 
-// D(i0.., j0..) += sum_k a(i, k) b(k, j), k in [0, Kdim) (Kdim rounded up to 4 by the caller's zero padding)
-// (unrolled by 4 so that the LDS reads of four k-steps are in flight before the dependent MFMA chain consumes them)
-#define GCRNN_TILE_MAC(acc, Kdim, AEXPR, BEXPR)                       \
-  _Pragma("unroll 4")                                                 \
-  for (int k0_ = 0; k0_ < (Kdim); k0_ += 4) {                         \
-    const int kk = k0_ + lk;                                          \
-    acc = Mf<T>::mma((AEXPR), (BEXPR), acc);                          \
+// acc += sum over `ksteps` k-steps of A(i, k) B(k, j): ap / bp point at this lane's element of k-step 0 and advance by
+// astep / bstep elements per k-step. Branch-free (masked lanes point at a row of zeros) and batched by four so that
+// eight LDS reads are in flight before the dependent MFMA chain consumes them.
+template <typename T>
+__device__ __forceinline__ typename Mf<T>::acc tile_mac(typename Mf<T>::acc acc, const T* ap, int astep, const T* bp,
+                                                        int bstep, int ksteps, T ascale = T(1), T bscale = T(1)) {
+  int s = 0;
+  for (; s + 4 <= ksteps; s += 4) {
+    const T a0 = ap[0], a1 = ap[astep], a2 = ap[2 * astep], a3 = ap[3 * astep];
+    const T b0 = bp[0], b1 = bp[bstep], b2 = bp[2 * bstep], b3 = bp[3 * bstep];
+    ap += 4 * astep; bp += 4 * bstep;
+    acc = Mf<T>::mma(a0 * ascale, b0 * bscale, acc);
+    acc = Mf<T>::mma(a1 * ascale, b1 * bscale, acc);
+    acc = Mf<T>::mma(a2 * ascale, b2 * bscale, acc);
+    acc = Mf<T>::mma(a3 * ascale, b3 * bscale, acc);
   }
+  for (; s < ksteps; ++s) {
+    acc = Mf<T>::mma(ap[0] * ascale, bp[0] * bscale, acc);
+    ap += astep; bp += bstep;
+  }
+  return acc;
+}
+
+// same with a per-k-step multiplier table on the A operand (time gates: x-columns times gi, h-columns times gf)
+template <typename T>
+__device__ __forceinline__ typename Mf<T>::acc tile_mac_gated(typename Mf<T>::acc acc, const T* ap, const T* gp, const T* bp,
+                                                              int bstep, int ksteps) {
+  int s = 0;
+  for (; s + 4 <= ksteps; s += 4) {
+    const T a0 = ap[0] * gp[0], a1 = ap[4] * gp[4], a2 = ap[8] * gp[8], a3 = ap[12] * gp[12];
+    const T b0 = bp[0], b1 = bp[bstep], b2 = bp[2 * bstep], b3 = bp[3 * bstep];
+    ap += 16; gp += 16; bp += 4 * bstep;
+    acc = Mf<T>::mma(a0, b0, acc);
+    acc = Mf<T>::mma(a1, b1, acc);
+    acc = Mf<T>::mma(a2, b2, acc);
+    acc = Mf<T>::mma(a3, b3, acc);
+  }
+  for (; s < ksteps; ++s) {
+    acc = Mf<T>::mma(ap[0] * gp[0], bp[0], acc);
+    ap += 4; gp += 4; bp += bstep;
+  }
+  return acc;
+}
 
 // ------------------------------------------------------------------------------------------------------------------
 // forward
@@ -80,6 +120,8 @@ __global__ __launch_bounds__(1024) void small_dense_fwd_kernel(
   T* Z = S + (size_t)N4 * Ns;                      // [KC4][Ns]  (level k = rows k C .. k C + C - 1)
   T* W = Z + (size_t)KC4 * Ns;                     // [F16][KCs] combined taps, F16 = F rounded up to 16
   const int F16 = (F + 15) & ~15;
+  T* zrow = W + (size_t)F16 * KCs;                 // [Ns] zeros: what masked lanes read
+  T* gtab = zrow + Ns;                             // [KC4] gate of every flattened tap column (time-gated cells)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, lk = lane >> 4;
   const int b = blockIdx.x;
@@ -89,6 +131,7 @@ __global__ __launch_bounds__(1024) void small_dense_fwd_kernel(
     S[i] = (m < N && n < N) ? Sd[(size_t)m * N + n] : T(0);
   }
   for (int i = tid; i < KC4 * Ns; i += 1024) Z[i] = T(0);
+  for (int i = tid; i < Ns + KC4; i += 1024) zrow[i] = T(0);
   for (int i = tid; i < F16 * KCs; i += 1024) {
     const int f = i / KCs, kc = i - f * KCs;
     T v = T(0);
@@ -120,6 +163,11 @@ __global__ __launch_bounds__(1024) void small_dense_fwd_kernel(
       Z[g * Ns + n] = xt[i];
     }
     if (t + 1 < Tn && tid < GN) xpre = xt[GN + tid];
+    T gin = T(1), gfo = T(1);
+    if (gi) {
+      gin = gi[(size_t)t * B + b]; gfo = gf[(size_t)t * B + b];
+      if (tid < KC4) gtab[tid] = (tid < KC) ? (((tid % C) < G) ? gin : gfo) : T(0);
+    }
     __syncthreads();
     // ---- hops: Z_k = Z_{k-1} S
     for (int k = 1; k < K; ++k) {
@@ -128,8 +176,8 @@ __global__ __launch_bounds__(1024) void small_dense_fwd_kernel(
       for (int tile = wave; tile < tilesC * tilesN; tile += 16) {
         const int i0 = (tile / tilesN) << 4, j0 = (tile % tilesN) << 4;
         acc_t acc = {0, 0, 0, 0};
-        const bool arow = i0 + li < C;
-        GCRNN_TILE_MAC(acc, N4, arow ? zp[(i0 + li) * Ns + kk] : T(0), S[kk * Ns + j0 + li]);
+        const T* ap = (i0 + li < C) ? zp + (i0 + li) * Ns + lk : zrow + lk;
+        acc = tile_mac<T>(acc, ap, 4, S + lk * Ns + j0 + li, 4 * Ns, N4 >> 2);
         const int n = j0 + li;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -140,8 +188,6 @@ __global__ __launch_bounds__(1024) void small_dense_fwd_kernel(
       __syncthreads();
     }
     // ---- taps: pre = W Zflat (time gates scale the x- and h-columns of W)
-    T gin = T(1), gfo = T(1);
-    if (gi) { gin = gi[(size_t)t * B + b]; gfo = gf[(size_t)t * B + b]; }
     acc_t outv[MAXT];
 #pragma unroll
     for (int q = 0; q < MAXT; ++q) {
@@ -149,12 +195,9 @@ __global__ __launch_bounds__(1024) void small_dense_fwd_kernel(
       if (tile >= tilesF * tilesN) break;
       const int i0 = (tile / tilesN) << 4, j0 = (tile % tilesN) << 4;
       acc_t acc = {0, 0, 0, 0};
-      const T* wr = W + (i0 + li) * KCs;
-      if (gi) {
-        GCRNN_TILE_MAC(acc, KC4, wr[kk] * (((kk % C) < G) ? gin : gfo), Z[kk * Ns + j0 + li]);
-      } else {
-        GCRNN_TILE_MAC(acc, KC4, wr[kk], Z[kk * Ns + j0 + li]);
-      }
+      const T* wr = W + (i0 + li) * KCs + lk;
+      if (gi) acc = tile_mac_gated<T>(acc, wr, gtab + lk, Z + lk * Ns + j0 + li, 4 * Ns, KC4 >> 2);
+      else    acc = tile_mac<T>(acc, wr, 4, Z + lk * Ns + j0 + li, 4 * Ns, KC4 >> 2);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int f = i0 + Mf<T>::row(lane, r);
@@ -190,7 +233,7 @@ size_t dense_fwd_lds(int64_t N, int64_t G, int64_t F, int64_t K) {
   const int C = (int)(G + F), KC = (int)K * C;
   const int Ns = lds_stride<T>((int)N), KCs = lds_stride<T>(KC);
   const int N4 = ((int)N + 3) & ~3, KC4 = (KC + 3) & ~3, F16 = ((int)F + 15) & ~15;
-  return sizeof(T) * ((size_t)N4 * Ns + (size_t)KC4 * Ns + (size_t)F16 * KCs) + 16;
+  return sizeof(T) * ((size_t)N4 * Ns + (size_t)KC4 * Ns + (size_t)F16 * KCs + Ns + KC4) + 16;
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -210,7 +253,7 @@ __global__ __launch_bounds__(1024) void small_dense_bwd_kernel(
   extern __shared__ __attribute__((aligned(16))) char smem_dense[];
   const int K = Kin > Kst ? Kin : Kst;
   const int C = G + F;
-  const int Ns = lds_stride<T>(N), Fs = lds_stride<T>(F), Cs = lds_stride<T>(C);
+  const int Ns = lds_stride<T>(N), Fs = lds_stride<T>(F + 1), Cs = lds_stride<T>(C);      // Fs > F: column F of WBt is zero
   const int N4 = (N + 3) & ~3, F4 = (F + 3) & ~3, C4 = (C + 3) & ~3, C16 = (C + 15) & ~15, F16 = (F + 15) & ~15;
   T* S = reinterpret_cast<T*>(smem_dense);         // [max(N4, 16 tilesN)][Ns]   dense S; rows also serve as B operand S[n][m]
   const int tilesN = (N + 15) >> 4, tilesC = C16 >> 4, tilesF = F16 >> 4;
@@ -222,7 +265,8 @@ __global__ __launch_bounds__(1024) void small_dense_bwd_kernel(
   T* WBt = carry + (size_t)F4 * Ns;                // [Kst][F4 (f)][Fs (f2)]   w_B[f][k][f2]
   T* WAl = WBt + (size_t)Kst * F4 * Fs;            // GATED: [F][K][Cs] combined taps
   T* red = WAl + (GATED ? (size_t)F * K * Cs : 0);     // [64]
-  (void)C16;
+  T* zrow = red + 64;                                  // [max(Ns, K Cs)] zeros: what masked lanes read
+  (void)C16; (void)F16;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, lk = lane >> 4;
   const int b = blockIdx.x;
@@ -232,6 +276,7 @@ __global__ __launch_bounds__(1024) void small_dense_bwd_kernel(
     S[i] = (m < N && n < N) ? Sd[(size_t)m * N + n] : T(0);
   }
   for (int i = tid; i < 2 * C4 * Ns + 2 * F4 * Ns; i += 1024) Z0[i] = T(0);        // Z0, Z1, dpre, carry are contiguous
+  for (int i = tid; i < (Ns > K * Cs ? Ns : K * Cs); i += 1024) zrow[i] = T(0);
   for (int i = tid; i < Kst * F4 * Fs; i += 1024) {
     const int k = i / (F4 * Fs), rem = i - k * (F4 * Fs);
     const int f = rem / Fs, f2 = rem - f * Fs;
@@ -289,13 +334,10 @@ __global__ __launch_bounds__(1024) void small_dense_bwd_kernel(
           const int rem = tile - k * (tilesF * tilesC);
           const int i0 = (rem / tilesC) << 4, j0 = (rem % tilesC) << 4;
           // A = dpre (i = f, k = n), B = Z_k^T (k = n, j = c): both "lanes over rows, lane groups over consecutive n"
-          const bool am = i0 + li < F, bm = j0 + li < C;
-          const T* ar = dpre + (am ? i0 + li : 0) * Ns;
-          const T* br = zc + (bm ? j0 + li : 0) * Ns;
-          const T sc = bm ? ((j0 + li < G) ? gin : gfo) : T(0);
-          acc_t acc = wacc[q];
-          GCRNN_TILE_MAC(acc, N4, am ? ar[kk] : T(0), br[kk] * sc);
-          wacc[q] = acc;
+          const T* ap = (i0 + li < F) ? dpre + (i0 + li) * Ns + lk : zrow + lk;
+          const T* bp = (j0 + li < C) ? zc + (j0 + li) * Ns + lk : zrow + lk;
+          // A = dpre (i = f, k = n), B = Z_k^T (k = n, j = c) scaled by the gate of column c
+          wacc[q] = tile_mac<T>(wacc[q], ap, 4, bp, 4, N4 >> 2, T(1), (j0 + li < G) ? gin : gfo);
         }
       }
       if (GATED) {
@@ -304,14 +346,13 @@ __global__ __launch_bounds__(1024) void small_dense_bwd_kernel(
           const int tile = wave + q * 16;
           if (tile >= tilesF * tilesN) break;
           const int i0 = (tile / tilesN) << 4, j0 = (tile % tilesN) << 4;
-          const bool am = i0 + li < F;
-          const T* wr = WAl + ((size_t)(am ? i0 + li : 0) * K + k) * Cs;
+          const T* wr = (i0 + li < F) ? WAl + ((size_t)(i0 + li) * K + k) * Cs : zrow;      // columns C .. Cs-1 are zero
           acc_t a = ya[q], bq = yb[q];
           const int G4 = (G + 3) & ~3;
-          // x-columns c < G into ya, h-columns into yb (a k-step that straddles G contributes to both with masks)
+          // x-columns c < G into ya, h-columns into yb (a k-step that straddles G contributes to both, masked by select)
           for (int c0 = 0; c0 < C4; c0 += 4) {
             const int c = c0 + lk;
-            const T wv = (am && c < C) ? wr[c] : T(0);
+            const T wv = wr[c];
             const T zv = zc[c * Ns + j0 + li];                       // rows C .. C4-1 are zero
             if (c0 < G4) a = Mf<T>::mma(c < G ? wv : T(0), zv, a);
             if (c0 + 3 >= G) bq = Mf<T>::mma(c >= G ? wv : T(0), zv, bq);
@@ -324,9 +365,8 @@ __global__ __launch_bounds__(1024) void small_dense_bwd_kernel(
           const int tl = (tile + 5) % (tilesC * tilesN);          // start the hop tiles on other waves than the dW tiles
           const int i0 = (tl / tilesN) << 4, j0 = (tl % tilesN) << 4;
           acc_t acc = {0, 0, 0, 0};
-          const bool am = i0 + li < C;
-          const T* ar = zc + (am ? i0 + li : 0) * Ns;
-          GCRNN_TILE_MAC(acc, N4, am ? ar[kk] : T(0), S[kk * Ns + j0 + li]);
+          const T* ap = (i0 + li < C) ? zc + (i0 + li) * Ns + lk : zrow + lk;
+          acc = tile_mac<T>(acc, ap, 4, S + lk * Ns + j0 + li, 4 * Ns, N4 >> 2);
           const int n = j0 + li;
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
@@ -386,12 +426,11 @@ __global__ __launch_bounds__(1024) void small_dense_bwd_kernel(
         acc_t acc = {0, 0, 0, 0};
         // A = B_k^T (i = f2, k = f) = wk[f][f2], B = dpre (k = f, j = n)
         const bool acol = i0 + li < F;
-        GCRNN_TILE_MAC(acc, F4, acol ? wk[kk * Fs + i0 + li] * gfo : T(0), dpre[kk * Ns + j0 + li]);
+        acc = tile_mac<T>(acc, wk + lk * Fs + (acol ? i0 + li : F), 4 * Fs, dpre + lk * Ns + j0 + li, 4 * Ns, F4 >> 2, gfo);
         if (k < Kst - 1) {
           // A = acc (i = f2, k = m), B = S^T (k = m, j = n) = S[n][m]
-          const T* ar = ac + (acol ? i0 + li : 0) * Ns;
-          const T* sr = S + (j0 + li) * Ns;
-          GCRNN_TILE_MAC(acc, N4, acol ? ar[kk] : T(0), sr[kk]);
+          const T* ap = acol ? ac + (i0 + li) * Ns + lk : zrow + lk;
+          acc = tile_mac<T>(acc, ap, 4, S + (j0 + li) * Ns + lk, 4, N4 >> 2);
         }
         const int n = j0 + li;
 #pragma unroll
@@ -434,11 +473,11 @@ __global__ __launch_bounds__(1024) void small_dense_bwd_kernel(
 template <typename T>
 size_t dense_bwd_lds(int64_t N, int64_t G, int64_t F, int64_t Kin, int64_t Kst, bool gated) {
   const int K = (int)(Kin > Kst ? Kin : Kst), C = (int)(G + F);
-  const int Ns = lds_stride<T>((int)N), Fs = lds_stride<T>((int)F), Cs = lds_stride<T>(C);
+  const int Ns = lds_stride<T>((int)N), Fs = lds_stride<T>((int)F + 1), Cs = lds_stride<T>(C);
   const int F4 = ((int)F + 3) & ~3, C4 = (C + 3) & ~3;
   const int SR = (((int)N + 15) >> 4) * 16;
   return sizeof(T) * ((size_t)SR * Ns + 2 * (size_t)C4 * Ns + 2 * (size_t)F4 * Ns + (size_t)Kst * F4 * Fs +
-                      (gated ? (size_t)F * K * Cs : 0) + 64) + 16;
+                      (gated ? (size_t)F * K * Cs : 0) + 64 + (size_t)(Ns > K * Cs ? Ns : K * Cs)) + 16;
 }
 
 constexpr size_t DENSE_LDS_MAX = 160 * 1024;
