@@ -155,7 +155,10 @@ def test_g5_classification_seismic_graph(dev, tag, K, name, tg):
         x, h0 = T(g['x'], dt, dev), T(g['h0'], dt, dev)
         assert maxdiff(m(x, h0), g['y']) <= tol      # logits sum 1180 state entries
         Hl = m.stateGCRNN(x, h0)[:, -1]
-        assert maxdiff(Hl, g['h_last']) <= (1e-11 if dt == torch.float64 else 1e-5)
+        # fp32: this recurrence (G = 1, reference init, 20..200 steps) amplifies rounding ~100x -- the reference's own
+        # algorithm evaluated in fp32 is 2.3e-5 away from its fp64 result (tests/test_oracle_golden.py pins that), so the
+        # 1e-5 bar of the well-conditioned cases cannot apply to the last state here
+        assert maxdiff(Hl, g['h_last']) <= (1e-11 if dt == torch.float64 else 1e-4)
 
 
 def test_g8_midsize_n1000(dev):
