@@ -93,6 +93,8 @@ def main():
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32', 'f64'])
     ap.add_argument('--mode', default='fwd', choices=['fwd', 'train'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--time-gating', action='store_true', help='secondary point: the time-gated cell (forward only); '
+                    'the headline workload is the un-gated cell')
     ap.add_argument('--hipgraph', type=int, default=0, help='replay the fused forward as one captured hipGraph (bf16 fwd)')
     args = ap.parse_args()
 
@@ -117,7 +119,8 @@ def main():
     S = sbm_graph(N)
     nnz = int(np.count_nonzero(S))
     torch.manual_seed(0)
-    cell = gml.GGCRNNCell(G, F, K, K, torch.tanh, False, None, 1, True)      # reference init U(+-1/sqrt(G*K))
+    assert not (args.time_gating and args.mode == 'train'), 'time-gated training runs on the composed fp32/fp64 path'
+    cell = gml.GGCRNNCell(G, F, K, K, torch.tanh, args.time_gating, None, 1, True)      # reference init U(+-1/sqrt(G*K))
     cell.addGSO(torch.tensor(S))
     params = {k: v.detach().numpy().copy() for k, v in cell.state_dict().items()}
     cell = cell.to(dev).to(dt)
@@ -183,7 +186,7 @@ def main():
 
     # ---- dominant kernel: the fused step kernel, timed live with HIP events on the stream it is launched on ----
     kern = None
-    if args.dtype == 'bf16' and args.mode == 'fwd':
+    if args.dtype == 'bf16' and args.mode == 'fwd' and not args.time_gating:
         from gated_gcrnns_amd import ops
         with torch.no_grad():
             for _ in range(2):
@@ -201,7 +204,7 @@ def main():
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype,
             'data': 'synthetic',
             'config': {'workload': 'BASELINE configs[1]: synthetic k-step prediction, sparse SBM N=1000 nnz=%d, K=5 taps, '
-                                   'T=32, G=F=64, un-gated GGCRNNCell forward, h0=0' % nnz,
+                                   'T=32, G=F=64, %s GGCRNNCell forward, h0=0' % (nnz, 'time-gated' if args.time_gating else 'un-gated'),
                        'batch_per_gpu': B, 'global_batch': world * B, 'mode': args.mode, 'hipgraph': bool(runner is not None), 'parallelism': 'dp%d' % world},
         }
         if kern is not None:

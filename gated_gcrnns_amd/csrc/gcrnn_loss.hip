@@ -28,7 +28,29 @@ __global__ __launch_bounds__(256) void l1_loss_kernel(const T* __restrict__ x, c
   __shared__ A red[4];
   A acc = A(0);
   const int64_t stride = (int64_t)gridDim.x * 256 * ELEMS;
-  for (int64_t base = ((int64_t)blockIdx.x * 256 + threadIdx.x) * ELEMS; base < n; base += stride) {
+  int64_t base = ((int64_t)blockIdx.x * 256 + threadIdx.x) * ELEMS;
+  // two independent 16-byte chunks per thread and trip while both are whole: twice the loads in flight
+  for (; base + stride + ELEMS <= n; base += 2 * stride) {
+    T xa[ELEMS], ya[ELEMS], xb[ELEMS], yb[ELEMS], ga[ELEMS], gb[ELEMS];
+    *reinterpret_cast<uint4*>(xa) = *reinterpret_cast<const uint4*>(x + base);
+    *reinterpret_cast<uint4*>(ya) = *reinterpret_cast<const uint4*>(y + base);
+    *reinterpret_cast<uint4*>(xb) = *reinterpret_cast<const uint4*>(x + base + stride);
+    *reinterpret_cast<uint4*>(yb) = *reinterpret_cast<const uint4*>(y + base + stride);
+#pragma unroll
+    for (int e = 0; e < ELEMS; ++e) {
+      const A da = (A)ld(xa, e) - (A)ld(ya, e), db = (A)ld(xb, e) - (A)ld(yb, e);
+      acc += (da < A(0) ? -da : da) + (db < A(0) ? -db : db);
+      if (grad) {
+        st(ga, e, da > A(0) ? inv_n : (da < A(0) ? -inv_n : A(0)));
+        st(gb, e, db > A(0) ? inv_n : (db < A(0) ? -inv_n : A(0)));
+      }
+    }
+    if (grad) {
+      *reinterpret_cast<uint4*>(grad + base) = *reinterpret_cast<const uint4*>(ga);
+      *reinterpret_cast<uint4*>(grad + base + stride) = *reinterpret_cast<const uint4*>(gb);
+    }
+  }
+  for (; base < n; base += stride) {
     if (base + ELEMS <= n) {
       T xv[ELEMS], yv[ELEMS];
       *reinterpret_cast<uint4*>(xv) = *reinterpret_cast<const uint4*>(x + base);
