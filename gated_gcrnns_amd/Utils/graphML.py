@@ -416,7 +416,18 @@ class GGCRNNCell(nn.Module):
 
     def _forward_small(self, X, h0, train=False):
         gi = gf = None
-        if self.time_gating == True:  # noqa: E712   gates read (x_t, h0) only: one batched pass over all t
+        if self.time_gating == True and ops.small_gates_supported(  # noqa: E712
+                self.N, self.G, self.F, self.Kin, self.Kst, X.dtype, backward=train):
+            # both gates of every step in one launch on the matrix cores (parameters stacked input | forget)
+            gin, gfo = self.GFL_in, self.GFL_forget
+            lin_i, lin_f = self.MLP_in[0], self.MLP_forget[0]
+            gates = ops.small_time_gates(
+                X, h0, torch.stack((gin.weight_A[:, 0], gfo.weight_A[:, 0])), torch.stack((gin.weight_B[:, 0], gfo.weight_B[:, 0])),
+                torch.stack((gin.bias.view(-1), gfo.bias.view(-1))) if gin.bias is not None else None,
+                torch.stack((lin_i.weight.view(-1), lin_f.weight.view(-1))),
+                torch.stack((lin_i.bias.view(()), lin_f.bias.view(()))) if lin_i.bias is not None else None, self.graph)
+            gi, gf = gates[0], gates[1]
+        elif self.time_gating == True:  # noqa: E712   gates read (x_t, h0) only: one batched pass over all t
             B = X.shape[0]
             Xn = ops.pack_node_major(X)
             h0n = ops.pack_node_major(h0.reshape(B, 1, self.F, self.N))

@@ -501,6 +501,56 @@ def small_cell_train(X, h0, wA, wB, bias, graph, gi=None, gf=None):
     return _SmallCell.apply(X, h0, wA, wB, bias, gi, gf, graph)
 
 
+def small_gates_supported(N, G, F, Kin, Kst, dtype, backward):
+    if dtype not in (torch.float32, torch.float64) or os.environ.get('GCRNN_SMALL_GATHER'):
+        return False
+    return bool(lib.gcrnn_small_gates_supported(dtype_code(dtype), int(N), int(G), int(F), int(Kin), int(Kst), int(backward)))
+
+
+class _SmallTimeGates(torch.autograd.Function):
+    """Both time gates of a small-graph cell for all steps: one launch forward, one backward (reference
+    graphML.py:2357-2374). Parameters stacked over (input, forget). Returns gates [2][T][B]. No gradient for X."""
+
+    @staticmethod
+    def forward(ctx, X, h0, wA2, wB2, bias2, lw2, lb2, graph):
+        X, h0, wA2, wB2, lw2 = X.contiguous(), h0.contiguous(), wA2.contiguous(), wB2.contiguous(), lw2.contiguous()
+        bias2 = bias2.contiguous() if bias2 is not None else None
+        lb2 = lb2.contiguous() if lb2 is not None else None
+        B, T, G, N = X.shape
+        F, Kin, Kst = wA2.shape[1], wA2.shape[2], wB2.shape[2]
+        Sd = graph.dense(X.dtype)
+        gates = torch.empty((2, T, B), dtype=X.dtype, device=X.device)
+        check(lib.gcrnn_small_gates_forward(dtype_code(X.dtype), _p(X), _p(h0), _p(wA2), _p(wB2), _p(bias2), _p(lw2), _p(lb2),
+                                            _p(Sd), _p(gates), B, T, N, G, F, Kin, Kst, _stream()), 'small_gates_forward')
+        ctx.save_for_backward(X, h0, wA2, wB2, bias2, lw2, gates)
+        ctx.graph, ctx.has_lb = graph, lb2 is not None
+        return gates
+
+    @staticmethod
+    def backward(ctx, dgates):
+        X, h0, wA2, wB2, bias2, lw2, gates = ctx.saved_tensors
+        B, T, G, N = X.shape
+        F, Kin, Kst = wA2.shape[1], wA2.shape[2], wB2.shape[2]
+        dt, dev = X.dtype, X.device
+        dsum = (dgates * gates * (1 - gates)).contiguous()                    # through the sigmoid
+        Sd = ctx.graph.dense(dt)
+        pA = torch.empty((B, 2, F, Kin, G), dtype=dt, device=dev)
+        pB = torch.empty((B, 2, F, Kst, F), dtype=dt, device=dev)
+        pb = torch.empty((B, 2, F), dtype=dt, device=dev)
+        plw = torch.empty((B, 2, F * N), dtype=dt, device=dev)
+        plb = torch.empty((B, 2), dtype=dt, device=dev)
+        pdh0 = torch.empty((B, 2, F, N), dtype=dt, device=dev) if ctx.needs_input_grad[1] else None
+        check(lib.gcrnn_small_gates_backward(dtype_code(dt), _p(X), _p(h0), _p(wA2), _p(wB2), _p(bias2), _p(lw2), _p(Sd),
+                                             _p(dsum), _p(pA), _p(pB), _p(pb), _p(plw), _p(plb), _p(pdh0), B, T, N, G, F, Kin,
+                                             Kst, _stream()), 'small_gates_backward')
+        return (None, pdh0.sum(dim=1) if pdh0 is not None else None, pA.sum(dim=0), pB.sum(dim=0),
+                pb.sum(dim=0) if bias2 is not None else None, plw.sum(dim=0), plb.sum(dim=0) if ctx.has_lb else None, None)
+
+
+def small_time_gates(X, h0, wA2, wB2, bias2, lw2, lb2, graph):
+    return _SmallTimeGates.apply(X, h0, wA2, wB2, bias2, lw2, lb2, graph)
+
+
 # ------------------------------------------------------------------------------------------ loss
 class _L1Loss(torch.autograd.Function):
     """mean |x - y| with the gradient produced in the same pass (reference batchTimeL1Loss, miscTools.py:112-119)."""

@@ -224,6 +224,21 @@ int gcrnn_small_dense_backward(int dtype, const void* X, const void* h0, const v
                                void* pA, void* pB, void* pb, void* dgi, void* dgf, void* dh0, int64_t B, int64_t T,
                                int64_t N, int64_t G, int64_t F, int64_t Kin, int64_t Kst, void* stream);
 
+/* Time gates of the small-graph regime (GGCRNNCell time gating, graphML.py:2248-2278, 2357-2374), both gates in one launch:
+ *   gate[g][t][b] = sigmoid( lw_g . vec_{F,N}( tanh(A_g(S) x_t + B_g(S) h0 + 2 b_g) ) + lb_g ),  g = 0 input, 1 forget.
+ * Parameters stacked over the two gates: wA2 [2][F][Kin][G], wB2 [2][F][Kst][F], bias2 [2][F] or NULL, lw2 [2][F*N]
+ * (nn.Linear weight, row-major over (f, n)), lb2 [2] or NULL. backward: dsum [2][T][B] = d loss / d (pre-sigmoid value);
+ * per-sequence partial sums pA [B][2][F][Kin][G], pB [B][2][F][Kst][F], pb [B][2][F], plw [B][2][F*N], plb [B][2],
+ * pdh0 [B][2][F][N] (or NULL). */
+int gcrnn_small_gates_supported(int dtype, int64_t N, int64_t G, int64_t F, int64_t Kin, int64_t Kst, int backward);
+int gcrnn_small_gates_forward(int dtype, const void* X, const void* h0, const void* wA2, const void* wB2, const void* bias2,
+                              const void* lw2, const void* lb2, const void* Sdense, void* gate, int64_t B, int64_t T,
+                              int64_t N, int64_t G, int64_t F, int64_t Kin, int64_t Kst, void* stream);
+int gcrnn_small_gates_backward(int dtype, const void* X, const void* h0, const void* wA2, const void* wB2, const void* bias2,
+                               const void* lw2, const void* Sdense, const void* dsum, void* pA, void* pB, void* pb, void* plw,
+                               void* plb, void* pdh0, int64_t B, int64_t T, int64_t N, int64_t G, int64_t F, int64_t Kin,
+                               int64_t Kst, void* stream);
+
 /* ==== training-loop loss ==========================================================================================
  * batchTimeL1Loss (Utils/miscTools.py:112-119 = nn.L1Loss: mean |x - y| over every entry) and its gradient in one pass.
  * x, y, grad: n contiguous elements of `dtype` (F32 / F64 / BF16), 16-byte aligned; grad (may be NULL) =
