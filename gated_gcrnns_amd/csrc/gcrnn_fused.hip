@@ -238,29 +238,14 @@ extern "C" int gcrnn_fused_pack_weights(int wdtype, const void* wA, const void* 
     asm volatile("s_waitcnt lgkmcnt(" #n ")" ::: "memory");       \
     __builtin_amdgcn_sched_barrier(0);                            \
   } while (0)
-#define LGKM_WAITN(n) LGKM_WAIT(n)
 #define KEEP_ALIVE(v) asm volatile("" ::"v"(v))
 
 // One gather trip of the resident pipeline: group g has its weights in VC and its 4 gathered quads in XC*;
 // issue cols(g+2) -> CC, then (after cols(g+1) = CN landed) vals(g+1) -> VN and the gathers of g+1 -> XN*;
 // then wait for VC / XC* (issued one trip earlier) and do the 16 FMAs. lgkmcnt(6): the 6 reads just issued may
 // stay in flight. E and O name the two ping-pong register sets. Uses the locals g, gwend, gwlast, colb, valb, lds0, qx.
-#if defined(GCRNN_DEBUG_SERIAL_WAITS)
-#define GCRNN_TRIP_WAIT LGKM_WAIT(0)
-#define GCRNN_TRIP_WAIT2 LGKM_WAIT(0)
-#elif defined(GCRNN_DEBUG_SERIAL_WAIT_A)
-#define GCRNN_TRIP_WAIT LGKM_WAIT(0)
-#define GCRNN_TRIP_WAIT2 LGKM_WAIT(6)
-#elif defined(GCRNN_DEBUG_SERIAL_WAIT_B)
-#define GCRNN_TRIP_WAIT LGKM_WAIT(6)
-#define GCRNN_TRIP_WAIT2 LGKM_WAIT(0)
-#elif defined(GCRNN_DEBUG_WAIT2)
-#define GCRNN_TRIP_WAIT LGKM_WAIT(6)
-#define GCRNN_TRIP_WAIT2 LGKM_WAITN(GCRNN_DEBUG_WAIT2)
-#else
 #define GCRNN_TRIP_WAIT LGKM_WAIT(6)
 #define GCRNN_TRIP_WAIT2 LGKM_WAIT(6)
-#endif
 #define GCRNN_TRIP(ACC, CC, CN, VC, VN, XC0, XC1, XC2, XC3, XN0, XN1, XN2, XN3)                    \
   do {                                                                                             \
     const int g1_ = (g + 1 < gwend) ? g + 1 : gwlast, g2_ = (g + 2 < gwend) ? g + 2 : gwlast;      \
@@ -1007,9 +992,6 @@ __global__ __launch_bounds__(512, 2) void fused_wgrad_kernel(
         GCRNN_HOP_TILED(GCRNN_WG_INIT, GCRNN_WG_STORE);
 #undef GCRNN_WG_INIT
 #undef GCRNN_WG_STORE
-#ifdef GCRNN_DEBUG_BARRIER_AFTER_HOP
-        __syncthreads();
-#endif
 #endif
       }
       if (has_tile) {
