@@ -86,3 +86,37 @@ class KStepPrediction(object):
     def evaluate(yHat, y):
         from .miscTools import batchTimeMSELoss
         return batchTimeMSELoss(yHat, y)
+
+
+def kstep_prediction_on_device(S, K, n, horizon, device, dtype=torch.float32, sigmaSpatial=0.1, sigmaTemporal=0.1,
+                               generator=None, noise=None):
+    """The KStepPrediction recipe (reference dataTools.py:1282-1302: x_0 ~ U[0,1)^N, x_{t+1} = x_t A + spatial noise +
+    temporal noise) generated ON the device with the same CSR SpMM the filters use -- no host pass, no dense A, so it also
+    serves graphs whose dense GSO would not fit (BASELINE configs[1], [4]).
+
+    S: the already normalised GSO (E x N x N tensor / array with E = 1, or a GraphOperator). Returns
+    (signals, labels), both n x seqLen x N with seqLen = horizon - K, labels = the sequence K steps ahead.
+    noise: optional (x0 [N][n], spatial [horizon][N][n], temporal [horizon][N][n]) for reproducible tests."""
+    from .. import ops
+    from ..graph import as_operator, GraphOperator
+    graph = S if isinstance(S, GraphOperator) else as_operator(torch.as_tensor(np.asarray(S) if not isinstance(S, torch.Tensor) else S))
+    graph = graph.to(device)
+    N = graph.N
+    if noise is None:
+        x = torch.rand((1, N, n), device=device, dtype=dtype, generator=generator)
+        spatial = sigmaSpatial * torch.randn((horizon, 1, N, n), device=device, dtype=dtype, generator=generator)
+        temporal = sigmaTemporal * torch.randn((horizon, 1, N, n), device=device, dtype=dtype, generator=generator)
+    else:
+        x = noise[0].to(device=device, dtype=dtype).reshape(1, N, n).contiguous()
+        spatial = noise[1].to(device=device, dtype=dtype).reshape(horizon, 1, N, n)
+        temporal = noise[2].to(device=device, dtype=dtype).reshape(horizon, 1, N, n)
+    xs = torch.empty((horizon + 1, N, n), device=device, dtype=dtype)
+    xs[0] = x[0]
+    csr = graph.fwd[0]                                   # row-vector shift x A on node-major data = CSR(A^T) SpMM
+    for t in range(horizon):
+        nxt = (spatial[t] + temporal[t]).contiguous()
+        ops.spmm_raw(csr, x.contiguous(), out=nxt, accumulate=True)          # nxt += x A
+        xs[t + 1] = nxt[0]
+        x = nxt
+    seq = xs.permute(2, 0, 1)                            # n x (horizon + 1) x N
+    return seq[:, 0:horizon - K].contiguous(), seq[:, K:horizon].contiguous()

@@ -442,3 +442,23 @@ def test_l1_loss_kernel(dev, dt, tol, shape):
     n = x.numel()
     assert float((gx.double() - x.grad.double()).abs().max()) <= tol * 3.0 / n + (1e-2 * 3.0 / n if dt == torch.bfloat16 else 0)
     assert float((gy.double() - y.grad.double()).abs().max()) <= tol * 3.0 / n + (1e-2 * 3.0 / n if dt == torch.bfloat16 else 0)
+
+
+def test_kstep_data_generated_on_device(dev):
+    """dataTools.kstep_prediction_on_device: the diffusion recipe on the CSR SpMM vs a dense evaluation of the same noise."""
+    from gated_gcrnns_amd.Utils import dataTools
+    rng = np.random.default_rng(3)
+    N, n, K, horizon = 40, 17, 3, 10
+    W = dataTools.sbm_adjacency(N, 4, 0.6, 0.2, rng)
+    A = dataTools.normalised_gso(W)
+    x0 = rng.random((N, n)); sp = 0.1 * rng.standard_normal((horizon, N, n)); tp = 0.1 * rng.standard_normal((horizon, N, n))
+    sig, lab = dataTools.kstep_prediction_on_device(torch.tensor(A[None]), K, n, horizon, dev, torch.float64,
+                                                    noise=(torch.tensor(x0), torch.tensor(sp), torch.tensor(tp)))
+    xs = [x0.T]                                          # n x N rows
+    for t in range(horizon):
+        xs.append(xs[-1] @ A + sp[t].T + tp[t].T)
+    ref = np.stack(xs, axis=1)                           # n x (horizon + 1) x N
+    assert tuple(sig.shape) == (n, horizon - K, N) and tuple(lab.shape) == (n, horizon - K, N)
+    assert maxdiff(sig, ref[:, 0:horizon - K]) <= 1e-12 and maxdiff(lab, ref[:, K:horizon]) <= 1e-12
+    s2, _ = dataTools.kstep_prediction_on_device(torch.tensor(A[None]), K, n, horizon, dev, torch.float32)      # random path runs
+    assert torch.isfinite(s2).all()
