@@ -98,6 +98,11 @@ class GatedGCRNNforRegression(_GatedGCRNNBase):
         if self.mlpType == 'multipMlp':
             # one perceptron shared by all nodes (reference :1616-1627 loops over nodes; here one batched GEMM)
             assert self.F_h > 1, "the reference's per-node squeeze() breaks for F_h = 1 (architectures.py:1622)"
+            lin = self.outputNN[0] if len(self.outputNN) == 1 and isinstance(self.outputNN[0], nn.Linear) else None
+            if lin is not None and ops.node_linear_supported(self.F_h, lin.out_features, flatH.dtype):
+                # the drivers' head (dimLayersMLP = [1]): one kernel on the user layout, no transposes
+                flatY = ops.node_linear(flatH, lin.weight, lin.bias)            # (BT) x out x N
+                return flatY.reshape(batchSize, seqLength, -1).unsqueeze(2)
             rows = flatH.transpose(1, 2).reshape(-1, self.F_h)                  # (BT*N) x F_h
             flatY = _apply_mlp_rows(self.outputNN, rows).reshape(flatH.shape[0], self.N, -1).transpose(1, 2)   # (BT) x out x N
         else:

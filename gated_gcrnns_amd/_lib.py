@@ -82,6 +82,9 @@ def _bind(lib):
         'gcrnn_small_gates_supported': (C.c_int, [C.c_int, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, C.c_int]),
         'gcrnn_small_gates_forward': (C.c_int, [C.c_int] + [_c_p] * 9 + [_c_i64] * 7 + [_c_p]),
         'gcrnn_small_gates_backward': (C.c_int, [C.c_int] + [_c_p] * 14 + [_c_i64] * 7 + [_c_p]),
+        'gcrnn_node_linear_blocks': (_c_i64, [_c_i64, _c_i64]),
+        'gcrnn_node_linear_forward': (C.c_int, [C.c_int, _c_p, _c_p, _c_p, _c_p, _c_i64, _c_i64, _c_i64, _c_i64, _c_p]),
+        'gcrnn_node_linear_backward': (C.c_int, [C.c_int, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_i64, _c_i64, _c_i64, _c_i64, _c_p]),
         'gcrnn_l1_loss_blocks': (_c_i64, [_c_i64]),
         'gcrnn_l1_loss': (C.c_int, [C.c_int, _c_p, _c_p, _c_p, _c_p, _c_i64, C.c_double, _c_p]),
         'gcrnn_attention_forward': (C.c_int, [C.c_int] + [_c_p] * 11 + [_c_i64] * 5 + [C.c_double, _c_p]),

@@ -551,6 +551,47 @@ def small_time_gates(X, h0, wA2, wB2, bias2, lw2, lb2, graph):
     return _SmallTimeGates.apply(X, h0, wA2, wB2, bias2, lw2, lb2, graph)
 
 
+# ------------------------------------------------------------------------------------------ per-node head
+def node_linear_supported(F, O, dtype):
+    return dtype in (torch.float32, torch.float64) and 0 < F <= 64 and 0 < O <= 8
+
+
+class _NodeLinear(torch.autograd.Function):
+    """y[r][o][n] = sum_f w[o][f] h[r][f][n] + b[o] on the user layout (the 'multipMlp' head, architectures.py:1616-1627)."""
+
+    @staticmethod
+    def forward(ctx, h, w, b):
+        require_device(h, w)
+        hc, wc = h.contiguous(), w.contiguous()
+        bc = b.contiguous() if b is not None else None
+        R, F, N = hc.shape
+        O = wc.shape[0]
+        y = torch.empty((R, O, N), dtype=hc.dtype, device=hc.device)
+        check(lib.gcrnn_node_linear_forward(dtype_code(hc.dtype), _p(hc), _p(wc), _p(bc), _p(y), R, N, F, O, _stream()),
+              'node_linear_forward')
+        ctx.save_for_backward(hc, wc)
+        ctx.has_bias = b is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        h, w = ctx.saved_tensors
+        R, F, N = h.shape
+        O = w.shape[0]
+        dyc = dy.contiguous()
+        nb = int(lib.gcrnn_node_linear_blocks(R, N))
+        dh = torch.empty_like(h) if ctx.needs_input_grad[0] else None
+        pw = torch.empty((nb, O, F), dtype=h.dtype, device=h.device)
+        pb = torch.empty((nb, O), dtype=h.dtype, device=h.device)
+        check(lib.gcrnn_node_linear_backward(dtype_code(h.dtype), _p(h), _p(w), _p(dyc), _p(dh), _p(pw), _p(pb), R, N, F, O,
+                                             _stream()), 'node_linear_backward')
+        return dh, pw.sum(dim=0), (pb.sum(dim=0) if ctx.has_bias else None)
+
+
+def node_linear(h, weight, bias=None):
+    return _NodeLinear.apply(h, weight, bias)
+
+
 # ------------------------------------------------------------------------------------------ loss
 class _L1Loss(torch.autograd.Function):
     """mean |x - y| with the gradient produced in the same pass (reference batchTimeL1Loss, miscTools.py:112-119)."""

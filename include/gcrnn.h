@@ -239,6 +239,16 @@ int gcrnn_small_gates_backward(int dtype, const void* X, const void* h0, const v
                                void* plb, void* pdh0, int64_t B, int64_t T, int64_t N, int64_t G, int64_t F, int64_t Kin,
                                int64_t Kst, void* stream);
 
+/* ==== per-node output head =========================================================================================
+ * mlpType = 'multipMlp' of GatedGCRNNforRegression (architectures.py:1616-1627: one Linear(F -> O) applied to every node's
+ * state in a Python loop over nodes), on the user layout: h [R][F][N] -> y [R][O][N], R = B * T, F <= 64, O <= 8, F32 / F64.
+ * backward: dh [R][F][N] (or NULL), pw [gcrnn_node_linear_blocks(R, N)][O][F] and pb [blocks][O] partial sums of dw / db. */
+int64_t gcrnn_node_linear_blocks(int64_t R, int64_t N);
+int gcrnn_node_linear_forward(int dtype, const void* h, const void* w, const void* b, void* y, int64_t R, int64_t N, int64_t F,
+                              int64_t O, void* stream);
+int gcrnn_node_linear_backward(int dtype, const void* h, const void* w, const void* dy, void* dh, void* pw, void* pb, int64_t R,
+                               int64_t N, int64_t F, int64_t O, void* stream);
+
 /* ==== training-loop loss ==========================================================================================
  * batchTimeL1Loss (Utils/miscTools.py:112-119 = nn.L1Loss: mean |x - y| over every entry) and its gradient in one pass.
  * x, y, grad: n contiguous elements of `dtype` (F32 / F64 / BF16), 16-byte aligned; grad (may be NULL) =

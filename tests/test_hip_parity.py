@@ -462,3 +462,25 @@ def test_kstep_data_generated_on_device(dev):
     assert maxdiff(sig, ref[:, 0:horizon - K]) <= 1e-12 and maxdiff(lab, ref[:, K:horizon]) <= 1e-12
     s2, _ = dataTools.kstep_prediction_on_device(torch.tensor(A[None]), K, n, horizon, dev, torch.float32)      # random path runs
     assert torch.isfinite(s2).all()
+
+
+@pytest.mark.parametrize('dt,tol', [(torch.float64, 1e-12), (torch.float32, 2e-5)])
+@pytest.mark.parametrize('R,F,N,O,bias', [(500, 20, 80, 1, True), (7, 64, 33, 3, True), (40, 5, 257, 8, False), (1, 2, 1, 1, True)])
+def test_node_linear_head_kernel(dev, dt, tol, R, F, N, O, bias):
+    """gcrnn_node_linear_forward / _backward (the 'multipMlp' head on the user layout) vs nn.Linear on the transposed rows."""
+    from gated_gcrnns_amd import ops
+    gen = torch.Generator(device='cpu'); gen.manual_seed(R + N)
+    mk = lambda *s: torch.randn(*s, generator=gen, dtype=torch.float64).to(dev).to(dt).requires_grad_(True)
+    h, w = mk(R, F, N), mk(O, F)
+    b = mk(O) if bias else None
+    r = torch.randn(R, O, N, generator=gen, dtype=torch.float64).to(dev).to(dt)
+    y = ops.node_linear(h, w, b)
+    (y * r).sum().backward()
+    got = [y.detach().clone(), h.grad.clone(), w.grad.clone()] + ([b.grad.clone()] if bias else [])
+    h.grad = w.grad = None
+    if bias: b.grad = None
+    yr = torch.nn.functional.linear(h.transpose(1, 2), w, b).transpose(1, 2)
+    (yr * r).sum().backward()
+    ref = [yr.detach(), h.grad, w.grad] + ([b.grad] if bias else [])
+    for a, c in zip(got, ref):
+        assert float((a - c).abs().max()) <= tol * (float(c.abs().max()) + 1e-30)
