@@ -230,7 +230,7 @@ def main():
                                'kernel': 'whole T-step recurrence (composed path: all launches of one step)',
                                'algorithmic_bytes_per_step': abytes, 'device_ms_per_step': 1e3 * step_s,
                                'gflop_per_step': flops_per_seq(T, N, nnz, K, G, F) * B / 1e9}
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:          # the host baseline is a single-GPU-run item (rank 0, N = 1)
             out['cpu_baseline'] = cpu_baseline(S, params, T, G, F)
         print(json.dumps(out), flush=True)
     if dist_on:
