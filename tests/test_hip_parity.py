@@ -364,7 +364,8 @@ def test_small_graph_bptt_kernel_vs_reference_gradients(dev, name, tg, dt, tol, 
 @pytest.mark.parametrize('dt,gtol', [(torch.float64, 1e-9), (torch.float32, 5e-4)])
 @pytest.mark.parametrize('N,G,F,Kin,Kst,Tn,B,tg', [(80, 1, 20, 5, 5, 5, 100, False), (59, 1, 20, 3, 3, 200, 16, True),
                                                      (50, 1, 20, 2, 2, 8, 100, True), (64, 3, 7, 1, 4, 6, 5, False),
-                                                     (120, 2, 20, 3, 2, 4, 3, True)])
+                                                     (120, 2, 20, 3, 2, 4, 3, True), (100, 4, 40, 2, 2, 3, 2, False),
+                                                     (72, 3, 33, 3, 3, 3, 2, True)])
 def test_small_graph_bptt_kernel_vs_composed_path(dev, dt, gtol, N, G, F, Kin, Kst, Tn, B, tg, small_impl):
     """Same cell, same inputs: one-launch BPTT vs the composed (autograd over LSIGF nodes) path, incl. Kin != Kst,
     even / odd N, P = 2 and P = 4 slot passes and the long T = 200 sequence."""
@@ -378,7 +379,9 @@ def test_small_graph_bptt_kernel_vs_composed_path(dev, dt, gtol, N, G, F, Kin, K
     X = torch.randn(B, Tn, G, N, dtype=torch.float64).to(dev).to(dt)
     h0 = (0.3 * torch.randn(B, F, N, dtype=torch.float64)).to(dev).to(dt).requires_grad_(True)
     r = torch.randn(B, Tn, F, N, dtype=torch.float64).to(dev).to(dt)
-    assert cell._use_small_training(X, h0)
+    if not cell._use_small_training(X, h0):
+        assert (N, F, dt) == (100, 40, torch.float64)               # the one shape whose fp64 working set exceeds LDS
+        pytest.skip('shape does not fit the small-graph kernels in this precision')
     (cell(X, h0) * r).sum().backward()
     got = {k: p.grad.clone() for k, p in cell.named_parameters() if p.grad is not None}
     got['h0'] = h0.grad.clone()
