@@ -59,6 +59,8 @@ def _bind(lib):
         'gcrnn_ell_assign_rows': (C.c_int, [_c_p, _c_p, _c_i64, _c_p, C.c_int, _c_i64, _c_p]),
         'gcrnn_fused_supported': (C.c_int, [_c_i64, _c_i64, _c_i64, _c_i64]),
         'gcrnn_fused_padded_nodes': (_c_i64, []),
+        'gcrnn_fused_step_waves': (_c_i64, []),
+        'gcrnn_fused_wgrad_waves': (_c_i64, []),
         'gcrnn_pack_seq_major': (C.c_int, [C.c_int, _c_p, _c_p, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_p, _c_p]),
         'gcrnn_unpack_seq_major': (C.c_int, [C.c_int, _c_p, _c_p, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_p, _c_p]),
         'gcrnn_fused_pack_weights': (C.c_int, [C.c_int, _c_p, _c_p, _c_p, _c_i64, _c_i64, _c_i64, _c_i64, _c_p]),

@@ -34,9 +34,15 @@ typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 
 namespace {
 constexpr int FC = 16;          // output features per workgroup
-constexpr int WAVES = 8;
+constexpr int WAVES = 8;        // weight-gradient kernel: 8 waves x 8 tiles
 constexpr int TILES = 8;        // node tiles (16 nodes) per wave
 constexpr int NP = WAVES * TILES * 16;   // 1024 padded nodes
+#ifndef GCRNN_STEP_WAVES
+#define GCRNN_STEP_WAVES 8
+#endif
+constexpr int SWAVES = GCRNN_STEP_WAVES;      // step kernel: waves per workgroup ...
+constexpr int STILES = NP / 16 / SWAVES;      // ... and node tiles per wave
+constexpr int STHREADS = 64 * SWAVES;
 }
 
 __device__ __forceinline__ uint16_t f2bf(float f) {
@@ -271,7 +277,7 @@ extern "C" int gcrnn_fused_pack_weights(int wdtype, const void* wA, const void* 
 // Uses the locals tbeg, tend, lds_col, lds_val, lds0, qx, r.
 #define GCRNN_HOP_STREAM(INIT, STORE)                                                              \
   do {                                                                                             \
-    const int gwbeg = tbeg[0] >> 2, gwend = tend[TILES - 1] >> 2, gwlast = gwend - 1;              \
+    const int gwbeg = tbeg[0] >> 2, gwend = tend[HT - 1] >> 2, gwlast = gwend - 1;              \
     const uint32_t colb = lds_col + r * 8, valb = lds_val + r * 16;                                \
     uint64_t cE = 0, cO = 0;                                                                       \
     f32x4 vE, vO, xE0, xE1, xE2, xE3, xO0, xO1, xO2, xO3;                                          \
@@ -287,7 +293,7 @@ extern "C" int gcrnn_fused_pack_weights(int wdtype, const void* wA, const void* 
       DS_READ_B128(xE2, lds0 + (((uint32_t)(cE >> 32) & 0xffffu) ^ qx));                           \
       DS_READ_B128(xE3, lds0 + ((uint32_t)(cE >> 48) ^ qx));                                       \
     }                                                                                              \
-    _Pragma("unroll") for (int i = 0; i < TILES; ++i) {                                            \
+    _Pragma("unroll") for (int i = 0; i < HT; ++i) {                                               \
       const int ge = tend[i] >> 2;                                                                 \
       f32x4 acc = INIT(i);                                                                         \
       if (g < ge) {                                                                                \
@@ -315,7 +321,7 @@ extern "C" int gcrnn_fused_pack_weights(int wdtype, const void* wA, const void* 
 #define GCRNN_HOP_TILED(INIT, STORE)                                                               \
   do {                                                                                             \
     const uint32_t colb = lds_col + r * 8, valb = lds_val + r * 16;                                \
-    _Pragma("unroll") for (int i = 0; i < TILES; ++i) {                                            \
+    _Pragma("unroll") for (int i = 0; i < HT; ++i) {                                               \
       const int gwbeg = tbeg[i] >> 2, gwend = tend[i] >> 2, gwlast = gwend - 1;                    \
       f32x4 acc = INIT(i);                                                                         \
       if (gwbeg < gwend) {                                                                         \
@@ -350,7 +356,7 @@ extern "C" int gcrnn_fused_pack_weights(int wdtype, const void* wA, const void* 
 // padded with node ids >= N that have no edges); memory rows are in natural node order.
 // EPI: 0 = state epilogue (bias, tanh, bf16 store), 1 = time-gate pre-pass (dot-reduce), 2 = BPTT data-gradient step
 template <int K, int HS, int XS, bool GATED, bool RESIDENT, int EPI = 0>
-__global__ __launch_bounds__(512, 2) void fused_step_kernel(
+__global__ __launch_bounds__(STHREADS) void fused_step_kernel(
     const uint16_t* __restrict__ xt,        // [B][NP][G]   bf16
     const uint16_t* __restrict__ hprev,     // [B][NP][F]   bf16
     uint16_t* __restrict__ hout,            // [B][NP][F]   bf16
@@ -391,15 +397,16 @@ __global__ __launch_bounds__(512, 2) void fused_step_kernel(
   const int seq_slots = (gridDim.x / (8 * NCH)) * 8;
   if (b0 >= B) return;
 
+  constexpr int HT = STILES;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // provably wave-uniform -> scalar loads below
   const int r = lane & 15, q = lane >> 4;
 
-  for (int i = tid; i < K * KS * 64; i += 512) wl[i] = wpack[(int64_t)chunk * K * KS * 64 + i];
+  for (int i = tid; i < K * KS * 64; i += STHREADS) wl[i] = wpack[(int64_t)chunk * K * KS * 64 + i];
   if (RESIDENT) {
     const int n = (entries >> 2) * 16;                         // the host packed the LDS image: straight copies,
-    for (int i0 = 0; i0 < n; i0 += 512 * 4) {                  // 4 loads in flight per lane before the first LDS store
-      const int i_0 = i0 + tid, i_1 = i_0 + 512, i_2 = i_0 + 1024, i_3 = i_0 + 1536, nl = n - 1;
+    for (int i0 = 0; i0 < n; i0 += STHREADS * 4) {                  // 4 loads in flight per lane before the first LDS store
+      const int i_0 = i0 + tid, i_1 = i_0 + STHREADS, i_2 = i_0 + 2 * STHREADS, i_3 = i_0 + 3 * STHREADS, nl = n - 1;
       const float4 tv0 = ell_val4[i_0 < n ? i_0 : nl], tv1 = ell_val4[i_1 < n ? i_1 : nl];
       const float4 tv2 = ell_val4[i_2 < n ? i_2 : nl], tv3 = ell_val4[i_3 < n ? i_3 : nl];
       const uint2 tc0 = ell_col4[i_0 < n ? i_0 : nl], tc1 = ell_col4[i_1 < n ? i_1 : nl];
@@ -411,16 +418,16 @@ __global__ __launch_bounds__(512, 2) void fused_step_kernel(
     }
   }
   // per-wave tile ranges, fetched once through the scalar path
-  int tbeg[TILES], tend[TILES];
+  int tbeg[STILES], tend[STILES];
 #pragma unroll
-  for (int i = 0; i < TILES; ++i) {
-    tbeg[i] = tile_off[wave * TILES + i];
-    tend[i] = tile_off[wave * TILES + i + 1];
+  for (int i = 0; i < STILES; ++i) {
+    tbeg[i] = tile_off[wave * STILES + i];
+    tend[i] = tile_off[wave * STILES + i + 1];
   }
-  f32x4 u[TILES][K - 1];   // taps 0..K-2 (tap K-1 seeds the LDS state directly); later: the hop results
-  int woff[TILES];      // low 16 bits: byte offset of this lane's quad in the (swizzled) state row of its node; high: node id
+  f32x4 u[STILES][K - 1];   // taps 0..K-2 (tap K-1 seeds the LDS state directly); later: the hop results
+  int woff[STILES];      // low 16 bits: byte offset of this lane's quad in the (swizzled) state row of its node; high: node id
 #pragma unroll
-  for (int i = 0; i < TILES; ++i) woff[i] = tile_nodes[(wave * TILES + i) * 16 + r] ^ (q << 4);   // slot = node << 16 | row << 6 | swz << 4
+  for (int i = 0; i < STILES; ++i) woff[i] = tile_nodes[(wave * STILES + i) * 16 + r] ^ (q << 4);   // slot = node << 16 | row << 6 | swz << 4
   float bvec[4] = {0.f, 0.f, 0.f, 0.f};
   if (bias) {
 #pragma unroll
@@ -447,15 +454,15 @@ __global__ __launch_bounds__(512, 2) void fused_step_kernel(
   // ---- phase 1: taps on the matrix cores ------------------------------------------------------
 #ifdef GCRNN_ABLATE_PHASE1      // profiling builds only (tools/ablate.sh): results are wrong by construction
 #pragma unroll
-  for (int i = 0; i < TILES; ++i)
+  for (int i = 0; i < STILES; ++i)
 #pragma unroll
     for (int tap = 0; tap < K - 1; ++tap) u[i][tap] = f32x4{0.f, 0.f, 0.f, (float)woff[i]};
 #else
   // all B-operand fragments of the wave (8 tiles x 4 x 16 B per lane) are requested before the first MFMA: one
   // memory latency per sequence instead of one per tile; the registers are free again before the taps fill up.
-  bf16x8 bfr[TILES][KS];
+  bf16x8 bfr[STILES][KS];
 #pragma unroll
-  for (int i = 0; i < TILES; ++i) {
+  for (int i = 0; i < STILES; ++i) {
     int w = woff[i];
     asm volatile("" : "+v"(w));      // opaque per iteration: keeps hipcc from hoisting (and spilling) 16+ row offsets
     const int roh = (w >> 16) * (F * 2) + 16 * q, rox = (w >> 16) * (G * 2) + 16 * q;
@@ -471,7 +478,7 @@ __global__ __launch_bounds__(512, 2) void fused_step_kernel(
 #endif
   }
 #pragma unroll
-  for (int i = 0; i < TILES; ++i) {
+  for (int i = 0; i < STILES; ++i) {
 #pragma unroll
     for (int tap = 0; tap < K; ++tap) {
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -554,7 +561,7 @@ __global__ __launch_bounds__(512, 2) void fused_step_kernel(
 #undef GCRNN_FWD_STORE
     } else {
 #pragma unroll
-      for (int i = 0; i < TILES; ++i) {
+      for (int i = 0; i < STILES; ++i) {
         const int beg = tbeg[i], end = tend[i];
         f32x4 acc = u[i][K - 1 - j];
         for (int e = beg; e < end; e += 4) {      // entry counts are padded to multiples of 4
@@ -573,7 +580,7 @@ __global__ __launch_bounds__(512, 2) void fused_step_kernel(
     if (j < K - 1) {
       __syncthreads();
 #pragma unroll
-      for (int i = 0; i < TILES; ++i) {
+      for (int i = 0; i < STILES; ++i) {
         int wv = woff[i];
         asm volatile("" : "+v"(wv));
         *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(state) + (wv & 0xffff)) = u[i][K - 1 - j];
@@ -593,7 +600,7 @@ __global__ __launch_bounds__(512, 2) void fused_step_kernel(
     // gate pre-pass: partial dot product of tanh(pre) with the gate's linear weights over this chunk, one atomic per wave
     float part = 0.f;
 #pragma unroll
-    for (int i = 0; i < TILES; ++i) {
+    for (int i = 0; i < STILES; ++i) {
       int wv = woff[i];
       asm volatile("" : "+v"(wv));
       const int node = wv >> 16;
@@ -606,13 +613,13 @@ __global__ __launch_bounds__(512, 2) void fused_step_kernel(
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) part += __shfl_down(part, off, 64);
-    if (lane == 0) gate_out[(int64_t)b * (NCH * WAVES) + chunk * WAVES + wave] = part;   // fixed-order sum by the caller
+    if (lane == 0) gate_out[(int64_t)b * (NCH * SWAVES) + chunk * SWAVES + wave] = part;   // fixed-order sum by the caller
   } else if (EPI == 2) {
     // BPTT data-gradient step: the hops just applied sum_k (S)^k (dpre_t W_k) = d h_{t-1} (recurrent part); add the
     // upstream gradient of h_{t-1} and go through tanh':  dpre_{t-1} = (acc + dH_{t-1}) * (1 - h_{t-1}^2).
     // With aux0 == null the raw state gradient is stored (d h0).
 #pragma unroll
-    for (int i = 0; i < TILES; ++i) {
+    for (int i = 0; i < STILES; ++i) {
       int wv = woff[i];
       asm volatile("" : "+v"(wv));
       const int node = wv >> 16;
@@ -641,7 +648,7 @@ __global__ __launch_bounds__(512, 2) void fused_step_kernel(
     }
   } else {
 #pragma unroll
-  for (int i = 0; i < TILES; ++i) {
+  for (int i = 0; i < STILES; ++i) {
     int wv = woff[i];
     asm volatile("" : "+v"(wv));
     const int node = wv >> 16;
@@ -665,7 +672,7 @@ __global__ __launch_bounds__(512, 2) void fused_step_kernel(
     char* tst = reinterpret_cast<char*>(state);
     __syncthreads();                                   // every wave has finished reading `state` in the last hop
 #pragma unroll
-    for (int i = 0; i < TILES; ++i) {
+    for (int i = 0; i < STILES; ++i) {
       int wv = woff[i];
       asm volatile("" : "+v"(wv));
       const int node = wv >> 16;
@@ -678,7 +685,7 @@ __global__ __launch_bounds__(512, 2) void fused_step_kernel(
     __syncthreads();
     const int segs = N >> 3;                           // 16-byte segments per row (N % 8 == 0 checked by the host)
     uint16_t* ub = const_cast<uint16_t*>(aux1) + (int64_t)b * ubstride + (int64_t)(chunk * FC) * N;
-    for (int idx = tid; idx < FC * segs; idx += 512) {
+    for (int idx = tid; idx < FC * segs; idx += STHREADS) {
       const int f = idx / segs, sg = idx - f * segs;
       *reinterpret_cast<uint4*>(ub + (int64_t)f * N + sg * 8) = *reinterpret_cast<const uint4*>(tst + f * RS + sg * 16);
     }
@@ -728,7 +735,7 @@ static int fused_launch_t(int mode /*0 plain, 1 gated, 2 gate pre-pass, 3 BPTT d
   const int64_t xstep = B * NP * G, hstep = B * NP * F;
   GCRNN_PRE_LAUNCH();
   if (mode == 2) {
-    kern<<<grid, 512, lds, st>>>(x, (const uint16_t*)h0, nullptr, (const uint4*)wpack, bias, nullptr, nullptr, ga.tile_nodes,
+    kern<<<grid, STHREADS, lds, st>>>(x, (const uint16_t*)h0, nullptr, (const uint4*)wpack, bias, nullptr, nullptr, ga.tile_nodes,
                                  ga.tile_off, ga.ell_col, ga.ell_val, (const float4*)ga.ell_val4, (const uint2*)ga.ell_col4,
                                  gate_w, gate_out, nullptr, nullptr, 0, (int)ga.entries, (int)items, (int)B, (int)N);
   } else if (mode == 3) {
@@ -737,19 +744,19 @@ static int fused_launch_t(int mode /*0 plain, 1 gated, 2 gate pre-pass, 3 BPTT d
     const uint16_t* hst = (const uint16_t*)bw_hs;
     for (int64_t t = T - 1; t >= 1; --t) {
       const uint16_t* hprev_state = (t - 1 >= 1 || true) ? hst + (t - 1) * hstep : nullptr;
-      kern<<<grid, 512, lds, st>>>(nullptr, h + t * hstep, h + (t - 1) * hstep, (const uint4*)wpack, nullptr, nullptr, nullptr,
+      kern<<<grid, STHREADS, lds, st>>>(nullptr, h + t * hstep, h + (t - 1) * hstep, (const uint4*)wpack, nullptr, nullptr, nullptr,
                                    ga.tile_nodes, ga.tile_off, ga.ell_col, ga.ell_val, (const float4*)ga.ell_val4,
                                    (const uint2*)ga.ell_col4, nullptr, nullptr, dH + (t - 1) * hstep, hprev_state, 0,
                                    (int)ga.entries, (int)B, (int)B, (int)N);
     }
     if (bw_dh0)
-      kern<<<grid, 512, lds, st>>>(nullptr, h, (uint16_t*)bw_dh0, (const uint4*)wpack, nullptr, nullptr, nullptr, ga.tile_nodes,
+      kern<<<grid, STHREADS, lds, st>>>(nullptr, h, (uint16_t*)bw_dh0, (const uint4*)wpack, nullptr, nullptr, nullptr, ga.tile_nodes,
                                    ga.tile_off, ga.ell_col, ga.ell_val, (const float4*)ga.ell_val4, (const uint2*)ga.ell_col4,
                                    nullptr, nullptr, nullptr, nullptr, 0, (int)ga.entries, (int)B, (int)B, (int)N);
   } else {
     for (int64_t t = 0; t < T; ++t) {
       const uint16_t* hp = (t == 0) ? (const uint16_t*)h0 : h + (t - 1) * hstep;
-      kern<<<grid, 512, lds, st>>>(x + t * xstep, hp, h + t * hstep, (const uint4*)wpack, bias, mode == 1 ? gi + t * B : nullptr,
+      kern<<<grid, STHREADS, lds, st>>>(x + t * xstep, hp, h + t * hstep, (const uint4*)wpack, bias, mode == 1 ? gi + t * B : nullptr,
                                    mode == 1 ? gf + t * B : nullptr, ga.tile_nodes, ga.tile_off, ga.ell_col, ga.ell_val,
                                    (const float4*)ga.ell_val4, (const uint2*)ga.ell_col4, nullptr, nullptr, nullptr,
                                    huser ? (const uint16_t*)huser + t * F * N : nullptr, (int)(T * F * N),
@@ -854,6 +861,7 @@ __global__ __launch_bounds__(512, 2) void fused_wgrad_kernel(
   const int items = B * Tn;
   if (it0 >= items) return;
 
+  constexpr int HT = TILES;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 15, q = lane >> 4;
@@ -1103,3 +1111,7 @@ extern "C" int gcrnn_fused_supported(int64_t N, int64_t F, int64_t G, int64_t K)
 }
 
 extern "C" int64_t gcrnn_fused_padded_nodes(void) { return NP; }
+// waves per workgroup of the step kernels / of the weight-gradient kernel: the ELL tiles of a plan are dealt out over that
+// many waves (storage tile w * (NP/16/waves) + i belongs to wave w)
+extern "C" int64_t gcrnn_fused_step_waves(void) { return SWAVES; }
+extern "C" int64_t gcrnn_fused_wgrad_waves(void) { return WAVES; }

@@ -135,11 +135,12 @@ class GraphOperator(object):
             self._mask_t = mt
         return mt
 
-    def fused_plan(self, adjoint=False):
+    def fused_plan(self, adjoint=False, kernel='step'):
         """Degree-sorted sliced ELL of CSR(S^T) (forward shift) or, with adjoint=True, of CSR(S) (the shift of the
         backward pass) for the fused step kernels (E = 1): device tensors order (int32 [N]), tile_off
         (int32 [ntiles+1]), ell_col (int32 [entries*16]), ell_val (fp32) and the packed LDS image."""
-        key = '_fused_plan_adj' if adjoint else '_fused_plan'
+        waves = int(_lib.lib.gcrnn_fused_wgrad_waves() if kernel == 'wgrad' else _lib.lib.gcrnn_fused_step_waves())
+        key = ('_fused_plan_adj' if adjoint else '_fused_plan') + '_w%d' % waves
         plan = self.__dict__.get(key)
         if plan is not None:
             return plan
@@ -152,10 +153,10 @@ class GraphOperator(object):
         col = np.ascontiguousarray(c.col.cpu().numpy())
         val = np.ascontiguousarray(c.val(torch.float64).cpu().numpy())
         order = degree_order(rowptr)
-        # tiles of 16 slots in degree order; the kernel's wave w owns STORAGE tiles 8w .. 8w+7 (contiguous, so its hop
-        # is one stream of ELL groups) -- deal the degree-ranked tiles round-robin over the 8 waves to balance them.
+        # tiles of 16 slots in degree order; the kernel's wave w owns `per` consecutive STORAGE tiles (contiguous, so its hop
+        # is one stream of ELL groups) -- deal the degree-ranked tiles round-robin over the waves to balance them.
         slots = np.concatenate([order, np.arange(self.N, npad, dtype=np.int32)]).astype(np.int32).reshape(ntiles, 16)
-        waves, per = 8, ntiles // 8
+        per = ntiles // waves
         storage = np.empty_like(slots)
         for w in range(waves):
             for i in range(per):

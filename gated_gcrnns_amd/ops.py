@@ -289,7 +289,7 @@ def fused_cell_forward(X, h0, wA, wB, bias, graph, gates=None, return_states=Fal
             wp = _fused_pack_weights(wA_g, wB_g, st)
             bg = bias_g.detach().float().contiguous().view(-1) if bias_g is not None else None
             gw = lin_w.detach().float().view(F, N).t().contiguous()          # row-major vec over (f, n) -> [N][F]
-            parts = torch.empty((T * B, (F // 16) * 8), dtype=torch.float32, device=dev)
+            parts = torch.empty((T * B, (F // 16) * int(lib.gcrnn_fused_step_waves())), dtype=torch.float32, device=dev)
             check(lib.gcrnn_fused_gate_prepass_bf16(_p(xs), _p(h0s), _p(wp), _p(bg), _p(gw), _p(parts), *gargs,
                                                     B, T, N, F, G, K, st), 'gate_prepass')
             acc = parts.sum(dim=1)                                            # fixed order: deterministic gates
@@ -335,7 +335,7 @@ def fused_backward_weight(dpre, X, H, h0, graph, F, G, K, want_bias=False):
     user-layout bf16 tensors X [B][T][G][N], H [B][T][F][N] (forward output), h0 [B][F][N].
     With want_bias also returns sum_{t,b,n} dpre [F] (the bias gradient is twice that)."""
     T, B = dpre.shape[0], dpre.shape[1]
-    plan = graph.fused_plan(adjoint=True)
+    plan = graph.fused_plan(adjoint=True, kernel='wgrad')
     dW = torch.zeros((F, K, F + G), dtype=torch.float32, device=dpre.device)
     dbs = torch.zeros(F, dtype=torch.float32, device=dpre.device) if want_bias else None
     Xc, Hc, h0c = X.contiguous(), H.contiguous(), h0.contiguous()

@@ -126,6 +126,11 @@ int gcrnn_ell_pack_lds(const int32_t* ell_col, const float* ell_val, int64_t ent
 /* 1 if gcrnn_fused_forward_bf16 has a kernel for this shape (K = max(Kin, Kst) taps). */
 int gcrnn_fused_supported(int64_t N, int64_t F, int64_t G, int64_t K);
 int64_t gcrnn_fused_padded_nodes(void);
+/* Waves per workgroup of the step kernels (forward, gate pre-pass, BPTT data gradient) and of the weight-gradient kernel.
+ * A plan's storage tiles are dealt out wave-major: tile w * (NPad/16/waves) + i belongs to wave w, so a plan is built for
+ * one of the two wave counts (degree-ranked tiles go round-robin over the waves). */
+int64_t gcrnn_fused_step_waves(void);
+int64_t gcrnn_fused_wgrad_waves(void);
 /* user [B][T][C][N] <-> sequence-major [T][B][NPad][C]; row p holds node perm[p] (perm NULL = identity);
  * rows >= N are zero. dtype GCRNN_BF16 or GCRNN_F32 (same type both sides). */
 int gcrnn_pack_seq_major(int dtype, const void* src, void* dst, int64_t B, int64_t T, int64_t C, int64_t N,

@@ -18,11 +18,15 @@ def random_graph(N, density, seed, isolated=0):
     return (S / lam).reshape(1, N, N)
 
 
+@pytest.mark.parametrize('kernel', ['step', 'wgrad'])
 @pytest.mark.parametrize('N,density,iso', [(200, 0.05, 7), (1000, 0.01, 0), (1024, 0.004, 30), (17, 0.5, 0)])
-def test_ell_plan_reproduces_shift_exactly(N, density, iso):
-    """CPU: the degree-sorted sliced ELL is a permuted, padded but otherwise exact copy of CSR(S^T)."""
+def test_ell_plan_reproduces_shift_exactly(N, density, iso, kernel):
+    """CPU: the degree-sorted sliced ELL is a permuted, padded but otherwise exact copy of CSR(S^T) -- for the wave count
+    of the step kernels and for that of the weight-gradient kernel."""
+    from gated_gcrnns_amd import _lib
+    waves = int(_lib.lib.gcrnn_fused_wgrad_waves() if kernel == 'wgrad' else _lib.lib.gcrnn_fused_step_waves())
     S = random_graph(N, density, 5, iso)
-    plan = GraphOperator(S).fused_plan()
+    plan = GraphOperator(S).fused_plan(kernel=kernel)
     order = plan['order'].numpy()
     toff, ecol, eval_ = plan['tile_off'].numpy(), plan['ell_col'].numpy(), plan['ell_val'].numpy()
     assert sorted(order.tolist()) == list(range(N))
@@ -30,10 +34,10 @@ def test_ell_plan_reproduces_shift_exactly(N, density, iso):
     assert np.all(np.diff(deg[order]) <= 0)                         # descending degree
     tn = plan['tile_nodes'].numpy()
     assert sorted(tn.tolist()) == list(range(plan['npad']))         # every row (incl. padding rows) in exactly one slot
-    # wave w owns storage tiles 8w..8w+7 = degree-ranked tiles w, w+8, ...: per-wave work is balanced
+    # wave w owns `per` consecutive storage tiles = degree-ranked tiles w, w + waves, ...: per-wave work is balanced
     per_tile = np.diff(toff)
-    per_wave = per_tile.reshape(8, -1).sum(axis=1)
-    assert per_wave.max() - per_wave.min() <= 4 * 8
+    per_wave = per_tile.reshape(waves, -1).sum(axis=1)
+    assert per_wave.max() - per_wave.min() <= per_tile.max()       # round-robin over descending depths: at most one tile's worth
     assert toff[0] == 0 and np.all(np.diff(toff) % 4 == 0) and toff[-1] == plan['entries']
     # rebuild the dense operator from the ELL (slot -> node through tile_nodes) and compare with P = S^T
     P = np.zeros((plan['npad'], plan['npad']))
