@@ -397,10 +397,17 @@ class GGCRNNCell(nn.Module):
         return ops.unpack_node_major(Hn)
 
     # -- small-graph persistent path (fp32 / fp64, un-gated / time-gated, sigma = tanh, inference) -------
+    def _small_node_gating_ok(self, X, backward):
+        """Per-node gates run on the matrix-core family only (dense GSO in LDS)."""
+        return self.spatial_gating == 'node' and \
+            ops.small_dense_supported(self.N, self.G, self.F, self.Kin, self.Kst, X.dtype, backward=backward, gated=True)
+
     def _use_small(self, X, h0):
         if torch.is_grad_enabled() and (X.requires_grad or h0.requires_grad or self.weight_A.requires_grad):
             return False
-        if self.spatial_gating is not None or self.sigma not in (torch.tanh, nn.functional.tanh):
+        if self.sigma not in (torch.tanh, nn.functional.tanh):
+            return False
+        if self.spatial_gating is not None and not self._small_node_gating_ok(X, False):
             return False
         return self.weight_A.dtype == X.dtype and h0.dtype == X.dtype and \
             ops.small_supported(self.N, self.graph.fwd[0].nnz, self.G, self.F, self.Kin, self.Kst, X.dtype, self.E)
@@ -409,7 +416,9 @@ class GGCRNNCell(nn.Module):
         """Small graphs, gradients wanted for parameters / h0 but not for X: forward and BPTT are one launch each."""
         if not torch.is_grad_enabled() or X.requires_grad:
             return False
-        if self.spatial_gating is not None or self.sigma not in (torch.tanh, nn.functional.tanh):
+        if self.sigma not in (torch.tanh, nn.functional.tanh):
+            return False
+        if self.spatial_gating is not None and not self._small_node_gating_ok(X, True):
             return False
         return self.weight_A.dtype == X.dtype and h0.dtype == X.dtype and \
             ops.small_training_supported(self.N, self.graph.fwd[0].nnz, self.G, self.F, self.Kin, self.Kst, X.dtype, self.E)
@@ -433,6 +442,16 @@ class GGCRNNCell(nn.Module):
             h0n = ops.pack_node_major(h0.reshape(B, 1, self.F, self.N))
             gi = self._time_gate(self.GFL_in, self.MLP_in, Xn, h0n).reshape(X.shape[1], B)
             gf = self._time_gate(self.GFL_forget, self.MLP_forget, Xn, h0n).reshape(X.shape[1], B)
+        if self.spatial_gating == 'node':
+            # node gates (graphML.py:2379-2399) from one batched pass over all t; the recurrence takes them per node,
+            # multiplied by the time gates when both are on: gates [B][T][N]
+            B = X.shape[0]
+            Xn = ops.pack_node_major(X)
+            h0n = ops.pack_node_major(h0.reshape(B, 1, self.F, self.N))
+            ni = self._node_gate(self.GRNN_node_in, self.GFL_node_in, Xn, h0n).squeeze(3).permute(2, 0, 1)      # B x T x N
+            nf = self._node_gate(self.GRNN_node_forget, self.GFL_node_forget, Xn, h0n).squeeze(3).permute(2, 0, 1)
+            gi = ni if gi is None else ni * gi.t().unsqueeze(2)
+            gf = nf if gf is None else nf * gf.t().unsqueeze(2)
         if train:
             return ops.small_cell_train(X, h0, self.weight_A, self.weight_B, self.bias, self.graph, gi, gf)
         return ops.small_cell_forward(X, h0, self.weight_A, self.weight_B, self.bias, self.graph, gi, gf)

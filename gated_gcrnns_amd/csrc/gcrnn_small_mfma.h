@@ -60,26 +60,27 @@ __device__ __forceinline__ typename Mf<T>::acc tile_mac(typename Mf<T>::acc acc,
   return acc;
 }
 
-// same with a per-k-step multiplier table on the A operand (time gates: x-columns times gi, h-columns times gf)
+// acc += sum_k A(i, k) (B(k, j) g(k)): both operands step by 4 elements per k-step (transposed B), and the B operand is
+// scaled by a per-k gate g read through gp (gp steps with k too). `bfirst`: the first pointer is the B operand.
 template <typename T>
-__device__ __forceinline__ typename Mf<T>::acc tile_mac_gated(typename Mf<T>::acc acc, const T* ap, const T* gp, const T* bp,
-                                                              int bstep, int ksteps) {
+__device__ __forceinline__ typename Mf<T>::acc tile_mac_gated(typename Mf<T>::acc acc, const T* bp, const T* gp, const T* ap,
+                                                              int astep, int ksteps, bool bfirst) {
+  (void)bfirst;
   int s = 0;
   for (; s + 4 <= ksteps; s += 4) {
-    const T a0 = ap[0] * gp[0], a1 = ap[4] * gp[4], a2 = ap[8] * gp[8], a3 = ap[12] * gp[12];
-    const T b0 = bp[0], b1 = bp[bstep], b2 = bp[2 * bstep], b3 = bp[3 * bstep];
-    ap += 16; gp += 16; bp += 4 * bstep;
+    const T b0 = bp[0] * gp[0], b1 = bp[4] * gp[4], b2 = bp[8] * gp[8], b3 = bp[12] * gp[12];
+    const T a0 = ap[0], a1 = ap[astep], a2 = ap[2 * astep], a3 = ap[3 * astep];
+    bp += 16; gp += 16; ap += 4 * astep;
     acc = Mf<T>::mma(a0, b0, acc);
     acc = Mf<T>::mma(a1, b1, acc);
     acc = Mf<T>::mma(a2, b2, acc);
     acc = Mf<T>::mma(a3, b3, acc);
   }
   for (; s < ksteps; ++s) {
-    acc = Mf<T>::mma(ap[0] * gp[0], bp[0], acc);
-    ap += 4; gp += 4; bp += bstep;
+    acc = Mf<T>::mma(ap[0], bp[0] * gp[0], acc);
+    bp += 4; gp += 4; ap += astep;
   }
   return acc;
 }
-
 
 }  // namespace

@@ -31,7 +31,7 @@ __global__ __launch_bounds__(1024) void small_dense_fwd_kernel(
     const T* __restrict__ wA,      // [F][Kin][G]
     const T* __restrict__ wB,      // [F][Kst][F]
     const T* __restrict__ bias,    // [F] or null
-    const T* __restrict__ gi, const T* __restrict__ gf,       // [Tn][B] or null
+    const T* __restrict__ gi, const T* __restrict__ gf,       // [B][Tn][N] per-node gates of the input / state filter, or null
     const T* __restrict__ Sd,      // [N][N] dense S (row m, column n)
     T* __restrict__ H,             // [B][Tn][F][N]
     int Tn, int N, int G, int F, int Kin, int Kst, int B) {
@@ -46,7 +46,7 @@ __global__ __launch_bounds__(1024) void small_dense_fwd_kernel(
   T* W = Z + (size_t)KC4 * Ns;                     // [F16][KCs] combined taps, F16 = F rounded up to 16
   const int F16 = (F + 15) & ~15;
   T* zrow = W + (size_t)F16 * KCs;                 // [Ns] zeros: what masked lanes read
-  T* gtab = zrow + Ns;                             // [KC4] gate of every flattened tap column (time-gated cells)
+  T* gvec = zrow + Ns;                             // [2][Ns] gates of this step: input-filter | state-filter, per node
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, lk = lane >> 4;
   const int b = blockIdx.x;
@@ -56,7 +56,7 @@ __global__ __launch_bounds__(1024) void small_dense_fwd_kernel(
     S[i] = (m < N && n < N) ? Sd[(size_t)m * N + n] : T(0);
   }
   for (int i = tid; i < KC4 * Ns; i += 1024) Z[i] = T(0);
-  for (int i = tid; i < Ns + KC4; i += 1024) zrow[i] = T(0);
+  for (int i = tid; i < 3 * Ns; i += 1024) zrow[i] = T(0);
   for (int i = tid; i < F16 * KCs; i += 1024) {
     const int f = i / KCs, kc = i - f * KCs;
     T v = T(0);
@@ -88,10 +88,9 @@ __global__ __launch_bounds__(1024) void small_dense_fwd_kernel(
       Z[g * Ns + n] = xt[i];
     }
     if (t + 1 < Tn && tid < GN) xpre = xt[GN + tid];
-    T gin = T(1), gfo = T(1);
-    if (gi) {
-      gin = gi[(size_t)t * B + b]; gfo = gf[(size_t)t * B + b];
-      if (tid < KC4) gtab[tid] = (tid < KC) ? (((tid % C) < G) ? gin : gfo) : T(0);
+    if (gi && tid < 2 * N) {
+      const int w = tid >= N, n = tid - w * N;
+      gvec[w * Ns + n] = (w ? gf : gi)[((size_t)b * Tn + t) * N + n];
     }
     __syncthreads();
     // ---- hops: Z_k = Z_{k-1} S
@@ -121,13 +120,26 @@ __global__ __launch_bounds__(1024) void small_dense_fwd_kernel(
       const int i0 = (tile / tilesN) << 4, j0 = (tile % tilesN) << 4;
       acc_t acc = {0, 0, 0, 0};
       const T* wr = W + (i0 + li) * KCs + lk;
-      if (gi) acc = tile_mac_gated<T>(acc, wr, gtab + lk, Z + lk * Ns + j0 + li, 4 * Ns, KC4 >> 2);
-      else    acc = tile_mac<T>(acc, wr, 4, Z + lk * Ns + j0 + li, 4 * Ns, KC4 >> 2);
+      acc = tile_mac<T>(acc, wr, 4, Z + lk * Ns + j0 + li, 4 * Ns, KC4 >> 2);          // A(S)x + B(S)h
+      T gxn = T(1), ghn = T(1);
+      acc_t ax = {0, 0, 0, 0};
+      if (gi) {
+        // gates multiply the two filters separately: the input filter's share is the (few) x-columns k C + g again
+        const int n = j0 + li;
+        gxn = gvec[n < N ? n : 0]; ghn = gvec[Ns + (n < N ? n : 0)];
+        for (int k = 0; k < Kin; ++k)
+          for (int g0 = 0; g0 < G; g0 += 4) {
+            const int g = g0 + lk, gc = g < G ? g : G - 1;
+            const T a = (W + (i0 + li) * KCs)[k * C + gc] * (g < G ? T(1) : T(0));
+            ax = Mf<T>::mma(a, Z[(k * C + gc) * Ns + j0 + li], ax);
+          }
+      }
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int f = i0 + Mf<T>::row(lane, r);
         const T bb = (bias && f < F) ? bias[f] : T(0);
-        acc[r] = Mf<T>::tanh_(acc[r] + (gin + gfo) * bb);
+        const T pre = gi ? gxn * (ax[r] + bb) + ghn * ((acc[r] - ax[r]) + bb) : acc[r] + T(2) * bb;
+        acc[r] = Mf<T>::tanh_(pre);
       }
       outv[q] = acc;
     }
@@ -158,7 +170,7 @@ size_t dense_fwd_lds(int64_t N, int64_t G, int64_t F, int64_t K) {
   const int C = (int)(G + F), KC = (int)K * C;
   const int Ns = lds_stride<T>((int)N), KCs = lds_stride<T>(KC);
   const int N4 = ((int)N + 3) & ~3, KC4 = (KC + 3) & ~3, F16 = ((int)F + 15) & ~15;
-  return sizeof(T) * ((size_t)N4 * Ns + (size_t)KC4 * Ns + (size_t)F16 * KCs + Ns + KC4) + 16;
+  return sizeof(T) * ((size_t)N4 * Ns + (size_t)KC4 * Ns + (size_t)F16 * KCs + 3 * (size_t)Ns) + 16;
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -168,11 +180,13 @@ template <typename T, bool GATED, int MAXW>
 __global__ __launch_bounds__(1024) void small_dense_bwd_kernel(
     const T* __restrict__ X, const T* __restrict__ h0, const T* __restrict__ H, const T* __restrict__ dH,
     const T* __restrict__ wA, const T* __restrict__ wB, const T* __restrict__ bias,
-    const T* __restrict__ gi, const T* __restrict__ gf, const T* __restrict__ Sd,
+    const T* __restrict__ gi, const T* __restrict__ gf,       // [B][Tn][N] per-node gates (GATED)
+    const T* __restrict__ Sd,
     T* __restrict__ pA,             // [B][F][Kin][G]
     T* __restrict__ pB,             // [B][F][Kst][F]
     T* __restrict__ pb,             // [B][F]
-    T* __restrict__ dgi, T* __restrict__ dgf, T* __restrict__ dh0,
+    T* __restrict__ dgi, T* __restrict__ dgf,                 // [B][Tn][N] gradients of the gates (GATED)
+    T* __restrict__ dh0,
     int Tn, int N, int G, int F, int Kin, int Kst, int B) {
   typedef typename Mf<T>::acc acc_t;
   extern __shared__ __attribute__((aligned(16))) char smem_dense[];
@@ -191,6 +205,9 @@ __global__ __launch_bounds__(1024) void small_dense_bwd_kernel(
   T* WAl = WBt + (size_t)Kst * F4 * Fs;            // GATED: [F][K][Cs] combined taps
   T* red = WAl + (GATED ? (size_t)F * K * Cs : 0);     // [64]
   T* zrow = red + 64;                                  // [max(Ns, K Cs)] zeros: what masked lanes read
+  const int ZR = Ns > K * Cs ? Ns : K * Cs;
+  T* gvec = zrow + ZR;                                 // GATED: [2][Ns] gates of this step (input | state filter) per node
+  T* gpart = gvec + 2 * Ns;                            // GATED: [2][tilesF][Ns] partial column sums of the gate gradients
   (void)C16; (void)F16;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, lk = lane >> 4;
@@ -201,7 +218,7 @@ __global__ __launch_bounds__(1024) void small_dense_bwd_kernel(
     S[i] = (m < N && n < N) ? Sd[(size_t)m * N + n] : T(0);
   }
   for (int i = tid; i < 2 * C4 * Ns + 2 * F4 * Ns; i += 1024) Z0[i] = T(0);        // Z0, Z1, dpre, carry are contiguous
-  for (int i = tid; i < (Ns > K * Cs ? Ns : K * Cs); i += 1024) zrow[i] = T(0);
+  for (int i = tid; i < ZR + (GATED ? 2 * Ns + 2 * tilesF * Ns : 0); i += 1024) zrow[i] = T(0);
   for (int i = tid; i < Kst * F4 * Fs; i += 1024) {
     const int k = i / (F4 * Fs), rem = i - k * (F4 * Fs);
     const int f = rem / Fs, f2 = rem - f * Fs;
@@ -233,8 +250,10 @@ __global__ __launch_bounds__(1024) void small_dense_bwd_kernel(
     const T* hp = (t == 0) ? h0 + (size_t)b * FN : H + ((size_t)b * Tn + t - 1) * FN;
     const T* ht = H + ((size_t)b * Tn + t) * FN;
     const T* dht = dH + ((size_t)b * Tn + t) * FN;
-    T gin = T(1), gfo = T(1);
-    if (GATED) { gin = gi[(size_t)t * B + b]; gfo = gf[(size_t)t * B + b]; }
+    if (GATED && tid < 2 * N) {
+      const int w = tid >= N, n = tid - w * N;
+      gvec[w * Ns + n] = (w ? gf : gi)[((size_t)b * Tn + t) * N + n];
+    }
     for (int i = tid; i < (G + F) * N; i += 1024) {
       const int c = i / N, n = i - c * N;
       Z0[c * Ns + n] = (c < G) ? xt[i] : hp[i - GN];
@@ -261,8 +280,9 @@ __global__ __launch_bounds__(1024) void small_dense_bwd_kernel(
           // A = dpre (i = f, k = n), B = Z_k^T (k = n, j = c): both "lanes over rows, lane groups over consecutive n"
           const T* ap = (i0 + li < F) ? dpre + (i0 + li) * Ns + lk : zrow + lk;
           const T* bp = (j0 + li < C) ? zc + (j0 + li) * Ns + lk : zrow + lk;
-          // A = dpre (i = f, k = n), B = Z_k^T (k = n, j = c) scaled by the gate of column c
-          wacc[q] = tile_mac<T>(wacc[q], ap, 4, bp, 4, N4 >> 2, T(1), (j0 + li < G) ? gin : gfo);
+          // A = dpre (i = f, k = n), B = Z_k^T (k = n, j = c) scaled by the gate of (filter of column c, node n)
+          if (GATED) wacc[q] = tile_mac_gated<T>(wacc[q], bp, gvec + ((j0 + li < G) ? 0 : Ns) + lk, ap, 4, N4 >> 2, true);
+          else       wacc[q] = tile_mac<T>(wacc[q], ap, 4, bp, 4, N4 >> 2);
         }
       }
       if (GATED) {
@@ -308,17 +328,20 @@ __global__ __launch_bounds__(1024) void small_dense_bwd_kernel(
     if (tid < F) {
       const T* dr = dpre + tid * Ns;
       T s = T(0);
-      for (int n = 0; n < N; ++n) s += dr[n];
-      bacc += (gin + gfo) * s;
+      if (GATED) { for (int n = 0; n < N; ++n) s += dr[n] * (gvec[n] + gvec[Ns + n]); }
+      else       { for (int n = 0; n < N; ++n) s += dr[n]; s *= T(2); }
+      bacc += s;
     }
     if (GATED) {
-      T si = T(0), sf = T(0);
+      // d gate[n] = sum_f dpre[f][n] (filter output[f][n] + b[f]): each lane holds 4 rows of its column; the 4 lanes of a
+      // column (lane, lane ^ 16, ^ 32, ^ 48) are folded by shuffles, the tilesF row tiles through LDS in a fixed order
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
         const int tile = wave + q * 16;
         if (tile >= tilesF * tilesN) break;
         const int i0 = (tile / tilesN) << 4, j0 = (tile % tilesN) << 4;
         const int n = j0 + li;
+        T si = T(0), sf = T(0);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int f = i0 + Mf<T>::row(lane, r);
@@ -329,15 +352,19 @@ __global__ __launch_bounds__(1024) void small_dense_bwd_kernel(
             sf += d * (yb[q][r] + bb);
           }
         }
+        si += __shfl_xor(si, 16, 64); si += __shfl_xor(si, 32, 64);
+        sf += __shfl_xor(sf, 16, 64); sf += __shfl_xor(sf, 32, 64);
+        if (n < N && lk == 0) {
+          gpart[(i0 >> 4) * Ns + n] = si;
+          gpart[(tilesF + (i0 >> 4)) * Ns + n] = sf;
+        }
       }
-      for (int o = 32; o > 0; o >>= 1) { si += __shfl_down(si, o, 64); sf += __shfl_down(sf, o, 64); }
-      if (lane == 0) { red[wave * 2] = si; red[wave * 2 + 1] = sf; }
       __syncthreads();
-      if (tid == 0) {
-        T a = T(0), c2 = T(0);
-        for (int w = 0; w < 16; ++w) { a += red[2 * w]; c2 += red[2 * w + 1]; }
-        dgi[(size_t)t * B + b] = a;
-        dgf[(size_t)t * B + b] = c2;
+      if (tid < 2 * N) {
+        const int w = tid >= N, n = tid - w * N;
+        T a = T(0);
+        for (int p = 0; p < tilesF; ++p) a += gpart[(w * tilesF + p) * Ns + n];
+        (w ? dgf : dgi)[((size_t)b * Tn + t) * N + n] = a;
       }
     }
     // ---- carry_{t-1}: acc <- gf B_k^T dpre + acc S^T, k = Kst-1 .. 0
@@ -351,7 +378,9 @@ __global__ __launch_bounds__(1024) void small_dense_bwd_kernel(
         acc_t acc = {0, 0, 0, 0};
         // A = B_k^T (i = f2, k = f) = wk[f][f2], B = dpre (k = f, j = n)
         const bool acol = i0 + li < F;
-        acc = tile_mac<T>(acc, wk + lk * Fs + (acol ? i0 + li : F), 4 * Fs, dpre + lk * Ns + j0 + li, 4 * Ns, F4 >> 2, gfo);
+        const int nb = j0 + li;
+        acc = tile_mac<T>(acc, wk + lk * Fs + (acol ? i0 + li : F), 4 * Fs, dpre + lk * Ns + j0 + li, 4 * Ns, F4 >> 2, T(1),
+                          GATED ? gvec[Ns + (nb < N ? nb : 0)] : T(1));
         if (k < Kst - 1) {
           // A = acc (i = f2, k = m), B = S^T (k = m, j = n) = S[n][m]
           const T* ap = acol ? ac + (i0 + li) * Ns + lk : zrow + lk;
@@ -402,7 +431,8 @@ size_t dense_bwd_lds(int64_t N, int64_t G, int64_t F, int64_t Kin, int64_t Kst, 
   const int F4 = ((int)F + 3) & ~3, C4 = (C + 3) & ~3;
   const int SR = (((int)N + 15) >> 4) * 16;
   return sizeof(T) * ((size_t)SR * Ns + 2 * (size_t)C4 * Ns + 2 * (size_t)F4 * Ns + (size_t)Kst * F4 * Fs +
-                      (gated ? (size_t)F * K * Cs : 0) + 64 + (size_t)(Ns > K * Cs ? Ns : K * Cs)) + 16;
+                      (gated ? (size_t)F * K * Cs : 0) + 64 + (size_t)(Ns > K * Cs ? Ns : K * Cs) +
+                      (gated ? (2 + 2 * (size_t)(((int)F + 15) >> 4)) * Ns : 0)) + 16;
 }
 
 constexpr size_t DENSE_LDS_MAX = 160 * 1024;

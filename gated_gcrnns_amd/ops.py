@@ -417,9 +417,21 @@ def small_dense_supported(N, G, F, Kin, Kst, dtype, backward, gated):
                                                 int(backward), int(gated)))
 
 
+def _node_gates(g, B, T, N):
+    """[T][B] scalar gates -> [B][T][N] (what the matrix-core kernels take); [B][T][N] gates pass through."""
+    if g is None:
+        return None
+    if g.dim() == 2:
+        return g.t().unsqueeze(2).expand(B, T, N).contiguous()
+    assert tuple(g.shape) == (B, T, N)
+    return g.contiguous()
+
+
 def small_cell_forward(X, h0, wA, wB, bias, graph, gi=None, gf=None):
     """Whole recurrence in one launch, one workgroup per sequence (small graphs). X: B x T x G x N, h0: B x F x N
-    (user layout, fp32 / fp64) -> H: B x T x F x N. gi / gf: [T][B] time gates or None. Inference only."""
+    (user layout, fp32 / fp64) -> H: B x T x F x N. gi / gf: gates of the input / state filter or None: [T][B] scalars per
+    sequence and step (time gating) or [B][T][N] per node (node gating, or the product of both; matrix-core kernels only).
+    Inference only."""
     require_device(X, h0, wA, wB, bias)
     B, T, G, N = X.shape
     F, Kin, Kst = wA.shape[0], wA.shape[2], wB.shape[2]
@@ -431,9 +443,11 @@ def small_cell_forward(X, h0, wA, wB, bias, graph, gi=None, gf=None):
     Xc, h0c, wAc, wBc, vals = X.contiguous(), h0.contiguous(), wA.contiguous(), wB.contiguous(), csr.val(X.dtype)
     if small_dense_supported(N, G, F, Kin, Kst, X.dtype, backward=False, gated=gi is not None):
         Sd = graph.dense(X.dtype)
-        check(lib.gcrnn_small_dense_forward(dtype_code(X.dtype), _p(Xc), _p(h0c), _p(wAc), _p(wBc), _p(bvec), _p(gi), _p(gf),
+        gx, gh = _node_gates(gi, B, T, N), _node_gates(gf, B, T, N)
+        check(lib.gcrnn_small_dense_forward(dtype_code(X.dtype), _p(Xc), _p(h0c), _p(wAc), _p(wBc), _p(bvec), _p(gx), _p(gh),
                                             _p(Sd), _p(H), B, T, N, G, F, Kin, Kst, _stream()), 'small_dense_forward')
         return H
+    assert gi is None or gi.dim() == 2, 'per-node gates need the matrix-core kernels (small_dense_supported)'
     check(lib.gcrnn_small_forward(dtype_code(X.dtype), _p(Xc), _p(h0c), _p(wAc),
                                   _p(wBc), _p(bvec), _p(gi), _p(gf), _p(csr.rowptr), _p(csr.col),
                                   _p(vals), _p(H), B, T, N, G, F, Kin, Kst, csr.nnz, _stream()),
@@ -471,10 +485,13 @@ class _SmallCell(torch.autograd.Function):
         pB = torch.empty((B, 1 if dense else 2, F, Kst, F), dtype=dt, device=dev)
         pb = torch.empty((B, F), dtype=dt, device=dev)
         dgi = dgf = None
+        scalar_gates = gi is not None and gi.dim() == 2
         if gi is not None:
+            assert dense or scalar_gates, 'per-node gates need the matrix-core kernels (small_dense_supported)'
             gi, gf = gi.to(dt).contiguous(), gf.to(dt).contiguous()
-            dgi = torch.empty((T, B), dtype=dt, device=dev)
-            dgf = torch.empty((T, B), dtype=dt, device=dev)
+            shape = (B, T, N) if dense else (T, B)
+            dgi = torch.empty(shape, dtype=dt, device=dev)
+            dgf = torch.empty(shape, dtype=dt, device=dev)
         dh0 = torch.empty_like(h0) if ctx.needs_input_grad[1] else None
         bvec = bias.detach().contiguous().view(-1) if bias is not None else None
         # every operand is a named local: a temporary (dH.contiguous(), a first-use adj.val(dt)) would be released --
@@ -482,9 +499,12 @@ class _SmallCell(torch.autograd.Function):
         dHc, wAc, wBc, fval, aval = dH.contiguous(), wA.contiguous(), wB.contiguous(), fwd.val(dt), adj.val(dt)
         if dense:
             Sd = ctx.graph.dense(dt)
+            gx, gh = _node_gates(gi, B, T, N), _node_gates(gf, B, T, N)
             check(lib.gcrnn_small_dense_backward(dtype_code(dt), _p(X), _p(h0), _p(H), _p(dHc), _p(wAc), _p(wBc), _p(bvec),
-                                                 _p(gi), _p(gf), _p(Sd), _p(pA), _p(pB), _p(pb), _p(dgi), _p(dgf), _p(dh0),
+                                                 _p(gx), _p(gh), _p(Sd), _p(pA), _p(pB), _p(pb), _p(dgi), _p(dgf), _p(dh0),
                                                  B, T, N, G, F, Kin, Kst, _stream()), 'small_dense_backward')
+            if scalar_gates:                                  # a scalar gate collects the gradients of all its nodes
+                dgi, dgf = dgi.sum(dim=2).t(), dgf.sum(dim=2).t()
         else:
             check(lib.gcrnn_small_backward(dtype_code(dt), _p(X), _p(h0), _p(H), _p(dHc), _p(wAc),
                                            _p(wBc), _p(bvec), _p(gi), _p(gf), _p(fwd.rowptr), _p(fwd.col),

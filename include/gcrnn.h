@@ -217,8 +217,10 @@ int gcrnn_small_backward(int dtype, const void* X, const void* h0, const void* H
 /* Same contract on the matrix cores for graphs whose DENSE N x N GSO fits in LDS (the drivers' N = 50..80): every hop,
  * tap, weight-gradient and adjoint product of a time step is a small GEMM on v_mfma_f64_16x16x4_f64 /
  * v_mfma_f32_16x16x4_f32 with operands read from LDS. Sdense = S itself, row-major [N][N] in the data dtype
- * (z S: out[c][n] = sum_m z[c][m] S[m][n]). backward: pA [B][F][Kin][G], pB [B][F][Kst][F], pb [B][F] per-sequence
- * partial sums (added over B by the caller), dgi / dgf / dh0 as for gcrnn_small_backward. */
+ * (z S: out[c][n] = sum_m z[c][m] S[m][n]). Gates here are PER NODE: gi / gf [B][T][N] multiply the input / state filter's
+ * output at every node (time gates: constant over n; node gates graphML.py:2379-2407; or their product), both NULL = un-gated.
+ * backward: pA [B][F][Kin][G], pB [B][F][Kst][F], pb [B][F] per-sequence partial sums (added over B by the caller),
+ * dgi / dgf [B][T][N], dh0 [B][F][N] or NULL. */
 int gcrnn_small_dense_supported(int dtype, int64_t N, int64_t G, int64_t F, int64_t Kin, int64_t Kst, int backward,
                                 int gated);
 int gcrnn_small_dense_forward(int dtype, const void* X, const void* h0, const void* wA, const void* wB, const void* bias,

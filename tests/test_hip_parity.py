@@ -253,17 +253,23 @@ def test_kstep_data_and_driver_pieces(dev):
     assert float(l1) < float(l0) and float(data.evaluate(yh, yb)) > 0
 
 
-@pytest.mark.parametrize('name,tg', [('none', False), ('time', True)])
-def test_small_graph_persistent_kernel_g3(dev, name, tg, small_impl):
-    """Small-graph regime: the one-launch persistent kernel (inference) against the G3 goldens, fp64 and fp32."""
+@pytest.mark.parametrize('name,tg,sg', [('none', False, None), ('time', True, None), ('node', False, 'node'),
+                                        ('time_node', True, 'node')])
+def test_small_graph_persistent_kernel_g3(dev, name, tg, sg, small_impl):
+    """Small-graph regime: the one-launch persistent kernel (inference) against the G3 goldens, fp64 and fp32.
+    Node gating (per-node gates) exists in the matrix-core family only."""
+    if sg is not None and small_impl == 'gather':
+        pytest.skip('per-node gates: matrix-core kernels only')
     g = load_golden('g3_cell_' + name)
     for dt, tol in ((torch.float64, 1e-11), (torch.float32, 1e-5)):
-        cell = build_cell(g, tg, None, dt, dev)
+        cell = build_cell(g, tg, sg, dt, dev)
         X, h0 = T(g['X'], dt, dev), T(g['h0'], dt, dev)
         with torch.no_grad():
             assert cell._use_small(X, h0)
             H = cell(X, h0)
         assert maxdiff(H, g['H']) <= tol
+    if sg is not None:
+        return
     g = load_golden('g3_cell_%s_nobias' % name)          # no bias, Kin != Kst
     cell = build_cell(g, tg, None, torch.float64, dev, bias=False, Kst=2)
     with torch.no_grad():
@@ -329,13 +335,16 @@ def test_edge_attention_kernels(dev, dt, tol, N, B, F, Tn):
 
 
 @pytest.mark.parametrize('dt,tol,gtol', DTYPES)
-@pytest.mark.parametrize('name,tg', [('none', False), ('time', True)])
-def test_small_graph_bptt_kernel_vs_reference_gradients(dev, name, tg, dt, tol, gtol, small_impl):
+@pytest.mark.parametrize('name,tg,sg', [('none', False, None), ('time', True, None), ('node', False, 'node'),
+                                        ('time_node', True, 'node')])
+def test_small_graph_bptt_kernel_vs_reference_gradients(dev, name, tg, sg, dt, tol, gtol, small_impl):
     """X without gradient -> GGCRNNCell runs forward and BPTT on the one-launch small-graph kernels
     (gcrnn_small_forward / gcrnn_small_backward); parameter and h0 gradients vs the reference's (G4)."""
     from gated_gcrnns_amd import ops
+    if sg is not None and small_impl == 'gather':
+        pytest.skip('per-node gates: matrix-core kernels only')
     g = load_golden('g3_cell_' + name)
-    cell = build_cell(g, tg, None, dt, dev)
+    cell = build_cell(g, tg, sg, dt, dev)
     X, h0 = T(g['X'], dt, dev), T(g['h0'], dt, dev, True)
     assert cell._use_small_training(X, h0)
     calls = []
@@ -487,3 +496,38 @@ def test_node_linear_head_kernel(dev, dt, tol, R, F, N, O, bias):
     ref = [yr.detach(), h.grad, w.grad] + ([b.grad] if bias else [])
     for a, c in zip(got, ref):
         assert float((a - c).abs().max()) <= tol * (float(c.abs().max()) + 1e-30)
+
+
+@pytest.mark.parametrize('dt,gtol', [(torch.float64, 1e-9), (torch.float32, 5e-4)])
+@pytest.mark.parametrize('N,G,F,K,Tn,B,tg', [(80, 1, 20, 5, 5, 100, False), (59, 1, 20, 3, 40, 8, True), (72, 3, 33, 2, 3, 2, False)])
+def test_small_graph_node_gated_bptt_vs_composed_path(dev, dt, gtol, N, G, F, K, Tn, B, tg):
+    """Node gating (and node x time gating) on the matrix-core small-graph kernels -- per-node gate vectors in the one-launch
+    recurrence and its BPTT -- vs the composed autograd path: states and every parameter gradient (incl. the gate sub-networks)."""
+    rng = np.random.default_rng(N + Tn)
+    S = rng.standard_normal((N, N)) * (rng.random((N, N)) < 0.08)
+    S = S / (np.abs(np.linalg.eigvals(S)).max() + 1e-9)
+    torch.manual_seed(1)
+    cell = gml().GGCRNNCell(G, F, K, K, torch.tanh, tg, 'node', 1, True)
+    cell.addGSO(torch.tensor(S[None]))
+    cell = cell.to(dev).to(dt)
+    X = torch.randn(B, Tn, G, N, dtype=torch.float64).to(dev).to(dt)
+    h0 = (0.3 * torch.randn(B, F, N, dtype=torch.float64)).to(dev).to(dt).requires_grad_(True)
+    r = torch.randn(B, Tn, F, N, dtype=torch.float64).to(dev).to(dt)
+    if not cell._use_small_training(X, h0):
+        assert (N, F, dt) == (72, 33, torch.float64)                # the one shape whose gated fp64 working set exceeds LDS
+        pytest.skip('shape does not fit the small-graph kernels in this precision')
+    H1 = cell(X, h0)
+    (H1 * r).sum().backward()
+    got = {k: p.grad.clone() for k, p in cell.named_parameters() if p.grad is not None}
+    got['h0'] = h0.grad.clone()
+    cell.zero_grad(); h0.grad = None
+    cell._use_small_training = lambda *a: False
+    H2 = cell(X, h0)
+    (H2 * r).sum().backward()
+    ref = {k: p.grad for k, p in cell.named_parameters() if p.grad is not None}
+    ref['h0'] = h0.grad
+    assert float((H1 - H2).abs().max()) <= (1e-11 if dt == torch.float64 else 2e-5)
+    assert set(got) == set(ref)
+    for k in ref:
+        scale = float(ref[k].abs().max()) + 1e-30
+        assert float((got[k] - ref[k]).abs().max()) / scale <= gtol, k
