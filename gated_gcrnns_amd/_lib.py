@@ -79,8 +79,8 @@ def _bind(lib):
         'gcrnn_small_backward_supported': (C.c_int, [C.c_int, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64]),
         'gcrnn_small_backward': (C.c_int, [C.c_int] + [_c_p] * 21 + [_c_i64] * 8 + [_c_p]),
         'gcrnn_small_dense_supported': (C.c_int, [C.c_int, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, C.c_int, C.c_int]),
-        'gcrnn_small_dense_forward': (C.c_int, [C.c_int] + [_c_p] * 9 + [_c_i64] * 7 + [_c_p]),
-        'gcrnn_small_dense_backward': (C.c_int, [C.c_int] + [_c_p] * 16 + [_c_i64] * 7 + [_c_p]),
+        'gcrnn_small_dense_forward': (C.c_int, [C.c_int] + [_c_p] * 9 + [_c_i64] * 10 + [_c_p]),
+        'gcrnn_small_dense_backward': (C.c_int, [C.c_int] + [_c_p] * 16 + [_c_i64] * 10 + [_c_p]),
         'gcrnn_small_gates_supported': (C.c_int, [C.c_int, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, C.c_int]),
         'gcrnn_small_gates_forward': (C.c_int, [C.c_int] + [_c_p] * 9 + [_c_i64] * 7 + [_c_p]),
         'gcrnn_small_gates_backward': (C.c_int, [C.c_int] + [_c_p] * 14 + [_c_i64] * 7 + [_c_p]),

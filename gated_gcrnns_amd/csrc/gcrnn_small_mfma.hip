@@ -31,10 +31,11 @@ __global__ __launch_bounds__(1024) void small_dense_fwd_kernel(
     const T* __restrict__ wA,      // [F][Kin][G]
     const T* __restrict__ wB,      // [F][Kst][F]
     const T* __restrict__ bias,    // [F] or null
-    const T* __restrict__ gi, const T* __restrict__ gf,       // [B][Tn][N] per-node gates of the input / state filter, or null
+    const T* __restrict__ gi, const T* __restrict__ gf,       // gates of the input / state filter per (b, t, n) through strides, or null
     const T* __restrict__ Sd,      // [N][N] dense S (row m, column n)
     T* __restrict__ H,             // [B][Tn][F][N]
-    int Tn, int N, int G, int F, int Kin, int Kst, int B) {
+    int Tn, int N, int G, int F, int Kin, int Kst, int B,
+    int64_t gsb, int64_t gst, int64_t gsn) {     // gate element (b, t, n) sits at b gsb + t gst + n gsn
   typedef typename Mf<T>::acc acc_t;
   extern __shared__ __attribute__((aligned(16))) char smem_dense[];
   const int K = Kin > Kst ? Kin : Kst;
@@ -90,7 +91,7 @@ __global__ __launch_bounds__(1024) void small_dense_fwd_kernel(
     if (t + 1 < Tn && tid < GN) xpre = xt[GN + tid];
     if (gi && tid < 2 * N) {
       const int w = tid >= N, n = tid - w * N;
-      gvec[w * Ns + n] = (w ? gf : gi)[((size_t)b * Tn + t) * N + n];
+      gvec[w * Ns + n] = (w ? gf : gi)[b * gsb + t * gst + n * gsn];
     }
     __syncthreads();
     // ---- hops: Z_k = Z_{k-1} S
@@ -180,14 +181,15 @@ template <typename T, bool GATED, int MAXW>
 __global__ __launch_bounds__(1024) void small_dense_bwd_kernel(
     const T* __restrict__ X, const T* __restrict__ h0, const T* __restrict__ H, const T* __restrict__ dH,
     const T* __restrict__ wA, const T* __restrict__ wB, const T* __restrict__ bias,
-    const T* __restrict__ gi, const T* __restrict__ gf,       // [B][Tn][N] per-node gates (GATED)
+    const T* __restrict__ gi, const T* __restrict__ gf,       // gates per (b, t, n) through strides (GATED)
     const T* __restrict__ Sd,
     T* __restrict__ pA,             // [B][F][Kin][G]
     T* __restrict__ pB,             // [B][F][Kst][F]
     T* __restrict__ pb,             // [B][F]
     T* __restrict__ dgi, T* __restrict__ dgf,                 // [B][Tn][N] gradients of the gates (GATED)
     T* __restrict__ dh0,
-    int Tn, int N, int G, int F, int Kin, int Kst, int B) {
+    int Tn, int N, int G, int F, int Kin, int Kst, int B,
+    int64_t gsb, int64_t gst, int64_t gsn) {     // gate element (b, t, n) sits at b gsb + t gst + n gsn (dgi / dgf are dense)
   typedef typename Mf<T>::acc acc_t;
   extern __shared__ __attribute__((aligned(16))) char smem_dense[];
   const int K = Kin > Kst ? Kin : Kst;
@@ -252,7 +254,7 @@ __global__ __launch_bounds__(1024) void small_dense_bwd_kernel(
     const T* dht = dH + ((size_t)b * Tn + t) * FN;
     if (GATED && tid < 2 * N) {
       const int w = tid >= N, n = tid - w * N;
-      gvec[w * Ns + n] = (w ? gf : gi)[((size_t)b * Tn + t) * N + n];
+      gvec[w * Ns + n] = (w ? gf : gi)[b * gsb + t * gst + n * gsn];
     }
     for (int i = tid; i < (G + F) * N; i += 1024) {
       const int c = i / N, n = i - c * N;
@@ -465,7 +467,7 @@ extern "C" int gcrnn_small_dense_supported(int dtype, int64_t N, int64_t G, int6
 template <typename T>
 static int dense_fwd_launch(const void* X, const void* h0, const void* wA, const void* wB, const void* bias, const void* gi,
                             const void* gf, const void* Sd, void* H, int64_t B, int64_t Tn, int64_t N, int64_t G, int64_t F,
-                            int64_t Kin, int64_t Kst, hipStream_t st) {
+                            int64_t Kin, int64_t Kst, int64_t gsb, int64_t gst, int64_t gsn, hipStream_t st) {
   const int64_t K = Kin > Kst ? Kin : Kst;
   const size_t lds = dense_fwd_lds<T>(N, G, F, K);
   const int64_t ot = ((F + 15) / 16) * ((N + 15) / 16);             // output tiles per step, dealt over 16 waves
@@ -475,7 +477,7 @@ static int dense_fwd_launch(const void* X, const void* h0, const void* wA, const
   GCRNN_PRE_LAUNCH();
   kern<<<(unsigned)B, 1024, lds, st>>>((const T*)X, (const T*)h0, (const T*)wA, (const T*)wB, (const T*)bias, (const T*)gi,
                                       (const T*)gf, (const T*)Sd, (T*)H, (int)Tn, (int)N, (int)G, (int)F, (int)Kin, (int)Kst,
-                                      (int)B);
+                                      (int)B, gsb, gst, gsn);
   GCRNN_CHECK_LAUNCH();
   return GCRNN_OK;
 }
@@ -483,21 +485,23 @@ static int dense_fwd_launch(const void* X, const void* h0, const void* wA, const
 extern "C" int gcrnn_small_dense_forward(int dtype, const void* X, const void* h0, const void* wA, const void* wB,
                                          const void* bias, const void* gi, const void* gf, const void* Sdense, void* H,
                                          int64_t B, int64_t T, int64_t N, int64_t G, int64_t F, int64_t Kin, int64_t Kst,
-                                         void* stream) {
+                                         int64_t gate_stride_b, int64_t gate_stride_t, int64_t gate_stride_n, void* stream) {
   if (!X || !h0 || !wA || !wB || !Sdense || !H) return GCRNN_ERR_NULL_POINTER;
   if ((gi == nullptr) != (gf == nullptr)) return GCRNN_ERR_NULL_POINTER;
   if (B <= 0 || T <= 0 || B > 2147483647LL) return GCRNN_ERR_BAD_SHAPE;
   if (!gcrnn_small_dense_supported(dtype, N, G, F, Kin, Kst, 0, gi != nullptr)) return GCRNN_ERR_UNSUPPORTED;
   if (dtype == GCRNN_F32)
-    return dense_fwd_launch<float>(X, h0, wA, wB, bias, gi, gf, Sdense, H, B, T, N, G, F, Kin, Kst, as_stream(stream));
-  return dense_fwd_launch<double>(X, h0, wA, wB, bias, gi, gf, Sdense, H, B, T, N, G, F, Kin, Kst, as_stream(stream));
+    return dense_fwd_launch<float>(X, h0, wA, wB, bias, gi, gf, Sdense, H, B, T, N, G, F, Kin, Kst, gate_stride_b,
+                                   gate_stride_t, gate_stride_n, as_stream(stream));
+  return dense_fwd_launch<double>(X, h0, wA, wB, bias, gi, gf, Sdense, H, B, T, N, G, F, Kin, Kst, gate_stride_b, gate_stride_t,
+                                  gate_stride_n, as_stream(stream));
 }
 
 template <typename T, bool GATED>
 static int dense_bwd_launch(const void* X, const void* h0, const void* H, const void* dH, const void* wA, const void* wB,
                             const void* bias, const void* gi, const void* gf, const void* Sd, void* pA, void* pB, void* pb,
                             void* dgi, void* dgf, void* dh0, int64_t B, int64_t Tn, int64_t N, int64_t G, int64_t F,
-                            int64_t Kin, int64_t Kst, hipStream_t st) {
+                            int64_t Kin, int64_t Kst, int64_t gsb, int64_t gst, int64_t gsn, hipStream_t st) {
   const size_t lds = dense_bwd_lds<T>(N, G, F, Kin, Kst, GATED);
   const int64_t wt = (Kin > Kst ? Kin : Kst) * ((F + 15) / 16) * ((G + F + 15) / 16);   // weight-gradient tiles, persistent
   auto kern = wt <= 16 ? small_dense_bwd_kernel<T, GATED, 1>
@@ -507,7 +511,8 @@ static int dense_bwd_launch(const void* X, const void* h0, const void* H, const 
   GCRNN_PRE_LAUNCH();
   kern<<<(unsigned)B, 1024, lds, st>>>((const T*)X, (const T*)h0, (const T*)H, (const T*)dH, (const T*)wA, (const T*)wB,
                                       (const T*)bias, (const T*)gi, (const T*)gf, (const T*)Sd, (T*)pA, (T*)pB, (T*)pb,
-                                      (T*)dgi, (T*)dgf, (T*)dh0, (int)Tn, (int)N, (int)G, (int)F, (int)Kin, (int)Kst, (int)B);
+                                      (T*)dgi, (T*)dgf, (T*)dh0, (int)Tn, (int)N, (int)G, (int)F, (int)Kin, (int)Kst, (int)B, gsb,
+                                      gst, gsn);
   GCRNN_CHECK_LAUNCH();
   return GCRNN_OK;
 }
@@ -516,7 +521,7 @@ extern "C" int gcrnn_small_dense_backward(int dtype, const void* X, const void* 
                                           const void* wA, const void* wB, const void* bias, const void* gi, const void* gf,
                                           const void* Sdense, void* pA, void* pB, void* pb, void* dgi, void* dgf, void* dh0,
                                           int64_t B, int64_t T, int64_t N, int64_t G, int64_t F, int64_t Kin, int64_t Kst,
-                                          void* stream) {
+                                          int64_t gate_stride_b, int64_t gate_stride_t, int64_t gate_stride_n, void* stream) {
   if (!X || !h0 || !H || !dH || !wA || !wB || !Sdense || !pA || !pB || !pb) return GCRNN_ERR_NULL_POINTER;
   if ((gi == nullptr) != (gf == nullptr)) return GCRNN_ERR_NULL_POINTER;
   if (gi && (!dgi || !dgf)) return GCRNN_ERR_NULL_POINTER;
@@ -524,8 +529,8 @@ extern "C" int gcrnn_small_dense_backward(int dtype, const void* X, const void* 
   if (!gcrnn_small_dense_supported(dtype, N, G, F, Kin, Kst, 1, gi != nullptr)) return GCRNN_ERR_UNSUPPORTED;
   hipStream_t st = as_stream(stream);
   if (dtype == GCRNN_F32)
-    return gi ? dense_bwd_launch<float, true>(X, h0, H, dH, wA, wB, bias, gi, gf, Sdense, pA, pB, pb, dgi, dgf, dh0, B, T, N, G, F, Kin, Kst, st)
-              : dense_bwd_launch<float, false>(X, h0, H, dH, wA, wB, bias, gi, gf, Sdense, pA, pB, pb, dgi, dgf, dh0, B, T, N, G, F, Kin, Kst, st);
-  return gi ? dense_bwd_launch<double, true>(X, h0, H, dH, wA, wB, bias, gi, gf, Sdense, pA, pB, pb, dgi, dgf, dh0, B, T, N, G, F, Kin, Kst, st)
-            : dense_bwd_launch<double, false>(X, h0, H, dH, wA, wB, bias, gi, gf, Sdense, pA, pB, pb, dgi, dgf, dh0, B, T, N, G, F, Kin, Kst, st);
+    return gi ? dense_bwd_launch<float, true>(X, h0, H, dH, wA, wB, bias, gi, gf, Sdense, pA, pB, pb, dgi, dgf, dh0, B, T, N, G, F, Kin, Kst, gate_stride_b, gate_stride_t, gate_stride_n, st)
+              : dense_bwd_launch<float, false>(X, h0, H, dH, wA, wB, bias, gi, gf, Sdense, pA, pB, pb, dgi, dgf, dh0, B, T, N, G, F, Kin, Kst, gate_stride_b, gate_stride_t, gate_stride_n, st);
+  return gi ? dense_bwd_launch<double, true>(X, h0, H, dH, wA, wB, bias, gi, gf, Sdense, pA, pB, pb, dgi, dgf, dh0, B, T, N, G, F, Kin, Kst, gate_stride_b, gate_stride_t, gate_stride_n, st)
+            : dense_bwd_launch<double, false>(X, h0, H, dH, wA, wB, bias, gi, gf, Sdense, pA, pB, pb, dgi, dgf, dh0, B, T, N, G, F, Kin, Kst, gate_stride_b, gate_stride_t, gate_stride_n, st);
 }

@@ -417,14 +417,15 @@ def small_dense_supported(N, G, F, Kin, Kst, dtype, backward, gated):
                                                 int(backward), int(gated)))
 
 
-def _node_gates(g, B, T, N):
-    """[T][B] scalar gates -> [B][T][N] (what the matrix-core kernels take); [B][T][N] gates pass through."""
+def _gate_strides(g, B, T, N):
+    """Element strides (b, t, n) with which the matrix-core kernels read a gate tensor: [T][B] scalar gates or [B][T][N]."""
     if g is None:
-        return None
+        return 0, 0, 0
     if g.dim() == 2:
-        return g.t().unsqueeze(2).expand(B, T, N).contiguous()
+        assert tuple(g.shape) == (T, B)
+        return 1, B, 0
     assert tuple(g.shape) == (B, T, N)
-    return g.contiguous()
+    return T * N, N, 1
 
 
 def small_cell_forward(X, h0, wA, wB, bias, graph, gi=None, gf=None):
@@ -443,9 +444,11 @@ def small_cell_forward(X, h0, wA, wB, bias, graph, gi=None, gf=None):
     Xc, h0c, wAc, wBc, vals = X.contiguous(), h0.contiguous(), wA.contiguous(), wB.contiguous(), csr.val(X.dtype)
     if small_dense_supported(N, G, F, Kin, Kst, X.dtype, backward=False, gated=gi is not None):
         Sd = graph.dense(X.dtype)
-        gx, gh = _node_gates(gi, B, T, N), _node_gates(gf, B, T, N)
-        check(lib.gcrnn_small_dense_forward(dtype_code(X.dtype), _p(Xc), _p(h0c), _p(wAc), _p(wBc), _p(bvec), _p(gx), _p(gh),
-                                            _p(Sd), _p(H), B, T, N, G, F, Kin, Kst, _stream()), 'small_dense_forward')
+        gs = _gate_strides(gi, B, T, N)
+        assert gs == _gate_strides(gf, B, T, N)
+        check(lib.gcrnn_small_dense_forward(dtype_code(X.dtype), _p(Xc), _p(h0c), _p(wAc), _p(wBc), _p(bvec), _p(gi), _p(gf),
+                                            _p(Sd), _p(H), B, T, N, G, F, Kin, Kst, gs[0], gs[1], gs[2], _stream()),
+              'small_dense_forward')
         return H
     assert gi is None or gi.dim() == 2, 'per-node gates need the matrix-core kernels (small_dense_supported)'
     check(lib.gcrnn_small_forward(dtype_code(X.dtype), _p(Xc), _p(h0c), _p(wAc),
@@ -499,10 +502,10 @@ class _SmallCell(torch.autograd.Function):
         dHc, wAc, wBc, fval, aval = dH.contiguous(), wA.contiguous(), wB.contiguous(), fwd.val(dt), adj.val(dt)
         if dense:
             Sd = ctx.graph.dense(dt)
-            gx, gh = _node_gates(gi, B, T, N), _node_gates(gf, B, T, N)
+            gs = _gate_strides(gi, B, T, N)
             check(lib.gcrnn_small_dense_backward(dtype_code(dt), _p(X), _p(h0), _p(H), _p(dHc), _p(wAc), _p(wBc), _p(bvec),
-                                                 _p(gx), _p(gh), _p(Sd), _p(pA), _p(pB), _p(pb), _p(dgi), _p(dgf), _p(dh0),
-                                                 B, T, N, G, F, Kin, Kst, _stream()), 'small_dense_backward')
+                                                 _p(gi), _p(gf), _p(Sd), _p(pA), _p(pB), _p(pb), _p(dgi), _p(dgf), _p(dh0),
+                                                 B, T, N, G, F, Kin, Kst, gs[0], gs[1], gs[2], _stream()), 'small_dense_backward')
             if scalar_gates:                                  # a scalar gate collects the gradients of all its nodes
                 dgi, dgf = dgi.sum(dim=2).t(), dgf.sum(dim=2).t()
         else:

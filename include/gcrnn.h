@@ -217,19 +217,22 @@ int gcrnn_small_backward(int dtype, const void* X, const void* h0, const void* H
 /* Same contract on the matrix cores for graphs whose DENSE N x N GSO fits in LDS (the drivers' N = 50..80): every hop,
  * tap, weight-gradient and adjoint product of a time step is a small GEMM on v_mfma_f64_16x16x4_f64 /
  * v_mfma_f32_16x16x4_f32 with operands read from LDS. Sdense = S itself, row-major [N][N] in the data dtype
- * (z S: out[c][n] = sum_m z[c][m] S[m][n]). Gates here are PER NODE: gi / gf [B][T][N] multiply the input / state filter's
- * output at every node (time gates: constant over n; node gates graphML.py:2379-2407; or their product), both NULL = un-gated.
- * backward: pA [B][F][Kin][G], pB [B][F][Kst][F], pb [B][F] per-sequence partial sums (added over B by the caller),
- * dgi / dgf [B][T][N], dh0 [B][F][N] or NULL. */
+ * (z S: out[c][n] = sum_m z[c][m] S[m][n]). Gates here are PER NODE: gi / gf multiply the input / state filter's output at
+ * every node; element (b, t, n) is read at b * gate_stride_b + t * gate_stride_t + n * gate_stride_n, so [T][B] time gates
+ * (strides 1, B, 0), [B][T][N] node gates (graphML.py:2379-2407) or their product (strides T N, N, 1) need no copy; both
+ * NULL = un-gated. backward: pA [B][F][Kin][G], pB [B][F][Kst][F], pb [B][F] per-sequence partial sums (added over B by the
+ * caller), dgi / dgf [B][T][N] (dense; a scalar gate's gradient is their sum over n), dh0 [B][F][N] or NULL. */
 int gcrnn_small_dense_supported(int dtype, int64_t N, int64_t G, int64_t F, int64_t Kin, int64_t Kst, int backward,
                                 int gated);
 int gcrnn_small_dense_forward(int dtype, const void* X, const void* h0, const void* wA, const void* wB, const void* bias,
                               const void* gi, const void* gf, const void* Sdense, void* H, int64_t B, int64_t T, int64_t N,
-                              int64_t G, int64_t F, int64_t Kin, int64_t Kst, void* stream);
+                              int64_t G, int64_t F, int64_t Kin, int64_t Kst, int64_t gate_stride_b, int64_t gate_stride_t,
+                              int64_t gate_stride_n, void* stream);
 int gcrnn_small_dense_backward(int dtype, const void* X, const void* h0, const void* H, const void* dH, const void* wA,
                                const void* wB, const void* bias, const void* gi, const void* gf, const void* Sdense,
                                void* pA, void* pB, void* pb, void* dgi, void* dgf, void* dh0, int64_t B, int64_t T,
-                               int64_t N, int64_t G, int64_t F, int64_t Kin, int64_t Kst, void* stream);
+                               int64_t N, int64_t G, int64_t F, int64_t Kin, int64_t Kst, int64_t gate_stride_b,
+                               int64_t gate_stride_t, int64_t gate_stride_n, void* stream);
 
 /* Time gates of the small-graph regime (GGCRNNCell time gating, graphML.py:2248-2278, 2357-2374), both gates in one launch:
  *   gate[g][t][b] = sigmoid( lw_g . vec_{F,N}( tanh(A_g(S) x_t + B_g(S) h0 + 2 b_g) ) + lb_g ),  g = 0 input, 1 forget.
