@@ -93,7 +93,7 @@ def main():
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32', 'f64'])
     ap.add_argument('--mode', default='fwd', choices=['fwd', 'train'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--time-gating', action='store_true', help='secondary point: the time-gated cell (forward only); '
+    ap.add_argument('--time-gating', action='store_true', help='secondary point: the time-gated cell (fwd or train); '
                     'the headline workload is the un-gated cell')
     ap.add_argument('--hipgraph', type=int, default=0, help='replay the fused forward as one captured hipGraph (bf16 fwd)')
     args = ap.parse_args()
@@ -119,7 +119,6 @@ def main():
     S = sbm_graph(N)
     nnz = int(np.count_nonzero(S))
     torch.manual_seed(0)
-    assert not (args.time_gating and args.mode == 'train'), 'time-gated training runs on the composed fp32/fp64 path'
     cell = gml.GGCRNNCell(G, F, K, K, torch.tanh, args.time_gating, None, 1, True)      # reference init U(+-1/sqrt(G*K))
     cell.addGSO(torch.tensor(S))
     params = {k: v.detach().numpy().copy() for k, v in cell.state_dict().items()}
@@ -131,8 +130,9 @@ def main():
     sync_grads = None
     if args.mode == 'train':
         # one optimiser step of the k-step-prediction loop (reference train_rnn.py:247-281): forward, L1 loss on the
-        # state sequence, BPTT, ONE flat gradient all-reduce over RCCL, Adam. Runs on the fp32/fp64 composed path.
-        # bf16: fp32 master weights, bf16 activations -> fused forward + fused BPTT; f32 / f64: composed path
+        # state sequence, BPTT, ONE flat gradient all-reduce over RCCL, Adam.
+        # bf16: fp32 master weights, bf16 activations -> fused forward + fused BPTT (un-gated and time-gated cells);
+        # f32 / f64: composed path
         from gated_gcrnns_amd.parallel import FlatGradAllReduce
         from gated_gcrnns_amd.Utils.miscTools import batchTimeL1Loss
         if args.dtype == 'bf16':

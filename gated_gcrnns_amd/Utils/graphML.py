@@ -294,7 +294,8 @@ class GGCRNNCell(nn.Module):
         B, T, F_in, N = X.shape
         assert F_in == self.G and N == self.N
         if self._use_fused_training(X, h0):
-            return ops.fused_cell_train(X, h0, self.weight_A, self.weight_B, self.bias, self.graph)
+            return ops.fused_cell_train(X, h0, self.weight_A, self.weight_B, self.bias, self.graph,
+                                        self._fused_gates() if self.time_gating == True else None)  # noqa: E712
         if self._use_fused(X, h0):
             return self._forward_fused(X, h0)
         if self._use_small(X, h0):
@@ -456,7 +457,7 @@ class GGCRNNCell(nn.Module):
             return ops.small_cell_train(X, h0, self.weight_A, self.weight_B, self.bias, self.graph, gi, gf)
         return ops.small_cell_forward(X, h0, self.weight_A, self.weight_B, self.bias, self.graph, gi, gf)
 
-    # -- fused flagship path (bf16, un-gated / time-gated, sigma = tanh, inference) -------------------
+    # -- fused flagship path (bf16, un-gated / time-gated, sigma = tanh; inference here, training via ops.fused_cell_train) ----
     def _use_fused(self, X, h0):
         if torch.is_grad_enabled() and (X.requires_grad or h0.requires_grad or self.weight_A.requires_grad):
             return False            # BPTT runs on the composed path
@@ -466,27 +467,31 @@ class GGCRNNCell(nn.Module):
             self.weight_A.dtype in (X.dtype, torch.float32) and h0.dtype == X.dtype
 
     def _use_fused_training(self, X, h0):
-        """bf16 activations (parameters bf16 or fp32 master weights), plain cell, gradients wanted for the parameters
-        (and optionally h0) but not for X: forward and BPTT on the fused kernels."""
+        """bf16 activations (parameters bf16 or fp32 master weights), plain or time-gated cell, gradients wanted for the
+        parameters (and, for the plain cell, optionally h0) but not for X: forward and BPTT on the fused kernels."""
         if not torch.is_grad_enabled() or X.requires_grad:
             return False
         if not (self.weight_A.requires_grad or h0.requires_grad):
             return False
-        if self.time_gating == True or self.spatial_gating is not None:  # noqa: E712
+        if self.spatial_gating is not None:
             return False
+        if self.time_gating == True:  # noqa: E712   the fused gates give no gradient to h0; their sub-cells share the cell's shapes
+            if h0.requires_grad or self.bias is None or self.GFL_in.weight_A.dtype != self.weight_A.dtype:
+                return False
         if self.sigma not in (torch.tanh, nn.functional.tanh) or X.dtype != torch.bfloat16 or h0.dtype != X.dtype:
             return False
         if self.weight_A.dtype not in (torch.bfloat16, torch.float32):
             return False
         return ops.fused_training_supported(self.graph, self.N, self.F, self.G, self.Kin, self.Kst, self.E)
 
+    def _fused_gates(self):
+        return {'in': (self.GFL_in.weight_A, self.GFL_in.weight_B, self.GFL_in.bias,
+                       self.MLP_in[0].weight, self.MLP_in[0].bias),
+                'forget': (self.GFL_forget.weight_A, self.GFL_forget.weight_B, self.GFL_forget.bias,
+                           self.MLP_forget[0].weight, self.MLP_forget[0].bias)}
+
     def _forward_fused(self, X, h0):
-        gates = None
-        if self.time_gating == True:  # noqa: E712
-            gates = {'in': (self.GFL_in.weight_A, self.GFL_in.weight_B, self.GFL_in.bias,
-                            self.MLP_in[0].weight, self.MLP_in[0].bias),
-                     'forget': (self.GFL_forget.weight_A, self.GFL_forget.weight_B, self.GFL_forget.bias,
-                                self.MLP_forget[0].weight, self.MLP_forget[0].bias)}
+        gates = self._fused_gates() if self.time_gating == True else None  # noqa: E712
         return ops.fused_cell_forward(X, h0, self.weight_A, self.weight_B, self.bias, self.graph, gates)
 
     def extra_repr(self):

@@ -354,7 +354,9 @@ extern "C" int gcrnn_fused_pack_weights(int wdtype, const void* wA, const void* 
 // LDS map (dynamic): state [NP][16] fp32 (64 KiB) | weight fragments K*KS KiB | RESIDENT: lval4 (f32x4), lcol4 (u16x4).
 // Tiles hold 16 nodes of similar degree: tile_nodes[p] lists the node of every slot p (degree-sorted order,
 // padded with node ids >= N that have no edges); memory rows are in natural node order.
-// EPI: 0 = state epilogue (bias, tanh, bf16 store), 1 = time-gate pre-pass (dot-reduce), 2 = BPTT data-gradient step
+// EPI: 0 = state epilogue (bias, tanh, bf16 store), 1 = time-gate pre-pass (dot-reduce; optionally also stores the
+// gate cell's state c = tanh(pre) for its BPTT), 2 = BPTT data-gradient step (optionally scaled by the forget gate),
+// 3 = gate-gradient pass: sum_{f,n} (filter output + b) * dpre of every item (the gradient w.r.t. a scalar time gate)
 template <int K, int HS, int XS, bool GATED, bool RESIDENT, int EPI = 0>
 __global__ __launch_bounds__(STHREADS) void fused_step_kernel(
     const uint16_t* __restrict__ xt,        // [B][NP][G]   bf16
@@ -363,7 +365,7 @@ __global__ __launch_bounds__(STHREADS) void fused_step_kernel(
     const uint4* __restrict__ wpack,        // [F/16][K][KS][64] x 16 B
     const float* __restrict__ bias,         // [F] or null
     const float* __restrict__ gi,           // [B] (GATED)
-    const float* __restrict__ gf,           // [B] (GATED)
+    const float* __restrict__ gf,           // [B] (GATED); EPI 2: forget gate of the step being back-propagated, or null
     const int32_t* __restrict__ tile_nodes, // [NP] node id of each tile slot
     const int32_t* __restrict__ tile_off,   // [NP/16 + 1], in entries
     const int32_t* __restrict__ ell_col,    // [entries][16] neighbour node id            (used when !RESIDENT)
@@ -372,14 +374,14 @@ __global__ __launch_bounds__(STHREADS) void fused_step_kernel(
     const uint2* __restrict__ ell_col4,     // [entries/4][16] x 4 u16 (row offset | swizzle)
     const float* __restrict__ gate_w,       // GATEOUT: [N][F] node-major weights of the gate's Linear(N*F -> 1)
     float* __restrict__ gate_out,           // GATEOUT: [B][F/16][8] per-(chunk, wave) partials of sum_{n,f} tanh(pre) * gate_w
-    const uint16_t* __restrict__ aux0,      // EPI 2: upstream gradient dH_{t-1} [B][NP][F] bf16 (or null)
+    const uint16_t* __restrict__ aux0,      // EPI 2: upstream gradient dH_{t-1} [B][NP][F] bf16 (or null); EPI 3: dpre [B][NP][F] bf16
     const uint16_t* __restrict__ aux1,      // EPI 2: state h_{t-1} [B][NP][F] bf16;  EPI 0: user-layout output H[.][t][F][N] (or null)
     int ubstride,                           // EPI 0: elements between consecutive sequences of the user-layout output (T*F*N)
     int entries, int B, int hmod, int N) {
   constexpr int KS = HS + XS;
   constexpr int F = 32 * HS, G = 32 * XS;
   constexpr int NCH = F / FC;
-  constexpr bool GATEOUT = (EPI == 1);
+  constexpr bool GATEOUT = (EPI == 1 || EPI == 3);      // per-item scalar outputs (partials per chunk and wave)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* state = reinterpret_cast<float*>(smem);
   uint4* wl = reinterpret_cast<uint4*>(smem + NP * FC * 4);
@@ -440,8 +442,8 @@ __global__ __launch_bounds__(STHREADS) void fused_step_kernel(
   // alive (and spill) across the sequence loop.
   const __amdgpu_buffer_rsrc_t rsrc_h = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(hprev), 0, hmod * (NP * F * 2), 0x00020000);
   const __amdgpu_buffer_rsrc_t rsrc_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(xt), 0, B * (NP * G * 2), 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsrc_o = __builtin_amdgcn_make_buffer_rsrc(hout, 0, GATEOUT ? 0 : B * (NP * F * 2), 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsrc_a0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(aux0), 0, (EPI == 2 && aux0) ? B * (NP * F * 2) : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_o = __builtin_amdgcn_make_buffer_rsrc(hout, 0, hout ? B * (NP * F * 2) : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_a0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(aux0), 0, ((EPI == 2 || EPI == 3) && aux0) ? B * (NP * F * 2) : 0, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsrc_a1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(aux1), 0, (EPI == 2 && aux0) ? B * (NP * F * 2) : 0, 0x00020000);
 
   for (int b = b0; b < B; b += seq_slots) {
@@ -596,20 +598,44 @@ __global__ __launch_bounds__(STHREADS) void fused_step_kernel(
 #pragma unroll
     for (int c = 0; c < 4; ++c) bsum[c] = bs * bvec[c];
   }
-  if (GATEOUT) {
-    // gate pre-pass: partial dot product of tanh(pre) with the gate's linear weights over this chunk, one atomic per wave
+  if (EPI == 3) {
+    // gate-gradient pass: the hops produced the filter output of this item's chunk; its inner product with dpre (one
+    // bias: this is ONE filter, A(S)x + b or B(S)h + b) is the chunk's share of d loss / d gate (graphML.py:2420-2421)
     float part = 0.f;
 #pragma unroll
     for (int i = 0; i < STILES; ++i) {
       int wv = woff[i];
       asm volatile("" : "+v"(wv));
       const int node = wv >> 16;
+      const u32x2 d2 = __builtin_amdgcn_raw_buffer_load_b64(rsrc_a0, node * (F * 2) + (chunk * FC + q * 4) * 2, b * (NP * F * 2), 0);
+      const f32x4 acc = u[i][0];
+      if (node < N)
+        part += (acc[0] + bvec[0]) * bf2f((uint16_t)(d2[0] & 0xffffu)) + (acc[1] + bvec[1]) * bf2f((uint16_t)(d2[0] >> 16)) +
+                (acc[2] + bvec[2]) * bf2f((uint16_t)(d2[1] & 0xffffu)) + (acc[3] + bvec[3]) * bf2f((uint16_t)(d2[1] >> 16));
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) part += __shfl_down(part, off, 64);
+    if (lane == 0) gate_out[(int64_t)b * (NCH * SWAVES) + chunk * SWAVES + wave] = part;   // fixed-order sum by the caller
+  } else if (GATEOUT) {
+    // gate pre-pass: partial dot product of tanh(pre) with the gate's linear weights over this chunk, one partial per wave;
+    // with hout the gate cell's state c = tanh(pre) is also stored (bf16, sequence-major) for the gate's BPTT
+    float part = 0.f;
+#pragma unroll
+    for (int i = 0; i < STILES; ++i) {
+      int wv = woff[i];
+      asm volatile("" : "+v"(wv));
+      const int node = wv >> 16;
+      uint2 pk{0u, 0u};
       if (node < N) {
         const float4 w4 = *reinterpret_cast<const float4*>(gate_w + (int64_t)node * F + chunk * FC + q * 4);
         const f32x4 acc = u[i][0];
-        part += fast_tanh(acc[0] + bsum[0]) * w4.x + fast_tanh(acc[1] + bsum[1]) * w4.y +
-                fast_tanh(acc[2] + bsum[2]) * w4.z + fast_tanh(acc[3] + bsum[3]) * w4.w;
+        const float o0 = fast_tanh(acc[0] + bsum[0]), o1 = fast_tanh(acc[1] + bsum[1]);
+        const float o2 = fast_tanh(acc[2] + bsum[2]), o3 = fast_tanh(acc[3] + bsum[3]);
+        part += o0 * w4.x + o1 * w4.y + o2 * w4.z + o3 * w4.w;
+        pk.x = (uint32_t)f2bf(o0) | ((uint32_t)f2bf(o1) << 16);
+        pk.y = (uint32_t)f2bf(o2) | ((uint32_t)f2bf(o3) << 16);
       }
+      if (hout) __builtin_amdgcn_raw_buffer_store_b64(u32x2{pk.x, pk.y}, rsrc_o, node * (F * 2) + (chunk * FC + q * 4) * 2, b * (NP * F * 2), 0);
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) part += __shfl_down(part, off, 64);
@@ -617,14 +643,16 @@ __global__ __launch_bounds__(STHREADS) void fused_step_kernel(
   } else if (EPI == 2) {
     // BPTT data-gradient step: the hops just applied sum_k (S)^k (dpre_t W_k) = d h_{t-1} (recurrent part); add the
     // upstream gradient of h_{t-1} and go through tanh':  dpre_{t-1} = (acc + dH_{t-1}) * (1 - h_{t-1}^2).
-    // With aux0 == null the raw state gradient is stored (d h0).
+    // With aux0 == null the raw state gradient is stored (d h0). Time-gated cell: the recurrent part carries the forget
+    // gate of the step it came through, gf_t[b] (the adjoint chain is linear, so the scale is applied here).
+    const float gsc = gf ? gf[b] : 1.f;
 #pragma unroll
     for (int i = 0; i < STILES; ++i) {
       int wv = woff[i];
       asm volatile("" : "+v"(wv));
       const int node = wv >> 16;
       const int eoff = node * (F * 2) + (chunk * FC + q * 4) * 2;
-      f32x4 o = u[i][0];
+      f32x4 o = u[i][0] * gsc;
       if (aux0) {
         const u32x2 g2 = __builtin_amdgcn_raw_buffer_load_b64(rsrc_a0, eoff, b * (NP * F * 2), 0);
         const u32x2 h2 = __builtin_amdgcn_raw_buffer_load_b64(rsrc_a1, eoff, b * (NP * F * 2), 0);
@@ -706,8 +734,8 @@ struct FusedGraphArgs {
 };
 
 template <int K, int HS, int XS>
-static int fused_launch_t(int mode /*0 plain, 1 gated, 2 gate pre-pass, 3 BPTT data gradient*/, const void* xs, const void* h0,
-                          void* hs, const void* wpack, const float* bias, const float* gi, const float* gf,
+static int fused_launch_t(int mode /*0 plain, 1 gated, 2 gate pre-pass, 3 BPTT data gradient, 4 gate-gradient pass*/, const void* xs,
+                          const void* h0, void* hs, const void* wpack, const float* bias, const float* gi, const float* gf,
                           const float* gate_w, float* gate_out, const FusedGraphArgs& ga, int64_t B, int64_t T, int64_t N,
                           hipStream_t st, const void* bw_dHs = nullptr, const void* bw_hs = nullptr, const void* bw_h0 = nullptr,
                           void* bw_dh0 = nullptr, void* huser = nullptr) {
@@ -717,43 +745,63 @@ static int fused_launch_t(int mode /*0 plain, 1 gated, 2 gate pre-pass, 3 BPTT d
   const bool resident = resident_bytes <= 160 * 1024 && ga.ell_val4 && ga.ell_col4;
   const size_t lds = resident ? resident_bytes : base;
   fused_kern_t kern;
-  if (mode == 3)      kern = resident ? (fused_kern_t)fused_step_kernel<K, HS, XS, false, true, 2> : (fused_kern_t)fused_step_kernel<K, HS, XS, false, false, 2>;
+  if (mode == 4)      kern = resident ? (fused_kern_t)fused_step_kernel<K, HS, XS, false, true, 3> : (fused_kern_t)fused_step_kernel<K, HS, XS, false, false, 3>;
+  else if (mode == 3) kern = resident ? (fused_kern_t)fused_step_kernel<K, HS, XS, false, true, 2> : (fused_kern_t)fused_step_kernel<K, HS, XS, false, false, 2>;
   else if (mode == 2) kern = resident ? (fused_kern_t)fused_step_kernel<K, HS, XS, false, true, 1> : (fused_kern_t)fused_step_kernel<K, HS, XS, false, false, 1>;
   else if (mode == 1) kern = resident ? (fused_kern_t)fused_step_kernel<K, HS, XS, true, true> : (fused_kern_t)fused_step_kernel<K, HS, XS, true, false>;
   else                kern = resident ? (fused_kern_t)fused_step_kernel<K, HS, XS, false, true> : (fused_kern_t)fused_step_kernel<K, HS, XS, false, false>;
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
     return GCRNN_ERR_LAUNCH;
   const int NCH = F / FC;
-  const int64_t items = (mode == 2) ? B * T : B;       // the gate pre-pass has no recurrence: all (t, b) in one launch
-  // one workgroup per CU: 256 / NCH sequence slots (rounded to the 8 XCDs), fewer when the batch is small
-  int64_t slots = cdiv(items, 8) * 8;
-  const int64_t max_slots = (256 / NCH) / 8 * 8 > 0 ? (256 / NCH) / 8 * 8 : 8;
-  if (slots > max_slots) slots = max_slots;
-  const unsigned grid = (unsigned)(slots * NCH);
   const uint16_t* x = (const uint16_t*)xs;
   uint16_t* h = (uint16_t*)hs;
   const int64_t xstep = B * NP * G, hstep = B * NP * F;
+  // one workgroup per CU: 256 / NCH sequence slots (rounded to the 8 XCDs), fewer when the batch is small
+  auto grid_for = [&](int64_t items) {
+    int64_t slots = cdiv(items, 8) * 8;
+    const int64_t max_slots = (256 / NCH) / 8 * 8 > 0 ? (256 / NCH) / 8 * 8 : 8;
+    if (slots > max_slots) slots = max_slots;
+    return (unsigned)(slots * NCH);
+  };
   GCRNN_PRE_LAUNCH();
-  if (mode == 2) {
-    kern<<<grid, STHREADS, lds, st>>>(x, (const uint16_t*)h0, nullptr, (const uint4*)wpack, bias, nullptr, nullptr, ga.tile_nodes,
-                                 ga.tile_off, ga.ell_col, ga.ell_val, (const float4*)ga.ell_val4, (const uint2*)ga.ell_col4,
-                                 gate_w, gate_out, nullptr, nullptr, 0, (int)ga.entries, (int)items, (int)B, (int)N);
+  if (mode == 2 || mode == 4) {
+    // no recurrence: all (t, b) items in one launch -- split over whole time steps where the 32-bit buffer offsets of
+    // one launch (items * NP * max(F, G) * 2 bytes) would overflow
+    const int64_t row_bytes = (int64_t)NP * (F > G ? F : G) * 2;
+    int64_t tchunk = (2147483647LL / row_bytes) / B;
+    if (tchunk < 1) return GCRNN_ERR_BAD_SHAPE;
+    if (tchunk > T) tchunk = T;
+    for (int64_t t0 = 0; t0 < T; t0 += tchunk) {
+      const int64_t nt = (T - t0 < tchunk) ? T - t0 : tchunk, items = nt * B;
+      float* go = gate_out + t0 * B * (NCH * SWAVES);
+      if (mode == 2)      // operands [h0 | x_t]; optional store of c_t = tanh(pre) into hs
+        kern<<<grid_for(items), STHREADS, lds, st>>>(x + t0 * xstep, (const uint16_t*)h0, h ? h + t0 * hstep : nullptr, (const uint4*)wpack, bias,
+                                     nullptr, nullptr, ga.tile_nodes, ga.tile_off, ga.ell_col, ga.ell_val, (const float4*)ga.ell_val4,
+                                     (const uint2*)ga.ell_col4, gate_w, go, nullptr, nullptr, 0, (int)ga.entries, (int)items, (int)B, (int)N);
+      else                // operand = one [T*B][NP][F] array (XS = 0), per-item dpre in bw_dHs
+        kern<<<grid_for(items), STHREADS, lds, st>>>(nullptr, (const uint16_t*)h0 + t0 * hstep, nullptr, (const uint4*)wpack, bias, nullptr, nullptr,
+                                     ga.tile_nodes, ga.tile_off, ga.ell_col, ga.ell_val, (const float4*)ga.ell_val4,
+                                     (const uint2*)ga.ell_col4, nullptr, go, (const uint16_t*)bw_dHs + t0 * hstep, nullptr, 0,
+                                     (int)ga.entries, (int)items, (int)items, (int)N);
+    }
   } else if (mode == 3) {
-    // BPTT: hs (= dpre, [T][B][NP][F]) already holds dpre_{T-1}; walk t = T-1 .. 1, then optionally d h0
+    // BPTT: hs (= dpre, [T][B][NP][F]) already holds dpre_{T-1}; walk t = T-1 .. 1, then optionally d h0.
+    // gf (time-gated cell, [T][B]): step t's recurrent gradient is scaled by its forget gate gf_t.
+    const unsigned grid = grid_for(B);
     const uint16_t* dH = (const uint16_t*)bw_dHs;
     const uint16_t* hst = (const uint16_t*)bw_hs;
     for (int64_t t = T - 1; t >= 1; --t) {
-      const uint16_t* hprev_state = (t - 1 >= 1 || true) ? hst + (t - 1) * hstep : nullptr;
-      kern<<<grid, STHREADS, lds, st>>>(nullptr, h + t * hstep, h + (t - 1) * hstep, (const uint4*)wpack, nullptr, nullptr, nullptr,
-                                   ga.tile_nodes, ga.tile_off, ga.ell_col, ga.ell_val, (const float4*)ga.ell_val4,
-                                   (const uint2*)ga.ell_col4, nullptr, nullptr, dH + (t - 1) * hstep, hprev_state, 0,
-                                   (int)ga.entries, (int)B, (int)B, (int)N);
+      kern<<<grid, STHREADS, lds, st>>>(nullptr, h + t * hstep, h + (t - 1) * hstep, (const uint4*)wpack, nullptr, nullptr,
+                                   gf ? gf + t * B : nullptr, ga.tile_nodes, ga.tile_off, ga.ell_col, ga.ell_val,
+                                   (const float4*)ga.ell_val4, (const uint2*)ga.ell_col4, nullptr, nullptr, dH + (t - 1) * hstep,
+                                   hst + (t - 1) * hstep, 0, (int)ga.entries, (int)B, (int)B, (int)N);
     }
     if (bw_dh0)
-      kern<<<grid, STHREADS, lds, st>>>(nullptr, h, (uint16_t*)bw_dh0, (const uint4*)wpack, nullptr, nullptr, nullptr, ga.tile_nodes,
+      kern<<<grid, STHREADS, lds, st>>>(nullptr, h, (uint16_t*)bw_dh0, (const uint4*)wpack, nullptr, nullptr, gf, ga.tile_nodes,
                                    ga.tile_off, ga.ell_col, ga.ell_val, (const float4*)ga.ell_val4, (const uint2*)ga.ell_col4,
                                    nullptr, nullptr, nullptr, nullptr, 0, (int)ga.entries, (int)B, (int)B, (int)N);
   } else {
+    const unsigned grid = grid_for(B);
     for (int64_t t = 0; t < T; ++t) {
       const uint16_t* hp = (t == 0) ? (const uint16_t*)h0 : h + (t - 1) * hstep;
       kern<<<grid, STHREADS, lds, st>>>(x + t * xstep, hp, h + t * hstep, (const uint4*)wpack, bias, mode == 1 ? gi + t * B : nullptr,
@@ -783,7 +831,7 @@ static int fused_dispatch(int mode, const void* xs, const void* h0, void* hs, co
   GCRNN_FUSED_CASE(5, 1, 1)
   GCRNN_FUSED_CASE(3, 1, 1)
   GCRNN_FUSED_CASE(2, 1, 1)
-  GCRNN_FUSED_CASE(5, 2, 0)      // BPTT data-gradient steps: the operand is dpre alone (no x part)
+  GCRNN_FUSED_CASE(5, 2, 0)      // BPTT data-gradient steps and gate-gradient passes: ONE operand array (dpre, x or h alone)
   GCRNN_FUSED_CASE(4, 2, 0)
   GCRNN_FUSED_CASE(3, 2, 0)
   GCRNN_FUSED_CASE(2, 2, 0)
@@ -810,14 +858,28 @@ extern "C" int gcrnn_fused_forward_bf16(const void* xs, const void* h0, void* hs
 }
 
 extern "C" int gcrnn_fused_gate_prepass_bf16(const void* xs, const void* h0, const void* wpack, const float* bias,
-                                             const float* gate_w, float* gate_out, const int32_t* tile_nodes,
+                                             const float* gate_w, float* gate_out, void* cs, const int32_t* tile_nodes,
                                              const int32_t* tile_off, const int32_t* ell_col, const float* ell_val,
                                              const void* ell_val4, const void* ell_col4, int64_t entries, int64_t B,
                                              int64_t T, int64_t N, int64_t F, int64_t G, int64_t K, void* stream) {
   if (!xs || !h0 || !wpack || !gate_w || !gate_out || !tile_nodes || !tile_off || !ell_col || !ell_val) return GCRNN_ERR_NULL_POINTER;
   if (B <= 0 || T <= 0 || N <= 0 || N > NP || B * T > (1 << 24) || entries < 0 || entries % 4) return GCRNN_ERR_BAD_SHAPE;
   const FusedGraphArgs ga{tile_nodes, tile_off, ell_col, ell_val, ell_val4, ell_col4, entries};
-  return fused_dispatch(2, xs, h0, nullptr, wpack, bias, nullptr, nullptr, gate_w, gate_out, ga, B, T, N, F, G, K, as_stream(stream));
+  return fused_dispatch(2, xs, h0, cs, wpack, bias, nullptr, nullptr, gate_w, gate_out, ga, B, T, N, F, G, K, as_stream(stream));
+}
+
+// d loss / d (scalar time gate) of one filter of the gated cell:  out[t*B+b][partials] summed = sum_{f,n} (W(S) z + b) . dpre
+// z: [T][B][NP][F] bf16 sequence-major operand of that filter (x_t for the input filter, h_{t-1} for the state filter;
+// F input features), wpack: its taps packed as a state-only operand (gcrnn_fused_pack_weights with G = 0), bias [F] or
+// null (added once), dpre: [T][B][NP][F] bf16. Reference: the gates multiply the two filter outputs, graphML.py:2420-2421.
+extern "C" int gcrnn_fused_gate_grad_bf16(const void* zs, const void* dpre, const void* wpack, const float* bias, float* out,
+                                          const int32_t* tile_nodes, const int32_t* tile_off, const int32_t* ell_col,
+                                          const float* ell_val, const void* ell_val4, const void* ell_col4, int64_t entries,
+                                          int64_t B, int64_t T, int64_t N, int64_t F, int64_t K, void* stream) {
+  if (!zs || !dpre || !wpack || !out || !tile_nodes || !tile_off || !ell_col || !ell_val) return GCRNN_ERR_NULL_POINTER;
+  if (B <= 0 || T <= 0 || N <= 0 || N > NP || B * T > (1 << 24) || entries < 0 || entries % 4) return GCRNN_ERR_BAD_SHAPE;
+  const FusedGraphArgs ga{tile_nodes, tile_off, ell_col, ell_val, ell_val4, ell_col4, entries};
+  return fused_dispatch(4, nullptr, zs, nullptr, wpack, bias, nullptr, nullptr, nullptr, out, ga, B, T, N, F, 0, K, as_stream(stream), dpre);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -842,9 +904,13 @@ __global__ __launch_bounds__(512, 2) void fused_wgrad_kernel(
     const uint16_t* __restrict__ Huser,      // [B][T][F][N] bf16 (forward output)
     const uint16_t* __restrict__ h0user,     // [B][F][N]   bf16
     float* __restrict__ dW,                  // [F][K][F+G] fp32, += (atomics)
-    float* __restrict__ dbsum,               // [F] fp32, += sum_{t,b,n} dpre (or null); the caller scales by 2 (bias enters both filters)
+    float* __restrict__ dbsum,               // [F] fp32, += the bias gradient: sum_{t,b} (gi + gf) sum_n dpre, 2 sum dpre without gates (or null)
     const int32_t* __restrict__ tile_nodes, const int32_t* __restrict__ tile_off,
-    const float4* __restrict__ ell_val4, const uint2* __restrict__ ell_col4, int entries, int B, int Tn, int N) {
+    const float4* __restrict__ ell_val4, const uint2* __restrict__ ell_col4,
+    const float* __restrict__ gi,            // [T][B] input-filter gates of the time-gated cell, or null
+    const float* __restrict__ gf,            // [T][B] state-filter gates, or null
+    int h_is_h0,                             // the state operand of EVERY item is h0 (gate sub-cells, graphML.py:2362, 2370)
+    int entries, int B, int Tn, int N) {
   constexpr int F = 32 * HS, G = 32 * XS, C = F + G, NCH = F / FC, JT = C / 16;
   static_assert(JT <= WAVES, "one input-feature tile per wave");
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -891,6 +957,11 @@ __global__ __launch_bounds__(512, 2) void fused_wgrad_kernel(
   const bool has_tile = wave < JT;
   const bool is_x = wave >= F / 16;                 // wave-uniform: tiles 0..F/16-1 are h features, the rest x features
   const int jrow = (is_x ? wave * 16 - F : wave * 16) + r;      // this lane's row (feature) inside its source block
+  // Time-gated cell: item (t, b) enters dW_A with weight gi_t[b] and dW_B with gf_t[b]. A wave owns features of ONE of the
+  // two filters, so its accumulators are kept in units of the current item's gate: accD_true = gprev * accD. Re-basing
+  // costs K*4 multiplies per item and no registers; items whose gate underflowed contribute nothing.
+  const float* gw_ = is_x ? gi : gf;
+  float gprev = 1.f;
   const __amdgpu_buffer_rsrc_t rsrc_d = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(dpre), 0, Tn * B * (NP * F * 2) > 0 ? Tn * B * (NP * F * 2) : 0x7fffffff, 0x00020000);
   __syncthreads();
 
@@ -903,8 +974,18 @@ __global__ __launch_bounds__(512, 2) void fused_wgrad_kernel(
     bf16x8 bfr[16];
     const uint16_t* zsrc;
     int zrows;
+    float gcur = gprev;
+    float gbias = 2.f;                                    // the one bias enters both filters
+    if (gw_) { gcur = gw_[t * B + b]; gbias = gi[t * B + b] + gf[t * B + b]; }
+    const bool live = has_tile && gcur > 1e-12f;          // wave-uniform
+    if (live && gcur != gprev) {
+      const float rb = gprev / gcur;
+#pragma unroll
+      for (int k = 0; k < K; ++k) accD[k] *= rb;
+      gprev = gcur;
+    }
     if (is_x) { zsrc = Xuser + ((int64_t)b * Tn + t) * G * N; zrows = G; }
-    else if (t > 0) { zsrc = Huser + ((int64_t)b * Tn + (t - 1)) * F * N; zrows = F; }
+    else if (t > 0 && !h_is_h0) { zsrc = Huser + ((int64_t)b * Tn + (t - 1)) * F * N; zrows = F; }
     else { zsrc = h0user + (int64_t)b * F * N; zrows = F; }
     const __amdgpu_buffer_rsrc_t rsrc_z = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(zsrc), 0, has_tile ? zrows * N * 2 : 0, 0x00020000);
     const int vo = (jrow * N + 8 * q) * 2;
@@ -931,7 +1012,7 @@ __global__ __launch_bounds__(512, 2) void fused_wgrad_kernel(
         float v = bacc[c];
 #pragma unroll
         for (int off = 1; off < 16; off <<= 1) v += __shfl_xor(v, off, 64);     // over the 16 slots r of this quad
-        if (r == 0) atomicAdd(lbias + q * 4 + c, v);
+        if (r == 0) atomicAdd(lbias + q * 4 + c, v * gbias);
       }
     }
 #pragma unroll
@@ -951,7 +1032,7 @@ __global__ __launch_bounds__(512, 2) void fused_wgrad_kernel(
       }
       __syncthreads();
       // S2: D_k += du_k^T z over nodes 0..511
-      if (has_tile) {
+      if (live) {
 #pragma unroll
         for (int s4 = 0; s4 < 16; s4 += 4) {            // 4 A fragments in flight per batch: LDS latency overlaps the MFMAs
           bf16x8 a4[4];
@@ -1002,7 +1083,7 @@ __global__ __launch_bounds__(512, 2) void fused_wgrad_kernel(
 #undef GCRNN_WG_STORE
 #endif
       }
-      if (has_tile) {
+      if (live) {
 #pragma unroll
         for (int h2 = 0; h2 < 2; ++h2) {
           bf16x8 bl[8];
@@ -1026,7 +1107,7 @@ __global__ __launch_bounds__(512, 2) void fused_wgrad_kernel(
     for (int k = 0; k < K; ++k)
 #pragma unroll
       for (int c = 0; c < 4; ++c)
-        atomicAdd(dW + ((int64_t)(chunk * FC + q * 4 + c) * K + k) * C + wave * 16 + r, accD[k][c]);
+        atomicAdd(dW + ((int64_t)(chunk * FC + q * 4 + c) * K + k) * C + wave * 16 + r, accD[k][c] * gprev);
   }
   __syncthreads();
   if (dbsum && tid < FC) atomicAdd(dbsum + chunk * FC + tid, lbias[tid]);
@@ -1034,7 +1115,8 @@ __global__ __launch_bounds__(512, 2) void fused_wgrad_kernel(
 
 template <int K, int HS, int XS>
 static int fused_wgrad_t(const void* dpre, const void* Xuser, const void* Huser, const void* h0user, float* dW, float* dbsum,
-                         const FusedGraphArgs& ga, int64_t B, int64_t T, int64_t N, hipStream_t st) {
+                         const FusedGraphArgs& ga, const float* gi, const float* gf, int h_is_h0, int64_t B, int64_t T, int64_t N,
+                         hipStream_t st) {
   constexpr int F = 32 * HS;
   const size_t lds = (size_t)NP * FC * 4 + (size_t)ga.entries * 96 + TBYTES + 64;
   if (lds > 160 * 1024 || !ga.ell_val4 || !ga.ell_col4) return GCRNN_ERR_UNSUPPORTED;
@@ -1048,8 +1130,8 @@ static int fused_wgrad_t(const void* dpre, const void* Xuser, const void* Huser,
   GCRNN_PRE_LAUNCH();
   kern<<<(unsigned)(slots * NCH), 512, lds, st>>>((const uint16_t*)dpre, (const uint16_t*)Xuser, (const uint16_t*)Huser,
                                                    (const uint16_t*)h0user, dW, dbsum, ga.tile_nodes, ga.tile_off,
-                                                   (const float4*)ga.ell_val4, (const uint2*)ga.ell_col4, (int)ga.entries,
-                                                   (int)B, (int)T, (int)N);
+                                                   (const float4*)ga.ell_val4, (const uint2*)ga.ell_col4, gi, gf, h_is_h0,
+                                                   (int)ga.entries, (int)B, (int)T, (int)N);
   GCRNN_CHECK_LAUNCH();
   return GCRNN_OK;
 }
@@ -1057,14 +1139,16 @@ static int fused_wgrad_t(const void* dpre, const void* Xuser, const void* Huser,
 extern "C" int gcrnn_fused_backward_weight_bf16(const void* dpre, const void* Xuser, const void* Huser, const void* h0user,
                                                 float* dW, float* dbsum, const int32_t* tile_nodes, const int32_t* tile_off,
                                                 const void* ell_val4, const void* ell_col4, int64_t entries, int64_t B,
-                                                int64_t T, int64_t N, int64_t F, int64_t G, int64_t K, void* stream) {
-  if (!dpre || !Xuser || !Huser || !h0user || !dW || !tile_nodes || !tile_off || !ell_val4 || !ell_col4) return GCRNN_ERR_NULL_POINTER;
+                                                int64_t T, int64_t N, int64_t F, int64_t G, int64_t K, const float* gi,
+                                                const float* gf, int h_is_h0, void* stream) {
+  if ((gi == nullptr) != (gf == nullptr)) return GCRNN_ERR_NULL_POINTER;
+  if (!dpre || !Xuser || (!Huser && !h_is_h0) || !h0user || !dW || !tile_nodes || !tile_off || !ell_val4 || !ell_col4) return GCRNN_ERR_NULL_POINTER;
   if (B <= 0 || T <= 0 || N <= 0 || N > NP || N % 8 || entries < 0 || entries % 4 || B * T > (1 << 24)) return GCRNN_ERR_BAD_SHAPE;
   if (T * B * (NP * F * 2) > 2147483647LL) return GCRNN_ERR_BAD_SHAPE;      // 32-bit buffer offsets into dpre
   const FusedGraphArgs ga{tile_nodes, tile_off, nullptr, nullptr, ell_val4, ell_col4, entries};
   hipStream_t st = as_stream(stream);
 #define GCRNN_WG_CASE(KK, HH, XX) \
-  if (K == KK && F == 32 * HH && G == 32 * XX) return fused_wgrad_t<KK, HH, XX>(dpre, Xuser, Huser, h0user, dW, dbsum, ga, B, T, N, st);
+  if (K == KK && F == 32 * HH && G == 32 * XX) return fused_wgrad_t<KK, HH, XX>(dpre, Xuser, Huser, h0user, dW, dbsum, ga, gi, gf, h_is_h0, B, T, N, st);
   GCRNN_WG_CASE(5, 2, 2)
   GCRNN_WG_CASE(4, 2, 2)
   GCRNN_WG_CASE(3, 2, 2)
@@ -1090,7 +1174,7 @@ extern "C" int gcrnn_fused_backward_data_bf16(const void* dHs, const void* hs, v
                                               const int32_t* tile_nodes, const int32_t* tile_off, const int32_t* ell_col,
                                               const float* ell_val, const void* ell_val4, const void* ell_col4,
                                               int64_t entries, int64_t B, int64_t T, int64_t N, int64_t F, int64_t K,
-                                              void* stream) {
+                                              const float* gf, void* stream) {
   if (!dHs || !hs || !dpre || !wpackT || !tile_nodes || !tile_off || !ell_col || !ell_val) return GCRNN_ERR_NULL_POINTER;
   if (B <= 0 || T <= 0 || N <= 0 || N > NP || B > (1 << 24) || entries < 0 || entries % 4) return GCRNN_ERR_BAD_SHAPE;
   const int64_t step = B * NP * F;
@@ -1099,8 +1183,55 @@ extern "C" int gcrnn_fused_backward_data_bf16(const void* dHs, const void* hs, v
       (const uint16_t*)dHs + (T - 1) * step, (const uint16_t*)hs + (T - 1) * step, (uint16_t*)dpre + (T - 1) * step, step);
   GCRNN_CHECK_LAUNCH();
   const FusedGraphArgs ga{tile_nodes, tile_off, ell_col, ell_val, ell_val4, ell_col4, entries};
-  return fused_dispatch(3, nullptr, nullptr, dpre, wpackT, nullptr, nullptr, nullptr, nullptr, nullptr, ga, B, T, N, F, 0, K,
+  return fused_dispatch(3, nullptr, nullptr, dpre, wpackT, nullptr, nullptr, gf, nullptr, nullptr, ga, B, T, N, F, 0, K,
                         as_stream(stream), dHs, hs, dh0);
+}
+
+// ------------------------------------------------------------------------------------------
+// BPTT through a time gate's read-out (graphML.py:2364-2366): gate = sigmoid(w . vec(c) + c0), c = tanh(pre_g) stored by the
+// gate pre-pass. One pass over c [items][NPad][F] (bf16, in place):
+//     dpre_g[item][n][f] = dlogit[item] * w[n][f] * (1 - c^2)          (overwrites c; feeds the weight-gradient kernel)
+//     dw[n][f]          += dlogit[item] * c[item][n][f]                (per item-slab partial sums, plain stores)
+// A thread owns one pair of adjacent (n, f) columns and walks its slab's items; consecutive threads touch consecutive 4-byte
+// words, so every wave reads and writes whole 256-byte lines.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gate_readout_bwd_kernel(uint16_t* __restrict__ cs, const float* __restrict__ dlogit,
+                                                               const float* __restrict__ gate_w, float* __restrict__ dw_part,
+                                                               int items, int cols /* NPad*F */, int valid /* N*F */, int per_slab) {
+  const int col = (blockIdx.x * 256 + threadIdx.x) * 2;
+  if (col >= cols) return;
+  const int it0 = blockIdx.y * per_slab, it1 = min(items, it0 + per_slab);
+  float w0 = 0.f, w1 = 0.f;
+  if (col < valid) { w0 = gate_w[col]; w1 = gate_w[col + 1]; }      // rows >= N: c is zero there and stays zero
+  float a0 = 0.f, a1 = 0.f;
+  uint32_t* p = reinterpret_cast<uint32_t*>(cs + (int64_t)it0 * cols + col);
+  const int64_t stride = cols / 2;
+#pragma unroll 4
+  for (int it = it0; it < it1; ++it, p += stride) {
+    const uint32_t v = *p;
+    const float c0 = bf2f((uint16_t)(v & 0xffffu)), c1 = bf2f((uint16_t)(v >> 16));
+    const float dl = dlogit[it];
+    a0 += dl * c0;
+    a1 += dl * c1;
+    *p = (uint32_t)f2bf(dl * w0 * (1.f - c0 * c0)) | ((uint32_t)f2bf(dl * w1 * (1.f - c1 * c1)) << 16);
+  }
+  *reinterpret_cast<float2*>(dw_part + (int64_t)blockIdx.y * cols + col) = float2{a0, a1};
+}
+
+extern "C" int64_t gcrnn_fused_gate_readout_slabs(int64_t items) { return items < 64 ? 1 : (items < 1024 ? 8 : 32); }
+
+extern "C" int gcrnn_fused_gate_readout_backward_bf16(void* cs, const float* dlogit, const float* gate_w, float* dw_part,
+                                                      int64_t items, int64_t N, int64_t F, void* stream) {
+  if (!cs || !dlogit || !gate_w || !dw_part) return GCRNN_ERR_NULL_POINTER;
+  if (items <= 0 || items > (1 << 24) || N <= 0 || N > NP || F <= 0 || F % 2) return GCRNN_ERR_BAD_SHAPE;
+  const int64_t slabs = gcrnn_fused_gate_readout_slabs(items);
+  const int cols = (int)(NP * F);
+  GCRNN_PRE_LAUNCH();
+  dim3 grid((unsigned)cdiv(cols / 2, 256), (unsigned)slabs);
+  gate_readout_bwd_kernel<<<grid, 256, 0, as_stream(stream)>>>((uint16_t*)cs, dlogit, gate_w, dw_part, (int)items, cols,
+                                                              (int)(N * F), (int)cdiv(items, slabs));
+  GCRNN_CHECK_LAUNCH();
+  return GCRNN_OK;
 }
 
 extern "C" int gcrnn_fused_supported(int64_t N, int64_t F, int64_t G, int64_t K) {

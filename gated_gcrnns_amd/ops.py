@@ -255,95 +255,155 @@ def _fused_pack_weights(wA, wB, st):
     return wpack
 
 
-def fused_cell_forward(X, h0, wA, wB, bias, graph, gates=None, return_states=False):
+def _fused_graph_args(plan):
+    return (_p(plan['tile_slots']), _p(plan['tile_off']), _p(plan['ell_addr']), _p(plan['ell_val']),
+            _p(plan['ell_val4']), _p(plan['ell_col4']), plan['entries'])
+
+
+def fused_pack_inputs(X, h0, graph):
+    """user-layout bf16 X [B][T][G][N], h0 [B][F][N] -> sequence-major xs [T][B][NPad][G] and the state buffer
+    hs_all [T+1][B][NPad][F] whose slot 0 holds h0 (slots 1..T receive h_1..h_T: hs_all[:T] is then the h_{t-1} operand of
+    every step, which the gate-gradient pass reads as one array)."""
+    B, T, G, N = X.shape
+    F = h0.shape[1]
+    npad = graph.fused_plan()['npad']
+    st = _stream()
+    Xc, h0c = X.contiguous(), h0.contiguous()
+    xs = torch.empty((T, B, npad, G), dtype=torch.bfloat16, device=X.device)
+    hs_all = torch.empty((T + 1, B, npad, F), dtype=torch.bfloat16, device=X.device)
+    check(lib.gcrnn_pack_seq_major(_lib.BF16, _p(Xc), _p(xs), B, T, G, N, npad, None, st), 'pack_seq')
+    check(lib.gcrnn_pack_seq_major(_lib.BF16, _p(h0c), _p(hs_all), B, 1, F, N, npad, None, st), 'pack_seq')
+    return xs, hs_all
+
+
+def fused_time_gate(xs, h0s, wA_g, wB_g, bias_g, lin_w, lin_b, graph, N, store_states=False):
+    """One time gate of the fused path for all (t, b) (graphML.py:2357-2374): sigmoid(Linear(vec(tanh(A_g(S)x_t + B_g(S)h0
+    + 2 b_g)))) as ONE pre-pass launch. xs [T][B][NPad][G], h0s [1][B][NPad][F] sequence-major bf16. Returns the gate
+    [T][B] fp32 (and, with store_states, the gate cell's states c [T][B][NPad][F] bf16 for its BPTT)."""
+    T, B, npad, G = xs.shape
+    F = wA_g.shape[0]
+    K = max(wA_g.shape[2], wB_g.shape[2])
+    plan = graph.fused_plan()
+    st = _stream()
+    wp = _fused_pack_weights(wA_g.detach(), wB_g.detach(), st)
+    bg = bias_g.detach().float().contiguous().view(-1) if bias_g is not None else None
+    gw = lin_w.detach().float().view(F, N).t().contiguous()                  # row-major vec over (f, n) -> [N][F]
+    parts = torch.empty((T * B, (F // 16) * int(lib.gcrnn_fused_step_waves())), dtype=torch.float32, device=xs.device)
+    cs = torch.empty((T, B, npad, F), dtype=torch.bfloat16, device=xs.device) if store_states else None
+    check(lib.gcrnn_fused_gate_prepass_bf16(_p(xs), _p(h0s), _p(wp), _p(bg), _p(gw), _p(parts), _p(cs),
+                                            *_fused_graph_args(plan), B, T, N, F, G, K, st), 'gate_prepass')
+    acc = parts.sum(dim=1)                                                    # fixed order: deterministic gates
+    if lin_b is not None:
+        acc = acc + lin_b.detach().float()
+    gate = torch.sigmoid(acc).view(T, B).contiguous()
+    return (gate, cs, gw) if store_states else gate
+
+
+def fused_cell_forward(X, h0, wA, wB, bias, graph, gates=None, return_states=False, gate_values=None, packed=None):
     """Whole GGCRNNCell forward (un-gated or time-gated) on the fused bf16 step kernel.
 
     X: B x T x G x N bf16, h0: B x F x N bf16 (user layout) -> H: B x T x F x N bf16.
     gates: None, or {'in': (wA_g, wB_g, bias_g, lin_weight [1, F*N], lin_bias), 'forget': (...)} -- the time-gate
     sub-networks GFL_* / MLP_* of the reference (graphML.py:2248-2278); each gate costs one pre-pass launch over all
-    (t, b). Inference only (no autograd graph is recorded).
+    (t, b). gate_values: the two gates themselves, (gi, gf) [T][B] fp32, instead of their sub-networks. packed: the result
+    of fused_pack_inputs (shared with the gates by the training path). No autograd graph is recorded here.
+    return_states: also returns the state buffer hs_all [T+1][B][NPad][F] (slot 0 = h0) and the plan.
     """
     require_device(X, h0, wA, wB, bias)
     B, T, G, N = X.shape
     F = wA.shape[0]
     K = max(wA.shape[2], wB.shape[2])
     plan = graph.fused_plan()
-    npad = plan['npad']
     st = _stream()
     dev = X.device
     X = X.contiguous()
     h0 = h0.contiguous()
-    xs = torch.empty((T, B, npad, G), dtype=torch.bfloat16, device=dev)
-    h0s = torch.empty((1, B, npad, F), dtype=torch.bfloat16, device=dev)
-    hs = torch.empty((T, B, npad, F), dtype=torch.bfloat16, device=dev)
-    check(lib.gcrnn_pack_seq_major(_lib.BF16, _p(X), _p(xs), B, T, G, N, npad, None, st), 'pack_seq')
-    check(lib.gcrnn_pack_seq_major(_lib.BF16, _p(h0), _p(h0s), B, 1, F, N, npad, None, st), 'pack_seq')
-    gargs = (_p(plan['tile_slots']), _p(plan['tile_off']), _p(plan['ell_addr']), _p(plan['ell_val']),
-             _p(plan['ell_val4']), _p(plan['ell_col4']), plan['entries'])
+    xs, hs_all = packed if packed is not None else fused_pack_inputs(X, h0, graph)
+    h0s, hs = hs_all[:1], hs_all[1:]
     gi = gf = None
-    if gates is not None:
+    if gate_values is not None:
+        gi, gf = (g.detach().float().contiguous() for g in gate_values)
+        assert tuple(gi.shape) == (T, B) and tuple(gf.shape) == (T, B)
+    elif gates is not None:
         g = {}
         for name in ('in', 'forget'):
             wA_g, wB_g, bias_g, lin_w, lin_b = gates[name]
             assert max(wA_g.shape[2], wB_g.shape[2]) == K and wA_g.shape[0] == F
-            wp = _fused_pack_weights(wA_g, wB_g, st)
-            bg = bias_g.detach().float().contiguous().view(-1) if bias_g is not None else None
-            gw = lin_w.detach().float().view(F, N).t().contiguous()          # row-major vec over (f, n) -> [N][F]
-            parts = torch.empty((T * B, (F // 16) * int(lib.gcrnn_fused_step_waves())), dtype=torch.float32, device=dev)
-            check(lib.gcrnn_fused_gate_prepass_bf16(_p(xs), _p(h0s), _p(wp), _p(bg), _p(gw), _p(parts), *gargs,
-                                                    B, T, N, F, G, K, st), 'gate_prepass')
-            acc = parts.sum(dim=1)                                            # fixed order: deterministic gates
-            if lin_b is not None:
-                acc = acc + lin_b.detach().float()
-            g[name] = torch.sigmoid(acc).contiguous()                        # [T][B] fp32
+            g[name] = fused_time_gate(xs, h0s, wA_g, wB_g, bias_g, lin_w, lin_b, graph, N)
         gi, gf = g['in'], g['forget']
     wpack = _fused_pack_weights(wA, wB, st)
     b32 = bias.detach().float().contiguous().view(-1) if bias is not None else None
     H = torch.empty((B, T, F, N), dtype=torch.bfloat16, device=dev)
     direct = (N % 8 == 0)                 # the step kernels write the user layout themselves (16-byte row stores)
-    check(lib.gcrnn_fused_forward_bf16(_p(xs), _p(h0s), _p(hs), _p(wpack), _p(b32), _p(gi), _p(gf), *gargs,
+    check(lib.gcrnn_fused_forward_bf16(_p(xs), _p(h0s), _p(hs), _p(wpack), _p(b32), _p(gi), _p(gf), *_fused_graph_args(plan),
                                        B, T, N, F, G, K, _p(H) if direct else None, st), 'fused_forward')
     if not direct:
-        check(lib.gcrnn_unpack_seq_major(_lib.BF16, _p(hs), _p(H), B, T, F, N, npad, None, st), 'unpack_seq')
+        check(lib.gcrnn_unpack_seq_major(_lib.BF16, _p(hs), _p(H), B, T, F, N, plan['npad'], None, st), 'unpack_seq')
     if return_states:
-        return hs, plan, H
+        return hs_all, plan, H
     return H
 
 
-def fused_backward_data(dHs, hs, wB, graph, want_dh0=True):
-    """BPTT data-gradient chain of the un-gated fused cell. dHs, hs: [T][B][NPad][F] bf16 sequence-major (gradient of
-    the loss w.r.t. every state; the states). Returns (dpre [T][B][NPad][F] bf16, dh0 [B][NPad][F] bf16 or None)."""
+def _fused_pack_state_taps(w, K, st):
+    """Taps of ONE filter, w [F_out][1][k][C_in] (C_in == F_out on the fused path), packed as a state-only operand (G = 0)
+    with K taps (zero beyond k)."""
+    F, _, k, Cin = w.shape
+    assert Cin == F
+    wc = w.detach().contiguous()
+    wpack = torch.empty(((F // 16) * K * (F // 32) * 64 * 8,), dtype=torch.bfloat16, device=w.device)
+    check(lib.gcrnn_fused_pack_weights(dtype_code(wc.dtype), _p(wc), _p(wc), _p(wpack), F, 0, K, k, st), 'pack_weights')
+    return wpack
+
+
+def fused_backward_data(dHs, hs, wB, graph, want_dh0=True, gf=None):
+    """BPTT data-gradient chain of the fused cell. dHs, hs: [T][B][NPad][F] bf16 sequence-major (gradient of the loss
+    w.r.t. every state; the states). gf: [T][B] fp32 forget gates of the time-gated cell or None.
+    Returns (dpre [T][B][NPad][F] bf16, dh0 [B][NPad][F] bf16 or None)."""
     T, B, npad, F = hs.shape
     K = wB.shape[2]
     plan = graph.fused_plan(adjoint=True)
     st = _stream()
     wBt = wB.detach()[:, 0].permute(2, 1, 0).contiguous().unsqueeze(1)      # [F_in][1][K][F_out]: transposed taps
-    F_, G0 = F, 0
-    wpack = torch.empty(((F // 16) * K * (F // 32) * 64 * 8,), dtype=torch.bfloat16, device=hs.device)
-    check(lib.gcrnn_fused_pack_weights(dtype_code(wBt.dtype), _p(wBt), _p(wBt), _p(wpack), F_, G0, K, K, st), 'pack_weights')
-    dpre = torch.empty_like(hs)
+    wpack = _fused_pack_state_taps(wBt, K, st)
+    dpre = torch.empty((T, B, npad, F), dtype=torch.bfloat16, device=hs.device)
     dh0 = torch.empty((B, npad, F), dtype=torch.bfloat16, device=hs.device) if want_dh0 else None
-    check(lib.gcrnn_fused_backward_data_bf16(_p(dHs), _p(hs), _p(dpre), _p(dh0), _p(wpack), _p(plan['tile_slots']),
-                                             _p(plan['tile_off']), _p(plan['ell_addr']), _p(plan['ell_val']),
-                                             _p(plan['ell_val4']), _p(plan['ell_col4']), plan['entries'],
-                                             B, T, graph.N, F, K, st), 'fused_backward_data')
+    check(lib.gcrnn_fused_backward_data_bf16(_p(dHs), _p(hs), _p(dpre), _p(dh0), _p(wpack), *_fused_graph_args(plan),
+                                             B, T, graph.N, F, K, _p(gf), st), 'fused_backward_data')
     return dpre, dh0
 
 
-def fused_backward_weight(dpre, X, H, h0, graph, F, G, K, want_bias=False):
+def fused_backward_weight(dpre, X, H, h0, graph, F, G, K, want_bias=False, gi=None, gf=None, h_is_h0=False):
     """dW [F][K][F+G] fp32 (columns: F state features, then G input features) from dpre (sequence-major bf16) and the
-    user-layout bf16 tensors X [B][T][G][N], H [B][T][F][N] (forward output), h0 [B][F][N].
-    With want_bias also returns sum_{t,b,n} dpre [F] (the bias gradient is twice that)."""
+    user-layout bf16 tensors X [B][T][G][N], H [B][T][F][N] (forward output), h0 [B][F][N]. gi / gf [T][B] fp32: item
+    (t, b) enters the input-filter columns with weight gi and the state-filter columns with gf (time-gated cell).
+    h_is_h0: every item's state operand is h0 (gate sub-cells; H may be None).
+    With want_bias also returns the bias gradient [F]: sum_{t,b} (gi + gf) sum_n dpre (the one bias enters both filters)."""
     T, B = dpre.shape[0], dpre.shape[1]
     plan = graph.fused_plan(adjoint=True, kernel='wgrad')
     dW = torch.zeros((F, K, F + G), dtype=torch.float32, device=dpre.device)
     dbs = torch.zeros(F, dtype=torch.float32, device=dpre.device) if want_bias else None
-    Xc, Hc, h0c = X.contiguous(), H.contiguous(), h0.contiguous()
+    Xc, h0c = X.contiguous(), h0.contiguous()
+    Hc = H.contiguous() if H is not None else None
     check(lib.gcrnn_fused_backward_weight_bf16(_p(dpre), _p(Xc), _p(Hc), _p(h0c), _p(dW),
                                                _p(dbs), _p(plan['tile_slots']), _p(plan['tile_off']), _p(plan['ell_val4']),
-                                               _p(plan['ell_col4']), plan['entries'], B, T, graph.N, F, G, K, _stream()),
+                                               _p(plan['ell_col4']), plan['entries'], B, T, graph.N, F, G, K,
+                                               _p(gi), _p(gf), int(h_is_h0), _stream()),
           'fused_backward_weight')
     return (dW, dbs) if want_bias else dW
+
+
+def fused_gate_grad(zs, dpre, w, bias, graph, K):
+    """d loss / d gate [T][B] fp32 of one filter of the time-gated cell: sum_{f,n} (w(S) z + bias) . dpre per item.
+    zs, dpre: [T][B][NPad][F] bf16 sequence-major; w: that filter's taps F x 1 x k x F; bias F x 1 or None."""
+    T, B, npad, F = dpre.shape
+    plan = graph.fused_plan()
+    st = _stream()
+    wp = _fused_pack_state_taps(w, K, st)
+    b32 = bias.detach().float().contiguous().view(-1) if bias is not None else None
+    parts = torch.empty((T * B, (F // 16) * int(lib.gcrnn_fused_step_waves())), dtype=torch.float32, device=dpre.device)
+    check(lib.gcrnn_fused_gate_grad_bf16(_p(zs), _p(dpre), _p(wp), _p(b32), _p(parts), *_fused_graph_args(plan),
+                                         B, T, graph.N, F, K, st), 'fused_gate_grad')
+    return parts.sum(dim=1).view(T, B)
 
 
 def fused_training_supported(graph, N, F, G, Kin, Kst, E=1):
@@ -355,24 +415,72 @@ def fused_training_supported(graph, N, F, G, Kin, Kst, E=1):
     return 65536 + 96 * entries + 16 * 1056 + 64 <= 160 * 1024
 
 
-class _FusedCell(torch.autograd.Function):
-    """Un-gated GGCRNNCell on the fused kernels, forward and BPTT (bf16 activations, fp32 or bf16 parameters).
+class _FusedTimeGate(torch.autograd.Function):
+    """One time gate of the fused path with its BPTT (reference graphML.py:2357-2374): gate[t][b] = sigmoid(lin(vec(c_t))),
+    c_t = tanh(A_g(S) x_t + B_g(S) h0 + 2 b_g).
 
-    backward = pack(dH) -> data-gradient chain (T launches of the step kernel on the adjoint graph with transposed taps)
-    -> ONE weight-gradient launch over all T*B items -> bias gradient 2 * sum(dpre). The gradient w.r.t. X is not
-    produced (the training loops never ask for it, train_rnn.py:247-276)."""
+    forward  = ONE pre-pass launch over all (t, b) that also stores c (bf16);
+    backward = one in-place pass over c (read-out gradient + dpre_g = dlogit w (1 - c^2)), then the weight-gradient kernel
+               over all items with h0 as every item's state operand. No gradient for X or h0 (the training loops start
+               from h0 = 0 and never ask for either, train_rnn.py:247-276)."""
 
     @staticmethod
-    def forward(ctx, X, h0, wA, wB, bias, graph):
-        hs, plan, H = fused_cell_forward(X, h0, wA, wB, bias, graph, return_states=True)
-        ctx.save_for_backward(X, h0, wA, wB, bias, H, hs)
+    def forward(ctx, xs, h0s, X, h0, wA_g, wB_g, bias_g, lin_w, lin_b, graph):
+        N = X.shape[3]
+        gate, cs, gw = fused_time_gate(xs, h0s, wA_g, wB_g, bias_g, lin_w, lin_b, graph, N, store_states=True)
+        ctx.save_for_backward(X, h0, wA_g, wB_g, bias_g, lin_w, lin_b, gate, cs, gw)
+        ctx.graph = graph
+        return gate
+
+    @staticmethod
+    def backward(ctx, dgate):
+        X, h0, wA_g, wB_g, bias_g, lin_w, lin_b, gate, cs, gw = ctx.saved_tensors
+        if ctx.needs_input_grad[2] or ctx.needs_input_grad[3]:
+            raise GcrnnError('the fused time gate does not produce gradients w.r.t. X or h0')
+        B, T, G, N = X.shape
+        F, Kin, Kst = wA_g.shape[0], wA_g.shape[2], wB_g.shape[2]
+        K = max(Kin, Kst)
+        T_, B_, npad, _ = cs.shape
+        items = T * B
+        dlogit = (dgate.float() * gate * (1.0 - gate)).contiguous().view(-1)          # through the sigmoid
+        slabs = int(lib.gcrnn_fused_gate_readout_slabs(items))
+        dw_part = torch.empty((slabs, npad * F), dtype=torch.float32, device=X.device)
+        # cs becomes dpre_g in place: a second backward through the same graph is not supported (retain_graph)
+        check(lib.gcrnn_fused_gate_readout_backward_bf16(_p(cs), _p(dlogit), _p(gw), _p(dw_part), items, N, F, _stream()),
+              'gate_readout_backward')
+        dW, dbs = fused_backward_weight(cs, X, None, h0, ctx.graph, F, G, K, want_bias=True, h_is_h0=True)
+        gA = dW[:, :Kin, F:].unsqueeze(1).to(wA_g.dtype) if ctx.needs_input_grad[4] else None
+        gB = dW[:, :Kst, :F].unsqueeze(1).to(wB_g.dtype) if ctx.needs_input_grad[5] else None
+        gb = dbs.view_as(bias_g).to(bias_g.dtype) if (bias_g is not None and ctx.needs_input_grad[6]) else None
+        glw = None
+        if ctx.needs_input_grad[7]:
+            glw = dw_part.sum(dim=0).view(npad, F)[:N].t().reshape(1, F * N).to(lin_w.dtype)     # [N][F] -> vec over (f, n)
+        glb = dlogit.sum().view(1).to(lin_b.dtype) if (lin_b is not None and ctx.needs_input_grad[8]) else None
+        return None, None, None, None, gA, gB, gb, glw, glb, None
+
+
+class _FusedCell(torch.autograd.Function):
+    """GGCRNNCell (un-gated, or time-gated with the gates as differentiable inputs) on the fused kernels, forward and BPTT
+    (bf16 activations, fp32 or bf16 parameters).
+
+    backward = pack(dH) -> data-gradient chain (T launches of the step kernel on the adjoint graph with transposed taps,
+    the recurrent part scaled by the forget gate) -> ONE weight-gradient launch over all T*B items (item weights gi / gf)
+    -> with gates: two gate-gradient passes  d gi = <A(S)x_t + b, dpre_t>,  d gf = <B(S)h_{t-1} + b, dpre_t>.
+    The gradient w.r.t. X is not produced (the training loops never ask for it, train_rnn.py:247-276)."""
+
+    @staticmethod
+    def forward(ctx, X, h0, wA, wB, bias, gi, gf, graph, xs, hs_all):
+        gv = (gi, gf) if gi is not None else None
+        hs_all, plan, H = fused_cell_forward(X, h0, wA, wB, bias, graph, return_states=True, gate_values=gv,
+                                             packed=(xs, hs_all) if xs is not None else None)
+        ctx.save_for_backward(X, h0, wA, wB, bias, H, hs_all, gi, gf, xs)
         ctx.graph = graph
         ctx.npad = plan['npad']
         return H
 
     @staticmethod
     def backward(ctx, dH):
-        X, h0, wA, wB, bias, H, hs = ctx.saved_tensors
+        X, h0, wA, wB, bias, H, hs_all, gi, gf, xs = ctx.saved_tensors
         graph, npad = ctx.graph, ctx.npad
         B, T, G, N = X.shape
         F, Kin, Kst = wA.shape[0], wA.shape[2], wB.shape[2]
@@ -380,27 +488,53 @@ class _FusedCell(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             raise GcrnnError('the fused BPTT does not produce the gradient w.r.t. the input sequence X')
         st = _stream()
+        hs = hs_all[1:]
+        gated = gi is not None
+        if gated:
+            gi, gf = gi.detach().float().contiguous(), gf.detach().float().contiguous()
         dH = dH.to(torch.bfloat16).contiguous()
         dHs = torch.empty((T, B, npad, F), dtype=torch.bfloat16, device=X.device)
         check(lib.gcrnn_pack_seq_major(_lib.BF16, _p(dH), _p(dHs), B, T, F, N, npad, None, st), 'pack_seq')
         wBk = wB if Kst == K else torch.cat([wB, wB.new_zeros(F, 1, K - Kst, F)], dim=2)
-        dpre, dh0s = fused_backward_data(dHs, hs, wBk, graph, want_dh0=ctx.needs_input_grad[1])
+        dpre, dh0s = fused_backward_data(dHs, hs, wBk, graph, want_dh0=ctx.needs_input_grad[1], gf=gf if gated else None)
         want_b = bias is not None and ctx.needs_input_grad[4]
-        dW, dbs = fused_backward_weight(dpre, X, H, h0, graph, F, G, K, want_bias=True)       # [F][K][F+G], [F] fp32
+        dW, dbs = fused_backward_weight(dpre, X, H, h0, graph, F, G, K, want_bias=True,
+                                        gi=gi if gated else None, gf=gf if gated else None)       # [F][K][F+G], [F] fp32
         gA = dW[:, :Kin, F:].unsqueeze(1).to(wA.dtype) if ctx.needs_input_grad[2] else None
         gB = dW[:, :Kst, :F].unsqueeze(1).to(wB.dtype) if ctx.needs_input_grad[3] else None
-        gb = (2.0 * dbs).view_as(bias).to(bias.dtype) if want_b else None            # the bias enters both filters
+        gb = dbs.view_as(bias).to(bias.dtype) if want_b else None
+        dgi = dgf = None
+        if gated and ctx.needs_input_grad[5]:
+            xsq = xs if xs is not None else fused_pack_inputs(X, h0, graph)[0]
+            dgi = fused_gate_grad(xsq, dpre, wA, bias, graph, K)
+        if gated and ctx.needs_input_grad[6]:
+            dgf = fused_gate_grad(hs_all[:T], dpre, wB, bias, graph, K)
         gh0 = None
         if ctx.needs_input_grad[1]:
             gh0 = torch.empty((B, 1, F, N), dtype=torch.bfloat16, device=X.device)
             check(lib.gcrnn_unpack_seq_major(_lib.BF16, _p(dh0s), _p(gh0), B, 1, F, N, npad, None, st), 'unpack_seq')
             gh0 = gh0.view(B, F, N).to(h0.dtype)
-        return None, gh0, gA, gB, gb, None
+        return None, gh0, gA, gB, gb, dgi, dgf, None, None, None
 
 
-def fused_cell_train(X, h0, wA, wB, bias, graph):
+def fused_cell_train(X, h0, wA, wB, bias, graph, gates=None):
+    """Training forward of the fused cell. gates: None, or the time-gate sub-networks {'in': (wA_g, wB_g, bias_g, lin_w,
+    lin_b), 'forget': (...)} (graphML.py:2248-2278): both gates are evaluated (and back-propagated) on the fused kernels and
+    enter the cell as differentiable [T][B] inputs."""
     require_device(X, h0, wA, wB, bias)
-    return _FusedCell.apply(X, h0, wA, wB, bias, graph)
+    if gates is None:
+        return _FusedCell.apply(X, h0, wA, wB, bias, None, None, graph, None, None)
+    with torch.no_grad():
+        xs, hs_all = fused_pack_inputs(X, h0, graph)
+    gi = _FusedTimeGate.apply(xs, hs_all[:1], X, h0, *gates['in'], graph)
+    gf = _FusedTimeGate.apply(xs, hs_all[:1], X, h0, *gates['forget'], graph)
+    return _FusedCell.apply(X, h0, wA, wB, bias, gi, gf, graph, xs, hs_all)
+
+
+def fused_cell_train_with_gates(X, h0, wA, wB, bias, graph, gi, gf):
+    """Training forward of the time-gated fused cell with the gates [T][B] computed elsewhere (any autograd graph)."""
+    require_device(X, h0, wA, wB, bias, gi, gf)
+    return _FusedCell.apply(X, h0, wA, wB, bias, gi, gf, graph, None, None)
 
 
 # ------------------------------------------------------------------------------------------ small-graph persistent path

@@ -161,34 +161,59 @@ int gcrnn_fused_forward_bf16(const void* xs, const void* h0, void* hs, const voi
  *    gate deterministic, which float atomics would not)
  * with the gate sub-cell's packed weights (gcrnn_fused_pack_weights of GFL_in / GFL_forget) and gate_w = the gate's
  * Linear(N*F -> 1) weight re-laid node-major [N][F] (fp32). All T*B items run in ONE launch because the reference's gates
- * read h0, never h_{t-1} (graphML.py:2362, 2370). The caller applies sigmoid(sum + c). */
+ * read h0, never h_{t-1} (graphML.py:2362, 2370). The caller applies sigmoid(sum + c).
+ * cs (or NULL): [T][B][NPad][F] bf16, receives the gate cell's state c_t = tanh(.) for the gate's BPTT (padded rows zero).
+ * Launches are split over whole time steps where T*B*NPad*F*2 bytes exceed the 32-bit buffer offsets. */
 int gcrnn_fused_gate_prepass_bf16(const void* xs, const void* h0, const void* wpack, const float* bias,
-                                  const float* gate_w, float* gate_out, const int32_t* tile_nodes,
+                                  const float* gate_w, float* gate_out, void* cs, const int32_t* tile_nodes,
                                   const int32_t* tile_off, const int32_t* ell_col, const float* ell_val,
                                   const void* ell_val4, const void* ell_col4, int64_t entries, int64_t B, int64_t T,
                                   int64_t N, int64_t F, int64_t G, int64_t K, void* stream);
 
-/* BPTT data gradient of the un-gated fused cell (adjoint of graphML.py:2420-2423), bf16 sequence-major arrays [T][B][NPad][F]:
+/* d loss / d (scalar time gate) of ONE filter of the time-gated cell (the gates multiply the filter outputs, graphML.py:2420-2421):
+ *   sum over out[t][b][0 .. F/16*8) = sum_{f,n} ( W(S) z[t][b] + bias )[n][f] * dpre[t][b][n][f]
+ * z: [T][B][NPad][F] bf16 sequence-major operand of that filter (x_t for the input filter -- G = F on this path --, h_{t-1} for
+ * the state filter), wpack = gcrnn_fused_pack_weights of its taps as a state-only operand (G = 0), bias [F] or NULL (added once),
+ * dpre = output of gcrnn_fused_backward_data_bf16. All T*B items in one launch (split like the gate pre-pass). */
+int gcrnn_fused_gate_grad_bf16(const void* zs, const void* dpre, const void* wpack, const float* bias, float* out,
+                               const int32_t* tile_nodes, const int32_t* tile_off, const int32_t* ell_col, const float* ell_val,
+                               const void* ell_val4, const void* ell_col4, int64_t entries, int64_t B, int64_t T, int64_t N,
+                               int64_t F, int64_t K, void* stream);
+
+/* BPTT through a time gate's read-out gate = sigmoid(w . vec(c) + c0) (graphML.py:2364-2366), one pass, in place:
+ *   cs [items][NPad][F] bf16: on entry the gate cell's states c (gcrnn_fused_gate_prepass_bf16), on return
+ *   dpre_g = dlogit[item] * w[n][f] * (1 - c^2) (the operand of gcrnn_fused_backward_weight_bf16 with h_is_h0);
+ *   dw_part [gcrnn_fused_gate_readout_slabs(items)][NPad*F] fp32: per-slab partial sums of dlogit[item] * c (plain stores;
+ *   the caller adds the slabs in a fixed order); gate_w [N][F] fp32 node-major read-out weights; dlogit [items] fp32. */
+int64_t gcrnn_fused_gate_readout_slabs(int64_t items);
+int gcrnn_fused_gate_readout_backward_bf16(void* cs, const float* dlogit, const float* gate_w, float* dw_part, int64_t items,
+                                           int64_t N, int64_t F, void* stream);
+
+/* BPTT data gradient of the fused cell (adjoint of graphML.py:2420-2423), bf16 sequence-major arrays [T][B][NPad][F]:
  *   dpre[T-1] = dHs[T-1] * (1 - hs[T-1]^2);   for t = T-1 .. 1:
- *   dpre[t-1] = ( sum_k (S)^k (dpre[t] B_k) + dHs[t-1] ) * (1 - hs[t-1]^2);        dh0 = sum_k (S)^k (dpre[0] B_k)  (optional)
+ *   dpre[t-1] = ( gf[t] sum_k (S)^k (dpre[t] B_k) + dHs[t-1] ) * (1 - hs[t-1]^2);   dh0 = gf[0] sum_k (S)^k (dpre[0] B_k)  (optional)
+ * gf: [T][B] fp32 forget gates of the time-gated cell, or NULL (= 1).
  * dHs = gradient of the loss w.r.t. every state, hs = the states of the forward. wpackT = gcrnn_fused_pack_weights of the
  * TRANSPOSED state taps (wB^T [F_in][Kst][F_out] passed as "wB", G = 0); the graph arrays are the ELL of CSR(S) (the adjoint
  * shift). One launch per step; same kernel as the forward with a different epilogue. */
 int gcrnn_fused_backward_data_bf16(const void* dHs, const void* hs, void* dpre, void* dh0, const void* wpackT,
                                    const int32_t* tile_nodes, const int32_t* tile_off, const int32_t* ell_col,
                                    const float* ell_val, const void* ell_val4, const void* ell_col4, int64_t entries,
-                                   int64_t B, int64_t T, int64_t N, int64_t F, int64_t K, void* stream);
+                                   int64_t B, int64_t T, int64_t N, int64_t F, int64_t K, const float* gf, void* stream);
 
-/* BPTT weight gradient of the un-gated fused cell (adjoint of the taps, graphML.py:134-135), all T*B items in ONE launch:
- *   dW[f'][k][j] += sum_{t,b,n} (S^k dpre[t][b])[n][f'] * z[t][b][n][j],   z = [h_{t-1} | x_t],   j < F: weight_B, j >= F: weight_A
+/* BPTT weight gradient of the fused cell (adjoint of the taps, graphML.py:134-135), all T*B items in ONE launch:
+ *   dW[f'][k][j] += sum_{t,b,n} g[t][b] (S^k dpre[t][b])[n][f'] * z[t][b][n][j],   z = [h_{t-1} | x_t],   j < F: weight_B (g = gf),
+ *   j >= F: weight_A (g = gi); gi / gf: [T][B] fp32 time gates or both NULL (= 1). h_is_h0 != 0: the state operand of every
+ *   item is h0 (the gate sub-cells, graphML.py:2362, 2370; Huser may then be NULL).
  * dpre: output of gcrnn_fused_backward_data_bf16; Xuser [B][T][G][N], Huser [B][T][F][N] (the forward's output) and
  * h0user [B][F][N] are the bf16 USER-layout tensors (node-contiguous rows feed the matrix cores directly; needs N % 8 == 0);
  * dW fp32 [F][K][F+G], accumulated with atomics (caller zeroes); graph arrays = LDS image of the ELL of CSR(S).
  * Returns GCRNN_ERR_UNSUPPORTED when the graph image does not fit in LDS next to the state. */
 int gcrnn_fused_backward_weight_bf16(const void* dpre, const void* Xuser, const void* Huser, const void* h0user, float* dW,
-                                     float* dbsum /* [F] += sum dpre, or NULL; bias gradient = 2 * dbsum */, const int32_t* tile_nodes, const int32_t* tile_off, const void* ell_val4,
+                                     float* dbsum /* [F] += bias gradient sum_{t,b} (gi + gf) sum_n dpre (2 sum dpre without gates), or NULL */,
+                                     const int32_t* tile_nodes, const int32_t* tile_off, const void* ell_val4,
                                      const void* ell_col4, int64_t entries, int64_t B, int64_t T, int64_t N, int64_t F,
-                                     int64_t G, int64_t K, void* stream);
+                                     int64_t G, int64_t K, const float* gi, const float* gf, int h_is_h0, void* stream);
 
 /* ==== small-graph regime: the whole T-step recurrence of a sequence inside one workgroup, one launch ============
  * Replaces GGCRNNCell.forward (graphML.py:2336-2427, un-gated or time-gated with precomputed gates) when

@@ -192,7 +192,8 @@ def test_fused_backward_data_chain(N, F, K, B, T):
     with torch.no_grad():
         Xd = torch.tensor(X, dtype=torch.bfloat16, device=dev)
         hd = torch.tensor(h0, dtype=torch.bfloat16, device=dev)
-        hs, plan, _Hu = ops.fused_cell_forward(Xd, hd, cell.weight_A, cell.weight_B, cell.bias, cell.graph, return_states=True)
+        hs_all, plan, _Hu = ops.fused_cell_forward(Xd, hd, cell.weight_A, cell.weight_B, cell.bias, cell.graph, return_states=True)
+        hs = hs_all[1:]                                              # slot 0 holds h0
         npad = plan['npad']
         dHd = torch.tensor(dH, dtype=torch.bfloat16, device=dev)
         dHs = torch.empty((T, B, npad, F), dtype=torch.bfloat16, device=dev)
@@ -209,7 +210,7 @@ def test_fused_backward_data_chain(N, F, K, B, T):
         H = torch.empty((B, T, F, N), dtype=torch.bfloat16, device=dev)
         _lib.check(_lib.lib.gcrnn_unpack_seq_major(_lib.BF16, ops._p(hs), ops._p(H), B, T, F, N, npad, None, ops._stream()), 'unpack')
         dW, dbs = ops.fused_backward_weight(dpre, Xd, H, hd, cell.graph, F, G, K, want_bias=True)
-        dW, db = dW.cpu().numpy(), 2.0 * dbs.cpu().numpy()
+        dW, db = dW.cpu().numpy(), dbs.cpu().numpy()              # the kernel returns the bias gradient itself (2 sum dpre)
         assert np.allclose(db, 2.0 * dpre.float().sum(dim=(0, 1, 2)).cpu().numpy(), rtol=1e-3, atol=1e-3 * np.abs(db).max())
     ref_cell = _bwd_reference(S, params, X, h0, dH)[0]
     gB = ref_cell.weight_B.grad[:, 0].cpu().numpy()          # [F][K][F]
@@ -290,3 +291,129 @@ def test_bf16_streaming_path_for_graphs_beyond_the_fused_kernel(N, F, K, B, T):
     ref = orc.ggcrnn_cell(params, S, X, h0)
     err = np.abs(H - ref)
     assert err.max() <= 5e-2 and err.mean() <= 4e-3, (err.max(), err.mean())
+
+
+def _gated_pair(N, F, K, S, seed, dev, master=torch.float32):
+    """A time-gated cell with bf16-representable parameters and its fp32 composed-path twin."""
+    import gated_gcrnns_amd.Utils.graphML as gml
+    torch.manual_seed(seed)
+    cell = gml.GGCRNNCell(F, F, K, K, torch.tanh, True, None, 1, True)
+    cell.addGSO(torch.tensor(S))
+    cell = cell.to(torch.bfloat16).to(torch.float32)
+    ref = gml.GGCRNNCell(F, F, K, K, torch.tanh, True, None, 1, True)
+    ref.addGSO(torch.tensor(S))
+    ref.load_state_dict(cell.state_dict())
+    return cell.to(dev).to(master), ref.to(dev)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('N,F,K,B,T,master', [(1000, 64, 5, 6, 5, torch.float32), (200, 32, 3, 9, 4, torch.float32),
+                                              (600, 64, 3, 4, 3, torch.bfloat16), (1000, 64, 2, 3, 3, torch.float32)])
+def test_fused_time_gated_training_matches_composed_autograd(N, F, K, B, T, master):
+    """Time-gated cell, bf16 activations: forward, both gate sub-networks and the whole BPTT run on the fused kernels
+    (ops.fused_cell_train) and reproduce the fp32 autograd gradients of the composed path for EVERY trained parameter --
+    the cell's taps and bias, the gate cells' taps and biases, the gates' read-out layers (reference graphML.py:2357-2374,
+    2420-2423). h0 != 0: the gates read (x_t, h0)."""
+    dev = torch.device('cuda:0')
+    S = random_graph(N, min(0.5, 10.0 / N), 43)
+    rng = np.random.default_rng(9)
+    X = bf16_round(rng.standard_normal((B, T, F, N)))
+    h0 = bf16_round(0.4 * rng.standard_normal((B, F, N)))
+    dH = bf16_round(rng.standard_normal((B, T, F, N)))
+    cell, ref = _gated_pair(N, F, K, S, 17, dev, master)
+    # make the gates informative: the reference init gives logits of O(10) magnitude spread, fine; nothing to rescale
+    Hr = ref(torch.tensor(X, dtype=torch.float32, device=dev), torch.tensor(h0, dtype=torch.float32, device=dev))
+    dHd = torch.tensor(dH, dtype=torch.float32, device=dev)
+    (Hr * dHd).sum().backward()
+    Xd = torch.tensor(X, dtype=torch.bfloat16, device=dev)
+    hd = torch.tensor(h0, dtype=torch.bfloat16, device=dev)
+    assert cell._use_fused_training(Xd, hd)
+    H = cell(Xd, hd)
+    assert H.dtype == torch.bfloat16 and H.requires_grad
+    err = (H.detach().float() - Hr.detach()).abs()
+    assert float(err.max()) <= 4e-2 and float(err.mean()) <= 3e-3, (float(err.max()), float(err.mean()))
+    (H.float() * dHd).sum().backward()
+    names = [n for n, p in ref.named_parameters() if p.grad is not None]
+    assert any(n.startswith('GFL_in.') for n in names) and any(n.startswith('MLP_forget.') for n in names)
+    got = dict(cell.named_parameters())
+    for n, p in ref.named_parameters():
+        if p.grad is None:                       # GFL_out / MLP_out: built, never used (graphML.py:2280-2290)
+            assert got[n].grad is None, n
+            continue
+        g, gr = got[n].grad.float().cpu().numpy(), p.grad.cpu().numpy()
+        assert g.shape == gr.shape, n
+        sc = np.abs(gr).max()
+        e = np.abs(g - gr)
+        assert sc > 0 and e.max() <= 4e-2 * sc and e.mean() <= 8e-3 * sc, (n, e.max() / sc, e.mean() / sc)
+
+
+@pytest.mark.gpu
+def test_fused_gated_cell_gate_gradients_match_composed_gates():
+    """The cell alone with the gates as differentiable inputs (ops.fused_cell_train_with_gates): d loss / d gi, d gf of the
+    fused BPTT against autograd through the composed fp32 path fed the same gate values."""
+    import gated_gcrnns_amd.Utils.graphML as gml
+    from gated_gcrnns_amd import ops
+    dev = torch.device('cuda:0')
+    N, F, K, B, T = 1000, 64, 4, 5, 4
+    S = random_graph(N, 0.01, 47)
+    rng = np.random.default_rng(13)
+    X = bf16_round(rng.standard_normal((B, T, F, N)))
+    h0 = bf16_round(0.4 * rng.standard_normal((B, F, N)))
+    dH = torch.tensor(bf16_round(rng.standard_normal((B, T, F, N))), dtype=torch.float32, device=dev)
+    gi0 = torch.tensor(rng.uniform(0.1, 0.9, (T, B)), dtype=torch.float32, device=dev)
+    gf0 = torch.tensor(rng.uniform(0.1, 0.9, (T, B)), dtype=torch.float32, device=dev)
+    torch.manual_seed(19)
+    cell = gml.GGCRNNCell(F, F, K, K, torch.tanh, False, None, 1, True)
+    cell.addGSO(torch.tensor(S))
+    cell = cell.to(torch.bfloat16).to(torch.float32).to(dev)
+    # composed fp32 reference with explicit scalar gates: h_t = tanh(gi (A x_t + b) + gf (B h_{t-1} + b))
+    gi_r, gf_r = gi0.clone().requires_grad_(True), gf0.clone().requires_grad_(True)
+    Xn = ops.pack_node_major(torch.tensor(X, dtype=torch.float32, device=dev))
+    h = ops.pack_node_major(torch.tensor(h0, dtype=torch.float32, device=dev).reshape(B, 1, F, N))
+    ya = ops.lsigf_node_major(Xn, cell.weight_A, cell.bias, cell.graph, 1.0)
+    Hs = []
+    for t in range(T):
+        yb = ops.lsigf_node_major(h, cell.weight_B, cell.bias, cell.graph, 1.0)
+        h = torch.tanh(gi_r[t].view(1, 1, B, 1) * ya[t:t + 1] + gf_r[t].view(1, 1, B, 1) * yb)
+        Hs.append(h)
+    Hr = ops.unpack_node_major(torch.cat(Hs, dim=0))
+    (Hr * dH).sum().backward()
+    ref_grads = {n: p.grad.clone() for n, p in cell.named_parameters()}
+    cell.zero_grad()
+    gi_f, gf_f = gi0.clone().requires_grad_(True), gf0.clone().requires_grad_(True)
+    H = ops.fused_cell_train_with_gates(torch.tensor(X, dtype=torch.bfloat16, device=dev), torch.tensor(h0, dtype=torch.bfloat16, device=dev),
+                                        cell.weight_A, cell.weight_B, cell.bias, cell.graph, gi_f, gf_f)
+    (H.float() * dH).sum().backward()
+    for name, g, gr in (('gi', gi_f.grad, gi_r.grad), ('gf', gf_f.grad, gf_r.grad)):
+        sc = float(gr.abs().max())
+        e = (g - gr).abs()
+        assert float(e.max()) <= 3e-2 * sc, (name, float(e.max()) / sc)
+    for n, p in cell.named_parameters():
+        sc = float(ref_grads[n].abs().max())
+        e = (p.grad - ref_grads[n]).abs()
+        assert float(e.max()) <= 3e-2 * sc, (n, float(e.max()) / sc)
+
+
+@pytest.mark.gpu
+def test_fused_gate_prepass_splits_launches_beyond_32bit_offsets():
+    """T*B*NPad*F*2 bytes > 2 GiB: the all-items gate pre-pass is split over whole time steps; gates equal those of
+    single-step calls."""
+    import gated_gcrnns_amd.Utils.graphML as gml
+    from gated_gcrnns_amd import ops
+    dev = torch.device('cuda:0')
+    N, F, K, B, T = 1000, 64, 2, 520, 32                      # 16640 items x 128 KiB per item row block
+    S = random_graph(N, 0.01, 53)
+    torch.manual_seed(23)
+    cell = gml.GGCRNNCell(F, F, K, K, torch.tanh, True, None, 1, True)
+    cell.addGSO(torch.tensor(S))
+    cell = cell.to(dev).to(torch.bfloat16)
+    X = torch.randn(B, T, F, N, device=dev).to(torch.bfloat16)
+    h0 = (0.3 * torch.randn(B, F, N, device=dev)).to(torch.bfloat16)
+    g = cell._fused_gates()['in']
+    with torch.no_grad():
+        xs, hs_all = ops.fused_pack_inputs(X, h0, cell.graph)
+        full = ops.fused_time_gate(xs, hs_all[:1], *g, cell.graph, N)
+        for t in (0, 30, 31):
+            one = ops.fused_time_gate(xs[t:t + 1], hs_all[:1], *g, cell.graph, N)
+            assert torch.equal(one[0], full[t]), t
+    assert float(full.std()) > 1e-3
