@@ -444,7 +444,7 @@ __global__ __launch_bounds__(STHREADS) void fused_step_kernel(
   const __amdgpu_buffer_rsrc_t rsrc_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(xt), 0, B * (NP * G * 2), 0x00020000);
   const __amdgpu_buffer_rsrc_t rsrc_o = __builtin_amdgcn_make_buffer_rsrc(hout, 0, hout ? B * (NP * F * 2) : 0, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsrc_a0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(aux0), 0, ((EPI == 2 || EPI == 3) && aux0) ? B * (NP * F * 2) : 0, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsrc_a1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(aux1), 0, (EPI == 2 && aux0) ? B * (NP * F * 2) : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_a1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(aux1), 0, (EPI == 2 && aux1) ? B * (NP * F * 2) : 0, 0x00020000);
 
   for (int b = b0; b < B; b += seq_slots) {
   const int soff_h = (b % hmod) * (NP * F * 2);     // hmod < B: every item of the gate pre-pass reads h0[b]
@@ -646,24 +646,32 @@ __global__ __launch_bounds__(STHREADS) void fused_step_kernel(
     // With aux0 == null the raw state gradient is stored (d h0). Time-gated cell: the recurrent part carries the forget
     // gate of the step it came through, gf_t[b] (the adjoint chain is linear, so the scale is applied here).
     const float gsc = gf ? gf[b] : 1.f;
+    // With gate_out the launch also emits <h_{t-1}, sum_k (S)^k (dpre_t B_k)> = <B(S) h_{t-1}, dpre_t> (adjoint identity): the
+    // bias-free part of d loss / d gf_t -- the forget gate's gradient without a pass of its own.
+    float part = 0.f;
 #pragma unroll
     for (int i = 0; i < STILES; ++i) {
       int wv = woff[i];
       asm volatile("" : "+v"(wv));
       const int node = wv >> 16;
       const int eoff = node * (F * 2) + (chunk * FC + q * 4) * 2;
-      f32x4 o = u[i][0] * gsc;
+      const f32x4 raw = u[i][0];
+      f32x4 o = raw * gsc;
+      float hv0 = 0.f, hv1 = 0.f, hv2 = 0.f, hv3 = 0.f;
+      if (aux1) {
+        const u32x2 h2 = __builtin_amdgcn_raw_buffer_load_b64(rsrc_a1, eoff, b * (NP * F * 2), 0);
+        hv0 = bf2f((uint16_t)(h2[0] & 0xffffu)); hv1 = bf2f((uint16_t)(h2[0] >> 16));
+        hv2 = bf2f((uint16_t)(h2[1] & 0xffffu)); hv3 = bf2f((uint16_t)(h2[1] >> 16));
+      }
+      if (gate_out) part += raw[0] * hv0 + raw[1] * hv1 + raw[2] * hv2 + raw[3] * hv3;     // rows >= N of h are zero
       if (aux0) {
         const u32x2 g2 = __builtin_amdgcn_raw_buffer_load_b64(rsrc_a0, eoff, b * (NP * F * 2), 0);
-        const u32x2 h2 = __builtin_amdgcn_raw_buffer_load_b64(rsrc_a1, eoff, b * (NP * F * 2), 0);
         const float g0 = bf2f((uint16_t)(g2[0] & 0xffffu)), g1 = bf2f((uint16_t)(g2[0] >> 16));
         const float g2f = bf2f((uint16_t)(g2[1] & 0xffffu)), g3 = bf2f((uint16_t)(g2[1] >> 16));
-        const float h0f = bf2f((uint16_t)(h2[0] & 0xffffu)), h1 = bf2f((uint16_t)(h2[0] >> 16));
-        const float h2f = bf2f((uint16_t)(h2[1] & 0xffffu)), h3 = bf2f((uint16_t)(h2[1] >> 16));
-        o[0] = (o[0] + g0) * (1.f - h0f * h0f);
-        o[1] = (o[1] + g1) * (1.f - h1 * h1);
-        o[2] = (o[2] + g2f) * (1.f - h2f * h2f);
-        o[3] = (o[3] + g3) * (1.f - h3 * h3);
+        o[0] = (o[0] + g0) * (1.f - hv0 * hv0);
+        o[1] = (o[1] + g1) * (1.f - hv1 * hv1);
+        o[2] = (o[2] + g2f) * (1.f - hv2 * hv2);
+        o[3] = (o[3] + g3) * (1.f - hv3 * hv3);
       }
       uint2 pk;
       if (node < N) {
@@ -672,7 +680,12 @@ __global__ __launch_bounds__(STHREADS) void fused_step_kernel(
       } else {
         pk.x = 0u; pk.y = 0u;
       }
-      __builtin_amdgcn_raw_buffer_store_b64(u32x2{pk.x, pk.y}, rsrc_o, eoff, b * (NP * F * 2), 0);
+      __builtin_amdgcn_raw_buffer_store_b64(u32x2{pk.x, pk.y}, rsrc_o, eoff, b * (NP * F * 2), 0);     // dropped when hout is null
+    }
+    if (gate_out) {
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) part += __shfl_down(part, off, 64);
+      if (lane == 0) gate_out[(int64_t)b * (NCH * SWAVES) + chunk * SWAVES + wave] = part;   // fixed-order sum by the caller
     }
   } else {
 #pragma unroll
@@ -790,16 +803,18 @@ static int fused_launch_t(int mode /*0 plain, 1 gated, 2 gate pre-pass, 3 BPTT d
     const unsigned grid = grid_for(B);
     const uint16_t* dH = (const uint16_t*)bw_dHs;
     const uint16_t* hst = (const uint16_t*)bw_hs;
+    const int64_t gstep = B * (NCH * SWAVES);             // gate_out (or null): [T][B][NCH*SWAVES] partials of <h_{t-1}, adjoint chain of dpre_t>
     for (int64_t t = T - 1; t >= 1; --t) {
       kern<<<grid, STHREADS, lds, st>>>(nullptr, h + t * hstep, h + (t - 1) * hstep, (const uint4*)wpack, nullptr, nullptr,
                                    gf ? gf + t * B : nullptr, ga.tile_nodes, ga.tile_off, ga.ell_col, ga.ell_val,
-                                   (const float4*)ga.ell_val4, (const uint2*)ga.ell_col4, nullptr, nullptr, dH + (t - 1) * hstep,
-                                   hst + (t - 1) * hstep, 0, (int)ga.entries, (int)B, (int)B, (int)N);
+                                   (const float4*)ga.ell_val4, (const uint2*)ga.ell_col4, nullptr, gate_out ? gate_out + t * gstep : nullptr,
+                                   dH + (t - 1) * hstep, hst + (t - 1) * hstep, 0, (int)ga.entries, (int)B, (int)B, (int)N);
     }
-    if (bw_dh0)
+    if (bw_dh0 || gate_out)
       kern<<<grid, STHREADS, lds, st>>>(nullptr, h, (uint16_t*)bw_dh0, (const uint4*)wpack, nullptr, nullptr, gf, ga.tile_nodes,
                                    ga.tile_off, ga.ell_col, ga.ell_val, (const float4*)ga.ell_val4, (const uint2*)ga.ell_col4,
-                                   nullptr, nullptr, nullptr, nullptr, 0, (int)ga.entries, (int)B, (int)B, (int)N);
+                                   nullptr, gate_out, nullptr, gate_out ? (const uint16_t*)bw_h0 : nullptr, 0, (int)ga.entries,
+                                   (int)B, (int)B, (int)N);
   } else {
     const unsigned grid = grid_for(B);
     for (int64_t t = 0; t < T; ++t) {
@@ -819,11 +834,11 @@ static int fused_dispatch(int mode, const void* xs, const void* h0, void* hs, co
                           const float* gi, const float* gf, const float* gate_w, float* gate_out, const FusedGraphArgs& ga,
                           int64_t B, int64_t T, int64_t N, int64_t F, int64_t G, int64_t K, hipStream_t st,
                           const void* bw_dHs = nullptr, const void* bw_hs = nullptr, void* bw_dh0 = nullptr,
-                          void* huser = nullptr) {
+                          void* huser = nullptr, const void* bw_h0 = nullptr) {
 #define GCRNN_FUSED_CASE(KK, HH, XX) \
   if (K == KK && F == 32 * HH && G == 32 * XX) \
     return fused_launch_t<KK, HH, XX>(mode, xs, h0, hs, wpack, bias, gi, gf, gate_w, gate_out, ga, B, T, N, st, bw_dHs, \
-                                      bw_hs, nullptr, bw_dh0, huser);
+                                      bw_hs, bw_h0, bw_dh0, huser);
   GCRNN_FUSED_CASE(5, 2, 2)
   GCRNN_FUSED_CASE(4, 2, 2)
   GCRNN_FUSED_CASE(3, 2, 2)
@@ -1174,7 +1189,8 @@ extern "C" int gcrnn_fused_backward_data_bf16(const void* dHs, const void* hs, v
                                               const int32_t* tile_nodes, const int32_t* tile_off, const int32_t* ell_col,
                                               const float* ell_val, const void* ell_val4, const void* ell_col4,
                                               int64_t entries, int64_t B, int64_t T, int64_t N, int64_t F, int64_t K,
-                                              const float* gf, void* stream) {
+                                              const float* gf, const void* h0s, float* dgf_parts, void* stream) {
+  if (dgf_parts && !h0s) return GCRNN_ERR_NULL_POINTER;
   if (!dHs || !hs || !dpre || !wpackT || !tile_nodes || !tile_off || !ell_col || !ell_val) return GCRNN_ERR_NULL_POINTER;
   if (B <= 0 || T <= 0 || N <= 0 || N > NP || B > (1 << 24) || entries < 0 || entries % 4) return GCRNN_ERR_BAD_SHAPE;
   const int64_t step = B * NP * F;
@@ -1183,8 +1199,8 @@ extern "C" int gcrnn_fused_backward_data_bf16(const void* dHs, const void* hs, v
       (const uint16_t*)dHs + (T - 1) * step, (const uint16_t*)hs + (T - 1) * step, (uint16_t*)dpre + (T - 1) * step, step);
   GCRNN_CHECK_LAUNCH();
   const FusedGraphArgs ga{tile_nodes, tile_off, ell_col, ell_val, ell_val4, ell_col4, entries};
-  return fused_dispatch(3, nullptr, nullptr, dpre, wpackT, nullptr, nullptr, gf, nullptr, nullptr, ga, B, T, N, F, 0, K,
-                        as_stream(stream), dHs, hs, dh0);
+  return fused_dispatch(3, nullptr, nullptr, dpre, wpackT, nullptr, nullptr, gf, nullptr, dgf_parts, ga, B, T, N, F, 0, K,
+                        as_stream(stream), dHs, hs, dh0, nullptr, h0s);
 }
 
 // ------------------------------------------------------------------------------------------

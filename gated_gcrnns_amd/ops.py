@@ -355,10 +355,12 @@ def _fused_pack_state_taps(w, K, st):
     return wpack
 
 
-def fused_backward_data(dHs, hs, wB, graph, want_dh0=True, gf=None):
+def fused_backward_data(dHs, hs, wB, graph, want_dh0=True, gf=None, h0s=None, bias=None):
     """BPTT data-gradient chain of the fused cell. dHs, hs: [T][B][NPad][F] bf16 sequence-major (gradient of the loss
     w.r.t. every state; the states). gf: [T][B] fp32 forget gates of the time-gated cell or None.
-    Returns (dpre [T][B][NPad][F] bf16, dh0 [B][NPad][F] bf16 or None)."""
+    Returns (dpre [T][B][NPad][F] bf16, dh0 [B][NPad][F] bf16 or None), and with h0s ([1][B][NPad][F], the initial state)
+    also d loss / d gf [T][B] fp32 = <B(S) h_{t-1} + bias, dpre_t>: its filter part is <h_{t-1}, adjoint chain of dpre_t>,
+    read off the chain these launches evaluate anyway; the bias part is a column sum of dpre."""
     T, B, npad, F = hs.shape
     K = wB.shape[2]
     plan = graph.fused_plan(adjoint=True)
@@ -367,9 +369,17 @@ def fused_backward_data(dHs, hs, wB, graph, want_dh0=True, gf=None):
     wpack = _fused_pack_state_taps(wBt, K, st)
     dpre = torch.empty((T, B, npad, F), dtype=torch.bfloat16, device=hs.device)
     dh0 = torch.empty((B, npad, F), dtype=torch.bfloat16, device=hs.device) if want_dh0 else None
+    parts = None
+    if h0s is not None:
+        parts = torch.empty((T * B, (F // 16) * int(lib.gcrnn_fused_step_waves())), dtype=torch.float32, device=hs.device)
     check(lib.gcrnn_fused_backward_data_bf16(_p(dHs), _p(hs), _p(dpre), _p(dh0), _p(wpack), *_fused_graph_args(plan),
-                                             B, T, graph.N, F, K, _p(gf), st), 'fused_backward_data')
-    return dpre, dh0
+                                             B, T, graph.N, F, K, _p(gf), _p(h0s), _p(parts), st), 'fused_backward_data')
+    if h0s is None:
+        return dpre, dh0
+    dgf = parts.sum(dim=1).view(T, B)
+    if bias is not None:
+        dgf = dgf + dpre.sum(dim=2, dtype=torch.float32) @ bias.detach().float().view(-1)
+    return dpre, dh0, dgf
 
 
 def fused_backward_weight(dpre, X, H, h0, graph, F, G, K, want_bias=False, gi=None, gf=None, h_is_h0=False):
@@ -465,7 +475,8 @@ class _FusedCell(torch.autograd.Function):
 
     backward = pack(dH) -> data-gradient chain (T launches of the step kernel on the adjoint graph with transposed taps,
     the recurrent part scaled by the forget gate) -> ONE weight-gradient launch over all T*B items (item weights gi / gf)
-    -> with gates: two gate-gradient passes  d gi = <A(S)x_t + b, dpre_t>,  d gf = <B(S)h_{t-1} + b, dpre_t>.
+    -> with gates:  d gf = <B(S)h_{t-1} + b, dpre_t> = <h_{t-1}, adjoint chain of dpre_t> + b . colsum(dpre_t) falls out of
+    the data-gradient launches (adjoint identity); d gi = <A(S)x_t + b, dpre_t> is one gate-gradient pass over all items.
     The gradient w.r.t. X is not produced (the training loops never ask for it, train_rnn.py:247-276)."""
 
     @staticmethod
@@ -496,19 +507,22 @@ class _FusedCell(torch.autograd.Function):
         dHs = torch.empty((T, B, npad, F), dtype=torch.bfloat16, device=X.device)
         check(lib.gcrnn_pack_seq_major(_lib.BF16, _p(dH), _p(dHs), B, T, F, N, npad, None, st), 'pack_seq')
         wBk = wB if Kst == K else torch.cat([wB, wB.new_zeros(F, 1, K - Kst, F)], dim=2)
-        dpre, dh0s = fused_backward_data(dHs, hs, wBk, graph, want_dh0=ctx.needs_input_grad[1], gf=gf if gated else None)
+        dgf = None
+        if gated and ctx.needs_input_grad[6]:
+            dpre, dh0s, dgf = fused_backward_data(dHs, hs, wBk, graph, want_dh0=ctx.needs_input_grad[1], gf=gf,
+                                                  h0s=hs_all[:1], bias=bias)
+        else:
+            dpre, dh0s = fused_backward_data(dHs, hs, wBk, graph, want_dh0=ctx.needs_input_grad[1], gf=gf if gated else None)
         want_b = bias is not None and ctx.needs_input_grad[4]
         dW, dbs = fused_backward_weight(dpre, X, H, h0, graph, F, G, K, want_bias=True,
                                         gi=gi if gated else None, gf=gf if gated else None)       # [F][K][F+G], [F] fp32
         gA = dW[:, :Kin, F:].unsqueeze(1).to(wA.dtype) if ctx.needs_input_grad[2] else None
         gB = dW[:, :Kst, :F].unsqueeze(1).to(wB.dtype) if ctx.needs_input_grad[3] else None
         gb = dbs.view_as(bias).to(bias.dtype) if want_b else None
-        dgi = dgf = None
+        dgi = None
         if gated and ctx.needs_input_grad[5]:
             xsq = xs if xs is not None else fused_pack_inputs(X, h0, graph)[0]
             dgi = fused_gate_grad(xsq, dpre, wA, bias, graph, K)
-        if gated and ctx.needs_input_grad[6]:
-            dgf = fused_gate_grad(hs_all[:T], dpre, wB, bias, graph, K)
         gh0 = None
         if ctx.needs_input_grad[1]:
             gh0 = torch.empty((B, 1, F, N), dtype=torch.bfloat16, device=X.device)

@@ -193,13 +193,17 @@ int gcrnn_fused_gate_readout_backward_bf16(void* cs, const float* dlogit, const 
  *   dpre[T-1] = dHs[T-1] * (1 - hs[T-1]^2);   for t = T-1 .. 1:
  *   dpre[t-1] = ( gf[t] sum_k (S)^k (dpre[t] B_k) + dHs[t-1] ) * (1 - hs[t-1]^2);   dh0 = gf[0] sum_k (S)^k (dpre[0] B_k)  (optional)
  * gf: [T][B] fp32 forget gates of the time-gated cell, or NULL (= 1).
+ * dgf_parts (or NULL; needs h0s = h0 [B][NPad][F] bf16 sequence-major): [T][B][F/16*8] fp32 partials whose sum over the last
+ * axis is <h_{t-1}, sum_k (S)^k (dpre[t] B_k)> = <B(S) h_{t-1}, dpre[t]> -- by the adjoint identity the bias-free part of
+ * d loss / d gf[t][b], read off the chain this entry point evaluates anyway (the dh0 launch then always runs; dh0 may be NULL).
  * dHs = gradient of the loss w.r.t. every state, hs = the states of the forward. wpackT = gcrnn_fused_pack_weights of the
  * TRANSPOSED state taps (wB^T [F_in][Kst][F_out] passed as "wB", G = 0); the graph arrays are the ELL of CSR(S) (the adjoint
  * shift). One launch per step; same kernel as the forward with a different epilogue. */
 int gcrnn_fused_backward_data_bf16(const void* dHs, const void* hs, void* dpre, void* dh0, const void* wpackT,
                                    const int32_t* tile_nodes, const int32_t* tile_off, const int32_t* ell_col,
                                    const float* ell_val, const void* ell_val4, const void* ell_col4, int64_t entries,
-                                   int64_t B, int64_t T, int64_t N, int64_t F, int64_t K, const float* gf, void* stream);
+                                   int64_t B, int64_t T, int64_t N, int64_t F, int64_t K, const float* gf, const void* h0s,
+                                   float* dgf_parts, void* stream);
 
 /* BPTT weight gradient of the fused cell (adjoint of the taps, graphML.py:134-135), all T*B items in ONE launch:
  *   dW[f'][k][j] += sum_{t,b,n} g[t][b] (S^k dpre[t][b])[n][f'] * z[t][b][n][j],   z = [h_{t-1} | x_t],   j < F: weight_B (g = gf),
