@@ -34,6 +34,13 @@ def _apply_mlp_rows(mlp, x2d):
     return x2d
 
 
+def _to_param_dtype(h, mlp):
+    """bf16 states from the fused cell meeting fp32 master weights in a library-GEMM head: compute in the parameters' dtype."""
+    for p in mlp.parameters():
+        return h if h.dtype == p.dtype else h.to(p.dtype)
+    return h
+
+
 def _build_mlp(dimInputMLP, dimLayersMLP, sigma2, sigma3, bias):
     fc = []
     if len(dimLayersMLP) > 0:
@@ -99,14 +106,14 @@ class GatedGCRNNforRegression(_GatedGCRNNBase):
             # one perceptron shared by all nodes (reference :1616-1627 loops over nodes; here one batched GEMM)
             assert self.F_h > 1, "the reference's per-node squeeze() breaks for F_h = 1 (architectures.py:1622)"
             lin = self.outputNN[0] if len(self.outputNN) == 1 and isinstance(self.outputNN[0], nn.Linear) else None
-            if lin is not None and ops.node_linear_supported(self.F_h, lin.out_features, flatH.dtype):
+            if lin is not None and ops.node_linear_supported(self.F_h, lin.out_features, flatH.dtype, self.N, lin.weight.dtype):
                 # the drivers' head (dimLayersMLP = [1]): one kernel on the user layout, no transposes
                 flatY = ops.node_linear(flatH, lin.weight, lin.bias)            # (BT) x out x N
                 return flatY.reshape(batchSize, seqLength, -1).unsqueeze(2)
-            rows = flatH.transpose(1, 2).reshape(-1, self.F_h)                  # (BT*N) x F_h
+            rows = _to_param_dtype(flatH, self.outputNN).transpose(1, 2).reshape(-1, self.F_h)                  # (BT*N) x F_h
             flatY = _apply_mlp_rows(self.outputNN, rows).reshape(flatH.shape[0], self.N, -1).transpose(1, 2)   # (BT) x out x N
         else:
-            flatY = self.outputNN(flatH.reshape(-1, self.F_h * self.N))
+            flatY = self.outputNN(_to_param_dtype(flatH, self.outputNN).reshape(-1, self.F_h * self.N))
         return flatY.reshape(batchSize, seqLength, -1).unsqueeze(2)
 
 
@@ -126,4 +133,4 @@ class GatedGCRNNforClassification(_GatedGCRNNBase):
     def forward(self, x, h0):
         H = self.stateGCRNN(x, h0)
         h = H.select(1, -1)                                          # reference :1844
-        return self.outputNN(h.reshape(-1, self.F_h * self.N))
+        return self.outputNN(_to_param_dtype(h, self.outputNN).reshape(-1, self.F_h * self.N))

@@ -91,6 +91,10 @@ def _bind(lib):
         'gcrnn_node_linear_blocks': (_c_i64, [_c_i64, _c_i64]),
         'gcrnn_node_linear_forward': (C.c_int, [C.c_int, _c_p, _c_p, _c_p, _c_p, _c_i64, _c_i64, _c_i64, _c_i64, _c_p]),
         'gcrnn_node_linear_backward': (C.c_int, [C.c_int, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_i64, _c_i64, _c_i64, _c_i64, _c_p]),
+        'gcrnn_node_linear_bf16_supported': (C.c_int, [_c_i64, _c_i64, _c_i64]),
+        'gcrnn_node_linear_bf16_blocks': (_c_i64, [_c_i64, _c_i64]),
+        'gcrnn_node_linear_bf16_forward': (C.c_int, [C.c_int, _c_p, _c_p, _c_p, _c_p, _c_i64, _c_i64, _c_i64, _c_i64, _c_p]),
+        'gcrnn_node_linear_bf16_backward': (C.c_int, [C.c_int, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_i64, _c_i64, _c_i64, _c_i64, _c_p]),
         'gcrnn_l1_loss_blocks': (_c_i64, [_c_i64]),
         'gcrnn_l1_loss': (C.c_int, [C.c_int, _c_p, _c_p, _c_p, _c_p, _c_i64, C.c_double, _c_p]),
         'gcrnn_attention_forward': (C.c_int, [C.c_int] + [_c_p] * 11 + [_c_i64] * 5 + [C.c_double, _c_p]),

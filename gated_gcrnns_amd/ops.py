@@ -723,12 +723,16 @@ def small_time_gates(X, h0, wA2, wB2, bias2, lw2, lb2, graph):
 
 
 # ------------------------------------------------------------------------------------------ per-node head
-def node_linear_supported(F, O, dtype):
-    return dtype in (torch.float32, torch.float64) and 0 < F <= 64 and 0 < O <= 8
+def node_linear_supported(F, O, dtype, N=None, wdtype=None):
+    if dtype == torch.bfloat16:            # bf16 activations (the fused cell's output), fp32 master or bf16 parameters
+        return N is not None and wdtype in (torch.float32, torch.bfloat16) and \
+            bool(lib.gcrnn_node_linear_bf16_supported(int(N), int(F), int(O)))
+    return dtype in (torch.float32, torch.float64) and (wdtype is None or wdtype == dtype) and 0 < F <= 64 and 0 < O <= 8
 
 
 class _NodeLinear(torch.autograd.Function):
-    """y[r][o][n] = sum_f w[o][f] h[r][f][n] + b[o] on the user layout (the 'multipMlp' head, architectures.py:1616-1627)."""
+    """y[r][o][n] = sum_f w[o][f] h[r][f][n] + b[o] on the user layout (the 'multipMlp' head, architectures.py:1616-1627).
+    fp32 / fp64 throughout, or bf16 activations with fp32 / bf16 parameters (fp32 accumulation, bf16 output)."""
 
     @staticmethod
     def forward(ctx, h, w, b):
@@ -738,8 +742,13 @@ class _NodeLinear(torch.autograd.Function):
         R, F, N = hc.shape
         O = wc.shape[0]
         y = torch.empty((R, O, N), dtype=hc.dtype, device=hc.device)
-        check(lib.gcrnn_node_linear_forward(dtype_code(hc.dtype), _p(hc), _p(wc), _p(bc), _p(y), R, N, F, O, _stream()),
-              'node_linear_forward')
+        if hc.dtype == torch.bfloat16:
+            assert bc is None or bc.dtype == wc.dtype
+            check(lib.gcrnn_node_linear_bf16_forward(dtype_code(wc.dtype), _p(hc), _p(wc), _p(bc), _p(y), R, N, F, O, _stream()),
+                  'node_linear_bf16_forward')
+        else:
+            check(lib.gcrnn_node_linear_forward(dtype_code(hc.dtype), _p(hc), _p(wc), _p(bc), _p(y), R, N, F, O, _stream()),
+                  'node_linear_forward')
         ctx.save_for_backward(hc, wc)
         ctx.has_bias = b is not None
         return y
@@ -750,8 +759,16 @@ class _NodeLinear(torch.autograd.Function):
         R, F, N = h.shape
         O = w.shape[0]
         dyc = dy.contiguous()
-        nb = int(lib.gcrnn_node_linear_blocks(R, N))
         dh = torch.empty_like(h) if ctx.needs_input_grad[0] else None
+        if h.dtype == torch.bfloat16:
+            dyc = dyc.to(torch.bfloat16)
+            nb = int(lib.gcrnn_node_linear_bf16_blocks(R, N))
+            pw = torch.empty((nb, O, F), dtype=torch.float32, device=h.device)
+            pb = torch.empty((nb, O), dtype=torch.float32, device=h.device)
+            check(lib.gcrnn_node_linear_bf16_backward(dtype_code(w.dtype), _p(h), _p(w), _p(dyc), _p(dh), _p(pw), _p(pb), R, N, F, O,
+                                                      _stream()), 'node_linear_bf16_backward')
+            return dh, pw.sum(dim=0).to(w.dtype), (pb.sum(dim=0).to(w.dtype) if ctx.has_bias else None)
+        nb = int(lib.gcrnn_node_linear_blocks(R, N))
         pw = torch.empty((nb, O, F), dtype=h.dtype, device=h.device)
         pb = torch.empty((nb, O), dtype=h.dtype, device=h.device)
         check(lib.gcrnn_node_linear_backward(dtype_code(h.dtype), _p(h), _p(w), _p(dyc), _p(dh), _p(pw), _p(pb), R, N, F, O,

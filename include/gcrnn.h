@@ -288,6 +288,16 @@ int gcrnn_node_linear_forward(int dtype, const void* h, const void* w, const voi
 int gcrnn_node_linear_backward(int dtype, const void* h, const void* w, const void* dy, void* dh, void* pw, void* pb, int64_t R,
                                int64_t N, int64_t F, int64_t O, void* stream);
 
+/* The same head on bf16 activations (the fused cell's output): h, dy, y, dh are bf16 arrays, the parameters w [O][F], b [O]
+ * are fp32 (wdtype GCRNN_F32: master weights) or bf16, accumulation and the partial sums pw [blocks][O][F], pb [blocks][O]
+ * (blocks = gcrnn_node_linear_bf16_blocks(R, N); added by the caller in a fixed order) are fp32. N even, F <= 64, O <= 2. */
+int gcrnn_node_linear_bf16_supported(int64_t N, int64_t F, int64_t O);
+int64_t gcrnn_node_linear_bf16_blocks(int64_t R, int64_t N);
+int gcrnn_node_linear_bf16_forward(int wdtype, const void* h, const void* w, const void* b, void* y, int64_t R, int64_t N,
+                                   int64_t F, int64_t O, void* stream);
+int gcrnn_node_linear_bf16_backward(int wdtype, const void* h, const void* w, const void* dy, void* dh, float* pw, float* pb,
+                                    int64_t R, int64_t N, int64_t F, int64_t O, void* stream);
+
 /* ==== training-loop loss ==========================================================================================
  * batchTimeL1Loss (Utils/miscTools.py:112-119 = nn.L1Loss: mean |x - y| over every entry) and its gradient in one pass.
  * x, y, grad: n contiguous elements of `dtype` (F32 / F64 / BF16), 16-byte aligned; grad (may be NULL) =

@@ -420,3 +420,52 @@ def test_fused_gate_prepass_splits_launches_beyond_32bit_offsets():
             one = ops.fused_time_gate(xs[t:t + 1], hs_all[:1], *g, cell.graph, N)
             assert torch.equal(one[0], full[t]), t
     assert float(full.std()) > 1e-3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('head,tg', [('multipMlp', False), ('multipMlp', True), ('oneMlp', False), ('classification', True)])
+def test_fused_cell_inside_the_models_bf16_activations_fp32_master_weights(head, tg):
+    """GatedGCRNNforRegression / forClassification (reference architectures.py:1405-1859) with bf16 inputs and fp32 master
+    weights: the cell trains on the fused kernels, the per-node head on its bf16 kernel, the dense heads in the parameters'
+    dtype; outputs and every parameter gradient against the same model run in fp32 on the composed path."""
+    import gated_gcrnns_amd.Modules.architectures as archit
+    dev = torch.device('cuda:0')
+    N, F, K, B, T = 200, 32, 3, 6, 4
+    S = random_graph(N, 0.05, 61)
+    rng = np.random.default_rng(15)
+    X = bf16_round(rng.standard_normal((B, T, F, N)))
+    h0 = np.zeros((B, F, N))
+
+    def build():
+        torch.manual_seed(29)
+        if head == 'classification':
+            m = archit.GatedGCRNNforClassification(F, F, K, K, torch.tanh, torch.nn.ReLU, [5], S[0], True, time_gating=tg)
+        else:
+            m = archit.GatedGCRNNforRegression(F, F, K, K, torch.tanh, torch.nn.ReLU, [1], S[0], True, time_gating=tg,
+                                               spatial_gating=None, mlpType=head)
+        return m.to(torch.bfloat16).to(torch.float32).to(dev)             # bf16-representable values, fp32 storage
+
+    ref, mod = build(), build()
+    yr = ref(torch.tensor(X, dtype=torch.float32, device=dev), torch.tensor(h0, dtype=torch.float32, device=dev))
+    w = torch.tensor(bf16_round(rng.standard_normal(tuple(yr.shape))), dtype=torch.float32, device=dev)
+    (yr * w).sum().backward()
+    Xd = torch.tensor(X, dtype=torch.bfloat16, device=dev)
+    hd = torch.tensor(h0, dtype=torch.bfloat16, device=dev)
+    assert mod.stateGCRNN._use_fused_training(Xd, hd)
+    y = mod(Xd, hd)
+    assert tuple(y.shape) == tuple(yr.shape)
+    sc = float(yr.abs().max())
+    assert float((y.float() - yr).abs().max()) <= 3e-2 * sc, float((y.float() - yr).abs().max()) / sc
+    (y.float() * w).sum().backward()
+    got = dict(mod.named_parameters())
+    for n, p in ref.named_parameters():
+        if p.grad is None:
+            assert got[n].grad is None, n
+            continue
+        g, gr = got[n].grad.float(), p.grad
+        s = float(gr.abs().max())
+        if s == 0.0:                                   # h0 = 0: the gate cells' state taps get exactly no gradient, in both
+            assert float(g.abs().max()) == 0.0, n
+            continue
+        e = (g - gr).abs()
+        assert float(e.max()) <= 5e-2 * s and (e.numel() < 16 or float(e.mean()) <= 1e-2 * s), (n, float(e.max()) / s, float(e.mean()) / s)

@@ -531,3 +531,34 @@ def test_small_graph_node_gated_bptt_vs_composed_path(dev, dt, gtol, N, G, F, K,
     for k in ref:
         scale = float(ref[k].abs().max()) + 1e-30
         assert float((got[k] - ref[k]).abs().max()) / scale <= gtol, k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('R,F,N,O,wdt', [(24, 64, 1000, 1, torch.float32), (7, 32, 200, 2, torch.float32), (40, 20, 58, 1, torch.bfloat16),
+                                         (3, 64, 1024, 1, torch.bfloat16)])
+def test_node_linear_bf16_head_matches_fp32(R, F, N, O, wdt):
+    """Per-node head on bf16 activations (fp32 master or bf16 parameters, fp32 accumulation) vs the fp32 kernels on the same
+    bf16-rounded values: forward to bf16 rounding of the output, gradients to bf16 rounding of dy / dh."""
+    from gated_gcrnns_amd import ops
+    dev = torch.device('cuda:0')
+    g = torch.Generator(device='cpu').manual_seed(3)
+    h = torch.randn(R, F, N, generator=g).to(torch.bfloat16)
+    w = (torch.randn(O, F, generator=g) / F ** 0.5).to(torch.bfloat16)
+    b = torch.randn(O, generator=g).to(torch.bfloat16)
+    dy = torch.randn(R, O, N, generator=g).to(torch.bfloat16)
+    hr, wr, br = (t.float().to(dev).requires_grad_(True) for t in (h, w, b))
+    yr = ops.node_linear(hr, wr, br)
+    (yr * dy.float().to(dev)).sum().backward()
+    hb = h.to(dev).requires_grad_(True)
+    wb, bb = w.to(wdt).to(dev).requires_grad_(True), b.to(wdt).to(dev).requires_grad_(True)
+    assert ops.node_linear_supported(F, O, torch.bfloat16, N, wdt)
+    yb = ops.node_linear(hb, wb, bb)
+    assert yb.dtype == torch.bfloat16
+    (yb.float() * dy.float().to(dev)).sum().backward()
+    sc = float(yr.abs().max())
+    assert float((yb.float() - yr).abs().max()) <= 2 ** -8 * sc
+    assert hb.grad.dtype == torch.bfloat16 and wb.grad.dtype == wdt
+    for name, got, ref in (('dh', hb.grad.float(), hr.grad), ('dw', wb.grad.float(), wr.grad), ('db', bb.grad.float(), br.grad)):
+        s = float(ref.abs().max())
+        tol = 2 ** -7 if (name == 'dh' or wdt == torch.bfloat16) else 1e-4       # bf16 store of dh / of the parameter gradient
+        assert float((got - ref).abs().max()) <= tol * s, (name, float((got - ref).abs().max()) / s)
