@@ -81,7 +81,7 @@ def cpu_baseline(S, params, T, G, F, seconds_budget=20.0):
         cores = os.cpu_count()
     return {'value': Bc / best, 'unit': 'sequences/s', 'cores': cores, 'kind': 'port',
             'sample': 'oracle/gcrnn_oracle.py ggcrnn_cell (dense x@S hops, numpy/BLAS fp32), B=%d full T=%d N=%d '
-                      'K=5 G=F=64 sequences, best of %d passes (%.2f s each)' % (Bc, T, N, reps, best)}
+                      'K=5 G=%d F=%d sequences, best of %d passes (%.2f s each)' % (Bc, T, N, G, F, reps, best)}
 
 
 def main():
@@ -95,6 +95,8 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--time-gating', action='store_true', help='secondary point: the time-gated cell (fwd or train); '
                     'the headline workload is the un-gated cell')
+    ap.add_argument('--in-features', type=int, default=CFG['G'], help='secondary point: input features per node (the reference '
+                    'drivers feed G = 1; the headline workload is G = F = 64)')
     ap.add_argument('--hipgraph', type=int, default=0, help='replay the fused forward as one captured hipGraph (bf16 fwd)')
     args = ap.parse_args()
 
@@ -112,7 +114,7 @@ def main():
 
     import gated_gcrnns_amd.Utils.graphML as gml
 
-    N, K, T, G, F = CFG['N'], CFG['K'], CFG['T'], CFG['G'], CFG['F']
+    N, K, T, G, F = CFG['N'], CFG['K'], CFG['T'], args.in_features, CFG['F']
     B = args.batch
     dt = {'bf16': torch.bfloat16, 'f32': torch.float32, 'f64': torch.float64}[args.dtype]
     elt = {'bf16': 2, 'f32': 4, 'f64': 8}[args.dtype]
@@ -204,7 +206,8 @@ def main():
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype,
             'data': 'synthetic',
             'config': {'workload': 'BASELINE configs[1]: synthetic k-step prediction, sparse SBM N=1000 nnz=%d, K=5 taps, '
-                                   'T=32, G=F=64, %s GGCRNNCell forward, h0=0' % (nnz, 'time-gated' if args.time_gating else 'un-gated'),
+                                   'T=32, G=%d, F=64, %s GGCRNNCell %s, h0=0' % (nnz, G, 'time-gated' if args.time_gating else 'un-gated',
+                                                                              'forward' if args.mode == 'fwd' else 'training step'),
                        'batch_per_gpu': B, 'global_batch': world * B, 'mode': args.mode, 'hipgraph': bool(runner is not None), 'parallelism': 'dp%d' % world},
         }
         if kern is not None:
@@ -219,7 +222,7 @@ def main():
                     traffic = tj['hbm_bytes_per_launch']
             out['roofline'] = {'bound': 'hbm', 'achieved': kach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                                'frac': kach / HBM_PEAK_GBS, 'traffic': traffic,
-                               'kernel': 'fused_step_kernel<5,2,2> (one launch = one time step of the whole batch)',
+                               'kernel': 'fused_step_kernel<5,2,%d> (one launch = one time step of the whole batch)' % (2 if G > 32 else 1),
                                'kernel_avg_us': kern['avg_us'], 'launches_timed': kern['launches'],
                                'algorithmic_bytes_per_launch': kbytes,
                                'gflop_per_launch': flops_per_seq(1, N, nnz, K, G, F) * B / 1e9,
@@ -227,7 +230,8 @@ def main():
         else:
             out['roofline'] = {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                                'frac': achieved / HBM_PEAK_GBS, 'traffic': None,
-                               'kernel': 'whole T-step recurrence (composed path: all launches of one step)',
+                               'kernel': 'whole T-step recurrence (all launches of one step: %s)' % (
+                                   'fused kernels' if args.dtype == 'bf16' else 'composed path'),
                                'algorithmic_bytes_per_step': abytes, 'device_ms_per_step': 1e3 * step_s,
                                'gflop_per_step': flops_per_seq(T, N, nnz, K, G, F) * B / 1e9}
         if not args.no_cpu_baseline and world == 1:          # the host baseline is a single-GPU-run item (rank 0, N = 1)

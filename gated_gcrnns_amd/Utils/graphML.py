@@ -294,7 +294,8 @@ class GGCRNNCell(nn.Module):
         B, T, F_in, N = X.shape
         assert F_in == self.G and N == self.N
         if self._use_fused_training(X, h0):
-            return ops.fused_cell_train(X, h0, self.weight_A, self.weight_B, self.bias, self.graph,
+            Xp, wA = ops.fused_pad_operands(X, self.weight_A)          # G < 32 (the drivers' G = 1): zero-padded channels
+            return ops.fused_cell_train(Xp, h0, wA, self.weight_B, self.bias, self.graph,
                                         self._fused_gates() if self.time_gating == True else None)  # noqa: E712
         if self._use_fused(X, h0):
             return self._forward_fused(X, h0)
@@ -485,14 +486,17 @@ class GGCRNNCell(nn.Module):
         return ops.fused_training_supported(self.graph, self.N, self.F, self.G, self.Kin, self.Kst, self.E)
 
     def _fused_gates(self):
-        return {'in': (self.GFL_in.weight_A, self.GFL_in.weight_B, self.GFL_in.bias,
+        Gp = ops.fused_padded_inputs(self.F, self.G)
+        pad = (lambda w: w) if Gp == self.G else (lambda w: nn.functional.pad(w, (0, Gp - self.G)))
+        return {'in': (pad(self.GFL_in.weight_A), self.GFL_in.weight_B, self.GFL_in.bias,
                        self.MLP_in[0].weight, self.MLP_in[0].bias),
-                'forget': (self.GFL_forget.weight_A, self.GFL_forget.weight_B, self.GFL_forget.bias,
+                'forget': (pad(self.GFL_forget.weight_A), self.GFL_forget.weight_B, self.GFL_forget.bias,
                            self.MLP_forget[0].weight, self.MLP_forget[0].bias)}
 
     def _forward_fused(self, X, h0):
         gates = self._fused_gates() if self.time_gating == True else None  # noqa: E712
-        return ops.fused_cell_forward(X, h0, self.weight_A, self.weight_B, self.bias, self.graph, gates)
+        Xp, wA = ops.fused_pad_operands(X, self.weight_A)
+        return ops.fused_cell_forward(Xp, h0, wA, self.weight_B, self.bias, self.graph, gates)
 
     def extra_repr(self):
         return 'in_features=%d, state_features=%d, taps=(%d,%d), time_gating=%s, spatial_gating=%s, %s' % (

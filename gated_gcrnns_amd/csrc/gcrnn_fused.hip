@@ -791,11 +791,16 @@ static int fused_launch_t(int mode /*0 plain, 1 gated, 2 gate pre-pass, 3 BPTT d
         kern<<<grid_for(items), STHREADS, lds, st>>>(x + t0 * xstep, (const uint16_t*)h0, h ? h + t0 * hstep : nullptr, (const uint4*)wpack, bias,
                                      nullptr, nullptr, ga.tile_nodes, ga.tile_off, ga.ell_col, ga.ell_val, (const float4*)ga.ell_val4,
                                      (const uint2*)ga.ell_col4, gate_w, go, nullptr, nullptr, 0, (int)ga.entries, (int)items, (int)B, (int)N);
-      else                // operand = one [T*B][NP][F] array (XS = 0), per-item dpre in bw_dHs
+      else if (XS == 0)   // operand = one [T*B][NP][F] array, per-item dpre in bw_dHs
         kern<<<grid_for(items), STHREADS, lds, st>>>(nullptr, (const uint16_t*)h0 + t0 * hstep, nullptr, (const uint4*)wpack, bias, nullptr, nullptr,
                                      ga.tile_nodes, ga.tile_off, ga.ell_col, ga.ell_val, (const float4*)ga.ell_val4,
                                      (const uint2*)ga.ell_col4, nullptr, go, (const uint16_t*)bw_dHs + t0 * hstep, nullptr, 0,
                                      (int)ga.entries, (int)items, (int)items, (int)N);
+      else                // input filter with G != F: operand [0 | x_t] -- ONE all-zero state block shared by every item (hmod = 1)
+        kern<<<grid_for(items), STHREADS, lds, st>>>(x + t0 * xstep, (const uint16_t*)h0, nullptr, (const uint4*)wpack, bias, nullptr, nullptr,
+                                     ga.tile_nodes, ga.tile_off, ga.ell_col, ga.ell_val, (const float4*)ga.ell_val4,
+                                     (const uint2*)ga.ell_col4, nullptr, go, (const uint16_t*)bw_dHs + t0 * hstep, nullptr, 0,
+                                     (int)ga.entries, (int)items, 1, (int)N);
     }
   } else if (mode == 3) {
     // BPTT: hs (= dpre, [T][B][NP][F]) already holds dpre_{T-1}; walk t = T-1 .. 1, then optionally d h0.
@@ -846,6 +851,10 @@ static int fused_dispatch(int mode, const void* xs, const void* h0, void* hs, co
   GCRNN_FUSED_CASE(5, 1, 1)
   GCRNN_FUSED_CASE(3, 1, 1)
   GCRNN_FUSED_CASE(2, 1, 1)
+  GCRNN_FUSED_CASE(5, 2, 1)      // F = 64 with up to 32 input features (the drivers' G = 1, zero-padded to 32 by the caller)
+  GCRNN_FUSED_CASE(4, 2, 1)
+  GCRNN_FUSED_CASE(3, 2, 1)
+  GCRNN_FUSED_CASE(2, 2, 1)
   GCRNN_FUSED_CASE(5, 2, 0)      // BPTT data-gradient steps and gate-gradient passes: ONE operand array (dpre, x or h alone)
   GCRNN_FUSED_CASE(4, 2, 0)
   GCRNN_FUSED_CASE(3, 2, 0)
@@ -884,17 +893,20 @@ extern "C" int gcrnn_fused_gate_prepass_bf16(const void* xs, const void* h0, con
 }
 
 // d loss / d (scalar time gate) of one filter of the gated cell:  out[t*B+b][partials] summed = sum_{f,n} (W(S) z + b) . dpre
-// z: [T][B][NP][F] bf16 sequence-major operand of that filter (x_t for the input filter, h_{t-1} for the state filter;
-// F input features), wpack: its taps packed as a state-only operand (gcrnn_fused_pack_weights with G = 0), bias [F] or
-// null (added once), dpre: [T][B][NP][F] bf16. Reference: the gates multiply the two filter outputs, graphML.py:2420-2421.
-extern "C" int gcrnn_fused_gate_grad_bf16(const void* zs, const void* dpre, const void* wpack, const float* bias, float* out,
-                                          const int32_t* tile_nodes, const int32_t* tile_off, const int32_t* ell_col,
+// xs == null (G = 0): z = zs [T][B][NP][F] bf16 sequence-major is that filter's operand (h_{t-1} for the state filter, or x_t
+// for an input filter with G == F), wpack its taps packed as a state-only operand (gcrnn_fused_pack_weights with G = 0).
+// xs != null: input filter with G != F input features: operand [0 | x_t], xs [T][B][NP][G], zs = ONE all-zero block [NP][F],
+// wpack = gcrnn_fused_pack_weights(A, zero state taps). bias [F] or null (added once), dpre: [T][B][NP][F] bf16.
+// Reference: the gates multiply the two filter outputs, graphML.py:2420-2421.
+extern "C" int gcrnn_fused_gate_grad_bf16(const void* zs, const void* xs, const void* dpre, const void* wpack, const float* bias,
+                                          float* out, const int32_t* tile_nodes, const int32_t* tile_off, const int32_t* ell_col,
                                           const float* ell_val, const void* ell_val4, const void* ell_col4, int64_t entries,
-                                          int64_t B, int64_t T, int64_t N, int64_t F, int64_t K, void* stream) {
+                                          int64_t B, int64_t T, int64_t N, int64_t F, int64_t G, int64_t K, void* stream) {
   if (!zs || !dpre || !wpack || !out || !tile_nodes || !tile_off || !ell_col || !ell_val) return GCRNN_ERR_NULL_POINTER;
+  if ((xs == nullptr) != (G == 0)) return GCRNN_ERR_BAD_SHAPE;
   if (B <= 0 || T <= 0 || N <= 0 || N > NP || B * T > (1 << 24) || entries < 0 || entries % 4) return GCRNN_ERR_BAD_SHAPE;
   const FusedGraphArgs ga{tile_nodes, tile_off, ell_col, ell_val, ell_val4, ell_col4, entries};
-  return fused_dispatch(4, nullptr, zs, nullptr, wpack, bias, nullptr, nullptr, nullptr, out, ga, B, T, N, F, 0, K, as_stream(stream), dpre);
+  return fused_dispatch(4, xs, zs, nullptr, wpack, bias, nullptr, nullptr, nullptr, out, ga, B, T, N, F, G, K, as_stream(stream), dpre);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1171,6 +1183,10 @@ extern "C" int gcrnn_fused_backward_weight_bf16(const void* dpre, const void* Xu
   GCRNN_WG_CASE(5, 1, 1)
   GCRNN_WG_CASE(3, 1, 1)
   GCRNN_WG_CASE(2, 1, 1)
+  GCRNN_WG_CASE(5, 2, 1)
+  GCRNN_WG_CASE(4, 2, 1)
+  GCRNN_WG_CASE(3, 2, 1)
+  GCRNN_WG_CASE(2, 2, 1)
 #undef GCRNN_WG_CASE
   return GCRNN_ERR_UNSUPPORTED;
 }
@@ -1252,7 +1268,7 @@ extern "C" int gcrnn_fused_gate_readout_backward_bf16(void* cs, const float* dlo
 
 extern "C" int gcrnn_fused_supported(int64_t N, int64_t F, int64_t G, int64_t K) {
   if (N <= 0 || N > NP) return 0;
-  const bool big = (F == 64 && G == 64 && K >= 2 && K <= 5);
+  const bool big = (F == 64 && (G == 64 || G == 32) && K >= 2 && K <= 5);
   const bool small = (F == 32 && G == 32 && (K == 2 || K == 3 || K == 5));
   return (big || small) ? 1 : 0;
 }

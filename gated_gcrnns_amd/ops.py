@@ -201,14 +201,40 @@ def lsigf_node_major(X, w, bias, graph, bias_scale=1.0):
 
 
 # ------------------------------------------------------------------------------------------ fused flagship path
+def fused_padded_inputs(F, G):
+    """Input-feature count the fused kernels run with for a cell with G input and F state features: the x operand is
+    consumed in 32-feature MFMA steps, so G is zero-padded to 32 (or 64) channels -- the reference drivers' G = 1
+    (kStepPredGRNNs.py:220, epicenterEstimation.py:170) runs as 32. None: no kernel for this pair."""
+    if F in (32, 64) and 0 < G <= 32:
+        return 32
+    if F == 64 and 32 < G <= 64:
+        return 64
+    return None
+
+
+def fused_pad_operands(X, wA):
+    """Zero-pad the input sequence X [B][T][G][N] and the input taps wA [F][1][K][G] to the kernels' channel count
+    (differentiable w.r.t. wA: the padding's gradient is dropped by autograd)."""
+    F, G = wA.shape[0], wA.shape[3]
+    Gp = fused_padded_inputs(F, G)
+    if Gp == G:
+        return X, wA
+    B, T, _, N = X.shape
+    Xp = X.new_zeros((B, T, Gp, N))
+    Xp[:, :, :G] = X
+    return Xp, torch.nn.functional.pad(wA, (0, Gp - G))
+
+
 def fused_supported(N, F, G, Kin, Kst, dtype, E=1):
-    return (E == 1 and dtype == torch.bfloat16 and
-            bool(lib.gcrnn_fused_supported(int(N), int(F), int(G), int(max(Kin, Kst)))))
+    Gp = fused_padded_inputs(F, G)
+    return (E == 1 and dtype == torch.bfloat16 and Gp is not None and
+            bool(lib.gcrnn_fused_supported(int(N), int(F), int(Gp), int(max(Kin, Kst)))))
 
 
 def time_fused_step_kernel(X, h0, wA, wB, bias, graph, reps=3):
     """Average duration of ONE fused step launch, measured with HIP events on the launch stream
     (inputs pre-packed, only the T step launches sit between the events)."""
+    X, wA = fused_pad_operands(X, wA.detach())
     B, T, G, N = X.shape
     F = wA.shape[0]
     Kin, Kst = wA.shape[2], wB.shape[2]
@@ -310,6 +336,8 @@ def fused_cell_forward(X, h0, wA, wB, bias, graph, gates=None, return_states=Fal
     return_states: also returns the state buffer hs_all [T+1][B][NPad][F] (slot 0 = h0) and the plan.
     """
     require_device(X, h0, wA, wB, bias)
+    if packed is None:
+        X, wA = fused_pad_operands(X, wA.detach())        # G < 32: zero-padded input channels (no-op when already padded)
     B, T, G, N = X.shape
     F = wA.shape[0]
     K = max(wA.shape[2], wB.shape[2])
@@ -328,6 +356,8 @@ def fused_cell_forward(X, h0, wA, wB, bias, graph, gates=None, return_states=Fal
         g = {}
         for name in ('in', 'forget'):
             wA_g, wB_g, bias_g, lin_w, lin_b = gates[name]
+            if wA_g.shape[3] != G:
+                wA_g = torch.nn.functional.pad(wA_g.detach(), (0, G - wA_g.shape[3]))
             assert max(wA_g.shape[2], wB_g.shape[2]) == K and wA_g.shape[0] == F
             g[name] = fused_time_gate(xs, h0s, wA_g, wB_g, bias_g, lin_w, lin_b, graph, N)
         gi, gf = g['in'], g['forget']
@@ -404,22 +434,35 @@ def fused_backward_weight(dpre, X, H, h0, graph, F, G, K, want_bias=False, gi=No
 
 def fused_gate_grad(zs, dpre, w, bias, graph, K):
     """d loss / d gate [T][B] fp32 of one filter of the time-gated cell: sum_{f,n} (w(S) z + bias) . dpre per item.
-    zs, dpre: [T][B][NPad][F] bf16 sequence-major; w: that filter's taps F x 1 x k x F; bias F x 1 or None."""
+    zs: that filter's operand [T][B][NPad][C] bf16 sequence-major (h_{t-1}, or x_t), dpre: [T][B][NPad][F]; w: its taps
+    F x 1 x k x C; bias F x 1 or None. C == F runs the operand alone; an input filter with C != F runs as [0 | x_t]."""
     T, B, npad, F = dpre.shape
+    Cin = w.shape[3]
     plan = graph.fused_plan()
     st = _stream()
-    wp = _fused_pack_state_taps(w, K, st)
     b32 = bias.detach().float().contiguous().view(-1) if bias is not None else None
     parts = torch.empty((T * B, (F // 16) * int(lib.gcrnn_fused_step_waves())), dtype=torch.float32, device=dpre.device)
-    check(lib.gcrnn_fused_gate_grad_bf16(_p(zs), _p(dpre), _p(wp), _p(b32), _p(parts), *_fused_graph_args(plan),
-                                         B, T, graph.N, F, K, st), 'fused_gate_grad')
+    if Cin == F:
+        wp = _fused_pack_state_taps(w, K, st)
+        check(lib.gcrnn_fused_gate_grad_bf16(_p(zs), None, _p(dpre), _p(wp), _p(b32), _p(parts), *_fused_graph_args(plan),
+                                             B, T, graph.N, F, 0, K, st), 'fused_gate_grad')
+    else:
+        wd = w.detach()
+        wz = wd.new_zeros((F, 1, K, F))
+        if wd.shape[2] < K:
+            wd = torch.cat([wd, wd.new_zeros(F, 1, K - wd.shape[2], Cin)], dim=2)
+        wp = _fused_pack_weights(wd, wz, st)
+        zero_h = torch.zeros((1, npad, F), dtype=torch.bfloat16, device=dpre.device)
+        check(lib.gcrnn_fused_gate_grad_bf16(_p(zero_h), _p(zs), _p(dpre), _p(wp), _p(b32), _p(parts), *_fused_graph_args(plan),
+                                             B, T, graph.N, F, Cin, K, st), 'fused_gate_grad')
     return parts.sum(dim=1).view(T, B)
 
 
 def fused_training_supported(graph, N, F, G, Kin, Kst, E=1):
     """The fused BPTT needs the forward kernel's shapes, node-contiguous rows that are 16-byte aligned (N % 8 == 0)
     and the adjoint graph image next to the state and the transposed tile in LDS."""
-    if E != 1 or N % 8 != 0 or not bool(lib.gcrnn_fused_supported(int(N), int(F), int(G), int(max(Kin, Kst)))):
+    Gp = fused_padded_inputs(F, G)
+    if E != 1 or N % 8 != 0 or Gp is None or not bool(lib.gcrnn_fused_supported(int(N), int(F), int(Gp), int(max(Kin, Kst)))):
         return False
     entries = graph.fused_plan(adjoint=True)['entries']
     return 65536 + 96 * entries + 16 * 1056 + 64 <= 160 * 1024

@@ -172,13 +172,15 @@ int gcrnn_fused_gate_prepass_bf16(const void* xs, const void* h0, const void* wp
 
 /* d loss / d (scalar time gate) of ONE filter of the time-gated cell (the gates multiply the filter outputs, graphML.py:2420-2421):
  *   sum over out[t][b][0 .. F/16*8) = sum_{f,n} ( W(S) z[t][b] + bias )[n][f] * dpre[t][b][n][f]
- * z: [T][B][NPad][F] bf16 sequence-major operand of that filter (x_t for the input filter -- G = F on this path --, h_{t-1} for
- * the state filter), wpack = gcrnn_fused_pack_weights of its taps as a state-only operand (G = 0), bias [F] or NULL (added once),
- * dpre = output of gcrnn_fused_backward_data_bf16. All T*B items in one launch (split like the gate pre-pass). */
-int gcrnn_fused_gate_grad_bf16(const void* zs, const void* dpre, const void* wpack, const float* bias, float* out,
+ * xs == NULL, G = 0: z = zs [T][B][NPad][F] bf16 sequence-major is that filter's operand (h_{t-1} for the state filter, x_t for
+ * an input filter with G == F), wpack = gcrnn_fused_pack_weights of its taps as a state-only operand (G = 0);
+ * xs != NULL: input filter with G != F: operand [0 | x_t] with xs [T][B][NPad][G], zs = ONE all-zero block [NPad][F] and
+ * wpack = gcrnn_fused_pack_weights(A, zero state taps). bias [F] or NULL (added once), dpre = output of
+ * gcrnn_fused_backward_data_bf16. All T*B items in one launch (split like the gate pre-pass). */
+int gcrnn_fused_gate_grad_bf16(const void* zs, const void* xs, const void* dpre, const void* wpack, const float* bias, float* out,
                                const int32_t* tile_nodes, const int32_t* tile_off, const int32_t* ell_col, const float* ell_val,
                                const void* ell_val4, const void* ell_col4, int64_t entries, int64_t B, int64_t T, int64_t N,
-                               int64_t F, int64_t K, void* stream);
+                               int64_t F, int64_t G, int64_t K, void* stream);
 
 /* BPTT through a time gate's read-out gate = sigmoid(w . vec(c) + c0) (graphML.py:2364-2366), one pass, in place:
  *   cs [items][NPad][F] bf16: on entry the gate cell's states c (gcrnn_fused_gate_prepass_bf16), on return

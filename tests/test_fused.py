@@ -469,3 +469,53 @@ def test_fused_cell_inside_the_models_bf16_activations_fp32_master_weights(head,
             continue
         e = (g - gr).abs()
         assert float(e.max()) <= 5e-2 * s and (e.numel() < 16 or float(e.mean()) <= 1e-2 * s), (n, float(e.max()) / s, float(e.mean()) / s)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('N,G,F,K,B,T,tg', [(1000, 1, 64, 5, 4, 4, False), (1000, 1, 64, 3, 3, 3, True), (200, 3, 32, 3, 5, 4, False),
+                                            (520, 20, 64, 2, 3, 3, True), (304, 32, 64, 4, 3, 3, False), (200, 1, 32, 5, 4, 3, True)])
+def test_fused_cell_with_few_input_features(N, G, F, K, B, T, tg):
+    """The reference drivers feed ONE input feature per node (kStepPredGRNNs.py:220): G < 32 runs on the fused kernels with the
+    x operand zero-padded to one 32-feature MFMA step. Forward against the fp64 oracle, training against fp32 autograd on
+    the composed path, for the un-gated and the time-gated cell."""
+    import gated_gcrnns_amd.Utils.graphML as gml
+    dev = torch.device('cuda:0')
+    S = random_graph(N, min(0.5, 10.0 / N), 71)
+    rng = np.random.default_rng(17)
+    X = bf16_round(rng.standard_normal((B, T, G, N)))
+    h0 = bf16_round(0.4 * rng.standard_normal((B, F, N)))
+    dH = bf16_round(rng.standard_normal((B, T, F, N)))
+    torch.manual_seed(31)
+    cell = gml.GGCRNNCell(G, F, K, K, torch.tanh, tg, None, 1, True)
+    cell.addGSO(torch.tensor(S))
+    cell = cell.to(torch.bfloat16).to(torch.float32)
+    params = {k: v.detach().double().numpy() for k, v in cell.state_dict().items()}
+    Href = orc.ggcrnn_cell(params, S.astype(np.float32).astype(np.float64), X, h0, tg, None)
+    ref = gml.GGCRNNCell(G, F, K, K, torch.tanh, tg, None, 1, True)
+    ref.addGSO(torch.tensor(S))
+    ref.load_state_dict(cell.state_dict())
+    ref = ref.to(dev)
+    dHd = torch.tensor(dH, dtype=torch.float32, device=dev)
+    (ref(torch.tensor(X, dtype=torch.float32, device=dev), torch.tensor(h0, dtype=torch.float32, device=dev)) * dHd).sum().backward()
+    cell = cell.to(dev)
+    Xd = torch.tensor(X, dtype=torch.bfloat16, device=dev)
+    hd = torch.tensor(h0, dtype=torch.bfloat16, device=dev)
+    with torch.no_grad():
+        assert cell.to(torch.bfloat16)._use_fused(Xd, hd)
+        Hi = cell(Xd, hd)                                        # inference kernels (bf16 parameters)
+        cell = cell.to(torch.float32)
+    err = np.abs(Hi.double().cpu().numpy() - Href)
+    assert err.max() <= 4e-2 and err.mean() <= 3e-3, (err.max(), err.mean())
+    assert cell._use_fused_training(Xd, hd)
+    H = cell(Xd, hd)
+    (H.float() * dHd).sum().backward()
+    got = dict(cell.named_parameters())
+    for n, p in ref.named_parameters():
+        if p.grad is None:
+            assert got[n].grad is None, n
+            continue
+        g, gr = got[n].grad.float(), p.grad
+        assert g.shape == gr.shape, n
+        s = float(gr.abs().max())
+        e = (g - gr).abs()
+        assert s > 0 and float(e.max()) <= 4e-2 * s and (e.numel() < 16 or float(e.mean()) <= 8e-3 * s), (n, float(e.max()) / s, float(e.mean()) / s)
