@@ -3,8 +3,11 @@
 (graph -> S = W/lambda_max -> data -> models -> train -> test; its lines 598-1677), reduced to the GCRNN models.
 
     python examples/kstep_prediction.py [--nodes 80] [--taps 5] [--seq 5] [--epochs 1] [--dtype f64]
+    python examples/kstep_prediction.py --nodes 1000 --features 64 --seq 32 --dtype bf16 --ntrain 1024 --batch 256 --sparse
 
-Defaults follow the reference driver (N=80 SBM 0.8/0.2, 5 taps, K=seqLen=5, F=20, batch 100, Adam 1e-3).
+Defaults follow the reference driver (N=80 SBM 0.8/0.2, 5 taps, K=seqLen=5, F=20, batch 100, Adam 1e-3). --dtype bf16 feeds
+bf16 batches to fp32 master weights: GCRNN and TimeGCRNN then run on the fused kernels (N <= 1024, F in {32, 64}), the node- and
+edge-gated variants on the composed path in fp32. --sparse draws the BASELINE configs[1] graph (mean degree ~10).
 """
 import argparse
 import os
@@ -29,15 +32,18 @@ def main():
     ap.add_argument('--epochs', type=int, default=1)
     ap.add_argument('--batch', type=int, default=100)
     ap.add_argument('--ntrain', type=int, default=2000)
-    ap.add_argument('--dtype', default='f64', choices=['f32', 'f64'])
+    ap.add_argument('--dtype', default='f64', choices=['f32', 'f64', 'bf16'])
+    ap.add_argument('--sparse', action='store_true', help='SBM with p_in 0.04 / p_out 0.0025 (BASELINE configs[1]) instead of 0.8 / 0.2')
+    ap.add_argument('--models', default='GCRNNMLP,TimeGCRNNMLP,NodeGCRNNMLP,EdgeGCRNNMLP')
     ap.add_argument('--seed', type=int, default=0)
     args = ap.parse_args()
-    dt = torch.float64 if args.dtype == 'f64' else torch.float32
+    dt = torch.float64 if args.dtype == 'f64' else torch.float32       # parameter dtype (bf16: fp32 master weights)
+    data_dt = torch.bfloat16 if args.dtype == 'bf16' else dt
     torch.set_default_dtype(dt)                                   # the reference driver runs in float64 (line 44)
     dev = torch.device('cuda:0')
     rng = np.random.default_rng(args.seed)
     torch.manual_seed(args.seed)
-    W = dataTools.sbm_adjacency(args.nodes, 5, 0.8, 0.2, rng)
+    W = dataTools.sbm_adjacency(args.nodes, 5, 0.04, 0.0025, rng) if args.sparse else dataTools.sbm_adjacency(args.nodes, 5, 0.8, 0.2, rng)
     S = dataTools.normalised_gso(W)
     K = args.seq
     data = dataTools.KStepPrediction(W, K, args.ntrain, 200, 200, horizon=2 * K, rng=rng, dataType=dt)
@@ -45,6 +51,8 @@ def main():
     models = {}
     for name, tg, sg in (('GCRNNMLP', False, None), ('TimeGCRNNMLP', True, None), ('NodeGCRNNMLP', False, 'node'),
                          ('EdgeGCRNNMLP', False, 'edge')):
+        if name not in args.models.split(','):
+            continue
         m = archit.GatedGCRNNforRegression(1, args.features, args.taps, args.taps, torch.tanh, torch.nn.ReLU, [1], S, True,
                                            time_gating=tg, spatial_gating=sg, mlpType='multipMlp').to(dev)
         opt = torch.optim.Adam(m.parameters(), lr=1e-3, betas=(0.9, 0.999))
@@ -52,15 +60,15 @@ def main():
     xT, yT = data.getSamples('train')
     xV, yV = data.getSamples('valid')
     out = MultipleModels(models, xT, yT, xV, yV, args.epochs, args.batch, data.seqLen, args.features,
-                         data.evaluate, validationInterval=5, rng=rng, doPrint=False)
+                         data.evaluate, validationInterval=5, rng=rng, doPrint=False, dataType=data_dt)
     xE, yE = data.getSamples('test')
-    xE = xE.view(xE.shape[0], data.seqLen, -1).to(dev).unsqueeze(2)
-    yE = yE.view(yE.shape[0], data.seqLen, -1).to(dev).unsqueeze(2)
+    xE = xE.view(xE.shape[0], data.seqLen, -1).to(dev, data_dt).unsqueeze(2)
+    yE = yE.view(yE.shape[0], data.seqLen, -1).to(dev, data_dt).unsqueeze(2)
     for name, tm in models.items():
         tm.load('Best')
         with torch.no_grad():
-            h0 = torch.zeros(xE.shape[0], args.features, args.nodes, device=dev)
-            score = float(data.evaluate(tm.archit(xE, h0), yE))
+            h0 = torch.zeros(xE.shape[0], args.features, args.nodes, device=dev, dtype=data_dt)
+            score = float(data.evaluate(tm.archit(xE, h0).to(yE.dtype), yE))
         t = np.median(out['timeTrain'][name])
         print('%-14s test RMSE-metric %.4f   loss %.4f -> %.4f   median %.1f ms/batch (%.0f seq/s)' % (
             name, score, out['lossTrain'][name][0], out['lossTrain'][name][-1], 1e3 * t, args.batch / t))

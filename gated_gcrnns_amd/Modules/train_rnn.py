@@ -61,18 +61,20 @@ class TrainableModel(object):
 
 
 def MultipleModels(modelsDict, xTrain, yTrain, xValid, yValid, nEpochs, batchSize, seqLen, stateFeat,
-                   evaluate, validationInterval=5, rank=0, world=1, doPrint=False, rng=None):
+                   evaluate, validationInterval=5, rank=0, world=1, doPrint=False, rng=None, dataType=None):
     """Train every model of `modelsDict` (name -> TrainableModel, names containing 'GCRNN') on the same batches.
 
     xTrain / yTrain: nTrain x seqLen x N tensors (host or device); evaluate(yHat, y) is the dataset metric
     (batchTimeMSELoss for k-step prediction). With world > 1 each rank takes its shard of every batch and the
-    gradients are averaged by one flat all-reduce. Returns dicts of per-step loss / metric / seconds per model.
+    gradients are averaged by one flat all-reduce. dataType: dtype of the batches on the device (default: the parameters'
+    dtype); torch.bfloat16 with fp32 parameters = bf16 activations over fp32 master weights (the fused kernels).
+    Returns dicts of per-step loss / metric / seconds per model.
     """
     rng = rng if rng is not None else np.random
     nTrain = xTrain.shape[0]
     sizes, index = batch_partition(nTrain, batchSize)
     dev = next(iter(modelsDict.values())).archit.stateGCRNN.weight_A.device
-    dt = next(iter(modelsDict.values())).archit.stateGCRNN.weight_A.dtype
+    dt = dataType if dataType is not None else next(iter(modelsDict.values())).archit.stateGCRNN.weight_A.dtype
     syncs = {k: (FlatGradAllReduce(m.archit.parameters()) if world > 1 else None) for k, m in modelsDict.items()}
     lossTrain = {k: [] for k in modelsDict}
     evalTrain = {k: [] for k in modelsDict}
@@ -97,7 +99,7 @@ def MultipleModels(modelsDict, xTrain, yTrain, xValid, yValid, nEpochs, batchSiz
                 torch.cuda.synchronize() if dev.type == 'cuda' else None
                 timeTrain[key].append(time.perf_counter() - t0)
                 lossTrain[key].append(float(loss))
-                evalTrain[key].append(float(evaluate(yHat, yo)))
+                evalTrain[key].append(float(evaluate(yHat.to(yo.dtype), yo)))
             step = epoch * len(sizes) + b
             if validationInterval and step % validationInterval == 0 and xValid is not None:
                 xv = xValid.view(xValid.shape[0], seqLen, -1).to(dev, dt).unsqueeze(2)
@@ -105,7 +107,7 @@ def MultipleModels(modelsDict, xTrain, yTrain, xValid, yValid, nEpochs, batchSiz
                 for key, m in modelsDict.items():
                     with torch.no_grad():
                         h0 = torch.zeros(xv.shape[0], stateFeat, xv.shape[3], dtype=dt, device=dev)
-                        score = float(evaluate(m.archit(xv, h0), yv))
+                        score = float(evaluate(m.archit(xv, h0).to(yv.dtype), yv))
                     evalValid[key].append(score)
                     if key not in best or score < best[key]:
                         best[key] = score

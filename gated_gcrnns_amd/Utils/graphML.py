@@ -305,6 +305,8 @@ class GGCRNNCell(nn.Module):
             return self._forward_small(X, h0, train=True)
         if self._use_horner(X, h0):
             return self._forward_horner(X, h0)
+        if X.dtype != self.weight_A.dtype:      # e.g. bf16 batches meeting fp32 master weights in a variant without fused
+            X, h0 = X.to(self.weight_A.dtype), h0.to(self.weight_A.dtype)      # kernels: the composed path runs in the parameters' dtype
         Xn = ops.pack_node_major(X)                                     # T x N x B x G
         h0n = ops.pack_node_major(h0.reshape(B, 1, self.F, N))          # 1 x N x B x F
         ya = ops.lsigf_node_major(Xn, self.weight_A, self.bias, self.graph, 1.0)      # all t at once
