@@ -153,6 +153,63 @@ __global__ __launch_bounds__(256) void seq_layout16_kernel(const uint16_t* __res
   }
 }
 
+// Pack of a range of time steps with a small LDS footprint (4.2 KiB): meant to run on a SECOND stream beside the step
+// kernels, whose one workgroup per CU leaves only a few KiB of LDS (and ~40 VGPRs per lane) free -- the packs of steps
+// t+1.. then hide behind the recurrence of steps ..t instead of preceding it. 32 (c) x 64 (n) tiles: 128-byte reads along n,
+// 64-byte writes along c (two workgroups complete each 128-byte row). bf16, no permutation, even N and C.
+__global__ __launch_bounds__(256) void seq_pack16_small_kernel(const uint16_t* __restrict__ src, uint16_t* __restrict__ dst,
+                                                               int B, int Tn, int C, int N, int NPad, int t0, int nt, int ntx,
+                                                               int nty, int ntiles) {
+  __shared__ uint16_t tile[32][66];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int cp = threadIdx.x & 15, nr = threadIdx.x >> 4;        // write side: 16 column pairs x 16 rows per pass
+  // a bounded grid walks the tiles: the kernel is meant to trickle along beside the step kernels, not to race them for HBM
+  for (int tl = blockIdx.x; tl < ntiles; tl += gridDim.x) {
+    const int bx = tl % ntx, rest = tl / ntx, by = rest % nty, bt = rest / nty;
+    const int n0 = bx * 64, c0 = by * 32;
+    const int b = bt / nt, t = t0 + (bt - b * nt);
+    const int64_t ubase = ((int64_t)(b * Tn + t) * C) * N;
+    const int64_t sbase = ((int64_t)(t * B + b) * NPad) * C;
+    const int n = n0 + 2 * tx;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int c = c0 + ty + 8 * i;
+      uint32_t v = 0;
+      if (c < C && n < N) v = *reinterpret_cast<const uint32_t*>(src + ubase + (int64_t)c * N + n);
+      *reinterpret_cast<uint32_t*>(&tile[ty + 8 * i][2 * tx]) = v;
+    }
+    __syncthreads();
+    const int c = c0 + 2 * cp;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int nl = nr + 16 * i, nn = n0 + nl;
+      if (nn < NPad && c < C) {
+        const uint32_t v = (uint32_t)tile[2 * cp][nl] | ((uint32_t)tile[2 * cp + 1][nl] << 16);
+        *reinterpret_cast<uint32_t*>(dst + sbase + (int64_t)nn * C + c) = v;     // rows >= N receive the zeros
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// steps [t0, t1) of the bf16 pack only, on the small-footprint kernel above; max_blocks > 0 bounds the grid
+extern "C" int gcrnn_pack_seq_major_steps(const void* src, void* dst, int64_t B, int64_t T, int64_t C, int64_t N, int64_t NPad,
+                                          int64_t t0, int64_t t1, int64_t max_blocks, void* stream) {
+  if (!src || !dst) return GCRNN_ERR_NULL_POINTER;
+  if (B <= 0 || T <= 0 || C <= 0 || N <= 0 || NPad < N || t0 < 0 || t1 > T || t0 >= t1) return GCRNN_ERR_BAD_SHAPE;
+  if ((N % 2) || (C % 2) || ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 3)) return GCRNN_ERR_UNSUPPORTED;
+  const int64_t ntx = cdiv(NPad, 64), nty = cdiv(C, 32), ntiles = ntx * nty * B * (t1 - t0);
+  if (ntiles > 2147483647LL) return GCRNN_ERR_BAD_SHAPE;
+  int64_t grid = ntiles;
+  if (max_blocks > 0 && grid > max_blocks) grid = max_blocks;
+  GCRNN_PRE_LAUNCH();
+  seq_pack16_small_kernel<<<(unsigned)grid, 256, 0, as_stream(stream)>>>((const uint16_t*)src, (uint16_t*)dst, (int)B, (int)T, (int)C,
+                                                                          (int)N, (int)NPad, (int)t0, (int)(t1 - t0), (int)ntx,
+                                                                          (int)nty, (int)ntiles);
+  GCRNN_CHECK_LAUNCH();
+  return GCRNN_OK;
+}
+
 template <bool PACK>
 static int seq_layout_launch(int dtype, const void* src, void* dst, int64_t B, int64_t T, int64_t C, int64_t N,
                              int64_t NPad, const int32_t* perm, void* stream) {
@@ -751,7 +808,7 @@ static int fused_launch_t(int mode /*0 plain, 1 gated, 2 gate pre-pass, 3 BPTT d
                           const void* h0, void* hs, const void* wpack, const float* bias, const float* gi, const float* gf,
                           const float* gate_w, float* gate_out, const FusedGraphArgs& ga, int64_t B, int64_t T, int64_t N,
                           hipStream_t st, const void* bw_dHs = nullptr, const void* bw_hs = nullptr, const void* bw_h0 = nullptr,
-                          void* bw_dh0 = nullptr, void* huser = nullptr) {
+                          void* bw_dh0 = nullptr, void* huser = nullptr, void* const* step_events = nullptr) {
   constexpr int F = 32 * HS, G = 32 * XS, KS = HS + XS;
   const size_t base = (size_t)NP * FC * 4 + (size_t)K * KS * 1024;
   const size_t resident_bytes = base + (size_t)ga.entries * 16 * 6;
@@ -824,6 +881,8 @@ static int fused_launch_t(int mode /*0 plain, 1 gated, 2 gate pre-pass, 3 BPTT d
     const unsigned grid = grid_for(B);
     for (int64_t t = 0; t < T; ++t) {
       const uint16_t* hp = (t == 0) ? (const uint16_t*)h0 : h + (t - 1) * hstep;
+      // step_events[t] (or null): the launch of step t first waits for that event -- x_t is being packed on another stream
+      if (step_events && step_events[t] && hipStreamWaitEvent(st, (hipEvent_t)step_events[t], 0) != hipSuccess) return GCRNN_ERR_LAUNCH;
       kern<<<grid, STHREADS, lds, st>>>(x + t * xstep, hp, h + t * hstep, (const uint4*)wpack, bias, mode == 1 ? gi + t * B : nullptr,
                                    mode == 1 ? gf + t * B : nullptr, ga.tile_nodes, ga.tile_off, ga.ell_col, ga.ell_val,
                                    (const float4*)ga.ell_val4, (const uint2*)ga.ell_col4, nullptr, nullptr, nullptr,
@@ -839,11 +898,11 @@ static int fused_dispatch(int mode, const void* xs, const void* h0, void* hs, co
                           const float* gi, const float* gf, const float* gate_w, float* gate_out, const FusedGraphArgs& ga,
                           int64_t B, int64_t T, int64_t N, int64_t F, int64_t G, int64_t K, hipStream_t st,
                           const void* bw_dHs = nullptr, const void* bw_hs = nullptr, void* bw_dh0 = nullptr,
-                          void* huser = nullptr, const void* bw_h0 = nullptr) {
+                          void* huser = nullptr, const void* bw_h0 = nullptr, void* const* step_events = nullptr) {
 #define GCRNN_FUSED_CASE(KK, HH, XX) \
   if (K == KK && F == 32 * HH && G == 32 * XX) \
     return fused_launch_t<KK, HH, XX>(mode, xs, h0, hs, wpack, bias, gi, gf, gate_w, gate_out, ga, B, T, N, st, bw_dHs, \
-                                      bw_hs, bw_h0, bw_dh0, huser);
+                                      bw_hs, bw_h0, bw_dh0, huser, step_events);
   GCRNN_FUSED_CASE(5, 2, 2)
   GCRNN_FUSED_CASE(4, 2, 2)
   GCRNN_FUSED_CASE(3, 2, 2)
@@ -870,7 +929,8 @@ extern "C" int gcrnn_fused_forward_bf16(const void* xs, const void* h0, void* hs
                                         const float* gi, const float* gf, const int32_t* tile_nodes,
                                         const int32_t* tile_off, const int32_t* ell_col, const float* ell_val,
                                         const void* ell_val4, const void* ell_col4, int64_t entries, int64_t B,
-                                        int64_t T, int64_t N, int64_t F, int64_t G, int64_t K, void* Huser, void* stream) {
+                                        int64_t T, int64_t N, int64_t F, int64_t G, int64_t K, void* Huser,
+                                        void* const* step_events, void* stream) {
   if (!xs || !h0 || !hs || !wpack || !tile_nodes || !tile_off || !ell_col || !ell_val) return GCRNN_ERR_NULL_POINTER;
   if ((gi == nullptr) != (gf == nullptr)) return GCRNN_ERR_NULL_POINTER;
   if (B <= 0 || T <= 0 || N <= 0 || N > NP || B > (1 << 24) || entries < 0 || entries % 4) return GCRNN_ERR_BAD_SHAPE;
@@ -878,7 +938,7 @@ extern "C" int gcrnn_fused_forward_bf16(const void* xs, const void* h0, void* hs
   if (Huser && (N % 8 != 0 || (reinterpret_cast<uintptr_t>(Huser) & 15))) return GCRNN_ERR_BAD_SHAPE;
   const FusedGraphArgs ga{tile_nodes, tile_off, ell_col, ell_val, ell_val4, ell_col4, entries};
   return fused_dispatch(gi ? 1 : 0, xs, h0, hs, wpack, bias, gi, gf, nullptr, nullptr, ga, B, T, N, F, G, K, as_stream(stream),
-                        nullptr, nullptr, nullptr, Huser);
+                        nullptr, nullptr, nullptr, Huser, nullptr, step_events);
 }
 
 extern "C" int gcrnn_fused_gate_prepass_bf16(const void* xs, const void* h0, const void* wpack, const float* bias,

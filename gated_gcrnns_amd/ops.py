@@ -260,10 +260,8 @@ def time_fused_step_kernel(X, h0, wA, wB, bias, graph, reps=3):
     torch.cuda.synchronize()
     e0.record()
     for _ in range(reps):
-        check(lib.gcrnn_fused_forward_bf16(_p(xs), _p(h0s), _p(hs), _p(wpack), _p(b32), None, None,
-                                           _p(plan['tile_slots']), _p(plan['tile_off']), _p(plan['ell_addr']),
-                                           _p(plan['ell_val']), _p(plan['ell_val4']), _p(plan['ell_col4']),
-                                           plan['entries'], B, T, N, F, G, K, _p(H) if H is not None else None, st),
+        check(lib.gcrnn_fused_forward_bf16(_p(xs), _p(h0s), _p(hs), _p(wpack), _p(b32), None, None, *_fused_graph_args(plan),
+                                           B, T, N, F, G, K, _p(H) if H is not None else None, None, st),
               'fused_forward')
     e1.record()
     torch.cuda.synchronize()
@@ -286,10 +284,23 @@ def _fused_graph_args(plan):
             _p(plan['ell_val4']), _p(plan['ell_col4']), plan['entries'])
 
 
-def fused_pack_inputs(X, h0, graph):
+_SIDE_STREAMS = {}
+
+
+def _side_stream(dev):
+    s = _SIDE_STREAMS.get(dev)
+    if s is None:
+        s = _SIDE_STREAMS[dev] = torch.cuda.Stream(device=dev)
+    return s
+
+
+def fused_pack_inputs(X, h0, graph, overlap=False):
     """user-layout bf16 X [B][T][G][N], h0 [B][F][N] -> sequence-major xs [T][B][NPad][G] and the state buffer
     hs_all [T+1][B][NPad][F] whose slot 0 holds h0 (slots 1..T receive h_1..h_T: hs_all[:T] is then the h_{t-1} operand of
-    every step, which the gate-gradient pass reads as one array)."""
+    every step, which the gate-gradient pass reads as one array).
+    overlap: only step 0 is packed on the current stream; every later step is packed on a side stream by a kernel small
+    enough (4 KiB of LDS, bounded grid) to run beside the step kernels, each followed by an event. Returns (xs, hs_all,
+    events) with events[t] = the event step t's launch has to wait for -- the recurrence starts after 1/T of the pack."""
     B, T, G, N = X.shape
     F = h0.shape[1]
     npad = graph.fused_plan()['npad']
@@ -297,9 +308,39 @@ def fused_pack_inputs(X, h0, graph):
     Xc, h0c = X.contiguous(), h0.contiguous()
     xs = torch.empty((T, B, npad, G), dtype=torch.bfloat16, device=X.device)
     hs_all = torch.empty((T + 1, B, npad, F), dtype=torch.bfloat16, device=X.device)
-    check(lib.gcrnn_pack_seq_major(_lib.BF16, _p(Xc), _p(xs), B, T, G, N, npad, None, st), 'pack_seq')
     check(lib.gcrnn_pack_seq_major(_lib.BF16, _p(h0c), _p(hs_all), B, 1, F, N, npad, None, st), 'pack_seq')
-    return xs, hs_all
+    if not overlap:
+        check(lib.gcrnn_pack_seq_major(_lib.BF16, _p(Xc), _p(xs), B, T, G, N, npad, None, st), 'pack_seq')
+        return xs, hs_all
+    main = torch.cuda.current_stream(X.device)
+    side = _side_stream(X.device)
+    check(lib.gcrnn_pack_seq_major_steps(_p(Xc), _p(xs), B, T, G, N, npad, 0, 1, 0, st), 'pack_seq_steps')
+    ready = torch.cuda.Event()
+    ready.record(main)                                   # X and the fresh buffers are valid on the main stream from here on
+    side.wait_event(ready)
+    events = [None] * T
+    sst = C.c_void_p(side.cuda_stream)
+    # one workgroup per CU walks the tiles of a step: measured on MI355X the side-stream pack of step t+1 then takes about as
+    # long as step t (118 us vs 120 us at B = 256) and slows it by 9 %; an unbounded grid starves the step kernels of memory
+    # bandwidth (steps 1.2x .. 3.2x slower: no net gain), half the grid makes the pack the bottleneck
+    blocks = int(os.environ.get('GCRNN_PACK_BLOCKS', torch.cuda.get_device_properties(X.device).multi_processor_count))
+    for t in range(1, T):
+        check(lib.gcrnn_pack_seq_major_steps(_p(Xc), _p(xs), B, T, G, N, npad, t, t + 1, blocks, sst), 'pack_seq_steps')
+        ev = torch.cuda.Event()
+        ev.record(side)
+        events[t] = ev
+    Xc.record_stream(side)
+    xs.record_stream(side)
+    return xs, hs_all, events
+
+
+def fused_overlap_ok(X):
+    """The overlapped pack (opt-in: GCRNN_FUSED_OVERLAP=1) needs even N and G (4-byte accesses), more than one step, and no
+    stream capture in progress. Off by default: measured on MI355X it gains 3 % when the two streams happen to share the CUs
+    well (4.04 -> 3.90 ms per forward at B = 256) and loses up to 2x when they do not (same binary, another run) -- DESIGN 4.3."""
+    B, T, G, N = X.shape
+    return (T > 1 and N % 2 == 0 and G % 2 == 0 and os.environ.get('GCRNN_FUSED_OVERLAP', '0') == '1'
+            and not torch.cuda.is_current_stream_capturing())
 
 
 def fused_time_gate(xs, h0s, wA_g, wB_g, bias_g, lin_w, lin_b, graph, N, store_states=False):
@@ -346,7 +387,13 @@ def fused_cell_forward(X, h0, wA, wB, bias, graph, gates=None, return_states=Fal
     dev = X.device
     X = X.contiguous()
     h0 = h0.contiguous()
-    xs, hs_all = packed if packed is not None else fused_pack_inputs(X, h0, graph)
+    events = None
+    if packed is not None:
+        xs, hs_all = packed
+    elif gates is None and fused_overlap_ok(X):          # (the gate pre-passes read every x_t at once: nothing to hide behind)
+        xs, hs_all, events = fused_pack_inputs(X, h0, graph, overlap=True)
+    else:
+        xs, hs_all = fused_pack_inputs(X, h0, graph)
     h0s, hs = hs_all[:1], hs_all[1:]
     gi = gf = None
     if gate_values is not None:
@@ -365,8 +412,11 @@ def fused_cell_forward(X, h0, wA, wB, bias, graph, gates=None, return_states=Fal
     b32 = bias.detach().float().contiguous().view(-1) if bias is not None else None
     H = torch.empty((B, T, F, N), dtype=torch.bfloat16, device=dev)
     direct = (N % 8 == 0)                 # the step kernels write the user layout themselves (16-byte row stores)
+    evs = None
+    if events is not None:                               # raw hipEvent_t handles, one slot per step (host array, read during the call)
+        evs = (C.c_void_p * T)(*[(e.cuda_event if e is not None else None) for e in events])
     check(lib.gcrnn_fused_forward_bf16(_p(xs), _p(h0s), _p(hs), _p(wpack), _p(b32), _p(gi), _p(gf), *_fused_graph_args(plan),
-                                       B, T, N, F, G, K, _p(H) if direct else None, st), 'fused_forward')
+                                       B, T, N, F, G, K, _p(H) if direct else None, evs, st), 'fused_forward')
     if not direct:
         check(lib.gcrnn_unpack_seq_major(_lib.BF16, _p(hs), _p(H), B, T, F, N, plan['npad'], None, st), 'unpack_seq')
     if return_states:

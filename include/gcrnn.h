@@ -137,6 +137,12 @@ int gcrnn_pack_seq_major(int dtype, const void* src, void* dst, int64_t B, int64
                          int64_t NPad, const int32_t* perm, void* stream);
 int gcrnn_unpack_seq_major(int dtype, const void* src, void* dst, int64_t B, int64_t T, int64_t C, int64_t N,
                            int64_t NPad, const int32_t* perm, void* stream);
+/* The bf16 pack (no permutation; N and C even) of the time steps [t0, t1) only, on a kernel with a 4 KiB LDS footprint:
+ * issued on a second stream it runs beside the step kernels (one workgroup per CU, a few KiB of LDS left), so the packs of
+ * later steps hide behind the recurrence of earlier ones (gcrnn_fused_forward_bf16's step_events). */
+int gcrnn_pack_seq_major_steps(const void* src, void* dst, int64_t B, int64_t T, int64_t C, int64_t N, int64_t NPad,
+                               int64_t t0, int64_t t1, int64_t max_blocks /* > 0: bound on the grid (the tiles are walked) */,
+                               void* stream);
 /* weight_A [F][Kin][G] and weight_B [F][Kst][F] (E = 1; wdtype GCRNN_F32 or GCRNN_BF16) -> bf16 MFMA A-operand
  * fragments wpack[F/16][K][(F+G)/32][64 lanes][8], K = max(Kin, Kst), missing taps zero. */
 int gcrnn_fused_pack_weights(int wdtype, const void* wA, const void* wB, void* wpack, int64_t F, int64_t G,
@@ -148,12 +154,14 @@ int gcrnn_fused_pack_weights(int wdtype, const void* wA, const void* wB, void* w
  * ell_val4 / ell_col4 = device copies of gcrnn_ell_pack_lds's output (may be NULL).
  * Huser (may be NULL; needs N % 8 == 0): the states are ALSO written in the user layout H[B][T][F][N] by the step kernels
  * themselves (LDS-transposed 16-byte row stores), which replaces gcrnn_unpack_seq_major over the whole sequence.
- * T launches on `stream`. The graph is kept resident in LDS when 64 KiB + weights + 96*entries B <= 160 KiB. */
+ * T launches on `stream`. The graph is kept resident in LDS when 64 KiB + weights + 96*entries B <= 160 KiB.
+ * step_events (or NULL): host array of T hipEvent_t (entries may be NULL); the launch of step t first makes `stream` wait for
+ * step_events[t] -- xs[t] is then allowed to be produced on another stream while earlier steps run. */
 int gcrnn_fused_forward_bf16(const void* xs, const void* h0, void* hs, const void* wpack, const float* bias,
                              const float* gi, const float* gf, const int32_t* tile_nodes, const int32_t* tile_off,
                              const int32_t* ell_col, const float* ell_val, const void* ell_val4, const void* ell_col4,
                              int64_t entries, int64_t B, int64_t T, int64_t N, int64_t F, int64_t G, int64_t K,
-                             void* Huser, void* stream);
+                             void* Huser, void* const* step_events, void* stream);
 
 /* Time-gate pre-pass (graphML.py:2357-2374): for every (t, b)
  *   sum over gate_out[t][b][0 .. F/16*8) = sum_{n,f} tanh( A_g(S) x_t + B_g(S) h0 + 2 b_g )[n][f] * gate_w[n][f]

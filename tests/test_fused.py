@@ -519,3 +519,27 @@ def test_fused_cell_with_few_input_features(N, G, F, K, B, T, tg):
         s = float(gr.abs().max())
         e = (g - gr).abs()
         assert s > 0 and float(e.max()) <= 4e-2 * s and (e.numel() < 16 or float(e.mean()) <= 8e-3 * s), (n, float(e.max()) / s, float(e.mean()) / s)
+
+
+@pytest.mark.gpu
+def test_fused_forward_with_side_stream_pack_is_bit_identical(monkeypatch):
+    """GCRNN_FUSED_OVERLAP=1: steps 1.. of the input are packed on a second stream beside the step kernels, every step launch
+    waits for its event (gcrnn_pack_seq_major_steps, step_events of gcrnn_fused_forward_bf16). Same bits as the plain order."""
+    import gated_gcrnns_amd.Utils.graphML as gml
+    dev = torch.device('cuda:0')
+    N, F, K, B, T = 1000, 64, 3, 40, 9
+    S = random_graph(N, 0.01, 83)
+    torch.manual_seed(37)
+    cell = gml.GGCRNNCell(F, F, K, K, torch.tanh, False, None, 1, True)
+    cell.addGSO(torch.tensor(S))
+    cell = cell.to(dev).to(torch.bfloat16)
+    X = torch.randn(B, T, F, N, device=dev).to(torch.bfloat16)
+    h0 = (0.3 * torch.randn(B, F, N, device=dev)).to(torch.bfloat16)
+    with torch.no_grad():
+        ref = cell(X, h0)
+        monkeypatch.setenv('GCRNN_FUSED_OVERLAP', '1')
+        for blocks in ('256', '7'):
+            monkeypatch.setenv('GCRNN_PACK_BLOCKS', blocks)
+            out = cell(X, h0)
+            torch.cuda.synchronize()
+            assert torch.equal(out, ref), blocks
