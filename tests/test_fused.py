@@ -310,7 +310,8 @@ def _gated_pair(N, F, K, S, seed, dev, master=torch.float32):
 @pytest.mark.parametrize('N,F,K,B,T,master', [(1000, 64, 5, 6, 5, torch.float32), (200, 32, 3, 9, 4, torch.float32),
                                               (600, 64, 3, 4, 3, torch.bfloat16), (1000, 64, 2, 3, 3, torch.float32),
                                               (304, 32, 5, 4, 3, torch.float32), (200, 32, 2, 5, 3, torch.float32),
-                                              (1000, 64, 4, 3, 3, torch.float32)])     # every (K, F) the fused kernels are built for
+                                              (1000, 64, 4, 3, 3, torch.float32),      # every (K, F) the fused kernels are built for
+                                              (200, 32, 3, 1, 1, torch.float32), (1024, 64, 2, 2, 1, torch.float32)])   # T = 1, B = 1, N = NPad
 def test_fused_time_gated_training_matches_composed_autograd(N, F, K, B, T, master):
     """Time-gated cell, bf16 activations: forward, both gate sub-networks and the whole BPTT run on the fused kernels
     (ops.fused_cell_train) and reproduce the fp32 autograd gradients of the composed path for EVERY trained parameter --
