@@ -40,6 +40,9 @@ constexpr int NP = WAVES * TILES * 16;   // 1024 padded nodes
 #ifndef GCRNN_STEP_WAVES
 #define GCRNN_STEP_WAVES 8
 #endif
+#ifndef GCRNN_P1_GROUP
+#define GCRNN_P1_GROUP 2      // tiles that share a weight fragment in phase 1 of the step kernel (1, 2 or 4)
+#endif
 constexpr int SWAVES = GCRNN_STEP_WAVES;      // step kernel: waves per workgroup ...
 constexpr int STILES = NP / 16 / SWAVES;      // ... and node tiles per wave
 constexpr int STHREADS = 64 * SWAVES;
@@ -536,50 +539,74 @@ __global__ __launch_bounds__(STHREADS) void fused_step_kernel(
       bfr[i][HS + s] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, rox + 64 * s, soff_x, 0));
 #endif
   }
+#if !defined(GCRNN_ABLATE_P1_MFMA)
+  // GP tiles share every weight fragment: 1/GP of the A-operand LDS reads and GP independent MFMA chains per tap
+  // (GP = 2: 248 VGPRs, -3 us per launch; GP = 4 spills in some instantiations -- tools/p1pair_ab.sh)
+  {
+    constexpr int GP = GCRNN_P1_GROUP;
+    static_assert(STILES % GP == 0, "tile groups");
+#pragma unroll
+    for (int i = 0; i < STILES; i += GP) {
+#pragma unroll
+      for (int tap = 0; tap < K; ++tap) {
+        f32x4 accg[GP];
+#pragma unroll
+        for (int p = 0; p < GP; ++p) accg[p] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < HS; ++s) {
+          const bf16x8 a = __builtin_bit_cast(bf16x8, wl[(tap * KS + s) * 64 + lane]);
+#pragma unroll
+          for (int p = 0; p < GP; ++p) accg[p] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bfr[i + p][s], accg[p], 0, 0, 0);
+        }
+        // time-gated cell: gi (x W_x) + gf (h W_h) on ONE accumulator: h-chain, scale by gf/gi, continue the chain with x, scale
+        // by gi (gi = sigmoid(.) > 0; the wave-uniform guard covers an underflowed gate)
+        const bool xpart = !GATED || gin > 1e-30f;
+        if (GATED) {
+#pragma unroll
+          for (int p = 0; p < GP; ++p) accg[p] *= (xpart ? gratio : gfo);
+        }
+        if (xpart) {
+#pragma unroll
+          for (int s = HS; s < KS; ++s) {
+            const bf16x8 a = __builtin_bit_cast(bf16x8, wl[(tap * KS + s) * 64 + lane]);
+#pragma unroll
+            for (int p = 0; p < GP; ++p) accg[p] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bfr[i + p][s], accg[p], 0, 0, 0);
+          }
+          if (GATED) {
+#pragma unroll
+            for (int p = 0; p < GP; ++p) accg[p] *= gin;
+          }
+        }
+#pragma unroll
+        for (int p = 0; p < GP; ++p) {
+          if (tap == K - 1) {
+            int wv = woff[i + p];
+            asm volatile("" : "+v"(wv));      // opaque: the masked LDS offsets are not hoisted out of the tile loop
+            *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(state) + (wv & 0xffff)) = accg[p];
+          } else {
+            u[i + p][tap] = accg[p];
+          }
+        }
+      }
+    }
+  }
+#else      // profiling build (tools/ablate.sh): the MFMAs replaced by a few adds on the loaded fragments; results are wrong
 #pragma unroll
   for (int i = 0; i < STILES; ++i) {
 #pragma unroll
     for (int tap = 0; tap < K; ++tap) {
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-      if (GATED) {
-        // gi (x W_x) + gf (h W_h) on ONE accumulator: h-chain, scale by gf/gi, continue the chain with x, scale by gi.
-        // (gi = sigmoid(.) > 0; the wave-uniform guard covers an underflowed gate.)
 #pragma unroll
-        for (int s = 0; s < HS; ++s) {
-          const bf16x8 a = __builtin_bit_cast(bf16x8, wl[(tap * KS + s) * 64 + lane]);
-          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bfr[i][s], acc, 0, 0, 0);
-        }
-        if (gin > 1e-30f) {
-          acc *= gratio;
-#pragma unroll
-          for (int s = HS; s < KS; ++s) {
-            const bf16x8 a = __builtin_bit_cast(bf16x8, wl[(tap * KS + s) * 64 + lane]);
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bfr[i][s], acc, 0, 0, 0);
-          }
-          acc *= gin;
-        } else {
-          acc *= gfo;
-        }
-      } else {
-#ifdef GCRNN_ABLATE_P1_MFMA
-#pragma unroll
-        for (int s = 0; s < KS; ++s) { const f32x4 t = __builtin_bit_cast(f32x4, bfr[i][s]); acc += t * (float)(tap + 1); }
-#else
-#pragma unroll
-        for (int s = 0; s < KS; ++s) {
-          const bf16x8 a = __builtin_bit_cast(bf16x8, wl[(tap * KS + s) * 64 + lane]);
-          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bfr[i][s], acc, 0, 0, 0);
-        }
-#endif
-      }
+      for (int s = 0; s < KS; ++s) { const f32x4 t = __builtin_bit_cast(f32x4, bfr[i][s]); acc += t * (float)(tap + 1); }
       if (tap == K - 1) {
         int wv = woff[i];
-        asm volatile("" : "+v"(wv));      // opaque: the masked LDS offsets are not hoisted out of the tile loop
+        asm volatile("" : "+v"(wv));
         *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(state) + (wv & 0xffff)) = acc;
       }
       else u[i][tap] = acc;
     }
   }
+#endif
 #endif
   __syncthreads();
 
