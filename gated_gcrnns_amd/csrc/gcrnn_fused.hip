@@ -1172,7 +1172,11 @@ __global__ __launch_bounds__(512, 2) void fused_wgrad_kernel(
       }
       __syncthreads();
       // S4: du_{k+1} = S du_k (reads `state`; the transposed image of du_k stays valid);  S5: second half of the contraction
+#ifdef GCRNN_WGRAD_ABLATE_HOP      // profiling builds (tools/wgrad_ablate.sh): results are wrong by construction
+      if (false) {
+#else
       if (k < K - 1) {
+#endif
 #ifdef GCRNN_WGRAD_PLAIN_HOP
 #pragma unroll
         for (int i = 0; i < TILES; ++i) {
@@ -1203,7 +1207,11 @@ __global__ __launch_bounds__(512, 2) void fused_wgrad_kernel(
           bf16x8 bl[8];
 #pragma unroll
           for (int s2 = 0; s2 < 8; ++s2)
+#ifdef GCRNN_WGRAD_ABLATE_REFETCH
+            bl[s2] = bfr[8 * h2 + s2];
+#else
             bl[s2] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsrc_z, vo + 64 * (16 + 8 * h2 + s2), 0, 0));
+#endif
           bf16x8 al[8];
 #pragma unroll
           for (int s2 = 0; s2 < 8; ++s2)
