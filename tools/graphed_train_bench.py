@@ -16,7 +16,8 @@ S = dataTools.normalised_gso(W)
 data = dataTools.KStepPrediction(W, 5, 400, 10, 10, horizon=10, rng=rng)
 xT, yT = data.getSamples('train')
 x = xT[:100].view(100, 5, 1, 80).to(dev); y = yT[:100].view(100, 5, 1, 80).to(dev)
-for name, tg, sg in (('GCRNNMLP', False, None), ('TimeGCRNNMLP', True, None), ('NodeGCRNNMLP', False, 'node')):
+for name, tg, sg in (('GCRNNMLP', False, None), ('TimeGCRNNMLP', True, None), ('NodeGCRNNMLP', False, 'node'),
+                     ('EdgeGCRNNMLP', False, 'edge')):
     res = {}
     for mode in ('eager', 'hipgraph'):
         torch.manual_seed(0)
