@@ -1,0 +1,702 @@
+// Fused GCRNN time step for gfx950 (CDNA4): the flagship path (N <= 1024 nodes, bf16 storage, fp32 accumulate).
+//
+// One launch = one time step t for a whole batch:
+//     h_t = tanh( gi * (A(S) x_t + b) + gf * (B(S) h_{t-1} + b) )                (reference graphML.py:2420-2423)
+// One workgroup (512 threads = 8 waves, 2 per SIMD) owns one (sequence b, 16-feature output chunk c).
+//
+// Algebra.  With P = S^T acting on node-major rows and W_k = [B_k | A_k] (F x (F+G)) the step is
+//     pre = sum_k P^k ([h|x] W_k^T)  + 2b          (taps and shifts commute: they act on different axes)
+// evaluated in Horner form   acc = u_{K-1};  acc = P acc + u_{K-2}; ... ; acc = P acc + u_0,
+// u_k = [h|x] W_k^T restricted to the chunk's 16 output features. x and h share one accumulator chain, so
+// only (K-1) hops over 16 channels are needed per chunk (the reference does 2(K-1) hops over G+F channels).
+//
+// Phase 1 (MFMA): u_k^T tile = W_k(chunk) [16 x 128] * [h|x]^T [128 x 16 nodes] with v_mfma_f32_16x16x32_bf16.
+//     A operand = weight fragments, pre-arranged per lane in LDS (one ds_read_b128 each);
+//     B operand = 8 consecutive bf16 features of one node, a 16-byte global load from the node-major row;
+//     D: lane holds 4 consecutive output features of node (lane & 15) -> exactly one 16-byte LDS slot.
+//     u_{K-1} goes to LDS, u_0..u_{K-2} stay in registers (8 tiles x K x 4 fp32 per lane).
+// Phase 2 (LDS gather): K-1 hops acc'[n] = sum_m P[n,m] acc[m] + u_k[n] on ONE fp32 [1024][16] image in LDS
+//     (64-byte rows): a hop's results stay in the tap's registers until every wave has finished reading, then
+//     are written back (two barriers per hop). That leaves room to keep the graph itself in LDS: a
+//     degree-sorted sliced ELL (16 nodes per slice, entries [e][16], u16 column + f32 weight), so the
+//     neighbour loop is wave-uniform, no gather ever waits on global memory, and each gather is one
+//     ds_read_b128 + 4 FMAs per lane. Graphs whose ELL does not fit are read from global memory instead.
+// Epilogue: + bias, tanh, bf16 store of the chunk into the node-major state h_t[b][n][c*16 .. +15].
+//
+// HBM traffic per (sequence, step): read x_t and h_{t-1} (each N*64*2 B; the 4 chunk workgroups of a sequence
+// are placed on one XCD so that three of the four reads hit its L2), write h_t: the compulsory
+// T*s*N*(G+2F) of SURVEY.md section 8d.
+#pragma once
+#include "gcrnn_common.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+
+namespace {
+constexpr int FC = 16;          // output features per workgroup
+constexpr int WAVES = 8;        // weight-gradient kernel: 8 waves x 8 tiles
+constexpr int TILES = 8;        // node tiles (16 nodes) per wave
+constexpr int NP = WAVES * TILES * 16;   // 1024 padded nodes
+#ifndef GCRNN_STEP_WAVES
+#define GCRNN_STEP_WAVES 8
+#endif
+#ifndef GCRNN_P1_GROUP
+#define GCRNN_P1_GROUP 2      // tiles that share a weight fragment in phase 1 of the step kernel (1, 2 or 4)
+#endif
+constexpr int SWAVES = GCRNN_STEP_WAVES;      // step kernel: waves per workgroup ...
+constexpr int STILES = NP / 16 / SWAVES;      // ... and node tiles per wave
+constexpr int STHREADS = 64 * SWAVES;
+}
+
+__device__ __forceinline__ uint16_t f2bf(float f) {
+  return __builtin_bit_cast(uint16_t, (__bf16)f);   // v_cvt_pk_bf16_f32: round-to-nearest-even, NaN-safe
+}
+__device__ __forceinline__ float bf2f(uint16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
+
+// tanh(x) = 1 - 2 / (1 + exp(2x)) on the hardware exp2/rcp units: abs error < 3e-7 for all x (inf-safe: exp -> inf
+// gives 1, exp -> 0 gives -1), far below the bf16 rounding of the stored state.
+__device__ __forceinline__ float fast_tanh(float x) {
+  const float e = __builtin_amdgcn_exp2f(x * 2.8853900817779268f);      // exp(2x)
+  return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + e);
+}
+// ------------------------------------------------------------------------------------------
+// the fused step
+// ------------------------------------------------------------------------------------------
+// Hand-pipelined LDS reads for the hop loop (cdna_hip_programming.md section 5.7): hipcc does not count asm loads,
+// so every wait below is ours. LDS ops of one wave return in order, hence lgkmcnt(N) = "all but the N youngest".
+#define DS_READ_B64(dst, addr) asm volatile("ds_read_b64 %0, %1" : "=v"(dst) : "v"(addr))
+#define DS_READ_B128(dst, addr) asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(addr))
+#define LGKM_WAIT(n)                                              \
+  do {                                                            \
+    asm volatile("s_waitcnt lgkmcnt(" #n ")" ::: "memory");       \
+    __builtin_amdgcn_sched_barrier(0);                            \
+  } while (0)
+#define KEEP_ALIVE(v) asm volatile("" ::"v"(v))
+
+// One gather trip of the resident pipeline: group g has its weights in VC and its 4 gathered quads in XC*;
+// issue cols(g+2) -> CC, then (after cols(g+1) = CN landed) vals(g+1) -> VN and the gathers of g+1 -> XN*;
+// then wait for VC / XC* (issued one trip earlier) and do the 16 FMAs. lgkmcnt(6): the 6 reads just issued may
+// stay in flight. E and O name the two ping-pong register sets. Uses the locals g, gwend, gwlast, colb, valb, lds0, qx.
+#define GCRNN_TRIP_WAIT LGKM_WAIT(6)
+#define GCRNN_TRIP_WAIT2 LGKM_WAIT(6)
+#define GCRNN_TRIP(ACC, CC, CN, VC, VN, XC0, XC1, XC2, XC3, XN0, XN1, XN2, XN3)                    \
+  do {                                                                                             \
+    const int g1_ = (g + 1 < gwend) ? g + 1 : gwlast, g2_ = (g + 2 < gwend) ? g + 2 : gwlast;      \
+    DS_READ_B64(CC, colb + g2_ * 128);                                                             \
+    GCRNN_TRIP_WAIT;                                                                               \
+    DS_READ_B128(VN, valb + g1_ * 256);                                                            \
+    DS_READ_B128(XN0, lds0 + (((uint32_t)CN & 0xffffu) ^ qx));                                     \
+    DS_READ_B128(XN1, lds0 + ((((uint32_t)CN >> 16) & 0xffffu) ^ qx));                             \
+    DS_READ_B128(XN2, lds0 + (((uint32_t)(CN >> 32) & 0xffffu) ^ qx));                             \
+    DS_READ_B128(XN3, lds0 + ((uint32_t)(CN >> 48) ^ qx));                                         \
+    GCRNN_TRIP_WAIT2;                                                                              \
+    ACC += VC[0] * XC0;                                                                            \
+    ACC += VC[1] * XC1;                                                                            \
+    ACC += VC[2] * XC2;                                                                            \
+    ACC += VC[3] * XC3;                                                                            \
+  } while (0)
+#define GCRNN_TRIP_E(ACC) GCRNN_TRIP(ACC, cE, cO, vE, vO, xE0, xE1, xE2, xE3, xO0, xO1, xO2, xO3)
+#define GCRNN_TRIP_O(ACC) GCRNN_TRIP(ACC, cO, cE, vO, vE, xO0, xO1, xO2, xO3, xE0, xE1, xE2, xE3)
+
+// One hop of one wave over the LDS-resident graph: acc_i = INIT(i) + sum over the neighbours of tile i's slots, for
+// the wave's TILES tiles. The tiles are stored back to back, so the whole hop is ONE continuous stream of groups:
+// the pipeline is primed once, runs across tile boundaries (only the accumulator changes) and is drained once.
+// Uses the locals tbeg, tend, lds_col, lds_val, lds0, qx, r.
+#define GCRNN_HOP_STREAM(INIT, STORE)                                                              \
+  do {                                                                                             \
+    const int gwbeg = tbeg[0] >> 2, gwend = tend[HT - 1] >> 2, gwlast = gwend - 1;              \
+    const uint32_t colb = lds_col + r * 8, valb = lds_val + r * 16;                                \
+    uint64_t cE = 0, cO = 0;                                                                       \
+    f32x4 vE, vO, xE0, xE1, xE2, xE3, xO0, xO1, xO2, xO3;                                          \
+    int g = gwbeg;                                                                                 \
+    int par = 0; /* 0: the current group sits in set E, 1: in set O (wave-uniform) */              \
+    if (gwbeg < gwend) {                                                                           \
+      DS_READ_B64(cE, colb + gwbeg * 128);                                                         \
+      DS_READ_B64(cO, colb + ((gwbeg + 1 < gwend) ? gwbeg + 1 : gwlast) * 128);                    \
+      DS_READ_B128(vE, valb + gwbeg * 256);                                                        \
+      LGKM_WAIT(2);                                                                                \
+      DS_READ_B128(xE0, lds0 + (((uint32_t)cE & 0xffffu) ^ qx));                                   \
+      DS_READ_B128(xE1, lds0 + ((((uint32_t)cE >> 16) & 0xffffu) ^ qx));                           \
+      DS_READ_B128(xE2, lds0 + (((uint32_t)(cE >> 32) & 0xffffu) ^ qx));                           \
+      DS_READ_B128(xE3, lds0 + ((uint32_t)(cE >> 48) ^ qx));                                       \
+    }                                                                                              \
+    _Pragma("unroll") for (int i = 0; i < HT; ++i) {                                               \
+      const int ge = tend[i] >> 2;                                                                 \
+      f32x4 acc = INIT(i);                                                                         \
+      if (g < ge) {                                                                                \
+        if (par) { GCRNN_TRIP_O(acc); ++g; par = 0; }                                              \
+        while (g < ge) {                                                                           \
+          GCRNN_TRIP_E(acc);                                                                       \
+          if (++g >= ge) { par = 1; break; }                                                       \
+          GCRNN_TRIP_O(acc);                                                                       \
+          ++g;                                                                                     \
+        }                                                                                          \
+      }                                                                                            \
+      STORE(i, acc);                                                                               \
+    }                                                                                              \
+    if (gwbeg < gwend) {                                                                           \
+      LGKM_WAIT(0); /* drain the tail prefetches before their registers may be reused */           \
+      KEEP_ALIVE(cE); KEEP_ALIVE(cO); KEEP_ALIVE(vE); KEEP_ALIVE(vO);                              \
+      KEEP_ALIVE(xE0); KEEP_ALIVE(xE1); KEEP_ALIVE(xE2); KEEP_ALIVE(xE3);                          \
+      KEEP_ALIVE(xO0); KEEP_ALIVE(xO1); KEEP_ALIVE(xO2); KEEP_ALIVE(xO3);                          \
+    }                                                                                              \
+  } while (0)
+
+// Same hop, but the pipeline is primed and drained per tile: nothing is in flight at the control-flow joins between
+// the unrolled tiles. Needed where register pressure makes hipcc insert copies of the ping-pong sets at those joins
+// (a copy of a register whose asm load has not landed yet captures stale data: cdna_hip_programming.md 5.7 item 1).
+#define GCRNN_HOP_TILED(INIT, STORE)                                                               \
+  do {                                                                                             \
+    const uint32_t colb = lds_col + r * 8, valb = lds_val + r * 16;                                \
+    _Pragma("unroll") for (int i = 0; i < HT; ++i) {                                               \
+      const int gwbeg = tbeg[i] >> 2, gwend = tend[i] >> 2, gwlast = gwend - 1;                    \
+      f32x4 acc = INIT(i);                                                                         \
+      if (gwbeg < gwend) {                                                                         \
+        uint64_t cE, cO;                                                                           \
+        f32x4 vE, vO, xE0, xE1, xE2, xE3, xO0, xO1, xO2, xO3;                                      \
+        DS_READ_B64(cE, colb + gwbeg * 128);                                                       \
+        DS_READ_B64(cO, colb + ((gwbeg + 1 < gwend) ? gwbeg + 1 : gwlast) * 128);                  \
+        DS_READ_B128(vE, valb + gwbeg * 256);                                                      \
+        LGKM_WAIT(2);                                                                              \
+        DS_READ_B128(xE0, lds0 + (((uint32_t)cE & 0xffffu) ^ qx));                                 \
+        DS_READ_B128(xE1, lds0 + ((((uint32_t)cE >> 16) & 0xffffu) ^ qx));                         \
+        DS_READ_B128(xE2, lds0 + (((uint32_t)(cE >> 32) & 0xffffu) ^ qx));                         \
+        DS_READ_B128(xE3, lds0 + ((uint32_t)(cE >> 48) ^ qx));                                     \
+        int g = gwbeg;                                                                             \
+        while (true) {                                                                             \
+          GCRNN_TRIP_E(acc);                                                                       \
+          if (++g >= gwend) break;                                                                 \
+          GCRNN_TRIP_O(acc);                                                                       \
+          if (++g >= gwend) break;                                                                 \
+        }                                                                                          \
+        LGKM_WAIT(0);                                                                              \
+        KEEP_ALIVE(cE); KEEP_ALIVE(cO); KEEP_ALIVE(vE); KEEP_ALIVE(vO);                            \
+        KEEP_ALIVE(xE0); KEEP_ALIVE(xE1); KEEP_ALIVE(xE2); KEEP_ALIVE(xE3);                        \
+        KEEP_ALIVE(xO0); KEEP_ALIVE(xO1); KEEP_ALIVE(xO2); KEEP_ALIVE(xO3);                        \
+      }                                                                                            \
+      STORE(i, acc);                                                                               \
+    }                                                                                              \
+  } while (0)
+
+// LDS map (dynamic): state [NP][16] fp32 (64 KiB) | weight fragments K*KS KiB | RESIDENT: lval4 (f32x4), lcol4 (u16x4).
+// Tiles hold 16 nodes of similar degree: tile_nodes[p] lists the node of every slot p (degree-sorted order,
+// padded with node ids >= N that have no edges); memory rows are in natural node order.
+// EPI: 0 = state epilogue (bias, tanh, bf16 store), 1 = time-gate pre-pass (dot-reduce; optionally also stores the
+// gate cell's state c = tanh(pre) for its BPTT), 2 = BPTT data-gradient step (optionally scaled by the forget gate),
+// 3 = gate-gradient pass: sum_{f,n} (filter output + b) * dpre of every item (the gradient w.r.t. a scalar time gate)
+template <int K, int HS, int XS, bool GATED, bool RESIDENT, int EPI = 0>
+__global__ __launch_bounds__(STHREADS) void fused_step_kernel(
+    const uint16_t* __restrict__ xt,        // [B][NP][G]   bf16
+    const uint16_t* __restrict__ hprev,     // [B][NP][F]   bf16
+    uint16_t* __restrict__ hout,            // [B][NP][F]   bf16
+    const uint4* __restrict__ wpack,        // [F/16][K][KS][64] x 16 B
+    const float* __restrict__ bias,         // [F] or null
+    const float* __restrict__ gi,           // [B] (GATED)
+    const float* __restrict__ gf,           // [B] (GATED); EPI 2: forget gate of the step being back-propagated, or null
+    const int32_t* __restrict__ tile_nodes, // [NP] node id of each tile slot
+    const int32_t* __restrict__ tile_off,   // [NP/16 + 1], in entries
+    const int32_t* __restrict__ ell_col,    // [entries][16] neighbour node id            (used when !RESIDENT)
+    const float* __restrict__ ell_val,      // [entries][16]
+    const float4* __restrict__ ell_val4,    // [entries/4][16] x 4 weights                  (LDS image, RESIDENT)
+    const uint2* __restrict__ ell_col4,     // [entries/4][16] x 4 u16 (row offset | swizzle)
+    const float* __restrict__ gate_w,       // GATEOUT: [N][F] node-major weights of the gate's Linear(N*F -> 1)
+    float* __restrict__ gate_out,           // GATEOUT: [B][F/16][8] per-(chunk, wave) partials of sum_{n,f} tanh(pre) * gate_w
+    const uint16_t* __restrict__ aux0,      // EPI 2: upstream gradient dH_{t-1} [B][NP][F] bf16 (or null); EPI 3: dpre [B][NP][F] bf16
+    const uint16_t* __restrict__ aux1,      // EPI 2: state h_{t-1} [B][NP][F] bf16;  EPI 0: user-layout output H[.][t][F][N] (or null)
+    int ubstride,                           // EPI 0: elements between consecutive sequences of the user-layout output (T*F*N)
+    int entries, int B, int hmod, int N) {
+  constexpr int KS = HS + XS;
+  constexpr int F = 32 * HS, G = 32 * XS;
+  constexpr int NCH = F / FC;
+  constexpr bool GATEOUT = (EPI == 1 || EPI == 3);      // per-item scalar outputs (partials per chunk and wave)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* state = reinterpret_cast<float*>(smem);
+  uint4* wl = reinterpret_cast<uint4*>(smem + NP * FC * 4);
+  // resident graph: per group of 4 entries and tile slot r:  lval4[g][r] = 4 weights, lcol4[g][r] = 4 x u16 = (col * 64)
+  float4* lval4 = reinterpret_cast<float4*>(smem + NP * FC * 4 + K * KS * 1024);
+  uint2* lcol4 = reinterpret_cast<uint2*>(lval4 + (RESIDENT ? entries * 4 : 0));
+
+  // XCD-aware placement: the NCH chunk workgroups of one sequence get block ids that are equal mod 8,
+  // i.e. one XCD under round-robin dispatch (speed only; nothing depends on it).
+  // Each workgroup stays on its CU for the whole launch and walks the sequences b0, b0 + SEQ_SLOTS, ...: weights and
+  // graph are staged into LDS once per launch, not once per sequence.
+  const int L = blockIdx.x;
+  const int grp = L / (8 * NCH), rem = L - grp * (8 * NCH);
+  const int chunk = rem >> 3, b0 = grp * 8 + (rem & 7);
+  const int seq_slots = (gridDim.x / (8 * NCH)) * 8;
+  if (b0 >= B) return;
+
+  constexpr int HT = STILES;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // provably wave-uniform -> scalar loads below
+  const int r = lane & 15, q = lane >> 4;
+
+  for (int i = tid; i < K * KS * 64; i += STHREADS) wl[i] = wpack[(int64_t)chunk * K * KS * 64 + i];
+  if (RESIDENT) {
+    const int n = (entries >> 2) * 16;                         // the host packed the LDS image: straight copies,
+    for (int i0 = 0; i0 < n; i0 += STHREADS * 4) {                  // 4 loads in flight per lane before the first LDS store
+      const int i_0 = i0 + tid, i_1 = i_0 + STHREADS, i_2 = i_0 + 2 * STHREADS, i_3 = i_0 + 3 * STHREADS, nl = n - 1;
+      const float4 tv0 = ell_val4[i_0 < n ? i_0 : nl], tv1 = ell_val4[i_1 < n ? i_1 : nl];
+      const float4 tv2 = ell_val4[i_2 < n ? i_2 : nl], tv3 = ell_val4[i_3 < n ? i_3 : nl];
+      const uint2 tc0 = ell_col4[i_0 < n ? i_0 : nl], tc1 = ell_col4[i_1 < n ? i_1 : nl];
+      const uint2 tc2 = ell_col4[i_2 < n ? i_2 : nl], tc3 = ell_col4[i_3 < n ? i_3 : nl];
+      if (i_0 < n) { lval4[i_0] = tv0; lcol4[i_0] = tc0; }
+      if (i_1 < n) { lval4[i_1] = tv1; lcol4[i_1] = tc1; }
+      if (i_2 < n) { lval4[i_2] = tv2; lcol4[i_2] = tc2; }
+      if (i_3 < n) { lval4[i_3] = tv3; lcol4[i_3] = tc3; }
+    }
+  }
+  // per-wave tile ranges, fetched once through the scalar path
+  int tbeg[STILES], tend[STILES];
+#pragma unroll
+  for (int i = 0; i < STILES; ++i) {
+    tbeg[i] = tile_off[wave * STILES + i];
+    tend[i] = tile_off[wave * STILES + i + 1];
+  }
+  f32x4 u[STILES][K - 1];   // taps 0..K-2 (tap K-1 seeds the LDS state directly); later: the hop results
+  int woff[STILES];      // low 16 bits: byte offset of this lane's quad in the (swizzled) state row of its node; high: node id
+#pragma unroll
+  for (int i = 0; i < STILES; ++i) woff[i] = tile_nodes[(wave * STILES + i) * 16 + r] ^ (q << 4);   // slot = node << 16 | row << 6 | swz << 4
+  float bvec[4] = {0.f, 0.f, 0.f, 0.f};
+  if (bias) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) bvec[c] = bias[chunk * FC + q * 4 + c];
+  }
+  __syncthreads();
+
+  // Row traffic goes through buffer instructions: descriptor in SGPRs (built from kernel arguments only, so provably
+  // wave-uniform), 32-bit lane offset, per-sequence base as the scalar offset -- no per-lane 64-bit pointers to keep
+  // alive (and spill) across the sequence loop.
+  const __amdgpu_buffer_rsrc_t rsrc_h = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(hprev), 0, hmod * (NP * F * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(xt), 0, B * (NP * G * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_o = __builtin_amdgcn_make_buffer_rsrc(hout, 0, hout ? B * (NP * F * 2) : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_a0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(aux0), 0, ((EPI == 2 || EPI == 3) && aux0) ? B * (NP * F * 2) : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_a1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(aux1), 0, (EPI == 2 && aux1) ? B * (NP * F * 2) : 0, 0x00020000);
+
+  for (int b = b0; b < B; b += seq_slots) {
+  const int soff_h = (b % hmod) * (NP * F * 2);     // hmod < B: every item of the gate pre-pass reads h0[b]
+  const int soff_x = b * (NP * G * 2);
+  float gin = 1.f, gfo = 1.f;
+  float gratio = 1.f;
+  if (GATED) { gin = gi[b]; gfo = gf[b]; gratio = gfo / fmaxf(gin, 1e-30f); }
+
+  // ---- phase 1: taps on the matrix cores ------------------------------------------------------
+#ifdef GCRNN_ABLATE_PHASE1      // profiling builds only (tools/ablate.sh): results are wrong by construction
+#pragma unroll
+  for (int i = 0; i < STILES; ++i)
+#pragma unroll
+    for (int tap = 0; tap < K - 1; ++tap) u[i][tap] = f32x4{0.f, 0.f, 0.f, (float)woff[i]};
+#else
+  // all B-operand fragments of the wave (8 tiles x 4 x 16 B per lane) are requested before the first MFMA: one
+  // memory latency per sequence instead of one per tile; the registers are free again before the taps fill up.
+  bf16x8 bfr[STILES][KS];
+#pragma unroll
+  for (int i = 0; i < STILES; ++i) {
+    int w = woff[i];
+    asm volatile("" : "+v"(w));      // opaque per iteration: keeps hipcc from hoisting (and spilling) 16+ row offsets
+    const int roh = (w >> 16) * (F * 2) + 16 * q, rox = (w >> 16) * (G * 2) + 16 * q;
+#pragma unroll
+#ifdef GCRNN_ABLATE_P1_LOADS
+    for (int s = 0; s < KS; ++s) bfr[i][s] = __builtin_bit_cast(bf16x8, uint4{(unsigned)roh, (unsigned)rox, (unsigned)s, 1u});
+#else
+    for (int s = 0; s < HS; ++s)
+      bfr[i][s] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsrc_h, roh + 64 * s, soff_h, 0));
+#pragma unroll
+    for (int s = 0; s < XS; ++s)
+      bfr[i][HS + s] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, rox + 64 * s, soff_x, 0));
+#endif
+  }
+#if !defined(GCRNN_ABLATE_P1_MFMA)
+  // GP tiles share every weight fragment: 1/GP of the A-operand LDS reads and GP independent MFMA chains per tap
+  // (GP = 2: 248 VGPRs, -3 us per launch; GP = 4 spills in some instantiations -- tools/p1pair_ab.sh)
+  {
+    constexpr int GP = GCRNN_P1_GROUP;
+    static_assert(STILES % GP == 0, "tile groups");
+#pragma unroll
+    for (int i = 0; i < STILES; i += GP) {
+#pragma unroll
+      for (int tap = 0; tap < K; ++tap) {
+        f32x4 accg[GP];
+#pragma unroll
+        for (int p = 0; p < GP; ++p) accg[p] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < HS; ++s) {
+          const bf16x8 a = __builtin_bit_cast(bf16x8, wl[(tap * KS + s) * 64 + lane]);
+#pragma unroll
+          for (int p = 0; p < GP; ++p) accg[p] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bfr[i + p][s], accg[p], 0, 0, 0);
+        }
+        // time-gated cell: gi (x W_x) + gf (h W_h) on ONE accumulator: h-chain, scale by gf/gi, continue the chain with x, scale
+        // by gi (gi = sigmoid(.) > 0; the wave-uniform guard covers an underflowed gate)
+        const bool xpart = !GATED || gin > 1e-30f;
+        if (GATED) {
+#pragma unroll
+          for (int p = 0; p < GP; ++p) accg[p] *= (xpart ? gratio : gfo);
+        }
+        if (xpart) {
+#pragma unroll
+          for (int s = HS; s < KS; ++s) {
+            const bf16x8 a = __builtin_bit_cast(bf16x8, wl[(tap * KS + s) * 64 + lane]);
+#pragma unroll
+            for (int p = 0; p < GP; ++p) accg[p] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bfr[i + p][s], accg[p], 0, 0, 0);
+          }
+          if (GATED) {
+#pragma unroll
+            for (int p = 0; p < GP; ++p) accg[p] *= gin;
+          }
+        }
+#pragma unroll
+        for (int p = 0; p < GP; ++p) {
+          if (tap == K - 1) {
+            int wv = woff[i + p];
+            asm volatile("" : "+v"(wv));      // opaque: the masked LDS offsets are not hoisted out of the tile loop
+            *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(state) + (wv & 0xffff)) = accg[p];
+          } else {
+            u[i + p][tap] = accg[p];
+          }
+        }
+      }
+    }
+  }
+#else      // profiling build (tools/ablate.sh): the MFMAs replaced by a few adds on the loaded fragments; results are wrong
+#pragma unroll
+  for (int i = 0; i < STILES; ++i) {
+#pragma unroll
+    for (int tap = 0; tap < K; ++tap) {
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < KS; ++s) { const f32x4 t = __builtin_bit_cast(f32x4, bfr[i][s]); acc += t * (float)(tap + 1); }
+      if (tap == K - 1) {
+        int wv = woff[i];
+        asm volatile("" : "+v"(wv));
+        *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(state) + (wv & 0xffff)) = acc;
+      }
+      else u[i][tap] = acc;
+    }
+  }
+#endif
+#endif
+  __syncthreads();
+
+  // L2 prefetch of the NEXT sequence of this workgroup: while the hops keep the LDS busy, every thread touches one
+  // 128-byte row (= one cache line) of [h | x]; the NCH chunk workgroups of a sequence share an XCD and split the
+  // 2 * NP rows between them. Phase 1 of the next sequence then streams from L2 instead of stalling on HBM.
+  uint32_t prefetched = 0;
+  if (b + seq_slots < B) {
+    constexpr int LINES = (XS > 0 ? 2 : 1) * NP;                         // rows of [h | x] (x absent in the BPTT step)
+    const int line = chunk * (LINES / NCH) + tid;                        // LINES / NCH == 512 for F = G = 64
+    if (tid < LINES / NCH) {
+      prefetched = (line < NP)
+          ? __builtin_amdgcn_raw_buffer_load_b32(rsrc_h, line * (F * 2), ((b + seq_slots) % hmod) * (NP * F * 2), 0)
+          : __builtin_amdgcn_raw_buffer_load_b32(rsrc_x, (line - NP) * (G * 2), (b + seq_slots) * (NP * G * 2), 0);
+    }
+  }
+
+  // ---- phase 2: Horner hops, state image in LDS -------------------------------------------------
+  const char* sbytes = reinterpret_cast<const char*>(state);
+  const int qoff = q * 16;
+  // 32-bit LDS byte addresses for the asm reads (low half of the flat LDS address = offset in the allocation)
+  const uint32_t lds0 = (uint32_t)reinterpret_cast<uintptr_t>(smem);
+  const uint32_t qx = (uint32_t)qoff;     // stored column = (col << 6) | (swizzle << 4);  ^ (q << 4) selects this lane's quad
+  const uint32_t lds_val = lds0 + NP * FC * 4 + K * KS * 1024;
+  const uint32_t lds_col = lds_val + (RESIDENT ? entries * 64 : 0);
+#ifdef GCRNN_ABLATE_HOPS
+#define GCRNN_HOP_FIRST K
+#else
+#define GCRNN_HOP_FIRST 1
+#endif
+#pragma unroll
+  for (int j = GCRNN_HOP_FIRST; j < K; ++j) {
+    if (RESIDENT) {
+#define GCRNN_FWD_INIT(i) u[i][K - 1 - j]
+#define GCRNN_FWD_STORE(i, a) u[i][K - 1 - j] = a   /* the new value lives in the tap's registers until every wave has read `state` */
+      GCRNN_HOP_STREAM(GCRNN_FWD_INIT, GCRNN_FWD_STORE);
+#undef GCRNN_FWD_INIT
+#undef GCRNN_FWD_STORE
+    } else {
+#pragma unroll
+      for (int i = 0; i < STILES; ++i) {
+        const int beg = tbeg[i], end = tend[i];
+        f32x4 acc = u[i][K - 1 - j];
+        for (int e = beg; e < end; e += 4) {      // entry counts are padded to multiples of 4
+          int cc[4]; float vv[4]; f32x4 xv[4];
+#pragma unroll
+          for (int p = 0; p < 4; ++p) { cc[p] = ell_col[(e + p) * 16 + r]; vv[p] = ell_val[(e + p) * 16 + r]; }
+#pragma unroll
+          for (int p = 0; p < 4; ++p)
+            xv[p] = *reinterpret_cast<const f32x4*>(sbytes + (cc[p] ^ qoff));      // ell_col = node_addr of the neighbour
+#pragma unroll
+          for (int p = 0; p < 4; ++p) acc += vv[p] * xv[p];
+        }
+        u[i][K - 1 - j] = acc;
+      }
+    }
+    if (j < K - 1) {
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < STILES; ++i) {
+        int wv = woff[i];
+        asm volatile("" : "+v"(wv));
+        *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(state) + (wv & 0xffff)) = u[i][K - 1 - j];
+      }
+      __syncthreads();
+    }
+  }
+
+  // ---- epilogue: bias, tanh, bf16 store into the node-major state h_t ------------------------------
+  float bsum[4];
+  {
+    const float bs = gin + gfo;     // the one bias is added by both filters (graphML.py:2420-2421)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) bsum[c] = bs * bvec[c];
+  }
+  if (EPI == 3) {
+    // gate-gradient pass: the hops produced the filter output of this item's chunk; its inner product with dpre (one
+    // bias: this is ONE filter, A(S)x + b or B(S)h + b) is the chunk's share of d loss / d gate (graphML.py:2420-2421)
+    float part = 0.f;
+#pragma unroll
+    for (int i = 0; i < STILES; ++i) {
+      int wv = woff[i];
+      asm volatile("" : "+v"(wv));
+      const int node = wv >> 16;
+      const u32x2 d2 = __builtin_amdgcn_raw_buffer_load_b64(rsrc_a0, node * (F * 2) + (chunk * FC + q * 4) * 2, b * (NP * F * 2), 0);
+      const f32x4 acc = u[i][0];
+      if (node < N)
+        part += (acc[0] + bvec[0]) * bf2f((uint16_t)(d2[0] & 0xffffu)) + (acc[1] + bvec[1]) * bf2f((uint16_t)(d2[0] >> 16)) +
+                (acc[2] + bvec[2]) * bf2f((uint16_t)(d2[1] & 0xffffu)) + (acc[3] + bvec[3]) * bf2f((uint16_t)(d2[1] >> 16));
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) part += __shfl_down(part, off, 64);
+    if (lane == 0) gate_out[(int64_t)b * (NCH * SWAVES) + chunk * SWAVES + wave] = part;   // fixed-order sum by the caller
+  } else if (GATEOUT) {
+    // gate pre-pass: partial dot product of tanh(pre) with the gate's linear weights over this chunk, one partial per wave;
+    // with hout the gate cell's state c = tanh(pre) is also stored (bf16, sequence-major) for the gate's BPTT
+    float part = 0.f;
+#pragma unroll
+    for (int i = 0; i < STILES; ++i) {
+      int wv = woff[i];
+      asm volatile("" : "+v"(wv));
+      const int node = wv >> 16;
+      uint2 pk{0u, 0u};
+      if (node < N) {
+        const float4 w4 = *reinterpret_cast<const float4*>(gate_w + (int64_t)node * F + chunk * FC + q * 4);
+        const f32x4 acc = u[i][0];
+        const float o0 = fast_tanh(acc[0] + bsum[0]), o1 = fast_tanh(acc[1] + bsum[1]);
+        const float o2 = fast_tanh(acc[2] + bsum[2]), o3 = fast_tanh(acc[3] + bsum[3]);
+        part += o0 * w4.x + o1 * w4.y + o2 * w4.z + o3 * w4.w;
+        pk.x = (uint32_t)f2bf(o0) | ((uint32_t)f2bf(o1) << 16);
+        pk.y = (uint32_t)f2bf(o2) | ((uint32_t)f2bf(o3) << 16);
+      }
+      if (hout) __builtin_amdgcn_raw_buffer_store_b64(u32x2{pk.x, pk.y}, rsrc_o, node * (F * 2) + (chunk * FC + q * 4) * 2, b * (NP * F * 2), 0);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) part += __shfl_down(part, off, 64);
+    if (lane == 0) gate_out[(int64_t)b * (NCH * SWAVES) + chunk * SWAVES + wave] = part;   // fixed-order sum by the caller
+  } else if (EPI == 2) {
+    // BPTT data-gradient step: the hops just applied sum_k (S)^k (dpre_t W_k) = d h_{t-1} (recurrent part); add the
+    // upstream gradient of h_{t-1} and go through tanh':  dpre_{t-1} = (acc + dH_{t-1}) * (1 - h_{t-1}^2).
+    // With aux0 == null the raw state gradient is stored (d h0). Time-gated cell: the recurrent part carries the forget
+    // gate of the step it came through, gf_t[b] (the adjoint chain is linear, so the scale is applied here).
+    const float gsc = gf ? gf[b] : 1.f;
+    // With gate_out the launch also emits <h_{t-1}, sum_k (S)^k (dpre_t B_k)> = <B(S) h_{t-1}, dpre_t> (adjoint identity): the
+    // bias-free part of d loss / d gf_t -- the forget gate's gradient without a pass of its own.
+    float part = 0.f;
+#pragma unroll
+    for (int i = 0; i < STILES; ++i) {
+      int wv = woff[i];
+      asm volatile("" : "+v"(wv));
+      const int node = wv >> 16;
+      const int eoff = node * (F * 2) + (chunk * FC + q * 4) * 2;
+      const f32x4 raw = u[i][0];
+      f32x4 o = raw * gsc;
+      float hv0 = 0.f, hv1 = 0.f, hv2 = 0.f, hv3 = 0.f;
+      if (aux1) {
+        const u32x2 h2 = __builtin_amdgcn_raw_buffer_load_b64(rsrc_a1, eoff, b * (NP * F * 2), 0);
+        hv0 = bf2f((uint16_t)(h2[0] & 0xffffu)); hv1 = bf2f((uint16_t)(h2[0] >> 16));
+        hv2 = bf2f((uint16_t)(h2[1] & 0xffffu)); hv3 = bf2f((uint16_t)(h2[1] >> 16));
+      }
+      if (gate_out) part += raw[0] * hv0 + raw[1] * hv1 + raw[2] * hv2 + raw[3] * hv3;     // rows >= N of h are zero
+      if (aux0) {
+        const u32x2 g2 = __builtin_amdgcn_raw_buffer_load_b64(rsrc_a0, eoff, b * (NP * F * 2), 0);
+        const float g0 = bf2f((uint16_t)(g2[0] & 0xffffu)), g1 = bf2f((uint16_t)(g2[0] >> 16));
+        const float g2f = bf2f((uint16_t)(g2[1] & 0xffffu)), g3 = bf2f((uint16_t)(g2[1] >> 16));
+        o[0] = (o[0] + g0) * (1.f - hv0 * hv0);
+        o[1] = (o[1] + g1) * (1.f - hv1 * hv1);
+        o[2] = (o[2] + g2f) * (1.f - hv2 * hv2);
+        o[3] = (o[3] + g3) * (1.f - hv3 * hv3);
+      }
+      uint2 pk;
+      if (node < N) {
+        pk.x = (uint32_t)f2bf(o[0]) | ((uint32_t)f2bf(o[1]) << 16);
+        pk.y = (uint32_t)f2bf(o[2]) | ((uint32_t)f2bf(o[3]) << 16);
+      } else {
+        pk.x = 0u; pk.y = 0u;
+      }
+      __builtin_amdgcn_raw_buffer_store_b64(u32x2{pk.x, pk.y}, rsrc_o, eoff, b * (NP * F * 2), 0);     // dropped when hout is null
+    }
+    if (gate_out) {
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) part += __shfl_down(part, off, 64);
+      if (lane == 0) gate_out[(int64_t)b * (NCH * SWAVES) + chunk * SWAVES + wave] = part;   // fixed-order sum by the caller
+    }
+  } else {
+#pragma unroll
+  for (int i = 0; i < STILES; ++i) {
+    int wv = woff[i];
+    asm volatile("" : "+v"(wv));
+    const int node = wv >> 16;
+    const f32x4 acc = u[i][0];
+    uint2 pk;
+    if (node < N) {
+      const float o0 = fast_tanh(acc[0] + bsum[0]), o1 = fast_tanh(acc[1] + bsum[1]);
+      const float o2 = fast_tanh(acc[2] + bsum[2]), o3 = fast_tanh(acc[3] + bsum[3]);
+      pk.x = (uint32_t)f2bf(o0) | ((uint32_t)f2bf(o1) << 16);
+      pk.y = (uint32_t)f2bf(o2) | ((uint32_t)f2bf(o3) << 16);
+    } else {
+      pk.x = 0u; pk.y = 0u;          // padded rows stay zero
+    }
+    __builtin_amdgcn_raw_buffer_store_b64(u32x2{pk.x, pk.y}, rsrc_o, node * (F * 2) + (chunk * FC + q * 4) * 2, b * (NP * F * 2), 0);
+    u[i][0] = f32x4{__uint_as_float(pk.x), __uint_as_float(pk.y), 0.f, 0.f};      // keep the packed bf16 for the user-layout copy
+  }
+  if (EPI == 0 && aux1) {
+    // the state is also delivered in the USER layout H[b][t][f][:] (node-contiguous rows): transposed bf16 tile in LDS
+    // (row stride 2080 B), then 16-byte coalesced row stores -- replaces a separate unpack pass over the whole sequence.
+    constexpr int RS = 2 * NP + 32;
+    char* tst = reinterpret_cast<char*>(state);
+    __syncthreads();                                   // every wave has finished reading `state` in the last hop
+#pragma unroll
+    for (int i = 0; i < STILES; ++i) {
+      int wv = woff[i];
+      asm volatile("" : "+v"(wv));
+      const int node = wv >> 16;
+      const uint32_t p0 = __float_as_uint(u[i][0][0]), p1 = __float_as_uint(u[i][0][1]);
+      *reinterpret_cast<uint16_t*>(tst + (q * 4 + 0) * RS + node * 2) = (uint16_t)(p0 & 0xffffu);
+      *reinterpret_cast<uint16_t*>(tst + (q * 4 + 1) * RS + node * 2) = (uint16_t)(p0 >> 16);
+      *reinterpret_cast<uint16_t*>(tst + (q * 4 + 2) * RS + node * 2) = (uint16_t)(p1 & 0xffffu);
+      *reinterpret_cast<uint16_t*>(tst + (q * 4 + 3) * RS + node * 2) = (uint16_t)(p1 >> 16);
+    }
+    __syncthreads();
+    const int segs = N >> 3;                           // 16-byte segments per row (N % 8 == 0 checked by the host)
+    uint16_t* ub = const_cast<uint16_t*>(aux1) + (int64_t)b * ubstride + (int64_t)(chunk * FC) * N;
+    for (int idx = tid; idx < FC * segs; idx += STHREADS) {
+      const int f = idx / segs, sg = idx - f * segs;
+      *reinterpret_cast<uint4*>(ub + (int64_t)f * N + sg * 8) = *reinterpret_cast<const uint4*>(tst + f * RS + sg * 16);
+    }
+  }
+  }
+  asm volatile("" ::"v"(prefetched));      // the prefetch load retires here at the latest
+  __syncthreads();     // the last hop's reads of `state` are done before the next sequence overwrites it
+  }  // sequences
+}
+
+typedef void (*fused_kern_t)(const uint16_t*, const uint16_t*, uint16_t*, const uint4*, const float*, const float*,
+                             const float*, const int32_t*, const int32_t*, const int32_t*, const float*, const float4*,
+                             const uint2*, const float*, float*, const uint16_t*, const uint16_t*, int, int, int, int, int);
+
+struct FusedGraphArgs {
+  const int32_t* tile_nodes; const int32_t* tile_off; const int32_t* ell_col; const float* ell_val;
+  const void* ell_val4; const void* ell_col4; int64_t entries;
+};
+
+template <int K, int HS, int XS>
+int fused_launch_t(int mode /*0 plain, 1 gated, 2 gate pre-pass, 3 BPTT data gradient, 4 gate-gradient pass*/, const void* xs,
+                          const void* h0, void* hs, const void* wpack, const float* bias, const float* gi, const float* gf,
+                          const float* gate_w, float* gate_out, const FusedGraphArgs& ga, int64_t B, int64_t T, int64_t N,
+                          hipStream_t st, const void* bw_dHs = nullptr, const void* bw_hs = nullptr, const void* bw_h0 = nullptr,
+                          void* bw_dh0 = nullptr, void* huser = nullptr, void* const* step_events = nullptr) {
+  constexpr int F = 32 * HS, G = 32 * XS, KS = HS + XS;
+  const size_t base = (size_t)NP * FC * 4 + (size_t)K * KS * 1024;
+  const size_t resident_bytes = base + (size_t)ga.entries * 16 * 6;
+  const bool resident = resident_bytes <= 160 * 1024 && ga.ell_val4 && ga.ell_col4;
+  const size_t lds = resident ? resident_bytes : base;
+  fused_kern_t kern;
+  if (mode == 4)      kern = resident ? (fused_kern_t)fused_step_kernel<K, HS, XS, false, true, 3> : (fused_kern_t)fused_step_kernel<K, HS, XS, false, false, 3>;
+  else if (mode == 3) kern = resident ? (fused_kern_t)fused_step_kernel<K, HS, XS, false, true, 2> : (fused_kern_t)fused_step_kernel<K, HS, XS, false, false, 2>;
+  else if (mode == 2) kern = resident ? (fused_kern_t)fused_step_kernel<K, HS, XS, false, true, 1> : (fused_kern_t)fused_step_kernel<K, HS, XS, false, false, 1>;
+  else if (mode == 1) kern = resident ? (fused_kern_t)fused_step_kernel<K, HS, XS, true, true> : (fused_kern_t)fused_step_kernel<K, HS, XS, true, false>;
+  else                kern = resident ? (fused_kern_t)fused_step_kernel<K, HS, XS, false, true> : (fused_kern_t)fused_step_kernel<K, HS, XS, false, false>;
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    return GCRNN_ERR_LAUNCH;
+  const int NCH = F / FC;
+  const uint16_t* x = (const uint16_t*)xs;
+  uint16_t* h = (uint16_t*)hs;
+  const int64_t xstep = B * NP * G, hstep = B * NP * F;
+  // one workgroup per CU: 256 / NCH sequence slots (rounded to the 8 XCDs), fewer when the batch is small
+  auto grid_for = [&](int64_t items) {
+    int64_t slots = cdiv(items, 8) * 8;
+    const int64_t max_slots = (256 / NCH) / 8 * 8 > 0 ? (256 / NCH) / 8 * 8 : 8;
+    if (slots > max_slots) slots = max_slots;
+    return (unsigned)(slots * NCH);
+  };
+  GCRNN_PRE_LAUNCH();
+  if (mode == 2 || mode == 4) {
+    // no recurrence: all (t, b) items in one launch -- split over whole time steps where the 32-bit buffer offsets of
+    // one launch (items * NP * max(F, G) * 2 bytes) would overflow
+    const int64_t row_bytes = (int64_t)NP * (F > G ? F : G) * 2;
+    int64_t tchunk = (2147483647LL / row_bytes) / B;
+    if (tchunk < 1) return GCRNN_ERR_BAD_SHAPE;
+    if (tchunk > T) tchunk = T;
+    for (int64_t t0 = 0; t0 < T; t0 += tchunk) {
+      const int64_t nt = (T - t0 < tchunk) ? T - t0 : tchunk, items = nt * B;
+      float* go = gate_out + t0 * B * (NCH * SWAVES);
+      if (mode == 2)      // operands [h0 | x_t]; optional store of c_t = tanh(pre) into hs
+        kern<<<grid_for(items), STHREADS, lds, st>>>(x + t0 * xstep, (const uint16_t*)h0, h ? h + t0 * hstep : nullptr, (const uint4*)wpack, bias,
+                                     nullptr, nullptr, ga.tile_nodes, ga.tile_off, ga.ell_col, ga.ell_val, (const float4*)ga.ell_val4,
+                                     (const uint2*)ga.ell_col4, gate_w, go, nullptr, nullptr, 0, (int)ga.entries, (int)items, (int)B, (int)N);
+      else if (XS == 0)   // operand = one [T*B][NP][F] array, per-item dpre in bw_dHs
+        kern<<<grid_for(items), STHREADS, lds, st>>>(nullptr, (const uint16_t*)h0 + t0 * hstep, nullptr, (const uint4*)wpack, bias, nullptr, nullptr,
+                                     ga.tile_nodes, ga.tile_off, ga.ell_col, ga.ell_val, (const float4*)ga.ell_val4,
+                                     (const uint2*)ga.ell_col4, nullptr, go, (const uint16_t*)bw_dHs + t0 * hstep, nullptr, 0,
+                                     (int)ga.entries, (int)items, (int)items, (int)N);
+      else                // input filter with G != F: operand [0 | x_t] -- ONE all-zero state block shared by every item (hmod = 1)
+        kern<<<grid_for(items), STHREADS, lds, st>>>(x + t0 * xstep, (const uint16_t*)h0, nullptr, (const uint4*)wpack, bias, nullptr, nullptr,
+                                     ga.tile_nodes, ga.tile_off, ga.ell_col, ga.ell_val, (const float4*)ga.ell_val4,
+                                     (const uint2*)ga.ell_col4, nullptr, go, (const uint16_t*)bw_dHs + t0 * hstep, nullptr, 0,
+                                     (int)ga.entries, (int)items, 1, (int)N);
+    }
+  } else if (mode == 3) {
+    // BPTT: hs (= dpre, [T][B][NP][F]) already holds dpre_{T-1}; walk t = T-1 .. 1, then optionally d h0.
+    // gf (time-gated cell, [T][B]): step t's recurrent gradient is scaled by its forget gate gf_t.
+    const unsigned grid = grid_for(B);
+    const uint16_t* dH = (const uint16_t*)bw_dHs;
+    const uint16_t* hst = (const uint16_t*)bw_hs;
+    const int64_t gstep = B * (NCH * SWAVES);             // gate_out (or null): [T][B][NCH*SWAVES] partials of <h_{t-1}, adjoint chain of dpre_t>
+    for (int64_t t = T - 1; t >= 1; --t) {
+      kern<<<grid, STHREADS, lds, st>>>(nullptr, h + t * hstep, h + (t - 1) * hstep, (const uint4*)wpack, nullptr, nullptr,
+                                   gf ? gf + t * B : nullptr, ga.tile_nodes, ga.tile_off, ga.ell_col, ga.ell_val,
+                                   (const float4*)ga.ell_val4, (const uint2*)ga.ell_col4, nullptr, gate_out ? gate_out + t * gstep : nullptr,
+                                   dH + (t - 1) * hstep, hst + (t - 1) * hstep, 0, (int)ga.entries, (int)B, (int)B, (int)N);
+    }
+    if (bw_dh0 || gate_out)
+      kern<<<grid, STHREADS, lds, st>>>(nullptr, h, (uint16_t*)bw_dh0, (const uint4*)wpack, nullptr, nullptr, gf, ga.tile_nodes,
+                                   ga.tile_off, ga.ell_col, ga.ell_val, (const float4*)ga.ell_val4, (const uint2*)ga.ell_col4,
+                                   nullptr, gate_out, nullptr, gate_out ? (const uint16_t*)bw_h0 : nullptr, 0, (int)ga.entries,
+                                   (int)B, (int)B, (int)N);
+  } else {
+    const unsigned grid = grid_for(B);
+    for (int64_t t = 0; t < T; ++t) {
+      const uint16_t* hp = (t == 0) ? (const uint16_t*)h0 : h + (t - 1) * hstep;
+      // step_events[t] (or null): the launch of step t first waits for that event -- x_t is being packed on another stream
+      if (step_events && step_events[t] && hipStreamWaitEvent(st, (hipEvent_t)step_events[t], 0) != hipSuccess) return GCRNN_ERR_LAUNCH;
+      kern<<<grid, STHREADS, lds, st>>>(x + t * xstep, hp, h + t * hstep, (const uint4*)wpack, bias, mode == 1 ? gi + t * B : nullptr,
+                                   mode == 1 ? gf + t * B : nullptr, ga.tile_nodes, ga.tile_off, ga.ell_col, ga.ell_val,
+                                   (const float4*)ga.ell_val4, (const uint2*)ga.ell_col4, nullptr, nullptr, nullptr,
+                                   huser ? (const uint16_t*)huser + t * F * N : nullptr, (int)(T * F * N),
+                                   (int)ga.entries, (int)B, (int)B, (int)N);
+    }
+  }
+  GCRNN_CHECK_LAUNCH();
+  return GCRNN_OK;
+}
+
+// The step kernel's instantiations are spread over several translation units (gcrnn_fused_step_k*.hip) so that the library
+// builds in parallel; gcrnn_fused.hip only declares them.
+#define GCRNN_STEP_SIG (int, const void*, const void*, void*, const void*, const float*, const float*, const float*, const float*, float*, const FusedGraphArgs&, int64_t, int64_t, int64_t, hipStream_t, const void*, const void*, const void*, void*, void*, void* const*)
+#define GCRNN_STEP_DECLARE(K, HS, XS) extern template int fused_launch_t<K, HS, XS> GCRNN_STEP_SIG;
+#define GCRNN_STEP_DEFINE(K, HS, XS) template int fused_launch_t<K, HS, XS> GCRNN_STEP_SIG;
+// the (HS, XS) operand shapes built for a tap count K: [h | x] with F = G = 64 / 32, F = 64 with G <= 32, and the state-only
+// operands of the BPTT data-gradient steps and gate-gradient passes
+#define GCRNN_STEP_FOR_K5(M) M(5, 2, 2) M(5, 1, 1) M(5, 2, 1) M(5, 2, 0) M(5, 1, 0)
+#define GCRNN_STEP_FOR_K4(M) M(4, 2, 2) M(4, 2, 1) M(4, 2, 0)
+#define GCRNN_STEP_FOR_K3(M) M(3, 2, 2) M(3, 1, 1) M(3, 2, 1) M(3, 2, 0) M(3, 1, 0)
+#define GCRNN_STEP_FOR_K2(M) M(2, 2, 2) M(2, 1, 1) M(2, 2, 1) M(2, 2, 0) M(2, 1, 0)

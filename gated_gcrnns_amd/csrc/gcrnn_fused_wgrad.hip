@@ -1,0 +1,292 @@
+// Weight-gradient kernel of the fused BPTT (shares the hop macros and the graph image of gcrnn_fused_step.h).
+#include "gcrnn_fused_step.h"
+
+// ------------------------------------------------------------------------------------------
+// BPTT weight gradient of the un-gated cell:   dW_k[f'][j] = sum_{t,b,n} du_k[t,b][n][f'] * z[t,b][n][j],
+//   du_0 = dpre_t,  du_k = S du_{k-1}  (adjoint hops, CSR(S)),   z = [h_{t-1} | x_t]   (adjoint of graphML.py:134-135).
+// One workgroup = one (item (t,b), 16-feature chunk of dpre); wave w owns input-feature tile w of z. Every item is
+// independent (no recurrence once dpre is known), so ONE launch covers all T*B items and each workgroup keeps its
+// K accumulator tiles D_k [16 f' x 16 j] in registers across its items; one atomic flush at the end.
+//  - node index = the MFMA contraction dimension. B operand: 8 consecutive nodes of one input feature = one 16-byte
+//    load from the USER layout (x[b][t][g][:], H[b][t-1][f][:] are node-contiguous), held in registers across the taps.
+//    A operand: du_k transposed, a bf16 [16 f'][512 nodes] LDS image per half of the nodes, row stride 1056 B chosen so
+//    that the 16-lane groups of ds_read_b128 hit 16 distinct 16-byte bank slots (slot = 2 f' + kg mod 16).
+//  - du_k is consumed by the GEMM of tap k and by the hop that produces du_{k+1}: no per-tap storage at all.
+// LDS: state fp32 [1024][16] (64 KiB) | graph image 96 B x entries | transposed half image (16.5 KiB).
+// ------------------------------------------------------------------------------------------
+namespace { constexpr int TSTRIDE = 1056; constexpr int TBYTES = 16 * TSTRIDE; }
+
+template <int K, int HS, int XS>
+__global__ __launch_bounds__(512, 2) void fused_wgrad_kernel(
+    const uint16_t* __restrict__ dpre,       // [T][B][NP][F] bf16 sequence-major
+    const uint16_t* __restrict__ Xuser,      // [B][T][G][N] bf16
+    const uint16_t* __restrict__ Huser,      // [B][T][F][N] bf16 (forward output)
+    const uint16_t* __restrict__ h0user,     // [B][F][N]   bf16
+    float* __restrict__ dW,                  // [F][K][F+G] fp32, += (atomics)
+    float* __restrict__ dbsum,               // [F] fp32, += the bias gradient: sum_{t,b} (gi + gf) sum_n dpre, 2 sum dpre without gates (or null)
+    const int32_t* __restrict__ tile_nodes, const int32_t* __restrict__ tile_off,
+    const float4* __restrict__ ell_val4, const uint2* __restrict__ ell_col4,
+    const float* __restrict__ gi,            // [T][B] input-filter gates of the time-gated cell, or null
+    const float* __restrict__ gf,            // [T][B] state-filter gates, or null
+    int h_is_h0,                             // the state operand of EVERY item is h0 (gate sub-cells, graphML.py:2362, 2370)
+    int entries, int B, int Tn, int N) {
+  constexpr int F = 32 * HS, G = 32 * XS, C = F + G, NCH = F / FC, JT = C / 16;
+  static_assert(JT <= WAVES, "one input-feature tile per wave");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* state = reinterpret_cast<float*>(smem);
+  float4* lval4 = reinterpret_cast<float4*>(smem + NP * FC * 4);
+  uint2* lcol4 = reinterpret_cast<uint2*>(lval4 + entries * 4);
+  char* tbuf = reinterpret_cast<char*>(lcol4 + entries * 4);
+  float* lbias = reinterpret_cast<float*>(tbuf + TBYTES);          // [16] bias-gradient partial sums of this workgroup
+
+  const int L = blockIdx.x;
+  const int grp = L / (8 * NCH), rem = L - grp * (8 * NCH);
+  const int chunk = rem >> 3, it0 = grp * 8 + (rem & 7);
+  const int seq_slots = (gridDim.x / (8 * NCH)) * 8;
+  const int items = B * Tn;
+  if (it0 >= items) return;
+
+  constexpr int HT = TILES;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 15, q = lane >> 4;
+
+  {
+    const int n = (entries >> 2) * 16;
+    for (int i = tid; i < n; i += 512) { lval4[i] = ell_val4[i]; lcol4[i] = ell_col4[i]; }
+  }
+  int tbeg[TILES], tend[TILES], woff[TILES];
+#pragma unroll
+  for (int i = 0; i < TILES; ++i) {
+    tbeg[i] = tile_off[wave * TILES + i];
+    tend[i] = tile_off[wave * TILES + i + 1];
+    const int nd = tile_nodes[(wave * TILES + i) * 16 + r];
+    woff[i] = nd ^ (q << 4);                       // slot = node << 16 | row << 6 | swz << 4
+  }
+  const int qoff = q * 16;
+  const uint32_t lds0 = (uint32_t)reinterpret_cast<uintptr_t>(smem);
+  const uint32_t qx = (uint32_t)qoff;
+  const uint32_t lds_val = lds0 + NP * FC * 4;
+  const uint32_t lds_col = lds_val + entries * 64;
+
+  f32x4 accD[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) accD[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (tid < FC) lbias[tid] = 0.f;
+  const bool has_tile = wave < JT;
+  const bool is_x = wave >= F / 16;                 // wave-uniform: tiles 0..F/16-1 are h features, the rest x features
+  const int jrow = (is_x ? wave * 16 - F : wave * 16) + r;      // this lane's row (feature) inside its source block
+  // Time-gated cell: item (t, b) enters dW_A with weight gi_t[b] and dW_B with gf_t[b]. A wave owns features of ONE of the
+  // two filters, so its accumulators are kept in units of the current item's gate: accD_true = gprev * accD. Re-basing
+  // costs K*4 multiplies per item and no registers; items whose gate underflowed contribute nothing.
+  const float* gw_ = is_x ? gi : gf;
+  float gprev = 1.f;
+  const __amdgpu_buffer_rsrc_t rsrc_d = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(dpre), 0, Tn * B * (NP * F * 2) > 0 ? Tn * B * (NP * F * 2) : 0x7fffffff, 0x00020000);
+  __syncthreads();
+
+  for (int it = it0; it < items; it += seq_slots) {
+    const int t = it / B, b = it - t * B;
+    // ---- B operand: this wave's 16 input features x 1024 nodes, straight from the user layout --------------------
+    // The fragments of nodes 0..511 stay in registers across the taps; those of nodes 512..1023 are re-fetched per tap
+    // (L2-resident after the first tap) through registers that the hop pipeline has just released -- the kernel must
+    // stay spill-free: a spilled destination of an in-flight asm ds_read would be saved before its data lands.
+    bf16x8 bfr[16];
+    const uint16_t* zsrc;
+    int zrows;
+    float gcur = gprev;
+    float gbias = 2.f;                                    // the one bias enters both filters
+    if (gw_) { gcur = gw_[t * B + b]; gbias = gi[t * B + b] + gf[t * B + b]; }
+    const bool live = has_tile && gcur > 1e-12f;          // wave-uniform
+    if (live && gcur != gprev) {
+      const float rb = gprev / gcur;
+#pragma unroll
+      for (int k = 0; k < K; ++k) accD[k] *= rb;
+      gprev = gcur;
+    }
+    if (is_x) { zsrc = Xuser + ((int64_t)b * Tn + t) * G * N; zrows = G; }
+    else if (t > 0 && !h_is_h0) { zsrc = Huser + ((int64_t)b * Tn + (t - 1)) * F * N; zrows = F; }
+    else { zsrc = h0user + (int64_t)b * F * N; zrows = F; }
+    const __amdgpu_buffer_rsrc_t rsrc_z = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(zsrc), 0, has_tile ? zrows * N * 2 : 0, 0x00020000);
+    const int vo = (jrow * N + 8 * q) * 2;
+#pragma unroll
+    for (int s2 = 0; s2 < 16; ++s2)
+      bfr[s2] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsrc_z, vo + 64 * s2, 0, 0));
+    // ---- du_0 = dpre chunk of this item ------------------------------------------------------------------------
+    f32x4 cur[TILES];
+    const int soff_d = ((t * B + b) * NP) * (F * 2);
+#pragma unroll
+    for (int i = 0; i < TILES; ++i) {
+      int wv = woff[i];
+      asm volatile("" : "+v"(wv));
+      const u32x2 d2 = __builtin_amdgcn_raw_buffer_load_b64(rsrc_d, (wv >> 16) * (F * 2) + (chunk * FC + q * 4) * 2, soff_d, 0);
+      cur[i] = f32x4{bf2f((uint16_t)(d2[0] & 0xffffu)), bf2f((uint16_t)(d2[0] >> 16)),
+                     bf2f((uint16_t)(d2[1] & 0xffffu)), bf2f((uint16_t)(d2[1] >> 16))};
+    }
+    if (dbsum) {                                        // sum of dpre over this item's nodes (padded rows are zero)
+      f32x4 bacc = cur[0];
+#pragma unroll
+      for (int i = 1; i < TILES; ++i) bacc += cur[i];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        float v = bacc[c];
+#pragma unroll
+        for (int off = 1; off < 16; off <<= 1) v += __shfl_xor(v, off, 64);     // over the 16 slots r of this quad
+        if (r == 0) atomicAdd(lbias + q * 4 + c, v * gbias);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      // S1: du_k -> LDS state rows (for the next hop) and the transposed bf16 image of nodes 0..511
+#pragma unroll
+      for (int i = 0; i < TILES; ++i) {
+        int wv = woff[i];
+        asm volatile("" : "+v"(wv));
+        if (k < K - 1) *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(state) + (wv & 0xffff)) = cur[i];
+        const int node = wv >> 16;
+        if (node < 512) {
+#pragma unroll
+          for (int c = 0; c < 4; ++c)
+            *reinterpret_cast<uint16_t*>(tbuf + (q * 4 + c) * TSTRIDE + node * 2) = f2bf(cur[i][c]);
+        }
+      }
+      __syncthreads();
+      // S2: D_k += du_k^T z over nodes 0..511
+      if (live) {
+#pragma unroll
+        for (int s4 = 0; s4 < 16; s4 += 4) {            // 4 A fragments in flight per batch: LDS latency overlaps the MFMAs
+          bf16x8 a4[4];
+#pragma unroll
+          for (int p = 0; p < 4; ++p)
+            a4[p] = *reinterpret_cast<const bf16x8*>(tbuf + r * TSTRIDE + (32 * (s4 + p) + 8 * q) * 2);
+#pragma unroll
+          for (int p = 0; p < 4; ++p) accD[k] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a4[p], bfr[s4 + p], accD[k], 0, 0, 0);
+        }
+      }
+      __syncthreads();
+      // S3: transposed image of nodes 512..1023
+#pragma unroll
+      for (int i = 0; i < TILES; ++i) {
+        int wv = woff[i];
+        asm volatile("" : "+v"(wv));
+        const int node = wv >> 16;
+        if (node >= 512) {
+#pragma unroll
+          for (int c = 0; c < 4; ++c)
+            *reinterpret_cast<uint16_t*>(tbuf + (q * 4 + c) * TSTRIDE + (node - 512) * 2) = f2bf(cur[i][c]);
+        }
+      }
+      __syncthreads();
+      // S4: du_{k+1} = S du_k (reads `state`; the transposed image of du_k stays valid);  S5: second half of the contraction
+#ifdef GCRNN_WGRAD_ABLATE_HOP      // profiling builds (tools/wgrad_ablate.sh): results are wrong by construction
+      if (false) {
+#else
+      if (k < K - 1) {
+#endif
+#ifdef GCRNN_WGRAD_PLAIN_HOP
+#pragma unroll
+        for (int i = 0; i < TILES; ++i) {
+          f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+          for (int gq = tbeg[i] >> 2; gq < (tend[i] >> 2); ++gq) {
+            const uint2 c4 = lcol4[gq * 16 + r];
+            const float4 v4 = lval4[gq * 16 + r];
+            const char* sb = reinterpret_cast<const char*>(state);
+            acc += v4.x * *reinterpret_cast<const f32x4*>(sb + ((c4.x & 0xffffu) ^ qx));
+            acc += v4.y * *reinterpret_cast<const f32x4*>(sb + ((c4.x >> 16) ^ qx));
+            acc += v4.z * *reinterpret_cast<const f32x4*>(sb + ((c4.y & 0xffffu) ^ qx));
+            acc += v4.w * *reinterpret_cast<const f32x4*>(sb + ((c4.y >> 16) ^ qx));
+          }
+          cur[i] = acc;
+        }
+#else
+        LGKM_WAIT(0);
+#define GCRNN_WG_INIT(i) f32x4{0.f, 0.f, 0.f, 0.f}
+#define GCRNN_WG_STORE(i, a) cur[i] = a
+        GCRNN_HOP_TILED(GCRNN_WG_INIT, GCRNN_WG_STORE);
+#undef GCRNN_WG_INIT
+#undef GCRNN_WG_STORE
+#endif
+      }
+      if (live) {
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2) {
+          bf16x8 bl[8];
+#pragma unroll
+          for (int s2 = 0; s2 < 8; ++s2)
+#ifdef GCRNN_WGRAD_ABLATE_REFETCH
+            bl[s2] = bfr[8 * h2 + s2];
+#else
+            bl[s2] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsrc_z, vo + 64 * (16 + 8 * h2 + s2), 0, 0));
+#endif
+          bf16x8 al[8];
+#pragma unroll
+          for (int s2 = 0; s2 < 8; ++s2)
+            al[s2] = *reinterpret_cast<const bf16x8*>(tbuf + r * TSTRIDE + (32 * (8 * h2 + s2) + 8 * q) * 2);
+#pragma unroll
+          for (int s2 = 0; s2 < 8; ++s2) accD[k] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[s2], bl[s2], accD[k], 0, 0, 0);
+        }
+      }
+      __syncthreads();
+    }
+  }
+  // ---- flush: D_k[f' = 4q + c][j = 16 wave + r] -> dW[chunk*16 + f'][k][j] -------------------------------------------
+  if (has_tile) {
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+        atomicAdd(dW + ((int64_t)(chunk * FC + q * 4 + c) * K + k) * C + wave * 16 + r, accD[k][c] * gprev);
+  }
+  __syncthreads();
+  if (dbsum && tid < FC) atomicAdd(dbsum + chunk * FC + tid, lbias[tid]);
+}
+
+template <int K, int HS, int XS>
+static int fused_wgrad_t(const void* dpre, const void* Xuser, const void* Huser, const void* h0user, float* dW, float* dbsum,
+                         const FusedGraphArgs& ga, const float* gi, const float* gf, int h_is_h0, int64_t B, int64_t T, int64_t N,
+                         hipStream_t st) {
+  constexpr int F = 32 * HS;
+  const size_t lds = (size_t)NP * FC * 4 + (size_t)ga.entries * 96 + TBYTES + 64;
+  if (lds > 160 * 1024 || !ga.ell_val4 || !ga.ell_col4) return GCRNN_ERR_UNSUPPORTED;
+  auto kern = fused_wgrad_kernel<K, HS, XS>;
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    return GCRNN_ERR_LAUNCH;
+  const int NCH = F / FC;
+  int64_t slots = cdiv(B * T, 8) * 8;
+  const int64_t max_slots = (256 / NCH) / 8 * 8 > 0 ? (256 / NCH) / 8 * 8 : 8;
+  if (slots > max_slots) slots = max_slots;
+  GCRNN_PRE_LAUNCH();
+  kern<<<(unsigned)(slots * NCH), 512, lds, st>>>((const uint16_t*)dpre, (const uint16_t*)Xuser, (const uint16_t*)Huser,
+                                                   (const uint16_t*)h0user, dW, dbsum, ga.tile_nodes, ga.tile_off,
+                                                   (const float4*)ga.ell_val4, (const uint2*)ga.ell_col4, gi, gf, h_is_h0,
+                                                   (int)ga.entries, (int)B, (int)T, (int)N);
+  GCRNN_CHECK_LAUNCH();
+  return GCRNN_OK;
+}
+
+extern "C" int gcrnn_fused_backward_weight_bf16(const void* dpre, const void* Xuser, const void* Huser, const void* h0user,
+                                                float* dW, float* dbsum, const int32_t* tile_nodes, const int32_t* tile_off,
+                                                const void* ell_val4, const void* ell_col4, int64_t entries, int64_t B,
+                                                int64_t T, int64_t N, int64_t F, int64_t G, int64_t K, const float* gi,
+                                                const float* gf, int h_is_h0, void* stream) {
+  if ((gi == nullptr) != (gf == nullptr)) return GCRNN_ERR_NULL_POINTER;
+  if (!dpre || !Xuser || (!Huser && !h_is_h0) || !h0user || !dW || !tile_nodes || !tile_off || !ell_val4 || !ell_col4) return GCRNN_ERR_NULL_POINTER;
+  if (B <= 0 || T <= 0 || N <= 0 || N > NP || N % 8 || entries < 0 || entries % 4 || B * T > (1 << 24)) return GCRNN_ERR_BAD_SHAPE;
+  if (T * B * (NP * F * 2) > 2147483647LL) return GCRNN_ERR_BAD_SHAPE;      // 32-bit buffer offsets into dpre
+  const FusedGraphArgs ga{tile_nodes, tile_off, nullptr, nullptr, ell_val4, ell_col4, entries};
+  hipStream_t st = as_stream(stream);
+#define GCRNN_WG_CASE(KK, HH, XX) \
+  if (K == KK && F == 32 * HH && G == 32 * XX) return fused_wgrad_t<KK, HH, XX>(dpre, Xuser, Huser, h0user, dW, dbsum, ga, gi, gf, h_is_h0, B, T, N, st);
+  GCRNN_WG_CASE(5, 2, 2)
+  GCRNN_WG_CASE(4, 2, 2)
+  GCRNN_WG_CASE(3, 2, 2)
+  GCRNN_WG_CASE(2, 2, 2)
+  GCRNN_WG_CASE(5, 1, 1)
+  GCRNN_WG_CASE(3, 1, 1)
+  GCRNN_WG_CASE(2, 1, 1)
+  GCRNN_WG_CASE(5, 2, 1)
+  GCRNN_WG_CASE(4, 2, 1)
+  GCRNN_WG_CASE(3, 2, 1)
+  GCRNN_WG_CASE(2, 2, 1)
+#undef GCRNN_WG_CASE
+  return GCRNN_ERR_UNSUPPORTED;
+}

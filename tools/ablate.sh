@@ -6,7 +6,7 @@ mkdir -p /tmp/abl
 VARIANTS="full nohops nophase1 neither nohops_noloads nohops_nomfma"
 for v in $VARIANTS; do
   case $v in full) D="";; nohops) D="-DGCRNN_ABLATE_HOPS";; nophase1) D="-DGCRNN_ABLATE_PHASE1";; neither) D="-DGCRNN_ABLATE_HOPS -DGCRNN_ABLATE_PHASE1";; nohops_noloads) D="-DGCRNN_ABLATE_HOPS -DGCRNN_ABLATE_P1_LOADS";; nohops_nomfma) D="-DGCRNN_ABLATE_HOPS -DGCRNN_ABLATE_P1_MFMA";; esac
-  /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC -shared $D -o /tmp/abl/lib_$v.so $C/gcrnn_fused.hip $C/gcrnn_generic.hip $C/gcrnn_host.cpp &
+  /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC -shared $D -o /tmp/abl/lib_$v.so $C/*.hip $C/gcrnn_host.cpp &
 done
 wait
 for v in $VARIANTS; do
