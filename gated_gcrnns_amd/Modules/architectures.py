@@ -131,6 +131,6 @@ class GatedGCRNNforClassification(_GatedGCRNNBase):
         self.outputNN = _build_mlp(self.N * self.F_h, self.dimLayersMLP, self.sigma2, self.sigma3, self.bias)
 
     def forward(self, x, h0):
-        H = self.stateGCRNN(x, h0)
+        H = self.stateGCRNN(x, h0, last_only=not torch.is_grad_enabled())     # inference: only the last state is materialised
         h = H.select(1, -1)                                          # reference :1844
         return self.outputNN(_to_param_dtype(h, self.outputNN).reshape(-1, self.F_h * self.N))

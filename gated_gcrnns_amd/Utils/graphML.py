@@ -288,7 +288,13 @@ class GGCRNNCell(nn.Module):
         d = sub._gate_state(Xn, h0n)
         return torch.sigmoid(gfl[0].forward_node_major(d))
 
-    def forward(self, X, h0):
+    def forward(self, X, h0, last_only=False):
+        """last_only (an extension the classification model uses in inference): return B x 1 x F x N, the last state only --
+        the fused kernels then skip the user-layout store of every other step; the other paths slice."""
+        if last_only:
+            if (not torch.is_grad_enabled()) and self._use_fused(X, h0):
+                return self._forward_fused(X, h0, last_only=True)
+            return self.forward(X, h0)[:, -1:]
         assert h0.shape[0] == X.shape[0]
         ops.require_device(X, h0, self.weight_A)
         B, T, F_in, N = X.shape
@@ -495,10 +501,10 @@ class GGCRNNCell(nn.Module):
                 'forget': (pad(self.GFL_forget.weight_A), self.GFL_forget.weight_B, self.GFL_forget.bias,
                            self.MLP_forget[0].weight, self.MLP_forget[0].bias)}
 
-    def _forward_fused(self, X, h0):
+    def _forward_fused(self, X, h0, last_only=False):
         gates = self._fused_gates() if self.time_gating == True else None  # noqa: E712
         Xp, wA = ops.fused_pad_operands(X, self.weight_A)
-        return ops.fused_cell_forward(Xp, h0, wA, self.weight_B, self.bias, self.graph, gates)
+        return ops.fused_cell_forward(Xp, h0, wA, self.weight_B, self.bias, self.graph, gates, last_only=last_only)
 
     def extra_repr(self):
         return 'in_features=%d, state_features=%d, taps=(%d,%d), time_gating=%s, spatial_gating=%s, %s' % (

@@ -66,7 +66,7 @@ def _bind(lib):
         'gcrnn_fused_pack_weights': (C.c_int, [C.c_int, _c_p, _c_p, _c_p, _c_i64, _c_i64, _c_i64, _c_i64, _c_p]),
         'gcrnn_fused_forward_bf16': (C.c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p,
                                                _c_p, _c_p,
-                                               _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_p, _c_p, _c_p]),
+                                               _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_p, C.c_int, _c_p, _c_p]),
         'gcrnn_pack_seq_major_steps': (C.c_int, [_c_p, _c_p, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_p]),
         'gcrnn_fused_gate_prepass_bf16': (C.c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p,
                                                     _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_p]),

@@ -603,7 +603,7 @@ int fused_launch_t(int mode /*0 plain, 1 gated, 2 gate pre-pass, 3 BPTT data gra
                           const void* h0, void* hs, const void* wpack, const float* bias, const float* gi, const float* gf,
                           const float* gate_w, float* gate_out, const FusedGraphArgs& ga, int64_t B, int64_t T, int64_t N,
                           hipStream_t st, const void* bw_dHs = nullptr, const void* bw_hs = nullptr, const void* bw_h0 = nullptr,
-                          void* bw_dh0 = nullptr, void* huser = nullptr, void* const* step_events = nullptr) {
+                          void* bw_dh0 = nullptr, void* huser = nullptr, void* const* step_events = nullptr, int huser_last_only = 0) {
   constexpr int F = 32 * HS, G = 32 * XS, KS = HS + XS;
   const size_t base = (size_t)NP * FC * 4 + (size_t)K * KS * 1024;
   const size_t resident_bytes = base + (size_t)ga.entries * 16 * 6;
@@ -681,7 +681,8 @@ int fused_launch_t(int mode /*0 plain, 1 gated, 2 gate pre-pass, 3 BPTT data gra
       kern<<<grid, STHREADS, lds, st>>>(x + t * xstep, hp, h + t * hstep, (const uint4*)wpack, bias, mode == 1 ? gi + t * B : nullptr,
                                    mode == 1 ? gf + t * B : nullptr, ga.tile_nodes, ga.tile_off, ga.ell_col, ga.ell_val,
                                    (const float4*)ga.ell_val4, (const uint2*)ga.ell_col4, nullptr, nullptr, nullptr,
-                                   huser ? (const uint16_t*)huser + t * F * N : nullptr, (int)(T * F * N),
+                                   !huser ? nullptr : (!huser_last_only ? (const uint16_t*)huser + t * F * N : (t == T - 1 ? (const uint16_t*)huser : nullptr)),
+                                   (int)((huser_last_only ? 1 : T) * F * N),
                                    (int)ga.entries, (int)B, (int)B, (int)N);
     }
   }
@@ -691,7 +692,7 @@ int fused_launch_t(int mode /*0 plain, 1 gated, 2 gate pre-pass, 3 BPTT data gra
 
 // The step kernel's instantiations are spread over several translation units (gcrnn_fused_step_k*.hip) so that the library
 // builds in parallel; gcrnn_fused.hip only declares them.
-#define GCRNN_STEP_SIG (int, const void*, const void*, void*, const void*, const float*, const float*, const float*, const float*, float*, const FusedGraphArgs&, int64_t, int64_t, int64_t, hipStream_t, const void*, const void*, const void*, void*, void*, void* const*)
+#define GCRNN_STEP_SIG (int, const void*, const void*, void*, const void*, const float*, const float*, const float*, const float*, float*, const FusedGraphArgs&, int64_t, int64_t, int64_t, hipStream_t, const void*, const void*, const void*, void*, void*, void* const*, int)
 #define GCRNN_STEP_DECLARE(K, HS, XS) extern template int fused_launch_t<K, HS, XS> GCRNN_STEP_SIG;
 #define GCRNN_STEP_DEFINE(K, HS, XS) template int fused_launch_t<K, HS, XS> GCRNN_STEP_SIG;
 // the (HS, XS) operand shapes built for a tap count K: [h | x] with F = G = 64 / 32, F = 64 with G <= 32, and the state-only

@@ -261,7 +261,7 @@ def time_fused_step_kernel(X, h0, wA, wB, bias, graph, reps=3):
     e0.record()
     for _ in range(reps):
         check(lib.gcrnn_fused_forward_bf16(_p(xs), _p(h0s), _p(hs), _p(wpack), _p(b32), None, None, *_fused_graph_args(plan),
-                                           B, T, N, F, G, K, _p(H) if H is not None else None, None, st),
+                                           B, T, N, F, G, K, _p(H) if H is not None else None, 0, None, st),
               'fused_forward')
     e1.record()
     torch.cuda.synchronize()
@@ -366,7 +366,8 @@ def fused_time_gate(xs, h0s, wA_g, wB_g, bias_g, lin_w, lin_b, graph, N, store_s
     return (gate, cs, gw) if store_states else gate
 
 
-def fused_cell_forward(X, h0, wA, wB, bias, graph, gates=None, return_states=False, gate_values=None, packed=None):
+def fused_cell_forward(X, h0, wA, wB, bias, graph, gates=None, return_states=False, gate_values=None, packed=None,
+                       last_only=False):
     """Whole GGCRNNCell forward (un-gated or time-gated) on the fused bf16 step kernel.
 
     X: B x T x G x N bf16, h0: B x F x N bf16 (user layout) -> H: B x T x F x N bf16.
@@ -375,6 +376,8 @@ def fused_cell_forward(X, h0, wA, wB, bias, graph, gates=None, return_states=Fal
     (t, b). gate_values: the two gates themselves, (gi, gf) [T][B] fp32, instead of their sub-networks. packed: the result
     of fused_pack_inputs (shared with the gates by the training path). No autograd graph is recorded here.
     return_states: also returns the state buffer hs_all [T+1][B][NPad][F] (slot 0 = h0) and the plan.
+    last_only: H is B x 1 x F x N, the last state alone (the classification models' read-out); the user-layout store of the
+    other steps is skipped.
     """
     require_device(X, h0, wA, wB, bias)
     if packed is None:
@@ -410,15 +413,16 @@ def fused_cell_forward(X, h0, wA, wB, bias, graph, gates=None, return_states=Fal
         gi, gf = g['in'], g['forget']
     wpack = _fused_pack_weights(wA, wB, st)
     b32 = bias.detach().float().contiguous().view(-1) if bias is not None else None
-    H = torch.empty((B, T, F, N), dtype=torch.bfloat16, device=dev)
+    H = torch.empty((B, 1 if last_only else T, F, N), dtype=torch.bfloat16, device=dev)
     direct = (N % 8 == 0)                 # the step kernels write the user layout themselves (16-byte row stores)
     evs = None
     if events is not None:                               # raw hipEvent_t handles, one slot per step (host array, read during the call)
         evs = (C.c_void_p * T)(*[(e.cuda_event if e is not None else None) for e in events])
     check(lib.gcrnn_fused_forward_bf16(_p(xs), _p(h0s), _p(hs), _p(wpack), _p(b32), _p(gi), _p(gf), *_fused_graph_args(plan),
-                                       B, T, N, F, G, K, _p(H) if direct else None, evs, st), 'fused_forward')
+                                       B, T, N, F, G, K, _p(H) if direct else None, int(last_only), evs, st), 'fused_forward')
     if not direct:
-        check(lib.gcrnn_unpack_seq_major(_lib.BF16, _p(hs), _p(H), B, T, F, N, plan['npad'], None, st), 'unpack_seq')
+        src = hs[T - 1:] if last_only else hs
+        check(lib.gcrnn_unpack_seq_major(_lib.BF16, _p(src), _p(H), B, 1 if last_only else T, F, N, plan['npad'], None, st), 'unpack_seq')
     if return_states:
         return hs_all, plan, H
     return H

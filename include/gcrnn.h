@@ -155,13 +155,15 @@ int gcrnn_fused_pack_weights(int wdtype, const void* wA, const void* wB, void* w
  * Huser (may be NULL; needs N % 8 == 0): the states are ALSO written in the user layout H[B][T][F][N] by the step kernels
  * themselves (LDS-transposed 16-byte row stores), which replaces gcrnn_unpack_seq_major over the whole sequence.
  * T launches on `stream`. The graph is kept resident in LDS when 64 KiB + weights + 96*entries B <= 160 KiB.
+ * huser_last_only != 0: Huser is [B][1][F][N] and receives the LAST state only (the classification models read nothing else,
+ * architectures.py:1841-1850); the other steps skip the user-layout store.
  * step_events (or NULL): host array of T hipEvent_t (entries may be NULL); the launch of step t first makes `stream` wait for
  * step_events[t] -- xs[t] is then allowed to be produced on another stream while earlier steps run. */
 int gcrnn_fused_forward_bf16(const void* xs, const void* h0, void* hs, const void* wpack, const float* bias,
                              const float* gi, const float* gf, const int32_t* tile_nodes, const int32_t* tile_off,
                              const int32_t* ell_col, const float* ell_val, const void* ell_val4, const void* ell_col4,
                              int64_t entries, int64_t B, int64_t T, int64_t N, int64_t F, int64_t G, int64_t K,
-                             void* Huser, void* const* step_events, void* stream);
+                             void* Huser, int huser_last_only, void* const* step_events, void* stream);
 
 /* Time-gate pre-pass (graphML.py:2357-2374): for every (t, b)
  *   sum over gate_out[t][b][0 .. F/16*8) = sum_{n,f} tanh( A_g(S) x_t + B_g(S) h0 + 2 b_g )[n][f] * gate_w[n][f]
