@@ -69,7 +69,7 @@ def _bind(lib):
                                                _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_p, C.c_int, _c_p, _c_p]),
         'gcrnn_pack_seq_major_steps': (C.c_int, [_c_p, _c_p, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_p]),
         'gcrnn_fused_gate_prepass_bf16': (C.c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p,
-                                                    _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_p]),
+                                                    _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_p, _c_p]),
         'gcrnn_fused_gate_readout_slabs': (_c_i64, [_c_i64]),
         'gcrnn_fused_gate_readout_backward_bf16': (C.c_int, [_c_p, _c_p, _c_p, _c_p, _c_i64, _c_i64, _c_i64, _c_p]),
         'gcrnn_fused_gate_grad_bf16': (C.c_int, [_c_p] * 12 + [_c_i64] * 7 + [_c_p]),
@@ -77,7 +77,7 @@ def _bind(lib):
                                                      _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_p, _c_p, _c_p, _c_p]),
         'gcrnn_fused_backward_weight_bf16': (C.c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p,
                                                        _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_p, _c_p,
-                                                       C.c_int, _c_p]),
+                                                       C.c_int, _c_p, _c_p]),
         'gcrnn_small_supported': (C.c_int, [C.c_int, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64]),
         'gcrnn_small_forward': (C.c_int, [C.c_int, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p,
                                           _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_p]),

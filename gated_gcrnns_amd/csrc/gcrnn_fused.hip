@@ -245,11 +245,11 @@ static int fused_dispatch(int mode, const void* xs, const void* h0, void* hs, co
                           int64_t B, int64_t T, int64_t N, int64_t F, int64_t G, int64_t K, hipStream_t st,
                           const void* bw_dHs = nullptr, const void* bw_hs = nullptr, void* bw_dh0 = nullptr,
                           void* huser = nullptr, const void* bw_h0 = nullptr, void* const* step_events = nullptr,
-                          int huser_last_only = 0) {
+                          int huser_last_only = 0, const int32_t* hzero_flag = nullptr) {
 #define GCRNN_FUSED_CASE(KK, HH, XX) \
   if (K == KK && F == 32 * HH && G == 32 * XX) \
     return fused_launch_t<KK, HH, XX>(mode, xs, h0, hs, wpack, bias, gi, gf, gate_w, gate_out, ga, B, T, N, st, bw_dHs, \
-                                      bw_hs, bw_h0, bw_dh0, huser, step_events, huser_last_only);
+                                      bw_hs, bw_h0, bw_dh0, huser, step_events, huser_last_only, hzero_flag);
   GCRNN_FUSED_CASE(5, 2, 2)
   GCRNN_FUSED_CASE(4, 2, 2)
   GCRNN_FUSED_CASE(3, 2, 2)
@@ -292,11 +292,13 @@ extern "C" int gcrnn_fused_gate_prepass_bf16(const void* xs, const void* h0, con
                                              const float* gate_w, float* gate_out, void* cs, const int32_t* tile_nodes,
                                              const int32_t* tile_off, const int32_t* ell_col, const float* ell_val,
                                              const void* ell_val4, const void* ell_col4, int64_t entries, int64_t B,
-                                             int64_t T, int64_t N, int64_t F, int64_t G, int64_t K, void* stream) {
+                                             int64_t T, int64_t N, int64_t F, int64_t G, int64_t K, const int32_t* h0_zero_flag,
+                                             void* stream) {
   if (!xs || !h0 || !wpack || !gate_w || !gate_out || !tile_nodes || !tile_off || !ell_col || !ell_val) return GCRNN_ERR_NULL_POINTER;
   if (B <= 0 || T <= 0 || N <= 0 || N > NP || B * T > (1 << 24) || entries < 0 || entries % 4) return GCRNN_ERR_BAD_SHAPE;
   const FusedGraphArgs ga{tile_nodes, tile_off, ell_col, ell_val, ell_val4, ell_col4, entries};
-  return fused_dispatch(2, xs, h0, cs, wpack, bias, nullptr, nullptr, gate_w, gate_out, ga, B, T, N, F, G, K, as_stream(stream));
+  return fused_dispatch(2, xs, h0, cs, wpack, bias, nullptr, nullptr, gate_w, gate_out, ga, B, T, N, F, G, K, as_stream(stream),
+                        nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, h0_zero_flag);
 }
 
 // d loss / d (scalar time gate) of one filter of the gated cell:  out[t*B+b][partials] summed = sum_{f,n} (W(S) z + b) . dpre

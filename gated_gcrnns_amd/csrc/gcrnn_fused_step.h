@@ -205,7 +205,8 @@ __global__ __launch_bounds__(STHREADS) void fused_step_kernel(
     const uint16_t* __restrict__ aux0,      // EPI 2: upstream gradient dH_{t-1} [B][NP][F] bf16 (or null); EPI 3: dpre [B][NP][F] bf16
     const uint16_t* __restrict__ aux1,      // EPI 2: state h_{t-1} [B][NP][F] bf16;  EPI 0: user-layout output H[.][t][F][N] (or null)
     int ubstride,                           // EPI 0: elements between consecutive sequences of the user-layout output (T*F*N)
-    int entries, int B, int hmod, int N) {
+    int entries, int B, int hmod, int N,
+    const int32_t* __restrict__ flags) {   // EPI 1 (or null): flags[0] != 0 = the state operand h0 is all zeros -> its loads and MFMAs are skipped
   constexpr int KS = HS + XS;
   constexpr int F = 32 * HS, G = 32 * XS;
   constexpr int NCH = F / FC;
@@ -274,6 +275,9 @@ __global__ __launch_bounds__(STHREADS) void fused_step_kernel(
   const __amdgpu_buffer_rsrc_t rsrc_a0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(aux0), 0, ((EPI == 2 || EPI == 3) && aux0) ? B * (NP * F * 2) : 0, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsrc_a1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(aux1), 0, (EPI == 2 && aux1) ? B * (NP * F * 2) : 0, 0x00020000);
 
+  // gate pre-pass with an all-zero initial state (every training loop of the reference starts from h0 = 0, train_rnn.py:256): the
+  // state half of the operand contributes exactly nothing -- skip its loads and MFMAs (wave-uniform)
+  const bool skip_h = (EPI == 1) && flags && flags[0] != 0;
   for (int b = b0; b < B; b += seq_slots) {
   const int soff_h = (b % hmod) * (NP * F * 2);     // hmod < B: every item of the gate pre-pass reads h0[b]
   const int soff_x = b * (NP * G * 2);
@@ -301,7 +305,8 @@ __global__ __launch_bounds__(STHREADS) void fused_step_kernel(
     for (int s = 0; s < KS; ++s) bfr[i][s] = __builtin_bit_cast(bf16x8, uint4{(unsigned)roh, (unsigned)rox, (unsigned)s, 1u});
 #else
     for (int s = 0; s < HS; ++s)
-      bfr[i][s] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsrc_h, roh + 64 * s, soff_h, 0));
+      bfr[i][s] = skip_h ? __builtin_bit_cast(bf16x8, uint4{0u, 0u, 0u, 0u})
+                         : __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsrc_h, roh + 64 * s, soff_h, 0));
 #pragma unroll
     for (int s = 0; s < XS; ++s)
       bfr[i][HS + s] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, rox + 64 * s, soff_x, 0));
@@ -320,11 +325,13 @@ __global__ __launch_bounds__(STHREADS) void fused_step_kernel(
         f32x4 accg[GP];
 #pragma unroll
         for (int p = 0; p < GP; ++p) accg[p] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (!skip_h) {
 #pragma unroll
-        for (int s = 0; s < HS; ++s) {
-          const bf16x8 a = __builtin_bit_cast(bf16x8, wl[(tap * KS + s) * 64 + lane]);
+          for (int s = 0; s < HS; ++s) {
+            const bf16x8 a = __builtin_bit_cast(bf16x8, wl[(tap * KS + s) * 64 + lane]);
 #pragma unroll
-          for (int p = 0; p < GP; ++p) accg[p] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bfr[i + p][s], accg[p], 0, 0, 0);
+            for (int p = 0; p < GP; ++p) accg[p] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bfr[i + p][s], accg[p], 0, 0, 0);
+          }
         }
         // time-gated cell: gi (x W_x) + gf (h W_h) on ONE accumulator: h-chain, scale by gf/gi, continue the chain with x, scale
         // by gi (gi = sigmoid(.) > 0; the wave-uniform guard covers an underflowed gate)
@@ -591,7 +598,7 @@ __global__ __launch_bounds__(STHREADS) void fused_step_kernel(
 
 typedef void (*fused_kern_t)(const uint16_t*, const uint16_t*, uint16_t*, const uint4*, const float*, const float*,
                              const float*, const int32_t*, const int32_t*, const int32_t*, const float*, const float4*,
-                             const uint2*, const float*, float*, const uint16_t*, const uint16_t*, int, int, int, int, int);
+                             const uint2*, const float*, float*, const uint16_t*, const uint16_t*, int, int, int, int, int, const int32_t*);
 
 struct FusedGraphArgs {
   const int32_t* tile_nodes; const int32_t* tile_off; const int32_t* ell_col; const float* ell_val;
@@ -603,7 +610,8 @@ int fused_launch_t(int mode /*0 plain, 1 gated, 2 gate pre-pass, 3 BPTT data gra
                           const void* h0, void* hs, const void* wpack, const float* bias, const float* gi, const float* gf,
                           const float* gate_w, float* gate_out, const FusedGraphArgs& ga, int64_t B, int64_t T, int64_t N,
                           hipStream_t st, const void* bw_dHs = nullptr, const void* bw_hs = nullptr, const void* bw_h0 = nullptr,
-                          void* bw_dh0 = nullptr, void* huser = nullptr, void* const* step_events = nullptr, int huser_last_only = 0) {
+                          void* bw_dh0 = nullptr, void* huser = nullptr, void* const* step_events = nullptr, int huser_last_only = 0,
+                          const int32_t* hzero_flag = nullptr) {
   constexpr int F = 32 * HS, G = 32 * XS, KS = HS + XS;
   const size_t base = (size_t)NP * FC * 4 + (size_t)K * KS * 1024;
   const size_t resident_bytes = base + (size_t)ga.entries * 16 * 6;
@@ -642,17 +650,17 @@ int fused_launch_t(int mode /*0 plain, 1 gated, 2 gate pre-pass, 3 BPTT data gra
       if (mode == 2)      // operands [h0 | x_t]; optional store of c_t = tanh(pre) into hs
         kern<<<grid_for(items), STHREADS, lds, st>>>(x + t0 * xstep, (const uint16_t*)h0, h ? h + t0 * hstep : nullptr, (const uint4*)wpack, bias,
                                      nullptr, nullptr, ga.tile_nodes, ga.tile_off, ga.ell_col, ga.ell_val, (const float4*)ga.ell_val4,
-                                     (const uint2*)ga.ell_col4, gate_w, go, nullptr, nullptr, 0, (int)ga.entries, (int)items, (int)B, (int)N);
+                                     (const uint2*)ga.ell_col4, gate_w, go, nullptr, nullptr, 0, (int)ga.entries, (int)items, (int)B, (int)N, hzero_flag);
       else if (XS == 0)   // operand = one [T*B][NP][F] array, per-item dpre in bw_dHs
         kern<<<grid_for(items), STHREADS, lds, st>>>(nullptr, (const uint16_t*)h0 + t0 * hstep, nullptr, (const uint4*)wpack, bias, nullptr, nullptr,
                                      ga.tile_nodes, ga.tile_off, ga.ell_col, ga.ell_val, (const float4*)ga.ell_val4,
                                      (const uint2*)ga.ell_col4, nullptr, go, (const uint16_t*)bw_dHs + t0 * hstep, nullptr, 0,
-                                     (int)ga.entries, (int)items, (int)items, (int)N);
+                                     (int)ga.entries, (int)items, (int)items, (int)N, nullptr);
       else                // input filter with G != F: operand [0 | x_t] -- ONE all-zero state block shared by every item (hmod = 1)
         kern<<<grid_for(items), STHREADS, lds, st>>>(x + t0 * xstep, (const uint16_t*)h0, nullptr, (const uint4*)wpack, bias, nullptr, nullptr,
                                      ga.tile_nodes, ga.tile_off, ga.ell_col, ga.ell_val, (const float4*)ga.ell_val4,
                                      (const uint2*)ga.ell_col4, nullptr, go, (const uint16_t*)bw_dHs + t0 * hstep, nullptr, 0,
-                                     (int)ga.entries, (int)items, 1, (int)N);
+                                     (int)ga.entries, (int)items, 1, (int)N, nullptr);
     }
   } else if (mode == 3) {
     // BPTT: hs (= dpre, [T][B][NP][F]) already holds dpre_{T-1}; walk t = T-1 .. 1, then optionally d h0.
@@ -665,13 +673,13 @@ int fused_launch_t(int mode /*0 plain, 1 gated, 2 gate pre-pass, 3 BPTT data gra
       kern<<<grid, STHREADS, lds, st>>>(nullptr, h + t * hstep, h + (t - 1) * hstep, (const uint4*)wpack, nullptr, nullptr,
                                    gf ? gf + t * B : nullptr, ga.tile_nodes, ga.tile_off, ga.ell_col, ga.ell_val,
                                    (const float4*)ga.ell_val4, (const uint2*)ga.ell_col4, nullptr, gate_out ? gate_out + t * gstep : nullptr,
-                                   dH + (t - 1) * hstep, hst + (t - 1) * hstep, 0, (int)ga.entries, (int)B, (int)B, (int)N);
+                                   dH + (t - 1) * hstep, hst + (t - 1) * hstep, 0, (int)ga.entries, (int)B, (int)B, (int)N, nullptr);
     }
     if (bw_dh0 || gate_out)
       kern<<<grid, STHREADS, lds, st>>>(nullptr, h, (uint16_t*)bw_dh0, (const uint4*)wpack, nullptr, nullptr, gf, ga.tile_nodes,
                                    ga.tile_off, ga.ell_col, ga.ell_val, (const float4*)ga.ell_val4, (const uint2*)ga.ell_col4,
                                    nullptr, gate_out, nullptr, gate_out ? (const uint16_t*)bw_h0 : nullptr, 0, (int)ga.entries,
-                                   (int)B, (int)B, (int)N);
+                                   (int)B, (int)B, (int)N, nullptr);
   } else {
     const unsigned grid = grid_for(B);
     for (int64_t t = 0; t < T; ++t) {
@@ -683,7 +691,7 @@ int fused_launch_t(int mode /*0 plain, 1 gated, 2 gate pre-pass, 3 BPTT data gra
                                    (const float4*)ga.ell_val4, (const uint2*)ga.ell_col4, nullptr, nullptr, nullptr,
                                    !huser ? nullptr : (!huser_last_only ? (const uint16_t*)huser + t * F * N : (t == T - 1 ? (const uint16_t*)huser : nullptr)),
                                    (int)((huser_last_only ? 1 : T) * F * N),
-                                   (int)ga.entries, (int)B, (int)B, (int)N);
+                                   (int)ga.entries, (int)B, (int)B, (int)N, nullptr);
     }
   }
   GCRNN_CHECK_LAUNCH();
@@ -692,7 +700,7 @@ int fused_launch_t(int mode /*0 plain, 1 gated, 2 gate pre-pass, 3 BPTT data gra
 
 // The step kernel's instantiations are spread over several translation units (gcrnn_fused_step_k*.hip) so that the library
 // builds in parallel; gcrnn_fused.hip only declares them.
-#define GCRNN_STEP_SIG (int, const void*, const void*, void*, const void*, const float*, const float*, const float*, const float*, float*, const FusedGraphArgs&, int64_t, int64_t, int64_t, hipStream_t, const void*, const void*, const void*, void*, void*, void* const*, int)
+#define GCRNN_STEP_SIG (int, const void*, const void*, void*, const void*, const float*, const float*, const float*, const float*, float*, const FusedGraphArgs&, int64_t, int64_t, int64_t, hipStream_t, const void*, const void*, const void*, void*, void*, void* const*, int, const int32_t*)
 #define GCRNN_STEP_DECLARE(K, HS, XS) extern template int fused_launch_t<K, HS, XS> GCRNN_STEP_SIG;
 #define GCRNN_STEP_DEFINE(K, HS, XS) template int fused_launch_t<K, HS, XS> GCRNN_STEP_SIG;
 // the (HS, XS) operand shapes built for a tap count K: [h | x] with F = G = 64 / 32, F = 64 with G <= 32, and the state-only

@@ -29,6 +29,7 @@ __global__ __launch_bounds__(512, 2) void fused_wgrad_kernel(
     const float* __restrict__ gi,            // [T][B] input-filter gates of the time-gated cell, or null
     const float* __restrict__ gf,            // [T][B] state-filter gates, or null
     int h_is_h0,                             // the state operand of EVERY item is h0 (gate sub-cells, graphML.py:2362, 2370)
+    const int32_t* __restrict__ hzero,       // with h_is_h0 (or null): hzero[0] != 0 = h0 is all zeros: the state-feature waves skip their loads and MFMAs
     int entries, int B, int Tn, int N) {
   constexpr int F = 32 * HS, G = 32 * XS, C = F + G, NCH = F / FC, JT = C / 16;
   static_assert(JT <= WAVES, "one input-feature tile per wave");
@@ -96,7 +97,7 @@ __global__ __launch_bounds__(512, 2) void fused_wgrad_kernel(
     float gcur = gprev;
     float gbias = 2.f;                                    // the one bias enters both filters
     if (gw_) { gcur = gw_[t * B + b]; gbias = gi[t * B + b] + gf[t * B + b]; }
-    const bool live = has_tile && gcur > 1e-12f;          // wave-uniform
+    const bool live = has_tile && gcur > 1e-12f && !(h_is_h0 && !is_x && hzero && hzero[0] != 0);      // wave-uniform
     if (live && gcur != gprev) {
       const float rb = gprev / gcur;
 #pragma unroll
@@ -106,7 +107,7 @@ __global__ __launch_bounds__(512, 2) void fused_wgrad_kernel(
     if (is_x) { zsrc = Xuser + ((int64_t)b * Tn + t) * G * N; zrows = G; }
     else if (t > 0 && !h_is_h0) { zsrc = Huser + ((int64_t)b * Tn + (t - 1)) * F * N; zrows = F; }
     else { zsrc = h0user + (int64_t)b * F * N; zrows = F; }
-    const __amdgpu_buffer_rsrc_t rsrc_z = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(zsrc), 0, has_tile ? zrows * N * 2 : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_z = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(zsrc), 0, live ? zrows * N * 2 : 0, 0x00020000);      // dead waves: zero-length buffer, the loads cost nothing
     const int vo = (jrow * N + 8 * q) * 2;
 #pragma unroll
     for (int s2 = 0; s2 < 16; ++s2)
@@ -242,8 +243,8 @@ __global__ __launch_bounds__(512, 2) void fused_wgrad_kernel(
 
 template <int K, int HS, int XS>
 static int fused_wgrad_t(const void* dpre, const void* Xuser, const void* Huser, const void* h0user, float* dW, float* dbsum,
-                         const FusedGraphArgs& ga, const float* gi, const float* gf, int h_is_h0, int64_t B, int64_t T, int64_t N,
-                         hipStream_t st) {
+                         const FusedGraphArgs& ga, const float* gi, const float* gf, int h_is_h0, const int32_t* hzero, int64_t B,
+                         int64_t T, int64_t N, hipStream_t st) {
   constexpr int F = 32 * HS;
   const size_t lds = (size_t)NP * FC * 4 + (size_t)ga.entries * 96 + TBYTES + 64;
   if (lds > 160 * 1024 || !ga.ell_val4 || !ga.ell_col4) return GCRNN_ERR_UNSUPPORTED;
@@ -257,7 +258,7 @@ static int fused_wgrad_t(const void* dpre, const void* Xuser, const void* Huser,
   GCRNN_PRE_LAUNCH();
   kern<<<(unsigned)(slots * NCH), 512, lds, st>>>((const uint16_t*)dpre, (const uint16_t*)Xuser, (const uint16_t*)Huser,
                                                    (const uint16_t*)h0user, dW, dbsum, ga.tile_nodes, ga.tile_off,
-                                                   (const float4*)ga.ell_val4, (const uint2*)ga.ell_col4, gi, gf, h_is_h0,
+                                                   (const float4*)ga.ell_val4, (const uint2*)ga.ell_col4, gi, gf, h_is_h0, hzero,
                                                    (int)ga.entries, (int)B, (int)T, (int)N);
   GCRNN_CHECK_LAUNCH();
   return GCRNN_OK;
@@ -267,7 +268,7 @@ extern "C" int gcrnn_fused_backward_weight_bf16(const void* dpre, const void* Xu
                                                 float* dW, float* dbsum, const int32_t* tile_nodes, const int32_t* tile_off,
                                                 const void* ell_val4, const void* ell_col4, int64_t entries, int64_t B,
                                                 int64_t T, int64_t N, int64_t F, int64_t G, int64_t K, const float* gi,
-                                                const float* gf, int h_is_h0, void* stream) {
+                                                const float* gf, int h_is_h0, const int32_t* h0_zero_flag, void* stream) {
   if ((gi == nullptr) != (gf == nullptr)) return GCRNN_ERR_NULL_POINTER;
   if (!dpre || !Xuser || (!Huser && !h_is_h0) || !h0user || !dW || !tile_nodes || !tile_off || !ell_val4 || !ell_col4) return GCRNN_ERR_NULL_POINTER;
   if (B <= 0 || T <= 0 || N <= 0 || N > NP || N % 8 || entries < 0 || entries % 4 || B * T > (1 << 24)) return GCRNN_ERR_BAD_SHAPE;
@@ -275,7 +276,7 @@ extern "C" int gcrnn_fused_backward_weight_bf16(const void* dpre, const void* Xu
   const FusedGraphArgs ga{tile_nodes, tile_off, nullptr, nullptr, ell_val4, ell_col4, entries};
   hipStream_t st = as_stream(stream);
 #define GCRNN_WG_CASE(KK, HH, XX) \
-  if (K == KK && F == 32 * HH && G == 32 * XX) return fused_wgrad_t<KK, HH, XX>(dpre, Xuser, Huser, h0user, dW, dbsum, ga, gi, gf, h_is_h0, B, T, N, st);
+  if (K == KK && F == 32 * HH && G == 32 * XX) return fused_wgrad_t<KK, HH, XX>(dpre, Xuser, Huser, h0user, dW, dbsum, ga, gi, gf, h_is_h0, h_is_h0 ? h0_zero_flag : nullptr, B, T, N, st);
   GCRNN_WG_CASE(5, 2, 2)
   GCRNN_WG_CASE(4, 2, 2)
   GCRNN_WG_CASE(3, 2, 2)

@@ -343,9 +343,17 @@ def fused_overlap_ok(X):
             and not torch.cuda.is_current_stream_capturing())
 
 
-def fused_time_gate(xs, h0s, wA_g, wB_g, bias_g, lin_w, lin_b, graph, N, store_states=False):
+def fused_h0_zero_flag(h0):
+    """int32 [1] on the device: 1 when the initial state is all zeros (every training loop of the reference starts from
+    zeros(B, F, N), train_rnn.py:256). The gate kernels read it and skip the state operand's loads and matrix products -- a
+    data-dependent short cut with bit-identical results, decided on the device (no host synchronisation)."""
+    return (h0 == 0).all().to(torch.int32).view(1)
+
+
+def fused_time_gate(xs, h0s, wA_g, wB_g, bias_g, lin_w, lin_b, graph, N, store_states=False, hzero=None):
     """One time gate of the fused path for all (t, b) (graphML.py:2357-2374): sigmoid(Linear(vec(tanh(A_g(S)x_t + B_g(S)h0
-    + 2 b_g)))) as ONE pre-pass launch. xs [T][B][NPad][G], h0s [1][B][NPad][F] sequence-major bf16. Returns the gate
+    + 2 b_g)))) as ONE pre-pass launch. xs [T][B][NPad][G], h0s [1][B][NPad][F] sequence-major bf16. hzero: device int32
+    flag (fused_h0_zero_flag), non-zero when h0 is all zeros -- the kernel then skips the state half of the operand. Returns the gate
     [T][B] fp32 (and, with store_states, the gate cell's states c [T][B][NPad][F] bf16 for its BPTT)."""
     T, B, npad, G = xs.shape
     F = wA_g.shape[0]
@@ -358,7 +366,7 @@ def fused_time_gate(xs, h0s, wA_g, wB_g, bias_g, lin_w, lin_b, graph, N, store_s
     parts = torch.empty((T * B, (F // 16) * int(lib.gcrnn_fused_step_waves())), dtype=torch.float32, device=xs.device)
     cs = torch.empty((T, B, npad, F), dtype=torch.bfloat16, device=xs.device) if store_states else None
     check(lib.gcrnn_fused_gate_prepass_bf16(_p(xs), _p(h0s), _p(wp), _p(bg), _p(gw), _p(parts), _p(cs),
-                                            *_fused_graph_args(plan), B, T, N, F, G, K, st), 'gate_prepass')
+                                            *_fused_graph_args(plan), B, T, N, F, G, K, _p(hzero), st), 'gate_prepass')
     acc = parts.sum(dim=1)                                                    # fixed order: deterministic gates
     if lin_b is not None:
         acc = acc + lin_b.detach().float()
@@ -403,13 +411,14 @@ def fused_cell_forward(X, h0, wA, wB, bias, graph, gates=None, return_states=Fal
         gi, gf = (g.detach().float().contiguous() for g in gate_values)
         assert tuple(gi.shape) == (T, B) and tuple(gf.shape) == (T, B)
     elif gates is not None:
+        hzero = fused_h0_zero_flag(h0)
         g = {}
         for name in ('in', 'forget'):
             wA_g, wB_g, bias_g, lin_w, lin_b = gates[name]
             if wA_g.shape[3] != G:
                 wA_g = torch.nn.functional.pad(wA_g.detach(), (0, G - wA_g.shape[3]))
             assert max(wA_g.shape[2], wB_g.shape[2]) == K and wA_g.shape[0] == F
-            g[name] = fused_time_gate(xs, h0s, wA_g, wB_g, bias_g, lin_w, lin_b, graph, N)
+            g[name] = fused_time_gate(xs, h0s, wA_g, wB_g, bias_g, lin_w, lin_b, graph, N, hzero=hzero)
         gi, gf = g['in'], g['forget']
     wpack = _fused_pack_weights(wA, wB, st)
     b32 = bias.detach().float().contiguous().view(-1) if bias is not None else None
@@ -466,7 +475,7 @@ def fused_backward_data(dHs, hs, wB, graph, want_dh0=True, gf=None, h0s=None, bi
     return dpre, dh0, dgf
 
 
-def fused_backward_weight(dpre, X, H, h0, graph, F, G, K, want_bias=False, gi=None, gf=None, h_is_h0=False):
+def fused_backward_weight(dpre, X, H, h0, graph, F, G, K, want_bias=False, gi=None, gf=None, h_is_h0=False, hzero=None):
     """dW [F][K][F+G] fp32 (columns: F state features, then G input features) from dpre (sequence-major bf16) and the
     user-layout bf16 tensors X [B][T][G][N], H [B][T][F][N] (forward output), h0 [B][F][N]. gi / gf [T][B] fp32: item
     (t, b) enters the input-filter columns with weight gi and the state-filter columns with gf (time-gated cell).
@@ -481,7 +490,7 @@ def fused_backward_weight(dpre, X, H, h0, graph, F, G, K, want_bias=False, gi=No
     check(lib.gcrnn_fused_backward_weight_bf16(_p(dpre), _p(Xc), _p(Hc), _p(h0c), _p(dW),
                                                _p(dbs), _p(plan['tile_slots']), _p(plan['tile_off']), _p(plan['ell_val4']),
                                                _p(plan['ell_col4']), plan['entries'], B, T, graph.N, F, G, K,
-                                               _p(gi), _p(gf), int(h_is_h0), _stream()),
+                                               _p(gi), _p(gf), int(h_is_h0), _p(hzero), _stream()),
           'fused_backward_weight')
     return (dW, dbs) if want_bias else dW
 
@@ -532,16 +541,16 @@ class _FusedTimeGate(torch.autograd.Function):
                from h0 = 0 and never ask for either, train_rnn.py:247-276)."""
 
     @staticmethod
-    def forward(ctx, xs, h0s, X, h0, wA_g, wB_g, bias_g, lin_w, lin_b, graph):
+    def forward(ctx, xs, h0s, X, h0, wA_g, wB_g, bias_g, lin_w, lin_b, graph, hzero):
         N = X.shape[3]
-        gate, cs, gw = fused_time_gate(xs, h0s, wA_g, wB_g, bias_g, lin_w, lin_b, graph, N, store_states=True)
-        ctx.save_for_backward(X, h0, wA_g, wB_g, bias_g, lin_w, lin_b, gate, cs, gw)
+        gate, cs, gw = fused_time_gate(xs, h0s, wA_g, wB_g, bias_g, lin_w, lin_b, graph, N, store_states=True, hzero=hzero)
+        ctx.save_for_backward(X, h0, wA_g, wB_g, bias_g, lin_w, lin_b, gate, cs, gw, hzero)
         ctx.graph = graph
         return gate
 
     @staticmethod
     def backward(ctx, dgate):
-        X, h0, wA_g, wB_g, bias_g, lin_w, lin_b, gate, cs, gw = ctx.saved_tensors
+        X, h0, wA_g, wB_g, bias_g, lin_w, lin_b, gate, cs, gw, hzero = ctx.saved_tensors
         if ctx.needs_input_grad[2] or ctx.needs_input_grad[3]:
             raise GcrnnError('the fused time gate does not produce gradients w.r.t. X or h0')
         B, T, G, N = X.shape
@@ -555,7 +564,7 @@ class _FusedTimeGate(torch.autograd.Function):
         # cs becomes dpre_g in place: a second backward through the same graph is not supported (retain_graph)
         check(lib.gcrnn_fused_gate_readout_backward_bf16(_p(cs), _p(dlogit), _p(gw), _p(dw_part), items, N, F, _stream()),
               'gate_readout_backward')
-        dW, dbs = fused_backward_weight(cs, X, None, h0, ctx.graph, F, G, K, want_bias=True, h_is_h0=True)
+        dW, dbs = fused_backward_weight(cs, X, None, h0, ctx.graph, F, G, K, want_bias=True, h_is_h0=True, hzero=hzero)
         gA = dW[:, :Kin, F:].unsqueeze(1).to(wA_g.dtype) if ctx.needs_input_grad[4] else None
         gB = dW[:, :Kst, :F].unsqueeze(1).to(wB_g.dtype) if ctx.needs_input_grad[5] else None
         gb = dbs.view_as(bias_g).to(bias_g.dtype) if (bias_g is not None and ctx.needs_input_grad[6]) else None
@@ -563,7 +572,7 @@ class _FusedTimeGate(torch.autograd.Function):
         if ctx.needs_input_grad[7]:
             glw = dw_part.sum(dim=0).view(npad, F)[:N].t().reshape(1, F * N).to(lin_w.dtype)     # [N][F] -> vec over (f, n)
         glb = dlogit.sum().view(1).to(lin_b.dtype) if (lin_b is not None and ctx.needs_input_grad[8]) else None
-        return None, None, None, None, gA, gB, gb, glw, glb, None
+        return None, None, None, None, gA, gB, gb, glw, glb, None, None
 
 
 class _FusedCell(torch.autograd.Function):
@@ -637,8 +646,9 @@ def fused_cell_train(X, h0, wA, wB, bias, graph, gates=None):
         return _FusedCell.apply(X, h0, wA, wB, bias, None, None, graph, None, None)
     with torch.no_grad():
         xs, hs_all = fused_pack_inputs(X, h0, graph)
-    gi = _FusedTimeGate.apply(xs, hs_all[:1], X, h0, *gates['in'], graph)
-    gf = _FusedTimeGate.apply(xs, hs_all[:1], X, h0, *gates['forget'], graph)
+        hzero = fused_h0_zero_flag(h0)
+    gi = _FusedTimeGate.apply(xs, hs_all[:1], X, h0, *gates['in'], graph, hzero)
+    gf = _FusedTimeGate.apply(xs, hs_all[:1], X, h0, *gates['forget'], graph, hzero)
     return _FusedCell.apply(X, h0, wA, wB, bias, gi, gf, graph, xs, hs_all)
 
 

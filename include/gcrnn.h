@@ -172,13 +172,15 @@ int gcrnn_fused_forward_bf16(const void* xs, const void* h0, void* hs, const voi
  * with the gate sub-cell's packed weights (gcrnn_fused_pack_weights of GFL_in / GFL_forget) and gate_w = the gate's
  * Linear(N*F -> 1) weight re-laid node-major [N][F] (fp32). All T*B items run in ONE launch because the reference's gates
  * read h0, never h_{t-1} (graphML.py:2362, 2370). The caller applies sigmoid(sum + c).
+ * h0_zero_flag (or NULL): device int32; non-zero = h0 is all zeros (every training loop of the reference starts there,
+ * train_rnn.py:256): the state half of the operand then contributes exactly nothing and its loads and MFMAs are skipped.
  * cs (or NULL): [T][B][NPad][F] bf16, receives the gate cell's state c_t = tanh(.) for the gate's BPTT (padded rows zero).
  * Launches are split over whole time steps where T*B*NPad*F*2 bytes exceed the 32-bit buffer offsets. */
 int gcrnn_fused_gate_prepass_bf16(const void* xs, const void* h0, const void* wpack, const float* bias,
                                   const float* gate_w, float* gate_out, void* cs, const int32_t* tile_nodes,
                                   const int32_t* tile_off, const int32_t* ell_col, const float* ell_val,
                                   const void* ell_val4, const void* ell_col4, int64_t entries, int64_t B, int64_t T,
-                                  int64_t N, int64_t F, int64_t G, int64_t K, void* stream);
+                                  int64_t N, int64_t F, int64_t G, int64_t K, const int32_t* h0_zero_flag, void* stream);
 
 /* d loss / d (scalar time gate) of ONE filter of the time-gated cell (the gates multiply the filter outputs, graphML.py:2420-2421):
  *   sum over out[t][b][0 .. F/16*8) = sum_{f,n} ( W(S) z[t][b] + bias )[n][f] * dpre[t][b][n][f]
@@ -229,7 +231,9 @@ int gcrnn_fused_backward_weight_bf16(const void* dpre, const void* Xuser, const 
                                      float* dbsum /* [F] += bias gradient sum_{t,b} (gi + gf) sum_n dpre (2 sum dpre without gates), or NULL */,
                                      const int32_t* tile_nodes, const int32_t* tile_off, const void* ell_val4,
                                      const void* ell_col4, int64_t entries, int64_t B, int64_t T, int64_t N, int64_t F,
-                                     int64_t G, int64_t K, const float* gi, const float* gf, int h_is_h0, void* stream);
+                                     int64_t G, int64_t K, const float* gi, const float* gf, int h_is_h0,
+                                     const int32_t* h0_zero_flag /* with h_is_h0 (or NULL): device int32, non-zero = h0 is all zeros */,
+                                     void* stream);
 
 /* ==== small-graph regime: the whole T-step recurrence of a sequence inside one workgroup, one launch ============
  * Replaces GGCRNNCell.forward (graphML.py:2336-2427, un-gated or time-gated with precomputed gates) when
