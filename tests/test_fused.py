@@ -573,3 +573,70 @@ def test_fused_last_state_only_matches_full_forward(N, tg):
         H = m.stateGCRNN(X, h0)
         ref = m.outputNN(H.select(1, -1).reshape(-1, F * N))
     assert tuple(logits.shape) == (B, 7) and torch.equal(logits, ref)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('tg', [False, True])
+def test_fused_full_size_batch_independence_and_determinism(tg):
+    """BASELINE configs[1] at the bench's full size (N=1000, K=5, T=32, G=F=64, B=256; the oracle cannot run this in seconds):
+    size-independent properties instead -- (1) every sequence's states are the same bits whether it runs in the batch of 256
+    (one workgroup per CU walking the sequences) or in a batch of 8; (2) two runs agree bit for bit (no atomics on the path);
+    (3) the first sequences match the fp64 oracle on a single step."""
+    import bench
+    import gated_gcrnns_amd.Utils.graphML as gml
+    dev = torch.device('cuda:0')
+    N, K, T, F, B = 1000, 5, 32, 64, 256
+    S = bench.sbm_graph(N)
+    torch.manual_seed(0)
+    cell = gml.GGCRNNCell(F, F, K, K, torch.tanh, tg, None, 1, True)
+    cell.addGSO(torch.tensor(S))
+    cell = cell.to(torch.bfloat16)
+    params = {k: v.detach().double().numpy() for k, v in cell.state_dict().items()}
+    cell = cell.to(dev)
+    gen = torch.Generator(device=dev); gen.manual_seed(5)
+    X = torch.randn(B, T, F, N, device=dev, generator=gen).to(torch.bfloat16)
+    h0 = (0.3 * torch.randn(B, F, N, device=dev, generator=gen)).to(torch.bfloat16)
+    with torch.no_grad():
+        H = cell(X, h0)
+        H2 = cell(X, h0)
+        Hs = cell(X[100:108].contiguous(), h0[100:108].contiguous())
+    assert torch.equal(H, H2)
+    assert torch.equal(H[100:108], Hs)
+    Href = orc.ggcrnn_cell(params, S.astype(np.float32).astype(np.float64), X[:2, :1].double().cpu().numpy(),
+                           h0[:2].double().cpu().numpy(), tg, None)
+    err = np.abs(H[:2, :1].double().cpu().numpy() - Href)
+    assert err.max() <= 4e-3, err.max()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('tg', [False, True])
+def test_fused_full_size_training_gradients_add_over_the_batch(tg):
+    """Full bench size (B=256, T=32, N=1000, K=5, G=F=64), fused BPTT: sequences are independent, so the parameter gradients of
+    the batch equal the sum of those of its two halves (linearity over the batch; the weight-gradient kernel accumulates
+    with float atomics, hence a tolerance instead of bit equality). Covers the grid walk over 8192 (t, b) items."""
+    import bench
+    import gated_gcrnns_amd.Utils.graphML as gml
+    dev = torch.device('cuda:0')
+    N, K, T, F, B = 1000, 5, 32, 64, 256
+    torch.manual_seed(0)
+    cell = gml.GGCRNNCell(F, F, K, K, torch.tanh, tg, None, 1, True)
+    cell.addGSO(torch.tensor(bench.sbm_graph(N)))
+    cell = cell.to(dev)
+    gen = torch.Generator(device=dev); gen.manual_seed(7)
+    X = torch.randn(B, T, F, N, device=dev, generator=gen).to(torch.bfloat16)
+    W = torch.randn(B, T, F, N, device=dev, generator=gen).to(torch.bfloat16)
+    h0 = torch.zeros(B, F, N, device=dev, dtype=torch.bfloat16)
+
+    def grads(sl):
+        cell.zero_grad()
+        assert cell._use_fused_training(X[sl], h0[sl])
+        (cell(X[sl].contiguous(), h0[sl].contiguous()).float() * W[sl].float()).sum().backward()
+        return {n: p.grad.clone() for n, p in cell.named_parameters() if p.grad is not None}
+
+    full, a, b = grads(slice(0, B)), grads(slice(0, B // 2)), grads(slice(B // 2, B))
+    assert set(full) == set(a) == set(b) and len(full) >= (11 if tg else 3)
+    for n, g in full.items():
+        s = a[n] + b[n]
+        sc = float(g.abs().max())
+        assert sc > 0 or float(s.abs().max()) == 0, n
+        assert float((g - s).abs().max()) <= 2e-3 * sc + 1e-12, (n, float((g - s).abs().max()) / max(sc, 1e-30))
