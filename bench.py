@@ -92,26 +92,111 @@ def cpu_baseline(S, params, T, G, F, seconds_budget=20.0):
                       'K=5 G=%d F=%d sequences, best of %d passes (%.2f s each)' % (Bc, T, N, G, F, reps, best)}
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--batch', type=int, default=256, help='sequences per GPU per step')
+    ap.add_argument('--batch', type=int, default=None, help='sequences per GPU per step (default: 256; cfg5: 8; cfg4: 100)')
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32', 'f64'])
     ap.add_argument('--mode', default='fwd', choices=['fwd', 'train'])
+    ap.add_argument('--config', default='cfg2', choices=['cfg2', 'cfg4', 'cfg5'],
+                    help='cfg2 = BASELINE configs[1] (the headline, default); cfg4 = configs[3] (seismic graph N=59, T=200: latency-bound); '
+                         'cfg5 = configs[4] (N=100k, nnz=1e7 streaming CSR SpMM)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--time-gating', action='store_true', help='secondary point: the time-gated cell (fwd or train); '
                     'the headline workload is the un-gated cell')
+    ap.add_argument('--spatial-gating', default=None, choices=['node', 'edge'], help='secondary point: node- / edge-gated cell')
     ap.add_argument('--in-features', type=int, default=CFG['G'], help='secondary point: input features per node (the reference '
                     'drivers feed G = 1; the headline workload is G = F = 64)')
     ap.add_argument('--hipgraph', type=int, default=0, help='replay the fused forward as one captured hipGraph (bf16 fwd)')
-    args = ap.parse_args()
+    ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'], help='process-group backend ("nccl" is RCCL on ROCm; '
+                    'gloo only with --dry-run)')
+    ap.add_argument('--dry-run', action='store_true', help='launcher / rendezvous / reduction plumbing only: no GPU, no kernels '
+                    '(CPU test of the N > 1 entry)')
+    return ap.parse_args(argv)
 
+
+def free_port():
+    import socket
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def self_launch(args, argv):
+    """`python bench.py --gpus N` with N > 1 and no RANK in the environment: start the N ranks as CHILD processes
+    (python -m torch.distributed.run, one rank per GPU, rendezvous on 127.0.0.1) before this process has made any GPU
+    call, relay rank 0's JSON line, and exit with the children's status. The parent never touches the GPU and never
+    re-executes itself."""
+    import subprocess
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
+           '--master-addr', '127.0.0.1', '--master-port', str(free_port()), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')        # dmabuf IPC only on this pool (RCCL needs it)
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    lines = []
+    for line in proc.stdout:
+        s = line.strip()
+        if s.startswith('{') and '"metric"' in s:
+            lines.append(s)
+        else:
+            sys.stderr.write(line)
+    rc = proc.wait()
+    for s in lines:
+        print(s, flush=True)
+    if rc != 0 or not lines:
+        sys.stderr.write('bench.py: the %d-rank launch failed (exit %d): %s\n' % (args.gpus, rc, ' '.join(cmd)))
+        sys.exit(rc if rc != 0 else 1)
+    sys.exit(0)
+
+
+def dry_run(args, rank, world):
+    """No GPU: rendezvous, one timed fake step per rank, MAX over ranks, rank 0 prints the JSON line."""
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group(args.backend if args.backend == 'gloo' else 'gloo')
+    B = args.batch or 256
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        time.sleep(1e-3)
+    wall = time.perf_counter() - t0
+    if world > 1:
+        tw = torch.tensor([wall], dtype=torch.float64)
+        dist.all_reduce(tw, op=dist.ReduceOp.MAX)
+        wall = float(tw.item())
+    if rank == 0:
+        print(json.dumps({'metric': 'sequences/sec (node), N=1000 K=5 T=32 F=64', 'value': world * B * args.steps / wall,
+                          'unit': 'sequences/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+                          'ms_per_step': 1e3 * wall / args.steps, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+                          'dtype': args.dtype, 'data': 'dry-run (no kernels)',
+                          'config': {'workload': 'dry-run', 'batch_per_gpu': B, 'global_batch': world * B, 'mode': args.mode,
+                                     'parallelism': 'dp%d' % world}}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    args = parse_args(argv)
+    if args.gpus > 1 and 'RANK' not in os.environ:
+        self_launch(args, argv)                       # does not return
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
-    assert world == args.gpus, 'launch with torch.distributed.run --nproc-per-node %d' % args.gpus
+    if world != args.gpus:
+        sys.exit('bench.py: --gpus %d but WORLD_SIZE=%d; run `python bench.py --gpus %d` (it starts the ranks itself) or '
+                 '`python -m torch.distributed.run --nnodes=1 --nproc-per-node %d --master-addr 127.0.0.1 bench.py --gpus %d`'
+                 % (args.gpus, world, args.gpus, args.gpus, args.gpus))
+    if args.dry_run:
+        return dry_run(args, rank, world)
+    if args.backend != 'nccl':
+        sys.exit('bench.py: --backend gloo is for --dry-run only (the product has no CPU path)')
+    if args.batch is None:
+        args.batch = {'cfg2': 256, 'cfg4': 100, 'cfg5': 8}[args.config]
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     dist_on = 'RANK' in os.environ and 'WORLD_SIZE' in os.environ          # launched by torch.distributed.run
@@ -120,55 +205,27 @@ def main():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         dist.init_process_group('nccl', device_id=dev)                      # "nccl" is RCCL on ROCm
 
-    import gated_gcrnns_amd.Utils.graphML as gml
+    ctx = dict(args=args, rank=rank, world=world, dev=dev, dist_on=dist_on)
+    if args.config == 'cfg5':
+        out = run_cfg5(ctx)
+    elif args.config == 'cfg4':
+        out = run_cfg4(ctx)
+    else:
+        out = run_cfg2(ctx)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if dist_on:
+        torch.distributed.destroy_process_group()
 
-    N, K, T, G, F = CFG['N'], CFG['K'], CFG['T'], args.in_features, CFG['F']
-    B = args.batch
-    dt = {'bf16': torch.bfloat16, 'f32': torch.float32, 'f64': torch.float64}[args.dtype]
-    elt = {'bf16': 2, 'f32': 4, 'f64': 8}[args.dtype]
-    S = sbm_graph(N)
-    nnz = int(np.count_nonzero(S))
-    torch.manual_seed(0)
-    cell = gml.GGCRNNCell(G, F, K, K, torch.tanh, args.time_gating, None, 1, True)      # reference init U(+-1/sqrt(G*K))
-    cell.addGSO(torch.tensor(S))
-    params = {k: v.detach().numpy().copy() for k, v in cell.state_dict().items()}
-    cell = cell.to(dev).to(dt)
-    gen = torch.Generator(device=dev); gen.manual_seed(1234 + rank)
-    X = torch.randn(B, T, G, N, device=dev, dtype=torch.float32, generator=gen).to(dt)
-    h0 = torch.zeros(B, F, N, device=dev, dtype=dt)
 
-    sync_grads = None
-    if args.mode == 'train':
-        # one optimiser step of the k-step-prediction loop (reference train_rnn.py:247-281): forward, L1 loss on the
-        # state sequence, BPTT, ONE flat gradient all-reduce over RCCL, Adam.
-        # bf16: fp32 master weights, bf16 activations -> fused forward + fused BPTT (un-gated and time-gated cells);
-        # f32 / f64: composed path
-        from gated_gcrnns_amd.parallel import FlatGradAllReduce
-        from gated_gcrnns_amd.Utils.miscTools import batchTimeL1Loss
-        if args.dtype == 'bf16':
-            cell = cell.float()
-        target = torch.randn(B, T, F, N, device=dev, dtype=torch.float32).to(dt)
-        opt = torch.optim.Adam(cell.parameters(), lr=1e-3)
-        sync_grads = FlatGradAllReduce(cell.parameters()) if dist_on else None
+MFMA_BF16_PEAK_TFLOPS = 2500.0   # MI355X_MICROARCH.md: ~2.5 PF dense bf16
+MFMA_F64_PEAK_TFLOPS = 78.6      # v_mfma_f64_16x16x4: 64 cycles per 16x16x4 MFMA per SIMD on MI355X = half the fp32 matrix rate
 
-    runner = None
-    if args.mode == 'fwd' and args.dtype == 'bf16' and args.hipgraph:
-        from gated_gcrnns_amd.ops import FusedForwardGraph
-        runner = FusedForwardGraph(cell, B, T)
 
-    def step():
-        if args.mode == 'fwd':
-            if runner is not None:
-                return runner(X, h0)          # copies X, h0 into the graph's static inputs, then ONE graph launch
-            with torch.no_grad():
-                return cell(X, h0)
-        cell.zero_grad()
-        loss = batchTimeL1Loss(cell(X, h0), target)      # the drivers' loss (reference miscTools.py:112-119), one fused pass
-        loss.backward()
-        if sync_grads is not None:
-            sync_grads.all_reduce_()
-        opt.step()
-        return loss
+def timed_steps(ctx, step):
+    """W untimed warm-up steps, then EXACTLY K steps bracketed by barrier + synchronize on both sides; wall = MAX over ranks.
+    Returns (wall seconds, device milliseconds between HIP events on the current stream)."""
+    args, dev, dist_on = ctx['args'], ctx['dev'], ctx['dist_on']
 
     def sync():
         if dist_on:
@@ -191,62 +248,290 @@ def main():
         tw = torch.tensor([wall], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(tw, op=torch.distributed.ReduceOp.MAX)
         wall = float(tw.item())
-    ms_per_step = 1e3 * wall / args.steps
+    return wall, dev_ms
+
+
+def base_line(ctx, value, wall, workload, B, extra=None):
+    args, world = ctx['args'], ctx['world']
+    cfg = {'workload': workload, 'batch_per_gpu': B, 'global_batch': world * B, 'mode': args.mode, 'parallelism': 'dp%d' % world}
+    cfg.update(extra or {})
+    return {'metric': 'sequences/sec (node), N=1000 K=5 T=32 F=64', 'value': value, 'unit': 'sequences/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * wall / args.steps,
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic', 'config': cfg}
+
+
+def profile_traffic(name, B):
+    tf = os.path.join(ROOT, 'profiles', name)
+    if os.path.exists(tf):
+        tj = json.load(open(tf))
+        if tj.get('batch') == B:
+            return tj
+    return None
+
+
+def run_cfg2(ctx):
+    args, rank, world, dev, dist_on = ctx['args'], ctx['rank'], ctx['world'], ctx['dev'], ctx['dist_on']
+    import gated_gcrnns_amd.Utils.graphML as gml
+
+    N, K, T, G, F = CFG['N'], CFG['K'], CFG['T'], args.in_features, CFG['F']
+    B = args.batch
+    dt = {'bf16': torch.bfloat16, 'f32': torch.float32, 'f64': torch.float64}[args.dtype]
+    elt = {'bf16': 2, 'f32': 4, 'f64': 8}[args.dtype]
+    S = sbm_graph(N)
+    nnz = int(np.count_nonzero(S))
+    torch.manual_seed(0)
+    cell = gml.GGCRNNCell(G, F, K, K, torch.tanh, args.time_gating, args.spatial_gating, 1, True)      # reference init U(+-1/sqrt(G*K))
+    cell.addGSO(torch.tensor(S))
+    params = {k: v.detach().numpy().copy() for k, v in cell.state_dict().items()}
+    cell = cell.to(dev).to(dt)
+    gen = torch.Generator(device=dev); gen.manual_seed(1234 + rank)
+    X = torch.randn(B, T, G, N, device=dev, dtype=torch.float32, generator=gen).to(dt)
+    h0 = torch.zeros(B, F, N, device=dev, dtype=dt)
+
+    opt = None
+    if args.mode == 'train':
+        # one optimiser step of the k-step-prediction loop (reference train_rnn.py:247-281): zero_grad (one memset of the flat
+        # gradient buffer), forward, L1 loss on the state sequence, BPTT, ONE flat gradient all-reduce over RCCL, Adam as one
+        # kernel over the flat buffers.
+        # bf16: fp32 master weights, bf16 activations -> fused forward + fused BPTT; f32 / f64: composed path
+        from gated_gcrnns_amd.optim import FlatAdam
+        from gated_gcrnns_amd.Utils.miscTools import batchTimeL1Loss
+        if args.dtype == 'bf16':
+            cell = cell.float()
+        target = torch.randn(B, T, F, N, device=dev, dtype=torch.float32).to(dt)
+        opt = FlatAdam(cell.parameters(), lr=1e-3)
+
+    runner = None
+    if args.mode == 'fwd' and args.dtype == 'bf16' and args.hipgraph:
+        from gated_gcrnns_amd.ops import FusedForwardGraph
+        runner = FusedForwardGraph(cell, B, T, X=X, h0=h0)      # captured on the caller's own tensors: no staging copy
+
+    def step():
+        if args.mode == 'fwd':
+            if runner is not None:
+                return runner()               # ONE graph launch
+            with torch.no_grad():
+                return cell(X, h0)
+        opt.zero_grad()
+        loss = batchTimeL1Loss(cell(X, h0), target)      # the drivers' loss (reference miscTools.py:112-119), one fused pass
+        loss.backward()
+        if dist_on:
+            opt.sync.all_reduce_()
+        opt.step()
+        return loss
+
+    wall, dev_ms = timed_steps(ctx, step)
     value = world * B * args.steps / wall
 
     # ---- dominant kernel: the fused step kernel, timed live with HIP events on the stream it is launched on ----
     kern = None
-    if args.dtype == 'bf16' and args.mode == 'fwd' and not args.time_gating:
+    if args.dtype == 'bf16' and args.mode == 'fwd' and not args.time_gating and args.spatial_gating is None:
         from gated_gcrnns_amd import ops
         with torch.no_grad():
             for _ in range(2):
                 ops.fused_cell_forward(X, h0, cell.weight_A, cell.weight_B, cell.bias, cell.graph, return_states=True)
             torch.cuda.synchronize()
             kern = ops.time_fused_step_kernel(X, h0, cell.weight_A, cell.weight_B, cell.bias, cell.graph, reps=3)
+    ar = None
+    if args.mode == 'train':
+        # the collective on its own: HIP events around back-to-back all-reduces of the flat gradient buffer
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        reps = 20
+        e0.record()
+        for _ in range(reps):
+            opt.sync.all_reduce_(1.0)
+        e1.record()
+        torch.cuda.synchronize()
+        ar = {'allreduce_bytes': opt.sync.nbytes(), 'allreduce_us': 1e3 * e0.elapsed_time(e1) / reps,
+              'allreduce_note': 'one flat buffer per optimiser step (RCCL when n_gpus > 1; no collective at n_gpus = 1)'}
+    if rank != 0:
+        return None
+    gating = ('time-gated' if args.time_gating else 'un-gated') + ('' if args.spatial_gating is None else ' + %s-gated' % args.spatial_gating)
+    abytes = algorithmic_bytes_per_seq(T, N, G, F, elt) * B           # per step (= per launch chain), per GPU
+    step_s = (dev_ms / 1e3) / args.steps
+    achieved = abytes / step_s / 1e9
+    out = base_line(ctx, value, wall, 'BASELINE configs[1]: synthetic k-step prediction, sparse SBM N=1000 nnz=%d, K=5 taps, '
+                    'T=32, G=%d, F=64, %s GGCRNNCell %s, h0=0' % (nnz, G, gating, 'forward' if args.mode == 'fwd' else 'training step'),
+                    B, {'hipgraph': bool(runner is not None)})
+    if ar is not None:
+        out['config'].update(ar)
+    if kern is not None:
+        # algorithmic bytes of ONE launch (one time step for the whole batch): read x_t, read h_{t-1}, write h_t
+        kbytes = elt * N * (G + 2 * F) * B
+        kach = kbytes / (kern['avg_us'] * 1e-6) / 1e9
+        tj = profile_traffic('step_kernel_traffic.json', B)
+        Gp = 64 if G > 32 else 32
+        mfma_flops = 2.0 * 1024 * K * F * (F + Gp) * B                 # executed on the matrix cores per launch (1024 padded node rows)
+        out['roofline'] = {'bound': 'hbm', 'achieved': kach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                           'frac': kach / HBM_PEAK_GBS, 'traffic': tj['hbm_bytes_per_launch'] if tj else None,
+                           'kernel': 'fused_step_kernel<5,2,%d> (one launch = one time step of the whole batch)' % (2 if G > 32 else 1),
+                           'kernel_avg_us': kern['avg_us'], 'launches_timed': kern['launches'],
+                           'algorithmic_bytes_per_launch': kbytes,
+                           'gflop_per_launch': flops_per_seq(1, N, nnz, K, G, F) * B / 1e9,
+                           'mfma_util': mfma_flops / (kern['avg_us'] * 1e-6) / 1e12 / MFMA_BF16_PEAK_TFLOPS,
+                           'mfma_util_note': 'taps GEMM flops executed per launch / duration / 2.5 PF dense bf16 peak'
+                                             + (' (PMC: SQ_VALU_MFMA_BUSY_CYCLES %.3g per launch)' % tj['mfma_busy_cycles'] if tj and 'mfma_busy_cycles' in tj else ''),
+                           'whole_step_GBps': achieved, 'device_ms_per_step': 1e3 * step_s}
+    else:
+        out['roofline'] = {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                           'frac': achieved / HBM_PEAK_GBS, 'traffic': None,
+                           'kernel': 'whole T-step recurrence (all launches of one step: %s)' % (
+                               'fused kernels' if args.dtype == 'bf16' else 'composed path'),
+                           'algorithmic_bytes_per_step': abytes, 'device_ms_per_step': 1e3 * step_s,
+                           'gflop_per_step': flops_per_seq(T, N, nnz, K, G, F) * B / 1e9}
+    if not args.no_cpu_baseline and world == 1:          # the host baseline is a single-GPU-run item (rank 0, N = 1)
+        out['cpu_baseline'] = cpu_baseline(S, params, T, G, F)
+    return out
 
-    if rank == 0:
-        abytes = algorithmic_bytes_per_seq(T, N, G, F, elt) * B           # per step (= per launch chain), per GPU
-        step_s = (dev_ms / 1e3) / args.steps
-        achieved = abytes / step_s / 1e9
-        out = {
-            'metric': 'sequences/sec (node), N=1000 K=5 T=32 F=64', 'value': value, 'unit': 'sequences/s',
-            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_per_step,
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype,
-            'data': 'synthetic',
-            'config': {'workload': 'BASELINE configs[1]: synthetic k-step prediction, sparse SBM N=1000 nnz=%d, K=5 taps, '
-                                   'T=32, G=%d, F=64, %s GGCRNNCell %s, h0=0' % (nnz, G, 'time-gated' if args.time_gating else 'un-gated',
-                                                                              'forward' if args.mode == 'fwd' else 'training step'),
-                       'batch_per_gpu': B, 'global_batch': world * B, 'mode': args.mode, 'hipgraph': bool(runner is not None), 'parallelism': 'dp%d' % world},
-        }
-        if kern is not None:
-            # algorithmic bytes of ONE launch (one time step for the whole batch): read x_t, read h_{t-1}, write h_t
-            kbytes = elt * N * (G + 2 * F) * B
-            kach = kbytes / (kern['avg_us'] * 1e-6) / 1e9
-            traffic = None
-            tf = os.path.join(ROOT, 'profiles', 'step_kernel_traffic.json')
-            if os.path.exists(tf):
-                tj = json.load(open(tf))
-                if tj.get('batch') == B:
-                    traffic = tj['hbm_bytes_per_launch']
-            out['roofline'] = {'bound': 'hbm', 'achieved': kach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                               'frac': kach / HBM_PEAK_GBS, 'traffic': traffic,
-                               'kernel': 'fused_step_kernel<5,2,%d> (one launch = one time step of the whole batch)' % (2 if G > 32 else 1),
-                               'kernel_avg_us': kern['avg_us'], 'launches_timed': kern['launches'],
-                               'algorithmic_bytes_per_launch': kbytes,
-                               'gflop_per_launch': flops_per_seq(1, N, nnz, K, G, F) * B / 1e9,
-                               'whole_step_GBps': achieved, 'device_ms_per_step': 1e3 * step_s}
-        else:
-            out['roofline'] = {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                               'frac': achieved / HBM_PEAK_GBS, 'traffic': None,
-                               'kernel': 'whole T-step recurrence (all launches of one step: %s)' % (
-                                   'fused kernels' if args.dtype == 'bf16' else 'composed path'),
-                               'algorithmic_bytes_per_step': abytes, 'device_ms_per_step': 1e3 * step_s,
-                               'gflop_per_step': flops_per_seq(T, N, nnz, K, G, F) * B / 1e9}
-        if not args.no_cpu_baseline and world == 1:          # the host baseline is a single-GPU-run item (rank 0, N = 1)
-            out['cpu_baseline'] = cpu_baseline(S, params, T, G, F)
-        print(json.dumps(out), flush=True)
-    if dist_on:
-        torch.distributed.destroy_process_group()
+
+def run_cfg5(ctx):
+    """BASELINE configs[4]: directed Erdos-Renyi graph N = 1e5, density 1e-3 (nnz ~ 1e7), K = 3 taps, T = 16, G = F = 32,
+    B = 8 sequences per GPU, un-gated cell, h0 = 0 -- the streaming regime: every hop is one CSR SpMM pass over the
+    [N][B F] state (GGCRNNCell._forward_horner). The reference cannot run it (dense 1e5 x 1e5 GSO = 40 GB)."""
+    args, rank, world, dev = ctx['args'], ctx['rank'], ctx['world'], ctx['dev']
+    import gated_gcrnns_amd.Utils.graphML as gml
+    from gated_gcrnns_amd import ops
+    from gated_gcrnns_amd.graph import erdos_renyi_csr, operator_from_csr
+    N, K, T, G, F = 100000, 3, 16, 32, 32
+    B = args.batch
+    assert args.mode == 'fwd', 'cfg5 is an inference workload'
+    dt = {'bf16': torch.bfloat16, 'f32': torch.float32, 'f64': torch.float64}[args.dtype]
+    elt = {'bf16': 2, 'f32': 4, 'f64': 8}[args.dtype]
+    rowptr, col, val = erdos_renyi_csr(N, 1e-3, seed=0)
+    nnz = int(col.size)
+    graph = operator_from_csr(rowptr, col, val, N, device=dev)
+    torch.manual_seed(0)
+    cell = gml.GGCRNNCell(G, F, K, K, torch.tanh, False, None, 1, True)
+    cell.addGSO(graph)
+    params = {k: v.detach().double().numpy().copy() for k, v in cell.state_dict().items()}
+    cell = cell.to(dev).to(dt)
+    gen = torch.Generator(device=dev); gen.manual_seed(1234 + rank)
+    X = torch.randn(B, T, G, N, device=dev, dtype=torch.float32, generator=gen).to(dt)
+    h0 = torch.zeros(B, F, N, device=dev, dtype=dt)
+
+    def step():
+        with torch.no_grad():
+            return cell(X, h0)
+
+    wall, dev_ms = timed_steps(ctx, step)
+    value = world * B * args.steps / wall
+    # dominant kernel: spmm_stream_kernel, one launch = one hop of one time step for the whole batch; timed live with HIP events
+    acc = torch.randn(1, N, B, F, device=dev).to(dt)
+    dst = torch.randn(1, N, B, F, device=dev).to(dt)
+    for _ in range(3):
+        ops.spmm_raw(graph.fwd[0], acc, out=dst, accumulate=True)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    reps = 20
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(reps):
+        ops.spmm_raw(graph.fwd[0], acc, out=dst, accumulate=True)
+    e1.record()
+    torch.cuda.synchronize()
+    hop_us = 1e3 * e0.elapsed_time(e1) / reps
+    if rank != 0:
+        return None
+    csr_bytes = nnz * (4 + (8 if args.dtype == 'f64' else 4)) + 4 * (N + 1)
+    hop_survey = csr_bytes + 2 * elt * N * B * (G + F)           # SURVEY 8d hop-streaming bytes of one hop: CSR + read + write of the (G+F)-channel operand
+    hop_horner = csr_bytes + 3 * elt * N * B * F                 # what this launch must move at least: CSR + read acc + read u_k + write
+    gathered = nnz * B * F * elt                                 # bytes the gather pulls through the caches (every non-zero fetches one B*F row)
+    step_survey = (K - 1) * hop_survey + elt * N * B * (G + 2 * F)
+    ach = hop_survey / (hop_us * 1e-6) / 1e9
+    out = base_line(ctx, value, wall, 'BASELINE configs[4]: directed Erdos-Renyi N=%d nnz=%d (density 1e-3), K=3 taps, T=16, G=F=32, '
+                    'un-gated GGCRNNCell forward on the streaming CSR path, h0=0' % (N, nnz), B)
+    out['metric'] = 'sequences/sec (node), N=100k density 1e-3 K=3 T=16 F=32'
+    tj = profile_traffic('cfg5_spmm_traffic.json', B)
+    out['roofline'] = {'bound': 'hbm', 'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': ach / HBM_PEAK_GBS,
+                       'traffic': tj['hbm_bytes_per_launch'] if tj and tj.get('dtype') == args.dtype else None,
+                       'kernel': 'spmm_stream_kernel (one launch = one graph hop of one time step, whole batch)',
+                       'kernel_avg_us': hop_us, 'launches_timed': reps,
+                       'algorithmic_bytes_per_launch': hop_survey,
+                       'algorithmic_bytes_note': 'SURVEY 8d hop-streaming: CSR + 2 s N B (G+F); the Horner-form hop this kernel runs needs '
+                                                 'CSR + 3 s N B F = %d bytes; the gather itself pulls %d bytes per launch through the caches '
+                                                 '(every non-zero one B*F-wide row)' % (hop_horner, gathered),
+                       'gathered_GBps': gathered / (hop_us * 1e-6) / 1e9,
+                       'whole_step_GBps': step_survey * T / ((dev_ms / 1e3) / args.steps) / 1e9,
+                       'ms_per_time_step': dev_ms / args.steps / T}
+    if not args.no_cpu_baseline and world == 1:
+        out['cpu_baseline'] = cpu_baseline_cfg5(rowptr, col, val, params, N, B, T, G, F)
+    return out
+
+
+def cpu_baseline_cfg5(rowptr, col, val, params, N, B, T, G, F):
+    """The oracle's CSR restatement (the reference itself cannot hold this graph) on ONE time step of the batch, all nodes."""
+    import scipy.sparse as sp
+    from oracle import gcrnn_oracle as orc
+    P = sp.csr_matrix((val, col, rowptr), shape=(N, N)).T.tocsr()
+    rng = np.random.default_rng(1)
+    x = rng.standard_normal((B, G, N)).astype(np.float32).astype(np.float64)
+    h = np.tanh(rng.standard_normal((B, F, N)))
+    t0 = time.perf_counter()
+    orc.cell_step_rows_csr(params, P, x, h, np.arange(N))
+    dt_ = time.perf_counter() - t0
+    return {'value': B / (T * dt_), 'unit': 'sequences/s', 'cores': 1, 'kind': 'port',
+            'sample': 'oracle/gcrnn_oracle.py cell_step_rows_csr (scipy CSR products, fp64, single thread) on ONE of the T=%d time steps '
+                      'of the B=%d batch, all %d nodes: %.1f s; value = B / (T x that)' % (T, B, N, dt_)}
+
+
+def run_cfg4(ctx):
+    """BASELINE configs[3]: the seismograph graph of the reference (Adj.p: directed, N = 59, 10 in-neighbours per node), T = 200,
+    K = 3 taps, G = 1, F = 20, B = 100, fp64 like the reference drivers -- latency-bound: 200 dependent steps of a tiny
+    problem, run by the one-launch small-graph kernels (one workgroup per sequence on the fp64 matrix cores)."""
+    args, rank, world, dev = ctx['args'], ctx['rank'], ctx['world'], ctx['dev']
+    import gated_gcrnns_amd.Utils.graphML as gml
+    A = np.load(os.path.join(ROOT, 'tests', 'golden', 'adj59.npy')).astype(np.float64)
+    N, K, T, G, F = A.shape[0], 3, 200, 1, 20
+    B = args.batch
+    dt = {'bf16': torch.float64, 'f32': torch.float32, 'f64': torch.float64}[args.dtype]      # default dtype of this config: fp64
+    S = (A / np.max(np.abs(np.linalg.eigvals(A)))).reshape(1, N, N)                              # epicenterEstimation.py:619
+    torch.manual_seed(0)
+    cell = gml.GGCRNNCell(G, F, K, K, torch.tanh, args.time_gating, None, 1, True)
+    with torch.no_grad():
+        cell.weight_B.mul_(0.25)            # as in the T=200 golden (DESIGN section 2): the G=1 init makes the 20x20 state map chaotic
+    cell.addGSO(torch.tensor(S))
+    params = {k: v.detach().double().numpy().copy() for k, v in cell.state_dict().items()}
+    cell = cell.to(dev).to(dt)
+    gen = torch.Generator(device=dev); gen.manual_seed(1234 + rank)
+    X = torch.randn(B, T, G, N, device=dev, dtype=torch.float64, generator=gen).to(dt)
+    h0 = torch.zeros(B, F, N, device=dev, dtype=dt)
+    assert args.mode == 'fwd'
+
+    def step():
+        with torch.no_grad():
+            return cell(X, h0)
+
+    wall, dev_ms = timed_steps(ctx, step)
+    value = world * B * args.steps / wall
+    if rank != 0:
+        return None
+    nnz = int(np.count_nonzero(S))
+    us_per_time_step = 1e3 * dev_ms / args.steps / T
+    # matrix-core work of one time step of ONE sequence (dense-S kernels): hops (K-1)(G+F) N^2 + taps K F (G+F) N, x2 flops
+    flop_step = 2.0 * ((K - 1) * (G + F) * N * N + K * F * (G + F) * N)
+    cus = torch.cuda.get_device_properties(dev).multi_processor_count
+    ach = flop_step * min(B, cus) / (us_per_time_step * 1e-6) / 1e12          # one workgroup (sequence) per CU runs concurrently
+    dname = 'f64' if dt == torch.float64 else 'f32'
+    peak = MFMA_F64_PEAK_TFLOPS if dt == torch.float64 else 157.3
+    out = base_line(ctx, value, wall, 'BASELINE configs[3]: seismograph graph N=59 nnz=%d (directed), T=200, K=3 taps, G=1, F=20, %s '
+                    'GGCRNNCell forward, one launch for the whole recurrence, h0=0' % (nnz, 'time-gated' if args.time_gating else 'un-gated'), B)
+    out['metric'] = 'sequences/sec (node), N=59 K=3 T=200 F=20'
+    out['dtype'] = dname
+    out['roofline'] = {'bound': 'mfma', 'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s', 'frac': ach / peak, 'traffic': None,
+                       'kernel': 'small_dense kernels: whole T-step recurrence in one launch, one workgroup per sequence',
+                       'us_per_time_step': us_per_time_step,
+                       'note': 'latency-bound configuration (SURVEY 8d): %d of %d CUs hold one sequence each and walk 200 dependent steps; '
+                               'the figure to read is us_per_time_step against the ~1.2-1.5 us a dependent kernel boundary would cost per step '
+                               '(MI355X_MICROARCH.md, row boundary) if the loop were launches' % (min(B, cus), cus)}
+    if not args.no_cpu_baseline and world == 1:
+        from oracle import gcrnn_oracle as orc
+        Xc = X[:16].double().cpu().numpy()
+        t0 = time.perf_counter()
+        orc.ggcrnn_cell(params, S, Xc, np.zeros((16, F, N)), bool(args.time_gating), None)
+        dt_ = time.perf_counter() - t0
+        out['cpu_baseline'] = {'value': 16 / dt_, 'unit': 'sequences/s', 'cores': min(16, os.cpu_count() or 1), 'kind': 'port',
+                               'sample': 'oracle ggcrnn_cell (dense x@S, numpy fp64) on 16 full T=200 sequences: %.2f s' % dt_}
+    return out
 
 
 if __name__ == '__main__':

@@ -28,17 +28,31 @@ def batch_partition(nTrain, batchSize):
     return sizes, np.cumsum([0] + sizes).tolist()
 
 
-def train_step(archit, loss_fn, optim, x, y, stateFeat, sync=None):
-    """One optimiser step on a batch x, y: B x T x 1 x N (already on the device). Returns (loss, yHat)."""
+def train_step(archit, loss_fn, optim, x, y, stateFeat, sync=None, weight=None):
+    """One optimiser step on a batch x, y: B x T x 1 x N (already on the device). Returns (loss, yHat).
+    weight: this rank's share of the global batch (local / global); the flat all-reduce sums the ranks' mean-loss
+    gradients with these weights = the gradient of the global-batch mean. A rank whose shard is empty (global batch
+    smaller than the world) contributes zeros and still joins the collective."""
     B, N = x.shape[0], x.shape[3]
-    archit.zero_grad()
-    h0 = torch.zeros(B, stateFeat, N, dtype=x.dtype, device=x.device)
-    yHat = archit(x, h0)
-    loss = loss_fn(yHat, y)
-    loss.backward()
+    if sync is None and hasattr(optim, 'sync'):
+        sync_z = optim.sync                      # optim.FlatAdam: the gradients live in its flat buffer
+    else:
+        sync_z = sync
+    if sync_z is not None:
+        sync_z.zero_grad()                       # one memset of the flat gradient buffer
+    else:
+        archit.zero_grad()
+    loss, yHat = None, None
+    if B > 0:
+        h0 = torch.zeros(B, stateFeat, N, dtype=x.dtype, device=x.device)
+        yHat = archit(x, h0)
+        loss = loss_fn(yHat, y)
+        loss.backward()
     if sync is not None:
-        sync.all_reduce_()
+        sync.all_reduce_(weight)
     optim.step()
+    if loss is None:
+        return torch.zeros((), dtype=x.dtype, device=x.device), None
     return loss.detach(), yHat.detach()
 
 
@@ -70,12 +84,17 @@ def MultipleModels(modelsDict, xTrain, yTrain, xValid, yValid, nEpochs, batchSiz
     dtype); torch.bfloat16 with fp32 parameters = bf16 activations over fp32 master weights (the fused kernels).
     Returns dicts of per-step loss / metric / seconds per model.
     """
-    rng = rng if rng is not None else np.random
+    if rng is None:
+        # every rank must draw the SAME epoch permutations: with world > 1 the default generator is seeded identically on
+        # all ranks (rank 0's seed would need a broadcast; a fixed seed needs none); a single process keeps numpy's global
+        # state like the reference (train_rnn.py:193)
+        rng = np.random.RandomState(20231) if world > 1 else np.random
     nTrain = xTrain.shape[0]
     sizes, index = batch_partition(nTrain, batchSize)
     dev = next(iter(modelsDict.values())).archit.stateGCRNN.weight_A.device
     dt = dataType if dataType is not None else next(iter(modelsDict.values())).archit.stateGCRNN.weight_A.dtype
-    syncs = {k: (FlatGradAllReduce(m.archit.parameters()) if world > 1 else None) for k, m in modelsDict.items()}
+    syncs = {k: ((m.optim.sync if hasattr(m.optim, 'sync') else FlatGradAllReduce(m.archit.parameters())) if world > 1 else None)
+             for k, m in modelsDict.items()}
     lossTrain = {k: [] for k in modelsDict}
     evalTrain = {k: [] for k in modelsDict}
     evalValid = {k: [] for k in modelsDict}
@@ -85,8 +104,10 @@ def MultipleModels(modelsDict, xTrain, yTrain, xValid, yValid, nEpochs, batchSiz
         perm = [int(i) for i in rng.permutation(nTrain)]
         for b in range(len(sizes)):
             idx = perm[index[b]:index[b + 1]]
-            lo, hi = shard_range(len(idx), rank, world)
+            nGlobal = len(idx)
+            lo, hi = shard_range(nGlobal, rank, world)
             idx = idx[lo:hi]
+            share = len(idx) / float(nGlobal)                                     # this rank's weight in the flat all-reduce
             xb = xTrain[idx].view(len(idx), seqLen, -1).to(dev, dt)
             yb = yTrain[idx].view(len(idx), seqLen, -1).to(dev, dt)
             for key, m in modelsDict.items():
@@ -95,16 +116,17 @@ def MultipleModels(modelsDict, xTrain, yTrain, xValid, yValid, nEpochs, batchSiz
                 xo, yo = xo.unsqueeze(2), yb.unsqueeze(2)                         # B x T x 1 x N
                 torch.cuda.synchronize() if dev.type == 'cuda' else None
                 t0 = time.perf_counter()
-                loss, yHat = train_step(m.archit, m.loss, m.optim, xo, yo, stateFeat, syncs[key])
+                loss, yHat = train_step(m.archit, m.loss, m.optim, xo, yo, stateFeat, syncs[key], share if world > 1 else None)
                 torch.cuda.synchronize() if dev.type == 'cuda' else None
                 timeTrain[key].append(time.perf_counter() - t0)
                 lossTrain[key].append(float(loss))
-                evalTrain[key].append(float(evaluate(yHat.to(yo.dtype), yo)))
+                evalTrain[key].append(float(evaluate(yHat.to(yo.dtype), yo)) if yHat is not None else float('nan'))
             step = epoch * len(sizes) + b
             if validationInterval and step % validationInterval == 0 and xValid is not None:
-                xv = xValid.view(xValid.shape[0], seqLen, -1).to(dev, dt).unsqueeze(2)
+                xv0 = xValid.view(xValid.shape[0], seqLen, -1).to(dev, dt)
                 yv = yValid.view(yValid.shape[0], seqLen, -1).to(dev, dt).unsqueeze(2)
                 for key, m in modelsDict.items():
+                    xv = (xv0[:, :, m.order] if m.order is not None else xv0).unsqueeze(2)      # reference train_rnn.py:349
                     with torch.no_grad():
                         h0 = torch.zeros(xv.shape[0], stateFeat, xv.shape[3], dtype=dt, device=dev)
                         score = float(evaluate(m.archit(xv, h0).to(yv.dtype), yv))

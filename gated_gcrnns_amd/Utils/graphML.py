@@ -263,6 +263,12 @@ class GGCRNNCell(nn.Module):
             self.graph = self.graph.to(self.weight_A.device)
         return self
 
+    def _wants_grad(self, X, h0):
+        """Gradient wanted for anything the forward touches: the inputs or ANY parameter of the cell incl. its gate
+        sub-networks (a frozen weight_A with trainable weight_B / gates must still record an autograd graph)."""
+        return torch.is_grad_enabled() and (X.requires_grad or h0.requires_grad or
+                                            any(p.requires_grad for p in self.parameters()))
+
     # -- node-major building blocks ---------------------------------------------------------------
     def _gate_state(self, Xn, h0n):
         """sigma(A(S)x_t + b + B(S)h0 + b) for all t of an un-gated sub-cell: [T][N][B][F] (graphML.py:2362)."""
@@ -345,9 +351,10 @@ class GGCRNNCell(nn.Module):
 
     # -- streaming inference in Horner form (any size, fp32 / fp64, un-gated / time-gated) ------------------
     def _use_horner(self, X, h0):
-        if torch.is_grad_enabled() and (X.requires_grad or h0.requires_grad or self.weight_A.requires_grad):
+        if self._wants_grad(X, h0):
             return False            # BPTT runs on the LSIGF autograd nodes
-        if X.dtype == torch.bfloat16 and (self.F % 8 or self.time_gating == True):  # noqa: E712  (16-byte bf16 rows; gates are fp32/fp64 code)
+        if X.dtype == torch.bfloat16 and (self.time_gating == True or self.G > 64 or  # noqa: E712  (gates are fp32 / fp64 code)
+                                          not ops.taps_bf16_supported(self.F, 32 if self.G <= 32 else 64, max(self.Kin, self.Kst))):
             return False
         return self.spatial_gating is None and self.E == 1 and \
             X.dtype in (torch.float32, torch.float64, torch.bfloat16) and self.weight_A.dtype == X.dtype and h0.dtype == X.dtype
@@ -356,7 +363,9 @@ class GGCRNNCell(nn.Module):
         """Taps and shifts act on different axes, so  pre_t = sum_k P^k (gi x_t A_k^T + gf h_{t-1} B_k^T) + (gi + gf) b  is
         evaluated as  acc <- P acc + u_k  (k = K-1 .. 0): K-1 hops over F channels per step, x and h sharing them,
         instead of the reference order's 2 (K-1) hops over G + F channels (graphML.py:118-135 applied twice per step).
-        Every hop is one accumulate-SpMM pass over the [N][B F] state; the taps are plain library GEMMs."""
+        Every hop is one accumulate-SpMM pass over the [N][B F] state (ops.spmm_raw -> gcrnn_spmm_ex); the last hop's
+        epilogue adds the bias and applies tanh, writing h_t in place. Taps: one matrix-core pass for all K taps of a step
+        in bf16 (gcrnn_taps_bf16_forward), the LDS-tiled tap kernel (gcrnn_taps_forward) in fp32 / fp64 -- no library GEMM."""
         B, T, G, N = X.shape
         F, Kin, Kst = self.F, self.Kin, self.Kst
         K = max(Kin, Kst)
@@ -366,44 +375,58 @@ class GGCRNNCell(nn.Module):
         if self.time_gating == True:  # noqa: E712
             gi = self._time_gate(self.GFL_in, self.MLP_in, Xn, h)       # T x 1 x B x 1
             gf = self._time_gate(self.GFL_forget, self.MLP_forget, Xn, h)
-        wA = self.weight_A[:, 0]                                        # F x Kin x G
-        wB = self.weight_B[:, 0]                                        # F x Kst x F
-        # x-side taps of all steps in one GEMM per tap when they fit in 8 GiB, else per step
-        batched = Kin * T * N * B * F * X.element_size() <= (8 << 30)
-        ux = [torch.matmul(Xn, wA[:, k].t()) for k in range(Kin)] if batched else None
-        if ux is not None and gi is not None:
-            ux = [u * gi for u in ux]
         csr = self.graph.fwd[0]
         Hn = torch.empty((T, N, B, F), dtype=X.dtype, device=X.device)
+        tanh_fused = self.sigma in (torch.tanh, nn.functional.tanh) and gi is None
+        bvec = self.bias.detach().reshape(-1) if self.bias is not None else None
+        if X.dtype == torch.bfloat16:
+            bvec = bvec.float() if bvec is not None else None           # the kernels take fp32 bias / CSR weights with bf16 rows
+            Gp = 32 if G <= 32 else 64
+            wA = self.weight_A
+            if Gp != G:                                                 # the matrix-core taps consume whole 32-feature steps
+                Xp = Xn.new_zeros((T, N, B, Gp))
+                Xp[..., :G] = Xn
+                Xn, wA = Xp, nn.functional.pad(wA, (0, Gp - G))
+            for t in range(T):
+                _, rest = ops.taps_bf16(h, Xn[t:t + 1], wA, self.weight_B, out0=Hn[t:t + 1])     # u_0 -> Hn[t], u_1.. -> rest
+                acc = rest[K - 2] if K > 1 else None
+                for k in range(K - 2, -1, -1):
+                    dst = rest[k - 1] if k > 0 else Hn[t:t + 1]
+                    ops.spmm_raw(csr, acc, out=dst, accumulate=True, bias=bvec, bias_scale=2.0, tanh=(k == 0 and tanh_fused))
+                    acc = dst
+                if K == 1 or not tanh_fused:
+                    pre = Hn[t:t + 1].float() + (2.0 * bvec.view(1, 1, 1, F) if bvec is not None else 0.0)
+                    Hn[t:t + 1] = self.sigma(pre).to(X.dtype)
+                h = Hn[t:t + 1]
+            return ops.unpack_node_major(Hn)
+        wA = [self.weight_A[:, 0, k].contiguous() for k in range(Kin)]  # F x G each
+        wB = [self.weight_B[:, 0, k].contiguous() for k in range(Kst)]  # F x F each
         for t in range(T):
             acc = None
             for k in range(K - 1, -1, -1):
-                u = None
-                if k < Kin:
-                    if ux is not None:
-                        u = ux[k][t:t + 1]
-                        if acc is not None or k < Kst:
-                            u = u.clone() if k >= Kst else u          # spmm accumulates in place: never into the cached taps
-                    else:
-                        u = torch.matmul(Xn[t:t + 1], wA[:, k].t())
-                        if gi is not None:
-                            u = u * gi[t:t + 1]
+                dst = Hn[t:t + 1] if k == 0 else torch.empty((1, N, B, F), dtype=X.dtype, device=X.device)
+                first = True
                 if k < Kst:
-                    uh = torch.matmul(h, wB[:, k].t())
+                    ops.taps_rows(h, wB[k], out=dst)
                     if gf is not None:
-                        uh = uh * gf[t:t + 1]
-                    u = uh if u is None else uh.add_(u)
+                        dst.mul_(gf[t:t + 1])
+                    first = False
+                if k < Kin:
+                    if gi is None:
+                        ops.taps_rows(Xn[t:t + 1], wA[k], out=dst, accumulate=not first)
+                    else:
+                        u = ops.taps_rows(Xn[t:t + 1], wA[k]).mul_(gi[t:t + 1])
+                        dst.copy_(u) if first else dst.add_(u)
                 if acc is not None:
-                    ops.spmm_raw(csr, acc, out=u, accumulate=True)      # u += P acc
-                acc = u
-            if self.bias is not None:
-                bb = self.bias.view(1, 1, 1, F)
-                acc = acc + (2.0 * bb if gi is None else (gi[t:t + 1] + gf[t:t + 1]) * bb)
-            if self.sigma in (torch.tanh, nn.functional.tanh):
-                h = torch.tanh(acc, out=Hn[t:t + 1])
-            else:
-                Hn[t:t + 1] = self.sigma(acc)
-                h = Hn[t:t + 1]
+                    ops.spmm_raw(csr, acc, out=dst, accumulate=True, bias=bvec, bias_scale=2.0, tanh=(k == 0 and tanh_fused))
+                acc = dst
+            if K == 1 or not tanh_fused:
+                pre = acc
+                if bvec is not None:
+                    bb = bvec.view(1, 1, 1, F)
+                    pre = pre + (2.0 * bb if gi is None else (gi[t:t + 1] + gf[t:t + 1]) * bb)
+                Hn[t:t + 1] = self.sigma(pre)
+            h = Hn[t:t + 1]
         return ops.unpack_node_major(Hn)
 
     # -- small-graph persistent path (fp32 / fp64, un-gated / time-gated, sigma = tanh, inference) -------
@@ -413,7 +436,7 @@ class GGCRNNCell(nn.Module):
             ops.small_dense_supported(self.N, self.G, self.F, self.Kin, self.Kst, X.dtype, backward=backward, gated=True)
 
     def _use_small(self, X, h0):
-        if torch.is_grad_enabled() and (X.requires_grad or h0.requires_grad or self.weight_A.requires_grad):
+        if self._wants_grad(X, h0):
             return False
         if self.sigma not in (torch.tanh, nn.functional.tanh):
             return False
@@ -468,8 +491,8 @@ class GGCRNNCell(nn.Module):
 
     # -- fused flagship path (bf16, un-gated / time-gated, sigma = tanh; inference here, training via ops.fused_cell_train) ----
     def _use_fused(self, X, h0):
-        if torch.is_grad_enabled() and (X.requires_grad or h0.requires_grad or self.weight_A.requires_grad):
-            return False            # BPTT runs on the composed path
+        if self._wants_grad(X, h0):
+            return False            # BPTT runs on the fused training path or the composed path
         if self.spatial_gating is not None or self.sigma not in (torch.tanh, nn.functional.tanh):
             return False
         return ops.fused_supported(self.N, self.F, self.G, self.Kin, self.Kst, X.dtype, self.E) and \
@@ -480,7 +503,7 @@ class GGCRNNCell(nn.Module):
         parameters (and, for the plain cell, optionally h0) but not for X: forward and BPTT on the fused kernels."""
         if not torch.is_grad_enabled() or X.requires_grad:
             return False
-        if not (self.weight_A.requires_grad or h0.requires_grad):
+        if not (h0.requires_grad or any(p.requires_grad for p in self.parameters())):
             return False
         if self.spatial_gating is not None:
             return False

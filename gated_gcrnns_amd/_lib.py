@@ -48,6 +48,14 @@ def _bind(lib):
         'gcrnn_pack_node_major': (C.c_int, [C.c_int, _c_p, _c_p, _c_i64, _c_i64, _c_i64, _c_i64, _c_p, _c_p]),
         'gcrnn_unpack_node_major': (C.c_int, [C.c_int, _c_p, _c_p, _c_i64, _c_i64, _c_i64, _c_i64, _c_p, _c_p]),
         'gcrnn_spmm': (C.c_int, [C.c_int, _c_i64, _c_p, _c_p, _c_p, _c_p, _c_p, _c_i64, _c_i64, C.c_int, _c_p]),
+        'gcrnn_spmm_ex': (C.c_int, [C.c_int, _c_i64, _c_p, _c_p, _c_p, _c_p, _c_p, _c_i64, _c_i64, C.c_int, _c_p, C.c_double, _c_i64,
+                                    C.c_int, C.c_int, C.c_int, C.c_int, _c_p]),
+        'gcrnn_taps_bf16_supported': (C.c_int, [_c_i64, _c_i64, _c_i64]),
+        'gcrnn_taps_bf16_forward': (C.c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_i64, _c_i64, _c_i64, _c_i64, _c_p]),
+        'gcrnn_batch_time_mse_slabs': (_c_i64, [_c_i64, _c_i64]),
+        'gcrnn_batch_time_mse': (C.c_int, [C.c_int, _c_p, _c_p, _c_p, _c_p, _c_i64, _c_i64, _c_p]),
+        'gcrnn_adam_flat': (C.c_int, [C.c_int, _c_p, _c_p, _c_p, _c_p, _c_i64, C.c_double, C.c_double, C.c_double, C.c_double,
+                                      C.c_double, _c_p, _c_p]),
         'gcrnn_taps_forward': (C.c_int, [C.c_int, _c_p, _c_p, _c_i64, _c_p, _c_p, C.c_double, _c_p,
                                          _c_i64, _c_i64, _c_i64, _c_i64, C.c_int, _c_p]),
         'gcrnn_taps_backward_data': (C.c_int, [C.c_int, _c_p, _c_p, _c_p, _c_p, _c_i64,

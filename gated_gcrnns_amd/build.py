@@ -48,9 +48,13 @@ def _build_locked(verbose):
     # compile objects one by one (parallel-friendly, clearer errors), then link
     objs = []
     procs = []
+    headers = glob.glob(os.path.join(CSRC, '*.h')) + [os.path.join(os.path.dirname(PKG), 'include', 'gcrnn.h')]
+    hdr_time = max(os.path.getmtime(h) for h in headers)
     for src in sources():
         obj = os.path.join(LIBDIR, os.path.basename(src) + '.o')
         objs.append(obj)
+        if os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(src), hdr_time) and not os.environ.get('GCRNN_REBUILD_ALL'):
+            continue                             # object newer than its source and every header: keep it
         cmd = [HIPCC] + [f for f in FLAGS if f != '-shared'] + ['-c', src, '-o', obj]
         if verbose:
             print(' '.join(cmd), flush=True)

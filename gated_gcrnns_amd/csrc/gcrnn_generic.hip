@@ -91,114 +91,35 @@ extern "C" int gcrnn_unpack_node_major(int dtype, const void* src, void* dst, in
 
 // ------------------------------------------------------------------------------------------
 // graph shift: Y[i][n][:] = sum_j val[j] * X[i][col[j]][:]
-// One workgroup per (row n, column chunk, batch i). The neighbour loop is wave-uniform
-// (rowptr/col/val depend on blockIdx only -> scalar loads); each lane streams 16 B of every
-// neighbour row, so a wave reads 1 KiB contiguous per neighbour.
+// The vector path (rows that are whole 16-byte vectors, 16-byte aligned) is the streaming kernel of gcrnn_spmm.hip
+// (gcrnn_spmm_ex). What stays here is the scalar fallback for odd row lengths: one workgroup per (row n, column block,
+// batch i), wave-uniform neighbour loop, one element per lane.
 // ------------------------------------------------------------------------------------------
-template <typename T, int V>
-__global__ void spmm_kernel(int64_t N, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
-                            const T* __restrict__ val, const T* __restrict__ X, T* __restrict__ Y, int64_t L,
-                            int accumulate) {
+template <typename T>
+__global__ void spmm_scalar_kernel(int64_t N, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+                                   const T* __restrict__ val, const T* __restrict__ X, T* __restrict__ Y, int64_t L,
+                                   int accumulate) {
   const int64_t n = blockIdx.x;
-  const int64_t l = ((int64_t)blockIdx.y * blockDim.x + threadIdx.x) * V;
+  const int64_t l = (int64_t)blockIdx.y * blockDim.x + threadIdx.x;
   if (l >= L) return;
   const int64_t base = (int64_t)blockIdx.z * N * L;
   const int s = rowptr[n], e = rowptr[n + 1];
-  T acc[V];
-#pragma unroll
-  for (int v = 0; v < V; ++v) acc[v] = T(0);
+  T acc = T(0);
   const T* xb = X + base + l;
-  for (int j = s; j < e; ++j) {
-    const int64_t c = col[j];
-    const T w = val[j];
-    if (V > 1) {
-      typedef typename Vec16<T>::type VT;
-      const VT xv = *reinterpret_cast<const VT*>(xb + c * L);
-      const T* xs = reinterpret_cast<const T*>(&xv);
-#pragma unroll
-      for (int v = 0; v < V; ++v) acc[v] += w * xs[v];
-    } else {
-      acc[0] += w * xb[c * L];
-    }
-  }
+  for (int j = s; j < e; ++j) acc += val[j] * xb[(int64_t)col[j] * L];
   T* yp = Y + base + n * L + l;
-  if (V > 1) {
-    typedef typename Vec16<T>::type VT;
-    VT out;
-    T* os = reinterpret_cast<T*>(&out);
-    if (accumulate) out = *reinterpret_cast<const VT*>(yp);
-#pragma unroll
-    for (int v = 0; v < V; ++v) os[v] = accumulate ? (os[v] + acc[v]) : acc[v];
-    *reinterpret_cast<VT*>(yp) = out;
-  } else {
-    yp[0] = accumulate ? (yp[0] + acc[0]) : acc[0];
-  }
-}
-
-// bf16 storage, fp32 weights and accumulation: 8 values (16 B) per lane, L / 8 lanes per row, 64 / (L / 8) rows per
-// 64-thread workgroup when a row is narrower than a wave (the large-graph streaming path: half the gather bytes of fp32).
-__global__ __launch_bounds__(64) void spmm_bf16_kernel(int64_t N, const int32_t* __restrict__ rowptr,
-                                                       const int32_t* __restrict__ col, const float* __restrict__ val,
-                                                       const uint16_t* __restrict__ X, uint16_t* __restrict__ Y, int64_t L,
-                                                       int lanes_per_row, int accumulate) {
-  const int rows_per_block = lanes_per_row >= 64 ? 1 : 64 / lanes_per_row;
-  const int sub = lanes_per_row >= 64 ? 0 : threadIdx.x / lanes_per_row;
-  const int lane = lanes_per_row >= 64 ? threadIdx.x : threadIdx.x - sub * lanes_per_row;
-  const int64_t n = (int64_t)blockIdx.x * rows_per_block + sub;
-  const int64_t l = ((int64_t)blockIdx.y * 64 + lane) * 8;
-  if (n >= N || l >= L || sub >= rows_per_block) return;
-  const int64_t base = (int64_t)blockIdx.z * N * L;
-  float acc[8];
-#pragma unroll
-  for (int v = 0; v < 8; ++v) acc[v] = 0.f;
-  const uint16_t* xb = X + base + l;
-  for (int j = rowptr[n]; j < rowptr[n + 1]; ++j) {
-    const float w = val[j];
-    const uint4 xv = *reinterpret_cast<const uint4*>(xb + (int64_t)col[j] * L);
-    const uint32_t p[4] = {xv.x, xv.y, xv.z, xv.w};
-#pragma unroll
-    for (int v = 0; v < 4; ++v) {
-      acc[2 * v] += w * __uint_as_float(p[v] << 16);
-      acc[2 * v + 1] += w * __uint_as_float(p[v] & 0xffff0000u);
-    }
-  }
-  uint16_t* yp = Y + base + n * L + l;
-  if (accumulate) {
-    const uint4 yv = *reinterpret_cast<const uint4*>(yp);
-    const uint32_t p[4] = {yv.x, yv.y, yv.z, yv.w};
-#pragma unroll
-    for (int v = 0; v < 4; ++v) {
-      acc[2 * v] += __uint_as_float(p[v] << 16);
-      acc[2 * v + 1] += __uint_as_float(p[v] & 0xffff0000u);
-    }
-  }
-  uint32_t o[4];
-#pragma unroll
-  for (int v = 0; v < 4; ++v) {
-    // round to nearest even
-    uint32_t a = __float_as_uint(acc[2 * v]), b = __float_as_uint(acc[2 * v + 1]);
-    a += 0x7fffu + ((a >> 16) & 1u);
-    b += 0x7fffu + ((b >> 16) & 1u);
-    o[v] = (a >> 16) | (b & 0xffff0000u);
-  }
-  *reinterpret_cast<uint4*>(yp) = uint4{o[0], o[1], o[2], o[3]};
+  yp[0] = accumulate ? (yp[0] + acc) : acc;
 }
 
 template <typename T>
-static int spmm_launch(int64_t N, const int32_t* rowptr, const int32_t* col, const void* val, const void* X, void* Y,
-                       int64_t L, int64_t nbatch, int accumulate, void* stream) {
-  constexpr int V = Vec16<T>::n;
-  const bool vec = (L % V == 0) && ((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(Y)) % 16 == 0);
-  const int64_t lanes = vec ? L / V : L;
-  int threads = lanes >= 256 ? 256 : (int)(cdiv(lanes, 64) * 64);
-  const int64_t gy = cdiv(lanes, threads);
+static int spmm_scalar_launch(int64_t N, const int32_t* rowptr, const int32_t* col, const void* val, const void* X, void* Y,
+                              int64_t L, int64_t nbatch, int accumulate, void* stream) {
+  int threads = L >= 256 ? 256 : (int)(cdiv(L, 64) * 64);
+  const int64_t gy = cdiv(L, threads);
   if (gy > 65535 || nbatch > 65535) return GCRNN_ERR_BAD_SHAPE;
   GCRNN_PRE_LAUNCH();
   dim3 grid((unsigned)N, (unsigned)gy, (unsigned)nbatch);
-  if (vec)
-    spmm_kernel<T, V><<<grid, threads, 0, as_stream(stream)>>>(N, rowptr, col, (const T*)val, (const T*)X, (T*)Y, L, accumulate);
-  else
-    spmm_kernel<T, 1><<<grid, threads, 0, as_stream(stream)>>>(N, rowptr, col, (const T*)val, (const T*)X, (T*)Y, L, accumulate);
+  spmm_scalar_kernel<T><<<grid, threads, 0, as_stream(stream)>>>(N, rowptr, col, (const T*)val, (const T*)X, (T*)Y, L, accumulate);
   GCRNN_CHECK_LAUNCH();
   return GCRNN_OK;
 }
@@ -208,23 +129,13 @@ extern "C" int gcrnn_spmm(int dtype, int64_t N, const int32_t* rowptr, const int
   if (!rowptr || !X || !Y) return GCRNN_ERR_NULL_POINTER;
   if (N <= 0 || L <= 0 || nbatch <= 0 || N > 2147483647LL) return GCRNN_ERR_BAD_SHAPE;
   if (X == Y) return GCRNN_ERR_UNSUPPORTED;  // a hop cannot run in place
-  if (dtype == GCRNN_F32) return spmm_launch<float>(N, rowptr, col, val, X, Y, L, nbatch, accumulate, stream);
-  if (dtype == GCRNN_F64) return spmm_launch<double>(N, rowptr, col, val, X, Y, L, nbatch, accumulate, stream);
-  if (dtype == GCRNN_BF16) {                      // bf16 rows, fp32 `val`
-    if (L % 8 || ((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(Y)) % 16)) return GCRNN_ERR_UNSUPPORTED;
-    const int64_t lanes = L / 8;
-    int lpr = 64;
-    if (lanes < 64) { lpr = 1; while (lpr < lanes) lpr <<= 1; }       // power of two so that rows tile the 64 threads
-    const int rpb = lpr >= 64 ? 1 : 64 / lpr;
-    const int64_t gx = cdiv(N, rpb), gy = cdiv(lanes, 64);
-    if (gx > 2147483647LL || gy > 65535 || nbatch > 65535) return GCRNN_ERR_BAD_SHAPE;
-    GCRNN_PRE_LAUNCH();
-    spmm_bf16_kernel<<<dim3((unsigned)gx, (unsigned)gy, (unsigned)nbatch), 64, 0, as_stream(stream)>>>(
-        N, rowptr, col, (const float*)val, (const uint16_t*)X, (uint16_t*)Y, L, lpr, accumulate);
-    GCRNN_CHECK_LAUNCH();
-    return GCRNN_OK;
-  }
-  return GCRNN_ERR_BAD_DTYPE;
+  const int ve = dtype == GCRNN_F32 ? 4 : (dtype == GCRNN_F64 ? 2 : (dtype == GCRNN_BF16 ? 8 : 0));
+  if (!ve) return GCRNN_ERR_BAD_DTYPE;
+  const bool vec = (L % ve == 0) && ((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(Y)) % 16 == 0);
+  if (vec) return gcrnn_spmm_ex(dtype, N, rowptr, col, val, X, Y, L, nbatch, accumulate, nullptr, 0.0, 0, 0, 0, 0, 0, stream);
+  if (dtype == GCRNN_F32) return spmm_scalar_launch<float>(N, rowptr, col, val, X, Y, L, nbatch, accumulate, stream);
+  if (dtype == GCRNN_F64) return spmm_scalar_launch<double>(N, rowptr, col, val, X, Y, L, nbatch, accumulate, stream);
+  return GCRNN_ERR_UNSUPPORTED;                 // bf16 rows must be whole 16-byte vectors
 }
 
 // ------------------------------------------------------------------------------------------

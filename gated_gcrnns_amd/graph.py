@@ -226,17 +226,20 @@ _CACHE = {}
 def as_operator(S):
     """Accept a GraphOperator or a dense E x N x N tensor. Dense tensors are converted once and cached on
     (storage address, shape, version, device, dtype); the cache entry holds a reference to the tensor so that its
-    address cannot be recycled for a different matrix while the entry is alive."""
+    address cannot be recycled for a different matrix while the entry is alive. Strides and storage offset are part of the
+    key: S.transpose(1, 2) shares address, shape and version counter with S but is a different operator. A GSO edited in
+    place through a path that does not bump `_version` (numpy-shared memory, `.data`) must be passed to addGSO again."""
     if isinstance(S, GraphOperator):
         return S
     assert isinstance(S, torch.Tensor), 'GSO must be a torch.Tensor or a GraphOperator'
     assert S.dim() == 3, 'GSO must be E x N x N'
-    key = (S.data_ptr(), tuple(S.shape), S._version, str(S.device), S.dtype)
+    key = (S.data_ptr(), tuple(S.shape), tuple(S.stride()), S.storage_offset(), S._version, str(S.device), S.dtype)
     hit = _CACHE.get(key)
     if hit is not None and hit[0] is S:
         return hit[1]
-    if hit is not None and hit[0].data_ptr() == S.data_ptr() and hit[0]._version == S._version:
-        return hit[1]                      # a view of the same live storage
+    if hit is not None and hit[0].data_ptr() == S.data_ptr() and hit[0]._version == S._version and \
+            hit[0].stride() == S.stride() and hit[0].storage_offset() == S.storage_offset():
+        return hit[1]                      # the same view (address, strides, offset) of the same live storage
     if len(_CACHE) > 16:
         _CACHE.clear()
     op = GraphOperator(S, device=S.device)
@@ -253,10 +256,8 @@ def operator_from_csr(rowptr, col, val, N, device=None):
     val = np.ascontiguousarray(val, dtype=np.float64)
     assert rowptr.size == N + 1 and col.size == val.size == rowptr[-1]
     rows = np.repeat(np.arange(N, dtype=np.int32), np.diff(rowptr))
-    order = np.lexsort((rows, col))                      # sort by (column, row): CSR of the transpose
-    t_rowptr = np.zeros(N + 1, dtype=np.int64)
-    np.add.at(t_rowptr, col.astype(np.int64) + 1, 1)
-    t_rowptr = np.cumsum(t_rowptr)
+    order = np.argsort(col, kind='stable')               # entries are row-sorted already: stable by column = (column, row) order
+    t_rowptr = np.concatenate([[0], np.cumsum(np.bincount(col, minlength=N))]).astype(np.int64)
     op = GraphOperator.__new__(GraphOperator)
     op.E, op.N = 1, int(N)
     op.device = torch.device(device if device is not None else 'cpu')
@@ -265,3 +266,21 @@ def operator_from_csr(rowptr, col, val, N, device=None):
     op.mask, op.mask_vals = None, None
     op.nnz = int(col.size)
     return op
+
+
+def erdos_renyi_csr(N, density, seed=0):
+    """Directed Erdos-Renyi graph generated directly in CSR (never dense) -- the synthetic graph of BASELINE configs[4]
+    (N = 1e5, p = 1e-3, nnz ~ 1e7): per-row degrees ~ Binomial(N, p), columns uniform without
+    repetition, weights U(0, 1) scaled by 1 / (max row sum) as a cheap spectral bound. Returns (rowptr int64[N+1],
+    col int32[nnz], val float64[nnz]) of S (row m lists S[m, :], columns ascending)."""
+    rng = np.random.default_rng(seed)
+    deg = rng.binomial(N, density, size=N).astype(np.int64)
+    rows = np.repeat(np.arange(N, dtype=np.int64), deg)
+    cols = rng.integers(0, N, size=rows.size, dtype=np.int64)
+    key = np.unique(rows * N + cols)                      # sorted by (row, column); a repeated column in a row is dropped
+    rows, cols = key // N, (key % N).astype(np.int32)
+    rowptr = np.concatenate([[0], np.cumsum(np.bincount(rows, minlength=N))]).astype(np.int64)
+    val = rng.random(cols.size)
+    rowsum = np.bincount(rows, weights=val, minlength=N)
+    val /= rowsum.max()
+    return rowptr, cols, val

@@ -80,8 +80,14 @@ def unpack_node_major(X):
 
 
 # ------------------------------------------------------------------------------------------ shift
-def spmm_raw(csr, X, out=None, accumulate=False):
-    """Y[i][n][:] (+)= sum_j val[j] X[i][col[j]][:] on a contiguous [nbatch][N][L...] tensor."""
+_SPMM_TUNE = {}      # {'piece_lanes': .., 'unroll': .., 'rows_per_wave': ..}: overrides for tuning sweeps (tools/spmm_sweep.py)
+
+
+def spmm_raw(csr, X, out=None, accumulate=False, bias=None, bias_scale=0.0, tanh=False, tune=None):
+    """Y[i][n][:] (+)= sum_j val[j] X[i][col[j]][:] on a contiguous [nbatch][N][L...] tensor (bf16 / fp32 / fp64 rows; the
+    CSR weights are fp32 for bf16 rows). tanh: Y = tanh(. + bias_scale * bias[l % F]) -- the last hop of a Horner-form step
+    (bias: [F] in the weights' dtype or None). Rows that are whole 16-byte vectors run on the streaming kernel
+    (gcrnn_spmm_ex); other shapes fall back to the scalar kernel (no epilogue there)."""
     N = csr.N
     assert X.is_contiguous() and X.dim() >= 3
     nbatch = X.shape[0]
@@ -90,8 +96,60 @@ def spmm_raw(csr, X, out=None, accumulate=False):
     if out is None:
         assert not accumulate
         out = torch.empty_like(X)
+    ve = 16 // X.element_size()
+    if L % ve == 0 and X.data_ptr() % 16 == 0 and out.data_ptr() % 16 == 0:
+        t = tune if tune is not None else _SPMM_TUNE
+        F = bias.numel() if bias is not None else 0
+        check(lib.gcrnn_spmm_ex(dtype_code(X.dtype), N, _p(csr.rowptr), _p(csr.col), _p(csr.val(X.dtype)), _p(X), _p(out),
+                                L, nbatch, int(accumulate), _p(bias), float(bias_scale), F, int(tanh),
+                                int(t.get('piece_lanes', 0)), int(t.get('unroll', 0)), int(t.get('rows_per_wave', 0)), _stream()), 'spmm_ex')
+        return out
     check(lib.gcrnn_spmm(dtype_code(X.dtype), N, _p(csr.rowptr), _p(csr.col), _p(csr.val(X.dtype)), _p(X), _p(out),
                          L, nbatch, int(accumulate), _stream()), 'spmm')
+    if tanh:
+        if bias is not None:
+            out.add_(bias_scale * bias.view(-1).repeat(L // bias.numel()).view(out.shape[2:]))
+        torch.tanh(out, out=out)
+    return out
+
+
+def taps_bf16_supported(F, G, K):
+    return bool(lib.gcrnn_taps_bf16_supported(int(F), int(G), int(K)))
+
+
+def taps_bf16(zh, zx, wA, wB, out0=None):
+    """All K = max(Kin, Kst) taps of a Horner-form step in one pass on the matrix cores: u_k = zh B_k^T + zx A_k^T.
+    zh [..][F], zx [..][G] bf16 node-major rows (same leading shape; zx None for a state-only operand), wA F x 1 x Kin x G,
+    wB F x 1 x Kst x F (bf16 or fp32). Returns (u_0 [..][F], u_rest [K-1][..][F]) bf16; out0: where tap 0 is written."""
+    F = wB.shape[0]
+    G = wA.shape[3] if zx is not None else 0
+    K = max(wA.shape[2], wB.shape[2])
+    st = _stream()
+    if zx is not None:
+        wpack = _fused_pack_weights(wA.detach(), wB.detach(), st)
+    else:
+        wpack = _fused_pack_state_taps(wB, K, st)
+    zh = zh.contiguous()
+    zx = zx.contiguous() if zx is not None else None
+    R = zh.numel() // F
+    if out0 is None:
+        out0 = torch.empty_like(zh)
+    rest = torch.empty((max(K - 1, 1),) + tuple(zh.shape), dtype=torch.bfloat16, device=zh.device)
+    check(lib.gcrnn_taps_bf16_forward(_p(zh), _p(zx), _p(wpack), _p(out0), _p(rest), R, F, G, K, st), 'taps_bf16')
+    return out0, rest
+
+
+def taps_rows(z, w, out=None, accumulate=False):
+    """y[r][:] (+)= z[r][:] w^T on node-major rows with the LDS-tiled tap kernel (fp32 / fp64): z [..][C], w [F][C]."""
+    Cin = z.shape[-1]
+    F = w.shape[0]
+    z, w = z.contiguous(), w.contiguous()
+    rows = z.numel() // Cin
+    if out is None:
+        assert not accumulate
+        out = torch.empty(tuple(z.shape[:-1]) + (F,), dtype=z.dtype, device=z.device)
+    check(lib.gcrnn_taps_forward(dtype_code(z.dtype), _p(z), None, 0, _p(w), None, 0.0, _p(out), rows, 1, Cin, F,
+                                 int(accumulate), _stream()), 'taps_forward')
     return out
 
 
@@ -551,6 +609,10 @@ class _FusedTimeGate(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dgate):
         X, h0, wA_g, wB_g, bias_g, lin_w, lin_b, gate, cs, gw, hzero = ctx.saved_tensors
+        if getattr(ctx, 'consumed', False):
+            raise GcrnnError('the fused time gate was already back-propagated: its saved states are turned into gradients in '
+                             'place, so a second backward over the same graph (retain_graph) is not supported')
+        ctx.consumed = True
         if ctx.needs_input_grad[2] or ctx.needs_input_grad[3]:
             raise GcrnnError('the fused time gate does not produce gradients w.r.t. X or h0')
         B, T, G, N = X.shape
@@ -895,6 +957,10 @@ class _L1Loss(torch.autograd.Function):
     def forward(ctx, x, y):
         require_device(x, y)
         xc, yc = x.contiguous(), y.contiguous()
+        if xc.data_ptr() % 16:                       # the kernel moves 16-byte vectors: re-base a slice with an odd offset
+            xc = xc.clone()
+        if yc.data_ptr() % 16:
+            yc = yc.clone()
         n = xc.numel()
         want = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
         grad = torch.empty_like(xc) if want else None
@@ -913,6 +979,19 @@ class _L1Loss(torch.autograd.Function):
 def l1_loss(x, y):
     assert x.shape == y.shape and x.dtype == y.dtype
     return _L1Loss.apply(x, y)
+
+
+def batch_time_mse(xv, yv):
+    """mean_c sqrt(sum_r (x - y)^2) / sqrt(sum_r y^2) of two [R][C] matrices (reference batchTimeMSELoss,
+    miscTools.py:121-130); no autograd. Returns a 0-dim tensor (fp64 for fp64 inputs, else fp32)."""
+    require_device(xv, yv)
+    R, Cc = xv.shape
+    acc_dt = torch.float64 if xv.dtype == torch.float64 else torch.float32
+    slabs = int(lib.gcrnn_batch_time_mse_slabs(R, Cc))
+    part = torch.empty((slabs, 2, Cc), dtype=acc_dt, device=xv.device)
+    out = torch.empty((1,), dtype=acc_dt, device=xv.device)
+    check(lib.gcrnn_batch_time_mse(dtype_code(xv.dtype), _p(xv), _p(yv), _p(part), _p(out), R, Cc, _stream()), 'batch_time_mse')
+    return out[0]
 
 
 # ------------------------------------------------------------------------------------------ row-linear layers
@@ -996,17 +1075,21 @@ def edge_attention(Wx, s1, s2, graph, e=0, negative_slope=0.2):
 # ------------------------------------------------------------------------------------------ hipGraph replay
 class FusedForwardGraph(object):
     """The fused forward of one fixed problem (shapes, weights, graph) captured as a hipGraph: pack -> gate pre-passes ->
-    T step launches -> unpack become one graph launch per call. Inputs are copied into static buffers; the output
-    tensor is reused between calls (clone it if it must survive the next replay).
+    T step launches become one graph launch per call. The capture runs on the CALLER's tensors when they are given
+    (zero-copy: refill X / h0 in place, or keep feeding the same resident batch, and call the runner with no arguments);
+    without them the runner owns static inputs and `runner(X, h0)` copies into them first. The output tensor is reused
+    between calls (clone it if it must survive the next replay).
 
-        runner = FusedForwardGraph(cell, B, T);  H = runner(X, h0)
+        runner = FusedForwardGraph(cell, B, T, X=X, h0=h0);  H = runner()          # replays on X, h0 as they are now
+        runner = FusedForwardGraph(cell, B, T);              H = runner(X2, h02)   # copies, then replays
     """
 
-    def __init__(self, cell, B, T, device=None):
+    def __init__(self, cell, B, T, device=None, X=None, h0=None):
         dev = device if device is not None else cell.weight_A.device
         self.cell = cell
-        self.X = torch.zeros((B, T, cell.G, cell.N), dtype=torch.bfloat16, device=dev)
-        self.h0 = torch.zeros((B, cell.F, cell.N), dtype=torch.bfloat16, device=dev)
+        self.X = X if X is not None else torch.zeros((B, T, cell.G, cell.N), dtype=torch.bfloat16, device=dev)
+        self.h0 = h0 if h0 is not None else torch.zeros((B, cell.F, cell.N), dtype=torch.bfloat16, device=dev)
+        assert tuple(self.X.shape) == (B, T, cell.G, cell.N) and self.X.is_contiguous() and self.h0.is_contiguous()
         cell.graph.fused_plan()                                   # host-side preparation happens outside the capture
         with torch.no_grad():
             s = torch.cuda.Stream(device=dev)
@@ -1019,8 +1102,10 @@ class FusedForwardGraph(object):
             with torch.cuda.graph(self.graph):
                 self.H = cell._forward_fused(self.X, self.h0)
 
-    def __call__(self, X, h0):
-        self.X.copy_(X)
-        self.h0.copy_(h0)
+    def __call__(self, X=None, h0=None):
+        if X is not None and X.data_ptr() != self.X.data_ptr():
+            self.X.copy_(X)
+        if h0 is not None and h0.data_ptr() != self.h0.data_ptr():
+            self.h0.copy_(h0)
         self.graph.replay()
         return self.H

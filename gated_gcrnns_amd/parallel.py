@@ -1,9 +1,13 @@
 """Batch-sharded data parallelism for the GCRNN recurrence.
 
 Sequences are independent in the forward pass and in BPTT; S and the parameters are replicated. The only
-communication is ONE all-reduce of ONE flat fp32 gradient buffer per optimiser step (164 KB for the plain
+communication is ONE all-reduce of ONE flat gradient buffer per optimiser step (164 KB for the plain
 cell at K=5, G=F=64; ~1.4 MB time-gated) -- latency-bound over xGMI, so it is a single contiguous RCCL call,
 never a ring over per-parameter tensors. Inference needs no communication at all.
+
+The parameters' `.grad` tensors ARE views into that flat buffer (autograd accumulates into them in place), so there is
+no pack / unpack pass around the collective: zero_grad is one memset, the all-reduce reads the buffer where backward
+left it, and the optimiser (optim.FlatAdam: one kernel over the flat buffers) reads it where the collective left it.
 
 One process per GPU (`torch.distributed`, backend "nccl" = RCCL on ROCm; "gloo" in the CPU tests).
 """
@@ -26,11 +30,15 @@ def shard_batch(rank, world, *tensors):
 
 
 class FlatGradAllReduce(object):
-    """Owns one flat fp32 buffer that mirrors the gradients of `params` (parameters without gradient, such as
-    the reference's unused output gate GFL_out / MLP_out, contribute zeros so every rank reduces the same layout).
+    """One flat gradient buffer (fp32; fp64 when the parameters are fp64) whose slices are the `.grad` of `params`.
+    Parameters that never receive a gradient (the reference's unused output gate GFL_out / MLP_out) keep their zeros,
+    so every rank reduces the same layout.
 
         sync = FlatGradAllReduce(model.parameters())
-        loss.backward(); sync.all_reduce_(weights=local_batch / global_batch); optim.step()
+        sync.zero_grad(); loss.backward(); sync.all_reduce_(weight=local_batch / global_batch); optim.step()
+
+    Parameters whose dtype differs from the buffer's (bf16 parameters) cannot alias it: they are copied in and out
+    around the collective (`staged`), the only case that still costs per-parameter launches.
     """
 
     def __init__(self, params, group=None):
@@ -38,42 +46,54 @@ class FlatGradAllReduce(object):
         self.group = group
         self.numel = sum(p.numel() for p in self.params)
         dev = self.params[0].device if self.params else torch.device('cpu')
-        self.flat = torch.zeros(self.numel, dtype=torch.float32, device=dev)
+        self.dtype = torch.float64 if any(p.dtype == torch.float64 for p in self.params) else torch.float32
+        self.flat = torch.zeros(self.numel, dtype=self.dtype, device=dev)
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        self.views, self.staged = [], []
+        off = 0
+        for p in self.params:
+            n = p.numel()
+            v = self.flat[off:off + n].view_as(p)
+            self.views.append(v)
+            if p.dtype == self.dtype:
+                p.grad = v                              # autograd accumulates in place: the view survives backward()
+            else:
+                self.staged.append((p, v))
+            off += n
 
     def nbytes(self):
-        return self.numel * 4
+        return self.numel * self.flat.element_size()
 
-    def pack_(self, scale=1.0):
-        off = 0
-        for p in self.params:
-            n = p.numel()
-            if p.grad is None:
-                self.flat[off:off + n].zero_()
-            else:
-                self.flat[off:off + n].copy_(p.grad.reshape(-1))
-                if scale != 1.0:
-                    self.flat[off:off + n].mul_(scale)
-            off += n
+    def attach_(self):
+        """Re-point the `.grad` of every aliased parameter at its slice (after a zero_grad(set_to_none=True) elsewhere)."""
+        for p, v in zip(self.params, self.views):
+            if p.dtype == self.dtype and p.grad is not v:
+                if p.grad is not None:
+                    v.copy_(p.grad)
+                p.grad = v
 
-    def unpack_(self):
-        off = 0
-        for p in self.params:
-            n = p.numel()
-            g = self.flat[off:off + n].view_as(p).to(p.dtype)
-            if p.grad is None:
-                p.grad = g.clone()
-            else:
-                p.grad.copy_(g)
-            off += n
+    def zero_grad(self):
+        """One memset instead of one per parameter."""
+        self.flat.zero_()
+        for p, _ in self.staged:
+            p.grad = None
+        self.attach_()
 
     def all_reduce_(self, weight=None):
         """Sum of per-rank gradients, each pre-scaled by `weight` (default 1/world: equal local batches and
         mean-reduced local losses then give exactly the gradient of the global-batch mean loss)."""
         if weight is None:
             weight = 1.0 / self.world
-        self.pack_(weight)
+        self.attach_()
+        for p, v in self.staged:
+            if p.grad is None:
+                v.zero_()
+            else:
+                v.copy_(p.grad)
+        if weight != 1.0:
+            self.flat.mul_(weight)
         if self.world > 1:
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
-        self.unpack_()
+        for p, v in self.staged:
+            p.grad = v.to(p.dtype)
         return self.flat

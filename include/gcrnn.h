@@ -76,6 +76,23 @@ int gcrnn_unpack_node_major(int dtype, const void* src, void* dst, int64_t B, in
  * Replaces x = torch.matmul(x, S) (graphML.py:123) and, with CSR(S), its adjoint. */
 int gcrnn_spmm(int dtype, int64_t N, const int32_t* rowptr, const int32_t* col, const void* val,
                const void* X, void* Y, int64_t L, int64_t nbatch, int accumulate, void* stream);
+/* The streaming kernel behind gcrnn_spmm with its tuning and epilogue exposed (graphs beyond LDS: BASELINE configs[4]).
+ * Rows must be whole 16-byte vectors (L % (16 / elt) == 0), X / Y 16-byte aligned; GCRNN_BF16: bf16 rows, fp32 val / bias.
+ * act = 1: Y = tanh(. + bias_scale * bias[l % F]) (bias may be NULL) -- the last hop of a Horner-form step writes h_t
+ * (graphML.py:2420-2423: the one bias enters through both filters, bias_scale = 2, or gi + gf).
+ * piece_lanes (0 = auto; 4..64, power of two): lanes per gathered row piece = column chunk of 16 * piece_lanes bytes; all
+ * workgroups of one XCD work on the same chunk. unroll (0 = auto; 2, 4, 8): gather instructions in flight per wave.
+ * rows_per_wave (0 = auto). Replaces x = torch.matmul(x, S) (graphML.py:123). */
+int gcrnn_spmm_ex(int dtype, int64_t N, const int32_t* rowptr, const int32_t* col, const void* val, const void* X, void* Y,
+                  int64_t L, int64_t nbatch, int accumulate, const void* bias, double bias_scale, int64_t F, int act,
+                  int piece_lanes, int unroll, int rows_per_wave, void* stream);
+/* All K taps of a Horner-form step in one pass on the matrix cores (bf16 rows, fp32 accumulation):
+ *   u_k[r][:] = zh[r][:] B_k^T + zx[r][:] A_k^T,  k < K,  r < R rows of the node-major layout ([N][B] flattened).
+ * wpack = gcrnn_fused_pack_weights(A, B); out0 [R][F] receives tap 0, outrest [K-1][R][F] taps 1..K-1. F in {32, 64},
+ * G in {0, 32, 64} (zx NULL when G == 0). Replaces the per-tap contraction of LSIGF (graphML.py:134-135). */
+int gcrnn_taps_bf16_supported(int64_t F, int64_t G, int64_t K);
+int gcrnn_taps_bf16_forward(const void* zh, const void* zx, const void* wpack, void* out0, void* outrest, int64_t R,
+                            int64_t F, int64_t G, int64_t K, void* stream);
 
 /* ---- filter taps ----------------------------------------------------------------------------
  * rows = number of (t, n, b) rows; KK = E*K taps; z_0 = z0, z_k = zrest + (k-1)*zstride (k >= 1),
@@ -321,6 +338,19 @@ int gcrnn_node_linear_bf16_backward(int wdtype, const void* h, const void* w, co
  * caller adds up in a fixed order and scales by inv_n. */
 int64_t gcrnn_l1_loss_blocks(int64_t n);
 int gcrnn_l1_loss(int dtype, const void* x, const void* y, void* grad, void* partial, int64_t n, double inv_n, void* stream);
+/* batchTimeMSELoss, the drivers' metric (Utils/miscTools.py:121-130): x, y as [R][C] matrices (R = batch * time rows,
+ * C = N * F columns; F32 / F64 / BF16): out[0] = mean_c sqrt(sum_r (x - y)^2) / sqrt(sum_r y^2). part: scratch of
+ * gcrnn_batch_time_mse_slabs(R, C) * 2 * C accumulators (fp64 for F64, else fp32); out: one accumulator. Deterministic. */
+int64_t gcrnn_batch_time_mse_slabs(int64_t R, int64_t C);
+int gcrnn_batch_time_mse(int dtype, const void* x, const void* y, void* part, void* out, int64_t R, int64_t C, void* stream);
+
+/* ==== optimiser ====================================================================================================
+ * torch.optim.Adam (kStepPredGRNNs.py:158-161, stepped at train_rnn.py:276) over ONE flat parameter / gradient / moment
+ * buffer of n elements (F32 or F64): the gradient buffer is the one the data-parallel all-reduce has just reduced.
+ * g is multiplied by grad_scale on the fly. step_dev: device int64 step counter, incremented by the call before use
+ * (capturable: no host value is baked into the launch). */
+int gcrnn_adam_flat(int dtype, void* p, const void* g, void* m, void* v, int64_t n, double lr, double beta1, double beta2,
+                    double eps, double grad_scale, int64_t* step_dev, void* stream);
 
 /* ==== edge gate: graph attention on the CSR support of S + I ====================================================
  * Replaces graphAttention (graphML.py:521-627: dense B x N x N scores, mask, softmax, weighted sum) inside

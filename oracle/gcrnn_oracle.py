@@ -248,3 +248,51 @@ def csr_matvec_rows(rowptr, col, val, Xn):
         if e > s:
             Y[n] = val[s:e] @ Xn[col[s:e]]
     return Y
+
+
+# ---------------------------------------------------------------------------
+# graphs that cannot be held densely (BASELINE configs[4]: N = 1e5): the same arithmetic, LSIGF (graphML.py:116-139) and the
+# un-gated cell step (graphML.py:2420-2423), with the shift x @ S written as a sparse product and evaluated only on the
+# node rows that are asked for. Checked against the dense functions above on small graphs (tests/test_oracle_golden.py).
+# ---------------------------------------------------------------------------
+
+def lsigf_rows_csr(h, P, x, b, rows):
+    """LSIGF output on the nodes `rows` only. h: F x 1 x K x G, P: scipy.sparse CSR of S^T (row n lists S[:, n]),
+    x: B x G x N, b: F x 1 or None  ->  B x F x len(rows).
+    (x S^k)[:, :, n] is row n of P^k applied to the node-major matrix Z0 = x^T ([N][B*G]); z_k is needed on `rows` for
+    every k, hence z_{k-1} on rows + their in-neighbours, and so on down to z_0 which is known everywhere."""
+    F, E, K, G = h.shape
+    assert E == 1
+    B, _, N = x.shape
+    rows = np.asarray(rows)
+    need = [None] * K
+    need[K - 1] = np.unique(rows)
+    for k in range(K - 1, 0, -1):
+        need[k - 1] = np.union1d(need[k], P[need[k]].indices)
+    Z = np.ascontiguousarray(np.transpose(x, (2, 0, 1)).reshape(N, B * G))          # z_0, valid on every row
+    y = np.zeros((B, F, rows.size), dtype=np.result_type(h.dtype, x.dtype))
+    for k in range(K):
+        if k > 0:
+            nxt = np.zeros_like(Z)
+            nxt[need[k]] = P[need[k]] @ Z                                               # z_k on the rows still needed
+            Z = nxt
+        zk = Z[rows].reshape(rows.size, B, G)                                           # rows x B x G
+        y = y + np.einsum('fg,nbg->bfn', h[:, 0, k, :], zk)
+    if b is not None:
+        y = y + b.reshape(1, F, 1)
+    return y
+
+
+def cell_step_rows_csr(params, P, x_t, h_prev, rows):
+    """One step of the un-gated cell on the nodes `rows`: tanh(LSIGF(A, S, x_t, b) + LSIGF(B, S, h_prev, b)) -- the one bias
+    enters through both filters (graphML.py:2420-2423). x_t: B x G x N, h_prev: B x F x N -> B x F x len(rows).
+    With equal tap counts the two filters are ONE filter on the stacked signal [h; x] with taps [B | A] (the sum of two
+    contractions over disjoint channel blocks), which shares the sparse products between them."""
+    b = params.get('bias')
+    A, Bw = params['weight_A'], params['weight_B']
+    if A.shape[2] == Bw.shape[2]:
+        y = lsigf_rows_csr(np.concatenate([Bw, A], axis=3), P, np.concatenate([h_prev, x_t], axis=1), None, rows)
+        return np.tanh(y + (2.0 * b.reshape(1, -1, 1) if b is not None else 0.0))
+    ya = lsigf_rows_csr(A, P, x_t, b, rows)
+    yb = lsigf_rows_csr(Bw, P, h_prev, b, rows)
+    return np.tanh(ya + yb)

@@ -562,3 +562,32 @@ def test_node_linear_bf16_head_matches_fp32(R, F, N, O, wdt):
         s = float(ref.abs().max())
         tol = 2 ** -7 if (name == 'dh' or wdt == torch.bfloat16) else 1e-4       # bf16 store of dh / of the parameter gradient
         assert float((got - ref).abs().max()) <= tol * s, (name, float((got - ref).abs().max()) / s)
+
+
+@pytest.mark.gpu
+def test_flat_adam_matches_torch_adam_and_batch_time_mse():
+    """optim.FlatAdam (one kernel over the flat parameter / gradient buffers, device step counter) reproduces
+    torch.optim.Adam step for step; ops.batch_time_mse reproduces the reference's metric expression (miscTools.py:121-130)."""
+    from gated_gcrnns_amd.optim import FlatAdam
+    from gated_gcrnns_amd.Utils import miscTools
+    dev = torch.device('cuda:0')
+    for dt, tol in ((torch.float64, 1e-12), (torch.float32, 2e-6)):
+        torch.manual_seed(0)
+        net = torch.nn.Sequential(torch.nn.Linear(7, 5), torch.nn.Tanh(), torch.nn.Linear(5, 3)).to(dev, dt)
+        ref = torch.nn.Sequential(torch.nn.Linear(7, 5), torch.nn.Tanh(), torch.nn.Linear(5, 3)).to(dev, dt)
+        ref.load_state_dict(net.state_dict())
+        opt, ropt = FlatAdam(net.parameters(), lr=1e-2), torch.optim.Adam(ref.parameters(), lr=1e-2)
+        x, y = torch.randn(16, 7, device=dev, dtype=dt), torch.randn(16, 3, device=dev, dtype=dt)
+        for it in range(5):
+            opt.zero_grad(); (net(x) - y).abs().mean().backward(); opt.step()
+            ropt.zero_grad(); (ref(x) - y).abs().mean().backward(); ropt.step()
+            for p, q in zip(net.parameters(), ref.parameters()):
+                assert float((p - q).abs().max()) <= tol, (dt, it)
+        assert int(opt.step_dev.item()) == 5
+    for dt, tol in ((torch.float64, 1e-12), (torch.float32, 1e-5), (torch.bfloat16, 1e-5)):
+        x = torch.randn(13, 5, 1, 1000, device=dev).to(dt)
+        y = torch.randn(13, 5, 1, 1000, device=dev).to(dt)
+        got = miscTools.batchTimeMSELoss(x, y)
+        xv, yv = x.double().reshape(-1, 1000), y.double().reshape(-1, 1000)
+        want = torch.mean(torch.sqrt(torch.sum((xv - yv) ** 2, dim=0)) / torch.norm(yv, dim=0))
+        assert abs(float(got) - float(want)) <= tol * float(want), (dt, float(got), float(want))

@@ -63,7 +63,8 @@ def worker(rank, world, port, ret):
     gathered = [torch.zeros_like(mine) for _ in range(world)]
     dist.all_gather(gathered, mine)
     ok &= bool(all(torch.equal(g, gathered[0]) for g in gathered))
-    ok &= flat.numel() == sum(p.numel() for p in model.parameters()) and flat.dtype == torch.float32
+    ok &= flat.numel() == sum(p.numel() for p in model.parameters()) and flat.dtype == torch.float64      # fp64 parameters: fp64 buffer (fp32 otherwise)
+    ok &= all(p.grad.data_ptr() >= flat.data_ptr() and p.grad.data_ptr() < flat.data_ptr() + flat.numel() * 8 for p in model.parameters())   # .grad are views of it
     ret[rank] = ok
     dist.destroy_process_group()
 
@@ -92,3 +93,66 @@ def test_shard_range_is_a_partition():
 def test_batch_partition_matches_reference_rule(nTrain, bs, expect):
     sizes, index = batch_partition(nTrain, bs)
     assert sizes == expect and index[-1] == nTrain and len(index) == len(sizes) + 1
+
+
+def adam_worker(rank, world, port, ret):
+    """FlatAdam (parameters and gradients as views of flat buffers) + the flat all-reduce with unequal shards (weights
+    local / global) reproduces torch.optim.Adam on the whole batch, step after step."""
+    from gated_gcrnns_amd.optim import FlatAdam
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.manual_seed(0)
+    model = Tiny().double()
+    ref = Tiny().double()
+    ref.load_state_dict(model.state_dict())
+    x = torch.randn(7, 6, dtype=torch.float64)            # 7 = 4 + 3: unequal shards
+    y = torch.randn(7, 1, dtype=torch.float64)
+    ropt = torch.optim.Adam(ref.parameters(), lr=1e-2)
+    opt = FlatAdam(model.parameters(), lr=1e-2)
+    lo, hi = shard_range(7, rank, world)
+    ok = True
+    for it in range(4):
+        ropt.zero_grad()
+        torch.nn.functional.l1_loss(ref(x), y).backward()
+        ropt.step()
+        opt.zero_grad()
+        torch.nn.functional.l1_loss(model(x[lo:hi]), y[lo:hi]).backward()
+        opt.sync.all_reduce_((hi - lo) / 7.0)
+        opt.step()
+        for (n, p), (_, q) in zip(model.named_parameters(), ref.named_parameters()):
+            ok &= bool(torch.allclose(p, q, atol=1e-12, rtol=0))
+    ok &= all(p.grad.data_ptr() >= opt.sync.flat.data_ptr() for p in model.parameters())     # still views of the flat buffer
+    ret[rank] = bool(ok)
+    dist.destroy_process_group()
+
+
+def test_flat_adam_world2_matches_torch_adam_on_the_whole_batch():
+    world = 2
+    port = free_port()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(adam_worker, args=(world, port, ret), nprocs=world, join=True)
+    assert all(ret[r] for r in range(world)), dict(ret)
+
+
+def test_bench_self_launches_its_ranks():
+    """`python bench.py --gpus 2` with no RANK in the environment starts its own two ranks as child processes and relays ONE
+    JSON line (here with --dry-run --backend gloo: launcher, rendezvous and the MAX-over-ranks reduction, no GPU)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_PORT')}
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '0', '--dry-run',
+                        '--backend', 'gloo'], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out['n_gpus'] == 2 and out['config']['global_batch'] == 2 * out['config']['batch_per_gpu'] and out['steps'] == 2
+    # a mismatched external launch is refused with the exact command instead of an assert
+    env2 = dict(env, RANK='0', WORLD_SIZE='1', LOCAL_RANK='0')
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--dry-run'], capture_output=True, text=True,
+                       env=env2, timeout=600)
+    assert r.returncode != 0 and 'torch.distributed.run' in r.stderr
