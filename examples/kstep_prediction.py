@@ -21,9 +21,11 @@ import torch
 import gated_gcrnns_amd.Modules.architectures as archit
 from gated_gcrnns_amd.Modules.train_rnn import MultipleModels, TrainableModel
 from gated_gcrnns_amd.Utils import dataTools, miscTools
+from gated_gcrnns_amd.optim import FlatAdam
 
 
-def main():
+def main(argv=None):
+    """Returns {model name: dict(loss=[per-step training loss], score=test metric, ms=median ms per batch)}."""
     ap = argparse.ArgumentParser()
     ap.add_argument('--nodes', type=int, default=80)
     ap.add_argument('--taps', type=int, default=5)
@@ -36,7 +38,9 @@ def main():
     ap.add_argument('--sparse', action='store_true', help='SBM with p_in 0.04 / p_out 0.0025 (BASELINE configs[1]) instead of 0.8 / 0.2')
     ap.add_argument('--models', default='GCRNNMLP,TimeGCRNNMLP,NodeGCRNNMLP,EdgeGCRNNMLP')
     ap.add_argument('--seed', type=int, default=0)
-    args = ap.parse_args()
+    ap.add_argument('--optim', default='flat', choices=['flat', 'torch'], help='flat: optim.FlatAdam (one kernel over the flat '
+                    'parameter / gradient buffers); torch: torch.optim.Adam as in the reference driver')
+    args = ap.parse_args(argv)
     dt = torch.float64 if args.dtype == 'f64' else torch.float32       # parameter dtype (bf16: fp32 master weights)
     data_dt = torch.bfloat16 if args.dtype == 'bf16' else dt
     torch.set_default_dtype(dt)                                   # the reference driver runs in float64 (line 44)
@@ -55,7 +59,10 @@ def main():
             continue
         m = archit.GatedGCRNNforRegression(1, args.features, args.taps, args.taps, torch.tanh, torch.nn.ReLU, [1], S, True,
                                            time_gating=tg, spatial_gating=sg, mlpType='multipMlp').to(dev)
-        opt = torch.optim.Adam(m.parameters(), lr=1e-3, betas=(0.9, 0.999))
+        if args.optim == 'flat':
+            opt = FlatAdam(m.parameters(), lr=1e-3, betas=(0.9, 0.999))          # kStepPredGRNNs.py:158-161
+        else:
+            opt = torch.optim.Adam(m.parameters(), lr=1e-3, betas=(0.9, 0.999))
         models[name] = TrainableModel(m, miscTools.batchTimeL1Loss, opt, name, saveDir)
     xT, yT = data.getSamples('train')
     xV, yV = data.getSamples('valid')
@@ -64,6 +71,7 @@ def main():
     xE, yE = data.getSamples('test')
     xE = xE.view(xE.shape[0], data.seqLen, -1).to(dev, data_dt).unsqueeze(2)
     yE = yE.view(yE.shape[0], data.seqLen, -1).to(dev, data_dt).unsqueeze(2)
+    result = {}
     for name, tm in models.items():
         tm.load('Best')
         with torch.no_grad():
@@ -72,6 +80,8 @@ def main():
         t = np.median(out['timeTrain'][name])
         print('%-14s test RMSE-metric %.4f   loss %.4f -> %.4f   median %.1f ms/batch (%.0f seq/s)' % (
             name, score, out['lossTrain'][name][0], out['lossTrain'][name][-1], 1e3 * t, args.batch / t))
+        result[name] = dict(loss=list(out['lossTrain'][name]), score=score, ms=1e3 * t)
+    return result
 
 
 if __name__ == '__main__':

@@ -47,19 +47,28 @@ class KStepPrediction(object):
     """
 
     def __init__(self, W, K, nTrain, nValid, nTest, horizon, sigmaSpatial=0.1, sigmaTemporal=0.1,
-                 rhoSpatial=0.0, rhoTemporal=0.0, rng=None, dataType=torch.float64):
+                 rhoSpatial=0.0, rhoTemporal=0.0, rng=None, dataType=torch.float64, noise=None):
+        """noise: optional (x0 [nTotal][N], spatial [horizon][nTotal][N], temporal [horizon][nTotal][N]) used instead of
+        fresh draws -- the arrays the reference drew make this class reproduce the reference's samples exactly
+        (tests/golden/g10_kstep_data.npz)."""
         rng = rng if rng is not None else np.random.default_rng()
         N = W.shape[0]
         self.N, self.K, self.horizon, self.seqLen = N, K, horizon, horizon - K
         self.nTrain, self.nValid, self.nTest = nTrain, nValid, nTest
         A = normalised_gso(W)
         nTotal = nTrain + nValid + nTest
-        covT = sigmaTemporal ** 2 * np.eye(horizon) + rhoTemporal ** 2 * np.ones((horizon, horizon))
-        tempNoise = rng.multivariate_normal(np.zeros(horizon), covT, (nTotal, N)).transpose(2, 0, 1)
-        x_t = rng.random((nTotal, N))
+        if noise is not None:
+            x_t, spat_in, tempNoise = (np.asarray(a, dtype=np.float64) for a in noise)
+            assert x_t.shape == (nTotal, N) and spat_in.shape == (horizon, nTotal, N) and tempNoise.shape == (horizon, nTotal, N)
+        else:
+            covT = sigmaTemporal ** 2 * np.eye(horizon) + rhoTemporal ** 2 * np.ones((horizon, horizon))
+            tempNoise = rng.multivariate_normal(np.zeros(horizon), covT, (nTotal, N)).transpose(2, 0, 1)
+            x_t = rng.random((nTotal, N))
         xs = [x_t]
         for t in range(horizon):
-            if rhoSpatial == 0.0:
+            if noise is not None:
+                spatial = spat_in[t]
+            elif rhoSpatial == 0.0:
                 spatial = sigmaSpatial * rng.standard_normal((nTotal, N))
             else:
                 covS = sigmaSpatial ** 2 * np.eye(N) + rhoSpatial ** 2 * np.ones((N, N))

@@ -310,7 +310,95 @@ def g8_midsize():
          H_b0_t3_f0=H[0, 3, 0], H_b1_t0=H[1, 0, :, :8])
 
 
+def bf16_round(a):
+    """Nearest bf16-representable value (round to nearest even on the fp32 bit pattern), returned as float64."""
+    u = np.asarray(a, dtype=np.float32).view(np.uint32).astype(np.uint64)
+    u = ((u + 0x7fff + ((u >> 16) & 1)) >> 16) << 16
+    return u.astype(np.uint32).view(np.float32).astype(np.float64)
+
+
+def g9_fused_bptt():
+    """Reference autograd gradients at a shape the fused bf16 kernels support (N=200, F=G=32, K=3, T=4, B=3): every
+    operand is bf16-representable (S fp32-representable) so that the bf16 kernels and the fp64 reference see the SAME
+    numbers; non-zero h0, directed weighted S; losses H.sum() and L1 against a random target (the drivers' loss,
+    miscTools.py:112-119). Un-gated, time-gated and node-gated cells; gradients of every parameter incl. the gate sub-networks."""
+    N, T, G, F, K, B = 200, 4, 32, 32, 3, 3
+    rng = np.random.default_rng(19)
+    M = (rng.random((N, N)) < 0.05) * rng.uniform(0.2, 1.5, (N, N)) * rng.choice([-1.0, 1.0], (N, N), p=[0.2, 0.8])
+    np.fill_diagonal(M, 0.0)
+    S = (M / np.max(np.abs(np.linalg.eigvals(M)))).astype(np.float32).astype(np.float64).reshape(1, N, N)
+    X = bf16_round(rng.standard_normal((B, T, G, N)))
+    h0 = bf16_round(0.5 * rng.standard_normal((B, F, N)))
+    target = bf16_round(rng.standard_normal((B, T, F, N)))
+    rows, cols = np.nonzero(S[0])
+    for name, tg, sg in (('none', False, None), ('time', True, None), ('node', False, 'node')):
+        torch.manual_seed(90)
+        cell = gml.GGCRNNCell(G, F, K, K, torch.tanh, tg, sg, 1, True)
+        cell.addGSO(torch.tensor(S))
+        with torch.no_grad():
+            for q in cell.parameters():
+                q.copy_(torch.tensor(bf16_round(q.detach().numpy())))
+        p = sd_np(cell)
+        h0t = torch.tensor(h0, requires_grad=True)
+        H = cell(torch.tensor(X), h0t)
+        check(orc.ggcrnn_cell(p, S, X, h0, tg, sg), H.detach().numpy(), 'G9 ' + name)
+        cell.zero_grad()
+        H.sum().backward(retain_graph=True)
+        g_sum, gh0_sum = grads_np(cell), h0t.grad.numpy().copy()
+        cell.zero_grad(); h0t.grad = None
+        torch.nn.L1Loss()(H, torch.tensor(target)).backward()
+        g_l1 = grads_np(cell)
+        f32 = lambda d: {k: (v.astype(np.float32) if v is not None else None) for k, v in d.items()}
+        save('g9_fused_' + name, coo_row=rows.astype(np.int16), coo_col=cols.astype(np.int16), coo_val=S[0][rows, cols].astype(np.float32),
+             shape=np.array([N, T, G, F, K, B]), X=X.astype(np.float32), h0=h0.astype(np.float32), target=target.astype(np.float32),
+             H=H.detach().numpy().astype(np.float32), params=f32(p), grad_sum=f32(g_sum), grad_sum_h0=gh0_sum.astype(np.float32),
+             grad_l1=f32(g_l1), grad_l1_h0=h0t.grad.numpy().astype(np.float32))
+
+
+def g10_kstep_data():
+    """The reference's KStepPrediction dataset (Utils/dataTools.py:1259-1317) on a reference SBM graph
+    (Utils/graphTools.py createGraph 'SBM'), with the numpy global generator seeded: stores the graph, the noise arrays the
+    reference drew (replayed with the same calls in the same order after re-seeding) and the signals / labels of every split.
+    `gensim` (dataTools.py:1001, used by an unrelated text dataset) is absent here: an empty stand-in module lets the import
+    through -- a generator-side shim, nothing of it is stored."""
+    import types
+    sys.modules.setdefault('gensim', types.ModuleType('gensim'))
+    import Utils.dataTools as rdata
+    import Utils.graphTools as rgraph
+    N, K, horizon, nTrain, nValid, nTest = 20, 2, 7, 6, 2, 2
+    sigS, sigT = 0.1, 0.1
+    np.random.seed(1234)
+    G = rgraph.Graph('SBM', N, {'nCommunities': 2, 'probIntra': 0.8, 'probInter': 0.2})
+    np.random.seed(4321)
+    data = rdata.KStepPrediction(K, G, nTrain, nValid, nTest, horizon, sigmaSpatial=sigS, sigmaTemporal=sigT)
+    # replay of the reference's draws (dataTools.py:1284-1297), same calls, same order
+    np.random.seed(4321)
+    nTotal = nTrain + nValid + nTest
+    x0 = np.random.rand(nTotal, N)
+    temp = np.random.multivariate_normal(np.zeros(horizon), sigT ** 2 * np.eye(horizon) + 0.0 * np.ones((horizon, horizon)), (nTotal, N))
+    temp = np.transpose(temp, (2, 0, 1))                                  # horizon x nTotal x N
+    spat = np.stack([np.random.multivariate_normal(np.zeros(N), sigS ** 2 * np.eye(N) + 0.0 * np.ones((N, N)), nTotal)
+                     for _ in range(horizon)])                              # horizon x nTotal x N
+    out = {}
+    for split in ('train', 'valid', 'test'):
+        xs, ys = data.getSamples(split)
+        out[split + '_signals'] = np.asarray(xs)
+        out[split + '_labels'] = np.asarray(ys)
+    # self-check of the replay: x_1 = x_0 A + noise must be what the reference stored as the second step of the signals
+    EW = np.linalg.eigvalsh(G.W)
+    A = G.W / np.max(EW)
+    allsig = np.concatenate([out['train_signals'], out['valid_signals'], out['test_signals']], axis=0)
+    assert np.max(np.abs(allsig[:, :N] - x0)) <= 1e-14
+    assert np.max(np.abs(allsig[:, N:2 * N] - (x0 @ A + spat[0] + temp[0]))) <= 1e-12
+    save('g10_kstep_data', W=np.asarray(G.W, dtype=np.float64), x0=x0, spatial=spat, temporal=temp,
+         shape=np.array([N, K, horizon, nTrain, nValid, nTest]), sigma=np.array([sigS, sigT]), **out)
+
+
 if __name__ == '__main__':
+    if len(sys.argv) > 1:                       # regenerate selected fixtures only: make_golden.py g9_fused_bptt ...
+        for fn in sys.argv[1:]:
+            globals()[fn]()
+        sys.exit(0)
     g1_lsigf()
     g2_graphfilter()
     g3_g4_cells()
@@ -318,4 +406,6 @@ if __name__ == '__main__':
     g6_training_trace()
     g7_csr()
     g8_midsize()
+    g9_fused_bptt()
+    g10_kstep_data()
     print('all oracle checks passed at tol', TOL)

@@ -640,3 +640,63 @@ def test_fused_full_size_training_gradients_add_over_the_batch(tg):
         sc = float(g.abs().max())
         assert sc > 0 or float(s.abs().max()) == 0, n
         assert float((g - s).abs().max()) <= 2e-3 * sc + 1e-12, (n, float((g - s).abs().max()) / max(sc, 1e-30))
+
+
+def _g9_cell(g, tg, sg, dev):
+    """The fixture's cell (parameters by state_dict key, fp32 master weights holding bf16-representable values) and inputs."""
+    import gated_gcrnns_amd.Utils.graphML as gml
+    N, T, G, F, K, B = (int(v) for v in g['shape'])
+    S = np.zeros((1, N, N))
+    S[0, g['coo_row'].astype(np.int64), g['coo_col'].astype(np.int64)] = g['coo_val'].astype(np.float64)
+    cell = gml.GGCRNNCell(G, F, K, K, torch.tanh, tg, sg, 1, True)
+    cell.addGSO(torch.tensor(S))
+    cell.load_state_dict({k: torch.tensor(v) for k, v in g['params'].items()})
+    return cell.float().to(dev), S
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('name,tg,sg', [('none', False, None), ('time', True, None), ('node', False, 'node')])
+@pytest.mark.parametrize('loss', ['sum', 'l1'])
+def test_fused_bptt_matches_reference_autograd_fixture(golden, name, tg, sg, loss):
+    """G9: the fused forward + BPTT against gradients the REFERENCE's autograd produced (tests/golden/make_golden.py
+    g9_fused_bptt: Utils/graphML.py:2336-2427 under torch autograd, fp64) at a fused-supported shape with bf16-representable
+    operands, non-zero h0 and a directed weighted S -- every trained parameter incl. the gate sub-networks, and h0 where the
+    fused path produces it. Tolerances are those of bf16 activations, relative to each gradient's max."""
+    g = golden('g9_fused_' + name)
+    dev = torch.device('cuda:0')
+    cell, S = _g9_cell(g, tg, sg, dev)
+    X = torch.tensor(g['X'], dtype=torch.bfloat16, device=dev)
+    h0 = torch.tensor(g['h0'], dtype=torch.bfloat16, device=dev, requires_grad=(not tg and sg is None))
+    assert float((X.float().cpu() - torch.tensor(g['X'])).abs().max()) == 0.0          # operands are bf16-exact
+    if not cell._use_fused_training(X, h0):
+        pytest.skip('no fused training kernels for the %s-gated cell' % name)
+    H = cell(X, h0)
+    assert H.dtype == torch.bfloat16
+    err = (H.detach().float().cpu() - torch.tensor(g['H'])).abs()
+    assert float(err.max()) <= 4e-2 and float(err.mean()) <= 3e-3, (float(err.max()), float(err.mean()))
+    if loss == 'sum':
+        H.float().sum().backward()
+        want, want_h0 = g['grad_sum'], g['grad_sum_h0']
+    else:
+        torch.nn.functional.l1_loss(H.float(), torch.tensor(g['target'], device=dev)).backward()
+        want, want_h0 = g['grad_l1'], g['grad_l1_h0']
+    got = dict(cell.named_parameters())
+    checked = 0
+    for k, gr in want.items():
+        gg = got[k].grad
+        assert gg is not None, k
+        gg = gg.float().cpu().numpy()
+        sc = np.abs(gr).max()
+        e = np.abs(gg - gr)
+        # L1: dH = sign(H - target) / count flips where the bf16 rounding of H crosses the target -> looser single-entry bound
+        mx = 6e-2 if loss == 'l1' else 4e-2
+        assert sc > 0 and e.max() <= mx * sc and (e.size < 16 or e.mean() <= 1e-2 * sc), (k, e.max() / sc, e.mean() / sc)
+        checked += 1
+    assert checked >= 3
+    for k, p in got.items():                          # parameters the reference leaves without gradient (unused output gate)
+        if k not in want:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
+    if h0.requires_grad:
+        e = (h0.grad.float().cpu() - torch.tensor(want_h0)).abs()
+        sc = float(np.abs(want_h0).max())
+        assert float(e.max()) <= 6e-2 * sc, float(e.max()) / sc

@@ -131,3 +131,31 @@ def test_g5_seismic_fp32_conditioning():
     H0 = orc.ggcrnn_cell(p64, g['S'], g['x'], g['h0'])
     H2 = orc.ggcrnn_cell(p64, g['S'], x2, g['h0'])
     assert np.abs(H2[:, -1] - H0[:, -1]).max() > 1e-6
+
+
+def test_kstep_dataset_reproduces_reference_samples(golden):
+    """G10: with the noise arrays the reference drew, dataTools.KStepPrediction reproduces the signals and
+    labels of the reference's KStepPrediction (Utils/dataTools.py:1275-1302) for every split."""
+    import torch
+    from gated_gcrnns_amd.Utils.dataTools import KStepPrediction
+    g = golden('g10_kstep_data')
+    N, K, horizon, nTrain, nValid, nTest = (int(v) for v in g['shape'])
+    d = KStepPrediction(g['W'], K, nTrain, nValid, nTest, horizon, sigmaSpatial=float(g['sigma'][0]),
+                        sigmaTemporal=float(g['sigma'][1]), noise=(g['x0'], g['spatial'], g['temporal']))
+    for split in ('train', 'valid', 'test'):
+        xs, ys = d.getSamples(split)
+        assert xs.dtype == torch.float64 and tuple(xs.shape) == g[split + '_signals'].shape
+        assert np.max(np.abs(xs.numpy() - g[split + '_signals'])) <= 1e-12
+        assert np.max(np.abs(ys.numpy() - g[split + '_labels'])) <= 1e-12
+
+
+@pytest.mark.parametrize('name,tg,sg', [('none', False, None), ('time', True, None), ('node', False, 'node')])
+def test_oracle_reproduces_g9_states(golden, name, tg, sg):
+    """G9 stores the reference's states as float32: the oracle on the fixture's operands agrees to that rounding."""
+    g = golden('g9_fused_' + name)
+    N, T, G, F, K, B = (int(v) for v in g['shape'])
+    S = np.zeros((1, N, N))
+    S[0, g['coo_row'].astype(np.int64), g['coo_col'].astype(np.int64)] = g['coo_val'].astype(np.float64)
+    p = {k: v.astype(np.float64) for k, v in g['params'].items()}
+    H = orc.ggcrnn_cell(p, S, g['X'].astype(np.float64), g['h0'].astype(np.float64), tg, sg)
+    assert np.max(np.abs(H - g['H'])) <= 2e-7
