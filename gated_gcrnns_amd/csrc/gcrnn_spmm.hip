@@ -208,8 +208,12 @@ int launch_t(int N, const int32_t* rowptr, const int32_t* col, const void* val, 
     const int64_t lanes = L / VE;
     piece_lanes = 64;
     while (piece_lanes > 4 && piece_lanes / 2 >= lanes) piece_lanes >>= 1;
+    // An operand far beyond the XCDs' L2 (4 MiB each) is gathered from the Infinity Cache at a rate set by 128-byte line
+    // requests (measured at cfg5, N = 1e5, nnz = 1e7, bf16: 512 / 256 / 128 / 64-byte pieces -> 7.8 / 8.2 / 8.9 / 4.5 TB/s):
+    // 128-byte pieces keep whole lines and give an XCD the smallest slab (N x 128 B) to find again in its L2.
+    if ((int64_t)N * L * (16 / VE) > (8LL << 20) && piece_lanes > 8) piece_lanes = 8;
   }
-  if (unroll <= 0) unroll = (piece_lanes >= 32) ? 8 : 4;
+  if (unroll <= 0) unroll = (piece_lanes >= 8) ? 8 : 4;
   if (rows_per_wave <= 0) rows_per_wave = 4;
 #define GCRNN_SPMM_CASE(LPV, UV)                                                                                             \
   if (piece_lanes == LPV && unroll == UV)                                                                                    \
