@@ -353,8 +353,7 @@ class GGCRNNCell(nn.Module):
     def _use_horner(self, X, h0):
         if self._wants_grad(X, h0):
             return False            # BPTT runs on the LSIGF autograd nodes
-        if X.dtype == torch.bfloat16 and (self.time_gating == True or self.G > 64 or  # noqa: E712  (gates are fp32 / fp64 code)
-                                          not ops.taps_bf16_supported(self.F, 32 if self.G <= 32 else 64, max(self.Kin, self.Kst))):
+        if X.dtype == torch.bfloat16 and (self.time_gating == True or self.F % 8):  # noqa: E712  (gates are fp32 / fp64 code; 16-byte bf16 rows)
             return False
         return self.spatial_gating is None and self.E == 1 and \
             X.dtype in (torch.float32, torch.float64, torch.bfloat16) and self.weight_A.dtype == X.dtype and h0.dtype == X.dtype
@@ -383,12 +382,23 @@ class GGCRNNCell(nn.Module):
             bvec = bvec.float() if bvec is not None else None           # the kernels take fp32 bias / CSR weights with bf16 rows
             Gp = 32 if G <= 32 else 64
             wA = self.weight_A
-            if Gp != G:                                                 # the matrix-core taps consume whole 32-feature steps
+            mfma = G <= 64 and ops.taps_bf16_supported(F, Gp, K)
+            if mfma and Gp != G:                                        # the matrix-core taps consume whole 32-feature steps
                 Xp = Xn.new_zeros((T, N, B, Gp))
                 Xp[..., :G] = Xn
                 Xn, wA = Xp, nn.functional.pad(wA, (0, Gp - G))
             for t in range(T):
-                _, rest = ops.taps_bf16(h, Xn[t:t + 1], wA, self.weight_B, out0=Hn[t:t + 1])     # u_0 -> Hn[t], u_1.. -> rest
+                if mfma:
+                    _, rest = ops.taps_bf16(h, Xn[t:t + 1], wA, self.weight_B, out0=Hn[t:t + 1])     # u_0 -> Hn[t], u_1.. -> rest
+                else:
+                    # shapes outside the matrix-core tap kernel (F not 32 / 64): fp32 taps on the LDS-tiled kernel, rounded to bf16 rows
+                    hf, xf = h.float(), Xn[t:t + 1].float()
+                    rest = torch.empty((max(K - 1, 1), 1, N, B, F), dtype=X.dtype, device=X.device)
+                    for k in range(K):
+                        u = ops.taps_rows(hf, self.weight_B[:, 0, k].float()) if k < Kst else None
+                        if k < Kin:
+                            u = ops.taps_rows(xf, self.weight_A[:, 0, k].float(), out=u, accumulate=u is not None)
+                        (Hn[t:t + 1] if k == 0 else rest[k - 1]).copy_(u)
                 acc = rest[K - 2] if K > 1 else None
                 for k in range(K - 2, -1, -1):
                     dst = rest[k - 1] if k > 0 else Hn[t:t + 1]
@@ -397,6 +407,20 @@ class GGCRNNCell(nn.Module):
                 if K == 1 or not tanh_fused:
                     pre = Hn[t:t + 1].float() + (2.0 * bvec.view(1, 1, 1, F) if bvec is not None else 0.0)
                     Hn[t:t + 1] = self.sigma(pre).to(X.dtype)
+                h = Hn[t:t + 1]
+            return ops.unpack_node_major(Hn)
+        if gi is None and ops.taps_mfma_supported(X.dtype, F, F, G):
+            # every tap of a step in one launch on the fp32 / fp64 matrix cores, then the same hop chain as the bf16 branch
+            for t in range(T):
+                _, rest = ops.taps_mfma(h, Xn[t:t + 1], self.weight_A, self.weight_B, out0=Hn[t:t + 1])
+                acc = rest[K - 2] if K > 1 else None
+                for k in range(K - 2, -1, -1):
+                    dst = rest[k - 1] if k > 0 else Hn[t:t + 1]
+                    ops.spmm_raw(csr, acc, out=dst, accumulate=True, bias=bvec, bias_scale=2.0, tanh=(k == 0 and tanh_fused))
+                    acc = dst
+                if K == 1 or not tanh_fused:
+                    pre = Hn[t:t + 1] + (2.0 * bvec.view(1, 1, 1, F) if bvec is not None else 0.0)
+                    Hn[t:t + 1] = self.sigma(pre)
                 h = Hn[t:t + 1]
             return ops.unpack_node_major(Hn)
         wA = [self.weight_A[:, 0, k].contiguous() for k in range(Kin)]  # F x G each

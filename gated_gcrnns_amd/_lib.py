@@ -50,6 +50,8 @@ def _bind(lib):
         'gcrnn_spmm': (C.c_int, [C.c_int, _c_i64, _c_p, _c_p, _c_p, _c_p, _c_p, _c_i64, _c_i64, C.c_int, _c_p]),
         'gcrnn_spmm_ex': (C.c_int, [C.c_int, _c_i64, _c_p, _c_p, _c_p, _c_p, _c_p, _c_i64, _c_i64, C.c_int, _c_p, C.c_double, _c_i64,
                                     C.c_int, C.c_int, C.c_int, C.c_int, _c_p]),
+        'gcrnn_taps_mfma_supported': (C.c_int, [C.c_int, _c_i64, _c_i64, _c_i64]),
+        'gcrnn_taps_mfma_forward': (C.c_int, [C.c_int, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_p]),
         'gcrnn_taps_bf16_supported': (C.c_int, [_c_i64, _c_i64, _c_i64]),
         'gcrnn_taps_bf16_forward': (C.c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_i64, _c_i64, _c_i64, _c_i64, _c_p]),
         'gcrnn_batch_time_mse_slabs': (_c_i64, [_c_i64, _c_i64]),
@@ -60,6 +62,7 @@ def _bind(lib):
                                          _c_i64, _c_i64, _c_i64, _c_i64, C.c_int, _c_p]),
         'gcrnn_taps_backward_data': (C.c_int, [C.c_int, _c_p, _c_p, _c_p, _c_p, _c_i64,
                                                _c_i64, _c_i64, _c_i64, _c_i64, _c_p]),
+        'gcrnn_taps_backward_weight_parts': (C.c_int, [_c_i64, _c_i64, _c_i64, _c_i64, C.POINTER(_c_i64), C.POINTER(_c_i64)]),
         'gcrnn_taps_backward_weight': (C.c_int, [C.c_int, _c_p, _c_p, _c_p, _c_i64, _c_p, _c_p, C.c_double,
                                                  _c_i64, _c_i64, _c_i64, _c_i64, _c_p]),
         'gcrnn_ell_size': (C.c_int, [_c_p, _c_i64, _c_p, C.c_int, C.c_int, _c_i64, C.POINTER(_c_i64)]),
@@ -83,6 +86,7 @@ def _bind(lib):
         'gcrnn_fused_gate_grad_bf16': (C.c_int, [_c_p] * 12 + [_c_i64] * 7 + [_c_p]),
         'gcrnn_fused_backward_data_bf16': (C.c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p,
                                                      _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_p, _c_p, _c_p, _c_p]),
+        'gcrnn_fused_wgrad_slots': (_c_i64, [_c_i64, _c_i64]),
         'gcrnn_fused_backward_weight_bf16': (C.c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p,
                                                        _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_p, _c_p,
                                                        C.c_int, _c_p, _c_p]),

@@ -6,7 +6,8 @@
 //   du_0 = dpre_t,  du_k = S du_{k-1}  (adjoint hops, CSR(S)),   z = [h_{t-1} | x_t]   (adjoint of graphML.py:134-135).
 // One workgroup = one (item (t,b), 16-feature chunk of dpre); wave w owns input-feature tile w of z. Every item is
 // independent (no recurrence once dpre is known), so ONE launch covers all T*B items and each workgroup keeps its
-// K accumulator tiles D_k [16 f' x 16 j] in registers across its items; one atomic flush at the end.
+// K accumulator tiles D_k [16 f' x 16 j] in registers across its items and stores them once, as ITS partial sum: the
+// caller adds the partials of the workgroup slots in a fixed order (no atomics anywhere: two runs give the same bits).
 //  - node index = the MFMA contraction dimension. B operand: 8 consecutive nodes of one input feature = one 16-byte
 //    load from the USER layout (x[b][t][g][:], H[b][t-1][f][:] are node-contiguous), held in registers across the taps.
 //    A operand: du_k transposed, a bf16 [16 f'][512 nodes] LDS image per half of the nodes, row stride 1056 B chosen so
@@ -22,8 +23,8 @@ __global__ __launch_bounds__(512, 2) void fused_wgrad_kernel(
     const uint16_t* __restrict__ Xuser,      // [B][T][G][N] bf16
     const uint16_t* __restrict__ Huser,      // [B][T][F][N] bf16 (forward output)
     const uint16_t* __restrict__ h0user,     // [B][F][N]   bf16
-    float* __restrict__ dW,                  // [F][K][F+G] fp32, += (atomics)
-    float* __restrict__ dbsum,               // [F] fp32, += the bias gradient: sum_{t,b} (gi + gf) sum_n dpre, 2 sum dpre without gates (or null)
+    float* __restrict__ dW,                  // [slots][F][K][F+G] fp32 partial sums, slot = this workgroup's item slot (plain stores)
+    float* __restrict__ dbsum,               // [slots][F] fp32 partials of the bias gradient: sum_{t,b} (gi + gf) sum_n dpre, 2 sum dpre without gates (or null)
     const int32_t* __restrict__ tile_nodes, const int32_t* __restrict__ tile_off,
     const float4* __restrict__ ell_val4, const uint2* __restrict__ ell_col4,
     const float* __restrict__ gi,            // [T][B] input-filter gates of the time-gated cell, or null
@@ -38,7 +39,7 @@ __global__ __launch_bounds__(512, 2) void fused_wgrad_kernel(
   float4* lval4 = reinterpret_cast<float4*>(smem + NP * FC * 4);
   uint2* lcol4 = reinterpret_cast<uint2*>(lval4 + entries * 4);
   char* tbuf = reinterpret_cast<char*>(lcol4 + entries * 4);
-  float* lbias = reinterpret_cast<float*>(tbuf + TBYTES);          // [16] bias-gradient partial sums of this workgroup
+  float* lbias = reinterpret_cast<float*>(tbuf + TBYTES);          // [WAVES][16] bias-gradient partial sums, one row per wave (no LDS atomics)
 
   const int L = blockIdx.x;
   const int grp = L / (8 * NCH), rem = L - grp * (8 * NCH);
@@ -73,7 +74,7 @@ __global__ __launch_bounds__(512, 2) void fused_wgrad_kernel(
   f32x4 accD[K];
 #pragma unroll
   for (int k = 0; k < K; ++k) accD[k] = f32x4{0.f, 0.f, 0.f, 0.f};
-  if (tid < FC) lbias[tid] = 0.f;
+  if (tid < WAVES * FC) lbias[tid] = 0.f;       // row w: wave w's share of the bias gradient (its lanes r == 0 own quad q's 4 features)
   const bool has_tile = wave < JT;
   const bool is_x = wave >= F / 16;                 // wave-uniform: tiles 0..F/16-1 are h features, the rest x features
   const int jrow = (is_x ? wave * 16 - F : wave * 16) + r;      // this lane's row (feature) inside its source block
@@ -132,7 +133,7 @@ __global__ __launch_bounds__(512, 2) void fused_wgrad_kernel(
         float v = bacc[c];
 #pragma unroll
         for (int off = 1; off < 16; off <<= 1) v += __shfl_xor(v, off, 64);     // over the 16 slots r of this quad
-        if (r == 0) atomicAdd(lbias + q * 4 + c, v * gbias);
+        if (r == 0) lbias[wave * FC + q * 4 + c] += v * gbias;                  // one owner lane per address, items in program order: deterministic
       }
     }
 #pragma unroll
@@ -229,16 +230,33 @@ __global__ __launch_bounds__(512, 2) void fused_wgrad_kernel(
       __syncthreads();
     }
   }
-  // ---- flush: D_k[f' = 4q + c][j = 16 wave + r] -> dW[chunk*16 + f'][k][j] -------------------------------------------
+  // ---- flush: D_k[f' = 4q + c][j = 16 wave + r] -> this slot's partial dW[it0][chunk*16 + f'][k][j] (every element of the
+  // slot's [F][K][C] block is written by exactly one lane of one workgroup) ----------------------------------------------
   if (has_tile) {
+    float* dWs = dW + (int64_t)it0 * (F * K * C);
 #pragma unroll
     for (int k = 0; k < K; ++k)
 #pragma unroll
       for (int c = 0; c < 4; ++c)
-        atomicAdd(dW + ((int64_t)(chunk * FC + q * 4 + c) * K + k) * C + wave * 16 + r, accD[k][c] * gprev);
+        dWs[((int64_t)(chunk * FC + q * 4 + c) * K + k) * C + wave * 16 + r] = accD[k][c] * gprev;
   }
-  __syncthreads();
-  if (dbsum && tid < FC) atomicAdd(dbsum + chunk * FC + tid, lbias[tid]);
+  if (dbsum) {
+    __syncthreads();
+    if (tid < FC) {
+      float v = 0.f;
+#pragma unroll
+      for (int w = 0; w < WAVES; ++w) v += lbias[w * FC + tid];                // fixed order over the waves
+      dbsum[(int64_t)it0 * F + chunk * FC + tid] = v;
+    }
+  }
+}
+
+// Number of partial-sum slots gcrnn_fused_backward_weight_bf16 writes for B*T items and F state features.
+extern "C" int64_t gcrnn_fused_wgrad_slots(int64_t items, int64_t F) {
+  const int64_t NCH = F / FC;
+  int64_t slots = cdiv(items, 8) * 8;
+  const int64_t max_slots = (256 / NCH) / 8 * 8 > 0 ? (256 / NCH) / 8 * 8 : 8;
+  return slots > max_slots ? max_slots : slots;
 }
 
 template <int K, int HS, int XS>
@@ -246,15 +264,13 @@ static int fused_wgrad_t(const void* dpre, const void* Xuser, const void* Huser,
                          const FusedGraphArgs& ga, const float* gi, const float* gf, int h_is_h0, const int32_t* hzero, int64_t B,
                          int64_t T, int64_t N, hipStream_t st) {
   constexpr int F = 32 * HS;
-  const size_t lds = (size_t)NP * FC * 4 + (size_t)ga.entries * 96 + TBYTES + 64;
+  const size_t lds = (size_t)NP * FC * 4 + (size_t)ga.entries * 96 + TBYTES + WAVES * FC * 4;
   if (lds > 160 * 1024 || !ga.ell_val4 || !ga.ell_col4) return GCRNN_ERR_UNSUPPORTED;
   auto kern = fused_wgrad_kernel<K, HS, XS>;
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
     return GCRNN_ERR_LAUNCH;
   const int NCH = F / FC;
-  int64_t slots = cdiv(B * T, 8) * 8;
-  const int64_t max_slots = (256 / NCH) / 8 * 8 > 0 ? (256 / NCH) / 8 * 8 : 8;
-  if (slots > max_slots) slots = max_slots;
+  const int64_t slots = gcrnn_fused_wgrad_slots(B * T, F);
   GCRNN_PRE_LAUNCH();
   kern<<<(unsigned)(slots * NCH), 512, lds, st>>>((const uint16_t*)dpre, (const uint16_t*)Xuser, (const uint16_t*)Huser,
                                                    (const uint16_t*)h0user, dW, dbsum, ga.tile_nodes, ga.tile_off,

@@ -181,7 +181,8 @@ template <typename T>
 struct BdC { TapOperand<T> dz;
   __device__ __forceinline__ void operator()(int64_t i, int64_t j, T v) const { *const_cast<T*>(dz.ptr(i, j)) = v; } };
 
-// backward weight: A(i=f, k=r) = dy[r][f] (i fast), B(k=r, j=kk) = Zcat[r][kk] (j fast), C -> atomicAdd dw[f][kk]
+// backward weight: A(i=f, k=r) = dy[r][f] (i fast), B(k=r, j=kk) = Zcat[r][kk] (j fast), C -> dw_part[split][f][kk]: every row
+// split (blockIdx.z) stores its own partial sum, the caller adds the splits in a fixed order (deterministic, no atomics)
 template <typename T>
 struct BwA { const T* dy; int F; static constexpr bool KFAST = false;
   __device__ __forceinline__ T operator()(int64_t i, int64_t k) const { return dy[k * F + i]; } };
@@ -189,8 +190,8 @@ template <typename T>
 struct BwB { TapOperand<T> z; static constexpr bool KFAST = false;
   __device__ __forceinline__ T operator()(int64_t k, int64_t j) const { return *z.ptr(k, j); } };
 template <typename T>
-struct BwC { T* dw; int64_t Kd;
-  __device__ __forceinline__ void operator()(int64_t i, int64_t j, T v) const { atomicAdd(dw + i * Kd + j, v); } };
+struct BwC { T* dw; int64_t Kd; int64_t FKd;
+  __device__ __forceinline__ void operator()(int64_t i, int64_t j, T v) const { dw[(int64_t)blockIdx.z * FKd + i * Kd + j] = v; } };
 
 template <typename T, typename AL, typename BL, typename CS>
 __global__ __launch_bounds__(256) void gemm64_kernel(AL a, BL b, CS c, int64_t M, int64_t Nc, int64_t Kd,
@@ -249,9 +250,9 @@ __global__ __launch_bounds__(256) void gemm64_kernel(AL a, BL b, CS c, int64_t M
   }
 }
 
-// dbias[f] += scale * sum_r dy[r][f].  256 threads = (256 / FP) row lanes x FP column lanes (FP = F rounded up to a
-// power of two, <= 256): every thread sums a strided subset of the block's rows, an LDS tree folds the row lanes,
-// one atomic per column and block.
+// dbias_part[block][f] = scale * sum over the block's rows of dy[r][f].  256 threads = (256 / FP) row lanes x FP column lanes
+// (FP = F rounded up to a power of two, <= 256): every thread sums a strided subset of the block's rows, an LDS tree folds
+// the row lanes, one plain store per column and block (the caller adds the blocks in a fixed order).
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ dy, T* __restrict__ dbias, T scale,
                                                      int64_t rows, int F, int FP, int64_t rows_per_block) {
@@ -271,7 +272,7 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ dy, T
       if (rl < step) part[threadIdx.x] += part[threadIdx.x + step * FP];
       __syncthreads();
     }
-    if (rl == 0 && f < F) atomicAdd(dbias + f, scale * part[cf]);
+    if (rl == 0 && f < F) dbias[(int64_t)blockIdx.x * F + f] = scale * part[cf];
     __syncthreads();
   }
 }
@@ -329,20 +330,43 @@ extern "C" int gcrnn_taps_backward_data(int dtype, const void* dy, const void* w
   return GCRNN_ERR_BAD_DTYPE;
 }
 
+// row splits of the weight-gradient GEMM and row blocks of the bias reduction for a (rows, KK, G, F) problem
+static void bwd_weight_plan(int64_t rows, int64_t KK, int64_t G, int64_t F, int64_t* splits, int64_t* ksplit, int64_t* bblocks, int64_t* rpb) {
+  const int64_t Kd = KK * G;
+  // split the (huge) row reduction so that the grid fills the chip: aim at >= 1024 workgroups
+  const int64_t tiles = cdiv(F, 64) * cdiv(Kd, 64);
+  int64_t sp = cdiv(1024, tiles);
+  int64_t ks = cdiv(cdiv(rows, sp), 16) * 16;
+  if (ks < 64) ks = 64;
+  sp = cdiv(rows, ks);
+  if (sp > 65535) { ks = cdiv(cdiv(rows, 65535), 16) * 16; sp = cdiv(rows, ks); }
+  *splits = sp; *ksplit = ks;
+  int FP = 1;
+  while (FP < F && FP < 256) FP <<= 1;
+  int64_t r = cdiv(rows, 512);                     // ~512 blocks, at least 256/FP * 8 rows each
+  const int64_t min_rpb = (int64_t)(256 / FP) * 8;
+  if (r < min_rpb) r = min_rpb;
+  *rpb = r; *bblocks = cdiv(rows, r);
+}
+
+// Partial-sum counts of gcrnn_taps_backward_weight: dw_part is [splits][F][KK*G], dbias_part [bias_blocks][F].
+extern "C" int gcrnn_taps_backward_weight_parts(int64_t rows, int64_t KK, int64_t G, int64_t F, int64_t* splits, int64_t* bias_blocks) {
+  if (!splits || !bias_blocks) return GCRNN_ERR_NULL_POINTER;
+  if (!tap_shape_ok(rows, KK, G, F)) return GCRNN_ERR_BAD_SHAPE;
+  int64_t ks, rpb;
+  bwd_weight_plan(rows, KK, G, F, splits, &ks, bias_blocks, &rpb);
+  return GCRNN_OK;
+}
+
 template <typename T>
 static int taps_bwd_weight(const void* dy, const void* z0, const void* zrest, int64_t zstride, void* dw, void* dbias,
                            double bias_scale, int64_t rows, int64_t KK, int64_t G, int64_t F, void* stream) {
   const int64_t Kd = KK * G;
+  int64_t splits, ksplit, bblocks, rpb;
+  bwd_weight_plan(rows, KK, G, F, &splits, &ksplit, &bblocks, &rpb);
   BwA<T> a{(const T*)dy, (int)F};
   BwB<T> b{{(const T*)z0, (const T*)zrest, zstride, (int)G}};
-  BwC<T> c{(T*)dw, Kd};
-  // split the (huge) row reduction so that the grid fills the chip: aim at >= 1024 workgroups
-  const int64_t tiles = cdiv(F, 64) * cdiv(Kd, 64);
-  int64_t splits = cdiv(1024, tiles);
-  int64_t ksplit = cdiv(cdiv(rows, splits), 16) * 16;
-  if (ksplit < 64) ksplit = 64;
-  splits = cdiv(rows, ksplit);
-  if (splits > 65535) { ksplit = cdiv(cdiv(rows, 65535), 16) * 16; splits = cdiv(rows, ksplit); }
+  BwC<T> c{(T*)dw, Kd, F * Kd};
   GCRNN_PRE_LAUNCH();
   dim3 grid((unsigned)cdiv(F, 64), (unsigned)cdiv(Kd, 64), (unsigned)splits);
   gemm64_kernel<T><<<grid, 256, 0, as_stream(stream)>>>(a, b, c, F, Kd, rows, ksplit);
@@ -350,11 +374,7 @@ static int taps_bwd_weight(const void* dy, const void* z0, const void* zrest, in
   if (dbias) {
     int FP = 1;
     while (FP < F && FP < 256) FP <<= 1;
-    int64_t rpb = cdiv(rows, 512);                 // ~512 blocks, at least 256/FP * 8 rows each
-    const int64_t min_rpb = (int64_t)(256 / FP) * 8;
-    if (rpb < min_rpb) rpb = min_rpb;
-    colsum_kernel<T><<<(unsigned)cdiv(rows, rpb), 256, 0, as_stream(stream)>>>((const T*)dy, (T*)dbias, (T)bias_scale,
-                                                                                rows, (int)F, FP, rpb);
+    colsum_kernel<T><<<(unsigned)bblocks, 256, 0, as_stream(stream)>>>((const T*)dy, (T*)dbias, (T)bias_scale, rows, (int)F, FP, rpb);
     GCRNN_CHECK_LAUNCH();
   }
   return GCRNN_OK;

@@ -139,6 +139,31 @@ def taps_bf16(zh, zx, wA, wB, out0=None):
     return out0, rest
 
 
+def taps_mfma_supported(dtype, F, Ch, Cx):
+    return dtype in (torch.float32, torch.float64) and bool(lib.gcrnn_taps_mfma_supported(dtype_code(dtype), int(F), int(Ch), int(Cx)))
+
+
+def taps_mfma(zh, zx, wA, wB, out0=None):
+    """fp32 / fp64 counterpart of taps_bf16 on the fp32 / fp64 matrix cores (gcrnn_taps_mfma_forward): all
+    K = max(Kin, Kst) taps u_k = zh B_k^T + zx A_k^T of a Horner-form step. zh [..][F], zx [..][G] node-major rows, wA
+    F x 1 x Kin x G, wB F x 1 x Kst x F in the rows' dtype. Returns (u_0, u_rest [K-1][..][F])."""
+    F, Ch = wB.shape[0], wB.shape[3]
+    Cx = wA.shape[3] if zx is not None else 0
+    Kst, Kin = wB.shape[2], (wA.shape[2] if zx is not None else 0)
+    K = max(Kin, Kst)
+    zh = zh.contiguous()
+    zx = zx.contiguous() if zx is not None else None
+    wBc = wB.detach().contiguous()
+    wAc = wA.detach().contiguous() if zx is not None else None
+    R = zh.numel() // Ch
+    if out0 is None:
+        out0 = torch.empty(tuple(zh.shape[:-1]) + (F,), dtype=zh.dtype, device=zh.device)
+    rest = torch.empty((max(K - 1, 1),) + tuple(out0.shape), dtype=zh.dtype, device=zh.device)
+    check(lib.gcrnn_taps_mfma_forward(dtype_code(zh.dtype), _p(zh), _p(zx), _p(wBc), _p(wAc), _p(out0), _p(rest), R, F, Ch, Cx,
+                                      Kst, Kin, _stream()), 'taps_mfma')
+    return out0, rest
+
+
 def taps_rows(z, w, out=None, accumulate=False):
     """y[r][:] (+)= z[r][:] w^T on node-major rows with the LDS-tiled tap kernel (fp32 / fp64): z [..][C], w [F][C]."""
     Cin = z.shape[-1]
@@ -222,8 +247,8 @@ class _LSIGF(torch.autograd.Function):
         st = _stream()
         need_x, need_w, need_b = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.needs_input_grad[2] and ctx.has_bias
         dX = None
-        dW = torch.zeros_like(wc) if need_w else None
-        db = torch.zeros(F, dtype=X.dtype, device=X.device) if need_b else None
+        dW = torch.zeros_like(wc) if (need_w and E > 1) else None
+        db = None
         for e in range(E):
             we = wc[:, e].contiguous() if E > 1 else wc
             if need_x:
@@ -237,14 +262,20 @@ class _LSIGF(torch.autograd.Function):
                     spmm_raw(graph.adj[e], dzr[k - 1], out=dst, accumulate=True)
                 dX = dz0 if dX is None else dX.add_(dz0)
             if need_w or need_b:
-                dwe = dW if E == 1 else torch.zeros((F, K, G), dtype=X.dtype, device=X.device)
-                if not need_w:
-                    dwe = torch.zeros((F, K, G), dtype=X.dtype, device=X.device)
+                # per-split partial sums, added in a fixed order: the weight gradient is bit-reproducible
+                nsp, nbb = C.c_int64(0), C.c_int64(0)
+                check(lib.gcrnn_taps_backward_weight_parts(rows, K, G, F, C.byref(nsp), C.byref(nbb)), 'taps_backward_weight_parts')
+                dwp = torch.empty((nsp.value, F, K, G), dtype=X.dtype, device=X.device)
+                dbp = torch.empty((nbb.value, F), dtype=X.dtype, device=X.device) if (need_b and e == 0) else None
                 check(lib.gcrnn_taps_backward_weight(dt, _p(dy), _p(X), _p(zrest[e]) if K > 1 else None, zstride,
-                                                     _p(dwe), _p(db) if (need_b and e == 0) else None,
-                                                     ctx.bias_scale, rows, K, G, F, st), 'taps_backward_weight')
-                if need_w and E > 1:
-                    dW[:, e] = dwe
+                                                     _p(dwp), _p(dbp), ctx.bias_scale, rows, K, G, F, st), 'taps_backward_weight')
+                if need_w:
+                    if E == 1:
+                        dW = dwp.sum(dim=0).view(F, 1, K, G)
+                    else:
+                        dW[:, e] = dwp.sum(dim=0)
+                if dbp is not None:
+                    db = dbp.sum(dim=0)
         if db is not None:
             db = db.view(ctx.bias_shape)
         return dX, dW, db, None, None
@@ -541,15 +572,18 @@ def fused_backward_weight(dpre, X, H, h0, graph, F, G, K, want_bias=False, gi=No
     With want_bias also returns the bias gradient [F]: sum_{t,b} (gi + gf) sum_n dpre (the one bias enters both filters)."""
     T, B = dpre.shape[0], dpre.shape[1]
     plan = graph.fused_plan(adjoint=True, kernel='wgrad')
-    dW = torch.zeros((F, K, F + G), dtype=torch.float32, device=dpre.device)
-    dbs = torch.zeros(F, dtype=torch.float32, device=dpre.device) if want_bias else None
+    slots = int(lib.gcrnn_fused_wgrad_slots(T * B, F))
+    dWp = torch.zeros((slots, F, K, F + G), dtype=torch.float32, device=dpre.device)      # per-slot partial sums (plain stores)
+    dbp = torch.zeros((slots, F), dtype=torch.float32, device=dpre.device) if want_bias else None
     Xc, h0c = X.contiguous(), h0.contiguous()
     Hc = H.contiguous() if H is not None else None
-    check(lib.gcrnn_fused_backward_weight_bf16(_p(dpre), _p(Xc), _p(Hc), _p(h0c), _p(dW),
-                                               _p(dbs), _p(plan['tile_slots']), _p(plan['tile_off']), _p(plan['ell_val4']),
+    check(lib.gcrnn_fused_backward_weight_bf16(_p(dpre), _p(Xc), _p(Hc), _p(h0c), _p(dWp),
+                                               _p(dbp), _p(plan['tile_slots']), _p(plan['tile_off']), _p(plan['ell_val4']),
                                                _p(plan['ell_col4']), plan['entries'], B, T, graph.N, F, G, K,
                                                _p(gi), _p(gf), int(h_is_h0), _p(hzero), _stream()),
           'fused_backward_weight')
+    dW = dWp.sum(dim=0)                                   # fixed order over the slots: bit-reproducible
+    dbs = dbp.sum(dim=0) if want_bias else None
     return (dW, dbs) if want_bias else dW
 
 
@@ -586,7 +620,7 @@ def fused_training_supported(graph, N, F, G, Kin, Kst, E=1):
     if E != 1 or N % 8 != 0 or Gp is None or not bool(lib.gcrnn_fused_supported(int(N), int(F), int(Gp), int(max(Kin, Kst)))):
         return False
     entries = graph.fused_plan(adjoint=True)['entries']
-    return 65536 + 96 * entries + 16 * 1056 + 64 <= 160 * 1024
+    return 65536 + 96 * entries + 16 * 1056 + 8 * 16 * 4 <= 160 * 1024
 
 
 class _FusedTimeGate(torch.autograd.Function):

@@ -90,6 +90,12 @@ int gcrnn_spmm_ex(int dtype, int64_t N, const int32_t* rowptr, const int32_t* co
  *   u_k[r][:] = zh[r][:] B_k^T + zx[r][:] A_k^T,  k < K,  r < R rows of the node-major layout ([N][B] flattened).
  * wpack = gcrnn_fused_pack_weights(A, B); out0 [R][F] receives tap 0, outrest [K-1][R][F] taps 1..K-1. F in {32, 64},
  * G in {0, 32, 64} (zx NULL when G == 0). Replaces the per-tap contraction of LSIGF (graphML.py:134-135). */
+/* The same on the fp32 / fp64 matrix cores (exact fp32 / fp64 products and sums: the 1e-5 / 1e-11 parity modes): zh [R][Ch],
+ * zx [R][Cx] (NULL when Cx == 0), wB [F][Kst][Ch], wA [F][Kin][Cx] (the reference's F x 1 x K x C tap tensors as they are).
+ * F % 16 == 0; Ch, Cx multiples of 16 (F32) / 8 (F64) with (Ch + Cx) / that in {1, 2, 4, 8, 16}. */
+int gcrnn_taps_mfma_supported(int dtype, int64_t F, int64_t Ch, int64_t Cx);
+int gcrnn_taps_mfma_forward(int dtype, const void* zh, const void* zx, const void* wB, const void* wA, void* out0, void* outrest,
+                            int64_t R, int64_t F, int64_t Ch, int64_t Cx, int64_t Kst, int64_t Kin, void* stream);
 int gcrnn_taps_bf16_supported(int64_t F, int64_t G, int64_t K);
 int gcrnn_taps_bf16_forward(const void* zh, const void* zx, const void* wpack, void* out0, void* outrest, int64_t R,
                             int64_t F, int64_t G, int64_t K, void* stream);
@@ -101,15 +107,17 @@ int gcrnn_taps_bf16_forward(const void* zh, const void* zx, const void* wpack, v
  * forward : y[r][f] = (accumulate ? y[r][f] : 0) + sum_{k,g} z_k[r][g] w[f][k][g] + bias_scale*bias[f]
  *           (graphML.py:134-139; bias_scale = 2 folds the double bias add of graphML.py:2420-2421)
  * bwd_data: dz_k[r][g] = sum_f dy[r][f] w[f][k][g]           (dz0 / dzrest mirror z0 / zrest)
- * bwd_wgt : dw[f][k][g] += sum_r dy[r][f] z_k[r][g] ; dbias[f] += bias_scale * sum_r dy[r][f]
- *           (dw / dbias are accumulated into; the caller zeroes them). */
+ * bwd_wgt : dw_part[s][f][k][g] = sum over row split s of dy[r][f] z_k[r][g] ; dbias_part[b][f] = bias_scale * sum over row
+ *           block b of dy[r][f]; s < splits, b < bias_blocks from gcrnn_taps_backward_weight_parts. Plain stores: the caller
+ *           adds the partials in a fixed order (deterministic; no atomics). */
 int gcrnn_taps_forward(int dtype, const void* z0, const void* zrest, int64_t zstride, const void* w,
                        const void* bias, double bias_scale, void* y, int64_t rows, int64_t KK, int64_t G,
                        int64_t F, int accumulate, void* stream);
 int gcrnn_taps_backward_data(int dtype, const void* dy, const void* w, void* dz0, void* dzrest, int64_t zstride,
                              int64_t rows, int64_t KK, int64_t G, int64_t F, void* stream);
+int gcrnn_taps_backward_weight_parts(int64_t rows, int64_t KK, int64_t G, int64_t F, int64_t* splits, int64_t* bias_blocks);
 int gcrnn_taps_backward_weight(int dtype, const void* dy, const void* z0, const void* zrest, int64_t zstride,
-                               void* dw, void* dbias, double bias_scale, int64_t rows, int64_t KK, int64_t G,
+                               void* dw_part, void* dbias_part, double bias_scale, int64_t rows, int64_t KK, int64_t G,
                                int64_t F, void* stream);
 
 /* ==== fused flagship path (N <= gcrnn_fused_padded_nodes(), bf16 storage, fp32 accumulate) =====
@@ -242,10 +250,13 @@ int gcrnn_fused_backward_data_bf16(const void* dHs, const void* hs, void* dpre, 
  *   item is h0 (the gate sub-cells, graphML.py:2362, 2370; Huser may then be NULL).
  * dpre: output of gcrnn_fused_backward_data_bf16; Xuser [B][T][G][N], Huser [B][T][F][N] (the forward's output) and
  * h0user [B][F][N] are the bf16 USER-layout tensors (node-contiguous rows feed the matrix cores directly; needs N % 8 == 0);
- * dW fp32 [F][K][F+G], accumulated with atomics (caller zeroes); graph arrays = LDS image of the ELL of CSR(S).
+ * dW fp32 [slots][F][K][F+G], slots = gcrnn_fused_wgrad_slots(B*T, F): every workgroup slot stores ITS partial sum with plain
+ * stores (the caller zero-fills the buffer and adds the slots in a fixed order: no atomics, two runs give the same bits);
+ * graph arrays = LDS image of the ELL of CSR(S).
  * Returns GCRNN_ERR_UNSUPPORTED when the graph image does not fit in LDS next to the state. */
+int64_t gcrnn_fused_wgrad_slots(int64_t items, int64_t F);
 int gcrnn_fused_backward_weight_bf16(const void* dpre, const void* Xuser, const void* Huser, const void* h0user, float* dW,
-                                     float* dbsum /* [F] += bias gradient sum_{t,b} (gi + gf) sum_n dpre (2 sum dpre without gates), or NULL */,
+                                     float* dbsum /* [slots][F] partials of the bias gradient sum_{t,b} (gi + gf) sum_n dpre (2 sum dpre without gates), or NULL */,
                                      const int32_t* tile_nodes, const int32_t* tile_off, const void* ell_val4,
                                      const void* ell_col4, int64_t entries, int64_t B, int64_t T, int64_t N, int64_t F,
                                      int64_t G, int64_t K, const float* gi, const float* gf, int h_is_h0,
