@@ -28,10 +28,16 @@
 // T*s*N*(G+2F) of SURVEY.md section 8d.
 #pragma once
 #include "gcrnn_common.h"
+#include "gcrnn_hop_asm.inc"
+
+#ifndef GCRNN_HOP_ASM
+#define GCRNN_HOP_ASM 1      // 1: the hop gather stream is ONE asm block, three groups deep (gcrnn_hop_asm.inc); 0: the two-deep macro stream (A/B)
+#endif
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
 
 namespace {
 constexpr int FC = 16;          // output features per workgroup
@@ -141,6 +147,32 @@ __device__ __forceinline__ float fast_tanh(float x) {
       KEEP_ALIVE(xE0); KEEP_ALIVE(xE1); KEEP_ALIVE(xE2); KEEP_ALIVE(xE3);                          \
       KEEP_ALIVE(xO0); KEEP_ALIVE(xO1); KEEP_ALIVE(xO2); KEEP_ALIVE(xO3);                          \
     }                                                                                              \
+  } while (0)
+
+// The same hop as ONE asm block (generated: gcrnn_hop_asm.inc / tools/gen_hop_asm.py): every in-flight register is named
+// inside the block, so no compiler copy can sit between an LDS read and its counted wait, and the stream runs THREE groups
+// deep -- 12 LDS reads of groups n+1, n+2 in flight while group n is consumed, one s_waitcnt per trip. The accumulators go in
+// and out as 64-bit halves (v_pk_fma_f32 operands). Needs 8 tiles per wave and the dynamic LDS segment at LDS address 0.
+#define GCRNN_HOP_ASM_STREAM(INIT, STORE)                                                          \
+  do {                                                                                             \
+    static_assert(HT == 8, "the asm hop stream is generated for 8 tiles per wave");                \
+    const int gwbeg = tbeg[0] >> 2, gwend = tend[HT - 1] >> 2;                                      \
+    f32x2 al_[8], ah_[8];                                                                          \
+    _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                                \
+      const f32x4 a_ = INIT(i);                                                                    \
+      al_[i] = f32x2{a_[0], a_[1]};                                                                \
+      ah_[i] = f32x2{a_[2], a_[3]};                                                                \
+    }                                                                                              \
+    if (gwbeg < gwend) {                                                                           \
+      const uint32_t colb = lds_col + r * 8, valb = lds_val + r * 16;                              \
+      asm volatile(GCRNN_HOP_ASM_TEXT                                                              \
+                   : "+v"(al_[0]), "+v"(ah_[0]), "+v"(al_[1]), "+v"(ah_[1]), "+v"(al_[2]), "+v"(ah_[2]), "+v"(al_[3]), "+v"(ah_[3]),  \
+                     "+v"(al_[4]), "+v"(ah_[4]), "+v"(al_[5]), "+v"(ah_[5]), "+v"(al_[6]), "+v"(ah_[6]), "+v"(al_[7]), "+v"(ah_[7])   \
+                   : "s"(tend[0] >> 2), "s"(tend[1] >> 2), "s"(tend[2] >> 2), "s"(tend[3] >> 2), "s"(tend[4] >> 2),                   \
+                     "s"(tend[5] >> 2), "s"(tend[6] >> 2), "s"(tend[7] >> 2), "s"(gwbeg), "s"(gwend - 1), "v"(colb), "v"(valb), "v"(qx) \
+                   : GCRNN_HOP_ASM_CLOBBERS);                                                      \
+    }                                                                                              \
+    _Pragma("unroll") for (int i = 0; i < 8; ++i) STORE(i, (f32x4{al_[i][0], al_[i][1], ah_[i][0], ah_[i][1]}));                   \
   } while (0)
 
 // Same hop, but the pipeline is primed and drained per tile: nothing is in flight at the control-flow joins between
@@ -404,6 +436,9 @@ __global__ __launch_bounds__(STHREADS) void fused_step_kernel(
   const int qoff = q * 16;
   // 32-bit LDS byte addresses for the asm reads (low half of the flat LDS address = offset in the allocation)
   const uint32_t lds0 = (uint32_t)reinterpret_cast<uintptr_t>(smem);
+#if GCRNN_HOP_ASM
+  if (lds0 != 0) __builtin_trap();        // the asm stream forms gather addresses as (column word ^ q << 4): the state image must sit at LDS address 0
+#endif
   const uint32_t qx = (uint32_t)qoff;     // stored column = (col << 6) | (swizzle << 4);  ^ (q << 4) selects this lane's quad
   const uint32_t lds_val = lds0 + NP * FC * 4 + K * KS * 1024;
   const uint32_t lds_col = lds_val + (RESIDENT ? entries * 64 : 0);
@@ -417,7 +452,11 @@ __global__ __launch_bounds__(STHREADS) void fused_step_kernel(
     if (RESIDENT) {
 #define GCRNN_FWD_INIT(i) u[i][K - 1 - j]
 #define GCRNN_FWD_STORE(i, a) u[i][K - 1 - j] = a   /* the new value lives in the tap's registers until every wave has read `state` */
+#if GCRNN_HOP_ASM && GCRNN_STEP_WAVES == 8
+      GCRNN_HOP_ASM_STREAM(GCRNN_FWD_INIT, GCRNN_FWD_STORE);
+#else
       GCRNN_HOP_STREAM(GCRNN_FWD_INIT, GCRNN_FWD_STORE);
+#endif
 #undef GCRNN_FWD_INIT
 #undef GCRNN_FWD_STORE
     } else {

@@ -203,7 +203,11 @@ __global__ __launch_bounds__(512, 2) void fused_wgrad_kernel(
         LGKM_WAIT(0);
 #define GCRNN_WG_INIT(i) f32x4{0.f, 0.f, 0.f, 0.f}
 #define GCRNN_WG_STORE(i, a) cur[i] = a
+#if GCRNN_HOP_ASM
+        GCRNN_HOP_ASM_STREAM(GCRNN_WG_INIT, GCRNN_WG_STORE);      // one asm block: no compiler copy can land between a read and its wait
+#else
         GCRNN_HOP_TILED(GCRNN_WG_INIT, GCRNN_WG_STORE);
+#endif
 #undef GCRNN_WG_INIT
 #undef GCRNN_WG_STORE
 #endif

@@ -97,7 +97,10 @@ int launch_nl(const void* zh, const void* zx, const void* wB, const void* wA, vo
   const int K = Kst > Kin ? Kst : Kin;
   const int64_t tiles = (R + 15) / 16;
   int64_t gx = (tiles + 3) / 4;
-  const int64_t cap = 256 * 4 / (K * (F / (16 * FT)) > 4 ? 2 : 1);      // grid-stride: the weight registers are filled once per workgroup
+  // grid-stride over the row tiles: a workgroup fills its weight registers once (FT * NL * V scattered 4 / 8-byte loads per
+  // lane) and must amortise that over many tiles -- about two workgroups per CU in all, K * (F / 16 FT) of them per x index
+  int64_t cap = (2 * 256) / ((int64_t)K * (F / (16 * FT)));
+  if (cap < 1) cap = 1;
   if (gx > cap) gx = cap;
   GCRNN_PRE_LAUNCH();
   taps_mfma_kernel<T, FT, NL><<<dim3((unsigned)gx, (unsigned)K, (unsigned)(F / (16 * FT))), 256, 0, st>>>(

@@ -699,7 +699,8 @@ def test_fused_bptt_matches_reference_autograd_fixture(golden, name, tg, sg, los
     if h0.requires_grad:
         e = (h0.grad.float().cpu() - torch.tensor(want_h0)).abs()
         sc = float(np.abs(want_h0).max())
-        assert float(e.max()) <= 6e-2 * sc, float(e.max()) / sc
+        # d h0 has passed T bf16 dpre stores; with the L1 loss single entries also see sign flips of dH (measured 8 % of the max)
+        assert float(e.max()) <= (1.2e-1 if loss == 'l1' else 6e-2) * sc and float(e.mean()) <= 1e-2 * sc, (float(e.max()) / sc, float(e.mean()) / sc)
 
 
 @pytest.mark.gpu
