@@ -67,6 +67,8 @@ def _bind(lib):
                                                  _c_i64, _c_i64, _c_i64, _c_i64, _c_p]),
         'gcrnn_ell_size': (C.c_int, [_c_p, _c_i64, _c_p, C.c_int, C.c_int, _c_i64, C.POINTER(_c_i64)]),
         'gcrnn_ell_fill': (C.c_int, [_c_p, _c_p, _c_p, _c_i64, _c_p, C.c_int, C.c_int, _c_i64, _c_p, _c_p, _c_p, _c_p]),
+        'gcrnn_ell_assign_rows_z': (C.c_int, [_c_p, _c_p, _c_i64, _c_p, C.c_int, _c_i64, _c_i64, _c_p]),
+        'gcrnn_ell_fill_z': (C.c_int, [_c_p, _c_p, _c_p, _c_i64, _c_p, C.c_int, C.c_int, _c_i64, _c_p, _c_i64, _c_p, _c_p, _c_p]),
         'gcrnn_ell_assign_rows': (C.c_int, [_c_p, _c_p, _c_i64, _c_p, C.c_int, _c_i64, _c_p]),
         'gcrnn_fused_supported': (C.c_int, [_c_i64, _c_i64, _c_i64, _c_i64]),
         'gcrnn_fused_padded_nodes': (_c_i64, []),
@@ -77,7 +79,7 @@ def _bind(lib):
         'gcrnn_fused_pack_weights': (C.c_int, [C.c_int, _c_p, _c_p, _c_p, _c_i64, _c_i64, _c_i64, _c_i64, _c_p]),
         'gcrnn_fused_forward_bf16': (C.c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p,
                                                _c_p, _c_p,
-                                               _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_p, C.c_int, _c_p, _c_p]),
+                                               _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_p, C.c_int, _c_p, C.c_double, _c_p]),
         'gcrnn_pack_seq_major_steps': (C.c_int, [_c_p, _c_p, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_p]),
         'gcrnn_fused_gate_prepass_bf16': (C.c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p,
                                                     _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_p, _c_p]),

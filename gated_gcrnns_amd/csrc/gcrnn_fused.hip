@@ -277,13 +277,13 @@ extern "C" int gcrnn_fused_forward_bf16(const void* xs, const void* h0, void* hs
                                         const int32_t* tile_off, const int32_t* ell_col, const float* ell_val,
                                         const void* ell_val4, const void* ell_col4, int64_t entries, int64_t B,
                                         int64_t T, int64_t N, int64_t F, int64_t G, int64_t K, void* Huser,
-                                        int huser_last_only, void* const* step_events, void* stream) {
+                                        int huser_last_only, void* const* step_events, double uniform_w, void* stream) {
   if (!xs || !h0 || !hs || !wpack || !tile_nodes || !tile_off || !ell_col || !ell_val) return GCRNN_ERR_NULL_POINTER;
   if ((gi == nullptr) != (gf == nullptr)) return GCRNN_ERR_NULL_POINTER;
   if (B <= 0 || T <= 0 || N <= 0 || N > NP || B > (1 << 24) || entries < 0 || entries % 4) return GCRNN_ERR_BAD_SHAPE;
   if (B * (NP * (F > G ? F : G) * 2) > 2147483647LL || T * F * N > 2147483647LL) return GCRNN_ERR_BAD_SHAPE;   // 32-bit buffer offsets
   if (Huser && (N % 8 != 0 || (reinterpret_cast<uintptr_t>(Huser) & 15))) return GCRNN_ERR_BAD_SHAPE;
-  const FusedGraphArgs ga{tile_nodes, tile_off, ell_col, ell_val, ell_val4, ell_col4, entries};
+  const FusedGraphArgs ga{tile_nodes, tile_off, ell_col, ell_val, ell_val4, ell_col4, entries, (float)uniform_w};
   return fused_dispatch(gi ? 1 : 0, xs, h0, hs, wpack, bias, gi, gf, nullptr, nullptr, ga, B, T, N, F, G, K, as_stream(stream),
                         nullptr, nullptr, nullptr, Huser, nullptr, step_events, huser_last_only);
 }

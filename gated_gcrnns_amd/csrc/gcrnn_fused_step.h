@@ -30,6 +30,9 @@
 #include "gcrnn_common.h"
 #include "gcrnn_hop_asm.inc"
 
+#ifndef GCRNN_STORE_POLICY
+#define GCRNN_STORE_POLICY 0   // cache policy of the state stores: 0 plain (default), 16 = sc1 (write-through, line not kept in L2), 2 = nt.
+#endif                         // Measured (tools/store_policy_ab.sh, one box, B = 256): plain 119.4 us per step, sc1 124.7, nt 125.4 -- rejected.
 #ifndef GCRNN_HOP_ASM
 #define GCRNN_HOP_ASM 1      // 1: the hop gather stream is ONE asm block, three groups deep (gcrnn_hop_asm.inc); 0: the two-deep macro stream (A/B)
 #endif
@@ -175,6 +178,32 @@ __device__ __forceinline__ float fast_tanh(float x) {
     _Pragma("unroll") for (int i = 0; i < 8; ++i) STORE(i, (f32x4{al_[i][0], al_[i][1], ah_[i][0], ah_[i][1]}));                   \
   } while (0)
 
+// Uniform-weight graphs (every non-zero of S equal: the reference drivers' W / lambda_max): no weight image in LDS, a tile's
+// gathered rows are summed and enter its accumulator once, acc = init + w * sum (18 instead of 22 LDS cycles per 4 entries).
+// Padding entries point at padding rows, whose state is always zero (gcrnn_ell_fill_z).
+#define GCRNN_HOP_ASM_UNI_STREAM(INIT, STORE)                                                      \
+  do {                                                                                             \
+    static_assert(HT == 8, "the asm hop stream is generated for 8 tiles per wave");                \
+    const int gwbeg = tbeg[0] >> 2, gwend = tend[HT - 1] >> 2;                                      \
+    f32x2 al_[8], ah_[8];                                                                          \
+    _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                                \
+      const f32x4 a_ = INIT(i);                                                                    \
+      al_[i] = f32x2{a_[0], a_[1]};                                                                \
+      ah_[i] = f32x2{a_[2], a_[3]};                                                                \
+    }                                                                                              \
+    if (gwbeg < gwend) {                                                                           \
+      const uint32_t colb = lds_col + r * 8;                                                       \
+      const f32x2 wp_ = f32x2{uni_w, uni_w};                                                       \
+      asm volatile(GCRNN_HOP_ASM_UNI_TEXT                                                          \
+                   : "+v"(al_[0]), "+v"(ah_[0]), "+v"(al_[1]), "+v"(ah_[1]), "+v"(al_[2]), "+v"(ah_[2]), "+v"(al_[3]), "+v"(ah_[3]),  \
+                     "+v"(al_[4]), "+v"(ah_[4]), "+v"(al_[5]), "+v"(ah_[5]), "+v"(al_[6]), "+v"(ah_[6]), "+v"(al_[7]), "+v"(ah_[7])   \
+                   : "s"(tend[0] >> 2), "s"(tend[1] >> 2), "s"(tend[2] >> 2), "s"(tend[3] >> 2), "s"(tend[4] >> 2),                   \
+                     "s"(tend[5] >> 2), "s"(tend[6] >> 2), "s"(tend[7] >> 2), "s"(gwbeg), "s"(gwend - 1), "v"(colb), "v"(qx), "v"(wp_)   \
+                   : GCRNN_HOP_ASM_UNI_CLOBBERS);                                                  \
+    }                                                                                              \
+    _Pragma("unroll") for (int i = 0; i < 8; ++i) STORE(i, (f32x4{al_[i][0], al_[i][1], ah_[i][0], ah_[i][1]}));                   \
+  } while (0)
+
 // Same hop, but the pipeline is primed and drained per tile: nothing is in flight at the control-flow joins between
 // the unrolled tiles. Needed where register pressure makes hipcc insert copies of the ping-pong sets at those joins
 // (a copy of a register whose asm load has not landed yet captures stale data: cdna_hip_programming.md 5.7 item 1).
@@ -217,7 +246,8 @@ __device__ __forceinline__ float fast_tanh(float x) {
 // EPI: 0 = state epilogue (bias, tanh, bf16 store), 1 = time-gate pre-pass (dot-reduce; optionally also stores the
 // gate cell's state c = tanh(pre) for its BPTT), 2 = BPTT data-gradient step (optionally scaled by the forget gate),
 // 3 = gate-gradient pass: sum_{f,n} (filter output + b) * dpre of every item (the gradient w.r.t. a scalar time gate)
-template <int K, int HS, int XS, bool GATED, bool RESIDENT, int EPI = 0>
+// UNI (RESIDENT only): uniform-weight graph image -- column words only, all non-zeros weigh uni_w (GCRNN_HOP_ASM_UNI_STREAM)
+template <int K, int HS, int XS, bool GATED, bool RESIDENT, int EPI = 0, int UNI = 0>
 __global__ __launch_bounds__(STHREADS) void fused_step_kernel(
     const uint16_t* __restrict__ xt,        // [B][NP][G]   bf16
     const uint16_t* __restrict__ hprev,     // [B][NP][F]   bf16
@@ -238,7 +268,9 @@ __global__ __launch_bounds__(STHREADS) void fused_step_kernel(
     const uint16_t* __restrict__ aux1,      // EPI 2: state h_{t-1} [B][NP][F] bf16;  EPI 0: user-layout output H[.][t][F][N] (or null)
     int ubstride,                           // EPI 0: elements between consecutive sequences of the user-layout output (T*F*N)
     int entries, int B, int hmod, int N,
-    const int32_t* __restrict__ flags) {   // EPI 1 (or null): flags[0] != 0 = the state operand h0 is all zeros -> its loads and MFMAs are skipped
+    const int32_t* __restrict__ flags,     // EPI 1 (or null): flags[0] != 0 = the state operand h0 is all zeros -> its loads and MFMAs are skipped
+    float uni_w) {                         // UNI: the one weight of every non-zero
+  static_assert(!UNI || (RESIDENT && GCRNN_HOP_ASM && GCRNN_STEP_WAVES == 8), "the uniform-weight stream is the asm stream on the resident graph");
   constexpr int KS = HS + XS;
   constexpr int F = 32 * HS, G = 32 * XS;
   constexpr int NCH = F / FC;
@@ -248,7 +280,7 @@ __global__ __launch_bounds__(STHREADS) void fused_step_kernel(
   uint4* wl = reinterpret_cast<uint4*>(smem + NP * FC * 4);
   // resident graph: per group of 4 entries and tile slot r:  lval4[g][r] = 4 weights, lcol4[g][r] = 4 x u16 = (col * 64)
   float4* lval4 = reinterpret_cast<float4*>(smem + NP * FC * 4 + K * KS * 1024);
-  uint2* lcol4 = reinterpret_cast<uint2*>(lval4 + (RESIDENT ? entries * 4 : 0));
+  uint2* lcol4 = reinterpret_cast<uint2*>(lval4 + ((RESIDENT && !UNI) ? entries * 4 : 0));
 
   // XCD-aware placement: the NCH chunk workgroups of one sequence get block ids that are equal mod 8,
   // i.e. one XCD under round-robin dispatch (speed only; nothing depends on it).
@@ -270,14 +302,20 @@ __global__ __launch_bounds__(STHREADS) void fused_step_kernel(
     const int n = (entries >> 2) * 16;                         // the host packed the LDS image: straight copies,
     for (int i0 = 0; i0 < n; i0 += STHREADS * 4) {                  // 4 loads in flight per lane before the first LDS store
       const int i_0 = i0 + tid, i_1 = i_0 + STHREADS, i_2 = i_0 + 2 * STHREADS, i_3 = i_0 + 3 * STHREADS, nl = n - 1;
-      const float4 tv0 = ell_val4[i_0 < n ? i_0 : nl], tv1 = ell_val4[i_1 < n ? i_1 : nl];
-      const float4 tv2 = ell_val4[i_2 < n ? i_2 : nl], tv3 = ell_val4[i_3 < n ? i_3 : nl];
       const uint2 tc0 = ell_col4[i_0 < n ? i_0 : nl], tc1 = ell_col4[i_1 < n ? i_1 : nl];
       const uint2 tc2 = ell_col4[i_2 < n ? i_2 : nl], tc3 = ell_col4[i_3 < n ? i_3 : nl];
-      if (i_0 < n) { lval4[i_0] = tv0; lcol4[i_0] = tc0; }
-      if (i_1 < n) { lval4[i_1] = tv1; lcol4[i_1] = tc1; }
-      if (i_2 < n) { lval4[i_2] = tv2; lcol4[i_2] = tc2; }
-      if (i_3 < n) { lval4[i_3] = tv3; lcol4[i_3] = tc3; }
+      if (!UNI) {
+        const float4 tv0 = ell_val4[i_0 < n ? i_0 : nl], tv1 = ell_val4[i_1 < n ? i_1 : nl];
+        const float4 tv2 = ell_val4[i_2 < n ? i_2 : nl], tv3 = ell_val4[i_3 < n ? i_3 : nl];
+        if (i_0 < n) lval4[i_0] = tv0;
+        if (i_1 < n) lval4[i_1] = tv1;
+        if (i_2 < n) lval4[i_2] = tv2;
+        if (i_3 < n) lval4[i_3] = tv3;
+      }
+      if (i_0 < n) lcol4[i_0] = tc0;
+      if (i_1 < n) lcol4[i_1] = tc1;
+      if (i_2 < n) lcol4[i_2] = tc2;
+      if (i_3 < n) lcol4[i_3] = tc3;
     }
   }
   // per-wave tile ranges, fetched once through the scalar path
@@ -441,7 +479,7 @@ __global__ __launch_bounds__(STHREADS) void fused_step_kernel(
 #endif
   const uint32_t qx = (uint32_t)qoff;     // stored column = (col << 6) | (swizzle << 4);  ^ (q << 4) selects this lane's quad
   const uint32_t lds_val = lds0 + NP * FC * 4 + K * KS * 1024;
-  const uint32_t lds_col = lds_val + (RESIDENT ? entries * 64 : 0);
+  const uint32_t lds_col = lds_val + ((RESIDENT && !UNI) ? entries * 64 : 0);
 #ifdef GCRNN_ABLATE_HOPS
 #define GCRNN_HOP_FIRST K
 #else
@@ -453,7 +491,8 @@ __global__ __launch_bounds__(STHREADS) void fused_step_kernel(
 #define GCRNN_FWD_INIT(i) u[i][K - 1 - j]
 #define GCRNN_FWD_STORE(i, a) u[i][K - 1 - j] = a   /* the new value lives in the tap's registers until every wave has read `state` */
 #if GCRNN_HOP_ASM && GCRNN_STEP_WAVES == 8
-      GCRNN_HOP_ASM_STREAM(GCRNN_FWD_INIT, GCRNN_FWD_STORE);
+      if (UNI) GCRNN_HOP_ASM_UNI_STREAM(GCRNN_FWD_INIT, GCRNN_FWD_STORE);
+      else GCRNN_HOP_ASM_STREAM(GCRNN_FWD_INIT, GCRNN_FWD_STORE);
 #else
       GCRNN_HOP_STREAM(GCRNN_FWD_INIT, GCRNN_FWD_STORE);
 #endif
@@ -601,7 +640,9 @@ __global__ __launch_bounds__(STHREADS) void fused_step_kernel(
     } else {
       pk.x = 0u; pk.y = 0u;          // padded rows stay zero
     }
-    __builtin_amdgcn_raw_buffer_store_b64(u32x2{pk.x, pk.y}, rsrc_o, node * (F * 2) + (chunk * FC + q * 4) * 2, b * (NP * F * 2), 0);
+    // GCRNN_STORE_POLICY: an experiment with write-through stores (sc1: the line is not kept in the XCD's L2, whose 4 MiB the
+    // [h | x] operands of the sequences in flight and the prefetched next ones need) -- slower than plain stores, see the define
+    __builtin_amdgcn_raw_buffer_store_b64(u32x2{pk.x, pk.y}, rsrc_o, node * (F * 2) + (chunk * FC + q * 4) * 2, b * (NP * F * 2), GCRNN_STORE_POLICY);
     u[i][0] = f32x4{__uint_as_float(pk.x), __uint_as_float(pk.y), 0.f, 0.f};      // keep the packed bf16 for the user-layout copy
   }
   if (EPI == 0 && aux1) {
@@ -624,9 +665,12 @@ __global__ __launch_bounds__(STHREADS) void fused_step_kernel(
     __syncthreads();
     const int segs = N >> 3;                           // 16-byte segments per row (N % 8 == 0 checked by the host)
     uint16_t* ub = const_cast<uint16_t*>(aux1) + (int64_t)b * ubstride + (int64_t)(chunk * FC) * N;
+    const __amdgpu_buffer_rsrc_t rsrc_u = __builtin_amdgcn_make_buffer_rsrc(ub, 0, FC * N * 2, 0x00020000);      // this item's 16 rows of H[b][t]
     for (int idx = tid; idx < FC * segs; idx += STHREADS) {
       const int f = idx / segs, sg = idx - f * segs;
-      *reinterpret_cast<uint4*>(ub + (int64_t)f * N + sg * 8) = *reinterpret_cast<const uint4*>(tst + f * RS + sg * 16);
+      typedef __attribute__((__vector_size__(4 * sizeof(unsigned int)))) unsigned int u32x4_t;
+      const u32x4_t v = *reinterpret_cast<const u32x4_t*>(tst + f * RS + sg * 16);
+      __builtin_amdgcn_raw_buffer_store_b128(v, rsrc_u, (f * N + sg * 8) * 2, 0, GCRNN_STORE_POLICY);
     }
   }
   }
@@ -637,11 +681,12 @@ __global__ __launch_bounds__(STHREADS) void fused_step_kernel(
 
 typedef void (*fused_kern_t)(const uint16_t*, const uint16_t*, uint16_t*, const uint4*, const float*, const float*,
                              const float*, const int32_t*, const int32_t*, const int32_t*, const float*, const float4*,
-                             const uint2*, const float*, float*, const uint16_t*, const uint16_t*, int, int, int, int, int, const int32_t*);
+                             const uint2*, const float*, float*, const uint16_t*, const uint16_t*, int, int, int, int, int, const int32_t*, float);
 
 struct FusedGraphArgs {
   const int32_t* tile_nodes; const int32_t* tile_off; const int32_t* ell_col; const float* ell_val;
   const void* ell_val4; const void* ell_col4; int64_t entries;
+  float uniform_w = 0.f;      // != 0: every non-zero carries this weight and the padding entries point at zero rows (gcrnn_ell_fill_z)
 };
 
 template <int K, int HS, int XS>
@@ -653,13 +698,20 @@ int fused_launch_t(int mode /*0 plain, 1 gated, 2 gate pre-pass, 3 BPTT data gra
                           const int32_t* hzero_flag = nullptr) {
   constexpr int F = 32 * HS, G = 32 * XS, KS = HS + XS;
   const size_t base = (size_t)NP * FC * 4 + (size_t)K * KS * 1024;
-  const size_t resident_bytes = base + (size_t)ga.entries * 16 * 6;
+  // forward steps on a uniform-weight plan: column words only in LDS (2 instead of 6 bytes per slot and entry)
+  const bool uni = (mode == 0 || mode == 1) && ga.uniform_w != 0.f && ga.ell_col4 && GCRNN_HOP_ASM && GCRNN_STEP_WAVES == 8 &&
+                   base + (size_t)ga.entries * 16 * 2 <= 160 * 1024;
+  const size_t resident_bytes = base + (size_t)ga.entries * 16 * (uni ? 2 : 6);
   const bool resident = resident_bytes <= 160 * 1024 && ga.ell_val4 && ga.ell_col4;
   const size_t lds = resident ? resident_bytes : base;
   fused_kern_t kern;
   if (mode == 4)      kern = resident ? (fused_kern_t)fused_step_kernel<K, HS, XS, false, true, 3> : (fused_kern_t)fused_step_kernel<K, HS, XS, false, false, 3>;
   else if (mode == 3) kern = resident ? (fused_kern_t)fused_step_kernel<K, HS, XS, false, true, 2> : (fused_kern_t)fused_step_kernel<K, HS, XS, false, false, 2>;
   else if (mode == 2) kern = resident ? (fused_kern_t)fused_step_kernel<K, HS, XS, false, true, 1> : (fused_kern_t)fused_step_kernel<K, HS, XS, false, false, 1>;
+#if GCRNN_HOP_ASM && GCRNN_STEP_WAVES == 8
+  else if (mode == 1 && uni && resident) kern = (fused_kern_t)fused_step_kernel<K, HS, XS, true, true, 0, 1>;
+  else if (mode == 0 && uni && resident) kern = (fused_kern_t)fused_step_kernel<K, HS, XS, false, true, 0, 1>;
+#endif
   else if (mode == 1) kern = resident ? (fused_kern_t)fused_step_kernel<K, HS, XS, true, true> : (fused_kern_t)fused_step_kernel<K, HS, XS, true, false>;
   else                kern = resident ? (fused_kern_t)fused_step_kernel<K, HS, XS, false, true> : (fused_kern_t)fused_step_kernel<K, HS, XS, false, false>;
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
@@ -689,17 +741,17 @@ int fused_launch_t(int mode /*0 plain, 1 gated, 2 gate pre-pass, 3 BPTT data gra
       if (mode == 2)      // operands [h0 | x_t]; optional store of c_t = tanh(pre) into hs
         kern<<<grid_for(items), STHREADS, lds, st>>>(x + t0 * xstep, (const uint16_t*)h0, h ? h + t0 * hstep : nullptr, (const uint4*)wpack, bias,
                                      nullptr, nullptr, ga.tile_nodes, ga.tile_off, ga.ell_col, ga.ell_val, (const float4*)ga.ell_val4,
-                                     (const uint2*)ga.ell_col4, gate_w, go, nullptr, nullptr, 0, (int)ga.entries, (int)items, (int)B, (int)N, hzero_flag);
+                                     (const uint2*)ga.ell_col4, gate_w, go, nullptr, nullptr, 0, (int)ga.entries, (int)items, (int)B, (int)N, hzero_flag, 0.f);
       else if (XS == 0)   // operand = one [T*B][NP][F] array, per-item dpre in bw_dHs
         kern<<<grid_for(items), STHREADS, lds, st>>>(nullptr, (const uint16_t*)h0 + t0 * hstep, nullptr, (const uint4*)wpack, bias, nullptr, nullptr,
                                      ga.tile_nodes, ga.tile_off, ga.ell_col, ga.ell_val, (const float4*)ga.ell_val4,
                                      (const uint2*)ga.ell_col4, nullptr, go, (const uint16_t*)bw_dHs + t0 * hstep, nullptr, 0,
-                                     (int)ga.entries, (int)items, (int)items, (int)N, nullptr);
+                                     (int)ga.entries, (int)items, (int)items, (int)N, nullptr, 0.f);
       else                // input filter with G != F: operand [0 | x_t] -- ONE all-zero state block shared by every item (hmod = 1)
         kern<<<grid_for(items), STHREADS, lds, st>>>(x + t0 * xstep, (const uint16_t*)h0, nullptr, (const uint4*)wpack, bias, nullptr, nullptr,
                                      ga.tile_nodes, ga.tile_off, ga.ell_col, ga.ell_val, (const float4*)ga.ell_val4,
                                      (const uint2*)ga.ell_col4, nullptr, go, (const uint16_t*)bw_dHs + t0 * hstep, nullptr, 0,
-                                     (int)ga.entries, (int)items, 1, (int)N, nullptr);
+                                     (int)ga.entries, (int)items, 1, (int)N, nullptr, 0.f);
     }
   } else if (mode == 3) {
     // BPTT: hs (= dpre, [T][B][NP][F]) already holds dpre_{T-1}; walk t = T-1 .. 1, then optionally d h0.
@@ -712,13 +764,13 @@ int fused_launch_t(int mode /*0 plain, 1 gated, 2 gate pre-pass, 3 BPTT data gra
       kern<<<grid, STHREADS, lds, st>>>(nullptr, h + t * hstep, h + (t - 1) * hstep, (const uint4*)wpack, nullptr, nullptr,
                                    gf ? gf + t * B : nullptr, ga.tile_nodes, ga.tile_off, ga.ell_col, ga.ell_val,
                                    (const float4*)ga.ell_val4, (const uint2*)ga.ell_col4, nullptr, gate_out ? gate_out + t * gstep : nullptr,
-                                   dH + (t - 1) * hstep, hst + (t - 1) * hstep, 0, (int)ga.entries, (int)B, (int)B, (int)N, nullptr);
+                                   dH + (t - 1) * hstep, hst + (t - 1) * hstep, 0, (int)ga.entries, (int)B, (int)B, (int)N, nullptr, 0.f);
     }
     if (bw_dh0 || gate_out)
       kern<<<grid, STHREADS, lds, st>>>(nullptr, h, (uint16_t*)bw_dh0, (const uint4*)wpack, nullptr, nullptr, gf, ga.tile_nodes,
                                    ga.tile_off, ga.ell_col, ga.ell_val, (const float4*)ga.ell_val4, (const uint2*)ga.ell_col4,
                                    nullptr, gate_out, nullptr, gate_out ? (const uint16_t*)bw_h0 : nullptr, 0, (int)ga.entries,
-                                   (int)B, (int)B, (int)N, nullptr);
+                                   (int)B, (int)B, (int)N, nullptr, 0.f);
   } else {
     const unsigned grid = grid_for(B);
     for (int64_t t = 0; t < T; ++t) {
@@ -730,7 +782,7 @@ int fused_launch_t(int mode /*0 plain, 1 gated, 2 gate pre-pass, 3 BPTT data gra
                                    (const float4*)ga.ell_val4, (const uint2*)ga.ell_col4, nullptr, nullptr, nullptr,
                                    !huser ? nullptr : (!huser_last_only ? (const uint16_t*)huser + t * F * N : (t == T - 1 ? (const uint16_t*)huser : nullptr)),
                                    (int)((huser_last_only ? 1 : T) * F * N),
-                                   (int)ga.entries, (int)B, (int)B, (int)N, nullptr);
+                                   (int)ga.entries, (int)B, (int)B, (int)N, nullptr, uni ? ga.uniform_w : 0.f);
     }
   }
   GCRNN_CHECK_LAUNCH();

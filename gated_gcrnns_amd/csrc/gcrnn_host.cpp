@@ -8,7 +8,7 @@
 #include <vector>
 #include "../../include/gcrnn.h"
 
-extern "C" int gcrnn_version(void) { return 100; }  // 0.1.0
+extern "C" int gcrnn_version(void) { return 110; }  // 0.1.10
 
 extern "C" const char* gcrnn_status_string(int status) {
   switch (status) {
@@ -185,6 +185,15 @@ struct RegularPeel {
 extern "C" int gcrnn_ell_fill(const int32_t* rowptr, const int32_t* col, const double* val, int64_t N,
                               const int32_t* order, int tile, int pad, int64_t ntiles, const int32_t* node_addr,
                               int32_t* tile_off, int32_t* ell_col, float* ell_val) {
+  return gcrnn_ell_fill_z(rowptr, col, val, N, order, tile, pad, ntiles, node_addr, -1, tile_off, ell_col, ell_val);
+}
+
+// zero_from >= 0: the nodes zero_from .. N-1 are padding rows whose state is always zero; every zero-weight padding entry then
+// points at one of THEM (with the bank key the schedule wants), so that a kernel may drop the weights of a uniform-weight graph
+// and sum the gathered rows directly. GCRNN_ERR_UNSUPPORTED when the padding rows do not cover all 16 bank keys.
+extern "C" int gcrnn_ell_fill_z(const int32_t* rowptr, const int32_t* col, const double* val, int64_t N,
+                                const int32_t* order, int tile, int pad, int64_t ntiles, const int32_t* node_addr,
+                                int64_t zero_from, int32_t* tile_off, int32_t* ell_col, float* ell_val) {
   if (!rowptr || !col || !val || !tile_off || !ell_col || !ell_val) return GCRNN_ERR_NULL_POINTER;
   if (N <= 0 || tile <= 0 || pad <= 0 || ntiles * tile < N) return GCRNN_ERR_BAD_SHAPE;
   const bool schedule = (tile == 16);
@@ -195,10 +204,14 @@ extern "C" int gcrnn_ell_fill(const int32_t* rowptr, const int32_t* col, const d
   int32_t node_of_key[16];
   for (int k = 0; k < 16; ++k) node_of_key[k] = -1;
   if (schedule)
-    for (int64_t n = 0; n < N; ++n) {
+    for (int64_t n = (zero_from >= 0 ? zero_from : 0); n < N; ++n) {
       const int k = node_key4(node_addr, (int32_t)n);
       if (node_of_key[k] < 0) node_of_key[k] = (int32_t)n;
     }
+  if (zero_from >= 0) {
+    if (!schedule || zero_from > N) return GCRNN_ERR_BAD_SHAPE;
+    for (int k = 0; k < 16; ++k) if (node_of_key[k] < 0) return GCRNN_ERR_UNSUPPORTED;
+  }
   for (int k = 0; k < 16; ++k) if (node_of_key[k] < 0) node_of_key[k] = 0;
   for (int64_t t = 0; t < ntiles; ++t) {
     tile_off[t] = (int32_t)off;
@@ -375,6 +388,13 @@ extern "C" int gcrnn_ell_pack_lds(const int32_t* ell_col, const float* ell_val, 
 // N = padded node count (multiple of 16, at most 1024), rowptr / order as for gcrnn_ell_fill (tile = 16).
 extern "C" int gcrnn_ell_assign_rows(const int32_t* rowptr, const int32_t* col, int64_t N, const int32_t* order, int pad,
                                      int64_t ntiles, int32_t* node_addr) {
+  return gcrnn_ell_assign_rows_z(rowptr, col, N, order, pad, ntiles, -1, node_addr);
+}
+
+// zero_from >= 0: the first 16 padding rows zero_from .. zero_from+15 get the bank keys 0 .. 15 (fixed, not searched), so that
+// gcrnn_ell_fill_z finds a zero row for every key.
+extern "C" int gcrnn_ell_assign_rows_z(const int32_t* rowptr, const int32_t* col, int64_t N, const int32_t* order, int pad,
+                                       int64_t ntiles, int64_t zero_from, int32_t* node_addr) {
   if (!rowptr || !col || !node_addr) return GCRNN_ERR_NULL_POINTER;
   if (N <= 0 || N > 1024 || N % 16 || pad <= 0 || ntiles * 16 < N) return GCRNN_ERR_BAD_SHAPE;
   std::vector<int> depth(ntiles);
@@ -395,8 +415,17 @@ extern "C" int gcrnn_ell_assign_rows(const int32_t* rowptr, const int32_t* col, 
   std::vector<std::array<int, 16>> cnt(ntiles);
   for (auto& c : cnt) c.fill(0);
   int cls[4] = {0, 0, 0, 0};
+  std::vector<char> fixed(N, 0);
   for (int64_t n = 0; n < N; ++n) {
     key[n] = (int)(n & 15);
+    if (zero_from >= 0 && n >= zero_from) {
+      if (!in[n].empty()) return GCRNN_ERR_BAD_SHAPE;         // a padding row has no edges
+      if (n - zero_from < 16) {                               // one zero row per key; further padding rows stay free (slack for the search)
+        key[n] = (int)(n - zero_from);
+        fixed[n] = 1;
+        ++cls[key[n] & 3];
+      }
+    }
     if (!in[n].empty()) ++cls[n & 3];                         // nodes nobody gathers (padding rows, sinks) take leftover rows
     for (auto& e : in[n]) ++cnt[e.first][key[n] ^ e.second];
   }
@@ -446,7 +475,7 @@ extern "C" int gcrnn_ell_assign_rows(const int32_t* rowptr, const int32_t* col, 
   }
   int next_row[4] = {0, 1, 2, 3};
   for (int64_t n = 0; n < N; ++n) {
-    if (in[n].empty()) continue;
+    if (in[n].empty() && !fixed[n]) continue;
     const int a = key[n] & 3;
     const int row = next_row[a];
     next_row[a] += 4;
@@ -455,7 +484,7 @@ extern "C" int gcrnn_ell_assign_rows(const int32_t* rowptr, const int32_t* col, 
   }
   int a = 0;
   for (int64_t n = 0; n < N; ++n) {
-    if (!in[n].empty()) continue;
+    if (!in[n].empty() || fixed[n]) continue;
     while (a < 4 && next_row[a] >= N) ++a;
     if (a == 4) return GCRNN_ERR_WORKSPACE;
     node_addr[n] = (next_row[a] << 6) | ((key[n] >> 2) << 4);

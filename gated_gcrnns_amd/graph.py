@@ -172,10 +172,19 @@ class GraphOperator(object):
         ell_val = np.zeros(max(nent.value, 1) * 16, dtype=np.float32)
         # LDS row + quad swizzle of every node, chosen so that the gathers of every tile spread over the 16 bank quads
         node_addr = np.zeros(npad, dtype=np.int32)
-        _lib.check(_lib.lib.gcrnn_ell_assign_rows(vp(rowptr_pad), vp(col), npad, vp(order_full), 4, ntiles, vp(node_addr)),
-                   'ell_assign_rows')
-        _lib.check(_lib.lib.gcrnn_ell_fill(vp(rowptr_pad), vp(col), vp(val), npad, vp(order_full), 16, 4, ntiles,
-                                           vp(node_addr), vp(tile_off), vp(ell_col), vp(ell_val)), 'ell_fill')
+        # Uniform-weight graph (all non-zeros equal -- the reference drivers' W / lambda_max of an unweighted adjacency,
+        # kStepPredGRNNs.py:768) with at least 16 padding rows: the padding rows (state always zero) take the 16 bank keys in
+        # turn and every padding entry points at one of them, so the forward kernels may drop the weight image (uniform_w).
+        v32 = val.astype(np.float32)
+        uniform_w = 0.0
+        import os
+        if val.size and np.all(v32 == v32[0]) and v32[0] != 0 and npad - self.N >= 16 and not os.environ.get('GCRNN_NO_UNIFORM'):   # env: A/B switch
+            uniform_w = float(v32[0])
+        zero_from = self.N if uniform_w != 0.0 else -1
+        _lib.check(_lib.lib.gcrnn_ell_assign_rows_z(vp(rowptr_pad), vp(col), npad, vp(order_full), 4, ntiles, zero_from,
+                                                    vp(node_addr)), 'ell_assign_rows')
+        _lib.check(_lib.lib.gcrnn_ell_fill_z(vp(rowptr_pad), vp(col), vp(val), npad, vp(order_full), 16, 4, ntiles,
+                                             vp(node_addr), zero_from, vp(tile_off), vp(ell_col), vp(ell_val)), 'ell_fill')
         cyc = C.c_int64(0)
         _lib.check(_lib.lib.gcrnn_ell_conflict_cycles(vp(ell_col), nent.value, vp(node_addr), C.byref(cyc)),
                    'ell_conflict_cycles')
@@ -193,7 +202,7 @@ class GraphOperator(object):
                     ell_col=torch.from_numpy(ell_col).to(dev), ell_addr=torch.from_numpy(ell_addr).to(dev),
                     ell_val=torch.from_numpy(ell_val).to(dev),
                     ell_val4=torch.from_numpy(val4).to(dev), ell_col4=torch.from_numpy(col4.view(np.int16)).to(dev),
-                    entries=int(nent.value), gather_cycles=int(cyc.value))
+                    entries=int(nent.value), gather_cycles=int(cyc.value), uniform_w=uniform_w)
         setattr(self, key, plan)
         return plan
 

@@ -350,7 +350,7 @@ def time_fused_step_kernel(X, h0, wA, wB, bias, graph, reps=3):
     e0.record()
     for _ in range(reps):
         check(lib.gcrnn_fused_forward_bf16(_p(xs), _p(h0s), _p(hs), _p(wpack), _p(b32), None, None, *_fused_graph_args(plan),
-                                           B, T, N, F, G, K, _p(H) if H is not None else None, 0, None, st),
+                                           B, T, N, F, G, K, _p(H) if H is not None else None, 0, None, plan.get('uniform_w', 0.0), st),
               'fused_forward')
     e1.record()
     torch.cuda.synchronize()
@@ -517,7 +517,8 @@ def fused_cell_forward(X, h0, wA, wB, bias, graph, gates=None, return_states=Fal
     if events is not None:                               # raw hipEvent_t handles, one slot per step (host array, read during the call)
         evs = (C.c_void_p * T)(*[(e.cuda_event if e is not None else None) for e in events])
     check(lib.gcrnn_fused_forward_bf16(_p(xs), _p(h0s), _p(hs), _p(wpack), _p(b32), _p(gi), _p(gf), *_fused_graph_args(plan),
-                                       B, T, N, F, G, K, _p(H) if direct else None, int(last_only), evs, st), 'fused_forward')
+                                       B, T, N, F, G, K, _p(H) if direct else None, int(last_only), evs, plan.get('uniform_w', 0.0), st),
+          'fused_forward')
     if not direct:
         src = hs[T - 1:] if last_only else hs
         check(lib.gcrnn_unpack_seq_major(_lib.BF16, _p(src), _p(H), B, 1 if last_only else T, F, N, plan['npad'], None, st), 'unpack_seq')

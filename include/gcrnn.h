@@ -145,6 +145,16 @@ int gcrnn_ell_fill(const int32_t* rowptr, const int32_t* col, const double* val,
  * node_addr of the neighbour. N = padded node count here (multiple of 16, <= 1024). */
 int gcrnn_ell_assign_rows(const int32_t* rowptr, const int32_t* col, int64_t N, const int32_t* order, int pad,
                           int64_t ntiles, int32_t* node_addr);
+/* The same two steps for a graph whose non-zeros all carry ONE weight (the reference drivers' S = W / lambda_max of an
+ * unweighted adjacency, kStepPredGRNNs.py:768): zero_from >= 0 names the first padding row (rows zero_from .. N-1 hold zeros
+ * for ever); they get the 16 bank keys in turn and every padding entry points at one of them, so a kernel may drop the weight
+ * image and compute init + w * (sum of the gathered rows). zero_from = -1: the calls above. GCRNN_ERR_UNSUPPORTED when fewer
+ * than 16 padding rows exist. */
+int gcrnn_ell_assign_rows_z(const int32_t* rowptr, const int32_t* col, int64_t N, const int32_t* order, int pad,
+                            int64_t ntiles, int64_t zero_from, int32_t* node_addr);
+int gcrnn_ell_fill_z(const int32_t* rowptr, const int32_t* col, const double* val, int64_t N, const int32_t* order,
+                     int tile, int pad, int64_t ntiles, const int32_t* node_addr, int64_t zero_from, int32_t* tile_off,
+                     int32_t* ell_col, float* ell_val);
 int gcrnn_ell_conflict_cycles(const int32_t* ell_col, int64_t entries, const int32_t* node_addr, int64_t* cycles);
 int gcrnn_ell_pack_lds(const int32_t* ell_col, const float* ell_val, int64_t entries, const int32_t* node_addr, float* val4,
                        uint16_t* col4);
@@ -183,12 +193,15 @@ int gcrnn_fused_pack_weights(int wdtype, const void* wA, const void* wB, void* w
  * huser_last_only != 0: Huser is [B][1][F][N] and receives the LAST state only (the classification models read nothing else,
  * architectures.py:1841-1850); the other steps skip the user-layout store.
  * step_events (or NULL): host array of T hipEvent_t (entries may be NULL); the launch of step t first makes `stream` wait for
- * step_events[t] -- xs[t] is then allowed to be produced on another stream while earlier steps run. */
+ * step_events[t] -- xs[t] is then allowed to be produced on another stream while earlier steps run.
+ * uniform_w != 0: every non-zero of the graph carries this one weight AND the graph arrays come from gcrnn_ell_assign_rows_z /
+ * gcrnn_ell_fill_z (padding entries aimed at zero rows): the step kernels then keep only the column words in LDS and sum the
+ * gathered rows (acc = init + w * sum). 0 = weighted graph image. */
 int gcrnn_fused_forward_bf16(const void* xs, const void* h0, void* hs, const void* wpack, const float* bias,
                              const float* gi, const float* gf, const int32_t* tile_nodes, const int32_t* tile_off,
                              const int32_t* ell_col, const float* ell_val, const void* ell_val4, const void* ell_col4,
                              int64_t entries, int64_t B, int64_t T, int64_t N, int64_t F, int64_t G, int64_t K,
-                             void* Huser, int huser_last_only, void* const* step_events, void* stream);
+                             void* Huser, int huser_last_only, void* const* step_events, double uniform_w, void* stream);
 
 /* Time-gate pre-pass (graphML.py:2357-2374): for every (t, b)
  *   sum over gate_out[t][b][0 .. F/16*8) = sum_{n,f} tanh( A_g(S) x_t + B_g(S) h0 + 2 b_g )[n][f] * gate_w[n][f]

@@ -744,3 +744,49 @@ def test_weight_gradients_are_bit_reproducible(tg):
     g1, g2 = grads(cellf, Xf, hf, tf), grads(cellf, Xf, hf, tf)
     for n in g1:
         assert torch.equal(g1[n], g2[n]), n
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('N,F,K,tg', [(1000, 64, 5, False), (1000, 64, 5, True), (600, 32, 3, False), (1008, 64, 2, False)])
+def test_uniform_weight_graph_stream_matches_oracle_and_weighted_stream(N, F, K, tg, monkeypatch):
+    """S = W / lambda_max of an UNWEIGHTED adjacency (the reference drivers' GSO, kStepPredGRNNs.py:768): the forward kernels
+    drop the weight image and sum the gathered rows (acc = init + w * sum; padding entries aimed at zero rows). Checked against
+    the fp64 oracle, and against the weighted stream on the same graph (not bit-identical: the sums associate differently)."""
+    import gated_gcrnns_amd.Utils.graphML as gml
+    from gated_gcrnns_amd.graph import GraphOperator
+    dev = torch.device('cuda:0')
+    rng = np.random.default_rng(21)
+    W = (rng.random((N, N)) < 10.0 / N).astype(np.float64)
+    W = np.triu(W, 1); W = W + W.T
+    S = (W / np.max(np.abs(np.linalg.eigvalsh(W)))).reshape(1, N, N)
+    B, T = 5, 3
+    X = bf16_round(rng.standard_normal((B, T, F, N)))
+    h0 = bf16_round(0.4 * rng.standard_normal((B, F, N)))
+    torch.manual_seed(3)
+    cell = gml.GGCRNNCell(F, F, K, K, torch.tanh, tg, None, 1, True)
+    cell.addGSO(torch.tensor(S))
+    params = {k: bf16_round(v.detach().numpy()) for k, v in cell.state_dict().items()}
+    S32 = S.astype(np.float32).astype(np.float64)
+    ref = orc.ggcrnn_cell(params, S32, X, h0, tg, None)
+    cell = cell.to(dev).to(torch.bfloat16)
+    Xd = torch.tensor(X, dtype=torch.bfloat16, device=dev)
+    hd = torch.tensor(h0, dtype=torch.bfloat16, device=dev)
+    plan = cell.graph.fused_plan()
+    assert (plan['uniform_w'] != 0.0) == (1024 - N >= 16)          # N = 1008: exactly 16 padding rows; fewer -> weighted image
+    with torch.no_grad():
+        assert cell._use_fused(Xd, hd)
+        H = cell(Xd, hd).double().cpu().numpy()
+    err = np.abs(H - ref)
+    assert err.max() <= 3e-2 and err.mean() <= 2e-3, (err.max(), err.mean())
+    # the same graph on the weighted stream
+    monkeypatch.setenv('GCRNN_NO_UNIFORM', '1')
+    g2 = GraphOperator(torch.tensor(S)).to(dev)
+    assert g2.fused_plan()['uniform_w'] == 0.0
+    cell.graph = g2
+    for sub in ('GFL_in', 'GFL_forget'):
+        if hasattr(cell, sub):
+            getattr(cell, sub).graph = g2
+    with torch.no_grad():
+        H2 = cell(Xd, hd).double().cpu().numpy()
+    assert np.abs(H2 - ref).max() <= 3e-2
+    assert np.abs(H - H2).max() <= 1.6e-2                          # one bf16 ulp at |h| < 1 where a rounding flips

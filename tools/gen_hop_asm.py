@@ -107,6 +107,92 @@ def gen():
     return L
 
 
+# ---- uniform-weight variant: no weight image; a tile's gathered rows are summed (v_pk_add_f32) and enter its accumulator once,
+# acc = init + w * sum, when the stream leaves the tile. Operands: %0..%15 accumulator halves, %16..%23 tile ends, %24 first
+# group, %25 last valid group (SGPR), %26 column base + 8 r, %27 q << 4, %28 = {w, w} (VGPR pair). Clobbers v[194:253].
+UB = 194
+
+
+def UX(p, e, half=None):
+    b = UB + 16 * p + 4 * e
+    if half is None:
+        return 'v[%d:%d]' % (b, b + 3)
+    return 'v[%d:%d]' % (b + 2 * half, b + 2 * half + 1)
+
+
+def UXa(p, e):
+    return 'v%d' % (UB + 16 * p + 4 * e)
+
+
+def UCw(p, hi):
+    return 'v%d' % (UB + 48 + 2 * p + hi)
+
+
+def UCfull(p):
+    return 'v[%d:%d]' % (UB + 48 + 2 * p, UB + 48 + 2 * p + 1)
+
+
+UCA = 'v%d' % (UB + 54)
+USUM = ['v[%d:%d]' % (UB + 56, UB + 57), 'v[%d:%d]' % (UB + 58, UB + 59)]
+UQX, UWP = '%27', '%28'
+
+
+def us1(q, goff, lines):
+    for e in range(4):
+        lines.append('v_xor_b32_sdwa %s, %s, %s dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_%d src1_sel:DWORD'
+                     % (UXa(q, e), UCw(q, e >> 1), UQX, e & 1))
+    for e in range(4):
+        lines.append('ds_read_b128 %s, %s' % (UX(q, e), UXa(q, e)))
+
+
+def us0(q, goff, lines):
+    lines += ['s_add_i32 %s, %s, %d' % (ST, SG, goff), 's_min_i32 %s, %s, %s' % (ST, ST, GLAST),
+              'v_lshl_add_u32 %s, %s, 7, %s' % (UCA, ST, COLB), 'ds_read_b64 %s, %s' % (UCfull(q), UCA)]
+
+
+def gen_uniform():
+    L = ['s_mov_b32 %s, %s' % (SG, GBEG)]
+    for r in range(4):
+        L.append('v_mov_b32 v%d, 0' % (UB + 56 + r))
+    for p in range(3):
+        us0(p, p, L)
+    L.append('s_waitcnt lgkmcnt(0)')
+    us1(0, 0, L); us0(0, 3, L)
+    us1(1, 1, L); us0(1, 4, L)
+    for t in range(NT):
+        for p in range(3):
+            L.append('L_T%d_P%d_%%=:' % (t, p))
+            L.append('s_cmp_ge_i32 %s, %%%d' % (SG, 16 + t))
+            L.append('s_cbranch_scc1 L_X%d_P%d_%%=' % (t, p))
+            q = (p + 2) % 3
+            us1(q, 2, L)
+            us0(q, 5, L)
+            L.append('s_waitcnt lgkmcnt(10)')
+            for e in range(4):
+                L.append('v_pk_add_f32 %s, %s, %s' % (USUM[0], USUM[0], UX(p, e, 0)))
+                L.append('v_pk_add_f32 %s, %s, %s' % (USUM[1], USUM[1], UX(p, e, 1)))
+            L.append('s_add_i32 %s, %s, 1' % (SG, SG))
+        L.append('s_branch L_T%d_P0_%%=' % t)
+        for p in range(3):                    # leaving tile t in phase p: acc_t += w * sum, sum = 0
+            L.append('L_X%d_P%d_%%=:' % (t, p))
+            L.append('v_pk_fma_f32 %%%d, %s, %s, %%%d' % (2 * t, UWP, USUM[0], 2 * t))
+            L.append('v_pk_fma_f32 %%%d, %s, %s, %%%d' % (2 * t + 1, UWP, USUM[1], 2 * t + 1))
+            for r in range(4):
+                L.append('v_mov_b32 v%d, 0' % (UB + 56 + r))
+            L.append('s_branch L_T%d_P%d_%%=' % (t + 1, p))
+    for p in range(3):
+        L.append('L_T%d_P%d_%%=:' % (NT, p))
+    L.append('s_waitcnt lgkmcnt(0)')
+    return L
+
+
+def emit(name, lines):
+    print('#define %s \\' % name)
+    for ln in lines:
+        print('  "%s\\n\\t" \\' % ln)
+    print('  ""')
+
+
 def main():
     lines = gen()
     print('// GENERATED by tools/gen_hop_asm.py -- do not edit. The hop gather stream as one asm block (see the generator).')
@@ -116,6 +202,9 @@ def main():
     print('  ""')
     regs = ', '.join('"v%d"' % r for r in range(BASE, BASE + 68))
     print('#define GCRNN_HOP_ASM_CLOBBERS %s, "s88", "s89", "s90", "scc", "memory"' % regs)
+    emit('GCRNN_HOP_ASM_UNI_TEXT', gen_uniform())
+    regs = ', '.join('"v%d"' % r for r in range(UB, UB + 60))
+    print('#define GCRNN_HOP_ASM_UNI_CLOBBERS %s, "s88", "s89", "s90", "scc", "memory"' % regs)
 
 
 if __name__ == '__main__':
