@@ -332,6 +332,12 @@ def run_cfg2(ctx):
                 ops.fused_cell_forward(X, h0, cell.weight_A, cell.weight_B, cell.bias, cell.graph, return_states=True)
             torch.cuda.synchronize()
             kern = ops.time_fused_step_kernel(X, h0, cell.weight_A, cell.weight_B, cell.bias, cell.graph, reps=3)
+    kern3 = None
+    if args.dtype == 'f32' and args.mode == 'fwd' and not args.time_gating and args.spatial_gating is None:
+        from gated_gcrnns_amd import ops
+        with torch.no_grad():
+            if cell._use_fused_x3(X, h0):
+                kern3 = ops.time_fused_x3_kernel(X, h0, cell.weight_A, cell.weight_B, cell.bias, cell.graph, reps=2)
     ar = None
     if args.mode == 'train':
         # the collective on its own: HIP events around back-to-back all-reduces of the flat gradient buffer
@@ -372,6 +378,20 @@ def run_cfg2(ctx):
                            'mfma_util': mfma_flops / (kern['avg_us'] * 1e-6) / 1e12 / MFMA_BF16_PEAK_TFLOPS,
                            'mfma_util_note': 'taps GEMM flops executed per launch / duration / 2.5 PF dense bf16 peak'
                                              + (' (PMC: SQ_VALU_MFMA_BUSY_CYCLES %.3g per launch)' % tj['mfma_busy_cycles'] if tj and 'mfma_busy_cycles' in tj else ''),
+                           'whole_step_GBps': achieved, 'device_ms_per_step': 1e3 * step_s}
+    elif kern3 is not None:
+        # the fp32-accurate fused step (three bf16 planes per operand): algorithmic bytes = the fp32 tensors of the API
+        kbytes = 4 * N * (G + 2 * F) * B
+        kach = kbytes / (kern3['avg_us'] * 1e-6) / 1e9
+        Gp = 64 if G > 32 else 32
+        mfma_flops = 6 * 2.0 * 1024 * K * F * (F + Gp) * B              # six partial products per tap product
+        out['roofline'] = {'bound': 'hbm', 'achieved': kach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': kach / HBM_PEAK_GBS,
+                           'traffic': None,
+                           'kernel': 'fused_step_x3_kernel<5,2,%d> (fp32-accurate: 3 bf16 planes per operand, 6 partial products; one launch = one time step)' % (2 if G > 32 else 1),
+                           'kernel_avg_us': kern3['avg_us'], 'launches_timed': kern3['launches'], 'algorithmic_bytes_per_launch': kbytes,
+                           'moved_bytes_per_launch_min': 6 * N * (G + 2 * F) * B + 4 * N * F * B,
+                           'mfma_util': mfma_flops / (kern3['avg_us'] * 1e-6) / 1e12 / MFMA_BF16_PEAK_TFLOPS,
+                           'mfma_util_note': 'bf16 MFMA flops executed per launch (6 x the tap GEMM) / duration / 2.5 PF',
                            'whole_step_GBps': achieved, 'device_ms_per_step': 1e3 * step_s}
     else:
         out['roofline'] = {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',

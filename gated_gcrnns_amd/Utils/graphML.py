@@ -300,6 +300,8 @@ class GGCRNNCell(nn.Module):
         if last_only:
             if (not torch.is_grad_enabled()) and self._use_fused(X, h0):
                 return self._forward_fused(X, h0, last_only=True)
+            if (not torch.is_grad_enabled()) and self._use_fused_x3(X, h0):
+                return ops.fused_cell_forward_x3(X, h0, self.weight_A, self.weight_B, self.bias, self.graph, last_only=True)
             return self.forward(X, h0)[:, -1:]
         assert h0.shape[0] == X.shape[0]
         ops.require_device(X, h0, self.weight_A)
@@ -311,6 +313,8 @@ class GGCRNNCell(nn.Module):
                                         self._fused_gates() if self.time_gating == True else None)  # noqa: E712
         if self._use_fused(X, h0):
             return self._forward_fused(X, h0)
+        if self._use_fused_x3(X, h0):
+            return ops.fused_cell_forward_x3(X, h0, self.weight_A, self.weight_B, self.bias, self.graph)
         if self._use_small(X, h0):
             return self._forward_small(X, h0)
         if self._use_small_training(X, h0):
@@ -521,6 +525,19 @@ class GGCRNNCell(nn.Module):
             return False
         return ops.fused_supported(self.N, self.F, self.G, self.Kin, self.Kst, X.dtype, self.E) and \
             self.weight_A.dtype in (X.dtype, torch.float32) and h0.dtype == X.dtype
+
+    def _use_fused_x3(self, X, h0):
+        """fp32 inference of the un-gated cell on the fp32-accurate fused kernels (three bf16 planes per operand): graphs that fit
+        the fused kernels, too large for the one-launch small-graph kernels, with one weight on every edge."""
+        if self._wants_grad(X, h0):
+            return False
+        if self.time_gating == True or self.spatial_gating is not None or self.sigma not in (torch.tanh, nn.functional.tanh):  # noqa: E712
+            return False
+        if X.dtype != torch.float32 or h0.dtype != X.dtype or self.weight_A.dtype != X.dtype:
+            return False
+        if ops.small_supported(self.N, self.graph.fwd[0].nnz, self.G, self.F, self.Kin, self.Kst, X.dtype, self.E):
+            return False
+        return ops.fused_x3_supported(self.graph, self.N, self.F, self.G, self.Kin, self.Kst, X.dtype, self.E)
 
     def _use_fused_training(self, X, h0):
         """bf16 activations (parameters bf16 or fp32 master weights), plain or time-gated cell, gradients wanted for the

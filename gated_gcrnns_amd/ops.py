@@ -83,6 +83,23 @@ def unpack_node_major(X):
 _SPMM_TUNE = {}      # {'piece_lanes': .., 'unroll': .., 'rows_per_wave': ..}: overrides for tuning sweeps (tools/spmm_sweep.py)
 
 
+def spmm_auto_tune(csr, L, elt):
+    """Piece width / loads in flight of the streaming SpMM from what the host knows (the kernel's own default knows neither the
+    mean degree nor where the operand lives). Dense neighbourhoods on an operand far beyond L2 (cfg5: ~100 non-zeros per row,
+    51 MB): 128-byte pieces, 8 slots x 8 loads (measured best, tools/spmm_sweep.py). Sparse rows (cfg2: ~10 per row) on wide
+    node rows: whole-wave pieces and as many loads in flight as a row has neighbours, otherwise most slots idle."""
+    deg = csr.nnz / max(csr.N, 1)
+    row_bytes = L * elt
+    lanes = max(4, min(64, 1 << max(0, (row_bytes // 16 - 1)).bit_length()))        # lanes that cover one row (power of two)
+    if csr.N * row_bytes > (8 << 20) and deg >= 32:
+        return dict(piece_lanes=min(lanes, 8), unroll=8, rows_per_wave=4)
+    slots = 64 // lanes
+    unroll = 8 if deg > 16 * slots else (4 if deg > 2 * slots else 2)                # measured at cfg2 (deg 10, 1 KiB pieces): 4 beats 8
+    if unroll == 2 and lanes > 8:
+        unroll = 4                                                                   # (2-deep variants are built for narrow pieces only)
+    return dict(piece_lanes=lanes, unroll=unroll, rows_per_wave=1 if csr.N <= 4096 else 4)
+
+
 def spmm_raw(csr, X, out=None, accumulate=False, bias=None, bias_scale=0.0, tanh=False, tune=None):
     """Y[i][n][:] (+)= sum_j val[j] X[i][col[j]][:] on a contiguous [nbatch][N][L...] tensor (bf16 / fp32 / fp64 rows; the
     CSR weights are fp32 for bf16 rows). tanh: Y = tanh(. + bias_scale * bias[l % F]) -- the last hop of a Horner-form step
@@ -98,7 +115,7 @@ def spmm_raw(csr, X, out=None, accumulate=False, bias=None, bias_scale=0.0, tanh
         out = torch.empty_like(X)
     ve = 16 // X.element_size()
     if L % ve == 0 and X.data_ptr() % 16 == 0 and out.data_ptr() % 16 == 0:
-        t = tune if tune is not None else _SPMM_TUNE
+        t = tune if tune is not None else (_SPMM_TUNE or spmm_auto_tune(csr, L, X.element_size()))
         F = bias.numel() if bias is not None else 0
         check(lib.gcrnn_spmm_ex(dtype_code(X.dtype), N, _p(csr.rowptr), _p(csr.col), _p(csr.val(X.dtype)), _p(X), _p(out),
                                 L, nbatch, int(accumulate), _p(bias), float(bias_scale), F, int(tanh),
@@ -524,6 +541,80 @@ def fused_cell_forward(X, h0, wA, wB, bias, graph, gates=None, return_states=Fal
         check(lib.gcrnn_unpack_seq_major(_lib.BF16, _p(src), _p(H), B, 1 if last_only else T, F, N, plan['npad'], None, st), 'unpack_seq')
     if return_states:
         return hs_all, plan, H
+    return H
+
+
+def fused_x3_supported(graph, N, F, G, Kin, Kst, dtype, E=1):
+    """fp32-accurate fused inference (gcrnn_fused_forward_x3): fp32 tensors, un-gated cell, N <= 1024 with N % 4 == 0, the fused
+    shapes, and a UNIFORM-weight graph (all non-zeros equal: the drivers' W / lambda_max) with >= 16 padding rows."""
+    if E != 1 or dtype != torch.float32 or N > int(lib.gcrnn_fused_padded_nodes()):
+        return False
+    Gp = fused_padded_inputs(F, G)
+    if Gp is None:
+        return False
+    plan = graph.fused_plan()
+    return plan.get('uniform_w', 0.0) != 0.0 and bool(lib.gcrnn_fused_x3_supported(int(N), int(F), int(Gp), int(max(Kin, Kst)), plan['entries']))
+
+
+def time_fused_x3_kernel(X, h0, wA, wB, bias, graph, reps=3):
+    """Average duration of ONE launch of the fp32-accurate step kernel (HIP events on the launch stream, inputs pre-packed)."""
+    X, wA = fused_pad_operands(X, wA.detach())
+    B, T, G, N = X.shape
+    F, Kin, Kst = wA.shape[0], wA.shape[2], wB.shape[2]
+    K = max(Kin, Kst)
+    plan = graph.fused_plan()
+    npad, st, dev = plan['npad'], _stream(), X.device
+    Xc, h0c = X.contiguous(), h0.contiguous()
+    xs3 = torch.empty((T, 3, B, npad, G), dtype=torch.bfloat16, device=dev)
+    h03 = torch.empty((1, 3, B, npad, F), dtype=torch.bfloat16, device=dev)
+    hs3 = torch.empty((T, 3, B, npad, F), dtype=torch.bfloat16, device=dev)
+    check(lib.gcrnn_pack_seq_major_x3(_p(Xc), _p(xs3), B, T, G, N, npad, st), 'pack_seq_x3')
+    check(lib.gcrnn_pack_seq_major_x3(_p(h0c), _p(h03), B, 1, F, N, npad, st), 'pack_seq_x3')
+    wAc, wBc = wA.float().contiguous(), wB.detach().float().contiguous()
+    wp3 = torch.empty((3 * (F // 16) * K * ((F + G) // 32) * 64 * 8,), dtype=torch.bfloat16, device=dev)
+    check(lib.gcrnn_fused_pack_weights_x3(_p(wAc), _p(wBc), _p(wp3), F, G, Kin, Kst, st), 'pack_weights_x3')
+    b32 = bias.detach().float().contiguous().view(-1) if bias is not None else None
+    H = torch.empty((B, T, F, N), dtype=torch.float32, device=dev)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(reps):
+        check(lib.gcrnn_fused_forward_x3(_p(xs3), _p(h03), _p(hs3), _p(wp3), _p(b32), _p(plan['tile_slots']), _p(plan['tile_off']),
+                                         _p(plan['ell_col4']), plan['entries'], B, T, N, F, G, K, plan['uniform_w'], _p(H), 0, st),
+              'fused_forward_x3')
+    e1.record()
+    torch.cuda.synchronize()
+    return {'avg_us': 1e3 * e0.elapsed_time(e1) / (reps * T), 'launches': reps * T}
+
+
+def fused_cell_forward_x3(X, h0, wA, wB, bias, graph, last_only=False):
+    """Un-gated GGCRNNCell forward to fp32 accuracy on the fused kernels (three bf16 planes per fp32 operand, six partial
+    products per tap product on the bf16 matrix cores, fp32 hops / tanh). X: B x T x G x N fp32, h0: B x F x N fp32 ->
+    H: B x T x F x N fp32 (B x 1 x F x N with last_only). Inference only (no autograd graph)."""
+    require_device(X, h0, wA, wB, bias)
+    X, wA = fused_pad_operands(X, wA.detach())
+    B, T, G, N = X.shape
+    F = wA.shape[0]
+    Kin, Kst = wA.shape[2], wB.shape[2]
+    K = max(Kin, Kst)
+    plan = graph.fused_plan()
+    npad = plan['npad']
+    st = _stream()
+    dev = X.device
+    Xc, h0c = X.contiguous(), h0.contiguous()
+    xs3 = torch.empty((T, 3, B, npad, G), dtype=torch.bfloat16, device=dev)
+    h03 = torch.empty((1, 3, B, npad, F), dtype=torch.bfloat16, device=dev)
+    hs3 = torch.empty((T, 3, B, npad, F), dtype=torch.bfloat16, device=dev)
+    check(lib.gcrnn_pack_seq_major_x3(_p(Xc), _p(xs3), B, T, G, N, npad, st), 'pack_seq_x3')
+    check(lib.gcrnn_pack_seq_major_x3(_p(h0c), _p(h03), B, 1, F, N, npad, st), 'pack_seq_x3')
+    wAc, wBc = wA.float().contiguous(), wB.detach().float().contiguous()
+    wp3 = torch.empty((3 * (F // 16) * K * ((F + G) // 32) * 64 * 8,), dtype=torch.bfloat16, device=dev)
+    check(lib.gcrnn_fused_pack_weights_x3(_p(wAc), _p(wBc), _p(wp3), F, G, Kin, Kst, st), 'pack_weights_x3')
+    b32 = bias.detach().float().contiguous().view(-1) if bias is not None else None
+    H = torch.empty((B, 1 if last_only else T, F, N), dtype=torch.float32, device=dev)
+    check(lib.gcrnn_fused_forward_x3(_p(xs3), _p(h03), _p(hs3), _p(wp3), _p(b32), _p(plan['tile_slots']), _p(plan['tile_off']),
+                                     _p(plan['ell_col4']), plan['entries'], B, T, N, F, G, K, plan['uniform_w'], _p(H),
+                                     int(last_only), st), 'fused_forward_x3')
     return H
 
 

@@ -134,6 +134,26 @@ int gcrnn_ell_size(const int32_t* rowptr, int64_t N, const int32_t* order, int t
 int gcrnn_ell_fill(const int32_t* rowptr, const int32_t* col, const double* val, int64_t N, const int32_t* order,
                    int tile, int pad, int64_t ntiles, const int32_t* node_addr, int32_t* tile_off, int32_t* ell_col,
                    float* ell_val);
+/* ==== fp32-accurate fused path ("x3": three bf16 planes per fp32 operand, six partial products on the bf16 matrix cores) ========
+ * The un-gated cell h_t = tanh(A(S)x_t + b + B(S)h_{t-1} + b) (Utils/graphML.py:2420-2423) to fp32 accuracy (the north_star's
+ * 1e-5 mode) at fused-kernel speed: v = v1 + v2 + v3 with v1 = bf16(v), v2 = bf16(v - v1), v3 = bf16(v - v1 - v2) for state,
+ * input and taps; z.w = z1w1 + z1w2 + z1w3 + z2w1 + z2w2 + z3w1 with fp32 accumulation; hops / bias / tanh in fp32.
+ * gcrnn_pack_seq_major_x3: user fp32 [B][T][C][N] -> planes [T][3][B][NPad][C] bf16 (C even), rows N..NPad-1 zero.
+ * gcrnn_fused_pack_weights_x3: fp32 taps wA [F][Kin][G], wB [F][Kst][F] -> wpack3 [3][F/16][K][(F+G)/32][64][8] bf16.
+ * gcrnn_fused_forward_x3: T launches; xs3 [T][3][B][NPad][G], h03 [3][B][NPad][F], hs3 [T][3][B][NPad][F]; bias fp32 [F] or NULL;
+ * graph arrays of a UNIFORM-weight plan (gcrnn_ell_assign_rows_z / gcrnn_ell_fill_z; ell_col4 = the column half of
+ * gcrnn_ell_pack_lds; uniform_w = the one weight); Huser fp32 [B][T][F][N] (or [B][1][F][N] with last_only != 0) or NULL.
+ * gcrnn_fused_x3_supported: F = G in {32, 64} or F = 64 with G = 32, K in 2..5, N <= 1024, N % 4 == 0, and the image fits LDS
+ * (64 KiB state + 3 tap planes + 32 B x entries <= 160 KiB). */
+int gcrnn_fused_x3_supported(int64_t N, int64_t F, int64_t G, int64_t K, int64_t entries);
+int gcrnn_pack_seq_major_x3(const void* src, void* dst, int64_t B, int64_t T, int64_t C, int64_t N, int64_t NPad, void* stream);
+int gcrnn_fused_pack_weights_x3(const void* wA, const void* wB, void* wpack3, int64_t F, int64_t G, int64_t Kin, int64_t Kst,
+                                void* stream);
+int gcrnn_fused_forward_x3(const void* xs3, const void* h03, void* hs3, const void* wpack3, const float* bias,
+                           const int32_t* tile_nodes, const int32_t* tile_off, const void* ell_col4, int64_t entries, int64_t B,
+                           int64_t T, int64_t N, int64_t F, int64_t G, int64_t K, double uniform_w, void* Huser, int last_only,
+                           void* stream);
+
 /* LDS placement of the hop state (tile = 16). node_addr[n] = (row << 6) | (swz << 4): node n's 64-byte state row sits at
  * LDS row `row`, its four 16-byte quads XOR-swizzled by `swz` (NULL = identity: row n, swz (n >> 2) & 3).
  * gcrnn_ell_assign_rows chooses rows and swizzles (local search over the 16 bank-quad keys a node can take) so that no

@@ -790,3 +790,37 @@ def test_uniform_weight_graph_stream_matches_oracle_and_weighted_stream(N, F, K,
         H2 = cell(Xd, hd).double().cpu().numpy()
     assert np.abs(H2 - ref).max() <= 3e-2
     assert np.abs(H - H2).max() <= 1.6e-2                          # one bf16 ulp at |h| < 1 where a rounding flips
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('N,F,G,K,B,T', [(1000, 64, 64, 5, 3, 6), (1000, 64, 1, 5, 2, 4), (600, 32, 32, 3, 5, 3), (1008, 64, 32, 2, 2, 3),
+                                         (1000, 64, 64, 4, 2, 2)])
+def test_fp32_accurate_fused_path_matches_oracle_to_1e5(N, F, G, K, B, T):
+    """gcrnn_fused_forward_x3: the un-gated cell on the fused kernels with every fp32 operand carried as three bf16 planes and
+    six partial products per tap product -- fp32 inputs, fp32 output, <= 1e-5 against the fp64 oracle (the north_star's
+    tolerance), non-zero h0, the drivers' G = 1 (padded channels), and the last-state-only read-out."""
+    import gated_gcrnns_amd.Utils.graphML as gml
+    dev = torch.device('cuda:0')
+    rng = np.random.default_rng(31)
+    W = (rng.random((N, N)) < 10.0 / N).astype(np.float64)
+    W = np.triu(W, 1); W = W + W.T
+    S = (W / np.max(np.abs(np.linalg.eigvalsh(W)))).reshape(1, N, N)
+    X = rng.standard_normal((B, T, G, N)).astype(np.float32)
+    h0 = (0.5 * rng.standard_normal((B, F, N))).astype(np.float32)
+    torch.manual_seed(4)
+    cell = gml.GGCRNNCell(G, F, K, K, torch.tanh, False, None, 1, True)
+    cell.addGSO(torch.tensor(S))
+    cell = cell.float()
+    params = {k: v.detach().double().numpy() for k, v in cell.state_dict().items()}
+    ref = orc.ggcrnn_cell(params, S.astype(np.float32).astype(np.float64), X.astype(np.float64), h0.astype(np.float64))
+    cell = cell.to(dev)
+    Xd, hd = torch.tensor(X, device=dev), torch.tensor(h0, device=dev)
+    with torch.no_grad():
+        assert cell._use_fused_x3(Xd, hd)
+        H = cell(Xd, hd)
+        Hl = cell(Xd, hd, last_only=True)
+        H2 = cell(Xd, hd)
+    assert H.dtype == torch.float32 and tuple(H.shape) == (B, T, F, N)
+    err = np.abs(H.double().cpu().numpy() - ref).max()
+    assert err <= 1e-5, err
+    assert torch.equal(Hl, H[:, -1:]) and torch.equal(H, H2)               # same bits: last-only read-out, second run
