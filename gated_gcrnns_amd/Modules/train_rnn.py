@@ -148,7 +148,8 @@ class GraphedTrainStep(object):
 
     The reference's training configurations (N = 50..80 nodes, T = 5..20, batch 100; kStepPredGRNNs.py:110-127) are
     launch-bound on a GPU: a step is several hundred tiny kernels. Capturing the whole step removes the per-launch host
-    cost. Inputs are copied into static buffers; the optimiser must be created with capturable=True (torch.optim.Adam).
+    cost. Inputs are copied into static buffers; the optimiser is optim.FlatAdam (one kernel over the flat buffers, device step
+    counter: capturable as it is) or torch.optim.Adam created with capturable=True.
 
         step = GraphedTrainStep(archit, loss_fn, optim, x_example, y_example, stateFeat)
         loss = step(x, y)        # x, y: B x T x 1 x N on the device, same shapes as the examples
@@ -168,8 +169,12 @@ class GraphedTrainStep(object):
                 self._eager()
         torch.cuda.current_stream(x.device).wait_stream(s)
         self.graph = torch.cuda.CUDAGraph()
-        self.optim.zero_grad(set_to_none=True)
+        self.flat = hasattr(self.optim, 'sync')          # optim.FlatAdam: gradients are views of one flat buffer, step counter on the device
+        if not self.flat:
+            self.optim.zero_grad(set_to_none=True)
         with torch.cuda.graph(self.graph):
+            if self.flat:
+                self.optim.zero_grad()                   # one memset node; backward accumulates into the views in place
             self.yHat = self.archit(self.x, self.h0)
             self.loss = self.loss_fn(self.yHat, self.y)
             self.loss.backward()

@@ -135,45 +135,55 @@ __global__ __launch_bounds__(STHREADS) void fused_step_x3_kernel(
 
   for (int b = b0; b < B; b += seq_slots) {
     // ---- phase 1: taps, six partial products per operand pair, two tiles per weight fragment ------------------------------
+    // 12 (tile pair, plane) stages; the fragments of stage g+1 are requested before the MFMAs of stage g (two register sets),
+    // so one L2 latency is exposed per sequence instead of one per stage.
     f32x4 u[STILES][K - 1];
-#pragma unroll
-    for (int i = 0; i < STILES; i += 2) {
-      f32x4 acc[K][2];
-#pragma unroll
-      for (int tap = 0; tap < K; ++tap) { acc[tap][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[tap][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-#pragma unroll
-      for (int p = 0; p < 3; ++p) {
-        bf16x8 fr[2][KS];
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          int w = woff[i + j];
-          asm volatile("" : "+v"(w));
-          const int roh = (w >> 16) * (F * 2) + 16 * q, rox = (w >> 16) * (G * 2) + 16 * q;
-#pragma unroll
-          for (int s = 0; s < HS; ++s)
-            fr[j][s] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsrc_h, roh + 64 * s, (p * B + b) * (NP * F * 2), 0));
-#pragma unroll
-          for (int s = 0; s < XS; ++s)
-            fr[j][HS + s] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, rox + 64 * s, (p * B + b) * (NP * G * 2), 0));
-        }
-#pragma unroll
-        for (int tap = 0; tap < K; ++tap)
-#pragma unroll
-          for (int s = 0; s < KS; ++s)
-#pragma unroll
-            for (int wp = 0; wp < 3 - p; ++wp) {             // operand plane p meets weight planes 0 .. 2-p
-              const bf16x8 a = __builtin_bit_cast(bf16x8, wl[wp * WPL + (tap * KS + s) * 64 + lane]);
-              acc[tap][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, fr[0][s], acc[tap][0], 0, 0, 0);
-              acc[tap][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, fr[1][s], acc[tap][1], 0, 0, 0);
-            }
-      }
+    bf16x8 fr[2][2][KS];                     // [set][tile of the pair][k-step]
+    auto load_stage = [&](int g, int set) {
+      const int i = 2 * (g / 3), p = g % 3;
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
+        int w = woff[i + j];
+        asm volatile("" : "+v"(w));
+        const int roh = (w >> 16) * (F * 2) + 16 * q, rox = (w >> 16) * (G * 2) + 16 * q;
 #pragma unroll
-        for (int tap = 0; tap < K - 1; ++tap) u[i + j][tap] = acc[tap][j];
-        int wv = woff[i + j];
-        asm volatile("" : "+v"(wv));
-        *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(state) + (wv & 0xffff)) = acc[K - 1][j];
+        for (int s = 0; s < HS; ++s)
+          fr[set][j][s] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsrc_h, roh + 64 * s, (p * B + b) * (NP * F * 2), 0));
+#pragma unroll
+        for (int s = 0; s < XS; ++s)
+          fr[set][j][HS + s] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, rox + 64 * s, (p * B + b) * (NP * G * 2), 0));
+      }
+    };
+    load_stage(0, 0);
+    f32x4 acc[K][2];
+#pragma unroll
+    for (int g = 0; g < 3 * (STILES / 2); ++g) {
+      const int i = 2 * (g / 3), p = g % 3, set = g & 1;
+      if (p == 0) {
+#pragma unroll
+        for (int tap = 0; tap < K; ++tap) { acc[tap][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[tap][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+      }
+      if (g + 1 < 3 * (STILES / 2)) load_stage(g + 1, set ^ 1);
+      __builtin_amdgcn_sched_barrier(0);       // keep the next stage's loads ahead of this stage's MFMAs
+#pragma unroll
+      for (int tap = 0; tap < K; ++tap)
+#pragma unroll
+        for (int s = 0; s < KS; ++s)
+#pragma unroll
+          for (int wp = 0; wp < 3 - p; ++wp) {             // operand plane p meets weight planes 0 .. 2-p
+            const bf16x8 a = __builtin_bit_cast(bf16x8, wl[wp * WPL + (tap * KS + s) * 64 + lane]);
+            acc[tap][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, fr[set][0][s], acc[tap][0], 0, 0, 0);
+            acc[tap][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, fr[set][1][s], acc[tap][1], 0, 0, 0);
+          }
+      if (p == 2) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+#pragma unroll
+          for (int tap = 0; tap < K - 1; ++tap) u[i + j][tap] = acc[tap][j];
+          int wv = woff[i + j];
+          asm volatile("" : "+v"(wv));
+          *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(state) + (wv & 0xffff)) = acc[K - 1][j];
+        }
       }
     }
     __syncthreads();

@@ -9,8 +9,9 @@ from conftest import load_golden
 pytestmark = pytest.mark.gpu
 
 
+@pytest.mark.parametrize('flat', [False, True])
 @pytest.mark.parametrize('name,tg', [('GCRNNMLP', False), ('TimeGCRNNMLP', True)])
-def test_g6_twenty_adam_steps_match_reference(name, tg):
+def test_g6_twenty_adam_steps_match_reference(name, tg, flat):
     import gated_gcrnns_amd.Modules.architectures as archit
     from gated_gcrnns_amd.Modules.train_rnn import train_step
     from gated_gcrnns_amd.Utils.miscTools import batchTimeL1Loss, batchTimeMSELoss
@@ -20,7 +21,11 @@ def test_g6_twenty_adam_steps_match_reference(name, tg):
                                        time_gating=tg, spatial_gating=None, mlpType='multipMlp').double()
     m.load_state_dict({k: torch.tensor(v) for k, v in g['params0'].items()})
     m = m.to(dev)
-    opt = torch.optim.Adam(m.parameters(), lr=1e-3, betas=(0.9, 0.999))      # kStepPredGRNNs.py:158-161
+    if flat:       # the flat-buffer Adam kernel + gradients as views of the flat all-reduce buffer (N3)
+        from gated_gcrnns_amd.optim import FlatAdam
+        opt = FlatAdam(m.parameters(), lr=1e-3, betas=(0.9, 0.999))
+    else:
+        opt = torch.optim.Adam(m.parameters(), lr=1e-3, betas=(0.9, 0.999))      # kStepPredGRNNs.py:158-161
     x = torch.tensor(g['x'], device=dev)
     y = torch.tensor(g['y'], device=dev)
     losses, metrics = [], []
@@ -54,3 +59,33 @@ def test_harness_runs_and_checkpoints(tmp_path):
     assert (tmp_path / 'savedModels' / 'GCRNNMLPArchitBest.ckpt').exists()
     assert (tmp_path / 'savedModels' / 'GCRNNMLPArchitLast.ckpt').exists()
     tm.load('Last')
+
+
+def test_graphed_training_step_with_flat_adam_matches_eager():
+    """zero_grad -> forward -> L1 loss -> BPTT -> FlatAdam captured as ONE hipGraph (device step counter, gradients accumulate into
+    views of the flat buffer) reproduces the eager steps bit for bit over several replays."""
+    import gated_gcrnns_amd.Modules.architectures as archit
+    from gated_gcrnns_amd.Modules.train_rnn import train_step, GraphedTrainStep
+    from gated_gcrnns_amd.Utils.miscTools import batchTimeL1Loss
+    from gated_gcrnns_amd.optim import FlatAdam
+    g = load_golden('g6_trace_GCRNNMLP')
+    dev = torch.device('cuda:0')
+    x = torch.tensor(g['x'], device=dev)
+    y = torch.tensor(g['y'], device=dev)
+    ms = []
+    for _ in range(2):
+        m = archit.GatedGCRNNforRegression(1, 20, 3, 3, torch.tanh, torch.nn.ReLU, [1], g['S'][0], True,
+                                           time_gating=False, spatial_gating=None, mlpType='multipMlp').double()
+        m.load_state_dict({k: torch.tensor(v) for k, v in g['params0'].items()})
+        ms.append(m.to(dev))
+    opt_e, opt_g = FlatAdam(ms[0].parameters(), lr=1e-3), FlatAdam(ms[1].parameters(), lr=1e-3)
+    stepper = GraphedTrainStep(ms[1], batchTimeL1Loss, opt_g, x, y, 20)            # 3 eager warm-up steps inside
+    for _ in range(3):
+        train_step(ms[0], batchTimeL1Loss, opt_e, x, y, 20)
+    for it in range(5):
+        le, _ = train_step(ms[0], batchTimeL1Loss, opt_e, x, y, 20)
+        lg, _ = stepper(x, y)
+        assert float(le) == float(lg), it
+    for p, q in zip(ms[0].parameters(), ms[1].parameters()):
+        assert torch.equal(p, q)
+    assert int(opt_g.step_dev.item()) == 8
