@@ -313,6 +313,8 @@ class GGCRNNCell(nn.Module):
                                         self._fused_gates() if self.time_gating == True else None)  # noqa: E712
         if self._use_fused(X, h0):
             return self._forward_fused(X, h0)
+        if self._use_fused_node(X, h0):
+            return self._forward_fused_node(X, h0)
         if self._use_fused_x3(X, h0):
             return ops.fused_cell_forward_x3(X, h0, self.weight_A, self.weight_B, self.bias, self.graph)
         if self._use_small(X, h0):
@@ -525,6 +527,27 @@ class GGCRNNCell(nn.Module):
             return False
         return ops.fused_supported(self.N, self.F, self.G, self.Kin, self.Kst, X.dtype, self.E) and \
             self.weight_A.dtype in (X.dtype, torch.float32) and h0.dtype == X.dtype
+
+    def _use_fused_node(self, X, h0):
+        """Node-gated cell (optionally time-gated too), bf16, inference: fused kernels (gates, A(S)x_t + b and both gate filters for
+        all steps at once; the recurrence on the state-only operand with per-node gates in its epilogue)."""
+        if self._wants_grad(X, h0) or self.spatial_gating != 'node' or self.sigma not in (torch.tanh, nn.functional.tanh):
+            return False
+        if self.bias is None and self.time_gating == True:  # noqa: E712
+            return False
+        return ops.fused_node_supported(self.graph, self.N, self.F, self.G, self.Kin, self.Kst, X.dtype, self.E) and \
+            self.weight_A.dtype in (X.dtype, torch.float32) and h0.dtype == X.dtype
+
+    def _node_gate_params(self):
+        out = {}
+        for name, sub, gfl in (('in', self.GRNN_node_in, self.GFL_node_in[0]), ('forget', self.GRNN_node_forget, self.GFL_node_forget[0])):
+            out[name] = (sub.weight_A, sub.weight_B, sub.bias, gfl.weight, gfl.bias)
+        return out
+
+    def _forward_fused_node(self, X, h0, last_only=False):
+        tg = self._fused_gates() if self.time_gating == True else None  # noqa: E712
+        return ops.fused_node_cell_forward(X, h0, self.weight_A, self.weight_B, self.bias, self.graph, self._node_gate_params(),
+                                           time_gates=tg, last_only=last_only)
 
     def _use_fused_x3(self, X, h0):
         """fp32 inference of the un-gated cell on the fp32-accurate fused kernels (three bf16 planes per operand): graphs that fit

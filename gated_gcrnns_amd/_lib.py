@@ -80,6 +80,10 @@ def _bind(lib):
         'gcrnn_fused_forward_bf16': (C.c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p,
                                                _c_p, _c_p,
                                                _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_p, C.c_int, _c_p, C.c_double, _c_p]),
+        'gcrnn_fused_filter_output_bf16': (C.c_int, [_c_p] * 11 + [_c_i64] * 7 + [_c_p]),
+        'gcrnn_fused_node_forward_bf16': (C.c_int, [_c_p] * 15 + [_c_i64] * 6 + [_c_p, C.c_int, _c_p]),
+        'gcrnn_node_gate_dot': (C.c_int, [_c_p, _c_p, _c_p, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_p]),
+        'gcrnn_node_gate_dot_backward': (C.c_int, [_c_p, _c_p, _c_p, _c_p, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_p]),
         'gcrnn_fused_x3_supported': (C.c_int, [_c_i64, _c_i64, _c_i64, _c_i64, _c_i64]),
         'gcrnn_pack_seq_major_x3': (C.c_int, [_c_p, _c_p, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_p]),
         'gcrnn_fused_pack_weights_x3': (C.c_int, [_c_p, _c_p, _c_p, _c_i64, _c_i64, _c_i64, _c_i64, _c_p]),

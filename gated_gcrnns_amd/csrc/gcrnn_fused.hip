@@ -319,6 +319,42 @@ extern "C" int gcrnn_fused_gate_grad_bf16(const void* zs, const void* xs, const 
 }
 
 
+// Filter output of every (t, b) item in one launch: out[t][b][n][:] = (W(S) z)[n][:] + bias, bf16 sequence-major -- the input
+// filter A(S)x_t + b of the node-gated cell for all steps at once (it does not depend on the recurrence; graphML.py:2402-2403).
+// Operand conventions of gcrnn_fused_gate_grad_bf16: xs == null (G = 0): zs [T][B][NP][F] is the operand (an input with G == F
+// packed like a state), wpack its taps as a state-only operand; xs != null: operand [0 | x_t], zs = ONE all-zero block [NP][F].
+extern "C" int gcrnn_fused_filter_output_bf16(const void* zs, const void* xs, const void* wpack, const float* bias, void* out,
+                                              const int32_t* tile_nodes, const int32_t* tile_off, const int32_t* ell_col,
+                                              const float* ell_val, const void* ell_val4, const void* ell_col4, int64_t entries,
+                                              int64_t B, int64_t T, int64_t N, int64_t F, int64_t G, int64_t K, void* stream) {
+  if (!zs || !wpack || !out || !tile_nodes || !tile_off || !ell_col || !ell_val) return GCRNN_ERR_NULL_POINTER;
+  if ((xs == nullptr) != (G == 0)) return GCRNN_ERR_BAD_SHAPE;
+  if (B <= 0 || T <= 0 || N <= 0 || N > NP || B * T > (1 << 24) || entries < 0 || entries % 4) return GCRNN_ERR_BAD_SHAPE;
+  const FusedGraphArgs ga{tile_nodes, tile_off, ell_col, ell_val, ell_val4, ell_col4, entries};
+  return fused_dispatch(5, xs, zs, out, wpack, bias, nullptr, nullptr, nullptr, nullptr, ga, B, T, N, F, G, K, as_stream(stream));
+}
+
+// Node-gated cell (graphML.py:2379-2407), T launches:  h_t = tanh(gi ni_t . Yx_t + gf nf_t . (B(S)h_{t-1} + b)).
+// h0s [B][NP][F], hs [T][B][NP][F] (out), yx [T][B][NP][F] = A(S)x_t + b from gcrnn_fused_filter_output_bf16 (all bf16 sequence-major);
+// ngates fp32 [T][2][B][N]: per-node input gates then forget gates of every step; gi / gf fp32 [T][B] scalar time gates or both NULL;
+// wpackB = the state taps packed as a state-only operand (gcrnn_fused_pack_weights with G = 0); yh_out (or NULL) [T][B][NP][F]
+// receives B(S)h_{t-1} + b (kept for the BPTT); Huser as in gcrnn_fused_forward_bf16.
+extern "C" int gcrnn_fused_node_forward_bf16(const void* h0s, void* hs, const void* yx, const float* ngates, const float* gi,
+                                             const float* gf, const void* wpackB, const float* bias, void* yh_out,
+                                             const int32_t* tile_nodes, const int32_t* tile_off, const int32_t* ell_col,
+                                             const float* ell_val, const void* ell_val4, const void* ell_col4, int64_t entries,
+                                             int64_t B, int64_t T, int64_t N, int64_t F, int64_t K, void* Huser, int huser_last_only,
+                                             void* stream) {
+  if (!h0s || !hs || !yx || !ngates || !wpackB || !tile_nodes || !tile_off || !ell_col || !ell_val) return GCRNN_ERR_NULL_POINTER;
+  if ((gi == nullptr) != (gf == nullptr)) return GCRNN_ERR_NULL_POINTER;
+  if (B <= 0 || T <= 0 || N <= 0 || N > NP || B > (1 << 24) || entries < 0 || entries % 4) return GCRNN_ERR_BAD_SHAPE;
+  if (B * (NP * F * 2) > 2147483647LL || T * F * N > 2147483647LL) return GCRNN_ERR_BAD_SHAPE;
+  if (Huser && (N % 8 != 0 || (reinterpret_cast<uintptr_t>(Huser) & 15))) return GCRNN_ERR_BAD_SHAPE;
+  const FusedGraphArgs ga{tile_nodes, tile_off, ell_col, ell_val, ell_val4, ell_col4, entries};
+  return fused_dispatch(6, nullptr, h0s, hs, wpackB, bias, gi, gf, ngates, nullptr, ga, B, T, N, F, 0, K, as_stream(stream), yx, nullptr,
+                        yh_out, Huser, nullptr, nullptr, huser_last_only);
+}
+
 // dpre[i] = dH[i] * (1 - h[i]^2) on bf16 arrays (the seed of the BPTT chain, t = T-1)
 __global__ void bwd_seed_kernel(const uint16_t* __restrict__ dH, const uint16_t* __restrict__ h, uint16_t* __restrict__ out, int64_t n) {
   const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 2;

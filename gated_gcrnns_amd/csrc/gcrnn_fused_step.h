@@ -245,7 +245,12 @@ __device__ __forceinline__ float fast_tanh(float x) {
 // padded with node ids >= N that have no edges); memory rows are in natural node order.
 // EPI: 0 = state epilogue (bias, tanh, bf16 store), 1 = time-gate pre-pass (dot-reduce; optionally also stores the
 // gate cell's state c = tanh(pre) for its BPTT), 2 = BPTT data-gradient step (optionally scaled by the forget gate),
-// 3 = gate-gradient pass: sum_{f,n} (filter output + b) * dpre of every item (the gradient w.r.t. a scalar time gate)
+// 3 = gate-gradient pass: sum_{f,n} (filter output + b) * dpre of every item (the gradient w.r.t. a scalar time gate),
+// 4 = filter-output pass: stores (filter output + b) of every item, bf16 sequence-major (the input filter A(S)x_t + b of the
+//     node-gated cell for all t at once: it does not depend on the recurrence),
+// 5 = node-gated step (graphML.py:2379-2407), state-only operand (XS = 0):
+//     h_t = tanh(gi ni_t[n] Yx_t[n][f] + gf nf_t[n] (B(S)h_{t-1} + b)[n][f]);  Yx_t from the EPI 4 pass (aux0), node gates [2][B][N]
+//     fp32 in gate_w (ni then nf), scalar time gates gi / gf [B] or null (= 1); optionally stores Yh = B(S)h_{t-1} + b (for BPTT)
 // UNI (RESIDENT only): uniform-weight graph image -- column words only, all non-zeros weigh uni_w (GCRNN_HOP_ASM_UNI_STREAM)
 template <int K, int HS, int XS, bool GATED, bool RESIDENT, int EPI = 0, int UNI = 0>
 __global__ __launch_bounds__(STHREADS) void fused_step_kernel(
@@ -342,7 +347,9 @@ __global__ __launch_bounds__(STHREADS) void fused_step_kernel(
   const __amdgpu_buffer_rsrc_t rsrc_h = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(hprev), 0, hmod * (NP * F * 2), 0x00020000);
   const __amdgpu_buffer_rsrc_t rsrc_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(xt), 0, B * (NP * G * 2), 0x00020000);
   const __amdgpu_buffer_rsrc_t rsrc_o = __builtin_amdgcn_make_buffer_rsrc(hout, 0, hout ? B * (NP * F * 2) : 0, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsrc_a0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(aux0), 0, ((EPI == 2 || EPI == 3) && aux0) ? B * (NP * F * 2) : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_a0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(aux0), 0, ((EPI == 2 || EPI == 3 || EPI == 5) && aux0) ? B * (NP * F * 2) : 0, 0x00020000);
+  // EPI 5 (XS = 0: no input operand): the xt argument carries the optional Yh output [B][NP][F] instead
+  const __amdgpu_buffer_rsrc_t rsrc_yh = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(xt), 0, (EPI == 5 && xt) ? B * (NP * F * 2) : 0, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsrc_a1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(aux1), 0, (EPI == 2 && aux1) ? B * (NP * F * 2) : 0, 0x00020000);
 
   // gate pre-pass with an all-zero initial state (every training loop of the reference starts from h0 = 0, train_rnn.py:256): the
@@ -354,6 +361,7 @@ __global__ __launch_bounds__(STHREADS) void fused_step_kernel(
   float gin = 1.f, gfo = 1.f;
   float gratio = 1.f;
   if (GATED) { gin = gi[b]; gfo = gf[b]; gratio = gfo / fmaxf(gin, 1e-30f); }
+  if (EPI == 5 && gi) { gin = gi[b]; gfo = gf[b]; }      // scalar time gates on top of the node gates (applied in the epilogue)
 
   // ---- phase 1: taps on the matrix cores ------------------------------------------------------
 #ifdef GCRNN_ABLATE_PHASE1      // profiling builds only (tools/ablate.sh): results are wrong by construction
@@ -553,6 +561,21 @@ __global__ __launch_bounds__(STHREADS) void fused_step_kernel(
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) part += __shfl_down(part, off, 64);
     if (lane == 0) gate_out[(int64_t)b * (NCH * SWAVES) + chunk * SWAVES + wave] = part;   // fixed-order sum by the caller
+  } else if (EPI == 4) {
+    // filter-output pass: the hops produced this item's chunk of A(S)x_t (or any one filter); + b, bf16, sequence-major
+#pragma unroll
+    for (int i = 0; i < STILES; ++i) {
+      int wv = woff[i];
+      asm volatile("" : "+v"(wv));
+      const int node = wv >> 16;
+      uint2 pk{0u, 0u};
+      if (node < N) {
+        const f32x4 acc = u[i][0];
+        pk.x = (uint32_t)f2bf(acc[0] + bvec[0]) | ((uint32_t)f2bf(acc[1] + bvec[1]) << 16);
+        pk.y = (uint32_t)f2bf(acc[2] + bvec[2]) | ((uint32_t)f2bf(acc[3] + bvec[3]) << 16);
+      }
+      __builtin_amdgcn_raw_buffer_store_b64(u32x2{pk.x, pk.y}, rsrc_o, node * (F * 2) + (chunk * FC + q * 4) * 2, b * (NP * F * 2), 0);
+    }
   } else if (GATEOUT) {
     // gate pre-pass: partial dot product of tanh(pre) with the gate's linear weights over this chunk, one partial per wave;
     // with hout the gate cell's state c = tanh(pre) is also stored (bf16, sequence-major) for the gate's BPTT
@@ -633,19 +656,35 @@ __global__ __launch_bounds__(STHREADS) void fused_step_kernel(
     const f32x4 acc = u[i][0];
     uint2 pk;
     if (node < N) {
-      const float o0 = fast_tanh(acc[0] + bsum[0]), o1 = fast_tanh(acc[1] + bsum[1]);
-      const float o2 = fast_tanh(acc[2] + bsum[2]), o3 = fast_tanh(acc[3] + bsum[3]);
+      float o0, o1, o2, o3;
+      if (EPI == 5) {
+        // node-gated cell: the x part comes from the all-steps pass, both parts are scaled per node (and per sequence)
+        const int eoff = node * (F * 2) + (chunk * FC + q * 4) * 2;
+        const u32x2 y2 = __builtin_amdgcn_raw_buffer_load_b64(rsrc_a0, eoff, b * (NP * F * 2), 0);
+        const float ni = gin * gate_w[(int64_t)b * N + node], nf = gfo * gate_w[(int64_t)(B + b) * N + node];
+        const float yh0 = acc[0] + bvec[0], yh1 = acc[1] + bvec[1], yh2 = acc[2] + bvec[2], yh3 = acc[3] + bvec[3];
+        if (xt) __builtin_amdgcn_raw_buffer_store_b64(u32x2{(uint32_t)f2bf(yh0) | ((uint32_t)f2bf(yh1) << 16), (uint32_t)f2bf(yh2) | ((uint32_t)f2bf(yh3) << 16)},
+                                                     rsrc_yh, eoff, b * (NP * F * 2), 0);
+        o0 = fast_tanh(ni * bf2f((uint16_t)(y2[0] & 0xffffu)) + nf * yh0);
+        o1 = fast_tanh(ni * bf2f((uint16_t)(y2[0] >> 16)) + nf * yh1);
+        o2 = fast_tanh(ni * bf2f((uint16_t)(y2[1] & 0xffffu)) + nf * yh2);
+        o3 = fast_tanh(ni * bf2f((uint16_t)(y2[1] >> 16)) + nf * yh3);
+      } else {
+        o0 = fast_tanh(acc[0] + bsum[0]); o1 = fast_tanh(acc[1] + bsum[1]);
+        o2 = fast_tanh(acc[2] + bsum[2]); o3 = fast_tanh(acc[3] + bsum[3]);
+      }
       pk.x = (uint32_t)f2bf(o0) | ((uint32_t)f2bf(o1) << 16);
       pk.y = (uint32_t)f2bf(o2) | ((uint32_t)f2bf(o3) << 16);
     } else {
       pk.x = 0u; pk.y = 0u;          // padded rows stay zero
+      if (EPI == 5 && xt) __builtin_amdgcn_raw_buffer_store_b64(u32x2{0u, 0u}, rsrc_yh, node * (F * 2) + (chunk * FC + q * 4) * 2, b * (NP * F * 2), 0);
     }
     // GCRNN_STORE_POLICY: an experiment with write-through stores (sc1: the line is not kept in the XCD's L2, whose 4 MiB the
     // [h | x] operands of the sequences in flight and the prefetched next ones need) -- slower than plain stores, see the define
     __builtin_amdgcn_raw_buffer_store_b64(u32x2{pk.x, pk.y}, rsrc_o, node * (F * 2) + (chunk * FC + q * 4) * 2, b * (NP * F * 2), GCRNN_STORE_POLICY);
     u[i][0] = f32x4{__uint_as_float(pk.x), __uint_as_float(pk.y), 0.f, 0.f};      // keep the packed bf16 for the user-layout copy
   }
-  if (EPI == 0 && aux1) {
+  if ((EPI == 0 || EPI == 5) && aux1) {
     // the state is also delivered in the USER layout H[b][t][f][:] (node-contiguous rows): transposed bf16 tile in LDS
     // (row stride 2080 B), then 16-byte coalesced row stores -- replaces a separate unpack pass over the whole sequence.
     constexpr int RS = 2 * NP + 32;
@@ -690,7 +729,7 @@ struct FusedGraphArgs {
 };
 
 template <int K, int HS, int XS>
-int fused_launch_t(int mode /*0 plain, 1 gated, 2 gate pre-pass, 3 BPTT data gradient, 4 gate-gradient pass*/, const void* xs,
+int fused_launch_t(int mode /*0 plain, 1 gated, 2 gate pre-pass, 3 BPTT data gradient, 4 gate-gradient pass, 5 filter-output pass, 6 node-gated steps*/, const void* xs,
                           const void* h0, void* hs, const void* wpack, const float* bias, const float* gi, const float* gf,
                           const float* gate_w, float* gate_out, const FusedGraphArgs& ga, int64_t B, int64_t T, int64_t N,
                           hipStream_t st, const void* bw_dHs = nullptr, const void* bw_hs = nullptr, const void* bw_h0 = nullptr,
@@ -705,7 +744,12 @@ int fused_launch_t(int mode /*0 plain, 1 gated, 2 gate pre-pass, 3 BPTT data gra
   const bool resident = resident_bytes <= 160 * 1024 && ga.ell_val4 && ga.ell_col4;
   const size_t lds = resident ? resident_bytes : base;
   fused_kern_t kern;
-  if (mode == 4)      kern = resident ? (fused_kern_t)fused_step_kernel<K, HS, XS, false, true, 3> : (fused_kern_t)fused_step_kernel<K, HS, XS, false, false, 3>;
+  if (mode == 6) {
+    if constexpr (XS == 0) kern = resident ? (fused_kern_t)fused_step_kernel<K, HS, XS, false, true, 5> : (fused_kern_t)fused_step_kernel<K, HS, XS, false, false, 5>;
+    else return GCRNN_ERR_UNSUPPORTED;
+  }
+  else if (mode == 5) kern = resident ? (fused_kern_t)fused_step_kernel<K, HS, XS, false, true, 4> : (fused_kern_t)fused_step_kernel<K, HS, XS, false, false, 4>;
+  else if (mode == 4) kern = resident ? (fused_kern_t)fused_step_kernel<K, HS, XS, false, true, 3> : (fused_kern_t)fused_step_kernel<K, HS, XS, false, false, 3>;
   else if (mode == 3) kern = resident ? (fused_kern_t)fused_step_kernel<K, HS, XS, false, true, 2> : (fused_kern_t)fused_step_kernel<K, HS, XS, false, false, 2>;
   else if (mode == 2) kern = resident ? (fused_kern_t)fused_step_kernel<K, HS, XS, false, true, 1> : (fused_kern_t)fused_step_kernel<K, HS, XS, false, false, 1>;
 #if GCRNN_HOP_ASM && GCRNN_STEP_WAVES == 8
@@ -728,7 +772,37 @@ int fused_launch_t(int mode /*0 plain, 1 gated, 2 gate pre-pass, 3 BPTT data gra
     return (unsigned)(slots * NCH);
   };
   GCRNN_PRE_LAUNCH();
-  if (mode == 2 || mode == 4) {
+  if (mode == 6) {
+    // node-gated recurrence: h = hs, Yx_t = bw_dHs [T][B][NP][F], node gates gate_w [T][2][B][N], optional Yh output bw_dh0 [T][B][NP][F]
+    const unsigned grid = grid_for(B);
+    const uint16_t* yx = (const uint16_t*)bw_dHs;
+    uint16_t* yh = (uint16_t*)bw_dh0;
+    for (int64_t t = 0; t < T; ++t) {
+      const uint16_t* hp = (t == 0) ? (const uint16_t*)h0 : h + (t - 1) * hstep;
+      kern<<<grid, STHREADS, lds, st>>>(yh ? yh + t * hstep : nullptr, hp, h + t * hstep, (const uint4*)wpack, bias, gi ? gi + t * B : nullptr,
+                                   gi ? gf + t * B : nullptr, ga.tile_nodes, ga.tile_off, ga.ell_col, ga.ell_val,
+                                   (const float4*)ga.ell_val4, (const uint2*)ga.ell_col4, gate_w + t * 2 * B * N, nullptr, yx + t * hstep,
+                                   !huser ? nullptr : (!huser_last_only ? (const uint16_t*)huser + t * F * N : (t == T - 1 ? (const uint16_t*)huser : nullptr)),
+                                   (int)((huser_last_only ? 1 : T) * F * N), (int)ga.entries, (int)B, (int)B, (int)N, nullptr, 0.f);
+    }
+  } else if (mode == 5) {
+    // filter output of every (t, b) item in one launch (split over whole time steps like mode 2 / 4): hs receives A(S)x_t + b
+    const int64_t row_bytes = (int64_t)NP * (F > G ? F : G) * 2;
+    int64_t tchunk = (2147483647LL / row_bytes) / B;
+    if (tchunk < 1) return GCRNN_ERR_BAD_SHAPE;
+    if (tchunk > T) tchunk = T;
+    for (int64_t t0 = 0; t0 < T; t0 += tchunk) {
+      const int64_t nt = (T - t0 < tchunk) ? T - t0 : tchunk, items = nt * B;
+      if (XS == 0)        // operand = one [T*B][NP][F] array (an input with G == F, packed like a state)
+        kern<<<grid_for(items), STHREADS, lds, st>>>(nullptr, (const uint16_t*)h0 + t0 * hstep, h + t0 * hstep, (const uint4*)wpack, bias, nullptr, nullptr,
+                                     ga.tile_nodes, ga.tile_off, ga.ell_col, ga.ell_val, (const float4*)ga.ell_val4, (const uint2*)ga.ell_col4,
+                                     nullptr, nullptr, nullptr, nullptr, 0, (int)ga.entries, (int)items, (int)items, (int)N, nullptr, 0.f);
+      else                // operand [0 | x_t]: ONE all-zero state block shared by every item (hmod = 1)
+        kern<<<grid_for(items), STHREADS, lds, st>>>(x + t0 * xstep, (const uint16_t*)h0, h + t0 * hstep, (const uint4*)wpack, bias, nullptr, nullptr,
+                                     ga.tile_nodes, ga.tile_off, ga.ell_col, ga.ell_val, (const float4*)ga.ell_val4, (const uint2*)ga.ell_col4,
+                                     nullptr, nullptr, nullptr, nullptr, 0, (int)ga.entries, (int)items, 1, (int)N, nullptr, 0.f);
+    }
+  } else if (mode == 2 || mode == 4) {
     // no recurrence: all (t, b) items in one launch -- split over whole time steps where the 32-bit buffer offsets of
     // one launch (items * NP * max(F, G) * 2 bytes) would overflow
     const int64_t row_bytes = (int64_t)NP * (F > G ? F : G) * 2;

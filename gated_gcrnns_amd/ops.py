@@ -544,6 +544,115 @@ def fused_cell_forward(X, h0, wA, wB, bias, graph, gates=None, return_states=Fal
     return H
 
 
+# ------------------------------------------------------------------------------------------ node-gated cell on the fused path
+def fused_filter_output(xs, w, bias, graph, K, N):
+    """(w(S) x_t + bias) for every (t, b) in one launch: [T][B][NPad][F] bf16 sequence-major (gcrnn_fused_filter_output_bf16).
+    xs [T][B][NPad][C] bf16; w F x 1 x k x C (k <= K taps); C == F runs the operand as a state, otherwise as [0 | x_t]."""
+    T, B, npad, Cin = xs.shape
+    F = w.shape[0]
+    plan = graph.fused_plan()
+    st = _stream()
+    b32 = bias.detach().float().contiguous().view(-1) if bias is not None else None
+    out = torch.empty((T, B, npad, F), dtype=torch.bfloat16, device=xs.device)
+    if Cin == F:
+        wp = _fused_pack_state_taps(w, K, st)
+        check(lib.gcrnn_fused_filter_output_bf16(_p(xs), None, _p(wp), _p(b32), _p(out), *_fused_graph_args(plan), B, T, N, F, 0, K, st),
+              'fused_filter_output')
+    else:
+        wd = w.detach()
+        if wd.shape[2] < K:
+            wd = torch.cat([wd, wd.new_zeros(F, 1, K - wd.shape[2], Cin)], dim=2)
+        wp = _fused_pack_weights(wd, wd.new_zeros((F, 1, K, F)), st)
+        zero_h = torch.zeros((1, npad, F), dtype=torch.bfloat16, device=xs.device)
+        check(lib.gcrnn_fused_filter_output_bf16(_p(zero_h), _p(xs), _p(wp), _p(b32), _p(out), *_fused_graph_args(plan), B, T, N, F, Cin, K, st),
+              'fused_filter_output')
+    return out
+
+
+def node_gate_logits(cs, wf, bf, graph, N):
+    """GraphFilter_{F -> 1} of the gate-cell states (graphML.py:2387), taps first: s_k = cs . w_k per node (one pass over cs), then
+    K-1 accumulate-SpMM hops on the ONE-channel signals in node-major layout [N][items]. cs [T][B][NPad][F] bf16, wf 1 x 1 x K x F,
+    bf 1 x 1 or None -> logits [T][B][N] fp32 (and the pieces the backward needs)."""
+    T, B, npad, F = cs.shape
+    K = wf.shape[2]
+    items = T * B
+    wk = wf.detach().float().reshape(K, F).contiguous()
+    s = torch.empty((items, K, 1, N), dtype=torch.float32, device=cs.device)
+    for i0 in range(0, items, 32768):            # gridDim.y limit of the dot kernel
+        n_i = min(32768, items - i0)
+        check(lib.gcrnn_node_gate_dot(_p(cs.view(items, npad, F)[i0:]), _p(wk), _p(s[i0:]), n_i, N, npad, F, K, _stream()), 'node_gate_dot')
+    sn = _pack_raw(s)                                                  # [K][N][items][1]
+    acc = sn[K - 1:K]
+    csr = graph.fwd[0]
+    for k in range(K - 2, -1, -1):
+        spmm_raw(csr, acc, out=sn[k:k + 1], accumulate=True)         # sn[k] += P acc  (Horner)
+        acc = sn[k:k + 1]
+    logit = _unpack_raw(acc).view(T, B, N)                             # [items][1][1][N]
+    if bf is not None:
+        logit = logit + bf.detach().float().view(())
+    return logit, wk
+
+
+def fused_node_supported(graph, N, F, G, Kin, Kst, dtype, E=1):
+    """Node-gated cell on the fused kernels: the fused shapes in bf16 plus a state-only instantiation for K = max(Kin, Kst)."""
+    return fused_supported(N, F, G, Kin, Kst, dtype, E) and max(Kin, Kst) in (2, 3, 4, 5) and not (max(Kin, Kst) == 4 and F == 32)
+
+
+def fused_node_cell_forward(X, h0, wA, wB, bias, graph, node_gates, time_gates=None, last_only=False, keep=False):
+    """Node-gated GGCRNNCell forward (optionally time-gated too) on the fused kernels (graphML.py:2379-2407, 2420-2423).
+    node_gates = {'in': (wA_g, wB_g, bias_g, wf, bf), 'forget': (...)}: the gate cell GRNN_node_* and its F -> 1 GraphFilter
+    GFL_node_*; time_gates as in fused_cell_forward. X B x T x G x N bf16, h0 B x F x N bf16 -> H B x T x F x N bf16.
+    Everything that does not depend on h_{t-1} -- both gate cells, their filters, A(S)x_t + b -- runs for all T steps at once.
+    keep: also return what the BPTT needs (no autograd graph is recorded here)."""
+    require_device(X, h0, wA, wB, bias)
+    X, wA = fused_pad_operands(X, wA.detach())
+    B, T, G, N = X.shape
+    F, Kin, Kst = wA.shape[0], wA.shape[2], wB.shape[2]
+    K = max(Kin, Kst)
+    plan = graph.fused_plan()
+    st = _stream()
+    xs, hs_all = fused_pack_inputs(X.contiguous(), h0.contiguous(), graph)
+    h0s, hs = hs_all[:1], hs_all[1:]
+    hzero = fused_h0_zero_flag(h0)
+    zero_lin = torch.zeros((1, F * N), dtype=torch.float32, device=X.device)
+    ng, saved = [], {}
+    for name in ('in', 'forget'):
+        wA_g, wB_g, bias_g, wf, bf = node_gates[name]
+        if wA_g.shape[3] != G:
+            wA_g = torch.nn.functional.pad(wA_g.detach(), (0, G - wA_g.shape[3]))
+        _, cs, _ = fused_time_gate(xs, h0s, wA_g, wB_g, bias_g, zero_lin, None, graph, N, store_states=True, hzero=hzero)
+        logit, wk = node_gate_logits(cs, wf, bf, graph, N)
+        gate = torch.sigmoid(logit)
+        ng.append(gate)
+        saved[name] = (cs, gate, wk)
+    ngates = torch.stack(ng, dim=1).contiguous()                        # [T][2][B][N]
+    gi = gf = None
+    if time_gates is not None:
+        g = {}
+        for name in ('in', 'forget'):
+            wA_g, wB_g, bias_g, lin_w, lin_b = time_gates[name]
+            if wA_g.shape[3] != G:
+                wA_g = torch.nn.functional.pad(wA_g.detach(), (0, G - wA_g.shape[3]))
+            g[name] = fused_time_gate(xs, h0s, wA_g, wB_g, bias_g, lin_w, lin_b, graph, N, hzero=hzero)
+        gi, gf = g['in'], g['forget']
+    yx = fused_filter_output(xs, wA, bias, graph, K, N)
+    wBk = wB.detach() if Kst == K else torch.cat([wB.detach(), wB.new_zeros(F, 1, K - Kst, F)], dim=2)
+    wpB = _fused_pack_state_taps(wBk, K, st)
+    b32 = bias.detach().float().contiguous().view(-1) if bias is not None else None
+    H = torch.empty((B, 1 if last_only else T, F, N), dtype=torch.bfloat16, device=X.device)
+    yh = torch.empty_like(yx) if keep else None
+    direct = (N % 8 == 0)
+    check(lib.gcrnn_fused_node_forward_bf16(_p(h0s), _p(hs), _p(yx), _p(ngates), _p(gi), _p(gf), _p(wpB), _p(b32), _p(yh),
+                                            *_fused_graph_args(plan), B, T, N, F, K, _p(H) if direct else None, int(last_only), st),
+          'fused_node_forward')
+    if not direct:
+        src = hs[T - 1:] if last_only else hs
+        check(lib.gcrnn_unpack_seq_major(_lib.BF16, _p(src), _p(H), B, 1 if last_only else T, F, N, plan['npad'], None, st), 'unpack_seq')
+    if keep:
+        return H, dict(xs=xs, hs_all=hs_all, yx=yx, yh=yh, ngates=ngates, gi=gi, gf=gf, gates=saved, hzero=hzero, X=X)
+    return H
+
+
 def fused_x3_supported(graph, N, F, G, Kin, Kst, dtype, E=1):
     """fp32-accurate fused inference (gcrnn_fused_forward_x3): fp32 tensors, un-gated cell, N <= 1024 with N % 4 == 0, the fused
     shapes, and a UNIFORM-weight graph (all non-zeros equal: the drivers' W / lambda_max) with >= 16 padding rows."""

@@ -134,6 +134,31 @@ int gcrnn_ell_size(const int32_t* rowptr, int64_t N, const int32_t* order, int t
 int gcrnn_ell_fill(const int32_t* rowptr, const int32_t* col, const double* val, int64_t N, const int32_t* order,
                    int tile, int pad, int64_t ntiles, const int32_t* node_addr, int32_t* tile_off, int32_t* ell_col,
                    float* ell_val);
+/* ==== node-gated cell on the fused path (Utils/graphML.py:2379-2407) ================================================================
+ *   h_t = tanh( gi ni_t[n] (A(S)x_t + b)[n][f] + gf nf_t[n] (B(S)h_{t-1} + b)[n][f] ),  ni / nf = sigmoid(GraphFilter_{F->1}(gate cell state))
+ * gcrnn_fused_filter_output_bf16: out[t][b] = W(S) z + bias for every (t, b) in one launch (the x part does not depend on the
+ *   recurrence); operand conventions of gcrnn_fused_gate_grad_bf16 (xs == NULL: zs is the operand and G = 0; else [0 | x_t]).
+ * gcrnn_fused_node_forward_bf16: the T recurrent launches on the state-only operand; yx from the call above, ngates fp32
+ *   [T][2][B][N] (input gates, forget gates), gi / gf fp32 [T][B] scalar time gates or both NULL, wpackB = state taps packed with
+ *   G = 0, yh_out (or NULL) [T][B][NPad][F] receives B(S)h_{t-1} + b for the BPTT, Huser as in gcrnn_fused_forward_bf16.
+ * gcrnn_node_gate_dot: s[item][k][n] = sum_f d[item][n][f] w[k][f] -- the F -> 1 node-gate filter taps-first (d = gate cell states
+ *   [items][NPad][F] bf16 from gcrnn_fused_gate_prepass_bf16, w [K][F] fp32 = the GraphFilter weight 1 x 1 x K x F, graphML.py:2303);
+ *   the K-1 hops then run on one-channel signals (gcrnn_spmm_ex on [N][items]). gcrnn_node_gate_dot_backward: ds [items][K][N] ->
+ *   d overwritten by the gate cell's pre-activation gradient (sum_k ds_k w_k)(1 - d^2), dw_part [items][K][F] partial sums. */
+int gcrnn_fused_filter_output_bf16(const void* zs, const void* xs, const void* wpack, const float* bias, void* out,
+                                   const int32_t* tile_nodes, const int32_t* tile_off, const int32_t* ell_col, const float* ell_val,
+                                   const void* ell_val4, const void* ell_col4, int64_t entries, int64_t B, int64_t T, int64_t N,
+                                   int64_t F, int64_t G, int64_t K, void* stream);
+int gcrnn_fused_node_forward_bf16(const void* h0s, void* hs, const void* yx, const float* ngates, const float* gi, const float* gf,
+                                  const void* wpackB, const float* bias, void* yh_out, const int32_t* tile_nodes,
+                                  const int32_t* tile_off, const int32_t* ell_col, const float* ell_val, const void* ell_val4,
+                                  const void* ell_col4, int64_t entries, int64_t B, int64_t T, int64_t N, int64_t F, int64_t K,
+                                  void* Huser, int huser_last_only, void* stream);
+int gcrnn_node_gate_dot(const void* d, const float* w, float* s, int64_t items, int64_t N, int64_t NPad, int64_t F, int64_t K,
+                        void* stream);
+int gcrnn_node_gate_dot_backward(void* d, const float* ds, const float* w, float* dw_part, int64_t items, int64_t N, int64_t NPad,
+                                 int64_t F, int64_t K, void* stream);
+
 /* ==== fp32-accurate fused path ("x3": three bf16 planes per fp32 operand, six partial products on the bf16 matrix cores) ========
  * The un-gated cell h_t = tanh(A(S)x_t + b + B(S)h_{t-1} + b) (Utils/graphML.py:2420-2423) to fp32 accuracy (the north_star's
  * 1e-5 mode) at fused-kernel speed: v = v1 + v2 + v3 with v1 = bf16(v), v2 = bf16(v - v1), v3 = bf16(v - v1 - v2) for state,
