@@ -309,8 +309,10 @@ class GGCRNNCell(nn.Module):
         assert F_in == self.G and N == self.N
         if self._use_fused_training(X, h0):
             Xp, wA = ops.fused_pad_operands(X, self.weight_A)          # G < 32 (the drivers' G = 1): zero-padded channels
-            return ops.fused_cell_train(Xp, h0, wA, self.weight_B, self.bias, self.graph,
-                                        self._fused_gates() if self.time_gating == True else None)  # noqa: E712
+            tgates = self._fused_gates() if self.time_gating == True else None  # noqa: E712
+            if self.spatial_gating == 'node':
+                return ops.fused_node_cell_train(Xp, h0, wA, self.weight_B, self.bias, self.graph, self._node_gate_params(pad=True), tgates)
+            return ops.fused_cell_train(Xp, h0, wA, self.weight_B, self.bias, self.graph, tgates)
         if self._use_fused(X, h0):
             return self._forward_fused(X, h0)
         if self._use_fused_node(X, h0):
@@ -538,10 +540,13 @@ class GGCRNNCell(nn.Module):
         return ops.fused_node_supported(self.graph, self.N, self.F, self.G, self.Kin, self.Kst, X.dtype, self.E) and \
             self.weight_A.dtype in (X.dtype, torch.float32) and h0.dtype == X.dtype
 
-    def _node_gate_params(self):
+    def _node_gate_params(self, pad=False):
+        """pad: the gate cells' input taps zero-padded to the kernels' channel count by a differentiable pad (training)."""
+        Gp = ops.fused_padded_inputs(self.F, self.G)
+        padf = (lambda w: w) if (not pad or Gp == self.G) else (lambda w: nn.functional.pad(w, (0, Gp - self.G)))
         out = {}
         for name, sub, gfl in (('in', self.GRNN_node_in, self.GFL_node_in[0]), ('forget', self.GRNN_node_forget, self.GFL_node_forget[0])):
-            out[name] = (sub.weight_A, sub.weight_B, sub.bias, gfl.weight, gfl.bias)
+            out[name] = (padf(sub.weight_A), sub.weight_B, sub.bias, gfl.weight, gfl.bias)
         return out
 
     def _forward_fused_node(self, X, h0, last_only=False):
@@ -570,7 +575,10 @@ class GGCRNNCell(nn.Module):
         if not (h0.requires_grad or any(p.requires_grad for p in self.parameters())):
             return False
         if self.spatial_gating is not None:
-            return False
+            if self.spatial_gating != 'node' or h0.requires_grad or self.bias is None or \
+                    self.GRNN_node_in.weight_A.dtype != self.weight_A.dtype or \
+                    not ops.fused_node_supported(self.graph, self.N, self.F, self.G, self.Kin, self.Kst, X.dtype, self.E):
+                return False
         if self.time_gating == True:  # noqa: E712   the fused gates give no gradient to h0; their sub-cells share the cell's shapes
             if h0.requires_grad or self.bias is None or self.GFL_in.weight_A.dtype != self.weight_A.dtype:
                 return False

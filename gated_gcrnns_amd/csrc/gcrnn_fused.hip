@@ -365,6 +365,46 @@ __global__ void bwd_seed_kernel(const uint16_t* __restrict__ dH, const uint16_t*
   *reinterpret_cast<uint32_t*>(out + i) = (uint32_t)f2bf(g0 * (1.f - h0 * h0)) | ((uint32_t)f2bf(g1 * (1.f - h1 * h1)) << 16);
 }
 
+// out[i][n][:] = in[i][n][:] * g[i][n]  (bf16 rows of F, fp32 per-node factors; rows >= N stay zero)
+__global__ void scale_rows_kernel(const uint16_t* __restrict__ in, const float* __restrict__ g, uint16_t* __restrict__ out, int64_t items,
+                                  int N, int NPad, int F) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;       // one thread = one feature pair of one row
+  const int fp = F / 2;
+  if (idx >= items * NPad * fp) return;
+  const int64_t row = idx / fp;
+  const int n = (int)(row % NPad);
+  const int64_t item = row / NPad;
+  uint32_t o = 0;
+  if (n < N) {
+    const uint32_t v = *reinterpret_cast<const uint32_t*>(in + idx * 2);
+    const float gn = g[item * N + n];
+    o = (uint32_t)f2bf(bf2f((uint16_t)(v & 0xffffu)) * gn) | ((uint32_t)f2bf(bf2f((uint16_t)(v >> 16)) * gn) << 16);
+  }
+  *reinterpret_cast<uint32_t*>(out + idx * 2) = o;
+}
+
+// BPTT data-gradient chain of the NODE-gated cell (graphML.py:2402-2407 under autograd): dpre_t = (dH_t + rec_t)(1 - h_t^2),
+// rec_{t-1} = sum_k S^k ((gf nf)_t . dpre_t B_k). dHs, hs, dpre (out), dyh (out: (gf nf) . dpre, the chain's operands):
+// [T][B][NPad][F] bf16 sequence-major; ngf fp32 [T][B][N] = gf_t[b] nf_t[b][n]; wpackT / graph arrays as in
+// gcrnn_fused_backward_data_bf16. T launches of the same step kernel.
+extern "C" int gcrnn_fused_node_backward_data_bf16(const void* dHs, const void* hs, void* dpre, void* dyh, const float* ngf,
+                                                   const void* wpackT, const int32_t* tile_nodes, const int32_t* tile_off,
+                                                   const int32_t* ell_col, const float* ell_val, const void* ell_val4,
+                                                   const void* ell_col4, int64_t entries, int64_t B, int64_t T, int64_t N, int64_t F,
+                                                   int64_t K, void* stream) {
+  if (!dHs || !hs || !dpre || !dyh || !ngf || !wpackT || !tile_nodes || !tile_off || !ell_col || !ell_val) return GCRNN_ERR_NULL_POINTER;
+  if (B <= 0 || T <= 0 || N <= 0 || N > NP || B > (1 << 24) || entries < 0 || entries % 4 || F % 2) return GCRNN_ERR_BAD_SHAPE;
+  const int64_t step = B * NP * F;
+  GCRNN_PRE_LAUNCH();
+  bwd_seed_kernel<<<(unsigned)cdiv(step / 2, 256), 256, 0, as_stream(stream)>>>(
+      (const uint16_t*)dHs + (T - 1) * step, (const uint16_t*)hs + (T - 1) * step, (uint16_t*)dpre + (T - 1) * step, step);
+  scale_rows_kernel<<<(unsigned)cdiv(step / 2, 256), 256, 0, as_stream(stream)>>>(
+      (const uint16_t*)dpre + (T - 1) * step, ngf + (T - 1) * B * N, (uint16_t*)dyh + (T - 1) * step, B, (int)N, NP, (int)F);
+  GCRNN_CHECK_LAUNCH();
+  const FusedGraphArgs ga{tile_nodes, tile_off, ell_col, ell_val, ell_val4, ell_col4, entries};
+  return fused_dispatch(7, dyh, nullptr, dpre, wpackT, nullptr, nullptr, nullptr, ngf, nullptr, ga, B, T, N, F, 0, K, as_stream(stream), dHs, hs);
+}
+
 extern "C" int gcrnn_fused_backward_data_bf16(const void* dHs, const void* hs, void* dpre, void* dh0, const void* wpackT,
                                               const int32_t* tile_nodes, const int32_t* tile_off, const int32_t* ell_col,
                                               const float* ell_val, const void* ell_val4, const void* ell_col4,

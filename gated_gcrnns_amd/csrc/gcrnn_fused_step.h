@@ -349,7 +349,8 @@ __global__ __launch_bounds__(STHREADS) void fused_step_kernel(
   const __amdgpu_buffer_rsrc_t rsrc_o = __builtin_amdgcn_make_buffer_rsrc(hout, 0, hout ? B * (NP * F * 2) : 0, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsrc_a0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(aux0), 0, ((EPI == 2 || EPI == 3 || EPI == 5) && aux0) ? B * (NP * F * 2) : 0, 0x00020000);
   // EPI 5 (XS = 0: no input operand): the xt argument carries the optional Yh output [B][NP][F] instead
-  const __amdgpu_buffer_rsrc_t rsrc_yh = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(xt), 0, (EPI == 5 && xt) ? B * (NP * F * 2) : 0, 0x00020000);
+  // EPI 2 on a state-only operand: xt is the optional second output of the node-gated BPTT (the next launch's operand)
+  const __amdgpu_buffer_rsrc_t rsrc_yh = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(xt), 0, ((EPI == 5 || (EPI == 2 && XS == 0)) && xt) ? B * (NP * F * 2) : 0, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsrc_a1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(aux1), 0, (EPI == 2 && aux1) ? B * (NP * F * 2) : 0, 0x00020000);
 
   // gate pre-pass with an all-zero initial state (every training loop of the reference starts from h0 = 0, train_rnn.py:256): the
@@ -641,6 +642,17 @@ __global__ __launch_bounds__(STHREADS) void fused_step_kernel(
         pk.x = 0u; pk.y = 0u;
       }
       __builtin_amdgcn_raw_buffer_store_b64(u32x2{pk.x, pk.y}, rsrc_o, eoff, b * (NP * F * 2), 0);     // dropped when hout is null
+      if (XS == 0 && xt) {
+        // node-gated cell: the operand of the NEXT launch of the chain is d(B(S)h + b) = (gf nf)[n] . dpre, scaled per node here
+        // (a per-node scale does not commute with the graph shifts, so it cannot wait for the epilogue of that launch)
+        uint2 pg{0u, 0u};
+        if (node < N) {
+          const float gn = gate_w[(int64_t)b * N + node];
+          pg.x = (uint32_t)f2bf(o[0] * gn) | ((uint32_t)f2bf(o[1] * gn) << 16);
+          pg.y = (uint32_t)f2bf(o[2] * gn) | ((uint32_t)f2bf(o[3] * gn) << 16);
+        }
+        __builtin_amdgcn_raw_buffer_store_b64(u32x2{pg.x, pg.y}, rsrc_yh, eoff, b * (NP * F * 2), 0);
+      }
     }
     if (gate_out) {
 #pragma unroll
@@ -729,7 +741,7 @@ struct FusedGraphArgs {
 };
 
 template <int K, int HS, int XS>
-int fused_launch_t(int mode /*0 plain, 1 gated, 2 gate pre-pass, 3 BPTT data gradient, 4 gate-gradient pass, 5 filter-output pass, 6 node-gated steps*/, const void* xs,
+int fused_launch_t(int mode /*0 plain, 1 gated, 2 gate pre-pass, 3 BPTT data gradient, 4 gate-gradient pass, 5 filter-output pass, 6 node-gated steps, 7 node-gated BPTT data chain*/, const void* xs,
                           const void* h0, void* hs, const void* wpack, const float* bias, const float* gi, const float* gf,
                           const float* gate_w, float* gate_out, const FusedGraphArgs& ga, int64_t B, int64_t T, int64_t N,
                           hipStream_t st, const void* bw_dHs = nullptr, const void* bw_hs = nullptr, const void* bw_h0 = nullptr,
@@ -750,7 +762,7 @@ int fused_launch_t(int mode /*0 plain, 1 gated, 2 gate pre-pass, 3 BPTT data gra
   }
   else if (mode == 5) kern = resident ? (fused_kern_t)fused_step_kernel<K, HS, XS, false, true, 4> : (fused_kern_t)fused_step_kernel<K, HS, XS, false, false, 4>;
   else if (mode == 4) kern = resident ? (fused_kern_t)fused_step_kernel<K, HS, XS, false, true, 3> : (fused_kern_t)fused_step_kernel<K, HS, XS, false, false, 3>;
-  else if (mode == 3) kern = resident ? (fused_kern_t)fused_step_kernel<K, HS, XS, false, true, 2> : (fused_kern_t)fused_step_kernel<K, HS, XS, false, false, 2>;
+  else if (mode == 3 || mode == 7) kern = resident ? (fused_kern_t)fused_step_kernel<K, HS, XS, false, true, 2> : (fused_kern_t)fused_step_kernel<K, HS, XS, false, false, 2>;
   else if (mode == 2) kern = resident ? (fused_kern_t)fused_step_kernel<K, HS, XS, false, true, 1> : (fused_kern_t)fused_step_kernel<K, HS, XS, false, false, 1>;
 #if GCRNN_HOP_ASM && GCRNN_STEP_WAVES == 8
   else if (mode == 1 && uni && resident) kern = (fused_kern_t)fused_step_kernel<K, HS, XS, true, true, 0, 1>;
@@ -772,7 +784,23 @@ int fused_launch_t(int mode /*0 plain, 1 gated, 2 gate pre-pass, 3 BPTT data gra
     return (unsigned)(slots * NCH);
   };
   GCRNN_PRE_LAUNCH();
-  if (mode == 6) {
+  if (mode == 7) {
+    // BPTT data chain of the node-gated cell: hs = dpre [T][B][NP][F] (slot T-1 seeded), xs = dyh [T][B][NP][F] = (gf nf) . dpre (slot
+    // T-1 seeded; every launch reads its operand from it and writes the next one), gate_w = gf nf [T][B][N] fp32
+    if constexpr (XS == 0) {
+      const unsigned grid = grid_for(B);
+      const uint16_t* dH = (const uint16_t*)bw_dHs;
+      const uint16_t* hst = (const uint16_t*)bw_hs;
+      uint16_t* dyh = (uint16_t*)const_cast<void*>(xs);
+      for (int64_t t = T - 1; t >= 1; --t)
+        kern<<<grid, STHREADS, lds, st>>>(dyh + (t - 1) * hstep, dyh + t * hstep, h + (t - 1) * hstep, (const uint4*)wpack, nullptr, nullptr,
+                                     nullptr, ga.tile_nodes, ga.tile_off, ga.ell_col, ga.ell_val, (const float4*)ga.ell_val4,
+                                     (const uint2*)ga.ell_col4, gate_w + (t - 1) * B * N, nullptr, dH + (t - 1) * hstep, hst + (t - 1) * hstep, 0,
+                                     (int)ga.entries, (int)B, (int)B, (int)N, nullptr, 0.f);
+    } else {
+      return GCRNN_ERR_UNSUPPORTED;
+    }
+  } else if (mode == 6) {
     // node-gated recurrence: h = hs, Yx_t = bw_dHs [T][B][NP][F], node gates gate_w [T][2][B][N], optional Yh output bw_dh0 [T][B][NP][F]
     const unsigned grid = grid_for(B);
     const uint16_t* yx = (const uint16_t*)bw_dHs;

@@ -89,7 +89,82 @@ __global__ __launch_bounds__(512) void node_gate_dot_bwd_kernel(uint16_t* __rest
   if (kf < K * F) dw_part[item * (K * F) + kf] = dacc;
 }
 
+// Gate gradients of the node-gated cell for all items at once (one workgroup per item, thread per node):
+//   a[n] = sum_f dpre[n][f] Yx[n][f],  c[n] = sum_f dpre[n][f] Yh[n][f]
+//   d ni[n] = gi a[n],  d nf[n] = gf c[n],  d gi += ni[n] a[n],  d gf += nf[n] c[n],  dYx[n][:] = gi ni[n] dpre[n][:]
+template <int F>
+__global__ __launch_bounds__(256) void node_cell_bwd_kernel(const uint16_t* __restrict__ dpre, const uint16_t* __restrict__ yx,
+                                                            const uint16_t* __restrict__ yh, const float* __restrict__ ngates,
+                                                            const float* __restrict__ gi, const float* __restrict__ gf,
+                                                            uint16_t* __restrict__ dyx, float* __restrict__ dni, float* __restrict__ dnf,
+                                                            float* __restrict__ dgi, float* __restrict__ dgf, int B, int N, int NPad) {
+  __shared__ float red[2][4];
+  const int64_t item = blockIdx.x;
+  const int t = (int)(item / B), b = (int)(item - (int64_t)t * B);
+  const float gin = gi ? gi[item] : 1.f, gfo = gf ? gf[item] : 1.f;
+  const float* ni = ngates + ((int64_t)(t * 2 + 0) * B + b) * N;
+  const float* nf = ngates + ((int64_t)(t * 2 + 1) * B + b) * N;
+  float pgi = 0.f, pgf = 0.f;
+  for (int n = threadIdx.x; n < NPad; n += 256) {
+    const int64_t ro = (item * NPad + n) * F;
+    if (n >= N) {                                   // padding rows of dYx stay zero
+#pragma unroll
+      for (int j = 0; j < F / 8; ++j) reinterpret_cast<uint4*>(dyx + ro)[j] = uint4{0u, 0u, 0u, 0u};
+      continue;
+    }
+    const float nin = ni[n], nfn = nf[n];
+    const float sc = gin * nin;
+    float a = 0.f, c = 0.f;
+#pragma unroll
+    for (int j = 0; j < F / 8; ++j) {
+      const uint4 dv = reinterpret_cast<const uint4*>(dpre + ro)[j];
+      const uint4 xv = reinterpret_cast<const uint4*>(yx + ro)[j];
+      const uint4 hv = reinterpret_cast<const uint4*>(yh + ro)[j];
+      const uint32_t dp[4] = {dv.x, dv.y, dv.z, dv.w}, xp[4] = {xv.x, xv.y, xv.z, xv.w}, hp[4] = {hv.x, hv.y, hv.z, hv.w};
+      uint32_t op[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float d0 = __uint_as_float(dp[e] << 16), d1 = __uint_as_float(dp[e] & 0xffff0000u);
+        a += d0 * __uint_as_float(xp[e] << 16) + d1 * __uint_as_float(xp[e] & 0xffff0000u);
+        c += d0 * __uint_as_float(hp[e] << 16) + d1 * __uint_as_float(hp[e] & 0xffff0000u);
+        op[e] = (uint32_t)f2bf_(sc * d0) | ((uint32_t)f2bf_(sc * d1) << 16);
+      }
+      reinterpret_cast<uint4*>(dyx + ro)[j] = uint4{op[0], op[1], op[2], op[3]};
+    }
+    dni[item * N + n] = gin * a;
+    dnf[item * N + n] = gfo * c;
+    pgi += nin * a;
+    pgf += nfn * c;
+  }
+  for (int o = 32; o > 0; o >>= 1) { pgi += __shfl_down(pgi, o, 64); pgf += __shfl_down(pgf, o, 64); }
+  if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = pgi; red[1][threadIdx.x >> 6] = pgf; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    if (dgi) dgi[item] = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+    if (dgf) dgf[item] = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+  }
+}
+
 }  // namespace
+
+// Gate gradients and the x-part pre-activation gradient of the node-gated cell (graphML.py:2402-2405 under autograd), all T*B items:
+// dpre / yx / yh / dyx [T*B][NPad][F] bf16 (yx = A(S)x_t + b, yh = B(S)h_{t-1} + b from the forward; dyx out = gi ni . dpre), ngates
+// fp32 [T][2][B][N], gi / gf fp32 [T*B] or NULL (= 1); out: dni, dnf fp32 [T*B][N]; dgi, dgf fp32 [T*B] (may be NULL).
+extern "C" int gcrnn_node_cell_backward(const void* dpre, const void* yx, const void* yh, const float* ngates, const float* gi,
+                                        const float* gf, void* dyx, float* dni, float* dnf, float* dgi, float* dgf, int64_t B, int64_t T,
+                                        int64_t N, int64_t NPad, int64_t F, void* stream) {
+  if (!dpre || !yx || !yh || !ngates || !dyx || !dni || !dnf) return GCRNN_ERR_NULL_POINTER;
+  if (B <= 0 || T <= 0 || B * T > 2147483647LL || N <= 0 || NPad < N || (F != 32 && F != 64)) return GCRNN_ERR_BAD_SHAPE;
+  GCRNN_PRE_LAUNCH();
+  if (F == 64)
+    node_cell_bwd_kernel<64><<<(unsigned)(B * T), 256, 0, as_stream(stream)>>>((const uint16_t*)dpre, (const uint16_t*)yx, (const uint16_t*)yh, ngates,
+                                                                             gi, gf, (uint16_t*)dyx, dni, dnf, dgi, dgf, (int)B, (int)N, (int)NPad);
+  else
+    node_cell_bwd_kernel<32><<<(unsigned)(B * T), 256, 0, as_stream(stream)>>>((const uint16_t*)dpre, (const uint16_t*)yx, (const uint16_t*)yh, ngates,
+                                                                             gi, gf, (uint16_t*)dyx, dni, dnf, dgi, dgf, (int)B, (int)N, (int)NPad);
+  GCRNN_CHECK_LAUNCH();
+  return GCRNN_OK;
+}
 
 // s[item][k][n] (fp32) = sum_f d[item][n][f] w[k][f]:  d [items][NPad][F] bf16 sequence-major gate-cell states, w [K][F] fp32 (the
 // reference's GraphFilter weight 1 x 1 x K x F, graphML.py:2303), K <= 8, F in {32, 64}.

@@ -653,6 +653,145 @@ def fused_node_cell_forward(X, h0, wA, wB, bias, graph, node_gates, time_gates=N
     return H
 
 
+class _FusedNodeGate(torch.autograd.Function):
+    """One node gate of the fused path with its BPTT (graphML.py:2379-2399): gate[t][b][n] = sigmoid(GraphFilter_{F->1}(c_t))[n],
+    c_t = tanh(A_g(S)x_t + B_g(S)h0 + 2 b_g) the state of the gate cell GRNN_node_*.
+    forward  = the gate pre-pass over all (t, b) storing c, the taps-first F -> 1 filter (node_gate_logits), sigmoid;
+    backward = adjoint Horner of the one-channel hops, one pass over c (filter-weight gradient + the gate cell's pre-activation
+               gradient in place), then the weight-gradient kernel with h0 as every item's state operand. No gradient for X / h0."""
+
+    @staticmethod
+    def forward(ctx, xs, h0s, X, h0, wA_g, wB_g, bias_g, wf, bf, graph, hzero):
+        N, F = X.shape[3], wA_g.shape[0]
+        zero_lin = torch.zeros((1, F * N), dtype=torch.float32, device=X.device)
+        _, cs, _ = fused_time_gate(xs, h0s, wA_g, wB_g, bias_g, zero_lin, None, graph, N, store_states=True, hzero=hzero)
+        logit, wk = node_gate_logits(cs, wf, bf, graph, N)
+        gate = torch.sigmoid(logit)
+        ctx.save_for_backward(X, h0, wA_g, wB_g, bias_g, wf, bf, gate, cs, wk, hzero)
+        ctx.graph = graph
+        return gate
+
+    @staticmethod
+    def backward(ctx, dgate):
+        X, h0, wA_g, wB_g, bias_g, wf, bf, gate, cs, wk, hzero = ctx.saved_tensors
+        if getattr(ctx, 'consumed', False):
+            raise GcrnnError('the fused node gate was already back-propagated (its saved states are turned into gradients in place)')
+        ctx.consumed = True
+        if ctx.needs_input_grad[2] or ctx.needs_input_grad[3]:
+            raise GcrnnError('the fused node gate does not produce gradients w.r.t. X or h0')
+        graph = ctx.graph
+        B, T, G, N = X.shape
+        F, Kin, Kst = wA_g.shape[0], wA_g.shape[2], wB_g.shape[2]
+        Kc = max(Kin, Kst)
+        K = wf.shape[2]
+        npad = cs.shape[2]
+        items = T * B
+        dlogit = (dgate.float() * gate * (1.0 - gate)).contiguous()                     # through the sigmoid: [T][B][N]
+        # logit = sum_k P^k s_k + b  =>  d s_k = (P^T)^k dlogit: K-1 one-channel hops with the adjoint graph (CSR(S))
+        dn = torch.empty((K, N, items, 1), dtype=torch.float32, device=X.device)
+        dn[0:1] = _pack_raw(dlogit.view(items, 1, 1, N))
+        for k in range(1, K):
+            spmm_raw(graph.adj[0], dn[k - 1:k], out=dn[k:k + 1])
+        ds = _unpack_raw(dn)                                                              # [items][K][1][N]
+        dw_part = torch.empty((items, K, F), dtype=torch.float32, device=X.device)
+        check(lib.gcrnn_node_gate_dot_backward(_p(cs), _p(ds), _p(wk), _p(dw_part), items, N, npad, F, K, _stream()), 'node_gate_dot_backward')
+        gwf = dw_part.sum(dim=0).view(1, 1, K, F).to(wf.dtype) if ctx.needs_input_grad[7] else None
+        gbf = dlogit.sum().view_as(bf).to(bf.dtype) if (bf is not None and ctx.needs_input_grad[8]) else None
+        # cs now holds the gate cell's pre-activation gradient
+        dW, dbs = fused_backward_weight(cs, X, None, h0, graph, F, G, Kc, want_bias=True, h_is_h0=True, hzero=hzero)
+        gA = dW[:, :Kin, F:].unsqueeze(1).to(wA_g.dtype) if ctx.needs_input_grad[4] else None
+        gB = dW[:, :Kst, :F].unsqueeze(1).to(wB_g.dtype) if ctx.needs_input_grad[5] else None
+        gb = dbs.view_as(bias_g).to(bias_g.dtype) if (bias_g is not None and ctx.needs_input_grad[6]) else None
+        return None, None, None, None, gA, gB, gb, gwf, gbf, None, None
+
+
+class _FusedNodeCell(torch.autograd.Function):
+    """Node-gated GGCRNNCell (optionally time-gated too) on the fused kernels with its BPTT; the gates enter as differentiable
+    inputs ni, nf [T][B][N] (and gi, gf [T][B] or None). backward = data chain with the per-node forget gates folded into every
+    launch's operand -> one all-items pass for the gate gradients and the x filter's pre-activation gradient -> two weight-gradient
+    launches (input filter on gi ni . dpre, state filter on gf nf . dpre). No gradient for X or h0."""
+
+    @staticmethod
+    def forward(ctx, X, h0, wA, wB, bias, ni, nf, gi, gf, graph, xs, hs_all):
+        B, T, G, N = X.shape
+        F, Kin, Kst = wA.shape[0], wA.shape[2], wB.shape[2]
+        K = max(Kin, Kst)
+        plan = graph.fused_plan()
+        st = _stream()
+        h0s, hs = hs_all[:1], hs_all[1:]
+        yx = fused_filter_output(xs, wA, bias, graph, K, N)
+        ngates = torch.stack([ni.detach().float(), nf.detach().float()], dim=1).contiguous()
+        gic = gi.detach().float().contiguous() if gi is not None else None
+        gfc = gf.detach().float().contiguous() if gf is not None else None
+        wBk = wB.detach() if Kst == K else torch.cat([wB.detach(), wB.new_zeros(F, 1, K - Kst, F)], dim=2)
+        wpB = _fused_pack_state_taps(wBk, K, st)
+        b32 = bias.detach().float().contiguous().view(-1) if bias is not None else None
+        H = torch.empty((B, T, F, N), dtype=torch.bfloat16, device=X.device)
+        yh = torch.empty_like(yx)
+        check(lib.gcrnn_fused_node_forward_bf16(_p(h0s), _p(hs), _p(yx), _p(ngates), _p(gic), _p(gfc), _p(wpB), _p(b32), _p(yh),
+                                                *_fused_graph_args(plan), B, T, N, F, K, _p(H), 0, st), 'fused_node_forward')
+        ctx.save_for_backward(X, h0, wA, wB, bias, H, hs_all, yx, yh, ngates, gic, gfc)
+        ctx.graph, ctx.npad = graph, plan['npad']
+        return H
+
+    @staticmethod
+    def backward(ctx, dH):
+        X, h0, wA, wB, bias, H, hs_all, yx, yh, ngates, gi, gf = ctx.saved_tensors
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
+            raise GcrnnError('the fused node-gated BPTT does not produce gradients w.r.t. X or h0')
+        graph, npad = ctx.graph, ctx.npad
+        B, T, G, N = X.shape
+        F, Kin, Kst = wA.shape[0], wA.shape[2], wB.shape[2]
+        K = max(Kin, Kst)
+        st = _stream()
+        hs = hs_all[1:]
+        dH = dH.to(torch.bfloat16).contiguous()
+        dHs = torch.empty((T, B, npad, F), dtype=torch.bfloat16, device=X.device)
+        check(lib.gcrnn_pack_seq_major(_lib.BF16, _p(dH), _p(dHs), B, T, F, N, npad, None, st), 'pack_seq')
+        ngf = (ngates[:, 1] * gf.unsqueeze(2)).contiguous() if gf is not None else ngates[:, 1].contiguous()       # [T][B][N]
+        wBk = wB.detach() if Kst == K else torch.cat([wB.detach(), wB.new_zeros(F, 1, K - Kst, F)], dim=2)
+        wBt = wBk[:, 0].permute(2, 1, 0).contiguous().unsqueeze(1)                      # transposed taps [F_in][1][K][F_out]
+        wpT = _fused_pack_state_taps(wBt, K, st)
+        aplan = graph.fused_plan(adjoint=True)
+        dpre = torch.empty((T, B, npad, F), dtype=torch.bfloat16, device=X.device)
+        dyh = torch.empty_like(dpre)
+        check(lib.gcrnn_fused_node_backward_data_bf16(_p(dHs), _p(hs), _p(dpre), _p(dyh), _p(ngf), _p(wpT), *_fused_graph_args(aplan),
+                                                      B, T, N, F, K, st), 'fused_node_backward_data')
+        dyx = torch.empty_like(dpre)
+        dni = torch.empty((T, B, N), dtype=torch.float32, device=X.device)
+        dnf = torch.empty_like(dni)
+        dgi = torch.empty((T, B), dtype=torch.float32, device=X.device) if gi is not None else None
+        dgf = torch.empty((T, B), dtype=torch.float32, device=X.device) if gf is not None else None
+        check(lib.gcrnn_node_cell_backward(_p(dpre), _p(yx), _p(yh), _p(ngates), _p(gi), _p(gf), _p(dyx), _p(dni), _p(dnf), _p(dgi), _p(dgf),
+                                           B, T, N, npad, F, st), 'node_cell_backward')
+        one = torch.ones((T, B), dtype=torch.float32, device=X.device)
+        zero = torch.zeros_like(one)
+        dWx, dbx = fused_backward_weight(dyx, X, H, h0, graph, F, G, K, want_bias=True, gi=one, gf=zero)      # input-filter columns
+        dWh, dbh = fused_backward_weight(dyh, X, H, h0, graph, F, G, K, want_bias=True, gi=zero, gf=one)      # state-filter columns
+        gA = dWx[:, :Kin, F:].unsqueeze(1).to(wA.dtype) if ctx.needs_input_grad[2] else None
+        gB = dWh[:, :Kst, :F].unsqueeze(1).to(wB.dtype) if ctx.needs_input_grad[3] else None
+        gb = (dbx + dbh).view_as(bias).to(bias.dtype) if (bias is not None and ctx.needs_input_grad[4]) else None
+        return (None, None, gA, gB, gb, dni if ctx.needs_input_grad[5] else None, dnf if ctx.needs_input_grad[6] else None,
+                dgi if (gi is not None and ctx.needs_input_grad[7]) else None, dgf if (gf is not None and ctx.needs_input_grad[8]) else None,
+                None, None, None)
+
+
+def fused_node_cell_train(X, h0, wA, wB, bias, graph, node_gates, time_gates=None):
+    """Training forward of the node-gated (optionally time + node gated) cell on the fused kernels: every gate sub-network is an
+    autograd node of its own (_FusedNodeGate / _FusedTimeGate) and enters the cell (_FusedNodeCell) as a differentiable input."""
+    require_device(X, h0, wA, wB, bias)
+    with torch.no_grad():
+        xs, hs_all = fused_pack_inputs(X, h0, graph)
+        hzero = fused_h0_zero_flag(h0)
+    ni = _FusedNodeGate.apply(xs, hs_all[:1], X, h0, *node_gates['in'], graph, hzero)
+    nf = _FusedNodeGate.apply(xs, hs_all[:1], X, h0, *node_gates['forget'], graph, hzero)
+    gi = gf = None
+    if time_gates is not None:
+        gi = _FusedTimeGate.apply(xs, hs_all[:1], X, h0, *time_gates['in'], graph, hzero)
+        gf = _FusedTimeGate.apply(xs, hs_all[:1], X, h0, *time_gates['forget'], graph, hzero)
+    return _FusedNodeCell.apply(X, h0, wA, wB, bias, ni, nf, gi, gf, graph, xs, hs_all)
+
+
 def fused_x3_supported(graph, N, F, G, Kin, Kst, dtype, E=1):
     """fp32-accurate fused inference (gcrnn_fused_forward_x3): fp32 tensors, un-gated cell, N <= 1024 with N % 4 == 0, the fused
     shapes, and a UNIFORM-weight graph (all non-zeros equal: the drivers' W / lambda_max) with >= 16 padding rows."""

@@ -154,6 +154,19 @@ int gcrnn_fused_node_forward_bf16(const void* h0s, void* hs, const void* yx, con
                                   const int32_t* tile_off, const int32_t* ell_col, const float* ell_val, const void* ell_val4,
                                   const void* ell_col4, int64_t entries, int64_t B, int64_t T, int64_t N, int64_t F, int64_t K,
                                   void* Huser, int huser_last_only, void* stream);
+/* BPTT of the node-gated cell. gcrnn_fused_node_backward_data_bf16: the data-gradient chain dpre_t = (dH_t + rec_t)(1 - h_t^2),
+ * rec_{t-1} = sum_k S^k ((gf nf)_t . dpre_t B_k): dHs, hs, dpre (out), dyh (out = (gf nf) . dpre) [T][B][NPad][F] bf16; ngf fp32
+ * [T][B][N] = gf_t[b] nf_t[b][n]; wpackT and the graph arrays as in gcrnn_fused_backward_data_bf16 (ELL of CSR(S)).
+ * gcrnn_node_cell_backward: all items at once -- d ni = gi <dpre, Yx>_f, d nf = gf <dpre, Yh>_f per node, d gi / d gf per item,
+ * dyx = gi ni . dpre (the x filter's pre-activation gradient). The weight gradients then come from
+ * gcrnn_fused_backward_weight_bf16 on dyx (input filter) and dyh (state filter). */
+int gcrnn_fused_node_backward_data_bf16(const void* dHs, const void* hs, void* dpre, void* dyh, const float* ngf, const void* wpackT,
+                                        const int32_t* tile_nodes, const int32_t* tile_off, const int32_t* ell_col,
+                                        const float* ell_val, const void* ell_val4, const void* ell_col4, int64_t entries, int64_t B,
+                                        int64_t T, int64_t N, int64_t F, int64_t K, void* stream);
+int gcrnn_node_cell_backward(const void* dpre, const void* yx, const void* yh, const float* ngates, const float* gi, const float* gf,
+                             void* dyx, float* dni, float* dnf, float* dgi, float* dgf, int64_t B, int64_t T, int64_t N,
+                             int64_t NPad, int64_t F, void* stream);
 int gcrnn_node_gate_dot(const void* d, const float* w, float* s, int64_t items, int64_t N, int64_t NPad, int64_t F, int64_t K,
                         void* stream);
 int gcrnn_node_gate_dot_backward(void* d, const float* ds, const float* w, float* dw_part, int64_t items, int64_t N, int64_t NPad,

@@ -854,3 +854,57 @@ def test_fused_node_gated_forward_matches_oracle(N, F, G, K, tg):
     err = np.abs(H.double().cpu().numpy() - ref)
     # bf16 states, the x part A(S)x_t + b stored in bf16 between its pass and the recurrence: same tolerance class as the fused cell
     assert err.max() <= 4e-2 and err.mean() <= 3e-3, (err.max(), err.mean())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('N,F,G,K,B,T,tg', [(1000, 64, 64, 5, 4, 4, False), (200, 32, 32, 3, 6, 3, True), (600, 64, 1, 3, 3, 3, False),
+                                            (1000, 64, 64, 2, 2, 2, True)])
+def test_fused_node_gated_training_matches_composed_autograd(N, F, G, K, B, T, tg):
+    """Node-gated (and time + node gated) cell, bf16 activations over fp32 master weights: forward, both node-gate sub-networks
+    (gate cell + F -> 1 graph filter), the time gates and the whole BPTT on the fused kernels reproduce the fp32 autograd gradients
+    of the composed path for EVERY trained parameter (reference graphML.py:2379-2407, 2420-2423). h0 != 0."""
+    import gated_gcrnns_amd.Utils.graphML as gml
+    dev = torch.device('cuda:0')
+    S = random_graph(N, min(0.5, 10.0 / N), 53)
+    rng = np.random.default_rng(14)
+    X = bf16_round(rng.standard_normal((B, T, G, N)))
+    h0 = bf16_round(0.4 * rng.standard_normal((B, F, N)))
+    dH = bf16_round(rng.standard_normal((B, T, F, N)))
+    torch.manual_seed(19)
+    cell = gml.GGCRNNCell(G, F, K, K, torch.tanh, tg, 'node', 1, True)
+    cell.addGSO(torch.tensor(S))
+    cell = cell.to(torch.bfloat16).to(torch.float32)
+    ref = gml.GGCRNNCell(G, F, K, K, torch.tanh, tg, 'node', 1, True)
+    ref.addGSO(torch.tensor(S))
+    ref.load_state_dict(cell.state_dict())
+    cell, ref = cell.to(dev), ref.to(dev)
+    Hr = ref(torch.tensor(X, dtype=torch.float32, device=dev), torch.tensor(h0, dtype=torch.float32, device=dev))
+    dHd = torch.tensor(dH, dtype=torch.float32, device=dev)
+    (Hr * dHd).sum().backward()
+    Xd = torch.tensor(X, dtype=torch.bfloat16, device=dev)
+    hd = torch.tensor(h0, dtype=torch.bfloat16, device=dev)
+    assert cell._use_fused_training(Xd, hd)
+    H = cell(Xd, hd)
+    assert H.dtype == torch.bfloat16 and H.requires_grad
+    err = (H.detach().float() - Hr.detach()).abs()
+    assert float(err.max()) <= 4e-2 and float(err.mean()) <= 3e-3, (float(err.max()), float(err.mean()))
+    (H.float() * dHd).sum().backward()
+    got = dict(cell.named_parameters())
+    checked = 0
+    for n, p in ref.named_parameters():
+        if p.grad is None:
+            assert got[n].grad is None or float(got[n].grad.abs().max()) == 0.0, n
+            continue
+        assert got[n].grad is not None, n
+        g, gr = got[n].grad.float().cpu().numpy(), p.grad.cpu().numpy()
+        sc = np.abs(gr).max()
+        if gr.size == 1 and n.endswith('.bias'):
+            # a scalar bias gradient is a signed sum over every (t, b, n) and may cancel to far below its terms: measure it on the
+            # scale of its sibling weight's gradient (the same terms times values of magnitude <= 1)
+            sib = dict(ref.named_parameters()).get(n[:-5] + '.weight')
+            if sib is not None and sib.grad is not None:
+                sc = max(sc, float(sib.grad.abs().max()))
+        e = np.abs(g - gr)
+        assert sc > 0 and e.max() <= 5e-2 * sc and (e.size < 16 or e.mean() <= 1e-2 * sc), (n, e.max() / sc, e.mean() / sc)
+        checked += 1
+    assert checked >= 11 + (6 if tg else 0)          # cell 3 + two gate cells 6 + two F -> 1 filters 4 (+ time gates)
