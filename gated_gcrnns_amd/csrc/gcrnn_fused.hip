@@ -293,10 +293,10 @@ extern "C" int gcrnn_fused_gate_prepass_bf16(const void* xs, const void* h0, con
                                              const int32_t* tile_off, const int32_t* ell_col, const float* ell_val,
                                              const void* ell_val4, const void* ell_col4, int64_t entries, int64_t B,
                                              int64_t T, int64_t N, int64_t F, int64_t G, int64_t K, const int32_t* h0_zero_flag,
-                                             void* stream) {
+                                             double uniform_w, void* stream) {
   if (!xs || !h0 || !wpack || !gate_w || !gate_out || !tile_nodes || !tile_off || !ell_col || !ell_val) return GCRNN_ERR_NULL_POINTER;
   if (B <= 0 || T <= 0 || N <= 0 || N > NP || B * T > (1 << 24) || entries < 0 || entries % 4) return GCRNN_ERR_BAD_SHAPE;
-  const FusedGraphArgs ga{tile_nodes, tile_off, ell_col, ell_val, ell_val4, ell_col4, entries};
+  const FusedGraphArgs ga{tile_nodes, tile_off, ell_col, ell_val, ell_val4, ell_col4, entries, (float)uniform_w};
   return fused_dispatch(2, xs, h0, cs, wpack, bias, nullptr, nullptr, gate_w, gate_out, ga, B, T, N, F, G, K, as_stream(stream),
                         nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, h0_zero_flag);
 }
@@ -326,11 +326,11 @@ extern "C" int gcrnn_fused_gate_grad_bf16(const void* zs, const void* xs, const 
 extern "C" int gcrnn_fused_filter_output_bf16(const void* zs, const void* xs, const void* wpack, const float* bias, void* out,
                                               const int32_t* tile_nodes, const int32_t* tile_off, const int32_t* ell_col,
                                               const float* ell_val, const void* ell_val4, const void* ell_col4, int64_t entries,
-                                              int64_t B, int64_t T, int64_t N, int64_t F, int64_t G, int64_t K, void* stream) {
+                                              int64_t B, int64_t T, int64_t N, int64_t F, int64_t G, int64_t K, double uniform_w, void* stream) {
   if (!zs || !wpack || !out || !tile_nodes || !tile_off || !ell_col || !ell_val) return GCRNN_ERR_NULL_POINTER;
   if ((xs == nullptr) != (G == 0)) return GCRNN_ERR_BAD_SHAPE;
   if (B <= 0 || T <= 0 || N <= 0 || N > NP || B * T > (1 << 24) || entries < 0 || entries % 4) return GCRNN_ERR_BAD_SHAPE;
-  const FusedGraphArgs ga{tile_nodes, tile_off, ell_col, ell_val, ell_val4, ell_col4, entries};
+  const FusedGraphArgs ga{tile_nodes, tile_off, ell_col, ell_val, ell_val4, ell_col4, entries, (float)uniform_w};
   return fused_dispatch(5, xs, zs, out, wpack, bias, nullptr, nullptr, nullptr, nullptr, ga, B, T, N, F, G, K, as_stream(stream));
 }
 
@@ -344,13 +344,13 @@ extern "C" int gcrnn_fused_node_forward_bf16(const void* h0s, void* hs, const vo
                                              const int32_t* tile_nodes, const int32_t* tile_off, const int32_t* ell_col,
                                              const float* ell_val, const void* ell_val4, const void* ell_col4, int64_t entries,
                                              int64_t B, int64_t T, int64_t N, int64_t F, int64_t K, void* Huser, int huser_last_only,
-                                             void* stream) {
+                                             double uniform_w, void* stream) {
   if (!h0s || !hs || !yx || !ngates || !wpackB || !tile_nodes || !tile_off || !ell_col || !ell_val) return GCRNN_ERR_NULL_POINTER;
   if ((gi == nullptr) != (gf == nullptr)) return GCRNN_ERR_NULL_POINTER;
   if (B <= 0 || T <= 0 || N <= 0 || N > NP || B > (1 << 24) || entries < 0 || entries % 4) return GCRNN_ERR_BAD_SHAPE;
   if (B * (NP * F * 2) > 2147483647LL || T * F * N > 2147483647LL) return GCRNN_ERR_BAD_SHAPE;
   if (Huser && (N % 8 != 0 || (reinterpret_cast<uintptr_t>(Huser) & 15))) return GCRNN_ERR_BAD_SHAPE;
-  const FusedGraphArgs ga{tile_nodes, tile_off, ell_col, ell_val, ell_val4, ell_col4, entries};
+  const FusedGraphArgs ga{tile_nodes, tile_off, ell_col, ell_val, ell_val4, ell_col4, entries, (float)uniform_w};
   return fused_dispatch(6, nullptr, h0s, hs, wpackB, bias, gi, gf, ngates, nullptr, ga, B, T, N, F, 0, K, as_stream(stream), yx, nullptr,
                         yh_out, Huser, nullptr, nullptr, huser_last_only);
 }
@@ -391,7 +391,7 @@ extern "C" int gcrnn_fused_node_backward_data_bf16(const void* dHs, const void* 
                                                    const void* wpackT, const int32_t* tile_nodes, const int32_t* tile_off,
                                                    const int32_t* ell_col, const float* ell_val, const void* ell_val4,
                                                    const void* ell_col4, int64_t entries, int64_t B, int64_t T, int64_t N, int64_t F,
-                                                   int64_t K, void* stream) {
+                                                   int64_t K, double uniform_w, void* stream) {
   if (!dHs || !hs || !dpre || !dyh || !ngf || !wpackT || !tile_nodes || !tile_off || !ell_col || !ell_val) return GCRNN_ERR_NULL_POINTER;
   if (B <= 0 || T <= 0 || N <= 0 || N > NP || B > (1 << 24) || entries < 0 || entries % 4 || F % 2) return GCRNN_ERR_BAD_SHAPE;
   const int64_t step = B * NP * F;
@@ -401,7 +401,7 @@ extern "C" int gcrnn_fused_node_backward_data_bf16(const void* dHs, const void* 
   scale_rows_kernel<<<(unsigned)cdiv(step / 2, 256), 256, 0, as_stream(stream)>>>(
       (const uint16_t*)dpre + (T - 1) * step, ngf + (T - 1) * B * N, (uint16_t*)dyh + (T - 1) * step, B, (int)N, NP, (int)F);
   GCRNN_CHECK_LAUNCH();
-  const FusedGraphArgs ga{tile_nodes, tile_off, ell_col, ell_val, ell_val4, ell_col4, entries};
+  const FusedGraphArgs ga{tile_nodes, tile_off, ell_col, ell_val, ell_val4, ell_col4, entries, (float)uniform_w};
   return fused_dispatch(7, dyh, nullptr, dpre, wpackT, nullptr, nullptr, nullptr, ngf, nullptr, ga, B, T, N, F, 0, K, as_stream(stream), dHs, hs);
 }
 
@@ -409,7 +409,7 @@ extern "C" int gcrnn_fused_backward_data_bf16(const void* dHs, const void* hs, v
                                               const int32_t* tile_nodes, const int32_t* tile_off, const int32_t* ell_col,
                                               const float* ell_val, const void* ell_val4, const void* ell_col4,
                                               int64_t entries, int64_t B, int64_t T, int64_t N, int64_t F, int64_t K,
-                                              const float* gf, const void* h0s, float* dgf_parts, void* stream) {
+                                              const float* gf, const void* h0s, float* dgf_parts, double uniform_w, void* stream) {
   if (dgf_parts && !h0s) return GCRNN_ERR_NULL_POINTER;
   if (!dHs || !hs || !dpre || !wpackT || !tile_nodes || !tile_off || !ell_col || !ell_val) return GCRNN_ERR_NULL_POINTER;
   if (B <= 0 || T <= 0 || N <= 0 || N > NP || B > (1 << 24) || entries < 0 || entries % 4) return GCRNN_ERR_BAD_SHAPE;
@@ -418,7 +418,7 @@ extern "C" int gcrnn_fused_backward_data_bf16(const void* dHs, const void* hs, v
   bwd_seed_kernel<<<(unsigned)cdiv(step / 2, 256), 256, 0, as_stream(stream)>>>(
       (const uint16_t*)dHs + (T - 1) * step, (const uint16_t*)hs + (T - 1) * step, (uint16_t*)dpre + (T - 1) * step, step);
   GCRNN_CHECK_LAUNCH();
-  const FusedGraphArgs ga{tile_nodes, tile_off, ell_col, ell_val, ell_val4, ell_col4, entries};
+  const FusedGraphArgs ga{tile_nodes, tile_off, ell_col, ell_val, ell_val4, ell_col4, entries, (float)uniform_w};
   return fused_dispatch(3, nullptr, nullptr, dpre, wpackT, nullptr, nullptr, gf, nullptr, dgf_parts, ga, B, T, N, F, 0, K,
                         as_stream(stream), dHs, hs, dh0, nullptr, h0s);
 }

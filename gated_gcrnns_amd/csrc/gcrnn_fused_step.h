@@ -749,17 +749,27 @@ int fused_launch_t(int mode /*0 plain, 1 gated, 2 gate pre-pass, 3 BPTT data gra
                           const int32_t* hzero_flag = nullptr) {
   constexpr int F = 32 * HS, G = 32 * XS, KS = HS + XS;
   const size_t base = (size_t)NP * FC * 4 + (size_t)K * KS * 1024;
-  // forward steps on a uniform-weight plan: column words only in LDS (2 instead of 6 bytes per slot and entry)
-  const bool uni = (mode == 0 || mode == 1) && ga.uniform_w != 0.f && ga.ell_col4 && GCRNN_HOP_ASM && GCRNN_STEP_WAVES == 8 &&
+  // uniform-weight plan: column words only in LDS (2 instead of 6 bytes per slot and entry); every mode but the gate-gradient pass
+  const bool uni = mode != 4 && ga.uniform_w != 0.f && ga.ell_col4 && GCRNN_HOP_ASM && GCRNN_STEP_WAVES == 8 &&
                    base + (size_t)ga.entries * 16 * 2 <= 160 * 1024;
   const size_t resident_bytes = base + (size_t)ga.entries * 16 * (uni ? 2 : 6);
   const bool resident = resident_bytes <= 160 * 1024 && ga.ell_val4 && ga.ell_col4;
   const size_t lds = resident ? resident_bytes : base;
   fused_kern_t kern;
   if (mode == 6) {
-    if constexpr (XS == 0) kern = resident ? (fused_kern_t)fused_step_kernel<K, HS, XS, false, true, 5> : (fused_kern_t)fused_step_kernel<K, HS, XS, false, false, 5>;
+    if constexpr (XS == 0) {
+      kern = resident ? (fused_kern_t)fused_step_kernel<K, HS, XS, false, true, 5> : (fused_kern_t)fused_step_kernel<K, HS, XS, false, false, 5>;
+#if GCRNN_HOP_ASM && GCRNN_STEP_WAVES == 8
+      if (uni && resident) kern = (fused_kern_t)fused_step_kernel<K, HS, XS, false, true, 5, 1>;
+#endif
+    }
     else return GCRNN_ERR_UNSUPPORTED;
   }
+#if GCRNN_HOP_ASM && GCRNN_STEP_WAVES == 8
+  else if (mode == 5 && uni && resident) kern = (fused_kern_t)fused_step_kernel<K, HS, XS, false, true, 4, 1>;
+  else if ((mode == 3 || mode == 7) && uni && resident) kern = (fused_kern_t)fused_step_kernel<K, HS, XS, false, true, 2, 1>;
+  else if (mode == 2 && uni && resident) kern = (fused_kern_t)fused_step_kernel<K, HS, XS, false, true, 1, 1>;
+#endif
   else if (mode == 5) kern = resident ? (fused_kern_t)fused_step_kernel<K, HS, XS, false, true, 4> : (fused_kern_t)fused_step_kernel<K, HS, XS, false, false, 4>;
   else if (mode == 4) kern = resident ? (fused_kern_t)fused_step_kernel<K, HS, XS, false, true, 3> : (fused_kern_t)fused_step_kernel<K, HS, XS, false, false, 3>;
   else if (mode == 3 || mode == 7) kern = resident ? (fused_kern_t)fused_step_kernel<K, HS, XS, false, true, 2> : (fused_kern_t)fused_step_kernel<K, HS, XS, false, false, 2>;
@@ -796,7 +806,7 @@ int fused_launch_t(int mode /*0 plain, 1 gated, 2 gate pre-pass, 3 BPTT data gra
         kern<<<grid, STHREADS, lds, st>>>(dyh + (t - 1) * hstep, dyh + t * hstep, h + (t - 1) * hstep, (const uint4*)wpack, nullptr, nullptr,
                                      nullptr, ga.tile_nodes, ga.tile_off, ga.ell_col, ga.ell_val, (const float4*)ga.ell_val4,
                                      (const uint2*)ga.ell_col4, gate_w + (t - 1) * B * N, nullptr, dH + (t - 1) * hstep, hst + (t - 1) * hstep, 0,
-                                     (int)ga.entries, (int)B, (int)B, (int)N, nullptr, 0.f);
+                                     (int)ga.entries, (int)B, (int)B, (int)N, nullptr, uni ? ga.uniform_w : 0.f);
     } else {
       return GCRNN_ERR_UNSUPPORTED;
     }
@@ -811,7 +821,7 @@ int fused_launch_t(int mode /*0 plain, 1 gated, 2 gate pre-pass, 3 BPTT data gra
                                    gi ? gf + t * B : nullptr, ga.tile_nodes, ga.tile_off, ga.ell_col, ga.ell_val,
                                    (const float4*)ga.ell_val4, (const uint2*)ga.ell_col4, gate_w + t * 2 * B * N, nullptr, yx + t * hstep,
                                    !huser ? nullptr : (!huser_last_only ? (const uint16_t*)huser + t * F * N : (t == T - 1 ? (const uint16_t*)huser : nullptr)),
-                                   (int)((huser_last_only ? 1 : T) * F * N), (int)ga.entries, (int)B, (int)B, (int)N, nullptr, 0.f);
+                                   (int)((huser_last_only ? 1 : T) * F * N), (int)ga.entries, (int)B, (int)B, (int)N, nullptr, uni ? ga.uniform_w : 0.f);
     }
   } else if (mode == 5) {
     // filter output of every (t, b) item in one launch (split over whole time steps like mode 2 / 4): hs receives A(S)x_t + b
@@ -824,11 +834,11 @@ int fused_launch_t(int mode /*0 plain, 1 gated, 2 gate pre-pass, 3 BPTT data gra
       if (XS == 0)        // operand = one [T*B][NP][F] array (an input with G == F, packed like a state)
         kern<<<grid_for(items), STHREADS, lds, st>>>(nullptr, (const uint16_t*)h0 + t0 * hstep, h + t0 * hstep, (const uint4*)wpack, bias, nullptr, nullptr,
                                      ga.tile_nodes, ga.tile_off, ga.ell_col, ga.ell_val, (const float4*)ga.ell_val4, (const uint2*)ga.ell_col4,
-                                     nullptr, nullptr, nullptr, nullptr, 0, (int)ga.entries, (int)items, (int)items, (int)N, nullptr, 0.f);
+                                     nullptr, nullptr, nullptr, nullptr, 0, (int)ga.entries, (int)items, (int)items, (int)N, nullptr, uni ? ga.uniform_w : 0.f);
       else                // operand [0 | x_t]: ONE all-zero state block shared by every item (hmod = 1)
         kern<<<grid_for(items), STHREADS, lds, st>>>(x + t0 * xstep, (const uint16_t*)h0, h + t0 * hstep, (const uint4*)wpack, bias, nullptr, nullptr,
                                      ga.tile_nodes, ga.tile_off, ga.ell_col, ga.ell_val, (const float4*)ga.ell_val4, (const uint2*)ga.ell_col4,
-                                     nullptr, nullptr, nullptr, nullptr, 0, (int)ga.entries, (int)items, 1, (int)N, nullptr, 0.f);
+                                     nullptr, nullptr, nullptr, nullptr, 0, (int)ga.entries, (int)items, 1, (int)N, nullptr, uni ? ga.uniform_w : 0.f);
     }
   } else if (mode == 2 || mode == 4) {
     // no recurrence: all (t, b) items in one launch -- split over whole time steps where the 32-bit buffer offsets of
@@ -843,17 +853,17 @@ int fused_launch_t(int mode /*0 plain, 1 gated, 2 gate pre-pass, 3 BPTT data gra
       if (mode == 2)      // operands [h0 | x_t]; optional store of c_t = tanh(pre) into hs
         kern<<<grid_for(items), STHREADS, lds, st>>>(x + t0 * xstep, (const uint16_t*)h0, h ? h + t0 * hstep : nullptr, (const uint4*)wpack, bias,
                                      nullptr, nullptr, ga.tile_nodes, ga.tile_off, ga.ell_col, ga.ell_val, (const float4*)ga.ell_val4,
-                                     (const uint2*)ga.ell_col4, gate_w, go, nullptr, nullptr, 0, (int)ga.entries, (int)items, (int)B, (int)N, hzero_flag, 0.f);
+                                     (const uint2*)ga.ell_col4, gate_w, go, nullptr, nullptr, 0, (int)ga.entries, (int)items, (int)B, (int)N, hzero_flag, uni ? ga.uniform_w : 0.f);
       else if (XS == 0)   // operand = one [T*B][NP][F] array, per-item dpre in bw_dHs
         kern<<<grid_for(items), STHREADS, lds, st>>>(nullptr, (const uint16_t*)h0 + t0 * hstep, nullptr, (const uint4*)wpack, bias, nullptr, nullptr,
                                      ga.tile_nodes, ga.tile_off, ga.ell_col, ga.ell_val, (const float4*)ga.ell_val4,
                                      (const uint2*)ga.ell_col4, nullptr, go, (const uint16_t*)bw_dHs + t0 * hstep, nullptr, 0,
-                                     (int)ga.entries, (int)items, (int)items, (int)N, nullptr, 0.f);
+                                     (int)ga.entries, (int)items, (int)items, (int)N, nullptr, uni ? ga.uniform_w : 0.f);
       else                // input filter with G != F: operand [0 | x_t] -- ONE all-zero state block shared by every item (hmod = 1)
         kern<<<grid_for(items), STHREADS, lds, st>>>(x + t0 * xstep, (const uint16_t*)h0, nullptr, (const uint4*)wpack, bias, nullptr, nullptr,
                                      ga.tile_nodes, ga.tile_off, ga.ell_col, ga.ell_val, (const float4*)ga.ell_val4,
                                      (const uint2*)ga.ell_col4, nullptr, go, (const uint16_t*)bw_dHs + t0 * hstep, nullptr, 0,
-                                     (int)ga.entries, (int)items, 1, (int)N, nullptr, 0.f);
+                                     (int)ga.entries, (int)items, 1, (int)N, nullptr, uni ? ga.uniform_w : 0.f);
     }
   } else if (mode == 3) {
     // BPTT: hs (= dpre, [T][B][NP][F]) already holds dpre_{T-1}; walk t = T-1 .. 1, then optionally d h0.
@@ -866,13 +876,13 @@ int fused_launch_t(int mode /*0 plain, 1 gated, 2 gate pre-pass, 3 BPTT data gra
       kern<<<grid, STHREADS, lds, st>>>(nullptr, h + t * hstep, h + (t - 1) * hstep, (const uint4*)wpack, nullptr, nullptr,
                                    gf ? gf + t * B : nullptr, ga.tile_nodes, ga.tile_off, ga.ell_col, ga.ell_val,
                                    (const float4*)ga.ell_val4, (const uint2*)ga.ell_col4, nullptr, gate_out ? gate_out + t * gstep : nullptr,
-                                   dH + (t - 1) * hstep, hst + (t - 1) * hstep, 0, (int)ga.entries, (int)B, (int)B, (int)N, nullptr, 0.f);
+                                   dH + (t - 1) * hstep, hst + (t - 1) * hstep, 0, (int)ga.entries, (int)B, (int)B, (int)N, nullptr, uni ? ga.uniform_w : 0.f);
     }
     if (bw_dh0 || gate_out)
       kern<<<grid, STHREADS, lds, st>>>(nullptr, h, (uint16_t*)bw_dh0, (const uint4*)wpack, nullptr, nullptr, gf, ga.tile_nodes,
                                    ga.tile_off, ga.ell_col, ga.ell_val, (const float4*)ga.ell_val4, (const uint2*)ga.ell_col4,
                                    nullptr, gate_out, nullptr, gate_out ? (const uint16_t*)bw_h0 : nullptr, 0, (int)ga.entries,
-                                   (int)B, (int)B, (int)N, nullptr, 0.f);
+                                   (int)B, (int)B, (int)N, nullptr, uni ? ga.uniform_w : 0.f);
   } else {
     const unsigned grid = grid_for(B);
     for (int64_t t = 0; t < T; ++t) {

@@ -472,7 +472,7 @@ def fused_time_gate(xs, h0s, wA_g, wB_g, bias_g, lin_w, lin_b, graph, N, store_s
     parts = torch.empty((T * B, (F // 16) * int(lib.gcrnn_fused_step_waves())), dtype=torch.float32, device=xs.device)
     cs = torch.empty((T, B, npad, F), dtype=torch.bfloat16, device=xs.device) if store_states else None
     check(lib.gcrnn_fused_gate_prepass_bf16(_p(xs), _p(h0s), _p(wp), _p(bg), _p(gw), _p(parts), _p(cs),
-                                            *_fused_graph_args(plan), B, T, N, F, G, K, _p(hzero), st), 'gate_prepass')
+                                            *_fused_graph_args(plan), B, T, N, F, G, K, _p(hzero), plan.get('uniform_w', 0.0), st), 'gate_prepass')
     acc = parts.sum(dim=1)                                                    # fixed order: deterministic gates
     if lin_b is not None:
         acc = acc + lin_b.detach().float()
@@ -556,7 +556,8 @@ def fused_filter_output(xs, w, bias, graph, K, N):
     out = torch.empty((T, B, npad, F), dtype=torch.bfloat16, device=xs.device)
     if Cin == F:
         wp = _fused_pack_state_taps(w, K, st)
-        check(lib.gcrnn_fused_filter_output_bf16(_p(xs), None, _p(wp), _p(b32), _p(out), *_fused_graph_args(plan), B, T, N, F, 0, K, st),
+        check(lib.gcrnn_fused_filter_output_bf16(_p(xs), None, _p(wp), _p(b32), _p(out), *_fused_graph_args(plan), B, T, N, F, 0, K,
+                                                 plan.get('uniform_w', 0.0), st),
               'fused_filter_output')
     else:
         wd = w.detach()
@@ -564,7 +565,8 @@ def fused_filter_output(xs, w, bias, graph, K, N):
             wd = torch.cat([wd, wd.new_zeros(F, 1, K - wd.shape[2], Cin)], dim=2)
         wp = _fused_pack_weights(wd, wd.new_zeros((F, 1, K, F)), st)
         zero_h = torch.zeros((1, npad, F), dtype=torch.bfloat16, device=xs.device)
-        check(lib.gcrnn_fused_filter_output_bf16(_p(zero_h), _p(xs), _p(wp), _p(b32), _p(out), *_fused_graph_args(plan), B, T, N, F, Cin, K, st),
+        check(lib.gcrnn_fused_filter_output_bf16(_p(zero_h), _p(xs), _p(wp), _p(b32), _p(out), *_fused_graph_args(plan), B, T, N, F, Cin, K,
+                                                 plan.get('uniform_w', 0.0), st),
               'fused_filter_output')
     return out
 
@@ -643,7 +645,8 @@ def fused_node_cell_forward(X, h0, wA, wB, bias, graph, node_gates, time_gates=N
     yh = torch.empty_like(yx) if keep else None
     direct = (N % 8 == 0)
     check(lib.gcrnn_fused_node_forward_bf16(_p(h0s), _p(hs), _p(yx), _p(ngates), _p(gi), _p(gf), _p(wpB), _p(b32), _p(yh),
-                                            *_fused_graph_args(plan), B, T, N, F, K, _p(H) if direct else None, int(last_only), st),
+                                            *_fused_graph_args(plan), B, T, N, F, K, _p(H) if direct else None, int(last_only),
+                                            plan.get('uniform_w', 0.0), st),
           'fused_node_forward')
     if not direct:
         src = hs[T - 1:] if last_only else hs
@@ -729,7 +732,7 @@ class _FusedNodeCell(torch.autograd.Function):
         H = torch.empty((B, T, F, N), dtype=torch.bfloat16, device=X.device)
         yh = torch.empty_like(yx)
         check(lib.gcrnn_fused_node_forward_bf16(_p(h0s), _p(hs), _p(yx), _p(ngates), _p(gic), _p(gfc), _p(wpB), _p(b32), _p(yh),
-                                                *_fused_graph_args(plan), B, T, N, F, K, _p(H), 0, st), 'fused_node_forward')
+                                                *_fused_graph_args(plan), B, T, N, F, K, _p(H), 0, plan.get('uniform_w', 0.0), st), 'fused_node_forward')
         ctx.save_for_backward(X, h0, wA, wB, bias, H, hs_all, yx, yh, ngates, gic, gfc)
         ctx.graph, ctx.npad = graph, plan['npad']
         return H
@@ -756,7 +759,7 @@ class _FusedNodeCell(torch.autograd.Function):
         dpre = torch.empty((T, B, npad, F), dtype=torch.bfloat16, device=X.device)
         dyh = torch.empty_like(dpre)
         check(lib.gcrnn_fused_node_backward_data_bf16(_p(dHs), _p(hs), _p(dpre), _p(dyh), _p(ngf), _p(wpT), *_fused_graph_args(aplan),
-                                                      B, T, N, F, K, st), 'fused_node_backward_data')
+                                                      B, T, N, F, K, aplan.get('uniform_w', 0.0), st), 'fused_node_backward_data')
         dyx = torch.empty_like(dpre)
         dni = torch.empty((T, B, N), dtype=torch.float32, device=X.device)
         dnf = torch.empty_like(dni)
@@ -895,7 +898,7 @@ def fused_backward_data(dHs, hs, wB, graph, want_dh0=True, gf=None, h0s=None, bi
     if h0s is not None:
         parts = torch.empty((T * B, (F // 16) * int(lib.gcrnn_fused_step_waves())), dtype=torch.float32, device=hs.device)
     check(lib.gcrnn_fused_backward_data_bf16(_p(dHs), _p(hs), _p(dpre), _p(dh0), _p(wpack), *_fused_graph_args(plan),
-                                             B, T, graph.N, F, K, _p(gf), _p(h0s), _p(parts), st), 'fused_backward_data')
+                                             B, T, graph.N, F, K, _p(gf), _p(h0s), _p(parts), plan.get('uniform_w', 0.0), st), 'fused_backward_data')
     if h0s is None:
         return dpre, dh0
     dgf = parts.sum(dim=1).view(T, B)

@@ -148,12 +148,12 @@ int gcrnn_ell_fill(const int32_t* rowptr, const int32_t* col, const double* val,
 int gcrnn_fused_filter_output_bf16(const void* zs, const void* xs, const void* wpack, const float* bias, void* out,
                                    const int32_t* tile_nodes, const int32_t* tile_off, const int32_t* ell_col, const float* ell_val,
                                    const void* ell_val4, const void* ell_col4, int64_t entries, int64_t B, int64_t T, int64_t N,
-                                   int64_t F, int64_t G, int64_t K, void* stream);
+                                   int64_t F, int64_t G, int64_t K, double uniform_w, void* stream);
 int gcrnn_fused_node_forward_bf16(const void* h0s, void* hs, const void* yx, const float* ngates, const float* gi, const float* gf,
                                   const void* wpackB, const float* bias, void* yh_out, const int32_t* tile_nodes,
                                   const int32_t* tile_off, const int32_t* ell_col, const float* ell_val, const void* ell_val4,
                                   const void* ell_col4, int64_t entries, int64_t B, int64_t T, int64_t N, int64_t F, int64_t K,
-                                  void* Huser, int huser_last_only, void* stream);
+                                  void* Huser, int huser_last_only, double uniform_w, void* stream);
 /* BPTT of the node-gated cell. gcrnn_fused_node_backward_data_bf16: the data-gradient chain dpre_t = (dH_t + rec_t)(1 - h_t^2),
  * rec_{t-1} = sum_k S^k ((gf nf)_t . dpre_t B_k): dHs, hs, dpre (out), dyh (out = (gf nf) . dpre) [T][B][NPad][F] bf16; ngf fp32
  * [T][B][N] = gf_t[b] nf_t[b][n]; wpackT and the graph arrays as in gcrnn_fused_backward_data_bf16 (ELL of CSR(S)).
@@ -163,7 +163,7 @@ int gcrnn_fused_node_forward_bf16(const void* h0s, void* hs, const void* yx, con
 int gcrnn_fused_node_backward_data_bf16(const void* dHs, const void* hs, void* dpre, void* dyh, const float* ngf, const void* wpackT,
                                         const int32_t* tile_nodes, const int32_t* tile_off, const int32_t* ell_col,
                                         const float* ell_val, const void* ell_val4, const void* ell_col4, int64_t entries, int64_t B,
-                                        int64_t T, int64_t N, int64_t F, int64_t K, void* stream);
+                                        int64_t T, int64_t N, int64_t F, int64_t K, double uniform_w, void* stream);
 int gcrnn_node_cell_backward(const void* dpre, const void* yx, const void* yh, const float* ngates, const float* gi, const float* gf,
                              void* dyx, float* dni, float* dnf, float* dgi, float* dgf, int64_t B, int64_t T, int64_t N,
                              int64_t NPad, int64_t F, void* stream);
@@ -254,7 +254,8 @@ int gcrnn_fused_pack_weights(int wdtype, const void* wA, const void* wB, void* w
  * step_events[t] -- xs[t] is then allowed to be produced on another stream while earlier steps run.
  * uniform_w != 0: every non-zero of the graph carries this one weight AND the graph arrays come from gcrnn_ell_assign_rows_z /
  * gcrnn_ell_fill_z (padding entries aimed at zero rows): the step kernels then keep only the column words in LDS and sum the
- * gathered rows (acc = init + w * sum). 0 = weighted graph image. */
+ * gathered rows (acc = init + w * sum). 0 = weighted graph image. The same trailing parameter exists on the gate pre-pass, the
+ * filter-output pass, the node-gated steps and both BPTT data chains. */
 int gcrnn_fused_forward_bf16(const void* xs, const void* h0, void* hs, const void* wpack, const float* bias,
                              const float* gi, const float* gf, const int32_t* tile_nodes, const int32_t* tile_off,
                              const int32_t* ell_col, const float* ell_val, const void* ell_val4, const void* ell_col4,
@@ -276,7 +277,7 @@ int gcrnn_fused_gate_prepass_bf16(const void* xs, const void* h0, const void* wp
                                   const float* gate_w, float* gate_out, void* cs, const int32_t* tile_nodes,
                                   const int32_t* tile_off, const int32_t* ell_col, const float* ell_val,
                                   const void* ell_val4, const void* ell_col4, int64_t entries, int64_t B, int64_t T,
-                                  int64_t N, int64_t F, int64_t G, int64_t K, const int32_t* h0_zero_flag, void* stream);
+                                  int64_t N, int64_t F, int64_t G, int64_t K, const int32_t* h0_zero_flag, double uniform_w, void* stream);
 
 /* d loss / d (scalar time gate) of ONE filter of the time-gated cell (the gates multiply the filter outputs, graphML.py:2420-2421):
  *   sum over out[t][b][0 .. F/16*8) = sum_{f,n} ( W(S) z[t][b] + bias )[n][f] * dpre[t][b][n][f]
@@ -313,7 +314,7 @@ int gcrnn_fused_backward_data_bf16(const void* dHs, const void* hs, void* dpre, 
                                    const int32_t* tile_nodes, const int32_t* tile_off, const int32_t* ell_col,
                                    const float* ell_val, const void* ell_val4, const void* ell_col4, int64_t entries,
                                    int64_t B, int64_t T, int64_t N, int64_t F, int64_t K, const float* gf, const void* h0s,
-                                   float* dgf_parts, void* stream);
+                                   float* dgf_parts, double uniform_w, void* stream);
 
 /* BPTT weight gradient of the fused cell (adjoint of the taps, graphML.py:134-135), all T*B items in ONE launch:
  *   dW[f'][k][j] += sum_{t,b,n} g[t][b] (S^k dpre[t][b])[n][f'] * z[t][b][n][j],   z = [h_{t-1} | x_t],   j < F: weight_B (g = gf),
