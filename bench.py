@@ -95,8 +95,8 @@ def cpu_baseline(S, params, T, G, F, seconds_budget=20.0):
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=10)
-    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--steps', type=int, default=None, help='timed steps (default: 30; cfg5: 10)')
+    ap.add_argument('--warmup', type=int, default=None, help='untimed warm-up steps (default: 5; cfg5: 3)')
     ap.add_argument('--batch', type=int, default=None, help='sequences per GPU per step (default: 256; cfg5: 8; cfg4: 100)')
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32', 'f64'])
     ap.add_argument('--mode', default='fwd', choices=['fwd', 'train'])
@@ -182,6 +182,10 @@ def dry_run(args, rank, world):
 def main(argv=None):
     argv = sys.argv[1:] if argv is None else argv
     args = parse_args(argv)
+    if args.steps is None:
+        args.steps = 10 if args.config == 'cfg5' else 30
+    if args.warmup is None:
+        args.warmup = 3 if args.config == 'cfg5' else 5
     if args.gpus > 1 and 'RANK' not in os.environ:
         self_launch(args, argv)                       # does not return
     rank = int(os.environ.get('RANK', '0'))
