@@ -468,15 +468,21 @@ __global__ __launch_bounds__(STHREADS) void fused_step_kernel(
   // 128-byte row (= one cache line) of [h | x]; the NCH chunk workgroups of a sequence share an XCD and split the
   // 2 * NP rows between them. Phase 1 of the next sequence then streams from L2 instead of stalling on HBM.
   uint32_t prefetched = 0;
-  if (b + seq_slots < B) {
-    constexpr int LINES = (XS > 0 ? 2 : 1) * NP;                         // rows of [h | x] (x absent in the BPTT step)
-    const int line = chunk * (LINES / NCH) + tid;                        // LINES / NCH == 512 for F = G = 64
-    if (tid < LINES / NCH) {
-      prefetched = (line < NP)
-          ? __builtin_amdgcn_raw_buffer_load_b32(rsrc_h, line * (F * 2), ((b + seq_slots) % hmod) * (NP * F * 2), 0)
-          : __builtin_amdgcn_raw_buffer_load_b32(rsrc_x, (line - NP) * (G * 2), (b + seq_slots) * (NP * G * 2), 0);
+#ifndef GCRNN_PREFETCH_AT
+#define GCRNN_PREFETCH_AT 1      // 0: no L2 prefetch, 1: at the start of the hops (default), 2: before the last hop (A/B: tools/prefetch_ab.sh)
+#endif
+  auto prefetch_next = [&]() {
+    if (b + seq_slots < B) {
+      constexpr int LINES = (XS > 0 ? 2 : 1) * NP;                         // rows of [h | x] (x absent in the BPTT step)
+      const int line = chunk * (LINES / NCH) + tid;                        // LINES / NCH == 512 for F = G = 64
+      if (tid < LINES / NCH) {
+        prefetched = (line < NP)
+            ? __builtin_amdgcn_raw_buffer_load_b32(rsrc_h, line * (F * 2), ((b + seq_slots) % hmod) * (NP * F * 2), 0)
+            : __builtin_amdgcn_raw_buffer_load_b32(rsrc_x, (line - NP) * (G * 2), (b + seq_slots) * (NP * G * 2), 0);
+      }
     }
-  }
+  };
+  if (GCRNN_PREFETCH_AT == 1 || (GCRNN_PREFETCH_AT == 2 && K <= 2)) prefetch_next();
 
   // ---- phase 2: Horner hops, state image in LDS -------------------------------------------------
   const char* sbytes = reinterpret_cast<const char*>(state);
@@ -496,6 +502,7 @@ __global__ __launch_bounds__(STHREADS) void fused_step_kernel(
 #endif
 #pragma unroll
   for (int j = GCRNN_HOP_FIRST; j < K; ++j) {
+    if (GCRNN_PREFETCH_AT == 2 && K > 2 && j == K - 1) prefetch_next();
     if (RESIDENT) {
 #define GCRNN_FWD_INIT(i) u[i][K - 1 - j]
 #define GCRNN_FWD_STORE(i, a) u[i][K - 1 - j] = a   /* the new value lives in the tap's registers until every wave has read `state` */

@@ -632,3 +632,61 @@ def test_kstep_driver_counterpart_trains(dev, argv):
         loss = r['loss']
         assert np.isfinite(loss).all() and np.isfinite(r['score']), name
         assert np.mean(loss[-2:]) < loss[0], (name, loss[0], loss[-2:])
+
+
+@pytest.mark.parametrize('argv', [['--config', 'cfg2', '--batch', '16'], ['--config', 'cfg2', '--batch', '16', '--dtype', 'f32'],
+                                  ['--config', 'cfg2', '--batch', '8', '--mode', 'train'], ['--config', 'cfg2', '--batch', '8', '--mode', 'train', '--spatial-gating', 'node'],
+                                  ['--config', 'cfg4', '--batch', '8'], ['--config', 'cfg5', '--batch', '2']])
+def test_bench_lines_run(dev, argv):
+    """Every bench configuration prints ONE well-formed JSON line with `roofline` (and, at N = 1, `cpu_baseline` unless switched
+    off) -- a smoke of the measurement harness itself at small batches."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '1', '--warmup', '1', '--no-cpu-baseline'] + argv,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline', 'dtype', 'data', 'config', 'roofline'):
+        assert k in out, k
+    rf = out['roofline']
+    assert rf['bound'] in ('hbm', 'mfma') and rf['frac'] > 0 and abs(rf['frac'] - rf['achieved'] / rf['peak']) < 1e-9
+    assert out['value'] > 0 and out['n_gpus'] == 1 and 'workload' in out['config']
+
+
+def test_streaming_spmm_edge_cases(dev):
+    """Empty graph, a single row, rows narrower than the narrowest piece, an odd row length (scalar fallback incl. the tanh
+    epilogue), a destination count that is not a multiple of the rows per workgroup."""
+    from gated_gcrnns_amd import ops
+    from gated_gcrnns_amd.graph import operator_from_csr
+    rng = np.random.default_rng(2)
+    # no edges at all: Y = 0 (or Y unchanged with accumulate)
+    N = 37
+    g0 = operator_from_csr(np.zeros(N + 1, dtype=np.int64), np.zeros(0, np.int32), np.zeros(0), N, device=dev)
+    X = torch.randn(1, N, 8, device=dev)
+    Y = torch.randn(1, N, 8, device=dev)
+    Y0 = Y.clone()
+    ops.spmm_raw(g0.fwd[0], X, out=Y, accumulate=True)
+    assert torch.equal(Y, Y0)
+    assert float(ops.spmm_raw(g0.fwd[0], X).abs().max()) == 0.0
+    # random small graph, several row lengths incl. odd ones
+    deg = rng.integers(0, 6, size=N)
+    rowptr = np.concatenate([[0], np.cumsum(deg)])
+    col = np.concatenate([np.sort(rng.choice(N, size=d, replace=False)) for d in deg] + [np.zeros(0, np.int64)]).astype(np.int32)
+    val = rng.uniform(-1, 1, col.size)
+    g = operator_from_csr(rowptr, col, val, N, device=dev)
+    dense = np.zeros((N, N)); dense[np.repeat(np.arange(N), deg), col] = val
+    for L in (4, 5, 12, 33, 64):
+        X = torch.randn(2, N, L, dtype=torch.float64, device=dev)
+        ref = torch.einsum('mn,imc->inc', torch.tensor(dense, device=dev), X)
+        Y = ops.spmm_raw(g.fwd[0], X)
+        assert float((Y - ref).abs().max()) <= 1e-12, L
+        bias = torch.randn(L if L % 2 else L // 2, dtype=torch.float64, device=dev)
+        Y = torch.zeros_like(X)
+        ops.spmm_raw(g.fwd[0], X, out=Y, accumulate=True, bias=bias, bias_scale=2.0, tanh=True)
+        want = torch.tanh(ref + 2.0 * bias.repeat(L // bias.numel()))
+        assert float((Y - want).abs().max()) <= 1e-12, L
