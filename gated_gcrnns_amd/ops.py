@@ -600,12 +600,12 @@ def fused_node_supported(graph, N, F, G, Kin, Kst, dtype, E=1):
     return fused_supported(N, F, G, Kin, Kst, dtype, E) and max(Kin, Kst) in (2, 3, 4, 5) and not (max(Kin, Kst) == 4 and F == 32)
 
 
-def fused_node_cell_forward(X, h0, wA, wB, bias, graph, node_gates, time_gates=None, last_only=False, keep=False):
+def fused_node_cell_forward(X, h0, wA, wB, bias, graph, node_gates, time_gates=None, last_only=False):
     """Node-gated GGCRNNCell forward (optionally time-gated too) on the fused kernels (graphML.py:2379-2407, 2420-2423).
     node_gates = {'in': (wA_g, wB_g, bias_g, wf, bf), 'forget': (...)}: the gate cell GRNN_node_* and its F -> 1 GraphFilter
     GFL_node_*; time_gates as in fused_cell_forward. X B x T x G x N bf16, h0 B x F x N bf16 -> H B x T x F x N bf16.
     Everything that does not depend on h_{t-1} -- both gate cells, their filters, A(S)x_t + b -- runs for all T steps at once.
-    keep: also return what the BPTT needs (no autograd graph is recorded here)."""
+    Inference (no autograd graph is recorded here; training goes through fused_node_cell_train)."""
     require_device(X, h0, wA, wB, bias)
     X, wA = fused_pad_operands(X, wA.detach())
     B, T, G, N = X.shape
@@ -617,16 +617,14 @@ def fused_node_cell_forward(X, h0, wA, wB, bias, graph, node_gates, time_gates=N
     h0s, hs = hs_all[:1], hs_all[1:]
     hzero = fused_h0_zero_flag(h0)
     zero_lin = torch.zeros((1, F * N), dtype=torch.float32, device=X.device)
-    ng, saved = [], {}
+    ng = []
     for name in ('in', 'forget'):
         wA_g, wB_g, bias_g, wf, bf = node_gates[name]
         if wA_g.shape[3] != G:
             wA_g = torch.nn.functional.pad(wA_g.detach(), (0, G - wA_g.shape[3]))
         _, cs, _ = fused_time_gate(xs, h0s, wA_g, wB_g, bias_g, zero_lin, None, graph, N, store_states=True, hzero=hzero)
-        logit, wk = node_gate_logits(cs, wf, bf, graph, N)
-        gate = torch.sigmoid(logit)
-        ng.append(gate)
-        saved[name] = (cs, gate, wk)
+        logit, _ = node_gate_logits(cs, wf, bf, graph, N)
+        ng.append(torch.sigmoid(logit))
     ngates = torch.stack(ng, dim=1).contiguous()                        # [T][2][B][N]
     gi = gf = None
     if time_gates is not None:
@@ -642,17 +640,14 @@ def fused_node_cell_forward(X, h0, wA, wB, bias, graph, node_gates, time_gates=N
     wpB = _fused_pack_state_taps(wBk, K, st)
     b32 = bias.detach().float().contiguous().view(-1) if bias is not None else None
     H = torch.empty((B, 1 if last_only else T, F, N), dtype=torch.bfloat16, device=X.device)
-    yh = torch.empty_like(yx) if keep else None
     direct = (N % 8 == 0)
-    check(lib.gcrnn_fused_node_forward_bf16(_p(h0s), _p(hs), _p(yx), _p(ngates), _p(gi), _p(gf), _p(wpB), _p(b32), _p(yh),
+    check(lib.gcrnn_fused_node_forward_bf16(_p(h0s), _p(hs), _p(yx), _p(ngates), _p(gi), _p(gf), _p(wpB), _p(b32), None,
                                             *_fused_graph_args(plan), B, T, N, F, K, _p(H) if direct else None, int(last_only),
                                             plan.get('uniform_w', 0.0), st),
           'fused_node_forward')
     if not direct:
         src = hs[T - 1:] if last_only else hs
         check(lib.gcrnn_unpack_seq_major(_lib.BF16, _p(src), _p(H), B, 1 if last_only else T, F, N, plan['npad'], None, st), 'unpack_seq')
-    if keep:
-        return H, dict(xs=xs, hs_all=hs_all, yx=yx, yh=yh, ngates=ngates, gi=gi, gf=gf, gates=saved, hzero=hzero, X=X)
     return H
 
 
