@@ -302,6 +302,10 @@ class GGCRNNCell(nn.Module):
                 return self._forward_fused(X, h0, last_only=True)
             if (not torch.is_grad_enabled()) and self._use_fused_x3(X, h0):
                 return ops.fused_cell_forward_x3(X, h0, self.weight_A, self.weight_B, self.bias, self.graph, last_only=True)
+            if (not torch.is_grad_enabled()) and self._use_fused_node(X, h0):
+                return self._forward_fused_node(X, h0, last_only=True)
+            if (not torch.is_grad_enabled()) and self._use_fused_edge(X, h0):
+                return self._forward_fused_edge(X, h0, last_only=True)
             return self.forward(X, h0)[:, -1:]
         assert h0.shape[0] == X.shape[0]
         ops.require_device(X, h0, self.weight_A)
@@ -317,6 +321,8 @@ class GGCRNNCell(nn.Module):
             return self._forward_fused(X, h0)
         if self._use_fused_node(X, h0):
             return self._forward_fused_node(X, h0)
+        if self._use_fused_edge(X, h0):
+            return self._forward_fused_edge(X, h0)
         if self._use_fused_x3(X, h0):
             return ops.fused_cell_forward_x3(X, h0, self.weight_A, self.weight_B, self.bias, self.graph)
         if self._use_small(X, h0):
@@ -553,6 +559,25 @@ class GGCRNNCell(nn.Module):
         tg = self._fused_gates() if self.time_gating == True else None  # noqa: E712
         return ops.fused_node_cell_forward(X, h0, self.weight_A, self.weight_B, self.bias, self.graph, self._node_gate_params(),
                                            time_gates=tg, last_only=last_only)
+
+    def _use_fused_edge(self, X, h0):
+        """Edge-gated cell (optionally time-gated too), bf16, inference: the attention's mixing matrix is folded into the filter taps,
+        the x branch runs for all steps at once, every step is a filter pass plus the attention kernel."""
+        if self._wants_grad(X, h0) or self.spatial_gating != 'edge' or self.sigma not in (torch.tanh, nn.functional.tanh):
+            return False
+        if self.bias is None and self.time_gating == True:  # noqa: E712
+            return False
+        att = self.input_attention
+        if att.K != 1 or att.E != 1 or not att.concatenate or att.nonlinearity is not nn.functional.relu:
+            return False
+        return ops.fused_edge_supported(self.graph, self.N, self.F, self.G, self.Kin, self.Kst, X.dtype, self.E) and \
+            self.weight_A.dtype in (X.dtype, torch.float32) and h0.dtype == X.dtype
+
+    def _forward_fused_edge(self, X, h0, last_only=False):
+        tg = self._fused_gates() if self.time_gating == True else None  # noqa: E712
+        return ops.fused_edge_cell_forward(X, h0, self.weight_A, self.weight_B, self.bias, self.graph,
+                                           (self.input_attention.mixer, self.input_attention.weight),
+                                           (self.forget_attention.mixer, self.forget_attention.weight), time_gates=tg, last_only=last_only)
 
     def _use_fused_x3(self, X, h0):
         """fp32 inference of the un-gated cell on the fp32-accurate fused kernels (three bf16 planes per operand): graphs that fit

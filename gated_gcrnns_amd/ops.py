@@ -790,6 +790,92 @@ def fused_node_cell_train(X, h0, wA, wB, bias, graph, node_gates, time_gates=Non
     return _FusedNodeCell.apply(X, h0, wA, wB, bias, ni, nf, gi, gf, graph, xs, hs_all)
 
 
+# ------------------------------------------------------------------------------------------ edge-gated cell, fused path
+def fused_edge_supported(graph, N, F, G, Kin, Kst, dtype, E=1):
+    """Edge-gated cell on the fused kernels: the node-gated path's shapes (state-only instantiation of the step kernel for the
+    filter passes) plus the attention kernel's (N % 8 == 0, z [N][F] bf16 and the per-node scalars in LDS)."""
+    return fused_node_supported(graph, N, F, G, Kin, Kst, dtype, E) and bool(lib.gcrnn_fused_edge_attention_supported(int(N), int(F)))
+
+
+def _edge_composite(w, bias, att_w):
+    """The attention's mixing matrix folded into a filter: z = W (sum_k S^k u C_k + b) = sum_k S^k u (W C_k) + W b
+    (W acts on features, S on nodes). w F x 1 x k x C, bias F x 1 or None, att_w 1 x 1 x F x F -> (W C) F x 1 x k x C fp32, W b [F]."""
+    W = att_w[0, 0].float()
+    wc = torch.einsum('pf,fekc->pekc', W, w.float())
+    bc = (W @ bias.float().view(-1)) if bias is not None else None
+    return wc, bc
+
+
+def fused_edge_attention(z, a12, graph, gx=None, gi=None, gf=None, out=None, r_out=None, Huser=None, huser_item_stride=0, N=None,
+                         negative_slope=0.2):
+    """The attention of the fused edge gate (gcrnn_fused_edge_attention_bf16) on the items of z [..][NPad][F] bf16 (leading dims =
+    items). gx None: relu(att(z)); else tanh(gi gx + gf relu(att(z))) with per-item scalars gi / gf (fp32, or None)."""
+    npad, F = z.shape[-2], z.shape[-1]
+    items = z.numel() // (npad * F)
+    ep = graph.edge_plan()
+    if out is None:
+        out = torch.empty_like(z)
+    check(lib.gcrnn_fused_edge_attention_bf16(_p(z), _p(a12), _p(gx), _p(gi), _p(gf), _p(ep['rowptr']), _p(ep['r_edge']),
+                                              _p(ep['t_rowptr']), _p(ep['t_edge']), _p(out), _p(r_out), _p(Huser), int(huser_item_stride),
+                                              items, int(N if N is not None else graph.N), npad, F, float(negative_slope), _stream()),
+          'fused_edge_attention')
+    return out
+
+
+def fused_edge_cell_forward(X, h0, wA, wB, bias, graph, att_in, att_f, time_gates=None, last_only=False, negative_slope=0.2):
+    """Edge-gated GGCRNNCell forward (optionally time-gated too) on the fused kernels (graphML.py:2409-2416, 2420-2423).
+    att_in / att_f = (mixer 1 x 1 x 2F, weight 1 x 1 x F x F) of input_attention / forget_attention; time_gates as in
+    fused_cell_forward. X B x T x G x N bf16, h0 B x F x N bf16 -> H B x T x F x N bf16 (B x 1 x F x N with last_only).
+    The x branch relu(att_in(A(S)x_t + b)) does not depend on the recurrence: one filter pass and one attention pass over all
+    T * B items; every step is then two launches: the state filter pass (composite taps) and the attention + tanh epilogue.
+    Inference only (training goes through fused_edge_cell_train)."""
+    require_device(X, h0, wA, wB, bias)
+    X, wA = fused_pad_operands(X, wA.detach())
+    B, T, G, N = X.shape
+    F, Kin, Kst = wA.shape[0], wA.shape[2], wB.shape[2]
+    K = max(Kin, Kst)
+    plan = graph.fused_plan()
+    npad = plan['npad']
+    st = _stream()
+    xs, hs_all = fused_pack_inputs(X.contiguous(), h0.contiguous(), graph)
+    gi = gf = None
+    if time_gates is not None:
+        hzero = fused_h0_zero_flag(h0)
+        g = {}
+        for name in ('in', 'forget'):
+            wA_g, wB_g, bias_g, lin_w, lin_b = time_gates[name]
+            if wA_g.shape[3] != G:
+                wA_g = torch.nn.functional.pad(wA_g.detach(), (0, G - wA_g.shape[3]))
+            g[name] = fused_time_gate(xs, hs_all[:1], wA_g, wB_g, bias_g, lin_w, lin_b, graph, N, hzero=hzero)
+        gi, gf = g['in'].contiguous(), g['forget'].contiguous()
+    wAc, bA = _edge_composite(wA.detach(), bias.detach() if bias is not None else None, att_in[1].detach())
+    wBc, bB = _edge_composite(wB.detach(), bias.detach() if bias is not None else None, att_f[1].detach())
+    a_in = att_in[0].detach().float().reshape(2, F).contiguous()
+    a_f = att_f[0].detach().float().reshape(2, F).contiguous()
+    zx = fused_filter_output(xs, wAc, bA, graph, K, N)                  # [T][B][NPad][F]
+    gx = fused_edge_attention(zx, a_in, graph, out=zx, N=N, negative_slope=negative_slope)      # in place: every workgroup reads its item first
+    if Kst < K:
+        wBc = torch.cat([wBc, wBc.new_zeros(F, 1, K - Kst, F)], dim=2)
+    wpB = _fused_pack_state_taps(wBc, K, st)
+    bB32 = bB.contiguous() if bB is not None else None
+    H = torch.empty((B, 1 if last_only else T, F, N), dtype=torch.bfloat16, device=X.device)
+    zh = torch.empty((1, B, npad, F), dtype=torch.bfloat16, device=X.device)
+    ga = _fused_graph_args(plan)
+    uw = plan.get('uniform_w', 0.0)
+    for t in range(T):
+        check(lib.gcrnn_fused_filter_output_bf16(_p(hs_all[t]), None, _p(wpB), _p(bB32), _p(zh), *ga, B, 1, N, F, 0, K, uw, st),
+              'fused_filter_output')
+        hu = None
+        if not last_only:
+            hu = H[:, t]
+        elif t == T - 1:
+            hu = H[:, 0]
+        fused_edge_attention(zh, a_f, graph, gx=gx[t], gi=gi[t] if gi is not None else None, gf=gf[t] if gf is not None else None,
+                             out=hs_all[t + 1], Huser=hu, huser_item_stride=(1 if last_only else T) * F * N, N=N,
+                             negative_slope=negative_slope)
+    return H
+
+
 def fused_x3_supported(graph, N, F, G, Kin, Kst, dtype, E=1):
     """fp32-accurate fused inference (gcrnn_fused_forward_x3): fp32 tensors, un-gated cell, N <= 1024 with N % 4 == 0, the fused
     shapes, and a UNIFORM-weight graph (all non-zeros equal: the drivers' W / lambda_max) with >= 16 padding rows."""

@@ -172,6 +172,23 @@ int gcrnn_node_gate_dot(const void* d, const float* w, float* s, int64_t items, 
 int gcrnn_node_gate_dot_backward(void* d, const float* ds, const float* w, float* dw_part, int64_t items, int64_t N, int64_t NPad,
                                  int64_t F, int64_t K, void* stream);
 
+/* ==== Edge-gated cell on the fused path (Utils/graphML.py:2409-2416; GraphAttentional graphML.py:1999-2128, graphAttention 521-627)
+ *   h_t = tanh( gi att_in(A(S)x_t + b) + gf att_f(B(S)h_{t-1} + b) ),  att(y)[n] = relu(sum_m z_m (S+I)[m][n] alpha[m][n]),  z = W y,
+ *   alpha[m][.] = softmax over the support row m of LeakyReLU(a1.z_n + a2.z_m).
+ * W commutes with the shift, so z is a filter output with composite taps C_k W^T and bias W b: gcrnn_fused_filter_output_bf16
+ * produces it (all items for the x branch, one call per step for the state branch) and gcrnn_fused_edge_attention_bf16 is the
+ * attention itself, one workgroup per item: z [items][NPad][F] bf16, a12 fp32 [2][F] (mixer halves a1, a2), support rows
+ * rowptr / r_edge = {n, bits of (S+I)[m][n]} and columns t_rowptr / t_edge = {m, bits} (int32 pairs).
+ *   gx == NULL: out_seq = relu(att(z)) (the x branch, all items);
+ *   gx != NULL: out_seq = h = tanh(gi gx + gf relu(att(z))) with per-item scalars gi / gf (or both NULL); r_out (or NULL) keeps
+ *   relu(att(z)) for the BPTT; Huser (or NULL): item i's block in the user layout starts at Huser + i * huser_item_stride elements,
+ *   element (f, n) at f * N + n. Rows >= N of the sequence-major outputs are written as zeros. N % 8 == 0, F in {32, 64}. */
+int gcrnn_fused_edge_attention_supported(int64_t N, int64_t F);
+int gcrnn_fused_edge_attention_bf16(const void* z, const float* a12, const void* gx, const float* gi, const float* gf,
+                                    const int32_t* rowptr, const void* r_edge, const int32_t* t_rowptr, const void* t_edge,
+                                    void* out_seq, void* r_out, void* Huser, int64_t huser_item_stride, int64_t items, int64_t N,
+                                    int64_t NPad, int64_t F, double negative_slope, void* stream);
+
 /* ==== fp32-accurate fused path ("x3": three bf16 planes per fp32 operand, six partial products on the bf16 matrix cores) ========
  * The un-gated cell h_t = tanh(A(S)x_t + b + B(S)h_{t-1} + b) (Utils/graphML.py:2420-2423) to fp32 accuracy (the north_star's
  * 1e-5 mode) at fused-kernel speed: v = v1 + v2 + v3 with v1 = bf16(v), v2 = bf16(v - v1), v3 = bf16(v - v1 - v2) for state,
