@@ -87,7 +87,7 @@ def _bind(lib):
         'gcrnn_node_gate_dot': (C.c_int, [_c_p, _c_p, _c_p, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_p]),
         'gcrnn_node_gate_dot_backward': (C.c_int, [_c_p, _c_p, _c_p, _c_p, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_p]),
         'gcrnn_fused_edge_attention_supported': (C.c_int, [_c_i64, _c_i64]),
-        'gcrnn_fused_edge_attention_bf16': (C.c_int, [_c_p] * 12 + [_c_i64] * 5 + [C.c_double, _c_p]),
+        'gcrnn_fused_edge_attention_bf16': (C.c_int, [_c_p] * 13 + [_c_i64] * 5 + [C.c_double, _c_p]),
         'gcrnn_fused_x3_supported': (C.c_int, [_c_i64, _c_i64, _c_i64, _c_i64, _c_i64]),
         'gcrnn_pack_seq_major_x3': (C.c_int, [_c_p, _c_p, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_p]),
         'gcrnn_fused_pack_weights_x3': (C.c_int, [_c_p, _c_p, _c_p, _c_i64, _c_i64, _c_i64, _c_i64, _c_p]),

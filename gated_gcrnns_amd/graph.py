@@ -138,15 +138,18 @@ class GraphOperator(object):
     def edge_plan(self, e=0):
         """Packed attention support for the fused edge gate (gcrnn_fused_edge_attention_bf16 and its backward): support rows m
         (rowptr, r_edge[j] = {n, bits of (S+I)[m][n]}), support columns n (t_rowptr, t_edge[q] = {m, bits of (S+I)[m][n]}) and
-        t_pos[q] = the position of column-ordered edge q in the row order; all int32 on the device."""
+        t_pos[q] = the position of column-ordered edge q in the row order, t_order = the nodes by descending in-degree; all int32
+        on the device."""
         cache = self.__dict__.setdefault('_edge_plan', {})
         if e not in cache:
             trp, trow, tpos, _ = self.mask_transposed()
             bits = self.mask_vals[e].to(torch.float32).contiguous().view(torch.int32)
             r_edge = torch.stack([self.mask.col.to(torch.int32), bits], dim=1).contiguous()
             t_edge = torch.stack([trow, bits[tpos.long()]], dim=1).contiguous()
+            indeg = (trp[1:] - trp[:-1]).long()
+            t_order = torch.argsort(indeg, descending=True, stable=True).to(torch.int32).contiguous()
             cache[e] = {'rowptr': self.mask.rowptr, 'r_edge': r_edge, 't_rowptr': trp, 't_edge': t_edge, 't_pos': tpos,
-                        'nnz': int(self.mask.nnz)}
+                        't_order': t_order, 'nnz': int(self.mask.nnz)}
         return cache[e]
 
     def fused_plan(self, adjoint=False, kernel='step'):

@@ -816,7 +816,7 @@ def fused_edge_attention(z, a12, graph, gx=None, gi=None, gf=None, out=None, r_o
     if out is None:
         out = torch.empty_like(z)
     check(lib.gcrnn_fused_edge_attention_bf16(_p(z), _p(a12), _p(gx), _p(gi), _p(gf), _p(ep['rowptr']), _p(ep['r_edge']),
-                                              _p(ep['t_rowptr']), _p(ep['t_edge']), _p(out), _p(r_out), _p(Huser), int(huser_item_stride),
+                                              _p(ep['t_rowptr']), _p(ep['t_edge']), _p(ep['t_order']), _p(out), _p(r_out), _p(Huser), int(huser_item_stride),
                                               items, int(N if N is not None else graph.N), npad, F, float(negative_slope), _stream()),
           'fused_edge_attention')
     return out

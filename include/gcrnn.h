@@ -178,7 +178,8 @@ int gcrnn_node_gate_dot_backward(void* d, const float* ds, const float* w, float
  * W commutes with the shift, so z is a filter output with composite taps C_k W^T and bias W b: gcrnn_fused_filter_output_bf16
  * produces it (all items for the x branch, one call per step for the state branch) and gcrnn_fused_edge_attention_bf16 is the
  * attention itself, one workgroup per item: z [items][NPad][F] bf16, a12 fp32 [2][F] (mixer halves a1, a2), support rows
- * rowptr / r_edge = {n, bits of (S+I)[m][n]} and columns t_rowptr / t_edge = {m, bits} (int32 pairs).
+ * rowptr / r_edge = {n, bits of (S+I)[m][n]} and columns t_rowptr / t_edge = {m, bits} (int32 pairs), t_order = the nodes by
+ * descending in-degree (the order in which the workgroup visits them).
  *   gx == NULL: out_seq = relu(att(z)) (the x branch, all items);
  *   gx != NULL: out_seq = h = tanh(gi gx + gf relu(att(z))) with per-item scalars gi / gf (or both NULL); r_out (or NULL) keeps
  *   relu(att(z)) for the BPTT; Huser (or NULL): item i's block in the user layout starts at Huser + i * huser_item_stride elements,
@@ -186,7 +187,7 @@ int gcrnn_node_gate_dot_backward(void* d, const float* ds, const float* w, float
 int gcrnn_fused_edge_attention_supported(int64_t N, int64_t F);
 int gcrnn_fused_edge_attention_bf16(const void* z, const float* a12, const void* gx, const float* gi, const float* gf,
                                     const int32_t* rowptr, const void* r_edge, const int32_t* t_rowptr, const void* t_edge,
-                                    void* out_seq, void* r_out, void* Huser, int64_t huser_item_stride, int64_t items, int64_t N,
+                                    const int32_t* t_order, void* out_seq, void* r_out, void* Huser, int64_t huser_item_stride, int64_t items, int64_t N,
                                     int64_t NPad, int64_t F, double negative_slope, void* stream);
 
 /* ==== fp32-accurate fused path ("x3": three bf16 planes per fp32 operand, six partial products on the bf16 matrix cores) ========

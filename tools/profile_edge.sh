@@ -11,5 +11,5 @@ stats() {  # name, bench args
   echo "$n: $(head -c 300 $O/bench_$n.json)"
 }
 stats bench_fwd_edgegated --spatial-gating edge --steps 2 --warmup 1
-stats bench_train_edgegated --mode train --spatial-gating edge --steps 2 --warmup 1
+[ "$2" = fwd ] || stats bench_train_edgegated --mode train --spatial-gating edge --steps 2 --warmup 1
 rm -rf $O/kt_*
