@@ -316,6 +316,10 @@ class GGCRNNCell(nn.Module):
             tgates = self._fused_gates() if self.time_gating == True else None  # noqa: E712
             if self.spatial_gating == 'node':
                 return ops.fused_node_cell_train(Xp, h0, wA, self.weight_B, self.bias, self.graph, self._node_gate_params(pad=True), tgates)
+            if self.spatial_gating == 'edge':
+                return ops.fused_edge_cell_train(Xp, h0, wA, self.weight_B, self.bias, self.graph,
+                                                 (self.input_attention.mixer, self.input_attention.weight),
+                                                 (self.forget_attention.mixer, self.forget_attention.weight), tgates)
             return ops.fused_cell_train(Xp, h0, wA, self.weight_B, self.bias, self.graph, tgates)
         if self._use_fused(X, h0):
             return self._forward_fused(X, h0)
@@ -599,11 +603,18 @@ class GGCRNNCell(nn.Module):
             return False
         if not (h0.requires_grad or any(p.requires_grad for p in self.parameters())):
             return False
-        if self.spatial_gating is not None:
-            if self.spatial_gating != 'node' or h0.requires_grad or self.bias is None or \
-                    self.GRNN_node_in.weight_A.dtype != self.weight_A.dtype or \
+        if self.spatial_gating == 'node':
+            if h0.requires_grad or self.bias is None or self.GRNN_node_in.weight_A.dtype != self.weight_A.dtype or \
                     not ops.fused_node_supported(self.graph, self.N, self.F, self.G, self.Kin, self.Kst, X.dtype, self.E):
                 return False
+        elif self.spatial_gating == 'edge':
+            att = self.input_attention
+            if h0.requires_grad or att.K != 1 or att.E != 1 or not att.concatenate or att.nonlinearity is not nn.functional.relu or \
+                    att.weight.dtype != self.weight_A.dtype or \
+                    not ops.fused_edge_training_supported(self.graph, self.N, self.F, self.G, self.Kin, self.Kst, self.E):
+                return False
+        elif self.spatial_gating is not None:
+            return False
         if self.time_gating == True:  # noqa: E712   the fused gates give no gradient to h0; their sub-cells share the cell's shapes
             if h0.requires_grad or self.bias is None or self.GFL_in.weight_A.dtype != self.weight_A.dtype:
                 return False

@@ -286,6 +286,282 @@ static int edge_att_fwd_t(const void* z, const float* a12, const void* gx, const
   return GCRNN_OK;
 }
 
+
+// ------------------------------------------------------------------------------------------
+// Backward of one attention (autograd of graphAttention, graphML.py:585-627, composed with the layer's ReLU and the branch's gate):
+//   do[n]      = g dpre[n] . [r[n] > 0]                      r = relu(att(z)) kept by the forward, g the branch's scalar time gate
+//   d alpha    = v (z_m . do[n])                              per support edge (m -> n)
+//   dz_m       = sum_{n in row m} v alpha do[n]               direct path, the SAME gathered rows do[n] serve both
+//   softmax:     dl[m][n] = alpha (d alpha - R_m) lrelu'(s1[n] + s2[m]),  R_m = sum_n alpha d alpha
+//   scores:      ds2[m] = sum_n dl[m][n] (row sum),  ds1[n] = sum_m dl[m][n] (column sum, through the per-edge scratch E)
+//   dz_m      += a1 ds1[m] + a2 ds2[m];   da1 = sum_n ds1[n] z_n,  da2 = sum_m ds2[m] z_m   (per-item partials)
+// One workgroup per item. LDS: the do image [N][F] bf16 and sc[n] = {s1, s2, row max -> ds2, 1 / row sum -> ds1}. Rows are
+// visited by descending out-degree; a row's F/8 lanes hold its z piece and its edge records in registers (out-degree <= 32).
+// ------------------------------------------------------------------------------------------
+template <int CTRL> __device__ __forceinline__ float dpp_f(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+template <int LPN> __device__ __forceinline__ float group_sum(float v) {       // sum over the LPN (4 or 8) aligned lanes of a node
+  v += dpp_f<0xB1>(v);                 // quad_perm [1,0,3,2]
+  v += dpp_f<0x4E>(v);                 // quad_perm [2,3,0,1]
+  if (LPN == 8) v += dpp_f<0x141>(v);  // row_half_mirror: the other quad's total
+  return v;
+}
+
+template <int F>
+__global__ __launch_bounds__(ETHREADS) void edge_att_bwd_kernel(
+    const uint16_t* __restrict__ dpre,       // [items][NPad][F] bf16
+    const uint16_t* __restrict__ r,          // [items][NPad][F] bf16: relu(att(z)) of this branch
+    const float* __restrict__ g,             // [items] scalar gate of this branch, or null (= 1)
+    const uint16_t* __restrict__ z,          // [items][NPad][F] bf16
+    const float* __restrict__ a12,           // [2][F]
+    const int32_t* __restrict__ rowptr, const int2* __restrict__ r_edge, const int32_t* __restrict__ r_order,
+    const int32_t* __restrict__ t_rowptr, const int32_t* __restrict__ t_pos,
+    float* __restrict__ E,                   // [items][nnz] scratch: dl per support edge, row order
+    uint16_t* __restrict__ dz,               // [items][NPad][F] bf16 (rows >= N written as zeros)
+    float* __restrict__ da_part,             // [items][2][F]
+    float* __restrict__ dgate,               // [items]: sum dpre . r (the gradient of g), or null
+    int N, int NPad, int nnz, float slope) {
+  using L = EdgeLds<F>;
+  constexpr int LPN = L::LPN, NPP = L::NPP;
+  constexpr int MAXC = 32 / LPN, GPC = LPN / 4;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  uint4* dol = reinterpret_cast<uint4*>(smem);
+  float4* sc = reinterpret_cast<float4*>(smem + (size_t)N * F * 2);
+
+  const int tid = threadIdx.x;
+  const int p = tid % LPN, nl = tid / LPN;
+  const int64_t item = blockIdx.x;
+  const uint4* zsrc = reinterpret_cast<const uint4*>(z + item * NPad * F);
+  const uint4* dsrc = reinterpret_cast<const uint4*>(dpre + item * NPad * F);
+  const uint4* rsrc = reinterpret_cast<const uint4*>(r + item * NPad * F);
+  uint4* dzd = reinterpret_cast<uint4*>(dz + item * NPad * F);
+  float* Ei = E + item * nnz;
+  const float gv = g ? g[item] : 1.f;
+  const int total = N * LPN;
+
+  float a1r[8], a2r[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { a1r[j] = a12[p * 8 + j]; a2r[j] = a12[F + p * 8 + j]; }
+  // ---- phase 0: do image, scores, gate gradient -------------------------------------------------------------------------
+  float gsum = 0.f;
+  for (int i0 = tid; i0 < total; i0 += 2 * ETHREADS) {
+    uint4 vz[2], vd[2], vr[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int idx = i0 + u * ETHREADS;
+      const bool ok = idx < total;
+      vz[u] = ok ? zsrc[idx] : uint4{0, 0, 0, 0};
+      vd[u] = ok ? dsrc[idx] : uint4{0, 0, 0, 0};
+      vr[u] = ok ? rsrc[idx] : uint4{0, 0, 0, 0};
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int idx = i0 + u * ETHREADS;
+      float zf[8], df[8], rf[8];
+      unpack8(vz[u], zf);
+      unpack8(vd[u], df);
+      unpack8(vr[u], rf);
+      float d1 = 0.f, d2 = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        d1 += a1r[j] * zf[j];
+        d2 += a2r[j] * zf[j];
+        gsum += df[j] * rf[j];
+        df[j] = rf[j] > 0.f ? gv * df[j] : 0.f;
+      }
+      d1 = group_sum<LPN>(d1);
+      d2 = group_sum<LPN>(d2);
+      if (idx < total) {
+        dol[idx] = pack8(df);
+        if (p == 0) sc[idx / LPN] = float4{d1, d2, 0.f, 0.f};
+      }
+    }
+  }
+  __syncthreads();
+  // ---- phase A: softmax statistics of every support row ------------------------------------------------------------------
+  for (int m = tid; m < N; m += ETHREADS) {
+    const int j0 = rowptr[m], j1 = rowptr[m + 1];
+    const float s2m = sc[m].y;
+    float mx = -1e30f, sum = 0.f;
+#pragma unroll 4
+    for (int j = j0; j < j1; ++j) {
+      float e = sc[r_edge[j].x].x + s2m;
+      e = e > 0.f ? e : slope * e;
+      const float nm = fmaxf(mx, e);
+      sum = sum * eexp(mx - nm) + eexp(e - nm);
+      mx = nm;
+    }
+    sc[m].z = mx;
+    sc[m].w = sum > 0.f ? 1.f / sum : 0.f;
+  }
+  __syncthreads();
+  // ---- phase R: rows by descending out-degree ----------------------------------------------------------------------------
+  auto bounds = [&](int base, int& m, int& j0, int& deg) {
+    m = -1; j0 = 0; deg = 0;
+    if (base + nl < N) { m = r_order[base + nl]; j0 = rowptr[m]; deg = rowptr[m + 1] - j0; }
+  };
+  auto load_recs = [&](int j0, int deg, int2* rc) {
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) rc[c] = (c * LPN + p < deg) ? r_edge[j0 + c * LPN + p] : int2{0, 0};
+  };
+  int ma, j0a, dega, mb, j0b, degb;
+  bounds(0, ma, j0a, dega);
+  bounds(NPP, mb, j0b, degb);
+  int2 reca[MAXC];
+  load_recs(j0a, dega, reca);
+  uint4 zva = uint4{0, 0, 0, 0};
+  if (ma >= 0) zva = zsrc[ma * LPN + p];
+  for (int base = 0; base < N; base += NPP) {
+    int2 recb[MAXC];
+    load_recs(j0b, degb, recb);
+    uint4 zvb = uint4{0, 0, 0, 0};
+    if (mb >= 0) zvb = zsrc[mb * LPN + p];
+    int mc, j0c, degc;
+    bounds(base + 2 * NPP, mc, j0c, degc);
+    const int m = ma;
+    const bool valid = m >= 0;
+    float4 sm = float4{0.f, 0.f, 0.f, 0.f};
+    if (valid) sm = sc[m];
+    int dmax = dega;
+#pragma unroll
+    for (int off = LPN; off < 64; off <<= 1) dmax = max(dmax, __shfl_xor(dmax, off, 64));
+    dmax = __builtin_amdgcn_readfirstlane(dmax);
+    float zf[8];
+    unpack8(zva, zf);
+    // this lane's records: alpha, v alpha and the LeakyReLU slope factor
+    float al[MAXC], cown[MAXC], lr[MAXC], dal[MAXC];
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+      al[c] = 0.f; cown[c] = 0.f; lr[c] = 1.f; dal[c] = 0.f;
+      if (c * LPN < dmax) {
+        const float v = __int_as_float(reca[c].y);
+        float e = sc[reca[c].x].x + sm.y;
+        lr[c] = e > 0.f ? 1.f : slope;
+        e *= lr[c];
+        al[c] = (v != 0.f) ? eexp(e - sm.z) * sm.w : 0.f;
+        cown[c] = v * al[c];
+      }
+    }
+    f32x2 acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] = f32x2{0.f, 0.f};
+#pragma unroll
+    for (int gq = 0; gq < MAXC * GPC; ++gq) {
+      if (gq * 4 < dmax) {
+        const int c = gq / GPC, off = (gq % GPC) * 4;
+        int nn[4];
+        float cc[4];
+        uint4 dr[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { nn[i] = __shfl(reca[c].x, off + i, LPN); cc[i] = __shfl(cown[c], off + i, LPN); }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dr[i] = dol[nn[i] * LPN + p];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          float df[8];
+          unpack8(dr[i], df);
+          float dot = 0.f;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) dot += zf[j] * df[j];
+          dot = group_sum<LPN>(dot);
+          if (p == off + i) dal[c] = dot;                     // the lane that owns this record keeps z_m . do[n]
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[j] += cc[i] * f32x2{df[2 * j], df[2 * j + 1]};
+        }
+      }
+    }
+    // softmax / LeakyReLU backward on this lane's records
+    float rsum = 0.f;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) { dal[c] *= __int_as_float(reca[c].y); rsum += al[c] * dal[c]; }
+    rsum = group_sum<LPN>(rsum);
+    float ds2 = 0.f;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+      const float dl = al[c] * (dal[c] - rsum) * lr[c];
+      ds2 += dl;
+      if (c * LPN + p < dega) Ei[j0a + c * LPN + p] = dl;
+    }
+    ds2 = group_sum<LPN>(ds2);
+    if (valid) {
+      if (p == 0) sc[m].z = ds2;                              // the row statistics of m are in this group's registers: the slot is free
+      float o8[8];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { o8[2 * j] = acc[j].x + a2r[2 * j] * ds2; o8[2 * j + 1] = acc[j].y + a2r[2 * j + 1] * ds2; }
+      dzd[m * LPN + p] = pack8(o8);
+    }
+    ma = mb; j0a = j0b; dega = degb; zva = zvb; mb = mc; j0b = j0c; degb = degc;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) reca[c] = recb[c];
+  }
+  __threadfence_block();
+  __syncthreads();
+  // ---- phase C: ds1[n] = column sums of dl through the scratch (this workgroup's own stores) --------------------------------
+  for (int n = tid; n < N; n += ETHREADS) {
+    float acc1 = 0.f;
+    for (int q = t_rowptr[n]; q < t_rowptr[n + 1]; ++q) acc1 += Ei[t_pos[q]];
+    sc[n].w = acc1;
+  }
+  __syncthreads();
+  // ---- phase F: dz += a1 ds1, per-item partials of da ----------------------------------------------------------------------
+  f32x2 dacc[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) dacc[j] = f32x2{0.f, 0.f};
+  for (int idx = tid; idx < total; idx += ETHREADS) {
+    const int n = idx / LPN;
+    const uint4 vz = zsrc[idx], vp = dzd[idx];
+    const float4 s = sc[n];
+    float zf[8], pf[8];
+    unpack8(vz, zf);
+    unpack8(vp, pf);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      pf[j] += a1r[j] * s.w;
+      dacc[j] += f32x2{s.w, s.z} * zf[j];
+    }
+    dzd[idx] = pack8(pf);
+  }
+  for (int idx = total + tid; idx < NPad * LPN; idx += ETHREADS) dzd[idx] = uint4{0, 0, 0, 0};
+  // block reductions (fixed order): da over the nodes, the gate gradient over everything; the do image is dead
+  __syncthreads();
+  float* red = reinterpret_cast<float*>(smem);                 // [ETHREADS / LPN][LPN * 16] da partials, then [ETHREADS] gate partials
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { red[(nl * LPN + p) * 16 + j] = dacc[j].x; red[(nl * LPN + p) * 16 + 8 + j] = dacc[j].y; }
+  float* gred = red + ETHREADS * 16;
+  gred[tid] = gsum;
+  __syncthreads();
+  if (tid < 2 * F) {
+    const int which = tid / F, f = tid % F, pp = f / 8, j = f % 8;
+    float sum = 0.f;
+    for (int k = 0; k < ETHREADS / LPN; ++k) sum += red[(k * LPN + pp) * 16 + which * 8 + j];
+    da_part[item * 2 * F + tid] = sum;
+  }
+  if (dgate && tid == 2 * F) {
+    float sum = 0.f;
+    for (int k = 0; k < ETHREADS; ++k) sum += gred[k];
+    dgate[item] = sum;
+  }
+}
+
+template <int F>
+static int edge_att_bwd_t(const void* dpre, const void* r, const float* g, const void* z, const float* a12, const int32_t* rowptr,
+                          const void* r_edge, const int32_t* r_order, const int32_t* t_rowptr, const int32_t* t_pos, float* E, void* dz,
+                          float* da_part, float* dgate, int64_t items, int64_t N, int64_t NPad, int64_t nnz, float slope, hipStream_t st) {
+  size_t lds = (size_t)N * F * 2 + (size_t)N * 16;
+  const size_t red = (size_t)ETHREADS * 17 * 4;
+  if (lds < red) lds = red;
+  if (lds > 160 * 1024) return GCRNN_ERR_UNSUPPORTED;
+  auto kern = edge_att_bwd_kernel<F>;
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    return GCRNN_ERR_LAUNCH;
+  GCRNN_PRE_LAUNCH();
+  kern<<<(unsigned)items, ETHREADS, lds, st>>>((const uint16_t*)dpre, (const uint16_t*)r, g, (const uint16_t*)z, a12, rowptr, (const int2*)r_edge,
+                                               r_order, t_rowptr, t_pos, E, (uint16_t*)dz, da_part, dgate, (int)N, (int)NPad, (int)nnz, slope);
+  GCRNN_CHECK_LAUNCH();
+  return GCRNN_OK;
+}
+
 }  // namespace
 
 extern "C" int gcrnn_fused_edge_attention_supported(int64_t N, int64_t F) {
@@ -306,5 +582,28 @@ extern "C" int gcrnn_fused_edge_attention_bf16(const void* z, const float* a12, 
   hipStream_t st = as_stream(stream);
   if (F == 64) return edge_att_fwd_t<64>(z, a12, gx, gi, gf, rowptr, r_edge, t_rowptr, t_edge, t_order, out_seq, r_out, Huser, huser_item_stride, items, N, NPad, (float)negative_slope, st);
   if (F == 32) return edge_att_fwd_t<32>(z, a12, gx, gi, gf, rowptr, r_edge, t_rowptr, t_edge, t_order, out_seq, r_out, Huser, huser_item_stride, items, N, NPad, (float)negative_slope, st);
+  return GCRNN_ERR_UNSUPPORTED;
+}
+
+// Backward of gcrnn_fused_edge_attention_bf16 for one branch: dpre = d loss / d (pre-activation of the cell) [items][NPad][F] bf16,
+// r = relu(att(z)) kept by the forward, g [items] the branch's scalar time gate (or NULL = 1) -> dz [items][NPad][F] bf16 (the
+// gradient w.r.t. the composite filter output z), da_part fp32 [items][2][F] (per-item partials of the mixer gradient: the caller
+// adds the items in a fixed order), dgate fp32 [items] = sum dpre . r (or NULL). r_order = support rows by descending out-degree,
+// t_pos = position of every column-ordered support edge in the row order, E = fp32 scratch [items][nnz]. The support's largest
+// out-degree (self-loop included) must be <= 32 (gcrnn_fused_edge_attention_backward_supported).
+extern "C" int gcrnn_fused_edge_attention_backward_supported(int64_t N, int64_t F, int64_t max_out_degree) {
+  return gcrnn_fused_edge_attention_supported(N, F) && max_out_degree <= 32;
+}
+
+extern "C" int gcrnn_fused_edge_attention_backward_bf16(const void* dpre, const void* r, const float* g, const void* z, const float* a12,
+                                                        const int32_t* rowptr, const void* r_edge, const int32_t* r_order,
+                                                        const int32_t* t_rowptr, const int32_t* t_pos, float* scratch, void* dz,
+                                                        float* da_part, float* dgate, int64_t items, int64_t N, int64_t NPad, int64_t F,
+                                                        int64_t nnz, double negative_slope, void* stream) {
+  if (!dpre || !r || !z || !a12 || !rowptr || !r_edge || !r_order || !t_rowptr || !t_pos || !scratch || !dz || !da_part) return GCRNN_ERR_NULL_POINTER;
+  if (items <= 0 || items > 2147483647LL || N <= 0 || N > NPad || N % 8 || nnz <= 0 || items * nnz > (1LL << 40)) return GCRNN_ERR_BAD_SHAPE;
+  hipStream_t st = as_stream(stream);
+  if (F == 64) return edge_att_bwd_t<64>(dpre, r, g, z, a12, rowptr, r_edge, r_order, t_rowptr, t_pos, scratch, dz, da_part, dgate, items, N, NPad, nnz, (float)negative_slope, st);
+  if (F == 32) return edge_att_bwd_t<32>(dpre, r, g, z, a12, rowptr, r_edge, r_order, t_rowptr, t_pos, scratch, dz, da_part, dgate, items, N, NPad, nnz, (float)negative_slope, st);
   return GCRNN_ERR_UNSUPPORTED;
 }

@@ -405,6 +405,30 @@ extern "C" int gcrnn_fused_node_backward_data_bf16(const void* dHs, const void* 
   return fused_dispatch(7, dyh, nullptr, dpre, wpackT, nullptr, nullptr, nullptr, ngf, nullptr, ga, B, T, N, F, 0, K, as_stream(stream), dHs, hs);
 }
 
+// ONE step of the BPTT data chain with explicit arrays (the edge-gated cell interleaves it with the attention backward):
+//   dpre_prev = (sum_k S^k (operand W_k) + dH_prev) (1 - h_prev^2);  operand, dH_prev, h_prev, dpre_prev: [B][NPad][F] bf16
+// sequence-major, wpackT = the transposed taps packed as a state-only operand (as in gcrnn_fused_backward_data_bf16).
+// bwd_seed_kernel's formula dpre = dH (1 - h^2) for the last step is gcrnn_fused_backward_seed_bf16.
+extern "C" int gcrnn_fused_backward_step_bf16(const void* operand, const void* dH_prev, const void* h_prev, void* dpre_prev,
+                                              const void* wpackT, const int32_t* tile_nodes, const int32_t* tile_off,
+                                              const int32_t* ell_col, const float* ell_val, const void* ell_val4, const void* ell_col4,
+                                              int64_t entries, int64_t B, int64_t N, int64_t F, int64_t K, double uniform_w, void* stream) {
+  if (!operand || !dH_prev || !h_prev || !dpre_prev || !wpackT || !tile_nodes || !tile_off || !ell_col || !ell_val) return GCRNN_ERR_NULL_POINTER;
+  if (B <= 0 || N <= 0 || N > NP || B > (1 << 24) || entries < 0 || entries % 4) return GCRNN_ERR_BAD_SHAPE;
+  const FusedGraphArgs ga{tile_nodes, tile_off, ell_col, ell_val, ell_val4, ell_col4, entries, (float)uniform_w};
+  return fused_dispatch(8, nullptr, operand, dpre_prev, wpackT, nullptr, nullptr, nullptr, nullptr, nullptr, ga, B, 1, N, F, 0, K,
+                        as_stream(stream), dH_prev, h_prev);
+}
+
+extern "C" int gcrnn_fused_backward_seed_bf16(const void* dH, const void* h, void* dpre, int64_t elements, void* stream) {
+  if (!dH || !h || !dpre) return GCRNN_ERR_NULL_POINTER;
+  if (elements <= 0 || elements % 2) return GCRNN_ERR_BAD_SHAPE;
+  GCRNN_PRE_LAUNCH();
+  bwd_seed_kernel<<<(unsigned)cdiv(elements / 2, 256), 256, 0, as_stream(stream)>>>((const uint16_t*)dH, (const uint16_t*)h, (uint16_t*)dpre, elements);
+  GCRNN_CHECK_LAUNCH();
+  return GCRNN_OK;
+}
+
 extern "C" int gcrnn_fused_backward_data_bf16(const void* dHs, const void* hs, void* dpre, void* dh0, const void* wpackT,
                                               const int32_t* tile_nodes, const int32_t* tile_off, const int32_t* ell_col,
                                               const float* ell_val, const void* ell_val4, const void* ell_col4,

@@ -748,7 +748,7 @@ struct FusedGraphArgs {
 };
 
 template <int K, int HS, int XS>
-int fused_launch_t(int mode /*0 plain, 1 gated, 2 gate pre-pass, 3 BPTT data gradient, 4 gate-gradient pass, 5 filter-output pass, 6 node-gated steps, 7 node-gated BPTT data chain*/, const void* xs,
+int fused_launch_t(int mode /*0 plain, 1 gated, 2 gate pre-pass, 3 BPTT data gradient, 4 gate-gradient pass, 5 filter-output pass, 6 node-gated steps, 7 node-gated BPTT data chain, 8 one BPTT step*/, const void* xs,
                           const void* h0, void* hs, const void* wpack, const float* bias, const float* gi, const float* gf,
                           const float* gate_w, float* gate_out, const FusedGraphArgs& ga, int64_t B, int64_t T, int64_t N,
                           hipStream_t st, const void* bw_dHs = nullptr, const void* bw_hs = nullptr, const void* bw_h0 = nullptr,
@@ -774,12 +774,12 @@ int fused_launch_t(int mode /*0 plain, 1 gated, 2 gate pre-pass, 3 BPTT data gra
   }
 #if GCRNN_HOP_ASM && GCRNN_STEP_WAVES == 8
   else if (mode == 5 && uni && resident) kern = (fused_kern_t)fused_step_kernel<K, HS, XS, false, true, 4, 1>;
-  else if ((mode == 3 || mode == 7) && uni && resident) kern = (fused_kern_t)fused_step_kernel<K, HS, XS, false, true, 2, 1>;
+  else if ((mode == 3 || mode == 7 || mode == 8) && uni && resident) kern = (fused_kern_t)fused_step_kernel<K, HS, XS, false, true, 2, 1>;
   else if (mode == 2 && uni && resident) kern = (fused_kern_t)fused_step_kernel<K, HS, XS, false, true, 1, 1>;
 #endif
   else if (mode == 5) kern = resident ? (fused_kern_t)fused_step_kernel<K, HS, XS, false, true, 4> : (fused_kern_t)fused_step_kernel<K, HS, XS, false, false, 4>;
   else if (mode == 4) kern = resident ? (fused_kern_t)fused_step_kernel<K, HS, XS, false, true, 3> : (fused_kern_t)fused_step_kernel<K, HS, XS, false, false, 3>;
-  else if (mode == 3 || mode == 7) kern = resident ? (fused_kern_t)fused_step_kernel<K, HS, XS, false, true, 2> : (fused_kern_t)fused_step_kernel<K, HS, XS, false, false, 2>;
+  else if (mode == 3 || mode == 7 || mode == 8) kern = resident ? (fused_kern_t)fused_step_kernel<K, HS, XS, false, true, 2> : (fused_kern_t)fused_step_kernel<K, HS, XS, false, false, 2>;
   else if (mode == 2) kern = resident ? (fused_kern_t)fused_step_kernel<K, HS, XS, false, true, 1> : (fused_kern_t)fused_step_kernel<K, HS, XS, false, false, 1>;
 #if GCRNN_HOP_ASM && GCRNN_STEP_WAVES == 8
   else if (mode == 1 && uni && resident) kern = (fused_kern_t)fused_step_kernel<K, HS, XS, true, true, 0, 1>;
@@ -872,6 +872,13 @@ int fused_launch_t(int mode /*0 plain, 1 gated, 2 gate pre-pass, 3 BPTT data gra
                                      (const uint2*)ga.ell_col4, nullptr, go, (const uint16_t*)bw_dHs + t0 * hstep, nullptr, 0,
                                      (int)ga.entries, (int)items, 1, (int)N, nullptr, uni ? ga.uniform_w : 0.f);
     }
+  } else if (mode == 8) {
+    // ONE BPTT step with explicit arrays (edge-gated cell: the operand of step t is the attention backward's output):
+    // h0 = operand [B][NP][F], hs = dpre_{t-1} (out), bw_dHs = dH_{t-1}, bw_hs = h_{t-1}
+    kern<<<grid_for(B), STHREADS, lds, st>>>(nullptr, (const uint16_t*)h0, h, (const uint4*)wpack, nullptr, nullptr, nullptr, ga.tile_nodes,
+                                 ga.tile_off, ga.ell_col, ga.ell_val, (const float4*)ga.ell_val4, (const uint2*)ga.ell_col4, nullptr, nullptr,
+                                 (const uint16_t*)bw_dHs, (const uint16_t*)bw_hs, 0, (int)ga.entries, (int)B, (int)B, (int)N, nullptr,
+                                 uni ? ga.uniform_w : 0.f);
   } else if (mode == 3) {
     // BPTT: hs (= dpre, [T][B][NP][F]) already holds dpre_{T-1}; walk t = T-1 .. 1, then optionally d h0.
     // gf (time-gated cell, [T][B]): step t's recurrent gradient is scaled by its forget gate gf_t.

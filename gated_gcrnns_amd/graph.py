@@ -138,8 +138,8 @@ class GraphOperator(object):
     def edge_plan(self, e=0):
         """Packed attention support for the fused edge gate (gcrnn_fused_edge_attention_bf16 and its backward): support rows m
         (rowptr, r_edge[j] = {n, bits of (S+I)[m][n]}), support columns n (t_rowptr, t_edge[q] = {m, bits of (S+I)[m][n]}) and
-        t_pos[q] = the position of column-ordered edge q in the row order, t_order = the nodes by descending in-degree; all int32
-        on the device."""
+        t_pos[q] = the position of column-ordered edge q in the row order, t_order / r_order = the nodes by descending in- / out-degree;
+        all int32 on the device."""
         cache = self.__dict__.setdefault('_edge_plan', {})
         if e not in cache:
             trp, trow, tpos, _ = self.mask_transposed()
@@ -148,8 +148,11 @@ class GraphOperator(object):
             t_edge = torch.stack([trow, bits[tpos.long()]], dim=1).contiguous()
             indeg = (trp[1:] - trp[:-1]).long()
             t_order = torch.argsort(indeg, descending=True, stable=True).to(torch.int32).contiguous()
+            outdeg = (self.mask.rowptr[1:] - self.mask.rowptr[:-1]).long()
+            r_order = torch.argsort(outdeg, descending=True, stable=True).to(torch.int32).contiguous()
             cache[e] = {'rowptr': self.mask.rowptr, 'r_edge': r_edge, 't_rowptr': trp, 't_edge': t_edge, 't_pos': tpos,
-                        't_order': t_order, 'nnz': int(self.mask.nnz)}
+                        't_order': t_order, 'r_order': r_order, 'nnz': int(self.mask.nnz),
+                        'max_out_degree': int(outdeg.max().item()) if outdeg.numel() else 0}
         return cache[e]
 
     def fused_plan(self, adjoint=False, kernel='step'):

@@ -876,6 +876,165 @@ def fused_edge_cell_forward(X, h0, wA, wB, bias, graph, att_in, att_f, time_gate
     return H
 
 
+def fused_edge_training_supported(graph, N, F, G, Kin, Kst, E=1):
+    """Edge-gated training on the fused kernels: the fused BPTT's shapes, the attention kernels' and a support whose largest
+    out-degree (self-loop included) fits the backward kernel's register-resident edge records."""
+    if not (fused_training_supported(graph, N, F, G, Kin, Kst, E) and fused_edge_supported(graph, N, F, G, Kin, Kst, torch.bfloat16, E)):
+        return False
+    return bool(lib.gcrnn_fused_edge_attention_backward_supported(int(N), int(F), int(graph.edge_plan()['max_out_degree'])))
+
+
+def fused_edge_attention_backward(dpre, r, g, z, a12, graph, N, scratch=None, negative_slope=0.2, dz=None, da_part=None, dgate=None):
+    """Backward of fused_edge_attention for one branch over the items of dpre [..][NPad][F] (gcrnn_fused_edge_attention_backward_bf16):
+    returns (dz like z, da_part fp32 [items][2][F], dgate fp32 [items] or None); dz / da_part / dgate: optional output buffers."""
+    npad, F = z.shape[-2], z.shape[-1]
+    items = z.numel() // (npad * F)
+    ep = graph.edge_plan()
+    if dz is None:
+        dz = torch.empty_like(z)
+    if da_part is None:
+        da_part = torch.empty((items, 2, F), dtype=torch.float32, device=z.device)
+    if dgate is None and g is not None:
+        dgate = torch.empty((items,), dtype=torch.float32, device=z.device)
+    if scratch is None:
+        scratch = torch.empty((items, ep['nnz']), dtype=torch.float32, device=z.device)
+    assert scratch.numel() >= items * ep['nnz']
+    check(lib.gcrnn_fused_edge_attention_backward_bf16(_p(dpre), _p(r), _p(g), _p(z), _p(a12), _p(ep['rowptr']), _p(ep['r_edge']),
+                                                       _p(ep['r_order']), _p(ep['t_rowptr']), _p(ep['t_pos']), _p(scratch), _p(dz),
+                                                       _p(da_part), _p(dgate), items, int(N), npad, F, ep['nnz'], float(negative_slope),
+                                                       _stream()), 'fused_edge_attention_backward')
+    return dz, da_part, dgate
+
+
+class _FusedEdgeCell(torch.autograd.Function):
+    """Edge-gated GGCRNNCell (optionally time-gated too) on the fused kernels with its BPTT (graphML.py:2409-2416 under autograd).
+    forward: the x branch for all steps (filter pass with composite taps W_in A_k, attention), then two launches per step (state
+    filter pass with W_f B_k, attention + tanh), keeping z, relu(att(z)) of both branches.
+    backward, per step from the end: attention backward (dz_t, mixer partials, d gf_t) -> one launch of the data chain on dz_t
+    (-> dpre_{t-1}); then the x branch's attention backward over all items, two weight-gradient launches (composite taps of the
+    two filters) and the chain rule from the composite taps back to (taps, mixing matrix, bias). No gradient for X or h0."""
+
+    @staticmethod
+    def forward(ctx, X, h0, wA, wB, bias, mix_in, w_in, mix_f, w_f, gi, gf, graph, xs, hs_all, slope):
+        B, T, G, N = X.shape
+        F, Kin, Kst = wA.shape[0], wA.shape[2], wB.shape[2]
+        K = max(Kin, Kst)
+        plan = graph.fused_plan()
+        npad = plan['npad']
+        st = _stream()
+        bd = bias.detach() if bias is not None else None
+        wAc, bA = _edge_composite(wA.detach(), bd, w_in.detach())
+        wBc, bB = _edge_composite(wB.detach(), bd, w_f.detach())
+        a_in = mix_in.detach().float().reshape(2, F).contiguous()
+        a_f = mix_f.detach().float().reshape(2, F).contiguous()
+        gic = gi.detach().float().contiguous() if gi is not None else None
+        gfc = gf.detach().float().contiguous() if gf is not None else None
+        zx = fused_filter_output(xs, wAc, bA, graph, K, N)
+        gx = fused_edge_attention(zx, a_in, graph, N=N, negative_slope=slope)
+        wBk = wBc if Kst == K else torch.cat([wBc, wBc.new_zeros(F, 1, K - Kst, F)], dim=2)
+        wpB = _fused_pack_state_taps(wBk, K, st)
+        bB32 = bB.contiguous() if bB is not None else None
+        H = torch.empty((B, T, F, N), dtype=torch.bfloat16, device=X.device)
+        zh = torch.empty((T, B, npad, F), dtype=torch.bfloat16, device=X.device)
+        rh = torch.empty_like(zh)
+        ga = _fused_graph_args(plan)
+        uw = plan.get('uniform_w', 0.0)
+        for t in range(T):
+            check(lib.gcrnn_fused_filter_output_bf16(_p(hs_all[t]), None, _p(wpB), _p(bB32), _p(zh[t]), *ga, B, 1, N, F, 0, K, uw, st),
+                  'fused_filter_output')
+            fused_edge_attention(zh[t], a_f, graph, gx=gx[t], gi=gic[t] if gic is not None else None,
+                                 gf=gfc[t] if gfc is not None else None, out=hs_all[t + 1], r_out=rh[t], Huser=H[:, t],
+                                 huser_item_stride=T * F * N, N=N, negative_slope=slope)
+        ctx.save_for_backward(X, h0, wA, wB, bias, mix_in, w_in, mix_f, w_f, H, hs_all, zx, gx, zh, rh, gic, gfc, wBk)
+        ctx.graph, ctx.npad, ctx.slope = graph, npad, slope
+        return H
+
+    @staticmethod
+    def backward(ctx, dH):
+        X, h0, wA, wB, bias, mix_in, w_in, mix_f, w_f, H, hs_all, zx, gx, zh, rh, gi, gf, wBk = ctx.saved_tensors
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
+            raise GcrnnError('the fused edge-gated BPTT does not produce gradients w.r.t. X or h0')
+        graph, npad, slope = ctx.graph, ctx.npad, ctx.slope
+        B, T, G, N = X.shape
+        F, Kin, Kst = wA.shape[0], wA.shape[2], wB.shape[2]
+        K = max(Kin, Kst)
+        st = _stream()
+        dev = X.device
+        hs = hs_all[1:]
+        a_in = mix_in.detach().float().reshape(2, F).contiguous()
+        a_f = mix_f.detach().float().reshape(2, F).contiguous()
+        dH = dH.to(torch.bfloat16).contiguous()
+        dHs = torch.empty((T, B, npad, F), dtype=torch.bfloat16, device=dev)
+        check(lib.gcrnn_pack_seq_major(_lib.BF16, _p(dH), _p(dHs), B, T, F, N, npad, None, st), 'pack_seq')
+        wBt = wBk[:, 0].permute(2, 1, 0).contiguous().unsqueeze(1)                  # transposed composite taps [F_in][1][K][F_out]
+        wpT = _fused_pack_state_taps(wBt, K, st)
+        aplan = graph.fused_plan(adjoint=True)
+        aga = _fused_graph_args(aplan)
+        auw = aplan.get('uniform_w', 0.0)
+        nnz = graph.edge_plan()['nnz']
+        tchunk = max(1, min(T, (1 << 26) // max(1, B * nnz)))                       # <= 256 MiB of per-edge scratch
+        scratch = torch.empty((tchunk * B, nnz), dtype=torch.float32, device=dev)
+        dpre = torch.empty((T, B, npad, F), dtype=torch.bfloat16, device=dev)
+        dzh = torch.empty_like(dpre)
+        da_f = torch.empty((T, B, 2, F), dtype=torch.float32, device=dev)
+        dgf = torch.empty((T, B), dtype=torch.float32, device=dev) if gf is not None else None
+        step = B * npad * F
+        check(lib.gcrnn_fused_backward_seed_bf16(_p(dHs[T - 1]), _p(hs[T - 1]), _p(dpre[T - 1]), step, st), 'backward_seed')
+        for t in range(T - 1, -1, -1):
+            fused_edge_attention_backward(dpre[t], rh[t], gf[t] if gf is not None else None, zh[t], a_f, graph, N, scratch=scratch,
+                                          negative_slope=slope, dz=dzh[t], da_part=da_f[t], dgate=dgf[t] if dgf is not None else None)
+            if t > 0:
+                check(lib.gcrnn_fused_backward_step_bf16(_p(dzh[t]), _p(dHs[t - 1]), _p(hs[t - 1]), _p(dpre[t - 1]), _p(wpT), *aga,
+                                                         B, N, F, K, auw, st), 'fused_backward_step')
+        dzx = torch.empty_like(dpre)
+        da_i = torch.empty((T, B, 2, F), dtype=torch.float32, device=dev)
+        dgi = torch.empty((T, B), dtype=torch.float32, device=dev) if gi is not None else None
+        for t0 in range(0, T, tchunk):
+            t1 = min(T, t0 + tchunk)
+            fused_edge_attention_backward(dpre[t0:t1], gx[t0:t1], gi[t0:t1] if gi is not None else None, zx[t0:t1], a_in, graph, N,
+                                          scratch=scratch, negative_slope=slope, dz=dzx[t0:t1], da_part=da_i[t0:t1],
+                                          dgate=dgi[t0:t1] if dgi is not None else None)
+        one = torch.ones((T, B), dtype=torch.float32, device=dev)
+        zero = torch.zeros_like(one)
+        dWx, dbx = fused_backward_weight(dzx, X, H, h0, graph, F, G, K, want_bias=True, gi=one, gf=zero)       # composite input taps
+        dWh, dbh = fused_backward_weight(dzh, X, H, h0, graph, F, G, K, want_bias=True, gi=zero, gf=one)       # composite state taps
+        dAc, dBc = dWx[:, :Kin, F:], dWh[:, :Kst, :F]                                 # [F'][k][C] fp32
+        Wi, Wf = w_in.detach()[0, 0].float(), w_f.detach()[0, 0].float()
+        A32, B32 = wA.detach()[:, 0].float(), wB.detach()[:, 0].float()              # [F][k][C]
+        gA = torch.einsum('pf,pkc->fkc', Wi, dAc).unsqueeze(1).to(wA.dtype) if ctx.needs_input_grad[2] else None
+        gB = torch.einsum('pf,pkc->fkc', Wf, dBc).unsqueeze(1).to(wB.dtype) if ctx.needs_input_grad[3] else None
+        gWi = torch.einsum('pkc,fkc->pf', dAc, A32)
+        gWf = torch.einsum('pkc,fkc->pf', dBc, B32)
+        gb = None
+        if bias is not None:
+            b32 = bias.detach().float().view(-1)
+            gWi = gWi + torch.outer(dbx, b32)
+            gWf = gWf + torch.outer(dbh, b32)
+            if ctx.needs_input_grad[4]:
+                gb = (Wi.t() @ dbx + Wf.t() @ dbh).view_as(bias).to(bias.dtype)
+        g_mix_in = da_i.view(T * B, 2 * F).sum(dim=0).view_as(mix_in).to(mix_in.dtype) if ctx.needs_input_grad[5] else None
+        g_w_in = gWi.view_as(w_in).to(w_in.dtype) if ctx.needs_input_grad[6] else None
+        g_mix_f = da_f.view(T * B, 2 * F).sum(dim=0).view_as(mix_f).to(mix_f.dtype) if ctx.needs_input_grad[7] else None
+        g_w_f = gWf.view_as(w_f).to(w_f.dtype) if ctx.needs_input_grad[8] else None
+        return (None, None, gA, gB, gb, g_mix_in, g_w_in, g_mix_f, g_w_f,
+                dgi if (gi is not None and ctx.needs_input_grad[9]) else None,
+                dgf if (gf is not None and ctx.needs_input_grad[10]) else None, None, None, None, None)
+
+
+def fused_edge_cell_train(X, h0, wA, wB, bias, graph, att_in, att_f, time_gates=None, negative_slope=0.2):
+    """Training forward of the edge-gated (optionally time + edge gated) cell on the fused kernels; the time gates are autograd
+    nodes of their own (_FusedTimeGate) and enter _FusedEdgeCell as differentiable [T][B] inputs."""
+    require_device(X, h0, wA, wB, bias)
+    with torch.no_grad():
+        xs, hs_all = fused_pack_inputs(X, h0, graph)
+        hzero = fused_h0_zero_flag(h0)
+    gi = gf = None
+    if time_gates is not None:
+        gi = _FusedTimeGate.apply(xs, hs_all[:1], X, h0, *time_gates['in'], graph, hzero)
+        gf = _FusedTimeGate.apply(xs, hs_all[:1], X, h0, *time_gates['forget'], graph, hzero)
+    return _FusedEdgeCell.apply(X, h0, wA, wB, bias, att_in[0], att_in[1], att_f[0], att_f[1], gi, gf, graph, xs, hs_all, float(negative_slope))
+
+
 def fused_x3_supported(graph, N, F, G, Kin, Kst, dtype, E=1):
     """fp32-accurate fused inference (gcrnn_fused_forward_x3): fp32 tensors, un-gated cell, N <= 1024 with N % 4 == 0, the fused
     shapes, and a UNIFORM-weight graph (all non-zeros equal: the drivers' W / lambda_max) with >= 16 padding rows."""

@@ -190,6 +190,27 @@ int gcrnn_fused_edge_attention_bf16(const void* z, const float* a12, const void*
                                     const int32_t* t_order, void* out_seq, void* r_out, void* Huser, int64_t huser_item_stride, int64_t items, int64_t N,
                                     int64_t NPad, int64_t F, double negative_slope, void* stream);
 
+/* Backward of gcrnn_fused_edge_attention_bf16 for one branch (autograd of graphAttention composed with the layer's ReLU and the
+ * branch's scalar gate): dpre = d loss / d (cell pre-activation) [items][NPad][F] bf16, r = relu(att(z)) kept by the forward,
+ * g [items] (or NULL = 1) -> dz [items][NPad][F] bf16 (w.r.t. the composite filter output), da_part fp32 [items][2][F] (per-item
+ * partials of the mixer gradient), dgate fp32 [items] = sum dpre . r (or NULL). r_order = support rows by descending out-degree,
+ * t_pos = position of every column-ordered support edge in the row order, scratch fp32 [items][nnz]. Largest out-degree of the
+ * support (self-loop included) <= 32. Deterministic (gathers and fixed-order sums only).
+ * gcrnn_fused_backward_step_bf16: ONE launch of the BPTT data chain with explicit arrays, dpre_prev = (sum_k S^k (operand W_k) +
+ * dH_prev)(1 - h_prev^2) -- the edge-gated cell alternates it with the attention backward (the chain's operand of step t is dz_t);
+ * gcrnn_fused_backward_seed_bf16: dpre = dH (1 - h^2) on bf16 arrays (the last step). */
+int gcrnn_fused_edge_attention_backward_supported(int64_t N, int64_t F, int64_t max_out_degree);
+int gcrnn_fused_edge_attention_backward_bf16(const void* dpre, const void* r, const float* g, const void* z, const float* a12,
+                                             const int32_t* rowptr, const void* r_edge, const int32_t* r_order,
+                                             const int32_t* t_rowptr, const int32_t* t_pos, float* scratch, void* dz, float* da_part,
+                                             float* dgate, int64_t items, int64_t N, int64_t NPad, int64_t F, int64_t nnz,
+                                             double negative_slope, void* stream);
+int gcrnn_fused_backward_step_bf16(const void* operand, const void* dH_prev, const void* h_prev, void* dpre_prev, const void* wpackT,
+                                   const int32_t* tile_nodes, const int32_t* tile_off, const int32_t* ell_col, const float* ell_val,
+                                   const void* ell_val4, const void* ell_col4, int64_t entries, int64_t B, int64_t N, int64_t F,
+                                   int64_t K, double uniform_w, void* stream);
+int gcrnn_fused_backward_seed_bf16(const void* dH, const void* h, void* dpre, int64_t elements, void* stream);
+
 /* ==== fp32-accurate fused path ("x3": three bf16 planes per fp32 operand, six partial products on the bf16 matrix cores) ========
  * The un-gated cell h_t = tanh(A(S)x_t + b + B(S)h_{t-1} + b) (Utils/graphML.py:2420-2423) to fp32 accuracy (the north_star's
  * 1e-5 mode) at fused-kernel speed: v = v1 + v2 + v3 with v1 = bf16(v), v2 = bf16(v - v1), v3 = bf16(v - v1 - v2) for state,

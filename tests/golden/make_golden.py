@@ -317,11 +317,12 @@ def bf16_round(a):
     return u.astype(np.uint32).view(np.float32).astype(np.float64)
 
 
-def g9_fused_bptt():
+def g9_fused_bptt(variants=(('none', False, None), ('time', True, None), ('node', False, 'node'))):
     """Reference autograd gradients at a shape the fused bf16 kernels support (N=200, F=G=32, K=3, T=4, B=3): every
     operand is bf16-representable (S fp32-representable) so that the bf16 kernels and the fp64 reference see the SAME
     numbers; non-zero h0, directed weighted S; losses H.sum() and L1 against a random target (the drivers' loss,
-    miscTools.py:112-119). Un-gated, time-gated and node-gated cells; gradients of every parameter incl. the gate sub-networks."""
+    miscTools.py:112-119). Un-gated, time-gated and node-gated cells (edge-gated: g9_fused_bptt_edge); gradients of every parameter incl. the gate
+    sub-networks."""
     N, T, G, F, K, B = 200, 4, 32, 32, 3, 3
     rng = np.random.default_rng(19)
     M = (rng.random((N, N)) < 0.05) * rng.uniform(0.2, 1.5, (N, N)) * rng.choice([-1.0, 1.0], (N, N), p=[0.2, 0.8])
@@ -331,7 +332,7 @@ def g9_fused_bptt():
     h0 = bf16_round(0.5 * rng.standard_normal((B, F, N)))
     target = bf16_round(rng.standard_normal((B, T, F, N)))
     rows, cols = np.nonzero(S[0])
-    for name, tg, sg in (('none', False, None), ('time', True, None), ('node', False, 'node')):
+    for name, tg, sg in variants:
         torch.manual_seed(90)
         cell = gml.GGCRNNCell(G, F, K, K, torch.tanh, tg, sg, 1, True)
         cell.addGSO(torch.tensor(S))
@@ -353,6 +354,12 @@ def g9_fused_bptt():
              shape=np.array([N, T, G, F, K, B]), X=X.astype(np.float32), h0=h0.astype(np.float32), target=target.astype(np.float32),
              H=H.detach().numpy().astype(np.float32), params=f32(p), grad_sum=f32(g_sum), grad_sum_h0=gh0_sum.astype(np.float32),
              grad_l1=f32(g_l1), grad_l1_h0=h0t.grad.numpy().astype(np.float32))
+
+
+def g9_fused_bptt_edge():
+    """G9 for the edge-gated cells (round 2: fused attention kernels): same graph, operands and losses, the reference's
+    GraphAttentional gates (graphML.py:2409-2416) under autograd."""
+    g9_fused_bptt((('edge', False, 'edge'), ('time_edge', True, 'edge')))
 
 
 def g10_kstep_data():
@@ -407,5 +414,6 @@ if __name__ == '__main__':
     g7_csr()
     g8_midsize()
     g9_fused_bptt()
+    g9_fused_bptt_edge()
     g10_kstep_data()
     print('all oracle checks passed at tol', TOL)

@@ -149,7 +149,8 @@ def test_kstep_dataset_reproduces_reference_samples(golden):
         assert np.max(np.abs(ys.numpy() - g[split + '_labels'])) <= 1e-12
 
 
-@pytest.mark.parametrize('name,tg,sg', [('none', False, None), ('time', True, None), ('node', False, 'node')])
+@pytest.mark.parametrize('name,tg,sg', [('none', False, None), ('time', True, None), ('node', False, 'node'), ('edge', False, 'edge'),
+                                        ('time_edge', True, 'edge')])
 def test_oracle_reproduces_g9_states(golden, name, tg, sg):
     """G9 stores the reference's states as float32: the oracle on the fixture's operands agrees to that rounding."""
     g = golden('g9_fused_' + name)
