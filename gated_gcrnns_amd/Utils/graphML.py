@@ -335,6 +335,12 @@ class GGCRNNCell(nn.Module):
             return self._forward_small(X, h0, train=True)
         if self._use_horner(X, h0):
             return self._forward_horner(X, h0)
+        if self.weight_A.dtype == torch.bfloat16:
+            # bf16 parameters in a variant / shape without bf16 kernels: the composed path has fp32 and fp64 kernels only, so it runs on
+            # fp32 views of the parameters (differentiable casts: gradients reach the bf16 parameters) and returns bf16 states
+            from torch.func import functional_call
+            p32 = {k: v.float() for k, v in self.named_parameters()}
+            return functional_call(self, p32, (X.float(), h0.float())).to(torch.bfloat16)
         if X.dtype != self.weight_A.dtype:      # e.g. bf16 batches meeting fp32 master weights in a variant without fused
             X, h0 = X.to(self.weight_A.dtype), h0.to(self.weight_A.dtype)      # kernels: the composed path runs in the parameters' dtype
         Xn = ops.pack_node_major(X)                                     # T x N x B x G

@@ -690,3 +690,37 @@ def test_streaming_spmm_edge_cases(dev):
         ops.spmm_raw(g.fwd[0], X, out=Y, accumulate=True, bias=bias, bias_scale=2.0, tanh=True)
         want = torch.tanh(ref + 2.0 * bias.repeat(L // bias.numel()))
         assert float((Y - want).abs().max()) <= 1e-12, L
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('sg,tg', [('edge', False), ('node', True), (None, True)])
+def test_bf16_parameters_without_bf16_kernels_run_on_fp32_views(sg, tg):
+    """A cell moved to bf16 at a shape no bf16 kernel covers (F = 12) runs the composed path on fp32 views of its parameters:
+    states equal the fp32 cell's up to the bf16 rounding of parameters / output, and gradients reach the bf16 parameters."""
+    import gated_gcrnns_amd.Utils.graphML as gml
+    dev = torch.device('cuda:0')
+    rng = np.random.default_rng(5)
+    N, G, F, K, B, T = 50, 3, 12, 3, 4, 5
+    S = (rng.random((1, N, N)) < 0.15) * rng.uniform(0.2, 1.0, (1, N, N))
+    S = S / np.max(np.abs(np.linalg.eigvals(S[0])))
+    torch.manual_seed(3)
+    cell = gml.GGCRNNCell(G, F, K, K, torch.tanh, tg, sg, 1, True)
+    cell.addGSO(torch.tensor(S))
+    cell = cell.to(dev).to(torch.bfloat16)
+    ref = gml.GGCRNNCell(G, F, K, K, torch.tanh, tg, sg, 1, True)
+    ref.addGSO(torch.tensor(S))
+    ref.load_state_dict({k: v.float() for k, v in cell.state_dict().items()})
+    ref = ref.to(dev)
+    X = torch.tensor(rng.standard_normal((B, T, G, N)), dtype=torch.float32, device=dev).to(torch.bfloat16)
+    h0 = torch.tensor(0.3 * rng.standard_normal((B, F, N)), dtype=torch.float32, device=dev).to(torch.bfloat16)
+    with torch.no_grad():
+        H = cell(X, h0)
+        Hr = ref(X.float(), h0.float())
+    assert H.dtype == torch.bfloat16
+    assert float((H.float() - Hr).abs().max()) <= 1.0 / 128                  # |h| < 1: half a bf16 ulp is 2^-9
+    Hg = cell(X, h0)
+    Hg.float().square().mean().backward()
+    for n, p in cell.named_parameters():
+        if 'GFL_out' in n or 'MLP_out' in n:
+            continue
+        assert p.grad is not None and p.grad.dtype == torch.bfloat16 and torch.isfinite(p.grad.float()).all(), n
