@@ -16,6 +16,8 @@ stats bench_f32_x3 --dtype f32 --steps 3 --warmup 1
 stats bench_train_bf16 --mode train --steps 3 --warmup 1
 stats bench_train_timegated --mode train --time-gating --steps 3 --warmup 1
 stats bench_train_nodegated --mode train --spatial-gating node --steps 3 --warmup 1
+stats bench_fwd_edgegated --spatial-gating edge --steps 3 --warmup 1
+stats bench_train_edgegated --mode train --spatial-gating edge --steps 3 --warmup 1
 stats bench_cfg5_bf16 --config cfg5 --steps 3 --warmup 1
 stats bench_cfg5_f32 --config cfg5 --dtype f32 --steps 2 --warmup 1
 stats bench_cfg4 --config cfg4 --steps 5 --warmup 2
