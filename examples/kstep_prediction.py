@@ -6,8 +6,8 @@
     python examples/kstep_prediction.py --nodes 1000 --features 64 --seq 32 --dtype bf16 --ntrain 1024 --batch 256 --sparse
 
 Defaults follow the reference driver (N=80 SBM 0.8/0.2, 5 taps, K=seqLen=5, F=20, batch 100, Adam 1e-3). --dtype bf16 feeds
-bf16 batches to fp32 master weights: GCRNN and TimeGCRNN then run on the fused kernels (N <= 1024, F in {32, 64}), the node- and
-edge-gated variants on the composed path in fp32. --sparse draws the BASELINE configs[1] graph (mean degree ~10).
+bf16 batches to fp32 master weights: all four variants (un-gated, time-, node- and edge-gated) then train on the fused kernels
+(N <= 1024, F in {32, 64}; other shapes: composed path in fp32). --sparse draws the BASELINE configs[1] graph (mean degree ~10).
 """
 import argparse
 import os

@@ -611,11 +611,11 @@ def test_kstep_on_device_reproduces_reference_dataset(dev, golden):
 
 @pytest.mark.parametrize('argv', [['--epochs', '1', '--ntrain', '1000', '--models', 'GCRNNMLP,TimeGCRNNMLP,NodeGCRNNMLP,EdgeGCRNNMLP'],
                                   ['--epochs', '1', '--dtype', 'bf16', '--sparse', '--nodes', '1000', '--features', '64', '--seq', '8',
-                                   '--ntrain', '1024', '--batch', '128', '--models', 'GCRNNMLP,TimeGCRNNMLP']])
+                                   '--ntrain', '1024', '--batch', '128', '--models', 'GCRNNMLP,TimeGCRNNMLP,NodeGCRNNMLP,EdgeGCRNNMLP']])
 def test_kstep_driver_counterpart_trains(dev, argv):
     """examples/kstep_prediction.py (counterpart of kStepPredGRNNs.py:598-1677) end to end: graph -> data -> models -> training
     with validation / checkpoints -> test metric; the training loss goes down. Second case: the BASELINE configs[1] graph in
-    bf16 over fp32 master weights = the fused kernels."""
+    bf16 over fp32 master weights = the fused kernels, all four gating variants."""
     import importlib.util
     import os
     from conftest import ROOT
@@ -636,6 +636,7 @@ def test_kstep_driver_counterpart_trains(dev, argv):
 
 @pytest.mark.parametrize('argv', [['--config', 'cfg2', '--batch', '16'], ['--config', 'cfg2', '--batch', '16', '--dtype', 'f32'],
                                   ['--config', 'cfg2', '--batch', '8', '--mode', 'train'], ['--config', 'cfg2', '--batch', '8', '--mode', 'train', '--spatial-gating', 'node'],
+                                  ['--config', 'cfg2', '--batch', '8', '--spatial-gating', 'edge'], ['--config', 'cfg2', '--batch', '8', '--mode', 'train', '--spatial-gating', 'edge', '--time-gating'],
                                   ['--config', 'cfg4', '--batch', '8'], ['--config', 'cfg5', '--batch', '2']])
 def test_bench_lines_run(dev, argv):
     """Every bench configuration prints ONE well-formed JSON line with `roofline` (and, at N = 1, `cpu_baseline` unless switched
