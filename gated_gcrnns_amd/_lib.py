@@ -107,7 +107,7 @@ def _bind(lib):
         'gcrnn_fused_wgrad_slots': (_c_i64, [_c_i64, _c_i64]),
         'gcrnn_fused_backward_weight_bf16': (C.c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p,
                                                        _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_p, _c_p,
-                                                       C.c_int, _c_p, _c_p]),
+                                                       C.c_int, _c_p, C.c_double, _c_p]),
         'gcrnn_small_supported': (C.c_int, [C.c_int, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64]),
         'gcrnn_small_forward': (C.c_int, [C.c_int, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p,
                                           _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_p]),

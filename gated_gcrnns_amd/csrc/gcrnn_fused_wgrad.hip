@@ -15,9 +15,12 @@
 //  - du_k is consumed by the GEMM of tap k and by the hop that produces du_{k+1}: no per-tap storage at all.
 // LDS: state fp32 [1024][16] (64 KiB) | graph image 96 B x entries | transposed half image (16.5 KiB).
 // ------------------------------------------------------------------------------------------
-namespace { constexpr int TSTRIDE = 1056; constexpr int TBYTES = 16 * TSTRIDE; }
+namespace { constexpr int TSTRIDE = 1056; constexpr int TBYTES = 16 * TSTRIDE; constexpr bool HT_IS_8 = (TILES == 8); }
 
-template <int K, int HS, int XS>
+// UNI (uniform-weight graphs, gcrnn_ell_fill_z): no weight image in LDS, so BOTH halves of the transposed du_k image fit; a tap
+// is then {images of all nodes} barrier {MFMAs of the first half | re-fetched fragments of the second half in two batches, the
+// second one in flight across the hop | adjoint hop on the uniform stream} barrier -- two barriers per tap instead of four.
+template <int K, int HS, int XS, int UNI>
 __global__ __launch_bounds__(512, 2) void fused_wgrad_kernel(
     const uint16_t* __restrict__ dpre,       // [T][B][NP][F] bf16 sequence-major
     const uint16_t* __restrict__ Xuser,      // [B][T][G][N] bf16
@@ -31,15 +34,15 @@ __global__ __launch_bounds__(512, 2) void fused_wgrad_kernel(
     const float* __restrict__ gf,            // [T][B] state-filter gates, or null
     int h_is_h0,                             // the state operand of EVERY item is h0 (gate sub-cells, graphML.py:2362, 2370)
     const int32_t* __restrict__ hzero,       // with h_is_h0 (or null): hzero[0] != 0 = h0 is all zeros: the state-feature waves skip their loads and MFMAs
-    int entries, int B, int Tn, int N) {
+    int entries, int B, int Tn, int N, float uni_w) {
   constexpr int F = 32 * HS, G = 32 * XS, C = F + G, NCH = F / FC, JT = C / 16;
   static_assert(JT <= WAVES, "one input-feature tile per wave");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* state = reinterpret_cast<float*>(smem);
   float4* lval4 = reinterpret_cast<float4*>(smem + NP * FC * 4);
-  uint2* lcol4 = reinterpret_cast<uint2*>(lval4 + entries * 4);
+  uint2* lcol4 = reinterpret_cast<uint2*>(lval4 + (UNI ? 0 : entries * 4));
   char* tbuf = reinterpret_cast<char*>(lcol4 + entries * 4);
-  float* lbias = reinterpret_cast<float*>(tbuf + TBYTES);          // [WAVES][16] bias-gradient partial sums, one row per wave (no LDS atomics)
+  float* lbias = reinterpret_cast<float*>(tbuf + (UNI ? 2 : 1) * TBYTES);      // [WAVES][16] bias-gradient partial sums, one row per wave (no LDS atomics)
 
   const int L = blockIdx.x;
   const int grp = L / (8 * NCH), rem = L - grp * (8 * NCH);
@@ -55,7 +58,7 @@ __global__ __launch_bounds__(512, 2) void fused_wgrad_kernel(
 
   {
     const int n = (entries >> 2) * 16;
-    for (int i = tid; i < n; i += 512) { lval4[i] = ell_val4[i]; lcol4[i] = ell_col4[i]; }
+    for (int i = tid; i < n; i += 512) { if (!UNI) lval4[i] = ell_val4[i]; lcol4[i] = ell_col4[i]; }
   }
   int tbeg[TILES], tend[TILES], woff[TILES];
 #pragma unroll
@@ -69,7 +72,7 @@ __global__ __launch_bounds__(512, 2) void fused_wgrad_kernel(
   const uint32_t lds0 = (uint32_t)reinterpret_cast<uintptr_t>(smem);
   const uint32_t qx = (uint32_t)qoff;
   const uint32_t lds_val = lds0 + NP * FC * 4;
-  const uint32_t lds_col = lds_val + entries * 64;
+  const uint32_t lds_col = lds_val + (UNI ? 0 : entries * 64);
 
   f32x4 accD[K];
 #pragma unroll
@@ -136,6 +139,74 @@ __global__ __launch_bounds__(512, 2) void fused_wgrad_kernel(
         if (r == 0) lbias[wave * FC + q * 4 + c] += v * gbias;                  // one owner lane per address, items in program order: deterministic
       }
     }
+    if constexpr (UNI != 0) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      // first batch of the second half's fragments: requested before the images are written, consumed after the first half
+      bf16x8 bl0[8];
+#pragma unroll
+      for (int s2 = 0; s2 < 8; ++s2)
+        bl0[s2] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsrc_z, vo + 64 * (16 + s2), 0, 0));
+      // S1: du_k -> LDS state rows (for the next hop) and the transposed bf16 images of both node halves
+#pragma unroll
+      for (int i = 0; i < TILES; ++i) {
+        int wv = woff[i];
+        asm volatile("" : "+v"(wv));
+        if (k < K - 1) *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(state) + (wv & 0xffff)) = cur[i];
+        const int node = wv >> 16;
+        char* tb = tbuf + (node >= 512 ? TBYTES - 512 * 2 : 0) + node * 2;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) *reinterpret_cast<uint16_t*>(tb + (q * 4 + c) * TSTRIDE) = f2bf(cur[i][c]);
+      }
+      __syncthreads();
+      // S2: D_k += du_k^T z over nodes 0..511 (register-resident fragments), then the first re-fetched batch (nodes 512..767)
+      if (live) {
+#pragma unroll
+        for (int s4 = 0; s4 < 16; s4 += 4) {
+          bf16x8 a4[4];
+#pragma unroll
+          for (int p = 0; p < 4; ++p)
+            a4[p] = *reinterpret_cast<const bf16x8*>(tbuf + r * TSTRIDE + (32 * (s4 + p) + 8 * q) * 2);
+#pragma unroll
+          for (int p = 0; p < 4; ++p) accD[k] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a4[p], bfr[s4 + p], accD[k], 0, 0, 0);
+        }
+#pragma unroll
+        for (int s4 = 0; s4 < 8; s4 += 4) {
+          bf16x8 a4[4];
+#pragma unroll
+          for (int p = 0; p < 4; ++p)
+            a4[p] = *reinterpret_cast<const bf16x8*>(tbuf + TBYTES + r * TSTRIDE + (32 * (s4 + p) + 8 * q) * 2);
+#pragma unroll
+          for (int p = 0; p < 4; ++p) accD[k] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a4[p], bl0[s4 + p], accD[k], 0, 0, 0);
+        }
+      }
+      // second batch (nodes 768..1023): in flight across the hop
+      bf16x8 bl1[8];
+#pragma unroll
+      for (int s2 = 0; s2 < 8; ++s2)
+        bl1[s2] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsrc_z, vo + 64 * (24 + s2), 0, 0));
+      if (k < K - 1) {
+        LGKM_WAIT(0);
+#define GCRNN_WG_INIT(i) f32x4{0.f, 0.f, 0.f, 0.f}
+#define GCRNN_WG_STORE(i, a) cur[i] = a
+        GCRNN_HOP_ASM_UNI_STREAM(GCRNN_WG_INIT, GCRNN_WG_STORE);
+#undef GCRNN_WG_INIT
+#undef GCRNN_WG_STORE
+      }
+      if (live) {
+#pragma unroll
+        for (int s4 = 0; s4 < 8; s4 += 4) {
+          bf16x8 a4[4];
+#pragma unroll
+          for (int p = 0; p < 4; ++p)
+            a4[p] = *reinterpret_cast<const bf16x8*>(tbuf + TBYTES + r * TSTRIDE + (32 * (8 + s4 + p) + 8 * q) * 2);
+#pragma unroll
+          for (int p = 0; p < 4; ++p) accD[k] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a4[p], bl1[s4 + p], accD[k], 0, 0, 0);
+        }
+      }
+      __syncthreads();
+    }
+    } else {
 #pragma unroll
     for (int k = 0; k < K; ++k) {
       // S1: du_k -> LDS state rows (for the next hop) and the transposed bf16 image of nodes 0..511
@@ -233,6 +304,7 @@ __global__ __launch_bounds__(512, 2) void fused_wgrad_kernel(
       }
       __syncthreads();
     }
+    }
   }
   // ---- flush: D_k[f' = 4q + c][j = 16 wave + r] -> this slot's partial dW[it0][chunk*16 + f'][k][j] (every element of the
   // slot's [F][K][C] block is written by exactly one lane of one workgroup) ----------------------------------------------
@@ -268,9 +340,15 @@ static int fused_wgrad_t(const void* dpre, const void* Xuser, const void* Huser,
                          const FusedGraphArgs& ga, const float* gi, const float* gf, int h_is_h0, const int32_t* hzero, int64_t B,
                          int64_t T, int64_t N, hipStream_t st) {
   constexpr int F = 32 * HS;
-  const size_t lds = (size_t)NP * FC * 4 + (size_t)ga.entries * 96 + TBYTES + WAVES * FC * 4;
+#if GCRNN_HOP_ASM
+  const bool uni = ga.uniform_w != 0.f && HT_IS_8;
+#else
+  const bool uni = false;
+#endif
+  const size_t lds = uni ? (size_t)NP * FC * 4 + (size_t)ga.entries * 32 + 2 * TBYTES + WAVES * FC * 4
+                         : (size_t)NP * FC * 4 + (size_t)ga.entries * 96 + TBYTES + WAVES * FC * 4;
   if (lds > 160 * 1024 || !ga.ell_val4 || !ga.ell_col4) return GCRNN_ERR_UNSUPPORTED;
-  auto kern = fused_wgrad_kernel<K, HS, XS>;
+  auto kern = uni ? fused_wgrad_kernel<K, HS, XS, 1> : fused_wgrad_kernel<K, HS, XS, 0>;
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
     return GCRNN_ERR_LAUNCH;
   const int NCH = F / FC;
@@ -279,7 +357,7 @@ static int fused_wgrad_t(const void* dpre, const void* Xuser, const void* Huser,
   kern<<<(unsigned)(slots * NCH), 512, lds, st>>>((const uint16_t*)dpre, (const uint16_t*)Xuser, (const uint16_t*)Huser,
                                                    (const uint16_t*)h0user, dW, dbsum, ga.tile_nodes, ga.tile_off,
                                                    (const float4*)ga.ell_val4, (const uint2*)ga.ell_col4, gi, gf, h_is_h0, hzero,
-                                                   (int)ga.entries, (int)B, (int)T, (int)N);
+                                                   (int)ga.entries, (int)B, (int)T, (int)N, ga.uniform_w);
   GCRNN_CHECK_LAUNCH();
   return GCRNN_OK;
 }
@@ -288,12 +366,12 @@ extern "C" int gcrnn_fused_backward_weight_bf16(const void* dpre, const void* Xu
                                                 float* dW, float* dbsum, const int32_t* tile_nodes, const int32_t* tile_off,
                                                 const void* ell_val4, const void* ell_col4, int64_t entries, int64_t B,
                                                 int64_t T, int64_t N, int64_t F, int64_t G, int64_t K, const float* gi,
-                                                const float* gf, int h_is_h0, const int32_t* h0_zero_flag, void* stream) {
+                                                const float* gf, int h_is_h0, const int32_t* h0_zero_flag, double uniform_w, void* stream) {
   if ((gi == nullptr) != (gf == nullptr)) return GCRNN_ERR_NULL_POINTER;
   if (!dpre || !Xuser || (!Huser && !h_is_h0) || !h0user || !dW || !tile_nodes || !tile_off || !ell_val4 || !ell_col4) return GCRNN_ERR_NULL_POINTER;
   if (B <= 0 || T <= 0 || N <= 0 || N > NP || N % 8 || entries < 0 || entries % 4 || B * T > (1 << 24)) return GCRNN_ERR_BAD_SHAPE;
   if (T * B * (NP * F * 2) > 2147483647LL) return GCRNN_ERR_BAD_SHAPE;      // 32-bit buffer offsets into dpre
-  const FusedGraphArgs ga{tile_nodes, tile_off, nullptr, nullptr, ell_val4, ell_col4, entries};
+  const FusedGraphArgs ga{tile_nodes, tile_off, nullptr, nullptr, ell_val4, ell_col4, entries, (float)uniform_w};
   hipStream_t st = as_stream(stream);
 #define GCRNN_WG_CASE(KK, HH, XX) \
   if (K == KK && F == 32 * HH && G == 32 * XX) return fused_wgrad_t<KK, HH, XX>(dpre, Xuser, Huser, h0user, dW, dbsum, ga, gi, gf, h_is_h0, h_is_h0 ? h0_zero_flag : nullptr, B, T, N, st);

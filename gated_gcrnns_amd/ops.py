@@ -1163,7 +1163,8 @@ def fused_backward_weight(dpre, X, H, h0, graph, F, G, K, want_bias=False, gi=No
     check(lib.gcrnn_fused_backward_weight_bf16(_p(dpre), _p(Xc), _p(Hc), _p(h0c), _p(dWp),
                                                _p(dbp), _p(plan['tile_slots']), _p(plan['tile_off']), _p(plan['ell_val4']),
                                                _p(plan['ell_col4']), plan['entries'], B, T, graph.N, F, G, K,
-                                               _p(gi), _p(gf), int(h_is_h0), _p(hzero), _stream()),
+                                               _p(gi), _p(gf), int(h_is_h0), _p(hzero),
+                                               0.0 if os.environ.get('GCRNN_WGRAD_NO_UNIFORM') else plan.get('uniform_w', 0.0), _stream()),      # env: A/B switch
           'fused_backward_weight')
     dW = dWp.sum(dim=0)                                   # fixed order over the slots: bit-reproducible
     dbs = dbp.sum(dim=0) if want_bias else None

@@ -372,6 +372,7 @@ int gcrnn_fused_backward_weight_bf16(const void* dpre, const void* Xuser, const 
                                      const void* ell_col4, int64_t entries, int64_t B, int64_t T, int64_t N, int64_t F,
                                      int64_t G, int64_t K, const float* gi, const float* gf, int h_is_h0,
                                      const int32_t* h0_zero_flag /* with h_is_h0 (or NULL): device int32, non-zero = h0 is all zeros */,
+                                     double uniform_w /* != 0: uniform-weight image (gcrnn_ell_fill_z): both image halves in LDS, two barriers per tap */,
                                      void* stream);
 
 /* ==== small-graph regime: the whole T-step recurrence of a sequence inside one workgroup, one launch ============
