@@ -277,15 +277,30 @@ extern "C" int gcrnn_fused_forward_bf16(const void* xs, const void* h0, void* hs
                                         const int32_t* tile_off, const int32_t* ell_col, const float* ell_val,
                                         const void* ell_val4, const void* ell_col4, int64_t entries, int64_t B,
                                         int64_t T, int64_t N, int64_t F, int64_t G, int64_t K, void* Huser,
-                                        int huser_last_only, void* const* step_events, double uniform_w, void* stream) {
+                                        int huser_last_only, void* const* step_events, double uniform_w, const void* Xuser_inline,
+                                        void* stream) {
   if (!xs || !h0 || !hs || !wpack || !tile_nodes || !tile_off || !ell_col || !ell_val) return GCRNN_ERR_NULL_POINTER;
   if ((gi == nullptr) != (gf == nullptr)) return GCRNN_ERR_NULL_POINTER;
+  if (Xuser_inline && (gi || step_events || (reinterpret_cast<uintptr_t>(Xuser_inline) & 15))) return GCRNN_ERR_BAD_SHAPE;
   if (B <= 0 || T <= 0 || N <= 0 || N > NP || B > (1 << 24) || entries < 0 || entries % 4) return GCRNN_ERR_BAD_SHAPE;
   if (B * (NP * (F > G ? F : G) * 2) > 2147483647LL || T * F * N > 2147483647LL) return GCRNN_ERR_BAD_SHAPE;   // 32-bit buffer offsets
   if (Huser && (N % 8 != 0 || (reinterpret_cast<uintptr_t>(Huser) & 15))) return GCRNN_ERR_BAD_SHAPE;
   const FusedGraphArgs ga{tile_nodes, tile_off, ell_col, ell_val, ell_val4, ell_col4, entries, (float)uniform_w};
   return fused_dispatch(gi ? 1 : 0, xs, h0, hs, wpack, bias, gi, gf, nullptr, nullptr, ga, B, T, N, F, G, K, as_stream(stream),
-                        nullptr, nullptr, nullptr, Huser, nullptr, step_events, huser_last_only);
+                        Xuser_inline, nullptr, nullptr, Huser, nullptr, step_events, huser_last_only);
+}
+
+// Can gcrnn_fused_forward_bf16 take Xuser_inline for this problem (un-gated cell, uniform-weight graph image that leaves LDS
+// room for the [G][NPad / (F/16)] input tile, N % 8 == 0)?
+extern "C" int gcrnn_fused_inline_pack_supported(int64_t N, int64_t F, int64_t G, int64_t K, int64_t entries, double uniform_w) {
+#if GCRNN_HOP_ASM && GCRNN_STEP_WAVES == 8
+  if (uniform_w == 0.0 || N % 8 || N > NP || G <= 0 || G % 32 || (F != 32 && F != 64) || entries % 4) return 0;
+  const size_t base = (size_t)NP * FC * 4 + (size_t)K * ((F + G) / 32) * 1024;
+  const size_t need = base + (size_t)entries * 32 + (size_t)G * (NP / (F / FC)) * 2;
+  return need <= 160 * 1024;
+#else
+  return 0;
+#endif
 }
 
 extern "C" int gcrnn_fused_gate_prepass_bf16(const void* xs, const void* h0, const void* wpack, const float* bias,

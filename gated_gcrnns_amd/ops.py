@@ -339,7 +339,8 @@ def fused_supported(N, F, G, Kin, Kst, dtype, E=1):
 
 def time_fused_step_kernel(X, h0, wA, wB, bias, graph, reps=3):
     """Average duration of ONE fused step launch, measured with HIP events on the launch stream
-    (inputs pre-packed, only the T step launches sit between the events)."""
+    (inputs pre-packed, only the T step launches sit between the events; on uniform-weight graphs each launch also lays out
+    x_{t+1}, exactly as in fused_cell_forward)."""
     X, wA = fused_pad_operands(X, wA.detach())
     B, T, G, N = X.shape
     F = wA.shape[0]
@@ -365,9 +366,11 @@ def time_fused_step_kernel(X, h0, wA, wB, bias, graph, reps=3):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize()
     e0.record()
+    inline = fused_inline_pack_ok(plan, N, F, G, K)      # the launches as the forward issues them: with the inline pack of x_{t+1} where it applies
     for _ in range(reps):
         check(lib.gcrnn_fused_forward_bf16(_p(xs), _p(h0s), _p(hs), _p(wpack), _p(b32), None, None, *_fused_graph_args(plan),
-                                           B, T, N, F, G, K, _p(H) if H is not None else None, 0, None, plan.get('uniform_w', 0.0), st),
+                                           B, T, N, F, G, K, _p(H) if H is not None else None, 0, None, plan.get('uniform_w', 0.0),
+                                           _p(Xc) if inline else None, st),
               'fused_forward')
     e1.record()
     torch.cuda.synchronize()
@@ -400,7 +403,15 @@ def _side_stream(dev):
     return s
 
 
-def fused_pack_inputs(X, h0, graph, overlap=False):
+def fused_inline_pack_ok(plan, N, F, G, K):
+    """The step kernel can lay out x_{t+1} itself (gcrnn_fused_forward_bf16 with Xuser_inline): uniform-weight graph image with LDS
+    room for the input tile, N % 8 == 0. GCRNN_NO_INLINE_PACK=1 switches it off (A/B)."""
+    if os.environ.get('GCRNN_NO_INLINE_PACK'):
+        return False
+    return bool(lib.gcrnn_fused_inline_pack_supported(int(N), int(F), int(G), int(K), int(plan['entries']), float(plan.get('uniform_w', 0.0))))
+
+
+def fused_pack_inputs(X, h0, graph, overlap=False, first_only=False):
     """user-layout bf16 X [B][T][G][N], h0 [B][F][N] -> sequence-major xs [T][B][NPad][G] and the state buffer
     hs_all [T+1][B][NPad][F] whose slot 0 holds h0 (slots 1..T receive h_1..h_T: hs_all[:T] is then the h_{t-1} operand of
     every step, which the gate-gradient pass reads as one array).
@@ -415,6 +426,9 @@ def fused_pack_inputs(X, h0, graph, overlap=False):
     xs = torch.empty((T, B, npad, G), dtype=torch.bfloat16, device=X.device)
     hs_all = torch.empty((T + 1, B, npad, F), dtype=torch.bfloat16, device=X.device)
     check(lib.gcrnn_pack_seq_major(_lib.BF16, _p(h0c), _p(hs_all), B, 1, F, N, npad, None, st), 'pack_seq')
+    if first_only:                                       # x_0 only: the step kernels lay out every later step themselves (inline pack)
+        check(lib.gcrnn_pack_seq_major_steps(_p(Xc), _p(xs), B, T, G, N, npad, 0, 1, 0, st), 'pack_seq_steps')
+        return xs, hs_all
     if not overlap:
         check(lib.gcrnn_pack_seq_major(_lib.BF16, _p(Xc), _p(xs), B, T, G, N, npad, None, st), 'pack_seq')
         return xs, hs_all
@@ -505,8 +519,14 @@ def fused_cell_forward(X, h0, wA, wB, bias, graph, gates=None, return_states=Fal
     X = X.contiguous()
     h0 = h0.contiguous()
     events = None
+    inline = False
     if packed is not None:
         xs, hs_all = packed
+    elif gates is None and gate_values is None and fused_inline_pack_ok(plan, N, F, G, K):
+        # un-gated cell on a uniform-weight graph: only x_0 is packed here, launch t lays out x_{t+1} itself (LDS-DMA into the room
+        # the missing weight image leaves, read back transposed after the epilogue) -- no pack pass over X
+        xs, hs_all = fused_pack_inputs(X, h0, graph, first_only=True)
+        inline = True
     elif gates is None and fused_overlap_ok(X):          # (the gate pre-passes read every x_t at once: nothing to hide behind)
         xs, hs_all, events = fused_pack_inputs(X, h0, graph, overlap=True)
     else:
@@ -534,7 +554,8 @@ def fused_cell_forward(X, h0, wA, wB, bias, graph, gates=None, return_states=Fal
     if events is not None:                               # raw hipEvent_t handles, one slot per step (host array, read during the call)
         evs = (C.c_void_p * T)(*[(e.cuda_event if e is not None else None) for e in events])
     check(lib.gcrnn_fused_forward_bf16(_p(xs), _p(h0s), _p(hs), _p(wpack), _p(b32), _p(gi), _p(gf), *_fused_graph_args(plan),
-                                       B, T, N, F, G, K, _p(H) if direct else None, int(last_only), evs, plan.get('uniform_w', 0.0), st),
+                                       B, T, N, F, G, K, _p(H) if direct else None, int(last_only), evs, plan.get('uniform_w', 0.0),
+                                       _p(X) if inline else None, st),
           'fused_forward')
     if not direct:
         src = hs[T - 1:] if last_only else hs

@@ -295,11 +295,15 @@ int gcrnn_fused_pack_weights(int wdtype, const void* wA, const void* wB, void* w
  * gcrnn_ell_fill_z (padding entries aimed at zero rows): the step kernels then keep only the column words in LDS and sum the
  * gathered rows (acc = init + w * sum). 0 = weighted graph image. The same trailing parameter exists on the gate pre-pass, the
  * filter-output pass, the node-gated steps and both BPTT data chains. */
+int gcrnn_fused_inline_pack_supported(int64_t N, int64_t F, int64_t G, int64_t K, int64_t entries, double uniform_w);
 int gcrnn_fused_forward_bf16(const void* xs, const void* h0, void* hs, const void* wpack, const float* bias,
                              const float* gi, const float* gf, const int32_t* tile_nodes, const int32_t* tile_off,
                              const int32_t* ell_col, const float* ell_val, const void* ell_val4, const void* ell_col4,
                              int64_t entries, int64_t B, int64_t T, int64_t N, int64_t F, int64_t G, int64_t K,
-                             void* Huser, int huser_last_only, void* const* step_events, double uniform_w, void* stream);
+                             void* Huser, int huser_last_only, void* const* step_events, double uniform_w,
+                             const void* Xuser_inline /* NULL, or X [B][T][G][N] bf16 in the user layout: launch t also lays out x_{t+1} into
+                                xs[t+1] (only xs[0] has to be packed by the caller); un-gated cell, gcrnn_fused_inline_pack_supported() */,
+                             void* stream);
 
 /* Time-gate pre-pass (graphML.py:2357-2374): for every (t, b)
  *   sum over gate_out[t][b][0 .. F/16*8) = sum_{n,f} tanh( A_g(S) x_t + B_g(S) h0 + 2 b_g )[n][f] * gate_w[n][f]

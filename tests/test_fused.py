@@ -1130,3 +1130,37 @@ def test_fused_edge_attention_kernels_match_dense_autograd(N, F, items, gated):
     if gated:
         dg_ref = (r[:, :N].double().cpu() * torch.tensor(dpre)).sum(dim=(1, 2))
         assert float((dgate.double().cpu() - dg_ref).abs().max()) <= 1e-4 * float(dg_ref.abs().max()) + 1e-4
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('N,F,G,K,B,T', [(1000, 64, 64, 5, 5, 4), (1000, 64, 1, 3, 3, 3), (400, 32, 32, 3, 7, 3), (1000, 64, 64, 2, 2, 2),
+                                         (1000, 64, 32, 4, 3, 3)])
+def test_inline_pack_of_next_input_is_bit_identical(N, F, G, K, B, T, monkeypatch):
+    """Uniform-weight graphs: every launch of the un-gated recurrence lays out x_{t+1} itself (LDS-DMA of the user-layout rows,
+    transposed read-back after the epilogue) instead of a pack pass over X. Same bits as the packed path for the states, the
+    user-layout output and the sequence-major inputs it wrote (rows >= N zero); training forward included."""
+    import gated_gcrnns_amd.Utils.graphML as gml
+    from gated_gcrnns_amd import ops
+    dev = torch.device('cuda:0')
+    rng = np.random.default_rng(41)
+    W = (rng.random((N, N)) < 10.0 / N).astype(np.float64)
+    W = np.triu(W, 1); W = W + W.T
+    S = (W / np.max(np.abs(np.linalg.eigvalsh(W)))).reshape(1, N, N)
+    torch.manual_seed(11)
+    cell = gml.GGCRNNCell(G, F, K, K, torch.tanh, False, None, 1, True)
+    cell.addGSO(torch.tensor(S))
+    cell = cell.to(dev).to(torch.bfloat16)
+    X = torch.tensor(rng.standard_normal((B, T, G, N)), dtype=torch.float32, device=dev).to(torch.bfloat16)
+    h0 = torch.tensor(0.3 * rng.standard_normal((B, F, N)), dtype=torch.float32, device=dev).to(torch.bfloat16)
+    Xp, wA = ops.fused_pad_operands(X, cell.weight_A.detach())
+    plan = cell.graph.fused_plan()
+    assert plan['uniform_w'] != 0.0 and ops.fused_inline_pack_ok(plan, N, F, Xp.shape[2], K)
+    with torch.no_grad():
+        hs1, _, H1 = ops.fused_cell_forward(Xp, h0, wA, cell.weight_B, cell.bias, cell.graph, return_states=True)
+        Hl1 = cell(X, h0, last_only=True)
+        monkeypatch.setenv('GCRNN_NO_INLINE_PACK', '1')
+        assert not ops.fused_inline_pack_ok(plan, N, F, Xp.shape[2], K)
+        hs0, _, H0 = ops.fused_cell_forward(Xp, h0, wA, cell.weight_B, cell.bias, cell.graph, return_states=True)
+        Hl0 = cell(X, h0, last_only=True)
+    assert torch.equal(H0, H1) and torch.equal(hs0, hs1) and torch.equal(Hl0, Hl1)
+    assert float(hs1[:, :, N:].abs().max()) == 0.0
