@@ -448,8 +448,10 @@ extern "C" int gcrnn_fused_backward_data_bf16(const void* dHs, const void* hs, v
                                               const int32_t* tile_nodes, const int32_t* tile_off, const int32_t* ell_col,
                                               const float* ell_val, const void* ell_val4, const void* ell_col4,
                                               int64_t entries, int64_t B, int64_t T, int64_t N, int64_t F, int64_t K,
-                                              const float* gf, const void* h0s, float* dgf_parts, double uniform_w, void* stream) {
+                                              const float* gf, const void* h0s, float* dgf_parts, double uniform_w,
+                                              const void* dHuser_inline, void* stream) {
   if (dgf_parts && !h0s) return GCRNN_ERR_NULL_POINTER;
+  if (dHuser_inline && (reinterpret_cast<uintptr_t>(dHuser_inline) & 15)) return GCRNN_ERR_BAD_SHAPE;
   if (!dHs || !hs || !dpre || !wpackT || !tile_nodes || !tile_off || !ell_col || !ell_val) return GCRNN_ERR_NULL_POINTER;
   if (B <= 0 || T <= 0 || N <= 0 || N > NP || B > (1 << 24) || entries < 0 || entries % 4) return GCRNN_ERR_BAD_SHAPE;
   const int64_t step = B * NP * F;
@@ -458,7 +460,7 @@ extern "C" int gcrnn_fused_backward_data_bf16(const void* dHs, const void* hs, v
       (const uint16_t*)dHs + (T - 1) * step, (const uint16_t*)hs + (T - 1) * step, (uint16_t*)dpre + (T - 1) * step, step);
   GCRNN_CHECK_LAUNCH();
   const FusedGraphArgs ga{tile_nodes, tile_off, ell_col, ell_val, ell_val4, ell_col4, entries, (float)uniform_w};
-  return fused_dispatch(3, nullptr, nullptr, dpre, wpackT, nullptr, nullptr, gf, nullptr, dgf_parts, ga, B, T, N, F, 0, K,
+  return fused_dispatch(3, dHuser_inline, nullptr, dpre, wpackT, nullptr, nullptr, gf, nullptr, dgf_parts, ga, B, T, N, F, 0, K,
                         as_stream(stream), dHs, hs, dh0, nullptr, h0s);
 }
 

@@ -275,13 +275,17 @@ __global__ __launch_bounds__(STHREADS) void fused_step_kernel(
     int entries, int B, int hmod, int N,
     const int32_t* __restrict__ flags,     // EPI 1 (or null): flags[0] != 0 = the state operand h0 is all zeros -> its loads and MFMAs are skipped
     float uni_w,                           // UNI: the one weight of every non-zero
-    int xustride) {                        // EPI 0, UNI, inline pack of the NEXT step's input: aux0 = X[0][t+1] in the USER layout ([G][N] rows,
-                                           // xustride elements between sequences), gate_out = xs[t+1] (sequence-major, written here); or aux0 null
+    const uint16_t* __restrict__ pk_src,   // UNI, EPI 0 / EPI 2, inline pack of the NEXT launch's operand (or null): its USER-layout block of sequence 0
+                                           // (EPI 0: x_{t+1} = X[0][t+1], G rows of N; EPI 2: dH_{t-2} = dH[0][t-2], F rows of N), ...
+    uint16_t* __restrict__ pk_dst,         // ... the sequence-major array it is laid out into here ([B][NP][rows]) ...
+    int pk_stride) {                       // ... and the elements between consecutive sequences of the user-layout tensor
   static_assert(!UNI || (RESIDENT && GCRNN_HOP_ASM && GCRNN_STEP_WAVES == 8), "the uniform-weight stream is the asm stream on the resident graph");
   constexpr int KS = HS + XS;
   constexpr int F = 32 * HS, G = 32 * XS;
   constexpr int NCH = F / FC;
   constexpr bool GATEOUT = (EPI == 1 || EPI == 3);      // per-item scalar outputs (partials per chunk and wave)
+  // rows of the operand an inline pack lays out for the next launch (0: this instantiation has none)
+  constexpr int PKROWS = (UNI != 0 && EPI == 0 && XS > 0) ? G : ((UNI != 0 && EPI == 2 && XS == 0) ? F : 0);
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* state = reinterpret_cast<float*>(smem);
   uint4* wl = reinterpret_cast<uint4*>(smem + NP * FC * 4);
@@ -505,16 +509,17 @@ __global__ __launch_bounds__(STHREADS) void fused_step_kernel(
 #pragma unroll
   for (int j = GCRNN_HOP_FIRST; j < K; ++j) {
     if (GCRNN_PREFETCH_AT == 2 && K > 2 && j == K - 1) prefetch_next();
-    if constexpr (EPI == 0 && XS > 0 && UNI != 0) {
+    if constexpr (PKROWS > 0) {
       // Inline pack (uniform graphs leave LDS room next to the column image): this workgroup's node range [chunk NPC, +NPC) of
-      // x_{t+1}[b], all G feature rows of the USER layout, is requested by LDS-DMA (no registers) when the LAST hop starts and
-      // lands while that hop keeps the LDS busy; after the epilogue it is read back transposed and stored sequence-major --
-      // the separate pack pass over X disappears (only x_0 is packed by the caller).
-      if (j == K - 1 && aux0) {
-        constexpr int NPC = NP / NCH, PPR = NPC / 8, PIECES = G * PPR;
+      // the next launch's operand (EPI 0: x_{t+1}[b]; EPI 2: the upstream gradient dH_{t-2}[b]), all feature rows of the USER layout,
+      // is requested by LDS-DMA (no registers) when the LAST hop starts and lands while that hop keeps the LDS busy; after the
+      // epilogue it is read back transposed and stored sequence-major -- the separate pack pass over X (dH) disappears (only the
+      // first step(s) are packed by the caller).
+      if (j == K - 1 && pk_src) {
+        constexpr int NPC = NP / NCH, PPR = NPC / 8, PIECES = PKROWS * PPR;
         static_assert(PIECES % STHREADS == 0, "whole pieces per thread");
         char* xtile = smem + NP * FC * 4 + K * KS * 1024 + entries * 32;
-        const uint16_t* xsrc = aux0 + (int64_t)b * xustride + chunk * NPC;
+        const uint16_t* xsrc = pk_src + (int64_t)b * pk_stride + chunk * NPC;
 #pragma unroll
         for (int i = 0; i < PIECES / STHREADS; ++i) {
           // LDS slot id = (row, cs) receives the row's 8-node piece col = (cs - (row >> 3)) mod PPR: every group of 8 feature rows is
@@ -569,11 +574,11 @@ __global__ __launch_bounds__(STHREADS) void fused_step_kernel(
     }
   }
 
-  if constexpr (EPI == 0 && XS > 0 && UNI != 0) {
+  if constexpr (PKROWS > 0) {
     // inline pack: this wave's LDS-DMA pieces have had the whole last hop to land; wait for them HERE, before any barrier of the
     // epilogue -- hipcc only waits (vmcnt) before a wave's OWN aliasing LDS reads, i.e. after the barrier that is supposed to
     // publish the pieces to the other waves
-    if (aux0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (pk_src) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
   // ---- epilogue: bias, tanh, bf16 store into the node-major state h_t ------------------------------
   float bsum[4];
@@ -762,14 +767,15 @@ __global__ __launch_bounds__(STHREADS) void fused_step_kernel(
       __builtin_amdgcn_raw_buffer_store_b128(v, rsrc_u, (f * N + sg * 8) * 2, 0, GCRNN_STORE_POLICY);
     }
   }
-  if constexpr (EPI == 0 && XS > 0 && UNI != 0) {
-    if (aux0) {
-      // second half of the inline pack: the [G][NPC] tile (every wave waited for its DMA pieces before the epilogue's barriers) -> rows of
-      // 8-feature pieces; the G/8 pieces of a node sit in consecutive lanes (whole 16 G-byte rows per store), rows >= N are zeros
-      constexpr int NPC = NP / NCH, PCS = G / 8;
+  }
+  if constexpr (PKROWS > 0) {
+    if (pk_src) {
+      // second half of the inline pack: the [rows][NPC] tile (every wave waited for its DMA pieces before the epilogue) -> rows of
+      // 8-feature pieces; the pieces of a node sit in consecutive lanes (whole rows per store), rows >= N are zeros
+      constexpr int NPC = NP / NCH, PCS = PKROWS / 8;
       const char* xtile = smem + NP * FC * 4 + K * KS * 1024 + entries * 32;
-      if (!aux1) __syncthreads();                  // (with the user-layout output the two barriers above have already passed)
-      const __amdgpu_buffer_rsrc_t rsrc_xn = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<uint16_t*>(gate_out), 0, B * (NP * G * 2), 0x00020000);
+      if (!(EPI == 0 && aux1)) __syncthreads();   // (EPI 0 with the user-layout output: its two barriers have already passed)
+      const __amdgpu_buffer_rsrc_t rsrc_xn = __builtin_amdgcn_make_buffer_rsrc(pk_dst, 0, B * (NP * PKROWS * 2), 0x00020000);
       // all reads first, then the stores: the 16-byte stores' data registers stay untouched afterwards (a VALU write to them in the
       // very next instruction lost the first dword on gfx950 -- hipcc sees no hazard for a store with an SGPR soffset)
       constexpr int RI = PCS * NPC / STHREADS;
@@ -794,10 +800,9 @@ __global__ __launch_bounds__(STHREADS) void fused_step_kernel(
         const bool ok = node < N;
         typedef __attribute__((__vector_size__(4 * sizeof(unsigned int)))) unsigned int u32x4_t;
         __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{ok ? w4[i][0] : 0u, ok ? w4[i][1] : 0u, ok ? w4[i][2] : 0u, ok ? w4[i][3] : 0u}, rsrc_xn,
-                                               node * (G * 2) + pc * 16, b * (NP * G * 2), 0);
+                                               node * (PKROWS * 2) + pc * 16, b * (NP * PKROWS * 2), 0);
       }
     }
-  }
   }
   asm volatile("" ::"v"(prefetched));      // the prefetch load retires here at the latest
   __syncthreads();     // the last hop's reads of `state` are done before the next sequence overwrites it
@@ -806,7 +811,7 @@ __global__ __launch_bounds__(STHREADS) void fused_step_kernel(
 
 typedef void (*fused_kern_t)(const uint16_t*, const uint16_t*, uint16_t*, const uint4*, const float*, const float*,
                              const float*, const int32_t*, const int32_t*, const int32_t*, const float*, const float4*,
-                             const uint2*, const float*, float*, const uint16_t*, const uint16_t*, int, int, int, int, int, const int32_t*, float, int);
+                             const uint2*, const float*, float*, const uint16_t*, const uint16_t*, int, int, int, int, int, const int32_t*, float, const uint16_t*, uint16_t*, int);
 
 struct FusedGraphArgs {
   const int32_t* tile_nodes; const int32_t* tile_off; const int32_t* ell_col; const float* ell_val;
@@ -830,9 +835,12 @@ int fused_launch_t(int mode /*0 plain, 1 gated, 2 gate pre-pass, 3 BPTT data gra
   const bool resident = resident_bytes <= 160 * 1024 && ga.ell_val4 && ga.ell_col4;
   // inline pack of the next step's input (mode 0 with the user-layout X in bw_dHs): needs the uniform image and room for a
   // [G][NP / NCH] bf16 tile behind it
-  const size_t xtile_bytes = (size_t)G * (NP / (F / FC)) * 2;
-  const bool inline_pack = mode == 0 && bw_dHs != nullptr;
-  if (inline_pack && !(XS > 0 && uni && resident && N % 8 == 0 && resident_bytes + xtile_bytes <= 160 * 1024 && T * G * N <= 2147483647LL))
+  // (mode 3: the BPTT chain lays out dH_{t-2} the same way, the user-layout dH arrives in xs and the tile has F rows)
+  const bool inline_bw = mode == 3 && xs != nullptr;
+  const size_t xtile_bytes = (size_t)(inline_bw ? F : G) * (NP / (F / FC)) * 2;
+  const bool inline_pack = (mode == 0 && bw_dHs != nullptr) || inline_bw;
+  if (inline_pack && !((XS > 0 || inline_bw) && uni && resident && N % 8 == 0 && resident_bytes + xtile_bytes <= 160 * 1024 &&
+                       T * (inline_bw ? F : G) * N <= 2147483647LL))
     return GCRNN_ERR_UNSUPPORTED;
   const size_t lds = (resident ? resident_bytes : base) + (inline_pack ? xtile_bytes : 0);
   fused_kern_t kern;
@@ -886,7 +894,7 @@ int fused_launch_t(int mode /*0 plain, 1 gated, 2 gate pre-pass, 3 BPTT data gra
         kern<<<grid, STHREADS, lds, st>>>(dyh + (t - 1) * hstep, dyh + t * hstep, h + (t - 1) * hstep, (const uint4*)wpack, nullptr, nullptr,
                                      nullptr, ga.tile_nodes, ga.tile_off, ga.ell_col, ga.ell_val, (const float4*)ga.ell_val4,
                                      (const uint2*)ga.ell_col4, gate_w + (t - 1) * B * N, nullptr, dH + (t - 1) * hstep, hst + (t - 1) * hstep, 0,
-                                     (int)ga.entries, (int)B, (int)B, (int)N, nullptr, uni ? ga.uniform_w : 0.f, 0);
+                                     (int)ga.entries, (int)B, (int)B, (int)N, nullptr, uni ? ga.uniform_w : 0.f, nullptr, nullptr, 0);
     } else {
       return GCRNN_ERR_UNSUPPORTED;
     }
@@ -901,7 +909,7 @@ int fused_launch_t(int mode /*0 plain, 1 gated, 2 gate pre-pass, 3 BPTT data gra
                                    gi ? gf + t * B : nullptr, ga.tile_nodes, ga.tile_off, ga.ell_col, ga.ell_val,
                                    (const float4*)ga.ell_val4, (const uint2*)ga.ell_col4, gate_w + t * 2 * B * N, nullptr, yx + t * hstep,
                                    !huser ? nullptr : (!huser_last_only ? (const uint16_t*)huser + t * F * N : (t == T - 1 ? (const uint16_t*)huser : nullptr)),
-                                   (int)((huser_last_only ? 1 : T) * F * N), (int)ga.entries, (int)B, (int)B, (int)N, nullptr, uni ? ga.uniform_w : 0.f, 0);
+                                   (int)((huser_last_only ? 1 : T) * F * N), (int)ga.entries, (int)B, (int)B, (int)N, nullptr, uni ? ga.uniform_w : 0.f, nullptr, nullptr, 0);
     }
   } else if (mode == 5) {
     // filter output of every (t, b) item in one launch (split over whole time steps like mode 2 / 4): hs receives A(S)x_t + b
@@ -914,11 +922,11 @@ int fused_launch_t(int mode /*0 plain, 1 gated, 2 gate pre-pass, 3 BPTT data gra
       if (XS == 0)        // operand = one [T*B][NP][F] array (an input with G == F, packed like a state)
         kern<<<grid_for(items), STHREADS, lds, st>>>(nullptr, (const uint16_t*)h0 + t0 * hstep, h + t0 * hstep, (const uint4*)wpack, bias, nullptr, nullptr,
                                      ga.tile_nodes, ga.tile_off, ga.ell_col, ga.ell_val, (const float4*)ga.ell_val4, (const uint2*)ga.ell_col4,
-                                     nullptr, nullptr, nullptr, nullptr, 0, (int)ga.entries, (int)items, (int)items, (int)N, nullptr, uni ? ga.uniform_w : 0.f, 0);
+                                     nullptr, nullptr, nullptr, nullptr, 0, (int)ga.entries, (int)items, (int)items, (int)N, nullptr, uni ? ga.uniform_w : 0.f, nullptr, nullptr, 0);
       else                // operand [0 | x_t]: ONE all-zero state block shared by every item (hmod = 1)
         kern<<<grid_for(items), STHREADS, lds, st>>>(x + t0 * xstep, (const uint16_t*)h0, h + t0 * hstep, (const uint4*)wpack, bias, nullptr, nullptr,
                                      ga.tile_nodes, ga.tile_off, ga.ell_col, ga.ell_val, (const float4*)ga.ell_val4, (const uint2*)ga.ell_col4,
-                                     nullptr, nullptr, nullptr, nullptr, 0, (int)ga.entries, (int)items, 1, (int)N, nullptr, uni ? ga.uniform_w : 0.f, 0);
+                                     nullptr, nullptr, nullptr, nullptr, 0, (int)ga.entries, (int)items, 1, (int)N, nullptr, uni ? ga.uniform_w : 0.f, nullptr, nullptr, 0);
     }
   } else if (mode == 2 || mode == 4) {
     // no recurrence: all (t, b) items in one launch -- split over whole time steps where the 32-bit buffer offsets of
@@ -933,17 +941,17 @@ int fused_launch_t(int mode /*0 plain, 1 gated, 2 gate pre-pass, 3 BPTT data gra
       if (mode == 2)      // operands [h0 | x_t]; optional store of c_t = tanh(pre) into hs
         kern<<<grid_for(items), STHREADS, lds, st>>>(x + t0 * xstep, (const uint16_t*)h0, h ? h + t0 * hstep : nullptr, (const uint4*)wpack, bias,
                                      nullptr, nullptr, ga.tile_nodes, ga.tile_off, ga.ell_col, ga.ell_val, (const float4*)ga.ell_val4,
-                                     (const uint2*)ga.ell_col4, gate_w, go, nullptr, nullptr, 0, (int)ga.entries, (int)items, (int)B, (int)N, hzero_flag, uni ? ga.uniform_w : 0.f, 0);
+                                     (const uint2*)ga.ell_col4, gate_w, go, nullptr, nullptr, 0, (int)ga.entries, (int)items, (int)B, (int)N, hzero_flag, uni ? ga.uniform_w : 0.f, nullptr, nullptr, 0);
       else if (XS == 0)   // operand = one [T*B][NP][F] array, per-item dpre in bw_dHs
         kern<<<grid_for(items), STHREADS, lds, st>>>(nullptr, (const uint16_t*)h0 + t0 * hstep, nullptr, (const uint4*)wpack, bias, nullptr, nullptr,
                                      ga.tile_nodes, ga.tile_off, ga.ell_col, ga.ell_val, (const float4*)ga.ell_val4,
                                      (const uint2*)ga.ell_col4, nullptr, go, (const uint16_t*)bw_dHs + t0 * hstep, nullptr, 0,
-                                     (int)ga.entries, (int)items, (int)items, (int)N, nullptr, uni ? ga.uniform_w : 0.f, 0);
+                                     (int)ga.entries, (int)items, (int)items, (int)N, nullptr, uni ? ga.uniform_w : 0.f, nullptr, nullptr, 0);
       else                // input filter with G != F: operand [0 | x_t] -- ONE all-zero state block shared by every item (hmod = 1)
         kern<<<grid_for(items), STHREADS, lds, st>>>(x + t0 * xstep, (const uint16_t*)h0, nullptr, (const uint4*)wpack, bias, nullptr, nullptr,
                                      ga.tile_nodes, ga.tile_off, ga.ell_col, ga.ell_val, (const float4*)ga.ell_val4,
                                      (const uint2*)ga.ell_col4, nullptr, go, (const uint16_t*)bw_dHs + t0 * hstep, nullptr, 0,
-                                     (int)ga.entries, (int)items, 1, (int)N, nullptr, uni ? ga.uniform_w : 0.f, 0);
+                                     (int)ga.entries, (int)items, 1, (int)N, nullptr, uni ? ga.uniform_w : 0.f, nullptr, nullptr, 0);
     }
   } else if (mode == 8) {
     // ONE BPTT step with explicit arrays (edge-gated cell: the operand of step t is the attention backward's output):
@@ -951,7 +959,7 @@ int fused_launch_t(int mode /*0 plain, 1 gated, 2 gate pre-pass, 3 BPTT data gra
     kern<<<grid_for(B), STHREADS, lds, st>>>(nullptr, (const uint16_t*)h0, h, (const uint4*)wpack, nullptr, nullptr, nullptr, ga.tile_nodes,
                                  ga.tile_off, ga.ell_col, ga.ell_val, (const float4*)ga.ell_val4, (const uint2*)ga.ell_col4, nullptr, nullptr,
                                  (const uint16_t*)bw_dHs, (const uint16_t*)bw_hs, 0, (int)ga.entries, (int)B, (int)B, (int)N, nullptr,
-                                 uni ? ga.uniform_w : 0.f, 0);
+                                 uni ? ga.uniform_w : 0.f, nullptr, nullptr, 0);
   } else if (mode == 3) {
     // BPTT: hs (= dpre, [T][B][NP][F]) already holds dpre_{T-1}; walk t = T-1 .. 1, then optionally d h0.
     // gf (time-gated cell, [T][B]): step t's recurrent gradient is scaled by its forget gate gf_t.
@@ -960,16 +968,19 @@ int fused_launch_t(int mode /*0 plain, 1 gated, 2 gate pre-pass, 3 BPTT data gra
     const uint16_t* hst = (const uint16_t*)bw_hs;
     const int64_t gstep = B * (NCH * SWAVES);             // gate_out (or null): [T][B][NCH*SWAVES] partials of <h_{t-1}, adjoint chain of dpre_t>
     for (int64_t t = T - 1; t >= 1; --t) {
+      // inline pack: this launch consumes dHs[t-1] and lays out dHs[t-2] from the user-layout dH (the caller packed the last two steps)
+      const uint16_t* dun = (inline_bw && t >= 2) ? (const uint16_t*)xs + (t - 2) * F * N : nullptr;
       kern<<<grid, STHREADS, lds, st>>>(nullptr, h + t * hstep, h + (t - 1) * hstep, (const uint4*)wpack, nullptr, nullptr,
                                    gf ? gf + t * B : nullptr, ga.tile_nodes, ga.tile_off, ga.ell_col, ga.ell_val,
                                    (const float4*)ga.ell_val4, (const uint2*)ga.ell_col4, nullptr, gate_out ? gate_out + t * gstep : nullptr,
-                                   dH + (t - 1) * hstep, hst + (t - 1) * hstep, 0, (int)ga.entries, (int)B, (int)B, (int)N, nullptr, uni ? ga.uniform_w : 0.f, 0);
+                                   dH + (t - 1) * hstep, hst + (t - 1) * hstep, 0, (int)ga.entries, (int)B, (int)B, (int)N, nullptr, uni ? ga.uniform_w : 0.f,
+                                   dun, dun ? const_cast<uint16_t*>(dH) + (t - 2) * hstep : nullptr, (int)(T * F * N));
     }
     if (bw_dh0 || gate_out)
       kern<<<grid, STHREADS, lds, st>>>(nullptr, h, (uint16_t*)bw_dh0, (const uint4*)wpack, nullptr, nullptr, gf, ga.tile_nodes,
                                    ga.tile_off, ga.ell_col, ga.ell_val, (const float4*)ga.ell_val4, (const uint2*)ga.ell_col4,
                                    nullptr, gate_out, nullptr, gate_out ? (const uint16_t*)bw_h0 : nullptr, 0, (int)ga.entries,
-                                   (int)B, (int)B, (int)N, nullptr, uni ? ga.uniform_w : 0.f, 0);
+                                   (int)B, (int)B, (int)N, nullptr, uni ? ga.uniform_w : 0.f, nullptr, nullptr, 0);
   } else {
     const unsigned grid = grid_for(B);
     for (int64_t t = 0; t < T; ++t) {
@@ -980,11 +991,11 @@ int fused_launch_t(int mode /*0 plain, 1 gated, 2 gate pre-pass, 3 BPTT data gra
       const uint16_t* xun = (inline_pack && t + 1 < T) ? (const uint16_t*)bw_dHs + (t + 1) * G * N : nullptr;
       kern<<<grid, STHREADS, lds, st>>>(x + t * xstep, hp, h + t * hstep, (const uint4*)wpack, bias, mode == 1 ? gi + t * B : nullptr,
                                    mode == 1 ? gf + t * B : nullptr, ga.tile_nodes, ga.tile_off, ga.ell_col, ga.ell_val,
-                                   (const float4*)ga.ell_val4, (const uint2*)ga.ell_col4, nullptr,
-                                   xun ? reinterpret_cast<float*>(const_cast<uint16_t*>(x) + (t + 1) * xstep) : nullptr, xun,
+                                   (const float4*)ga.ell_val4, (const uint2*)ga.ell_col4, nullptr, nullptr, nullptr,
                                    !huser ? nullptr : (!huser_last_only ? (const uint16_t*)huser + t * F * N : (t == T - 1 ? (const uint16_t*)huser : nullptr)),
                                    (int)((huser_last_only ? 1 : T) * F * N),
-                                   (int)ga.entries, (int)B, (int)B, (int)N, nullptr, uni ? ga.uniform_w : 0.f, (int)(T * G * N));
+                                   (int)ga.entries, (int)B, (int)B, (int)N, nullptr, uni ? ga.uniform_w : 0.f,
+                                   xun, xun ? const_cast<uint16_t*>(x) + (t + 1) * xstep : nullptr, (int)(T * G * N));
     }
   }
   GCRNN_CHECK_LAUNCH();

@@ -1141,7 +1141,23 @@ def _fused_pack_state_taps(w, K, st):
     return wpack
 
 
-def fused_backward_data(dHs, hs, wB, graph, want_dh0=True, gf=None, h0s=None, bias=None):
+def fused_pack_upstream(dH, graph, K):
+    """dH [B][T][F][N] bf16 (user layout) -> (dHs [T][B][NPad][F] sequence-major, dH_user or None). On uniform-weight graphs only the
+    last two steps are packed here and dH_user = dH: the BPTT launch that consumes dHs[t-1] lays out dHs[t-2] itself (inline pack,
+    gcrnn_fused_backward_data_bf16 with dHuser_inline); otherwise the whole tensor is packed and dH_user is None."""
+    B, T, F, N = dH.shape
+    plan = graph.fused_plan(adjoint=True)
+    npad = plan['npad']
+    st = _stream()
+    dHs = torch.empty((T, B, npad, F), dtype=torch.bfloat16, device=dH.device)
+    if fused_inline_pack_ok(plan, N, F, F, K) and dH.data_ptr() % 16 == 0:
+        check(lib.gcrnn_pack_seq_major_steps(_p(dH), _p(dHs), B, T, F, N, npad, max(T - 2, 0), T, 0, st), 'pack_seq_steps')
+        return dHs, dH
+    check(lib.gcrnn_pack_seq_major(_lib.BF16, _p(dH), _p(dHs), B, T, F, N, npad, None, st), 'pack_seq')
+    return dHs, None
+
+
+def fused_backward_data(dHs, hs, wB, graph, want_dh0=True, gf=None, h0s=None, bias=None, dH_user=None):
     """BPTT data-gradient chain of the fused cell. dHs, hs: [T][B][NPad][F] bf16 sequence-major (gradient of the loss
     w.r.t. every state; the states). gf: [T][B] fp32 forget gates of the time-gated cell or None.
     Returns (dpre [T][B][NPad][F] bf16, dh0 [B][NPad][F] bf16 or None), and with h0s ([1][B][NPad][F], the initial state)
@@ -1159,7 +1175,8 @@ def fused_backward_data(dHs, hs, wB, graph, want_dh0=True, gf=None, h0s=None, bi
     if h0s is not None:
         parts = torch.empty((T * B, (F // 16) * int(lib.gcrnn_fused_step_waves())), dtype=torch.float32, device=hs.device)
     check(lib.gcrnn_fused_backward_data_bf16(_p(dHs), _p(hs), _p(dpre), _p(dh0), _p(wpack), *_fused_graph_args(plan),
-                                             B, T, graph.N, F, K, _p(gf), _p(h0s), _p(parts), plan.get('uniform_w', 0.0), st), 'fused_backward_data')
+                                             B, T, graph.N, F, K, _p(gf), _p(h0s), _p(parts), plan.get('uniform_w', 0.0), _p(dH_user), st),
+          'fused_backward_data')
     if h0s is None:
         return dpre, dh0
     dgf = parts.sum(dim=1).view(T, B)
@@ -1311,15 +1328,14 @@ class _FusedCell(torch.autograd.Function):
         if gated:
             gi, gf = gi.detach().float().contiguous(), gf.detach().float().contiguous()
         dH = dH.to(torch.bfloat16).contiguous()
-        dHs = torch.empty((T, B, npad, F), dtype=torch.bfloat16, device=X.device)
-        check(lib.gcrnn_pack_seq_major(_lib.BF16, _p(dH), _p(dHs), B, T, F, N, npad, None, st), 'pack_seq')
+        dHs, dHu = fused_pack_upstream(dH, graph, K)
         wBk = wB if Kst == K else torch.cat([wB, wB.new_zeros(F, 1, K - Kst, F)], dim=2)
         dgf = None
         if gated and ctx.needs_input_grad[6]:
             dpre, dh0s, dgf = fused_backward_data(dHs, hs, wBk, graph, want_dh0=ctx.needs_input_grad[1], gf=gf,
-                                                  h0s=hs_all[:1], bias=bias)
+                                                  h0s=hs_all[:1], bias=bias, dH_user=dHu)
         else:
-            dpre, dh0s = fused_backward_data(dHs, hs, wBk, graph, want_dh0=ctx.needs_input_grad[1], gf=gf if gated else None)
+            dpre, dh0s = fused_backward_data(dHs, hs, wBk, graph, want_dh0=ctx.needs_input_grad[1], gf=gf if gated else None, dH_user=dHu)
         want_b = bias is not None and ctx.needs_input_grad[4]
         dW, dbs = fused_backward_weight(dpre, X, H, h0, graph, F, G, K, want_bias=True,
                                         gi=gi if gated else None, gf=gf if gated else None)       # [F][K][F+G], [F] fp32

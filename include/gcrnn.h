@@ -357,7 +357,10 @@ int gcrnn_fused_backward_data_bf16(const void* dHs, const void* hs, void* dpre, 
                                    const int32_t* tile_nodes, const int32_t* tile_off, const int32_t* ell_col,
                                    const float* ell_val, const void* ell_val4, const void* ell_col4, int64_t entries,
                                    int64_t B, int64_t T, int64_t N, int64_t F, int64_t K, const float* gf, const void* h0s,
-                                   float* dgf_parts, double uniform_w, void* stream);
+                                   float* dgf_parts, double uniform_w,
+                                   const void* dHuser_inline /* NULL, or dH [B][T][F][N] bf16 in the user layout: the launch that consumes dHs[t-1]
+                                      also lays out dHs[t-2] (the caller packs steps T-2, T-1 only); gcrnn_fused_inline_pack_supported(N, F, F, ...) */,
+                                   void* stream);
 
 /* BPTT weight gradient of the fused cell (adjoint of the taps, graphML.py:134-135), all T*B items in ONE launch:
  *   dW[f'][k][j] += sum_{t,b,n} g[t][b] (S^k dpre[t][b])[n][f'] * z[t][b][n][j],   z = [h_{t-1} | x_t],   j < F: weight_B (g = gf),

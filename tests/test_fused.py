@@ -1164,3 +1164,38 @@ def test_inline_pack_of_next_input_is_bit_identical(N, F, G, K, B, T, monkeypatc
         Hl0 = cell(X, h0, last_only=True)
     assert torch.equal(H0, H1) and torch.equal(hs0, hs1) and torch.equal(Hl0, Hl1)
     assert float(hs1[:, :, N:].abs().max()) == 0.0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('tg', [False, True])
+def test_inline_pack_in_the_bptt_chain_is_bit_identical(tg, monkeypatch):
+    """Training step on a uniform-weight graph: the forward launches lay out x_{t+1}, the BPTT launches dH_{t-2} (only the first /
+    last two steps go through the pack kernel). Same bits for every gradient as with the pack passes."""
+    import gated_gcrnns_amd.Utils.graphML as gml
+    dev = torch.device('cuda:0')
+    N, F, G, K, B, T = 1000, 64, 64, 5, 6, 5
+    rng = np.random.default_rng(43)
+    W = (rng.random((N, N)) < 10.0 / N).astype(np.float64)
+    W = np.triu(W, 1); W = W + W.T
+    S = (W / np.max(np.abs(np.linalg.eigvalsh(W)))).reshape(1, N, N)
+    torch.manual_seed(13)
+    cell = gml.GGCRNNCell(G, F, K, K, torch.tanh, tg, None, 1, True)
+    cell.addGSO(torch.tensor(S))
+    cell = cell.to(dev)
+    X = torch.tensor(rng.standard_normal((B, T, G, N)), dtype=torch.float32, device=dev).to(torch.bfloat16)
+    h0 = torch.tensor(0.3 * rng.standard_normal((B, F, N)), dtype=torch.float32, device=dev).to(torch.bfloat16)
+    tgt = torch.tensor(rng.standard_normal((B, T, F, N)), dtype=torch.float32, device=dev)
+
+    def step():
+        cell.zero_grad(set_to_none=True)
+        assert cell._use_fused_training(X, h0)
+        H = cell(X, h0)
+        torch.nn.functional.l1_loss(H.float(), tgt).backward()
+        return H.detach().clone(), {n: p.grad.clone() for n, p in cell.named_parameters() if p.grad is not None}
+
+    H1, g1 = step()
+    monkeypatch.setenv('GCRNN_NO_INLINE_PACK', '1')
+    H0, g0 = step()
+    assert torch.equal(H0, H1) and g0.keys() == g1.keys() and len(g1) >= 3
+    for n in g1:
+        assert torch.equal(g0[n], g1[n]), n
