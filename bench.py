@@ -336,6 +336,8 @@ def run_cfg2(ctx):
                 ops.fused_cell_forward(X, h0, cell.weight_A, cell.weight_B, cell.bias, cell.graph, return_states=True)
             torch.cuda.synchronize()
             kern = ops.time_fused_step_kernel(X, h0, cell.weight_A, cell.weight_B, cell.bias, cell.graph, reps=3)
+            if kern.get('inline_pack'):          # for comparison with earlier rounds: the same launches without the inline pack of x_{t+1}
+                kern['bare_avg_us'] = ops.time_fused_step_kernel(X, h0, cell.weight_A, cell.weight_B, cell.bias, cell.graph, reps=3, inline=False)['avg_us']
     kern3 = None
     if args.dtype == 'f32' and args.mode == 'fwd' and not args.time_gating and args.spatial_gating is None:
         from gated_gcrnns_amd import ops
@@ -383,6 +385,13 @@ def run_cfg2(ctx):
                            'mfma_util_note': 'taps GEMM flops executed per launch / duration / 2.5 PF dense bf16 peak'
                                              + (' (PMC: SQ_VALU_MFMA_BUSY_CYCLES %.3g per launch)' % tj['mfma_busy_cycles'] if tj and 'mfma_busy_cycles' in tj else ''),
                            'whole_step_GBps': achieved, 'device_ms_per_step': 1e3 * step_s}
+        if kern.get('inline_pack'):
+            # uniform-weight graph: every launch ALSO lays out x_{t+1} (the former pack pass over X: 2 N G B more bytes per launch that
+            # `achieved` does not count). frac is that of the launch as issued; the bare step kernel is timed next to it.
+            out['roofline']['inline_pack'] = {'extra_bytes_per_launch': 2 * elt * N * G * B, 'bare_kernel_avg_us': kern['bare_avg_us'],
+                                              'bare_frac': kbytes / (kern['bare_avg_us'] * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                                              'note': 'each launch also lays out the next step input from the user layout (LDS-DMA during the last '
+                                                      'hop); the separate pack pass over X (0.5 ms per forward at B = 256) is gone'}
     elif kern3 is not None:
         # the fp32-accurate fused step (three bf16 planes per operand): algorithmic bytes = the fp32 tensors of the API
         kbytes = 4 * N * (G + 2 * F) * B

@@ -337,7 +337,7 @@ def fused_supported(N, F, G, Kin, Kst, dtype, E=1):
             bool(lib.gcrnn_fused_supported(int(N), int(F), int(Gp), int(max(Kin, Kst)))))
 
 
-def time_fused_step_kernel(X, h0, wA, wB, bias, graph, reps=3):
+def time_fused_step_kernel(X, h0, wA, wB, bias, graph, reps=3, inline=None):
     """Average duration of ONE fused step launch, measured with HIP events on the launch stream
     (inputs pre-packed, only the T step launches sit between the events; on uniform-weight graphs each launch also lays out
     x_{t+1}, exactly as in fused_cell_forward)."""
@@ -366,7 +366,8 @@ def time_fused_step_kernel(X, h0, wA, wB, bias, graph, reps=3):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize()
     e0.record()
-    inline = fused_inline_pack_ok(plan, N, F, G, K)      # the launches as the forward issues them: with the inline pack of x_{t+1} where it applies
+    ok = fused_inline_pack_ok(plan, N, F, G, K)          # the launches as the forward issues them: with the inline pack of x_{t+1} where it
+    inline = ok if inline is None else (ok and inline)   # applies; inline=False times the bare step for comparison
     for _ in range(reps):
         check(lib.gcrnn_fused_forward_bf16(_p(xs), _p(h0s), _p(hs), _p(wpack), _p(b32), None, None, *_fused_graph_args(plan),
                                            B, T, N, F, G, K, _p(H) if H is not None else None, 0, None, plan.get('uniform_w', 0.0),
@@ -374,7 +375,7 @@ def time_fused_step_kernel(X, h0, wA, wB, bias, graph, reps=3):
               'fused_forward')
     e1.record()
     torch.cuda.synchronize()
-    return {'avg_us': 1e3 * e0.elapsed_time(e1) / (reps * T), 'launches': reps * T}
+    return {'avg_us': 1e3 * e0.elapsed_time(e1) / (reps * T), 'launches': reps * T, 'inline_pack': bool(inline)}
 
 
 def _fused_pack_weights(wA, wB, st):
