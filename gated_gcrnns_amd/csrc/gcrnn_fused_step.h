@@ -285,7 +285,7 @@ __global__ __launch_bounds__(STHREADS) void fused_step_kernel(
   constexpr int NCH = F / FC;
   constexpr bool GATEOUT = (EPI == 1 || EPI == 3);      // per-item scalar outputs (partials per chunk and wave)
   // rows of the operand an inline pack lays out for the next launch (0: this instantiation has none)
-  constexpr int PKROWS = (UNI != 0 && EPI == 0 && XS > 0) ? G : ((UNI != 0 && EPI == 2 && XS == 0) ? F : 0);
+  constexpr int PKROWS = (UNI != 0 && EPI == 0 && XS > 0 && !GATED) ? G : ((UNI != 0 && EPI == 2 && XS == 0) ? F : 0);   // (the gated cell's pre-passes need every x_t up front)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* state = reinterpret_cast<float*>(smem);
   uint4* wl = reinterpret_cast<uint4*>(smem + NP * FC * 4);
