@@ -776,32 +776,39 @@ __global__ __launch_bounds__(STHREADS) void fused_step_kernel(
       const char* xtile = smem + NP * FC * 4 + K * KS * 1024 + entries * 32;
       if (!(EPI == 0 && aux1)) __syncthreads();   // (EPI 0 with the user-layout output: its two barriers have already passed)
       const __amdgpu_buffer_rsrc_t rsrc_xn = __builtin_amdgcn_make_buffer_rsrc(pk_dst, 0, B * (NP * PKROWS * 2), 0x00020000);
-      // all reads first, then the stores: the 16-byte stores' data registers stay untouched afterwards (a VALU write to them in the
-      // very next instruction lost the first dword on gfx950 -- hipcc sees no hazard for a store with an SGPR soffset)
+      // gfx950: a 16-byte buffer store whose soffset is an SGPR followed IMMEDIATELY by a VALU write of its first data register
+      // loses that dword in a few lanes, rarely (hipcc models no hazard for this form and happily reuses one register tuple for
+      // consecutive stores). So: all LDS reads first; the RI pieces are built in RI DISTINCT tuples that stay reserved until every
+      // store has retired (s_waitcnt vmcnt(0) below); the stores take an immediate soffset (the form hipcc does pad).
       constexpr int RI = PCS * NPC / STHREADS;
-      uint32_t w4[RI][4];
+      typedef __attribute__((__vector_size__(4 * sizeof(unsigned int)))) unsigned int u32x4_t;
+      u32x4_t vv[RI];
 #pragma unroll
       for (int i = 0; i < RI; ++i) {
         const int id = i * STHREADS + tid;
         const int nl = id / PCS, pc = id - nl * PCS;
         const char* src = xtile + (pc * 8) * (NPC * 2) + ((nl + 8 * pc) & (NPC - 1)) * 2;      // rows 8 pc .. 8 pc + 7 share the rotation
+        uint32_t w4[4];
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) {
           const uint32_t lo = *reinterpret_cast<const uint16_t*>(src + (2 * jj) * (NPC * 2));
           const uint32_t hi = *reinterpret_cast<const uint16_t*>(src + (2 * jj + 1) * (NPC * 2));
-          w4[i][jj] = lo | (hi << 16);
+          w4[jj] = lo | (hi << 16);
         }
+        const bool ok = chunk * NPC + nl < N;
+        vv[i] = u32x4_t{ok ? w4[0] : 0u, ok ? w4[1] : 0u, ok ? w4[2] : 0u, ok ? w4[3] : 0u};
       }
+#pragma unroll
+      for (int i = 0; i < RI; ++i) asm volatile("" : "+v"(vv[i]));          // every piece materialised in its own tuple before the first store
 #pragma unroll
       for (int i = 0; i < RI; ++i) {
         const int id = i * STHREADS + tid;
         const int nl = id / PCS, pc = id - nl * PCS;
-        const int node = chunk * NPC + nl;
-        const bool ok = node < N;
-        typedef __attribute__((__vector_size__(4 * sizeof(unsigned int)))) unsigned int u32x4_t;
-        __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{ok ? w4[i][0] : 0u, ok ? w4[i][1] : 0u, ok ? w4[i][2] : 0u, ok ? w4[i][3] : 0u}, rsrc_xn,
-                                               node * (PKROWS * 2) + pc * 16, b * (NP * PKROWS * 2), 0);
+        __builtin_amdgcn_raw_buffer_store_b128(vv[i], rsrc_xn, (chunk * NPC + nl) * (PKROWS * 2) + pc * 16 + b * (NP * PKROWS * 2), 0, 0);
       }
+      asm volatile("s_waitcnt vmcnt(0)" ::"v"(vv[0]), "v"(vv[RI - 1]) : "memory");      // the tuples are released only after the stores retired
+#pragma unroll
+      for (int i = 1; i + 1 < RI; ++i) asm volatile("" ::"v"(vv[i]));
     }
   }
   asm volatile("" ::"v"(prefetched));      // the prefetch load retires here at the latest
