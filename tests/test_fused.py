@@ -1,4 +1,5 @@
 """Fused flagship path (bf16 step kernel): host-side ELL plan on CPU, kernel parity on the GPU."""
+import os
 import numpy as np
 import pytest
 import torch
@@ -1199,3 +1200,29 @@ def test_inline_pack_in_the_bptt_chain_is_bit_identical(tg, monkeypatch):
     assert torch.equal(H0, H1) and g0.keys() == g1.keys() and len(g1) >= 3
     for n in g1:
         assert torch.equal(g0[n], g1[n]), n
+
+
+@pytest.mark.gpu
+def test_inline_pack_full_size_repeated_forwards_match_the_packed_path():
+    """30 forwards at the bench's full size (B = 256, T = 32: 250k inline-packed (item, step) tiles) against the packed path, bit for
+    bit. Guards the store-data hazard found on gfx950 (a 16-byte buffer store with an SGPR soffset followed at once by a
+    VALU write of its first data register), which corrupted about one tile in 3 million before the read-back was restructured."""
+    import bench
+    import gated_gcrnns_amd.Utils.graphML as gml
+    dev = torch.device('cuda:0')
+    N, K, T, F, B = 1000, 5, 32, 64, 256
+    torch.manual_seed(0)
+    cell = gml.GGCRNNCell(F, F, K, K, torch.tanh, False, None, 1, True)
+    cell.addGSO(torch.tensor(bench.sbm_graph(N)))
+    cell = cell.to(torch.bfloat16).to(dev)
+    gen = torch.Generator(device=dev); gen.manual_seed(9)
+    X = torch.randn(B, T, F, N, device=dev, generator=gen).to(torch.bfloat16)
+    h0 = (0.3 * torch.randn(B, F, N, device=dev, generator=gen)).to(torch.bfloat16)
+    with torch.no_grad():
+        os.environ['GCRNN_NO_INLINE_PACK'] = '1'
+        try:
+            Href = cell(X, h0).clone()
+        finally:
+            del os.environ['GCRNN_NO_INLINE_PACK']
+        for r in range(30):
+            assert torch.equal(cell(X, h0), Href), r
