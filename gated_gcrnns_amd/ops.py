@@ -367,7 +367,7 @@ def time_fused_step_kernel(X, h0, wA, wB, bias, graph, reps=3, inline=None):
     torch.cuda.synchronize()
     e0.record()
     ok = fused_inline_pack_ok(plan, N, F, G, K)          # the launches as the forward issues them: with the inline pack of x_{t+1} where it
-    inline = ok if inline is None else (ok and inline)   # applies; inline=False times the bare step for comparison
+    inline = (ok if inline is None else (ok and inline)) and X.data_ptr() % 16 == 0     # applies; inline=False times the bare step for comparison
     for _ in range(reps):
         check(lib.gcrnn_fused_forward_bf16(_p(xs), _p(h0s), _p(hs), _p(wpack), _p(b32), None, None, *_fused_graph_args(plan),
                                            B, T, N, F, G, K, _p(H) if H is not None else None, 0, None, plan.get('uniform_w', 0.0),
@@ -523,7 +523,7 @@ def fused_cell_forward(X, h0, wA, wB, bias, graph, gates=None, return_states=Fal
     inline = False
     if packed is not None:
         xs, hs_all = packed
-    elif gates is None and gate_values is None and fused_inline_pack_ok(plan, N, F, G, K):
+    elif gates is None and gate_values is None and fused_inline_pack_ok(plan, N, F, G, K) and X.data_ptr() % 16 == 0:
         # un-gated cell on a uniform-weight graph: only x_0 is packed here, launch t lays out x_{t+1} itself (LDS-DMA into the room
         # the missing weight image leaves, read back transposed after the epilogue) -- no pack pass over X
         xs, hs_all = fused_pack_inputs(X, h0, graph, first_only=True)
