@@ -1226,3 +1226,34 @@ def test_inline_pack_full_size_repeated_forwards_match_the_packed_path():
             del os.environ['GCRNN_NO_INLINE_PACK']
         for r in range(30):
             assert torch.equal(cell(X, h0), Href), r
+
+
+@pytest.mark.gpu
+def test_edge_gated_training_falls_back_when_a_hub_exceeds_the_register_records():
+    """The attention backward keeps a row's edge records in registers (out-degree <= 32 incl. the self-loop). A graph with a hub row
+    must not take the fused training path (the composed path trains it instead); fused INFERENCE handles hubs (slow loop) and still
+    matches the composed path."""
+    import gated_gcrnns_amd.Utils.graphML as gml
+    dev = torch.device('cuda:0')
+    N, F, G, K, B, T = 200, 32, 32, 3, 3, 3
+    rng = np.random.default_rng(3)
+    S = (rng.random((N, N)) < 0.04) * rng.uniform(0.2, 1.0, (N, N))
+    S[7, :60] = rng.uniform(0.2, 1.0, 60)            # row 7 reaches 60 nodes; column 11 is reached by 70
+    S[:70, 11] = rng.uniform(0.2, 1.0, 70)
+    S = (S / np.max(np.abs(np.linalg.eigvals(S)))).reshape(1, N, N)
+    torch.manual_seed(2)
+    cell = gml.GGCRNNCell(G, F, K, K, torch.tanh, False, 'edge', 1, True)
+    cell.addGSO(torch.tensor(S))
+    cell = cell.to(torch.bfloat16).float().to(dev)
+    X = torch.tensor(rng.standard_normal((B, T, G, N)), dtype=torch.float32, device=dev).to(torch.bfloat16)
+    h0 = torch.tensor(0.3 * rng.standard_normal((B, F, N)), dtype=torch.float32, device=dev).to(torch.bfloat16)
+    assert cell.graph.edge_plan()['max_out_degree'] > 32
+    assert not cell._use_fused_training(X, h0)
+    H = cell(X, h0)                                   # composed path (fp32 parameters)
+    H.float().square().mean().backward()
+    assert cell.input_attention.mixer.grad is not None and torch.isfinite(cell.input_attention.mixer.grad).all()
+    with torch.no_grad():
+        assert cell._use_fused_edge(X, h0)
+        Hf = cell(X, h0)
+    err = (Hf.float() - H.detach().float()).abs()
+    assert float(err.max()) <= 4e-2 and float(err.mean()) <= 3e-3, (float(err.max()), float(err.mean()))
