@@ -129,6 +129,7 @@ def _bind(lib):
         'gcrnn_node_linear_bf16_backward': (C.c_int, [C.c_int, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_i64, _c_i64, _c_i64, _c_i64, _c_p]),
         'gcrnn_l1_loss_blocks': (_c_i64, [_c_i64]),
         'gcrnn_l1_loss': (C.c_int, [C.c_int, _c_p, _c_p, _c_p, _c_p, _c_i64, C.c_double, _c_p]),
+        'gcrnn_scale_unless_one': (C.c_int, [C.c_int, _c_p, _c_p, _c_i64, _c_p]),
         'gcrnn_attention_forward': (C.c_int, [C.c_int] + [_c_p] * 11 + [_c_i64] * 5 + [C.c_double, _c_p]),
         'gcrnn_attention_backward': (C.c_int, [C.c_int] + [_c_p] * 15 + [_c_i64] * 5 + [C.c_double, _c_p]),
         'gcrnn_ell_conflict_cycles': (C.c_int, [_c_p, _c_i64, _c_p, C.POINTER(_c_i64)]),

@@ -86,6 +86,35 @@ int l1_launch(const void* x, const void* y, void* grad, void* partial, int64_t n
   return GCRNN_OK;
 }
 
+// data[i] *= r[0] unless r[0] == 1 (then every workgroup returns after one scalar load): the upstream gradient of a scalar loss
+// is almost always exactly 1, and a full pass over a gradient the size of the state sequence just to multiply by it is 3 % of a
+// training step. r is a device scalar of the accumulation type.
+template <typename T, typename A, int ELEMS>
+__global__ __launch_bounds__(256) void scale_unless_one_kernel(T* __restrict__ data, const A* __restrict__ r, int64_t n) {
+  const A rv = r[0];
+  if (rv == A(1)) return;
+  const int64_t stride = (int64_t)gridDim.x * 256 * ELEMS;
+  for (int64_t base = ((int64_t)blockIdx.x * 256 + threadIdx.x) * ELEMS; base < n; base += stride) {
+    if (base + ELEMS <= n) {
+      T v[ELEMS];
+      *reinterpret_cast<uint4*>(v) = *reinterpret_cast<const uint4*>(data + base);
+#pragma unroll
+      for (int e = 0; e < ELEMS; ++e) st(v, e, (A)ld(v, e) * rv);
+      *reinterpret_cast<uint4*>(data + base) = *reinterpret_cast<const uint4*>(v);
+    } else {
+      for (int64_t i = base; i < n; ++i) st(data, i, (A)ld(data, i) * rv);
+    }
+  }
+}
+
+template <typename T, typename A, int ELEMS>
+int scale_launch(void* data, const void* r, int64_t n, int64_t nblocks, hipStream_t st_) {
+  GCRNN_PRE_LAUNCH();
+  scale_unless_one_kernel<T, A, ELEMS><<<(unsigned)nblocks, 256, 0, st_>>>((T*)data, (const A*)r, n);
+  GCRNN_CHECK_LAUNCH();
+  return GCRNN_OK;
+}
+
 }  // namespace
 
 // Number of partial sums (= workgroups) gcrnn_l1_loss writes for n elements.
@@ -104,5 +133,19 @@ extern "C" int gcrnn_l1_loss(int dtype, const void* x, const void* y, void* grad
   if (dtype == GCRNN_F32) return l1_launch<float, float, 4>(x, y, grad, partial, n, nb, inv_n, as_stream(stream));
   if (dtype == GCRNN_F64) return l1_launch<double, double, 2>(x, y, grad, partial, n, nb, inv_n, as_stream(stream));
   if (dtype == GCRNN_BF16) return l1_launch<uint16_t, float, 8>(x, y, grad, partial, n, nb, inv_n, as_stream(stream));
+  return GCRNN_ERR_BAD_DTYPE;
+}
+
+// data[i] *= r[0] in place, skipped entirely when the device scalar r[0] (fp32; fp64 for fp64 data) equals 1: the backward of a
+// scalar loss whose gradient tensor gcrnn_l1_loss has already written (d loss / d x = upstream * sign(x - y) / n, miscTools.py:112-119
+// under autograd) without a second pass over it in the common case upstream == 1.
+extern "C" int gcrnn_scale_unless_one(int dtype, void* data, const void* r, int64_t n, void* stream) {
+  if (!data || !r) return GCRNN_ERR_NULL_POINTER;
+  if (n <= 0) return GCRNN_ERR_BAD_SHAPE;
+  if (reinterpret_cast<uintptr_t>(data) & 15) return GCRNN_ERR_UNSUPPORTED;
+  const int64_t nb = gcrnn_l1_loss_blocks(n);
+  if (dtype == GCRNN_F32) return scale_launch<float, float, 4>(data, r, n, nb, as_stream(stream));
+  if (dtype == GCRNN_F64) return scale_launch<double, double, 2>(data, r, n, nb, as_stream(stream));
+  if (dtype == GCRNN_BF16) return scale_launch<uint16_t, float, 8>(data, r, n, nb, as_stream(stream));
   return GCRNN_ERR_BAD_DTYPE;
 }

@@ -1624,12 +1624,19 @@ class _L1Loss(torch.autograd.Function):
         partial = torch.empty((int(lib.gcrnn_l1_loss_blocks(n)),), dtype=acc_dt, device=xc.device)
         check(lib.gcrnn_l1_loss(dtype_code(xc.dtype), _p(xc), _p(yc), _p(grad), _p(partial), n, 1.0 / n, _stream()), 'l1_loss')
         ctx.grad = grad
+        ctx.scale = torch.ones((1,), dtype=acc_dt, device=xc.device) if want else None      # what ctx.grad currently carries (device scalar)
         return (partial.sum() / n).to(x.dtype)
 
     @staticmethod
     def backward(ctx, gout):
-        g = ctx.grad * gout.to(ctx.grad.dtype) if ctx.grad is not None else None
-        return (g if ctx.needs_input_grad[0] else None), (-g if ctx.needs_input_grad[1] else None)
+        g = ctx.grad
+        if g is not None:
+            # chain rule through the scalar loss WITHOUT a pass over g when the upstream gradient is 1 (loss.backward()): the kernel
+            # reads the device scalar r = gout / (scale g already carries) and returns at once when r == 1 (no host sync: capturable)
+            r = (gout.detach().to(ctx.scale.dtype).reshape(1) / ctx.scale).contiguous()
+            check(lib.gcrnn_scale_unless_one(dtype_code(g.dtype), _p(g), _p(r), g.numel(), _stream()), 'scale_unless_one')
+            ctx.scale = gout.detach().to(ctx.scale.dtype).reshape(1).clone()
+        return (g if ctx.needs_input_grad[0] else None), (-g if (g is not None and ctx.needs_input_grad[1]) else None)
 
 
 def l1_loss(x, y):

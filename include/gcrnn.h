@@ -468,6 +468,9 @@ int gcrnn_node_linear_bf16_backward(int wdtype, const void* h, const void* w, co
  * caller adds up in a fixed order and scales by inv_n. */
 int64_t gcrnn_l1_loss_blocks(int64_t n);
 int gcrnn_l1_loss(int dtype, const void* x, const void* y, void* grad, void* partial, int64_t n, double inv_n, void* stream);
+/* data[i] *= r[0] in place unless the DEVICE scalar r[0] (fp32; fp64 for fp64 data) equals 1 -- the chain rule through a scalar loss
+ * whose gradient tensor gcrnn_l1_loss already wrote, without a second pass over it when the upstream gradient is 1. */
+int gcrnn_scale_unless_one(int dtype, void* data, const void* r, int64_t n, void* stream);
 /* batchTimeMSELoss, the drivers' metric (Utils/miscTools.py:121-130): x, y as [R][C] matrices (R = batch * time rows,
  * C = N * F columns; F32 / F64 / BF16): out[0] = mean_c sqrt(sum_r (x - y)^2) / sqrt(sum_r y^2). part: scratch of
  * gcrnn_batch_time_mse_slabs(R, C) * 2 * C accumulators (fp64 for F64, else fp32); out: one accumulator. Deterministic. */
