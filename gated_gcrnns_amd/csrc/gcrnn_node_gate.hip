@@ -12,31 +12,57 @@ namespace {
 __device__ __forceinline__ float bf2f_(uint16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
 __device__ __forceinline__ uint16_t f2bf_(float f) { return __builtin_bit_cast(uint16_t, (__bf16)f); }
 
-// s[item][k][n] = sum_f d[item][n][f] w[k][f];  thread = (item = blockIdx.y, node)
-template <int F>
+template <int CTRL> __device__ __forceinline__ float dpp_f_(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+template <int LPN> __device__ __forceinline__ float group_sum_(float v) {      // sum over the LPN (4 or 8) aligned lanes of a node
+  v += dpp_f_<0xB1>(v);                 // quad_perm [1,0,3,2]
+  v += dpp_f_<0x4E>(v);                 // quad_perm [2,3,0,1]
+  if (LPN == 8) v += dpp_f_<0x141>(v);  // row_half_mirror: the other quad's total
+  return v;
+}
+
+// s[item][k][n] = sum_f d[item][n][f] w[k][f].  F/8 lanes per node, each owning one 16-byte piece of the row: a wave reads whole
+// 128-byte lines (the first version's thread-per-node walk touched 64 lines per load and staged the weights through LDS reads:
+// 0.95 ms per pass over 1 GB), the K partial dots are summed over the node's lanes by DPP, the weights live in registers.
+template <int F, int KMAX>
 __global__ __launch_bounds__(256) void node_gate_dot_kernel(const uint16_t* __restrict__ d, const float* __restrict__ w, float* __restrict__ s,
                                                             int N, int NPad, int K) {
-  __shared__ float ws[8 * F];
-  for (int i = threadIdx.x; i < K * F; i += 256) ws[i] = w[i];
-  __syncthreads();
-  const int n = blockIdx.x * 256 + threadIdx.x;
-  if (n >= N) return;
-  const int64_t item = blockIdx.y;
-  const uint4* row = reinterpret_cast<const uint4*>(d + (item * NPad + n) * F);
-  float acc[8];
+  constexpr int LPN = F / 8, NPP = 256 / LPN;
+  const int tid = threadIdx.x, p = tid % LPN, nl = tid / LPN;
+  const int64_t item = blockIdx.x;
+  float wr[KMAX][8];
 #pragma unroll
-  for (int k = 0; k < 8; ++k) acc[k] = 0.f;
+  for (int k = 0; k < KMAX; ++k)
 #pragma unroll
-  for (int j = 0; j < F / 8; ++j) {
-    const uint4 v = row[j];
-    const uint32_t p[4] = {v.x, v.y, v.z, v.w};
+    for (int j = 0; j < 8; ++j) wr[k][j] = k < K ? w[k * F + p * 8 + j] : 0.f;
+  const uint4* rows = reinterpret_cast<const uint4*>(d + item * NPad * F);
+  for (int base = 0; base < N; base += 2 * NPP) {                      // two independent rows per lane and trip
+    const int n0 = base + nl, n1 = base + NPP + nl;
+    const uint4 v0 = n0 < N ? rows[n0 * LPN + p] : uint4{0, 0, 0, 0};
+    const uint4 v1 = n1 < N ? rows[n1 * LPN + p] : uint4{0, 0, 0, 0};
+    const uint32_t q0[4] = {v0.x, v0.y, v0.z, v0.w}, q1[4] = {v1.x, v1.y, v1.z, v1.w};
+    float f0[8], f1[8];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      const float lo = __uint_as_float(p[e] << 16), hi = __uint_as_float(p[e] & 0xffff0000u);
-      for (int k = 0; k < K; ++k) acc[k] += lo * ws[k * F + 8 * j + 2 * e] + hi * ws[k * F + 8 * j + 2 * e + 1];
+      f0[2 * e] = __uint_as_float(q0[e] << 16); f0[2 * e + 1] = __uint_as_float(q0[e] & 0xffff0000u);
+      f1[2 * e] = __uint_as_float(q1[e] << 16); f1[2 * e + 1] = __uint_as_float(q1[e] & 0xffff0000u);
+    }
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+      if (k < K) {                                                        // (wave-uniform)
+        float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { a0 += wr[k][j] * f0[j]; a1 += wr[k][j] * f1[j]; }
+        a0 = group_sum_<LPN>(a0);                                         // every lane of the node's group now holds the full dot
+        a1 = group_sum_<LPN>(a1);
+        if ((k % LPN) == p) {                                             // lane k mod LPN of the group stores tap k
+          if (n0 < N) s[(item * K + k) * N + n0] = a0;
+          if (n1 < N) s[(item * K + k) * N + n1] = a1;
+        }
+      }
     }
   }
-  for (int k = 0; k < K; ++k) s[(item * K + k) * N + n] = acc[k];
 }
 
 // One workgroup per item: dpre_g[n][f] = (sum_k ds[k][n] w[k][f]) (1 - d[n][f]^2) overwrites d (bf16);
@@ -89,7 +115,7 @@ __global__ __launch_bounds__(512) void node_gate_dot_bwd_kernel(uint16_t* __rest
   if (kf < K * F) dw_part[item * (K * F) + kf] = dacc;
 }
 
-// Gate gradients of the node-gated cell for all items at once (one workgroup per item, thread per node):
+// Gate gradients of the node-gated cell for all items at once (one workgroup per item, F/8 lanes per node, coalesced 16-byte pieces):
 //   a[n] = sum_f dpre[n][f] Yx[n][f],  c[n] = sum_f dpre[n][f] Yh[n][f]
 //   d ni[n] = gi a[n],  d nf[n] = gf c[n],  d gi += ni[n] a[n],  d gf += nf[n] c[n],  dYx[n][:] = gi ni[n] dpre[n][:]
 template <int F>
@@ -98,43 +124,43 @@ __global__ __launch_bounds__(256) void node_cell_bwd_kernel(const uint16_t* __re
                                                             const float* __restrict__ gi, const float* __restrict__ gf,
                                                             uint16_t* __restrict__ dyx, float* __restrict__ dni, float* __restrict__ dnf,
                                                             float* __restrict__ dgi, float* __restrict__ dgf, int B, int N, int NPad) {
+  constexpr int LPN = F / 8, NPP = 256 / LPN;
   __shared__ float red[2][4];
+  const int tid = threadIdx.x, p = tid % LPN, nl = tid / LPN;
   const int64_t item = blockIdx.x;
   const int t = (int)(item / B), b = (int)(item - (int64_t)t * B);
   const float gin = gi ? gi[item] : 1.f, gfo = gf ? gf[item] : 1.f;
   const float* ni = ngates + ((int64_t)(t * 2 + 0) * B + b) * N;
   const float* nf = ngates + ((int64_t)(t * 2 + 1) * B + b) * N;
+  const uint4* dr = reinterpret_cast<const uint4*>(dpre + item * NPad * F);
+  const uint4* xr = reinterpret_cast<const uint4*>(yx + item * NPad * F);
+  const uint4* hr = reinterpret_cast<const uint4*>(yh + item * NPad * F);
+  uint4* orow = reinterpret_cast<uint4*>(dyx + item * NPad * F);
   float pgi = 0.f, pgf = 0.f;
-  for (int n = threadIdx.x; n < NPad; n += 256) {
-    const int64_t ro = (item * NPad + n) * F;
-    if (n >= N) {                                   // padding rows of dYx stay zero
-#pragma unroll
-      for (int j = 0; j < F / 8; ++j) reinterpret_cast<uint4*>(dyx + ro)[j] = uint4{0u, 0u, 0u, 0u};
-      continue;
-    }
+  for (int n = nl; n < NPad; n += NPP) {
+    if (n >= N) { orow[n * LPN + p] = uint4{0u, 0u, 0u, 0u}; continue; }      // padding rows of dYx stay zero (whole lane groups)
+    const uint4 dv = dr[n * LPN + p], xv = xr[n * LPN + p], hv = hr[n * LPN + p];
     const float nin = ni[n], nfn = nf[n];
     const float sc = gin * nin;
+    const uint32_t dp[4] = {dv.x, dv.y, dv.z, dv.w}, xp[4] = {xv.x, xv.y, xv.z, xv.w}, hp[4] = {hv.x, hv.y, hv.z, hv.w};
+    uint32_t op[4];
     float a = 0.f, c = 0.f;
 #pragma unroll
-    for (int j = 0; j < F / 8; ++j) {
-      const uint4 dv = reinterpret_cast<const uint4*>(dpre + ro)[j];
-      const uint4 xv = reinterpret_cast<const uint4*>(yx + ro)[j];
-      const uint4 hv = reinterpret_cast<const uint4*>(yh + ro)[j];
-      const uint32_t dp[4] = {dv.x, dv.y, dv.z, dv.w}, xp[4] = {xv.x, xv.y, xv.z, xv.w}, hp[4] = {hv.x, hv.y, hv.z, hv.w};
-      uint32_t op[4];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const float d0 = __uint_as_float(dp[e] << 16), d1 = __uint_as_float(dp[e] & 0xffff0000u);
-        a += d0 * __uint_as_float(xp[e] << 16) + d1 * __uint_as_float(xp[e] & 0xffff0000u);
-        c += d0 * __uint_as_float(hp[e] << 16) + d1 * __uint_as_float(hp[e] & 0xffff0000u);
-        op[e] = (uint32_t)f2bf_(sc * d0) | ((uint32_t)f2bf_(sc * d1) << 16);
-      }
-      reinterpret_cast<uint4*>(dyx + ro)[j] = uint4{op[0], op[1], op[2], op[3]};
+    for (int e = 0; e < 4; ++e) {
+      const float d0 = __uint_as_float(dp[e] << 16), d1 = __uint_as_float(dp[e] & 0xffff0000u);
+      a += d0 * __uint_as_float(xp[e] << 16) + d1 * __uint_as_float(xp[e] & 0xffff0000u);
+      c += d0 * __uint_as_float(hp[e] << 16) + d1 * __uint_as_float(hp[e] & 0xffff0000u);
+      op[e] = (uint32_t)f2bf_(sc * d0) | ((uint32_t)f2bf_(sc * d1) << 16);
     }
-    dni[item * N + n] = gin * a;
-    dnf[item * N + n] = gfo * c;
-    pgi += nin * a;
-    pgf += nfn * c;
+    orow[n * LPN + p] = uint4{op[0], op[1], op[2], op[3]};
+    a = group_sum_<LPN>(a);
+    c = group_sum_<LPN>(c);
+    if (p == 0) {
+      dni[item * N + n] = gin * a;
+      dnf[item * N + n] = gfo * c;
+      pgi += nin * a;
+      pgf += nfn * c;
+    }
   }
   for (int o = 32; o > 0; o >>= 1) { pgi += __shfl_down(pgi, o, 64); pgf += __shfl_down(pgf, o, 64); }
   if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = pgi; red[1][threadIdx.x >> 6] = pgf; }
@@ -172,11 +198,9 @@ extern "C" int gcrnn_node_gate_dot(const void* d, const float* w, float* s, int6
                                    void* stream) {
   if (!d || !w || !s) return GCRNN_ERR_NULL_POINTER;
   if (items <= 0 || items > 65535 * 64 || N <= 0 || NPad < N || K <= 0 || K > 8 || (F != 32 && F != 64)) return GCRNN_ERR_BAD_SHAPE;
-  if (items > 65535) return GCRNN_ERR_BAD_SHAPE;
   GCRNN_PRE_LAUNCH();
-  const dim3 grid((unsigned)cdiv(N, 256), (unsigned)items);
-  if (F == 64) node_gate_dot_kernel<64><<<grid, 256, 0, as_stream(stream)>>>((const uint16_t*)d, w, s, (int)N, (int)NPad, (int)K);
-  else node_gate_dot_kernel<32><<<grid, 256, 0, as_stream(stream)>>>((const uint16_t*)d, w, s, (int)N, (int)NPad, (int)K);
+  if (F == 64) node_gate_dot_kernel<64, 8><<<(unsigned)items, 256, 0, as_stream(stream)>>>((const uint16_t*)d, w, s, (int)N, (int)NPad, (int)K);
+  else node_gate_dot_kernel<32, 8><<<(unsigned)items, 256, 0, as_stream(stream)>>>((const uint16_t*)d, w, s, (int)N, (int)NPad, (int)K);
   GCRNN_CHECK_LAUNCH();
   return GCRNN_OK;
 }
