@@ -406,8 +406,9 @@ extern "C" int gcrnn_fused_node_backward_data_bf16(const void* dHs, const void* 
                                                    const void* wpackT, const int32_t* tile_nodes, const int32_t* tile_off,
                                                    const int32_t* ell_col, const float* ell_val, const void* ell_val4,
                                                    const void* ell_col4, int64_t entries, int64_t B, int64_t T, int64_t N, int64_t F,
-                                                   int64_t K, double uniform_w, void* stream) {
+                                                   int64_t K, double uniform_w, const void* dHuser_inline, void* stream) {
   if (!dHs || !hs || !dpre || !dyh || !ngf || !wpackT || !tile_nodes || !tile_off || !ell_col || !ell_val) return GCRNN_ERR_NULL_POINTER;
+  if (dHuser_inline && (reinterpret_cast<uintptr_t>(dHuser_inline) & 15)) return GCRNN_ERR_BAD_SHAPE;
   if (B <= 0 || T <= 0 || N <= 0 || N > NP || B > (1 << 24) || entries < 0 || entries % 4 || F % 2) return GCRNN_ERR_BAD_SHAPE;
   const int64_t step = B * NP * F;
   GCRNN_PRE_LAUNCH();
@@ -417,22 +418,27 @@ extern "C" int gcrnn_fused_node_backward_data_bf16(const void* dHs, const void* 
       (const uint16_t*)dpre + (T - 1) * step, ngf + (T - 1) * B * N, (uint16_t*)dyh + (T - 1) * step, B, (int)N, NP, (int)F);
   GCRNN_CHECK_LAUNCH();
   const FusedGraphArgs ga{tile_nodes, tile_off, ell_col, ell_val, ell_val4, ell_col4, entries, (float)uniform_w};
-  return fused_dispatch(7, dyh, nullptr, dpre, wpackT, nullptr, nullptr, nullptr, ngf, nullptr, ga, B, T, N, F, 0, K, as_stream(stream), dHs, hs);
+  return fused_dispatch(7, dyh, nullptr, dpre, wpackT, nullptr, nullptr, nullptr, ngf, nullptr, ga, B, T, N, F, 0, K, as_stream(stream), dHs, hs,
+                        nullptr, nullptr, dHuser_inline);
 }
 
 // ONE step of the BPTT data chain with explicit arrays (the edge-gated cell interleaves it with the attention backward):
 //   dpre_prev = (sum_k S^k (operand W_k) + dH_prev) (1 - h_prev^2);  operand, dH_prev, h_prev, dpre_prev: [B][NPad][F] bf16
 // sequence-major, wpackT = the transposed taps packed as a state-only operand (as in gcrnn_fused_backward_data_bf16).
+// dHuser_next / dHs_next (or both NULL): inline pack -- the user-layout block dH[0][t-2] (T = sequence length: its item stride is
+// T F N) is laid out into dHs_next = dHs[t-2] by this launch (uniform-weight graphs, gcrnn_fused_inline_pack_supported).
 // bwd_seed_kernel's formula dpre = dH (1 - h^2) for the last step is gcrnn_fused_backward_seed_bf16.
 extern "C" int gcrnn_fused_backward_step_bf16(const void* operand, const void* dH_prev, const void* h_prev, void* dpre_prev,
                                               const void* wpackT, const int32_t* tile_nodes, const int32_t* tile_off,
                                               const int32_t* ell_col, const float* ell_val, const void* ell_val4, const void* ell_col4,
-                                              int64_t entries, int64_t B, int64_t N, int64_t F, int64_t K, double uniform_w, void* stream) {
+                                              int64_t entries, int64_t B, int64_t N, int64_t F, int64_t K, double uniform_w,
+                                              const void* dHuser_next, void* dHs_next, int64_t T, void* stream) {
   if (!operand || !dH_prev || !h_prev || !dpre_prev || !wpackT || !tile_nodes || !tile_off || !ell_col || !ell_val) return GCRNN_ERR_NULL_POINTER;
   if (B <= 0 || N <= 0 || N > NP || B > (1 << 24) || entries < 0 || entries % 4) return GCRNN_ERR_BAD_SHAPE;
+  if ((dHuser_next == nullptr) != (dHs_next == nullptr) || (dHuser_next && (T <= 0 || (reinterpret_cast<uintptr_t>(dHuser_next) & 15)))) return GCRNN_ERR_BAD_SHAPE;
   const FusedGraphArgs ga{tile_nodes, tile_off, ell_col, ell_val, ell_val4, ell_col4, entries, (float)uniform_w};
-  return fused_dispatch(8, nullptr, operand, dpre_prev, wpackT, nullptr, nullptr, nullptr, nullptr, nullptr, ga, B, 1, N, F, 0, K,
-                        as_stream(stream), dH_prev, h_prev);
+  return fused_dispatch(8, dHuser_next, operand, dpre_prev, wpackT, nullptr, nullptr, nullptr, nullptr, nullptr, ga, B, dHuser_next ? T : 1, N, F, 0, K,
+                        as_stream(stream), dH_prev, h_prev, dHs_next);
 }
 
 extern "C" int gcrnn_fused_backward_seed_bf16(const void* dH, const void* h, void* dpre, int64_t elements, void* stream) {

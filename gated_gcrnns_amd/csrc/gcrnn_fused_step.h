@@ -843,7 +843,7 @@ int fused_launch_t(int mode /*0 plain, 1 gated, 2 gate pre-pass, 3 BPTT data gra
   // inline pack of the next step's input (mode 0 with the user-layout X in bw_dHs): needs the uniform image and room for a
   // [G][NP / NCH] bf16 tile behind it
   // (mode 3: the BPTT chain lays out dH_{t-2} the same way, the user-layout dH arrives in xs and the tile has F rows)
-  const bool inline_bw = mode == 3 && xs != nullptr;
+  const bool inline_bw = (mode == 3 && xs != nullptr) || (mode == 7 && bw_h0 != nullptr) || (mode == 8 && xs != nullptr);      // (mode 7: the user-layout dH arrives in bw_h0)
   const size_t xtile_bytes = (size_t)(inline_bw ? F : G) * (NP / (F / FC)) * 2;
   const bool inline_pack = (mode == 0 && bw_dHs != nullptr) || inline_bw;
   if (inline_pack && !((XS > 0 || inline_bw) && uni && resident && N % 8 == 0 && resident_bytes + xtile_bytes <= 160 * 1024 &&
@@ -897,11 +897,14 @@ int fused_launch_t(int mode /*0 plain, 1 gated, 2 gate pre-pass, 3 BPTT data gra
       const uint16_t* dH = (const uint16_t*)bw_dHs;
       const uint16_t* hst = (const uint16_t*)bw_hs;
       uint16_t* dyh = (uint16_t*)const_cast<void*>(xs);
-      for (int64_t t = T - 1; t >= 1; --t)
+      for (int64_t t = T - 1; t >= 1; --t) {
+        const uint16_t* dun = (inline_bw && t >= 2) ? (const uint16_t*)bw_h0 + (t - 2) * F * N : nullptr;      // inline pack of dH_{t-2}, as in mode 3
         kern<<<grid, STHREADS, lds, st>>>(dyh + (t - 1) * hstep, dyh + t * hstep, h + (t - 1) * hstep, (const uint4*)wpack, nullptr, nullptr,
                                      nullptr, ga.tile_nodes, ga.tile_off, ga.ell_col, ga.ell_val, (const float4*)ga.ell_val4,
                                      (const uint2*)ga.ell_col4, gate_w + (t - 1) * B * N, nullptr, dH + (t - 1) * hstep, hst + (t - 1) * hstep, 0,
-                                     (int)ga.entries, (int)B, (int)B, (int)N, nullptr, uni ? ga.uniform_w : 0.f, nullptr, nullptr, 0);
+                                     (int)ga.entries, (int)B, (int)B, (int)N, nullptr, uni ? ga.uniform_w : 0.f,
+                                     dun, dun ? const_cast<uint16_t*>(dH) + (t - 2) * hstep : nullptr, (int)(T * F * N));
+      }
     } else {
       return GCRNN_ERR_UNSUPPORTED;
     }
@@ -963,10 +966,11 @@ int fused_launch_t(int mode /*0 plain, 1 gated, 2 gate pre-pass, 3 BPTT data gra
   } else if (mode == 8) {
     // ONE BPTT step with explicit arrays (edge-gated cell: the operand of step t is the attention backward's output):
     // h0 = operand [B][NP][F], hs = dpre_{t-1} (out), bw_dHs = dH_{t-1}, bw_hs = h_{t-1}
+    // inline pack: xs = the user-layout block dH[0][t-2] (or null), bw_dh0 = dHs[t-2] to lay it out into, T = the sequence length
     kern<<<grid_for(B), STHREADS, lds, st>>>(nullptr, (const uint16_t*)h0, h, (const uint4*)wpack, nullptr, nullptr, nullptr, ga.tile_nodes,
                                  ga.tile_off, ga.ell_col, ga.ell_val, (const float4*)ga.ell_val4, (const uint2*)ga.ell_col4, nullptr, nullptr,
                                  (const uint16_t*)bw_dHs, (const uint16_t*)bw_hs, 0, (int)ga.entries, (int)B, (int)B, (int)N, nullptr,
-                                 uni ? ga.uniform_w : 0.f, nullptr, nullptr, 0);
+                                 uni ? ga.uniform_w : 0.f, (const uint16_t*)xs, (uint16_t*)bw_dh0, (int)(T * F * N));
   } else if (mode == 3) {
     // BPTT: hs (= dpre, [T][B][NP][F]) already holds dpre_{T-1}; walk t = T-1 .. 1, then optionally d h0.
     // gf (time-gated cell, [T][B]): step t's recurrent gradient is scaled by its forget gate gf_t.

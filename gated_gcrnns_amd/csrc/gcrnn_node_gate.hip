@@ -67,52 +67,75 @@ __global__ __launch_bounds__(256) void node_gate_dot_kernel(const uint16_t* __re
 
 // One workgroup per item: dpre_g[n][f] = (sum_k ds[k][n] w[k][f]) (1 - d[n][f]^2) overwrites d (bf16);
 // dw_part[item][k][f] = sum_n ds[k][n] d[n][f] (the caller adds the items in a fixed order).
-template <int F>
-__global__ __launch_bounds__(512) void node_gate_dot_bwd_kernel(uint16_t* __restrict__ d, const float* __restrict__ ds, const float* __restrict__ w,
+// F/8 lanes per node: a lane keeps its 8 features of the row, the K x 8 weights and its K x 8 partial sums of dw in registers (the
+// first version staged 128-row tiles in LDS and read every operand of every multiply-add from there: 0.8 ms per pass over 1 GB);
+// the partial sums are folded over the wave's nodes by xor shuffles, over the waves through 5 KB of LDS, in a fixed order.
+template <int F, int KMAX>
+__global__ __launch_bounds__(256) void node_gate_dot_bwd_kernel(uint16_t* __restrict__ d, const float* __restrict__ ds, const float* __restrict__ w,
                                                                 float* __restrict__ dw_part, int N, int NPad, int K) {
-  constexpr int RT = 128;                       // rows (nodes) per tile
-  __shared__ float ws[8 * F];
-  __shared__ float dss[8][RT];
-  __shared__ uint16_t ct[RT][F + 2];            // +2: odd word stride against bank conflicts of the column reads
-  const int tid = threadIdx.x;
+  constexpr int LPN = F / 8, NPP = 256 / LPN;
+  __shared__ float red[4][LPN][KMAX * 8];
+  const int tid = threadIdx.x, p = tid % LPN, nl = tid / LPN, wave = tid >> 6, lane = tid & 63;
   const int64_t item = blockIdx.x;
-  for (int i = tid; i < K * F; i += 512) ws[i] = w[i];
-  const int kf = tid;                           // phase 2 role: (k, f) = (tid / F, tid % F) for tid < K * F
-  float dacc = 0.f;
-  for (int n0 = 0; n0 < N; n0 += RT) {
-    __syncthreads();
-    // stage the tile: ds[k][n0 .. n0+RT) and the original d rows
-    for (int i = tid; i < K * RT; i += 512) {
-      const int k = i / RT, rr = i - k * RT;
-      dss[k][rr] = (n0 + rr < N) ? ds[(item * K + k) * N + n0 + rr] : 0.f;
+  float wr[KMAX][8], dacc[KMAX][8];
+#pragma unroll
+  for (int k = 0; k < KMAX; ++k)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { wr[k][j] = k < K ? w[k * F + p * 8 + j] : 0.f; dacc[k][j] = 0.f; }
+  uint4* rows = reinterpret_cast<uint4*>(d + item * NPad * F);
+  const float* dsi = ds + item * K * N;
+  constexpr int U = 4;                                // rows per lane and trip: all their loads are issued before the first store (the
+  for (int n0 = nl; n0 < N; n0 += U * NPP) {          // in-place update would otherwise serialise one memory latency per row)
+    uint4 v[U];
+    float dv[U][KMAX];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int n = n0 + u * NPP;
+      v[u] = n < N ? rows[n * LPN + p] : uint4{0u, 0u, 0u, 0u};
+#pragma unroll
+      for (int k = 0; k < KMAX; ++k) dv[u][k] = (k < K && n < N) ? dsi[k * N + n] : 0.f;
     }
-    for (int i = tid; i < RT * (F / 2); i += 512) {
-      const int rr = i / (F / 2), c2 = i - rr * (F / 2);
-      uint32_t v = 0;
-      if (n0 + rr < N) v = *reinterpret_cast<const uint32_t*>(d + (item * NPad + n0 + rr) * F + 2 * c2);
-      ct[rr][2 * c2] = (uint16_t)(v & 0xffffu);
-      ct[rr][2 * c2 + 1] = (uint16_t)(v >> 16);
-    }
-    __syncthreads();
-    // phase 1: the gate cell's pre-activation gradient, in place (thread = (row, feature pair))
-    for (int i = tid; i < RT * (F / 2); i += 512) {
-      const int rr = i / (F / 2), c2 = i - rr * (F / 2);
-      if (n0 + rr < N) {
-        float g0 = 0.f, g1 = 0.f;
-        for (int k = 0; k < K; ++k) { g0 += dss[k][rr] * ws[k * F + 2 * c2]; g1 += dss[k][rr] * ws[k * F + 2 * c2 + 1]; }
-        const float c0 = bf2f_(ct[rr][2 * c2]), c1 = bf2f_(ct[rr][2 * c2 + 1]);
-        *reinterpret_cast<uint32_t*>(d + (item * NPad + n0 + rr) * F + 2 * c2) =
-            (uint32_t)f2bf_(g0 * (1.f - c0 * c0)) | ((uint32_t)f2bf_(g1 * (1.f - c1 * c1)) << 16);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int n = n0 + u * NPP;
+      const uint32_t q4[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+      float c[8], g[8];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { c[2 * e] = __uint_as_float(q4[e] << 16); c[2 * e + 1] = __uint_as_float(q4[e] & 0xffff0000u); }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) g[j] = 0.f;
+#pragma unroll
+      for (int k = 0; k < KMAX; ++k) {
+        if (k < K) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) { g[j] += dv[u][k] * wr[k][j]; dacc[k][j] += dv[u][k] * c[j]; }
+        }
       }
-    }
-    // phase 2: dw[k][f] += sum_rows ds[k][row] d[row][f] (rows past N were staged as zeros)
-    if (kf < K * F) {
-      const int k = kf / F, f = kf - k * F;
-#pragma unroll 8
-      for (int rr = 0; rr < RT; ++rr) dacc += dss[k][rr] * bf2f_(ct[rr][f]);
+      uint32_t o4[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        o4[e] = (uint32_t)f2bf_(g[2 * e] * (1.f - c[2 * e] * c[2 * e])) | ((uint32_t)f2bf_(g[2 * e + 1] * (1.f - c[2 * e + 1] * c[2 * e + 1])) << 16);
+      if (n < N) rows[n * LPN + p] = uint4{o4[0], o4[1], o4[2], o4[3]};
     }
   }
-  if (kf < K * F) dw_part[item * (K * F) + kf] = dacc;
+  // fold over the nodes of a wave (lanes with equal p: xor 8, 16, 32 for LPN = 8; xor 4 .. 32 for LPN = 4), then over the waves
+#pragma unroll
+  for (int k = 0; k < KMAX; ++k) {
+    if (k < K) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float v = dacc[k][j];
+#pragma unroll
+        for (int off = LPN; off < 64; off <<= 1) v += __shfl_xor(v, off, 64);
+        if (lane < LPN) red[wave][p][k * 8 + j] = v;
+      }
+    }
+  }
+  __syncthreads();
+  for (int o = tid; o < K * F; o += 256) {
+    const int k = o / F, f = o - k * F, pp = f / 8, j = f % 8;
+    dw_part[item * (K * F) + o] = red[0][pp][k * 8 + j] + red[1][pp][k * 8 + j] + red[2][pp][k * 8 + j] + red[3][pp][k * 8 + j];
+  }
 }
 
 // Gate gradients of the node-gated cell for all items at once (one workgroup per item, F/8 lanes per node, coalesced 16-byte pieces):
@@ -213,8 +236,13 @@ extern "C" int gcrnn_node_gate_dot_backward(void* d, const float* ds, const floa
   if (!d || !ds || !w || !dw_part) return GCRNN_ERR_NULL_POINTER;
   if (items <= 0 || items > 2147483647LL || N <= 0 || NPad < N || K <= 0 || K > 8 || (F != 32 && F != 64) || K * F > 512) return GCRNN_ERR_BAD_SHAPE;
   GCRNN_PRE_LAUNCH();
-  if (F == 64) node_gate_dot_bwd_kernel<64><<<(unsigned)items, 512, 0, as_stream(stream)>>>((uint16_t*)d, ds, w, dw_part, (int)N, (int)NPad, (int)K);
-  else node_gate_dot_bwd_kernel<32><<<(unsigned)items, 512, 0, as_stream(stream)>>>((uint16_t*)d, ds, w, dw_part, (int)N, (int)NPad, (int)K);
+  if (K * F > 256) {      // the final fold uses one thread per (k, f): K <= 4 for F = 64 goes through the 8-tap instantiation's 256 threads twice
+    if (F == 64) node_gate_dot_bwd_kernel<64, 8><<<(unsigned)items, 256, 0, as_stream(stream)>>>((uint16_t*)d, ds, w, dw_part, (int)N, (int)NPad, (int)K);
+    else node_gate_dot_bwd_kernel<32, 8><<<(unsigned)items, 256, 0, as_stream(stream)>>>((uint16_t*)d, ds, w, dw_part, (int)N, (int)NPad, (int)K);
+  } else {
+    if (F == 64) node_gate_dot_bwd_kernel<64, 4><<<(unsigned)items, 256, 0, as_stream(stream)>>>((uint16_t*)d, ds, w, dw_part, (int)N, (int)NPad, (int)K);
+    else node_gate_dot_bwd_kernel<32, 8><<<(unsigned)items, 256, 0, as_stream(stream)>>>((uint16_t*)d, ds, w, dw_part, (int)N, (int)NPad, (int)K);
+  }
   GCRNN_CHECK_LAUNCH();
   return GCRNN_OK;
 }

@@ -766,8 +766,7 @@ class _FusedNodeCell(torch.autograd.Function):
         st = _stream()
         hs = hs_all[1:]
         dH = dH.to(torch.bfloat16).contiguous()
-        dHs = torch.empty((T, B, npad, F), dtype=torch.bfloat16, device=X.device)
-        check(lib.gcrnn_pack_seq_major(_lib.BF16, _p(dH), _p(dHs), B, T, F, N, npad, None, st), 'pack_seq')
+        dHs, dHu = fused_pack_upstream(dH, graph, K)
         ngf = (ngates[:, 1] * gf.unsqueeze(2)).contiguous() if gf is not None else ngates[:, 1].contiguous()       # [T][B][N]
         wBk = wB.detach() if Kst == K else torch.cat([wB.detach(), wB.new_zeros(F, 1, K - Kst, F)], dim=2)
         wBt = wBk[:, 0].permute(2, 1, 0).contiguous().unsqueeze(1)                      # transposed taps [F_in][1][K][F_out]
@@ -776,7 +775,7 @@ class _FusedNodeCell(torch.autograd.Function):
         dpre = torch.empty((T, B, npad, F), dtype=torch.bfloat16, device=X.device)
         dyh = torch.empty_like(dpre)
         check(lib.gcrnn_fused_node_backward_data_bf16(_p(dHs), _p(hs), _p(dpre), _p(dyh), _p(ngf), _p(wpT), *_fused_graph_args(aplan),
-                                                      B, T, N, F, K, aplan.get('uniform_w', 0.0), st), 'fused_node_backward_data')
+                                                      B, T, N, F, K, aplan.get('uniform_w', 0.0), _p(dHu), st), 'fused_node_backward_data')
         dyx = torch.empty_like(dpre)
         dni = torch.empty((T, B, N), dtype=torch.float32, device=X.device)
         dnf = torch.empty_like(dni)
@@ -986,8 +985,7 @@ class _FusedEdgeCell(torch.autograd.Function):
         a_in = mix_in.detach().float().reshape(2, F).contiguous()
         a_f = mix_f.detach().float().reshape(2, F).contiguous()
         dH = dH.to(torch.bfloat16).contiguous()
-        dHs = torch.empty((T, B, npad, F), dtype=torch.bfloat16, device=dev)
-        check(lib.gcrnn_pack_seq_major(_lib.BF16, _p(dH), _p(dHs), B, T, F, N, npad, None, st), 'pack_seq')
+        dHs, dHu = fused_pack_upstream(dH, graph, K)          # uniform graphs: only the last two steps; the chain launches lay out the rest
         wBt = wBk[:, 0].permute(2, 1, 0).contiguous().unsqueeze(1)                  # transposed composite taps [F_in][1][K][F_out]
         wpT = _fused_pack_state_taps(wBt, K, st)
         aplan = graph.fused_plan(adjoint=True)
@@ -1006,8 +1004,10 @@ class _FusedEdgeCell(torch.autograd.Function):
             fused_edge_attention_backward(dpre[t], rh[t], gf[t] if gf is not None else None, zh[t], a_f, graph, N, scratch=scratch,
                                           negative_slope=slope, dz=dzh[t], da_part=da_f[t], dgate=dgf[t] if dgf is not None else None)
             if t > 0:
+                nxt = dHu is not None and t >= 2
                 check(lib.gcrnn_fused_backward_step_bf16(_p(dzh[t]), _p(dHs[t - 1]), _p(hs[t - 1]), _p(dpre[t - 1]), _p(wpT), *aga,
-                                                         B, N, F, K, auw, st), 'fused_backward_step')
+                                                         B, N, F, K, auw, _p(dHu[:, t - 2]) if nxt else None, _p(dHs[t - 2]) if nxt else None, T, st),
+                      'fused_backward_step')
         dzx = torch.empty_like(dpre)
         da_i = torch.empty((T, B, 2, F), dtype=torch.float32, device=dev)
         dgi = torch.empty((T, B), dtype=torch.float32, device=dev) if gi is not None else None

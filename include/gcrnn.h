@@ -163,7 +163,8 @@ int gcrnn_fused_node_forward_bf16(const void* h0s, void* hs, const void* yx, con
 int gcrnn_fused_node_backward_data_bf16(const void* dHs, const void* hs, void* dpre, void* dyh, const float* ngf, const void* wpackT,
                                         const int32_t* tile_nodes, const int32_t* tile_off, const int32_t* ell_col,
                                         const float* ell_val, const void* ell_val4, const void* ell_col4, int64_t entries, int64_t B,
-                                        int64_t T, int64_t N, int64_t F, int64_t K, double uniform_w, void* stream);
+                                        int64_t T, int64_t N, int64_t F, int64_t K, double uniform_w,
+                                        const void* dHuser_inline /* as in gcrnn_fused_backward_data_bf16 */, void* stream);
 int gcrnn_node_cell_backward(const void* dpre, const void* yx, const void* yh, const float* ngates, const float* gi, const float* gf,
                              void* dyx, float* dni, float* dnf, float* dgi, float* dgf, int64_t B, int64_t T, int64_t N,
                              int64_t NPad, int64_t F, void* stream);
@@ -208,7 +209,9 @@ int gcrnn_fused_edge_attention_backward_bf16(const void* dpre, const void* r, co
 int gcrnn_fused_backward_step_bf16(const void* operand, const void* dH_prev, const void* h_prev, void* dpre_prev, const void* wpackT,
                                    const int32_t* tile_nodes, const int32_t* tile_off, const int32_t* ell_col, const float* ell_val,
                                    const void* ell_val4, const void* ell_col4, int64_t entries, int64_t B, int64_t N, int64_t F,
-                                   int64_t K, double uniform_w, void* stream);
+                                   int64_t K, double uniform_w,
+                                   const void* dHuser_next /* NULL, or the user-layout block dH[0][t-2] ... */, void* dHs_next /* ... laid out into dHs[t-2] */,
+                                   int64_t T /* sequence length (item stride T F N of the user-layout tensor) */, void* stream);
 int gcrnn_fused_backward_seed_bf16(const void* dH, const void* h, void* dpre, int64_t elements, void* stream);
 
 /* ==== fp32-accurate fused path ("x3": three bf16 planes per fp32 operand, six partial products on the bf16 matrix cores) ========
