@@ -1,3 +1,4 @@
+import os
 #!/usr/bin/env python3
 """Generator of gated_gcrnns_amd/csrc/gcrnn_hop_asm.inc: the graph-hop gather stream of the fused kernels as ONE inline-asm
 block per hop (python3 tools/gen_hop_asm.py > gated_gcrnns_amd/csrc/gcrnn_hop_asm.inc).
@@ -142,7 +143,10 @@ def us1(q, goff, lines):
         lines.append('v_xor_b32_sdwa %s, %s, %s dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_%d src1_sel:DWORD'
                      % (UXa(q, e), UCw(q, e >> 1), UQX, e & 1))
     for e in range(4):
-        lines.append('ds_read_b128 %s, %s' % (UX(q, e), UXa(q, e)))
+        if os.environ.get('GCRNN_HOP_EXPERIMENT_B64'):      # timing experiment only (wrong results): what would 8-byte gathers of a bf16 state image buy?
+            lines.append('ds_read_b64 %s, %s' % (UX(q, e, 0), UXa(q, e)))
+        else:
+            lines.append('ds_read_b128 %s, %s' % (UX(q, e), UXa(q, e)))
 
 
 def us0(q, goff, lines):
