@@ -39,3 +39,27 @@ with torch.no_grad():
             print('rep', r, 'B=8 mismatches', int(d.sum()), 'b', np.unique(b), 'first t', t.min(), 'f', np.unique(f)[:16], 'n', n.min(), n.max())
         del junk
 print('bad runs', bad, 'of', 2 * reps)
+
+if len(sys.argv) > 3 and sys.argv[3] == 'train':
+    # training steps: every gradient must equal the packed path's, bit for bit, in every repetition
+    cellt = gml.GGCRNNCell(F, F, K, K, torch.tanh, False, None, 1, True)
+    cellt.addGSO(torch.tensor(S))
+    cellt = cellt.to(dev)
+    tgt = torch.randn(B, T, F, N, device=dev, generator=gen)
+
+    def step():
+        cellt.zero_grad(set_to_none=True)
+        H = cellt(X, h0)
+        torch.nn.functional.l1_loss(H.float(), tgt).backward()
+        return {n: p.grad.clone() for n, p in cellt.named_parameters() if p.grad is not None}
+
+    os.environ['GCRNN_NO_INLINE_PACK'] = '1'
+    gref = step()
+    del os.environ['GCRNN_NO_INLINE_PACK']
+    badt = 0
+    for r in range(reps):
+        g = step()
+        if any(not torch.equal(g[n], gref[n]) for n in gref):
+            badt += 1
+            print('rep', r, 'gradient mismatch in', [n for n in gref if not torch.equal(g[n], gref[n])])
+    print('bad training steps', badt, 'of', reps)
