@@ -100,6 +100,12 @@ class GatedGCRNNforRegression(_GatedGCRNNBase):
 
     def forward(self, x, h0):
         batchSize, seqLength = x.shape[0], x.shape[1]
+        if self.mlpType == 'multipMlp' and not torch.is_grad_enabled() and len(self.outputNN) == 1 and \
+                isinstance(self.outputNN[0], nn.Linear) and self.outputNN[0].out_features == 1:
+            # inference with the drivers' head (dimLayersMLP = [1]): fused onto the cell's h_t store, H is never materialised
+            y = self.stateGCRNN.forward_with_head(x, h0, self.outputNN[0].weight, self.outputNN[0].bias)
+            if y is not None:
+                return y.to(x.dtype)
         H = self.stateGCRNN(x, h0)                                  # B x T x F_h x N
         flatH = H.reshape(-1, self.F_h, self.N)
         if self.mlpType == 'multipMlp':

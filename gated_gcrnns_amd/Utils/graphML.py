@@ -17,6 +17,7 @@ data runs in a node-major layout internally; `.to(device)` moves the graph too
 device -- there is no CPU path.
 """
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -638,10 +639,18 @@ class GGCRNNCell(nn.Module):
                 'forget': (pad(self.GFL_forget.weight_A), self.GFL_forget.weight_B, self.GFL_forget.bias,
                            self.MLP_forget[0].weight, self.MLP_forget[0].bias)}
 
-    def _forward_fused(self, X, h0, last_only=False):
+    def _forward_fused(self, X, h0, last_only=False, head=None):
         gates = self._fused_gates() if self.time_gating == True else None  # noqa: E712
         Xp, wA = ops.fused_pad_operands(X, self.weight_A)
-        return ops.fused_cell_forward(Xp, h0, wA, self.weight_B, self.bias, self.graph, gates, last_only=last_only)
+        return ops.fused_cell_forward(Xp, h0, wA, self.weight_B, self.bias, self.graph, gates, last_only=last_only, head=head)
+
+    def forward_with_head(self, X, h0, weight, bias):
+        """Inference of cell + output head Linear(F -> 1) shared by all nodes (the regression model's `multipMlp` head with one
+        output, reference architectures.py:1616-1627) with the head fused onto the h_t store of the fused step kernel: returns
+        y: B x T x 1 x N (fp32) without ever writing H in the user layout; None when this cell / input does not run on that path."""
+        if torch.is_grad_enabled() or not self._use_fused(X, h0) or self.N % 8 != 0 or os.environ.get('GCRNN_NO_FUSED_HEAD'):      # env: A/B switch
+            return None
+        return self._forward_fused(X, h0, head=(weight, bias))
 
     def extra_repr(self):
         return 'in_features=%d, state_features=%d, taps=(%d,%d), time_gating=%s, spatial_gating=%s, %s' % (

@@ -278,15 +278,16 @@ extern "C" int gcrnn_fused_forward_bf16(const void* xs, const void* h0, void* hs
                                         const void* ell_val4, const void* ell_col4, int64_t entries, int64_t B,
                                         int64_t T, int64_t N, int64_t F, int64_t G, int64_t K, void* Huser,
                                         int huser_last_only, void* const* step_events, double uniform_w, const void* Xuser_inline,
-                                        void* stream) {
+                                        const float* head_w, float* head_part, void* stream) {
   if (!xs || !h0 || !hs || !wpack || !tile_nodes || !tile_off || !ell_col || !ell_val) return GCRNN_ERR_NULL_POINTER;
   if ((gi == nullptr) != (gf == nullptr)) return GCRNN_ERR_NULL_POINTER;
   if (Xuser_inline && (gi || step_events || (reinterpret_cast<uintptr_t>(Xuser_inline) & 15))) return GCRNN_ERR_BAD_SHAPE;
+  if ((head_w == nullptr) != (head_part == nullptr)) return GCRNN_ERR_NULL_POINTER;
   if (B <= 0 || T <= 0 || N <= 0 || N > NP || B > (1 << 24) || entries < 0 || entries % 4) return GCRNN_ERR_BAD_SHAPE;
   if (B * (NP * (F > G ? F : G) * 2) > 2147483647LL || T * F * N > 2147483647LL) return GCRNN_ERR_BAD_SHAPE;   // 32-bit buffer offsets
   if (Huser && (N % 8 != 0 || (reinterpret_cast<uintptr_t>(Huser) & 15))) return GCRNN_ERR_BAD_SHAPE;
   const FusedGraphArgs ga{tile_nodes, tile_off, ell_col, ell_val, ell_val4, ell_col4, entries, (float)uniform_w};
-  return fused_dispatch(gi ? 1 : 0, xs, h0, hs, wpack, bias, gi, gf, nullptr, nullptr, ga, B, T, N, F, G, K, as_stream(stream),
+  return fused_dispatch(gi ? 1 : 0, xs, h0, hs, wpack, bias, gi, gf, head_w, head_part, ga, B, T, N, F, G, K, as_stream(stream),
                         Xuser_inline, nullptr, nullptr, Huser, nullptr, step_events, huser_last_only);
 }
 

@@ -251,6 +251,8 @@ __device__ __forceinline__ float fast_tanh(float x) {
 // 5 = node-gated step (graphML.py:2379-2407), state-only operand (XS = 0):
 //     h_t = tanh(gi ni_t[n] Yx_t[n][f] + gf nf_t[n] (B(S)h_{t-1} + b)[n][f]);  Yx_t from the EPI 4 pass (aux0), node gates [2][B][N]
 //     fp32 in gate_w (ni then nf), scalar time gates gi / gf [B] or null (= 1); optionally stores Yh = B(S)h_{t-1} + b (for BPTT)
+// 6 = the state epilogue of EPI 0 plus a fused output head Linear(F -> 1) (gate_w = its weights [F], gate_out = partials [B][F/16][N]);
+//     no user-layout copy of h_t
 // UNI (RESIDENT only): uniform-weight graph image -- column words only, all non-zeros weigh uni_w (GCRNN_HOP_ASM_UNI_STREAM)
 template <int K, int HS, int XS, bool GATED, bool RESIDENT, int EPI = 0, int UNI = 0>
 __global__ __launch_bounds__(STHREADS) void fused_step_kernel(
@@ -285,7 +287,7 @@ __global__ __launch_bounds__(STHREADS) void fused_step_kernel(
   constexpr int NCH = F / FC;
   constexpr bool GATEOUT = (EPI == 1 || EPI == 3);      // per-item scalar outputs (partials per chunk and wave)
   // rows of the operand an inline pack lays out for the next launch (0: this instantiation has none)
-  constexpr int PKROWS = (UNI != 0 && EPI == 0 && XS > 0 && !GATED) ? G : ((UNI != 0 && EPI == 2 && XS == 0) ? F : 0);   // (the gated cell's pre-passes need every x_t up front)
+  constexpr int PKROWS = (UNI != 0 && (EPI == 0 || EPI == 6) && XS > 0 && !GATED) ? G : ((UNI != 0 && EPI == 2 && XS == 0) ? F : 0);   // (the gated cell's pre-passes need every x_t up front)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* state = reinterpret_cast<float*>(smem);
   uint4* wl = reinterpret_cast<uint4*>(smem + NP * FC * 4);
@@ -703,6 +705,12 @@ __global__ __launch_bounds__(STHREADS) void fused_step_kernel(
       if (lane == 0) gate_out[(int64_t)b * (NCH * SWAVES) + chunk * SWAVES + wave] = part;   // fixed-order sum by the caller
     }
   } else {
+  float hp[STILES];                                    // EPI 6 (state epilogue + fused output head): this lane's per-tile partials ...
+  float hw[4] = {0.f, 0.f, 0.f, 0.f};                  // ... and its four weights (gate_w = [F]), fetched per item (EPI 6 is an
+  if constexpr (EPI == 6) {                            // instantiation of its own: the plain state epilogue keeps its register allocation)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) hw[c] = gate_w[chunk * FC + q * 4 + c];
+  }
 #pragma unroll
   for (int i = 0; i < STILES; ++i) {
     int wv = woff[i];
@@ -738,6 +746,34 @@ __global__ __launch_bounds__(STHREADS) void fused_step_kernel(
     // [h | x] operands of the sequences in flight and the prefetched next ones need) -- slower than plain stores, see the define
     __builtin_amdgcn_raw_buffer_store_b64(u32x2{pk.x, pk.y}, rsrc_o, node * (F * 2) + (chunk * FC + q * 4) * 2, b * (NP * F * 2), GCRNN_STORE_POLICY);
     u[i][0] = f32x4{__uint_as_float(pk.x), __uint_as_float(pk.y), 0.f, 0.f};      // keep the packed bf16 for the user-layout copy
+    if constexpr (EPI == 6) {
+      // Output head fused onto the h_t store (reference architectures.py:1616-1627, `multipMlp` with one output: the same
+      // Linear(F -> 1) on every node): this chunk's share  sum_{f in chunk} w[f] h_t[n][f]  on the bf16-rounded state, summed over the four
+      // feature quads of the node (lanes r, r + 16, r + 32, r + 48); the caller adds the F / 16 chunk partials and the bias. With it the
+      // user-layout copy of H can be dropped altogether (aux1 = null): inference of the regression model never materialises H.
+      float part = hw[0] * bf2f((uint16_t)(pk.x & 0xffffu)) + hw[1] * bf2f((uint16_t)(pk.x >> 16)) +
+                   hw[2] * bf2f((uint16_t)(pk.y & 0xffffu)) + hw[3] * bf2f((uint16_t)(pk.y >> 16));
+      part += __shfl_xor(part, 16, 64);
+      part += __shfl_xor(part, 32, 64);
+      hp[i] = part;
+    }
+  }
+  if constexpr (EPI == 6) {
+    // the tile nodes are degree-ranked, i.e. scattered: stage the per-node partials in the (now dead) state region and store them
+    // in node order, coalesced
+    float* hstage = state;
+    __syncthreads();                                   // every wave has finished reading `state` in the last hop
+    if (q == 0) {
+#pragma unroll
+      for (int i = 0; i < STILES; ++i) {
+        int wv = woff[i];
+        asm volatile("" : "+v"(wv));
+        hstage[wv >> 16] = hp[i];
+      }
+    }
+    __syncthreads();
+    float* go = gate_out + ((int64_t)b * NCH + chunk) * N;
+    for (int n = tid; n < N; n += STHREADS) go[n] = hstage[n];
   }
   if ((EPI == 0 || EPI == 5) && aux1) {
     // the state is also delivered in the USER layout H[b][t][f][:] (node-contiguous rows): transposed bf16 tile in LDS
@@ -774,7 +810,7 @@ __global__ __launch_bounds__(STHREADS) void fused_step_kernel(
       // 8-feature pieces; the pieces of a node sit in consecutive lanes (whole rows per store), rows >= N are zeros
       constexpr int NPC = NP / NCH, PCS = PKROWS / 8;
       const char* xtile = smem + NP * FC * 4 + K * KS * 1024 + entries * 32;
-      if (!(EPI == 0 && aux1)) __syncthreads();   // (EPI 0 with the user-layout output: its two barriers have already passed)
+      if (!((EPI == 0 && aux1) || EPI == 6)) __syncthreads();   // (EPI 0 with the user-layout output / EPI 6: their two barriers have already passed)
       const __amdgpu_buffer_rsrc_t rsrc_xn = __builtin_amdgcn_make_buffer_rsrc(pk_dst, 0, B * (NP * PKROWS * 2), 0x00020000);
       // gfx950: a 16-byte buffer store whose soffset is an SGPR followed IMMEDIATELY by a VALU write of its first data register
       // loses that dword in a few lanes, rarely (hipcc models no hazard for this form and happily reuses one register tuple for
@@ -851,7 +887,19 @@ int fused_launch_t(int mode /*0 plain, 1 gated, 2 gate pre-pass, 3 BPTT data gra
     return GCRNN_ERR_UNSUPPORTED;
   const size_t lds = (resident ? resident_bytes : base) + (inline_pack ? xtile_bytes : 0);
   fused_kern_t kern;
-  if (mode == 6) {
+  const bool head = (mode == 0 || mode == 1) && gate_w != nullptr;      // fused output head: EPI 6 instantiations
+  if (head) {
+    if constexpr (XS > 0) {
+      if (huser) return GCRNN_ERR_BAD_SHAPE;                             // (the head replaces the user-layout copy of H)
+      if (mode == 1) kern = resident ? (fused_kern_t)fused_step_kernel<K, HS, XS, true, true, 6> : (fused_kern_t)fused_step_kernel<K, HS, XS, true, false, 6>;
+      else kern = resident ? (fused_kern_t)fused_step_kernel<K, HS, XS, false, true, 6> : (fused_kern_t)fused_step_kernel<K, HS, XS, false, false, 6>;
+#if GCRNN_HOP_ASM && GCRNN_STEP_WAVES == 8
+      if (uni && resident) kern = mode == 1 ? (fused_kern_t)fused_step_kernel<K, HS, XS, true, true, 6, 1> : (fused_kern_t)fused_step_kernel<K, HS, XS, false, true, 6, 1>;
+#endif
+    } else {
+      return GCRNN_ERR_UNSUPPORTED;
+    }
+  } else if (mode == 6) {
     if constexpr (XS == 0) {
       kern = resident ? (fused_kern_t)fused_step_kernel<K, HS, XS, false, true, 5> : (fused_kern_t)fused_step_kernel<K, HS, XS, false, false, 5>;
 #if GCRNN_HOP_ASM && GCRNN_STEP_WAVES == 8
@@ -1000,9 +1048,10 @@ int fused_launch_t(int mode /*0 plain, 1 gated, 2 gate pre-pass, 3 BPTT data gra
       if (step_events && step_events[t] && hipStreamWaitEvent(st, (hipEvent_t)step_events[t], 0) != hipSuccess) return GCRNN_ERR_LAUNCH;
       // inline pack (mode 0, uniform graph): launch t also lays out x_{t+1} from the user-layout X (bw_dHs) into xs[t+1]
       const uint16_t* xun = (inline_pack && t + 1 < T) ? (const uint16_t*)bw_dHs + (t + 1) * G * N : nullptr;
+      // modes 0 / 1 with gate_w: the fused output head (weights [F]); gate_out = its partials [T][B][F/16][N]
       kern<<<grid, STHREADS, lds, st>>>(x + t * xstep, hp, h + t * hstep, (const uint4*)wpack, bias, mode == 1 ? gi + t * B : nullptr,
                                    mode == 1 ? gf + t * B : nullptr, ga.tile_nodes, ga.tile_off, ga.ell_col, ga.ell_val,
-                                   (const float4*)ga.ell_val4, (const uint2*)ga.ell_col4, nullptr, nullptr, nullptr,
+                                   (const float4*)ga.ell_val4, (const uint2*)ga.ell_col4, gate_w, gate_w ? gate_out + t * B * NCH * N : nullptr, nullptr,
                                    !huser ? nullptr : (!huser_last_only ? (const uint16_t*)huser + t * F * N : (t == T - 1 ? (const uint16_t*)huser : nullptr)),
                                    (int)((huser_last_only ? 1 : T) * F * N),
                                    (int)ga.entries, (int)B, (int)B, (int)N, nullptr, uni ? ga.uniform_w : 0.f,

@@ -371,7 +371,7 @@ def time_fused_step_kernel(X, h0, wA, wB, bias, graph, reps=3, inline=None):
     for _ in range(reps):
         check(lib.gcrnn_fused_forward_bf16(_p(xs), _p(h0s), _p(hs), _p(wpack), _p(b32), None, None, *_fused_graph_args(plan),
                                            B, T, N, F, G, K, _p(H) if H is not None else None, 0, None, plan.get('uniform_w', 0.0),
-                                           _p(Xc) if inline else None, st),
+                                           _p(Xc) if inline else None, None, None, st),
               'fused_forward')
     e1.record()
     torch.cuda.synchronize()
@@ -496,7 +496,7 @@ def fused_time_gate(xs, h0s, wA_g, wB_g, bias_g, lin_w, lin_b, graph, N, store_s
 
 
 def fused_cell_forward(X, h0, wA, wB, bias, graph, gates=None, return_states=False, gate_values=None, packed=None,
-                       last_only=False):
+                       last_only=False, head=None):
     """Whole GGCRNNCell forward (un-gated or time-gated) on the fused bf16 step kernel.
 
     X: B x T x G x N bf16, h0: B x F x N bf16 (user layout) -> H: B x T x F x N bf16.
@@ -507,6 +507,9 @@ def fused_cell_forward(X, h0, wA, wB, bias, graph, gates=None, return_states=Fal
     return_states: also returns the state buffer hs_all [T+1][B][NPad][F] (slot 0 = h0) and the plan.
     last_only: H is B x 1 x F x N, the last state alone (the classification models' read-out); the user-layout store of the
     other steps is skipped.
+    head: None, or (weight 1 x F, bias [1] or None) of an output head Linear(F -> 1) shared by all nodes (the regression model's
+    `multipMlp` head with one output, architectures.py:1616-1627): it is evaluated in the step kernel's epilogue, H is never written
+    in the user layout, and the function returns y: B x T x 1 x N (fp32) instead of H.
     """
     require_device(X, h0, wA, wB, bias)
     if packed is None:
@@ -549,14 +552,26 @@ def fused_cell_forward(X, h0, wA, wB, bias, graph, gates=None, return_states=Fal
         gi, gf = g['in'], g['forget']
     wpack = _fused_pack_weights(wA, wB, st)
     b32 = bias.detach().float().contiguous().view(-1) if bias is not None else None
-    H = torch.empty((B, 1 if last_only else T, F, N), dtype=torch.bfloat16, device=dev)
     direct = (N % 8 == 0)                 # the step kernels write the user layout themselves (16-byte row stores)
     evs = None
     if events is not None:                               # raw hipEvent_t handles, one slot per step (host array, read during the call)
         evs = (C.c_void_p * T)(*[(e.cuda_event if e is not None else None) for e in events])
+    if head is not None:
+        assert not return_states and not last_only
+        hw = head[0].detach().float().reshape(-1).contiguous()
+        assert hw.numel() == F
+        part = torch.empty((T, B, F // 16, N), dtype=torch.float32, device=dev)
+        check(lib.gcrnn_fused_forward_bf16(_p(xs), _p(h0s), _p(hs), _p(wpack), _p(b32), _p(gi), _p(gf), *_fused_graph_args(plan),
+                                           B, T, N, F, G, K, None, 0, evs, plan.get('uniform_w', 0.0), _p(X) if inline else None,
+                                           _p(hw), _p(part), st), 'fused_forward')
+        y = part.sum(dim=2)                                          # fixed order over the F / 16 chunks
+        if head[1] is not None:
+            y = y + head[1].detach().float().reshape(())
+        return y.permute(1, 0, 2).unsqueeze(2).contiguous()          # B x T x 1 x N
+    H = torch.empty((B, 1 if last_only else T, F, N), dtype=torch.bfloat16, device=dev)
     check(lib.gcrnn_fused_forward_bf16(_p(xs), _p(h0s), _p(hs), _p(wpack), _p(b32), _p(gi), _p(gf), *_fused_graph_args(plan),
                                        B, T, N, F, G, K, _p(H) if direct else None, int(last_only), evs, plan.get('uniform_w', 0.0),
-                                       _p(X) if inline else None, st),
+                                       _p(X) if inline else None, None, None, st),
           'fused_forward')
     if not direct:
         src = hs[T - 1:] if last_only else hs

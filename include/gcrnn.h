@@ -306,6 +306,10 @@ int gcrnn_fused_forward_bf16(const void* xs, const void* h0, void* hs, const voi
                              void* Huser, int huser_last_only, void* const* step_events, double uniform_w,
                              const void* Xuser_inline /* NULL, or X [B][T][G][N] bf16 in the user layout: launch t also lays out x_{t+1} into
                                 xs[t+1] (only xs[0] has to be packed by the caller); un-gated cell, gcrnn_fused_inline_pack_supported() */,
+                             const float* head_w /* NULL, or [F]: the weights of an output head Linear(F -> 1) shared by all nodes (architectures.py:
+                                1616-1627 with one output), fused onto the h_t store ... */,
+                             float* head_part /* ... its partial sums fp32 [T][B][F/16][N] (the caller adds the F/16 chunks and the bias); with a head,
+                                Huser may be NULL: the regression model's inference then never materialises H */,
                              void* stream);
 
 /* Time-gate pre-pass (graphML.py:2357-2374): for every (t, b)

@@ -26,7 +26,7 @@ for r in range(reps):
     xs, _ = ops.fused_pack_inputs(X, h0, cell.graph, first_only=True)
     xs[1:] = 7.0
     check(lib.gcrnn_fused_forward_bf16(_p(xs), _p(hs_all[:1]), _p(hs_all[1:]), _p(wpack), _p(b32), None, None, *ops._fused_graph_args(plan),
-                                       B, T, N, F, G, K, _p(H), 0, None, plan['uniform_w'], _p(X), st), 'fwd')
+                                       B, T, N, F, G, K, _p(H), 0, None, plan['uniform_w'], _p(X), None, None, st), 'fwd')
     torch.cuda.synchronize()
     d = (xs.view(torch.int16) != xs_ref.view(torch.int16))
     if bool(d.any()):
