@@ -1293,3 +1293,42 @@ def test_regression_head_fused_onto_the_state_store(N, F, G, K, tg, uniform):
     with torch.no_grad():
         yf = m.stateGCRNN.forward_with_head(X, h0, lin.weight, lin.bias)             # fp32 result of the fused epilogue
     assert float((yf.double() - want).abs().max()) <= 1e-5 * max(1.0, float(want.abs().max()))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('sg', ['edge', None])
+def test_fused_paths_without_bias(sg):
+    """Cells built with bias=False (the reference allows it, graphML.py:2218-2222) on the fused kernels: forward and training against
+    the composed fp32 path."""
+    import gated_gcrnns_amd.Utils.graphML as gml
+    dev = torch.device('cuda:0')
+    N, F, G, K, B, T = 400, 64, 64, 3, 4, 3
+    S = random_graph(N, 10.0 / N, 97)
+    rng = np.random.default_rng(23)
+    X = bf16_round(rng.standard_normal((B, T, G, N)))
+    h0 = bf16_round(0.4 * rng.standard_normal((B, F, N)))
+    torch.manual_seed(31)
+    cell = gml.GGCRNNCell(G, F, K, K, torch.tanh, False, sg, 1, False)
+    cell.addGSO(torch.tensor(S))
+    assert cell.bias is None
+    cell = cell.to(torch.bfloat16).to(torch.float32)
+    ref = gml.GGCRNNCell(G, F, K, K, torch.tanh, False, sg, 1, False)
+    ref.addGSO(torch.tensor(S))
+    ref.load_state_dict(cell.state_dict())
+    cell, ref = cell.to(dev), ref.to(dev)
+    Hr = ref(torch.tensor(X, dtype=torch.float32, device=dev), torch.tensor(h0, dtype=torch.float32, device=dev))
+    Hr.square().mean().backward()
+    Xd = torch.tensor(X, dtype=torch.bfloat16, device=dev)
+    hd = torch.tensor(h0, dtype=torch.bfloat16, device=dev)
+    with torch.no_grad():
+        assert cell._use_fused_edge(Xd, hd) if sg == 'edge' else cell._use_fused(Xd, hd)
+        Hi = cell(Xd, hd)
+    assert float((Hi.float() - Hr.detach()).abs().max()) <= 4e-2
+    assert cell._use_fused_training(Xd, hd)
+    H = cell(Xd, hd)
+    H.float().square().mean().backward()
+    for n, p in ref.named_parameters():
+        g, gr = dict(cell.named_parameters())[n].grad.float().cpu().numpy(), p.grad.cpu().numpy()
+        sc, tmax, tmean = _grad_scale_and_bounds(n, {k: v.grad.cpu().numpy() for k, v in ref.named_parameters()}, 5e-2, 1e-2)
+        e = np.abs(g - gr)
+        assert sc > 0 and e.max() <= tmax * sc and (e.size < 16 or e.mean() <= tmean * sc), (n, e.max() / sc, e.mean() / sc)
