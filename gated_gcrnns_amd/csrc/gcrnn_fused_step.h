@@ -476,6 +476,9 @@ __global__ __launch_bounds__(STHREADS) void fused_step_kernel(
   // 128-byte row (= one cache line) of [h | x]; the NCH chunk workgroups of a sequence share an XCD and split the
   // 2 * NP rows between them. Phase 1 of the next sequence then streams from L2 instead of stalling on HBM.
   uint32_t prefetched = 0;
+#ifndef GCRNN_EPI2_PREFETCH
+#define GCRNN_EPI2_PREFETCH 1      // 0: the BPTT step loads its epilogue operands in the epilogue (A/B)
+#endif
 #ifndef GCRNN_PREFETCH_AT
 #define GCRNN_PREFETCH_AT 1      // 0: no L2 prefetch, 1: at the start of the hops (default), 2: before the last hop (A/B: tools/prefetch_ab.sh)
 #endif
@@ -508,9 +511,24 @@ __global__ __launch_bounds__(STHREADS) void fused_step_kernel(
 #else
 #define GCRNN_HOP_FIRST 1
 #endif
+  // EPI 2: the epilogue's operands (h_{t-1} for tanh', the upstream gradient dH_{t-1}) are requested when the LAST hop starts -- by
+  // then the registers of the taps already folded in are free -- and land while it runs (their latency used to sit in the epilogue)
+  u32x2 eph[(EPI == 2 && GCRNN_EPI2_PREFETCH) ? STILES : 1], epg[(EPI == 2 && GCRNN_EPI2_PREFETCH) ? STILES : 1];
 #pragma unroll
   for (int j = GCRNN_HOP_FIRST; j < K; ++j) {
     if (GCRNN_PREFETCH_AT == 2 && K > 2 && j == K - 1) prefetch_next();
+    if constexpr (EPI == 2 && GCRNN_EPI2_PREFETCH) {
+      if (j == K - 1) {
+#pragma unroll
+        for (int i = 0; i < STILES; ++i) {
+          int wv = woff[i];
+          asm volatile("" : "+v"(wv));
+          const int eoff = (wv >> 16) * (F * 2) + (chunk * FC + q * 4) * 2;
+          eph[i] = __builtin_amdgcn_raw_buffer_load_b64(rsrc_a1, eoff, b * (NP * F * 2), 0);      // zero-length descriptor when aux1 is null: 0
+          epg[i] = __builtin_amdgcn_raw_buffer_load_b64(rsrc_a0, eoff, b * (NP * F * 2), 0);
+        }
+      }
+    }
     if constexpr (PKROWS > 0) {
       // Inline pack (uniform graphs leave LDS room next to the column image): this workgroup's node range [chunk NPC, +NPC) of
       // the next launch's operand (EPI 0: x_{t+1}[b]; EPI 2: the upstream gradient dH_{t-2}[b]), all feature rows of the USER layout,
@@ -665,13 +683,13 @@ __global__ __launch_bounds__(STHREADS) void fused_step_kernel(
       f32x4 o = raw * gsc;
       float hv0 = 0.f, hv1 = 0.f, hv2 = 0.f, hv3 = 0.f;
       if (aux1) {
-        const u32x2 h2 = __builtin_amdgcn_raw_buffer_load_b64(rsrc_a1, eoff, b * (NP * F * 2), 0);
+        const u32x2 h2 = (GCRNN_EPI2_PREFETCH && K > 1) ? eph[GCRNN_EPI2_PREFETCH ? i : 0] : __builtin_amdgcn_raw_buffer_load_b64(rsrc_a1, eoff, b * (NP * F * 2), 0);
         hv0 = bf2f((uint16_t)(h2[0] & 0xffffu)); hv1 = bf2f((uint16_t)(h2[0] >> 16));
         hv2 = bf2f((uint16_t)(h2[1] & 0xffffu)); hv3 = bf2f((uint16_t)(h2[1] >> 16));
       }
       if (gate_out) part += raw[0] * hv0 + raw[1] * hv1 + raw[2] * hv2 + raw[3] * hv3;     // rows >= N of h are zero
       if (aux0) {
-        const u32x2 g2 = __builtin_amdgcn_raw_buffer_load_b64(rsrc_a0, eoff, b * (NP * F * 2), 0);
+        const u32x2 g2 = (GCRNN_EPI2_PREFETCH && K > 1) ? epg[GCRNN_EPI2_PREFETCH ? i : 0] : __builtin_amdgcn_raw_buffer_load_b64(rsrc_a0, eoff, b * (NP * F * 2), 0);
         const float g0 = bf2f((uint16_t)(g2[0] & 0xffffu)), g1 = bf2f((uint16_t)(g2[0] >> 16));
         const float g2f = bf2f((uint16_t)(g2[1] & 0xffffu)), g3 = bf2f((uint16_t)(g2[1] >> 16));
         o[0] = (o[0] + g0) * (1.f - hv0 * hv0);
