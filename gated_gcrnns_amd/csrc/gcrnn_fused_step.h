@@ -513,7 +513,8 @@ __global__ __launch_bounds__(STHREADS) void fused_step_kernel(
 #endif
   // EPI 2: the epilogue's operands (h_{t-1} for tanh', the upstream gradient dH_{t-1}) are requested when the LAST hop starts -- by
   // then the registers of the taps already folded in are free -- and land while it runs (their latency used to sit in the epilogue)
-  u32x2 eph[(EPI == 2 && GCRNN_EPI2_PREFETCH) ? STILES : 1], epg[(EPI == 2 && GCRNN_EPI2_PREFETCH) ? STILES : 1];
+  u32x2 eph[(EPI == 2 && GCRNN_EPI2_PREFETCH) ? STILES : 1], epg[((EPI == 2 || EPI == 5) && GCRNN_EPI2_PREFETCH) ? STILES : 1];
+  float epn[(EPI == 5 && GCRNN_EPI2_PREFETCH) ? STILES : 1][2];      // EPI 5: the node's input / forget gate (Yx_t goes through epg)
 #pragma unroll
   for (int j = GCRNN_HOP_FIRST; j < K; ++j) {
     if (GCRNN_PREFETCH_AT == 2 && K > 2 && j == K - 1) prefetch_next();
@@ -526,6 +527,19 @@ __global__ __launch_bounds__(STHREADS) void fused_step_kernel(
           const int eoff = (wv >> 16) * (F * 2) + (chunk * FC + q * 4) * 2;
           eph[i] = __builtin_amdgcn_raw_buffer_load_b64(rsrc_a1, eoff, b * (NP * F * 2), 0);      // zero-length descriptor when aux1 is null: 0
           epg[i] = __builtin_amdgcn_raw_buffer_load_b64(rsrc_a0, eoff, b * (NP * F * 2), 0);
+        }
+      }
+    }
+    if constexpr (EPI == 5 && GCRNN_EPI2_PREFETCH) {
+      if (j == K - 1) {
+#pragma unroll
+        for (int i = 0; i < STILES; ++i) {
+          int wv = woff[i];
+          asm volatile("" : "+v"(wv));
+          const int node = wv >> 16;
+          epg[i] = __builtin_amdgcn_raw_buffer_load_b64(rsrc_a0, node * (F * 2) + (chunk * FC + q * 4) * 2, b * (NP * F * 2), 0);
+          epn[i][0] = node < N ? gate_w[(int64_t)b * N + node] : 0.f;
+          epn[i][1] = node < N ? gate_w[(int64_t)(B + b) * N + node] : 0.f;
         }
       }
     }
@@ -741,8 +755,9 @@ __global__ __launch_bounds__(STHREADS) void fused_step_kernel(
       if (EPI == 5) {
         // node-gated cell: the x part comes from the all-steps pass, both parts are scaled per node (and per sequence)
         const int eoff = node * (F * 2) + (chunk * FC + q * 4) * 2;
-        const u32x2 y2 = __builtin_amdgcn_raw_buffer_load_b64(rsrc_a0, eoff, b * (NP * F * 2), 0);
-        const float ni = gin * gate_w[(int64_t)b * N + node], nf = gfo * gate_w[(int64_t)(B + b) * N + node];
+        const u32x2 y2 = GCRNN_EPI2_PREFETCH ? epg[GCRNN_EPI2_PREFETCH ? i : 0] : __builtin_amdgcn_raw_buffer_load_b64(rsrc_a0, eoff, b * (NP * F * 2), 0);
+        const float ni = gin * (GCRNN_EPI2_PREFETCH ? epn[GCRNN_EPI2_PREFETCH ? i : 0][0] : gate_w[(int64_t)b * N + node]);
+        const float nf = gfo * (GCRNN_EPI2_PREFETCH ? epn[GCRNN_EPI2_PREFETCH ? i : 0][1] : gate_w[(int64_t)(B + b) * N + node]);
         const float yh0 = acc[0] + bvec[0], yh1 = acc[1] + bvec[1], yh2 = acc[2] + bvec[2], yh3 = acc[3] + bvec[3];
         if (xt) __builtin_amdgcn_raw_buffer_store_b64(u32x2{(uint32_t)f2bf(yh0) | ((uint32_t)f2bf(yh1) << 16), (uint32_t)f2bf(yh2) | ((uint32_t)f2bf(yh3) << 16)},
                                                      rsrc_yh, eoff, b * (NP * F * 2), 0);
