@@ -515,6 +515,8 @@ __global__ __launch_bounds__(STHREADS) void fused_step_kernel(
   // then the registers of the taps already folded in are free -- and land while it runs (their latency used to sit in the epilogue)
   u32x2 eph[(EPI == 2 && GCRNN_EPI2_PREFETCH) ? STILES : 1], epg[((EPI == 2 || EPI == 5) && GCRNN_EPI2_PREFETCH) ? STILES : 1];
   float epn[(EPI == 5 && GCRNN_EPI2_PREFETCH) ? STILES : 1][2];      // EPI 5: the node's input / forget gate (Yx_t goes through epg)
+  float4 epw[(EPI == 1 && GCRNN_EPI2_PREFETCH) ? STILES : 1];        // EPI 1: the gate read-out's weights of this lane's (node, 4 features)
+  u32x2 epd[(EPI == 3 && GCRNN_EPI2_PREFETCH) ? STILES : 1];         // EPI 3: dpre of this lane's (node, 4 features)
 #pragma unroll
   for (int j = GCRNN_HOP_FIRST; j < K; ++j) {
     if (GCRNN_PREFETCH_AT == 2 && K > 2 && j == K - 1) prefetch_next();
@@ -527,6 +529,21 @@ __global__ __launch_bounds__(STHREADS) void fused_step_kernel(
           const int eoff = (wv >> 16) * (F * 2) + (chunk * FC + q * 4) * 2;
           eph[i] = __builtin_amdgcn_raw_buffer_load_b64(rsrc_a1, eoff, b * (NP * F * 2), 0);      // zero-length descriptor when aux1 is null: 0
           epg[i] = __builtin_amdgcn_raw_buffer_load_b64(rsrc_a0, eoff, b * (NP * F * 2), 0);
+        }
+      }
+    }
+    if constexpr ((EPI == 1 || EPI == 3) && GCRNN_EPI2_PREFETCH) {
+      if (j == K - 1) {
+#pragma unroll
+        for (int i = 0; i < STILES; ++i) {
+          int wv = woff[i];
+          asm volatile("" : "+v"(wv));
+          const int node = wv >> 16;
+          if constexpr (EPI == 1) {
+            epw[i] = node < N ? *reinterpret_cast<const float4*>(gate_w + (int64_t)node * F + chunk * FC + q * 4) : float4{0.f, 0.f, 0.f, 0.f};
+          } else {
+            epd[i] = __builtin_amdgcn_raw_buffer_load_b64(rsrc_a0, node * (F * 2) + (chunk * FC + q * 4) * 2, b * (NP * F * 2), 0);
+          }
         }
       }
     }
@@ -630,7 +647,8 @@ __global__ __launch_bounds__(STHREADS) void fused_step_kernel(
       int wv = woff[i];
       asm volatile("" : "+v"(wv));
       const int node = wv >> 16;
-      const u32x2 d2 = __builtin_amdgcn_raw_buffer_load_b64(rsrc_a0, node * (F * 2) + (chunk * FC + q * 4) * 2, b * (NP * F * 2), 0);
+      const u32x2 d2 = GCRNN_EPI2_PREFETCH ? epd[GCRNN_EPI2_PREFETCH ? i : 0]
+                                            : __builtin_amdgcn_raw_buffer_load_b64(rsrc_a0, node * (F * 2) + (chunk * FC + q * 4) * 2, b * (NP * F * 2), 0);
       const f32x4 acc = u[i][0];
       if (node < N)
         part += (acc[0] + bvec[0]) * bf2f((uint16_t)(d2[0] & 0xffffu)) + (acc[1] + bvec[1]) * bf2f((uint16_t)(d2[0] >> 16)) +
@@ -665,7 +683,7 @@ __global__ __launch_bounds__(STHREADS) void fused_step_kernel(
       const int node = wv >> 16;
       uint2 pk{0u, 0u};
       if (node < N) {
-        const float4 w4 = *reinterpret_cast<const float4*>(gate_w + (int64_t)node * F + chunk * FC + q * 4);
+        const float4 w4 = GCRNN_EPI2_PREFETCH ? epw[GCRNN_EPI2_PREFETCH ? i : 0] : *reinterpret_cast<const float4*>(gate_w + (int64_t)node * F + chunk * FC + q * 4);
         const f32x4 acc = u[i][0];
         const float o0 = fast_tanh(acc[0] + bsum[0]), o1 = fast_tanh(acc[1] + bsum[1]);
         const float o2 = fast_tanh(acc[2] + bsum[2]), o3 = fast_tanh(acc[3] + bsum[3]);
