@@ -476,8 +476,8 @@ __global__ __launch_bounds__(STHREADS) void fused_step_kernel(
   // 128-byte row (= one cache line) of [h | x]; the NCH chunk workgroups of a sequence share an XCD and split the
   // 2 * NP rows between them. Phase 1 of the next sequence then streams from L2 instead of stalling on HBM.
   uint32_t prefetched = 0;
-#ifndef GCRNN_EPI2_PREFETCH
-#define GCRNN_EPI2_PREFETCH 1      // 0: the BPTT step loads its epilogue operands in the epilogue (A/B)
+#ifndef GCRNN_EPI_PREFETCH
+#define GCRNN_EPI_PREFETCH 1       // 0: epilogue operands (EPI 1, 2, 3, 5) are loaded in the epilogue instead of at the start of the last hop (A/B)
 #endif
 #ifndef GCRNN_PREFETCH_AT
 #define GCRNN_PREFETCH_AT 1      // 0: no L2 prefetch, 1: at the start of the hops (default), 2: before the last hop (A/B: tools/prefetch_ab.sh)
@@ -513,14 +513,14 @@ __global__ __launch_bounds__(STHREADS) void fused_step_kernel(
 #endif
   // EPI 2: the epilogue's operands (h_{t-1} for tanh', the upstream gradient dH_{t-1}) are requested when the LAST hop starts -- by
   // then the registers of the taps already folded in are free -- and land while it runs (their latency used to sit in the epilogue)
-  u32x2 eph[(EPI == 2 && GCRNN_EPI2_PREFETCH) ? STILES : 1], epg[((EPI == 2 || EPI == 5) && GCRNN_EPI2_PREFETCH) ? STILES : 1];
-  float epn[(EPI == 5 && GCRNN_EPI2_PREFETCH) ? STILES : 1][2];      // EPI 5: the node's input / forget gate (Yx_t goes through epg)
-  float4 epw[(EPI == 1 && GCRNN_EPI2_PREFETCH) ? STILES : 1];        // EPI 1: the gate read-out's weights of this lane's (node, 4 features)
-  u32x2 epd[(EPI == 3 && GCRNN_EPI2_PREFETCH) ? STILES : 1];         // EPI 3: dpre of this lane's (node, 4 features)
+  u32x2 eph[(EPI == 2 && GCRNN_EPI_PREFETCH) ? STILES : 1], epg[((EPI == 2 || EPI == 5) && GCRNN_EPI_PREFETCH) ? STILES : 1];
+  float epn[(EPI == 5 && GCRNN_EPI_PREFETCH) ? STILES : 1][2];      // EPI 5: the node's input / forget gate (Yx_t goes through epg)
+  float4 epw[(EPI == 1 && GCRNN_EPI_PREFETCH) ? STILES : 1];        // EPI 1: the gate read-out's weights of this lane's (node, 4 features)
+  u32x2 epd[(EPI == 3 && GCRNN_EPI_PREFETCH) ? STILES : 1];         // EPI 3: dpre of this lane's (node, 4 features)
 #pragma unroll
   for (int j = GCRNN_HOP_FIRST; j < K; ++j) {
     if (GCRNN_PREFETCH_AT == 2 && K > 2 && j == K - 1) prefetch_next();
-    if constexpr (EPI == 2 && GCRNN_EPI2_PREFETCH) {
+    if constexpr (EPI == 2 && GCRNN_EPI_PREFETCH) {
       if (j == K - 1) {
 #pragma unroll
         for (int i = 0; i < STILES; ++i) {
@@ -532,7 +532,7 @@ __global__ __launch_bounds__(STHREADS) void fused_step_kernel(
         }
       }
     }
-    if constexpr ((EPI == 1 || EPI == 3) && GCRNN_EPI2_PREFETCH) {
+    if constexpr ((EPI == 1 || EPI == 3) && GCRNN_EPI_PREFETCH) {
       if (j == K - 1) {
 #pragma unroll
         for (int i = 0; i < STILES; ++i) {
@@ -547,7 +547,7 @@ __global__ __launch_bounds__(STHREADS) void fused_step_kernel(
         }
       }
     }
-    if constexpr (EPI == 5 && GCRNN_EPI2_PREFETCH) {
+    if constexpr (EPI == 5 && GCRNN_EPI_PREFETCH) {
       if (j == K - 1) {
 #pragma unroll
         for (int i = 0; i < STILES; ++i) {
@@ -647,7 +647,7 @@ __global__ __launch_bounds__(STHREADS) void fused_step_kernel(
       int wv = woff[i];
       asm volatile("" : "+v"(wv));
       const int node = wv >> 16;
-      const u32x2 d2 = GCRNN_EPI2_PREFETCH ? epd[GCRNN_EPI2_PREFETCH ? i : 0]
+      const u32x2 d2 = GCRNN_EPI_PREFETCH ? epd[GCRNN_EPI_PREFETCH ? i : 0]
                                             : __builtin_amdgcn_raw_buffer_load_b64(rsrc_a0, node * (F * 2) + (chunk * FC + q * 4) * 2, b * (NP * F * 2), 0);
       const f32x4 acc = u[i][0];
       if (node < N)
@@ -683,7 +683,7 @@ __global__ __launch_bounds__(STHREADS) void fused_step_kernel(
       const int node = wv >> 16;
       uint2 pk{0u, 0u};
       if (node < N) {
-        const float4 w4 = GCRNN_EPI2_PREFETCH ? epw[GCRNN_EPI2_PREFETCH ? i : 0] : *reinterpret_cast<const float4*>(gate_w + (int64_t)node * F + chunk * FC + q * 4);
+        const float4 w4 = GCRNN_EPI_PREFETCH ? epw[GCRNN_EPI_PREFETCH ? i : 0] : *reinterpret_cast<const float4*>(gate_w + (int64_t)node * F + chunk * FC + q * 4);
         const f32x4 acc = u[i][0];
         const float o0 = fast_tanh(acc[0] + bsum[0]), o1 = fast_tanh(acc[1] + bsum[1]);
         const float o2 = fast_tanh(acc[2] + bsum[2]), o3 = fast_tanh(acc[3] + bsum[3]);
@@ -715,13 +715,13 @@ __global__ __launch_bounds__(STHREADS) void fused_step_kernel(
       f32x4 o = raw * gsc;
       float hv0 = 0.f, hv1 = 0.f, hv2 = 0.f, hv3 = 0.f;
       if (aux1) {
-        const u32x2 h2 = (GCRNN_EPI2_PREFETCH && K > 1) ? eph[GCRNN_EPI2_PREFETCH ? i : 0] : __builtin_amdgcn_raw_buffer_load_b64(rsrc_a1, eoff, b * (NP * F * 2), 0);
+        const u32x2 h2 = (GCRNN_EPI_PREFETCH && K > 1) ? eph[GCRNN_EPI_PREFETCH ? i : 0] : __builtin_amdgcn_raw_buffer_load_b64(rsrc_a1, eoff, b * (NP * F * 2), 0);
         hv0 = bf2f((uint16_t)(h2[0] & 0xffffu)); hv1 = bf2f((uint16_t)(h2[0] >> 16));
         hv2 = bf2f((uint16_t)(h2[1] & 0xffffu)); hv3 = bf2f((uint16_t)(h2[1] >> 16));
       }
       if (gate_out) part += raw[0] * hv0 + raw[1] * hv1 + raw[2] * hv2 + raw[3] * hv3;     // rows >= N of h are zero
       if (aux0) {
-        const u32x2 g2 = (GCRNN_EPI2_PREFETCH && K > 1) ? epg[GCRNN_EPI2_PREFETCH ? i : 0] : __builtin_amdgcn_raw_buffer_load_b64(rsrc_a0, eoff, b * (NP * F * 2), 0);
+        const u32x2 g2 = (GCRNN_EPI_PREFETCH && K > 1) ? epg[GCRNN_EPI_PREFETCH ? i : 0] : __builtin_amdgcn_raw_buffer_load_b64(rsrc_a0, eoff, b * (NP * F * 2), 0);
         const float g0 = bf2f((uint16_t)(g2[0] & 0xffffu)), g1 = bf2f((uint16_t)(g2[0] >> 16));
         const float g2f = bf2f((uint16_t)(g2[1] & 0xffffu)), g3 = bf2f((uint16_t)(g2[1] >> 16));
         o[0] = (o[0] + g0) * (1.f - hv0 * hv0);
@@ -773,9 +773,9 @@ __global__ __launch_bounds__(STHREADS) void fused_step_kernel(
       if (EPI == 5) {
         // node-gated cell: the x part comes from the all-steps pass, both parts are scaled per node (and per sequence)
         const int eoff = node * (F * 2) + (chunk * FC + q * 4) * 2;
-        const u32x2 y2 = GCRNN_EPI2_PREFETCH ? epg[GCRNN_EPI2_PREFETCH ? i : 0] : __builtin_amdgcn_raw_buffer_load_b64(rsrc_a0, eoff, b * (NP * F * 2), 0);
-        const float ni = gin * (GCRNN_EPI2_PREFETCH ? epn[GCRNN_EPI2_PREFETCH ? i : 0][0] : gate_w[(int64_t)b * N + node]);
-        const float nf = gfo * (GCRNN_EPI2_PREFETCH ? epn[GCRNN_EPI2_PREFETCH ? i : 0][1] : gate_w[(int64_t)(B + b) * N + node]);
+        const u32x2 y2 = GCRNN_EPI_PREFETCH ? epg[GCRNN_EPI_PREFETCH ? i : 0] : __builtin_amdgcn_raw_buffer_load_b64(rsrc_a0, eoff, b * (NP * F * 2), 0);
+        const float ni = gin * (GCRNN_EPI_PREFETCH ? epn[GCRNN_EPI_PREFETCH ? i : 0][0] : gate_w[(int64_t)b * N + node]);
+        const float nf = gfo * (GCRNN_EPI_PREFETCH ? epn[GCRNN_EPI_PREFETCH ? i : 0][1] : gate_w[(int64_t)(B + b) * N + node]);
         const float yh0 = acc[0] + bvec[0], yh1 = acc[1] + bvec[1], yh2 = acc[2] + bvec[2], yh3 = acc[3] + bvec[3];
         if (xt) __builtin_amdgcn_raw_buffer_store_b64(u32x2{(uint32_t)f2bf(yh0) | ((uint32_t)f2bf(yh1) << 16), (uint32_t)f2bf(yh2) | ((uint32_t)f2bf(yh3) << 16)},
                                                      rsrc_yh, eoff, b * (NP * F * 2), 0);
