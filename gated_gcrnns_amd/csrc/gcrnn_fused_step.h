@@ -42,6 +42,9 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 typedef __attribute__((ext_vector_type(2))) float f32x2;
 
+#ifndef GCRNN_P1_AHEAD
+#define GCRNN_P1_AHEAD 0           // tiles (of 8 per wave) of the next sequence's operand requested during the last hop (experiment: every depth spills)
+#endif
 namespace {
 constexpr int FC = 16;          // output features per workgroup
 constexpr int WAVES = 8;        // weight-gradient kernel: 8 waves x 8 tiles
@@ -364,6 +367,29 @@ __global__ __launch_bounds__(STHREADS) void fused_step_kernel(
   // gate pre-pass with an all-zero initial state (every training loop of the reference starts from h0 = 0, train_rnn.py:256): the
   // state half of the operand contributes exactly nothing -- skip its loads and MFMAs (wave-uniform)
   const bool skip_h = (EPI == 1) && flags && flags[0] != 0;
+  // Cross-item fragment prefetch (GCRNN_P1_AHEAD tiles of the NEXT sequence's B operand): requested when the LAST hop of the current
+  // sequence starts -- the registers of the taps already folded in are free then, the hop is LDS-bound and does not use the L2 -> CU
+  // path -- so that most of phase 1's operand transfer overlaps the hops instead of preceding them.
+  constexpr int PT = (GCRNN_P1_AHEAD < 0) ? 0 : (GCRNN_P1_AHEAD > STILES ? STILES : GCRNN_P1_AHEAD);
+  constexpr int PTE = (EPI == 1 || EPI == 2 || EPI == 5) && KS == 4 ? (PT > 4 ? 4 : PT) : PT;      // instantiations whose epilogue prefetch also needs registers
+  bf16x8 pf[PTE > 0 ? PTE : 1][KS];
+  auto load_ahead = [&](int bn) {
+    const int sh = (bn % hmod) * (NP * F * 2), sx = bn * (NP * G * 2);
+#pragma unroll
+    for (int i = 0; i < PTE; ++i) {
+      int w = woff[i];
+      asm volatile("" : "+v"(w));
+      const int roh = (w >> 16) * (F * 2) + 16 * q, rox = (w >> 16) * (G * 2) + 16 * q;
+#pragma unroll
+      for (int s = 0; s < HS; ++s)
+        pf[i][s] = skip_h ? __builtin_bit_cast(bf16x8, uint4{0u, 0u, 0u, 0u})
+                          : __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsrc_h, roh + 64 * s, sh, 0));
+#pragma unroll
+      for (int s = 0; s < XS; ++s)
+        pf[i][HS + s] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, rox + 64 * s, sx, 0));
+    }
+  };
+  if (PTE > 0) load_ahead(b0);
   for (int b = b0; b < B; b += seq_slots) {
   const int soff_h = (b % hmod) * (NP * F * 2);     // hmod < B: every item of the gate pre-pass reads h0[b]
   const int soff_x = b * (NP * G * 2);
@@ -384,6 +410,11 @@ __global__ __launch_bounds__(STHREADS) void fused_step_kernel(
   bf16x8 bfr[STILES][KS];
 #pragma unroll
   for (int i = 0; i < STILES; ++i) {
+    if (i < PTE) {                   // requested during the previous sequence's last hop (or before the loop)
+#pragma unroll
+      for (int s = 0; s < KS; ++s) bfr[i][s] = pf[i][s];
+      continue;
+    }
     int w = woff[i];
     asm volatile("" : "+v"(w));      // opaque per iteration: keeps hipcc from hoisting (and spilling) 16+ row offsets
     const int roh = (w >> 16) * (F * 2) + 16 * q, rox = (w >> 16) * (G * 2) + 16 * q;
@@ -520,6 +551,9 @@ __global__ __launch_bounds__(STHREADS) void fused_step_kernel(
 #pragma unroll
   for (int j = GCRNN_HOP_FIRST; j < K; ++j) {
     if (GCRNN_PREFETCH_AT == 2 && K > 2 && j == K - 1) prefetch_next();
+    if constexpr (PTE > 0) {
+      if (j == K - 1 && b + seq_slots < B) load_ahead(b + seq_slots);
+    }
     if constexpr (EPI == 2 && GCRNN_EPI_PREFETCH) {
       if (j == K - 1) {
 #pragma unroll
