@@ -296,7 +296,8 @@ static int edge_att_fwd_t(const void* z, const float* a12, const void* gx, const
 //   scores:      ds2[m] = sum_n dl[m][n] (row sum),  ds1[n] = sum_m dl[m][n] (column sum, through the per-edge scratch E)
 //   dz_m      += a1 ds1[m] + a2 ds2[m];   da1 = sum_n ds1[n] z_n,  da2 = sum_m ds2[m] z_m   (per-item partials)
 // One workgroup per item. LDS: the do image [N][F] bf16 and sc[n] = {s1, s2, row max -> ds2, 1 / row sum -> ds1}. Rows are
-// visited by descending out-degree; a row's F/8 lanes hold its z piece and its edge records in registers (out-degree <= 32).
+// visited by descending out-degree; a row's F/8 lanes hold its z piece and its edge records in registers (hub rows with more than 32
+// records continue chunk by chunk, d alpha parked in the scratch).
 // ------------------------------------------------------------------------------------------
 template <int CTRL> __device__ __forceinline__ float dpp_f(float v) {
   return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
@@ -475,6 +476,34 @@ __global__ __launch_bounds__(ETHREADS) void edge_att_bwd_kernel(
     float rsum = 0.f;
 #pragma unroll
     for (int c = 0; c < MAXC; ++c) { dal[c] *= __int_as_float(reca[c].y); rsum += al[c] * dal[c]; }
+    // hub rows (out-degree beyond the register chunks): the same gather chunk by chunk; d alpha of those records waits in the
+    // scratch (each lane reads back only what it wrote itself) until the row sum R is complete
+    for (int e0 = MAXC * LPN; e0 < dmax; e0 += LPN) {
+      const int2 rc = (e0 + p < dega) ? r_edge[j0a + e0 + p] : int2{0, 0};
+      const float v = __int_as_float(rc.y);
+      float e = sc[rc.x].x + sm.y;
+      e = e > 0.f ? e : slope * e;
+      const float alx = (v != 0.f) ? eexp(e - sm.z) * sm.w : 0.f;
+      const float cx = v * alx;
+      float dmine = 0.f;
+#pragma unroll
+      for (int i = 0; i < LPN; ++i) {
+        const int nn = __shfl(rc.x, i, LPN);
+        const float cc = __shfl(cx, i, LPN);
+        float df[8];
+        unpack8(dol[nn * LPN + p], df);
+        float dot = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) dot += zf[j] * df[j];
+        dot = group_sum<LPN>(dot);
+        if (p == i) dmine = dot;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] += cc * f32x2{df[2 * j], df[2 * j + 1]};
+      }
+      dmine *= v;
+      rsum += alx * dmine;
+      if (e0 + p < dega) Ei[j0a + e0 + p] = dmine;
+    }
     rsum = group_sum<LPN>(rsum);
     float ds2 = 0.f;
 #pragma unroll
@@ -482,6 +511,18 @@ __global__ __launch_bounds__(ETHREADS) void edge_att_bwd_kernel(
       const float dl = al[c] * (dal[c] - rsum) * lr[c];
       ds2 += dl;
       if (c * LPN + p < dega) Ei[j0a + c * LPN + p] = dl;
+    }
+    for (int e0 = MAXC * LPN; e0 < dmax; e0 += LPN) {
+      if (e0 + p < dega) {
+        const int2 rc = r_edge[j0a + e0 + p];
+        float e = sc[rc.x].x + sm.y;
+        const float lrx = e > 0.f ? 1.f : slope;
+        e *= lrx;
+        const float alx = eexp(e - sm.z) * sm.w;
+        const float dl = alx * (Ei[j0a + e0 + p] - rsum) * lrx;
+        ds2 += dl;
+        Ei[j0a + e0 + p] = dl;
+      }
     }
     ds2 = group_sum<LPN>(ds2);
     if (valid) {
@@ -589,10 +630,11 @@ extern "C" int gcrnn_fused_edge_attention_bf16(const void* z, const float* a12, 
 // r = relu(att(z)) kept by the forward, g [items] the branch's scalar time gate (or NULL = 1) -> dz [items][NPad][F] bf16 (the
 // gradient w.r.t. the composite filter output z), da_part fp32 [items][2][F] (per-item partials of the mixer gradient: the caller
 // adds the items in a fixed order), dgate fp32 [items] = sum dpre . r (or NULL). r_order = support rows by descending out-degree,
-// t_pos = position of every column-ordered support edge in the row order, E = fp32 scratch [items][nnz]. The support's largest
-// out-degree (self-loop included) must be <= 32 (gcrnn_fused_edge_attention_backward_supported).
+// t_pos = position of every column-ordered support edge in the row order, E = fp32 scratch [items][nnz]. Rows with more than 32
+// support entries (hubs) take a slower chunked loop.
 extern "C" int gcrnn_fused_edge_attention_backward_supported(int64_t N, int64_t F, int64_t max_out_degree) {
-  return gcrnn_fused_edge_attention_supported(N, F) && max_out_degree <= 32;
+  (void)max_out_degree;      // rows beyond 32 records take a slower chunked loop (their d alpha waits in the scratch)
+  return gcrnn_fused_edge_attention_supported(N, F);
 }
 
 extern "C" int gcrnn_fused_edge_attention_backward_bf16(const void* dpre, const void* r, const float* g, const void* z, const float* a12,

@@ -913,8 +913,8 @@ def fused_edge_cell_forward(X, h0, wA, wB, bias, graph, att_in, att_f, time_gate
 
 
 def fused_edge_training_supported(graph, N, F, G, Kin, Kst, E=1):
-    """Edge-gated training on the fused kernels: the fused BPTT's shapes, the attention kernels' and a support whose largest
-    out-degree (self-loop included) fits the backward kernel's register-resident edge records."""
+    """Edge-gated training on the fused kernels: the fused BPTT's shapes and the attention kernels' (hub rows beyond the backward
+    kernel's 32 register-resident edge records take its slower chunked loop)."""
     if not (fused_training_supported(graph, N, F, G, Kin, Kst, E) and fused_edge_supported(graph, N, F, G, Kin, Kst, torch.bfloat16, E)):
         return False
     return bool(lib.gcrnn_fused_edge_attention_backward_supported(int(N), int(F), int(graph.edge_plan()['max_out_degree'])))

@@ -195,8 +195,8 @@ int gcrnn_fused_edge_attention_bf16(const void* z, const float* a12, const void*
  * branch's scalar gate): dpre = d loss / d (cell pre-activation) [items][NPad][F] bf16, r = relu(att(z)) kept by the forward,
  * g [items] (or NULL = 1) -> dz [items][NPad][F] bf16 (w.r.t. the composite filter output), da_part fp32 [items][2][F] (per-item
  * partials of the mixer gradient), dgate fp32 [items] = sum dpre . r (or NULL). r_order = support rows by descending out-degree,
- * t_pos = position of every column-ordered support edge in the row order, scratch fp32 [items][nnz]. Largest out-degree of the
- * support (self-loop included) <= 32. Deterministic (gathers and fixed-order sums only).
+ * t_pos = position of every column-ordered support edge in the row order, scratch fp32 [items][nnz]. Rows with more than 32 support
+ * entries take a slower chunked loop. Deterministic (gathers and fixed-order sums only).
  * gcrnn_fused_backward_step_bf16: ONE launch of the BPTT data chain with explicit arrays, dpre_prev = (sum_k S^k (operand W_k) +
  * dH_prev)(1 - h_prev^2) -- the edge-gated cell alternates it with the attention backward (the chain's operand of step t is dz_t);
  * gcrnn_fused_backward_seed_bf16: dpre = dH (1 - h^2) on bf16 arrays (the last step). */

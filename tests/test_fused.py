@@ -1229,70 +1229,45 @@ def test_inline_pack_full_size_repeated_forwards_match_the_packed_path():
 
 
 @pytest.mark.gpu
-def test_edge_gated_training_falls_back_when_a_hub_exceeds_the_register_records():
-    """The attention backward keeps a row's edge records in registers (out-degree <= 32 incl. the self-loop). A graph with a hub row
-    must not take the fused training path (the composed path trains it instead); fused INFERENCE handles hubs (slow loop) and still
-    matches the composed path."""
+def test_edge_gated_cell_with_hub_nodes_on_the_fused_kernels():
+    """The attention kernels keep a node's edge records in registers (32 per node); hubs -- a row reaching 60 nodes, a column reached
+    by 70 -- continue chunk by chunk (forward: slow in-degree loop; backward: d alpha of the extra records parked in the scratch).
+    Fused inference and the whole fused BPTT against the composed fp32 path."""
     import gated_gcrnns_amd.Utils.graphML as gml
     dev = torch.device('cuda:0')
     N, F, G, K, B, T = 200, 32, 32, 3, 3, 3
     rng = np.random.default_rng(3)
     S = (rng.random((N, N)) < 0.04) * rng.uniform(0.2, 1.0, (N, N))
-    S[7, :60] = rng.uniform(0.2, 1.0, 60)            # row 7 reaches 60 nodes; column 11 is reached by 70
+    S[7, :60] = rng.uniform(0.2, 1.0, 60)
     S[:70, 11] = rng.uniform(0.2, 1.0, 70)
     S = (S / np.max(np.abs(np.linalg.eigvals(S)))).reshape(1, N, N)
     torch.manual_seed(2)
     cell = gml.GGCRNNCell(G, F, K, K, torch.tanh, False, 'edge', 1, True)
     cell.addGSO(torch.tensor(S))
-    cell = cell.to(torch.bfloat16).float().to(dev)
+    cell = cell.to(torch.bfloat16).float()
+    ref = gml.GGCRNNCell(G, F, K, K, torch.tanh, False, 'edge', 1, True)
+    ref.addGSO(torch.tensor(S))
+    ref.load_state_dict(cell.state_dict())
+    cell, ref = cell.to(dev), ref.to(dev)
     X = torch.tensor(rng.standard_normal((B, T, G, N)), dtype=torch.float32, device=dev).to(torch.bfloat16)
     h0 = torch.tensor(0.3 * rng.standard_normal((B, F, N)), dtype=torch.float32, device=dev).to(torch.bfloat16)
     assert cell.graph.edge_plan()['max_out_degree'] > 32
-    assert not cell._use_fused_training(X, h0)
-    H = cell(X, h0)                                   # composed path (fp32 parameters)
-    H.float().square().mean().backward()
-    assert cell.input_attention.mixer.grad is not None and torch.isfinite(cell.input_attention.mixer.grad).all()
+    Hr = ref(X.float(), h0.float())                    # composed path
+    Hr.square().mean().backward()
     with torch.no_grad():
         assert cell._use_fused_edge(X, h0)
         Hf = cell(X, h0)
-    err = (Hf.float() - H.detach().float()).abs()
+    err = (Hf.float() - Hr.detach()).abs()
     assert float(err.max()) <= 4e-2 and float(err.mean()) <= 3e-3, (float(err.max()), float(err.mean()))
-
-
-@pytest.mark.gpu
-@pytest.mark.parametrize('N,F,G,K,tg,uniform', [(1000, 64, 64, 5, False, True), (1000, 64, 1, 3, True, True), (400, 32, 32, 3, False, False),
-                                                (600, 64, 64, 2, True, False)])
-def test_regression_head_fused_onto_the_state_store(N, F, G, K, tg, uniform):
-    """the regression model's `multipMlp` head with one output (reference architectures.py:1616-1627: the same
-    Linear(F -> 1) on every node) evaluated in the step kernel's epilogue, H never written in the user layout. Same numbers as
-    cell -> head kernel on the bf16-rounded states (fp32 sums in another order), un-gated and time-gated, uniform and weighted graphs."""
-    import gated_gcrnns_amd.Modules.architectures as archit
-    dev = torch.device('cuda:0')
-    rng = np.random.default_rng(51)
-    if uniform:
-        W = (rng.random((N, N)) < 10.0 / N).astype(np.float64)
-        W = np.triu(W, 1); W = W + W.T
-        S = W / np.max(np.abs(np.linalg.eigvalsh(W)))
-    else:
-        S = random_graph(N, 10.0 / N, 91)[0]
-    torch.manual_seed(17)
-    m = archit.GatedGCRNNforRegression(G, F, K, K, torch.tanh, torch.nn.ReLU, [1], S, True, time_gating=tg, spatial_gating=None,
-                                       mlpType='multipMlp').to(dev).float()
-    B, T = 5, 4
-    X = torch.tensor(rng.standard_normal((B, T, G, N)), dtype=torch.float32, device=dev).to(torch.bfloat16)
-    h0 = torch.tensor(0.3 * rng.standard_normal((B, F, N)), dtype=torch.float32, device=dev).to(torch.bfloat16)
-    with torch.no_grad():
-        y = m(X, h0)                                                 # fused head
-        assert m.stateGCRNN.forward_with_head(X, h0, m.outputNN[0].weight, m.outputNN[0].bias) is not None
-        H = m.stateGCRNN(X, h0)                                      # the cell alone, then the head by hand in fp64
-        lin = m.outputNN[0]
-        want = torch.einsum('of,btfn->bton', lin.weight.double(), H.double()) + lin.bias.double().view(1, 1, -1, 1)
-    assert tuple(y.shape) == (B, T, 1, N)
-    err = (y.double() - want).abs().max()
-    assert float(err) <= 1.0 / 128 * float(want.abs().max()), float(err)            # y is returned in the input dtype (bf16)
-    with torch.no_grad():
-        yf = m.stateGCRNN.forward_with_head(X, h0, lin.weight, lin.bias)             # fp32 result of the fused epilogue
-    assert float((yf.double() - want).abs().max()) <= 1e-5 * max(1.0, float(want.abs().max()))
+    assert cell._use_fused_training(X, h0)
+    H = cell(X, h0)
+    H.float().square().mean().backward()
+    refg = {k: v.grad.cpu().numpy() for k, v in ref.named_parameters()}
+    for n, p in cell.named_parameters():
+        g, gr = p.grad.float().cpu().numpy(), refg[n]
+        sc, tmax, tmean = _grad_scale_and_bounds(n, refg, 5e-2, 1e-2)
+        e = np.abs(g - gr)
+        assert sc > 0 and e.max() <= tmax * sc and (e.size < 16 or e.mean() <= tmean * sc), (n, e.max() / sc, e.mean() / sc)
 
 
 @pytest.mark.gpu
