@@ -1271,6 +1271,42 @@ def test_edge_gated_cell_with_hub_nodes_on_the_fused_kernels():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('N,F,G,K,tg,uniform', [(1000, 64, 64, 5, False, True), (1000, 64, 1, 3, True, True), (400, 32, 32, 3, False, False),
+                                                (600, 64, 64, 2, True, False)])
+def test_regression_head_fused_onto_the_state_store(N, F, G, K, tg, uniform):
+    """the regression model's `multipMlp` head with one output (reference architectures.py:1616-1627: the same
+    Linear(F -> 1) on every node) evaluated in the step kernel's epilogue, H never written in the user layout. Same numbers as
+    cell -> head kernel on the bf16-rounded states (fp32 sums in another order), un-gated and time-gated, uniform and weighted graphs."""
+    import gated_gcrnns_amd.Modules.architectures as archit
+    dev = torch.device('cuda:0')
+    rng = np.random.default_rng(51)
+    if uniform:
+        W = (rng.random((N, N)) < 10.0 / N).astype(np.float64)
+        W = np.triu(W, 1); W = W + W.T
+        S = W / np.max(np.abs(np.linalg.eigvalsh(W)))
+    else:
+        S = random_graph(N, 10.0 / N, 91)[0]
+    torch.manual_seed(17)
+    m = archit.GatedGCRNNforRegression(G, F, K, K, torch.tanh, torch.nn.ReLU, [1], S, True, time_gating=tg, spatial_gating=None,
+                                       mlpType='multipMlp').to(dev).float()
+    B, T = 5, 4
+    X = torch.tensor(rng.standard_normal((B, T, G, N)), dtype=torch.float32, device=dev).to(torch.bfloat16)
+    h0 = torch.tensor(0.3 * rng.standard_normal((B, F, N)), dtype=torch.float32, device=dev).to(torch.bfloat16)
+    with torch.no_grad():
+        y = m(X, h0)                                                 # fused head
+        assert m.stateGCRNN.forward_with_head(X, h0, m.outputNN[0].weight, m.outputNN[0].bias) is not None
+        H = m.stateGCRNN(X, h0)                                      # the cell alone, then the head by hand in fp64
+        lin = m.outputNN[0]
+        want = torch.einsum('of,btfn->bton', lin.weight.double(), H.double()) + lin.bias.double().view(1, 1, -1, 1)
+    assert tuple(y.shape) == (B, T, 1, N)
+    err = (y.double() - want).abs().max()
+    assert float(err) <= 1.0 / 128 * float(want.abs().max()), float(err)            # y is returned in the input dtype (bf16)
+    with torch.no_grad():
+        yf = m.stateGCRNN.forward_with_head(X, h0, lin.weight, lin.bias)             # fp32 result of the fused epilogue
+    assert float((yf.double() - want).abs().max()) <= 1e-5 * max(1.0, float(want.abs().max()))
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('sg', ['edge', None])
 def test_fused_paths_without_bias(sg):
     """Cells built with bias=False (the reference allows it, graphML.py:2218-2222) on the fused kernels: forward and training against
