@@ -90,7 +90,7 @@ def _bind(lib):
         'gcrnn_fused_edge_attention_supported': (C.c_int, [_c_i64, _c_i64]),
         'gcrnn_fused_edge_attention_bf16': (C.c_int, [_c_p] * 13 + [_c_i64] * 5 + [C.c_double, _c_p]),
         'gcrnn_fused_edge_attention_backward_supported': (C.c_int, [_c_i64, _c_i64, _c_i64]),
-        'gcrnn_fused_edge_attention_backward_bf16': (C.c_int, [_c_p] * 14 + [_c_i64] * 5 + [C.c_double, _c_p]),
+        'gcrnn_fused_edge_attention_backward_bf16': (C.c_int, [_c_p] * 14 + [_c_i64] * 6 + [C.c_double, _c_p]),
         'gcrnn_fused_backward_step_bf16': (C.c_int, [_c_p] * 11 + [_c_i64] * 5 + [C.c_double, _c_p, _c_p, _c_i64, _c_p]),
         'gcrnn_fused_backward_seed_bf16': (C.c_int, [_c_p, _c_p, _c_p, _c_i64, _c_p]),
         'gcrnn_fused_x3_supported': (C.c_int, [_c_i64, _c_i64, _c_i64, _c_i64, _c_i64]),

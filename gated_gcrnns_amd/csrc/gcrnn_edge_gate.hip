@@ -46,6 +46,41 @@ __device__ __forceinline__ uint4 pack8(const float* o) {
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
+// Softmax statistics (max, 1 / sum of exp) of every support row, one thread per row. The row's records and the scores they point at
+// are fetched eight at a time (eight independent global loads, then eight LDS reads) -- a serial walk costs one global and one LDS
+// latency PER EDGE, and at one workgroup per CU nothing else hides it.
+template <int THREADS>
+__device__ __forceinline__ void row_softmax_stats(float4* __restrict__ sc, const int32_t* __restrict__ rowptr, const int2* __restrict__ r_edge,
+                                                  int N, float slope, int tid) {
+  for (int m = tid; m < N; m += THREADS) {
+    const int j0 = rowptr[m], j1 = rowptr[m + 1];
+    const float s2m = sc[m].y;
+    float mx = -1e30f, sum = 0.f;
+    for (int j = j0; j < j1; j += 8) {
+      int nn[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) nn[u] = (j + u < j1) ? r_edge[j + u].x : -1;
+      float ev[8];
+      float cm = -1e30f;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        float e = (nn[u] >= 0 ? sc[nn[u]].x : 0.f) + s2m;
+        e = e > 0.f ? e : slope * e;
+        ev[u] = nn[u] >= 0 ? e : -1e30f;
+        cm = fmaxf(cm, ev[u]);
+      }
+      const float nm = fmaxf(mx, cm);
+      float add = 0.f;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) add += nn[u] >= 0 ? eexp(ev[u] - nm) : 0.f;
+      sum = sum * eexp(mx - nm) + add;
+      mx = nm;
+    }
+    sc[m].z = mx;
+    sc[m].w = sum > 0.f ? 1.f / sum : 0.f;
+  }
+}
+
 // LDS carve-up: rows of 8-feature pieces, then the per-node scalars sc[n] = {s1, s2, row max, 1 / row sum}; once the aggregation
 // is done the same bytes hold the transposed image [F][N + 64] of h for the user-layout store (row f shifted by 8 (f >> 3)
 // columns, which spreads the eight feature groups of a wave's ds_write_b16 over all banks)
@@ -115,22 +150,8 @@ __global__ __launch_bounds__(ETHREADS) void edge_att_fwd_kernel(
     }
   }
   __syncthreads();
-  // ---- phase A: softmax statistics of every support row (one thread per row, online max / sum) ----------------------------
-  for (int m = tid; m < N; m += ETHREADS) {
-    const int j0 = rowptr[m], j1 = rowptr[m + 1];
-    const float s2m = sc[m].y;
-    float mx = -1e30f, sum = 0.f;
-#pragma unroll 4
-    for (int j = j0; j < j1; ++j) {
-      float e = sc[r_edge[j].x].x + s2m;
-      e = e > 0.f ? e : slope * e;
-      const float nm = fmaxf(mx, e);
-      sum = sum * eexp(mx - nm) + eexp(e - nm);
-      mx = nm;
-    }
-    sc[m].z = mx;
-    sc[m].w = sum > 0.f ? 1.f / sum : 0.f;
-  }
+  // ---- phase A: softmax statistics of every support row -----------------------------------------------------------------
+  row_softmax_stats<ETHREADS>(sc, rowptr, r_edge, N, slope, tid);
   __syncthreads();
   // ---- phase B: aggregation over the in-edges, epilogue; slot base + nl of a pass is node t_order[base + nl] ---------------
   float giv = 1.f, gfv = 1.f;
@@ -309,8 +330,8 @@ template <int LPN> __device__ __forceinline__ float group_sum(float v) {       /
   return v;
 }
 
-template <int F>
-__global__ __launch_bounds__(ETHREADS) void edge_att_bwd_kernel(
+template <int F, bool HUB>
+__global__ __launch_bounds__(HUB ? 512 : 1024) void edge_att_bwd_kernel(
     const uint16_t* __restrict__ dpre,       // [items][NPad][F] bf16
     const uint16_t* __restrict__ r,          // [items][NPad][F] bf16: relu(att(z)) of this branch
     const float* __restrict__ g,             // [items] scalar gate of this branch, or null (= 1)
@@ -323,8 +344,10 @@ __global__ __launch_bounds__(ETHREADS) void edge_att_bwd_kernel(
     float* __restrict__ da_part,             // [items][2][F]
     float* __restrict__ dgate,               // [items]: sum dpre . r (the gradient of g), or null
     int N, int NPad, int nnz, float slope) {
+  // HUB: rows with more than 32 records exist: their extra chunks need registers the lean variant (16 waves) does not have -> 8 waves
+  constexpr int BT = HUB ? 512 : 1024;
   using L = EdgeLds<F>;
-  constexpr int LPN = L::LPN, NPP = L::NPP;
+  constexpr int LPN = L::LPN, NPP = BT / LPN;
   constexpr int MAXC = 32 / LPN, GPC = LPN / 4;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   uint4* dol = reinterpret_cast<uint4*>(smem);
@@ -346,11 +369,11 @@ __global__ __launch_bounds__(ETHREADS) void edge_att_bwd_kernel(
   for (int j = 0; j < 8; ++j) { a1r[j] = a12[p * 8 + j]; a2r[j] = a12[F + p * 8 + j]; }
   // ---- phase 0: do image, scores, gate gradient -------------------------------------------------------------------------
   float gsum = 0.f;
-  for (int i0 = tid; i0 < total; i0 += 2 * ETHREADS) {
+  for (int i0 = tid; i0 < total; i0 += 2 * BT) {
     uint4 vz[2], vd[2], vr[2];
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
-      const int idx = i0 + u * ETHREADS;
+      const int idx = i0 + u * BT;
       const bool ok = idx < total;
       vz[u] = ok ? zsrc[idx] : uint4{0, 0, 0, 0};
       vd[u] = ok ? dsrc[idx] : uint4{0, 0, 0, 0};
@@ -358,7 +381,7 @@ __global__ __launch_bounds__(ETHREADS) void edge_att_bwd_kernel(
     }
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
-      const int idx = i0 + u * ETHREADS;
+      const int idx = i0 + u * BT;
       float zf[8], df[8], rf[8];
       unpack8(vz[u], zf);
       unpack8(vd[u], df);
@@ -381,21 +404,7 @@ __global__ __launch_bounds__(ETHREADS) void edge_att_bwd_kernel(
   }
   __syncthreads();
   // ---- phase A: softmax statistics of every support row ------------------------------------------------------------------
-  for (int m = tid; m < N; m += ETHREADS) {
-    const int j0 = rowptr[m], j1 = rowptr[m + 1];
-    const float s2m = sc[m].y;
-    float mx = -1e30f, sum = 0.f;
-#pragma unroll 4
-    for (int j = j0; j < j1; ++j) {
-      float e = sc[r_edge[j].x].x + s2m;
-      e = e > 0.f ? e : slope * e;
-      const float nm = fmaxf(mx, e);
-      sum = sum * eexp(mx - nm) + eexp(e - nm);
-      mx = nm;
-    }
-    sc[m].z = mx;
-    sc[m].w = sum > 0.f ? 1.f / sum : 0.f;
-  }
+  row_softmax_stats<BT>(sc, rowptr, r_edge, N, slope, tid);
   __syncthreads();
   // ---- phase R: rows by descending out-degree ----------------------------------------------------------------------------
   auto bounds = [&](int base, int& m, int& j0, int& deg) {
@@ -478,6 +487,7 @@ __global__ __launch_bounds__(ETHREADS) void edge_att_bwd_kernel(
     for (int c = 0; c < MAXC; ++c) { dal[c] *= __int_as_float(reca[c].y); rsum += al[c] * dal[c]; }
     // hub rows (out-degree beyond the register chunks): the same gather chunk by chunk; d alpha of those records waits in the
     // scratch (each lane reads back only what it wrote itself) until the row sum R is complete
+    if constexpr (HUB)
     for (int e0 = MAXC * LPN; e0 < dmax; e0 += LPN) {
       const int2 rc = (e0 + p < dega) ? r_edge[j0a + e0 + p] : int2{0, 0};
       const float v = __int_as_float(rc.y);
@@ -512,6 +522,7 @@ __global__ __launch_bounds__(ETHREADS) void edge_att_bwd_kernel(
       ds2 += dl;
       if (c * LPN + p < dega) Ei[j0a + c * LPN + p] = dl;
     }
+    if constexpr (HUB)
     for (int e0 = MAXC * LPN; e0 < dmax; e0 += LPN) {
       if (e0 + p < dega) {
         const int2 rc = r_edge[j0a + e0 + p];
@@ -539,9 +550,16 @@ __global__ __launch_bounds__(ETHREADS) void edge_att_bwd_kernel(
   __threadfence_block();
   __syncthreads();
   // ---- phase C: ds1[n] = column sums of dl through the scratch (this workgroup's own stores) --------------------------------
-  for (int n = tid; n < N; n += ETHREADS) {
+  for (int n = tid; n < N; n += BT) {
     float acc1 = 0.f;
-    for (int q = t_rowptr[n]; q < t_rowptr[n + 1]; ++q) acc1 += Ei[t_pos[q]];
+    const int q1 = t_rowptr[n + 1];
+    for (int q = t_rowptr[n]; q < q1; q += 8) {             // eight positions, then eight scratch reads: two latencies per chunk
+      int tp[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) tp[u] = (q + u < q1) ? t_pos[q + u] : -1;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc1 += tp[u] >= 0 ? Ei[tp[u]] : 0.f;
+    }
     sc[n].w = acc1;
   }
   __syncthreads();
@@ -549,38 +567,49 @@ __global__ __launch_bounds__(ETHREADS) void edge_att_bwd_kernel(
   f32x2 dacc[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) dacc[j] = f32x2{0.f, 0.f};
-  for (int idx = tid; idx < total; idx += ETHREADS) {
-    const int n = idx / LPN;
-    const uint4 vz = zsrc[idx], vp = dzd[idx];
-    const float4 s = sc[n];
-    float zf[8], pf[8];
-    unpack8(vz, zf);
-    unpack8(vp, pf);
+  for (int i0 = tid; i0 < total; i0 += 2 * BT) {        // two rows per lane and trip: their loads are issued before the first store
+    uint4 vz[2], vp[2];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      pf[j] += a1r[j] * s.w;
-      dacc[j] += f32x2{s.w, s.z} * zf[j];
+    for (int u = 0; u < 2; ++u) {
+      const int idx = i0 + u * BT;
+      vz[u] = idx < total ? zsrc[idx] : uint4{0, 0, 0, 0};
+      vp[u] = idx < total ? dzd[idx] : uint4{0, 0, 0, 0};
     }
-    dzd[idx] = pack8(pf);
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int idx = i0 + u * BT;
+      if (idx < total) {
+        const float4 s = sc[idx / LPN];
+        float zf[8], pf[8];
+        unpack8(vz[u], zf);
+        unpack8(vp[u], pf);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          pf[j] += a1r[j] * s.w;
+          dacc[j] += f32x2{s.w, s.z} * zf[j];
+        }
+        dzd[idx] = pack8(pf);
+      }
+    }
   }
-  for (int idx = total + tid; idx < NPad * LPN; idx += ETHREADS) dzd[idx] = uint4{0, 0, 0, 0};
+  for (int idx = total + tid; idx < NPad * LPN; idx += BT) dzd[idx] = uint4{0, 0, 0, 0};
   // block reductions (fixed order): da over the nodes, the gate gradient over everything; the do image is dead
   __syncthreads();
-  float* red = reinterpret_cast<float*>(smem);                 // [ETHREADS / LPN][LPN * 16] da partials, then [ETHREADS] gate partials
+  float* red = reinterpret_cast<float*>(smem);                 // [BT / LPN][LPN * 16] da partials, then [BT] gate partials
 #pragma unroll
   for (int j = 0; j < 8; ++j) { red[(nl * LPN + p) * 16 + j] = dacc[j].x; red[(nl * LPN + p) * 16 + 8 + j] = dacc[j].y; }
-  float* gred = red + ETHREADS * 16;
+  float* gred = red + BT * 16;
   gred[tid] = gsum;
   __syncthreads();
   if (tid < 2 * F) {
     const int which = tid / F, f = tid % F, pp = f / 8, j = f % 8;
     float sum = 0.f;
-    for (int k = 0; k < ETHREADS / LPN; ++k) sum += red[(k * LPN + pp) * 16 + which * 8 + j];
+    for (int k = 0; k < BT / LPN; ++k) sum += red[(k * LPN + pp) * 16 + which * 8 + j];
     da_part[item * 2 * F + tid] = sum;
   }
   if (dgate && tid == 2 * F) {
     float sum = 0.f;
-    for (int k = 0; k < ETHREADS; ++k) sum += gred[k];
+    for (int k = 0; k < BT; ++k) sum += gred[k];
     dgate[item] = sum;
   }
 }
@@ -588,16 +617,17 @@ __global__ __launch_bounds__(ETHREADS) void edge_att_bwd_kernel(
 template <int F>
 static int edge_att_bwd_t(const void* dpre, const void* r, const float* g, const void* z, const float* a12, const int32_t* rowptr,
                           const void* r_edge, const int32_t* r_order, const int32_t* t_rowptr, const int32_t* t_pos, float* E, void* dz,
-                          float* da_part, float* dgate, int64_t items, int64_t N, int64_t NPad, int64_t nnz, float slope, hipStream_t st) {
+                          float* da_part, float* dgate, int64_t items, int64_t N, int64_t NPad, int64_t nnz, float slope, bool hub, hipStream_t st) {
   size_t lds = (size_t)N * F * 2 + (size_t)N * 16;
-  const size_t red = (size_t)ETHREADS * 17 * 4;
+  const int bt = hub ? 512 : 1024;
+  const size_t red = (size_t)bt * 17 * 4;
   if (lds < red) lds = red;
   if (lds > 160 * 1024) return GCRNN_ERR_UNSUPPORTED;
-  auto kern = edge_att_bwd_kernel<F>;
+  auto kern = hub ? edge_att_bwd_kernel<F, true> : edge_att_bwd_kernel<F, false>;
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
     return GCRNN_ERR_LAUNCH;
   GCRNN_PRE_LAUNCH();
-  kern<<<(unsigned)items, ETHREADS, lds, st>>>((const uint16_t*)dpre, (const uint16_t*)r, g, (const uint16_t*)z, a12, rowptr, (const int2*)r_edge,
+  kern<<<(unsigned)items, bt, lds, st>>>((const uint16_t*)dpre, (const uint16_t*)r, g, (const uint16_t*)z, a12, rowptr, (const int2*)r_edge,
                                                r_order, t_rowptr, t_pos, E, (uint16_t*)dz, da_part, dgate, (int)N, (int)NPad, (int)nnz, slope);
   GCRNN_CHECK_LAUNCH();
   return GCRNN_OK;
@@ -641,11 +671,11 @@ extern "C" int gcrnn_fused_edge_attention_backward_bf16(const void* dpre, const 
                                                         const int32_t* rowptr, const void* r_edge, const int32_t* r_order,
                                                         const int32_t* t_rowptr, const int32_t* t_pos, float* scratch, void* dz,
                                                         float* da_part, float* dgate, int64_t items, int64_t N, int64_t NPad, int64_t F,
-                                                        int64_t nnz, double negative_slope, void* stream) {
+                                                        int64_t nnz, int64_t max_out_degree, double negative_slope, void* stream) {
   if (!dpre || !r || !z || !a12 || !rowptr || !r_edge || !r_order || !t_rowptr || !t_pos || !scratch || !dz || !da_part) return GCRNN_ERR_NULL_POINTER;
   if (items <= 0 || items > 2147483647LL || N <= 0 || N > NPad || N % 8 || nnz <= 0 || items * nnz > (1LL << 40)) return GCRNN_ERR_BAD_SHAPE;
   hipStream_t st = as_stream(stream);
-  if (F == 64) return edge_att_bwd_t<64>(dpre, r, g, z, a12, rowptr, r_edge, r_order, t_rowptr, t_pos, scratch, dz, da_part, dgate, items, N, NPad, nnz, (float)negative_slope, st);
-  if (F == 32) return edge_att_bwd_t<32>(dpre, r, g, z, a12, rowptr, r_edge, r_order, t_rowptr, t_pos, scratch, dz, da_part, dgate, items, N, NPad, nnz, (float)negative_slope, st);
+  if (F == 64) return edge_att_bwd_t<64>(dpre, r, g, z, a12, rowptr, r_edge, r_order, t_rowptr, t_pos, scratch, dz, da_part, dgate, items, N, NPad, nnz, (float)negative_slope, max_out_degree > 32 || F == 32 /* (the lean F = 32 instantiation would spill: eight record chunks) */, st);
+  if (F == 32) return edge_att_bwd_t<32>(dpre, r, g, z, a12, rowptr, r_edge, r_order, t_rowptr, t_pos, scratch, dz, da_part, dgate, items, N, NPad, nnz, (float)negative_slope, max_out_degree > 32 || F == 32 /* (the lean F = 32 instantiation would spill: eight record chunks) */, st);
   return GCRNN_ERR_UNSUPPORTED;
 }

@@ -937,7 +937,7 @@ def fused_edge_attention_backward(dpre, r, g, z, a12, graph, N, scratch=None, ne
     assert scratch.numel() >= items * ep['nnz']
     check(lib.gcrnn_fused_edge_attention_backward_bf16(_p(dpre), _p(r), _p(g), _p(z), _p(a12), _p(ep['rowptr']), _p(ep['r_edge']),
                                                        _p(ep['r_order']), _p(ep['t_rowptr']), _p(ep['t_pos']), _p(scratch), _p(dz),
-                                                       _p(da_part), _p(dgate), items, int(N), npad, F, ep['nnz'], float(negative_slope),
+                                                       _p(da_part), _p(dgate), items, int(N), npad, F, ep['nnz'], int(ep['max_out_degree']), float(negative_slope),
                                                        _stream()), 'fused_edge_attention_backward')
     return dz, da_part, dgate
 

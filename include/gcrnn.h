@@ -205,6 +205,7 @@ int gcrnn_fused_edge_attention_backward_bf16(const void* dpre, const void* r, co
                                              const int32_t* rowptr, const void* r_edge, const int32_t* r_order,
                                              const int32_t* t_rowptr, const int32_t* t_pos, float* scratch, void* dz, float* da_part,
                                              float* dgate, int64_t items, int64_t N, int64_t NPad, int64_t F, int64_t nnz,
+                                             int64_t max_out_degree /* of the support: > 32 selects the hub variant (8 waves, chunked extra records) */,
                                              double negative_slope, void* stream);
 int gcrnn_fused_backward_step_bf16(const void* operand, const void* dH_prev, const void* h_prev, void* dpre_prev, const void* wpackT,
                                    const int32_t* tile_nodes, const int32_t* tile_off, const int32_t* ell_col, const float* ell_val,
