@@ -239,15 +239,35 @@ def timed_steps(ctx, step):
     for _ in range(args.warmup):
         step()
     sync()
+    if dist_on:
+        # the collectives of the timing protocol itself, once, outside the timed region: RCCL sets up a communicator's channels and
+        # loads its kernels on first use (seen on a cold box: one 40-60 ms stall inside a 5-step window, tools/dist_cold_probe.py)
+        tw = torch.zeros(1, device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(tw, op=torch.distributed.ReduceOp.MAX)
+        sync()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    import gc
+    gc.collect()                  # like timeit: no cyclic-garbage pass of the interpreter inside the timed steps (its position
+    gc_was_on = gc.isenabled()    # depends on the process's allocation history, not on the workload)
+    gc.disable()
     t0 = time.perf_counter()
     ev0.record()
+    trace = [] if os.environ.get('GCRNN_BENCH_TRACE') else None       # diagnosis only: per-step host time and a device event
     for _ in range(args.steps):
         step()
+        if trace is not None:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            trace.append((time.perf_counter(), e))
     ev1.record()
     sync()
     wall = time.perf_counter() - t0
+    if gc_was_on:
+        gc.enable()
     dev_ms = ev0.elapsed_time(ev1)
+    if trace:
+        sys.stderr.write('bench trace host ms: %s\n' % ' '.join('%.1f' % (1e3 * (t - (trace[i - 1][0] if i else t0))) for i, (t, _) in enumerate(trace)))
+        sys.stderr.write('bench trace dev  ms: %s\n' % ' '.join('%.1f' % (trace[i - 1][1] if i else ev0).elapsed_time(e) for i, (_, e) in enumerate(trace)))
     if dist_on:
         tw = torch.tensor([wall], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(tw, op=torch.distributed.ReduceOp.MAX)
