@@ -4,6 +4,7 @@
 #include <array>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <numeric>
 #include <vector>
 #include "../../include/gcrnn.h"
@@ -391,12 +392,158 @@ extern "C" int gcrnn_ell_assign_rows(const int32_t* rowptr, const int32_t* col, 
   return gcrnn_ell_assign_rows_z(rowptr, col, N, order, pad, ntiles, -1, node_addr);
 }
 
+// Write-aware key search (default). A node's 4-bit gather key is key4 = swz << 2 | (row & 3); the state write-backs
+// (ds_write_b128: 8 groups of 8 contiguous lanes on 32 banks = 8 bank quads; lane = slot + 16 quad, address = row << 6 | (swz ^ quad) << 4)
+// are conflict-free exactly when the 8 slots of every HALF TILE sit on 8 different write keys wkey = (row & 1) << 2 | swz. That is kept
+// as a hard constraint: each half tile holds a permutation of the 8 write keys; bit 1 of the row class is free. The search moves inside
+// that space -- exchange the keys of two slots of one half tile; exchange the free bit of two nodes of equal row parity (the four row
+// classes stay at N / 4 nodes each) -- and minimises the gather cycles of the tiles (sum over tiles of max(depth, largest key count)),
+// then the squared overshoot. A pure function of the graph (fixed pseudo-random visiting order).
+namespace {
+struct KeySearch {
+  int64_t N, ntiles;
+  std::vector<std::vector<std::pair<int, int>>> in;     // node -> (tile, flip) of every slot that gathers it
+  std::vector<int> depth, key;
+  std::vector<std::array<int, 16>> cnt;
+  std::vector<int> touched;
+  std::vector<int> stamp;
+  int epoch = 0;
+  void add(int32_t n, int d) { for (auto& e : in[n]) cnt[e.first][key[n] ^ e.second] += d; }
+  void mark(int32_t n) {
+    for (auto& e : in[n]) if (stamp[e.first] != epoch) { stamp[e.first] = epoch; touched.push_back(e.first); }
+  }
+  void cost(long& c1, long& c2) const {
+    c1 = 0; c2 = 0;
+    for (int t : touched) {
+      int mx = 0;
+      for (int q = 0; q < 16; ++q) {
+        mx = std::max(mx, cnt[t][q]);
+        const int over = cnt[t][q] - depth[t] + 1;
+        if (over > 0) c2 += (long)over * over;
+      }
+      c1 += std::max(depth[t], mx);
+    }
+  }
+  // exchange-type move on two nodes: keys become (ka, kb); returns true (and keeps it) when the cost drops
+  bool try_move(int32_t a, int32_t b, int ka, int kb) {
+    ++epoch; touched.clear(); mark(a); mark(b);
+    if (touched.empty()) return false;
+    long p1, p2, q1, q2;
+    cost(p1, p2);
+    const int oa = key[a], ob = key[b];
+    add(a, -1); add(b, -1); key[a] = ka; key[b] = kb; add(a, 1); add(b, 1);
+    cost(q1, q2);
+    if (q1 < p1 || (q1 == p1 && q2 < p2)) return true;
+    add(a, -1); add(b, -1); key[a] = oa; key[b] = ob; add(a, 1); add(b, 1);
+    return false;
+  }
+};
+}  // namespace
+
+static int assign_rows_write_aware(const int32_t* rowptr, const int32_t* col, int64_t N, const int32_t* order, int pad,
+                                   int64_t ntiles, int64_t zero_from, int32_t* node_addr) {
+  KeySearch ks;
+  ks.N = N; ks.ntiles = ntiles;
+  ks.depth.resize(ntiles);
+  for (int64_t t = 0; t < ntiles; ++t) ks.depth[t] = ell_tile_deg(rowptr, order, N, t, 16, pad);
+  ks.in.assign(N, {});
+  std::vector<int> half(N, -1);
+  for (int64_t p = 0; p < N; ++p) {
+    const int32_t n = order ? order[p] : (int32_t)p;
+    if (n < 0 || n >= N || half[n] >= 0) return GCRNN_ERR_BAD_SHAPE;        // every node sits in exactly one slot
+    half[n] = (int)(p >> 3);
+    const int t = (int)(p >> 4), r = (int)(p & 15);
+    for (int32_t j = rowptr[n]; j < rowptr[n + 1]; ++j) {
+      if (col[j] < 0 || col[j] >= N) return GCRNN_ERR_BAD_SHAPE;
+      ks.in[col[j]].push_back({t, (r >= 4 && r < 12) ? 4 : 0});
+    }
+  }
+  const int64_t nhalf = N / 8;
+  std::vector<std::array<int32_t, 8>> member(nhalf);
+  std::vector<int> fill(nhalf, 0);
+  for (int64_t p = 0; p < N; ++p) member[p >> 3][fill[p >> 3]++] = order ? order[p] : (int32_t)p;
+  auto key_of = [](int w, int b1) { return ((w & 3) << 2) | (b1 << 1) | (w >> 2); };
+  ks.key.assign(N, -1);
+  std::vector<char> fixed(N, 0);
+  int cls[4] = {0, 0, 0, 0};
+  if (zero_from >= 0)
+    for (int64_t n = zero_from; n < N && n - zero_from < 16; ++n) {
+      if (rowptr[n + 1] != rowptr[n] || !ks.in[n].empty()) return GCRNN_ERR_BAD_SHAPE;   // a padding row has no edges
+      const int i = (int)(n - zero_from);                     // one zero row per gather key; any 8 consecutive ones differ in the write key
+      ks.key[n] = key_of(i & 7, i >> 3);
+      fixed[n] = 1;
+      ++cls[ks.key[n] & 3];
+    }
+  for (int64_t h = 0; h < nhalf; ++h) {
+    bool used[8] = {false};
+    for (int32_t n : member[h]) if (fixed[n]) {
+      const int w = ((ks.key[n] & 1) << 2) | (ks.key[n] >> 2);
+      if (used[w]) return GCRNN_ERR_UNSUPPORTED;
+      used[w] = true;
+    }
+    int w = 0;
+    for (int32_t n : member[h]) {
+      if (fixed[n]) continue;
+      while (used[w]) ++w;
+      used[w] = true;
+      const int b0 = w >> 2;
+      const int b1 = cls[2 | b0] < cls[b0] ? 1 : 0;           // keep the two classes of this row parity level
+      ks.key[n] = key_of(w, b1);
+      ++cls[ks.key[n] & 3];
+    }
+  }
+  if (cls[0] != N / 4 || cls[1] != N / 4 || cls[2] != N / 4 || cls[3] != N / 4) return GCRNN_ERR_UNSUPPORTED;
+  ks.cnt.assign(ntiles, {});
+  for (auto& c : ks.cnt) c.fill(0);
+  ks.stamp.assign(ntiles, 0);
+  for (int64_t n = 0; n < N; ++n) ks.add((int32_t)n, 1);
+  std::vector<int32_t> visit(N);
+  std::iota(visit.begin(), visit.end(), 0);
+  uint64_t lcg = 0x9E3779B97F4A7C15ull;
+  auto rnd = [&](uint64_t m) { lcg = lcg * 6364136223846793005ull + 1442695040888963407ull; return (lcg >> 33) % m; };
+  for (int64_t i = N - 1; i > 0; --i) std::swap(visit[i], visit[rnd((uint64_t)(i + 1))]);
+  for (int pass = 0; pass < 12; ++pass) {
+    bool changed = false;
+    for (int64_t vi = 0; vi < N; ++vi) {
+      const int32_t a = visit[vi];
+      if (fixed[a]) continue;
+      // (1) exchange keys with another slot of the same half tile
+      for (int32_t b : member[half[a]]) {
+        if (b == a || fixed[b] || ks.key[a] == ks.key[b]) continue;
+        if (ks.in[a].empty() && ks.in[b].empty()) continue;
+        if (ks.try_move(a, b, ks.key[b], ks.key[a])) changed = true;
+      }
+      // (2) exchange the free row bit with a node of the same row parity (a few pseudo-random partners)
+      if (!ks.in[a].empty())
+        for (int tries = 0; tries < 12; ++tries) {
+          const int32_t b = (int32_t)rnd((uint64_t)N);
+          if (b == a || fixed[b]) continue;
+          if (((ks.key[a] ^ ks.key[b]) & 3) != 2) continue;   // same parity, other free bit
+          if (ks.try_move(a, b, ks.key[a] ^ 2, ks.key[b] ^ 2)) changed = true;
+        }
+    }
+    if (!changed) break;
+  }
+  int next_row[4] = {0, 1, 2, 3};
+  for (int64_t n = 0; n < N; ++n) {
+    const int a = ks.key[n] & 3;
+    if (next_row[a] >= N) return GCRNN_ERR_WORKSPACE;
+    node_addr[n] = (next_row[a] << 6) | ((ks.key[n] >> 2) << 4);
+    next_row[a] += 4;
+  }
+  return GCRNN_OK;
+}
+
 // zero_from >= 0: the first 16 padding rows zero_from .. zero_from+15 get the bank keys 0 .. 15 (fixed, not searched), so that
 // gcrnn_ell_fill_z finds a zero row for every key.
 extern "C" int gcrnn_ell_assign_rows_z(const int32_t* rowptr, const int32_t* col, int64_t N, const int32_t* order, int pad,
                                        int64_t ntiles, int64_t zero_from, int32_t* node_addr) {
   if (!rowptr || !col || !node_addr) return GCRNN_ERR_NULL_POINTER;
   if (N <= 0 || N > 1024 || N % 16 || pad <= 0 || ntiles * 16 < N) return GCRNN_ERR_BAD_SHAPE;
+  if (!getenv("GCRNN_PLAN_LEGACY_KEYS")) {                      // A/B switch: the round-1 search below looks at the gathers only
+    const int rc = assign_rows_write_aware(rowptr, col, N, order, pad, ntiles, zero_from, node_addr);
+    if (rc != GCRNN_ERR_UNSUPPORTED) return rc;
+  }
   std::vector<int> depth(ntiles);
   for (int64_t t = 0; t < ntiles; ++t) depth[t] = ell_tile_deg(rowptr, order, N, t, 16, pad);
   // incoming edges of every node: (tile, flip) with flip = 4 for slots 4..11

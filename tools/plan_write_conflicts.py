@@ -1,0 +1,28 @@
+# Host-side model of the LDS cycles of a fused plan (runs on the CPU):   python tools/plan_write_conflicts.py [adjoint]
+# gathers: the plan's own gcrnn_ell_conflict_cycles; state write-backs (ds_write_b128: 8 groups of 8 contiguous lanes, 32 banks):
+# a group = 8 consecutive slots of a tile at one quad q, its cycles = the largest number of slots on one bank quad.
+import os, sys
+import numpy as np, torch
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+import bench
+from gated_gcrnns_amd.graph import GraphOperator, as_operator
+
+def write_cycles(plan):
+    slots = plan['tile_slots'].cpu().numpy().astype(np.int64) & 0xFFFF
+    row, swz = slots >> 6, (slots >> 4) & 3
+    wkey = ((row & 1) << 2) | swz
+    tiles = wkey.reshape(-1, 2, 8)
+    m = np.zeros(tiles.shape[:2], dtype=np.int64)
+    for k in range(8):
+        m = np.maximum(m, (tiles == k).sum(-1))
+    return int(4 * m.sum()), int(4 * m.size), np.bincount(m.reshape(-1), minlength=9)
+
+if __name__ == '__main__':
+    adjoint = len(sys.argv) > 1 and sys.argv[1] == 'adjoint'
+    S = bench.sbm_graph()
+    op = as_operator(torch.from_numpy(S).float())
+    plan = op.fused_plan(adjoint=adjoint)
+    cyc, ideal, hist = write_cycles(plan)
+    ent = plan['entries']
+    print('entries %d  gather cycles %d (conflict-free %d)  write-back LDS cycles per hop %d (conflict-free %d)  half-tile multiplicity histogram %s'
+          % (ent, plan['gather_cycles'], ent * 4, cyc, ideal, hist.tolist()))
