@@ -872,10 +872,16 @@ __global__ __launch_bounds__(STHREADS) void fused_step_kernel(
       asm volatile("" : "+v"(wv));
       const int node = wv >> 16;
       const uint32_t p0 = __float_as_uint(u[i][0][0]), p1 = __float_as_uint(u[i][0][1]);
-      *reinterpret_cast<uint16_t*>(tst + (q * 4 + 0) * RS + node * 2) = (uint16_t)(p0 & 0xffffu);
-      *reinterpret_cast<uint16_t*>(tst + (q * 4 + 1) * RS + node * 2) = (uint16_t)(p0 >> 16);
-      *reinterpret_cast<uint16_t*>(tst + (q * 4 + 2) * RS + node * 2) = (uint16_t)(p1 & 0xffffu);
-      *reinterpret_cast<uint16_t*>(tst + (q * 4 + 3) * RS + node * 2) = (uint16_t)(p1 >> 16);
+      // odd quads write their rows in the order 2, 3, 0, 1: RS = 8 banks mod 32, so the two quads of a 32-lane store group would
+      // otherwise hit one bank for one node in every instruction; with the rotation they sit 16 banks apart, and a tile whose nodes
+      // differ in (node >> 1) & 15 (graph.spread_tile_classes) scatters conflict-free
+      const uint32_t pa = (q & 1) ? p1 : p0, pb = (q & 1) ? p0 : p1;
+      char* ra = tst + (q * 4 + ((q & 1) ? 2 : 0)) * RS + node * 2;
+      char* rb = tst + (q * 4 + ((q & 1) ? 0 : 2)) * RS + node * 2;
+      *reinterpret_cast<uint16_t*>(ra) = (uint16_t)(pa & 0xffffu);
+      *reinterpret_cast<uint16_t*>(ra + RS) = (uint16_t)(pa >> 16);
+      *reinterpret_cast<uint16_t*>(rb) = (uint16_t)(pb & 0xffffu);
+      *reinterpret_cast<uint16_t*>(rb + RS) = (uint16_t)(pb >> 16);
     }
     __syncthreads();
     const int segs = N >> 3;                           // 16-byte segments per row (N % 8 == 0 checked by the host)

@@ -155,8 +155,14 @@ __global__ __launch_bounds__(512, 2) void fused_wgrad_kernel(
         if (k < K - 1) *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(state) + (wv & 0xffff)) = cur[i];
         const int node = wv >> 16;
         char* tb = tbuf + (node >= 512 ? TBYTES - 512 * 2 : 0) + node * 2;
+        // odd quads write their rows in the order 2, 3, 0, 1 (TSTRIDE = 8 banks mod 32: the two quads of a 32-lane store group then sit
+        // 16 banks apart instead of on one bank; with graph.spread_tile_classes the 2-byte scatter of a tile is conflict-free)
+        const int ro = (q & 1) ? 2 : 0;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) *reinterpret_cast<uint16_t*>(tb + (q * 4 + c) * TSTRIDE) = f2bf(cur[i][c]);
+        for (int c = 0; c < 4; ++c) {
+          const float v = (q & 1) ? cur[i][c ^ 2] : cur[i][c];
+          *reinterpret_cast<uint16_t*>(tb + (q * 4 + (c ^ ro)) * TSTRIDE) = f2bf(v);
+        }
       }
       __syncthreads();
       // S2: D_k += du_k^T z over nodes 0..511 (register-resident fragments), then the first re-fetched batch (nodes 512..767)
@@ -217,9 +223,12 @@ __global__ __launch_bounds__(512, 2) void fused_wgrad_kernel(
         if (k < K - 1) *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(state) + (wv & 0xffff)) = cur[i];
         const int node = wv >> 16;
         if (node < 512) {
+          const int ro = (q & 1) ? 2 : 0;                    // odd quads: rows in the order 2, 3, 0, 1 (see the uniform variant)
 #pragma unroll
-          for (int c = 0; c < 4; ++c)
-            *reinterpret_cast<uint16_t*>(tbuf + (q * 4 + c) * TSTRIDE + node * 2) = f2bf(cur[i][c]);
+          for (int c = 0; c < 4; ++c) {
+            const float v = (q & 1) ? cur[i][c ^ 2] : cur[i][c];
+            *reinterpret_cast<uint16_t*>(tbuf + (q * 4 + (c ^ ro)) * TSTRIDE + node * 2) = f2bf(v);
+          }
         }
       }
       __syncthreads();
@@ -243,9 +252,12 @@ __global__ __launch_bounds__(512, 2) void fused_wgrad_kernel(
         asm volatile("" : "+v"(wv));
         const int node = wv >> 16;
         if (node >= 512) {
+          const int ro = (q & 1) ? 2 : 0;
 #pragma unroll
-          for (int c = 0; c < 4; ++c)
-            *reinterpret_cast<uint16_t*>(tbuf + (q * 4 + c) * TSTRIDE + (node - 512) * 2) = f2bf(cur[i][c]);
+          for (int c = 0; c < 4; ++c) {
+            const float v = (q & 1) ? cur[i][c ^ 2] : cur[i][c];
+            *reinterpret_cast<uint16_t*>(tbuf + (q * 4 + (c ^ ro)) * TSTRIDE + (node - 512) * 2) = f2bf(v);
+          }
         }
       }
       __syncthreads();

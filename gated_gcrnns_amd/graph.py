@@ -82,6 +82,52 @@ def degree_order(rowptr):
     return order
 
 
+def spread_tile_classes(slots, deg, nreal, pad=4):
+    """slots [ntiles][16]: node ids in descending-degree order (padding rows last). The kernels scatter a tile's results 2 bytes at a time
+    into transposed [feature][node] LDS images (user-layout output of the step kernels, du_k image of the weight gradient); with the
+    rows rotated per quad, such a scatter is bank-conflict-free exactly when the 16 nodes of a tile differ in (node >> 1) & 15.
+    Exchange nodes between tiles until (nearly) every tile has that property, never raising a tile's depth (a node only moves to a tile
+    at least as deep as its degree), so the ELL keeps its size. Padding rows stay where they are. Deterministic."""
+    slots = slots.copy()
+    ntiles = slots.shape[0]
+    dg = np.concatenate([deg, np.zeros(ntiles * 16 - deg.size, dtype=deg.dtype)]).astype(np.int64)
+    depth = ((dg[slots].max(axis=1) + pad - 1) // pad) * pad
+    tile_of = np.repeat(np.arange(ntiles), 16).reshape(ntiles, 16)
+    for _ in range(6):
+        cls = (slots >> 1) & 15
+        count = np.zeros((ntiles, 16), dtype=np.int64)
+        np.add.at(count, (tile_of.reshape(-1), cls.reshape(-1)), 1)
+        moved = False
+        for t in range(ntiles):
+            for r in range(16):
+                a = int(slots[t, r])
+                c = (a >> 1) & 15
+                if count[t, c] < 2 or a >= nreal:
+                    continue
+                missing = np.nonzero(count[t] == 0)[0]
+                if missing.size == 0:
+                    continue
+                fcls = (slots >> 1) & 15
+                ok = np.isin(fcls, missing) & (dg[slots] <= depth[t]) & (depth[:, None] >= dg[a]) & (slots < nreal) & (tile_of != t)
+                if not ok.any():
+                    continue
+                # what the exchange does to the other tile: it loses a node of class m (good if m was doubled there), gains one of class c
+                du = -(count[tile_of, fcls] > 1).astype(np.int64) + (count[:, c][:, None] >= 1).astype(np.int64)
+                du = np.where(ok, du, 9)
+                u, ru = np.unravel_index(int(np.argmin(du)), du.shape)
+                if du[u, ru] > 0:
+                    continue                                  # would only move the conflict
+                b = int(slots[u, ru])
+                m = (b >> 1) & 15
+                slots[t, r], slots[u, ru] = b, a
+                count[t, c] -= 1; count[t, m] += 1
+                count[u, m] -= 1; count[u, c] += 1
+                moved = True
+        if not moved:
+            break
+    return slots
+
+
 class GraphOperator(object):
     """Device-resident sparse form of a GSO  S: E x N x N  (numpy array or torch tensor)."""
 
@@ -176,6 +222,9 @@ class GraphOperator(object):
         # tiles of 16 slots in degree order; the kernel's wave w owns `per` consecutive STORAGE tiles (contiguous, so its hop
         # is one stream of ELL groups) -- deal the degree-ranked tiles round-robin over the waves to balance them.
         slots = np.concatenate([order, np.arange(self.N, npad, dtype=np.int32)]).astype(np.int32).reshape(ntiles, 16)
+        import os
+        if not os.environ.get('GCRNN_PLAN_NO_CLASS_SPREAD'):                 # env: A/B switch
+            slots = spread_tile_classes(slots, (rowptr[1:] - rowptr[:-1]), self.N)
         per = ntiles // waves
         storage = np.empty_like(slots)
         for w in range(waves):
