@@ -525,6 +525,34 @@ __global__ __launch_bounds__(STHREADS) void fused_step_kernel(
     }
   };
   if (GCRNN_PREFETCH_AT == 1 || (GCRNN_PREFETCH_AT == 2 && K <= 2)) prefetch_next();
+  // EPI 2 (BPTT step): the epilogue's operands h_{t-1} (last touched a whole forward ago) and dH_{t-1} come cold from HBM, and every
+  // CU asks for them at the same moment (the start of its last hop): 2 x 32.8 MB in one hop's time at B = 256. Touch their lines
+  // now -- the chunk workgroups of a sequence split them, one line per thread -- so that the register prefetch below hits L2.
+#ifndef GCRNN_EPI_L2_PREFETCH
+#define GCRNN_EPI_L2_PREFETCH 1      // A/B switch
+#endif
+  // Inline pack: the rows of the user layout that the LDS-DMA of the last hop will fetch (x_{t+1}[b] / dH_{t-2}[b], never touched
+  // before) are cold as well: touch this workgroup's 512 bytes of every row now (128-byte steps plus the last dword of the range).
+  uint32_t prefetched_pk = 0;
+  if constexpr (PKROWS > 0 && GCRNN_EPI_L2_PREFETCH) {
+    constexpr int NPC = NP / NCH;
+    const int prow = tid >> 3, pj = tid & 7;
+    if (pk_src && prow < PKROWS && pj < 5 && chunk * NPC < N) {
+      int node = chunk * NPC + (pj < 4 ? pj * 64 : NPC - 2);
+      node = node < N - 2 ? node : N - 2;                                     // N % 8 == 0 on this path: an even element index, inside the row
+      prefetched_pk = *reinterpret_cast<const uint32_t*>(pk_src + (int64_t)b * pk_stride + (int64_t)prow * N + node);
+    }
+  }
+  uint32_t prefetched_epi = 0;
+  if constexpr (EPI == 2 && GCRNN_EPI_L2_PREFETCH) {
+    constexpr int ELINES = NP * F * 2 / 128 / NCH;                          // 128-byte lines of one operand per chunk workgroup
+    const int idx = tid < ELINES ? tid : tid - ELINES;
+    if (tid < 2 * ELINES) {
+      const int eo = (chunk * ELINES + idx) * 128;
+      prefetched_epi = tid < ELINES ? __builtin_amdgcn_raw_buffer_load_b32(rsrc_a1, eo, b * (NP * F * 2), 0)      // zero-length descriptors when absent
+                                    : __builtin_amdgcn_raw_buffer_load_b32(rsrc_a0, eo, b * (NP * F * 2), 0);
+    }
+  }
 
   // ---- phase 2: Horner hops, state image in LDS -------------------------------------------------
   const char* sbytes = reinterpret_cast<const char*>(state);
@@ -938,7 +966,7 @@ __global__ __launch_bounds__(STHREADS) void fused_step_kernel(
       for (int i = 1; i + 1 < RI; ++i) asm volatile("" ::"v"(vv[i]));
     }
   }
-  asm volatile("" ::"v"(prefetched));      // the prefetch load retires here at the latest
+  asm volatile("" ::"v"(prefetched), "v"(prefetched_epi), "v"(prefetched_pk));      // the prefetch loads retire here at the latest
   __syncthreads();     // the last hop's reads of `state` are done before the next sequence overwrites it
   }  // sequences
 }
