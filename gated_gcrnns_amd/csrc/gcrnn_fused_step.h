@@ -313,6 +313,12 @@ __global__ __launch_bounds__(STHREADS) void fused_step_kernel(
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // provably wave-uniform -> scalar loads below
   const int r = lane & 15, q = lane >> 4;
 
+#ifdef GCRNN_STAGGER_US      // experiment (tools/stagger_ab.sh): every second group of workgroups starts late, so that the chip's CUs are not all in the same phase
+  if (grp & 1) {
+    const uint64_t t0 = wall_clock64();
+    while (wall_clock64() - t0 < (uint64_t)(GCRNN_STAGGER_US) * 100u) __builtin_amdgcn_s_sleep(8);
+  }
+#endif
   for (int i = tid; i < K * KS * 64; i += STHREADS) wl[i] = wpack[(int64_t)chunk * K * KS * 64 + i];
   if (RESIDENT) {
     const int n = (entries >> 2) * 16;                         // the host packed the LDS image: straight copies,
