@@ -550,13 +550,17 @@ __global__ __launch_bounds__(STHREADS) void fused_step_kernel(
     }
   }
   uint32_t prefetched_epi = 0;
-  if constexpr (EPI == 2 && GCRNN_EPI_L2_PREFETCH) {
+  if constexpr ((EPI == 2 || EPI == 5) && GCRNN_EPI_L2_PREFETCH) {          // EPI 5 (node-gated step): Yx_t of the all-steps pass (rsrc_a0)
     constexpr int ELINES = NP * F * 2 / 128 / NCH;                          // 128-byte lines of one operand per chunk workgroup
     const int idx = tid < ELINES ? tid : tid - ELINES;
     if (tid < 2 * ELINES) {
       const int eo = (chunk * ELINES + idx) * 128;
-      prefetched_epi = tid < ELINES ? __builtin_amdgcn_raw_buffer_load_b32(rsrc_a1, eo, b * (NP * F * 2), 0)      // zero-length descriptors when absent
-                                    : __builtin_amdgcn_raw_buffer_load_b32(rsrc_a0, eo, b * (NP * F * 2), 0);
+      if (EPI == 5) {
+        if (tid >= ELINES) prefetched_epi = __builtin_amdgcn_raw_buffer_load_b32(rsrc_a0, eo, b * (NP * F * 2), 0);
+      } else {
+        prefetched_epi = tid < ELINES ? __builtin_amdgcn_raw_buffer_load_b32(rsrc_a1, eo, b * (NP * F * 2), 0)      // zero-length descriptors when absent
+                                      : __builtin_amdgcn_raw_buffer_load_b32(rsrc_a0, eo, b * (NP * F * 2), 0);
+      }
     }
   }
 
