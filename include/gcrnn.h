@@ -238,7 +238,10 @@ int gcrnn_fused_forward_x3(const void* xs3, const void* h03, void* hs3, const vo
 /* LDS placement of the hop state (tile = 16). node_addr[n] = (row << 6) | (swz << 4): node n's 64-byte state row sits at
  * LDS row `row`, its four 16-byte quads XOR-swizzled by `swz` (NULL = identity: row n, swz (n >> 2) & 3).
  * gcrnn_ell_assign_rows chooses rows and swizzles (local search over the 16 bank-quad keys a node can take) so that no
- * tile asks for one key more often than it has entries; gcrnn_ell_fill then orders each row's neighbours -- and aims its
+ * tile asks for one key more often than it has entries AND (r2) the 8 slots of every half tile sit on 8 different write keys
+ * (row & 1) << 2 | swz, which makes the kernels' ds_write_b128 write-backs of the state conflict-free (`order` must then place
+ * every node in exactly one slot; GCRNN_PLAN_LEGACY_KEYS=1 in the environment keeps the gather-only search);
+ * gcrnn_ell_fill then orders each row's neighbours -- and aims its
  * zero-weight padding entries -- by peeling perfect matchings off the slots x keys multigraph: the 16-lane groups of the
  * kernel's ds_read_b128 gathers hit distinct banks (greedy maximum matchings where a key is over-subscribed).
  * gcrnn_ell_conflict_cycles reports the LDS cycles per gather summed over entries (4 * entries = conflict-free);
@@ -248,7 +251,7 @@ int gcrnn_ell_assign_rows(const int32_t* rowptr, const int32_t* col, int64_t N, 
                           int64_t ntiles, int32_t* node_addr);
 /* The same two steps for a graph whose non-zeros all carry ONE weight (the reference drivers' S = W / lambda_max of an
  * unweighted adjacency, kStepPredGRNNs.py:768): zero_from >= 0 names the first padding row (rows zero_from .. N-1 hold zeros
- * for ever); they get the 16 bank keys in turn and every padding entry points at one of them, so a kernel may drop the weight
+ * for ever); the first 16 of them get the 16 bank keys (fixed) and every padding entry points at one of them, so a kernel may drop the weight
  * image and compute init + w * (sum of the gathered rows). zero_from = -1: the calls above. GCRNN_ERR_UNSUPPORTED when fewer
  * than 16 padding rows exist. */
 int gcrnn_ell_assign_rows_z(const int32_t* rowptr, const int32_t* col, int64_t N, const int32_t* order, int pad,
