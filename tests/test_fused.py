@@ -1343,3 +1343,50 @@ def test_fused_paths_without_bias(sg):
         sc, tmax, tmean = _grad_scale_and_bounds(n, {k: v.grad.cpu().numpy() for k, v in ref.named_parameters()}, 5e-2, 1e-2)
         e = np.abs(g - gr)
         assert sc > 0 and e.max() <= tmax * sc and (e.size < 16 or e.mean() <= tmean * sc), (n, e.max() / sc, e.mean() / sc)
+
+
+@pytest.mark.parametrize('N,density,iso,uniform', [(1000, 0.01, 0, True), (1000, 0.01, 0, False), (200, 0.05, 7, True), (1024, 0.004, 30, False),
+                                                   (1001, 0.01, 0, True)])
+def test_plan_bank_keys_make_write_backs_and_scatters_conflict_free(N, density, iso, uniform):
+    """CPU: host side of the LDS placement (write-aware keys). (1) every node sits in exactly one slot and every LDS row is
+    used once; (2) the 8 slots of every half tile carry 8 different write keys (row & 1) << 2 | swz -- the kernels' ds_write_b128
+    write-backs of the state (8-lane groups, 32 banks) are then conflict-free; (3) a uniform-weight plan has a zero row for each of the 16
+    gather keys; (4) the modelled gather cycles stay within 8 % of conflict-free; (5) spreading the tiles over the (node >> 1) & 15
+    classes neither changes the ELL size nor a tile's depth bound; (6) the plan is a pure function of the graph."""
+    S = random_graph(N, density, 11, iso)
+    if uniform:
+        S = (S != 0).astype(np.float64) * 0.03125
+    g = GraphOperator(S)
+    plan = g.fused_plan()
+    npad = plan['npad']
+    slots = plan['tile_slots'].numpy().astype(np.int64)
+    nodes, addr = slots >> 16, slots & 0xffff
+    assert sorted(nodes.tolist()) == list(range(npad))
+    rows, swz = addr >> 6, (addr >> 4) & 3
+    assert sorted(rows.tolist()) == list(range(npad)) and np.all(addr & 15 == 0)
+    wkey = ((rows & 1) << 2) | swz
+    assert all(len(set(h.tolist())) == 8 for h in wkey.reshape(-1, 8))
+    if uniform and npad - N >= 16:
+        assert plan['uniform_w'] != 0.0
+        na = plan['node_addr'].numpy()[N:N + 16].astype(np.int64)
+        key4 = (((na >> 4) & 3) << 2) | ((na >> 6) & 3)
+        assert sorted(key4.tolist()) == list(range(16))
+    else:
+        assert plan['uniform_w'] == 0.0 or npad - N >= 16
+    assert plan['gather_cycles'] <= 1.08 * 4 * plan['entries']
+    # tiles: depth bound kept, ELL size equal to the plain degree-ranked composition
+    import os
+    os.environ['GCRNN_PLAN_NO_CLASS_SPREAD'] = '1'
+    try:
+        plain = GraphOperator(S).fused_plan()
+    finally:
+        del os.environ['GCRNN_PLAN_NO_CLASS_SPREAD']
+    assert plain['entries'] == plan['entries']
+    assert np.array_equal(plain['tile_off'].numpy(), plan['tile_off'].numpy())
+    cls = (nodes.reshape(-1, 16) >> 1) & 15
+    dup_new = sum(16 - len(set(r.tolist())) for r in cls)
+    dup_old = sum(16 - len(set(r.tolist())) for r in ((plain['tile_slots'].numpy().astype(np.int64) >> 16).reshape(-1, 16) >> 1) & 15)
+    assert dup_new <= dup_old
+    again = GraphOperator(S).fused_plan()
+    assert np.array_equal(again['tile_slots'].numpy(), plan['tile_slots'].numpy())
+    assert np.array_equal(again['ell_col'].numpy(), plan['ell_col'].numpy())
