@@ -326,11 +326,11 @@ extern "C" int gcrnn_fused_gate_prepass_bf16(const void* xs, const void* h0, con
 extern "C" int gcrnn_fused_gate_grad_bf16(const void* zs, const void* xs, const void* dpre, const void* wpack, const float* bias,
                                           float* out, const int32_t* tile_nodes, const int32_t* tile_off, const int32_t* ell_col,
                                           const float* ell_val, const void* ell_val4, const void* ell_col4, int64_t entries,
-                                          int64_t B, int64_t T, int64_t N, int64_t F, int64_t G, int64_t K, void* stream) {
+                                          int64_t B, int64_t T, int64_t N, int64_t F, int64_t G, int64_t K, double uniform_w, void* stream) {
   if (!zs || !dpre || !wpack || !out || !tile_nodes || !tile_off || !ell_col || !ell_val) return GCRNN_ERR_NULL_POINTER;
   if ((xs == nullptr) != (G == 0)) return GCRNN_ERR_BAD_SHAPE;
   if (B <= 0 || T <= 0 || N <= 0 || N > NP || B * T > (1 << 24) || entries < 0 || entries % 4) return GCRNN_ERR_BAD_SHAPE;
-  const FusedGraphArgs ga{tile_nodes, tile_off, ell_col, ell_val, ell_val4, ell_col4, entries};
+  const FusedGraphArgs ga{tile_nodes, tile_off, ell_col, ell_val, ell_val4, ell_col4, entries, (float)uniform_w};
   return fused_dispatch(4, xs, zs, nullptr, wpack, bias, nullptr, nullptr, nullptr, out, ga, B, T, N, F, G, K, as_stream(stream), dpre);
 }
 

@@ -1000,8 +1000,8 @@ int fused_launch_t(int mode /*0 plain, 1 gated, 2 gate pre-pass, 3 BPTT data gra
                           const int32_t* hzero_flag = nullptr) {
   constexpr int F = 32 * HS, G = 32 * XS, KS = HS + XS;
   const size_t base = (size_t)NP * FC * 4 + (size_t)K * KS * 1024;
-  // uniform-weight plan: column words only in LDS (2 instead of 6 bytes per slot and entry); every mode but the gate-gradient pass
-  const bool uni = mode != 4 && ga.uniform_w != 0.f && ga.ell_col4 && GCRNN_HOP_ASM && GCRNN_STEP_WAVES == 8 &&
+  // uniform-weight plan: column words only in LDS (2 instead of 6 bytes per slot and entry)
+  const bool uni = ga.uniform_w != 0.f && ga.ell_col4 && GCRNN_HOP_ASM && GCRNN_STEP_WAVES == 8 &&
                    base + (size_t)ga.entries * 16 * 2 <= 160 * 1024;
   const size_t resident_bytes = base + (size_t)ga.entries * 16 * (uni ? 2 : 6);
   const bool resident = resident_bytes <= 160 * 1024 && ga.ell_val4 && ga.ell_col4;
@@ -1041,6 +1041,7 @@ int fused_launch_t(int mode /*0 plain, 1 gated, 2 gate pre-pass, 3 BPTT data gra
   else if (mode == 5 && uni && resident) kern = (fused_kern_t)fused_step_kernel<K, HS, XS, false, true, 4, 1>;
   else if ((mode == 3 || mode == 7 || mode == 8) && uni && resident) kern = (fused_kern_t)fused_step_kernel<K, HS, XS, false, true, 2, 1>;
   else if (mode == 2 && uni && resident) kern = (fused_kern_t)fused_step_kernel<K, HS, XS, false, true, 1, 1>;
+  else if (mode == 4 && uni && resident) kern = (fused_kern_t)fused_step_kernel<K, HS, XS, false, true, 3, 1>;
 #endif
   else if (mode == 5) kern = resident ? (fused_kern_t)fused_step_kernel<K, HS, XS, false, true, 4> : (fused_kern_t)fused_step_kernel<K, HS, XS, false, false, 4>;
   else if (mode == 4) kern = resident ? (fused_kern_t)fused_step_kernel<K, HS, XS, false, true, 3> : (fused_kern_t)fused_step_kernel<K, HS, XS, false, false, 3>;

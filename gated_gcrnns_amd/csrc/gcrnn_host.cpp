@@ -9,7 +9,7 @@
 #include <vector>
 #include "../../include/gcrnn.h"
 
-extern "C" int gcrnn_version(void) { return 110; }  // 0.1.10
+extern "C" int gcrnn_version(void) { return 111; }  // 0.1.11
 
 extern "C" const char* gcrnn_status_string(int status) {
   switch (status) {

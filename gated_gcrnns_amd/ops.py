@@ -1238,7 +1238,7 @@ def fused_gate_grad(zs, dpre, w, bias, graph, K):
     if Cin == F:
         wp = _fused_pack_state_taps(w, K, st)
         check(lib.gcrnn_fused_gate_grad_bf16(_p(zs), None, _p(dpre), _p(wp), _p(b32), _p(parts), *_fused_graph_args(plan),
-                                             B, T, graph.N, F, 0, K, st), 'fused_gate_grad')
+                                             B, T, graph.N, F, 0, K, plan.get('uniform_w', 0.0), st), 'fused_gate_grad')
     else:
         wd = w.detach()
         wz = wd.new_zeros((F, 1, K, F))
@@ -1247,7 +1247,7 @@ def fused_gate_grad(zs, dpre, w, bias, graph, K):
         wp = _fused_pack_weights(wd, wz, st)
         zero_h = torch.zeros((1, npad, F), dtype=torch.bfloat16, device=dpre.device)
         check(lib.gcrnn_fused_gate_grad_bf16(_p(zero_h), _p(zs), _p(dpre), _p(wp), _p(b32), _p(parts), *_fused_graph_args(plan),
-                                             B, T, graph.N, F, Cin, K, st), 'fused_gate_grad')
+                                             B, T, graph.N, F, Cin, K, plan.get('uniform_w', 0.0), st), 'fused_gate_grad')
     return parts.sum(dim=1).view(T, B)
 
 

@@ -343,7 +343,7 @@ int gcrnn_fused_gate_prepass_bf16(const void* xs, const void* h0, const void* wp
 int gcrnn_fused_gate_grad_bf16(const void* zs, const void* xs, const void* dpre, const void* wpack, const float* bias, float* out,
                                const int32_t* tile_nodes, const int32_t* tile_off, const int32_t* ell_col, const float* ell_val,
                                const void* ell_val4, const void* ell_col4, int64_t entries, int64_t B, int64_t T, int64_t N,
-                               int64_t F, int64_t G, int64_t K, void* stream);
+                               int64_t F, int64_t G, int64_t K, double uniform_w /* as in gcrnn_fused_forward_bf16 */, void* stream);
 
 /* BPTT through a time gate's read-out gate = sigmoid(w . vec(c) + c0) (graphML.py:2364-2366), one pass, in place:
  *   cs [items][NPad][F] bf16: on entry the gate cell's states c (gcrnn_fused_gate_prepass_bf16), on return
