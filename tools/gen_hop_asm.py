@@ -138,7 +138,21 @@ USUM = ['v[%d:%d]' % (UB + 56, UB + 57), 'v[%d:%d]' % (UB + 58, UB + 59)]
 UQX, UWP = '%27', '%28'
 
 
+MFMA_EXP = bool(os.environ.get('GCRNN_HOP_EXPERIMENT_MFMA'))     # timing experiment only (wrong results): bf16 state image (two 16-byte
+# gathers per 4 entries: a lane fetches half of ONE neighbour's 32-byte row) summed on the matrix cores by a one-hot A operand
+# (v_mfma_f32_16x16x32_bf16: D[feature][node] += sum over 2 entries) instead of 8 v_pk_add_f32. A operand = v[UB+8:UB+11] (free here).
+UMA = 'v[%d:%d]' % (UB + 8, UB + 11)
+USUM4 = 'v[%d:%d]' % (UB + 56, UB + 59)
+
+
 def us1(q, goff, lines):
+    if MFMA_EXP:
+        for e in range(2):
+            lines.append('v_xor_b32_sdwa %s, %s, %s dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_%d src1_sel:DWORD'
+                         % (UXa(q, e), UCw(q, 0), UQX, e & 1))
+        for e in range(2):
+            lines.append('ds_read_b128 %s, %s' % (UX(q, e), UXa(q, e)))
+        return
     for e in range(4):
         lines.append('v_xor_b32_sdwa %s, %s, %s dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_%d src1_sel:DWORD'
                      % (UXa(q, e), UCw(q, e >> 1), UQX, e & 1))
@@ -156,6 +170,9 @@ def us0(q, goff, lines):
 
 def gen_uniform():
     L = ['s_mov_b32 %s, %s' % (SG, GBEG)]
+    if MFMA_EXP:
+        for r in range(4):
+            L.append('v_mov_b32 v%d, 0x3f803f80' % (UB + 8 + r))
     for r in range(4):
         L.append('v_mov_b32 v%d, 0' % (UB + 56 + r))
     for p in range(3):
@@ -171,10 +188,15 @@ def gen_uniform():
             q = (p + 2) % 3
             us1(q, 2, L)
             us0(q, 5, L)
-            L.append('s_waitcnt lgkmcnt(10)')
-            for e in range(4):
-                L.append('v_pk_add_f32 %s, %s, %s' % (USUM[0], USUM[0], UX(p, e, 0)))
-                L.append('v_pk_add_f32 %s, %s, %s' % (USUM[1], USUM[1], UX(p, e, 1)))
+            if MFMA_EXP:
+                L.append('s_waitcnt lgkmcnt(6)')
+                for e in range(2):
+                    L.append('v_mfma_f32_16x16x32_bf16 %s, %s, %s, %s' % (USUM4, UMA, UX(p, e), USUM4))
+            else:
+                L.append('s_waitcnt lgkmcnt(10)')
+                for e in range(4):
+                    L.append('v_pk_add_f32 %s, %s, %s' % (USUM[0], USUM[0], UX(p, e, 0)))
+                    L.append('v_pk_add_f32 %s, %s, %s' % (USUM[1], USUM[1], UX(p, e, 1)))
             L.append('s_add_i32 %s, %s, 1' % (SG, SG))
         L.append('s_branch L_T%d_P0_%%=' % t)
         for p in range(3):                    # leaving tile t in phase p: acc_t += w * sum, sum = 0
