@@ -26,7 +26,7 @@ def needs_build():
     if not os.path.exists(LIBPATH):
         return True
     t = os.path.getmtime(LIBPATH)
-    deps = sources() + glob.glob(os.path.join(CSRC, '*.h')) + [os.path.join(os.path.dirname(PKG), 'include', 'gcrnn.h')]
+    deps = sources() + glob.glob(os.path.join(CSRC, '*.h')) + glob.glob(os.path.join(CSRC, '*.inc')) + [os.path.join(os.path.dirname(PKG), 'include', 'gcrnn.h')]
     return any(os.path.getmtime(d) > t for d in deps)
 
 
@@ -48,7 +48,7 @@ def _build_locked(verbose):
     # compile objects one by one (parallel-friendly, clearer errors), then link
     objs = []
     procs = []
-    headers = glob.glob(os.path.join(CSRC, '*.h')) + [os.path.join(os.path.dirname(PKG), 'include', 'gcrnn.h')]
+    headers = glob.glob(os.path.join(CSRC, '*.h')) + glob.glob(os.path.join(CSRC, '*.inc')) + [os.path.join(os.path.dirname(PKG), 'include', 'gcrnn.h')]
     hdr_time = max(os.path.getmtime(h) for h in headers)
     for src in sources():
         obj = os.path.join(LIBDIR, os.path.basename(src) + '.o')

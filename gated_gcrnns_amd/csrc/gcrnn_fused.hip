@@ -286,9 +286,9 @@ extern "C" int gcrnn_fused_forward_bf16(const void* xs, const void* h0, void* hs
   if (B <= 0 || T <= 0 || N <= 0 || N > NP || B > (1 << 24) || entries < 0 || entries % 4) return GCRNN_ERR_BAD_SHAPE;
   if (B * (NP * (F > G ? F : G) * 2) > 2147483647LL || T * F * N > 2147483647LL) return GCRNN_ERR_BAD_SHAPE;   // 32-bit buffer offsets
   if (Huser && (N % 8 != 0 || (reinterpret_cast<uintptr_t>(Huser) & 15))) return GCRNN_ERR_BAD_SHAPE;
-  const FusedGraphArgs ga{tile_nodes, tile_off, ell_col, ell_val, ell_val4, ell_col4, entries, (float)uniform_w};
+  const FusedGraphArgs ga{tile_nodes, tile_off, ell_col, ell_val, ell_val4, ell_col4, entries, (float)uniform_w, (huser_last_only >> 1) & 1};
   return fused_dispatch(gi ? 1 : 0, xs, h0, hs, wpack, bias, gi, gf, head_w, head_part, ga, B, T, N, F, G, K, as_stream(stream),
-                        Xuser_inline, nullptr, nullptr, Huser, nullptr, step_events, huser_last_only);
+                        Xuser_inline, nullptr, nullptr, Huser, nullptr, step_events, huser_last_only & 1);
 }
 
 // Can gcrnn_fused_forward_bf16 take Xuser_inline for this problem (un-gated cell, uniform-weight graph image that leaves LDS

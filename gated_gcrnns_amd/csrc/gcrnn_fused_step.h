@@ -72,6 +72,18 @@ __device__ __forceinline__ float fast_tanh(float x) {
   const float e = __builtin_amdgcn_exp2f(x * 2.8853900817779268f);      // exp(2x)
   return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + e);
 }
+// Write this lane's 4 features of a node into the LDS hop image: fp32 (16 bytes of a 64-byte row) or, IMG16, bf16 (8 bytes of a
+// 32-byte row; the hop then sums gathered rows on the matrix cores, GCRNN_HOP_ASM_UNI16_STREAM).
+template <bool IMG16>
+__device__ __forceinline__ void state_put(float* state, int wv, const f32x4& v) {
+  char* p = reinterpret_cast<char*>(state) + (wv & 0xffff);
+  if constexpr (IMG16) {
+    typedef __attribute__((__vector_size__(2 * sizeof(unsigned int)))) unsigned int u32x2_;
+    *reinterpret_cast<u32x2_*>(p) = u32x2_{(uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16), (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16)};
+  } else {
+    *reinterpret_cast<f32x4*>(p) = v;
+  }
+}
 // ------------------------------------------------------------------------------------------
 // the fused step
 // ------------------------------------------------------------------------------------------
@@ -256,7 +268,40 @@ __device__ __forceinline__ float fast_tanh(float x) {
 //     fp32 in gate_w (ni then nf), scalar time gates gi / gf [B] or null (= 1); optionally stores Yh = B(S)h_{t-1} + b (for BPTT)
 // 6 = the state epilogue of EPI 0 plus a fused output head Linear(F -> 1) (gate_w = its weights [F], gate_out = partials [B][F/16][N]);
 //     no user-layout copy of h_t
+// The uniform-weight hop on a bf16 image, summed on the matrix cores (generator: gen_uniform16): a lane gathers 16 bytes = half a
+// neighbour's 32-byte row, v_mfma_f32_16x16x32_bf16 with a one-hot A operand adds two neighbours per instruction into D, whose layout
+// is the accumulators'. A operand of lane (i = lane & 15, kg = lane >> 4): A[i][8 kg + s] = 1 iff i == 8 (kg & 1) + s.
+#define GCRNN_HOP_ASM_UNI16_STREAM(INIT, STORE)                                                    \
+  do {                                                                                             \
+    static_assert(HT == 8, "the asm hop stream is generated for 8 tiles per wave");                \
+    const int gwbeg = tbeg[0] >> 2, gwend = tend[HT - 1] >> 2;                                      \
+    f32x2 al_[8], ah_[8];                                                                          \
+    _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                                \
+      const f32x4 a_ = INIT(i);                                                                    \
+      al_[i] = f32x2{a_[0], a_[1]};                                                                \
+      ah_[i] = f32x2{a_[2], a_[3]};                                                                \
+    }                                                                                              \
+    if (gwbeg < gwend) {                                                                           \
+      typedef __attribute__((__vector_size__(4 * sizeof(unsigned int)))) unsigned int u32x4a_;     \
+      const uint32_t colb = lds_col + r * 8;                                                       \
+      const f32x2 wp_ = f32x2{uni_w, uni_w};                                                       \
+      const int hit_ = ((r >> 3) == (q & 1)) ? (r & 7) : 8;       /* position of this lane's 1.0 among its 8 A elements, or none */ \
+      const uint32_t one_ = (hit_ & 1) ? 0x3f800000u : 0x00003f80u;                                \
+      u32x4a_ aop_ = {(hit_ >> 1) == 0 ? one_ : 0u, (hit_ >> 1) == 1 ? one_ : 0u, (hit_ >> 1) == 2 ? one_ : 0u, (hit_ >> 1) == 3 ? one_ : 0u}; \
+      const uint32_t qh_ = (uint32_t)(q & 1) << 4, qe_ = (uint32_t)(q >> 1);                       \
+      asm volatile(GCRNN_HOP_ASM_UNI16_TEXT                                                        \
+                   : "+v"(al_[0]), "+v"(ah_[0]), "+v"(al_[1]), "+v"(ah_[1]), "+v"(al_[2]), "+v"(ah_[2]), "+v"(al_[3]), "+v"(ah_[3]),  \
+                     "+v"(al_[4]), "+v"(ah_[4]), "+v"(al_[5]), "+v"(ah_[5]), "+v"(al_[6]), "+v"(ah_[6]), "+v"(al_[7]), "+v"(ah_[7])   \
+                   : "s"(tend[0] >> 2), "s"(tend[1] >> 2), "s"(tend[2] >> 2), "s"(tend[3] >> 2), "s"(tend[4] >> 2),                   \
+                     "s"(tend[5] >> 2), "s"(tend[6] >> 2), "s"(tend[7] >> 2), "s"(gwbeg), "s"(gwend - 1), "v"(colb), "v"(qh_), "v"(wp_), \
+                     "v"(aop_), "v"(qe_)                                                           \
+                   : GCRNN_HOP_ASM_UNI16_CLOBBERS);                                                \
+    }                                                                                              \
+    _Pragma("unroll") for (int i = 0; i < 8; ++i) STORE(i, (f32x4{al_[i][0], al_[i][1], ah_[i][0], ah_[i][1]}));                   \
+  } while (0)
+
 // UNI (RESIDENT only): uniform-weight graph image -- column words only, all non-zeros weigh uni_w (GCRNN_HOP_ASM_UNI_STREAM)
+// UNI == 2: the same on a bf16 image of the hop state with matrix-core sums (GCRNN_HOP_ASM_UNI16_STREAM; plan arrays of graph.fused_plan(img16=True))
 template <int K, int HS, int XS, bool GATED, bool RESIDENT, int EPI = 0, int UNI = 0>
 __global__ __launch_bounds__(STHREADS) void fused_step_kernel(
     const uint16_t* __restrict__ xt,        // [B][NP][G]   bf16
@@ -350,7 +395,8 @@ __global__ __launch_bounds__(STHREADS) void fused_step_kernel(
   f32x4 u[STILES][K - 1];   // taps 0..K-2 (tap K-1 seeds the LDS state directly); later: the hop results
   int woff[STILES];      // low 16 bits: byte offset of this lane's quad in the (swizzled) state row of its node; high: node id
 #pragma unroll
-  for (int i = 0; i < STILES; ++i) woff[i] = tile_nodes[(wave * STILES + i) * 16 + r] ^ (q << 4);   // slot = node << 16 | row << 6 | swz << 4
+  for (int i = 0; i < STILES; ++i)      // slot = node << 16 | row << 6 | swz << 4;  UNI == 2 (bf16 image): node << 16 | row << 5 | hswz << 4, a lane's 8 bytes = half q >> 1, piece q & 1
+    woff[i] = tile_nodes[(wave * STILES + i) * 16 + r] ^ (UNI == 2 ? (((q >> 1) << 4) | ((q & 1) << 3)) : (q << 4));
   float bvec[4] = {0.f, 0.f, 0.f, 0.f};
   if (bias) {
 #pragma unroll
@@ -481,7 +527,7 @@ __global__ __launch_bounds__(STHREADS) void fused_step_kernel(
           if (tap == K - 1) {
             int wv = woff[i + p];
             asm volatile("" : "+v"(wv));      // opaque: the masked LDS offsets are not hoisted out of the tile loop
-            *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(state) + (wv & 0xffff)) = accg[p];
+            state_put<UNI == 2>(state, wv, accg[p]);
           } else {
             u[i + p][tap] = accg[p];
           }
@@ -500,7 +546,7 @@ __global__ __launch_bounds__(STHREADS) void fused_step_kernel(
       if (tap == K - 1) {
         int wv = woff[i];
         asm volatile("" : "+v"(wv));
-        *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(state) + (wv & 0xffff)) = acc;
+        state_put<UNI == 2>(state, wv, acc);
       }
       else u[i][tap] = acc;
     }
@@ -660,7 +706,8 @@ __global__ __launch_bounds__(STHREADS) void fused_step_kernel(
 #define GCRNN_FWD_INIT(i) u[i][K - 1 - j]
 #define GCRNN_FWD_STORE(i, a) u[i][K - 1 - j] = a   /* the new value lives in the tap's registers until every wave has read `state` */
 #if GCRNN_HOP_ASM && GCRNN_STEP_WAVES == 8
-      if (UNI) GCRNN_HOP_ASM_UNI_STREAM(GCRNN_FWD_INIT, GCRNN_FWD_STORE);
+      if (UNI == 2) GCRNN_HOP_ASM_UNI16_STREAM(GCRNN_FWD_INIT, GCRNN_FWD_STORE);
+      else if (UNI) GCRNN_HOP_ASM_UNI_STREAM(GCRNN_FWD_INIT, GCRNN_FWD_STORE);
       else GCRNN_HOP_ASM_STREAM(GCRNN_FWD_INIT, GCRNN_FWD_STORE);
 #else
       GCRNN_HOP_STREAM(GCRNN_FWD_INIT, GCRNN_FWD_STORE);
@@ -691,7 +738,7 @@ __global__ __launch_bounds__(STHREADS) void fused_step_kernel(
       for (int i = 0; i < STILES; ++i) {
         int wv = woff[i];
         asm volatile("" : "+v"(wv));
-        *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(state) + (wv & 0xffff)) = u[i][K - 1 - j];
+        state_put<UNI == 2>(state, wv, u[i][K - 1 - j]);
       }
       __syncthreads();
     }
@@ -989,6 +1036,7 @@ struct FusedGraphArgs {
   const int32_t* tile_nodes; const int32_t* tile_off; const int32_t* ell_col; const float* ell_val;
   const void* ell_val4; const void* ell_col4; int64_t entries;
   float uniform_w = 0.f;      // != 0: every non-zero carries this weight and the padding entries point at zero rows (gcrnn_ell_fill_z)
+  int img16 = 0;              // != 0: tile_nodes / ell_col4 address a bf16 hop image (32-byte rows, graph.fused_plan_img16): matrix-core sums
 };
 
 template <int K, int HS, int XS>
@@ -1015,6 +1063,7 @@ int fused_launch_t(int mode /*0 plain, 1 gated, 2 gate pre-pass, 3 BPTT data gra
                        T * (inline_bw ? F : G) * N <= 2147483647LL))
     return GCRNN_ERR_UNSUPPORTED;
   const size_t lds = (resident ? resident_bytes : base) + (inline_pack ? xtile_bytes : 0);
+  if (ga.img16 && !(mode == 0 && uni && resident)) return GCRNN_ERR_UNSUPPORTED;      // the bf16-image plan: un-gated forward steps only (with or without the fused head)
   fused_kern_t kern;
   const bool head = (mode == 0 || mode == 1) && gate_w != nullptr;      // fused output head: EPI 6 instantiations
   if (head) {
@@ -1024,6 +1073,7 @@ int fused_launch_t(int mode /*0 plain, 1 gated, 2 gate pre-pass, 3 BPTT data gra
       else kern = resident ? (fused_kern_t)fused_step_kernel<K, HS, XS, false, true, 6> : (fused_kern_t)fused_step_kernel<K, HS, XS, false, false, 6>;
 #if GCRNN_HOP_ASM && GCRNN_STEP_WAVES == 8
       if (uni && resident) kern = mode == 1 ? (fused_kern_t)fused_step_kernel<K, HS, XS, true, true, 6, 1> : (fused_kern_t)fused_step_kernel<K, HS, XS, false, true, 6, 1>;
+      if (uni && resident && ga.img16 && mode == 0) kern = (fused_kern_t)fused_step_kernel<K, HS, XS, false, true, 6, 2>;
 #endif
     } else {
       return GCRNN_ERR_UNSUPPORTED;
@@ -1049,6 +1099,10 @@ int fused_launch_t(int mode /*0 plain, 1 gated, 2 gate pre-pass, 3 BPTT data gra
   else if (mode == 2) kern = resident ? (fused_kern_t)fused_step_kernel<K, HS, XS, false, true, 1> : (fused_kern_t)fused_step_kernel<K, HS, XS, false, false, 1>;
 #if GCRNN_HOP_ASM && GCRNN_STEP_WAVES == 8
   else if (mode == 1 && uni && resident) kern = (fused_kern_t)fused_step_kernel<K, HS, XS, true, true, 0, 1>;
+  else if (mode == 0 && uni && resident && ga.img16) {
+    if constexpr (XS > 0) kern = (fused_kern_t)fused_step_kernel<K, HS, XS, false, true, 0, 2>;
+    else return GCRNN_ERR_UNSUPPORTED;
+  }
   else if (mode == 0 && uni && resident) kern = (fused_kern_t)fused_step_kernel<K, HS, XS, false, true, 0, 1>;
 #endif
   else if (mode == 1) kern = resident ? (fused_kern_t)fused_step_kernel<K, HS, XS, true, true> : (fused_kern_t)fused_step_kernel<K, HS, XS, true, false>;

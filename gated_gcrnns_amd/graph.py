@@ -275,6 +275,58 @@ class GraphOperator(object):
         setattr(self, key, plan)
         return plan
 
+    def fused_plan_img16(self):
+        """The forward plan re-addressed for a bf16 hop image (32-byte state rows; the un-gated step kernel then sums the gathered
+        rows on the matrix cores, csrc GCRNN_HOP_ASM_UNI16_STREAM), or None when the graph has no uniform-weight plan.
+        A row's two 16-byte halves are XOR-swizzled by `hswz`; node_addr16 = row16 << 5 | hswz << 4. The gather key of the fp32 image
+        (swz << 2 | row & 3, slots 4..11 flipped by 4) maps one-to-one onto the new one ((row16 & 7) << 1 | hswz, flipped by 1) with
+        hswz = swz & 1 and row16 & 7 a bijection of (row & 3, swz >> 1), so the conflict-free schedule of the entries carries over as it is.
+        Column words per slot and group of four entries: (entry 0, entry 2, entry 1, entry 3) as four uint16 neighbour addresses."""
+        plan16 = self.__dict__.get('_fused_plan_img16', False)
+        if plan16 is not False:
+            return plan16
+        plan = self.fused_plan()
+        plan16 = None
+        if plan.get('uniform_w', 0.0) != 0.0 and plan['entries'] > 0:
+            npad = plan['npad']
+            na = plan['node_addr'].cpu().numpy().astype(np.int64)
+            row, swz = na >> 6, (na >> 4) & 3
+            # row16 & 7 = row bit 0 | swz bit 1 << 1 | row bit 1 << 2: bits 0..1 and hswz are then the three bits the fp32 image's
+            # write-aware search makes a permutation in every half tile -> every (row16 & 3, hswz) exactly twice per tile, the best a
+            # 16-lane ds_write_b64 group can have (2-way); bit 2 is that search's free bit
+            cls8 = (row & 1) | ((swz >> 1) << 1) | (((row >> 1) & 1) << 2)
+            hswz = swz & 1
+            cap = npad // 8
+            row16 = np.zeros(npad, dtype=np.int64)
+            refs = np.bincount(plan['ell_col'].cpu().numpy().astype(np.int64), minlength=npad)
+            order = np.argsort(-refs, kind='stable')         # the most-gathered rows (the zero rows of the padding entries first) keep their class
+            left = []
+            cnt = np.zeros(8, dtype=np.int64)
+            for n in order:
+                c = int(cls8[n])
+                if cnt[c] < cap:
+                    row16[n] = c + 8 * cnt[c]; cnt[c] += 1
+                else:
+                    left.append(int(n))
+            for n in left:                                   # class full: the sibling class (other value of the free row bit), else any
+                c = int(cls8[n]) ^ 4
+                if cnt[c] >= cap:
+                    c = int(np.argmin(cnt))
+                row16[n] = c + 8 * cnt[c]; cnt[c] += 1
+            addr16 = ((row16 << 5) | (hswz << 4)).astype(np.int64)
+            tile_nodes = plan['tile_nodes'].cpu().numpy().astype(np.int64)
+            tile_slots = ((tile_nodes << 16) | addr16[tile_nodes]).astype(np.int32)
+            ent = plan['entries']
+            nb = addr16[plan['ell_col'].cpu().numpy().astype(np.int64)].reshape(ent // 4, 4, 16)          # [group][entry][slot]
+            col4 = np.ascontiguousarray(nb[:, [0, 2, 1, 3], :].transpose(0, 2, 1)).astype(np.uint16)     # [group][slot][e0, e2, e1, e3]
+            dev = self.device
+            plan16 = dict(plan)
+            plan16.update(tile_slots=torch.from_numpy(tile_slots).to(dev),
+                          ell_col4=torch.from_numpy(col4.reshape(-1).view(np.int16)).to(dev),
+                          node_addr16=torch.from_numpy(addr16.astype(np.int32)).to(dev), img16=True, img16_moved=len(left))
+        self._fused_plan_img16 = plan16
+        return plan16
+
     def to(self, device):
         device = torch.device(device)
         if device.type == 'cuda' and device.index is None:

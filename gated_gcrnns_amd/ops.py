@@ -368,9 +368,10 @@ def time_fused_step_kernel(X, h0, wA, wB, bias, graph, reps=3, inline=None):
     e0.record()
     ok = fused_inline_pack_ok(plan, N, F, G, K)          # the launches as the forward issues them: with the inline pack of x_{t+1} where it
     inline = (ok if inline is None else (ok and inline)) and X.data_ptr() % 16 == 0     # applies; inline=False times the bare step for comparison
+    plan16 = fused_img16_plan(graph, False, None)
     for _ in range(reps):
-        check(lib.gcrnn_fused_forward_bf16(_p(xs), _p(h0s), _p(hs), _p(wpack), _p(b32), None, None, *_fused_graph_args(plan),
-                                           B, T, N, F, G, K, _p(H) if H is not None else None, 0, None, plan.get('uniform_w', 0.0),
+        check(lib.gcrnn_fused_forward_bf16(_p(xs), _p(h0s), _p(hs), _p(wpack), _p(b32), None, None, *_fused_graph_args(plan16 or plan),
+                                           B, T, N, F, G, K, _p(H) if H is not None else None, 2 if plan16 else 0, None, plan.get('uniform_w', 0.0),
                                            _p(Xc) if inline else None, None, None, st),
               'fused_forward')
     e1.record()
@@ -387,6 +388,15 @@ def _fused_pack_weights(wA, wB, st):
     check(lib.gcrnn_fused_pack_weights(dtype_code(wA.dtype), _p(wAc), _p(wBc), _p(wpack),
                                        F, G, Kin, Kst, st), 'pack_weights')
     return wpack
+
+
+def fused_img16_plan(graph, gated, head):
+    """The bf16-image plan of the un-gated forward steps (GraphOperator.fused_plan_img16), or None: uniform-weight graphs only, no
+    time gates (the fused head is fine); GCRNN_NO_IMG16=1 switches it off (A/B, and the fp32-image tests)."""
+    import os
+    if gated or os.environ.get('GCRNN_NO_IMG16'):
+        return None
+    return graph.fused_plan_img16()
 
 
 def _fused_graph_args(plan):
@@ -561,17 +571,19 @@ def fused_cell_forward(X, h0, wA, wB, bias, graph, gates=None, return_states=Fal
         hw = head[0].detach().float().reshape(-1).contiguous()
         assert hw.numel() == F
         part = torch.empty((T, B, F // 16, N), dtype=torch.float32, device=dev)
-        check(lib.gcrnn_fused_forward_bf16(_p(xs), _p(h0s), _p(hs), _p(wpack), _p(b32), _p(gi), _p(gf), *_fused_graph_args(plan),
-                                           B, T, N, F, G, K, None, 0, evs, plan.get('uniform_w', 0.0), _p(X) if inline else None,
+        plan16 = fused_img16_plan(graph, gi is not None, head)
+        check(lib.gcrnn_fused_forward_bf16(_p(xs), _p(h0s), _p(hs), _p(wpack), _p(b32), _p(gi), _p(gf), *_fused_graph_args(plan16 or plan),
+                                           B, T, N, F, G, K, None, 2 if plan16 else 0, evs, plan.get('uniform_w', 0.0), _p(X) if inline else None,
                                            _p(hw), _p(part), st), 'fused_forward')
         y = part.sum(dim=2)                                          # fixed order over the F / 16 chunks
         if head[1] is not None:
             y = y + head[1].detach().float().reshape(())
         return y.permute(1, 0, 2).unsqueeze(2).contiguous()          # B x T x 1 x N
     H = torch.empty((B, 1 if last_only else T, F, N), dtype=torch.bfloat16, device=dev)
-    check(lib.gcrnn_fused_forward_bf16(_p(xs), _p(h0s), _p(hs), _p(wpack), _p(b32), _p(gi), _p(gf), *_fused_graph_args(plan),
-                                       B, T, N, F, G, K, _p(H) if direct else None, int(last_only), evs, plan.get('uniform_w', 0.0),
-                                       _p(X) if inline else None, None, None, st),
+    plan16 = fused_img16_plan(graph, gi is not None, None)
+    check(lib.gcrnn_fused_forward_bf16(_p(xs), _p(h0s), _p(hs), _p(wpack), _p(b32), _p(gi), _p(gf), *_fused_graph_args(plan16 or plan),
+                                       B, T, N, F, G, K, _p(H) if direct else None, int(last_only) | (2 if plan16 else 0), evs,
+                                       plan.get('uniform_w', 0.0), _p(X) if inline else None, None, None, st),
           'fused_forward')
     if not direct:
         src = hs[T - 1:] if last_only else hs

@@ -294,7 +294,9 @@ int gcrnn_fused_pack_weights(int wdtype, const void* wA, const void* wB, void* w
  * Huser (may be NULL; needs N % 8 == 0): the states are ALSO written in the user layout H[B][T][F][N] by the step kernels
  * themselves (LDS-transposed 16-byte row stores), which replaces gcrnn_unpack_seq_major over the whole sequence.
  * T launches on `stream`. The graph is kept resident in LDS when 64 KiB + weights + 96*entries B <= 160 KiB.
- * huser_last_only != 0: Huser is [B][1][F][N] and receives the LAST state only (the classification models read nothing else,
+ * huser_last_only bit 1 (value 2, r2): tile_nodes / ell_col4 are the arrays of a bf16 hop image (un-gated cell, uniform_w != 0;
+ *   GraphOperator.fused_plan_img16 (head_w allowed): 32-byte state rows, neighbour rows summed on the matrix cores); GCRNN_ERR_UNSUPPORTED otherwise.
+ * huser_last_only bit 0: Huser is [B][1][F][N] and receives the LAST state only (the classification models read nothing else,
  * architectures.py:1841-1850); the other steps skip the user-layout store.
  * step_events (or NULL): host array of T hipEvent_t (entries may be NULL); the launch of step t first makes `stream` wait for
  * step_events[t] -- xs[t] is then allowed to be produced on another stream while earlier steps run.

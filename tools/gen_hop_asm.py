@@ -212,6 +212,67 @@ def gen_uniform():
     return L
 
 
+# ---- uniform-weight variant on a bf16 state image (32-byte rows), summed on the matrix cores -----------------------------------
+# A lane (slot r, quad q) gathers 16 bytes = features 8 (q & 1) .. + 7 of ONE neighbour: of entry (q >> 1) for the first MFMA of a
+# trip, of entry 2 + (q >> 1) for the second. v_mfma_f32_16x16x32_bf16 with the one-hot A operand A[i][k] = (i == k mod 16) then adds
+# both neighbours' rows to D[feature][slot], whose register layout (lane (r, q): features 4q .. 4q+3 of slot r) is the accumulators'.
+# Column words per slot and trip: dword 0 = addr(entry 0) | addr(entry 2) << 16, dword 1 = addr(entry 1) | addr(entry 3) << 16.
+# Operands: %0..%15 accumulator halves, %16..%23 tile ends, %24 first group, %25 last valid group (SGPR), %26 column base + 8 r,
+# %27 = (q & 1) << 4, %28 = {w, w}, %29 = the lane's A operand (4 VGPRs), %30 = q >> 1. Clobbers v[194:253], s[88:90], scc, vcc.
+def VX(p, e):
+    b = UB + 16 * p + 4 * e
+    return 'v[%d:%d]' % (b, b + 3)
+
+
+VSEL = 'v%d' % (UB + 55)
+
+
+def vs1(q, lines):
+    lines.append('v_cndmask_b32 %s, %s, %s, vcc' % (VSEL, UCw(q, 0), UCw(q, 1)))
+    for e in range(2):
+        lines.append('v_xor_b32_sdwa %s, %s, %s dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_%d src1_sel:DWORD'
+                     % (UXa(q, e), VSEL, UQX, e))
+    for e in range(2):
+        lines.append('ds_read_b128 %s, %s' % (VX(q, e), UXa(q, e)))
+
+
+def gen_uniform16():
+    L = ['s_mov_b32 %s, %s' % (SG, GBEG), 'v_cmp_ne_u32 vcc, 0, %30']
+    for r in range(4):
+        L.append('v_mov_b32 v%d, 0' % (UB + 56 + r))
+    for p in range(3):
+        us0(p, p, L)
+    L.append('s_waitcnt lgkmcnt(0)')
+    vs1(0, L); us0(0, 3, L)
+    vs1(1, L); us0(1, 4, L)
+    for t in range(NT):
+        for p in range(3):
+            L.append('L_T%d_P%d_%%=:' % (t, p))
+            L.append('s_cmp_ge_i32 %s, %%%d' % (SG, 16 + t))
+            L.append('s_cbranch_scc1 L_X%d_P%d_%%=' % (t, p))
+            q = (p + 2) % 3
+            vs1(q, L)                                             # (the set's registers were B operands of the PREVIOUS trip's MFMAs: read long ago)
+            us0(q, 5, L)
+            L.append('s_waitcnt lgkmcnt(6)')
+            for e in range(2):
+                L.append('v_mfma_f32_16x16x32_bf16 %s, %%29, %s, %s' % (USUM4, VX(p, e), USUM4))
+            L.append('s_add_i32 %s, %s, 1' % (SG, SG))
+        L.append('s_branch L_T%d_P0_%%=' % t)
+        for p in range(3):                    # leaving tile t in phase p: acc_t += w * sum, sum = 0
+            L.append('L_X%d_P%d_%%=:' % (t, p))
+            L += ['s_nop 11']                                     # matrix-core result (8 passes) -> VALU read: 11 wait states
+            L.append('v_pk_fma_f32 %%%d, %s, %s, %%%d' % (2 * t, UWP, USUM[0], 2 * t))
+            L.append('v_pk_fma_f32 %%%d, %s, %s, %%%d' % (2 * t + 1, UWP, USUM[1], 2 * t + 1))
+            for r in range(4):
+                L.append('v_mov_b32 v%d, 0' % (UB + 56 + r))
+            L.append('s_nop 1')                                   # VALU write -> matrix-core read of the accumulator
+            L.append('s_branch L_T%d_P%d_%%=' % (t + 1, p))
+    for p in range(3):
+        L.append('L_T%d_P%d_%%=:' % (NT, p))
+    L.append('s_waitcnt lgkmcnt(0)')
+    return L
+
+
 def emit(name, lines):
     print('#define %s \\' % name)
     for ln in lines:
@@ -229,8 +290,10 @@ def main():
     regs = ', '.join('"v%d"' % r for r in range(BASE, BASE + 68))
     print('#define GCRNN_HOP_ASM_CLOBBERS %s, "s88", "s89", "s90", "scc", "memory"' % regs)
     emit('GCRNN_HOP_ASM_UNI_TEXT', gen_uniform())
+    emit('GCRNN_HOP_ASM_UNI16_TEXT', gen_uniform16())
     regs = ', '.join('"v%d"' % r for r in range(UB, UB + 60))
     print('#define GCRNN_HOP_ASM_UNI_CLOBBERS %s, "s88", "s89", "s90", "scc", "memory"' % regs)
+    print('#define GCRNN_HOP_ASM_UNI16_CLOBBERS %s, "s88", "s89", "s90", "scc", "vcc", "memory"' % regs)
 
 
 if __name__ == '__main__':
