@@ -456,7 +456,7 @@ extern "C" int gcrnn_fused_backward_data_bf16(const void* dHs, const void* hs, v
                                               const float* ell_val, const void* ell_val4, const void* ell_col4,
                                               int64_t entries, int64_t B, int64_t T, int64_t N, int64_t F, int64_t K,
                                               const float* gf, const void* h0s, float* dgf_parts, double uniform_w,
-                                              const void* dHuser_inline, void* stream) {
+                                              const void* dHuser_inline, int img16, void* stream) {
   if (dgf_parts && !h0s) return GCRNN_ERR_NULL_POINTER;
   if (dHuser_inline && (reinterpret_cast<uintptr_t>(dHuser_inline) & 15)) return GCRNN_ERR_BAD_SHAPE;
   if (!dHs || !hs || !dpre || !wpackT || !tile_nodes || !tile_off || !ell_col || !ell_val) return GCRNN_ERR_NULL_POINTER;
@@ -466,7 +466,7 @@ extern "C" int gcrnn_fused_backward_data_bf16(const void* dHs, const void* hs, v
   bwd_seed_kernel<<<(unsigned)cdiv(step / 2, 256), 256, 0, as_stream(stream)>>>(
       (const uint16_t*)dHs + (T - 1) * step, (const uint16_t*)hs + (T - 1) * step, (uint16_t*)dpre + (T - 1) * step, step);
   GCRNN_CHECK_LAUNCH();
-  const FusedGraphArgs ga{tile_nodes, tile_off, ell_col, ell_val, ell_val4, ell_col4, entries, (float)uniform_w};
+  const FusedGraphArgs ga{tile_nodes, tile_off, ell_col, ell_val, ell_val4, ell_col4, entries, (float)uniform_w, img16 ? 1 : 0};
   return fused_dispatch(3, dHuser_inline, nullptr, dpre, wpackT, nullptr, nullptr, gf, nullptr, dgf_parts, ga, B, T, N, F, 0, K,
                         as_stream(stream), dHs, hs, dh0, nullptr, h0s);
 }

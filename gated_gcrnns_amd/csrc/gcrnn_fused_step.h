@@ -283,18 +283,18 @@ __device__ __forceinline__ void state_put(float* state, int wv, const f32x4& v) 
     }                                                                                              \
     if (gwbeg < gwend) {                                                                           \
       typedef __attribute__((__vector_size__(4 * sizeof(unsigned int)))) unsigned int u32x4a_;     \
-      const uint32_t colb = lds_col + r * 8;                                                       \
+      const uint32_t colb = lds_col + r * 8 + (q >> 1) * 4;       /* this lane's own column dword of a slot's pair */ \
       const f32x2 wp_ = f32x2{uni_w, uni_w};                                                       \
       const int hit_ = ((r >> 3) == (q & 1)) ? (r & 7) : 8;       /* position of this lane's 1.0 among its 8 A elements, or none */ \
       const uint32_t one_ = (hit_ & 1) ? 0x3f800000u : 0x00003f80u;                                \
       u32x4a_ aop_ = {(hit_ >> 1) == 0 ? one_ : 0u, (hit_ >> 1) == 1 ? one_ : 0u, (hit_ >> 1) == 2 ? one_ : 0u, (hit_ >> 1) == 3 ? one_ : 0u}; \
-      const uint32_t qh_ = (uint32_t)(q & 1) << 4, qe_ = (uint32_t)(q >> 1);                       \
+      const uint32_t qh_ = (uint32_t)(q & 1) << 4;                                                 \
       asm volatile(GCRNN_HOP_ASM_UNI16_TEXT                                                        \
                    : "+v"(al_[0]), "+v"(ah_[0]), "+v"(al_[1]), "+v"(ah_[1]), "+v"(al_[2]), "+v"(ah_[2]), "+v"(al_[3]), "+v"(ah_[3]),  \
                      "+v"(al_[4]), "+v"(ah_[4]), "+v"(al_[5]), "+v"(ah_[5]), "+v"(al_[6]), "+v"(ah_[6]), "+v"(al_[7]), "+v"(ah_[7])   \
                    : "s"(tend[0] >> 2), "s"(tend[1] >> 2), "s"(tend[2] >> 2), "s"(tend[3] >> 2), "s"(tend[4] >> 2),                   \
                      "s"(tend[5] >> 2), "s"(tend[6] >> 2), "s"(tend[7] >> 2), "s"(gwbeg), "s"(gwend - 1), "v"(colb), "v"(qh_), "v"(wp_), \
-                     "v"(aop_), "v"(qe_)                                                           \
+                     "v"(aop_)                                                                     \
                    : GCRNN_HOP_ASM_UNI16_CLOBBERS);                                                \
     }                                                                                              \
     _Pragma("unroll") for (int i = 0; i < 8; ++i) STORE(i, (f32x4{al_[i][0], al_[i][1], ah_[i][0], ah_[i][1]}));                   \
@@ -1063,7 +1063,7 @@ int fused_launch_t(int mode /*0 plain, 1 gated, 2 gate pre-pass, 3 BPTT data gra
                        T * (inline_bw ? F : G) * N <= 2147483647LL))
     return GCRNN_ERR_UNSUPPORTED;
   const size_t lds = (resident ? resident_bytes : base) + (inline_pack ? xtile_bytes : 0);
-  if (ga.img16 && !(mode == 0 && uni && resident)) return GCRNN_ERR_UNSUPPORTED;      // the bf16-image plan: un-gated forward steps only (with or without the fused head)
+  if (ga.img16 && !((mode == 0 || mode == 3) && uni && resident)) return GCRNN_ERR_UNSUPPORTED;      // the bf16-image plan: un-gated forward steps (with or without the fused head) and the BPTT data chain
   fused_kern_t kern;
   const bool head = (mode == 0 || mode == 1) && gate_w != nullptr;      // fused output head: EPI 6 instantiations
   if (head) {
@@ -1089,6 +1089,10 @@ int fused_launch_t(int mode /*0 plain, 1 gated, 2 gate pre-pass, 3 BPTT data gra
   }
 #if GCRNN_HOP_ASM && GCRNN_STEP_WAVES == 8
   else if (mode == 5 && uni && resident) kern = (fused_kern_t)fused_step_kernel<K, HS, XS, false, true, 4, 1>;
+  else if (mode == 3 && uni && resident && ga.img16) {
+    if constexpr (XS == 0) kern = (fused_kern_t)fused_step_kernel<K, HS, XS, false, true, 2, 2>;
+    else return GCRNN_ERR_UNSUPPORTED;
+  }
   else if ((mode == 3 || mode == 7 || mode == 8) && uni && resident) kern = (fused_kern_t)fused_step_kernel<K, HS, XS, false, true, 2, 1>;
   else if (mode == 2 && uni && resident) kern = (fused_kern_t)fused_step_kernel<K, HS, XS, false, true, 1, 1>;
   else if (mode == 4 && uni && resident) kern = (fused_kern_t)fused_step_kernel<K, HS, XS, false, true, 3, 1>;

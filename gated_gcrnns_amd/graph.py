@@ -275,17 +275,18 @@ class GraphOperator(object):
         setattr(self, key, plan)
         return plan
 
-    def fused_plan_img16(self):
+    def fused_plan_img16(self, adjoint=False):
         """The forward plan re-addressed for a bf16 hop image (32-byte state rows; the un-gated step kernel then sums the gathered
         rows on the matrix cores, csrc GCRNN_HOP_ASM_UNI16_STREAM), or None when the graph has no uniform-weight plan.
         A row's two 16-byte halves are XOR-swizzled by `hswz`; node_addr16 = row16 << 5 | hswz << 4. The gather key of the fp32 image
         (swz << 2 | row & 3, slots 4..11 flipped by 4) maps one-to-one onto the new one ((row16 & 7) << 1 | hswz, flipped by 1) with
         hswz = swz & 1 and row16 & 7 a bijection of (row & 3, swz >> 1), so the conflict-free schedule of the entries carries over as it is.
         Column words per slot and group of four entries: (entry 0, entry 2, entry 1, entry 3) as four uint16 neighbour addresses."""
-        plan16 = self.__dict__.get('_fused_plan_img16', False)
+        key = '_fused_plan_img16_adj' if adjoint else '_fused_plan_img16'
+        plan16 = self.__dict__.get(key, False)
         if plan16 is not False:
             return plan16
-        plan = self.fused_plan()
+        plan = self.fused_plan(adjoint=adjoint)
         plan16 = None
         if plan.get('uniform_w', 0.0) != 0.0 and plan['entries'] > 0:
             npad = plan['npad']
@@ -324,7 +325,7 @@ class GraphOperator(object):
             plan16.update(tile_slots=torch.from_numpy(tile_slots).to(dev),
                           ell_col4=torch.from_numpy(col4.reshape(-1).view(np.int16)).to(dev),
                           node_addr16=torch.from_numpy(addr16.astype(np.int32)).to(dev), img16=True, img16_moved=len(left))
-        self._fused_plan_img16 = plan16
+        setattr(self, key, plan16)
         return plan16
 
     def to(self, device):

@@ -1202,8 +1202,11 @@ def fused_backward_data(dHs, hs, wB, graph, want_dh0=True, gf=None, h0s=None, bi
     parts = None
     if h0s is not None:
         parts = torch.empty((T * B, (F // 16) * int(lib.gcrnn_fused_step_waves())), dtype=torch.float32, device=hs.device)
-    check(lib.gcrnn_fused_backward_data_bf16(_p(dHs), _p(hs), _p(dpre), _p(dh0), _p(wpack), *_fused_graph_args(plan),
-                                             B, T, graph.N, F, K, _p(gf), _p(h0s), _p(parts), plan.get('uniform_w', 0.0), _p(dH_user), st),
+    import os
+    plan16 = None if os.environ.get('GCRNN_NO_IMG16') else graph.fused_plan_img16(adjoint=True)      # bf16 hop image, matrix-core sums (uniform graphs)
+    check(lib.gcrnn_fused_backward_data_bf16(_p(dHs), _p(hs), _p(dpre), _p(dh0), _p(wpack), *_fused_graph_args(plan16 or plan),
+                                             B, T, graph.N, F, K, _p(gf), _p(h0s), _p(parts), plan.get('uniform_w', 0.0), _p(dH_user),
+                                             1 if plan16 else 0, st),
           'fused_backward_data')
     if h0s is None:
         return dpre, dh0

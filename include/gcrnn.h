@@ -373,6 +373,7 @@ int gcrnn_fused_backward_data_bf16(const void* dHs, const void* hs, void* dpre, 
                                    float* dgf_parts, double uniform_w,
                                    const void* dHuser_inline /* NULL, or dH [B][T][F][N] bf16 in the user layout: the launch that consumes dHs[t-1]
                                       also lays out dHs[t-2] (the caller packs steps T-2, T-1 only); gcrnn_fused_inline_pack_supported(N, F, F, ...) */,
+                                   int img16 /* != 0: the graph arrays address a bf16 hop image (GraphOperator.fused_plan_img16(adjoint=True), uniform_w != 0) */,
                                    void* stream);
 
 /* BPTT weight gradient of the fused cell (adjoint of the taps, graphML.py:134-135), all T*B items in ONE launch:

@@ -218,7 +218,8 @@ def gen_uniform():
 # both neighbours' rows to D[feature][slot], whose register layout (lane (r, q): features 4q .. 4q+3 of slot r) is the accumulators'.
 # Column words per slot and trip: dword 0 = addr(entry 0) | addr(entry 2) << 16, dword 1 = addr(entry 1) | addr(entry 3) << 16.
 # Operands: %0..%15 accumulator halves, %16..%23 tile ends, %24 first group, %25 last valid group (SGPR), %26 column base + 8 r,
-# %27 = (q & 1) << 4, %28 = {w, w}, %29 = the lane's A operand (4 VGPRs), %30 = q >> 1. Clobbers v[194:253], s[88:90], scc, vcc.
+# (+ 4 (q >> 1): a lane reads only its own dword), %27 = (q & 1) << 4, %28 = {w, w}, %29 = the lane's A operand (4 VGPRs).
+# Clobbers v[194:253], s[88:90], scc.
 def VX(p, e):
     b = UB + 16 * p + 4 * e
     return 'v[%d:%d]' % (b, b + 3)
@@ -228,23 +229,27 @@ VSEL = 'v%d' % (UB + 55)
 
 
 def vs1(q, lines):
-    lines.append('v_cndmask_b32 %s, %s, %s, vcc' % (VSEL, UCw(q, 0), UCw(q, 1)))
     for e in range(2):
         lines.append('v_xor_b32_sdwa %s, %s, %s dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_%d src1_sel:DWORD'
-                     % (UXa(q, e), VSEL, UQX, e))
+                     % (UXa(q, e), UCw(q, 0), UQX, e))
     for e in range(2):
         lines.append('ds_read_b128 %s, %s' % (VX(q, e), UXa(q, e)))
 
 
+def vs0(q, goff, lines):      # the lane's OWN column dword of group g + goff (column base operand = base + 8 r + 4 (q >> 1))
+    lines += ['s_add_i32 %s, %s, %d' % (ST, SG, goff), 's_min_i32 %s, %s, %s' % (ST, ST, GLAST),
+              'v_lshl_add_u32 %s, %s, 7, %s' % (UCA, ST, COLB), 'ds_read_b32 %s, %s' % (UCw(q, 0), UCA)]
+
+
 def gen_uniform16():
-    L = ['s_mov_b32 %s, %s' % (SG, GBEG), 'v_cmp_ne_u32 vcc, 0, %30']
+    L = ['s_mov_b32 %s, %s' % (SG, GBEG)]
     for r in range(4):
         L.append('v_mov_b32 v%d, 0' % (UB + 56 + r))
     for p in range(3):
-        us0(p, p, L)
+        vs0(p, p, L)
     L.append('s_waitcnt lgkmcnt(0)')
-    vs1(0, L); us0(0, 3, L)
-    vs1(1, L); us0(1, 4, L)
+    vs1(0, L); vs0(0, 3, L)
+    vs1(1, L); vs0(1, 4, L)
     for t in range(NT):
         for p in range(3):
             L.append('L_T%d_P%d_%%=:' % (t, p))
@@ -252,7 +257,7 @@ def gen_uniform16():
             L.append('s_cbranch_scc1 L_X%d_P%d_%%=' % (t, p))
             q = (p + 2) % 3
             vs1(q, L)                                             # (the set's registers were B operands of the PREVIOUS trip's MFMAs: read long ago)
-            us0(q, 5, L)
+            vs0(q, 5, L)
             L.append('s_waitcnt lgkmcnt(6)')
             for e in range(2):
                 L.append('v_mfma_f32_16x16x32_bf16 %s, %%29, %s, %s' % (USUM4, VX(p, e), USUM4))
