@@ -1390,3 +1390,80 @@ def test_plan_bank_keys_make_write_backs_and_scatters_conflict_free(N, density, 
     again = GraphOperator(S).fused_plan()
     assert np.array_equal(again['tile_slots'].numpy(), plan['tile_slots'].numpy())
     assert np.array_equal(again['ell_col'].numpy(), plan['ell_col'].numpy())
+    # (7) the same plan re-addressed for the bf16 hop image (32-byte rows): unique rows, gather keys a bijection of the fp32 image's
+    # (the conflict-free entry schedule carries over; only the few rows that did not fit their class may differ), every
+    # (row & 3, half swizzle) exactly twice per tile = the 2-way minimum of a 16-lane ds_write_b64 group, column words = neighbour
+    # addresses in the order (entry 0, 2, 1, 3)
+    p16 = g.fused_plan_img16()
+    if plan['uniform_w'] == 0.0:
+        assert p16 is None
+        return
+    a16 = p16['node_addr16'].numpy().astype(np.int64)
+    assert sorted((a16 >> 5).tolist()) == list(range(npad)) and np.all(a16 & 15 == 0) and a16.max() < 32768
+    na = plan['node_addr'].numpy().astype(np.int64)
+    old_key, new_key = (na >> 4) & 15, (a16 >> 4) & 15
+    same = sum(1 for k in range(16) if len(set(new_key[old_key == k].tolist())) <= 1)
+    assert same >= 16 - 2 * max(1, p16['img16_moved']) and p16['img16_moved'] <= npad // 32
+    s16 = p16['tile_slots'].numpy().astype(np.int64)
+    assert np.array_equal(s16 >> 16, nodes) and np.array_equal(s16 & 0xffff, a16[nodes])
+    wk16 = ((((s16 & 0xffff) >> 5) & 3) << 1) | (((s16 & 0xffff) >> 4) & 1)
+    assert sum(max(np.bincount(t, minlength=8)) > 2 for t in wk16.reshape(-1, 16)) <= max(2, 2 * p16['img16_moved'])
+    ec = plan['ell_col'].numpy().astype(np.int64).reshape(-1, 4, 16)
+    c16 = p16['ell_col4'].numpy().view(np.uint16).astype(np.int64).reshape(-1, 16, 4)
+    for w_, e_ in enumerate((0, 2, 1, 3)):
+        assert np.array_equal(a16[ec[:, e_, :]], c16[:, :, w_])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('N,F,K,T', [(1000, 64, 5, 32), (600, 32, 3, 8)])
+def test_bf16_hop_image_with_matrix_core_sums_against_oracle_and_fp32_image(N, F, K, T, monkeypatch):
+    """The un-gated step kernels on uniform-weight graphs keep the hop state as a bf16 image and sum the gathered neighbour rows on
+    the matrix cores. Same fp64 oracle, same tolerances as the fp32 image over a full-length sequence; the extra
+    rounding of the hop intermediates must not cost more than a third on top of the fp32 image's own error; gradients of a training
+    step (forward AND the BPTT data chain on the bf16 image) against the fp32-image kernels."""
+    import gated_gcrnns_amd.Utils.graphML as gml
+    from gated_gcrnns_amd import ops
+    dev = torch.device('cuda:0')
+    rng = np.random.default_rng(33)
+    W = (rng.random((N, N)) < 10.0 / N).astype(np.float64)
+    W = np.triu(W, 1); W = W + W.T
+    S = (W / np.max(np.abs(np.linalg.eigvalsh(W)))).reshape(1, N, N)
+    B = 3
+    X = bf16_round(rng.standard_normal((B, T, F, N)))
+    h0 = bf16_round(0.4 * rng.standard_normal((B, F, N)))
+    torch.manual_seed(5)
+    cell = gml.GGCRNNCell(F, F, K, K, torch.tanh, False, None, 1, True)
+    cell.addGSO(torch.tensor(S))
+    params = {k: bf16_round(v.detach().numpy()) for k, v in cell.state_dict().items()}
+    ref = orc.ggcrnn_cell(params, S.astype(np.float32).astype(np.float64), X, h0)
+    cell = cell.to(dev).to(torch.bfloat16)
+    Xd = torch.tensor(X, dtype=torch.bfloat16, device=dev)
+    hd = torch.tensor(h0, dtype=torch.bfloat16, device=dev)
+    assert cell.graph.fused_plan_img16() is not None and ops.fused_img16_plan(cell.graph, False, None) is not None
+    with torch.no_grad():
+        H16 = cell(Xd, hd).double().cpu().numpy()
+    monkeypatch.setenv('GCRNN_NO_IMG16', '1')
+    assert ops.fused_img16_plan(cell.graph, False, None) is None
+    with torch.no_grad():
+        H32 = cell(Xd, hd).double().cpu().numpy()
+    monkeypatch.delenv('GCRNN_NO_IMG16')
+    e16, e32 = np.abs(H16 - ref), np.abs(H32 - ref)
+    print('bf16 image: max %.2e mean %.2e   fp32 image: max %.2e mean %.2e' % (e16.max(), e16.mean(), e32.max(), e32.mean()))
+    assert e16[:, 0].max() <= 4.0e-3 and e16.max() <= 3e-2 and e16.mean() <= 2e-3, (e16.max(), e16.mean())
+    assert e16.mean() <= 1.34 * e32.mean() + 1e-5, (e16.mean(), e32.mean())
+    # training step: gradients with the bf16 image (forward + BPTT data chain) vs the fp32 image
+    cellf = cell.float()
+    tgt = torch.tensor(rng.standard_normal((B, T, F, N)), dtype=torch.float32, device=dev)
+    def grads():
+        for p_ in cellf.parameters():
+            p_.grad = None
+        Hh = cellf(Xd, hd)
+        ((Hh.float() - tgt) ** 2).mean().backward()
+        return {n: p_.grad.detach().double().cpu().numpy().copy() for n, p_ in cellf.named_parameters() if p_.grad is not None}
+    g16 = grads()
+    monkeypatch.setenv('GCRNN_NO_IMG16', '1')
+    g32 = grads()
+    assert set(g16) == set(g32) and 'weight_A' in g16
+    for n in g16:
+        sc = np.abs(g32[n]).max()
+        assert sc > 0 and np.abs(g16[n] - g32[n]).max() <= 3e-2 * sc, (n, np.abs(g16[n] - g32[n]).max() / sc)
