@@ -405,6 +405,8 @@ def run_cfg2(ctx):
                            'mfma_util_note': 'taps GEMM flops executed per launch / duration / 2.5 PF dense bf16 peak'
                                              + (' (PMC: SQ_VALU_MFMA_BUSY_CYCLES %.3g per launch)' % tj['mfma_busy_cycles'] if tj and 'mfma_busy_cycles' in tj else ''),
                            'whole_step_GBps': achieved, 'device_ms_per_step': 1e3 * step_s}
+        out['roofline']['hop_state_image'] = ('bf16 rows, neighbour rows summed on the matrix cores (one-hot A operand; uniform-weight graph)'
+                                              if ops.fused_img16_plan(cell.graph, False, None) is not None else 'fp32 rows, packed VALU sums')
         if kern.get('inline_pack'):
             # uniform-weight graph: every launch ALSO lays out x_{t+1} (the former pack pass over X: 2 N G B more bytes per launch that
             # `achieved` does not count). frac is that of the launch as issued; the bare step kernel is timed next to it.
