@@ -99,7 +99,7 @@ def _bind(lib):
         'gcrnn_fused_forward_x3': (C.c_int, [_c_p] * 8 + [_c_i64] * 7 + [C.c_double, _c_p, C.c_int, _c_p]),
         'gcrnn_pack_seq_major_steps': (C.c_int, [_c_p, _c_p, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_p]),
         'gcrnn_fused_gate_prepass_bf16': (C.c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p,
-                                                    _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_p, C.c_double, _c_p]),
+                                                    _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_p, C.c_double, C.c_int, _c_p]),
         'gcrnn_fused_gate_readout_slabs': (_c_i64, [_c_i64]),
         'gcrnn_fused_gate_readout_backward_bf16': (C.c_int, [_c_p, _c_p, _c_p, _c_p, _c_i64, _c_i64, _c_i64, _c_p]),
         'gcrnn_fused_gate_grad_bf16': (C.c_int, [_c_p] * 12 + [_c_i64] * 7 + [C.c_double, _c_p]),

@@ -309,10 +309,10 @@ extern "C" int gcrnn_fused_gate_prepass_bf16(const void* xs, const void* h0, con
                                              const int32_t* tile_off, const int32_t* ell_col, const float* ell_val,
                                              const void* ell_val4, const void* ell_col4, int64_t entries, int64_t B,
                                              int64_t T, int64_t N, int64_t F, int64_t G, int64_t K, const int32_t* h0_zero_flag,
-                                             double uniform_w, void* stream) {
+                                             double uniform_w, int img16, void* stream) {
   if (!xs || !h0 || !wpack || !gate_w || !gate_out || !tile_nodes || !tile_off || !ell_col || !ell_val) return GCRNN_ERR_NULL_POINTER;
   if (B <= 0 || T <= 0 || N <= 0 || N > NP || B * T > (1 << 24) || entries < 0 || entries % 4) return GCRNN_ERR_BAD_SHAPE;
-  const FusedGraphArgs ga{tile_nodes, tile_off, ell_col, ell_val, ell_val4, ell_col4, entries, (float)uniform_w};
+  const FusedGraphArgs ga{tile_nodes, tile_off, ell_col, ell_val, ell_val4, ell_col4, entries, (float)uniform_w, img16 ? 1 : 0};
   return fused_dispatch(2, xs, h0, cs, wpack, bias, nullptr, nullptr, gate_w, gate_out, ga, B, T, N, F, G, K, as_stream(stream),
                         nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, h0_zero_flag);
 }

@@ -1063,7 +1063,7 @@ int fused_launch_t(int mode /*0 plain, 1 gated, 2 gate pre-pass, 3 BPTT data gra
                        T * (inline_bw ? F : G) * N <= 2147483647LL))
     return GCRNN_ERR_UNSUPPORTED;
   const size_t lds = (resident ? resident_bytes : base) + (inline_pack ? xtile_bytes : 0);
-  if (ga.img16 && !((mode == 0 || mode == 3) && uni && resident)) return GCRNN_ERR_UNSUPPORTED;      // the bf16-image plan: un-gated forward steps (with or without the fused head) and the BPTT data chain
+  if (ga.img16 && !((mode == 0 || mode == 1 || mode == 2 || mode == 3) && uni && resident)) return GCRNN_ERR_UNSUPPORTED;      // the bf16-image plan: forward steps (un-gated / time-gated, with or without the fused head), gate pre-pass, BPTT data chain
   fused_kern_t kern;
   const bool head = (mode == 0 || mode == 1) && gate_w != nullptr;      // fused output head: EPI 6 instantiations
   if (head) {
@@ -1073,7 +1073,7 @@ int fused_launch_t(int mode /*0 plain, 1 gated, 2 gate pre-pass, 3 BPTT data gra
       else kern = resident ? (fused_kern_t)fused_step_kernel<K, HS, XS, false, true, 6> : (fused_kern_t)fused_step_kernel<K, HS, XS, false, false, 6>;
 #if GCRNN_HOP_ASM && GCRNN_STEP_WAVES == 8
       if (uni && resident) kern = mode == 1 ? (fused_kern_t)fused_step_kernel<K, HS, XS, true, true, 6, 1> : (fused_kern_t)fused_step_kernel<K, HS, XS, false, true, 6, 1>;
-      if (uni && resident && ga.img16 && mode == 0) kern = (fused_kern_t)fused_step_kernel<K, HS, XS, false, true, 6, 2>;
+      if (uni && resident && ga.img16) kern = mode == 1 ? (fused_kern_t)fused_step_kernel<K, HS, XS, true, true, 6, 2> : (fused_kern_t)fused_step_kernel<K, HS, XS, false, true, 6, 2>;
 #endif
     } else {
       return GCRNN_ERR_UNSUPPORTED;
@@ -1094,6 +1094,10 @@ int fused_launch_t(int mode /*0 plain, 1 gated, 2 gate pre-pass, 3 BPTT data gra
     else return GCRNN_ERR_UNSUPPORTED;
   }
   else if ((mode == 3 || mode == 7 || mode == 8) && uni && resident) kern = (fused_kern_t)fused_step_kernel<K, HS, XS, false, true, 2, 1>;
+  else if (mode == 2 && uni && resident && ga.img16) {
+    if constexpr (XS > 0) kern = (fused_kern_t)fused_step_kernel<K, HS, XS, false, true, 1, 2>;
+    else return GCRNN_ERR_UNSUPPORTED;
+  }
   else if (mode == 2 && uni && resident) kern = (fused_kern_t)fused_step_kernel<K, HS, XS, false, true, 1, 1>;
   else if (mode == 4 && uni && resident) kern = (fused_kern_t)fused_step_kernel<K, HS, XS, false, true, 3, 1>;
 #endif
@@ -1102,6 +1106,10 @@ int fused_launch_t(int mode /*0 plain, 1 gated, 2 gate pre-pass, 3 BPTT data gra
   else if (mode == 3 || mode == 7 || mode == 8) kern = resident ? (fused_kern_t)fused_step_kernel<K, HS, XS, false, true, 2> : (fused_kern_t)fused_step_kernel<K, HS, XS, false, false, 2>;
   else if (mode == 2) kern = resident ? (fused_kern_t)fused_step_kernel<K, HS, XS, false, true, 1> : (fused_kern_t)fused_step_kernel<K, HS, XS, false, false, 1>;
 #if GCRNN_HOP_ASM && GCRNN_STEP_WAVES == 8
+  else if (mode == 1 && uni && resident && ga.img16) {
+    if constexpr (XS > 0) kern = (fused_kern_t)fused_step_kernel<K, HS, XS, true, true, 0, 2>;
+    else return GCRNN_ERR_UNSUPPORTED;
+  }
   else if (mode == 1 && uni && resident) kern = (fused_kern_t)fused_step_kernel<K, HS, XS, true, true, 0, 1>;
   else if (mode == 0 && uni && resident && ga.img16) {
     if constexpr (XS > 0) kern = (fused_kern_t)fused_step_kernel<K, HS, XS, false, true, 0, 2>;

@@ -391,10 +391,10 @@ def _fused_pack_weights(wA, wB, st):
 
 
 def fused_img16_plan(graph, gated, head):
-    """The bf16-image plan of the un-gated forward steps (GraphOperator.fused_plan_img16), or None: uniform-weight graphs only, no
-    time gates (the fused head is fine); GCRNN_NO_IMG16=1 switches it off (A/B, and the fp32-image tests)."""
+    """The bf16-image plan of the un-gated forward steps (GraphOperator.fused_plan_img16), or None: uniform-weight graphs only
+    (un-gated and time-gated cells, with or without the fused head); GCRNN_NO_IMG16=1 switches it off (A/B, and the fp32-image tests)."""
     import os
-    if gated or os.environ.get('GCRNN_NO_IMG16'):
+    if os.environ.get('GCRNN_NO_IMG16'):
         return None
     return graph.fused_plan_img16()
 
@@ -496,8 +496,10 @@ def fused_time_gate(xs, h0s, wA_g, wB_g, bias_g, lin_w, lin_b, graph, N, store_s
     gw = lin_w.detach().float().view(F, N).t().contiguous()                  # row-major vec over (f, n) -> [N][F]
     parts = torch.empty((T * B, (F // 16) * int(lib.gcrnn_fused_step_waves())), dtype=torch.float32, device=xs.device)
     cs = torch.empty((T, B, npad, F), dtype=torch.bfloat16, device=xs.device) if store_states else None
+    plan16 = fused_img16_plan(graph, True, None)
     check(lib.gcrnn_fused_gate_prepass_bf16(_p(xs), _p(h0s), _p(wp), _p(bg), _p(gw), _p(parts), _p(cs),
-                                            *_fused_graph_args(plan), B, T, N, F, G, K, _p(hzero), plan.get('uniform_w', 0.0), st), 'gate_prepass')
+                                            *_fused_graph_args(plan16 or plan), B, T, N, F, G, K, _p(hzero), plan.get('uniform_w', 0.0),
+                                            1 if plan16 else 0, st), 'gate_prepass')
     acc = parts.sum(dim=1)                                                    # fixed order: deterministic gates
     if lin_b is not None:
         acc = acc + lin_b.detach().float()

@@ -294,7 +294,7 @@ int gcrnn_fused_pack_weights(int wdtype, const void* wA, const void* wB, void* w
  * Huser (may be NULL; needs N % 8 == 0): the states are ALSO written in the user layout H[B][T][F][N] by the step kernels
  * themselves (LDS-transposed 16-byte row stores), which replaces gcrnn_unpack_seq_major over the whole sequence.
  * T launches on `stream`. The graph is kept resident in LDS when 64 KiB + weights + 96*entries B <= 160 KiB.
- * huser_last_only bit 1 (value 2, r2): tile_nodes / ell_col4 are the arrays of a bf16 hop image (un-gated cell, uniform_w != 0;
+ * huser_last_only bit 1 (value 2, r2): tile_nodes / ell_col4 are the arrays of a bf16 hop image (un-gated or time-gated cell, uniform_w != 0;
  *   GraphOperator.fused_plan_img16 (head_w allowed): 32-byte state rows, neighbour rows summed on the matrix cores); GCRNN_ERR_UNSUPPORTED otherwise.
  * huser_last_only bit 0: Huser is [B][1][F][N] and receives the LAST state only (the classification models read nothing else,
  * architectures.py:1841-1850); the other steps skip the user-layout store.
@@ -333,7 +333,8 @@ int gcrnn_fused_gate_prepass_bf16(const void* xs, const void* h0, const void* wp
                                   const float* gate_w, float* gate_out, void* cs, const int32_t* tile_nodes,
                                   const int32_t* tile_off, const int32_t* ell_col, const float* ell_val,
                                   const void* ell_val4, const void* ell_col4, int64_t entries, int64_t B, int64_t T,
-                                  int64_t N, int64_t F, int64_t G, int64_t K, const int32_t* h0_zero_flag, double uniform_w, void* stream);
+                                  int64_t N, int64_t F, int64_t G, int64_t K, const int32_t* h0_zero_flag, double uniform_w,
+                                  int img16 /* as in gcrnn_fused_backward_data_bf16 (forward plan) */, void* stream);
 
 /* d loss / d (scalar time gate) of ONE filter of the time-gated cell (the gates multiply the filter outputs, graphML.py:2420-2421):
  *   sum over out[t][b][0 .. F/16*8) = sum_{f,n} ( W(S) z[t][b] + bias )[n][f] * dpre[t][b][n][f]
