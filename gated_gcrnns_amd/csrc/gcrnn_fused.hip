@@ -342,11 +342,11 @@ extern "C" int gcrnn_fused_gate_grad_bf16(const void* zs, const void* xs, const 
 extern "C" int gcrnn_fused_filter_output_bf16(const void* zs, const void* xs, const void* wpack, const float* bias, void* out,
                                               const int32_t* tile_nodes, const int32_t* tile_off, const int32_t* ell_col,
                                               const float* ell_val, const void* ell_val4, const void* ell_col4, int64_t entries,
-                                              int64_t B, int64_t T, int64_t N, int64_t F, int64_t G, int64_t K, double uniform_w, void* stream) {
+                                              int64_t B, int64_t T, int64_t N, int64_t F, int64_t G, int64_t K, double uniform_w, int img16, void* stream) {
   if (!zs || !wpack || !out || !tile_nodes || !tile_off || !ell_col || !ell_val) return GCRNN_ERR_NULL_POINTER;
   if ((xs == nullptr) != (G == 0)) return GCRNN_ERR_BAD_SHAPE;
   if (B <= 0 || T <= 0 || N <= 0 || N > NP || B * T > (1 << 24) || entries < 0 || entries % 4) return GCRNN_ERR_BAD_SHAPE;
-  const FusedGraphArgs ga{tile_nodes, tile_off, ell_col, ell_val, ell_val4, ell_col4, entries, (float)uniform_w};
+  const FusedGraphArgs ga{tile_nodes, tile_off, ell_col, ell_val, ell_val4, ell_col4, entries, (float)uniform_w, img16 ? 1 : 0};
   return fused_dispatch(5, xs, zs, out, wpack, bias, nullptr, nullptr, nullptr, nullptr, ga, B, T, N, F, G, K, as_stream(stream));
 }
 
@@ -366,9 +366,9 @@ extern "C" int gcrnn_fused_node_forward_bf16(const void* h0s, void* hs, const vo
   if (B <= 0 || T <= 0 || N <= 0 || N > NP || B > (1 << 24) || entries < 0 || entries % 4) return GCRNN_ERR_BAD_SHAPE;
   if (B * (NP * F * 2) > 2147483647LL || T * F * N > 2147483647LL) return GCRNN_ERR_BAD_SHAPE;
   if (Huser && (N % 8 != 0 || (reinterpret_cast<uintptr_t>(Huser) & 15))) return GCRNN_ERR_BAD_SHAPE;
-  const FusedGraphArgs ga{tile_nodes, tile_off, ell_col, ell_val, ell_val4, ell_col4, entries, (float)uniform_w};
+  const FusedGraphArgs ga{tile_nodes, tile_off, ell_col, ell_val, ell_val4, ell_col4, entries, (float)uniform_w, (huser_last_only >> 1) & 1};
   return fused_dispatch(6, nullptr, h0s, hs, wpackB, bias, gi, gf, ngates, nullptr, ga, B, T, N, F, 0, K, as_stream(stream), yx, nullptr,
-                        yh_out, Huser, nullptr, nullptr, huser_last_only);
+                        yh_out, Huser, nullptr, nullptr, huser_last_only & 1);
 }
 
 // dpre[i] = dH[i] * (1 - h[i]^2) on bf16 arrays (the seed of the BPTT chain, t = T-1)

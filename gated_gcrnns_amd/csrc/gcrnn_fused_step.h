@@ -1063,7 +1063,7 @@ int fused_launch_t(int mode /*0 plain, 1 gated, 2 gate pre-pass, 3 BPTT data gra
                        T * (inline_bw ? F : G) * N <= 2147483647LL))
     return GCRNN_ERR_UNSUPPORTED;
   const size_t lds = (resident ? resident_bytes : base) + (inline_pack ? xtile_bytes : 0);
-  if (ga.img16 && !((mode == 0 || mode == 1 || mode == 2 || mode == 3) && uni && resident)) return GCRNN_ERR_UNSUPPORTED;      // the bf16-image plan: forward steps (un-gated / time-gated, with or without the fused head), gate pre-pass, BPTT data chain
+  if (ga.img16 && !((mode == 0 || mode == 1 || mode == 2 || mode == 3 || mode == 5 || mode == 6) && uni && resident)) return GCRNN_ERR_UNSUPPORTED;      // the bf16-image plan: forward steps (un-gated / time-gated, with or without the fused head), gate pre-pass, BPTT data chain
   fused_kern_t kern;
   const bool head = (mode == 0 || mode == 1) && gate_w != nullptr;      // fused output head: EPI 6 instantiations
   if (head) {
@@ -1083,11 +1083,13 @@ int fused_launch_t(int mode /*0 plain, 1 gated, 2 gate pre-pass, 3 BPTT data gra
       kern = resident ? (fused_kern_t)fused_step_kernel<K, HS, XS, false, true, 5> : (fused_kern_t)fused_step_kernel<K, HS, XS, false, false, 5>;
 #if GCRNN_HOP_ASM && GCRNN_STEP_WAVES == 8
       if (uni && resident) kern = (fused_kern_t)fused_step_kernel<K, HS, XS, false, true, 5, 1>;
+      if (uni && resident && ga.img16) kern = (fused_kern_t)fused_step_kernel<K, HS, XS, false, true, 5, 2>;
 #endif
     }
     else return GCRNN_ERR_UNSUPPORTED;
   }
 #if GCRNN_HOP_ASM && GCRNN_STEP_WAVES == 8
+  else if (mode == 5 && uni && resident && ga.img16) kern = (fused_kern_t)fused_step_kernel<K, HS, XS, false, true, 4, 2>;
   else if (mode == 5 && uni && resident) kern = (fused_kern_t)fused_step_kernel<K, HS, XS, false, true, 4, 1>;
   else if (mode == 3 && uni && resident && ga.img16) {
     if constexpr (XS == 0) kern = (fused_kern_t)fused_step_kernel<K, HS, XS, false, true, 2, 2>;

@@ -602,13 +602,14 @@ def fused_filter_output(xs, w, bias, graph, K, N):
     T, B, npad, Cin = xs.shape
     F = w.shape[0]
     plan = graph.fused_plan()
+    plan16 = fused_img16_plan(graph, False, None)
     st = _stream()
     b32 = bias.detach().float().contiguous().view(-1) if bias is not None else None
     out = torch.empty((T, B, npad, F), dtype=torch.bfloat16, device=xs.device)
     if Cin == F:
         wp = _fused_pack_state_taps(w, K, st)
-        check(lib.gcrnn_fused_filter_output_bf16(_p(xs), None, _p(wp), _p(b32), _p(out), *_fused_graph_args(plan), B, T, N, F, 0, K,
-                                                 plan.get('uniform_w', 0.0), st),
+        check(lib.gcrnn_fused_filter_output_bf16(_p(xs), None, _p(wp), _p(b32), _p(out), *_fused_graph_args(plan16 or plan), B, T, N, F, 0, K,
+                                                 plan.get('uniform_w', 0.0), 1 if plan16 else 0, st),
               'fused_filter_output')
     else:
         wd = w.detach()
@@ -616,8 +617,8 @@ def fused_filter_output(xs, w, bias, graph, K, N):
             wd = torch.cat([wd, wd.new_zeros(F, 1, K - wd.shape[2], Cin)], dim=2)
         wp = _fused_pack_weights(wd, wd.new_zeros((F, 1, K, F)), st)
         zero_h = torch.zeros((1, npad, F), dtype=torch.bfloat16, device=xs.device)
-        check(lib.gcrnn_fused_filter_output_bf16(_p(zero_h), _p(xs), _p(wp), _p(b32), _p(out), *_fused_graph_args(plan), B, T, N, F, Cin, K,
-                                                 plan.get('uniform_w', 0.0), st),
+        check(lib.gcrnn_fused_filter_output_bf16(_p(zero_h), _p(xs), _p(wp), _p(b32), _p(out), *_fused_graph_args(plan16 or plan), B, T, N, F, Cin, K,
+                                                 plan.get('uniform_w', 0.0), 1 if plan16 else 0, st),
               'fused_filter_output')
     return out
 
@@ -692,9 +693,10 @@ def fused_node_cell_forward(X, h0, wA, wB, bias, graph, node_gates, time_gates=N
     b32 = bias.detach().float().contiguous().view(-1) if bias is not None else None
     H = torch.empty((B, 1 if last_only else T, F, N), dtype=torch.bfloat16, device=X.device)
     direct = (N % 8 == 0)
+    plan16 = fused_img16_plan(graph, False, None)
     check(lib.gcrnn_fused_node_forward_bf16(_p(h0s), _p(hs), _p(yx), _p(ngates), _p(gi), _p(gf), _p(wpB), _p(b32), None,
-                                            *_fused_graph_args(plan), B, T, N, F, K, _p(H) if direct else None, int(last_only),
-                                            plan.get('uniform_w', 0.0), st),
+                                            *_fused_graph_args(plan16 or plan), B, T, N, F, K, _p(H) if direct else None,
+                                            int(last_only) | (2 if plan16 else 0), plan.get('uniform_w', 0.0), st),
           'fused_node_forward')
     if not direct:
         src = hs[T - 1:] if last_only else hs
@@ -777,8 +779,10 @@ class _FusedNodeCell(torch.autograd.Function):
         b32 = bias.detach().float().contiguous().view(-1) if bias is not None else None
         H = torch.empty((B, T, F, N), dtype=torch.bfloat16, device=X.device)
         yh = torch.empty_like(yx)
+        plan16 = fused_img16_plan(graph, False, None)
         check(lib.gcrnn_fused_node_forward_bf16(_p(h0s), _p(hs), _p(yx), _p(ngates), _p(gic), _p(gfc), _p(wpB), _p(b32), _p(yh),
-                                                *_fused_graph_args(plan), B, T, N, F, K, _p(H), 0, plan.get('uniform_w', 0.0), st), 'fused_node_forward')
+                                                *_fused_graph_args(plan16 or plan), B, T, N, F, K, _p(H), 2 if plan16 else 0,
+                                                plan.get('uniform_w', 0.0), st), 'fused_node_forward')
         ctx.save_for_backward(X, h0, wA, wB, bias, H, hs_all, yx, yh, ngates, gic, gfc)
         ctx.graph, ctx.npad = graph, plan['npad']
         return H
@@ -910,10 +914,11 @@ def fused_edge_cell_forward(X, h0, wA, wB, bias, graph, att_in, att_f, time_gate
     bB32 = bB.contiguous() if bB is not None else None
     H = torch.empty((B, 1 if last_only else T, F, N), dtype=torch.bfloat16, device=X.device)
     zh = torch.empty((1, B, npad, F), dtype=torch.bfloat16, device=X.device)
-    ga = _fused_graph_args(plan)
+    plan16 = fused_img16_plan(graph, False, None)
+    ga = _fused_graph_args(plan16 or plan)
     uw = plan.get('uniform_w', 0.0)
     for t in range(T):
-        check(lib.gcrnn_fused_filter_output_bf16(_p(hs_all[t]), None, _p(wpB), _p(bB32), _p(zh), *ga, B, 1, N, F, 0, K, uw, st),
+        check(lib.gcrnn_fused_filter_output_bf16(_p(hs_all[t]), None, _p(wpB), _p(bB32), _p(zh), *ga, B, 1, N, F, 0, K, uw, 1 if plan16 else 0, st),
               'fused_filter_output')
         hu = None
         if not last_only:
@@ -987,10 +992,11 @@ class _FusedEdgeCell(torch.autograd.Function):
         H = torch.empty((B, T, F, N), dtype=torch.bfloat16, device=X.device)
         zh = torch.empty((T, B, npad, F), dtype=torch.bfloat16, device=X.device)
         rh = torch.empty_like(zh)
-        ga = _fused_graph_args(plan)
+        plan16 = fused_img16_plan(graph, False, None)
+        ga = _fused_graph_args(plan16 or plan)
         uw = plan.get('uniform_w', 0.0)
         for t in range(T):
-            check(lib.gcrnn_fused_filter_output_bf16(_p(hs_all[t]), None, _p(wpB), _p(bB32), _p(zh[t]), *ga, B, 1, N, F, 0, K, uw, st),
+            check(lib.gcrnn_fused_filter_output_bf16(_p(hs_all[t]), None, _p(wpB), _p(bB32), _p(zh[t]), *ga, B, 1, N, F, 0, K, uw, 1 if plan16 else 0, st),
                   'fused_filter_output')
             fused_edge_attention(zh[t], a_f, graph, gx=gx[t], gi=gic[t] if gic is not None else None,
                                  gf=gfc[t] if gfc is not None else None, out=hs_all[t + 1], r_out=rh[t], Huser=H[:, t],

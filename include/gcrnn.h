@@ -148,7 +148,9 @@ int gcrnn_ell_fill(const int32_t* rowptr, const int32_t* col, const double* val,
 int gcrnn_fused_filter_output_bf16(const void* zs, const void* xs, const void* wpack, const float* bias, void* out,
                                    const int32_t* tile_nodes, const int32_t* tile_off, const int32_t* ell_col, const float* ell_val,
                                    const void* ell_val4, const void* ell_col4, int64_t entries, int64_t B, int64_t T, int64_t N,
-                                   int64_t F, int64_t G, int64_t K, double uniform_w, void* stream);
+                                   int64_t F, int64_t G, int64_t K, double uniform_w, int img16 /* as in gcrnn_fused_backward_data_bf16 (forward plan) */,
+                                   void* stream);
+/* (huser_last_only: bit 0 and bit 1 as in gcrnn_fused_forward_bf16) */
 int gcrnn_fused_node_forward_bf16(const void* h0s, void* hs, const void* yx, const float* ngates, const float* gi, const float* gf,
                                   const void* wpackB, const float* bias, void* yh_out, const int32_t* tile_nodes,
                                   const int32_t* tile_off, const int32_t* ell_col, const float* ell_val, const void* ell_val4,
