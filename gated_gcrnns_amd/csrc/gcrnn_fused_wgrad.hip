@@ -66,7 +66,7 @@ __global__ __launch_bounds__(512, 2) void fused_wgrad_kernel(
     tbeg[i] = tile_off[wave * TILES + i];
     tend[i] = tile_off[wave * TILES + i + 1];
     const int nd = tile_nodes[(wave * TILES + i) * 16 + r];
-    woff[i] = nd ^ (q << 4);                       // slot = node << 16 | row << 6 | swz << 4
+    woff[i] = nd ^ (UNI == 2 ? (((q >> 1) << 4) | ((q & 1) << 3)) : (q << 4));      // slot = node << 16 | row << 6 | swz << 4  (UNI == 2: bf16 image, row16 << 5 | hswz << 4)
   }
   const int qoff = q * 16;
   const uint32_t lds0 = (uint32_t)reinterpret_cast<uintptr_t>(smem);
@@ -152,7 +152,7 @@ __global__ __launch_bounds__(512, 2) void fused_wgrad_kernel(
       for (int i = 0; i < TILES; ++i) {
         int wv = woff[i];
         asm volatile("" : "+v"(wv));
-        if (k < K - 1) *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(state) + (wv & 0xffff)) = cur[i];
+        if (k < K - 1) state_put<UNI == 2>(state, wv, cur[i]);
         const int node = wv >> 16;
         char* tb = tbuf + (node >= 512 ? TBYTES - 512 * 2 : 0) + node * 2;
         // odd quads write their rows in the order 2, 3, 0, 1 (TSTRIDE = 8 banks mod 32: the two quads of a 32-lane store group then sit
@@ -195,7 +195,8 @@ __global__ __launch_bounds__(512, 2) void fused_wgrad_kernel(
         LGKM_WAIT(0);
 #define GCRNN_WG_INIT(i) f32x4{0.f, 0.f, 0.f, 0.f}
 #define GCRNN_WG_STORE(i, a) cur[i] = a
-        GCRNN_HOP_ASM_UNI_STREAM(GCRNN_WG_INIT, GCRNN_WG_STORE);
+        if constexpr (UNI == 2) GCRNN_HOP_ASM_UNI16_STREAM(GCRNN_WG_INIT, GCRNN_WG_STORE);
+        else GCRNN_HOP_ASM_UNI_STREAM(GCRNN_WG_INIT, GCRNN_WG_STORE);
 #undef GCRNN_WG_INIT
 #undef GCRNN_WG_STORE
       }
@@ -360,7 +361,8 @@ static int fused_wgrad_t(const void* dpre, const void* Xuser, const void* Huser,
   const size_t lds = uni ? (size_t)NP * FC * 4 + (size_t)ga.entries * 32 + 2 * TBYTES + WAVES * FC * 4
                          : (size_t)NP * FC * 4 + (size_t)ga.entries * 96 + TBYTES + WAVES * FC * 4;
   if (lds > 160 * 1024 || !ga.ell_val4 || !ga.ell_col4) return GCRNN_ERR_UNSUPPORTED;
-  auto kern = uni ? fused_wgrad_kernel<K, HS, XS, 1> : fused_wgrad_kernel<K, HS, XS, 0>;
+  if (ga.img16 && !uni) return GCRNN_ERR_UNSUPPORTED;
+  auto kern = uni ? (ga.img16 ? fused_wgrad_kernel<K, HS, XS, 2> : fused_wgrad_kernel<K, HS, XS, 1>) : fused_wgrad_kernel<K, HS, XS, 0>;
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
     return GCRNN_ERR_LAUNCH;
   const int NCH = F / FC;
@@ -379,11 +381,13 @@ extern "C" int gcrnn_fused_backward_weight_bf16(const void* dpre, const void* Xu
                                                 const void* ell_val4, const void* ell_col4, int64_t entries, int64_t B,
                                                 int64_t T, int64_t N, int64_t F, int64_t G, int64_t K, const float* gi,
                                                 const float* gf, int h_is_h0, const int32_t* h0_zero_flag, double uniform_w, void* stream) {
+  const int img16 = (h_is_h0 >> 1) & 1;      // bit 1: the graph arrays address a bf16 hop image (fused_plan_img16(adjoint=True))
+  h_is_h0 &= 1;
   if ((gi == nullptr) != (gf == nullptr)) return GCRNN_ERR_NULL_POINTER;
   if (!dpre || !Xuser || (!Huser && !h_is_h0) || !h0user || !dW || !tile_nodes || !tile_off || !ell_val4 || !ell_col4) return GCRNN_ERR_NULL_POINTER;
   if (B <= 0 || T <= 0 || N <= 0 || N > NP || N % 8 || entries < 0 || entries % 4 || B * T > (1 << 24)) return GCRNN_ERR_BAD_SHAPE;
   if (T * B * (NP * F * 2) > 2147483647LL) return GCRNN_ERR_BAD_SHAPE;      // 32-bit buffer offsets into dpre
-  const FusedGraphArgs ga{tile_nodes, tile_off, nullptr, nullptr, ell_val4, ell_col4, entries, (float)uniform_w};
+  const FusedGraphArgs ga{tile_nodes, tile_off, nullptr, nullptr, ell_val4, ell_col4, entries, (float)uniform_w, img16};
   hipStream_t st = as_stream(stream);
 #define GCRNN_WG_CASE(KK, HH, XX) \
   if (K == KK && F == 32 * HH && G == 32 * XX) return fused_wgrad_t<KK, HH, XX>(dpre, Xuser, Huser, h0user, dW, dbsum, ga, gi, gf, h_is_h0, h_is_h0 ? h0_zero_flag : nullptr, B, T, N, st);

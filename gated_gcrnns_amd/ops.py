@@ -1237,11 +1237,13 @@ def fused_backward_weight(dpre, X, H, h0, graph, F, G, K, want_bias=False, gi=No
     dbp = torch.zeros((slots, F), dtype=torch.float32, device=dpre.device) if want_bias else None
     Xc, h0c = X.contiguous(), h0.contiguous()
     Hc = H.contiguous() if H is not None else None
+    uw = 0.0 if os.environ.get('GCRNN_WGRAD_NO_UNIFORM') else plan.get('uniform_w', 0.0)      # env: A/B switch
+    plan16 = None if (uw == 0.0 or os.environ.get('GCRNN_NO_IMG16')) else graph.fused_plan_img16(adjoint=True)      # bf16 hop image
+    pl = plan16 or plan
     check(lib.gcrnn_fused_backward_weight_bf16(_p(dpre), _p(Xc), _p(Hc), _p(h0c), _p(dWp),
-                                               _p(dbp), _p(plan['tile_slots']), _p(plan['tile_off']), _p(plan['ell_val4']),
-                                               _p(plan['ell_col4']), plan['entries'], B, T, graph.N, F, G, K,
-                                               _p(gi), _p(gf), int(h_is_h0), _p(hzero),
-                                               0.0 if os.environ.get('GCRNN_WGRAD_NO_UNIFORM') else plan.get('uniform_w', 0.0), _stream()),      # env: A/B switch
+                                               _p(dbp), _p(pl['tile_slots']), _p(pl['tile_off']), _p(pl['ell_val4']),
+                                               _p(pl['ell_col4']), pl['entries'], B, T, graph.N, F, G, K,
+                                               _p(gi), _p(gf), int(h_is_h0) | (2 if plan16 else 0), _p(hzero), uw, _stream()),
           'fused_backward_weight')
     dW = dWp.sum(dim=0)                                   # fixed order over the slots: bit-reproducible
     dbs = dbp.sum(dim=0) if want_bias else None

@@ -388,7 +388,8 @@ int gcrnn_fused_backward_data_bf16(const void* dHs, const void* hs, void* dpre, 
  * dW fp32 [slots][F][K][F+G], slots = gcrnn_fused_wgrad_slots(B*T, F): every workgroup slot stores ITS partial sum with plain
  * stores (the caller zero-fills the buffer and adds the slots in a fixed order: no atomics, two runs give the same bits);
  * graph arrays = LDS image of the ELL of CSR(S).
- * Returns GCRNN_ERR_UNSUPPORTED when the graph image does not fit in LDS next to the state. */
+ * Returns GCRNN_ERR_UNSUPPORTED when the graph image does not fit in LDS next to the state. 
+ * h_is_h0 bit 1 (value 2, r2): the graph arrays address a bf16 hop image (GraphOperator.fused_plan_img16(adjoint=True), uniform_w != 0). */
 int64_t gcrnn_fused_wgrad_slots(int64_t items, int64_t F);
 int gcrnn_fused_backward_weight_bf16(const void* dpre, const void* Xuser, const void* Huser, const void* h0user, float* dW,
                                      float* dbsum /* [slots][F] partials of the bias gradient sum_{t,b} (gi + gf) sum_n dpre (2 sum dpre without gates), or NULL */,
