@@ -83,7 +83,7 @@ def _bind(lib):
         'gcrnn_fused_inline_pack_supported': (C.c_int, [_c_i64, _c_i64, _c_i64, _c_i64, _c_i64, C.c_double]),
         'gcrnn_fused_filter_output_bf16': (C.c_int, [_c_p] * 11 + [_c_i64] * 7 + [C.c_double, C.c_int, _c_p]),
         'gcrnn_fused_node_forward_bf16': (C.c_int, [_c_p] * 15 + [_c_i64] * 6 + [_c_p, C.c_int, C.c_double, _c_p]),
-        'gcrnn_fused_node_backward_data_bf16': (C.c_int, [_c_p] * 12 + [_c_i64] * 6 + [C.c_double, _c_p, _c_p]),
+        'gcrnn_fused_node_backward_data_bf16': (C.c_int, [_c_p] * 12 + [_c_i64] * 6 + [C.c_double, _c_p, C.c_int, _c_p]),
         'gcrnn_node_cell_backward': (C.c_int, [_c_p] * 11 + [_c_i64] * 5 + [_c_p]),
         'gcrnn_node_gate_dot': (C.c_int, [_c_p, _c_p, _c_p, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_p]),
         'gcrnn_node_gate_dot_backward': (C.c_int, [_c_p, _c_p, _c_p, _c_p, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_p]),
@@ -91,7 +91,7 @@ def _bind(lib):
         'gcrnn_fused_edge_attention_bf16': (C.c_int, [_c_p] * 13 + [_c_i64] * 5 + [C.c_double, _c_p]),
         'gcrnn_fused_edge_attention_backward_supported': (C.c_int, [_c_i64, _c_i64, _c_i64]),
         'gcrnn_fused_edge_attention_backward_bf16': (C.c_int, [_c_p] * 14 + [_c_i64] * 6 + [C.c_double, _c_p]),
-        'gcrnn_fused_backward_step_bf16': (C.c_int, [_c_p] * 11 + [_c_i64] * 5 + [C.c_double, _c_p, _c_p, _c_i64, _c_p]),
+        'gcrnn_fused_backward_step_bf16': (C.c_int, [_c_p] * 11 + [_c_i64] * 5 + [C.c_double, _c_p, _c_p, _c_i64, C.c_int, _c_p]),
         'gcrnn_fused_backward_seed_bf16': (C.c_int, [_c_p, _c_p, _c_p, _c_i64, _c_p]),
         'gcrnn_fused_x3_supported': (C.c_int, [_c_i64, _c_i64, _c_i64, _c_i64, _c_i64]),
         'gcrnn_pack_seq_major_x3': (C.c_int, [_c_p, _c_p, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_p]),
@@ -102,7 +102,7 @@ def _bind(lib):
                                                     _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_p, C.c_double, C.c_int, _c_p]),
         'gcrnn_fused_gate_readout_slabs': (_c_i64, [_c_i64]),
         'gcrnn_fused_gate_readout_backward_bf16': (C.c_int, [_c_p, _c_p, _c_p, _c_p, _c_i64, _c_i64, _c_i64, _c_p]),
-        'gcrnn_fused_gate_grad_bf16': (C.c_int, [_c_p] * 12 + [_c_i64] * 7 + [C.c_double, _c_p]),
+        'gcrnn_fused_gate_grad_bf16': (C.c_int, [_c_p] * 12 + [_c_i64] * 7 + [C.c_double, C.c_int, _c_p]),
         'gcrnn_fused_backward_data_bf16': (C.c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p,
                                                      _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_p, _c_p, _c_p, C.c_double, _c_p, C.c_int, _c_p]),
         'gcrnn_fused_wgrad_slots': (_c_i64, [_c_i64, _c_i64]),

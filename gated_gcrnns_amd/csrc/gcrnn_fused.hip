@@ -326,11 +326,11 @@ extern "C" int gcrnn_fused_gate_prepass_bf16(const void* xs, const void* h0, con
 extern "C" int gcrnn_fused_gate_grad_bf16(const void* zs, const void* xs, const void* dpre, const void* wpack, const float* bias,
                                           float* out, const int32_t* tile_nodes, const int32_t* tile_off, const int32_t* ell_col,
                                           const float* ell_val, const void* ell_val4, const void* ell_col4, int64_t entries,
-                                          int64_t B, int64_t T, int64_t N, int64_t F, int64_t G, int64_t K, double uniform_w, void* stream) {
+                                          int64_t B, int64_t T, int64_t N, int64_t F, int64_t G, int64_t K, double uniform_w, int img16, void* stream) {
   if (!zs || !dpre || !wpack || !out || !tile_nodes || !tile_off || !ell_col || !ell_val) return GCRNN_ERR_NULL_POINTER;
   if ((xs == nullptr) != (G == 0)) return GCRNN_ERR_BAD_SHAPE;
   if (B <= 0 || T <= 0 || N <= 0 || N > NP || B * T > (1 << 24) || entries < 0 || entries % 4) return GCRNN_ERR_BAD_SHAPE;
-  const FusedGraphArgs ga{tile_nodes, tile_off, ell_col, ell_val, ell_val4, ell_col4, entries, (float)uniform_w};
+  const FusedGraphArgs ga{tile_nodes, tile_off, ell_col, ell_val, ell_val4, ell_col4, entries, (float)uniform_w, img16 ? 1 : 0};
   return fused_dispatch(4, xs, zs, nullptr, wpack, bias, nullptr, nullptr, nullptr, out, ga, B, T, N, F, G, K, as_stream(stream), dpre);
 }
 
@@ -407,7 +407,7 @@ extern "C" int gcrnn_fused_node_backward_data_bf16(const void* dHs, const void* 
                                                    const void* wpackT, const int32_t* tile_nodes, const int32_t* tile_off,
                                                    const int32_t* ell_col, const float* ell_val, const void* ell_val4,
                                                    const void* ell_col4, int64_t entries, int64_t B, int64_t T, int64_t N, int64_t F,
-                                                   int64_t K, double uniform_w, const void* dHuser_inline, void* stream) {
+                                                   int64_t K, double uniform_w, const void* dHuser_inline, int img16, void* stream) {
   if (!dHs || !hs || !dpre || !dyh || !ngf || !wpackT || !tile_nodes || !tile_off || !ell_col || !ell_val) return GCRNN_ERR_NULL_POINTER;
   if (dHuser_inline && (reinterpret_cast<uintptr_t>(dHuser_inline) & 15)) return GCRNN_ERR_BAD_SHAPE;
   if (B <= 0 || T <= 0 || N <= 0 || N > NP || B > (1 << 24) || entries < 0 || entries % 4 || F % 2) return GCRNN_ERR_BAD_SHAPE;
@@ -418,7 +418,7 @@ extern "C" int gcrnn_fused_node_backward_data_bf16(const void* dHs, const void* 
   scale_rows_kernel<<<(unsigned)cdiv(step / 2, 256), 256, 0, as_stream(stream)>>>(
       (const uint16_t*)dpre + (T - 1) * step, ngf + (T - 1) * B * N, (uint16_t*)dyh + (T - 1) * step, B, (int)N, NP, (int)F);
   GCRNN_CHECK_LAUNCH();
-  const FusedGraphArgs ga{tile_nodes, tile_off, ell_col, ell_val, ell_val4, ell_col4, entries, (float)uniform_w};
+  const FusedGraphArgs ga{tile_nodes, tile_off, ell_col, ell_val, ell_val4, ell_col4, entries, (float)uniform_w, img16 ? 1 : 0};
   return fused_dispatch(7, dyh, nullptr, dpre, wpackT, nullptr, nullptr, nullptr, ngf, nullptr, ga, B, T, N, F, 0, K, as_stream(stream), dHs, hs,
                         nullptr, nullptr, dHuser_inline);
 }
@@ -433,11 +433,11 @@ extern "C" int gcrnn_fused_backward_step_bf16(const void* operand, const void* d
                                               const void* wpackT, const int32_t* tile_nodes, const int32_t* tile_off,
                                               const int32_t* ell_col, const float* ell_val, const void* ell_val4, const void* ell_col4,
                                               int64_t entries, int64_t B, int64_t N, int64_t F, int64_t K, double uniform_w,
-                                              const void* dHuser_next, void* dHs_next, int64_t T, void* stream) {
+                                              const void* dHuser_next, void* dHs_next, int64_t T, int img16, void* stream) {
   if (!operand || !dH_prev || !h_prev || !dpre_prev || !wpackT || !tile_nodes || !tile_off || !ell_col || !ell_val) return GCRNN_ERR_NULL_POINTER;
   if (B <= 0 || N <= 0 || N > NP || B > (1 << 24) || entries < 0 || entries % 4) return GCRNN_ERR_BAD_SHAPE;
   if ((dHuser_next == nullptr) != (dHs_next == nullptr) || (dHuser_next && (T <= 0 || (reinterpret_cast<uintptr_t>(dHuser_next) & 15)))) return GCRNN_ERR_BAD_SHAPE;
-  const FusedGraphArgs ga{tile_nodes, tile_off, ell_col, ell_val, ell_val4, ell_col4, entries, (float)uniform_w};
+  const FusedGraphArgs ga{tile_nodes, tile_off, ell_col, ell_val, ell_val4, ell_col4, entries, (float)uniform_w, img16 ? 1 : 0};
   return fused_dispatch(8, dHuser_next, operand, dpre_prev, wpackT, nullptr, nullptr, nullptr, nullptr, nullptr, ga, B, dHuser_next ? T : 1, N, F, 0, K,
                         as_stream(stream), dH_prev, h_prev, dHs_next);
 }

@@ -1063,7 +1063,7 @@ int fused_launch_t(int mode /*0 plain, 1 gated, 2 gate pre-pass, 3 BPTT data gra
                        T * (inline_bw ? F : G) * N <= 2147483647LL))
     return GCRNN_ERR_UNSUPPORTED;
   const size_t lds = (resident ? resident_bytes : base) + (inline_pack ? xtile_bytes : 0);
-  if (ga.img16 && !((mode == 0 || mode == 1 || mode == 2 || mode == 3 || mode == 5 || mode == 6) && uni && resident)) return GCRNN_ERR_UNSUPPORTED;      // the bf16-image plan: forward steps (un-gated / time-gated, with or without the fused head), gate pre-pass, BPTT data chain
+  if (ga.img16 && !(uni && resident)) return GCRNN_ERR_UNSUPPORTED;      // the bf16-image plan needs the uniform-weight asm stream on the LDS-resident graph (every mode has its UNI == 2 instantiation)
   fused_kern_t kern;
   const bool head = (mode == 0 || mode == 1) && gate_w != nullptr;      // fused output head: EPI 6 instantiations
   if (head) {
@@ -1091,7 +1091,7 @@ int fused_launch_t(int mode /*0 plain, 1 gated, 2 gate pre-pass, 3 BPTT data gra
 #if GCRNN_HOP_ASM && GCRNN_STEP_WAVES == 8
   else if (mode == 5 && uni && resident && ga.img16) kern = (fused_kern_t)fused_step_kernel<K, HS, XS, false, true, 4, 2>;
   else if (mode == 5 && uni && resident) kern = (fused_kern_t)fused_step_kernel<K, HS, XS, false, true, 4, 1>;
-  else if (mode == 3 && uni && resident && ga.img16) {
+  else if ((mode == 3 || mode == 7 || mode == 8) && uni && resident && ga.img16) {
     if constexpr (XS == 0) kern = (fused_kern_t)fused_step_kernel<K, HS, XS, false, true, 2, 2>;
     else return GCRNN_ERR_UNSUPPORTED;
   }
@@ -1101,6 +1101,7 @@ int fused_launch_t(int mode /*0 plain, 1 gated, 2 gate pre-pass, 3 BPTT data gra
     else return GCRNN_ERR_UNSUPPORTED;
   }
   else if (mode == 2 && uni && resident) kern = (fused_kern_t)fused_step_kernel<K, HS, XS, false, true, 1, 1>;
+  else if (mode == 4 && uni && resident && ga.img16) kern = (fused_kern_t)fused_step_kernel<K, HS, XS, false, true, 3, 2>;
   else if (mode == 4 && uni && resident) kern = (fused_kern_t)fused_step_kernel<K, HS, XS, false, true, 3, 1>;
 #endif
   else if (mode == 5) kern = resident ? (fused_kern_t)fused_step_kernel<K, HS, XS, false, true, 4> : (fused_kern_t)fused_step_kernel<K, HS, XS, false, false, 4>;

@@ -9,7 +9,7 @@
 #include <vector>
 #include "../../include/gcrnn.h"
 
-extern "C" int gcrnn_version(void) { return 115; }  // 0.1.15
+extern "C" int gcrnn_version(void) { return 116; }  // 0.1.16
 
 extern "C" const char* gcrnn_status_string(int status) {
   switch (status) {

@@ -805,10 +805,11 @@ class _FusedNodeCell(torch.autograd.Function):
         wBt = wBk[:, 0].permute(2, 1, 0).contiguous().unsqueeze(1)                      # transposed taps [F_in][1][K][F_out]
         wpT = _fused_pack_state_taps(wBt, K, st)
         aplan = graph.fused_plan(adjoint=True)
+        aplan16 = None if os.environ.get('GCRNN_NO_IMG16') else graph.fused_plan_img16(adjoint=True)
         dpre = torch.empty((T, B, npad, F), dtype=torch.bfloat16, device=X.device)
         dyh = torch.empty_like(dpre)
-        check(lib.gcrnn_fused_node_backward_data_bf16(_p(dHs), _p(hs), _p(dpre), _p(dyh), _p(ngf), _p(wpT), *_fused_graph_args(aplan),
-                                                      B, T, N, F, K, aplan.get('uniform_w', 0.0), _p(dHu), st), 'fused_node_backward_data')
+        check(lib.gcrnn_fused_node_backward_data_bf16(_p(dHs), _p(hs), _p(dpre), _p(dyh), _p(ngf), _p(wpT), *_fused_graph_args(aplan16 or aplan),
+                                                      B, T, N, F, K, aplan.get('uniform_w', 0.0), _p(dHu), 1 if aplan16 else 0, st), 'fused_node_backward_data')
         dyx = torch.empty_like(dpre)
         dni = torch.empty((T, B, N), dtype=torch.float32, device=X.device)
         dnf = torch.empty_like(dni)
@@ -1024,7 +1025,8 @@ class _FusedEdgeCell(torch.autograd.Function):
         wBt = wBk[:, 0].permute(2, 1, 0).contiguous().unsqueeze(1)                  # transposed composite taps [F_in][1][K][F_out]
         wpT = _fused_pack_state_taps(wBt, K, st)
         aplan = graph.fused_plan(adjoint=True)
-        aga = _fused_graph_args(aplan)
+        aplan16 = None if os.environ.get('GCRNN_NO_IMG16') else graph.fused_plan_img16(adjoint=True)
+        aga = _fused_graph_args(aplan16 or aplan)
         auw = aplan.get('uniform_w', 0.0)
         nnz = graph.edge_plan()['nnz']
         tchunk = max(1, min(T, (1 << 26) // max(1, B * nnz)))                       # <= 256 MiB of per-edge scratch
@@ -1041,7 +1043,8 @@ class _FusedEdgeCell(torch.autograd.Function):
             if t > 0:
                 nxt = dHu is not None and t >= 2
                 check(lib.gcrnn_fused_backward_step_bf16(_p(dzh[t]), _p(dHs[t - 1]), _p(hs[t - 1]), _p(dpre[t - 1]), _p(wpT), *aga,
-                                                         B, N, F, K, auw, _p(dHu[:, t - 2]) if nxt else None, _p(dHs[t - 2]) if nxt else None, T, st),
+                                                         B, N, F, K, auw, _p(dHu[:, t - 2]) if nxt else None, _p(dHs[t - 2]) if nxt else None, T,
+                                                         1 if aplan16 else 0, st),
                       'fused_backward_step')
         dzx = torch.empty_like(dpre)
         da_i = torch.empty((T, B, 2, F), dtype=torch.float32, device=dev)
@@ -1257,13 +1260,14 @@ def fused_gate_grad(zs, dpre, w, bias, graph, K):
     T, B, npad, F = dpre.shape
     Cin = w.shape[3]
     plan = graph.fused_plan()
+    plan16 = fused_img16_plan(graph, True, None)
     st = _stream()
     b32 = bias.detach().float().contiguous().view(-1) if bias is not None else None
     parts = torch.empty((T * B, (F // 16) * int(lib.gcrnn_fused_step_waves())), dtype=torch.float32, device=dpre.device)
     if Cin == F:
         wp = _fused_pack_state_taps(w, K, st)
-        check(lib.gcrnn_fused_gate_grad_bf16(_p(zs), None, _p(dpre), _p(wp), _p(b32), _p(parts), *_fused_graph_args(plan),
-                                             B, T, graph.N, F, 0, K, plan.get('uniform_w', 0.0), st), 'fused_gate_grad')
+        check(lib.gcrnn_fused_gate_grad_bf16(_p(zs), None, _p(dpre), _p(wp), _p(b32), _p(parts), *_fused_graph_args(plan16 or plan),
+                                             B, T, graph.N, F, 0, K, plan.get('uniform_w', 0.0), 1 if plan16 else 0, st), 'fused_gate_grad')
     else:
         wd = w.detach()
         wz = wd.new_zeros((F, 1, K, F))
@@ -1271,8 +1275,8 @@ def fused_gate_grad(zs, dpre, w, bias, graph, K):
             wd = torch.cat([wd, wd.new_zeros(F, 1, K - wd.shape[2], Cin)], dim=2)
         wp = _fused_pack_weights(wd, wz, st)
         zero_h = torch.zeros((1, npad, F), dtype=torch.bfloat16, device=dpre.device)
-        check(lib.gcrnn_fused_gate_grad_bf16(_p(zero_h), _p(zs), _p(dpre), _p(wp), _p(b32), _p(parts), *_fused_graph_args(plan),
-                                             B, T, graph.N, F, Cin, K, plan.get('uniform_w', 0.0), st), 'fused_gate_grad')
+        check(lib.gcrnn_fused_gate_grad_bf16(_p(zero_h), _p(zs), _p(dpre), _p(wp), _p(b32), _p(parts), *_fused_graph_args(plan16 or plan),
+                                             B, T, graph.N, F, Cin, K, plan.get('uniform_w', 0.0), 1 if plan16 else 0, st), 'fused_gate_grad')
     return parts.sum(dim=1).view(T, B)
 
 

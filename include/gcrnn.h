@@ -166,7 +166,7 @@ int gcrnn_fused_node_backward_data_bf16(const void* dHs, const void* hs, void* d
                                         const int32_t* tile_nodes, const int32_t* tile_off, const int32_t* ell_col,
                                         const float* ell_val, const void* ell_val4, const void* ell_col4, int64_t entries, int64_t B,
                                         int64_t T, int64_t N, int64_t F, int64_t K, double uniform_w,
-                                        const void* dHuser_inline /* as in gcrnn_fused_backward_data_bf16 */, void* stream);
+                                        const void* dHuser_inline /* as in gcrnn_fused_backward_data_bf16 */, int img16 /* likewise */, void* stream);
 int gcrnn_node_cell_backward(const void* dpre, const void* yx, const void* yh, const float* ngates, const float* gi, const float* gf,
                              void* dyx, float* dni, float* dnf, float* dgi, float* dgf, int64_t B, int64_t T, int64_t N,
                              int64_t NPad, int64_t F, void* stream);
@@ -214,7 +214,8 @@ int gcrnn_fused_backward_step_bf16(const void* operand, const void* dH_prev, con
                                    const void* ell_val4, const void* ell_col4, int64_t entries, int64_t B, int64_t N, int64_t F,
                                    int64_t K, double uniform_w,
                                    const void* dHuser_next /* NULL, or the user-layout block dH[0][t-2] ... */, void* dHs_next /* ... laid out into dHs[t-2] */,
-                                   int64_t T /* sequence length (item stride T F N of the user-layout tensor) */, void* stream);
+                                   int64_t T /* sequence length (item stride T F N of the user-layout tensor) */,
+                                   int img16 /* as in gcrnn_fused_backward_data_bf16 */, void* stream);
 int gcrnn_fused_backward_seed_bf16(const void* dH, const void* h, void* dpre, int64_t elements, void* stream);
 
 /* ==== fp32-accurate fused path ("x3": three bf16 planes per fp32 operand, six partial products on the bf16 matrix cores) ========
@@ -348,7 +349,8 @@ int gcrnn_fused_gate_prepass_bf16(const void* xs, const void* h0, const void* wp
 int gcrnn_fused_gate_grad_bf16(const void* zs, const void* xs, const void* dpre, const void* wpack, const float* bias, float* out,
                                const int32_t* tile_nodes, const int32_t* tile_off, const int32_t* ell_col, const float* ell_val,
                                const void* ell_val4, const void* ell_col4, int64_t entries, int64_t B, int64_t T, int64_t N,
-                               int64_t F, int64_t G, int64_t K, double uniform_w /* as in gcrnn_fused_forward_bf16 */, void* stream);
+                               int64_t F, int64_t G, int64_t K, double uniform_w /* as in gcrnn_fused_forward_bf16 */,
+                               int img16 /* as in gcrnn_fused_backward_data_bf16 (forward plan) */, void* stream);
 
 /* BPTT through a time gate's read-out gate = sigmoid(w . vec(c) + c0) (graphML.py:2364-2366), one pass, in place:
  *   cs [items][NPad][F] bf16: on entry the gate cell's states c (gcrnn_fused_gate_prepass_bf16), on return
