@@ -220,59 +220,76 @@ def gen_uniform():
 # Operands: %0..%15 accumulator halves, %16..%23 tile ends, %24 first group, %25 last valid group (SGPR), %26 column base + 8 r,
 # (+ 4 (q >> 1): a lane reads only its own dword), %27 = (q & 1) << 4, %28 = {w, w}, %29 = the lane's A operand (4 VGPRs).
 # Clobbers v[194:253], s[88:90], scc.
+VD = int(os.environ.get('GCRNN_HOP16_DEPTH', '3'))      # groups in flight (register sets): 3 = as the fp32 streams; the two 16-byte gathers of a
+# set leave room for 5 sets inside v[194:253] -- the trips are short now, so the LDS latency needs more of them in flight
+
+
 def VX(p, e):
-    b = UB + 16 * p + 4 * e
+    b = UB + 8 * p + 4 * e
     return 'v[%d:%d]' % (b, b + 3)
 
 
-VSEL = 'v%d' % (UB + 55)
+def VXa(p, e):
+    return 'v%d' % (UB + 8 * p + 4 * e)
+
+
+def VC(p):
+    return 'v%d' % (UB + 40 + p)
+
+
+VCA = 'v%d' % (UB + 46)
+VSUMB = [UB + 56]                                                 # the D accumulator (4 VGPRs)
+VSUM4 = ['v[%d:%d]' % (b_, b_ + 3) for b_ in VSUMB]
+VSUMH = [['v[%d:%d]' % (b_, b_ + 1), 'v[%d:%d]' % (b_ + 2, b_ + 3)] for b_ in VSUMB]
 
 
 def vs1(q, lines):
     for e in range(2):
         lines.append('v_xor_b32_sdwa %s, %s, %s dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_%d src1_sel:DWORD'
-                     % (UXa(q, e), UCw(q, 0), UQX, e))
+                     % (VXa(q, e), VC(q), UQX, e))
     for e in range(2):
-        lines.append('ds_read_b128 %s, %s' % (VX(q, e), UXa(q, e)))
+        lines.append('ds_read_b128 %s, %s' % (VX(q, e), VXa(q, e)))
 
 
 def vs0(q, goff, lines):      # the lane's OWN column dword of group g + goff (column base operand = base + 8 r + 4 (q >> 1))
     lines += ['s_add_i32 %s, %s, %d' % (ST, SG, goff), 's_min_i32 %s, %s, %s' % (ST, ST, GLAST),
-              'v_lshl_add_u32 %s, %s, 7, %s' % (UCA, ST, COLB), 'ds_read_b32 %s, %s' % (UCw(q, 0), UCA)]
+              'v_lshl_add_u32 %s, %s, 7, %s' % (VCA, ST, COLB), 'ds_read_b32 %s, %s' % (VC(q), VCA)]
 
 
 def gen_uniform16():
+    D = VD
+    assert 2 <= D <= 5
     L = ['s_mov_b32 %s, %s' % (SG, GBEG)]
     for r in range(4):
-        L.append('v_mov_b32 v%d, 0' % (UB + 56 + r))
-    for p in range(3):
+        L.append('v_mov_b32 v%d, 0' % (VSUMB[0] + r))
+    for p in range(D):
         vs0(p, p, L)
     L.append('s_waitcnt lgkmcnt(0)')
-    vs1(0, L); vs0(0, 3, L)
-    vs1(1, L); vs0(1, 4, L)
+    for p in range(D - 1):                    # gathers of groups 0 .. D-2; their column slots take groups D .. 2D-2
+        vs1(p, L); vs0(p, D + p, L)
     for t in range(NT):
-        for p in range(3):
+        for p in range(D):
             L.append('L_T%d_P%d_%%=:' % (t, p))
             L.append('s_cmp_ge_i32 %s, %%%d' % (SG, 16 + t))
             L.append('s_cbranch_scc1 L_X%d_P%d_%%=' % (t, p))
-            q = (p + 2) % 3
+            q = (p + D - 1) % D
             vs1(q, L)                                             # (the set's registers were B operands of the PREVIOUS trip's MFMAs: read long ago)
-            vs0(q, 5, L)
-            L.append('s_waitcnt lgkmcnt(6)')
-            for e in range(2):
-                L.append('v_mfma_f32_16x16x32_bf16 %s, %%29, %s, %s' % (USUM4, VX(p, e), USUM4))
+            vs0(q, 2 * D - 1, L)
+            L.append('s_waitcnt lgkmcnt(%d)' % (3 * (D - 1)))
+            for e in range(2):                                    # one accumulator (two, so that an MFMA never waits for its predecessor: slower, the exits pay more)
+                L.append('v_mfma_f32_16x16x32_bf16 %s, %%29, %s, %s' % (VSUM4[0], VX(p, e), VSUM4[0]))
             L.append('s_add_i32 %s, %s, 1' % (SG, SG))
         L.append('s_branch L_T%d_P0_%%=' % t)
-        for p in range(3):                    # leaving tile t in phase p: acc_t += w * sum, sum = 0
+        for p in range(D):                    # leaving tile t in phase p: acc_t += w * (sum_0 + sum_1), sums = 0
             L.append('L_X%d_P%d_%%=:' % (t, p))
             L += ['s_nop 11']                                     # matrix-core result (8 passes) -> VALU read: 11 wait states
-            L.append('v_pk_fma_f32 %%%d, %s, %s, %%%d' % (2 * t, UWP, USUM[0], 2 * t))
-            L.append('v_pk_fma_f32 %%%d, %s, %s, %%%d' % (2 * t + 1, UWP, USUM[1], 2 * t + 1))
+            L.append('v_pk_fma_f32 %%%d, %s, %s, %%%d' % (2 * t, UWP, VSUMH[0][0], 2 * t))
+            L.append('v_pk_fma_f32 %%%d, %s, %s, %%%d' % (2 * t + 1, UWP, VSUMH[0][1], 2 * t + 1))
             for r in range(4):
-                L.append('v_mov_b32 v%d, 0' % (UB + 56 + r))
+                L.append('v_mov_b32 v%d, 0' % (VSUMB[0] + r))
             L.append('s_nop 1')                                   # VALU write -> matrix-core read of the accumulator
             L.append('s_branch L_T%d_P%d_%%=' % (t + 1, p))
-    for p in range(3):
+    for p in range(D):
         L.append('L_T%d_P%d_%%=:' % (NT, p))
     L.append('s_waitcnt lgkmcnt(0)')
     return L
