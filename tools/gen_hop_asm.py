@@ -238,6 +238,7 @@ def VC(p):
 
 
 VCA = 'v%d' % (UB + 46)
+VP5, VPCL = 'v%d' % (UB + 44), 'v%d' % (UB + 45)                   # running column pointer of group g + 2 D - 1, and its clamp (last valid group)
 VSUMB = [UB + 56]                                                 # the D accumulator (4 VGPRs)
 VSUM4 = ['v[%d:%d]' % (b_, b_ + 3) for b_ in VSUMB]
 VSUMH = [['v[%d:%d]' % (b_, b_ + 1), 'v[%d:%d]' % (b_ + 2, b_ + 3)] for b_ in VSUMB]
@@ -256,6 +257,10 @@ def vs0(q, goff, lines):      # the lane's OWN column dword of group g + goff (c
               'v_lshl_add_u32 %s, %s, 7, %s' % (VCA, ST, COLB), 'ds_read_b32 %s, %s' % (VC(q), VCA)]
 
 
+def vs0p(q, lines):            # steady state: the same read through the running pointer -- no scalar arithmetic in the trip
+    lines += ['v_min_u32 %s, %s, %s' % (VCA, VP5, VPCL), 'ds_read_b32 %s, %s' % (VC(q), VCA), 'v_add_u32 %s, 128, %s' % (VP5, VP5)]
+
+
 def gen_uniform16():
     D = VD
     assert 2 <= D <= 5
@@ -267,6 +272,8 @@ def gen_uniform16():
     L.append('s_waitcnt lgkmcnt(0)')
     for p in range(D - 1):                    # gathers of groups 0 .. D-2; their column slots take groups D .. 2D-2
         vs1(p, L); vs0(p, D + p, L)
+    L += ['s_add_i32 %s, %s, %d' % (ST, SG, 2 * D - 1), 'v_lshl_add_u32 %s, %s, 7, %s' % (VP5, ST, COLB),
+          'v_lshl_add_u32 %s, %s, 7, %s' % (VPCL, GLAST, COLB)]
     for t in range(NT):
         for p in range(D):
             L.append('L_T%d_P%d_%%=:' % (t, p))
@@ -274,7 +281,7 @@ def gen_uniform16():
             L.append('s_cbranch_scc1 L_X%d_P%d_%%=' % (t, p))
             q = (p + D - 1) % D
             vs1(q, L)                                             # (the set's registers were B operands of the PREVIOUS trip's MFMAs: read long ago)
-            vs0(q, 2 * D - 1, L)
+            vs0p(q, L)
             L.append('s_waitcnt lgkmcnt(%d)' % (3 * (D - 1)))
             for e in range(2):                                    # one accumulator (two, so that an MFMA never waits for its predecessor: slower, the exits pay more)
                 L.append('v_mfma_f32_16x16x32_bf16 %s, %%29, %s, %s' % (VSUM4[0], VX(p, e), VSUM4[0]))
