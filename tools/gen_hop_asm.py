@@ -264,6 +264,7 @@ def vs0p(q, lines):            # steady state: the same read through the running
 def gen_uniform16():
     D = VD
     assert 2 <= D <= 5
+    SC = 's90'                                # (group - tile end) of the current tile, counted up: the carry of its increment ends the tile
     L = ['s_mov_b32 %s, %s' % (SG, GBEG)]
     for r in range(4):
         L.append('v_mov_b32 v%d, 0' % (VSUMB[0] + r))
@@ -273,11 +274,11 @@ def gen_uniform16():
     for p in range(D - 1):                    # gathers of groups 0 .. D-2; their column slots take groups D .. 2D-2
         vs1(p, L); vs0(p, D + p, L)
     L += ['s_add_i32 %s, %s, %d' % (ST, SG, 2 * D - 1), 'v_lshl_add_u32 %s, %s, 7, %s' % (VP5, ST, COLB),
-          'v_lshl_add_u32 %s, %s, 7, %s' % (VPCL, GLAST, COLB)]
+          'v_lshl_add_u32 %s, %s, 7, %s' % (VPCL, GLAST, COLB),
+          's_sub_u32 %s, %s, %%16' % (SC, GBEG), 's_cmp_eq_u32 %s, 0' % SC]
     for t in range(NT):
         for p in range(D):
             L.append('L_T%d_P%d_%%=:' % (t, p))
-            L.append('s_cmp_ge_i32 %s, %%%d' % (SG, 16 + t))
             L.append('s_cbranch_scc1 L_X%d_P%d_%%=' % (t, p))
             q = (p + D - 1) % D
             vs1(q, L)                                             # (the set's registers were B operands of the PREVIOUS trip's MFMAs: read long ago)
@@ -285,15 +286,17 @@ def gen_uniform16():
             L.append('s_waitcnt lgkmcnt(%d)' % (3 * (D - 1)))
             for e in range(2):                                    # one accumulator (two, so that an MFMA never waits for its predecessor: slower, the exits pay more)
                 L.append('v_mfma_f32_16x16x32_bf16 %s, %%29, %s, %s' % (VSUM4[0], VX(p, e), VSUM4[0]))
-            L.append('s_add_i32 %s, %s, 1' % (SG, SG))
+            L.append('s_add_u32 %s, %s, 1' % (SC, SC))            # SCC = carry = this was the tile's last group
         L.append('s_branch L_T%d_P0_%%=' % t)
-        for p in range(D):                    # leaving tile t in phase p: acc_t += w * (sum_0 + sum_1), sums = 0
+        for p in range(D):                    # leaving tile t in phase p: acc_t += w * sum, sum = 0
             L.append('L_X%d_P%d_%%=:' % (t, p))
             L += ['s_nop 11']                                     # matrix-core result (8 passes) -> VALU read: 11 wait states
             L.append('v_pk_fma_f32 %%%d, %s, %s, %%%d' % (2 * t, UWP, VSUMH[0][0], 2 * t))
             L.append('v_pk_fma_f32 %%%d, %s, %s, %%%d' % (2 * t + 1, UWP, VSUMH[0][1], 2 * t + 1))
             for r in range(4):
                 L.append('v_mov_b32 v%d, 0' % (VSUMB[0] + r))
+            if t + 1 < NT:                                        # the next tile runs from this tile's end to its own
+                L += ['s_sub_u32 %s, %%%d, %%%d' % (SC, 16 + t, 16 + t + 1), 's_cmp_eq_u32 %s, 0' % SC]
             L.append('s_nop 1')                                   # VALU write -> matrix-core read of the accumulator
             L.append('s_branch L_T%d_P%d_%%=' % (t + 1, p))
     for p in range(D):
