@@ -1467,3 +1467,45 @@ def test_bf16_hop_image_with_matrix_core_sums_against_oracle_and_fp32_image(N, F
     for n in g16:
         sc = np.abs(g32[n]).max()
         assert sc > 0 and np.abs(g16[n] - g32[n]).max() <= 3e-2 * sc, (n, np.abs(g16[n] - g32[n]).max() / sc)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('N,F,K,tg,hub', [(200, 32, 5, False, 90), (1008, 64, 2, True, 0), (496, 64, 4, False, 150), (1000, 32, 3, True, 60),
+                                          (136, 64, 5, False, 0)])
+def test_bf16_hop_image_on_hub_graphs_small_graphs_and_sixteen_padding_rows(N, F, K, tg, hub, monkeypatch):
+    """The matrix-core hop stream at the edges of its domain: a hub row / column of degree `hub` (deep first tile, every other tile
+    shallow), few nodes (most of the image is padding rows), exactly 16 padding rows (N = 1008: the zero rows of the 16 gather keys
+    are all the padding there is), time gates (gate pre-pass + gated steps). Against the fp64 oracle and the fp32-image kernels."""
+    import gated_gcrnns_amd.Utils.graphML as gml
+    from gated_gcrnns_amd import ops
+    dev = torch.device('cuda:0')
+    rng = np.random.default_rng(1000 + N + hub)
+    W = (rng.random((N, N)) < 8.0 / N).astype(np.float64)
+    W = np.triu(W, 1)
+    if hub:
+        W[0, rng.choice(np.arange(1, N), size=min(hub, N - 1), replace=False)] = 1.0
+    W = W + W.T
+    S = (W / np.max(np.abs(np.linalg.eigvalsh(W)))).reshape(1, N, N)
+    B, T = 3, 4
+    X = bf16_round(rng.standard_normal((B, T, F, N)))
+    h0 = bf16_round(0.4 * rng.standard_normal((B, F, N)))
+    torch.manual_seed(9)
+    cell = gml.GGCRNNCell(F, F, K, K, torch.tanh, tg, None, 1, True)
+    cell.addGSO(torch.tensor(S))
+    params = {k: bf16_round(v.detach().numpy()) for k, v in cell.state_dict().items()}
+    ref = orc.ggcrnn_cell(params, S.astype(np.float32).astype(np.float64), X, h0, tg, None)
+    cell = cell.to(dev).to(torch.bfloat16)
+    Xd = torch.tensor(X, dtype=torch.bfloat16, device=dev)
+    hd = torch.tensor(h0, dtype=torch.bfloat16, device=dev)
+    p16 = cell.graph.fused_plan_img16()
+    assert p16 is not None and ops.fused_img16_plan(cell.graph, tg, None) is p16
+    with torch.no_grad():
+        assert cell._use_fused(Xd, hd)
+        H16 = cell(Xd, hd).double().cpu().numpy()
+    monkeypatch.setenv('GCRNN_NO_IMG16', '1')
+    with torch.no_grad():
+        H32 = cell(Xd, hd).double().cpu().numpy()
+    e16, e32 = np.abs(H16 - ref), np.abs(H32 - ref)
+    assert e16.max() <= 3e-2 and e16.mean() <= 2e-3, (e16.max(), e16.mean())
+    assert e16.mean() <= 1.5 * e32.mean() + 1e-5, (e16.mean(), e32.mean())
+    assert np.abs(H16 - H32).max() <= 1.6e-2
