@@ -276,9 +276,11 @@ def gen_uniform16():
     L += ['s_add_i32 %s, %s, %d' % (ST, SG, 2 * D - 1), 'v_lshl_add_u32 %s, %s, 7, %s' % (VP5, ST, COLB),
           'v_lshl_add_u32 %s, %s, 7, %s' % (VPCL, GLAST, COLB),
           's_sub_u32 %s, %s, %%16' % (SC, GBEG), 's_cmp_eq_u32 %s, 0' % SC]
+    R = int(os.environ.get('GCRNN_HOP16_UNROLL', '2'))           # the D phases are laid out R times before the loop branches back
     for t in range(NT):
-        for p in range(D):
-            L.append('L_T%d_P%d_%%=:' % (t, p))
+        for pp in range(D * R):
+            p = pp % D
+            L.append('L_T%d_P%d_%%=:' % (t, pp))
             L.append('s_cbranch_scc1 L_X%d_P%d_%%=' % (t, p))
             q = (p + D - 1) % D
             vs1(q, L)                                             # (the set's registers were B operands of the PREVIOUS trip's MFMAs: read long ago)
