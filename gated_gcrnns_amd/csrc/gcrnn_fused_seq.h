@@ -1,0 +1,466 @@
+// Sequence-resident fused GCRNN recurrence for gfx950 (round 3): ONE workgroup owns a WHOLE sequence -- for every time step.
+//
+// The chunk-parallel step kernel (gcrnn_fused_step.h) gives every 16-feature output chunk of a sequence its own workgroup, and each
+// of them pulls the complete operand [h_{t-1} | x_t] of the sequence (256 KB at F = G = 64) through its CU's L2 path: 4x redundant,
+// 268 MB per launch at B = 256, the "operand transfer" third of that launch. It has to: its taps u_0..u_{K-2} live in
+// registers in fp32 (128 VGPRs per lane), which leaves no room to keep the operand.
+// Here the registers hold the OPERAND instead of the taps: 8 node tiles x (F+G)/32 k-steps x 16 bytes per lane = the same 128
+// VGPRs, but they serve all F/16 chunks. The workgroup walks the chunks one after the other; for chunk c the tap a hop needs is
+// evaluated from the resident operand right before that hop (u_k = W_k(c) [h|x]^T on the matrix cores, the SAME 32 MFMAs per tap
+// and wave, only later), so per chunk only one tap (32 VGPRs) is live. The operand crosses L2 -> CU once per sequence and step:
+// the compulsory 256 KB. Arithmetic and its order are those of the chunk-parallel kernel (tap chains over k-steps, hop sums on
+// the matrix cores over the bf16 image, fp32 accumulators, bias / tanh / bf16 epilogue): results are bit-identical (tested).
+//
+// Uniform-weight graphs on the bf16 hop image only (UNI == 2 in the step kernel's terms: GCRNN_HOP_ASM_UNI16_STREAM and the
+// plan arrays of graph.fused_plan(img16=True)); other graphs keep the chunk-parallel kernel.
+// LDS: hop image / transposed output tile 33 KB | weight fragments of the current and the next chunk 2 x K*KS KB (the next
+// chunk's arrive by LDS-DMA while the last hop runs) | column words 32 B x entries | inline-pack tile (G or F) x 256 x 2 B.
+//
+// Persistent over time: a sequence's steps depend on nothing but that sequence, so ONE launch runs all T steps (the BPTT chain: all
+// T-1) -- the workgroup stores h_t, waits for its own stores (s_waitcnt vmcnt(0) + barrier: same CU, same L1) and reads it back as the
+// next step's operand. Graph image and tile tables are staged once per launch instead of once per step, there are no launch
+// boundaries inside a forward, and the hipGraph of the T-loop is a single kernel node.
+//
+// MODE 0: forward step   h_t = tanh(sum_k S^k([h|x] W_k) + 2b)            (reference Utils/graphML.py:2420-2423)
+// MODE 2: BPTT data step dpre_{t-1} = (gsc * sum_k S^k(dpre_t W_k^T) + dH_{t-1}) (1 - h_{t-1}^2)   (autograd of the same lines)
+#pragma once
+
+// In-kernel phase stamps (diagnostic builds only, -DGCRNN_SEQ_STAMPS; tools/seq_stamps.py): wave 0 of every workgroup records
+// s_memtime at its phase boundaries into a buffer of its own that no other code reads (MI355X_MICROARCH.md, DVFS item 6).
+#if defined(GCRNN_SEQ_STAMPS) && defined(GCRNN_SEQ_STAMPS_READER)      // (the K = 5 translation unit only)
+static __device__ unsigned long long gcrnn_seq_stamps[256 * 64];      // one copy per translation unit; the K = 5 unit exports the reader
+// (staged in the 512 spare bytes behind the transposed output tile -- an LDS address needs no scalar registers -- and copied out at the end)
+#define GCRNN_STAMP(slot)                                                                                     \
+  do {                                                                                                        \
+    if (tid == 0) *reinterpret_cast<volatile unsigned long long*>(smem + 33280 + 8 * (slot)) = __builtin_amdgcn_s_memtime(); \
+  } while (0)
+#define GCRNN_STAMP_FLUSH()                                                                                   \
+  do {                                                                                                        \
+    __syncthreads();                                                                                          \
+    if (tid < 64 && blockIdx.x < 256) gcrnn_seq_stamps[blockIdx.x * 64 + tid] = *reinterpret_cast<volatile unsigned long long*>(smem + 33280 + 8 * tid); \
+  } while (0)
+#if 1
+extern "C" int gcrnn_debug_read_seq_stamps(void* host) {
+  return hipMemcpyFromSymbol(host, HIP_SYMBOL(gcrnn_seq_stamps), sizeof(unsigned long long) * 256 * 64) == hipSuccess ? 0 : 1;
+}
+#endif
+#else
+#define GCRNN_STAMP(slot) do {} while (0)
+#define GCRNN_STAMP_FLUSH() do {} while (0)
+#endif
+
+struct SeqArgs {
+  const uint16_t* x0; int64_t xstride;                 // MODE 0: x of step 0 [B][NP][G] bf16, elements between steps
+  const uint16_t* hfirst; const uint16_t* hrest; int64_t hstride;   // operand h_{t-1} (MODE 2: dpre_t): step 0 = hfirst, step i > 0 = hrest + (i - 1) hstride
+  uint16_t* out0; int64_t ostride;                     // output of step 0 [B][NP][F] (or null), elements between steps
+  const uint4* wpack;                                  // [F/16][K][KS][64] x 16 B
+  const float* bias;                                   // [F] or null
+  const float* gf0; int64_t gfstride;                  // MODE 2: forget gates [B] of the step back-propagated, or null
+  const int32_t* tile_nodes; const int32_t* tile_off; const uint2* ell_col4;      // bf16-image plan
+  float* go0; int64_t gostride;                        // MODE 2 (or null): [B][F/16 * 8] partials of <h_{t-1}, adjoint chain of dpre_t>
+  const uint16_t* a0; int64_t a0stride;                // MODE 2: upstream gradient dH_{t-1} [B][NP][F] (or null)
+  const uint16_t* a1; int64_t a1stride;                // MODE 2: state h_{t-1} (or null); MODE 0: user-layout output H[0][t] (or null)
+  int a1_last_only;                                    // MODE 0: only the last step writes the user-layout output (at a1 itself)
+  int ubstride;                                        // MODE 0: elements between consecutive sequences of the user-layout output
+  int entries, B, N; float uni_w;
+  const uint16_t* pk_src0; int64_t pksrc_stride;       // inline pack of the NEXT step's operand: user-layout block of sequence 0 for step 0 (or null)
+  uint16_t* pk_dst0; int64_t pkdst_stride;             // ... the sequence-major array [B][NP][rows] it is laid out into
+  int pk_stride;                                       // ... elements between consecutive sequences of the user-layout tensor
+  int nsteps;                                          // steps of this launch; every step but the last lays out the next one's operand
+  int pk_all;                                          // ... != 0: the last step too (per-step launches: the host decides)
+};
+
+template <int K, int HS, int XS, int MODE>
+__global__ __launch_bounds__(STHREADS) void fused_seq_kernel(const SeqArgs a) {
+  constexpr int KS = HS + XS;
+  constexpr int F = 32 * HS, G = 32 * XS;
+  constexpr int NCH = F / FC;
+  constexpr int HT = STILES;
+  constexpr int PKROWS = (MODE == 0) ? G : F;
+  constexpr int IMG = 33 * 1024;                 // bf16 hop image [NP][16] (32 KB); the transposed output tile needs 8 x 4128 B
+  constexpr int WB = K * KS * 1024;              // one chunk's weight fragments
+  static_assert(STILES == 8 && GCRNN_HOP_ASM, "generated hop stream: 8 tiles per wave");
+  static_assert(MODE == 0 ? XS > 0 : XS == 0, "forward takes [h | x], the BPTT step its one operand");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* state = reinterpret_cast<float*>(smem);
+  const int entries = a.entries, B = a.B, N = a.N;
+  const float uni_w = a.uni_w;
+  char* xtile = smem + IMG + 2 * WB + entries * 32;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 15, q = lane >> 4;
+  if ((int)blockIdx.x >= B) return;
+  GCRNN_STAMP(0);
+
+  // once per launch: tile tables, and -- by LDS-DMA, all pieces in flight together -- the column image and chunk 0's weights
+  int tbeg[STILES], tend[STILES];
+#pragma unroll
+  for (int i = 0; i < STILES; ++i) {
+    tbeg[i] = a.tile_off[wave * STILES + i];
+    tend[i] = a.tile_off[wave * STILES + i + 1];
+  }
+  int woff[STILES];      // node << 16 | row16 << 5 | hswz << 4, xor this lane's (half, piece)
+#pragma unroll
+  for (int i = 0; i < STILES; ++i)
+    woff[i] = a.tile_nodes[(wave * STILES + i) * 16 + r] ^ (((q >> 1) << 4) | ((q & 1) << 3));
+  {
+    const int cbytes = entries * 32;
+    const char* csrc = reinterpret_cast<const char*>(a.ell_col4);
+    for (int p = wave; p * 1024 < cbytes; p += SWAVES)
+      if (p * 1024 + lane * 16 < cbytes)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(csrc + p * 1024 + lane * 16),
+                                         (__attribute__((address_space(3))) void*)(smem + IMG + 2 * WB + p * 1024), 16, 0, 0);
+    const char* wsrc = reinterpret_cast<const char*>(a.wpack);
+    for (int p = wave; p < WB / 1024; p += SWAVES)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc + p * 1024 + lane * 16),
+                                       (__attribute__((address_space(3))) void*)(smem + IMG + p * 1024), 16, 0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __syncthreads();
+
+  const uint32_t lds0 = (uint32_t)reinterpret_cast<uintptr_t>(smem);
+  if (lds0 != 0) __builtin_trap();        // the asm stream forms gather addresses from column words: the image must sit at LDS address 0
+  const uint32_t lds_col = lds0 + IMG + 2 * WB;
+
+  for (int b = blockIdx.x; b < B; b += gridDim.x) {
+#pragma unroll 1
+  for (int step = 0; step < a.nsteps; ++step) {
+    // this step's arrays (wave-uniform pointer arithmetic; descriptors in SGPRs)
+    const uint16_t* hprev = step == 0 ? a.hfirst : a.hrest + (int64_t)(step - 1) * a.hstride;
+    const uint16_t* xt = (XS > 0) ? a.x0 + (int64_t)step * a.xstride : nullptr;
+    uint16_t* hout = a.out0 ? a.out0 + (int64_t)step * a.ostride : nullptr;
+    const uint16_t* aux0 = a.a0 ? a.a0 + (int64_t)step * a.a0stride : nullptr;
+    const uint16_t* aux1 = a.a1 ? (a.a1_last_only ? (step == a.nsteps - 1 ? a.a1 : nullptr) : a.a1 + (int64_t)step * a.a1stride) : nullptr;
+    const bool pk = a.pk_src0 && (a.pk_all || step + 1 < a.nsteps);
+    const uint16_t* pk_src = pk ? a.pk_src0 + (int64_t)step * a.pksrc_stride : nullptr;
+    uint16_t* pk_dst = pk ? a.pk_dst0 + (int64_t)step * a.pkdst_stride : nullptr;
+    const int pk_stride = a.pk_stride, ubstride = a.ubstride;
+    float* gate_out = a.go0 ? a.go0 + (int64_t)step * a.gostride : nullptr;
+    const __amdgpu_buffer_rsrc_t rsrc_h = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(hprev), 0, B * (NP * F * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(xt), 0, (XS > 0 && xt) ? B * (NP * G * 2) : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_o = __builtin_amdgcn_make_buffer_rsrc(hout, 0, hout ? B * (NP * F * 2) : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_a0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(aux0), 0, (MODE == 2 && aux0) ? B * (NP * F * 2) : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_a1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(aux1), 0, (MODE == 2 && aux1) ? B * (NP * F * 2) : 0, 0x00020000);
+
+    // ---- the operand of this sequence and step: every B fragment of the wave, requested at once, resident for all chunks -------
+    bf16x8 bfr[STILES][KS];
+#pragma unroll
+    for (int i = 0; i < STILES; ++i) {
+      int w = woff[i];
+      asm volatile("" : "+v"(w));
+      const int roh = (w >> 16) * (F * 2) + 16 * q, rox = (w >> 16) * (G * 2) + 16 * q;
+#pragma unroll
+      for (int s = 0; s < HS; ++s)
+        bfr[i][s] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsrc_h, roh + 64 * s, b * (NP * F * 2), 0));
+#pragma unroll
+      for (int s = 0; s < XS; ++s)
+        bfr[i][HS + s] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, rox + 64 * s, b * (NP * G * 2), 0));
+    }
+    float gsc = 1.f;
+    if (MODE == 2 && a.gf0) gsc = a.gf0[(int64_t)step * a.gfstride + b];
+    GCRNN_STAMP(1);
+
+    f32x4 u[STILES];
+    // u_tap of chunk c for the wave's 8 tiles: one weight fragment feeds 8 independent MFMA chains
+    auto taps = [&](int tap, int c) {
+      const uint4* wl = reinterpret_cast<const uint4*>(smem + IMG + (c & 1) * WB);
+#pragma unroll
+      for (int i = 0; i < STILES; ++i) u[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        const bf16x8 af = __builtin_bit_cast(bf16x8, wl[(tap * KS + s) * 64 + lane]);
+#pragma unroll
+        for (int i = 0; i < STILES; ++i) u[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bfr[i][s], u[i], 0, 0, 0);
+      }
+    };
+    // seed of chunk c: tap K-1 goes straight into the hop image (every wave has left the image: the barrier before)
+    auto seed = [&](int c) {
+      taps(K - 1, c);
+#pragma unroll
+      for (int i = 0; i < STILES; ++i) {
+        int wv = woff[i];
+        asm volatile("" : "+v"(wv));
+        state_put<true>(state, wv, u[i]);
+      }
+    };
+    seed(0);
+
+#pragma unroll 1
+    for (int chunk = 0; chunk < NCH; ++chunk) {
+      // opaque per chunk: the index arithmetic of the prefetches, the LDS-DMA pieces and the epilogue's row stores is re-derived
+      // from it inside the loop -- hoisted out of the loops it would have to be spilled (the operand owns 128 registers)
+      int tl = tid;
+      asm volatile("" : "+v"(tl));
+      float bvec[4] = {0.f, 0.f, 0.f, 0.f};
+      if (MODE == 0 && a.bias) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) bvec[c] = a.bias[chunk * FC + q * 4 + c];
+      }
+      lds_barrier();      // the seed is in the image
+      GCRNN_STAMP(2 + chunk * 14);
+
+      // cold lines: the user-layout rows the LDS-DMA of the last hop will fetch; MODE 2: the epilogue's operands
+      uint32_t prefetched_pk = 0;
+      {
+        constexpr int NPC = NP / NCH;
+        const int prow = tl >> 3, pj = tl & 7;
+        if (pk_src && prow < PKROWS && pj < 5 && chunk * NPC < N) {
+          int node = chunk * NPC + (pj < 4 ? pj * 64 : NPC - 2);
+          node = node < N - 2 ? node : N - 2;
+          prefetched_pk = *reinterpret_cast<const uint32_t*>(pk_src + (int64_t)b * pk_stride + (int64_t)prow * N + node);
+        }
+      }
+      uint32_t prefetched_epi = 0;
+      if constexpr (MODE == 2) {
+        constexpr int ELINES = NP * F * 2 / 128 / NCH;
+        const int idx = tl < ELINES ? tl : tl - ELINES;
+        // (two branches, each with a wave-uniform descriptor: a per-lane choice of the descriptor becomes a waterfall loop)
+        if (tl < ELINES) prefetched_epi = __builtin_amdgcn_raw_buffer_load_b32(rsrc_a1, (chunk * ELINES + idx) * 128, b * (NP * F * 2), 0);
+        else if (tl < 2 * ELINES) prefetched_epi = __builtin_amdgcn_raw_buffer_load_b32(rsrc_a0, (chunk * ELINES + idx) * 128, b * (NP * F * 2), 0);
+      }
+
+      u32x2 eph[MODE == 2 ? STILES : 1], epg[MODE == 2 ? STILES : 1];
+      // ---- Horner hops on the bf16 image; the tap a hop adds is evaluated from the resident operand right before it -------------
+#pragma unroll
+      for (int j = 1; j < K; ++j) {
+        taps(K - 1 - j, chunk);
+        GCRNN_STAMP(2 + chunk * 14 + 2 * j - 1);
+        if (j == K - 1) {
+          if constexpr (MODE == 2) {
+#pragma unroll
+            for (int i = 0; i < STILES; ++i) {
+              int wv = woff[i];
+              asm volatile("" : "+v"(wv));
+              const int eoff = (wv >> 16) * (F * 2) + (chunk * FC + q * 4) * 2;
+              eph[i] = __builtin_amdgcn_raw_buffer_load_b64(rsrc_a1, eoff, b * (NP * F * 2), 0);
+              epg[i] = __builtin_amdgcn_raw_buffer_load_b64(rsrc_a0, eoff, b * (NP * F * 2), 0);
+            }
+          }
+          // the next chunk's weight fragments (after the last chunk: those of chunk 0, for the next step): LDS-DMA into the other buffer
+          {
+            const int nc = (chunk + 1) % NCH;
+            const char* wsrc = reinterpret_cast<const char*>(a.wpack) + (size_t)nc * WB;
+            char* wdst = smem + IMG + (nc & 1) * WB;
+#pragma unroll
+            for (int i = 0; i < (WB / 1024 + SWAVES - 1) / SWAVES; ++i) {
+              const int piece = i * SWAVES + wave;
+              if (piece < WB / 1024)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc + piece * 1024 + lane * 16),
+                                                 (__attribute__((address_space(3))) void*)(wdst + piece * 1024), 16, 0, 0);
+            }
+          }
+          if (pk_src) {
+            constexpr int NPC = NP / NCH, PPR = NPC / 8, PIECES = PKROWS * PPR;
+            static_assert(PIECES % STHREADS == 0, "whole pieces per thread");
+            const uint16_t* xsrc = pk_src + (int64_t)b * pk_stride + chunk * NPC;
+#pragma unroll
+            for (int i = 0; i < PIECES / STHREADS; ++i) {
+              const int id = i * STHREADS + tl;
+              const int row = id / PPR, cs = id - row * PPR;
+              const int col = (cs - (row >> 3)) & (PPR - 1);
+              if (chunk * NPC + col * 8 < N)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xsrc + (int64_t)row * N + col * 8),
+                                                 (__attribute__((address_space(3))) void*)(xtile + (i * STHREADS + wave * 64) * 16), 16, 0, 0);
+            }
+          }
+        }
+#define GCRNN_SEQ_INIT(i) u[i]
+#define GCRNN_SEQ_STORE(i, a_) u[i] = a_
+        GCRNN_HOP_ASM_UNI16_STREAM(GCRNN_SEQ_INIT, GCRNN_SEQ_STORE);
+#undef GCRNN_SEQ_INIT
+#undef GCRNN_SEQ_STORE
+        GCRNN_STAMP(2 + chunk * 14 + 2 * j);
+        if (j < K - 1) {
+          lds_barrier();
+#pragma unroll
+          for (int i = 0; i < STILES; ++i) {
+            int wv = woff[i];
+            asm volatile("" : "+v"(wv));
+            state_put<true>(state, wv, u[i]);
+          }
+          lds_barrier();
+        }
+      }
+      // the LDS-DMA pieces (next weights, inline-pack tile) have had the last hop to land; wait before the epilogue's barriers
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      GCRNN_STAMP(2 + chunk * 14 + 9);
+
+      if constexpr (MODE == 2) {
+        float part = 0.f;
+#pragma unroll
+        for (int i = 0; i < STILES; ++i) {
+          int wv = woff[i];
+          asm volatile("" : "+v"(wv));
+          const int node = wv >> 16;
+          const int eoff = node * (F * 2) + (chunk * FC + q * 4) * 2;
+          const f32x4 raw = u[i];
+          f32x4 o = raw * gsc;
+          float hv0 = 0.f, hv1 = 0.f, hv2 = 0.f, hv3 = 0.f;
+          if (aux1) {
+            const u32x2 h2 = (K > 1) ? eph[i] : __builtin_amdgcn_raw_buffer_load_b64(rsrc_a1, eoff, b * (NP * F * 2), 0);
+            hv0 = bf2f((uint16_t)(h2[0] & 0xffffu)); hv1 = bf2f((uint16_t)(h2[0] >> 16));
+            hv2 = bf2f((uint16_t)(h2[1] & 0xffffu)); hv3 = bf2f((uint16_t)(h2[1] >> 16));
+          }
+          if (gate_out) part += raw[0] * hv0 + raw[1] * hv1 + raw[2] * hv2 + raw[3] * hv3;
+          if (aux0) {
+            const u32x2 g2 = (K > 1) ? epg[i] : __builtin_amdgcn_raw_buffer_load_b64(rsrc_a0, eoff, b * (NP * F * 2), 0);
+            const float g0 = bf2f((uint16_t)(g2[0] & 0xffffu)), g1 = bf2f((uint16_t)(g2[0] >> 16));
+            const float g2f = bf2f((uint16_t)(g2[1] & 0xffffu)), g3 = bf2f((uint16_t)(g2[1] >> 16));
+            o[0] = (o[0] + g0) * (1.f - hv0 * hv0);
+            o[1] = (o[1] + g1) * (1.f - hv1 * hv1);
+            o[2] = (o[2] + g2f) * (1.f - hv2 * hv2);
+            o[3] = (o[3] + g3) * (1.f - hv3 * hv3);
+          }
+          uint2 pkd;
+          if (node < N) {
+            pkd.x = (uint32_t)f2bf(o[0]) | ((uint32_t)f2bf(o[1]) << 16);
+            pkd.y = (uint32_t)f2bf(o[2]) | ((uint32_t)f2bf(o[3]) << 16);
+          } else {
+            pkd.x = 0u; pkd.y = 0u;
+          }
+          __builtin_amdgcn_raw_buffer_store_b64(u32x2{pkd.x, pkd.y}, rsrc_o, eoff, b * (NP * F * 2), 0);
+        }
+        if (gate_out) {
+#pragma unroll
+          for (int off = 32; off > 0; off >>= 1) part += __shfl_down(part, off, 64);
+          if (lane == 0) gate_out[(int64_t)b * (NCH * SWAVES) + chunk * SWAVES + wave] = part;
+        }
+      } else {
+        float bsum[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) bsum[c] = 2.f * bvec[c];      // the one bias is added by both filters (graphML.py:2420-2421)
+#pragma unroll
+        for (int i = 0; i < STILES; ++i) {
+          int wv = woff[i];
+          asm volatile("" : "+v"(wv));
+          const int node = wv >> 16;
+          const f32x4 acc = u[i];
+          uint2 pkd;
+          if (node < N) {
+            const float o0 = fast_tanh(acc[0] + bsum[0]), o1 = fast_tanh(acc[1] + bsum[1]);
+            const float o2 = fast_tanh(acc[2] + bsum[2]), o3 = fast_tanh(acc[3] + bsum[3]);
+            pkd.x = (uint32_t)f2bf(o0) | ((uint32_t)f2bf(o1) << 16);
+            pkd.y = (uint32_t)f2bf(o2) | ((uint32_t)f2bf(o3) << 16);
+          } else {
+            pkd.x = 0u; pkd.y = 0u;
+          }
+          __builtin_amdgcn_raw_buffer_store_b64(u32x2{pkd.x, pkd.y}, rsrc_o, node * (F * 2) + (chunk * FC + q * 4) * 2, b * (NP * F * 2), 0);
+          u[i] = f32x4{__uint_as_float(pkd.x), __uint_as_float(pkd.y), 0.f, 0.f};
+        }
+        GCRNN_STAMP(2 + chunk * 14 + 10);
+        if (aux1) {
+          // user layout H[b][t][f][:] (node-contiguous rows). The tile nodes are degree-ranked, i.e. scattered, so the chunk goes through a
+          // transposed LDS tile -- of 32-bit words [feature pair][node] = {h[n][2p], h[n][2p+1]}: a lane's two packed registers ARE two such
+          // words, 16 ds_write_b32 per lane instead of the chunk-parallel kernel's 32 two-byte scatters (measured there: 14 LDS cycles per
+          // ds_write_b16, 11 % of a chunk). The row stores split the pairs again (v_perm_b32): 8 nodes x 2 features per thread and trip.
+          constexpr int RS2 = 4 * NP + 32;               // 8 words more per row: the rows of a lane pair (q, q + 1) sit 16 banks apart
+          char* tst = reinterpret_cast<char*>(state);
+          lds_barrier();
+#pragma unroll
+          for (int i = 0; i < STILES; ++i) {
+            int wv = woff[i];
+            asm volatile("" : "+v"(wv));
+            const int node = wv >> 16;
+            char* ra = tst + (2 * q) * RS2 + node * 4;
+            *reinterpret_cast<uint32_t*>(ra) = __float_as_uint(u[i][0]);
+            *reinterpret_cast<uint32_t*>(ra + RS2) = __float_as_uint(u[i][1]);
+          }
+          lds_barrier();
+          GCRNN_STAMP(2 + chunk * 14 + 11);
+          const int segs = N >> 3;
+          uint16_t* ub = const_cast<uint16_t*>(aux1) + (int64_t)b * ubstride + (int64_t)(chunk * FC) * N;
+          const __amdgpu_buffer_rsrc_t rsrc_u = __builtin_amdgcn_make_buffer_rsrc(ub, 0, FC * N * 2, 0x00020000);
+          for (int idx = tl; idx < (FC / 2) * segs; idx += STHREADS) {
+            const int fp = idx / segs, sg = idx - fp * segs;
+            typedef __attribute__((__vector_size__(4 * sizeof(unsigned int)))) unsigned int u32x4_t;
+            const u32x4_t w0 = *reinterpret_cast<const u32x4_t*>(tst + fp * RS2 + sg * 32);
+            const u32x4_t w1 = *reinterpret_cast<const u32x4_t*>(tst + fp * RS2 + sg * 32 + 16);
+            const u32x4_t ev = {__builtin_amdgcn_perm(w0[1], w0[0], 0x05040100u), __builtin_amdgcn_perm(w0[3], w0[2], 0x05040100u),
+                                __builtin_amdgcn_perm(w1[1], w1[0], 0x05040100u), __builtin_amdgcn_perm(w1[3], w1[2], 0x05040100u)};
+            const u32x4_t od = {__builtin_amdgcn_perm(w0[1], w0[0], 0x07060302u), __builtin_amdgcn_perm(w0[3], w0[2], 0x07060302u),
+                                __builtin_amdgcn_perm(w1[1], w1[0], 0x07060302u), __builtin_amdgcn_perm(w1[3], w1[2], 0x07060302u)};
+            __builtin_amdgcn_raw_buffer_store_b128(ev, rsrc_u, ((2 * fp) * N + sg * 8) * 2, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(od, rsrc_u, ((2 * fp + 1) * N + sg * 8) * 2, 0, 0);
+          }
+        }
+      }
+      GCRNN_STAMP(2 + chunk * 14 + 12);
+      // second half of the inline pack (as the chunk-parallel kernel): [rows][NPC] tile -> whole sequence-major rows. gfx950 store-data
+      // hazard: every piece sits in its own register tuple, which stays reserved until the stores have retired -- here
+      // that wait comes AFTER the next chunk's seed, whose MFMAs cover the drain of this chunk's stores.
+      constexpr int NPCp = NP / NCH, PCS = PKROWS / 8, RI = PCS * NPCp / STHREADS;
+      typedef __attribute__((__vector_size__(4 * sizeof(unsigned int)))) unsigned int u32x4_t;
+      u32x4_t vv[RI];
+#pragma unroll
+      for (int i = 0; i < RI; ++i) vv[i] = u32x4_t{0u, 0u, 0u, 0u};
+      if (pk_src) {
+        if (!(MODE == 0 && aux1)) lds_barrier();
+        const __amdgpu_buffer_rsrc_t rsrc_xn = __builtin_amdgcn_make_buffer_rsrc(pk_dst, 0, B * (NP * PKROWS * 2), 0x00020000);
+#pragma unroll
+        for (int i = 0; i < RI; ++i) {
+          const int id = i * STHREADS + tl;
+          const int nl = id / PCS, pc = id - nl * PCS;
+          const char* src = xtile + (pc * 8) * (NPCp * 2) + ((nl + 8 * pc) & (NPCp - 1)) * 2;
+          uint32_t w4[4];
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj) {
+            const uint32_t lo = *reinterpret_cast<const uint16_t*>(src + (2 * jj) * (NPCp * 2));
+            const uint32_t hi = *reinterpret_cast<const uint16_t*>(src + (2 * jj + 1) * (NPCp * 2));
+            w4[jj] = lo | (hi << 16);
+          }
+          const bool ok = chunk * NPCp + nl < N;
+          vv[i] = u32x4_t{ok ? w4[0] : 0u, ok ? w4[1] : 0u, ok ? w4[2] : 0u, ok ? w4[3] : 0u};
+        }
+#pragma unroll
+        for (int i = 0; i < RI; ++i) asm volatile("" : "+v"(vv[i]));          // every piece in its own tuple before the first store
+#pragma unroll
+        for (int i = 0; i < RI; ++i) {
+          const int id = i * STHREADS + tl;
+          const int nl = id / PCS, pc = id - nl * PCS;
+          __builtin_amdgcn_raw_buffer_store_b128(vv[i], rsrc_xn, (chunk * NPCp + nl) * (PKROWS * 2) + pc * 16 + b * (NP * PKROWS * 2), 0, 0);
+        }
+      }
+      lds_barrier();     // the last hop's reads of the image (and the epilogue's of its tiles) are done: the image may be seeded again
+      GCRNN_STAMP(2 + chunk * 14 + 13);
+      if (chunk + 1 < NCH) seed(chunk + 1);
+      // every store of this chunk has retired before its registers are reused (and, after the last chunk, before this workgroup
+      // reads its own h_t / laid-out rows back as the next step's operand)
+      asm volatile("s_waitcnt vmcnt(0)" ::"v"(vv[0]), "v"(vv[RI - 1]) : "memory");
+#pragma unroll
+      for (int i = 1; i + 1 < RI; ++i) asm volatile("" ::"v"(vv[i]));
+      asm volatile("" ::"v"(prefetched_epi), "v"(prefetched_pk));
+    }  // chunks
+#pragma unroll
+    for (int i = 0; i < STILES; ++i)
+#pragma unroll
+      for (int s = 0; s < KS; ++s) asm volatile("" ::"v"(bfr[i][s]));
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    lds_barrier();       // every wave's stores of this step have retired (the waits above): the next step may read them
+  }  // steps
+  }  // sequences
+  GCRNN_STAMP_FLUSH();
+}
+
+// LDS bytes of the sequence-resident kernel, or 0 when the problem does not fit
+template <int K, int HS, int XS>
+static size_t fused_seq_lds(int64_t entries, bool inline_pack, int pkrows) {
+  const size_t need = (size_t)33 * 1024 + 2 * (size_t)K * (HS + XS) * 1024 + (size_t)entries * 32 +
+                      (inline_pack ? (size_t)pkrows * (NP / (32 * HS / FC)) * 2 : 0);
+  return need <= 160 * 1024 ? need : 0;
+}
+
+// Which launches take the sequence-resident kernel: it has B workgroups, so it needs B to fill the chip (GCRNN_SEQ_MIN_B, default
+// 160 of the 256 CUs); GCRNN_SEQ_KERNEL=0 keeps the chunk-parallel kernel (A/B, tests).
+// GCRNN_SEQ_PERSIST=0: one launch per time step instead of one per forward / chain (A/B)
+static inline bool fused_seq_persistent() {
+  const char* e = getenv("GCRNN_SEQ_PERSIST");
+  return !(e && e[0] == '0');
+}
+static inline bool fused_seq_wanted(int64_t B) {
+  const char* off = getenv("GCRNN_SEQ_KERNEL");      // read per call (once per forward / chain, not per step): tests switch it in-process
+  if (off && off[0] == '0') return false;
+  const char* mb = getenv("GCRNN_SEQ_MIN_B");
+  const int min_b = mb ? atoi(mb) : 160;
+  return B >= (min_b < 1 ? 1 : min_b);
+}

@@ -84,6 +84,13 @@ __device__ __forceinline__ void state_put(float* state, int wv, const f32x4& v) 
     *reinterpret_cast<f32x4*>(p) = v;
   }
 }
+// Workgroup barrier for LDS hand-offs only: __syncthreads() is a workgroup-scope fence too, for which hipcc drains EVERY outstanding
+// vector-memory operation first (s_waitcnt vmcnt(0)) -- at the barriers of the epilogue that is the drain of the state stores just
+// issued (measured in the sequence-resident kernel: ~1.5 k cycles per chunk). Where only LDS contents change hands, waiting for this
+// wave's LDS operations is enough; the places that hand GLOBAL data between waves (LDS-DMA tiles, a step boundary inside a launch) wait
+// for vmcnt(0) explicitly.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // ------------------------------------------------------------------------------------------
 // the fused step
 // ------------------------------------------------------------------------------------------
@@ -271,6 +278,8 @@ __device__ __forceinline__ void state_put(float* state, int wv, const f32x4& v) 
 // The uniform-weight hop on a bf16 image, summed on the matrix cores (generator: gen_uniform16): a lane gathers 16 bytes = half a
 // neighbour's 32-byte row, v_mfma_f32_16x16x32_bf16 with a one-hot A operand adds two neighbours per instruction into D, whose layout
 // is the accumulators'. A operand of lane (i = lane & 15, kg = lane >> 4): A[i][8 kg + s] = 1 iff i == 8 (kg & 1) + s.
+// (tile ranges are wave-uniform; should they have been parked in vector registers, the "s" operands get them back through v_readfirstlane)
+#define GCRNN_SGPR(x) __builtin_amdgcn_readfirstlane(x)
 #define GCRNN_HOP_ASM_UNI16_STREAM(INIT, STORE)                                                    \
   do {                                                                                             \
     static_assert(HT == 8, "the asm hop stream is generated for 8 tiles per wave");                \
@@ -292,8 +301,8 @@ __device__ __forceinline__ void state_put(float* state, int wv, const f32x4& v) 
       asm volatile(GCRNN_HOP_ASM_UNI16_TEXT                                                        \
                    : "+v"(al_[0]), "+v"(ah_[0]), "+v"(al_[1]), "+v"(ah_[1]), "+v"(al_[2]), "+v"(ah_[2]), "+v"(al_[3]), "+v"(ah_[3]),  \
                      "+v"(al_[4]), "+v"(ah_[4]), "+v"(al_[5]), "+v"(ah_[5]), "+v"(al_[6]), "+v"(ah_[6]), "+v"(al_[7]), "+v"(ah_[7])   \
-                   : "s"(tend[0] >> 2), "s"(tend[1] >> 2), "s"(tend[2] >> 2), "s"(tend[3] >> 2), "s"(tend[4] >> 2),                   \
-                     "s"(tend[5] >> 2), "s"(tend[6] >> 2), "s"(tend[7] >> 2), "s"(gwbeg), "s"(gwend - 1), "v"(colb), "v"(qh_), "v"(wp_), \
+                   : "s"(GCRNN_SGPR(tend[0] >> 2)), "s"(GCRNN_SGPR(tend[1] >> 2)), "s"(GCRNN_SGPR(tend[2] >> 2)), "s"(GCRNN_SGPR(tend[3] >> 2)), "s"(GCRNN_SGPR(tend[4] >> 2)), \
+                     "s"(GCRNN_SGPR(tend[5] >> 2)), "s"(GCRNN_SGPR(tend[6] >> 2)), "s"(GCRNN_SGPR(tend[7] >> 2)), "s"(GCRNN_SGPR(gwbeg)), "s"(GCRNN_SGPR(gwend - 1)), "v"(colb), "v"(qh_), "v"(wp_), \
                      "v"(aop_)                                                                     \
                    : GCRNN_HOP_ASM_UNI16_CLOBBERS);                                                \
     }                                                                                              \
@@ -553,7 +562,7 @@ __global__ __launch_bounds__(STHREADS) void fused_step_kernel(
   }
 #endif
 #endif
-  __syncthreads();
+  lds_barrier();
 
   // L2 prefetch of the NEXT sequence of this workgroup: while the hops keep the LDS busy, every thread touches one
   // 128-byte row (= one cache line) of [h | x]; the NCH chunk workgroups of a sequence share an XCD and split the
@@ -733,14 +742,14 @@ __global__ __launch_bounds__(STHREADS) void fused_step_kernel(
       }
     }
     if (j < K - 1) {
-      __syncthreads();
+      lds_barrier();
 #pragma unroll
       for (int i = 0; i < STILES; ++i) {
         int wv = woff[i];
         asm volatile("" : "+v"(wv));
         state_put<UNI == 2>(state, wv, u[i][K - 1 - j]);
       }
-      __syncthreads();
+      lds_barrier();
     }
   }
 
@@ -932,7 +941,7 @@ __global__ __launch_bounds__(STHREADS) void fused_step_kernel(
     // the tile nodes are degree-ranked, i.e. scattered: stage the per-node partials in the (now dead) state region and store them
     // in node order, coalesced
     float* hstage = state;
-    __syncthreads();                                   // every wave has finished reading `state` in the last hop
+    lds_barrier();                                   // every wave has finished reading `state` in the last hop
     if (q == 0) {
 #pragma unroll
       for (int i = 0; i < STILES; ++i) {
@@ -941,7 +950,7 @@ __global__ __launch_bounds__(STHREADS) void fused_step_kernel(
         hstage[wv >> 16] = hp[i];
       }
     }
-    __syncthreads();
+    lds_barrier();
     float* go = gate_out + ((int64_t)b * NCH + chunk) * N;
     for (int n = tid; n < N; n += STHREADS) go[n] = hstage[n];
   }
@@ -950,7 +959,7 @@ __global__ __launch_bounds__(STHREADS) void fused_step_kernel(
     // (row stride 2080 B), then 16-byte coalesced row stores -- replaces a separate unpack pass over the whole sequence.
     constexpr int RS = 2 * NP + 32;
     char* tst = reinterpret_cast<char*>(state);
-    __syncthreads();                                   // every wave has finished reading `state` in the last hop
+    lds_barrier();                                   // every wave has finished reading `state` in the last hop
 #pragma unroll
     for (int i = 0; i < STILES; ++i) {
       int wv = woff[i];
@@ -968,7 +977,7 @@ __global__ __launch_bounds__(STHREADS) void fused_step_kernel(
       *reinterpret_cast<uint16_t*>(rb) = (uint16_t)(pb & 0xffffu);
       *reinterpret_cast<uint16_t*>(rb + RS) = (uint16_t)(pb >> 16);
     }
-    __syncthreads();
+    lds_barrier();
     const int segs = N >> 3;                           // 16-byte segments per row (N % 8 == 0 checked by the host)
     uint16_t* ub = const_cast<uint16_t*>(aux1) + (int64_t)b * ubstride + (int64_t)(chunk * FC) * N;
     const __amdgpu_buffer_rsrc_t rsrc_u = __builtin_amdgcn_make_buffer_rsrc(ub, 0, FC * N * 2, 0x00020000);      // this item's 16 rows of H[b][t]
@@ -986,7 +995,7 @@ __global__ __launch_bounds__(STHREADS) void fused_step_kernel(
       // 8-feature pieces; the pieces of a node sit in consecutive lanes (whole rows per store), rows >= N are zeros
       constexpr int NPC = NP / NCH, PCS = PKROWS / 8;
       const char* xtile = smem + NP * FC * 4 + K * KS * 1024 + entries * 32;
-      if (!((EPI == 0 && aux1) || EPI == 6)) __syncthreads();   // (EPI 0 with the user-layout output / EPI 6: their two barriers have already passed)
+      if (!((EPI == 0 && aux1) || EPI == 6)) lds_barrier();   // (EPI 0 with the user-layout output / EPI 6: their two barriers have already passed)
       const __amdgpu_buffer_rsrc_t rsrc_xn = __builtin_amdgcn_make_buffer_rsrc(pk_dst, 0, B * (NP * PKROWS * 2), 0x00020000);
       // gfx950: a 16-byte buffer store whose soffset is an SGPR followed IMMEDIATELY by a VALU write of its first data register
       // loses that dword in a few lanes, rarely (hipcc models no hazard for this form and happily reuses one register tuple for
@@ -1024,9 +1033,11 @@ __global__ __launch_bounds__(STHREADS) void fused_step_kernel(
     }
   }
   asm volatile("" ::"v"(prefetched), "v"(prefetched_epi), "v"(prefetched_pk));      // the prefetch loads retire here at the latest
-  __syncthreads();     // the last hop's reads of `state` are done before the next sequence overwrites it
+  lds_barrier();     // the last hop's reads of `state` are done before the next sequence overwrites it
   }  // sequences
 }
+
+#include "gcrnn_fused_seq.h"
 
 typedef void (*fused_kern_t)(const uint16_t*, const uint16_t*, uint16_t*, const uint4*, const float*, const float*,
                              const float*, const int32_t*, const int32_t*, const int32_t*, const float*, const float4*,
@@ -1122,12 +1133,117 @@ int fused_launch_t(int mode /*0 plain, 1 gated, 2 gate pre-pass, 3 BPTT data gra
 #endif
   else if (mode == 1) kern = resident ? (fused_kern_t)fused_step_kernel<K, HS, XS, true, true> : (fused_kern_t)fused_step_kernel<K, HS, XS, true, false>;
   else                kern = resident ? (fused_kern_t)fused_step_kernel<K, HS, XS, false, true> : (fused_kern_t)fused_step_kernel<K, HS, XS, false, false>;
-  if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-    return GCRNN_ERR_LAUNCH;
   const int NCH = F / FC;
   const uint16_t* x = (const uint16_t*)xs;
   uint16_t* h = (uint16_t*)hs;
   const int64_t xstep = B * NP * G, hstep = B * NP * F;
+#if GCRNN_HOP_ASM && GCRNN_STEP_WAVES == 8
+  // Sequence-resident kernel (gcrnn_fused_seq.h): one workgroup per sequence keeps the operand in registers for all chunks -- the
+  // un-gated forward steps and the plain BPTT data chain on uniform-weight bf16-image plans, when the batch fills the chip.
+  if (ga.uniform_w != 0.f && ga.img16 && ga.ell_col4 && !head && !step_events && fused_seq_wanted(B) && (mode == 0 || mode == 3)) {
+    const size_t slds = fused_seq_lds<K, HS, XS>(ga.entries, inline_pack, mode == 3 ? F : G);
+    const unsigned sgrid = (unsigned)(B < 256 ? B : 256);
+    const bool persist = fused_seq_persistent();
+    SeqArgs sa{};
+    sa.wpack = (const uint4*)wpack; sa.tile_nodes = ga.tile_nodes; sa.tile_off = ga.tile_off; sa.ell_col4 = (const uint2*)ga.ell_col4;
+    sa.entries = (int)ga.entries; sa.B = (int)B; sa.N = (int)N; sa.uni_w = ga.uniform_w;
+    if constexpr (XS > 0) {
+      if (mode == 0 && slds) {
+        auto sk = fused_seq_kernel<K, HS, XS, 0>;
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(sk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)slds) != hipSuccess)
+          return GCRNN_ERR_LAUNCH;
+        GCRNN_PRE_LAUNCH();
+        sa.bias = bias;
+        sa.x0 = x; sa.xstride = xstep;
+        sa.hfirst = (const uint16_t*)h0; sa.hrest = h; sa.hstride = hstep;
+        sa.out0 = h; sa.ostride = hstep;
+        sa.a1 = (const uint16_t*)huser; sa.a1stride = F * N; sa.a1_last_only = huser_last_only ? 1 : 0;
+        sa.ubstride = (int)((huser_last_only ? 1 : T) * F * N);
+        if (inline_pack && T > 1) {
+          sa.pk_src0 = (const uint16_t*)bw_dHs + G * N; sa.pksrc_stride = G * N;
+          sa.pk_dst0 = const_cast<uint16_t*>(x) + xstep; sa.pkdst_stride = xstep;
+          sa.pk_stride = (int)(T * G * N);
+        }
+        if (persist) {
+          sa.nsteps = (int)T;
+          sk<<<sgrid, STHREADS, slds, st>>>(sa);
+        } else {
+          for (int64_t t = 0; t < T; ++t) {         // the same kernel, one step per launch
+            SeqArgs s1 = sa;
+            s1.nsteps = 1; s1.pk_all = 1;
+            s1.x0 = x + t * xstep;
+            s1.hfirst = (t == 0) ? (const uint16_t*)h0 : h + (t - 1) * hstep;
+            s1.out0 = h + t * hstep;
+            s1.a1 = !huser ? nullptr : (!huser_last_only ? (const uint16_t*)huser + t * F * N : (t == T - 1 ? (const uint16_t*)huser : nullptr));
+            s1.a1_last_only = 0;
+            const bool pkt = sa.pk_src0 && t + 1 < T;
+            s1.pk_src0 = pkt ? sa.pk_src0 + t * sa.pksrc_stride : nullptr;
+            s1.pk_dst0 = pkt ? sa.pk_dst0 + t * sa.pkdst_stride : nullptr;
+            sk<<<sgrid, STHREADS, slds, st>>>(s1);
+          }
+        }
+        GCRNN_CHECK_LAUNCH();
+        return GCRNN_OK;
+      }
+    } else {
+      if (mode == 3 && slds) {
+        auto sk = fused_seq_kernel<K, HS, 0, 2>;
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(sk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)slds) != hipSuccess)
+          return GCRNN_ERR_LAUNCH;
+        GCRNN_PRE_LAUNCH();
+        const uint16_t* dH = (const uint16_t*)bw_dHs;
+        const uint16_t* hst = (const uint16_t*)bw_hs;
+        const int64_t gstep = B * (NCH * SWAVES);
+        if (T >= 2) {
+          // steps i = 0 .. T-2 walk t = T-1 .. 1: operand dpre_t, output dpre_{t-1}, epilogue operands dH_{t-1} / h_{t-1}; step i lays out dH_{t-2}
+          sa.hfirst = h + (T - 1) * hstep; sa.hrest = h + (T - 2) * hstep; sa.hstride = -hstep;
+          sa.out0 = h + (T - 2) * hstep; sa.ostride = -hstep;
+          sa.gf0 = gf ? gf + (T - 1) * B : nullptr; sa.gfstride = -B;
+          sa.go0 = gate_out ? gate_out + (T - 1) * gstep : nullptr; sa.gostride = -gstep;
+          sa.a0 = dH + (T - 2) * hstep; sa.a0stride = -hstep;
+          sa.a1 = hst + (T - 2) * hstep; sa.a1stride = -hstep;
+          if (inline_bw && T >= 3) {
+            sa.pk_src0 = (const uint16_t*)xs + (T - 3) * F * N; sa.pksrc_stride = -(F * N);
+            sa.pk_dst0 = const_cast<uint16_t*>(dH) + (T - 3) * hstep; sa.pkdst_stride = -hstep;
+            sa.pk_stride = (int)(T * F * N);
+          }
+          if (persist) {
+            sa.nsteps = (int)(T - 1);
+            sk<<<sgrid, STHREADS, slds, st>>>(sa);
+          } else {
+            for (int64_t i = 0; i + 1 < T; ++i) {
+              SeqArgs s1 = sa;
+              s1.nsteps = 1; s1.pk_all = 1;
+              s1.hfirst = sa.hfirst + i * sa.hstride;
+              s1.out0 = sa.out0 + i * sa.ostride;
+              s1.gf0 = sa.gf0 ? sa.gf0 + i * sa.gfstride : nullptr;
+              s1.go0 = sa.go0 ? sa.go0 + i * sa.gostride : nullptr;
+              s1.a0 = sa.a0 + i * sa.a0stride; s1.a1 = sa.a1 + i * sa.a1stride;
+              const bool pkt = sa.pk_src0 && i + 2 < T;
+              s1.pk_src0 = pkt ? sa.pk_src0 + i * sa.pksrc_stride : nullptr;
+              s1.pk_dst0 = pkt ? sa.pk_dst0 + i * sa.pkdst_stride : nullptr;
+              sk<<<sgrid, STHREADS, slds, st>>>(s1);
+            }
+          }
+        }
+        if (bw_dh0 || gate_out) {
+          // d h0 (and the forget gate's partials of step 0): the raw state gradient of dpre_0, no tanh' and no upstream term
+          SeqArgs s0{};
+          s0.wpack = sa.wpack; s0.tile_nodes = sa.tile_nodes; s0.tile_off = sa.tile_off; s0.ell_col4 = sa.ell_col4;
+          s0.entries = sa.entries; s0.B = sa.B; s0.N = sa.N; s0.uni_w = sa.uni_w;
+          s0.hfirst = h; s0.out0 = (uint16_t*)bw_dh0; s0.gf0 = gf; s0.go0 = gate_out;
+          s0.a1 = gate_out ? (const uint16_t*)bw_h0 : nullptr;
+          s0.nsteps = 1;
+          sk<<<sgrid, STHREADS, slds, st>>>(s0);
+        }
+        GCRNN_CHECK_LAUNCH();
+        return GCRNN_OK;
+      }
+    }
+  }
+#endif
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    return GCRNN_ERR_LAUNCH;
   // one workgroup per CU: 256 / NCH sequence slots (rounded to the 8 XCDs), fewer when the batch is small
   auto grid_for = [&](int64_t items) {
     int64_t slots = cdiv(items, 8) * 8;

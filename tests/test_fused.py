@@ -1509,3 +1509,78 @@ def test_bf16_hop_image_on_hub_graphs_small_graphs_and_sixteen_padding_rows(N, F
     assert e16.max() <= 3e-2 and e16.mean() <= 2e-3, (e16.max(), e16.mean())
     assert e16.mean() <= 1.5 * e32.mean() + 1e-5, (e16.mean(), e32.mean())
     assert np.abs(H16 - H32).max() <= 1.6e-2
+
+
+def _uniform_cell(N, G, F, K, tg, seed, dev, dtype=torch.bfloat16):
+    import gated_gcrnns_amd.Utils.graphML as gml
+    rng = np.random.default_rng(seed)
+    W = (rng.random((N, N)) < 10.0 / N).astype(np.float64)
+    W = np.triu(W, 1); W = W + W.T
+    S = (W / np.max(np.abs(np.linalg.eigvalsh(W)))).reshape(1, N, N)
+    torch.manual_seed(seed)
+    cell = gml.GGCRNNCell(G, F, K, K, torch.tanh, tg, None, 1, True)
+    cell.addGSO(torch.tensor(S))
+    cell = cell.to(dev)
+    return (cell.to(dtype) if dtype is not None else cell), rng, S
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('N,F,G,K,B,T', [(1000, 64, 64, 5, 5, 4), (1000, 64, 1, 3, 3, 3), (400, 32, 32, 3, 7, 3), (1000, 64, 64, 2, 2, 2),
+                                         (1000, 64, 32, 4, 3, 3), (1008, 64, 64, 5, 260, 2)])
+def test_sequence_resident_kernel_is_bit_identical_to_the_chunk_parallel_kernel(N, F, G, K, B, T, monkeypatch):
+    """gcrnn_fused_seq.h: one workgroup per sequence keeps the operand [h | x] in registers and walks the F/16 chunks, evaluating
+    each tap right before the hop that adds it. Same arithmetic in the same order as the chunk-parallel step kernel: same bits for
+    the states, the user-layout output, the inline-packed inputs and the last-state-only path (with and without the inline pack;
+    B = 260 > 256 workgroups exercises the sequence loop and the LDS-DMA'd weights of the next sequence's first chunk)."""
+    from gated_gcrnns_amd import ops
+    dev = torch.device('cuda:0')
+    cell, rng, _ = _uniform_cell(N, G, F, K, False, 71, dev)
+    X = torch.tensor(rng.standard_normal((B, T, G, N)), dtype=torch.float32, device=dev).to(torch.bfloat16)
+    h0 = torch.tensor(0.3 * rng.standard_normal((B, F, N)), dtype=torch.float32, device=dev).to(torch.bfloat16)
+    Xp, wA = ops.fused_pad_operands(X, cell.weight_A.detach())
+    monkeypatch.setenv('GCRNN_SEQ_MIN_B', '1')
+    for nopack in ('0', '1'):
+        monkeypatch.setenv('GCRNN_NO_INLINE_PACK', nopack) if nopack == '1' else monkeypatch.delenv('GCRNN_NO_INLINE_PACK', raising=False)
+        with torch.no_grad():
+            monkeypatch.setenv('GCRNN_SEQ_KERNEL', '1')
+            hs1, _, H1 = ops.fused_cell_forward(Xp, h0, wA, cell.weight_B, cell.bias, cell.graph, return_states=True)
+            Hl1 = cell(X, h0, last_only=True)
+            monkeypatch.setenv('GCRNN_SEQ_KERNEL', '0')
+            hs0, _, H0 = ops.fused_cell_forward(Xp, h0, wA, cell.weight_B, cell.bias, cell.graph, return_states=True)
+            Hl0 = cell(X, h0, last_only=True)
+        assert torch.equal(H0, H1) and torch.equal(hs0, hs1) and torch.equal(Hl0, Hl1), nopack
+        assert float(hs1[:, :, N:].abs().max()) == 0.0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('tg,N,F,K', [(False, 1000, 64, 5), (True, 1000, 64, 5), (False, 400, 32, 3), (False, 1000, 64, 2)])
+def test_sequence_resident_bptt_chain_is_bit_identical(tg, N, F, K, monkeypatch):
+    """Training step with the forward steps and the BPTT data chain on the sequence-resident kernel (MODE 2: operand dpre_t in
+    registers, epilogue operands prefetched at the last hop, inline pack of dH, forget-gate scale and the <h, chain> partials of the
+    time-gated cell): every gradient has the bits of the chunk-parallel kernels."""
+    dev = torch.device('cuda:0')
+    G, B, T = F, 6, 5
+    cell, rng, _ = _uniform_cell(N, G, F, K, tg, 73, dev, dtype=None)
+    X = torch.tensor(rng.standard_normal((B, T, G, N)), dtype=torch.float32, device=dev).to(torch.bfloat16)
+    h0 = torch.tensor(0.3 * rng.standard_normal((B, F, N)), dtype=torch.float32, device=dev).to(torch.bfloat16).requires_grad_(not tg)      # (the fused time gates give h0 no gradient)
+    tgt = torch.tensor(rng.standard_normal((B, T, F, N)), dtype=torch.float32, device=dev)
+    monkeypatch.setenv('GCRNN_SEQ_MIN_B', '1')
+
+    def step():
+        cell.zero_grad(set_to_none=True)
+        h0.grad = None
+        assert cell._use_fused_training(X, h0)
+        H = cell(X, h0)
+        torch.nn.functional.l1_loss(H.float(), tgt).backward()
+        g = {n: p.grad.clone() for n, p in cell.named_parameters() if p.grad is not None}
+        if not tg:
+            g['h0'] = h0.grad.clone()
+        return H.detach().clone(), g
+
+    monkeypatch.setenv('GCRNN_SEQ_KERNEL', '1')
+    H1, g1 = step()
+    monkeypatch.setenv('GCRNN_SEQ_KERNEL', '0')
+    H0, g0 = step()
+    assert torch.equal(H0, H1) and g0.keys() == g1.keys() and len(g1) >= 4
+    for n in g1:
+        assert torch.equal(g0[n], g1[n]), n

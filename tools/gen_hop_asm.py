@@ -219,27 +219,30 @@ def gen_uniform():
 # Column words per slot and trip: dword 0 = addr(entry 0) | addr(entry 2) << 16, dword 1 = addr(entry 1) | addr(entry 3) << 16.
 # Operands: %0..%15 accumulator halves, %16..%23 tile ends, %24 first group, %25 last valid group (SGPR), %26 column base + 8 r,
 # (+ 4 (q >> 1): a lane reads only its own dword), %27 = (q & 1) << 4, %28 = {w, w}, %29 = the lane's A operand (4 VGPRs).
-# Clobbers v[194:253], s[88:90], scc.
+# Clobbers v[218:253] (UB16 ..), s[88:90], scc, vcc.
 VD = int(os.environ.get('GCRNN_HOP16_DEPTH', '3'))      # groups in flight (register sets): 3 = as the fp32 streams; the two 16-byte gathers of a
 # set leave room for 5 sets inside v[194:253] -- the trips are short now, so the LDS latency needs more of them in flight
 
 
+UB16 = 218          # the bf16-image stream's own register window v[218:253]: 36 registers (5 gather sets would need v[UB16:UB16+39] + 12: D <= 3 here)
+
+
 def VX(p, e):
-    b = UB + 8 * p + 4 * e
+    b = UB16 + 8 * p + 4 * e
     return 'v[%d:%d]' % (b, b + 3)
 
 
 def VXa(p, e):
-    return 'v%d' % (UB + 8 * p + 4 * e)
+    return 'v%d' % (UB16 + 8 * p + 4 * e)
 
 
 def VC(p):
-    return 'v%d' % (UB + 40 + p)
+    return 'v%d' % (UB16 + 24 + p)
 
 
-VCA = 'v%d' % (UB + 46)
-VP5, VPCL = 'v%d' % (UB + 44), 'v%d' % (UB + 45)                   # running column pointer of group g + 2 D - 1, and its clamp (last valid group)
-VSUMB = [UB + 56]                                                 # the D accumulator (4 VGPRs)
+VCA = 'v%d' % (UB16 + 31)
+VP5, VPCL = 'v%d' % (UB16 + 29), 'v%d' % (UB16 + 30)               # running column pointer of group g + 2 D - 1, and its clamp (last valid group)
+VSUMB = [UB16 + 32]                                               # the D accumulator (4 VGPRs)
 VSUM4 = ['v[%d:%d]' % (b_, b_ + 3) for b_ in VSUMB]
 VSUMH = [['v[%d:%d]' % (b_, b_ + 1), 'v[%d:%d]' % (b_ + 2, b_ + 3)] for b_ in VSUMB]
 
@@ -263,7 +266,7 @@ def vs0p(q, lines):            # steady state: the same read through the running
 
 def gen_uniform16():
     D = VD
-    assert 2 <= D <= 5
+    assert 2 <= D <= 3      # (the register window holds three gather sets; 2 / 3 / 4 / 5 sets measured equal)
     SC = 's90'                                # (group - tile end) of the current tile, counted up: the carry of its increment ends the tile
     L = ['s_mov_b32 %s, %s' % (SG, GBEG)]
     for r in range(4):
@@ -327,7 +330,8 @@ def main():
     emit('GCRNN_HOP_ASM_UNI16_TEXT', gen_uniform16())
     regs = ', '.join('"v%d"' % r for r in range(UB, UB + 60))
     print('#define GCRNN_HOP_ASM_UNI_CLOBBERS %s, "s88", "s89", "s90", "scc", "memory"' % regs)
-    print('#define GCRNN_HOP_ASM_UNI16_CLOBBERS %s, "s88", "s89", "s90", "scc", "vcc", "memory"' % regs)
+    regs16 = ', '.join('"v%d"' % r for r in range(UB16, UB16 + 36))
+    print('#define GCRNN_HOP_ASM_UNI16_CLOBBERS %s, "s88", "s89", "s90", "scc", "vcc", "memory"' % regs16)
 
 
 if __name__ == '__main__':

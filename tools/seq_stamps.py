@@ -1,0 +1,57 @@
+#!/usr/bin/env python3
+"""Phase timeline of the sequence-resident step kernel (gcrnn_fused_seq.h) from in-kernel s_memtime stamps.
+Builds a diagnostic library with -DGCRNN_SEQ_STAMPS into /tmp, runs forwards at the bench's size and prints, per phase, the median
+over workgroups of the stamp differences (100 MHz ticks -> us). Usage on the GPU box: python3 tools/seq_stamps.py [train]"""
+import ctypes, glob, os, subprocess, sys
+R = os.environ.get('GRAFT_REPO_ROOT', os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+C = os.path.join(R, 'gated_gcrnns_amd', 'csrc')
+out = '/tmp/seqst'
+os.makedirs(out, exist_ok=True)
+procs = []
+for f in sorted(glob.glob(C + '/*.hip') + glob.glob(C + '/*.cpp')):
+    o = os.path.join(out, os.path.basename(f) + '.o')
+    procs.append(subprocess.Popen(['/opt/rocm/bin/hipcc', '-O3', '-std=c++17', '--offload-arch=gfx950', '-fPIC', '-DGCRNN_SEQ_STAMPS', '-c', f, '-o', o]))
+assert all(p.wait() == 0 for p in procs)
+lib = os.path.join(out, 'lib.so')
+subprocess.check_call(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-shared', '-fPIC', '-o', lib] + sorted(glob.glob(out + '/*.o')))
+os.environ['GCRNN_LIBPATH'] = lib
+sys.path.insert(0, R)
+import numpy as np, torch
+import bench
+import gated_gcrnns_amd.Utils.graphML as gml
+from gated_gcrnns_amd import _lib
+dev = torch.device('cuda:0')
+N, K, T, F, B = 1000, 5, 32, 64, 256
+torch.manual_seed(0)
+cell = gml.GGCRNNCell(F, F, K, K, torch.tanh, False, None, 1, True)
+cell.addGSO(torch.tensor(bench.sbm_graph(N)))
+cell = cell.to(torch.bfloat16).to(dev)
+X = torch.randn(B, T, F, N, device=dev).to(torch.bfloat16)
+h0 = torch.zeros(B, F, N, device=dev, dtype=torch.bfloat16)
+with torch.no_grad():
+    for _ in range(3):
+        cell(X, h0)
+torch.cuda.synchronize()
+buf = np.zeros(256 * 64, dtype=np.uint64)
+dll = ctypes.CDLL(lib)
+assert dll.gcrnn_debug_read_seq_stamps(buf.ctypes.data_as(ctypes.c_void_p)) == 0
+st = buf.reshape(256, 64).astype(np.int64)
+names = {0: 'start', 1: 'operand requested'}
+for c in range(4):
+    b0 = 2 + 14 * c
+    names[b0] = 'c%d seeded+barrier' % c
+    for j in range(1, K):
+        names[b0 + 2 * j - 1] = 'c%d taps(hop %d)' % (c, j)
+        names[b0 + 2 * j] = 'c%d hop %d (+put)' % (c, j)
+    names[b0 + 9] = 'c%d vmcnt(0)' % c
+    names[b0 + 10] = 'c%d tanh + state stores' % c
+    names[b0 + 11] = 'c%d transposed tile + barriers' % c
+    names[b0 + 12] = 'c%d user-layout row stores' % c
+    names[b0 + 13] = 'c%d pack + end barrier' % c
+prev = 0
+print('stamps of the LAST step (T-1) of the persistent launch, median over 256 workgroups; unit = 100 shader cycles (s_memtime)')
+for s in sorted(names):
+    d = st[:, s] - st[:, prev]
+    print('%-34s +%7.2f   (min %.2f max %.2f)   t = %.2f' % (names[s], np.median(d) / 100.0, d.min() / 100.0, d.max() / 100.0, np.median(st[:, s] - st[:, 0]) / 100.0))
+    prev = s
+
