@@ -60,7 +60,7 @@ def cpu_baseline(S, params, T, G, F, seconds_budget=20.0):
     from oracle import gcrnn_oracle as orc
     N = S.shape[1]
     rng = np.random.default_rng(1)
-    Bc = 32                                                    # ~10-20 s of host work in all (5 passes)
+    Bc = 8                                                     # bounded sample: ~0.6 s per pass, <= 5 passes -- the GPU region is not drowned by the host baseline
     X = rng.standard_normal((Bc, T, G, N)).astype(np.float32)
     h0 = np.zeros((Bc, F, N), np.float32)
     p32 = {k: v.astype(np.float32) for k, v in params.items()}
@@ -104,12 +104,14 @@ def parse_args(argv=None):
                     help='cfg2 = BASELINE configs[1] (the headline, default); cfg4 = configs[3] (seismic graph N=59, T=200: latency-bound); '
                          'cfg5 = configs[4] (N=100k, nnz=1e7 streaming CSR SpMM)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-secondary', action='store_true', help='skip the secondary points of the default line (fp32-accurate forward, bf16 training step)')
     ap.add_argument('--time-gating', action='store_true', help='secondary point: the time-gated cell (fwd or train); '
                     'the headline workload is the un-gated cell')
     ap.add_argument('--spatial-gating', default=None, choices=['node', 'edge'], help='secondary point: node- / edge-gated cell')
     ap.add_argument('--in-features', type=int, default=CFG['G'], help='secondary point: input features per node (the reference '
                     'drivers feed G = 1; the headline workload is G = F = 64)')
-    ap.add_argument('--hipgraph', type=int, default=0, help='replay the fused forward as one captured hipGraph (bf16 fwd)')
+    ap.add_argument('--hipgraph', type=int, default=None, help='replay the fused forward as one captured hipGraph (bf16 fwd); default: 1 when the '
+                    'capture succeeds (bit-identical replay, tests/test_fused.py), else eager')
     ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'], help='process-group backend ("nccl" is RCCL on ROCm; '
                     'gloo only with --dry-run)')
     ap.add_argument('--dry-run', action='store_true', help='launcher / rendezvous / reduction plumbing only: no GPU, no kernels '
@@ -326,9 +328,15 @@ def run_cfg2(ctx):
         opt = FlatAdam(cell.parameters(), lr=1e-3)
 
     runner = None
-    if args.mode == 'fwd' and args.dtype == 'bf16' and args.hipgraph:
+    if args.mode == 'fwd' and args.dtype == 'bf16' and args.hipgraph != 0 and args.spatial_gating is None:
         from gated_gcrnns_amd.ops import FusedForwardGraph
-        runner = FusedForwardGraph(cell, B, T, X=X, h0=h0)      # captured on the caller's own tensors: no staging copy
+        try:
+            runner = FusedForwardGraph(cell, B, T, X=X, h0=h0)      # captured on the caller's own tensors: no staging copy
+        except Exception as e:                                      # noqa: BLE001 -- default "auto": fall back to eager launches, say so
+            if args.hipgraph:
+                raise
+            sys.stderr.write('bench.py: hipGraph capture failed (%s); eager launches\n' % e)
+            runner = None
 
     def step():
         if args.mode == 'fwd':
@@ -348,7 +356,7 @@ def run_cfg2(ctx):
     value = world * B * args.steps / wall
 
     # ---- dominant kernel: the fused step kernel, timed live with HIP events on the stream it is launched on ----
-    kern = None
+    kern, native = None, None
     if args.dtype == 'bf16' and args.mode == 'fwd' and not args.time_gating and args.spatial_gating is None:
         from gated_gcrnns_amd import ops
         with torch.no_grad():
@@ -357,7 +365,8 @@ def run_cfg2(ctx):
             torch.cuda.synchronize()
             kern = ops.time_fused_step_kernel(X, h0, cell.weight_A, cell.weight_B, cell.bias, cell.graph, reps=3)
             if kern.get('inline_pack'):          # for comparison with earlier rounds: the same launches without the inline pack of x_{t+1}
-                kern['bare_avg_us'] = ops.time_fused_step_kernel(X, h0, cell.weight_A, cell.weight_B, cell.bias, cell.graph, reps=3, inline=False)['avg_us']
+                kern['bare_launch_avg_us'] = ops.time_fused_step_kernel(X, h0, cell.weight_A, cell.weight_B, cell.bias, cell.graph, reps=3, inline=False)['launch_avg_us']
+            native = ops.time_fused_step_kernel(X, h0, cell.weight_A, cell.weight_B, cell.bias, cell.graph, reps=3, inline=False, user_layout=False)
     kern3 = None
     if args.dtype == 'f32' and args.mode == 'fwd' and not args.time_gating and args.spatial_gating is None:
         from gated_gcrnns_amd import ops
@@ -389,31 +398,46 @@ def run_cfg2(ctx):
     if ar is not None:
         out['config'].update(ar)
     if kern is not None:
-        # algorithmic bytes of ONE launch (one time step for the whole batch): read x_t, read h_{t-1}, write h_t
-        kbytes = elt * N * (G + 2 * F) * B
-        kach = kbytes / (kern['avg_us'] * 1e-6) / 1e9
-        tj = profile_traffic('step_kernel_traffic.json', B)
+        # algorithmic bytes of ONE launch: per unit (one time step of one sequence) read x_t, read h_{t-1}, write h_t; a launch
+        # of the sequence-resident persistent kernel covers T steps of the whole batch, one of the chunk-parallel kernel one step
+        spl = kern['steps_per_launch']
+        kbytes = elt * N * (G + 2 * F) * B * spl
+        kach = kbytes / (kern['launch_avg_us'] * 1e-6) / 1e9
+        tname = 'seq_kernel_traffic.json' if kern['kernel'] == 'fused_seq_kernel' else 'step_kernel_traffic.json'
+        tj = profile_traffic(tname, B)
         Gp = 64 if G > 32 else 32
-        mfma_flops = 2.0 * 1024 * K * F * (F + Gp) * B                 # executed on the matrix cores per launch (1024 padded node rows)
+        mfma_flops = 2.0 * 1024 * K * F * (F + Gp) * B * spl           # executed on the matrix cores per launch (1024 padded node rows)
+        kdesc = ('fused_seq_kernel<5,2,%d,0> (sequence-resident persistent kernel: one launch = all T = %d time steps of the whole batch)' % (2 if G > 32 else 1, spl)
+                 if kern['kernel'] == 'fused_seq_kernel' and spl > 1 else
+                 '%s<5,2,%d> (one launch = one time step of the whole batch)' % (kern['kernel'], 2 if G > 32 else 1))
         out['roofline'] = {'bound': 'hbm', 'achieved': kach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                            'frac': kach / HBM_PEAK_GBS, 'traffic': tj['hbm_bytes_per_launch'] if tj else None,
-                           'kernel': 'fused_step_kernel<5,2,%d> (one launch = one time step of the whole batch)' % (2 if G > 32 else 1),
-                           'kernel_avg_us': kern['avg_us'], 'launches_timed': kern['launches'],
+                           'kernel': kdesc, 'kernel_avg_us': kern['launch_avg_us'], 'launches_timed': kern['launches'],
+                           'steps_per_launch': spl, 'us_per_time_step': kern['avg_us'],
                            'algorithmic_bytes_per_launch': kbytes,
-                           'gflop_per_launch': flops_per_seq(1, N, nnz, K, G, F) * B / 1e9,
-                           'mfma_util': mfma_flops / (kern['avg_us'] * 1e-6) / 1e12 / MFMA_BF16_PEAK_TFLOPS,
+                           'gflop_per_launch': flops_per_seq(1, N, nnz, K, G, F) * B * spl / 1e9,
+                           'mfma_util': mfma_flops / (kern['launch_avg_us'] * 1e-6) / 1e12 / MFMA_BF16_PEAK_TFLOPS,
                            'mfma_util_note': 'taps GEMM flops executed per launch / duration / 2.5 PF dense bf16 peak'
                                              + (' (PMC: SQ_VALU_MFMA_BUSY_CYCLES %.3g per launch)' % tj['mfma_busy_cycles'] if tj and 'mfma_busy_cycles' in tj else ''),
                            'whole_step_GBps': achieved, 'device_ms_per_step': 1e3 * step_s}
         out['roofline']['hop_state_image'] = ('bf16 rows, neighbour rows summed on the matrix cores (one-hot A operand; uniform-weight graph)'
                                               if ops.fused_img16_plan(cell.graph, False, None) is not None else 'fp32 rows, packed VALU sums')
         if kern.get('inline_pack'):
-            # uniform-weight graph: every launch ALSO lays out x_{t+1} (the former pack pass over X: 2 N G B more bytes per launch that
-            # `achieved` does not count). frac is that of the launch as issued; the bare step kernel is timed next to it.
-            out['roofline']['inline_pack'] = {'extra_bytes_per_launch': 2 * elt * N * G * B, 'bare_kernel_avg_us': kern['bare_avg_us'],
-                                              'bare_frac': kbytes / (kern['bare_avg_us'] * 1e-6) / 1e9 / HBM_PEAK_GBS,
-                                              'note': 'each launch also lays out the next step input from the user layout (LDS-DMA during the last '
+            # uniform-weight graph: every step ALSO lays out x_{t+1} (the former pack pass over X: 2 N G B more bytes per step that
+            # `achieved` does not count). frac is that of the launch as issued; the bare kernel is timed next to it.
+            out['roofline']['inline_pack'] = {'extra_bytes_per_launch': 2 * elt * N * G * B * spl, 'bare_kernel_avg_us': kern['bare_launch_avg_us'],
+                                              'bare_frac': kbytes / (kern['bare_launch_avg_us'] * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                                              'note': 'each step also lays out the next step input from the user layout (LDS-DMA during the last '
                                                       'hop); the separate pack pass over X (0.5 ms per forward at B = 256) is gone'}
+        if native is not None:
+            # the same kernel on the sequence-major arrays alone (the cell's `native_layout` output is a view of the state
+            # image): no user-layout copy of h_t, no lay-out of x_{t+1} -- the launch moves what the algorithm needs
+            out['roofline_native_layout'] = {'bound': 'hbm', 'achieved': kbytes / (native['launch_avg_us'] * 1e-6) / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                                             'frac': kbytes / (native['launch_avg_us'] * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                                             'traffic': tj.get('native_hbm_bytes_per_launch') if tj else None,
+                                             'kernel_avg_us': native['launch_avg_us'], 'us_per_time_step': native['avg_us'],
+                                             'steps_per_launch': native['steps_per_launch'], 'algorithmic_bytes_per_launch': kbytes,
+                                             'note': 'sequence-major X in, sequence-major H out (views): GGCRNNCell.forward_native'}
     elif kern3 is not None:
         # the fp32-accurate fused step (three bf16 planes per operand): algorithmic bytes = the fp32 tensors of the API
         kbytes = 4 * N * (G + 2 * F) * B
@@ -435,9 +459,89 @@ def run_cfg2(ctx):
                                'fused kernels' if args.dtype == 'bf16' else 'composed path'),
                            'algorithmic_bytes_per_step': abytes, 'device_ms_per_step': 1e3 * step_s,
                            'gflop_per_step': flops_per_seq(T, N, nnz, K, G, F) * B / 1e9}
+    if (world == 1 and not args.no_secondary and args.dtype == 'bf16' and args.mode == 'fwd' and not args.time_gating
+            and args.spatial_gating is None and G == CFG['G']):
+        del X, h0
+        out['secondary'] = secondary_points(ctx, S, params, B)
     if not args.no_cpu_baseline and world == 1:          # the host baseline is a single-GPU-run item (rank 0, N = 1)
         out['cpu_baseline'] = cpu_baseline(S, params, T, G, F)
     return out
+
+
+def _timed(fn, steps, warmup):
+    """(seconds per call) of fn: `warmup` untimed calls, then `steps` calls between two synchronisations."""
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps
+
+
+def secondary_points(ctx, S, params, B, steps=8, warmup=2):
+    """Two more points of the SAME workload, timed in this process next to the headline (single GPU): the forward at the north_star's
+    1e-5 fp32 tolerance (fused three-plane kernels) and one bf16 training step (fp32 master weights: forward, L1 loss, BPTT, Adam).
+    At most `steps` timed calls each; the headline fields are unaffected."""
+    import gc
+    import gated_gcrnns_amd.Utils.graphML as gml
+    from gated_gcrnns_amd import ops
+    from gated_gcrnns_amd.optim import FlatAdam
+    from gated_gcrnns_amd.Utils.miscTools import batchTimeL1Loss
+    dev = ctx['dev']
+    N, K, T, G, F = CFG['N'], CFG['K'], CFG['T'], CFG['G'], CFG['F']
+    sec = {}
+
+    def fresh_cell(dtype):
+        torch.manual_seed(0)
+        c = gml.GGCRNNCell(G, F, K, K, torch.tanh, False, None, 1, True)
+        c.addGSO(torch.tensor(S))
+        c.load_state_dict({k: torch.tensor(v) for k, v in params.items()})
+        return c.to(dev).to(dtype)
+
+    gen = torch.Generator(device=dev); gen.manual_seed(99)
+    # ---- fp32-accurate forward (x3 kernels): <= 1e-5 against the fp64 oracle (tests/test_fused.py) ----
+    try:
+        cell = fresh_cell(torch.float32)
+        X = torch.randn(B, T, G, N, device=dev, dtype=torch.float32, generator=gen)
+        h0 = torch.zeros(B, F, N, device=dev, dtype=torch.float32)
+        with torch.no_grad():
+            if cell._use_fused_x3(X, h0):
+                dt = _timed(lambda: cell(X, h0), steps, warmup)
+                k3 = ops.time_fused_x3_kernel(X, h0, cell.weight_A, cell.weight_B, cell.bias, cell.graph, reps=1)
+                kb = 4 * N * (G + 2 * F) * B
+                sec['f32_x3'] = {'value': B / dt, 'unit': 'sequences/s', 'ms_per_step': 1e3 * dt, 'steps': steps, 'dtype': 'f32',
+                                 'tolerance': '<= 1e-5 abs against the fp64 oracle (north_star)', 'kernel_avg_us': k3['avg_us'],
+                                 'frac': kb / (k3['avg_us'] * 1e-6) / 1e9 / HBM_PEAK_GBS, 'algorithmic_bytes_per_launch': kb,
+                                 'kernel': 'fused_step_x3_kernel (one launch = one time step; bytes = the fp32 tensors of the API)'}
+        del cell, X, h0
+    except Exception as e:      # noqa: BLE001 -- a secondary point never takes the headline line down
+        sec['f32_x3'] = {'error': str(e)[:200]}
+    gc.collect(); torch.cuda.empty_cache()
+    # ---- bf16 training step ----
+    try:
+        cell = fresh_cell(torch.float32)
+        X = torch.randn(B, T, G, N, device=dev, dtype=torch.float32, generator=gen).to(torch.bfloat16)
+        h0 = torch.zeros(B, F, N, device=dev, dtype=torch.bfloat16)
+        target = torch.randn(B, T, F, N, device=dev, dtype=torch.float32, generator=gen).to(torch.bfloat16)
+        opt = FlatAdam(cell.parameters(), lr=1e-3)
+
+        def tstep():
+            opt.zero_grad()
+            batchTimeL1Loss(cell(X, h0), target).backward()
+            opt.step()
+
+        dt = _timed(tstep, steps, warmup)
+        sec['train_bf16'] = {'value': B / dt, 'unit': 'sequences/s', 'ms_per_step': 1e3 * dt, 'steps': steps, 'dtype': 'bf16',
+                             'what': 'zero_grad, forward, L1 loss, BPTT (data chain + weight gradient), FlatAdam; fp32 master weights',
+                             'frac': algorithmic_bytes_per_seq(T, N, G, F, 2) * B / dt / 1e9 / HBM_PEAK_GBS,
+                             'frac_note': 'forward algorithmic bytes / step time (as --mode train reports it)'}
+        del cell, X, h0, target, opt
+    except Exception as e:      # noqa: BLE001
+        sec['train_bf16'] = {'error': str(e)[:200]}
+    gc.collect(); torch.cuda.empty_cache()
+    return sec
 
 
 def run_cfg5(ctx):

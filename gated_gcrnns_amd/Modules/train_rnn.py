@@ -108,8 +108,9 @@ def MultipleModels(modelsDict, xTrain, yTrain, xValid, yValid, nEpochs, batchSiz
             lo, hi = shard_range(nGlobal, rank, world)
             idx = idx[lo:hi]
             share = len(idx) / float(nGlobal)                                     # this rank's weight in the flat all-reduce
-            xb = xTrain[idx].view(len(idx), seqLen, -1).to(dev, dt)
-            yb = yTrain[idx].view(len(idx), seqLen, -1).to(dev, dt)
+            # (explicit last dimension: an EMPTY shard -- a global batch smaller than the world -- cannot infer a -1)
+            xb = xTrain[idx].reshape(len(idx), seqLen, xTrain[0].numel() // seqLen).to(dev, dt)
+            yb = yTrain[idx].reshape(len(idx), seqLen, yTrain[0].numel() // seqLen).to(dev, dt)
             for key, m in modelsDict.items():
                 assert 'GCRNN' in key or 'gcrnn' in key or 'GCRnn' in key        # reference dispatches on the name
                 xo = xb[:, :, m.order] if m.order is not None else xb

@@ -642,7 +642,22 @@ class GGCRNNCell(nn.Module):
     def _forward_fused(self, X, h0, last_only=False, head=None):
         gates = self._fused_gates() if self.time_gating == True else None  # noqa: E712
         Xp, wA = ops.fused_pad_operands(X, self.weight_A)
-        return ops.fused_cell_forward(Xp, h0, wA, self.weight_B, self.bias, self.graph, gates, last_only=last_only, head=head)
+        return ops.fused_cell_forward(Xp, h0, wA, self.weight_B, self.bias, self.graph, gates, last_only=last_only, head=head,
+                                      native_out=bool(getattr(self, 'native_layout', False)) and head is None)
+
+    def forward_native(self, xs, h0s=None):
+        """The un-gated recurrence on the fused kernels' own layout end to end (inference): xs [T][B][NPad][G] bf16 sequence-major
+        (ops.to_sequence_major, or a generator that emits it), h0s [B][NPad][F] or None (zeros) -> hs [T][B][NPad][F] bf16;
+        `hs.permute(1, 0, 3, 2)[..., :N]` is H in the reference's B x T x F x N shape (graphML.py:2425-2427) without a copy.
+        The module flag `native_layout = True` gives the same view from the ordinary forward(X, h0) (user-layout X in)."""
+        assert self.graph is not None and self.time_gating != True and self.spatial_gating is None  # noqa: E712
+        assert not torch.is_grad_enabled() or not any(p.requires_grad for p in self.parameters()), 'forward_native is an inference path'
+        assert xs.dtype == torch.bfloat16 and self.weight_A.dtype == torch.bfloat16 and self.sigma in (torch.tanh, nn.functional.tanh)
+        wA = self.weight_A
+        if wA.shape[3] != xs.shape[3]:                   # G < 32: the padded taps of ops.fused_pad_operands
+            wA = torch.nn.functional.pad(wA.detach(), (0, xs.shape[3] - wA.shape[3]))
+        assert ops.fused_supported(self.N, self.F, xs.shape[3], self.Kin, self.Kst, torch.bfloat16, self.E), 'shape outside the fused kernels'
+        return ops.fused_cell_forward_native(xs, h0s, wA, self.weight_B, self.bias, self.graph, self.N)
 
     def forward_with_head(self, X, h0, weight, bias):
         """Inference of cell + output head Linear(F -> 1) shared by all nodes (the regression model's `multipMlp` head with one

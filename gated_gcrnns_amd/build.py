@@ -41,21 +41,35 @@ def build(force=False, verbose=True):
         fcntl.flock(lock, fcntl.LOCK_EX)
         if not force and not needs_build():
             return LIBPATH
-        return _build_locked(verbose)
+        return _build_locked(verbose, force)
 
 
-def _build_locked(verbose):
+def _flags_stamp():
+    import hashlib
+    return hashlib.sha256((' '.join([HIPCC] + FLAGS + [os.environ.get('GCRNN_EXTRA_FLAGS', '')])).encode()).hexdigest()
+
+
+def _build_locked(verbose, force=False):
     # compile objects one by one (parallel-friendly, clearer errors), then link
     objs = []
     procs = []
     headers = glob.glob(os.path.join(CSRC, '*.h')) + glob.glob(os.path.join(CSRC, '*.inc')) + [os.path.join(os.path.dirname(PKG), 'include', 'gcrnn.h')]
     hdr_time = max(os.path.getmtime(h) for h in headers)
+    # objects are reused only when they were built with the same compiler and flags (force=True rebuilds everything)
+    stamp_file = os.path.join(LIBDIR, '.flags')
+    stamp = _flags_stamp()
+    try:
+        same_flags = open(stamp_file).read().strip() == stamp
+    except OSError:
+        same_flags = False
+    reuse = same_flags and not force and not os.environ.get('GCRNN_REBUILD_ALL')
+    extra = os.environ.get('GCRNN_EXTRA_FLAGS', '').split()
     for src in sources():
         obj = os.path.join(LIBDIR, os.path.basename(src) + '.o')
         objs.append(obj)
-        if os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(src), hdr_time) and not os.environ.get('GCRNN_REBUILD_ALL'):
-            continue                             # object newer than its source and every header: keep it
-        cmd = [HIPCC] + [f for f in FLAGS if f != '-shared'] + ['-c', src, '-o', obj]
+        if reuse and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(src), hdr_time):
+            continue                             # object newer than its source and every header, same flags: keep it
+        cmd = [HIPCC] + [f for f in FLAGS if f != '-shared'] + extra + ['-c', src, '-o', obj]
         if verbose:
             print(' '.join(cmd), flush=True)
         procs.append((src, subprocess.Popen(cmd)))
@@ -67,6 +81,8 @@ def _build_locked(verbose):
     if verbose:
         print(' '.join(cmd), flush=True)
     subprocess.check_call(cmd)
+    with open(stamp_file, 'w') as fh:
+        fh.write(stamp + '\n')
     os.replace(tmp, LIBPATH)                 # atomic: a concurrent dlopen sees the old or the new library, never a partial file
     return LIBPATH
 

@@ -304,6 +304,27 @@ extern "C" int gcrnn_fused_inline_pack_supported(int64_t N, int64_t F, int64_t G
 #endif
 }
 
+// Will gcrnn_fused_forward_bf16 (backward = 0) / gcrnn_fused_backward_data_bf16 (backward != 0) run this problem on the sequence-
+// resident persistent kernel (gcrnn_fused_seq.h: ONE launch for all T steps, one workgroup per sequence) rather than on T launches
+// of the chunk-parallel step kernel? Un-gated cell without a fused head, uniform-weight bf16-image plan (img16), a batch that fills
+// whole rounds of the chip (cost model in gcrnn_fused_seq.h; GCRNN_SEQ_KERNEL=0 / GCRNN_SEQ_MIN_B override it). Returns the number
+// of time steps one launch covers: T (persistent), 1 (the same kernel launched per step: GCRNN_SEQ_PERSIST=0) or 0 (chunk-parallel).
+extern "C" int64_t gcrnn_fused_seq_steps_per_launch(int64_t B, int64_t T, int64_t N, int64_t F, int64_t G, int64_t K, int64_t entries,
+                                                    double uniform_w, int img16, int inline_pack, int backward) {
+#if GCRNN_HOP_ASM && GCRNN_STEP_WAVES == 8
+  if (uniform_w == 0.0 || !img16 || N <= 0 || N > NP || B <= 0 || T <= 0 || entries % 4 || !gcrnn_fused_supported(N, F, G > 0 ? (G > 32 ? 64 : 32) : F, K)) return 0;
+  if (F != 32 && F != 64) return 0;
+  const int nch = (int)(F / FC);
+  if (!fused_seq_wanted(B, nch)) return 0;
+  const int64_t ks = backward ? F / 32 : (F + G) / 32, pkrows = backward ? F : G;
+  const size_t need = (size_t)33 * 1024 + 2 * (size_t)K * ks * 1024 + (size_t)entries * 32 + (inline_pack ? (size_t)pkrows * (NP / nch) * 2 : 0);
+  if (need > 160 * 1024) return 0;
+  return fused_seq_persistent() ? (backward ? (T > 1 ? T - 1 : 1) : T) : 1;
+#else
+  return 0;
+#endif
+}
+
 extern "C" int gcrnn_fused_gate_prepass_bf16(const void* xs, const void* h0, const void* wpack, const float* bias,
                                              const float* gate_w, float* gate_out, void* cs, const int32_t* tile_nodes,
                                              const int32_t* tile_off, const int32_t* ell_col, const float* ell_val,

@@ -450,17 +450,20 @@ static size_t fused_seq_lds(int64_t entries, bool inline_pack, int pkrows) {
   return need <= 160 * 1024 ? need : 0;
 }
 
-// Which launches take the sequence-resident kernel: it has B workgroups, so it needs B to fill the chip (GCRNN_SEQ_MIN_B, default
-// 160 of the 256 CUs); GCRNN_SEQ_KERNEL=0 keeps the chunk-parallel kernel (A/B, tests).
+// Which launches take the sequence-resident kernel: it has ONE workgroup per sequence, so it wins where whole rounds of 256
+// sequences fill the chip. Cost model (measured at B = 256, K = 5: a sequence costs the sequence-resident kernel 0.875 x the time of
+// its F/16 chunk items in the chunk-parallel kernel, which deals 256 chunk items per round): rounds_seq x 0.875 NCH < rounds_chunk.
+// GCRNN_SEQ_MIN_B=n overrides the model (tests), GCRNN_SEQ_KERNEL=0 keeps the chunk-parallel kernel (A/B).
 // GCRNN_SEQ_PERSIST=0: one launch per time step instead of one per forward / chain (A/B)
 static inline bool fused_seq_persistent() {
   const char* e = getenv("GCRNN_SEQ_PERSIST");
   return !(e && e[0] == '0');
 }
-static inline bool fused_seq_wanted(int64_t B) {
+static inline bool fused_seq_wanted(int64_t B, int nch) {
   const char* off = getenv("GCRNN_SEQ_KERNEL");      // read per call (once per forward / chain, not per step): tests switch it in-process
   if (off && off[0] == '0') return false;
   const char* mb = getenv("GCRNN_SEQ_MIN_B");
-  const int min_b = mb ? atoi(mb) : 160;
-  return B >= (min_b < 1 ? 1 : min_b);
+  if (mb) return B >= (atoi(mb) < 1 ? 1 : atoi(mb));
+  const double rounds_seq = (double)((B + 255) / 256), rounds_chunk = (double)((B * nch + 255) / 256);
+  return rounds_seq * 0.875 * nch < rounds_chunk;
 }

@@ -37,6 +37,10 @@
 #define GCRNN_HOP_ASM 1      // 1: the hop gather stream is ONE asm block, three groups deep (gcrnn_hop_asm.inc); 0: the two-deep macro stream (A/B)
 #endif
 
+#if (!GCRNN_HOP_ASM || (defined(GCRNN_STEP_WAVES) && GCRNN_STEP_WAVES != 8)) && !defined(GCRNN_DIAGNOSTIC_STREAMS)
+#error "the compiler-scheduled asm hop pipelines (GCRNN_HOP_ASM=0 / GCRNN_STEP_WAVES != 8) are A/B builds: a spill inside them corrupts results silently (cdna_hip_programming.md 5.7). Build with -DGCRNN_DIAGNOSTIC_STREAMS and check ScratchSize == 0 (tools/kernel_resources.sh)."
+#endif
+
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
@@ -1140,7 +1144,7 @@ int fused_launch_t(int mode /*0 plain, 1 gated, 2 gate pre-pass, 3 BPTT data gra
 #if GCRNN_HOP_ASM && GCRNN_STEP_WAVES == 8
   // Sequence-resident kernel (gcrnn_fused_seq.h): one workgroup per sequence keeps the operand in registers for all chunks -- the
   // un-gated forward steps and the plain BPTT data chain on uniform-weight bf16-image plans, when the batch fills the chip.
-  if (ga.uniform_w != 0.f && ga.img16 && ga.ell_col4 && !head && !step_events && fused_seq_wanted(B) && (mode == 0 || mode == 3)) {
+  if (ga.uniform_w != 0.f && ga.img16 && ga.ell_col4 && !head && !step_events && fused_seq_wanted(B, NCH) && (mode == 0 || mode == 3)) {
     const size_t slds = fused_seq_lds<K, HS, XS>(ga.entries, inline_pack, mode == 3 ? F : G);
     const unsigned sgrid = (unsigned)(B < 256 ? B : 256);
     const bool persist = fused_seq_persistent();

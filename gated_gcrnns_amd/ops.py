@@ -337,7 +337,7 @@ def fused_supported(N, F, G, Kin, Kst, dtype, E=1):
             bool(lib.gcrnn_fused_supported(int(N), int(F), int(Gp), int(max(Kin, Kst)))))
 
 
-def time_fused_step_kernel(X, h0, wA, wB, bias, graph, reps=3, inline=None):
+def time_fused_step_kernel(X, h0, wA, wB, bias, graph, reps=3, inline=None, user_layout=True):
     """Average duration of ONE fused step launch, measured with HIP events on the launch stream
     (inputs pre-packed, only the T step launches sit between the events; on uniform-weight graphs each launch also lays out
     x_{t+1}, exactly as in fused_cell_forward)."""
@@ -362,7 +362,8 @@ def time_fused_step_kernel(X, h0, wA, wB, bias, graph, reps=3, inline=None):
                                        F, G, Kin, Kst, st), 'pack_weights')
     b32 = bias.detach().float().contiguous().view(-1) if bias is not None else None
     # same launch configuration as fused_cell_forward: the kernel also writes the user-layout output when it can
-    H = torch.empty((B, T, F, N), dtype=torch.bfloat16, device=dev) if N % 8 == 0 else None
+    # (user_layout=False: sequence-major in and out only -- what GGCRNNCell.forward_native issues)
+    H = torch.empty((B, T, F, N), dtype=torch.bfloat16, device=dev) if (N % 8 == 0 and user_layout) else None
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize()
     e0.record()
@@ -376,7 +377,12 @@ def time_fused_step_kernel(X, h0, wA, wB, bias, graph, reps=3, inline=None):
               'fused_forward')
     e1.record()
     torch.cuda.synchronize()
-    return {'avg_us': 1e3 * e0.elapsed_time(e1) / (reps * T), 'launches': reps * T, 'inline_pack': bool(inline)}
+    # time steps one launch covers: T on the sequence-resident persistent kernel (gcrnn_fused_seq.h), else 1 (one launch per step)
+    spl = int(lib.gcrnn_fused_seq_steps_per_launch(B, T, N, F, G, K, int((plan16 or plan)['entries']), float(plan.get('uniform_w', 0.0)),
+                                                   1 if plan16 else 0, 1 if inline else 0, 0))
+    per_step = 1e3 * e0.elapsed_time(e1) / (reps * T)
+    return {'avg_us': per_step, 'launches': reps * T // max(spl, 1), 'inline_pack': bool(inline), 'steps_per_launch': max(spl, 1),
+            'launch_avg_us': per_step * max(spl, 1), 'kernel': 'fused_seq_kernel' if spl else 'fused_step_kernel'}
 
 
 def _fused_pack_weights(wA, wB, st):
@@ -508,7 +514,7 @@ def fused_time_gate(xs, h0s, wA_g, wB_g, bias_g, lin_w, lin_b, graph, N, store_s
 
 
 def fused_cell_forward(X, h0, wA, wB, bias, graph, gates=None, return_states=False, gate_values=None, packed=None,
-                       last_only=False, head=None):
+                       last_only=False, head=None, native_out=False):
     """Whole GGCRNNCell forward (un-gated or time-gated) on the fused bf16 step kernel.
 
     X: B x T x G x N bf16, h0: B x F x N bf16 (user layout) -> H: B x T x F x N bf16.
@@ -522,6 +528,9 @@ def fused_cell_forward(X, h0, wA, wB, bias, graph, gates=None, return_states=Fal
     head: None, or (weight 1 x F, bias [1] or None) of an output head Linear(F -> 1) shared by all nodes (the regression model's
     `multipMlp` head with one output, architectures.py:1616-1627): it is evaluated in the step kernel's epilogue, H is never written
     in the user layout, and the function returns y: B x T x 1 x N (fp32) instead of H.
+    native_out: H is returned as a VIEW of the sequence-major state image the recurrence keeps anyway (hs [T][B][NPad][F]:
+    hs.permute(1, 0, 3, 2)[..., :N] has the reference's B x T x F x N shape, reference graphML.py:2425-2427) -- the launches skip the
+    user-layout copy of every h_t (a third of the bytes they write); callers that need contiguity call .contiguous() themselves.
     """
     require_device(X, h0, wA, wB, bias)
     if packed is None:
@@ -581,8 +590,16 @@ def fused_cell_forward(X, h0, wA, wB, bias, graph, gates=None, return_states=Fal
         if head[1] is not None:
             y = y + head[1].detach().float().reshape(())
         return y.permute(1, 0, 2).unsqueeze(2).contiguous()          # B x T x 1 x N
-    H = torch.empty((B, 1 if last_only else T, F, N), dtype=torch.bfloat16, device=dev)
     plan16 = fused_img16_plan(graph, gi is not None, None)
+    if native_out:
+        assert not return_states
+        check(lib.gcrnn_fused_forward_bf16(_p(xs), _p(h0s), _p(hs), _p(wpack), _p(b32), _p(gi), _p(gf), *_fused_graph_args(plan16 or plan),
+                                           B, T, N, F, G, K, None, (2 if plan16 else 0), evs,
+                                           plan.get('uniform_w', 0.0), _p(X) if inline else None, None, None, st),
+              'fused_forward')
+        Hv = hs.permute(1, 0, 3, 2)[:, :, :, :N]                     # B x T x F x N, strides of the sequence-major image
+        return Hv[:, T - 1:] if last_only else Hv
+    H = torch.empty((B, 1 if last_only else T, F, N), dtype=torch.bfloat16, device=dev)
     check(lib.gcrnn_fused_forward_bf16(_p(xs), _p(h0s), _p(hs), _p(wpack), _p(b32), _p(gi), _p(gf), *_fused_graph_args(plan16 or plan),
                                        B, T, N, F, G, K, _p(H) if direct else None, int(last_only) | (2 if plan16 else 0), evs,
                                        plan.get('uniform_w', 0.0), _p(X) if inline else None, None, None, st),
@@ -593,6 +610,44 @@ def fused_cell_forward(X, h0, wA, wB, bias, graph, gates=None, return_states=Fal
     if return_states:
         return hs_all, plan, H
     return H
+
+
+def fused_cell_forward_native(xs, h0s, wA, wB, bias, graph, N):
+    """Un-gated GGCRNNCell forward on sequence-major arrays end to end: xs [T][B][NPad][G] bf16 (rows >= N zero; G = 32 or 64: the
+    fused kernels' input widths), h0s [B][NPad][F] bf16 or None (= zeros, every call site of the reference: train_rnn.py:256) ->
+    hs [T][B][NPad][F] bf16 (rows >= N zero). No pack, no inline pack, no user-layout copy: the launch moves the algorithm's own
+    bytes (read x_t, read h_{t-1}, write h_t). `hs.permute(1, 0, 3, 2)[..., :N]` is the reference's B x T x F x N view of it."""
+    require_device(xs, wA, wB, bias)
+    T, B, npad, G = xs.shape
+    F = wA.shape[0]
+    K = max(wA.shape[2], wB.shape[2])
+    plan = graph.fused_plan()
+    assert npad == plan['npad'] and xs.dtype == torch.bfloat16 and xs.is_contiguous() and wA.shape[3] == G
+    st = _stream()
+    hs_all = torch.empty((T + 1, B, npad, F), dtype=torch.bfloat16, device=xs.device)
+    if h0s is None:
+        hs_all[0].zero_()
+    else:
+        assert tuple(h0s.shape) == (B, npad, F) and h0s.dtype == torch.bfloat16
+        hs_all[0].copy_(h0s)
+    wpack = _fused_pack_weights(wA.detach(), wB.detach(), st)
+    b32 = bias.detach().float().contiguous().view(-1) if bias is not None else None
+    plan16 = fused_img16_plan(graph, False, None)
+    check(lib.gcrnn_fused_forward_bf16(_p(xs), _p(hs_all[:1]), _p(hs_all[1:]), _p(wpack), _p(b32), None, None, *_fused_graph_args(plan16 or plan),
+                                       B, T, N, F, G, K, None, (2 if plan16 else 0), None, plan.get('uniform_w', 0.0), None, None, None, st),
+          'fused_forward')
+    return hs_all[1:]
+
+
+def to_sequence_major(X, graph):
+    """user layout X [B][T][C][N] bf16 -> the fused kernels' sequence-major array [T][B][NPad][C] (rows >= N zero)."""
+    require_device(X)
+    B, T, Cc, N = X.shape
+    npad = graph.fused_plan()['npad']
+    Xc = X.contiguous()
+    xs = torch.empty((T, B, npad, Cc), dtype=torch.bfloat16, device=X.device)
+    check(lib.gcrnn_pack_seq_major(_lib.BF16, _p(Xc), _p(xs), B, T, Cc, N, npad, None, _stream()), 'pack_seq')
+    return xs
 
 
 # ------------------------------------------------------------------------------------------ node-gated cell on the fused path
@@ -1668,18 +1723,23 @@ class _L1Loss(torch.autograd.Function):
         partial = torch.empty((int(lib.gcrnn_l1_loss_blocks(n)),), dtype=acc_dt, device=xc.device)
         check(lib.gcrnn_l1_loss(dtype_code(xc.dtype), _p(xc), _p(yc), _p(grad), _p(partial), n, 1.0 / n, _stream()), 'l1_loss')
         ctx.grad = grad
-        ctx.scale = torch.ones((1,), dtype=acc_dt, device=xc.device) if want else None      # what ctx.grad currently carries (device scalar)
+        ctx.used = False
         return (partial.sum() / n).to(x.dtype)
 
     @staticmethod
     def backward(ctx, gout):
         g = ctx.grad
         if g is not None:
+            if ctx.used:
+                # the buffer was scaled in place and handed out by the first backward: a second one (retain_graph) would rescale
+                # gradients that other tensors already alias -- refuse, as the fused gates do
+                raise RuntimeError('batchTimeL1Loss: backward through the fused loss a second time (its gradient buffer was released '
+                                   'by the first backward); recompute the loss')
+            ctx.used = True
             # chain rule through the scalar loss WITHOUT a pass over g when the upstream gradient is 1 (loss.backward()): the kernel
-            # reads the device scalar r = gout / (scale g already carries) and returns at once when r == 1 (no host sync: capturable)
-            r = (gout.detach().to(ctx.scale.dtype).reshape(1) / ctx.scale).contiguous()
+            # reads the device scalar r = gout and returns at once when r == 1 (no host sync: capturable)
+            r = gout.detach().to(torch.float64 if g.dtype == torch.float64 else torch.float32).reshape(1).contiguous()
             check(lib.gcrnn_scale_unless_one(dtype_code(g.dtype), _p(g), _p(r), g.numel(), _stream()), 'scale_unless_one')
-            ctx.scale = gout.detach().to(ctx.scale.dtype).reshape(1).clone()
         return (g if ctx.needs_input_grad[0] else None), (-g if (g is not None and ctx.needs_input_grad[1]) else None)
 
 

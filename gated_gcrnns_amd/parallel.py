@@ -48,7 +48,6 @@ class FlatGradAllReduce(object):
         dev = self.params[0].device if self.params else torch.device('cpu')
         self.dtype = torch.float64 if any(p.dtype == torch.float64 for p in self.params) else torch.float32
         self.flat = torch.zeros(self.numel, dtype=self.dtype, device=dev)
-        self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
         self.views, self.staged = [], []
         off = 0
         for p in self.params:
@@ -60,6 +59,12 @@ class FlatGradAllReduce(object):
             else:
                 self.staged.append((p, v))
             off += n
+
+    @property
+    def world(self):
+        """Read at every use, never cached: the object may be built (optim.FlatAdam does, at model-building time) before
+        dist.init_process_group -- a world size frozen at 1 there would skip the collective and silently train on scaled gradients."""
+        return dist.get_world_size(self.group) if dist.is_available() and dist.is_initialized() else 1
 
     def nbytes(self):
         return self.numel * self.flat.element_size()
@@ -73,17 +78,23 @@ class FlatGradAllReduce(object):
                 p.grad = v
 
     def zero_grad(self):
-        """One memset instead of one per parameter."""
+        """One memset instead of one per parameter. Gradients that live OUTSIDE the buffer (a backward after someone set the grads to
+        None) are dropped, not copied back in: zero_grad means zero."""
         self.flat.zero_()
         for p, _ in self.staged:
             p.grad = None
-        self.attach_()
+        for p, v in zip(self.params, self.views):
+            if p.dtype == self.dtype and p.grad is not v:
+                p.grad = v
 
     def all_reduce_(self, weight=None):
         """Sum of per-rank gradients, each pre-scaled by `weight` (default 1/world: equal local batches and
         mean-reduced local losses then give exactly the gradient of the global-batch mean loss)."""
+        world = self.world
         if weight is None:
-            weight = 1.0 / self.world
+            weight = 1.0 / world
+        elif world == 1 and weight != 1.0 and dist.is_available() and dist.is_initialized():
+            raise RuntimeError('FlatGradAllReduce: a shard weight of %g in a process group of one rank' % weight)
         self.attach_()
         for p, v in self.staged:
             if p.grad is None:
@@ -92,7 +103,7 @@ class FlatGradAllReduce(object):
                 v.copy_(p.grad)
         if weight != 1.0:
             self.flat.mul_(weight)
-        if self.world > 1:
+        if world > 1:
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
         for p, v in self.staged:
             p.grad = v.to(p.dtype)

@@ -308,6 +308,13 @@ int gcrnn_fused_pack_weights(int wdtype, const void* wA, const void* wB, void* w
  * gathered rows (acc = init + w * sum). 0 = weighted graph image. The same trailing parameter exists on the gate pre-pass, the
  * filter-output pass, the node-gated steps and both BPTT data chains. */
 int gcrnn_fused_inline_pack_supported(int64_t N, int64_t F, int64_t G, int64_t K, int64_t entries, double uniform_w);
+/* Time steps ONE launch of gcrnn_fused_forward_bf16 (backward = 0) / gcrnn_fused_backward_data_bf16 (backward != 0) covers for this
+ * problem: T (T - 1 for the chain) when the sequence-resident persistent kernel takes it -- one workgroup per sequence keeps the
+ * operand [h_{t-1} | x_t] in registers for all F/16 chunks and runs every time step of the recurrence (the T-loop of
+ * Utils/graphML.py:2351-2427) inside one launch --, 1 when that kernel is launched per step (GCRNN_SEQ_PERSIST=0), 0 when the
+ * chunk-parallel step kernel runs (gated cells, fused head, weighted graphs, batches that do not fill rounds of 256 sequences). */
+int64_t gcrnn_fused_seq_steps_per_launch(int64_t B, int64_t T, int64_t N, int64_t F, int64_t G, int64_t K, int64_t entries,
+                                         double uniform_w, int img16, int inline_pack, int backward);
 int gcrnn_fused_forward_bf16(const void* xs, const void* h0, void* hs, const void* wpack, const float* bias,
                              const float* gi, const float* gf, const int32_t* tile_nodes, const int32_t* tile_off,
                              const int32_t* ell_col, const float* ell_val, const void* ell_val4, const void* ell_col4,

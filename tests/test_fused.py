@@ -1584,3 +1584,33 @@ def test_sequence_resident_bptt_chain_is_bit_identical(tg, N, F, K, monkeypatch)
     assert torch.equal(H0, H1) and g0.keys() == g1.keys() and len(g1) >= 4
     for n in g1:
         assert torch.equal(g0[n], g1[n]), n
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('N,F,G,K,B,T', [(1000, 64, 64, 5, 5, 4), (400, 32, 32, 3, 7, 3), (1008, 64, 64, 5, 257, 2), (1000, 64, 1, 3, 3, 3)])
+def test_native_layout_output_and_sequence_major_forward_are_bit_identical(N, F, G, K, B, T, monkeypatch):
+    """the cell output as a VIEW of the sequence-major state image (module flag `native_layout`: the launches skip
+    the user-layout copy of every h_t) and the forward on sequence-major arrays end to end (`forward_native`: no pack, no inline
+    pack) give the bits of the ordinary user-layout forward, on both step kernels."""
+    from gated_gcrnns_amd import ops
+    dev = torch.device('cuda:0')
+    cell, rng, _ = _uniform_cell(N, G, F, K, False, 81, dev)
+    X = torch.tensor(rng.standard_normal((B, T, G, N)), dtype=torch.float32, device=dev).to(torch.bfloat16)
+    h0 = torch.tensor(0.3 * rng.standard_normal((B, F, N)), dtype=torch.float32, device=dev).to(torch.bfloat16)
+    for seq in ('1', '0'):
+        monkeypatch.setenv('GCRNN_SEQ_KERNEL', seq)
+        monkeypatch.setenv('GCRNN_SEQ_MIN_B', '1')
+        with torch.no_grad():
+            cell.native_layout = False
+            H = cell(X, h0)
+            Hl = cell(X, h0, last_only=True)
+            cell.native_layout = True
+            Hv = cell(X, h0)
+            Hvl = cell(X, h0, last_only=True)
+            cell.native_layout = False
+            assert Hv.shape == H.shape and not Hv.is_contiguous() and torch.equal(Hv, H) and torch.equal(Hvl, Hl)
+            Xp, _ = ops.fused_pad_operands(X, cell.weight_A.detach())
+            xs = ops.to_sequence_major(Xp, cell.graph)
+            h0s = ops.to_sequence_major(h0.unsqueeze(1), cell.graph)[0]
+            hs = cell.forward_native(xs, h0s)
+            assert torch.equal(hs.permute(1, 0, 3, 2)[:, :, :, :N], H) and float(hs[:, :, N:].abs().max()) == 0.0

@@ -731,17 +731,22 @@ def test_bf16_parameters_without_bf16_kernels_run_on_fp32_views(sg, tg):
 @pytest.mark.parametrize('dt', [torch.float32, torch.bfloat16, torch.float64])
 def test_l1_loss_backward_rescales_in_place_only_when_needed(dt):
     """The loss kernel writes sign(x - y) / n in its forward; backward multiplies by the upstream gradient through a kernel that reads
-    the ratio (upstream / what the buffer already carries) from the device and returns at once when it is 1. Repeated backward calls
-    with different upstream gradients over one retained graph must each give upstream * sign / n."""
+    it from the device and returns at once when it is 1 (no pass over the gradient, no host sync). Any upstream value gives
+    upstream * sign / n (0 included); the buffer is handed out by that backward, so a second backward over a retained graph is
+    refused instead of rescaling gradients that are already out."""
     from gated_gcrnns_amd.Utils import miscTools
     dev = torch.device('cuda:0')
     gen = torch.Generator(device='cpu'); gen.manual_seed(8)
     x = torch.randn(6, 5, 8, 40, generator=gen, dtype=torch.float64).to(dt).to(dev).requires_grad_(True)
     y = torch.randn(6, 5, 8, 40, generator=gen, dtype=torch.float64).to(dt).to(dev)
-    loss = miscTools.batchTimeL1Loss(x, y)
     unit = torch.sign(x.detach().double() - y.double()) / x.numel()
-    for up in (1.0, 0.5, 0.5, 2.0, 1.0):
+    for up in (1.0, 0.5, 0.0, 2.0):
         x.grad = None
+        loss = miscTools.batchTimeL1Loss(x, y)
         loss.backward(torch.tensor(up, dtype=loss.dtype, device=dev), retain_graph=True)
         want = (up * unit).to(dt).double()
         assert float((x.grad.double() - want).abs().max()) <= (1e-2 if dt == torch.bfloat16 else 1e-7) * up / x.numel(), up
+        kept = x.grad.clone()
+        with pytest.raises(RuntimeError, match='second time'):
+            loss.backward(torch.tensor(3.0, dtype=loss.dtype, device=dev))
+        assert torch.equal(x.grad, kept)                 # what was handed out is untouched

@@ -156,3 +156,84 @@ def test_bench_self_launches_its_ranks():
     r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--dry-run'], capture_output=True, text=True,
                        env=env2, timeout=600)
     assert r.returncode != 0 and 'torch.distributed.run' in r.stderr
+
+
+class TinyGCRNN(torch.nn.Module):
+    """CPU stand-in with the surface MultipleModels touches (archit.stateGCRNN.weight_A for device / dtype, archit(x, h0))."""
+
+    def __init__(self, N):
+        super().__init__()
+        self.stateGCRNN = torch.nn.Module()
+        self.stateGCRNN.weight_A = torch.nn.Parameter(torch.randn(N, N, dtype=torch.float64) * 0.1)
+
+    def forward(self, x, h0):                       # x: B x T x 1 x N
+        return torch.tanh(x @ self.stateGCRNN.weight_A) + 0.0 * h0.sum()
+
+
+def harness_worker(rank, world, port, ret):
+    """MultipleModels with nTrain % batchSize < world: the last global batch has ONE sample, so rank 1's shard is empty. It
+    must still join every collective (zeros, weight 0) and end with the same parameters as rank 0 -- and as a single process
+    that trains on the whole batches (the empty slice used to die in `.view(0, T, -1)` while rank 0 hung)."""
+    from gated_gcrnns_amd.Modules.train_rnn import MultipleModels, TrainableModel
+    from gated_gcrnns_amd.optim import FlatAdam
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    N, T, nTrain, bs = 6, 3, 5, 4                     # batches of 4 and 1: the second one leaves rank 1 without a sample
+    g = torch.Generator().manual_seed(3)
+    xT = torch.randn(nTrain, T, N, dtype=torch.float64, generator=g)
+    yT = torch.randn(nTrain, T, N, dtype=torch.float64, generator=g)
+
+    def build():
+        torch.manual_seed(5)
+        m = TinyGCRNN(N)
+        return m, TrainableModel(m, torch.nn.functional.l1_loss, FlatAdam(m.parameters(), lr=1e-2), 'TinyGCRNN', '/tmp')
+
+    # the optimiser (and with it the flat gradient buffer) is built BEFORE the process group exists: the world size must be read late
+    mdl, tm = build()
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    out = MultipleModels({'TinyGCRNN': tm}, xT, yT, None, None, nEpochs=2, batchSize=bs, seqLen=T, stateFeat=2,
+                         evaluate=lambda a, b: (a - b).abs().mean(), validationInterval=0, rank=rank, world=world,
+                         rng=np.random.RandomState(11))
+    mine = mdl.stateGCRNN.weight_A.detach().reshape(-1).clone()
+    gathered = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(gathered, mine)
+    ok = all(torch.equal(t, gathered[0]) for t in gathered)
+    dist.destroy_process_group()
+    ref, rtm = build()                                # the same two epochs in one process
+    MultipleModels({'TinyGCRNN': rtm}, xT, yT, None, None, nEpochs=2, batchSize=bs, seqLen=T, stateFeat=2,
+                   evaluate=lambda a, b: (a - b).abs().mean(), validationInterval=0, rng=np.random.RandomState(11))
+    ok &= bool(torch.allclose(mine, ref.stateGCRNN.weight_A.detach().reshape(-1), atol=1e-12, rtol=0))
+    ret[rank] = bool(ok)
+
+
+def test_multiple_models_survives_an_empty_shard():
+    world = 2
+    port = free_port()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(harness_worker, args=(world, port, ret), nprocs=world, join=True)
+    assert all(ret[r] for r in range(world)), dict(ret)
+
+
+def test_zero_grad_drops_gradients_that_live_outside_the_flat_buffer():
+    """ADVICE r2: after archit.zero_grad() (grads -> None) and a backward, the gradients are fresh tensors outside the flat buffer;
+    sync.zero_grad() must zero, not copy them back in."""
+    torch.manual_seed(0)
+    m = Tiny().double()
+    sync = FlatGradAllReduce(m.parameters())
+    m.zero_grad(set_to_none=True)
+    m(torch.randn(4, 6, dtype=torch.float64)).sum().backward()
+    assert m.a.weight.grad is not None and m.a.weight.grad.data_ptr() != sync.views[0].data_ptr()
+    sync.zero_grad()
+    assert float(sync.flat.abs().max()) == 0.0
+    assert all(p.grad.data_ptr() == v.data_ptr() for p, v in zip(sync.params, sync.views))
+    assert sync.world == 1
+    with pytest.raises(RuntimeError):
+        # a shard weight with an initialised group of ONE rank is a bug (nothing would be reduced)
+        os.environ['MASTER_ADDR'] = '127.0.0.1'
+        os.environ['MASTER_PORT'] = str(free_port())
+        dist.init_process_group('gloo', rank=0, world_size=1)
+        try:
+            sync.all_reduce_(0.5)
+        finally:
+            dist.destroy_process_group()

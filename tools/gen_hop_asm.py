@@ -289,7 +289,9 @@ def gen_uniform16():
             vs1(q, L)                                             # (the set's registers were B operands of the PREVIOUS trip's MFMAs: read long ago)
             vs0p(q, L)
             L.append('s_waitcnt lgkmcnt(%d)' % (3 * (D - 1)))
-            for e in range(2):                                    # one accumulator (two, so that an MFMA never waits for its predecessor: slower, the exits pay more)
+            for e in range(1 if os.environ.get('GCRNN_HOP16_EXPERIMENT_ONE_MFMA') else 2):      # (timing experiment, wrong results: what would ONE
+                # matrix instruction per four entries -- a 2:4-sparse v_smfmac_f32_16x16x64_bf16 with the one-hot A -- buy?)
+                # one accumulator (two, so that an MFMA never waits for its predecessor: slower, the exits pay more)
                 L.append('v_mfma_f32_16x16x32_bf16 %s, %%29, %s, %s' % (VSUM4[0], VX(p, e), VSUM4[0]))
             L.append('s_add_u32 %s, %s, 1' % (SC, SC))            # SCC = carry = this was the tile's last group
         L.append('s_branch L_T%d_P0_%%=' % t)

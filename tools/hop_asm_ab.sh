@@ -3,7 +3,7 @@
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 C=$R/gated_gcrnns_amd/csrc
 mkdir -p /tmp/hab
-/opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC -shared -DGCRNN_HOP_ASM=0 -o /tmp/hab/lib_macro.so $C/*.hip $C/gcrnn_host.cpp &
+/opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC -shared -DGCRNN_HOP_ASM=0 -DGCRNN_DIAGNOSTIC_STREAMS -o /tmp/hab/lib_macro.so $C/*.hip $C/gcrnn_host.cpp &
 wait
 for rep in 1 2 3; do
   echo -n "asm uniform : "; python3 $R/tools/step_kernel_probe.py 256 16 3 2>&1 | tail -1

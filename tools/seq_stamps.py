@@ -7,10 +7,20 @@ R = os.environ.get('GRAFT_REPO_ROOT', os.path.dirname(os.path.dirname(os.path.ab
 C = os.path.join(R, 'gated_gcrnns_amd', 'csrc')
 out = '/tmp/seqst'
 os.makedirs(out, exist_ok=True)
+if os.environ.get('GCRNN_HOP16_EXPERIMENT_ONE_MFMA'):      # timing experiment (wrong results): regenerate the stream into a private include directory
+    inc = os.path.join(out, 'inc')
+    os.makedirs(inc, exist_ok=True)
+    for f in glob.glob(C + '/*'):
+        subprocess.check_call(['cp', f, inc])
+    with open(os.path.join(inc, 'gcrnn_hop_asm.inc'), 'w') as fh:
+        subprocess.check_call([sys.executable, os.path.join(R, 'tools', 'gen_hop_asm.py')], stdout=fh)
+    os.makedirs('/tmp/include', exist_ok=True)      # (the sources include "../../include/gcrnn.h")
+    subprocess.check_call(['cp', os.path.join(R, 'include', 'gcrnn.h'), '/tmp/include/'])
+    C = inc
 procs = []
 for f in sorted(glob.glob(C + '/*.hip') + glob.glob(C + '/*.cpp')):
     o = os.path.join(out, os.path.basename(f) + '.o')
-    procs.append(subprocess.Popen(['/opt/rocm/bin/hipcc', '-O3', '-std=c++17', '--offload-arch=gfx950', '-fPIC', '-DGCRNN_SEQ_STAMPS', '-c', f, '-o', o]))
+    procs.append(subprocess.Popen(['/opt/rocm/bin/hipcc', '-O3', '-std=c++17', '--offload-arch=gfx950', '-fPIC', '-DGCRNN_SEQ_STAMPS', '-I' + os.path.join(R, 'include'), '-c', f, '-o', o]))
 assert all(p.wait() == 0 for p in procs)
 lib = os.path.join(out, 'lib.so')
 subprocess.check_call(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-shared', '-fPIC', '-o', lib] + sorted(glob.glob(out + '/*.o')))

@@ -5,7 +5,7 @@ C=$R/gated_gcrnns_amd/csrc
 mkdir -p /tmp/wab
 for w in 8 16; do for v in full nohops nophase1; do
   case $v in full) D="";; nohops) D="-DGCRNN_ABLATE_HOPS";; nophase1) D="-DGCRNN_ABLATE_PHASE1";; esac
-  /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC -shared -DGCRNN_STEP_WAVES=$w $D -o /tmp/wab/lib_${w}_$v.so $C/*.hip $C/gcrnn_host.cpp &
+  /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC -shared -DGCRNN_STEP_WAVES=$w -DGCRNN_DIAGNOSTIC_STREAMS $D -o /tmp/wab/lib_${w}_$v.so $C/*.hip $C/gcrnn_host.cpp &
 done; done
 wait
 for w in 8 16; do for v in full nohops nophase1; do
