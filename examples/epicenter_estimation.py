@@ -45,7 +45,7 @@ def synthetic_waves(S, n, T, regions, rng):
     return x, regions[src]
 
 
-def main():
+def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument('--seq', type=int, default=200)
     ap.add_argument('--taps', type=int, default=3)
@@ -55,7 +55,7 @@ def main():
     ap.add_argument('--lr', type=float, default=5e-3, help='the reference driver uses 1e-3 over many epochs')
     ap.add_argument('--time-gating', action='store_true')
     ap.add_argument('--dtype', default='f64', choices=['f32', 'f64'])
-    args = ap.parse_args()
+    args = ap.parse_args(argv)
     dt = torch.float64 if args.dtype == 'f64' else torch.float32
     torch.set_default_dtype(dt)                                      # the reference driver runs in float64
     dev = torch.device('cuda:0')
@@ -73,13 +73,14 @@ def main():
     opt = torch.optim.Adam(model.parameters(), lr=args.lr, betas=(0.9, 0.999))
     ce = torch.nn.CrossEntropyLoss()
     xtr_d, ytr_d = to_x(xtr), torch.tensor(ytr, device=dev)
-    times, first = [], None
+    times, first, losses = [], None, []
     for it in range(args.steps):
         idx = torch.tensor(rng.choice(xtr.shape[0], args.batch, replace=False), device=dev)
         torch.cuda.synchronize(); t0 = time.perf_counter()
         loss, _ = train_step(model, ce, opt, xtr_d[idx], ytr_d[idx], args.features)
         torch.cuda.synchronize(); times.append(time.perf_counter() - t0)
         first = float(loss) if first is None else first
+        losses.append(float(loss))
     with torch.no_grad():
         xe = to_x(xte)
         h0 = torch.zeros(xe.shape[0], args.features, N, dtype=dt, device=dev)
@@ -88,6 +89,7 @@ def main():
     print('%sGCRNN classification N=%d T=%d K=%d F=%d %s: loss %.3f -> %.3f, test accuracy %.3f (chance %.3f), '
           'median %.2f ms/step (%.0f seq/s)' % ('Time' if args.time_gating else '', N, args.seq, args.taps, args.features,
                                                args.dtype, first, float(loss), acc, 1 / 11, ms, args.batch / (ms / 1e3)))
+    return {'loss': losses, 'accuracy': acc, 'ms_per_step': ms}
 
 
 if __name__ == '__main__':

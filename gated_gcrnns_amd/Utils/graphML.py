@@ -605,10 +605,12 @@ class GGCRNNCell(nn.Module):
 
     def _use_fused_training(self, X, h0):
         """bf16 activations (parameters bf16 or fp32 master weights), plain or time-gated cell, gradients wanted for the
-        parameters (and, for the plain cell, optionally h0) but not for X: forward and BPTT on the fused kernels."""
-        if not torch.is_grad_enabled() or X.requires_grad:
+        parameters (and, for the plain cell, optionally h0; X too when G == F): forward and BPTT on the fused kernels."""
+        if not torch.is_grad_enabled():
             return False
-        if not (h0.requires_grad or any(p.requires_grad for p in self.parameters())):
+        if X.requires_grad and (self.spatial_gating is not None or self.time_gating == True or not ops.fused_input_grad_ok(self.F, self.G)):  # noqa: E712
+            return False                                   # dX: un-gated cell with G == F (the input filter's adjoint pass; the gates' sub-networks give X no gradient)
+        if not (h0.requires_grad or X.requires_grad or any(p.requires_grad for p in self.parameters())):
             return False
         if self.spatial_gating == 'node':
             if h0.requires_grad or self.bias is None or self.GRNN_node_in.weight_A.dtype != self.weight_A.dtype or \

@@ -651,13 +651,17 @@ def to_sequence_major(X, graph):
 
 
 # ------------------------------------------------------------------------------------------ node-gated cell on the fused path
-def fused_filter_output(xs, w, bias, graph, K, N):
+def fused_filter_output(xs, w, bias, graph, K, N, adjoint=False):
     """(w(S) x_t + bias) for every (t, b) in one launch: [T][B][NPad][F] bf16 sequence-major (gcrnn_fused_filter_output_bf16).
-    xs [T][B][NPad][C] bf16; w F x 1 x k x C (k <= K taps); C == F runs the operand as a state, otherwise as [0 | x_t]."""
+    xs [T][B][NPad][C] bf16; w F x 1 x k x C (k <= K taps); C == F runs the operand as a state, otherwise as [0 | x_t].
+    adjoint: the shifts run on the adjoint graph (S^T): with transposed taps this is the filter's input gradient."""
     T, B, npad, Cin = xs.shape
     F = w.shape[0]
-    plan = graph.fused_plan()
-    plan16 = fused_img16_plan(graph, False, None)
+    plan = graph.fused_plan(adjoint=adjoint)
+    if adjoint:
+        plan16 = None if os.environ.get('GCRNN_NO_IMG16') else graph.fused_plan_img16(adjoint=True)
+    else:
+        plan16 = fused_img16_plan(graph, False, None)
     st = _stream()
     b32 = bias.detach().float().contiguous().view(-1) if bias is not None else None
     out = torch.empty((T, B, npad, F), dtype=torch.bfloat16, device=xs.device)
@@ -1401,7 +1405,9 @@ class _FusedCell(torch.autograd.Function):
     the recurrent part scaled by the forget gate) -> ONE weight-gradient launch over all T*B items (item weights gi / gf)
     -> with gates:  d gf = <B(S)h_{t-1} + b, dpre_t> = <h_{t-1}, adjoint chain of dpre_t> + b . colsum(dpre_t) falls out of
     the data-gradient launches (adjoint identity); d gi = <A(S)x_t + b, dpre_t> is one gate-gradient pass over all items.
-    The gradient w.r.t. X is not produced (the training loops never ask for it, train_rnn.py:247-276)."""
+    The gradient w.r.t. X (no training loop of the reference asks for it, train_rnn.py:247-276, but its autograd gives it) is the
+    input filter's adjoint on dpre, gi_t (S^T)^k (dpre_t A_k): ONE all-items launch of the filter-output pass on the adjoint graph with
+    the transposed input taps (G == F; ops.fused_input_grad_ok)."""
 
     @staticmethod
     def forward(ctx, X, h0, wA, wB, bias, gi, gf, graph, xs, hs_all):
@@ -1420,8 +1426,8 @@ class _FusedCell(torch.autograd.Function):
         B, T, G, N = X.shape
         F, Kin, Kst = wA.shape[0], wA.shape[2], wB.shape[2]
         K = max(Kin, Kst)
-        if ctx.needs_input_grad[0]:
-            raise GcrnnError('the fused BPTT does not produce the gradient w.r.t. the input sequence X')
+        if ctx.needs_input_grad[0] and not fused_input_grad_ok(F, G):
+            raise GcrnnError('the fused BPTT produces the gradient w.r.t. the input sequence X only for G == F')
         st = _stream()
         hs = hs_all[1:]
         gated = gi is not None
@@ -1451,7 +1457,23 @@ class _FusedCell(torch.autograd.Function):
             gh0 = torch.empty((B, 1, F, N), dtype=torch.bfloat16, device=X.device)
             check(lib.gcrnn_unpack_seq_major(_lib.BF16, _p(dh0s), _p(gh0), B, 1, F, N, npad, None, st), 'unpack_seq')
             gh0 = gh0.view(B, F, N).to(h0.dtype)
-        return None, gh0, gA, gB, gb, dgi, dgf, None, None, None
+        gX = None
+        if ctx.needs_input_grad[0]:
+            # dX_t = gi_t sum_k (dpre_t A_k) shifted k times by S^T: the input filter's adjoint, every item in one launch
+            wAk = wA if Kin == K else torch.cat([wA, wA.new_zeros(F, 1, K - Kin, G)], dim=2)
+            wAt = wAk.detach()[:, 0].permute(2, 1, 0).contiguous().unsqueeze(1)       # [G][1][K][F]: transposed taps
+            dxs = fused_filter_output(dpre, wAt, None, graph, K, N, adjoint=True)     # [T][B][NPad][G] bf16
+            gX = torch.empty((B, T, G, N), dtype=torch.bfloat16, device=X.device)
+            check(lib.gcrnn_unpack_seq_major(_lib.BF16, _p(dxs), _p(gX), B, T, G, N, npad, None, st), 'unpack_seq')
+            if gated:
+                gX = gX * gi.t().reshape(B, T, 1, 1).to(gX.dtype)
+            gX = gX.to(X.dtype)
+        return gX, gh0, gA, gB, gb, dgi, dgf, None, None, None
+
+
+def fused_input_grad_ok(F, G):
+    """d loss / d X on the fused path: the adjoint of the input filter runs as a square (state-like) operand of the filter-output pass."""
+    return int(F) == int(G)
 
 
 def fused_cell_train(X, h0, wA, wB, bias, graph, gates=None):

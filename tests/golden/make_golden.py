@@ -341,19 +341,21 @@ def g9_fused_bptt(variants=(('none', False, None), ('time', True, None), ('node'
                 q.copy_(torch.tensor(bf16_round(q.detach().numpy())))
         p = sd_np(cell)
         h0t = torch.tensor(h0, requires_grad=True)
-        H = cell(torch.tensor(X), h0t)
+        Xt = torch.tensor(X, requires_grad=True)            # (round 3: the reference's gradient w.r.t. the input sequence too)
+        H = cell(Xt, h0t)
         check(orc.ggcrnn_cell(p, S, X, h0, tg, sg), H.detach().numpy(), 'G9 ' + name)
         cell.zero_grad()
         H.sum().backward(retain_graph=True)
-        g_sum, gh0_sum = grads_np(cell), h0t.grad.numpy().copy()
-        cell.zero_grad(); h0t.grad = None
+        g_sum, gh0_sum, gX_sum = grads_np(cell), h0t.grad.numpy().copy(), Xt.grad.numpy().copy()
+        cell.zero_grad(); h0t.grad = None; Xt.grad = None
         torch.nn.L1Loss()(H, torch.tensor(target)).backward()
         g_l1 = grads_np(cell)
         f32 = lambda d: {k: (v.astype(np.float32) if v is not None else None) for k, v in d.items()}
         save('g9_fused_' + name, coo_row=rows.astype(np.int16), coo_col=cols.astype(np.int16), coo_val=S[0][rows, cols].astype(np.float32),
              shape=np.array([N, T, G, F, K, B]), X=X.astype(np.float32), h0=h0.astype(np.float32), target=target.astype(np.float32),
              H=H.detach().numpy().astype(np.float32), params=f32(p), grad_sum=f32(g_sum), grad_sum_h0=gh0_sum.astype(np.float32),
-             grad_l1=f32(g_l1), grad_l1_h0=h0t.grad.numpy().astype(np.float32))
+             grad_l1=f32(g_l1), grad_l1_h0=h0t.grad.numpy().astype(np.float32),
+             grad_sum_X=gX_sum.astype(np.float32), grad_l1_X=Xt.grad.numpy().astype(np.float32))
 
 
 def g9_fused_bptt_edge():

@@ -684,6 +684,7 @@ def test_fused_bptt_matches_reference_autograd_fixture(golden, name, tg, sg, los
     X = torch.tensor(g['X'], dtype=torch.bfloat16, device=dev)
     h0 = torch.tensor(g['h0'], dtype=torch.bfloat16, device=dev, requires_grad=(not tg and sg is None))
     assert float((X.float().cpu() - torch.tensor(g['X'])).abs().max()) == 0.0          # operands are bf16-exact
+    X.requires_grad_(sg is None and not tg)          # round 3: d loss / d X on the fused path (un-gated cell, G == F)
     if not cell._use_fused_training(X, h0):
         pytest.skip('no fused training kernels for the %s-gated cell' % name)
     H = cell(X, h0)
@@ -711,6 +712,11 @@ def test_fused_bptt_matches_reference_autograd_fixture(golden, name, tg, sg, los
     for k, p in got.items():                          # parameters the reference leaves without gradient (unused output gate)
         if k not in want:
             assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
+    if X.requires_grad:
+        want_X = g['grad_sum_X' if loss == 'sum' else 'grad_l1_X']
+        e = (X.grad.float().cpu() - torch.tensor(want_X)).abs()
+        sc = float(np.abs(want_X).max())
+        assert float(e.max()) <= (1.2e-1 if loss == 'l1' else 6e-2) * sc and float(e.mean()) <= 1e-2 * sc, ('dX', float(e.max()) / sc, float(e.mean()) / sc)
     if h0.requires_grad:
         e = (h0.grad.float().cpu() - torch.tensor(want_h0)).abs()
         sc = float(np.abs(want_h0).max())

@@ -634,6 +634,54 @@ def test_kstep_driver_counterpart_trains(dev, argv):
         assert np.mean(loss[-2:]) < loss[0], (name, loss[0], loss[-2:])
 
 
+@pytest.mark.gpu
+def test_epicenter_driver_counterpart_trains(dev):
+    """examples/epicenter_estimation.py (counterpart of epicenterEstimation.py:445-1245: seismograph graph -> S = A / |lambda_max| ->
+    GatedGCRNNforClassification on the last state -> cross-entropy): 50 optimiser steps on the drivers' shapes (N = 59, F = 20,
+    K = 3; T = 50), the loss goes down and the test accuracy leaves chance (1 / 11). VERDICT r2: H2 names both drivers."""
+    import importlib.util
+    import os
+    from conftest import ROOT
+    spec = importlib.util.spec_from_file_location('epicenter_example', os.path.join(ROOT, 'examples', 'epicenter_estimation.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    prev = torch.get_default_dtype()
+    try:
+        res = mod.main(['--steps', '50', '--seq', '50'])
+    finally:
+        torch.set_default_dtype(prev)
+    loss = res['loss']
+    assert np.isfinite(loss).all() and np.mean(loss[-5:]) < 0.8 * np.mean(loss[:3]), (loss[:3], loss[-5:])
+    assert res['accuracy'] > 2.0 / 11
+
+
+@pytest.mark.gpu
+def test_bench_training_step_under_torch_distributed_run_on_one_rank():
+    """Multi-GPU readiness that one GPU can prove: the training bench under `python -m torch.distributed.run
+    --nproc-per-node 1` -- RCCL communicator set-up, the ONE flat gradient all-reduce per optimiser step, FlatAdam, the MAX-reduce
+    of the wall time -- prints the contract's JSON line, and the collective's payload is the whole flat fp32 gradient buffer."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    from conftest import ROOT
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--mode', 'train', '--steps', '2', '--warmup', '1',
+           '--batch', '64', '--no-cpu-baseline']
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith('{') and '"metric"' in ln]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 1 and d['steps'] == 2 and d['value'] > 0 and d['config']['mode'] == 'train' and d['config']['parallelism'] == 'dp1'
+    numel = 2 * 64 * 5 * 64 + 64                     # weight_A + weight_B (F x 1 x K x {G, F}) + bias of the un-gated cell
+    assert d['config']['allreduce_bytes'] == 4 * numel, d['config']
+
+
 @pytest.mark.parametrize('argv', [['--config', 'cfg2', '--batch', '16'], ['--config', 'cfg2', '--batch', '16', '--dtype', 'f32'],
                                   ['--config', 'cfg2', '--batch', '8', '--mode', 'train'], ['--config', 'cfg2', '--batch', '8', '--mode', 'train', '--spatial-gating', 'node'],
                                   ['--config', 'cfg2', '--batch', '8', '--spatial-gating', 'edge'], ['--config', 'cfg2', '--batch', '8', '--mode', 'train', '--spatial-gating', 'edge', '--time-gating'],
