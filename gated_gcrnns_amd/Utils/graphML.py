@@ -234,6 +234,7 @@ class GGCRNNCell(nn.Module):
         self.N = graph.N
         self.S = S
         self.graph = graph
+        self.__dict__.pop('_pc', None)                     # (the padded-state shadow of _state_padded belongs to the old graph)
         if self.time_gating == True:  # noqa: E712  (the reference compares with ==)
             dimInputMLP = self.N * self.F
             self.GFL_in = self._sub_cell()
@@ -295,9 +296,64 @@ class GGCRNNCell(nn.Module):
         d = sub._gate_state(Xn, h0n)
         return torch.sigmoid(gfl[0].forward_node_major(d))
 
+    # -- state widths between the fused kernels' (F = 20 of the reference drivers, kStepPredGRNNs.py:220-222) -------------------
+    def _state_padded(self, X, h0):
+        """The fused kernels are built for F = 32 / 64 state features. A cell with fewer (un-gated or time-gated, tanh) runs on them
+        as the SAME cell with zero-padded state channels: padded rows of the taps / bias / read-out weights are zero, so a padded
+        channel computes tanh(0 + 2 * 0) = 0 at every step and feeds nothing back -- results are those of the F-feature cell. Returns
+        (shadow cell with F padded, padded h0) or None when the cell does not need / cannot take that route."""
+        Fn = nn.functional
+        if self.graph is None or self.F in (32, 64) or self.F > 64 or self.spatial_gating is not None or self.E != 1:
+            return None
+        if self.sigma not in (torch.tanh, Fn.tanh) or X.dtype not in (torch.bfloat16, torch.float32) or h0.dtype != X.dtype:
+            return None
+        Fp = 32 if self.F <= 32 else 64
+        if X.dtype == torch.float32:
+            if ops.small_supported(self.N, self.graph.fwd[0].nnz, self.G, self.F, self.Kin, self.Kst, X.dtype, self.E) or \
+                    self._wants_grad(X, h0) or self.time_gating == True or \
+                    not ops.fused_x3_supported(self.graph, self.N, Fp, self.G, self.Kin, self.Kst, X.dtype, self.E):  # noqa: E712
+                return None
+        elif not ops.fused_supported(self.N, Fp, self.G, self.Kin, self.Kst, X.dtype, self.E):
+            return None
+        pc = self.__dict__.get('_pc')
+        if pc is None or pc.F != Fp or pc.graph is not self.graph or pc.weight_A.dtype != self.weight_A.dtype or \
+                pc.weight_A.device != self.weight_A.device:
+            with torch.random.fork_rng(devices=[]):          # the shadow's own initialisation must not move the caller's generator
+                pc = GGCRNNCell(self.G, Fp, self.Kin, self.Kst, self.sigma, self.time_gating, None, self.E, self.bias_flag)
+                pc.addGSO(self.graph)
+            pc = pc.to(device=self.weight_A.device, dtype=self.weight_A.dtype)
+            for q in pc.parameters():
+                q.requires_grad_(False)
+            object.__setattr__(self, '_pc', pc)               # not a sub-module: state_dict keys stay the reference's
+        pc.native_layout = bool(getattr(self, 'native_layout', False))
+        return pc, Fn.pad(h0, (0, 0, 0, Fp - self.F))
+
+    def _padded_params(self, Fp):
+        """This cell's parameters zero-padded to Fp state features (differentiable: autograd drops the padding's gradient)."""
+        Fn, F, d, N = nn.functional, self.F, Fp - self.F, self.N
+        out = {}
+        for name, p in self.named_parameters():
+            if name.endswith('weight_A'):
+                p = Fn.pad(p, (0, 0, 0, 0, 0, 0, 0, d))
+            elif name.endswith('weight_B'):
+                p = Fn.pad(p, (0, d, 0, 0, 0, 0, 0, d))
+            elif name.endswith('bias') and tuple(p.shape) == (F, 1):
+                p = Fn.pad(p, (0, 0, 0, d))
+            elif name.endswith('.0.weight') and tuple(p.shape) == (1, F * N):       # gate read-out Linear(N F -> 1), vec over (f, n)
+                p = Fn.pad(p.view(1, F, N), (0, 0, 0, d)).reshape(1, Fp * N)
+            out[name] = p
+        return out
+
     def forward(self, X, h0, last_only=False):
         """last_only (an extension the classification model uses in inference): return B x 1 x F x N, the last state only --
         the fused kernels then skip the user-layout store of every other step; the other paths slice."""
+        padded = self._state_padded(X, h0)
+        if padded is not None:
+            from torch.func import functional_call
+            pc, h0p = padded
+            Hp = functional_call(pc, self._padded_params(pc.F), (X, h0p), {'last_only': last_only})
+            H = Hp[:, :, :self.F]
+            return H if pc.native_layout else H.contiguous()
         if last_only:
             if (not torch.is_grad_enabled()) and self._use_fused(X, h0):
                 return self._forward_fused(X, h0, last_only=True)
@@ -643,8 +699,8 @@ class GGCRNNCell(nn.Module):
 
     def _forward_fused(self, X, h0, last_only=False, head=None):
         gates = self._fused_gates() if self.time_gating == True else None  # noqa: E712
-        Xp, wA = ops.fused_pad_operands(X, self.weight_A)
-        return ops.fused_cell_forward(Xp, h0, wA, self.weight_B, self.bias, self.graph, gates, last_only=last_only, head=head,
+        # (G < 32, the drivers' G = 1: the taps are padded here, X by the pack kernel itself -- no padded copy of X)
+        return ops.fused_cell_forward(X, h0, ops.fused_pad_taps(self.weight_A), self.weight_B, self.bias, self.graph, gates, last_only=last_only, head=head,
                                       native_out=bool(getattr(self, 'native_layout', False)) and head is None)
 
     def forward_native(self, xs, h0s=None):

@@ -75,6 +75,7 @@ def _bind(lib):
         'gcrnn_fused_step_waves': (_c_i64, []),
         'gcrnn_fused_wgrad_waves': (_c_i64, []),
         'gcrnn_pack_seq_major': (C.c_int, [C.c_int, _c_p, _c_p, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_p, _c_p]),
+        'gcrnn_pack_seq_major_padded': (C.c_int, [_c_p, _c_p] + [_c_i64] * 6 + [_c_p]),
         'gcrnn_unpack_seq_major': (C.c_int, [C.c_int, _c_p, _c_p, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_p, _c_p]),
         'gcrnn_fused_pack_weights': (C.c_int, [C.c_int, _c_p, _c_p, _c_p, _c_i64, _c_i64, _c_i64, _c_i64, _c_p]),
         'gcrnn_fused_forward_bf16': (C.c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p,

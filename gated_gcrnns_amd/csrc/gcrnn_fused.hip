@@ -56,12 +56,16 @@ __global__ __launch_bounds__(256) void seq_layout_kernel(const E* __restrict__ s
 // in 128-byte segments.
 template <bool PACK>
 __global__ __launch_bounds__(256) void seq_layout16_kernel(const uint16_t* __restrict__ src, uint16_t* __restrict__ dst,
-                                                           int B, int Tn, int C, int N, int NPad) {
+                                                           int B, int Tn, int C, int N, int NPad, int Cs = 0) {
+  // PACK with Cs < C (Cs = channels of the USER tensor, C = channels of the sequence-major one): channels >= Cs are written as
+  // zeros -- the reference drivers' G = 1 input (kStepPredGRNNs.py:220) reaches the kernels' 32-channel operand without a padded
+  // copy of X in the user layout. Cs = 0: the same channel count on both sides.
   __shared__ uint16_t tile[64][66];
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
   const int n0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
   const int bt = blockIdx.z, b = bt / Tn, t = bt - b * Tn;
-  const int64_t ubase = ((int64_t)(b * Tn + t) * C) * N;
+  const int Cu = (PACK && Cs > 0) ? Cs : C;
+  const int64_t ubase = ((int64_t)(b * Tn + t) * Cu) * N;
   const int64_t sbase = ((int64_t)(t * B + b) * NPad) * C;
   if (PACK) {
     const int n = n0 + 2 * tx;
@@ -69,7 +73,7 @@ __global__ __launch_bounds__(256) void seq_layout16_kernel(const uint16_t* __res
     for (int i = 0; i < 8; ++i) {
       const int c = c0 + ty + 8 * i;
       uint32_t v = 0;
-      if (c < C && n < N) v = *reinterpret_cast<const uint32_t*>(src + ubase + (int64_t)c * N + n);
+      if (c < Cu && n < N) v = *reinterpret_cast<const uint32_t*>(src + ubase + (int64_t)c * N + n);
       *reinterpret_cast<uint32_t*>(&tile[ty + 8 * i][2 * tx]) = v;
     }
     __syncthreads();
@@ -191,6 +195,22 @@ extern "C" int gcrnn_pack_seq_major(int dtype, const void* src, void* dst, int64
                                     int64_t NPad, const int32_t* perm, void* stream) {
   return seq_layout_launch<true>(dtype, src, dst, B, T, C, N, NPad, perm, stream);
 }
+// bf16 pack with channel padding: user [B][T][Cs][N] -> sequence-major [T][B][NPad][C], C >= Cs even, channels >= Cs zero.
+// Replaces "zero-pad X to the kernels' input width in the user layout, then pack" (ops.fused_pad_operands materialised a 32x larger
+// copy of the drivers' one-channel X, kStepPredGRNNs.py:220). N even, 4-byte aligned arrays.
+extern "C" int gcrnn_pack_seq_major_padded(const void* src, void* dst, int64_t B, int64_t T, int64_t Cs, int64_t C, int64_t N,
+                                           int64_t NPad, void* stream) {
+  if (!src || !dst) return GCRNN_ERR_NULL_POINTER;
+  if (B <= 0 || T <= 0 || Cs <= 0 || C < Cs || N <= 0 || NPad < N || B * T > 65535 || cdiv(C, 64) > 65535) return GCRNN_ERR_BAD_SHAPE;
+  if ((N % 2) || (C % 2) || ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 3)) return GCRNN_ERR_UNSUPPORTED;
+  GCRNN_PRE_LAUNCH();
+  dim3 grid((unsigned)cdiv(NPad, 64), (unsigned)cdiv(C, 64), (unsigned)(B * T));
+  seq_layout16_kernel<true><<<grid, 256, 0, as_stream(stream)>>>((const uint16_t*)src, (uint16_t*)dst, (int)B, (int)T, (int)C, (int)N,
+                                                                 (int)NPad, (int)Cs);
+  GCRNN_CHECK_LAUNCH();
+  return GCRNN_OK;
+}
+
 extern "C" int gcrnn_unpack_seq_major(int dtype, const void* src, void* dst, int64_t B, int64_t T, int64_t C,
                                       int64_t N, int64_t NPad, const int32_t* perm, void* stream) {
   return seq_layout_launch<false>(dtype, src, dst, B, T, C, N, NPad, perm, stream);
@@ -255,6 +275,7 @@ static int fused_dispatch(int mode, const void* xs, const void* h0, void* hs, co
   GCRNN_FUSED_CASE(3, 2, 2)
   GCRNN_FUSED_CASE(2, 2, 2)
   GCRNN_FUSED_CASE(5, 1, 1)
+  GCRNN_FUSED_CASE(4, 1, 1)
   GCRNN_FUSED_CASE(3, 1, 1)
   GCRNN_FUSED_CASE(2, 1, 1)
   GCRNN_FUSED_CASE(5, 2, 1)      // F = 64 with up to 32 input features (the drivers' G = 1, zero-padded to 32 by the caller)
@@ -266,6 +287,7 @@ static int fused_dispatch(int mode, const void* xs, const void* h0, void* hs, co
   GCRNN_FUSED_CASE(3, 2, 0)
   GCRNN_FUSED_CASE(2, 2, 0)
   GCRNN_FUSED_CASE(5, 1, 0)
+  GCRNN_FUSED_CASE(4, 1, 0)
   GCRNN_FUSED_CASE(3, 1, 0)
   GCRNN_FUSED_CASE(2, 1, 0)
 #undef GCRNN_FUSED_CASE
@@ -542,7 +564,7 @@ extern "C" int gcrnn_fused_gate_readout_backward_bf16(void* cs, const float* dlo
 extern "C" int gcrnn_fused_supported(int64_t N, int64_t F, int64_t G, int64_t K) {
   if (N <= 0 || N > NP) return 0;
   const bool big = (F == 64 && (G == 64 || G == 32) && K >= 2 && K <= 5);
-  const bool small = (F == 32 && G == 32 && (K == 2 || K == 3 || K == 5));
+  const bool small = (F == 32 && G == 32 && K >= 2 && K <= 5);
   return (big || small) ? 1 : 0;
 }
 

@@ -1389,6 +1389,6 @@ int fused_launch_t(int mode /*0 plain, 1 gated, 2 gate pre-pass, 3 BPTT data gra
 // the (HS, XS) operand shapes built for a tap count K: [h | x] with F = G = 64 / 32, F = 64 with G <= 32, and the state-only
 // operands of the BPTT data-gradient steps and gate-gradient passes
 #define GCRNN_STEP_FOR_K5(M) M(5, 2, 2) M(5, 1, 1) M(5, 2, 1) M(5, 2, 0) M(5, 1, 0)
-#define GCRNN_STEP_FOR_K4(M) M(4, 2, 2) M(4, 2, 1) M(4, 2, 0)
+#define GCRNN_STEP_FOR_K4(M) M(4, 2, 2) M(4, 1, 1) M(4, 2, 1) M(4, 2, 0) M(4, 1, 0)
 #define GCRNN_STEP_FOR_K3(M) M(3, 2, 2) M(3, 1, 1) M(3, 2, 1) M(3, 2, 0) M(3, 1, 0)
 #define GCRNN_STEP_FOR_K2(M) M(2, 2, 2) M(2, 1, 1) M(2, 2, 1) M(2, 2, 0) M(2, 1, 0)

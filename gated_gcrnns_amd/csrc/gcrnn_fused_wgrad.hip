@@ -396,6 +396,7 @@ extern "C" int gcrnn_fused_backward_weight_bf16(const void* dpre, const void* Xu
   GCRNN_WG_CASE(3, 2, 2)
   GCRNN_WG_CASE(2, 2, 2)
   GCRNN_WG_CASE(5, 1, 1)
+  GCRNN_WG_CASE(4, 1, 1)
   GCRNN_WG_CASE(3, 1, 1)
   GCRNN_WG_CASE(2, 1, 1)
   GCRNN_WG_CASE(5, 2, 1)

@@ -428,7 +428,14 @@ def fused_inline_pack_ok(plan, N, F, G, K):
     return bool(lib.gcrnn_fused_inline_pack_supported(int(N), int(F), int(G), int(K), int(plan['entries']), float(plan.get('uniform_w', 0.0))))
 
 
-def fused_pack_inputs(X, h0, graph, overlap=False, first_only=False):
+def fused_pad_taps(wA):
+    """Input taps wA [F][1][K][G] zero-padded to the kernels' input width (differentiable; see fused_pad_operands)."""
+    F, G = wA.shape[0], wA.shape[3]
+    Gp = fused_padded_inputs(F, G)
+    return wA if Gp == G else torch.nn.functional.pad(wA, (0, Gp - G))
+
+
+def fused_pack_inputs(X, h0, graph, overlap=False, first_only=False, channels=None):
     """user-layout bf16 X [B][T][G][N], h0 [B][F][N] -> sequence-major xs [T][B][NPad][G] and the state buffer
     hs_all [T+1][B][NPad][F] whose slot 0 holds h0 (slots 1..T receive h_1..h_T: hs_all[:T] is then the h_{t-1} operand of
     every step, which the gate-gradient pass reads as one array).
@@ -440,6 +447,14 @@ def fused_pack_inputs(X, h0, graph, overlap=False, first_only=False):
     npad = graph.fused_plan()['npad']
     st = _stream()
     Xc, h0c = X.contiguous(), h0.contiguous()
+    if channels is not None and channels != G:
+        # X keeps its own G channels in the user layout; the sequence-major array gets `channels` of them, the rest zeros
+        assert channels > G and not overlap and not first_only
+        xs = torch.empty((T, B, npad, channels), dtype=torch.bfloat16, device=X.device)
+        hs_all = torch.empty((T + 1, B, npad, F), dtype=torch.bfloat16, device=X.device)
+        check(lib.gcrnn_pack_seq_major(_lib.BF16, _p(h0c), _p(hs_all), B, 1, F, N, npad, None, st), 'pack_seq')
+        check(lib.gcrnn_pack_seq_major_padded(_p(Xc), _p(xs), B, T, G, channels, N, npad, st), 'pack_seq_padded')
+        return xs, hs_all
     xs = torch.empty((T, B, npad, G), dtype=torch.bfloat16, device=X.device)
     hs_all = torch.empty((T + 1, B, npad, F), dtype=torch.bfloat16, device=X.device)
     check(lib.gcrnn_pack_seq_major(_lib.BF16, _p(h0c), _p(hs_all), B, 1, F, N, npad, None, st), 'pack_seq')
@@ -533,9 +548,19 @@ def fused_cell_forward(X, h0, wA, wB, bias, graph, gates=None, return_states=Fal
     user-layout copy of every h_t (a third of the bytes they write); callers that need contiguity call .contiguous() themselves.
     """
     require_device(X, h0, wA, wB, bias)
-    if packed is None:
+    if packed is None and X.shape[2] < wA.shape[3]:
+        # taps already padded to the kernels' input width, X still with its own G channels (the drivers' G = 1): lay X out for the
+        # kernels with the channel padding done by the pack itself -- no 32-channel copy of X in the user layout
+        if X.shape[3] % 2 == 0 and X.dtype == torch.bfloat16:
+            packed = fused_pack_inputs(X, h0, graph, channels=wA.shape[3])
+        else:
+            Xz = X.new_zeros((X.shape[0], X.shape[1], wA.shape[3], X.shape[3]))
+            Xz[:, :, :X.shape[2]] = X
+            X = Xz
+    elif packed is None:
         X, wA = fused_pad_operands(X, wA.detach())        # G < 32: zero-padded input channels (no-op when already padded)
-    B, T, G, N = X.shape
+    B, T, _, N = X.shape
+    G = wA.shape[3]
     F = wA.shape[0]
     K = max(wA.shape[2], wB.shape[2])
     plan = graph.fused_plan()

@@ -277,6 +277,11 @@ int64_t gcrnn_fused_wgrad_waves(void);
  * rows >= N are zero. dtype GCRNN_BF16 or GCRNN_F32 (same type both sides). */
 int gcrnn_pack_seq_major(int dtype, const void* src, void* dst, int64_t B, int64_t T, int64_t C, int64_t N,
                          int64_t NPad, const int32_t* perm, void* stream);
+/* bf16 pack with channel padding: user [B][T][Cs][N] -> sequence-major [T][B][NPad][C], channels Cs .. C-1 and rows N .. NPad-1 zero
+ * (C even, N even). The fused kernels consume the input in 32-feature steps; the reference drivers feed G = 1 (kStepPredGRNNs.py:220,
+ * epicenterEstimation.py:170): this lays their X out for the kernels without a zero-padded copy in the user layout. */
+int gcrnn_pack_seq_major_padded(const void* src, void* dst, int64_t B, int64_t T, int64_t Cs, int64_t C, int64_t N, int64_t NPad,
+                                void* stream);
 int gcrnn_unpack_seq_major(int dtype, const void* src, void* dst, int64_t B, int64_t T, int64_t C, int64_t N,
                            int64_t NPad, const int32_t* perm, void* stream);
 /* The bf16 pack (no permutation; N and C even) of the time steps [t0, t1) only, on a kernel with a 4 KiB LDS footprint:

@@ -1620,3 +1620,80 @@ def test_native_layout_output_and_sequence_major_forward_are_bit_identical(N, F,
             h0s = ops.to_sequence_major(h0.unsqueeze(1), cell.graph)[0]
             hs = cell.forward_native(xs, h0s)
             assert torch.equal(hs.permute(1, 0, 3, 2)[:, :, :, :N], H) and float(hs[:, :, N:].abs().max()) == 0.0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('N,G,F,K,B,T,tg', [(1000, 1, 20, 5, 4, 4, False), (1000, 1, 20, 5, 3, 3, True), (200, 3, 20, 4, 5, 4, False),
+                                            (520, 20, 40, 2, 3, 3, True), (304, 1, 8, 4, 3, 3, False), (1000, 64, 48, 5, 3, 3, False)])
+def test_fused_cell_with_state_widths_between_the_kernels(N, G, F, K, B, T, tg):
+    """The reference drivers' own state width is F1 = 20 with K1 = 5 taps (kStepPredGRNNs.py:220-222): F not in {32, 64} runs on the
+    fused kernels with ZERO-PADDED state channels (GGCRNNCell._state_padded: padded tap / bias / read-out rows are zero, a padded
+    channel stays tanh(0) = 0 at every step); F = 32 with K = 4 has its instantiations now. Forward against the fp64 oracle,
+    training (every parameter incl. the time gates' sub-networks) against fp32 autograd on the composed path; the state_dict keeps
+    the reference's keys and shapes, the caller's RNG stream is not touched by the shadow cell."""
+    import gated_gcrnns_amd.Utils.graphML as gml
+    dev = torch.device('cuda:0')
+    S = random_graph(N, min(0.5, 10.0 / N), 73)
+    rng = np.random.default_rng(19)
+    X = bf16_round(rng.standard_normal((B, T, G, N)))
+    h0 = bf16_round(0.4 * rng.standard_normal((B, F, N)))
+    dH = bf16_round(rng.standard_normal((B, T, F, N)))
+    torch.manual_seed(33)
+    cell = gml.GGCRNNCell(G, F, K, K, torch.tanh, tg, None, 1, True)
+    cell.addGSO(torch.tensor(S))
+    cell = cell.to(torch.bfloat16).to(torch.float32)
+    keys = {k: tuple(v.shape) for k, v in cell.state_dict().items()}
+    params = {k: v.detach().double().numpy() for k, v in cell.state_dict().items()}
+    Href = orc.ggcrnn_cell(params, S.astype(np.float32).astype(np.float64), X, h0, tg, None)
+    ref = gml.GGCRNNCell(G, F, K, K, torch.tanh, tg, None, 1, True)
+    ref.addGSO(torch.tensor(S))
+    ref.load_state_dict(cell.state_dict())
+    ref = ref.to(dev)
+    dHd = torch.tensor(dH, dtype=torch.float32, device=dev)
+    (ref(torch.tensor(X, dtype=torch.float32, device=dev), torch.tensor(h0, dtype=torch.float32, device=dev)) * dHd).sum().backward()
+    cell = cell.to(dev)
+    Xd = torch.tensor(X, dtype=torch.bfloat16, device=dev)
+    hd = torch.tensor(h0, dtype=torch.bfloat16, device=dev)
+    with torch.no_grad():
+        cell = cell.to(torch.bfloat16)
+        assert cell._state_padded(Xd, hd) is not None
+        rng_state = torch.random.get_rng_state()
+        Hi = cell(Xd, hd)                                        # inference kernels (bf16 parameters)
+        assert torch.equal(torch.random.get_rng_state(), rng_state)
+        Hl = cell(Xd, hd, last_only=True)
+        cell = cell.to(torch.float32)
+    assert Hi.shape == (B, T, F, N) and Hi.is_contiguous() and torch.equal(Hl, Hi[:, -1:])
+    err = np.abs(Hi.double().cpu().numpy() - Href)
+    assert err.max() <= 4e-2 and err.mean() <= 3e-3, (err.max(), err.mean())
+    H = cell(Xd, hd)
+    (H.float() * dHd).sum().backward()
+    got = dict(cell.named_parameters())
+    for n, p in ref.named_parameters():
+        if p.grad is None:
+            assert got[n].grad is None or float(got[n].grad.abs().max()) == 0.0, n
+            continue
+        g, gr = got[n].grad.float(), p.grad
+        assert g.shape == gr.shape, n
+        s = float(gr.abs().max())
+        e = (g - gr).abs()
+        assert s > 0 and float(e.max()) <= 4e-2 * s and (e.numel() < 16 or float(e.mean()) <= 8e-3 * s), (n, float(e.max()) / s, float(e.mean()) / s)
+    assert {k: tuple(v.shape) for k, v in cell.state_dict().items()} == keys          # the shadow cell is not a sub-module
+
+
+@pytest.mark.gpu
+def test_few_input_channels_are_padded_by_the_pack_not_by_a_copy_of_X():
+    """G = 1 in inference: the pack kernel writes the kernels' 32 input channels itself (gcrnn_pack_seq_major_padded); the bits are
+    those of the old route (zero-padded copy of X in the user layout, then pack + inline pack)."""
+    from gated_gcrnns_amd import ops
+    dev = torch.device('cuda:0')
+    for (N, G, F, K, B, T) in [(1000, 1, 64, 5, 5, 4), (600, 3, 32, 3, 4, 3), (1000, 20, 64, 4, 3, 2)]:
+        cell, rng, _ = _uniform_cell(N, G, F, K, False, 91, dev)
+        X = torch.tensor(rng.standard_normal((B, T, G, N)), dtype=torch.float32, device=dev).to(torch.bfloat16)
+        h0 = torch.tensor(0.3 * rng.standard_normal((B, F, N)), dtype=torch.float32, device=dev).to(torch.bfloat16)
+        with torch.no_grad():
+            H1 = cell(X, h0)
+            Xp, wA = ops.fused_pad_operands(X, cell.weight_A.detach())
+            H0 = ops.fused_cell_forward(Xp, h0, wA, cell.weight_B, cell.bias, cell.graph)
+            xs = ops.fused_pack_inputs(X, h0, cell.graph, channels=Xp.shape[2])[0]
+            assert torch.equal(xs, ops.to_sequence_major(Xp, cell.graph))
+        assert torch.equal(H0, H1)
