@@ -32,7 +32,7 @@ static __device__ unsigned long long gcrnn_seq_stamps[256 * 64];      // one cop
 // (staged in the 512 spare bytes behind the transposed output tile -- an LDS address needs no scalar registers -- and copied out at the end)
 #define GCRNN_STAMP(slot)                                                                                     \
   do {                                                                                                        \
-    if (tid == 0) *reinterpret_cast<volatile unsigned long long*>(smem + 33280 + 8 * (slot)) = __builtin_amdgcn_s_memtime(); \
+    if (tid == 0 && stamp_on) *reinterpret_cast<volatile unsigned long long*>(smem + 33280 + 8 * (slot)) = __builtin_amdgcn_s_memtime(); \
   } while (0)
 #define GCRNN_STAMP_FLUSH()                                                                                   \
   do {                                                                                                        \
@@ -91,6 +91,7 @@ __global__ __launch_bounds__(STHREADS) void fused_seq_kernel(const SeqArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 15, q = lane >> 4;
   if ((int)blockIdx.x >= B) return;
+  [[maybe_unused]] bool stamp_on = true;      // (diagnostic builds: which step's phases are recorded)
   GCRNN_STAMP(0);
 
   // once per launch: tile tables, and -- by LDS-DMA, all pieces in flight together -- the column image and chunk 0's weights
@@ -117,6 +118,10 @@ __global__ __launch_bounds__(STHREADS) void fused_seq_kernel(const SeqArgs a) {
                                        (__attribute__((address_space(3))) void*)(smem + IMG + p * 1024), 16, 0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
+  // the bias (2 b: the one bias enters through both filters, graphML.py:2420-2421) in the 256 spare bytes behind the transposed tile:
+  // a chunk reads its four values from LDS instead of waiting for a global load at the top of every chunk
+  float* lbias = reinterpret_cast<float*>(smem + 33024);
+  if (MODE == 0 && tid < F) lbias[tid] = a.bias ? 2.f * a.bias[tid] : 0.f;
   __syncthreads();
 
   const uint32_t lds0 = (uint32_t)reinterpret_cast<uintptr_t>(smem);
@@ -126,6 +131,7 @@ __global__ __launch_bounds__(STHREADS) void fused_seq_kernel(const SeqArgs a) {
   for (int b = blockIdx.x; b < B; b += gridDim.x) {
 #pragma unroll 1
   for (int step = 0; step < a.nsteps; ++step) {
+    stamp_on = (step == (a.nsteps > 1 ? a.nsteps - 2 : 0));      // a typical step: it also lays out the next step's operand
     // this step's arrays (wave-uniform pointer arithmetic; descriptors in SGPRs)
     const uint16_t* hprev = step == 0 ? a.hfirst : a.hrest + (int64_t)(step - 1) * a.hstride;
     const uint16_t* xt = (XS > 0) ? a.x0 + (int64_t)step * a.xstride : nullptr;
@@ -145,17 +151,18 @@ __global__ __launch_bounds__(STHREADS) void fused_seq_kernel(const SeqArgs a) {
 
     // ---- the operand of this sequence and step: every B fragment of the wave, requested at once, resident for all chunks -------
     bf16x8 bfr[STILES][KS];
+    // (k-step major: the seed's first MFMAs need k-step 0 of every tile, which is then the first quarter of the requests to land)
 #pragma unroll
-    for (int i = 0; i < STILES; ++i) {
-      int w = woff[i];
-      asm volatile("" : "+v"(w));
-      const int roh = (w >> 16) * (F * 2) + 16 * q, rox = (w >> 16) * (G * 2) + 16 * q;
+    for (int s = 0; s < KS; ++s) {
 #pragma unroll
-      for (int s = 0; s < HS; ++s)
-        bfr[i][s] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsrc_h, roh + 64 * s, b * (NP * F * 2), 0));
-#pragma unroll
-      for (int s = 0; s < XS; ++s)
-        bfr[i][HS + s] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, rox + 64 * s, b * (NP * G * 2), 0));
+      for (int i = 0; i < STILES; ++i) {
+        int w = woff[i];
+        asm volatile("" : "+v"(w));
+        if (s < HS)
+          bfr[i][s] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsrc_h, (w >> 16) * (F * 2) + 16 * q + 64 * s, b * (NP * F * 2), 0));
+        else
+          bfr[i][s] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, (w >> 16) * (G * 2) + 16 * q + 64 * (s - HS), b * (NP * G * 2), 0));
+      }
     }
     float gsc = 1.f;
     if (MODE == 2 && a.gf0) gsc = a.gf0[(int64_t)step * a.gfstride + b];
@@ -192,11 +199,6 @@ __global__ __launch_bounds__(STHREADS) void fused_seq_kernel(const SeqArgs a) {
       // from it inside the loop -- hoisted out of the loops it would have to be spilled (the operand owns 128 registers)
       int tl = tid;
       asm volatile("" : "+v"(tl));
-      float bvec[4] = {0.f, 0.f, 0.f, 0.f};
-      if (MODE == 0 && a.bias) {
-#pragma unroll
-        for (int c = 0; c < 4; ++c) bvec[c] = a.bias[chunk * FC + q * 4 + c];
-      }
       lds_barrier();      // the seed is in the image
       GCRNN_STAMP(2 + chunk * 14);
 
@@ -205,19 +207,24 @@ __global__ __launch_bounds__(STHREADS) void fused_seq_kernel(const SeqArgs a) {
       {
         constexpr int NPC = NP / NCH;
         const int prow = tl >> 3, pj = tl & 7;
+#ifdef GCRNN_SEQ_PK_PREFETCH      // A/B (tools/seq_stamps.py, GCRNN_STAMP_FLAGS): touching the cold user-layout rows from here makes hop 1 take 64 instead of 42 k-cycles/100 and the launch 4.4 % longer (profiles/r03_seq_stamps_*.txt) -- off
         if (pk_src && prow < PKROWS && pj < 5 && chunk * NPC < N) {
           int node = chunk * NPC + (pj < 4 ? pj * 64 : NPC - 2);
           node = node < N - 2 ? node : N - 2;
           prefetched_pk = *reinterpret_cast<const uint32_t*>(pk_src + (int64_t)b * pk_stride + (int64_t)prow * N + node);
         }
+#endif
       }
-      uint32_t prefetched_epi = 0;
+      uint32_t prefetched_epi = 0, prefetched_epi2 = 0;
       if constexpr (MODE == 2) {
         constexpr int ELINES = NP * F * 2 / 128 / NCH;
         const int idx = tl < ELINES ? tl : tl - ELINES;
-        // (two branches, each with a wave-uniform descriptor: a per-lane choice of the descriptor becomes a waterfall loop)
+        // two branches, each with a wave-uniform descriptor (a per-lane choice of the descriptor becomes a waterfall loop) and its OWN
+        // destination register (two in-flight loads into one register make hipcc wait for the first: a cold HBM latency per chunk)
+#ifdef GCRNN_SEQ_EPI_PREFETCH      // A/B: with the operand loads spread over the hops (below) a touch of their lines from here only costs (taps of hop 1: 35 instead of 5 k-cycles/100, launch + 4.2 %) -- off
         if (tl < ELINES) prefetched_epi = __builtin_amdgcn_raw_buffer_load_b32(rsrc_a1, (chunk * ELINES + idx) * 128, b * (NP * F * 2), 0);
-        else if (tl < 2 * ELINES) prefetched_epi = __builtin_amdgcn_raw_buffer_load_b32(rsrc_a0, (chunk * ELINES + idx) * 128, b * (NP * F * 2), 0);
+        else if (tl < 2 * ELINES) prefetched_epi2 = __builtin_amdgcn_raw_buffer_load_b32(rsrc_a0, (chunk * ELINES + idx) * 128, b * (NP * F * 2), 0);
+#endif
       }
 
       u32x2 eph[MODE == 2 ? STILES : 1], epg[MODE == 2 ? STILES : 1];
@@ -226,10 +233,15 @@ __global__ __launch_bounds__(STHREADS) void fused_seq_kernel(const SeqArgs a) {
       for (int j = 1; j < K; ++j) {
         taps(K - 1 - j, chunk);
         GCRNN_STAMP(2 + chunk * 14 + 2 * j - 1);
-        if (j == K - 1) {
-          if constexpr (MODE == 2) {
+        if constexpr (MODE == 2) {
+          // the epilogue's operands h_{t-1}, dH_{t-1} of this lane's (node, 4 features): 8-byte gathers of 32-byte row pieces, whose
+          // issue alone costs ~4.5 k cycles per chunk when all 16 are requested at once (measured at the last hop). Spread over the
+          // hops -- STILES / (K - 1) tiles before each -- the memory pipeline absorbs them while the wave streams LDS.
+          constexpr int HL = (K > 2) ? K - 2 : 1;                     // hops that carry loads: all but the last (it issues the LDS-DMA pieces)
+          constexpr int PER = (STILES + HL - 1) / HL;
+          if (j <= HL) {
 #pragma unroll
-            for (int i = 0; i < STILES; ++i) {
+            for (int i = (j - 1) * PER; i < j * PER && i < STILES; ++i) {
               int wv = woff[i];
               asm volatile("" : "+v"(wv));
               const int eoff = (wv >> 16) * (F * 2) + (chunk * FC + q * 4) * 2;
@@ -237,7 +249,10 @@ __global__ __launch_bounds__(STHREADS) void fused_seq_kernel(const SeqArgs a) {
               epg[i] = __builtin_amdgcn_raw_buffer_load_b64(rsrc_a0, eoff, b * (NP * F * 2), 0);
             }
           }
+        }
+        if (j == (K > 2 ? K - 2 : K - 1)) {
           // the next chunk's weight fragments (after the last chunk: those of chunk 0, for the next step): LDS-DMA into the other buffer
+          // (free since this chunk's seed: the previous chunk was its last reader), one hop before the inline-pack pieces
           {
             const int nc = (chunk + 1) % NCH;
             const char* wsrc = reinterpret_cast<const char*>(a.wpack) + (size_t)nc * WB;
@@ -250,6 +265,8 @@ __global__ __launch_bounds__(STHREADS) void fused_seq_kernel(const SeqArgs a) {
                                                  (__attribute__((address_space(3))) void*)(wdst + piece * 1024), 16, 0, 0);
             }
           }
+        }
+        if (j == K - 1) {
           if (pk_src) {
             constexpr int NPC = NP / NCH, PPR = NPC / 8, PIECES = PKROWS * PPR;
             static_assert(PIECES % STHREADS == 0, "whole pieces per thread");
@@ -329,7 +346,7 @@ __global__ __launch_bounds__(STHREADS) void fused_seq_kernel(const SeqArgs a) {
       } else {
         float bsum[4];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) bsum[c] = 2.f * bvec[c];      // the one bias is added by both filters (graphML.py:2420-2421)
+        for (int c = 0; c < 4; ++c) bsum[c] = lbias[chunk * FC + q * 4 + c];
 #pragma unroll
         for (int i = 0; i < STILES; ++i) {
           int wv = woff[i];
@@ -429,7 +446,7 @@ __global__ __launch_bounds__(STHREADS) void fused_seq_kernel(const SeqArgs a) {
       asm volatile("s_waitcnt vmcnt(0)" ::"v"(vv[0]), "v"(vv[RI - 1]) : "memory");
 #pragma unroll
       for (int i = 1; i + 1 < RI; ++i) asm volatile("" ::"v"(vv[i]));
-      asm volatile("" ::"v"(prefetched_epi), "v"(prefetched_pk));
+      asm volatile("" ::"v"(prefetched_epi), "v"(prefetched_epi2), "v"(prefetched_pk));
     }  // chunks
 #pragma unroll
     for (int i = 0; i < STILES; ++i)

@@ -20,7 +20,7 @@ if os.environ.get('GCRNN_HOP16_EXPERIMENT_ONE_MFMA'):      # timing experiment (
 procs = []
 for f in sorted(glob.glob(C + '/*.hip') + glob.glob(C + '/*.cpp')):
     o = os.path.join(out, os.path.basename(f) + '.o')
-    procs.append(subprocess.Popen(['/opt/rocm/bin/hipcc', '-O3', '-std=c++17', '--offload-arch=gfx950', '-fPIC', '-DGCRNN_SEQ_STAMPS', '-I' + os.path.join(R, 'include'), '-c', f, '-o', o]))
+    procs.append(subprocess.Popen(['/opt/rocm/bin/hipcc', '-O3', '-std=c++17', '--offload-arch=gfx950', '-fPIC', '-DGCRNN_SEQ_STAMPS'] + os.environ.get('GCRNN_STAMP_FLAGS', '').split() + ['-I' + os.path.join(R, 'include'), '-c', f, '-o', o]))
 assert all(p.wait() == 0 for p in procs)
 lib = os.path.join(out, 'lib.so')
 subprocess.check_call(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-shared', '-fPIC', '-o', lib] + sorted(glob.glob(out + '/*.o')))
@@ -38,9 +38,17 @@ cell.addGSO(torch.tensor(bench.sbm_graph(N)))
 cell = cell.to(torch.bfloat16).to(dev)
 X = torch.randn(B, T, F, N, device=dev).to(torch.bfloat16)
 h0 = torch.zeros(B, F, N, device=dev, dtype=torch.bfloat16)
-with torch.no_grad():
-    for _ in range(3):
-        cell(X, h0)
+TRAIN = len(sys.argv) > 1 and sys.argv[1] == 'train'      # (GCRNN_STAMP_FLAGS='-DGCRNN_SEQ_NO_PK_PREFETCH' etc. for A/B builds)
+if TRAIN:        # the stamps then come from the BPTT data chain (MODE 2), the last sequence-resident launch of a training step
+    cell = cell.float()
+    target = torch.randn(B, T, F, N, device=dev).to(torch.bfloat16)
+    for _ in range(2):
+        cell.zero_grad()
+        torch.nn.functional.l1_loss(cell(X, h0).float(), target.float()).backward()
+else:
+    with torch.no_grad():
+        for _ in range(3):
+            cell(X, h0)
 torch.cuda.synchronize()
 buf = np.zeros(256 * 64, dtype=np.uint64)
 dll = ctypes.CDLL(lib)
