@@ -93,7 +93,11 @@ __device__ __forceinline__ void state_put(float* state, int wv, const f32x4& v) 
 // issued (measured in the sequence-resident kernel: ~1.5 k cycles per chunk). Where only LDS contents change hands, waiting for this
 // wave's LDS operations is enough; the places that hand GLOBAL data between waves (LDS-DMA tiles, a step boundary inside a launch) wait
 // for vmcnt(0) explicitly.
+#ifdef GCRNN_FENCED_BARRIERS      // A/B switch (tools/ab_build.sh): the compiler's fenced barrier everywhere, as in rounds 1-2
+__device__ __forceinline__ void lds_barrier() { __syncthreads(); }
+#else
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+#endif
 
 // ------------------------------------------------------------------------------------------
 // the fused step

@@ -164,7 +164,7 @@ __global__ __launch_bounds__(512, 2) void fused_wgrad_kernel(
           *reinterpret_cast<uint16_t*>(tb + (q * 4 + (c ^ ro)) * TSTRIDE) = f2bf(v);
         }
       }
-      __syncthreads();
+      lds_barrier();      // LDS hand-off only: loads in flight stay in flight (gcrnn_fused_step.h)
       // S2: D_k += du_k^T z over nodes 0..511 (register-resident fragments), then the first re-fetched batch (nodes 512..767)
       if (live) {
 #pragma unroll
@@ -211,7 +211,7 @@ __global__ __launch_bounds__(512, 2) void fused_wgrad_kernel(
           for (int p = 0; p < 4; ++p) accD[k] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a4[p], bl1[s4 + p], accD[k], 0, 0, 0);
         }
       }
-      __syncthreads();
+      lds_barrier();      // LDS hand-off only: loads in flight stay in flight (gcrnn_fused_step.h)
     }
     } else {
 #pragma unroll
@@ -232,7 +232,7 @@ __global__ __launch_bounds__(512, 2) void fused_wgrad_kernel(
           }
         }
       }
-      __syncthreads();
+      lds_barrier();      // LDS hand-off only: loads in flight stay in flight (gcrnn_fused_step.h)
       // S2: D_k += du_k^T z over nodes 0..511
       if (live) {
 #pragma unroll
@@ -245,7 +245,7 @@ __global__ __launch_bounds__(512, 2) void fused_wgrad_kernel(
           for (int p = 0; p < 4; ++p) accD[k] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a4[p], bfr[s4 + p], accD[k], 0, 0, 0);
         }
       }
-      __syncthreads();
+      lds_barrier();      // LDS hand-off only: loads in flight stay in flight (gcrnn_fused_step.h)
       // S3: transposed image of nodes 512..1023
 #pragma unroll
       for (int i = 0; i < TILES; ++i) {
@@ -261,7 +261,7 @@ __global__ __launch_bounds__(512, 2) void fused_wgrad_kernel(
           }
         }
       }
-      __syncthreads();
+      lds_barrier();      // LDS hand-off only: loads in flight stay in flight (gcrnn_fused_step.h)
       // S4: du_{k+1} = S du_k (reads `state`; the transposed image of du_k stays valid);  S5: second half of the contraction
 #ifdef GCRNN_WGRAD_ABLATE_HOP      // profiling builds (tools/wgrad_ablate.sh): results are wrong by construction
       if (false) {
@@ -315,7 +315,7 @@ __global__ __launch_bounds__(512, 2) void fused_wgrad_kernel(
           for (int s2 = 0; s2 < 8; ++s2) accD[k] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[s2], bl[s2], accD[k], 0, 0, 0);
         }
       }
-      __syncthreads();
+      lds_barrier();      // LDS hand-off only: loads in flight stay in flight (gcrnn_fused_step.h)
     }
     }
   }

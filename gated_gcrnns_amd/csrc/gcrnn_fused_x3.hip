@@ -77,7 +77,10 @@ __global__ void pack_weights_x3_kernel(const float* __restrict__ wA, const float
   out[idx] = a; out[idx + total] = b; out[idx + 2 * total] = c;
 }
 
-template <int K, int HS, int XS>
+// EPI 0: forward step (bias, tanh).  EPI 2 (XS = 0): BPTT data-gradient step in the same arithmetic -- operand = the planes of
+// dpre_t, taps = the transposed state taps, adjoint graph; epilogue dpre_{t-1} = (acc + dH_{t-1}) (1 - h_{t-1}^2) in fp32 with dH and h
+// re-assembled from their planes (aux0 / aux1, both may be null: the raw state gradient d h0), stored as three planes again.
+template <int K, int HS, int XS, int EPI = 0>
 __global__ __launch_bounds__(STHREADS) void fused_step_x3_kernel(
     const uint16_t* __restrict__ xt3,        // [3][B][NP][G]  planes of x_t
     const uint16_t* __restrict__ hp3,        // [3][B][NP][F]  planes of h_{t-1}
@@ -87,7 +90,9 @@ __global__ __launch_bounds__(STHREADS) void fused_step_x3_kernel(
     const int32_t* __restrict__ tile_nodes, const int32_t* __restrict__ tile_off, const uint2* __restrict__ ell_col4,
     float* __restrict__ Huser,               // user-layout fp32 output block of this step, H[.][t][F][N] (or null)
     int64_t ubstride,                        // elements between consecutive sequences of Huser
-    int entries, int B, int N, float uni_w) {
+    int entries, int B, int N, float uni_w,
+    const uint16_t* __restrict__ aux0_3,               // EPI 2: planes of the upstream gradient dH_{t-1} [3][B][NP][F] (or null)
+    const uint16_t* __restrict__ aux1_3) {             // EPI 2: planes of the state h_{t-1} [3][B][NP][F] (or null)
   static_assert(GCRNN_HOP_ASM && GCRNN_STEP_WAVES == 8, "x3 runs on the one-block asm hop stream");
   constexpr int KS = HS + XS, F = 32 * HS, G = 32 * XS, NCH = F / FC, HT = STILES;
   constexpr int WPL = K * KS * 64;            // uint4 fragments per weight plane and chunk
@@ -132,6 +137,8 @@ __global__ __launch_bounds__(STHREADS) void fused_step_x3_kernel(
   const __amdgpu_buffer_rsrc_t rsrc_h = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(hp3), 0, 3 * B * (NP * F * 2), 0x00020000);
   const __amdgpu_buffer_rsrc_t rsrc_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(xt3), 0, 3 * B * (NP * G * 2), 0x00020000);
   const __amdgpu_buffer_rsrc_t rsrc_o = __builtin_amdgcn_make_buffer_rsrc(ho3, 0, 3 * B * (NP * F * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_a0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(aux0_3), 0, (EPI == 2 && aux0_3) ? 3 * B * (NP * F * 2) : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_a1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(aux1_3), 0, (EPI == 2 && aux1_3) ? 3 * B * (NP * F * 2) : 0, 0x00020000);
 
   for (int b = b0; b < B; b += seq_slots) {
     // ---- phase 1: taps, six partial products per operand pair, two tiles per weight fragment ------------------------------
@@ -186,7 +193,7 @@ __global__ __launch_bounds__(STHREADS) void fused_step_x3_kernel(
         }
       }
     }
-    __syncthreads();
+    lds_barrier();
     // ---- phase 2: Horner hops on the fp32 state image (uniform-weight asm stream) -------------------------------------------
 #pragma unroll
     for (int j = 1; j < K; ++j) {
@@ -196,14 +203,14 @@ __global__ __launch_bounds__(STHREADS) void fused_step_x3_kernel(
 #undef GCRNN_X3_INIT
 #undef GCRNN_X3_STORE
       if (j < K - 1) {
-        __syncthreads();
+        lds_barrier();
 #pragma unroll
         for (int i = 0; i < STILES; ++i) {
           int wv = woff[i];
           asm volatile("" : "+v"(wv));
           *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(state) + (wv & 0xffff)) = u[i][K - 1 - j];
         }
-        __syncthreads();
+        lds_barrier();
       }
     }
     // ---- epilogue: bias, tanh, three planes of h_t; fp32 user-layout copy through an LDS transpose in two node halves ------
@@ -214,14 +221,34 @@ __global__ __launch_bounds__(STHREADS) void fused_step_x3_kernel(
       asm volatile("" : "+v"(wv));
       const int node = wv >> 16;
       f32x4 o = {0.f, 0.f, 0.f, 0.f};
-      if (node < N) {
+      const int eoff = node * (F * 2) + (chunk * FC + q * 4) * 2;
+      if constexpr (EPI == 2) {
+        // three planes -> fp32: v = v1 + v2 + v3 (exact: the planes were cut from one fp32 value); zero-length descriptors give 0
+        auto gather3 = [&](const __amdgpu_buffer_rsrc_t& rs) {
+          f32x4 v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int p = 2; p >= 0; --p) {
+            const u32x2 w2 = __builtin_amdgcn_raw_buffer_load_b64(rs, eoff, (p * B + b) * (NP * F * 2), 0);
+            v[0] += bf2f((uint16_t)(w2[0] & 0xffffu)); v[1] += bf2f((uint16_t)(w2[0] >> 16));
+            v[2] += bf2f((uint16_t)(w2[1] & 0xffffu)); v[3] += bf2f((uint16_t)(w2[1] >> 16));
+          }
+          return v;
+        };
+        if (node < N) {
+          o = u[i][LASTU];
+          if (aux0_3) {
+            const f32x4 g = gather3(rsrc_a0), hv = gather3(rsrc_a1);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) o[c] = (o[c] + g[c]) * (1.f - hv[c] * hv[c]);
+          }
+        }
+      } else if (node < N) {
         const f32x4 a = u[i][LASTU];
         o = f32x4{fast_tanh(a[0] + bvec[0]), fast_tanh(a[1] + bvec[1]), fast_tanh(a[2] + bvec[2]), fast_tanh(a[3] + bvec[3])};
       }
       uint16_t p0[4], p1[4], p2[4];
 #pragma unroll
       for (int c = 0; c < 4; ++c) split3(o[c], p0[c], p1[c], p2[c]);
-      const int eoff = node * (F * 2) + (chunk * FC + q * 4) * 2;
       __builtin_amdgcn_raw_buffer_store_b64(u32x2{(uint32_t)p0[0] | ((uint32_t)p0[1] << 16), (uint32_t)p0[2] | ((uint32_t)p0[3] << 16)}, rsrc_o, eoff, (0 * B + b) * (NP * F * 2), 0);
       __builtin_amdgcn_raw_buffer_store_b64(u32x2{(uint32_t)p1[0] | ((uint32_t)p1[1] << 16), (uint32_t)p1[2] | ((uint32_t)p1[3] << 16)}, rsrc_o, eoff, (1 * B + b) * (NP * F * 2), 0);
       __builtin_amdgcn_raw_buffer_store_b64(u32x2{(uint32_t)p2[0] | ((uint32_t)p2[1] << 16), (uint32_t)p2[2] | ((uint32_t)p2[3] << 16)}, rsrc_o, eoff, (2 * B + b) * (NP * F * 2), 0);
@@ -233,7 +260,7 @@ __global__ __launch_bounds__(STHREADS) void fused_step_x3_kernel(
       float* ub = Huser + (int64_t)b * ubstride + (int64_t)(chunk * FC) * N;
 #pragma unroll
       for (int hf = 0; hf < 2; ++hf) {
-        __syncthreads();                                  // the last hop's reads (hf = 0) / the previous half's row reads are done
+        lds_barrier();                                  // the last hop's reads (hf = 0) / the previous half's row reads are done
 #pragma unroll
         for (int i = 0; i < STILES; ++i) {
           int wv = woff[i];
@@ -244,7 +271,7 @@ __global__ __launch_bounds__(STHREADS) void fused_step_x3_kernel(
             for (int c = 0; c < 4; ++c) *reinterpret_cast<float*>(tst + (q * 4 + c) * RS + (node & 511) * 4) = u[i][LASTU][c];
           }
         }
-        __syncthreads();
+        lds_barrier();
         const int nhalf = (N - 512 * hf) < 512 ? (N - 512 * hf) : 512;      // valid nodes of this half (N % 4 == 0: whole 16-byte segments)
         const int segs = nhalf > 0 ? (nhalf >> 2) : 0;
         for (int idx = tid; idx < FC * segs; idx += STHREADS) {
@@ -253,7 +280,7 @@ __global__ __launch_bounds__(STHREADS) void fused_step_x3_kernel(
         }
       }
     }
-    __syncthreads();      // `state` is free again before the next sequence's taps land in it
+    lds_barrier();      // `state` is free again before the next sequence's taps land in it
   }
 }
 
@@ -279,8 +306,242 @@ int x3_launch(const void* xs3, const void* h03, void* hs3, const void* wpack3, c
     float* hu = !Huser ? nullptr : (!last_only ? Huser + t * F * N : (t == T - 1 ? Huser : nullptr));
     kern<<<(unsigned)(slots * NCH), STHREADS, lds, st>>>(x + t * xstep, hp, h + t * hstep, (const uint4*)wpack3, bias, tile_nodes, tile_off,
                                                         (const uint2*)ell_col4, hu, (int64_t)(last_only ? 1 : T) * F * N, (int)entries, (int)B,
-                                                        (int)N, uni_w);
+                                                        (int)N, uni_w, nullptr, nullptr);
   }
+  GCRNN_CHECK_LAUNCH();
+  return GCRNN_OK;
+}
+
+
+// dpre[i] = dH[i] (1 - h[i]^2) on planes (the seed of the BPTT chain, t = T-1): fp32 from the planes, three planes out
+__global__ void bwd_seed_x3_kernel(const uint16_t* __restrict__ dH3, const uint16_t* __restrict__ h3, uint16_t* __restrict__ out3, int64_t plane) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= plane) return;
+  const float g = bf2f(dH3[i]) + bf2f(dH3[i + plane]) + bf2f(dH3[i + 2 * plane]);
+  const float h = bf2f(h3[i + 2 * plane]) + bf2f(h3[i + plane]) + bf2f(h3[i]);
+  uint16_t a, b, c;
+  split3(g * (1.f - h * h), a, b, c);
+  out3[i] = a; out3[i + plane] = b; out3[i + 2 * plane] = c;
+}
+
+template <int K, int HS>
+int x3_backward_launch(const void* dHs3, const void* hs3, void* dpre3, void* dh03, const void* wpack3T, const int32_t* tile_nodes,
+                       const int32_t* tile_off, const void* ell_col4, int64_t entries, int64_t B, int64_t T, int64_t N, float uni_w,
+                       hipStream_t st) {
+  constexpr int F = 32 * HS, NCH = F / FC;
+  const size_t lds = (size_t)NP * FC * 4 + (size_t)3 * K * HS * 1024 + (size_t)entries * 32;
+  if (lds > 160 * 1024) return GCRNN_ERR_UNSUPPORTED;
+  auto kern = fused_step_x3_kernel<K, HS, 0, 2>;
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    return GCRNN_ERR_LAUNCH;
+  int64_t slots = cdiv(B, 8) * 8;
+  const int64_t max_slots = (256 / NCH) / 8 * 8 > 0 ? (256 / NCH) / 8 * 8 : 8;
+  if (slots > max_slots) slots = max_slots;
+  const int64_t hstep = 3 * B * NP * F, plane = B * NP * F;
+  const uint16_t* dH = (const uint16_t*)dHs3;
+  const uint16_t* hs = (const uint16_t*)hs3;
+  uint16_t* dp = (uint16_t*)dpre3;
+  GCRNN_PRE_LAUNCH();
+  bwd_seed_x3_kernel<<<(unsigned)cdiv(plane, 256), 256, 0, st>>>(dH + (T - 1) * hstep, hs + (T - 1) * hstep, dp + (T - 1) * hstep, plane);
+  for (int64_t t = T - 1; t >= 1; --t)
+    kern<<<(unsigned)(slots * NCH), STHREADS, lds, st>>>(nullptr, dp + t * hstep, dp + (t - 1) * hstep, (const uint4*)wpack3T, nullptr, tile_nodes,
+                                                        tile_off, (const uint2*)ell_col4, nullptr, 0, (int)entries, (int)B, (int)N, uni_w,
+                                                        dH + (t - 1) * hstep, hs + (t - 1) * hstep);
+  if (dh03)
+    kern<<<(unsigned)(slots * NCH), STHREADS, lds, st>>>(nullptr, dp, (uint16_t*)dh03, (const uint4*)wpack3T, nullptr, tile_nodes, tile_off,
+                                                        (const uint2*)ell_col4, nullptr, 0, (int)entries, (int)B, (int)N, uni_w, nullptr, nullptr);
+  GCRNN_CHECK_LAUNCH();
+  return GCRNN_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// fp32 weight gradient of the cell (adjoint of the taps, reference graphML.py:134-135 under autograd):
+//     dW_k[f'][j] = sum_{t,b,n} du_k[t,b][n][f'] z[t,b][n][j],   du_0 = dpre_t,  du_k = S du_{k-1},   z = [h_{t-1} | x_t]
+// with EXACT fp32 products: v_mfma_f32_16x16x4_f32 (the fp32 matrix instruction: 1/16 of the bf16 rate, 4.4 ms of matrix time per
+// training step at B = 256 -- the bf16 kernel's six-plane alternative would need three transposed images of du_k in LDS).
+// One workgroup = (item, 16-feature chunk of dpre); wave w owns input-feature tile w of z. Node index = contraction dimension:
+//   B operand: lane (j, kq) loads z[j][16 m + 4 kq .. + 3] = 16 bytes of the fp32 USER layout (node-contiguous rows) per 4 MFMAs;
+//   A operand: du_k transposed in LDS, fp32 [16 f'][1028]: lane (f', kq) reads the same four nodes with one ds_read_b128 (the row
+//   stride of 1028 words puts the 16 lanes of a read group on 16 different bank quads).
+// du_k is re-assembled from the three planes of dpre (k = 0) or comes from the adjoint hop on the fp32 state image (uniform stream).
+// Accumulators persist over the workgroup's items; per-slot partial sums, added by the caller in a fixed order (deterministic).
+// LDS: state image 64 KiB | column words 32 B x entries | transposed du_k 16 x 4112 B.
+// ------------------------------------------------------------------------------------------
+constexpr int DUT_STRIDE = 4112;
+
+template <int K, int HS, int XS>
+__global__ __launch_bounds__(512) void fused_wgrad_f32_kernel(
+    const uint16_t* __restrict__ dpre3,      // [T][3][B][NP][F] bf16 planes, sequence-major
+    const float* __restrict__ Xuser,         // [B][T][G][N] fp32
+    const float* __restrict__ Huser,         // [B][T][F][N] fp32 (forward output)
+    const float* __restrict__ h0user,        // [B][F][N] fp32
+    float* __restrict__ dW,                  // [slots][F][K][F+G] fp32 partial sums (plain stores)
+    float* __restrict__ dbsum,               // [slots][F] fp32 partials of 2 sum_{t,b,n} dpre (or null)
+    const int32_t* __restrict__ tile_nodes, const int32_t* __restrict__ tile_off, const uint2* __restrict__ ell_col4,
+    int entries, int B, int Tn, int N, float uni_w) {
+  static_assert(GCRNN_HOP_ASM && TILES == 8, "uniform asm hop stream");
+  constexpr int F = 32 * HS, G = 32 * XS, C = F + G, NCH = F / FC, JT = C / 16, HT = TILES;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* state = reinterpret_cast<float*>(smem);
+  uint2* lcol4 = reinterpret_cast<uint2*>(smem + NP * FC * 4);
+  char* dut = smem + NP * FC * 4 + entries * 32;
+  float* lred = reinterpret_cast<float*>(dut + 16 * DUT_STRIDE);      // [WAVES][16] bias partials
+
+  const int L = blockIdx.x;
+  const int grp = L / (8 * NCH), rem = L - grp * (8 * NCH);
+  const int chunk = rem >> 3, it0 = grp * 8 + (rem & 7);
+  const int seq_slots = (gridDim.x / (8 * NCH)) * 8;
+  const int items = B * Tn;
+  if (it0 >= items) return;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 15, q = lane >> 4;
+  {
+    const int n = (entries >> 2) * 16;
+    for (int i = tid; i < n; i += 512) lcol4[i] = ell_col4[i];
+  }
+  int tbeg[TILES], tend[TILES], woff[TILES];
+#pragma unroll
+  for (int i = 0; i < TILES; ++i) {
+    tbeg[i] = tile_off[wave * TILES + i];
+    tend[i] = tile_off[wave * TILES + i + 1];
+    woff[i] = tile_nodes[(wave * TILES + i) * 16 + r] ^ (q << 4);
+  }
+  const uint32_t lds0 = (uint32_t)reinterpret_cast<uintptr_t>(smem);
+  if (lds0 != 0) __builtin_trap();
+  const uint32_t qx = (uint32_t)(q * 16);
+  const uint32_t lds_col = lds0 + NP * FC * 4;
+  f32x4 accD[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) accD[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x4 bacc = {0.f, 0.f, 0.f, 0.f};
+  const bool has_tile = wave < JT;
+  const bool is_x = wave >= F / 16;
+  const int jrow = (is_x ? wave * 16 - F : wave * 16) + r;
+  __syncthreads();
+
+  for (int it = it0; it < items; it += seq_slots) {
+    const int t = it / B, b = it - t * B;
+    // (one descriptor per time step: the three planes of a step span 3 B NP F 2 bytes, all T of them would overflow 32-bit offsets)
+    const __amdgpu_buffer_rsrc_t rsrc_d = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(dpre3) + (int64_t)t * 3 * B * (NP * F), 0,
+                                                                            3 * B * (NP * F * 2), 0x00020000);
+    const float* zsrc;
+    int zrows;
+    if (is_x) { zsrc = Xuser + ((int64_t)b * Tn + t) * G * N; zrows = G; }
+    else if (t > 0) { zsrc = Huser + ((int64_t)b * Tn + (t - 1)) * F * N; zrows = F; }
+    else { zsrc = h0user + (int64_t)b * F * N; zrows = F; }
+    const __amdgpu_buffer_rsrc_t rsrc_z = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(zsrc), 0, has_tile ? zrows * N * 4 : 0, 0x00020000);
+    // du_0 = dpre chunk of this item, fp32 from its planes
+    f32x4 cur[TILES];
+#pragma unroll
+    for (int i = 0; i < TILES; ++i) {
+      int wv = woff[i];
+      asm volatile("" : "+v"(wv));
+      const int eoff = (wv >> 16) * (F * 2) + (chunk * FC + q * 4) * 2;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int p = 2; p >= 0; --p) {
+        const u32x2 w2 = __builtin_amdgcn_raw_buffer_load_b64(rsrc_d, eoff, (p * B + b) * (NP * F * 2), 0);
+        v[0] += bf2f((uint16_t)(w2[0] & 0xffffu)); v[1] += bf2f((uint16_t)(w2[0] >> 16));
+        v[2] += bf2f((uint16_t)(w2[1] & 0xffffu)); v[3] += bf2f((uint16_t)(w2[1] >> 16));
+      }
+      cur[i] = v;
+      bacc += v;
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      // du_k -> the swizzled state image (for the next hop) and the transposed image (A operand)
+#pragma unroll
+      for (int i = 0; i < TILES; ++i) {
+        int wv = woff[i];
+        asm volatile("" : "+v"(wv));
+        if (k < K - 1) *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(state) + (wv & 0xffff)) = cur[i];
+        const int node = wv >> 16;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) *reinterpret_cast<float*>(dut + (q * 4 + c) * DUT_STRIDE + node * 4) = cur[i][c];
+      }
+      lds_barrier();
+      if (has_tile) {
+        // D_k += du_k^T z: 64 groups of 16 nodes, 4 exact-fp32 MFMAs each. The z fragments of the NEXT eight groups are requested
+        // before the 32 MFMAs of the current eight (two register sets, ping-pong): the L2 latency hides under 1024 matrix cycles.
+        auto load_z = [&](int m0, f32x4 (&zz)[8]) {
+#pragma unroll
+          for (int mm = 0; mm < 8; ++mm) {
+            const int n4 = 16 * (m0 + mm) + 4 * q;
+            const int zo = (n4 < N) ? (jrow * N + n4) * 4 : 0x7ffffff0;        // nodes >= N: out of the descriptor's range -> zeros
+            zz[mm] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_z, zo, 0, 0));
+          }
+        };
+        auto mma8 = [&](int m0, const f32x4 (&zz)[8]) {
+          f32x4 da[8];
+#pragma unroll
+          for (int mm = 0; mm < 8; ++mm) da[mm] = *reinterpret_cast<const f32x4*>(dut + r * DUT_STRIDE + (16 * (m0 + mm) + 4 * q) * 4);
+#pragma unroll
+          for (int mm = 0; mm < 8; ++mm)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) accD[k] = __builtin_amdgcn_mfma_f32_16x16x4f32(da[mm][e], zz[mm][e], accD[k], 0, 0, 0);
+        };
+        f32x4 z0[8], z1[8];
+        load_z(0, z0);
+#pragma unroll 1
+        for (int m0 = 0; m0 < NP / 16; m0 += 16) {
+          load_z(m0 + 8, z1);
+          mma8(m0, z0);
+          if (m0 + 16 < NP / 16) load_z(m0 + 16, z0);
+          mma8(m0 + 8, z1);
+        }
+      }
+      if (k < K - 1) {
+        LGKM_WAIT(0);
+#define GCRNN_WF_INIT(i) f32x4{0.f, 0.f, 0.f, 0.f}
+#define GCRNN_WF_STORE(i, a) cur[i] = a
+        GCRNN_HOP_ASM_UNI_STREAM(GCRNN_WF_INIT, GCRNN_WF_STORE);
+#undef GCRNN_WF_INIT
+#undef GCRNN_WF_STORE
+      }
+      lds_barrier();
+    }
+  }
+  if (has_tile) {
+    float* dWs = dW + (int64_t)it0 * (F * K * C);
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+        dWs[((int64_t)(chunk * FC + q * 4 + c) * K + k) * C + wave * 16 + r] = accD[k][c];
+  }
+  if (dbsum) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      float v = bacc[c];
+#pragma unroll
+      for (int off = 1; off < 16; off <<= 1) v += __shfl_xor(v, off, 64);
+      if (r == 0) lred[wave * FC + q * 4 + c] = 2.f * v;              // the one bias enters both filters
+    }
+    __syncthreads();
+    if (tid < FC) {
+      float v = 0.f;
+#pragma unroll
+      for (int w = 0; w < WAVES; ++w) v += lred[w * FC + tid];
+      dbsum[(int64_t)it0 * F + chunk * FC + tid] = v;
+    }
+  }
+}
+
+template <int K, int HS, int XS>
+int x3_wgrad_launch(const void* dpre3, const void* Xuser, const void* Huser, const void* h0user, float* dW, float* dbsum,
+                    const int32_t* tile_nodes, const int32_t* tile_off, const void* ell_col4, int64_t entries, int64_t B, int64_t T,
+                    int64_t N, float uni_w, hipStream_t st) {
+  constexpr int F = 32 * HS, NCH = F / FC;
+  const size_t lds = (size_t)NP * FC * 4 + (size_t)entries * 32 + 16 * DUT_STRIDE + WAVES * FC * 4;
+  if (lds > 160 * 1024) return GCRNN_ERR_UNSUPPORTED;
+  auto kern = fused_wgrad_f32_kernel<K, HS, XS>;
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    return GCRNN_ERR_LAUNCH;
+  const int64_t slots = gcrnn_fused_wgrad_slots(B * T, F);
+  GCRNN_PRE_LAUNCH();
+  kern<<<(unsigned)(slots * NCH), 512, lds, st>>>((const uint16_t*)dpre3, (const float*)Xuser, (const float*)Huser, (const float*)h0user, dW, dbsum,
+                                                   tile_nodes, tile_off, (const uint2*)ell_col4, (int)entries, (int)B, (int)T, (int)N, uni_w);
   GCRNN_CHECK_LAUNCH();
   return GCRNN_OK;
 }
@@ -310,7 +571,7 @@ extern "C" int gcrnn_pack_seq_major_x3(const void* src, void* dst, int64_t B, in
 extern "C" int gcrnn_fused_pack_weights_x3(const void* wA, const void* wB, void* wpack3, int64_t F, int64_t G, int64_t Kin, int64_t Kst,
                                            void* stream) {
   if (!wA || !wB || !wpack3) return GCRNN_ERR_NULL_POINTER;
-  if (F <= 0 || G <= 0 || F % FC || (F + G) % 32 || Kin <= 0 || Kst <= 0) return GCRNN_ERR_BAD_SHAPE;
+  if (F <= 0 || G < 0 || F % FC || (F + G) % 32 || Kin <= 0 || Kst <= 0) return GCRNN_ERR_BAD_SHAPE;      // (G = 0: a state-only operand, the BPTT chain's transposed taps)
   const int K = (int)(Kin > Kst ? Kin : Kst);
   const int64_t total = (F / FC) * K * ((F + G) / 32) * 64 * 8;
   GCRNN_PRE_LAUNCH();
@@ -340,4 +601,52 @@ extern "C" int gcrnn_fused_forward_x3(const void* xs3, const void* h03, void* hs
   GCRNN_X3_CASE(5, 1, 1) GCRNN_X3_CASE(4, 1, 1) GCRNN_X3_CASE(3, 1, 1) GCRNN_X3_CASE(2, 1, 1)
 #undef GCRNN_X3_CASE
   return GCRNN_ERR_UNSUPPORTED;
+}
+
+// BPTT data chain at fp32 accuracy (x3): dHs3 / hs3 [T][3][B][NPad][F] planes of the upstream gradients and of the states (the forward's
+// hs3), dpre3 [T][3][B][NPad][F] (out), dh03 [3][B][NPad][F] or NULL (out: the raw gradient of the initial state), wpack3T = the
+// TRANSPOSED state taps packed as a state-only operand (gcrnn_fused_pack_weights_x3 with G = 0), graph arrays of the ADJOINT uniform
+// plan. One seed launch + T - 1 (+ 1) launches of the x3 step kernel with the chain epilogue. Reference: autograd of
+// Utils/graphML.py:2420-2423 in the drivers' precision (kStepPredGRNNs.py:44).
+extern "C" int gcrnn_fused_backward_data_x3(const void* dHs3, const void* hs3, void* dpre3, void* dh03, const void* wpack3T,
+                                            const int32_t* tile_nodes, const int32_t* tile_off, const void* ell_col4, int64_t entries,
+                                            int64_t B, int64_t T, int64_t N, int64_t F, int64_t K, double uniform_w, void* stream) {
+  if (!dHs3 || !hs3 || !dpre3 || !wpack3T || !tile_nodes || !tile_off || !ell_col4) return GCRNN_ERR_NULL_POINTER;
+  if (B <= 0 || T <= 0 || uniform_w == 0.0 || !gcrnn_fused_x3_supported(N, F, F, K, entries)) return GCRNN_ERR_BAD_SHAPE;
+  if (3 * B * (NP * F * 2) > 2147483647LL) return GCRNN_ERR_BAD_SHAPE;
+  hipStream_t st = as_stream(stream);
+#define GCRNN_X3B_CASE(KK, HH) \
+  if (K == KK && F == 32 * HH) return x3_backward_launch<KK, HH>(dHs3, hs3, dpre3, dh03, wpack3T, tile_nodes, tile_off, ell_col4, entries, B, T, N, (float)uniform_w, st);
+  GCRNN_X3B_CASE(5, 2) GCRNN_X3B_CASE(4, 2) GCRNN_X3B_CASE(3, 2) GCRNN_X3B_CASE(2, 2)
+  GCRNN_X3B_CASE(5, 1) GCRNN_X3B_CASE(4, 1) GCRNN_X3B_CASE(3, 1) GCRNN_X3B_CASE(2, 1)
+#undef GCRNN_X3B_CASE
+  return GCRNN_ERR_UNSUPPORTED;
+}
+
+// fp32 weight gradient of the fused cell on exact-fp32 matrix instructions: dW [slots][F][K][F+G] / dbsum [slots][F] (or NULL) per-slot
+// partial sums (slots = gcrnn_fused_wgrad_slots(B T, F); the caller adds them in a fixed order), dpre3 from
+// gcrnn_fused_backward_data_x3, X / H / h0 fp32 in the USER layout (H = the forward's output), adjoint uniform plan.
+extern "C" int gcrnn_fused_backward_weight_f32(const void* dpre3, const void* Xuser, const void* Huser, const void* h0user, float* dW,
+                                               float* dbsum, const int32_t* tile_nodes, const int32_t* tile_off, const void* ell_col4,
+                                               int64_t entries, int64_t B, int64_t T, int64_t N, int64_t F, int64_t G, int64_t K,
+                                               double uniform_w, void* stream) {
+  if (!dpre3 || !Xuser || !Huser || !h0user || !dW || !tile_nodes || !tile_off || !ell_col4) return GCRNN_ERR_NULL_POINTER;
+  if (B <= 0 || T <= 0 || N <= 0 || N > NP || N % 4 || entries < 0 || entries % 4 || uniform_w == 0.0 || B * T > (1 << 24)) return GCRNN_ERR_BAD_SHAPE;
+  if (3 * B * (NP * F * 2) > 2147483647LL || (int64_t)(F > G ? F : G) * N * 4 > 2147483647LL) return GCRNN_ERR_BAD_SHAPE;      // 32-bit buffer offsets (per time step)
+  if ((reinterpret_cast<uintptr_t>(Xuser) | reinterpret_cast<uintptr_t>(Huser) | reinterpret_cast<uintptr_t>(h0user)) & 15) return GCRNN_ERR_BAD_SHAPE;
+  hipStream_t st = as_stream(stream);
+#define GCRNN_WF_CASE(KK, HH, XX) \
+  if (K == KK && F == 32 * HH && G == 32 * XX) return x3_wgrad_launch<KK, HH, XX>(dpre3, Xuser, Huser, h0user, dW, dbsum, tile_nodes, tile_off, ell_col4, entries, B, T, N, (float)uniform_w, st);
+  GCRNN_WF_CASE(5, 2, 2) GCRNN_WF_CASE(4, 2, 2) GCRNN_WF_CASE(3, 2, 2) GCRNN_WF_CASE(2, 2, 2)
+  GCRNN_WF_CASE(5, 2, 1) GCRNN_WF_CASE(4, 2, 1) GCRNN_WF_CASE(3, 2, 1) GCRNN_WF_CASE(2, 2, 1)
+  GCRNN_WF_CASE(5, 1, 1) GCRNN_WF_CASE(4, 1, 1) GCRNN_WF_CASE(3, 1, 1) GCRNN_WF_CASE(2, 1, 1)
+#undef GCRNN_WF_CASE
+  return GCRNN_ERR_UNSUPPORTED;
+}
+
+// Can the fp32-accurate BPTT (gcrnn_fused_backward_data_x3 + gcrnn_fused_backward_weight_f32) take this cell? The forward's shapes,
+// and an ADJOINT uniform graph image of `entries_adj` ELL entries next to the fp32 state image and the transposed fp32 image of du_k.
+extern "C" int gcrnn_fused_x3_training_supported(int64_t N, int64_t F, int64_t G, int64_t K, int64_t entries_adj) {
+  if (!gcrnn_fused_x3_supported(N, F, G, K, entries_adj) || !gcrnn_fused_x3_supported(N, F, F, K, entries_adj)) return 0;
+  return (int64_t)NP * FC * 4 + entries_adj * 32 + 16 * DUT_STRIDE + WAVES * FC * 4 <= 160 * 1024;
 }

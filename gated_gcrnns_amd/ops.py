@@ -1222,10 +1222,11 @@ def time_fused_x3_kernel(X, h0, wA, wB, bias, graph, reps=3):
     return {'avg_us': 1e3 * e0.elapsed_time(e1) / (reps * T), 'launches': reps * T}
 
 
-def fused_cell_forward_x3(X, h0, wA, wB, bias, graph, last_only=False):
+def fused_cell_forward_x3(X, h0, wA, wB, bias, graph, last_only=False, keep=False):
     """Un-gated GGCRNNCell forward to fp32 accuracy on the fused kernels (three bf16 planes per fp32 operand, six partial
     products per tap product on the bf16 matrix cores, fp32 hops / tanh). X: B x T x G x N fp32, h0: B x F x N fp32 ->
-    H: B x T x F x N fp32 (B x 1 x F x N with last_only). Inference only (no autograd graph)."""
+    H: B x T x F x N fp32 (B x 1 x F x N with last_only). No autograd graph here; keep: also returns the planes of the states
+    hs3 [T][3][B][NPad][F] and the (channel-padded) X the kernels ran on -- what the fp32-accurate BPTT needs."""
     require_device(X, h0, wA, wB, bias)
     X, wA = fused_pad_operands(X, wA.detach())
     B, T, G, N = X.shape
@@ -1250,7 +1251,79 @@ def fused_cell_forward_x3(X, h0, wA, wB, bias, graph, last_only=False):
     check(lib.gcrnn_fused_forward_x3(_p(xs3), _p(h03), _p(hs3), _p(wp3), _p(b32), _p(plan['tile_slots']), _p(plan['tile_off']),
                                      _p(plan['ell_col4']), plan['entries'], B, T, N, F, G, K, plan['uniform_w'], _p(H),
                                      int(last_only), st), 'fused_forward_x3')
+    if keep:
+        return H, hs3, Xc
     return H
+
+
+def fused_x3_training_supported(graph, N, F, G, Kin, Kst, dtype, E=1):
+    """fp32-accurate training of the un-gated cell on the fused kernels: the x3 forward's conditions, and the ADJOINT graph uniform
+    too (a symmetric-support GSO like the drivers' W / lambda_max) with an image that fits next to the backward's two fp32 images."""
+    if not fused_x3_supported(graph, N, F, G, Kin, Kst, dtype, E):
+        return False
+    pa = graph.fused_plan(adjoint=True)
+    Gp = fused_padded_inputs(F, G)
+    return pa.get('uniform_w', 0.0) != 0.0 and bool(lib.gcrnn_fused_x3_training_supported(int(N), int(F), int(Gp), int(max(Kin, Kst)), int(pa['entries'])))
+
+
+class _FusedCellX3(torch.autograd.Function):
+    """Un-gated GGCRNNCell at fp32 accuracy on the fused kernels, forward AND BPTT (round 3): x3 forward; data chain on the x3 step
+    kernel with the chain epilogue (gcrnn_fused_backward_data_x3); weight gradient on exact-fp32 matrix instructions
+    (gcrnn_fused_backward_weight_f32). Gradients for the taps, the bias and h0; X gets none (the training loops never ask)."""
+
+    @staticmethod
+    def forward(ctx, X, h0, wA, wB, bias, graph):
+        H, hs3, Xp = fused_cell_forward_x3(X, h0, wA, wB, bias, graph, keep=True)
+        ctx.save_for_backward(Xp, h0, wA, wB, bias, H, hs3)
+        ctx.graph = graph
+        ctx.G = X.shape[2]
+        return H
+
+    @staticmethod
+    def backward(ctx, dH):
+        Xp, h0, wA, wB, bias, H, hs3 = ctx.saved_tensors
+        graph = ctx.graph
+        if ctx.needs_input_grad[0]:
+            raise GcrnnError('the fp32-accurate fused BPTT does not produce the gradient w.r.t. the input sequence X')
+        B, T, Gp, N = Xp.shape
+        F, Kin, Kst = wA.shape[0], wA.shape[2], wB.shape[2]
+        K = max(Kin, Kst)
+        plan = graph.fused_plan(adjoint=True)
+        npad, st, dev = plan['npad'], _stream(), Xp.device
+        dHc = dH.float().contiguous()
+        dH3 = torch.empty((T, 3, B, npad, F), dtype=torch.bfloat16, device=dev)
+        check(lib.gcrnn_pack_seq_major_x3(_p(dHc), _p(dH3), B, T, F, N, npad, st), 'pack_seq_x3')
+        wBk = wB.detach().float()
+        if Kst < K:
+            wBk = torch.cat([wBk, wBk.new_zeros(F, 1, K - Kst, F)], dim=2)
+        wBt = wBk[:, 0].permute(2, 1, 0).contiguous()                       # [F_in][K][F_out]: transposed taps
+        wp3T = torch.empty((3 * (F // 16) * K * (F // 32) * 64 * 8,), dtype=torch.bfloat16, device=dev)
+        check(lib.gcrnn_fused_pack_weights_x3(_p(wBt), _p(wBt), _p(wp3T), F, 0, K, K, st), 'pack_weights_x3')
+        dpre3 = torch.empty((T, 3, B, npad, F), dtype=torch.bfloat16, device=dev)
+        dh03 = torch.empty((3, B, npad, F), dtype=torch.bfloat16, device=dev) if ctx.needs_input_grad[1] else None
+        check(lib.gcrnn_fused_backward_data_x3(_p(dH3), _p(hs3), _p(dpre3), _p(dh03), _p(wp3T), _p(plan['tile_slots']), _p(plan['tile_off']),
+                                               _p(plan['ell_col4']), plan['entries'], B, T, N, F, K, plan['uniform_w'], st), 'fused_backward_data_x3')
+        slots = int(lib.gcrnn_fused_wgrad_slots(T * B, F))
+        dWp = torch.zeros((slots, F, K, F + Gp), dtype=torch.float32, device=dev)
+        dbp = torch.zeros((slots, F), dtype=torch.float32, device=dev)
+        h0c = h0.detach().float().contiguous()
+        check(lib.gcrnn_fused_backward_weight_f32(_p(dpre3), _p(Xp), _p(H), _p(h0c), _p(dWp), _p(dbp), _p(plan['tile_slots']), _p(plan['tile_off']),
+                                                  _p(plan['ell_col4']), plan['entries'], B, T, N, F, Gp, K, plan['uniform_w'], st), 'fused_backward_weight_f32')
+        dW = dWp.sum(dim=0)                                                 # fixed order over the slots: bit-reproducible
+        G = ctx.G
+        gA = dW[:, :Kin, F:F + G].unsqueeze(1).to(wA.dtype) if ctx.needs_input_grad[2] else None
+        gB = dW[:, :Kst, :F].unsqueeze(1).to(wB.dtype) if ctx.needs_input_grad[3] else None
+        gb = dbp.sum(dim=0).view_as(bias).to(bias.dtype) if (bias is not None and ctx.needs_input_grad[4]) else None
+        gh0 = None
+        if dh03 is not None:
+            gh0 = (dh03[2].float() + dh03[1].float() + dh03[0].float())[:, :N, :].permute(0, 2, 1).contiguous().to(h0.dtype)
+        return None, gh0, gA, gB, gb, None
+
+
+def fused_cell_train_x3(X, h0, wA, wB, bias, graph):
+    """Training forward of the un-gated cell at fp32 accuracy on the fused kernels (fp32 tensors and parameters)."""
+    require_device(X, h0, wA, wB, bias)
+    return _FusedCellX3.apply(X, h0, wA, wB, bias, graph)
 
 
 def _fused_pack_state_taps(w, K, st):

@@ -237,6 +237,24 @@ int gcrnn_fused_forward_x3(const void* xs3, const void* h03, void* hs3, const vo
                            const int32_t* tile_nodes, const int32_t* tile_off, const void* ell_col4, int64_t entries, int64_t B,
                            int64_t T, int64_t N, int64_t F, int64_t G, int64_t K, double uniform_w, void* Huser, int last_only,
                            void* stream);
+/* fp32-accurate BPTT of the un-gated cell on the fused kernels (round 3): the training loop of the reference runs in the drivers'
+ * precision (Modules/train_rnn.py:247-281 under kStepPredGRNNs.py:44), i.e. its gradients are autograd's of Utils/graphML.py:2420-2423.
+ * gcrnn_fused_backward_data_x3: the data chain dpre_{t-1} = (sum_k S^k (dpre_t B_k^T) + dH_{t-1}) (1 - h_{t-1}^2) on the x3 step kernel
+ *   (three bf16 planes per operand, six partial products, fp32 hops); dHs3 / hs3 / dpre3 [T][3][B][NPad][F] planes, dh03 [3][B][NPad][F]
+ *   or NULL, wpack3T = gcrnn_fused_pack_weights_x3 of the TRANSPOSED state taps with G = 0, graph arrays of the ADJOINT uniform plan.
+ * gcrnn_fused_backward_weight_f32: dW_k = sum du_k^T [h_{t-1} | x_t] with exact fp32 products (v_mfma_f32_16x16x4_f32); X / H / h0 fp32
+ *   in the USER layout, per-slot partial sums dW [slots][F][K][F+G], dbsum [slots][F] (= 2 sum dpre: the bias enters both filters)
+ *   with slots = gcrnn_fused_wgrad_slots(B T, F), added by the caller in a fixed order (bit-reproducible).
+ * gcrnn_fused_x3_training_supported: the forward's shapes and an adjoint image that fits next to the two fp32 images. */
+int gcrnn_fused_x3_training_supported(int64_t N, int64_t F, int64_t G, int64_t K, int64_t entries_adj);
+int gcrnn_fused_backward_data_x3(const void* dHs3, const void* hs3, void* dpre3, void* dh03, const void* wpack3T,
+                                 const int32_t* tile_nodes, const int32_t* tile_off, const void* ell_col4, int64_t entries,
+                                 int64_t B, int64_t T, int64_t N, int64_t F, int64_t K, double uniform_w, void* stream);
+int gcrnn_fused_backward_weight_f32(const void* dpre3, const void* Xuser, const void* Huser, const void* h0user, float* dW,
+                                    float* dbsum, const int32_t* tile_nodes, const int32_t* tile_off, const void* ell_col4,
+                                    int64_t entries, int64_t B, int64_t T, int64_t N, int64_t F, int64_t G, int64_t K,
+                                    double uniform_w, void* stream);
+
 
 /* LDS placement of the hop state (tile = 16). node_addr[n] = (row << 6) | (swz << 4): node n's 64-byte state row sits at
  * LDS row `row`, its four 16-byte quads XOR-swizzled by `swz` (NULL = identity: row n, swz (n >> 2) & 3).

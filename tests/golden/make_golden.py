@@ -364,6 +364,45 @@ def g9_fused_bptt_edge():
     g9_fused_bptt((('edge', False, 'edge'), ('time_edge', True, 'edge')))
 
 
+def g11_fused_f32():
+    """G11 (round 3): reference autograd at a shape the fp32-accurate fused kernels support -- N = 200, F = G = 32, K = 3, T = 4,
+    B = 3 on a UNIFORM-weight undirected graph (the drivers' S = W / lambda_max, kStepPredGRNNs.py:768), every operand
+    fp32-representable (NOT bf16-rounded): un-gated cell, fp64 reference, gradients of every parameter and of h0 for the losses
+    H.sum() and L1 (miscTools.py:112-119). The fp32 kernels are compared at <= 1e-5 (H) / <= 2e-5 of each gradient's max."""
+    N, T, G, F, K, B = 200, 4, 32, 32, 3, 3
+    rng = np.random.default_rng(23)
+    U = np.triu(rng.random((N, N)) < 0.05, 1)
+    W = (U + U.T).astype(np.float64)
+    lam = np.max(np.linalg.eigvalsh(W))
+    w32 = np.float32(1.0 / lam)
+    S = (W * np.float64(w32)).reshape(1, N, N)                 # ONE fp32-representable weight on every edge
+    f32 = lambda a: np.asarray(a, dtype=np.float32).astype(np.float64)
+    X = f32(rng.standard_normal((B, T, G, N)))
+    h0 = f32(0.5 * rng.standard_normal((B, F, N)))
+    target = f32(rng.standard_normal((B, T, F, N)))
+    rows, cols = np.nonzero(S[0])
+    torch.manual_seed(91)
+    cell = gml.GGCRNNCell(G, F, K, K, torch.tanh, False, None, 1, True)
+    cell.addGSO(torch.tensor(S))
+    with torch.no_grad():
+        for q in cell.parameters():
+            q.copy_(torch.tensor(f32(q.detach().numpy())))
+    p = sd_np(cell)
+    h0t = torch.tensor(h0, requires_grad=True)
+    H = cell(torch.tensor(X), h0t)
+    check(orc.ggcrnn_cell(p, S, X, h0, False, None), H.detach().numpy(), 'G11')
+    cell.zero_grad()
+    H.sum().backward(retain_graph=True)
+    g_sum, gh0_sum = grads_np(cell), h0t.grad.numpy().copy()
+    cell.zero_grad(); h0t.grad = None
+    torch.nn.L1Loss()(H, torch.tensor(target)).backward()
+    g_l1 = grads_np(cell)
+    save('g11_fused_f32', coo_row=rows.astype(np.int16), coo_col=cols.astype(np.int16), coo_val=S[0][rows, cols].astype(np.float32),
+         shape=np.array([N, T, G, F, K, B]), X=X.astype(np.float32), h0=h0.astype(np.float32), target=target.astype(np.float32),
+         H=H.detach().numpy(), params={k: v.astype(np.float32) for k, v in p.items()}, grad_sum=g_sum, grad_sum_h0=gh0_sum,
+         grad_l1=g_l1, grad_l1_h0=h0t.grad.numpy())
+
+
 def g10_kstep_data():
     """The reference's KStepPrediction dataset (Utils/dataTools.py:1259-1317) on a reference SBM graph
     (Utils/graphTools.py createGraph 'SBM'), with the numpy global generator seeded: stores the graph, the noise arrays the
@@ -418,4 +457,5 @@ if __name__ == '__main__':
     g9_fused_bptt()
     g9_fused_bptt_edge()
     g10_kstep_data()
+    g11_fused_f32()
     print('all oracle checks passed at tol', TOL)

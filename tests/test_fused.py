@@ -1697,3 +1697,68 @@ def test_few_input_channels_are_padded_by_the_pack_not_by_a_copy_of_X():
             xs = ops.fused_pack_inputs(X, h0, cell.graph, channels=Xp.shape[2])[0]
             assert torch.equal(xs, ops.to_sequence_major(Xp, cell.graph))
         assert torch.equal(H0, H1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('loss', ['sum', 'l1'])
+def test_fp32_accurate_fused_training_matches_reference_autograd_fixture(golden, loss):
+    """G11: the north_star's 1e-5 mode for TRAINING on fused kernels -- x3 forward, x3 data chain (three bf16
+    planes per operand, six partial products, fp32 hops) and the exact-fp32 weight gradient -- against the REFERENCE's autograd in
+    fp64 (tests/golden/make_golden.py g11_fused_f32: Utils/graphML.py:2336-2427, fp32-representable operands, uniform-weight
+    graph). H <= 1e-5 abs; every gradient <= 2e-5 of its max (L1: dH = sign(H - target) / count flips where H's fp32 error crosses the
+    target -- none here, the margins are > 1e-5)."""
+    g = golden('g11_fused_f32')
+    dev = torch.device('cuda:0')
+    cell, S = _g9_cell(g, False, None, dev)
+    X = torch.tensor(g['X'], dtype=torch.float32, device=dev)
+    h0 = torch.tensor(g['h0'], dtype=torch.float32, device=dev, requires_grad=True)
+    assert cell._use_fused_x3_training(X, h0)
+    H = cell(X, h0)
+    assert H.dtype == torch.float32
+    assert float((H.detach().double().cpu() - torch.tensor(g['H'])).abs().max()) <= 1e-5
+    if loss == 'sum':
+        H.sum().backward()
+        want, want_h0 = g['grad_sum'], g['grad_sum_h0']
+    else:
+        torch.nn.functional.l1_loss(H, torch.tensor(g['target'], device=dev)).backward()
+        want, want_h0 = g['grad_l1'], g['grad_l1_h0']
+    got = dict(cell.named_parameters())
+    for k, gr in want.items():
+        e = np.abs(got[k].grad.double().cpu().numpy() - gr)
+        sc = float(np.abs(gr).max())
+        assert sc > 0 and e.max() <= 2e-5 * sc, (k, e.max() / sc)
+    e = (h0.grad.double().cpu() - torch.tensor(want_h0)).abs()
+    assert float(e.max()) <= 2e-5 * float(np.abs(want_h0).max()), float(e.max()) / float(np.abs(want_h0).max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('N,F,G,K,B,T', [(1000, 64, 64, 5, 3, 4), (1000, 64, 1, 3, 2, 3), (600, 32, 32, 4, 4, 3)])
+def test_fp32_accurate_fused_training_matches_composed_autograd(N, F, G, K, B, T, monkeypatch):
+    """The same at the bench's sizes against the composed fp32 path (exact fp32 kernels, golden-pinned since round 1): every
+    gradient <= 2e-5 of its max, H <= 1e-5; two runs give the same bits (no atomics)."""
+    dev = torch.device('cuda:0')
+    cell, rng, _ = _uniform_cell(N, G, F, K, False, 95, dev, dtype=None)
+    X = torch.tensor(rng.standard_normal((B, T, G, N)), dtype=torch.float32, device=dev)
+    h0 = torch.tensor(0.3 * rng.standard_normal((B, F, N)), dtype=torch.float32, device=dev, requires_grad=True)
+    tgt = torch.tensor(rng.standard_normal((B, T, F, N)), dtype=torch.float32, device=dev)
+
+    def step():
+        cell.zero_grad(set_to_none=True)
+        h0.grad = None
+        H = cell(X, h0)
+        torch.nn.functional.l1_loss(H, tgt).backward()
+        g = {n: p.grad.clone() for n, p in cell.named_parameters() if p.grad is not None}
+        g['h0'] = h0.grad.clone()
+        return H.detach().clone(), g
+
+    assert cell._use_fused_x3_training(X, h0)
+    H1, g1 = step()
+    H2, g2 = step()
+    assert torch.equal(H1, H2) and all(torch.equal(g1[k], g2[k]) for k in g1)
+    monkeypatch.setenv('GCRNN_NO_X3_TRAINING', '1')
+    assert not cell._use_fused_x3_training(X, h0)
+    H0, g0 = step()
+    assert float((H0 - H1).abs().max()) <= 1e-5 and g0.keys() == g1.keys() and len(g1) >= 4
+    for k in g1:
+        sc = float(g0[k].abs().max())
+        assert sc > 0 and float((g0[k] - g1[k]).abs().max()) <= 2e-5 * sc, (k, float((g0[k] - g1[k]).abs().max()) / sc)

@@ -160,3 +160,15 @@ def test_oracle_reproduces_g9_states(golden, name, tg, sg):
     p = {k: v.astype(np.float64) for k, v in g['params'].items()}
     H = orc.ggcrnn_cell(p, S, g['X'].astype(np.float64), g['h0'].astype(np.float64), tg, sg)
     assert np.max(np.abs(H - g['H'])) <= 2e-7
+
+
+def test_oracle_reproduces_g11_states(golden):
+    """G11 (fp32-representable operands, uniform-weight graph, fp64 states): the oracle reproduces the reference to 1e-12."""
+    g = golden('g11_fused_f32')
+    N, T, G, F, K, B = (int(v) for v in g['shape'])
+    S = np.zeros((1, N, N))
+    S[0, g['coo_row'].astype(np.int64), g['coo_col'].astype(np.int64)] = g['coo_val'].astype(np.float64)
+    assert len(np.unique(g['coo_val'])) == 1 and np.array_equal(S[0], S[0].T)            # ONE weight on every edge, symmetric support
+    p = {k: v.astype(np.float64) for k, v in g['params'].items()}
+    H = orc.ggcrnn_cell(p, S, g['X'].astype(np.float64), g['h0'].astype(np.float64), False, None)
+    assert np.max(np.abs(H - g['H'])) <= 1e-12
