@@ -517,21 +517,21 @@ def secondary_points(ctx, S, params, B, steps=8, warmup=2):
                                  'kernel': 'fused_step_x3_kernel (one launch = one time step; bytes = the fp32 tensors of the API)'}
             # ... and ONE optimiser step in the same precision: x3 forward, x3 data chain, exact-fp32 weight gradient (G11: <= 2e-5 of each
             # gradient's max against the reference's autograd)
-            cell.requires_grad_(True)
-            if cell._use_fused_x3_training(X, h0):
-                target = torch.randn(B, T, F, N, device=dev, dtype=torch.float32, generator=gen)
-                opt = FlatAdam(cell.parameters(), lr=1e-3)
+            with torch.enable_grad():
+                if cell._use_fused_x3_training(X, h0):
+                    target = torch.randn(B, T, F, N, device=dev, dtype=torch.float32, generator=gen)
+                    opt = FlatAdam(cell.parameters(), lr=1e-3)
 
-                def t32():
-                    opt.zero_grad()
-                    batchTimeL1Loss(cell(X, h0), target).backward()
-                    opt.step()
+                    def t32():
+                        opt.zero_grad()
+                        batchTimeL1Loss(cell(X, h0), target).backward()
+                        opt.step()
 
-                dt = _timed(t32, 3, 1)
-                sec['train_f32_x3'] = {'value': B / dt, 'unit': 'sequences/s', 'ms_per_step': 1e3 * dt, 'steps': 3, 'dtype': 'f32',
-                                       'tolerance': 'gradients <= 2e-5 of their max against the reference autograd (tests G11)',
-                                       'what': 'x3 forward + x3 BPTT data chain + exact-fp32 weight gradient + FlatAdam'}
-                del target, opt
+                    dt = _timed(t32, 3, 1)
+                    sec['train_f32_x3'] = {'value': B / dt, 'unit': 'sequences/s', 'ms_per_step': 1e3 * dt, 'steps': 3, 'dtype': 'f32',
+                                           'tolerance': 'gradients <= 2e-5 of their max against the reference autograd (tests G11)',
+                                           'what': 'x3 forward + x3 BPTT data chain + exact-fp32 weight gradient + FlatAdam'}
+                    del target, opt
         del cell, X, h0
     except Exception as e:      # noqa: BLE001 -- a secondary point never takes the headline line down
         sec['f32_x3'] = {'error': str(e)[:200]}

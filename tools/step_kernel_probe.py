@@ -20,6 +20,19 @@ plan = cell.graph.fused_plan()
 print('entries', plan['entries'], 'nnz', cell.graph.nnz, 'lds bytes', 65536 + 20480 + plan['entries'] * 96)
 X = torch.randn(B, T, 64, 1000, device=dev).to(torch.bfloat16)
 h0 = torch.zeros(B, 64, 1000, device=dev, dtype=torch.bfloat16)
+NATIVE = len(sys.argv) > 4 and sys.argv[4] == 'native'      # sequence-major in and out only (GGCRNNCell.forward_native)
+if NATIVE:
+    xs = ops.to_sequence_major(X, cell.graph)
+    with torch.no_grad():
+        for _ in range(reps):
+            cell.forward_native(xs, None)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            cell.forward_native(xs, None)
+        torch.cuda.synchronize()
+    print('per step (native layout): %.1f us' % (1e6 * (time.perf_counter() - t0) / reps / T))
+    sys.exit(0)
 with torch.no_grad():
     for _ in range(reps):
         hs, _, _Hu = ops.fused_cell_forward(X, h0, cell.weight_A, cell.weight_B, cell.bias, cell.graph, return_states=True)
