@@ -68,6 +68,9 @@ class FlatAdam(object):
                                                 self.betas[1], self.eps, float(grad_scale), C.c_void_p(self.step_dev.data_ptr()), st),
                        'adam_flat')
             return
+        # TEST-ONLY branch (CPU tensors): the same update in torch ops, so that the N > 1 logic around the optimiser (flat buffers,
+        # sharded batches, the collective) can run over gloo in a container without a GPU (tests/test_parallel_gloo.py). The product
+        # path -- the recurrence and everything on its data -- has no CPU implementation (GcrnnError on CPU tensors).
         b1, b2 = self.betas
         self.step_dev += 1
         t = float(self.step_dev.item())
