@@ -23,6 +23,13 @@
 //
 // MODE 0: forward step   h_t = tanh(sum_k S^k([h|x] W_k) + 2b)            (reference Utils/graphML.py:2420-2423)
 // MODE 2: BPTT data step dpre_{t-1} = (gsc * sum_k S^k(dpre_t W_k^T) + dH_{t-1}) (1 - h_{t-1}^2)   (autograd of the same lines)
+// MODE 0 with GATED: the time-gated step  h_t = tanh(gi_t (A(S)x_t + b) + gf_t (B(S)h_{t-1} + b)),  gates = scalars per (t, sequence)
+//         (graphML.py:2357-2374): h-chain, scale by gf/gi, x-chain, scale by gi -- one accumulator chain, as in the chunk-parallel kernel.
+// MODE 1: time-gate pre-pass (graphML.py:2362-2366), all T*B items of one gate in one launch ("step" = none, the items are the
+//         batch): c = tanh(A_g(S)x_t + B_g(S)h0 + 2 b_g) per item, gate logit partials sum_{n,f} c[n][f] w[n][f] per (chunk, wave)
+//         (fixed-order sum by the caller); c stored bf16 sequence-major when asked (the gate's BPTT, the node gates' filters);
+//         with flags[0] != 0 (h0 all zeros: every training loop of the reference, train_rnn.py:256) the state half of the
+//         operand is neither loaded nor multiplied.
 #pragma once
 
 // In-kernel phase stamps (diagnostic builds only, -DGCRNN_SEQ_STAMPS; tools/seq_stamps.py): wave 0 of every workgroup records
@@ -55,7 +62,11 @@ struct SeqArgs {
   uint16_t* out0; int64_t ostride;                     // output of step 0 [B][NP][F] (or null), elements between steps
   const uint4* wpack;                                  // [F/16][K][KS][64] x 16 B
   const float* bias;                                   // [F] or null
-  const float* gf0; int64_t gfstride;                  // MODE 2: forget gates [B] of the step back-propagated, or null
+  const float* gf0; int64_t gfstride;                  // MODE 2: forget gates [B] of the step back-propagated, or null; GATED: forget gates of step 0
+  const float* gi0;                                    // GATED: input gates [B] of step 0 (stride gfstride)
+  const float* gw;                                     // MODE 1: the gate read-out's weights, node-major [N][F] fp32
+  const int32_t* flags;                                // MODE 1 (or null): flags[0] != 0 = the state operand h0 is all zeros
+  int hmod;                                            // MODE 1: item i reads the state operand of sequence i % hmod (h0 of its sequence); else 0
   const int32_t* tile_nodes; const int32_t* tile_off; const uint2* ell_col4;      // bf16-image plan
   float* go0; int64_t gostride;                        // MODE 2 (or null): [B][F/16 * 8] partials of <h_{t-1}, adjoint chain of dpre_t>
   const uint16_t* a0; int64_t a0stride;                // MODE 2: upstream gradient dH_{t-1} [B][NP][F] (or null)
@@ -70,7 +81,7 @@ struct SeqArgs {
   int pk_all;                                          // ... != 0: the last step too (per-step launches: the host decides)
 };
 
-template <int K, int HS, int XS, int MODE>
+template <int K, int HS, int XS, int MODE, bool GATED = false>
 __global__ __launch_bounds__(STHREADS) void fused_seq_kernel(const SeqArgs a) {
   constexpr int KS = HS + XS;
   constexpr int F = 32 * HS, G = 32 * XS;
@@ -80,7 +91,8 @@ __global__ __launch_bounds__(STHREADS) void fused_seq_kernel(const SeqArgs a) {
   constexpr int IMG = 33 * 1024;                 // bf16 hop image [NP][16] (32 KB); the transposed output tile needs 8 x 4128 B
   constexpr int WB = K * KS * 1024;              // one chunk's weight fragments
   static_assert(STILES == 8 && GCRNN_HOP_ASM, "generated hop stream: 8 tiles per wave");
-  static_assert(MODE == 0 ? XS > 0 : XS == 0, "forward takes [h | x], the BPTT step its one operand");
+  static_assert((MODE == 0 || MODE == 1) ? XS > 0 : XS == 0, "forward / pre-pass take [h | x], the BPTT step its one operand");
+  static_assert(!GATED || MODE == 0, "gated steps are forward steps");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* state = reinterpret_cast<float*>(smem);
   const int entries = a.entries, B = a.B, N = a.N;
@@ -118,10 +130,10 @@ __global__ __launch_bounds__(STHREADS) void fused_seq_kernel(const SeqArgs a) {
                                        (__attribute__((address_space(3))) void*)(smem + IMG + p * 1024), 16, 0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
-  // the bias (2 b: the one bias enters through both filters, graphML.py:2420-2421) in the 256 spare bytes behind the transposed tile:
+  // the bias (it enters through both filters, graphML.py:2420-2421: scaled by gi + gf = 2 at its use) in the 256 spare bytes behind the tile:
   // a chunk reads its four values from LDS instead of waiting for a global load at the top of every chunk
   float* lbias = reinterpret_cast<float*>(smem + 33024);
-  if (MODE == 0 && tid < F) lbias[tid] = a.bias ? 2.f * a.bias[tid] : 0.f;
+  if ((MODE == 0 || MODE == 1) && tid < F) lbias[tid] = a.bias ? a.bias[tid] : 0.f;
   __syncthreads();
 
   const uint32_t lds0 = (uint32_t)reinterpret_cast<uintptr_t>(smem);
@@ -143,7 +155,10 @@ __global__ __launch_bounds__(STHREADS) void fused_seq_kernel(const SeqArgs a) {
     uint16_t* pk_dst = pk ? a.pk_dst0 + (int64_t)step * a.pkdst_stride : nullptr;
     const int pk_stride = a.pk_stride, ubstride = a.ubstride;
     float* gate_out = a.go0 ? a.go0 + (int64_t)step * a.gostride : nullptr;
-    const __amdgpu_buffer_rsrc_t rsrc_h = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(hprev), 0, B * (NP * F * 2), 0x00020000);
+    const bool skip_h = (MODE == 1) && a.flags && a.flags[0] != 0;          // wave-uniform
+    // (skipped state operand: a zero-length descriptor -- its loads return zeros and cost nothing)
+    const __amdgpu_buffer_rsrc_t rsrc_h = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(hprev), 0, skip_h ? 0 : (MODE == 1 ? a.hmod : B) * (NP * F * 2), 0x00020000);
+    const int bh = (MODE == 1) ? b % a.hmod : b;
     const __amdgpu_buffer_rsrc_t rsrc_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(xt), 0, (XS > 0 && xt) ? B * (NP * G * 2) : 0, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsrc_o = __builtin_amdgcn_make_buffer_rsrc(hout, 0, hout ? B * (NP * F * 2) : 0, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsrc_a0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(aux0), 0, (MODE == 2 && aux0) ? B * (NP * F * 2) : 0, 0x00020000);
@@ -159,13 +174,19 @@ __global__ __launch_bounds__(STHREADS) void fused_seq_kernel(const SeqArgs a) {
         int w = woff[i];
         asm volatile("" : "+v"(w));
         if (s < HS)
-          bfr[i][s] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsrc_h, (w >> 16) * (F * 2) + 16 * q + 64 * s, b * (NP * F * 2), 0));
+          bfr[i][s] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsrc_h, (w >> 16) * (F * 2) + 16 * q + 64 * s, bh * (NP * F * 2), 0));
         else
           bfr[i][s] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, (w >> 16) * (G * 2) + 16 * q + 64 * (s - HS), b * (NP * G * 2), 0));
       }
     }
     float gsc = 1.f;
     if (MODE == 2 && a.gf0) gsc = a.gf0[(int64_t)step * a.gfstride + b];
+    float gin = 1.f, gfo = 1.f, gratio = 1.f;
+    if constexpr (GATED) {
+      gin = a.gi0[(int64_t)step * a.gfstride + b];
+      gfo = a.gf0[(int64_t)step * a.gfstride + b];
+      gratio = gfo / fmaxf(gin, 1e-30f);
+    }
     GCRNN_STAMP(1);
 
     f32x4 u[STILES];
@@ -174,11 +195,41 @@ __global__ __launch_bounds__(STHREADS) void fused_seq_kernel(const SeqArgs a) {
       const uint4* wl = reinterpret_cast<const uint4*>(smem + IMG + (c & 1) * WB);
 #pragma unroll
       for (int i = 0; i < STILES; ++i) u[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if constexpr (GATED || MODE == 1) {
+        // (GATED) gi (x W_x) + gf (h W_h) on ONE accumulator chain: h-chain, scale by gf / gi, continue with x, scale by gi (gi = sigmoid(.) > 0;
+        // the wave-uniform guard covers an underflowed gate); (MODE 1) the state half is skipped when h0 is all zeros
+        if (!skip_h) {
 #pragma unroll
-      for (int s = 0; s < KS; ++s) {
-        const bf16x8 af = __builtin_bit_cast(bf16x8, wl[(tap * KS + s) * 64 + lane]);
+          for (int s = 0; s < HS; ++s) {
+            const bf16x8 af = __builtin_bit_cast(bf16x8, wl[(tap * KS + s) * 64 + lane]);
 #pragma unroll
-        for (int i = 0; i < STILES; ++i) u[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bfr[i][s], u[i], 0, 0, 0);
+            for (int i = 0; i < STILES; ++i) u[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bfr[i][s], u[i], 0, 0, 0);
+          }
+        }
+        const bool xpart = !GATED || gin > 1e-30f;
+        if constexpr (GATED) {
+#pragma unroll
+          for (int i = 0; i < STILES; ++i) u[i] *= (xpart ? gratio : gfo);
+        }
+        if (xpart) {
+#pragma unroll
+          for (int s = HS; s < KS; ++s) {
+            const bf16x8 af = __builtin_bit_cast(bf16x8, wl[(tap * KS + s) * 64 + lane]);
+#pragma unroll
+            for (int i = 0; i < STILES; ++i) u[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bfr[i][s], u[i], 0, 0, 0);
+          }
+          if constexpr (GATED) {
+#pragma unroll
+            for (int i = 0; i < STILES; ++i) u[i] *= gin;
+          }
+        }
+      } else {
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+          const bf16x8 af = __builtin_bit_cast(bf16x8, wl[(tap * KS + s) * 64 + lane]);
+#pragma unroll
+          for (int i = 0; i < STILES; ++i) u[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bfr[i][s], u[i], 0, 0, 0);
+        }
       }
     };
     // seed of chunk c: tap K-1 goes straight into the hop image (every wave has left the image: the barrier before)
@@ -343,10 +394,38 @@ __global__ __launch_bounds__(STHREADS) void fused_seq_kernel(const SeqArgs a) {
           for (int off = 32; off > 0; off >>= 1) part += __shfl_down(part, off, 64);
           if (lane == 0) gate_out[(int64_t)b * (NCH * SWAVES) + chunk * SWAVES + wave] = part;
         }
+      } else if constexpr (MODE == 1) {
+        // gate pre-pass: partial dot product of tanh(pre) with the gate's read-out weights over this chunk, one partial per wave (the
+        // caller adds them in a fixed order); with an output array the gate cell's state c = tanh(pre) is also stored (bf16)
+        float bs2[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) bs2[c] = 2.f * lbias[chunk * FC + q * 4 + c];
+        float part = 0.f;
+#pragma unroll
+        for (int i = 0; i < STILES; ++i) {
+          int wv = woff[i];
+          asm volatile("" : "+v"(wv));
+          const int node = wv >> 16;
+          uint2 pkd{0u, 0u};
+          if (node < N) {
+            // (the read-out weights [N][F] fp32 are shared by every item: L2- / L1-resident; held across an asm block they would spill)
+            const float4 w4 = *reinterpret_cast<const float4*>(a.gw + (int64_t)node * F + chunk * FC + q * 4);
+            const f32x4 acc = u[i];
+            const float o0 = fast_tanh(acc[0] + bs2[0]), o1 = fast_tanh(acc[1] + bs2[1]);
+            const float o2 = fast_tanh(acc[2] + bs2[2]), o3 = fast_tanh(acc[3] + bs2[3]);
+            part += o0 * w4.x + o1 * w4.y + o2 * w4.z + o3 * w4.w;
+            pkd.x = (uint32_t)f2bf(o0) | ((uint32_t)f2bf(o1) << 16);
+            pkd.y = (uint32_t)f2bf(o2) | ((uint32_t)f2bf(o3) << 16);
+          }
+          if (hout) __builtin_amdgcn_raw_buffer_store_b64(u32x2{pkd.x, pkd.y}, rsrc_o, node * (F * 2) + (chunk * FC + q * 4) * 2, b * (NP * F * 2), 0);
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) part += __shfl_down(part, off, 64);
+        if (lane == 0) gate_out[(int64_t)b * (NCH * SWAVES) + chunk * SWAVES + wave] = part;
       } else {
         float bsum[4];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) bsum[c] = lbias[chunk * FC + q * 4 + c];
+        for (int c = 0; c < 4; ++c) bsum[c] = (gin + gfo) * lbias[chunk * FC + q * 4 + c];      // the one bias is added by both filters
 #pragma unroll
         for (int i = 0; i < STILES; ++i) {
           int wv = woff[i];

@@ -1148,7 +1148,8 @@ int fused_launch_t(int mode /*0 plain, 1 gated, 2 gate pre-pass, 3 BPTT data gra
 #if GCRNN_HOP_ASM && GCRNN_STEP_WAVES == 8
   // Sequence-resident kernel (gcrnn_fused_seq.h): one workgroup per sequence keeps the operand in registers for all chunks -- the
   // un-gated forward steps and the plain BPTT data chain on uniform-weight bf16-image plans, when the batch fills the chip.
-  if (ga.uniform_w != 0.f && ga.img16 && ga.ell_col4 && !head && !step_events && fused_seq_wanted(B, NCH) && (mode == 0 || mode == 3)) {
+  if (ga.uniform_w != 0.f && ga.img16 && ga.ell_col4 && !head && !step_events && (mode == 0 || mode == 1 || mode == 2 || mode == 3) &&
+      fused_seq_wanted(mode == 2 ? B * T : B, NCH)) {
     const size_t slds = fused_seq_lds<K, HS, XS>(ga.entries, inline_pack, mode == 3 ? F : G);
     const unsigned sgrid = (unsigned)(B < 256 ? B : 256);
     const bool persist = fused_seq_persistent();
@@ -1156,6 +1157,61 @@ int fused_launch_t(int mode /*0 plain, 1 gated, 2 gate pre-pass, 3 BPTT data gra
     sa.wpack = (const uint4*)wpack; sa.tile_nodes = ga.tile_nodes; sa.tile_off = ga.tile_off; sa.ell_col4 = (const uint2*)ga.ell_col4;
     sa.entries = (int)ga.entries; sa.B = (int)B; sa.N = (int)N; sa.uni_w = ga.uniform_w;
     if constexpr (XS > 0) {
+      if (mode == 2 && slds) {
+        // gate pre-pass: every (t, b) item of one gate in one launch (split over whole time steps where the 32-bit buffer offsets of
+        // items * NP * max(F, G) * 2 bytes would overflow), one workgroup per item
+        auto sk = fused_seq_kernel<K, HS, XS, 1>;
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(sk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)slds) != hipSuccess)
+          return GCRNN_ERR_LAUNCH;
+        const int64_t row_bytes = (int64_t)NP * (F > G ? F : G) * 2;
+        int64_t tchunk = (2147483647LL / row_bytes) / B;
+        if (tchunk < 1) return GCRNN_ERR_BAD_SHAPE;
+        if (tchunk > T) tchunk = T;
+        GCRNN_PRE_LAUNCH();
+        for (int64_t t0 = 0; t0 < T; t0 += tchunk) {
+          const int64_t nt = (T - t0 < tchunk) ? T - t0 : tchunk, items = nt * B;
+          SeqArgs s1 = sa;
+          s1.bias = bias; s1.B = (int)items; s1.hmod = (int)B; s1.nsteps = 1;
+          s1.x0 = x + t0 * xstep; s1.hfirst = (const uint16_t*)h0;
+          s1.out0 = h ? h + t0 * hstep : nullptr;
+          s1.gw = gate_w; s1.go0 = gate_out + t0 * B * (NCH * SWAVES); s1.flags = hzero_flag;
+          sk<<<(unsigned)(items < 256 ? items : 256), STHREADS, slds, st>>>(s1);
+        }
+        GCRNN_CHECK_LAUNCH();
+        return GCRNN_OK;
+      }
+      if (mode == 1 && slds) {
+        // time-gated recurrence: the gates of every (t, b) are known before the first step (they read (x_t, h0)); one persistent launch
+        auto sk = fused_seq_kernel<K, HS, XS, 0, true>;
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(sk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)slds) != hipSuccess)
+          return GCRNN_ERR_LAUNCH;
+        GCRNN_PRE_LAUNCH();
+        sa.bias = bias;
+        sa.x0 = x; sa.xstride = xstep;
+        sa.hfirst = (const uint16_t*)h0; sa.hrest = h; sa.hstride = hstep;
+        sa.out0 = h; sa.ostride = hstep;
+        sa.gi0 = gi; sa.gf0 = gf; sa.gfstride = B;
+        sa.a1 = (const uint16_t*)huser; sa.a1stride = F * N; sa.a1_last_only = huser_last_only ? 1 : 0;
+        sa.ubstride = (int)((huser_last_only ? 1 : T) * F * N);
+        if (persist) {
+          sa.nsteps = (int)T;
+          sk<<<sgrid, STHREADS, slds, st>>>(sa);
+        } else {
+          for (int64_t t = 0; t < T; ++t) {
+            SeqArgs s1 = sa;
+            s1.nsteps = 1;
+            s1.x0 = x + t * xstep;
+            s1.hfirst = (t == 0) ? (const uint16_t*)h0 : h + (t - 1) * hstep;
+            s1.out0 = h + t * hstep;
+            s1.gi0 = gi + t * B; s1.gf0 = gf + t * B;
+            s1.a1 = !huser ? nullptr : (!huser_last_only ? (const uint16_t*)huser + t * F * N : (t == T - 1 ? (const uint16_t*)huser : nullptr));
+            s1.a1_last_only = 0;
+            sk<<<sgrid, STHREADS, slds, st>>>(s1);
+          }
+        }
+        GCRNN_CHECK_LAUNCH();
+        return GCRNN_OK;
+      }
       if (mode == 0 && slds) {
         auto sk = fused_seq_kernel<K, HS, XS, 0>;
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(sk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)slds) != hipSuccess)

@@ -1762,3 +1762,27 @@ def test_fp32_accurate_fused_training_matches_composed_autograd(N, F, G, K, B, T
     for k in g1:
         sc = float(g0[k].abs().max())
         assert sc > 0 and float((g0[k] - g1[k]).abs().max()) <= 2e-5 * sc, (k, float((g0[k] - g1[k]).abs().max()) / sc)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('N,F,G,K,B,T,hz', [(1000, 64, 64, 5, 5, 4, False), (1000, 64, 64, 5, 4, 3, True), (400, 32, 32, 3, 7, 3, False),
+                                            (1000, 64, 1, 3, 3, 3, True), (1000, 64, 64, 2, 2, 2, False)])
+def test_sequence_resident_time_gated_forward_is_bit_identical(N, F, G, K, B, T, hz, monkeypatch):
+    """The time-gated cell on the sequence-resident kernel: both gate pre-passes (MODE 1: one workgroup per (t, b) item, the state half
+    of the operand skipped when h0 is all zeros) and the gated recurrence (GATED: h-chain, scale by gf / gi, x-chain, scale by gi)
+    give the bits of the chunk-parallel kernels, for zero and non-zero h0."""
+    dev = torch.device('cuda:0')
+    cell, rng, _ = _uniform_cell(N, G, F, K, True, 97, dev)
+    X = torch.tensor(rng.standard_normal((B, T, G, N)), dtype=torch.float32, device=dev).to(torch.bfloat16)
+    h0 = torch.zeros(B, F, N, device=dev, dtype=torch.bfloat16) if hz else \
+        torch.tensor(0.3 * rng.standard_normal((B, F, N)), dtype=torch.float32, device=dev).to(torch.bfloat16)
+    monkeypatch.setenv('GCRNN_SEQ_MIN_B', '1')
+    with torch.no_grad():
+        monkeypatch.setenv('GCRNN_SEQ_KERNEL', '1')
+        H1, Hl1 = cell(X, h0), cell(X, h0, last_only=True)
+        monkeypatch.setenv('GCRNN_SEQ_PERSIST', '0')
+        H2 = cell(X, h0)
+        monkeypatch.delenv('GCRNN_SEQ_PERSIST')
+        monkeypatch.setenv('GCRNN_SEQ_KERNEL', '0')
+        H0, Hl0 = cell(X, h0), cell(X, h0, last_only=True)
+    assert torch.equal(H0, H1) and torch.equal(H0, H2) and torch.equal(Hl0, Hl1)
