@@ -90,9 +90,9 @@ def test_fused_step_matches_oracle(N, F, K, B, T, iso):
     assert H.dtype == torch.bfloat16 and tuple(H.shape) == (B, T, F, N)
     err = np.abs(H.double().cpu().numpy() - Href)
     # one-step error: only the final bf16 store (|h| <= 1 -> <= 2^-9); later steps add propagated rounding
-    assert err[:, 0].max() <= 4.0e-3, err[:, 0].max()
-    assert err.max() <= 3.0e-2, err.max()
-    assert err.mean() <= 2.0e-3, err.mean()
+    assert err[:, 0].max() <= 2.0e-3, err[:, 0].max()
+    assert err.max() <= 5.0e-3, err.max()
+    assert err.mean() <= 1.0e-3, err.mean()
 
 
 @pytest.mark.gpu
@@ -126,7 +126,7 @@ def test_fused_time_gated_matches_oracle(N, F, K, B, T):
         H = cell(Xd, hd)
     err = np.abs(H.double().cpu().numpy() - Href)
     assert err[:, 0].max() <= 6.0e-3, err[:, 0].max()
-    assert err.max() <= 3.0e-2 and err.mean() <= 2.0e-3, (err.max(), err.mean())
+    assert err.max() <= 5.0e-3 and err.mean() <= 1.0e-3, (err.max(), err.mean())
 
 
 @pytest.mark.gpu
@@ -335,7 +335,7 @@ def test_fused_time_gated_training_matches_composed_autograd(N, F, K, B, T, mast
     H = cell(Xd, hd)
     assert H.dtype == torch.bfloat16 and H.requires_grad
     err = (H.detach().float() - Hr.detach()).abs()
-    assert float(err.max()) <= 4e-2 and float(err.mean()) <= 3e-3, (float(err.max()), float(err.mean()))
+    assert float(err.max()) <= 6e-3 and float(err.mean()) <= 1.2e-3, (float(err.max()), float(err.mean()))
     (H.float() * dHd).sum().backward()
     names = [n for n, p in ref.named_parameters() if p.grad is not None]
     assert any(n.startswith('GFL_in.') for n in names) and any(n.startswith('MLP_forget.') for n in names)
@@ -507,7 +507,9 @@ def test_fused_cell_with_few_input_features(N, G, F, K, B, T, tg):
         Hi = cell(Xd, hd)                                        # inference kernels (bf16 parameters)
         cell = cell.to(torch.float32)
     err = np.abs(Hi.double().cpu().numpy() - Href)
-    assert err.max() <= 4e-2 and err.mean() <= 3e-3, (err.max(), err.mean())
+    # (G = 1: the reference init U(+-1/sqrt(G K)) gives taps of +-0.45 -- pre-activations, and with them the rounding of the stored
+    # states, are larger than at G = 64: measured max 1.5e-2 / mean 1.0e-3)
+    assert err.max() <= 2.5e-2 and err.mean() <= 1.5e-3, (err.max(), err.mean())
     assert cell._use_fused_training(Xd, hd)
     H = cell(Xd, hd)
     (H.float() * dHd).sum().backward()
@@ -690,7 +692,7 @@ def test_fused_bptt_matches_reference_autograd_fixture(golden, name, tg, sg, los
     H = cell(X, h0)
     assert H.dtype == torch.bfloat16
     err = (H.detach().float().cpu() - torch.tensor(g['H'])).abs()
-    assert float(err.max()) <= 4e-2 and float(err.mean()) <= 3e-3, (float(err.max()), float(err.mean()))
+    assert float(err.max()) <= 1.2e-2 and float(err.mean()) <= 1.5e-3, (float(err.max()), float(err.mean()))
     if loss == 'sum':
         H.float().sum().backward()
         want, want_h0 = g['grad_sum'], g['grad_sum_h0']
@@ -798,7 +800,7 @@ def test_uniform_weight_graph_stream_matches_oracle_and_weighted_stream(N, F, K,
         assert cell._use_fused(Xd, hd)
         H = cell(Xd, hd).double().cpu().numpy()
     err = np.abs(H - ref)
-    assert err.max() <= 3e-2 and err.mean() <= 2e-3, (err.max(), err.mean())
+    assert err.max() <= 5e-3 and err.mean() <= 1e-3, (err.max(), err.mean())
     # the same graph on the weighted stream
     monkeypatch.setenv('GCRNN_NO_UNIFORM', '1')
     g2 = GraphOperator(torch.tensor(S)).to(dev)
@@ -874,7 +876,7 @@ def test_fused_node_gated_forward_matches_oracle(N, F, G, K, tg):
         H = cell(Xd, hd)
     err = np.abs(H.double().cpu().numpy() - ref)
     # bf16 states, the x part A(S)x_t + b stored in bf16 between its pass and the recurrence: same tolerance class as the fused cell
-    assert err.max() <= 4e-2 and err.mean() <= 3e-3, (err.max(), err.mean())
+    assert err.max() <= 1.2e-2 and err.mean() <= 1.5e-3, (err.max(), err.mean())
 
 
 @pytest.mark.gpu
@@ -908,7 +910,7 @@ def test_fused_node_gated_training_matches_composed_autograd(N, F, G, K, B, T, t
     H = cell(Xd, hd)
     assert H.dtype == torch.bfloat16 and H.requires_grad
     err = (H.detach().float() - Hr.detach()).abs()
-    assert float(err.max()) <= 4e-2 and float(err.mean()) <= 3e-3, (float(err.max()), float(err.mean()))
+    assert float(err.max()) <= 1.2e-2 and float(err.mean()) <= 1.5e-3, (float(err.max()), float(err.mean()))
     (H.float() * dHd).sum().backward()
     got = dict(cell.named_parameters())
     checked = 0
@@ -960,7 +962,7 @@ def test_full_size_bf16_states_track_the_fp32_accurate_path():
         Hb = cb(Xb, h0).float()
     err = (Hb - H32).abs()
     per_step = err.amax(dim=(0, 2, 3))
-    assert float(err.max()) <= 3e-2 and float(err.mean()) <= 2e-3, (float(err.max()), float(err.mean()))
+    assert float(err.max()) <= 5e-3 and float(err.mean()) <= 1e-3, (float(err.max()), float(err.mean()))
     assert float(per_step[-1]) <= 3e-2 and float(per_step[-8:].mean()) <= 1.5 * float(per_step[:8].mean()) + 5e-3, per_step.tolist()
 
 
@@ -994,7 +996,7 @@ def test_fused_edge_gated_forward_matches_oracle(N, F, G, K, tg, sym):
         Hl = cell(Xd, hd, last_only=True)
     err = np.abs(H.double().cpu().numpy() - ref)
     # bf16 states; the filter outputs z (composite taps rounded to bf16) and the x branch are stored in bf16 between the passes
-    assert err.max() <= 4e-2 and err.mean() <= 3e-3, (err.max(), err.mean())
+    assert err.max() <= 1.2e-2 and err.mean() <= 1.5e-3, (err.max(), err.mean())
     assert torch.equal(Hl[:, 0], H[:, -1])
 
 
@@ -1029,7 +1031,7 @@ def test_fused_edge_gated_training_matches_composed_autograd(N, F, G, K, B, T, t
     H = cell(Xd, hd)
     assert H.dtype == torch.bfloat16 and H.requires_grad
     err = (H.detach().float() - Hr.detach()).abs()
-    assert float(err.max()) <= 4e-2 and float(err.mean()) <= 3e-3, (float(err.max()), float(err.mean()))
+    assert float(err.max()) <= 1.2e-2 and float(err.mean()) <= 1.5e-3, (float(err.max()), float(err.mean()))
     (H.float() * dHd).sum().backward()
     got = dict(cell.named_parameters())
     refg = {n: p.grad.cpu().numpy() for n, p in ref.named_parameters() if p.grad is not None}
@@ -1455,7 +1457,7 @@ def test_bf16_hop_image_with_matrix_core_sums_against_oracle_and_fp32_image(N, F
     monkeypatch.delenv('GCRNN_NO_IMG16')
     e16, e32 = np.abs(H16 - ref), np.abs(H32 - ref)
     print('bf16 image: max %.2e mean %.2e   fp32 image: max %.2e mean %.2e' % (e16.max(), e16.mean(), e32.max(), e32.mean()))
-    assert e16[:, 0].max() <= 4.0e-3 and e16.max() <= 3e-2 and e16.mean() <= 2e-3, (e16.max(), e16.mean())
+    assert e16[:, 0].max() <= 3.0e-3 and e16.max() <= 5e-3 and e16.mean() <= 1e-3, (e16.max(), e16.mean())
     assert e16.mean() <= 1.34 * e32.mean() + 1e-5, (e16.mean(), e32.mean())
     # training step: gradients with the bf16 image (forward + BPTT data chain) vs the fp32 image
     cellf = cell.float()
@@ -1512,7 +1514,7 @@ def test_bf16_hop_image_on_hub_graphs_small_graphs_and_sixteen_padding_rows(N, F
     with torch.no_grad():
         H32 = cell(Xd, hd).double().cpu().numpy()
     e16, e32 = np.abs(H16 - ref), np.abs(H32 - ref)
-    assert e16.max() <= 3e-2 and e16.mean() <= 2e-3, (e16.max(), e16.mean())
+    assert e16.max() <= 5e-3 and e16.mean() <= 1e-3, (e16.max(), e16.mean())
     assert e16.mean() <= 1.5 * e32.mean() + 1e-5, (e16.mean(), e32.mean())
     assert np.abs(H16 - H32).max() <= 1.6e-2
 
@@ -1664,7 +1666,7 @@ def test_fused_cell_with_state_widths_between_the_kernels(N, G, F, K, B, T, tg):
         cell = cell.to(torch.float32)
     assert Hi.shape == (B, T, F, N) and Hi.is_contiguous() and torch.equal(Hl, Hi[:, -1:])
     err = np.abs(Hi.double().cpu().numpy() - Href)
-    assert err.max() <= 4e-2 and err.mean() <= 3e-3, (err.max(), err.mean())
+    assert err.max() <= 2.5e-2 and err.mean() <= 1.5e-3, (err.max(), err.mean())      # (G = 1 cases: see test_fused_cell_with_few_input_features)
     H = cell(Xd, hd)
     (H.float() * dHd).sum().backward()
     got = dict(cell.named_parameters())
