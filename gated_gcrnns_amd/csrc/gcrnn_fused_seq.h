@@ -191,7 +191,7 @@ __global__ __launch_bounds__(STHREADS) void fused_seq_kernel(const SeqArgs a) {
 
     f32x4 u[STILES];
     // u_tap of chunk c for the wave's 8 tiles: one weight fragment feeds 8 independent MFMA chains
-    auto taps = [&](int tap, int c) {
+    auto taps_to = [&](int tap, int c, f32x4 (&u)[STILES]) {
       const uint4* wl = reinterpret_cast<const uint4*>(smem + IMG + (c & 1) * WB);
 #pragma unroll
       for (int i = 0; i < STILES; ++i) u[i] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -232,6 +232,7 @@ __global__ __launch_bounds__(STHREADS) void fused_seq_kernel(const SeqArgs a) {
         }
       }
     };
+    auto taps = [&](int tap, int c) { taps_to(tap, c, u); };
     // seed of chunk c: tap K-1 goes straight into the hop image (every wave has left the image: the barrier before)
     auto seed = [&](int c) {
       taps(K - 1, c);
@@ -282,6 +283,9 @@ __global__ __launch_bounds__(STHREADS) void fused_seq_kernel(const SeqArgs a) {
       // ---- Horner hops on the bf16 image; the tap a hop adds is evaluated from the resident operand right before it -------------
 #pragma unroll
       for (int j = 1; j < K; ++j) {
+#ifdef GCRNN_SEQ_TAPS_AFTER      // A/B (measured: 107.2k vs 107.6k seq/s, no gain, profiles/r03_taps_after_ab.txt): the tap of hop j + 1 evaluated right after hop j's stream
+        if (j == 1)
+#endif
         taps(K - 1 - j, chunk);
         GCRNN_STAMP(2 + chunk * 14 + 2 * j - 1);
         if constexpr (MODE == 2) {
@@ -340,6 +344,12 @@ __global__ __launch_bounds__(STHREADS) void fused_seq_kernel(const SeqArgs a) {
 #undef GCRNN_SEQ_STORE
         GCRNN_STAMP(2 + chunk * 14 + 2 * j);
         if (j < K - 1) {
+#ifdef GCRNN_SEQ_TAPS_AFTER
+          // the next hop's tap, from the resident operand, while the slower waves still stream: a wave that arrives early runs its 32
+          // MFMAs beside other waves' LDS gathers instead of all eight waves queueing on the matrix pipes after the barrier
+          f32x4 un[STILES];
+          taps_to(K - 2 - j, chunk, un);
+#endif
           lds_barrier();
 #pragma unroll
           for (int i = 0; i < STILES; ++i) {
@@ -348,6 +358,10 @@ __global__ __launch_bounds__(STHREADS) void fused_seq_kernel(const SeqArgs a) {
             state_put<true>(state, wv, u[i]);
           }
           lds_barrier();
+#ifdef GCRNN_SEQ_TAPS_AFTER
+#pragma unroll
+          for (int i = 0; i < STILES; ++i) u[i] = un[i];
+#endif
         }
       }
       // the LDS-DMA pieces (next weights, inline-pack tile) have had the last hop to land; wait before the epilogue's barriers
