@@ -140,6 +140,21 @@ __global__ __launch_bounds__(512, 2) void fused_wgrad_kernel(
       }
     }
     if constexpr (UNI != 0) {
+    // Transposed image of du_k as 32-BIT words [feature pair][node] = {du[n][2p], du[n][2p+1]} (round 3): a lane's four values are two
+    // such words -> 2 ds_write_b32 per tile instead of 4 two-byte scatters (measured in the step kernels: 14 LDS cycles per ds_write_b16);
+    // an A fragment (8 nodes of ONE feature) is then two 16-byte reads of its pair's row + 4 v_perm_b32 that pick the lane's parity.
+    // Row stride 2096 B (= 16 x 131, 131 = 3 mod 16): the eight pair rows of a read group sit on distinct bank quads.
+    constexpr int RS2 = 2096, TB2 = 8 * RS2;
+    static_assert(2 * TB2 <= 2 * TBYTES, "the two half images fit the transposed-image allocation");
+    typedef __attribute__((__vector_size__(4 * sizeof(unsigned int)))) unsigned int u32x4w;
+    const uint32_t psel = (r & 1) ? 0x07060302u : 0x05040100u;       // hi / lo halves of two words -> one register of the fragment
+    auto afrag = [&](int half, int s4p) {
+      const char* rowp = tbuf + half * TB2 + (r >> 1) * RS2 + (32 * s4p + 8 * q) * 4;
+      const u32x4w w0 = *reinterpret_cast<const u32x4w*>(rowp), w1 = *reinterpret_cast<const u32x4w*>(rowp + 16);
+      const u32x4w f = {__builtin_amdgcn_perm(w0[1], w0[0], psel), __builtin_amdgcn_perm(w0[3], w0[2], psel),
+                        __builtin_amdgcn_perm(w1[1], w1[0], psel), __builtin_amdgcn_perm(w1[3], w1[2], psel)};
+      return __builtin_bit_cast(bf16x8, f);
+    };
 #pragma unroll
     for (int k = 0; k < K; ++k) {
       // first batch of the second half's fragments: requested before the images are written, consumed after the first half
@@ -147,22 +162,16 @@ __global__ __launch_bounds__(512, 2) void fused_wgrad_kernel(
 #pragma unroll
       for (int s2 = 0; s2 < 8; ++s2)
         bl0[s2] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsrc_z, vo + 64 * (16 + s2), 0, 0));
-      // S1: du_k -> LDS state rows (for the next hop) and the transposed bf16 images of both node halves
+      // S1: du_k -> LDS state rows (for the next hop) and the transposed word images of both node halves
 #pragma unroll
       for (int i = 0; i < TILES; ++i) {
         int wv = woff[i];
         asm volatile("" : "+v"(wv));
         if (k < K - 1) state_put<UNI == 2>(state, wv, cur[i]);
         const int node = wv >> 16;
-        char* tb = tbuf + (node >= 512 ? TBYTES - 512 * 2 : 0) + node * 2;
-        // odd quads write their rows in the order 2, 3, 0, 1 (TSTRIDE = 8 banks mod 32: the two quads of a 32-lane store group then sit
-        // 16 banks apart instead of on one bank; with graph.spread_tile_classes the 2-byte scatter of a tile is conflict-free)
-        const int ro = (q & 1) ? 2 : 0;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          const float v = (q & 1) ? cur[i][c ^ 2] : cur[i][c];
-          *reinterpret_cast<uint16_t*>(tb + (q * 4 + (c ^ ro)) * TSTRIDE) = f2bf(v);
-        }
+        char* tb = tbuf + (node >= 512 ? TB2 : 0) + (node & 511) * 4 + (2 * q) * RS2;
+        *reinterpret_cast<uint32_t*>(tb) = (uint32_t)f2bf(cur[i][0]) | ((uint32_t)f2bf(cur[i][1]) << 16);
+        *reinterpret_cast<uint32_t*>(tb + RS2) = (uint32_t)f2bf(cur[i][2]) | ((uint32_t)f2bf(cur[i][3]) << 16);
       }
       lds_barrier();      // LDS hand-off only: loads in flight stay in flight (gcrnn_fused_step.h)
       // S2: D_k += du_k^T z over nodes 0..511 (register-resident fragments), then the first re-fetched batch (nodes 512..767)
@@ -171,8 +180,7 @@ __global__ __launch_bounds__(512, 2) void fused_wgrad_kernel(
         for (int s4 = 0; s4 < 16; s4 += 4) {
           bf16x8 a4[4];
 #pragma unroll
-          for (int p = 0; p < 4; ++p)
-            a4[p] = *reinterpret_cast<const bf16x8*>(tbuf + r * TSTRIDE + (32 * (s4 + p) + 8 * q) * 2);
+          for (int p = 0; p < 4; ++p) a4[p] = afrag(0, s4 + p);
 #pragma unroll
           for (int p = 0; p < 4; ++p) accD[k] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a4[p], bfr[s4 + p], accD[k], 0, 0, 0);
         }
@@ -180,8 +188,7 @@ __global__ __launch_bounds__(512, 2) void fused_wgrad_kernel(
         for (int s4 = 0; s4 < 8; s4 += 4) {
           bf16x8 a4[4];
 #pragma unroll
-          for (int p = 0; p < 4; ++p)
-            a4[p] = *reinterpret_cast<const bf16x8*>(tbuf + TBYTES + r * TSTRIDE + (32 * (s4 + p) + 8 * q) * 2);
+          for (int p = 0; p < 4; ++p) a4[p] = afrag(1, s4 + p);
 #pragma unroll
           for (int p = 0; p < 4; ++p) accD[k] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a4[p], bl0[s4 + p], accD[k], 0, 0, 0);
         }
@@ -205,8 +212,7 @@ __global__ __launch_bounds__(512, 2) void fused_wgrad_kernel(
         for (int s4 = 0; s4 < 8; s4 += 4) {
           bf16x8 a4[4];
 #pragma unroll
-          for (int p = 0; p < 4; ++p)
-            a4[p] = *reinterpret_cast<const bf16x8*>(tbuf + TBYTES + r * TSTRIDE + (32 * (8 + s4 + p) + 8 * q) * 2);
+          for (int p = 0; p < 4; ++p) a4[p] = afrag(1, 8 + s4 + p);
 #pragma unroll
           for (int p = 0; p < 4; ++p) accD[k] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a4[p], bl1[s4 + p], accD[k], 0, 0, 0);
         }

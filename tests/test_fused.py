@@ -1788,3 +1788,28 @@ def test_sequence_resident_time_gated_forward_is_bit_identical(N, F, G, K, B, T,
         monkeypatch.setenv('GCRNN_SEQ_KERNEL', '0')
         H0, Hl0 = cell(X, h0), cell(X, h0, last_only=True)
     assert torch.equal(H0, H1) and torch.equal(H0, H2) and torch.equal(Hl0, Hl1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('tg', [False, True])
+def test_sequence_resident_kernel_full_size_matches_the_chunk_parallel_kernel(tg, monkeypatch):
+    """The bench's full size (B = 256 sequences = one per CU, T = 32 steps inside ONE launch, N = 1000, K = 5, G = F = 64): the
+    persistent sequence-resident kernel -- each workgroup reads its own h_t back as the next step's operand 31 times -- gives the
+    bits of 32 launches of the chunk-parallel kernel, un-gated (with the inline pack) and time-gated (pre-passes + gated steps)."""
+    import bench
+    import gated_gcrnns_amd.Utils.graphML as gml
+    dev = torch.device('cuda:0')
+    N, K, T, F, B = 1000, 5, 32, 64, 256
+    torch.manual_seed(0)
+    cell = gml.GGCRNNCell(F, F, K, K, torch.tanh, tg, None, 1, True)
+    cell.addGSO(torch.tensor(bench.sbm_graph(N)))
+    cell = cell.to(torch.bfloat16).to(dev)
+    gen = torch.Generator(device=dev); gen.manual_seed(11)
+    X = torch.randn(B, T, F, N, device=dev, generator=gen).to(torch.bfloat16)
+    h0 = (0.3 * torch.randn(B, F, N, device=dev, generator=gen)).to(torch.bfloat16)
+    with torch.no_grad():
+        monkeypatch.setenv('GCRNN_SEQ_KERNEL', '0')
+        Href = cell(X, h0).clone()
+        monkeypatch.setenv('GCRNN_SEQ_KERNEL', '1')
+        for r in range(3):
+            assert torch.equal(cell(X, h0), Href), r
