@@ -46,6 +46,9 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 typedef __attribute__((ext_vector_type(2))) float f32x2;
 
+#ifndef GCRNN_HOP16_SPARSE
+#define GCRNN_HOP16_SPARSE 1     // bf16-image hop sums: ONE 2:4-sparse v_smfmac_f32_16x16x64_bf16 per four entries (one-hot A, both gathers as its K = 64 operand) instead of two dense MFMAs; 0: the dense pair (A/B)
+#endif
 #ifndef GCRNN_P1_AHEAD
 #define GCRNN_P1_AHEAD 0           // tiles (of 8 per wave) of the next sequence's operand requested during the last hop (experiment: every depth spills)
 #endif
@@ -306,13 +309,22 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
       const uint32_t one_ = (hit_ & 1) ? 0x3f800000u : 0x00003f80u;                                \
       u32x4a_ aop_ = {(hit_ >> 1) == 0 ? one_ : 0u, (hit_ >> 1) == 1 ? one_ : 0u, (hit_ >> 1) == 2 ? one_ : 0u, (hit_ >> 1) == 3 ? one_ : 0u}; \
       const uint32_t qh_ = (uint32_t)(q & 1) << 4;                                                 \
-      asm volatile(GCRNN_HOP_ASM_UNI16_TEXT                                                        \
+      if constexpr (GCRNN_HOP16_SPARSE) {                                                            \
+        asm volatile(GCRNN_HOP_ASM_UNI16_SPARSE_TEXT                                               \
+                     : "+v"(al_[0]), "+v"(ah_[0]), "+v"(al_[1]), "+v"(ah_[1]), "+v"(al_[2]), "+v"(ah_[2]), "+v"(al_[3]), "+v"(ah_[3]),  \
+                       "+v"(al_[4]), "+v"(ah_[4]), "+v"(al_[5]), "+v"(ah_[5]), "+v"(al_[6]), "+v"(ah_[6]), "+v"(al_[7]), "+v"(ah_[7])   \
+                     : "s"(GCRNN_SGPR(tend[0] >> 2)), "s"(GCRNN_SGPR(tend[1] >> 2)), "s"(GCRNN_SGPR(tend[2] >> 2)), "s"(GCRNN_SGPR(tend[3] >> 2)), "s"(GCRNN_SGPR(tend[4] >> 2)), \
+                       "s"(GCRNN_SGPR(tend[5] >> 2)), "s"(GCRNN_SGPR(tend[6] >> 2)), "s"(GCRNN_SGPR(tend[7] >> 2)), "s"(GCRNN_SGPR(gwbeg)), "s"(GCRNN_SGPR(gwend - 1)), "v"(colb), "v"(qh_), "v"(wp_) \
+                     : GCRNN_HOP_ASM_UNI16_SPARSE_CLOBBERS);                                        \
+      } else {                                                                                     \
+        asm volatile(GCRNN_HOP_ASM_UNI16_TEXT                                                        \
                    : "+v"(al_[0]), "+v"(ah_[0]), "+v"(al_[1]), "+v"(ah_[1]), "+v"(al_[2]), "+v"(ah_[2]), "+v"(al_[3]), "+v"(ah_[3]),  \
                      "+v"(al_[4]), "+v"(ah_[4]), "+v"(al_[5]), "+v"(ah_[5]), "+v"(al_[6]), "+v"(ah_[6]), "+v"(al_[7]), "+v"(ah_[7])   \
                    : "s"(GCRNN_SGPR(tend[0] >> 2)), "s"(GCRNN_SGPR(tend[1] >> 2)), "s"(GCRNN_SGPR(tend[2] >> 2)), "s"(GCRNN_SGPR(tend[3] >> 2)), "s"(GCRNN_SGPR(tend[4] >> 2)), \
                      "s"(GCRNN_SGPR(tend[5] >> 2)), "s"(GCRNN_SGPR(tend[6] >> 2)), "s"(GCRNN_SGPR(tend[7] >> 2)), "s"(GCRNN_SGPR(gwbeg)), "s"(GCRNN_SGPR(gwend - 1)), "v"(colb), "v"(qh_), "v"(wp_), \
                      "v"(aop_)                                                                     \
-                   : GCRNN_HOP_ASM_UNI16_CLOBBERS);                                                \
+                   : GCRNN_HOP_ASM_UNI16_CLOBBERS);                                                        \
+      }                                                \
     }                                                                                              \
     _Pragma("unroll") for (int i = 0; i < 8; ++i) STORE(i, (f32x4{al_[i][0], al_[i][1], ah_[i][0], ah_[i][1]}));                   \
   } while (0)

@@ -225,6 +225,7 @@ VD = int(os.environ.get('GCRNN_HOP16_DEPTH', '3'))      # groups in flight (regi
 
 
 UB16 = 218          # the bf16-image stream's own register window v[218:253]: 36 registers (5 gather sets would need v[UB16:UB16+39] + 12: D <= 3 here)
+SPA = 212           # sparse variant (v_smfmac): compressed one-hot A operand v[212:215], index register v216, scratch v217 -- window v[212:253]
 
 
 def VX(p, e):
@@ -264,11 +265,39 @@ def vs0p(q, lines):            # steady state: the same read through the running
     lines += ['v_min_u32 %s, %s, %s' % (VCA, VP5, VPCL), 'ds_read_b32 %s, %s' % (VC(q), VCA), 'v_add_u32 %s, 128, %s' % (VP5, VP5)]
 
 
-def gen_uniform16():
+def gen_uniform16(sparse=False):
+    """sparse: ONE v_smfmac_f32_16x16x64_bf16 per trip instead of two v_mfma_f32_16x16x32_bf16 -- the 2:4-sparse instruction takes a dense
+    B of K = 64 = [first gather | second gather] (probed: tools/probes/smfmac_probe.hip, profiles/r03_smfmac_layout_probe.txt: B elements
+    0..7 of lane (j, kg) are k = 8 kg + e, elements 8..15 are k = 32 + 8 kg + e, i.e. the two dense operands stacked along K) and a
+    compressed A: lane (i, sg) holds the kept values of dense k = 16 sg .. 16 sg + 15 (4 groups of 4, two kept per group, 2-bit positions
+    in the index register). The one-hot A[i][k] = (i == k mod 16) has ONE non-zero per lane: group i >> 2, position i & 3. Both are built
+    from the lane id in the block's prologue (the asm statement is at its 30-operand limit: the dense variant's A operand %29 goes away)."""
     D = VD
     assert 2 <= D <= 3      # (the register window holds three gather sets; 2 / 3 / 4 / 5 sets measured equal, DESIGN 4.1h)
     SC = 's90'                                # (group - tile end) of the current tile, counted up: the carry of its increment ends the tile
     L = ['s_mov_b32 %s, %s' % (SG, GBEG)]
+    if sparse:
+        A0, IDX, TMP = SPA, SPA + 4, SPA + 5
+        vM, vP, vVal, vNib = 'v%d' % A0, 'v%d' % (A0 + 1), 'v%d' % (A0 + 2), 'v%d' % (A0 + 3)      # temporaries first live in the A registers
+        L += ['v_mbcnt_lo_u32_b32 v%d, -1, 0' % TMP, 'v_mbcnt_hi_u32_b32 v%d, -1, v%d' % (TMP, TMP),
+              'v_and_b32 v%d, 15, v%d' % (TMP, TMP),                      # i = lane & 15
+              'v_and_b32 v%d, 3, v%d' % (IDX, TMP),                       # pos = i & 3
+              'v_lshrrev_b32 v%d, 2, v%d' % (TMP, TMP),                   # m = i >> 2: the lane's group with the non-zero
+              'v_cmp_eq_u32 vcc, 3, v%d' % IDX,
+              'v_or_b32 v%d, 12, v%d' % (IDX, IDX),                       # nibble: first kept at pos, second kept at 3 ...
+              'v_cndmask_b32 v%d, v%d, 12, vcc' % (IDX, IDX),              # ... pos == 3: first kept at 0 (a zero), second kept at 3 (the one)
+              'v_mov_b32 v%d, 0x3f80' % (A0 + 3),
+              'v_mov_b32 v%d, 0x3f800000' % (A0 + 2),
+              'v_cndmask_b32 v%d, v%d, v%d, vcc' % (A0 + 3, A0 + 3, A0 + 2),   # the group's register: 1.0 in its low (first kept) or high (second kept) half
+              'v_xor_b32 v%d, 4, v%d' % (IDX, IDX),                        # index = 0x4444 with nibble m replaced
+              'v_lshlrev_b32 v%d, 2, v%d' % (A0 + 2, TMP),
+              'v_lshlrev_b32 v%d, v%d, v%d' % (IDX, A0 + 2, IDX),
+              'v_xor_b32 v%d, 0x4444, v%d' % (IDX, IDX),
+              'v_mov_b32 v%d, v%d' % (A0 + 2, A0 + 3)]                     # vVal
+        # A registers: group g' holds vVal iff g' == m (set 3, 1, 0 first: they do not hold vVal; then 2)
+        for g in (3, 1, 0):
+            L += ['v_cmp_eq_u32 vcc, %d, v%d' % (g, TMP), 'v_cndmask_b32 v%d, 0, v%d, vcc' % (A0 + g, A0 + 2)]
+        L += ['v_cmp_eq_u32 vcc, 2, v%d' % TMP, 'v_cndmask_b32 v%d, 0, v%d, vcc' % (A0 + 2, A0 + 2)]
     for r in range(4):
         L.append('v_mov_b32 v%d, 0' % (VSUMB[0] + r))
     for p in range(D):
@@ -289,7 +318,9 @@ def gen_uniform16():
             vs1(q, L)                                             # (the set's registers were B operands of the PREVIOUS trip's MFMAs: read long ago)
             vs0p(q, L)
             L.append('s_waitcnt lgkmcnt(%d)' % (3 * (D - 1)))
-            for e in range(1 if os.environ.get('GCRNN_HOP16_EXPERIMENT_ONE_MFMA') else 2):      # (timing experiment, wrong results: what would ONE
+            if sparse:
+                L.append('v_smfmac_f32_16x16x64_bf16 %s, v[%d:%d], v[%d:%d], v%d' % (VSUM4[0], SPA, SPA + 3, UB16 + 8 * p, UB16 + 8 * p + 7, SPA + 4))
+            for e in range(0 if sparse else (1 if os.environ.get('GCRNN_HOP16_EXPERIMENT_ONE_MFMA') else 2)):      # (timing experiment, wrong results: what would ONE
                 # matrix instruction per four entries -- a 2:4-sparse v_smfmac_f32_16x16x64_bf16 with the one-hot A -- buy?)
                 # one accumulator (two, so that an MFMA never waits for its predecessor: slower, the exits pay more)
                 L.append('v_mfma_f32_16x16x32_bf16 %s, %%29, %s, %s' % (VSUM4[0], VX(p, e), VSUM4[0]))
@@ -297,7 +328,7 @@ def gen_uniform16():
         L.append('s_branch L_T%d_P0_%%=' % t)
         for p in range(D):                    # leaving tile t in phase p: acc_t += w * sum, sum = 0
             L.append('L_X%d_P%d_%%=:' % (t, p))
-            L += ['s_nop 11']                                     # matrix-core result (8 passes) -> VALU read: 11 wait states
+            L += ['s_nop 15', 's_nop 7'] if sparse else ['s_nop 11']       # matrix-core result -> VALU read: 11 wait states after the 8-pass dense MFMA; the sparse one is given the 16-pass distance
             L.append('v_pk_fma_f32 %%%d, %s, %s, %%%d' % (2 * t, UWP, VSUMH[0][0], 2 * t))
             L.append('v_pk_fma_f32 %%%d, %s, %s, %%%d' % (2 * t + 1, UWP, VSUMH[0][1], 2 * t + 1))
             for r in range(4):
@@ -330,10 +361,13 @@ def main():
     print('#define GCRNN_HOP_ASM_CLOBBERS %s, "s88", "s89", "s90", "scc", "memory"' % regs)
     emit('GCRNN_HOP_ASM_UNI_TEXT', gen_uniform())
     emit('GCRNN_HOP_ASM_UNI16_TEXT', gen_uniform16())
+    emit('GCRNN_HOP_ASM_UNI16_SPARSE_TEXT', gen_uniform16(sparse=True))
     regs = ', '.join('"v%d"' % r for r in range(UB, UB + 60))
     print('#define GCRNN_HOP_ASM_UNI_CLOBBERS %s, "s88", "s89", "s90", "scc", "memory"' % regs)
     regs16 = ', '.join('"v%d"' % r for r in range(UB16, UB16 + 36))
     print('#define GCRNN_HOP_ASM_UNI16_CLOBBERS %s, "s88", "s89", "s90", "scc", "vcc", "memory"' % regs16)
+    regs16s = ', '.join('"v%d"' % r for r in range(SPA, UB16 + 36))
+    print('#define GCRNN_HOP_ASM_UNI16_SPARSE_CLOBBERS %s, "s88", "s89", "s90", "scc", "vcc", "memory"' % regs16s)
 
 
 if __name__ == '__main__':
