@@ -79,6 +79,9 @@ struct SeqArgs {
   int pk_stride;                                       // ... elements between consecutive sequences of the user-layout tensor
   int nsteps;                                          // steps of this launch; every step but the last lays out the next one's operand
   int pk_all;                                          // ... != 0: the last step too (per-step launches: the host decides)
+  int xprefetch;                                       // MODE 0, experiment: request the x half of the next step's operand during the last hop (needs pk_ahead >= 2 or a fully packed X)
+  int pk_ahead;                                        // the inline pack of step i lays out the operand of step i + pk_ahead (1; forward: 2, so that x_{t+1} is complete -- and can be
+                                                       // requested into the dead operand registers -- while step t still runs); 0 = 1
 };
 
 template <int K, int HS, int XS, int MODE, bool GATED = false>
@@ -141,6 +144,9 @@ __global__ __launch_bounds__(STHREADS) void fused_seq_kernel(const SeqArgs a) {
   const uint32_t lds_col = lds0 + IMG + 2 * WB;
 
   for (int b = blockIdx.x; b < B; b += gridDim.x) {
+  // ---- the operand of a sequence and step: every B fragment of the wave, resident for all chunks ----------------------------------
+  bf16x8 bfr[STILES][KS];
+  [[maybe_unused]] bool xpre = false;        // (GCRNN_SEQ_X_PREFETCH) the x half of the NEXT step's operand has been requested (wave-uniform)
 #pragma unroll 1
   for (int step = 0; step < a.nsteps; ++step) {
     stamp_on = (step == (a.nsteps > 1 ? a.nsteps - 2 : 0));      // a typical step: it also lays out the next step's operand
@@ -150,7 +156,8 @@ __global__ __launch_bounds__(STHREADS) void fused_seq_kernel(const SeqArgs a) {
     uint16_t* hout = a.out0 ? a.out0 + (int64_t)step * a.ostride : nullptr;
     const uint16_t* aux0 = a.a0 ? a.a0 + (int64_t)step * a.a0stride : nullptr;
     const uint16_t* aux1 = a.a1 ? (a.a1_last_only ? (step == a.nsteps - 1 ? a.a1 : nullptr) : a.a1 + (int64_t)step * a.a1stride) : nullptr;
-    const bool pk = a.pk_src0 && (a.pk_all || step + 1 < a.nsteps);
+    const int pka = a.pk_ahead > 0 ? a.pk_ahead : 1;
+    const bool pk = a.pk_src0 && (a.pk_all || step + pka < a.nsteps);
     const uint16_t* pk_src = pk ? a.pk_src0 + (int64_t)step * a.pksrc_stride : nullptr;
     uint16_t* pk_dst = pk ? a.pk_dst0 + (int64_t)step * a.pkdst_stride : nullptr;
     const int pk_stride = a.pk_stride, ubstride = a.ubstride;
@@ -164,11 +171,13 @@ __global__ __launch_bounds__(STHREADS) void fused_seq_kernel(const SeqArgs a) {
     const __amdgpu_buffer_rsrc_t rsrc_a0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(aux0), 0, (MODE == 2 && aux0) ? B * (NP * F * 2) : 0, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsrc_a1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(aux1), 0, (MODE == 2 && aux1) ? B * (NP * F * 2) : 0, 0x00020000);
 
-    // ---- the operand of this sequence and step: every B fragment of the wave, requested at once, resident for all chunks -------
-    bf16x8 bfr[STILES][KS];
-    // (k-step major: the seed's first MFMAs need k-step 0 of every tile, which is then the first quarter of the requests to land)
+    // (k-step major: the seed's first MFMAs need k-step 0 of every tile, which is then the first quarter of the requests to land;
+    //  the x half may already be on its way: requested during the previous step's last hop, see below)
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
+#ifdef GCRNN_SEQ_X_PREFETCH
+      if (s >= HS && xpre) continue;
+#endif
 #pragma unroll
       for (int i = 0; i < STILES; ++i) {
         int w = woff[i];
@@ -179,6 +188,7 @@ __global__ __launch_bounds__(STHREADS) void fused_seq_kernel(const SeqArgs a) {
           bfr[i][s] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, (w >> 16) * (G * 2) + 16 * q + 64 * (s - HS), b * (NP * G * 2), 0));
       }
     }
+    xpre = false;
     float gsc = 1.f;
     if (MODE == 2 && a.gf0) gsc = a.gf0[(int64_t)step * a.gfstride + b];
     float gin = 1.f, gfo = 1.f, gratio = 1.f;
@@ -321,6 +331,26 @@ __global__ __launch_bounds__(STHREADS) void fused_seq_kernel(const SeqArgs a) {
             }
           }
         }
+#ifdef GCRNN_SEQ_X_PREFETCH      // compile-time experiment (tools/ab_build.sh "-DGCRNN_SEQ_X_PREFETCH" with GCRNN_SEQ_PK_AHEAD=2)
+        if constexpr (MODE == 0 && XS > 0) {
+          // Cross-step operand prefetch (EXPERIMENT, off: measured slower, see the launcher): after the last tap of the last chunk the x half of the operand registers is dead, and x_{t+1}
+          // does not depend on this step -- it is complete in its sequence-major array (packed by the caller, or laid out by the inline
+          // pack TWO steps ahead) -- so it is requested now and lands while the last hop and the epilogue run; the step boundary then
+          // waits for h_t alone. (The h half IS this step's output.)
+          if (a.xprefetch && j == K - 1 && chunk == NCH - 1 && step + 1 < a.nsteps && (!a.pk_src0 || pka >= 2)) {
+            const __amdgpu_buffer_rsrc_t rsrc_xn = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(a.x0 + (int64_t)(step + 1) * a.xstride), 0, B * (NP * G * 2), 0x00020000);
+#pragma unroll
+            for (int s2 = HS; s2 < KS; ++s2)
+#pragma unroll
+              for (int i = 0; i < STILES; ++i) {
+                int w = woff[i];
+                asm volatile("" : "+v"(w));
+                bfr[i][s2] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsrc_xn, (w >> 16) * (G * 2) + 16 * q + 64 * (s2 - HS), b * (NP * G * 2), 0));
+              }
+            xpre = true;
+          }
+        }
+#endif
         if (j == K - 1) {
           if (pk_src) {
             constexpr int NPC = NP / NCH, PPR = NPC / 8, PIECES = PKROWS * PPR;

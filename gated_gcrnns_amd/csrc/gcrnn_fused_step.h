@@ -1235,11 +1235,19 @@ int fused_launch_t(int mode /*0 plain, 1 gated, 2 gate pre-pass, 3 BPTT data gra
         sa.out0 = h; sa.ostride = hstep;
         sa.a1 = (const uint16_t*)huser; sa.a1stride = F * N; sa.a1_last_only = huser_last_only ? 1 : 0;
         sa.ubstride = (int)((huser_last_only ? 1 : T) * F * N);
-        if (inline_pack && T > 1) {
-          sa.pk_src0 = (const uint16_t*)bw_dHs + G * N; sa.pksrc_stride = G * N;
-          sa.pk_dst0 = const_cast<uint16_t*>(x) + xstep; sa.pkdst_stride = xstep;
+        // A/B (GCRNN_SEQ_PK_AHEAD=2): the inline pack two steps ahead + the x half of the next operand requested during the last hop.
+        // Measured on one box (profiles/r03_x_prefetch_ab.txt): 68.3-69.3 vs 66.2-67.6 us per step -- SLOWER (the 16 extra requests per lane
+        // join the LDS-DMA pieces and the stores of the busiest moment of the step); default 1.
+        const char* pka_env = getenv("GCRNN_SEQ_PK_AHEAD");
+        const int pka = (pka_env && pka_env[0] == '2') ? 2 : 1;
+        if (inline_pack && T > pka) {
+          // step t lays out x_{t+2} (the caller packed x_0 and x_1): x_{t+1} is complete while step t runs, the kernel requests it early
+          sa.pk_src0 = (const uint16_t*)bw_dHs + pka * G * N; sa.pksrc_stride = G * N;
+          sa.pk_dst0 = const_cast<uint16_t*>(x) + pka * xstep; sa.pkdst_stride = xstep;
           sa.pk_stride = (int)(T * G * N);
+          sa.pk_ahead = pka;
         }
+        sa.xprefetch = (pka == 2) ? 1 : 0;
         if (persist) {
           sa.nsteps = (int)T;
           sk<<<sgrid, STHREADS, slds, st>>>(sa);
@@ -1252,7 +1260,7 @@ int fused_launch_t(int mode /*0 plain, 1 gated, 2 gate pre-pass, 3 BPTT data gra
             s1.out0 = h + t * hstep;
             s1.a1 = !huser ? nullptr : (!huser_last_only ? (const uint16_t*)huser + t * F * N : (t == T - 1 ? (const uint16_t*)huser : nullptr));
             s1.a1_last_only = 0;
-            const bool pkt = sa.pk_src0 && t + 1 < T;
+            const bool pkt = sa.pk_src0 && t + pka < T;
             s1.pk_src0 = pkt ? sa.pk_src0 + t * sa.pksrc_stride : nullptr;
             s1.pk_dst0 = pkt ? sa.pk_dst0 + t * sa.pkdst_stride : nullptr;
             sk<<<sgrid, STHREADS, slds, st>>>(s1);

@@ -458,8 +458,9 @@ def fused_pack_inputs(X, h0, graph, overlap=False, first_only=False, channels=No
     xs = torch.empty((T, B, npad, G), dtype=torch.bfloat16, device=X.device)
     hs_all = torch.empty((T + 1, B, npad, F), dtype=torch.bfloat16, device=X.device)
     check(lib.gcrnn_pack_seq_major(_lib.BF16, _p(h0c), _p(hs_all), B, 1, F, N, npad, None, st), 'pack_seq')
-    if first_only:                                       # x_0 only: the step kernels lay out every later step themselves (inline pack)
-        check(lib.gcrnn_pack_seq_major_steps(_p(Xc), _p(xs), B, T, G, N, npad, 0, 1, 0, st), 'pack_seq_steps')
+    if first_only:                                       # x_0 and x_1 only: the step kernels lay out every later step themselves (inline pack;
+        # the sequence-resident kernel works two steps ahead, the chunk-parallel one re-writes x_1 with the same bits)
+        check(lib.gcrnn_pack_seq_major_steps(_p(Xc), _p(xs), B, T, G, N, npad, 0, min(2, T), 0, st), 'pack_seq_steps')
         return xs, hs_all
     if not overlap:
         check(lib.gcrnn_pack_seq_major(_lib.BF16, _p(Xc), _p(xs), B, T, G, N, npad, None, st), 'pack_seq')
