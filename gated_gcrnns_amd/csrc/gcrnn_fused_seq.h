@@ -94,7 +94,7 @@ __global__ __launch_bounds__(STHREADS) void fused_seq_kernel(const SeqArgs a) {
   constexpr int IMG = 33 * 1024;                 // bf16 hop image [NP][16] (32 KB); the transposed output tile needs 8 x 4128 B
   constexpr int WB = K * KS * 1024;              // one chunk's weight fragments
   static_assert(STILES == 8 && GCRNN_HOP_ASM, "generated hop stream: 8 tiles per wave");
-  static_assert((MODE == 0 || MODE == 1) ? XS > 0 : XS == 0, "forward / pre-pass take [h | x], the BPTT step its one operand");
+  static_assert((MODE == 0 || MODE == 1) ? XS > 0 : (MODE == 2 ? XS == 0 : MODE == 4), "forward / pre-pass take [h | x], the BPTT step its one operand, the filter-output pass either");
   static_assert(!GATED || MODE == 0, "gated steps are forward steps");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* state = reinterpret_cast<float*>(smem);
@@ -136,7 +136,7 @@ __global__ __launch_bounds__(STHREADS) void fused_seq_kernel(const SeqArgs a) {
   // the bias (it enters through both filters, graphML.py:2420-2421: scaled by gi + gf = 2 at its use) in the 256 spare bytes behind the tile:
   // a chunk reads its four values from LDS instead of waiting for a global load at the top of every chunk
   float* lbias = reinterpret_cast<float*>(smem + 33024);
-  if ((MODE == 0 || MODE == 1) && tid < F) lbias[tid] = a.bias ? a.bias[tid] : 0.f;
+  if ((MODE == 0 || MODE == 1 || MODE == 4) && tid < F) lbias[tid] = a.bias ? a.bias[tid] : 0.f;
   __syncthreads();
 
   const uint32_t lds0 = (uint32_t)reinterpret_cast<uintptr_t>(smem);
@@ -162,7 +162,8 @@ __global__ __launch_bounds__(STHREADS) void fused_seq_kernel(const SeqArgs a) {
     uint16_t* pk_dst = pk ? a.pk_dst0 + (int64_t)step * a.pkdst_stride : nullptr;
     const int pk_stride = a.pk_stride, ubstride = a.ubstride;
     float* gate_out = a.go0 ? a.go0 + (int64_t)step * a.gostride : nullptr;
-    const bool skip_h = (MODE == 1) && a.flags && a.flags[0] != 0;          // wave-uniform
+    // wave-uniform; MODE 4 with an input operand filters [0 | x_t]: the state half is all zeros by contract
+    const bool skip_h = (MODE == 4 && XS > 0) || ((MODE == 1) && a.flags && a.flags[0] != 0);
     // (skipped state operand: a zero-length descriptor -- its loads return zeros and cost nothing)
     const __amdgpu_buffer_rsrc_t rsrc_h = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(hprev), 0, skip_h ? 0 : (MODE == 1 ? a.hmod : B) * (NP * F * 2), 0x00020000);
     const int bh = (MODE == 1) ? b % a.hmod : b;
@@ -205,7 +206,7 @@ __global__ __launch_bounds__(STHREADS) void fused_seq_kernel(const SeqArgs a) {
       const uint4* wl = reinterpret_cast<const uint4*>(smem + IMG + (c & 1) * WB);
 #pragma unroll
       for (int i = 0; i < STILES; ++i) u[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if constexpr (GATED || MODE == 1) {
+      if constexpr (GATED || MODE == 1 || (MODE == 4 && XS > 0)) {
         // (GATED) gi (x W_x) + gf (h W_h) on ONE accumulator chain: h-chain, scale by gf / gi, continue with x, scale by gi (gi = sigmoid(.) > 0;
         // the wave-uniform guard covers an underflowed gate); (MODE 1) the state half is skipped when h0 is all zeros
         if (!skip_h) {
@@ -438,12 +439,32 @@ __global__ __launch_bounds__(STHREADS) void fused_seq_kernel(const SeqArgs a) {
           for (int off = 32; off > 0; off >>= 1) part += __shfl_down(part, off, 64);
           if (lane == 0) gate_out[(int64_t)b * (NCH * SWAVES) + chunk * SWAVES + wave] = part;
         }
+      } else if constexpr (MODE == 4) {
+        // filter-output pass (graphML.py:2420, one filter of an item): A(S) operand + b, bf16, sequence-major, no non-linearity
+        const int ql = (tl & 63) >> 4;      // (from the per-chunk opaque id: hoisted out of the loops these addresses are spilled)
+        float bv[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) bv[c] = lbias[chunk * FC + ql * 4 + c];
+#pragma unroll
+        for (int i = 0; i < STILES; ++i) {
+          int wv = woff[i];
+          asm volatile("" : "+v"(wv));
+          const int node = wv >> 16;
+          uint2 pkd{0u, 0u};
+          if (node < N) {
+            const f32x4 acc = u[i];
+            pkd.x = (uint32_t)f2bf(acc[0] + bv[0]) | ((uint32_t)f2bf(acc[1] + bv[1]) << 16);
+            pkd.y = (uint32_t)f2bf(acc[2] + bv[2]) | ((uint32_t)f2bf(acc[3] + bv[3]) << 16);
+          }
+          __builtin_amdgcn_raw_buffer_store_b64(u32x2{pkd.x, pkd.y}, rsrc_o, node * (F * 2) + (chunk * FC + q * 4) * 2, b * (NP * F * 2), 0);
+        }
       } else if constexpr (MODE == 1) {
         // gate pre-pass: partial dot product of tanh(pre) with the gate's read-out weights over this chunk, one partial per wave (the
         // caller adds them in a fixed order); with an output array the gate cell's state c = tanh(pre) is also stored (bf16)
+        const int ql = (tl & 63) >> 4;      // (from the per-chunk opaque id: hoisted out of the loops these addresses are spilled)
         float bs2[4];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) bs2[c] = 2.f * lbias[chunk * FC + q * 4 + c];
+        for (int c = 0; c < 4; ++c) bs2[c] = 2.f * lbias[chunk * FC + ql * 4 + c];
         float part = 0.f;
 #pragma unroll
         for (int i = 0; i < STILES; ++i) {
@@ -453,7 +474,7 @@ __global__ __launch_bounds__(STHREADS) void fused_seq_kernel(const SeqArgs a) {
           uint2 pkd{0u, 0u};
           if (node < N) {
             // (the read-out weights [N][F] fp32 are shared by every item: L2- / L1-resident; held across an asm block they would spill)
-            const float4 w4 = *reinterpret_cast<const float4*>(a.gw + (int64_t)node * F + chunk * FC + q * 4);
+            const float4 w4 = *reinterpret_cast<const float4*>(a.gw + (int64_t)node * F + chunk * FC + ql * 4);
             const f32x4 acc = u[i];
             const float o0 = fast_tanh(acc[0] + bs2[0]), o1 = fast_tanh(acc[1] + bs2[1]);
             const float o2 = fast_tanh(acc[2] + bs2[2]), o3 = fast_tanh(acc[3] + bs2[3]);

@@ -1160,14 +1160,37 @@ int fused_launch_t(int mode /*0 plain, 1 gated, 2 gate pre-pass, 3 BPTT data gra
 #if GCRNN_HOP_ASM && GCRNN_STEP_WAVES == 8
   // Sequence-resident kernel (gcrnn_fused_seq.h): one workgroup per sequence keeps the operand in registers for all chunks -- the
   // un-gated forward steps and the plain BPTT data chain on uniform-weight bf16-image plans, when the batch fills the chip.
-  if (ga.uniform_w != 0.f && ga.img16 && ga.ell_col4 && !head && !step_events && (mode == 0 || mode == 1 || mode == 2 || mode == 3) &&
-      fused_seq_wanted(mode == 2 ? B * T : B, NCH)) {
+  if (ga.uniform_w != 0.f && ga.img16 && ga.ell_col4 && !head && !step_events && (mode == 0 || mode == 1 || mode == 2 || mode == 3 || mode == 5) &&
+      fused_seq_wanted((mode == 2 || mode == 5) ? B * T : B, NCH)) {
     const size_t slds = fused_seq_lds<K, HS, XS>(ga.entries, inline_pack, mode == 3 ? F : G);
     const unsigned sgrid = (unsigned)(B < 256 ? B : 256);
     const bool persist = fused_seq_persistent();
     SeqArgs sa{};
     sa.wpack = (const uint4*)wpack; sa.tile_nodes = ga.tile_nodes; sa.tile_off = ga.tile_off; sa.ell_col4 = (const uint2*)ga.ell_col4;
     sa.entries = (int)ga.entries; sa.B = (int)B; sa.N = (int)N; sa.uni_w = ga.uniform_w;
+    if (mode == 5 && slds) {
+      // filter output A(S) operand + b of every (t, b) item, one workgroup per item (time-chunked like mode 2): the operand is one
+      // state-like array (XS == 0) or [0 | x_t] with the zero half skipped
+      auto sk = fused_seq_kernel<K, HS, XS, 4>;
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(sk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)slds) != hipSuccess)
+        return GCRNN_ERR_LAUNCH;
+      const int64_t row_bytes = (int64_t)NP * (F > G ? F : G) * 2;
+      int64_t tchunk = (2147483647LL / row_bytes) / B;
+      if (tchunk < 1) return GCRNN_ERR_BAD_SHAPE;
+      if (tchunk > T) tchunk = T;
+      GCRNN_PRE_LAUNCH();
+      for (int64_t t0 = 0; t0 < T; t0 += tchunk) {
+        const int64_t nt = (T - t0 < tchunk) ? T - t0 : tchunk, items = nt * B;
+        SeqArgs s1 = sa;
+        s1.bias = bias; s1.B = (int)items; s1.nsteps = 1;
+        if (XS == 0) s1.hfirst = (const uint16_t*)h0 + t0 * hstep;
+        else s1.x0 = x + t0 * xstep;
+        s1.out0 = h + t0 * hstep;
+        sk<<<(unsigned)(items < 256 ? items : 256), STHREADS, slds, st>>>(s1);
+      }
+      GCRNN_CHECK_LAUNCH();
+      return GCRNN_OK;
+    }
     if constexpr (XS > 0) {
       if (mode == 2 && slds) {
         // gate pre-pass: every (t, b) item of one gate in one launch (split over whole time steps where the 32-bit buffer offsets of

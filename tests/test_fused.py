@@ -1595,6 +1595,45 @@ def test_sequence_resident_bptt_chain_is_bit_identical(tg, N, F, K, monkeypatch)
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('N,F,C,K,B,T,adj', [(1000, 64, 64, 5, 5, 3, False), (1000, 64, 64, 5, 3, 2, True), (400, 32, 32, 3, 7, 2, False),
+                                             (1000, 64, 32, 2, 4, 3, False), (1008, 32, 32, 4, 130, 2, False)])
+def test_filter_output_pass_on_the_sequence_resident_kernel_is_bit_identical(N, F, C, K, B, T, adj, monkeypatch):
+    """The all-items filter-output pass A(S) x_t + b (graphML.py:2420: the node- and edge-gated cells' x filter, the edge-gated cell's
+    per-step state filter, the input gradient dX) on the sequence-resident kernel -- one workgroup per (t, b) item, the operand a
+    state-like array (C == F) or [0 | x_t] with the zero half skipped -- gives the bits of the chunk-parallel kernel, and both agree
+    with an fp64 evaluation of the filter on the bf16-rounded operands."""
+    from gated_gcrnns_amd import ops
+    dev = torch.device('cuda:0')
+    cell, rng, S = _uniform_cell(N, C, F, K, False, 83, dev)
+    w = torch.tensor(bf16_round(0.2 * rng.standard_normal((F, 1, K, C))), dtype=torch.float32, device=dev)
+    bias = torch.tensor(0.1 * rng.standard_normal((F, 1)), dtype=torch.float32, device=dev)
+    x = torch.tensor(bf16_round(rng.standard_normal((B, T, C, N))), dtype=torch.float32, device=dev).to(torch.bfloat16)
+    xs = ops.to_sequence_major(x, cell.graph)
+    outs = {}
+    for seq in ('1', '0'):
+        monkeypatch.setenv('GCRNN_SEQ_KERNEL', seq)
+        monkeypatch.setenv('GCRNN_SEQ_MIN_B', '1')
+        outs[seq] = ops.fused_filter_output(xs, w, bias, cell.graph, K, N, adjoint=adj)
+        torch.cuda.synchronize()
+    assert torch.equal(outs['1'], outs['0'])
+    assert float(outs['1'][:, :, N:].abs().max()) == 0.0
+    # fp64 check of one item: sum_k S^k x w_k + b (S^T on the adjoint graph)
+    Sd = np.asarray(S, dtype=np.float64).reshape(N, N)
+    Sd = Sd.T if adj else Sd
+    xi = x[B - 1, T - 1].double().cpu().numpy()                      # [C][N]
+    acc = np.zeros((F, N))
+    z = xi.copy()
+    wd = w.double().cpu().numpy()
+    for k in range(K):
+        acc += wd[:, 0, k, :] @ z
+        z = z @ Sd
+    ref = acc + bias.double().cpu().numpy()
+    got = outs['1'][T - 1, B - 1, :N].float().cpu().numpy().T
+    scale = float(np.abs(ref).max())
+    assert float(np.abs(got - ref).max()) <= 2.5e-2 * scale
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('N,F,G,K,B,T', [(1000, 64, 64, 5, 5, 4), (400, 32, 32, 3, 7, 3), (1008, 64, 64, 5, 257, 2), (1000, 64, 1, 3, 3, 3)])
 def test_native_layout_output_and_sequence_major_forward_are_bit_identical(N, F, G, K, B, T, monkeypatch):
     """the cell output as a VIEW of the sequence-major state image (module flag `native_layout`: the launches skip
