@@ -360,6 +360,43 @@ extern "C" int gcrnn_fused_gate_prepass_bf16(const void* xs, const void* h0, con
                         nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, h0_zero_flag);
 }
 
+// The gate pre-pass that also lays out X: x_user = the user-layout input [B][T][G][N] bf16 (channels already padded to the kernels'
+// 32 / 64), xs = the sequence-major array [T][B][NP][G] with its first gcrnn_fused_gate_prepass_lays_out(...) time steps laid out by
+// the caller; on return every step is. Each item of the sequence-resident kernel lays out the operand of its workgroup's next item
+// (as the forward steps lay out x_{t+1}), so the separate pass over X (0.5 ms at B = 256, T = 32) goes away for gated cells.
+extern "C" int gcrnn_fused_gate_prepass_pack_bf16(const void* x_user, void* xs, const void* h0, const void* wpack, const float* bias,
+                                                  const float* gate_w, float* gate_out, void* cs, const int32_t* tile_nodes,
+                                                  const int32_t* tile_off, const int32_t* ell_col, const float* ell_val,
+                                                  const void* ell_val4, const void* ell_col4, int64_t entries, int64_t B,
+                                                  int64_t T, int64_t N, int64_t F, int64_t G, int64_t K, const int32_t* h0_zero_flag,
+                                                  double uniform_w, int img16, void* stream) {
+  if (!x_user || !xs || !h0 || !wpack || !gate_w || !gate_out || !tile_nodes || !tile_off || !ell_col || !ell_val) return GCRNN_ERR_NULL_POINTER;
+  if (B <= 0 || T <= 0 || N <= 0 || N > NP || B * T > (1 << 24) || entries < 0 || entries % 4) return GCRNN_ERR_BAD_SHAPE;
+  const FusedGraphArgs ga{tile_nodes, tile_off, ell_col, ell_val, ell_val4, ell_col4, entries, (float)uniform_w, img16 ? 1 : 0};
+  return fused_dispatch(2, xs, h0, cs, wpack, bias, nullptr, nullptr, gate_w, gate_out, ga, B, T, N, F, G, K, as_stream(stream),
+                        x_user, nullptr, nullptr, nullptr, nullptr, nullptr, 0, h0_zero_flag);
+}
+
+// 0: gcrnn_fused_gate_prepass_pack_bf16 is not available for this shape (chunk-parallel kernel, weighted graph, N % 8, LDS); else the
+// number of leading time steps of xs the caller must lay out itself (the items of the first round of workgroups).
+extern "C" int64_t gcrnn_fused_gate_prepass_lays_out(int64_t B, int64_t T, int64_t N, int64_t F, int64_t G, int64_t K, int64_t entries,
+                                                     double uniform_w, int img16) {
+#if GCRNN_HOP_ASM && GCRNN_STEP_WAVES == 8
+  if (uniform_w == 0.0 || !img16 || N <= 0 || N > NP || N % 8 || B <= 0 || T <= 0 || entries % 4 || (G != 32 && G != 64) || (F != 32 && F != 64)) return 0;
+  if (!gcrnn_fused_supported(N, F, G, K)) return 0;
+  const int nch = (int)(F / FC);
+  if (!fused_seq_wanted(B * T, nch)) return 0;
+  const size_t need = (size_t)33 * 1024 + 2 * (size_t)K * ((F + G) / 32) * 1024 + (size_t)entries * 32 + (size_t)G * (NP / nch) * 2;
+  if (need > 160 * 1024 || T * G * N > 2147483647LL) return 0;
+  const int64_t row_bytes = (int64_t)NP * (F > G ? F : G) * 2;
+  if ((2147483647LL / row_bytes) / B < T) return 0;                  // (the launch would be split over time: not with the pack)
+  const int64_t first = B * T < 256 ? B * T : 256;
+  return (first + B - 1) / B;
+#else
+  return 0;
+#endif
+}
+
 // d loss / d (scalar time gate) of one filter of the gated cell:  out[t*B+b][partials] summed = sum_{f,n} (W(S) z + b) . dpre
 // xs == null (G = 0): z = zs [T][B][NP][F] bf16 sequence-major is that filter's operand (h_{t-1} for the state filter, or x_t
 // for an input filter with G == F), wpack its taps packed as a state-only operand (gcrnn_fused_pack_weights with G = 0).

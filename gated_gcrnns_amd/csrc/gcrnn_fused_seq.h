@@ -90,7 +90,7 @@ __global__ __launch_bounds__(STHREADS) void fused_seq_kernel(const SeqArgs a) {
   constexpr int F = 32 * HS, G = 32 * XS;
   constexpr int NCH = F / FC;
   constexpr int HT = STILES;
-  constexpr int PKROWS = (MODE == 0) ? G : F;
+  constexpr int PKROWS = (MODE == 0 || MODE == 1) ? G : F;
   constexpr int IMG = 33 * 1024;                 // bf16 hop image [NP][16] (32 KB); the transposed output tile needs 8 x 4128 B
   constexpr int WB = K * KS * 1024;              // one chunk's weight fragments
   static_assert(STILES == 8 && GCRNN_HOP_ASM, "generated hop stream: 8 tiles per wave");
@@ -157,10 +157,15 @@ __global__ __launch_bounds__(STHREADS) void fused_seq_kernel(const SeqArgs a) {
     const uint16_t* aux0 = a.a0 ? a.a0 + (int64_t)step * a.a0stride : nullptr;
     const uint16_t* aux1 = a.a1 ? (a.a1_last_only ? (step == a.nsteps - 1 ? a.a1 : nullptr) : a.a1 + (int64_t)step * a.a1stride) : nullptr;
     const int pka = a.pk_ahead > 0 ? a.pk_ahead : 1;
-    const bool pk = a.pk_src0 && (a.pk_all || step + pka < a.nsteps);
+    // MODE 1 (items, no recurrence): the pack lays out the operand of the NEXT item of this workgroup's loop, item b + gridDim.x =
+    // (t', b') = (nb / hmod, nb % hmod) of the user-layout X[b'][t'] -- the caller laid out the first gridDim.x items
+    const int nb = b + (int)gridDim.x;
+    const bool pk = a.pk_src0 && (MODE == 1 ? nb < B : (a.pk_all || step + pka < a.nsteps));
     const uint16_t* pk_src = pk ? a.pk_src0 + (int64_t)step * a.pksrc_stride : nullptr;
     uint16_t* pk_dst = pk ? a.pk_dst0 + (int64_t)step * a.pkdst_stride : nullptr;
     const int pk_stride = a.pk_stride, ubstride = a.ubstride;
+    const int64_t pk_soff = (MODE == 1) ? (int64_t)(nb % a.hmod) * pk_stride + (int64_t)(nb / a.hmod) * a.pksrc_stride : (int64_t)b * pk_stride;
+    const int pk_db = (MODE == 1) ? nb : b;
     float* gate_out = a.go0 ? a.go0 + (int64_t)step * a.gostride : nullptr;
     // wave-uniform; MODE 4 with an input operand filters [0 | x_t]: the state half is all zeros by contract
     const bool skip_h = (MODE == 4 && XS > 0) || ((MODE == 1) && a.flags && a.flags[0] != 0);
@@ -274,7 +279,7 @@ __global__ __launch_bounds__(STHREADS) void fused_seq_kernel(const SeqArgs a) {
         if (pk_src && prow < PKROWS && pj < 5 && chunk * NPC < N) {
           int node = chunk * NPC + (pj < 4 ? pj * 64 : NPC - 2);
           node = node < N - 2 ? node : N - 2;
-          prefetched_pk = *reinterpret_cast<const uint32_t*>(pk_src + (int64_t)b * pk_stride + (int64_t)prow * N + node);
+          prefetched_pk = *reinterpret_cast<const uint32_t*>(pk_src + pk_soff + (int64_t)prow * N + node);
         }
 #endif
       }
@@ -356,7 +361,7 @@ __global__ __launch_bounds__(STHREADS) void fused_seq_kernel(const SeqArgs a) {
           if (pk_src) {
             constexpr int NPC = NP / NCH, PPR = NPC / 8, PIECES = PKROWS * PPR;
             static_assert(PIECES % STHREADS == 0, "whole pieces per thread");
-            const uint16_t* xsrc = pk_src + (int64_t)b * pk_stride + chunk * NPC;
+            const uint16_t* xsrc = pk_src + pk_soff + chunk * NPC;
 #pragma unroll
             for (int i = 0; i < PIECES / STHREADS; ++i) {
               const int id = i * STHREADS + tl;
@@ -579,7 +584,7 @@ __global__ __launch_bounds__(STHREADS) void fused_seq_kernel(const SeqArgs a) {
         for (int i = 0; i < RI; ++i) {
           const int id = i * STHREADS + tl;
           const int nl = id / PCS, pc = id - nl * PCS;
-          __builtin_amdgcn_raw_buffer_store_b128(vv[i], rsrc_xn, (chunk * NPCp + nl) * (PKROWS * 2) + pc * 16 + b * (NP * PKROWS * 2), 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b128(vv[i], rsrc_xn, (chunk * NPCp + nl) * (PKROWS * 2) + pc * 16 + pk_db * (NP * PKROWS * 2), 0, 0);
         }
       }
       lds_barrier();     // the last hop's reads of the image (and the epilogue's of its tiles) are done: the image may be seeded again

@@ -1089,11 +1089,13 @@ int fused_launch_t(int mode /*0 plain, 1 gated, 2 gate pre-pass, 3 BPTT data gra
   // (mode 3: the BPTT chain lays out dH_{t-2} the same way, the user-layout dH arrives in xs and the tile has F rows)
   const bool inline_bw = (mode == 3 && xs != nullptr) || (mode == 7 && bw_h0 != nullptr) || (mode == 8 && xs != nullptr);      // (mode 7: the user-layout dH arrives in bw_h0)
   const size_t xtile_bytes = (size_t)(inline_bw ? F : G) * (NP / (F / FC)) * 2;
-  const bool inline_pack = (mode == 0 && bw_dHs != nullptr) || inline_bw;
-  if (inline_pack && !((XS > 0 || inline_bw) && uni && resident && N % 8 == 0 && resident_bytes + xtile_bytes <= 160 * 1024 &&
-                       T * (inline_bw ? F : G) * N <= 2147483647LL))
+  const bool prepass_pack = (mode == 2 && bw_dHs != nullptr);       // gate pre-pass that also lays out X (sequence-resident kernel only)
+  const bool inline_pack = (mode == 0 && bw_dHs != nullptr) || inline_bw || prepass_pack;
+  if (inline_pack && !prepass_pack && !((XS > 0 || inline_bw) && uni && resident && N % 8 == 0 && resident_bytes + xtile_bytes <= 160 * 1024 &&
+                                        T * (inline_bw ? F : G) * N <= 2147483647LL))
     return GCRNN_ERR_UNSUPPORTED;
-  const size_t lds = (resident ? resident_bytes : base) + (inline_pack ? xtile_bytes : 0);
+  if (prepass_pack && !(XS > 0 && uni && N % 8 == 0 && T * G * N <= 2147483647LL)) return GCRNN_ERR_UNSUPPORTED;
+  const size_t lds = (resident ? resident_bytes : base) + ((inline_pack && !prepass_pack) ? xtile_bytes : 0);
   if (ga.img16 && !(uni && resident)) return GCRNN_ERR_UNSUPPORTED;      // the bf16-image plan needs the uniform-weight asm stream on the LDS-resident graph (every mode has its UNI == 2 instantiation)
   fused_kern_t kern;
   const bool head = (mode == 0 || mode == 1) && gate_w != nullptr;      // fused output head: EPI 6 instantiations
@@ -1210,6 +1212,13 @@ int fused_launch_t(int mode /*0 plain, 1 gated, 2 gate pre-pass, 3 BPTT data gra
           s1.x0 = x + t0 * xstep; s1.hfirst = (const uint16_t*)h0;
           s1.out0 = h ? h + t0 * hstep : nullptr;
           s1.gw = gate_w; s1.go0 = gate_out + t0 * B * (NCH * SWAVES); s1.flags = hzero_flag;
+          if (prepass_pack) {
+            // every item lays out the operand of the workgroup's next item from the user-layout X [B][T][G][N] (the caller laid out
+            // the first min(items, 256)): the pass over X that packed the whole input goes away
+            if (tchunk != T) return GCRNN_ERR_UNSUPPORTED;
+            s1.pk_src0 = (const uint16_t*)bw_dHs; s1.pksrc_stride = G * N; s1.pk_stride = (int)(T * G * N);
+            s1.pk_dst0 = const_cast<uint16_t*>(x);
+          }
           sk<<<(unsigned)(items < 256 ? items : 256), STHREADS, slds, st>>>(s1);
         }
         GCRNN_CHECK_LAUNCH();
@@ -1349,6 +1358,7 @@ int fused_launch_t(int mode /*0 plain, 1 gated, 2 gate pre-pass, 3 BPTT data gra
     }
   }
 #endif
+  if (prepass_pack) return GCRNN_ERR_UNSUPPORTED;      // (gcrnn_fused_gate_prepass_lays_out tells the caller beforehand)
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
     return GCRNN_ERR_LAUNCH;
   // one workgroup per CU: 256 / NCH sequence slots (rounded to the 8 XCDs), fewer when the batch is small

@@ -487,6 +487,29 @@ def fused_pack_inputs(X, h0, graph, overlap=False, first_only=False, channels=No
     return xs, hs_all, events
 
 
+def fused_pack_inputs_gated(X, h0, graph, F, K):
+    """fused_pack_inputs for a cell whose FIRST consumer of xs is a gate pre-pass (fused_time_gate): on a uniform-weight graph with
+    a batch that fills the chip, only the first time step(s) are laid out here and that pre-pass lays out the rest while it runs
+    (gcrnn_fused_gate_prepass_pack_bf16: every item packs the operand of its workgroup's next item) -- the 0.5 ms pass over X at
+    B = 256, T = 32 goes away. The pending user-layout tensor travels with xs (`_pending_user`) until that pre-pass has run."""
+    B, T, G, N = X.shape
+    plan = graph.fused_plan()
+    plan16 = fused_img16_plan(graph, True, None)
+    steps = 0
+    if plan16 is not None and X.dtype == torch.bfloat16 and X.is_contiguous() and X.data_ptr() % 16 == 0 and not os.environ.get('GCRNN_NO_INLINE_PACK'):
+        steps = int(lib.gcrnn_fused_gate_prepass_lays_out(B, T, N, F, G, K, plan16['entries'], plan.get('uniform_w', 0.0), 1))
+    if steps <= 0 or steps >= T:
+        return fused_pack_inputs(X, h0, graph)
+    npad = plan['npad']
+    st = _stream()
+    xs = torch.empty((T, B, npad, G), dtype=torch.bfloat16, device=X.device)
+    hs_all = torch.empty((T + 1, B, npad, F), dtype=torch.bfloat16, device=X.device)
+    check(lib.gcrnn_pack_seq_major(_lib.BF16, _p(h0.contiguous()), _p(hs_all), B, 1, F, N, npad, None, st), 'pack_seq')
+    check(lib.gcrnn_pack_seq_major_steps(_p(X), _p(xs), B, T, G, N, npad, 0, steps, 0, st), 'pack_seq_steps')
+    xs._pending_user = X
+    return xs, hs_all
+
+
 def fused_overlap_ok(X):
     """The overlapped pack (opt-in: GCRNN_FUSED_OVERLAP=1) needs even N and G (4-byte accesses), more than one step, and no
     stream capture in progress. Off by default: measured on MI355X it gains 3 % when the two streams happen to share the CUs
@@ -519,9 +542,18 @@ def fused_time_gate(xs, h0s, wA_g, wB_g, bias_g, lin_w, lin_b, graph, N, store_s
     parts = torch.empty((T * B, (F // 16) * int(lib.gcrnn_fused_step_waves())), dtype=torch.float32, device=xs.device)
     cs = torch.empty((T, B, npad, F), dtype=torch.bfloat16, device=xs.device) if store_states else None
     plan16 = fused_img16_plan(graph, True, None)
-    check(lib.gcrnn_fused_gate_prepass_bf16(_p(xs), _p(h0s), _p(wp), _p(bg), _p(gw), _p(parts), _p(cs),
-                                            *_fused_graph_args(plan16 or plan), B, T, N, F, G, K, _p(hzero), plan.get('uniform_w', 0.0),
-                                            1 if plan16 else 0, st), 'gate_prepass')
+    x_user = getattr(xs, '_pending_user', None)
+    if x_user is not None:
+        # xs holds its first time step(s) only (fused_pack_inputs_gated): this pre-pass lays out the rest
+        assert plan16 is not None
+        check(lib.gcrnn_fused_gate_prepass_pack_bf16(_p(x_user), _p(xs), _p(h0s), _p(wp), _p(bg), _p(gw), _p(parts), _p(cs),
+                                                     *_fused_graph_args(plan16), B, T, N, F, G, K, _p(hzero), plan.get('uniform_w', 0.0),
+                                                     1, st), 'gate_prepass_pack')
+        del xs._pending_user
+    else:
+        check(lib.gcrnn_fused_gate_prepass_bf16(_p(xs), _p(h0s), _p(wp), _p(bg), _p(gw), _p(parts), _p(cs),
+                                                *_fused_graph_args(plan16 or plan), B, T, N, F, G, K, _p(hzero), plan.get('uniform_w', 0.0),
+                                                1 if plan16 else 0, st), 'gate_prepass')
     acc = parts.sum(dim=1)                                                    # fixed order: deterministic gates
     if lin_b is not None:
         acc = acc + lin_b.detach().float()
@@ -580,6 +612,8 @@ def fused_cell_forward(X, h0, wA, wB, bias, graph, gates=None, return_states=Fal
         inline = True
     elif gates is None and fused_overlap_ok(X):          # (the gate pre-passes read every x_t at once: nothing to hide behind)
         xs, hs_all, events = fused_pack_inputs(X, h0, graph, overlap=True)
+    elif gates is not None and gate_values is None:
+        xs, hs_all = fused_pack_inputs_gated(X, h0, graph, F, K)       # (the first gate pre-pass lays out x_1 .. x_{T-1})
     else:
         xs, hs_all = fused_pack_inputs(X, h0, graph)
     h0s, hs = hs_all[:1], hs_all[1:]
@@ -597,6 +631,7 @@ def fused_cell_forward(X, h0, wA, wB, bias, graph, gates=None, return_states=Fal
             assert max(wA_g.shape[2], wB_g.shape[2]) == K and wA_g.shape[0] == F
             g[name] = fused_time_gate(xs, h0s, wA_g, wB_g, bias_g, lin_w, lin_b, graph, N, hzero=hzero)
         gi, gf = g['in'], g['forget']
+    assert getattr(xs, '_pending_user', None) is None
     wpack = _fused_pack_weights(wA, wB, st)
     b32 = bias.detach().float().contiguous().view(-1) if bias is not None else None
     direct = (N % 8 == 0)                 # the step kernels write the user layout themselves (16-byte row stores)
@@ -750,7 +785,7 @@ def fused_node_cell_forward(X, h0, wA, wB, bias, graph, node_gates, time_gates=N
     K = max(Kin, Kst)
     plan = graph.fused_plan()
     st = _stream()
-    xs, hs_all = fused_pack_inputs(X.contiguous(), h0.contiguous(), graph)
+    xs, hs_all = fused_pack_inputs_gated(X.contiguous(), h0.contiguous(), graph, F, K)      # (the first gate cell's pre-pass lays out the rest of X)
     h0s, hs = hs_all[:1], hs_all[1:]
     hzero = fused_h0_zero_flag(h0)
     zero_lin = torch.zeros((1, F * N), dtype=torch.float32, device=X.device)
@@ -763,6 +798,7 @@ def fused_node_cell_forward(X, h0, wA, wB, bias, graph, node_gates, time_gates=N
         logit, _ = node_gate_logits(cs, wf, bf, graph, N)
         ng.append(torch.sigmoid(logit))
     ngates = torch.stack(ng, dim=1).contiguous()                        # [T][2][B][N]
+    assert getattr(xs, '_pending_user', None) is None
     gi = gf = None
     if time_gates is not None:
         g = {}
@@ -919,10 +955,11 @@ def fused_node_cell_train(X, h0, wA, wB, bias, graph, node_gates, time_gates=Non
     autograd node of its own (_FusedNodeGate / _FusedTimeGate) and enters the cell (_FusedNodeCell) as a differentiable input."""
     require_device(X, h0, wA, wB, bias)
     with torch.no_grad():
-        xs, hs_all = fused_pack_inputs(X, h0, graph)
+        xs, hs_all = fused_pack_inputs_gated(X.contiguous(), h0, graph, wA.shape[0], max(wA.shape[2], wB.shape[2]))
         hzero = fused_h0_zero_flag(h0)
     ni = _FusedNodeGate.apply(xs, hs_all[:1], X, h0, *node_gates['in'], graph, hzero)
     nf = _FusedNodeGate.apply(xs, hs_all[:1], X, h0, *node_gates['forget'], graph, hzero)
+    assert getattr(xs, '_pending_user', None) is None          # (the first pre-pass laid out the rest of X)
     gi = gf = None
     if time_gates is not None:
         gi = _FusedTimeGate.apply(xs, hs_all[:1], X, h0, *time_gates['in'], graph, hzero)
@@ -977,7 +1014,10 @@ def fused_edge_cell_forward(X, h0, wA, wB, bias, graph, att_in, att_f, time_gate
     plan = graph.fused_plan()
     npad = plan['npad']
     st = _stream()
-    xs, hs_all = fused_pack_inputs(X.contiguous(), h0.contiguous(), graph)
+    if time_gates is not None:      # (the first time-gate pre-pass lays out the rest of X)
+        xs, hs_all = fused_pack_inputs_gated(X.contiguous(), h0.contiguous(), graph, F, K)
+    else:
+        xs, hs_all = fused_pack_inputs(X.contiguous(), h0.contiguous(), graph)
     gi = gf = None
     if time_gates is not None:
         hzero = fused_h0_zero_flag(h0)
@@ -1171,12 +1211,16 @@ def fused_edge_cell_train(X, h0, wA, wB, bias, graph, att_in, att_f, time_gates=
     nodes of their own (_FusedTimeGate) and enter _FusedEdgeCell as differentiable [T][B] inputs."""
     require_device(X, h0, wA, wB, bias)
     with torch.no_grad():
-        xs, hs_all = fused_pack_inputs(X, h0, graph)
+        if time_gates is not None:
+            xs, hs_all = fused_pack_inputs_gated(X.contiguous(), h0, graph, wA.shape[0], max(wA.shape[2], wB.shape[2]))
+        else:
+            xs, hs_all = fused_pack_inputs(X, h0, graph)
         hzero = fused_h0_zero_flag(h0)
     gi = gf = None
     if time_gates is not None:
         gi = _FusedTimeGate.apply(xs, hs_all[:1], X, h0, *time_gates['in'], graph, hzero)
         gf = _FusedTimeGate.apply(xs, hs_all[:1], X, h0, *time_gates['forget'], graph, hzero)
+        assert getattr(xs, '_pending_user', None) is None
     return _FusedEdgeCell.apply(X, h0, wA, wB, bias, att_in[0], att_in[1], att_f[0], att_f[1], gi, gf, graph, xs, hs_all, float(negative_slope))
 
 
@@ -1583,10 +1627,11 @@ def fused_cell_train(X, h0, wA, wB, bias, graph, gates=None):
     if gates is None:
         return _FusedCell.apply(X, h0, wA, wB, bias, None, None, graph, None, None)
     with torch.no_grad():
-        xs, hs_all = fused_pack_inputs(X, h0, graph)
+        xs, hs_all = fused_pack_inputs_gated(X.contiguous(), h0, graph, wA.shape[0], max(wA.shape[2], wB.shape[2]))
         hzero = fused_h0_zero_flag(h0)
     gi = _FusedTimeGate.apply(xs, hs_all[:1], X, h0, *gates['in'], graph, hzero)
     gf = _FusedTimeGate.apply(xs, hs_all[:1], X, h0, *gates['forget'], graph, hzero)
+    assert getattr(xs, '_pending_user', None) is None          # (the first pre-pass laid out the rest of X)
     return _FusedCell.apply(X, h0, wA, wB, bias, gi, gf, graph, xs, hs_all)
 
 

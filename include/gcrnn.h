@@ -369,6 +369,23 @@ int gcrnn_fused_gate_prepass_bf16(const void* xs, const void* h0, const void* wp
                                   int64_t N, int64_t F, int64_t G, int64_t K, const int32_t* h0_zero_flag, double uniform_w,
                                   int img16 /* as in gcrnn_fused_backward_data_bf16 (forward plan) */, void* stream);
 
+/* The same pre-pass, which ALSO lays out the input: x_user = X [B][T][G][N] bf16 in the reference's layout (graphML.py:2409: B x T x G x N;
+ * G already padded to the kernels' 32 / 64 channels), xs = the sequence-major array [T][B][NPad][G] whose first
+ * gcrnn_fused_gate_prepass_lays_out(...) time steps the caller laid out (gcrnn_pack_seq_major_steps); on return every step is laid
+ * out. Each item of the sequence-resident kernel packs the operand of its workgroup's next item while its own hops run, as the
+ * forward steps do for x_{t+1} -- gated cells no longer need a pass over X before their first pre-pass.
+ * GCRNN_ERR_UNSUPPORTED where gcrnn_fused_gate_prepass_lays_out returns 0. */
+int gcrnn_fused_gate_prepass_pack_bf16(const void* x_user, void* xs, const void* h0, const void* wpack, const float* bias,
+                                       const float* gate_w, float* gate_out, void* cs, const int32_t* tile_nodes,
+                                       const int32_t* tile_off, const int32_t* ell_col, const float* ell_val,
+                                       const void* ell_val4, const void* ell_col4, int64_t entries, int64_t B, int64_t T,
+                                       int64_t N, int64_t F, int64_t G, int64_t K, const int32_t* h0_zero_flag, double uniform_w,
+                                       int img16, void* stream);
+/* 0 = not available for this shape / graph (weighted graph, N % 8 != 0, a batch the sequence-resident kernel does not take, LDS);
+ * else the number of leading time steps of xs the caller lays out itself (the items of the first round of workgroups). */
+int64_t gcrnn_fused_gate_prepass_lays_out(int64_t B, int64_t T, int64_t N, int64_t F, int64_t G, int64_t K, int64_t entries,
+                                          double uniform_w, int img16);
+
 /* d loss / d (scalar time gate) of ONE filter of the time-gated cell (the gates multiply the filter outputs, graphML.py:2420-2421):
  *   sum over out[t][b][0 .. F/16*8) = sum_{f,n} ( W(S) z[t][b] + bias )[n][f] * dpre[t][b][n][f]
  * xs == NULL, G = 0: z = zs [T][B][NPad][F] bf16 sequence-major is that filter's operand (h_{t-1} for the state filter, x_t for

@@ -1595,6 +1595,42 @@ def test_sequence_resident_bptt_chain_is_bit_identical(tg, N, F, K, monkeypatch)
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('N,F,G,K,B,T,zero_h0', [(1000, 64, 64, 5, 70, 5, True), (1008, 64, 32, 3, 300, 3, False), (400, 32, 32, 4, 7, 40, True),
+                                                 (1000, 64, 64, 2, 130, 2, False)])
+def test_gate_prepass_that_lays_out_the_input_is_bit_identical(N, F, G, K, B, T, zero_h0, monkeypatch):
+    """gcrnn_fused_gate_prepass_pack_bf16: the FIRST gate pre-pass of a time-gated cell lays out x_t of every step beyond the first
+    round of workgroups itself (item i packs the operand of item i + gridDim) -- same gates, same states, same gradients as with
+    the separate pack pass over X (GCRNN_NO_INLINE_PACK=1); items = B T below, at and above 256 workgroups, a ragged last round."""
+    from gated_gcrnns_amd import ops
+    dev = torch.device('cuda:0')
+    cell, rng, _ = _uniform_cell(N, G, F, K, True, 89, dev)
+    X = torch.tensor(rng.standard_normal((B, T, G, N)), dtype=torch.float32, device=dev).to(torch.bfloat16)
+    h0 = torch.zeros((B, F, N), dtype=torch.bfloat16, device=dev) if zero_h0 else \
+        torch.tensor(0.3 * rng.standard_normal((B, F, N)), dtype=torch.float32, device=dev).to(torch.bfloat16)
+    tgt = torch.tensor(rng.standard_normal((B, T, F, N)), dtype=torch.float32, device=dev)
+    monkeypatch.setenv('GCRNN_SEQ_MIN_B', '1')
+    plan16 = ops.fused_img16_plan(cell.graph, True, None)
+    steps = int(ops.lib.gcrnn_fused_gate_prepass_lays_out(B, T, N, F, G, K, plan16['entries'], cell.graph.fused_plan()['uniform_w'], 1))
+    assert steps == -(-min(B * T, 256) // B)
+
+    def run():
+        with torch.no_grad():
+            H = cell(X, h0)
+        cell.zero_grad(set_to_none=True)
+        assert cell._use_fused_training(X, h0)
+        Ht = cell(X, h0)
+        torch.nn.functional.l1_loss(Ht.float(), tgt).backward()
+        return H, Ht.detach(), {n: p.grad.clone() for n, p in cell.named_parameters() if p.grad is not None}
+
+    H1, Ht1, g1 = run()
+    monkeypatch.setenv('GCRNN_NO_INLINE_PACK', '1')
+    H0, Ht0, g0 = run()
+    assert torch.equal(H1, H0) and torch.equal(Ht1, Ht0) and g0.keys() == g1.keys() and len(g1) >= 8
+    for n in g1:
+        assert torch.equal(g0[n], g1[n]), n
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('N,F,C,K,B,T,adj', [(1000, 64, 64, 5, 5, 3, False), (1000, 64, 64, 5, 3, 2, True), (400, 32, 32, 3, 7, 2, False),
                                              (1000, 64, 32, 2, 4, 3, False), (1008, 32, 32, 4, 130, 2, False)])
 def test_filter_output_pass_on_the_sequence_resident_kernel_is_bit_identical(N, F, C, K, B, T, adj, monkeypatch):
