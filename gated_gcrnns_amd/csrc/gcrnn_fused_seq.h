@@ -471,15 +471,28 @@ __global__ __launch_bounds__(STHREADS) void fused_seq_kernel(const SeqArgs a) {
 #pragma unroll
         for (int c = 0; c < 4; ++c) bs2[c] = 2.f * lbias[chunk * FC + ql * 4 + c];
         float part = 0.f;
+        // the read-out weights [N][F] fp32 (shared by every item: L2-resident; held across an asm block they would spill): requested
+        // four tiles at a time, right after the last hop's stream -- its register window is free here. Inside the per-tile `node < N`
+        // regions they were eight dependent L2 round trips per chunk.
+        constexpr int WBATCH = 4;
+        float4 w8[WBATCH];
 #pragma unroll
         for (int i = 0; i < STILES; ++i) {
+          if (i % WBATCH == 0) {
+#pragma unroll
+            for (int i2 = 0; i2 < WBATCH; ++i2) {
+              int wv2 = woff[i + i2];
+              asm volatile("" : "+v"(wv2));
+              const int node2 = (wv2 >> 16) < N ? (wv2 >> 16) : N - 1;
+              w8[i2] = *reinterpret_cast<const float4*>(a.gw + (int64_t)node2 * F + chunk * FC + ql * 4);
+            }
+          }
           int wv = woff[i];
           asm volatile("" : "+v"(wv));
           const int node = wv >> 16;
           uint2 pkd{0u, 0u};
           if (node < N) {
-            // (the read-out weights [N][F] fp32 are shared by every item: L2- / L1-resident; held across an asm block they would spill)
-            const float4 w4 = *reinterpret_cast<const float4*>(a.gw + (int64_t)node * F + chunk * FC + ql * 4);
+            const float4 w4 = w8[i % WBATCH];
             const f32x4 acc = u[i];
             const float o0 = fast_tanh(acc[0] + bs2[0]), o1 = fast_tanh(acc[1] + bs2[1]);
             const float o2 = fast_tanh(acc[2] + bs2[2]), o3 = fast_tanh(acc[3] + bs2[3]);
@@ -487,7 +500,7 @@ __global__ __launch_bounds__(STHREADS) void fused_seq_kernel(const SeqArgs a) {
             pkd.x = (uint32_t)f2bf(o0) | ((uint32_t)f2bf(o1) << 16);
             pkd.y = (uint32_t)f2bf(o2) | ((uint32_t)f2bf(o3) << 16);
           }
-          if (hout) __builtin_amdgcn_raw_buffer_store_b64(u32x2{pkd.x, pkd.y}, rsrc_o, node * (F * 2) + (chunk * FC + q * 4) * 2, b * (NP * F * 2), 0);
+          if (hout) __builtin_amdgcn_raw_buffer_store_b64(u32x2{pkd.x, pkd.y}, rsrc_o, node * (F * 2) + (chunk * FC + ql * 4) * 2, b * (NP * F * 2), 0);
         }
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) part += __shfl_down(part, off, 64);
