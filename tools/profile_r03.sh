@@ -28,6 +28,10 @@ python3 $R/bench.py --time-gating --steps 10 --warmup 3 --no-cpu-baseline > $O/$
 python3 $R/bench.py --spatial-gating node --steps 10 --warmup 3 --no-cpu-baseline > $O/${TAG}_bench_fwd_nodegated.json 2>/dev/null
 python3 $R/bench.py --spatial-gating edge --steps 10 --warmup 3 --no-cpu-baseline > $O/${TAG}_bench_fwd_edgegated.json 2>/dev/null
 python3 $R/bench.py --in-features 1 --steps 10 --warmup 3 --no-cpu-baseline > $O/${TAG}_bench_fwd_g1.json 2>/dev/null
+python3 $R/bench.py --mode train --time-gating --steps 10 --warmup 3 --no-cpu-baseline > $O/${TAG}_bench_train_timegated.json 2>/dev/null
+python3 $R/bench.py --mode train --spatial-gating node --steps 10 --warmup 3 --no-cpu-baseline > $O/${TAG}_bench_train_nodegated.json 2>/dev/null
+python3 $R/bench.py --mode train --spatial-gating edge --steps 10 --warmup 3 --no-cpu-baseline > $O/${TAG}_bench_train_edgegated.json 2>/dev/null
+python3 $R/bench.py --dtype f32 --steps 10 --warmup 3 --no-cpu-baseline > $O/${TAG}_bench_f32_x3.json 2>/dev/null
 python3 $R/tools/driver_shape_bench.py > $O/${TAG}_driver_shape_f20.jsonl 2>/dev/null
 # ---- PMC: the sequence-resident kernel at B = 256, T = 32 (user-layout API, inline pack), one set per pass
 for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_WAIT_INST_LDS" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_MFMA SQ_LDS_ADDR_CONFLICT" "SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VMEM SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_ACTIVE_INST_SCA" "TCC_HIT_sum TCC_MISS_sum" "GRBM_GUI_ACTIVE" "FETCH_SIZE" "WRITE_SIZE"; do
