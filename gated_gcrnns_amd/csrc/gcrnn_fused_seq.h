@@ -77,6 +77,8 @@ struct SeqArgs {
   const uint16_t* pk_src0; int64_t pksrc_stride;       // inline pack of the NEXT step's operand: user-layout block of sequence 0 for step 0 (or null)
   uint16_t* pk_dst0; int64_t pkdst_stride;             // ... the sequence-major array [B][NP][rows] it is laid out into
   int pk_stride;                                       // ... elements between consecutive sequences of the user-layout tensor
+  const float* ng0; int64_t ngstride;                  // MODE 5: node gates of step 0 [2][B][N] fp32 (input gates, forget gates), elements between steps
+  uint16_t* yh0; int64_t yhstride;                     // MODE 5 (or null): receives Yh_t = B(S)h_{t-1} + b [B][NP][F] bf16 (training keeps it)
   int nsteps;                                          // steps of this launch; every step but the last lays out the next one's operand
   int pk_all;                                          // ... != 0: the last step too (per-step launches: the host decides)
   int xprefetch;                                       // MODE 0, experiment: request the x half of the next step's operand during the last hop (needs pk_ahead >= 2 or a fully packed X)
@@ -94,7 +96,7 @@ __global__ __launch_bounds__(STHREADS) void fused_seq_kernel(const SeqArgs a) {
   constexpr int IMG = 33 * 1024;                 // bf16 hop image [NP][16] (32 KB); the transposed output tile needs 8 x 4128 B
   constexpr int WB = K * KS * 1024;              // one chunk's weight fragments
   static_assert(STILES == 8 && GCRNN_HOP_ASM, "generated hop stream: 8 tiles per wave");
-  static_assert((MODE == 0 || MODE == 1) ? XS > 0 : (MODE == 2 ? XS == 0 : MODE == 4), "forward / pre-pass take [h | x], the BPTT step its one operand, the filter-output pass either");
+  static_assert((MODE == 0 || MODE == 1) ? XS > 0 : ((MODE == 2 || MODE == 5) ? XS == 0 : MODE == 4), "forward / pre-pass take [h | x], the BPTT and the node-gated step their one operand, the filter-output pass either");
   static_assert(!GATED || MODE == 0, "gated steps are forward steps");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* state = reinterpret_cast<float*>(smem);
@@ -136,7 +138,7 @@ __global__ __launch_bounds__(STHREADS) void fused_seq_kernel(const SeqArgs a) {
   // the bias (it enters through both filters, graphML.py:2420-2421: scaled by gi + gf = 2 at its use) in the 256 spare bytes behind the tile:
   // a chunk reads its four values from LDS instead of waiting for a global load at the top of every chunk
   float* lbias = reinterpret_cast<float*>(smem + 33024);
-  if ((MODE == 0 || MODE == 1 || MODE == 4) && tid < F) lbias[tid] = a.bias ? a.bias[tid] : 0.f;
+  if ((MODE == 0 || MODE == 1 || MODE == 4 || MODE == 5) && tid < F) lbias[tid] = a.bias ? a.bias[tid] : 0.f;
   __syncthreads();
 
   const uint32_t lds0 = (uint32_t)reinterpret_cast<uintptr_t>(smem);
@@ -174,7 +176,9 @@ __global__ __launch_bounds__(STHREADS) void fused_seq_kernel(const SeqArgs a) {
     const int bh = (MODE == 1) ? b % a.hmod : b;
     const __amdgpu_buffer_rsrc_t rsrc_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(xt), 0, (XS > 0 && xt) ? B * (NP * G * 2) : 0, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsrc_o = __builtin_amdgcn_make_buffer_rsrc(hout, 0, hout ? B * (NP * F * 2) : 0, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsrc_a0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(aux0), 0, (MODE == 2 && aux0) ? B * (NP * F * 2) : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_a0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(aux0), 0, ((MODE == 2 || MODE == 5) && aux0) ? B * (NP * F * 2) : 0, 0x00020000);
+    uint16_t* yhout = (MODE == 5 && a.yh0) ? a.yh0 + (int64_t)step * a.yhstride : nullptr;
+    const __amdgpu_buffer_rsrc_t rsrc_yh = __builtin_amdgcn_make_buffer_rsrc(yhout, 0, yhout ? B * (NP * F * 2) : 0, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsrc_a1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(aux1), 0, (MODE == 2 && aux1) ? B * (NP * F * 2) : 0, 0x00020000);
 
     // (k-step major: the seed's first MFMAs need k-step 0 of every tile, which is then the first quarter of the requests to land;
@@ -198,6 +202,19 @@ __global__ __launch_bounds__(STHREADS) void fused_seq_kernel(const SeqArgs a) {
     float gsc = 1.f;
     if (MODE == 2 && a.gf0) gsc = a.gf0[(int64_t)step * a.gfstride + b];
     float gin = 1.f, gfo = 1.f, gratio = 1.f;
+    [[maybe_unused]] float epn[MODE == 5 ? STILES : 1][2];      // MODE 5: this lane's node gates (x scalar time gates) per tile, for all chunks of the step
+    if constexpr (MODE == 5) {
+      if (a.gi0) { gin = a.gi0[(int64_t)step * a.gfstride + b]; gfo = a.gf0[(int64_t)step * a.gfstride + b]; }
+      const float* ng = a.ng0 + (int64_t)step * a.ngstride;
+#pragma unroll
+      for (int i = 0; i < STILES; ++i) {
+        int wv = woff[i];
+        asm volatile("" : "+v"(wv));
+        const int node = (wv >> 16) < N ? (wv >> 16) : N - 1;
+        epn[i][0] = gin * ng[(int64_t)b * N + node];
+        epn[i][1] = gfo * ng[(int64_t)(B + b) * N + node];
+      }
+    }
     if constexpr (GATED) {
       gin = a.gi0[(int64_t)step * a.gfstride + b];
       gfo = a.gf0[(int64_t)step * a.gfstride + b];
@@ -295,7 +312,7 @@ __global__ __launch_bounds__(STHREADS) void fused_seq_kernel(const SeqArgs a) {
 #endif
       }
 
-      u32x2 eph[MODE == 2 ? STILES : 1], epg[MODE == 2 ? STILES : 1];
+      u32x2 eph[MODE == 2 ? STILES : 1], epg[(MODE == 2 || MODE == 5) ? STILES : 1];
       // ---- Horner hops on the bf16 image; the tap a hop adds is evaluated from the resident operand right before it -------------
 #pragma unroll
       for (int j = 1; j < K; ++j) {
@@ -304,6 +321,19 @@ __global__ __launch_bounds__(STHREADS) void fused_seq_kernel(const SeqArgs a) {
 #endif
         taps(K - 1 - j, chunk);
         GCRNN_STAMP(2 + chunk * 14 + 2 * j - 1);
+        if constexpr (MODE == 5) {
+          // Yx_t = A(S)x_t + b of the all-items pass, this lane's (node, 4 features) per tile: spread over the hops like the chain's operands
+          constexpr int HL = (K > 2) ? K - 2 : 1;
+          constexpr int PER = (STILES + HL - 1) / HL;
+          if (j <= HL) {
+#pragma unroll
+            for (int i = (j - 1) * PER; i < j * PER && i < STILES; ++i) {
+              int wv = woff[i];
+              asm volatile("" : "+v"(wv));
+              epg[i] = __builtin_amdgcn_raw_buffer_load_b64(rsrc_a0, (wv >> 16) * (F * 2) + (chunk * FC + q * 4) * 2, b * (NP * F * 2), 0);
+            }
+          }
+        }
         if constexpr (MODE == 2) {
           // the epilogue's operands h_{t-1}, dH_{t-1} of this lane's (node, 4 features): 8-byte gathers of 32-byte row pieces, whose
           // issue alone costs ~4.5 k cycles per chunk when all 16 are requested at once (measured at the last hop). Spread over the
@@ -508,7 +538,7 @@ __global__ __launch_bounds__(STHREADS) void fused_seq_kernel(const SeqArgs a) {
       } else {
         float bsum[4];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) bsum[c] = (gin + gfo) * lbias[chunk * FC + q * 4 + c];      // the one bias is added by both filters
+        for (int c = 0; c < 4; ++c) bsum[c] = (MODE == 5 ? 1.f : (gin + gfo)) * lbias[chunk * FC + q * 4 + c];      // the one bias is added by both filters (MODE 5: Yx carries its own)
 #pragma unroll
         for (int i = 0; i < STILES; ++i) {
           int wv = woff[i];
@@ -516,7 +546,26 @@ __global__ __launch_bounds__(STHREADS) void fused_seq_kernel(const SeqArgs a) {
           const int node = wv >> 16;
           const f32x4 acc = u[i];
           uint2 pkd;
-          if (node < N) {
+          if constexpr (MODE == 5) {
+            // node-gated step (graphML.py:2420-2423): h_t = tanh(ni (A(S)x_t + b) + nf (B(S)h_{t-1} + b)), gates per node (and sequence)
+            const int eoff = node * (F * 2) + (chunk * FC + q * 4) * 2;
+            if (node < N) {
+              const u32x2 y2 = (K > 1) ? epg[i] : __builtin_amdgcn_raw_buffer_load_b64(rsrc_a0, eoff, b * (NP * F * 2), 0);
+              const float ni = epn[i][0], nf = epn[i][1];
+              const float yh0 = acc[0] + bsum[0], yh1 = acc[1] + bsum[1], yh2 = acc[2] + bsum[2], yh3 = acc[3] + bsum[3];
+              if (yhout) __builtin_amdgcn_raw_buffer_store_b64(u32x2{(uint32_t)f2bf(yh0) | ((uint32_t)f2bf(yh1) << 16), (uint32_t)f2bf(yh2) | ((uint32_t)f2bf(yh3) << 16)},
+                                                               rsrc_yh, eoff, b * (NP * F * 2), 0);
+              const float o0 = fast_tanh(ni * bf2f((uint16_t)(y2[0] & 0xffffu)) + nf * yh0);
+              const float o1 = fast_tanh(ni * bf2f((uint16_t)(y2[0] >> 16)) + nf * yh1);
+              const float o2 = fast_tanh(ni * bf2f((uint16_t)(y2[1] & 0xffffu)) + nf * yh2);
+              const float o3 = fast_tanh(ni * bf2f((uint16_t)(y2[1] >> 16)) + nf * yh3);
+              pkd.x = (uint32_t)f2bf(o0) | ((uint32_t)f2bf(o1) << 16);
+              pkd.y = (uint32_t)f2bf(o2) | ((uint32_t)f2bf(o3) << 16);
+            } else {
+              pkd.x = 0u; pkd.y = 0u;
+              if (yhout) __builtin_amdgcn_raw_buffer_store_b64(u32x2{0u, 0u}, rsrc_yh, eoff, b * (NP * F * 2), 0);
+            }
+          } else if (node < N) {
             const float o0 = fast_tanh(acc[0] + bsum[0]), o1 = fast_tanh(acc[1] + bsum[1]);
             const float o2 = fast_tanh(acc[2] + bsum[2]), o3 = fast_tanh(acc[3] + bsum[3]);
             pkd.x = (uint32_t)f2bf(o0) | ((uint32_t)f2bf(o1) << 16);

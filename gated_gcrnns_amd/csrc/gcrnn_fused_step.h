@@ -1162,7 +1162,7 @@ int fused_launch_t(int mode /*0 plain, 1 gated, 2 gate pre-pass, 3 BPTT data gra
 #if GCRNN_HOP_ASM && GCRNN_STEP_WAVES == 8
   // Sequence-resident kernel (gcrnn_fused_seq.h): one workgroup per sequence keeps the operand in registers for all chunks -- the
   // un-gated forward steps and the plain BPTT data chain on uniform-weight bf16-image plans, when the batch fills the chip.
-  if (ga.uniform_w != 0.f && ga.img16 && ga.ell_col4 && !head && !step_events && (mode == 0 || mode == 1 || mode == 2 || mode == 3 || mode == 5) &&
+  if (ga.uniform_w != 0.f && ga.img16 && ga.ell_col4 && !head && !step_events && (mode == 0 || mode == 1 || mode == 2 || mode == 3 || mode == 5 || mode == 6) &&
       fused_seq_wanted((mode == 2 || mode == 5) ? B * T : B, NCH)) {
     const size_t slds = fused_seq_lds<K, HS, XS>(ga.entries, inline_pack, mode == 3 ? F : G);
     const unsigned sgrid = (unsigned)(B < 256 ? B : 256);
@@ -1302,6 +1302,43 @@ int fused_launch_t(int mode /*0 plain, 1 gated, 2 gate pre-pass, 3 BPTT data gra
         return GCRNN_OK;
       }
     } else {
+      if (mode == 6 && slds) {
+        // node-gated recurrence (graphML.py:2379-2407, 2420-2423): every gate is known before step 0, so ONE persistent launch walks
+        // the T steps; Yx_t = A(S)x_t + b from the all-items pass (bw_dHs), node gates gate_w [T][2][B][N], optional Yh output (bw_dh0)
+        auto sk = fused_seq_kernel<K, HS, 0, 5>;
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(sk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)slds) != hipSuccess)
+          return GCRNN_ERR_LAUNCH;
+        GCRNN_PRE_LAUNCH();
+        sa.bias = bias;
+        sa.hfirst = (const uint16_t*)h0; sa.hrest = h; sa.hstride = hstep;
+        sa.out0 = h; sa.ostride = hstep;
+        sa.a0 = (const uint16_t*)bw_dHs; sa.a0stride = hstep;
+        sa.ng0 = gate_w; sa.ngstride = 2 * B * N;
+        sa.gi0 = gi; sa.gf0 = gi ? gf : nullptr; sa.gfstride = B;
+        sa.yh0 = (uint16_t*)bw_dh0; sa.yhstride = hstep;
+        sa.a1 = (const uint16_t*)huser; sa.a1stride = F * N; sa.a1_last_only = huser_last_only ? 1 : 0;
+        sa.ubstride = (int)((huser_last_only ? 1 : T) * F * N);
+        if (persist) {
+          sa.nsteps = (int)T;
+          sk<<<sgrid, STHREADS, slds, st>>>(sa);
+        } else {
+          for (int64_t t = 0; t < T; ++t) {
+            SeqArgs s1 = sa;
+            s1.nsteps = 1;
+            s1.hfirst = (t == 0) ? (const uint16_t*)h0 : h + (t - 1) * hstep;
+            s1.out0 = h + t * hstep;
+            s1.a0 = sa.a0 + t * hstep;
+            s1.ng0 = gate_w + t * 2 * B * N;
+            s1.gi0 = gi ? gi + t * B : nullptr; s1.gf0 = gi ? gf + t * B : nullptr;
+            s1.yh0 = sa.yh0 ? sa.yh0 + t * hstep : nullptr;
+            s1.a1 = !huser ? nullptr : (!huser_last_only ? (const uint16_t*)huser + t * F * N : (t == T - 1 ? (const uint16_t*)huser : nullptr));
+            s1.a1_last_only = 0;
+            sk<<<sgrid, STHREADS, slds, st>>>(s1);
+          }
+        }
+        GCRNN_CHECK_LAUNCH();
+        return GCRNN_OK;
+      }
       if (mode == 3 && slds) {
         auto sk = fused_seq_kernel<K, HS, 0, 2>;
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(sk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)slds) != hipSuccess)

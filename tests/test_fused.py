@@ -1631,6 +1631,49 @@ def test_gate_prepass_that_lays_out_the_input_is_bit_identical(N, F, G, K, B, T,
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('N,F,G,K,B,T,tg', [(1000, 64, 64, 5, 5, 4, False), (1008, 64, 32, 3, 260, 2, True), (400, 32, 32, 3, 7, 3, False),
+                                            (1000, 64, 64, 2, 3, 3, True)])
+def test_node_gated_recurrence_on_the_sequence_resident_kernel_is_bit_identical(N, F, G, K, B, T, tg, monkeypatch):
+    """The node-gated steps h_t = tanh(ni (A(S)x_t + b) + nf (B(S)h_{t-1} + b)) (graphML.py:2420-2423) as ONE persistent launch of the
+    sequence-resident kernel (MODE 5: node gates held per tile for all chunks of a step, Yx_t gathered while the hops run, Yh_t kept for
+    the backward): same states, last-state read-out and gradients as the chunk-parallel kernel's per-step launches."""
+    import gated_gcrnns_amd.Utils.graphML as gml
+    dev = torch.device('cuda:0')
+    _, rng, S = _uniform_cell(N, G, F, K, False, 97, dev)
+    torch.manual_seed(23)
+    cell = gml.GGCRNNCell(G, F, K, K, torch.tanh, tg, 'node', 1, True)
+    cell.addGSO(torch.tensor(S))
+    cell = cell.to(dev).to(torch.bfloat16)
+    X = torch.tensor(rng.standard_normal((B, T, G, N)), dtype=torch.float32, device=dev).to(torch.bfloat16)
+    h0 = torch.tensor(0.3 * rng.standard_normal((B, F, N)), dtype=torch.float32, device=dev).to(torch.bfloat16)
+    tgt = torch.tensor(rng.standard_normal((B, T, F, N)), dtype=torch.float32, device=dev)
+    monkeypatch.setenv('GCRNN_SEQ_MIN_B', '1')
+
+    def run():
+        with torch.no_grad():
+            assert cell._use_fused_node(X, h0)
+            H = cell(X, h0)
+            Hl = cell(X, h0, last_only=True)
+        cell.zero_grad(set_to_none=True)
+        assert cell._use_fused_training(X, h0)
+        Ht = cell(X, h0)
+        torch.nn.functional.l1_loss(Ht.float(), tgt).backward()
+        return H, Hl, Ht.detach(), {n: p.grad.clone() for n, p in cell.named_parameters() if p.grad is not None}
+
+    monkeypatch.setenv('GCRNN_SEQ_KERNEL', '1')
+    H1, Hl1, Ht1, g1 = run()
+    monkeypatch.setenv('GCRNN_SEQ_PERSIST', '0')
+    H1s, _, _, _ = run()
+    monkeypatch.delenv('GCRNN_SEQ_PERSIST')
+    monkeypatch.setenv('GCRNN_SEQ_KERNEL', '0')
+    H0, Hl0, Ht0, g0 = run()
+    assert torch.equal(H1, H0) and torch.equal(H1s, H0) and torch.equal(Hl1, Hl0) and torch.equal(Hl1, H1[:, -1:]) and torch.equal(Ht1, Ht0)
+    assert g0.keys() == g1.keys() and len(g1) >= 11
+    for n in g1:
+        assert torch.equal(g0[n], g1[n]), n
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('N,F,C,K,B,T,adj', [(1000, 64, 64, 5, 5, 3, False), (1000, 64, 64, 5, 3, 2, True), (400, 32, 32, 3, 7, 2, False),
                                              (1000, 64, 32, 2, 4, 3, False), (1008, 32, 32, 4, 130, 2, False)])
 def test_filter_output_pass_on_the_sequence_resident_kernel_is_bit_identical(N, F, C, K, B, T, adj, monkeypatch):
