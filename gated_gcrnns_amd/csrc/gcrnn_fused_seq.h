@@ -148,6 +148,9 @@ __global__ __launch_bounds__(STHREADS) void fused_seq_kernel(const SeqArgs a) {
   for (int b = blockIdx.x; b < B; b += gridDim.x) {
   // ---- the operand of a sequence and step: every B fragment of the wave, resident for all chunks ----------------------------------
   bf16x8 bfr[STILES][KS];
+  // MODE 1: does this item lay out the operand of the workgroup's next item? A scalar integer on purpose: as a lane mask hipcc also parks
+  // a per-lane copy of the (loop-invariant) condition in a vector register -- and spills that
+  [[maybe_unused]] const int pk_item = __builtin_amdgcn_readfirstlane((MODE == 1 && a.pk_src0 && b + (int)gridDim.x < B) ? 1 : 0);
   [[maybe_unused]] bool xpre = false;        // (GCRNN_SEQ_X_PREFETCH) the x half of the NEXT step's operand has been requested (wave-uniform)
 #pragma unroll 1
   for (int step = 0; step < a.nsteps; ++step) {
@@ -162,15 +165,25 @@ __global__ __launch_bounds__(STHREADS) void fused_seq_kernel(const SeqArgs a) {
     // MODE 1 (items, no recurrence): the pack lays out the operand of the NEXT item of this workgroup's loop, item b + gridDim.x =
     // (t', b') = (nb / hmod, nb % hmod) of the user-layout X[b'][t'] -- the caller laid out the first gridDim.x items
     const int nb = b + (int)gridDim.x;
-    const bool pk = a.pk_src0 && (MODE == 1 ? nb < B : (a.pk_all || step + pka < a.nsteps));
-    const uint16_t* pk_src = pk ? a.pk_src0 + (int64_t)step * a.pksrc_stride : nullptr;
-    uint16_t* pk_dst = pk ? a.pk_dst0 + (int64_t)step * a.pkdst_stride : nullptr;
+    const uint16_t* pk_src;
+    uint16_t* pk_dst;
+    if constexpr (MODE == 1) {       // (integer mask instead of a boolean select: see pk_item)
+      const uintptr_t m = (uintptr_t)0 - (uintptr_t)pk_item;
+      pk_src = reinterpret_cast<const uint16_t*>(reinterpret_cast<uintptr_t>(a.pk_src0) & m);
+      pk_dst = reinterpret_cast<uint16_t*>(reinterpret_cast<uintptr_t>(a.pk_dst0) & m);
+    } else {
+      const bool pk = a.pk_src0 && (a.pk_all || step + pka < a.nsteps);
+      pk_src = pk ? a.pk_src0 + (int64_t)step * a.pksrc_stride : nullptr;
+      pk_dst = pk ? a.pk_dst0 + (int64_t)step * a.pkdst_stride : nullptr;
+    }
     const int pk_stride = a.pk_stride, ubstride = a.ubstride;
     const int64_t pk_soff = (MODE == 1) ? (int64_t)(nb % a.hmod) * pk_stride + (int64_t)(nb / a.hmod) * a.pksrc_stride : (int64_t)b * pk_stride;
     const int pk_db = (MODE == 1) ? nb : b;
     float* gate_out = a.go0 ? a.go0 + (int64_t)step * a.gostride : nullptr;
     // wave-uniform; MODE 4 with an input operand filters [0 | x_t]: the state half is all zeros by contract
-    const bool skip_h = (MODE == 4 && XS > 0) || ((MODE == 1) && a.flags && a.flags[0] != 0);
+    // (kept as a scalar integer: as a lane mask hipcc also parks a per-lane copy of it in a vector register -- and spills that)
+    const int skip_hi = __builtin_amdgcn_readfirstlane(((MODE == 4 && XS > 0) || ((MODE == 1) && a.flags && a.flags[0] != 0)) ? 1 : 0);
+    const bool skip_h = skip_hi != 0;
     // (skipped state operand: a zero-length descriptor -- its loads return zeros and cost nothing)
     const __amdgpu_buffer_rsrc_t rsrc_h = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(hprev), 0, skip_h ? 0 : (MODE == 1 ? a.hmod : B) * (NP * F * 2), 0x00020000);
     const int bh = (MODE == 1) ? b % a.hmod : b;
@@ -183,6 +196,8 @@ __global__ __launch_bounds__(STHREADS) void fused_seq_kernel(const SeqArgs a) {
 
     // (k-step major: the seed's first MFMAs need k-step 0 of every tile, which is then the first quarter of the requests to land;
     //  the x half may already be on its way: requested during the previous step's last hop, see below)
+    int qo = q;                                        // (opaque per step, as above)
+    asm volatile("" : "+v"(qo));
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
 #ifdef GCRNN_SEQ_X_PREFETCH
@@ -193,9 +208,9 @@ __global__ __launch_bounds__(STHREADS) void fused_seq_kernel(const SeqArgs a) {
         int w = woff[i];
         asm volatile("" : "+v"(w));
         if (s < HS)
-          bfr[i][s] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsrc_h, (w >> 16) * (F * 2) + 16 * q + 64 * s, bh * (NP * F * 2), 0));
+          bfr[i][s] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsrc_h, (w >> 16) * (F * 2) + 16 * qo + 64 * s, bh * (NP * F * 2), 0));
         else
-          bfr[i][s] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, (w >> 16) * (G * 2) + 16 * q + 64 * (s - HS), b * (NP * G * 2), 0));
+          bfr[i][s] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, (w >> 16) * (G * 2) + 16 * qo + 64 * (s - HS), b * (NP * G * 2), 0));
       }
     }
     xpre = false;
@@ -225,7 +240,9 @@ __global__ __launch_bounds__(STHREADS) void fused_seq_kernel(const SeqArgs a) {
     f32x4 u[STILES];
     // u_tap of chunk c for the wave's 8 tiles: one weight fragment feeds 8 independent MFMA chains
     auto taps_to = [&](int tap, int c, f32x4 (&u)[STILES]) {
-      const uint4* wl = reinterpret_cast<const uint4*>(smem + IMG + (c & 1) * WB);
+      int ln = lane;                                   // (opaque per call: the fragment address is re-derived, not kept -- or spilled -- across the hops)
+      asm volatile("" : "+v"(ln));
+      const uint32_t wofs = (uint32_t)(IMG + (c & 1) * WB) + (uint32_t)ln * 16u;       // 32-bit LDS offset of this lane's fragment piece
 #pragma unroll
       for (int i = 0; i < STILES; ++i) u[i] = f32x4{0.f, 0.f, 0.f, 0.f};
       if constexpr (GATED || MODE == 1 || (MODE == 4 && XS > 0)) {
@@ -234,7 +251,7 @@ __global__ __launch_bounds__(STHREADS) void fused_seq_kernel(const SeqArgs a) {
         if (!skip_h) {
 #pragma unroll
           for (int s = 0; s < HS; ++s) {
-            const bf16x8 af = __builtin_bit_cast(bf16x8, wl[(tap * KS + s) * 64 + lane]);
+            const bf16x8 af = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(smem + wofs + (uint32_t)((tap * KS + s) * 1024)));
 #pragma unroll
             for (int i = 0; i < STILES; ++i) u[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bfr[i][s], u[i], 0, 0, 0);
           }
@@ -247,7 +264,7 @@ __global__ __launch_bounds__(STHREADS) void fused_seq_kernel(const SeqArgs a) {
         if (xpart) {
 #pragma unroll
           for (int s = HS; s < KS; ++s) {
-            const bf16x8 af = __builtin_bit_cast(bf16x8, wl[(tap * KS + s) * 64 + lane]);
+            const bf16x8 af = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(smem + wofs + (uint32_t)((tap * KS + s) * 1024)));
 #pragma unroll
             for (int i = 0; i < STILES; ++i) u[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bfr[i][s], u[i], 0, 0, 0);
           }
@@ -259,7 +276,7 @@ __global__ __launch_bounds__(STHREADS) void fused_seq_kernel(const SeqArgs a) {
       } else {
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
-          const bf16x8 af = __builtin_bit_cast(bf16x8, wl[(tap * KS + s) * 64 + lane]);
+          const bf16x8 af = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(smem + wofs + (uint32_t)((tap * KS + s) * 1024)));
 #pragma unroll
           for (int i = 0; i < STILES; ++i) u[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bfr[i][s], u[i], 0, 0, 0);
         }
@@ -284,6 +301,7 @@ __global__ __launch_bounds__(STHREADS) void fused_seq_kernel(const SeqArgs a) {
       // from it inside the loop -- hoisted out of the loops it would have to be spilled (the operand owns 128 registers)
       int tl = tid;
       asm volatile("" : "+v"(tl));
+      const int r = tl & 15, q = (tl >> 4) & 3, lane = tl & 63;      // (shadow the kernel-scope lane coordinates: per-chunk copies are cheaper than their spills)
       lds_barrier();      // the seed is in the image
       GCRNN_STAMP(2 + chunk * 14);
 
@@ -316,10 +334,12 @@ __global__ __launch_bounds__(STHREADS) void fused_seq_kernel(const SeqArgs a) {
       // ---- Horner hops on the bf16 image; the tap a hop adds is evaluated from the resident operand right before it -------------
 #pragma unroll
       for (int j = 1; j < K; ++j) {
+#ifdef GCRNN_SEQ_STREAM_ACCUMULATES      // A/B: round 2's stream (acc += w sum at every tile exit), the tap evaluated before it
 #ifdef GCRNN_SEQ_TAPS_AFTER      // A/B (measured: 107.2k vs 107.6k seq/s, no gain, profiles/r03_taps_after_ab.txt): the tap of hop j + 1 evaluated right after hop j's stream
         if (j == 1)
 #endif
         taps(K - 1 - j, chunk);
+#endif
         GCRNN_STAMP(2 + chunk * 14 + 2 * j - 1);
         if constexpr (MODE == 5) {
           // Yx_t = A(S)x_t + b of the all-items pass, this lane's (node, 4 features) per tile: spread over the hops like the chain's operands
@@ -403,11 +423,25 @@ __global__ __launch_bounds__(STHREADS) void fused_seq_kernel(const SeqArgs a) {
             }
           }
         }
+#ifdef GCRNN_SEQ_STREAM_ACCUMULATES
 #define GCRNN_SEQ_INIT(i) u[i]
 #define GCRNN_SEQ_STORE(i, a_) u[i] = a_
         GCRNN_HOP_ASM_UNI16_STREAM(GCRNN_SEQ_INIT, GCRNN_SEQ_STORE);
 #undef GCRNN_SEQ_INIT
 #undef GCRNN_SEQ_STORE
+#else
+        // the stream only sums the gathered rows of every tile (its exits then cost nothing); the tap this hop adds is evaluated from the
+        // resident operand after it, and acc = tap + w * sum is the same fused multiply-add the accumulating stream applies per tile
+        {
+          f32x4 dsum[STILES];
+          GCRNN_HOP_ASM_UNI16_SUMS_STREAM(dsum);
+          taps(K - 1 - j, chunk);
+#pragma unroll
+          for (int i = 0; i < STILES; ++i)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) u[i][c] = __builtin_fmaf(uni_w, dsum[i][c], u[i][c]);
+        }
+#endif
         GCRNN_STAMP(2 + chunk * 14 + 2 * j);
         if (j < K - 1) {
 #ifdef GCRNN_SEQ_TAPS_AFTER
@@ -450,7 +484,7 @@ __global__ __launch_bounds__(STHREADS) void fused_seq_kernel(const SeqArgs a) {
             hv0 = bf2f((uint16_t)(h2[0] & 0xffffu)); hv1 = bf2f((uint16_t)(h2[0] >> 16));
             hv2 = bf2f((uint16_t)(h2[1] & 0xffffu)); hv3 = bf2f((uint16_t)(h2[1] >> 16));
           }
-          if (gate_out) part += raw[0] * hv0 + raw[1] * hv1 + raw[2] * hv2 + raw[3] * hv3;
+          if (gate_out) part = __builtin_fmaf(raw[3], hv3, __builtin_fmaf(raw[2], hv2, __builtin_fmaf(raw[1], hv1, __builtin_fmaf(raw[0], hv0, part))));      // (explicit chain: with -ffp-contract=fast the association of a*b + c*d + .. is the compiler's choice, per instantiation)
           if (aux0) {
             const u32x2 g2 = (K > 1) ? epg[i] : __builtin_amdgcn_raw_buffer_load_b64(rsrc_a0, eoff, b * (NP * F * 2), 0);
             const float g0 = bf2f((uint16_t)(g2[0] & 0xffffu)), g1 = bf2f((uint16_t)(g2[0] >> 16));
@@ -502,9 +536,9 @@ __global__ __launch_bounds__(STHREADS) void fused_seq_kernel(const SeqArgs a) {
         for (int c = 0; c < 4; ++c) bs2[c] = 2.f * lbias[chunk * FC + ql * 4 + c];
         float part = 0.f;
         // the read-out weights [N][F] fp32 (shared by every item: L2-resident; held across an asm block they would spill): requested
-        // four tiles at a time, right after the last hop's stream -- its register window is free here. Inside the per-tile `node < N`
+        // two tiles at a time (more in flight spills in this instantiation), right after the last hop's stream -- its register window is free here. Inside the per-tile `node < N`
         // regions they were eight dependent L2 round trips per chunk.
-        constexpr int WBATCH = 4;
+        constexpr int WBATCH = 2;
         float4 w8[WBATCH];
 #pragma unroll
         for (int i = 0; i < STILES; ++i) {
@@ -526,7 +560,7 @@ __global__ __launch_bounds__(STHREADS) void fused_seq_kernel(const SeqArgs a) {
             const f32x4 acc = u[i];
             const float o0 = fast_tanh(acc[0] + bs2[0]), o1 = fast_tanh(acc[1] + bs2[1]);
             const float o2 = fast_tanh(acc[2] + bs2[2]), o3 = fast_tanh(acc[3] + bs2[3]);
-            part += o0 * w4.x + o1 * w4.y + o2 * w4.z + o3 * w4.w;
+            part = __builtin_fmaf(o3, w4.w, __builtin_fmaf(o2, w4.z, __builtin_fmaf(o1, w4.y, __builtin_fmaf(o0, w4.x, part))));      // (explicit chain, as the chain's partials)
             pkd.x = (uint32_t)f2bf(o0) | ((uint32_t)f2bf(o1) << 16);
             pkd.y = (uint32_t)f2bf(o2) | ((uint32_t)f2bf(o3) << 16);
           }

@@ -329,6 +329,39 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
     _Pragma("unroll") for (int i = 0; i < 8; ++i) STORE(i, (f32x4{al_[i][0], al_[i][1], ah_[i][0], ah_[i][1]}));                   \
   } while (0)
 
+// The summing variant (generator: gen_uniform16(sums=True)): tile i's gathered rows are summed straight into D[i] (f32x4, zeroed here);
+// the caller applies acc = init + w * D afterwards. A tile exit only switches tiles -- the per-tile matrix-core -> VALU wait states,
+// packed FMAs and re-zeroing of the stream above are gone (they cost 6.5 % of the forward launch: tools/hop16_exit_experiment.sh).
+// Used by the sequence-resident kernel, whose taps are evaluated per hop anyway (gcrnn_fused_seq.h).
+#define GCRNN_HOP_ASM_UNI16_SUMS_STREAM(D)                                                         \
+  do {                                                                                             \
+    static_assert(HT == 8, "the asm hop stream is generated for 8 tiles per wave");                \
+    const int gwbeg = tbeg[0] >> 2, gwend = tend[HT - 1] >> 2;                                      \
+    _Pragma("unroll") for (int i = 0; i < 8; ++i) D[i] = f32x4{0.f, 0.f, 0.f, 0.f};               \
+    if (gwbeg < gwend) {                                                                           \
+      typedef __attribute__((__vector_size__(4 * sizeof(unsigned int)))) unsigned int u32x4a_;     \
+      const uint32_t colb = lds_col + r * 8 + (q >> 1) * 4;       /* this lane's own column dword of a slot's pair */ \
+      const uint32_t qh_ = (uint32_t)(q & 1) << 4;                                                 \
+      if constexpr (GCRNN_HOP16_SPARSE) {                                                          \
+        asm volatile(GCRNN_HOP_ASM_UNI16_SUMS_SPARSE_TEXT                                          \
+                     : "+v"(D[0]), "+v"(D[1]), "+v"(D[2]), "+v"(D[3]), "+v"(D[4]), "+v"(D[5]), "+v"(D[6]), "+v"(D[7])  \
+                     : "s"(GCRNN_SGPR(tend[0] >> 2)), "s"(GCRNN_SGPR(tend[1] >> 2)), "s"(GCRNN_SGPR(tend[2] >> 2)), "s"(GCRNN_SGPR(tend[3] >> 2)), "s"(GCRNN_SGPR(tend[4] >> 2)), \
+                       "s"(GCRNN_SGPR(tend[5] >> 2)), "s"(GCRNN_SGPR(tend[6] >> 2)), "s"(GCRNN_SGPR(tend[7] >> 2)), "s"(GCRNN_SGPR(gwbeg)), "s"(GCRNN_SGPR(gwend - 1)), "v"(colb), "v"(qh_) \
+                     : GCRNN_HOP_ASM_UNI16_SUMS_SPARSE_CLOBBERS);                                   \
+      } else {                                                                                     \
+        const int hit_ = ((r >> 3) == (q & 1)) ? (r & 7) : 8;     /* position of this lane's 1.0 among its 8 A elements, or none */ \
+        const uint32_t one_ = (hit_ & 1) ? 0x3f800000u : 0x00003f80u;                              \
+        u32x4a_ aop_ = {(hit_ >> 1) == 0 ? one_ : 0u, (hit_ >> 1) == 1 ? one_ : 0u, (hit_ >> 1) == 2 ? one_ : 0u, (hit_ >> 1) == 3 ? one_ : 0u}; \
+        asm volatile(GCRNN_HOP_ASM_UNI16_SUMS_TEXT                                                 \
+                     : "+v"(D[0]), "+v"(D[1]), "+v"(D[2]), "+v"(D[3]), "+v"(D[4]), "+v"(D[5]), "+v"(D[6]), "+v"(D[7])  \
+                     : "s"(GCRNN_SGPR(tend[0] >> 2)), "s"(GCRNN_SGPR(tend[1] >> 2)), "s"(GCRNN_SGPR(tend[2] >> 2)), "s"(GCRNN_SGPR(tend[3] >> 2)), "s"(GCRNN_SGPR(tend[4] >> 2)), \
+                       "s"(GCRNN_SGPR(tend[5] >> 2)), "s"(GCRNN_SGPR(tend[6] >> 2)), "s"(GCRNN_SGPR(tend[7] >> 2)), "s"(GCRNN_SGPR(gwbeg)), "s"(GCRNN_SGPR(gwend - 1)), "v"(colb), "v"(qh_), \
+                       "v"(aop_)                                                                   \
+                     : GCRNN_HOP_ASM_UNI16_SUMS_CLOBBERS);                                          \
+      }                                                                                            \
+    }                                                                                              \
+  } while (0)
+
 // UNI (RESIDENT only): uniform-weight graph image -- column words only, all non-zeros weigh uni_w (GCRNN_HOP_ASM_UNI_STREAM)
 // UNI == 2: the same on a bf16 image of the hop state with matrix-core sums (GCRNN_HOP_ASM_UNI16_STREAM; plan arrays of graph.fused_plan(img16=True))
 template <int K, int HS, int XS, bool GATED, bool RESIDENT, int EPI = 0, int UNI = 0>
@@ -835,7 +868,7 @@ __global__ __launch_bounds__(STHREADS) void fused_step_kernel(
         const f32x4 acc = u[i][0];
         const float o0 = fast_tanh(acc[0] + bsum[0]), o1 = fast_tanh(acc[1] + bsum[1]);
         const float o2 = fast_tanh(acc[2] + bsum[2]), o3 = fast_tanh(acc[3] + bsum[3]);
-        part += o0 * w4.x + o1 * w4.y + o2 * w4.z + o3 * w4.w;
+        part = __builtin_fmaf(o3, w4.w, __builtin_fmaf(o2, w4.z, __builtin_fmaf(o1, w4.y, __builtin_fmaf(o0, w4.x, part))));      // (explicit chain, as the chain's partials)
         pk.x = (uint32_t)f2bf(o0) | ((uint32_t)f2bf(o1) << 16);
         pk.y = (uint32_t)f2bf(o2) | ((uint32_t)f2bf(o3) << 16);
       }
@@ -867,7 +900,7 @@ __global__ __launch_bounds__(STHREADS) void fused_step_kernel(
         hv0 = bf2f((uint16_t)(h2[0] & 0xffffu)); hv1 = bf2f((uint16_t)(h2[0] >> 16));
         hv2 = bf2f((uint16_t)(h2[1] & 0xffffu)); hv3 = bf2f((uint16_t)(h2[1] >> 16));
       }
-      if (gate_out) part += raw[0] * hv0 + raw[1] * hv1 + raw[2] * hv2 + raw[3] * hv3;     // rows >= N of h are zero
+      if (gate_out) part = __builtin_fmaf(raw[3], hv3, __builtin_fmaf(raw[2], hv2, __builtin_fmaf(raw[1], hv1, __builtin_fmaf(raw[0], hv0, part))));      // (explicit chain: with -ffp-contract=fast the association of a*b + c*d + .. is the compiler's choice, per instantiation)     // rows >= N of h are zero
       if (aux0) {
         const u32x2 g2 = (GCRNN_EPI_PREFETCH && K > 1) ? epg[GCRNN_EPI_PREFETCH ? i : 0] : __builtin_amdgcn_raw_buffer_load_b64(rsrc_a0, eoff, b * (NP * F * 2), 0);
         const float g0 = bf2f((uint16_t)(g2[0] & 0xffffu)), g1 = bf2f((uint16_t)(g2[0] >> 16));

@@ -237,8 +237,11 @@ def VXa(p, e):
     return 'v%d' % (UB16 + 8 * p + 4 * e)
 
 
+VCOFF = 24          # column-word slots behind three gather sets (the summing variants pack their window: 8 D)
+
+
 def VC(p):
-    return 'v%d' % (UB16 + 24 + p)
+    return 'v%d' % (UB16 + VCOFF + p)
 
 
 VCA = 'v%d' % (UB16 + 31)
@@ -265,16 +268,34 @@ def vs0p(q, lines):            # steady state: the same read through the running
     lines += ['v_min_u32 %s, %s, %s' % (VCA, VP5, VPCL), 'ds_read_b32 %s, %s' % (VC(q), VCA), 'v_add_u32 %s, 128, %s' % (VP5, VP5)]
 
 
-def gen_uniform16(sparse=False):
-    """sparse: ONE v_smfmac_f32_16x16x64_bf16 per trip instead of two v_mfma_f32_16x16x32_bf16 -- the 2:4-sparse instruction takes a dense
+SUMS_D = int(os.environ.get('GCRNN_HOP16_SUMS_DEPTH', '2'))      # groups in flight of the summing variants (2 and 3 measured equal: profiles/r03_hop16_depth_ab.txt)
+SUMS_UB16 = (254 - (9 * SUMS_D + 3)) & ~1                        # their packed register window v[SUMS_UB16:253] (even base: the 8-register B tuples) ...
+SUMS_SPA = SUMS_UB16 - 6                                         # ... sparse: v[SUMS_SPA:253]
+
+
+def gen_uniform16(sparse=False, sums=False):
+    """sums: the stream only SUMS -- tile t's gathered rows go straight into its own accumulator tuple (operand %t, zeroed by the caller),
+    the caller applies acc = init + w * sum after the block. A tile exit then only switches tiles: no matrix-core -> VALU wait states, no
+    packed FMAs, no re-zeroing per tile (timing experiment GCRNN_HOP16_EXPERIMENT_CHEAP_EXIT: the exits cost 6.5 % of the launch). Operands:
+    %0..%7 the tiles' D tuples (4 VGPRs each), %8..%15 tile ends, %16 first group, %17 last valid group, %18 column base, %19 = (q & 1) << 4,
+    dense variant: %20 = the lane's A operand.
+    sparse: ONE v_smfmac_f32_16x16x64_bf16 per trip instead of two v_mfma_f32_16x16x32_bf16 -- the 2:4-sparse instruction takes a dense
     B of K = 64 = [first gather | second gather] (probed: tools/probes/smfmac_probe.hip, profiles/r03_smfmac_layout_probe.txt: B elements
     0..7 of lane (j, kg) are k = 8 kg + e, elements 8..15 are k = 32 + 8 kg + e, i.e. the two dense operands stacked along K) and a
     compressed A: lane (i, sg) holds the kept values of dense k = 16 sg .. 16 sg + 15 (4 groups of 4, two kept per group, 2-bit positions
     in the index register). The one-hot A[i][k] = (i == k mod 16) has ONE non-zero per lane: group i >> 2, position i & 3. Both are built
     from the lane id in the block's prologue (the asm statement is at its 30-operand limit: the dense variant's A operand %29 goes away)."""
-    D = VD
+    D = SUMS_D if sums else VD
     assert 2 <= D <= 3      # (the register window holds three gather sets; 2 / 3 / 4 / 5 sets measured equal, DESIGN 4.1h)
     SC = 's90'                                # (group - tile end) of the current tile, counted up: the carry of its increment ends the tile
+    global COLB, GBEG, GLAST, UQX, UB16, SPA, VCOFF, VCA, VP5, VPCL
+    saved = (COLB, GBEG, GLAST, UQX, UB16, SPA, VCOFF, VCA, VP5, VPCL)
+    TEND0, AOP = 16, '%29'
+    if sums:
+        GBEG, GLAST, COLB, UQX, TEND0, AOP = '%16', '%17', '%18', '%19', 8, '%20'
+        # packed window ending at v253: D gather sets, D column words, pointer, clamp, address (sparse: + A operand, index, scratch below)
+        UB16, SPA, VCOFF = SUMS_UB16, SUMS_SPA, 8 * D
+        VP5, VPCL, VCA = 'v%d' % (UB16 + 9 * D), 'v%d' % (UB16 + 9 * D + 1), 'v%d' % (UB16 + 9 * D + 2)
     L = ['s_mov_b32 %s, %s' % (SG, GBEG)]
     if sparse:
         A0, IDX, TMP = SPA, SPA + 4, SPA + 5
@@ -298,8 +319,9 @@ def gen_uniform16(sparse=False):
         for g in (3, 1, 0):
             L += ['v_cmp_eq_u32 vcc, %d, v%d' % (g, TMP), 'v_cndmask_b32 v%d, 0, v%d, vcc' % (A0 + g, A0 + 2)]
         L += ['v_cmp_eq_u32 vcc, 2, v%d' % TMP, 'v_cndmask_b32 v%d, 0, v%d, vcc' % (A0 + 2, A0 + 2)]
-    for r in range(4):
-        L.append('v_mov_b32 v%d, 0' % (VSUMB[0] + r))
+    if not sums:
+        for r in range(4):
+            L.append('v_mov_b32 v%d, 0' % (VSUMB[0] + r))
     for p in range(D):
         vs0(p, p, L)
     L.append('s_waitcnt lgkmcnt(0)')
@@ -307,7 +329,7 @@ def gen_uniform16(sparse=False):
         vs1(p, L); vs0(p, D + p, L)
     L += ['s_add_i32 %s, %s, %d' % (ST, SG, 2 * D - 1), 'v_lshl_add_u32 %s, %s, 7, %s' % (VP5, ST, COLB),
           'v_lshl_add_u32 %s, %s, 7, %s' % (VPCL, GLAST, COLB),
-          's_sub_u32 %s, %s, %%16' % (SC, GBEG), 's_cmp_eq_u32 %s, 0' % SC]
+          's_sub_u32 %s, %s, %%%d' % (SC, GBEG, TEND0), 's_cmp_eq_u32 %s, 0' % SC]
     R = int(os.environ.get('GCRNN_HOP16_UNROLL', '2'))           # the D phases are laid out R times before the loop branches back
     for t in range(NT):
         for pp in range(D * R):
@@ -318,28 +340,34 @@ def gen_uniform16(sparse=False):
             vs1(q, L)                                             # (the set's registers were B operands of the PREVIOUS trip's MFMAs: read long ago)
             vs0p(q, L)
             L.append('s_waitcnt lgkmcnt(%d)' % (3 * (D - 1)))
+            acc = ('%%%d' % t) if sums else VSUM4[0]
             if sparse:
-                L.append('v_smfmac_f32_16x16x64_bf16 %s, v[%d:%d], v[%d:%d], v%d' % (VSUM4[0], SPA, SPA + 3, UB16 + 8 * p, UB16 + 8 * p + 7, SPA + 4))
+                L.append('v_smfmac_f32_16x16x64_bf16 %s, v[%d:%d], v[%d:%d], v%d' % (acc, SPA, SPA + 3, UB16 + 8 * p, UB16 + 8 * p + 7, SPA + 4))
             for e in range(0 if sparse else (1 if os.environ.get('GCRNN_HOP16_EXPERIMENT_ONE_MFMA') else 2)):      # (timing experiment, wrong results: what would ONE
                 # matrix instruction per four entries -- a 2:4-sparse v_smfmac_f32_16x16x64_bf16 with the one-hot A -- buy?)
                 # one accumulator (two, so that an MFMA never waits for its predecessor: slower, the exits pay more)
-                L.append('v_mfma_f32_16x16x32_bf16 %s, %%29, %s, %s' % (VSUM4[0], VX(p, e), VSUM4[0]))
+                L.append('v_mfma_f32_16x16x32_bf16 %s, %s, %s, %s' % (acc, AOP, VX(p, e), acc))
             L.append('s_add_u32 %s, %s, 1' % (SC, SC))            # SCC = carry = this was the tile's last group
         L.append('s_branch L_T%d_P0_%%=' % t)
         for p in range(D):                    # leaving tile t in phase p: acc_t += w * sum, sum = 0
             L.append('L_X%d_P%d_%%=:' % (t, p))
-            L += ['s_nop 15', 's_nop 7'] if sparse else ['s_nop 11']       # matrix-core result -> VALU read: 11 wait states after the 8-pass dense MFMA; the sparse one is given the 16-pass distance
-            L.append('v_pk_fma_f32 %%%d, %s, %s, %%%d' % (2 * t, UWP, VSUMH[0][0], 2 * t))
-            L.append('v_pk_fma_f32 %%%d, %s, %s, %%%d' % (2 * t + 1, UWP, VSUMH[0][1], 2 * t + 1))
-            for r in range(4):
-                L.append('v_mov_b32 v%d, 0' % (VSUMB[0] + r))
+            if not sums and not os.environ.get('GCRNN_HOP16_EXPERIMENT_CHEAP_EXIT'):      # (timing experiment, wrong results: what do the tile exits cost?)
+                L += ['s_nop 15', 's_nop 7'] if sparse else ['s_nop 11']       # matrix-core result -> VALU read: 11 wait states after the 8-pass dense MFMA; the sparse one is given the 16-pass distance
+                L.append('v_pk_fma_f32 %%%d, %s, %s, %%%d' % (2 * t, UWP, VSUMH[0][0], 2 * t))
+                L.append('v_pk_fma_f32 %%%d, %s, %s, %%%d' % (2 * t + 1, UWP, VSUMH[0][1], 2 * t + 1))
+                for r in range(4):
+                    L.append('v_mov_b32 v%d, 0' % (VSUMB[0] + r))
             if t + 1 < NT:                                        # the next tile runs from this tile's end to its own
-                L += ['s_sub_u32 %s, %%%d, %%%d' % (SC, 16 + t, 16 + t + 1), 's_cmp_eq_u32 %s, 0' % SC]
-            L.append('s_nop 1')                                   # VALU write -> matrix-core read of the accumulator
+                L += ['s_sub_u32 %s, %%%d, %%%d' % (SC, TEND0 + t, TEND0 + t + 1), 's_cmp_eq_u32 %s, 0' % SC]
+            if not sums:
+                L.append('s_nop 1')                               # VALU write -> matrix-core read of the accumulator
             L.append('s_branch L_T%d_P%d_%%=' % (t + 1, p))
     for p in range(D):
         L.append('L_T%d_P%d_%%=:' % (NT, p))
     L.append('s_waitcnt lgkmcnt(0)')
+    if sums:                                                      # matrix-core results -> the caller's VALU reads: once per block (16-pass distance)
+        L += ['s_nop 15', 's_nop 7']
+    COLB, GBEG, GLAST, UQX, UB16, SPA, VCOFF, VCA, VP5, VPCL = saved
     return L
 
 
@@ -362,12 +390,17 @@ def main():
     emit('GCRNN_HOP_ASM_UNI_TEXT', gen_uniform())
     emit('GCRNN_HOP_ASM_UNI16_TEXT', gen_uniform16())
     emit('GCRNN_HOP_ASM_UNI16_SPARSE_TEXT', gen_uniform16(sparse=True))
+    emit('GCRNN_HOP_ASM_UNI16_SUMS_TEXT', gen_uniform16(sparse=False, sums=True))
+    emit('GCRNN_HOP_ASM_UNI16_SUMS_SPARSE_TEXT', gen_uniform16(sparse=True, sums=True))
     regs = ', '.join('"v%d"' % r for r in range(UB, UB + 60))
     print('#define GCRNN_HOP_ASM_UNI_CLOBBERS %s, "s88", "s89", "s90", "scc", "memory"' % regs)
     regs16 = ', '.join('"v%d"' % r for r in range(UB16, UB16 + 36))
     print('#define GCRNN_HOP_ASM_UNI16_CLOBBERS %s, "s88", "s89", "s90", "scc", "vcc", "memory"' % regs16)
     regs16s = ', '.join('"v%d"' % r for r in range(SPA, UB16 + 36))
     print('#define GCRNN_HOP_ASM_UNI16_SPARSE_CLOBBERS %s, "s88", "s89", "s90", "scc", "vcc", "memory"' % regs16s)
+    # the summing variants do not use the stream's own D accumulator (the last four registers of the window)
+    print('#define GCRNN_HOP_ASM_UNI16_SUMS_CLOBBERS %s, "s88", "s89", "s90", "scc", "vcc", "memory"' % ', '.join('"v%d"' % r for r in range(SUMS_UB16, 254)))
+    print('#define GCRNN_HOP_ASM_UNI16_SUMS_SPARSE_CLOBBERS %s, "s88", "s89", "s90", "scc", "vcc", "memory"' % ', '.join('"v%d"' % r for r in range(SUMS_SPA, 254)))
 
 
 if __name__ == '__main__':
