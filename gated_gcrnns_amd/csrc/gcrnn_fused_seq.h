@@ -436,10 +436,13 @@ __global__ __launch_bounds__(STHREADS) void fused_seq_kernel(const SeqArgs a) {
           f32x4 dsum[STILES];
           GCRNN_HOP_ASM_UNI16_SUMS_STREAM(dsum);
           taps(K - 1 - j, chunk);
+          const f32x2 w2 = f32x2{uni_w, uni_w};
 #pragma unroll
-          for (int i = 0; i < STILES; ++i)
-#pragma unroll
-            for (int c = 0; c < 4; ++c) u[i][c] = __builtin_fmaf(uni_w, dsum[i][c], u[i][c]);
+          for (int i = 0; i < STILES; ++i) {       // (two packed FMAs per tile, as the accumulating stream's exits)
+            const f32x2 lo = __builtin_elementwise_fma(w2, f32x2{dsum[i][0], dsum[i][1]}, f32x2{u[i][0], u[i][1]});
+            const f32x2 hi = __builtin_elementwise_fma(w2, f32x2{dsum[i][2], dsum[i][3]}, f32x2{u[i][2], u[i][3]});
+            u[i] = f32x4{lo[0], lo[1], hi[0], hi[1]};
+          }
         }
 #endif
         GCRNN_STAMP(2 + chunk * 14 + 2 * j);
