@@ -24,6 +24,11 @@ constexpr int ETHREADS = GCRNN_EDGE_THREADS;      // 16 waves: the aggregation i
 
 __device__ __forceinline__ float ebf2f(uint16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
 __device__ __forceinline__ uint16_t ef2bf(float f) { return __builtin_bit_cast(uint16_t, (__bf16)f); }
+__device__ __forceinline__ uint32_t epack2bf(float a, float b) {      // one v_cvt_pk_bf16_f32 for the pair
+  typedef __attribute__((ext_vector_type(2))) float f2v_t;
+  typedef __attribute__((ext_vector_type(2))) __bf16 b2v_t;
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(f2v_t{a, b}, b2v_t));
+}
 __device__ __forceinline__ float etanh(float x) {
   const float e = __builtin_amdgcn_exp2f(x * 2.8853900817779268f);
   return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + e);
@@ -37,10 +42,10 @@ __device__ __forceinline__ void unpack8(const uint4 v, float* o) {
 }
 __device__ __forceinline__ uint4 pack8(const float* o) {
   uint4 v;
-  v.x = (uint32_t)ef2bf(o[0]) | ((uint32_t)ef2bf(o[1]) << 16);
-  v.y = (uint32_t)ef2bf(o[2]) | ((uint32_t)ef2bf(o[3]) << 16);
-  v.z = (uint32_t)ef2bf(o[4]) | ((uint32_t)ef2bf(o[5]) << 16);
-  v.w = (uint32_t)ef2bf(o[6]) | ((uint32_t)ef2bf(o[7]) << 16);
+  v.x = epack2bf(o[0], o[1]);
+  v.y = epack2bf(o[2], o[3]);
+  v.z = epack2bf(o[4], o[5]);
+  v.w = epack2bf(o[6], o[7]);
   return v;
 }
 

@@ -458,7 +458,7 @@ __global__ void bwd_seed_kernel(const uint16_t* __restrict__ dH, const uint16_t*
   const uint32_t g = *reinterpret_cast<const uint32_t*>(dH + i), hv = *reinterpret_cast<const uint32_t*>(h + i);
   const float g0 = bf2f((uint16_t)(g & 0xffffu)), g1 = bf2f((uint16_t)(g >> 16));
   const float h0 = bf2f((uint16_t)(hv & 0xffffu)), h1 = bf2f((uint16_t)(hv >> 16));
-  *reinterpret_cast<uint32_t*>(out + i) = (uint32_t)f2bf(g0 * (1.f - h0 * h0)) | ((uint32_t)f2bf(g1 * (1.f - h1 * h1)) << 16);
+  *reinterpret_cast<uint32_t*>(out + i) = pack2bf(g0 * (1.f - h0 * h0), g1 * (1.f - h1 * h1));
 }
 
 // out[i][n][:] = in[i][n][:] * g[i][n]  (bf16 rows of F, fp32 per-node factors; rows >= N stay zero)
@@ -474,7 +474,7 @@ __global__ void scale_rows_kernel(const uint16_t* __restrict__ in, const float* 
   if (n < N) {
     const uint32_t v = *reinterpret_cast<const uint32_t*>(in + idx * 2);
     const float gn = g[item * N + n];
-    o = (uint32_t)f2bf(bf2f((uint16_t)(v & 0xffffu)) * gn) | ((uint32_t)f2bf(bf2f((uint16_t)(v >> 16)) * gn) << 16);
+    o = pack2bf(bf2f((uint16_t)(v & 0xffffu)) * gn, bf2f((uint16_t)(v >> 16)) * gn);
   }
   *reinterpret_cast<uint32_t*>(out + idx * 2) = o;
 }
@@ -577,7 +577,7 @@ __global__ __launch_bounds__(256) void gate_readout_bwd_kernel(uint16_t* __restr
     const float dl = dlogit[it];
     a0 += dl * c0;
     a1 += dl * c1;
-    *p = (uint32_t)f2bf(dl * w0 * (1.f - c0 * c0)) | ((uint32_t)f2bf(dl * w1 * (1.f - c1 * c1)) << 16);
+    *p = pack2bf(dl * w0 * (1.f - c0 * c0), dl * w1 * (1.f - c1 * c1));
   }
   *reinterpret_cast<float2*>(dw_part + (int64_t)blockIdx.y * cols + col) = float2{a0, a1};
 }

@@ -499,8 +499,8 @@ __global__ __launch_bounds__(STHREADS) void fused_seq_kernel(const SeqArgs a) {
           }
           uint2 pkd;
           if (node < N) {
-            pkd.x = (uint32_t)f2bf(o[0]) | ((uint32_t)f2bf(o[1]) << 16);
-            pkd.y = (uint32_t)f2bf(o[2]) | ((uint32_t)f2bf(o[3]) << 16);
+            pkd.x = pack2bf(o[0], o[1]);
+            pkd.y = pack2bf(o[2], o[3]);
           } else {
             pkd.x = 0u; pkd.y = 0u;
           }
@@ -525,8 +525,8 @@ __global__ __launch_bounds__(STHREADS) void fused_seq_kernel(const SeqArgs a) {
           uint2 pkd{0u, 0u};
           if (node < N) {
             const f32x4 acc = u[i];
-            pkd.x = (uint32_t)f2bf(acc[0] + bv[0]) | ((uint32_t)f2bf(acc[1] + bv[1]) << 16);
-            pkd.y = (uint32_t)f2bf(acc[2] + bv[2]) | ((uint32_t)f2bf(acc[3] + bv[3]) << 16);
+            pkd.x = pack2bf(acc[0] + bv[0], acc[1] + bv[1]);
+            pkd.y = pack2bf(acc[2] + bv[2], acc[3] + bv[3]);
           }
           __builtin_amdgcn_raw_buffer_store_b64(u32x2{pkd.x, pkd.y}, rsrc_o, node * (F * 2) + (chunk * FC + q * 4) * 2, b * (NP * F * 2), 0);
         }
@@ -564,8 +564,8 @@ __global__ __launch_bounds__(STHREADS) void fused_seq_kernel(const SeqArgs a) {
             const float o0 = fast_tanh(acc[0] + bs2[0]), o1 = fast_tanh(acc[1] + bs2[1]);
             const float o2 = fast_tanh(acc[2] + bs2[2]), o3 = fast_tanh(acc[3] + bs2[3]);
             part = __builtin_fmaf(o3, w4.w, __builtin_fmaf(o2, w4.z, __builtin_fmaf(o1, w4.y, __builtin_fmaf(o0, w4.x, part))));      // (explicit chain, as the chain's partials)
-            pkd.x = (uint32_t)f2bf(o0) | ((uint32_t)f2bf(o1) << 16);
-            pkd.y = (uint32_t)f2bf(o2) | ((uint32_t)f2bf(o3) << 16);
+            pkd.x = pack2bf(o0, o1);
+            pkd.y = pack2bf(o2, o3);
           }
           if (hout) __builtin_amdgcn_raw_buffer_store_b64(u32x2{pkd.x, pkd.y}, rsrc_o, node * (F * 2) + (chunk * FC + ql * 4) * 2, b * (NP * F * 2), 0);
         }
@@ -590,14 +590,14 @@ __global__ __launch_bounds__(STHREADS) void fused_seq_kernel(const SeqArgs a) {
               const u32x2 y2 = (K > 1) ? epg[i] : __builtin_amdgcn_raw_buffer_load_b64(rsrc_a0, eoff, b * (NP * F * 2), 0);
               const float ni = epn[i][0], nf = epn[i][1];
               const float yh0 = acc[0] + bsum[0], yh1 = acc[1] + bsum[1], yh2 = acc[2] + bsum[2], yh3 = acc[3] + bsum[3];
-              if (yhout) __builtin_amdgcn_raw_buffer_store_b64(u32x2{(uint32_t)f2bf(yh0) | ((uint32_t)f2bf(yh1) << 16), (uint32_t)f2bf(yh2) | ((uint32_t)f2bf(yh3) << 16)},
+              if (yhout) __builtin_amdgcn_raw_buffer_store_b64(u32x2{pack2bf(yh0, yh1), pack2bf(yh2, yh3)},
                                                                rsrc_yh, eoff, b * (NP * F * 2), 0);
               const float o0 = fast_tanh(ni * bf2f((uint16_t)(y2[0] & 0xffffu)) + nf * yh0);
               const float o1 = fast_tanh(ni * bf2f((uint16_t)(y2[0] >> 16)) + nf * yh1);
               const float o2 = fast_tanh(ni * bf2f((uint16_t)(y2[1] & 0xffffu)) + nf * yh2);
               const float o3 = fast_tanh(ni * bf2f((uint16_t)(y2[1] >> 16)) + nf * yh3);
-              pkd.x = (uint32_t)f2bf(o0) | ((uint32_t)f2bf(o1) << 16);
-              pkd.y = (uint32_t)f2bf(o2) | ((uint32_t)f2bf(o3) << 16);
+              pkd.x = pack2bf(o0, o1);
+              pkd.y = pack2bf(o2, o3);
             } else {
               pkd.x = 0u; pkd.y = 0u;
               if (yhout) __builtin_amdgcn_raw_buffer_store_b64(u32x2{0u, 0u}, rsrc_yh, eoff, b * (NP * F * 2), 0);
@@ -605,8 +605,8 @@ __global__ __launch_bounds__(STHREADS) void fused_seq_kernel(const SeqArgs a) {
           } else if (node < N) {
             const float o0 = fast_tanh(acc[0] + bsum[0]), o1 = fast_tanh(acc[1] + bsum[1]);
             const float o2 = fast_tanh(acc[2] + bsum[2]), o3 = fast_tanh(acc[3] + bsum[3]);
-            pkd.x = (uint32_t)f2bf(o0) | ((uint32_t)f2bf(o1) << 16);
-            pkd.y = (uint32_t)f2bf(o2) | ((uint32_t)f2bf(o3) << 16);
+            pkd.x = pack2bf(o0, o1);
+            pkd.y = pack2bf(o2, o3);
           } else {
             pkd.x = 0u; pkd.y = 0u;
           }

@@ -72,6 +72,13 @@ __device__ __forceinline__ uint16_t f2bf(float f) {
   return __builtin_bit_cast(uint16_t, (__bf16)f);   // v_cvt_pk_bf16_f32: round-to-nearest-even, NaN-safe
 }
 __device__ __forceinline__ float bf2f(uint16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
+// two floats -> one dword {bf16(a), bf16(b) << 16}: ONE v_cvt_pk_bf16_f32 (f2bf(a) | f2bf(b) << 16 compiles to two conversions, a shift and
+// an or -- 8 instead of 2 vector instructions for a lane's four features, at every hop's write-back and in every epilogue)
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2v_t;
+__device__ __forceinline__ uint32_t pack2bf(float a, float b) {
+  typedef __attribute__((ext_vector_type(2))) float f32x2v_t;
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2v_t{a, b}, bf16x2v_t));
+}
 
 // tanh(x) = 1 - 2 / (1 + exp(2x)) on the hardware exp2/rcp units: abs error < 3e-7 for all x (inf-safe: exp -> inf
 // gives 1, exp -> 0 gives -1), far below the bf16 rounding of the stored state.
@@ -86,7 +93,7 @@ __device__ __forceinline__ void state_put(float* state, int wv, const f32x4& v) 
   char* p = reinterpret_cast<char*>(state) + (wv & 0xffff);
   if constexpr (IMG16) {
     typedef __attribute__((__vector_size__(2 * sizeof(unsigned int)))) unsigned int u32x2_;
-    *reinterpret_cast<u32x2_*>(p) = u32x2_{(uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16), (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16)};
+    *reinterpret_cast<u32x2_*>(p) = u32x2_{pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
   } else {
     *reinterpret_cast<f32x4*>(p) = v;
   }
@@ -848,8 +855,8 @@ __global__ __launch_bounds__(STHREADS) void fused_step_kernel(
       uint2 pk{0u, 0u};
       if (node < N) {
         const f32x4 acc = u[i][0];
-        pk.x = (uint32_t)f2bf(acc[0] + bvec[0]) | ((uint32_t)f2bf(acc[1] + bvec[1]) << 16);
-        pk.y = (uint32_t)f2bf(acc[2] + bvec[2]) | ((uint32_t)f2bf(acc[3] + bvec[3]) << 16);
+        pk.x = pack2bf(acc[0] + bvec[0], acc[1] + bvec[1]);
+        pk.y = pack2bf(acc[2] + bvec[2], acc[3] + bvec[3]);
       }
       __builtin_amdgcn_raw_buffer_store_b64(u32x2{pk.x, pk.y}, rsrc_o, node * (F * 2) + (chunk * FC + q * 4) * 2, b * (NP * F * 2), 0);
     }
@@ -869,8 +876,8 @@ __global__ __launch_bounds__(STHREADS) void fused_step_kernel(
         const float o0 = fast_tanh(acc[0] + bsum[0]), o1 = fast_tanh(acc[1] + bsum[1]);
         const float o2 = fast_tanh(acc[2] + bsum[2]), o3 = fast_tanh(acc[3] + bsum[3]);
         part = __builtin_fmaf(o3, w4.w, __builtin_fmaf(o2, w4.z, __builtin_fmaf(o1, w4.y, __builtin_fmaf(o0, w4.x, part))));      // (explicit chain, as the chain's partials)
-        pk.x = (uint32_t)f2bf(o0) | ((uint32_t)f2bf(o1) << 16);
-        pk.y = (uint32_t)f2bf(o2) | ((uint32_t)f2bf(o3) << 16);
+        pk.x = pack2bf(o0, o1);
+        pk.y = pack2bf(o2, o3);
       }
       if (hout) __builtin_amdgcn_raw_buffer_store_b64(u32x2{pk.x, pk.y}, rsrc_o, node * (F * 2) + (chunk * FC + q * 4) * 2, b * (NP * F * 2), 0);
     }
@@ -912,8 +919,8 @@ __global__ __launch_bounds__(STHREADS) void fused_step_kernel(
       }
       uint2 pk;
       if (node < N) {
-        pk.x = (uint32_t)f2bf(o[0]) | ((uint32_t)f2bf(o[1]) << 16);
-        pk.y = (uint32_t)f2bf(o[2]) | ((uint32_t)f2bf(o[3]) << 16);
+        pk.x = pack2bf(o[0], o[1]);
+        pk.y = pack2bf(o[2], o[3]);
       } else {
         pk.x = 0u; pk.y = 0u;
       }
@@ -924,8 +931,8 @@ __global__ __launch_bounds__(STHREADS) void fused_step_kernel(
         uint2 pg{0u, 0u};
         if (node < N) {
           const float gn = gate_w[(int64_t)b * N + node];
-          pg.x = (uint32_t)f2bf(o[0] * gn) | ((uint32_t)f2bf(o[1] * gn) << 16);
-          pg.y = (uint32_t)f2bf(o[2] * gn) | ((uint32_t)f2bf(o[3] * gn) << 16);
+          pg.x = pack2bf(o[0] * gn, o[1] * gn);
+          pg.y = pack2bf(o[2] * gn, o[3] * gn);
         }
         __builtin_amdgcn_raw_buffer_store_b64(u32x2{pg.x, pg.y}, rsrc_yh, eoff, b * (NP * F * 2), 0);
       }
@@ -958,7 +965,7 @@ __global__ __launch_bounds__(STHREADS) void fused_step_kernel(
         const float ni = gin * (GCRNN_EPI_PREFETCH ? epn[GCRNN_EPI_PREFETCH ? i : 0][0] : gate_w[(int64_t)b * N + node]);
         const float nf = gfo * (GCRNN_EPI_PREFETCH ? epn[GCRNN_EPI_PREFETCH ? i : 0][1] : gate_w[(int64_t)(B + b) * N + node]);
         const float yh0 = acc[0] + bvec[0], yh1 = acc[1] + bvec[1], yh2 = acc[2] + bvec[2], yh3 = acc[3] + bvec[3];
-        if (xt) __builtin_amdgcn_raw_buffer_store_b64(u32x2{(uint32_t)f2bf(yh0) | ((uint32_t)f2bf(yh1) << 16), (uint32_t)f2bf(yh2) | ((uint32_t)f2bf(yh3) << 16)},
+        if (xt) __builtin_amdgcn_raw_buffer_store_b64(u32x2{pack2bf(yh0, yh1), pack2bf(yh2, yh3)},
                                                      rsrc_yh, eoff, b * (NP * F * 2), 0);
         o0 = fast_tanh(ni * bf2f((uint16_t)(y2[0] & 0xffffu)) + nf * yh0);
         o1 = fast_tanh(ni * bf2f((uint16_t)(y2[0] >> 16)) + nf * yh1);
@@ -968,8 +975,8 @@ __global__ __launch_bounds__(STHREADS) void fused_step_kernel(
         o0 = fast_tanh(acc[0] + bsum[0]); o1 = fast_tanh(acc[1] + bsum[1]);
         o2 = fast_tanh(acc[2] + bsum[2]); o3 = fast_tanh(acc[3] + bsum[3]);
       }
-      pk.x = (uint32_t)f2bf(o0) | ((uint32_t)f2bf(o1) << 16);
-      pk.y = (uint32_t)f2bf(o2) | ((uint32_t)f2bf(o3) << 16);
+      pk.x = pack2bf(o0, o1);
+      pk.y = pack2bf(o2, o3);
     } else {
       pk.x = 0u; pk.y = 0u;          // padded rows stay zero
       if (EPI == 5 && xt) __builtin_amdgcn_raw_buffer_store_b64(u32x2{0u, 0u}, rsrc_yh, node * (F * 2) + (chunk * FC + q * 4) * 2, b * (NP * F * 2), 0);

@@ -170,8 +170,8 @@ __global__ __launch_bounds__(512, 2) void fused_wgrad_kernel(
         if (k < K - 1) state_put<UNI == 2>(state, wv, cur[i]);
         const int node = wv >> 16;
         char* tb = tbuf + (node >= 512 ? TB2 : 0) + (node & 511) * 4 + (2 * q) * RS2;
-        *reinterpret_cast<uint32_t*>(tb) = (uint32_t)f2bf(cur[i][0]) | ((uint32_t)f2bf(cur[i][1]) << 16);
-        *reinterpret_cast<uint32_t*>(tb + RS2) = (uint32_t)f2bf(cur[i][2]) | ((uint32_t)f2bf(cur[i][3]) << 16);
+        *reinterpret_cast<uint32_t*>(tb) = pack2bf(cur[i][0], cur[i][1]);
+        *reinterpret_cast<uint32_t*>(tb + RS2) = pack2bf(cur[i][2], cur[i][3]);
       }
       lds_barrier();      // LDS hand-off only: loads in flight stay in flight (gcrnn_fused_step.h)
       // S2: D_k += du_k^T z over nodes 0..511 (register-resident fragments), then the first re-fetched batch (nodes 512..767)
