@@ -377,6 +377,44 @@ extern "C" int gcrnn_fused_gate_prepass_pack_bf16(const void* x_user, void* xs, 
                         x_user, nullptr, nullptr, nullptr, nullptr, nullptr, 0, h0_zero_flag);
 }
 
+// The gate-cell pre-pass of a NODE gate at inference (graphML.py:2379-2393): tanh(A_g(S) x_t + B_g(S) h0 + 2 b_g) for every (t, b), and -- fused
+// into its epilogue -- the per-tap dot products s_k[n] = <c[n, :], w_k> that start the gate's F -> 1 GraphFilter (taps first, :2387).
+// tap_frags: the taps as MFMA A fragments, [F/16][3][64] x 8 B (three bf16 planes of the fp32 taps: lane l = 16 kg + tap holds
+// w_plane[tap][16 chunk + 4 kg + e], e = 0..3; taps >= ntaps zero); taps_out [T*B][ntaps][N] fp32. cs (or NULL) as in the plain
+// pre-pass; x_user (or NULL) as in gcrnn_fused_gate_prepass_pack_bf16. Sequence-resident kernel only: GCRNN_ERR_UNSUPPORTED where
+// gcrnn_fused_gate_prepass_taps_supported returns 0.
+extern "C" int gcrnn_fused_gate_prepass_taps_bf16(const void* x_user, void* xs, const void* h0, const void* wpack, const float* bias,
+                                                  const void* tap_frags, float* taps_out, int64_t ntaps, void* cs,
+                                                  const int32_t* tile_nodes, const int32_t* tile_off, const int32_t* ell_col,
+                                                  const float* ell_val, const void* ell_val4, const void* ell_col4, int64_t entries,
+                                                  int64_t B, int64_t T, int64_t N, int64_t F, int64_t G, int64_t K,
+                                                  const int32_t* h0_zero_flag, double uniform_w, int img16, void* stream) {
+  if (!xs || !h0 || !wpack || !tap_frags || !taps_out || !tile_nodes || !tile_off || !ell_col || !ell_val) return GCRNN_ERR_NULL_POINTER;
+  if (B <= 0 || T <= 0 || N <= 0 || N > NP || B * T > (1 << 24) || entries < 0 || entries % 4 || ntaps < 1 || ntaps > 8) return GCRNN_ERR_BAD_SHAPE;
+  const FusedGraphArgs ga{tile_nodes, tile_off, ell_col, ell_val, ell_val4, ell_col4, entries, (float)uniform_w, img16 ? 1 : 0};
+  return fused_dispatch(2, xs, h0, cs, wpack, bias, nullptr, nullptr, nullptr, nullptr, ga, B, T, N, F, G, K, as_stream(stream),
+                        x_user, tap_frags, taps_out, nullptr, nullptr, nullptr, (int)ntaps, h0_zero_flag);
+}
+
+// 1 when gcrnn_fused_gate_prepass_taps_bf16 takes this shape (with_pack: together with the layout of X)
+extern "C" int gcrnn_fused_gate_prepass_taps_supported(int64_t B, int64_t T, int64_t N, int64_t F, int64_t G, int64_t K, int64_t entries,
+                                                       double uniform_w, int img16, int with_pack, int64_t ntaps) {
+#if GCRNN_HOP_ASM && GCRNN_STEP_WAVES == 8
+  if (uniform_w == 0.0 || !img16 || N <= 0 || N > NP || B <= 0 || T <= 0 || entries % 4 || (G != 32 && G != 64) || (F != 32 && F != 64)) return 0;
+  if (ntaps < 1 || ntaps > 8 || !gcrnn_fused_supported(N, F, G, K) || (with_pack && N % 8)) return 0;
+  const int nch = (int)(F / FC);
+  if (!fused_seq_wanted(B * T, nch)) return 0;
+  const size_t need = (size_t)33 * 1024 + 2 * (size_t)K * ((F + G) / 32) * 1024 + (size_t)entries * 32 + (with_pack ? (size_t)G * (NP / nch) * 2 : 0) +
+                      (size_t)ntaps * NP * 4 + (size_t)nch * 3 * 512;
+  if (need > 160 * 1024) return 0;
+  const int64_t row_bytes = (int64_t)NP * (F > G ? F : G) * 2;
+  if ((2147483647LL / row_bytes) / B < T) return 0;
+  return 1;
+#else
+  return 0;
+#endif
+}
+
 // 0: gcrnn_fused_gate_prepass_pack_bf16 is not available for this shape (chunk-parallel kernel, weighted graph, N % 8, LDS); else the
 // number of leading time steps of xs the caller must lay out itself (the items of the first round of workgroups).
 extern "C" int64_t gcrnn_fused_gate_prepass_lays_out(int64_t B, int64_t T, int64_t N, int64_t F, int64_t G, int64_t K, int64_t entries,

@@ -77,6 +77,9 @@ struct SeqArgs {
   const uint16_t* pk_src0; int64_t pksrc_stride;       // inline pack of the NEXT step's operand: user-layout block of sequence 0 for step 0 (or null)
   uint16_t* pk_dst0; int64_t pkdst_stride;             // ... the sequence-major array [B][NP][rows] it is laid out into
   int pk_stride;                                       // ... elements between consecutive sequences of the user-layout tensor
+  const uint2* tapf; float* taps_out; int ntaps;       // MODE 1 (or null): fused F -> 1 tap dots of the gate cell's state (node gates, graphML.py:2387): A fragments
+                                                       // [F/16][3 planes][64 lanes] x 8 B of the taps, output [items][ntaps][N] fp32
+  int sacc_off, tapf_off;                              // ... LDS byte offsets of the per-item accumulators [ntaps][NP] fp32 and of the staged fragments
   const float* ng0; int64_t ngstride;                  // MODE 5: node gates of step 0 [2][B][N] fp32 (input gates, forget gates), elements between steps
   uint16_t* yh0; int64_t yhstride;                     // MODE 5 (or null): receives Yh_t = B(S)h_{t-1} + b [B][NP][F] bf16 (training keeps it)
   int nsteps;                                          // steps of this launch; every step but the last lays out the next one's operand
@@ -137,6 +140,12 @@ __global__ __launch_bounds__(STHREADS) void fused_seq_kernel(const SeqArgs a) {
   }
   // the bias (it enters through both filters, graphML.py:2420-2421: scaled by gi + gf = 2 at its use) in the 256 spare bytes behind the tile:
   // a chunk reads its four values from LDS instead of waiting for a global load at the top of every chunk
+  if constexpr (MODE == 1) {
+    if (a.tapf) {      // (wave-uniform) tap fragments into LDS, accumulators to zero
+      for (int idx = tid; idx < NCH * 3 * 64; idx += STHREADS) reinterpret_cast<uint2*>(smem + a.tapf_off)[idx] = a.tapf[idx];
+      for (int idx = tid; idx < a.ntaps * NP; idx += STHREADS) reinterpret_cast<float*>(smem + a.sacc_off)[idx] = 0.f;
+    }
+  }
   float* lbias = reinterpret_cast<float*>(smem + 33024);
   if ((MODE == 0 || MODE == 1 || MODE == 4 || MODE == 5) && tid < F) lbias[tid] = a.bias ? a.bias[tid] : 0.f;
   __syncthreads();
@@ -537,6 +546,60 @@ __global__ __launch_bounds__(STHREADS) void fused_seq_kernel(const SeqArgs a) {
         float bs2[4];
 #pragma unroll
         for (int c = 0; c < 4; ++c) bs2[c] = 2.f * lbias[chunk * FC + ql * 4 + c];
+        if (a.tapf) {
+          // Node gates (inference): the F -> 1 GraphFilter of the gate cell's state starts with its per-tap dot products s_k[n] = <c[n, :], w_k>
+          // (graphML.py:2387, taps first). They are taken here, from the bf16-rounded c this lane has just packed (the values the stored
+          // states would hold), on the matrix cores: D[tap][slot] = sum_f W[tap][f] c[f][slot] with the taps as A rows -- a lane's packed
+          // pair of dwords IS its B operand of v_mfma_f32_16x16x16_bf16 (k = 4 q + e = the lane's four features), the fp32 taps enter as
+          // three bf16 planes (their sum is the fp32 value to 24 bits, every product with a bf16 c is exact in fp32). Lane (r, q') then
+          // holds taps 4 q' .. 4 q' + 3 of ITS OWN node and adds them to the item's accumulators in LDS; the item's last chunk is followed
+          // by a coalesced copy-out. Neither the state array nor a second pass over it is needed.
+          typedef __attribute__((__vector_size__(4 * sizeof(short)))) short s16x4;
+          const char* tf = smem + a.tapf_off + chunk * (3 * 512) + (tl & 63) * 8;
+          const s16x4 wa0 = *reinterpret_cast<const s16x4*>(tf), wa1 = *reinterpret_cast<const s16x4*>(tf + 512), wa2 = *reinterpret_cast<const s16x4*>(tf + 1024);
+          float* sacc = reinterpret_cast<float*>(smem + a.sacc_off);
+#pragma unroll
+          for (int i = 0; i < STILES; ++i) {
+            int wv = woff[i];
+            asm volatile("" : "+v"(wv));
+            const int node = wv >> 16;
+            uint2 pkd{0u, 0u};
+            if (node < N) {
+              const f32x4 acc = u[i];
+              const float o0 = fast_tanh(acc[0] + bs2[0]), o1 = fast_tanh(acc[1] + bs2[1]);
+              const float o2 = fast_tanh(acc[2] + bs2[2]), o3 = fast_tanh(acc[3] + bs2[3]);
+              pkd.x = pack2bf(o0, o1);
+              pkd.y = pack2bf(o2, o3);
+            }
+            if (hout) __builtin_amdgcn_raw_buffer_store_b64(u32x2{pkd.x, pkd.y}, rsrc_o, node * (F * 2) + (chunk * FC + ql * 4) * 2, b * (NP * F * 2), 0);
+            const s16x4 cb = __builtin_bit_cast(s16x4, pkd);
+            f32x4 d = f32x4{0.f, 0.f, 0.f, 0.f};
+            d = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(wa0, cb, d, 0, 0, 0);
+            d = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(wa1, cb, d, 0, 0, 0);
+            d = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(wa2, cb, d, 0, 0, 0);
+            u[i] = d;                                  // (the tile's accumulator is dead: it keeps the tap dots until the adds below)
+          }
+          // add to the item's accumulators: plain read-modify-write -- a (tap, node) pair belongs to ONE lane of one wave (LDS float
+          // atomics measured 12 % of the pre-pass); two tiles per round so that eight reads are in flight
+#pragma unroll
+          for (int i0 = 0; i0 < STILES; i0 += 2) {
+            float old[2][4];
+            int nd[2];
+#pragma unroll
+            for (int t2 = 0; t2 < 2; ++t2) {
+              int wv = woff[i0 + t2];
+              asm volatile("" : "+v"(wv));
+              nd[t2] = wv >> 16;
+#pragma unroll
+              for (int c = 0; c < 4; ++c) old[t2][c] = (nd[t2] < N && ql * 4 + c < a.ntaps) ? sacc[(ql * 4 + c) * NP + nd[t2]] : 0.f;
+            }
+#pragma unroll
+            for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+              for (int c = 0; c < 4; ++c)
+                if (nd[t2] < N && ql * 4 + c < a.ntaps) sacc[(ql * 4 + c) * NP + nd[t2]] = old[t2][c] + u[i0 + t2][c];
+          }
+        } else {
         float part = 0.f;
         // the read-out weights [N][F] fp32 (shared by every item: L2-resident; held across an asm block they would spill): requested
         // two tiles at a time (more in flight spills in this instantiation), right after the last hop's stream -- its register window is free here. Inside the per-tile `node < N`
@@ -572,6 +635,7 @@ __global__ __launch_bounds__(STHREADS) void fused_seq_kernel(const SeqArgs a) {
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) part += __shfl_down(part, off, 64);
         if (lane == 0) gate_out[(int64_t)b * (NCH * SWAVES) + chunk * SWAVES + wave] = part;
+        }
       } else {
         float bsum[4];
 #pragma unroll
@@ -702,6 +766,19 @@ __global__ __launch_bounds__(STHREADS) void fused_seq_kernel(const SeqArgs a) {
       for (int s = 0; s < KS; ++s) asm volatile("" ::"v"(bfr[i][s]));
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     lds_barrier();       // every wave's stores of this step have retired (the waits above): the next step may read them
+    if constexpr (MODE == 1) {
+      if (a.tapf) {
+        // the item's tap dots: accumulators (every wave's adds are in: the barrier above) -> [ntaps][N] fp32, coalesced; zeroed for the
+        // workgroup's next item, whose first add comes many barriers later
+        float* sacc = reinterpret_cast<float*>(smem + a.sacc_off);
+        float* so = a.taps_out + (int64_t)b * a.ntaps * N;
+        for (int tap = 0; tap < a.ntaps; ++tap)
+          for (int n = tid; n < N; n += STHREADS) {
+            so[tap * N + n] = sacc[tap * NP + n];
+            sacc[tap * NP + n] = 0.f;
+          }
+      }
+    }
   }  // steps
   }  // sequences
   GCRNN_STAMP_FLUSH();
@@ -709,9 +786,9 @@ __global__ __launch_bounds__(STHREADS) void fused_seq_kernel(const SeqArgs a) {
 
 // LDS bytes of the sequence-resident kernel, or 0 when the problem does not fit
 template <int K, int HS, int XS>
-static size_t fused_seq_lds(int64_t entries, bool inline_pack, int pkrows) {
+static size_t fused_seq_lds(int64_t entries, bool inline_pack, int pkrows, size_t extra = 0) {
   const size_t need = (size_t)33 * 1024 + 2 * (size_t)K * (HS + XS) * 1024 + (size_t)entries * 32 +
-                      (inline_pack ? (size_t)pkrows * (NP / (32 * HS / FC)) * 2 : 0);
+                      (inline_pack ? (size_t)pkrows * (NP / (32 * HS / FC)) * 2 : 0) + extra;
   return need <= 160 * 1024 ? need : 0;
 }
 

@@ -1204,7 +1204,8 @@ int fused_launch_t(int mode /*0 plain, 1 gated, 2 gate pre-pass, 3 BPTT data gra
   // un-gated forward steps and the plain BPTT data chain on uniform-weight bf16-image plans, when the batch fills the chip.
   if (ga.uniform_w != 0.f && ga.img16 && ga.ell_col4 && !head && !step_events && (mode == 0 || mode == 1 || mode == 2 || mode == 3 || mode == 5 || mode == 6) &&
       fused_seq_wanted((mode == 2 || mode == 5) ? B * T : B, NCH)) {
-    const size_t slds = fused_seq_lds<K, HS, XS>(ga.entries, inline_pack, mode == 3 ? F : G);
+    const size_t tap_extra = (mode == 2 && bw_hs) ? (size_t)huser_last_only * NP * 4 + (size_t)NCH * 3 * 512 : 0;      // per-item tap accumulators + staged fragments
+    const size_t slds = fused_seq_lds<K, HS, XS>(ga.entries, inline_pack, mode == 3 ? F : G, tap_extra);
     const unsigned sgrid = (unsigned)(B < 256 ? B : 256);
     const bool persist = fused_seq_persistent();
     SeqArgs sa{};
@@ -1234,6 +1235,11 @@ int fused_launch_t(int mode /*0 plain, 1 gated, 2 gate pre-pass, 3 BPTT data gra
       return GCRNN_OK;
     }
     if constexpr (XS > 0) {
+      if (mode == 2 && bw_hs != nullptr) {
+        // (the pre-pass with fused F -> 1 tap dots exists on this kernel only; bw_hs = tap fragments, bw_dh0 = [items][ntaps][N] fp32,
+        //  huser_last_only carries the tap count)
+        if (!slds || !bw_dh0 || huser_last_only < 1 || huser_last_only > 8) return GCRNN_ERR_UNSUPPORTED;
+      }
       if (mode == 2 && slds) {
         // gate pre-pass: every (t, b) item of one gate in one launch (split over whole time steps where the 32-bit buffer offsets of
         // items * NP * max(F, G) * 2 bytes would overflow), one workgroup per item
@@ -1251,7 +1257,12 @@ int fused_launch_t(int mode /*0 plain, 1 gated, 2 gate pre-pass, 3 BPTT data gra
           s1.bias = bias; s1.B = (int)items; s1.hmod = (int)B; s1.nsteps = 1;
           s1.x0 = x + t0 * xstep; s1.hfirst = (const uint16_t*)h0;
           s1.out0 = h ? h + t0 * hstep : nullptr;
-          s1.gw = gate_w; s1.go0 = gate_out + t0 * B * (NCH * SWAVES); s1.flags = hzero_flag;
+          s1.gw = gate_w; s1.go0 = gate_out ? gate_out + t0 * B * (NCH * SWAVES) : nullptr; s1.flags = hzero_flag;
+          if (bw_hs) {
+            if (tchunk != T) return GCRNN_ERR_UNSUPPORTED;
+            s1.tapf = (const uint2*)bw_hs; s1.taps_out = (float*)bw_dh0; s1.ntaps = huser_last_only;
+            s1.sacc_off = (int)(slds - tap_extra); s1.tapf_off = s1.sacc_off + huser_last_only * NP * 4;
+          }
           if (prepass_pack) {
             // every item lays out the operand of the workgroup's next item from the user-layout X [B][T][G][N] (the caller laid out
             // the first min(items, 256)): the pass over X that packed the whole input goes away
@@ -1435,7 +1446,7 @@ int fused_launch_t(int mode /*0 plain, 1 gated, 2 gate pre-pass, 3 BPTT data gra
     }
   }
 #endif
-  if (prepass_pack) return GCRNN_ERR_UNSUPPORTED;      // (gcrnn_fused_gate_prepass_lays_out tells the caller beforehand)
+  if (prepass_pack || (mode == 2 && bw_hs)) return GCRNN_ERR_UNSUPPORTED;      // (gcrnn_fused_gate_prepass_lays_out / _taps_supported tell the caller beforehand)
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
     return GCRNN_ERR_LAUNCH;
   // one workgroup per CU: 256 / NCH sequence slots (rounded to the 8 XCDs), fewer when the batch is small

@@ -755,6 +755,13 @@ def node_gate_logits(cs, wf, bf, graph, N):
     for i0 in range(0, items, 32768):            # gridDim.y limit of the dot kernel
         n_i = min(32768, items - i0)
         check(lib.gcrnn_node_gate_dot(_p(cs.view(items, npad, F)[i0:]), _p(wk), _p(s[i0:]), n_i, N, npad, F, K, _stream()), 'node_gate_dot')
+    return _node_gate_logits_from_taps(s, bf, graph, T, B, N), wk
+
+
+def _node_gate_logits_from_taps(s, bf, graph, T, B, N):
+    """Second stage of the F -> 1 GraphFilter: s [items][K][1][N] fp32 per-tap dot products -> logits [T][B][N] (K-1 Horner hops on
+    the one-channel signals, node-major)."""
+    K = s.shape[1]
     sn = _pack_raw(s)                                                  # [K][N][items][1]
     acc = sn[K - 1:K]
     csr = graph.fwd[0]
@@ -764,7 +771,49 @@ def node_gate_logits(cs, wf, bf, graph, N):
     logit = _unpack_raw(acc).view(T, B, N)                             # [items][1][1][N]
     if bf is not None:
         logit = logit + bf.detach().float().view(())
-    return logit, wk
+    return logit
+
+
+def _tap_fragments(wf, F):
+    """The F -> 1 filter's taps wf 1 x 1 x K x F (fp32) as the A fragments gcrnn_fused_gate_prepass_taps_bf16 takes: three bf16 planes
+    (p0 + p1 + p2 = w to 24 bits), bf16 [F/16][3][64][4] with lane l = 16 kg + tap holding w_p[tap][16 chunk + 4 kg + e]."""
+    K = wf.shape[2]
+    w = wf.detach().float().reshape(K, F)
+    p0 = w.to(torch.bfloat16)
+    r1 = w - p0.float()
+    p1 = r1.to(torch.bfloat16)
+    p2 = (r1 - p1.float()).to(torch.bfloat16)
+    pl = torch.zeros((3, 16, F), dtype=torch.bfloat16, device=w.device)
+    pl[:, :K] = torch.stack([p0, p1, p2])
+    # [plane][tap][chunk][kg][e] -> [chunk][plane][kg][tap][e]
+    return pl.view(3, 16, F // 16, 4, 4).permute(2, 0, 3, 1, 4).contiguous()
+
+
+def fused_node_gate_taps(xs, h0s, wA_g, wB_g, bias_g, wf, graph, N, hzero=None):
+    """Gate cell of a node gate at inference with the per-tap dot products of its F -> 1 filter fused into the pre-pass
+    (gcrnn_fused_gate_prepass_taps_bf16): returns s [T*B][K][1][N] fp32, or None where the fused pre-pass does not apply (the caller
+    then stores the states and runs gcrnn_node_gate_dot over them). Lays out X too when xs carries a pending user-layout tensor."""
+    T, B, npad, G = xs.shape
+    F = wA_g.shape[0]
+    K = max(wA_g.shape[2], wB_g.shape[2])
+    Kt = wf.shape[2]
+    plan = graph.fused_plan()
+    plan16 = fused_img16_plan(graph, True, None)
+    x_user = getattr(xs, '_pending_user', None)
+    if plan16 is None or os.environ.get('GCRNN_NO_FUSED_TAPS') or not int(lib.gcrnn_fused_gate_prepass_taps_supported(
+            B, T, N, F, G, K, plan16['entries'], plan.get('uniform_w', 0.0), 1, 1 if x_user is not None else 0, Kt)):
+        return None
+    st = _stream()
+    wp = _fused_pack_weights(wA_g.detach(), wB_g.detach(), st)
+    bg = bias_g.detach().float().contiguous().view(-1) if bias_g is not None else None
+    frags = _tap_fragments(wf, F)
+    s = torch.empty((T * B, Kt, 1, N), dtype=torch.float32, device=xs.device)
+    check(lib.gcrnn_fused_gate_prepass_taps_bf16(_p(x_user), _p(xs), _p(h0s), _p(wp), _p(bg), _p(frags), _p(s), Kt, None,
+                                                 *_fused_graph_args(plan16), B, T, N, F, G, K, _p(hzero), plan.get('uniform_w', 0.0), 1, st),
+          'gate_prepass_taps')
+    if x_user is not None:
+        del xs._pending_user
+    return s
 
 
 def fused_node_supported(graph, N, F, G, Kin, Kst, dtype, E=1):
@@ -794,8 +843,12 @@ def fused_node_cell_forward(X, h0, wA, wB, bias, graph, node_gates, time_gates=N
         wA_g, wB_g, bias_g, wf, bf = node_gates[name]
         if wA_g.shape[3] != G:
             wA_g = torch.nn.functional.pad(wA_g.detach(), (0, G - wA_g.shape[3]))
-        _, cs, _ = fused_time_gate(xs, h0s, wA_g, wB_g, bias_g, zero_lin, None, graph, N, store_states=True, hzero=hzero)
-        logit, _ = node_gate_logits(cs, wf, bf, graph, N)
+        staps = fused_node_gate_taps(xs, h0s, wA_g, wB_g, bias_g, wf, graph, N, hzero=hzero)
+        if staps is not None:          # the filter's tap dots came out of the pre-pass itself: no state array, no pass over it
+            logit = _node_gate_logits_from_taps(staps, bf, graph, T, B, N)
+        else:
+            _, cs, _ = fused_time_gate(xs, h0s, wA_g, wB_g, bias_g, zero_lin, None, graph, N, store_states=True, hzero=hzero)
+            logit, _ = node_gate_logits(cs, wf, bf, graph, N)
         ng.append(torch.sigmoid(logit))
     ngates = torch.stack(ng, dim=1).contiguous()                        # [T][2][B][N]
     assert getattr(xs, '_pending_user', None) is None

@@ -386,6 +386,20 @@ int gcrnn_fused_gate_prepass_pack_bf16(const void* x_user, void* xs, const void*
 int64_t gcrnn_fused_gate_prepass_lays_out(int64_t B, int64_t T, int64_t N, int64_t F, int64_t G, int64_t K, int64_t entries,
                                           double uniform_w, int img16);
 
+/* Gate-cell pre-pass of a NODE gate at inference (graphML.py:2379-2393) with the first stage of the gate's F -> 1 GraphFilter fused into its
+ * epilogue (taps first, :2387): taps_out[t*B + b][k][n] = < tanh(A_g(S) x_t + B_g(S) h0 + 2 b_g)[n, :], w_k >, k < ntaps <= 8, fp32 --
+ * computed from the bf16-rounded states (the values cs would hold) on the matrix cores. tap_frags: the taps as A fragments of
+ * v_mfma_f32_16x16x16_bf16, bf16 [F/16][3][64][4]: plane p of the three-way bf16 split of the fp32 taps (p0 + p1 + p2 = w to 24 bits),
+ * lane l = 16 kg + tap: w_p[tap][16 chunk + 4 kg + e], taps >= ntaps zero. cs (or NULL): also store the states; x_user (or NULL): also lay
+ * out X (as gcrnn_fused_gate_prepass_pack_bf16, same contract for xs). GCRNN_ERR_UNSUPPORTED where ..._taps_supported returns 0. */
+int gcrnn_fused_gate_prepass_taps_bf16(const void* x_user, void* xs, const void* h0, const void* wpack, const float* bias,
+                                       const void* tap_frags, float* taps_out, int64_t ntaps, void* cs, const int32_t* tile_nodes,
+                                       const int32_t* tile_off, const int32_t* ell_col, const float* ell_val, const void* ell_val4,
+                                       const void* ell_col4, int64_t entries, int64_t B, int64_t T, int64_t N, int64_t F, int64_t G,
+                                       int64_t K, const int32_t* h0_zero_flag, double uniform_w, int img16, void* stream);
+int gcrnn_fused_gate_prepass_taps_supported(int64_t B, int64_t T, int64_t N, int64_t F, int64_t G, int64_t K, int64_t entries,
+                                            double uniform_w, int img16, int with_pack, int64_t ntaps);
+
 /* d loss / d (scalar time gate) of ONE filter of the time-gated cell (the gates multiply the filter outputs, graphML.py:2420-2421):
  *   sum over out[t][b][0 .. F/16*8) = sum_{f,n} ( W(S) z[t][b] + bias )[n][f] * dpre[t][b][n][f]
  * xs == NULL, G = 0: z = zs [T][B][NPad][F] bf16 sequence-major is that filter's operand (h_{t-1} for the state filter, x_t for

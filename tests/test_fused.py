@@ -1648,6 +1648,7 @@ def test_node_gated_recurrence_on_the_sequence_resident_kernel_is_bit_identical(
     h0 = torch.tensor(0.3 * rng.standard_normal((B, F, N)), dtype=torch.float32, device=dev).to(torch.bfloat16)
     tgt = torch.tensor(rng.standard_normal((B, T, F, N)), dtype=torch.float32, device=dev)
     monkeypatch.setenv('GCRNN_SEQ_MIN_B', '1')
+    monkeypatch.setenv('GCRNN_NO_FUSED_TAPS', '1')       # (the fused tap dots sum in another order: compared below, with a tolerance)
 
     def run():
         with torch.no_grad():
@@ -1671,6 +1672,32 @@ def test_node_gated_recurrence_on_the_sequence_resident_kernel_is_bit_identical(
     assert g0.keys() == g1.keys() and len(g1) >= 11
     for n in g1:
         assert torch.equal(g0[n], g1[n]), n
+    # inference with the F -> 1 filters' tap dots fused into the gate cells' pre-passes (gcrnn_fused_gate_prepass_taps_bf16): the same
+    # bf16 states times the same fp32 taps (three exact bf16 planes), summed on the matrix cores -- per-tap dot products equal to the
+    # separate pass over the stored states up to the order of the fp32 sums, states equal up to a rare bf16 rounding flip
+    from gated_gcrnns_amd import ops
+    monkeypatch.setenv('GCRNN_SEQ_KERNEL', '1')
+    monkeypatch.delenv('GCRNN_NO_FUSED_TAPS')
+    with torch.no_grad():
+        Hf = cell(X, h0)
+        Xp, wAp = ops.fused_pad_operands(X, cell.GRNN_node_in.weight_A.detach()) if hasattr(cell, 'GRNN_node_in') else (None, None)
+    d = (Hf.float() - H1.float()).abs()
+    assert float(d.max()) <= 8e-3 and float((d > 0).float().mean()) <= 1e-3, (float(d.max()), float((d > 0).float().mean()))
+    sub = cell.GRNN_node_in if hasattr(cell, 'GRNN_node_in') else None
+    if sub is not None:
+        xs = ops.to_sequence_major(Xp, cell.graph)
+        h0s = ops.to_sequence_major(h0.unsqueeze(1), cell.graph)
+        hz = ops.fused_h0_zero_flag(h0)
+        wf = cell.GFL_node_in.weight if hasattr(cell.GFL_node_in, 'weight') else cell.GFL_node_in[0].weight
+        with torch.no_grad():
+            sf = ops.fused_node_gate_taps(xs, h0s, wAp, sub.weight_B.detach(), sub.bias.detach(), wf.detach(), cell.graph, N, hzero=hz)
+            assert sf is not None
+            zl = torch.zeros((1, F * N), dtype=torch.float32, device=dev)
+            _, cs, _ = ops.fused_time_gate(xs, h0s, wAp, sub.weight_B.detach(), sub.bias.detach(), zl, None, cell.graph, N, store_states=True, hzero=hz)
+            wk = wf.detach().float().reshape(wf.shape[2], F)
+            ref = torch.einsum('tbnf,kf->tbkn', cs[:, :, :N].double(), wk.double()).reshape(T * B, wf.shape[2], 1, N)
+        err = (sf.double() - ref).abs().max().item()
+        assert err <= 2e-5 * max(1.0, ref.abs().max().item()), err
 
 
 @pytest.mark.gpu
