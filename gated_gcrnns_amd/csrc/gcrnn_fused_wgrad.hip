@@ -202,7 +202,12 @@ __global__ __launch_bounds__(512, 2) void fused_wgrad_kernel(
         LGKM_WAIT(0);
 #define GCRNN_WG_INIT(i) f32x4{0.f, 0.f, 0.f, 0.f}
 #define GCRNN_WG_STORE(i, a) cur[i] = a
-        if constexpr (UNI == 2) GCRNN_HOP_ASM_UNI16_STREAM(GCRNN_WG_INIT, GCRNN_WG_STORE);
+        if constexpr (UNI == 2) {
+          // the summing stream (tile exits cost nothing, register window 28 instead of 42): du_{k+1} = w * (sum of the gathered rows)
+          GCRNN_HOP_ASM_UNI16_SUMS_STREAM(cur);
+#pragma unroll
+          for (int i = 0; i < TILES; ++i) cur[i] *= uni_w;
+        }
         else GCRNN_HOP_ASM_UNI_STREAM(GCRNN_WG_INIT, GCRNN_WG_STORE);
 #undef GCRNN_WG_INIT
 #undef GCRNN_WG_STORE
