@@ -558,6 +558,23 @@ def secondary_points(ctx, S, params, B, steps=8, warmup=2):
     except Exception as e:      # noqa: BLE001
         sec['train_bf16'] = {'error': str(e)[:200]}
     gc.collect(); torch.cuda.empty_cache()
+    # ---- gated cells, bf16 forward (reference graphML.py:2357-2407, 2420-2423; random-init gate sub-networks of the reference's shapes) ----
+    for name, tg, sg in (('fwd_timegated', True, None), ('fwd_nodegated', False, 'node'), ('fwd_edgegated', False, 'edge')):
+        try:
+            torch.manual_seed(0)
+            c = gml.GGCRNNCell(G, F, K, K, torch.tanh, tg, sg, 1, True)
+            c.addGSO(torch.tensor(S))
+            c = c.to(dev).to(torch.bfloat16)
+            X = torch.randn(B, T, G, N, device=dev, dtype=torch.float32, generator=gen).to(torch.bfloat16)
+            h0 = torch.zeros(B, F, N, device=dev, dtype=torch.bfloat16)
+            with torch.no_grad():
+                dt = _timed(lambda: c(X, h0), 5, 2)
+            sec[name] = {'value': B / dt, 'unit': 'sequences/s', 'ms_per_step': 1e3 * dt, 'steps': 5, 'dtype': 'bf16',
+                         'what': 'GGCRNNCell(time_gating=%s, spatial_gating=%s) forward, same workload' % (tg, sg)}
+            del c, X, h0
+        except Exception as e:      # noqa: BLE001
+            sec[name] = {'error': str(e)[:200]}
+        gc.collect(); torch.cuda.empty_cache()
     return sec
 
 
