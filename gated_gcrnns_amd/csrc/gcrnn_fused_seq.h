@@ -31,6 +31,8 @@
 //         with flags[0] != 0 (h0 all zeros: every training loop of the reference, train_rnn.py:256) the state half of the
 //         operand is neither loaded nor multiplied.
 #pragma once
+#include <utility>
+#include <type_traits>
 
 // In-kernel phase stamps (diagnostic builds only, -DGCRNN_SEQ_STAMPS; tools/seq_stamps.py): wave 0 of every workgroup records
 // s_memtime at its phase boundaries into a buffer of its own that no other code reads (MI355X_MICROARCH.md, DVFS item 6).
@@ -89,6 +91,12 @@ struct SeqArgs {
                                                        // requested into the dead operand registers -- while step t still runs); 0 = 1
 };
 
+// f(integral_constant<1>), f(integral_constant<2>), ... : the hops of a chunk with compile-time indices
+template <class Fn, int... J>
+__device__ __forceinline__ void seq_static_for(Fn&& f, std::integer_sequence<int, J...>) {
+  (f(std::integral_constant<int, J + 1>{}), ...);
+}
+
 template <int K, int HS, int XS, int MODE, bool GATED = false>
 __global__ __launch_bounds__(STHREADS) void fused_seq_kernel(const SeqArgs a) {
   constexpr int KS = HS + XS;
@@ -96,7 +104,13 @@ __global__ __launch_bounds__(STHREADS) void fused_seq_kernel(const SeqArgs a) {
   constexpr int NCH = F / FC;
   constexpr int HT = STILES;
   constexpr int PKROWS = (MODE == 0 || MODE == 1) ? G : F;
-  constexpr int IMG = 33 * 1024;                 // bf16 hop image [NP][16] (32 KB); the transposed output tile needs 8 x 4128 B
+  // LDS map: [0, 33792) hop image A [NP][16] bf16 (32 KB) / the transposed output tile (8 x 4128 B), bias at 33024, flags and stamps at 33280;
+  // [33792, 66560) hop image B = the inline-pack tile (free during the hops that read it: see the hop loop); then 2 x WB weight fragments,
+  // the column words, MODE 1's tap accumulators. The hops alternate between the two images: a wave writes its tiles of hop j into the
+  // image hop j + 1 reads as soon as ITS stream is done, and one barrier per hop hands over (one image needs two: done reading, done writing)
+  constexpr int IMGB = GCRNN_HOP_IMAGE_B_OFFSET;
+  constexpr int IMG = IMGB + 32 * 1024;          // end of the two images = start of the weight fragments
+  static_assert(IMGB >= 33 * 1024 && IMGB % 1024 == 0, "image B sits behind image A / the transposed tile (33024 B) / bias (256 B) / flags and stamps (512 B)");
   constexpr int WB = K * KS * 1024;              // one chunk's weight fragments
   static_assert(STILES == 8 && GCRNN_HOP_ASM, "generated hop stream: 8 tiles per wave");
   static_assert((MODE == 0 || MODE == 1) ? XS > 0 : ((MODE == 2 || MODE == 5) ? XS == 0 : MODE == 4), "forward / pre-pass take [h | x], the BPTT and the node-gated step their one operand, the filter-output pass either");
@@ -105,7 +119,7 @@ __global__ __launch_bounds__(STHREADS) void fused_seq_kernel(const SeqArgs a) {
   float* state = reinterpret_cast<float*>(smem);
   const int entries = a.entries, B = a.B, N = a.N;
   const float uni_w = a.uni_w;
-  char* xtile = smem + IMG + 2 * WB + entries * 32;
+  char* xtile = smem + IMGB;
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -293,13 +307,16 @@ __global__ __launch_bounds__(STHREADS) void fused_seq_kernel(const SeqArgs a) {
     };
     auto taps = [&](int tap, int c) { taps_to(tap, c, u); };
     // seed of chunk c: tap K-1 goes straight into the hop image (every wave has left the image: the barrier before)
+    // hop j (1 .. K-1) reads image B when K - 1 - j is odd: the LAST hop always reads image A, because the inline-pack tile (= image B)
+    // is filled by LDS-DMA during it; the seed goes into the image hop 1 reads
+    constexpr bool SEED_B = ((K - 2) & 1) != 0;
     auto seed = [&](int c) {
       taps(K - 1, c);
 #pragma unroll
       for (int i = 0; i < STILES; ++i) {
         int wv = woff[i];
         asm volatile("" : "+v"(wv));
-        state_put<true>(state, wv, u[i]);
+        state_put<true>(reinterpret_cast<float*>(smem + (SEED_B ? IMGB : 0)), wv, u[i]);
       }
     };
     seed(0);
@@ -341,14 +358,8 @@ __global__ __launch_bounds__(STHREADS) void fused_seq_kernel(const SeqArgs a) {
 
       u32x2 eph[MODE == 2 ? STILES : 1], epg[(MODE == 2 || MODE == 5) ? STILES : 1];
       // ---- Horner hops on the bf16 image; the tap a hop adds is evaluated from the resident operand right before it -------------
-#pragma unroll
-      for (int j = 1; j < K; ++j) {
-#ifdef GCRNN_SEQ_STREAM_ACCUMULATES      // A/B: round 2's stream (acc += w sum at every tile exit), the tap evaluated before it
-#ifdef GCRNN_SEQ_TAPS_AFTER      // A/B (measured: 107.2k vs 107.6k seq/s, no gain, profiles/r03_taps_after_ab.txt): the tap of hop j + 1 evaluated right after hop j's stream
-        if (j == 1)
-#endif
-        taps(K - 1 - j, chunk);
-#endif
+      auto hop = [&](auto jc) __attribute__((always_inline)) {
+        constexpr int j = decltype(jc)::value;      // (a compile-time hop index: which image it reads is part of the stream's text)
         GCRNN_STAMP(2 + chunk * 14 + 2 * j - 1);
         if constexpr (MODE == 5) {
           // Yx_t = A(S)x_t + b of the all-items pass, this lane's (node, 4 features) per tile: spread over the hops like the chain's operands
@@ -432,18 +443,12 @@ __global__ __launch_bounds__(STHREADS) void fused_seq_kernel(const SeqArgs a) {
             }
           }
         }
-#ifdef GCRNN_SEQ_STREAM_ACCUMULATES
-#define GCRNN_SEQ_INIT(i) u[i]
-#define GCRNN_SEQ_STORE(i, a_) u[i] = a_
-        GCRNN_HOP_ASM_UNI16_STREAM(GCRNN_SEQ_INIT, GCRNN_SEQ_STORE);
-#undef GCRNN_SEQ_INIT
-#undef GCRNN_SEQ_STORE
-#else
         // the stream only sums the gathered rows of every tile (its exits then cost nothing); the tap this hop adds is evaluated from the
         // resident operand after it, and acc = tap + w * sum is the same fused multiply-add the accumulating stream applies per tile
+        constexpr bool READ_B = ((K - 1 - j) & 1) != 0;          // (j is a compile-time constant: the loop is unrolled)
         {
           f32x4 dsum[STILES];
-          GCRNN_HOP_ASM_UNI16_SUMS_STREAM(dsum);
+          GCRNN_HOP_ASM_UNI16_SUMS_STREAM_IMG(dsum, READ_B);
           taps(K - 1 - j, chunk);
           const f32x2 w2 = f32x2{uni_w, uni_w};
 #pragma unroll
@@ -453,29 +458,20 @@ __global__ __launch_bounds__(STHREADS) void fused_seq_kernel(const SeqArgs a) {
             u[i] = f32x4{lo[0], lo[1], hi[0], hi[1]};
           }
         }
-#endif
         GCRNN_STAMP(2 + chunk * 14 + 2 * j);
         if (j < K - 1) {
-#ifdef GCRNN_SEQ_TAPS_AFTER
-          // the next hop's tap, from the resident operand, while the slower waves still stream: a wave that arrives early runs its 32
-          // MFMAs beside other waves' LDS gathers instead of all eight waves queueing on the matrix pipes after the barrier
-          f32x4 un[STILES];
-          taps_to(K - 2 - j, chunk, un);
-#endif
-          lds_barrier();
+          // write-back into the OTHER image (nobody reads it during this hop: its last readers passed the previous barrier), then the
+          // hop's one barrier: every wave's rows are in, every wave has left the image just read
 #pragma unroll
           for (int i = 0; i < STILES; ++i) {
             int wv = woff[i];
             asm volatile("" : "+v"(wv));
-            state_put<true>(state, wv, u[i]);
+            state_put<true>(reinterpret_cast<float*>(smem + (READ_B ? 0 : IMGB)), wv, u[i]);
           }
           lds_barrier();
-#ifdef GCRNN_SEQ_TAPS_AFTER
-#pragma unroll
-          for (int i = 0; i < STILES; ++i) u[i] = un[i];
-#endif
         }
-      }
+      };
+      seq_static_for(hop, std::make_integer_sequence<int, K - 1>{});
       // the LDS-DMA pieces (next weights, inline-pack tile) have had the last hop to land; wait before the epilogue's barriers
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       GCRNN_STAMP(2 + chunk * 14 + 9);
@@ -786,9 +782,8 @@ __global__ __launch_bounds__(STHREADS) void fused_seq_kernel(const SeqArgs a) {
 
 // LDS bytes of the sequence-resident kernel, or 0 when the problem does not fit
 template <int K, int HS, int XS>
-static size_t fused_seq_lds(int64_t entries, bool inline_pack, int pkrows, size_t extra = 0) {
-  const size_t need = (size_t)33 * 1024 + 2 * (size_t)K * (HS + XS) * 1024 + (size_t)entries * 32 +
-                      (inline_pack ? (size_t)pkrows * (NP / (32 * HS / FC)) * 2 : 0) + extra;
+static size_t fused_seq_lds(int64_t entries, bool /*inline_pack: its tile is the second hop image*/, int /*pkrows*/, size_t extra = 0) {
+  const size_t need = (size_t)GCRNN_HOP_IMAGE_B_OFFSET + 32 * 1024 + 2 * (size_t)K * (HS + XS) * 1024 + (size_t)entries * 32 + extra;
   return need <= 160 * 1024 ? need : 0;
 }
 

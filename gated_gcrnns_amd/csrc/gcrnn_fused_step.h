@@ -340,31 +340,33 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 // the caller applies acc = init + w * D afterwards. A tile exit only switches tiles -- the per-tile matrix-core -> VALU wait states,
 // packed FMAs and re-zeroing of the stream above are gone (they cost 6.5 % of the forward launch: tools/hop16_exit_experiment.sh).
 // Used by the sequence-resident kernel, whose taps are evaluated per hop anyway (gcrnn_fused_seq.h).
-#define GCRNN_HOP_ASM_UNI16_SUMS_STREAM(D)                                                         \
+#define GCRNN_HOP_ASM_UNI16_SUMS_STREAM(D) GCRNN_HOP_ASM_UNI16_SUMS_STREAM_IMG(D, false)
+// IMGB_ (compile-time): the gathers read the second hop image, GCRNN_HOP_IMAGE_B_OFFSET bytes behind the first (sequence-resident kernel)
+#define GCRNN_HOP_ASM_UNI16_SUMS_ASM_(TEXT_, CLOB_, ...)                                           \
+        asm volatile(TEXT_                                                                         \
+                     : "+v"(D_[0]), "+v"(D_[1]), "+v"(D_[2]), "+v"(D_[3]), "+v"(D_[4]), "+v"(D_[5]), "+v"(D_[6]), "+v"(D_[7])  \
+                     : "s"(GCRNN_SGPR(tend[0] >> 2)), "s"(GCRNN_SGPR(tend[1] >> 2)), "s"(GCRNN_SGPR(tend[2] >> 2)), "s"(GCRNN_SGPR(tend[3] >> 2)), "s"(GCRNN_SGPR(tend[4] >> 2)), \
+                       "s"(GCRNN_SGPR(tend[5] >> 2)), "s"(GCRNN_SGPR(tend[6] >> 2)), "s"(GCRNN_SGPR(tend[7] >> 2)), "s"(GCRNN_SGPR(gwbeg)), "s"(GCRNN_SGPR(gwend - 1)), "v"(colb), "v"(qh_) __VA_ARGS__ \
+                     : CLOB_)
+#define GCRNN_HOP_ASM_UNI16_SUMS_STREAM_IMG(D, IMGB_)                                              \
   do {                                                                                             \
     static_assert(HT == 8, "the asm hop stream is generated for 8 tiles per wave");                \
     const int gwbeg = tbeg[0] >> 2, gwend = tend[HT - 1] >> 2;                                      \
-    _Pragma("unroll") for (int i = 0; i < 8; ++i) D[i] = f32x4{0.f, 0.f, 0.f, 0.f};               \
+    f32x4 (&D_)[8] = D;                                                                            \
+    _Pragma("unroll") for (int i = 0; i < 8; ++i) D_[i] = f32x4{0.f, 0.f, 0.f, 0.f};              \
     if (gwbeg < gwend) {                                                                           \
       typedef __attribute__((__vector_size__(4 * sizeof(unsigned int)))) unsigned int u32x4a_;     \
       const uint32_t colb = lds_col + r * 8 + (q >> 1) * 4;       /* this lane's own column dword of a slot's pair */ \
       const uint32_t qh_ = (uint32_t)(q & 1) << 4;                                                 \
       if constexpr (GCRNN_HOP16_SPARSE) {                                                          \
-        asm volatile(GCRNN_HOP_ASM_UNI16_SUMS_SPARSE_TEXT                                          \
-                     : "+v"(D[0]), "+v"(D[1]), "+v"(D[2]), "+v"(D[3]), "+v"(D[4]), "+v"(D[5]), "+v"(D[6]), "+v"(D[7])  \
-                     : "s"(GCRNN_SGPR(tend[0] >> 2)), "s"(GCRNN_SGPR(tend[1] >> 2)), "s"(GCRNN_SGPR(tend[2] >> 2)), "s"(GCRNN_SGPR(tend[3] >> 2)), "s"(GCRNN_SGPR(tend[4] >> 2)), \
-                       "s"(GCRNN_SGPR(tend[5] >> 2)), "s"(GCRNN_SGPR(tend[6] >> 2)), "s"(GCRNN_SGPR(tend[7] >> 2)), "s"(GCRNN_SGPR(gwbeg)), "s"(GCRNN_SGPR(gwend - 1)), "v"(colb), "v"(qh_) \
-                     : GCRNN_HOP_ASM_UNI16_SUMS_SPARSE_CLOBBERS);                                   \
+        if constexpr (IMGB_) GCRNN_HOP_ASM_UNI16_SUMS_ASM_(GCRNN_HOP_ASM_UNI16_SUMS_SPARSE_TEXT_B, GCRNN_HOP_ASM_UNI16_SUMS_SPARSE_CLOBBERS);   \
+        else GCRNN_HOP_ASM_UNI16_SUMS_ASM_(GCRNN_HOP_ASM_UNI16_SUMS_SPARSE_TEXT, GCRNN_HOP_ASM_UNI16_SUMS_SPARSE_CLOBBERS);                     \
       } else {                                                                                     \
         const int hit_ = ((r >> 3) == (q & 1)) ? (r & 7) : 8;     /* position of this lane's 1.0 among its 8 A elements, or none */ \
         const uint32_t one_ = (hit_ & 1) ? 0x3f800000u : 0x00003f80u;                              \
         u32x4a_ aop_ = {(hit_ >> 1) == 0 ? one_ : 0u, (hit_ >> 1) == 1 ? one_ : 0u, (hit_ >> 1) == 2 ? one_ : 0u, (hit_ >> 1) == 3 ? one_ : 0u}; \
-        asm volatile(GCRNN_HOP_ASM_UNI16_SUMS_TEXT                                                 \
-                     : "+v"(D[0]), "+v"(D[1]), "+v"(D[2]), "+v"(D[3]), "+v"(D[4]), "+v"(D[5]), "+v"(D[6]), "+v"(D[7])  \
-                     : "s"(GCRNN_SGPR(tend[0] >> 2)), "s"(GCRNN_SGPR(tend[1] >> 2)), "s"(GCRNN_SGPR(tend[2] >> 2)), "s"(GCRNN_SGPR(tend[3] >> 2)), "s"(GCRNN_SGPR(tend[4] >> 2)), \
-                       "s"(GCRNN_SGPR(tend[5] >> 2)), "s"(GCRNN_SGPR(tend[6] >> 2)), "s"(GCRNN_SGPR(tend[7] >> 2)), "s"(GCRNN_SGPR(gwbeg)), "s"(GCRNN_SGPR(gwend - 1)), "v"(colb), "v"(qh_), \
-                       "v"(aop_)                                                                   \
-                     : GCRNN_HOP_ASM_UNI16_SUMS_CLOBBERS);                                          \
+        if constexpr (IMGB_) GCRNN_HOP_ASM_UNI16_SUMS_ASM_(GCRNN_HOP_ASM_UNI16_SUMS_TEXT_B, GCRNN_HOP_ASM_UNI16_SUMS_CLOBBERS, , "v"(aop_));     \
+        else GCRNN_HOP_ASM_UNI16_SUMS_ASM_(GCRNN_HOP_ASM_UNI16_SUMS_TEXT, GCRNN_HOP_ASM_UNI16_SUMS_CLOBBERS, , "v"(aop_));                       \
       }                                                                                            \
     }                                                                                              \
   } while (0)

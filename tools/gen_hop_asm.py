@@ -237,6 +237,7 @@ def VXa(p, e):
     return 'v%d' % (UB16 + 8 * p + 4 * e)
 
 
+IMGOFF = 0          # LDS byte offset of the hop image the gathers read (the summing variants have a second image: gen_uniform16(img_off=..))
 VCOFF = 24          # column-word slots behind three gather sets (the summing variants pack their window: 8 D)
 
 
@@ -256,7 +257,7 @@ def vs1(q, lines):
         lines.append('v_xor_b32_sdwa %s, %s, %s dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_%d src1_sel:DWORD'
                      % (VXa(q, e), VC(q), UQX, e))
     for e in range(2):
-        lines.append('ds_read_b128 %s, %s' % (VX(q, e), VXa(q, e)))
+        lines.append('ds_read_b128 %s, %s' % (VX(q, e), VXa(q, e)) + (' offset:%d' % IMGOFF if IMGOFF else ''))
 
 
 def vs0(q, goff, lines):      # the lane's OWN column dword of group g + goff (column base operand = base + 8 r + 4 (q >> 1))
@@ -268,12 +269,13 @@ def vs0p(q, lines):            # steady state: the same read through the running
     lines += ['v_min_u32 %s, %s, %s' % (VCA, VP5, VPCL), 'ds_read_b32 %s, %s' % (VC(q), VCA), 'v_add_u32 %s, 128, %s' % (VP5, VP5)]
 
 
+IMAGE_B_OFFSET = 33792      # second hop image of the sequence-resident kernel: behind image A / the transposed tile / bias / flags (gcrnn_fused_seq.h LDS map)
 SUMS_D = int(os.environ.get('GCRNN_HOP16_SUMS_DEPTH', '2'))      # groups in flight of the summing variants (2 and 3 measured equal: profiles/r03_hop16_depth_ab.txt)
 SUMS_UB16 = (254 - (9 * SUMS_D + 3)) & ~1                        # their packed register window v[SUMS_UB16:253] (even base: the 8-register B tuples) ...
 SUMS_SPA = SUMS_UB16 - 6                                         # ... sparse: v[SUMS_SPA:253]
 
 
-def gen_uniform16(sparse=False, sums=False):
+def gen_uniform16(sparse=False, sums=False, img_off=0):
     """sums: the stream only SUMS -- tile t's gathered rows go straight into its own accumulator tuple (operand %t, zeroed by the caller),
     the caller applies acc = init + w * sum after the block. A tile exit then only switches tiles: no matrix-core -> VALU wait states, no
     packed FMAs, no re-zeroing per tile (timing experiment GCRNN_HOP16_EXPERIMENT_CHEAP_EXIT: the exits cost 6.5 % of the launch). Operands:
@@ -288,8 +290,9 @@ def gen_uniform16(sparse=False, sums=False):
     D = SUMS_D if sums else VD
     assert 2 <= D <= 3      # (the register window holds three gather sets; 2 / 3 / 4 / 5 sets measured equal)
     SC = 's90'                                # (group - tile end) of the current tile, counted up: the carry of its increment ends the tile
-    global COLB, GBEG, GLAST, UQX, UB16, SPA, VCOFF, VCA, VP5, VPCL
+    global COLB, GBEG, GLAST, UQX, UB16, SPA, VCOFF, VCA, VP5, VPCL, IMGOFF
     saved = (COLB, GBEG, GLAST, UQX, UB16, SPA, VCOFF, VCA, VP5, VPCL)
+    IMGOFF = img_off
     TEND0, AOP = 16, '%29'
     if sums:
         GBEG, GLAST, COLB, UQX, TEND0, AOP = '%16', '%17', '%18', '%19', 8, '%20'
@@ -368,6 +371,7 @@ def gen_uniform16(sparse=False, sums=False):
     if sums:                                                      # matrix-core results -> the caller's VALU reads: once per block (16-pass distance)
         L += ['s_nop 15', 's_nop 7']
     COLB, GBEG, GLAST, UQX, UB16, SPA, VCOFF, VCA, VP5, VPCL = saved
+    IMGOFF = 0
     return L
 
 
@@ -392,6 +396,10 @@ def main():
     emit('GCRNN_HOP_ASM_UNI16_SPARSE_TEXT', gen_uniform16(sparse=True))
     emit('GCRNN_HOP_ASM_UNI16_SUMS_TEXT', gen_uniform16(sparse=False, sums=True))
     emit('GCRNN_HOP_ASM_UNI16_SUMS_SPARSE_TEXT', gen_uniform16(sparse=True, sums=True))
+    # the same two reading the SECOND hop image (sequence-resident kernel: hops alternate between two images, one barrier per hop)
+    print('#define GCRNN_HOP_IMAGE_B_OFFSET %d' % IMAGE_B_OFFSET)
+    emit('GCRNN_HOP_ASM_UNI16_SUMS_TEXT_B', gen_uniform16(sparse=False, sums=True, img_off=IMAGE_B_OFFSET))
+    emit('GCRNN_HOP_ASM_UNI16_SUMS_SPARSE_TEXT_B', gen_uniform16(sparse=True, sums=True, img_off=IMAGE_B_OFFSET))
     regs = ', '.join('"v%d"' % r for r in range(UB, UB + 60))
     print('#define GCRNN_HOP_ASM_UNI_CLOBBERS %s, "s88", "s89", "s90", "scc", "memory"' % regs)
     regs16 = ', '.join('"v%d"' % r for r in range(UB16, UB16 + 36))
