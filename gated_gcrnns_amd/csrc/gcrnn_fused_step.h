@@ -341,6 +341,11 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 // packed FMAs and re-zeroing of the stream above are gone (they cost 6.5 % of the forward launch: tools/hop16_exit_experiment.sh).
 // Used by the sequence-resident kernel, whose taps are evaluated per hop anyway (gcrnn_fused_seq.h).
 #define GCRNN_HOP_ASM_UNI16_SUMS_STREAM(D) GCRNN_HOP_ASM_UNI16_SUMS_STREAM_IMG(D, false)
+// timing experiment (WRONG results): -DGCRNN_EXPERIMENT_STREAM_WAVES="&& (wave & 1) == 0" lets only some waves stream -- does a wave's
+// trip time depend on how many other waves gather? (tools/ab_build.sh)
+#ifndef GCRNN_EXPERIMENT_STREAM_WAVES
+#define GCRNN_EXPERIMENT_STREAM_WAVES
+#endif
 // IMGB_ (compile-time): the gathers read the second hop image, GCRNN_HOP_IMAGE_B_OFFSET bytes behind the first (sequence-resident kernel)
 #define GCRNN_HOP_ASM_UNI16_SUMS_ASM_(TEXT_, CLOB_, ...)                                           \
         asm volatile(TEXT_                                                                         \
@@ -354,7 +359,7 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
     const int gwbeg = tbeg[0] >> 2, gwend = tend[HT - 1] >> 2;                                      \
     f32x4 (&D_)[8] = D;                                                                            \
     _Pragma("unroll") for (int i = 0; i < 8; ++i) D_[i] = f32x4{0.f, 0.f, 0.f, 0.f};              \
-    if (gwbeg < gwend) {                                                                           \
+    if (gwbeg < gwend GCRNN_EXPERIMENT_STREAM_WAVES) {                                             \
       typedef __attribute__((__vector_size__(4 * sizeof(unsigned int)))) unsigned int u32x4a_;     \
       const uint32_t colb = lds_col + r * 8 + (q >> 1) * 4;       /* this lane's own column dword of a slot's pair */ \
       const uint32_t qh_ = (uint32_t)(q & 1) << 4;                                                 \

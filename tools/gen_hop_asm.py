@@ -300,6 +300,9 @@ def gen_uniform16(sparse=False, sums=False, img_off=0):
         UB16, SPA, VCOFF = SUMS_UB16, SUMS_SPA, 8 * D
         VP5, VPCL, VCA = 'v%d' % (UB16 + 9 * D), 'v%d' % (UB16 + 9 * D + 1), 'v%d' % (UB16 + 9 * D + 2)
     L = ['s_mov_b32 %s, %s' % (SG, GBEG)]
+    if sums:                                  # the first column words are requested before the A operand is built: its ~25 VALU instructions cover their latency
+        for p in range(D):
+            vs0(p, p, L)
     if sparse:
         A0, IDX, TMP = SPA, SPA + 4, SPA + 5
         vM, vP, vVal, vNib = 'v%d' % A0, 'v%d' % (A0 + 1), 'v%d' % (A0 + 2), 'v%d' % (A0 + 3)      # temporaries first live in the A registers
@@ -325,8 +328,9 @@ def gen_uniform16(sparse=False, sums=False, img_off=0):
     if not sums:
         for r in range(4):
             L.append('v_mov_b32 v%d, 0' % (VSUMB[0] + r))
-    for p in range(D):
-        vs0(p, p, L)
+    if not sums:
+        for p in range(D):
+            vs0(p, p, L)
     L.append('s_waitcnt lgkmcnt(0)')
     for p in range(D - 1):                    # gathers of groups 0 .. D-2; their column slots take groups D .. 2D-2
         vs1(p, L); vs0(p, D + p, L)
@@ -342,9 +346,10 @@ def gen_uniform16(sparse=False, sums=False, img_off=0):
             q = (p + D - 1) % D
             vs1(q, L)                                             # (the set's registers were B operands of the PREVIOUS trip's MFMAs: read long ago)
             vs0p(q, L)
-            L.append('s_waitcnt lgkmcnt(%d)' % (3 * (D - 1)))
+            if not os.environ.get('GCRNN_HOP16_EXPERIMENT_NO_WAIT'):      # (timing experiments, wrong results: where does a trip stall?)
+                L.append('s_waitcnt lgkmcnt(%d)' % (3 * (D - 1)))
             acc = ('%%%d' % t) if sums else VSUM4[0]
-            if sparse:
+            if sparse and not os.environ.get('GCRNN_HOP16_EXPERIMENT_NO_MFMA'):
                 L.append('v_smfmac_f32_16x16x64_bf16 %s, v[%d:%d], v[%d:%d], v%d' % (acc, SPA, SPA + 3, UB16 + 8 * p, UB16 + 8 * p + 7, SPA + 4))
             for e in range(0 if sparse else (1 if os.environ.get('GCRNN_HOP16_EXPERIMENT_ONE_MFMA') else 2)):      # (timing experiment, wrong results: what would ONE
                 # matrix instruction per four entries -- a 2:4-sparse v_smfmac_f32_16x16x64_bf16 with the one-hot A -- buy?)
@@ -367,9 +372,9 @@ def gen_uniform16(sparse=False, sums=False, img_off=0):
             L.append('s_branch L_T%d_P%d_%%=' % (t + 1, p))
     for p in range(D):
         L.append('L_T%d_P%d_%%=:' % (NT, p))
+    if sums:                                                      # matrix-core results -> the caller's VALU reads: once per block (16-pass distance),
+        L += ['s_nop 15', 's_nop 7']                              # while the last (unused, clamped) gathers drain
     L.append('s_waitcnt lgkmcnt(0)')
-    if sums:                                                      # matrix-core results -> the caller's VALU reads: once per block (16-pass distance)
-        L += ['s_nop 15', 's_nop 7']
     COLB, GBEG, GLAST, UQX, UB16, SPA, VCOFF, VCA, VP5, VPCL = saved
     IMGOFF = 0
     return L

@@ -7,7 +7,7 @@ R = os.environ.get('GRAFT_REPO_ROOT', os.path.dirname(os.path.dirname(os.path.ab
 C = os.path.join(R, 'gated_gcrnns_amd', 'csrc')
 out = '/tmp/seqst'
 os.makedirs(out, exist_ok=True)
-if os.environ.get('GCRNN_HOP16_EXPERIMENT_ONE_MFMA'):      # timing experiment (wrong results): regenerate the stream into a private include directory
+if any(k.startswith('GCRNN_HOP16_') for k in os.environ):      # timing experiments (wrong results) / generator switches: regenerate the stream into a private include directory
     inc = os.path.join(out, 'inc')
     os.makedirs(inc, exist_ok=True)
     for f in glob.glob(C + '/*'):
