@@ -253,11 +253,16 @@ VSUMH = [['v[%d:%d]' % (b_, b_ + 1), 'v[%d:%d]' % (b_ + 2, b_ + 3)] for b_ in VS
 
 
 def vs1(q, lines):
+    X = os.environ.get('GCRNN_HOP16_EXPERIMENT_TRIP', '')      # timing experiments (wrong results): which of a trip's instructions cost its time?
     for e in range(2):
-        lines.append('v_xor_b32_sdwa %s, %s, %s dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_%d src1_sel:DWORD'
-                     % (VXa(q, e), VC(q), UQX, e))
+        if 'plainxor' in X:                                    # a plain VALU op instead of the SDWA one (in-range, aligned, wrong addresses)
+            lines.append('v_and_b32 %s, 0x7ff0, %s' % (VXa(q, e), VC(q)))
+        elif 'noxor' not in X:
+            lines.append('v_xor_b32_sdwa %s, %s, %s dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_%d src1_sel:DWORD'
+                         % (VXa(q, e), VC(q), UQX, e))
     for e in range(2):
-        lines.append('ds_read_b128 %s, %s' % (VX(q, e), VXa(q, e)) + (' offset:%d' % IMGOFF if IMGOFF else ''))
+        if 'nogather' not in X:
+            lines.append('ds_read_b128 %s, %s' % (VX(q, e), (VXa(q, e) if 'noxor' not in X else VPCL)) + (' offset:%d' % IMGOFF if IMGOFF else ''))
 
 
 def vs0(q, goff, lines):      # the lane's OWN column dword of group g + goff (column base operand = base + 8 r + 4 (q >> 1))
@@ -266,6 +271,8 @@ def vs0(q, goff, lines):      # the lane's OWN column dword of group g + goff (c
 
 
 def vs0p(q, lines):            # steady state: the same read through the running pointer -- no scalar arithmetic in the trip
+    if 'nocol' in os.environ.get('GCRNN_HOP16_EXPERIMENT_TRIP', ''):
+        return
     lines += ['v_min_u32 %s, %s, %s' % (VCA, VP5, VPCL), 'ds_read_b32 %s, %s' % (VC(q), VCA), 'v_add_u32 %s, 128, %s' % (VP5, VP5)]
 
 
@@ -343,6 +350,10 @@ def gen_uniform16(sparse=False, sums=False, img_off=0):
             p = pp % D
             L.append('L_T%d_P%d_%%=:' % (t, pp))
             L.append('s_cbranch_scc1 L_X%d_P%d_%%=' % (t, p))
+            if sums and not os.environ.get('GCRNN_HOP16_COUNTER_LAST'):
+                # the counter's increment right behind the branch that consumed its carry: the next trip's branch then finds SCC long settled
+                # (at the end of the trip the scalar result -> branch latency was exposed every trip; nothing in between writes SCC)
+                L.append('s_add_u32 %s, %s, 1' % (SC, SC))
             q = (p + D - 1) % D
             vs1(q, L)                                             # (the set's registers were B operands of the PREVIOUS trip's MFMAs: read long ago)
             vs0p(q, L)
@@ -355,7 +366,8 @@ def gen_uniform16(sparse=False, sums=False, img_off=0):
                 # matrix instruction per four entries -- a 2:4-sparse v_smfmac_f32_16x16x64_bf16 with the one-hot A -- buy?)
                 # one accumulator (two, so that an MFMA never waits for its predecessor: slower, the exits pay more)
                 L.append('v_mfma_f32_16x16x32_bf16 %s, %s, %s, %s' % (acc, AOP, VX(p, e), acc))
-            L.append('s_add_u32 %s, %s, 1' % (SC, SC))            # SCC = carry = this was the tile's last group
+            if not sums or os.environ.get('GCRNN_HOP16_COUNTER_LAST'):
+                L.append('s_add_u32 %s, %s, 1' % (SC, SC))        # SCC = carry = this was the tile's last group
         L.append('s_branch L_T%d_P0_%%=' % t)
         for p in range(D):                    # leaving tile t in phase p: acc_t += w * sum, sum = 0
             L.append('L_X%d_P%d_%%=:' % (t, p))
