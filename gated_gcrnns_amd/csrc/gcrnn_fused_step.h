@@ -345,6 +345,8 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 // trip time depend on how many other waves gather? (tools/ab_build.sh)
 #ifndef GCRNN_EXPERIMENT_STREAM_WAVES
 #define GCRNN_EXPERIMENT_STREAM_WAVES
+#elif !defined(GCRNN_SEQ_STAMPS)
+#error "GCRNN_EXPERIMENT_STREAM_WAVES gives wrong results by construction: diagnostic stamp builds (tools/seq_stamps.py) only"
 #endif
 // IMGB_ (compile-time): the gathers read the second hop image, GCRNN_HOP_IMAGE_B_OFFSET bytes behind the first (sequence-resident kernel)
 #define GCRNN_HOP_ASM_UNI16_SUMS_ASM_(TEXT_, CLOB_, ...)                                           \
