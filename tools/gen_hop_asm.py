@@ -355,8 +355,15 @@ def gen_uniform16(sparse=False, sums=False, img_off=0):
                 # (at the end of the trip the scalar result -> branch latency was exposed every trip; nothing in between writes SCC)
                 L.append('s_add_u32 %s, %s, 1' % (SC, SC))
             q = (p + D - 1) % D
-            vs1(q, L)                                             # (the set's registers were B operands of the PREVIOUS trip's MFMAs: read long ago)
-            vs0p(q, L)
+            if sums and os.environ.get('GCRNN_HOP16_TRIP_ORDER_SPREAD') and not os.environ.get('GCRNN_HOP16_EXPERIMENT_TRIP'):      # (A/B: 116.3-116.5k vs 116.0-117.4k seq/s, no gain: profiles/r03_hop16_trip_order_ab.txt)
+                # the same seven instructions with no instruction right behind the one it depends on (in-order issue: a gather behind its
+                # address XOR, the column read behind its clamp, each waited for the VALU result): clamp, XORs, column read, pointer, gathers
+                a_, b_ = [], []
+                vs1(q, a_); vs0p(q, b_)                           # a_ = xor, xor, gather, gather; b_ = v_min, ds_read_b32, v_add
+                L += [b_[0], a_[0], a_[1], b_[1], b_[2], a_[2], a_[3]]
+            else:
+                vs1(q, L)                                         # (the set's registers were B operands of the PREVIOUS trip's MFMAs: read long ago)
+                vs0p(q, L)
             if not os.environ.get('GCRNN_HOP16_EXPERIMENT_NO_WAIT'):      # (timing experiments, wrong results: where does a trip stall?)
                 L.append('s_waitcnt lgkmcnt(%d)' % (3 * (D - 1)))
             acc = ('%%%d' % t) if sums else VSUM4[0]
