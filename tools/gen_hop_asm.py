@@ -350,6 +350,10 @@ def gen_uniform16(sparse=False, sums=False, img_off=0):
             p = pp % D
             L.append('L_T%d_P%d_%%=:' % (t, pp))
             L.append('s_cbranch_scc1 L_X%d_P%d_%%=' % (t, p))
+            for _ in range(int(os.environ.get('GCRNN_HOP16_EXPERIMENT_EXTRA_BRANCHES', '0'))):      # (timing experiment: what does a not-taken branch cost? ~6 cycles)
+                L.append('s_cbranch_scc1 L_X%d_P%d_%%=' % (t, p))
+            for _ in range(int(os.environ.get('GCRNN_HOP16_EXPERIMENT_EXTRA_SALU', '0'))):          # (... and a scalar instruction? ~3 cycles)
+                L.append('s_mov_b32 s89, s88')
             if sums and not os.environ.get('GCRNN_HOP16_COUNTER_LAST'):
                 # the counter's increment right behind the branch that consumed its carry: the next trip's branch then finds SCC long settled
                 # (at the end of the trip the scalar result -> branch latency was exposed every trip; nothing in between writes SCC)

@@ -34,7 +34,9 @@ dev = torch.device('cuda:0')
 N, K, T, F, B = 1000, 5, 32, 64, 256
 torch.manual_seed(0)
 cell = gml.GGCRNNCell(F, F, K, K, torch.tanh, False, None, 1, True)
-cell.addGSO(torch.tensor(bench.sbm_graph(N)))
+_dens = float(os.environ.get('GCRNN_STAMP_DENSITY', '1'))      # scales the graph's edge probabilities (stream time vs trips per hop)
+cell.addGSO(torch.tensor(bench.sbm_graph(N, p_in=0.04 * _dens, p_out=0.0025 * _dens)))
+print('graph: density x%g, ELL entries %d (trips per hop and wave = entries / 32)' % (_dens, cell.graph.fused_plan()['entries']))
 cell = cell.to(torch.bfloat16).to(dev)
 X = torch.randn(B, T, F, N, device=dev).to(torch.bfloat16)
 h0 = torch.zeros(B, F, N, device=dev, dtype=torch.bfloat16)
