@@ -95,7 +95,11 @@ __global__ __launch_bounds__(512, 2) void fused_wgrad_kernel(
     // The fragments of nodes 0..511 stay in registers across the taps; those of nodes 512..1023 are re-fetched per tap
     // (L2-resident after the first tap) through registers that the hop pipeline has just released -- the kernel must
     // stay spill-free: a spilled destination of an in-flight asm ds_read would be saved before its data lands.
-    bf16x8 bfr[16];
+#ifndef GCRNN_WGRAD_Z_RESIDENT
+#define GCRNN_WGRAD_Z_RESIDENT 1      // UNI == 2: all 32 fragments of z stay in registers for the item (the summing stream's window is 28 registers, not 60)
+#endif
+    constexpr bool ZRES = (UNI == 2) && GCRNN_WGRAD_Z_RESIDENT;
+    bf16x8 bfr[ZRES ? 32 : 16];
     const uint16_t* zsrc;
     int zrows;
     float gcur = gprev;
@@ -114,7 +118,7 @@ __global__ __launch_bounds__(512, 2) void fused_wgrad_kernel(
     const __amdgpu_buffer_rsrc_t rsrc_z = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(zsrc), 0, live ? zrows * N * 2 : 0, 0x00020000);      // dead waves: zero-length buffer, the loads cost nothing
     const int vo = (jrow * N + 8 * q) * 2;
 #pragma unroll
-    for (int s2 = 0; s2 < 16; ++s2)
+    for (int s2 = 0; s2 < (ZRES ? 32 : 16); ++s2)
       bfr[s2] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsrc_z, vo + 64 * s2, 0, 0));
     // ---- du_0 = dpre chunk of this item ------------------------------------------------------------------------
     f32x4 cur[TILES];
@@ -158,10 +162,12 @@ __global__ __launch_bounds__(512, 2) void fused_wgrad_kernel(
 #pragma unroll
     for (int k = 0; k < K; ++k) {
       // first batch of the second half's fragments: requested before the images are written, consumed after the first half
-      bf16x8 bl0[8];
+      bf16x8 bl0[ZRES ? 1 : 8];
+      if constexpr (!ZRES) {
 #pragma unroll
-      for (int s2 = 0; s2 < 8; ++s2)
-        bl0[s2] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsrc_z, vo + 64 * (16 + s2), 0, 0));
+        for (int s2 = 0; s2 < 8; ++s2)
+          bl0[s2] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsrc_z, vo + 64 * (16 + s2), 0, 0));
+      }
       // S1: du_k -> LDS state rows (for the next hop) and the transposed word images of both node halves
 #pragma unroll
       for (int i = 0; i < TILES; ++i) {
@@ -190,14 +196,16 @@ __global__ __launch_bounds__(512, 2) void fused_wgrad_kernel(
 #pragma unroll
           for (int p = 0; p < 4; ++p) a4[p] = afrag(1, s4 + p);
 #pragma unroll
-          for (int p = 0; p < 4; ++p) accD[k] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a4[p], bl0[s4 + p], accD[k], 0, 0, 0);
+          for (int p = 0; p < 4; ++p) accD[k] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a4[p], ZRES ? bfr[(ZRES ? 16 : 0) + s4 + p] : bl0[ZRES ? 0 : s4 + p], accD[k], 0, 0, 0);
         }
       }
       // second batch (nodes 768..1023): in flight across the hop
-      bf16x8 bl1[8];
+      bf16x8 bl1[ZRES ? 1 : 8];
+      if constexpr (!ZRES) {
 #pragma unroll
-      for (int s2 = 0; s2 < 8; ++s2)
-        bl1[s2] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsrc_z, vo + 64 * (24 + s2), 0, 0));
+        for (int s2 = 0; s2 < 8; ++s2)
+          bl1[s2] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsrc_z, vo + 64 * (24 + s2), 0, 0));
+      }
       if (k < K - 1) {
         LGKM_WAIT(0);
 #define GCRNN_WG_INIT(i) f32x4{0.f, 0.f, 0.f, 0.f}
@@ -219,7 +227,7 @@ __global__ __launch_bounds__(512, 2) void fused_wgrad_kernel(
 #pragma unroll
           for (int p = 0; p < 4; ++p) a4[p] = afrag(1, 8 + s4 + p);
 #pragma unroll
-          for (int p = 0; p < 4; ++p) accD[k] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a4[p], bl1[s4 + p], accD[k], 0, 0, 0);
+          for (int p = 0; p < 4; ++p) accD[k] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a4[p], ZRES ? bfr[(ZRES ? 24 : 0) + s4 + p] : bl1[ZRES ? 0 : s4 + p], accD[k], 0, 0, 0);
         }
       }
       lds_barrier();      // LDS hand-off only: loads in flight stay in flight (gcrnn_fused_step.h)
