@@ -160,6 +160,8 @@ __global__ __launch_bounds__(STHREADS) void fused_seq_kernel(const SeqArgs a) {
       for (int idx = tid; idx < a.ntaps * NP; idx += STHREADS) reinterpret_cast<float*>(smem + a.sacc_off)[idx] = 0.f;
     }
   }
+  // zeros behind the column image: the summing stream's running column pointer is not clamped (GCRNN_HOP_COLUMN_PAD)
+  if (tid < GCRNN_HOP_COLUMN_PAD / 4) reinterpret_cast<uint32_t*>(smem + IMG + 2 * WB + entries * 32)[tid] = 0u;
   float* lbias = reinterpret_cast<float*>(smem + 33024);
   if ((MODE == 0 || MODE == 1 || MODE == 4 || MODE == 5) && tid < F) lbias[tid] = a.bias ? a.bias[tid] : 0.f;
   __syncthreads();
@@ -783,7 +785,7 @@ __global__ __launch_bounds__(STHREADS) void fused_seq_kernel(const SeqArgs a) {
 // LDS bytes of the sequence-resident kernel, or 0 when the problem does not fit
 template <int K, int HS, int XS>
 static size_t fused_seq_lds(int64_t entries, bool /*inline_pack: its tile is the second hop image*/, int /*pkrows*/, size_t extra = 0) {
-  const size_t need = (size_t)GCRNN_HOP_IMAGE_B_OFFSET + 32 * 1024 + 2 * (size_t)K * (HS + XS) * 1024 + (size_t)entries * 32 + extra;
+  const size_t need = (size_t)GCRNN_HOP_IMAGE_B_OFFSET + 32 * 1024 + 2 * (size_t)K * (HS + XS) * 1024 + (size_t)entries * 32 + GCRNN_HOP_COLUMN_PAD + extra;
   return need <= 160 * 1024 ? need : 0;
 }
 

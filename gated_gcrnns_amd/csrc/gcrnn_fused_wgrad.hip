@@ -41,7 +41,7 @@ __global__ __launch_bounds__(512, 2) void fused_wgrad_kernel(
   float* state = reinterpret_cast<float*>(smem);
   float4* lval4 = reinterpret_cast<float4*>(smem + NP * FC * 4);
   uint2* lcol4 = reinterpret_cast<uint2*>(lval4 + (UNI ? 0 : entries * 4));
-  char* tbuf = reinterpret_cast<char*>(lcol4 + entries * 4);
+  char* tbuf = reinterpret_cast<char*>(lcol4 + entries * 4) + (UNI == 2 ? GCRNN_HOP_COLUMN_PAD : 0);      // (UNI == 2: zeros behind the column image, the summing stream does not clamp its column pointer)
   float* lbias = reinterpret_cast<float*>(tbuf + (UNI ? 2 : 1) * TBYTES);      // [WAVES][16] bias-gradient partial sums, one row per wave (no LDS atomics)
 
   const int L = blockIdx.x;
@@ -59,6 +59,7 @@ __global__ __launch_bounds__(512, 2) void fused_wgrad_kernel(
   {
     const int n = (entries >> 2) * 16;
     for (int i = tid; i < n; i += 512) { if (!UNI) lval4[i] = ell_val4[i]; lcol4[i] = ell_col4[i]; }
+    if (UNI == 2 && tid < GCRNN_HOP_COLUMN_PAD / 4) reinterpret_cast<uint32_t*>(lcol4 + entries * 4)[tid] = 0u;
   }
   int tbeg[TILES], tend[TILES], woff[TILES];
 #pragma unroll
@@ -377,7 +378,7 @@ static int fused_wgrad_t(const void* dpre, const void* Xuser, const void* Huser,
 #else
   const bool uni = false;
 #endif
-  const size_t lds = uni ? (size_t)NP * FC * 4 + (size_t)ga.entries * 32 + 2 * TBYTES + WAVES * FC * 4
+  const size_t lds = uni ? (size_t)NP * FC * 4 + (size_t)ga.entries * 32 + 2 * TBYTES + WAVES * FC * 4 + (ga.img16 ? GCRNN_HOP_COLUMN_PAD : 0)
                          : (size_t)NP * FC * 4 + (size_t)ga.entries * 96 + TBYTES + WAVES * FC * 4;
   if (lds > 160 * 1024 || !ga.ell_val4 || !ga.ell_col4) return GCRNN_ERR_UNSUPPORTED;
   if (ga.img16 && !uni) return GCRNN_ERR_UNSUPPORTED;

@@ -237,6 +237,7 @@ def VXa(p, e):
     return 'v%d' % (UB16 + 8 * p + 4 * e)
 
 
+NOCLAMP = False     # (gen_uniform16(sums=True) sets it: see vs0p)
 IMGOFF = 0          # LDS byte offset of the hop image the gathers read (the summing variants have a second image: gen_uniform16(img_off=..))
 VCOFF = 24          # column-word slots behind three gather sets (the summing variants pack their window: 8 D)
 
@@ -273,6 +274,11 @@ def vs0(q, goff, lines):      # the lane's OWN column dword of group g + goff (c
 def vs0p(q, lines):            # steady state: the same read through the running pointer -- no scalar arithmetic in the trip
     if 'nocol' in os.environ.get('GCRNN_HOP16_EXPERIMENT_TRIP', ''):
         return
+    if NOCLAMP:
+        # (summing variants) no clamp of the running column pointer: past its last group a wave reads the next wave's column words, the last
+        # wave GCRNN_HOP_COLUMN_PAD bytes of zeros the kernels keep behind the column image -- valid, aligned gather addresses, unused sums
+        lines += ['ds_read_b32 %s, %s' % (VC(q), VP5), 'v_add_u32 %s, 128, %s' % (VP5, VP5)]
+        return
     lines += ['v_min_u32 %s, %s, %s' % (VCA, VP5, VPCL), 'ds_read_b32 %s, %s' % (VC(q), VCA), 'v_add_u32 %s, 128, %s' % (VP5, VP5)]
 
 
@@ -297,9 +303,10 @@ def gen_uniform16(sparse=False, sums=False, img_off=0):
     D = SUMS_D if sums else VD
     assert 2 <= D <= 3      # (the register window holds three gather sets; 2 / 3 / 4 / 5 sets measured equal)
     SC = 's90'                                # (group - tile end) of the current tile, counted up: the carry of its increment ends the tile
-    global COLB, GBEG, GLAST, UQX, UB16, SPA, VCOFF, VCA, VP5, VPCL, IMGOFF
+    global COLB, GBEG, GLAST, UQX, UB16, SPA, VCOFF, VCA, VP5, VPCL, IMGOFF, NOCLAMP
     saved = (COLB, GBEG, GLAST, UQX, UB16, SPA, VCOFF, VCA, VP5, VPCL)
     IMGOFF = img_off
+    NOCLAMP = sums and not os.environ.get('GCRNN_HOP16_CLAMP')
     TEND0, AOP = 16, '%29'
     if sums:
         GBEG, GLAST, COLB, UQX, TEND0, AOP = '%16', '%17', '%18', '%19', 8, '%20'
@@ -400,6 +407,7 @@ def gen_uniform16(sparse=False, sums=False, img_off=0):
     L.append('s_waitcnt lgkmcnt(0)')
     COLB, GBEG, GLAST, UQX, UB16, SPA, VCOFF, VCA, VP5, VPCL = saved
     IMGOFF = 0
+    NOCLAMP = False
     return L
 
 
@@ -426,6 +434,7 @@ def main():
     emit('GCRNN_HOP_ASM_UNI16_SUMS_SPARSE_TEXT', gen_uniform16(sparse=True, sums=True))
     # the same two reading the SECOND hop image (sequence-resident kernel: hops alternate between two images, one barrier per hop)
     print('#define GCRNN_HOP_IMAGE_B_OFFSET %d' % IMAGE_B_OFFSET)
+    print('#define GCRNN_HOP_COLUMN_PAD 512      /* bytes of zeros behind the column image: the summing streams read up to three groups past a wave\'s last one */')
     emit('GCRNN_HOP_ASM_UNI16_SUMS_TEXT_B', gen_uniform16(sparse=False, sums=True, img_off=IMAGE_B_OFFSET))
     emit('GCRNN_HOP_ASM_UNI16_SUMS_SPARSE_TEXT_B', gen_uniform16(sparse=True, sums=True, img_off=IMAGE_B_OFFSET))
     regs = ', '.join('"v%d"' % r for r in range(UB, UB + 60))
