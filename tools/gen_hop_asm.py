@@ -238,6 +238,7 @@ def VXa(p, e):
 
 
 NOCLAMP = False     # (gen_uniform16(sums=True) sets it: see vs0p)
+IMMOFF = None
 IMGOFF = 0          # LDS byte offset of the hop image the gathers read (the summing variants have a second image: gen_uniform16(img_off=..))
 VCOFF = 24          # column-word slots behind three gather sets (the summing variants pack their window: 8 D)
 
@@ -276,8 +277,13 @@ def vs0p(q, lines):            # steady state: the same read through the running
         return
     if NOCLAMP:
         # (summing variants) no clamp of the running column pointer: past its last group a wave reads the next wave's column words, the last
-        # wave GCRNN_HOP_COLUMN_PAD bytes of zeros the kernels keep behind the column image -- valid, aligned gather addresses, unused sums
-        lines += ['ds_read_b32 %s, %s' % (VC(q), VP5), 'v_add_u32 %s, 128, %s' % (VP5, VP5)]
+        # wave GCRNN_HOP_COLUMN_PAD bytes of zeros the kernels keep behind the column image -- valid, aligned gather addresses, unused sums.
+        # IMMOFF (position of the trip in the unrolled loop body, or None): the group's offset rides in the instruction, the pointer moves
+        # once per loop iteration (and by the positions skipped at a tile exit)
+        if IMMOFF is None:
+            lines += ['ds_read_b32 %s, %s' % (VC(q), VP5), 'v_add_u32 %s, 128, %s' % (VP5, VP5)]
+        else:
+            lines += ['ds_read_b32 %s, %s' % (VC(q), VP5) + (' offset:%d' % (128 * IMMOFF) if IMMOFF else '')]
         return
     lines += ['v_min_u32 %s, %s, %s' % (VCA, VP5, VPCL), 'ds_read_b32 %s, %s' % (VC(q), VCA), 'v_add_u32 %s, 128, %s' % (VP5, VP5)]
 
@@ -303,7 +309,7 @@ def gen_uniform16(sparse=False, sums=False, img_off=0):
     D = SUMS_D if sums else VD
     assert 2 <= D <= 3      # (the register window holds three gather sets; 2 / 3 / 4 / 5 sets measured equal)
     SC = 's90'                                # (group - tile end) of the current tile, counted up: the carry of its increment ends the tile
-    global COLB, GBEG, GLAST, UQX, UB16, SPA, VCOFF, VCA, VP5, VPCL, IMGOFF, NOCLAMP
+    global COLB, GBEG, GLAST, UQX, UB16, SPA, VCOFF, VCA, VP5, VPCL, IMGOFF, NOCLAMP, IMMOFF
     saved = (COLB, GBEG, GLAST, UQX, UB16, SPA, VCOFF, VCA, VP5, VPCL)
     IMGOFF = img_off
     NOCLAMP = sums and not os.environ.get('GCRNN_HOP16_CLAMP')
@@ -353,10 +359,12 @@ def gen_uniform16(sparse=False, sums=False, img_off=0):
           's_sub_u32 %s, %s, %%%d' % (SC, GBEG, TEND0), 's_cmp_eq_u32 %s, 0' % SC]
     R = int(os.environ.get('GCRNN_HOP16_UNROLL', '2'))           # the D phases are laid out R times before the loop branches back
     for t in range(NT):
+        IMM = NOCLAMP and bool(os.environ.get('GCRNN_HOP16_IMMEDIATE_OFFSETS'))      # column reads with immediate group offsets, pointer moved once per loop iteration: A/B 118.8-120.1k vs 119.3-119.8k seq/s, no gain (profiles/r03_hop16_immediate_offsets_ab.txt) -- off
         for pp in range(D * R):
             p = pp % D
             L.append('L_T%d_P%d_%%=:' % (t, pp))
-            L.append('s_cbranch_scc1 L_X%d_P%d_%%=' % (t, p))
+            L.append('s_cbranch_scc1 L_X%d_P%d_%%=' % (t, pp if IMM else p))
+            IMMOFF = pp if IMM else None
             for _ in range(int(os.environ.get('GCRNN_HOP16_EXPERIMENT_EXTRA_BRANCHES', '0'))):      # (timing experiment: what does a not-taken branch cost? ~6 cycles)
                 L.append('s_cbranch_scc1 L_X%d_P%d_%%=' % (t, p))
             for _ in range(int(os.environ.get('GCRNN_HOP16_EXPERIMENT_EXTRA_SALU', '0'))):          # (... and a scalar instruction? ~3 cycles)
@@ -386,9 +394,15 @@ def gen_uniform16(sparse=False, sums=False, img_off=0):
                 L.append('v_mfma_f32_16x16x32_bf16 %s, %s, %s, %s' % (acc, AOP, VX(p, e), acc))
             if not sums or os.environ.get('GCRNN_HOP16_COUNTER_LAST'):
                 L.append('s_add_u32 %s, %s, 1' % (SC, SC))        # SCC = carry = this was the tile's last group
+        IMMOFF = None
+        if IMM:
+            L.append('v_add_u32 %s, %d, %s' % (VP5, 128 * D * R, VP5))
         L.append('s_branch L_T%d_P0_%%=' % t)
-        for p in range(D):                    # leaving tile t in phase p: acc_t += w * sum, sum = 0
-            L.append('L_X%d_P%d_%%=:' % (t, p))
+        for px in range(D * R if IMM else D):                    # leaving tile t in phase p: acc_t += w * sum, sum = 0
+            p = px % D
+            L.append('L_X%d_P%d_%%=:' % (t, px))
+            if IMM and px >= D:                                   # positions of the loop body this exit skips: the next tile enters at position p
+                L.append('v_add_u32 %s, %d, %s' % (VP5, 128 * (px - p), VP5))
             if not sums and not os.environ.get('GCRNN_HOP16_EXPERIMENT_CHEAP_EXIT'):      # (timing experiment, wrong results: what do the tile exits cost?)
                 L += ['s_nop 15', 's_nop 7'] if sparse else ['s_nop 11']       # matrix-core result -> VALU read: 11 wait states after the 8-pass dense MFMA; the sparse one is given the 16-pass distance
                 L.append('v_pk_fma_f32 %%%d, %s, %s, %%%d' % (2 * t, UWP, VSUMH[0][0], 2 * t))
