@@ -313,12 +313,16 @@ def gen_uniform16(sparse=False, sums=False, img_off=0):
     saved = (COLB, GBEG, GLAST, UQX, UB16, SPA, VCOFF, VCA, VP5, VPCL)
     IMGOFF = img_off
     NOCLAMP = sums and not os.environ.get('GCRNN_HOP16_CLAMP')
+    PIPEADR = sums and sparse and NOCLAMP and bool(os.environ.get('GCRNN_HOP16_PIPELINED_ADDRESSES'))      # A/B: 120.3-120.5k vs 120.3-121.0k seq/s, no gain (profiles/r03_hop16_pipelined_addresses_ab.txt) -- off
+    ADR = None
     TEND0, AOP = 16, '%29'
     if sums:
         GBEG, GLAST, COLB, UQX, TEND0, AOP = '%16', '%17', '%18', '%19', 8, '%20'
         # packed window ending at v253: D gather sets, D column words, pointer, clamp, address (sparse: + A operand, index, scratch below)
         UB16, SPA, VCOFF = SUMS_UB16, SUMS_SPA, 8 * D
         VP5, VPCL, VCA = 'v%d' % (UB16 + 9 * D), 'v%d' % (UB16 + 9 * D + 1), 'v%d' % (UB16 + 9 * D + 2)
+        ADR = [VPCL, 'v%d' % (UB16 + 9 * D + 3)]                # (pipelined gather addresses: the clamp register is free without the clamp; + the window's last register)
+        assert UB16 + 9 * D + 3 <= 253
     L = ['s_mov_b32 %s, %s' % (SG, GBEG)]
     if sums:                                  # the first column words are requested before the A operand is built: its ~25 VALU instructions cover their latency
         for p in range(D):
@@ -355,8 +359,12 @@ def gen_uniform16(sparse=False, sums=False, img_off=0):
     for p in range(D - 1):                    # gathers of groups 0 .. D-2; their column slots take groups D .. 2D-2
         vs1(p, L); vs0(p, D + p, L)
     L += ['s_add_i32 %s, %s, %d' % (ST, SG, 2 * D - 1), 'v_lshl_add_u32 %s, %s, 7, %s' % (VP5, ST, COLB),
-          'v_lshl_add_u32 %s, %s, 7, %s' % (VPCL, GLAST, COLB),
-          's_sub_u32 %s, %s, %%%d' % (SC, GBEG, TEND0), 's_cmp_eq_u32 %s, 0' % SC]
+          'v_lshl_add_u32 %s, %s, 7, %s' % (VPCL, GLAST, COLB)]
+    if PIPEADR:
+        # (the clamp register doubles as an address register: nothing reads the clamp without the clamp) the addresses of group D - 1, for trip 0
+        for e in range(2):
+            L.append('v_xor_b32_sdwa %s, %s, %s dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_%d src1_sel:DWORD' % (ADR[e], VC(D - 1), UQX, e))
+    L += ['s_sub_u32 %s, %s, %%%d' % (SC, GBEG, TEND0), 's_cmp_eq_u32 %s, 0' % SC]
     R = int(os.environ.get('GCRNN_HOP16_UNROLL', '2'))           # the D phases are laid out R times before the loop branches back
     for t in range(NT):
         IMM = NOCLAMP and bool(os.environ.get('GCRNN_HOP16_IMMEDIATE_OFFSETS'))      # column reads with immediate group offsets, pointer moved once per loop iteration: A/B 118.8-120.1k vs 119.3-119.8k seq/s, no gain (profiles/r03_hop16_immediate_offsets_ab.txt) -- off
@@ -374,6 +382,17 @@ def gen_uniform16(sparse=False, sums=False, img_off=0):
                 # (at the end of the trip the scalar result -> branch latency was exposed every trip; nothing in between writes SCC)
                 L.append('s_add_u32 %s, %s, 1' % (SC, SC))
             q = (p + D - 1) % D
+            if PIPEADR:
+                # gathers from addresses formed at the END of the previous trip (no address instruction right in front of its gather: in-order
+                # issue waits for the VALU result there -- what the clamp in front of the column read cost too); this trip forms the next one's
+                L += ['ds_read_b128 %s, %s' % (VX(q, 0), ADR[0]) + (' offset:%d' % IMGOFF if IMGOFF else ''),
+                      'ds_read_b128 %s, %s' % (VX(q, 1), ADR[1]) + (' offset:%d' % IMGOFF if IMGOFF else '')]
+                vs0p(q, L)
+                L.append('s_waitcnt lgkmcnt(%d)' % (3 * (D - 1)))
+                L.append('v_smfmac_f32_16x16x64_bf16 %s, v[%d:%d], v[%d:%d], v%d' % ('%%%d' % t, SPA, SPA + 3, UB16 + 8 * p, UB16 + 8 * p + 7, SPA + 4))
+                for e in range(2):
+                    L.append('v_xor_b32_sdwa %s, %s, %s dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_%d src1_sel:DWORD' % (ADR[e], VC(p), UQX, e))
+                continue
             if sums and os.environ.get('GCRNN_HOP16_TRIP_ORDER_SPREAD') and not os.environ.get('GCRNN_HOP16_EXPERIMENT_TRIP'):      # (A/B: 116.3-116.5k vs 116.0-117.4k seq/s, no gain: profiles/r03_hop16_trip_order_ab.txt)
                 # the same seven instructions with no instruction right behind the one it depends on (in-order issue: a gather behind its
                 # address XOR, the column read behind its clamp, each waited for the VALU result): clamp, XORs, column read, pointer, gathers
