@@ -359,6 +359,8 @@ class GGCRNNCell(nn.Module):
                 return self._forward_fused(X, h0, last_only=True)
             if (not torch.is_grad_enabled()) and self._use_fused_x3(X, h0):
                 return ops.fused_cell_forward_x3(X, h0, self.weight_A, self.weight_B, self.bias, self.graph, last_only=True)
+            if (not torch.is_grad_enabled()) and self._use_fused_x3(X, h0, time_gated=True):
+                return ops.fused_cell_forward_x3_gated(X, h0, self.weight_A, self.weight_B, self.bias, self.graph, self._fused_gates(), last_only=True)
             if (not torch.is_grad_enabled()) and self._use_fused_node(X, h0):
                 return self._forward_fused_node(X, h0, last_only=True)
             if (not torch.is_grad_enabled()) and self._use_fused_edge(X, h0):
@@ -388,6 +390,8 @@ class GGCRNNCell(nn.Module):
             return self._forward_fused_edge(X, h0)
         if self._use_fused_x3(X, h0):
             return ops.fused_cell_forward_x3(X, h0, self.weight_A, self.weight_B, self.bias, self.graph)
+        if self._use_fused_x3(X, h0, time_gated=True):
+            return ops.fused_cell_forward_x3_gated(X, h0, self.weight_A, self.weight_B, self.bias, self.graph, self._fused_gates())
         if self._use_small(X, h0):
             return self._forward_small(X, h0)
         if self._use_small_training(X, h0):
@@ -648,12 +652,15 @@ class GGCRNNCell(nn.Module):
                                            (self.input_attention.mixer, self.input_attention.weight),
                                            (self.forget_attention.mixer, self.forget_attention.weight), time_gates=tg, last_only=last_only)
 
-    def _use_fused_x3(self, X, h0):
+    def _use_fused_x3(self, X, h0, time_gated=False):
         """fp32 inference of the un-gated cell on the fp32-accurate fused kernels (three bf16 planes per operand): graphs that fit
-        the fused kernels, too large for the one-launch small-graph kernels, with one weight on every edge."""
+        the fused kernels, too large for the one-launch small-graph kernels, with one weight on every edge. time_gated=True: the same
+        question for the time-gated cell (ops.fused_cell_forward_x3_gated: gates and scaled steps composed from the same kernel)."""
         if self._wants_grad(X, h0):
             return False
-        if self.time_gating == True or self.spatial_gating is not None or self.sigma not in (torch.tanh, nn.functional.tanh):  # noqa: E712
+        if (self.time_gating == True) != bool(time_gated) or self.spatial_gating is not None or self.sigma not in (torch.tanh, nn.functional.tanh):  # noqa: E712
+            return False
+        if time_gated and (X.shape[0] > 2048 or os.environ.get('GCRNN_NO_X3_GATED')):
             return False
         if X.dtype != torch.float32 or h0.dtype != X.dtype or self.weight_A.dtype != X.dtype:
             return False

@@ -99,6 +99,7 @@ def _bind(lib):
         'gcrnn_pack_seq_major_x3': (C.c_int, [_c_p, _c_p, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_p]),
         'gcrnn_fused_pack_weights_x3': (C.c_int, [_c_p, _c_p, _c_p, _c_i64, _c_i64, _c_i64, _c_i64, _c_p]),
         'gcrnn_fused_forward_x3': (C.c_int, [_c_p] * 8 + [_c_i64] * 7 + [C.c_double, _c_p, C.c_int, _c_p]),
+        'gcrnn_fused_forward_x3_scaled': (C.c_int, [_c_p] * 9 + [_c_i64] * 7 + [C.c_double, _c_p, _c_i64, _c_p]),
         'gcrnn_fused_x3_training_supported': (C.c_int, [_c_i64] * 5),
         'gcrnn_fused_backward_data_x3': (C.c_int, [_c_p] * 8 + [_c_i64] * 6 + [C.c_double, _c_p]),
         'gcrnn_fused_backward_weight_f32': (C.c_int, [_c_p] * 9 + [_c_i64] * 7 + [C.c_double, _c_p]),

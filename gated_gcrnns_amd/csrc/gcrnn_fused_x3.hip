@@ -92,7 +92,8 @@ __global__ __launch_bounds__(STHREADS) void fused_step_x3_kernel(
     int64_t ubstride,                        // elements between consecutive sequences of Huser
     int entries, int B, int N, float uni_w,
     const uint16_t* __restrict__ aux0_3,               // EPI 2: planes of the upstream gradient dH_{t-1} [3][B][NP][F] (or null)
-    const uint16_t* __restrict__ aux1_3) {             // EPI 2: planes of the state h_{t-1} [3][B][NP][F] (or null)
+    const uint16_t* __restrict__ aux1_3,               // EPI 2: planes of the state h_{t-1} [3][B][NP][F] (or null)
+    const float* __restrict__ bscale) {                // EPI 0 (or null): per-sequence weight of the bias [B] instead of 2 (time-gated cell: gi + gf)
   static_assert(GCRNN_HOP_ASM && GCRNN_STEP_WAVES == 8, "x3 runs on the one-block asm hop stream");
   constexpr int KS = HS + XS, F = 32 * HS, G = 32 * XS, NCH = F / FC, HT = STILES;
   constexpr int WPL = K * KS * 64;            // uint4 fragments per weight plane and chunk
@@ -127,7 +128,7 @@ __global__ __launch_bounds__(STHREADS) void fused_step_x3_kernel(
   float bvec[4] = {0.f, 0.f, 0.f, 0.f};
   if (bias) {
 #pragma unroll
-    for (int c = 0; c < 4; ++c) bvec[c] = 2.f * bias[chunk * FC + q * 4 + c];   // the one bias enters through both filters (graphML.py:2420-2421)
+    for (int c = 0; c < 4; ++c) bvec[c] = bias[chunk * FC + q * 4 + c];        // the one bias enters through both filters (graphML.py:2420-2421): weight 2, or gi + gf
   }
   __syncthreads();
   const uint32_t lds0 = (uint32_t)reinterpret_cast<uintptr_t>(smem);
@@ -244,7 +245,8 @@ __global__ __launch_bounds__(STHREADS) void fused_step_x3_kernel(
         }
       } else if (node < N) {
         const f32x4 a = u[i][LASTU];
-        o = f32x4{fast_tanh(a[0] + bvec[0]), fast_tanh(a[1] + bvec[1]), fast_tanh(a[2] + bvec[2]), fast_tanh(a[3] + bvec[3])};
+        const float bs = bscale ? bscale[b] : 2.f;          // (2 b is exact: the un-gated results keep their bits)
+        o = f32x4{fast_tanh(a[0] + bs * bvec[0]), fast_tanh(a[1] + bs * bvec[1]), fast_tanh(a[2] + bs * bvec[2]), fast_tanh(a[3] + bs * bvec[3])};
       }
       uint16_t p0[4], p1[4], p2[4];
 #pragma unroll
@@ -287,7 +289,7 @@ __global__ __launch_bounds__(STHREADS) void fused_step_x3_kernel(
 template <int K, int HS, int XS>
 int x3_launch(const void* xs3, const void* h03, void* hs3, const void* wpack3, const float* bias, const int32_t* tile_nodes,
               const int32_t* tile_off, const void* ell_col4, int64_t entries, int64_t B, int64_t T, int64_t N, float uni_w, float* Huser,
-              int last_only, hipStream_t st) {
+              int last_only, hipStream_t st, const float* bscale = nullptr, int64_t hu_stride = 0) {
   constexpr int F = 32 * HS, G = 32 * XS, KS = HS + XS, NCH = F / FC;
   const size_t lds = (size_t)NP * FC * 4 + (size_t)3 * K * KS * 1024 + (size_t)entries * 32;
   if (lds > 160 * 1024) return GCRNN_ERR_UNSUPPORTED;
@@ -305,8 +307,8 @@ int x3_launch(const void* xs3, const void* h03, void* hs3, const void* wpack3, c
     const uint16_t* hp = (t == 0) ? (const uint16_t*)h03 : h + (t - 1) * hstep;
     float* hu = !Huser ? nullptr : (!last_only ? Huser + t * F * N : (t == T - 1 ? Huser : nullptr));
     kern<<<(unsigned)(slots * NCH), STHREADS, lds, st>>>(x + t * xstep, hp, h + t * hstep, (const uint4*)wpack3, bias, tile_nodes, tile_off,
-                                                        (const uint2*)ell_col4, hu, (int64_t)(last_only ? 1 : T) * F * N, (int)entries, (int)B,
-                                                        (int)N, uni_w, nullptr, nullptr);
+                                                        (const uint2*)ell_col4, hu, hu_stride ? hu_stride : (int64_t)(last_only ? 1 : T) * F * N, (int)entries, (int)B,
+                                                        (int)N, uni_w, nullptr, nullptr, bscale ? bscale + t * B : nullptr);
   }
   GCRNN_CHECK_LAUNCH();
   return GCRNN_OK;
@@ -346,10 +348,10 @@ int x3_backward_launch(const void* dHs3, const void* hs3, void* dpre3, void* dh0
   for (int64_t t = T - 1; t >= 1; --t)
     kern<<<(unsigned)(slots * NCH), STHREADS, lds, st>>>(nullptr, dp + t * hstep, dp + (t - 1) * hstep, (const uint4*)wpack3T, nullptr, tile_nodes,
                                                         tile_off, (const uint2*)ell_col4, nullptr, 0, (int)entries, (int)B, (int)N, uni_w,
-                                                        dH + (t - 1) * hstep, hs + (t - 1) * hstep);
+                                                        dH + (t - 1) * hstep, hs + (t - 1) * hstep, nullptr);
   if (dh03)
     kern<<<(unsigned)(slots * NCH), STHREADS, lds, st>>>(nullptr, dp, (uint16_t*)dh03, (const uint4*)wpack3T, nullptr, tile_nodes, tile_off,
-                                                        (const uint2*)ell_col4, nullptr, 0, (int)entries, (int)B, (int)N, uni_w, nullptr, nullptr);
+                                                        (const uint2*)ell_col4, nullptr, 0, (int)entries, (int)B, (int)N, uni_w, nullptr, nullptr, nullptr);
   GCRNN_CHECK_LAUNCH();
   return GCRNN_OK;
 }
@@ -596,6 +598,31 @@ extern "C" int gcrnn_fused_forward_x3(const void* xs3, const void* h03, void* hs
 #define GCRNN_X3_CASE(KK, HH, XX) \
   if (K == KK && F == 32 * HH && G == 32 * XX) \
     return x3_launch<KK, HH, XX>(xs3, h03, hs3, wpack3, bias, tile_nodes, tile_off, ell_col4, entries, B, T, N, (float)uniform_w, (float*)Huser, last_only, st);
+  GCRNN_X3_CASE(5, 2, 2) GCRNN_X3_CASE(4, 2, 2) GCRNN_X3_CASE(3, 2, 2) GCRNN_X3_CASE(2, 2, 2)
+  GCRNN_X3_CASE(5, 2, 1) GCRNN_X3_CASE(4, 2, 1) GCRNN_X3_CASE(3, 2, 1) GCRNN_X3_CASE(2, 2, 1)
+  GCRNN_X3_CASE(5, 1, 1) GCRNN_X3_CASE(4, 1, 1) GCRNN_X3_CASE(3, 1, 1) GCRNN_X3_CASE(2, 1, 1)
+#undef GCRNN_X3_CASE
+  return GCRNN_ERR_UNSUPPORTED;
+}
+
+// The same forward with a per-(t, b) weight of the bias instead of 2 (bias_scale [T][B] fp32 or NULL) and an explicit distance between
+// consecutive sequences of Huser (huser_seq_stride elements, 0 = T F N): what the time-gated cell at fp32 accuracy is composed from --
+// gi (A(S) x_t + b) + gf (B(S) h_{t-1} + b) = A(S)(gi x_t) + B(S)(gf h_{t-1}) + (gi + gf) b (graphML.py:2420-2423): the caller scales the
+// operands (exact in fp32, before they are cut into planes) and passes gi + gf here.
+extern "C" int gcrnn_fused_forward_x3_scaled(const void* xs3, const void* h03, void* hs3, const void* wpack3, const float* bias,
+                                             const float* bias_scale, const int32_t* tile_nodes, const int32_t* tile_off, const void* ell_col4,
+                                             int64_t entries, int64_t B, int64_t T, int64_t N, int64_t F, int64_t G, int64_t K,
+                                             double uniform_w, void* Huser, int64_t huser_seq_stride, void* stream) {
+  if (!xs3 || !h03 || !hs3 || !wpack3 || !tile_nodes || !tile_off || !ell_col4) return GCRNN_ERR_NULL_POINTER;
+  if (B <= 0 || T <= 0 || uniform_w == 0.0 || !gcrnn_fused_x3_supported(N, F, G, K, entries)) return GCRNN_ERR_BAD_SHAPE;
+  if (3 * B * (NP * (F > G ? F : G) * 2) > 2147483647LL) return GCRNN_ERR_BAD_SHAPE;         // 32-bit buffer offsets
+  if (Huser && (reinterpret_cast<uintptr_t>(Huser) & 15)) return GCRNN_ERR_BAD_SHAPE;
+  if (huser_seq_stride < 0 || (huser_seq_stride % 4)) return GCRNN_ERR_BAD_SHAPE;
+  hipStream_t st = as_stream(stream);
+#define GCRNN_X3_CASE(KK, HH, XX) \
+  if (K == KK && F == 32 * HH && G == 32 * XX) \
+    return x3_launch<KK, HH, XX>(xs3, h03, hs3, wpack3, bias, tile_nodes, tile_off, ell_col4, entries, B, T, N, (float)uniform_w, (float*)Huser, 0, st, \
+                                 bias_scale, huser_seq_stride);
   GCRNN_X3_CASE(5, 2, 2) GCRNN_X3_CASE(4, 2, 2) GCRNN_X3_CASE(3, 2, 2) GCRNN_X3_CASE(2, 2, 2)
   GCRNN_X3_CASE(5, 2, 1) GCRNN_X3_CASE(4, 2, 1) GCRNN_X3_CASE(3, 2, 1) GCRNN_X3_CASE(2, 2, 1)
   GCRNN_X3_CASE(5, 1, 1) GCRNN_X3_CASE(4, 1, 1) GCRNN_X3_CASE(3, 1, 1) GCRNN_X3_CASE(2, 1, 1)

@@ -1355,6 +1355,63 @@ def fused_cell_forward_x3(X, h0, wA, wB, bias, graph, last_only=False, keep=Fals
     return H
 
 
+def fused_cell_forward_x3_gated(X, h0, wA, wB, bias, graph, gates, last_only=False):
+    """Time-gated GGCRNNCell forward to fp32 accuracy, composed from the fp32-accurate fused step (round 3; reference
+    graphML.py:2357-2374, 2420-2423). gates = {'in': (wA_g, wB_g, bias_g, lin_w, lin_b), 'forget': (...)} as in fused_cell_forward.
+      * a gate reads (x_t, h0): its gate cell is ONE un-gated step from h0 for every (t, b) -- the x3 forward on T*B "sequences" of length
+        one (in slices that keep the 32-bit buffer offsets), followed by the Linear(F N -> 1) read-out on the fp32 states (torch);
+      * gi (A(S)x_t + b) + gf (B(S)h_{t-1} + b) = A(S)(gi x_t) + B(S)(gf h_{t-1}) + (gi + gf) b: the operands are scaled in fp32 BEFORE they are
+        cut into bf16 planes (exact), the bias weight gi + gf goes to the kernel (gcrnn_fused_forward_x3_scaled), one launch per step.
+    X: B x T x G x N fp32, h0: B x F x N fp32 -> H: B x T x F x N fp32 (B x 1 x F x N with last_only). No autograd graph."""
+    require_device(X, h0, wA, wB, bias)
+    Xp, wAp = fused_pad_operands(X, wA.detach())
+    B, T, G, N = Xp.shape
+    F = wAp.shape[0]
+    Kin, Kst = wAp.shape[2], wB.shape[2]
+    K = max(Kin, Kst)
+    plan = graph.fused_plan()
+    npad, st, dev = plan['npad'], _stream(), X.device
+    # ---- the two gates [T][B] ----
+    per = max(1, min(T, 2048 // B)) if B <= 2048 else 0
+    assert per > 0, 'batch too large for the x3 gate evaluation'
+    g = {}
+    for name in ('in', 'forget'):
+        wA_g, wB_g, bias_g, lin_w, lin_b = gates[name]
+        lw = lin_w.detach().float().reshape(-1)
+        logit = torch.empty((T, B), dtype=torch.float32, device=dev)
+        for t0 in range(0, T, per):
+            nt = min(per, T - t0)
+            Xi = Xp[:, t0:t0 + nt].permute(1, 0, 2, 3).reshape(nt * B, 1, G, N)                  # item = t B + b
+            h0i = h0.unsqueeze(0).expand(nt, B, F, N).reshape(nt * B, F, N)
+            c = fused_cell_forward_x3(Xi, h0i, wA_g, wB_g, bias_g, graph)                       # [items][1][F][N] fp32
+            logit[t0:t0 + nt] = (c.reshape(nt * B, F * N) @ lw).view(nt, B)
+        if lin_b is not None:
+            logit = logit + lin_b.detach().float().view(())
+        g[name] = torch.sigmoid(logit)
+    gi, gf = g['in'], g['forget']                                                                # [T][B]
+    # ---- the recurrence, one scaled step per launch ----
+    Xs = (Xp * gi.t().reshape(B, T, 1, 1)).contiguous()
+    xs3 = torch.empty((T, 3, B, npad, G), dtype=torch.bfloat16, device=dev)
+    check(lib.gcrnn_pack_seq_major_x3(_p(Xs), _p(xs3), B, T, G, N, npad, st), 'pack_seq_x3')
+    wAc, wBc = wAp.float().contiguous(), wB.detach().float().contiguous()
+    wp3 = torch.empty((3 * (F // 16) * K * ((F + G) // 32) * 64 * 8,), dtype=torch.bfloat16, device=dev)
+    check(lib.gcrnn_fused_pack_weights_x3(_p(wAc), _p(wBc), _p(wp3), F, G, Kin, Kst, st), 'pack_weights_x3')
+    b32 = bias.detach().float().contiguous().view(-1) if bias is not None else None
+    bsc = (gi + gf).contiguous()                                                                 # [T][B]
+    H = torch.empty((B, T, F, N), dtype=torch.float32, device=dev)
+    h3 = torch.empty((1, 3, B, npad, F), dtype=torch.bfloat16, device=dev)
+    ho3 = torch.empty((1, 3, B, npad, F), dtype=torch.bfloat16, device=dev)
+    hprev = h0
+    for t in range(T):
+        hs_ = (hprev * gf[t].view(B, 1, 1)).contiguous()
+        check(lib.gcrnn_pack_seq_major_x3(_p(hs_), _p(h3), B, 1, F, N, npad, st), 'pack_seq_x3')
+        check(lib.gcrnn_fused_forward_x3_scaled(_p(xs3[t]), _p(h3), _p(ho3), _p(wp3), _p(b32), _p(bsc[t]), _p(plan['tile_slots']), _p(plan['tile_off']),
+                                                _p(plan['ell_col4']), plan['entries'], B, 1, N, F, G, K, plan['uniform_w'], _p(H[:, t]), T * F * N, st),
+              'fused_forward_x3_scaled')
+        hprev = H[:, t]
+    return H[:, T - 1:].contiguous() if last_only else H
+
+
 def fused_x3_training_supported(graph, N, F, G, Kin, Kst, dtype, E=1):
     """fp32-accurate training of the un-gated cell on the fused kernels: the x3 forward's conditions, and the ADJOINT graph uniform
     too (a symmetric-support GSO like the drivers' W / lambda_max) with an image that fits next to the backward's two fp32 images."""

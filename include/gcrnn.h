@@ -237,6 +237,14 @@ int gcrnn_fused_forward_x3(const void* xs3, const void* h03, void* hs3, const vo
                            const int32_t* tile_nodes, const int32_t* tile_off, const void* ell_col4, int64_t entries, int64_t B,
                            int64_t T, int64_t N, int64_t F, int64_t G, int64_t K, double uniform_w, void* Huser, int last_only,
                            void* stream);
+/* gcrnn_fused_forward_x3 with a per-(t, b) weight of the bias (bias_scale [T][B] fp32, NULL = 2) and an explicit distance between the
+ * sequences of Huser (huser_seq_stride elements, 0 = T*F*N; Huser = the block of step 0). The time-gated cell at fp32 accuracy
+ * (Utils/graphML.py:2357-2374, 2420-2423) is composed from it: gi (A(S)x_t + b) + gf (B(S)h_{t-1} + b) = A(S)(gi x_t) + B(S)(gf h_{t-1}) +
+ * (gi + gf) b -- the caller scales the operands in fp32 and passes gi + gf. */
+int gcrnn_fused_forward_x3_scaled(const void* xs3, const void* h03, void* hs3, const void* wpack3, const float* bias,
+                                  const float* bias_scale, const int32_t* tile_nodes, const int32_t* tile_off, const void* ell_col4,
+                                  int64_t entries, int64_t B, int64_t T, int64_t N, int64_t F, int64_t G, int64_t K, double uniform_w,
+                                  void* Huser, int64_t huser_seq_stride, void* stream);
 /* fp32-accurate BPTT of the un-gated cell on the fused kernels (round 3): the training loop of the reference runs in the drivers'
  * precision (Modules/train_rnn.py:247-281 under kStepPredGRNNs.py:44), i.e. its gradients are autograd's of Utils/graphML.py:2420-2423.
  * gcrnn_fused_backward_data_x3: the data chain dpre_{t-1} = (sum_k S^k (dpre_t B_k^T) + dH_{t-1}) (1 - h_{t-1}^2) on the x3 step kernel

@@ -816,6 +816,45 @@ def test_uniform_weight_graph_stream_matches_oracle_and_weighted_stream(N, F, K,
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('N,F,G,K,B,T,zero_h0', [(1000, 64, 64, 5, 3, 5, False), (1000, 64, 1, 5, 2, 4, True), (600, 32, 32, 3, 5, 3, False),
+                                                 (1008, 64, 32, 2, 700, 4, True)])
+def test_fp32_accurate_time_gated_cell_matches_oracle_to_1e5(N, F, G, K, B, T, zero_h0, monkeypatch):
+    """The time-gated cell at the north_star's 1e-5 on the fused kernels (ops.fused_cell_forward_x3_gated): both gates from the x3 step on
+    (x_t, h0) + the Linear(F N -> 1) read-out, the recurrence as scaled x3 steps (gcrnn_fused_forward_x3_scaled) -- against the fp64 oracle
+    (reference graphML.py:2357-2374, 2420-2423), the drivers' G = 1, a batch whose gate items need several slices (B T = 2800), and the
+    composed path it replaces."""
+    import gated_gcrnns_amd.Utils.graphML as gml
+    dev = torch.device('cuda:0')
+    rng = np.random.default_rng(37)
+    W = (rng.random((N, N)) < 10.0 / N).astype(np.float64)
+    W = np.triu(W, 1); W = W + W.T
+    S = (W / np.max(np.abs(np.linalg.eigvalsh(W)))).reshape(1, N, N)
+    Bo = min(B, 3)                                               # the oracle checks the first sequences (dense fp64 hops)
+    X = rng.standard_normal((B, T, G, N)).astype(np.float32)
+    h0 = np.zeros((B, F, N), np.float32) if zero_h0 else (0.5 * rng.standard_normal((B, F, N))).astype(np.float32)
+    torch.manual_seed(8)
+    cell = gml.GGCRNNCell(G, F, K, K, torch.tanh, True, None, 1, True)
+    cell.addGSO(torch.tensor(S))
+    cell = cell.float()
+    params = {k: v.detach().double().numpy() for k, v in cell.state_dict().items()}
+    ref = orc.ggcrnn_cell(params, S.astype(np.float32).astype(np.float64), X[:Bo].astype(np.float64), h0[:Bo].astype(np.float64), True, None)
+    cell = cell.to(dev)
+    Xd, hd = torch.tensor(X, device=dev), torch.tensor(h0, device=dev)
+    with torch.no_grad():
+        assert cell._use_fused_x3(Xd, hd, time_gated=True) and not cell._use_fused_x3(Xd, hd)
+        H = cell(Xd, hd)
+        Hl = cell(Xd, hd, last_only=True)
+        monkeypatch.setenv('GCRNN_NO_X3_GATED', '1')
+        assert not cell._use_fused_x3(Xd, hd, time_gated=True)
+        Hc = cell(Xd[:Bo], hd[:Bo])                              # the composed path
+    assert H.dtype == torch.float32 and tuple(H.shape) == (B, T, F, N)
+    err = np.abs(H[:Bo].double().cpu().numpy() - ref).max()
+    assert err <= 1e-5, err
+    assert torch.equal(Hl, H[:, -1:])
+    assert float((H[:Bo] - Hc).abs().max()) <= 2e-5
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('N,F,G,K,B,T', [(1000, 64, 64, 5, 3, 6), (1000, 64, 1, 5, 2, 4), (600, 32, 32, 3, 5, 3), (1008, 64, 32, 2, 2, 3),
                                          (1000, 64, 64, 4, 2, 2)])
 def test_fp32_accurate_fused_path_matches_oracle_to_1e5(N, F, G, K, B, T):
