@@ -558,6 +558,24 @@ def secondary_points(ctx, S, params, B, steps=8, warmup=2):
     except Exception as e:      # noqa: BLE001
         sec['train_bf16'] = {'error': str(e)[:200]}
     gc.collect(); torch.cuda.empty_cache()
+    # ---- time-gated cell at the north_star's 1e-5 (x3 kernels: gates = x3 steps from h0 + read-out, recurrence = scaled x3 steps) ----
+    try:
+        torch.manual_seed(0)
+        c = gml.GGCRNNCell(G, F, K, K, torch.tanh, True, None, 1, True)
+        c.addGSO(torch.tensor(S))
+        c = c.to(dev).float()
+        X = torch.randn(B, T, G, N, device=dev, dtype=torch.float32, generator=gen)
+        h0 = torch.zeros(B, F, N, device=dev, dtype=torch.float32)
+        with torch.no_grad():
+            if c._use_fused_x3(X, h0, time_gated=True):
+                dt = _timed(lambda: c(X, h0), 3, 1)
+                sec['fwd_timegated_f32_x3'] = {'value': B / dt, 'unit': 'sequences/s', 'ms_per_step': 1e3 * dt, 'steps': 3, 'dtype': 'f32',
+                                               'tolerance': '<= 1e-5 abs against the fp64 oracle (tests/test_fused.py)',
+                                               'what': 'GGCRNNCell(time_gating=True) forward on the fp32-accurate fused kernels'}
+        del c, X, h0
+    except Exception as e:      # noqa: BLE001
+        sec['fwd_timegated_f32_x3'] = {'error': str(e)[:200]}
+    gc.collect(); torch.cuda.empty_cache()
     # ---- gated cells, bf16 forward (reference graphML.py:2357-2407, 2420-2423; random-init gate sub-networks of the reference's shapes) ----
     for name, tg, sg in (('fwd_timegated', True, None), ('fwd_nodegated', False, 'node'), ('fwd_edgegated', False, 'edge')):
         try:
