@@ -14,6 +14,7 @@ line train_nodegated --mode train --spatial-gating node
 line train_edgegated --mode train --spatial-gating edge
 line train_timeedge --mode train --spatial-gating edge --time-gating
 line f32_x3 --dtype f32
+line f32_x3_timegated --dtype f32 --time-gating --steps 5 --warmup 2
 line f64_b128 --dtype f64 --batch 128
 line cfg4 --config cfg4
 line cfg5_bf16 --config cfg5
