@@ -1,0 +1,406 @@
+// Sequence-resident fused GCRNN recurrence, 32-feature chunks (round 4): the flagship forward of uniform-weight graphs.
+//
+// gcrnn_fused_seq.h keeps a sequence's operand [h_{t-1} | x_t] in registers and walks its F/16 output chunks; its phase stamps said
+// (DESIGN 4.0): a hop stream costs ~1,150 fixed cycles + 73 per trip for ONE wave whatever the other waves do, the tap MFMAs and
+// the acc = tap + w * sum FMAs follow strictly behind it, every chunk ends in a barrier-separated epilogue, and every step waits
+// ~100 units for the operand it has just stored to come back from L2. This kernel changes what a hop processes:
+//  * 32 output features per chunk as TWO 16-feature image planes (plane 1 = plane 0 + GCRNN_HOP_WIDE_PLANE bytes) read by ONE stream:
+//    one column read and two address XORs per trip serve four 16-byte gathers and two v_smfmac (GCRNN_HOP_ASM_WIDE32_TEXT,
+//    tools/gen_hop_asm.py gen_wide32) -- half the streams, barriers, seeds and epilogues per step, the per-trip overhead amortised
+//    over twice the bytes. Plan arrays are those of the 16-feature bf16 image (graph.fused_plan_img16) unchanged.
+//  * the graph weight w is folded into the tap weights (W_k <- w^k W_k, gcrnn_fused_pack_weights_wide): Horner then reads
+//    t_j = u~_j + P0 t_{j+1} on the 0/1 pattern P0, so a hop's sums need no multiply and the tap MFMAs accumulate straight ONTO them
+//    (D = A B + D): no separate tap tuple, no packed FMAs -- the registers that frees hold the second half's accumulators.
+//  * output features are assigned to MFMA rows so that lane (r, q) ends a chunk holding features 32 c + 8 q .. + 7 of its node
+//    (half h, row 4 q + e <-> feature 32 c + 8 q + 4 h + e; a permutation of the weight rows only): ONE 16-byte state store per lane
+//    and tile -- and those four packed registers ARE the lane's B fragment of k-step c for the next time step. The last chunk's state
+//    is handed over in registers; the earlier chunks' (stored long before) and x_{t+1} are requested at the start of the last
+//    chunk's epilogue, so the step boundary waits for nothing that was not already on its way.
+//  * LDS: planes / transposed user-layout tile 66 KB | ONE chunk's weight fragments K*KS*2 KB (the next chunk's arrive by LDS-DMA
+//    during the epilogue) | column words | a 128-node inline-pack tile (8 rounds per step, one per hop at K = 5).
+// Arithmetic differs from the 16-feature kernels only in rounding (w^k W_k rounded to bf16 instead of W_k, sums before taps), so this
+// kernel is pinned to the fp64 oracle directly (tests/test_fused.py), not bit-compared with them.
+//
+// MODE 0: forward step h_t = tanh(sum_k S^k([h|x] W_k) + 2b)   (reference Utils/graphML.py:2420-2423), un-gated.
+#pragma once
+
+struct Seq32Args {
+  const uint16_t* x0; int64_t xstride;                 // x of step 0 [B][NP][G] bf16 sequence-major, elements between steps
+  const uint16_t* hfirst;                              // h_{-1} = h0 [B][NP][F]
+  uint16_t* out0; int64_t ostride;                     // h_t of step 0 [B][NP][F], elements between steps
+  const uint4* wpack;                                  // [F/32][K][2][KS][64] x 16 B (gcrnn_fused_pack_weights_wide)
+  const float* bias;                                   // [F] or null
+  const uint16_t* a1; int64_t a1stride;                // user-layout output H[0][t] (or null)
+  int a1_last_only;                                    // only the last step writes the user-layout output (at a1 itself)
+  int ubstride;                                        // elements between consecutive sequences of the user-layout output
+  const int32_t* tile_nodes; const int32_t* tile_off; const uint2* ell_col4;      // bf16-image plan (graph.fused_plan_img16)
+  int entries, B, N;
+  const uint16_t* pk_src0; int64_t pksrc_stride;       // inline pack: user-layout block X[0][pk_ahead] (or null), elements between steps
+  uint16_t* pk_dst0; int64_t pkdst_stride;             // ... the sequence-major array of step pk_ahead it is laid out into
+  int pk_stride;                                       // ... elements between consecutive sequences of the user-layout tensor
+  int pk_ahead;                                        // step t lays out the operand of step t + pk_ahead (2: x_{t+1} is complete -- and requested early -- while step t runs)
+  int nsteps;
+};
+
+// this lane's id, re-derived where it is needed (two VALU instructions; volatile: neither hoisted nor kept): anything derived from the
+// thread id that lives across a hop's asm block costs a register the operand, the accumulators and the stream's window do not leave
+__device__ __forceinline__ int lane_now() {
+  int ln;
+  asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln));
+  return ln;
+}
+
+#define GCRNN_HOP_ASM_WIDE32_STREAM(D)                                                             \
+  do {                                                                                             \
+    const int gwbeg = tbeg[0] >> 2, gwend = tend[STILES - 1] >> 2;                                 \
+    _Pragma("unroll") for (int i_ = 0; i_ < STILES; ++i_) { D[i_][0] = f32x4{0.f, 0.f, 0.f, 0.f}; D[i_][1] = f32x4{0.f, 0.f, 0.f, 0.f}; } \
+    if (gwbeg < gwend) {                                                                           \
+      const uint32_t colb = lds_col + r * 8 + (q >> 1) * 4;       /* this lane's own column dword of a slot's pair */ \
+      const uint32_t qh_ = (uint32_t)(q & 1) << 4;                                                 \
+      asm volatile(GCRNN_HOP_ASM_WIDE32_TEXT                                                       \
+                   : "+v"(D[0][0]), "+v"(D[0][1]), "+v"(D[1][0]), "+v"(D[1][1]), "+v"(D[2][0]), "+v"(D[2][1]), "+v"(D[3][0]), "+v"(D[3][1]), \
+                     "+v"(D[4][0]), "+v"(D[4][1]), "+v"(D[5][0]), "+v"(D[5][1]), "+v"(D[6][0]), "+v"(D[6][1]), "+v"(D[7][0]), "+v"(D[7][1])  \
+                   : "s"(GCRNN_SGPR(tend[0] >> 2)), "s"(GCRNN_SGPR(tend[1] >> 2)), "s"(GCRNN_SGPR(tend[2] >> 2)), "s"(GCRNN_SGPR(tend[3] >> 2)), \
+                     "s"(GCRNN_SGPR(tend[4] >> 2)), "s"(GCRNN_SGPR(tend[5] >> 2)), "s"(GCRNN_SGPR(tend[6] >> 2)), "s"(GCRNN_SGPR(tend[7] >> 2)), \
+                     "s"(GCRNN_SGPR(gwbeg)), "s"(GCRNN_SGPR(gwend - 1)), "v"(colb), "v"(qh_)               \
+                   : GCRNN_HOP_ASM_WIDE32_CLOBBERS);                                               \
+    }                                                                                              \
+  } while (0)
+
+template <int K, int HS, int XS>
+struct Seq32Map {
+  static constexpr int KS = HS + XS;
+  static constexpr int PL = GCRNN_HOP_WIDE_PLANE;          // plane 1 of the hop image
+  static constexpr int RS2 = 4 * NP + 16;                  // row of the transposed user-layout tile: [feature pair][node] words; q and q + 1 sit 16 banks apart
+  static constexpr int BIAS_OFF = PL + 32 * 1024;          // behind plane 1 (the transposed tile, 16 rows, ends below it)
+  static constexpr int FLAG_OFF = BIAS_OFF + 256;
+  static constexpr int WOFF = 2 * PL;                      // one chunk's weight fragments
+  static constexpr int WB = K * KS * 2048;
+  static constexpr int COL_OFF = WOFF + WB;
+  static constexpr int NPCK = 128;                         // nodes per inline-pack round
+  static_assert(16 * RS2 <= BIAS_OFF && FLAG_OFF + 768 <= WOFF, "LDS map");
+  static size_t lds_bytes(int64_t entries, bool inline_pack) {
+    const size_t need = (size_t)COL_OFF + (size_t)entries * 32 + GCRNN_HOP_COLUMN_PAD + NP * 4 + (inline_pack ? (size_t)(32 * XS) * NPCK * 2 : 0);
+    return need <= 160 * 1024 ? need : 0;
+  }
+};
+
+template <int K, int HS, int XS>
+__global__ __launch_bounds__(STHREADS) void fused_seq32_kernel(const Seq32Args a) {
+  using M = Seq32Map<K, HS, XS>;
+  constexpr int KS = HS + XS;
+  constexpr int F = 32 * HS, G = 32 * XS;
+  constexpr int NCH = HS;                         // 32-feature output chunks
+  constexpr int PL = M::PL, WOFF = M::WOFF, WB = M::WB, COL_OFF = M::COL_OFF, RS2 = M::RS2;
+  constexpr int NPCK = M::NPCK, NRND = NP / NPCK, NH = NCH * (K - 1), RPH = (NRND + NH - 1) / NH;      // pack rounds per step / hops per step / rounds per hop
+  constexpr int PKROWS = G;
+  static_assert(STILES == 8 && GCRNN_HOP_ASM && K >= 2 && XS > 0, "generated hop stream: 8 tiles per wave");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int entries = a.entries, B = a.B, N = a.N;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 15, q = lane >> 4;
+  if ((int)blockIdx.x >= B) return;
+
+  // once per launch: tile tables, and -- by LDS-DMA, all pieces in flight together -- the column image and chunk 0's weights
+  int tbeg[STILES], tend[STILES];
+#pragma unroll
+  for (int i = 0; i < STILES; ++i) {
+    tbeg[i] = a.tile_off[wave * STILES + i];
+    tend[i] = a.tile_off[wave * STILES + i + 1];
+  }
+  // slot table node << 16 | row16 << 5 | hswz << 4 of every tile slot, in LDS: a lane reads its slot's word where it needs it (eight
+  // live registers would not survive the hops: operand 128 + accumulators 64 + the stream's window)
+  char* wtab = smem + COL_OFF + entries * 32 + GCRNN_HOP_COLUMN_PAD;
+  for (int idx = tid; idx < NP; idx += STHREADS) reinterpret_cast<int32_t*>(wtab)[idx] = a.tile_nodes[idx];
+  // (one asm statement: eight reads in flight, one wait; volatile so that the words are re-read at every use, not kept)
+  auto slot_words = [&](int ln, int (&w)[STILES]) {
+    const uint32_t ad = (uint32_t)(COL_OFF + entries * 32 + GCRNN_HOP_COLUMN_PAD) + (uint32_t)((wave * STILES * 16 + (ln & 15)) * 4);
+    asm volatile("ds_read_b32 %0, %8\n\tds_read_b32 %1, %8 offset:64\n\tds_read_b32 %2, %8 offset:128\n\tds_read_b32 %3, %8 offset:192\n\t"
+                 "ds_read_b32 %4, %8 offset:256\n\tds_read_b32 %5, %8 offset:320\n\tds_read_b32 %6, %8 offset:384\n\tds_read_b32 %7, %8 offset:448\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(w[0]), "=&v"(w[1]), "=&v"(w[2]), "=&v"(w[3]), "=&v"(w[4]), "=&v"(w[5]), "=&v"(w[6]), "=&v"(w[7])
+                 : "v"(ad));
+    const int lb = (((ln >> 4) >> 1) << 4) | (((ln >> 4) & 1) << 3);      // xor this lane's (half, piece)
+#pragma unroll
+    for (int i = 0; i < STILES; ++i) w[i] ^= lb;
+  };
+  {
+    const int cbytes = entries * 32;
+    const char* csrc = reinterpret_cast<const char*>(a.ell_col4);
+    for (int p = wave; p * 1024 < cbytes; p += SWAVES)
+      if (p * 1024 + lane * 16 < cbytes)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(csrc + p * 1024 + lane * 16),
+                                         (__attribute__((address_space(3))) void*)(smem + COL_OFF + p * 1024), 16, 0, 0);
+    const char* wsrc = reinterpret_cast<const char*>(a.wpack);
+    for (int p = wave; p < WB / 1024; p += SWAVES)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc + p * 1024 + lane * 16),
+                                       (__attribute__((address_space(3))) void*)(smem + WOFF + p * 1024), 16, 0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  // zeros behind the column image: the stream's running column pointer is not clamped (GCRNN_HOP_COLUMN_PAD)
+  if (tid < GCRNN_HOP_COLUMN_PAD / 4) reinterpret_cast<uint32_t*>(smem + COL_OFF + entries * 32)[tid] = 0u;
+  float* lbias = reinterpret_cast<float*>(smem + M::BIAS_OFF);
+  if (tid < F) lbias[tid] = a.bias ? a.bias[tid] : 0.f;
+  __syncthreads();
+
+  const uint32_t lds0 = (uint32_t)reinterpret_cast<uintptr_t>(smem);
+  if (lds0 != 0) __builtin_trap();        // the asm stream forms gather addresses from column words: the image must sit at LDS address 0
+  const uint32_t lds_col = lds0 + COL_OFF;
+  char* xtile = wtab + NP * 4;
+
+  for (int b = blockIdx.x; b < B; b += gridDim.x) {
+  // ---- the operand of a sequence and step: every B fragment of the wave, resident for all chunks ----------------------------------
+  bf16x8 bfr[STILES][KS];
+  {
+    const __amdgpu_buffer_rsrc_t rsrc_h = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(a.hfirst), 0, B * (NP * F * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(a.x0), 0, B * (NP * G * 2), 0x00020000);
+    const int ln0 = lane_now(), qo = ln0 >> 4;
+    int sw[STILES];
+    slot_words(ln0, sw);
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+#pragma unroll
+      for (int i = 0; i < STILES; ++i) {
+        const int w = sw[i];
+        if (s < HS)
+          bfr[i][s] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsrc_h, (w >> 16) * (F * 2) + 16 * qo + 64 * s, b * (NP * F * 2), 0));
+        else
+          bfr[i][s] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, (w >> 16) * (G * 2) + 16 * qo + 64 * (s - HS), b * (NP * G * 2), 0));
+      }
+    }
+  }
+#pragma unroll 1
+  for (int step = 0; step < a.nsteps; ++step) {
+    uint16_t* hout = a.out0 + (int64_t)step * a.ostride;
+    const uint16_t* aux1 = a.a1 ? (a.a1_last_only ? (step == a.nsteps - 1 ? a.a1 : nullptr) : a.a1 + (int64_t)step * a.a1stride) : nullptr;
+    const int pka = a.pk_ahead > 0 ? a.pk_ahead : 1;
+    const bool pk = a.pk_src0 && step + pka < a.nsteps;
+    const uint16_t* pk_src = pk ? a.pk_src0 + (int64_t)step * a.pksrc_stride : nullptr;
+    uint16_t* pk_dst = pk ? a.pk_dst0 + (int64_t)step * a.pkdst_stride : nullptr;
+    const int pk_stride = a.pk_stride, ubstride = a.ubstride;
+    const int64_t pk_soff = (int64_t)b * pk_stride;
+    const __amdgpu_buffer_rsrc_t rsrc_o = __builtin_amdgcn_make_buffer_rsrc(hout, 0, B * (NP * F * 2), 0x00020000);
+    const bool more = step + 1 < a.nsteps;      // the next step's operand is requested at the start of this step's last epilogue
+    const __amdgpu_buffer_rsrc_t rsrc_xn = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(a.x0 + (int64_t)(step + 1) * a.xstride), 0, more ? B * (NP * G * 2) : 0, 0x00020000);
+
+    f32x4 acc[STILES][2];
+    // acc[i][h] += W_tap(c, half h) [h|x]^T for the wave's 8 tiles: one weight fragment feeds 8 independent MFMA chains
+    auto taps = [&](int tap) {
+      const int ln = lane_now();                       // (the fragment address is re-derived per call, not kept -- or spilled -- across the hops)
+      const uint32_t wofs = (uint32_t)WOFF + (uint32_t)ln * 16u;
+      // (the next fragment is requested before the current one's eight MFMAs)
+      uint4 af[2];
+      af[0] = *reinterpret_cast<const uint4*>(smem + wofs + (uint32_t)((tap * 2 * KS) * 1024));
+#pragma unroll
+      for (int hs = 0; hs < 2 * KS; ++hs) {
+        const int h = hs / KS, s = hs - h * KS;
+        if (hs + 1 < 2 * KS) af[(hs + 1) & 1] = *reinterpret_cast<const uint4*>(smem + wofs + (uint32_t)((tap * 2 * KS + hs + 1) * 1024));
+        const bf16x8 afr = __builtin_bit_cast(bf16x8, af[hs & 1]);
+#pragma unroll
+        for (int i = 0; i < STILES; ++i) acc[i][h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr, bfr[i][s], acc[i][h], 0, 0, 0);
+      }
+    };
+    auto put = [&]() {
+      int sw[STILES];
+      slot_words(lane_now(), sw);
+#pragma unroll
+      for (int i = 0; i < STILES; ++i) {
+        const int wv = sw[i];
+        state_put<true>(reinterpret_cast<float*>(smem), wv, acc[i][0]);
+        state_put<true>(reinterpret_cast<float*>(smem + PL), wv, acc[i][1]);
+      }
+    };
+    // seed of a chunk: tap K-1 goes straight into the hop image (every wave has left the image: the barrier before)
+    auto seed = [&]() {
+#pragma unroll
+      for (int i = 0; i < STILES; ++i) { acc[i][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[i][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+      taps(K - 1);
+      put();
+    };
+    seed();
+
+#pragma unroll 1
+    for (int chunk = 0; chunk < NCH; ++chunk) {
+      // opaque per chunk: index arithmetic is re-derived from it inside the loop -- hoisted out it would have to be spilled
+      const int lane = lane_now();
+      const int tl = wave * 64 + lane;
+      const int r = lane & 15, q = lane >> 4;
+      const bool last = chunk == NCH - 1;
+      lds_barrier();      // the seed is in the image
+
+      // inline pack, round rnd: x_{t+pka}[:, rnd * 128 .. + 127] (user layout, rows = features) by LDS-DMA into the tile ...
+      auto pack_issue = [&](int rnd) {
+        constexpr int PPR = NPCK / 8, PIECES = PKROWS * PPR;
+        static_assert(PIECES % STHREADS == 0, "whole pieces per thread");
+        const uint16_t* xsrc = pk_src + pk_soff + rnd * NPCK;
+#pragma unroll
+        for (int i = 0; i < PIECES / STHREADS; ++i) {
+          const int id = i * STHREADS + tl;
+          const int row = id / PPR, cs = id - row * PPR;
+          const int col = (cs - (row >> 3)) & (PPR - 1);
+          if (rnd * NPCK + col * 8 < N)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xsrc + (int64_t)row * N + col * 8),
+                                             (__attribute__((address_space(3))) void*)(xtile + (i * STHREADS + wave * 64) * 16), 16, 0, 0);
+        }
+      };
+      // ... and out of it transposed: whole sequence-major rows [node][features]
+      auto pack_drain = [&](int rnd) {
+        constexpr int PCS = PKROWS / 8, RI = PCS * NPCK / STHREADS;
+        static_assert(PCS * NPCK % STHREADS == 0, "whole row pieces per thread");
+        typedef __attribute__((__vector_size__(4 * sizeof(unsigned int)))) unsigned int u32x4_t;
+        const __amdgpu_buffer_rsrc_t rsrc_pk = __builtin_amdgcn_make_buffer_rsrc(pk_dst, 0, B * (NP * PKROWS * 2), 0x00020000);
+        u32x4_t vv[RI];
+#pragma unroll
+        for (int i = 0; i < RI; ++i) {
+          const int id = i * STHREADS + tl;
+          const int nl = id / PCS, pc = id - nl * PCS;
+          const char* src = xtile + (pc * 8) * (NPCK * 2) + ((nl + 8 * pc) & (NPCK - 1)) * 2;
+          uint32_t w4[4];
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj) {
+            const uint32_t lo = *reinterpret_cast<const uint16_t*>(src + (2 * jj) * (NPCK * 2));
+            const uint32_t hi = *reinterpret_cast<const uint16_t*>(src + (2 * jj + 1) * (NPCK * 2));
+            w4[jj] = lo | (hi << 16);
+          }
+          const bool ok = rnd * NPCK + nl < N;
+          vv[i] = u32x4_t{ok ? w4[0] : 0u, ok ? w4[1] : 0u, ok ? w4[2] : 0u, ok ? w4[3] : 0u};
+        }
+#pragma unroll
+        for (int i = 0; i < RI; ++i) asm volatile("" : "+v"(vv[i]));          // every piece in its own tuple before the first store (gfx950 store-data hazard)
+#pragma unroll
+        for (int i = 0; i < RI; ++i) {
+          const int id = i * STHREADS + tl;
+          const int nl = id / PCS, pc = id - nl * PCS;
+          __builtin_amdgcn_raw_buffer_store_b128(vv[i], rsrc_pk, (rnd * NPCK + nl) * (PKROWS * 2) + pc * 16 + b * (NP * PKROWS * 2), 0, 0);
+        }
+      };
+
+      // ---- Horner hops on the two-plane bf16 image; the tap a hop adds accumulates onto its sums --------------------------------
+      auto hop = [&](auto jc) __attribute__((always_inline)) {
+        constexpr int j = decltype(jc)::value;
+        const int r0 = (chunk * (K - 1) + (j - 1)) * RPH;      // this hop's first pack round
+        if (pk_src && r0 < NRND) pack_issue(r0);
+        GCRNN_HOP_ASM_WIDE32_STREAM(acc);
+        taps(K - 1 - j);
+        if (pk_src) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's LDS-DMA pieces have landed (they had the stream)
+        lds_barrier();      // every wave has left the image (and the weights, after the last hop); every piece of the pack tile is in
+        if (j < K - 1) put();
+        if (j == K - 1) {
+          // the next chunk's weight fragments (after the last chunk: chunk 0's, for the next step): LDS-DMA over the ones just used,
+          // landed by the end-of-chunk wait
+          const int nc = (chunk + 1) % NCH;
+          if (NCH > 1) {
+            const char* wsrc = reinterpret_cast<const char*>(a.wpack) + (size_t)nc * WB;
+#pragma unroll
+            for (int i = 0; i < (WB / 1024 + SWAVES - 1) / SWAVES; ++i) {
+              const int piece = i * SWAVES + wave;
+              if (piece < WB / 1024)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc + piece * 1024 + lane * 16),
+                                                 (__attribute__((address_space(3))) void*)(smem + WOFF + piece * 1024), 16, 0, 0);
+            }
+          }
+        }
+        if (pk_src && r0 < NRND) pack_drain(r0);
+#pragma unroll
+        for (int e = 1; e < RPH; ++e) {       // (fewer hops than rounds: the extra rounds are not hidden behind a stream)
+          if (pk_src && r0 + e < NRND) {
+            lds_barrier();
+            pack_issue(r0 + e);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            lds_barrier();
+            pack_drain(r0 + e);
+          }
+        }
+        if (j < K - 1) lds_barrier();      // the image is complete (and the pack tile read)
+      };
+      seq_static_for(hop, std::make_integer_sequence<int, K - 1>{});
+
+      // ---- epilogue: + 2 b, tanh, bf16; lane (r, q) holds features 32 c + 8 q .. + 7 of its node: ONE 16-byte store per tile ------------
+      typedef __attribute__((__vector_size__(4 * sizeof(unsigned int)))) unsigned int u32x4_t;
+      if (last && more) {
+        // the next step's operand: x_{t+1} (laid out two steps ahead, or by the caller) and the state features of the earlier chunks
+        // (stored -- and waited for -- at their chunk's end); the last chunk's come from this epilogue's registers below
+        const int qo = lane_now() >> 4;
+        int sw[STILES];
+        slot_words(lane, sw);
+        const __amdgpu_buffer_rsrc_t rsrc_hn = __builtin_amdgcn_make_buffer_rsrc(hout, 0, B * (NP * F * 2), 0x00020000);
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+          if (s == HS - 1) continue;
+#pragma unroll
+          for (int i = 0; i < STILES; ++i) {
+            const int w = sw[i];
+            if (s < HS)
+              bfr[i][s] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsrc_hn, (w >> 16) * (F * 2) + 16 * qo + 64 * s, b * (NP * F * 2), 0));
+            else
+              bfr[i][s] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsrc_xn, (w >> 16) * (G * 2) + 16 * qo + 64 * (s - HS), b * (NP * G * 2), 0));
+          }
+        }
+      }
+      float bs[2][4];
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) bs[h][e] = 2.f * lbias[chunk * 32 + q * 8 + h * 4 + e];      // the one bias is added by both filters (graphML.py:2420-2421)
+      u32x4_t pkd[STILES];
+      int swe[STILES];
+      slot_words(lane, swe);
+#pragma unroll
+      for (int i = 0; i < STILES; ++i) {
+        const int node = swe[i] >> 16;
+        u32x4_t p{0u, 0u, 0u, 0u};
+        if (node < N) {
+          const f32x4 a0 = acc[i][0], a1 = acc[i][1];
+          p[0] = pack2bf(fast_tanh(a0[0] + bs[0][0]), fast_tanh(a0[1] + bs[0][1]));
+          p[1] = pack2bf(fast_tanh(a0[2] + bs[0][2]), fast_tanh(a0[3] + bs[0][3]));
+          p[2] = pack2bf(fast_tanh(a1[0] + bs[1][0]), fast_tanh(a1[1] + bs[1][1]));
+          p[3] = pack2bf(fast_tanh(a1[2] + bs[1][2]), fast_tanh(a1[3] + bs[1][3]));
+        }
+        pkd[i] = p;
+        __builtin_amdgcn_raw_buffer_store_b128(p, rsrc_o, node * (F * 2) + (chunk * 32 + q * 8) * 2, b * (NP * F * 2), 0);
+      }
+      if (last) {
+        // h_t's last 32 features ARE the lanes' B fragments of k-step HS-1: handed to the next step in registers
+#pragma unroll
+        for (int i = 0; i < STILES; ++i) bfr[i][HS - 1] = __builtin_bit_cast(bf16x8, pkd[i]);
+      }
+      if (aux1) {
+        // user layout H[b][t][f][:] (node-contiguous rows) through a transposed LDS tile of 32-bit words [feature pair][node]: a lane's
+        // four packed registers are four such words (pairs 4 q .. 4 q + 3). Nobody reads the image any more (the last hop's barrier).
+        char* tst = smem;
+        int swt[STILES];
+        slot_words(lane, swt);
+#pragma unroll
+        for (int i = 0; i < STILES; ++i) {
+          const int node = swt[i] >> 16;
+          char* ra = tst + (4 * q) * RS2 + node * 4;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) *reinterpret_cast<uint32_t*>(ra + k * RS2) = pkd[i][k];
+        }
+        lds_barrier();
+        const int segs = N >> 3;
+        uint16_t* ub = const_cast<uint16_t*>(aux1) + (int64_t)b * ubstride + (int64_t)(chunk * 32) * N;
+        const __amdgpu_buffer_rsrc_t rsrc_u = __builtin_amdgcn_make_buffer_rsrc(ub, 0, 32 * N * 2, 0x00020000);
+        for (int idx = tl; idx < 16 * segs; idx += STHREADS) {
+          const int fp = idx / segs, sg = idx - fp * segs;
+          const u32x4_t w0 = *reinterpret_cast<const u32x4_t*>(tst + fp * RS2 + sg * 32);
+          const u32x4_t w1 = *reinterpret_cast<const u32x4_t*>(tst + fp * RS2 + sg * 32 + 16);
+          const u32x4_t ev = {__builtin_amdgcn_perm(w0[1], w0[0], 0x05040100u), __builtin_amdgcn_perm(w0[3], w0[2], 0x05040100u),
+                              __builtin_amdgcn_perm(w1[1], w1[0], 0x05040100u), __builtin_amdgcn_perm(w1[3], w1[2], 0x05040100u)};
+          const u32x4_t od = {__builtin_amdgcn_perm(w0[1], w0[0], 0x07060302u), __builtin_amdgcn_perm(w0[3], w0[2], 0x07060302u),
+                              __builtin_amdgcn_perm(w1[1], w1[0], 0x07060302u), __builtin_amdgcn_perm(w1[3], w1[2], 0x07060302u)};
+          __builtin_amdgcn_raw_buffer_store_b128(ev, rsrc_u, ((2 * fp) * N + sg * 8) * 2, 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b128(od, rsrc_u, ((2 * fp + 1) * N + sg * 8) * 2, 0, 0);
+        }
+      }
+      // the next chunk's weights have landed (LDS-DMA), this chunk's stores have retired (the next step reads some of them back),
+      // the tile has been read: the image may be seeded again
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      lds_barrier();
+      if (chunk + 1 < NCH) seed();
+    }  // chunks
+  }  // steps
+  }  // sequences
+}

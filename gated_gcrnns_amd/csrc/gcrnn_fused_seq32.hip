@@ -1,0 +1,140 @@
+// 32-feature-chunk sequence-resident forward (gcrnn_fused_seq32.h): weight packing, dispatch, C entry points.
+#include "gcrnn_fused_step.h"
+#include "gcrnn_fused_seq32.h"
+
+// weights -> per-lane MFMA A fragments (bf16) of the wide kernel:  wpack[chunk32][tap][half][kstep][lane][8]
+//   MFMA row m = lane & 15 of (chunk c, half h) is output feature 32 c + 8 (m >> 2) + 4 h + (m & 3) -- lane (r, q) of the D tile then holds
+//   features 32 c + 8 q .. + 7 of its node (gcrnn_fused_seq32.h); k = 32 kstep + 8 (lane >> 4) + j over the concatenated [h | x] features.
+//   Tap k is scaled by w^k (w = the graph's one weight): the hops then sum the 0/1 pattern, no multiply (Horner t_j = w^j v_j).
+template <typename W>
+__global__ void pack_weights_wide_kernel(const W* __restrict__ wA, const W* __restrict__ wB, uint16_t* __restrict__ out,
+                                         int F, int G, int Kin, int Kst, int K, float w) {
+  const int KS = (F + G) / 32;
+  const int64_t total = (int64_t)(F / 32) * K * 2 * KS * 64 * 8;
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int j = idx & 7, lane = (idx >> 3) & 63;
+  int64_t rest = idx >> 9;
+  const int s = rest % KS; rest /= KS;
+  const int h = rest & 1; rest >>= 1;
+  const int tap = rest % K;
+  const int chunk = rest / K;
+  const int m = lane & 15;
+  const int f = chunk * 32 + 8 * (m >> 2) + 4 * h + (m & 3);
+  const int feat = 32 * s + 8 * (lane >> 4) + j;
+  float v = 0.f;
+  if (feat < F) { if (tap < Kst) v = (float)wB[((int64_t)f * Kst + tap) * F + feat]; }
+  else          { if (tap < Kin) v = (float)wA[((int64_t)f * Kin + tap) * G + (feat - F)]; }
+  float sc = 1.f;
+  for (int k = 0; k < tap; ++k) sc *= w;
+  out[idx] = f2bf(v * sc);
+}
+
+extern "C" int gcrnn_fused_pack_weights_wide(int wdtype, const void* wA, const void* wB, void* wpack, int64_t F, int64_t G,
+                                             int64_t Kin, int64_t Kst, double uniform_w, void* stream) {
+  if (!wA || !wB || !wpack) return GCRNN_ERR_NULL_POINTER;
+  if (F <= 0 || G < 0 || F % 32 || (F + G) % 32 || Kin <= 0 || Kst <= 0 || uniform_w == 0.0) return GCRNN_ERR_BAD_SHAPE;
+  const int K = (int)(Kin > Kst ? Kin : Kst);
+  const int64_t total = (F / 32) * K * 2 * ((F + G) / 32) * 64 * 8;
+  GCRNN_PRE_LAUNCH();
+  if (wdtype == GCRNN_F32)
+    pack_weights_wide_kernel<float><<<(unsigned)cdiv(total, 256), 256, 0, as_stream(stream)>>>(
+        (const float*)wA, (const float*)wB, (uint16_t*)wpack, (int)F, (int)G, (int)Kin, (int)Kst, K, (float)uniform_w);
+  else if (wdtype == GCRNN_BF16)
+    pack_weights_wide_kernel<__hip_bfloat16><<<(unsigned)cdiv(total, 256), 256, 0, as_stream(stream)>>>(
+        (const __hip_bfloat16*)wA, (const __hip_bfloat16*)wB, (uint16_t*)wpack, (int)F, (int)G, (int)Kin, (int)Kst, K, (float)uniform_w);
+  else
+    return GCRNN_ERR_BAD_DTYPE;
+  GCRNN_CHECK_LAUNCH();
+  return GCRNN_OK;
+}
+
+// GCRNN_SEQ32=0 keeps the 16-feature kernels (A/B); GCRNN_SEQ32_MIN_B=n overrides the batch rule (tests)
+static bool seq32_wanted(int64_t B) {
+  const char* off = getenv("GCRNN_SEQ32");
+  if (off && off[0] == '0') return false;
+  const char* mb = getenv("GCRNN_SEQ32_MIN_B");
+  if (mb) return B >= (atoi(mb) < 1 ? 1 : atoi(mb));
+  const char* off16 = getenv("GCRNN_SEQ_KERNEL");      // (no sequence-resident kernel at all: A/B against the chunk-parallel kernel)
+  if (off16 && off16[0] == '0') return false;
+  // one workgroup per sequence: whole rounds of 256 sequences (fused_seq_wanted's cost model with the 16-feature chunk count;
+  // GCRNN_SEQ_MIN_B, the 16-feature kernel's test override, does not move problems onto this one)
+  const double rounds_seq = (double)((B + 255) / 256), rounds_chunk = (double)((B * 4 + 255) / 256);
+  return rounds_seq * 0.875 * 4 < rounds_chunk;
+}
+
+template <int K, int HS, int XS>
+static size_t seq32_lds(int64_t entries, bool inline_pack) { return Seq32Map<K, HS, XS>::lds_bytes(entries, inline_pack); }
+
+static size_t seq32_lds_for(int64_t F, int64_t G, int64_t K, int64_t entries, bool inline_pack) {
+#define GCRNN_SEQ32_CASE(KK, HH, XX) if (K == KK && F == 32 * HH && G == 32 * XX) return seq32_lds<KK, HH, XX>(entries, inline_pack);
+  GCRNN_SEQ32_CASE(5, 2, 2) GCRNN_SEQ32_CASE(4, 2, 2) GCRNN_SEQ32_CASE(3, 2, 2) GCRNN_SEQ32_CASE(2, 2, 2)
+  GCRNN_SEQ32_CASE(5, 2, 1) GCRNN_SEQ32_CASE(4, 2, 1) GCRNN_SEQ32_CASE(3, 2, 1) GCRNN_SEQ32_CASE(2, 2, 1)
+  GCRNN_SEQ32_CASE(5, 1, 1) GCRNN_SEQ32_CASE(4, 1, 1) GCRNN_SEQ32_CASE(3, 1, 1) GCRNN_SEQ32_CASE(2, 1, 1)
+#undef GCRNN_SEQ32_CASE
+  return 0;
+}
+
+// 1 when gcrnn_fused_forward_wide_bf16 takes this problem (un-gated cell, uniform-weight bf16-image plan, a batch that fills whole rounds
+// of the chip, LDS room); inline_pack: with the layout of X inside the launch (N % 8 == 0, T > 2: the caller lays out x_0 and x_1)
+extern "C" int gcrnn_fused_forward_wide_supported(int64_t B, int64_t T, int64_t N, int64_t F, int64_t G, int64_t K, int64_t entries,
+                                                  double uniform_w, int img16, int inline_pack) {
+  if (uniform_w == 0.0 || !img16 || N <= 0 || N > NP || B <= 0 || T <= 0 || entries <= 0 || entries % 4) return 0;
+  if (inline_pack && (N % 8 || T * G * N > 2147483647LL)) return 0;
+  if (B * (NP * (F > G ? F : G) * 2) > 2147483647LL || T * F * N > 2147483647LL) return 0;
+  if (!seq32_wanted(B)) return 0;
+  return seq32_lds_for(F, G, K, entries, inline_pack != 0) ? 1 : 0;
+}
+
+template <int K, int HS, int XS>
+static int seq32_launch(const Seq32Args& sa, bool inline_pack, hipStream_t st) {
+  const size_t lds = seq32_lds<K, HS, XS>(sa.entries, inline_pack);
+  if (!lds) return GCRNN_ERR_UNSUPPORTED;
+  auto sk = fused_seq32_kernel<K, HS, XS>;
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(sk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    return GCRNN_ERR_LAUNCH;
+  GCRNN_PRE_LAUNCH();
+  sk<<<(unsigned)(sa.B < 256 ? sa.B : 256), STHREADS, lds, st>>>(sa);
+  GCRNN_CHECK_LAUNCH();
+  return GCRNN_OK;
+}
+
+// Whole un-gated forward as ONE launch of the wide sequence-resident kernel (reference Utils/graphML.py:2351-2427 without gates).
+// xs [T][B][NP][G] bf16 sequence-major (every step laid out, or -- with Xuser_inline = the user-layout X [B][T][G][N] -- steps 0 and 1 only:
+// step t lays out x_{t+2}), h0 [B][NP][F], hs [T][B][NP][F] (out), wpack from gcrnn_fused_pack_weights_wide, bias [F] fp32 or NULL,
+// plan arrays of the bf16-image plan; Huser [B][T or 1][F][N] bf16 or NULL (huser_last_only: the last step only).
+extern "C" int gcrnn_fused_forward_wide_bf16(const void* xs, const void* h0, void* hs, const void* wpack, const float* bias,
+                                             const int32_t* tile_nodes, const int32_t* tile_off, const void* ell_col4, int64_t entries,
+                                             int64_t B, int64_t T, int64_t N, int64_t F, int64_t G, int64_t K, void* Huser,
+                                             int huser_last_only, const void* Xuser_inline, void* stream) {
+  if (!xs || !h0 || !hs || !wpack || !tile_nodes || !tile_off || !ell_col4) return GCRNN_ERR_NULL_POINTER;
+  if (B <= 0 || T <= 0 || N <= 0 || N > NP || B > (1 << 24) || entries <= 0 || entries % 4) return GCRNN_ERR_BAD_SHAPE;
+  if (B * (NP * (F > G ? F : G) * 2) > 2147483647LL || T * F * N > 2147483647LL) return GCRNN_ERR_BAD_SHAPE;   // 32-bit buffer offsets
+  if (Huser && (N % 8 != 0 || (reinterpret_cast<uintptr_t>(Huser) & 15))) return GCRNN_ERR_BAD_SHAPE;
+  if (Xuser_inline && (N % 8 != 0 || (reinterpret_cast<uintptr_t>(Xuser_inline) & 15) || T * G * N > 2147483647LL)) return GCRNN_ERR_BAD_SHAPE;
+  const int64_t xstep = B * NP * G, hstep = B * NP * F;
+  Seq32Args sa{};
+  sa.x0 = (const uint16_t*)xs; sa.xstride = xstep;
+  sa.hfirst = (const uint16_t*)h0;
+  sa.out0 = (uint16_t*)hs; sa.ostride = hstep;
+  sa.wpack = (const uint4*)wpack; sa.bias = bias;
+  sa.a1 = (const uint16_t*)Huser; sa.a1stride = F * N; sa.a1_last_only = huser_last_only ? 1 : 0;
+  sa.ubstride = (int)((huser_last_only ? 1 : T) * F * N);
+  sa.tile_nodes = tile_nodes; sa.tile_off = tile_off; sa.ell_col4 = (const uint2*)ell_col4;
+  sa.entries = (int)entries; sa.B = (int)B; sa.N = (int)N;
+  sa.nsteps = (int)T;
+  const bool inline_pack = Xuser_inline != nullptr && T > 2;
+  if (inline_pack) {
+    sa.pk_ahead = 2;
+    sa.pk_src0 = (const uint16_t*)Xuser_inline + 2 * G * N; sa.pksrc_stride = G * N;
+    sa.pk_dst0 = const_cast<uint16_t*>(sa.x0) + 2 * xstep; sa.pkdst_stride = xstep;
+    sa.pk_stride = (int)(T * G * N);
+  }
+  hipStream_t st = as_stream(stream);
+#define GCRNN_SEQ32_CASE(KK, HH, XX) if (K == KK && F == 32 * HH && G == 32 * XX) return seq32_launch<KK, HH, XX>(sa, inline_pack, st);
+  GCRNN_SEQ32_CASE(5, 2, 2) GCRNN_SEQ32_CASE(4, 2, 2) GCRNN_SEQ32_CASE(3, 2, 2) GCRNN_SEQ32_CASE(2, 2, 2)
+  GCRNN_SEQ32_CASE(5, 2, 1) GCRNN_SEQ32_CASE(4, 2, 1) GCRNN_SEQ32_CASE(3, 2, 1) GCRNN_SEQ32_CASE(2, 2, 1)
+  GCRNN_SEQ32_CASE(5, 1, 1) GCRNN_SEQ32_CASE(4, 1, 1) GCRNN_SEQ32_CASE(3, 1, 1) GCRNN_SEQ32_CASE(2, 1, 1)
+#undef GCRNN_SEQ32_CASE
+  return GCRNN_ERR_UNSUPPORTED;
+}

@@ -368,6 +368,20 @@ def time_fused_step_kernel(X, h0, wA, wB, bias, graph, reps=3, inline=None, user
     ok = fused_inline_pack_ok(plan, N, F, G, K)          # the launches as the forward issues them: with the inline pack of x_{t+1} where it
     inline = (ok if inline is None else (ok and inline)) and X.data_ptr() % 16 == 0     # applies; inline=False times the bare step for comparison
     plan16 = fused_img16_plan(graph, False, None)
+    wide = fused_wide_plan(graph, B, T, N, F, G, K, inline)
+    if wide is not None:
+        # the wide sequence-resident kernel (what fused_cell_forward issues for this problem): ONE launch per forward
+        wpw = _fused_pack_weights_wide(wAc, wBc, wide['uniform_w'], st)
+        for rep in range(reps + 1):
+            if rep == 1:
+                torch.cuda.synchronize()
+                e0.record()
+            _fused_forward_wide(wide, xs, h0s, hs, wAc, wBc, b32, B, T, N, F, G, K, H, False, Xc if inline else None, st, wpw=wpw)
+        e1.record()
+        torch.cuda.synchronize()
+        per_step = 1e3 * e0.elapsed_time(e1) / (reps * T)
+        return {'avg_us': per_step, 'launches': reps, 'inline_pack': bool(inline), 'steps_per_launch': T,
+                'launch_avg_us': per_step * T, 'kernel': 'fused_seq32_kernel'}
     for rep in range(reps + 1):
         if rep == 1:                                     # (launch 0 is a warm-up: first touch of the fresh output buffers, code and plan not yet in cache)
             torch.cuda.synchronize()
@@ -395,6 +409,39 @@ def _fused_pack_weights(wA, wB, st):
     check(lib.gcrnn_fused_pack_weights(dtype_code(wA.dtype), _p(wAc), _p(wBc), _p(wpack),
                                        F, G, Kin, Kst, st), 'pack_weights')
     return wpack
+
+
+def _fused_pack_weights_wide(wA, wB, uniform_w, st):
+    """Taps as the MFMA A fragments of the wide sequence-resident kernel (csrc/gcrnn_fused_seq32.h): 32-feature chunks, feature
+    permutation of the rows, tap k scaled by uniform_w^k."""
+    F, G = wA.shape[0], wA.shape[3]
+    Kin, Kst = wA.shape[2], wB.shape[2]
+    K = max(Kin, Kst)
+    wpack = torch.empty(((F // 32) * K * 2 * ((F + G) // 32) * 64 * 8,), dtype=torch.bfloat16, device=wA.device)
+    wAc, wBc = wA.contiguous(), wB.contiguous()
+    check(lib.gcrnn_fused_pack_weights_wide(dtype_code(wA.dtype), _p(wAc), _p(wBc), _p(wpack), F, G, Kin, Kst, float(uniform_w), st),
+          'pack_weights_wide')
+    return wpack
+
+
+def fused_wide_plan(graph, B, T, N, F, G, K, inline):
+    """The bf16-image plan when the wide sequence-resident kernel (gcrnn_fused_forward_wide_bf16: un-gated forward as ONE launch, 32-feature
+    chunks) takes this problem, else None. GCRNN_SEQ32=0 switches it off (A/B)."""
+    plan16 = fused_img16_plan(graph, False, None)
+    if plan16 is None or F % 32 or G % 32:
+        return None
+    ok = lib.gcrnn_fused_forward_wide_supported(int(B), int(T), int(N), int(F), int(G), int(K), int(plan16['entries']),
+                                                float(plan16.get('uniform_w', 0.0)), 1, 1 if inline else 0)
+    return plan16 if ok else None
+
+
+def _fused_forward_wide(plan16, xs, h0s, hs, wA, wB, b32, B, T, N, F, G, K, H, last_only, Xinline, st, wpw=None):
+    if wpw is None:
+        wpw = _fused_pack_weights_wide(wA.detach(), wB.detach(), plan16['uniform_w'], st)
+    check(lib.gcrnn_fused_forward_wide_bf16(_p(xs), _p(h0s), _p(hs), _p(wpw), _p(b32), _p(plan16['tile_slots']), _p(plan16['tile_off']),
+                                            _p(plan16['ell_col4']), plan16['entries'], B, T, N, F, G, K,
+                                            _p(H) if H is not None else None, int(bool(last_only)), _p(Xinline) if Xinline is not None else None, st),
+          'fused_forward_wide')
 
 
 def fused_img16_plan(graph, gated, head):
@@ -652,6 +699,22 @@ def fused_cell_forward(X, h0, wA, wB, bias, graph, gates=None, return_states=Fal
         if head[1] is not None:
             y = y + head[1].detach().float().reshape(())
         return y.permute(1, 0, 2).unsqueeze(2).contiguous()          # B x T x 1 x N
+    wide = fused_wide_plan(graph, B, T, N, F, G, K, inline) if (gi is None and evs is None) else None
+    if wide is not None:
+        # un-gated cell, uniform-weight graph, a batch that fills the chip: ONE launch of the wide sequence-resident kernel
+        if native_out:
+            assert not return_states
+            _fused_forward_wide(wide, xs, h0s, hs, wA, wB, b32, B, T, N, F, G, K, None, False, X if inline else None, st)
+            Hv = hs.permute(1, 0, 3, 2)[:, :, :, :N]
+            return Hv[:, T - 1:] if last_only else Hv
+        H = torch.empty((B, 1 if last_only else T, F, N), dtype=torch.bfloat16, device=dev)
+        _fused_forward_wide(wide, xs, h0s, hs, wA, wB, b32, B, T, N, F, G, K, H if direct else None, last_only, X if inline else None, st)
+        if not direct:
+            src = hs[T - 1:] if last_only else hs
+            check(lib.gcrnn_unpack_seq_major(_lib.BF16, _p(src), _p(H), B, 1 if last_only else T, F, N, plan['npad'], None, st), 'unpack_seq')
+        if return_states:
+            return hs_all, plan, H
+        return H
     plan16 = fused_img16_plan(graph, gi is not None, None)
     if native_out:
         assert not return_states
@@ -694,6 +757,10 @@ def fused_cell_forward_native(xs, h0s, wA, wB, bias, graph, N):
         hs_all[0].copy_(h0s)
     wpack = _fused_pack_weights(wA.detach(), wB.detach(), st)
     b32 = bias.detach().float().contiguous().view(-1) if bias is not None else None
+    wide = fused_wide_plan(graph, B, T, N, F, G, K, False)
+    if wide is not None:
+        _fused_forward_wide(wide, xs, hs_all[:1], hs_all[1:], wA, wB, b32, B, T, N, F, G, K, None, False, None, st)
+        return hs_all[1:]
     plan16 = fused_img16_plan(graph, False, None)
     check(lib.gcrnn_fused_forward_bf16(_p(xs), _p(hs_all[:1]), _p(hs_all[1:]), _p(wpack), _p(b32), None, None, *_fused_graph_args(plan16 or plan),
                                        B, T, N, F, G, K, None, (2 if plan16 else 0), None, plan.get('uniform_w', 0.0), None, None, None, st),

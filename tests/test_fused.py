@@ -1991,6 +1991,7 @@ def test_sequence_resident_kernel_full_size_matches_the_chunk_parallel_kernel(tg
     gen = torch.Generator(device=dev); gen.manual_seed(11)
     X = torch.randn(B, T, F, N, device=dev, generator=gen).to(torch.bfloat16)
     h0 = (0.3 * torch.randn(B, F, N, device=dev, generator=gen)).to(torch.bfloat16)
+    monkeypatch.setenv('GCRNN_SEQ32', '0')      # (the 16-feature sequence-resident kernel: the wide one is pinned to the oracle in tests/test_wide.py)
     with torch.no_grad():
         monkeypatch.setenv('GCRNN_SEQ_KERNEL', '0')
         Href = cell(X, h0).clone()

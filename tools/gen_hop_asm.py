@@ -444,6 +444,101 @@ def gen_uniform16(sparse=False, sums=False, img_off=0):
     return L
 
 
+# ---- two-plane ("wide") summing stream of the 32-feature-chunk sequence-resident kernel (gcrnn_fused_seq32.h) ---------------------
+# The hop image is TWO bf16 planes of 32-byte rows (plane h = output features half h of the chunk), plane 1 WIDE_PLANE bytes behind
+# plane 0, both addressed by the SAME column words (the img16 plan, graph.fused_plan_img16): one column read and two address XORs per
+# trip serve four 16-byte gathers (plane 1 through the instruction's offset field) and two v_smfmac_f32_16x16x64_bf16 -- the per-trip
+# instruction overhead and the per-stream fixed cost are paid once for twice the bytes.
+# Operands: %0..%15 the tiles' D tuples (tile t: %(2t) = half 0, %(2t+1) = half 1; 4 VGPRs each, zeroed by the caller), %16..%23 tile
+# ends, %24 first group, %25 last valid group, %26 column base (+ 8 r + 4 (q >> 1)), %27 = (q & 1) << 4.
+# A set (16 VGPRs) = [plane-1 gather of entry pair word 0 | plane-1 word 1 | plane-0 word 0 | plane-0 word 1]; the address registers are
+# the first registers of the plane-0 tuples, so the plane-1 gathers (which read them) are issued BEFORE the plane-0 gathers overwrite them.
+WIDE_PLANE = IMAGE_B_OFFSET
+WIDE_D = int(os.environ.get('GCRNN_WIDE_DEPTH', '2'))
+WIDE_WIN = 16 * WIDE_D + WIDE_D + 2 + 6               # gather sets, column words, pointer, prologue address; sparse A (4) + index + scratch
+WIDE_BASE = (254 - WIDE_WIN) & ~1
+
+
+def gen_wide32():
+    D = WIDE_D
+    assert 2 <= D <= 3
+    A0 = WIDE_BASE
+    IDX, TMP = A0 + 4, A0 + 5
+    UB = A0 + 6
+    assert UB % 2 == 0 and UB + 16 * D + D + 2 <= 254
+    VCw = lambda p: 'v%d' % (UB + 16 * D + p)
+    VP, VA = 'v%d' % (UB + 16 * D + D), 'v%d' % (UB + 16 * D + D + 1)
+    SGr, STr, SCr = 's88', 's89', 's90'
+    GB, GL, CB, QX, TE = '%24', '%25', '%26', '%27', 16
+    Y = lambda p, e: UB + 16 * p + 4 * e              # plane-1 tuple of word e
+    Xr = lambda p, e: UB + 16 * p + 8 + 4 * e         # plane-0 tuple of word e (its first register holds the gather address)
+    tup = lambda b: 'v[%d:%d]' % (b, b + 3)
+
+    def col_clamped(p, goff, L):
+        L += ['s_add_i32 %s, %s, %d' % (STr, SGr, goff), 's_min_i32 %s, %s, %s' % (STr, STr, GL),
+              'v_lshl_add_u32 %s, %s, 7, %s' % (VA, STr, CB), 'ds_read_b32 %s, %s' % (VCw(p), VA)]
+
+    def gathers(q, L):
+        for e in range(2):
+            L.append('v_xor_b32_sdwa v%d, %s, %s dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_%d src1_sel:DWORD' % (Xr(q, e), VCw(q), QX, e))
+        for e in range(2):
+            L.append('ds_read_b128 %s, v%d offset:%d' % (tup(Y(q, e)), Xr(q, e), WIDE_PLANE))
+        for e in range(2):
+            L.append('ds_read_b128 %s, v%d' % (tup(Xr(q, e)), Xr(q, e)))
+
+    L = ['s_mov_b32 %s, %s' % (SGr, GB)]
+    for p in range(D):
+        col_clamped(p, p, L)
+    # the compressed one-hot A operand of v_smfmac (one non-zero per lane: group (lane & 15) >> 2, position lane & 3) and its index register
+    L += ['v_mbcnt_lo_u32_b32 v%d, -1, 0' % TMP, 'v_mbcnt_hi_u32_b32 v%d, -1, v%d' % (TMP, TMP),
+          'v_and_b32 v%d, 15, v%d' % (TMP, TMP),
+          'v_and_b32 v%d, 3, v%d' % (IDX, TMP),
+          'v_lshrrev_b32 v%d, 2, v%d' % (TMP, TMP),
+          'v_cmp_eq_u32 vcc, 3, v%d' % IDX,
+          'v_or_b32 v%d, 12, v%d' % (IDX, IDX),
+          'v_cndmask_b32 v%d, v%d, 12, vcc' % (IDX, IDX),
+          'v_mov_b32 v%d, 0x3f80' % (A0 + 3),
+          'v_mov_b32 v%d, 0x3f800000' % (A0 + 2),
+          'v_cndmask_b32 v%d, v%d, v%d, vcc' % (A0 + 3, A0 + 3, A0 + 2),
+          'v_xor_b32 v%d, 4, v%d' % (IDX, IDX),
+          'v_lshlrev_b32 v%d, 2, v%d' % (A0 + 2, TMP),
+          'v_lshlrev_b32 v%d, v%d, v%d' % (IDX, A0 + 2, IDX),
+          'v_xor_b32 v%d, 0x4444, v%d' % (IDX, IDX),
+          'v_mov_b32 v%d, v%d' % (A0 + 2, A0 + 3)]
+    for g in (3, 1, 0):
+        L += ['v_cmp_eq_u32 vcc, %d, v%d' % (g, TMP), 'v_cndmask_b32 v%d, 0, v%d, vcc' % (A0 + g, A0 + 2)]
+    L += ['v_cmp_eq_u32 vcc, 2, v%d' % TMP, 'v_cndmask_b32 v%d, 0, v%d, vcc' % (A0 + 2, A0 + 2)]
+    L.append('s_waitcnt lgkmcnt(0)')
+    for p in range(D - 1):
+        gathers(p, L); col_clamped(p, D + p, L)
+    L += ['s_add_i32 %s, %s, %d' % (STr, SGr, 2 * D - 1), 'v_lshl_add_u32 %s, %s, 7, %s' % (VP, STr, CB)]
+    L += ['s_sub_u32 %s, %s, %%%d' % (SCr, GB, TE), 's_cmp_eq_u32 %s, 0' % SCr]
+    R = 2
+    Aop, Iop = 'v[%d:%d]' % (A0, A0 + 3), 'v%d' % IDX
+    for t in range(NT):
+        for pp in range(D * R):
+            p = pp % D
+            q = (p + D - 1) % D
+            L.append('L_T%d_P%d_%%=:' % (t, pp))
+            L.append('s_cbranch_scc1 L_X%d_P%d_%%=' % (t, p))
+            L.append('s_add_u32 %s, %s, 1' % (SCr, SCr))
+            gathers(q, L)
+            L += ['ds_read_b32 %s, %s' % (VCw(q), VP), 'v_add_u32 %s, 128, %s' % (VP, VP)]
+            L.append('s_waitcnt lgkmcnt(%d)' % (5 * (D - 1)))
+            L.append('v_smfmac_f32_16x16x64_bf16 %%%d, %s, v[%d:%d], %s' % (2 * t + 1, Aop, Y(p, 0), Y(p, 0) + 7, Iop))
+            L.append('v_smfmac_f32_16x16x64_bf16 %%%d, %s, v[%d:%d], %s' % (2 * t, Aop, Xr(p, 0), Xr(p, 0) + 7, Iop))
+        L.append('s_branch L_T%d_P0_%%=' % t)
+        for p in range(D):
+            L.append('L_X%d_P%d_%%=:' % (t, p))
+            if t + 1 < NT:
+                L += ['s_sub_u32 %s, %%%d, %%%d' % (SCr, TE + t, TE + t + 1), 's_cmp_eq_u32 %s, 0' % SCr]
+            L.append('s_branch L_T%d_P%d_%%=' % (t + 1, p))
+    for p in range(D):
+        L.append('L_T%d_P%d_%%=:' % (NT, p))
+    L += ['s_nop 15', 's_nop 7', 's_waitcnt lgkmcnt(0)']
+    return L
+
+
 def emit(name, lines):
     print('#define %s \\' % name)
     for ln in lines:
@@ -470,6 +565,9 @@ def main():
     print('#define GCRNN_HOP_COLUMN_PAD 512      /* bytes of zeros behind the column image: the summing streams read up to three groups past a wave\'s last one */')
     emit('GCRNN_HOP_ASM_UNI16_SUMS_TEXT_B', gen_uniform16(sparse=False, sums=True, img_off=IMAGE_B_OFFSET))
     emit('GCRNN_HOP_ASM_UNI16_SUMS_SPARSE_TEXT_B', gen_uniform16(sparse=True, sums=True, img_off=IMAGE_B_OFFSET))
+    emit('GCRNN_HOP_ASM_WIDE32_TEXT', gen_wide32())
+    print('#define GCRNN_HOP_WIDE_PLANE %d' % WIDE_PLANE)
+    print('#define GCRNN_HOP_ASM_WIDE32_CLOBBERS %s, "s88", "s89", "s90", "scc", "vcc", "memory"' % ', '.join('"v%d"' % r for r in range(WIDE_BASE, 254)))
     regs = ', '.join('"v%d"' % r for r in range(UB, UB + 60))
     print('#define GCRNN_HOP_ASM_UNI_CLOBBERS %s, "s88", "s89", "s90", "scc", "memory"' % regs)
     regs16 = ', '.join('"v%d"' % r for r in range(UB16, UB16 + 36))
