@@ -24,6 +24,53 @@
 // MODE 0: forward step h_t = tanh(sum_k S^k([h|x] W_k) + 2b)   (reference Utils/graphML.py:2420-2423), un-gated.
 #pragma once
 
+// In-kernel phase stamps (diagnostic builds only, -DGCRNN_SEQ_STAMPS; tools/seq32_stamps.py): lane 0 of wave 0 records s_memtime at its
+// phase boundaries of ONE step into LDS (FLAG_OFF, no scalar registers held), copied out at the end.
+#if defined(GCRNN_SEQ_STAMPS)
+static __device__ unsigned long long gcrnn_seq32_stamps[256 * 96];
+#define GCRNN_STAMP32(slot)                                                                                   \
+  do {                                                                                                        \
+    if (wave == 0 && stamp_on && lane_now() == 0) *reinterpret_cast<volatile unsigned long long*>(smem + M::FLAG_OFF + 8 * (slot)) = __builtin_amdgcn_s_memtime(); \
+  } while (0)
+#define GCRNN_STAMP32_WAVE(slot0)                                                                             \
+  do {                                                                                                        \
+    if (stamp_on && lane_now() == 0) *reinterpret_cast<volatile unsigned long long*>(smem + M::FLAG_OFF + 8 * ((slot0) + wave)) = __builtin_amdgcn_s_memtime(); \
+  } while (0)
+#define GCRNN_STAMP32_FLUSH()                                                                                 \
+  do {                                                                                                        \
+    __syncthreads();                                                                                          \
+    if (threadIdx.x < 96 && blockIdx.x < 256) gcrnn_seq32_stamps[blockIdx.x * 96 + threadIdx.x] = *reinterpret_cast<volatile unsigned long long*>(smem + M::FLAG_OFF + 8 * threadIdx.x); \
+  } while (0)
+extern "C" int gcrnn_debug_read_seq32_stamps(void* host) {
+  return hipMemcpyFromSymbol(host, HIP_SYMBOL(gcrnn_seq32_stamps), sizeof(unsigned long long) * 256 * 96) == hipSuccess ? 0 : 1;
+}
+#else
+#define GCRNN_STAMP32_WAVE(slot0) do {} while (0)
+#define GCRNN_STAMP32(slot) do {} while (0)
+#define GCRNN_STAMP32_FLUSH() do {} while (0)
+#endif
+
+#ifndef GCRNN_SEQ32_OPERAND_AT
+#define GCRNN_SEQ32_OPERAND_AT 1      // where the last chunk requests the next step's operand: 0 = at the start of its epilogue, 1 = behind its state stores, 2 = behind its row stores (A/B)
+#endif
+// cache policy experiments (aux bits of the buffer / LDS-DMA instructions: 2 = nt): traffic this launch never reads again should not
+// displace from L2 what it reads back one step later (x_{t+1} laid out by the pack, h_t's first chunk)
+#ifndef GCRNN_SEQ32_NT_ROWS
+#define GCRNN_SEQ32_NT_ROWS 0      // user-layout row stores
+#endif
+#ifndef GCRNN_SEQ32_NT_DMA
+#define GCRNN_SEQ32_NT_DMA 0       // LDS-DMA reads of the user-layout input
+#endif
+#ifndef GCRNN_SEQ32_NT_XLOAD
+#define GCRNN_SEQ32_NT_XLOAD 0     // requests of the next operand (read once)
+#endif
+#ifndef GCRNN_SEQ32_NT_STATE
+#define GCRNN_SEQ32_NT_STATE 0     // state stores of the LAST chunk (handed over in registers: not read back by this launch)
+#endif
+#ifndef GCRNN_SEQ32_SAME_ORDER
+#define GCRNN_SEQ32_SAME_ORDER 0      // 1: every wave streams first, then evaluates the tap (A/B: tools/ab_build.sh "-DGCRNN_SEQ32_SAME_ORDER=1")
+#endif
+
 struct Seq32Args {
   const uint16_t* x0; int64_t xstride;                 // x of step 0 [B][NP][G] bf16 sequence-major, elements between steps
   const uint16_t* hfirst;                              // h_{-1} = h0 [B][NP][F]
@@ -35,11 +82,11 @@ struct Seq32Args {
   int ubstride;                                        // elements between consecutive sequences of the user-layout output
   const int32_t* tile_nodes; const int32_t* tile_off; const uint2* ell_col4;      // bf16-image plan (graph.fused_plan_img16)
   int entries, B, N;
-  const uint16_t* pk_src0; int64_t pksrc_stride;       // inline pack: user-layout block X[0][pk_ahead] (or null), elements between steps
-  uint16_t* pk_dst0; int64_t pkdst_stride;             // ... the sequence-major array of step pk_ahead it is laid out into
+  const uint16_t* pk_src0; int64_t pksrc_stride;       // inline pack: user-layout block X[0][0] (or null), elements between steps
+  uint16_t* pk_dst0; int64_t pkdst_stride;             // ... the sequence-major array of step 0, elements between steps
   int pk_stride;                                       // ... elements between consecutive sequences of the user-layout tensor
-  int pk_ahead;                                        // step t lays out the operand of step t + pk_ahead (2: x_{t+1} is complete -- and requested early -- while step t runs)
   int nsteps;
+  int stagger;                                         // > 0: workgroup i starts ((i / 8) % 8) * stagger shader cycles late (de-synchronises the CUs' memory phases for the whole launch)
 };
 
 // this lane's id, re-derived where it is needed (two VALU instructions; volatile: neither hoisted nor kept): anything derived from the
@@ -50,10 +97,10 @@ __device__ __forceinline__ int lane_now() {
   return ln;
 }
 
+// (the stream ADDS the gathered rows to D: the caller zeroes D, or has already put the hop's tap there)
 #define GCRNN_HOP_ASM_WIDE32_STREAM(D)                                                             \
   do {                                                                                             \
     const int gwbeg = tbeg[0] >> 2, gwend = tend[STILES - 1] >> 2;                                 \
-    _Pragma("unroll") for (int i_ = 0; i_ < STILES; ++i_) { D[i_][0] = f32x4{0.f, 0.f, 0.f, 0.f}; D[i_][1] = f32x4{0.f, 0.f, 0.f, 0.f}; } \
     if (gwbeg < gwend) {                                                                           \
       const uint32_t colb = lds_col + r * 8 + (q >> 1) * 4;       /* this lane's own column dword of a slot's pair */ \
       const uint32_t qh_ = (uint32_t)(q & 1) << 4;                                                 \
@@ -145,6 +192,14 @@ __global__ __launch_bounds__(STHREADS) void fused_seq32_kernel(const Seq32Args a
   if (tid < F) lbias[tid] = a.bias ? a.bias[tid] : 0.f;
   __syncthreads();
 
+  if (a.stagger > 0) {
+    // All 256 workgroups run the same phases at the same time, so the chip's HBM sees every CU's operand requests / state stores / row
+    // stores as bursts (11 B per clock and CU when all ask at once: profiles/r04_seq32_stamps_*.txt). A one-time offset per group of
+    // workgroups persists over all T steps of this launch (same code, same speed) and spreads those bursts over the step.
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    const unsigned long long d = (unsigned long long)((blockIdx.x >> 3) & 7) * (unsigned long long)a.stagger;
+    while (__builtin_amdgcn_s_memtime() - t0 < d) __builtin_amdgcn_s_sleep(16);
+  }
   const uint32_t lds0 = (uint32_t)reinterpret_cast<uintptr_t>(smem);
   if (lds0 != 0) __builtin_trap();        // the asm stream forms gather addresses from column words: the image must sit at LDS address 0
   const uint32_t lds_col = lds0 + COL_OFF;
@@ -175,13 +230,17 @@ __global__ __launch_bounds__(STHREADS) void fused_seq32_kernel(const Seq32Args a
   for (int step = 0; step < a.nsteps; ++step) {
     uint16_t* hout = a.out0 + (int64_t)step * a.ostride;
     const uint16_t* aux1 = a.a1 ? (a.a1_last_only ? (step == a.nsteps - 1 ? a.a1 : nullptr) : a.a1 + (int64_t)step * a.a1stride) : nullptr;
-    const int pka = a.pk_ahead > 0 ? a.pk_ahead : 1;
-    const bool pk = a.pk_src0 && step + pka < a.nsteps;
-    const uint16_t* pk_src = pk ? a.pk_src0 + (int64_t)step * a.pksrc_stride : nullptr;
-    uint16_t* pk_dst = pk ? a.pk_dst0 + (int64_t)step * a.pkdst_stride : nullptr;
-    const int pk_stride = a.pk_stride, ubstride = a.ubstride;
-    const int64_t pk_soff = (int64_t)b * pk_stride;
+    // Inline pack: the 128-node rounds of a step's input are laid out ONE HOP ahead of "during the step before": hop i of step t takes
+    // round i + 1 of x_{t+1}, the step's last hop round 0 of x_{t+2}. x_{t+1} is then complete (stored, waited for, behind a barrier) when
+    // step t's last epilogue requests it -- and recent: an input laid out a whole step earlier has left the caches by the time it is read
+    // (the requests of all CUs then run at HBM latency: ~190 instead of ~70 units per step, profiles/r04_seq32_stamps_*). The caller lays
+    // out steps 0 and 1.
+    const bool pk_any = a.pk_src0 != nullptr;
+    const int ubstride = a.ubstride;
+    const int64_t pk_soff = (int64_t)b * a.pk_stride;
     const __amdgpu_buffer_rsrc_t rsrc_o = __builtin_amdgcn_make_buffer_rsrc(hout, 0, B * (NP * F * 2), 0x00020000);
+    [[maybe_unused]] const bool stamp_on = (step == (a.nsteps > 2 ? a.nsteps - 3 : 0)) && b == (int)blockIdx.x;      // a typical step (diagnostic builds)
+    GCRNN_STAMP32(0);
     const bool more = step + 1 < a.nsteps;      // the next step's operand is requested at the start of this step's last epilogue
     const __amdgpu_buffer_rsrc_t rsrc_xn = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(a.x0 + (int64_t)(step + 1) * a.xstride), 0, more ? B * (NP * G * 2) : 0, 0x00020000);
 
@@ -229,9 +288,21 @@ __global__ __launch_bounds__(STHREADS) void fused_seq32_kernel(const Seq32Args a
       const int r = lane & 15, q = lane >> 4;
       const bool last = chunk == NCH - 1;
       lds_barrier();      // the seed is in the image
+      GCRNN_STAMP32(1 + chunk * 24);
 
-      // inline pack, round rnd: x_{t+pka}[:, rnd * 128 .. + 127] (user layout, rows = features) by LDS-DMA into the tile ...
-      auto pack_issue = [&](int rnd) {
+      // virtual round v of this step (NRND per step, shifted by one hop) -> (target step, round); false: nothing to lay out
+      auto pack_target = [&](int v, int& tgt, int& rnd) -> bool {
+        v += RPH;
+        const int wrap = v >= NRND ? 1 : 0;
+        rnd = v - wrap * NRND;
+        tgt = step + 1 + wrap;
+        return pk_any && tgt >= 2 && tgt < a.nsteps;
+      };
+      // inline pack, round rnd of step tgt: x_tgt[:, rnd * 128 .. + 127] (user layout, rows = features) by LDS-DMA into the tile ...
+      auto pack_issue = [&](int v) {
+        int tgt, rnd;
+        if (!pack_target(v, tgt, rnd)) return;
+        const uint16_t* pk_src = a.pk_src0 + (int64_t)tgt * a.pksrc_stride;
         constexpr int PPR = NPCK / 8, PIECES = PKROWS * PPR;
         static_assert(PIECES % STHREADS == 0, "whole pieces per thread");
         const uint16_t* xsrc = pk_src + pk_soff + rnd * NPCK;
@@ -242,11 +313,14 @@ __global__ __launch_bounds__(STHREADS) void fused_seq32_kernel(const Seq32Args a
           const int col = (cs - (row >> 3)) & (PPR - 1);
           if (rnd * NPCK + col * 8 < N)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xsrc + (int64_t)row * N + col * 8),
-                                             (__attribute__((address_space(3))) void*)(xtile + (i * STHREADS + wave * 64) * 16), 16, 0, 0);
+                                             (__attribute__((address_space(3))) void*)(xtile + (i * STHREADS + wave * 64) * 16), 16, 0, GCRNN_SEQ32_NT_DMA);
         }
       };
       // ... and out of it transposed: whole sequence-major rows [node][features]
-      auto pack_drain = [&](int rnd) {
+      auto pack_drain = [&](int v) {
+        int tgt, rnd;
+        if (!pack_target(v, tgt, rnd)) return;
+        uint16_t* pk_dst = a.pk_dst0 + (int64_t)tgt * a.pkdst_stride;
         constexpr int PCS = PKROWS / 8, RI = PCS * NPCK / STHREADS;
         static_assert(PCS * NPCK % STHREADS == 0, "whole row pieces per thread");
         typedef __attribute__((__vector_size__(4 * sizeof(unsigned int)))) unsigned int u32x4_t;
@@ -277,35 +351,65 @@ __global__ __launch_bounds__(STHREADS) void fused_seq32_kernel(const Seq32Args a
         }
       };
 
+      // Weight fragments of chunk wc, tap `tap` -> their place in LDS (2 KS pieces of 1 KB). One tap at a time, into a place whose last
+      // reader is a barrier behind: during hop j the NEXT chunk's tap K - j (read by this chunk's seed / hop j - 1), during hop 1 also this
+      // chunk's own tap 0 (its place still held the previous chunk's, read at that chunk's last hop). Every piece is covered by the hop's
+      // vmcnt(0) + barrier, and no LDS-DMA is pending during an epilogue -- hipcc orders each LDS access of a wave behind its pending
+      // LDS-DMA pieces with a vmcnt(0), which in the last epilogue would also wait for the next operand's requests.
+      auto r0_of = [&](int j) { return (chunk * (K - 1) + (j - 1)) * RPH; };
+      auto weights_issue = [&](int wc, int tap) {
+        const char* wsrc = reinterpret_cast<const char*>(a.wpack) + (size_t)wc * WB + (size_t)tap * (2 * KS * 1024);
+#pragma unroll
+        for (int i = 0; i < (2 * KS + SWAVES - 1) / SWAVES; ++i) {
+          const int piece = i * SWAVES + wave;
+          if (piece < 2 * KS)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc + piece * 1024 + lane * 16),
+                                             (__attribute__((address_space(3))) void*)(smem + WOFF + tap * (2 * KS * 1024) + piece * 1024), 16, 0, 0);
+        }
+      };
       // ---- Horner hops on the two-plane bf16 image; the tap a hop adds accumulates onto its sums --------------------------------
       auto hop = [&](auto jc) __attribute__((always_inline)) {
         constexpr int j = decltype(jc)::value;
-        const int r0 = (chunk * (K - 1) + (j - 1)) * RPH;      // this hop's first pack round
-        if (pk_src && r0 < NRND) pack_issue(r0);
-        GCRNN_HOP_ASM_WIDE32_STREAM(acc);
-        taps(K - 1 - j);
-        if (pk_src) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's LDS-DMA pieces have landed (they had the stream)
-        lds_barrier();      // every wave has left the image (and the weights, after the last hop); every piece of the pack tile is in
-        if (j < K - 1) put();
-        if (j == K - 1) {
-          // the next chunk's weight fragments (after the last chunk: chunk 0's, for the next step): LDS-DMA over the ones just used,
-          // landed by the end-of-chunk wait
-          const int nc = (chunk + 1) % NCH;
+        auto dma_issue = [&]() {      // this wave's LDS-DMA pieces of the hop, right in front of its stream
           if (NCH > 1) {
-            const char* wsrc = reinterpret_cast<const char*>(a.wpack) + (size_t)nc * WB;
-#pragma unroll
-            for (int i = 0; i < (WB / 1024 + SWAVES - 1) / SWAVES; ++i) {
-              const int piece = i * SWAVES + wave;
-              if (piece < WB / 1024)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc + piece * 1024 + lane * 16),
-                                                 (__attribute__((address_space(3))) void*)(smem + WOFF + piece * 1024), 16, 0, 0);
-            }
+            weights_issue((chunk + 1) % NCH, K - j);
+            if (j == 1 && K > 2) weights_issue(chunk, 0);
           }
+          if (r0_of(j) < NRND) pack_issue(r0_of(j));
+        };
+        const int r0 = r0_of(j);      // this hop's first pack round
+        // The two waves of a SIMD take the hop's two phases in opposite order: issue arbitration favours the older wave, so with all
+        // eight streaming at once waves 4..7 finish their streams ~30 % after waves 0..3 and only then start their tap MFMAs while the
+        // others wait at the barrier (profiles/r04_seq32_stamps_native_same_order.txt). The tap of a hop does not depend on its sums
+        // (D = A B + D accumulates either way), so waves 4..7 evaluate it FIRST: their MFMAs run beside the streams of waves 0..3, which
+        // then have the LDS to four waves, and the other way round afterwards.
+#pragma unroll
+        for (int i = 0; i < STILES; ++i) { acc[i][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[i][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        // (the pack's LDS-DMA pieces go out right before the wave's stream: hipcc orders every later LDS read of the wave behind them with a
+        //  vmcnt(0) -- behind the stream that wait is free, in front of the tap's weight reads it would expose the pieces' whole latency)
+        if (wave < SWAVES / 2 || GCRNN_SEQ32_SAME_ORDER) {
+          dma_issue();
+          GCRNN_HOP_ASM_WIDE32_STREAM(acc);
+          GCRNN_STAMP32(1 + chunk * 24 + 4 * (j - 1) + 1);
+          if (j == 2 && chunk == 0) GCRNN_STAMP32_WAVE(56);
+          taps(K - 1 - j);
+        } else {
+          taps(K - 1 - j);
+          if (j == 2 && chunk == 0) GCRNN_STAMP32_WAVE(56);
+          dma_issue();
+          GCRNN_HOP_ASM_WIDE32_STREAM(acc);
         }
-        if (pk_src && r0 < NRND) pack_drain(r0);
+        GCRNN_STAMP32(1 + chunk * 24 + 4 * (j - 1) + 2);
+        if (j == 2 && chunk == 0) GCRNN_STAMP32_WAVE(64);
+        if (pk_any || NCH > 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's LDS-DMA pieces have landed (they had the stream)
+        lds_barrier();      // every wave has left the image (and the weights, after the last hop); every piece of the pack tile is in
+        GCRNN_STAMP32(1 + chunk * 24 + 4 * (j - 1) + 3);
+        if (j < K - 1) put();
+        if (K == 2 && NCH > 1) weights_issue((chunk + 1) % NCH, 0);      // (K = 2: tap 0's fragments are free only now, and needed at the next chunk's only hop)
+        if (r0 < NRND) pack_drain(r0);
 #pragma unroll
         for (int e = 1; e < RPH; ++e) {       // (fewer hops than rounds: the extra rounds are not hidden behind a stream)
-          if (pk_src && r0 + e < NRND) {
+          if (pk_any && r0 + e < NRND) {
             lds_barrier();
             pack_issue(r0 + e);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -314,12 +418,14 @@ __global__ __launch_bounds__(STHREADS) void fused_seq32_kernel(const Seq32Args a
           }
         }
         if (j < K - 1) lds_barrier();      // the image is complete (and the pack tile read)
+        GCRNN_STAMP32(1 + chunk * 24 + 4 * (j - 1) + 4);
       };
       seq_static_for(hop, std::make_integer_sequence<int, K - 1>{});
 
       // ---- epilogue: + 2 b, tanh, bf16; lane (r, q) holds features 32 c + 8 q .. + 7 of its node: ONE 16-byte store per tile ------------
       typedef __attribute__((__vector_size__(4 * sizeof(unsigned int)))) unsigned int u32x4_t;
-      if (last && more) {
+      auto request_next_operand = [&]() {
+        if (!(last && more)) return;
         // the next step's operand: x_{t+1} (laid out two steps ahead, or by the caller) and the state features of the earlier chunks
         // (stored -- and waited for -- at their chunk's end); the last chunk's come from this epilogue's registers below
         const int qo = lane_now() >> 4;
@@ -332,13 +438,17 @@ __global__ __launch_bounds__(STHREADS) void fused_seq32_kernel(const Seq32Args a
 #pragma unroll
           for (int i = 0; i < STILES; ++i) {
             const int w = sw[i];
+#ifdef GCRNN_SEQ32_EXPERIMENT_SKIP      // timing experiment, WRONG results: 1 = no state requests, 2 = no input requests (which half of the operand costs the wait?)
+            if ((GCRNN_SEQ32_EXPERIMENT_SKIP == 1) == (s < HS)) continue;
+#endif
             if (s < HS)
-              bfr[i][s] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsrc_hn, (w >> 16) * (F * 2) + 16 * qo + 64 * s, b * (NP * F * 2), 0));
+              bfr[i][s] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsrc_hn, (w >> 16) * (F * 2) + 16 * qo + 64 * s, b * (NP * F * 2), GCRNN_SEQ32_NT_XLOAD));
             else
-              bfr[i][s] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsrc_xn, (w >> 16) * (G * 2) + 16 * qo + 64 * (s - HS), b * (NP * G * 2), 0));
+              bfr[i][s] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsrc_xn, (w >> 16) * (G * 2) + 16 * qo + 64 * (s - HS), b * (NP * G * 2), GCRNN_SEQ32_NT_XLOAD));
           }
         }
-      }
+      };
+      if (GCRNN_SEQ32_OPERAND_AT == 0) request_next_operand();
       float bs[2][4];
 #pragma unroll
       for (int h = 0; h < 2; ++h)
@@ -359,13 +469,16 @@ __global__ __launch_bounds__(STHREADS) void fused_seq32_kernel(const Seq32Args a
           p[3] = pack2bf(fast_tanh(a1[2] + bs[1][2]), fast_tanh(a1[3] + bs[1][3]));
         }
         pkd[i] = p;
-        __builtin_amdgcn_raw_buffer_store_b128(p, rsrc_o, node * (F * 2) + (chunk * 32 + q * 8) * 2, b * (NP * F * 2), 0);
+        if (GCRNN_SEQ32_NT_STATE && last) __builtin_amdgcn_raw_buffer_store_b128(p, rsrc_o, node * (F * 2) + (chunk * 32 + q * 8) * 2, b * (NP * F * 2), GCRNN_SEQ32_NT_STATE);
+        else __builtin_amdgcn_raw_buffer_store_b128(p, rsrc_o, node * (F * 2) + (chunk * 32 + q * 8) * 2, b * (NP * F * 2), 0);
       }
+      GCRNN_STAMP32(1 + chunk * 24 + 17);
       if (last) {
         // h_t's last 32 features ARE the lanes' B fragments of k-step HS-1: handed to the next step in registers
 #pragma unroll
         for (int i = 0; i < STILES; ++i) bfr[i][HS - 1] = __builtin_bit_cast(bf16x8, pkd[i]);
       }
+      if (GCRNN_SEQ32_OPERAND_AT == 1) request_next_operand();
       if (aux1) {
         // user layout H[b][t][f][:] (node-contiguous rows) through a transposed LDS tile of 32-bit words [feature pair][node]: a lane's
         // four packed registers are four such words (pairs 4 q .. 4 q + 3). Nobody reads the image any more (the last hop's barrier).
@@ -380,6 +493,7 @@ __global__ __launch_bounds__(STHREADS) void fused_seq32_kernel(const Seq32Args a
           for (int k = 0; k < 4; ++k) *reinterpret_cast<uint32_t*>(ra + k * RS2) = pkd[i][k];
         }
         lds_barrier();
+        GCRNN_STAMP32(1 + chunk * 24 + 18);
         const int segs = N >> 3;
         uint16_t* ub = const_cast<uint16_t*>(aux1) + (int64_t)b * ubstride + (int64_t)(chunk * 32) * N;
         const __amdgpu_buffer_rsrc_t rsrc_u = __builtin_amdgcn_make_buffer_rsrc(ub, 0, 32 * N * 2, 0x00020000);
@@ -391,16 +505,20 @@ __global__ __launch_bounds__(STHREADS) void fused_seq32_kernel(const Seq32Args a
                               __builtin_amdgcn_perm(w1[1], w1[0], 0x05040100u), __builtin_amdgcn_perm(w1[3], w1[2], 0x05040100u)};
           const u32x4_t od = {__builtin_amdgcn_perm(w0[1], w0[0], 0x07060302u), __builtin_amdgcn_perm(w0[3], w0[2], 0x07060302u),
                               __builtin_amdgcn_perm(w1[1], w1[0], 0x07060302u), __builtin_amdgcn_perm(w1[3], w1[2], 0x07060302u)};
-          __builtin_amdgcn_raw_buffer_store_b128(ev, rsrc_u, ((2 * fp) * N + sg * 8) * 2, 0, 0);
-          __builtin_amdgcn_raw_buffer_store_b128(od, rsrc_u, ((2 * fp + 1) * N + sg * 8) * 2, 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b128(ev, rsrc_u, ((2 * fp) * N + sg * 8) * 2, 0, GCRNN_SEQ32_NT_ROWS);
+          __builtin_amdgcn_raw_buffer_store_b128(od, rsrc_u, ((2 * fp + 1) * N + sg * 8) * 2, 0, GCRNN_SEQ32_NT_ROWS);
         }
       }
-      // the next chunk's weights have landed (LDS-DMA), this chunk's stores have retired (the next step reads some of them back),
-      // the tile has been read: the image may be seeded again
+      // this chunk's stores have retired (the next step reads some of them back; K = 2: the next chunk's tap 0 has landed), the tile
+      // has been read: the image may be seeded again
+      if (GCRNN_SEQ32_OPERAND_AT == 2) request_next_operand();
+      GCRNN_STAMP32(1 + chunk * 24 + 19);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       lds_barrier();
+      GCRNN_STAMP32(1 + chunk * 24 + 20);
       if (chunk + 1 < NCH) seed();
     }  // chunks
   }  // steps
   }  // sequences
+  GCRNN_STAMP32_FLUSH();
 }

@@ -123,11 +123,15 @@ extern "C" int gcrnn_fused_forward_wide_bf16(const void* xs, const void* h0, voi
   sa.tile_nodes = tile_nodes; sa.tile_off = tile_off; sa.ell_col4 = (const uint2*)ell_col4;
   sa.entries = (int)entries; sa.B = (int)B; sa.N = (int)N;
   sa.nsteps = (int)T;
+  {
+    // de-synchronised starts pay when the launch is long enough and every CU has a sequence (GCRNN_SEQ32_STAGGER=cycles overrides, 0 = off)
+    const char* sg = getenv("GCRNN_SEQ32_STAGGER");
+    sa.stagger = sg ? atoi(sg) : 0;
+  }
   const bool inline_pack = Xuser_inline != nullptr && T > 2;
-  if (inline_pack) {
-    sa.pk_ahead = 2;
-    sa.pk_src0 = (const uint16_t*)Xuser_inline + 2 * G * N; sa.pksrc_stride = G * N;
-    sa.pk_dst0 = const_cast<uint16_t*>(sa.x0) + 2 * xstep; sa.pkdst_stride = xstep;
+  if (inline_pack) {      // (the kernel lays out steps 2 .. T-1, each finished one hop before the step that reads it ends: gcrnn_fused_seq32.h)
+    sa.pk_src0 = (const uint16_t*)Xuser_inline; sa.pksrc_stride = G * N;
+    sa.pk_dst0 = const_cast<uint16_t*>(sa.x0); sa.pkdst_stride = xstep;
     sa.pk_stride = (int)(T * G * N);
   }
   hipStream_t st = as_stream(stream);

@@ -1,0 +1,74 @@
+#!/usr/bin/env python3
+"""Phase timeline of the wide sequence-resident kernel (gcrnn_fused_seq32.h) from in-kernel s_memtime stamps: builds a diagnostic
+library with -DGCRNN_SEQ_STAMPS into /tmp, runs forwards at the bench's size and prints, per phase, the median over workgroups of the
+stamp differences (unit: 100 shader cycles). Usage on the GPU box: python3 tools/seq32_stamps.py [native]"""
+import ctypes, glob, os, subprocess, sys
+R = os.environ.get('GRAFT_REPO_ROOT', os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+C = os.path.join(R, 'gated_gcrnns_amd', 'csrc')
+out = '/tmp/seq32st'
+os.makedirs(out, exist_ok=True)
+procs = []
+for f in sorted(glob.glob(C + '/*.hip') + glob.glob(C + '/*.cpp')):
+    o = os.path.join(out, os.path.basename(f) + '.o')
+    procs.append(subprocess.Popen(['/opt/rocm/bin/hipcc', '-O3', '-std=c++17', '--offload-arch=gfx950', '-fPIC', '-DGCRNN_SEQ_STAMPS'] + os.environ.get('GCRNN_STAMP_FLAGS', '').split() + ['-c', f, '-o', o]))
+assert all(p.wait() == 0 for p in procs)
+lib = os.path.join(out, 'lib.so')
+subprocess.check_call(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-shared', '-fPIC', '-o', lib] + sorted(glob.glob(out + '/*.o')))
+os.environ['GCRNN_LIBPATH'] = lib
+sys.path.insert(0, R)
+import numpy as np, torch
+import bench
+import gated_gcrnns_amd.Utils.graphML as gml
+dev = torch.device('cuda:0')
+N, K, T, F, B = 1000, 5, 32, 64, 256
+torch.manual_seed(0)
+cell = gml.GGCRNNCell(F, F, K, K, torch.tanh, False, None, 1, True)
+cell.addGSO(torch.tensor(bench.sbm_graph(N)))
+cell = cell.to(torch.bfloat16).to(dev)
+X = torch.randn(B, T, F, N, device=dev).to(torch.bfloat16)
+h0 = torch.zeros(B, F, N, device=dev, dtype=torch.bfloat16)
+native = len(sys.argv) > 1 and sys.argv[1] == 'native'
+with torch.no_grad():
+    if native:
+        from gated_gcrnns_amd import ops
+        xs = ops.to_sequence_major(X, cell.graph)
+        for _ in range(3):
+            cell.forward_native(xs, None)
+    else:
+        for _ in range(3):
+            cell(X, h0)
+torch.cuda.synchronize()
+buf = np.zeros(256 * 96, dtype=np.uint64)
+dll = ctypes.CDLL(lib)
+assert dll.gcrnn_debug_read_seq32_stamps(buf.ctypes.data_as(ctypes.c_void_p)) == 0
+st = buf.reshape(256, 96).astype(np.int64)
+names = {0: 'step start (operand in registers)'}
+for c in range(2):
+    b0 = 1 + 24 * c
+    names[b0] = 'c%d seed + barrier' % c
+    for j in range(1, K):
+        names[b0 + 4 * (j - 1) + 1] = 'c%d hop %d stream' % (c, j)
+        names[b0 + 4 * (j - 1) + 2] = 'c%d hop %d taps' % (c, j)
+        names[b0 + 4 * (j - 1) + 3] = 'c%d hop %d dma wait + barrier' % (c, j)
+        names[b0 + 4 * (j - 1) + 4] = 'c%d hop %d put + weights dma + pack drain + barrier' % (c, j)
+    names[b0 + 17] = 'c%d next operand requests + tanh + state stores' % c
+    names[b0 + 18] = 'c%d transposed tile + barrier' % c
+    names[b0 + 19] = 'c%d user-layout row stores' % c
+    names[b0 + 20] = 'c%d vmcnt(0) + end barrier' % c
+prev = 0
+print('stamps of step T-3 of the persistent launch (%s), median over 256 workgroups; unit = 100 shader cycles (s_memtime)' % ('native layout' if native else 'user layout + inline pack'))
+tot = {}
+for s in sorted(names):
+    d = st[:, s] - st[:, prev]
+    print('%-52s +%7.2f   (min %.2f max %.2f)   t = %.2f' % (names[s], np.median(d) / 100.0, d.min() / 100.0, d.max() / 100.0, np.median(st[:, s] - st[:, 0]) / 100.0))
+    key = names[s].split(' ', 1)[1] if names[s][0] == 'c' else names[s]
+    key = ' '.join(w for w in key.split() if not w.isdigit())
+    tot[key] = tot.get(key, 0.0) + np.median(d) / 100.0
+    prev = s
+print('--- per wave, c0 hop 2: first / second phase (waves 0-3: stream, taps; waves 4-7: taps, stream) done, units after the start of the hop')
+ref = st[:, 5]          # end of hop 1 (wave 0)
+for w in range(8):
+    print('wave %d: first phase done +%.2f   second phase done +%.2f' % (w, np.median(st[:, 56 + w] - ref) / 100.0, np.median(st[:, 64 + w] - ref) / 100.0))
+print('--- per step, by phase kind')
+for k, v in tot.items():
+    print('%-52s %8.2f' % (k, v))
