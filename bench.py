@@ -403,11 +403,14 @@ def run_cfg2(ctx):
         spl = kern['steps_per_launch']
         kbytes = elt * N * (G + 2 * F) * B * spl
         kach = kbytes / (kern['launch_avg_us'] * 1e-6) / 1e9
-        tname = 'seq_kernel_traffic.json' if kern['kernel'] == 'fused_seq_kernel' else 'step_kernel_traffic.json'
+        tname = {'fused_seq32_kernel': 'seq32_kernel_traffic.json', 'fused_seq_kernel': 'seq_kernel_traffic.json'}.get(kern['kernel'], 'step_kernel_traffic.json')
         tj = profile_traffic(tname, B)
         Gp = 64 if G > 32 else 32
         mfma_flops = 2.0 * 1024 * K * F * (F + Gp) * B * spl           # executed on the matrix cores per launch (1024 padded node rows)
-        kdesc = ('fused_seq_kernel<5,2,%d,0> (sequence-resident persistent kernel: one launch = all T = %d time steps of the whole batch)' % (2 if G > 32 else 1, spl)
+        kdesc = ('fused_seq32_kernel<5,2,%d,%d> (wide sequence-resident persistent kernel, 32-feature chunks: one launch = all T = %d time steps of the whole batch; '
+                 'last template argument: bit 0 = inline pack, bit 1 = user-layout output -- native layout = <..,0>)' % (2 if G > 32 else 1, 3 if kern.get('inline_pack') else 2, spl)
+                 if kern['kernel'] == 'fused_seq32_kernel' else
+                 'fused_seq_kernel<5,2,%d,0> (sequence-resident persistent kernel: one launch = all T = %d time steps of the whole batch)' % (2 if G > 32 else 1, spl)
                  if kern['kernel'] == 'fused_seq_kernel' and spl > 1 else
                  '%s<5,2,%d> (one launch = one time step of the whole batch)' % (kern['kernel'], 2 if G > 32 else 1))
         out['roofline'] = {'bound': 'hbm', 'achieved': kach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
@@ -427,8 +430,8 @@ def run_cfg2(ctx):
             # `achieved` does not count). frac is that of the launch as issued; the bare kernel is timed next to it.
             out['roofline']['inline_pack'] = {'extra_bytes_per_launch': 2 * elt * N * G * B * spl, 'bare_kernel_avg_us': kern['bare_launch_avg_us'],
                                               'bare_frac': kbytes / (kern['bare_launch_avg_us'] * 1e-6) / 1e9 / HBM_PEAK_GBS,
-                                              'note': 'each step also lays out the next step input from the user layout (LDS-DMA during the last '
-                                                      'hop); the separate pack pass over X (0.5 ms per forward at B = 256) is gone'}
+                                              'note': 'each step also lays out the next step input from the user layout (LDS-DMA during the '
+                                                      'hops); the separate pack pass over X (0.5 ms per forward at B = 256) is gone'}
         if native is not None:
             # the same kernel on the sequence-major arrays alone (the cell's `native_layout` output is a view of the state
             # image): no user-layout copy of h_t, no lay-out of x_{t+1} -- the launch moves what the algorithm needs

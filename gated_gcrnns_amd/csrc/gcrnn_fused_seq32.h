@@ -132,8 +132,12 @@ struct Seq32Map {
   }
 };
 
-template <int K, int HS, int XS>
+// VAR: bit 0 = the launch lays out the input itself (inline pack), bit 1 = it writes the user-layout output. Compile-time so that every way
+// the forward is issued -- as the module issues it (3), caller-packed X (2), sequence-major in and out (0) -- is a kernel symbol of its own in a
+// trace (profiles/*kernel_stats.csv reproduce the bench line's roofline fraction), and the paths not taken cost neither code nor registers.
+template <int K, int HS, int XS, int VAR>
 __global__ __launch_bounds__(STHREADS) void fused_seq32_kernel(const Seq32Args a) {
+  constexpr bool PKV = (VAR & 1) != 0, USERV = (VAR & 2) != 0;
   using M = Seq32Map<K, HS, XS>;
   constexpr int KS = HS + XS;
   constexpr int F = 32 * HS, G = 32 * XS;
@@ -229,13 +233,13 @@ __global__ __launch_bounds__(STHREADS) void fused_seq32_kernel(const Seq32Args a
 #pragma unroll 1
   for (int step = 0; step < a.nsteps; ++step) {
     uint16_t* hout = a.out0 + (int64_t)step * a.ostride;
-    const uint16_t* aux1 = a.a1 ? (a.a1_last_only ? (step == a.nsteps - 1 ? a.a1 : nullptr) : a.a1 + (int64_t)step * a.a1stride) : nullptr;
+    const uint16_t* aux1 = (USERV && a.a1) ? (a.a1_last_only ? (step == a.nsteps - 1 ? a.a1 : nullptr) : a.a1 + (int64_t)step * a.a1stride) : nullptr;
     // Inline pack: the 128-node rounds of a step's input are laid out ONE HOP ahead of "during the step before": hop i of step t takes
     // round i + 1 of x_{t+1}, the step's last hop round 0 of x_{t+2}. x_{t+1} is then complete (stored, waited for, behind a barrier) when
     // step t's last epilogue requests it -- and recent: an input laid out a whole step earlier has left the caches by the time it is read
     // (the requests of all CUs then run at HBM latency: ~190 instead of ~70 units per step, profiles/r04_seq32_stamps_*). The caller lays
     // out steps 0 and 1.
-    const bool pk_any = a.pk_src0 != nullptr;
+    const bool pk_any = PKV && a.pk_src0 != nullptr;
     const int ubstride = a.ubstride;
     const int64_t pk_soff = (int64_t)b * a.pk_stride;
     const __amdgpu_buffer_rsrc_t rsrc_o = __builtin_amdgcn_make_buffer_rsrc(hout, 0, B * (NP * F * 2), 0x00020000);

@@ -86,17 +86,28 @@ extern "C" int gcrnn_fused_forward_wide_supported(int64_t B, int64_t T, int64_t 
   return seq32_lds_for(F, G, K, entries, inline_pack != 0) ? 1 : 0;
 }
 
-template <int K, int HS, int XS>
-static int seq32_launch(const Seq32Args& sa, bool inline_pack, hipStream_t st) {
-  const size_t lds = seq32_lds<K, HS, XS>(sa.entries, inline_pack);
-  if (!lds) return GCRNN_ERR_UNSUPPORTED;
-  auto sk = fused_seq32_kernel<K, HS, XS>;
+template <int K, int HS, int XS, int VAR>
+static int seq32_launch_v(const Seq32Args& sa, size_t lds, hipStream_t st) {
+  auto sk = fused_seq32_kernel<K, HS, XS, VAR>;
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(sk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
     return GCRNN_ERR_LAUNCH;
   GCRNN_PRE_LAUNCH();
   sk<<<(unsigned)(sa.B < 256 ? sa.B : 256), STHREADS, lds, st>>>(sa);
   GCRNN_CHECK_LAUNCH();
   return GCRNN_OK;
+}
+
+template <int K, int HS, int XS>
+static int seq32_launch(const Seq32Args& sa, bool inline_pack, hipStream_t st) {
+  const size_t lds = seq32_lds<K, HS, XS>(sa.entries, inline_pack);
+  if (!lds) return GCRNN_ERR_UNSUPPORTED;
+  const int var = (inline_pack ? 1 : 0) | (sa.a1 ? 2 : 0);
+  switch (var) {
+    case 0: return seq32_launch_v<K, HS, XS, 0>(sa, lds, st);
+    case 1: return seq32_launch_v<K, HS, XS, 1>(sa, lds, st);
+    case 2: return seq32_launch_v<K, HS, XS, 2>(sa, lds, st);
+    default: return seq32_launch_v<K, HS, XS, 3>(sa, lds, st);
+  }
 }
 
 // Whole un-gated forward as ONE launch of the wide sequence-resident kernel (reference Utils/graphML.py:2351-2427 without gates).

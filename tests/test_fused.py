@@ -662,6 +662,14 @@ def _grad_scale_and_bounds(name, grads, mx, mean):
     return sc, mx, mean
 
 
+def _tol_report(line):
+    """GCRNN_TOL_REPORT=<file>: append the measured error ratios (the gates sit at <= 2x the worst measured: tools/tolerance_probe.py)."""
+    f = os.environ.get('GCRNN_TOL_REPORT')
+    if f:
+        with open(f, 'a') as fh:
+            fh.write(line + '\n')
+
+
 def _g9_cell(g, tg, sg, dev):
     """The fixture's cell (parameters by state_dict key, fp32 master weights holding bf16-representable values) and inputs."""
     import gated_gcrnns_amd.Utils.graphML as gml
@@ -711,6 +719,7 @@ def test_fused_bptt_matches_reference_autograd_fixture(golden, name, tg, sg, los
         e = np.abs(gg - gr)
         # L1: dH = sign(H - target) / count flips where the bf16 rounding of H crosses the target -> looser single-entry bound
         sc, mx, mn = _grad_scale_and_bounds(k, want, 6e-2 if loss == 'l1' else 4e-2, 1e-2)
+        _tol_report('g9 %s %s %s max %.3e mean %.3e (gate %.1e / %.1e)' % (name, loss, k, e.max() / sc, e.mean() / sc, mx, mn))
         assert sc > 0 and e.max() <= mx * sc and (e.size < 16 or e.mean() <= mn * sc), (k, e.max() / sc, e.mean() / sc)
         checked += 1
     assert checked >= 3
@@ -721,11 +730,13 @@ def test_fused_bptt_matches_reference_autograd_fixture(golden, name, tg, sg, los
         want_X = g['grad_sum_X' if loss == 'sum' else 'grad_l1_X']
         e = (X.grad.float().cpu() - torch.tensor(want_X)).abs()
         sc = float(np.abs(want_X).max())
+        _tol_report('g9 %s %s dX max %.3e mean %.3e' % (name, loss, float(e.max()) / sc, float(e.mean()) / sc))
         assert float(e.max()) <= (1.2e-1 if loss == 'l1' else 6e-2) * sc and float(e.mean()) <= 1e-2 * sc, ('dX', float(e.max()) / sc, float(e.mean()) / sc)
     if h0.requires_grad:
         e = (h0.grad.float().cpu() - torch.tensor(want_h0)).abs()
         sc = float(np.abs(want_h0).max())
         # d h0 has passed T bf16 dpre stores; with the L1 loss single entries also see sign flips of dH (measured 8 % of the max)
+        _tol_report('g9 %s %s dh0 max %.3e mean %.3e' % (name, loss, float(e.max()) / sc, float(e.mean()) / sc))
         assert float(e.max()) <= (1.2e-1 if loss == 'l1' else 6e-2) * sc and float(e.mean()) <= 1e-2 * sc, (float(e.max()) / sc, float(e.mean()) / sc)
 
 

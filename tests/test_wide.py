@@ -76,7 +76,11 @@ def test_wide_kernel_matches_oracle(N, F, G, K, B, T, monkeypatch):
     tol1 = 2.5e-2 if G == 1 else 4.0e-3                 # (G = 1: taps of +-0.45 under the reference init, as for the 16-feature kernels)
     assert err[:, 0].max() <= tol1, err[:, 0].max()
     assert err.max() <= (6.0e-2 if G == 1 else 5.0e-3), err.max()      # (G = 1: measured 3.1e-2 after three chaotic steps)
-    err16 = np.abs(H16[:nb].double().cpu().numpy() - Href)      # the 16-feature kernel on the same problem: the wide one is no worse
+    # the 16-feature sequence-resident kernel (GCRNN_SEQ_MIN_B = 1) on the same problem, pinned to the oracle DIRECTLY as well (elsewhere it
+    # is bit-compared with the chunk-parallel kernel, which the oracle tests cover at small batches): the wide one is no worse
+    err16 = np.abs(H16[:nb].double().cpu().numpy() - Href)
+    assert err16[:, 0].max() <= tol1 and err16.max() <= (6.0e-2 if G == 1 else 5.0e-3) and err16.mean() <= (2.5e-3 if G == 1 else 1.0e-3), \
+        (err16[:, 0].max(), err16.max(), err16.mean())
     assert err.mean() <= max(1.0e-3, 1.5 * err16.mean()), (err.mean(), err16.mean())
     assert err.max() <= max(5.0e-3, 2.0 * err16.max()), (err.max(), err16.max())
     d16 = (H.float() - H16.float()).abs()
