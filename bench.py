@@ -386,6 +386,15 @@ def run_cfg2(ctx):
         torch.cuda.synchronize()
         ar = {'allreduce_bytes': opt.sync.nbytes(), 'allreduce_us': 1e3 * e0.elapsed_time(e1) / reps,
               'allreduce_note': 'one flat buffer per optimiser step (RCCL when n_gpus > 1; no collective at n_gpus = 1)'}
+    dist_sec = None
+    headline = (args.dtype == 'bf16' and args.mode == 'fwd' and not args.time_gating and args.spatial_gating is None and G == CFG['G'])
+    if dist_on and headline and not args.no_secondary:
+        # launched under torch.distributed (the driver's --gpus N form): the forward line has no collective, so every rank also takes ONE
+        # training point with the gradient all-reduce in it -- one driver command then measures inference scaling and the collective
+        try:
+            dist_sec = dist_train_point(ctx, S, params, B)
+        except Exception as e:      # noqa: BLE001 -- never takes the headline down (all ranks raise or none: same code, same shapes)
+            dist_sec = {'error': str(e)[:200]}
     if rank != 0:
         return None
     gating = ('time-gated' if args.time_gating else 'un-gated') + ('' if args.spatial_gating is None else ' + %s-gated' % args.spatial_gating)
@@ -464,8 +473,14 @@ def run_cfg2(ctx):
                            'gflop_per_step': flops_per_seq(T, N, nnz, K, G, F) * B / 1e9}
     if (world == 1 and not args.no_secondary and args.dtype == 'bf16' and args.mode == 'fwd' and not args.time_gating
             and args.spatial_gating is None and G == CFG['G']):
-        del X, h0
+        # (the headline is complete here: should a secondary point take the process down -- an asynchronous fault is not an exception --
+        #  the line is already on stderr)
+        sys.stderr.write('bench.py headline before the secondary points: %s\n' % json.dumps(out))
+        sys.stderr.flush()
+        del X, h0, runner, step
         out['secondary'] = secondary_points(ctx, S, params, B)
+    if dist_sec is not None:
+        out.setdefault('secondary', {})['train_bf16'] = dist_sec
     if not args.no_cpu_baseline and world == 1:          # the host baseline is a single-GPU-run item (rank 0, N = 1)
         out['cpu_baseline'] = cpu_baseline(S, params, T, G, F)
     return out
@@ -481,6 +496,66 @@ def _timed(fn, steps, warmup):
         fn()
     torch.cuda.synchronize()
     return (time.perf_counter() - t0) / steps
+
+
+def dist_train_point(ctx, S, params, B, steps=5, warmup=2):
+    """Run under torch.distributed (EVERY rank calls this; the driver's `--gpus N` line): one bf16 optimiser step of the same workload with
+    the north_star's only collective in it -- zero_grad, forward, L1 loss, BPTT, ONE flat fp32 gradient all-reduce over RCCL
+    (reference position: Modules/train_rnn.py:273 -> 276), FlatAdam -- timed with the bench's protocol (barrier + synchronize on both
+    sides, MAX over ranks), and the collective alone between HIP events. Returns the point on rank 0, None elsewhere."""
+    import gated_gcrnns_amd.Utils.graphML as gml
+    from gated_gcrnns_amd.optim import FlatAdam
+    from gated_gcrnns_amd.Utils.miscTools import batchTimeL1Loss
+    dev, rank, world = ctx['dev'], ctx['rank'], ctx['world']
+    dist = torch.distributed
+    N, K, T, G, F = CFG['N'], CFG['K'], CFG['T'], CFG['G'], CFG['F']
+    torch.manual_seed(0)
+    cell = gml.GGCRNNCell(G, F, K, K, torch.tanh, False, None, 1, True)
+    cell.addGSO(torch.tensor(S))
+    cell.load_state_dict({k: torch.tensor(v) for k, v in params.items()})
+    cell = cell.to(dev).float()
+    gen = torch.Generator(device=dev); gen.manual_seed(4321 + rank)
+    X = torch.randn(B, T, G, N, device=dev, dtype=torch.float32, generator=gen).to(torch.bfloat16)
+    h0 = torch.zeros(B, F, N, device=dev, dtype=torch.bfloat16)
+    target = torch.randn(B, T, F, N, device=dev, dtype=torch.float32, generator=gen).to(torch.bfloat16)
+    opt = FlatAdam(cell.parameters(), lr=1e-3)
+
+    def tstep():
+        opt.zero_grad()
+        batchTimeL1Loss(cell(X, h0), target).backward()
+        opt.sync.all_reduce_()
+        opt.step()
+
+    def sync():
+        dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(warmup):
+        tstep()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        tstep()
+    sync()
+    tw = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+    dist.all_reduce(tw, op=dist.ReduceOp.MAX)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    reps = 20
+    sync()
+    e0.record()
+    for _ in range(reps):
+        opt.sync.all_reduce_(1.0)
+    e1.record()
+    torch.cuda.synchronize()
+    sync()
+    if rank != 0:
+        return None
+    dt = float(tw.item()) / steps
+    return {'value': world * B / dt, 'unit': 'sequences/s', 'ms_per_step': 1e3 * dt, 'steps': steps, 'dtype': 'bf16', 'n_gpus': world,
+            'what': 'zero_grad, forward, L1 loss, BPTT (data chain + weight gradient), ONE flat fp32 gradient all-reduce, FlatAdam; fp32 master '
+                    'weights; %d sequences per GPU (weak scaling), wall = MAX over ranks' % B,
+            'allreduce_bytes': opt.sync.nbytes(), 'allreduce_us': 1e3 * e0.elapsed_time(e1) / reps, 'ranks': opt.sync.world,
+            'allreduce_note': 'one flat buffer per optimiser step (RCCL when n_gpus > 1; a process group of one rank reduces over itself)'}
 
 
 def secondary_points(ctx, S, params, B, steps=8, warmup=2):

@@ -666,7 +666,7 @@ class GGCRNNCell(nn.Module):
             return False
         if ops.small_supported(self.N, self.graph.fwd[0].nnz, self.G, self.F, self.Kin, self.Kst, X.dtype, self.E):
             return False
-        return ops.fused_x3_supported(self.graph, self.N, self.F, self.G, self.Kin, self.Kst, X.dtype, self.E)
+        return ops.fused_x3_supported(self.graph, self.N, self.F, self.G, self.Kin, self.Kst, X.dtype, self.E, X.shape[0], X.shape[1])
 
     def _use_fused_x3_training(self, X, h0):
         """fp32 training of the un-gated cell at the north_star's tolerance on the fused kernels (x3 forward, x3 data chain, exact-fp32
@@ -681,7 +681,7 @@ class GGCRNNCell(nn.Module):
             return False
         if ops.small_supported(self.N, self.graph.fwd[0].nnz, self.G, self.F, self.Kin, self.Kst, X.dtype, self.E):
             return False
-        return ops.fused_x3_training_supported(self.graph, self.N, self.F, self.G, self.Kin, self.Kst, X.dtype, self.E)
+        return ops.fused_x3_training_supported(self.graph, self.N, self.F, self.G, self.Kin, self.Kst, X.dtype, self.E, X.shape[0], X.shape[1])
 
     def _use_fused_training(self, X, h0):
         """bf16 activations (parameters bf16 or fp32 master weights), plain or time-gated cell, gradients wanted for the

@@ -25,6 +25,11 @@ def sources():
 def needs_build():
     if not os.path.exists(LIBPATH):
         return True
+    try:      # a library built with other flags / another compiler (A/B switches in GCRNN_EXTRA_FLAGS) is stale even when it is newer than the sources
+        if open(os.path.join(LIBDIR, '.flags')).read().strip() != _flags_stamp():
+            return True
+    except OSError:
+        return True
     t = os.path.getmtime(LIBPATH)
     deps = sources() + glob.glob(os.path.join(CSRC, '*.h')) + glob.glob(os.path.join(CSRC, '*.inc')) + [os.path.join(os.path.dirname(PKG), 'include', 'gcrnn.h')]
     return any(os.path.getmtime(d) > t for d in deps)

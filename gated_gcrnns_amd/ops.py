@@ -1345,7 +1345,7 @@ def fused_edge_cell_train(X, h0, wA, wB, bias, graph, att_in, att_f, time_gates=
     return _FusedEdgeCell.apply(X, h0, wA, wB, bias, att_in[0], att_in[1], att_f[0], att_f[1], gi, gf, graph, xs, hs_all, float(negative_slope))
 
 
-def fused_x3_supported(graph, N, F, G, Kin, Kst, dtype, E=1):
+def fused_x3_supported(graph, N, F, G, Kin, Kst, dtype, E=1, B=None, T=None):
     """fp32-accurate fused inference (gcrnn_fused_forward_x3): fp32 tensors, un-gated cell, N <= 1024 with N % 4 == 0, the fused
     shapes, and a UNIFORM-weight graph (all non-zeros equal: the drivers' W / lambda_max) with >= 16 padding rows."""
     if E != 1 or dtype != torch.float32 or N > int(lib.gcrnn_fused_padded_nodes()):
@@ -1354,6 +1354,11 @@ def fused_x3_supported(graph, N, F, G, Kin, Kst, dtype, E=1):
     if Gp is None:
         return False
     plan = graph.fused_plan()
+    if B is not None and T is not None:
+        # limits of the x3 pack (gridDim.z = B * T) and of the 32-bit offsets into the three-plane arrays: such batches fall back to the
+        # composed path instead of failing inside the forward (or, worse, inside the backward after the forward has run)
+        if B * T > 65535 or 3 * B * plan['npad'] * max(F, Gp) * 2 > 2 ** 31 - 1:
+            return False
     return plan.get('uniform_w', 0.0) != 0.0 and bool(lib.gcrnn_fused_x3_supported(int(N), int(F), int(Gp), int(max(Kin, Kst)), plan['entries']))
 
 
@@ -1479,10 +1484,10 @@ def fused_cell_forward_x3_gated(X, h0, wA, wB, bias, graph, gates, last_only=Fal
     return H[:, T - 1:].contiguous() if last_only else H
 
 
-def fused_x3_training_supported(graph, N, F, G, Kin, Kst, dtype, E=1):
+def fused_x3_training_supported(graph, N, F, G, Kin, Kst, dtype, E=1, B=None, T=None):
     """fp32-accurate training of the un-gated cell on the fused kernels: the x3 forward's conditions, and the ADJOINT graph uniform
     too (a symmetric-support GSO like the drivers' W / lambda_max) with an image that fits next to the backward's two fp32 images."""
-    if not fused_x3_supported(graph, N, F, G, Kin, Kst, dtype, E):
+    if not fused_x3_supported(graph, N, F, G, Kin, Kst, dtype, E, B, T):
         return False
     pa = graph.fused_plan(adjoint=True)
     Gp = fused_padded_inputs(F, G)
@@ -2068,6 +2073,7 @@ class _L1Loss(torch.autograd.Function):
         check(lib.gcrnn_l1_loss(dtype_code(xc.dtype), _p(xc), _p(yc), _p(grad), _p(partial), n, 1.0 / n, _stream()), 'l1_loss')
         ctx.grad = grad
         ctx.used = False
+        ctx.operands = (xc, yc) if want else None      # (references, no copies: a second backward recomputes the gradient from them)
         return (partial.sum() / n).to(x.dtype)
 
     @staticmethod
@@ -2075,10 +2081,12 @@ class _L1Loss(torch.autograd.Function):
         g = ctx.grad
         if g is not None:
             if ctx.used:
-                # the buffer was scaled in place and handed out by the first backward: a second one (retain_graph) would rescale
-                # gradients that other tensors already alias -- refuse, as the fused gates do
-                raise RuntimeError('batchTimeL1Loss: backward through the fused loss a second time (its gradient buffer was released '
-                                   'by the first backward); recompute the loss')
+                # the buffer was scaled in place and handed out by the first backward (other tensors may alias it): a second backward over a
+                # retained graph (several heads, gradient-penalty loops -- torch's own L1Loss allows it, miscTools.py:112-119) gets a FRESH
+                # tensor recomputed from the operands, sign(x - y) * gout / n, instead
+                xc, yc = ctx.operands
+                g2 = torch.sign(xc - yc) * (gout.detach().to(xc.dtype) / xc.numel())
+                return (g2 if ctx.needs_input_grad[0] else None), (-g2 if ctx.needs_input_grad[1] else None)
             ctx.used = True
             # chain rule through the scalar loss WITHOUT a pass over g when the upstream gradient is 1 (loss.backward()): the kernel
             # reads the device scalar r = gout and returns at once when r == 1 (no host sync: capturable)

@@ -719,6 +719,16 @@ def test_fused_bptt_matches_reference_autograd_fixture(golden, name, tg, sg, los
         e = np.abs(gg - gr)
         # L1: dH = sign(H - target) / count flips where the bf16 rounding of H crosses the target -> looser single-entry bound
         sc, mx, mn = _grad_scale_and_bounds(k, want, 6e-2 if loss == 'l1' else 4e-2, 1e-2)
+        if loss == 'sum':
+            # round 4: gates at <= 2x the worst measured ratio (GCRNN_TOL_REPORT run, profiles/r04_gradient_tolerances.txt): weights 6.5e-3 of
+            # their max / 1.1e-3 mean, attention 6.2e-3 / 1.9e-3, (few-element) biases 1.8e-2. The L1 loss keeps 6e-2 (measured 3.6e-2; attention
+            # 5.4e-2 against 8e-2): sign flips of dH where the bf16 rounding of H crosses the target.
+            if k.endswith('bias'):
+                mx, mn = 3.6e-2, 3.6e-2
+            elif '_attention.' in k:
+                mx, mn = 1.3e-2, 4e-3
+            else:
+                mx, mn = 1.3e-2, 2.2e-3
         _tol_report('g9 %s %s %s max %.3e mean %.3e (gate %.1e / %.1e)' % (name, loss, k, e.max() / sc, e.mean() / sc, mx, mn))
         assert sc > 0 and e.max() <= mx * sc and (e.size < 16 or e.mean() <= mn * sc), (k, e.max() / sc, e.mean() / sc)
         checked += 1
@@ -731,13 +741,15 @@ def test_fused_bptt_matches_reference_autograd_fixture(golden, name, tg, sg, los
         e = (X.grad.float().cpu() - torch.tensor(want_X)).abs()
         sc = float(np.abs(want_X).max())
         _tol_report('g9 %s %s dX max %.3e mean %.3e' % (name, loss, float(e.max()) / sc, float(e.mean()) / sc))
-        assert float(e.max()) <= (1.2e-1 if loss == 'l1' else 6e-2) * sc and float(e.mean()) <= 1e-2 * sc, ('dX', float(e.max()) / sc, float(e.mean()) / sc)
+        # (measured: sum 3.0e-3 / 2.9e-4, L1 1.1e-1 / 2.4e-3 -- the L1 maximum is a single sign flip of dH)
+        assert float(e.max()) <= (1.4e-1 if loss == 'l1' else 6e-3) * sc and float(e.mean()) <= (5e-3 if loss == 'l1' else 6e-4) * sc, ('dX', float(e.max()) / sc, float(e.mean()) / sc)
     if h0.requires_grad:
         e = (h0.grad.float().cpu() - torch.tensor(want_h0)).abs()
         sc = float(np.abs(want_h0).max())
         # d h0 has passed T bf16 dpre stores; with the L1 loss single entries also see sign flips of dH (measured 8 % of the max)
         _tol_report('g9 %s %s dh0 max %.3e mean %.3e' % (name, loss, float(e.max()) / sc, float(e.mean()) / sc))
-        assert float(e.max()) <= (1.2e-1 if loss == 'l1' else 6e-2) * sc and float(e.mean()) <= 1e-2 * sc, (float(e.max()) / sc, float(e.mean()) / sc)
+        # (measured: sum 3.3e-3 / 2.3e-4, L1 8.1e-2 / 3.2e-3)
+        assert float(e.max()) <= (1.4e-1 if loss == 'l1' else 6.6e-3) * sc and float(e.mean()) <= (6.4e-3 if loss == 'l1' else 5e-4) * sc, (float(e.max()) / sc, float(e.mean()) / sc)
 
 
 @pytest.mark.gpu

@@ -682,6 +682,33 @@ def test_bench_training_step_under_torch_distributed_run_on_one_rank():
     assert d['config']['allreduce_bytes'] == 4 * numel, d['config']
 
 
+@pytest.mark.gpu
+def test_default_bench_line_under_torch_distributed_run_carries_the_collective():
+    """the driver launches the DEFAULT line (`--mode fwd`: no collective) for its scaling curve, so under
+    torch.distributed the line's `secondary.train_bf16` carries one training point with the north_star's only collective -- the flat
+    fp32 gradient all-reduce (reference position Modules/train_rnn.py:273 -> 276) -- its payload, its duration and the ranks RCCL saw."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    from conftest import ROOT
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--steps', '2', '--warmup', '1', '--batch', '64', '--no-cpu-baseline']
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith('{') and '"metric"' in ln]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 1 and d['config']['mode'] == 'fwd' and 'roofline' in d
+    tp = d['secondary']['train_bf16']
+    numel = 2 * 64 * 5 * 64 + 64
+    assert tp['allreduce_bytes'] == 4 * numel and tp['allreduce_us'] > 0 and tp['ranks'] == 1 and tp['n_gpus'] == 1 and tp['value'] > 0, tp
+
+
 @pytest.mark.parametrize('argv', [['--config', 'cfg2', '--batch', '16'], ['--config', 'cfg2', '--batch', '16', '--dtype', 'f32'],
                                   ['--config', 'cfg2', '--batch', '8', '--mode', 'train'], ['--config', 'cfg2', '--batch', '8', '--mode', 'train', '--spatial-gating', 'node'],
                                   ['--config', 'cfg2', '--batch', '8', '--spatial-gating', 'edge'], ['--config', 'cfg2', '--batch', '8', '--mode', 'train', '--spatial-gating', 'edge', '--time-gating'],
