@@ -86,6 +86,14 @@ struct Seq32Args {
   uint16_t* pk_dst0; int64_t pkdst_stride;             // ... the sequence-major array of step 0, elements between steps
   int pk_stride;                                       // ... elements between consecutive sequences of the user-layout tensor
   int nsteps;
+  // GATED (time-gated recurrence, graphML.py:2357-2374, 2420-2421): scalar gates of step 0 [B] fp32, elements between steps
+  const float* gi0; const float* gf0; int64_t gstride;
+  // MODE 1 (gate-PAIR pre-pass: both time gates' sub-cells of every (t, b) item in one pass, graphML.py:2362-2374):
+  int hmod;                                            // item i reads the state operand of sequence i % hmod (its h0)
+  const int32_t* flags;                                // (or null) flags[0] != 0: h0 is all zeros -- the state half is neither loaded nor multiplied
+  const float* gw;                                     // read-out weights of the two gates, [2][N][F] fp32 (node-major)
+  float* go;                                           // [items][2 * F/32 * 8] partial dot products per (chunk, wave); chunks 0 .. F/32-1 = input gate
+  uint16_t* out1;                                      // (or null, with out0) the forget gate cell's states [items][NP][F]; out0 = the input gate cell's
   int stagger;                                         // > 0: workgroup i starts ((i / 8) % 8) * stagger shader cycles late (de-synchronises the CUs' memory phases for the whole launch)
 };
 
@@ -102,6 +110,7 @@ __device__ __forceinline__ int lane_now() {
   do {                                                                                             \
     const int gwbeg = tbeg[0] >> 2, gwend = tend[STILES - 1] >> 2;                                 \
     if (gwbeg < gwend) {                                                                           \
+      const int ls_ = lane_now(), r = ls_ & 15, q = ls_ >> 4;                                      \
       const uint32_t colb = lds_col + r * 8 + (q >> 1) * 4;       /* this lane's own column dword of a slot's pair */ \
       const uint32_t qh_ = (uint32_t)(q & 1) << 4;                                                 \
       asm volatile(GCRNN_HOP_ASM_WIDE32_TEXT                                                       \
@@ -135,13 +144,18 @@ struct Seq32Map {
 // VAR: bit 0 = the launch lays out the input itself (inline pack), bit 1 = it writes the user-layout output. Compile-time so that every way
 // the forward is issued -- as the module issues it (3), caller-packed X (2), sequence-major in and out (0) -- is a kernel symbol of its own in a
 // trace (profiles/*kernel_stats.csv reproduce the bench line's roofline fraction), and the paths not taken cost neither code nor registers.
-template <int K, int HS, int XS, int VAR>
+// MODE 0: the recurrence (GATED: with the scalar time gates gi_t, gf_t known before step 0 -- they read (x_t, h0), never h_{t-1}).
+// MODE 1: the time gates' pre-pass for BOTH gates at once: an item (t, b) is one "sequence" of one step whose cell has 2 F outputs -- chunks
+//         0 .. F/32-1 the input gate's sub-cell, the rest the forget gate's (weights and biases concatenated by the caller) -- so the operand
+//         (x_t, h0) is loaded, and with VAR bit 0 laid out, ONCE per gate pair; epilogue: c = tanh(pre), partial <c, read-out weights>.
+template <int K, int HS, int XS, int VAR, int MODE = 0, bool GATED = false>
 __global__ __launch_bounds__(STHREADS) void fused_seq32_kernel(const Seq32Args a) {
-  constexpr bool PKV = (VAR & 1) != 0, USERV = (VAR & 2) != 0;
+  constexpr bool PKV = (VAR & 1) != 0, USERV = (VAR & 2) != 0 && MODE == 0;
+  static_assert(MODE == 0 || (MODE == 1 && !GATED), "modes");
   using M = Seq32Map<K, HS, XS>;
   constexpr int KS = HS + XS;
   constexpr int F = 32 * HS, G = 32 * XS;
-  constexpr int NCH = HS;                         // 32-feature output chunks
+  constexpr int NCH = (MODE == 1) ? 2 * HS : HS;  // 32-feature output chunks
   constexpr int PL = M::PL, WOFF = M::WOFF, WB = M::WB, COL_OFF = M::COL_OFF, RS2 = M::RS2;
   constexpr int NPCK = M::NPCK, NRND = NP / NPCK, NH = NCH * (K - 1), RPH = (NRND + NH - 1) / NH;      // pack rounds per step / hops per step / rounds per hop
   constexpr int PKROWS = G;
@@ -193,7 +207,7 @@ __global__ __launch_bounds__(STHREADS) void fused_seq32_kernel(const Seq32Args a
   // zeros behind the column image: the stream's running column pointer is not clamped (GCRNN_HOP_COLUMN_PAD)
   if (tid < GCRNN_HOP_COLUMN_PAD / 4) reinterpret_cast<uint32_t*>(smem + COL_OFF + entries * 32)[tid] = 0u;
   float* lbias = reinterpret_cast<float*>(smem + M::BIAS_OFF);
-  if (tid < F) lbias[tid] = a.bias ? a.bias[tid] : 0.f;
+  if (tid < NCH * 32) lbias[tid] = a.bias ? a.bias[tid] : 0.f;
   __syncthreads();
 
   if (a.stagger > 0) {
@@ -209,12 +223,17 @@ __global__ __launch_bounds__(STHREADS) void fused_seq32_kernel(const Seq32Args a
   const uint32_t lds_col = lds0 + COL_OFF;
   char* xtile = wtab + NP * 4;
 
+  // wave-uniform, as a scalar integer (a lane mask would also be parked in a vector register)
+  const int skip_hi = __builtin_amdgcn_readfirstlane((MODE == 1 && a.flags && a.flags[0] != 0) ? 1 : 0);
+  const bool skip_h = skip_hi != 0;
   for (int b = blockIdx.x; b < B; b += gridDim.x) {
   // ---- the operand of a sequence and step: every B fragment of the wave, resident for all chunks ----------------------------------
   bf16x8 bfr[STILES][KS];
   {
-    const __amdgpu_buffer_rsrc_t rsrc_h = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(a.hfirst), 0, B * (NP * F * 2), 0x00020000);
+    // (MODE 1 with an all-zero h0: a zero-length descriptor -- the loads return zeros and cost nothing)
+    const __amdgpu_buffer_rsrc_t rsrc_h = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(a.hfirst), 0, skip_h ? 0 : (MODE == 1 ? a.hmod : B) * (NP * F * 2), 0x00020000);
     const __amdgpu_buffer_rsrc_t rsrc_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(a.x0), 0, B * (NP * G * 2), 0x00020000);
+    const int bh = (MODE == 1) ? __builtin_amdgcn_readfirstlane(b % a.hmod) : b;
     const int ln0 = lane_now(), qo = ln0 >> 4;
     int sw[STILES];
     slot_words(ln0, sw);
@@ -224,7 +243,7 @@ __global__ __launch_bounds__(STHREADS) void fused_seq32_kernel(const Seq32Args a
       for (int i = 0; i < STILES; ++i) {
         const int w = sw[i];
         if (s < HS)
-          bfr[i][s] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsrc_h, (w >> 16) * (F * 2) + 16 * qo + 64 * s, b * (NP * F * 2), 0));
+          bfr[i][s] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsrc_h, (w >> 16) * (F * 2) + 16 * qo + 64 * s, bh * (NP * F * 2), 0));
         else
           bfr[i][s] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, (w >> 16) * (G * 2) + 16 * qo + 64 * (s - HS), b * (NP * G * 2), 0));
       }
@@ -232,7 +251,13 @@ __global__ __launch_bounds__(STHREADS) void fused_seq32_kernel(const Seq32Args a
   }
 #pragma unroll 1
   for (int step = 0; step < a.nsteps; ++step) {
-    uint16_t* hout = a.out0 + (int64_t)step * a.ostride;
+    uint16_t* hout = a.out0 ? a.out0 + (int64_t)step * a.ostride : nullptr;
+    float gin = 1.f, gfo = 1.f, gratio = 1.f;
+    if constexpr (GATED) {      // (wave-uniform: kept in scalar registers -- three vector registers live across the hops are three too many)
+      gin = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, a.gi0[(int64_t)step * a.gstride + b])));
+      gfo = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, a.gf0[(int64_t)step * a.gstride + b])));
+      gratio = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, gfo / fmaxf(gin, 1e-30f))));
+    }
     const uint16_t* aux1 = (USERV && a.a1) ? (a.a1_last_only ? (step == a.nsteps - 1 ? a.a1 : nullptr) : a.a1 + (int64_t)step * a.a1stride) : nullptr;
     // Inline pack: the 128-node rounds of a step's input are laid out ONE HOP ahead of "during the step before": hop i of step t takes
     // round i + 1 of x_{t+1}, the step's last hop round 0 of x_{t+2}. x_{t+1} is then complete (stored, waited for, behind a barrier) when
@@ -241,8 +266,12 @@ __global__ __launch_bounds__(STHREADS) void fused_seq32_kernel(const Seq32Args a
     // out steps 0 and 1.
     const bool pk_any = PKV && a.pk_src0 != nullptr;
     const int ubstride = a.ubstride;
-    const int64_t pk_soff = (int64_t)b * a.pk_stride;
-    const __amdgpu_buffer_rsrc_t rsrc_o = __builtin_amdgcn_make_buffer_rsrc(hout, 0, B * (NP * F * 2), 0x00020000);
+    // (MODE 1: the pack lays out the operand of the NEXT item of this workgroup's loop, item nb = (t', b') = (nb / hmod, nb % hmod))
+    const int nb = b + (int)gridDim.x;
+    const int nbq = (MODE == 1) ? __builtin_amdgcn_readfirstlane(nb / a.hmod) : 0, nbr = (MODE == 1) ? __builtin_amdgcn_readfirstlane(nb - nbq * a.hmod) : 0;      // (scalar registers)
+    const int64_t pk_soff = (MODE == 1) ? (int64_t)nbr * a.pk_stride + (int64_t)nbq * a.pksrc_stride : (int64_t)b * a.pk_stride;
+    const int pk_db = (MODE == 1) ? nb : b;
+    const __amdgpu_buffer_rsrc_t rsrc_o = __builtin_amdgcn_make_buffer_rsrc(hout, 0, hout ? B * (NP * F * 2) : 0, 0x00020000);
     [[maybe_unused]] const bool stamp_on = (step == (a.nsteps > 2 ? a.nsteps - 3 : 0)) && b == (int)blockIdx.x;      // a typical step (diagnostic builds)
     GCRNN_STAMP32(0);
     const bool more = step + 1 < a.nsteps;      // the next step's operand is requested at the start of this step's last epilogue
@@ -253,6 +282,39 @@ __global__ __launch_bounds__(STHREADS) void fused_seq32_kernel(const Seq32Args a
     auto taps = [&](int tap) {
       const int ln = lane_now();                       // (the fragment address is re-derived per call, not kept -- or spilled -- across the hops)
       const uint32_t wofs = (uint32_t)WOFF + (uint32_t)ln * 16u;
+      if constexpr (GATED || MODE == 1) {
+        // GATED: gi (x W_x) + gf (h W_h) on ONE accumulator chain per half: h-chain, scale by gf / gi, continue with x, scale by gi (gi = sigmoid(.)
+        // > 0; the wave-uniform guard covers an underflowed gate) -- the accumulators are ZERO on entry (every wave evaluates the tap before its
+        // stream, which then adds the hop's sums: exact, no reciprocal). MODE 1: the state half is skipped when h0 is all zeros.
+        const bool xpart = !GATED || gin > 1e-30f;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          if (!skip_h) {
+#pragma unroll
+            for (int s = 0; s < HS; ++s) {
+              const bf16x8 afr = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(smem + wofs + (uint32_t)(((tap * 2 + h) * KS + s) * 1024)));
+#pragma unroll
+              for (int i = 0; i < STILES; ++i) acc[i][h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr, bfr[i][s], acc[i][h], 0, 0, 0);
+            }
+          }
+          if constexpr (GATED) {
+#pragma unroll
+            for (int i = 0; i < STILES; ++i) acc[i][h] *= (xpart ? gratio : gfo);
+          }
+          if (xpart) {
+#pragma unroll
+            for (int s = HS; s < KS; ++s) {
+              const bf16x8 afr = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(smem + wofs + (uint32_t)(((tap * 2 + h) * KS + s) * 1024)));
+#pragma unroll
+              for (int i = 0; i < STILES; ++i) acc[i][h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr, bfr[i][s], acc[i][h], 0, 0, 0);
+            }
+            if constexpr (GATED) {
+#pragma unroll
+              for (int i = 0; i < STILES; ++i) acc[i][h] *= gin;
+            }
+          }
+        }
+      } else {
       // (the next fragment is requested before the current one's eight MFMAs)
       uint4 af[2];
       af[0] = *reinterpret_cast<const uint4*>(smem + wofs + (uint32_t)((tap * 2 * KS) * 1024));
@@ -263,6 +325,7 @@ __global__ __launch_bounds__(STHREADS) void fused_seq32_kernel(const Seq32Args a
         const bf16x8 afr = __builtin_bit_cast(bf16x8, af[hs & 1]);
 #pragma unroll
         for (int i = 0; i < STILES; ++i) acc[i][h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr, bfr[i][s], acc[i][h], 0, 0, 0);
+      }
       }
     };
     auto put = [&]() {
@@ -287,15 +350,17 @@ __global__ __launch_bounds__(STHREADS) void fused_seq32_kernel(const Seq32Args a
 #pragma unroll 1
     for (int chunk = 0; chunk < NCH; ++chunk) {
       // opaque per chunk: index arithmetic is re-derived from it inside the loop -- hoisted out it would have to be spilled
-      const int lane = lane_now();
-      const int tl = wave * 64 + lane;
-      const int r = lane & 15, q = lane >> 4;
+      // (nothing derived from the lane id lives across the hops: every use below re-derives it, lane_now())
       const bool last = chunk == NCH - 1;
       lds_barrier();      // the seed is in the image
       GCRNN_STAMP32(1 + chunk * 24);
 
       // virtual round v of this step (NRND per step, shifted by one hop) -> (target step, round); false: nothing to lay out
       auto pack_target = [&](int v, int& tgt, int& rnd) -> bool {
+        if constexpr (MODE == 1) {      // the workgroup's next item, round v (its operand is read when that item starts)
+          rnd = v; tgt = 0;
+          return pk_any && v < NRND && nb < B;
+        }
         v += RPH;
         const int wrap = v >= NRND ? 1 : 0;
         rnd = v - wrap * NRND;
@@ -306,10 +371,11 @@ __global__ __launch_bounds__(STHREADS) void fused_seq32_kernel(const Seq32Args a
       auto pack_issue = [&](int v) {
         int tgt, rnd;
         if (!pack_target(v, tgt, rnd)) return;
-        const uint16_t* pk_src = a.pk_src0 + (int64_t)tgt * a.pksrc_stride;
+        const uint16_t* pk_src = a.pk_src0 + (MODE == 1 ? 0 : (int64_t)tgt * a.pksrc_stride);
         constexpr int PPR = NPCK / 8, PIECES = PKROWS * PPR;
         static_assert(PIECES % STHREADS == 0, "whole pieces per thread");
         const uint16_t* xsrc = pk_src + pk_soff + rnd * NPCK;
+        const int tl = wave * 64 + lane_now();
 #pragma unroll
         for (int i = 0; i < PIECES / STHREADS; ++i) {
           const int id = i * STHREADS + tl;
@@ -324,11 +390,12 @@ __global__ __launch_bounds__(STHREADS) void fused_seq32_kernel(const Seq32Args a
       auto pack_drain = [&](int v) {
         int tgt, rnd;
         if (!pack_target(v, tgt, rnd)) return;
-        uint16_t* pk_dst = a.pk_dst0 + (int64_t)tgt * a.pkdst_stride;
+        uint16_t* pk_dst = a.pk_dst0 + (MODE == 1 ? 0 : (int64_t)tgt * a.pkdst_stride);
         constexpr int PCS = PKROWS / 8, RI = PCS * NPCK / STHREADS;
         static_assert(PCS * NPCK % STHREADS == 0, "whole row pieces per thread");
         typedef __attribute__((__vector_size__(4 * sizeof(unsigned int)))) unsigned int u32x4_t;
         const __amdgpu_buffer_rsrc_t rsrc_pk = __builtin_amdgcn_make_buffer_rsrc(pk_dst, 0, B * (NP * PKROWS * 2), 0x00020000);
+        const int tl = wave * 64 + lane_now();
         u32x4_t vv[RI];
 #pragma unroll
         for (int i = 0; i < RI; ++i) {
@@ -351,7 +418,7 @@ __global__ __launch_bounds__(STHREADS) void fused_seq32_kernel(const Seq32Args a
         for (int i = 0; i < RI; ++i) {
           const int id = i * STHREADS + tl;
           const int nl = id / PCS, pc = id - nl * PCS;
-          __builtin_amdgcn_raw_buffer_store_b128(vv[i], rsrc_pk, (rnd * NPCK + nl) * (PKROWS * 2) + pc * 16 + b * (NP * PKROWS * 2), 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b128(vv[i], rsrc_pk, (rnd * NPCK + nl) * (PKROWS * 2) + pc * 16 + pk_db * (NP * PKROWS * 2), 0, 0);
         }
       };
 
@@ -363,6 +430,7 @@ __global__ __launch_bounds__(STHREADS) void fused_seq32_kernel(const Seq32Args a
       auto r0_of = [&](int j) { return (chunk * (K - 1) + (j - 1)) * RPH; };
       auto weights_issue = [&](int wc, int tap) {
         const char* wsrc = reinterpret_cast<const char*>(a.wpack) + (size_t)wc * WB + (size_t)tap * (2 * KS * 1024);
+        const int lane = lane_now();
 #pragma unroll
         for (int i = 0; i < (2 * KS + SWAVES - 1) / SWAVES; ++i) {
           const int piece = i * SWAVES + wave;
@@ -391,7 +459,7 @@ __global__ __launch_bounds__(STHREADS) void fused_seq32_kernel(const Seq32Args a
         for (int i = 0; i < STILES; ++i) { acc[i][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[i][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
         // (the pack's LDS-DMA pieces go out right before the wave's stream: hipcc orders every later LDS read of the wave behind them with a
         //  vmcnt(0) -- behind the stream that wait is free, in front of the tap's weight reads it would expose the pieces' whole latency)
-        if (wave < SWAVES / 2 || GCRNN_SEQ32_SAME_ORDER) {
+        if (!(GATED || MODE == 1) && (wave < SWAVES / 2 || GCRNN_SEQ32_SAME_ORDER)) {
           dma_issue();
           GCRNN_HOP_ASM_WIDE32_STREAM(acc);
           GCRNN_STAMP32(1 + chunk * 24 + 4 * (j - 1) + 1);
@@ -428,8 +496,9 @@ __global__ __launch_bounds__(STHREADS) void fused_seq32_kernel(const Seq32Args a
 
       // ---- epilogue: + 2 b, tanh, bf16; lane (r, q) holds features 32 c + 8 q .. + 7 of its node: ONE 16-byte store per tile ------------
       typedef __attribute__((__vector_size__(4 * sizeof(unsigned int)))) unsigned int u32x4_t;
+      const int lane = lane_now(), q = lane >> 4, tl = wave * 64 + lane;
       auto request_next_operand = [&]() {
-        if (!(last && more)) return;
+        if (MODE != 0 || !(last && more)) return;
         // the next step's operand: x_{t+1} (laid out two steps ahead, or by the caller) and the state features of the earlier chunks
         // (stored -- and waited for -- at their chunk's end); the last chunk's come from this epilogue's registers below
         const int qo = lane_now() >> 4;
@@ -457,10 +526,50 @@ __global__ __launch_bounds__(STHREADS) void fused_seq32_kernel(const Seq32Args a
 #pragma unroll
       for (int h = 0; h < 2; ++h)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) bs[h][e] = 2.f * lbias[chunk * 32 + q * 8 + h * 4 + e];      // the one bias is added by both filters (graphML.py:2420-2421)
+        for (int e = 0; e < 4; ++e) bs[h][e] = (gin + gfo) * lbias[chunk * 32 + q * 8 + h * 4 + e];      // the one bias is added by both filters (graphML.py:2420-2421): 2 b, or (gi + gf) b
       u32x4_t pkd[STILES];
       int swe[STILES];
       slot_words(lane, swe);
+      if constexpr (MODE == 1) {
+        // gate pre-pass: c = tanh(pre) of this gate's sub-cell (chunk / HS = the gate), partial dot product with its read-out weights
+        // [N][F] fp32 (graphML.py:2364-2366: vec over (f, n)), one partial per (chunk, wave) -- the caller adds them in a fixed order; with
+        // output arrays the sub-cell's state is stored (bf16) for the gate's BPTT. The weights are shared by every item (L2-resident); two
+        // tiles' worth are requested at a time.
+        const int gate = chunk / HS, cg = chunk - gate * HS;
+        const float* gwp = a.gw + (int64_t)gate * N * F + cg * 32 + q * 8;
+        uint16_t* cso = gate ? a.out1 : a.out0;
+        const __amdgpu_buffer_rsrc_t rsrc_c = __builtin_amdgcn_make_buffer_rsrc(cso, 0, cso ? B * (NP * F * 2) : 0, 0x00020000);
+        float part = 0.f;
+#pragma unroll
+        for (int i0 = 0; i0 < STILES; i0 += 2) {
+          float4 w8[2][2];
+#pragma unroll
+          for (int t2 = 0; t2 < 2; ++t2) {
+            const int nd = (swe[i0 + t2] >> 16) < N ? (swe[i0 + t2] >> 16) : N - 1;
+            w8[t2][0] = *reinterpret_cast<const float4*>(gwp + (int64_t)nd * F);
+            w8[t2][1] = *reinterpret_cast<const float4*>(gwp + (int64_t)nd * F + 4);
+          }
+#pragma unroll
+          for (int t2 = 0; t2 < 2; ++t2) {
+            const int i = i0 + t2;
+            const int node = swe[i] >> 16;
+            u32x4_t p{0u, 0u, 0u, 0u};
+            if (node < N) {
+              const f32x4 a0 = acc[i][0], a1 = acc[i][1];
+              const float o0 = fast_tanh(a0[0] + bs[0][0]), o1 = fast_tanh(a0[1] + bs[0][1]), o2 = fast_tanh(a0[2] + bs[0][2]), o3 = fast_tanh(a0[3] + bs[0][3]);
+              const float o4 = fast_tanh(a1[0] + bs[1][0]), o5 = fast_tanh(a1[1] + bs[1][1]), o6 = fast_tanh(a1[2] + bs[1][2]), o7 = fast_tanh(a1[3] + bs[1][3]);
+              // (explicit chain: with -ffp-contract=fast the association of a*b + c*d + .. would be the compiler's choice per instantiation)
+              part = __builtin_fmaf(o3, w8[t2][0].w, __builtin_fmaf(o2, w8[t2][0].z, __builtin_fmaf(o1, w8[t2][0].y, __builtin_fmaf(o0, w8[t2][0].x, part))));
+              part = __builtin_fmaf(o7, w8[t2][1].w, __builtin_fmaf(o6, w8[t2][1].z, __builtin_fmaf(o5, w8[t2][1].y, __builtin_fmaf(o4, w8[t2][1].x, part))));
+              p[0] = pack2bf(o0, o1); p[1] = pack2bf(o2, o3); p[2] = pack2bf(o4, o5); p[3] = pack2bf(o6, o7);
+            }
+            if (cso) __builtin_amdgcn_raw_buffer_store_b128(p, rsrc_c, node * (F * 2) + (cg * 32 + q * 8) * 2, b * (NP * F * 2), 0);
+          }
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) part += __shfl_down(part, off, 64);
+        if (lane == 0) a.go[(int64_t)b * (NCH * SWAVES) + chunk * SWAVES + wave] = part;
+      } else {
 #pragma unroll
       for (int i = 0; i < STILES; ++i) {
         const int node = swe[i] >> 16;
@@ -476,8 +585,9 @@ __global__ __launch_bounds__(STHREADS) void fused_seq32_kernel(const Seq32Args a
         if (GCRNN_SEQ32_NT_STATE && last) __builtin_amdgcn_raw_buffer_store_b128(p, rsrc_o, node * (F * 2) + (chunk * 32 + q * 8) * 2, b * (NP * F * 2), GCRNN_SEQ32_NT_STATE);
         else __builtin_amdgcn_raw_buffer_store_b128(p, rsrc_o, node * (F * 2) + (chunk * 32 + q * 8) * 2, b * (NP * F * 2), 0);
       }
+      }
       GCRNN_STAMP32(1 + chunk * 24 + 17);
-      if (last) {
+      if (MODE == 0 && last) {
         // h_t's last 32 features ARE the lanes' B fragments of k-step HS-1: handed to the next step in registers
 #pragma unroll
         for (int i = 0; i < STILES; ++i) bfr[i][HS - 1] = __builtin_bit_cast(bf16x8, pkd[i]);

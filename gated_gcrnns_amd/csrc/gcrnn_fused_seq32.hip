@@ -6,11 +6,12 @@
 //   MFMA row m = lane & 15 of (chunk c, half h) is output feature 32 c + 8 (m >> 2) + 4 h + (m & 3) -- lane (r, q) of the D tile then holds
 //   features 32 c + 8 q .. + 7 of its node (gcrnn_fused_seq32.h); k = 32 kstep + 8 (lane >> 4) + j over the concatenated [h | x] features.
 //   Tap k is scaled by w^k (w = the graph's one weight): the hops then sum the 0/1 pattern, no multiply (Horner t_j = w^j v_j).
+//   Fout output rows over F state and G input features: Fout = F for a cell, 2 F for the two time gates' sub-cells stacked (gate pair pre-pass).
 template <typename W>
 __global__ void pack_weights_wide_kernel(const W* __restrict__ wA, const W* __restrict__ wB, uint16_t* __restrict__ out,
-                                         int F, int G, int Kin, int Kst, int K, float w) {
+                                         int Fout, int F, int G, int Kin, int Kst, int K, float w) {
   const int KS = (F + G) / 32;
-  const int64_t total = (int64_t)(F / 32) * K * 2 * KS * 64 * 8;
+  const int64_t total = (int64_t)(Fout / 32) * K * 2 * KS * 64 * 8;
   const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= total) return;
   const int j = idx & 7, lane = (idx >> 3) & 63;
@@ -30,19 +31,19 @@ __global__ void pack_weights_wide_kernel(const W* __restrict__ wA, const W* __re
   out[idx] = f2bf(v * sc);
 }
 
-extern "C" int gcrnn_fused_pack_weights_wide(int wdtype, const void* wA, const void* wB, void* wpack, int64_t F, int64_t G,
+extern "C" int gcrnn_fused_pack_weights_wide(int wdtype, const void* wA, const void* wB, void* wpack, int64_t Fout, int64_t F, int64_t G,
                                              int64_t Kin, int64_t Kst, double uniform_w, void* stream) {
   if (!wA || !wB || !wpack) return GCRNN_ERR_NULL_POINTER;
-  if (F <= 0 || G < 0 || F % 32 || (F + G) % 32 || Kin <= 0 || Kst <= 0 || uniform_w == 0.0) return GCRNN_ERR_BAD_SHAPE;
+  if (F <= 0 || G < 0 || F % 32 || (F + G) % 32 || Fout <= 0 || Fout % 32 || Kin <= 0 || Kst <= 0 || uniform_w == 0.0) return GCRNN_ERR_BAD_SHAPE;
   const int K = (int)(Kin > Kst ? Kin : Kst);
-  const int64_t total = (F / 32) * K * 2 * ((F + G) / 32) * 64 * 8;
+  const int64_t total = (Fout / 32) * K * 2 * ((F + G) / 32) * 64 * 8;
   GCRNN_PRE_LAUNCH();
   if (wdtype == GCRNN_F32)
     pack_weights_wide_kernel<float><<<(unsigned)cdiv(total, 256), 256, 0, as_stream(stream)>>>(
-        (const float*)wA, (const float*)wB, (uint16_t*)wpack, (int)F, (int)G, (int)Kin, (int)Kst, K, (float)uniform_w);
+        (const float*)wA, (const float*)wB, (uint16_t*)wpack, (int)Fout, (int)F, (int)G, (int)Kin, (int)Kst, K, (float)uniform_w);
   else if (wdtype == GCRNN_BF16)
     pack_weights_wide_kernel<__hip_bfloat16><<<(unsigned)cdiv(total, 256), 256, 0, as_stream(stream)>>>(
-        (const __hip_bfloat16*)wA, (const __hip_bfloat16*)wB, (uint16_t*)wpack, (int)F, (int)G, (int)Kin, (int)Kst, K, (float)uniform_w);
+        (const __hip_bfloat16*)wA, (const __hip_bfloat16*)wB, (uint16_t*)wpack, (int)Fout, (int)F, (int)G, (int)Kin, (int)Kst, K, (float)uniform_w);
   else
     return GCRNN_ERR_BAD_DTYPE;
   GCRNN_CHECK_LAUNCH();
@@ -86,9 +87,9 @@ extern "C" int gcrnn_fused_forward_wide_supported(int64_t B, int64_t T, int64_t 
   return seq32_lds_for(F, G, K, entries, inline_pack != 0) ? 1 : 0;
 }
 
-template <int K, int HS, int XS, int VAR>
+template <int K, int HS, int XS, int VAR, int MODE = 0, bool GATED = false>
 static int seq32_launch_v(const Seq32Args& sa, size_t lds, hipStream_t st) {
-  auto sk = fused_seq32_kernel<K, HS, XS, VAR>;
+  auto sk = fused_seq32_kernel<K, HS, XS, VAR, MODE, GATED>;
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(sk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
     return GCRNN_ERR_LAUNCH;
   GCRNN_PRE_LAUNCH();
@@ -101,6 +102,11 @@ template <int K, int HS, int XS>
 static int seq32_launch(const Seq32Args& sa, bool inline_pack, hipStream_t st) {
   const size_t lds = seq32_lds<K, HS, XS>(sa.entries, inline_pack);
   if (!lds) return GCRNN_ERR_UNSUPPORTED;
+  if (sa.gi0) {      // time-gated recurrence: the gate pre-pass has laid out X
+    if (inline_pack) return GCRNN_ERR_BAD_SHAPE;
+    if (sa.a1) return seq32_launch_v<K, HS, XS, 2, 0, true>(sa, lds, st);
+    return seq32_launch_v<K, HS, XS, 0, 0, true>(sa, lds, st);
+  }
   const int var = (inline_pack ? 1 : 0) | (sa.a1 ? 2 : 0);
   switch (var) {
     case 0: return seq32_launch_v<K, HS, XS, 0>(sa, lds, st);
@@ -110,15 +116,24 @@ static int seq32_launch(const Seq32Args& sa, bool inline_pack, hipStream_t st) {
   }
 }
 
-// Whole un-gated forward as ONE launch of the wide sequence-resident kernel (reference Utils/graphML.py:2351-2427 without gates).
+template <int K, int HS, int XS>
+static int seq32_launch_pair(const Seq32Args& sa, bool inline_pack, hipStream_t st) {
+  const size_t lds = seq32_lds<K, HS, XS>(sa.entries, inline_pack);
+  if (!lds) return GCRNN_ERR_UNSUPPORTED;
+  return inline_pack ? seq32_launch_v<K, HS, XS, 1, 1>(sa, lds, st) : seq32_launch_v<K, HS, XS, 0, 1>(sa, lds, st);
+}
+
+// Whole forward as ONE launch of the wide sequence-resident kernel (reference Utils/graphML.py:2351-2427): un-gated, or -- gi / gf [T][B]
+// fp32, the scalar time gates of every step (graphML.py:2357-2374; they read (x_t, h0), so all are known before step 0) -- time-gated.
 // xs [T][B][NP][G] bf16 sequence-major (every step laid out, or -- with Xuser_inline = the user-layout X [B][T][G][N] -- steps 0 and 1 only:
 // step t lays out x_{t+2}), h0 [B][NP][F], hs [T][B][NP][F] (out), wpack from gcrnn_fused_pack_weights_wide, bias [F] fp32 or NULL,
 // plan arrays of the bf16-image plan; Huser [B][T or 1][F][N] bf16 or NULL (huser_last_only: the last step only).
 extern "C" int gcrnn_fused_forward_wide_bf16(const void* xs, const void* h0, void* hs, const void* wpack, const float* bias,
-                                             const int32_t* tile_nodes, const int32_t* tile_off, const void* ell_col4, int64_t entries,
+                                             const float* gi, const float* gf, const int32_t* tile_nodes, const int32_t* tile_off, const void* ell_col4, int64_t entries,
                                              int64_t B, int64_t T, int64_t N, int64_t F, int64_t G, int64_t K, void* Huser,
                                              int huser_last_only, const void* Xuser_inline, void* stream) {
   if (!xs || !h0 || !hs || !wpack || !tile_nodes || !tile_off || !ell_col4) return GCRNN_ERR_NULL_POINTER;
+  if ((gi == nullptr) != (gf == nullptr) || (gi && Xuser_inline)) return GCRNN_ERR_BAD_SHAPE;
   if (B <= 0 || T <= 0 || N <= 0 || N > NP || B > (1 << 24) || entries <= 0 || entries % 4) return GCRNN_ERR_BAD_SHAPE;
   if (B * (NP * (F > G ? F : G) * 2) > 2147483647LL || T * F * N > 2147483647LL) return GCRNN_ERR_BAD_SHAPE;   // 32-bit buffer offsets
   if (Huser && (N % 8 != 0 || (reinterpret_cast<uintptr_t>(Huser) & 15))) return GCRNN_ERR_BAD_SHAPE;
@@ -134,6 +149,7 @@ extern "C" int gcrnn_fused_forward_wide_bf16(const void* xs, const void* h0, voi
   sa.tile_nodes = tile_nodes; sa.tile_off = tile_off; sa.ell_col4 = (const uint2*)ell_col4;
   sa.entries = (int)entries; sa.B = (int)B; sa.N = (int)N;
   sa.nsteps = (int)T;
+  sa.gi0 = gi; sa.gf0 = gf; sa.gstride = B;
   {
     // de-synchronised starts pay when the launch is long enough and every CU has a sequence (GCRNN_SEQ32_STAGGER=cycles overrides, 0 = off)
     const char* sg = getenv("GCRNN_SEQ32_STAGGER");
@@ -147,6 +163,59 @@ extern "C" int gcrnn_fused_forward_wide_bf16(const void* xs, const void* h0, voi
   }
   hipStream_t st = as_stream(stream);
 #define GCRNN_SEQ32_CASE(KK, HH, XX) if (K == KK && F == 32 * HH && G == 32 * XX) return seq32_launch<KK, HH, XX>(sa, inline_pack, st);
+  GCRNN_SEQ32_CASE(5, 2, 2) GCRNN_SEQ32_CASE(4, 2, 2) GCRNN_SEQ32_CASE(3, 2, 2) GCRNN_SEQ32_CASE(2, 2, 2)
+  GCRNN_SEQ32_CASE(5, 2, 1) GCRNN_SEQ32_CASE(4, 2, 1) GCRNN_SEQ32_CASE(3, 2, 1) GCRNN_SEQ32_CASE(2, 2, 1)
+  GCRNN_SEQ32_CASE(5, 1, 1) GCRNN_SEQ32_CASE(4, 1, 1) GCRNN_SEQ32_CASE(3, 1, 1) GCRNN_SEQ32_CASE(2, 1, 1)
+#undef GCRNN_SEQ32_CASE
+  return GCRNN_ERR_UNSUPPORTED;
+}
+
+
+// The two time gates' pre-pass as ONE launch over all (t, b) items (reference Utils/graphML.py:2357-2374): item i's operand (x_t, h0 of its
+// sequence) is loaded -- and with x_user laid out -- once for BOTH gates, whose sub-cells run as one cell of 2 F outputs on the wide kernel
+// (wpack = gcrnn_fused_pack_weights_wide(Fout = 2 F) of [GFL_in ; GFL_forget] stacked over the output features, bias2 [2 F], gw2 [2][N][F] fp32
+// the two read-outs' weights node-major). parts [T*B][2 * F/32 * 8] fp32: partial dot products <tanh(pre), read-out weights> per (chunk,
+// wave), chunks 0 .. F/32-1 the input gate's -- the caller adds them in a fixed order. cs_in / cs_f (both or neither): the sub-cells' states
+// [T][B][NPad][F] bf16 (their BPTT). x_user (or NULL): the user-layout X [B][T][G][N]; the caller has laid out the first
+// gcrnn_fused_gate_pair_wide_supported(..., 1) time steps of xs, the items lay out the rest. h0_zero_flag as in gcrnn_fused_gate_prepass_bf16.
+extern "C" int gcrnn_fused_gate_pair_wide_supported(int64_t B, int64_t T, int64_t N, int64_t F, int64_t G, int64_t K, int64_t entries,
+                                                    double uniform_w, int img16, int with_pack) {
+  if (uniform_w == 0.0 || !img16 || N <= 0 || N > NP || B <= 0 || T <= 0 || entries <= 0 || entries % 4) return 0;
+  if (with_pack && (N % 8 || T * G * N > 2147483647LL)) return 0;
+  if (B * T * (NP * (F > G ? F : G) * 2) > 2147483647LL) return 0;      // 32-bit buffer offsets over all items
+  if (!seq32_wanted(B * T)) return 0;
+  if (!seq32_lds_for(F, G, K, entries, with_pack != 0)) return 0;
+  if (!with_pack) return 1;
+  const int64_t first = B * T < 256 ? B * T : 256;      // the items of the first round of workgroups
+  return (int)((first + B - 1) / B);
+}
+
+extern "C" int gcrnn_fused_gate_pair_prepass_wide_bf16(const void* x_user, void* xs, const void* h0, const void* wpack, const float* bias2,
+                                                       const float* gw2, float* parts, void* cs_in, void* cs_f, const int32_t* tile_nodes,
+                                                       const int32_t* tile_off, const void* ell_col4, int64_t entries, int64_t B, int64_t T,
+                                                       int64_t N, int64_t F, int64_t G, int64_t K, const int32_t* h0_zero_flag, void* stream) {
+  if (!xs || !h0 || !wpack || !gw2 || !parts || !tile_nodes || !tile_off || !ell_col4) return GCRNN_ERR_NULL_POINTER;
+  if ((cs_in == nullptr) != (cs_f == nullptr)) return GCRNN_ERR_NULL_POINTER;
+  const int64_t items = B * T;
+  if (B <= 0 || T <= 0 || N <= 0 || N > NP || items > (1 << 24) || entries <= 0 || entries % 4) return GCRNN_ERR_BAD_SHAPE;
+  if (items * (NP * (F > G ? F : G) * 2) > 2147483647LL) return GCRNN_ERR_BAD_SHAPE;
+  if (x_user && (N % 8 != 0 || (reinterpret_cast<uintptr_t>(x_user) & 15) || T * G * N > 2147483647LL)) return GCRNN_ERR_BAD_SHAPE;
+  Seq32Args sa{};
+  sa.x0 = (const uint16_t*)xs;
+  sa.hfirst = (const uint16_t*)h0; sa.hmod = (int)B;
+  sa.out0 = (uint16_t*)cs_in; sa.out1 = (uint16_t*)cs_f;
+  sa.wpack = (const uint4*)wpack; sa.bias = bias2;
+  sa.tile_nodes = tile_nodes; sa.tile_off = tile_off; sa.ell_col4 = (const uint2*)ell_col4;
+  sa.entries = (int)entries; sa.B = (int)items; sa.N = (int)N;
+  sa.nsteps = 1;
+  sa.flags = h0_zero_flag; sa.gw = gw2; sa.go = parts;
+  const bool inline_pack = x_user != nullptr;
+  if (inline_pack) {
+    sa.pk_src0 = (const uint16_t*)x_user; sa.pksrc_stride = G * N; sa.pk_stride = (int)(T * G * N);
+    sa.pk_dst0 = (uint16_t*)xs;
+  }
+  hipStream_t st = as_stream(stream);
+#define GCRNN_SEQ32_CASE(KK, HH, XX) if (K == KK && F == 32 * HH && G == 32 * XX) return seq32_launch_pair<KK, HH, XX>(sa, inline_pack, st);
   GCRNN_SEQ32_CASE(5, 2, 2) GCRNN_SEQ32_CASE(4, 2, 2) GCRNN_SEQ32_CASE(3, 2, 2) GCRNN_SEQ32_CASE(2, 2, 2)
   GCRNN_SEQ32_CASE(5, 2, 1) GCRNN_SEQ32_CASE(4, 2, 1) GCRNN_SEQ32_CASE(3, 2, 1) GCRNN_SEQ32_CASE(2, 2, 1)
   GCRNN_SEQ32_CASE(5, 1, 1) GCRNN_SEQ32_CASE(4, 1, 1) GCRNN_SEQ32_CASE(3, 1, 1) GCRNN_SEQ32_CASE(2, 1, 1)

@@ -413,13 +413,14 @@ def _fused_pack_weights(wA, wB, st):
 
 def _fused_pack_weights_wide(wA, wB, uniform_w, st):
     """Taps as the MFMA A fragments of the wide sequence-resident kernel (csrc/gcrnn_fused_seq32.h): 32-feature chunks, feature
-    permutation of the rows, tap k scaled by uniform_w^k."""
-    F, G = wA.shape[0], wA.shape[3]
+    permutation of the rows, tap k scaled by uniform_w^k. wA [Fout][1][Kin][G], wB [Fout][1][Kst][F]: Fout = F for a cell, 2 F for the
+    two time gates' sub-cells stacked over their output features."""
+    Fout, G, F = wA.shape[0], wA.shape[3], wB.shape[3]
     Kin, Kst = wA.shape[2], wB.shape[2]
     K = max(Kin, Kst)
-    wpack = torch.empty(((F // 32) * K * 2 * ((F + G) // 32) * 64 * 8,), dtype=torch.bfloat16, device=wA.device)
+    wpack = torch.empty(((Fout // 32) * K * 2 * ((F + G) // 32) * 64 * 8,), dtype=torch.bfloat16, device=wA.device)
     wAc, wBc = wA.contiguous(), wB.contiguous()
-    check(lib.gcrnn_fused_pack_weights_wide(dtype_code(wA.dtype), _p(wAc), _p(wBc), _p(wpack), F, G, Kin, Kst, float(uniform_w), st),
+    check(lib.gcrnn_fused_pack_weights_wide(dtype_code(wA.dtype), _p(wAc), _p(wBc), _p(wpack), Fout, F, G, Kin, Kst, float(uniform_w), st),
           'pack_weights_wide')
     return wpack
 
@@ -435,10 +436,10 @@ def fused_wide_plan(graph, B, T, N, F, G, K, inline):
     return plan16 if ok else None
 
 
-def _fused_forward_wide(plan16, xs, h0s, hs, wA, wB, b32, B, T, N, F, G, K, H, last_only, Xinline, st, wpw=None):
+def _fused_forward_wide(plan16, xs, h0s, hs, wA, wB, b32, B, T, N, F, G, K, H, last_only, Xinline, st, wpw=None, gi=None, gf=None):
     if wpw is None:
         wpw = _fused_pack_weights_wide(wA.detach(), wB.detach(), plan16['uniform_w'], st)
-    check(lib.gcrnn_fused_forward_wide_bf16(_p(xs), _p(h0s), _p(hs), _p(wpw), _p(b32), _p(plan16['tile_slots']), _p(plan16['tile_off']),
+    check(lib.gcrnn_fused_forward_wide_bf16(_p(xs), _p(h0s), _p(hs), _p(wpw), _p(b32), _p(gi), _p(gf), _p(plan16['tile_slots']), _p(plan16['tile_off']),
                                             _p(plan16['ell_col4']), plan16['entries'], B, T, N, F, G, K,
                                             _p(H) if H is not None else None, int(bool(last_only)), _p(Xinline) if Xinline is not None else None, st),
           'fused_forward_wide')
@@ -545,7 +546,9 @@ def fused_pack_inputs_gated(X, h0, graph, F, K):
     plan16 = fused_img16_plan(graph, True, None)
     steps = 0
     if plan16 is not None and X.dtype == torch.bfloat16 and X.is_contiguous() and X.data_ptr() % 16 == 0 and not os.environ.get('GCRNN_NO_INLINE_PACK'):
-        steps = int(lib.gcrnn_fused_gate_prepass_lays_out(B, T, N, F, G, K, plan16['entries'], plan.get('uniform_w', 0.0), 1))
+        _, steps = fused_gate_pair_plan(graph, B, T, N, F, G, K, True)      # (the wide kernel's gate-pair pre-pass lays X out, when it takes the problem)
+        if steps <= 0:
+            steps = int(lib.gcrnn_fused_gate_prepass_lays_out(B, T, N, F, G, K, plan16['entries'], plan.get('uniform_w', 0.0), 1))
     if steps <= 0 or steps >= T:
         return fused_pack_inputs(X, h0, graph)
     npad = plan['npad']
@@ -607,6 +610,58 @@ def fused_time_gate(xs, h0s, wA_g, wB_g, bias_g, lin_w, lin_b, graph, N, store_s
         acc = acc + lin_b.detach().float()
     gate = torch.sigmoid(acc).view(T, B).contiguous()
     return (gate, cs, gw) if store_states else gate
+
+
+def fused_gate_pair_plan(graph, B, T, N, F, G, K, with_pack):
+    """(plan16, steps) when the wide kernel's gate-PAIR pre-pass takes this problem (gcrnn_fused_gate_pair_prepass_wide_bf16: both time
+    gates of every (t, b) in ONE launch), else (None, 0). steps: with_pack -- the leading time steps of xs the caller lays out itself."""
+    plan16 = fused_img16_plan(graph, True, None)
+    if plan16 is None or F % 32 or G % 32 or os.environ.get('GCRNN_NO_GATE_PAIR'):
+        return None, 0
+    steps = int(lib.gcrnn_fused_gate_pair_wide_supported(int(B), int(T), int(N), int(F), int(G), int(K), int(plan16['entries']),
+                                                         float(plan16.get('uniform_w', 0.0)), 1, 1 if with_pack else 0))
+    return (plan16, steps) if steps > 0 else (None, 0)
+
+
+def fused_time_gate_pair(xs, h0s, gate_in, gate_f, graph, N, store_states=False, hzero=None):
+    """BOTH time gates of the fused path for all (t, b) (graphML.py:2357-2374) as ONE pre-pass launch of the wide sequence-resident kernel: the
+    two sub-cells run as one cell of 2 F outputs, so an item's operand (x_t, h0) is loaded -- and, when xs still waits for its layout
+    (`_pending_user`), laid out -- once. gate_* = (wA_g, wB_g, bias_g, lin_w, lin_b). Returns (gi, gf) [T][B] fp32, and with store_states
+    also ((cs_in, gw_in), (cs_f, gw_f)): the sub-cells' states [T][B][NPad][F] bf16 and the read-out weights [N][F] fp32 for their BPTT."""
+    T, B, npad, G = xs.shape
+    F = gate_in[0].shape[0]
+    K = max(gate_in[0].shape[2], gate_in[1].shape[2])
+    st = _stream()
+    x_user = getattr(xs, '_pending_user', None)
+    plan16, _ = fused_gate_pair_plan(graph, B, T, N, F, G, K, x_user is not None)
+    assert plan16 is not None
+    wA2 = torch.cat([gate_in[0].detach(), gate_f[0].detach()], dim=0)
+    wB2 = torch.cat([gate_in[1].detach(), gate_f[1].detach()], dim=0)
+    wp = _fused_pack_weights_wide(wA2, wB2, plan16['uniform_w'], st)
+    zb = torch.zeros(F, dtype=torch.float32, device=xs.device)
+    b2 = torch.cat([(g[2].detach().float().reshape(-1) if g[2] is not None else zb) for g in (gate_in, gate_f)]).contiguous()
+    gws = [g[3].detach().float().view(F, N).t().contiguous() for g in (gate_in, gate_f)]      # row-major vec over (f, n) -> [N][F]
+    gw2 = torch.stack(gws, dim=0).contiguous()
+    nch = 2 * (F // 32)
+    waves = int(lib.gcrnn_fused_step_waves())
+    parts = torch.empty((T * B, nch * waves), dtype=torch.float32, device=xs.device)
+    cs_in = torch.empty((T, B, npad, F), dtype=torch.bfloat16, device=xs.device) if store_states else None
+    cs_f = torch.empty((T, B, npad, F), dtype=torch.bfloat16, device=xs.device) if store_states else None
+    check(lib.gcrnn_fused_gate_pair_prepass_wide_bf16(_p(x_user), _p(xs), _p(h0s), _p(wp), _p(b2), _p(gw2), _p(parts), _p(cs_in), _p(cs_f),
+                                                      _p(plan16['tile_slots']), _p(plan16['tile_off']), _p(plan16['ell_col4']), plan16['entries'],
+                                                      B, T, N, F, G, K, _p(hzero), st), 'gate_pair_prepass')
+    if x_user is not None:
+        del xs._pending_user
+    acc = parts.view(T * B, 2, (nch // 2) * waves).sum(dim=2)                  # fixed order: deterministic gates
+    out = []
+    for gidx, g in enumerate((gate_in, gate_f)):
+        a_ = acc[:, gidx]
+        if g[4] is not None:
+            a_ = a_ + g[4].detach().float()
+        out.append(torch.sigmoid(a_).view(T, B).contiguous())
+    if store_states:
+        return out[0], out[1], (cs_in, gws[0]), (cs_f, gws[1])
+    return out[0], out[1]
 
 
 def fused_cell_forward(X, h0, wA, wB, bias, graph, gates=None, return_states=False, gate_values=None, packed=None,
@@ -672,13 +727,20 @@ def fused_cell_forward(X, h0, wA, wB, bias, graph, gates=None, return_states=Fal
     elif gates is not None:
         hzero = fused_h0_zero_flag(h0)
         g = {}
+        gp = {}
         for name in ('in', 'forget'):
             wA_g, wB_g, bias_g, lin_w, lin_b = gates[name]
             if wA_g.shape[3] != G:
                 wA_g = torch.nn.functional.pad(wA_g.detach(), (0, G - wA_g.shape[3]))
             assert max(wA_g.shape[2], wB_g.shape[2]) == K and wA_g.shape[0] == F
-            g[name] = fused_time_gate(xs, h0s, wA_g, wB_g, bias_g, lin_w, lin_b, graph, N, hzero=hzero)
-        gi, gf = g['in'], g['forget']
+            gp[name] = (wA_g, wB_g, bias_g, lin_w, lin_b)
+        pair16, _ = fused_gate_pair_plan(graph, B, T, N, F, G, K, getattr(xs, '_pending_user', None) is not None)
+        if pair16 is not None:
+            gi, gf = fused_time_gate_pair(xs, h0s, gp['in'], gp['forget'], graph, N, hzero=hzero)      # ONE launch for both gates
+        else:
+            for name in ('in', 'forget'):
+                g[name] = fused_time_gate(xs, h0s, *gp[name], graph, N, hzero=hzero)
+            gi, gf = g['in'], g['forget']
     assert getattr(xs, '_pending_user', None) is None
     wpack = _fused_pack_weights(wA, wB, st)
     b32 = bias.detach().float().contiguous().view(-1) if bias is not None else None
@@ -699,16 +761,16 @@ def fused_cell_forward(X, h0, wA, wB, bias, graph, gates=None, return_states=Fal
         if head[1] is not None:
             y = y + head[1].detach().float().reshape(())
         return y.permute(1, 0, 2).unsqueeze(2).contiguous()          # B x T x 1 x N
-    wide = fused_wide_plan(graph, B, T, N, F, G, K, inline) if (gi is None and evs is None) else None
+    wide = fused_wide_plan(graph, B, T, N, F, G, K, inline) if (evs is None and head is None and not (gi is not None and inline)) else None
     if wide is not None:
         # un-gated cell, uniform-weight graph, a batch that fills the chip: ONE launch of the wide sequence-resident kernel
         if native_out:
             assert not return_states
-            _fused_forward_wide(wide, xs, h0s, hs, wA, wB, b32, B, T, N, F, G, K, None, False, X if inline else None, st)
+            _fused_forward_wide(wide, xs, h0s, hs, wA, wB, b32, B, T, N, F, G, K, None, False, X if inline else None, st, gi=gi, gf=gf)
             Hv = hs.permute(1, 0, 3, 2)[:, :, :, :N]
             return Hv[:, T - 1:] if last_only else Hv
         H = torch.empty((B, 1 if last_only else T, F, N), dtype=torch.bfloat16, device=dev)
-        _fused_forward_wide(wide, xs, h0s, hs, wA, wB, b32, B, T, N, F, G, K, H if direct else None, last_only, X if inline else None, st)
+        _fused_forward_wide(wide, xs, h0s, hs, wA, wB, b32, B, T, N, F, G, K, H if direct else None, last_only, X if inline else None, st, gi=gi, gf=gf)
         if not direct:
             src = hs[T - 1:] if last_only else hs
             check(lib.gcrnn_unpack_seq_major(_lib.BF16, _p(src), _p(H), B, 1 if last_only else T, F, N, plan['npad'], None, st), 'unpack_seq')

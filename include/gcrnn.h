@@ -359,24 +359,40 @@ int gcrnn_fused_forward_bf16(const void* xs, const void* h0, void* hs, const voi
                                 Huser may be NULL: the regression model's inference then never materialises H */,
                              void* stream);
 
-/* ---- The wide sequence-resident forward (round 4; csrc/gcrnn_fused_seq32.h): the un-gated recurrence of Utils/graphML.py:2351-2427 as
- * ONE launch, one workgroup per sequence, 32 output features per chunk as two 16-feature image planes read by one hop stream, the
- * graph weight folded into the taps (W_k <- w^k W_k), h_t handed to step t+1 in registers. Replaces gcrnn_fused_forward_bf16 for
- * un-gated cells on uniform-weight bf16-image plans when the batch fills whole rounds of the chip.
- * gcrnn_fused_pack_weights_wide: taps -> MFMA A fragments wpack [F/32][K][2][(F+G)/32][64][8] bf16 (F, F+G multiples of 32); MFMA row m of
- *   (chunk c, half h) is output feature 32 c + 8 (m >> 2) + 4 h + (m & 3); tap k is scaled by uniform_w^k.
+/* ---- The wide sequence-resident kernel (round 4; csrc/gcrnn_fused_seq32.h): the recurrence of Utils/graphML.py:2351-2427 as ONE launch,
+ * one workgroup per sequence, 32 output features per chunk as two 16-feature image planes read by one hop stream, the graph weight folded
+ * into the taps (W_k <- w^k W_k), h_t handed to step t+1 in registers. Replaces gcrnn_fused_forward_bf16 for un-gated and time-gated cells
+ * on uniform-weight bf16-image plans when the batch fills whole rounds of the chip, and both gcrnn_fused_gate_prepass_*_bf16 launches of a
+ * time-gated cell by ONE pass over the (t, b) items.
+ * gcrnn_fused_pack_weights_wide: taps -> MFMA A fragments wpack [Fout/32][K][2][(F+G)/32][64][8] bf16 (Fout output rows over F state and G
+ *   input features, all multiples of 32: Fout = F for a cell, 2 F for the two time gates' sub-cells stacked); MFMA row m of (chunk c, half h)
+ *   is output feature 32 c + 8 (m >> 2) + 4 h + (m & 3); tap k is scaled by uniform_w^k.
  * gcrnn_fused_forward_wide_supported: 1 when gcrnn_fused_forward_wide_bf16 takes the problem (inline_pack: with Xuser_inline).
  * gcrnn_fused_forward_wide_bf16: xs [T][B][NPad][G] bf16 sequence-major -- every step laid out, or with Xuser_inline (the user-layout
- *   X [B][T][G][N] bf16, N % 8 == 0) steps 0 and 1 only: step t lays out x_{t+2} --, h0 [B][NPad][F], hs [T][B][NPad][F] (out), bias [F]
- *   fp32 or NULL (added twice, graphML.py:2420-2421), tile_nodes / tile_off / ell_col4 = the bf16-image plan (graph.fused_plan_img16),
- *   Huser [B][T][F][N] bf16 or NULL (huser_last_only: [B][1][F][N], the last state only). */
-int gcrnn_fused_pack_weights_wide(int wdtype, const void* wA, const void* wB, void* wpack, int64_t F, int64_t G, int64_t Kin, int64_t Kst,
-                                  double uniform_w, void* stream);
+ *   X [B][T][G][N] bf16, N % 8 == 0; un-gated only) steps 0 and 1 only: the launch lays out the rest, each step one hop before the step that
+ *   reads it ends --, h0 [B][NPad][F], hs [T][B][NPad][F] (out), bias [F] fp32 or NULL (added by both filters, graphML.py:2420-2421),
+ *   gi / gf: NULL, or the scalar time gates [T][B] fp32 (graphML.py:2357-2374), tile_nodes / tile_off / ell_col4 = the bf16-image plan
+ *   (graph.fused_plan_img16), Huser [B][T][F][N] bf16 or NULL (huser_last_only: [B][1][F][N], the last state only).
+ * gcrnn_fused_gate_pair_wide_supported: 0, or -- with_pack -- the number of leading time steps of xs the caller lays out itself (1 without).
+ * gcrnn_fused_gate_pair_prepass_wide_bf16: both time gates of every (t, b) in one launch; wpack = gcrnn_fused_pack_weights_wide(Fout = 2 F) of
+ *   [GFL_in ; GFL_forget] stacked over the output features, bias2 [2 F], gw2 [2][N][F] fp32 = the read-outs' weights node-major, parts
+ *   [T*B][2 * F/32 * 8] fp32 partial dot products (chunks 0 .. F/32-1 the input gate's; fixed-order sum by the caller), cs_in / cs_f (both or
+ *   neither) the sub-cells' states [T][B][NPad][F] bf16, x_user as in gcrnn_fused_gate_prepass_pack_bf16, h0_zero_flag as in
+ *   gcrnn_fused_gate_prepass_bf16. */
+int gcrnn_fused_pack_weights_wide(int wdtype, const void* wA, const void* wB, void* wpack, int64_t Fout, int64_t F, int64_t G, int64_t Kin,
+                                  int64_t Kst, double uniform_w, void* stream);
 int gcrnn_fused_forward_wide_supported(int64_t B, int64_t T, int64_t N, int64_t F, int64_t G, int64_t K, int64_t entries, double uniform_w,
                                        int img16, int inline_pack);
-int gcrnn_fused_forward_wide_bf16(const void* xs, const void* h0, void* hs, const void* wpack, const float* bias, const int32_t* tile_nodes,
-                                  const int32_t* tile_off, const void* ell_col4, int64_t entries, int64_t B, int64_t T, int64_t N, int64_t F,
-                                  int64_t G, int64_t K, void* Huser, int huser_last_only, const void* Xuser_inline, void* stream);
+int gcrnn_fused_forward_wide_bf16(const void* xs, const void* h0, void* hs, const void* wpack, const float* bias, const float* gi,
+                                  const float* gf, const int32_t* tile_nodes, const int32_t* tile_off, const void* ell_col4, int64_t entries,
+                                  int64_t B, int64_t T, int64_t N, int64_t F, int64_t G, int64_t K, void* Huser, int huser_last_only,
+                                  const void* Xuser_inline, void* stream);
+int gcrnn_fused_gate_pair_wide_supported(int64_t B, int64_t T, int64_t N, int64_t F, int64_t G, int64_t K, int64_t entries, double uniform_w,
+                                         int img16, int with_pack);
+int gcrnn_fused_gate_pair_prepass_wide_bf16(const void* x_user, void* xs, const void* h0, const void* wpack, const float* bias2,
+                                            const float* gw2, float* parts, void* cs_in, void* cs_f, const int32_t* tile_nodes,
+                                            const int32_t* tile_off, const void* ell_col4, int64_t entries, int64_t B, int64_t T, int64_t N,
+                                            int64_t F, int64_t G, int64_t K, const int32_t* h0_zero_flag, void* stream);
 
 /* Time-gate pre-pass (graphML.py:2357-2374): for every (t, b)
  *   sum over gate_out[t][b][0 .. F/16*8) = sum_{n,f} tanh( A_g(S) x_t + B_g(S) h0 + 2 b_g )[n][f] * gate_w[n][f]

@@ -124,3 +124,53 @@ def test_wide_kernel_full_size_tracks_the_16_feature_kernel_and_replays_bit_iden
     d = (H.float() - H16.float()).abs()
     assert float(d.max()) <= 2.5e-2 and float(d.mean()) <= 1.5e-3, (float(d.max()), float(d.mean()))
     assert float(H.float().abs().mean()) > 0.05
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('N,F,G,K,B,T,hz', [(1000, 64, 64, 5, 5, 4, False), (1000, 64, 64, 5, 4, 3, True), (400, 32, 32, 3, 7, 3, False),
+                                            (1000, 64, 1, 3, 3, 3, True), (1000, 64, 64, 2, 2, 2, False), (1000, 64, 32, 4, 3, 5, True),
+                                            (1008, 64, 64, 5, 130, 3, True)])
+def test_wide_time_gated_cell_matches_oracle(N, F, G, K, B, T, hz, monkeypatch):
+    """The time-gated cell on the wide kernel: ONE pre-pass launch for BOTH gates (the two sub-cells as one cell of 2 F outputs; it also lays
+    out X; the state half of the operand skipped when h0 is all zeros) + the gated recurrence (h-chain, scale by gf / gi, x-chain, scale by
+    gi, then the hop's sums) against the fp64 oracle (reference Utils/graphML.py:2357-2374, 2420-2421) on bf16-rounded operands, zero and
+    non-zero h0 (the gates read h0, never h_{t-1}); the 16-feature kernels on the same problem are the yardstick."""
+    import gated_gcrnns_amd.Utils.graphML as gml
+    from gated_gcrnns_amd import ops
+    dev = torch.device('cuda:0')
+    rng = np.random.default_rng(97)
+    W = (rng.random((N, N)) < 10.0 / N).astype(np.float64)
+    W = np.triu(W, 1); W = W + W.T
+    S = (W / np.max(np.abs(np.linalg.eigvalsh(W)))).reshape(1, N, N)
+    torch.manual_seed(97)
+    cell = gml.GGCRNNCell(G, F, K, K, torch.tanh, True, None, 1, True)
+    cell.addGSO(torch.tensor(S))
+    with torch.no_grad():                               # make the scalar gates vary: larger read-out weights than the default init
+        cell.MLP_in[0].weight.mul_(8.0)
+        cell.MLP_forget[0].weight.mul_(8.0)
+    cell = cell.to(torch.bfloat16)
+    X = bf16_round(rng.standard_normal((B, T, G, N)))
+    h0 = np.zeros((B, F, N)) if hz else bf16_round(0.3 * rng.standard_normal((B, F, N)))
+    params = {k: v.detach().double().numpy() for k, v in cell.state_dict().items()}
+    nb = min(B, 3)
+    Href = orc.ggcrnn_cell(params, S.astype(np.float32).astype(np.float64), X[:nb], h0[:nb], True, None)
+    cell = cell.to(dev)
+    Xd = torch.tensor(X, dtype=torch.bfloat16, device=dev)
+    hd = torch.tensor(h0, dtype=torch.bfloat16, device=dev)
+    monkeypatch.setenv('GCRNN_SEQ32_MIN_B', '1')
+    Gp = ops.fused_padded_inputs(F, G)
+    assert ops.fused_gate_pair_plan(cell.graph, B, T, N, F, Gp, K, N % 8 == 0)[0] is not None
+    assert ops.fused_wide_plan(cell.graph, B, T, N, F, Gp, K, False) is not None
+    with torch.no_grad():
+        H = cell(Xd, hd)
+        Hl = cell(Xd, hd, last_only=True)
+        monkeypatch.setenv('GCRNN_NO_INLINE_PACK', '1')
+        H2 = cell(Xd, hd)
+        monkeypatch.delenv('GCRNN_NO_INLINE_PACK')
+        monkeypatch.setenv('GCRNN_SEQ32', '0')
+        monkeypatch.setenv('GCRNN_SEQ_MIN_B', '1')
+        H16 = cell(Xd, hd)
+    assert torch.equal(H, H2) and torch.equal(H[:, -1:], Hl)
+    err = np.abs(H[:nb].double().cpu().numpy() - Href)
+    err16 = np.abs(H16[:nb].double().cpu().numpy() - Href)
+    assert err.max() <= max(6.0e-3, 2.0 * err16.max()) and err.mean() <= max(1.0e-3, 1.5 * err16.mean()), (err.max(), err.mean(), err16.max(), err16.mean())
