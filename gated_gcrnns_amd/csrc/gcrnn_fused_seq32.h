@@ -282,14 +282,14 @@ __global__ __launch_bounds__(STHREADS) void fused_seq32_kernel(const Seq32Args a
     auto taps = [&](int tap) {
       const int ln = lane_now();                       // (the fragment address is re-derived per call, not kept -- or spilled -- across the hops)
       const uint32_t wofs = (uint32_t)WOFF + (uint32_t)ln * 16u;
-      if constexpr (GATED || MODE == 1) {
-        // GATED: gi (x W_x) + gf (h W_h) on ONE accumulator chain per half: h-chain, scale by gf / gi, continue with x, scale by gi (gi = sigmoid(.)
-        // > 0; the wave-uniform guard covers an underflowed gate) -- the accumulators are ZERO on entry (every wave evaluates the tap before its
-        // stream, which then adds the hop's sums: exact, no reciprocal). MODE 1: the state half is skipped when h0 is all zeros.
-        const bool xpart = !GATED || gin > 1e-30f;
+      if constexpr (GATED) {
+        // gi (x W_x) + gf (h W_h) on ONE accumulator chain per half: h-chain, scale by gf / gi, continue with x, scale by gi (gi = sigmoid(.) > 0;
+        // the wave-uniform guard covers an underflowed gate) -- the accumulators are ZERO on entry (every wave evaluates the tap before its
+        // stream, which then adds the hop's sums: exact, no reciprocal).
+        const bool xpart = gin > 1e-30f;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-          if (!skip_h) {
+          {
 #pragma unroll
             for (int s = 0; s < HS; ++s) {
               const bf16x8 afr = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(smem + wofs + (uint32_t)(((tap * 2 + h) * KS + s) * 1024)));
@@ -314,6 +314,17 @@ __global__ __launch_bounds__(STHREADS) void fused_seq32_kernel(const Seq32Args a
             }
           }
         }
+      } else if constexpr (MODE == 1) {
+        // (gate pre-pass; with an all-zero h0 the state half of the operand is neither loaded nor multiplied)
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+          for (int s = 0; s < KS; ++s) {
+            if (s < HS && skip_h) continue;
+            const bf16x8 afr = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(smem + wofs + (uint32_t)(((tap * 2 + h) * KS + s) * 1024)));
+#pragma unroll
+            for (int i = 0; i < STILES; ++i) acc[i][h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr, bfr[i][s], acc[i][h], 0, 0, 0);
+          }
       } else {
       // (the next fragment is requested before the current one's eight MFMAs)
       uint4 af[2];
@@ -459,7 +470,7 @@ __global__ __launch_bounds__(STHREADS) void fused_seq32_kernel(const Seq32Args a
         for (int i = 0; i < STILES; ++i) { acc[i][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[i][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
         // (the pack's LDS-DMA pieces go out right before the wave's stream: hipcc orders every later LDS read of the wave behind them with a
         //  vmcnt(0) -- behind the stream that wait is free, in front of the tap's weight reads it would expose the pieces' whole latency)
-        if (!(GATED || MODE == 1) && (wave < SWAVES / 2 || GCRNN_SEQ32_SAME_ORDER)) {
+        if (!GATED && (wave < SWAVES / 2 || GCRNN_SEQ32_SAME_ORDER)) {
           dma_issue();
           GCRNN_HOP_ASM_WIDE32_STREAM(acc);
           GCRNN_STAMP32(1 + chunk * 24 + 4 * (j - 1) + 1);

@@ -1145,8 +1145,7 @@ def fused_node_cell_train(X, h0, wA, wB, bias, graph, node_gates, time_gates=Non
     assert getattr(xs, '_pending_user', None) is None          # (the first pre-pass laid out the rest of X)
     gi = gf = None
     if time_gates is not None:
-        gi = _FusedTimeGate.apply(xs, hs_all[:1], X, h0, *time_gates['in'], graph, hzero)
-        gf = _FusedTimeGate.apply(xs, hs_all[:1], X, h0, *time_gates['forget'], graph, hzero)
+        gi, gf = fused_train_time_gates(xs, hs_all[:1], X, h0, time_gates, graph, hzero)
     return _FusedNodeCell.apply(X, h0, wA, wB, bias, ni, nf, gi, gf, graph, xs, hs_all)
 
 
@@ -1401,8 +1400,7 @@ def fused_edge_cell_train(X, h0, wA, wB, bias, graph, att_in, att_f, time_gates=
         hzero = fused_h0_zero_flag(h0)
     gi = gf = None
     if time_gates is not None:
-        gi = _FusedTimeGate.apply(xs, hs_all[:1], X, h0, *time_gates['in'], graph, hzero)
-        gf = _FusedTimeGate.apply(xs, hs_all[:1], X, h0, *time_gates['forget'], graph, hzero)
+        gi, gf = fused_train_time_gates(xs, hs_all[:1], X, h0, time_gates, graph, hzero)
         assert getattr(xs, '_pending_user', None) is None
     return _FusedEdgeCell.apply(X, h0, wA, wB, bias, att_in[0], att_in[1], att_f[0], att_f[1], gi, gf, graph, xs, hs_all, float(negative_slope))
 
@@ -1763,26 +1761,80 @@ class _FusedTimeGate(torch.autograd.Function):
         ctx.consumed = True
         if ctx.needs_input_grad[2] or ctx.needs_input_grad[3]:
             raise GcrnnError('the fused time gate does not produce gradients w.r.t. X or h0')
-        B, T, G, N = X.shape
-        F, Kin, Kst = wA_g.shape[0], wA_g.shape[2], wB_g.shape[2]
-        K = max(Kin, Kst)
-        T_, B_, npad, _ = cs.shape
-        items = T * B
-        dlogit = (dgate.float() * gate * (1.0 - gate)).contiguous().view(-1)          # through the sigmoid
-        slabs = int(lib.gcrnn_fused_gate_readout_slabs(items))
-        dw_part = torch.empty((slabs, npad * F), dtype=torch.float32, device=X.device)
-        # cs becomes dpre_g in place: a second backward through the same graph is not supported (retain_graph)
-        check(lib.gcrnn_fused_gate_readout_backward_bf16(_p(cs), _p(dlogit), _p(gw), _p(dw_part), items, N, F, _stream()),
-              'gate_readout_backward')
-        dW, dbs = fused_backward_weight(cs, X, None, h0, ctx.graph, F, G, K, want_bias=True, h_is_h0=True, hzero=hzero)
-        gA = dW[:, :Kin, F:].unsqueeze(1).to(wA_g.dtype) if ctx.needs_input_grad[4] else None
-        gB = dW[:, :Kst, :F].unsqueeze(1).to(wB_g.dtype) if ctx.needs_input_grad[5] else None
-        gb = dbs.view_as(bias_g).to(bias_g.dtype) if (bias_g is not None and ctx.needs_input_grad[6]) else None
-        glw = None
-        if ctx.needs_input_grad[7]:
-            glw = dw_part.sum(dim=0).view(npad, F)[:N].t().reshape(1, F * N).to(lin_w.dtype)     # [N][F] -> vec over (f, n)
-        glb = dlogit.sum().view(1).to(lin_b.dtype) if (lin_b is not None and ctx.needs_input_grad[8]) else None
-        return None, None, None, None, gA, gB, gb, glw, glb, None, None
+        return (None, None, None, None) + _time_gate_backward(X, h0, wA_g, wB_g, bias_g, lin_w, lin_b, gate, cs, gw, hzero, ctx.graph, dgate,
+                                                              ctx.needs_input_grad[4:9]) + (None, None)
+
+
+def _time_gate_backward(X, h0, wA_g, wB_g, bias_g, lin_w, lin_b, gate, cs, gw, hzero, graph, dgate, needs):
+    """BPTT of one time gate from its stored sub-cell states cs (turned into dpre_g IN PLACE): read-out gradient, then the weight-gradient
+    kernel over all items with h0 as every item's state operand. Returns (gA, gB, gb, glw, glb); needs = which of them are wanted."""
+    B, T, G, N = X.shape
+    F, Kin, Kst = wA_g.shape[0], wA_g.shape[2], wB_g.shape[2]
+    K = max(Kin, Kst)
+    T_, B_, npad, _ = cs.shape
+    items = T * B
+    dlogit = (dgate.float() * gate * (1.0 - gate)).contiguous().view(-1)          # through the sigmoid
+    slabs = int(lib.gcrnn_fused_gate_readout_slabs(items))
+    dw_part = torch.empty((slabs, npad * F), dtype=torch.float32, device=X.device)
+    # cs becomes dpre_g in place: a second backward through the same graph is not supported (retain_graph)
+    check(lib.gcrnn_fused_gate_readout_backward_bf16(_p(cs), _p(dlogit), _p(gw), _p(dw_part), items, N, F, _stream()),
+          'gate_readout_backward')
+    dW, dbs = fused_backward_weight(cs, X, None, h0, graph, F, G, K, want_bias=True, h_is_h0=True, hzero=hzero)
+    gA = dW[:, :Kin, F:].unsqueeze(1).to(wA_g.dtype) if needs[0] else None
+    gB = dW[:, :Kst, :F].unsqueeze(1).to(wB_g.dtype) if needs[1] else None
+    gb = dbs.view_as(bias_g).to(bias_g.dtype) if (bias_g is not None and needs[2]) else None
+    glw = None
+    if needs[3]:
+        glw = dw_part.sum(dim=0).view(npad, F)[:N].t().reshape(1, F * N).to(lin_w.dtype)     # [N][F] -> vec over (f, n)
+    glb = dlogit.sum().view(1).to(lin_b.dtype) if (lin_b is not None and needs[4]) else None
+    return gA, gB, gb, glw, glb
+
+
+class _FusedTimeGatePair(torch.autograd.Function):
+    """BOTH time gates of the fused path with their BPTT: forward = ONE pre-pass launch of the wide sequence-resident kernel over all (t, b)
+    (fused_time_gate_pair: the two sub-cells as one cell of 2 F outputs; states of both stored), backward = _FusedTimeGate's, once per gate."""
+
+    @staticmethod
+    def forward(ctx, xs, h0s, X, h0, wA_i, wB_i, b_i, lw_i, lb_i, wA_f, wB_f, b_f, lw_f, lb_f, graph, hzero):
+        N = X.shape[3]
+        gi, gf, (cs_i, gw_i), (cs_f, gw_f) = fused_time_gate_pair(xs, h0s, (wA_i, wB_i, b_i, lw_i, lb_i), (wA_f, wB_f, b_f, lw_f, lb_f), graph, N,
+                                                                  store_states=True, hzero=hzero)
+        ctx.save_for_backward(X, h0, wA_i, wB_i, b_i, lw_i, lb_i, wA_f, wB_f, b_f, lw_f, lb_f, gi, gf, cs_i, gw_i, cs_f, gw_f, hzero)
+        ctx.graph = graph
+        return gi, gf
+
+    @staticmethod
+    def backward(ctx, dgi, dgf):
+        X, h0, wA_i, wB_i, b_i, lw_i, lb_i, wA_f, wB_f, b_f, lw_f, lb_f, gi, gf, cs_i, gw_i, cs_f, gw_f, hzero = ctx.saved_tensors
+        if getattr(ctx, 'consumed', False):
+            raise GcrnnError('the fused time gates were already back-propagated: their saved states are turned into gradients in '
+                             'place, so a second backward over the same graph (retain_graph) is not supported')
+        ctx.consumed = True
+        if ctx.needs_input_grad[2] or ctx.needs_input_grad[3]:
+            raise GcrnnError('the fused time gate does not produce gradients w.r.t. X or h0')
+        zi = torch.zeros_like(gi) if dgi is None else dgi
+        zf = torch.zeros_like(gf) if dgf is None else dgf
+        g_in = _time_gate_backward(X, h0, wA_i, wB_i, b_i, lw_i, lb_i, gi, cs_i, gw_i, hzero, ctx.graph, zi, ctx.needs_input_grad[4:9])
+        g_f = _time_gate_backward(X, h0, wA_f, wB_f, b_f, lw_f, lb_f, gf, cs_f, gw_f, hzero, ctx.graph, zf, ctx.needs_input_grad[9:14])
+        return (None, None, None, None) + g_in + g_f + (None, None)
+
+
+def fused_train_time_gates(xs, h0s, X, h0, gates, graph, hzero):
+    """The two differentiable time gates [T][B] of a training step: ONE pre-pass launch for the pair where the wide kernel takes the problem
+    (uniform-weight graph, a batch that fills the chip), else one launch per gate."""
+    T, B, npad, G = xs.shape
+    N = X.shape[3]
+    gin, gfo = gates['in'], gates['forget']
+    F = gin[0].shape[0]
+    K = max(gin[0].shape[2], gin[1].shape[2])
+    pair16 = None
+    if gin[0].shape == gfo[0].shape and gin[1].shape == gfo[1].shape and gin[0].shape[3] == G and not os.environ.get('GCRNN_NO_GATE_PAIR_TRAIN'):
+        pair16, _ = fused_gate_pair_plan(graph, B, T, N, F, G, K, getattr(xs, '_pending_user', None) is not None)
+    if pair16 is not None:
+        return _FusedTimeGatePair.apply(xs, h0s, X, h0, *gin, *gfo, graph, hzero)
+    gi = _FusedTimeGate.apply(xs, h0s, X, h0, *gin, graph, hzero)
+    gf = _FusedTimeGate.apply(xs, h0s, X, h0, *gfo, graph, hzero)
+    return gi, gf
 
 
 class _FusedCell(torch.autograd.Function):
@@ -1874,8 +1926,7 @@ def fused_cell_train(X, h0, wA, wB, bias, graph, gates=None):
     with torch.no_grad():
         xs, hs_all = fused_pack_inputs_gated(X.contiguous(), h0, graph, wA.shape[0], max(wA.shape[2], wB.shape[2]))
         hzero = fused_h0_zero_flag(h0)
-    gi = _FusedTimeGate.apply(xs, hs_all[:1], X, h0, *gates['in'], graph, hzero)
-    gf = _FusedTimeGate.apply(xs, hs_all[:1], X, h0, *gates['forget'], graph, hzero)
+    gi, gf = fused_train_time_gates(xs, hs_all[:1], X, h0, gates, graph, hzero)
     assert getattr(xs, '_pending_user', None) is None          # (the first pre-pass laid out the rest of X)
     return _FusedCell.apply(X, h0, wA, wB, bias, gi, gf, graph, xs, hs_all)
 

@@ -174,3 +174,47 @@ def test_wide_time_gated_cell_matches_oracle(N, F, G, K, B, T, hz, monkeypatch):
     err = np.abs(H[:nb].double().cpu().numpy() - Href)
     err16 = np.abs(H16[:nb].double().cpu().numpy() - Href)
     assert err.max() <= max(6.0e-3, 2.0 * err16.max()) and err.mean() <= max(1.0e-3, 1.5 * err16.mean()), (err.max(), err.mean(), err16.max(), err16.mean())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('N,F,G,K,B,T', [(1000, 64, 64, 5, 4, 3), (400, 32, 32, 3, 6, 4)])
+def test_wide_gate_pair_training_matches_the_per_gate_path(N, F, G, K, B, T, monkeypatch):
+    """Time-gated TRAINING step with the gates' pre-pass as ONE launch for the pair (+ the gated recurrence on the wide kernel) against the
+    per-gate path on the 16-feature kernels (pinned to the reference's autograd by the G9 fixtures): same gates, same loss, every
+    parameter gradient within bf16 noise -- the pair's stored sub-cell states feed the same BPTT kernels."""
+    import gated_gcrnns_amd.Utils.graphML as gml
+    dev = torch.device('cuda:0')
+    rng = np.random.default_rng(13)
+    W = (rng.random((N, N)) < 10.0 / N).astype(np.float64)
+    W = np.triu(W, 1); W = W + W.T
+    S = (W / np.max(np.abs(np.linalg.eigvalsh(W)))).reshape(1, N, N)
+    torch.manual_seed(13)
+    cell = gml.GGCRNNCell(G, F, K, K, torch.tanh, True, None, 1, True)
+    cell.addGSO(torch.tensor(S))
+    with torch.no_grad():
+        cell.MLP_in[0].weight.mul_(8.0)
+        cell.MLP_forget[0].weight.mul_(8.0)
+    cell = cell.float().to(dev)
+    X = torch.tensor(rng.standard_normal((B, T, G, N)), dtype=torch.float32, device=dev).to(torch.bfloat16)
+    h0 = torch.zeros(B, F, N, device=dev, dtype=torch.bfloat16)
+    target = torch.tensor(rng.standard_normal((B, T, F, N)), dtype=torch.float32, device=dev)
+
+    def grads():
+        cell.zero_grad()
+        assert cell._use_fused_training(X, h0)
+        H = cell(X, h0)
+        loss = ((H.float() - target) ** 2).mean()
+        loss.backward()
+        return float(loss), H.detach().clone(), {n: p.grad.clone() for n, p in cell.named_parameters() if p.grad is not None}
+
+    monkeypatch.setenv('GCRNN_SEQ32_MIN_B', '1')
+    l1, H1, g1 = grads()
+    monkeypatch.setenv('GCRNN_SEQ32', '0')
+    monkeypatch.setenv('GCRNN_NO_GATE_PAIR', '1')
+    l0, H0, g0 = grads()
+    assert abs(l1 - l0) <= 2e-3 * abs(l0) and float((H1.float() - H0.float()).abs().max()) <= 2.5e-2
+    assert set(g1) == set(g0) and len(g1) >= 11
+    for n in g0:
+        sc = float(g0[n].abs().max())
+        d = float((g1[n] - g0[n]).abs().max())
+        assert sc > 0 and d <= 3e-2 * sc, (n, d / sc)
