@@ -58,10 +58,12 @@ static bool seq32_wanted(int64_t B) {
   if (mb) return B >= (atoi(mb) < 1 ? 1 : atoi(mb));
   const char* off16 = getenv("GCRNN_SEQ_KERNEL");      // (no sequence-resident kernel at all: A/B against the chunk-parallel kernel)
   if (off16 && off16[0] == '0') return false;
-  // one workgroup per sequence: whole rounds of 256 sequences (fused_seq_wanted's cost model with the 16-feature chunk count;
-  // GCRNN_SEQ_MIN_B, the 16-feature kernel's test override, does not move problems onto this one)
+  // one workgroup per sequence against the chunk-parallel kernel's one per (sequence, 16-feature chunk): measured at B = 256, K = 5 a round
+  // of 256 sequences costs this kernel 0.62 x the time of their 1024 chunk items there (1.70 vs 2.75 ms per forward), so it wins as soon
+  // as the batch needs three of the chunk-parallel kernel's rounds: B >= 129 (profiles/r04_small_batches.txt). GCRNN_SEQ_MIN_B, the
+  // 16-feature kernel's test override, does not move problems onto this one.
   const double rounds_seq = (double)((B + 255) / 256), rounds_chunk = (double)((B * 4 + 255) / 256);
-  return rounds_seq * 0.875 * 4 < rounds_chunk;
+  return rounds_seq * 0.62 * 4 < rounds_chunk;
 }
 
 template <int K, int HS, int XS>
