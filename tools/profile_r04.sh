@@ -41,3 +41,12 @@ cat $O/${TAG}_seq32_kernel_pmc.txt $O/${TAG}_seq32_kernel_native_pmc.txt
 rm -rf $O/pmc_seq $O/pmc_nat
 fi
 ls $O | head -60
+# ---- traces that contain ONLY one way of issuing the kernel (back-to-back forwards, as bench.py times them with HIP events): the average of the
+# fused_seq32_kernel row of each CSV is the duration the bench line's roofline.frac / roofline_native_layout.frac rest on
+cd /tmp
+rocprofv3 --kernel-trace --stats -d $O/kt_asissued -- python3 $R/tools/step_kernel_probe.py 256 32 10 > $O/probe_as_issued.log 2>&1
+python3 $R/tools/rocprof_db_stats.py $O/kt_asissued > $O/${TAG}_seq32_as_issued_only_kernel_stats.csv 2>/dev/null
+rocprofv3 --kernel-trace --stats -d $O/kt_native -- python3 $R/tools/step_kernel_probe.py 256 32 10 native > $O/probe_native.log 2>&1
+python3 $R/tools/rocprof_db_stats.py $O/kt_native > $O/${TAG}_seq32_native_only_kernel_stats.csv 2>/dev/null
+rm -rf $O/kt_asissued $O/kt_native
+head -3 $O/${TAG}_seq32_as_issued_only_kernel_stats.csv $O/${TAG}_seq32_native_only_kernel_stats.csv
