@@ -94,6 +94,14 @@ struct Seq32Args {
   const float* gw;                                     // read-out weights of the two gates, [2][N][F] fp32 (node-major)
   float* go;                                           // [items][2 * F/32 * 8] partial dot products per (chunk, wave); chunks 0 .. F/32-1 = input gate
   uint16_t* out1;                                      // (or null, with out0) the forget gate cell's states [items][NP][F]; out0 = the input gate cell's
+  // MODE 2 (BPTT data chain, the adjoint of graphML.py:2420-2423): step i walks t = T-1-i; operand dpre_t = hfirst (step 0) / the previous
+  // step's output, output dpre_{t-1} = out0 + i ostride; epilogue operands of step i (negative strides walk backwards in time):
+  const uint16_t* dh0_; int64_t dhstride;              // upstream gradient dH_{t-1} [B][NP][F] sequence-major
+  const uint16_t* hs0; int64_t hsstride;               // state h_{t-1}
+  const float* gsc0; int64_t gscstride;                // (or null) forget gates gf_t [B] of the time-gated cell
+  float* gpart0; int64_t gpartstride;                  // (or null) [B][F/32 * 8] partials of <h_{t-1}, adjoint chain of dpre_t> (the forget gate's gradient)
+  int final_raw;                                       // != 0: the launch's LAST step stores the raw state gradient (d h0: no upstream term, no tanh') into
+  uint16_t* final_out; const uint16_t* final_h;        // final_out (or null), with final_h (h0, or null) as the state of its partials
   int stagger;                                         // > 0: workgroup i starts ((i / 8) % 8) * stagger shader cycles late (de-synchronises the CUs' memory phases for the whole launch)
 };
 
@@ -136,7 +144,7 @@ struct Seq32Map {
   static constexpr int NPCK = 128;                         // nodes per inline-pack round
   static_assert(16 * RS2 <= BIAS_OFF && FLAG_OFF + 768 <= WOFF, "LDS map");
   static size_t lds_bytes(int64_t entries, bool inline_pack) {
-    const size_t need = (size_t)COL_OFF + (size_t)entries * 32 + GCRNN_HOP_COLUMN_PAD + NP * 4 + (inline_pack ? (size_t)(32 * XS) * NPCK * 2 : 0);
+    const size_t need = (size_t)COL_OFF + (size_t)entries * 32 + GCRNN_HOP_COLUMN_PAD + NP * 4 + (inline_pack ? (size_t)(32 * (XS > 0 ? XS : HS)) * NPCK * 2 : 0);
     return need <= 160 * 1024 ? need : 0;
   }
 };
@@ -148,18 +156,21 @@ struct Seq32Map {
 // MODE 1: the time gates' pre-pass for BOTH gates at once: an item (t, b) is one "sequence" of one step whose cell has 2 F outputs -- chunks
 //         0 .. F/32-1 the input gate's sub-cell, the rest the forget gate's (weights and biases concatenated by the caller) -- so the operand
 //         (x_t, h0) is loaded, and with VAR bit 0 laid out, ONCE per gate pair; epilogue: c = tanh(pre), partial <c, read-out weights>.
+// MODE 2: the BPTT data chain dpre_{t-1} = (gf_t sum_k S^k (dpre_t B_k^T) + dH_{t-1}) (1 - h_{t-1}^2) on the adjoint graph with the transposed
+//         state taps: a state-only operand (XS = 0) that is entirely this launch's own output -- the last chunk handed over in registers,
+//         the first re-read --, the epilogue's operands dH_{t-1}, h_{t-1} requested at the chunk's start; VAR bit 0: lays out dH.
 template <int K, int HS, int XS, int VAR, int MODE = 0, bool GATED = false>
 __global__ __launch_bounds__(STHREADS) void fused_seq32_kernel(const Seq32Args a) {
   constexpr bool PKV = (VAR & 1) != 0, USERV = (VAR & 2) != 0 && MODE == 0;
-  static_assert(MODE == 0 || (MODE == 1 && !GATED), "modes");
+  static_assert(MODE == 0 || ((MODE == 1 || MODE == 2) && !GATED), "modes");
   using M = Seq32Map<K, HS, XS>;
   constexpr int KS = HS + XS;
   constexpr int F = 32 * HS, G = 32 * XS;
   constexpr int NCH = (MODE == 1) ? 2 * HS : HS;  // 32-feature output chunks
   constexpr int PL = M::PL, WOFF = M::WOFF, WB = M::WB, COL_OFF = M::COL_OFF, RS2 = M::RS2;
   constexpr int NPCK = M::NPCK, NRND = NP / NPCK, NH = NCH * (K - 1), RPH = (NRND + NH - 1) / NH;      // pack rounds per step / hops per step / rounds per hop
-  constexpr int PKROWS = G;
-  static_assert(STILES == 8 && GCRNN_HOP_ASM && K >= 2 && XS > 0, "generated hop stream: 8 tiles per wave");
+  constexpr int PKROWS = (MODE == 2) ? F : G;
+  static_assert(STILES == 8 && GCRNN_HOP_ASM && K >= 2 && (MODE == 2 ? XS == 0 : XS > 0), "generated hop stream: 8 tiles per wave; the chain's operand is the state alone");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int entries = a.entries, B = a.B, N = a.N;
 
@@ -232,7 +243,7 @@ __global__ __launch_bounds__(STHREADS) void fused_seq32_kernel(const Seq32Args a
   {
     // (MODE 1 with an all-zero h0: a zero-length descriptor -- the loads return zeros and cost nothing)
     const __amdgpu_buffer_rsrc_t rsrc_h = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(a.hfirst), 0, skip_h ? 0 : (MODE == 1 ? a.hmod : B) * (NP * F * 2), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsrc_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(a.x0), 0, B * (NP * G * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(a.x0), 0, XS > 0 ? B * (NP * G * 2) : 0, 0x00020000);
     const int bh = (MODE == 1) ? __builtin_amdgcn_readfirstlane(b % a.hmod) : b;
     const int ln0 = lane_now(), qo = ln0 >> 4;
     int sw[STILES];
@@ -251,7 +262,15 @@ __global__ __launch_bounds__(STHREADS) void fused_seq32_kernel(const Seq32Args a
   }
 #pragma unroll 1
   for (int step = 0; step < a.nsteps; ++step) {
-    uint16_t* hout = a.out0 ? a.out0 + (int64_t)step * a.ostride : nullptr;
+    const bool fin = (MODE == 2) && a.final_raw && step == a.nsteps - 1;      // (chain: the d h0 step)
+    uint16_t* hout = fin ? a.final_out : (a.out0 ? a.out0 + (int64_t)step * a.ostride : nullptr);
+    [[maybe_unused]] const uint16_t* ep_dh = (MODE == 2 && !fin && a.dh0_) ? a.dh0_ + (int64_t)step * a.dhstride : nullptr;
+    [[maybe_unused]] const uint16_t* ep_h = (MODE == 2) ? (fin ? a.final_h : (a.hs0 ? a.hs0 + (int64_t)step * a.hsstride : nullptr)) : nullptr;
+    [[maybe_unused]] float* gpart = (MODE == 2 && a.gpart0) ? a.gpart0 + (int64_t)step * a.gpartstride : nullptr;
+    [[maybe_unused]] float gsc = 1.f;
+    if constexpr (MODE == 2) {
+      if (a.gsc0) gsc = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, a.gsc0[(int64_t)step * a.gscstride + b])));
+    }
     float gin = 1.f, gfo = 1.f, gratio = 1.f;
     if constexpr (GATED) {      // (wave-uniform: kept in scalar registers -- three vector registers live across the hops are three too many)
       gin = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, a.gi0[(int64_t)step * a.gstride + b])));
@@ -275,7 +294,7 @@ __global__ __launch_bounds__(STHREADS) void fused_seq32_kernel(const Seq32Args a
     [[maybe_unused]] const bool stamp_on = (step == (a.nsteps > 2 ? a.nsteps - 3 : 0)) && b == (int)blockIdx.x;      // a typical step (diagnostic builds)
     GCRNN_STAMP32(0);
     const bool more = step + 1 < a.nsteps;      // the next step's operand is requested at the start of this step's last epilogue
-    const __amdgpu_buffer_rsrc_t rsrc_xn = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(a.x0 + (int64_t)(step + 1) * a.xstride), 0, more ? B * (NP * G * 2) : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_xn = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(XS > 0 ? a.x0 + (int64_t)(step + 1) * a.xstride : nullptr), 0, (more && XS > 0) ? B * (NP * G * 2) : 0, 0x00020000);
 
     f32x4 acc[STILES][2];
     // acc[i][h] += W_tap(c, half h) [h|x]^T for the wave's 8 tiles: one weight fragment feeds 8 independent MFMA chains
@@ -372,6 +391,10 @@ __global__ __launch_bounds__(STHREADS) void fused_seq32_kernel(const Seq32Args a
           rnd = v; tgt = 0;
           return pk_any && v < NRND && nb < B;
         }
+        if constexpr (MODE == 2) {      // step i lays out the upstream gradient step i + 1's epilogue reads (the caller laid out step 0's)
+          rnd = v; tgt = step + 1;
+          return pk_any && v < NRND && tgt < a.nsteps - (a.final_raw ? 1 : 0);
+        }
         v += RPH;
         const int wrap = v >= NRND ? 1 : 0;
         rnd = v - wrap * NRND;
@@ -450,6 +473,22 @@ __global__ __launch_bounds__(STHREADS) void fused_seq32_kernel(const Seq32Args a
                                              (__attribute__((address_space(3))) void*)(smem + WOFF + tap * (2 * KS * 1024) + piece * 1024), 16, 0, 0);
         }
       };
+      // MODE 2: the epilogue's operands h_{t-1}, dH_{t-1} of this lane's (node, 8 features) per tile, requested now: they land while the hops run
+      typedef __attribute__((__vector_size__(4 * sizeof(unsigned int)))) unsigned int u32x4e_t;
+      [[maybe_unused]] u32x4e_t eph[MODE == 2 ? STILES : 1], epg[MODE == 2 ? STILES : 1];
+      if constexpr (MODE == 2) {
+        const int lq = lane_now();
+        int swp[STILES];
+        slot_words(lq, swp);
+        const __amdgpu_buffer_rsrc_t rsrc_eh = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(ep_h), 0, ep_h ? B * (NP * F * 2) : 0, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsrc_eg = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(ep_dh), 0, ep_dh ? B * (NP * F * 2) : 0, 0x00020000);
+#pragma unroll
+        for (int i = 0; i < STILES; ++i) {
+          const int eoff = (swp[i] >> 16) * (F * 2) + (chunk * 32 + (lq >> 4) * 8) * 2;
+          eph[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_eh, eoff, b * (NP * F * 2), 0);
+          epg[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_eg, eoff, b * (NP * F * 2), 0);
+        }
+      }
       // ---- Horner hops on the two-plane bf16 image; the tap a hop adds accumulates onto its sums --------------------------------
       auto hop = [&](auto jc) __attribute__((always_inline)) {
         constexpr int j = decltype(jc)::value;
@@ -509,7 +548,7 @@ __global__ __launch_bounds__(STHREADS) void fused_seq32_kernel(const Seq32Args a
       typedef __attribute__((__vector_size__(4 * sizeof(unsigned int)))) unsigned int u32x4_t;
       const int lane = lane_now(), q = lane >> 4, tl = wave * 64 + lane;
       auto request_next_operand = [&]() {
-        if (MODE != 0 || !(last && more)) return;
+        if (MODE == 1 || !(last && more)) return;
         // the next step's operand: x_{t+1} (laid out two steps ahead, or by the caller) and the state features of the earlier chunks
         // (stored -- and waited for -- at their chunk's end); the last chunk's come from this epilogue's registers below
         const int qo = lane_now() >> 4;
@@ -580,6 +619,41 @@ __global__ __launch_bounds__(STHREADS) void fused_seq32_kernel(const Seq32Args a
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) part += __shfl_down(part, off, 64);
         if (lane == 0) a.go[(int64_t)b * (NCH * SWAVES) + chunk * SWAVES + wave] = part;
+      } else if constexpr (MODE == 2) {
+        // BPTT data step: the hops applied sum_k (S)^k (dpre_t B_k^T) = d h_{t-1} (recurrent part, scaled by the forget gate of the step it came
+        // through); add the upstream gradient and go through tanh': dpre_{t-1} = (gsc acc + dH_{t-1}) (1 - h_{t-1}^2); without dH the raw state
+        // gradient is stored (d h0). gpart: <h_{t-1}, acc> = <B(S) h_{t-1}, dpre_t> by the adjoint identity (the forget gate's gradient).
+        float part = 0.f;
+#pragma unroll
+        for (int i = 0; i < STILES; ++i) {
+          const int node = swe[i] >> 16;
+          float hv[8], gv[8], rw[8];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            hv[2 * e] = bf2f((uint16_t)(eph[i][e] & 0xffffu)); hv[2 * e + 1] = bf2f((uint16_t)(eph[i][e] >> 16));
+            gv[2 * e] = bf2f((uint16_t)(epg[i][e] & 0xffffu)); gv[2 * e + 1] = bf2f((uint16_t)(epg[i][e] >> 16));
+            rw[e] = acc[i][0][e]; rw[4 + e] = acc[i][1][e];
+          }
+          if (gpart) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) part = __builtin_fmaf(rw[e], hv[e], part);      // (explicit chain; rows >= N of h are zero)
+          }
+          float o[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            o[e] = rw[e] * gsc;
+            if (ep_dh) o[e] = (o[e] + gv[e]) * (1.f - hv[e] * hv[e]);
+          }
+          u32x4_t p{0u, 0u, 0u, 0u};
+          if (node < N) { p[0] = pack2bf(o[0], o[1]); p[1] = pack2bf(o[2], o[3]); p[2] = pack2bf(o[4], o[5]); p[3] = pack2bf(o[6], o[7]); }
+          pkd[i] = p;
+          __builtin_amdgcn_raw_buffer_store_b128(p, rsrc_o, node * (F * 2) + (chunk * 32 + q * 8) * 2, b * (NP * F * 2), 0);      // (dropped when there is no output array)
+        }
+        if (gpart) {
+#pragma unroll
+          for (int off = 32; off > 0; off >>= 1) part += __shfl_down(part, off, 64);
+          if (lane == 0) gpart[(int64_t)b * (NCH * SWAVES) + chunk * SWAVES + wave] = part;
+        }
       } else {
 #pragma unroll
       for (int i = 0; i < STILES; ++i) {
@@ -598,7 +672,7 @@ __global__ __launch_bounds__(STHREADS) void fused_seq32_kernel(const Seq32Args a
       }
       }
       GCRNN_STAMP32(1 + chunk * 24 + 17);
-      if (MODE == 0 && last) {
+      if (MODE != 1 && last) {
         // h_t's last 32 features ARE the lanes' B fragments of k-step HS-1: handed to the next step in registers
 #pragma unroll
         for (int i = 0; i < STILES; ++i) bfr[i][HS - 1] = __builtin_bit_cast(bf16x8, pkd[i]);

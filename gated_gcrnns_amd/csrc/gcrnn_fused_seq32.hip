@@ -69,6 +69,14 @@ static bool seq32_wanted(int64_t B) {
 template <int K, int HS, int XS>
 static size_t seq32_lds(int64_t entries, bool inline_pack) { return Seq32Map<K, HS, XS>::lds_bytes(entries, inline_pack); }
 
+static size_t seq32_lds_chain(int64_t F, int64_t K, int64_t entries, bool inline_pack) {
+#define GCRNN_SEQ32_CASE(KK, HH) if (K == KK && F == 32 * HH) return seq32_lds<KK, HH, 0>(entries, inline_pack);
+  GCRNN_SEQ32_CASE(5, 2) GCRNN_SEQ32_CASE(4, 2) GCRNN_SEQ32_CASE(3, 2) GCRNN_SEQ32_CASE(2, 2)
+  GCRNN_SEQ32_CASE(5, 1) GCRNN_SEQ32_CASE(4, 1) GCRNN_SEQ32_CASE(3, 1) GCRNN_SEQ32_CASE(2, 1)
+#undef GCRNN_SEQ32_CASE
+  return 0;
+}
+
 static size_t seq32_lds_for(int64_t F, int64_t G, int64_t K, int64_t entries, bool inline_pack) {
 #define GCRNN_SEQ32_CASE(KK, HH, XX) if (K == KK && F == 32 * HH && G == 32 * XX) return seq32_lds<KK, HH, XX>(entries, inline_pack);
   GCRNN_SEQ32_CASE(5, 2, 2) GCRNN_SEQ32_CASE(4, 2, 2) GCRNN_SEQ32_CASE(3, 2, 2) GCRNN_SEQ32_CASE(2, 2, 2)
@@ -221,6 +229,85 @@ extern "C" int gcrnn_fused_gate_pair_prepass_wide_bf16(const void* x_user, void*
   GCRNN_SEQ32_CASE(5, 2, 2) GCRNN_SEQ32_CASE(4, 2, 2) GCRNN_SEQ32_CASE(3, 2, 2) GCRNN_SEQ32_CASE(2, 2, 2)
   GCRNN_SEQ32_CASE(5, 2, 1) GCRNN_SEQ32_CASE(4, 2, 1) GCRNN_SEQ32_CASE(3, 2, 1) GCRNN_SEQ32_CASE(2, 2, 1)
   GCRNN_SEQ32_CASE(5, 1, 1) GCRNN_SEQ32_CASE(4, 1, 1) GCRNN_SEQ32_CASE(3, 1, 1) GCRNN_SEQ32_CASE(2, 1, 1)
+#undef GCRNN_SEQ32_CASE
+  return GCRNN_ERR_UNSUPPORTED;
+}
+
+
+// dpre = dH (1 - h^2) on bf16 arrays: the seed of the chain (t = T-1)
+__global__ void seq32_seed_kernel(const uint16_t* __restrict__ dH, const uint16_t* __restrict__ h, uint16_t* __restrict__ out, int64_t n) {
+  const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 2;
+  if (i >= n) return;
+  const uint32_t g = *reinterpret_cast<const uint32_t*>(dH + i), hv = *reinterpret_cast<const uint32_t*>(h + i);
+  const float g0 = bf2f((uint16_t)(g & 0xffffu)), g1 = bf2f((uint16_t)(g >> 16));
+  const float h0 = bf2f((uint16_t)(hv & 0xffffu)), h1 = bf2f((uint16_t)(hv >> 16));
+  *reinterpret_cast<uint32_t*>(out + i) = pack2bf(g0 * (1.f - h0 * h0), g1 * (1.f - h1 * h1));
+}
+
+template <int K, int HS>
+static int seq32_launch_chain(const Seq32Args& sa, bool inline_pack, hipStream_t st) {
+  const size_t lds = seq32_lds<K, HS, 0>(sa.entries, inline_pack);
+  if (!lds) return GCRNN_ERR_UNSUPPORTED;
+  return inline_pack ? seq32_launch_v<K, HS, 0, 1, 2>(sa, lds, st) : seq32_launch_v<K, HS, 0, 0, 2>(sa, lds, st);
+}
+
+// 1 when gcrnn_fused_backward_data_wide_bf16 takes the problem (uniform-weight bf16-image plan of the ADJOINT graph, a batch that fills whole
+// rounds of the chip, LDS room; inline_pack: with dHuser_inline)
+extern "C" int gcrnn_fused_backward_data_wide_supported(int64_t B, int64_t T, int64_t N, int64_t F, int64_t K, int64_t entries, double uniform_w,
+                                                        int img16, int inline_pack) {
+  if (uniform_w == 0.0 || !img16 || N <= 0 || N > NP || B <= 0 || T <= 0 || entries <= 0 || entries % 4) return 0;
+  if (inline_pack && (N % 8 || T * F * N > 2147483647LL)) return 0;
+  if (B * (NP * F * 2) > 2147483647LL) return 0;
+  if (!seq32_wanted(B)) return 0;
+  return seq32_lds_chain(F, K, entries, inline_pack != 0) ? 1 : 0;
+}
+
+// BPTT data gradient of the fused cell as ONE launch of the wide sequence-resident kernel (the adjoint of Utils/graphML.py:2420-2423; contract
+// of gcrnn_fused_backward_data_bf16): dpre[T-1] = dHs[T-1] (1 - hs[T-1]^2); for t = T-1 .. 1: dpre[t-1] = (gf[t] sum_k (S)^k (dpre[t] B_k) +
+// dHs[t-1]) (1 - hs[t-1]^2); dh0 = gf[0] sum_k (S)^k (dpre[0] B_k) (optional). wpackT = gcrnn_fused_pack_weights_wide of the TRANSPOSED state taps
+// (G = 0, uniform_w of the adjoint plan); tile_nodes / tile_off / ell_col4: the bf16-image plan of the ADJOINT graph. dgf_parts (or NULL; needs
+// h0s): [T][B][F/32*8] fp32 partials of <h_{t-1}, adjoint chain of dpre[t]>. dHuser_inline (or NULL): dH [B][T][F][N] bf16 in the user layout
+// -- the caller has laid out dHs[T-1] and dHs[T-2], the launch lays out the rest.
+extern "C" int gcrnn_fused_backward_data_wide_bf16(const void* dHs, const void* hs, void* dpre, void* dh0, const void* wpackT,
+                                                   const int32_t* tile_nodes, const int32_t* tile_off, const void* ell_col4, int64_t entries,
+                                                   int64_t B, int64_t T, int64_t N, int64_t F, int64_t K, const float* gf, const void* h0s,
+                                                   float* dgf_parts, const void* dHuser_inline, void* stream) {
+  if (dgf_parts && !h0s) return GCRNN_ERR_NULL_POINTER;
+  if (dHuser_inline && (N % 8 != 0 || (reinterpret_cast<uintptr_t>(dHuser_inline) & 15) || T * F * N > 2147483647LL)) return GCRNN_ERR_BAD_SHAPE;
+  if (!dHs || !hs || !dpre || !wpackT || !tile_nodes || !tile_off || !ell_col4) return GCRNN_ERR_NULL_POINTER;
+  if (B <= 0 || T <= 0 || N <= 0 || N > NP || B > (1 << 24) || entries <= 0 || entries % 4) return GCRNN_ERR_BAD_SHAPE;
+  if (B * (NP * F * 2) > 2147483647LL) return GCRNN_ERR_BAD_SHAPE;
+  const int64_t hstep = B * NP * F;
+  hipStream_t st = as_stream(stream);
+  GCRNN_PRE_LAUNCH();
+  seq32_seed_kernel<<<(unsigned)cdiv(hstep / 2, 256), 256, 0, st>>>((const uint16_t*)dHs + (T - 1) * hstep, (const uint16_t*)hs + (T - 1) * hstep,
+                                                                 (uint16_t*)dpre + (T - 1) * hstep, hstep);
+  GCRNN_CHECK_LAUNCH();
+  const bool fin = dh0 != nullptr || dgf_parts != nullptr;
+  if (T < 2 && !fin) return GCRNN_OK;
+  const int nch = (int)(F / 32);
+  const int64_t gstep = B * (nch * SWAVES);
+  Seq32Args sa{};
+  sa.hfirst = (const uint16_t*)dpre + (T - 1) * hstep;
+  sa.out0 = (uint16_t*)dpre + (T - 2) * hstep; sa.ostride = -hstep;
+  sa.dh0_ = (const uint16_t*)dHs + (T - 2) * hstep; sa.dhstride = -hstep;
+  sa.hs0 = (const uint16_t*)hs + (T - 2) * hstep; sa.hsstride = -hstep;
+  sa.gsc0 = gf ? gf + (T - 1) * B : nullptr; sa.gscstride = -B;
+  sa.gpart0 = dgf_parts ? dgf_parts + (T - 1) * gstep : nullptr; sa.gpartstride = -gstep;
+  sa.final_raw = fin ? 1 : 0; sa.final_out = (uint16_t*)dh0; sa.final_h = dgf_parts ? (const uint16_t*)h0s : nullptr;
+  sa.wpack = (const uint4*)wpackT;
+  sa.tile_nodes = tile_nodes; sa.tile_off = tile_off; sa.ell_col4 = (const uint2*)ell_col4;
+  sa.entries = (int)entries; sa.B = (int)B; sa.N = (int)N;
+  sa.nsteps = (int)(T - 1) + (fin ? 1 : 0);
+  const bool inline_pack = dHuser_inline != nullptr && T > 2;
+  if (inline_pack) {      // chain step i reads dHs[T-2-i]: step 0's is the caller's, step i lays out step i + 1's
+    sa.pk_src0 = (const uint16_t*)dHuser_inline + (T - 2) * F * N; sa.pksrc_stride = -(F * N);
+    sa.pk_dst0 = const_cast<uint16_t*>((const uint16_t*)dHs) + (T - 2) * hstep; sa.pkdst_stride = -hstep;
+    sa.pk_stride = (int)(T * F * N);
+  }
+#define GCRNN_SEQ32_CASE(KK, HH) if (K == KK && F == 32 * HH) return seq32_launch_chain<KK, HH>(sa, inline_pack, st);
+  GCRNN_SEQ32_CASE(5, 2) GCRNN_SEQ32_CASE(4, 2) GCRNN_SEQ32_CASE(3, 2) GCRNN_SEQ32_CASE(2, 2)
+  GCRNN_SEQ32_CASE(5, 1) GCRNN_SEQ32_CASE(4, 1) GCRNN_SEQ32_CASE(3, 1) GCRNN_SEQ32_CASE(2, 1)
 #undef GCRNN_SEQ32_CASE
   return GCRNN_ERR_UNSUPPORTED;
 }

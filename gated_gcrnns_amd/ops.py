@@ -420,7 +420,9 @@ def _fused_pack_weights_wide(wA, wB, uniform_w, st):
     K = max(Kin, Kst)
     wpack = torch.empty(((Fout // 32) * K * 2 * ((F + G) // 32) * 64 * 8,), dtype=torch.bfloat16, device=wA.device)
     wAc, wBc = wA.contiguous(), wB.contiguous()
-    check(lib.gcrnn_fused_pack_weights_wide(dtype_code(wA.dtype), _p(wAc), _p(wBc), _p(wpack), Fout, F, G, Kin, Kst, float(uniform_w), st),
+    if G == 0:                                   # state-only operand (the BPTT chain's transposed taps): no input taps to read
+        wAc, Kin = wBc, Kst
+    check(lib.gcrnn_fused_pack_weights_wide(dtype_code(wB.dtype), _p(wAc), _p(wBc), _p(wpack), Fout, F, G, Kin, Kst, float(uniform_w), st),
           'pack_weights_wide')
     return wpack
 
@@ -1652,14 +1654,28 @@ def fused_backward_data(dHs, hs, wB, graph, want_dh0=True, gf=None, h0s=None, bi
     plan = graph.fused_plan(adjoint=True)
     st = _stream()
     wBt = wB.detach()[:, 0].permute(2, 1, 0).contiguous().unsqueeze(1)      # [F_in][1][K][F_out]: transposed taps
-    wpack = _fused_pack_state_taps(wBt, K, st)
     dpre = torch.empty((T, B, npad, F), dtype=torch.bfloat16, device=hs.device)
     dh0 = torch.empty((B, npad, F), dtype=torch.bfloat16, device=hs.device) if want_dh0 else None
+    import os
+    plan16 = None if os.environ.get('GCRNN_NO_IMG16') else graph.fused_plan_img16(adjoint=True)      # bf16 hop image, matrix-core sums (uniform graphs)
+    if plan16 is not None and F % 32 == 0 and not os.environ.get('GCRNN_NO_WIDE_CHAIN') and lib.gcrnn_fused_backward_data_wide_supported(
+            B, T, graph.N, F, K, int(plan16['entries']), float(plan16.get('uniform_w', 0.0)), 1, 1 if dH_user is not None else 0):
+        # the whole chain (seed, T - 1 steps, d h0 / the forget gate's step 0) as ONE launch of the wide sequence-resident kernel
+        wpw = _fused_pack_weights_wide(wBt.new_zeros((F, 1, K, 0)), wBt, plan16['uniform_w'], st)
+        parts = torch.empty((T * B, (F // 32) * int(lib.gcrnn_fused_step_waves())), dtype=torch.float32, device=hs.device) if h0s is not None else None
+        check(lib.gcrnn_fused_backward_data_wide_bf16(_p(dHs), _p(hs), _p(dpre), _p(dh0), _p(wpw), _p(plan16['tile_slots']), _p(plan16['tile_off']),
+                                                      _p(plan16['ell_col4']), plan16['entries'], B, T, graph.N, F, K, _p(gf), _p(h0s), _p(parts),
+                                                      _p(dH_user), st), 'fused_backward_data_wide')
+        if h0s is None:
+            return dpre, dh0
+        dgf = parts.sum(dim=1).view(T, B)
+        if bias is not None:
+            dgf = dgf + dpre.sum(dim=2, dtype=torch.float32) @ bias.detach().float().view(-1)
+        return dpre, dh0, dgf
+    wpack = _fused_pack_state_taps(wBt, K, st)
     parts = None
     if h0s is not None:
         parts = torch.empty((T * B, (F // 16) * int(lib.gcrnn_fused_step_waves())), dtype=torch.float32, device=hs.device)
-    import os
-    plan16 = None if os.environ.get('GCRNN_NO_IMG16') else graph.fused_plan_img16(adjoint=True)      # bf16 hop image, matrix-core sums (uniform graphs)
     check(lib.gcrnn_fused_backward_data_bf16(_p(dHs), _p(hs), _p(dpre), _p(dh0), _p(wpack), *_fused_graph_args(plan16 or plan),
                                              B, T, graph.N, F, K, _p(gf), _p(h0s), _p(parts), plan.get('uniform_w', 0.0), _p(dH_user),
                                              1 if plan16 else 0, st),

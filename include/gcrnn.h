@@ -389,6 +389,14 @@ int gcrnn_fused_forward_wide_bf16(const void* xs, const void* h0, void* hs, cons
                                   const void* Xuser_inline, void* stream);
 int gcrnn_fused_gate_pair_wide_supported(int64_t B, int64_t T, int64_t N, int64_t F, int64_t G, int64_t K, int64_t entries, double uniform_w,
                                          int img16, int with_pack);
+/* The BPTT data chain as ONE launch of the wide kernel: gcrnn_fused_backward_data_bf16's contract (seed included), with wpackT =
+ * gcrnn_fused_pack_weights_wide of the transposed state taps (G = 0), the bf16-image plan of the ADJOINT graph, dgf_parts [T][B][F/32*8]. */
+int gcrnn_fused_backward_data_wide_supported(int64_t B, int64_t T, int64_t N, int64_t F, int64_t K, int64_t entries, double uniform_w, int img16,
+                                             int inline_pack);
+int gcrnn_fused_backward_data_wide_bf16(const void* dHs, const void* hs, void* dpre, void* dh0, const void* wpackT, const int32_t* tile_nodes,
+                                        const int32_t* tile_off, const void* ell_col4, int64_t entries, int64_t B, int64_t T, int64_t N,
+                                        int64_t F, int64_t K, const float* gf, const void* h0s, float* dgf_parts, const void* dHuser_inline,
+                                        void* stream);
 int gcrnn_fused_gate_pair_prepass_wide_bf16(const void* x_user, void* xs, const void* h0, const void* wpack, const float* bias2,
                                             const float* gw2, float* parts, void* cs_in, void* cs_f, const int32_t* tile_nodes,
                                             const int32_t* tile_off, const void* ell_col4, int64_t entries, int64_t B, int64_t T, int64_t N,

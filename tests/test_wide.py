@@ -219,3 +219,49 @@ def test_wide_gate_pair_training_matches_the_per_gate_path(N, F, G, K, B, T, hz,
         sc = float(g0[n].abs().max())
         d = float((g1[n] - g0[n]).abs().max())
         assert d <= 3e-2 * sc, (n, d, sc)      # (sc == 0: the gates' state taps with an all-zero h0 -- both paths give exactly zero)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('N,F,K,B,T,gated', [(1000, 64, 5, 4, 5, False), (1000, 64, 5, 3, 4, True), (400, 32, 3, 6, 4, True), (1000, 64, 2, 2, 3, False),
+                                             (1000, 64, 4, 3, 1, True), (1008, 64, 5, 130, 3, False)])
+def test_wide_bptt_chain_matches_the_16_feature_chain(N, F, K, B, T, gated, monkeypatch):
+    """The BPTT data chain as ONE launch of the wide kernel (MODE 2: state-only operand handed from step to step in registers / re-read from
+    its own stores, epilogue operands requested at the chunk's start, d h0 and the forget gate's partials as the launch's last step) against
+    the 16-feature chain (pinned to the reference's autograd by the G9 / G11 fixtures): dpre of every step, d h0 and d gf within bf16
+    noise, with and without the inline layout of dH (the user-layout upstream gradient)."""
+    import gated_gcrnns_amd.Utils.graphML as gml
+    from gated_gcrnns_amd import ops
+    dev = torch.device('cuda:0')
+    cell, rng, S = _uniform_cell(N, F, F, K, 29)
+    cell = cell.to(dev)
+    dH = torch.tensor(rng.standard_normal((B, T, F, N)), dtype=torch.float32, device=dev).to(torch.bfloat16)
+    H = torch.tanh(torch.tensor(rng.standard_normal((B, T, F, N)), dtype=torch.float32, device=dev)).to(torch.bfloat16)
+    h0 = torch.tensor(0.3 * rng.standard_normal((B, F, N)), dtype=torch.float32, device=dev).to(torch.bfloat16)
+    gf = torch.tensor(rng.uniform(0.2, 0.9, (T, B)), dtype=torch.float32, device=dev) if gated else None
+    hs = ops.to_sequence_major(H, cell.graph)
+    h0s = ops.to_sequence_major(h0.view(B, 1, F, N), cell.graph)
+    wB = cell.weight_B.detach().float()
+
+    def run():
+        dHs, dHu = ops.fused_pack_upstream(dH, cell.graph, K)
+        if gated:
+            return ops.fused_backward_data(dHs, hs, wB, cell.graph, want_dh0=True, gf=gf, h0s=h0s, bias=cell.bias.detach().float(), dH_user=dHu)
+        return ops.fused_backward_data(dHs, hs, wB, cell.graph, want_dh0=True, dH_user=dHu)
+
+    monkeypatch.setenv('GCRNN_SEQ32_MIN_B', '1')
+    from gated_gcrnns_amd import _lib
+    p16 = cell.graph.fused_plan_img16(adjoint=True)
+    assert _lib.lib.gcrnn_fused_backward_data_wide_supported(B, T, N, F, K, int(p16['entries']), float(p16['uniform_w']), 1, 0) == 1
+    got = run()
+    monkeypatch.setenv('GCRNN_NO_INLINE_PACK', '1')
+    got2 = run()
+    monkeypatch.delenv('GCRNN_NO_INLINE_PACK')
+    monkeypatch.setenv('GCRNN_NO_WIDE_CHAIN', '1')
+    monkeypatch.setenv('GCRNN_SEQ_MIN_B', '1')
+    want = run()
+    assert len(got) == len(want)
+    for a_, b_, c_ in zip(got, got2, want):
+        assert torch.equal(a_, b_)                       # the inline layout of dH changes no bit
+        sc = float(c_.float().abs().max())
+        d = (a_.float() - c_.float()).abs()
+        assert float(d.max()) <= 2.5e-2 * sc and float(d.mean()) <= 2e-3 * sc, (float(d.max()) / sc, float(d.mean()) / sc)
