@@ -102,6 +102,7 @@ struct Seq32Args {
   float* gpart0; int64_t gpartstride;                  // (or null) [B][F/32 * 8] partials of <h_{t-1}, adjoint chain of dpre_t> (the forget gate's gradient)
   int final_raw;                                       // != 0: the launch's LAST step stores the raw state gradient (d h0: no upstream term, no tanh') into
   uint16_t* final_out; const uint16_t* final_h;        // final_out (or null), with final_h (h0, or null) as the state of its partials
+  const float* r1a; const float* r1b;                  // R1 (rank-1-weighted graph S[m][n] = a[m] b[n], plan of its 0/1 pattern): the factors [NP] fp32, zero for padding rows
   int stagger;                                         // > 0: workgroup i starts ((i / 8) % 8) * stagger shader cycles late (de-synchronises the CUs' memory phases for the whole launch)
 };
 
@@ -143,8 +144,8 @@ struct Seq32Map {
   static constexpr int COL_OFF = WOFF + WB;
   static constexpr int NPCK = 128;                         // nodes per inline-pack round
   static_assert(16 * RS2 <= BIAS_OFF && FLAG_OFF + 768 <= WOFF, "LDS map");
-  static size_t lds_bytes(int64_t entries, bool inline_pack) {
-    const size_t need = (size_t)COL_OFF + (size_t)entries * 32 + GCRNN_HOP_COLUMN_PAD + NP * 4 + (inline_pack ? (size_t)(32 * (XS > 0 ? XS : HS)) * NPCK * 2 : 0);
+  static size_t lds_bytes(int64_t entries, bool inline_pack, bool r1 = false) {
+    const size_t need = (size_t)COL_OFF + (size_t)entries * 32 + GCRNN_HOP_COLUMN_PAD + NP * 4 + (r1 ? 2 * NP * 4 : 0) + (inline_pack ? (size_t)(32 * (XS > 0 ? XS : HS)) * NPCK * 2 : 0);
     return need <= 160 * 1024 ? need : 0;
   }
 };
@@ -159,8 +160,12 @@ struct Seq32Map {
 // MODE 2: the BPTT data chain dpre_{t-1} = (gf_t sum_k S^k (dpre_t B_k^T) + dH_{t-1}) (1 - h_{t-1}^2) on the adjoint graph with the transposed
 //         state taps: a state-only operand (XS = 0) that is entirely this launch's own output -- the last chunk handed over in registers,
 //         the first re-read --, the epilogue's operands dH_{t-1}, h_{t-1} requested at the chunk's start; VAR bit 0: lays out dH.
-template <int K, int HS, int XS, int VAR, int MODE = 0, bool GATED = false>
+// R1: rank-1-weighted graph S[m][n] = a[m] b[n] (normalised adjacencies: graph.fused_plan_rank1) on the plan of its 0/1 pattern: a hop is
+//     b[n] sum_{m in N(n)} (a[m] v[m]) -- every image write is scaled by a (seed and hop outputs), a hop's sums by b BEFORE its tap is added
+//     (so every wave streams first), the taps carry no w^k (uniform_w = 1).
+template <int K, int HS, int XS, int VAR, int MODE = 0, bool GATED = false, bool R1 = false>
 __global__ __launch_bounds__(STHREADS) void fused_seq32_kernel(const Seq32Args a) {
+  static_assert(!R1 || (MODE == 0 && !GATED), "rank-1 graphs: the un-gated forward");
   constexpr bool PKV = (VAR & 1) != 0, USERV = (VAR & 2) != 0 && MODE == 0;
   static_assert(MODE == 0 || ((MODE == 1 || MODE == 2) && !GATED), "modes");
   using M = Seq32Map<K, HS, XS>;
@@ -190,6 +195,10 @@ __global__ __launch_bounds__(STHREADS) void fused_seq32_kernel(const Seq32Args a
   // live registers would not survive the hops: operand 128 + accumulators 64 + the stream's window)
   char* wtab = smem + COL_OFF + entries * 32 + GCRNN_HOP_COLUMN_PAD;
   for (int idx = tid; idx < NP; idx += STHREADS) reinterpret_cast<int32_t*>(wtab)[idx] = a.tile_nodes[idx];
+  [[maybe_unused]] float* r1tab = reinterpret_cast<float*>(wtab + NP * 4);      // R1: a[NP] then b[NP]
+  if constexpr (R1) {
+    for (int idx = tid; idx < NP; idx += STHREADS) { r1tab[idx] = a.r1a[idx]; r1tab[NP + idx] = a.r1b[idx]; }
+  }
   // (one asm statement: eight reads in flight, one wait; volatile so that the words are re-read at every use, not kept)
   auto slot_words = [&](int ln, int (&w)[STILES]) {
     const uint32_t ad = (uint32_t)(COL_OFF + entries * 32 + GCRNN_HOP_COLUMN_PAD) + (uint32_t)((wave * STILES * 16 + (ln & 15)) * 4);
@@ -232,7 +241,7 @@ __global__ __launch_bounds__(STHREADS) void fused_seq32_kernel(const Seq32Args a
   const uint32_t lds0 = (uint32_t)reinterpret_cast<uintptr_t>(smem);
   if (lds0 != 0) __builtin_trap();        // the asm stream forms gather addresses from column words: the image must sit at LDS address 0
   const uint32_t lds_col = lds0 + COL_OFF;
-  char* xtile = wtab + NP * 4;
+  char* xtile = wtab + NP * 4 + (R1 ? 2 * NP * 4 : 0);
 
   // wave-uniform, as a scalar integer (a lane mask would also be parked in a vector register)
   const int skip_hi = __builtin_amdgcn_readfirstlane((MODE == 1 && a.flags && a.flags[0] != 0) ? 1 : 0);
@@ -364,8 +373,14 @@ __global__ __launch_bounds__(STHREADS) void fused_seq32_kernel(const Seq32Args a
 #pragma unroll
       for (int i = 0; i < STILES; ++i) {
         const int wv = sw[i];
-        state_put<true>(reinterpret_cast<float*>(smem), wv, acc[i][0]);
-        state_put<true>(reinterpret_cast<float*>(smem + PL), wv, acc[i][1]);
+        if constexpr (R1) {      // the image holds a (.) v
+          const float av = r1tab[wv >> 16];
+          state_put<true>(reinterpret_cast<float*>(smem), wv, acc[i][0] * av);
+          state_put<true>(reinterpret_cast<float*>(smem + PL), wv, acc[i][1] * av);
+        } else {
+          state_put<true>(reinterpret_cast<float*>(smem), wv, acc[i][0]);
+          state_put<true>(reinterpret_cast<float*>(smem + PL), wv, acc[i][1]);
+        }
       }
     };
     // seed of a chunk: tap K-1 goes straight into the hop image (every wave has left the image: the barrier before)
@@ -509,9 +524,18 @@ __global__ __launch_bounds__(STHREADS) void fused_seq32_kernel(const Seq32Args a
         for (int i = 0; i < STILES; ++i) { acc[i][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[i][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
         // (the pack's LDS-DMA pieces go out right before the wave's stream: hipcc orders every later LDS read of the wave behind them with a
         //  vmcnt(0) -- behind the stream that wait is free, in front of the tap's weight reads it would expose the pieces' whole latency)
-        if (!GATED && (wave < SWAVES / 2 || GCRNN_SEQ32_SAME_ORDER)) {
+        if (!GATED && (R1 || wave < SWAVES / 2 || GCRNN_SEQ32_SAME_ORDER)) {
           dma_issue();
           GCRNN_HOP_ASM_WIDE32_STREAM(acc);
+          if constexpr (R1) {      // sums of a (.) v over the in-neighbours, times b[n]: then the tap
+            int swb[STILES];
+            slot_words(lane_now(), swb);
+#pragma unroll
+            for (int i = 0; i < STILES; ++i) {
+              const float bv = r1tab[NP + (swb[i] >> 16)];
+              acc[i][0] *= bv; acc[i][1] *= bv;
+            }
+          }
           GCRNN_STAMP32(1 + chunk * 24 + 4 * (j - 1) + 1);
           if (j == 2 && chunk == 0) GCRNN_STAMP32_WAVE(56);
           taps(K - 1 - j);

@@ -67,7 +67,7 @@ static bool seq32_wanted(int64_t B) {
 }
 
 template <int K, int HS, int XS>
-static size_t seq32_lds(int64_t entries, bool inline_pack) { return Seq32Map<K, HS, XS>::lds_bytes(entries, inline_pack); }
+static size_t seq32_lds(int64_t entries, bool inline_pack, bool r1 = false) { return Seq32Map<K, HS, XS>::lds_bytes(entries, inline_pack, r1); }
 
 static size_t seq32_lds_chain(int64_t F, int64_t K, int64_t entries, bool inline_pack) {
 #define GCRNN_SEQ32_CASE(KK, HH) if (K == KK && F == 32 * HH) return seq32_lds<KK, HH, 0>(entries, inline_pack);
@@ -77,8 +77,8 @@ static size_t seq32_lds_chain(int64_t F, int64_t K, int64_t entries, bool inline
   return 0;
 }
 
-static size_t seq32_lds_for(int64_t F, int64_t G, int64_t K, int64_t entries, bool inline_pack) {
-#define GCRNN_SEQ32_CASE(KK, HH, XX) if (K == KK && F == 32 * HH && G == 32 * XX) return seq32_lds<KK, HH, XX>(entries, inline_pack);
+static size_t seq32_lds_for(int64_t F, int64_t G, int64_t K, int64_t entries, bool inline_pack, bool r1 = false) {
+#define GCRNN_SEQ32_CASE(KK, HH, XX) if (K == KK && F == 32 * HH && G == 32 * XX) return seq32_lds<KK, HH, XX>(entries, inline_pack, r1);
   GCRNN_SEQ32_CASE(5, 2, 2) GCRNN_SEQ32_CASE(4, 2, 2) GCRNN_SEQ32_CASE(3, 2, 2) GCRNN_SEQ32_CASE(2, 2, 2)
   GCRNN_SEQ32_CASE(5, 2, 1) GCRNN_SEQ32_CASE(4, 2, 1) GCRNN_SEQ32_CASE(3, 2, 1) GCRNN_SEQ32_CASE(2, 2, 1)
   GCRNN_SEQ32_CASE(5, 1, 1) GCRNN_SEQ32_CASE(4, 1, 1) GCRNN_SEQ32_CASE(3, 1, 1) GCRNN_SEQ32_CASE(2, 1, 1)
@@ -89,17 +89,17 @@ static size_t seq32_lds_for(int64_t F, int64_t G, int64_t K, int64_t entries, bo
 // 1 when gcrnn_fused_forward_wide_bf16 takes this problem (un-gated cell, uniform-weight bf16-image plan, a batch that fills whole rounds
 // of the chip, LDS room); inline_pack: with the layout of X inside the launch (N % 8 == 0, T > 2: the caller lays out x_0 and x_1)
 extern "C" int gcrnn_fused_forward_wide_supported(int64_t B, int64_t T, int64_t N, int64_t F, int64_t G, int64_t K, int64_t entries,
-                                                  double uniform_w, int img16, int inline_pack) {
+                                                  double uniform_w, int img16 /* bit 1: rank-1-weighted graph (two factor tables in LDS) */, int inline_pack) {
   if (uniform_w == 0.0 || !img16 || N <= 0 || N > NP || B <= 0 || T <= 0 || entries <= 0 || entries % 4) return 0;
   if (inline_pack && (N % 8 || T * G * N > 2147483647LL)) return 0;
   if (B * (NP * (F > G ? F : G) * 2) > 2147483647LL || T * F * N > 2147483647LL) return 0;
   if (!seq32_wanted(B)) return 0;
-  return seq32_lds_for(F, G, K, entries, inline_pack != 0) ? 1 : 0;
+  return seq32_lds_for(F, G, K, entries, inline_pack != 0, (img16 & 2) != 0) ? 1 : 0;
 }
 
-template <int K, int HS, int XS, int VAR, int MODE = 0, bool GATED = false>
+template <int K, int HS, int XS, int VAR, int MODE = 0, bool GATED = false, bool R1 = false>
 static int seq32_launch_v(const Seq32Args& sa, size_t lds, hipStream_t st) {
-  auto sk = fused_seq32_kernel<K, HS, XS, VAR, MODE, GATED>;
+  auto sk = fused_seq32_kernel<K, HS, XS, VAR, MODE, GATED, R1>;
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(sk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
     return GCRNN_ERR_LAUNCH;
   GCRNN_PRE_LAUNCH();
@@ -110,8 +110,15 @@ static int seq32_launch_v(const Seq32Args& sa, size_t lds, hipStream_t st) {
 
 template <int K, int HS, int XS>
 static int seq32_launch(const Seq32Args& sa, bool inline_pack, hipStream_t st) {
-  const size_t lds = seq32_lds<K, HS, XS>(sa.entries, inline_pack);
+  const size_t lds = seq32_lds<K, HS, XS>(sa.entries, inline_pack, sa.r1a != nullptr);
   if (!lds) return GCRNN_ERR_UNSUPPORTED;
+  if (sa.r1a) {      // rank-1-weighted graph: un-gated forward, as the module issues it (3) or sequence-major in and out (0)
+    if (sa.gi0) return GCRNN_ERR_UNSUPPORTED;
+    if (inline_pack && sa.a1) return seq32_launch_v<K, HS, XS, 3, 0, false, true>(sa, lds, st);
+    if (!inline_pack && sa.a1) return seq32_launch_v<K, HS, XS, 2, 0, false, true>(sa, lds, st);
+    if (!inline_pack && !sa.a1) return seq32_launch_v<K, HS, XS, 0, 0, false, true>(sa, lds, st);
+    return seq32_launch_v<K, HS, XS, 1, 0, false, true>(sa, lds, st);
+  }
   if (sa.gi0) {      // time-gated recurrence: the gate pre-pass has laid out X
     if (inline_pack) return GCRNN_ERR_BAD_SHAPE;
     if (sa.a1) return seq32_launch_v<K, HS, XS, 2, 0, true>(sa, lds, st);
@@ -141,8 +148,10 @@ static int seq32_launch_pair(const Seq32Args& sa, bool inline_pack, hipStream_t 
 extern "C" int gcrnn_fused_forward_wide_bf16(const void* xs, const void* h0, void* hs, const void* wpack, const float* bias,
                                              const float* gi, const float* gf, const int32_t* tile_nodes, const int32_t* tile_off, const void* ell_col4, int64_t entries,
                                              int64_t B, int64_t T, int64_t N, int64_t F, int64_t G, int64_t K, void* Huser,
-                                             int huser_last_only, const void* Xuser_inline, void* stream) {
+                                             int huser_last_only, const void* Xuser_inline, const float* rank1_a, const float* rank1_b,
+                                             void* stream) {
   if (!xs || !h0 || !hs || !wpack || !tile_nodes || !tile_off || !ell_col4) return GCRNN_ERR_NULL_POINTER;
+  if ((rank1_a == nullptr) != (rank1_b == nullptr) || (rank1_a && gi)) return GCRNN_ERR_BAD_SHAPE;
   if ((gi == nullptr) != (gf == nullptr) || (gi && Xuser_inline)) return GCRNN_ERR_BAD_SHAPE;
   if (B <= 0 || T <= 0 || N <= 0 || N > NP || B > (1 << 24) || entries <= 0 || entries % 4) return GCRNN_ERR_BAD_SHAPE;
   if (B * (NP * (F > G ? F : G) * 2) > 2147483647LL || T * F * N > 2147483647LL) return GCRNN_ERR_BAD_SHAPE;   // 32-bit buffer offsets
@@ -160,6 +169,7 @@ extern "C" int gcrnn_fused_forward_wide_bf16(const void* xs, const void* h0, voi
   sa.entries = (int)entries; sa.B = (int)B; sa.N = (int)N;
   sa.nsteps = (int)T;
   sa.gi0 = gi; sa.gf0 = gf; sa.gstride = B;
+  sa.r1a = rank1_a; sa.r1b = rank1_b;
   {
     // de-synchronised starts pay when the launch is long enough and every CU has a sequence (GCRNN_SEQ32_STAGGER=cycles overrides, 0 = off)
     const char* sg = getenv("GCRNN_SEQ32_STAGGER");

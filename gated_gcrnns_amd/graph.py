@@ -201,6 +201,88 @@ class GraphOperator(object):
                         'max_out_degree': int(outdeg.max().item()) if outdeg.numel() else 0}
         return cache[e]
 
+    def rank1_factors(self, adjoint=False):
+        """(a, b, scale-free) with S[m][n] = a[m] b[n] on the support of S (E = 1), or None: the graphs a uniform adjacency turns into under the
+        usual normalisations -- D^-1/2 A D^-1/2 (a = b = d^-1/2; reference Utils/graphTools.py:64 normalizeAdjacency), the random-walk forms
+        D^-1 A / A D^-1, any of them divided by an eigenvalue. Found by propagating a[m] = S[m][n] / b[n] over the bipartite graph of rows and
+        columns, verified on every non-zero to 1e-6 relative. adjoint: the factors of S^T (a and b swap)."""
+        key = '_rank1_adj' if adjoint else '_rank1'
+        if key in self.__dict__:
+            return self.__dict__[key]
+        res = None
+        if self.E == 1 and self.nnz > 0:
+            c = self.adj[0]                                            # CSR(S): row m lists the columns n of S[m][:]
+            rp = c.rowptr.cpu().numpy().astype(np.int64)
+            col = c.col.cpu().numpy().astype(np.int64)
+            val = c.val(torch.float64).cpu().numpy()
+            N = self.N
+            rows = np.repeat(np.arange(N), np.diff(rp))
+            a = np.zeros(N); b = np.zeros(N)
+            seen_a = np.zeros(N, dtype=bool); seen_b = np.zeros(N, dtype=bool)
+            # column lists for the propagation
+            order = np.argsort(col, kind='stable')
+            cp = np.zeros(N + 1, dtype=np.int64); np.add.at(cp, col + 1, 1); cp = np.cumsum(cp)
+            ok = bool(np.all(val != 0))
+            for m0 in range(N):
+                if not ok:
+                    break
+                if seen_a[m0] or rp[m0] == rp[m0 + 1]:
+                    continue
+                a[m0] = 1.0; seen_a[m0] = True
+                stack = [('r', m0)]
+                while stack:
+                    kind, i = stack.pop()
+                    if kind == 'r':
+                        for e in range(rp[i], rp[i + 1]):
+                            n = col[e]
+                            if not seen_b[n]:
+                                b[n] = val[e] / a[i]; seen_b[n] = True
+                                stack.append(('c', n))
+                    else:
+                        for e in order[cp[i]:cp[i + 1]]:
+                            m = rows[e]
+                            if not seen_a[m]:
+                                a[m] = val[e] / b[i]; seen_a[m] = True
+                                stack.append(('r', m))
+            if ok and np.all(np.abs(a[rows] * b[col] - val) <= 1e-6 * np.abs(val)) and not np.all(val == val[0]):
+                # balance the two factors (any split works; this one keeps both in fp32's comfortable range)
+                na, nb_ = np.abs(a[seen_a]).max(), np.abs(b[seen_b]).max()
+                g = np.sqrt(nb_ / na) if na > 0 and nb_ > 0 else 1.0
+                res = (a * g, b / g)
+        if res is not None and adjoint:
+            res = (res[1], res[0])
+        self.__dict__[key] = res
+        return res
+
+    def fused_plan_rank1(self, adjoint=False):
+        """The bf16-image plan (as fused_plan_img16) of the 0/1 PATTERN of a rank-1-weighted graph plus its two factor tables, for the wide
+        sequence-resident kernel: a hop is b[n] * sum_{m in N(n)} (a[m] v[m]) -- the image holds a (.) v, the sums are scaled by b before the
+        tap is added (csrc/gcrnn_fused_seq32.h, R1). None for uniform graphs (they have their own plan) and graphs that are not rank-1."""
+        key = '_fused_plan_rank1_adj' if adjoint else '_fused_plan_rank1'
+        if key in self.__dict__:
+            return self.__dict__[key]
+        res = None
+        import os
+        fac = None if os.environ.get('GCRNN_NO_RANK1') else self.rank1_factors(adjoint=False)
+        if fac is not None:
+            pat = self.__dict__.get('_pattern_operator')
+            if pat is None:
+                Sd = np.zeros((1, self.N, self.N))
+                c = self.adj[0]
+                Sd[0, c.rows().cpu().numpy(), c.col.cpu().numpy().astype(np.int64)] = 1.0
+                pat = GraphOperator(Sd, device=self.device)
+                self._pattern_operator = pat
+            p16 = pat.fused_plan_img16(adjoint=adjoint)
+            if p16 is not None:
+                a, b = (fac[1], fac[0]) if adjoint else fac
+                npad = p16['npad']
+                ta = np.zeros(npad, dtype=np.float32); tb = np.zeros(npad, dtype=np.float32)
+                ta[:self.N] = a; tb[:self.N] = b
+                res = dict(p16)
+                res.update(rank1_a=torch.from_numpy(ta).to(self.device), rank1_b=torch.from_numpy(tb).to(self.device), uniform_w=1.0, rank1=True)
+        self.__dict__[key] = res
+        return res
+
     def fused_plan(self, adjoint=False, kernel='step'):
         """Degree-sorted sliced ELL of CSR(S^T) (forward shift) or, with adjoint=True, of CSR(S) (the shift of the
         backward pass) for the fused step kernels (E = 1): device tensors order (int32 [N]), tile_off

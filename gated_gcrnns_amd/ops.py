@@ -427,14 +427,16 @@ def _fused_pack_weights_wide(wA, wB, uniform_w, st):
     return wpack
 
 
-def fused_wide_plan(graph, B, T, N, F, G, K, inline):
+def fused_wide_plan(graph, B, T, N, F, G, K, inline, rank1=False):
     """The bf16-image plan when the wide sequence-resident kernel (gcrnn_fused_forward_wide_bf16: un-gated forward as ONE launch, 32-feature
     chunks) takes this problem, else None. GCRNN_SEQ32=0 switches it off (A/B)."""
     plan16 = fused_img16_plan(graph, False, None)
+    if plan16 is None and rank1 and not os.environ.get('GCRNN_NO_IMG16'):
+        plan16 = graph.fused_plan_rank1()                # rank-1-weighted graph (normalised adjacency): the plan of its 0/1 pattern + the two factor tables
     if plan16 is None or F % 32 or G % 32:
         return None
     ok = lib.gcrnn_fused_forward_wide_supported(int(B), int(T), int(N), int(F), int(G), int(K), int(plan16['entries']),
-                                                float(plan16.get('uniform_w', 0.0)), 1, 1 if inline else 0)
+                                                float(plan16.get('uniform_w', 0.0)), 3 if plan16.get('rank1') else 1, 1 if inline else 0)
     return plan16 if ok else None
 
 
@@ -443,7 +445,8 @@ def _fused_forward_wide(plan16, xs, h0s, hs, wA, wB, b32, B, T, N, F, G, K, H, l
         wpw = _fused_pack_weights_wide(wA.detach(), wB.detach(), plan16['uniform_w'], st)
     check(lib.gcrnn_fused_forward_wide_bf16(_p(xs), _p(h0s), _p(hs), _p(wpw), _p(b32), _p(gi), _p(gf), _p(plan16['tile_slots']), _p(plan16['tile_off']),
                                             _p(plan16['ell_col4']), plan16['entries'], B, T, N, F, G, K,
-                                            _p(H) if H is not None else None, int(bool(last_only)), _p(Xinline) if Xinline is not None else None, st),
+                                            _p(H) if H is not None else None, int(bool(last_only)), _p(Xinline) if Xinline is not None else None,
+                                            _p(plan16.get('rank1_a')), _p(plan16.get('rank1_b')), st),
           'fused_forward_wide')
 
 
@@ -710,7 +713,9 @@ def fused_cell_forward(X, h0, wA, wB, bias, graph, gates=None, return_states=Fal
     inline = False
     if packed is not None:
         xs, hs_all = packed
-    elif gates is None and gate_values is None and fused_inline_pack_ok(plan, N, F, G, K) and X.data_ptr() % 16 == 0:
+    elif gates is None and gate_values is None and X.data_ptr() % 16 == 0 and (
+            fused_inline_pack_ok(plan, N, F, G, K) or (head is None and not os.environ.get('GCRNN_NO_INLINE_PACK')
+                                                       and fused_wide_plan(graph, B, T, N, F, G, K, True, rank1=True) is not None)):
         # un-gated cell on a uniform-weight graph: only x_0 is packed here, launch t lays out x_{t+1} itself (LDS-DMA into the room
         # the missing weight image leaves, read back transposed after the epilogue) -- no pack pass over X
         xs, hs_all = fused_pack_inputs(X, h0, graph, first_only=True)
@@ -763,7 +768,7 @@ def fused_cell_forward(X, h0, wA, wB, bias, graph, gates=None, return_states=Fal
         if head[1] is not None:
             y = y + head[1].detach().float().reshape(())
         return y.permute(1, 0, 2).unsqueeze(2).contiguous()          # B x T x 1 x N
-    wide = fused_wide_plan(graph, B, T, N, F, G, K, inline) if (evs is None and head is None and not (gi is not None and inline)) else None
+    wide = fused_wide_plan(graph, B, T, N, F, G, K, inline, rank1=(gi is None)) if (evs is None and head is None and not (gi is not None and inline)) else None
     if wide is not None:
         # un-gated cell, uniform-weight graph, a batch that fills the chip: ONE launch of the wide sequence-resident kernel
         if native_out:

@@ -386,7 +386,11 @@ int gcrnn_fused_forward_wide_supported(int64_t B, int64_t T, int64_t N, int64_t 
 int gcrnn_fused_forward_wide_bf16(const void* xs, const void* h0, void* hs, const void* wpack, const float* bias, const float* gi,
                                   const float* gf, const int32_t* tile_nodes, const int32_t* tile_off, const void* ell_col4, int64_t entries,
                                   int64_t B, int64_t T, int64_t N, int64_t F, int64_t G, int64_t K, void* Huser, int huser_last_only,
-                                  const void* Xuser_inline, void* stream);
+                                  const void* Xuser_inline,
+                                  const float* rank1_a, const float* rank1_b /* both NULL, or -- un-gated forward on a RANK-1-weighted graph
+                                     S[m][n] = a[m] b[n] (normalised adjacencies, Utils/graphTools.py:64) -- the two factors [NPad] fp32 (zero for
+                                     padding rows); the plan arrays are then those of the graph's 0/1 pattern and wpack carries uniform_w = 1 */,
+                                  void* stream);
 int gcrnn_fused_gate_pair_wide_supported(int64_t B, int64_t T, int64_t N, int64_t F, int64_t G, int64_t K, int64_t entries, double uniform_w,
                                          int img16, int with_pack);
 /* The BPTT data chain as ONE launch of the wide kernel: gcrnn_fused_backward_data_bf16's contract (seed included), with wpackT =

@@ -265,3 +265,68 @@ def test_wide_bptt_chain_matches_the_16_feature_chain(N, F, K, B, T, gated, monk
         sc = float(c_.float().abs().max())
         d = (a_.float() - c_.float()).abs()
         assert float(d.max()) <= 2.5e-2 * sc and float(d.mean()) <= 2e-3 * sc, (float(d.max()) / sc, float(d.mean()) / sc)
+
+
+def _normalized_adjacency(N, seed, kind):
+    """Uniform adjacency under the reference's normalisations (Utils/graphTools.py:64 normalizeAdjacency: D^-1/2 A D^-1/2; 'rw': D^-1 A),
+    scaled by the largest eigenvalue magnitude as the drivers do (kStepPredGRNNs.py:768)."""
+    rng = np.random.default_rng(seed)
+    W = (rng.random((N, N)) < 10.0 / N).astype(np.float64)
+    W = np.triu(W, 1); W = W + W.T
+    d = W.sum(axis=1); d[d == 0] = 1.0
+    S = W / np.sqrt(d)[:, None] / np.sqrt(d)[None, :] if kind == 'sym' else W / d[:, None]
+    return (S / np.max(np.abs(np.linalg.eigvals(S)))).reshape(1, N, N), rng
+
+
+def test_rank1_factors_are_found_and_exact():
+    """CPU: S[m][n] = a[m] b[n] on the support -- found for both normalisations, exact to 1e-6, absent for uniform and random weights."""
+    from gated_gcrnns_amd.graph import GraphOperator
+    for kind in ('sym', 'rw'):
+        S, _ = _normalized_adjacency(300, 3, kind)
+        f = GraphOperator(S).rank1_factors()
+        assert f is not None
+        assert np.abs(np.outer(f[0], f[1]) * (S[0] != 0) - S[0]).max() <= 1e-12
+    S, rng = _normalized_adjacency(300, 3, 'sym')
+    assert GraphOperator((S != 0).astype(np.float64) * 0.1).rank1_factors() is None
+    assert GraphOperator(S * rng.uniform(0.5, 1.0, S.shape)).rank1_factors() is None
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('N,F,G,K,B,T,kind', [(1000, 64, 64, 5, 4, 4, 'sym'), (1000, 64, 64, 5, 3, 3, 'rw'), (400, 32, 32, 3, 6, 3, 'sym'),
+                                              (1000, 64, 32, 4, 3, 3, 'sym'), (1000, 64, 64, 2, 2, 2, 'rw')])
+def test_wide_kernel_on_rank1_weighted_graphs_matches_oracle(N, F, G, K, B, T, kind, monkeypatch):
+    """Normalised adjacencies (reference Utils/graphTools.py:64) are rank-1-weighted: S[m][n] = a[m] b[n] on the support. The wide kernel runs
+    them on the plan of the 0/1 pattern with the image holding a (.) v and a hop's sums scaled by b -- against the fp64 oracle with the
+    dense weighted S, and against the chunk-parallel kernel's weighted (fp32-image) path on the same problem."""
+    import gated_gcrnns_amd.Utils.graphML as gml
+    from gated_gcrnns_amd import ops
+    dev = torch.device('cuda:0')
+    S, rng = _normalized_adjacency(N, 41, kind)
+    torch.manual_seed(41)
+    cell = gml.GGCRNNCell(G, F, K, K, torch.tanh, False, None, 1, True)
+    cell.addGSO(torch.tensor(S))
+    cell = cell.to(torch.bfloat16)
+    X = bf16_round(rng.standard_normal((B, T, G, N)))
+    h0 = bf16_round(0.3 * rng.standard_normal((B, F, N)))
+    params = {k: v.detach().double().numpy() for k, v in cell.state_dict().items()}
+    nb = min(B, 3)
+    Href = orc.ggcrnn_cell(params, S.astype(np.float32).astype(np.float64), X[:nb], h0[:nb])
+    cell = cell.to(dev)
+    Xd = torch.tensor(X, dtype=torch.bfloat16, device=dev)
+    hd = torch.tensor(h0, dtype=torch.bfloat16, device=dev)
+    monkeypatch.setenv('GCRNN_SEQ32_MIN_B', '1')
+    assert cell.graph.fused_plan_img16() is None and cell.graph.fused_plan_rank1() is not None
+    assert ops.fused_wide_plan(cell.graph, B, T, N, F, ops.fused_padded_inputs(F, G), K, True, rank1=True) is not None
+    with torch.no_grad():
+        H = cell(Xd, hd)
+        Hl = cell(Xd, hd, last_only=True)
+        monkeypatch.setenv('GCRNN_NO_INLINE_PACK', '1')
+        H2 = cell(Xd, hd)
+        monkeypatch.delenv('GCRNN_NO_INLINE_PACK')
+        monkeypatch.setenv('GCRNN_SEQ32', '0')          # the chunk-parallel kernel's weighted path
+        Hw = cell(Xd, hd)
+    assert torch.equal(H, H2) and torch.equal(H[:, -1:], Hl)
+    err = np.abs(H[:nb].double().cpu().numpy() - Href)
+    errw = np.abs(Hw[:nb].double().cpu().numpy() - Href)
+    assert err[:, 0].max() <= 4.0e-3 and err.max() <= max(5.0e-3, 2.0 * errw.max()) and err.mean() <= max(1.0e-3, 1.5 * errw.mean()), \
+        (err[:, 0].max(), err.max(), err.mean(), errw.max(), errw.mean())
