@@ -28,7 +28,7 @@ HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s 
 CFG = dict(N=1000, K=5, T=32, G=64, F=64)
 
 
-def sbm_graph(N=1000, C=5, p_in=0.04, p_out=0.0025, seed=0):
+def sbm_graph(N=1000, C=5, p_in=0.04, p_out=0.0025, seed=0, normalized=False):
     """Undirected SBM adjacency / lambda_max (mean degree ~10, nnz ~1e4), redrawn until connected."""
     rng = np.random.default_rng(seed)
     labels = np.arange(N) * C // N
@@ -42,6 +42,9 @@ def sbm_graph(N=1000, C=5, p_in=0.04, p_out=0.0025, seed=0):
             seen[nxt] = True; frontier = nxt
         if seen.all():
             break
+    if normalized:      # reference Utils/graphTools.py:64 normalizeAdjacency: D^-1/2 W D^-1/2 -- a rank-1-weighted GSO (S[m][n] = d[m]^-1/2 d[n]^-1/2 on the support)
+        d = W.sum(axis=1)
+        W = W / np.sqrt(d)[:, None] / np.sqrt(d)[None, :]
     lam = np.max(np.linalg.eigvalsh(W))
     return (W / lam).reshape(1, N, N)
 
@@ -108,6 +111,8 @@ def parse_args(argv=None):
     ap.add_argument('--time-gating', action='store_true', help='secondary point: the time-gated cell (fwd or train); '
                     'the headline workload is the un-gated cell')
     ap.add_argument('--spatial-gating', default=None, choices=['node', 'edge'], help='secondary point: node- / edge-gated cell')
+    ap.add_argument('--gso', default='adjacency', choices=['adjacency', 'normalized'], help='secondary point: the GSO is the SBM adjacency / lambda_max '
+                    '(the drivers, kStepPredGRNNs.py:768: one weight on every edge) or its normalised form D^-1/2 W D^-1/2 / lambda_max (graphTools.py:64)')
     ap.add_argument('--in-features', type=int, default=CFG['G'], help='secondary point: input features per node (the reference '
                     'drivers feed G = 1; the headline workload is G = F = 64)')
     ap.add_argument('--hipgraph', type=int, default=None, help='replay the fused forward as one captured hipGraph (bf16 fwd); default: 1 when the '
@@ -303,7 +308,7 @@ def run_cfg2(ctx):
     B = args.batch
     dt = {'bf16': torch.bfloat16, 'f32': torch.float32, 'f64': torch.float64}[args.dtype]
     elt = {'bf16': 2, 'f32': 4, 'f64': 8}[args.dtype]
-    S = sbm_graph(N)
+    S = sbm_graph(N, normalized=(args.gso == 'normalized'))
     nnz = int(np.count_nonzero(S))
     torch.manual_seed(0)
     cell = gml.GGCRNNCell(G, F, K, K, torch.tanh, args.time_gating, args.spatial_gating, 1, True)      # reference init U(+-1/sqrt(G*K))
@@ -390,7 +395,7 @@ def run_cfg2(ctx):
         ar = {'allreduce_bytes': opt.sync.nbytes(), 'allreduce_us': 1e3 * e0.elapsed_time(e1) / reps,
               'allreduce_note': 'one flat buffer per optimiser step (RCCL when n_gpus > 1; no collective at n_gpus = 1)'}
     dist_sec = None
-    headline = (args.dtype == 'bf16' and args.mode == 'fwd' and not args.time_gating and args.spatial_gating is None and G == CFG['G'])
+    headline = (args.dtype == 'bf16' and args.mode == 'fwd' and not args.time_gating and args.spatial_gating is None and G == CFG['G'] and args.gso == 'adjacency')
     if dist_on and headline and not args.no_secondary:
         # launched under torch.distributed (the driver's --gpus N form): the forward line has no collective, so every rank also takes ONE
         # training point with the gradient all-reduce in it -- one driver command then measures inference scaling and the collective
@@ -404,8 +409,9 @@ def run_cfg2(ctx):
     abytes = algorithmic_bytes_per_seq(T, N, G, F, elt) * B           # per step (= per launch chain), per GPU
     step_s = (dev_ms / 1e3) / args.steps
     achieved = abytes / step_s / 1e9
-    out = base_line(ctx, value, wall, 'BASELINE configs[1]: synthetic k-step prediction, sparse SBM N=1000 nnz=%d, K=5 taps, '
-                    'T=32, G=%d, F=64, %s GGCRNNCell %s, h0=0' % (nnz, G, gating, 'forward' if args.mode == 'fwd' else 'training step'),
+    out = base_line(ctx, value, wall, 'BASELINE configs[1]: synthetic k-step prediction, sparse SBM N=1000 nnz=%d%s, K=5 taps, '
+                    'T=32, G=%d, F=64, %s GGCRNNCell %s, h0=0' % (nnz, ' (normalised adjacency)' if args.gso == 'normalized' else '', G, gating,
+                                                                  'forward' if args.mode == 'fwd' else 'training step'),
                     B, {'hipgraph': bool(runner is not None)})
     if ar is not None:
         out['config'].update(ar)
@@ -475,7 +481,7 @@ def run_cfg2(ctx):
                            'algorithmic_bytes_per_step': abytes, 'device_ms_per_step': 1e3 * step_s,
                            'gflop_per_step': flops_per_seq(T, N, nnz, K, G, F) * B / 1e9}
     if (world == 1 and not args.no_secondary and args.dtype == 'bf16' and args.mode == 'fwd' and not args.time_gating
-            and args.spatial_gating is None and G == CFG['G']):
+            and args.spatial_gating is None and G == CFG['G'] and args.gso == 'adjacency'):
         # (the headline is complete here: should a secondary point take the process down -- an asynchronous fault is not an exception --
         #  the line is already on stderr)
         sys.stderr.write('bench.py headline before the secondary points: %s\n' % json.dumps(out))
@@ -674,6 +680,23 @@ def secondary_points(ctx, S, params, B, steps=8, warmup=2):
         except Exception as e:      # noqa: BLE001
             sec[name] = {'error': str(e)[:200]}
         gc.collect(); torch.cuda.empty_cache()
+    # ---- the same workload on the NORMALISED adjacency D^-1/2 W D^-1/2 / lambda_max (reference Utils/graphTools.py:64): a rank-1-weighted GSO ----
+    try:
+        torch.manual_seed(0)
+        c = gml.GGCRNNCell(G, F, K, K, torch.tanh, False, None, 1, True)
+        c.addGSO(torch.tensor(sbm_graph(N, normalized=True)))
+        c = c.to(dev).to(torch.bfloat16)
+        X = torch.randn(B, T, G, N, device=dev, dtype=torch.float32, generator=gen).to(torch.bfloat16)
+        h0 = torch.zeros(B, F, N, device=dev, dtype=torch.bfloat16)
+        with torch.no_grad():
+            dt = _timed(lambda: c(X, h0), 5, 2)
+        sec['fwd_normalized_adjacency'] = {'value': B / dt, 'unit': 'sequences/s', 'ms_per_step': 1e3 * dt, 'steps': 5, 'dtype': 'bf16',
+                                           'kernel': 'fused_seq32_kernel<..,R1>' if c.graph.fused_plan_rank1() is not None else 'chunk-parallel weighted path',
+                                           'what': 'un-gated forward, GSO = normalizeAdjacency(W) / lambda_max (S[m][n] = a[m] b[n] on the support), same workload'}
+        del c, X, h0
+    except Exception as e:      # noqa: BLE001
+        sec['fwd_normalized_adjacency'] = {'error': str(e)[:200]}
+    gc.collect(); torch.cuda.empty_cache()
     return sec
 
 
