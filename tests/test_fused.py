@@ -1611,7 +1611,7 @@ def test_sequence_resident_kernel_is_bit_identical_to_the_chunk_parallel_kernel(
     X = torch.tensor(rng.standard_normal((B, T, G, N)), dtype=torch.float32, device=dev).to(torch.bfloat16)
     h0 = torch.tensor(0.3 * rng.standard_normal((B, F, N)), dtype=torch.float32, device=dev).to(torch.bfloat16)
     Xp, wA = ops.fused_pad_operands(X, cell.weight_A.detach())
-    monkeypatch.setenv('GCRNN_SEQ_MIN_B', '1')
+    monkeypatch.setenv('GCRNN_SEQ_MIN_B', '1'); monkeypatch.setenv('GCRNN_SEQ32', '0')      # (the 16-feature kernels: the wide one is pinned in tests/test_wide.py)
     for nopack in ('0', '1'):
         monkeypatch.setenv('GCRNN_NO_INLINE_PACK', nopack) if nopack == '1' else monkeypatch.delenv('GCRNN_NO_INLINE_PACK', raising=False)
         with torch.no_grad():
@@ -1637,7 +1637,7 @@ def test_sequence_resident_bptt_chain_is_bit_identical(tg, N, F, K, monkeypatch)
     X = torch.tensor(rng.standard_normal((B, T, G, N)), dtype=torch.float32, device=dev).to(torch.bfloat16)
     h0 = torch.tensor(0.3 * rng.standard_normal((B, F, N)), dtype=torch.float32, device=dev).to(torch.bfloat16).requires_grad_(not tg)      # (the fused time gates give h0 no gradient)
     tgt = torch.tensor(rng.standard_normal((B, T, F, N)), dtype=torch.float32, device=dev)
-    monkeypatch.setenv('GCRNN_SEQ_MIN_B', '1')
+    monkeypatch.setenv('GCRNN_SEQ_MIN_B', '1'); monkeypatch.setenv('GCRNN_SEQ32', '0')      # (the 16-feature kernels: the wide one is pinned in tests/test_wide.py)
 
     def step():
         cell.zero_grad(set_to_none=True)
@@ -1673,7 +1673,7 @@ def test_gate_prepass_that_lays_out_the_input_is_bit_identical(N, F, G, K, B, T,
     h0 = torch.zeros((B, F, N), dtype=torch.bfloat16, device=dev) if zero_h0 else \
         torch.tensor(0.3 * rng.standard_normal((B, F, N)), dtype=torch.float32, device=dev).to(torch.bfloat16)
     tgt = torch.tensor(rng.standard_normal((B, T, F, N)), dtype=torch.float32, device=dev)
-    monkeypatch.setenv('GCRNN_SEQ_MIN_B', '1')
+    monkeypatch.setenv('GCRNN_SEQ_MIN_B', '1'); monkeypatch.setenv('GCRNN_SEQ32', '0')      # (the 16-feature kernels: the wide one is pinned in tests/test_wide.py)
     plan16 = ops.fused_img16_plan(cell.graph, True, None)
     steps = int(ops.lib.gcrnn_fused_gate_prepass_lays_out(B, T, N, F, G, K, plan16['entries'], cell.graph.fused_plan()['uniform_w'], 1))
     assert steps == -(-min(B * T, 256) // B)
@@ -1712,7 +1712,7 @@ def test_node_gated_recurrence_on_the_sequence_resident_kernel_is_bit_identical(
     X = torch.tensor(rng.standard_normal((B, T, G, N)), dtype=torch.float32, device=dev).to(torch.bfloat16)
     h0 = torch.tensor(0.3 * rng.standard_normal((B, F, N)), dtype=torch.float32, device=dev).to(torch.bfloat16)
     tgt = torch.tensor(rng.standard_normal((B, T, F, N)), dtype=torch.float32, device=dev)
-    monkeypatch.setenv('GCRNN_SEQ_MIN_B', '1')
+    monkeypatch.setenv('GCRNN_SEQ_MIN_B', '1'); monkeypatch.setenv('GCRNN_SEQ32', '0')      # (the 16-feature kernels: the wide one is pinned in tests/test_wide.py)
     monkeypatch.setenv('GCRNN_NO_FUSED_TAPS', '1')       # (the fused tap dots sum in another order: compared below, with a tolerance)
 
     def run():
@@ -1783,7 +1783,7 @@ def test_filter_output_pass_on_the_sequence_resident_kernel_is_bit_identical(N, 
     outs = {}
     for seq in ('1', '0'):
         monkeypatch.setenv('GCRNN_SEQ_KERNEL', seq)
-        monkeypatch.setenv('GCRNN_SEQ_MIN_B', '1')
+        monkeypatch.setenv('GCRNN_SEQ_MIN_B', '1'); monkeypatch.setenv('GCRNN_SEQ32', '0')      # (the 16-feature kernels: the wide one is pinned in tests/test_wide.py)
         outs[seq] = ops.fused_filter_output(xs, w, bias, cell.graph, K, N, adjoint=adj)
         torch.cuda.synchronize()
     assert torch.equal(outs['1'], outs['0'])
@@ -1817,7 +1817,7 @@ def test_native_layout_output_and_sequence_major_forward_are_bit_identical(N, F,
     h0 = torch.tensor(0.3 * rng.standard_normal((B, F, N)), dtype=torch.float32, device=dev).to(torch.bfloat16)
     for seq in ('1', '0'):
         monkeypatch.setenv('GCRNN_SEQ_KERNEL', seq)
-        monkeypatch.setenv('GCRNN_SEQ_MIN_B', '1')
+        monkeypatch.setenv('GCRNN_SEQ_MIN_B', '1'); monkeypatch.setenv('GCRNN_SEQ32', '0')      # (the 16-feature kernels: the wide one is pinned in tests/test_wide.py)
         with torch.no_grad():
             cell.native_layout = False
             H = cell(X, h0)
@@ -1988,7 +1988,7 @@ def test_sequence_resident_time_gated_forward_is_bit_identical(N, F, G, K, B, T,
     X = torch.tensor(rng.standard_normal((B, T, G, N)), dtype=torch.float32, device=dev).to(torch.bfloat16)
     h0 = torch.zeros(B, F, N, device=dev, dtype=torch.bfloat16) if hz else \
         torch.tensor(0.3 * rng.standard_normal((B, F, N)), dtype=torch.float32, device=dev).to(torch.bfloat16)
-    monkeypatch.setenv('GCRNN_SEQ_MIN_B', '1')
+    monkeypatch.setenv('GCRNN_SEQ_MIN_B', '1'); monkeypatch.setenv('GCRNN_SEQ32', '0')      # (the 16-feature kernels: the wide one is pinned in tests/test_wide.py)
     with torch.no_grad():
         monkeypatch.setenv('GCRNN_SEQ_KERNEL', '1')
         H1, Hl1 = cell(X, h0), cell(X, h0, last_only=True)
