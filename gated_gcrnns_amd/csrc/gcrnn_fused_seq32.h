@@ -67,6 +67,17 @@ extern "C" int gcrnn_debug_read_seq32_stamps(void* host) {
 #ifndef GCRNN_SEQ32_NT_STATE
 #define GCRNN_SEQ32_NT_STATE 0     // state stores of the LAST chunk (handed over in registers: not read back by this launch)
 #endif
+#ifndef GCRNN_SEQ32_NO_ITEM_PREFETCH
+#define GCRNN_SEQ32_NO_ITEM_PREFETCH 0      // 1: the gate pre-pass loads every item's operand at the item's start (A/B)
+#endif
+#ifndef GCRNN_SEQ32_GATED_TAPS_FIRST
+#define GCRNN_SEQ32_GATED_TAPS_FIRST 1      // 1 (default): in the time-gated recurrence EVERY wave evaluates the tap before its stream (exact, no reciprocal).
+                                            // 0: waves 0..3 stream first and start the gated chain from S / gf -- built, but hipcc then spills 4-8 operand registers
+                                            // in the K = 4, 5 instantiations (the extra scaling pass keeps a reciprocal live across the MFMA chains): not the default
+#endif
+#ifndef GCRNN_SEQ32_END_WAIT
+#define GCRNN_SEQ32_END_WAIT 0     // 1: every chunk ends with s_waitcnt vmcnt(0) (as the first versions did; A/B)
+#endif
 #ifndef GCRNN_SEQ32_SAME_ORDER
 #define GCRNN_SEQ32_SAME_ORDER 0      // 1: every wave streams first, then evaluates the tap (A/B: tools/ab_build.sh "-DGCRNN_SEQ32_SAME_ORDER=1")
 #endif
@@ -246,10 +257,12 @@ __global__ __launch_bounds__(STHREADS) void fused_seq32_kernel(const Seq32Args a
   // wave-uniform, as a scalar integer (a lane mask would also be parked in a vector register)
   const int skip_hi = __builtin_amdgcn_readfirstlane((MODE == 1 && a.flags && a.flags[0] != 0) ? 1 : 0);
   const bool skip_h = skip_hi != 0;
-  for (int b = blockIdx.x; b < B; b += gridDim.x) {
   // ---- the operand of a sequence and step: every B fragment of the wave, resident for all chunks ----------------------------------
   bf16x8 bfr[STILES][KS];
-  {
+  // the operand of item / sequence `bb` (its first step): at the top of the loop, or -- MODE 1 -- requested behind the previous item's last state
+  // stores, when the operand registers have just died (the items of the pre-pass are one step each: without it every item starts with a
+  // wait for its whole operand)
+  auto load_first_operand = [&](int b) {
     // (MODE 1 with an all-zero h0: a zero-length descriptor -- the loads return zeros and cost nothing)
     const __amdgpu_buffer_rsrc_t rsrc_h = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(a.hfirst), 0, skip_h ? 0 : (MODE == 1 ? a.hmod : B) * (NP * F * 2), 0x00020000);
     const __amdgpu_buffer_rsrc_t rsrc_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(a.x0), 0, XS > 0 ? B * (NP * G * 2) : 0, 0x00020000);
@@ -268,7 +281,11 @@ __global__ __launch_bounds__(STHREADS) void fused_seq32_kernel(const Seq32Args a
           bfr[i][s] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, (w >> 16) * (G * 2) + 16 * qo + 64 * (s - HS), b * (NP * G * 2), 0));
       }
     }
-  }
+  };
+  bool have_operand = false;      // (wave-uniform)
+  for (int b = blockIdx.x; b < B; b += gridDim.x) {
+  if (!have_operand) load_first_operand(b);
+  have_operand = false;
 #pragma unroll 1
   for (int step = 0; step < a.nsteps; ++step) {
     const bool fin = (MODE == 2) && a.final_raw && step == a.nsteps - 1;      // (chain: the d h0 step)
@@ -307,17 +324,25 @@ __global__ __launch_bounds__(STHREADS) void fused_seq32_kernel(const Seq32Args a
 
     f32x4 acc[STILES][2];
     // acc[i][h] += W_tap(c, half h) [h|x]^T for the wave's 8 tiles: one weight fragment feeds 8 independent MFMA chains
-    auto taps = [&](int tap) {
+    auto taps = [&](int tap, [[maybe_unused]] bool on_sums = false) {
       const int ln = lane_now();                       // (the fragment address is re-derived per call, not kept -- or spilled -- across the hops)
       const uint32_t wofs = (uint32_t)WOFF + (uint32_t)ln * 16u;
       if constexpr (GATED) {
         // gi (x W_x) + gf (h W_h) on ONE accumulator chain per half: h-chain, scale by gf / gi, continue with x, scale by gi (gi = sigmoid(.) > 0;
-        // the wave-uniform guard covers an underflowed gate) -- the accumulators are ZERO on entry (every wave evaluates the tap before its
-        // stream, which then adds the hop's sums: exact, no reciprocal).
+        // the wave-uniform guard covers an underflowed gate). Waves 4..7 (tap first): the accumulators are ZERO on entry and the stream then
+        // adds the hop's sums to the finished tap.
+        // on_sums (the waves that stream first): the accumulators hold the hop's sums S; S + gf hW + gi xW comes out of the same chain started
+        // from S / gf (three more roundings at 1e-7 relative; an underflowed forget gate skips the h-chain instead)
         const bool xpart = gin > 1e-30f;
+        const bool hpart = !on_sums || gfo > 1e-30f;
+        if (on_sums) {
+          const float pre = hpart ? 1.f / gfo : (xpart ? 1.f / gin : 1.f);
+#pragma unroll
+          for (int i = 0; i < STILES; ++i) { acc[i][0] *= pre; acc[i][1] *= pre; }
+        }
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-          {
+          if (hpart) {
 #pragma unroll
             for (int s = 0; s < HS; ++s) {
               const bf16x8 afr = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(smem + wofs + (uint32_t)(((tap * 2 + h) * KS + s) * 1024)));
@@ -325,7 +350,7 @@ __global__ __launch_bounds__(STHREADS) void fused_seq32_kernel(const Seq32Args a
               for (int i = 0; i < STILES; ++i) acc[i][h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr, bfr[i][s], acc[i][h], 0, 0, 0);
             }
           }
-          if constexpr (GATED) {
+          if (hpart) {
 #pragma unroll
             for (int i = 0; i < STILES; ++i) acc[i][h] *= (xpart ? gratio : gfo);
           }
@@ -446,19 +471,42 @@ __global__ __launch_bounds__(STHREADS) void fused_seq32_kernel(const Seq32Args a
         const __amdgpu_buffer_rsrc_t rsrc_pk = __builtin_amdgcn_make_buffer_rsrc(pk_dst, 0, B * (NP * PKROWS * 2), 0x00020000);
         const int tl = wave * 64 + lane_now();
         u32x4_t vv[RI];
+        // the tile's 2-byte columns of this thread's row piece(s): ALL reads in flight, one wait (hipcc waits after every pair: eight LDS round
+        // trips per piece, ~8 of a hop's ~19 units of write-back; d16 loads cannot merge the halves -- with SRAM-ECC they rewrite the whole register)
+        static_assert(RI == 1 || RI == 2, "one or two row pieces per thread");
+        uint32_t h16[RI][8];
+        uint32_t sa[RI];
 #pragma unroll
         for (int i = 0; i < RI; ++i) {
           const int id = i * STHREADS + tl;
           const int nl = id / PCS, pc = id - nl * PCS;
-          const char* src = xtile + (pc * 8) * (NPCK * 2) + ((nl + 8 * pc) & (NPCK - 1)) * 2;
+          sa[i] = (uint32_t)(xtile - smem) + (uint32_t)((pc * 8) * (NPCK * 2) + ((nl + 8 * pc) & (NPCK - 1)) * 2);
+        }
+        static_assert(NPCK * 2 == 256, "row pitch of the pack tile in the asm offsets");
+        if constexpr (RI == 2) {
+          asm volatile("ds_read_u16 %0, %16\n\tds_read_u16 %1, %16 offset:256\n\tds_read_u16 %2, %16 offset:512\n\tds_read_u16 %3, %16 offset:768\n\t"
+                       "ds_read_u16 %4, %16 offset:1024\n\tds_read_u16 %5, %16 offset:1280\n\tds_read_u16 %6, %16 offset:1536\n\tds_read_u16 %7, %16 offset:1792\n\t"
+                       "ds_read_u16 %8, %17\n\tds_read_u16 %9, %17 offset:256\n\tds_read_u16 %10, %17 offset:512\n\tds_read_u16 %11, %17 offset:768\n\t"
+                       "ds_read_u16 %12, %17 offset:1024\n\tds_read_u16 %13, %17 offset:1280\n\tds_read_u16 %14, %17 offset:1536\n\tds_read_u16 %15, %17 offset:1792\n\t"
+                       "s_waitcnt lgkmcnt(0)"
+                       : "=&v"(h16[0][0]), "=&v"(h16[0][1]), "=&v"(h16[0][2]), "=&v"(h16[0][3]), "=&v"(h16[0][4]), "=&v"(h16[0][5]), "=&v"(h16[0][6]), "=&v"(h16[0][7]),
+                         "=&v"(h16[RI - 1][0]), "=&v"(h16[RI - 1][1]), "=&v"(h16[RI - 1][2]), "=&v"(h16[RI - 1][3]), "=&v"(h16[RI - 1][4]), "=&v"(h16[RI - 1][5]), "=&v"(h16[RI - 1][6]), "=&v"(h16[RI - 1][7])
+                       : "v"(sa[0]), "v"(sa[RI - 1]));
+        } else {
+          asm volatile("ds_read_u16 %0, %8\n\tds_read_u16 %1, %8 offset:256\n\tds_read_u16 %2, %8 offset:512\n\tds_read_u16 %3, %8 offset:768\n\t"
+                       "ds_read_u16 %4, %8 offset:1024\n\tds_read_u16 %5, %8 offset:1280\n\tds_read_u16 %6, %8 offset:1536\n\tds_read_u16 %7, %8 offset:1792\n\t"
+                       "s_waitcnt lgkmcnt(0)"
+                       : "=&v"(h16[0][0]), "=&v"(h16[0][1]), "=&v"(h16[0][2]), "=&v"(h16[0][3]), "=&v"(h16[0][4]), "=&v"(h16[0][5]), "=&v"(h16[0][6]), "=&v"(h16[0][7])
+                       : "v"(sa[0]));
+        }
+#pragma unroll
+        for (int i = 0; i < RI; ++i) {
+          const int id = i * STHREADS + tl;
+          const int nl = id / PCS;
+          const bool ok = rnd * NPCK + nl < N;
           uint32_t w4[4];
 #pragma unroll
-          for (int jj = 0; jj < 4; ++jj) {
-            const uint32_t lo = *reinterpret_cast<const uint16_t*>(src + (2 * jj) * (NPCK * 2));
-            const uint32_t hi = *reinterpret_cast<const uint16_t*>(src + (2 * jj + 1) * (NPCK * 2));
-            w4[jj] = lo | (hi << 16);
-          }
-          const bool ok = rnd * NPCK + nl < N;
+          for (int jj = 0; jj < 4; ++jj) w4[jj] = h16[i][2 * jj] | (h16[i][2 * jj + 1] << 16);
           vv[i] = u32x4_t{ok ? w4[0] : 0u, ok ? w4[1] : 0u, ok ? w4[2] : 0u, ok ? w4[3] : 0u};
         }
 #pragma unroll
@@ -524,7 +572,7 @@ __global__ __launch_bounds__(STHREADS) void fused_seq32_kernel(const Seq32Args a
         for (int i = 0; i < STILES; ++i) { acc[i][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[i][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
         // (the pack's LDS-DMA pieces go out right before the wave's stream: hipcc orders every later LDS read of the wave behind them with a
         //  vmcnt(0) -- behind the stream that wait is free, in front of the tap's weight reads it would expose the pieces' whole latency)
-        if (!GATED && (R1 || wave < SWAVES / 2 || GCRNN_SEQ32_SAME_ORDER)) {
+        if ((!GATED || !GCRNN_SEQ32_GATED_TAPS_FIRST) && (R1 || wave < SWAVES / 2 || GCRNN_SEQ32_SAME_ORDER)) {
           dma_issue();
           GCRNN_HOP_ASM_WIDE32_STREAM(acc);
           if constexpr (R1) {      // sums of a (.) v over the in-neighbours, times b[n]: then the tap
@@ -538,7 +586,7 @@ __global__ __launch_bounds__(STHREADS) void fused_seq32_kernel(const Seq32Args a
           }
           GCRNN_STAMP32(1 + chunk * 24 + 4 * (j - 1) + 1);
           if (j == 2 && chunk == 0) GCRNN_STAMP32_WAVE(56);
-          taps(K - 1 - j);
+          taps(K - 1 - j, true);
         } else {
           taps(K - 1 - j);
           if (j == 2 && chunk == 0) GCRNN_STAMP32_WAVE(56);
@@ -702,6 +750,14 @@ __global__ __launch_bounds__(STHREADS) void fused_seq32_kernel(const Seq32Args a
         for (int i = 0; i < STILES; ++i) bfr[i][HS - 1] = __builtin_bit_cast(bf16x8, pkd[i]);
       }
       if (GCRNN_SEQ32_OPERAND_AT == 1) request_next_operand();
+      if constexpr (MODE == 1) {
+        // the workgroup's next item: its input was laid out by this item's pack rounds (stored, waited for and behind barriers since the
+        // first half of the hops) or by the caller; its state operand is h0
+        if (last && b + (int)gridDim.x < B && !GCRNN_SEQ32_NO_ITEM_PREFETCH) {
+          load_first_operand(b + (int)gridDim.x);
+          have_operand = true;
+        }
+      }
       if (aux1) {
         // user layout H[b][t][f][:] (node-contiguous rows) through a transposed LDS tile of 32-bit words [feature pair][node]: a lane's
         // four packed registers are four such words (pairs 4 q .. 4 q + 3). Nobody reads the image any more (the last hop's barrier).
@@ -736,7 +792,12 @@ __global__ __launch_bounds__(STHREADS) void fused_seq32_kernel(const Seq32Args a
       // has been read: the image may be seeded again
       if (GCRNN_SEQ32_OPERAND_AT == 2) request_next_operand();
       GCRNN_STAMP32(1 + chunk * 24 + 19);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      // K = 2 only: the next chunk's tap 0 (LDS-DMA behind the last hop) has landed. Otherwise NO wait here: every LDS-DMA piece was covered by
+      // its hop's wait, the stores the next step reads back (the earlier chunks' states, the pack's rows) have been behind a hop's vmcnt(0)
+      // since, and the next operand's requests are waited for where the seed's MFMAs first use them (hipcc counts them: the state fragments
+      // were requested first, so the seed starts on them while the input's are still landing).
+      if (K == 2 && NCH > 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      else if (GCRNN_SEQ32_END_WAIT) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       lds_barrier();
       GCRNN_STAMP32(1 + chunk * 24 + 20);
       if (chunk + 1 < NCH) seed();
