@@ -697,6 +697,27 @@ def secondary_points(ctx, S, params, B, steps=8, warmup=2):
     except Exception as e:      # noqa: BLE001
         sec['fwd_normalized_adjacency'] = {'error': str(e)[:200]}
     gc.collect(); torch.cuda.empty_cache()
+    # ---- beyond the fused kernels' 1024 nodes (short of configs[4]): the same cell on an SBM of N = 2048, Horner-form streaming path ----
+    try:
+        N2 = 2048
+        torch.manual_seed(0)
+        c = gml.GGCRNNCell(G, F, K, K, torch.tanh, False, None, 1, True)
+        c.addGSO(torch.tensor(sbm_graph(N2, p_in=0.02, p_out=0.00125)))        # same mean degree (~10) as the headline graph
+        c = c.to(dev).to(torch.bfloat16)
+        B2 = B // 2                                                            # the same number of (sequence, node) pairs as the headline batch
+        X = torch.randn(B2, T, G, N2, device=dev, dtype=torch.float32, generator=gen).to(torch.bfloat16)
+        h0 = torch.zeros(B2, F, N2, device=dev, dtype=torch.bfloat16)
+        with torch.no_grad():
+            assert not c._use_fused(X, h0)
+            dt = _timed(lambda: c(X, h0), 3, 1)
+        sec['fwd_n2048_streaming'] = {'value': B2 / dt, 'unit': 'sequences/s', 'ms_per_step': 1e3 * dt, 'steps': 3, 'dtype': 'bf16', 'batch': B2,
+                                      'frac': algorithmic_bytes_per_seq(T, N2, G, F, 2) * B2 / dt / 1e9 / HBM_PEAK_GBS,
+                                      'what': 'un-gated forward at N = 2048 nodes (the fused kernels hold N <= 1024): Horner-form streaming path, '
+                                              'gcrnn_taps_bf16 + gcrnn_spmm per hop; frac on the compulsory bytes T s N (G + 2F) per sequence'}
+        del c, X, h0
+    except Exception as e:      # noqa: BLE001
+        sec['fwd_n2048_streaming'] = {'error': str(e)[:200]}
+    gc.collect(); torch.cuda.empty_cache()
     return sec
 
 
