@@ -741,6 +741,20 @@ __global__ __launch_bounds__(STHREADS) void fused_seq32_kernel(const Seq32Args a
         pkd[i] = p;
         if (GCRNN_SEQ32_NT_STATE && last) __builtin_amdgcn_raw_buffer_store_b128(p, rsrc_o, node * (F * 2) + (chunk * 32 + q * 8) * 2, b * (NP * F * 2), GCRNN_SEQ32_NT_STATE);
         else __builtin_amdgcn_raw_buffer_store_b128(p, rsrc_o, node * (F * 2) + (chunk * 32 + q * 8) * 2, b * (NP * F * 2), 0);
+        if (GCRNN_SEQ32_OPERAND_AT == 3 && last && more) {
+          // the next operand's fragments of THIS tile (its registers died with the last tap), a tile at a time between the epilogue's own
+          // work: a wave that issues all 24 requests at once sits in their issue for most of the fetch (the memory pipeline takes a request
+          // when a slot frees) and does nothing else meanwhile
+          const __amdgpu_buffer_rsrc_t rsrc_hn = __builtin_amdgcn_make_buffer_rsrc(hout, 0, B * (NP * F * 2), 0x00020000);
+#pragma unroll
+          for (int s = 0; s < KS; ++s) {
+            if (s == HS - 1) continue;
+            if (s < HS)
+              bfr[i][s] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsrc_hn, node * (F * 2) + 16 * q + 64 * s, b * (NP * F * 2), 0));
+            else
+              bfr[i][s] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsrc_xn, node * (G * 2) + 16 * q + 64 * (s - HS), b * (NP * G * 2), 0));
+          }
+        }
       }
       }
       GCRNN_STAMP32(1 + chunk * 24 + 17);
