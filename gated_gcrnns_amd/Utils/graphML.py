@@ -688,8 +688,8 @@ class GGCRNNCell(nn.Module):
         parameters (and, for the plain cell, optionally h0; X too when G == F): forward and BPTT on the fused kernels."""
         if not torch.is_grad_enabled():
             return False
-        if X.requires_grad and (self.spatial_gating is not None or self.time_gating == True or not ops.fused_input_grad_ok(self.F, self.G)):  # noqa: E712
-            return False                                   # dX: un-gated cell with G == F (the input filter's adjoint pass; the gates' sub-networks give X no gradient)
+        if X.requires_grad and (self.spatial_gating is not None or not ops.fused_input_grad_ok(self.F, self.G)):
+            return False                                   # dX: un-gated and (r4) time-gated cells with G == F (the input filters' adjoint passes, the gate cells' included)
         if not (h0.requires_grad or X.requires_grad or any(p.requires_grad for p in self.parameters())):
             return False
         if self.spatial_gating == 'node':
@@ -704,8 +704,8 @@ class GGCRNNCell(nn.Module):
                 return False
         elif self.spatial_gating is not None:
             return False
-        if self.time_gating == True:  # noqa: E712   the fused gates give no gradient to h0; their sub-cells share the cell's shapes
-            if h0.requires_grad or self.bias is None or self.GFL_in.weight_A.dtype != self.weight_A.dtype:
+        if self.time_gating == True:  # noqa: E712   the gates' sub-cells share the cell's shapes; (r4) they hand h0 its gradient when G == F
+            if (h0.requires_grad and not ops.fused_input_grad_ok(self.F, self.G)) or self.bias is None or self.GFL_in.weight_A.dtype != self.weight_A.dtype:
                 return False
         if self.sigma not in (torch.tanh, nn.functional.tanh) or X.dtype != torch.bfloat16 or h0.dtype != X.dtype:
             return False

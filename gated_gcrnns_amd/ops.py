@@ -1780,15 +1780,48 @@ class _FusedTimeGate(torch.autograd.Function):
             raise GcrnnError('the fused time gate was already back-propagated: its saved states are turned into gradients in '
                              'place, so a second backward over the same graph (retain_graph) is not supported')
         ctx.consumed = True
-        if ctx.needs_input_grad[2] or ctx.needs_input_grad[3]:
-            raise GcrnnError('the fused time gate does not produce gradients w.r.t. X or h0')
-        return (None, None, None, None) + _time_gate_backward(X, h0, wA_g, wB_g, bias_g, lin_w, lin_b, gate, cs, gw, hzero, ctx.graph, dgate,
-                                                              ctx.needs_input_grad[4:9]) + (None, None)
+        wx, wh = ctx.needs_input_grad[2], ctx.needs_input_grad[3]
+        if (wx or wh) and not fused_input_grad_ok(wA_g.shape[0], X.shape[2]):
+            raise GcrnnError('the fused time gate produces gradients w.r.t. X or h0 only for G == F')
+        res = _time_gate_backward(X, h0, wA_g, wB_g, bias_g, lin_w, lin_b, gate, cs, gw, hzero, ctx.graph, dgate, ctx.needs_input_grad[4:9], wx, wh)
+        if wx or wh:
+            return (None, None, res[0], res[1]) + res[2:] + (None, None)
+        return (None, None, None, None) + res + (None, None)
 
 
-def _time_gate_backward(X, h0, wA_g, wB_g, bias_g, lin_w, lin_b, gate, cs, gw, hzero, graph, dgate, needs):
+def _time_gate_input_grads(X, h0, wA_g, wB_g, dpre_g, graph, want_x, want_h0):
+    """d loss / d X and d loss / d h0 THROUGH a time gate (round 4; the reference's autograd gives both, graphML.py:2362, 2370: the gate cell
+    reads (x_t, h0)): the gate cell's filters' adjoints on its dpre_g -- dX_t = sum_k (S^T)^k (dpre_g,t A_g,k), d h0 = sum_t sum_k (S^T)^k
+    (dpre_g,t B_g,k) -- each ONE all-items launch of the filter-output pass on the adjoint graph with the transposed taps (G == F:
+    fused_input_grad_ok). dpre_g [T][B][NPad][F] bf16. Returns (gX [B][T][G][N], gh0 [B][F][N]) in X's / h0's dtype, or None."""
+    B, T, G, N = X.shape
+    F, Kin, Kst = wA_g.shape[0], wA_g.shape[2], wB_g.shape[2]
+    K = max(Kin, Kst)
+    npad = dpre_g.shape[2]
+    st = _stream()
+    gX = gh0 = None
+    if want_x:
+        wAk = wA_g if Kin == K else torch.cat([wA_g, wA_g.new_zeros(F, 1, K - Kin, G)], dim=2)
+        wAt = wAk.detach()[:, 0].permute(2, 1, 0).contiguous().unsqueeze(1)       # [G][1][K][F]: transposed taps
+        dxs = fused_filter_output(dpre_g, wAt, None, graph, K, N, adjoint=True)   # [T][B][NPad][G] bf16
+        gX = torch.empty((B, T, G, N), dtype=torch.bfloat16, device=X.device)
+        check(lib.gcrnn_unpack_seq_major(_lib.BF16, _p(dxs), _p(gX), B, T, G, N, npad, None, st), 'unpack_seq')
+        gX = gX.to(X.dtype)
+    if want_h0:
+        wBk = wB_g if Kst == K else torch.cat([wB_g, wB_g.new_zeros(F, 1, K - Kst, F)], dim=2)
+        wBt = wBk.detach()[:, 0].permute(2, 1, 0).contiguous().unsqueeze(1)
+        dhs = fused_filter_output(dpre_g, wBt, None, graph, K, N, adjoint=True)   # every item's contribution to its sequence's h0
+        dh = dhs.float().sum(dim=0).to(torch.bfloat16).unsqueeze(0).contiguous()  # [1][B][NPad][F]: fp32 sum over the T items of a sequence
+        gh0 = torch.empty((B, 1, F, N), dtype=torch.bfloat16, device=X.device)
+        check(lib.gcrnn_unpack_seq_major(_lib.BF16, _p(dh), _p(gh0), B, 1, F, N, npad, None, st), 'unpack_seq')
+        gh0 = gh0.view(B, F, N).to(h0.dtype)
+    return gX, gh0
+
+
+def _time_gate_backward(X, h0, wA_g, wB_g, bias_g, lin_w, lin_b, gate, cs, gw, hzero, graph, dgate, needs, want_x=False, want_h0=False):
     """BPTT of one time gate from its stored sub-cell states cs (turned into dpre_g IN PLACE): read-out gradient, then the weight-gradient
-    kernel over all items with h0 as every item's state operand. Returns (gA, gB, gb, glw, glb); needs = which of them are wanted."""
+    kernel over all items with h0 as every item's state operand. Returns (gA, gB, gb, glw, glb); needs = which of them are wanted.
+    want_x / want_h0: two more results in front, (gX, gh0) -- the gradients the gate hands to its inputs."""
     B, T, G, N = X.shape
     F, Kin, Kst = wA_g.shape[0], wA_g.shape[2], wB_g.shape[2]
     K = max(Kin, Kst)
@@ -1808,6 +1841,8 @@ def _time_gate_backward(X, h0, wA_g, wB_g, bias_g, lin_w, lin_b, gate, cs, gw, h
     if needs[3]:
         glw = dw_part.sum(dim=0).view(npad, F)[:N].t().reshape(1, F * N).to(lin_w.dtype)     # [N][F] -> vec over (f, n)
     glb = dlogit.sum().view(1).to(lin_b.dtype) if (lin_b is not None and needs[4]) else None
+    if want_x or want_h0:
+        return _time_gate_input_grads(X, h0, wA_g, wB_g, cs, graph, want_x, want_h0) + (gA, gB, gb, glw, glb)
     return gA, gB, gb, glw, glb
 
 
@@ -1831,13 +1866,19 @@ class _FusedTimeGatePair(torch.autograd.Function):
             raise GcrnnError('the fused time gates were already back-propagated: their saved states are turned into gradients in '
                              'place, so a second backward over the same graph (retain_graph) is not supported')
         ctx.consumed = True
-        if ctx.needs_input_grad[2] or ctx.needs_input_grad[3]:
-            raise GcrnnError('the fused time gate does not produce gradients w.r.t. X or h0')
+        wx, wh = ctx.needs_input_grad[2], ctx.needs_input_grad[3]
+        if (wx or wh) and not fused_input_grad_ok(wA_i.shape[0], X.shape[2]):
+            raise GcrnnError('the fused time gates produce gradients w.r.t. X or h0 only for G == F')
         zi = torch.zeros_like(gi) if dgi is None else dgi
         zf = torch.zeros_like(gf) if dgf is None else dgf
-        g_in = _time_gate_backward(X, h0, wA_i, wB_i, b_i, lw_i, lb_i, gi, cs_i, gw_i, hzero, ctx.graph, zi, ctx.needs_input_grad[4:9])
-        g_f = _time_gate_backward(X, h0, wA_f, wB_f, b_f, lw_f, lb_f, gf, cs_f, gw_f, hzero, ctx.graph, zf, ctx.needs_input_grad[9:14])
-        return (None, None, None, None) + g_in + g_f + (None, None)
+        g_in = _time_gate_backward(X, h0, wA_i, wB_i, b_i, lw_i, lb_i, gi, cs_i, gw_i, hzero, ctx.graph, zi, ctx.needs_input_grad[4:9], wx, wh)
+        g_f = _time_gate_backward(X, h0, wA_f, wB_f, b_f, lw_f, lb_f, gf, cs_f, gw_f, hzero, ctx.graph, zf, ctx.needs_input_grad[9:14], wx, wh)
+        gX = gh0 = None
+        if wx or wh:
+            gX = (g_in[0] + g_f[0]) if wx else None
+            gh0 = (g_in[1] + g_f[1]) if wh else None
+            g_in, g_f = g_in[2:], g_f[2:]
+        return (None, None, gX, gh0) + g_in + g_f + (None, None)
 
 
 def fused_train_time_gates(xs, h0s, X, h0, gates, graph, hzero):

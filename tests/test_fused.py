@@ -695,9 +695,9 @@ def test_fused_bptt_matches_reference_autograd_fixture(golden, name, tg, sg, los
     dev = torch.device('cuda:0')
     cell, S = _g9_cell(g, tg, sg, dev)
     X = torch.tensor(g['X'], dtype=torch.bfloat16, device=dev)
-    h0 = torch.tensor(g['h0'], dtype=torch.bfloat16, device=dev, requires_grad=(not tg and sg is None))
+    h0 = torch.tensor(g['h0'], dtype=torch.bfloat16, device=dev, requires_grad=(sg is None))
     assert float((X.float().cpu() - torch.tensor(g['X'])).abs().max()) == 0.0          # operands are bf16-exact
-    X.requires_grad_(sg is None and not tg)          # round 3: d loss / d X on the fused path (un-gated cell, G == F)
+    X.requires_grad_(sg is None)          # d loss / d X and d loss / d h0 on the fused path: un-gated (round 3) and time-gated (round 4: through the gate cells too), G == F
     if not cell._use_fused_training(X, h0):
         pytest.skip('no fused training kernels for the %s-gated cell' % name)
     H = cell(X, h0)
@@ -742,14 +742,15 @@ def test_fused_bptt_matches_reference_autograd_fixture(golden, name, tg, sg, los
         sc = float(np.abs(want_X).max())
         _tol_report('g9 %s %s dX max %.3e mean %.3e' % (name, loss, float(e.max()) / sc, float(e.mean()) / sc))
         # (measured: sum 3.0e-3 / 2.9e-4, L1 1.1e-1 / 2.4e-3 -- the L1 maximum is a single sign flip of dH)
-        assert float(e.max()) <= (1.4e-1 if loss == 'l1' else 6e-3) * sc and float(e.mean()) <= (5e-3 if loss == 'l1' else 6e-4) * sc, ('dX', float(e.max()) / sc, float(e.mean()) / sc)
+        # (time-gated, round 4: the gate cells' input gradients add two more bf16 chains -- measured sum 7.3e-3 / 4.0e-4, L1 3.7e-2 / 1.1e-3)
+        assert float(e.max()) <= (1.4e-1 if loss == 'l1' else (1.5e-2 if tg else 6e-3)) * sc and float(e.mean()) <= (5e-3 if loss == 'l1' else (8e-4 if tg else 6e-4)) * sc, ('dX', float(e.max()) / sc, float(e.mean()) / sc)
     if h0.requires_grad:
         e = (h0.grad.float().cpu() - torch.tensor(want_h0)).abs()
         sc = float(np.abs(want_h0).max())
         # d h0 has passed T bf16 dpre stores; with the L1 loss single entries also see sign flips of dH (measured 8 % of the max)
         _tol_report('g9 %s %s dh0 max %.3e mean %.3e' % (name, loss, float(e.max()) / sc, float(e.mean()) / sc))
         # (measured: sum 3.3e-3 / 2.3e-4, L1 8.1e-2 / 3.2e-3)
-        assert float(e.max()) <= (1.4e-1 if loss == 'l1' else 6.6e-3) * sc and float(e.mean()) <= (6.4e-3 if loss == 'l1' else 5e-4) * sc, (float(e.max()) / sc, float(e.mean()) / sc)
+        assert float(e.max()) <= (1.4e-1 if loss == 'l1' else (1.5e-2 if tg else 6.6e-3)) * sc and float(e.mean()) <= (6.4e-3 if loss == 'l1' else (1e-3 if tg else 5e-4)) * sc, (float(e.max()) / sc, float(e.mean()) / sc)
 
 
 @pytest.mark.gpu
