@@ -75,6 +75,9 @@ extern "C" int gcrnn_debug_read_seq32_stamps(void* host) {
                                             // 0: waves 0..3 stream first and start the gated chain from S / gf -- built, but hipcc then spills 4-8 operand registers
                                             // in the K = 4, 5 instantiations (the extra scaling pass keeps a reciprocal live across the MFMA chains): not the default
 #endif
+#ifndef GCRNN_SEQ32_YOUNG_PRIO
+#define GCRNN_SEQ32_YOUNG_PRIO 0
+#endif
 #ifndef GCRNN_SEQ32_END_WAIT
 #define GCRNN_SEQ32_END_WAIT 0     // 1: every chunk ends with s_waitcnt vmcnt(0) (as the first versions did; A/B)
 #endif
@@ -591,7 +594,13 @@ __global__ __launch_bounds__(STHREADS) void fused_seq32_kernel(const Seq32Args a
           taps(K - 1 - j);
           if (j == 2 && chunk == 0) GCRNN_STAMP32_WAVE(56);
           dma_issue();
+#if GCRNN_SEQ32_YOUNG_PRIO      // experiment: the younger wave of each SIMD streams at raised issue priority (it starts its stream a tap later)
+          __builtin_amdgcn_s_setprio(GCRNN_SEQ32_YOUNG_PRIO);
+#endif
           GCRNN_HOP_ASM_WIDE32_STREAM(acc);
+#if GCRNN_SEQ32_YOUNG_PRIO
+          __builtin_amdgcn_s_setprio(0);
+#endif
         }
         GCRNN_STAMP32(1 + chunk * 24 + 4 * (j - 1) + 2);
         if (j == 2 && chunk == 0) GCRNN_STAMP32_WAVE(64);
