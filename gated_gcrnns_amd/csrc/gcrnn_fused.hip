@@ -339,9 +339,8 @@ extern "C" int64_t gcrnn_fused_seq_steps_per_launch(int64_t B, int64_t T, int64_
   const int nch = (int)(F / FC);
   if (!fused_seq_wanted(B, nch)) return 0;
   const int64_t ks = backward ? F / 32 : (F + G) / 32, pkrows = backward ? F : G;
-  const size_t need = (size_t)GCRNN_HOP_IMAGE_B_OFFSET + 32 * 1024 + 2 * (size_t)K * ks * 1024 + (size_t)entries * 32 + GCRNN_HOP_COLUMN_PAD;      // (the inline-pack tile is the second hop image)
-  (void)pkrows;
-  if (need > 160 * 1024) return 0;
+  (void)pkrows;      // (the inline-pack tile is the second hop image)
+  if (!fused_seq_lds_bytes(K, ks, entries)) return 0;
   return fused_seq_persistent() ? (backward ? (T > 1 ? T - 1 : 1) : T) : 1;
 #else
   return 0;
@@ -405,9 +404,7 @@ extern "C" int gcrnn_fused_gate_prepass_taps_supported(int64_t B, int64_t T, int
   if (ntaps < 1 || ntaps > 8 || !gcrnn_fused_supported(N, F, G, K) || (with_pack && N % 8)) return 0;
   const int nch = (int)(F / FC);
   if (!fused_seq_wanted(B * T, nch)) return 0;
-  const size_t need = (size_t)GCRNN_HOP_IMAGE_B_OFFSET + 32 * 1024 + 2 * (size_t)K * ((F + G) / 32) * 1024 + (size_t)entries * 32 + GCRNN_HOP_COLUMN_PAD +
-                      (size_t)ntaps * NP * 4 + (size_t)nch * 3 * 512;
-  if (need > 160 * 1024) return 0;
+  if (!fused_seq_lds_bytes(K, (F + G) / 32, entries, (size_t)ntaps * NP * 4 + (size_t)nch * 3 * 512)) return 0;
   const int64_t row_bytes = (int64_t)NP * (F > G ? F : G) * 2;
   if ((2147483647LL / row_bytes) / B < T) return 0;
   return 1;
@@ -425,11 +422,10 @@ extern "C" int64_t gcrnn_fused_gate_prepass_lays_out(int64_t B, int64_t T, int64
   if (!gcrnn_fused_supported(N, F, G, K)) return 0;
   const int nch = (int)(F / FC);
   if (!fused_seq_wanted(B * T, nch)) return 0;
-  const size_t need = (size_t)GCRNN_HOP_IMAGE_B_OFFSET + 32 * 1024 + 2 * (size_t)K * ((F + G) / 32) * 1024 + (size_t)entries * 32 + GCRNN_HOP_COLUMN_PAD;
-  if (need > 160 * 1024 || T * G * N > 2147483647LL) return 0;
+  if (!fused_seq_lds_bytes(K, (F + G) / 32, entries) || T * G * N > 2147483647LL) return 0;
   const int64_t row_bytes = (int64_t)NP * (F > G ? F : G) * 2;
   if ((2147483647LL / row_bytes) / B < T) return 0;                  // (the launch would be split over time: not with the pack)
-  const int64_t first = B * T < 256 ? B * T : 256;
+  const int64_t first = B * T < GCRNN_SEQ_MAX_GRID ? B * T : GCRNN_SEQ_MAX_GRID;      // (the items of the first round of workgroups: the same constant as the launch)
   return (first + B - 1) / B;
 #else
   return 0;

@@ -783,10 +783,15 @@ __global__ __launch_bounds__(STHREADS) void fused_seq_kernel(const SeqArgs a) {
 }
 
 // LDS bytes of the sequence-resident kernel, or 0 when the problem does not fit
+// (ONE formula for the dispatch and for every query of gcrnn_fused.hip -- ADVICE r3: three hand copies had to stay equal to the launch's)
+constexpr int GCRNN_SEQ_MAX_GRID = 256;      // workgroups of a launch of the sequence-resident kernel: one per CU; all-items passes walk their items with this stride
+static inline size_t fused_seq_lds_bytes(int64_t K, int64_t ks, int64_t entries, size_t extra = 0) {
+  const size_t need = (size_t)GCRNN_HOP_IMAGE_B_OFFSET + 32 * 1024 + 2 * (size_t)K * (size_t)ks * 1024 + (size_t)entries * 32 + GCRNN_HOP_COLUMN_PAD + extra;
+  return need <= 160 * 1024 ? need : 0;
+}
 template <int K, int HS, int XS>
 static size_t fused_seq_lds(int64_t entries, bool /*inline_pack: its tile is the second hop image*/, int /*pkrows*/, size_t extra = 0) {
-  const size_t need = (size_t)GCRNN_HOP_IMAGE_B_OFFSET + 32 * 1024 + 2 * (size_t)K * (HS + XS) * 1024 + (size_t)entries * 32 + GCRNN_HOP_COLUMN_PAD + extra;
-  return need <= 160 * 1024 ? need : 0;
+  return fused_seq_lds_bytes(K, HS + XS, entries, extra);
 }
 
 // Which launches take the sequence-resident kernel: it has ONE workgroup per sequence, so it wins where whole rounds of 256

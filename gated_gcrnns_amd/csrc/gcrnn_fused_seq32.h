@@ -328,6 +328,9 @@ __global__ __launch_bounds__(STHREADS) void fused_seq32_kernel(const Seq32Args a
     f32x4 acc[STILES][2];
     // acc[i][h] += W_tap(c, half h) [h|x]^T for the wave's 8 tiles: one weight fragment feeds 8 independent MFMA chains
     auto taps = [&](int tap, [[maybe_unused]] bool on_sums = false) {
+#ifdef GCRNN_SEQ32_EXPERIMENT_NO_HOP_TAPS      // timing experiment, WRONG results: what would a hop cost if its tap were free (hidden inside the stream)?
+      if (tap != K - 1) return;
+#endif
       const int ln = lane_now();                       // (the fragment address is re-derived per call, not kept -- or spilled -- across the hops)
       const uint32_t wofs = (uint32_t)WOFF + (uint32_t)ln * 16u;
       if constexpr (GATED) {

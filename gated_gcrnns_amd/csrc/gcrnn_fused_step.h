@@ -1215,7 +1215,7 @@ int fused_launch_t(int mode /*0 plain, 1 gated, 2 gate pre-pass, 3 BPTT data gra
       fused_seq_wanted((mode == 2 || mode == 5) ? B * T : B, NCH)) {
     const size_t tap_extra = (mode == 2 && bw_hs) ? (size_t)huser_last_only * NP * 4 + (size_t)NCH * 3 * 512 : 0;      // per-item tap accumulators + staged fragments
     const size_t slds = fused_seq_lds<K, HS, XS>(ga.entries, inline_pack, mode == 3 ? F : G, tap_extra);
-    const unsigned sgrid = (unsigned)(B < 256 ? B : 256);
+    const unsigned sgrid = (unsigned)(B < GCRNN_SEQ_MAX_GRID ? B : GCRNN_SEQ_MAX_GRID);
     const bool persist = fused_seq_persistent();
     SeqArgs sa{};
     sa.wpack = (const uint4*)wpack; sa.tile_nodes = ga.tile_nodes; sa.tile_off = ga.tile_off; sa.ell_col4 = (const uint2*)ga.ell_col4;
@@ -1238,7 +1238,7 @@ int fused_launch_t(int mode /*0 plain, 1 gated, 2 gate pre-pass, 3 BPTT data gra
         if (XS == 0) s1.hfirst = (const uint16_t*)h0 + t0 * hstep;
         else s1.x0 = x + t0 * xstep;
         s1.out0 = h + t0 * hstep;
-        sk<<<(unsigned)(items < 256 ? items : 256), STHREADS, slds, st>>>(s1);
+        sk<<<(unsigned)(items < GCRNN_SEQ_MAX_GRID ? items : GCRNN_SEQ_MAX_GRID), STHREADS, slds, st>>>(s1);
       }
       GCRNN_CHECK_LAUNCH();
       return GCRNN_OK;
@@ -1279,7 +1279,7 @@ int fused_launch_t(int mode /*0 plain, 1 gated, 2 gate pre-pass, 3 BPTT data gra
             s1.pk_src0 = (const uint16_t*)bw_dHs; s1.pksrc_stride = G * N; s1.pk_stride = (int)(T * G * N);
             s1.pk_dst0 = const_cast<uint16_t*>(x);
           }
-          sk<<<(unsigned)(items < 256 ? items : 256), STHREADS, slds, st>>>(s1);
+          sk<<<(unsigned)(items < GCRNN_SEQ_MAX_GRID ? items : GCRNN_SEQ_MAX_GRID), STHREADS, slds, st>>>(s1);
         }
         GCRNN_CHECK_LAUNCH();
         return GCRNN_OK;

@@ -455,7 +455,8 @@ def gen_uniform16(sparse=False, sums=False, img_off=0):
 # the first registers of the plane-0 tuples, so the plane-1 gathers (which read them) are issued BEFORE the plane-0 gathers overwrite them.
 WIDE_PLANE = IMAGE_B_OFFSET
 WIDE_D = int(os.environ.get('GCRNN_WIDE_DEPTH', '2'))
-WIDE_WIN = 16 * WIDE_D + WIDE_D + 2 + 6               # gather sets, column words, pointer, prologue address; sparse A (4) + index + scratch
+WIDE_EXTRA = int(os.environ.get('GCRNN_WIDE_EXTRA_CLOBBER', '0'))      # (experiment: registers a stream with in-stream tap MFMAs would need for half a tap's fragments -- do the kernels still allocate?)
+WIDE_WIN = 16 * WIDE_D + WIDE_D + 2 + 6 + WIDE_EXTRA  # gather sets, column words, pointer, prologue address; sparse A (4) + index + scratch
 WIDE_BASE = (254 - WIDE_WIN) & ~1
 
 
