@@ -177,9 +177,13 @@ struct Seq32Map {
 // R1: rank-1-weighted graph S[m][n] = a[m] b[n] (normalised adjacencies: graph.fused_plan_rank1) on the plan of its 0/1 pattern: a hop is
 //     b[n] sum_{m in N(n)} (a[m] v[m]) -- every image write is scaled by a (seed and hop outputs), a hop's sums by b BEFORE its tap is added
 //     (so every wave streams first), the taps carry no w^k (uniform_w = 1).
-template <int K, int HS, int XS, int VAR, int MODE = 0, bool GATED = false, bool R1 = false>
+// SPLIT: batches that leave half of the chip idle (65 <= B <= 128 at F = 64): a sequence's F/32 chunks run as F/32 WORKGROUPS, one launch per time
+//     step (the launch boundary is the hand-over between them: no cross-workgroup wait inside a launch). Each loads the whole operand, runs its
+//     chunk, stores its 32 features and lays out its share of the next step's input; nothing is kept in registers across steps.
+template <int K, int HS, int XS, int VAR, int MODE = 0, bool GATED = false, bool R1 = false, bool SPLIT = false>
 __global__ __launch_bounds__(STHREADS) void fused_seq32_kernel(const Seq32Args a) {
   static_assert(!R1 || (MODE == 0 && !GATED), "rank-1 graphs: the un-gated forward");
+  static_assert(!SPLIT || (MODE == 0 && !GATED && !R1 && HS > 1), "split sequences: the un-gated forward with more than one chunk");
   constexpr bool PKV = (VAR & 1) != 0, USERV = (VAR & 2) != 0 && MODE == 0;
   static_assert(MODE == 0 || ((MODE == 1 || MODE == 2) && !GATED), "modes");
   using M = Seq32Map<K, HS, XS>;
@@ -196,7 +200,9 @@ __global__ __launch_bounds__(STHREADS) void fused_seq32_kernel(const Seq32Args a
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 15, q = lane >> 4;
-  if ((int)blockIdx.x >= B) return;
+  constexpr int NSPL = SPLIT ? HS : 1;
+  const int wg_seq = (int)blockIdx.x / NSPL, chunk0 = SPLIT ? (int)blockIdx.x % NSPL : 0, gseq = (int)gridDim.x / NSPL;
+  if (wg_seq >= B) return;
 
   // once per launch: tile tables, and -- by LDS-DMA, all pieces in flight together -- the column image and chunk 0's weights
   int tbeg[STILES], tend[STILES];
@@ -232,7 +238,7 @@ __global__ __launch_bounds__(STHREADS) void fused_seq32_kernel(const Seq32Args a
       if (p * 1024 + lane * 16 < cbytes)
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(csrc + p * 1024 + lane * 16),
                                          (__attribute__((address_space(3))) void*)(smem + COL_OFF + p * 1024), 16, 0, 0);
-    const char* wsrc = reinterpret_cast<const char*>(a.wpack);
+    const char* wsrc = reinterpret_cast<const char*>(a.wpack) + (size_t)chunk0 * WB;      // (SPLIT: this workgroup's chunk)
     for (int p = wave; p < WB / 1024; p += SWAVES)
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc + p * 1024 + lane * 16),
                                        (__attribute__((address_space(3))) void*)(smem + WOFF + p * 1024), 16, 0, 0);
@@ -286,7 +292,7 @@ __global__ __launch_bounds__(STHREADS) void fused_seq32_kernel(const Seq32Args a
     }
   };
   bool have_operand = false;      // (wave-uniform)
-  for (int b = blockIdx.x; b < B; b += gridDim.x) {
+  for (int b = wg_seq; b < B; b += gseq) {
   if (!have_operand) load_first_operand(b);
   have_operand = false;
 #pragma unroll 1
@@ -320,7 +326,7 @@ __global__ __launch_bounds__(STHREADS) void fused_seq32_kernel(const Seq32Args a
     const int64_t pk_soff = (MODE == 1) ? (int64_t)nbr * a.pk_stride + (int64_t)nbq * a.pksrc_stride : (int64_t)b * a.pk_stride;
     const int pk_db = (MODE == 1) ? nb : b;
     const __amdgpu_buffer_rsrc_t rsrc_o = __builtin_amdgcn_make_buffer_rsrc(hout, 0, hout ? B * (NP * F * 2) : 0, 0x00020000);
-    [[maybe_unused]] const bool stamp_on = (step == (a.nsteps > 2 ? a.nsteps - 3 : 0)) && b == (int)blockIdx.x;      // a typical step (diagnostic builds)
+    [[maybe_unused]] const bool stamp_on = (step == (a.nsteps > 2 ? a.nsteps - 3 : 0)) && b == wg_seq;      // a typical step (diagnostic builds)
     GCRNN_STAMP32(0);
     const bool more = step + 1 < a.nsteps;      // the next step's operand is requested at the start of this step's last epilogue
     const __amdgpu_buffer_rsrc_t rsrc_xn = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(XS > 0 ? a.x0 + (int64_t)(step + 1) * a.xstride : nullptr), 0, (more && XS > 0) ? B * (NP * G * 2) : 0, 0x00020000);
@@ -424,10 +430,10 @@ __global__ __launch_bounds__(STHREADS) void fused_seq32_kernel(const Seq32Args a
     seed();
 
 #pragma unroll 1
-    for (int chunk = 0; chunk < NCH; ++chunk) {
+    for (int chunk = chunk0; chunk < (SPLIT ? chunk0 + 1 : NCH); ++chunk) {
       // opaque per chunk: index arithmetic is re-derived from it inside the loop -- hoisted out it would have to be spilled
       // (nothing derived from the lane id lives across the hops: every use below re-derives it, lane_now())
-      const bool last = chunk == NCH - 1;
+      const bool last = SPLIT || chunk == NCH - 1;
       lds_barrier();      // the seed is in the image
       GCRNN_STAMP32(1 + chunk * 24);
 
@@ -436,6 +442,10 @@ __global__ __launch_bounds__(STHREADS) void fused_seq32_kernel(const Seq32Args a
         if constexpr (MODE == 1) {      // the workgroup's next item, round v (its operand is read when that item starts)
           rnd = v; tgt = 0;
           return pk_any && v < NRND && nb < B;
+        }
+        if constexpr (SPLIT) {      // one step per launch: this workgroup's rounds (those of its chunk's hops) of the NEXT step's input, the host has set the pointers
+          rnd = v; tgt = 0;
+          return pk_any && v < NRND;
         }
         if constexpr (MODE == 2) {      // step i lays out the upstream gradient step i + 1's epilogue reads (the caller laid out step 0's)
           rnd = v; tgt = step + 1;
@@ -451,7 +461,7 @@ __global__ __launch_bounds__(STHREADS) void fused_seq32_kernel(const Seq32Args a
       auto pack_issue = [&](int v) {
         int tgt, rnd;
         if (!pack_target(v, tgt, rnd)) return;
-        const uint16_t* pk_src = a.pk_src0 + (MODE == 1 ? 0 : (int64_t)tgt * a.pksrc_stride);
+        const uint16_t* pk_src = a.pk_src0 + ((MODE == 1 || SPLIT) ? 0 : (int64_t)tgt * a.pksrc_stride);
         constexpr int PPR = NPCK / 8, PIECES = PKROWS * PPR;
         static_assert(PIECES % STHREADS == 0, "whole pieces per thread");
         const uint16_t* xsrc = pk_src + pk_soff + rnd * NPCK;
@@ -470,7 +480,7 @@ __global__ __launch_bounds__(STHREADS) void fused_seq32_kernel(const Seq32Args a
       auto pack_drain = [&](int v) {
         int tgt, rnd;
         if (!pack_target(v, tgt, rnd)) return;
-        uint16_t* pk_dst = a.pk_dst0 + (MODE == 1 ? 0 : (int64_t)tgt * a.pkdst_stride);
+        uint16_t* pk_dst = a.pk_dst0 + ((MODE == 1 || SPLIT) ? 0 : (int64_t)tgt * a.pkdst_stride);
         constexpr int PCS = PKROWS / 8, RI = PCS * NPCK / STHREADS;
         static_assert(PCS * NPCK % STHREADS == 0, "whole row pieces per thread");
         typedef __attribute__((__vector_size__(4 * sizeof(unsigned int)))) unsigned int u32x4_t;
@@ -562,7 +572,7 @@ __global__ __launch_bounds__(STHREADS) void fused_seq32_kernel(const Seq32Args a
       auto hop = [&](auto jc) __attribute__((always_inline)) {
         constexpr int j = decltype(jc)::value;
         auto dma_issue = [&]() {      // this wave's LDS-DMA pieces of the hop, right in front of its stream
-          if (NCH > 1) {
+          if (NCH > 1 && !SPLIT) {
             weights_issue((chunk + 1) % NCH, K - j);
             if (j == 1 && K > 2) weights_issue(chunk, 0);
           }
@@ -607,11 +617,11 @@ __global__ __launch_bounds__(STHREADS) void fused_seq32_kernel(const Seq32Args a
         }
         GCRNN_STAMP32(1 + chunk * 24 + 4 * (j - 1) + 2);
         if (j == 2 && chunk == 0) GCRNN_STAMP32_WAVE(64);
-        if (pk_any || NCH > 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's LDS-DMA pieces have landed (they had the stream)
+        if (pk_any || (NCH > 1 && !SPLIT)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's LDS-DMA pieces have landed (they had the stream)
         lds_barrier();      // every wave has left the image (and the weights, after the last hop); every piece of the pack tile is in
         GCRNN_STAMP32(1 + chunk * 24 + 4 * (j - 1) + 3);
         if (j < K - 1) put();
-        if (K == 2 && NCH > 1) weights_issue((chunk + 1) % NCH, 0);      // (K = 2: tap 0's fragments are free only now, and needed at the next chunk's only hop)
+        if (K == 2 && NCH > 1 && !SPLIT) weights_issue((chunk + 1) % NCH, 0);      // (K = 2: tap 0's fragments are free only now, and needed at the next chunk's only hop)
         if (r0 < NRND) pack_drain(r0);
 #pragma unroll
         for (int e = 1; e < RPH; ++e) {       // (fewer hops than rounds: the extra rounds are not hidden behind a stream)
@@ -822,11 +832,11 @@ __global__ __launch_bounds__(STHREADS) void fused_seq32_kernel(const Seq32Args a
       // its hop's wait, the stores the next step reads back (the earlier chunks' states, the pack's rows) have been behind a hop's vmcnt(0)
       // since, and the next operand's requests are waited for where the seed's MFMAs first use them (hipcc counts them: the state fragments
       // were requested first, so the seed starts on them while the input's are still landing).
-      if (K == 2 && NCH > 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (K == 2 && NCH > 1 && !SPLIT) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       else if (GCRNN_SEQ32_END_WAIT) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       lds_barrier();
       GCRNN_STAMP32(1 + chunk * 24 + 20);
-      if (chunk + 1 < NCH) seed();
+      if (!SPLIT && chunk + 1 < NCH) seed();
     }  // chunks
   }  // steps
   }  // sequences

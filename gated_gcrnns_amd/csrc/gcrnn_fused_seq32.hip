@@ -50,6 +50,20 @@ extern "C" int gcrnn_fused_pack_weights_wide(int wdtype, const void* wA, const v
   return GCRNN_OK;
 }
 
+// Split sequences (one launch per step, F/32 workgroups per sequence): batches between a quarter and half of the chip's CUs, where the
+// chunk-parallel kernel needs two of its 64-sequence rounds and the persistent kernel leaves half of the CUs idle
+// (profiles/r04_small_batches.txt). GCRNN_SEQ32_SPLIT=0 switches it off, =1 forces it for any B <= 128 (tests).
+static bool seq32_split_wanted(int64_t B, int64_t F) {
+  const char* off = getenv("GCRNN_SEQ32");
+  if (off && off[0] == '0') return false;
+  const char* off16 = getenv("GCRNN_SEQ_KERNEL");
+  if (off16 && off16[0] == '0') return false;
+  if (F != 64 || B > 128) return false;
+  const char* sp = getenv("GCRNN_SEQ32_SPLIT");
+  if (sp) return sp[0] != '0';
+  return B > 64;
+}
+
 // GCRNN_SEQ32=0 keeps the 16-feature kernels (A/B); GCRNN_SEQ32_MIN_B=n overrides the batch rule (tests)
 static bool seq32_wanted(int64_t B) {
   const char* off = getenv("GCRNN_SEQ32");
@@ -93,7 +107,7 @@ extern "C" int gcrnn_fused_forward_wide_supported(int64_t B, int64_t T, int64_t 
   if (uniform_w == 0.0 || !img16 || N <= 0 || N > NP || B <= 0 || T <= 0 || entries <= 0 || entries % 4) return 0;
   if (inline_pack && (N % 8 || T * G * N > 2147483647LL)) return 0;
   if (B * (NP * (F > G ? F : G) * 2) > 2147483647LL || T * F * N > 2147483647LL) return 0;
-  if (!seq32_wanted(B)) return 0;
+  if (!seq32_wanted(B) && !((img16 & 6) == 0 && seq32_split_wanted(B, F))) return 0;      // (img16 bit 2: the caller will pass time gates -- no split variant)
   return seq32_lds_for(F, G, K, entries, inline_pack != 0, (img16 & 2) != 0) ? 1 : 0;
 }
 
@@ -108,10 +122,51 @@ static int seq32_launch_v(const Seq32Args& sa, size_t lds, hipStream_t st) {
   return GCRNN_OK;
 }
 
+// Split sequences (65 <= B <= 128, F = 64): one launch per time step, F/32 workgroups per sequence; the host walks the steps and hands every
+// launch its step's arrays (operand, output, user-layout block, the next step's input to lay out)
+template <int K, int HS, int XS, int VAR>
+static int seq32_launch_split(const Seq32Args& sa0, size_t lds, int64_t T, int64_t F, int64_t G, int64_t N, hipStream_t st) {
+  if constexpr (HS > 1) {
+    auto sk = fused_seq32_kernel<K, HS, XS, VAR, 0, false, false, true>;
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(sk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return GCRNN_ERR_LAUNCH;
+    const int64_t xstep = (int64_t)sa0.B * NP * G, hstep = (int64_t)sa0.B * NP * F;
+    const unsigned grid = (unsigned)((int64_t)sa0.B * HS < 256 ? (int64_t)sa0.B * HS : 256 / HS * HS);
+    GCRNN_PRE_LAUNCH();
+    for (int64_t t = 0; t < T; ++t) {
+      Seq32Args s1 = sa0;
+      s1.nsteps = 1;
+      s1.x0 = sa0.x0 + t * xstep;
+      s1.hfirst = (t == 0) ? sa0.hfirst : sa0.out0 + (t - 1) * hstep;
+      s1.out0 = sa0.out0 + t * hstep;
+      s1.a1 = !sa0.a1 ? nullptr : (!sa0.a1_last_only ? sa0.a1 + t * F * N : (t == T - 1 ? sa0.a1 : nullptr));
+      s1.a1_last_only = 0;
+      const bool pk = sa0.pk_src0 && t + 1 < T;      // this launch lays out x_{t+1} (the caller laid out x_0)
+      s1.pk_src0 = pk ? sa0.pk_src0 + (t + 1) * G * N : nullptr;
+      s1.pk_dst0 = pk ? sa0.pk_dst0 + (t + 1) * xstep : nullptr;
+      sk<<<grid, STHREADS, lds, st>>>(s1);
+    }
+    GCRNN_CHECK_LAUNCH();
+    return GCRNN_OK;
+  } else {
+    return GCRNN_ERR_UNSUPPORTED;
+  }
+}
+
 template <int K, int HS, int XS>
-static int seq32_launch(const Seq32Args& sa, bool inline_pack, hipStream_t st) {
+static int seq32_launch(const Seq32Args& sa, bool inline_pack, hipStream_t st, bool split = false, int64_t T = 0, int64_t N = 0) {
   const size_t lds = seq32_lds<K, HS, XS>(sa.entries, inline_pack, sa.r1a != nullptr);
   if (!lds) return GCRNN_ERR_UNSUPPORTED;
+  if (split) {
+    if (sa.r1a || sa.gi0) return GCRNN_ERR_UNSUPPORTED;
+    const int var = (inline_pack ? 1 : 0) | (sa.a1 ? 2 : 0);
+    switch (var) {
+      case 0: return seq32_launch_split<K, HS, XS, 0>(sa, lds, T, 32 * HS, 32 * XS, N, st);
+      case 1: return seq32_launch_split<K, HS, XS, 1>(sa, lds, T, 32 * HS, 32 * XS, N, st);
+      case 2: return seq32_launch_split<K, HS, XS, 2>(sa, lds, T, 32 * HS, 32 * XS, N, st);
+      default: return seq32_launch_split<K, HS, XS, 3>(sa, lds, T, 32 * HS, 32 * XS, N, st);
+    }
+  }
   if (sa.r1a) {      // rank-1-weighted graph: un-gated forward, as the module issues it (3) or sequence-major in and out (0)
     if (sa.gi0) return GCRNN_ERR_UNSUPPORTED;
     if (inline_pack && sa.a1) return seq32_launch_v<K, HS, XS, 3, 0, false, true>(sa, lds, st);
@@ -182,7 +237,15 @@ extern "C" int gcrnn_fused_forward_wide_bf16(const void* xs, const void* h0, voi
     sa.pk_stride = (int)(T * G * N);
   }
   hipStream_t st = as_stream(stream);
-#define GCRNN_SEQ32_CASE(KK, HH, XX) if (K == KK && F == 32 * HH && G == 32 * XX) return seq32_launch<KK, HH, XX>(sa, inline_pack, st);
+  // split sequences: the plain un-gated forward of a batch that would leave half of the chip idle (and is not forced onto the persistent form)
+  const bool split = !gi && !rank1_a && !seq32_wanted(B) && seq32_split_wanted(B, F);
+  const bool pack_split = Xuser_inline != nullptr && T > 1;      // (one launch per step: launch t lays out x_{t+1}; the caller laid out x_0)
+  if (split && pack_split && !inline_pack) {
+    sa.pk_src0 = (const uint16_t*)Xuser_inline; sa.pksrc_stride = G * N;
+    sa.pk_dst0 = const_cast<uint16_t*>(sa.x0); sa.pkdst_stride = xstep;
+    sa.pk_stride = (int)(T * G * N);
+  }
+#define GCRNN_SEQ32_CASE(KK, HH, XX) if (K == KK && F == 32 * HH && G == 32 * XX) return seq32_launch<KK, HH, XX>(sa, split ? pack_split : inline_pack, st, split, T, N);
   GCRNN_SEQ32_CASE(5, 2, 2) GCRNN_SEQ32_CASE(4, 2, 2) GCRNN_SEQ32_CASE(3, 2, 2) GCRNN_SEQ32_CASE(2, 2, 2)
   GCRNN_SEQ32_CASE(5, 2, 1) GCRNN_SEQ32_CASE(4, 2, 1) GCRNN_SEQ32_CASE(3, 2, 1) GCRNN_SEQ32_CASE(2, 2, 1)
   GCRNN_SEQ32_CASE(5, 1, 1) GCRNN_SEQ32_CASE(4, 1, 1) GCRNN_SEQ32_CASE(3, 1, 1) GCRNN_SEQ32_CASE(2, 1, 1)

@@ -427,7 +427,7 @@ def _fused_pack_weights_wide(wA, wB, uniform_w, st):
     return wpack
 
 
-def fused_wide_plan(graph, B, T, N, F, G, K, inline, rank1=False):
+def fused_wide_plan(graph, B, T, N, F, G, K, inline, rank1=False, gated=False):
     """The bf16-image plan when the wide sequence-resident kernel (gcrnn_fused_forward_wide_bf16: un-gated forward as ONE launch, 32-feature
     chunks) takes this problem, else None. GCRNN_SEQ32=0 switches it off (A/B)."""
     plan16 = fused_img16_plan(graph, False, None)
@@ -436,7 +436,7 @@ def fused_wide_plan(graph, B, T, N, F, G, K, inline, rank1=False):
     if plan16 is None or F % 32 or G % 32:
         return None
     ok = lib.gcrnn_fused_forward_wide_supported(int(B), int(T), int(N), int(F), int(G), int(K), int(plan16['entries']),
-                                                float(plan16.get('uniform_w', 0.0)), 3 if plan16.get('rank1') else 1, 1 if inline else 0)
+                                                float(plan16.get('uniform_w', 0.0)), (3 if plan16.get('rank1') else 1) | (4 if gated else 0), 1 if inline else 0)
     return plan16 if ok else None
 
 
@@ -768,7 +768,7 @@ def fused_cell_forward(X, h0, wA, wB, bias, graph, gates=None, return_states=Fal
         if head[1] is not None:
             y = y + head[1].detach().float().reshape(())
         return y.permute(1, 0, 2).unsqueeze(2).contiguous()          # B x T x 1 x N
-    wide = fused_wide_plan(graph, B, T, N, F, G, K, inline, rank1=(gi is None)) if (evs is None and head is None and not (gi is not None and inline)) else None
+    wide = fused_wide_plan(graph, B, T, N, F, G, K, inline, rank1=(gi is None), gated=(gi is not None)) if (evs is None and head is None and not (gi is not None and inline)) else None
     if wide is not None:
         # un-gated cell, uniform-weight graph, a batch that fills the chip: ONE launch of the wide sequence-resident kernel
         if native_out:

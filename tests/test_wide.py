@@ -367,3 +367,36 @@ def test_wide_kernel_edge_shapes_match_oracle(N, F, G, K, B, T, tg, monkeypatch)
     big = G < 32                                        # (few input features: larger taps under the reference init, as for G = 1)
     assert err.max() <= max(2.5e-2 if big else 6.0e-3, 2.0 * err16.max()) and err.mean() <= max(2.5e-3 if big else 1.0e-3, 1.5 * err16.mean()), \
         (err.max(), err.mean(), err16.max(), err16.mean())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('N,G,K,B,T', [(1000, 64, 5, 70, 4), (1000, 32, 3, 100, 3), (1000, 64, 2, 128, 2), (1000, 64, 4, 65, 1)])
+def test_wide_kernel_split_sequences_are_bit_identical_to_the_persistent_form(N, G, K, B, T, monkeypatch):
+    """65 <= B <= 128 at F = 64 (the reference drivers train with B = 100, kStepPredGRNNs.py:168): a sequence's two 32-feature chunks run as
+    two workgroups, one launch per time step. Same arithmetic per chunk as the persistent one-workgroup-per-sequence form: same bits for the
+    states and the user-layout output, with and without the inline layout of X, last state only included; and within bf16 of the oracle."""
+    from gated_gcrnns_amd import ops
+    dev = torch.device('cuda:0')
+    F = 64
+    cell, rng, S = _uniform_cell(N, G, F, K, 61)
+    X = bf16_round(rng.standard_normal((B, T, G, N)))
+    h0 = bf16_round(0.3 * rng.standard_normal((B, F, N)))
+    params = {k: v.detach().double().numpy() for k, v in cell.state_dict().items()}
+    Href = orc.ggcrnn_cell(params, S.astype(np.float32).astype(np.float64), X[:2], h0[:2])
+    cell = cell.to(dev)
+    Xd = torch.tensor(X, dtype=torch.bfloat16, device=dev)
+    hd = torch.tensor(h0, dtype=torch.bfloat16, device=dev)
+    assert ops.fused_wide_plan(cell.graph, B, T, N, F, ops.fused_padded_inputs(F, G), K, True) is not None      # default dispatch: split
+    with torch.no_grad():
+        Hs, Hsl = cell(Xd, hd), cell(Xd, hd, last_only=True)
+        monkeypatch.setenv('GCRNN_NO_INLINE_PACK', '1')
+        Hs2 = cell(Xd, hd)
+        monkeypatch.delenv('GCRNN_NO_INLINE_PACK')
+        monkeypatch.setenv('GCRNN_SEQ32_MIN_B', '1')      # the persistent form
+        Hp = cell(Xd, hd)
+        monkeypatch.delenv('GCRNN_SEQ32_MIN_B')
+        monkeypatch.setenv('GCRNN_SEQ32_SPLIT', '0')      # neither: the chunk-parallel kernel
+        assert ops.fused_wide_plan(cell.graph, B, T, N, F, ops.fused_padded_inputs(F, G), K, True) is None
+    assert torch.equal(Hs, Hp) and torch.equal(Hs, Hs2) and torch.equal(Hs[:, -1:], Hsl)
+    err = np.abs(Hs[:2].double().cpu().numpy() - Href)
+    assert err.max() <= 6.0e-3 and err.mean() <= 1.0e-3, (err.max(), err.mean())
