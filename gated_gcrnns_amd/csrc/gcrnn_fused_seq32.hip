@@ -107,7 +107,7 @@ extern "C" int gcrnn_fused_forward_wide_supported(int64_t B, int64_t T, int64_t 
   if (uniform_w == 0.0 || !img16 || N <= 0 || N > NP || B <= 0 || T <= 0 || entries <= 0 || entries % 4) return 0;
   if (inline_pack && (N % 8 || T * G * N > 2147483647LL)) return 0;
   if (B * (NP * (F > G ? F : G) * 2) > 2147483647LL || T * F * N > 2147483647LL) return 0;
-  if (!seq32_wanted(B) && !((img16 & 6) == 0 && seq32_split_wanted(B, F))) return 0;      // (img16 bit 2: the caller will pass time gates -- no split variant)
+  if (!seq32_wanted(B) && !((img16 & 2) == 0 && seq32_split_wanted(B, F))) return 0;      // (rank-1 graphs have no split variant)
   return seq32_lds_for(F, G, K, entries, inline_pack != 0, (img16 & 2) != 0) ? 1 : 0;
 }
 
@@ -124,10 +124,10 @@ static int seq32_launch_v(const Seq32Args& sa, size_t lds, hipStream_t st) {
 
 // Split sequences (65 <= B <= 128, F = 64): one launch per time step, F/32 workgroups per sequence; the host walks the steps and hands every
 // launch its step's arrays (operand, output, user-layout block, the next step's input to lay out)
-template <int K, int HS, int XS, int VAR>
+template <int K, int HS, int XS, int VAR, bool GATED = false>
 static int seq32_launch_split(const Seq32Args& sa0, size_t lds, int64_t T, int64_t F, int64_t G, int64_t N, hipStream_t st) {
   if constexpr (HS > 1) {
-    auto sk = fused_seq32_kernel<K, HS, XS, VAR, 0, false, false, true>;
+    auto sk = fused_seq32_kernel<K, HS, XS, VAR, 0, GATED, false, true>;
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(sk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
       return GCRNN_ERR_LAUNCH;
     const int64_t xstep = (int64_t)sa0.B * NP * G, hstep = (int64_t)sa0.B * NP * F;
@@ -141,6 +141,7 @@ static int seq32_launch_split(const Seq32Args& sa0, size_t lds, int64_t T, int64
       s1.out0 = sa0.out0 + t * hstep;
       s1.a1 = !sa0.a1 ? nullptr : (!sa0.a1_last_only ? sa0.a1 + t * F * N : (t == T - 1 ? sa0.a1 : nullptr));
       s1.a1_last_only = 0;
+      if (GATED) { s1.gi0 = sa0.gi0 + t * sa0.gstride; s1.gf0 = sa0.gf0 + t * sa0.gstride; }
       const bool pk = sa0.pk_src0 && t + 1 < T;      // this launch lays out x_{t+1} (the caller laid out x_0)
       s1.pk_src0 = pk ? sa0.pk_src0 + (t + 1) * G * N : nullptr;
       s1.pk_dst0 = pk ? sa0.pk_dst0 + (t + 1) * xstep : nullptr;
@@ -158,7 +159,12 @@ static int seq32_launch(const Seq32Args& sa, bool inline_pack, hipStream_t st, b
   const size_t lds = seq32_lds<K, HS, XS>(sa.entries, inline_pack, sa.r1a != nullptr);
   if (!lds) return GCRNN_ERR_UNSUPPORTED;
   if (split) {
-    if (sa.r1a || sa.gi0) return GCRNN_ERR_UNSUPPORTED;
+    if (sa.r1a) return GCRNN_ERR_UNSUPPORTED;
+    if (sa.gi0) {      // time-gated recurrence (the gate pre-pass has laid out X)
+      if (inline_pack) return GCRNN_ERR_BAD_SHAPE;
+      if (sa.a1) return seq32_launch_split<K, HS, XS, 2, true>(sa, lds, T, 32 * HS, 32 * XS, N, st);
+      return seq32_launch_split<K, HS, XS, 0, true>(sa, lds, T, 32 * HS, 32 * XS, N, st);
+    }
     const int var = (inline_pack ? 1 : 0) | (sa.a1 ? 2 : 0);
     switch (var) {
       case 0: return seq32_launch_split<K, HS, XS, 0>(sa, lds, T, 32 * HS, 32 * XS, N, st);
@@ -238,7 +244,7 @@ extern "C" int gcrnn_fused_forward_wide_bf16(const void* xs, const void* h0, voi
   }
   hipStream_t st = as_stream(stream);
   // split sequences: the plain un-gated forward of a batch that would leave half of the chip idle (and is not forced onto the persistent form)
-  const bool split = !gi && !rank1_a && !seq32_wanted(B) && seq32_split_wanted(B, F);
+  const bool split = !rank1_a && !seq32_wanted(B) && seq32_split_wanted(B, F);
   const bool pack_split = Xuser_inline != nullptr && T > 1;      // (one launch per step: launch t lays out x_{t+1}; the caller laid out x_0)
   if (split && pack_split && !inline_pack) {
     sa.pk_src0 = (const uint16_t*)Xuser_inline; sa.pksrc_stride = G * N;

@@ -400,3 +400,37 @@ def test_wide_kernel_split_sequences_are_bit_identical_to_the_persistent_form(N,
     assert torch.equal(Hs, Hp) and torch.equal(Hs, Hs2) and torch.equal(Hs[:, -1:], Hsl)
     err = np.abs(Hs[:2].double().cpu().numpy() - Href)
     assert err.max() <= 6.0e-3 and err.mean() <= 1.0e-3, (err.max(), err.mean())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('N,G,K,B,T,hz', [(1000, 64, 5, 100, 3, True), (1000, 64, 3, 70, 3, False)])
+def test_wide_time_gated_split_sequences_are_bit_identical_to_the_persistent_form(N, G, K, B, T, hz, monkeypatch):
+    """The time-gated recurrence at 65 <= B <= 128 (the drivers' default cell at their batch size 100): gate-pair pre-pass over the B T items,
+    then the gated recurrence with two workgroups per sequence and one launch per step -- the bits of the persistent form."""
+    import gated_gcrnns_amd.Utils.graphML as gml
+    dev = torch.device('cuda:0')
+    F = 64
+    rng = np.random.default_rng(67)
+    W = (rng.random((N, N)) < 10.0 / N).astype(np.float64)
+    W = np.triu(W, 1); W = W + W.T
+    S = (W / np.max(np.abs(np.linalg.eigvalsh(W)))).reshape(1, N, N)
+    torch.manual_seed(67)
+    cell = gml.GGCRNNCell(G, F, K, K, torch.tanh, True, None, 1, True)
+    cell.addGSO(torch.tensor(S))
+    with torch.no_grad():
+        cell.MLP_in[0].weight.mul_(8.0)
+        cell.MLP_forget[0].weight.mul_(8.0)
+    cell = cell.to(torch.bfloat16).to(dev)
+    Xd = torch.tensor(rng.standard_normal((B, T, G, N)), dtype=torch.float32, device=dev).to(torch.bfloat16)
+    hd = torch.zeros(B, F, N, device=dev, dtype=torch.bfloat16) if hz else \
+        torch.tensor(0.3 * rng.standard_normal((B, F, N)), dtype=torch.float32, device=dev).to(torch.bfloat16)
+    with torch.no_grad():
+        Hs, Hsl = cell(Xd, hd), cell(Xd, hd, last_only=True)
+        monkeypatch.setenv('GCRNN_SEQ32_MIN_B', '1')
+        Hp = cell(Xd, hd)
+        monkeypatch.delenv('GCRNN_SEQ32_MIN_B')
+        monkeypatch.setenv('GCRNN_SEQ32', '0')
+        H16 = cell(Xd, hd)
+    assert torch.equal(Hs, Hp) and torch.equal(Hs[:, -1:], Hsl)
+    d = (Hs.float() - H16.float()).abs()
+    assert float(d.max()) <= 2.5e-2 and float(d.mean()) <= 1.5e-3, (float(d.max()), float(d.mean()))
