@@ -323,10 +323,51 @@ __global__ void seq32_seed_kernel(const uint16_t* __restrict__ dH, const uint16_
   *reinterpret_cast<uint32_t*>(out + i) = pack2bf(g0 * (1.f - h0 * h0), g1 * (1.f - h1 * h1));
 }
 
+// split sequences (65 <= B <= 128, F = 64): one launch per chain step, F/32 workgroups per sequence (as seq32_launch_split)
+template <int K, int HS, int VAR>
+static int seq32_launch_chain_split(const Seq32Args& sa0, size_t lds, int64_t T, int64_t F, int64_t N, bool fin, hipStream_t st) {
+  if constexpr (HS > 1) {
+    auto sk = fused_seq32_kernel<K, HS, 0, VAR, 2, false, false, true>;
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(sk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return GCRNN_ERR_LAUNCH;
+    const unsigned grid = (unsigned)((int64_t)sa0.B * HS < 256 ? (int64_t)sa0.B * HS : 256 / HS * HS);
+    const int64_t hstep = (int64_t)sa0.B * NP * F;
+    GCRNN_PRE_LAUNCH();
+    for (int64_t i = 0; i + 1 < T; ++i) {      // chain step i: t = T-1-i
+      Seq32Args s1 = sa0;
+      s1.nsteps = 1; s1.final_raw = 0;
+      s1.hfirst = (i == 0) ? sa0.hfirst : sa0.out0 + (i - 1) * sa0.ostride;
+      s1.out0 = sa0.out0 + i * sa0.ostride;
+      s1.dh0_ = sa0.dh0_ + i * sa0.dhstride; s1.hs0 = sa0.hs0 + i * sa0.hsstride;
+      s1.gsc0 = sa0.gsc0 ? sa0.gsc0 + i * sa0.gscstride : nullptr;
+      s1.gpart0 = sa0.gpart0 ? sa0.gpart0 + i * sa0.gpartstride : nullptr;
+      const bool pk = sa0.pk_src0 && i + 2 < T;      // this launch lays out the upstream gradient of chain step i + 1
+      s1.pk_src0 = pk ? sa0.pk_src0 + (i + 1) * sa0.pksrc_stride : nullptr;
+      s1.pk_dst0 = pk ? sa0.pk_dst0 + (i + 1) * sa0.pkdst_stride : nullptr;
+      sk<<<grid, STHREADS, lds, st>>>(s1);
+    }
+    if (fin) {      // d h0 / the forget gate's step 0: operand dpre_0
+      Seq32Args s1 = sa0;
+      s1.nsteps = 1; s1.final_raw = 1;
+      s1.hfirst = (T >= 2) ? sa0.out0 + (T - 2) * sa0.ostride : sa0.hfirst;
+      s1.gsc0 = sa0.gsc0 ? sa0.gsc0 + (T - 1) * sa0.gscstride : nullptr;
+      s1.gpart0 = sa0.gpart0 ? sa0.gpart0 + (T - 1) * sa0.gpartstride : nullptr;
+      s1.pk_src0 = nullptr; s1.pk_dst0 = nullptr;
+      sk<<<grid, STHREADS, lds, st>>>(s1);
+    }
+    GCRNN_CHECK_LAUNCH();
+    return GCRNN_OK;
+  } else {
+    return GCRNN_ERR_UNSUPPORTED;
+  }
+}
+
 template <int K, int HS>
-static int seq32_launch_chain(const Seq32Args& sa, bool inline_pack, hipStream_t st) {
+static int seq32_launch_chain(const Seq32Args& sa, bool inline_pack, hipStream_t st, bool split = false, int64_t T = 0, int64_t N = 0, bool fin = false) {
   const size_t lds = seq32_lds<K, HS, 0>(sa.entries, inline_pack);
   if (!lds) return GCRNN_ERR_UNSUPPORTED;
+  if (split)
+    return inline_pack ? seq32_launch_chain_split<K, HS, 1>(sa, lds, T, 32 * HS, N, fin, st) : seq32_launch_chain_split<K, HS, 0>(sa, lds, T, 32 * HS, N, fin, st);
   return inline_pack ? seq32_launch_v<K, HS, 0, 1, 2>(sa, lds, st) : seq32_launch_v<K, HS, 0, 0, 2>(sa, lds, st);
 }
 
@@ -337,7 +378,7 @@ extern "C" int gcrnn_fused_backward_data_wide_supported(int64_t B, int64_t T, in
   if (uniform_w == 0.0 || !img16 || N <= 0 || N > NP || B <= 0 || T <= 0 || entries <= 0 || entries % 4) return 0;
   if (inline_pack && (N % 8 || T * F * N > 2147483647LL)) return 0;
   if (B * (NP * F * 2) > 2147483647LL) return 0;
-  if (!seq32_wanted(B)) return 0;
+  if (!seq32_wanted(B) && !seq32_split_wanted(B, F)) return 0;
   return seq32_lds_chain(F, K, entries, inline_pack != 0) ? 1 : 0;
 }
 
@@ -384,7 +425,8 @@ extern "C" int gcrnn_fused_backward_data_wide_bf16(const void* dHs, const void* 
     sa.pk_dst0 = const_cast<uint16_t*>((const uint16_t*)dHs) + (T - 2) * hstep; sa.pkdst_stride = -hstep;
     sa.pk_stride = (int)(T * F * N);
   }
-#define GCRNN_SEQ32_CASE(KK, HH) if (K == KK && F == 32 * HH) return seq32_launch_chain<KK, HH>(sa, inline_pack, st);
+  const bool split = !seq32_wanted(B) && seq32_split_wanted(B, F);
+#define GCRNN_SEQ32_CASE(KK, HH) if (K == KK && F == 32 * HH) return seq32_launch_chain<KK, HH>(sa, inline_pack, st, split, T, N, fin);
   GCRNN_SEQ32_CASE(5, 2) GCRNN_SEQ32_CASE(4, 2) GCRNN_SEQ32_CASE(3, 2) GCRNN_SEQ32_CASE(2, 2)
   GCRNN_SEQ32_CASE(5, 1) GCRNN_SEQ32_CASE(4, 1) GCRNN_SEQ32_CASE(3, 1) GCRNN_SEQ32_CASE(2, 1)
 #undef GCRNN_SEQ32_CASE

@@ -434,3 +434,44 @@ def test_wide_time_gated_split_sequences_are_bit_identical_to_the_persistent_for
     assert torch.equal(Hs, Hp) and torch.equal(Hs[:, -1:], Hsl)
     d = (Hs.float() - H16.float()).abs()
     assert float(d.max()) <= 2.5e-2 and float(d.mean()) <= 1.5e-3, (float(d.max()), float(d.mean()))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('N,K,B,T,gated', [(1000, 5, 100, 4, False), (1000, 5, 70, 3, True), (1000, 3, 128, 2, True), (1000, 4, 65, 1, True)])
+def test_wide_bptt_chain_split_sequences_are_bit_identical_to_the_persistent_form(N, K, B, T, gated, monkeypatch):
+    """The BPTT data chain at 65 <= B <= 128, F = 64 (training at the drivers' batch size 100, kStepPredGRNNs.py:168): two workgroups per
+    sequence, one launch per chain step (d h0 / the forget gate's step 0 as a launch of its own) -- the bits of the one-launch persistent
+    chain, with and without the inline layout of dH."""
+    from gated_gcrnns_amd import ops, _lib
+    dev = torch.device('cuda:0')
+    F = 64
+    cell, rng, S = _uniform_cell(N, F, F, K, 71)
+    cell = cell.to(dev)
+    dH = torch.tensor(rng.standard_normal((B, T, F, N)), dtype=torch.float32, device=dev).to(torch.bfloat16)
+    H = torch.tanh(torch.tensor(rng.standard_normal((B, T, F, N)), dtype=torch.float32, device=dev)).to(torch.bfloat16)
+    h0 = torch.tensor(0.3 * rng.standard_normal((B, F, N)), dtype=torch.float32, device=dev).to(torch.bfloat16)
+    gf = torch.tensor(rng.uniform(0.2, 0.9, (T, B)), dtype=torch.float32, device=dev) if gated else None
+    hs = ops.to_sequence_major(H, cell.graph)
+    h0s = ops.to_sequence_major(h0.view(B, 1, F, N), cell.graph)
+    wB = cell.weight_B.detach().float()
+
+    def run():
+        dHs, dHu = ops.fused_pack_upstream(dH, cell.graph, K)
+        if gated:
+            return ops.fused_backward_data(dHs, hs, wB, cell.graph, want_dh0=True, gf=gf, h0s=h0s, bias=cell.bias.detach().float(), dH_user=dHu)
+        return ops.fused_backward_data(dHs, hs, wB, cell.graph, want_dh0=True, dH_user=dHu)
+
+    p16 = cell.graph.fused_plan_img16(adjoint=True)
+    assert _lib.lib.gcrnn_fused_backward_data_wide_supported(B, T, N, F, K, int(p16['entries']), float(p16['uniform_w']), 1, 0) == 1      # split
+    got = run()
+    monkeypatch.setenv('GCRNN_NO_INLINE_PACK', '1')
+    got2 = run()
+    monkeypatch.delenv('GCRNN_NO_INLINE_PACK')
+    monkeypatch.setenv('GCRNN_SEQ32_MIN_B', '1')      # the persistent chain
+    want = run()
+    monkeypatch.delenv('GCRNN_SEQ32_MIN_B')
+    monkeypatch.setenv('GCRNN_SEQ32_SPLIT', '0')
+    assert _lib.lib.gcrnn_fused_backward_data_wide_supported(B, T, N, F, K, int(p16['entries']), float(p16['uniform_w']), 1, 0) == 0
+    assert len(got) == len(want)
+    for a_, b_, c_ in zip(got, got2, want):
+        assert torch.equal(a_, b_) and torch.equal(a_, c_)
