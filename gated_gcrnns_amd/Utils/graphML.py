@@ -384,6 +384,8 @@ class GGCRNNCell(nn.Module):
             return self._forward_fused(X, h0)
         if self._use_fused_x3_training(X, h0):
             return ops.fused_cell_train_x3(X, h0, self.weight_A, self.weight_B, self.bias, self.graph)
+        if self._use_fused_x3_training(X, h0, time_gated=True):
+            return ops.fused_cell_train_x3_gated(X, h0, self.weight_A, self.weight_B, self.bias, self.graph, self._fused_gates())
         if self._use_fused_node(X, h0):
             return self._forward_fused_node(X, h0)
         if self._use_fused_edge(X, h0):
@@ -668,19 +670,25 @@ class GGCRNNCell(nn.Module):
             return False
         return ops.fused_x3_supported(self.graph, self.N, self.F, self.G, self.Kin, self.Kst, X.dtype, self.E, X.shape[0], X.shape[1])
 
-    def _use_fused_x3_training(self, X, h0):
+    def _use_fused_x3_training(self, X, h0, time_gated=False):
         """fp32 training of the un-gated cell at the north_star's tolerance on the fused kernels (x3 forward, x3 data chain, exact-fp32
-        weight gradient): fp32 tensors and parameters, uniform-weight graph (forward and adjoint), gradients for the parameters and h0."""
+        weight gradient): fp32 tensors and parameters, uniform-weight graph (forward and adjoint), gradients for the parameters and h0.
+        time_gated=True (r4): the same question for the time-gated cell (ops.fused_cell_train_x3_gated: gradients for every parameter,
+        the gates' sub-cells and read-outs included; none for h0)."""
         if not torch.is_grad_enabled() or X.requires_grad:
             return False
         if not (h0.requires_grad or any(p.requires_grad for p in self.parameters())):
             return False
-        if self.time_gating == True or self.spatial_gating is not None or self.sigma not in (torch.tanh, nn.functional.tanh):  # noqa: E712
+        if (self.time_gating == True) != bool(time_gated) or self.spatial_gating is not None or self.sigma not in (torch.tanh, nn.functional.tanh):  # noqa: E712
             return False
         if X.dtype != torch.float32 or h0.dtype != X.dtype or self.weight_A.dtype != X.dtype or os.environ.get('GCRNN_NO_X3_TRAINING'):
             return False
         if ops.small_supported(self.N, self.graph.fwd[0].nnz, self.G, self.F, self.Kin, self.Kst, X.dtype, self.E):
             return False
+        if time_gated:
+            if h0.requires_grad or self.GFL_in.weight_A.dtype != X.dtype or os.environ.get('GCRNN_NO_X3_GATED'):
+                return False
+            return ops.fused_x3_time_training_supported(self.graph, self.N, self.F, self.G, self.Kin, self.Kst, X.dtype, self.E, X.shape[0], X.shape[1])
         return ops.fused_x3_training_supported(self.graph, self.N, self.F, self.G, self.Kin, self.Kst, X.dtype, self.E, X.shape[0], X.shape[1])
 
     def _use_fused_training(self, X, h0):

@@ -93,7 +93,9 @@ __global__ __launch_bounds__(STHREADS) void fused_step_x3_kernel(
     int entries, int B, int N, float uni_w,
     const uint16_t* __restrict__ aux0_3,               // EPI 2: planes of the upstream gradient dH_{t-1} [3][B][NP][F] (or null)
     const uint16_t* __restrict__ aux1_3,               // EPI 2: planes of the state h_{t-1} [3][B][NP][F] (or null)
-    const float* __restrict__ bscale) {                // EPI 0 (or null): per-sequence weight of the bias [B] instead of 2 (time-gated cell: gi + gf)
+    const float* __restrict__ bscale,                  // EPI 0 (or null): per-sequence weight of the bias [B] instead of 2 (time-gated cell: gi + gf);
+                                                       // EPI 2 (or null): per-sequence forget gate [B] of the step back-propagated (scales the hops' output)
+    float* __restrict__ gpart) {                       // EPI 2 (or null; needs aux1): [B][F/16 * 8] partials of <h_{t-1}, adjoint chain of dpre_t> = d loss / d gf_t
   static_assert(GCRNN_HOP_ASM && GCRNN_STEP_WAVES == 8, "x3 runs on the one-block asm hop stream");
   constexpr int KS = HS + XS, F = 32 * HS, G = 32 * XS, NCH = F / FC, HT = STILES;
   constexpr int WPL = K * KS * 64;            // uint4 fragments per weight plane and chunk
@@ -216,6 +218,7 @@ __global__ __launch_bounds__(STHREADS) void fused_step_x3_kernel(
     }
     // ---- epilogue: bias, tanh, three planes of h_t; fp32 user-layout copy through an LDS transpose in two node halves ------
     constexpr int LASTU = (K > 1) ? 0 : 0;
+    [[maybe_unused]] float part = 0.f;
 #pragma unroll
     for (int i = 0; i < STILES; ++i) {
       int wv = woff[i];
@@ -225,6 +228,8 @@ __global__ __launch_bounds__(STHREADS) void fused_step_x3_kernel(
       const int eoff = node * (F * 2) + (chunk * FC + q * 4) * 2;
       if constexpr (EPI == 2) {
         // three planes -> fp32: v = v1 + v2 + v3 (exact: the planes were cut from one fp32 value); zero-length descriptors give 0
+        // time-gated cell: the hops' output sum_k S^k (dpre_t B_k^T) is the forget gate's gradient when dotted with h_{t-1} (adjoint identity:
+        // <B(S) h_{t-1}, dpre_t>), and enters d h_{t-1} scaled by gf_t (graphML.py:2420-2423 under autograd)
         auto gather3 = [&](const __amdgpu_buffer_rsrc_t& rs) {
           f32x4 v = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -237,8 +242,16 @@ __global__ __launch_bounds__(STHREADS) void fused_step_x3_kernel(
         };
         if (node < N) {
           o = u[i][LASTU];
+          f32x4 hv = {0.f, 0.f, 0.f, 0.f};
+          if (aux1_3) hv = gather3(rsrc_a1);
+          if (gpart) part = __builtin_fmaf(o[3], hv[3], __builtin_fmaf(o[2], hv[2], __builtin_fmaf(o[1], hv[1], __builtin_fmaf(o[0], hv[0], part))));
+          if (bscale) {
+            const float gsc = bscale[b];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) o[c] *= gsc;
+          }
           if (aux0_3) {
-            const f32x4 g = gather3(rsrc_a0), hv = gather3(rsrc_a1);
+            const f32x4 g = gather3(rsrc_a0);
 #pragma unroll
             for (int c = 0; c < 4; ++c) o[c] = (o[c] + g[c]) * (1.f - hv[c] * hv[c]);
           }
@@ -255,6 +268,13 @@ __global__ __launch_bounds__(STHREADS) void fused_step_x3_kernel(
       __builtin_amdgcn_raw_buffer_store_b64(u32x2{(uint32_t)p1[0] | ((uint32_t)p1[1] << 16), (uint32_t)p1[2] | ((uint32_t)p1[3] << 16)}, rsrc_o, eoff, (1 * B + b) * (NP * F * 2), 0);
       __builtin_amdgcn_raw_buffer_store_b64(u32x2{(uint32_t)p2[0] | ((uint32_t)p2[1] << 16), (uint32_t)p2[2] | ((uint32_t)p2[3] << 16)}, rsrc_o, eoff, (2 * B + b) * (NP * F * 2), 0);
       u[i][LASTU] = o;
+    }
+    if constexpr (EPI == 2) {
+      if (gpart) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) part += __shfl_down(part, off, 64);
+        if (lane == 0) gpart[((int64_t)b * NCH + chunk) * 8 + wave] = part;
+      }
     }
     if (Huser) {
       constexpr int RS = 512 * 4 + 16;                    // row stride of the transposed half tile [16 f][512 nodes] fp32
@@ -308,7 +328,7 @@ int x3_launch(const void* xs3, const void* h03, void* hs3, const void* wpack3, c
     float* hu = !Huser ? nullptr : (!last_only ? Huser + t * F * N : (t == T - 1 ? Huser : nullptr));
     kern<<<(unsigned)(slots * NCH), STHREADS, lds, st>>>(x + t * xstep, hp, h + t * hstep, (const uint4*)wpack3, bias, tile_nodes, tile_off,
                                                         (const uint2*)ell_col4, hu, hu_stride ? hu_stride : (int64_t)(last_only ? 1 : T) * F * N, (int)entries, (int)B,
-                                                        (int)N, uni_w, nullptr, nullptr, bscale ? bscale + t * B : nullptr);
+                                                        (int)N, uni_w, nullptr, nullptr, bscale ? bscale + t * B : nullptr, nullptr);
   }
   GCRNN_CHECK_LAUNCH();
   return GCRNN_OK;
@@ -329,7 +349,7 @@ __global__ void bwd_seed_x3_kernel(const uint16_t* __restrict__ dH3, const uint1
 template <int K, int HS>
 int x3_backward_launch(const void* dHs3, const void* hs3, void* dpre3, void* dh03, const void* wpack3T, const int32_t* tile_nodes,
                        const int32_t* tile_off, const void* ell_col4, int64_t entries, int64_t B, int64_t T, int64_t N, float uni_w,
-                       hipStream_t st) {
+                       hipStream_t st, const float* gf = nullptr, const void* h03 = nullptr, float* gparts = nullptr) {
   constexpr int F = 32 * HS, NCH = F / FC;
   const size_t lds = (size_t)NP * FC * 4 + (size_t)3 * K * HS * 1024 + (size_t)entries * 32;
   if (lds > 160 * 1024) return GCRNN_ERR_UNSUPPORTED;
@@ -348,10 +368,32 @@ int x3_backward_launch(const void* dHs3, const void* hs3, void* dpre3, void* dh0
   for (int64_t t = T - 1; t >= 1; --t)
     kern<<<(unsigned)(slots * NCH), STHREADS, lds, st>>>(nullptr, dp + t * hstep, dp + (t - 1) * hstep, (const uint4*)wpack3T, nullptr, tile_nodes,
                                                         tile_off, (const uint2*)ell_col4, nullptr, 0, (int)entries, (int)B, (int)N, uni_w,
-                                                        dH + (t - 1) * hstep, hs + (t - 1) * hstep, nullptr);
-  if (dh03)
+                                                        dH + (t - 1) * hstep, hs + (t - 1) * hstep, gf ? gf + t * B : nullptr,
+                                                        gparts ? gparts + t * B * (NCH * 8) : nullptr);
+  if (dh03)      // the raw gradient of the initial state (scaled by gf_0); with gparts: d loss / d gf_0 against the planes of h0
     kern<<<(unsigned)(slots * NCH), STHREADS, lds, st>>>(nullptr, dp, (uint16_t*)dh03, (const uint4*)wpack3T, nullptr, tile_nodes, tile_off,
-                                                        (const uint2*)ell_col4, nullptr, 0, (int)entries, (int)B, (int)N, uni_w, nullptr, nullptr, nullptr);
+                                                        (const uint2*)ell_col4, nullptr, 0, (int)entries, (int)B, (int)N, uni_w, nullptr,
+                                                        gparts ? (const uint16_t*)h03 : nullptr, gf, gparts);
+  GCRNN_CHECK_LAUNCH();
+  return GCRNN_OK;
+}
+
+// One raw filter pass sum_k S^k (z W_k) on the x3 step kernel (the chain step without an epilogue operand): z3 / out3 [3][B][NP][F] planes
+template <int K, int HS>
+int x3_filter_launch(const void* z3, void* out3, const void* wpack3, const int32_t* tile_nodes, const int32_t* tile_off, const void* ell_col4,
+                     int64_t entries, int64_t B, int64_t N, float uni_w, hipStream_t st) {
+  constexpr int F = 32 * HS, NCH = F / FC;
+  const size_t lds = (size_t)NP * FC * 4 + (size_t)3 * K * HS * 1024 + (size_t)entries * 32;
+  if (lds > 160 * 1024) return GCRNN_ERR_UNSUPPORTED;
+  auto kern = fused_step_x3_kernel<K, HS, 0, 2>;
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    return GCRNN_ERR_LAUNCH;
+  int64_t slots = cdiv(B, 8) * 8;
+  const int64_t max_slots = (256 / NCH) / 8 * 8 > 0 ? (256 / NCH) / 8 * 8 : 8;
+  if (slots > max_slots) slots = max_slots;
+  GCRNN_PRE_LAUNCH();
+  kern<<<(unsigned)(slots * NCH), STHREADS, lds, st>>>(nullptr, (const uint16_t*)z3, (uint16_t*)out3, (const uint4*)wpack3, nullptr, tile_nodes, tile_off,
+                                                      (const uint2*)ell_col4, nullptr, 0, (int)entries, (int)B, (int)N, uni_w, nullptr, nullptr, nullptr, nullptr);
   GCRNN_CHECK_LAUNCH();
   return GCRNN_OK;
 }
@@ -380,7 +422,8 @@ __global__ __launch_bounds__(512) void fused_wgrad_f32_kernel(
     float* __restrict__ dW,                  // [slots][F][K][F+G] fp32 partial sums (plain stores)
     float* __restrict__ dbsum,               // [slots][F] fp32 partials of 2 sum_{t,b,n} dpre (or null)
     const int32_t* __restrict__ tile_nodes, const int32_t* __restrict__ tile_off, const uint2* __restrict__ ell_col4,
-    int entries, int B, int Tn, int N, float uni_w) {
+    int entries, int B, int Tn, int N, float uni_w,
+    const float* __restrict__ gi, const float* __restrict__ gf) {      // time-gated cell (or null): item (t, b) enters the input / state columns with weight gi / gf [T][B]
   static_assert(GCRNN_HOP_ASM && TILES == 8, "uniform asm hop stream");
   constexpr int F = 32 * HS, G = 32 * XS, C = F + G, NCH = F / FC, JT = C / 16, HT = TILES;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -433,6 +476,9 @@ __global__ __launch_bounds__(512) void fused_wgrad_f32_kernel(
     else if (t > 0) { zsrc = Huser + ((int64_t)b * Tn + (t - 1)) * F * N; zrows = F; }
     else { zsrc = h0user + (int64_t)b * F * N; zrows = F; }
     const __amdgpu_buffer_rsrc_t rsrc_z = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(zsrc), 0, has_tile ? zrows * N * 4 : 0, 0x00020000);
+    // gi (A(S) x_t + b) + gf (B(S) h_{t-1} + b): the operand columns scaled in fp32 (exactly the forward's scaled operands), the one bias weighted gi + gf
+    const float zsc = gi ? (is_x ? gi[it] : gf[it]) : 1.f;
+    const float bsc = gi ? gi[it] + gf[it] : 2.f;
     // du_0 = dpre chunk of this item, fp32 from its planes
     f32x4 cur[TILES];
 #pragma unroll
@@ -448,7 +494,7 @@ __global__ __launch_bounds__(512) void fused_wgrad_f32_kernel(
         v[2] += bf2f((uint16_t)(w2[1] & 0xffffu)); v[3] += bf2f((uint16_t)(w2[1] >> 16));
       }
       cur[i] = v;
-      bacc += v;
+      bacc += bsc * v;
     }
 #pragma unroll
     for (int k = 0; k < K; ++k) {
@@ -474,6 +520,12 @@ __global__ __launch_bounds__(512) void fused_wgrad_f32_kernel(
             zz[mm] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_z, zo, 0, 0));
           }
         };
+        auto scale_z = [&](f32x4 (&zz)[8]) {
+          if (gi) {
+#pragma unroll
+            for (int mm = 0; mm < 8; ++mm) zz[mm] *= zsc;
+          }
+        };
         auto mma8 = [&](int m0, const f32x4 (&zz)[8]) {
           f32x4 da[8];
 #pragma unroll
@@ -488,8 +540,10 @@ __global__ __launch_bounds__(512) void fused_wgrad_f32_kernel(
 #pragma unroll 1
         for (int m0 = 0; m0 < NP / 16; m0 += 16) {
           load_z(m0 + 8, z1);
+          scale_z(z0);
           mma8(m0, z0);
           if (m0 + 16 < NP / 16) load_z(m0 + 16, z0);
+          scale_z(z1);
           mma8(m0 + 8, z1);
         }
       }
@@ -518,7 +572,7 @@ __global__ __launch_bounds__(512) void fused_wgrad_f32_kernel(
       float v = bacc[c];
 #pragma unroll
       for (int off = 1; off < 16; off <<= 1) v += __shfl_xor(v, off, 64);
-      if (r == 0) lred[wave * FC + q * 4 + c] = 2.f * v;              // the one bias enters both filters
+      if (r == 0) lred[wave * FC + q * 4 + c] = v;                    // (weight 2 -- or gi + gf -- already in: the one bias enters both filters)
     }
     __syncthreads();
     if (tid < FC) {
@@ -533,7 +587,7 @@ __global__ __launch_bounds__(512) void fused_wgrad_f32_kernel(
 template <int K, int HS, int XS>
 int x3_wgrad_launch(const void* dpre3, const void* Xuser, const void* Huser, const void* h0user, float* dW, float* dbsum,
                     const int32_t* tile_nodes, const int32_t* tile_off, const void* ell_col4, int64_t entries, int64_t B, int64_t T,
-                    int64_t N, float uni_w, hipStream_t st) {
+                    int64_t N, float uni_w, hipStream_t st, const float* gi = nullptr, const float* gf = nullptr) {
   constexpr int F = 32 * HS, NCH = F / FC;
   const size_t lds = (size_t)NP * FC * 4 + (size_t)entries * 32 + 16 * DUT_STRIDE + WAVES * FC * 4;
   if (lds > 160 * 1024) return GCRNN_ERR_UNSUPPORTED;
@@ -543,7 +597,7 @@ int x3_wgrad_launch(const void* dpre3, const void* Xuser, const void* Huser, con
   const int64_t slots = gcrnn_fused_wgrad_slots(B * T, F);
   GCRNN_PRE_LAUNCH();
   kern<<<(unsigned)(slots * NCH), 512, lds, st>>>((const uint16_t*)dpre3, (const float*)Xuser, (const float*)Huser, (const float*)h0user, dW, dbsum,
-                                                   tile_nodes, tile_off, (const uint2*)ell_col4, (int)entries, (int)B, (int)T, (int)N, uni_w);
+                                                   tile_nodes, tile_off, (const uint2*)ell_col4, (int)entries, (int)B, (int)T, (int)N, uni_w, gi, gf);
   GCRNN_CHECK_LAUNCH();
   return GCRNN_OK;
 }
@@ -650,6 +704,46 @@ extern "C" int gcrnn_fused_backward_data_x3(const void* dHs3, const void* hs3, v
   return GCRNN_ERR_UNSUPPORTED;
 }
 
+// The same chain for the TIME-GATED cell (graphML.py:2357-2374, 2420-2423 under autograd): dpre_{t-1} = (gf_t sum_k S^k (dpre_t B_k^T) + dH_{t-1})
+// (1 - h_{t-1}^2), gf [T][B] fp32; dh03 (required) receives gf_0 times the raw gradient of the initial state. dgf_parts (or NULL; needs h03 =
+// the planes of h0 [3][B][NPad][F]): [T][B][F/16 * 8] fp32 partials of <h_{t-1}, sum_k S^k (dpre_t B_k^T)> = <B(S) h_{t-1}, dpre_t>, the
+// filter part of d loss / d gf_t (the caller adds them in a fixed order and the bias part).
+extern "C" int gcrnn_fused_backward_data_x3_gated(const void* dHs3, const void* hs3, void* dpre3, void* dh03, const void* wpack3T,
+                                                  const int32_t* tile_nodes, const int32_t* tile_off, const void* ell_col4, int64_t entries,
+                                                  int64_t B, int64_t T, int64_t N, int64_t F, int64_t K, double uniform_w, const float* gf,
+                                                  const void* h03, float* dgf_parts, void* stream) {
+  if (!dHs3 || !hs3 || !dpre3 || !dh03 || !wpack3T || !tile_nodes || !tile_off || !ell_col4 || !gf) return GCRNN_ERR_NULL_POINTER;
+  if (dgf_parts && !h03) return GCRNN_ERR_NULL_POINTER;
+  if (B <= 0 || T <= 0 || uniform_w == 0.0 || !gcrnn_fused_x3_supported(N, F, F, K, entries)) return GCRNN_ERR_BAD_SHAPE;
+  if (3 * B * (NP * F * 2) > 2147483647LL) return GCRNN_ERR_BAD_SHAPE;
+  hipStream_t st = as_stream(stream);
+#define GCRNN_X3B_CASE(KK, HH) \
+  if (K == KK && F == 32 * HH) return x3_backward_launch<KK, HH>(dHs3, hs3, dpre3, dh03, wpack3T, tile_nodes, tile_off, ell_col4, entries, B, T, N, (float)uniform_w, st, gf, h03, dgf_parts);
+  GCRNN_X3B_CASE(5, 2) GCRNN_X3B_CASE(4, 2) GCRNN_X3B_CASE(3, 2) GCRNN_X3B_CASE(2, 2)
+  GCRNN_X3B_CASE(5, 1) GCRNN_X3B_CASE(4, 1) GCRNN_X3B_CASE(3, 1) GCRNN_X3B_CASE(2, 1)
+#undef GCRNN_X3B_CASE
+  return GCRNN_ERR_UNSUPPORTED;
+}
+
+// One graph filter without bias or nonlinearity at fp32 accuracy: out = sum_k S^k (z W_k) (Utils/graphML.py:47-140 LSIGF), z3 / out3
+// [3][B][NPad][F] bf16 planes (F features in and out), wpack3 = the filter's taps packed as a state-only operand
+// (gcrnn_fused_pack_weights_x3 with G = 0), graph arrays of a uniform plan. The time-gated BPTT reads d loss / d gi_t = <A(S) x_t + b, dpre_t>
+// off it (items = all (t, b)).
+extern "C" int gcrnn_fused_filter_x3(const void* z3, void* out3, const void* wpack3, const int32_t* tile_nodes, const int32_t* tile_off,
+                                     const void* ell_col4, int64_t entries, int64_t B, int64_t N, int64_t F, int64_t K, double uniform_w,
+                                     void* stream) {
+  if (!z3 || !out3 || !wpack3 || !tile_nodes || !tile_off || !ell_col4) return GCRNN_ERR_NULL_POINTER;
+  if (B <= 0 || uniform_w == 0.0 || !gcrnn_fused_x3_supported(N, F, F, K, entries)) return GCRNN_ERR_BAD_SHAPE;
+  if (3 * B * (NP * F * 2) > 2147483647LL) return GCRNN_ERR_BAD_SHAPE;
+  hipStream_t st = as_stream(stream);
+#define GCRNN_X3F_CASE(KK, HH) \
+  if (K == KK && F == 32 * HH) return x3_filter_launch<KK, HH>(z3, out3, wpack3, tile_nodes, tile_off, ell_col4, entries, B, N, (float)uniform_w, st);
+  GCRNN_X3F_CASE(5, 2) GCRNN_X3F_CASE(4, 2) GCRNN_X3F_CASE(3, 2) GCRNN_X3F_CASE(2, 2)
+  GCRNN_X3F_CASE(5, 1) GCRNN_X3F_CASE(4, 1) GCRNN_X3F_CASE(3, 1) GCRNN_X3F_CASE(2, 1)
+#undef GCRNN_X3F_CASE
+  return GCRNN_ERR_UNSUPPORTED;
+}
+
 // fp32 weight gradient of the fused cell on exact-fp32 matrix instructions: dW [slots][F][K][F+G] / dbsum [slots][F] (or NULL) per-slot
 // partial sums (slots = gcrnn_fused_wgrad_slots(B T, F); the caller adds them in a fixed order), dpre3 from
 // gcrnn_fused_backward_data_x3, X / H / h0 fp32 in the USER layout (H = the forward's output), adjoint uniform plan.
@@ -664,6 +758,26 @@ extern "C" int gcrnn_fused_backward_weight_f32(const void* dpre3, const void* Xu
   hipStream_t st = as_stream(stream);
 #define GCRNN_WF_CASE(KK, HH, XX) \
   if (K == KK && F == 32 * HH && G == 32 * XX) return x3_wgrad_launch<KK, HH, XX>(dpre3, Xuser, Huser, h0user, dW, dbsum, tile_nodes, tile_off, ell_col4, entries, B, T, N, (float)uniform_w, st);
+  GCRNN_WF_CASE(5, 2, 2) GCRNN_WF_CASE(4, 2, 2) GCRNN_WF_CASE(3, 2, 2) GCRNN_WF_CASE(2, 2, 2)
+  GCRNN_WF_CASE(5, 2, 1) GCRNN_WF_CASE(4, 2, 1) GCRNN_WF_CASE(3, 2, 1) GCRNN_WF_CASE(2, 2, 1)
+  GCRNN_WF_CASE(5, 1, 1) GCRNN_WF_CASE(4, 1, 1) GCRNN_WF_CASE(3, 1, 1) GCRNN_WF_CASE(2, 1, 1)
+#undef GCRNN_WF_CASE
+  return GCRNN_ERR_UNSUPPORTED;
+}
+
+// The same weight gradient for the TIME-GATED cell: item (t, b) enters the input-filter columns with weight gi[t][b] and the state-filter
+// columns with gf[t][b] (operands scaled in fp32 as the forward scaled them), dbsum = per-slot partials of sum (gi + gf) sum_n dpre.
+extern "C" int gcrnn_fused_backward_weight_f32_gated(const void* dpre3, const void* Xuser, const void* Huser, const void* h0user, float* dW,
+                                                     float* dbsum, const int32_t* tile_nodes, const int32_t* tile_off, const void* ell_col4,
+                                                     int64_t entries, int64_t B, int64_t T, int64_t N, int64_t F, int64_t G, int64_t K,
+                                                     double uniform_w, const float* gi, const float* gf, void* stream) {
+  if (!dpre3 || !Xuser || !Huser || !h0user || !dW || !tile_nodes || !tile_off || !ell_col4 || !gi || !gf) return GCRNN_ERR_NULL_POINTER;
+  if (B <= 0 || T <= 0 || N <= 0 || N > NP || N % 4 || entries < 0 || entries % 4 || uniform_w == 0.0 || B * T > (1 << 24)) return GCRNN_ERR_BAD_SHAPE;
+  if (3 * B * (NP * F * 2) > 2147483647LL || (int64_t)(F > G ? F : G) * N * 4 > 2147483647LL) return GCRNN_ERR_BAD_SHAPE;
+  if ((reinterpret_cast<uintptr_t>(Xuser) | reinterpret_cast<uintptr_t>(Huser) | reinterpret_cast<uintptr_t>(h0user)) & 15) return GCRNN_ERR_BAD_SHAPE;
+  hipStream_t st = as_stream(stream);
+#define GCRNN_WF_CASE(KK, HH, XX) \
+  if (K == KK && F == 32 * HH && G == 32 * XX) return x3_wgrad_launch<KK, HH, XX>(dpre3, Xuser, Huser, h0user, dW, dbsum, tile_nodes, tile_off, ell_col4, entries, B, T, N, (float)uniform_w, st, gi, gf);
   GCRNN_WF_CASE(5, 2, 2) GCRNN_WF_CASE(4, 2, 2) GCRNN_WF_CASE(3, 2, 2) GCRNN_WF_CASE(2, 2, 2)
   GCRNN_WF_CASE(5, 2, 1) GCRNN_WF_CASE(4, 2, 1) GCRNN_WF_CASE(3, 2, 1) GCRNN_WF_CASE(2, 2, 1)
   GCRNN_WF_CASE(5, 1, 1) GCRNN_WF_CASE(4, 1, 1) GCRNN_WF_CASE(3, 1, 1) GCRNN_WF_CASE(2, 1, 1)

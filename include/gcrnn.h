@@ -262,6 +262,29 @@ int gcrnn_fused_backward_weight_f32(const void* dpre3, const void* Xuser, const 
                                     float* dbsum, const int32_t* tile_nodes, const int32_t* tile_off, const void* ell_col4,
                                     int64_t entries, int64_t B, int64_t T, int64_t N, int64_t F, int64_t G, int64_t K,
                                     double uniform_w, void* stream);
+/* fp32-accurate BPTT of the TIME-GATED cell (round 4; Utils/graphML.py:2357-2374 + 2420-2423 under autograd -- the reference's default
+ * cell, :2196, in the drivers' precision, kStepPredGRNNs.py:44):
+ * gcrnn_fused_backward_data_x3_gated: dpre_{t-1} = (gf_t sum_k S^k (dpre_t B_k^T) + dH_{t-1}) (1 - h_{t-1}^2), gf [T][B] fp32; dh03 (required)
+ *   receives gf_0 x the raw gradient of the initial state; dgf_parts (or NULL; needs h03 = planes of h0 [3][B][NPad][F]):
+ *   [T][B][F/16 * 8] fp32 partials of <h_{t-1}, sum_k S^k (dpre_t B_k^T)> = <B(S) h_{t-1}, dpre_t> (adjoint identity), the filter part of
+ *   d loss / d gf_t, added by the caller in a fixed order.
+ * gcrnn_fused_filter_x3: ONE graph filter without bias or nonlinearity (Utils/graphML.py:47-140 LSIGF) out = sum_k S^k (z W_k), z3 / out3
+ *   [3][B][NPad][F] planes, wpack3 = gcrnn_fused_pack_weights_x3 of the taps with G = 0 (F features in and out), uniform plan: d loss / d gi_t
+ *   = <A(S) x_t + b, dpre_t> is read off A(S) x_t over all items (t, b).
+ * gcrnn_fused_backward_weight_f32_gated: gcrnn_fused_backward_weight_f32 with item (t, b) entering the input-filter columns with weight
+ *   gi[t][b] and the state-filter columns with gf[t][b] (fp32 scaling of the operand, as the forward scaled it); dbsum = partials of
+ *   sum (gi + gf) sum_n dpre. */
+int gcrnn_fused_backward_data_x3_gated(const void* dHs3, const void* hs3, void* dpre3, void* dh03, const void* wpack3T,
+                                       const int32_t* tile_nodes, const int32_t* tile_off, const void* ell_col4, int64_t entries,
+                                       int64_t B, int64_t T, int64_t N, int64_t F, int64_t K, double uniform_w, const float* gf,
+                                       const void* h03, float* dgf_parts, void* stream);
+int gcrnn_fused_filter_x3(const void* z3, void* out3, const void* wpack3, const int32_t* tile_nodes, const int32_t* tile_off,
+                          const void* ell_col4, int64_t entries, int64_t B, int64_t N, int64_t F, int64_t K, double uniform_w,
+                          void* stream);
+int gcrnn_fused_backward_weight_f32_gated(const void* dpre3, const void* Xuser, const void* Huser, const void* h0user, float* dW,
+                                          float* dbsum, const int32_t* tile_nodes, const int32_t* tile_off, const void* ell_col4,
+                                          int64_t entries, int64_t B, int64_t T, int64_t N, int64_t F, int64_t G, int64_t K,
+                                          double uniform_w, const float* gi, const float* gf, void* stream);
 
 
 /* LDS placement of the hop state (tile = 16). node_addr[n] = (row << 6) | (swz << 4): node n's 64-byte state row sits at

@@ -403,6 +403,49 @@ def g11_fused_f32():
          grad_l1=g_l1, grad_l1_h0=h0t.grad.numpy())
 
 
+def g12_fused_f32_time():
+    """G12 (round 4): G11's graph, shapes and operand recipe for the TIME-GATED cell (the reference's default, graphML.py:2196): fp64
+    reference states and autograd gradients of EVERY parameter -- the cell's taps and bias, both gate sub-cells (GFL_in / GFL_forget) and
+    both read-outs (MLP_in / MLP_forget) -- for the losses H.sum() and L1 (miscTools.py:112-119); non-zero h0 so that the gate cells' state
+    taps get a gradient. The fp32-accurate fused training (ops.fused_cell_train_x3_gated) is compared at <= 1e-5 (H) / <= 2e-5 of each
+    gradient's max."""
+    N, T, G, F, K, B = 200, 4, 32, 32, 3, 3
+    rng = np.random.default_rng(29)
+    U = np.triu(rng.random((N, N)) < 0.05, 1)
+    W = (U + U.T).astype(np.float64)
+    lam = np.max(np.linalg.eigvalsh(W))
+    w32 = np.float32(1.0 / lam)
+    S = (W * np.float64(w32)).reshape(1, N, N)
+    f32 = lambda a: np.asarray(a, dtype=np.float32).astype(np.float64)
+    X = f32(rng.standard_normal((B, T, G, N)))
+    h0 = f32(0.5 * rng.standard_normal((B, F, N)))
+    target = f32(rng.standard_normal((B, T, F, N)))
+    rows, cols = np.nonzero(S[0])
+    torch.manual_seed(92)
+    cell = gml.GGCRNNCell(G, F, K, K, torch.tanh, True, None, 1, True)
+    cell.addGSO(torch.tensor(S))
+    with torch.no_grad():
+        for name, q in cell.named_parameters():
+            if name.startswith('MLP_'):
+                q.mul_(6.0)                              # read-outs of F N = 6400 inputs: default init leaves the gates within 1e-2 of 0.5
+        for q in cell.parameters():
+            q.copy_(torch.tensor(f32(q.detach().numpy())))
+    p = sd_np(cell)
+    H = cell(torch.tensor(X), torch.tensor(h0))
+    check(orc.ggcrnn_cell(p, S, X, h0, True, None), H.detach().numpy(), 'G12')
+    cell.zero_grad()
+    H.sum().backward(retain_graph=True)
+    g_sum = grads_np(cell)
+    cell.zero_grad()
+    torch.nn.L1Loss()(H, torch.tensor(target)).backward()
+    g_l1 = grads_np(cell)
+    used = {k: v for k, v in g_sum.items() if not k.startswith(('GFL_out', 'MLP_out'))}      # (created but never used by the reference's forward)
+    assert len(used) == 13 and all(v is not None and np.abs(v).max() > 0 for v in used.values()), list(used)
+    save('g12_fused_f32_time', coo_row=rows.astype(np.int16), coo_col=cols.astype(np.int16), coo_val=S[0][rows, cols].astype(np.float32),
+         shape=np.array([N, T, G, F, K, B]), X=X.astype(np.float32), h0=h0.astype(np.float32), target=target.astype(np.float32),
+         H=H.detach().numpy(), params={k: v.astype(np.float32) for k, v in p.items()}, grad_sum=g_sum, grad_l1=g_l1)
+
+
 def g10_kstep_data():
     """The reference's KStepPrediction dataset (Utils/dataTools.py:1259-1317) on a reference SBM graph
     (Utils/graphTools.py createGraph 'SBM'), with the numpy global generator seeded: stores the graph, the noise arrays the
@@ -458,4 +501,5 @@ if __name__ == '__main__':
     g9_fused_bptt_edge()
     g10_kstep_data()
     g11_fused_f32()
+    g12_fused_f32_time()
     print('all oracle checks passed at tol', TOL)

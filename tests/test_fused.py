@@ -1945,6 +1945,78 @@ def test_fp32_accurate_fused_training_matches_reference_autograd_fixture(golden,
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('loss', ['sum', 'l1'])
+def test_fp32_accurate_fused_time_gated_training_matches_reference_autograd_fixture(golden, loss):
+    """G12: the north_star's 1e-5 mode for what the drivers train -- the TIME-GATED cell (the reference's default,
+    Utils/graphML.py:2196) -- on fused kernels: gate cells and scaled recurrence on the x3 step kernel, gated x3 data chain (the forget
+    gate's gradient read off it), d gi off one x3 filter pass, exact-fp32 weight gradients with the gates as operand weights, the gate
+    cells' BPTT over the items; against the REFERENCE's autograd in fp64 (tests/golden/make_golden.py g12_fused_f32_time:
+    Utils/graphML.py:2336-2427 under torch autograd, fp32-representable operands). H <= 1e-5 abs; every one of the 13 gradients <= 2e-5
+    of its max."""
+    g = golden('g12_fused_f32_time')
+    dev = torch.device('cuda:0')
+    cell, S = _g9_cell(g, True, None, dev)
+    X = torch.tensor(g['X'], dtype=torch.float32, device=dev)
+    h0 = torch.tensor(g['h0'], dtype=torch.float32, device=dev)
+    assert cell._use_fused_x3_training(X, h0, time_gated=True) and not cell._use_fused_x3_training(X, h0)
+    H = cell(X, h0)
+    assert H.dtype == torch.float32 and type(H.grad_fn).__name__ == '_FusedTimeCellX3Backward'
+    assert float((H.detach().double().cpu() - torch.tensor(g['H'])).abs().max()) <= 1e-5
+    if loss == 'sum':
+        H.sum().backward()
+        want = g['grad_sum']
+    else:
+        torch.nn.functional.l1_loss(H, torch.tensor(g['target'], device=dev)).backward()
+        want = g['grad_l1']
+    got = dict(cell.named_parameters())
+    assert len(want) == 13
+    report = {}
+    for k, gr in want.items():
+        e = np.abs(got[k].grad.double().cpu().numpy() - gr)
+        sc = float(np.abs(gr).max())
+        report[k] = e.max() / sc
+        assert sc > 0 and e.max() <= 2e-5 * sc, (k, e.max() / sc)
+    _tol_report('x3 time-gated training vs G12 (%s): worst gradient error / max = %.2e (%s)' % (loss, max(report.values()), max(report, key=report.get)))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('N,F,G,K,B,T,hz', [(1000, 64, 64, 5, 3, 4, True), (1000, 64, 1, 3, 2, 3, False), (600, 32, 32, 4, 4, 3, True)])
+def test_fp32_accurate_fused_time_gated_training_matches_composed_autograd(N, F, G, K, B, T, hz, monkeypatch):
+    """The same at the bench's sizes against the composed fp32 path (exact fp32 kernels, golden-pinned since round 1), zero h0 (every
+    training loop of the reference, train_rnn.py:256) and non-zero h0, G = 1 input feature (padded channels) included: every gradient
+    <= 2e-5 of its max, H <= 1e-5; two runs give the same bits (no atomics)."""
+    dev = torch.device('cuda:0')
+    cell, rng, _ = _uniform_cell(N, G, F, K, True, 99, dev, dtype=None)
+    with torch.no_grad():
+        cell.MLP_in[0].weight.mul_(6.0)
+        cell.MLP_forget[0].weight.mul_(6.0)
+    X = torch.tensor(rng.standard_normal((B, T, G, N)), dtype=torch.float32, device=dev)
+    h0 = torch.zeros(B, F, N, device=dev) if hz else torch.tensor(0.3 * rng.standard_normal((B, F, N)), dtype=torch.float32, device=dev)
+    tgt = torch.tensor(rng.standard_normal((B, T, F, N)), dtype=torch.float32, device=dev)
+
+    def step():
+        cell.zero_grad(set_to_none=True)
+        H = cell(X, h0)
+        torch.nn.functional.l1_loss(H, tgt).backward()
+        return H.detach().clone(), {n: p.grad.clone() for n, p in cell.named_parameters() if p.grad is not None}
+
+    assert cell._use_fused_x3_training(X, h0, time_gated=True)
+    H1, g1 = step()
+    H2, g2 = step()
+    assert torch.equal(H1, H2) and all(torch.equal(g1[k], g2[k]) for k in g1)
+    monkeypatch.setenv('GCRNN_NO_X3_TRAINING', '1')
+    assert not cell._use_fused_x3_training(X, h0, time_gated=True)
+    H0, g0 = step()
+    assert float((H0 - H1).abs().max()) <= 1e-5 and g0.keys() == g1.keys() and len(g1) == 13
+    for k in g1:
+        sc = float(g0[k].abs().max())
+        if sc == 0.0:      # (zero h0: the gate cells' state taps see a zero operand)
+            assert float(g1[k].abs().max()) == 0.0, k
+            continue
+        assert float((g0[k] - g1[k]).abs().max()) <= 2e-5 * sc, (k, float((g0[k] - g1[k]).abs().max()) / sc)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('N,F,G,K,B,T', [(1000, 64, 64, 5, 3, 4), (1000, 64, 1, 3, 2, 3), (600, 32, 32, 4, 4, 3)])
 def test_fp32_accurate_fused_training_matches_composed_autograd(N, F, G, K, B, T, monkeypatch):
     """The same at the bench's sizes against the composed fp32 path (exact fp32 kernels, golden-pinned since round 1): every

@@ -172,3 +172,17 @@ def test_oracle_reproduces_g11_states(golden):
     p = {k: v.astype(np.float64) for k, v in g['params'].items()}
     H = orc.ggcrnn_cell(p, S, g['X'].astype(np.float64), g['h0'].astype(np.float64), False, None)
     assert np.max(np.abs(H - g['H'])) <= 1e-12
+
+
+def test_oracle_reproduces_g12_states(golden):
+    """G12 (G11's recipe for the TIME-GATED cell, fp64 states): the oracle reproduces the reference to 1e-12; the fixture holds the
+    reference's autograd gradient of every parameter the forward uses (cell, both gate sub-cells, both read-outs)."""
+    g = golden('g12_fused_f32_time')
+    N, T, G, F, K, B = (int(v) for v in g['shape'])
+    S = np.zeros((1, N, N))
+    S[0, g['coo_row'].astype(np.int64), g['coo_col'].astype(np.int64)] = g['coo_val'].astype(np.float64)
+    assert len(np.unique(g['coo_val'])) == 1 and np.array_equal(S[0], S[0].T)
+    p = {k: v.astype(np.float64) for k, v in g['params'].items()}
+    H = orc.ggcrnn_cell(p, S, g['X'].astype(np.float64), g['h0'].astype(np.float64), True, None)
+    assert np.max(np.abs(H - g['H'])) <= 1e-12
+    assert set(g['grad_sum']) == set(g['grad_l1']) and len(g['grad_sum']) == 13
