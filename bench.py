@@ -659,6 +659,24 @@ def secondary_points(ctx, S, params, B, steps=8, warmup=2):
                 sec['fwd_timegated_f32_x3'] = {'value': B / dt, 'unit': 'sequences/s', 'ms_per_step': 1e3 * dt, 'steps': 3, 'dtype': 'f32',
                                                'tolerance': '<= 1e-5 abs against the fp64 oracle (tests/test_fused.py)',
                                                'what': 'GGCRNNCell(time_gating=True) forward on the fp32-accurate fused kernels'}
+        # ... and ONE optimiser step of the time-gated cell in the same precision (what the reference's drivers train, in their precision:
+        # train_rnn.py:247-281 under kStepPredGRNNs.py:44): G12, every gradient <= 2e-5 of its max against the reference's autograd
+        with torch.enable_grad():
+            if c._use_fused_x3_training(X, h0, time_gated=True):
+                target = torch.randn(B, T, F, N, device=dev, dtype=torch.float32, generator=gen)
+                opt = FlatAdam(c.parameters(), lr=1e-3)
+
+                def tg32():
+                    opt.zero_grad()
+                    batchTimeL1Loss(c(X, h0), target).backward()
+                    opt.step()
+
+                dt = _timed(tg32, 2, 1)
+                sec['train_timegated_f32_x3'] = {'value': B / dt, 'unit': 'sequences/s', 'ms_per_step': 1e3 * dt, 'steps': 2, 'dtype': 'f32',
+                                                 'tolerance': 'gradients <= 2e-5 of their max against the reference autograd (tests G12)',
+                                                 'what': 'gate cells + scaled recurrence (x3), gated x3 data chain, x3 filter pass (d gi), exact-fp32 '
+                                                         'weight gradients of the cell and both gate cells, FlatAdam'}
+                del target, opt
         del c, X, h0
     except Exception as e:      # noqa: BLE001
         sec['fwd_timegated_f32_x3'] = {'error': str(e)[:200]}

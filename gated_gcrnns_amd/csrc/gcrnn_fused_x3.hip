@@ -23,18 +23,26 @@ __device__ __forceinline__ void split3(float v, uint16_t& a, uint16_t& b, uint16
 }
 
 // user fp32 [B][T][C][N]  ->  three bf16 planes, sequence-major [T][3][B][NPad][C], rows N..NPad-1 zero
+// Optional pre-operation, fused so that the scaled / derived tensor never exists in fp32: v' = item_scale[t][b] * rowmul[c][n] * (OMS ? 1 - v^2 : v)
+// (each factor optional) -- the time-gated cell's scaled operands gi x_t, gf h_{t-1} and its gate cells' upstream gradient
+// d logit[t][b] * w[c][n] * (1 - c^2) (graphML.py:2362-2374 under autograd).
 __global__ __launch_bounds__(256) void seq_pack_x3_kernel(const float* __restrict__ src, uint16_t* __restrict__ dst, int B, int Tn, int C,
-                                                          int N, int NPad) {
+                                                          int N, int NPad, const float* __restrict__ item_scale = nullptr,
+                                                          const float* __restrict__ rowmul = nullptr, int oms = 0, int64_t sstride = 0) {
   __shared__ float tile[32][33];
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
   const int n0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
   const int bt = blockIdx.z, b = bt / Tn, t = bt - b * Tn;
-  const int64_t ubase = ((int64_t)(b * Tn + t) * C) * N;
+  const int64_t ubase = sstride ? (int64_t)b * sstride + (int64_t)t * C * N : ((int64_t)(b * Tn + t) * C) * N;      // (sstride: elements between the sequences of src)
   const int n = n0 + tx;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int c = c0 + ty + 8 * i;
-    tile[ty + 8 * i][tx] = (c < C && n < N) ? src[ubase + (int64_t)c * N + n] : 0.f;
+    float v = (c < C && n < N) ? src[ubase + (int64_t)c * N + n] : 0.f;
+    if (oms) v = 1.f - v * v;
+    if (rowmul && c < C && n < N) v = rowmul[(int64_t)c * N + n] * v;
+    if (item_scale) v = item_scale[t * B + b] * v;
+    tile[ty + 8 * i][tx] = (c < C && n < N) ? v : 0.f;
   }
   __syncthreads();
   const int cp = threadIdx.x & 15, nr = threadIdx.x >> 4;             // 16 column pairs x 16 rows per pass
@@ -75,6 +83,40 @@ __global__ void pack_weights_x3_kernel(const float* __restrict__ wA, const float
   uint16_t a, b, c;
   split3(v, a, b, c);
   out[idx] = a; out[idx + total] = b; out[idx + 2 * total] = c;
+}
+
+// per item (t, b): <a, b> over the item's NPad x C elements (fp32 re-assembled from the planes) and <a, 1 vec^T> (vec [C] fp32: the bias part of
+// a gate's gradient); one workgroup per item, fixed summation order
+__global__ __launch_bounds__(256) void x3_item_dots_kernel(const uint16_t* __restrict__ a3, const uint16_t* __restrict__ b3, const float* __restrict__ vec,
+                                                           float* __restrict__ out_ab, float* __restrict__ out_av, int B, int NPad, int C) {
+  const int it = blockIdx.x, t = it / B, b = it - t * B;
+  const int64_t plane = (int64_t)B * NPad * C, base = ((int64_t)t * 3 * B + b) * NPad * C;
+  const int per = NPad * C / 2;                       // pairs (C even)
+  float sab = 0.f, sav = 0.f;
+  for (int i = threadIdx.x; i < per; i += 256) {
+    const int c = (2 * i) % C;
+    float av[2] = {0.f, 0.f}, bv[2] = {0.f, 0.f};
+#pragma unroll
+    for (int p = 2; p >= 0; --p) {
+      const uint32_t wa = *reinterpret_cast<const uint32_t*>(a3 + base + p * plane + 2 * (int64_t)i);
+      av[0] += bf2f((uint16_t)(wa & 0xffffu)); av[1] += bf2f((uint16_t)(wa >> 16));
+      if (b3) {
+        const uint32_t wb = *reinterpret_cast<const uint32_t*>(b3 + base + p * plane + 2 * (int64_t)i);
+        bv[0] += bf2f((uint16_t)(wb & 0xffffu)); bv[1] += bf2f((uint16_t)(wb >> 16));
+      }
+    }
+    sab = __builtin_fmaf(av[1], bv[1], __builtin_fmaf(av[0], bv[0], sab));
+    if (vec) sav = __builtin_fmaf(av[1], vec[c + 1], __builtin_fmaf(av[0], vec[c], sav));
+  }
+  __shared__ float red[2][4];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) { sab += __shfl_down(sab, off, 64); sav += __shfl_down(sav, off, 64); }
+  if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = sab; red[1][threadIdx.x >> 6] = sav; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    if (out_ab) out_ab[it] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+    if (out_av) out_av[it] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+  }
 }
 
 // EPI 0: forward step (bias, tanh).  EPI 2 (XS = 0): BPTT data-gradient step in the same arithmetic -- operand = the planes of
@@ -309,7 +351,7 @@ __global__ __launch_bounds__(STHREADS) void fused_step_x3_kernel(
 template <int K, int HS, int XS>
 int x3_launch(const void* xs3, const void* h03, void* hs3, const void* wpack3, const float* bias, const int32_t* tile_nodes,
               const int32_t* tile_off, const void* ell_col4, int64_t entries, int64_t B, int64_t T, int64_t N, float uni_w, float* Huser,
-              int last_only, hipStream_t st, const float* bscale = nullptr, int64_t hu_stride = 0) {
+              int last_only, hipStream_t st, const float* bscale = nullptr, int64_t hu_stride = 0, int fixed_state = 0) {
   constexpr int F = 32 * HS, G = 32 * XS, KS = HS + XS, NCH = F / FC;
   const size_t lds = (size_t)NP * FC * 4 + (size_t)3 * K * KS * 1024 + (size_t)entries * 32;
   if (lds > 160 * 1024) return GCRNN_ERR_UNSUPPORTED;
@@ -324,9 +366,10 @@ int x3_launch(const void* xs3, const void* h03, void* hs3, const void* wpack3, c
   uint16_t* h = (uint16_t*)hs3;
   GCRNN_PRE_LAUNCH();
   for (int64_t t = 0; t < T; ++t) {
-    const uint16_t* hp = (t == 0) ? (const uint16_t*)h03 : h + (t - 1) * hstep;
+    // (fixed_state: every step reads h03 and writes its planes over the same block -- T independent one-step cells, the time gates' sub-cells)
+    const uint16_t* hp = (t == 0 || fixed_state) ? (const uint16_t*)h03 : h + (t - 1) * hstep;
     float* hu = !Huser ? nullptr : (!last_only ? Huser + t * F * N : (t == T - 1 ? Huser : nullptr));
-    kern<<<(unsigned)(slots * NCH), STHREADS, lds, st>>>(x + t * xstep, hp, h + t * hstep, (const uint4*)wpack3, bias, tile_nodes, tile_off,
+    kern<<<(unsigned)(slots * NCH), STHREADS, lds, st>>>(x + t * xstep, hp, fixed_state ? h : h + t * hstep, (const uint4*)wpack3, bias, tile_nodes, tile_off,
                                                         (const uint2*)ell_col4, hu, hu_stride ? hu_stride : (int64_t)(last_only ? 1 : T) * F * N, (int)entries, (int)B,
                                                         (int)N, uni_w, nullptr, nullptr, bscale ? bscale + t * B : nullptr, nullptr);
   }
@@ -423,7 +466,8 @@ __global__ __launch_bounds__(512) void fused_wgrad_f32_kernel(
     float* __restrict__ dbsum,               // [slots][F] fp32 partials of 2 sum_{t,b,n} dpre (or null)
     const int32_t* __restrict__ tile_nodes, const int32_t* __restrict__ tile_off, const uint2* __restrict__ ell_col4,
     int entries, int B, int Tn, int N, float uni_w,
-    const float* __restrict__ gi, const float* __restrict__ gf) {      // time-gated cell (or null): item (t, b) enters the input / state columns with weight gi / gf [T][B]
+    const float* __restrict__ gi, const float* __restrict__ gf,        // time-gated cell (or null): item (t, b) enters the input / state columns with weight gi / gf [T][B]
+    int h_is_h0) {                                                     // != 0: every item's state operand is h0 (the time gates' sub-cells); a null state pointer = zeros: its tiles are skipped
   static_assert(GCRNN_HOP_ASM && TILES == 8, "uniform asm hop stream");
   constexpr int F = 32 * HS, G = 32 * XS, C = F + G, NCH = F / FC, JT = C / 16, HT = TILES;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -473,9 +517,10 @@ __global__ __launch_bounds__(512) void fused_wgrad_f32_kernel(
     const float* zsrc;
     int zrows;
     if (is_x) { zsrc = Xuser + ((int64_t)b * Tn + t) * G * N; zrows = G; }
-    else if (t > 0) { zsrc = Huser + ((int64_t)b * Tn + (t - 1)) * F * N; zrows = F; }
-    else { zsrc = h0user + (int64_t)b * F * N; zrows = F; }
-    const __amdgpu_buffer_rsrc_t rsrc_z = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(zsrc), 0, has_tile ? zrows * N * 4 : 0, 0x00020000);
+    else if (t > 0 && !h_is_h0) { zsrc = Huser + ((int64_t)b * Tn + (t - 1)) * F * N; zrows = F; }
+    else { zsrc = h0user ? h0user + (int64_t)b * F * N : nullptr; zrows = F; }
+    const bool tile_on = has_tile && zsrc != nullptr;      // (wave-uniform: a zero state operand contributes nothing)
+    const __amdgpu_buffer_rsrc_t rsrc_z = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(zsrc), 0, tile_on ? zrows * N * 4 : 0, 0x00020000);
     // gi (A(S) x_t + b) + gf (B(S) h_{t-1} + b): the operand columns scaled in fp32 (exactly the forward's scaled operands), the one bias weighted gi + gf
     const float zsc = gi ? (is_x ? gi[it] : gf[it]) : 1.f;
     const float bsc = gi ? gi[it] + gf[it] : 2.f;
@@ -509,7 +554,7 @@ __global__ __launch_bounds__(512) void fused_wgrad_f32_kernel(
         for (int c = 0; c < 4; ++c) *reinterpret_cast<float*>(dut + (q * 4 + c) * DUT_STRIDE + node * 4) = cur[i][c];
       }
       lds_barrier();
-      if (has_tile) {
+      if (tile_on) {
         // D_k += du_k^T z: 64 groups of 16 nodes, 4 exact-fp32 MFMAs each. The z fragments of the NEXT eight groups are requested
         // before the 32 MFMAs of the current eight (two register sets, ping-pong): the L2 latency hides under 1024 matrix cycles.
         auto load_z = [&](int m0, f32x4 (&zz)[8]) {
@@ -587,7 +632,7 @@ __global__ __launch_bounds__(512) void fused_wgrad_f32_kernel(
 template <int K, int HS, int XS>
 int x3_wgrad_launch(const void* dpre3, const void* Xuser, const void* Huser, const void* h0user, float* dW, float* dbsum,
                     const int32_t* tile_nodes, const int32_t* tile_off, const void* ell_col4, int64_t entries, int64_t B, int64_t T,
-                    int64_t N, float uni_w, hipStream_t st, const float* gi = nullptr, const float* gf = nullptr) {
+                    int64_t N, float uni_w, hipStream_t st, const float* gi = nullptr, const float* gf = nullptr, int h_is_h0 = 0) {
   constexpr int F = 32 * HS, NCH = F / FC;
   const size_t lds = (size_t)NP * FC * 4 + (size_t)entries * 32 + 16 * DUT_STRIDE + WAVES * FC * 4;
   if (lds > 160 * 1024) return GCRNN_ERR_UNSUPPORTED;
@@ -597,7 +642,7 @@ int x3_wgrad_launch(const void* dpre3, const void* Xuser, const void* Huser, con
   const int64_t slots = gcrnn_fused_wgrad_slots(B * T, F);
   GCRNN_PRE_LAUNCH();
   kern<<<(unsigned)(slots * NCH), 512, lds, st>>>((const uint16_t*)dpre3, (const float*)Xuser, (const float*)Huser, (const float*)h0user, dW, dbsum,
-                                                   tile_nodes, tile_off, (const uint2*)ell_col4, (int)entries, (int)B, (int)T, (int)N, uni_w, gi, gf);
+                                                   tile_nodes, tile_off, (const uint2*)ell_col4, (int)entries, (int)B, (int)T, (int)N, uni_w, gi, gf, h_is_h0);
   GCRNN_CHECK_LAUNCH();
   return GCRNN_OK;
 }
@@ -619,6 +664,37 @@ extern "C" int gcrnn_pack_seq_major_x3(const void* src, void* dst, int64_t B, in
   GCRNN_PRE_LAUNCH();
   seq_pack_x3_kernel<<<dim3((unsigned)cdiv(NPad, 32), (unsigned)cdiv(C, 32), (unsigned)(B * T)), 256, 0, as_stream(stream)>>>(
       (const float*)src, (uint16_t*)dst, (int)B, (int)T, (int)C, (int)N, (int)NPad);
+  GCRNN_CHECK_LAUNCH();
+  return GCRNN_OK;
+}
+
+// gcrnn_pack_seq_major_x3 of a derived tensor: v' = item_scale[t][b] * rowmul[c][n] * (one_minus_square ? 1 - v^2 : v), every factor optional
+// (item_scale [T][B], rowmul [C][N] fp32 or NULL); src_seq_stride: elements between consecutive sequences of src (0 = T C N: contiguous; one
+// step of a [B][T'][C][N] tensor is T = 1 with stride T' C N). The time-gated cell at fp32 accuracy packs its scaled operands gi x_t / gf h_{t-1} and its
+// gate cells' upstream gradient d logit * w * (1 - c^2) with it (Utils/graphML.py:2362-2374, 2420-2423 and their autograd).
+extern "C" int gcrnn_pack_seq_major_x3_ex(const void* src, void* dst, int64_t B, int64_t T, int64_t C, int64_t N, int64_t NPad,
+                                          const float* item_scale, const float* rowmul, int one_minus_square, int64_t src_seq_stride,
+                                          void* stream) {
+  if (!src || !dst) return GCRNN_ERR_NULL_POINTER;
+  if (B <= 0 || T <= 0 || C <= 0 || C % 2 || N <= 0 || NPad < N || B * T > 65535 || cdiv(C, 32) > 65535) return GCRNN_ERR_BAD_SHAPE;
+  if (src_seq_stride < 0 || (src_seq_stride && src_seq_stride < T * C * N)) return GCRNN_ERR_BAD_SHAPE;
+  GCRNN_PRE_LAUNCH();
+  seq_pack_x3_kernel<<<dim3((unsigned)cdiv(NPad, 32), (unsigned)cdiv(C, 32), (unsigned)(B * T)), 256, 0, as_stream(stream)>>>(
+      (const float*)src, (uint16_t*)dst, (int)B, (int)T, (int)C, (int)N, (int)NPad, item_scale, rowmul, one_minus_square, src_seq_stride);
+  GCRNN_CHECK_LAUNCH();
+  return GCRNN_OK;
+}
+
+// Per item (t, b) of plane arrays a3, b3 [T][3][B][NPad][C]: out_ab[t][b] = <a, b> (b3 / out_ab may be NULL), out_av[t][b] = sum_{n,c} a[n][c]
+// vec[c] (vec [C] fp32; vec / out_av may be NULL), fp32 values re-assembled from the planes, fixed summation order. The time-gated BPTT
+// reads d loss / d gi_t = <A(S) x_t, dpre_t> + <b, sum_n dpre_t> off it.
+extern "C" int gcrnn_x3_item_dots(const void* a3, const void* b3, const float* vec, float* out_ab, float* out_av, int64_t B, int64_t T,
+                                  int64_t NPad, int64_t C, void* stream) {
+  if (!a3 || (b3 && !out_ab) || (vec && !out_av)) return GCRNN_ERR_NULL_POINTER;
+  if (B <= 0 || T <= 0 || NPad <= 0 || C <= 0 || C % 2 || B * T > 2147483647LL) return GCRNN_ERR_BAD_SHAPE;
+  GCRNN_PRE_LAUNCH();
+  x3_item_dots_kernel<<<(unsigned)(B * T), 256, 0, as_stream(stream)>>>((const uint16_t*)a3, (const uint16_t*)b3, vec, b3 ? out_ab : nullptr,
+                                                                        vec ? out_av : nullptr, (int)B, (int)NPad, (int)C);
   GCRNN_CHECK_LAUNCH();
   return GCRNN_OK;
 }
@@ -677,6 +753,30 @@ extern "C" int gcrnn_fused_forward_x3_scaled(const void* xs3, const void* h03, v
   if (K == KK && F == 32 * HH && G == 32 * XX) \
     return x3_launch<KK, HH, XX>(xs3, h03, hs3, wpack3, bias, tile_nodes, tile_off, ell_col4, entries, B, T, N, (float)uniform_w, (float*)Huser, 0, st, \
                                  bias_scale, huser_seq_stride);
+  GCRNN_X3_CASE(5, 2, 2) GCRNN_X3_CASE(4, 2, 2) GCRNN_X3_CASE(3, 2, 2) GCRNN_X3_CASE(2, 2, 2)
+  GCRNN_X3_CASE(5, 2, 1) GCRNN_X3_CASE(4, 2, 1) GCRNN_X3_CASE(3, 2, 1) GCRNN_X3_CASE(2, 2, 1)
+  GCRNN_X3_CASE(5, 1, 1) GCRNN_X3_CASE(4, 1, 1) GCRNN_X3_CASE(3, 1, 1) GCRNN_X3_CASE(2, 1, 1)
+#undef GCRNN_X3_CASE
+  return GCRNN_ERR_UNSUPPORTED;
+}
+
+// The time gates' sub-cells at fp32 accuracy (Utils/graphML.py:2362-2366): T x B independent ONE-step cells c[t][b] = tanh(A_g(S) x_t + B_g(S) h0
+// + 2 b_g), every one from the same initial state: gcrnn_fused_forward_x3 whose every step reads h03 (xs3 [T][3][B][NPad][G] the planes of X as
+// the recurrence packs them -- no per-item copies of X or h0). scratch3 [3][B][NPad][F] receives (and re-receives) a step's planes; Cuser fp32
+// [B][T][F][N] the gate states, user layout.
+extern "C" int gcrnn_fused_gate_cells_x3(const void* xs3, const void* h03, void* scratch3, const void* wpack3, const float* bias,
+                                         const int32_t* tile_nodes, const int32_t* tile_off, const void* ell_col4, int64_t entries,
+                                         int64_t B, int64_t T, int64_t N, int64_t F, int64_t G, int64_t K, double uniform_w, void* Cuser,
+                                         void* stream) {
+  if (!xs3 || !h03 || !scratch3 || !wpack3 || !tile_nodes || !tile_off || !ell_col4 || !Cuser) return GCRNN_ERR_NULL_POINTER;
+  if (B <= 0 || T <= 0 || uniform_w == 0.0 || !gcrnn_fused_x3_supported(N, F, G, K, entries)) return GCRNN_ERR_BAD_SHAPE;
+  if (3 * B * (NP * (F > G ? F : G) * 2) > 2147483647LL) return GCRNN_ERR_BAD_SHAPE;
+  if (reinterpret_cast<uintptr_t>(Cuser) & 15) return GCRNN_ERR_BAD_SHAPE;
+  hipStream_t st = as_stream(stream);
+#define GCRNN_X3_CASE(KK, HH, XX) \
+  if (K == KK && F == 32 * HH && G == 32 * XX) \
+    return x3_launch<KK, HH, XX>(xs3, h03, scratch3, wpack3, bias, tile_nodes, tile_off, ell_col4, entries, B, T, N, (float)uniform_w, (float*)Cuser, 0, st, \
+                                 nullptr, 0, 1);
   GCRNN_X3_CASE(5, 2, 2) GCRNN_X3_CASE(4, 2, 2) GCRNN_X3_CASE(3, 2, 2) GCRNN_X3_CASE(2, 2, 2)
   GCRNN_X3_CASE(5, 2, 1) GCRNN_X3_CASE(4, 2, 1) GCRNN_X3_CASE(3, 2, 1) GCRNN_X3_CASE(2, 2, 1)
   GCRNN_X3_CASE(5, 1, 1) GCRNN_X3_CASE(4, 1, 1) GCRNN_X3_CASE(3, 1, 1) GCRNN_X3_CASE(2, 1, 1)
@@ -766,18 +866,21 @@ extern "C" int gcrnn_fused_backward_weight_f32(const void* dpre3, const void* Xu
 }
 
 // The same weight gradient for the TIME-GATED cell: item (t, b) enters the input-filter columns with weight gi[t][b] and the state-filter
-// columns with gf[t][b] (operands scaled in fp32 as the forward scaled them), dbsum = per-slot partials of sum (gi + gf) sum_n dpre.
+// columns with gf[t][b] (operands scaled in fp32 as the forward scaled them), dbsum = per-slot partials of sum (gi + gf) sum_n dpre
+// (gi = gf = NULL: weights 1 and 2). h_is_h0 != 0: every item's state operand is h0 (the time gates' sub-cells read (x_t, h0),
+// graphML.py:2362-2374; Huser unused); h0user = NULL then means a zero initial state (train_rnn.py:256): the state columns stay zero.
 extern "C" int gcrnn_fused_backward_weight_f32_gated(const void* dpre3, const void* Xuser, const void* Huser, const void* h0user, float* dW,
                                                      float* dbsum, const int32_t* tile_nodes, const int32_t* tile_off, const void* ell_col4,
                                                      int64_t entries, int64_t B, int64_t T, int64_t N, int64_t F, int64_t G, int64_t K,
-                                                     double uniform_w, const float* gi, const float* gf, void* stream) {
-  if (!dpre3 || !Xuser || !Huser || !h0user || !dW || !tile_nodes || !tile_off || !ell_col4 || !gi || !gf) return GCRNN_ERR_NULL_POINTER;
+                                                     double uniform_w, const float* gi, const float* gf, int h_is_h0, void* stream) {
+  if (!dpre3 || !Xuser || !dW || !tile_nodes || !tile_off || !ell_col4 || (!gi) != (!gf)) return GCRNN_ERR_NULL_POINTER;
+  if (!h_is_h0 && (!Huser || !h0user)) return GCRNN_ERR_NULL_POINTER;
   if (B <= 0 || T <= 0 || N <= 0 || N > NP || N % 4 || entries < 0 || entries % 4 || uniform_w == 0.0 || B * T > (1 << 24)) return GCRNN_ERR_BAD_SHAPE;
   if (3 * B * (NP * F * 2) > 2147483647LL || (int64_t)(F > G ? F : G) * N * 4 > 2147483647LL) return GCRNN_ERR_BAD_SHAPE;
   if ((reinterpret_cast<uintptr_t>(Xuser) | reinterpret_cast<uintptr_t>(Huser) | reinterpret_cast<uintptr_t>(h0user)) & 15) return GCRNN_ERR_BAD_SHAPE;
   hipStream_t st = as_stream(stream);
 #define GCRNN_WF_CASE(KK, HH, XX) \
-  if (K == KK && F == 32 * HH && G == 32 * XX) return x3_wgrad_launch<KK, HH, XX>(dpre3, Xuser, Huser, h0user, dW, dbsum, tile_nodes, tile_off, ell_col4, entries, B, T, N, (float)uniform_w, st, gi, gf);
+  if (K == KK && F == 32 * HH && G == 32 * XX) return x3_wgrad_launch<KK, HH, XX>(dpre3, Xuser, Huser, h0user, dW, dbsum, tile_nodes, tile_off, ell_col4, entries, B, T, N, (float)uniform_w, st, gi, gf, h_is_h0);
   GCRNN_WF_CASE(5, 2, 2) GCRNN_WF_CASE(4, 2, 2) GCRNN_WF_CASE(3, 2, 2) GCRNN_WF_CASE(2, 2, 2)
   GCRNN_WF_CASE(5, 2, 1) GCRNN_WF_CASE(4, 2, 1) GCRNN_WF_CASE(3, 2, 1) GCRNN_WF_CASE(2, 2, 1)
   GCRNN_WF_CASE(5, 1, 1) GCRNN_WF_CASE(4, 1, 1) GCRNN_WF_CASE(3, 1, 1) GCRNN_WF_CASE(2, 1, 1)

@@ -1640,12 +1640,14 @@ def fused_x3_time_training_supported(graph, N, F, G, Kin, Kst, dtype, E=1, B=Non
 
 class _FusedTimeCellX3(torch.autograd.Function):
     """Time-gated GGCRNNCell (the reference's default, Utils/graphML.py:2196, :2357-2374, :2420-2423) at fp32 accuracy on the fused kernels,
-    forward AND BPTT (round 4). Forward: the two gate cells as one un-gated x3 step from h0 per item (t, b) + the Linear(F N -> 1) read-out;
-    the recurrence as scaled x3 steps (fused_cell_forward_x3_gated), keeping the states' planes. Backward: the gated x3 data chain
-    (gcrnn_fused_backward_data_x3_gated; the forget gate's gradient is read off the chain), d loss / d gi off one x3 filter pass A(S) x_t,
-    the cell's weight gradient on exact-fp32 matrix instructions with the gates as operand weights (gcrnn_fused_backward_weight_f32_gated),
-    and the gate cells' gradients: read-out by one GEMV over the kept gate states, taps / biases by the same weight-gradient kernel over the
-    items. Gradients for every parameter; X and h0 get none (the training loops never ask: train_rnn.py:256 starts from zeros)."""
+    forward AND BPTT (round 4). Forward: the two gate cells as T x B one-step x3 cells that all read h0 (gcrnn_fused_gate_cells_x3, on the
+    planes of X) + the Linear(F N -> 1) read-out; the recurrence as scaled x3 steps (operands scaled while they are cut into planes), keeping
+    the states' planes. Backward: the gated x3 data chain (gcrnn_fused_backward_data_x3_gated; the forget gate's gradient is read off the
+    chain), d loss / d gi off one x3 filter pass A(S) x_t (gcrnn_fused_filter_x3 + gcrnn_x3_item_dots), the cell's weight gradient on
+    exact-fp32 matrix instructions with the gates as operand weights (gcrnn_fused_backward_weight_f32_gated), and the gate cells' gradients:
+    read-out by one GEMV over the kept gate states, taps / biases by the same weight-gradient kernel over all items (state operand = h0,
+    skipped when it is zero). Gradients for every parameter; X and h0 get none (the training loops never ask: train_rnn.py:256 starts from
+    zeros)."""
 
     @staticmethod
     def forward(ctx, X, h0, wA, wB, bias, gA_i, gB_i, gb_i, lw_i, lb_i, gA_f, gB_f, gb_f, lw_f, lb_f, graph):
@@ -1656,28 +1658,32 @@ class _FusedTimeCellX3(torch.autograd.Function):
         K = max(Kin, Kst)
         plan = graph.fused_plan()
         npad, st, dev = plan['npad'], _stream(), X.device
-        Xp = Xp.contiguous()
+        Xp = Xp.float().contiguous()
         h0c = h0.detach().float().contiguous()
+        hzero = not bool(h0c.any())
+        gargs = (_p(plan['tile_slots']), _p(plan['tile_off']), _p(plan['ell_col4']), plan['entries'])
+        xs3 = torch.empty((T, 3, B, npad, Gp), dtype=torch.bfloat16, device=dev)
+        check(lib.gcrnn_pack_seq_major_x3(_p(Xp), _p(xs3), B, T, Gp, N, npad, st), 'pack_seq_x3')
+        h03 = torch.empty((1, 3, B, npad, F), dtype=torch.bfloat16, device=dev)
+        check(lib.gcrnn_pack_seq_major_x3(_p(h0c), _p(h03), B, 1, F, N, npad, st), 'pack_seq_x3')
+        h3 = torch.empty((1, 3, B, npad, F), dtype=torch.bfloat16, device=dev)
         gates, cs = [], []
         for (wA_g, wB_g, bias_g, lin_w, lin_b) in ((gA_i, gB_i, gb_i, lw_i, lb_i), (gA_f, gB_f, gb_f, lw_f, lb_f)):
-            lw = lin_w.detach().float().reshape(-1)
-            logit = torch.empty((T, B), dtype=torch.float32, device=dev)
-            c_all = torch.empty((T * B, F, N), dtype=torch.float32, device=dev)      # item = t B + b: the gate cell's state, kept for its BPTT
-            for t0, nt in _x3_item_slices(B, T):
-                Xi = Xp[:, t0:t0 + nt].permute(1, 0, 2, 3).reshape(nt * B, 1, Gp, N)
-                h0i = h0c.unsqueeze(0).expand(nt, B, F, N).reshape(nt * B, F, N)
-                c = fused_cell_forward_x3(Xi, h0i, wA_g.detach(), wB_g.detach(), bias_g.detach() if bias_g is not None else None, graph)
-                c_all[t0 * B:(t0 + nt) * B] = c.view(nt * B, F, N)
-                logit[t0:t0 + nt] = (c.reshape(nt * B, F * N) @ lw).view(nt, B)
+            Kg = max(wA_g.shape[2], wB_g.shape[2])
+            wAg, wBg = wA_g.detach().float().contiguous(), wB_g.detach().float().contiguous()
+            wpg = torch.empty((3 * (F // 16) * Kg * ((F + Gp) // 32) * 64 * 8,), dtype=torch.bfloat16, device=dev)
+            check(lib.gcrnn_fused_pack_weights_x3(_p(wAg), _p(wBg), _p(wpg), F, Gp, wA_g.shape[2], wB_g.shape[2], st), 'pack_weights_x3')
+            bg = bias_g.detach().float().contiguous().view(-1) if bias_g is not None else None
+            c = torch.empty((B, T, F, N), dtype=torch.float32, device=dev)          # the gate cells' states, kept for their BPTT
+            check(lib.gcrnn_fused_gate_cells_x3(_p(xs3), _p(h03), _p(h3), _p(wpg), _p(bg), *gargs, B, T, N, F, Gp, Kg, plan['uniform_w'], _p(c), st),
+                  'fused_gate_cells_x3')
+            logit = (c.view(B * T, F * N) @ lin_w.detach().float().reshape(-1)).view(B, T).t()
             if lin_b is not None:
                 logit = logit + lin_b.detach().float().view(())
-            gates.append(torch.sigmoid(logit))
-            cs.append(c_all)
-        gi, gf = gates[0].contiguous(), gates[1].contiguous()                                        # [T][B]
-        Xs = (Xp * gi.t().reshape(B, T, 1, 1)).contiguous()
-        xs3 = torch.empty((T, 3, B, npad, Gp), dtype=torch.bfloat16, device=dev)
-        check(lib.gcrnn_pack_seq_major_x3(_p(Xs), _p(xs3), B, T, Gp, N, npad, st), 'pack_seq_x3')
-        del Xs
+            gates.append(torch.sigmoid(logit).contiguous())                          # [T][B]
+            cs.append(c)
+        gi, gf = gates
+        check(lib.gcrnn_pack_seq_major_x3_ex(_p(Xp), _p(xs3), B, T, Gp, N, npad, _p(gi), None, 0, 0, st), 'pack_seq_x3_ex')      # planes of gi x_t
         wAc, wBc = wAp.float().contiguous(), wB.detach().float().contiguous()
         wp3 = torch.empty((3 * (F // 16) * K * ((F + Gp) // 32) * 64 * 8,), dtype=torch.bfloat16, device=dev)
         check(lib.gcrnn_fused_pack_weights_x3(_p(wAc), _p(wBc), _p(wp3), F, Gp, Kin, Kst, st), 'pack_weights_x3')
@@ -1685,17 +1691,15 @@ class _FusedTimeCellX3(torch.autograd.Function):
         bsc = (gi + gf).contiguous()
         H = torch.empty((B, T, F, N), dtype=torch.float32, device=dev)
         hs3 = torch.empty((T, 3, B, npad, F), dtype=torch.bfloat16, device=dev)
-        h3 = torch.empty((1, 3, B, npad, F), dtype=torch.bfloat16, device=dev)
-        hprev = h0c
         for t in range(T):
-            hsc = (hprev * gf[t].view(B, 1, 1)).contiguous()
-            check(lib.gcrnn_pack_seq_major_x3(_p(hsc), _p(h3), B, 1, F, N, npad, st), 'pack_seq_x3')
-            check(lib.gcrnn_fused_forward_x3_scaled(_p(xs3[t]), _p(h3), _p(hs3[t]), _p(wp3), _p(b32), _p(bsc[t]), _p(plan['tile_slots']), _p(plan['tile_off']),
-                                                    _p(plan['ell_col4']), plan['entries'], B, 1, N, F, Gp, K, plan['uniform_w'], _p(H[:, t]), T * F * N, st),
-                  'fused_forward_x3_scaled')
-            hprev = H[:, t]
+            hprev = h0c if t == 0 else H[:, t - 1]
+            check(lib.gcrnn_pack_seq_major_x3_ex(_p(hprev), _p(h3), B, 1, F, N, npad, _p(gf[t]), None, 0, 0 if t == 0 else T * F * N, st),
+                  'pack_seq_x3_ex')                                                                  # planes of gf_t h_{t-1}
+            check(lib.gcrnn_fused_forward_x3_scaled(_p(xs3[t]), _p(h3), _p(hs3[t]), _p(wp3), _p(b32), _p(bsc[t]), *gargs, B, 1, N, F, Gp, K,
+                                                    plan['uniform_w'], _p(H[:, t]), T * F * N, st), 'fused_forward_x3_scaled')
+        del xs3
         ctx.save_for_backward(Xp, h0c, wA, wB, bias, gA_i, gB_i, gb_i, lw_i, lb_i, gA_f, gB_f, gb_f, lw_f, lb_f, H, hs3, gi, gf, cs[0], cs[1])
-        ctx.graph, ctx.G = graph, X.shape[2]
+        ctx.graph, ctx.G, ctx.hzero = graph, X.shape[2], hzero
         return H
 
     @staticmethod
@@ -1709,6 +1713,8 @@ class _FusedTimeCellX3(torch.autograd.Function):
         K = max(Kin, Kst)
         plan, pa = graph.fused_plan(), graph.fused_plan(adjoint=True)
         npad, st, dev = pa['npad'], _stream(), Xp.device
+        gargs = (_p(plan['tile_slots']), _p(plan['tile_off']), _p(plan['ell_col4']), plan['entries'])
+        aargs = (_p(pa['tile_slots']), _p(pa['tile_off']), _p(pa['ell_col4']), pa['entries'])
         nparts = (F // 16) * 8
         # ---- the gated data chain, d gf read off it ----
         dHc = dH.float().contiguous()
@@ -1725,89 +1731,69 @@ class _FusedTimeCellX3(torch.autograd.Function):
         dpre3 = torch.empty((T, 3, B, npad, F), dtype=torch.bfloat16, device=dev)
         dh03 = torch.empty((3, B, npad, F), dtype=torch.bfloat16, device=dev)
         parts = torch.empty((T, B, nparts), dtype=torch.float32, device=dev)
-        check(lib.gcrnn_fused_backward_data_x3_gated(_p(dH3), _p(hs3), _p(dpre3), _p(dh03), _p(wp3T), _p(pa['tile_slots']), _p(pa['tile_off']),
-                                                     _p(pa['ell_col4']), pa['entries'], B, T, N, F, K, pa['uniform_w'], _p(gf), _p(h03), _p(parts), st),
-              'fused_backward_data_x3_gated')
+        check(lib.gcrnn_fused_backward_data_x3_gated(_p(dH3), _p(hs3), _p(dpre3), _p(dh03), _p(wp3T), *aargs, B, T, N, F, K, pa['uniform_w'],
+                                                     _p(gf), _p(h03), _p(parts), st), 'fused_backward_data_x3_gated')
         del dH3, dh03
-        dpre = _x3_planes_to_f32(dpre3)                                                              # [T][B][NPad][F] fp32
-        colsum = dpre.sum(dim=2)                                                                     # [T][B][F]
-        cb = colsum @ bias.detach().float().view(-1) if bias is not None else torch.zeros((T, B), dtype=torch.float32, device=dev)
-        dgf = parts.sum(dim=2) + cb
-        # ---- d gi = <A(S) x_t + b, dpre_t>: one filter pass over all items (the input taps as an F -> F filter, zero columns beyond G) ----
+        # ---- d gi = <A(S) x_t + b, dpre_t>: one filter pass per step over the planes of X (the input taps as an F -> F filter, zero columns
+        # beyond G), dotted with dpre per item; the bias part <b, sum_n dpre_t> is shared with d gf ----
+        bvec = bias.detach().float().contiguous().view(-1) if bias is not None else torch.zeros(F, dtype=torch.float32, device=dev)
         wAk = wA.detach().float()[:, 0]                                                              # [F][Kin][G]
         wAsq = torch.zeros((F, K, F), dtype=torch.float32, device=dev)
         wAsq[:, :Kin, :wAk.shape[2]] = wAk
         wp3A = torch.empty((3 * (F // 16) * K * (F // 32) * 64 * 8,), dtype=torch.bfloat16, device=dev)
         check(lib.gcrnn_fused_pack_weights_x3(_p(wAsq), _p(wAsq), _p(wp3A), F, 0, K, K, st), 'pack_weights_x3')
+        Xf = Xp if Gp == F else torch.nn.functional.pad(Xp, (0, 0, 0, F - Gp)).contiguous()
+        z3 = torch.empty((T, 3, B, npad, F), dtype=torch.bfloat16, device=dev)
+        check(lib.gcrnn_pack_seq_major_x3(_p(Xf), _p(z3), B, T, F, N, npad, st), 'pack_seq_x3')
+        del Xf
+        y3 = torch.empty((T, 3, B, npad, F), dtype=torch.bfloat16, device=dev)
+        for t in range(T):
+            check(lib.gcrnn_fused_filter_x3(_p(z3[t]), _p(y3[t]), _p(wp3A), *gargs, B, N, F, K, plan['uniform_w'], st), 'fused_filter_x3')
+        del z3
         dgi = torch.empty((T, B), dtype=torch.float32, device=dev)
-        for t0, nt in _x3_item_slices(B, T):
-            items = nt * B
-            Xi = Xp[:, t0:t0 + nt].permute(1, 0, 2, 3).reshape(items, 1, Gp, N)
-            if Gp < F:
-                Xi = torch.nn.functional.pad(Xi, (0, 0, 0, F - Gp))
-            Xi = Xi.contiguous()
-            z3 = torch.empty((1, 3, items, npad, F), dtype=torch.bfloat16, device=dev)
-            check(lib.gcrnn_pack_seq_major_x3(_p(Xi), _p(z3), items, 1, F, N, npad, st), 'pack_seq_x3')
-            y3 = torch.empty((3, items, npad, F), dtype=torch.bfloat16, device=dev)
-            check(lib.gcrnn_fused_filter_x3(_p(z3), _p(y3), _p(wp3A), _p(plan['tile_slots']), _p(plan['tile_off']), _p(plan['ell_col4']),
-                                            plan['entries'], items, N, F, K, plan['uniform_w'], st), 'fused_filter_x3')
-            yx = _x3_planes_to_f32(y3)                                                               # [items][NPad][F]
-            dgi[t0:t0 + nt] = (yx * dpre[t0:t0 + nt].reshape(items, npad, F)).sum(dim=(1, 2)).view(nt, B)
-            del z3, y3, yx
+        cb = torch.empty((T, B), dtype=torch.float32, device=dev)
+        check(lib.gcrnn_x3_item_dots(_p(dpre3), _p(y3), _p(bvec), _p(dgi), _p(cb), B, T, npad, F, st), 'x3_item_dots')
+        del y3
         dgi = dgi + cb
-        del dpre
+        dgf = parts.sum(dim=2) + cb
         # ---- the cell's taps and bias: exact-fp32 weight gradient, the gates as operand weights ----
         slots = int(lib.gcrnn_fused_wgrad_slots(T * B, F))
         dWp = torch.zeros((slots, F, K, F + Gp), dtype=torch.float32, device=dev)
         dbp = torch.zeros((slots, F), dtype=torch.float32, device=dev)
-        check(lib.gcrnn_fused_backward_weight_f32_gated(_p(dpre3), _p(Xp), _p(H), _p(h0c), _p(dWp), _p(dbp), _p(pa['tile_slots']), _p(pa['tile_off']),
-                                                        _p(pa['ell_col4']), pa['entries'], B, T, N, F, Gp, K, pa['uniform_w'], _p(gi), _p(gf), st),
-              'fused_backward_weight_f32_gated')
+        check(lib.gcrnn_fused_backward_weight_f32_gated(_p(dpre3), _p(Xp), _p(H), _p(h0c), _p(dWp), _p(dbp), *aargs, B, T, N, F, Gp, K,
+                                                        pa['uniform_w'], _p(gi), _p(gf), 0, st), 'fused_backward_weight_f32_gated')
         dW = dWp.sum(dim=0)
         G = ctx.G
         need = ctx.needs_input_grad
         gA = dW[:, :Kin, F:F + G].unsqueeze(1).to(wA.dtype) if need[2] else None
         gB = dW[:, :Kst, :F].unsqueeze(1).to(wB.dtype) if need[3] else None
         gb = dbp.sum(dim=0).view_as(bias).to(bias.dtype) if (bias is not None and need[4]) else None
-        del dWp, dbp, dpre3
-        # ---- the gate cells: read-out by a GEMV over the kept states; taps / bias by the weight-gradient kernel over the items ----
+        del dWp, dbp
+        # ---- the gate cells: read-out by a GEMV over the kept states; taps / bias by the weight-gradient kernel over all items, the upstream
+        # gradient d logit * w * (1 - c^2) formed while it is cut into planes (dpre3's buffer is reused) ----
         out = []
-        for base, dgate, g, c_all, (wA_g, wB_g, bias_g, lin_w, lin_b) in ((5, dgi, gi, c_i, (gA_i, gB_i, gb_i, lw_i, lb_i)),
-                                                                          (10, dgf, gf, c_f, (gA_f, gB_f, gb_f, lw_f, lb_f))):
+        for base, dgate, g, c, (wA_g, wB_g, bias_g, lin_w, lin_b) in ((5, dgi, gi, c_i, (gA_i, gB_i, gb_i, lw_i, lb_i)),
+                                                                      (10, dgf, gf, c_f, (gA_f, gB_f, gb_f, lw_f, lb_f))):
             dlogit = (dgate * g * (1.0 - g)).contiguous()                                            # [T][B]
             Kg_in, Kg_st = wA_g.shape[2], wB_g.shape[2]
             Kg = max(Kg_in, Kg_st)
             Ggp = wA_g.shape[3]
-            g_lw = (dlogit.view(1, T * B) @ c_all.view(T * B, F * N)).view_as(lin_w).to(lin_w.dtype) if need[base + 3] else None
+            g_lw = (dlogit.t().reshape(1, B * T) @ c.view(B * T, F * N)).view_as(lin_w).to(lin_w.dtype) if need[base + 3] else None
             g_lb = dlogit.sum().view_as(lin_b).to(lin_b.dtype) if (lin_b is not None and need[base + 4]) else None
             g_wA = g_wB = g_b = None
             if need[base] or need[base + 1] or (bias_g is not None and need[base + 2]):
-                lwv = lin_w.detach().float().view(1, F, N)
-                dWg = torch.zeros((F, Kg, F + Ggp), dtype=torch.float32, device=dev)
-                dbg = torch.zeros((F,), dtype=torch.float32, device=dev)
-                for t0, nt in _x3_item_slices(B, T):
-                    items = nt * B
-                    cc = c_all[t0 * B:(t0 + nt) * B]
-                    dpg = (dlogit[t0:t0 + nt].reshape(items, 1, 1) * lwv * (1.0 - cc * cc)).view(items, 1, F, N).contiguous()
-                    dpg3 = torch.empty((1, 3, items, npad, F), dtype=torch.bfloat16, device=dev)
-                    check(lib.gcrnn_pack_seq_major_x3(_p(dpg), _p(dpg3), items, 1, F, N, npad, st), 'pack_seq_x3')
-                    Xi = Xp[:, t0:t0 + nt].permute(1, 0, 2, 3).reshape(items, 1, Gp, N)
-                    if Ggp != Gp:
-                        Xi = Xi[:, :, :Ggp]
-                    Xi = Xi.contiguous()
-                    h0i = h0c.unsqueeze(0).expand(nt, B, F, N).reshape(items, F, N).contiguous()
-                    sl = int(lib.gcrnn_fused_wgrad_slots(items, F))
-                    dWs = torch.zeros((sl, F, Kg, F + Ggp), dtype=torch.float32, device=dev)
-                    dbs = torch.zeros((sl, F), dtype=torch.float32, device=dev)
-                    check(lib.gcrnn_fused_backward_weight_f32(_p(dpg3), _p(Xi), _p(h0i), _p(h0i), _p(dWs), _p(dbs), _p(pa['tile_slots']), _p(pa['tile_off']),
-                                                              _p(pa['ell_col4']), pa['entries'], items, 1, N, F, Ggp, Kg, pa['uniform_w'], st),
-                          'fused_backward_weight_f32')
-                    dWg += dWs.sum(dim=0)
-                    dbg += dbs.sum(dim=0)
-                    del dpg, dpg3, dWs, dbs
+                lwv = lin_w.detach().float().contiguous().view(F, N)
+                check(lib.gcrnn_pack_seq_major_x3_ex(_p(c), _p(dpre3), B, T, F, N, npad, _p(dlogit), _p(lwv), 1, 0, st), 'pack_seq_x3_ex')
+                Xg = Xp if Ggp == Gp else Xp[:, :, :Ggp].contiguous()
+                dWs = torch.zeros((slots, F, Kg, F + Ggp), dtype=torch.float32, device=dev)
+                dbs = torch.zeros((slots, F), dtype=torch.float32, device=dev)
+                check(lib.gcrnn_fused_backward_weight_f32_gated(_p(dpre3), _p(Xg), None, None if ctx.hzero else _p(h0c), _p(dWs), _p(dbs), *aargs,
+                                                                B, T, N, F, Ggp, Kg, pa['uniform_w'], None, None, 1, st), 'fused_backward_weight_f32_gated')
+                dWg, dbg = dWs.sum(dim=0), dbs.sum(dim=0)
                 g_wA = dWg[:, :Kg_in, F:F + Ggp].unsqueeze(1).to(wA_g.dtype) if need[base] else None
                 g_wB = dWg[:, :Kg_st, :F].unsqueeze(1).to(wB_g.dtype) if need[base + 1] else None
                 g_b = dbg.view_as(bias_g).to(bias_g.dtype) if (bias_g is not None and need[base + 2]) else None
+                del dWs, dbs
             out += [g_wA, g_wB, g_b, g_lw, g_lb]
         return (None, None, gA, gB, gb, *out, None)
 
