@@ -122,7 +122,9 @@ __global__ __launch_bounds__(256) void x3_item_dots_kernel(const uint16_t* __res
 // EPI 0: forward step (bias, tanh).  EPI 2 (XS = 0): BPTT data-gradient step in the same arithmetic -- operand = the planes of
 // dpre_t, taps = the transposed state taps, adjoint graph; epilogue dpre_{t-1} = (acc + dH_{t-1}) (1 - h_{t-1}^2) in fp32 with dH and h
 // re-assembled from their planes (aux0 / aux1, both may be null: the raw state gradient d h0), stored as three planes again.
-template <int K, int HS, int XS, int EPI = 0>
+// SZ (EPI 0): the state operand is all zeros (gate cells from a zero h0, train_rnn.py:256): its fragments are neither loaded nor multiplied
+// (exact: the skipped products are zeros) -- a kernel of its own, so that the general one keeps its registers.
+template <int K, int HS, int XS, int EPI = 0, bool SZ = false>
 __global__ __launch_bounds__(STHREADS) void fused_step_x3_kernel(
     const uint16_t* __restrict__ xt3,        // [3][B][NP][G]  planes of x_t
     const uint16_t* __restrict__ hp3,        // [3][B][NP][F]  planes of h_{t-1}
@@ -138,6 +140,7 @@ __global__ __launch_bounds__(STHREADS) void fused_step_x3_kernel(
     const float* __restrict__ bscale,                  // EPI 0 (or null): per-sequence weight of the bias [B] instead of 2 (time-gated cell: gi + gf);
                                                        // EPI 2 (or null): per-sequence forget gate [B] of the step back-propagated (scales the hops' output)
     float* __restrict__ gpart) {                       // EPI 2 (or null; needs aux1): [B][F/16 * 8] partials of <h_{t-1}, adjoint chain of dpre_t> = d loss / d gf_t
+  static_assert(!SZ || (EPI == 0 && XS > 0), "zero state: forward cells with an input operand");
   static_assert(GCRNN_HOP_ASM && GCRNN_STEP_WAVES == 8, "x3 runs on the one-block asm hop stream");
   constexpr int KS = HS + XS, F = 32 * HS, G = 32 * XS, NCH = F / FC, HT = STILES;
   constexpr int WPL = K * KS * 64;            // uint4 fragments per weight plane and chunk
@@ -198,9 +201,11 @@ __global__ __launch_bounds__(STHREADS) void fused_step_x3_kernel(
         int w = woff[i + j];
         asm volatile("" : "+v"(w));
         const int roh = (w >> 16) * (F * 2) + 16 * q, rox = (w >> 16) * (G * 2) + 16 * q;
+        if constexpr (!SZ) {
 #pragma unroll
-        for (int s = 0; s < HS; ++s)
-          fr[set][j][s] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsrc_h, roh + 64 * s, (p * B + b) * (NP * F * 2), 0));
+          for (int s = 0; s < HS; ++s)
+            fr[set][j][s] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsrc_h, roh + 64 * s, (p * B + b) * (NP * F * 2), 0));
+        }
 #pragma unroll
         for (int s = 0; s < XS; ++s)
           fr[set][j][HS + s] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, rox + 64 * s, (p * B + b) * (NP * G * 2), 0));
@@ -220,13 +225,15 @@ __global__ __launch_bounds__(STHREADS) void fused_step_x3_kernel(
 #pragma unroll
       for (int tap = 0; tap < K; ++tap)
 #pragma unroll
-        for (int s = 0; s < KS; ++s)
+        for (int s = 0; s < KS; ++s) {
+          if (SZ && s < HS) continue;
 #pragma unroll
           for (int wp = 0; wp < 3 - p; ++wp) {             // operand plane p meets weight planes 0 .. 2-p
             const bf16x8 a = __builtin_bit_cast(bf16x8, wl[wp * WPL + (tap * KS + s) * 64 + lane]);
             acc[tap][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, fr[set][0][s], acc[tap][0], 0, 0, 0);
             acc[tap][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, fr[set][1][s], acc[tap][1], 0, 0, 0);
           }
+        }
       if (p == 2) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
@@ -351,11 +358,11 @@ __global__ __launch_bounds__(STHREADS) void fused_step_x3_kernel(
 template <int K, int HS, int XS>
 int x3_launch(const void* xs3, const void* h03, void* hs3, const void* wpack3, const float* bias, const int32_t* tile_nodes,
               const int32_t* tile_off, const void* ell_col4, int64_t entries, int64_t B, int64_t T, int64_t N, float uni_w, float* Huser,
-              int last_only, hipStream_t st, const float* bscale = nullptr, int64_t hu_stride = 0, int fixed_state = 0) {
+              int last_only, hipStream_t st, const float* bscale = nullptr, int64_t hu_stride = 0, int fixed_state = 0, int state_zero = 0) {
   constexpr int F = 32 * HS, G = 32 * XS, KS = HS + XS, NCH = F / FC;
   const size_t lds = (size_t)NP * FC * 4 + (size_t)3 * K * KS * 1024 + (size_t)entries * 32;
   if (lds > 160 * 1024) return GCRNN_ERR_UNSUPPORTED;
-  auto kern = fused_step_x3_kernel<K, HS, XS>;
+  auto kern = (fixed_state && state_zero) ? fused_step_x3_kernel<K, HS, XS, 0, true> : fused_step_x3_kernel<K, HS, XS>;
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
     return GCRNN_ERR_LAUNCH;
   int64_t slots = cdiv(B, 8) * 8;
@@ -762,12 +769,13 @@ extern "C" int gcrnn_fused_forward_x3_scaled(const void* xs3, const void* h03, v
 
 // The time gates' sub-cells at fp32 accuracy (Utils/graphML.py:2362-2366): T x B independent ONE-step cells c[t][b] = tanh(A_g(S) x_t + B_g(S) h0
 // + 2 b_g), every one from the same initial state: gcrnn_fused_forward_x3 whose every step reads h03 (xs3 [T][3][B][NPad][G] the planes of X as
-// the recurrence packs them -- no per-item copies of X or h0). scratch3 [3][B][NPad][F] receives (and re-receives) a step's planes; Cuser fp32
+// the recurrence packs them -- no per-item copies of X or h0; state_zero != 0: h0 is all zeros, train_rnn.py:256, and its half of the tap
+// products is skipped -- exact). scratch3 [3][B][NPad][F] receives (and re-receives) a step's planes; Cuser fp32
 // [B][T][F][N] the gate states, user layout.
 extern "C" int gcrnn_fused_gate_cells_x3(const void* xs3, const void* h03, void* scratch3, const void* wpack3, const float* bias,
                                          const int32_t* tile_nodes, const int32_t* tile_off, const void* ell_col4, int64_t entries,
                                          int64_t B, int64_t T, int64_t N, int64_t F, int64_t G, int64_t K, double uniform_w, void* Cuser,
-                                         void* stream) {
+                                         int state_zero, void* stream) {
   if (!xs3 || !h03 || !scratch3 || !wpack3 || !tile_nodes || !tile_off || !ell_col4 || !Cuser) return GCRNN_ERR_NULL_POINTER;
   if (B <= 0 || T <= 0 || uniform_w == 0.0 || !gcrnn_fused_x3_supported(N, F, G, K, entries)) return GCRNN_ERR_BAD_SHAPE;
   if (3 * B * (NP * (F > G ? F : G) * 2) > 2147483647LL) return GCRNN_ERR_BAD_SHAPE;
@@ -776,7 +784,7 @@ extern "C" int gcrnn_fused_gate_cells_x3(const void* xs3, const void* h03, void*
 #define GCRNN_X3_CASE(KK, HH, XX) \
   if (K == KK && F == 32 * HH && G == 32 * XX) \
     return x3_launch<KK, HH, XX>(xs3, h03, scratch3, wpack3, bias, tile_nodes, tile_off, ell_col4, entries, B, T, N, (float)uniform_w, (float*)Cuser, 0, st, \
-                                 nullptr, 0, 1);
+                                 nullptr, 0, 1, state_zero);
   GCRNN_X3_CASE(5, 2, 2) GCRNN_X3_CASE(4, 2, 2) GCRNN_X3_CASE(3, 2, 2) GCRNN_X3_CASE(2, 2, 2)
   GCRNN_X3_CASE(5, 2, 1) GCRNN_X3_CASE(4, 2, 1) GCRNN_X3_CASE(3, 2, 1) GCRNN_X3_CASE(2, 2, 1)
   GCRNN_X3_CASE(5, 1, 1) GCRNN_X3_CASE(4, 1, 1) GCRNN_X3_CASE(3, 1, 1) GCRNN_X3_CASE(2, 1, 1)

@@ -1495,60 +1495,10 @@ def fused_cell_forward_x3(X, h0, wA, wB, bias, graph, last_only=False, keep=Fals
 
 
 def fused_cell_forward_x3_gated(X, h0, wA, wB, bias, graph, gates, last_only=False):
-    """Time-gated GGCRNNCell forward to fp32 accuracy, composed from the fp32-accurate fused step (round 3; reference
-    graphML.py:2357-2374, 2420-2423). gates = {'in': (wA_g, wB_g, bias_g, lin_w, lin_b), 'forget': (...)} as in fused_cell_forward.
-      * a gate reads (x_t, h0): its gate cell is ONE un-gated step from h0 for every (t, b) -- the x3 forward on T*B "sequences" of length
-        one (in slices that keep the 32-bit buffer offsets), followed by the Linear(F N -> 1) read-out on the fp32 states (torch);
-      * gi (A(S)x_t + b) + gf (B(S)h_{t-1} + b) = A(S)(gi x_t) + B(S)(gf h_{t-1}) + (gi + gf) b: the operands are scaled in fp32 BEFORE they are
-        cut into bf16 planes (exact), the bias weight gi + gf goes to the kernel (gcrnn_fused_forward_x3_scaled), one launch per step.
-    X: B x T x G x N fp32, h0: B x F x N fp32 -> H: B x T x F x N fp32 (B x 1 x F x N with last_only). No autograd graph."""
-    require_device(X, h0, wA, wB, bias)
-    Xp, wAp = fused_pad_operands(X, wA.detach())
-    B, T, G, N = Xp.shape
-    F = wAp.shape[0]
-    Kin, Kst = wAp.shape[2], wB.shape[2]
-    K = max(Kin, Kst)
-    plan = graph.fused_plan()
-    npad, st, dev = plan['npad'], _stream(), X.device
-    # ---- the two gates [T][B] ----
-    per = max(1, min(T, 2048 // B)) if B <= 2048 else 0
-    assert per > 0, 'batch too large for the x3 gate evaluation'
-    g = {}
-    for name in ('in', 'forget'):
-        wA_g, wB_g, bias_g, lin_w, lin_b = gates[name]
-        lw = lin_w.detach().float().reshape(-1)
-        logit = torch.empty((T, B), dtype=torch.float32, device=dev)
-        for t0 in range(0, T, per):
-            nt = min(per, T - t0)
-            Xi = Xp[:, t0:t0 + nt].permute(1, 0, 2, 3).reshape(nt * B, 1, G, N)                  # item = t B + b
-            h0i = h0.unsqueeze(0).expand(nt, B, F, N).reshape(nt * B, F, N)
-            c = fused_cell_forward_x3(Xi, h0i, wA_g, wB_g, bias_g, graph)                       # [items][1][F][N] fp32
-            logit[t0:t0 + nt] = (c.reshape(nt * B, F * N) @ lw).view(nt, B)
-        if lin_b is not None:
-            logit = logit + lin_b.detach().float().view(())
-        g[name] = torch.sigmoid(logit)
-    gi, gf = g['in'], g['forget']                                                                # [T][B]
-    # ---- the recurrence, one scaled step per launch ----
-    Xs = (Xp * gi.t().reshape(B, T, 1, 1)).contiguous()
-    xs3 = torch.empty((T, 3, B, npad, G), dtype=torch.bfloat16, device=dev)
-    check(lib.gcrnn_pack_seq_major_x3(_p(Xs), _p(xs3), B, T, G, N, npad, st), 'pack_seq_x3')
-    wAc, wBc = wAp.float().contiguous(), wB.detach().float().contiguous()
-    wp3 = torch.empty((3 * (F // 16) * K * ((F + G) // 32) * 64 * 8,), dtype=torch.bfloat16, device=dev)
-    check(lib.gcrnn_fused_pack_weights_x3(_p(wAc), _p(wBc), _p(wp3), F, G, Kin, Kst, st), 'pack_weights_x3')
-    b32 = bias.detach().float().contiguous().view(-1) if bias is not None else None
-    bsc = (gi + gf).contiguous()                                                                 # [T][B]
-    H = torch.empty((B, T, F, N), dtype=torch.float32, device=dev)
-    h3 = torch.empty((1, 3, B, npad, F), dtype=torch.bfloat16, device=dev)
-    ho3 = torch.empty((1, 3, B, npad, F), dtype=torch.bfloat16, device=dev)
-    hprev = h0
-    for t in range(T):
-        hs_ = (hprev * gf[t].view(B, 1, 1)).contiguous()
-        check(lib.gcrnn_pack_seq_major_x3(_p(hs_), _p(h3), B, 1, F, N, npad, st), 'pack_seq_x3')
-        check(lib.gcrnn_fused_forward_x3_scaled(_p(xs3[t]), _p(h3), _p(ho3), _p(wp3), _p(b32), _p(bsc[t]), _p(plan['tile_slots']), _p(plan['tile_off']),
-                                                _p(plan['ell_col4']), plan['entries'], B, 1, N, F, G, K, plan['uniform_w'], _p(H[:, t]), T * F * N, st),
-              'fused_forward_x3_scaled')
-        hprev = H[:, t]
-    return H[:, T - 1:].contiguous() if last_only else H
+    """Time-gated GGCRNNCell forward to fp32 accuracy on the fp32-accurate fused kernels (round 3; round 4: the gate cells run on the planes
+    of X instead of per-item copies -- _x3_time_gated_forward). gates = {'in': (wA_g, wB_g, bias_g, lin_w, lin_b), 'forget': (...)} as in
+    fused_cell_forward. X: B x T x G x N fp32, h0: B x F x N fp32 -> H: B x T x F x N fp32 (B x 1 x F x N with last_only). No autograd graph."""
+    return _x3_time_gated_forward(X, h0, wA, wB, bias, graph, gates, keep=False, last_only=last_only)
 
 
 def fused_x3_training_supported(graph, N, F, G, Kin, Kst, dtype, E=1, B=None, T=None):
@@ -1638,6 +1588,68 @@ def fused_x3_time_training_supported(graph, N, F, G, Kin, Kst, dtype, E=1, B=Non
     return (B is None or B <= 2048) and fused_x3_training_supported(graph, N, F, G, Kin, Kst, dtype, E, B, T)
 
 
+def _x3_time_gated_forward(X, h0, wA, wB, bias, graph, gates, keep=False, last_only=False):
+    """Forward of the time-gated cell at fp32 accuracy (reference graphML.py:2357-2374, 2420-2423): both gate cells as T x B one-step x3 cells
+    that read (x_t, h0) on the planes of X (gcrnn_fused_gate_cells_x3), the Linear(F N -> 1) read-outs as GEMVs over their fp32 states, the
+    recurrence as one scaled x3 step per launch -- gi (A(S)x_t + b) + gf (B(S)h_{t-1} + b) = A(S)(gi x_t) + B(S)(gf h_{t-1}) + (gi + gf) b, the
+    operands scaled in fp32 while they are cut into planes (gcrnn_pack_seq_major_x3_ex). keep: what the BPTT needs."""
+    require_device(X, h0, wA, wB, bias)
+    Xp, wAp = fused_pad_operands(X, wA.detach())
+    B, T, Gp, N = Xp.shape
+    F, Kin, Kst = wAp.shape[0], wAp.shape[2], wB.shape[2]
+    K = max(Kin, Kst)
+    plan = graph.fused_plan()
+    npad, st, dev = plan['npad'], _stream(), X.device
+    Xp = Xp.float().contiguous()
+    h0c = h0.detach().float().contiguous()
+    hzero = not bool(h0c.any())
+    gargs = (_p(plan['tile_slots']), _p(plan['tile_off']), _p(plan['ell_col4']), plan['entries'])
+    xs3 = torch.empty((T, 3, B, npad, Gp), dtype=torch.bfloat16, device=dev)
+    check(lib.gcrnn_pack_seq_major_x3(_p(Xp), _p(xs3), B, T, Gp, N, npad, st), 'pack_seq_x3')
+    h03 = torch.empty((1, 3, B, npad, F), dtype=torch.bfloat16, device=dev)
+    check(lib.gcrnn_pack_seq_major_x3(_p(h0c), _p(h03), B, 1, F, N, npad, st), 'pack_seq_x3')
+    h3 = torch.empty((1, 3, B, npad, F), dtype=torch.bfloat16, device=dev)
+    gvals, cs = [], []
+    for (wA_g, wB_g, bias_g, lin_w, lin_b) in (gates['in'], gates['forget']):
+        Kg = max(wA_g.shape[2], wB_g.shape[2])
+        wAg, wBg = wA_g.detach().float().contiguous(), wB_g.detach().float().contiguous()
+        wpg = torch.empty((3 * (F // 16) * Kg * ((F + Gp) // 32) * 64 * 8,), dtype=torch.bfloat16, device=dev)
+        check(lib.gcrnn_fused_pack_weights_x3(_p(wAg), _p(wBg), _p(wpg), F, Gp, wA_g.shape[2], wB_g.shape[2], st), 'pack_weights_x3')
+        bg = bias_g.detach().float().contiguous().view(-1) if bias_g is not None else None
+        c = torch.empty((B, T, F, N), dtype=torch.float32, device=dev)          # the gate cells' states (training keeps them for their BPTT)
+        check(lib.gcrnn_fused_gate_cells_x3(_p(xs3), _p(h03), _p(h3), _p(wpg), _p(bg), *gargs, B, T, N, F, Gp, Kg, plan['uniform_w'], _p(c), int(hzero), st),
+              'fused_gate_cells_x3')
+        logit = (c.view(B * T, F * N) @ lin_w.detach().float().reshape(-1)).view(B, T).t()
+        if lin_b is not None:
+            logit = logit + lin_b.detach().float().view(())
+        gvals.append(torch.sigmoid(logit).contiguous())                          # [T][B]
+        cs.append(c if keep else None)
+        del c
+    gi, gf = gvals
+    xu3 = xs3 if (keep and Gp == F) else None                                               # (the backward's filter pass A(S) x_t reads the planes of X again)
+    if xu3 is not None:
+        xs3 = torch.empty_like(xu3)
+    check(lib.gcrnn_pack_seq_major_x3_ex(_p(Xp), _p(xs3), B, T, Gp, N, npad, _p(gi), None, 0, 0, st), 'pack_seq_x3_ex')      # planes of gi x_t
+    wAc, wBc = wAp.float().contiguous(), wB.detach().float().contiguous()
+    wp3 = torch.empty((3 * (F // 16) * K * ((F + Gp) // 32) * 64 * 8,), dtype=torch.bfloat16, device=dev)
+    check(lib.gcrnn_fused_pack_weights_x3(_p(wAc), _p(wBc), _p(wp3), F, Gp, Kin, Kst, st), 'pack_weights_x3')
+    b32 = bias.detach().float().contiguous().view(-1) if bias is not None else None
+    bsc = (gi + gf).contiguous()
+    H = torch.empty((B, T, F, N), dtype=torch.float32, device=dev)
+    hs3 = torch.empty((T, 3, B, npad, F), dtype=torch.bfloat16, device=dev)
+    for t in range(T):
+        hprev = h0c if t == 0 else H[:, t - 1]
+        check(lib.gcrnn_pack_seq_major_x3_ex(_p(hprev), _p(h3), B, 1, F, N, npad, _p(gf[t]), None, 0, 0 if t == 0 else T * F * N, st),
+              'pack_seq_x3_ex')                                                                  # planes of gf_t h_{t-1}
+        check(lib.gcrnn_fused_forward_x3_scaled(_p(xs3[t]), _p(h3), _p(hs3[t]), _p(wp3), _p(b32), _p(bsc[t]), *gargs, B, 1, N, F, Gp, K,
+                                                plan['uniform_w'], _p(H[:, t]), T * F * N, st), 'fused_forward_x3_scaled')
+    del xs3
+    if last_only:
+        return H[:, T - 1:].contiguous()
+    return (H, Xp, h0c, hs3, gi, gf, cs[0], cs[1], hzero, xu3) if keep else H
+
+
+
 class _FusedTimeCellX3(torch.autograd.Function):
     """Time-gated GGCRNNCell (the reference's default, Utils/graphML.py:2196, :2357-2374, :2420-2423) at fp32 accuracy on the fused kernels,
     forward AND BPTT (round 4). Forward: the two gate cells as T x B one-step x3 cells that all read h0 (gcrnn_fused_gate_cells_x3, on the
@@ -1651,55 +1663,10 @@ class _FusedTimeCellX3(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, X, h0, wA, wB, bias, gA_i, gB_i, gb_i, lw_i, lb_i, gA_f, gB_f, gb_f, lw_f, lb_f, graph):
-        require_device(X, h0, wA, wB, bias)
-        Xp, wAp = fused_pad_operands(X, wA.detach())
-        B, T, Gp, N = Xp.shape
-        F, Kin, Kst = wAp.shape[0], wAp.shape[2], wB.shape[2]
-        K = max(Kin, Kst)
-        plan = graph.fused_plan()
-        npad, st, dev = plan['npad'], _stream(), X.device
-        Xp = Xp.float().contiguous()
-        h0c = h0.detach().float().contiguous()
-        hzero = not bool(h0c.any())
-        gargs = (_p(plan['tile_slots']), _p(plan['tile_off']), _p(plan['ell_col4']), plan['entries'])
-        xs3 = torch.empty((T, 3, B, npad, Gp), dtype=torch.bfloat16, device=dev)
-        check(lib.gcrnn_pack_seq_major_x3(_p(Xp), _p(xs3), B, T, Gp, N, npad, st), 'pack_seq_x3')
-        h03 = torch.empty((1, 3, B, npad, F), dtype=torch.bfloat16, device=dev)
-        check(lib.gcrnn_pack_seq_major_x3(_p(h0c), _p(h03), B, 1, F, N, npad, st), 'pack_seq_x3')
-        h3 = torch.empty((1, 3, B, npad, F), dtype=torch.bfloat16, device=dev)
-        gates, cs = [], []
-        for (wA_g, wB_g, bias_g, lin_w, lin_b) in ((gA_i, gB_i, gb_i, lw_i, lb_i), (gA_f, gB_f, gb_f, lw_f, lb_f)):
-            Kg = max(wA_g.shape[2], wB_g.shape[2])
-            wAg, wBg = wA_g.detach().float().contiguous(), wB_g.detach().float().contiguous()
-            wpg = torch.empty((3 * (F // 16) * Kg * ((F + Gp) // 32) * 64 * 8,), dtype=torch.bfloat16, device=dev)
-            check(lib.gcrnn_fused_pack_weights_x3(_p(wAg), _p(wBg), _p(wpg), F, Gp, wA_g.shape[2], wB_g.shape[2], st), 'pack_weights_x3')
-            bg = bias_g.detach().float().contiguous().view(-1) if bias_g is not None else None
-            c = torch.empty((B, T, F, N), dtype=torch.float32, device=dev)          # the gate cells' states, kept for their BPTT
-            check(lib.gcrnn_fused_gate_cells_x3(_p(xs3), _p(h03), _p(h3), _p(wpg), _p(bg), *gargs, B, T, N, F, Gp, Kg, plan['uniform_w'], _p(c), st),
-                  'fused_gate_cells_x3')
-            logit = (c.view(B * T, F * N) @ lin_w.detach().float().reshape(-1)).view(B, T).t()
-            if lin_b is not None:
-                logit = logit + lin_b.detach().float().view(())
-            gates.append(torch.sigmoid(logit).contiguous())                          # [T][B]
-            cs.append(c)
-        gi, gf = gates
-        check(lib.gcrnn_pack_seq_major_x3_ex(_p(Xp), _p(xs3), B, T, Gp, N, npad, _p(gi), None, 0, 0, st), 'pack_seq_x3_ex')      # planes of gi x_t
-        wAc, wBc = wAp.float().contiguous(), wB.detach().float().contiguous()
-        wp3 = torch.empty((3 * (F // 16) * K * ((F + Gp) // 32) * 64 * 8,), dtype=torch.bfloat16, device=dev)
-        check(lib.gcrnn_fused_pack_weights_x3(_p(wAc), _p(wBc), _p(wp3), F, Gp, Kin, Kst, st), 'pack_weights_x3')
-        b32 = bias.detach().float().contiguous().view(-1) if bias is not None else None
-        bsc = (gi + gf).contiguous()
-        H = torch.empty((B, T, F, N), dtype=torch.float32, device=dev)
-        hs3 = torch.empty((T, 3, B, npad, F), dtype=torch.bfloat16, device=dev)
-        for t in range(T):
-            hprev = h0c if t == 0 else H[:, t - 1]
-            check(lib.gcrnn_pack_seq_major_x3_ex(_p(hprev), _p(h3), B, 1, F, N, npad, _p(gf[t]), None, 0, 0 if t == 0 else T * F * N, st),
-                  'pack_seq_x3_ex')                                                                  # planes of gf_t h_{t-1}
-            check(lib.gcrnn_fused_forward_x3_scaled(_p(xs3[t]), _p(h3), _p(hs3[t]), _p(wp3), _p(b32), _p(bsc[t]), *gargs, B, 1, N, F, Gp, K,
-                                                    plan['uniform_w'], _p(H[:, t]), T * F * N, st), 'fused_forward_x3_scaled')
-        del xs3
-        ctx.save_for_backward(Xp, h0c, wA, wB, bias, gA_i, gB_i, gb_i, lw_i, lb_i, gA_f, gB_f, gb_f, lw_f, lb_f, H, hs3, gi, gf, cs[0], cs[1])
-        ctx.graph, ctx.G, ctx.hzero = graph, X.shape[2], hzero
+        gates = {'in': (gA_i, gB_i, gb_i, lw_i, lb_i), 'forget': (gA_f, gB_f, gb_f, lw_f, lb_f)}
+        H, Xp, h0c, hs3, gi, gf, c_i, c_f, hzero, xu3 = _x3_time_gated_forward(X, h0, wA, wB, bias, graph, gates, keep=True)
+        ctx.save_for_backward(Xp, h0c, wA, wB, bias, gA_i, gB_i, gb_i, lw_i, lb_i, gA_f, gB_f, gb_f, lw_f, lb_f, H, hs3, gi, gf, c_i, c_f)
+        ctx.graph, ctx.G, ctx.hzero, ctx.xu3 = graph, X.shape[2], hzero, xu3
         return H
 
     @staticmethod
@@ -1742,10 +1709,13 @@ class _FusedTimeCellX3(torch.autograd.Function):
         wAsq[:, :Kin, :wAk.shape[2]] = wAk
         wp3A = torch.empty((3 * (F // 16) * K * (F // 32) * 64 * 8,), dtype=torch.bfloat16, device=dev)
         check(lib.gcrnn_fused_pack_weights_x3(_p(wAsq), _p(wAsq), _p(wp3A), F, 0, K, K, st), 'pack_weights_x3')
-        Xf = Xp if Gp == F else torch.nn.functional.pad(Xp, (0, 0, 0, F - Gp)).contiguous()
-        z3 = torch.empty((T, 3, B, npad, F), dtype=torch.bfloat16, device=dev)
-        check(lib.gcrnn_pack_seq_major_x3(_p(Xf), _p(z3), B, T, F, N, npad, st), 'pack_seq_x3')
-        del Xf
+        z3 = ctx.xu3
+        ctx.xu3 = None
+        if z3 is None:
+            Xf = Xp if Gp == F else torch.nn.functional.pad(Xp, (0, 0, 0, F - Gp)).contiguous()
+            z3 = torch.empty((T, 3, B, npad, F), dtype=torch.bfloat16, device=dev)
+            check(lib.gcrnn_pack_seq_major_x3(_p(Xf), _p(z3), B, T, F, N, npad, st), 'pack_seq_x3')
+            del Xf
         y3 = torch.empty((T, 3, B, npad, F), dtype=torch.bfloat16, device=dev)
         for t in range(T):
             check(lib.gcrnn_fused_filter_x3(_p(z3[t]), _p(y3[t]), _p(wp3A), *gargs, B, N, F, K, plan['uniform_w'], st), 'fused_filter_x3')

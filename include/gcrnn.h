@@ -289,7 +289,8 @@ int gcrnn_fused_backward_weight_f32_gated(const void* dpre3, const void* Xuser, 
  * gcrnn_fused_backward_weight_f32_gated with gi = gf = NULL (weights 1 / 2) and h_is_h0 != 0: every item's state operand is h0 (Huser unused;
  *   h0user = NULL: a zero initial state, train_rnn.py:256 -- the state columns are skipped and stay zero).
  * gcrnn_fused_gate_cells_x3: the T x B independent one-step cells c[t][b] = tanh(A_g(S) x_t + B_g(S) h0 + 2 b_g) as T launches of the x3 step
- *   kernel that all read h03; xs3 = the planes of X [T][3][B][NPad][G], scratch3 [3][B][NPad][F], Cuser fp32 [B][T][F][N] (out).
+ *   kernel that all read h03; xs3 = the planes of X [T][3][B][NPad][G], scratch3 [3][B][NPad][F], Cuser fp32 [B][T][F][N] (out); state_zero != 0: h0 is all
+ *   zeros and the state half of the tap products is skipped (exact).
  * gcrnn_pack_seq_major_x3_ex: gcrnn_pack_seq_major_x3 of v' = item_scale[t][b] * rowmul[c][n] * (one_minus_square ? 1 - v^2 : v) (factors
  *   optional; src_seq_stride = elements between the sequences of src, 0 = contiguous): the scaled operands gi x_t / gf h_{t-1} and the gate
  *   cells' upstream gradient d logit * w * (1 - c^2) without an fp32 copy.
@@ -297,7 +298,7 @@ int gcrnn_fused_backward_weight_f32_gated(const void* dpre3, const void* Xuser, 
  *   d loss / d gi_t = <A(S) x_t, dpre_t> + <b, sum_n dpre_t>. */
 int gcrnn_fused_gate_cells_x3(const void* xs3, const void* h03, void* scratch3, const void* wpack3, const float* bias,
                               const int32_t* tile_nodes, const int32_t* tile_off, const void* ell_col4, int64_t entries, int64_t B,
-                              int64_t T, int64_t N, int64_t F, int64_t G, int64_t K, double uniform_w, void* Cuser, void* stream);
+                              int64_t T, int64_t N, int64_t F, int64_t G, int64_t K, double uniform_w, void* Cuser, int state_zero, void* stream);
 int gcrnn_pack_seq_major_x3_ex(const void* src, void* dst, int64_t B, int64_t T, int64_t C, int64_t N, int64_t NPad,
                                const float* item_scale, const float* rowmul, int one_minus_square, int64_t src_seq_stride, void* stream);
 int gcrnn_x3_item_dots(const void* a3, const void* b3, const float* vec, float* out_ab, float* out_av, int64_t B, int64_t T, int64_t NPad,
