@@ -105,15 +105,15 @@ def _bind(lib):
         'gcrnn_fused_x3_supported': (C.c_int, [_c_i64, _c_i64, _c_i64, _c_i64, _c_i64]),
         'gcrnn_pack_seq_major_x3': (C.c_int, [_c_p, _c_p, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_p]),
         'gcrnn_fused_pack_weights_x3': (C.c_int, [_c_p, _c_p, _c_p, _c_i64, _c_i64, _c_i64, _c_i64, _c_p]),
-        'gcrnn_fused_forward_x3': (C.c_int, [_c_p] * 8 + [_c_i64] * 7 + [C.c_double, _c_p, C.c_int, _c_p]),
-        'gcrnn_fused_forward_x3_scaled': (C.c_int, [_c_p] * 9 + [_c_i64] * 7 + [C.c_double, _c_p, _c_i64, _c_p]),
+        'gcrnn_fused_forward_x3': (C.c_int, [_c_p] * 8 + [_c_i64] * 7 + [C.c_double, _c_p, C.c_int, _c_p, _c_p]),
+        'gcrnn_fused_forward_x3_scaled': (C.c_int, [_c_p] * 9 + [_c_i64] * 7 + [C.c_double, _c_p, _c_i64, _c_p, _c_p]),
         'gcrnn_fused_x3_training_supported': (C.c_int, [_c_i64] * 5),
-        'gcrnn_fused_backward_data_x3': (C.c_int, [_c_p] * 8 + [_c_i64] * 6 + [C.c_double, _c_p]),
-        'gcrnn_fused_backward_weight_f32': (C.c_int, [_c_p] * 9 + [_c_i64] * 7 + [C.c_double, _c_p]),
-        'gcrnn_fused_backward_data_x3_gated': (C.c_int, [_c_p] * 8 + [_c_i64] * 6 + [C.c_double, _c_p, _c_p, _c_p, _c_p]),
-        'gcrnn_fused_filter_x3': (C.c_int, [_c_p] * 6 + [_c_i64] * 5 + [C.c_double, _c_p]),
-        'gcrnn_fused_backward_weight_f32_gated': (C.c_int, [_c_p] * 9 + [_c_i64] * 7 + [C.c_double, _c_p, _c_p, C.c_int, _c_p]),
-        'gcrnn_fused_gate_cells_x3': (C.c_int, [_c_p] * 8 + [_c_i64] * 7 + [C.c_double, _c_p, C.c_int, _c_p]),
+        'gcrnn_fused_backward_data_x3': (C.c_int, [_c_p] * 8 + [_c_i64] * 6 + [C.c_double, _c_p, _c_p]),
+        'gcrnn_fused_backward_weight_f32': (C.c_int, [_c_p] * 9 + [_c_i64] * 7 + [C.c_double, _c_p, _c_p]),
+        'gcrnn_fused_backward_data_x3_gated': (C.c_int, [_c_p] * 8 + [_c_i64] * 6 + [C.c_double, _c_p, _c_p, _c_p, _c_p, _c_p]),
+        'gcrnn_fused_filter_x3': (C.c_int, [_c_p] * 6 + [_c_i64] * 5 + [C.c_double, _c_p, _c_p]),
+        'gcrnn_fused_backward_weight_f32_gated': (C.c_int, [_c_p] * 9 + [_c_i64] * 7 + [C.c_double, _c_p, _c_p, C.c_int, _c_p, _c_p]),
+        'gcrnn_fused_gate_cells_x3': (C.c_int, [_c_p] * 8 + [_c_i64] * 7 + [C.c_double, _c_p, C.c_int, _c_p, _c_p]),
         'gcrnn_pack_seq_major_x3_ex': (C.c_int, [_c_p, _c_p] + [_c_i64] * 5 + [_c_p, _c_p, C.c_int, _c_i64, _c_p]),
         'gcrnn_x3_item_dots': (C.c_int, [_c_p] * 5 + [_c_i64] * 4 + [_c_p]),
         'gcrnn_pack_seq_major_steps': (C.c_int, [_c_p, _c_p, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_p]),

@@ -124,7 +124,8 @@ __global__ __launch_bounds__(256) void x3_item_dots_kernel(const uint16_t* __res
 // re-assembled from their planes (aux0 / aux1, both may be null: the raw state gradient d h0), stored as three planes again.
 // SZ (EPI 0): the state operand is all zeros (gate cells from a zero h0, train_rnn.py:256): its fragments are neither loaded nor multiplied
 // (exact: the skipped products are zeros) -- a kernel of its own, so that the general one keeps its registers.
-template <int K, int HS, int XS, int EPI = 0, bool SZ = false>
+// R1: rank-1-weighted graph (the r1 table) -- compile-time as well, so that uniform graphs keep their code and registers.
+template <int K, int HS, int XS, int EPI = 0, bool SZ = false, bool R1 = false>
 __global__ __launch_bounds__(STHREADS) void fused_step_x3_kernel(
     const uint16_t* __restrict__ xt3,        // [3][B][NP][G]  planes of x_t
     const uint16_t* __restrict__ hp3,        // [3][B][NP][F]  planes of h_{t-1}
@@ -139,7 +140,10 @@ __global__ __launch_bounds__(STHREADS) void fused_step_x3_kernel(
     const uint16_t* __restrict__ aux1_3,               // EPI 2: planes of the state h_{t-1} [3][B][NP][F] (or null)
     const float* __restrict__ bscale,                  // EPI 0 (or null): per-sequence weight of the bias [B] instead of 2 (time-gated cell: gi + gf);
                                                        // EPI 2 (or null): per-sequence forget gate [B] of the step back-propagated (scales the hops' output)
-    float* __restrict__ gpart) {                       // EPI 2 (or null; needs aux1): [B][F/16 * 8] partials of <h_{t-1}, adjoint chain of dpre_t> = d loss / d gf_t
+    float* __restrict__ gpart,                         // EPI 2 (or null; needs aux1): [B][F/16 * 8] partials of <h_{t-1}, adjoint chain of dpre_t> = d loss / d gf_t
+    const float* __restrict__ r1) {                    // rank-1-weighted graph S[m][n] = a[m] b[n] on the plan of its 0/1 pattern (or null): [4][NP] fp32 = a | a b | 1 / b | b
+                                                       // (source factor, its product with the destination factor, destination factor and inverse; 1 where b = 0).
+                                                       // Horner in t' = t / b: t'_j = u_j / b + sum_{m in N(n)} (a b t'_{j+1})[m], t_0 = b t'_0 -- the stream still adds in place.
   static_assert(!SZ || (EPI == 0 && XS > 0), "zero state: forward cells with an input operand");
   static_assert(GCRNN_HOP_ASM && GCRNN_STEP_WAVES == 8, "x3 runs on the one-block asm hop stream");
   constexpr int KS = HS + XS, F = 32 * HS, G = 32 * XS, NCH = F / FC, HT = STILES;
@@ -237,11 +241,18 @@ __global__ __launch_bounds__(STHREADS) void fused_step_x3_kernel(
       if (p == 2) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-#pragma unroll
-          for (int tap = 0; tap < K - 1; ++tap) u[i + j][tap] = acc[tap][j];
           int wv = woff[i + j];
           asm volatile("" : "+v"(wv));
-          *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(state) + (wv & 0xffff)) = acc[K - 1][j];
+          f32x4 top = acc[K - 1][j];
+          if constexpr (R1) {
+            const float binv = r1[2 * NP + (wv >> 16)], a1 = r1[wv >> 16];
+#pragma unroll
+            for (int tap = 0; tap < K - 1; ++tap) acc[tap][j] *= binv;
+            top *= a1;
+          }
+#pragma unroll
+          for (int tap = 0; tap < K - 1; ++tap) u[i + j][tap] = acc[tap][j];
+          *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(state) + (wv & 0xffff)) = top;
         }
       }
     }
@@ -260,9 +271,19 @@ __global__ __launch_bounds__(STHREADS) void fused_step_x3_kernel(
         for (int i = 0; i < STILES; ++i) {
           int wv = woff[i];
           asm volatile("" : "+v"(wv));
-          *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(state) + (wv & 0xffff)) = u[i][K - 1 - j];
+          f32x4 im = u[i][K - 1 - j];
+          if constexpr (R1) im *= r1[NP + (wv >> 16)];
+          *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(state) + (wv & 0xffff)) = im;
         }
         lds_barrier();
+      }
+    }
+    if constexpr (R1) {
+#pragma unroll
+      for (int i = 0; i < STILES; ++i) {
+        int wv = woff[i];
+        asm volatile("" : "+v"(wv));
+        u[i][0] *= r1[3 * NP + (wv >> 16)];
       }
     }
     // ---- epilogue: bias, tanh, three planes of h_t; fp32 user-layout copy through an LDS transpose in two node halves ------
@@ -358,11 +379,12 @@ __global__ __launch_bounds__(STHREADS) void fused_step_x3_kernel(
 template <int K, int HS, int XS>
 int x3_launch(const void* xs3, const void* h03, void* hs3, const void* wpack3, const float* bias, const int32_t* tile_nodes,
               const int32_t* tile_off, const void* ell_col4, int64_t entries, int64_t B, int64_t T, int64_t N, float uni_w, float* Huser,
-              int last_only, hipStream_t st, const float* bscale = nullptr, int64_t hu_stride = 0, int fixed_state = 0, int state_zero = 0) {
+              int last_only, hipStream_t st, const float* r1, const float* bscale = nullptr, int64_t hu_stride = 0, int fixed_state = 0, int state_zero = 0) {
   constexpr int F = 32 * HS, G = 32 * XS, KS = HS + XS, NCH = F / FC;
   const size_t lds = (size_t)NP * FC * 4 + (size_t)3 * K * KS * 1024 + (size_t)entries * 32;
   if (lds > 160 * 1024) return GCRNN_ERR_UNSUPPORTED;
-  auto kern = (fixed_state && state_zero) ? fused_step_x3_kernel<K, HS, XS, 0, true> : fused_step_x3_kernel<K, HS, XS>;
+  auto kern = r1 ? ((fixed_state && state_zero) ? fused_step_x3_kernel<K, HS, XS, 0, true, true> : fused_step_x3_kernel<K, HS, XS, 0, false, true>)
+                 : ((fixed_state && state_zero) ? fused_step_x3_kernel<K, HS, XS, 0, true> : fused_step_x3_kernel<K, HS, XS>);
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
     return GCRNN_ERR_LAUNCH;
   int64_t slots = cdiv(B, 8) * 8;
@@ -378,7 +400,7 @@ int x3_launch(const void* xs3, const void* h03, void* hs3, const void* wpack3, c
     float* hu = !Huser ? nullptr : (!last_only ? Huser + t * F * N : (t == T - 1 ? Huser : nullptr));
     kern<<<(unsigned)(slots * NCH), STHREADS, lds, st>>>(x + t * xstep, hp, fixed_state ? h : h + t * hstep, (const uint4*)wpack3, bias, tile_nodes, tile_off,
                                                         (const uint2*)ell_col4, hu, hu_stride ? hu_stride : (int64_t)(last_only ? 1 : T) * F * N, (int)entries, (int)B,
-                                                        (int)N, uni_w, nullptr, nullptr, bscale ? bscale + t * B : nullptr, nullptr);
+                                                        (int)N, uni_w, nullptr, nullptr, bscale ? bscale + t * B : nullptr, nullptr, r1);
   }
   GCRNN_CHECK_LAUNCH();
   return GCRNN_OK;
@@ -399,11 +421,11 @@ __global__ void bwd_seed_x3_kernel(const uint16_t* __restrict__ dH3, const uint1
 template <int K, int HS>
 int x3_backward_launch(const void* dHs3, const void* hs3, void* dpre3, void* dh03, const void* wpack3T, const int32_t* tile_nodes,
                        const int32_t* tile_off, const void* ell_col4, int64_t entries, int64_t B, int64_t T, int64_t N, float uni_w,
-                       hipStream_t st, const float* gf = nullptr, const void* h03 = nullptr, float* gparts = nullptr) {
+                       hipStream_t st, const float* r1, const float* gf = nullptr, const void* h03 = nullptr, float* gparts = nullptr) {
   constexpr int F = 32 * HS, NCH = F / FC;
   const size_t lds = (size_t)NP * FC * 4 + (size_t)3 * K * HS * 1024 + (size_t)entries * 32;
   if (lds > 160 * 1024) return GCRNN_ERR_UNSUPPORTED;
-  auto kern = fused_step_x3_kernel<K, HS, 0, 2>;
+  auto kern = r1 ? fused_step_x3_kernel<K, HS, 0, 2, false, true> : fused_step_x3_kernel<K, HS, 0, 2>;
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
     return GCRNN_ERR_LAUNCH;
   int64_t slots = cdiv(B, 8) * 8;
@@ -419,11 +441,11 @@ int x3_backward_launch(const void* dHs3, const void* hs3, void* dpre3, void* dh0
     kern<<<(unsigned)(slots * NCH), STHREADS, lds, st>>>(nullptr, dp + t * hstep, dp + (t - 1) * hstep, (const uint4*)wpack3T, nullptr, tile_nodes,
                                                         tile_off, (const uint2*)ell_col4, nullptr, 0, (int)entries, (int)B, (int)N, uni_w,
                                                         dH + (t - 1) * hstep, hs + (t - 1) * hstep, gf ? gf + t * B : nullptr,
-                                                        gparts ? gparts + t * B * (NCH * 8) : nullptr);
+                                                        gparts ? gparts + t * B * (NCH * 8) : nullptr, r1);
   if (dh03)      // the raw gradient of the initial state (scaled by gf_0); with gparts: d loss / d gf_0 against the planes of h0
     kern<<<(unsigned)(slots * NCH), STHREADS, lds, st>>>(nullptr, dp, (uint16_t*)dh03, (const uint4*)wpack3T, nullptr, tile_nodes, tile_off,
                                                         (const uint2*)ell_col4, nullptr, 0, (int)entries, (int)B, (int)N, uni_w, nullptr,
-                                                        gparts ? (const uint16_t*)h03 : nullptr, gf, gparts);
+                                                        gparts ? (const uint16_t*)h03 : nullptr, gf, gparts, r1);
   GCRNN_CHECK_LAUNCH();
   return GCRNN_OK;
 }
@@ -431,11 +453,11 @@ int x3_backward_launch(const void* dHs3, const void* hs3, void* dpre3, void* dh0
 // One raw filter pass sum_k S^k (z W_k) on the x3 step kernel (the chain step without an epilogue operand): z3 / out3 [3][B][NP][F] planes
 template <int K, int HS>
 int x3_filter_launch(const void* z3, void* out3, const void* wpack3, const int32_t* tile_nodes, const int32_t* tile_off, const void* ell_col4,
-                     int64_t entries, int64_t B, int64_t N, float uni_w, hipStream_t st) {
+                     int64_t entries, int64_t B, int64_t N, float uni_w, hipStream_t st, const float* r1) {
   constexpr int F = 32 * HS, NCH = F / FC;
   const size_t lds = (size_t)NP * FC * 4 + (size_t)3 * K * HS * 1024 + (size_t)entries * 32;
   if (lds > 160 * 1024) return GCRNN_ERR_UNSUPPORTED;
-  auto kern = fused_step_x3_kernel<K, HS, 0, 2>;
+  auto kern = r1 ? fused_step_x3_kernel<K, HS, 0, 2, false, true> : fused_step_x3_kernel<K, HS, 0, 2>;
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
     return GCRNN_ERR_LAUNCH;
   int64_t slots = cdiv(B, 8) * 8;
@@ -443,7 +465,7 @@ int x3_filter_launch(const void* z3, void* out3, const void* wpack3, const int32
   if (slots > max_slots) slots = max_slots;
   GCRNN_PRE_LAUNCH();
   kern<<<(unsigned)(slots * NCH), STHREADS, lds, st>>>(nullptr, (const uint16_t*)z3, (uint16_t*)out3, (const uint4*)wpack3, nullptr, tile_nodes, tile_off,
-                                                      (const uint2*)ell_col4, nullptr, 0, (int)entries, (int)B, (int)N, uni_w, nullptr, nullptr, nullptr, nullptr);
+                                                      (const uint2*)ell_col4, nullptr, 0, (int)entries, (int)B, (int)N, uni_w, nullptr, nullptr, nullptr, nullptr, r1);
   GCRNN_CHECK_LAUNCH();
   return GCRNN_OK;
 }
@@ -474,7 +496,8 @@ __global__ __launch_bounds__(512) void fused_wgrad_f32_kernel(
     const int32_t* __restrict__ tile_nodes, const int32_t* __restrict__ tile_off, const uint2* __restrict__ ell_col4,
     int entries, int B, int Tn, int N, float uni_w,
     const float* __restrict__ gi, const float* __restrict__ gf,        // time-gated cell (or null): item (t, b) enters the input / state columns with weight gi / gf [T][B]
-    int h_is_h0) {                                                     // != 0: every item's state operand is h0 (the time gates' sub-cells); a null state pointer = zeros: its tiles are skipped
+    int h_is_h0,                                                       // != 0: every item's state operand is h0 (the time gates' sub-cells); a null state pointer = zeros: its tiles are skipped
+    const float* __restrict__ r1) {                                    // rank-1-weighted graph (or null): the [4][NP] table of fused_step_x3_kernel; du_k = b (.) sum (a (.) du_{k-1})
   static_assert(GCRNN_HOP_ASM && TILES == 8, "uniform asm hop stream");
   constexpr int F = 32 * HS, G = 32 * XS, C = F + G, NCH = F / FC, JT = C / 16, HT = TILES;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -555,7 +578,7 @@ __global__ __launch_bounds__(512) void fused_wgrad_f32_kernel(
       for (int i = 0; i < TILES; ++i) {
         int wv = woff[i];
         asm volatile("" : "+v"(wv));
-        if (k < K - 1) *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(state) + (wv & 0xffff)) = cur[i];
+        if (k < K - 1) *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(state) + (wv & 0xffff)) = r1 ? cur[i] * r1[wv >> 16] : cur[i];
         const int node = wv >> 16;
 #pragma unroll
         for (int c = 0; c < 4; ++c) *reinterpret_cast<float*>(dut + (q * 4 + c) * DUT_STRIDE + node * 4) = cur[i][c];
@@ -606,6 +629,14 @@ __global__ __launch_bounds__(512) void fused_wgrad_f32_kernel(
         GCRNN_HOP_ASM_UNI_STREAM(GCRNN_WF_INIT, GCRNN_WF_STORE);
 #undef GCRNN_WF_INIT
 #undef GCRNN_WF_STORE
+        if (r1) {
+#pragma unroll
+          for (int i = 0; i < TILES; ++i) {
+            int wv = woff[i];
+            asm volatile("" : "+v"(wv));
+            cur[i] *= r1[3 * NP + (wv >> 16)];
+          }
+        }
       }
       lds_barrier();
     }
@@ -639,7 +670,7 @@ __global__ __launch_bounds__(512) void fused_wgrad_f32_kernel(
 template <int K, int HS, int XS>
 int x3_wgrad_launch(const void* dpre3, const void* Xuser, const void* Huser, const void* h0user, float* dW, float* dbsum,
                     const int32_t* tile_nodes, const int32_t* tile_off, const void* ell_col4, int64_t entries, int64_t B, int64_t T,
-                    int64_t N, float uni_w, hipStream_t st, const float* gi = nullptr, const float* gf = nullptr, int h_is_h0 = 0) {
+                    int64_t N, float uni_w, hipStream_t st, const float* r1, const float* gi = nullptr, const float* gf = nullptr, int h_is_h0 = 0) {
   constexpr int F = 32 * HS, NCH = F / FC;
   const size_t lds = (size_t)NP * FC * 4 + (size_t)entries * 32 + 16 * DUT_STRIDE + WAVES * FC * 4;
   if (lds > 160 * 1024) return GCRNN_ERR_UNSUPPORTED;
@@ -649,7 +680,7 @@ int x3_wgrad_launch(const void* dpre3, const void* Xuser, const void* Huser, con
   const int64_t slots = gcrnn_fused_wgrad_slots(B * T, F);
   GCRNN_PRE_LAUNCH();
   kern<<<(unsigned)(slots * NCH), 512, lds, st>>>((const uint16_t*)dpre3, (const float*)Xuser, (const float*)Huser, (const float*)h0user, dW, dbsum,
-                                                   tile_nodes, tile_off, (const uint2*)ell_col4, (int)entries, (int)B, (int)T, (int)N, uni_w, gi, gf, h_is_h0);
+                                                   tile_nodes, tile_off, (const uint2*)ell_col4, (int)entries, (int)B, (int)T, (int)N, uni_w, gi, gf, h_is_h0, r1);
   GCRNN_CHECK_LAUNCH();
   return GCRNN_OK;
 }
@@ -726,7 +757,7 @@ extern "C" int gcrnn_fused_pack_weights_x3(const void* wA, const void* wB, void*
 extern "C" int gcrnn_fused_forward_x3(const void* xs3, const void* h03, void* hs3, const void* wpack3, const float* bias,
                                       const int32_t* tile_nodes, const int32_t* tile_off, const void* ell_col4, int64_t entries,
                                       int64_t B, int64_t T, int64_t N, int64_t F, int64_t G, int64_t K, double uniform_w, void* Huser,
-                                      int last_only, void* stream) {
+                                      int last_only, const float* rank1, void* stream) {
   if (!xs3 || !h03 || !hs3 || !wpack3 || !tile_nodes || !tile_off || !ell_col4) return GCRNN_ERR_NULL_POINTER;
   if (B <= 0 || T <= 0 || uniform_w == 0.0 || !gcrnn_fused_x3_supported(N, F, G, K, entries)) return GCRNN_ERR_BAD_SHAPE;
   if (3 * B * (NP * (F > G ? F : G) * 2) > 2147483647LL) return GCRNN_ERR_BAD_SHAPE;         // 32-bit buffer offsets
@@ -734,7 +765,7 @@ extern "C" int gcrnn_fused_forward_x3(const void* xs3, const void* h03, void* hs
   hipStream_t st = as_stream(stream);
 #define GCRNN_X3_CASE(KK, HH, XX) \
   if (K == KK && F == 32 * HH && G == 32 * XX) \
-    return x3_launch<KK, HH, XX>(xs3, h03, hs3, wpack3, bias, tile_nodes, tile_off, ell_col4, entries, B, T, N, (float)uniform_w, (float*)Huser, last_only, st);
+    return x3_launch<KK, HH, XX>(xs3, h03, hs3, wpack3, bias, tile_nodes, tile_off, ell_col4, entries, B, T, N, (float)uniform_w, (float*)Huser, last_only, st, rank1);
   GCRNN_X3_CASE(5, 2, 2) GCRNN_X3_CASE(4, 2, 2) GCRNN_X3_CASE(3, 2, 2) GCRNN_X3_CASE(2, 2, 2)
   GCRNN_X3_CASE(5, 2, 1) GCRNN_X3_CASE(4, 2, 1) GCRNN_X3_CASE(3, 2, 1) GCRNN_X3_CASE(2, 2, 1)
   GCRNN_X3_CASE(5, 1, 1) GCRNN_X3_CASE(4, 1, 1) GCRNN_X3_CASE(3, 1, 1) GCRNN_X3_CASE(2, 1, 1)
@@ -749,7 +780,7 @@ extern "C" int gcrnn_fused_forward_x3(const void* xs3, const void* h03, void* hs
 extern "C" int gcrnn_fused_forward_x3_scaled(const void* xs3, const void* h03, void* hs3, const void* wpack3, const float* bias,
                                              const float* bias_scale, const int32_t* tile_nodes, const int32_t* tile_off, const void* ell_col4,
                                              int64_t entries, int64_t B, int64_t T, int64_t N, int64_t F, int64_t G, int64_t K,
-                                             double uniform_w, void* Huser, int64_t huser_seq_stride, void* stream) {
+                                             double uniform_w, void* Huser, int64_t huser_seq_stride, const float* rank1, void* stream) {
   if (!xs3 || !h03 || !hs3 || !wpack3 || !tile_nodes || !tile_off || !ell_col4) return GCRNN_ERR_NULL_POINTER;
   if (B <= 0 || T <= 0 || uniform_w == 0.0 || !gcrnn_fused_x3_supported(N, F, G, K, entries)) return GCRNN_ERR_BAD_SHAPE;
   if (3 * B * (NP * (F > G ? F : G) * 2) > 2147483647LL) return GCRNN_ERR_BAD_SHAPE;         // 32-bit buffer offsets
@@ -758,7 +789,7 @@ extern "C" int gcrnn_fused_forward_x3_scaled(const void* xs3, const void* h03, v
   hipStream_t st = as_stream(stream);
 #define GCRNN_X3_CASE(KK, HH, XX) \
   if (K == KK && F == 32 * HH && G == 32 * XX) \
-    return x3_launch<KK, HH, XX>(xs3, h03, hs3, wpack3, bias, tile_nodes, tile_off, ell_col4, entries, B, T, N, (float)uniform_w, (float*)Huser, 0, st, \
+    return x3_launch<KK, HH, XX>(xs3, h03, hs3, wpack3, bias, tile_nodes, tile_off, ell_col4, entries, B, T, N, (float)uniform_w, (float*)Huser, 0, st, rank1, \
                                  bias_scale, huser_seq_stride);
   GCRNN_X3_CASE(5, 2, 2) GCRNN_X3_CASE(4, 2, 2) GCRNN_X3_CASE(3, 2, 2) GCRNN_X3_CASE(2, 2, 2)
   GCRNN_X3_CASE(5, 2, 1) GCRNN_X3_CASE(4, 2, 1) GCRNN_X3_CASE(3, 2, 1) GCRNN_X3_CASE(2, 2, 1)
@@ -775,7 +806,7 @@ extern "C" int gcrnn_fused_forward_x3_scaled(const void* xs3, const void* h03, v
 extern "C" int gcrnn_fused_gate_cells_x3(const void* xs3, const void* h03, void* scratch3, const void* wpack3, const float* bias,
                                          const int32_t* tile_nodes, const int32_t* tile_off, const void* ell_col4, int64_t entries,
                                          int64_t B, int64_t T, int64_t N, int64_t F, int64_t G, int64_t K, double uniform_w, void* Cuser,
-                                         int state_zero, void* stream) {
+                                         int state_zero, const float* rank1, void* stream) {
   if (!xs3 || !h03 || !scratch3 || !wpack3 || !tile_nodes || !tile_off || !ell_col4 || !Cuser) return GCRNN_ERR_NULL_POINTER;
   if (B <= 0 || T <= 0 || uniform_w == 0.0 || !gcrnn_fused_x3_supported(N, F, G, K, entries)) return GCRNN_ERR_BAD_SHAPE;
   if (3 * B * (NP * (F > G ? F : G) * 2) > 2147483647LL) return GCRNN_ERR_BAD_SHAPE;
@@ -783,7 +814,7 @@ extern "C" int gcrnn_fused_gate_cells_x3(const void* xs3, const void* h03, void*
   hipStream_t st = as_stream(stream);
 #define GCRNN_X3_CASE(KK, HH, XX) \
   if (K == KK && F == 32 * HH && G == 32 * XX) \
-    return x3_launch<KK, HH, XX>(xs3, h03, scratch3, wpack3, bias, tile_nodes, tile_off, ell_col4, entries, B, T, N, (float)uniform_w, (float*)Cuser, 0, st, \
+    return x3_launch<KK, HH, XX>(xs3, h03, scratch3, wpack3, bias, tile_nodes, tile_off, ell_col4, entries, B, T, N, (float)uniform_w, (float*)Cuser, 0, st, rank1, \
                                  nullptr, 0, 1, state_zero);
   GCRNN_X3_CASE(5, 2, 2) GCRNN_X3_CASE(4, 2, 2) GCRNN_X3_CASE(3, 2, 2) GCRNN_X3_CASE(2, 2, 2)
   GCRNN_X3_CASE(5, 2, 1) GCRNN_X3_CASE(4, 2, 1) GCRNN_X3_CASE(3, 2, 1) GCRNN_X3_CASE(2, 2, 1)
@@ -799,13 +830,13 @@ extern "C" int gcrnn_fused_gate_cells_x3(const void* xs3, const void* h03, void*
 // Utils/graphML.py:2420-2423 in the drivers' precision (kStepPredGRNNs.py:44).
 extern "C" int gcrnn_fused_backward_data_x3(const void* dHs3, const void* hs3, void* dpre3, void* dh03, const void* wpack3T,
                                             const int32_t* tile_nodes, const int32_t* tile_off, const void* ell_col4, int64_t entries,
-                                            int64_t B, int64_t T, int64_t N, int64_t F, int64_t K, double uniform_w, void* stream) {
+                                            int64_t B, int64_t T, int64_t N, int64_t F, int64_t K, double uniform_w, const float* rank1, void* stream) {
   if (!dHs3 || !hs3 || !dpre3 || !wpack3T || !tile_nodes || !tile_off || !ell_col4) return GCRNN_ERR_NULL_POINTER;
   if (B <= 0 || T <= 0 || uniform_w == 0.0 || !gcrnn_fused_x3_supported(N, F, F, K, entries)) return GCRNN_ERR_BAD_SHAPE;
   if (3 * B * (NP * F * 2) > 2147483647LL) return GCRNN_ERR_BAD_SHAPE;
   hipStream_t st = as_stream(stream);
 #define GCRNN_X3B_CASE(KK, HH) \
-  if (K == KK && F == 32 * HH) return x3_backward_launch<KK, HH>(dHs3, hs3, dpre3, dh03, wpack3T, tile_nodes, tile_off, ell_col4, entries, B, T, N, (float)uniform_w, st);
+  if (K == KK && F == 32 * HH) return x3_backward_launch<KK, HH>(dHs3, hs3, dpre3, dh03, wpack3T, tile_nodes, tile_off, ell_col4, entries, B, T, N, (float)uniform_w, st, rank1);
   GCRNN_X3B_CASE(5, 2) GCRNN_X3B_CASE(4, 2) GCRNN_X3B_CASE(3, 2) GCRNN_X3B_CASE(2, 2)
   GCRNN_X3B_CASE(5, 1) GCRNN_X3B_CASE(4, 1) GCRNN_X3B_CASE(3, 1) GCRNN_X3B_CASE(2, 1)
 #undef GCRNN_X3B_CASE
@@ -819,14 +850,14 @@ extern "C" int gcrnn_fused_backward_data_x3(const void* dHs3, const void* hs3, v
 extern "C" int gcrnn_fused_backward_data_x3_gated(const void* dHs3, const void* hs3, void* dpre3, void* dh03, const void* wpack3T,
                                                   const int32_t* tile_nodes, const int32_t* tile_off, const void* ell_col4, int64_t entries,
                                                   int64_t B, int64_t T, int64_t N, int64_t F, int64_t K, double uniform_w, const float* gf,
-                                                  const void* h03, float* dgf_parts, void* stream) {
+                                                  const void* h03, float* dgf_parts, const float* rank1, void* stream) {
   if (!dHs3 || !hs3 || !dpre3 || !dh03 || !wpack3T || !tile_nodes || !tile_off || !ell_col4 || !gf) return GCRNN_ERR_NULL_POINTER;
   if (dgf_parts && !h03) return GCRNN_ERR_NULL_POINTER;
   if (B <= 0 || T <= 0 || uniform_w == 0.0 || !gcrnn_fused_x3_supported(N, F, F, K, entries)) return GCRNN_ERR_BAD_SHAPE;
   if (3 * B * (NP * F * 2) > 2147483647LL) return GCRNN_ERR_BAD_SHAPE;
   hipStream_t st = as_stream(stream);
 #define GCRNN_X3B_CASE(KK, HH) \
-  if (K == KK && F == 32 * HH) return x3_backward_launch<KK, HH>(dHs3, hs3, dpre3, dh03, wpack3T, tile_nodes, tile_off, ell_col4, entries, B, T, N, (float)uniform_w, st, gf, h03, dgf_parts);
+  if (K == KK && F == 32 * HH) return x3_backward_launch<KK, HH>(dHs3, hs3, dpre3, dh03, wpack3T, tile_nodes, tile_off, ell_col4, entries, B, T, N, (float)uniform_w, st, rank1, gf, h03, dgf_parts);
   GCRNN_X3B_CASE(5, 2) GCRNN_X3B_CASE(4, 2) GCRNN_X3B_CASE(3, 2) GCRNN_X3B_CASE(2, 2)
   GCRNN_X3B_CASE(5, 1) GCRNN_X3B_CASE(4, 1) GCRNN_X3B_CASE(3, 1) GCRNN_X3B_CASE(2, 1)
 #undef GCRNN_X3B_CASE
@@ -839,13 +870,13 @@ extern "C" int gcrnn_fused_backward_data_x3_gated(const void* dHs3, const void* 
 // off it (items = all (t, b)).
 extern "C" int gcrnn_fused_filter_x3(const void* z3, void* out3, const void* wpack3, const int32_t* tile_nodes, const int32_t* tile_off,
                                      const void* ell_col4, int64_t entries, int64_t B, int64_t N, int64_t F, int64_t K, double uniform_w,
-                                     void* stream) {
+                                     const float* rank1, void* stream) {
   if (!z3 || !out3 || !wpack3 || !tile_nodes || !tile_off || !ell_col4) return GCRNN_ERR_NULL_POINTER;
   if (B <= 0 || uniform_w == 0.0 || !gcrnn_fused_x3_supported(N, F, F, K, entries)) return GCRNN_ERR_BAD_SHAPE;
   if (3 * B * (NP * F * 2) > 2147483647LL) return GCRNN_ERR_BAD_SHAPE;
   hipStream_t st = as_stream(stream);
 #define GCRNN_X3F_CASE(KK, HH) \
-  if (K == KK && F == 32 * HH) return x3_filter_launch<KK, HH>(z3, out3, wpack3, tile_nodes, tile_off, ell_col4, entries, B, N, (float)uniform_w, st);
+  if (K == KK && F == 32 * HH) return x3_filter_launch<KK, HH>(z3, out3, wpack3, tile_nodes, tile_off, ell_col4, entries, B, N, (float)uniform_w, st, rank1);
   GCRNN_X3F_CASE(5, 2) GCRNN_X3F_CASE(4, 2) GCRNN_X3F_CASE(3, 2) GCRNN_X3F_CASE(2, 2)
   GCRNN_X3F_CASE(5, 1) GCRNN_X3F_CASE(4, 1) GCRNN_X3F_CASE(3, 1) GCRNN_X3F_CASE(2, 1)
 #undef GCRNN_X3F_CASE
@@ -858,14 +889,14 @@ extern "C" int gcrnn_fused_filter_x3(const void* z3, void* out3, const void* wpa
 extern "C" int gcrnn_fused_backward_weight_f32(const void* dpre3, const void* Xuser, const void* Huser, const void* h0user, float* dW,
                                                float* dbsum, const int32_t* tile_nodes, const int32_t* tile_off, const void* ell_col4,
                                                int64_t entries, int64_t B, int64_t T, int64_t N, int64_t F, int64_t G, int64_t K,
-                                               double uniform_w, void* stream) {
+                                               double uniform_w, const float* rank1, void* stream) {
   if (!dpre3 || !Xuser || !Huser || !h0user || !dW || !tile_nodes || !tile_off || !ell_col4) return GCRNN_ERR_NULL_POINTER;
   if (B <= 0 || T <= 0 || N <= 0 || N > NP || N % 4 || entries < 0 || entries % 4 || uniform_w == 0.0 || B * T > (1 << 24)) return GCRNN_ERR_BAD_SHAPE;
   if (3 * B * (NP * F * 2) > 2147483647LL || (int64_t)(F > G ? F : G) * N * 4 > 2147483647LL) return GCRNN_ERR_BAD_SHAPE;      // 32-bit buffer offsets (per time step)
   if ((reinterpret_cast<uintptr_t>(Xuser) | reinterpret_cast<uintptr_t>(Huser) | reinterpret_cast<uintptr_t>(h0user)) & 15) return GCRNN_ERR_BAD_SHAPE;
   hipStream_t st = as_stream(stream);
 #define GCRNN_WF_CASE(KK, HH, XX) \
-  if (K == KK && F == 32 * HH && G == 32 * XX) return x3_wgrad_launch<KK, HH, XX>(dpre3, Xuser, Huser, h0user, dW, dbsum, tile_nodes, tile_off, ell_col4, entries, B, T, N, (float)uniform_w, st);
+  if (K == KK && F == 32 * HH && G == 32 * XX) return x3_wgrad_launch<KK, HH, XX>(dpre3, Xuser, Huser, h0user, dW, dbsum, tile_nodes, tile_off, ell_col4, entries, B, T, N, (float)uniform_w, st, rank1);
   GCRNN_WF_CASE(5, 2, 2) GCRNN_WF_CASE(4, 2, 2) GCRNN_WF_CASE(3, 2, 2) GCRNN_WF_CASE(2, 2, 2)
   GCRNN_WF_CASE(5, 2, 1) GCRNN_WF_CASE(4, 2, 1) GCRNN_WF_CASE(3, 2, 1) GCRNN_WF_CASE(2, 2, 1)
   GCRNN_WF_CASE(5, 1, 1) GCRNN_WF_CASE(4, 1, 1) GCRNN_WF_CASE(3, 1, 1) GCRNN_WF_CASE(2, 1, 1)
@@ -880,7 +911,7 @@ extern "C" int gcrnn_fused_backward_weight_f32(const void* dpre3, const void* Xu
 extern "C" int gcrnn_fused_backward_weight_f32_gated(const void* dpre3, const void* Xuser, const void* Huser, const void* h0user, float* dW,
                                                      float* dbsum, const int32_t* tile_nodes, const int32_t* tile_off, const void* ell_col4,
                                                      int64_t entries, int64_t B, int64_t T, int64_t N, int64_t F, int64_t G, int64_t K,
-                                                     double uniform_w, const float* gi, const float* gf, int h_is_h0, void* stream) {
+                                                     double uniform_w, const float* gi, const float* gf, int h_is_h0, const float* rank1, void* stream) {
   if (!dpre3 || !Xuser || !dW || !tile_nodes || !tile_off || !ell_col4 || (!gi) != (!gf)) return GCRNN_ERR_NULL_POINTER;
   if (!h_is_h0 && (!Huser || !h0user)) return GCRNN_ERR_NULL_POINTER;
   if (B <= 0 || T <= 0 || N <= 0 || N > NP || N % 4 || entries < 0 || entries % 4 || uniform_w == 0.0 || B * T > (1 << 24)) return GCRNN_ERR_BAD_SHAPE;
@@ -888,7 +919,7 @@ extern "C" int gcrnn_fused_backward_weight_f32_gated(const void* dpre3, const vo
   if ((reinterpret_cast<uintptr_t>(Xuser) | reinterpret_cast<uintptr_t>(Huser) | reinterpret_cast<uintptr_t>(h0user)) & 15) return GCRNN_ERR_BAD_SHAPE;
   hipStream_t st = as_stream(stream);
 #define GCRNN_WF_CASE(KK, HH, XX) \
-  if (K == KK && F == 32 * HH && G == 32 * XX) return x3_wgrad_launch<KK, HH, XX>(dpre3, Xuser, Huser, h0user, dW, dbsum, tile_nodes, tile_off, ell_col4, entries, B, T, N, (float)uniform_w, st, gi, gf, h_is_h0);
+  if (K == KK && F == 32 * HH && G == 32 * XX) return x3_wgrad_launch<KK, HH, XX>(dpre3, Xuser, Huser, h0user, dW, dbsum, tile_nodes, tile_off, ell_col4, entries, B, T, N, (float)uniform_w, st, rank1, gi, gf, h_is_h0);
   GCRNN_WF_CASE(5, 2, 2) GCRNN_WF_CASE(4, 2, 2) GCRNN_WF_CASE(3, 2, 2) GCRNN_WF_CASE(2, 2, 2)
   GCRNN_WF_CASE(5, 2, 1) GCRNN_WF_CASE(4, 2, 1) GCRNN_WF_CASE(3, 2, 1) GCRNN_WF_CASE(2, 2, 1)
   GCRNN_WF_CASE(5, 1, 1) GCRNN_WF_CASE(4, 1, 1) GCRNN_WF_CASE(3, 1, 1) GCRNN_WF_CASE(2, 1, 1)

@@ -283,6 +283,42 @@ class GraphOperator(object):
         self.__dict__[key] = res
         return res
 
+    def fused_plan_x3(self, adjoint=False):
+        """The plan the fp32-accurate ("x3") kernels run on: fused_plan(adjoint) for uniform-weight graphs; for RANK-1-weighted graphs
+        (rank1_factors: normalised adjacencies, Utils/graphTools.py:64) the plan of the 0/1 pattern (uniform_w = 1) plus 'rank1_x3', the
+        [4][NPad] fp32 table a | a b | 1 / b | b of include/gcrnn.h (a = source factor, b = destination factor of this direction; 1 where b = 0).
+        Other graphs: fused_plan(adjoint) as it is (uniform_w = 0: the x3 predicates say no)."""
+        key = '_fused_plan_x3_adj' if adjoint else '_fused_plan_x3'
+        if key in self.__dict__:
+            return self.__dict__[key]
+        res = self.fused_plan(adjoint=adjoint)
+        import os
+        if res.get('uniform_w', 0.0) == 0.0 and not os.environ.get('GCRNN_NO_RANK1'):
+            fac = self.rank1_factors(adjoint=False)
+            if fac is not None:
+                pat = self.__dict__.get('_pattern_operator')
+                if pat is None:
+                    Sd = np.zeros((1, self.N, self.N))
+                    c = self.adj[0]
+                    Sd[0, c.rows().cpu().numpy(), c.col.cpu().numpy().astype(np.int64)] = 1.0
+                    pat = GraphOperator(Sd, device=self.device)
+                    self._pattern_operator = pat
+                pp = pat.fused_plan(adjoint=adjoint)
+                if pp.get('uniform_w', 0.0) == 1.0:
+                    a, b = (fac[1], fac[0]) if adjoint else (fac[0], fac[1])
+                    npad = pp['npad']
+                    tab = np.zeros((4, npad), dtype=np.float64)
+                    tab[2:] = 1.0
+                    nz = b != 0
+                    tab[0, :self.N] = a
+                    tab[1, :self.N] = a * np.where(nz, b, 1.0)
+                    tab[2, :self.N] = np.where(nz, 1.0 / np.where(nz, b, 1.0), 1.0)
+                    tab[3, :self.N] = np.where(nz, b, 1.0)
+                    res = dict(pp)
+                    res['rank1_x3'] = torch.from_numpy(tab.astype(np.float32)).to(self.device).contiguous()
+        self.__dict__[key] = res
+        return res
+
     def fused_plan(self, adjoint=False, kernel='step'):
         """Degree-sorted sliced ELL of CSR(S^T) (forward shift) or, with adjoint=True, of CSR(S) (the shift of the
         backward pass) for the fused step kernels (E = 1): device tensors order (int32 [N]), tile_off

@@ -1420,7 +1420,7 @@ def fused_x3_supported(graph, N, F, G, Kin, Kst, dtype, E=1, B=None, T=None):
     Gp = fused_padded_inputs(F, G)
     if Gp is None:
         return False
-    plan = graph.fused_plan()
+    plan = graph.fused_plan_x3()
     if B is not None and T is not None:
         # limits of the x3 pack (gridDim.z = B * T) and of the 32-bit offsets into the three-plane arrays: such batches fall back to the
         # composed path instead of failing inside the forward (or, worse, inside the backward after the forward has run)
@@ -1435,7 +1435,7 @@ def time_fused_x3_kernel(X, h0, wA, wB, bias, graph, reps=3):
     B, T, G, N = X.shape
     F, Kin, Kst = wA.shape[0], wA.shape[2], wB.shape[2]
     K = max(Kin, Kst)
-    plan = graph.fused_plan()
+    plan = graph.fused_plan_x3()
     npad, st, dev = plan['npad'], _stream(), X.device
     Xc, h0c = X.contiguous(), h0.contiguous()
     xs3 = torch.empty((T, 3, B, npad, G), dtype=torch.bfloat16, device=dev)
@@ -1453,7 +1453,7 @@ def time_fused_x3_kernel(X, h0, wA, wB, bias, graph, reps=3):
     e0.record()
     for _ in range(reps):
         check(lib.gcrnn_fused_forward_x3(_p(xs3), _p(h03), _p(hs3), _p(wp3), _p(b32), _p(plan['tile_slots']), _p(plan['tile_off']),
-                                         _p(plan['ell_col4']), plan['entries'], B, T, N, F, G, K, plan['uniform_w'], _p(H), 0, st),
+                                         _p(plan['ell_col4']), plan['entries'], B, T, N, F, G, K, plan['uniform_w'], _p(H), 0, _p(plan.get('rank1_x3')), st),
               'fused_forward_x3')
     e1.record()
     torch.cuda.synchronize()
@@ -1471,7 +1471,7 @@ def fused_cell_forward_x3(X, h0, wA, wB, bias, graph, last_only=False, keep=Fals
     F = wA.shape[0]
     Kin, Kst = wA.shape[2], wB.shape[2]
     K = max(Kin, Kst)
-    plan = graph.fused_plan()
+    plan = graph.fused_plan_x3()
     npad = plan['npad']
     st = _stream()
     dev = X.device
@@ -1488,7 +1488,7 @@ def fused_cell_forward_x3(X, h0, wA, wB, bias, graph, last_only=False, keep=Fals
     H = torch.empty((B, 1 if last_only else T, F, N), dtype=torch.float32, device=dev)
     check(lib.gcrnn_fused_forward_x3(_p(xs3), _p(h03), _p(hs3), _p(wp3), _p(b32), _p(plan['tile_slots']), _p(plan['tile_off']),
                                      _p(plan['ell_col4']), plan['entries'], B, T, N, F, G, K, plan['uniform_w'], _p(H),
-                                     int(last_only), st), 'fused_forward_x3')
+                                     int(last_only), _p(plan.get('rank1_x3')), st), 'fused_forward_x3')
     if keep:
         return H, hs3, Xc
     return H
@@ -1506,7 +1506,7 @@ def fused_x3_training_supported(graph, N, F, G, Kin, Kst, dtype, E=1, B=None, T=
     too (a symmetric-support GSO like the drivers' W / lambda_max) with an image that fits next to the backward's two fp32 images."""
     if not fused_x3_supported(graph, N, F, G, Kin, Kst, dtype, E, B, T):
         return False
-    pa = graph.fused_plan(adjoint=True)
+    pa = graph.fused_plan_x3(adjoint=True)
     Gp = fused_padded_inputs(F, G)
     return pa.get('uniform_w', 0.0) != 0.0 and bool(lib.gcrnn_fused_x3_training_supported(int(N), int(F), int(Gp), int(max(Kin, Kst)), int(pa['entries'])))
 
@@ -1533,7 +1533,7 @@ class _FusedCellX3(torch.autograd.Function):
         B, T, Gp, N = Xp.shape
         F, Kin, Kst = wA.shape[0], wA.shape[2], wB.shape[2]
         K = max(Kin, Kst)
-        plan = graph.fused_plan(adjoint=True)
+        plan = graph.fused_plan_x3(adjoint=True)
         npad, st, dev = plan['npad'], _stream(), Xp.device
         dHc = dH.float().contiguous()
         dH3 = torch.empty((T, 3, B, npad, F), dtype=torch.bfloat16, device=dev)
@@ -1547,13 +1547,13 @@ class _FusedCellX3(torch.autograd.Function):
         dpre3 = torch.empty((T, 3, B, npad, F), dtype=torch.bfloat16, device=dev)
         dh03 = torch.empty((3, B, npad, F), dtype=torch.bfloat16, device=dev) if ctx.needs_input_grad[1] else None
         check(lib.gcrnn_fused_backward_data_x3(_p(dH3), _p(hs3), _p(dpre3), _p(dh03), _p(wp3T), _p(plan['tile_slots']), _p(plan['tile_off']),
-                                               _p(plan['ell_col4']), plan['entries'], B, T, N, F, K, plan['uniform_w'], st), 'fused_backward_data_x3')
+                                               _p(plan['ell_col4']), plan['entries'], B, T, N, F, K, plan['uniform_w'], _p(plan.get('rank1_x3')), st), 'fused_backward_data_x3')
         slots = int(lib.gcrnn_fused_wgrad_slots(T * B, F))
         dWp = torch.zeros((slots, F, K, F + Gp), dtype=torch.float32, device=dev)
         dbp = torch.zeros((slots, F), dtype=torch.float32, device=dev)
         h0c = h0.detach().float().contiguous()
         check(lib.gcrnn_fused_backward_weight_f32(_p(dpre3), _p(Xp), _p(H), _p(h0c), _p(dWp), _p(dbp), _p(plan['tile_slots']), _p(plan['tile_off']),
-                                                  _p(plan['ell_col4']), plan['entries'], B, T, N, F, Gp, K, plan['uniform_w'], st), 'fused_backward_weight_f32')
+                                                  _p(plan['ell_col4']), plan['entries'], B, T, N, F, Gp, K, plan['uniform_w'], _p(plan.get('rank1_x3')), st), 'fused_backward_weight_f32')
         dW = dWp.sum(dim=0)                                                 # fixed order over the slots: bit-reproducible
         G = ctx.G
         gA = dW[:, :Kin, F:F + G].unsqueeze(1).to(wA.dtype) if ctx.needs_input_grad[2] else None
@@ -1598,7 +1598,7 @@ def _x3_time_gated_forward(X, h0, wA, wB, bias, graph, gates, keep=False, last_o
     B, T, Gp, N = Xp.shape
     F, Kin, Kst = wAp.shape[0], wAp.shape[2], wB.shape[2]
     K = max(Kin, Kst)
-    plan = graph.fused_plan()
+    plan = graph.fused_plan_x3()
     npad, st, dev = plan['npad'], _stream(), X.device
     Xp = Xp.float().contiguous()
     h0c = h0.detach().float().contiguous()
@@ -1617,7 +1617,7 @@ def _x3_time_gated_forward(X, h0, wA, wB, bias, graph, gates, keep=False, last_o
         check(lib.gcrnn_fused_pack_weights_x3(_p(wAg), _p(wBg), _p(wpg), F, Gp, wA_g.shape[2], wB_g.shape[2], st), 'pack_weights_x3')
         bg = bias_g.detach().float().contiguous().view(-1) if bias_g is not None else None
         c = torch.empty((B, T, F, N), dtype=torch.float32, device=dev)          # the gate cells' states (training keeps them for their BPTT)
-        check(lib.gcrnn_fused_gate_cells_x3(_p(xs3), _p(h03), _p(h3), _p(wpg), _p(bg), *gargs, B, T, N, F, Gp, Kg, plan['uniform_w'], _p(c), int(hzero), st),
+        check(lib.gcrnn_fused_gate_cells_x3(_p(xs3), _p(h03), _p(h3), _p(wpg), _p(bg), *gargs, B, T, N, F, Gp, Kg, plan['uniform_w'], _p(c), int(hzero), _p(plan.get('rank1_x3')), st),
               'fused_gate_cells_x3')
         logit = (c.view(B * T, F * N) @ lin_w.detach().float().reshape(-1)).view(B, T).t()
         if lin_b is not None:
@@ -1642,7 +1642,7 @@ def _x3_time_gated_forward(X, h0, wA, wB, bias, graph, gates, keep=False, last_o
         check(lib.gcrnn_pack_seq_major_x3_ex(_p(hprev), _p(h3), B, 1, F, N, npad, _p(gf[t]), None, 0, 0 if t == 0 else T * F * N, st),
               'pack_seq_x3_ex')                                                                  # planes of gf_t h_{t-1}
         check(lib.gcrnn_fused_forward_x3_scaled(_p(xs3[t]), _p(h3), _p(hs3[t]), _p(wp3), _p(b32), _p(bsc[t]), *gargs, B, 1, N, F, Gp, K,
-                                                plan['uniform_w'], _p(H[:, t]), T * F * N, st), 'fused_forward_x3_scaled')
+                                                plan['uniform_w'], _p(H[:, t]), T * F * N, _p(plan.get('rank1_x3')), st), 'fused_forward_x3_scaled')
     del xs3
     if last_only:
         return H[:, T - 1:].contiguous()
@@ -1678,7 +1678,7 @@ class _FusedTimeCellX3(torch.autograd.Function):
         B, T, Gp, N = Xp.shape
         F, Kin, Kst = wA.shape[0], wA.shape[2], wB.shape[2]
         K = max(Kin, Kst)
-        plan, pa = graph.fused_plan(), graph.fused_plan(adjoint=True)
+        plan, pa = graph.fused_plan_x3(), graph.fused_plan_x3(adjoint=True)
         npad, st, dev = pa['npad'], _stream(), Xp.device
         gargs = (_p(plan['tile_slots']), _p(plan['tile_off']), _p(plan['ell_col4']), plan['entries'])
         aargs = (_p(pa['tile_slots']), _p(pa['tile_off']), _p(pa['ell_col4']), pa['entries'])
@@ -1699,7 +1699,7 @@ class _FusedTimeCellX3(torch.autograd.Function):
         dh03 = torch.empty((3, B, npad, F), dtype=torch.bfloat16, device=dev)
         parts = torch.empty((T, B, nparts), dtype=torch.float32, device=dev)
         check(lib.gcrnn_fused_backward_data_x3_gated(_p(dH3), _p(hs3), _p(dpre3), _p(dh03), _p(wp3T), *aargs, B, T, N, F, K, pa['uniform_w'],
-                                                     _p(gf), _p(h03), _p(parts), st), 'fused_backward_data_x3_gated')
+                                                     _p(gf), _p(h03), _p(parts), _p(pa.get('rank1_x3')), st), 'fused_backward_data_x3_gated')
         del dH3, dh03
         # ---- d gi = <A(S) x_t + b, dpre_t>: one filter pass per step over the planes of X (the input taps as an F -> F filter, zero columns
         # beyond G), dotted with dpre per item; the bias part <b, sum_n dpre_t> is shared with d gf ----
@@ -1718,7 +1718,7 @@ class _FusedTimeCellX3(torch.autograd.Function):
             del Xf
         y3 = torch.empty((T, 3, B, npad, F), dtype=torch.bfloat16, device=dev)
         for t in range(T):
-            check(lib.gcrnn_fused_filter_x3(_p(z3[t]), _p(y3[t]), _p(wp3A), *gargs, B, N, F, K, plan['uniform_w'], st), 'fused_filter_x3')
+            check(lib.gcrnn_fused_filter_x3(_p(z3[t]), _p(y3[t]), _p(wp3A), *gargs, B, N, F, K, plan['uniform_w'], _p(plan.get('rank1_x3')), st), 'fused_filter_x3')
         del z3
         dgi = torch.empty((T, B), dtype=torch.float32, device=dev)
         cb = torch.empty((T, B), dtype=torch.float32, device=dev)
@@ -1731,7 +1731,7 @@ class _FusedTimeCellX3(torch.autograd.Function):
         dWp = torch.zeros((slots, F, K, F + Gp), dtype=torch.float32, device=dev)
         dbp = torch.zeros((slots, F), dtype=torch.float32, device=dev)
         check(lib.gcrnn_fused_backward_weight_f32_gated(_p(dpre3), _p(Xp), _p(H), _p(h0c), _p(dWp), _p(dbp), *aargs, B, T, N, F, Gp, K,
-                                                        pa['uniform_w'], _p(gi), _p(gf), 0, st), 'fused_backward_weight_f32_gated')
+                                                        pa['uniform_w'], _p(gi), _p(gf), 0, _p(pa.get('rank1_x3')), st), 'fused_backward_weight_f32_gated')
         dW = dWp.sum(dim=0)
         G = ctx.G
         need = ctx.needs_input_grad
@@ -1758,7 +1758,7 @@ class _FusedTimeCellX3(torch.autograd.Function):
                 dWs = torch.zeros((slots, F, Kg, F + Ggp), dtype=torch.float32, device=dev)
                 dbs = torch.zeros((slots, F), dtype=torch.float32, device=dev)
                 check(lib.gcrnn_fused_backward_weight_f32_gated(_p(dpre3), _p(Xg), None, None if ctx.hzero else _p(h0c), _p(dWs), _p(dbs), *aargs,
-                                                                B, T, N, F, Ggp, Kg, pa['uniform_w'], None, None, 1, st), 'fused_backward_weight_f32_gated')
+                                                                B, T, N, F, Ggp, Kg, pa['uniform_w'], None, None, 1, _p(pa.get('rank1_x3')), st), 'fused_backward_weight_f32_gated')
                 dWg, dbg = dWs.sum(dim=0), dbs.sum(dim=0)
                 g_wA = dWg[:, :Kg_in, F:F + Ggp].unsqueeze(1).to(wA_g.dtype) if need[base] else None
                 g_wB = dWg[:, :Kg_st, :F].unsqueeze(1).to(wB_g.dtype) if need[base + 1] else None

@@ -229,6 +229,10 @@ int gcrnn_fused_backward_seed_bf16(const void* dH, const void* h, void* dpre, in
  * gcrnn_ell_pack_lds; uniform_w = the one weight); Huser fp32 [B][T][F][N] (or [B][1][F][N] with last_only != 0) or NULL.
  * gcrnn_fused_x3_supported: F = G in {32, 64} or F = 64 with G = 32, K in 2..5, N <= 1024, N % 4 == 0, and the image fits LDS
  * (64 KiB state + 3 tap planes + 32 B x entries <= 160 KiB). */
+/* (r4) rank1 (last pointer of every x3 compute entry; NULL = a uniform-weight graph): a RANK-1-weighted graph S[m][n] = a[m] b[n] on its support
+ * (normalised adjacencies, Utils/graphTools.py:64) runs on the plan of its 0/1 PATTERN (uniform_w = 1) with a [4][NPad] fp32 table
+ * a | a b | 1 / b | b (1 where b = 0; zeros in the padding rows of the first two): the Horner recursion is carried in t' = t / b, t'_j = u_j / b +
+ * sum_{m in N(n)} (a b t'_{j+1})[m], t_0 = b t'_0, so the uniform stream still adds in place. Adjoint plans take the table of S^T (a and b swap). */
 int gcrnn_fused_x3_supported(int64_t N, int64_t F, int64_t G, int64_t K, int64_t entries);
 int gcrnn_pack_seq_major_x3(const void* src, void* dst, int64_t B, int64_t T, int64_t C, int64_t N, int64_t NPad, void* stream);
 int gcrnn_fused_pack_weights_x3(const void* wA, const void* wB, void* wpack3, int64_t F, int64_t G, int64_t Kin, int64_t Kst,
@@ -236,7 +240,7 @@ int gcrnn_fused_pack_weights_x3(const void* wA, const void* wB, void* wpack3, in
 int gcrnn_fused_forward_x3(const void* xs3, const void* h03, void* hs3, const void* wpack3, const float* bias,
                            const int32_t* tile_nodes, const int32_t* tile_off, const void* ell_col4, int64_t entries, int64_t B,
                            int64_t T, int64_t N, int64_t F, int64_t G, int64_t K, double uniform_w, void* Huser, int last_only,
-                           void* stream);
+                           const float* rank1, void* stream);
 /* gcrnn_fused_forward_x3 with a per-(t, b) weight of the bias (bias_scale [T][B] fp32, NULL = 2) and an explicit distance between the
  * sequences of Huser (huser_seq_stride elements, 0 = T*F*N; Huser = the block of step 0). The time-gated cell at fp32 accuracy
  * (Utils/graphML.py:2357-2374, 2420-2423) is composed from it: gi (A(S)x_t + b) + gf (B(S)h_{t-1} + b) = A(S)(gi x_t) + B(S)(gf h_{t-1}) +
@@ -244,7 +248,7 @@ int gcrnn_fused_forward_x3(const void* xs3, const void* h03, void* hs3, const vo
 int gcrnn_fused_forward_x3_scaled(const void* xs3, const void* h03, void* hs3, const void* wpack3, const float* bias,
                                   const float* bias_scale, const int32_t* tile_nodes, const int32_t* tile_off, const void* ell_col4,
                                   int64_t entries, int64_t B, int64_t T, int64_t N, int64_t F, int64_t G, int64_t K, double uniform_w,
-                                  void* Huser, int64_t huser_seq_stride, void* stream);
+                                  void* Huser, int64_t huser_seq_stride, const float* rank1, void* stream);
 /* fp32-accurate BPTT of the un-gated cell on the fused kernels (round 3): the training loop of the reference runs in the drivers'
  * precision (Modules/train_rnn.py:247-281 under kStepPredGRNNs.py:44), i.e. its gradients are autograd's of Utils/graphML.py:2420-2423.
  * gcrnn_fused_backward_data_x3: the data chain dpre_{t-1} = (sum_k S^k (dpre_t B_k^T) + dH_{t-1}) (1 - h_{t-1}^2) on the x3 step kernel
@@ -257,11 +261,11 @@ int gcrnn_fused_forward_x3_scaled(const void* xs3, const void* h03, void* hs3, c
 int gcrnn_fused_x3_training_supported(int64_t N, int64_t F, int64_t G, int64_t K, int64_t entries_adj);
 int gcrnn_fused_backward_data_x3(const void* dHs3, const void* hs3, void* dpre3, void* dh03, const void* wpack3T,
                                  const int32_t* tile_nodes, const int32_t* tile_off, const void* ell_col4, int64_t entries,
-                                 int64_t B, int64_t T, int64_t N, int64_t F, int64_t K, double uniform_w, void* stream);
+                                 int64_t B, int64_t T, int64_t N, int64_t F, int64_t K, double uniform_w, const float* rank1, void* stream);
 int gcrnn_fused_backward_weight_f32(const void* dpre3, const void* Xuser, const void* Huser, const void* h0user, float* dW,
                                     float* dbsum, const int32_t* tile_nodes, const int32_t* tile_off, const void* ell_col4,
                                     int64_t entries, int64_t B, int64_t T, int64_t N, int64_t F, int64_t G, int64_t K,
-                                    double uniform_w, void* stream);
+                                    double uniform_w, const float* rank1, void* stream);
 /* fp32-accurate BPTT of the TIME-GATED cell (round 4; Utils/graphML.py:2357-2374 + 2420-2423 under autograd -- the reference's default
  * cell, :2196, in the drivers' precision, kStepPredGRNNs.py:44):
  * gcrnn_fused_backward_data_x3_gated: dpre_{t-1} = (gf_t sum_k S^k (dpre_t B_k^T) + dH_{t-1}) (1 - h_{t-1}^2), gf [T][B] fp32; dh03 (required)
@@ -277,14 +281,14 @@ int gcrnn_fused_backward_weight_f32(const void* dpre3, const void* Xuser, const 
 int gcrnn_fused_backward_data_x3_gated(const void* dHs3, const void* hs3, void* dpre3, void* dh03, const void* wpack3T,
                                        const int32_t* tile_nodes, const int32_t* tile_off, const void* ell_col4, int64_t entries,
                                        int64_t B, int64_t T, int64_t N, int64_t F, int64_t K, double uniform_w, const float* gf,
-                                       const void* h03, float* dgf_parts, void* stream);
+                                       const void* h03, float* dgf_parts, const float* rank1, void* stream);
 int gcrnn_fused_filter_x3(const void* z3, void* out3, const void* wpack3, const int32_t* tile_nodes, const int32_t* tile_off,
                           const void* ell_col4, int64_t entries, int64_t B, int64_t N, int64_t F, int64_t K, double uniform_w,
-                          void* stream);
+                          const float* rank1, void* stream);
 int gcrnn_fused_backward_weight_f32_gated(const void* dpre3, const void* Xuser, const void* Huser, const void* h0user, float* dW,
                                           float* dbsum, const int32_t* tile_nodes, const int32_t* tile_off, const void* ell_col4,
                                           int64_t entries, int64_t B, int64_t T, int64_t N, int64_t F, int64_t G, int64_t K,
-                                          double uniform_w, const float* gi, const float* gf, int h_is_h0, void* stream);
+                                          double uniform_w, const float* gi, const float* gf, int h_is_h0, const float* rank1, void* stream);
 /* ... and the pieces its gate cells (Utils/graphML.py:2362-2374: both gates read (x_t, h0), never h_{t-1}) run on:
  * gcrnn_fused_backward_weight_f32_gated with gi = gf = NULL (weights 1 / 2) and h_is_h0 != 0: every item's state operand is h0 (Huser unused;
  *   h0user = NULL: a zero initial state, train_rnn.py:256 -- the state columns are skipped and stay zero).
@@ -298,7 +302,7 @@ int gcrnn_fused_backward_weight_f32_gated(const void* dpre3, const void* Xuser, 
  *   d loss / d gi_t = <A(S) x_t, dpre_t> + <b, sum_n dpre_t>. */
 int gcrnn_fused_gate_cells_x3(const void* xs3, const void* h03, void* scratch3, const void* wpack3, const float* bias,
                               const int32_t* tile_nodes, const int32_t* tile_off, const void* ell_col4, int64_t entries, int64_t B,
-                              int64_t T, int64_t N, int64_t F, int64_t G, int64_t K, double uniform_w, void* Cuser, int state_zero, void* stream);
+                              int64_t T, int64_t N, int64_t F, int64_t G, int64_t K, double uniform_w, void* Cuser, int state_zero, const float* rank1, void* stream);
 int gcrnn_pack_seq_major_x3_ex(const void* src, void* dst, int64_t B, int64_t T, int64_t C, int64_t N, int64_t NPad,
                                const float* item_scale, const float* rowmul, int one_minus_square, int64_t src_seq_stride, void* stream);
 int gcrnn_x3_item_dots(const void* a3, const void* b3, const float* vec, float* out_ab, float* out_av, int64_t B, int64_t T, int64_t NPad,

@@ -2017,6 +2017,72 @@ def test_fp32_accurate_fused_time_gated_training_matches_composed_autograd(N, F,
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('N,F,G,K,B,T,kind,tg', [(1000, 64, 64, 5, 3, 4, 'sym', False), (1000, 64, 64, 3, 2, 3, 'rw', False), (400, 32, 32, 4, 3, 3, 'sym', True),
+                                                (1000, 64, 1, 5, 2, 3, 'rw', True)])
+def test_fp32_accurate_fused_kernels_on_rank1_weighted_graphs(N, F, G, K, B, T, kind, tg, monkeypatch):
+    """the 1e-5 mode on RANK-1-weighted graphs -- the normalised adjacencies of the reference (Utils/graphTools.py:64
+    normalizeAdjacency D^-1/2 A D^-1/2; 'rw': D^-1 A, a directed weighting), scaled by the largest eigenvalue as the drivers do
+    (kStepPredGRNNs.py:768). The x3 kernels run on the plan of the 0/1 pattern with the factor table of graph.fused_plan_x3 (Horner carried
+    in t / b): forward <= 1e-5 against the fp64 oracle on the dense S, un-gated and time-gated; training (forward, x3 chain, exact-fp32
+    weight gradients -- the adjoint plan takes the swapped factors) <= 2e-5 of each gradient's max against the composed fp32 path."""
+    import gated_gcrnns_amd.Utils.graphML as gml
+    dev = torch.device('cuda:0')
+    rng = np.random.default_rng(41)
+    W = (rng.random((N, N)) < 10.0 / N).astype(np.float64)
+    W = np.triu(W, 1); W = W + W.T
+    d = W.sum(axis=1); d[d == 0] = 1.0
+    S = W / np.sqrt(d)[:, None] / np.sqrt(d)[None, :] if kind == 'sym' else W / d[:, None]
+    S = (S / np.max(np.abs(np.linalg.eigvals(S)))).astype(np.float32).astype(np.float64).reshape(1, N, N)
+    torch.manual_seed(41)
+    cell = gml.GGCRNNCell(G, F, K, K, torch.tanh, tg, None, 1, True)
+    cell.addGSO(torch.tensor(S))
+    cell = cell.float()
+    if tg:
+        with torch.no_grad():
+            cell.MLP_in[0].weight.mul_(6.0)
+            cell.MLP_forget[0].weight.mul_(6.0)
+    X = rng.standard_normal((B, T, G, N)).astype(np.float32)
+    h0 = (0.4 * rng.standard_normal((B, F, N))).astype(np.float32)
+    params = {k: v.detach().double().numpy() for k, v in cell.state_dict().items()}
+    ref = orc.ggcrnn_cell(params, S, X.astype(np.float64), h0.astype(np.float64), tg, None)
+    cell = cell.to(dev)
+    assert cell.graph.fused_plan().get('uniform_w', 0.0) == 0.0 and cell.graph.fused_plan_x3().get('rank1_x3') is not None
+    Xd, hd = torch.tensor(X, device=dev), torch.tensor(h0, device=dev)
+    with torch.no_grad():
+        assert cell._use_fused_x3(Xd, hd, time_gated=tg)
+        H = cell(Xd, hd)
+    err = np.abs(H.double().cpu().numpy() - ref).max()
+    assert err <= 1e-5, err
+    tgt = torch.tensor(rng.standard_normal((B, T, F, N)), dtype=torch.float32, device=dev)
+
+    def step():
+        cell.zero_grad(set_to_none=True)
+        Ht = cell(Xd, hd)
+        torch.nn.functional.l1_loss(Ht, tgt).backward()
+        return Ht.detach().clone(), {n: p.grad.clone() for n, p in cell.named_parameters() if p.grad is not None}
+
+    assert cell._use_fused_x3_training(Xd, hd, time_gated=tg)
+    H1, g1 = step()
+    assert torch.equal(H1, H)
+    monkeypatch.setenv('GCRNN_NO_X3_TRAINING', '1')
+    assert not cell._use_fused_x3_training(Xd, hd, time_gated=tg)
+    H0, g0 = step()
+    assert g0.keys() == g1.keys() and len(g1) == (13 if tg else 3)
+    worst = 0.0
+    for k in g1:
+        sc = float(g0[k].abs().max())
+        e = float((g0[k] - g1[k]).abs().max()) / sc
+        worst = max(worst, e)
+        assert e <= 2e-5, (k, e)
+    _tol_report('x3 on a rank-1 graph (%s, time-gated %s): H err %.2e, worst gradient error / max %.2e' % (kind, tg, err, worst))
+    monkeypatch.setenv('GCRNN_NO_RANK1', '1')
+    cell.graph.__dict__.pop('_fused_plan_x3', None); cell.graph.__dict__.pop('_fused_plan_x3_adj', None)
+    with torch.no_grad():
+        assert not cell._use_fused_x3(Xd, hd, time_gated=tg)      # without the factorisation: the composed path
+    cell.graph.__dict__.pop('_fused_plan_x3', None); cell.graph.__dict__.pop('_fused_plan_x3_adj', None)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('N,F,G,K,B,T', [(1000, 64, 64, 5, 3, 4), (1000, 64, 1, 3, 2, 3), (600, 32, 32, 4, 4, 3)])
 def test_fp32_accurate_fused_training_matches_composed_autograd(N, F, G, K, B, T, monkeypatch):
     """The same at the bench's sizes against the composed fp32 path (exact fp32 kernels, golden-pinned since round 1): every
