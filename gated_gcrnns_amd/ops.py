@@ -400,15 +400,49 @@ def time_fused_step_kernel(X, h0, wA, wB, bias, graph, reps=3, inline=None, user
             'launch_avg_us': per_step * max(spl, 1), 'kernel': 'fused_seq_kernel' if spl else 'fused_step_kernel'}
 
 
+_PACK_CACHE = {}
+
+
+def _cached_pack(kind, tensors, extra, st, make):
+    """Packed forms of PARAMETERS (tap fragments, the fp32 bias) are kept between calls while the parameters are unchanged: the key holds each
+    tensor's storage pointer, shape, strides, dtype and autograd version counter (every in-place update -- an optimiser step, load_state_dict --
+    bumps it), and the entry keeps the tensors alive so that their storage cannot be recycled under the key. Inference loops then issue no
+    pack kernels; a training step misses and packs as before. One entry per launch stream. GCRNN_NO_PACK_CACHE=1 switches it off."""
+    if os.environ.get('GCRNN_NO_PACK_CACHE'):
+        return make()
+    key = (kind, extra, st.value) + tuple((t.data_ptr(), t._version, tuple(t.shape), tuple(t.stride()), t.dtype) for t in tensors)
+    hit = _PACK_CACHE.get(key)
+    if hit is not None:
+        return hit[0]
+    out = make()
+    while len(_PACK_CACHE) >= 64:
+        _PACK_CACHE.pop(next(iter(_PACK_CACHE)))
+    _PACK_CACHE[key] = (out, tensors)
+    return out
+
+
+def _bias_f32(bias, st):
+    """[F] fp32 copy of the bias (or None), cached while the parameter is unchanged."""
+    if bias is None:
+        return None
+    b = bias.detach()
+    if b.dtype == torch.float32 and b.is_contiguous():
+        return b.view(-1)
+    return _cached_pack('bias', (b,), None, st, lambda: b.float().contiguous().view(-1))
+
+
 def _fused_pack_weights(wA, wB, st):
     F, G = wA.shape[0], wA.shape[3]
     Kin, Kst = wA.shape[2], wB.shape[2]
     K = max(Kin, Kst)
-    wpack = torch.empty(((F // 16) * K * ((F + G) // 32) * 64 * 8,), dtype=torch.bfloat16, device=wA.device)
-    wAc, wBc = wA.contiguous(), wB.contiguous()
-    check(lib.gcrnn_fused_pack_weights(dtype_code(wA.dtype), _p(wAc), _p(wBc), _p(wpack),
-                                       F, G, Kin, Kst, st), 'pack_weights')
-    return wpack
+
+    def make():
+        wpack = torch.empty(((F // 16) * K * ((F + G) // 32) * 64 * 8,), dtype=torch.bfloat16, device=wA.device)
+        wAc, wBc = wA.contiguous(), wB.contiguous()
+        check(lib.gcrnn_fused_pack_weights(dtype_code(wA.dtype), _p(wAc), _p(wBc), _p(wpack),
+                                           F, G, Kin, Kst, st), 'pack_weights')
+        return wpack
+    return _cached_pack('taps16', (wA.detach(), wB.detach()), None, st, make)
 
 
 def _fused_pack_weights_wide(wA, wB, uniform_w, st):
@@ -418,13 +452,16 @@ def _fused_pack_weights_wide(wA, wB, uniform_w, st):
     Fout, G, F = wA.shape[0], wA.shape[3], wB.shape[3]
     Kin, Kst = wA.shape[2], wB.shape[2]
     K = max(Kin, Kst)
-    wpack = torch.empty(((Fout // 32) * K * 2 * ((F + G) // 32) * 64 * 8,), dtype=torch.bfloat16, device=wA.device)
-    wAc, wBc = wA.contiguous(), wB.contiguous()
-    if G == 0:                                   # state-only operand (the BPTT chain's transposed taps): no input taps to read
-        wAc, Kin = wBc, Kst
-    check(lib.gcrnn_fused_pack_weights_wide(dtype_code(wB.dtype), _p(wAc), _p(wBc), _p(wpack), Fout, F, G, Kin, Kst, float(uniform_w), st),
-          'pack_weights_wide')
-    return wpack
+
+    def make():
+        wpack = torch.empty(((Fout // 32) * K * 2 * ((F + G) // 32) * 64 * 8,), dtype=torch.bfloat16, device=wA.device)
+        wAc, wBc, kin = wA.contiguous(), wB.contiguous(), Kin
+        if G == 0:                                   # state-only operand (the BPTT chain's transposed taps): no input taps to read
+            wAc, kin = wBc, Kst
+        check(lib.gcrnn_fused_pack_weights_wide(dtype_code(wB.dtype), _p(wAc), _p(wBc), _p(wpack), Fout, F, G, kin, Kst, float(uniform_w), st),
+              'pack_weights_wide')
+        return wpack
+    return _cached_pack('taps32', (wA.detach(), wB.detach()), float(uniform_w), st, make)
 
 
 def fused_wide_plan(graph, B, T, N, F, G, K, inline, rank1=False, gated=False):
@@ -749,8 +786,7 @@ def fused_cell_forward(X, h0, wA, wB, bias, graph, gates=None, return_states=Fal
                 g[name] = fused_time_gate(xs, h0s, *gp[name], graph, N, hzero=hzero)
             gi, gf = g['in'], g['forget']
     assert getattr(xs, '_pending_user', None) is None
-    wpack = _fused_pack_weights(wA, wB, st)
-    b32 = bias.detach().float().contiguous().view(-1) if bias is not None else None
+    b32 = _bias_f32(bias, st)
     direct = (N % 8 == 0)                 # the step kernels write the user layout themselves (16-byte row stores)
     evs = None
     if events is not None:                               # raw hipEvent_t handles, one slot per step (host array, read during the call)
@@ -761,6 +797,7 @@ def fused_cell_forward(X, h0, wA, wB, bias, graph, gates=None, return_states=Fal
         assert hw.numel() == F
         part = torch.empty((T, B, F // 16, N), dtype=torch.float32, device=dev)
         plan16 = fused_img16_plan(graph, gi is not None, head)
+        wpack = _fused_pack_weights(wA, wB, st)
         check(lib.gcrnn_fused_forward_bf16(_p(xs), _p(h0s), _p(hs), _p(wpack), _p(b32), _p(gi), _p(gf), *_fused_graph_args(plan16 or plan),
                                            B, T, N, F, G, K, None, 2 if plan16 else 0, evs, plan.get('uniform_w', 0.0), _p(X) if inline else None,
                                            _p(hw), _p(part), st), 'fused_forward')
@@ -785,6 +822,7 @@ def fused_cell_forward(X, h0, wA, wB, bias, graph, gates=None, return_states=Fal
             return hs_all, plan, H
         return H
     plan16 = fused_img16_plan(graph, gi is not None, None)
+    wpack = _fused_pack_weights(wA, wB, st)
     if native_out:
         assert not return_states
         check(lib.gcrnn_fused_forward_bf16(_p(xs), _p(h0s), _p(hs), _p(wpack), _p(b32), _p(gi), _p(gf), *_fused_graph_args(plan16 or plan),

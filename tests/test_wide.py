@@ -475,3 +475,44 @@ def test_wide_bptt_chain_split_sequences_are_bit_identical_to_the_persistent_for
     assert len(got) == len(want)
     for a_, b_, c_ in zip(got, got2, want):
         assert torch.equal(a_, b_) and torch.equal(a_, c_)
+
+
+@pytest.mark.gpu
+def test_packed_parameter_cache_follows_in_place_updates(monkeypatch):
+    """ops._cached_pack keeps the packed taps / the fp32 bias between forwards while the parameters are unchanged (inference loops issue no
+    pack kernels). Every way a parameter changes -- an in-place update (optimiser step), copy_ (load_state_dict), a new tensor behind .data --
+    must miss: the outputs equal those of a run with the cache switched off, bit for bit."""
+    from gated_gcrnns_amd import ops
+    dev = torch.device('cuda:0')
+    N, G, F, K, B, T = 1000, 64, 64, 5, 130, 2
+    cell, rng, S = _uniform_cell(N, G, F, K, 83)
+    cell = cell.to(dev)
+    X = torch.tensor(rng.standard_normal((B, T, G, N)), dtype=torch.float32, device=dev).to(torch.bfloat16)
+    h0 = torch.tensor(0.3 * rng.standard_normal((B, F, N)), dtype=torch.float32, device=dev).to(torch.bfloat16)
+
+    def both():
+        with torch.no_grad():
+            a = cell(X, h0)
+            n = len(ops._PACK_CACHE)
+            b = cell(X, h0)
+            assert len(ops._PACK_CACHE) == n                     # the second forward packed nothing
+            monkeypatch.setenv('GCRNN_NO_PACK_CACHE', '1')
+            c = cell(X, h0)
+            monkeypatch.delenv('GCRNN_NO_PACK_CACHE')
+        assert torch.equal(a, b) and torch.equal(a, c)
+        return a
+
+    ops._PACK_CACHE.clear()
+    H0 = both()
+    assert len(ops._PACK_CACHE) >= 1
+    with torch.no_grad():
+        cell.weight_B.mul_(0.5)                                   # in place: the version counter moves
+    H1 = both()
+    assert not torch.equal(H0, H1)
+    with torch.no_grad():
+        cell.bias.copy_(torch.full_like(cell.bias, 0.25))
+    H2 = both()
+    assert not torch.equal(H1, H2)
+    cell.weight_A.data = (cell.weight_A.data * 2.0).contiguous()  # a new tensor behind the parameter
+    H3 = both()
+    assert not torch.equal(H2, H3)
