@@ -124,6 +124,7 @@ def _bind(lib):
         'gcrnn_fused_gate_prepass_taps_bf16': (C.c_int, [_c_p] * 7 + [_c_i64] + [_c_p] * 7 + [_c_i64] * 7 + [_c_p, C.c_double, C.c_int, _c_p]),
         'gcrnn_fused_gate_prepass_taps_supported': (C.c_int, [_c_i64] * 7 + [C.c_double, C.c_int, C.c_int, _c_i64]),
         'gcrnn_fused_gate_readout_slabs': (_c_i64, [_c_i64]),
+        'gcrnn_all_zero_flag_bf16': (C.c_int, [_c_p, _c_i64, _c_p, _c_p]),
         'gcrnn_fused_gate_readout_backward_bf16': (C.c_int, [_c_p, _c_p, _c_p, _c_p, _c_i64, _c_i64, _c_i64, _c_p]),
         'gcrnn_fused_gate_grad_bf16': (C.c_int, [_c_p] * 12 + [_c_i64] * 7 + [C.c_double, C.c_int, _c_p]),
         'gcrnn_fused_backward_data_bf16': (C.c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p,

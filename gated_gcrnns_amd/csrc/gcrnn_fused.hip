@@ -164,6 +164,33 @@ extern "C" int gcrnn_pack_seq_major_steps(const void* src, void* dst, int64_t B,
   return GCRNN_OK;
 }
 
+// flag[0] = 1 when every bf16 element of src is +-0, else 0 (flag pre-set to 1 by the host call; a workgroup that meets a non-zero clears it)
+__global__ __launch_bounds__(256) void all_zero_flag_kernel(const uint4* __restrict__ src, int64_t n16, int32_t* __restrict__ flag) {
+  uint32_t any = 0;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (int64_t)gridDim.x * 256) {
+    const uint4 v = src[i];
+    any |= (v.x | v.y | v.z | v.w) & 0x7fff7fffu;
+  }
+  if (__builtin_amdgcn_ballot_w64(any != 0) != 0 && (threadIdx.x & 63) == 0) *flag = 0;      // (plain store of the same value by every finder: no atomics needed)
+}
+
+// The time-gated cell's "h0 is all zeros" flag (every training loop of the reference starts from zeros, Modules/train_rnn.py:256; the gate
+// kernels then skip the state half of their operand -- exact), decided on the device without a host round trip: flag int32[1] = 1 when all
+// `elements` bf16 values at src are +-0. elements % 8 == 0, 16-byte aligned src.
+extern "C" int gcrnn_all_zero_flag_bf16(const void* src, int64_t elements, int32_t* flag, void* stream) {
+  if (!src || !flag) return GCRNN_ERR_NULL_POINTER;
+  if (elements <= 0 || elements % 8 || (reinterpret_cast<uintptr_t>(src) & 15)) return GCRNN_ERR_BAD_SHAPE;
+  hipStream_t st = as_stream(stream);
+  GCRNN_PRE_LAUNCH();
+  const int64_t n16 = elements / 8;
+  int64_t grid = cdiv(n16, 256 * 8);
+  if (grid > 2048) grid = 2048;
+  if (hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(flag), 1, 1, st) != hipSuccess) return GCRNN_ERR_LAUNCH;
+  all_zero_flag_kernel<<<(unsigned)grid, 256, 0, st>>>((const uint4*)src, n16, flag);
+  GCRNN_CHECK_LAUNCH();
+  return GCRNN_OK;
+}
+
 template <bool PACK>
 static int seq_layout_launch(int dtype, const void* src, void* dst, int64_t B, int64_t T, int64_t C, int64_t N,
                              int64_t NPad, const int32_t* perm, void* stream) {

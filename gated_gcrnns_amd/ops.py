@@ -616,6 +616,10 @@ def fused_h0_zero_flag(h0):
     """int32 [1] on the device: 1 when the initial state is all zeros (every training loop of the reference starts from
     zeros(B, F, N), train_rnn.py:256). The gate kernels read it and skip the state operand's loads and matrix products -- a
     data-dependent short cut with bit-identical results, decided on the device (no host synchronisation)."""
+    if h0.dtype == torch.bfloat16 and h0.is_contiguous() and h0.numel() % 8 == 0 and h0.data_ptr() % 16 == 0 and h0.is_cuda:
+        flag = torch.empty(1, dtype=torch.int32, device=h0.device)
+        check(lib.gcrnn_all_zero_flag_bf16(_p(h0), h0.numel(), _p(flag), _stream()), 'all_zero_flag')      # one pass at HBM rate, no temporaries
+        return flag
     return (h0 == 0).all().to(torch.int32).view(1)
 
 
@@ -677,13 +681,17 @@ def fused_time_gate_pair(xs, h0s, gate_in, gate_f, graph, N, store_states=False,
     x_user = getattr(xs, '_pending_user', None)
     plan16, _ = fused_gate_pair_plan(graph, B, T, N, F, G, K, x_user is not None)
     assert plan16 is not None
-    wA2 = torch.cat([gate_in[0].detach(), gate_f[0].detach()], dim=0)
-    wB2 = torch.cat([gate_in[1].detach(), gate_f[1].detach()], dim=0)
-    wp = _fused_pack_weights_wide(wA2, wB2, plan16['uniform_w'], st)
-    zb = torch.zeros(F, dtype=torch.float32, device=xs.device)
-    b2 = torch.cat([(g[2].detach().float().reshape(-1) if g[2] is not None else zb) for g in (gate_in, gate_f)]).contiguous()
-    gws = [g[3].detach().float().view(F, N).t().contiguous() for g in (gate_in, gate_f)]      # row-major vec over (f, n) -> [N][F]
-    gw2 = torch.stack(gws, dim=0).contiguous()
+    def prepare():      # everything derived from the gates' parameters alone: cached while they are unchanged (_cached_pack)
+        wA2 = torch.cat([gate_in[0].detach(), gate_f[0].detach()], dim=0)
+        wB2 = torch.cat([gate_in[1].detach(), gate_f[1].detach()], dim=0)
+        wp_ = _fused_pack_weights_wide(wA2, wB2, plan16['uniform_w'], st)
+        zb = torch.zeros(F, dtype=torch.float32, device=xs.device)
+        b2_ = torch.cat([(g[2].detach().float().reshape(-1) if g[2] is not None else zb) for g in (gate_in, gate_f)]).contiguous()
+        gws_ = [g[3].detach().float().view(F, N).t().contiguous() for g in (gate_in, gate_f)]      # row-major vec over (f, n) -> [N][F]
+        lbs_ = [(g[4].detach().float() if g[4] is not None else None) for g in (gate_in, gate_f)]
+        return wp_, b2_, gws_, torch.stack(gws_, dim=0).contiguous(), lbs_
+    ptens = tuple(t.detach() for g in (gate_in, gate_f) for t in g if t is not None)
+    wp, b2, gws, gw2, lbs = _cached_pack('gatepair', ptens, (float(plan16['uniform_w']), tuple(t is None for g in (gate_in, gate_f) for t in g)), st, prepare)
     nch = 2 * (F // 32)
     waves = int(lib.gcrnn_fused_step_waves())
     parts = torch.empty((T * B, nch * waves), dtype=torch.float32, device=xs.device)
@@ -698,8 +706,8 @@ def fused_time_gate_pair(xs, h0s, gate_in, gate_f, graph, N, store_states=False,
     out = []
     for gidx, g in enumerate((gate_in, gate_f)):
         a_ = acc[:, gidx]
-        if g[4] is not None:
-            a_ = a_ + g[4].detach().float()
+        if lbs[gidx] is not None:
+            a_ = a_ + lbs[gidx]
         out.append(torch.sigmoid(a_).view(T, B).contiguous())
     if store_states:
         return out[0], out[1], (cs_in, gws[0]), (cs_f, gws[1])
@@ -2561,8 +2569,8 @@ def edge_attention(Wx, s1, s2, graph, e=0, negative_slope=0.2):
 
 # ------------------------------------------------------------------------------------------ hipGraph replay
 class FusedForwardGraph(object):
-    """The fused forward of one fixed problem (shapes, weights, graph) captured as a hipGraph: pack -> gate pre-passes ->
-    T step launches become one graph launch per call. The capture runs on the CALLER's tensors when they are given
+    """The fused forward of one fixed problem (shapes, graph) captured as a hipGraph: pack -> gate pre-passes ->
+    T step launches become one graph launch per call (re-captured when a parameter of the cell has changed since). The capture runs on the CALLER's tensors when they are given
     (zero-copy: refill X / h0 in place, or keep feeding the same resident batch, and call the runner with no arguments);
     without them the runner owns static inputs and `runner(X, h0)` copies into them first. The output tensor is reused
     between calls (clone it if it must survive the next replay).
@@ -2578,15 +2586,25 @@ class FusedForwardGraph(object):
         self.h0 = h0 if h0 is not None else torch.zeros((B, cell.F, cell.N), dtype=torch.bfloat16, device=dev)
         assert tuple(self.X.shape) == (B, T, cell.G, cell.N) and self.X.is_contiguous() and self.h0.is_contiguous()
         cell.graph.fused_plan()                                   # host-side preparation happens outside the capture
+        self._dev = dev
+        self._stream = torch.cuda.Stream(device=dev)
+        self._capture()
+
+    def _capture(self):
+        """Warm-up and capture on ONE side stream: the packed parameters (ops._cached_pack, keyed by the launch stream) are made by the
+        warm-up and found by the capture, so the graph holds the layout kernels and the main kernel only. The graph then reads those cached
+        buffers: they are kept alive here, and a parameter update (autograd version counters) makes the next call capture again."""
+        cell, dev, s = self.cell, self._dev, self._stream
         with torch.no_grad():
-            s = torch.cuda.Stream(device=dev)
             s.wait_stream(torch.cuda.current_stream(dev))
             with torch.cuda.stream(s):
-                for _ in range(2):                                # warm-up on a side stream (allocator, func attributes)
+                for _ in range(2):                                # warm-up on the side stream (allocator, func attributes, packed parameters)
                     cell._forward_fused(self.X, self.h0)
             torch.cuda.current_stream(dev).wait_stream(s)
+            self._keep = list(_PACK_CACHE.values())
+            self._versions = tuple((p.data_ptr(), p._version) for p in cell.parameters())
             self.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph):
+            with torch.cuda.graph(self.graph, stream=s):
                 self.H = cell._forward_fused(self.X, self.h0)
 
     def __call__(self, X=None, h0=None):
@@ -2594,5 +2612,7 @@ class FusedForwardGraph(object):
             self.X.copy_(X)
         if h0 is not None and h0.data_ptr() != self.h0.data_ptr():
             self.h0.copy_(h0)
+        if self._versions != tuple((p.data_ptr(), p._version) for p in self.cell.parameters()):
+            self._capture()                                       # the parameters changed since the capture: their packed forms are stale
         self.graph.replay()
         return self.H

@@ -519,6 +519,10 @@ int gcrnn_fused_gate_grad_bf16(const void* zs, const void* xs, const void* dpre,
  *   dw_part [gcrnn_fused_gate_readout_slabs(items)][NPad*F] fp32: per-slab partial sums of dlogit[item] * c (plain stores;
  *   the caller adds the slabs in a fixed order); gate_w [N][F] fp32 node-major read-out weights; dlogit [items] fp32. */
 int64_t gcrnn_fused_gate_readout_slabs(int64_t items);
+/* flag int32[1] (device) = 1 when all `elements` bf16 values at src are +-0, else 0: the time-gated cell's "h0 is all zeros" flag (every training
+ * loop of the reference starts from zeros, Modules/train_rnn.py:256; the gate kernels then skip the state half of their operand), decided on
+ * the device. elements % 8 == 0, src 16-byte aligned. */
+int gcrnn_all_zero_flag_bf16(const void* src, int64_t elements, int32_t* flag, void* stream);
 int gcrnn_fused_gate_readout_backward_bf16(void* cs, const float* dlogit, const float* gate_w, float* dw_part, int64_t items,
                                            int64_t N, int64_t F, void* stream);
 

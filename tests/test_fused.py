@@ -151,6 +151,14 @@ def test_fused_forward_hipgraph_replay_is_bit_identical():
                 ref = cell(X, h0)
             out = runner(X, h0)
             assert torch.equal(out, ref)
+        # (r4) the graph reads the cached packed parameters: an in-place update (optimiser step, load_state_dict) must be followed
+        with torch.no_grad():
+            cell.weight_B.mul_(0.5)
+            cell.bias.add_(0.125)
+            ref2 = cell(X, h0)
+        out2 = runner(X, h0)
+        assert torch.equal(out2, ref2) and not torch.equal(ref2, ref)
+        assert torch.equal(runner(), ref2)                       # ... and plain replays stay on the new capture
 
 
 def _bwd_reference(S, params, X, h0, dH):

@@ -516,3 +516,24 @@ def test_packed_parameter_cache_follows_in_place_updates(monkeypatch):
     cell.weight_A.data = (cell.weight_A.data * 2.0).contiguous()  # a new tensor behind the parameter
     H3 = both()
     assert not torch.equal(H2, H3)
+
+
+@pytest.mark.gpu
+def test_all_zero_flag_kernel():
+    """ops.fused_h0_zero_flag on the device kernel (gcrnn_all_zero_flag_bf16): 1 for zeros (-0.0 included, as `h0 == 0` has it), 0 as soon as
+    one element anywhere is non-zero; the torch fallback for shapes the kernel does not take agrees."""
+    from gated_gcrnns_amd import ops
+    dev = torch.device('cuda:0')
+    h = torch.zeros(7, 64, 1000, device=dev, dtype=torch.bfloat16)
+    assert int(ops.fused_h0_zero_flag(h)) == 1
+    h.view(-1)[12345] = -0.0
+    assert int(ops.fused_h0_zero_flag(h)) == 1
+    for pos in (0, 1, 12345, h.numel() - 1, h.numel() // 2 + 3):
+        g = torch.zeros_like(h)
+        g.view(-1)[pos] = 1e-30
+        assert float(g.view(-1)[pos]) != 0.0
+        assert int(ops.fused_h0_zero_flag(g)) == 0, pos
+    odd = torch.zeros(3, 5, 7, device=dev, dtype=torch.bfloat16)      # numel % 8 != 0: the torch path
+    assert int(ops.fused_h0_zero_flag(odd)) == 1
+    odd[2, 4, 6] = 1.0
+    assert int(ops.fused_h0_zero_flag(odd)) == 0
