@@ -115,6 +115,8 @@ def parse_args(argv=None):
                     '(the drivers, kStepPredGRNNs.py:768: one weight on every edge) or its normalised form D^-1/2 W D^-1/2 / lambda_max (graphTools.py:64)')
     ap.add_argument('--in-features', type=int, default=CFG['G'], help='secondary point: input features per node (the reference '
                     'drivers feed G = 1; the headline workload is G = F = 64)')
+    ap.add_argument('--settle-ms', type=float, default=100.0, help='untimed steps for this long BEFORE the W warm-up steps (the chip\'s clock transient '
+                                                                    'behind an idle period, profiles/r04_clock_transient.txt); 0 = none')
     ap.add_argument('--hipgraph', type=int, default=None, help='replay the fused forward as one captured hipGraph (bf16 fwd); default: 1 when the '
                     'capture succeeds (bit-identical replay, tests/test_fused.py), else eager')
     ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'], help='process-group backend ("nccl" is RCCL on ROCm; '
@@ -193,6 +195,8 @@ def main(argv=None):
         args.steps = 10 if args.config == 'cfg5' else 30
     if args.warmup is None:
         args.warmup = 3 if args.config == 'cfg5' else 5
+    global SETTLE_MS
+    SETTLE_MS = float(args.settle_ms)
     if args.gpus > 1 and 'RANK' not in os.environ:
         self_launch(args, argv)                       # does not return
     rank = int(os.environ.get('RANK', '0'))
@@ -243,6 +247,24 @@ def timed_steps(ctx, step):
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
+    # settle phase (untimed, BEFORE the W warm-up steps; --settle-ms 0 switches it off): behind an idle period the chip runs its first ~30 ms
+    # of load 10-25 % slower than the steady state a server sees (clock transient: profiles/r04_clock_transient.txt), so a short window right
+    # behind a cold start would measure the transient, not the kernels. Reported in config.settle_ms / settle_steps.
+    import gc
+    gc.collect()                  # like timeit: no cyclic-garbage pass of the interpreter inside the timed steps (its position
+    gc_was_on = gc.isenabled()    # depends on the process's allocation history, not on the workload) -- and none between the warm-up
+    gc.disable()                  # and the timed steps either: an idle gap there restarts the transient
+    ctx['settle_steps'] = 0
+    if args.settle_ms > 0:
+        step()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); step(); e1.record()
+        torch.cuda.synchronize()
+        n = max(1, min(2000, int(args.settle_ms / max(e0.elapsed_time(e1), 1e-3))))
+        for _ in range(n):        # queued back to back (no synchronisation inside: the load must be continuous), straight into the warm-up steps
+            step()
+        ctx['settle_steps'] = n + 2
     for _ in range(args.warmup):
         step()
     sync()
@@ -253,10 +275,6 @@ def timed_steps(ctx, step):
         torch.distributed.all_reduce(tw, op=torch.distributed.ReduceOp.MAX)
         sync()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    import gc
-    gc.collect()                  # like timeit: no cyclic-garbage pass of the interpreter inside the timed steps (its position
-    gc_was_on = gc.isenabled()    # depends on the process's allocation history, not on the workload)
-    gc.disable()
     t0 = time.perf_counter()
     ev0.record()
     trace = [] if os.environ.get('GCRNN_BENCH_TRACE') else None       # diagnosis only: per-step host time and a device event
@@ -284,7 +302,9 @@ def timed_steps(ctx, step):
 
 def base_line(ctx, value, wall, workload, B, extra=None):
     args, world = ctx['args'], ctx['world']
-    cfg = {'workload': workload, 'batch_per_gpu': B, 'global_batch': world * B, 'mode': args.mode, 'parallelism': 'dp%d' % world}
+    cfg = {'workload': workload, 'batch_per_gpu': B, 'global_batch': world * B, 'mode': args.mode, 'parallelism': 'dp%d' % world,
+           'settle_ms': args.settle_ms, 'settle_steps': ctx.get('settle_steps', 0),
+           'settle_note': 'untimed steps before the W warm-up steps: the clock transient behind an idle period (profiles/r04_clock_transient.txt)'}
     cfg.update(extra or {})
     return {'metric': 'sequences/sec (node), N=1000 K=5 T=32 F=64', 'value': value, 'unit': 'sequences/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * wall / args.steps,
@@ -371,10 +391,11 @@ def run_cfg2(ctx):
             # (10 back-to-back launches after a warm-up one: three catch the chip at a higher clock than a longer run holds -- a kernel trace of
             #  20 such forwards averaged 5 % above the 3-launch figure, profiles/r04_seq32_as_issued_only_kernel_stats.csv)
             KREPS = 10
-            kern = ops.time_fused_step_kernel(X, h0, cell.weight_A, cell.weight_B, cell.bias, cell.graph, reps=KREPS)
+            KWARM = 30 if args.settle_ms > 0 else 1      # untimed launches queued in front of the timed ones (the settle phase of the kernel timing)
+            kern = ops.time_fused_step_kernel(X, h0, cell.weight_A, cell.weight_B, cell.bias, cell.graph, reps=KREPS, warm=KWARM)
             if kern.get('inline_pack'):          # for comparison with earlier rounds: the same launches without the inline pack of x_{t+1}
-                kern['bare_launch_avg_us'] = ops.time_fused_step_kernel(X, h0, cell.weight_A, cell.weight_B, cell.bias, cell.graph, reps=KREPS, inline=False)['launch_avg_us']
-            native = ops.time_fused_step_kernel(X, h0, cell.weight_A, cell.weight_B, cell.bias, cell.graph, reps=KREPS, inline=False, user_layout=False)
+                kern['bare_launch_avg_us'] = ops.time_fused_step_kernel(X, h0, cell.weight_A, cell.weight_B, cell.bias, cell.graph, reps=KREPS, inline=False, warm=KWARM)['launch_avg_us']
+            native = ops.time_fused_step_kernel(X, h0, cell.weight_A, cell.weight_B, cell.bias, cell.graph, reps=KREPS, inline=False, user_layout=False, warm=KWARM)
     kern3 = None
     if args.dtype == 'f32' and args.mode == 'fwd' and not args.time_gating and args.spatial_gating is None:
         from gated_gcrnns_amd import ops
@@ -495,11 +516,23 @@ def run_cfg2(ctx):
     return out
 
 
+SETTLE_MS = 100.0      # set from --settle-ms by main(): untimed continuous load in front of a timed window (profiles/r04_clock_transient.txt)
+
+
 def _timed(fn, steps, warmup):
-    """(seconds per call) of fn: `warmup` untimed calls, then `steps` calls between two synchronisations."""
+    """(seconds per call) of fn: `warmup` untimed calls (+ the settle phase: calls queued back to back for about SETTLE_MS / 2, at most 40),
+    then `steps` calls between two synchronisations."""
     for _ in range(warmup):
         fn()
     torch.cuda.synchronize()
+    if SETTLE_MS > 0:
+        t0 = time.perf_counter()
+        fn()
+        torch.cuda.synchronize()
+        one = max(time.perf_counter() - t0, 1e-6)
+        for _ in range(max(0, min(40, int(0.5e-3 * SETTLE_MS / one)))):
+            fn()
+        torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
         fn()

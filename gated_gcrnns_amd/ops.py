@@ -337,10 +337,11 @@ def fused_supported(N, F, G, Kin, Kst, dtype, E=1):
             bool(lib.gcrnn_fused_supported(int(N), int(F), int(Gp), int(max(Kin, Kst)))))
 
 
-def time_fused_step_kernel(X, h0, wA, wB, bias, graph, reps=3, inline=None, user_layout=True):
+def time_fused_step_kernel(X, h0, wA, wB, bias, graph, reps=3, inline=None, user_layout=True, warm=1):
     """Average duration of ONE fused step launch, measured with HIP events on the launch stream
     (inputs pre-packed, only the T step launches sit between the events; on uniform-weight graphs each launch also lays out
-    x_{t+1}, exactly as in fused_cell_forward)."""
+    x_{t+1}, exactly as in fused_cell_forward). warm: untimed launches queued in front of the timed ones without a gap (behind an idle
+    period the chip runs its first ~30 ms of load 10-25 % slower than its steady state, profiles/r04_clock_transient.txt)."""
     X, wA = fused_pad_operands(X, wA.detach())
     B, T, G, N = X.shape
     F = wA.shape[0]
@@ -372,10 +373,9 @@ def time_fused_step_kernel(X, h0, wA, wB, bias, graph, reps=3, inline=None, user
     if wide is not None:
         # the wide sequence-resident kernel (what fused_cell_forward issues for this problem): ONE launch per forward
         wpw = _fused_pack_weights_wide(wAc, wBc, wide['uniform_w'], st)
-        for rep in range(reps + 1):
-            if rep == 1:
-                torch.cuda.synchronize()
-                e0.record()
+        for rep in range(reps + warm):
+            if rep == warm:
+                e0.record()                              # (no synchronisation here: the timed launches follow the warm ones without an idle gap)
             _fused_forward_wide(wide, xs, h0s, hs, wAc, wBc, b32, B, T, N, F, G, K, H, False, Xc if inline else None, st, wpw=wpw)
         e1.record()
         torch.cuda.synchronize()
