@@ -367,9 +367,18 @@ def time_fused_step_kernel(X, h0, wA, wB, bias, graph, reps=3, inline=None, user
     H = torch.empty((B, T, F, N), dtype=torch.bfloat16, device=dev) if (N % 8 == 0 and user_layout) else None
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     ok = fused_inline_pack_ok(plan, N, F, G, K)          # the launches as the forward issues them: with the inline pack of x_{t+1} where it
+    inline_arg = inline
     inline = (ok if inline is None else (ok and inline)) and X.data_ptr() % 16 == 0     # applies; inline=False times the bare step for comparison
     plan16 = fused_img16_plan(graph, False, None)
     wide = fused_wide_plan(graph, B, T, N, F, G, K, inline)
+    if wide is None and plan16 is None:                  # rank-1-weighted graph (normalised adjacency): the wide kernel on the pattern plan, as fused_cell_forward issues it
+        inl1 = inline_arg is not False and not os.environ.get('GCRNN_NO_INLINE_PACK') and X.data_ptr() % 16 == 0
+        wide = fused_wide_plan(graph, B, T, N, F, G, K, inl1, rank1=True)
+        if wide is None and inl1:
+            inl1 = False
+            wide = fused_wide_plan(graph, B, T, N, F, G, K, False, rank1=True)
+        if wide is not None:
+            inline = inl1
     if wide is not None:
         # the wide sequence-resident kernel (what fused_cell_forward issues for this problem): ONE launch per forward
         wpw = _fused_pack_weights_wide(wAc, wBc, wide['uniform_w'], st)
