@@ -28,18 +28,28 @@
 // phase boundaries of ONE step into LDS (FLAG_OFF, no scalar registers held), copied out at the end.
 #if defined(GCRNN_SEQ_STAMPS)
 static __device__ unsigned long long gcrnn_seq32_stamps[256 * 96];
+// (explicit LDS instructions: a generic-pointer volatile access of the dynamic LDS array makes hipcc emit an illegal compare in some instantiations)
+static __device__ __forceinline__ void gcrnn_stamp32_put(uint32_t lds_addr) {
+  const unsigned long long tv = __builtin_amdgcn_s_memtime();
+  asm volatile("ds_write_b64 %0, %1" ::"v"(lds_addr), "v"(tv) : "memory");
+}
+static __device__ __forceinline__ unsigned long long gcrnn_stamp32_get(uint32_t lds_addr) {
+  unsigned long long tv;
+  asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(tv) : "v"(lds_addr) : "memory");
+  return tv;
+}
 #define GCRNN_STAMP32(slot)                                                                                   \
   do {                                                                                                        \
-    if (wave == 0 && stamp_on && lane_now() == 0) *reinterpret_cast<volatile unsigned long long*>(smem + M::FLAG_OFF + 8 * (slot)) = __builtin_amdgcn_s_memtime(); \
+    if (wave == 0 && stamp_on && lane_now() == 0) gcrnn_stamp32_put((uint32_t)reinterpret_cast<uintptr_t>(smem) + M::FLAG_OFF + 8 * (slot)); \
   } while (0)
 #define GCRNN_STAMP32_WAVE(slot0)                                                                             \
   do {                                                                                                        \
-    if (stamp_on && lane_now() == 0) *reinterpret_cast<volatile unsigned long long*>(smem + M::FLAG_OFF + 8 * ((slot0) + wave)) = __builtin_amdgcn_s_memtime(); \
+    if (stamp_on && lane_now() == 0) gcrnn_stamp32_put((uint32_t)reinterpret_cast<uintptr_t>(smem) + M::FLAG_OFF + 8 * ((slot0) + wave)); \
   } while (0)
 #define GCRNN_STAMP32_FLUSH()                                                                                 \
   do {                                                                                                        \
     __syncthreads();                                                                                          \
-    if (threadIdx.x < 96 && blockIdx.x < 256) gcrnn_seq32_stamps[blockIdx.x * 96 + threadIdx.x] = *reinterpret_cast<volatile unsigned long long*>(smem + M::FLAG_OFF + 8 * threadIdx.x); \
+    if (threadIdx.x < 96 && blockIdx.x < 256) gcrnn_seq32_stamps[blockIdx.x * 96 + threadIdx.x] = gcrnn_stamp32_get((uint32_t)reinterpret_cast<uintptr_t>(smem) + M::FLAG_OFF + 8 * threadIdx.x); \
   } while (0)
 extern "C" int gcrnn_debug_read_seq32_stamps(void* host) {
   return hipMemcpyFromSymbol(host, HIP_SYMBOL(gcrnn_seq32_stamps), sizeof(unsigned long long) * 256 * 96) == hipSuccess ? 0 : 1;

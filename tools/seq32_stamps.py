@@ -28,8 +28,16 @@ cell = cell.to(torch.bfloat16).to(dev)
 X = torch.randn(B, T, F, N, device=dev).to(torch.bfloat16)
 h0 = torch.zeros(B, F, N, device=dev, dtype=torch.bfloat16)
 native = len(sys.argv) > 1 and sys.argv[1] == 'native'
+chain = len(sys.argv) > 1 and sys.argv[1] == 'chain'      # the BPTT data chain (MODE 2): the last wide launch of a training step's backward
+if chain:
+    cell = cell.float()
+    for _ in range(2):
+        cell.zero_grad(set_to_none=True)
+        cell(X, h0).float().sum().backward()
 with torch.no_grad():
-    if native:
+    if chain:
+        pass
+    elif native:
         from gated_gcrnns_amd import ops
         xs = ops.to_sequence_major(X, cell.graph)
         for _ in range(3):
@@ -56,7 +64,7 @@ for c in range(2):
     names[b0 + 19] = 'c%d user-layout row stores' % c
     names[b0 + 20] = 'c%d vmcnt(0) + end barrier' % c
 prev = 0
-print('stamps of step T-3 of the persistent launch (%s), median over 256 workgroups; unit = 100 shader cycles (s_memtime)' % ('native layout' if native else 'user layout + inline pack'))
+print('stamps of step T-3 of the persistent launch (%s), median over 256 workgroups; unit = 100 shader cycles (s_memtime)' % ('BPTT data chain, inline layout of dH' if chain else 'native layout' if native else 'user layout + inline pack'))
 tot = {}
 for s in sorted(names):
     d = st[:, s] - st[:, prev]
