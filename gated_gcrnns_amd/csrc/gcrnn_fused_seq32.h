@@ -562,22 +562,34 @@ __global__ __launch_bounds__(STHREADS) void fused_seq32_kernel(const Seq32Args a
                                              (__attribute__((address_space(3))) void*)(smem + WOFF + tap * (2 * KS * 1024) + piece * 1024), 16, 0, 0);
         }
       };
-      // MODE 2: the epilogue's operands h_{t-1}, dH_{t-1} of this lane's (node, 8 features) per tile, requested now: they land while the hops run
+      // MODE 2: the epilogue's operands h_{t-1}, dH_{t-1} of this lane's (node, 8 features) per tile. Requested in the write-back phases of hops
+      // 1 .. EPH (behind the hop's vmcnt(0) + barrier), a share of the tiles each: they land under the NEXT hop's stream and are covered by its
+      // vmcnt(0). Requested in front of hop 1 (round 4's first form; still so for K < 4) the waves that tap first met hipcc's vmcnt(0) in front
+      // of the tap's weight reads a few hundred cycles later and sat out the whole HBM latency: hop 1 took ~200 units instead of ~75
+      // (profiles/r04_seq32_stamps_chain.txt).
       typedef __attribute__((__vector_size__(4 * sizeof(unsigned int)))) unsigned int u32x4e_t;
       [[maybe_unused]] u32x4e_t eph[MODE == 2 ? STILES : 1], epg[MODE == 2 ? STILES : 1];
-      if constexpr (MODE == 2) {
-        const int lq = lane_now();
-        int swp[STILES];
-        slot_words(lq, swp);
-        const __amdgpu_buffer_rsrc_t rsrc_eh = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(ep_h), 0, ep_h ? B * (NP * F * 2) : 0, 0x00020000);
-        const __amdgpu_buffer_rsrc_t rsrc_eg = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(ep_dh), 0, ep_dh ? B * (NP * F * 2) : 0, 0x00020000);
+#ifndef GCRNN_SEQ32_EP_EARLY
+#define GCRNN_SEQ32_EP_EARLY 0      // 1: all of them in front of hop 1 (A/B)
+#endif
+      constexpr int EPH = (MODE == 2 && K >= 4 && !GCRNN_SEQ32_EP_EARLY) ? K - 2 : 0;
+      auto ep_request = [&](auto i0c, auto i1c) __attribute__((always_inline)) {
+        if constexpr (MODE == 2) {
+          constexpr int I0 = decltype(i0c)::value, I1 = decltype(i1c)::value;
+          const int lq = lane_now();
+          int swp[STILES];
+          slot_words(lq, swp);
+          const __amdgpu_buffer_rsrc_t rsrc_eh = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(ep_h), 0, ep_h ? B * (NP * F * 2) : 0, 0x00020000);
+          const __amdgpu_buffer_rsrc_t rsrc_eg = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(ep_dh), 0, ep_dh ? B * (NP * F * 2) : 0, 0x00020000);
 #pragma unroll
-        for (int i = 0; i < STILES; ++i) {
-          const int eoff = (swp[i] >> 16) * (F * 2) + (chunk * 32 + (lq >> 4) * 8) * 2;
-          eph[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_eh, eoff, b * (NP * F * 2), 0);
-          epg[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_eg, eoff, b * (NP * F * 2), 0);
+          for (int i = I0; i < I1; ++i) {
+            const int eoff = (swp[i] >> 16) * (F * 2) + (chunk * 32 + (lq >> 4) * 8) * 2;
+            eph[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_eh, eoff, b * (NP * F * 2), 0);
+            epg[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_eg, eoff, b * (NP * F * 2), 0);
+          }
         }
-      }
+      };
+      if constexpr (MODE == 2 && EPH == 0) ep_request(std::integral_constant<int, 0>{}, std::integral_constant<int, STILES>{});
       // ---- Horner hops on the two-plane bf16 image; the tap a hop adds accumulates onto its sums --------------------------------
       auto hop = [&](auto jc) __attribute__((always_inline)) {
         constexpr int j = decltype(jc)::value;
@@ -643,6 +655,8 @@ __global__ __launch_bounds__(STHREADS) void fused_seq32_kernel(const Seq32Args a
             pack_drain(r0 + e);
           }
         }
+        if constexpr (MODE == 2 && EPH > 0 && j <= EPH)
+          ep_request(std::integral_constant<int, (j - 1) * STILES / (EPH > 0 ? EPH : 1)>{}, std::integral_constant<int, j * STILES / (EPH > 0 ? EPH : 1)>{});
         if (j < K - 1) lds_barrier();      // the image is complete (and the pack tile read)
         GCRNN_STAMP32(1 + chunk * 24 + 4 * (j - 1) + 4);
       };
