@@ -569,6 +569,9 @@ __global__ __launch_bounds__(STHREADS) void fused_seq32_kernel(const Seq32Args a
       // (profiles/r04_seq32_stamps_chain.txt).
       typedef __attribute__((__vector_size__(4 * sizeof(unsigned int)))) unsigned int u32x4e_t;
       [[maybe_unused]] u32x4e_t eph[MODE == 2 ? STILES : 1], epg[MODE == 2 ? STILES : 1];
+#ifndef GCRNN_SEQ32_EP_FIRST
+#define GCRNN_SEQ32_EP_FIRST 1      // the requests in front of the hop's write-back (0: behind it; same-box A/B: profiles/r04_seq32_chain_requests_ab.txt)
+#endif
 #ifndef GCRNN_SEQ32_EP_EARLY
 #define GCRNN_SEQ32_EP_EARLY 0      // 1: all of them in front of hop 1 (A/B)
 #endif
@@ -642,6 +645,10 @@ __global__ __launch_bounds__(STHREADS) void fused_seq32_kernel(const Seq32Args a
         if (pk_any || (NCH > 1 && !SPLIT)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's LDS-DMA pieces have landed (they had the stream)
         lds_barrier();      // every wave has left the image (and the weights, after the last hop); every piece of the pack tile is in
         GCRNN_STAMP32(1 + chunk * 24 + 4 * (j - 1) + 3);
+#if GCRNN_SEQ32_EP_FIRST      // (A/B: the requests in front of the write-back instead of behind it)
+        if constexpr (MODE == 2 && EPH > 0 && j <= EPH)
+          ep_request(std::integral_constant<int, (j - 1) * STILES / (EPH > 0 ? EPH : 1)>{}, std::integral_constant<int, j * STILES / (EPH > 0 ? EPH : 1)>{});
+#endif
         if (j < K - 1) put();
         if (K == 2 && NCH > 1 && !SPLIT) weights_issue((chunk + 1) % NCH, 0);      // (K = 2: tap 0's fragments are free only now, and needed at the next chunk's only hop)
         if (r0 < NRND) pack_drain(r0);
@@ -655,8 +662,10 @@ __global__ __launch_bounds__(STHREADS) void fused_seq32_kernel(const Seq32Args a
             pack_drain(r0 + e);
           }
         }
+#if !GCRNN_SEQ32_EP_FIRST
         if constexpr (MODE == 2 && EPH > 0 && j <= EPH)
           ep_request(std::integral_constant<int, (j - 1) * STILES / (EPH > 0 ? EPH : 1)>{}, std::integral_constant<int, j * STILES / (EPH > 0 ? EPH : 1)>{});
+#endif
         if (j < K - 1) lds_barrier();      // the image is complete (and the pack tile read)
         GCRNN_STAMP32(1 + chunk * 24 + 4 * (j - 1) + 4);
       };
