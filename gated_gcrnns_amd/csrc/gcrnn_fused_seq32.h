@@ -699,6 +699,7 @@ __global__ __launch_bounds__(STHREADS) void fused_seq32_kernel(const Seq32Args a
         }
       };
       if (GCRNN_SEQ32_OPERAND_AT == 0) request_next_operand();
+      if (MODE == 1) GCRNN_STAMP32(1 + chunk * 24 + 19);      // (diagnostic builds: start of the epilogue proper)
       float bs[2][4];
 #pragma unroll
       for (int h = 0; h < 2; ++h)
@@ -717,15 +718,28 @@ __global__ __launch_bounds__(STHREADS) void fused_seq32_kernel(const Seq32Args a
         uint16_t* cso = gate ? a.out1 : a.out0;
         const __amdgpu_buffer_rsrc_t rsrc_c = __builtin_amdgcn_make_buffer_rsrc(cso, 0, cso ? B * (NP * F * 2) : 0, 0x00020000);
         float part = 0.f;
-#pragma unroll
-        for (int i0 = 0; i0 < STILES; i0 += 2) {
-          float4 w8[2][2];
+        // (the read-out weights of the NEXT two tiles are requested before this pair is evaluated: one L2 round trip per chunk is exposed instead
+        //  of four; -0.6 % on the time-gated forward, profiles/r04_seq32_gate_readout_ab.txt. The same weights as bf16 -- half the bytes -- ran
+        //  SLOWER: this epilogue, 95 units per chunk against the recurrence's 35 in r04_seq32_stamps_gate_pair.txt, is not bound by their bytes)
+#ifndef GCRNN_SEQ32_GATE_W_PIPELINE
+#define GCRNN_SEQ32_GATE_W_PIPELINE 1
+#endif
+        float4 w8s[2][2][2];
+        auto w8_load = [&](int set, int i0l) __attribute__((always_inline)) {
 #pragma unroll
           for (int t2 = 0; t2 < 2; ++t2) {
-            const int nd = (swe[i0 + t2] >> 16) < N ? (swe[i0 + t2] >> 16) : N - 1;
-            w8[t2][0] = *reinterpret_cast<const float4*>(gwp + (int64_t)nd * F);
-            w8[t2][1] = *reinterpret_cast<const float4*>(gwp + (int64_t)nd * F + 4);
+            const int nd = (swe[i0l + t2] >> 16) < N ? (swe[i0l + t2] >> 16) : N - 1;
+            w8s[set][t2][0] = *reinterpret_cast<const float4*>(gwp + (int64_t)nd * F);
+            w8s[set][t2][1] = *reinterpret_cast<const float4*>(gwp + (int64_t)nd * F + 4);
           }
+        };
+        if (GCRNN_SEQ32_GATE_W_PIPELINE) w8_load(0, 0);
+#pragma unroll
+        for (int i0 = 0; i0 < STILES; i0 += 2) {
+          const int wset = GCRNN_SEQ32_GATE_W_PIPELINE ? (i0 >> 1) & 1 : 0;
+          if (GCRNN_SEQ32_GATE_W_PIPELINE) { if (i0 + 2 < STILES) w8_load(wset ^ 1, i0 + 2); }
+          else w8_load(0, i0);
+          const auto& w8 = w8s[wset];
 #pragma unroll
           for (int t2 = 0; t2 < 2; ++t2) {
             const int i = i0 + t2;
@@ -743,6 +757,7 @@ __global__ __launch_bounds__(STHREADS) void fused_seq32_kernel(const Seq32Args a
             if (cso) __builtin_amdgcn_raw_buffer_store_b128(p, rsrc_c, node * (F * 2) + (cg * 32 + q * 8) * 2, b * (NP * F * 2), 0);
           }
         }
+        GCRNN_STAMP32(1 + chunk * 24 + 18);      // (diagnostic builds: end of the tile loop)
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) part += __shfl_down(part, off, 64);
         if (lane == 0) a.go[(int64_t)b * (NCH * SWAVES) + chunk * SWAVES + wave] = part;

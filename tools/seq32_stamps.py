@@ -34,8 +34,21 @@ if chain:
     for _ in range(2):
         cell.zero_grad(set_to_none=True)
         cell(X, h0).float().sum().backward()
+gates = len(sys.argv) > 1 and sys.argv[1] == 'gates'      # the time gates' PAIR pre-pass (MODE 1: four 32-feature chunks per item), first item of every workgroup
+if gates:
+    from gated_gcrnns_amd import ops
+    torch.manual_seed(0)
+    cell = gml.GGCRNNCell(F, F, K, K, torch.tanh, True, None, 1, True)
+    cell.addGSO(torch.tensor(bench.sbm_graph(N)))
+    cell = cell.to(torch.bfloat16).to(dev)
+    xs = ops.to_sequence_major(X, cell.graph)
+    h0s = ops.to_sequence_major(h0.view(B, 1, F, N), cell.graph)
+    g = cell._fused_gates()
+    with torch.no_grad():
+        for _ in range(2):
+            ops.fused_time_gate_pair(xs, h0s, g['in'], g['forget'], cell.graph, N, hzero=ops.fused_h0_zero_flag(h0))
 with torch.no_grad():
-    if chain:
+    if chain or gates:
         pass
     elif native:
         from gated_gcrnns_amd import ops
@@ -51,7 +64,7 @@ dll = ctypes.CDLL(lib)
 assert dll.gcrnn_debug_read_seq32_stamps(buf.ctypes.data_as(ctypes.c_void_p)) == 0
 st = buf.reshape(256, 96).astype(np.int64)
 names = {0: 'step start (operand in registers)'}
-for c in range(2):
+for c in range(4 if gates else 2):
     b0 = 1 + 24 * c
     names[b0] = 'c%d seed + barrier' % c
     for j in range(1, K):
@@ -64,7 +77,7 @@ for c in range(2):
     names[b0 + 19] = 'c%d user-layout row stores' % c
     names[b0 + 20] = 'c%d vmcnt(0) + end barrier' % c
 prev = 0
-print('stamps of step T-3 of the persistent launch (%s), median over 256 workgroups; unit = 100 shader cycles (s_memtime)' % ('BPTT data chain, inline layout of dH' if chain else 'native layout' if native else 'user layout + inline pack'))
+print('stamps of step T-3 of the persistent launch (%s), median over 256 workgroups; unit = 100 shader cycles (s_memtime)' % ('time gates, pair pre-pass: first item of a workgroup, X laid out by the caller' if gates else 'BPTT data chain, inline layout of dH' if chain else 'native layout' if native else 'user layout + inline pack'))
 tot = {}
 for s in sorted(names):
     d = st[:, s] - st[:, prev]
@@ -73,6 +86,10 @@ for s in sorted(names):
     key = ' '.join(w for w in key.split() if not w.isdigit())
     tot[key] = tot.get(key, 0.0) + np.median(d) / 100.0
     prev = s
+if gates:
+    print('--- gate pre-pass epilogue, chunk 1: last hop done -> epilogue start -> tile loop done -> partial stored (units)')
+    b0 = 1 + 24
+    print('   %.2f  %.2f  %.2f' % (np.median(st[:, b0 + 19] - st[:, b0 + 16]) / 100.0, np.median(st[:, b0 + 18] - st[:, b0 + 19]) / 100.0, np.median(st[:, b0 + 17] - st[:, b0 + 18]) / 100.0))
 print('--- per wave, c0 hop 2: first / second phase (waves 0-3: stream, taps; waves 4-7: taps, stream) done, units after the start of the hop')
 ref = st[:, 5]          # end of hop 1 (wave 0)
 for w in range(8):
