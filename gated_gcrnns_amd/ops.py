@@ -916,19 +916,20 @@ def fused_filter_output(xs, w, bias, graph, K, N, adjoint=False):
     else:
         plan16 = fused_img16_plan(graph, False, None)
     st = _stream()
-    b32 = bias.detach().float().contiguous().view(-1) if bias is not None else None
+    b32 = _bias_f32(bias, st)
     out = torch.empty((T, B, npad, F), dtype=torch.bfloat16, device=xs.device)
     if Cin == F:
-        wp = _fused_pack_state_taps(w, K, st)
+        wp = _cached_pack('statetaps_f', (w.detach(),), int(K), st, lambda: _fused_pack_state_taps(w, K, st))
         check(lib.gcrnn_fused_filter_output_bf16(_p(xs), None, _p(wp), _p(b32), _p(out), *_fused_graph_args(plan16 or plan), B, T, N, F, 0, K,
                                                  plan.get('uniform_w', 0.0), 1 if plan16 else 0, st),
               'fused_filter_output')
     else:
-        wd = w.detach()
-        if wd.shape[2] < K:
-            wd = torch.cat([wd, wd.new_zeros(F, 1, K - wd.shape[2], Cin)], dim=2)
-        wp = _fused_pack_weights(wd, wd.new_zeros((F, 1, K, F)), st)
-        zero_h = torch.zeros((1, npad, F), dtype=torch.bfloat16, device=xs.device)
+        def pack_x():
+            wd = w.detach()
+            if wd.shape[2] < K:
+                wd = torch.cat([wd, wd.new_zeros(F, 1, K - wd.shape[2], Cin)], dim=2)
+            return _fused_pack_weights(wd, wd.new_zeros((F, 1, K, F)), st), torch.zeros((1, npad, F), dtype=torch.bfloat16, device=xs.device)
+        wp, zero_h = _cached_pack('filtertaps_x', (w.detach(),), (int(K), int(npad)), st, pack_x)
         check(lib.gcrnn_fused_filter_output_bf16(_p(zero_h), _p(xs), _p(wp), _p(b32), _p(out), *_fused_graph_args(plan16 or plan), B, T, N, F, Cin, K,
                                                  plan.get('uniform_w', 0.0), 1 if plan16 else 0, st),
               'fused_filter_output')
@@ -997,8 +998,8 @@ def fused_node_gate_taps(xs, h0s, wA_g, wB_g, bias_g, wf, graph, N, hzero=None):
         return None
     st = _stream()
     wp = _fused_pack_weights(wA_g.detach(), wB_g.detach(), st)
-    bg = bias_g.detach().float().contiguous().view(-1) if bias_g is not None else None
-    frags = _tap_fragments(wf, F)
+    bg = _bias_f32(bias_g, st)
+    frags = _cached_pack('tapfrags', (wf.detach(),), int(F), st, lambda: _tap_fragments(wf, F))      # (parameter-derived: kept while wf is unchanged)
     s = torch.empty((T * B, Kt, 1, N), dtype=torch.float32, device=xs.device)
     check(lib.gcrnn_fused_gate_prepass_taps_bf16(_p(x_user), _p(xs), _p(h0s), _p(wp), _p(bg), _p(frags), _p(s), Kt, None,
                                                  *_fused_graph_args(plan16), B, T, N, F, G, K, _p(hzero), plan.get('uniform_w', 0.0), 1, st),
@@ -1054,9 +1055,11 @@ def fused_node_cell_forward(X, h0, wA, wB, bias, graph, node_gates, time_gates=N
             g[name] = fused_time_gate(xs, h0s, wA_g, wB_g, bias_g, lin_w, lin_b, graph, N, hzero=hzero)
         gi, gf = g['in'], g['forget']
     yx = fused_filter_output(xs, wA, bias, graph, K, N)
-    wBk = wB.detach() if Kst == K else torch.cat([wB.detach(), wB.new_zeros(F, 1, K - Kst, F)], dim=2)
-    wpB = _fused_pack_state_taps(wBk, K, st)
-    b32 = bias.detach().float().contiguous().view(-1) if bias is not None else None
+    def pack_state():
+        wBk = wB.detach() if Kst == K else torch.cat([wB.detach(), wB.new_zeros(F, 1, K - Kst, F)], dim=2)
+        return _fused_pack_state_taps(wBk, K, st)
+    wpB = _cached_pack('statetaps', (wB.detach(),), int(K), st, pack_state)
+    b32 = _bias_f32(bias, st)
     H = torch.empty((B, 1 if last_only else T, F, N), dtype=torch.bfloat16, device=X.device)
     direct = (N % 8 == 0)
     plan16 = fused_img16_plan(graph, False, None)
