@@ -1988,11 +1988,13 @@ def test_fp32_accurate_fused_time_gated_training_matches_reference_autograd_fixt
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('N,F,G,K,B,T,hz', [(1000, 64, 64, 5, 3, 4, True), (1000, 64, 1, 3, 2, 3, False), (600, 32, 32, 4, 4, 3, True)])
+@pytest.mark.parametrize('N,F,G,K,B,T,hz', [(1000, 64, 64, 5, 3, 4, True), (1000, 64, 1, 3, 2, 3, False), (600, 32, 32, 4, 4, 3, True),
+                                            (1000, 64, 32, 3, 2, 3, False), (1000, 64, 64, 2, 2, 3, False), (1000, 64, 64, 5, 2, 1, False)])
 def test_fp32_accurate_fused_time_gated_training_matches_composed_autograd(N, F, G, K, B, T, hz, monkeypatch):
     """The same at the bench's sizes against the composed fp32 path (exact fp32 kernels, golden-pinned since round 1), zero h0 (every
-    training loop of the reference, train_rnn.py:256) and non-zero h0, G = 1 input feature (padded channels) included: every gradient
-    <= 2e-5 of its max, H <= 1e-5; two runs give the same bits (no atomics)."""
+    training loop of the reference, train_rnn.py:256) and non-zero h0, G = 1 input feature (padded channels), G = 32 < F = 64 (the d gi
+    filter pass on zero-padded tap columns), K = 2 and a single time step included: every gradient <= 2e-5 of its max, H <= 1e-5; two
+    runs give the same bits (no atomics)."""
     dev = torch.device('cuda:0')
     cell, rng, _ = _uniform_cell(N, G, F, K, True, 99, dev, dtype=None)
     with torch.no_grad():
