@@ -85,7 +85,7 @@ def _bind(lib):
         'gcrnn_fused_forward_wide_supported': (C.c_int, [_c_i64] * 7 + [C.c_double, C.c_int, C.c_int]),
         'gcrnn_fused_forward_wide_bf16': (C.c_int, [_c_p] * 10 + [_c_i64] * 7 + [_c_p, C.c_int, _c_p, _c_p, _c_p, _c_p]),
         'gcrnn_fused_backward_data_wide_supported': (C.c_int, [_c_i64] * 6 + [C.c_double, C.c_int, C.c_int]),
-        'gcrnn_fused_backward_data_wide_bf16': (C.c_int, [_c_p] * 8 + [_c_i64] * 6 + [_c_p] * 5),
+        'gcrnn_fused_backward_data_wide_bf16': (C.c_int, [_c_p] * 8 + [_c_i64] * 6 + [_c_p] * 7),
         'gcrnn_fused_gate_pair_wide_supported': (C.c_int, [_c_i64] * 7 + [C.c_double, C.c_int, C.c_int]),
         'gcrnn_fused_gate_pair_prepass_wide_bf16': (C.c_int, [_c_p] * 12 + [_c_i64] * 7 + [_c_p, _c_p]),
         'gcrnn_fused_inline_pack_supported': (C.c_int, [_c_i64, _c_i64, _c_i64, _c_i64, _c_i64, C.c_double]),
@@ -132,7 +132,7 @@ def _bind(lib):
         'gcrnn_fused_wgrad_slots': (_c_i64, [_c_i64, _c_i64]),
         'gcrnn_fused_backward_weight_bf16': (C.c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p,
                                                        _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_p, _c_p,
-                                                       C.c_int, _c_p, C.c_double, _c_p]),
+                                                       C.c_int, _c_p, C.c_double, _c_p, _c_p, _c_p]),
         'gcrnn_small_supported': (C.c_int, [C.c_int, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64]),
         'gcrnn_small_forward': (C.c_int, [C.c_int, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p,
                                           _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_p]),

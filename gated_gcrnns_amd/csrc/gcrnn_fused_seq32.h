@@ -192,7 +192,7 @@ struct Seq32Map {
 //     chunk, stores its 32 features and lays out its share of the next step's input; nothing is kept in registers across steps.
 template <int K, int HS, int XS, int VAR, int MODE = 0, bool GATED = false, bool R1 = false, bool SPLIT = false>
 __global__ __launch_bounds__(STHREADS) void fused_seq32_kernel(const Seq32Args a) {
-  static_assert(!R1 || (MODE == 0 && !GATED), "rank-1 graphs: the un-gated forward");
+  static_assert(!R1 || ((MODE == 0 || MODE == 2) && !GATED), "rank-1 graphs: the un-gated forward and the BPTT chain (on the adjoint plan: the factors swap)");
   static_assert(!SPLIT || ((MODE == 0 || MODE == 2) && !R1 && HS > 1), "split sequences: the (un-gated or time-gated) forward and the BPTT chain, with more than one chunk");
   constexpr bool PKV = (VAR & 1) != 0, USERV = (VAR & 2) != 0 && MODE == 0;
   static_assert(MODE == 0 || ((MODE == 1 || MODE == 2) && !GATED), "modes");

@@ -83,8 +83,8 @@ static bool seq32_wanted(int64_t B) {
 template <int K, int HS, int XS>
 static size_t seq32_lds(int64_t entries, bool inline_pack, bool r1 = false) { return Seq32Map<K, HS, XS>::lds_bytes(entries, inline_pack, r1); }
 
-static size_t seq32_lds_chain(int64_t F, int64_t K, int64_t entries, bool inline_pack) {
-#define GCRNN_SEQ32_CASE(KK, HH) if (K == KK && F == 32 * HH) return seq32_lds<KK, HH, 0>(entries, inline_pack);
+static size_t seq32_lds_chain(int64_t F, int64_t K, int64_t entries, bool inline_pack, bool r1 = false) {
+#define GCRNN_SEQ32_CASE(KK, HH) if (K == KK && F == 32 * HH) return seq32_lds<KK, HH, 0>(entries, inline_pack, r1);
   GCRNN_SEQ32_CASE(5, 2) GCRNN_SEQ32_CASE(4, 2) GCRNN_SEQ32_CASE(3, 2) GCRNN_SEQ32_CASE(2, 2)
   GCRNN_SEQ32_CASE(5, 1) GCRNN_SEQ32_CASE(4, 1) GCRNN_SEQ32_CASE(3, 1) GCRNN_SEQ32_CASE(2, 1)
 #undef GCRNN_SEQ32_CASE
@@ -364,22 +364,27 @@ static int seq32_launch_chain_split(const Seq32Args& sa0, size_t lds, int64_t T,
 
 template <int K, int HS>
 static int seq32_launch_chain(const Seq32Args& sa, bool inline_pack, hipStream_t st, bool split = false, int64_t T = 0, int64_t N = 0, bool fin = false) {
-  const size_t lds = seq32_lds<K, HS, 0>(sa.entries, inline_pack);
+  const size_t lds = seq32_lds<K, HS, 0>(sa.entries, inline_pack, sa.r1a != nullptr);
   if (!lds) return GCRNN_ERR_UNSUPPORTED;
+  if (sa.r1a) {      // rank-1-weighted graph (adjoint plan of its 0/1 pattern, factors swapped): the persistent chain only
+    if (split) return GCRNN_ERR_UNSUPPORTED;
+    return inline_pack ? seq32_launch_v<K, HS, 0, 1, 2, false, true>(sa, lds, st) : seq32_launch_v<K, HS, 0, 0, 2, false, true>(sa, lds, st);
+  }
   if (split)
     return inline_pack ? seq32_launch_chain_split<K, HS, 1>(sa, lds, T, 32 * HS, N, fin, st) : seq32_launch_chain_split<K, HS, 0>(sa, lds, T, 32 * HS, N, fin, st);
   return inline_pack ? seq32_launch_v<K, HS, 0, 1, 2>(sa, lds, st) : seq32_launch_v<K, HS, 0, 0, 2>(sa, lds, st);
 }
 
 // 1 when gcrnn_fused_backward_data_wide_bf16 takes the problem (uniform-weight bf16-image plan of the ADJOINT graph, a batch that fills whole
-// rounds of the chip, LDS room; inline_pack: with dHuser_inline)
+// rounds of the chip, LDS room; inline_pack: with dHuser_inline; img16 bit 1: a rank-1-weighted graph on the plan of its pattern)
 extern "C" int gcrnn_fused_backward_data_wide_supported(int64_t B, int64_t T, int64_t N, int64_t F, int64_t K, int64_t entries, double uniform_w,
                                                         int img16, int inline_pack) {
   if (uniform_w == 0.0 || !img16 || N <= 0 || N > NP || B <= 0 || T <= 0 || entries <= 0 || entries % 4) return 0;
   if (inline_pack && (N % 8 || T * F * N > 2147483647LL)) return 0;
   if (B * (NP * F * 2) > 2147483647LL) return 0;
-  if (!seq32_wanted(B) && !seq32_split_wanted(B, F)) return 0;
-  return seq32_lds_chain(F, K, entries, inline_pack != 0) ? 1 : 0;
+  const bool r1 = (img16 & 2) != 0;      // bit 1: rank-1-weighted graph (no split variant)
+  if (!seq32_wanted(B) && !(!r1 && seq32_split_wanted(B, F))) return 0;
+  return seq32_lds_chain(F, K, entries, inline_pack != 0, r1) ? 1 : 0;
 }
 
 // BPTT data gradient of the fused cell as ONE launch of the wide sequence-resident kernel (the adjoint of Utils/graphML.py:2420-2423; contract
@@ -391,8 +396,10 @@ extern "C" int gcrnn_fused_backward_data_wide_supported(int64_t B, int64_t T, in
 extern "C" int gcrnn_fused_backward_data_wide_bf16(const void* dHs, const void* hs, void* dpre, void* dh0, const void* wpackT,
                                                    const int32_t* tile_nodes, const int32_t* tile_off, const void* ell_col4, int64_t entries,
                                                    int64_t B, int64_t T, int64_t N, int64_t F, int64_t K, const float* gf, const void* h0s,
-                                                   float* dgf_parts, const void* dHuser_inline, void* stream) {
+                                                   float* dgf_parts, const void* dHuser_inline, const float* rank1_a,
+                                                   const float* rank1_b, void* stream) {
   if (dgf_parts && !h0s) return GCRNN_ERR_NULL_POINTER;
+  if ((rank1_a == nullptr) != (rank1_b == nullptr)) return GCRNN_ERR_NULL_POINTER;
   if (dHuser_inline && (N % 8 != 0 || (reinterpret_cast<uintptr_t>(dHuser_inline) & 15) || T * F * N > 2147483647LL)) return GCRNN_ERR_BAD_SHAPE;
   if (!dHs || !hs || !dpre || !wpackT || !tile_nodes || !tile_off || !ell_col4) return GCRNN_ERR_NULL_POINTER;
   if (B <= 0 || T <= 0 || N <= 0 || N > NP || B > (1 << 24) || entries <= 0 || entries % 4) return GCRNN_ERR_BAD_SHAPE;
@@ -418,6 +425,7 @@ extern "C" int gcrnn_fused_backward_data_wide_bf16(const void* dHs, const void* 
   sa.wpack = (const uint4*)wpackT;
   sa.tile_nodes = tile_nodes; sa.tile_off = tile_off; sa.ell_col4 = (const uint2*)ell_col4;
   sa.entries = (int)entries; sa.B = (int)B; sa.N = (int)N;
+  sa.r1a = rank1_a; sa.r1b = rank1_b;      // (rank-1-weighted graph: the factors of S^T -- a and b of the forward direction swapped)
   sa.nsteps = (int)(T - 1) + (fin ? 1 : 0);
   const bool inline_pack = dHuser_inline != nullptr && T > 2;
   if (inline_pack) {      // chain step i reads dHs[T-2-i]: step 0's is the caller's, step i lays out step i + 1's
@@ -425,7 +433,7 @@ extern "C" int gcrnn_fused_backward_data_wide_bf16(const void* dHs, const void* 
     sa.pk_dst0 = const_cast<uint16_t*>((const uint16_t*)dHs) + (T - 2) * hstep; sa.pkdst_stride = -hstep;
     sa.pk_stride = (int)(T * F * N);
   }
-  const bool split = !seq32_wanted(B) && seq32_split_wanted(B, F);
+  const bool split = !rank1_a && !seq32_wanted(B) && seq32_split_wanted(B, F);
 #define GCRNN_SEQ32_CASE(KK, HH) if (K == KK && F == 32 * HH) return seq32_launch_chain<KK, HH>(sa, inline_pack, st, split, T, N, fin);
   GCRNN_SEQ32_CASE(5, 2) GCRNN_SEQ32_CASE(4, 2) GCRNN_SEQ32_CASE(3, 2) GCRNN_SEQ32_CASE(2, 2)
   GCRNN_SEQ32_CASE(5, 1) GCRNN_SEQ32_CASE(4, 1) GCRNN_SEQ32_CASE(3, 1) GCRNN_SEQ32_CASE(2, 1)

@@ -20,7 +20,10 @@ namespace { constexpr int TSTRIDE = 1056; constexpr int TBYTES = 16 * TSTRIDE; c
 // UNI (uniform-weight graphs, gcrnn_ell_fill_z): no weight image in LDS, so BOTH halves of the transposed du_k image fit; a tap
 // is then {images of all nodes} barrier {MFMAs of the first half | re-fetched fragments of the second half in two batches, the
 // second one in flight across the hop | adjoint hop on the uniform stream} barrier -- two barriers per tap instead of four.
-template <int K, int HS, int XS, int UNI>
+// R1 (UNI == 2 only): rank-1-weighted graph S[m][n] = a[m] b[n] on the adjoint plan of its 0/1 pattern (graph.fused_plan_rank1(adjoint=True)):
+// du_{k+1} = b (.) sum over the pattern of (a (.) du_k) -- the hop image holds a (.) du_k, the sums are scaled by b (r1a / r1b: the factors of
+// this direction, [NP] fp32); the transposed image (the GEMM's operand) holds du_k itself.
+template <int K, int HS, int XS, int UNI, bool R1 = false>
 __global__ __launch_bounds__(512, 2) void fused_wgrad_kernel(
     const uint16_t* __restrict__ dpre,       // [T][B][NP][F] bf16 sequence-major
     const uint16_t* __restrict__ Xuser,      // [B][T][G][N] bf16
@@ -34,9 +37,11 @@ __global__ __launch_bounds__(512, 2) void fused_wgrad_kernel(
     const float* __restrict__ gf,            // [T][B] state-filter gates, or null
     int h_is_h0,                             // the state operand of EVERY item is h0 (gate sub-cells, graphML.py:2362, 2370)
     const int32_t* __restrict__ hzero,       // with h_is_h0 (or null): hzero[0] != 0 = h0 is all zeros: the state-feature waves skip their loads and MFMAs
-    int entries, int B, int Tn, int N, float uni_w) {
+    int entries, int B, int Tn, int N, float uni_w,
+    const float* __restrict__ r1a, const float* __restrict__ r1b) {
   constexpr int F = 32 * HS, G = 32 * XS, C = F + G, NCH = F / FC, JT = C / 16;
   static_assert(JT <= WAVES, "one input-feature tile per wave");
+  static_assert(!R1 || UNI == 2, "rank-1 graphs: the bf16-image variant");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* state = reinterpret_cast<float*>(smem);
   float4* lval4 = reinterpret_cast<float4*>(smem + NP * FC * 4);
@@ -174,7 +179,10 @@ __global__ __launch_bounds__(512, 2) void fused_wgrad_kernel(
       for (int i = 0; i < TILES; ++i) {
         int wv = woff[i];
         asm volatile("" : "+v"(wv));
-        if (k < K - 1) state_put<UNI == 2>(state, wv, cur[i]);
+        if (k < K - 1) {
+          if constexpr (R1) state_put<UNI == 2>(state, wv, cur[i] * r1a[wv >> 16]);
+          else state_put<UNI == 2>(state, wv, cur[i]);
+        }
         const int node = wv >> 16;
         char* tb = tbuf + (node >= 512 ? TB2 : 0) + (node & 511) * 4 + (2 * q) * RS2;
         *reinterpret_cast<uint32_t*>(tb) = pack2bf(cur[i][0], cur[i][1]);
@@ -214,8 +222,17 @@ __global__ __launch_bounds__(512, 2) void fused_wgrad_kernel(
         if constexpr (UNI == 2) {
           // the summing stream (tile exits cost nothing, register window 28 instead of 42): du_{k+1} = w * (sum of the gathered rows)
           GCRNN_HOP_ASM_UNI16_SUMS_STREAM(cur);
+          if constexpr (R1) {
 #pragma unroll
-          for (int i = 0; i < TILES; ++i) cur[i] *= uni_w;
+            for (int i = 0; i < TILES; ++i) {
+              int wv = woff[i];
+              asm volatile("" : "+v"(wv));
+              cur[i] *= r1b[wv >> 16];
+            }
+          } else {
+#pragma unroll
+            for (int i = 0; i < TILES; ++i) cur[i] *= uni_w;
+          }
         }
         else GCRNN_HOP_ASM_UNI_STREAM(GCRNN_WG_INIT, GCRNN_WG_STORE);
 #undef GCRNN_WG_INIT
@@ -371,7 +388,7 @@ extern "C" int64_t gcrnn_fused_wgrad_slots(int64_t items, int64_t F) {
 template <int K, int HS, int XS>
 static int fused_wgrad_t(const void* dpre, const void* Xuser, const void* Huser, const void* h0user, float* dW, float* dbsum,
                          const FusedGraphArgs& ga, const float* gi, const float* gf, int h_is_h0, const int32_t* hzero, int64_t B,
-                         int64_t T, int64_t N, hipStream_t st) {
+                         int64_t T, int64_t N, hipStream_t st, const float* r1a = nullptr, const float* r1b = nullptr) {
   constexpr int F = 32 * HS;
 #if GCRNN_HOP_ASM
   const bool uni = ga.uniform_w != 0.f && HT_IS_8;
@@ -382,7 +399,9 @@ static int fused_wgrad_t(const void* dpre, const void* Xuser, const void* Huser,
                          : (size_t)NP * FC * 4 + (size_t)ga.entries * 96 + TBYTES + WAVES * FC * 4;
   if (lds > 160 * 1024 || !ga.ell_val4 || !ga.ell_col4) return GCRNN_ERR_UNSUPPORTED;
   if (ga.img16 && !uni) return GCRNN_ERR_UNSUPPORTED;
-  auto kern = uni ? (ga.img16 ? fused_wgrad_kernel<K, HS, XS, 2> : fused_wgrad_kernel<K, HS, XS, 1>) : fused_wgrad_kernel<K, HS, XS, 0>;
+  if (r1a && !(uni && ga.img16)) return GCRNN_ERR_UNSUPPORTED;
+  auto kern = uni ? (ga.img16 ? (r1a ? fused_wgrad_kernel<K, HS, XS, 2, true> : fused_wgrad_kernel<K, HS, XS, 2>) : fused_wgrad_kernel<K, HS, XS, 1>)
+                  : fused_wgrad_kernel<K, HS, XS, 0>;
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
     return GCRNN_ERR_LAUNCH;
   const int NCH = F / FC;
@@ -391,7 +410,7 @@ static int fused_wgrad_t(const void* dpre, const void* Xuser, const void* Huser,
   kern<<<(unsigned)(slots * NCH), 512, lds, st>>>((const uint16_t*)dpre, (const uint16_t*)Xuser, (const uint16_t*)Huser,
                                                    (const uint16_t*)h0user, dW, dbsum, ga.tile_nodes, ga.tile_off,
                                                    (const float4*)ga.ell_val4, (const uint2*)ga.ell_col4, gi, gf, h_is_h0, hzero,
-                                                   (int)ga.entries, (int)B, (int)T, (int)N, ga.uniform_w);
+                                                   (int)ga.entries, (int)B, (int)T, (int)N, ga.uniform_w, r1a, r1b);
   GCRNN_CHECK_LAUNCH();
   return GCRNN_OK;
 }
@@ -400,17 +419,19 @@ extern "C" int gcrnn_fused_backward_weight_bf16(const void* dpre, const void* Xu
                                                 float* dW, float* dbsum, const int32_t* tile_nodes, const int32_t* tile_off,
                                                 const void* ell_val4, const void* ell_col4, int64_t entries, int64_t B,
                                                 int64_t T, int64_t N, int64_t F, int64_t G, int64_t K, const float* gi,
-                                                const float* gf, int h_is_h0, const int32_t* h0_zero_flag, double uniform_w, void* stream) {
+                                                const float* gf, int h_is_h0, const int32_t* h0_zero_flag, double uniform_w,
+                                                const float* rank1_a, const float* rank1_b, void* stream) {
   const int img16 = (h_is_h0 >> 1) & 1;      // bit 1: the graph arrays address a bf16 hop image (fused_plan_img16(adjoint=True))
   h_is_h0 &= 1;
-  if ((gi == nullptr) != (gf == nullptr)) return GCRNN_ERR_NULL_POINTER;
+  if ((gi == nullptr) != (gf == nullptr) || (rank1_a == nullptr) != (rank1_b == nullptr)) return GCRNN_ERR_NULL_POINTER;
+  if (rank1_a && !img16) return GCRNN_ERR_UNSUPPORTED;      // rank-1-weighted graphs: the bf16-image plan of the pattern only
   if (!dpre || !Xuser || (!Huser && !h_is_h0) || !h0user || !dW || !tile_nodes || !tile_off || !ell_val4 || !ell_col4) return GCRNN_ERR_NULL_POINTER;
   if (B <= 0 || T <= 0 || N <= 0 || N > NP || N % 8 || entries < 0 || entries % 4 || B * T > (1 << 24)) return GCRNN_ERR_BAD_SHAPE;
   if (T * B * (NP * F * 2) > 2147483647LL) return GCRNN_ERR_BAD_SHAPE;      // 32-bit buffer offsets into dpre
   const FusedGraphArgs ga{tile_nodes, tile_off, nullptr, nullptr, ell_val4, ell_col4, entries, (float)uniform_w, img16};
   hipStream_t st = as_stream(stream);
 #define GCRNN_WG_CASE(KK, HH, XX) \
-  if (K == KK && F == 32 * HH && G == 32 * XX) return fused_wgrad_t<KK, HH, XX>(dpre, Xuser, Huser, h0user, dW, dbsum, ga, gi, gf, h_is_h0, h_is_h0 ? h0_zero_flag : nullptr, B, T, N, st);
+  if (K == KK && F == 32 * HH && G == 32 * XX) return fused_wgrad_t<KK, HH, XX>(dpre, Xuser, Huser, h0user, dW, dbsum, ga, gi, gf, h_is_h0, h_is_h0 ? h0_zero_flag : nullptr, B, T, N, st, rank1_a, rank1_b);
   GCRNN_WG_CASE(5, 2, 2)
   GCRNN_WG_CASE(4, 2, 2)
   GCRNN_WG_CASE(3, 2, 2)

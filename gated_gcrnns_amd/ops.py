@@ -1876,14 +1876,18 @@ def fused_backward_data(dHs, hs, wB, graph, want_dh0=True, gf=None, h0s=None, bi
     dh0 = torch.empty((B, npad, F), dtype=torch.bfloat16, device=hs.device) if want_dh0 else None
     import os
     plan16 = None if os.environ.get('GCRNN_NO_IMG16') else graph.fused_plan_img16(adjoint=True)      # bf16 hop image, matrix-core sums (uniform graphs)
-    if plan16 is not None and F % 32 == 0 and not os.environ.get('GCRNN_NO_WIDE_CHAIN') and lib.gcrnn_fused_backward_data_wide_supported(
-            B, T, graph.N, F, K, int(plan16['entries']), float(plan16.get('uniform_w', 0.0)), 1, 1 if dH_user is not None else 0):
+    pw = plan16
+    if pw is None and not os.environ.get('GCRNN_NO_IMG16'):
+        pw = graph.fused_plan_rank1(adjoint=True)        # rank-1-weighted graph (normalised adjacency): the adjoint plan of its pattern + the swapped factors
+    if pw is not None and F % 32 == 0 and not os.environ.get('GCRNN_NO_WIDE_CHAIN') and lib.gcrnn_fused_backward_data_wide_supported(
+            B, T, graph.N, F, K, int(pw['entries']), float(pw.get('uniform_w', 0.0)), 3 if pw.get('rank1') else 1, 1 if dH_user is not None else 0):
+        plan16 = pw
         # the whole chain (seed, T - 1 steps, d h0 / the forget gate's step 0) as ONE launch of the wide sequence-resident kernel
         wpw = _fused_pack_weights_wide(wBt.new_zeros((F, 1, K, 0)), wBt, plan16['uniform_w'], st)
         parts = torch.empty((T * B, (F // 32) * int(lib.gcrnn_fused_step_waves())), dtype=torch.float32, device=hs.device) if h0s is not None else None
         check(lib.gcrnn_fused_backward_data_wide_bf16(_p(dHs), _p(hs), _p(dpre), _p(dh0), _p(wpw), _p(plan16['tile_slots']), _p(plan16['tile_off']),
                                                       _p(plan16['ell_col4']), plan16['entries'], B, T, graph.N, F, K, _p(gf), _p(h0s), _p(parts),
-                                                      _p(dH_user), st), 'fused_backward_data_wide')
+                                                      _p(dH_user), _p(plan16.get('rank1_a')), _p(plan16.get('rank1_b')), st), 'fused_backward_data_wide')
         if h0s is None:
             return dpre, dh0
         dgf = parts.sum(dim=1).view(T, B)
@@ -1921,11 +1925,16 @@ def fused_backward_weight(dpre, X, H, h0, graph, F, G, K, want_bias=False, gi=No
     Hc = H.contiguous() if H is not None else None
     uw = 0.0 if os.environ.get('GCRNN_WGRAD_NO_UNIFORM') else plan.get('uniform_w', 0.0)      # env: A/B switch
     plan16 = None if (uw == 0.0 or os.environ.get('GCRNN_NO_IMG16')) else graph.fused_plan_img16(adjoint=True)      # bf16 hop image
+    if plan16 is None and uw == 0.0 and not os.environ.get('GCRNN_NO_IMG16') and not os.environ.get('GCRNN_WGRAD_NO_UNIFORM'):
+        plan16 = graph.fused_plan_rank1(adjoint=True)    # rank-1-weighted graph: the adjoint plan of its 0/1 pattern + the factors of S^T (kernel variant R1)
+        if plan16 is not None:
+            uw = 1.0
     pl = plan16 or plan
     check(lib.gcrnn_fused_backward_weight_bf16(_p(dpre), _p(Xc), _p(Hc), _p(h0c), _p(dWp),
                                                _p(dbp), _p(pl['tile_slots']), _p(pl['tile_off']), _p(pl['ell_val4']),
                                                _p(pl['ell_col4']), pl['entries'], B, T, graph.N, F, G, K,
-                                               _p(gi), _p(gf), int(h_is_h0) | (2 if plan16 else 0), _p(hzero), uw, _stream()),
+                                               _p(gi), _p(gf), int(h_is_h0) | (2 if plan16 else 0), _p(hzero), uw,
+                                               _p(plan16.get('rank1_a')) if plan16 else None, _p(plan16.get('rank1_b')) if plan16 else None, _stream()),
           'fused_backward_weight')
     dW = dWp.sum(dim=0)                                   # fixed order over the slots: bit-reproducible
     dbs = dbp.sum(dim=0) if want_bias else None

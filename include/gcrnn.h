@@ -439,13 +439,15 @@ int gcrnn_fused_forward_wide_bf16(const void* xs, const void* h0, void* hs, cons
 int gcrnn_fused_gate_pair_wide_supported(int64_t B, int64_t T, int64_t N, int64_t F, int64_t G, int64_t K, int64_t entries, double uniform_w,
                                          int img16, int with_pack);
 /* The BPTT data chain as ONE launch of the wide kernel: gcrnn_fused_backward_data_bf16's contract (seed included), with wpackT =
- * gcrnn_fused_pack_weights_wide of the transposed state taps (G = 0), the bf16-image plan of the ADJOINT graph, dgf_parts [T][B][F/32*8]. */
+ * gcrnn_fused_pack_weights_wide of the transposed state taps (G = 0), the bf16-image plan of the ADJOINT graph, dgf_parts [T][B][F/32*8].
+ * rank1_a / rank1_b (both or neither; `img16` bit 1 of the query): a rank-1-weighted graph S[m][n] = a[m] b[n] (normalised adjacencies) on the
+ * adjoint plan of its 0/1 pattern -- the factor tables [NPad] fp32 of S^T, i.e. the forward direction's b and a (uniform_w = 1 in the weight pack). */
 int gcrnn_fused_backward_data_wide_supported(int64_t B, int64_t T, int64_t N, int64_t F, int64_t K, int64_t entries, double uniform_w, int img16,
                                              int inline_pack);
 int gcrnn_fused_backward_data_wide_bf16(const void* dHs, const void* hs, void* dpre, void* dh0, const void* wpackT, const int32_t* tile_nodes,
                                         const int32_t* tile_off, const void* ell_col4, int64_t entries, int64_t B, int64_t T, int64_t N,
                                         int64_t F, int64_t K, const float* gf, const void* h0s, float* dgf_parts, const void* dHuser_inline,
-                                        void* stream);
+                                        const float* rank1_a, const float* rank1_b, void* stream);
 int gcrnn_fused_gate_pair_prepass_wide_bf16(const void* x_user, void* xs, const void* h0, const void* wpack, const float* bias2,
                                             const float* gw2, float* parts, void* cs_in, void* cs_f, const int32_t* tile_nodes,
                                             const int32_t* tile_off, const void* ell_col4, int64_t entries, int64_t B, int64_t T, int64_t N,
@@ -565,6 +567,8 @@ int gcrnn_fused_backward_weight_bf16(const void* dpre, const void* Xuser, const 
                                      int64_t G, int64_t K, const float* gi, const float* gf, int h_is_h0,
                                      const int32_t* h0_zero_flag /* with h_is_h0 (or NULL): device int32, non-zero = h0 is all zeros */,
                                      double uniform_w /* != 0: uniform-weight image (gcrnn_ell_fill_z): both image halves in LDS, two barriers per tap */,
+                                     const float* rank1_a, const float* rank1_b /* both or neither; with the bf16 hop image only: a rank-1-weighted graph
+                                        S[m][n] = a[m] b[n] on the adjoint plan of its 0/1 pattern (uniform_w = 1) -- [NPad] fp32 factor tables of S^T */,
                                      void* stream);
 
 /* ==== small-graph regime: the whole T-step recurrence of a sequence inside one workgroup, one launch ============

@@ -537,3 +537,60 @@ def test_all_zero_flag_kernel():
     assert int(ops.fused_h0_zero_flag(odd)) == 1
     odd[2, 4, 6] = 1.0
     assert int(ops.fused_h0_zero_flag(odd)) == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('N,F,K,B,T,kind', [(1000, 64, 5, 4, 4, 'sym'), (1000, 64, 3, 3, 3, 'rw'), (400, 32, 4, 5, 3, 'sym')])
+def test_training_on_rank1_weighted_graphs_runs_on_the_wide_kernels(N, F, K, B, T, kind, monkeypatch):
+    """bf16 training on a normalised adjacency (rank-1-weighted GSO): forward on the wide kernel's R1 variant, the BPTT chain on its MODE 2 R1
+    variant (adjoint plan of the 0/1 pattern, factors swapped) and the weight gradient on fused_wgrad_kernel<..., 2, R1> -- every gradient
+    against the weighted chunk-parallel path (GCRNN_NO_RANK1=1: pinned to the reference's autograd by the G9 fixtures on a weighted directed
+    graph) within bf16 tolerances, the forward against the fp64 oracle."""
+    import gated_gcrnns_amd.Utils.graphML as gml
+    from gated_gcrnns_amd import ops, _lib
+    dev = torch.device('cuda:0')
+    S, rng = _normalized_adjacency(N, 93, kind)
+    torch.manual_seed(93)
+    cell = gml.GGCRNNCell(F, F, K, K, torch.tanh, False, None, 1, True)
+    cell.addGSO(torch.tensor(S))
+    cell = cell.float()
+    X = bf16_round(rng.standard_normal((B, T, F, N)))
+    h0 = bf16_round(0.3 * rng.standard_normal((B, F, N)))
+    tgt = torch.tensor(bf16_round(rng.standard_normal((B, T, F, N))), dtype=torch.bfloat16, device=dev)
+    with torch.no_grad():
+        for q in cell.parameters():
+            q.copy_(torch.tensor(bf16_round(q.detach().numpy())))
+    params = {k: v.detach().double().numpy() for k, v in cell.state_dict().items()}
+    Href = orc.ggcrnn_cell(params, S.astype(np.float32).astype(np.float64), X, h0)
+    cell = cell.to(dev)
+    Xd = torch.tensor(X, dtype=torch.bfloat16, device=dev)
+    hd = torch.tensor(h0, dtype=torch.bfloat16, device=dev, requires_grad=True)
+    monkeypatch.setenv('GCRNN_SEQ32_MIN_B', '1')
+    pa = cell.graph.fused_plan_rank1(adjoint=True)
+    assert pa is not None and _lib.lib.gcrnn_fused_backward_data_wide_supported(B, T, N, F, K, int(pa['entries']), 1.0, 3, 0) == 1
+
+    def step():
+        cell.zero_grad(set_to_none=True)
+        hd.grad = None
+        H = cell(Xd, hd)
+        (H.float() * tgt.float()).sum().backward()      # (linear in H: the upstream gradient is the same on both paths -- an L1 loss flips signs where their forwards differ by a rounding)
+        g = {n: p.grad.clone() for n, p in cell.named_parameters() if p.grad is not None}
+        g['h0'] = hd.grad.float().clone()
+        return H.detach().clone(), g
+
+    H1, g1 = step()
+    H2, g2 = step()
+    assert torch.equal(H1, H2) and all(torch.equal(g1[k], g2[k]) for k in g1)      # no atomics anywhere
+    err = np.abs(H1.double().cpu().numpy() - Href)
+    assert err.max() <= 8.0e-3 and err.mean() <= 1.2e-3, (err.max(), err.mean())
+    monkeypatch.setenv('GCRNN_NO_RANK1', '1')
+    for k in ('_fused_plan_rank1', '_fused_plan_rank1_adj'):
+        cell.graph.__dict__.pop(k, None)
+    H0, g0 = step()
+    for k in ('_fused_plan_rank1', '_fused_plan_rank1_adj'):
+        cell.graph.__dict__.pop(k, None)
+    assert g0.keys() == g1.keys() and len(g1) == 4
+    for k in g1:
+        sc = float(g0[k].abs().max())
+        d = (g0[k] - g1[k]).abs()
+        assert float(d.max()) <= 4e-2 * sc and float(d.mean()) <= 6e-3 * sc, (k, float(d.max()) / sc, float(d.mean()) / sc)
