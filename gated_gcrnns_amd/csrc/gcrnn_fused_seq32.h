@@ -60,6 +60,9 @@ extern "C" int gcrnn_debug_read_seq32_stamps(void* host) {
 #define GCRNN_STAMP32_FLUSH() do {} while (0)
 #endif
 
+#ifndef GCRNN_SEQ32_R1_STREAM_FIRST
+#define GCRNN_SEQ32_R1_STREAM_FIRST 0      // 1 (with R1): every wave streams first, as round 4's first rank-1 variant did (A/B)
+#endif
 #ifndef GCRNN_SEQ32_OPERAND_AT
 #define GCRNN_SEQ32_OPERAND_AT 1      // where the last chunk requests the next step's operand: 0 = at the start of its epilogue, 1 = behind its state stores, 2 = behind its row stores (A/B)
 #endif
@@ -241,6 +244,28 @@ __global__ __launch_bounds__(STHREADS) void fused_seq32_kernel(const Seq32Args a
 #pragma unroll
     for (int i = 0; i < STILES; ++i) w[i] ^= lb;
   };
+  // R1: the accumulators of this wave's tiles times a per-node factor -- kind 0: b, 1: 1 / b, 2: b (b = 0, a node without in-neighbours: 1 for
+  // kinds 1 and 2). Four tiles at a time: the eight slot words at once cost registers some instantiations do not have.
+  [[maybe_unused]] auto r1_scale = [&](f32x4 (&ac)[STILES][2], int kind) __attribute__((always_inline)) {
+    if constexpr (R1) {
+      const uint32_t ad = (uint32_t)(COL_OFF + entries * 32 + GCRNN_HOP_COLUMN_PAD) + (uint32_t)((wave * STILES * 16 + (lane_now() & 15)) * 4);
+#pragma unroll
+      for (int h4 = 0; h4 < STILES; h4 += 4) {
+        int w4[4];
+        asm volatile("ds_read_b32 %0, %4\n\tds_read_b32 %1, %4 offset:64\n\tds_read_b32 %2, %4 offset:128\n\tds_read_b32 %3, %4 offset:192\n\t"
+                     "s_waitcnt lgkmcnt(0)"
+                     : "=&v"(w4[0]), "=&v"(w4[1]), "=&v"(w4[2]), "=&v"(w4[3])
+                     : "v"(ad + (uint32_t)(h4 * 64)));
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float bv = r1tab[NP + (w4[e] >> 16)];
+          const float f = kind == 0 ? bv : (bv == 0.f ? 1.f : (kind == 1 ? __builtin_amdgcn_rcpf(bv) : bv));
+          ac[h4 + e][0] *= f; ac[h4 + e][1] *= f;
+        }
+      }
+    }
+  };
+
   {
     const int cbytes = entries * 32;
     const char* csrc = reinterpret_cast<const char*>(a.ell_col4);
@@ -414,14 +439,17 @@ __global__ __launch_bounds__(STHREADS) void fused_seq32_kernel(const Seq32Args a
       }
       }
     };
-    auto put = [&]() {
+    // R1, tprime: the accumulators hold t / b (a wave that taps first carries the hop in t' = t / b -- see the hop): the image's a (.) t is (a b) (.) t'
+    auto put = [&](auto tpc) __attribute__((always_inline)) {
+      constexpr bool tprime = decltype(tpc)::value;
       int sw[STILES];
       slot_words(lane_now(), sw);
 #pragma unroll
       for (int i = 0; i < STILES; ++i) {
         const int wv = sw[i];
         if constexpr (R1) {      // the image holds a (.) v
-          const float av = r1tab[wv >> 16];
+          float av = r1tab[wv >> 16];
+          if constexpr (tprime) { const float bv = r1tab[NP + (wv >> 16)]; av *= (bv == 0.f ? 1.f : bv); }
           state_put<true>(reinterpret_cast<float*>(smem), wv, acc[i][0] * av);
           state_put<true>(reinterpret_cast<float*>(smem + PL), wv, acc[i][1] * av);
         } else {
@@ -435,7 +463,7 @@ __global__ __launch_bounds__(STHREADS) void fused_seq32_kernel(const Seq32Args a
 #pragma unroll
       for (int i = 0; i < STILES; ++i) { acc[i][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[i][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
       taps(K - 1);
-      put();
+      put(std::false_type{});
     };
     seed();
 
@@ -613,23 +641,21 @@ __global__ __launch_bounds__(STHREADS) void fused_seq32_kernel(const Seq32Args a
         for (int i = 0; i < STILES; ++i) { acc[i][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[i][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
         // (the pack's LDS-DMA pieces go out right before the wave's stream: hipcc orders every later LDS read of the wave behind them with a
         //  vmcnt(0) -- behind the stream that wait is free, in front of the tap's weight reads it would expose the pieces' whole latency)
-        if ((!GATED || !GCRNN_SEQ32_GATED_TAPS_FIRST) && (R1 || wave < SWAVES / 2 || GCRNN_SEQ32_SAME_ORDER)) {
+        // R1 (S = a b^T on its pattern): a hop is t_j = u_j + b (.) sum (a (.) t_{j+1}). A wave that streams first scales its sums by b and adds the
+        // tap (it carries t; image write: a (.) t). A wave that taps first cannot scale the sums alone once the tap is in the accumulator -- it
+        // carries t' = t / b instead: t'_j = u_j / b + sum, image write (a b) (.) t', and b (.) t' after the chunk's last hop (b = 0: no
+        // in-neighbours, the sum is empty: factor 1). All in fp32 registers; round 4's first R1 made every wave stream first (-13 %).
+        const bool stream_first = (!GATED || !GCRNN_SEQ32_GATED_TAPS_FIRST) && (wave < SWAVES / 2 || GCRNN_SEQ32_SAME_ORDER || (R1 && GCRNN_SEQ32_R1_STREAM_FIRST));
+        if (stream_first) {
           dma_issue();
           GCRNN_HOP_ASM_WIDE32_STREAM(acc);
-          if constexpr (R1) {      // sums of a (.) v over the in-neighbours, times b[n]: then the tap
-            int swb[STILES];
-            slot_words(lane_now(), swb);
-#pragma unroll
-            for (int i = 0; i < STILES; ++i) {
-              const float bv = r1tab[NP + (swb[i] >> 16)];
-              acc[i][0] *= bv; acc[i][1] *= bv;
-            }
-          }
+          r1_scale(acc, 0);      // R1: sums of a (.) v over the in-neighbours, times b[n]: then the tap
           GCRNN_STAMP32(1 + chunk * 24 + 4 * (j - 1) + 1);
           if (j == 2 && chunk == 0) GCRNN_STAMP32_WAVE(56);
           taps(K - 1 - j, true);
         } else {
           taps(K - 1 - j);
+          r1_scale(acc, 1);      // R1: the tap in units of b (t' = t / b)
           if (j == 2 && chunk == 0) GCRNN_STAMP32_WAVE(56);
           dma_issue();
 #if GCRNN_SEQ32_YOUNG_PRIO      // experiment: the younger wave of each SIMD streams at raised issue priority (it starts its stream a tap later)
@@ -649,7 +675,13 @@ __global__ __launch_bounds__(STHREADS) void fused_seq32_kernel(const Seq32Args a
         if constexpr (MODE == 2 && EPH > 0 && j <= EPH)
           ep_request(std::integral_constant<int, (j - 1) * STILES / (EPH > 0 ? EPH : 1)>{}, std::integral_constant<int, j * STILES / (EPH > 0 ? EPH : 1)>{});
 #endif
-        if (j < K - 1) put();
+        if (j < K - 1) {
+          if (R1 && !stream_first) put(std::true_type{});
+          else put(std::false_type{});
+        }
+        if constexpr (R1 && j == K - 1) {
+          if (!stream_first) r1_scale(acc, 2);      // the chunk's result: t_0 = b (.) t'_0
+        }
         if (K == 2 && NCH > 1 && !SPLIT) weights_issue((chunk + 1) % NCH, 0);      // (K = 2: tap 0's fragments are free only now, and needed at the next chunk's only hop)
         if (r0 < NRND) pack_drain(r0);
 #pragma unroll
