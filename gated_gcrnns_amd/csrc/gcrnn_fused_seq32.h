@@ -195,7 +195,7 @@ struct Seq32Map {
 //     chunk, stores its 32 features and lays out its share of the next step's input; nothing is kept in registers across steps.
 template <int K, int HS, int XS, int VAR, int MODE = 0, bool GATED = false, bool R1 = false, bool SPLIT = false>
 __global__ __launch_bounds__(STHREADS) void fused_seq32_kernel(const Seq32Args a) {
-  static_assert(!R1 || ((MODE == 0 || MODE == 2) && !GATED), "rank-1 graphs: the un-gated forward and the BPTT chain (on the adjoint plan: the factors swap)");
+  static_assert(!R1 || !SPLIT, "rank-1 graphs: every mode of the persistent form (the BPTT chain takes the adjoint plan: the factors swap)");
   static_assert(!SPLIT || ((MODE == 0 || MODE == 2) && !R1 && HS > 1), "split sequences: the (un-gated or time-gated) forward and the BPTT chain, with more than one chunk");
   constexpr bool PKV = (VAR & 1) != 0, USERV = (VAR & 2) != 0 && MODE == 0;
   static_assert(MODE == 0 || ((MODE == 1 || MODE == 2) && !GATED), "modes");
@@ -228,9 +228,13 @@ __global__ __launch_bounds__(STHREADS) void fused_seq32_kernel(const Seq32Args a
   // live registers would not survive the hops: operand 128 + accumulators 64 + the stream's window)
   char* wtab = smem + COL_OFF + entries * 32 + GCRNN_HOP_COLUMN_PAD;
   for (int idx = tid; idx < NP; idx += STHREADS) reinterpret_cast<int32_t*>(wtab)[idx] = a.tile_nodes[idx];
-  [[maybe_unused]] float* r1tab = reinterpret_cast<float*>(wtab + NP * 4);      // R1: a[NP] then b[NP]
+  [[maybe_unused]] float* r1tab = reinterpret_cast<float*>(wtab + NP * 4);      // R1: a then b, in SLOT order (slot = (wave * STILES + tile) * 16 + row: one read, no index)
   if constexpr (R1) {
-    for (int idx = tid; idx < NP; idx += STHREADS) { r1tab[idx] = a.r1a[idx]; r1tab[NP + idx] = a.r1b[idx]; }
+    for (int idx = tid; idx < NP; idx += STHREADS) {
+      const int nd = a.tile_nodes[idx] >> 16;
+      r1tab[idx] = nd < NP ? a.r1a[nd] : 0.f;
+      r1tab[NP + idx] = nd < NP ? a.r1b[nd] : 0.f;
+    }
   }
   // (one asm statement: eight reads in flight, one wait; volatile so that the words are re-read at every use, not kept)
   auto slot_words = [&](int ln, int (&w)[STILES]) {
@@ -248,17 +252,21 @@ __global__ __launch_bounds__(STHREADS) void fused_seq32_kernel(const Seq32Args a
   // kinds 1 and 2). Four tiles at a time: the eight slot words at once cost registers some instantiations do not have.
   [[maybe_unused]] auto r1_scale = [&](f32x4 (&ac)[STILES][2], int kind) __attribute__((always_inline)) {
     if constexpr (R1) {
-      const uint32_t ad = (uint32_t)(COL_OFF + entries * 32 + GCRNN_HOP_COLUMN_PAD) + (uint32_t)((wave * STILES * 16 + (lane_now() & 15)) * 4);
+      const uint32_t ad = (uint32_t)(COL_OFF + entries * 32 + GCRNN_HOP_COLUMN_PAD + NP * 4 + NP * 4) + (uint32_t)((wave * STILES * 16 + (lane_now() & 15)) * 4);      // b, slot order
+      constexpr int NB = (GATED || MODE == 1 || K == 4) ? 1 : 4;      // factors read at a time (the instantiations at the register limit take them one by one: a few hundred cycles per hop)
 #pragma unroll
-      for (int h4 = 0; h4 < STILES; h4 += 4) {
-        int w4[4];
-        asm volatile("ds_read_b32 %0, %4\n\tds_read_b32 %1, %4 offset:64\n\tds_read_b32 %2, %4 offset:128\n\tds_read_b32 %3, %4 offset:192\n\t"
-                     "s_waitcnt lgkmcnt(0)"
-                     : "=&v"(w4[0]), "=&v"(w4[1]), "=&v"(w4[2]), "=&v"(w4[3])
-                     : "v"(ad + (uint32_t)(h4 * 64)));
+      for (int h4 = 0; h4 < STILES; h4 += NB) {
+        float b4[NB];
+        if constexpr (NB == 4)
+          asm volatile("ds_read_b32 %0, %4\n\tds_read_b32 %1, %4 offset:64\n\tds_read_b32 %2, %4 offset:128\n\tds_read_b32 %3, %4 offset:192\n\t"
+                       "s_waitcnt lgkmcnt(0)"
+                       : "=&v"(b4[0]), "=&v"(b4[1]), "=&v"(b4[2]), "=&v"(b4[3])
+                       : "v"(ad + (uint32_t)(h4 * 64)));
+        else
+          asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(b4[0]) : "v"(ad + (uint32_t)(h4 * 64)));
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float bv = r1tab[NP + (w4[e] >> 16)];
+        for (int e = 0; e < NB; ++e) {
+          const float bv = b4[e];
           const float f = kind == 0 ? bv : (bv == 0.f ? 1.f : (kind == 1 ? __builtin_amdgcn_rcpf(bv) : bv));
           ac[h4 + e][0] *= f; ac[h4 + e][1] *= f;
         }
@@ -448,8 +456,9 @@ __global__ __launch_bounds__(STHREADS) void fused_seq32_kernel(const Seq32Args a
       for (int i = 0; i < STILES; ++i) {
         const int wv = sw[i];
         if constexpr (R1) {      // the image holds a (.) v
-          float av = r1tab[wv >> 16];
-          if constexpr (tprime) { const float bv = r1tab[NP + (wv >> 16)]; av *= (bv == 0.f ? 1.f : bv); }
+          const int slot = (wave * STILES + i) * 16 + (lane_now() & 15);
+          float av = r1tab[slot];
+          if constexpr (tprime) { const float bv = r1tab[NP + slot]; av *= (bv == 0.f ? 1.f : bv); }
           state_put<true>(reinterpret_cast<float*>(smem), wv, acc[i][0] * av);
           state_put<true>(reinterpret_cast<float*>(smem + PL), wv, acc[i][1] * av);
         } else {

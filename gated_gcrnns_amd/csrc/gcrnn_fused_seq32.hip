@@ -173,8 +173,12 @@ static int seq32_launch(const Seq32Args& sa, bool inline_pack, hipStream_t st, b
       default: return seq32_launch_split<K, HS, XS, 3>(sa, lds, T, 32 * HS, 32 * XS, N, st);
     }
   }
-  if (sa.r1a) {      // rank-1-weighted graph: un-gated forward, as the module issues it (3) or sequence-major in and out (0)
-    if (sa.gi0) return GCRNN_ERR_UNSUPPORTED;
+  if (sa.r1a) {      // rank-1-weighted graph: un-gated forward, as the module issues it (3) or sequence-major in and out (0); time-gated recurrence
+    if (sa.gi0) {
+      if (inline_pack) return GCRNN_ERR_BAD_SHAPE;
+      if (sa.a1) return seq32_launch_v<K, HS, XS, 2, 0, true, true>(sa, lds, st);
+      return seq32_launch_v<K, HS, XS, 0, 0, true, true>(sa, lds, st);
+    }
     if (inline_pack && sa.a1) return seq32_launch_v<K, HS, XS, 3, 0, false, true>(sa, lds, st);
     if (!inline_pack && sa.a1) return seq32_launch_v<K, HS, XS, 2, 0, false, true>(sa, lds, st);
     if (!inline_pack && !sa.a1) return seq32_launch_v<K, HS, XS, 0, 0, false, true>(sa, lds, st);
@@ -196,8 +200,9 @@ static int seq32_launch(const Seq32Args& sa, bool inline_pack, hipStream_t st, b
 
 template <int K, int HS, int XS>
 static int seq32_launch_pair(const Seq32Args& sa, bool inline_pack, hipStream_t st) {
-  const size_t lds = seq32_lds<K, HS, XS>(sa.entries, inline_pack);
+  const size_t lds = seq32_lds<K, HS, XS>(sa.entries, inline_pack, sa.r1a != nullptr);
   if (!lds) return GCRNN_ERR_UNSUPPORTED;
+  if (sa.r1a) return inline_pack ? seq32_launch_v<K, HS, XS, 1, 1, false, true>(sa, lds, st) : seq32_launch_v<K, HS, XS, 0, 1, false, true>(sa, lds, st);
   return inline_pack ? seq32_launch_v<K, HS, XS, 1, 1>(sa, lds, st) : seq32_launch_v<K, HS, XS, 0, 1>(sa, lds, st);
 }
 
@@ -212,7 +217,7 @@ extern "C" int gcrnn_fused_forward_wide_bf16(const void* xs, const void* h0, voi
                                              int huser_last_only, const void* Xuser_inline, const float* rank1_a, const float* rank1_b,
                                              void* stream) {
   if (!xs || !h0 || !hs || !wpack || !tile_nodes || !tile_off || !ell_col4) return GCRNN_ERR_NULL_POINTER;
-  if ((rank1_a == nullptr) != (rank1_b == nullptr) || (rank1_a && gi)) return GCRNN_ERR_BAD_SHAPE;
+  if ((rank1_a == nullptr) != (rank1_b == nullptr)) return GCRNN_ERR_BAD_SHAPE;
   if ((gi == nullptr) != (gf == nullptr) || (gi && Xuser_inline)) return GCRNN_ERR_BAD_SHAPE;
   if (B <= 0 || T <= 0 || N <= 0 || N > NP || B > (1 << 24) || entries <= 0 || entries % 4) return GCRNN_ERR_BAD_SHAPE;
   if (B * (NP * (F > G ? F : G) * 2) > 2147483647LL || T * F * N > 2147483647LL) return GCRNN_ERR_BAD_SHAPE;   // 32-bit buffer offsets
@@ -273,7 +278,7 @@ extern "C" int gcrnn_fused_gate_pair_wide_supported(int64_t B, int64_t T, int64_
   if (with_pack && (N % 8 || T * G * N > 2147483647LL)) return 0;
   if (B * T * (NP * (F > G ? F : G) * 2) > 2147483647LL) return 0;      // 32-bit buffer offsets over all items
   if (!seq32_wanted(B * T)) return 0;
-  if (!seq32_lds_for(F, G, K, entries, with_pack != 0)) return 0;
+  if (!seq32_lds_for(F, G, K, entries, with_pack != 0, (img16 & 2) != 0)) return 0;      // (img16 bit 1: rank-1-weighted graph)
   if (!with_pack) return 1;
   const int64_t first = B * T < 256 ? B * T : 256;      // the items of the first round of workgroups
   return (int)((first + B - 1) / B);
@@ -282,8 +287,10 @@ extern "C" int gcrnn_fused_gate_pair_wide_supported(int64_t B, int64_t T, int64_
 extern "C" int gcrnn_fused_gate_pair_prepass_wide_bf16(const void* x_user, void* xs, const void* h0, const void* wpack, const float* bias2,
                                                        const float* gw2, float* parts, void* cs_in, void* cs_f, const int32_t* tile_nodes,
                                                        const int32_t* tile_off, const void* ell_col4, int64_t entries, int64_t B, int64_t T,
-                                                       int64_t N, int64_t F, int64_t G, int64_t K, const int32_t* h0_zero_flag, void* stream) {
+                                                       int64_t N, int64_t F, int64_t G, int64_t K, const int32_t* h0_zero_flag,
+                                                       const float* rank1_a, const float* rank1_b, void* stream) {
   if (!xs || !h0 || !wpack || !gw2 || !parts || !tile_nodes || !tile_off || !ell_col4) return GCRNN_ERR_NULL_POINTER;
+  if ((rank1_a == nullptr) != (rank1_b == nullptr)) return GCRNN_ERR_NULL_POINTER;
   if ((cs_in == nullptr) != (cs_f == nullptr)) return GCRNN_ERR_NULL_POINTER;
   const int64_t items = B * T;
   if (B <= 0 || T <= 0 || N <= 0 || N > NP || items > (1 << 24) || entries <= 0 || entries % 4) return GCRNN_ERR_BAD_SHAPE;
@@ -298,6 +305,7 @@ extern "C" int gcrnn_fused_gate_pair_prepass_wide_bf16(const void* x_user, void*
   sa.entries = (int)entries; sa.B = (int)items; sa.N = (int)N;
   sa.nsteps = 1;
   sa.flags = h0_zero_flag; sa.gw = gw2; sa.go = parts;
+  sa.r1a = rank1_a; sa.r1b = rank1_b;
   const bool inline_pack = x_user != nullptr;
   if (inline_pack) {
     sa.pk_src0 = (const uint16_t*)x_user; sa.pksrc_stride = G * N; sa.pk_stride = (int)(T * G * N);

@@ -671,10 +671,12 @@ def fused_gate_pair_plan(graph, B, T, N, F, G, K, with_pack):
     """(plan16, steps) when the wide kernel's gate-PAIR pre-pass takes this problem (gcrnn_fused_gate_pair_prepass_wide_bf16: both time
     gates of every (t, b) in ONE launch), else (None, 0). steps: with_pack -- the leading time steps of xs the caller lays out itself."""
     plan16 = fused_img16_plan(graph, True, None)
+    if plan16 is None and not os.environ.get('GCRNN_NO_IMG16'):
+        plan16 = graph.fused_plan_rank1()                # rank-1-weighted graph (normalised adjacency): the plan of its 0/1 pattern + the factor tables
     if plan16 is None or F % 32 or G % 32 or os.environ.get('GCRNN_NO_GATE_PAIR'):
         return None, 0
     steps = int(lib.gcrnn_fused_gate_pair_wide_supported(int(B), int(T), int(N), int(F), int(G), int(K), int(plan16['entries']),
-                                                         float(plan16.get('uniform_w', 0.0)), 1, 1 if with_pack else 0))
+                                                         float(plan16.get('uniform_w', 0.0)), 3 if plan16.get('rank1') else 1, 1 if with_pack else 0))
     return (plan16, steps) if steps > 0 else (None, 0)
 
 
@@ -708,7 +710,7 @@ def fused_time_gate_pair(xs, h0s, gate_in, gate_f, graph, N, store_states=False,
     cs_f = torch.empty((T, B, npad, F), dtype=torch.bfloat16, device=xs.device) if store_states else None
     check(lib.gcrnn_fused_gate_pair_prepass_wide_bf16(_p(x_user), _p(xs), _p(h0s), _p(wp), _p(b2), _p(gw2), _p(parts), _p(cs_in), _p(cs_f),
                                                       _p(plan16['tile_slots']), _p(plan16['tile_off']), _p(plan16['ell_col4']), plan16['entries'],
-                                                      B, T, N, F, G, K, _p(hzero), st), 'gate_pair_prepass')
+                                                      B, T, N, F, G, K, _p(hzero), _p(plan16.get('rank1_a')), _p(plan16.get('rank1_b')), st), 'gate_pair_prepass')
     if x_user is not None:
         del xs._pending_user
     acc = parts.view(T * B, 2, (nch // 2) * waves).sum(dim=2)                  # fixed order: deterministic gates
@@ -822,7 +824,7 @@ def fused_cell_forward(X, h0, wA, wB, bias, graph, gates=None, return_states=Fal
         if head[1] is not None:
             y = y + head[1].detach().float().reshape(())
         return y.permute(1, 0, 2).unsqueeze(2).contiguous()          # B x T x 1 x N
-    wide = fused_wide_plan(graph, B, T, N, F, G, K, inline, rank1=(gi is None), gated=(gi is not None)) if (evs is None and head is None and not (gi is not None and inline)) else None
+    wide = fused_wide_plan(graph, B, T, N, F, G, K, inline, rank1=True, gated=(gi is not None)) if (evs is None and head is None and not (gi is not None and inline)) else None
     if wide is not None:
         # un-gated cell, uniform-weight graph, a batch that fills the chip: ONE launch of the wide sequence-resident kernel
         if native_out:

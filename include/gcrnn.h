@@ -423,7 +423,8 @@ int gcrnn_fused_forward_bf16(const void* xs, const void* h0, void* hs, const voi
  *   [GFL_in ; GFL_forget] stacked over the output features, bias2 [2 F], gw2 [2][N][F] fp32 = the read-outs' weights node-major, parts
  *   [T*B][2 * F/32 * 8] fp32 partial dot products (chunks 0 .. F/32-1 the input gate's; fixed-order sum by the caller), cs_in / cs_f (both or
  *   neither) the sub-cells' states [T][B][NPad][F] bf16, x_user as in gcrnn_fused_gate_prepass_pack_bf16, h0_zero_flag as in
- *   gcrnn_fused_gate_prepass_bf16. */
+ *   gcrnn_fused_gate_prepass_bf16; rank1_a / rank1_b as in gcrnn_fused_forward_wide_bf16 (`img16` bit 1 of the query), which now takes them
+ *   together with gi / gf too (the time-gated recurrence on a rank-1-weighted graph). */
 int gcrnn_fused_pack_weights_wide(int wdtype, const void* wA, const void* wB, void* wpack, int64_t Fout, int64_t F, int64_t G, int64_t Kin,
                                   int64_t Kst, double uniform_w, void* stream);
 int gcrnn_fused_forward_wide_supported(int64_t B, int64_t T, int64_t N, int64_t F, int64_t G, int64_t K, int64_t entries, double uniform_w,
@@ -451,7 +452,8 @@ int gcrnn_fused_backward_data_wide_bf16(const void* dHs, const void* hs, void* d
 int gcrnn_fused_gate_pair_prepass_wide_bf16(const void* x_user, void* xs, const void* h0, const void* wpack, const float* bias2,
                                             const float* gw2, float* parts, void* cs_in, void* cs_f, const int32_t* tile_nodes,
                                             const int32_t* tile_off, const void* ell_col4, int64_t entries, int64_t B, int64_t T, int64_t N,
-                                            int64_t F, int64_t G, int64_t K, const int32_t* h0_zero_flag, void* stream);
+                                            int64_t F, int64_t G, int64_t K, const int32_t* h0_zero_flag, const float* rank1_a, const float* rank1_b,
+                                            void* stream);
 
 /* Time-gate pre-pass (graphML.py:2357-2374): for every (t, b)
  *   sum over gate_out[t][b][0 .. F/16*8) = sum_{n,f} tanh( A_g(S) x_t + B_g(S) h0 + 2 b_g )[n][f] * gate_w[n][f]

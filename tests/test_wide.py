@@ -594,3 +594,64 @@ def test_training_on_rank1_weighted_graphs_runs_on_the_wide_kernels(N, F, K, B, 
         sc = float(g0[k].abs().max())
         d = (g0[k] - g1[k]).abs()
         assert float(d.max()) <= 4e-2 * sc and float(d.mean()) <= 6e-3 * sc, (k, float(d.max()) / sc, float(d.mean()) / sc)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('N,F,K,B,T,kind,hz', [(1000, 64, 5, 4, 3, 'sym', False), (1000, 64, 3, 3, 3, 'rw', True), (400, 32, 4, 5, 3, 'sym', False)])
+def test_time_gated_cell_on_rank1_weighted_graphs_runs_on_the_wide_kernels(N, F, K, B, T, kind, hz, monkeypatch):
+    """The time-gated cell (the reference's default, Utils/graphML.py:2196) on a normalised adjacency: gate pair pre-pass and gated recurrence on
+    the wide kernel's rank-1 variants (the waves carry the hop in t / b: csrc/gcrnn_fused_seq32.h), forward against the fp64 oracle on the dense
+    S; training (pair pre-pass with stored states, gated chain, weight gradients of the cell and both gate cells on their R1 variants) against
+    the weighted chunk-parallel path within bf16 tolerances."""
+    import gated_gcrnns_amd.Utils.graphML as gml
+    from gated_gcrnns_amd import ops
+    dev = torch.device('cuda:0')
+    S, rng = _normalized_adjacency(N, 97, kind)
+    torch.manual_seed(97)
+    cell = gml.GGCRNNCell(F, F, K, K, torch.tanh, True, None, 1, True)
+    cell.addGSO(torch.tensor(S))
+    cell = cell.float()
+    with torch.no_grad():
+        cell.MLP_in[0].weight.mul_(8.0)
+        cell.MLP_forget[0].weight.mul_(8.0)
+        for q in cell.parameters():
+            q.copy_(torch.tensor(bf16_round(q.detach().numpy())))
+    X = bf16_round(rng.standard_normal((B, T, F, N)))
+    h0 = np.zeros((B, F, N)) if hz else bf16_round(0.3 * rng.standard_normal((B, F, N)))
+    tgt = torch.tensor(bf16_round(rng.standard_normal((B, T, F, N))), dtype=torch.bfloat16, device=dev)
+    params = {k: v.detach().double().numpy() for k, v in cell.state_dict().items()}
+    Href = orc.ggcrnn_cell(params, S.astype(np.float32).astype(np.float64), X, h0, True, None)
+    cell = cell.to(dev)
+    Xd = torch.tensor(X, dtype=torch.bfloat16, device=dev)
+    hd = torch.tensor(h0, dtype=torch.bfloat16, device=dev)
+    monkeypatch.setenv('GCRNN_SEQ32_MIN_B', '1')
+    assert ops.fused_gate_pair_plan(cell.graph, B, T, N, F, F, K, False)[0] is not None
+    assert ops.fused_wide_plan(cell.graph, B, T, N, F, F, K, False, rank1=True, gated=True) is not None
+
+    def step():
+        cell.zero_grad(set_to_none=True)
+        H = cell(Xd, hd)
+        (H.float() * tgt.float()).sum().backward()
+        return H.detach().clone(), {n: p.grad.clone() for n, p in cell.named_parameters() if p.grad is not None}
+
+    with torch.no_grad():
+        Hi = cell(Xd, hd)
+    err = np.abs(Hi.double().cpu().numpy() - Href)
+    assert err.max() <= 2.5e-2 and err.mean() <= 1.5e-3, (err.max(), err.mean())
+    H1, g1 = step()
+    H2, g2 = step()
+    assert torch.equal(H1, H2) and all(torch.equal(g1[k], g2[k]) for k in g1)
+    monkeypatch.setenv('GCRNN_NO_RANK1', '1')
+    for k in ('_fused_plan_rank1', '_fused_plan_rank1_adj'):
+        cell.graph.__dict__.pop(k, None)
+    H0, g0 = step()
+    for k in ('_fused_plan_rank1', '_fused_plan_rank1_adj'):
+        cell.graph.__dict__.pop(k, None)
+    assert g0.keys() == g1.keys() and len(g1) == 13
+    for k in g1:
+        sc = float(g0[k].abs().max())
+        if sc == 0.0:
+            assert float(g1[k].abs().max()) == 0.0, k
+            continue
+        d = (g0[k] - g1[k]).abs()
+        assert float(d.max()) <= 6e-2 * sc and (d.numel() == 1 or float(d.mean()) <= 8e-3 * sc), (k, float(d.max()) / sc, float(d.mean()) / sc)
