@@ -390,7 +390,7 @@ def run_cfg2(ctx):
             torch.cuda.synchronize()
             # (10 back-to-back launches after a warm-up one: three catch the chip at a higher clock than a longer run holds -- a kernel trace of
             #  20 such forwards averaged 5 % above the 3-launch figure, profiles/r04_seq32_as_issued_only_kernel_stats.csv)
-            KREPS = 10
+            KREPS = 30
             KWARM = 30 if args.settle_ms > 0 else 1      # untimed launches queued in front of the timed ones (the settle phase of the kernel timing)
             kern = ops.time_fused_step_kernel(X, h0, cell.weight_A, cell.weight_B, cell.bias, cell.graph, reps=KREPS, warm=KWARM)
             if kern.get('inline_pack'):          # for comparison with earlier rounds: the same launches without the inline pack of x_{t+1}

@@ -44,6 +44,9 @@ python3 $R/bench.py --steps 20 --warmup 5 --settle-ms 0 --no-cpu-baseline --no-s
 python3 $R/bench.py --mode train --batch 100 --steps 10 --warmup 3 --no-cpu-baseline > $O/${TAG}_bench_train_bf16_b100.json 2>/dev/null
 python3 $R/bench.py --time-gating --batch 100 --steps 10 --warmup 3 --no-cpu-baseline > $O/${TAG}_bench_fwd_timegated_b100.json 2>/dev/null
 python3 $R/bench.py --gso normalized --steps 10 --warmup 3 --no-cpu-baseline > $O/${TAG}_bench_fwd_normalized_adjacency.json 2>/dev/null
+python3 $R/bench.py --gso normalized --mode train --steps 10 --warmup 3 --no-cpu-baseline > $O/${TAG}_bench_train_normalized_adjacency.json 2>/dev/null
+python3 $R/bench.py --gso normalized --time-gating --steps 10 --warmup 3 --no-cpu-baseline > $O/${TAG}_bench_fwd_timegated_normalized_adjacency.json 2>/dev/null
+python3 $R/bench.py --gso normalized --time-gating --mode train --steps 6 --warmup 2 --no-cpu-baseline > $O/${TAG}_bench_train_timegated_normalized_adjacency.json 2>/dev/null
 # ---- PMC: the wide sequence-resident kernel at B = 256, T = 32 (user-layout API, inline pack), one set per pass
 for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_WAIT_INST_LDS" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_MFMA SQ_LDS_ADDR_CONFLICT" "SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VMEM SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_ACTIVE_INST_SCA" "TCC_HIT_sum TCC_MISS_sum" "GRBM_GUI_ACTIVE" "FETCH_SIZE" "WRITE_SIZE"; do
   n=$(echo $set | cut -d' ' -f1)
