@@ -255,7 +255,16 @@ def timed_steps(ctx, step):
     gc_was_on = gc.isenabled()    # depends on the process's allocation history, not on the workload) -- and none between the warm-up
     gc.disable()                  # and the timed steps either: an idle gap there restarts the transient
     ctx['settle_steps'] = 0
+    ctx['cold'] = None
     if args.settle_ms > 0:
+        # the same K steps once right here, behind the idle period of the set-up (this rank's own clock, no barrier): the cold-start figure the
+        # line would have carried without the settle phase -- reported next to `value` as config.cold_start_*
+        torch.cuda.synchronize()
+        tc = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize()
+        ctx['cold'] = (time.perf_counter() - tc) / args.steps
         step()
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -304,7 +313,11 @@ def base_line(ctx, value, wall, workload, B, extra=None):
     args, world = ctx['args'], ctx['world']
     cfg = {'workload': workload, 'batch_per_gpu': B, 'global_batch': world * B, 'mode': args.mode, 'parallelism': 'dp%d' % world,
            'settle_ms': args.settle_ms, 'settle_steps': ctx.get('settle_steps', 0),
-           'settle_note': 'untimed steps before the W warm-up steps: the clock transient behind an idle period (profiles/r04_clock_transient.txt)'}
+           'settle_note': 'untimed steps before the W warm-up steps: the clock transient behind an idle period (profiles/r04_clock_transient.txt); '
+                          'cold_start_*: the same K steps timed once BEFORE the settle phase, right behind the set-up'}
+    if ctx.get('cold'):
+        cfg['cold_start_ms_per_step'] = 1e3 * ctx['cold']
+        cfg['cold_start_value'] = world * B / ctx['cold']
     cfg.update(extra or {})
     return {'metric': 'sequences/sec (node), N=1000 K=5 T=32 F=64', 'value': value, 'unit': 'sequences/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * wall / args.steps,
