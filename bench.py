@@ -757,9 +757,20 @@ def secondary_points(ctx, S, params, B, steps=8, warmup=2):
         sec['fwd_normalized_adjacency'] = {'value': B / dt, 'unit': 'sequences/s', 'ms_per_step': 1e3 * dt, 'steps': 5, 'dtype': 'bf16',
                                            'kernel': 'fused_seq32_kernel<..,R1>' if c.graph.fused_plan_rank1() is not None else 'chunk-parallel weighted path',
                                            'what': 'un-gated forward, GSO = normalizeAdjacency(W) / lambda_max (S[m][n] = a[m] b[n] on the support), same workload'}
+        del c
+        # ... and the reference's default cell (time_gating=True, graphML.py:2196) on it: gate pair pre-pass + gated recurrence on the R1 variants
+        torch.manual_seed(0)
+        c = gml.GGCRNNCell(G, F, K, K, torch.tanh, True, None, 1, True)
+        c.addGSO(torch.tensor(sbm_graph(N, normalized=True)))
+        c = c.to(dev).to(torch.bfloat16)
+        with torch.no_grad():
+            dt = _timed(lambda: c(X, h0), 5, 2)
+        sec['fwd_timegated_normalized_adjacency'] = {'value': B / dt, 'unit': 'sequences/s', 'ms_per_step': 1e3 * dt, 'steps': 5, 'dtype': 'bf16',
+                                                     'what': 'GGCRNNCell(time_gating=True) forward on the normalised adjacency, same workload'}
         del c, X, h0
     except Exception as e:      # noqa: BLE001
-        sec['fwd_normalized_adjacency'] = {'error': str(e)[:200]}
+        sec.setdefault('fwd_normalized_adjacency', {'error': str(e)[:200]})
+        sec.setdefault('fwd_timegated_normalized_adjacency', {'error': str(e)[:200]})
     gc.collect(); torch.cuda.empty_cache()
     # ---- beyond the fused kernels' 1024 nodes (short of configs[4]): the same cell on an SBM of N = 2048, Horner-form streaming path ----
     try:
