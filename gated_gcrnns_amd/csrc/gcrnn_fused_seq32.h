@@ -119,6 +119,9 @@ struct Seq32Args {
   int hmod;                                            // item i reads the state operand of sequence i % hmod (its h0)
   const int32_t* flags;                                // (or null) flags[0] != 0: h0 is all zeros -- the state half is neither loaded nor multiplied
   const float* gw;                                     // read-out weights of the two gates, [2][N][F] fp32 (node-major)
+  const uint4* tapf; float* taps_out; int ntaps;       // MODE 1 (or null; then gw is unused): NODE gates (graphML.py:2379-2393) -- the gate cells' F -> 1 filters, taps first
+                                                       // (:2387): A fragments [2 gates][F/32][3 planes][64 lanes] x 16 B of their taps (p0 + p1 + p2 = w to 24 bits; lane
+                                                       // 16 kg + tap: w_p[tap][32 cg + 8 kg .. + 7]), output [items][2][F/32][ntaps][N] fp32 partial dots per chunk
   float* go;                                           // [items][2 * F/32 * 8] partial dot products per (chunk, wave); chunks 0 .. F/32-1 = input gate
   uint16_t* out1;                                      // (or null, with out0) the forget gate cell's states [items][NP][F]; out0 = the input gate cell's
   // MODE 2 (BPTT data chain, the adjoint of graphML.py:2420-2423): step i walks t = T-1-i; operand dpre_t = hfirst (step 0) / the previous
@@ -755,6 +758,40 @@ __global__ __launch_bounds__(STHREADS) void fused_seq32_kernel(const Seq32Args a
         // output arrays the sub-cell's state is stored (bf16) for the gate's BPTT. The weights are shared by every item (L2-resident); two
         // tiles' worth are requested at a time.
         const int gate = chunk / HS, cg = chunk - gate * HS;
+        if (a.tapf) {
+          // node gates: s_k[n] += sum_f c[n][f] w_k[f] over this chunk's 32 features on the matrix cores -- the lane's packed state (node r, features
+          // 8 q .. + 7) IS the B fragment (k = feature, n = node), the taps' three bf16 planes the A fragments (m = tap): rows 4 q' + e of D are
+          // taps, columns nodes; the chunk's partial goes to memory (the two chunks of a gate are added by the caller, fixed order)
+          typedef __attribute__((__vector_size__(4 * sizeof(unsigned int)))) unsigned int u32x4t;
+          const uint4* tfp = a.tapf + ((size_t)(gate * HS + cg) * 3) * 64 + lane;
+          bf16x8 ta[3];
+#pragma unroll
+          for (int pl = 0; pl < 3; ++pl) ta[pl] = __builtin_bit_cast(bf16x8, tfp[pl * 64]);
+          const __amdgpu_buffer_rsrc_t rsrc_c = __builtin_amdgcn_make_buffer_rsrc(gate ? a.out1 : a.out0, 0, (gate ? a.out1 : a.out0) ? B * (NP * F * 2) : 0, 0x00020000);
+          float* so = a.taps_out + (((int64_t)b * 2 + gate) * HS + cg) * (int64_t)a.ntaps * N;
+#pragma unroll
+          for (int i = 0; i < STILES; ++i) {
+            const int node = swe[i] >> 16;
+            u32x4t p{0u, 0u, 0u, 0u};
+            if (node < N) {
+              const f32x4 a0 = acc[i][0], a1 = acc[i][1];
+              p[0] = pack2bf(fast_tanh(a0[0] + bs[0][0]), fast_tanh(a0[1] + bs[0][1]));
+              p[1] = pack2bf(fast_tanh(a0[2] + bs[0][2]), fast_tanh(a0[3] + bs[0][3]));
+              p[2] = pack2bf(fast_tanh(a1[0] + bs[1][0]), fast_tanh(a1[1] + bs[1][1]));
+              p[3] = pack2bf(fast_tanh(a1[2] + bs[1][2]), fast_tanh(a1[3] + bs[1][3]));
+            }
+            if (gate ? a.out1 : a.out0) __builtin_amdgcn_raw_buffer_store_b128(p, rsrc_c, node * (F * 2) + (cg * 32 + q * 8) * 2, b * (NP * F * 2), 0);
+            f32x4 d = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int pl = 2; pl >= 0; --pl) d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ta[pl], __builtin_bit_cast(bf16x8, p), d, 0, 0, 0);
+            // D rows 4 q + e = taps, column r = this lane's node of the tile
+            if (node < N) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e)
+                if (q * 4 + e < a.ntaps) so[(int64_t)(q * 4 + e) * N + node] = d[e];
+            }
+          }
+        } else {
         const float* gwp = a.gw + (int64_t)gate * N * F + cg * 32 + q * 8;
         uint16_t* cso = gate ? a.out1 : a.out0;
         const __amdgpu_buffer_rsrc_t rsrc_c = __builtin_amdgcn_make_buffer_rsrc(cso, 0, cso ? B * (NP * F * 2) : 0, 0x00020000);
@@ -802,6 +839,7 @@ __global__ __launch_bounds__(STHREADS) void fused_seq32_kernel(const Seq32Args a
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) part += __shfl_down(part, off, 64);
         if (lane == 0) a.go[(int64_t)b * (NCH * SWAVES) + chunk * SWAVES + wave] = part;
+        }
       } else if constexpr (MODE == 2) {
         // BPTT data step: the hops applied sum_k (S)^k (dpre_t B_k^T) = d h_{t-1} (recurrent part, scaled by the forget gate of the step it came
         // through); add the upstream gradient and go through tanh': dpre_{t-1} = (gsc acc + dH_{t-1}) (1 - h_{t-1}^2); without dH the raw state

@@ -284,12 +284,13 @@ extern "C" int gcrnn_fused_gate_pair_wide_supported(int64_t B, int64_t T, int64_
   return (int)((first + B - 1) / B);
 }
 
-extern "C" int gcrnn_fused_gate_pair_prepass_wide_bf16(const void* x_user, void* xs, const void* h0, const void* wpack, const float* bias2,
-                                                       const float* gw2, float* parts, void* cs_in, void* cs_f, const int32_t* tile_nodes,
-                                                       const int32_t* tile_off, const void* ell_col4, int64_t entries, int64_t B, int64_t T,
-                                                       int64_t N, int64_t F, int64_t G, int64_t K, const int32_t* h0_zero_flag,
-                                                       const float* rank1_a, const float* rank1_b, void* stream) {
-  if (!xs || !h0 || !wpack || !gw2 || !parts || !tile_nodes || !tile_off || !ell_col4) return GCRNN_ERR_NULL_POINTER;
+static int gate_pair_prepass_impl(const void* x_user, void* xs, const void* h0, const void* wpack, const float* bias2,
+                                  const float* gw2, float* parts, const void* tapf, float* taps_out, int64_t ntaps, void* cs_in, void* cs_f,
+                                  const int32_t* tile_nodes, const int32_t* tile_off, const void* ell_col4, int64_t entries, int64_t B, int64_t T,
+                                  int64_t N, int64_t F, int64_t G, int64_t K, const int32_t* h0_zero_flag,
+                                  const float* rank1_a, const float* rank1_b, void* stream) {
+  if (!xs || !h0 || !wpack || !tile_nodes || !tile_off || !ell_col4) return GCRNN_ERR_NULL_POINTER;
+  if (tapf ? (!taps_out || ntaps <= 0 || ntaps > 16 || (reinterpret_cast<uintptr_t>(tapf) & 15)) : (!gw2 || !parts)) return GCRNN_ERR_NULL_POINTER;
   if ((rank1_a == nullptr) != (rank1_b == nullptr)) return GCRNN_ERR_NULL_POINTER;
   if ((cs_in == nullptr) != (cs_f == nullptr)) return GCRNN_ERR_NULL_POINTER;
   const int64_t items = B * T;
@@ -305,6 +306,7 @@ extern "C" int gcrnn_fused_gate_pair_prepass_wide_bf16(const void* x_user, void*
   sa.entries = (int)entries; sa.B = (int)items; sa.N = (int)N;
   sa.nsteps = 1;
   sa.flags = h0_zero_flag; sa.gw = gw2; sa.go = parts;
+  sa.tapf = (const uint4*)tapf; sa.taps_out = taps_out; sa.ntaps = (int)ntaps;
   sa.r1a = rank1_a; sa.r1b = rank1_b;
   const bool inline_pack = x_user != nullptr;
   if (inline_pack) {
@@ -318,6 +320,31 @@ extern "C" int gcrnn_fused_gate_pair_prepass_wide_bf16(const void* x_user, void*
   GCRNN_SEQ32_CASE(5, 1, 1) GCRNN_SEQ32_CASE(4, 1, 1) GCRNN_SEQ32_CASE(3, 1, 1) GCRNN_SEQ32_CASE(2, 1, 1)
 #undef GCRNN_SEQ32_CASE
   return GCRNN_ERR_UNSUPPORTED;
+}
+
+extern "C" int gcrnn_fused_gate_pair_prepass_wide_bf16(const void* x_user, void* xs, const void* h0, const void* wpack, const float* bias2,
+                                                       const float* gw2, float* parts, void* cs_in, void* cs_f, const int32_t* tile_nodes,
+                                                       const int32_t* tile_off, const void* ell_col4, int64_t entries, int64_t B, int64_t T,
+                                                       int64_t N, int64_t F, int64_t G, int64_t K, const int32_t* h0_zero_flag,
+                                                       const float* rank1_a, const float* rank1_b, void* stream) {
+  if (!gw2 || !parts) return GCRNN_ERR_NULL_POINTER;
+  return gate_pair_prepass_impl(x_user, xs, h0, wpack, bias2, gw2, parts, nullptr, nullptr, 0, cs_in, cs_f, tile_nodes, tile_off, ell_col4, entries, B, T,
+                                N, F, G, K, h0_zero_flag, rank1_a, rank1_b, stream);
+}
+
+// The same launch for the NODE gates (Utils/graphML.py:2379-2393): both gate cells of every (t, b), and instead of a read-out the first stage of
+// their F -> 1 graph filters (GFL_node_*, :2303, 2318; taps first, :2387): per-tap dot products of the gate cell's state on the matrix cores.
+// tapf [2 gates][F/32][3 planes][64 lanes] x 16 B: the taps' A fragments (three bf16 planes, p0 + p1 + p2 = w to 24 bits; lane 16 kg + tap holds
+// w_p[tap][32 cg + 8 kg .. + 7], taps >= ntaps zero); taps_out [T*B][2][F/32][ntaps][N] fp32: the partial dots of each 32-feature chunk (the caller
+// adds a gate's chunks in a fixed order, then runs the K - 1 one-channel hops and the sigmoid). cs_in / cs_f as above (training).
+extern "C" int gcrnn_fused_gate_pair_prepass_taps_wide_bf16(const void* x_user, void* xs, const void* h0, const void* wpack, const float* bias2,
+                                                            const void* tapf, float* taps_out, int64_t ntaps, void* cs_in, void* cs_f,
+                                                            const int32_t* tile_nodes, const int32_t* tile_off, const void* ell_col4,
+                                                            int64_t entries, int64_t B, int64_t T, int64_t N, int64_t F, int64_t G, int64_t K,
+                                                            const int32_t* h0_zero_flag, const float* rank1_a, const float* rank1_b, void* stream) {
+  if (!tapf || !taps_out) return GCRNN_ERR_NULL_POINTER;
+  return gate_pair_prepass_impl(x_user, xs, h0, wpack, bias2, nullptr, nullptr, tapf, taps_out, ntaps, cs_in, cs_f, tile_nodes, tile_off, ell_col4, entries,
+                                B, T, N, F, G, K, h0_zero_flag, rank1_a, rank1_b, stream);
 }
 
 

@@ -1011,6 +1011,62 @@ def fused_node_gate_taps(xs, h0s, wA_g, wB_g, bias_g, wf, graph, N, hzero=None):
     return s
 
 
+def _tap_fragments32(wfs, F):
+    """The F -> 1 filters' taps of BOTH node gates (each 1 x 1 x K x F) as the A fragments gcrnn_fused_gate_pair_prepass_taps_wide_bf16 takes:
+    three bf16 planes (p0 + p1 + p2 = w to 24 bits), bf16 [2][F/32][3][64][8] with lane l = 16 kg + tap holding w_p[tap][32 cg + 8 kg .. + 7]."""
+    out = []
+    for wf in wfs:
+        K = wf.shape[2]
+        w = wf.detach().float().reshape(K, F)
+        p0 = w.to(torch.bfloat16)
+        r1 = w - p0.float()
+        p1 = r1.to(torch.bfloat16)
+        p2 = (r1 - p1.float()).to(torch.bfloat16)
+        pl = torch.zeros((3, 16, F), dtype=torch.bfloat16, device=w.device)
+        pl[:, :K] = torch.stack([p0, p1, p2])
+        # [plane][tap][cg][kg][j] -> [cg][plane][kg][tap][j]
+        out.append(pl.view(3, 16, F // 32, 4, 8).permute(2, 0, 3, 1, 4).contiguous())
+    return torch.stack(out, dim=0).contiguous()
+
+
+def fused_node_gate_taps_pair(xs, h0s, gate_in, gate_f, graph, N, hzero=None):
+    """BOTH node gates' cells of every (t, b) with the per-tap dot products of their F -> 1 filters, as ONE pre-pass launch of the wide
+    sequence-resident kernel (gcrnn_fused_gate_pair_prepass_taps_wide_bf16; inference). gate_* = (wA_g, wB_g, bias_g, wf, bf) as in
+    fused_node_cell_forward. Returns (s_in, s_f), each [T*B][K][1][N] fp32, or None where the wide pre-pass does not apply."""
+    T, B, npad, G = xs.shape
+    F = gate_in[0].shape[0]
+    K = max(gate_in[0].shape[2], gate_in[1].shape[2])
+    Kt = gate_in[3].shape[2]
+    if gate_f[3].shape[2] != Kt or max(gate_f[0].shape[2], gate_f[1].shape[2]) != K or os.environ.get('GCRNN_NO_NODE_GATE_PAIR'):
+        return None
+    x_user = getattr(xs, '_pending_user', None)
+    plan16, _ = fused_gate_pair_plan(graph, B, T, N, F, G, K, x_user is not None)
+    if plan16 is None:
+        return None
+    st = _stream()
+
+    def prepare():
+        padx = lambda w: w.detach() if w.shape[3] == G else torch.nn.functional.pad(w.detach(), (0, G - w.shape[3]))      # (G < 32: zero input taps for the padded channels)
+        wA2 = torch.cat([padx(gate_in[0]), padx(gate_f[0])], dim=0)
+        wB2 = torch.cat([gate_in[1].detach(), gate_f[1].detach()], dim=0)
+        wp_ = _fused_pack_weights_wide(wA2, wB2, plan16['uniform_w'], st)
+        zb = torch.zeros(F, dtype=torch.float32, device=xs.device)
+        b2_ = torch.cat([(g[2].detach().float().reshape(-1) if g[2] is not None else zb) for g in (gate_in, gate_f)]).contiguous()
+        return wp_, b2_, _tap_fragments32((gate_in[3], gate_f[3]), F)
+    ptens = tuple(t.detach() for g in (gate_in, gate_f) for t in g[:4] if t is not None)
+    wp, b2, frags = _cached_pack('nodegatepair', ptens, (float(plan16['uniform_w']), tuple(t is None for g in (gate_in, gate_f) for t in g[:4])), st, prepare)
+    nch = F // 32
+    parts = torch.empty((T * B, 2, nch, Kt, N), dtype=torch.float32, device=xs.device)
+    check(lib.gcrnn_fused_gate_pair_prepass_taps_wide_bf16(_p(x_user), _p(xs), _p(h0s), _p(wp), _p(b2), _p(frags), _p(parts), Kt, None, None,
+                                                           _p(plan16['tile_slots']), _p(plan16['tile_off']), _p(plan16['ell_col4']), plan16['entries'],
+                                                           B, T, N, F, G, K, _p(hzero), _p(plan16.get('rank1_a')), _p(plan16.get('rank1_b')), st),
+          'gate_pair_prepass_taps')
+    if x_user is not None:
+        del xs._pending_user
+    s2 = parts.sum(dim=2) if nch > 1 else parts[:, :, 0]                # [items][2][Kt][N]: a gate's chunks, fixed order
+    return s2.reshape(T * B * 2, Kt, 1, N)                              # item-major, the two gates of an item next to each other
+
+
 def fused_node_supported(graph, N, F, G, Kin, Kst, dtype, E=1):
     """Node-gated cell on the fused kernels: the fused shapes in bf16 plus a state-only instantiation for K = max(Kin, Kst)."""
     return fused_supported(N, F, G, Kin, Kst, dtype, E) and max(Kin, Kst) in (2, 3, 4, 5) and not (max(Kin, Kst) == 4 and F == 32)
@@ -1034,7 +1090,15 @@ def fused_node_cell_forward(X, h0, wA, wB, bias, graph, node_gates, time_gates=N
     hzero = fused_h0_zero_flag(h0)
     zero_lin = torch.zeros((1, F * N), dtype=torch.float32, device=X.device)
     ng = []
-    for name in ('in', 'forget'):
+    pair = fused_node_gate_taps_pair(xs, h0s, node_gates['in'], node_gates['forget'], graph, N, hzero=hzero)      # both gate cells in ONE launch (wide kernel)
+    if pair is not None:
+        # second stage of both F -> 1 filters at once: the K - 1 one-channel hops on [items x 2 gates] signals, then each gate's bias and the sigmoid
+        lg = _node_gate_logits_from_taps(pair, None, graph, T, B * 2, N).view(T, B, 2, N)
+        for gidx, name in enumerate(('in', 'forget')):
+            bf = node_gates[name][4]
+            l1 = lg[:, :, gidx]
+            ng.append(torch.sigmoid(l1 + bf.detach().float().view(()) if bf is not None else l1))
+    for name in (() if pair is not None else ('in', 'forget')):
         wA_g, wB_g, bias_g, wf, bf = node_gates[name]
         if wA_g.shape[3] != G:
             wA_g = torch.nn.functional.pad(wA_g.detach(), (0, G - wA_g.shape[3]))

@@ -454,6 +454,16 @@ int gcrnn_fused_gate_pair_prepass_wide_bf16(const void* x_user, void* xs, const 
                                             const int32_t* tile_off, const void* ell_col4, int64_t entries, int64_t B, int64_t T, int64_t N,
                                             int64_t F, int64_t G, int64_t K, const int32_t* h0_zero_flag, const float* rank1_a, const float* rank1_b,
                                             void* stream);
+/* gcrnn_fused_gate_pair_prepass_wide_bf16 for the NODE gates (Utils/graphML.py:2379-2393): both gate cells of every (t, b) in one launch, and
+ * instead of a read-out the first stage of their F -> 1 graph filters GFL_node_* (:2303, 2318), taps first (:2387): tapf [2][F/32][3][64] x 16 B
+ * = the taps' A fragments (three bf16 planes, p0 + p1 + p2 = w to 24 bits; lane 16 kg + tap: w_p[tap][32 cg + 8 kg .. + 7], taps >= ntaps
+ * zero), taps_out [T*B][2][F/32][ntaps][N] fp32 = the partial dots per 32-feature chunk (the caller adds a gate's chunks, runs the one-channel
+ * hops and the sigmoid). */
+int gcrnn_fused_gate_pair_prepass_taps_wide_bf16(const void* x_user, void* xs, const void* h0, const void* wpack, const float* bias2,
+                                                 const void* tapf, float* taps_out, int64_t ntaps, void* cs_in, void* cs_f,
+                                                 const int32_t* tile_nodes, const int32_t* tile_off, const void* ell_col4, int64_t entries,
+                                                 int64_t B, int64_t T, int64_t N, int64_t F, int64_t G, int64_t K, const int32_t* h0_zero_flag,
+                                                 const float* rank1_a, const float* rank1_b, void* stream);
 
 /* Time-gate pre-pass (graphML.py:2357-2374): for every (t, b)
  *   sum over gate_out[t][b][0 .. F/16*8) = sum_{n,f} tanh( A_g(S) x_t + B_g(S) h0 + 2 b_g )[n][f] * gate_w[n][f]

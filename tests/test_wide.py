@@ -655,3 +655,47 @@ def test_time_gated_cell_on_rank1_weighted_graphs_runs_on_the_wide_kernels(N, F,
             continue
         d = (g0[k] - g1[k]).abs()
         assert float(d.max()) <= 6e-2 * sc and (d.numel() == 1 or float(d.mean()) <= 8e-3 * sc), (k, float(d.max()) / sc, float(d.mean()) / sc)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('N,F,G,K,B,T,hz', [(1000, 64, 64, 5, 5, 4, False), (1000, 64, 1, 3, 4, 3, True), (400, 32, 32, 3, 6, 3, False)])
+def test_node_gate_pair_prepass_on_the_wide_kernel(N, F, G, K, B, T, hz, monkeypatch):
+    """Node gates (Utils/graphML.py:2379-2407): BOTH gate cells of every (t, b) as ONE pre-pass launch of the wide kernel, the first stage of
+    their F -> 1 filters (tap dots, :2387) on the matrix cores in its epilogue (gcrnn_fused_gate_pair_prepass_taps_wide_bf16): the node-gated
+    forward against the fp64 oracle, and against the per-gate pre-passes of the 16-feature kernel (GCRNN_NO_NODE_GATE_PAIR=1) within bf16 noise."""
+    import gated_gcrnns_amd.Utils.graphML as gml
+    dev = torch.device('cuda:0')
+    rng = np.random.default_rng(101)
+    W = (rng.random((N, N)) < 10.0 / N).astype(np.float64)
+    W = np.triu(W, 1); W = W + W.T
+    S = (W / np.max(np.abs(np.linalg.eigvalsh(W)))).reshape(1, N, N)
+    torch.manual_seed(101)
+    cell = gml.GGCRNNCell(G, F, K, K, torch.tanh, False, 'node', 1, True)
+    cell.addGSO(torch.tensor(S))
+    cell = cell.float()
+    with torch.no_grad():
+        for q in cell.parameters():
+            q.copy_(torch.tensor(bf16_round(q.detach().numpy())))
+    X = bf16_round(rng.standard_normal((B, T, G, N)))
+    h0 = np.zeros((B, F, N)) if hz else bf16_round(0.3 * rng.standard_normal((B, F, N)))
+    params = {k: v.detach().double().numpy() for k, v in cell.state_dict().items()}
+    Href = orc.ggcrnn_cell(params, S.astype(np.float32).astype(np.float64), X, h0, False, 'node')
+    cell = cell.to(torch.bfloat16).to(dev)
+    Xd = torch.tensor(X, dtype=torch.bfloat16, device=dev)
+    hd = torch.tensor(h0, dtype=torch.bfloat16, device=dev)
+    monkeypatch.setenv('GCRNN_SEQ32_MIN_B', '1')
+    calls = []
+    from gated_gcrnns_amd import ops
+    orig = ops.fused_node_gate_taps_pair
+    monkeypatch.setattr(ops, 'fused_node_gate_taps_pair', lambda *a, **k: (calls.append(1), orig(*a, **k))[1])
+    with torch.no_grad():
+        assert cell._use_fused_node(Xd, hd)
+        H = cell(Xd, hd)
+        assert calls, 'the pair pre-pass was not asked'
+        monkeypatch.setenv('GCRNN_NO_NODE_GATE_PAIR', '1')
+        H16 = cell(Xd, hd)
+    err = np.abs(H.double().cpu().numpy() - Href)
+    assert err.max() <= 2.5e-2 and err.mean() <= 1.5e-3, (err.max(), err.mean())
+    d = (H.float() - H16.float()).abs()
+    assert float(d.max()) <= 2.5e-2 and float(d.mean()) <= 1.5e-3, (float(d.max()), float(d.mean()))
+    assert float(d.max()) > 0.0 or N < 100      # (two kernel families: not the same bits)
