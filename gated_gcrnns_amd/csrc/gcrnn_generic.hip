@@ -13,7 +13,9 @@
 template <typename T, bool PACK>
 __global__ __launch_bounds__(256) void layout_kernel(const T* __restrict__ src, T* __restrict__ dst, int64_t B,
                                                      int64_t Tn, int64_t C, int64_t N,
-                                                     const int32_t* __restrict__ perm) {
+                                                     const int32_t* __restrict__ perm, int64_t nsum = 1) {
+  // nsum > 1 (PACK): the user side is [B][nsum][T][C][N] and the nsum slices are ADDED on the way (in order: deterministic) -- partial sums
+  // that a producer kernel stored per slice (the node gates' tap dots per 32-feature chunk) cost no pass of their own
   __shared__ T tile[32][33];
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
   const int64_t n0 = (int64_t)blockIdx.x * 32, q0 = (int64_t)blockIdx.y * 32, t = blockIdx.z;
@@ -28,7 +30,8 @@ __global__ __launch_bounds__(256) void layout_kernel(const T* __restrict__ src, 
       T v = T(0);
       if (q < Q && n < N) {
         const int64_t b = q / C, c = q - b * C;
-        v = src[((b * Tn + t) * C + c) * N + nsrc];
+        v = src[(((b * nsum) * Tn + t) * C + c) * N + nsrc];
+        for (int64_t sl = 1; sl < nsum; ++sl) v += src[(((b * nsum + sl) * Tn + t) * C + c) * N + nsrc];
       }
       tile[ty + 8 * i][tx] = v;
     }
@@ -83,6 +86,18 @@ static int layout_launch(int dtype, const void* src, void* dst, int64_t B, int64
 extern "C" int gcrnn_pack_node_major(int dtype, const void* src, void* dst, int64_t B, int64_t T, int64_t C,
                                      int64_t N, const int32_t* perm, void* stream) {
   return layout_launch<true>(dtype, src, dst, B, T, C, N, perm, stream);
+}
+// gcrnn_pack_node_major of the SUM over S slices: src fp32 [B][S][T][C][N] -> dst [T][N][B][C] = sum_s src[b][s][t][c][n] (in slice order).
+extern "C" int gcrnn_pack_node_major_sum_f32(const void* src, void* dst, int64_t B, int64_t S, int64_t T, int64_t C, int64_t N, void* stream) {
+  if (!src || !dst) return GCRNN_ERR_NULL_POINTER;
+  if (B <= 0 || S <= 0 || T <= 0 || C <= 0 || N <= 0 || T > 65535) return GCRNN_ERR_BAD_SHAPE;
+  const int64_t gy = cdiv(B * C, 32);
+  if (gy > 65535) return GCRNN_ERR_BAD_SHAPE;
+  GCRNN_PRE_LAUNCH();
+  dim3 grid((unsigned)cdiv(N, 32), (unsigned)gy, (unsigned)T);
+  layout_kernel<float, true><<<grid, 256, 0, as_stream(stream)>>>((const float*)src, (float*)dst, B, T, C, N, nullptr, S);
+  GCRNN_CHECK_LAUNCH();
+  return GCRNN_OK;
 }
 extern "C" int gcrnn_unpack_node_major(int dtype, const void* src, void* dst, int64_t B, int64_t T, int64_t C,
                                        int64_t N, const int32_t* perm, void* stream) {

@@ -955,9 +955,14 @@ def node_gate_logits(cs, wf, bf, graph, N):
 
 def _node_gate_logits_from_taps(s, bf, graph, T, B, N):
     """Second stage of the F -> 1 GraphFilter: s [items][K][1][N] fp32 per-tap dot products -> logits [T][B][N] (K-1 Horner hops on
-    the one-channel signals, node-major)."""
-    K = s.shape[1]
-    sn = _pack_raw(s)                                                  # [K][N][items][1]
+    the one-channel signals, node-major). s [items][S][K][1][N]: per-slice partials, added by the layout pass (gcrnn_pack_node_major_sum_f32)."""
+    if s.dim() == 5:
+        items, S_, K = s.shape[0], s.shape[1], s.shape[2]
+        sn = torch.empty((K, N, items, 1), dtype=torch.float32, device=s.device)
+        check(lib.gcrnn_pack_node_major_sum_f32(_p(s), _p(sn), items, S_, K, 1, N, _stream()), 'pack_node_major_sum')
+    else:
+        K = s.shape[1]
+        sn = _pack_raw(s)                                              # [K][N][items][1]
     acc = sn[K - 1:K]
     csr = graph.fwd[0]
     for k in range(K - 2, -1, -1):
@@ -1063,8 +1068,7 @@ def fused_node_gate_taps_pair(xs, h0s, gate_in, gate_f, graph, N, hzero=None):
           'gate_pair_prepass_taps')
     if x_user is not None:
         del xs._pending_user
-    s2 = parts.sum(dim=2) if nch > 1 else parts[:, :, 0]                # [items][2][Kt][N]: a gate's chunks, fixed order
-    return s2.reshape(T * B * 2, Kt, 1, N)                              # item-major, the two gates of an item next to each other
+    return parts.view(T * B * 2, nch, Kt, 1, N)                         # row 2 i + g: item i, gate g; [.., chunk, tap, 1, node]: the caller's layout pass adds the chunks
 
 
 def fused_node_supported(graph, N, F, G, Kin, Kst, dtype, E=1):

@@ -68,6 +68,9 @@ int gcrnn_degree_order(const int32_t* rowptr, int64_t N, int32_t* order);
  * plumbing (graphML.py:2353-2354, 2425-2427). */
 int gcrnn_pack_node_major(int dtype, const void* src, void* dst, int64_t B, int64_t T, int64_t C, int64_t N,
                           const int32_t* perm, void* stream);
+/* gcrnn_pack_node_major of the sum over S slices (fp32): src [B][S][T][C][N] -> dst [T][N][B][C] = sum_s src[b][s][t][c][n], slices added in
+ * order (deterministic). The node gates' tap dots (Utils/graphML.py:2387) leave the gate pre-pass as one partial per 32-feature chunk. */
+int gcrnn_pack_node_major_sum_f32(const void* src, void* dst, int64_t B, int64_t S, int64_t T, int64_t C, int64_t N, void* stream);
 int gcrnn_unpack_node_major(int dtype, const void* src, void* dst, int64_t B, int64_t T, int64_t C, int64_t N,
                             const int32_t* perm, void* stream);
 
