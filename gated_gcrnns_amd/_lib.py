@@ -47,6 +47,8 @@ def _bind(lib):
         'gcrnn_degree_order': (C.c_int, [_c_p, _c_i64, _c_p]),
         'gcrnn_pack_node_major': (C.c_int, [C.c_int, _c_p, _c_p, _c_i64, _c_i64, _c_i64, _c_i64, _c_p, _c_p]),
         'gcrnn_pack_node_major_sum_f32': (C.c_int, [_c_p, _c_p, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_p]),
+        'gcrnn_node_gate_filter_supported': (C.c_int, [_c_i64, _c_i64, _c_i64, C.c_double]),
+        'gcrnn_node_gate_filter_f32': (C.c_int, [_c_p, _c_p, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_p, _c_p, _c_p, _c_i64, C.c_double, _c_p, C.c_int, _c_p]),
         'gcrnn_unpack_node_major': (C.c_int, [C.c_int, _c_p, _c_p, _c_i64, _c_i64, _c_i64, _c_i64, _c_p, _c_p]),
         'gcrnn_spmm': (C.c_int, [C.c_int, _c_i64, _c_p, _c_p, _c_p, _c_p, _c_p, _c_i64, _c_i64, C.c_int, _c_p]),
         'gcrnn_spmm_ex': (C.c_int, [C.c_int, _c_i64, _c_p, _c_p, _c_p, _c_p, _c_p, _c_i64, _c_i64, C.c_int, _c_p, C.c_double, _c_i64,

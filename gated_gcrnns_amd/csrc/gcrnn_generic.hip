@@ -99,6 +99,161 @@ extern "C" int gcrnn_pack_node_major_sum_f32(const void* src, void* dst, int64_t
   GCRNN_CHECK_LAUNCH();
   return GCRNN_OK;
 }
+// ------------------------------------------------------------------------------------------
+// second stage of the node gates' F -> 1 GraphFilter (Utils/graphML.py:2387-2399) in ONE pass: per item the K one-channel signals
+// u_k = sum_s parts[item][s][k][:] (the per-chunk tap dots the gate pre-pass stored) run the K - 1 Horner hops  a <- u_k + P a, then bias +
+// sigmoid, written where the node-gated recurrence reads its gates. HBM-bound on the partials (S K N floats per item in, N out), so:
+// persistent workgroups of 512 threads (thread = two nodes) over groups of 4 items, the CSR rows of P copied into LDS once per workgroup (col
+// as u16: N <= 1024; no weights at all for a uniform-weight graph), all S K fetches of a group issued up front (K x 8 accumulators), the
+// running signal of the 4 items in LDS as one float4 per node (one 16-byte gather per CSR entry), and 2-4 workgroups per CU so that one's
+// fetches overlap another's gathers.
+// ------------------------------------------------------------------------------------------
+template <int K, bool UNI>
+__global__ __launch_bounds__(512) void node_gate_filter_kernel(const float* __restrict__ parts, int S, int N, int64_t items, int groups, int64_t B,
+                                                               const int* __restrict__ rowptr, const int* __restrict__ col,
+                                                               const float* __restrict__ val, int nnz, float uniform_w,
+                                                               const float* __restrict__ bias, int sigmoid, float* __restrict__ out,
+                                                               int64_t ngroups) {
+  constexpr int I = 4;
+  extern __shared__ __align__(16) unsigned char node_gate_lds[];
+  float4* acc = reinterpret_cast<float4*>(node_gate_lds);                        // [N] x 4 items
+  float* vv = reinterpret_cast<float*>(acc + N);                                  // [nnz] (not for UNI)
+  uint16_t* cc = reinterpret_cast<uint16_t*>(vv + (UNI ? 0 : nnz));               // [nnz]
+  const int tid = threadIdx.x;
+  for (int j = tid; j < nnz; j += 512) {
+    if (!UNI) vv[j] = val[j];
+    cc[j] = (uint16_t)col[j];
+  }
+  int j0[2], j1[2], nc[2];
+  bool on[2];
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    const int n = tid + 512 * r;
+    on[r] = n < N;
+    nc[r] = on[r] ? n : N - 1;
+    j0[r] = on[r] ? rowptr[n] : 0;
+    j1[r] = on[r] ? rowptr[n + 1] : 0;
+  }
+  const int64_t kstride = (int64_t)K * N, istride = (int64_t)S * kstride;
+  for (int64_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+    const int64_t i0 = grp * I;
+    float u[K][2][I];
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+#pragma unroll
+      for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int i = 0; i < I; ++i) u[k][r][i] = 0.f;
+    // (no branch around a fetch: rows past N and items past the end read a clamped address and are never stored -- a conditional fetch
+    //  would put its wait inside the branch and run the K S 8 fetches one round trip after the other)
+    const float* pi[I];
+#pragma unroll
+    for (int i = 0; i < I; ++i) pi[i] = parts + (i0 + i < items ? i0 + i : items - 1) * istride;
+    for (int s = 0; s < S; ++s) {
+#pragma unroll
+      for (int k = 0; k < K; ++k)
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+          for (int i = 0; i < I; ++i) u[k][r][i] += pi[i][s * kstride + (int64_t)k * N + nc[r]];
+    }
+    float a[2][I];
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+      for (int i = 0; i < I; ++i) a[r][i] = u[K - 1][r][i];
+#pragma unroll
+    for (int k = K - 2; k >= 0; --k) {
+#pragma unroll
+      for (int r = 0; r < 2; ++r)
+        if (on[r]) acc[tid + 512 * r] = make_float4(a[r][0], a[r][1], a[r][2], a[r][3]);
+      __syncthreads();      // (the first one of a workgroup also covers the CSR copy)
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int j = j0[r]; j < j1[r]; ++j) {
+          const float4 v = acc[cc[j]];
+          const float w = UNI ? 1.f : vv[j];
+          sum.x = fmaf(w, v.x, sum.x);
+          sum.y = fmaf(w, v.y, sum.y);
+          sum.z = fmaf(w, v.z, sum.z);
+          sum.w = fmaf(w, v.w, sum.w);
+        }
+        const float sc = UNI ? uniform_w : 1.f;
+        a[r][0] = fmaf(sc, sum.x, u[k][r][0]);
+        a[r][1] = fmaf(sc, sum.y, u[k][r][1]);
+        a[r][2] = fmaf(sc, sum.z, u[k][r][2]);
+        a[r][3] = fmaf(sc, sum.w, u[k][r][3]);
+      }
+      __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < I; ++i) {
+      const int64_t item = i0 + i;
+      if (item < items) {
+        const int g = (int)(item % groups);
+        const int64_t ib = item / groups, t = ib / B, b = ib % B;
+        const float bg = bias ? bias[g] : 0.f;
+        float* o = out + ((t * groups + g) * B + b) * N;
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+          if (on[r]) {
+            const float v = a[r][i] + bg;
+            o[tid + 512 * r] = sigmoid ? 1.f / (1.f + __expf(-v)) : v;
+          }
+      }
+    }
+  }
+}
+static inline size_t node_gate_filter_lds(int64_t N, int64_t nnz, bool uni) { return (size_t)N * 16 + (size_t)nnz * (uni ? 2 : 6) + 16; }
+template <int K, bool UNI>
+static int node_gate_filter_launch(const float* parts, float* out, int64_t items, int S, int N, int groups, int64_t B, const int32_t* rowptr,
+                                   const int32_t* col, const float* val, int nnz, float uniform_w, const float* bias, int sigmoid, void* stream) {
+  const size_t lds = node_gate_filter_lds(N, nnz, UNI);
+  auto kern = node_gate_filter_kernel<K, UNI>;
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    return GCRNN_ERR_LAUNCH;
+  const int64_t ngroups = cdiv(items, (int64_t)4);
+  int64_t per_cu = (int64_t)(160 * 1024 / lds);      // workgroups of 8 waves per CU: LDS, and the register file (<= 96 VGPRs) allows 2
+  per_cu = per_cu < 1 ? 1 : (per_cu > 2 ? 2 : per_cu);
+  const int64_t slots = 256 * per_cu;
+  const unsigned grid = (unsigned)(ngroups < slots ? ngroups : slots);
+  kern<<<dim3(grid), 512, lds, as_stream(stream)>>>(parts, S, N, items, groups, B, rowptr, col, val, nnz, uniform_w, bias, sigmoid, out, ngroups);
+  return GCRNN_OK;
+}
+// 1 where gcrnn_node_gate_filter_f32 runs this problem (K <= 5 taps, N <= 1024, the CSR rows beside the running signal in LDS), else 0.
+extern "C" int gcrnn_node_gate_filter_supported(int64_t K, int64_t N, int64_t nnz, double uniform_w) {
+  return (K >= 1 && K <= 5 && N >= 1 && N <= 1024 && nnz >= 0 && nnz < (1 << 24) && node_gate_filter_lds(N, nnz, uniform_w != 0.0) <= 160 * 1024) ? 1 : 0;
+}
+// parts fp32 [items][S][K][N], item = (t B + b) groups + g  ->  out fp32 [T][groups][B][N] = act(sum_k P^k u_k + bias[g]); P = the CSR rows
+// (rowptr int32[N + 1], col int32[nnz], val fp32[nnz]; uniform_w != 0: every stored entry has this weight and val is not read),
+// bias fp32[groups] or NULL, act = sigmoid or identity.
+extern "C" int gcrnn_node_gate_filter_f32(const void* parts, void* out, int64_t items, int64_t S, int64_t K, int64_t N, int64_t groups, int64_t B,
+                                          const int32_t* rowptr, const int32_t* col, const void* val, int64_t nnz, double uniform_w,
+                                          const void* bias, int sigmoid, void* stream) {
+  const bool uni = uniform_w != 0.0;
+  if (!parts || !out || !rowptr || (nnz > 0 && (!col || (!uni && !val)))) return GCRNN_ERR_NULL_POINTER;
+  if (items <= 0 || S <= 0 || groups <= 0 || B <= 0 || items % (groups * B) || !gcrnn_node_gate_filter_supported(K, N, nnz, uniform_w))
+    return GCRNN_ERR_BAD_SHAPE;
+  GCRNN_PRE_LAUNCH();
+  int rc = GCRNN_OK;
+#define NGF(KK)                                                                                                                             \
+  rc = uni ? node_gate_filter_launch<KK, true>((const float*)parts, (float*)out, items, (int)S, (int)N, (int)groups, B, rowptr, col,        \
+                                               (const float*)val, (int)nnz, (float)uniform_w, (const float*)bias, sigmoid, stream)         \
+           : node_gate_filter_launch<KK, false>((const float*)parts, (float*)out, items, (int)S, (int)N, (int)groups, B, rowptr, col,       \
+                                                (const float*)val, (int)nnz, 0.f, (const float*)bias, sigmoid, stream)
+  switch ((int)K) {
+    case 1: NGF(1); break;
+    case 2: NGF(2); break;
+    case 3: NGF(3); break;
+    case 4: NGF(4); break;
+    default: NGF(5); break;
+  }
+#undef NGF
+  if (rc != GCRNN_OK) return rc;
+  GCRNN_CHECK_LAUNCH();
+  return GCRNN_OK;
+}
 extern "C" int gcrnn_unpack_node_major(int dtype, const void* src, void* dst, int64_t B, int64_t T, int64_t C,
                                        int64_t N, const int32_t* perm, void* stream) {
   return layout_launch<false>(dtype, src, dst, B, T, C, N, perm, stream);

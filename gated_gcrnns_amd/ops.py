@@ -1095,8 +1095,20 @@ def fused_node_cell_forward(X, h0, wA, wB, bias, graph, node_gates, time_gates=N
     zero_lin = torch.zeros((1, F * N), dtype=torch.float32, device=X.device)
     ng = []
     pair = fused_node_gate_taps_pair(xs, h0s, node_gates['in'], node_gates['forget'], graph, N, hzero=hzero)      # both gate cells in ONE launch (wide kernel)
-    if pair is not None:
-        # second stage of both F -> 1 filters at once: the K - 1 one-channel hops on [items x 2 gates] signals, then each gate's bias and the sigmoid
+    ngates = None
+    if pair is not None and not os.environ.get('GCRNN_NO_NODE_GATE_FILTER') and int(lib.gcrnn_node_gate_filter_supported(pair.shape[2], N, graph.fwd[0].nnz, plan.get('uniform_w', 0.0))):
+        # second stage of both F -> 1 filters in ONE pass over the tap dots: chunk sum, the K - 1 one-channel hops (running signal in LDS),
+        # each gate's bias, the sigmoid, written as the recurrence reads them (gcrnn_node_gate_filter_f32)
+        bfs = tuple(node_gates[name][4] for name in ('in', 'forget'))
+        b2 = None
+        if any(b is not None for b in bfs):
+            b2 = _cached_pack('nodegatebias', tuple(b.detach() for b in bfs if b is not None), tuple(b is None for b in bfs), st,
+                              lambda: torch.cat([(b.detach().float().reshape(1) if b is not None else torch.zeros(1, device=X.device)) for b in bfs]).contiguous())
+        csr = graph.fwd[0]
+        ngates = torch.empty((T, 2, B, N), dtype=torch.float32, device=X.device)
+        check(lib.gcrnn_node_gate_filter_f32(_p(pair), _p(ngates), T * B * 2, pair.shape[1], pair.shape[2], N, 2, B, _p(csr.rowptr), _p(csr.col),
+                                             _p(csr.val(torch.float32)), csr.nnz, plan.get('uniform_w', 0.0), _p(b2), 1, st), 'node_gate_filter')
+    elif pair is not None:
         lg = _node_gate_logits_from_taps(pair, None, graph, T, B * 2, N).view(T, B, 2, N)
         for gidx, name in enumerate(('in', 'forget')):
             bf = node_gates[name][4]
@@ -1113,7 +1125,8 @@ def fused_node_cell_forward(X, h0, wA, wB, bias, graph, node_gates, time_gates=N
             _, cs, _ = fused_time_gate(xs, h0s, wA_g, wB_g, bias_g, zero_lin, None, graph, N, store_states=True, hzero=hzero)
             logit, _ = node_gate_logits(cs, wf, bf, graph, N)
         ng.append(torch.sigmoid(logit))
-    ngates = torch.stack(ng, dim=1).contiguous()                        # [T][2][B][N]
+    if ngates is None:
+        ngates = torch.stack(ng, dim=1).contiguous()                    # [T][2][B][N]
     assert getattr(xs, '_pending_user', None) is None
     gi = gf = None
     if time_gates is not None:

@@ -71,6 +71,15 @@ int gcrnn_pack_node_major(int dtype, const void* src, void* dst, int64_t B, int6
 /* gcrnn_pack_node_major of the sum over S slices (fp32): src [B][S][T][C][N] -> dst [T][N][B][C] = sum_s src[b][s][t][c][n], slices added in
  * order (deterministic). The node gates' tap dots (Utils/graphML.py:2387) leave the gate pre-pass as one partial per 32-feature chunk. */
 int gcrnn_pack_node_major_sum_f32(const void* src, void* dst, int64_t B, int64_t S, int64_t T, int64_t C, int64_t N, void* stream);
+/* Second stage of the node gates' F -> 1 GraphFilter (Utils/graphML.py:2387-2399) in one pass over the tap dots: parts fp32 [items][S][K][N]
+ * (item = (t B + b) groups + g; S per-chunk partials, added in order) -> out fp32 [T][groups][B][N] = act(sum_k P^k u_k + bias[g]), P = the CSR
+ * rows (rowptr int32[N + 1], col int32[nnz], val fp32[nnz]; uniform_w != 0: every stored entry has that weight and val is not read),
+ * bias fp32[groups] or NULL, act = sigmoid (1) or identity (0).
+ * gcrnn_node_gate_filter_supported: K <= 5, N <= 1024 and the CSR rows fit in LDS beside the running signal. */
+int gcrnn_node_gate_filter_supported(int64_t K, int64_t N, int64_t nnz, double uniform_w);
+int gcrnn_node_gate_filter_f32(const void* parts, void* out, int64_t items, int64_t S, int64_t K, int64_t N, int64_t groups, int64_t B,
+                               const int32_t* rowptr, const int32_t* col, const void* val, int64_t nnz, double uniform_w, const void* bias,
+                               int sigmoid, void* stream);
 int gcrnn_unpack_node_major(int dtype, const void* src, void* dst, int64_t B, int64_t T, int64_t C, int64_t N,
                             const int32_t* perm, void* stream);
 

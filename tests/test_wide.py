@@ -699,3 +699,45 @@ def test_node_gate_pair_prepass_on_the_wide_kernel(N, F, G, K, B, T, hz, monkeyp
     d = (H.float() - H16.float()).abs()
     assert float(d.max()) <= 2.5e-2 and float(d.mean()) <= 1.5e-3, (float(d.max()), float(d.mean()))
     assert float(d.max()) > 0.0 or N < 100      # (two kernel families: not the same bits)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('N,S_,K,T,B,bias,uniform', [(1000, 2, 5, 3, 3, True, False), (1000, 2, 5, 5, 3, True, True), (300, 1, 3, 2, 5, False, True),
+                                                     (1024, 2, 1, 1, 4, True, False), (37, 3, 4, 2, 2, True, False), (600, 2, 2, 1, 1, False, False)])
+def test_node_gate_filter_one_pass(N, S_, K, T, B, bias, uniform):
+    """Second stage of the node gates' F -> 1 GraphFilter (Utils/graphML.py:2387-2399) as ONE pass over the tap dots
+    (gcrnn_node_gate_filter_f32): chunk sum, K - 1 one-channel hops, bias, sigmoid -- against the same arithmetic in fp64 (numpy), on item
+    counts that do not fill the last workgroup, and against the hop-per-launch path (_node_gate_logits_from_taps)."""
+    from gated_gcrnns_amd import ops, _lib
+    from gated_gcrnns_amd.graph import GraphOperator
+    dev = torch.device('cuda:0')
+    rng = np.random.default_rng(7 + N)
+    W = (rng.random((N, N)) < min(1.0, 8.0 / N)) * (1.0 if uniform else rng.standard_normal((N, N)))
+    Sg = (0.5 * W / max(1e-9, np.max(np.abs(np.linalg.eigvals(W))))).reshape(1, N, N)
+    graph = GraphOperator(Sg.astype(np.float32), device=dev)
+    items = T * B * 2
+    parts = rng.standard_normal((items, S_, K, 1, N)).astype(np.float32)
+    b2 = rng.standard_normal(2).astype(np.float32) if bias else None
+    pd = torch.tensor(parts, device=dev)
+    out = torch.empty((T, 2, B, N), dtype=torch.float32, device=dev)
+    csr = graph.fwd[0]
+    bd = torch.tensor(b2, device=dev) if bias else None
+    uw = float(csr.val(torch.float32)[0]) if uniform else 0.0          # (uniform-weight graphs: the kernel does not read val)
+    ops.check(_lib.lib.gcrnn_node_gate_filter_f32(ops._p(pd), ops._p(out), items, S_, K, N, 2, B, ops._p(csr.rowptr), ops._p(csr.col),
+                                                  ops._p(csr.val(torch.float32)), csr.nnz, uw, ops._p(bd), 1, ops._stream()), 'node_gate_filter')
+    # y = sum_k u_k S^k (row-vector convention of the reference: x S), u_k = the slice sum
+    u = parts.astype(np.float64).sum(axis=1)[:, :, 0, :]                 # [items][K][N]
+    S64 = Sg[0].astype(np.float32).astype(np.float64)
+    acc = u[:, K - 1]
+    for k in range(K - 2, -1, -1):
+        acc = u[:, k] + acc @ S64
+    acc = acc.reshape(T, B, 2, N).transpose(0, 2, 1, 3)
+    if bias:
+        acc = acc + b2.astype(np.float64).reshape(1, 2, 1, 1)
+    ref = 1.0 / (1.0 + np.exp(-acc))
+    err = np.abs(out.double().cpu().numpy() - ref)
+    assert err.max() <= 2e-6, err.max()
+    lg = ops._node_gate_logits_from_taps(pd, None, graph, T, B * 2, N).view(T, B, 2, N).permute(0, 2, 1, 3)
+    if bias:
+        lg = lg + bd.view(1, 2, 1, 1)
+    assert float((torch.sigmoid(lg) - out).abs().max()) <= 2e-6
