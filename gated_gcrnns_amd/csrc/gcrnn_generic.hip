@@ -104,12 +104,11 @@ extern "C" int gcrnn_pack_node_major_sum_f32(const void* src, void* dst, int64_t
 // u_k = sum_s parts[item][s][k][:] (the per-chunk tap dots the gate pre-pass stored) run the K - 1 Horner hops  a <- u_k + P a, then bias +
 // sigmoid, written where the node-gated recurrence reads its gates. HBM-bound on the partials (S K N floats per item in, N out), so:
 // persistent workgroups of 512 threads (thread = two nodes) over groups of 4 items, the CSR rows of P copied into LDS once per workgroup (col
-// as u16: N <= 1024; no weights at all for a uniform-weight graph), all S K fetches of a group issued up front (K x 8 accumulators), the
-// running signal of the 4 items in LDS as one float4 per node (one 16-byte gather per CSR entry), and 2-4 workgroups per CU so that one's
-// fetches overlap another's gathers.
+// as u16: N <= 1024; no weights at all for a uniform-weight graph), the fetches of u_k issued one hop ahead of their use, the running signal
+// of the 4 items in LDS as one float4 per node (one 16-byte gather per CSR entry), <= 64 registers so that up to four workgroups share a CU.
 // ------------------------------------------------------------------------------------------
 template <int K, bool UNI>
-__global__ __launch_bounds__(512) void node_gate_filter_kernel(const float* __restrict__ parts, int S, int N, int64_t items, int groups, int64_t B,
+__global__ __launch_bounds__(512, 8) void node_gate_filter_kernel(const float* __restrict__ parts, int S, int N, int64_t items, int groups, int64_t B,
                                                                const int* __restrict__ rowptr, const int* __restrict__ col,
                                                                const float* __restrict__ val, int nnz, float uniform_w,
                                                                const float* __restrict__ bias, int sigmoid, float* __restrict__ out,
@@ -135,39 +134,58 @@ __global__ __launch_bounds__(512) void node_gate_filter_kernel(const float* __re
     j1[r] = on[r] ? rowptr[n + 1] : 0;
   }
   const int64_t kstride = (int64_t)K * N, istride = (int64_t)S * kstride;
-  for (int64_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+  // u_k of group grp for this thread's two rows: S x 8 fetches, no branch around any of them (rows past N and items past the end read a
+  // clamped address and are never stored -- a conditional fetch keeps its wait inside the branch and the fetches run one round trip after
+  // the other). Fetches run ONE hop ahead of their use (and the next group's first signal during the last hop), so that they are in flight
+  // while the rows gather; 16 of them per thread keeps the kernel at <= 64 registers: four workgroups per CU.
+  auto fetch = [&](float (&dst)[2][I], int64_t grp, int k) {
     const int64_t i0 = grp * I;
-    float u[K][2][I];
+    const float* pi[I];
 #pragma unroll
-    for (int k = 0; k < K; ++k)
+    for (int i = 0; i < I; ++i) pi[i] = parts + (i0 + i < items ? i0 + i : items - 1) * istride + (int64_t)k * N;
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+      for (int i = 0; i < I; ++i) dst[r][i] = pi[i][nc[r]];
+    if (S == 2) {
 #pragma unroll
       for (int r = 0; r < 2; ++r)
 #pragma unroll
-        for (int i = 0; i < I; ++i) u[k][r][i] = 0.f;
-    // (no branch around a fetch: rows past N and items past the end read a clamped address and are never stored -- a conditional fetch
-    //  would put its wait inside the branch and run the K S 8 fetches one round trip after the other)
-    const float* pi[I];
-#pragma unroll
-    for (int i = 0; i < I; ++i) pi[i] = parts + (i0 + i < items ? i0 + i : items - 1) * istride;
-    for (int s = 0; s < S; ++s) {
-#pragma unroll
-      for (int k = 0; k < K; ++k)
+        for (int i = 0; i < I; ++i) dst[r][i] += pi[i][kstride + nc[r]];
+    } else {
+      for (int s = 1; s < S; ++s) {
 #pragma unroll
         for (int r = 0; r < 2; ++r)
 #pragma unroll
-          for (int i = 0; i < I; ++i) u[k][r][i] += pi[i][s * kstride + (int64_t)k * N + nc[r]];
+          for (int i = 0; i < I; ++i) dst[r][i] += pi[i][s * kstride + nc[r]];
+      }
     }
+  };
+  float un[2][I];
+  if ((int64_t)blockIdx.x < ngroups) fetch(un, blockIdx.x, K - 1);
+  for (int64_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+    const int64_t i0 = grp * I;
+    const int64_t nxt = grp + gridDim.x < ngroups ? grp + gridDim.x : grp;      // (the last group prefetches itself: harmless)
     float a[2][I];
 #pragma unroll
     for (int r = 0; r < 2; ++r)
 #pragma unroll
-      for (int i = 0; i < I; ++i) a[r][i] = u[K - 1][r][i];
+      for (int i = 0; i < I; ++i) a[r][i] = un[r][i];
+    if (K > 1) fetch(un, grp, K - 2);
+    else fetch(un, nxt, K - 1);
 #pragma unroll
     for (int k = K - 2; k >= 0; --k) {
 #pragma unroll
       for (int r = 0; r < 2; ++r)
         if (on[r]) acc[tid + 512 * r] = make_float4(a[r][0], a[r][1], a[r][2], a[r][3]);
       __syncthreads();      // (the first one of a workgroup also covers the CSR copy)
+      float uk[2][I];
+#pragma unroll
+      for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int i = 0; i < I; ++i) uk[r][i] = un[r][i];
+      if (k > 0) fetch(un, grp, k - 1);
+      else fetch(un, nxt, K - 1);
 #pragma unroll
       for (int r = 0; r < 2; ++r) {
         float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -180,10 +198,10 @@ __global__ __launch_bounds__(512) void node_gate_filter_kernel(const float* __re
           sum.w = fmaf(w, v.w, sum.w);
         }
         const float sc = UNI ? uniform_w : 1.f;
-        a[r][0] = fmaf(sc, sum.x, u[k][r][0]);
-        a[r][1] = fmaf(sc, sum.y, u[k][r][1]);
-        a[r][2] = fmaf(sc, sum.z, u[k][r][2]);
-        a[r][3] = fmaf(sc, sum.w, u[k][r][3]);
+        a[r][0] = fmaf(sc, sum.x, uk[r][0]);
+        a[r][1] = fmaf(sc, sum.y, uk[r][1]);
+        a[r][2] = fmaf(sc, sum.z, uk[r][2]);
+        a[r][3] = fmaf(sc, sum.w, uk[r][3]);
       }
       __syncthreads();
     }
@@ -214,8 +232,8 @@ static int node_gate_filter_launch(const float* parts, float* out, int64_t items
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
     return GCRNN_ERR_LAUNCH;
   const int64_t ngroups = cdiv(items, (int64_t)4);
-  int64_t per_cu = (int64_t)(160 * 1024 / lds);      // workgroups of 8 waves per CU: LDS, and the register file (<= 96 VGPRs) allows 2
-  per_cu = per_cu < 1 ? 1 : (per_cu > 2 ? 2 : per_cu);
+  int64_t per_cu = (int64_t)(160 * 1024 / lds);      // workgroups of 8 waves per CU: LDS, and the register file (<= 64 VGPRs) allows 4
+  per_cu = per_cu < 1 ? 1 : (per_cu > 4 ? 4 : per_cu);
   const int64_t slots = 256 * per_cu;
   const unsigned grid = (unsigned)(ngroups < slots ? ngroups : slots);
   kern<<<dim3(grid), 512, lds, as_stream(stream)>>>(parts, S, N, items, groups, B, rowptr, col, val, nnz, uniform_w, bias, sigmoid, out, ngroups);
