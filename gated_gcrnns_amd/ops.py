@@ -609,7 +609,24 @@ def fused_pack_inputs_gated(X, h0, graph, F, K):
     check(lib.gcrnn_pack_seq_major(_lib.BF16, _p(h0.contiguous()), _p(hs_all), B, 1, F, N, npad, None, st), 'pack_seq')
     check(lib.gcrnn_pack_seq_major_steps(_p(X), _p(xs), B, T, G, N, npad, 0, steps, 0, st), 'pack_seq_steps')
     xs._pending_user = X
+    xs._pending_steps = steps
     return xs, hs_all
+
+
+def _pending_layout_for(xs, consumer_steps):
+    """The user-layout tensor a gate pre-pass should lay out while it runs (fused_pack_inputs_gated), or None. The pending layout was sized
+    for the pre-pass that was expected to run first; when another one runs instead -- it does not lay out at this shape (consumer_steps
+    <= 0), or counts on a different number of leading steps -- the rest of X is laid out here, by the plain pack, and nothing is pending."""
+    x_user = getattr(xs, '_pending_user', None)
+    if x_user is None:
+        return None
+    done = int(getattr(xs, '_pending_steps', 0))
+    if consumer_steps > 0 and consumer_steps == done:
+        return x_user
+    T, B, npad, G = xs.shape
+    check(lib.gcrnn_pack_seq_major_steps(_p(x_user), _p(xs), B, T, G, x_user.shape[3], npad, done, T, 0, _stream()), 'pack_seq_steps')
+    del xs._pending_user
+    return None
 
 
 def fused_overlap_ok(X):
@@ -648,10 +665,12 @@ def fused_time_gate(xs, h0s, wA_g, wB_g, bias_g, lin_w, lin_b, graph, N, store_s
     parts = torch.empty((T * B, (F // 16) * int(lib.gcrnn_fused_step_waves())), dtype=torch.float32, device=xs.device)
     cs = torch.empty((T, B, npad, F), dtype=torch.bfloat16, device=xs.device) if store_states else None
     plan16 = fused_img16_plan(graph, True, None)
-    x_user = getattr(xs, '_pending_user', None)
+    x_user = None
+    if getattr(xs, '_pending_user', None) is not None:
+        lays = int(lib.gcrnn_fused_gate_prepass_lays_out(B, T, N, F, G, K, plan16['entries'], plan.get('uniform_w', 0.0), 1)) if plan16 is not None else 0
+        x_user = _pending_layout_for(xs, lays)
     if x_user is not None:
         # xs holds its first time step(s) only (fused_pack_inputs_gated): this pre-pass lays out the rest
-        assert plan16 is not None
         check(lib.gcrnn_fused_gate_prepass_pack_bf16(_p(x_user), _p(xs), _p(h0s), _p(wp), _p(bg), _p(gw), _p(parts), _p(cs),
                                                      *_fused_graph_args(plan16), B, T, N, F, G, K, _p(hzero), plan.get('uniform_w', 0.0),
                                                      1, st), 'gate_prepass_pack')
@@ -689,7 +708,9 @@ def fused_time_gate_pair(xs, h0s, gate_in, gate_f, graph, N, store_states=False,
     F = gate_in[0].shape[0]
     K = max(gate_in[0].shape[2], gate_in[1].shape[2])
     st = _stream()
-    x_user = getattr(xs, '_pending_user', None)
+    x_user = None
+    if getattr(xs, '_pending_user', None) is not None:
+        x_user = _pending_layout_for(xs, fused_gate_pair_plan(graph, B, T, N, F, G, K, True)[1])
     plan16, _ = fused_gate_pair_plan(graph, B, T, N, F, G, K, x_user is not None)
     assert plan16 is not None
     def prepare():      # everything derived from the gates' parameters alone: cached while they are unchanged (_cached_pack)
@@ -999,7 +1020,10 @@ def fused_node_gate_taps(xs, h0s, wA_g, wB_g, bias_g, wf, graph, N, hzero=None):
     Kt = wf.shape[2]
     plan = graph.fused_plan()
     plan16 = fused_img16_plan(graph, True, None)
-    x_user = getattr(xs, '_pending_user', None)
+    x_user = None
+    if getattr(xs, '_pending_user', None) is not None:
+        lays = int(lib.gcrnn_fused_gate_prepass_lays_out(B, T, N, F, G, K, plan16['entries'], plan.get('uniform_w', 0.0), 1)) if plan16 is not None else 0
+        x_user = _pending_layout_for(xs, lays)
     if plan16 is None or os.environ.get('GCRNN_NO_FUSED_TAPS') or not int(lib.gcrnn_fused_gate_prepass_taps_supported(
             B, T, N, F, G, K, plan16['entries'], plan.get('uniform_w', 0.0), 1, 1 if x_user is not None else 0, Kt)):
         return None
@@ -1044,7 +1068,11 @@ def fused_node_gate_taps_pair(xs, h0s, gate_in, gate_f, graph, N, hzero=None):
     Kt = gate_in[3].shape[2]
     if gate_f[3].shape[2] != Kt or max(gate_f[0].shape[2], gate_f[1].shape[2]) != K or os.environ.get('GCRNN_NO_NODE_GATE_PAIR'):
         return None
-    x_user = getattr(xs, '_pending_user', None)
+    if fused_gate_pair_plan(graph, B, T, N, F, G, K, getattr(xs, '_pending_user', None) is not None)[0] is None:
+        return None
+    x_user = None
+    if getattr(xs, '_pending_user', None) is not None:
+        x_user = _pending_layout_for(xs, fused_gate_pair_plan(graph, B, T, N, F, G, K, True)[1])
     plan16, _ = fused_gate_pair_plan(graph, B, T, N, F, G, K, x_user is not None)
     if plan16 is None:
         return None

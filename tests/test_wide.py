@@ -741,3 +741,51 @@ def test_node_gate_filter_one_pass(N, S_, K, T, B, bias, uniform):
     if bias:
         lg = lg + bd.view(1, 2, 1, 1)
     assert float((torch.sigmoid(lg) - out).abs().max()) <= 2e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('gating', ['node', 'time+node'])
+def test_pending_layout_is_settled_when_another_prepass_runs_first(gating, monkeypatch):
+    """fused_pack_inputs_gated leaves the layout of X to the first gate pre-pass and sizes the laid-out head for the pre-pass it expects
+    (the wide kernel's pair pre-pass). Where another one runs first -- node-gated TRAINING stores the gate cells' states through the
+    16-feature kernel's per-gate pre-pass, which does not lay out at B = 100 -- the rest of X is laid out by the plain pack
+    (ops._pending_layout_for) instead of failing (examples/kstep_prediction.py --nodes 1000 --sparse --dtype bf16: the drivers' batch,
+    kStepPredGRNNs.py:168, one input feature). Results equal the eager layout's (GCRNN_NO_INLINE_PACK=1) bit for bit."""
+    import gated_gcrnns_amd.Utils.graphML as gml
+    N, F, G, K, B, T = 1000, 64, 1, 5, 100, 8
+    dev = torch.device('cuda:0')
+    rng = np.random.default_rng(5)
+    W = (rng.random((N, N)) < 10.0 / N).astype(np.float64)
+    W = np.triu(W, 1); W = W + W.T
+    S = (W / np.max(np.abs(np.linalg.eigvalsh(W)))).reshape(1, N, N)
+    torch.manual_seed(5)
+    cell = gml.GGCRNNCell(G, F, K, K, torch.tanh, gating.startswith('time'), 'node', 1, True)
+    cell.addGSO(torch.tensor(S))
+    cell = cell.to(torch.bfloat16).to(dev)
+    X = torch.tensor(rng.standard_normal((B, T, G, N)), dtype=torch.bfloat16, device=dev)
+    h0 = torch.zeros((B, F, N), dtype=torch.bfloat16, device=dev)
+    tgt = torch.tensor(rng.standard_normal((B, T, F, N)), dtype=torch.bfloat16, device=dev)
+
+    def step():
+        for q in cell.parameters():
+            q.grad = None
+        H = cell(X, h0)
+        (H.float() * tgt.float()).sum().backward()
+        return H.detach().clone(), {k: q.grad.detach().clone() for k, q in cell.named_parameters() if q.grad is not None}
+    from gated_gcrnns_amd import ops
+    calls = []
+    orig = ops.fused_node_cell_train
+    monkeypatch.setattr(ops, 'fused_node_cell_train', lambda *a, **k: (calls.append(1), orig(*a, **k))[1])
+    H1, g1 = step()
+    assert calls, 'the fused node-gated training path was not taken'
+    monkeypatch.setenv('GCRNN_NO_INLINE_PACK', '1')
+    H0, g0 = step()
+    assert torch.isfinite(H1.float()).all() and len(g1) == len(g0) and len(g1) >= 11
+    assert torch.equal(H0, H1)
+    for k in g0:
+        assert torch.equal(g0[k], g1[k]), k
+    with torch.no_grad():      # inference takes the pair pre-pass (which lays out) -- and must agree with the training forward within bf16 noise
+        monkeypatch.delenv('GCRNN_NO_INLINE_PACK')
+        Hi = cell(X, h0)
+    d = (Hi.float() - H1.float()).abs()
+    assert float(d.max()) <= 2.5e-2 and float(d.mean()) <= 1.5e-3, (float(d.max()), float(d.mean()))
