@@ -789,3 +789,17 @@ def test_pending_layout_is_settled_when_another_prepass_runs_first(gating, monke
         Hi = cell(X, h0)
     d = (Hi.float() - H1.float()).abs()
     assert float(d.max()) <= 2.5e-2 and float(d.mean()) <= 1.5e-3, (float(d.max()), float(d.mean()))
+
+
+@pytest.mark.gpu
+def test_dispatch_shape_sweep_quick():
+    """Every gating x {inference, training} x B in {100, 256} x G in {1, 64} x both graph weightings at N = 1000, T = 4 (tools/shape_sweep.py quick):
+    the default dispatch raises nowhere, gives finite results and agrees with round 3's kernels (GCRNN_SEQ32=0, eager layouts) within bf16 noise --
+    the combinations between the parametrised parity tests (the drivers' own B = 100 and one input feature among them, kStepPredGRNNs.py:168)."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location('shape_sweep', os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools', 'shape_sweep.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    n, fails = mod.main(True)
+    assert n >= 60 and not fails, fails
