@@ -803,3 +803,7 @@ def test_dispatch_shape_sweep_quick():
     spec.loader.exec_module(mod)
     n, fails = mod.main(True)
     assert n >= 60 and not fails, fails
+    n, fails = mod.main(True, axes=True)                          # N = 999 (rows that are not 16-byte multiples), K = 3
+    assert n >= 30 and not fails, fails
+    n, fails = mod.sweep_f32(torch.device('cuda:0'), True)      # fp32 cells against the fp64 composed path
+    assert n >= 30 and not fails, fails

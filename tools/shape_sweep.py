@@ -2,7 +2,7 @@
 """Robustness sweep of the GGCRNNCell dispatch on the GPU box: every gating x {inference, training} x batch sizes / channel counts / step counts /
 graph weightings at N = 1000 (sparse SBM), each run once on the default dispatch and once with the wide kernel and the inline layouts switched off
 (GCRNN_SEQ32=0 GCRNN_NO_INLINE_PACK=1): no exception, finite results, and the two within bf16 noise of each other.
-python3 tools/shape_sweep.py [quick]"""
+python3 tools/shape_sweep.py [quick] [axes | f32]"""
 import itertools
 import os
 import sys
@@ -14,7 +14,72 @@ import bench
 import gated_gcrnns_amd.Utils.graphML as gml
 
 
-def main(quick=False):
+def random_graph(N, seed=3):
+    rng = np.random.default_rng(seed)
+    W = (rng.random((N, N)) < min(1.0, 10.0 / N)).astype(np.float64)
+    W = np.triu(W, 1)
+    W = W + W.T
+    return (W / np.max(np.abs(np.linalg.eigvalsh(W)))).reshape(1, N, N)
+
+
+def sweep_f32(dev, quick=False):
+    """fp32 cells (the x3 kernels where they apply, else the composed path) against the fp64 composed path on the same parameters and inputs:
+    H within 2e-5, every gradient within 3e-4 of its max (edge gates: 2e-3; scalars 5e-3)."""
+    import copy
+    N, K = 1000, 5
+    fails, n = [], 0
+    gatings = ((False, None), (True, None), (False, 'node'), (True, 'node'), (False, 'edge'))
+    for gname in ('uniform', 'normalized'):
+        St = torch.tensor(bench.sbm_graph(N, normalized=(gname == 'normalized')))
+        for (tg, sg), F, G, B, train in itertools.product(gatings, (64,) if quick else (32, 64), (1, 64), (100,) if quick else (100, 256), (False, True)):
+            if sg == 'edge' and (gname == 'normalized' or B > 128):
+                continue
+            T = 3
+            tag = 'f32 %s tg=%s sg=%s F=%d G=%d T=%d B=%d %s' % (gname, tg, sg, F, G, T, B, 'train' if train else 'infer')
+            n += 1
+            try:
+                torch.manual_seed(2)
+                cell = gml.GGCRNNCell(G, F, K, K, torch.tanh, tg, sg, 1, True)
+                cell.addGSO(St)
+                cell = cell.float().to(dev)
+                ref = copy.deepcopy(cell).double()
+                X = torch.randn(B, T, G, N, device=dev)
+                h0 = 0.3 * torch.randn(B, F, N, device=dev) if (B % 2) else torch.zeros(B, F, N, device=dev)
+                tgt = torch.randn(B, T, F, N, device=dev)
+
+                def run(c, X, h0, tgt):
+                    if not train:
+                        with torch.no_grad():
+                            return c(X, h0).double(), {}
+                    for q in c.parameters():
+                        q.grad = None
+                    H = c(X, h0)
+                    (H * tgt).sum().backward()
+                    return H.detach().double(), {k: q.grad.detach().double().clone() for k, q in c.named_parameters() if q.grad is not None}
+                H1, g1 = run(cell, X, h0, tgt)
+                Hr, gr = run(ref, X.double(), h0.double(), tgt.double())
+                d = float((H1 - Hr).abs().max())
+                assert d <= 2e-5, 'H differs from fp64: %.3g' % d
+                assert g1.keys() == gr.keys(), 'gradient sets differ'
+                gmax = max([float(v.abs().max()) for v in gr.values()] + [0.0])
+                for k in gr:
+                    sc = max(float(gr[k].abs().max()), 1e-3 * gmax)      # (a parameter whose gradient is tiny beside the others': absolute noise)
+                    dd = float((g1[k] - gr[k]).abs().max())
+                    tol = 5e-3 if g1[k].numel() == 1 else (2e-3 if sg == 'edge' else 3e-4)      # (fp32 sums over B T N (x edges) terms; a scalar's own size is no scale for its noise)
+                    assert dd <= tol * max(sc, 1e-2), 'grad %s differs: %.3g of %.3g' % (k, dd, sc)
+            except Exception as e:      # noqa: BLE001
+                fails.append((tag, repr(e)[:300]))
+                print('FAIL', tag, repr(e)[:300], flush=True)
+                if os.environ.get('SWEEP_TRACE'):
+                    traceback.print_exc()
+    print('shape sweep (f32 vs fp64): %d combinations, %d failures' % (n, len(fails)))
+    for t, e in fails:
+        print('  ', t, e)
+    return n, fails
+
+
+def main(quick=False, axes=False):
+    """axes: the other axes -- K in {2, 3, 4}, N in {104, 400, 999, 1024} (999: rows that are not 16-byte multiples), uniform-weight graphs."""
     dev = torch.device('cuda:0')
     N, K = 1000, 5
     graphs = {'uniform': bench.sbm_graph(N), 'normalized': bench.sbm_graph(N, normalized=True)}
@@ -22,6 +87,26 @@ def main(quick=False):
     Gs = (1, 64) if quick else (1, 32, 64)
     Fs = (64,) if quick else (32, 64)
     Ts = (4,) if quick else (1, 5)
+    if axes:
+        fails, n = [], 0
+        for Nn in ((999,) if quick else (104, 400, 999, 1024)):
+            S1 = random_graph(Nn)
+            for Kk in ((3,) if quick else (2, 3, 4)):
+                n1, f1 = sweep({'uniform N=%d K=%d' % (Nn, Kk): S1}, Nn, Kk, (100, 256), (1, 64), (32, 64), (3,), dev)
+                n += n1
+                fails += f1
+        print('shape sweep (axes): %d combinations, %d failures' % (n, len(fails)))
+        for t, e in fails:
+            print('  ', t, e)
+        return n, fails
+    n, fails = sweep(graphs, N, K, Bs, Gs, Fs, Ts, dev)
+    print('shape sweep: %d combinations, %d failures' % (n, len(fails)))
+    for t, e in fails:
+        print('  ', t, e)
+    return n, fails
+
+
+def sweep(graphs, N, K, Bs, Gs, Fs, Ts, dev):
     gatings = ((False, None), (True, None), (False, 'node'), (True, 'node'), (False, 'edge'))
     SWITCHES = {'GCRNN_SEQ32': '0', 'GCRNN_NO_INLINE_PACK': '1'}
     fails, n = [], 0
@@ -82,11 +167,10 @@ def main(quick=False):
                     traceback.print_exc()
             if n % 50 == 0:
                 print('%d combinations, %d failures' % (n, len(fails)), flush=True)
-    print('shape sweep: %d combinations, %d failures' % (n, len(fails)))
-    for t, e in fails:
-        print('  ', t, e)
     return n, fails
 
 
 if __name__ == '__main__':
-    sys.exit(1 if main(len(sys.argv) > 1 and sys.argv[1] == 'quick')[1] else 0)
+    if 'f32' in sys.argv[1:]:
+        sys.exit(1 if sweep_f32(torch.device('cuda:0'), 'quick' in sys.argv[1:])[1] else 0)
+    sys.exit(1 if main('quick' in sys.argv[1:], 'axes' in sys.argv[1:])[1] else 0)
