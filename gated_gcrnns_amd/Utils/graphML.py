@@ -303,12 +303,17 @@ class GGCRNNCell(nn.Module):
         channel computes tanh(0 + 2 * 0) = 0 at every step and feeds nothing back -- results are those of the F-feature cell. Returns
         (shadow cell with F padded, padded h0) or None when the cell does not need / cannot take that route."""
         Fn = nn.functional
-        if self.graph is None or self.F in (32, 64) or self.F > 64 or self.spatial_gating is not None or self.E != 1:
+        if self.graph is None or self.F in (32, 64) or self.F > 64 or self.spatial_gating not in (None, 'node') or self.E != 1:
             return None
         if self.sigma not in (torch.tanh, Fn.tanh) or X.dtype not in (torch.bfloat16, torch.float32) or h0.dtype != X.dtype:
             return None
         Fp = 32 if self.F <= 32 else 64
-        if X.dtype == torch.float32:
+        if self.spatial_gating == 'node':
+            # node gates (bf16 only: fp32 node-gated cells are the composed path's): the gate cells and their F -> 1 filters pad the same way --
+            # a padded gate-cell channel is tanh(0) = 0 under zero filter taps
+            if X.dtype != torch.bfloat16 or not ops.fused_node_supported(self.graph, self.N, Fp, self.G, self.Kin, self.Kst, X.dtype, self.E):
+                return None
+        elif X.dtype == torch.float32:
             if ops.small_supported(self.N, self.graph.fwd[0].nnz, self.G, self.F, self.Kin, self.Kst, X.dtype, self.E) or \
                     self._wants_grad(X, h0) or self.time_gating == True or \
                     not ops.fused_x3_supported(self.graph, self.N, Fp, self.G, self.Kin, self.Kst, X.dtype, self.E):  # noqa: E712
@@ -319,7 +324,7 @@ class GGCRNNCell(nn.Module):
         if pc is None or pc.F != Fp or pc.graph is not self.graph or pc.weight_A.dtype != self.weight_A.dtype or \
                 pc.weight_A.device != self.weight_A.device:
             with torch.random.fork_rng(devices=[]):          # the shadow's own initialisation must not move the caller's generator
-                pc = GGCRNNCell(self.G, Fp, self.Kin, self.Kst, self.sigma, self.time_gating, None, self.E, self.bias_flag)
+                pc = GGCRNNCell(self.G, Fp, self.Kin, self.Kst, self.sigma, self.time_gating, self.spatial_gating, self.E, self.bias_flag)
                 pc.addGSO(self.graph)
             pc = pc.to(device=self.weight_A.device, dtype=self.weight_A.dtype)
             for q in pc.parameters():
@@ -341,6 +346,8 @@ class GGCRNNCell(nn.Module):
                 p = Fn.pad(p, (0, 0, 0, d))
             elif name.endswith('.0.weight') and tuple(p.shape) == (1, F * N):       # gate read-out Linear(N F -> 1), vec over (f, n)
                 p = Fn.pad(p.view(1, F, N), (0, 0, 0, d)).reshape(1, Fp * N)
+            elif name.endswith('.0.weight') and p.dim() == 4 and p.shape[0] == 1 and p.shape[3] == F:      # node gate's GraphFilter F -> 1: 1 x E x K x F
+                p = Fn.pad(p, (0, d))
             out[name] = p
         return out
 

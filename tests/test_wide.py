@@ -807,3 +807,61 @@ def test_dispatch_shape_sweep_quick():
     assert n >= 30 and not fails, fails
     n, fails = mod.sweep_f32(torch.device('cuda:0'), True)      # fp32 cells against the fp64 composed path
     assert n >= 30 and not fails, fails
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('time_gating', [False, True])
+def test_node_gated_cell_with_the_drivers_state_width(time_gating, monkeypatch):
+    """F = 20 state features (the reference drivers' F1, kStepPredGRNNs.py:220-222) on a node-gated cell: the cell runs on the fused kernels as the
+    same cell with zero-padded state channels (GGCRNNCell._state_padded; the gate cells and their F -> 1 filters pad alike, a padded gate-cell
+    channel is tanh(0) = 0 under zero filter taps) -- against the fp64 oracle in inference, and in training against the fp64 composed path
+    on the same parameters (gradients of the padding are dropped: the F = 20 parameters get theirs)."""
+    import copy
+    import gated_gcrnns_amd.Utils.graphML as gml
+    from gated_gcrnns_amd import ops
+    N, F, G, K, B, T = 1000, 20, 1, 5, 100, 4
+    dev = torch.device('cuda:0')
+    rng = np.random.default_rng(11)
+    W = (rng.random((N, N)) < 10.0 / N).astype(np.float64)
+    W = np.triu(W, 1); W = W + W.T
+    S = (W / np.max(np.abs(np.linalg.eigvalsh(W)))).reshape(1, N, N)
+    torch.manual_seed(11)
+    cell = gml.GGCRNNCell(G, F, K, K, torch.tanh, time_gating, 'node', 1, True)
+    cell.addGSO(torch.tensor(S))
+    cell = cell.float()
+    with torch.no_grad():
+        for q in cell.parameters():
+            q.copy_(torch.tensor(bf16_round(q.detach().numpy())))
+        cell.weight_A.mul_(0.25)      # (one input feature: keep the cell out of the regime where a step doubles bf16 noise, profiles/r04_shape_sweep.txt)
+        cell.weight_A.copy_(torch.tensor(bf16_round(cell.weight_A.numpy())))
+    X = bf16_round(rng.standard_normal((B, T, G, N)))
+    h0 = bf16_round(0.3 * rng.standard_normal((B, F, N)))
+    params = {k: v.detach().double().numpy() for k, v in cell.state_dict().items()}
+    Href = orc.ggcrnn_cell(params, S.astype(np.float32).astype(np.float64), X, h0, time_gating, 'node')
+    ref = copy.deepcopy(cell).double().to(dev)
+    cell = cell.to(torch.bfloat16).to(dev)
+    Xd = torch.tensor(X, dtype=torch.bfloat16, device=dev)
+    hd = torch.tensor(h0, dtype=torch.bfloat16, device=dev)
+    calls = []
+    o1, o2 = ops.fused_node_cell_forward, ops.fused_node_cell_train
+    monkeypatch.setattr(ops, 'fused_node_cell_forward', lambda *a, **k: (calls.append('fwd'), o1(*a, **k))[1])
+    monkeypatch.setattr(ops, 'fused_node_cell_train', lambda *a, **k: (calls.append('train'), o2(*a, **k))[1])
+    with torch.no_grad():
+        H = cell(Xd, hd)
+    assert calls == ['fwd'] and tuple(H.shape) == (B, T, F, N)
+    err = np.abs(H.double().cpu().numpy() - Href)
+    assert err.max() <= 2.5e-2 and err.mean() <= 1.5e-3, (err.max(), err.mean())
+    tgt = torch.tensor(rng.standard_normal((B, T, F, N)), dtype=torch.bfloat16, device=dev)
+    Ht = cell(Xd, hd)
+    (Ht.float() * tgt.float()).sum().backward()
+    assert calls == ['fwd', 'train']
+    Hr = ref(Xd.double(), hd.double())
+    (Hr * tgt.double()).sum().backward()
+    for (k, q), (_, qr) in zip(cell.named_parameters(), ref.named_parameters()):
+        assert (q.grad is None) == (qr.grad is None), k
+        if q.grad is None:
+            continue
+        assert q.grad.shape == q.shape
+        sc = float(qr.grad.abs().max())
+        d = float((q.grad.double() - qr.grad).abs().max())
+        assert d <= (0.3 if q.numel() == 1 else 6e-2) * max(sc, 1e-6), (k, d, sc)
