@@ -810,6 +810,26 @@ def test_dispatch_shape_sweep_quick():
 
 
 @pytest.mark.gpu
+def test_model_sweep_quick():
+    """The two model classes (Modules/architectures.py: regression with oneMlp / multipMlp heads of one and two layers, classification) x every
+    gating x bf16 / f32 x inference / training at N = 1000, F = 20 (the drivers' state width), B = 100, against the same model in fp64
+    (tools/model_sweep.py quick): no exception, finite, outputs and the gradient vector within the dtype's noise."""
+    import importlib.util
+    import os
+    import sys
+    tools = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools')
+    sys.path.insert(0, tools)
+    try:
+        spec = importlib.util.spec_from_file_location('model_sweep', os.path.join(tools, 'model_sweep.py'))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        n, fails = mod.main(True)
+    finally:
+        sys.path.remove(tools)
+    assert n >= 60 and not fails, fails
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('time_gating', [False, True])
 def test_node_gated_cell_with_the_drivers_state_width(time_gating, monkeypatch):
     """F = 20 state features (the reference drivers' F1, kStepPredGRNNs.py:220-222) on a node-gated cell: the cell runs on the fused kernels as the
