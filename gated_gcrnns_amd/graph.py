@@ -498,6 +498,8 @@ def as_operator(S):
         return S
     assert isinstance(S, torch.Tensor), 'GSO must be a torch.Tensor or a GraphOperator'
     assert S.dim() == 3, 'GSO must be E x N x N'
+    if S.is_inference():                   # (made under torch.inference_mode: no version counter to key on -- converted, not cached)
+        return GraphOperator(S, device=S.device)
     key = (S.data_ptr(), tuple(S.shape), tuple(S.stride()), S.storage_offset(), S._version, str(S.device), S.dtype)
     hit = _CACHE.get(key)
     if hit is not None and hit[0] is S:

@@ -417,7 +417,7 @@ def _cached_pack(kind, tensors, extra, st, make):
     tensor's storage pointer, shape, strides, dtype and autograd version counter (every in-place update -- an optimiser step, load_state_dict --
     bumps it), and the entry keeps the tensors alive so that their storage cannot be recycled under the key. Inference loops then issue no
     pack kernels; a training step misses and packs as before. One entry per launch stream. GCRNN_NO_PACK_CACHE=1 switches it off."""
-    if os.environ.get('GCRNN_NO_PACK_CACHE'):
+    if os.environ.get('GCRNN_NO_PACK_CACHE') or any(t.is_inference() for t in tensors):      # (tensors made under torch.inference_mode carry no version counter: temporaries, not parameters)
         return make()
     key = (kind, extra, st.value) + tuple((t.data_ptr(), t._version, tuple(t.shape), tuple(t.stride()), t.dtype) for t in tensors)
     hit = _PACK_CACHE.get(key)

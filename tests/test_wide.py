@@ -885,3 +885,23 @@ def test_node_gated_cell_with_the_drivers_state_width(time_gating, monkeypatch):
         sc = float(qr.grad.abs().max())
         d = float((q.grad.double() - qr.grad).abs().max())
         assert d <= (0.3 if q.numel() == 1 else 6e-2) * max(sc, 1e-6), (k, d, sc)
+
+
+@pytest.mark.gpu
+def test_api_edge_cases():
+    """tools/api_edge_cases.py: non-contiguous X / h0 views, a batch-expanded h0, inputs that want gradients (dX, dh0), B = T = 1,
+    torch.inference_mode (temporaries carry no version counter: the pack cache steps aside), parameters updated in place between two calls --
+    un-gated, time-, node- and edge-gated cells in bf16 and fp32, each against the same cell in fp64."""
+    import importlib.util
+    import os
+    import sys
+    tools = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools')
+    sys.path.insert(0, tools)
+    try:
+        spec = importlib.util.spec_from_file_location('api_edge_cases', os.path.join(tools, 'api_edge_cases.py'))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        n, fails = mod.main()
+    finally:
+        sys.path.remove(tools)
+    assert n >= 48 and not fails, fails
