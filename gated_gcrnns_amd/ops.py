@@ -2720,6 +2720,19 @@ class FusedForwardGraph(object):
         cell.graph.fused_plan()                                   # host-side preparation happens outside the capture
         self._dev = dev
         self._stream = torch.cuda.Stream(device=dev)
+        # the fused forward of THIS cell: node- and edge-gated cells have their own (a runner that replayed the un-gated / time-gated path for them
+        # would compute another cell)
+        with torch.no_grad():
+            if cell.spatial_gating == 'node' and cell._use_fused_node(self.X, self.h0):
+                self._forward = cell._forward_fused_node
+            elif cell.spatial_gating == 'edge' and cell._use_fused_edge(self.X, self.h0):
+                self._forward = cell._forward_fused_edge
+            elif cell.spatial_gating is None and cell._use_fused(self.X, self.h0):
+                self._forward = cell._forward_fused
+            elif cell._state_padded(self.X, self.h0) is not None:
+                self._forward = lambda X_, h0_: cell(X_, h0_)      # (a state width between the kernels': the zero-padded shadow cell, pads captured with it)
+            else:
+                raise ValueError('FusedForwardGraph: this cell / problem does not run on the fused forward kernels (bf16, tanh, N <= 1024, F <= 64)')
         self._capture()
 
     def _capture(self):
@@ -2731,13 +2744,13 @@ class FusedForwardGraph(object):
             s.wait_stream(torch.cuda.current_stream(dev))
             with torch.cuda.stream(s):
                 for _ in range(2):                                # warm-up on the side stream (allocator, func attributes, packed parameters)
-                    cell._forward_fused(self.X, self.h0)
+                    self._forward(self.X, self.h0)
             torch.cuda.current_stream(dev).wait_stream(s)
             self._keep = list(_PACK_CACHE.values())
             self._versions = tuple((p.data_ptr(), p._version) for p in cell.parameters())
             self.graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph, stream=s):
-                self.H = cell._forward_fused(self.X, self.h0)
+                self.H = self._forward(self.X, self.h0)
 
     def __call__(self, X=None, h0=None):
         if X is not None and X.data_ptr() != self.X.data_ptr():

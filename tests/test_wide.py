@@ -905,3 +905,39 @@ def test_api_edge_cases():
     finally:
         sys.path.remove(tools)
     assert n >= 48 and not fails, fails
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('tg,sg,B,F', [(False, 'node', 100, 64), (True, 'node', 256, 64), (False, 'node', 100, 20), (True, None, 100, 20), (False, None, 256, 20),
+                                       (False, 'edge', 16, 64)])
+def test_hipgraph_runner_replays_the_cells_own_forward(tg, sg, B, F):
+    """ops.FusedForwardGraph on node- and edge-gated cells and on cells with the drivers' state width: the captured forward is THAT cell's fused
+    forward (it used to replay the un-gated / time-gated path whatever the cell was) -- bit-identical to the eager call, also after the
+    caller refills X in place; a cell the fused kernels do not take is refused."""
+    import gated_gcrnns_amd.Utils.graphML as gml
+    from gated_gcrnns_amd import ops
+    N, K, T = 1000, 5, 3
+    G = 64 if F == 64 else 1
+    dev = torch.device('cuda:0')
+    rng = np.random.default_rng(9)
+    W = (rng.random((N, N)) < 10.0 / N).astype(np.float64)
+    W = np.triu(W, 1); W = W + W.T
+    S = (W / np.max(np.abs(np.linalg.eigvalsh(W)))).reshape(1, N, N)
+    torch.manual_seed(6)
+    c = gml.GGCRNNCell(G, F, K, K, torch.tanh, tg, sg, 1, True)
+    c.addGSO(torch.tensor(S))
+    c = c.to(torch.bfloat16).to(dev)
+    X = torch.randn(B, T, G, N, device=dev).to(torch.bfloat16)
+    h0 = (0.3 * torch.randn(B, F, N, device=dev)).to(torch.bfloat16)
+    with torch.no_grad():
+        He = c(X, h0)
+        runner = ops.FusedForwardGraph(c, B, T, X=X, h0=h0)
+        assert torch.equal(He, runner())
+        X.copy_(torch.randn(B, T, G, N, device=dev).to(torch.bfloat16))
+        Hg = runner().clone()
+        assert torch.equal(c(X, h0), Hg)
+    relu = gml.GGCRNNCell(G, F, K, K, torch.relu, tg, sg, 1, True)
+    relu.addGSO(torch.tensor(S))
+    relu = relu.to(torch.bfloat16).to(dev)
+    with pytest.raises(ValueError):
+        ops.FusedForwardGraph(relu, B, T)
