@@ -11,6 +11,7 @@ import time
 import numpy as np
 import torch
 
+from .. import ops
 from ..parallel import FlatGradAllReduce, shard_range
 
 
@@ -192,4 +193,5 @@ class GraphedTrainStep(object):
         self.x.copy_(x)
         self.y.copy_(y)
         self.graph.replay()
+        ops.parameters_changed()      # (the replayed optimiser step wrote the parameters without moving their version counters)
         return self.loss.detach(), self.yHat.detach()

@@ -410,6 +410,14 @@ def time_fused_step_kernel(X, h0, wA, wB, bias, graph, reps=3, inline=None, user
 
 
 _PACK_CACHE = {}
+_PARAM_EPOCH = [0]
+
+
+def parameters_changed():
+    """Tell the pack cache that parameters were written through a path PyTorch does not see: a kernel that updates them through raw pointers
+    (optim.FlatAdam's flat Adam step, a replayed hipGraph of a whole training step) leaves their autograd version counters where they were, so the
+    counters alone would let a cached pack of the OLD values answer. Every such writer calls this; the epoch is part of every key."""
+    _PARAM_EPOCH[0] += 1
 
 
 def _cached_pack(kind, tensors, extra, st, make):
@@ -419,7 +427,7 @@ def _cached_pack(kind, tensors, extra, st, make):
     pack kernels; a training step misses and packs as before. One entry per launch stream. GCRNN_NO_PACK_CACHE=1 switches it off."""
     if os.environ.get('GCRNN_NO_PACK_CACHE') or any(t.is_inference() for t in tensors):      # (tensors made under torch.inference_mode carry no version counter: temporaries, not parameters)
         return make()
-    key = (kind, extra, st.value) + tuple((t.data_ptr(), t._version, tuple(t.shape), tuple(t.stride()), t.dtype) for t in tensors)
+    key = (kind, extra, st.value, _PARAM_EPOCH[0]) + tuple((t.data_ptr(), t._version, tuple(t.shape), tuple(t.stride()), t.dtype) for t in tensors)
     hit = _PACK_CACHE.get(key)
     if hit is not None:
         return hit[0]
@@ -2747,7 +2755,7 @@ class FusedForwardGraph(object):
                     self._forward(self.X, self.h0)
             torch.cuda.current_stream(dev).wait_stream(s)
             self._keep = list(_PACK_CACHE.values())
-            self._versions = tuple((p.data_ptr(), p._version) for p in cell.parameters())
+            self._versions = (_PARAM_EPOCH[0],) + tuple((p.data_ptr(), p._version) for p in cell.parameters())
             self.graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph, stream=s):
                 self.H = self._forward(self.X, self.h0)
@@ -2757,7 +2765,7 @@ class FusedForwardGraph(object):
             self.X.copy_(X)
         if h0 is not None and h0.data_ptr() != self.h0.data_ptr():
             self.h0.copy_(h0)
-        if self._versions != tuple((p.data_ptr(), p._version) for p in self.cell.parameters()):
+        if self._versions != (_PARAM_EPOCH[0],) + tuple((p.data_ptr(), p._version) for p in self.cell.parameters()):
             self._capture()                                       # the parameters changed since the capture: their packed forms are stale
         self.graph.replay()
         return self.H

@@ -67,6 +67,8 @@ class FlatAdam(object):
                                                 C.c_void_p(self.v.data_ptr()), self.flat_p.numel(), self.lr, self.betas[0],
                                                 self.betas[1], self.eps, float(grad_scale), C.c_void_p(self.step_dev.data_ptr()), st),
                        'adam_flat')
+            from . import ops
+            ops.parameters_changed()      # (written through raw pointers: the parameters' version counters did not move -- cached packs of the old values must not answer)
             return
         # TEST-ONLY branch (CPU tensors): the same update in torch ops, so that the N > 1 logic around the optimiser (flat buffers,
         # sharded batches, the collective) can run over gloo in a container without a GPU (tests/test_parallel_gloo.py). The product
@@ -79,6 +81,8 @@ class FlatAdam(object):
         self.v.mul_(b2).addcmul_(gs, gs, value=1 - b2)
         denom = (self.v.sqrt() / (1 - b2 ** t) ** 0.5).add_(self.eps)
         self.flat_p.addcdiv_(self.m, denom, value=-self.lr / (1 - b1 ** t))
+        from . import ops
+        ops.parameters_changed()
 
     def state_dict(self):
         return {'flat_p': self.flat_p.clone(), 'm': self.m.clone(), 'v': self.v.clone(), 'step': self.step_dev.clone(),
@@ -87,3 +91,5 @@ class FlatAdam(object):
     def load_state_dict(self, sd):
         self.flat_p.copy_(sd['flat_p']); self.m.copy_(sd['m']); self.v.copy_(sd['v']); self.step_dev.copy_(sd['step'])
         self.lr, self.betas, self.eps = sd['lr'], tuple(sd['betas']), sd['eps']
+        from . import ops
+        ops.parameters_changed()

@@ -941,3 +941,45 @@ def test_hipgraph_runner_replays_the_cells_own_forward(tg, sg, B, F):
     relu = relu.to(torch.bfloat16).to(dev)
     with pytest.raises(ValueError):
         ops.FusedForwardGraph(relu, B, T)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('tg,sg', [(False, None), (True, None), (False, 'node')])
+def test_pack_cache_sees_parameters_written_through_raw_pointers(tg, sg, monkeypatch):
+    """optim.FlatAdam updates the flat parameter buffer with one kernel through raw pointers: the parameters' autograd version counters do not
+    move. The pack cache (ops._cached_pack: packed tap fragments kept while the parameters are unchanged) keys on those counters -- so every
+    such writer bumps ops.parameters_changed(), which is part of every key. After optimiser steps the forward equals the one with the cache
+    switched off (GCRNN_NO_PACK_CACHE=1) bit for bit, eagerly and through the hipGraph runner (which captures again)."""
+    import gated_gcrnns_amd.Utils.graphML as gml
+    from gated_gcrnns_amd import ops
+    from gated_gcrnns_amd.optim import FlatAdam
+    N, K, F, G, B, T = 1000, 5, 64, 64, 256, 3
+    dev = torch.device('cuda:0')
+    rng = np.random.default_rng(9)
+    W = (rng.random((N, N)) < 10.0 / N).astype(np.float64)
+    W = np.triu(W, 1); W = W + W.T
+    S = (W / np.max(np.abs(np.linalg.eigvalsh(W)))).reshape(1, N, N)
+    torch.manual_seed(6)
+    c = gml.GGCRNNCell(G, F, K, K, torch.tanh, tg, sg, 1, True)
+    c.addGSO(torch.tensor(S))
+    c = c.float().to(dev)                                        # fp32 master parameters, bf16 activations
+    X = torch.randn(B, T, G, N, device=dev).to(torch.bfloat16)
+    h0 = torch.zeros(B, F, N, device=dev, dtype=torch.bfloat16)
+    tgt = torch.randn(B, T, F, N, device=dev)
+    opt = FlatAdam(c.parameters(), lr=1e-2)
+    with torch.no_grad():
+        H_before = c(X, h0).clone()
+        runner = ops.FusedForwardGraph(c, B, T, X=X, h0=h0)
+        assert torch.equal(runner(), H_before)
+    for _ in range(2):
+        opt.zero_grad()
+        (c(X, h0).float() * tgt).sum().backward()
+        opt.step()
+    with torch.no_grad():
+        Ha = c(X, h0).clone()
+        Hg = runner().clone()
+        monkeypatch.setenv('GCRNN_NO_PACK_CACHE', '1')
+        Hb = c(X, h0)
+    assert not torch.equal(Ha, H_before), 'the optimiser steps changed nothing'
+    assert torch.equal(Ha, Hb), float((Ha.float() - Hb.float()).abs().max())
+    assert torch.equal(Hg, Hb), float((Hg.float() - Hb.float()).abs().max())
