@@ -1779,7 +1779,9 @@ def _x3_time_gated_forward(X, h0, wA, wB, bias, graph, gates, keep=False, last_o
     npad, st, dev = plan['npad'], _stream(), X.device
     Xp = Xp.float().contiguous()
     h0c = h0.detach().float().contiguous()
-    hzero = not bool(h0c.any())
+    # h0 == 0 (every training loop of the reference, train_rnn.py:256): the gate cells skip the state operand. A host-side read, so not under
+    # stream capture (a captured step takes the general form: same results)
+    hzero = False if torch.cuda.is_current_stream_capturing() else not bool(h0c.any())
     gargs = (_p(plan['tile_slots']), _p(plan['tile_off']), _p(plan['ell_col4']), plan['entries'])
     xs3 = torch.empty((T, 3, B, npad, Gp), dtype=torch.bfloat16, device=dev)
     check(lib.gcrnn_pack_seq_major_x3(_p(Xp), _p(xs3), B, T, Gp, N, npad, st), 'pack_seq_x3')

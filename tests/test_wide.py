@@ -983,3 +983,23 @@ def test_pack_cache_sees_parameters_written_through_raw_pointers(tg, sg, monkeyp
     assert not torch.equal(Ha, H_before), 'the optimiser steps changed nothing'
     assert torch.equal(Ha, Hb), float((Ha.float() - Hb.float()).abs().max())
     assert torch.equal(Hg, Hb), float((Hg.float() - Hb.float()).abs().max())
+
+
+@pytest.mark.gpu
+def test_train_steps_sweep():
+    """tools/train_steps_sweep.py: six optimiser steps (model + batchTimeL1Loss + optimiser, Modules/train_rnn.py:247-281) and an inference forward
+    behind them, every gating x {torch Adam, FlatAdam, FlatAdam inside a replayed GraphedTrainStep} x N in {80, 1000}: the loss trajectory on the
+    default dispatch follows the one with the caches and the wide kernel switched off, and the loss falls (a learnable target)."""
+    import importlib.util
+    import os
+    import sys
+    tools = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools')
+    sys.path.insert(0, tools)
+    try:
+        spec = importlib.util.spec_from_file_location('train_steps_sweep', os.path.join(tools, 'train_steps_sweep.py'))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        n, fails = mod.main()
+    finally:
+        sys.path.remove(tools)
+    assert n >= 50 and not fails, fails
