@@ -13,11 +13,11 @@ GCRNN_STEP_FOR_K2(GCRNN_STEP_DECLARE)
 // ------------------------------------------------------------------------------------------
 template <typename E, bool PACK>
 __global__ __launch_bounds__(256) void seq_layout_kernel(const E* __restrict__ src, E* __restrict__ dst, int B, int Tn,
-                                                         int C, int N, int NPad, const int32_t* __restrict__ perm) {
+                                                         int C, int N, int NPad, const int32_t* __restrict__ perm, int z0 = 0) {
   __shared__ E tile[32][33];
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
   const int n0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
-  const int bt = blockIdx.z, b = bt / Tn, t = bt - b * Tn;
+  const int bt = (int)blockIdx.z + z0, b = bt / Tn, t = bt - b * Tn;      // (z0: launches of at most 65535 items each, the grid's z limit)
   const int64_t ubase = ((int64_t)(b * Tn + t) * C) * N;          // user [C][N] block
   const int64_t sbase = ((int64_t)(t * B + b) * NPad) * C;        // seq-major [NPad][C] block
   if (PACK) {
@@ -56,14 +56,14 @@ __global__ __launch_bounds__(256) void seq_layout_kernel(const E* __restrict__ s
 // in 128-byte segments.
 template <bool PACK>
 __global__ __launch_bounds__(256) void seq_layout16_kernel(const uint16_t* __restrict__ src, uint16_t* __restrict__ dst,
-                                                           int B, int Tn, int C, int N, int NPad, int Cs = 0) {
+                                                           int B, int Tn, int C, int N, int NPad, int Cs = 0, int z0 = 0) {
   // PACK with Cs < C (Cs = channels of the USER tensor, C = channels of the sequence-major one): channels >= Cs are written as
   // zeros -- the reference drivers' G = 1 input (kStepPredGRNNs.py:220) reaches the kernels' 32-channel operand without a padded
   // copy of X in the user layout. Cs = 0: the same channel count on both sides.
   __shared__ uint16_t tile[64][66];
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
   const int n0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
-  const int bt = blockIdx.z, b = bt / Tn, t = bt - b * Tn;
+  const int bt = (int)blockIdx.z + z0, b = bt / Tn, t = bt - b * Tn;
   const int Cu = (PACK && Cs > 0) ? Cs : C;
   const int64_t ubase = ((int64_t)(b * Tn + t) * Cu) * N;
   const int64_t sbase = ((int64_t)(t * B + b) * NPad) * C;
@@ -195,25 +195,27 @@ template <bool PACK>
 static int seq_layout_launch(int dtype, const void* src, void* dst, int64_t B, int64_t T, int64_t C, int64_t N,
                              int64_t NPad, const int32_t* perm, void* stream) {
   if (!src || !dst) return GCRNN_ERR_NULL_POINTER;
-  if (B <= 0 || T <= 0 || C <= 0 || N <= 0 || NPad < N || B * T > 65535 || cdiv(C, 32) > 65535) return GCRNN_ERR_BAD_SHAPE;
+  if (B <= 0 || T <= 0 || C <= 0 || N <= 0 || NPad < N || B * T > 2147483647LL || cdiv(C, 32) > 65535) return GCRNN_ERR_BAD_SHAPE;
+  if (dtype != GCRNN_BF16 && dtype != GCRNN_F32) return GCRNN_ERR_BAD_DTYPE;
   GCRNN_PRE_LAUNCH();
   const bool aligned = ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 3) == 0;
-  if (dtype == GCRNN_BF16 && !perm && (N % 2 == 0) && (C % 2 == 0) && aligned) {
-    dim3 grid((unsigned)cdiv(PACK ? NPad : N, 64), (unsigned)cdiv(C, 64), (unsigned)(B * T));
-    seq_layout16_kernel<PACK><<<grid, 256, 0, as_stream(stream)>>>((const uint16_t*)src, (uint16_t*)dst, (int)B, (int)T,
-                                                                    (int)C, (int)N, (int)NPad);
-    GCRNN_CHECK_LAUNCH();
-    return GCRNN_OK;
+  const bool fast = dtype == GCRNN_BF16 && !perm && (N % 2 == 0) && (C % 2 == 0) && aligned;
+  for (int64_t z0 = 0; z0 < B * T; z0 += 65535) {      // the grid's z extent holds 65535 items: more (B = 2048 at T = 32) run as several launches
+    const unsigned nz = (unsigned)(B * T - z0 < 65535 ? B * T - z0 : 65535);
+    if (fast) {
+      dim3 grid((unsigned)cdiv(PACK ? NPad : N, 64), (unsigned)cdiv(C, 64), nz);
+      seq_layout16_kernel<PACK><<<grid, 256, 0, as_stream(stream)>>>((const uint16_t*)src, (uint16_t*)dst, (int)B, (int)T,
+                                                                      (int)C, (int)N, (int)NPad, 0, (int)z0);
+      continue;
+    }
+    dim3 grid((unsigned)cdiv(PACK ? NPad : N, 32), (unsigned)cdiv(C, 32), nz);
+    if (dtype == GCRNN_BF16)
+      seq_layout_kernel<uint16_t, PACK><<<grid, 256, 0, as_stream(stream)>>>((const uint16_t*)src, (uint16_t*)dst, (int)B,
+                                                                               (int)T, (int)C, (int)N, (int)NPad, perm, (int)z0);
+    else
+      seq_layout_kernel<uint32_t, PACK><<<grid, 256, 0, as_stream(stream)>>>((const uint32_t*)src, (uint32_t*)dst, (int)B,
+                                                                               (int)T, (int)C, (int)N, (int)NPad, perm, (int)z0);
   }
-  dim3 grid((unsigned)cdiv(PACK ? NPad : N, 32), (unsigned)cdiv(C, 32), (unsigned)(B * T));
-  if (dtype == GCRNN_BF16)
-    seq_layout_kernel<uint16_t, PACK><<<grid, 256, 0, as_stream(stream)>>>((const uint16_t*)src, (uint16_t*)dst, (int)B,
-                                                                             (int)T, (int)C, (int)N, (int)NPad, perm);
-  else if (dtype == GCRNN_F32)
-    seq_layout_kernel<uint32_t, PACK><<<grid, 256, 0, as_stream(stream)>>>((const uint32_t*)src, (uint32_t*)dst, (int)B,
-                                                                             (int)T, (int)C, (int)N, (int)NPad, perm);
-  else
-    return GCRNN_ERR_BAD_DTYPE;
   GCRNN_CHECK_LAUNCH();
   return GCRNN_OK;
 }
@@ -228,12 +230,14 @@ extern "C" int gcrnn_pack_seq_major(int dtype, const void* src, void* dst, int64
 extern "C" int gcrnn_pack_seq_major_padded(const void* src, void* dst, int64_t B, int64_t T, int64_t Cs, int64_t C, int64_t N,
                                            int64_t NPad, void* stream) {
   if (!src || !dst) return GCRNN_ERR_NULL_POINTER;
-  if (B <= 0 || T <= 0 || Cs <= 0 || C < Cs || N <= 0 || NPad < N || B * T > 65535 || cdiv(C, 64) > 65535) return GCRNN_ERR_BAD_SHAPE;
+  if (B <= 0 || T <= 0 || Cs <= 0 || C < Cs || N <= 0 || NPad < N || B * T > 2147483647LL || cdiv(C, 64) > 65535) return GCRNN_ERR_BAD_SHAPE;
   if ((N % 2) || (C % 2) || ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 3)) return GCRNN_ERR_UNSUPPORTED;
   GCRNN_PRE_LAUNCH();
-  dim3 grid((unsigned)cdiv(NPad, 64), (unsigned)cdiv(C, 64), (unsigned)(B * T));
-  seq_layout16_kernel<true><<<grid, 256, 0, as_stream(stream)>>>((const uint16_t*)src, (uint16_t*)dst, (int)B, (int)T, (int)C, (int)N,
-                                                                 (int)NPad, (int)Cs);
+  for (int64_t z0 = 0; z0 < B * T; z0 += 65535) {
+    dim3 grid((unsigned)cdiv(NPad, 64), (unsigned)cdiv(C, 64), (unsigned)(B * T - z0 < 65535 ? B * T - z0 : 65535));
+    seq_layout16_kernel<true><<<grid, 256, 0, as_stream(stream)>>>((const uint16_t*)src, (uint16_t*)dst, (int)B, (int)T, (int)C, (int)N,
+                                                                   (int)NPad, (int)Cs, (int)z0);
+  }
   GCRNN_CHECK_LAUNCH();
   return GCRNN_OK;
 }

@@ -2038,6 +2038,21 @@ def fused_backward_weight(dpre, X, H, h0, graph, F, G, K, want_bias=False, gi=No
     h_is_h0: every item's state operand is h0 (gate sub-cells; H may be None).
     With want_bias also returns the bias gradient [F]: sum_{t,b} (gi + gf) sum_n dpre (the one bias enters both filters)."""
     T, B = dpre.shape[0], dpre.shape[1]
+    # the kernel addresses dpre with 32-bit byte offsets: batches whose dpre passes 2 GiB (B = 512 at T = 32, F = 64) run as batch chunks -- sequences
+    # are independent, the chunks' sums add (in chunk order: still bit-reproducible); the chunk of dpre is copied once to make it contiguous
+    lim = (2 ** 31 - 1) // (T * dpre.shape[2] * F * 2)
+    if B > lim >= 1:
+        step = max(256 * (lim // 256), 1) if lim >= 256 else lim
+        dW = dbs = None
+        for b0 in range(0, B, step):
+            b1 = min(B, b0 + step)
+            r = fused_backward_weight(dpre[:, b0:b1].contiguous(), X[b0:b1], H[b0:b1] if H is not None else None, h0[b0:b1], graph, F, G, K, want_bias,
+                                      gi[:, b0:b1].contiguous() if gi is not None else None, gf[:, b0:b1].contiguous() if gf is not None else None, h_is_h0, hzero)
+            w, bsum = r if want_bias else (r, None)
+            dW = w if dW is None else dW + w
+            if want_bias:
+                dbs = bsum if dbs is None else dbs + bsum
+        return (dW, dbs) if want_bias else dW
     plan = graph.fused_plan(adjoint=True, kernel='wgrad')
     slots = int(lib.gcrnn_fused_wgrad_slots(T * B, F))
     dWp = torch.zeros((slots, F, K, F + G), dtype=torch.float32, device=dpre.device)      # per-slot partial sums (plain stores)

@@ -1003,3 +1003,35 @@ def test_train_steps_sweep():
     finally:
         sys.path.remove(tools)
     assert n >= 50 and not fails, fails
+
+
+@pytest.mark.gpu
+def test_batches_past_the_32_bit_offsets_and_the_grid_limit():
+    """B = 512 at T = 32 (N = 1000, F = G = 64): dpre passes 2 GiB, which the weight-gradient kernel's 32-bit offsets do not reach -- the
+    gradient runs as batch chunks (ops.fused_backward_weight) instead of failing mid-backward; state and gradients equal the sum over chunks
+    of 256 sequences (tools/large_batch_check.py runs B up to 2048, all gatings). And the layout kernels take more than 65535 (b, t) items
+    (the grid's z extent: B = 2048 at T = 32) as several launches."""
+    import importlib.util
+    import os
+    import sys
+    from gated_gcrnns_amd import ops, _lib
+    tools = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools')
+    sys.path.insert(0, tools)
+    try:
+        spec = importlib.util.spec_from_file_location('large_batch_check', os.path.join(tools, 'large_batch_check.py'))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        n, fails = mod.main((512,))
+    finally:
+        sys.path.remove(tools)
+    assert n == 6 and not fails, fails
+    dev = torch.device('cuda:0')
+    B, T, C, N, NP = 2200, 30, 2, 16, 32
+    for dt, code in ((torch.bfloat16, _lib.BF16), (torch.float32, _lib.F32)):
+        X = torch.randn(B, T, C, N, device=dev).to(dt)
+        xs = torch.full((T, B, NP, C), 7.0, dtype=dt, device=dev)
+        ops.check(_lib.lib.gcrnn_pack_seq_major(code, ops._p(X), ops._p(xs), B, T, C, N, NP, None, ops._stream()), 'pack_seq')
+        assert torch.equal(xs[:, :, :N], X.permute(1, 0, 3, 2)) and float(xs[:, :, N:].abs().max()) == 0.0
+        back = torch.empty_like(X)
+        ops.check(_lib.lib.gcrnn_unpack_seq_major(code, ops._p(xs), ops._p(back), B, T, C, N, NP, None, ops._stream()), 'unpack_seq')
+        assert torch.equal(back, X)
