@@ -14,7 +14,8 @@ import gated_gcrnns_amd.Utils.graphML as gml
 
 def main(Bs=(512, 1024, 2048)):
     dev = torch.device('cuda:0')
-    N, K, F, G, T = 1000, 5, 64, 64, 32
+    N, K, F, G, T = 1000, 5, 64, 64, int(os.environ.get('T', 32))
+    CH = int(os.environ.get('CHUNK', 256))      # (env T / CHUNK: long sequences, e.g. T=200 CHUNK=64 with B = 128)
     S = torch.tensor(bench.sbm_graph(N))
     fails, n = [], 0
     for (tg, sg) in ((False, None), (True, None), (False, 'node')):
@@ -44,9 +45,9 @@ def main(Bs=(512, 1024, 2048)):
                     Hb, gb = run(X, h0, tgt)
                     gc = {}
                     dmax = 0.0
-                    for i in range(0, B, 256):
-                        Hc, g1 = run(X[i:i + 256].contiguous(), h0[i:i + 256].contiguous(), tgt[i:i + 256].contiguous())
-                        dmax = max(dmax, float((Hc.float() - Hb[i:i + 256].float()).abs().max()))
+                    for i in range(0, B, CH):
+                        Hc, g1 = run(X[i:i + CH].contiguous(), h0[i:i + CH].contiguous(), tgt[i:i + CH].contiguous())
+                        dmax = max(dmax, float((Hc.float() - Hb[i:i + CH].float()).abs().max()))
                         for k, v in g1.items():
                             gc[k] = gc.get(k, 0) + v
                     assert torch.isfinite(Hb.float()).all(), 'non-finite state'
