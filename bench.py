@@ -906,7 +906,8 @@ def run_cfg4(ctx):
     gen = torch.Generator(device=dev); gen.manual_seed(1234 + rank)
     X = torch.randn(B, T, G, N, device=dev, dtype=torch.float64, generator=gen).to(dt)
     h0 = torch.zeros(B, F, N, device=dev, dtype=dt)
-    assert args.mode == 'fwd'
+    if args.mode != 'fwd':
+        raise SystemExit('bench.py: --config cfg4 times the forward only (training steps at the drivers\' sizes: tools/graphed_train_bench.py)')
 
     def step():
         with torch.no_grad():
