@@ -69,6 +69,7 @@ class GraphFilter(nn.Module):
         self.weight.data.uniform_(-stdv, stdv)
         if self.bias is not None:
             self.bias.data.uniform_(-stdv, stdv)
+        ops.parameters_changed()                        # (.data writes do not move the version counters the packed-parameter cache keys on)
 
     def addGSO(self, S):
         graph = as_operator(S)
@@ -140,6 +141,7 @@ class GraphAttentional(nn.Module):
         stdv = 1. / math.sqrt(self.G * self.K)          # reference graphML.py:2069-2073
         self.weight.data.uniform_(-stdv, stdv)
         self.mixer.data.uniform_(-stdv, stdv)
+        ops.parameters_changed()
 
     def addGSO(self, S):
         graph = as_operator(S)
@@ -216,6 +218,7 @@ class GGCRNNCell(nn.Module):
         self.weight_B.data.uniform_(-stdv, stdv)
         if self.bias is not None:
             self.bias.data.uniform_(-stdv, stdv)
+        ops.parameters_changed()                        # (.data writes do not move the version counters the packed-parameter cache keys on)
 
     def _sub_cell(self):
         c = GGCRNNCell(self.G, self.F, self.Kin, self.Kst, self.sigma, time_gating=False, E=self.E, bias=self.bias_flag)

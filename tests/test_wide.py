@@ -1035,3 +1035,31 @@ def test_batches_past_the_32_bit_offsets_and_the_grid_limit():
         back = torch.empty_like(X)
         ops.check(_lib.lib.gcrnn_unpack_seq_major(code, ops._p(xs), ops._p(back), B, T, C, N, NP, None, ops._stream()), 'unpack_seq')
         assert torch.equal(back, X)
+
+
+@pytest.mark.gpu
+def test_reset_parameters_after_a_forward_is_seen(monkeypatch):
+    """The modules re-initialise through `.data.uniform_` like the reference (graphML.py:2229-2235), which moves no version counter: reset_parameters
+    tells the packed-parameter cache (ops.parameters_changed) -- a forward behind it uses the new weights."""
+    import gated_gcrnns_amd.Utils.graphML as gml
+    N, F, G, K, B, T = 1000, 64, 64, 5, 100, 3
+    dev = torch.device('cuda:0')
+    rng = np.random.default_rng(9)
+    W = (rng.random((N, N)) < 10.0 / N).astype(np.float64)
+    W = np.triu(W, 1); W = W + W.T
+    S = (W / np.max(np.abs(np.linalg.eigvalsh(W)))).reshape(1, N, N)
+    torch.manual_seed(6)
+    c = gml.GGCRNNCell(G, F, K, K, torch.tanh, True, None, 1, True)
+    c.addGSO(torch.tensor(S))
+    c = c.to(torch.bfloat16).to(dev)
+    X = torch.randn(B, T, G, N, device=dev).to(torch.bfloat16)
+    h0 = torch.zeros(B, F, N, device=dev, dtype=torch.bfloat16)
+    with torch.no_grad():
+        H1 = c(X, h0).clone()
+        for m in c.modules():
+            if hasattr(m, 'reset_parameters'):
+                m.reset_parameters()
+        H2 = c(X, h0).clone()
+        monkeypatch.setenv('GCRNN_NO_PACK_CACHE', '1')
+        H3 = c(X, h0)
+    assert not torch.equal(H1, H2) and torch.equal(H2, H3)
