@@ -110,6 +110,8 @@ def _graph_attention_node_major(u, mixer, weight, graph, negative_slope=0.2):
     neighbours n of row m; y_n = sum_m Wx_m (S+I)[m, n] alpha[m, n].
     """
     K, E, F, _ = weight.shape
+    if u.dtype == torch.bfloat16:      # (the stand-alone attention kernels are fp32 / fp64: a bf16 layer is evaluated in fp32 and rounded once)
+        return _graph_attention_node_major(u.float(), mixer.float(), weight.float(), graph, negative_slope).to(torch.bfloat16)
     outs = []
     for k in range(K):
         yk = None

@@ -303,6 +303,11 @@ def lsigf_node_major(X, w, bias, graph, bias_scale=1.0):
     require_device(X, w, bias)
     if w.dtype != X.dtype:
         raise GcrnnError('filter taps are %s but the signal is %s' % (w.dtype, X.dtype))
+    if X.dtype == torch.bfloat16:
+        # the any-shape filter kernels are fp32 / fp64 (bf16 lives in the cell's own kernels): a stand-alone bf16 filter is evaluated in fp32 and
+        # rounded once at the end -- differentiable, the casts' backward returns bf16 gradients
+        y = _LSIGF.apply(X.float(), w.float(), bias.float() if bias is not None else None, graph, bias_scale)
+        return y.to(torch.bfloat16)
     return _LSIGF.apply(X, w, bias, graph, bias_scale)
 
 

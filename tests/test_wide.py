@@ -1063,3 +1063,23 @@ def test_reset_parameters_after_a_forward_is_seen(monkeypatch):
         monkeypatch.setenv('GCRNN_NO_PACK_CACHE', '1')
         H3 = c(X, h0)
     assert not torch.equal(H1, H2) and torch.equal(H2, H3)
+
+
+@pytest.mark.gpu
+def test_standalone_layers_sweep_small_graph():
+    """tools/filter_sweep.py at N = 80: GraphFilter / LSIGF (one and two edge features, with and without bias, inputs shorter than N) and
+    GraphAttentional in bf16 and fp32 against the same layer in fp64, outputs and gradients -- a stand-alone bf16 layer is evaluated in fp32 and
+    rounded once (it used to raise: the any-shape filter kernels are fp32 / fp64)."""
+    import importlib.util
+    import os
+    import sys
+    tools = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools')
+    sys.path.insert(0, tools)
+    try:
+        spec = importlib.util.spec_from_file_location('filter_sweep', os.path.join(tools, 'filter_sweep.py'))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        n, fails = mod.main((80,))
+    finally:
+        sys.path.remove(tools)
+    assert n >= 250 and not fails, fails
