@@ -86,6 +86,50 @@ def sweep_f32(dev, quick=False, N=1000, Bs=None):
     return n, fails
 
 
+def sweep_bf16_large(dev, Ns=(1500, 2048)):
+    """bf16 cells on graphs beyond the LDS-resident kernels (streaming / composed path), every gating, against the same cell in fp64:
+    H within 6e-2, the gradient vector within 10 % in the L2 norm."""
+    import copy
+    K, B, T = 5, 20, 3
+    fails, n = [], 0
+    for N in Ns:
+        S = torch.tensor(random_graph(N, seed=4))
+        for (tg, sg), (F, G), train in itertools.product(((False, None), (True, None), (False, 'node'), (True, 'node'), (False, 'edge')),
+                                                         ((64, 64), (20, 1), (32, 32)), (False, True)):
+            tag = 'bf16 N=%d tg=%s sg=%s F=%d G=%d %s' % (N, tg, sg, F, G, 'train' if train else 'infer')
+            n += 1
+            try:
+                torch.manual_seed(2)
+                c = gml.GGCRNNCell(G, F, K, K, torch.tanh, tg, sg, 1, True)
+                c.addGSO(S)
+                with torch.no_grad():
+                    c.weight_A.mul_(0.25 if G == 1 else 1.0)
+                c = c.to(torch.bfloat16).to(dev)
+                r = copy.deepcopy(c).double()
+                X = torch.randn(B, T, G, N, device=dev).to(torch.bfloat16)
+                h0 = (0.3 * torch.randn(B, F, N, device=dev)).to(torch.bfloat16)
+                if train:
+                    H = c(X, h0)
+                    H.float().sum().backward()
+                    Hr = r(X.double(), h0.double())
+                    Hr.sum().backward()
+                    num = sum(float(((p.grad.double() - q.grad) ** 2).sum()) for p, q in zip(c.parameters(), r.parameters()) if q.grad is not None) ** 0.5
+                    den = sum(float((q.grad ** 2).sum()) for q in r.parameters() if q.grad is not None) ** 0.5
+                    assert num <= 0.1 * den, 'gradient differs: %.3g of %.3g (L2)' % (num, den)
+                else:
+                    with torch.no_grad():
+                        H, Hr = c(X, h0), r(X.double(), h0.double())
+                d = float((H.double() - Hr).abs().max())
+                assert d <= 6e-2, 'H differs: %.3g' % d
+            except Exception as e:      # noqa: BLE001
+                fails.append((tag, repr(e)[:300]))
+                print('FAIL', tag, repr(e)[:300], flush=True)
+                if os.environ.get('SWEEP_TRACE'):
+                    traceback.print_exc()
+    print('shape sweep (bf16 vs fp64, N = %s): %d combinations, %d failures' % ('/'.join(str(x) for x in Ns), n, len(fails)))
+    return n, fails
+
+
 def main(quick=False, axes=False):
     """axes: the other axes -- K in {2, 3, 4}, N in {104, 400, 999, 1024} (999: rows that are not 16-byte multiples), uniform-weight graphs."""
     dev = torch.device('cuda:0')
@@ -182,6 +226,6 @@ if __name__ == '__main__':
     if 'f32' in sys.argv[1:]:
         sys.exit(1 if sweep_f32(torch.device('cuda:0'), 'quick' in sys.argv[1:])[1] else 0)
     if 'large' in sys.argv[1:]:      # graphs beyond the LDS-resident kernels (streaming / composed path)
-        bad = sweep_f32(torch.device('cuda:0'), False, 1500, (20,))[1] + sweep_f32(torch.device('cuda:0'), False, 2048, (20,))[1]
+        bad = sweep_f32(torch.device('cuda:0'), False, 1500, (20,))[1] + sweep_f32(torch.device('cuda:0'), False, 2048, (20,))[1] + sweep_bf16_large(torch.device('cuda:0'))[1]
         sys.exit(1 if bad else 0)
     sys.exit(1 if main('quick' in sys.argv[1:], 'axes' in sys.argv[1:])[1] else 0)
