@@ -18,7 +18,7 @@ def main(Bs=(512, 1024, 2048)):
     CH = int(os.environ.get('CHUNK', 256))      # (env T / CHUNK: long sequences, e.g. T=200 CHUNK=64 with B = 128)
     S = torch.tensor(bench.sbm_graph(N))
     fails, n = [], 0
-    for (tg, sg) in ((False, None), (True, None), (False, 'node')):
+    for (tg, sg) in (((False, 'edge'),) if os.environ.get('EDGE') else ((False, None), (True, None), (False, 'node'))):      # (env EDGE=1: the edge-gated cell alone)
         torch.manual_seed(3)
         cell = gml.GGCRNNCell(G, F, K, K, torch.tanh, tg, sg, 1, True)
         cell.addGSO(S)
