@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """API edge cases of GGCRNNCell on the GPU box, each against the same cell in fp64: non-contiguous X / h0 views, inputs that want gradients
-(dX, dh0), B = 1, T = 1, torch.inference_mode, parameters updated in place between calls.   python3 tools/api_edge_cases.py"""
+(dX, dh0), B = 1, T = 1, torch.inference_mode, parameters updated in place between calls, last_only.   python3 tools/api_edge_cases.py"""
 import copy
 import os
 import sys
@@ -18,7 +18,7 @@ def main():
     fails, n = [], 0
     for (tg, sg) in ((False, None), (True, None), (False, 'node'), (False, 'edge')):
         for dt in (torch.bfloat16, torch.float32):
-            for case in ('noncontig', 'wants_dx', 'b1t1', 'inference_mode', 'inplace_update', 'expanded_h0'):
+            for case in ('noncontig', 'wants_dx', 'b1t1', 'inference_mode', 'inplace_update', 'expanded_h0', 'last_only'):
                 F, G = 64, 64
                 B, T = (1, 1) if case == 'b1t1' else ((8, 3) if sg == 'edge' else (100, 3))
                 tag = 'tg=%s sg=%s %s %s' % (tg, sg, str(dt).split('.')[1], case)
@@ -51,6 +51,12 @@ def main():
                             sc = float(b.abs().max())
                             d = float((a.double() - b).abs().max())
                             assert d <= (8e-2 if dt == torch.bfloat16 else 1e-4) * sc, '%s differs: %.3g of %.3g' % (nm, d, sc)
+                    elif case == 'last_only':      # the classification model's call: B x 1 x F x N, the last state of the full forward
+                        with torch.no_grad():
+                            H = c_last = cell(X, h0, last_only=True)
+                            Hr = ref(X.double(), h0.double())[:, -1:]
+                            assert tuple(c_last.shape) == (B, 1, F, N)
+                            assert float((c_last.double() - cell(X, h0)[:, -1:].double()).abs().max()) <= (4e-3 if dt == torch.bfloat16 else 1e-6), 'last_only differs from the full forward'
                     elif case == 'inference_mode':
                         with torch.inference_mode():
                             H = cell(X, h0)
