@@ -279,7 +279,7 @@ def timed_steps(ctx, step):
     sync()
     if dist_on:
         # the collectives of the timing protocol itself, once, outside the timed region: RCCL sets up a communicator's channels and
-        # loads its kernels on first use (seen on a cold box: one 40-60 ms stall inside a 5-step window, tools/dist_cold_probe.py)
+        # loads its kernels on first use (seen on a cold box: one 40-60 ms stall inside a 5-step window, tools/experiments/dist_cold_probe.py)
         tw = torch.zeros(1, device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(tw, op=torch.distributed.ReduceOp.MAX)
         sync()
@@ -475,6 +475,12 @@ def run_cfg2(ctx):
                            'mfma_util_note': 'taps GEMM flops executed per launch / duration / 2.5 PF dense bf16 peak'
                                              + (' (PMC: SQ_VALU_MFMA_BUSY_CYCLES %.3g per launch)' % tj['mfma_busy_cycles'] if tj and 'mfma_busy_cycles' in tj else ''),
                            'whole_step_GBps': achieved, 'device_ms_per_step': 1e3 * step_s}
+        if tj:
+            # the PMC figures are NOT counted in this run (bench.py cannot run under rocprofv3's counter passes): they are replayed from a tracked
+            # file, counted on the tree named inside it
+            out['roofline']['traffic_source'] = {'file': 'profiles/' + tname, 'counted_on_tree': tj.get('counted_on_tree'), 'counted_by': tj.get('source'),
+                                                 'note': 'PMC counters (FETCH_SIZE x 2 + WRITE_SIZE, SQ_VALU_MFMA_BUSY_CYCLES) collected in separate rocprofv3 --pmc passes and '
+                                                         'REPLAYED from the tracked file; not measured in this run'}
         out['roofline']['hop_state_image'] = ('bf16 rows, neighbour rows summed on the matrix cores (one-hot A operand; uniform-weight graph)'
                                               if ops.fused_img16_plan(cell.graph, False, None) is not None else 'fp32 rows, packed VALU sums')
         if kern.get('inline_pack'):

@@ -146,52 +146,83 @@ def MultipleModels(modelsDict, xTrain, yTrain, xValid, yValid, nEpochs, batchSiz
 
 
 class GraphedTrainStep(object):
-    """One optimiser step (zero_grad -> forward -> loss -> BPTT -> Adam) captured as a hipGraph and replayed.
+    """One optimiser step (zero_grad -> forward -> loss -> BPTT -> [flat gradient all-reduce] -> Adam) captured as hipGraphs and replayed.
 
     The reference's training configurations (N = 50..80 nodes, T = 5..20, batch 100; kStepPredGRNNs.py:110-127) are
     launch-bound on a GPU: a step is several hundred tiny kernels. Capturing the whole step removes the per-launch host
     cost. Inputs are copied into static buffers; the optimiser is optim.FlatAdam (one kernel over the flat buffers, device step
     counter: capturable as it is) or torch.optim.Adam created with capturable=True.
 
+    One process (`sync=None`): ONE graph holds the whole step. Batch-sharded over several ranks (`sync` = the parallel.FlatGradAllReduce whose
+    views are the parameters' `.grad`, `optim.sync` for FlatAdam): TWO graphs -- [zero_grad, forward, loss, BPTT] and [optimiser step] -- with the
+    ONE flat all-reduce between them, issued eagerly on the replay stream (the collective's position is the reference's
+    `loss.backward()` -> `optim.step()`, Modules/train_rnn.py:273-276; a collective inside a captured graph would tie the graph to one
+    communicator state). `weight` = local batch / global batch of this rank (default 1 / world). On a CPU device (the gloo tests) nothing can
+    be captured: the same two segments run eagerly, so the N > 1 logic -- what is reduced, when, with which weight -- is the code under test.
+
         step = GraphedTrainStep(archit, loss_fn, optim, x_example, y_example, stateFeat)
-        loss = step(x, y)        # x, y: B x T x 1 x N on the device, same shapes as the examples
+        loss, yHat = step(x, y)        # x, y: B x T x 1 x N on the device, same shapes as the examples
     """
 
-    def __init__(self, archit, loss_fn, optim, x, y, stateFeat, sync=None):
+    def __init__(self, archit, loss_fn, optim, x, y, stateFeat, sync=None, weight=None):
         self.x = x.clone()
         self.y = y.clone()
         self.archit, self.loss_fn, self.optim = archit, loss_fn, optim
+        self.sync, self.weight = sync, weight
         B, N = x.shape[0], x.shape[3]
         self.h0 = torch.zeros(B, stateFeat, N, dtype=x.dtype, device=x.device)
-        assert sync is None, 'capture the single-GPU step; the flat all-reduce stays outside the graph'
+        self.flat = hasattr(self.optim, 'sync')          # optim.FlatAdam: gradients are views of one flat buffer, step counter on the device
+        assert sync is None or self.flat and sync is self.optim.sync or not self.flat, 'FlatAdam reduces its own flat buffer: pass sync=optim.sync'
+        self.captured = x.device.type == 'cuda'
+        if not self.captured:
+            self.graph = self.graph_step = None
+            return
         s = torch.cuda.Stream(device=x.device)
         s.wait_stream(torch.cuda.current_stream(x.device))
         with torch.cuda.stream(s):
-            for _ in range(3):                                   # warm-up: allocator, lazily created optimiser state
+            for _ in range(3):                                   # warm-up: allocator, lazily created optimiser state, the communicator
                 self._eager()
         torch.cuda.current_stream(x.device).wait_stream(s)
         self.graph = torch.cuda.CUDAGraph()
-        self.flat = hasattr(self.optim, 'sync')          # optim.FlatAdam: gradients are views of one flat buffer, step counter on the device
         if not self.flat:
             self.optim.zero_grad(set_to_none=True)
         with torch.cuda.graph(self.graph):
-            if self.flat:
-                self.optim.zero_grad()                   # one memset node; backward accumulates into the views in place
-            self.yHat = self.archit(self.x, self.h0)
-            self.loss = self.loss_fn(self.yHat, self.y)
-            self.loss.backward()
-            self.optim.step()
+            self._segment_backward(first_capture=not self.flat)
+            if sync is None:
+                self.optim.step()
+        self.graph_step = None
+        if sync is not None:
+            self.graph_step = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph_step):
+                self.optim.step()
+
+    def _segment_backward(self, first_capture=False):
+        if self.flat:
+            self.optim.zero_grad()                   # one memset node; backward accumulates into the views in place
+        elif self.sync is not None:
+            self.sync.zero_grad()
+        elif not first_capture:
+            self.optim.zero_grad(set_to_none=True)
+        self.yHat = self.archit(self.x, self.h0)
+        self.loss = self.loss_fn(self.yHat, self.y)
+        self.loss.backward()
 
     def _eager(self):
-        self.optim.zero_grad(set_to_none=True)
-        loss = self.loss_fn(self.archit(self.x, self.h0), self.y)
-        loss.backward()
+        self._segment_backward()
+        if self.sync is not None:
+            self.sync.all_reduce_(self.weight)
         self.optim.step()
-        return loss
+        return self.loss
 
     def __call__(self, x, y):
         self.x.copy_(x)
         self.y.copy_(y)
-        self.graph.replay()
+        if not self.captured:
+            self._eager()
+        else:
+            self.graph.replay()
+            if self.graph_step is not None:
+                self.sync.all_reduce_(self.weight)       # between the two graphs, on the replay stream (stream order: behind graph 1, in front of graph 2)
+                self.graph_step.replay()
         ops.parameters_changed()      # (the replayed optimiser step wrote the parameters without moving their version counters)
         return self.loss.detach(), self.yHat.detach()

@@ -416,21 +416,53 @@ def time_fused_step_kernel(X, h0, wA, wB, bias, graph, reps=3, inline=None, user
 
 _PACK_CACHE = {}
 _PARAM_EPOCH = [0]
+_PACK_CACHE_ON = [bool(os.environ.get('GCRNN_PACK_CACHE'))]
 
 
 def parameters_changed():
-    """Tell the pack cache that parameters were written through a path PyTorch does not see: a kernel that updates them through raw pointers
-    (optim.FlatAdam's flat Adam step, a replayed hipGraph of a whole training step) leaves their autograd version counters where they were, so the
-    counters alone would let a cached pack of the OLD values answer. Every such writer calls this; the epoch is part of every key."""
+    """Tell the (opt-in) pack cache that parameters were written through a path PyTorch does not see: a kernel that updates them through raw
+    pointers (optim.FlatAdam's flat Adam step, a replayed hipGraph of a whole training step) leaves their autograd version counters where they
+    were. Every such writer calls this; the epoch is part of every key. Without `freeze_parameters()` nothing is cached and this is a no-op."""
     _PARAM_EPOCH[0] += 1
 
 
+def freeze_parameters(on=True):
+    """Opt in to (or out of) keeping the PACKED forms of parameters -- tap fragments, the fp32 bias, concatenated gate weights -- between
+    forwards. The default is OFF: every forward packs from the live parameters (three ~5 us kernels, ~1 % of a forward at the bench size), so
+    ANY write PyTorch permits is seen by the next forward -- including `p.data.mul_(2)`, `p.data.copy_(t)` and `dist.broadcast(p.data, 0)`,
+    which move no version counter the host could key on (the reference's own `reset_parameters`, Utils/graphML.py:2229-2235, writes that way).
+    With the cache on the caller promises not to write parameters through `.data` or raw pointers without calling `parameters_changed()`;
+    in-place updates under `torch.no_grad()`, `copy_`, `load_state_dict` and tensor swaps are still detected (storage pointer + version
+    counter in the key). GCRNN_PACK_CACHE=1 in the environment switches it on from the start. Returns the previous setting."""
+    prev = _PACK_CACHE_ON[0]
+    _PACK_CACHE_ON[0] = bool(on)
+    if not on:
+        _PACK_CACHE.clear()
+    return prev
+
+
+class frozen_parameters(object):
+    """`with ops.frozen_parameters(): ...` -- freeze_parameters(True) for the block (an inference loop over fixed weights)."""
+
+    def __enter__(self):
+        self._prev = freeze_parameters(True)
+        return self
+
+    def __exit__(self, *exc):
+        freeze_parameters(self._prev)
+        return False
+
+
 def _cached_pack(kind, tensors, extra, st, make):
-    """Packed forms of PARAMETERS (tap fragments, the fp32 bias) are kept between calls while the parameters are unchanged: the key holds each
-    tensor's storage pointer, shape, strides, dtype and autograd version counter (every in-place update -- an optimiser step, load_state_dict --
-    bumps it), and the entry keeps the tensors alive so that their storage cannot be recycled under the key. Inference loops then issue no
-    pack kernels; a training step misses and packs as before. One entry per launch stream. GCRNN_NO_PACK_CACHE=1 switches it off."""
-    if os.environ.get('GCRNN_NO_PACK_CACHE') or any(t.is_inference() for t in tensors):      # (tensors made under torch.inference_mode carry no version counter: temporaries, not parameters)
+    """Packed forms of PARAMETERS (tap fragments, the fp32 bias). DEFAULT: made on every call from the live parameters -- correct for every
+    way PyTorch lets a parameter be written (see freeze_parameters). With `freeze_parameters()` / GCRNN_PACK_CACHE=1 they are kept between
+    calls while the parameters are unchanged: the key holds each tensor's storage pointer, shape, strides, dtype and autograd version counter
+    plus the parameter epoch, and the entry keeps the tensors alive so that their storage cannot be recycled under the key. Never during a
+    stream capture: a miss there would store a buffer whose pack kernel was only RECORDED, and a second capture of the same cell would hit it
+    and record no pack at all (its replays would read memory another graph fills) -- every captured graph packs for itself, so its replays
+    always see the live weights. Temporaries made under torch.inference_mode (no version counter) are never cached."""
+    if (not _PACK_CACHE_ON[0] or os.environ.get('GCRNN_NO_PACK_CACHE') or torch.cuda.is_current_stream_capturing()
+            or any(t.is_inference() for t in tensors)):
         return make()
     key = (kind, extra, st.value, _PARAM_EPOCH[0]) + tuple((t.data_ptr(), t._version, tuple(t.shape), tuple(t.stride()), t.dtype) for t in tensors)
     hit = _PACK_CACHE.get(key)
@@ -2766,18 +2798,18 @@ class FusedForwardGraph(object):
         self._capture()
 
     def _capture(self):
-        """Warm-up and capture on ONE side stream: the packed parameters (ops._cached_pack, keyed by the launch stream) are made by the
-        warm-up and found by the capture, so the graph holds the layout kernels and the main kernel only. The graph then reads those cached
-        buffers: they are kept alive here, and a parameter update (autograd version counters) makes the next call capture again."""
+        """Warm-up and capture on ONE side stream. The capture records the parameter packs too (ops._cached_pack never answers from its cache
+        during a capture), so every replay packs from the LIVE parameters: in-place updates, optimiser steps through raw pointers and `.data`
+        writes are all seen without capturing again. Only a parameter whose STORAGE was replaced (`p.data = t`, `.to(...)`) needs a new capture:
+        the graph holds the old pointers."""
         cell, dev, s = self.cell, self._dev, self._stream
         with torch.no_grad():
             s.wait_stream(torch.cuda.current_stream(dev))
             with torch.cuda.stream(s):
-                for _ in range(2):                                # warm-up on the side stream (allocator, func attributes, packed parameters)
+                for _ in range(2):                                # warm-up on the side stream (allocator, func attributes)
                     self._forward(self.X, self.h0)
             torch.cuda.current_stream(dev).wait_stream(s)
-            self._keep = list(_PACK_CACHE.values())
-            self._versions = (_PARAM_EPOCH[0],) + tuple((p.data_ptr(), p._version) for p in cell.parameters())
+            self._ptrs = tuple((p.data_ptr(), p.dtype, tuple(p.shape)) for p in cell.parameters())
             self.graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph, stream=s):
                 self.H = self._forward(self.X, self.h0)
@@ -2787,7 +2819,7 @@ class FusedForwardGraph(object):
             self.X.copy_(X)
         if h0 is not None and h0.data_ptr() != self.h0.data_ptr():
             self.h0.copy_(h0)
-        if self._versions != (_PARAM_EPOCH[0],) + tuple((p.data_ptr(), p._version) for p in self.cell.parameters()):
-            self._capture()                                       # the parameters changed since the capture: their packed forms are stale
+        if self._ptrs != tuple((p.data_ptr(), p.dtype, tuple(p.shape)) for p in self.cell.parameters()):
+            self._capture()                                       # a parameter's storage was replaced: the graph holds the old pointer
         self.graph.replay()
         return self.H

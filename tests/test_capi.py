@@ -128,7 +128,7 @@ def test_fused_kernels_are_spill_free():
     """The hop gather stream is one asm block (gcrnn_hop_asm.inc): no asm LDS read is in flight across compiler-scheduled code any
     more, so a spill can no longer capture a register before its data has landed -- it only costs time. (The compiler-scheduled
     macro streams of round 1 -- GCRNN_HOP_ASM=0 or GCRNN_STEP_WAVES != 8 -- are diagnostic builds only: gcrnn_fused_step.h refuses to
-    compile them without -DGCRNN_DIAGNOSTIC_STREAMS, see tools/hop_asm_ab.sh.) The fused kernels sit at
+    compile them without -DGCRNN_DIAGNOSTIC_STREAMS, see tools/experiments/hop_asm_ab.sh.) The fused kernels sit at
     the 256-register budget of two waves per SIMD: enforce that no instantiation spills more than a few registers (two K = 5
     gate pre-pass instantiations spill 8 / 24 bytes per lane outside the stream), at build time (hipcc cross-compiles)."""
     import subprocess

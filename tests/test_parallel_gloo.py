@@ -237,3 +237,51 @@ def test_zero_grad_drops_gradients_that_live_outside_the_flat_buffer():
             sync.all_reduce_(0.5)
         finally:
             dist.destroy_process_group()
+
+
+def graphed_worker(rank, world, port, ret):
+    """train_rnn.GraphedTrainStep with a flat-gradient sync: segment 1 = zero_grad / forward / loss / BPTT, the ONE flat
+    all-reduce with this rank's shard weight, segment 2 = the optimiser step. On a GPU the two segments are two captured hipGraphs with the
+    collective between them; here (CPU, gloo) they run eagerly through the SAME class, so what is reduced, where and with which weight is
+    the code under test: unequal shards (4 + 3) reproduce torch.optim.Adam on the whole batch, step after step, and replicas stay identical."""
+    from gated_gcrnns_amd.Modules.train_rnn import GraphedTrainStep
+    from gated_gcrnns_amd.optim import FlatAdam
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    N, T, Bg = 6, 3, 7
+    gen = torch.Generator().manual_seed(4)
+    x = torch.randn(Bg, T, 1, N, dtype=torch.float64, generator=gen)
+    y = torch.randn(Bg, T, 1, N, dtype=torch.float64, generator=gen)
+    torch.manual_seed(5)
+    model, ref = TinyGCRNN(N), TinyGCRNN(N)
+    ref.load_state_dict(model.state_dict())
+    ropt = torch.optim.Adam(ref.parameters(), lr=1e-2)
+    opt = FlatAdam(model.parameters(), lr=1e-2)
+    lo, hi = shard_range(Bg, rank, world)
+    l1 = torch.nn.functional.l1_loss
+    step = GraphedTrainStep(model, l1, opt, x[lo:hi], y[lo:hi], 2, sync=opt.sync, weight=(hi - lo) / float(Bg))
+    assert not step.captured and step.graph is None          # CPU: the two segments run eagerly
+    ok = True
+    for it in range(4):
+        ropt.zero_grad()
+        l1(ref(x, torch.zeros(Bg, 2, N, dtype=torch.float64)), y).backward()
+        ropt.step()
+        loss, yhat = step(x[lo:hi] + 0.0, y[lo:hi] + 0.0)     # (fresh tensors: the step copies them into its static buffers)
+        ok &= bool(torch.allclose(model.stateGCRNN.weight_A, ref.stateGCRNN.weight_A, atol=1e-12, rtol=0))
+        ok &= tuple(yhat.shape) == (hi - lo, T, 1, N)
+    mine = model.stateGCRNN.weight_A.detach().reshape(-1).clone()
+    gathered = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(gathered, mine)
+    ok &= all(torch.equal(t, gathered[0]) for t in gathered)
+    ret[rank] = bool(ok)
+    dist.destroy_process_group()
+
+
+def test_graphed_train_step_world2_allreduce_between_the_two_segments():
+    world = 2
+    port = free_port()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(graphed_worker, args=(world, port, ret), nprocs=world, join=True)
+    assert all(ret[r] for r in range(world)), dict(ret)

@@ -89,3 +89,34 @@ def test_graphed_training_step_with_flat_adam_matches_eager():
     for p, q in zip(ms[0].parameters(), ms[1].parameters()):
         assert torch.equal(p, q)
     assert int(opt_g.step_dev.item()) == 8
+
+
+@pytest.mark.gpu
+def test_graphed_training_step_as_two_graphs_around_the_flat_allreduce():
+    """The multi-rank form of GraphedTrainStep (sync = the optimiser's flat gradient buffer): [zero_grad, forward, loss, BPTT] and [FlatAdam step]
+    captured as TWO hipGraphs, the one flat all-reduce issued between their replays (no process group here: the collective itself is skipped,
+    the scaling and the stream order are not). Losses and parameters equal the ONE-graph form bit for bit over several replays."""
+    import gated_gcrnns_amd.Modules.architectures as archit
+    from gated_gcrnns_amd.Modules.train_rnn import GraphedTrainStep
+    from gated_gcrnns_amd.Utils.miscTools import batchTimeL1Loss
+    from gated_gcrnns_amd.optim import FlatAdam
+    g = load_golden('g6_trace_GCRNNMLP')
+    dev = torch.device('cuda:0')
+    x = torch.tensor(g['x'], device=dev)
+    y = torch.tensor(g['y'], device=dev)
+    ms = []
+    for _ in range(2):
+        m = archit.GatedGCRNNforRegression(1, 20, 3, 3, torch.tanh, torch.nn.ReLU, [1], g['S'][0], True,
+                                           time_gating=False, spatial_gating=None, mlpType='multipMlp').double()
+        m.load_state_dict({k: torch.tensor(v) for k, v in g['params0'].items()})
+        ms.append(m.to(dev))
+    opt_1, opt_2 = FlatAdam(ms[0].parameters(), lr=1e-3), FlatAdam(ms[1].parameters(), lr=1e-3)
+    one = GraphedTrainStep(ms[0], batchTimeL1Loss, opt_1, x, y, 20)
+    two = GraphedTrainStep(ms[1], batchTimeL1Loss, opt_2, x, y, 20, sync=opt_2.sync)
+    assert one.graph_step is None and two.graph_step is not None
+    for it in range(5):
+        l1, _ = one(x, y)
+        l2, _ = two(x, y)
+        assert float(l1) == float(l2), it
+    for p, q in zip(ms[0].parameters(), ms[1].parameters()):
+        assert torch.equal(p, q)

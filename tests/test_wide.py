@@ -11,14 +11,14 @@ def bf16_round(a):
     return torch.tensor(a, dtype=torch.float32).to(torch.bfloat16).double().numpy()
 
 
-def _uniform_cell(N, G, F, K, seed):
+def _uniform_cell(N, G, F, K, seed, time_gating=False):
     import gated_gcrnns_amd.Utils.graphML as gml
     rng = np.random.default_rng(seed)
     W = (rng.random((N, N)) < 10.0 / N).astype(np.float64)
     W = np.triu(W, 1); W = W + W.T
     S = (W / np.max(np.abs(np.linalg.eigvalsh(W)))).reshape(1, N, N)
     torch.manual_seed(seed)
-    cell = gml.GGCRNNCell(G, F, K, K, torch.tanh, False, None, 1, True)
+    cell = gml.GGCRNNCell(G, F, K, K, torch.tanh, time_gating, None, 1, True)
     cell.addGSO(torch.tensor(S))
     return cell.to(torch.bfloat16), rng, S
 
@@ -478,10 +478,90 @@ def test_wide_bptt_chain_split_sequences_are_bit_identical_to_the_persistent_for
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('tg', [False, True])
+def test_forward_sees_every_parameter_write_pytorch_permits(tg):
+    """the DEFAULT must be correct for any write PyTorch permits. `p.data.mul_()`, `p.data.copy_()` and a
+    `dist.broadcast(p.data, 0)`-style write (a kernel filling the parameter's storage through a `.data` alias) move no version counter the host
+    can see; the reference's own reset_parameters writes that way (Utils/graphML.py:2229-2235). Without calling ops.parameters_changed(), the
+    next forward -- eager, and a replay of a hipGraph captured BEFORE the write -- must use the new values: each equals a fresh cell built from
+    the written state_dict, bit for bit."""
+    import copy
+    from gated_gcrnns_amd import ops
+    dev = torch.device('cuda:0')
+    N, G, F, K, B, T = 1000, 64, 64, 5, 130, 2
+    cell, rng, S = _uniform_cell(N, G, F, K, 83, time_gating=tg)
+    cell = cell.to(dev)
+    X = torch.tensor(rng.standard_normal((B, T, G, N)), dtype=torch.float32, device=dev).to(torch.bfloat16)
+    h0 = torch.tensor(0.3 * rng.standard_normal((B, F, N)), dtype=torch.float32, device=dev).to(torch.bfloat16)
+    assert not ops._PACK_CACHE_ON[0], 'the pack cache is opt-in'
+
+    def fresh():      # an independent cell holding the same values (nothing shared with `cell`, no cache could connect them)
+        c2 = copy.deepcopy(cell)
+        with torch.no_grad():
+            return c2(X, h0).clone()
+
+    with torch.no_grad():
+        H0 = cell(X, h0).clone()
+        runner = ops.FusedForwardGraph(cell, B, T, X=X, h0=h0)
+        assert torch.equal(runner(), H0)
+        writes = [lambda: cell.weight_B.data.mul_(0.5),
+                  lambda: cell.weight_A.data.copy_(0.7 * cell.weight_A.data),
+                  lambda: cell.bias.data.fill_(0.125),
+                  lambda: torch.nn.init.uniform_(cell.weight_B.data, -0.05, 0.05)]      # (what dist.broadcast(p.data, 0) does: a kernel writes the alias)
+        if tg:
+            writes.append(lambda: cell.GFL_in.weight_A.data.mul_(-1.0))
+            writes.append(lambda: cell.MLP_forget[0].weight.data.mul_(3.0))
+        prev = H0
+        for w in writes:
+            w()
+            He = cell(X, h0).clone()
+            Hg = runner().clone()
+            want = fresh()
+            assert not torch.equal(He, prev), 'the write changed nothing'
+            assert torch.equal(He, want) and torch.equal(Hg, want)
+            prev = He
+
+
+@pytest.mark.gpu
+def test_two_captures_of_one_cell_each_pack_for_themselves():
+    """two user captures of the same cell back to back (one graph per batch size, say), a parameter update, then ONLY the second graph
+    replayed: it must see the new weights. (A pack cache answering during the second capture would record no pack kernel there.) Run with the
+    cache switched ON -- the case the advisor describes -- and with the default."""
+    from gated_gcrnns_amd import ops
+    dev = torch.device('cuda:0')
+    N, G, F, K, B, T = 1000, 64, 64, 5, 130, 2
+    cell, rng, S = _uniform_cell(N, G, F, K, 84)
+    cell = cell.to(dev)
+    X = torch.tensor(rng.standard_normal((B, T, G, N)), dtype=torch.float32, device=dev).to(torch.bfloat16)
+    h0 = torch.tensor(0.3 * rng.standard_normal((B, F, N)), dtype=torch.float32, device=dev).to(torch.bfloat16)
+    for frozen in (True, False):
+        prev = ops.freeze_parameters(frozen)
+        try:
+            with torch.no_grad():
+                cell(X, h0)                                        # (warm-up; with the cache on this fills it)
+                s = torch.cuda.Stream(device=dev)
+                s.wait_stream(torch.cuda.current_stream(dev))
+                g1, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g1, stream=s):
+                    H1 = cell(X, h0)
+                with torch.cuda.graph(g2, stream=s):
+                    H2 = cell(X, h0)
+                cell.weight_B.mul_(0.5)
+                g2.replay()
+                torch.cuda.synchronize()
+                want = cell(X, h0)
+                assert torch.equal(H2, want), float((H2.float() - want.float()).abs().max())
+                del g1, g2, H1, H2
+        finally:
+            ops.freeze_parameters(prev)
+
+
+@pytest.mark.gpu
 def test_packed_parameter_cache_follows_in_place_updates(monkeypatch):
-    """ops._cached_pack keeps the packed taps / the fp32 bias between forwards while the parameters are unchanged (inference loops issue no
-    pack kernels). Every way a parameter changes -- an in-place update (optimiser step), copy_ (load_state_dict), a new tensor behind .data --
-    must miss: the outputs equal those of a run with the cache switched off, bit for bit."""
+    """The OPT-IN cache (ops.freeze_parameters / GCRNN_PACK_CACHE=1) keeps the packed taps / the fp32 bias between forwards while the parameters
+    are unchanged (inference loops issue no pack kernels). Every way a parameter changes that the host can see -- an in-place update (optimiser
+    step), copy_ (load_state_dict), a new tensor behind .data -- must miss: the outputs equal those of a run with the cache switched off, bit
+    for bit. By default nothing is cached."""
     from gated_gcrnns_amd import ops
     dev = torch.device('cuda:0')
     N, G, F, K, B, T = 1000, 64, 64, 5, 130, 2
@@ -489,6 +569,11 @@ def test_packed_parameter_cache_follows_in_place_updates(monkeypatch):
     cell = cell.to(dev)
     X = torch.tensor(rng.standard_normal((B, T, G, N)), dtype=torch.float32, device=dev).to(torch.bfloat16)
     h0 = torch.tensor(0.3 * rng.standard_normal((B, F, N)), dtype=torch.float32, device=dev).to(torch.bfloat16)
+    ops._PACK_CACHE.clear()
+    with torch.no_grad():
+        cell(X, h0)
+    assert len(ops._PACK_CACHE) == 0                               # default: every forward packs from the live parameters
+    monkeypatch.setattr(ops, '_PACK_CACHE_ON', [True])
 
     def both():
         with torch.no_grad():
@@ -953,6 +1038,7 @@ def test_pack_cache_sees_parameters_written_through_raw_pointers(tg, sg, monkeyp
     import gated_gcrnns_amd.Utils.graphML as gml
     from gated_gcrnns_amd import ops
     from gated_gcrnns_amd.optim import FlatAdam
+    monkeypatch.setattr(ops, '_PACK_CACHE_ON', [True])           # (the opt-in cache: with the default nothing is cached)
     N, K, F, G, B, T = 1000, 5, 64, 64, 256, 3
     dev = torch.device('cuda:0')
     rng = np.random.default_rng(9)
@@ -1042,6 +1128,8 @@ def test_reset_parameters_after_a_forward_is_seen(monkeypatch):
     """The modules re-initialise through `.data.uniform_` like the reference (graphML.py:2229-2235), which moves no version counter: reset_parameters
     tells the packed-parameter cache (ops.parameters_changed) -- a forward behind it uses the new weights."""
     import gated_gcrnns_amd.Utils.graphML as gml
+    from gated_gcrnns_amd import ops
+    monkeypatch.setattr(ops, '_PACK_CACHE_ON', [True])           # (the opt-in cache: with the default nothing is cached)
     N, F, G, K, B, T = 1000, 64, 64, 5, 100, 3
     dev = torch.device('cuda:0')
     rng = np.random.default_rng(9)
