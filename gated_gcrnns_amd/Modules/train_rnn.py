@@ -209,6 +209,13 @@ class GraphedTrainStep(object):
 
     def _eager(self):
         self._segment_backward()
+        if self.captured:
+            # (warm-up only) The gradients are persistent views of the flat buffer, so every backward ends in AccumulateGrad nodes that ADD
+            # in place -- on the stream their accumulators were created on (the default stream: "AccumulateGrad node's stream does not match"),
+            # not on the warm-up's side stream. The optimiser step issued on the side stream must not overtake them: without this wait a
+            # warm-up step could read the gradient buffer before the accumulation had run (seen in round 5 as a loss trajectory that
+            # started from two effective warm-up steps in one run and three in the next, tools/train_steps_sweep.py).
+            torch.cuda.synchronize(self.x.device)
         if self.sync is not None:
             self.sync.all_reduce_(self.weight)
         self.optim.step()

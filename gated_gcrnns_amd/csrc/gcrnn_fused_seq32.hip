@@ -80,6 +80,14 @@ static bool seq32_wanted(int64_t B) {
   return rounds_seq * 0.62 * 4 < rounds_chunk;
 }
 
+// The un-gated persistent forward on a uniform-weight graph runs the kernel with the hand-allocated hop (round 5, gcrnn_fused_seq32p.h:
+// tap MFMAs inside the gather stream, the next operand requested during the last hop); GCRNN_SEQ32P=0 keeps round 4's kernel (same-box A/B)
+int gcrnn_seq32p_forward(const Seq32Args& sa, int K, int HS, int XS, bool inline_pack, size_t lds, hipStream_t st);
+static bool seq32p_wanted() {
+  const char* e = getenv("GCRNN_SEQ32P");
+  return !(e && e[0] == '0');
+}
+
 template <int K, int HS, int XS>
 static size_t seq32_lds(int64_t entries, bool inline_pack, bool r1 = false) { return Seq32Map<K, HS, XS>::lds_bytes(entries, inline_pack, r1); }
 
@@ -189,6 +197,7 @@ static int seq32_launch(const Seq32Args& sa, bool inline_pack, hipStream_t st, b
     if (sa.a1) return seq32_launch_v<K, HS, XS, 2, 0, true>(sa, lds, st);
     return seq32_launch_v<K, HS, XS, 0, 0, true>(sa, lds, st);
   }
+  if (seq32p_wanted()) return gcrnn_seq32p_forward(sa, K, HS, XS, inline_pack, lds, st);      // the hand-allocated hop (gcrnn_fused_seq32p.h)
   const int var = (inline_pack ? 1 : 0) | (sa.a1 ? 2 : 0);
   switch (var) {
     case 0: return seq32_launch_v<K, HS, XS, 0>(sa, lds, st);

@@ -540,6 +540,180 @@ def gen_wide32():
     return L
 
 
+# ---- round 5: the WHOLE hop of the wide kernel as one hand-allocated block: gather stream + the hop's tap MFMAs + (last hop of a step) the
+# next step's operand requests (gcrnn_fused_seq32p.h). Round 4's stamps: a wave ran stream THEN taps (or taps then stream), so the LDS
+# array idled at both ends of every hop, and the step boundary's 192 KB of operand requests (170-190 of ~1,100 units per step) could not
+# start before the last tap had read the old operand. Here every register is pinned ("{v[a:b]}" constraints on 32-register tuples):
+#   v[0:127]   operand: k-step s, tile i = v[32 s + 4 i .. + 3]          (B fragments of the tap MFMAs)
+#   v[128:191] accumulators: half h, tile i = v[128 + 32 h + 4 i .. + 3]  (D of the stream's v_smfmac AND of the taps)
+#   v[192:253] the block's own: sparse A operand (4) + index + scratch | two gather sets (32) | column words (2) | pointer, address |
+#              two weight-fragment buffers (8) | tile node ids (8) | column base, q << 4, fragment base, 16 q
+# Tap MFMAs: the hop's 2 KS weight fragments (h, s) are issued one per TILE EXIT of the stream (8 exits per wave and hop, each passed exactly
+# once whatever the trip counts): exit e reads fragment e + 1 from LDS, issues fragment e's 8 MFMAs (one per tile; the tile the stream has
+# just left LAST, the one it enters next FIRST) while the next tile's first gathers are in flight, then waits for everything it has issued.
+# Fragments are ordered k-step-major, input k-steps first, the state k-step that is handed over in registers last: in the LAST hop of a step
+# k-step s of the operand is dead behind the exit that issues its half-1 fragment, and the requests of the NEXT step's k-step s (8
+# buffer_load_dwordx4 per wave, straight into the operand registers) follow it, `lpe` per exit -- dribbled through the stream instead of
+# 24 per wave at once in the epilogue (a wave blocked issuing loads issues nothing else).
+# Operands: %0 %1 = accumulator tuples (in/out); loads variant: %2 .. = the KS operand tuples (in/out); then the scalars: 8 tile ends, first
+# group, last valid group, LDS address of the column image, LDS address of the hop's tap in the weight fragments; loads variant: buffer
+# resources of h_t / x_{t+1} (128-bit scalars), their sequence offsets, LDS address of this wave's slot table (8 tiles x 16 words). Plain
+# variant: the KS operand tuples follow as inputs (never named by number: every vector register is named by its pinned position).
+P_A0, P_IDX, P_TMP, P_UB = 192, 196, 197, 198
+P_VCW0, P_VP, P_VA, P_WF0, P_ND0, P_VCB, P_QX, P_WFB, P_Q16 = 230, 232, 233, 234, 242, 250, 251, 252, 253
+
+
+def frag_order(HS, XS):
+    ks = list(range(HS, HS + XS)) + list(range(0, HS - 1)) + [HS - 1]
+    return [(s_, h) for s_ in ks for h in (0, 1)]
+
+
+def gen_wide32_taps(HS, XS, loads=False, lpe=4, fpe=1):
+    D, KS = 2, HS + XS
+    FO = frag_order(HS, XS)
+    NF = len(FO)
+    assert NF <= NT * fpe
+    A0, IDX, TMP, UB = P_A0, P_IDX, P_TMP, P_UB
+    VCw = lambda p: 'v%d' % (P_VCW0 + p)
+    VP, VA = 'v%d' % P_VP, 'v%d' % P_VA
+    WF = lambda e: P_WF0 + 4 * (e & 1)
+    ND = lambda i: 'v%d' % (P_ND0 + i)
+    VCB, QX, WFB, Q16 = 'v%d' % P_VCB, 'v%d' % P_QX, 'v%d' % P_WFB, 'v%d' % P_Q16
+    OP = lambda s_, i: 32 * s_ + 4 * i
+    ACC = lambda h, i: 128 + 32 * h + 4 * i
+    SGr, STr, SCr = 's88', 's89', 's90'
+    SB = 2 + KS if loads else 2          # first scalar operand: behind the in/out tuples (plain variant: the operand tuples are inputs, listed last)
+    TE = SB
+    GB, GL, COLS, WOFS = ('%%%d' % (SB + 8 + n) for n in range(4))
+    RH, RX, SOH, SOX, SLOT = ('%%%d' % (SB + 12 + n) for n in range(5))
+    Y = lambda p, e: UB + 16 * p + 4 * e
+    Xr = lambda p, e: UB + 16 * p + 8 + 4 * e
+    tup = lambda b: 'v[%d:%d]' % (b, b + 3)
+    foff = lambda f: (FO[f][1] * KS + FO[f][0]) * 1024
+
+    def col_clamped(p, goff, L):
+        L += ['s_add_i32 %s, %s, %d' % (STr, SGr, goff), 's_min_i32 %s, %s, %s' % (STr, STr, GL),
+              'v_lshl_add_u32 %s, %s, 7, %s' % (VA, STr, VCB), 'ds_read_b32 %s, %s' % (VCw(p), VA)]
+
+    def gathers(q, L):
+        for e in range(2):
+            L.append('v_xor_b32_sdwa v%d, %s, %s dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_%d src1_sel:DWORD' % (Xr(q, e), VCw(q), QX, e))
+        for e in range(2):
+            L.append('ds_read_b128 %s, v%d offset:%d' % (tup(Y(q, e)), Xr(q, e), WIDE_PLANE))
+        for e in range(2):
+            L.append('ds_read_b128 %s, v%d' % (tup(Xr(q, e)), Xr(q, e)))
+
+    L = ['s_mov_b32 %s, %s' % (SGr, GB)]
+    # lane id -> q << 4 (the half a lane gathers), 16 q, fragment base, this lane's column dword
+    L += ['v_mbcnt_lo_u32_b32 v%d, -1, 0' % TMP, 'v_mbcnt_hi_u32_b32 v%d, -1, v%d' % (TMP, TMP),
+          'v_lshrrev_b32 %s, 4, v%d' % (VA, TMP),
+          'v_and_b32 %s, 1, %s' % (QX, VA), 'v_lshlrev_b32 %s, 4, %s' % (QX, QX),
+          'v_lshlrev_b32 %s, 4, %s' % (Q16, VA),
+          'v_lshlrev_b32 %s, 4, v%d' % (WFB, TMP), 'v_add_u32 %s, %s, %s' % (WFB, WOFS, WFB),
+          'v_lshrrev_b32 %s, 1, %s' % (VA, VA), 'v_lshlrev_b32 %s, 2, %s' % (VA, VA),
+          'v_and_b32 %s, 15, v%d' % (VP, TMP),
+          'v_lshl_add_u32 %s, %s, 3, %s' % (VCB, VP, VA), 'v_add_u32 %s, %s, %s' % (VCB, COLS, VCB)]
+    if loads:
+        L += ['v_lshlrev_b32 %s, 2, %s' % (VA, VP), 'v_add_u32 %s, %s, %s' % (VA, SLOT, VA)]
+        for i in range(NT):
+            L.append('ds_read_b32 %s, %s offset:%d' % (ND(i), VA, 64 * i))
+    for p in range(D):
+        col_clamped(p, p, L)
+    # the compressed one-hot A operand of v_smfmac (one non-zero per lane: group (lane & 15) >> 2, position lane & 3) and its index register
+    L += ['v_and_b32 v%d, 15, v%d' % (TMP, TMP),
+          'v_and_b32 v%d, 3, v%d' % (IDX, TMP),
+          'v_lshrrev_b32 v%d, 2, v%d' % (TMP, TMP),
+          'v_cmp_eq_u32 vcc, 3, v%d' % IDX,
+          'v_or_b32 v%d, 12, v%d' % (IDX, IDX),
+          'v_cndmask_b32 v%d, v%d, 12, vcc' % (IDX, IDX),
+          'v_mov_b32 v%d, 0x3f80' % (A0 + 3),
+          'v_mov_b32 v%d, 0x3f800000' % (A0 + 2),
+          'v_cndmask_b32 v%d, v%d, v%d, vcc' % (A0 + 3, A0 + 3, A0 + 2),
+          'v_xor_b32 v%d, 4, v%d' % (IDX, IDX),
+          'v_lshlrev_b32 v%d, 2, v%d' % (A0 + 2, TMP),
+          'v_lshlrev_b32 v%d, v%d, v%d' % (IDX, A0 + 2, IDX),
+          'v_xor_b32 v%d, 0x4444, v%d' % (IDX, IDX),
+          'v_mov_b32 v%d, v%d' % (A0 + 2, A0 + 3)]
+    for g in (3, 1, 0):
+        L += ['v_cmp_eq_u32 vcc, %d, v%d' % (g, TMP), 'v_cndmask_b32 v%d, 0, v%d, vcc' % (A0 + g, A0 + 2)]
+    L += ['v_cmp_eq_u32 vcc, 2, v%d' % TMP, 'v_cndmask_b32 v%d, 0, v%d, vcc' % (A0 + 2, A0 + 2)]
+    L.append('ds_read_b128 %s, %s offset:%d' % (tup(WF(0)), WFB, foff(0)))
+    L.append('s_waitcnt lgkmcnt(0)')
+    if loads:
+        for i in range(NT):
+            L.append('v_lshrrev_b32 %s, 16, %s' % (ND(i), ND(i)))
+    for p in range(D - 1):
+        gathers(p, L); col_clamped(p, D + p, L)
+    L += ['s_add_i32 %s, %s, %d' % (STr, SGr, 2 * D - 1), 'v_lshl_add_u32 %s, %s, 7, %s' % (VP, STr, VCB)]
+    L += ['s_sub_u32 %s, %s, %%%d' % (SCr, GB, TE), 's_cmp_eq_u32 %s, 0' % SCr]
+    R = 2
+    Aop, Iop = 'v[%d:%d]' % (A0, A0 + 3), 'v%d' % IDX
+
+    # the operand requests of the loads variant, in the order their registers die
+    queue = []          # (exit behind which the k-step is dead, k-step, tile)
+    for f, (s_, h) in enumerate(FO):
+        if h == 1 and s_ != HS - 1:
+            queue += [(f // fpe, s_, i) for i in range(NT)]
+    if not loads:
+        queue = []
+    nloads = len(queue)
+
+    def burst(t, L, pending):
+        """tile exit t: fragments t*fpe .. of the hop's taps, the next fragment's read, operand requests"""
+        for f in range(t * fpe, min((t + 1) * fpe, NF)):
+            if f + 1 < NF:
+                L.append('ds_read_b128 %s, %s offset:%d' % (tup(WF(f + 1)), WFB, foff(f + 1)))
+            s_, h = FO[f]
+            for i in [(t + 1 + d) % NT for d in range(NT)]:
+                L.append('v_mfma_f32_16x16x32_bf16 %s, %s, %s, %s' % (tup(ACC(h, i)), tup(WF(f)), tup(OP(s_, i)), tup(ACC(h, i))))
+            if f + 1 < NF:
+                L.append('s_waitcnt lgkmcnt(0)')
+        if loads:
+            n = 0
+            while pending and pending[0][0] <= t and (n < lpe or t == NT - 1):
+                _, s_, i = pending.pop(0)
+                row_log2 = {1: 6, 2: 7}[HS if s_ < HS else XS]
+                L.append('v_lshl_add_u32 v%d, %s, %d, %s' % (TMP, ND(i), row_log2, Q16))
+                if s_ < HS:
+                    L.append('buffer_load_dwordx4 %s, v%d, %s, %s offen offset:%d' % (tup(OP(s_, i)), TMP, RH, SOH, 64 * s_))
+                else:
+                    L.append('buffer_load_dwordx4 %s, v%d, %s, %s offen offset:%d' % (tup(OP(s_, i)), TMP, RX, SOX, 64 * (s_ - HS)))
+                n += 1
+
+    exits = []
+    pend = list(queue)
+    for t in range(NT):
+        ex = []
+        burst(t, ex, pend)
+        exits.append(ex)
+    assert not pend
+    for t in range(NT):
+        for pp in range(D * R):
+            p = pp % D
+            q = (p + D - 1) % D
+            L.append('L_T%d_P%d_%%=:' % (t, pp))
+            L.append('s_cbranch_scc1 L_X%d_P%d_%%=' % (t, p))
+            L.append('s_add_u32 %s, %s, 1' % (SCr, SCr))
+            gathers(q, L)
+            L += ['ds_read_b32 %s, %s' % (VCw(q), VP), 'v_add_u32 %s, 128, %s' % (VP, VP)]
+            L.append('s_waitcnt lgkmcnt(%d)' % (5 * (D - 1)))
+            L.append('v_smfmac_f32_16x16x64_bf16 %s, %s, v[%d:%d], %s' % (tup(ACC(1, t)), Aop, Y(p, 0), Y(p, 0) + 7, Iop))
+            L.append('v_smfmac_f32_16x16x64_bf16 %s, %s, v[%d:%d], %s' % (tup(ACC(0, t)), Aop, Xr(p, 0), Xr(p, 0) + 7, Iop))
+        L.append('s_branch L_T%d_P0_%%=' % t)
+        for p in range(D):
+            L.append('L_X%d_P%d_%%=:' % (t, p))
+            L += exits[t]
+            if t + 1 < NT:
+                L += ['s_sub_u32 %s, %%%d, %%%d' % (SCr, TE + t, TE + t + 1), 's_cmp_eq_u32 %s, 0' % SCr]
+            L.append('s_branch L_T%d_P%d_%%=' % (t + 1, p))
+    for p in range(D):
+        L.append('L_T%d_P%d_%%=:' % (NT, p))
+    L += ['s_nop 15', 's_nop 7', 's_waitcnt lgkmcnt(0)']
+    # this wave's LDS-DMA pieces (issued in front of the block) have landed: everything but the operand requests behind them
+    L.append('s_waitcnt vmcnt(%d)' % (nloads if loads else 0))
+    return L, nloads
+
+
 def emit(name, lines):
     print('#define %s \\' % name)
     for ln in lines:
@@ -568,6 +742,13 @@ def main():
     emit('GCRNN_HOP_ASM_UNI16_SUMS_SPARSE_TEXT_B', gen_uniform16(sparse=True, sums=True, img_off=IMAGE_B_OFFSET))
     emit('GCRNN_HOP_ASM_WIDE32_TEXT', gen_wide32())
     print('#define GCRNN_HOP_WIDE_PLANE %d' % WIDE_PLANE)
+    lpe, fpe = int(os.environ.get('GCRNN_P_LPE', '4')), int(os.environ.get('GCRNN_P_FPE', '1'))
+    for (hs, xs) in ((2, 2), (2, 1), (1, 1)):
+        emit('GCRNN_HOP_ASM_P32_TEXT_%d_%d' % (hs, xs), gen_wide32_taps(hs, xs)[0])
+        ll, nl = gen_wide32_taps(hs, xs, loads=True, lpe=lpe, fpe=fpe)
+        emit('GCRNN_HOP_ASM_P32_LOADS_TEXT_%d_%d' % (hs, xs), ll)
+        print('#define GCRNN_HOP_ASM_P32_NLOADS_%d_%d %d' % (hs, xs, nl))
+    print('#define GCRNN_HOP_ASM_P32_CLOBBERS %s, "s88", "s89", "s90", "scc", "vcc", "memory"' % ', '.join('"v%d"' % r for r in range(192, 254)))
     print('#define GCRNN_HOP_ASM_WIDE32_CLOBBERS %s, "s88", "s89", "s90", "scc", "vcc", "memory"' % ', '.join('"v%d"' % r for r in range(WIDE_BASE, 254)))
     regs = ', '.join('"v%d"' % r for r in range(UB, UB + 60))
     print('#define GCRNN_HOP_ASM_UNI_CLOBBERS %s, "s88", "s89", "s90", "scc", "memory"' % regs)
