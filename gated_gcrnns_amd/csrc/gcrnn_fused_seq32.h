@@ -51,7 +51,10 @@ static __device__ __forceinline__ unsigned long long gcrnn_stamp32_get(uint32_t 
     __syncthreads();                                                                                          \
     if (threadIdx.x < 96 && blockIdx.x < 256) gcrnn_seq32_stamps[blockIdx.x * 96 + threadIdx.x] = gcrnn_stamp32_get((uint32_t)reinterpret_cast<uintptr_t>(smem) + M::FLAG_OFF + 8 * threadIdx.x); \
   } while (0)
-extern "C" int gcrnn_debug_read_seq32_stamps(void* host) {
+#ifndef GCRNN_SEQ32_STAMP_READER_NAME
+#define GCRNN_SEQ32_STAMP_READER_NAME gcrnn_debug_read_seq32_stamps      // (one reader per translation unit that includes this header: gcrnn_fused_seq32p.hip names its own)
+#endif
+extern "C" int GCRNN_SEQ32_STAMP_READER_NAME(void* host) {
   return hipMemcpyFromSymbol(host, HIP_SYMBOL(gcrnn_seq32_stamps), sizeof(unsigned long long) * 256 * 96) == hipSuccess ? 0 : 1;
 }
 #else
@@ -173,9 +176,11 @@ struct Seq32Map {
   static constexpr int WB = K * KS * 2048;
   static constexpr int COL_OFF = WOFF + WB;
   static constexpr int NPCK = 128;                         // nodes per inline-pack round
+  static constexpr int PFS = 256;                          // prefetch scratch (one dword per lane)
   static_assert(16 * RS2 <= BIAS_OFF && FLAG_OFF + 768 <= WOFF, "LDS map");
   static size_t lds_bytes(int64_t entries, bool inline_pack, bool r1 = false) {
-    const size_t need = (size_t)COL_OFF + (size_t)entries * 32 + GCRNN_HOP_COLUMN_PAD + NP * 4 + (r1 ? 2 * NP * 4 : 0) + (inline_pack ? (size_t)(32 * (XS > 0 ? XS : HS)) * NPCK * 2 : 0);
+    const size_t need = (size_t)COL_OFF + (size_t)entries * 32 + GCRNN_HOP_COLUMN_PAD + NP * 4 + (r1 ? 2 * NP * 4 : 0) + (inline_pack ? (size_t)(32 * (XS > 0 ? XS : HS)) * NPCK * 2 : 0)
+                        + PFS;      // (the last PFS bytes: where gcrnn_fused_seq32p.h's L2 prefetches land -- LDS-DMA needs a destination, nobody reads it)
     return need <= 160 * 1024 ? need : 0;
   }
 };

@@ -80,12 +80,16 @@ static bool seq32_wanted(int64_t B) {
   return rounds_seq * 0.62 * 4 < rounds_chunk;
 }
 
-// The un-gated persistent forward on a uniform-weight graph runs the kernel with the hand-allocated hop (round 5, gcrnn_fused_seq32p.h:
-// tap MFMAs inside the gather stream, the next operand requested during the last hop); GCRNN_SEQ32P=0 keeps round 4's kernel (same-box A/B)
+// The hand-allocated-hop kernel (round 5, gcrnn_fused_seq32p.h: pinned operand / accumulator tuples, tap MFMAs at the stream's tile exits, the
+// next operand requested inside the last hop) carries the un-gated persistent forward where it measures faster: the NATIVE layout
+// (sequence-major in and out: 1.365 ms against 1.407 ms per forward at the bench size, same box). With the inline pack and the user-layout
+// copy it is level with round 4's kernel (1.705 / 1.70 ms), which keeps those. GCRNN_SEQ32P=1 forces it for every un-gated launch, =0 switches
+// it off (same-box A/B: profiles/r05_p32_ab.txt).
 int gcrnn_seq32p_forward(const Seq32Args& sa, int K, int HS, int XS, bool inline_pack, size_t lds, hipStream_t st);
-static bool seq32p_wanted() {
+static bool seq32p_wanted(bool native) {
   const char* e = getenv("GCRNN_SEQ32P");
-  return !(e && e[0] == '0');
+  if (e) return e[0] != '0';
+  return native;
 }
 
 template <int K, int HS, int XS>
@@ -197,7 +201,7 @@ static int seq32_launch(const Seq32Args& sa, bool inline_pack, hipStream_t st, b
     if (sa.a1) return seq32_launch_v<K, HS, XS, 2, 0, true>(sa, lds, st);
     return seq32_launch_v<K, HS, XS, 0, 0, true>(sa, lds, st);
   }
-  if (seq32p_wanted()) return gcrnn_seq32p_forward(sa, K, HS, XS, inline_pack, lds, st);      // the hand-allocated hop (gcrnn_fused_seq32p.h)
+  if (seq32p_wanted(!inline_pack && !sa.a1)) return gcrnn_seq32p_forward(sa, K, HS, XS, inline_pack, lds, st);      // the hand-allocated hop (gcrnn_fused_seq32p.h)
   const int var = (inline_pack ? 1 : 0) | (sa.a1 ? 2 : 0);
   switch (var) {
     case 0: return seq32_launch_v<K, HS, XS, 0>(sa, lds, st);

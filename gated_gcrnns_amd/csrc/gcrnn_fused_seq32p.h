@@ -74,6 +74,19 @@ __device__ __forceinline__ p32_u32x4 p32_rsrc(const void* p, uint32_t bytes) {
                : P32_TILE_ENDS, "s"(lds_col), "s"(WOFS), "s"(RH), "s"(RX), "s"(SOH), "s"(SOX), "s"(SLOT)                                  \
                : GCRNN_HOP_ASM_P32_CLOBBERS)
 
+#ifndef GCRNN_P32_MODE
+#define GCRNN_P32_MODE 0         // 0: every wave runs the hop block with the tap MFMAs at the stream's tile exits, the next operand is requested inside the last hop
+                                 // 1: round 4's split -- waves 0..3 stream then tap, waves 4..7 tap then stream (the two waves of a SIMD run complementary
+                                 //    phases), the stream alone as the hand-allocated block (three sets of gathers in flight: no spill at this depth with the
+                                 //    pinned tuples), the operand requested behind the last chunk's state stores
+#endif
+#ifndef GCRNN_P32_PRIO
+#define GCRNN_P32_PRIO 0         // issue priority during the hop block: 1 = raised for waves 4..7 (the younger wave of each SIMD loses arbitration), 2 = for waves 0..3 (A/B)
+#endif
+#ifndef GCRNN_P32_PREFETCH
+#define GCRNN_P32_PREFETCH 1     // (native layout only; 0 = off, 2 / 3: hops 1.., K-2 of the last chunk share the prefetch instead of hops 2..; profiles/r05_p32_ab.txt) x_{t+1} is pulled into L2 during the last chunk's middle hops (one dword per 128-byte line by LDS-DMA into a scratch
+                                 // row: no register, nobody waits for it), so that the operand requests of the last hop are L2 hits instead of HBM misses
+#endif
 #ifndef GCRNN_P32_WAIT_AT
 #define GCRNN_P32_WAIT_AT 0      // where the next operand's requests are waited for: 0 = in front of the user-layout row stores (or the seed), 1 = at the seed with vmcnt(0) (A/B)
 #endif
@@ -144,6 +157,7 @@ __global__ __launch_bounds__(STHREADS) void fused_seq32p_kernel(const Seq32Args 
   const uint32_t xtile_off = slot_base + NP * 4;
   char* xtile = smem + xtile_off;
   const uint32_t slot_wave = __builtin_amdgcn_readfirstlane(slot_base + (uint32_t)(wave * STILES * 16 * 4));
+  [[maybe_unused]] const uint32_t pf_lds = xtile_off + (uint32_t)(PKV ? (32 * XS) * NPCK * 2 : 0);      // the prefetch scratch row (Seq32Map::PFS bytes at the end of the map)
 
   // ---- the operand of a sequence and step: every B fragment of the wave, resident for all chunks, in PINNED registers ----------------
   [[maybe_unused]] p32_u32x32 op0, op1, op2, op3;      // (the tuples of k-steps >= KS are never touched)
@@ -196,6 +210,8 @@ __global__ __launch_bounds__(STHREADS) void fused_seq32p_kernel(const Seq32Args 
     const p32_u32x4 rs_hn = p32_rsrc(hout, more ? (uint32_t)(B * (NP * F * 2)) : 0u);
     const p32_u32x4 rs_xn = p32_rsrc(a.x0 + (int64_t)(step + 1) * a.xstride, more ? (uint32_t)(B * (NP * G * 2)) : 0u);
     const uint32_t so_h = (uint32_t)(b * (NP * F * 2)), so_x = (uint32_t)(b * (NP * G * 2));
+    [[maybe_unused]] const bool stamp_on = (step == (a.nsteps > 2 ? a.nsteps - 3 : 0)) && b == (int)blockIdx.x;      // a typical step (diagnostic builds)
+    GCRNN_STAMP32(0);
 
     // acc[i][h] += W_tap(chunk c, half h) [h|x]^T over the wave's 8 tiles (the seed's tap; the hops' taps live inside the asm block)
     auto taps = [&](int tap) {
@@ -235,6 +251,7 @@ __global__ __launch_bounds__(STHREADS) void fused_seq32p_kernel(const Seq32Args 
     for (int chunk = 0; chunk < NCH; ++chunk) {
       const bool last = chunk == NCH - 1;
       lds_barrier();      // the seed is in the image
+      GCRNN_STAMP32(1 + chunk * 24);
 
       // inline pack, TWO hops ahead: virtual round v of this step -> (target step, round); false: nothing to lay out
       auto pack_target = [&](int v, int& tgt, int& rnd) -> bool {
@@ -340,7 +357,18 @@ __global__ __launch_bounds__(STHREADS) void fused_seq32p_kernel(const Seq32Args 
         }
         if (r0 < NRND) pack_issue(r0);
         const uint32_t wofs = (uint32_t)(WOFF + (K - 1 - j) * (2 * KS * 1024));
-        if (last && j == K - 1 && more) {
+        GCRNN_STAMP32(1 + chunk * 24 + 4 * (j - 1) + 1);
+        if (GCRNN_P32_PRIO == 1 && wave >= SWAVES / 2) __builtin_amdgcn_s_setprio(1);
+        if (GCRNN_P32_PRIO == 2 && wave < SWAVES / 2) __builtin_amdgcn_s_setprio(1);
+        if (j == 2 && chunk == 0) GCRNN_STAMP32_WAVE(56);
+        if (GCRNN_P32_MODE == 1) {
+          const bool stream_first = wave < SWAVES / 2;
+          if (!stream_first) taps(K - 1 - j);
+          if constexpr (HS == 2 && XS == 2) P32_HOP(GCRNN_HOP_ASM_P32_STREAM_TEXT_2_2, P32_OPS_IN_4, wofs);
+          else if constexpr (HS == 2 && XS == 1) P32_HOP(GCRNN_HOP_ASM_P32_STREAM_TEXT_2_1, P32_OPS_IN_3, wofs);
+          else P32_HOP(GCRNN_HOP_ASM_P32_STREAM_TEXT_1_1, P32_OPS_IN_2, wofs);
+          if (stream_first) taps(K - 1 - j);
+        } else if (last && j == K - 1 && more) {
           // (the asm text is a string literal: one statement per (HS, XS), the others are discarded)
           if constexpr (HS == 2 && XS == 2) P32_HOP_LOADS(GCRNN_HOP_ASM_P32_LOADS_TEXT_2_2, P32_OPS_IO_4, wofs, rs_hn, rs_xn, so_h, so_x, slot_wave);
           else if constexpr (HS == 2 && XS == 1) P32_HOP_LOADS(GCRNN_HOP_ASM_P32_LOADS_TEXT_2_1, P32_OPS_IO_3, wofs, rs_hn, rs_xn, so_h, so_x, slot_wave);
@@ -351,7 +379,43 @@ __global__ __launch_bounds__(STHREADS) void fused_seq32p_kernel(const Seq32Args 
           else if constexpr (HS == 2 && XS == 1) P32_HOP(GCRNN_HOP_ASM_P32_TEXT_2_1, P32_OPS_IN_3, wofs);
           else P32_HOP(GCRNN_HOP_ASM_P32_TEXT_1_1, P32_OPS_IN_2, wofs);
         }
+        if (GCRNN_P32_PRIO) __builtin_amdgcn_s_setprio(0);
+        GCRNN_STAMP32(1 + chunk * 24 + 4 * (j - 1) + 2);
+        if (j == 2 && chunk == 0) GCRNN_STAMP32_WAVE(64);
         lds_barrier();      // every wave has left the image (and the weights, after the last hop); every piece of the pack tile is in
+        GCRNN_STAMP32(1 + chunk * 24 + 4 * (j - 1) + 3);
+        if (GCRNN_P32_PREFETCH && !PKV && last && more && j < K - 1) {      // (with the inline pack x_{t+1} has just been written by this CU: no gain measured)
+          // L2 prefetch of the next operand, issued in the write-back phase (behind the hop's own wait: the NEXT hop's wait covers it). A CU
+          // has ~8 KB of misses in flight, so what it fetches costs 8 KB / latency: ~10 B per clock from HBM, ~29 from L2 (MI355X_MICROARCH.md,
+          // "Indexed rows") -- the operand requests of the last hop then hit lines that are already on their way or in L2.
+          // x_{t+1}: NP G 2 bytes = LINES 128-byte lines; instruction m = k * 8 + wave touches lines 64 m .. + 63, one dword each.
+          constexpr int LINES = NP * G * 2 / 128, NPF = LINES / 64;      // instructions per step and workgroup
+          constexpr int H0 = (GCRNN_P32_PREFETCH == 2) ? 1 : (GCRNN_P32_PREFETCH == 3 ? K - 2 : 2), NHOP = K - 1 - H0;      // hops H0 .. K-2 share them
+          const uint32_t voff = (uint32_t)lane_now() * 128u;
+#pragma unroll
+          for (int k = 0; k < (NPF + SWAVES - 1) / SWAVES; ++k) {
+            const int m = k * SWAVES + wave;
+            const int hm = H0 + (NHOP > 0 ? m * NHOP / NPF : 0);
+            if (m < NPF && (K - 1 <= H0 ? j == K - 2 : hm == j)) {
+              const uint32_t soff = so_x + (uint32_t)(m * 64 * 128);
+              asm volatile("s_mov_b32 m0, %3\n\tbuffer_load_dword %0, %1, %2 offen lds" ::"v"(voff), "s"(rs_xn), "s"(soff), "s"(pf_lds) : "memory");
+            }
+          }
+#if defined(GCRNN_P32_PREFETCH_H)
+          // ... and the first HS - 1 chunks of h_t (stored at their chunk's end, a whole chunk ago): the lines of its rows
+          if (HS > 1 && j == K - 2) {
+            constexpr int HLINES = NP * F * 2 / 128;
+#pragma unroll
+            for (int k = 0; k < (HLINES / 64 + SWAVES - 1) / SWAVES; ++k) {
+              const int m = k * SWAVES + wave;
+              if (m < HLINES / 64) {
+                const uint32_t soff = so_h + (uint32_t)(m * 64 * 128);
+                asm volatile("s_mov_b32 m0, %3\n\tbuffer_load_dword %0, %1, %2 offen lds" ::"v"(voff), "s"(rs_hn), "s"(soff), "s"(pf_lds) : "memory");
+              }
+            }
+          }
+#endif
+        }
         if (j < K - 1) put();
         if (K == 2 && NCH > 1) weights_issue((chunk + 1) % NCH, 0);
         if (r0 < NRND) drained_last = pack_drain(r0);
@@ -367,6 +431,7 @@ __global__ __launch_bounds__(STHREADS) void fused_seq32p_kernel(const Seq32Args 
           }
         }
         if (j < K - 1) lds_barrier();      // the image is complete (and the pack tile read)
+        GCRNN_STAMP32(1 + chunk * 24 + 4 * (j - 1) + 4);
       }
 
       // ---- epilogue: + 2 b, tanh, bf16; lane (r, q) holds features 32 c + 8 q .. + 7 of its node: ONE 16-byte store per tile -------------
@@ -401,6 +466,26 @@ __global__ __launch_bounds__(STHREADS) void fused_seq32p_kernel(const Seq32Args 
       });
       // the next operand's requests (issued inside the last hop) are waited for HERE, counted: younger are the 8 state stores and, when the
       // last hop's write-back drained a pack round, its row pieces
+      if (GCRNN_P32_MODE == 1 && last && more) {
+        // the next step's operand, requested behind the state stores (round 4's place): x_{t+1} and the state features of the earlier chunks;
+        // hipcc counts these loads and waits where the seed's MFMAs first use them
+        const __amdgpu_buffer_rsrc_t rsrc_hn = __builtin_amdgcn_make_buffer_rsrc(hout, 0, B * (NP * F * 2), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsrc_xn = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(a.x0 + (int64_t)(step + 1) * a.xstride), 0, B * (NP * G * 2), 0x00020000);
+        p32_forn<KS>([&](auto sc) {
+          constexpr int s = decltype(sc)::value;
+          if constexpr (s != HS - 1) {
+            p32_forn<STILES>([&](auto ic) {
+              constexpr int i = decltype(ic)::value;
+              const int node = swe[i] >> 16;
+              if constexpr (s < HS)
+                opset(sc, ic, __builtin_bit_cast(p32_u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_hn, node * (F * 2) + 16 * q + 64 * s, b * (NP * F * 2), 0)));
+              else
+                opset(sc, ic, __builtin_bit_cast(p32_u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_xn, node * (G * 2) + 16 * q + 64 * (s - HS), b * (NP * G * 2), 0)));
+            });
+          }
+        });
+      }
+      GCRNN_STAMP32(1 + chunk * 24 + 17);
       auto wait_requests = [&]() {
         if (!requested) return;
         constexpr int RIp = (PKROWS / 8) * NPCK / STHREADS;
@@ -411,6 +496,7 @@ __global__ __launch_bounds__(STHREADS) void fused_seq32p_kernel(const Seq32Args 
       if (aux1) {
         lds_barrier();
         if (GCRNN_P32_WAIT_AT == 0) wait_requests();
+        GCRNN_STAMP32(1 + chunk * 24 + 18);
         const int segs = N >> 3;
         uint16_t* ub = const_cast<uint16_t*>(aux1) + (int64_t)b * ubstride + (int64_t)(chunk * 32) * N;
         const __amdgpu_buffer_rsrc_t rsrc_u = __builtin_amdgcn_make_buffer_rsrc(ub, 0, 32 * N * 2, 0x00020000);
@@ -431,11 +517,14 @@ __global__ __launch_bounds__(STHREADS) void fused_seq32p_kernel(const Seq32Args 
       } else {
         wait_requests();
       }
+      GCRNN_STAMP32(1 + chunk * 24 + 19);
       // K = 2 only: the next chunk's tap 0 (LDS-DMA behind the last hop) has landed
       if (K == 2 && NCH > 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       lds_barrier();
+      GCRNN_STAMP32(1 + chunk * 24 + 20);
       if (chunk + 1 < NCH) seed();
     }  // chunks
   }  // steps
   }  // sequences
+  GCRNN_STAMP32_FLUSH();
 }

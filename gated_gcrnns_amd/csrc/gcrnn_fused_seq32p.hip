@@ -1,5 +1,6 @@
 // Instantiations and launcher of the hand-allocated-hop flagship forward (gcrnn_fused_seq32p.h).
 #include "gcrnn_fused_step.h"
+#define GCRNN_SEQ32_STAMP_READER_NAME gcrnn_debug_read_seq32p_stamps      // (diagnostic builds: this unit's own stamp array and reader)
 #include "gcrnn_fused_seq32.h"
 #include "gcrnn_fused_seq32p.h"
 

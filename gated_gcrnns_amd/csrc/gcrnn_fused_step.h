@@ -28,7 +28,10 @@
 // T*s*N*(G+2F) of SURVEY.md section 8d.
 #pragma once
 #include "gcrnn_common.h"
-#include "gcrnn_hop_asm.inc"
+#ifndef GCRNN_HOP_ASM_INC
+#define GCRNN_HOP_ASM_INC "gcrnn_hop_asm.inc"      // (A/B builds: -DGCRNN_HOP_ASM_INC='"/tmp/variant.inc"' with another output of tools/gen_hop_asm.py)
+#endif
+#include GCRNN_HOP_ASM_INC
 
 #ifndef GCRNN_STORE_POLICY
 #define GCRNN_STORE_POLICY 0   // cache policy of the state stores: 0 plain (default), 16 = sc1 (write-through, line not kept in L2), 2 = nt.

@@ -367,9 +367,14 @@ class GraphOperator(object):
             groups = (deg_pad[slots].max(axis=1) + 3) // 4
             load = np.zeros(waves, dtype=np.int64)
             fill = np.zeros(waves, dtype=np.int64)
+            # GCRNN_PLAN_YOUNG_COST=c (experiment): a group costs the second half of the waves c times what it costs the first -- the younger
+            # wave of each SIMD loses issue arbitration, so with every wave running the same program (gcrnn_fused_seq32p.h) waves 4..7 leave
+            # their streams ~30 % after waves 0..3 (profiles/r05_p32_stamps_*.txt); fewer groups for them levels the finish times
+            cost = np.ones(waves)
+            cost[waves // 2:] = float(os.environ.get('GCRNN_PLAN_YOUNG_COST', '1.0'))
             for t in np.argsort(-groups, kind='stable'):
                 free = np.flatnonzero(fill < per)
-                w = free[np.argmin(load[free])]
+                w = free[np.argmin((load[free] + groups[t]) * cost[free])]
                 storage[w * per + fill[w]] = slots[t]
                 load[w] += groups[t]
                 fill[w] += 1

@@ -559,26 +559,50 @@ def gen_wide32():
 # group, last valid group, LDS address of the column image, LDS address of the hop's tap in the weight fragments; loads variant: buffer
 # resources of h_t / x_{t+1} (128-bit scalars), their sequence offsets, LDS address of this wave's slot table (8 tiles x 16 words). Plain
 # variant: the KS operand tuples follow as inputs (never named by number: every vector register is named by its pinned position).
-P_A0, P_IDX, P_TMP, P_UB = 192, 196, 197, 198
-P_VCW0, P_VP, P_VA, P_WF0, P_ND0, P_VCB, P_QX, P_WFB, P_Q16 = 230, 232, 233, 234, 242, 250, 251, 252, 253
-
-
 def frag_order(HS, XS):
     ks = list(range(HS, HS + XS)) + list(range(0, HS - 1)) + [HS - 1]
     return [(s_, h) for s_ in ks for h in (0, 1)]
 
 
-def gen_wide32_taps(HS, XS, loads=False, lpe=4, fpe=1):
-    D, KS = 2, HS + XS
-    FO = frag_order(HS, XS)
+def gen_wide32_taps(HS, XS, loads=False, lpe=4, fpe=1, depth=None, taps=True):
+    """Registers (62: v192..v253): sparse A operand (4) + its index | D gather sets of 16 | D column words | running column pointer | q << 4 |
+    ONE weight-fragment buffer (4) whose registers double as the prologue's scratch (lane id, addresses) and, at every exit, as the address of
+    the next fragment's read (re-derived from the lane id: nothing fragment-related lives across the trips) | loads variant: 8 tile node
+    ids, 16 q, an address register. D = 3 fits the plain variant exactly; the loads variant (one hop of a step) runs two-deep."""
+    KS = HS + XS
+    D = depth if depth is not None else (2 if loads else int(os.environ.get('GCRNN_P_DEPTH', '2')))
+    # exit style: 'A' = two fragment buffers, the next fragment's read IN FRONT of the MFMAs and everything waited for behind them (the first
+    # form; needs D == 2); 'B' = one buffer, the read behind the MFMAs, a wait only when the tile was shorter than D - 1 trips
+    style = os.environ.get('GCRNN_P_EXIT', 'A' if D == 2 else 'B')
+    if not taps:
+        style = 'B'
+    assert style == 'B' or D == 2
+    FO = frag_order(HS, XS) if taps else []      # taps=False: the stream alone (the split form: a wave's tap MFMAs run before or behind its stream)
     NF = len(FO)
-    assert NF <= NT * fpe
-    A0, IDX, TMP, UB = P_A0, P_IDX, P_TMP, P_UB
-    VCw = lambda p: 'v%d' % (P_VCW0 + p)
-    VP, VA = 'v%d' % P_VP, 'v%d' % P_VA
-    WF = lambda e: P_WF0 + 4 * (e & 1)
-    ND = lambda i: 'v%d' % (P_ND0 + i)
-    VCB, QX, WFB, Q16 = 'v%d' % P_VCB, 'v%d' % P_QX, 'v%d' % P_WFB, 'v%d' % P_Q16
+    assert NF <= NT * fpe and 2 <= D <= 3
+    nxt = [192]
+
+    def alloc(n, even=False):
+        if even and nxt[0] % 2:
+            nxt[0] += 1
+        r = nxt[0]
+        nxt[0] += n
+        return r
+    A0 = alloc(4, True)
+    UB = alloc(16 * D, True)
+    WF0 = alloc(4, True)
+    WF1 = alloc(4, True) if style == 'A' else WF0
+    WFBn = alloc(1) if style == 'A' else None
+    IDX = alloc(1)
+    VCW0 = alloc(D)
+    VPn, QXn = alloc(1), alloc(1)
+    TMP, VAn, VCBn = WF0 + 1, WF0 + 2, WF0 + 3      # prologue scratch inside the fragment buffer (the first fragment is read behind their last use)
+    if loads:
+        ND0 = alloc(8)
+        Q16n, LAD = alloc(1), alloc(1)
+    assert nxt[0] <= 254, nxt[0]
+    VCw = lambda p: 'v%d' % (VCW0 + p)
+    VP, VA, VCB, QX = 'v%d' % VPn, 'v%d' % VAn, 'v%d' % VCBn, 'v%d' % QXn
     OP = lambda s_, i: 32 * s_ + 4 * i
     ACC = lambda h, i: 128 + 32 * h + 4 * i
     SGr, STr, SCr = 's88', 's89', 's90'
@@ -588,8 +612,9 @@ def gen_wide32_taps(HS, XS, loads=False, lpe=4, fpe=1):
     RH, RX, SOH, SOX, SLOT = ('%%%d' % (SB + 12 + n) for n in range(5))
     Y = lambda p, e: UB + 16 * p + 4 * e
     Xr = lambda p, e: UB + 16 * p + 8 + 4 * e
-    tup = lambda b: 'v[%d:%d]' % (b, b + 3)
+    tup = lambda b_: 'v[%d:%d]' % (b_, b_ + 3)
     foff = lambda f: (FO[f][1] * KS + FO[f][0]) * 1024
+    WFt = tup(WF0)
 
     def col_clamped(p, goff, L):
         L += ['s_add_i32 %s, %s, %d' % (STr, SGr, goff), 's_min_i32 %s, %s, %s' % (STr, STr, GL),
@@ -603,20 +628,26 @@ def gen_wide32_taps(HS, XS, loads=False, lpe=4, fpe=1):
         for e in range(2):
             L.append('ds_read_b128 %s, v%d' % (tup(Xr(q, e)), Xr(q, e)))
 
+    def frag_read(f, L):
+        """this lane's 16 bytes of weight fragment f -> the fragment buffer (address = lane * 16 + the tap's place, formed in the buffer's first register)"""
+        L += ['v_mbcnt_lo_u32_b32 v%d, -1, 0' % WF0, 'v_mbcnt_hi_u32_b32 v%d, -1, v%d' % (WF0, WF0),
+              'v_lshlrev_b32 v%d, 4, v%d' % (WF0, WF0), 'v_add_u32 v%d, %s, v%d' % (WF0, WOFS, WF0),
+              'ds_read_b128 %s, v%d offset:%d' % (WFt, WF0, foff(f))]
+
     L = ['s_mov_b32 %s, %s' % (SGr, GB)]
-    # lane id -> q << 4 (the half a lane gathers), 16 q, fragment base, this lane's column dword
+    # lane id -> q << 4 (the half a lane gathers), this lane's column dword
     L += ['v_mbcnt_lo_u32_b32 v%d, -1, 0' % TMP, 'v_mbcnt_hi_u32_b32 v%d, -1, v%d' % (TMP, TMP),
           'v_lshrrev_b32 %s, 4, v%d' % (VA, TMP),
-          'v_and_b32 %s, 1, %s' % (QX, VA), 'v_lshlrev_b32 %s, 4, %s' % (QX, QX),
-          'v_lshlrev_b32 %s, 4, %s' % (Q16, VA),
-          'v_lshlrev_b32 %s, 4, v%d' % (WFB, TMP), 'v_add_u32 %s, %s, %s' % (WFB, WOFS, WFB),
-          'v_lshrrev_b32 %s, 1, %s' % (VA, VA), 'v_lshlrev_b32 %s, 2, %s' % (VA, VA),
+          'v_and_b32 %s, 1, %s' % (QX, VA), 'v_lshlrev_b32 %s, 4, %s' % (QX, QX)]
+    if loads:
+        L.append('v_lshlrev_b32 v%d, 4, %s' % (Q16n, VA))
+    L += ['v_lshrrev_b32 %s, 1, %s' % (VA, VA), 'v_lshlrev_b32 %s, 2, %s' % (VA, VA),
           'v_and_b32 %s, 15, v%d' % (VP, TMP),
           'v_lshl_add_u32 %s, %s, 3, %s' % (VCB, VP, VA), 'v_add_u32 %s, %s, %s' % (VCB, COLS, VCB)]
     if loads:
         L += ['v_lshlrev_b32 %s, 2, %s' % (VA, VP), 'v_add_u32 %s, %s, %s' % (VA, SLOT, VA)]
         for i in range(NT):
-            L.append('ds_read_b32 %s, %s offset:%d' % (ND(i), VA, 64 * i))
+            L.append('ds_read_b32 v%d, %s offset:%d' % (ND0 + i, VA, 64 * i))
     for p in range(D):
         col_clamped(p, p, L)
     # the compressed one-hot A operand of v_smfmac (one non-zero per lane: group (lane & 15) >> 2, position lane & 3) and its index register
@@ -637,16 +668,24 @@ def gen_wide32_taps(HS, XS, loads=False, lpe=4, fpe=1):
     for g in (3, 1, 0):
         L += ['v_cmp_eq_u32 vcc, %d, v%d' % (g, TMP), 'v_cndmask_b32 v%d, 0, v%d, vcc' % (A0 + g, A0 + 2)]
     L += ['v_cmp_eq_u32 vcc, 2, v%d' % TMP, 'v_cndmask_b32 v%d, 0, v%d, vcc' % (A0 + 2, A0 + 2)]
-    L.append('ds_read_b128 %s, %s offset:%d' % (tup(WF(0)), WFB, foff(0)))
     L.append('s_waitcnt lgkmcnt(0)')
     if loads:
         for i in range(NT):
-            L.append('v_lshrrev_b32 %s, 16, %s' % (ND(i), ND(i)))
+            L.append('v_lshrrev_b32 v%d, 16, v%d' % (ND0 + i, ND0 + i))
     for p in range(D - 1):
         gathers(p, L); col_clamped(p, D + p, L)
     L += ['s_add_i32 %s, %s, %d' % (STr, SGr, 2 * D - 1), 'v_lshl_add_u32 %s, %s, 7, %s' % (VP, STr, VCB)]
+    if not taps:
+        pass
+    elif style == 'A':
+        L += ['v_mbcnt_lo_u32_b32 v%d, -1, 0' % WFBn, 'v_mbcnt_hi_u32_b32 v%d, -1, v%d' % (WFBn, WFBn),
+              'v_lshlrev_b32 v%d, 4, v%d' % (WFBn, WFBn), 'v_add_u32 v%d, %s, v%d' % (WFBn, WOFS, WFBn),
+              'ds_read_b128 %s, v%d offset:%d' % (WFt, WFBn, foff(0)), 's_waitcnt lgkmcnt(0)']
+        # (style A waits for the first fragment here; the prologue's gathers of the sets in flight are issued behind it)
+    else:
+        frag_read(0, L)      # (the prologue's scratch registers are dead)
     L += ['s_sub_u32 %s, %s, %%%d' % (SCr, GB, TE), 's_cmp_eq_u32 %s, 0' % SCr]
-    R = 2
+    R = 2 if D == 2 else 1
     Aop, Iop = 'v[%d:%d]' % (A0, A0 + 3), 'v%d' % IDX
 
     # the operand requests of the loads variant, in the order their registers die
@@ -659,33 +698,56 @@ def gen_wide32_taps(HS, XS, loads=False, lpe=4, fpe=1):
     nloads = len(queue)
 
     def burst(t, L, pending):
-        """tile exit t: fragments t*fpe .. of the hop's taps, the next fragment's read, operand requests"""
-        for f in range(t * fpe, min((t + 1) * fpe, NF)):
-            if f + 1 < NF:
-                L.append('ds_read_b128 %s, %s offset:%d' % (tup(WF(f + 1)), WFB, foff(f + 1)))
+        """tile exit t: fragment(s) t * fpe .. of the hop's taps, the next fragment's read, operand requests"""
+        if style == 'A':
+            for f in range(t * fpe, min((t + 1) * fpe, NF)):
+                wf = WF0 if f % 2 == 0 else WF1
+                if f + 1 < NF:
+                    L.append('ds_read_b128 %s, v%d offset:%d' % (tup(WF1 if f % 2 == 0 else WF0), WFBn, foff(f + 1)))
+                s_, h = FO[f]
+                for i in [(t + 1 + d) % NT for d in range(NT)]:
+                    L.append('v_mfma_f32_16x16x32_bf16 %s, %s, %s, %s' % (tup(ACC(h, i)), tup(wf), tup(OP(s_, i)), tup(ACC(h, i))))
+                if f + 1 < NF:
+                    L.append('s_waitcnt lgkmcnt(0)')
+        for f in (range(t * fpe, min((t + 1) * fpe, NF)) if style == 'B' else ()):
+            # The fragment was read at the previous exit (or in the prologue). Every trip waits for all but the 5 (D - 1) youngest LDS
+            # operations, so after D - 1 trips of this tile it has landed; a tile with fewer trips waits for it here.
+            first = (f == t * fpe)
+            if first:
+                L += ['s_sub_u32 %s, %%%d, %s' % (STr, TE + t, ('%%%d' % (TE + t - 1)) if t > 0 else GB),
+                      's_cmp_ge_u32 %s, %d' % (STr, D - 1), 's_cbranch_scc1 L_W%d_%%=' % t, 's_waitcnt lgkmcnt(0)',
+                      'L_W%d_%%=:' % t]
+            else:
+                L.append('s_waitcnt lgkmcnt(0)')
             s_, h = FO[f]
             for i in [(t + 1 + d) % NT for d in range(NT)]:
-                L.append('v_mfma_f32_16x16x32_bf16 %s, %s, %s, %s' % (tup(ACC(h, i)), tup(WF(f)), tup(OP(s_, i)), tup(ACC(h, i))))
+                L.append('v_mfma_f32_16x16x32_bf16 %s, %s, %s, %s' % (tup(ACC(h, i)), WFt, tup(OP(s_, i)), tup(ACC(h, i))))
             if f + 1 < NF:
-                L.append('s_waitcnt lgkmcnt(0)')
+                L.append('s_nop 1')      # (the fragment buffer's first register becomes an address right behind the MFMAs that read it)
+                frag_read(f + 1, L)
         if loads:
             n = 0
             while pending and pending[0][0] <= t and (n < lpe or t == NT - 1):
                 _, s_, i = pending.pop(0)
                 row_log2 = {1: 6, 2: 7}[HS if s_ < HS else XS]
-                L.append('v_lshl_add_u32 v%d, %s, %d, %s' % (TMP, ND(i), row_log2, Q16))
+                L.append('v_lshl_add_u32 v%d, v%d, %d, v%d' % (LAD, ND0 + i, row_log2, Q16n))
                 if s_ < HS:
-                    L.append('buffer_load_dwordx4 %s, v%d, %s, %s offen offset:%d' % (tup(OP(s_, i)), TMP, RH, SOH, 64 * s_))
+                    L.append('buffer_load_dwordx4 %s, v%d, %s, %s offen offset:%d' % (tup(OP(s_, i)), LAD, RH, SOH, 64 * s_))
                 else:
-                    L.append('buffer_load_dwordx4 %s, v%d, %s, %s offen offset:%d' % (tup(OP(s_, i)), TMP, RX, SOX, 64 * (s_ - HS)))
+                    L.append('buffer_load_dwordx4 %s, v%d, %s, %s offen offset:%d' % (tup(OP(s_, i)), LAD, RX, SOX, 64 * (s_ - HS)))
                 n += 1
 
-    exits = []
     pend = list(queue)
+    exits = []
     for t in range(NT):
-        ex = []
-        burst(t, ex, pend)
-        exits.append(ex)
+        per_phase = []
+        save = list(pend)
+        for p in range(D):
+            pend = list(save)
+            ex = []
+            burst(t, ex, pend)
+            per_phase.append(ex)
+        exits.append(per_phase)
     assert not pend
     for t in range(NT):
         for pp in range(D * R):
@@ -702,7 +764,8 @@ def gen_wide32_taps(HS, XS, loads=False, lpe=4, fpe=1):
         L.append('s_branch L_T%d_P0_%%=' % t)
         for p in range(D):
             L.append('L_X%d_P%d_%%=:' % (t, p))
-            L += exits[t]
+            # (labels inside an exit must be unique per copy)
+            L += [ln.replace('L_W%d_%%=' % t, 'L_W%dp%d_%%=' % (t, p)) for ln in exits[t][p]]
             if t + 1 < NT:
                 L += ['s_sub_u32 %s, %%%d, %%%d' % (SCr, TE + t, TE + t + 1), 's_cmp_eq_u32 %s, 0' % SCr]
             L.append('s_branch L_T%d_P%d_%%=' % (t + 1, p))
@@ -743,8 +806,10 @@ def main():
     emit('GCRNN_HOP_ASM_WIDE32_TEXT', gen_wide32())
     print('#define GCRNN_HOP_WIDE_PLANE %d' % WIDE_PLANE)
     lpe, fpe = int(os.environ.get('GCRNN_P_LPE', '4')), int(os.environ.get('GCRNN_P_FPE', '1'))
+    sdepth = int(os.environ.get('GCRNN_P_SDEPTH', '3'))
     for (hs, xs) in ((2, 2), (2, 1), (1, 1)):
         emit('GCRNN_HOP_ASM_P32_TEXT_%d_%d' % (hs, xs), gen_wide32_taps(hs, xs)[0])
+        emit('GCRNN_HOP_ASM_P32_STREAM_TEXT_%d_%d' % (hs, xs), gen_wide32_taps(hs, xs, taps=False, depth=sdepth)[0])
         ll, nl = gen_wide32_taps(hs, xs, loads=True, lpe=lpe, fpe=fpe)
         emit('GCRNN_HOP_ASM_P32_LOADS_TEXT_%d_%d' % (hs, xs), ll)
         print('#define GCRNN_HOP_ASM_P32_NLOADS_%d_%d %d' % (hs, xs, nl))

@@ -7,13 +7,15 @@ R = os.environ.get('GRAFT_REPO_ROOT', os.path.dirname(os.path.dirname(os.path.ab
 C = os.path.join(R, 'gated_gcrnns_amd', 'csrc')
 out = '/tmp/seq32st'
 os.makedirs(out, exist_ok=True)
-procs = []
-for f in sorted(glob.glob(C + '/*.hip') + glob.glob(C + '/*.cpp')):
-    o = os.path.join(out, os.path.basename(f) + '.o')
-    procs.append(subprocess.Popen(['/opt/rocm/bin/hipcc', '-O3', '-std=c++17', '--offload-arch=gfx950', '-fPIC', '-DGCRNN_SEQ_STAMPS'] + os.environ.get('GCRNN_STAMP_FLAGS', '').split() + ['-c', f, '-o', o]))
-assert all(p.wait() == 0 for p in procs)
-lib = os.path.join(out, 'lib.so')
-subprocess.check_call(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-shared', '-fPIC', '-o', lib] + sorted(glob.glob(out + '/*.o')))
+lib = os.environ.get('GCRNN_STAMP_LIB')      # a diagnostic library built beforehand (tools/build_stamp_lib.sh: the two wide units with -DGCRNN_SEQ_STAMPS, linked with the in-tree objects)
+if not (lib and os.path.exists(lib)):
+    procs = []
+    for f in sorted(glob.glob(C + '/*.hip') + glob.glob(C + '/*.cpp')):
+        o = os.path.join(out, os.path.basename(f) + '.o')
+        procs.append(subprocess.Popen(['/opt/rocm/bin/hipcc', '-O3', '-std=c++17', '--offload-arch=gfx950', '-fPIC', '-DGCRNN_SEQ_STAMPS'] + os.environ.get('GCRNN_STAMP_FLAGS', '').split() + ['-c', f, '-o', o]))
+    assert all(p.wait() == 0 for p in procs)
+    lib = os.path.join(out, 'lib.so')
+    subprocess.check_call(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-shared', '-fPIC', '-o', lib] + sorted(glob.glob(out + '/*.o')))
 os.environ['GCRNN_LIBPATH'] = lib
 sys.path.insert(0, R)
 import numpy as np, torch
@@ -61,15 +63,16 @@ with torch.no_grad():
 torch.cuda.synchronize()
 buf = np.zeros(256 * 96, dtype=np.uint64)
 dll = ctypes.CDLL(lib)
-assert dll.gcrnn_debug_read_seq32_stamps(buf.ctypes.data_as(ctypes.c_void_p)) == 0
+pinned = os.environ.get('GCRNN_SEQ32P', '1') != '0' and not (chain or gates)      # the un-gated forward runs the hand-allocated-hop kernel (gcrnn_fused_seq32p.h)
+assert (dll.gcrnn_debug_read_seq32p_stamps if pinned else dll.gcrnn_debug_read_seq32_stamps)(buf.ctypes.data_as(ctypes.c_void_p)) == 0
 st = buf.reshape(256, 96).astype(np.int64)
 names = {0: 'step start (operand in registers)'}
 for c in range(4 if gates else 2):
     b0 = 1 + 24 * c
     names[b0] = 'c%d seed + barrier' % c
     for j in range(1, K):
-        names[b0 + 4 * (j - 1) + 1] = 'c%d hop %d stream' % (c, j)
-        names[b0 + 4 * (j - 1) + 2] = 'c%d hop %d taps' % (c, j)
+        names[b0 + 4 * (j - 1) + 1] = ('c%d hop %d zero + dma issue' if pinned else 'c%d hop %d stream') % (c, j)
+        names[b0 + 4 * (j - 1) + 2] = ('c%d hop %d stream with taps' if pinned else 'c%d hop %d taps') % (c, j)
         names[b0 + 4 * (j - 1) + 3] = 'c%d hop %d dma wait + barrier' % (c, j)
         names[b0 + 4 * (j - 1) + 4] = 'c%d hop %d put + weights dma + pack drain + barrier' % (c, j)
     names[b0 + 17] = 'c%d next operand requests + tanh + state stores' % c
