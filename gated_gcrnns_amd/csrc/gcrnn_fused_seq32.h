@@ -135,6 +135,10 @@ struct Seq32Args {
   float* gpart0; int64_t gpartstride;                  // (or null) [B][F/32 * 8] partials of <h_{t-1}, adjoint chain of dpre_t> (the forget gate's gradient)
   int final_raw;                                       // != 0: the launch's LAST step stores the raw state gradient (d h0: no upstream term, no tanh') into
   uint16_t* final_out; const uint16_t* final_h;        // final_out (or null), with final_h (h0, or null) as the state of its partials
+  // MODE 3 (filter-output pass, graphML.py:2402-2403: A(S) x_t + b for every (t, b) item; operand [0 | x_t], the state half never loaded): out0
+  // [items][NP][F] bf16 receives acc + b (no activation). MODE 4 (node-gated recurrence, graphML.py:2379-2407, 2420-2423): state-only operand,
+  // h_t = tanh(gi ni_t . Yx_t + gf nf_t . (B(S) h_{t-1} + b)) -- Yx_t = dh0_ + step dhstride (MODE 3's output), the per-node gates:
+  const float* ng0; int64_t ngstride; int64_t nghalf;  // ng0 + step ngstride: ni [B][N] fp32, nf = + nghalf; optional scalar time gates gi0 / gf0 (+ step gstride)
   const float* r1a; const float* r1b;                  // R1 (rank-1-weighted graph S[m][n] = a[m] b[n], plan of its 0/1 pattern): the factors [NP] fp32, zero for padding rows
   int stagger;                                         // > 0: workgroup i starts ((i / 8) % 8) * stagger shader cycles late (de-synchronises the CUs' memory phases for the whole launch)
 };
@@ -205,16 +209,19 @@ template <int K, int HS, int XS, int VAR, int MODE = 0, bool GATED = false, bool
 __global__ __launch_bounds__(STHREADS) void fused_seq32_kernel(const Seq32Args a) {
   static_assert(!R1 || !SPLIT, "rank-1 graphs: every mode of the persistent form (the BPTT chain takes the adjoint plan: the factors swap)");
   static_assert(!SPLIT || ((MODE == 0 || MODE == 2) && !R1 && HS > 1), "split sequences: the (un-gated or time-gated) forward and the BPTT chain, with more than one chunk");
-  constexpr bool PKV = (VAR & 1) != 0, USERV = (VAR & 2) != 0 && MODE == 0;
-  static_assert(MODE == 0 || ((MODE == 1 || MODE == 2) && !GATED), "modes");
+  constexpr bool ITEMS = (MODE == 1 || MODE == 3);      // one-step items (t, b) instead of sequences
+  constexpr bool SONLY = (MODE == 2 || MODE == 4);      // state-only operand that is this launch's own output (XS = 0)
+  constexpr bool PKV = (VAR & 1) != 0, USERV = (VAR & 2) != 0 && (MODE == 0 || MODE == 4);
+  static_assert(MODE == 0 || ((MODE >= 1 && MODE <= 4) && !GATED), "modes");
+  static_assert(MODE < 3 || (!R1 && !SPLIT), "modes 3, 4: uniform-weight graphs, persistent form");
   using M = Seq32Map<K, HS, XS>;
   constexpr int KS = HS + XS;
   constexpr int F = 32 * HS, G = 32 * XS;
   constexpr int NCH = (MODE == 1) ? 2 * HS : HS;  // 32-feature output chunks
   constexpr int PL = M::PL, WOFF = M::WOFF, WB = M::WB, COL_OFF = M::COL_OFF, RS2 = M::RS2;
   constexpr int NPCK = M::NPCK, NRND = NP / NPCK, NH = NCH * (K - 1), RPH = (NRND + NH - 1) / NH;      // pack rounds per step / hops per step / rounds per hop
-  constexpr int PKROWS = (MODE == 2) ? F : G;
-  static_assert(STILES == 8 && GCRNN_HOP_ASM && K >= 2 && (MODE == 2 ? XS == 0 : XS > 0), "generated hop stream: 8 tiles per wave; the chain's operand is the state alone");
+  constexpr int PKROWS = SONLY ? F : G;
+  static_assert(STILES == 8 && GCRNN_HOP_ASM && K >= 2 && (SONLY ? XS == 0 : XS > 0), "generated hop stream: 8 tiles per wave; the chain's operand is the state alone");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int entries = a.entries, B = a.B, N = a.N;
 
@@ -261,7 +268,7 @@ __global__ __launch_bounds__(STHREADS) void fused_seq32_kernel(const Seq32Args a
   [[maybe_unused]] auto r1_scale = [&](f32x4 (&ac)[STILES][2], int kind) __attribute__((always_inline)) {
     if constexpr (R1) {
       const uint32_t ad = (uint32_t)(COL_OFF + entries * 32 + GCRNN_HOP_COLUMN_PAD + NP * 4 + NP * 4) + (uint32_t)((wave * STILES * 16 + (lane_now() & 15)) * 4);      // b, slot order
-      constexpr int NB = (GATED || MODE == 1 || K == 4) ? 1 : 4;      // factors read at a time (the instantiations at the register limit take them one by one: a few hundred cycles per hop)
+      constexpr int NB = (GATED || ITEMS || K == 4) ? 1 : 4;      // factors read at a time (the instantiations at the register limit take them one by one: a few hundred cycles per hop)
 #pragma unroll
       for (int h4 = 0; h4 < STILES; h4 += NB) {
         float b4[NB];
@@ -315,7 +322,7 @@ __global__ __launch_bounds__(STHREADS) void fused_seq32_kernel(const Seq32Args a
   char* xtile = wtab + NP * 4 + (R1 ? 2 * NP * 4 : 0);
 
   // wave-uniform, as a scalar integer (a lane mask would also be parked in a vector register)
-  const int skip_hi = __builtin_amdgcn_readfirstlane((MODE == 1 && a.flags && a.flags[0] != 0) ? 1 : 0);
+  const int skip_hi = __builtin_amdgcn_readfirstlane((MODE == 3 || (MODE == 1 && a.flags && a.flags[0] != 0)) ? 1 : 0);      // (MODE 3: the operand is [0 | x_t])
   const bool skip_h = skip_hi != 0;
   // ---- the operand of a sequence and step: every B fragment of the wave, resident for all chunks ----------------------------------
   bf16x8 bfr[STILES][KS];
@@ -324,9 +331,9 @@ __global__ __launch_bounds__(STHREADS) void fused_seq32_kernel(const Seq32Args a
   // wait for its whole operand)
   auto load_first_operand = [&](int b) {
     // (MODE 1 with an all-zero h0: a zero-length descriptor -- the loads return zeros and cost nothing)
-    const __amdgpu_buffer_rsrc_t rsrc_h = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(a.hfirst), 0, skip_h ? 0 : (MODE == 1 ? a.hmod : B) * (NP * F * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_h = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(a.hfirst), 0, skip_h ? 0 : (ITEMS ? a.hmod : B) * (NP * F * 2), 0x00020000);
     const __amdgpu_buffer_rsrc_t rsrc_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(a.x0), 0, XS > 0 ? B * (NP * G * 2) : 0, 0x00020000);
-    const int bh = (MODE == 1) ? __builtin_amdgcn_readfirstlane(b % a.hmod) : b;
+    const int bh = ITEMS ? __builtin_amdgcn_readfirstlane(b % a.hmod) : b;
     const int ln0 = lane_now(), qo = ln0 >> 4;
     int sw[STILES];
     slot_words(ln0, sw);
@@ -350,7 +357,8 @@ __global__ __launch_bounds__(STHREADS) void fused_seq32_kernel(const Seq32Args a
   for (int step = 0; step < a.nsteps; ++step) {
     const bool fin = (MODE == 2) && a.final_raw && step == a.nsteps - 1;      // (chain: the d h0 step)
     uint16_t* hout = fin ? a.final_out : (a.out0 ? a.out0 + (int64_t)step * a.ostride : nullptr);
-    [[maybe_unused]] const uint16_t* ep_dh = (MODE == 2 && !fin && a.dh0_) ? a.dh0_ + (int64_t)step * a.dhstride : nullptr;
+    [[maybe_unused]] const uint16_t* ep_dh = (SONLY && !fin && a.dh0_) ? a.dh0_ + (int64_t)step * a.dhstride : nullptr;      // (MODE 4: Yx_t)
+    [[maybe_unused]] const float* ep_ng = (MODE == 4) ? a.ng0 + (int64_t)step * a.ngstride : nullptr;
     [[maybe_unused]] const uint16_t* ep_h = (MODE == 2) ? (fin ? a.final_h : (a.hs0 ? a.hs0 + (int64_t)step * a.hsstride : nullptr)) : nullptr;
     [[maybe_unused]] float* gpart = (MODE == 2 && a.gpart0) ? a.gpart0 + (int64_t)step * a.gpartstride : nullptr;
     [[maybe_unused]] float gsc = 1.f;
@@ -358,6 +366,12 @@ __global__ __launch_bounds__(STHREADS) void fused_seq32_kernel(const Seq32Args a
       if (a.gsc0) gsc = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, a.gsc0[(int64_t)step * a.gscstride + b])));
     }
     float gin = 1.f, gfo = 1.f, gratio = 1.f;
+    if constexpr (MODE == 4) {      // scalar time gates on top of the node gates (applied in the epilogue)
+      if (a.gi0) {
+        gin = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, a.gi0[(int64_t)step * a.gstride + b])));
+        gfo = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, a.gf0[(int64_t)step * a.gstride + b])));
+      }
+    }
     if constexpr (GATED) {      // (wave-uniform: kept in scalar registers -- three vector registers live across the hops are three too many)
       gin = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, a.gi0[(int64_t)step * a.gstride + b])));
       gfo = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, a.gf0[(int64_t)step * a.gstride + b])));
@@ -373,9 +387,9 @@ __global__ __launch_bounds__(STHREADS) void fused_seq32_kernel(const Seq32Args a
     const int ubstride = a.ubstride;
     // (MODE 1: the pack lays out the operand of the NEXT item of this workgroup's loop, item nb = (t', b') = (nb / hmod, nb % hmod))
     const int nb = b + (int)gridDim.x;
-    const int nbq = (MODE == 1) ? __builtin_amdgcn_readfirstlane(nb / a.hmod) : 0, nbr = (MODE == 1) ? __builtin_amdgcn_readfirstlane(nb - nbq * a.hmod) : 0;      // (scalar registers)
-    const int64_t pk_soff = (MODE == 1) ? (int64_t)nbr * a.pk_stride + (int64_t)nbq * a.pksrc_stride : (int64_t)b * a.pk_stride;
-    const int pk_db = (MODE == 1) ? nb : b;
+    const int nbq = ITEMS ? __builtin_amdgcn_readfirstlane(nb / a.hmod) : 0, nbr = ITEMS ? __builtin_amdgcn_readfirstlane(nb - nbq * a.hmod) : 0;      // (scalar registers)
+    const int64_t pk_soff = ITEMS ? (int64_t)nbr * a.pk_stride + (int64_t)nbq * a.pksrc_stride : (int64_t)b * a.pk_stride;
+    const int pk_db = ITEMS ? nb : b;
     const __amdgpu_buffer_rsrc_t rsrc_o = __builtin_amdgcn_make_buffer_rsrc(hout, 0, hout ? B * (NP * F * 2) : 0, 0x00020000);
     [[maybe_unused]] const bool stamp_on = (step == (a.nsteps > 2 ? a.nsteps - 3 : 0)) && b == wg_seq;      // a typical step (diagnostic builds)
     GCRNN_STAMP32(0);
@@ -430,8 +444,8 @@ __global__ __launch_bounds__(STHREADS) void fused_seq32_kernel(const Seq32Args a
             }
           }
         }
-      } else if constexpr (MODE == 1) {
-        // (gate pre-pass; with an all-zero h0 the state half of the operand is neither loaded nor multiplied)
+      } else if constexpr (ITEMS) {
+        // (gate pre-pass / filter-output pass; with an all-zero h0 the state half of the operand is neither loaded nor multiplied)
 #pragma unroll
         for (int h = 0; h < 2; ++h)
 #pragma unroll
@@ -494,7 +508,7 @@ __global__ __launch_bounds__(STHREADS) void fused_seq32_kernel(const Seq32Args a
 
       // virtual round v of this step (NRND per step, shifted by one hop) -> (target step, round); false: nothing to lay out
       auto pack_target = [&](int v, int& tgt, int& rnd) -> bool {
-        if constexpr (MODE == 1) {      // the workgroup's next item, round v (its operand is read when that item starts)
+        if constexpr (ITEMS) {      // the workgroup's next item, round v (its operand is read when that item starts)
           rnd = v; tgt = 0;
           return pk_any && v < NRND && nb < B;
         }
@@ -516,7 +530,7 @@ __global__ __launch_bounds__(STHREADS) void fused_seq32_kernel(const Seq32Args a
       auto pack_issue = [&](int v) {
         int tgt, rnd;
         if (!pack_target(v, tgt, rnd)) return;
-        const uint16_t* pk_src = a.pk_src0 + ((MODE == 1 || SPLIT) ? 0 : (int64_t)tgt * a.pksrc_stride);
+        const uint16_t* pk_src = a.pk_src0 + ((ITEMS || SPLIT) ? 0 : (int64_t)tgt * a.pksrc_stride);
         constexpr int PPR = NPCK / 8, PIECES = PKROWS * PPR;
         static_assert(PIECES % STHREADS == 0, "whole pieces per thread");
         const uint16_t* xsrc = pk_src + pk_soff + rnd * NPCK;
@@ -535,7 +549,7 @@ __global__ __launch_bounds__(STHREADS) void fused_seq32_kernel(const Seq32Args a
       auto pack_drain = [&](int v) {
         int tgt, rnd;
         if (!pack_target(v, tgt, rnd)) return;
-        uint16_t* pk_dst = a.pk_dst0 + ((MODE == 1 || SPLIT) ? 0 : (int64_t)tgt * a.pkdst_stride);
+        uint16_t* pk_dst = a.pk_dst0 + ((ITEMS || SPLIT) ? 0 : (int64_t)tgt * a.pkdst_stride);
         constexpr int PCS = PKROWS / 8, RI = PCS * NPCK / STHREADS;
         static_assert(PCS * NPCK % STHREADS == 0, "whole row pieces per thread");
         typedef __attribute__((__vector_size__(4 * sizeof(unsigned int)))) unsigned int u32x4_t;
@@ -613,15 +627,32 @@ __global__ __launch_bounds__(STHREADS) void fused_seq32_kernel(const Seq32Args a
       // of the tap's weight reads a few hundred cycles later and sat out the whole HBM latency: hop 1 took ~200 units instead of ~75
       // (profiles/r04_seq32_stamps_chain.txt).
       typedef __attribute__((__vector_size__(4 * sizeof(unsigned int)))) unsigned int u32x4e_t;
-      [[maybe_unused]] u32x4e_t eph[MODE == 2 ? STILES : 1], epg[MODE == 2 ? STILES : 1];
+      [[maybe_unused]] u32x4e_t eph[MODE == 2 ? STILES : 1], epg[SONLY ? STILES : 1];
+      [[maybe_unused]] float epn[MODE == 4 ? STILES : 1][2];      // MODE 4: this lane's node's input / forget gate per tile
 #ifndef GCRNN_SEQ32_EP_FIRST
 #define GCRNN_SEQ32_EP_FIRST 1      // the requests in front of the hop's write-back (0: behind it; same-box A/B: profiles/r04_seq32_chain_requests_ab.txt)
 #endif
 #ifndef GCRNN_SEQ32_EP_EARLY
 #define GCRNN_SEQ32_EP_EARLY 0      // 1: all of them in front of hop 1 (A/B)
 #endif
-      constexpr int EPH = (MODE == 2 && K >= 4 && !GCRNN_SEQ32_EP_EARLY) ? K - 2 : 0;
+      constexpr int EPH = (SONLY && K >= 4 && !GCRNN_SEQ32_EP_EARLY) ? K - 2 : 0;
       auto ep_request = [&](auto i0c, auto i1c) __attribute__((always_inline)) {
+        if constexpr (MODE == 4) {
+          constexpr int I0 = decltype(i0c)::value, I1 = decltype(i1c)::value;
+          const int lq = lane_now();
+          int swp[STILES];
+          slot_words(lq, swp);
+          const __amdgpu_buffer_rsrc_t rsrc_eg = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(ep_dh), 0, ep_dh ? B * (NP * F * 2) : 0, 0x00020000);
+          const __amdgpu_buffer_rsrc_t rsrc_n = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ep_ng), 0, (int)(a.nghalf * 8), 0x00020000);      // ni | nf, 2 x nghalf floats; rows >= N: out of range -> 0
+#pragma unroll
+          for (int i = I0; i < I1; ++i) {
+            const int node = swp[i] >> 16;
+            epg[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_eg, node * (F * 2) + (chunk * 32 + (lq >> 4) * 8) * 2, b * (NP * F * 2), 0);
+            const int go = node < N ? (b * N + node) * 4 : 0x7ffffff0;
+            epn[i][0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc_n, go, 0, 0));
+            epn[i][1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc_n, go, (int)(a.nghalf * 4), 0));
+          }
+        }
         if constexpr (MODE == 2) {
           constexpr int I0 = decltype(i0c)::value, I1 = decltype(i1c)::value;
           const int lq = lane_now();
@@ -637,7 +668,7 @@ __global__ __launch_bounds__(STHREADS) void fused_seq32_kernel(const Seq32Args a
           }
         }
       };
-      if constexpr (MODE == 2 && EPH == 0) ep_request(std::integral_constant<int, 0>{}, std::integral_constant<int, STILES>{});
+      if constexpr (SONLY && EPH == 0) ep_request(std::integral_constant<int, 0>{}, std::integral_constant<int, STILES>{});
       // ---- Horner hops on the two-plane bf16 image; the tap a hop adds accumulates onto its sums --------------------------------
       auto hop = [&](auto jc) __attribute__((always_inline)) {
         constexpr int j = decltype(jc)::value;
@@ -689,7 +720,7 @@ __global__ __launch_bounds__(STHREADS) void fused_seq32_kernel(const Seq32Args a
         lds_barrier();      // every wave has left the image (and the weights, after the last hop); every piece of the pack tile is in
         GCRNN_STAMP32(1 + chunk * 24 + 4 * (j - 1) + 3);
 #if GCRNN_SEQ32_EP_FIRST      // (A/B: the requests in front of the write-back instead of behind it)
-        if constexpr (MODE == 2 && EPH > 0 && j <= EPH)
+        if constexpr (SONLY && EPH > 0 && j <= EPH)
           ep_request(std::integral_constant<int, (j - 1) * STILES / (EPH > 0 ? EPH : 1)>{}, std::integral_constant<int, j * STILES / (EPH > 0 ? EPH : 1)>{});
 #endif
         if (j < K - 1) {
@@ -712,7 +743,7 @@ __global__ __launch_bounds__(STHREADS) void fused_seq32_kernel(const Seq32Args a
           }
         }
 #if !GCRNN_SEQ32_EP_FIRST
-        if constexpr (MODE == 2 && EPH > 0 && j <= EPH)
+        if constexpr (SONLY && EPH > 0 && j <= EPH)
           ep_request(std::integral_constant<int, (j - 1) * STILES / (EPH > 0 ? EPH : 1)>{}, std::integral_constant<int, j * STILES / (EPH > 0 ? EPH : 1)>{});
 #endif
         if (j < K - 1) lds_barrier();      // the image is complete (and the pack tile read)
@@ -724,7 +755,7 @@ __global__ __launch_bounds__(STHREADS) void fused_seq32_kernel(const Seq32Args a
       typedef __attribute__((__vector_size__(4 * sizeof(unsigned int)))) unsigned int u32x4_t;
       const int lane = lane_now(), q = lane >> 4, tl = wave * 64 + lane;
       auto request_next_operand = [&]() {
-        if (MODE == 1 || !(last && more)) return;
+        if (ITEMS || !(last && more)) return;
         // the next step's operand: x_{t+1} (laid out two steps ahead, or by the caller) and the state features of the earlier chunks
         // (stored -- and waited for -- at their chunk's end); the last chunk's come from this epilogue's registers below
         const int qo = lane_now() >> 4;
@@ -748,12 +779,12 @@ __global__ __launch_bounds__(STHREADS) void fused_seq32_kernel(const Seq32Args a
         }
       };
       if (GCRNN_SEQ32_OPERAND_AT == 0) request_next_operand();
-      if (MODE == 1) GCRNN_STAMP32(1 + chunk * 24 + 19);      // (diagnostic builds: start of the epilogue proper)
+      if (ITEMS) GCRNN_STAMP32(1 + chunk * 24 + 19);      // (diagnostic builds: start of the epilogue proper)
       float bs[2][4];
 #pragma unroll
       for (int h = 0; h < 2; ++h)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) bs[h][e] = (gin + gfo) * lbias[chunk * 32 + q * 8 + h * 4 + e];      // the one bias is added by both filters (graphML.py:2420-2421): 2 b, or (gi + gf) b
+        for (int e = 0; e < 4; ++e) bs[h][e] = (MODE >= 3 ? 1.f : (gin + gfo)) * lbias[chunk * 32 + q * 8 + h * 4 + e];      // (modes 3, 4: ONE filter's bias)      // the one bias is added by both filters (graphML.py:2420-2421): 2 b, or (gi + gf) b
       u32x4_t pkd[STILES];
       int swe[STILES];
       slot_words(lane, swe);
@@ -845,6 +876,42 @@ __global__ __launch_bounds__(STHREADS) void fused_seq32_kernel(const Seq32Args a
         for (int off = 32; off > 0; off >>= 1) part += __shfl_down(part, off, 64);
         if (lane == 0) a.go[(int64_t)b * (NCH * SWAVES) + chunk * SWAVES + wave] = part;
         }
+      } else if constexpr (MODE == 3) {
+        // filter-output pass: A(S) x_t + b as it is (bf16), [items][NP][F]
+        const __amdgpu_buffer_rsrc_t rsrc_c = __builtin_amdgcn_make_buffer_rsrc(a.out0, 0, B * (NP * F * 2), 0x00020000);
+#pragma unroll
+        for (int i = 0; i < STILES; ++i) {
+          const int node = swe[i] >> 16;
+          u32x4_t p{0u, 0u, 0u, 0u};
+          if (node < N) {
+            const f32x4 a0 = acc[i][0], a1 = acc[i][1];
+            p[0] = pack2bf(a0[0] + bs[0][0], a0[1] + bs[0][1]); p[1] = pack2bf(a0[2] + bs[0][2], a0[3] + bs[0][3]);
+            p[2] = pack2bf(a1[0] + bs[1][0], a1[1] + bs[1][1]); p[3] = pack2bf(a1[2] + bs[1][2], a1[3] + bs[1][3]);
+          }
+          __builtin_amdgcn_raw_buffer_store_b128(p, rsrc_c, node * (F * 2) + (chunk * 32 + q * 8) * 2, b * (NP * F * 2), 0);
+        }
+      } else if constexpr (MODE == 4) {
+        // node-gated step: the x part comes from the all-items pass, both parts are scaled per node (and per sequence)
+#pragma unroll
+        for (int i = 0; i < STILES; ++i) {
+          const int node = swe[i] >> 16;
+          u32x4_t p{0u, 0u, 0u, 0u};
+          if (node < N) {
+            const float ni = gin * epn[i][0], nf = gfo * epn[i][1];
+            float yv[8], rw[8];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              yv[2 * e] = bf2f((uint16_t)(epg[i][e] & 0xffffu)); yv[2 * e + 1] = bf2f((uint16_t)(epg[i][e] >> 16));
+              rw[e] = acc[i][0][e] + bs[0][e]; rw[4 + e] = acc[i][1][e] + bs[1][e];
+            }
+            float o[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = fast_tanh(ni * yv[e] + nf * rw[e]);
+            p[0] = pack2bf(o[0], o[1]); p[1] = pack2bf(o[2], o[3]); p[2] = pack2bf(o[4], o[5]); p[3] = pack2bf(o[6], o[7]);
+          }
+          pkd[i] = p;
+          __builtin_amdgcn_raw_buffer_store_b128(p, rsrc_o, node * (F * 2) + (chunk * 32 + q * 8) * 2, b * (NP * F * 2), 0);
+        }
       } else if constexpr (MODE == 2) {
         // BPTT data step: the hops applied sum_k (S)^k (dpre_t B_k^T) = d h_{t-1} (recurrent part, scaled by the forget gate of the step it came
         // through); add the upstream gradient and go through tanh': dpre_{t-1} = (gsc acc + dH_{t-1}) (1 - h_{t-1}^2); without dH the raw state
@@ -912,13 +979,13 @@ __global__ __launch_bounds__(STHREADS) void fused_seq32_kernel(const Seq32Args a
       }
       }
       GCRNN_STAMP32(1 + chunk * 24 + 17);
-      if (MODE != 1 && last) {
+      if (!ITEMS && last) {
         // h_t's last 32 features ARE the lanes' B fragments of k-step HS-1: handed to the next step in registers
 #pragma unroll
         for (int i = 0; i < STILES; ++i) bfr[i][HS - 1] = __builtin_bit_cast(bf16x8, pkd[i]);
       }
       if (GCRNN_SEQ32_OPERAND_AT == 1) request_next_operand();
-      if constexpr (MODE == 1) {
+      if constexpr (ITEMS) {
         // the workgroup's next item: its input was laid out by this item's pack rounds (stored, waited for and behind barriers since the
         // first half of the hops) or by the caller; its state operand is h0
         if (last && b + (int)gridDim.x < B && !GCRNN_SEQ32_NO_ITEM_PREFETCH) {

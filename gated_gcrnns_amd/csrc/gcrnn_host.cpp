@@ -9,7 +9,7 @@
 #include <vector>
 #include "../../include/gcrnn.h"
 
-extern "C" int gcrnn_version(void) { return 118; }  // 0.1.18 (round 4: rank-1 parameters on the wide and x3 entries, gated x3 entries, one-pass node gate filter)
+extern "C" int gcrnn_version(void) { return 119; }  // 0.1.19 (round 5: hand-allocated-hop forward kernel, node-gated passes on the wide kernel)
 
 extern "C" const char* gcrnn_status_string(int status) {
   switch (status) {

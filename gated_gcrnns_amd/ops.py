@@ -1210,15 +1210,34 @@ def fused_node_cell_forward(X, h0, wA, wB, bias, graph, node_gates, time_gates=N
                 wA_g = torch.nn.functional.pad(wA_g.detach(), (0, G - wA_g.shape[3]))
             g[name] = fused_time_gate(xs, h0s, wA_g, wB_g, bias_g, lin_w, lin_b, graph, N, hzero=hzero)
         gi, gf = g['in'], g['forget']
-    yx = fused_filter_output(xs, wA, bias, graph, K, N)
+    plan16 = fused_img16_plan(graph, False, None)
+    uw = float(plan.get('uniform_w', 0.0))
+    b32 = _bias_f32(bias, st)
+    # (round 5) both state-size passes on the WIDE kernel when it takes them: A(S) x_t + b over all items (mode 3) and the recurrence with the
+    # per-node gates in its epilogue as ONE launch (mode 4); else round 3's 16-feature kernels
+    if plan16 is not None and F % 32 == 0 and G % 32 == 0 and lib.gcrnn_fused_filter_output_wide_supported(B, T, N, F, G, K, int(plan16['entries']), uw, 1):
+        wpx = _fused_pack_weights_wide(wA.detach(), wA.new_zeros((F, 1, K, F)), uw, st)      # (zero state taps, K of them: the pack's tap count is the kernel's)
+        yx = torch.empty((T, B, plan['npad'], F), dtype=torch.bfloat16, device=X.device)
+        check(lib.gcrnn_fused_filter_output_wide_bf16(_p(xs), _p(wpx), _p(b32), _p(yx), _p(plan16['tile_slots']), _p(plan16['tile_off']),
+                                                      _p(plan16['ell_col4']), plan16['entries'], B, T, N, F, G, K, st), 'fused_filter_output_wide')
+    else:
+        yx = fused_filter_output(xs, wA, bias, graph, K, N)
+    H = torch.empty((B, 1 if last_only else T, F, N), dtype=torch.bfloat16, device=X.device)
+    direct = (N % 8 == 0)
+    if plan16 is not None and F % 32 == 0 and lib.gcrnn_fused_node_forward_wide_supported(B, T, N, F, K, int(plan16['entries']), uw, 1):
+        wBk = wB.detach() if Kst == K else torch.cat([wB.detach(), wB.new_zeros(F, 1, K - Kst, F)], dim=2)
+        wpBw = _fused_pack_weights_wide(wB.new_zeros((F, 1, 1, 0)), wBk, uw, st)      # (state-only operand: G = 0)
+        check(lib.gcrnn_fused_node_forward_wide_bf16(_p(h0s), _p(hs), _p(yx), _p(ngates), _p(gi), _p(gf), _p(wpBw), _p(b32), _p(plan16['tile_slots']),
+                                                     _p(plan16['tile_off']), _p(plan16['ell_col4']), plan16['entries'], B, T, N, F, K,
+                                                     _p(H) if direct else None, int(last_only), st), 'fused_node_forward_wide')
+        if not direct:
+            src = hs[T - 1:] if last_only else hs
+            check(lib.gcrnn_unpack_seq_major(_lib.BF16, _p(src), _p(H), B, 1 if last_only else T, F, N, plan['npad'], None, st), 'unpack_seq')
+        return H
     def pack_state():
         wBk = wB.detach() if Kst == K else torch.cat([wB.detach(), wB.new_zeros(F, 1, K - Kst, F)], dim=2)
         return _fused_pack_state_taps(wBk, K, st)
     wpB = _cached_pack('statetaps', (wB.detach(),), int(K), st, pack_state)
-    b32 = _bias_f32(bias, st)
-    H = torch.empty((B, 1 if last_only else T, F, N), dtype=torch.bfloat16, device=X.device)
-    direct = (N % 8 == 0)
-    plan16 = fused_img16_plan(graph, False, None)
     check(lib.gcrnn_fused_node_forward_bf16(_p(h0s), _p(hs), _p(yx), _p(ngates), _p(gi), _p(gf), _p(wpB), _p(b32), None,
                                             *_fused_graph_args(plan16 or plan), B, T, N, F, K, _p(H) if direct else None,
                                             int(last_only) | (2 if plan16 else 0), plan.get('uniform_w', 0.0), st),

@@ -461,6 +461,26 @@ int gcrnn_fused_backward_data_wide_bf16(const void* dHs, const void* hs, void* d
                                         const int32_t* tile_off, const void* ell_col4, int64_t entries, int64_t B, int64_t T, int64_t N,
                                         int64_t F, int64_t K, const float* gf, const void* h0s, float* dgf_parts, const void* dHuser_inline,
                                         const float* rank1_a, const float* rank1_b, void* stream);
+/* Round 5: the node-gated cell's two state-size passes on the wide kernel (csrc/gcrnn_fused_seq32.h modes 3 and 4; reference
+ * Utils/graphML.py:2379-2407, 2420-2423). Until round 4 they ran the 16-feature kernels (gcrnn_fused_filter_output_bf16,
+ * gcrnn_fused_node_forward_bf16: 1.45 + 1.75 ms per forward at N = 1000, F = G = 64, K = 5, T = 32, B = 256).
+ * gcrnn_fused_filter_output_wide_bf16: A(S) x_t + b for every (t, b) item in ONE launch -- xs [T][B][NPad][G] bf16 sequence-major, wpack =
+ *   gcrnn_fused_pack_weights_wide(Fout = F) of the input taps with ZERO state taps (operand [0 | x_t]; the state half is neither loaded nor
+ *   multiplied), bias [F] fp32 or NULL, out [T][B][NPad][F] bf16 (no activation).
+ * gcrnn_fused_node_forward_wide_bf16: gcrnn_fused_node_forward_bf16's contract without yh_out (inference) as ONE launch: h0s [B][NPad][F], hs
+ *   [T][B][NPad][F] (out), yx = the filter-output pass, ngates fp32 [T][2][B][N] (input gates, forget gates), gi / gf fp32 [T][B] or both NULL,
+ *   wpackB = gcrnn_fused_pack_weights_wide of the state taps alone (G = 0), Huser [B][T or 1][F][N] bf16 or NULL.
+ * The _supported queries return 1 when the problem is taken (uniform-weight bf16-image plan: img16 == 1, a batch that fills the chip, LDS room). */
+int gcrnn_fused_filter_output_wide_supported(int64_t B, int64_t T, int64_t N, int64_t F, int64_t G, int64_t K, int64_t entries, double uniform_w,
+                                             int img16);
+int gcrnn_fused_filter_output_wide_bf16(const void* xs, const void* wpack, const float* bias, void* out, const int32_t* tile_nodes,
+                                        const int32_t* tile_off, const void* ell_col4, int64_t entries, int64_t B, int64_t T, int64_t N,
+                                        int64_t F, int64_t G, int64_t K, void* stream);
+int gcrnn_fused_node_forward_wide_supported(int64_t B, int64_t T, int64_t N, int64_t F, int64_t K, int64_t entries, double uniform_w, int img16);
+int gcrnn_fused_node_forward_wide_bf16(const void* h0s, void* hs, const void* yx, const float* ngates, const float* gi, const float* gf,
+                                       const void* wpackB, const float* bias, const int32_t* tile_nodes, const int32_t* tile_off,
+                                       const void* ell_col4, int64_t entries, int64_t B, int64_t T, int64_t N, int64_t F, int64_t K, void* Huser,
+                                       int huser_last_only, void* stream);
 int gcrnn_fused_gate_pair_prepass_wide_bf16(const void* x_user, void* xs, const void* h0, const void* wpack, const float* bias2,
                                             const float* gw2, float* parts, void* cs_in, void* cs_f, const int32_t* tile_nodes,
                                             const int32_t* tile_off, const void* ell_col4, int64_t entries, int64_t B, int64_t T, int64_t N,

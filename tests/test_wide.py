@@ -56,6 +56,8 @@ def test_wide_kernel_matches_oracle(N, F, G, K, B, T, monkeypatch):
     Xd = torch.tensor(X, dtype=torch.bfloat16, device=dev)
     hd = torch.tensor(h0, dtype=torch.bfloat16, device=dev)
     monkeypatch.setenv('GCRNN_SEQ32_MIN_B', '1')
+    monkeypatch.setenv('GCRNN_SEQ32P', '0')             # round 4's kernel for every variant (bit-equal within ONE kernel; the hand-allocated-hop kernel,
+                                                        # which carries the native view by default, has its own oracle test below)
     Gp = ops.fused_padded_inputs(F, G)
     assert ops.fused_wide_plan(cell.graph, B, T, N, F, Gp, K, N % 8 == 0) is not None
     with torch.no_grad():
@@ -119,10 +121,14 @@ def test_hand_allocated_hop_kernel_matches_oracle(N, F, G, K, B, T, monkeypatch)
         monkeypatch.delenv('GCRNN_NO_INLINE_PACK')
         cell.native_layout = True
         Hn = cell(Xd, hd)
-        monkeypatch.delenv('GCRNN_SEQ32P')                # the default dispatch: the native view runs it, too
-        Hd = cell(Xd, hd)
         cell.native_layout = False
-    assert torch.equal(H, H2) and torch.equal(H[:, -1:], Hl) and torch.equal(H, Hn.contiguous()) and torch.equal(Hn, Hd)
+        monkeypatch.delenv('GCRNN_SEQ32P')                # the default dispatch: sequence-major in AND out runs it, too
+        Xp, _ = ops.fused_pad_operands(Xd, cell.weight_A.detach())
+        xs = ops.to_sequence_major(Xp, cell.graph)
+        h0s = ops.to_sequence_major(hd.unsqueeze(1), cell.graph)[0]
+        hs = cell.forward_native(xs, h0s)
+    assert torch.equal(H, H2) and torch.equal(H[:, -1:], Hl) and torch.equal(H, Hn.contiguous())
+    assert torch.equal(hs.permute(1, 0, 3, 2)[:, :, :, :N], H) and float(hs[:, :, N:].abs().max()) == 0.0
     err = np.abs(H[:nb].double().cpu().numpy() - Href)
     err4 = np.abs(H4[:nb].double().cpu().numpy() - Href)
     tol1 = 2.5e-2 if G == 1 else 4.0e-3
@@ -830,6 +836,60 @@ def test_node_gate_pair_prepass_on_the_wide_kernel(N, F, G, K, B, T, hz, monkeyp
     d = (H.float() - H16.float()).abs()
     assert float(d.max()) <= 2.5e-2 and float(d.mean()) <= 1.5e-3, (float(d.max()), float(d.mean()))
     assert float(d.max()) > 0.0 or N < 100      # (two kernel families: not the same bits)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('N,F,G,K,B,T,tg,hz', [(1000, 64, 64, 5, 3, 4, False, False), (1000, 64, 64, 5, 2, 3, True, True), (400, 32, 32, 3, 4, 3, False, True),
+                                               (1000, 64, 32, 4, 3, 3, False, False), (1004, 64, 64, 2, 2, 3, True, False), (1000, 64, 1, 3, 2, 3, False, True)])
+def test_node_gated_passes_on_the_wide_kernel_match_oracle(N, F, G, K, B, T, tg, hz, monkeypatch):
+    """Round 5: the node-gated cell's two state-size passes on the wide kernel -- A(S) x_t + b over all (t, b) items (mode 3,
+    gcrnn_fused_filter_output_wide_bf16) and the recurrence h_t = tanh(gi ni_t . Yx_t + gf nf_t . (B(S) h_{t-1} + b)) as ONE launch with the
+    per-node gates in its epilogue (mode 4, gcrnn_fused_node_forward_wide_bf16); reference Utils/graphML.py:2379-2407, 2420-2423. Against the
+    fp64 oracle on bf16-rounded operands, against round 3's 16-feature passes (GCRNN_SEQ32_NODE=0) within bf16 noise, last state only, and a
+    node count that is not a multiple of 8 (the user-layout copy as a separate pass)."""
+    import gated_gcrnns_amd.Utils.graphML as gml
+    from gated_gcrnns_amd import _lib
+    dev = torch.device('cuda:0')
+    rng = np.random.default_rng(131)
+    W = (rng.random((N, N)) < 10.0 / N).astype(np.float64)
+    W = np.triu(W, 1); W = W + W.T
+    S = (W / np.max(np.abs(np.linalg.eigvalsh(W)))).reshape(1, N, N)
+    torch.manual_seed(131)
+    cell = gml.GGCRNNCell(G, F, K, K, torch.tanh, tg, 'node', 1, True)
+    cell.addGSO(torch.tensor(S))
+    cell = cell.float()
+    with torch.no_grad():
+        for q in cell.parameters():
+            q.copy_(torch.tensor(bf16_round(q.detach().numpy())))
+    X = bf16_round(rng.standard_normal((B, T, G, N)))
+    h0 = np.zeros((B, F, N)) if hz else bf16_round(0.3 * rng.standard_normal((B, F, N)))
+    params = {k: v.detach().double().numpy() for k, v in cell.state_dict().items()}
+    Href = orc.ggcrnn_cell(params, S.astype(np.float32).astype(np.float64), X, h0, tg, 'node')
+    cell = cell.to(torch.bfloat16).to(dev)
+    Xd = torch.tensor(X, dtype=torch.bfloat16, device=dev)
+    hd = torch.tensor(h0, dtype=torch.bfloat16, device=dev)
+    monkeypatch.setenv('GCRNN_SEQ32_MIN_B', '1')
+    calls = []
+    orig = _lib.lib.gcrnn_fused_node_forward_wide_bf16
+    p16 = cell.graph.fused_plan_img16()
+    Gp = 32 if G < 32 else G
+    assert _lib.lib.gcrnn_fused_filter_output_wide_supported(B, T, N, F, Gp, K, int(p16['entries']), float(p16['uniform_w']), 1) == 1
+    assert _lib.lib.gcrnn_fused_node_forward_wide_supported(B, T, N, F, K, int(p16['entries']), float(p16['uniform_w']), 1) == 1
+    with torch.no_grad():
+        assert cell._use_fused_node(Xd, hd)
+        H = cell(Xd, hd)
+        Hl = cell(Xd, hd, last_only=True)
+        monkeypatch.setenv('GCRNN_SEQ32_NODE', '0')
+        assert _lib.lib.gcrnn_fused_node_forward_wide_supported(B, T, N, F, K, int(p16['entries']), float(p16['uniform_w']), 1) == 0
+        H16 = cell(Xd, hd)
+    assert torch.equal(H[:, -1:], Hl)
+    err = np.abs(H.double().cpu().numpy() - Href)
+    err16 = np.abs(H16.double().cpu().numpy() - Href)
+    tolm = 6.0e-2 if G == 1 else 2.5e-2
+    assert err.max() <= tolm and err.mean() <= (3.0e-3 if G == 1 else 1.5e-3), (err.max(), err.mean())
+    assert err.mean() <= max(1.0e-3, 1.5 * err16.mean()), (err.mean(), err16.mean())
+    d = (H.float() - H16.float()).abs()
+    assert float(d.max()) <= (6e-2 if G == 1 else 2.5e-2) and float(d.mean()) <= 2.0e-3, (float(d.max()), float(d.mean()))
 
 
 @pytest.mark.gpu
