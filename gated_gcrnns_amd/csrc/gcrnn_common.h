@@ -20,6 +20,17 @@ extern "C" void gcrnn_note_hip_error(int code, const char* what);
 
 static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
+// Workgroups of a persistent launch of the sequence-resident kernels: one per compute unit, read from the device ONCE (256 on MI355X;
+// the same number where no device answers -- the CPU-side queries of the tests).
+static inline int gcrnn_persistent_grid() {
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) cus = n;
+    else cus = 256;
+  }
+  return cus;
+}
 static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 // 16-byte vector of T (4 x f32 or 2 x f64)

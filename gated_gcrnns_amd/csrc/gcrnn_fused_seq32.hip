@@ -129,7 +129,7 @@ static int seq32_launch_v(const Seq32Args& sa, size_t lds, hipStream_t st) {
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(sk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
     return GCRNN_ERR_LAUNCH;
   GCRNN_PRE_LAUNCH();
-  sk<<<(unsigned)(sa.B < 256 ? sa.B : 256), STHREADS, lds, st>>>(sa);
+  sk<<<(unsigned)(sa.B < gcrnn_persistent_grid() ? sa.B : gcrnn_persistent_grid()), STHREADS, lds, st>>>(sa);      // one workgroup per CU (count read from the device once)
   GCRNN_CHECK_LAUNCH();
   return GCRNN_OK;
 }
@@ -143,7 +143,7 @@ static int seq32_launch_split(const Seq32Args& sa0, size_t lds, int64_t T, int64
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(sk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
       return GCRNN_ERR_LAUNCH;
     const int64_t xstep = (int64_t)sa0.B * NP * G, hstep = (int64_t)sa0.B * NP * F;
-    const unsigned grid = (unsigned)((int64_t)sa0.B * HS < 256 ? (int64_t)sa0.B * HS : 256 / HS * HS);
+    const unsigned grid = (unsigned)((int64_t)sa0.B * HS < gcrnn_persistent_grid() ? (int64_t)sa0.B * HS : gcrnn_persistent_grid() / HS * HS);
     GCRNN_PRE_LAUNCH();
     for (int64_t t = 0; t < T; ++t) {
       Seq32Args s1 = sa0;
@@ -293,7 +293,7 @@ extern "C" int gcrnn_fused_gate_pair_wide_supported(int64_t B, int64_t T, int64_
   if (!seq32_wanted(B * T)) return 0;
   if (!seq32_lds_for(F, G, K, entries, with_pack != 0, (img16 & 2) != 0)) return 0;      // (img16 bit 1: rank-1-weighted graph)
   if (!with_pack) return 1;
-  const int64_t first = B * T < 256 ? B * T : 256;      // the items of the first round of workgroups
+  const int64_t first = B * T < gcrnn_persistent_grid() ? B * T : gcrnn_persistent_grid();      // the items of the first round of workgroups
   return (int)((first + B - 1) / B);
 }
 
@@ -378,7 +378,7 @@ static int seq32_launch_chain_split(const Seq32Args& sa0, size_t lds, int64_t T,
     auto sk = fused_seq32_kernel<K, HS, 0, VAR, 2, false, false, true>;
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(sk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
       return GCRNN_ERR_LAUNCH;
-    const unsigned grid = (unsigned)((int64_t)sa0.B * HS < 256 ? (int64_t)sa0.B * HS : 256 / HS * HS);
+    const unsigned grid = (unsigned)((int64_t)sa0.B * HS < gcrnn_persistent_grid() ? (int64_t)sa0.B * HS : gcrnn_persistent_grid() / HS * HS);
     const int64_t hstep = (int64_t)sa0.B * NP * F;
     GCRNN_PRE_LAUNCH();
     for (int64_t i = 0; i + 1 < T; ++i) {      // chain step i: t = T-1-i

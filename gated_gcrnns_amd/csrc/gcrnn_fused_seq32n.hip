@@ -23,7 +23,7 @@ static int seq32n_launch(const Seq32Args& sa, hipStream_t st) {
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(sk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
     return GCRNN_ERR_LAUNCH;
   GCRNN_PRE_LAUNCH();
-  sk<<<(unsigned)(sa.B < 256 ? sa.B : 256), STHREADS, lds, st>>>(sa);
+  sk<<<(unsigned)(sa.B < gcrnn_persistent_grid() ? sa.B : gcrnn_persistent_grid()), STHREADS, lds, st>>>(sa);      // one workgroup per CU (count read from the device once)
   GCRNN_CHECK_LAUNCH();
   return GCRNN_OK;
 }

@@ -670,6 +670,17 @@ def _grad_scale_and_bounds(name, grads, mx, mean):
     return sc, mx, mean
 
 
+def _load_g9_gates():
+    import json
+    f = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'g9_gradient_gates.json')
+    if os.environ.get('GCRNN_TOL_REPORT') or not os.path.exists(f):      # (a measuring run uses the class-level gates)
+        return {}
+    return json.load(open(f))
+
+
+_G9_GATES = _load_g9_gates()
+
+
 def _tol_report(line):
     """GCRNN_TOL_REPORT=<file>: append the measured error ratios (the gates sit at <= 2x the worst measured: tools/tolerance_probe.py)."""
     f = os.environ.get('GCRNN_TOL_REPORT')
@@ -737,6 +748,12 @@ def test_fused_bptt_matches_reference_autograd_fixture(golden, name, tg, sg, los
                 mx, mn = 1.3e-2, 4e-3
             else:
                 mx, mn = 1.3e-2, 2.2e-3
+        # round 5: ONE gate per parameter at 2x what was measured for it (tests/golden/g9_gradient_gates.json, written by
+        # tools/make_gradient_gates.py from a GCRNN_TOL_REPORT run on an MI355X; the kernels are bit-reproducible, so the measured ratios are
+        # the same on every run); the class-level gates above stay as the ceiling and for parameters the table does not list
+        pg = _G9_GATES.get('g9 %s %s %s' % (name, loss, k))
+        if pg is not None:
+            mx, mn = min(mx, max(2.0 * pg[0], 2e-4)), min(mn, max(2.0 * pg[1], 1e-4))
         _tol_report('g9 %s %s %s max %.3e mean %.3e (gate %.1e / %.1e)' % (name, loss, k, e.max() / sc, e.mean() / sc, mx, mn))
         assert sc > 0 and e.max() <= mx * sc and (e.size < 16 or e.mean() <= mn * sc), (k, e.max() / sc, e.mean() / sc)
         checked += 1
