@@ -186,14 +186,19 @@ class GraphedTrainStep(object):
         self.graph = torch.cuda.CUDAGraph()
         if not self.flat:
             self.optim.zero_grad(set_to_none=True)
-        with torch.cuda.graph(self.graph):
+        # Captured on the warm-up's OWN side stream (as ops.FusedForwardGraph does). Captured on torch.cuda.graph's default stream -- another one
+        # than the stream the warm-up created the autograd accumulators on -- every capture AFTER THE FIRST of a process replayed a step whose
+        # forward was not the eager one: same parameters, loss 0.2059 against the eager 0.1611, the same wrong value on every replay, for the
+        # time-gated N = 80 model at B = 256, F = 64 (round 5: tools/experiments/train_sweep_debug3.py; tools/train_steps_sweep.py caught it as
+        # a loss trajectory one step behind). With one stream for warm-up and capture every run replays the eager step bit for bit.
+        with torch.cuda.graph(self.graph, stream=s):
             self._segment_backward(first_capture=not self.flat)
             if sync is None:
                 self.optim.step()
         self.graph_step = None
         if sync is not None:
             self.graph_step = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph_step):
+            with torch.cuda.graph(self.graph_step, stream=s):
                 self.optim.step()
 
     def _segment_backward(self, first_capture=False):
@@ -210,11 +215,9 @@ class GraphedTrainStep(object):
     def _eager(self):
         self._segment_backward()
         if self.captured:
-            # (warm-up only) The gradients are persistent views of the flat buffer, so every backward ends in AccumulateGrad nodes that ADD
-            # in place -- on the stream their accumulators were created on (the default stream: "AccumulateGrad node's stream does not match"),
-            # not on the warm-up's side stream. The optimiser step issued on the side stream must not overtake them: without this wait a
-            # warm-up step could read the gradient buffer before the accumulation had run (seen in round 5 as a loss trajectory that
-            # started from two effective warm-up steps in one run and three in the next, tools/train_steps_sweep.py).
+            # (warm-up only) The gradients are persistent views of the flat buffer: every backward ends in AccumulateGrad nodes that ADD in place,
+            # on the stream their accumulators were created on. The optimiser step behind them waits for the device here, whatever stream
+            # autograd chose (PyTorch warns "AccumulateGrad node's stream does not match" on this pattern).
             torch.cuda.synchronize(self.x.device)
         if self.sync is not None:
             self.sync.all_reduce_(self.weight)

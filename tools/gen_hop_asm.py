@@ -573,9 +573,15 @@ def gen_wide32_taps(HS, XS, loads=False, lpe=4, fpe=1, depth=None, taps=True):
     D = depth if depth is not None else (2 if loads else int(os.environ.get('GCRNN_P_DEPTH', '2')))
     # exit style: 'A' = two fragment buffers, the next fragment's read IN FRONT of the MFMAs and everything waited for behind them (the first
     # form; needs D == 2); 'B' = one buffer, the read behind the MFMAs, a wait only when the tile was shorter than D - 1 trips
+    # 'C' = the tap MFMAs in groups of GSZ, one group per TRIP (a subroutine the trip calls between issuing its gathers and waiting for the
+    # previous ones; groups of equal byte size, addressed base + index * size), the rest behind the stream -- no bursts: a wave's partner on
+    # the SIMD never finds the matrix pipe taken for 8 MFMAs in a row; two fragment buffers (D == 2)
     style = os.environ.get('GCRNN_P_EXIT', 'A' if D == 2 else 'B')
     if not taps:
         style = 'B'
+    if loads and style == 'C':
+        style = 'A'
+    GSZ = int(os.environ.get('GCRNN_P_GROUP', '3'))
     assert style == 'B' or D == 2
     FO = frag_order(HS, XS) if taps else []      # taps=False: the stream alone (the split form: a wave's tap MFMAs run before or behind its stream)
     NF = len(FO)
@@ -591,8 +597,8 @@ def gen_wide32_taps(HS, XS, loads=False, lpe=4, fpe=1, depth=None, taps=True):
     A0 = alloc(4, True)
     UB = alloc(16 * D, True)
     WF0 = alloc(4, True)
-    WF1 = alloc(4, True) if style == 'A' else WF0
-    WFBn = alloc(1) if style == 'A' else None
+    WF1 = alloc(4, True) if style in ('A', 'C') else WF0
+    WFBn = alloc(1) if style in ('A', 'C') else None
     IDX = alloc(1)
     VCW0 = alloc(D)
     VPn, QXn = alloc(1), alloc(1)
@@ -677,7 +683,7 @@ def gen_wide32_taps(HS, XS, loads=False, lpe=4, fpe=1, depth=None, taps=True):
     L += ['s_add_i32 %s, %s, %d' % (STr, SGr, 2 * D - 1), 'v_lshl_add_u32 %s, %s, 7, %s' % (VP, STr, VCB)]
     if not taps:
         pass
-    elif style == 'A':
+    elif style in ('A', 'C'):
         L += ['v_mbcnt_lo_u32_b32 v%d, -1, 0' % WFBn, 'v_mbcnt_hi_u32_b32 v%d, -1, v%d' % (WFBn, WFBn),
               'v_lshlrev_b32 v%d, 4, v%d' % (WFBn, WFBn), 'v_add_u32 v%d, %s, v%d' % (WFBn, WOFS, WFBn),
               'ds_read_b128 %s, v%d offset:%d' % (WFt, WFBn, foff(0)), 's_waitcnt lgkmcnt(0)']
@@ -736,6 +742,42 @@ def gen_wide32_taps(HS, XS, loads=False, lpe=4, fpe=1, depth=None, taps=True):
                 else:
                     L.append('buffer_load_dwordx4 %s, v%d, %s, %s offen offset:%d' % (tup(OP(s_, i)), LAD, RX, SOX, 64 * (s_ - HS)))
                 n += 1
+
+    SRET, SGRP, SCG, SSV = 's[92:93]', 's[94:95]', 's91', 's96'
+    groups, GBYTES, NG = [], 0, 0
+    if style == 'C':
+        order = [(f, i) for f in range(NF) for i in range(NT)]
+        NG = (len(order) + GSZ - 1) // GSZ
+        GBYTES = 8 * GSZ + 8 + 4 + 4      # GSZ MFMAs, at most one fragment read + s_nop, s_setpc_b64
+        for g in range(NG):
+            G_ = []
+            nbytes = 0
+            for (f, i) in order[g * GSZ:(g + 1) * GSZ]:
+                s_, h = FO[f]
+                wf = WF0 if f % 2 == 0 else WF1
+                if i == 0 and f + 1 < NF:      # the next fragment's read, behind the last MFMA that read its buffer
+                    G_ += ['s_nop 1', 'ds_read_b128 %s, v%d offset:%d' % (tup(WF1 if f % 2 == 0 else WF0), WFBn, foff(f + 1))]
+                    nbytes += 12
+                G_.append('v_mfma_f32_16x16x32_bf16 %s, %s, %s, %s' % (tup(ACC(h, i)), tup(wf), tup(OP(s_, i)), tup(ACC(h, i))))
+                nbytes += 8
+            G_.append('s_setpc_b64 %s' % SRET)
+            nbytes += 4
+            assert nbytes <= GBYTES and (GBYTES - nbytes) % 4 == 0
+            G_ += ['s_nop 0'] * ((GBYTES - nbytes) // 4)      # (behind the return: never executed, keeps the groups one size)
+            groups.append(G_)
+        # prologue: the address of group 0, the group counter
+        L += ['s_getpc_b64 %s' % SGRP, 'L_PC_%=:', 's_add_u32 s94, s94, L_G0_%=-L_PC_%=', 's_addc_u32 s95, s95, 0', 's_mov_b32 %s, 0' % SCG]
+        # (the trip loop keeps its exit condition in scc across the body: re-established below)
+        L += ['s_sub_u32 %s, %s, %%%d' % (SCr, GB, TE), 's_cmp_eq_u32 %s, 0' % SCr]
+
+    def call_group(L):
+        """one tap group, if any is left (scc is the trip loop's: saved and put back)"""
+        L += ['s_cselect_b32 %s, 1, 0' % SSV,
+              's_cmp_ge_u32 %s, %d' % (SCG, NG), 's_cbranch_scc1 L_NG%d_%%=' % len(L),
+              's_swappc_b64 %s, %s' % (SRET, SGRP),
+              's_add_u32 s94, s94, %d' % GBYTES, 's_addc_u32 s95, s95, 0', 's_add_u32 %s, %s, 1' % (SCG, SCG),
+              'L_NG%d_%%=:' % (len(L) - 2),
+              's_cmp_lg_u32 %s, 0' % SSV]
 
     pend = list(queue)
     exits = []
