@@ -705,6 +705,8 @@ def gen_wide32_taps(HS, XS, loads=False, lpe=4, fpe=1, depth=None, taps=True):
 
     def burst(t, L, pending):
         """tile exit t: fragment(s) t * fpe .. of the hop's taps, the next fragment's read, operand requests"""
+        if style == 'C':
+            return
         if style == 'A':
             for f in range(t * fpe, min((t + 1) * fpe, NF)):
                 wf = WF0 if f % 2 == 0 else WF1
@@ -770,14 +772,17 @@ def gen_wide32_taps(HS, XS, loads=False, lpe=4, fpe=1, depth=None, taps=True):
         # (the trip loop keeps its exit condition in scc across the body: re-established below)
         L += ['s_sub_u32 %s, %s, %%%d' % (SCr, GB, TE), 's_cmp_eq_u32 %s, 0' % SCr]
 
+    ngc = [0]
+
     def call_group(L):
         """one tap group, if any is left (scc is the trip loop's: saved and put back)"""
         L += ['s_cselect_b32 %s, 1, 0' % SSV,
-              's_cmp_ge_u32 %s, %d' % (SCG, NG), 's_cbranch_scc1 L_NG%d_%%=' % len(L),
+              's_cmp_ge_u32 %s, %d' % (SCG, NG), 's_cbranch_scc1 L_NG%d_%%=' % ngc[0],
               's_swappc_b64 %s, %s' % (SRET, SGRP),
               's_add_u32 s94, s94, %d' % GBYTES, 's_addc_u32 s95, s95, 0', 's_add_u32 %s, %s, 1' % (SCG, SCG),
-              'L_NG%d_%%=:' % (len(L) - 2),
+              'L_NG%d_%%=:' % ngc[0],
               's_cmp_lg_u32 %s, 0' % SSV]
+        ngc[0] += 1
 
     pend = list(queue)
     exits = []
@@ -800,6 +805,8 @@ def gen_wide32_taps(HS, XS, loads=False, lpe=4, fpe=1, depth=None, taps=True):
             L.append('s_add_u32 %s, %s, 1' % (SCr, SCr))
             gathers(q, L)
             L += ['ds_read_b32 %s, %s' % (VCw(q), VP), 'v_add_u32 %s, 128, %s' % (VP, VP)]
+            if style == 'C':
+                call_group(L)      # this trip's share of the hop's tap MFMAs, while its gathers are in flight
             L.append('s_waitcnt lgkmcnt(%d)' % (5 * (D - 1)))
             L.append('v_smfmac_f32_16x16x64_bf16 %s, %s, v[%d:%d], %s' % (tup(ACC(1, t)), Aop, Y(p, 0), Y(p, 0) + 7, Iop))
             L.append('v_smfmac_f32_16x16x64_bf16 %s, %s, v[%d:%d], %s' % (tup(ACC(0, t)), Aop, Xr(p, 0), Xr(p, 0) + 7, Iop))
@@ -813,6 +820,14 @@ def gen_wide32_taps(HS, XS, loads=False, lpe=4, fpe=1, depth=None, taps=True):
             L.append('s_branch L_T%d_P%d_%%=' % (t + 1, p))
     for p in range(D):
         L.append('L_T%d_P%d_%%=:' % (NT, p))
+    if style == 'C':
+        # the groups the trips did not reach (a wave with fewer trips than groups), back to back; then skip over the group bodies
+        L += ['L_TAIL_%=:', 's_cmp_ge_u32 %s, %d' % (SCG, NG), 's_cbranch_scc1 L_TAILEND_%=', 's_waitcnt lgkmcnt(0)',
+              's_swappc_b64 %s, %s' % (SRET, SGRP), 's_add_u32 s94, s94, %d' % GBYTES, 's_addc_u32 s95, s95, 0',
+              's_add_u32 %s, %s, 1' % (SCG, SCG), 's_branch L_TAIL_%=', 'L_TAILEND_%=:', 's_branch L_END_%=', 'L_G0_%=:']
+        for G_ in groups:
+            L += G_
+        L.append('L_END_%=:')
     L += ['s_nop 15', 's_nop 7', 's_waitcnt lgkmcnt(0)']
     # this wave's LDS-DMA pieces (issued in front of the block) have landed: everything but the operand requests behind them
     L.append('s_waitcnt vmcnt(%d)' % (nloads if loads else 0))
@@ -855,7 +870,7 @@ def main():
         ll, nl = gen_wide32_taps(hs, xs, loads=True, lpe=lpe, fpe=fpe)
         emit('GCRNN_HOP_ASM_P32_LOADS_TEXT_%d_%d' % (hs, xs), ll)
         print('#define GCRNN_HOP_ASM_P32_NLOADS_%d_%d %d' % (hs, xs, nl))
-    print('#define GCRNN_HOP_ASM_P32_CLOBBERS %s, "s88", "s89", "s90", "scc", "vcc", "memory"' % ', '.join('"v%d"' % r for r in range(192, 254)))
+    print('#define GCRNN_HOP_ASM_P32_CLOBBERS %s, "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "s96", "scc", "vcc", "memory"' % ', '.join('"v%d"' % r for r in range(192, 254)))
     print('#define GCRNN_HOP_ASM_WIDE32_CLOBBERS %s, "s88", "s89", "s90", "scc", "vcc", "memory"' % ', '.join('"v%d"' % r for r in range(WIDE_BASE, 254)))
     regs = ', '.join('"v%d"' % r for r in range(UB, UB + 60))
     print('#define GCRNN_HOP_ASM_UNI_CLOBBERS %s, "s88", "s89", "s90", "scc", "memory"' % regs)
