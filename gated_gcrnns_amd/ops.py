@@ -1885,6 +1885,109 @@ def _x3_time_gated_forward(X, h0, wA, wB, bias, graph, gates, keep=False, last_o
 
 
 
+def fused_node_x3_supported(graph, N, F, G, Kin, Kst, dtype, E=1, B=None, T=None):
+    """Node-gated cell at fp32 accuracy on the x3 kernels (fused_node_cell_forward_x3): the x3 forward's conditions with G == F (the input
+    filter runs as an F -> F x3 filter pass over the planes of X)."""
+    return G == F and fused_x3_supported(graph, N, F, G, Kin, Kst, dtype, E, B, T) and not os.environ.get('GCRNN_NO_X3_NODE')
+
+
+def fused_node_cell_forward_x3(X, h0, wA, wB, bias, graph, node_gates, time_gates=None, last_only=False):
+    """Node-gated GGCRNNCell forward (optionally time-gated too) to fp32 accuracy on the fp32-accurate fused kernels (round 5; reference
+    Utils/graphML.py:2379-2407, 2420-2423, in the drivers' precision class, kStepPredGRNNs.py:44):
+        h_t = tanh( gi_t ni_t (.) (A(S) x_t + b) + gf_t nf_t (.) (B(S) h_{t-1} + b) )
+    * both gate cells as T x B one-step x3 cells on the planes of X (gcrnn_fused_gate_cells_x3: they read (x_t, h0), never h_{t-1}), their
+      F -> 1 graph filters on the fp32 any-shape filter kernels (lsigf_node_major), sigmoid;
+    * A(S) x_t for all steps and B(S) h_{t-1} per step as x3 filter passes (gcrnn_fused_filter_x3: three bf16 planes per operand, exact fp32
+      products on the matrix cores), the per-node gating and the tanh in fp32 between them -- the per-node gates multiply the filters'
+      OUTPUTS, so (unlike the scalar time gates) they cannot be folded into the operands.
+    node_gates = {'in': (wA_g, wB_g, bias_g, wf, bf), 'forget': (...)}, time_gates as in fused_cell_forward_x3_gated. X: B x T x G x N fp32 with
+    G == F, h0: B x F x N fp32 -> H: B x T x F x N fp32 (B x 1 x F x N with last_only). Inference (no autograd graph)."""
+    require_device(X, h0, wA, wB, bias)
+    B, T, G, N = X.shape
+    F, Kin, Kst = wA.shape[0], wA.shape[2], wB.shape[2]
+    assert G == F, 'the x3 filter pass takes F -> F filters'
+    K = max(Kin, Kst)
+    plan = graph.fused_plan_x3()
+    npad, st, dev = plan['npad'], _stream(), X.device
+    Xc = X.detach().float().contiguous()
+    h0c = h0.detach().float().contiguous()
+    hzero = False if torch.cuda.is_current_stream_capturing() else not bool(h0c.any())
+    gargs = (_p(plan['tile_slots']), _p(plan['tile_off']), _p(plan['ell_col4']), plan['entries'])
+    r1 = _p(plan.get('rank1_x3'))
+    xs3 = torch.empty((T, 3, B, npad, G), dtype=torch.bfloat16, device=dev)
+    check(lib.gcrnn_pack_seq_major_x3(_p(Xc), _p(xs3), B, T, G, N, npad, st), 'pack_seq_x3')
+    h03 = torch.empty((1, 3, B, npad, F), dtype=torch.bfloat16, device=dev)
+    check(lib.gcrnn_pack_seq_major_x3(_p(h0c), _p(h03), B, 1, F, N, npad, st), 'pack_seq_x3')
+    h3 = torch.empty((1, 3, B, npad, F), dtype=torch.bfloat16, device=dev)
+
+    def gate_cell_states(wA_g, wB_g, bias_g):
+        Kg = max(wA_g.shape[2], wB_g.shape[2])
+        wAg, wBg = wA_g.detach().float().contiguous(), wB_g.detach().float().contiguous()
+        wpg = torch.empty((3 * (F // 16) * Kg * ((F + G) // 32) * 64 * 8,), dtype=torch.bfloat16, device=dev)
+        check(lib.gcrnn_fused_pack_weights_x3(_p(wAg), _p(wBg), _p(wpg), F, G, wA_g.shape[2], wB_g.shape[2], st), 'pack_weights_x3')
+        bg = bias_g.detach().float().contiguous().view(-1) if bias_g is not None else None
+        c = torch.empty((B, T, F, N), dtype=torch.float32, device=dev)
+        check(lib.gcrnn_fused_gate_cells_x3(_p(xs3), _p(h03), _p(h3), _p(wpg), _p(bg), *gargs, B, T, N, F, G, Kg, plan['uniform_w'], _p(c), int(hzero), r1, st),
+              'fused_gate_cells_x3')
+        return c
+
+    # per-node gates [T][B][npad][1] fp32 (zero on the padding rows)
+    ngate = []
+    for name in ('in', 'forget'):
+        wA_g, wB_g, bias_g, wf, bf = node_gates[name]
+        c = gate_cell_states(wA_g, wB_g, bias_g)
+        logit = lsigf_node_major(pack_node_major(c), wf.detach().float(), bf.detach().float() if bf is not None else None, graph, 1.0)      # [T][N][B][1]
+        del c
+        g = torch.zeros((T, B, npad, 1), dtype=torch.float32, device=dev)
+        g[:, :, :N] = torch.sigmoid(logit).permute(0, 2, 1, 3)
+        ngate.append(g)
+        del logit
+    ni, nf = ngate
+    if time_gates is not None:
+        for which, name in ((0, 'in'), (1, 'forget')):
+            wA_g, wB_g, bias_g, lin_w, lin_b = time_gates[name]
+            c = gate_cell_states(wA_g, wB_g, bias_g)
+            logit = (c.view(B * T, F * N) @ lin_w.detach().float().reshape(-1)).view(B, T).t()
+            if lin_b is not None:
+                logit = logit + lin_b.detach().float().view(())
+            tgv = torch.sigmoid(logit).contiguous().view(T, B, 1, 1)
+            del c
+            if which == 0:
+                ni = ni * tgv
+            else:
+                nf = nf * tgv
+
+    def state_taps(w, k):      # F x 1 x k x F taps -> the x3 pack of a state-only operand with K taps
+        wk = w.detach().float()
+        if k < K:
+            wk = torch.cat([wk, wk.new_zeros(F, 1, K - k, F)], dim=2)
+        wk = wk.contiguous()
+        wp = torch.empty((3 * (F // 16) * K * (F // 32) * 64 * 8,), dtype=torch.bfloat16, device=dev)
+        check(lib.gcrnn_fused_pack_weights_x3(_p(wk), _p(wk), _p(wp), F, 0, K, K, st), 'pack_weights_x3')
+        return wp
+    wp3A, wp3B = state_taps(wA, Kin), state_taps(wB, Kst)
+    bvec = bias.detach().float().view(1, 1, F) if bias is not None else None
+    y3 = torch.empty((3, B, npad, F), dtype=torch.bfloat16, device=dev)
+    H = torch.empty((B, T, F, N), dtype=torch.float32, device=dev)
+    hprev = h0c
+    for t in range(T):
+        check(lib.gcrnn_fused_filter_x3(_p(xs3[t]), _p(y3), _p(wp3A), *gargs, B, N, F, K, plan['uniform_w'], r1, st), 'fused_filter_x3')
+        ya = y3.float().sum(dim=0)                                               # A(S) x_t: the three planes add up exactly in fp32
+        hp = hprev if hprev.is_contiguous() else hprev.contiguous()
+        check(lib.gcrnn_pack_seq_major_x3(_p(hp), _p(h3), B, 1, F, N, npad, st), 'pack_seq_x3')
+        check(lib.gcrnn_fused_filter_x3(_p(h3[0]), _p(y3), _p(wp3B), *gargs, B, N, F, K, plan['uniform_w'], r1, st), 'fused_filter_x3')
+        yb = y3.float().sum(dim=0)                                               # B(S) h_{t-1}
+        if bvec is not None:
+            ya = ya + bvec
+            yb = yb + bvec
+        ht = torch.tanh(ni[t] * ya + nf[t] * yb)                                 # [B][npad][F]; padding rows: tanh(0) = 0
+        H[:, t] = ht[:, :N].transpose(1, 2)
+        hprev = H[:, t]
+    if last_only:
+        return H[:, T - 1:].contiguous()
+    return H
+
+
 class _FusedTimeCellX3(torch.autograd.Function):
     """Time-gated GGCRNNCell (the reference's default, Utils/graphML.py:2196, :2357-2374, :2420-2423) at fp32 accuracy on the fused kernels,
     forward AND BPTT (round 4). Forward: the two gate cells as T x B one-step x3 cells that all read h0 (gcrnn_fused_gate_cells_x3, on the

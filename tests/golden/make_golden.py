@@ -446,6 +446,44 @@ def g12_fused_f32_time():
          H=H.detach().numpy(), params={k: v.astype(np.float32) for k, v in p.items()}, grad_sum=g_sum, grad_l1=g_l1)
 
 
+def g13_fused_f32_node():
+    """G13 (round 5): G11's graph, shapes and operand recipe for the NODE-gated cell (Utils/graphML.py:2379-2407) and the time + node gated one:
+    fp64 reference states (and autograd gradients of every used parameter for H.sum(): kept for the training path) with fp32-representable
+    operands and non-zero h0. The node-gated forward on the fp32-accurate fused kernels (ops.fused_node_cell_forward_x3) is compared at <= 1e-5."""
+    N, T, G, F, K, B = 200, 4, 32, 32, 3, 3
+    rng = np.random.default_rng(31)
+    U = np.triu(rng.random((N, N)) < 0.05, 1)
+    W = (U + U.T).astype(np.float64)
+    lam = np.max(np.linalg.eigvalsh(W))
+    w32 = np.float32(1.0 / lam)
+    S = (W * np.float64(w32)).reshape(1, N, N)
+    f32 = lambda a: np.asarray(a, dtype=np.float32).astype(np.float64)
+    X = f32(rng.standard_normal((B, T, G, N)))
+    h0 = f32(0.5 * rng.standard_normal((B, F, N)))
+    rows, cols = np.nonzero(S[0])
+    for name, tg in (('g13_fused_f32_node', False), ('g13_fused_f32_time_node', True)):
+        torch.manual_seed(93)
+        cell = gml.GGCRNNCell(G, F, K, K, torch.tanh, tg, 'node', 1, True)
+        cell.addGSO(torch.tensor(S))
+        with torch.no_grad():
+            for pname, q in cell.named_parameters():
+                if pname.startswith('MLP_'):
+                    q.mul_(6.0)
+                if pname.startswith('GFL_node_'):
+                    q.mul_(3.0)                          # (the F -> 1 gate filters: default init leaves the node gates within a few 1e-2 of 0.5)
+            for q in cell.parameters():
+                q.copy_(torch.tensor(f32(q.detach().numpy())))
+        p = sd_np(cell)
+        H = cell(torch.tensor(X), torch.tensor(h0))
+        check(orc.ggcrnn_cell(p, S, X, h0, tg, 'node'), H.detach().numpy(), name)
+        cell.zero_grad()
+        H.sum().backward()
+        g_sum = {k: v for k, v in grads_np(cell).items() if v is not None}
+        save(name, coo_row=rows.astype(np.int16), coo_col=cols.astype(np.int16), coo_val=S[0][rows, cols].astype(np.float32),
+             shape=np.array([N, T, G, F, K, B]), X=X.astype(np.float32), h0=h0.astype(np.float32),
+             H=H.detach().numpy(), params={k: v.astype(np.float32) for k, v in p.items()}, grad_sum=g_sum)
+
+
 def g10_kstep_data():
     """The reference's KStepPrediction dataset (Utils/dataTools.py:1259-1317) on a reference SBM graph
     (Utils/graphTools.py createGraph 'SBM'), with the numpy global generator seeded: stores the graph, the noise arrays the
@@ -502,4 +540,5 @@ if __name__ == '__main__':
     g10_kstep_data()
     g11_fused_f32()
     g12_fused_f32_time()
+    g13_fused_f32_node()
     print('all oracle checks passed at tol', TOL)

@@ -2005,6 +2005,69 @@ def test_fp32_accurate_fused_time_gated_training_matches_reference_autograd_fixt
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('name,tg', [('g13_fused_f32_node', False), ('g13_fused_f32_time_node', True)])
+def test_fp32_accurate_node_gated_forward_matches_reference_fixture(golden, name, tg):
+    """G13: the NODE-gated cell (Utils/graphML.py:2379-2407, 2420-2423; with and without the time gates) at the
+    north_star's 1e-5 on the fp32-accurate fused kernels -- gate cells as one-step x3 cells on the planes of X, their F -> 1 filters on the
+    fp32 filter kernels, A(S) x_t and B(S) h_{t-1} as x3 filter passes, the per-node gating and tanh in fp32 (ops.fused_node_cell_forward_x3)
+    -- against the REFERENCE's fp64 states (tests/golden/make_golden.py g13_fused_f32_node: fp32-representable operands, non-zero h0)."""
+    g = golden(name)
+    dev = torch.device('cuda:0')
+    cell, S = _g9_cell(g, tg, 'node', dev)
+    X = torch.tensor(g['X'], dtype=torch.float32, device=dev)
+    h0 = torch.tensor(g['h0'], dtype=torch.float32, device=dev)
+    calls = []
+    from gated_gcrnns_amd import ops
+    orig = ops.fused_node_cell_forward_x3
+    ops.fused_node_cell_forward_x3 = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+    try:
+        with torch.no_grad():
+            assert cell._use_fused_x3_node(X, h0)
+            H = cell(X, h0)
+            Hl = cell(X, h0, last_only=True)
+    finally:
+        ops.fused_node_cell_forward_x3 = orig
+    assert len(calls) == 2 and H.dtype == torch.float32
+    err = float((H.double().cpu() - torch.tensor(g['H'])).abs().max())
+    _tol_report('x3 node-gated forward vs %s: max |H - reference| = %.2e' % (name, err))
+    assert err <= 1e-5, err
+    assert torch.equal(H[:, -1:], Hl)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('N,F,K,B,T,tg,hz', [(1000, 64, 5, 3, 4, False, True), (1000, 64, 5, 2, 3, True, False), (600, 32, 3, 4, 3, False, False)])
+def test_fp32_accurate_node_gated_forward_matches_the_oracle_at_bench_sizes(N, F, K, B, T, tg, hz):
+    """The same at the bench's node count against the fp64 oracle on fp32-representable operands (uniform-weight graph, G = F)."""
+    dev = torch.device('cuda:0')
+    import gated_gcrnns_amd.Utils.graphML as gml
+    rng = np.random.default_rng(57)
+    W = (rng.random((N, N)) < 10.0 / N).astype(np.float64)
+    W = np.triu(W, 1); W = W + W.T
+    w32 = np.float32(1.0 / np.max(np.abs(np.linalg.eigvalsh(W))))
+    S = (W * np.float64(w32)).reshape(1, N, N)
+    torch.manual_seed(57)
+    cell = gml.GGCRNNCell(F, F, K, K, torch.tanh, tg, 'node', 1, True)
+    cell.addGSO(torch.tensor(S))
+    cell = cell.float()
+    with torch.no_grad():
+        for n_, q in cell.named_parameters():
+            if n_.startswith('GFL_node_'):
+                q.mul_(3.0)
+    f32 = lambda a: np.asarray(a, dtype=np.float32).astype(np.float64)
+    X = f32(rng.standard_normal((B, T, F, N)))
+    h0 = np.zeros((B, F, N)) if hz else f32(0.4 * rng.standard_normal((B, F, N)))
+    params = {k: v.detach().double().numpy() for k, v in cell.state_dict().items()}
+    Href = orc.ggcrnn_cell(params, S, X, h0, tg, 'node')
+    cell = cell.to(dev)
+    Xd, hd = torch.tensor(X, dtype=torch.float32, device=dev), torch.tensor(h0, dtype=torch.float32, device=dev)
+    with torch.no_grad():
+        assert cell._use_fused_x3_node(Xd, hd)
+        H = cell(Xd, hd)
+    err = float(np.abs(H.double().cpu().numpy() - Href).max())
+    assert err <= 1e-5, err
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('N,F,G,K,B,T,hz', [(1000, 64, 64, 5, 3, 4, True), (1000, 64, 1, 3, 2, 3, False), (600, 32, 32, 4, 4, 3, True),
                                             (1000, 64, 32, 3, 2, 3, False), (1000, 64, 64, 2, 2, 3, False), (1000, 64, 64, 5, 2, 1, False)])
 def test_fp32_accurate_fused_time_gated_training_matches_composed_autograd(N, F, G, K, B, T, hz, monkeypatch):
