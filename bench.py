@@ -763,7 +763,7 @@ def secondary_points(ctx, S, params, B, steps=8, warmup=2):
             graphed = False
             with torch.no_grad():
                 fn = lambda: c(X, h0)
-                if args.hipgraph != 0:      # as the headline: the forward replayed as ONE captured hipGraph (ops.FusedForwardGraph captures the gated cells' own forward)
+                if ctx['args'].hipgraph != 0:      # as the headline: the forward replayed as ONE captured hipGraph (ops.FusedForwardGraph captures the gated cells' own forward)
                     try:
                         from gated_gcrnns_amd.ops import FusedForwardGraph
                         fn = FusedForwardGraph(c, B, T, X=X, h0=h0)
