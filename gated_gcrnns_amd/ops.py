@@ -1454,20 +1454,37 @@ def fused_edge_cell_forward(X, h0, wA, wB, bias, graph, att_in, att_f, time_gate
     wBc, bB = _edge_composite(wB.detach(), bias.detach() if bias is not None else None, att_f[1].detach())
     a_in = att_in[0].detach().float().reshape(2, F).contiguous()
     a_f = att_f[0].detach().float().reshape(2, F).contiguous()
-    zx = fused_filter_output(xs, wAc, bA, graph, K, N)                  # [T][B][NPad][F]
+    plan16 = fused_img16_plan(graph, False, None)
+    uw = float(plan.get('uniform_w', 0.0))
+    # (round 5) both filter passes on the WIDE kernel's filter-output mode when it takes them (csrc/gcrnn_fused_seq32.h mode 3: 32-feature chunks,
+    # one workgroup per item): the x branch over all T B items, and per step the state filter with h_{t-1} as the mode's "input" operand
+    wide_x = plan16 is not None and F % 32 == 0 and G % 32 == 0 and bool(lib.gcrnn_fused_filter_output_wide_supported(B, T, N, F, G, K, int(plan16['entries']), uw, 1))
+    wide_h = plan16 is not None and F % 32 == 0 and bool(lib.gcrnn_fused_filter_output_wide_supported(B, 1, N, F, F, K, int(plan16['entries']), uw, 1))
+    p16 = (lambda: (_p(plan16['tile_slots']), _p(plan16['tile_off']), _p(plan16['ell_col4']), plan16['entries']))
+    if wide_x:
+        wpx = _fused_pack_weights_wide(wAc.contiguous(), wAc.new_zeros((F, 1, K, F)), uw, st)
+        zx = torch.empty((T, B, npad, F), dtype=torch.bfloat16, device=X.device)
+        check(lib.gcrnn_fused_filter_output_wide_bf16(_p(xs), _p(wpx), _p(bA.contiguous() if bA is not None else None), _p(zx), *p16(), B, T, N, F, G, K, st),
+              'fused_filter_output_wide')
+    else:
+        zx = fused_filter_output(xs, wAc, bA, graph, K, N)                  # [T][B][NPad][F]
     gx = fused_edge_attention(zx, a_in, graph, out=zx, N=N, negative_slope=negative_slope)      # in place: every workgroup reads its item first
     if Kst < K:
         wBc = torch.cat([wBc, wBc.new_zeros(F, 1, K - Kst, F)], dim=2)
-    wpB = _fused_pack_state_taps(wBc, K, st)
     bB32 = bB.contiguous() if bB is not None else None
+    if wide_h:
+        wpBw = _fused_pack_weights_wide(wBc.contiguous(), wBc.new_zeros((F, 1, K, F)), uw, st)      # the state taps as the "input" taps of [0 | h_{t-1}]
+    else:
+        wpB = _fused_pack_state_taps(wBc, K, st)
     H = torch.empty((B, 1 if last_only else T, F, N), dtype=torch.bfloat16, device=X.device)
     zh = torch.empty((1, B, npad, F), dtype=torch.bfloat16, device=X.device)
-    plan16 = fused_img16_plan(graph, False, None)
     ga = _fused_graph_args(plan16 or plan)
-    uw = plan.get('uniform_w', 0.0)
     for t in range(T):
-        check(lib.gcrnn_fused_filter_output_bf16(_p(hs_all[t]), None, _p(wpB), _p(bB32), _p(zh), *ga, B, 1, N, F, 0, K, uw, 1 if plan16 else 0, st),
-              'fused_filter_output')
+        if wide_h:
+            check(lib.gcrnn_fused_filter_output_wide_bf16(_p(hs_all[t]), _p(wpBw), _p(bB32), _p(zh), *p16(), B, 1, N, F, F, K, st), 'fused_filter_output_wide')
+        else:
+            check(lib.gcrnn_fused_filter_output_bf16(_p(hs_all[t]), None, _p(wpB), _p(bB32), _p(zh), *ga, B, 1, N, F, 0, K, uw, 1 if plan16 else 0, st),
+                  'fused_filter_output')
         hu = None
         if not last_only:
             hu = H[:, t]

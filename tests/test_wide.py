@@ -893,6 +893,48 @@ def test_node_gated_passes_on_the_wide_kernel_match_oracle(N, F, G, K, B, T, tg,
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('N,F,G,K,B,T,tg', [(1000, 64, 64, 5, 3, 3, False), (1000, 64, 64, 3, 2, 3, True), (400, 32, 32, 3, 4, 3, False), (1000, 64, 1, 3, 2, 3, False)])
+def test_edge_gated_filter_passes_on_the_wide_kernel_match_oracle(N, F, G, K, B, T, tg, monkeypatch):
+    """Round 5: the edge-gated cell's two filter passes (reference Utils/graphML.py:2409-2416: the attention reads the filters' outputs) on the
+    wide kernel's filter-output mode -- the x branch over all (t, b) items, and per step the state filter with h_{t-1} as the mode's input
+    operand (composite taps W_f B_k) -- against the fp64 oracle on a uniform-weight graph, and against round 3's kernels (GCRNN_SEQ32_NODE=0)."""
+    import gated_gcrnns_amd.Utils.graphML as gml
+    from gated_gcrnns_amd import _lib
+    dev = torch.device('cuda:0')
+    rng = np.random.default_rng(141)
+    W = (rng.random((N, N)) < 10.0 / N).astype(np.float64)
+    W = np.triu(W, 1); W = W + W.T
+    S = (W / np.max(np.abs(np.linalg.eigvalsh(W)))).reshape(1, N, N)
+    X = bf16_round(rng.standard_normal((B, T, G, N)))
+    h0 = bf16_round(0.4 * rng.standard_normal((B, F, N)))
+    torch.manual_seed(141)
+    cell = gml.GGCRNNCell(G, F, K, K, torch.tanh, tg, 'edge', 1, True)
+    cell.addGSO(torch.tensor(S))
+    params = {k: bf16_round(v.detach().numpy()) for k, v in cell.state_dict().items()}
+    ref = orc.ggcrnn_cell(params, S.astype(np.float32).astype(np.float64), X, h0, tg, 'edge')
+    cell.load_state_dict({k: torch.tensor(v) for k, v in params.items()})
+    cell = cell.to(dev).to(torch.bfloat16)
+    Xd = torch.tensor(X, dtype=torch.bfloat16, device=dev)
+    hd = torch.tensor(h0, dtype=torch.bfloat16, device=dev)
+    monkeypatch.setenv('GCRNN_SEQ32_MIN_B', '1')
+    calls = []
+    orig = _lib.lib.gcrnn_fused_filter_output_wide_bf16
+    with torch.no_grad():
+        assert cell._use_fused_edge(Xd, hd)
+        p16 = cell.graph.fused_plan_img16()
+        assert _lib.lib.gcrnn_fused_filter_output_wide_supported(B, 1, N, F, F, K, int(p16['entries']), float(p16['uniform_w']), 1) == 1
+        H = cell(Xd, hd)
+        monkeypatch.setenv('GCRNN_SEQ32_NODE', '0')
+        H16 = cell(Xd, hd)
+    err = np.abs(H.double().cpu().numpy() - ref)
+    err16 = np.abs(H16.double().cpu().numpy() - ref)
+    assert err.max() <= (6e-2 if G == 1 else 1.2e-2) and err.mean() <= (3e-3 if G == 1 else 1.5e-3), (err.max(), err.mean())
+    assert err.mean() <= max(1.0e-3, 1.5 * err16.mean()), (err.mean(), err16.mean())
+    d = (H.float() - H16.float()).abs()
+    assert float(d.max()) <= (6e-2 if G == 1 else 2.5e-2) and float(d.mean()) <= 2.0e-3 and float(d.max()) > 0.0, (float(d.max()), float(d.mean()))
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('N,S_,K,T,B,bias,uniform', [(1000, 2, 5, 3, 3, True, False), (1000, 2, 5, 5, 3, True, True), (300, 1, 3, 2, 5, False, True),
                                                      (1024, 2, 1, 1, 4, True, False), (37, 3, 4, 2, 2, True, False), (600, 2, 2, 1, 1, False, False)])
 def test_node_gate_filter_one_pass(N, S_, K, T, B, bias, uniform):
