@@ -17,7 +17,7 @@ static bool seq32n_wanted(int64_t rounds_of) {
 
 template <int K, int HS, int XS, int VAR, int MODE>
 static int seq32n_launch(const Seq32Args& sa, hipStream_t st) {
-  const size_t lds = Seq32Map<K, HS, XS>::lds_bytes(sa.entries, false, false);
+  const size_t lds = Seq32Map<K, HS, XS>::lds_bytes(sa.entries, (VAR & 1) != 0, false);
   if (!lds) return GCRNN_ERR_UNSUPPORTED;
   auto sk = fused_seq32_kernel<K, HS, XS, VAR, MODE>;
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(sk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
@@ -29,10 +29,10 @@ static int seq32n_launch(const Seq32Args& sa, hipStream_t st) {
 }
 
 template <int K, int HS, int XS>
-static size_t seq32n_lds(int64_t entries) { return Seq32Map<K, HS, XS>::lds_bytes(entries, false, false); }
+static size_t seq32n_lds(int64_t entries, bool pack) { return Seq32Map<K, HS, XS>::lds_bytes(entries, pack, false); }
 
-static size_t seq32n_lds_for(int64_t F, int64_t G, int64_t K, int64_t entries) {
-#define GCRNN_SEQ32_CASE(KK, HH, XX) if (K == KK && F == 32 * HH && G == 32 * XX) return seq32n_lds<KK, HH, XX>(entries);
+static size_t seq32n_lds_for(int64_t F, int64_t G, int64_t K, int64_t entries, bool pack = false) {
+#define GCRNN_SEQ32_CASE(KK, HH, XX) if (K == KK && F == 32 * HH && G == 32 * XX) return seq32n_lds<KK, HH, XX>(entries, pack);
   GCRNN_SEQ32_CASE(5, 2, 2) GCRNN_SEQ32_CASE(4, 2, 2) GCRNN_SEQ32_CASE(3, 2, 2) GCRNN_SEQ32_CASE(2, 2, 2)
   GCRNN_SEQ32_CASE(5, 2, 1) GCRNN_SEQ32_CASE(4, 2, 1) GCRNN_SEQ32_CASE(3, 2, 1) GCRNN_SEQ32_CASE(2, 2, 1)
   GCRNN_SEQ32_CASE(5, 1, 1) GCRNN_SEQ32_CASE(4, 1, 1) GCRNN_SEQ32_CASE(3, 1, 1) GCRNN_SEQ32_CASE(2, 1, 1)
@@ -42,24 +42,32 @@ static size_t seq32n_lds_for(int64_t F, int64_t G, int64_t K, int64_t entries) {
   return 0;
 }
 
-// A(S) x_t + b for every (t, b) item as ONE launch (graphML.py:2402-2403; the node-gated cell multiplies it by the input gate per node):
-// xs [T][B][NPad][G] bf16 sequence-major, wpack = gcrnn_fused_pack_weights_wide(Fout = F) of the input taps with ZERO state taps (the operand
-// is [0 | x_t]: its state half is neither loaded nor multiplied), bias [F] fp32 or NULL, out [T][B][NPad][F] bf16.
+// A(S) x_t + b for every (t, b) item as ONE launch (graphML.py:2402-2403; the node-gated cell multiplies it by the input gate per node, the
+// edge-gated cell feeds it to its attention): xs [T][B][NPad][G] bf16 sequence-major, wpack = gcrnn_fused_pack_weights_wide(Fout = F) of the
+// input taps with ZERO state taps (the operand is [0 | x_t]: its state half is neither loaded nor multiplied), bias [F] fp32 or NULL, out
+// [T][B][NPad][F] bf16. x_user (or NULL): the user-layout X [B][T][G][N] -- the caller has laid out only the leading time steps of xs (the
+// count gcrnn_fused_filter_output_wide_supported(..., with_pack = 1) returns), the items lay out the rest while they run (every item the
+// operand of its workgroup's NEXT item, as the gate pair pre-pass does).
 extern "C" int gcrnn_fused_filter_output_wide_supported(int64_t B, int64_t T, int64_t N, int64_t F, int64_t G, int64_t K, int64_t entries,
-                                                        double uniform_w, int img16) {
+                                                        double uniform_w, int img16, int with_pack) {
   if (uniform_w == 0.0 || img16 != 1 || N <= 0 || N > NP || B <= 0 || T <= 0 || G <= 0 || entries <= 0 || entries % 4) return 0;
   if (B * T * (NP * (F > G ? F : G) * 2) > 2147483647LL || B * T > (1 << 24)) return 0;
+  if (with_pack && (N % 8 || T * G * N > 2147483647LL)) return 0;
   if (!seq32n_wanted(B * T)) return 0;
-  return seq32n_lds_for(F, G, K, entries) ? 1 : 0;
+  if (!seq32n_lds_for(F, G, K, entries, with_pack != 0)) return 0;
+  if (!with_pack) return 1;
+  const int64_t first = B * T < gcrnn_persistent_grid() ? B * T : gcrnn_persistent_grid();      // the items of the first round of workgroups
+  return (int)((first + B - 1) / B);
 }
 
 extern "C" int gcrnn_fused_filter_output_wide_bf16(const void* xs, const void* wpack, const float* bias, void* out, const int32_t* tile_nodes,
                                                    const int32_t* tile_off, const void* ell_col4, int64_t entries, int64_t B, int64_t T,
-                                                   int64_t N, int64_t F, int64_t G, int64_t K, void* stream) {
+                                                   int64_t N, int64_t F, int64_t G, int64_t K, const void* x_user, void* stream) {
   if (!xs || !wpack || !out || !tile_nodes || !tile_off || !ell_col4) return GCRNN_ERR_NULL_POINTER;
   const int64_t items = B * T;
   if (B <= 0 || T <= 0 || N <= 0 || N > NP || items > (1 << 24) || entries <= 0 || entries % 4) return GCRNN_ERR_BAD_SHAPE;
   if (items * (NP * (F > G ? F : G) * 2) > 2147483647LL) return GCRNN_ERR_BAD_SHAPE;
+  if (x_user && (N % 8 != 0 || (reinterpret_cast<uintptr_t>(x_user) & 15) || T * G * N > 2147483647LL)) return GCRNN_ERR_BAD_SHAPE;
   Seq32Args sa{};
   sa.x0 = (const uint16_t*)xs;
   sa.hfirst = nullptr; sa.hmod = (int)B;
@@ -68,8 +76,12 @@ extern "C" int gcrnn_fused_filter_output_wide_bf16(const void* xs, const void* w
   sa.tile_nodes = tile_nodes; sa.tile_off = tile_off; sa.ell_col4 = (const uint2*)ell_col4;
   sa.entries = (int)entries; sa.B = (int)items; sa.N = (int)N;
   sa.nsteps = 1;
+  if (x_user) {
+    sa.pk_src0 = (const uint16_t*)x_user; sa.pksrc_stride = G * N; sa.pk_stride = (int)(T * G * N);
+    sa.pk_dst0 = (uint16_t*)const_cast<void*>(xs);
+  }
   hipStream_t st = as_stream(stream);
-#define GCRNN_SEQ32_CASE(KK, HH, XX) if (K == KK && F == 32 * HH && G == 32 * XX) return seq32n_launch<KK, HH, XX, 0, 3>(sa, st);
+#define GCRNN_SEQ32_CASE(KK, HH, XX) if (K == KK && F == 32 * HH && G == 32 * XX) return x_user ? seq32n_launch<KK, HH, XX, 1, 3>(sa, st) : seq32n_launch<KK, HH, XX, 0, 3>(sa, st);
   GCRNN_SEQ32_CASE(5, 2, 2) GCRNN_SEQ32_CASE(4, 2, 2) GCRNN_SEQ32_CASE(3, 2, 2) GCRNN_SEQ32_CASE(2, 2, 2)
   GCRNN_SEQ32_CASE(5, 2, 1) GCRNN_SEQ32_CASE(4, 2, 1) GCRNN_SEQ32_CASE(3, 2, 1) GCRNN_SEQ32_CASE(2, 2, 1)
   GCRNN_SEQ32_CASE(5, 1, 1) GCRNN_SEQ32_CASE(4, 1, 1) GCRNN_SEQ32_CASE(3, 1, 1) GCRNN_SEQ32_CASE(2, 1, 1)

@@ -1215,11 +1215,11 @@ def fused_node_cell_forward(X, h0, wA, wB, bias, graph, node_gates, time_gates=N
     b32 = _bias_f32(bias, st)
     # (round 5) both state-size passes on the WIDE kernel when it takes them: A(S) x_t + b over all items (mode 3) and the recurrence with the
     # per-node gates in its epilogue as ONE launch (mode 4); else round 3's 16-feature kernels
-    if plan16 is not None and F % 32 == 0 and G % 32 == 0 and lib.gcrnn_fused_filter_output_wide_supported(B, T, N, F, G, K, int(plan16['entries']), uw, 1):
+    if plan16 is not None and F % 32 == 0 and G % 32 == 0 and lib.gcrnn_fused_filter_output_wide_supported(B, T, N, F, G, K, int(plan16['entries']), uw, 1, 0):
         wpx = _fused_pack_weights_wide(wA.detach(), wA.new_zeros((F, 1, K, F)), uw, st)      # (zero state taps, K of them: the pack's tap count is the kernel's)
         yx = torch.empty((T, B, plan['npad'], F), dtype=torch.bfloat16, device=X.device)
         check(lib.gcrnn_fused_filter_output_wide_bf16(_p(xs), _p(wpx), _p(b32), _p(yx), _p(plan16['tile_slots']), _p(plan16['tile_off']),
-                                                      _p(plan16['ell_col4']), plan16['entries'], B, T, N, F, G, K, st), 'fused_filter_output_wide')
+                                                      _p(plan16['ell_col4']), plan16['entries'], B, T, N, F, G, K, None, st), 'fused_filter_output_wide')
     else:
         yx = fused_filter_output(xs, wA, bias, graph, K, N)
     H = torch.empty((B, 1 if last_only else T, F, N), dtype=torch.bfloat16, device=X.device)
@@ -1436,10 +1436,27 @@ def fused_edge_cell_forward(X, h0, wA, wB, bias, graph, att_in, att_f, time_gate
     plan = graph.fused_plan()
     npad = plan['npad']
     st = _stream()
+    x_pending = None
     if time_gates is not None:      # (the first time-gate pre-pass lays out the rest of X)
         xs, hs_all = fused_pack_inputs_gated(X.contiguous(), h0.contiguous(), graph, F, K)
     else:
-        xs, hs_all = fused_pack_inputs(X.contiguous(), h0.contiguous(), graph)
+        # (round 5) without time gates the first consumer of xs is the x branch's filter pass: when the wide kernel takes it, only the leading
+        # time step(s) are laid out here and its items lay out the rest while they run -- no separate pass over X (0.5 ms at B = 256, T = 32)
+        Xc = X.contiguous()
+        p16_ = fused_img16_plan(graph, True, None)
+        steps = 0
+        if (p16_ is not None and F % 32 == 0 and G % 32 == 0 and Xc.dtype == torch.bfloat16 and Xc.data_ptr() % 16 == 0
+                and not os.environ.get('GCRNN_NO_INLINE_PACK')):
+            steps = int(lib.gcrnn_fused_filter_output_wide_supported(B, T, N, F, G, K, int(p16_['entries']), float(plan.get('uniform_w', 0.0)), 1, 1))
+        if 0 < steps < T:
+            st0 = _stream()
+            xs = torch.empty((T, B, npad, G), dtype=torch.bfloat16, device=X.device)
+            hs_all = torch.empty((T + 1, B, npad, F), dtype=torch.bfloat16, device=X.device)
+            check(lib.gcrnn_pack_seq_major(_lib.BF16, _p(h0.contiguous()), _p(hs_all), B, 1, F, N, npad, None, st0), 'pack_seq')
+            check(lib.gcrnn_pack_seq_major_steps(_p(Xc), _p(xs), B, T, G, N, npad, 0, steps, 0, st0), 'pack_seq_steps')
+            x_pending = Xc
+        else:
+            xs, hs_all = fused_pack_inputs(Xc, h0.contiguous(), graph)
     gi = gf = None
     if time_gates is not None:
         hzero = fused_h0_zero_flag(h0)
@@ -1458,15 +1475,16 @@ def fused_edge_cell_forward(X, h0, wA, wB, bias, graph, att_in, att_f, time_gate
     uw = float(plan.get('uniform_w', 0.0))
     # (round 5) both filter passes on the WIDE kernel's filter-output mode when it takes them (csrc/gcrnn_fused_seq32.h mode 3: 32-feature chunks,
     # one workgroup per item): the x branch over all T B items, and per step the state filter with h_{t-1} as the mode's "input" operand
-    wide_x = plan16 is not None and F % 32 == 0 and G % 32 == 0 and bool(lib.gcrnn_fused_filter_output_wide_supported(B, T, N, F, G, K, int(plan16['entries']), uw, 1))
-    wide_h = plan16 is not None and F % 32 == 0 and bool(lib.gcrnn_fused_filter_output_wide_supported(B, 1, N, F, F, K, int(plan16['entries']), uw, 1))
+    wide_x = plan16 is not None and F % 32 == 0 and G % 32 == 0 and bool(lib.gcrnn_fused_filter_output_wide_supported(B, T, N, F, G, K, int(plan16['entries']), uw, 1, 0))
+    wide_h = plan16 is not None and F % 32 == 0 and bool(lib.gcrnn_fused_filter_output_wide_supported(B, 1, N, F, F, K, int(plan16['entries']), uw, 1, 0))
     p16 = (lambda: (_p(plan16['tile_slots']), _p(plan16['tile_off']), _p(plan16['ell_col4']), plan16['entries']))
     if wide_x:
         wpx = _fused_pack_weights_wide(wAc.contiguous(), wAc.new_zeros((F, 1, K, F)), uw, st)
         zx = torch.empty((T, B, npad, F), dtype=torch.bfloat16, device=X.device)
-        check(lib.gcrnn_fused_filter_output_wide_bf16(_p(xs), _p(wpx), _p(bA.contiguous() if bA is not None else None), _p(zx), *p16(), B, T, N, F, G, K, st),
+        check(lib.gcrnn_fused_filter_output_wide_bf16(_p(xs), _p(wpx), _p(bA.contiguous() if bA is not None else None), _p(zx), *p16(), B, T, N, F, G, K, _p(x_pending), st),
               'fused_filter_output_wide')
     else:
+        assert x_pending is None      # (the partial layout above was sized by the same query)
         zx = fused_filter_output(xs, wAc, bA, graph, K, N)                  # [T][B][NPad][F]
     gx = fused_edge_attention(zx, a_in, graph, out=zx, N=N, negative_slope=negative_slope)      # in place: every workgroup reads its item first
     if Kst < K:
@@ -1481,7 +1499,7 @@ def fused_edge_cell_forward(X, h0, wA, wB, bias, graph, att_in, att_f, time_gate
     ga = _fused_graph_args(plan16 or plan)
     for t in range(T):
         if wide_h:
-            check(lib.gcrnn_fused_filter_output_wide_bf16(_p(hs_all[t]), _p(wpBw), _p(bB32), _p(zh), *p16(), B, 1, N, F, F, K, st), 'fused_filter_output_wide')
+            check(lib.gcrnn_fused_filter_output_wide_bf16(_p(hs_all[t]), _p(wpBw), _p(bB32), _p(zh), *p16(), B, 1, N, F, F, K, None, st), 'fused_filter_output_wide')
         else:
             check(lib.gcrnn_fused_filter_output_bf16(_p(hs_all[t]), None, _p(wpB), _p(bB32), _p(zh), *ga, B, 1, N, F, 0, K, uw, 1 if plan16 else 0, st),
                   'fused_filter_output')

@@ -472,10 +472,13 @@ int gcrnn_fused_backward_data_wide_bf16(const void* dHs, const void* hs, void* d
  *   wpackB = gcrnn_fused_pack_weights_wide of the state taps alone (G = 0), Huser [B][T or 1][F][N] bf16 or NULL.
  * The _supported queries return 1 when the problem is taken (uniform-weight bf16-image plan: img16 == 1, a batch that fills the chip, LDS room). */
 int gcrnn_fused_filter_output_wide_supported(int64_t B, int64_t T, int64_t N, int64_t F, int64_t G, int64_t K, int64_t entries, double uniform_w,
-                                             int img16);
+                                             int img16, int with_pack /* 1: returns the number of leading time steps of xs the caller lays out itself */);
 int gcrnn_fused_filter_output_wide_bf16(const void* xs, const void* wpack, const float* bias, void* out, const int32_t* tile_nodes,
                                         const int32_t* tile_off, const void* ell_col4, int64_t entries, int64_t B, int64_t T, int64_t N,
-                                        int64_t F, int64_t G, int64_t K, void* stream);
+                                        int64_t F, int64_t G, int64_t K,
+                                        const void* x_user /* NULL, or the user-layout X [B][T][G][N] bf16 (N % 8 == 0): the items lay out the time steps of xs
+                                                              the caller has not (edge-gated cell without time gates: no separate pass over X) */,
+                                        void* stream);
 int gcrnn_fused_node_forward_wide_supported(int64_t B, int64_t T, int64_t N, int64_t F, int64_t K, int64_t entries, double uniform_w, int img16);
 int gcrnn_fused_node_forward_wide_bf16(const void* h0s, void* hs, const void* yx, const float* ngates, const float* gi, const float* gf,
                                        const void* wpackB, const float* bias, const int32_t* tile_nodes, const int32_t* tile_off,

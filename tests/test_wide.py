@@ -873,7 +873,7 @@ def test_node_gated_passes_on_the_wide_kernel_match_oracle(N, F, G, K, B, T, tg,
     orig = _lib.lib.gcrnn_fused_node_forward_wide_bf16
     p16 = cell.graph.fused_plan_img16()
     Gp = 32 if G < 32 else G
-    assert _lib.lib.gcrnn_fused_filter_output_wide_supported(B, T, N, F, Gp, K, int(p16['entries']), float(p16['uniform_w']), 1) == 1
+    assert _lib.lib.gcrnn_fused_filter_output_wide_supported(B, T, N, F, Gp, K, int(p16['entries']), float(p16['uniform_w']), 1, 0) == 1
     assert _lib.lib.gcrnn_fused_node_forward_wide_supported(B, T, N, F, K, int(p16['entries']), float(p16['uniform_w']), 1) == 1
     with torch.no_grad():
         assert cell._use_fused_node(Xd, hd)
@@ -922,7 +922,7 @@ def test_edge_gated_filter_passes_on_the_wide_kernel_match_oracle(N, F, G, K, B,
     with torch.no_grad():
         assert cell._use_fused_edge(Xd, hd)
         p16 = cell.graph.fused_plan_img16()
-        assert _lib.lib.gcrnn_fused_filter_output_wide_supported(B, 1, N, F, F, K, int(p16['entries']), float(p16['uniform_w']), 1) == 1
+        assert _lib.lib.gcrnn_fused_filter_output_wide_supported(B, 1, N, F, F, K, int(p16['entries']), float(p16['uniform_w']), 1, 0) == 1
         H = cell(Xd, hd)
         monkeypatch.setenv('GCRNN_SEQ32_NODE', '0')
         H16 = cell(Xd, hd)
@@ -932,6 +932,42 @@ def test_edge_gated_filter_passes_on_the_wide_kernel_match_oracle(N, F, G, K, B,
     assert err.mean() <= max(1.0e-3, 1.5 * err16.mean()), (err.mean(), err16.mean())
     d = (H.float() - H16.float()).abs()
     assert float(d.max()) <= (6e-2 if G == 1 else 2.5e-2) and float(d.mean()) <= 2.0e-3 and float(d.max()) > 0.0, (float(d.max()), float(d.mean()))
+
+
+@pytest.mark.gpu
+def test_edge_gated_forward_lays_out_x_inside_the_filter_pass(monkeypatch):
+    """Round 5: without time gates the edge-gated cell's first consumer of the sequence-major X is the x branch's filter pass; on the wide kernel
+    its items lay out the time steps the caller has not (gcrnn_fused_filter_output_wide_bf16 with x_user) -- no separate pass over X. B T = 390
+    items > one round of workgroups, so steps 0..1 are laid out by the caller and step 2 by the items: same bits as with the plain layout
+    (GCRNN_NO_INLINE_PACK=1), first sequences against the fp64 oracle."""
+    import gated_gcrnns_amd.Utils.graphML as gml
+    from gated_gcrnns_amd import _lib
+    dev = torch.device('cuda:0')
+    N, F, G, K, B, T = 1000, 64, 64, 5, 130, 3
+    rng = np.random.default_rng(151)
+    W = (rng.random((N, N)) < 10.0 / N).astype(np.float64)
+    W = np.triu(W, 1); W = W + W.T
+    S = (W / np.max(np.abs(np.linalg.eigvalsh(W)))).reshape(1, N, N)
+    X = bf16_round(rng.standard_normal((B, T, G, N)))
+    h0 = bf16_round(0.4 * rng.standard_normal((B, F, N)))
+    torch.manual_seed(151)
+    cell = gml.GGCRNNCell(G, F, K, K, torch.tanh, False, 'edge', 1, True)
+    cell.addGSO(torch.tensor(S))
+    params = {k: bf16_round(v.detach().numpy()) for k, v in cell.state_dict().items()}
+    ref = orc.ggcrnn_cell(params, S.astype(np.float32).astype(np.float64), X[:2], h0[:2], False, 'edge')
+    cell.load_state_dict({k: torch.tensor(v) for k, v in params.items()})
+    cell = cell.to(dev).to(torch.bfloat16)
+    Xd = torch.tensor(X, dtype=torch.bfloat16, device=dev)
+    hd = torch.tensor(h0, dtype=torch.bfloat16, device=dev)
+    p16 = cell.graph.fused_plan_img16()
+    assert _lib.lib.gcrnn_fused_filter_output_wide_supported(B, T, N, F, G, K, int(p16['entries']), float(p16['uniform_w']), 1, 1) == 2
+    with torch.no_grad():
+        H = cell(Xd, hd)
+        monkeypatch.setenv('GCRNN_NO_INLINE_PACK', '1')
+        H2 = cell(Xd, hd)
+    assert torch.equal(H, H2)
+    err = np.abs(H[:2].double().cpu().numpy() - ref)
+    assert err.max() <= 1.2e-2 and err.mean() <= 1.5e-3, (err.max(), err.mean())
 
 
 @pytest.mark.gpu
