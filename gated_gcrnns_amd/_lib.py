@@ -89,6 +89,7 @@ def _bind(lib):
         'gcrnn_fused_forward_wide_bf16': (C.c_int, [_c_p] * 10 + [_c_i64] * 7 + [_c_p, C.c_int, _c_p, _c_p, _c_p, _c_p]),
         'gcrnn_fused_backward_data_wide_supported': (C.c_int, [_c_i64] * 6 + [C.c_double, C.c_int, C.c_int]),
         'gcrnn_fused_backward_data_wide_bf16': (C.c_int, [_c_p] * 8 + [_c_i64] * 6 + [_c_p] * 7),
+        'gcrnn_gate_readout_finish': (C.c_int, [_c_p, _c_i64, _c_p, _c_p, _c_p, _c_p, _c_i64, _c_p]),
         'gcrnn_fused_filter_output_wide_supported': (C.c_int, [_c_i64] * 7 + [C.c_double, C.c_int, C.c_int]),
         'gcrnn_fused_filter_output_wide_bf16': (C.c_int, [_c_p] * 7 + [_c_i64] * 7 + [_c_p, _c_p]),
         'gcrnn_fused_node_forward_wide_supported': (C.c_int, [_c_i64] * 6 + [C.c_double, C.c_int]),

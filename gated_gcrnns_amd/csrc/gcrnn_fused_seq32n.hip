@@ -130,3 +130,31 @@ extern "C" int gcrnn_fused_node_forward_wide_bf16(const void* h0s, void* hs, con
 #undef GCRNN_SEQ32_CASE
   return GCRNN_ERR_UNSUPPORTED;
 }
+
+// The time gates' read-out, finished in ONE launch (reference Utils/graphML.py:2364-2366, 2372-2374: gate = sigmoid(w . vec(c) + c0)): the pair
+// pre-pass leaves per item and gate `nparts` partial dot products (one per 32-feature chunk and wave, gcrnn_fused_gate_pair_prepass_wide_bf16);
+// this adds them in a FIXED order (j = 0 .. nparts-1: the same bits on every run), adds the read-out's bias and applies the sigmoid.
+// parts [items][2][nparts] fp32, lb_in / lb_f device scalars (fp32) or NULL, gi / gf [items] fp32 (items = T B, item = t B + b).
+// Until round 4 this was five torch launches (sum, add, sigmoid, add, sigmoid) between the pre-pass and the recurrence.
+__global__ void gate_readout_finish_kernel(const float* __restrict__ parts, int nparts, const float* __restrict__ lb_in,
+                                           const float* __restrict__ lb_f, float* __restrict__ gi, float* __restrict__ gf, int64_t items) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= items) return;
+  const float* p = parts + i * 2 * nparts;
+  float a = 0.f, b = 0.f;
+  for (int j = 0; j < nparts; ++j) { a += p[j]; b += p[nparts + j]; }
+  if (lb_in) a += lb_in[0];
+  if (lb_f) b += lb_f[0];
+  gi[i] = 1.f / (1.f + __expf(-a));
+  gf[i] = 1.f / (1.f + __expf(-b));
+}
+
+extern "C" int gcrnn_gate_readout_finish(const float* parts, int64_t nparts, const float* lb_in, const float* lb_f, float* gi, float* gf,
+                                         int64_t items, void* stream) {
+  if (!parts || !gi || !gf) return GCRNN_ERR_NULL_POINTER;
+  if (items <= 0 || nparts <= 0 || nparts > 4096) return GCRNN_ERR_BAD_SHAPE;
+  GCRNN_PRE_LAUNCH();
+  gate_readout_finish_kernel<<<(unsigned)cdiv(items, 256), 256, 0, as_stream(stream)>>>(parts, (int)nparts, lb_in, lb_f, gi, gf, items);
+  GCRNN_CHECK_LAUNCH();
+  return GCRNN_OK;
+}

@@ -779,13 +779,10 @@ def fused_time_gate_pair(xs, h0s, gate_in, gate_f, graph, N, store_states=False,
                                                       B, T, N, F, G, K, _p(hzero), _p(plan16.get('rank1_a')), _p(plan16.get('rank1_b')), st), 'gate_pair_prepass')
     if x_user is not None:
         del xs._pending_user
-    acc = parts.view(T * B, 2, (nch // 2) * waves).sum(dim=2)                  # fixed order: deterministic gates
-    out = []
-    for gidx, g in enumerate((gate_in, gate_f)):
-        a_ = acc[:, gidx]
-        if lbs[gidx] is not None:
-            a_ = a_ + lbs[gidx]
-        out.append(torch.sigmoid(a_).view(T, B).contiguous())
+    # read-out finish in ONE launch (round 5; until round 4 five torch launches): partials added in a fixed order, + bias, sigmoid
+    out = [torch.empty((T, B), dtype=torch.float32, device=xs.device) for _ in range(2)]
+    lbp = [(lb.reshape(-1).contiguous() if lb is not None else None) for lb in lbs]
+    check(lib.gcrnn_gate_readout_finish(_p(parts), (nch // 2) * waves, _p(lbp[0]), _p(lbp[1]), _p(out[0]), _p(out[1]), T * B, st), 'gate_readout_finish')
     if store_states:
         return out[0], out[1], (cs_in, gws[0]), (cs_f, gws[1])
     return out[0], out[1]

@@ -484,6 +484,11 @@ int gcrnn_fused_node_forward_wide_bf16(const void* h0s, void* hs, const void* yx
                                        const void* wpackB, const float* bias, const int32_t* tile_nodes, const int32_t* tile_off,
                                        const void* ell_col4, int64_t entries, int64_t B, int64_t T, int64_t N, int64_t F, int64_t K, void* Huser,
                                        int huser_last_only, void* stream);
+/* The time gates' read-out finished in ONE launch (Utils/graphML.py:2364-2366, 2372-2374): gi[i] = sigmoid(sum_j parts[i][0][j] + lb_in),
+ * gf[i] likewise with parts[i][1][..] and lb_f; parts [items][2][nparts] fp32 as gcrnn_fused_gate_pair_prepass_wide_bf16 leaves them (items = T B),
+ * summed in a fixed order; lb_in / lb_f: device scalars (fp32) or NULL. */
+int gcrnn_gate_readout_finish(const float* parts, int64_t nparts, const float* lb_in, const float* lb_f, float* gi, float* gf, int64_t items,
+                              void* stream);
 int gcrnn_fused_gate_pair_prepass_wide_bf16(const void* x_user, void* xs, const void* h0, const void* wpack, const float* bias2,
                                             const float* gw2, float* parts, void* cs_in, void* cs_f, const int32_t* tile_nodes,
                                             const int32_t* tile_off, const void* ell_col4, int64_t entries, int64_t B, int64_t T, int64_t N,
