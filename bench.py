@@ -751,6 +751,30 @@ def secondary_points(ctx, S, params, B, steps=8, warmup=2):
     except Exception as e:      # noqa: BLE001
         sec['fwd_nodegated_f32_x3'] = {'error': str(e)[:200]}
     gc.collect(); torch.cuda.empty_cache()
+    # ---- edge-gated cell at 1e-5: both filters as x3 filter passes, the attentions on the fp32 edge-softmax kernels (G14); beside it the composed fp32 path ----
+    try:
+        torch.manual_seed(0)
+        c = gml.GGCRNNCell(G, F, K, K, torch.tanh, False, 'edge', 1, True)
+        c.addGSO(torch.tensor(S))
+        c = c.to(dev).float()
+        X = torch.randn(B, T, G, N, device=dev, dtype=torch.float32, generator=gen)
+        h0 = torch.zeros(B, F, N, device=dev, dtype=torch.float32)
+        with torch.no_grad():
+            if c._use_fused_x3_edge(X, h0):
+                dt = _timed(lambda: c(X, h0), 2, 1)
+                os.environ['GCRNN_NO_X3_EDGE'] = '1'
+                try:
+                    dtc = _timed(lambda: c(X, h0), 1, 1)
+                finally:
+                    del os.environ['GCRNN_NO_X3_EDGE']
+                sec['fwd_edgegated_f32_x3'] = {'value': B / dt, 'unit': 'sequences/s', 'ms_per_step': 1e3 * dt, 'steps': 2, 'dtype': 'f32',
+                                               'composed_fp32_path_sequences_per_s': B / dtc,
+                                               'tolerance': '<= 1e-5 abs against the reference fixture G14 and the fp64 oracle (tests/test_fused.py)',
+                                               'what': 'GGCRNNCell(spatial_gating=edge) forward, filters on the fp32-accurate fused kernels (ops.fused_edge_cell_forward_x3)'}
+        del c, X, h0
+    except Exception as e:      # noqa: BLE001
+        sec['fwd_edgegated_f32_x3'] = {'error': str(e)[:200]}
+    gc.collect(); torch.cuda.empty_cache()
     # ---- gated cells, bf16 forward (reference graphML.py:2357-2407, 2420-2423; random-init gate sub-networks of the reference's shapes) ----
     for name, tg, sg in (('fwd_timegated', True, None), ('fwd_nodegated', False, 'node'), ('fwd_edgegated', False, 'edge')):
         try:

@@ -412,6 +412,10 @@ class GGCRNNCell(nn.Module):
         if self._use_fused_x3_node(X, h0):
             return ops.fused_node_cell_forward_x3(X, h0, self.weight_A, self.weight_B, self.bias, self.graph, self._node_gate_params(),
                                                   self._fused_gates() if self.time_gating == True else None)  # noqa: E712
+        if self._use_fused_x3_edge(X, h0):
+            return ops.fused_edge_cell_forward_x3(X, h0, self.weight_A, self.weight_B, self.bias, self.graph,
+                                                  self.input_attention.forward_node_major, self.forget_attention.forward_node_major,
+                                                  self._fused_gates() if self.time_gating == True else None)  # noqa: E712
         if self._use_small(X, h0):
             return self._forward_small(X, h0)
         if self._use_small_training(X, h0):
@@ -698,6 +702,17 @@ class GGCRNNCell(nn.Module):
         if ops.small_supported(self.N, self.graph.fwd[0].nnz, self.G, self.F, self.Kin, self.Kst, X.dtype, self.E):
             return False
         return ops.fused_node_x3_supported(self.graph, self.N, self.F, self.G, self.Kin, self.Kst, X.dtype, self.E, X.shape[0], X.shape[1])
+
+    def _use_fused_x3_edge(self, X, h0):
+        """fp32 inference of the EDGE-gated cell (with or without time gates) with both filters on the fp32-accurate fused kernels (round 5,
+        ops.fused_edge_cell_forward_x3; the attentions run on the fp32 CSR edge-softmax kernels): the x3 conditions with G == F."""
+        if self._wants_grad(X, h0) or self.spatial_gating != 'edge' or self.sigma not in (torch.tanh, nn.functional.tanh):
+            return False
+        if X.dtype != torch.float32 or h0.dtype != X.dtype or self.weight_A.dtype != X.dtype or X.shape[0] > 2048 or os.environ.get('GCRNN_NO_X3_EDGE'):
+            return False
+        if ops.small_supported(self.N, self.graph.fwd[0].nnz, self.G, self.F, self.Kin, self.Kst, X.dtype, self.E):
+            return False
+        return self.G == self.F and ops.fused_x3_supported(self.graph, self.N, self.F, self.G, self.Kin, self.Kst, X.dtype, self.E, X.shape[0], X.shape[1])
 
     def _use_fused_x3_training(self, X, h0, time_gated=False):
         """fp32 training of the un-gated cell at the north_star's tolerance on the fused kernels (x3 forward, x3 data chain, exact-fp32

@@ -2020,6 +2020,86 @@ def fused_node_cell_forward_x3(X, h0, wA, wB, bias, graph, node_gates, time_gate
     return H
 
 
+def fused_edge_cell_forward_x3(X, h0, wA, wB, bias, graph, att_in, att_f, time_gates=None, last_only=False):
+    """Edge-gated GGCRNNCell forward (optionally time-gated too) to fp32 accuracy (round 5; reference Utils/graphML.py:2409-2416, 2420-2423,
+    graphAttention :521-627):  h_t = tanh( gi_t GAT_in(A(S) x_t + b) + gf_t GAT_f(B(S) h_{t-1} + b) ).
+    Both filters as x3 filter passes (gcrnn_fused_filter_x3: three bf16 planes per operand, exact fp32 products), the attentions on the fp32
+    CSR edge-softmax kernels (att_in / att_f: callables on node-major [T][N][B][F] fp32 tensors, GraphAttentional.forward_node_major), the time
+    gates' cells as one-step x3 cells. X: B x T x G x N fp32 with G == F, h0: B x F x N fp32 -> H: B x T x F x N fp32. Inference."""
+    require_device(X, h0, wA, wB, bias)
+    B, T, G, N = X.shape
+    F, Kin, Kst = wA.shape[0], wA.shape[2], wB.shape[2]
+    assert G == F, 'the x3 filter pass takes F -> F filters'
+    K = max(Kin, Kst)
+    plan = graph.fused_plan_x3()
+    npad, st, dev = plan['npad'], _stream(), X.device
+    Xc = X.detach().float().contiguous()
+    h0c = h0.detach().float().contiguous()
+    gargs = (_p(plan['tile_slots']), _p(plan['tile_off']), _p(plan['ell_col4']), plan['entries'])
+    r1 = _p(plan.get('rank1_x3'))
+    xs3 = torch.empty((T, 3, B, npad, G), dtype=torch.bfloat16, device=dev)
+    check(lib.gcrnn_pack_seq_major_x3(_p(Xc), _p(xs3), B, T, G, N, npad, st), 'pack_seq_x3')
+    h3 = torch.empty((1, 3, B, npad, F), dtype=torch.bfloat16, device=dev)
+    gi = gf = None
+    if time_gates is not None:
+        hzero = False if torch.cuda.is_current_stream_capturing() else not bool(h0c.any())
+        h03 = torch.empty((1, 3, B, npad, F), dtype=torch.bfloat16, device=dev)
+        check(lib.gcrnn_pack_seq_major_x3(_p(h0c), _p(h03), B, 1, F, N, npad, st), 'pack_seq_x3')
+        gv = []
+        for name in ('in', 'forget'):
+            wA_g, wB_g, bias_g, lin_w, lin_b = time_gates[name]
+            Kg = max(wA_g.shape[2], wB_g.shape[2])
+            wAg, wBg = wA_g.detach().float().contiguous(), wB_g.detach().float().contiguous()
+            wpg = torch.empty((3 * (F // 16) * Kg * ((F + G) // 32) * 64 * 8,), dtype=torch.bfloat16, device=dev)
+            check(lib.gcrnn_fused_pack_weights_x3(_p(wAg), _p(wBg), _p(wpg), F, G, wA_g.shape[2], wB_g.shape[2], st), 'pack_weights_x3')
+            bg = bias_g.detach().float().contiguous().view(-1) if bias_g is not None else None
+            c = torch.empty((B, T, F, N), dtype=torch.float32, device=dev)
+            check(lib.gcrnn_fused_gate_cells_x3(_p(xs3), _p(h03), _p(h3), _p(wpg), _p(bg), *gargs, B, T, N, F, G, Kg, plan['uniform_w'], _p(c), int(hzero), r1, st),
+                  'fused_gate_cells_x3')
+            logit = (c.view(B * T, F * N) @ lin_w.detach().float().reshape(-1)).view(B, T).t()
+            if lin_b is not None:
+                logit = logit + lin_b.detach().float().view(())
+            gv.append(torch.sigmoid(logit).contiguous())      # [T][B]
+            del c
+        gi, gf = gv
+
+    def state_taps(w, k):
+        wk = w.detach().float()
+        if k < K:
+            wk = torch.cat([wk, wk.new_zeros(F, 1, K - k, F)], dim=2)
+        wk = wk.contiguous()
+        wp = torch.empty((3 * (F // 16) * K * (F // 32) * 64 * 8,), dtype=torch.bfloat16, device=dev)
+        check(lib.gcrnn_fused_pack_weights_x3(_p(wk), _p(wk), _p(wp), F, 0, K, K, st), 'pack_weights_x3')
+        return wp
+    wp3A, wp3B = state_taps(wA, Kin), state_taps(wB, Kst)
+    bvec = bias.detach().float().view(1, 1, F) if bias is not None else None
+    y3 = torch.empty((3, B, npad, F), dtype=torch.bfloat16, device=dev)
+
+    def filt(z3, wp):      # [3][B][npad][F] planes -> filter output + bias, node-major [1][N][B][F] fp32
+        check(lib.gcrnn_fused_filter_x3(_p(z3), _p(y3), _p(wp), *gargs, B, N, F, K, plan['uniform_w'], r1, st), 'fused_filter_x3')
+        y = y3.float().sum(dim=0)
+        if bvec is not None:
+            y = y + bvec
+        return y[:, :N].permute(1, 0, 2).unsqueeze(0).contiguous()
+
+    H = torch.empty((B, T, F, N), dtype=torch.float32, device=dev)
+    hprev = h0c
+    for t in range(T):
+        gx = att_in(filt(xs3[t], wp3A))[0]                                   # [N][B][F]
+        hp = hprev if hprev.is_contiguous() else hprev.contiguous()
+        check(lib.gcrnn_pack_seq_major_x3(_p(hp), _p(h3), B, 1, F, N, npad, st), 'pack_seq_x3')
+        gh = att_f(filt(h3[0], wp3B))[0]
+        if gi is not None:
+            pre = gi[t].view(1, B, 1) * gx + gf[t].view(1, B, 1) * gh
+        else:
+            pre = gx + gh
+        H[:, t] = torch.tanh(pre).permute(1, 2, 0)
+        hprev = H[:, t]
+    if last_only:
+        return H[:, T - 1:].contiguous()
+    return H
+
+
 class _FusedTimeCellX3(torch.autograd.Function):
     """Time-gated GGCRNNCell (the reference's default, Utils/graphML.py:2196, :2357-2374, :2420-2423) at fp32 accuracy on the fused kernels,
     forward AND BPTT (round 4). Forward: the two gate cells as T x B one-step x3 cells that all read h0 (gcrnn_fused_gate_cells_x3, on the

@@ -484,6 +484,42 @@ def g13_fused_f32_node():
              H=H.detach().numpy(), params={k: v.astype(np.float32) for k, v in p.items()}, grad_sum=g_sum)
 
 
+def g14_fused_f32_edge():
+    """G14 (round 5): G13's graph, shapes and operand recipe for the EDGE-gated cell (Utils/graphML.py:2409-2416; graphAttention :521-627) and the
+    time + edge gated one: fp64 reference states with fp32-representable operands and non-zero h0. The edge-gated forward with both filters on
+    the fp32-accurate fused kernels (ops.fused_edge_cell_forward_x3) is compared at <= 1e-5."""
+    N, T, G, F, K, B = 200, 4, 32, 32, 3, 3
+    rng = np.random.default_rng(37)
+    U = np.triu(rng.random((N, N)) < 0.05, 1)
+    W = (U + U.T).astype(np.float64)
+    lam = np.max(np.linalg.eigvalsh(W))
+    w32 = np.float32(1.0 / lam)
+    S = (W * np.float64(w32)).reshape(1, N, N)
+    f32 = lambda a: np.asarray(a, dtype=np.float32).astype(np.float64)
+    X = f32(rng.standard_normal((B, T, G, N)))
+    h0 = f32(0.5 * rng.standard_normal((B, F, N)))
+    rows, cols = np.nonzero(S[0])
+    for name, tg in (('g14_fused_f32_edge', False), ('g14_fused_f32_time_edge', True)):
+        torch.manual_seed(94)
+        cell = gml.GGCRNNCell(G, F, K, K, torch.tanh, tg, 'edge', 1, True)
+        cell.addGSO(torch.tensor(S))
+        with torch.no_grad():
+            for pname, q in cell.named_parameters():
+                if pname.startswith('MLP_'):
+                    q.mul_(6.0)
+                if pname.endswith('attention.mixer'):
+                    q.mul_(4.0)                          # (default init leaves the attention coefficients near uniform over a neighbourhood)
+            for q in cell.parameters():
+                q.copy_(torch.tensor(f32(q.detach().numpy())))
+        p = sd_np(cell)
+        with torch.no_grad():
+            H = cell(torch.tensor(X), torch.tensor(h0))
+        check(orc.ggcrnn_cell(p, S, X, h0, tg, 'edge'), H.numpy(), name)
+        save(name, coo_row=rows.astype(np.int16), coo_col=cols.astype(np.int16), coo_val=S[0][rows, cols].astype(np.float32),
+             shape=np.array([N, T, G, F, K, B]), X=X.astype(np.float32), h0=h0.astype(np.float32),
+             H=H.numpy(), params={k: v.astype(np.float32) for k, v in p.items()})
+
+
 def g10_kstep_data():
     """The reference's KStepPrediction dataset (Utils/dataTools.py:1259-1317) on a reference SBM graph
     (Utils/graphTools.py createGraph 'SBM'), with the numpy global generator seeded: stores the graph, the noise arrays the
@@ -541,4 +577,5 @@ if __name__ == '__main__':
     g11_fused_f32()
     g12_fused_f32_time()
     g13_fused_f32_node()
+    g14_fused_f32_edge()
     print('all oracle checks passed at tol', TOL)

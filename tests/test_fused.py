@@ -2035,6 +2035,75 @@ def test_fp32_accurate_node_gated_forward_matches_reference_fixture(golden, name
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('name,tg', [('g14_fused_f32_edge', False), ('g14_fused_f32_time_edge', True)])
+def test_fp32_accurate_edge_gated_forward_matches_reference_fixture(golden, name, tg):
+    """G14: the EDGE-gated cell (Utils/graphML.py:2409-2416, 2420-2423, graphAttention :521-627; with and without the time gates) at the
+    north_star's 1e-5 with both filters as x3 filter passes, the attentions on the fp32 CSR edge-softmax kernels and the time gates' cells
+    as one-step x3 cells (ops.fused_edge_cell_forward_x3) -- against the REFERENCE's fp64 states (tests/golden/make_golden.py
+    g14_fused_f32_edge: fp32-representable operands, non-zero h0, mixers scaled so that the attention is far from uniform)."""
+    g = golden(name)
+    dev = torch.device('cuda:0')
+    cell, S = _g9_cell(g, tg, 'edge', dev)
+    X = torch.tensor(g['X'], dtype=torch.float32, device=dev)
+    h0 = torch.tensor(g['h0'], dtype=torch.float32, device=dev)
+    calls = []
+    from gated_gcrnns_amd import ops
+    orig = ops.fused_edge_cell_forward_x3
+    ops.fused_edge_cell_forward_x3 = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+    try:
+        with torch.no_grad():
+            assert cell._use_fused_x3_edge(X, h0)
+            H = cell(X, h0)
+    finally:
+        ops.fused_edge_cell_forward_x3 = orig
+    assert len(calls) == 1 and H.dtype == torch.float32
+    err = float((H.double().cpu() - torch.tensor(g['H'])).abs().max())
+    _tol_report('x3 edge-gated forward vs %s: max |H - reference| = %.2e' % (name, err))
+    assert err <= 1e-5, err
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('N,F,K,B,T,tg,hz', [(1000, 64, 5, 3, 3, False, True), (1000, 64, 5, 2, 3, True, False), (600, 32, 3, 4, 3, False, False)])
+def test_fp32_accurate_edge_gated_forward_matches_the_oracle_at_bench_sizes(N, F, K, B, T, tg, hz):
+    """The same at the bench's node count against the fp64 oracle on fp32-representable operands (uniform-weight graph, G = F)."""
+    dev = torch.device('cuda:0')
+    import gated_gcrnns_amd.Utils.graphML as gml
+    rng = np.random.default_rng(59)
+    W = (rng.random((N, N)) < 10.0 / N).astype(np.float64)
+    W = np.triu(W, 1); W = W + W.T
+    w32 = np.float32(1.0 / np.max(np.abs(np.linalg.eigvalsh(W))))
+    S = (W * np.float64(w32)).reshape(1, N, N)
+    torch.manual_seed(59)
+    cell = gml.GGCRNNCell(F, F, K, K, torch.tanh, tg, 'edge', 1, True)
+    cell.addGSO(torch.tensor(S))
+    cell = cell.float()
+    with torch.no_grad():
+        for n_, q in cell.named_parameters():
+            if n_.endswith('attention.mixer'):
+                q.mul_(4.0)
+    f32 = lambda a: np.asarray(a, dtype=np.float32).astype(np.float64)
+    X = f32(rng.standard_normal((B, T, F, N)))
+    h0 = np.zeros((B, F, N)) if hz else f32(0.4 * rng.standard_normal((B, F, N)))
+    params = {k: v.detach().double().numpy() for k, v in cell.state_dict().items()}
+    Href = orc.ggcrnn_cell(params, S, X, h0, tg, 'edge')
+    cell = cell.to(dev)
+    Xd, hd = torch.tensor(X, dtype=torch.float32, device=dev), torch.tensor(h0, dtype=torch.float32, device=dev)
+    with torch.no_grad():
+        assert cell._use_fused_x3_edge(Xd, hd)
+        H = cell(Xd, hd)
+        os.environ['GCRNN_NO_X3_EDGE'] = '1'
+        try:
+            assert not cell._use_fused_x3_edge(Xd, hd)
+            Hc = cell(Xd, hd)                    # the composed fp32 path (LSIGF + attention kernels)
+        finally:
+            del os.environ['GCRNN_NO_X3_EDGE']
+    err = float(np.abs(H.double().cpu().numpy() - Href).max())
+    errc = float(np.abs(Hc.double().cpu().numpy() - Href).max())
+    _tol_report('x3 edge-gated forward vs oracle N=%d F=%d K=%d tg=%s: %.2e (composed fp32 path: %.2e)' % (N, F, K, tg, err, errc))
+    assert err <= 1e-5 and errc <= 1e-5, (err, errc)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('N,F,K,B,T,tg,hz', [(1000, 64, 5, 3, 4, False, True), (1000, 64, 5, 2, 3, True, False), (600, 32, 3, 4, 3, False, False)])
 def test_fp32_accurate_node_gated_forward_matches_the_oracle_at_bench_sizes(N, F, K, B, T, tg, hz):
     """The same at the bench's node count against the fp64 oracle on fp32-representable operands (uniform-weight graph, G = F)."""
