@@ -15,6 +15,24 @@
 //  - du_k is consumed by the GEMM of tap k and by the hop that produces du_{k+1}: no per-tap storage at all.
 // LDS: state fp32 [1024][16] (64 KiB) | graph image 96 B x entries | transposed half image (16.5 KiB).
 // ------------------------------------------------------------------------------------------
+// In-kernel phase stamps (diagnostic builds only, -DGCRNN_WGRAD_STAMPS; tools/wgrad_stamps.py): thread 0 of every workgroup records s_memtime
+// at the phase boundaries of its THIRD item (a global store each; the timing build is not the shipped one).
+#if defined(GCRNN_WGRAD_STAMPS)
+static __device__ unsigned long long gcrnn_wgrad_stamps[1024 * 32];
+#define WG_STAMP(slot)                                                                                         \
+  do {                                                                                                         \
+    if (stamp_on && threadIdx.x == 0) {                                                                        \
+      unsigned long long tv_;                                                                                  \
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tv_)::"memory");                              \
+      gcrnn_wgrad_stamps[blockIdx.x * 32 + (slot)] = tv_;                                                      \
+    }                                                                                                          \
+  } while (0)
+extern "C" int gcrnn_debug_read_wgrad_stamps(void* host) {
+  return hipMemcpyFromSymbol(host, HIP_SYMBOL(gcrnn_wgrad_stamps), sizeof(unsigned long long) * 1024 * 32) == hipSuccess ? 0 : 1;
+}
+#else
+#define WG_STAMP(slot) do {} while (0)
+#endif
 namespace { constexpr int TSTRIDE = 1056; constexpr int TBYTES = 16 * TSTRIDE; constexpr bool HT_IS_8 = (TILES == 8); }
 
 // UNI (uniform-weight graphs, gcrnn_ell_fill_z): no weight image in LDS, so BOTH halves of the transposed du_k image fit; a tap
@@ -95,8 +113,36 @@ __global__ __launch_bounds__(512, 2) void fused_wgrad_kernel(
   const __amdgpu_buffer_rsrc_t rsrc_d = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(dpre), 0, Tn * B * (NP * F * 2) > 0 ? Tn * B * (NP * F * 2) : 0x7fffffff, 0x00020000);
   __syncthreads();
 
+#ifndef GCRNN_WGRAD_PREFETCH
+#define GCRNN_WGRAD_PREFETCH 1      // 0: off (A/B)
+#endif
+  // L2 prefetch of this workgroup slot's NEXT item (round 5): its x, h and dpre blocks, one dword per 128-byte line by LDS-DMA into a scratch row
+  // (no register, nobody waits for it), issued behind tap 0's GEMM -- the item's own loads have landed by then and the taps issue no global
+  // traffic. The NCH chunk workgroups of an item sit on one XCD (consecutive-by-8 workgroup ids) and share the lines between them. A CU pulls
+  // ~10-14 B per clock from HBM / Infinity Cache and ~29 from L2 (MI355X_MICROARCH.md): the item-start loads, 290 KB, were 40 % of an item
+  // (profiles/r05_wgrad_stamps_before.txt).
+  const uint32_t pf_lds = __builtin_amdgcn_readfirstlane((uint32_t)reinterpret_cast<uintptr_t>(lbias + WAVES * FC) + (uint32_t)wave * 256u);
+  auto prefetch_next_item = [&](int itn) {
+    if (!GCRNN_WGRAD_PREFETCH || itn >= items) return;
+    const int tn = itn / B, bn = itn - tn * B;
+    const uint16_t* hsrc = (tn > 0 && !h_is_h0) ? Huser + ((int64_t)bn * Tn + (tn - 1)) * F * N : h0user + (int64_t)bn * F * N;
+    const uint16_t* srcs[3] = {Xuser + ((int64_t)bn * Tn + tn) * G * N, hsrc, dpre + (int64_t)(tn * B + bn) * NP * F};
+    const uint32_t bytes[3] = {(uint32_t)(G * N * 2), (uint32_t)(F * N * 2), (uint32_t)(NP * F * 2)};
+#pragma unroll
+    for (int blk = 0; blk < 3; ++blk) {
+      const uint32_t lines = (bytes[blk] + 127u) / 128u, share = (lines + NCH - 1) / NCH;
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(srcs[blk]), 0, (int)bytes[blk], 0x00020000);
+      for (uint32_t l0 = 0; l0 < share; l0 += 512) {      // (wave-uniform trip count; lines past the block's end are dropped by the bounds check)
+        const uint32_t line = (uint32_t)chunk * share + l0 + (uint32_t)tid;
+        const uint32_t voff = (l0 + (uint32_t)tid < share) ? line * 128u : 0xfffffff0u;
+        asm volatile("s_mov_b32 m0, %2\n\tbuffer_load_dword %0, %1, 0 offen lds" ::"v"(voff), "s"(rs), "s"(pf_lds) : "memory");
+      }
+    }
+  };
   for (int it = it0; it < items; it += seq_slots) {
     const int t = it / B, b = it - t * B;
+    [[maybe_unused]] const bool stamp_on = (it == it0 + 2 * seq_slots) && blockIdx.x < 1024;
+    WG_STAMP(0);
     // ---- B operand: this wave's 16 input features x 1024 nodes, straight from the user layout --------------------
     // The fragments of nodes 0..511 stay in registers across the taps; those of nodes 512..1023 are re-fetched per tap
     // (L2-resident after the first tap) through registers that the hop pipeline has just released -- the kernel must
@@ -123,20 +169,26 @@ __global__ __launch_bounds__(512, 2) void fused_wgrad_kernel(
     else { zsrc = h0user + (int64_t)b * F * N; zrows = F; }
     const __amdgpu_buffer_rsrc_t rsrc_z = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(zsrc), 0, live ? zrows * N * 2 : 0, 0x00020000);      // dead waves: zero-length buffer, the loads cost nothing
     const int vo = (jrow * N + 8 * q) * 2;
-#pragma unroll
-    for (int s2 = 0; s2 < (ZRES ? 32 : 16); ++s2)
-      bfr[s2] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsrc_z, vo + 64 * s2, 0, 0));
-    // ---- du_0 = dpre chunk of this item ------------------------------------------------------------------------
+    // ---- du_0 = dpre chunk of this item: requested FIRST (round 5) -- memory returns in order, and tap 0's images and hop need du_0 only,
+    // so the 32 fragments of z (8 x the bytes) have until tap 0's GEMM to land instead of standing in front of everything
     f32x4 cur[TILES];
     const int soff_d = ((t * B + b) * NP) * (F * 2);
+    u32x2 d2r[TILES];
 #pragma unroll
     for (int i = 0; i < TILES; ++i) {
       int wv = woff[i];
       asm volatile("" : "+v"(wv));
-      const u32x2 d2 = __builtin_amdgcn_raw_buffer_load_b64(rsrc_d, (wv >> 16) * (F * 2) + (chunk * FC + q * 4) * 2, soff_d, 0);
-      cur[i] = f32x4{bf2f((uint16_t)(d2[0] & 0xffffu)), bf2f((uint16_t)(d2[0] >> 16)),
-                     bf2f((uint16_t)(d2[1] & 0xffffu)), bf2f((uint16_t)(d2[1] >> 16))};
+      d2r[i] = __builtin_amdgcn_raw_buffer_load_b64(rsrc_d, (wv >> 16) * (F * 2) + (chunk * FC + q * 4) * 2, soff_d, 0);
     }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int s2 = 0; s2 < (ZRES ? 32 : 16); ++s2)
+      bfr[s2] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsrc_z, vo + 64 * s2, 0, 0));
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < TILES; ++i)
+      cur[i] = f32x4{bf2f((uint16_t)(d2r[i][0] & 0xffffu)), bf2f((uint16_t)(d2r[i][0] >> 16)),
+                     bf2f((uint16_t)(d2r[i][1] & 0xffffu)), bf2f((uint16_t)(d2r[i][1] >> 16))};
     if (dbsum) {                                        // sum of dpre over this item's nodes (padded rows are zero)
       f32x4 bacc = cur[0];
 #pragma unroll
@@ -149,21 +201,25 @@ __global__ __launch_bounds__(512, 2) void fused_wgrad_kernel(
         if (r == 0) lbias[wave * FC + q * 4 + c] += v * gbias;                  // one owner lane per address, items in program order: deterministic
       }
     }
+    WG_STAMP(1);
     if constexpr (UNI != 0) {
-    // Transposed image of du_k as 32-BIT words [feature pair][node] = {du[n][2p], du[n][2p+1]} (round 3): a lane's four values are two
-    // such words -> 2 ds_write_b32 per tile instead of 4 two-byte scatters (measured in the step kernels: 14 LDS cycles per ds_write_b16);
-    // an A fragment (8 nodes of ONE feature) is then two 16-byte reads of its pair's row + 4 v_perm_b32 that pick the lane's parity.
-    // Row stride 2096 B (= 16 x 131, 131 = 3 mod 16): the eight pair rows of a read group sit on distinct bank quads.
-    constexpr int RS2 = 2096, TB2 = 8 * RS2;
-    static_assert(2 * TB2 <= 2 * TBYTES, "the two half images fit the transposed-image allocation");
-    typedef __attribute__((__vector_size__(4 * sizeof(unsigned int)))) unsigned int u32x4w;
-    const uint32_t psel = (r & 1) ? 0x07060302u : 0x05040100u;       // hi / lo halves of two words -> one register of the fragment
-    auto afrag = [&](int half, int s4p) {
-      const char* rowp = tbuf + half * TB2 + (r >> 1) * RS2 + (32 * s4p + 8 * q) * 4;
-      const u32x4w w0 = *reinterpret_cast<const u32x4w*>(rowp), w1 = *reinterpret_cast<const u32x4w*>(rowp + 16);
-      const u32x4w f = {__builtin_amdgcn_perm(w0[1], w0[0], psel), __builtin_amdgcn_perm(w0[3], w0[2], psel),
-                        __builtin_amdgcn_perm(w1[1], w1[0], psel), __builtin_amdgcn_perm(w1[3], w1[2], psel)};
-      return __builtin_bit_cast(bf16x8, f);
+    // The GEMM's image of du_k (round 5): plain bf16 rows [node][16 f'] in NODE order -- a lane's four values are one 8-byte ds_write_b64 --
+    // read back TRANSPOSED by the hardware: ds_read_b64_tr_b16 hands lane (f' = lane & 15, g = lane >> 4) the values of feature f' at four
+    // consecutive nodes, two such reads are the A fragment (8 nodes of ONE feature) of v_mfma_f32_16x16x32_bf16. (Rounds 3-4: 32-bit words
+    // [feature pair][node], two ds_write_b32 per tile, two 16-byte reads + 4 v_perm_b32 per fragment, half of every read discarded.)
+    // off(node) = 32 node ^ (node & 8) << 4: the two blocks a 32-lane half reads (nodes 8 apart) then sit on opposite halves of the 64 banks.
+    static_assert(NP * 32 <= 2 * TBYTES, "the node-order image fits the transposed-image allocation");
+    typedef short s16x4 __attribute__((ext_vector_type(4)));
+    typedef __attribute__((address_space(3))) s16x4* lds_s16x4;
+    const uint32_t tb0 = (uint32_t)reinterpret_cast<uintptr_t>(tbuf);
+    // lane 4 q' + p of group g: row (node) 8 g + 4 i + q' of the fragment's 32, columns 4 p .. 4 p + 3; the swizzle bit is (g & 1), so read i
+    // sits at 128 (i ^ (g & 1)): two base registers, the fragment index in the immediate offset
+    const uint32_t tr_lane = tb0 + (uint32_t)(256 * q + 32 * ((lane >> 2) & 3) + 8 * (lane & 3));
+    const lds_s16x4 tr_b0 = reinterpret_cast<lds_s16x4>(tr_lane + 128u * (uint32_t)(q & 1));
+    const lds_s16x4 tr_b1 = reinterpret_cast<lds_s16x4>(tr_lane + 128u * (uint32_t)((q & 1) ^ 1));
+    auto afrag = [&](int s) {
+      const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(tr_b0 + 128 * s), hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(tr_b1 + 128 * s);      // (+ 1024 s bytes)
+      return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
     };
 #pragma unroll
     for (int k = 0; k < K; ++k) {
@@ -184,18 +240,67 @@ __global__ __launch_bounds__(512, 2) void fused_wgrad_kernel(
           else state_put<UNI == 2>(state, wv, cur[i]);
         }
         const int node = wv >> 16;
-        char* tb = tbuf + (node >= 512 ? TB2 : 0) + (node & 511) * 4 + (2 * q) * RS2;
-        *reinterpret_cast<uint32_t*>(tb) = pack2bf(cur[i][0], cur[i][1]);
-        *reinterpret_cast<uint32_t*>(tb + RS2) = pack2bf(cur[i][2], cur[i][3]);
+        typedef __attribute__((__vector_size__(2 * sizeof(unsigned int)))) unsigned int u32x2w;
+        *reinterpret_cast<u32x2w*>(tbuf + (((node << 5) ^ ((node & 8) << 4)) + 8 * q)) = u32x2w{pack2bf(cur[i][0], cur[i][1]), pack2bf(cur[i][2], cur[i][3])};
       }
       lds_barrier();      // LDS hand-off only: loads in flight stay in flight (gcrnn_fused_step.h)
+      WG_STAMP(2 + 4 * k);
+      if constexpr (ZRES) {
+      // (round 5) the hop FIRST: it needs the hop image only, while tap 0's GEMM needs the item's z, still landing; then the tap's GEMM in one piece
+      if (k < K - 1) {
+        LGKM_WAIT(0);
+#define GCRNN_WG_INIT(i) f32x4{0.f, 0.f, 0.f, 0.f}
+#define GCRNN_WG_STORE(i, a) cur[i] = a
+        if constexpr (UNI == 2) {
+          // the summing stream (tile exits cost nothing, register window 28 instead of 42): du_{k+1} = w * (sum of the gathered rows)
+          GCRNN_HOP_ASM_UNI16_SUMS_STREAM(cur);
+          if constexpr (R1) {
+#pragma unroll
+            for (int i = 0; i < TILES; ++i) {
+              int wv = woff[i];
+              asm volatile("" : "+v"(wv));
+              cur[i] *= r1b[wv >> 16];
+            }
+          } else {
+#pragma unroll
+            for (int i = 0; i < TILES; ++i) cur[i] *= uni_w;
+          }
+        }
+        else GCRNN_HOP_ASM_UNI_STREAM(GCRNN_WG_INIT, GCRNN_WG_STORE);
+#undef GCRNN_WG_INIT
+#undef GCRNN_WG_STORE
+      }
+      WG_STAMP(3 + 4 * k);
+      if (live) {
+        f32x4 acc2 = {0.f, 0.f, 0.f, 0.f};      // two accumulation chains: 32 dependent MFMAs on one tile were the GEMM's whole duration
+#pragma unroll
+        for (int s4 = 0; s4 < 32; s4 += 4) {
+          bf16x8 a4[4];
+#pragma unroll
+          for (int p = 0; p < 4; ++p) a4[p] = afrag(s4 + p);
+#pragma unroll
+          for (int p = 0; p < 4; ++p) {
+            if (p & 1) acc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a4[p], bfr[(ZRES ? s4 + p : 0)], acc2, 0, 0, 0);
+            else accD[k] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a4[p], bfr[(ZRES ? s4 + p : 0)], accD[k], 0, 0, 0);
+          }
+        }
+        accD[k] += acc2;
+      }
+      if (k == 0) {
+        // every wave, live or not, has its z (the compiler's own waits sit inside `if (live)`: without this one it re-waits in every later
+        // tap -- and those waits would then also cover the prefetches below, which it does not know about)
+        __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0)
+        prefetch_next_item(it + seq_slots);
+      }
+      WG_STAMP(4 + 4 * k);
+      } else {
       // S2: D_k += du_k^T z over nodes 0..511 (register-resident fragments), then the first re-fetched batch (nodes 512..767)
       if (live) {
 #pragma unroll
         for (int s4 = 0; s4 < 16; s4 += 4) {
           bf16x8 a4[4];
 #pragma unroll
-          for (int p = 0; p < 4; ++p) a4[p] = afrag(0, s4 + p);
+          for (int p = 0; p < 4; ++p) a4[p] = afrag(s4 + p);
 #pragma unroll
           for (int p = 0; p < 4; ++p) accD[k] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a4[p], bfr[s4 + p], accD[k], 0, 0, 0);
         }
@@ -203,11 +308,12 @@ __global__ __launch_bounds__(512, 2) void fused_wgrad_kernel(
         for (int s4 = 0; s4 < 8; s4 += 4) {
           bf16x8 a4[4];
 #pragma unroll
-          for (int p = 0; p < 4; ++p) a4[p] = afrag(1, s4 + p);
+          for (int p = 0; p < 4; ++p) a4[p] = afrag(16 + s4 + p);
 #pragma unroll
           for (int p = 0; p < 4; ++p) accD[k] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a4[p], ZRES ? bfr[(ZRES ? 16 : 0) + s4 + p] : bl0[ZRES ? 0 : s4 + p], accD[k], 0, 0, 0);
         }
       }
+      WG_STAMP(3 + 4 * k);
       // second batch (nodes 768..1023): in flight across the hop
       bf16x8 bl1[ZRES ? 1 : 8];
       if constexpr (!ZRES) {
@@ -238,17 +344,20 @@ __global__ __launch_bounds__(512, 2) void fused_wgrad_kernel(
 #undef GCRNN_WG_INIT
 #undef GCRNN_WG_STORE
       }
+      WG_STAMP(4 + 4 * k);
       if (live) {
 #pragma unroll
         for (int s4 = 0; s4 < 8; s4 += 4) {
           bf16x8 a4[4];
 #pragma unroll
-          for (int p = 0; p < 4; ++p) a4[p] = afrag(1, 8 + s4 + p);
+          for (int p = 0; p < 4; ++p) a4[p] = afrag(24 + s4 + p);
 #pragma unroll
           for (int p = 0; p < 4; ++p) accD[k] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a4[p], ZRES ? bfr[(ZRES ? 24 : 0) + s4 + p] : bl1[ZRES ? 0 : s4 + p], accD[k], 0, 0, 0);
         }
       }
+      }
       lds_barrier();      // LDS hand-off only: loads in flight stay in flight (gcrnn_fused_step.h)
+      WG_STAMP(5 + 4 * k);
     }
     } else {
 #pragma unroll
@@ -395,8 +504,8 @@ static int fused_wgrad_t(const void* dpre, const void* Xuser, const void* Huser,
 #else
   const bool uni = false;
 #endif
-  const size_t lds = uni ? (size_t)NP * FC * 4 + (size_t)ga.entries * 32 + 2 * TBYTES + WAVES * FC * 4 + (ga.img16 ? GCRNN_HOP_COLUMN_PAD : 0)
-                         : (size_t)NP * FC * 4 + (size_t)ga.entries * 96 + TBYTES + WAVES * FC * 4;
+  const size_t lds = uni ? (size_t)NP * FC * 4 + (size_t)ga.entries * 32 + 2 * TBYTES + WAVES * FC * 4 + WAVES * 256 + (ga.img16 ? GCRNN_HOP_COLUMN_PAD : 0)
+                         : (size_t)NP * FC * 4 + (size_t)ga.entries * 96 + TBYTES + WAVES * FC * 4 + WAVES * 256;      // (the last 256 B per wave: where the L2 prefetches land)
   if (lds > 160 * 1024 || !ga.ell_val4 || !ga.ell_col4) return GCRNN_ERR_UNSUPPORTED;
   if (ga.img16 && !uni) return GCRNN_ERR_UNSUPPORTED;
   if (r1a && !(uni && ga.img16)) return GCRNN_ERR_UNSUPPORTED;
