@@ -139,6 +139,7 @@ def _bind(lib):
         'gcrnn_fused_backward_data_bf16': (C.c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p,
                                                      _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_p, _c_p, _c_p, C.c_double, _c_p, C.c_int, _c_p]),
         'gcrnn_fused_wgrad_slots': (_c_i64, [_c_i64, _c_i64]),
+        'gcrnn_fused_wgrad_bf16_slots': (_c_i64, [_c_i64, _c_i64, _c_i64, _c_i64, C.c_int]),
         'gcrnn_fused_backward_weight_bf16': (C.c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p,
                                                        _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_p, _c_p,
                                                        C.c_int, _c_p, C.c_double, _c_p, _c_p, _c_p]),

@@ -33,6 +33,10 @@ extern "C" int gcrnn_debug_read_wgrad_stamps(void* host) {
 #else
 #define WG_STAMP(slot) do {} while (0)
 #endif
+template <class Fn, int... J>
+__device__ __forceinline__ void wg_for(Fn&& f, std::integer_sequence<int, J...>) { (f(std::integral_constant<int, J>{}), ...); }
+template <int N, class Fn>
+__device__ __forceinline__ void wg_forn(Fn&& f) { wg_for(f, std::make_integer_sequence<int, N>{}); }
 namespace { constexpr int TSTRIDE = 1056; constexpr int TBYTES = 16 * TSTRIDE; constexpr bool HT_IS_8 = (TILES == 8); }
 
 // UNI (uniform-weight graphs, gcrnn_ell_fill_z): no weight image in LDS, so BOTH halves of the transposed du_k image fit; a tap
@@ -41,7 +45,11 @@ namespace { constexpr int TSTRIDE = 1056; constexpr int TBYTES = 16 * TSTRIDE; c
 // R1 (UNI == 2 only): rank-1-weighted graph S[m][n] = a[m] b[n] on the adjoint plan of its 0/1 pattern (graph.fused_plan_rank1(adjoint=True)):
 // du_{k+1} = b (.) sum over the pattern of (a (.) du_k) -- the hop image holds a (.) du_k, the sums are scaled by b (r1a / r1b: the factors of
 // this direction, [NP] fp32); the transposed image (the GEMM's operand) holds du_k itself.
-template <int K, int HS, int XS, int UNI, bool R1 = false>
+// CPW (round 5; UNI == 2, z resident): 16-feature chunks of dpre per workgroup VISIT of an item. With 2, the item's operand z -- 256 KB through a
+// CU's ~29 B per clock from L2: a quarter of a (item, chunk) -- is loaded once for two chunks; the accumulators of the chunk that is not being
+// worked on are parked in LDS (K f32x4 per thread, one 16-byte access each way per item: the order of the two chunks alternates from item
+// to item, so they change places once per item).
+template <int K, int HS, int XS, int UNI, bool R1 = false, int CPW = 1>
 __global__ __launch_bounds__(512, 2) void fused_wgrad_kernel(
     const uint16_t* __restrict__ dpre,       // [T][B][NP][F] bf16 sequence-major
     const uint16_t* __restrict__ Xuser,      // [B][T][G][N] bf16
@@ -58,19 +66,23 @@ __global__ __launch_bounds__(512, 2) void fused_wgrad_kernel(
     int entries, int B, int Tn, int N, float uni_w,
     const float* __restrict__ r1a, const float* __restrict__ r1b) {
   constexpr int F = 32 * HS, G = 32 * XS, C = F + G, NCH = F / FC, JT = C / 16;
+  constexpr int NWG = NCH / CPW;      // workgroups per item
+  constexpr int STB = (CPW == 2) ? NP * FC * 2 : NP * FC * 4;      // the hop image (CPW == 2: bf16 rows only, the fp32 size was half unused)
   static_assert(JT <= WAVES, "one input-feature tile per wave");
   static_assert(!R1 || UNI == 2, "rank-1 graphs: the bf16-image variant");
+  static_assert(CPW == 1 || (CPW == 2 && UNI == 2 && NCH % 2 == 0), "chunk pairs: the bf16-image variant, an even number of chunks");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* state = reinterpret_cast<float*>(smem);
-  float4* lval4 = reinterpret_cast<float4*>(smem + NP * FC * 4);
+  float4* lval4 = reinterpret_cast<float4*>(smem + STB);
   uint2* lcol4 = reinterpret_cast<uint2*>(lval4 + (UNI ? 0 : entries * 4));
   char* tbuf = reinterpret_cast<char*>(lcol4 + entries * 4) + (UNI == 2 ? GCRNN_HOP_COLUMN_PAD : 0);      // (UNI == 2: zeros behind the column image, the summing stream does not clamp its column pointer)
-  float* lbias = reinterpret_cast<float*>(tbuf + (UNI ? 2 : 1) * TBYTES);      // [WAVES][16] bias-gradient partial sums, one row per wave (no LDS atomics)
+  float* lbias = reinterpret_cast<float*>(tbuf + (UNI ? 2 : 1) * TBYTES);      // [CPW][WAVES][16] bias-gradient partial sums, one row per wave (no LDS atomics)
+  f32x4* park = reinterpret_cast<f32x4*>(reinterpret_cast<char*>(lbias) + CPW * WAVES * FC * 4 + WAVES * 256);      // CPW == 2: [K][512] the other chunk's accumulators (behind the prefetch scratch)
 
   const int L = blockIdx.x;
-  const int grp = L / (8 * NCH), rem = L - grp * (8 * NCH);
-  const int chunk = rem >> 3, it0 = grp * 8 + (rem & 7);
-  const int seq_slots = (gridDim.x / (8 * NCH)) * 8;
+  const int grp = L / (8 * NWG), rem = L - grp * (8 * NWG);
+  const int cw = rem >> 3, it0 = grp * 8 + (rem & 7);
+  const int seq_slots = (gridDim.x / (8 * NWG)) * 8;
   const int items = B * Tn;
   if (it0 >= items) return;
 
@@ -95,13 +107,19 @@ __global__ __launch_bounds__(512, 2) void fused_wgrad_kernel(
   const int qoff = q * 16;
   const uint32_t lds0 = (uint32_t)reinterpret_cast<uintptr_t>(smem);
   const uint32_t qx = (uint32_t)qoff;
-  const uint32_t lds_val = lds0 + NP * FC * 4;
+  const uint32_t lds_val = lds0 + STB;
   const uint32_t lds_col = lds_val + (UNI ? 0 : entries * 64);
 
   f32x4 accD[K];
 #pragma unroll
   for (int k = 0; k < K; ++k) accD[k] = f32x4{0.f, 0.f, 0.f, 0.f};
-  if (tid < WAVES * FC) lbias[tid] = 0.f;       // row w: wave w's share of the bias gradient (its lanes r == 0 own quad q's 4 features)
+  if (tid < CPW * WAVES * FC) lbias[tid] = 0.f;       // row w: wave w's share of the bias gradient (its lanes r == 0 own quad q's 4 features)
+  if constexpr (CPW == 2) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) park[k * 512 + tid] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  int held = 0;               // CPW == 2: which chunk of the pair (0 / 1) has its accumulators in registers; the item starts with it
+  float gpark = 1.f;          // ... and the gate unit of the parked ones (see gprev below)
   const bool has_tile = wave < JT;
   const bool is_x = wave >= F / 16;                 // wave-uniform: tiles 0..F/16-1 are h features, the rest x features
   const int jrow = (is_x ? wave * 16 - F : wave * 16) + r;      // this lane's row (feature) inside its source block
@@ -118,10 +136,10 @@ __global__ __launch_bounds__(512, 2) void fused_wgrad_kernel(
 #endif
   // L2 prefetch of this workgroup slot's NEXT item (round 5): its x, h and dpre blocks, one dword per 128-byte line by LDS-DMA into a scratch row
   // (no register, nobody waits for it), issued behind tap 0's GEMM -- the item's own loads have landed by then and the taps issue no global
-  // traffic. The NCH chunk workgroups of an item sit on one XCD (consecutive-by-8 workgroup ids) and share the lines between them. A CU pulls
+  // traffic. The NWG workgroups of an item sit on one XCD (consecutive-by-8 workgroup ids) and share the lines between them. A CU pulls
   // ~10-14 B per clock from HBM / Infinity Cache and ~29 from L2 (MI355X_MICROARCH.md): the item-start loads, 290 KB, were 40 % of an item
   // (profiles/r05_wgrad_stamps_before.txt).
-  const uint32_t pf_lds = __builtin_amdgcn_readfirstlane((uint32_t)reinterpret_cast<uintptr_t>(lbias + WAVES * FC) + (uint32_t)wave * 256u);
+  const uint32_t pf_lds = __builtin_amdgcn_readfirstlane((uint32_t)reinterpret_cast<uintptr_t>(lbias + CPW * WAVES * FC) + (uint32_t)wave * 256u);
   auto prefetch_next_item = [&](int itn) {
     if (!GCRNN_WGRAD_PREFETCH || itn >= items) return;
     const int tn = itn / B, bn = itn - tn * B;
@@ -130,10 +148,10 @@ __global__ __launch_bounds__(512, 2) void fused_wgrad_kernel(
     const uint32_t bytes[3] = {(uint32_t)(G * N * 2), (uint32_t)(F * N * 2), (uint32_t)(NP * F * 2)};
 #pragma unroll
     for (int blk = 0; blk < 3; ++blk) {
-      const uint32_t lines = (bytes[blk] + 127u) / 128u, share = (lines + NCH - 1) / NCH;
+      const uint32_t lines = (bytes[blk] + 127u) / 128u, share = (lines + NWG - 1) / NWG;
       const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(srcs[blk]), 0, (int)bytes[blk], 0x00020000);
       for (uint32_t l0 = 0; l0 < share; l0 += 512) {      // (wave-uniform trip count; lines past the block's end are dropped by the bounds check)
-        const uint32_t line = (uint32_t)chunk * share + l0 + (uint32_t)tid;
+        const uint32_t line = (uint32_t)cw * share + l0 + (uint32_t)tid;
         const uint32_t voff = (l0 + (uint32_t)tid < share) ? line * 128u : 0xfffffff0u;
         asm volatile("s_mov_b32 m0, %2\n\tbuffer_load_dword %0, %1, 0 offen lds" ::"v"(voff), "s"(rs), "s"(pf_lds) : "memory");
       }
@@ -141,8 +159,8 @@ __global__ __launch_bounds__(512, 2) void fused_wgrad_kernel(
   };
   for (int it = it0; it < items; it += seq_slots) {
     const int t = it / B, b = it - t * B;
-    [[maybe_unused]] const bool stamp_on = (it == it0 + 2 * seq_slots) && blockIdx.x < 1024;
-    WG_STAMP(0);
+    [[maybe_unused]] const bool stamp_item = (it == it0 + 2 * seq_slots) && blockIdx.x < 1024;
+    { [[maybe_unused]] const bool stamp_on = stamp_item; WG_STAMP(0); }
     // ---- B operand: this wave's 16 input features x 1024 nodes, straight from the user layout --------------------
     // The fragments of nodes 0..511 stay in registers across the taps; those of nodes 512..1023 are re-fetched per tap
     // (L2-resident after the first tap) through registers that the hop pipeline has just released -- the kernel must
@@ -158,12 +176,6 @@ __global__ __launch_bounds__(512, 2) void fused_wgrad_kernel(
     float gbias = 2.f;                                    // the one bias enters both filters
     if (gw_) { gcur = gw_[t * B + b]; gbias = gi[t * B + b] + gf[t * B + b]; }
     const bool live = has_tile && gcur > 1e-12f && !(h_is_h0 && !is_x && hzero && hzero[0] != 0);      // wave-uniform
-    if (live && gcur != gprev) {
-      const float rb = gprev / gcur;
-#pragma unroll
-      for (int k = 0; k < K; ++k) accD[k] *= rb;
-      gprev = gcur;
-    }
     if (is_x) { zsrc = Xuser + ((int64_t)b * Tn + t) * G * N; zrows = G; }
     else if (t > 0 && !h_is_h0) { zsrc = Huser + ((int64_t)b * Tn + (t - 1)) * F * N; zrows = F; }
     else { zsrc = h0user + (int64_t)b * F * N; zrows = F; }
@@ -173,6 +185,37 @@ __global__ __launch_bounds__(512, 2) void fused_wgrad_kernel(
     // so the 32 fragments of z (8 x the bytes) have until tap 0's GEMM to land instead of standing in front of everything
     f32x4 cur[TILES];
     const int soff_d = ((t * B + b) * NP) * (F * 2);
+    // the item's chunks (compile-time index: the two visits differ in what they request, and shared code would make the compiler's waits
+    // for du_0 cover the z loads as well)
+    wg_forn<CPW>([&](auto ccc) {
+    constexpr int cc = decltype(ccc)::value;
+    [[maybe_unused]] const bool stamp_on = stamp_item && cc == 0;
+    if constexpr (cc == 1) {
+      // the pair's other chunk: its accumulators (and their gate unit) change places with the parked ones
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        const f32x4 o = park[k * 512 + tid];
+        park[k * 512 + tid] = accD[k];
+        accD[k] = o;
+      }
+      const float go = gpark;
+      gpark = gprev;
+      gprev = go;
+      held ^= 1;
+    }
+    const int chunk = cw * CPW + (CPW == 2 ? held : 0);
+    float* lbias_c = lbias + (CPW == 2 ? held : 0) * (WAVES * FC);
+    if (live && gcur != gprev) {
+      const float rb = gprev / gcur;
+#pragma unroll
+      for (int k = 0; k < K; ++k) accD[k] *= rb;
+      gprev = gcur;
+    }
+    if constexpr (!ZRES) {      // (the variants that re-fetch half of z per tap sit at the register budget: their resident half first, as in rounds 1-4)
+#pragma unroll
+      for (int s2 = 0; s2 < 16; ++s2)
+        bfr[s2] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsrc_z, vo + 64 * s2, 0, 0));
+    }
     u32x2 d2r[TILES];
 #pragma unroll
     for (int i = 0; i < TILES; ++i) {
@@ -180,11 +223,15 @@ __global__ __launch_bounds__(512, 2) void fused_wgrad_kernel(
       asm volatile("" : "+v"(wv));
       d2r[i] = __builtin_amdgcn_raw_buffer_load_b64(rsrc_d, (wv >> 16) * (F * 2) + (chunk * FC + q * 4) * 2, soff_d, 0);
     }
-    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (ZRES) {
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (cc == 0) {
 #pragma unroll
-    for (int s2 = 0; s2 < (ZRES ? 32 : 16); ++s2)
-      bfr[s2] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsrc_z, vo + 64 * s2, 0, 0));
-    __builtin_amdgcn_sched_barrier(0);
+        for (int s2 = 0; s2 < 32; ++s2)
+          bfr[s2] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsrc_z, vo + 64 * s2, 0, 0));
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
 #pragma unroll
     for (int i = 0; i < TILES; ++i)
       cur[i] = f32x4{bf2f((uint16_t)(d2r[i][0] & 0xffffu)), bf2f((uint16_t)(d2r[i][0] >> 16)),
@@ -198,7 +245,7 @@ __global__ __launch_bounds__(512, 2) void fused_wgrad_kernel(
         float v = bacc[c];
 #pragma unroll
         for (int off = 1; off < 16; off <<= 1) v += __shfl_xor(v, off, 64);     // over the 16 slots r of this quad
-        if (r == 0) lbias[wave * FC + q * 4 + c] += v * gbias;                  // one owner lane per address, items in program order: deterministic
+        if (r == 0) lbias_c[wave * FC + q * 4 + c] += v * gbias;                  // one owner lane per address, items in program order: deterministic
       }
     }
     WG_STAMP(1);
@@ -246,47 +293,55 @@ __global__ __launch_bounds__(512, 2) void fused_wgrad_kernel(
       lds_barrier();      // LDS hand-off only: loads in flight stay in flight (gcrnn_fused_step.h)
       WG_STAMP(2 + 4 * k);
       if constexpr (ZRES) {
-      // (round 5) the hop FIRST: it needs the hop image only, while tap 0's GEMM needs the item's z, still landing; then the tap's GEMM in one piece
-      if (k < K - 1) {
-        LGKM_WAIT(0);
+      // (round 5) the item's first tap runs its hop FIRST -- the hop needs the hop image only, the GEMM the item's z, still landing -- every other
+      // tap its GEMM first: du_k's registers are dead then (the hop refills them), which is what lets eight A fragments be in flight
+      auto hop_phase = [&]() {
+  if (k < K - 1) {
+          LGKM_WAIT(0);
 #define GCRNN_WG_INIT(i) f32x4{0.f, 0.f, 0.f, 0.f}
 #define GCRNN_WG_STORE(i, a) cur[i] = a
-        if constexpr (UNI == 2) {
-          // the summing stream (tile exits cost nothing, register window 28 instead of 42): du_{k+1} = w * (sum of the gathered rows)
-          GCRNN_HOP_ASM_UNI16_SUMS_STREAM(cur);
-          if constexpr (R1) {
+          if constexpr (UNI == 2) {
+            // the summing stream (tile exits cost nothing, register window 28 instead of 42): du_{k+1} = w * (sum of the gathered rows)
+            GCRNN_HOP_ASM_UNI16_SUMS_STREAM(cur);
+            if constexpr (R1) {
 #pragma unroll
-            for (int i = 0; i < TILES; ++i) {
-              int wv = woff[i];
-              asm volatile("" : "+v"(wv));
-              cur[i] *= r1b[wv >> 16];
+              for (int i = 0; i < TILES; ++i) {
+                int wv = woff[i];
+                asm volatile("" : "+v"(wv));
+                cur[i] *= r1b[wv >> 16];
+              }
+            } else {
+#pragma unroll
+              for (int i = 0; i < TILES; ++i) cur[i] *= uni_w;
             }
-          } else {
-#pragma unroll
-            for (int i = 0; i < TILES; ++i) cur[i] *= uni_w;
           }
-        }
-        else GCRNN_HOP_ASM_UNI_STREAM(GCRNN_WG_INIT, GCRNN_WG_STORE);
+          else GCRNN_HOP_ASM_UNI_STREAM(GCRNN_WG_INIT, GCRNN_WG_STORE);
 #undef GCRNN_WG_INIT
 #undef GCRNN_WG_STORE
-      }
-      WG_STAMP(3 + 4 * k);
-      if (live) {
-        f32x4 acc2 = {0.f, 0.f, 0.f, 0.f};      // two accumulation chains: 32 dependent MFMAs on one tile were the GEMM's whole duration
-#pragma unroll
-        for (int s4 = 0; s4 < 32; s4 += 4) {
-          bf16x8 a4[4];
-#pragma unroll
-          for (int p = 0; p < 4; ++p) a4[p] = afrag(s4 + p);
-#pragma unroll
-          for (int p = 0; p < 4; ++p) {
-            if (p & 1) acc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a4[p], bfr[(ZRES ? s4 + p : 0)], acc2, 0, 0, 0);
-            else accD[k] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a4[p], bfr[(ZRES ? s4 + p : 0)], accD[k], 0, 0, 0);
-          }
         }
-        accD[k] += acc2;
-      }
-      if (k == 0) {
+      };
+      auto gemm_phase = [&]() {
+        if (live) {
+          f32x4 acc2 = {0.f, 0.f, 0.f, 0.f};      // two accumulation chains: 32 dependent MFMAs on one tile were the GEMM's whole duration
+#pragma unroll
+          for (int s8 = 0; s8 < 32; s8 += 8) {
+            bf16x8 a8[8];
+#pragma unroll
+            for (int p = 0; p < 8; ++p) a8[p] = afrag(s8 + p);
+#pragma unroll
+            for (int p = 0; p < 8; ++p) {
+              if (p & 1) acc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a8[p], bfr[(ZRES ? s8 + p : 0)], acc2, 0, 0, 0);
+              else accD[k] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a8[p], bfr[(ZRES ? s8 + p : 0)], accD[k], 0, 0, 0);
+            }
+          }
+          accD[k] += acc2;
+        }
+      };
+      const bool hop_first = (k == 0 && cc == 0);      // (a constant once the taps are unrolled)
+      if (hop_first) hop_phase(); else gemm_phase();
+      WG_STAMP(3 + 4 * k);
+      if (hop_first) gemm_phase(); else hop_phase();
+      if (k == 0 && cc == 0) {
         // every wave, live or not, has its z (the compiler's own waits sit inside `if (live)`: without this one it re-waits in every later
         // tap -- and those waits would then also cover the prefetches below, which it does not know about)
         __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0)
@@ -464,24 +519,34 @@ __global__ __launch_bounds__(512, 2) void fused_wgrad_kernel(
       lds_barrier();      // LDS hand-off only: loads in flight stay in flight (gcrnn_fused_step.h)
     }
     }
+    });      // chunks of the item
+    { [[maybe_unused]] const bool stamp_on = stamp_item; WG_STAMP(25); }
   }
   // ---- flush: D_k[f' = 4q + c][j = 16 wave + r] -> this slot's partial dW[it0][chunk*16 + f'][k][j] (every element of the
   // slot's [F][K][C] block is written by exactly one lane of one workgroup) ----------------------------------------------
   if (has_tile) {
     float* dWs = dW + (int64_t)it0 * (F * K * C);
 #pragma unroll
-    for (int k = 0; k < K; ++k)
+    for (int hc = 0; hc < CPW; ++hc) {
+      const int chunk = cw * CPW + (CPW == 2 ? (held ^ hc) : 0);      // first the chunk in registers, then the parked one
+      const float gs = hc ? gpark : gprev;
 #pragma unroll
-      for (int c = 0; c < 4; ++c)
-        dWs[((int64_t)(chunk * FC + q * 4 + c) * K + k) * C + wave * 16 + r] = accD[k][c] * gprev;
+      for (int k = 0; k < K; ++k) {
+        const f32x4 a = hc ? park[k * 512 + tid] : accD[k];
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+          dWs[((int64_t)(chunk * FC + q * 4 + c) * K + k) * C + wave * 16 + r] = a[c] * gs;
+      }
+    }
   }
   if (dbsum) {
     __syncthreads();
-    if (tid < FC) {
+    if (tid < CPW * FC) {
+      const int hc = tid / FC, f = tid - hc * FC;
       float v = 0.f;
 #pragma unroll
-      for (int w = 0; w < WAVES; ++w) v += lbias[w * FC + tid];                // fixed order over the waves
-      dbsum[(int64_t)it0 * F + chunk * FC + tid] = v;
+      for (int w = 0; w < WAVES; ++w) v += lbias[hc * (WAVES * FC) + w * FC + f];                // fixed order over the waves
+      dbsum[(int64_t)it0 * F + (cw * CPW + hc) * FC + f] = v;
     }
   }
 }
@@ -491,6 +556,28 @@ extern "C" int64_t gcrnn_fused_wgrad_slots(int64_t items, int64_t F) {
   const int64_t NCH = F / FC;
   int64_t slots = cdiv(items, 8) * 8;
   const int64_t max_slots = (256 / NCH) / 8 * 8 > 0 ? (256 / NCH) / 8 * 8 : 8;
+  return slots > max_slots ? max_slots : slots;
+}
+
+// LDS bytes of the bf16 weight-gradient kernel (cpw: 16-feature chunks per workgroup visit of an item)
+static size_t wgrad_lds_bytes(bool uni, bool img16, int64_t entries, int K, int cpw) {
+  if (!uni) return (size_t)NP * FC * 4 + (size_t)entries * 96 + TBYTES + WAVES * FC * 4 + WAVES * 256;      // (the last 256 B per wave: where the L2 prefetches land)
+  if (cpw == 2) return (size_t)NP * FC * 2 + (size_t)entries * 32 + 2 * TBYTES + 2 * WAVES * FC * 4 + WAVES * 256 + GCRNN_HOP_COLUMN_PAD + (size_t)K * 512 * 16;
+  return (size_t)NP * FC * 4 + (size_t)entries * 32 + 2 * TBYTES + WAVES * FC * 4 + WAVES * 256 + (img16 ? GCRNN_HOP_COLUMN_PAD : 0);
+}
+// chunks per visit the launch will use: pairs on the bf16-image plans (uniform-weight and rank-1 graphs) when F has an even number of chunks and the parked accumulators fit
+static int wgrad_cpw(bool uni, bool img16, int64_t entries, int64_t F, int K) {
+#ifdef GCRNN_WGRAD_NO_PAIRS
+  return 1;
+#endif
+  return (uni && img16 && (F / FC) % 2 == 0 && wgrad_lds_bytes(true, true, entries, K, 2) <= 160 * 1024) ? 2 : 1;
+}
+// ... and the slots of THAT launch: with chunk pairs an item has half the workgroups, so twice the slots fill the chip. img16: the graph arrays
+// address a bf16 hop image (bit 1 of h_is_h0 in gcrnn_fused_backward_weight_bf16).
+extern "C" int64_t gcrnn_fused_wgrad_bf16_slots(int64_t items, int64_t F, int64_t K, int64_t entries, int img16) {
+  const int64_t NWG = (F / FC) / wgrad_cpw(img16 != 0, img16 != 0, entries, F, (int)K);
+  int64_t slots = cdiv(items, 8) * 8;
+  const int64_t max_slots = (256 / NWG) / 8 * 8 > 0 ? (256 / NWG) / 8 * 8 : 8;
   return slots > max_slots ? max_slots : slots;
 }
 
@@ -504,19 +591,20 @@ static int fused_wgrad_t(const void* dpre, const void* Xuser, const void* Huser,
 #else
   const bool uni = false;
 #endif
-  const size_t lds = uni ? (size_t)NP * FC * 4 + (size_t)ga.entries * 32 + 2 * TBYTES + WAVES * FC * 4 + WAVES * 256 + (ga.img16 ? GCRNN_HOP_COLUMN_PAD : 0)
-                         : (size_t)NP * FC * 4 + (size_t)ga.entries * 96 + TBYTES + WAVES * FC * 4 + WAVES * 256;      // (the last 256 B per wave: where the L2 prefetches land)
+  const int cpw = wgrad_cpw(uni, ga.img16 != 0, ga.entries, F, K);
+  const size_t lds = wgrad_lds_bytes(uni, ga.img16 != 0, ga.entries, K, cpw);
   if (lds > 160 * 1024 || !ga.ell_val4 || !ga.ell_col4) return GCRNN_ERR_UNSUPPORTED;
   if (ga.img16 && !uni) return GCRNN_ERR_UNSUPPORTED;
   if (r1a && !(uni && ga.img16)) return GCRNN_ERR_UNSUPPORTED;
   auto kern = uni ? (ga.img16 ? (r1a ? fused_wgrad_kernel<K, HS, XS, 2, true> : fused_wgrad_kernel<K, HS, XS, 2>) : fused_wgrad_kernel<K, HS, XS, 1>)
                   : fused_wgrad_kernel<K, HS, XS, 0>;
+  if (cpw == 2) kern = r1a ? fused_wgrad_kernel<K, HS, XS, 2, true, 2> : fused_wgrad_kernel<K, HS, XS, 2, false, 2>;
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
     return GCRNN_ERR_LAUNCH;
-  const int NCH = F / FC;
-  const int64_t slots = gcrnn_fused_wgrad_slots(B * T, F);
+  const int NWG = (F / FC) / cpw;
+  const int64_t slots = gcrnn_fused_wgrad_bf16_slots(B * T, F, K, ga.entries, ga.img16);
   GCRNN_PRE_LAUNCH();
-  kern<<<(unsigned)(slots * NCH), 512, lds, st>>>((const uint16_t*)dpre, (const uint16_t*)Xuser, (const uint16_t*)Huser,
+  kern<<<(unsigned)(slots * NWG), 512, lds, st>>>((const uint16_t*)dpre, (const uint16_t*)Xuser, (const uint16_t*)Huser,
                                                    (const uint16_t*)h0user, dW, dbsum, ga.tile_nodes, ga.tile_off,
                                                    (const float4*)ga.ell_val4, (const uint2*)ga.ell_col4, gi, gf, h_is_h0, hzero,
                                                    (int)ga.entries, (int)B, (int)T, (int)N, ga.uniform_w, r1a, r1b);

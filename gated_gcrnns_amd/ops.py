@@ -2325,9 +2325,6 @@ def fused_backward_weight(dpre, X, H, h0, graph, F, G, K, want_bias=False, gi=No
                 dbs = bsum if dbs is None else dbs + bsum
         return (dW, dbs) if want_bias else dW
     plan = graph.fused_plan(adjoint=True, kernel='wgrad')
-    slots = int(lib.gcrnn_fused_wgrad_slots(T * B, F))
-    dWp = torch.zeros((slots, F, K, F + G), dtype=torch.float32, device=dpre.device)      # per-slot partial sums (plain stores)
-    dbp = torch.zeros((slots, F), dtype=torch.float32, device=dpre.device) if want_bias else None
     Xc, h0c = X.contiguous(), h0.contiguous()
     Hc = H.contiguous() if H is not None else None
     uw = 0.0 if os.environ.get('GCRNN_WGRAD_NO_UNIFORM') else plan.get('uniform_w', 0.0)      # env: A/B switch
@@ -2337,6 +2334,9 @@ def fused_backward_weight(dpre, X, H, h0, graph, F, G, K, want_bias=False, gi=No
         if plan16 is not None:
             uw = 1.0
     pl = plan16 or plan
+    slots = int(lib.gcrnn_fused_wgrad_bf16_slots(T * B, F, K, pl['entries'], 1 if plan16 else 0))
+    dWp = torch.zeros((slots, F, K, F + G), dtype=torch.float32, device=dpre.device)      # per-slot partial sums (plain stores)
+    dbp = torch.zeros((slots, F), dtype=torch.float32, device=dpre.device) if want_bias else None
     check(lib.gcrnn_fused_backward_weight_bf16(_p(dpre), _p(Xc), _p(Hc), _p(h0c), _p(dWp),
                                                _p(dbp), _p(pl['tile_slots']), _p(pl['tile_off']), _p(pl['ell_val4']),
                                                _p(pl['ell_col4']), pl['entries'], B, T, graph.N, F, G, K,

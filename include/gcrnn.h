@@ -606,12 +606,15 @@ int gcrnn_fused_backward_data_bf16(const void* dHs, const void* hs, void* dpre, 
  *   item is h0 (the gate sub-cells, graphML.py:2362, 2370; Huser may then be NULL).
  * dpre: output of gcrnn_fused_backward_data_bf16; Xuser [B][T][G][N], Huser [B][T][F][N] (the forward's output) and
  * h0user [B][F][N] are the bf16 USER-layout tensors (node-contiguous rows feed the matrix cores directly; needs N % 8 == 0);
- * dW fp32 [slots][F][K][F+G], slots = gcrnn_fused_wgrad_slots(B*T, F): every workgroup slot stores ITS partial sum with plain
+ * dW fp32 [slots][F][K][F+G], slots = gcrnn_fused_wgrad_bf16_slots(B*T, F, K, entries, img16) (round 5: on the bf16-image plans a workgroup visits
+ * an item for TWO 16-feature chunks of dpre, so an item has half the workgroups and twice the slots fill the chip; gcrnn_fused_wgrad_slots(B*T, F)
+ * is the count of the fp32-accurate kernel, gcrnn_fused_backward_weight_f32): every workgroup slot stores ITS partial sum with plain
  * stores (the caller zero-fills the buffer and adds the slots in a fixed order: no atomics, two runs give the same bits);
  * graph arrays = LDS image of the ELL of CSR(S).
  * Returns GCRNN_ERR_UNSUPPORTED when the graph image does not fit in LDS next to the state. 
  * h_is_h0 bit 1 (value 2, r2): the graph arrays address a bf16 hop image (GraphOperator.fused_plan_img16(adjoint=True), uniform_w != 0). */
 int64_t gcrnn_fused_wgrad_slots(int64_t items, int64_t F);
+int64_t gcrnn_fused_wgrad_bf16_slots(int64_t items, int64_t F, int64_t K, int64_t entries, int img16);
 int gcrnn_fused_backward_weight_bf16(const void* dpre, const void* Xuser, const void* Huser, const void* h0user, float* dW,
                                      float* dbsum /* [slots][F] partials of the bias gradient sum_{t,b} (gi + gf) sum_n dpre (2 sum dpre without gates), or NULL */,
                                      const int32_t* tile_nodes, const int32_t* tile_off, const void* ell_val4,

@@ -34,6 +34,7 @@ for k in range(K):
     names[3 + 4 * k] = 'tap %d adjoint hop' % k
     names[4 + 4 * k] = 'tap %d GEMM' % k
     names[5 + 4 * k] = 'tap %d end barrier' % k
+names[25] = 'the pair\'s second chunk, whole (z stays resident)'
 prev, tot = 0, {}
 for s in sorted(names):
     d = st[:, s] - st[:, prev]
