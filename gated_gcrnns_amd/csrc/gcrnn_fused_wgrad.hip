@@ -157,6 +157,59 @@ __global__ __launch_bounds__(512, 2) void fused_wgrad_kernel(
       }
     }
   };
+#ifndef GCRNN_WGRAD_Z_RESIDENT
+#define GCRNN_WGRAD_Z_RESIDENT 1      // UNI == 2: all 32 fragments of z stay in registers for the item (the summing stream's window is 28 registers, not 60)
+#endif
+#ifndef GCRNN_WGRAD_PIPELINE
+#define GCRNN_WGRAD_PIPELINE 0        // 1: the NEXT item's operands are requested inside the current item's last tap (A/B; measured: no gain)
+#endif
+  constexpr bool ZRES = (UNI == 2) && GCRNN_WGRAD_Z_RESIDENT;
+  // PIPE (round 5 experiment, off): z resident, the NEXT item's operands requested inside the current item's last tap -- du_0 of its first chunk
+  // behind that tap's images (du_k's registers are dead: no hop follows), then one fragment of z behind each MFMA that has just read the old one.
+  // Measured (profiles/r05_wgrad_stamps_pipeline.txt): the item start shrinks from 180 to 60 units and the last GEMM grows by the same 120 -- a
+  // CU keeps ~8 KB of requests in flight, so 290 KB take their ~10 k cycles wherever they are issued, and the only place the registers allow
+  // is one GEMM long. 862 vs 857 units per item pair.
+  constexpr bool PIPE = ZRES && GCRNN_WGRAD_PIPELINE;
+  bf16x8 bfr[ZRES ? 32 : 16];
+  u32x2 d2n[TILES];                                          // PIPE: du_0 of the upcoming item's first chunk, in flight across the item boundary
+  const int vo = (jrow * N + 8 * q) * 2;
+  // item -> this wave's z rows (a zero-length buffer when the wave has nothing to add: the loads cost nothing) and its gate units
+  struct ItemSrc { __amdgpu_buffer_rsrc_t rz, rd; float gcur, gbias; bool live; int soff_d; };
+  auto item_src = [&](int itx) {
+    ItemSrc o;
+    const bool valid = itx < items;
+    const int tx = valid ? itx / B : 0, bx = valid ? itx - tx * B : 0;
+    o.gcur = 1.f;
+    o.gbias = 2.f;                                         // the one bias enters both filters
+    if (gw_) { o.gcur = gw_[tx * B + bx]; o.gbias = gi[tx * B + bx] + gf[tx * B + bx]; }
+    o.live = has_tile && (!gw_ || o.gcur > 1e-12f) && !(h_is_h0 && !is_x && hzero && hzero[0] != 0);      // wave-uniform
+    const uint16_t* zsrc;
+    int zrows;
+    if (is_x) { zsrc = Xuser + ((int64_t)bx * Tn + tx) * G * N; zrows = G; }
+    else if (tx > 0 && !h_is_h0) { zsrc = Huser + ((int64_t)bx * Tn + (tx - 1)) * F * N; zrows = F; }
+    else { zsrc = h0user + (int64_t)bx * F * N; zrows = F; }
+    o.rz = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(zsrc), 0, (o.live && valid) ? zrows * N * 2 : 0, 0x00020000);
+    o.soff_d = ((tx * B + bx) * NP) * (F * 2);
+    o.rd = valid ? rsrc_d : __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(dpre), 0, 0, 0x00020000);      // (no such item: a zero-length buffer)
+    return o;
+  };
+  auto request_dpre = [&](u32x2* dst, const __amdgpu_buffer_rsrc_t& rd, int soff, int chunkx) {
+#pragma unroll
+    for (int i = 0; i < TILES; ++i) {
+      int wv = woff[i];
+      asm volatile("" : "+v"(wv));
+      dst[i] = __builtin_amdgcn_raw_buffer_load_b64(rd, (wv >> 16) * (F * 2) + (chunkx * FC + q * 4) * 2, soff, 0);
+    }
+  };
+  if constexpr (PIPE) {
+    const ItemSrc s0 = item_src(it0);
+    request_dpre(d2n, s0.rd, s0.soff_d, cw * CPW);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int s2 = 0; s2 < 32; ++s2)
+      bfr[s2] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(s0.rz, vo + 64 * s2, 0, 0));
+    __builtin_amdgcn_sched_barrier(0);
+  }
   for (int it = it0; it < items; it += seq_slots) {
     const int t = it / B, b = it - t * B;
     [[maybe_unused]] const bool stamp_item = (it == it0 + 2 * seq_slots) && blockIdx.x < 1024;
@@ -165,26 +218,14 @@ __global__ __launch_bounds__(512, 2) void fused_wgrad_kernel(
     // The fragments of nodes 0..511 stay in registers across the taps; those of nodes 512..1023 are re-fetched per tap
     // (L2-resident after the first tap) through registers that the hop pipeline has just released -- the kernel must
     // stay spill-free: a spilled destination of an in-flight asm ds_read would be saved before its data lands.
-#ifndef GCRNN_WGRAD_Z_RESIDENT
-#define GCRNN_WGRAD_Z_RESIDENT 1      // UNI == 2: all 32 fragments of z stay in registers for the item (the summing stream's window is 28 registers, not 60)
-#endif
-    constexpr bool ZRES = (UNI == 2) && GCRNN_WGRAD_Z_RESIDENT;
-    bf16x8 bfr[ZRES ? 32 : 16];
-    const uint16_t* zsrc;
-    int zrows;
-    float gcur = gprev;
-    float gbias = 2.f;                                    // the one bias enters both filters
-    if (gw_) { gcur = gw_[t * B + b]; gbias = gi[t * B + b] + gf[t * B + b]; }
-    const bool live = has_tile && gcur > 1e-12f && !(h_is_h0 && !is_x && hzero && hzero[0] != 0);      // wave-uniform
-    if (is_x) { zsrc = Xuser + ((int64_t)b * Tn + t) * G * N; zrows = G; }
-    else if (t > 0 && !h_is_h0) { zsrc = Huser + ((int64_t)b * Tn + (t - 1)) * F * N; zrows = F; }
-    else { zsrc = h0user + (int64_t)b * F * N; zrows = F; }
-    const __amdgpu_buffer_rsrc_t rsrc_z = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(zsrc), 0, live ? zrows * N * 2 : 0, 0x00020000);      // dead waves: zero-length buffer, the loads cost nothing
-    const int vo = (jrow * N + 8 * q) * 2;
+    const ItemSrc src = item_src(it);
+    const float gcur = gw_ ? src.gcur : gprev, gbias = src.gbias;
+    const bool live = src.live;
+    const __amdgpu_buffer_rsrc_t rsrc_z = src.rz;
     // ---- du_0 = dpre chunk of this item: requested FIRST (round 5) -- memory returns in order, and tap 0's images and hop need du_0 only,
     // so the 32 fragments of z (8 x the bytes) have until tap 0's GEMM to land instead of standing in front of everything
     f32x4 cur[TILES];
-    const int soff_d = ((t * B + b) * NP) * (F * 2);
+    const int soff_d = src.soff_d;
     // the item's chunks (compile-time index: the two visits differ in what they request, and shared code would make the compiler's waits
     // for du_0 cover the z loads as well)
     wg_forn<CPW>([&](auto ccc) {
@@ -217,13 +258,13 @@ __global__ __launch_bounds__(512, 2) void fused_wgrad_kernel(
         bfr[s2] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsrc_z, vo + 64 * s2, 0, 0));
     }
     u32x2 d2r[TILES];
+    if constexpr (PIPE && cc == 0) {
 #pragma unroll
-    for (int i = 0; i < TILES; ++i) {
-      int wv = woff[i];
-      asm volatile("" : "+v"(wv));
-      d2r[i] = __builtin_amdgcn_raw_buffer_load_b64(rsrc_d, (wv >> 16) * (F * 2) + (chunk * FC + q * 4) * 2, soff_d, 0);
+      for (int i = 0; i < TILES; ++i) d2r[i] = d2n[i];      // requested inside the previous item's last tap (or ahead of the first item)
+    } else {
+      request_dpre(d2r, src.rd, soff_d, chunk);
     }
-    if constexpr (ZRES) {
+    if constexpr (ZRES && !PIPE) {
       __builtin_amdgcn_sched_barrier(0);
       if constexpr (cc == 0) {
 #pragma unroll
@@ -320,7 +361,31 @@ __global__ __launch_bounds__(512, 2) void fused_wgrad_kernel(
 #undef GCRNN_WG_STORE
         }
       };
+      // the item's last GEMM also requests the NEXT item's operands (PIPE). It then runs whether the wave is live or not (a dead wave's z is zeros:
+      // its MFMAs add nothing) -- one straight-line block in which every fragment register is read by its MFMA and re-requested right behind it.
       auto gemm_phase = [&]() {
+        if constexpr (PIPE && cc == CPW - 1) {
+          if (k == K - 1) {      // (a constant once the taps are unrolled)
+            const ItemSrc nx = item_src(it + seq_slots);
+            request_dpre(d2n, nx.rd, nx.soff_d, cw * CPW + (CPW == 2 ? held : 0));      // (the pair's order alternates: the next item starts with the chunk that is in registers now)
+            __builtin_amdgcn_sched_barrier(0);
+            f32x4 acc2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s8 = 0; s8 < 32; s8 += 8) {
+              bf16x8 a8[8];
+#pragma unroll
+              for (int p = 0; p < 8; ++p) a8[p] = afrag(s8 + p);
+#pragma unroll
+              for (int p = 0; p < 8; ++p) {
+                if (p & 1) acc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a8[p], bfr[(ZRES ? s8 + p : 0)], acc2, 0, 0, 0);
+                else accD[k] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a8[p], bfr[(ZRES ? s8 + p : 0)], accD[k], 0, 0, 0);
+                bfr[(ZRES ? s8 + p : 0)] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(nx.rz, vo + 64 * (s8 + p), 0, 0));
+              }
+            }
+            accD[k] += acc2;
+            return;
+          }
+        }
         if (live) {
           f32x4 acc2 = {0.f, 0.f, 0.f, 0.f};      // two accumulation chains: 32 dependent MFMAs on one tile were the GEMM's whole duration
 #pragma unroll
