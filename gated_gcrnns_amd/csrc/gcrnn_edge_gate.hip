@@ -15,6 +15,25 @@
 // Every sum is a gather in a fixed order: results are deterministic.
 #include "gcrnn_common.h"
 
+// In-kernel phase stamps (diagnostic builds only, -DGCRNN_EDGE_STAMPS; tools/edge_att_stamps.py): thread 0 of every workgroup records s_memtime at
+// the attention kernel's phase boundaries (the last launch's values stay).
+#if defined(GCRNN_EDGE_STAMPS)
+static __device__ unsigned long long gcrnn_edge_stamps[1024 * 16];
+#define EA_STAMP(slot)                                                                                         \
+  do {                                                                                                         \
+    if (threadIdx.x == 0 && blockIdx.x < 1024) {                                                               \
+      unsigned long long tv_;                                                                                  \
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tv_)::"memory");                              \
+      gcrnn_edge_stamps[blockIdx.x * 16 + (slot)] = tv_;                                                       \
+    }                                                                                                          \
+  } while (0)
+extern "C" int gcrnn_debug_read_edge_stamps(void* host) {
+  return hipMemcpyFromSymbol(host, HIP_SYMBOL(gcrnn_edge_stamps), sizeof(unsigned long long) * 1024 * 16) == hipSuccess ? 0 : 1;
+}
+#else
+#define EA_STAMP(slot) do {} while (0)
+#endif
+
 namespace {
 
 #ifndef GCRNN_EDGE_THREADS
@@ -54,17 +73,30 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // Softmax statistics (max, 1 / sum of exp) of every support row, one thread per row. The row's records and the scores they point at
 // are fetched eight at a time (eight independent global loads, then eight LDS reads) -- a serial walk costs one global and one LDS
 // latency PER EDGE, and at one workgroup per CU nothing else hides it.
+// PRE (round 5): the bounds of row `tid` and the column indices of its first eight records were requested by the caller before it loaded z
+// (they depend on the graph only): the statistics of the first pass start without a global round trip.
+struct RowPre { int j0, j1; int nn[8]; };
 template <int THREADS>
+__device__ __forceinline__ RowPre row_softmax_prefetch(const int32_t* __restrict__ rowptr, const int2* __restrict__ r_edge, int N, int tid) {
+  RowPre o;
+  o.j0 = o.j1 = 0;
+  if (tid < N) { o.j0 = rowptr[tid]; o.j1 = rowptr[tid + 1]; }
+#pragma unroll
+  for (int u = 0; u < 8; ++u) o.nn[u] = (o.j0 + u < o.j1) ? r_edge[o.j0 + u].x : -1;
+  return o;
+}
+template <int THREADS, bool PRE = false>
 __device__ __forceinline__ void row_softmax_stats(float4* __restrict__ sc, const int32_t* __restrict__ rowptr, const int2* __restrict__ r_edge,
-                                                  int N, float slope, int tid) {
+                                                  int N, float slope, int tid, const RowPre* pre = nullptr) {
   for (int m = tid; m < N; m += THREADS) {
-    const int j0 = rowptr[m], j1 = rowptr[m + 1];
+    const bool first = PRE && m == tid;
+    const int j0 = first ? pre->j0 : rowptr[m], j1 = first ? pre->j1 : rowptr[m + 1];
     const float s2m = sc[m].y;
     float mx = -1e30f, sum = 0.f;
     for (int j = j0; j < j1; j += 8) {
       int nn[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) nn[u] = (j + u < j1) ? r_edge[j + u].x : -1;
+      for (int u = 0; u < 8; ++u) nn[u] = (first && j == j0) ? pre->nn[u] : ((j + u < j1) ? r_edge[j + u].x : -1);
       float ev[8];
       float cm = -1e30f;
 #pragma unroll
@@ -87,13 +119,16 @@ __device__ __forceinline__ void row_softmax_stats(float4* __restrict__ sc, const
 }
 
 // LDS carve-up: rows of 8-feature pieces, then the per-node scalars sc[n] = {s1, s2, row max, 1 / row sum}; once the aggregation
-// is done the same bytes hold the transposed image [F][N + 64] of h for the user-layout store (row f shifted by 8 (f >> 3)
-// columns, which spreads the eight feature groups of a wave's ds_write_b16 over all banks)
+// is done the same bytes hold the transposed image of h for the user-layout store: 32-bit words [feature pair][node] = {h[n][2q], h[n][2q+1]}
+// (round 5; the 8-node blocks of row q sit at block ^ (q >> 2 & 3), which spreads the pieces of one node over the banks)
 template <int F> struct EdgeLds {
   static constexpr int LPN = F / 8;                  // lanes per node = 16-byte pieces of a bf16 row
   static constexpr int NPP = ETHREADS / LPN;         // nodes per pass
+  static constexpr int MAXN = 1024;                  // the fused path's padded node count: a lane keeps one 16-byte piece of h per pass in registers
+  static constexpr int MAXPASS = MAXN / NPP;
+  static constexpr int WPITCH = MAXN;                // words per row of the transposed image [feature pair][node]
   static size_t fwd_bytes(int N) {
-    const size_t a = (size_t)N * F * 2 + (size_t)N * 16, b = (size_t)F * (N + 64) * 2;
+    const size_t a = (size_t)N * F * 2 + (size_t)N * 16, b = (size_t)(F / 2) * WPITCH * 4;
     return a > b ? a : b;
   }
 };
@@ -124,21 +159,67 @@ __global__ __launch_bounds__(ETHREADS) void edge_att_fwd_kernel(
   const int64_t item = blockIdx.x;
   const uint4* zsrc = reinterpret_cast<const uint4*>(z + item * NPad * F);
 
-  // ---- load z, scores (four 16-byte loads in flight per lane) ----------------------------------------------------------
+  EA_STAMP(0);
+  // ---- (round 5) the requests, in the order their answers are needed (memory returns in order, and a dependent load waits for everything older):
+  // 1. the heads of the graph-only chains (row bounds of phase A, the nodes of phase B's first two passes); 2. z, eight 16-byte loads in flight per
+  // lane (N <= 1024 rows are one trip); 3. the chains' second level (phase A's first eight records, the in-edge bounds of the two passes), which
+  // waits for 1. only; the records of phase B's first pass follow the scores.
+  float giv = 1.f, gfv = 1.f;
+  if (MODE == 1 && gi) { giv = gi[item]; gfv = gf[item]; }
+  uint4* oseq = reinterpret_cast<uint4*>(out_seq + item * NPad * F);
+  const uint4* gsrc = MODE == 1 ? reinterpret_cast<const uint4*>(gx + item * NPad * F) : nullptr;
+  uint4* rdst = (MODE == 1 && r_out) ? reinterpret_cast<uint4*>(r_out + item * NPad * F) : nullptr;
+  uint16_t* hu = (MODE == 1 && Huser) ? Huser + item * hu_stride : nullptr;
+  RowPre rpre;
+  rpre.j0 = rpre.j1 = 0;
+  if (tid < N) { rpre.j0 = rowptr[tid]; rpre.j1 = rowptr[tid + 1]; }
+  int na = (nl < N) ? t_order[nl] : -1, nb = (NPP + nl < N) ? t_order[NPP + nl] : -1;
+  __builtin_amdgcn_sched_barrier(0);
+  constexpr int ZU = 8;
+  const int ztotal = N * LPN;
+  uint4 zv[ZU];
+#pragma unroll
+  for (int u = 0; u < ZU; ++u) {
+    const int idx = tid + u * ETHREADS;
+    zv[u] = idx < ztotal ? zsrc[idx] : uint4{0, 0, 0, 0};
+  }
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int u = 0; u < 8; ++u) rpre.nn[u] = (rpre.j0 + u < rpre.j1) ? r_edge[rpre.j0 + u].x : -1;
+  auto in_edges = [&](int n, int& q0, int& deg) {
+    q0 = 0; deg = 0;
+    if (n >= 0) { q0 = t_rowptr[n]; deg = t_rowptr[n + 1] - q0; }
+  };
+  auto bounds = [&](int base, int& n, int& q0, int& deg) {
+    n = (base + nl < N) ? t_order[base + nl] : -1;
+    in_edges(n, q0, deg);
+  };
+  // records of a pass: lane p of a node's group holds the in-edges p, p + LPN, ... (MAXC chunks cover in-degrees <= 32 from
+  // registers; the records of the NEXT pass are requested before this pass computes, so their latency is never exposed)
+  constexpr int MAXC = 32 / LPN, GPC = LPN / 4;          // chunks per pass in registers; groups of 4 records per chunk
+  auto load_recs = [&](int q0, int deg, int2* r) {
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) r[c] = (c * LPN + p < deg) ? t_edge[q0 + c * LPN + p] : int2{0, 0};
+  };
+  int q0a, dega, q0b, degb;
+  in_edges(na, q0a, dega);
+  in_edges(nb, q0b, degb);
+  __builtin_amdgcn_sched_barrier(0);
+  // ---- z -> LDS, scores ----------------------------------------------------------------------------------------------------------
   {
     f32x2 ar[8];                                      // (a1[f], a2[f]) pairs of this lane's 8 features
 #pragma unroll
     for (int j = 0; j < 8; ++j) ar[j] = f32x2{a12[p * 8 + j], a12[F + p * 8 + j]};
-    const int total = N * LPN;
-    for (int i0 = tid; i0 < total; i0 += 4 * ETHREADS) {
-      uint4 v[4];
+    const int total = ztotal;
+    for (int i0 = tid; i0 < total; i0 += ZU * ETHREADS) {
+      uint4 v[ZU];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < ZU; ++u) {
         const int idx = i0 + u * ETHREADS;
-        v[u] = idx < total ? zsrc[idx] : uint4{0, 0, 0, 0};
+        v[u] = (i0 == tid) ? zv[u] : (idx < total ? zsrc[idx] : uint4{0, 0, 0, 0});
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < ZU; ++u) {
         const int idx = i0 + u * ETHREADS;
         float f8[8];
         unpack8(v[u], f8);
@@ -154,36 +235,24 @@ __global__ __launch_bounds__(ETHREADS) void edge_att_fwd_kernel(
       }
     }
   }
-  __syncthreads();
-  // ---- phase A: softmax statistics of every support row -----------------------------------------------------------------
-  row_softmax_stats<ETHREADS>(sc, rowptr, r_edge, N, slope, tid);
-  __syncthreads();
-  // ---- phase B: aggregation over the in-edges, epilogue; slot base + nl of a pass is node t_order[base + nl] ---------------
-  float giv = 1.f, gfv = 1.f;
-  if (MODE == 1 && gi) { giv = gi[item]; gfv = gf[item]; }
-  uint4* oseq = reinterpret_cast<uint4*>(out_seq + item * NPad * F);
-  const uint4* gsrc = MODE == 1 ? reinterpret_cast<const uint4*>(gx + item * NPad * F) : nullptr;
-  uint4* rdst = (MODE == 1 && r_out) ? reinterpret_cast<uint4*>(r_out + item * NPad * F) : nullptr;
-  uint16_t* hu = (MODE == 1 && Huser) ? Huser + item * hu_stride : nullptr;
-  auto bounds = [&](int base, int& n, int& q0, int& deg) {
-    n = -1; q0 = 0; deg = 0;
-    if (base + nl < N) { n = t_order[base + nl]; q0 = t_rowptr[n]; deg = t_rowptr[n + 1] - q0; }
-  };
-  // records of a pass: lane p of a node's group holds the in-edges p, p + LPN, ... (MAXC chunks cover in-degrees <= 32 from
-  // registers; the records of the NEXT pass are requested before this pass computes, so their latency is never exposed)
-  constexpr int MAXC = 32 / LPN, GPC = LPN / 4;          // chunks per pass in registers; groups of 4 records per chunk
-  auto load_recs = [&](int q0, int deg, int2* r) {
-#pragma unroll
-    for (int c = 0; c < MAXC; ++c) r[c] = (c * LPN + p < deg) ? t_edge[q0 + c * LPN + p] : int2{0, 0};
-  };
-  int na, q0a, dega, nb, q0b, degb;
-  bounds(0, na, q0a, dega);
-  bounds(NPP, nb, q0b, degb);
   int2 reca[MAXC];
   load_recs(q0a, dega, reca);
   uint4 gva = uint4{0, 0, 0, 0};
   if (MODE == 1 && na >= 0) gva = gsrc[na * LPN + p];
-  for (int base = 0; base < N; base += NPP) {
+  __syncthreads();
+  EA_STAMP(1);
+  // ---- phase A: softmax statistics of every support row -----------------------------------------------------------------
+  row_softmax_stats<ETHREADS, true>(sc, rowptr, r_edge, N, slope, tid, &rpre);
+  __syncthreads();
+  EA_STAMP(2);
+  // ---- phase B: aggregation over the in-edges, epilogue; slot base + nl of a pass is node t_order[base + nl] ---------------
+  uint4 keep[L::MAXPASS];      // MODE 1 with the user-layout copy: this lane's piece of h of every pass (no global round trip in the epilogue)
+#pragma unroll
+  for (int ps = 0; ps < L::MAXPASS; ++ps) keep[ps] = uint4{0, 0, 0, 0};
+#pragma unroll
+  for (int ps = 0; ps < L::MAXPASS; ++ps) {
+    const int base = ps * NPP;
+    if (base >= N) break;      // (workgroup-uniform)
     int2 recb[MAXC];
     load_recs(q0b, degb, recb);
     uint4 gvb = uint4{0, 0, 0, 0};
@@ -208,6 +277,8 @@ __global__ __launch_bounds__(ETHREADS) void edge_att_fwd_kernel(
       const float v = __int_as_float(r.y);
       return (v != 0.f) ? v * eexp(e - s.z) * s.w : 0.f;
     };
+    // (round 5: the broadcasts on the VALU's DPP path instead -- quad_perm, then row_shr / row_shl:4 into the other quad's bank -- measured no
+    //  faster, 725 against 698 units for the phase: it is bound by vector issue, not by the LDS instructions)
     auto group4 = [&](const int mx, const float cx, const int off) {       // four records: shuffles, then the row reads, then the FMAs
       int mm[4];
       float cc[4];
@@ -247,46 +318,52 @@ __global__ __launch_bounds__(ETHREADS) void edge_att_fwd_kernel(
       unpack8(gva, g8);
 #pragma unroll
       for (int j = 0; j < 8; ++j) o8[j] = etanh(giv * g8[j] + gfv * o8[j]);
-      if (valid) oseq[n * LPN + p] = pack8(o8);
+      const uint4 hv = pack8(o8);
+      if (valid) { oseq[n * LPN + p] = hv; keep[ps] = hv; }
     }
     na = nb; q0a = q0b; dega = degb; gva = gvb; nb = nc; q0b = q0c; degb = degc;
 #pragma unroll
     for (int c = 0; c < MAXC; ++c) reca[c] = recb[c];
   }
+  EA_STAMP(3);
   if (MODE == 1 && hu) {
-    // ---- user layout H[f][n]: the rows just written are read back (this workgroup's own stores, ordered by the barrier) into a
-    // transposed LDS image over the dead z / sc region, then stored along n in 16-byte pieces
-    constexpr int IST_PAD = 64;
-    const int IST = N + IST_PAD;
-    uint16_t* img = reinterpret_cast<uint16_t*>(smem);
-    __syncthreads();
-    const int total = N * LPN;
-    for (int i0 = tid; i0 < total; i0 += 4 * ETHREADS) {
-      uint4 v[4];
+    // ---- user layout H[f][n] (round 5): the pieces kept in registers go into a transposed LDS image over the dead z / sc region as 32-bit words
+    // {feature 2q, feature 2q + 1} of a node -- a piece is four such words as it is --, then every feature row is read back along n (two
+    // 16-byte reads + 4 v_perm_b32 pick the row's half of 8 words) and stored in 16-byte pieces. (Rounds 2-4: the rows just stored were read
+    // back from global memory behind a draining barrier and scattered with 8 ds_write_b16 per piece: 325 of the kernel's 1,075 units.)
+    constexpr int WP = L::WPITCH;
+    uint32_t* imgw = reinterpret_cast<uint32_t*>(smem);
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // every wave has left z and sc (LDS only: the stores above stay in flight)
+    EA_STAMP(4);
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int idx = i0 + u * ETHREADS;
-        v[u] = idx < total ? oseq[idx] : uint4{0, 0, 0, 0};
-      }
+    for (int ps = 0; ps < L::MAXPASS; ++ps) {
+      const int slot = ps * NPP + nl;
+      if (slot < N) {
+        const int n = t_order[slot];
+        const uint32_t w4[4] = {keep[ps].x, keep[ps].y, keep[ps].z, keep[ps].w};
+        const int nsw = n ^ (8 * (p & 3));                  // row q = 4 p + j: q >> 2 = p
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int idx = i0 + u * ETHREADS;
-        if (idx < total) {
-          const int n = idx / LPN;
-          const uint32_t w4[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
-#pragma unroll
-          for (int j = 0; j < 8; ++j)
-            img[(p * 8 + j) * IST + 8 * p + n] = (uint16_t)(j & 1 ? w4[j >> 1] >> 16 : w4[j >> 1] & 0xffffu);
-        }
+        for (int j = 0; j < 4; ++j) imgw[(4 * p + j) * WP + nsw] = w4[j];
       }
     }
     __syncthreads();
+    EA_STAMP(5);
     const int ppr = N / 8;                                                 // 16-byte pieces per feature row
     for (int idx = tid; idx < F * ppr; idx += ETHREADS) {
       const int f = idx / ppr, pc = idx - f * ppr;
-      *reinterpret_cast<uint4*>(hu + (int64_t)f * N + pc * 8) = *reinterpret_cast<const uint4*>(img + f * IST + 8 * (f >> 3) + pc * 8);
+      const int q2 = f >> 1;
+      const uint4* src = reinterpret_cast<const uint4*>(imgw + q2 * WP + 8 * (pc ^ ((q2 >> 2) & 3)));
+      const uint4 w0 = src[0], w1 = src[1];
+      const uint32_t sel = (f & 1) ? 0x07060302u : 0x05040100u;
+      uint4 o;
+      o.x = __builtin_amdgcn_perm(w0.y, w0.x, sel);
+      o.y = __builtin_amdgcn_perm(w0.w, w0.z, sel);
+      o.z = __builtin_amdgcn_perm(w1.y, w1.x, sel);
+      o.w = __builtin_amdgcn_perm(w1.w, w1.z, sel);
+      *reinterpret_cast<uint4*>(hu + (int64_t)f * N + pc * 8) = o;
     }
   }
+  EA_STAMP(6);
   for (int idx = N * LPN + tid; idx < NPad * LPN; idx += ETHREADS) {       // padding rows of the sequence-major output: zeros
     oseq[idx] = uint4{0, 0, 0, 0};
     if (rdst) rdst[idx] = uint4{0, 0, 0, 0};
@@ -641,7 +718,7 @@ static int edge_att_bwd_t(const void* dpre, const void* r, const float* g, const
 }  // namespace
 
 extern "C" int gcrnn_fused_edge_attention_supported(int64_t N, int64_t F) {
-  if (N <= 0 || N % 8 || (F != 32 && F != 64)) return 0;
+  if (N <= 0 || N % 8 || N > 1024 || (F != 32 && F != 64)) return 0;      // (N <= 1024: a lane keeps its pieces of h of at most 1024 / (nodes per pass) passes)
   const size_t lds = F == 64 ? EdgeLds<64>::fwd_bytes((int)N) : EdgeLds<32>::fwd_bytes((int)N);
   return lds <= 160 * 1024;
 }
