@@ -1964,16 +1964,44 @@ def fused_node_cell_forward_x3(X, h0, wA, wB, bias, graph, node_gates, time_gate
         return c
 
     # per-node gates [T][B][npad][1] fp32 (zero on the padding rows)
-    ngate = []
-    for name in ('in', 'forget'):
-        wA_g, wB_g, bias_g, wf, bf = node_gates[name]
-        c = gate_cell_states(wA_g, wB_g, bias_g)
-        logit = lsigf_node_major(pack_node_major(c), wf.detach().float(), bf.detach().float() if bf is not None else None, graph, 1.0)      # [T][N][B][1]
-        del c
-        g = torch.zeros((T, B, npad, 1), dtype=torch.float32, device=dev)
-        g[:, :, :N] = torch.sigmoid(logit).permute(0, 2, 1, 3)
-        ngate.append(g)
-        del logit
+    Kf = node_gates['in'][3].shape[2]
+    taps_first = (node_gates['forget'][3].shape[2] == Kf and not os.environ.get('GCRNN_NO_NODE_GATE_FILTER')
+                  and bool(lib.gcrnn_node_gate_filter_supported(Kf, N, graph.fwd[0].nnz, plan.get('uniform_w', 0.0))))
+    if taps_first:
+        # the F -> 1 filters taps-first (as the bf16 path): u_k = c w_k per node in fp32, then the K - 1 hops on ONE channel with the bias and the
+        # sigmoid in the same pass (gcrnn_node_gate_filter_f32) -- the filter on the F-channel states cost half of this forward (34 of 69 ms)
+        parts = torch.empty((T, B, 2, 1, Kf, N), dtype=torch.float32, device=dev)
+        for gidx, name in enumerate(('in', 'forget')):
+            wA_g, wB_g, bias_g, wf, bf = node_gates[name]
+            c = gate_cell_states(wA_g, wB_g, bias_g)
+            parts[:, :, gidx, 0] = torch.einsum('kf,btfn->tbkn', wf.detach().float()[0, 0], c)
+            del c
+        bfs = tuple(node_gates[name][4] for name in ('in', 'forget'))
+        b2 = None
+        if any(b is not None for b in bfs):
+            b2 = torch.cat([(b.detach().float().reshape(1) if b is not None else torch.zeros(1, device=dev)) for b in bfs]).contiguous()
+        csr = graph.fwd[0]
+        ng2 = torch.empty((T, 2, B, N), dtype=torch.float32, device=dev)
+        check(lib.gcrnn_node_gate_filter_f32(_p(parts), _p(ng2), T * B * 2, 1, Kf, N, 2, B, _p(csr.rowptr), _p(csr.col), _p(csr.val(torch.float32)), csr.nnz,
+                                             plan.get('uniform_w', 0.0), _p(b2), 1, st), 'node_gate_filter')
+        del parts
+        ngate = []
+        for gidx in range(2):
+            g = torch.zeros((T, B, npad, 1), dtype=torch.float32, device=dev)
+            g[:, :, :N, 0] = ng2[:, gidx]
+            ngate.append(g)
+        del ng2
+    else:
+        ngate = []
+        for name in ('in', 'forget'):
+            wA_g, wB_g, bias_g, wf, bf = node_gates[name]
+            c = gate_cell_states(wA_g, wB_g, bias_g)
+            logit = lsigf_node_major(pack_node_major(c), wf.detach().float(), bf.detach().float() if bf is not None else None, graph, 1.0)      # [T][N][B][1]
+            del c
+            g = torch.zeros((T, B, npad, 1), dtype=torch.float32, device=dev)
+            g[:, :, :N] = torch.sigmoid(logit).permute(0, 2, 1, 3)
+            ngate.append(g)
+            del logit
     ni, nf = ngate
     if time_gates is not None:
         for which, name in ((0, 'in'), (1, 'forget')):
@@ -2004,15 +2032,15 @@ def fused_node_cell_forward_x3(X, h0, wA, wB, bias, graph, node_gates, time_gate
     hprev = h0c
     for t in range(T):
         check(lib.gcrnn_fused_filter_x3(_p(xs3[t]), _p(y3), _p(wp3A), *gargs, B, N, F, K, plan['uniform_w'], r1, st), 'fused_filter_x3')
-        ya = y3.float().sum(dim=0)                                               # A(S) x_t: the three planes add up exactly in fp32
+        ya = torch.sum(y3, dim=0, dtype=torch.float32)                           # A(S) x_t: the three planes add up exactly in fp32 (one pass: the reduction converts)
         hp = hprev if hprev.is_contiguous() else hprev.contiguous()
         check(lib.gcrnn_pack_seq_major_x3(_p(hp), _p(h3), B, 1, F, N, npad, st), 'pack_seq_x3')
         check(lib.gcrnn_fused_filter_x3(_p(h3[0]), _p(y3), _p(wp3B), *gargs, B, N, F, K, plan['uniform_w'], r1, st), 'fused_filter_x3')
-        yb = y3.float().sum(dim=0)                                               # B(S) h_{t-1}
+        yb = torch.sum(y3, dim=0, dtype=torch.float32)                           # B(S) h_{t-1}
         if bvec is not None:
             ya = ya + bvec
             yb = yb + bvec
-        ht = torch.tanh(ni[t] * ya + nf[t] * yb)                                 # [B][npad][F]; padding rows: tanh(0) = 0
+        ht = torch.tanh(torch.addcmul(ni[t] * ya, nf[t], yb))                    # [B][npad][F]; padding rows: tanh(0) = 0
         H[:, t] = ht[:, :N].transpose(1, 2)
         hprev = H[:, t]
     if last_only:
@@ -2077,7 +2105,7 @@ def fused_edge_cell_forward_x3(X, h0, wA, wB, bias, graph, att_in, att_f, time_g
 
     def filt(z3, wp):      # [3][B][npad][F] planes -> filter output + bias, node-major [1][N][B][F] fp32
         check(lib.gcrnn_fused_filter_x3(_p(z3), _p(y3), _p(wp), *gargs, B, N, F, K, plan['uniform_w'], r1, st), 'fused_filter_x3')
-        y = y3.float().sum(dim=0)
+        y = torch.sum(y3, dim=0, dtype=torch.float32)      # (the three planes add up exactly in fp32)
         if bvec is not None:
             y = y + bvec
         return y[:, :N].permute(1, 0, 2).unsqueeze(0).contiguous()
