@@ -1965,8 +1965,9 @@ def fused_node_cell_forward_x3(X, h0, wA, wB, bias, graph, node_gates, time_gate
 
     # per-node gates [T][B][npad][1] fp32 (zero on the padding rows)
     Kf = node_gates['in'][3].shape[2]
+    uw_f = graph.fused_plan().get('uniform_w', 0.0)      # (the x3 plan of a rank-1-weighted graph is its 0 / 1 pattern with uniform_w = 1: the gate filter reads the GSO itself)
     taps_first = (node_gates['forget'][3].shape[2] == Kf and not os.environ.get('GCRNN_NO_NODE_GATE_FILTER')
-                  and bool(lib.gcrnn_node_gate_filter_supported(Kf, N, graph.fwd[0].nnz, plan.get('uniform_w', 0.0))))
+                  and bool(lib.gcrnn_node_gate_filter_supported(Kf, N, graph.fwd[0].nnz, uw_f)))
     if taps_first:
         # the F -> 1 filters taps-first (as the bf16 path): u_k = c w_k per node in fp32, then the K - 1 hops on ONE channel with the bias and the
         # sigmoid in the same pass (gcrnn_node_gate_filter_f32) -- the filter on the F-channel states cost half of this forward (34 of 69 ms)
@@ -1983,7 +1984,7 @@ def fused_node_cell_forward_x3(X, h0, wA, wB, bias, graph, node_gates, time_gate
         csr = graph.fwd[0]
         ng2 = torch.empty((T, 2, B, N), dtype=torch.float32, device=dev)
         check(lib.gcrnn_node_gate_filter_f32(_p(parts), _p(ng2), T * B * 2, 1, Kf, N, 2, B, _p(csr.rowptr), _p(csr.col), _p(csr.val(torch.float32)), csr.nnz,
-                                             plan.get('uniform_w', 0.0), _p(b2), 1, st), 'node_gate_filter')
+                                             uw_f, _p(b2), 1, st), 'node_gate_filter')
         del parts
         ngate = []
         for gidx in range(2):
