@@ -4,9 +4,9 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/pmc_wgrad_$TAG
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_WAIT_INST_LDS" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_MFMA SQ_LDS_ADDR_CONFLICT" "SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VMEM SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_VMEM" "GRBM_GUI_ACTIVE"; do
+for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_WAIT_INST_LDS" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_MFMA SQ_LDS_ADDR_CONFLICT" "SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VMEM SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_VMEM" "GRBM_GUI_ACTIVE" "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum"; do
   n=$(echo $set | cut -d' ' -f1)
-  rocprofv3 --pmc $set --kernel-trace --output-format csv -d $O/pmc/$n -- python3 $R/bench.py --mode train --steps 1 --warmup 1 --no-cpu-baseline > $O/pmc.$n.log 2>&1
+  rocprofv3 --pmc $set --kernel-trace --output-format csv -d $O/pmc/$n -- python3 $R/bench.py --mode train --steps 1 --warmup 1 --no-cpu-baseline --no-secondary > $O/pmc.$n.log 2>&1
 done
 python3 $R/tools/pmc_summary.py $O/pmc fused_wgrad > $O/${TAG}_wgrad_pmc.txt
 cat $O/${TAG}_wgrad_pmc.txt
