@@ -291,24 +291,26 @@ __global__ __launch_bounds__(512, 2) void fused_wgrad_kernel(
     }
     WG_STAMP(1);
     if constexpr (UNI != 0) {
-    // The GEMM's image of du_k (round 5): plain bf16 rows [node][16 f'] in NODE order -- a lane's four values are one 8-byte ds_write_b64 --
-    // read back TRANSPOSED by the hardware: ds_read_b64_tr_b16 hands lane (f' = lane & 15, g = lane >> 4) the values of feature f' at four
-    // consecutive nodes, two such reads are the A fragment (8 nodes of ONE feature) of v_mfma_f32_16x16x32_bf16. (Rounds 3-4: 32-bit words
-    // [feature pair][node], two ds_write_b32 per tile, two 16-byte reads + 4 v_perm_b32 per fragment, half of every read discarded.)
-    // off(node) = 32 node ^ (node & 8) << 4: the two blocks a 32-lane half reads (nodes 8 apart) then sit on opposite halves of the 64 banks.
-    static_assert(NP * 32 <= 2 * TBYTES, "the node-order image fits the transposed-image allocation");
+    // The GEMM's image of du_k (round 5): bf16 in NODE order, piece-major -- piece p (features 4 p .. 4 p + 3 of every node, 8 bytes per node) at
+    // p * 8 NP + CP[p] + 8 node: a lane's four values are one 8-byte ds_write_b64 -- read back TRANSPOSED by the hardware: ds_read_b64_tr_b16
+    // hands lane (f' = lane & 15, g = lane >> 4) the values of feature f' at four consecutive nodes, two such reads are the A fragment (8 nodes
+    // of ONE feature) of v_mfma_f32_16x16x32_bf16. (Rounds 3-4: 32-bit words [feature pair][node], two ds_write_b32 per tile, two 16-byte reads
+    // + 4 v_perm_b32 per fragment, half of every read discarded.) The pads CP = {0, 32, 128, 160} bytes put the 32 addresses of a 32-lane half of
+    // a transposed read (two blocks of 4 nodes x 4 pieces, 8 nodes apart) on 32 different bank pairs; a write's 16 lanes (one piece of 16
+    // arbitrary nodes) spread over 16 bank pairs by node -- with whole 32-byte rows per node they shared four (4-way by construction).
+    constexpr int PSTRIDE = NP * 8;
+    static_assert(4 * PSTRIDE + 160 + 64 <= 2 * TBYTES, "the node-order image fits the transposed-image allocation");
     typedef short s16x4 __attribute__((ext_vector_type(4)));
     typedef __attribute__((address_space(3))) s16x4* lds_s16x4;
     const uint32_t tb0 = (uint32_t)reinterpret_cast<uintptr_t>(tbuf);
-    // lane 4 q' + p of group g: row (node) 8 g + 4 i + q' of the fragment's 32, columns 4 p .. 4 p + 3; the swizzle bit is (g & 1), so read i
-    // sits at 128 (i ^ (g & 1)): two base registers, the fragment index in the immediate offset
-    const uint32_t tr_lane = tb0 + (uint32_t)(256 * q + 32 * ((lane >> 2) & 3) + 8 * (lane & 3));
-    const lds_s16x4 tr_b0 = reinterpret_cast<lds_s16x4>(tr_lane + 128u * (uint32_t)(q & 1));
-    const lds_s16x4 tr_b1 = reinterpret_cast<lds_s16x4>(tr_lane + 128u * (uint32_t)((q & 1) ^ 1));
+    auto piece_base = [](int pp) { return (uint32_t)(pp * PSTRIDE + ((pp >> 1) * 128 + (pp & 1) * 32)); };
+    // lane 4 q' + p of group g: node 8 g + 4 i + q' of the fragment's 32, piece p; read i and fragment s are immediate offsets (32 i + 256 s)
+    const lds_s16x4 tr_b = reinterpret_cast<lds_s16x4>(tb0 + piece_base(lane & 3) + (uint32_t)(8 * (8 * q + ((lane >> 2) & 3))));
     auto afrag = [&](int s) {
-      const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(tr_b0 + 128 * s), hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(tr_b1 + 128 * s);      // (+ 1024 s bytes)
+      const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(tr_b + 32 * s), hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(tr_b + 32 * s + 4);      // (+ 256 s, + 32 bytes)
       return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
     };
+    const uint32_t nat_q = piece_base(q);
 #pragma unroll
     for (int k = 0; k < K; ++k) {
       // first batch of the second half's fragments: requested before the images are written, consumed after the first half
@@ -329,7 +331,7 @@ __global__ __launch_bounds__(512, 2) void fused_wgrad_kernel(
         }
         const int node = wv >> 16;
         typedef __attribute__((__vector_size__(2 * sizeof(unsigned int)))) unsigned int u32x2w;
-        *reinterpret_cast<u32x2w*>(tbuf + (((node << 5) ^ ((node & 8) << 4)) + 8 * q)) = u32x2w{pack2bf(cur[i][0], cur[i][1]), pack2bf(cur[i][2], cur[i][3])};
+        *reinterpret_cast<u32x2w*>(tbuf + (nat_q + 8 * node)) = u32x2w{pack2bf(cur[i][0], cur[i][1]), pack2bf(cur[i][2], cur[i][3])};
       }
       lds_barrier();      // LDS hand-off only: loads in flight stay in flight (gcrnn_fused_step.h)
       WG_STAMP(2 + 4 * k);
