@@ -207,10 +207,13 @@ def sweep(graphs, N, K, Bs, Gs, Fs, Ts, dev):
                 hmax = 0.2 if G == 1 else 6e-2
                 assert float(d.max()) <= hmax and float(d.mean()) <= 3e-3, 'H differs: max %.3g mean %.3g' % (float(d.max()), float(d.mean()))
                 assert g1.keys() == g0.keys(), 'gradient sets differ'
+                smax = max([float(v.abs().max()) for v in g0.values() if v.numel() == 1] + [0.0])
                 for k in g1:
                     sc = float(g0[k].abs().max())
                     dd = float((g1[k] - g0[k]).abs().max())
-                    tol = 0.4 if g1[k].numel() == 1 else 8e-2      # (a scalar's gradient is one sum with cancellation: its own size is no scale for its noise)
+                    tol = 0.4 if g1[k].numel() == 1 else 8e-2      # (a scalar's gradient is one sum with cancellation: its own size is no scale for its noise --
+                    if g1[k].numel() == 1:                          #  GFL_node_in.0.bias = 0.54 beside its sibling's 463 at tg + node, G = 1, B = 64: both kernel families
+                        sc = max(sc, 0.02 * smax)                   #  sit 0.5-0.9 from the fp64 value, tools/sweep_case.py -- so the cell's largest scalar gradient bounds the scale from below)
                     assert torch.isfinite(g1[k]).all() and dd <= tol * max(sc, 1e-6), 'grad %s differs: %.3g of %.3g' % (k, dd, sc)
             except Exception as e:      # noqa: BLE001
                 fails.append((tag, repr(e)[:300]))
