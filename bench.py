@@ -697,6 +697,30 @@ def secondary_points(ctx, S, params, B, steps=8, warmup=2):
     except Exception as e:      # noqa: BLE001
         sec['train_bf16'] = {'error': str(e)[:200]}
     gc.collect(); torch.cuda.empty_cache()
+    # ---- bf16 training step of the TIME-GATED cell (the reference's default cell, graphML.py:2196): both gate sub-networks trained too ----
+    try:
+        torch.manual_seed(0)
+        cell = gml.GGCRNNCell(G, F, K, K, torch.tanh, True, None, 1, True)
+        cell.addGSO(torch.tensor(S))
+        cell = cell.to(dev).float()
+        X = torch.randn(B, T, G, N, device=dev, dtype=torch.float32, generator=gen).to(torch.bfloat16)
+        h0 = torch.zeros(B, F, N, device=dev, dtype=torch.bfloat16)
+        target = torch.randn(B, T, F, N, device=dev, dtype=torch.float32, generator=gen).to(torch.bfloat16)
+        opt = FlatAdam(cell.parameters(), lr=1e-3)
+
+        def tgstep():
+            opt.zero_grad()
+            batchTimeL1Loss(cell(X, h0), target).backward()
+            opt.step()
+
+        dt = _timed(tgstep, max(3, steps // 3), 2)
+        sec['train_timegated_bf16'] = {'value': B / dt, 'unit': 'sequences/s', 'ms_per_step': 1e3 * dt, 'steps': max(3, steps // 3), 'dtype': 'bf16',
+                                       'what': 'time-gated cell: zero_grad, forward (gate pre-pass + gated recurrence), L1 loss, BPTT (chain, gate gradients, three weight '
+                                               'gradients, read-outs), FlatAdam; fp32 master weights'}
+        del cell, X, h0, target, opt
+    except Exception as e:      # noqa: BLE001
+        sec['train_timegated_bf16'] = {'error': str(e)[:200]}
+    gc.collect(); torch.cuda.empty_cache()
     # ---- time-gated cell at the north_star's 1e-5 (x3 kernels: gates = x3 steps from h0 + read-out, recurrence = scaled x3 steps) ----
     try:
         torch.manual_seed(0)
