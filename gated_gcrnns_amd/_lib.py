@@ -125,6 +125,7 @@ def _bind(lib):
         'gcrnn_fused_gate_cells_x3': (C.c_int, [_c_p] * 8 + [_c_i64] * 7 + [C.c_double, _c_p, C.c_int, _c_p, _c_p]),
         'gcrnn_pack_seq_major_x3_ex': (C.c_int, [_c_p, _c_p] + [_c_i64] * 5 + [_c_p, _c_p, C.c_int, _c_i64, _c_p]),
         'gcrnn_x3_item_dots': (C.c_int, [_c_p] * 5 + [_c_i64] * 4 + [_c_p]),
+        'gcrnn_x3_node_gate_step': (C.c_int, [_c_p] * 7 + [_c_i64] * 5 + [_c_p]),
         'gcrnn_pack_seq_major_steps': (C.c_int, [_c_p, _c_p, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_p]),
         'gcrnn_fused_gate_prepass_bf16': (C.c_int, [_c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p,
                                                     _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_p, C.c_double, C.c_int, _c_p]),

@@ -136,6 +136,74 @@ static int seq_pack_x3_launch(const void* src, void* dst, int64_t B, int64_t T, 
   return GCRNN_OK;
 }
 
+// One step of the NODE-gated cell at fp32 accuracy behind its two x3 filter passes (Utils/graphML.py:2402-2407, 2420-2423), in one pass:
+//   h[b][n][f] = tanh( ni[b][n] (ya[b][n][f] + bias[f]) + nf[b][n] (yb[b][n][f] + bias[f]) ),   ya / yb re-assembled from their three planes,
+// stored as three planes again (the next step's operand: no separate plane cut of h) and, transposed through an LDS tile, as fp32 in the user
+// layout H[b][.][f][n]. Replaces nine torch kernels + a plane cut per step (0.35 ms of a step's 0.9 at the bench's size).
+// One workgroup = 64 nodes x F features of one sequence; F in {32, 64}; rows n >= N are written as zeros.
+template <int F>
+__global__ __launch_bounds__(256) void x3_node_step_kernel(const uint16_t* __restrict__ ya3, const uint16_t* __restrict__ yb3,
+                                                           const float* __restrict__ ni, const float* __restrict__ nf,
+                                                           const float* __restrict__ bias, uint16_t* __restrict__ h3,
+                                                           float* __restrict__ Huser, int64_t hu_stride, int B, int N, int NPad) {
+  constexpr int LPN = F / 8, NPP = 256 / LPN;      // lanes per node (8 features each), nodes per pass
+  __shared__ float tile[F][65];
+  const int tid = threadIdx.x, p = tid % LPN, nl = tid / LPN;
+  const int b = blockIdx.y, n0 = blockIdx.x * 64;
+  const int64_t plane = (int64_t)B * NPad * F;
+  float bv[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) bv[j] = bias ? bias[p * 8 + j] : 0.f;
+#pragma unroll
+  for (int ps = 0; ps < 64 / NPP; ++ps) {
+    const int nn = ps * NPP + nl, n = n0 + nn;
+    if (n < NPad) {
+      const int64_t o = ((int64_t)b * NPad + n) * F + p * 8;
+      float a[8], c[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { a[j] = 0.f; c[j] = 0.f; }
+#pragma unroll
+      for (int pl = 2; pl >= 0; --pl) {              // small to large: exact for planes cut from one fp32 value
+        const uint4 va = *reinterpret_cast<const uint4*>(ya3 + pl * plane + o), vc = *reinterpret_cast<const uint4*>(yb3 + pl * plane + o);
+        const uint32_t wa[4] = {va.x, va.y, va.z, va.w}, wc[4] = {vc.x, vc.y, vc.z, vc.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          a[2 * j] += __uint_as_float(wa[j] << 16); a[2 * j + 1] += __uint_as_float(wa[j] & 0xffff0000u);
+          c[2 * j] += __uint_as_float(wc[j] << 16); c[2 * j + 1] += __uint_as_float(wc[j] & 0xffff0000u);
+        }
+      }
+      const bool in = n < N;
+      const float gi = in ? ni[(int64_t)b * NPad + n] : 0.f, gf = in ? nf[(int64_t)b * NPad + n] : 0.f;
+      uint32_t w[3][4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float h2[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          const float pre = gi * (a[2 * j + e] + bv[2 * j + e]) + gf * (c[2 * j + e] + bv[2 * j + e]);
+          h2[e] = in ? tanhf(pre) : 0.f;
+          tile[p * 8 + 2 * j + e][nn] = h2[e];
+        }
+        uint16_t a0, a1, a2, b0, b1, b2;
+        split3(h2[0], a0, a1, a2);
+        split3(h2[1], b0, b1, b2);
+        w[0][j] = (uint32_t)a0 | ((uint32_t)b0 << 16);
+        w[1][j] = (uint32_t)a1 | ((uint32_t)b1 << 16);
+        w[2][j] = (uint32_t)a2 | ((uint32_t)b2 << 16);
+      }
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<uint4*>(h3 + pl * plane + o) = uint4{w[pl][0], w[pl][1], w[pl][2], w[pl][3]};
+    }
+  }
+  if (!Huser) return;
+  __syncthreads();
+  // user layout: row f of the tile along n, 16 bytes (4 nodes) per lane (N % 4 == 0: whole quads)
+  for (int idx = tid; idx < F * 16; idx += 256) {
+    const int f = idx >> 4, nq = 4 * (idx & 15), n = n0 + nq;
+    if (n < N) *reinterpret_cast<float4*>(Huser + (int64_t)b * hu_stride + (int64_t)f * N + n) = float4{tile[f][nq], tile[f][nq + 1], tile[f][nq + 2], tile[f][nq + 3]};
+  }
+}
+
 // taps -> three planes of per-lane MFMA A fragments: out[p][chunk][tap][kstep][lane][8] (layout of pack_weights_kernel per plane)
 __global__ void pack_weights_x3_kernel(const float* __restrict__ wA, const float* __restrict__ wB, uint16_t* __restrict__ out, int F, int G,
                                        int Kin, int Kst, int K) {
@@ -798,6 +866,26 @@ extern "C" int gcrnn_x3_item_dots(const void* a3, const void* b3, const float* v
   GCRNN_PRE_LAUNCH();
   x3_item_dots_kernel<<<(unsigned)(B * T), 256, 0, as_stream(stream)>>>((const uint16_t*)a3, (const uint16_t*)b3, vec, b3 ? out_ab : nullptr,
                                                                         vec ? out_av : nullptr, (int)B, (int)NPad, (int)C);
+  GCRNN_CHECK_LAUNCH();
+  return GCRNN_OK;
+}
+
+// One step of the node-gated cell behind its two x3 filter passes (x3_node_step_kernel): ya3 / yb3 / h3 [3][B][NPad][F] bf16 planes, ni / nf fp32
+// [B][NPad] (this step's node gates, time gate folded in by the caller; rows >= N are not read), bias fp32 [F] or NULL, Huser fp32 or NULL:
+// element (b, f, n) at b huser_seq_stride + f N + n (one step of H [B][T][F][N]: stride T F N). F in {32, 64}, N % 4 == 0, NPad % 64 == 0.
+extern "C" int gcrnn_x3_node_gate_step(const void* ya3, const void* yb3, const float* ni, const float* nf, const float* bias, void* h3, void* Huser,
+                                       int64_t huser_seq_stride, int64_t B, int64_t N, int64_t NPad, int64_t F, void* stream) {
+  if (!ya3 || !yb3 || !ni || !nf || !h3) return GCRNN_ERR_NULL_POINTER;
+  if (B <= 0 || B > 65535 || N <= 0 || N > NPad || N % 4 || NPad % 64 || (F != 32 && F != 64) || huser_seq_stride < 0 || huser_seq_stride % 4) return GCRNN_ERR_BAD_SHAPE;
+  if (Huser && (reinterpret_cast<uintptr_t>(Huser) & 15)) return GCRNN_ERR_BAD_SHAPE;
+  const dim3 grid((unsigned)(NPad / 64), (unsigned)B);
+  GCRNN_PRE_LAUNCH();
+  if (F == 64)
+    x3_node_step_kernel<64><<<grid, 256, 0, as_stream(stream)>>>((const uint16_t*)ya3, (const uint16_t*)yb3, ni, nf, bias, (uint16_t*)h3, (float*)Huser,
+                                                                 huser_seq_stride, (int)B, (int)N, (int)NPad);
+  else
+    x3_node_step_kernel<32><<<grid, 256, 0, as_stream(stream)>>>((const uint16_t*)ya3, (const uint16_t*)yb3, ni, nf, bias, (uint16_t*)h3, (float*)Huser,
+                                                                 huser_seq_stride, (int)B, (int)N, (int)NPad);
   GCRNN_CHECK_LAUNCH();
   return GCRNN_OK;
 }

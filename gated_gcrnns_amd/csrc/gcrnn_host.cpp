@@ -9,7 +9,7 @@
 #include <vector>
 #include "../../include/gcrnn.h"
 
-extern "C" int gcrnn_version(void) { return 120; }  // 0.1.20 (round 5: hand-allocated-hop forward kernel, node-gated passes on the wide kernel, chunk pairs in the weight-gradient kernel)
+extern "C" int gcrnn_version(void) { return 121; }  // 0.1.21 (round 5: hand-allocated-hop forward kernel, node-gated passes on the wide kernel, chunk pairs in the weight-gradient kernel)
 
 extern "C" const char* gcrnn_status_string(int status) {
   switch (status) {

@@ -2027,23 +2027,16 @@ def fused_node_cell_forward_x3(X, h0, wA, wB, bias, graph, node_gates, time_gate
         check(lib.gcrnn_fused_pack_weights_x3(_p(wk), _p(wk), _p(wp), F, 0, K, K, st), 'pack_weights_x3')
         return wp
     wp3A, wp3B = state_taps(wA, Kin), state_taps(wB, Kst)
-    bvec = bias.detach().float().view(1, 1, F) if bias is not None else None
-    y3 = torch.empty((3, B, npad, F), dtype=torch.bfloat16, device=dev)
+    b32 = bias.detach().float().contiguous().view(-1) if bias is not None else None
+    ya3 = torch.empty((3, B, npad, F), dtype=torch.bfloat16, device=dev)
+    yb3 = torch.empty((3, B, npad, F), dtype=torch.bfloat16, device=dev)
     H = torch.empty((B, T, F, N), dtype=torch.float32, device=dev)
-    hprev = h0c
+    check(lib.gcrnn_pack_seq_major_x3(_p(h0c), _p(h3), B, 1, F, N, npad, st), 'pack_seq_x3')
     for t in range(T):
-        check(lib.gcrnn_fused_filter_x3(_p(xs3[t]), _p(y3), _p(wp3A), *gargs, B, N, F, K, plan['uniform_w'], r1, st), 'fused_filter_x3')
-        ya = torch.sum(y3, dim=0, dtype=torch.float32)                           # A(S) x_t: the three planes add up exactly in fp32 (one pass: the reduction converts)
-        hp = hprev if hprev.is_contiguous() else hprev.contiguous()
-        check(lib.gcrnn_pack_seq_major_x3(_p(hp), _p(h3), B, 1, F, N, npad, st), 'pack_seq_x3')
-        check(lib.gcrnn_fused_filter_x3(_p(h3[0]), _p(y3), _p(wp3B), *gargs, B, N, F, K, plan['uniform_w'], r1, st), 'fused_filter_x3')
-        yb = torch.sum(y3, dim=0, dtype=torch.float32)                           # B(S) h_{t-1}
-        if bvec is not None:
-            ya = ya + bvec
-            yb = yb + bvec
-        ht = torch.tanh(torch.addcmul(ni[t] * ya, nf[t], yb))                    # [B][npad][F]; padding rows: tanh(0) = 0
-        H[:, t] = ht[:, :N].transpose(1, 2)
-        hprev = H[:, t]
+        # both filter passes, then ONE pass: planes -> fp32, bias, per-node gating, tanh, the planes of h_t (the next step's operand) and H[:, t]
+        check(lib.gcrnn_fused_filter_x3(_p(xs3[t]), _p(ya3), _p(wp3A), *gargs, B, N, F, K, plan['uniform_w'], r1, st), 'fused_filter_x3')      # A(S) x_t
+        check(lib.gcrnn_fused_filter_x3(_p(h3[0]), _p(yb3), _p(wp3B), *gargs, B, N, F, K, plan['uniform_w'], r1, st), 'fused_filter_x3')       # B(S) h_{t-1}
+        check(lib.gcrnn_x3_node_gate_step(_p(ya3), _p(yb3), _p(ni[t]), _p(nf[t]), _p(b32), _p(h3), _p(H[:, t]), T * F * N, B, N, npad, F, st), 'x3_node_gate_step')
     if last_only:
         return H[:, T - 1:].contiguous()
     return H

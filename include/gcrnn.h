@@ -319,6 +319,12 @@ int gcrnn_pack_seq_major_x3_ex(const void* src, void* dst, int64_t B, int64_t T,
                                const float* item_scale, const float* rowmul, int one_minus_square, int64_t src_seq_stride, void* stream);
 int gcrnn_x3_item_dots(const void* a3, const void* b3, const float* vec, float* out_ab, float* out_av, int64_t B, int64_t T, int64_t NPad,
                        int64_t C, void* stream);
+/* One step of the NODE-gated cell at fp32 accuracy behind its two x3 filter passes (round 5; Utils/graphML.py:2402-2407, 2420-2423):
+ *   h = tanh( ni (ya + bias) + nf (yb + bias) ), ya3 / yb3 / h3 [3][B][NPad][F] bf16 planes (h3: the next step's operand), ni / nf fp32 [B][NPad] (the
+ *   step's node gates, time gate folded in by the caller), bias fp32 [F] or NULL, Huser fp32 or NULL: element (b, f, n) at b huser_seq_stride + f N + n.
+ *   F in {32, 64}, N % 4 == 0, NPad % 64 == 0. */
+int gcrnn_x3_node_gate_step(const void* ya3, const void* yb3, const float* ni, const float* nf, const float* bias, void* h3, void* Huser,
+                            int64_t huser_seq_stride, int64_t B, int64_t N, int64_t NPad, int64_t F, void* stream);
 
 
 /* LDS placement of the hop state (tile = 16). node_addr[n] = (row << 6) | (swz << 4): node n's 64-byte state row sits at
