@@ -91,8 +91,26 @@ def test_argument_validation_without_gpu():
     assert lib.gcrnn_pack_node_major(0, one, one, 1, 0, 1, 1, None, None) == 2
     assert lib.gcrnn_taps_forward(0, one, None, 0, one, None, 1.0, one, 8, 3, 2, 5, 0, None) == 3   # K>1 needs zrest
     assert lib.gcrnn_taps_forward(0, one, one, 0, one, None, 1.0, one, 0, 3, 2, 5, 0, None) == 2
+    # round 5: one step of the node-gated cell at 1e-5 (F in {32, 64}, N % 4 == 0, NPad % 64 == 0, 16-byte aligned H)
+    assert lib.gcrnn_x3_node_gate_step(None, one, one, one, None, one, None, 0, 4, 1000, 1024, 64, None) == 3
+    assert lib.gcrnn_x3_node_gate_step(one, one, one, one, None, one, None, 0, 4, 1000, 1024, 48, None) == 2
+    assert lib.gcrnn_x3_node_gate_step(one, one, one, one, None, one, None, 0, 4, 1002, 1024, 64, None) == 2
+    assert lib.gcrnn_x3_node_gate_step(one, one, one, one, None, one, C.c_void_p(8), 0, 4, 1000, 1024, 64, None) == 2
     with pytest.raises(_lib.GcrnnError):
         _lib.check(2, 'x')
+
+
+def test_weight_gradient_slot_counts():
+    """Partial-sum slots of the bf16 weight-gradient launch (host arithmetic only): with the bf16-image plans a workgroup visits an item for TWO
+    16-feature chunks, so an item has half the workgroups and twice the slots fill the 256 CUs; without them (or when the parked accumulators do
+    not fit in LDS beside a large graph image) one chunk per visit, the fp32-accurate kernel's count."""
+    lib = _lib.lib
+    assert lib.gcrnn_fused_wgrad_slots(8192, 64) == 64 and lib.gcrnn_fused_wgrad_slots(8192, 32) == 128
+    assert lib.gcrnn_fused_wgrad_bf16_slots(8192, 64, 5, 736, 1) == 128          # pairs: 2 workgroups per item
+    assert lib.gcrnn_fused_wgrad_bf16_slots(8192, 64, 5, 736, 0) == 64           # fp32 image: 4 workgroups per item
+    assert lib.gcrnn_fused_wgrad_bf16_slots(8192, 32, 3, 736, 1) == 256          # F = 32: one workgroup per item
+    assert lib.gcrnn_fused_wgrad_bf16_slots(8192, 64, 5, 2400, 1) == 64          # a graph image that leaves no room for the parked accumulators
+    assert lib.gcrnn_fused_wgrad_bf16_slots(5, 64, 5, 736, 1) == 8               # fewer items than slots: rounded up to 8
 
 
 def test_module_rejects_cpu_tensors_loudly():
